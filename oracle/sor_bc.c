@@ -1,0 +1,622 @@
+/*
+ * sor_bc.c -- ORACLE (test infrastructure, never shipped, never on the product path).
+ *
+ * CPU restatement, in plain C, of the reference's cell-barcode assignment:
+ * 2-bit codec, mutate ops, the "mutation cycle" matcher and Parser.assignBarcode.
+ * The reference ships this path as bytecode only; citations are
+ *   FJ! = Jar/NanoporeBC_UMI_finder-2.1.jar!/com/rw/   TB! = Jar/lib/TwoFourBitNucAcidLibraryMaven-1.0.jar!/com/rw/
+ * followed by Class.java:Lnn = the original source line from the class's LineNumberTable
+ * (read with tools/classdis.py / tools/classfold.py).
+ *
+ * PARITY UNPINNED: the reference has no tests or fixtures for this path and no JVM exists in the build
+ * image, so this restatement is pinned only by the two read-name examples of the reference's README
+ * (README.md:400, README.md:452; tests/test_oracle_bc.py) and by hand-derived vectors.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may link or call this file.
+ */
+#include "sor.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------
+ * Java arithmetic helpers: long shifts use (count & 63) (JLS 15.19); this is observable, see
+ * sor_insert_deg at pos == len-2.
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t jshl(uint64_t v, int s) { return v << (s & 63); }
+static inline uint64_t jushr(uint64_t v, int s) { return v >> (s & 63); }
+
+/* TB!nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase.java:L78-87  BASE_TO_TWOBIT_ARRAY: A=0 G=1 C=2 T=3,
+ * every other char = (byte)-2 which is sign-extended when OR-ed into the long (L185). */
+static inline int64_t base_to_twobit(unsigned char c) {
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'G': case 'g': return 1;
+    case 'C': case 'c': return 2;
+    case 'T': case 't': return 3;
+    default: return -2;
+    }
+}
+
+/* NucleicAcidTwoBitPerBase.getLongHashForSeq, L183-187 */
+int64_t sor_twobit_encode(const char *s, int n) {
+    uint64_t r = 0;
+    for (int i = 0; i < n; i++) r = (r << 2) | (uint64_t)base_to_twobit((unsigned char)s[i]);
+    return (int64_t)r;
+}
+
+/* NucleicAcidTwoBitPerBase.longTwoBitToString, L337-342 (TWOBIT_TO_BASE_ARRAY L117-121) */
+void sor_twobit_decode(int64_t seq, int len, char *out) {
+    static const char T[4] = {'A', 'G', 'C', 'T'};
+    uint64_t s = (uint64_t)seq;
+    for (int i = len - 1; i >= 0; i--) {
+        out[i] = T[s & 3];
+        s >>= 2;
+    }
+    out[len] = 0;
+}
+
+/* NucleicAcidTwoBitPerBase.reverseComplement, L477-484 (REVERSE_COMP_ARRAY {3,2,1,0}, L72-76).
+ * Only the low 2*len bits of the source are read: a window poisoned by an 'N' comes out clean. */
+int64_t sor_twobit_revcomp(int64_t seq, int len) {
+    static const uint64_t RC[4] = {3, 2, 1, 0};
+    uint64_t src = (uint64_t)seq, t = 0;
+    for (int i = 0; i < len; i++) {
+        t = (t << 2) | RC[src & 3];
+        src >>= 2;
+    }
+    return (int64_t)t;
+}
+
+/* CLEAR_BITS_TWOBIT_ARRAY[i] (L89-100): l = -4; repeat: arr[i] = l; l = (l << 2) | 3 */
+static inline uint64_t clear_bits(int i) {
+    uint64_t l = (uint64_t)-4LL;
+    for (int k = 0; k < i; k++) l = (l << 2) | 3;
+    return l;
+}
+
+/* SET_BITS_TWOBIT_ARRAY[i][j] (L105-112): row 0 = {0,1,3,2}, row i+1 = row i << 2 */
+static inline uint64_t set_bits(int i, int j) {
+    static const uint64_t R0[4] = {0, 1, 3, 2};
+    return jshl(R0[j], 2 * i);
+}
+
+/* getLongHashReplaceByteDeg, L228-233 */
+void sor_replace_deg(int64_t seq_, int pos, int len, int64_t out[4]) {
+    uint64_t seq = (uint64_t)seq_ & clear_bits(len - pos - 1);
+    int shift = (len - (pos + 1)) << 1;
+    for (uint64_t b = 0; b < 4; b++) out[b] = (int64_t)(seq | jshl(b, shift));
+}
+
+/* getLongHashInsertByteDeg, L300-309.  Variant order is SET_BITS index 0,1,3,2 = bases A,G,C,T.
+ * At pos == len-2 the second shift count is 64 == 0 (mod 64): the dropped last base stays in bits 62..63. */
+void sor_insert_deg(int64_t hash_, int pos, int len, int64_t out[4]) {
+    uint64_t hash = (uint64_t)hash_;
+    int shift = (len - pos - 1) << 1;
+    uint64_t upper = jshl(jushr(hash, shift), shift);
+    shift = 64 - shift;
+    hash = jshl(hash, shift);
+    hash = jushr(hash, shift + 2);
+    static const int J[4] = {0, 1, 3, 2};
+    for (int k = 0; k < 4; k++) out[k] = (int64_t)(upper | hash | set_bits(len - (pos + 1) - 1, J[k]));
+}
+
+/* BYTE_TO_2BITLONG_ARRAY[0][b4] (L92-98): only the codes of A(1) G(2) C(4) T(8) are filled, the rest stay 0 */
+static inline uint64_t fourbit_to_2bitlong0(int b4) {
+    switch (b4) {
+    case 2: return 1;
+    case 4: return 2;
+    case 8: return 3;
+    default: return 0;
+    }
+}
+
+/* getLongHashdeleteByte, L321-327 */
+int64_t sor_delete_byte(int64_t hash_, int base_add_at_end4, int pos, int len) {
+    uint64_t hash = (uint64_t)hash_;
+    int shift = (len - pos) << 1;
+    uint64_t upper = jshl(jushr(hash, shift), shift);
+    shift = 64 - shift;
+    hash = jshl(hash, shift + 2);
+    hash = jushr(hash, shift);
+    return (int64_t)(upper | hash | fourbit_to_2bitlong0(base_add_at_end4));
+}
+
+/* TB!nuc/encoding/NucleicAcidByteCodeBase.java:L45-78 ENCODE_MATRIX (IUPAC bit masks A=1 G=2 C=4 T=8) */
+int sor_fourbit_encode_char(unsigned char c) {
+    switch (c) {
+    case '-': return 0;
+    case 'A': case 'a': return 1;
+    case 'G': case 'g': return 2;
+    case 'C': case 'c': return 4;
+    case 'T': case 't': return 8;
+    case 'N': case 'n': return 15;
+    case 'H': case 'h': return 13;
+    case 'R': case 'r': return 3;
+    case 'Y': case 'y': return 12;
+    case 'M': case 'm': return 5;
+    case 'K': case 'k': return 10;
+    case 'S': case 's': return 6;
+    case 'W': case 'w': return 9;
+    case 'B': case 'b': return 14;
+    case 'V': case 'v': return 7;
+    case 'D': case 'd': return 11;
+    default: return -1;
+    }
+}
+
+/* ONEBYTE_REVERSECOMP_MATRIX, NucleicAcidByteCodeBase.java:L100-133: complement = swap A<->T, G<->C bit-wise */
+int sor_fourbit_complement(int b) {
+    return ((b & 1) << 3) | ((b & 8) >> 3) | ((b & 2) << 1) | ((b & 4) >> 1);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Barcode set (membership is order-free: fastutil Long2ObjectOpenHashMap.keySet().contains)
+ * ---------------------------------------------------------------------------------------------- */
+struct sor_set {
+    uint64_t *slots;
+    uint8_t *used;
+    size_t mask;
+    size_t n;
+};
+
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+sor_set *sor_set_new(const int64_t *keys, size_t n) {
+    sor_set *s = (sor_set *)calloc(1, sizeof(*s));
+    size_t cap = 16;
+    while (cap < 2 * n + 2) cap <<= 1;
+    s->slots = (uint64_t *)calloc(cap, sizeof(uint64_t));
+    s->used = (uint8_t *)calloc(cap, 1);
+    s->mask = cap - 1;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t k = (uint64_t)keys[i];
+        size_t p = mix64(k) & s->mask;
+        while (s->used[p] && s->slots[p] != k) p = (p + 1) & s->mask;
+        if (!s->used[p]) {
+            s->used[p] = 1;
+            s->slots[p] = k;
+            s->n++;
+        }
+    }
+    return s;
+}
+
+void sor_set_free(sor_set *s) {
+    if (!s) return;
+    free(s->slots);
+    free(s->used);
+    free(s);
+}
+
+size_t sor_set_size(const sor_set *s) { return s->n; }
+
+int sor_set_contains(const sor_set *s, int64_t key) {
+    uint64_t k = (uint64_t)key;
+    size_t p = mix64(k) & s->mask;
+    while (s->used[p]) {
+        if (s->slots[p] == k) return 1;
+        p = (p + 1) & s->mask;
+    }
+    return 0;
+}
+
+/* growable scratch set for `tested` (membership only; eclipse-collections IntHashSet / LongHashSet) */
+typedef struct {
+    uint64_t *slots;
+    uint8_t *used;
+    size_t mask, n;
+} dynset;
+
+static void dynset_init(dynset *d) {
+    d->mask = 1023;
+    d->n = 0;
+    d->slots = (uint64_t *)calloc(d->mask + 1, sizeof(uint64_t));
+    d->used = (uint8_t *)calloc(d->mask + 1, 1);
+}
+static void dynset_free(dynset *d) {
+    free(d->slots);
+    free(d->used);
+}
+static int dynset_contains(const dynset *d, uint64_t k) {
+    size_t p = mix64(k) & d->mask;
+    while (d->used[p]) {
+        if (d->slots[p] == k) return 1;
+        p = (p + 1) & d->mask;
+    }
+    return 0;
+}
+static void dynset_add(dynset *d, uint64_t k);
+static void dynset_grow(dynset *d) {
+    dynset o = *d;
+    d->mask = o.mask * 2 + 1;
+    d->n = 0;
+    d->slots = (uint64_t *)calloc(d->mask + 1, sizeof(uint64_t));
+    d->used = (uint8_t *)calloc(d->mask + 1, 1);
+    for (size_t i = 0; i <= o.mask; i++)
+        if (o.used[i]) dynset_add(d, o.slots[i]);
+    dynset_free(&o);
+}
+static void dynset_add(dynset *d, uint64_t k) {
+    if ((d->n + 1) * 2 > d->mask) dynset_grow(d);
+    size_t p = mix64(k) & d->mask;
+    while (d->used[p]) {
+        if (d->slots[p] == k) return;
+        p = (p + 1) & d->mask;
+    }
+    d->used[p] = 1;
+    d->slots[p] = k;
+    d->n++;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * java.util.HashSet<OneMatch> emulation (iteration order is observable, Parser.java:L244-250).
+ * JDK HashMap: idx = (h ^ h>>>16) & (cap-1), cap 16, threshold 0.75*cap, bins keep insertion order,
+ * resize splits bins preserving relative order; a bin that already holds >= 8 nodes triggers
+ * treeifyBin, which below 64 buckets is just a resize.  Real treeification (>= 64 buckets and a
+ * 9-node bin) cannot be reached with <= 5*(ed+1) elements for ed <= 2 except through three
+ * consecutive 6-bit hash coincidences; it is reported through `unsupported`.
+ * OneMatch.hashCode = (int)(readSeq ^ readSeq>>>32) (BarcodeMatchTester.java:L443);
+ * OneMatch.equals compares (readSeq, editDistance, offsetFromPredicted) only (L433-436).
+ * ---------------------------------------------------------------------------------------------- */
+#define JHS_MAX 64
+typedef struct {
+    sor_match_t e[JHS_MAX];
+    uint32_t h[JHS_MAX]; /* spread hash */
+    int order[JHS_MAX];  /* element indices, grouped by bin in iteration order */
+    int n, cap, unsupported;
+} jhashset;
+
+static void jhs_init(jhashset *s) {
+    s->n = 0;
+    s->cap = 16;
+    s->unsupported = 0;
+}
+
+static uint32_t onematch_hash(const sor_match_t *m) {
+    uint64_t r = (uint64_t)m->read_seq;
+    uint32_t h = (uint32_t)(r ^ (r >> 32));
+    return h ^ (h >> 16);
+}
+
+/* iteration order for a given capacity: bins ascending, inside a bin insertion order.  Because resize
+ * preserves relative order inside split bins, the order is a pure function of (cap, insertion order). */
+static void jhs_iter(const jhashset *s, int *out) {
+    int k = 0;
+    for (int b = 0; b < s->cap; b++)
+        for (int i = 0; i < s->n; i++)
+            if ((int)(s->h[i] & (uint32_t)(s->cap - 1)) == b) out[k++] = i;
+}
+
+static int jhs_add(jhashset *s, const sor_match_t *m) {
+    uint32_t h = onematch_hash(m);
+    int bin = (int)(h & (uint32_t)(s->cap - 1));
+    int in_bin = 0;
+    for (int i = 0; i < s->n; i++) {
+        if ((int)(s->h[i] & (uint32_t)(s->cap - 1)) != bin) continue;
+        in_bin++;
+        if (s->h[i] == h && s->e[i].read_seq == m->read_seq && s->e[i].ed == m->ed && s->e[i].offset == m->offset)
+            return 0; /* HashMap.putVal: existing mapping kept, key not replaced */
+    }
+    if (s->n >= JHS_MAX) {
+        s->unsupported = 1;
+        return 0;
+    }
+    s->e[s->n] = *m;
+    s->h[s->n] = h;
+    s->n++;
+    if (in_bin >= 8) { /* binCount >= TREEIFY_THRESHOLD - 1 -> treeifyBin */
+        if (s->cap < 64)
+            s->cap <<= 1;
+        else
+            s->unsupported = 1;
+    }
+    if (s->n > (s->cap * 3) / 4) s->cap <<= 1;
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * BarcodeMatchTester (FJ!nanoporereadscanner/analyzers/BarcodeMatchTester.java) on top of
+ * NucTwoBitPerBaseEDtesterBase (FJ!nuc/encoding/TwoBit/ed/NucTwoBitPerBaseEDtesterBase.java)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t seq;
+    int16_t pos_prev_level, pos_cur, level;
+    int8_t n_sub, n_ins, n_del;
+} mutated; /* LongSeqMutated (FJ!nuc/encoding/TwoBit/LongSeqMutated.java:L44-77) */
+
+typedef struct {
+    const sor_set *search;
+    int64_t unmutated;
+    int len, ed, skip_full, allow_indels, do_next, offset;
+    const uint8_t *post; /* 4-bit codes, 1-based access post[i-1]; NULL = no post sequence */
+    int post_len;
+    int use_tested, tested_is_long;
+    dynset tested;
+    mutated *deque;
+    size_t dq_n, dq_cap;
+    jhashset matches;
+    uint64_t n_probes;
+} tester;
+
+static void dq_push(tester *t, const mutated *m) {
+    if (t->dq_n == t->dq_cap) {
+        t->dq_cap = t->dq_cap ? t->dq_cap * 2 : 64;
+        t->deque = (mutated *)realloc(t->deque, t->dq_cap * sizeof(mutated));
+    }
+    t->deque[t->dq_n++] = *m;
+}
+
+/* NucTwoBitPerBaseEDtesterBase.checkWhetherAlreadyTested L120 / addToTestedSeqs L105-109:
+ * IntHashSet of (int)seq for lengths 14..16 (and < 14) when ed >= 2, LongHashSet above 16 (ctor L82-95) */
+static int already_tested(tester *t, int64_t s) {
+    if (!t->use_tested) return 0;
+    uint64_t k = t->tested_is_long ? (uint64_t)s : (uint64_t)(uint32_t)(int32_t)s;
+    return dynset_contains(&t->tested, k);
+}
+static void add_tested(tester *t, int64_t s) {
+    if (!t->use_tested) return;
+    uint64_t k = t->tested_is_long ? (uint64_t)s : (uint64_t)(uint32_t)(int32_t)s;
+    dynset_add(&t->tested, k);
+}
+
+/* BarcodeMatchTester.checkMatchWithTestSets L367-374 */
+static int check_match(tester *t, const mutated *m, sor_match_t *out) {
+    if (t->skip_full && t->unmutated == m->seq) return 0;
+    t->n_probes++;
+    if (!sor_set_contains(t->search, m->seq)) return 0;
+    out->read_seq = t->unmutated;
+    out->matching_bc = m->seq;
+    out->ed = m->level;
+    out->offset = t->offset;
+    out->length = t->len;
+    out->subs = m->n_sub;
+    out->ins = m->n_ins;
+    out->dels = m->n_del;
+    return 1;
+}
+
+/* NucTwoBitPerBaseEDtesterBase.goNextEDlevel L133-142 (bailoutIfFoundAfterED is null on this path) */
+static void go_next_level(tester *t, const mutated *m) {
+    if (t->ed <= m->level) return;
+    mutated n = *m;
+    n.pos_prev_level = m->pos_cur;
+    n.pos_cur = -1;
+    n.level = (int16_t)(m->level + 1);
+    dq_push(t, &n);
+}
+
+/* BarcodeMatchTester.substitutions L257-269 */
+static void do_substitutions(tester *t, const mutated *cur) {
+    int64_t v[4];
+    sor_replace_deg(cur->seq, cur->pos_cur, t->len, v);
+    for (int k = 0; k < 4; k++) {
+        int64_t s = v[k];
+        if (s == cur->seq || already_tested(t, s)) continue;
+        mutated m = *cur;
+        m.n_sub++;
+        m.seq = s;
+        sor_match_t r;
+        int hit = check_match(t, &m, &r);
+        if (hit) jhs_add(&t->matches, &r);
+        if (hit || t->do_next) go_next_level(t, &m); /* L268: descends on hit, or always in assign mode */
+    }
+}
+
+/* BarcodeMatchTester.insertions L284-296: increments nDeletions (sic) */
+static void do_insertions(tester *t, const mutated *cur) {
+    int64_t v[4];
+    sor_insert_deg(cur->seq, cur->pos_cur, t->len, v);
+    for (int k = 0; k < 4; k++) {
+        int64_t s = v[k];
+        if (already_tested(t, s)) continue;
+        mutated m = *cur;
+        m.seq = s;
+        m.n_del++;
+        sor_match_t r;
+        int hit = check_match(t, &m, &r);
+        if (hit) jhs_add(&t->matches, &r);
+        if (!hit || t->do_next) go_next_level(t, &m); /* L295: descends on MISS, or always in assign mode */
+    }
+}
+
+/* BarcodeMatchTester.deletions L313-352: increments nInsertions (sic); appended base = post[nDeletions+1] */
+static void do_deletions(tester *t, const mutated *cur) {
+    if (t->post && cur->n_del + 1 > t->post_len) return; /* L315-316 */
+    int last = t->post ? t->post[cur->n_del + 1 - 1] : 0;  /* L329 getByteAt is 1-based */
+    int64_t m0 = sor_delete_byte(cur->seq, last, cur->pos_cur, t->len);
+    int64_t v[4];
+    int nv;
+    if (t->post) {
+        v[0] = m0;
+        nv = 1;
+    } else {
+        v[0] = m0;
+        v[1] = m0 | 1;
+        v[2] = m0 | 2;
+        v[3] = m0 | 3;
+        nv = 4;
+    }
+    for (int k = 0; k < nv; k++) {
+        int64_t s = v[k];
+        if (already_tested(t, s)) continue;
+        mutated m = *cur;
+        m.seq = s;
+        m.n_ins++;
+        sor_match_t r;
+        int hit = check_match(t, &m, &r);
+        if (hit) jhs_add(&t->matches, &r);
+        if (!hit || t->do_next) go_next_level(t, &m); /* L351 */
+    }
+}
+
+/* BarcodeMatchTester.doJob L198-244.  Returns the matches in HashSet iteration order. */
+int sor_bc_match(const sor_set *search, int64_t seq, int len, int ed, int skip_full_matches, int allow_indels,
+                 const uint8_t *post4, int post_len, int offset, int do_next_level_if_match_found, sor_match_t *out,
+                 int max_out, uint64_t *n_probes) {
+    tester t;
+    memset(&t, 0, sizeof(t));
+    t.search = search;
+    t.unmutated = seq;
+    t.len = len;
+    t.ed = ed;
+    t.skip_full = skip_full_matches;
+    t.allow_indels = allow_indels;
+    t.do_next = do_next_level_if_match_found;
+    t.offset = offset;
+    t.post = post4;
+    t.post_len = post_len;
+    t.use_tested = ed >= 2; /* ctor L82-83: present for every length once ed >= 2 */
+    t.tested_is_long = len > 16;
+    if (t.use_tested) dynset_init(&t.tested);
+    jhs_init(&t.matches);
+
+    mutated parent = {seq, -1, -1, 0, 0, 0, 0}; /* L198: LongSeqMutated(seq, nDel=0, level=0, offset) -> pos fields -1 */
+    sor_match_t r;
+    if (check_match(&t, &parent, &r)) jhs_add(&t.matches, &r); /* L204-206 */
+    if (ed != 0) {
+        parent.level = 1; /* L211 */
+        dq_push(&t, &parent);
+        int last = len - 1; /* barcodeSeqLengthMinusOne L214 */
+        while (t.dq_n) {
+            mutated cur = t.deque[--t.dq_n];             /* pollLast L218 */
+            cur.pos_cur = (int16_t)(cur.pos_cur + 1);      /* L222 */
+            if (cur.pos_cur < last) dq_push(&t, &cur);     /* L223-224 continuation copy */
+            if (cur.pos_prev_level == cur.pos_cur) continue; /* L227-228 (nothing added to `tested`) */
+            do_substitutions(&t, &cur);
+            if (t.allow_indels && cur.pos_cur < last) {
+                do_insertions(&t, &cur);
+                do_deletions(&t, &cur);
+            }
+            add_tested(&t, cur.seq); /* L241 */
+        }
+    }
+    int n = t.matches.n;
+    int idx[JHS_MAX];
+    jhs_iter(&t.matches, idx);
+    for (int i = 0; i < n && i < max_out; i++) out[i] = t.matches.e[idx[i]];
+    if (n_probes) *n_probes = t.n_probes;
+    int unsupported = t.matches.unsupported;
+    if (t.use_tested) dynset_free(&t.tested);
+    free(t.deque);
+    return unsupported ? -2 : n;
+}
+
+/* OneMatch.compareTo L449-461 */
+static int match_cmp(const sor_match_t *a, const sor_match_t *b) {
+    if (a->ed < b->ed) return -1;
+    if (a->ed > b->ed) return 1;
+    if (a->offset == 0 && b->offset != 0) return -1;
+    if (a->offset != 0 && b->offset == 0) return 1;
+    return 0;
+}
+
+/* Parser.assignBarcode (FJ!nanoporereadscanner/analyzers/Parser.java:L195-315) with the per-offset
+ * lambda (L205-242).  `stranded` is the read in stranded orientation, `adapterpos` = adapter_result.end
+ * (1-based).  Returns 1 if a barcode was accepted, 0 if not, -1 where the reference would throw
+ * StringIndexOutOfBoundsException from String.substring (window not inside the read), -2 see jhashset. */
+int sor_assign_barcode(const sor_set *search, const char *stranded, int read_len, int adapterpos, int max_ed,
+                       int test_plus_minus, int five_prime, int bc_len, sor_assign_t *res) {
+    jhashset all;
+    jhs_init(&all);
+    memset(res, 0, sizeof(*res));
+    res->ed_sec = 2147483647;
+    uint64_t probes_total = 0;
+    /* L203: rangeClosed(-k, k).boxed().sorted(comparingInt(Math::abs)) -- stable: 0,-1,+1,-2,+2 */
+    int offsets[64], no = 0;
+    offsets[no++] = 0;
+    for (int a = 1; a <= test_plus_minus; a++) {
+        offsets[no++] = -a;
+        offsets[no++] = a;
+    }
+    for (int oi = 0; oi < no; oi++) {
+        int off = offsets[oi];
+        int bc_start, bc_end;
+        if (!five_prime) {
+            bc_start = adapterpos - bc_len + off; /* L206 */
+            bc_end = adapterpos - 1 + off;        /* L207 */
+        } else {
+            bc_start = adapterpos + 1 + off;  /* L209 */
+            bc_end = adapterpos + bc_len + off; /* L210 */
+        }
+        /* L214 substring(bcStart-1, bcEnd) */
+        if (bc_start - 1 < 0 || bc_end > read_len || bc_start - 1 > bc_end) return -1;
+        int64_t bc = sor_twobit_encode(stranded + bc_start - 1, bc_end - (bc_start - 1));
+        uint8_t post[8];
+        int post_len = 5;
+        if (!five_prime) {
+            /* L218 new NucleicAcidOneBytePerBase(substring(bcStart-5, bcStart)).reverseComplement() */
+            if (bc_start - 5 < 0 || bc_start > read_len) return -1;
+            for (int i = 0; i < 5; i++) {
+                int c = sor_fourbit_encode_char((unsigned char)stranded[bc_start - 5 + (4 - i)]);
+                if (c < 0) return -1;
+                post[i] = (uint8_t)sor_fourbit_complement(c);
+            }
+            bc = sor_twobit_revcomp(bc, bc_len); /* L221 */
+        } else {
+            /* L219 substring(bcEnd, bcEnd+5) */
+            if (bc_end + 5 > read_len) return -1;
+            for (int i = 0; i < 5; i++) {
+                int c = sor_fourbit_encode_char((unsigned char)stranded[bc_end + i]);
+                if (c < 0) return -1;
+                post[i] = (uint8_t)c;
+            }
+        }
+        sor_match_t m[JHS_MAX];
+        uint64_t np = 0;
+        /* L230-238: skipFullMatches=false, allowIndels=true, doNextLevelIfMatchFound=true */
+        int nm = sor_bc_match(search, bc, bc_len, max_ed, 0, 1, post, post_len, off, 1, m, JHS_MAX, &np);
+        probes_total += np;
+        if (nm < 0) return nm;
+        for (int i = 0; i < nm; i++) jhs_add(&all, &m[i]); /* L240 addMatches -> HashSet.addAll in m's iteration order */
+    }
+    res->n_probes = probes_total;
+    if (all.unsupported) return -2;
+    if (all.n == 0) return 0; /* L244 */
+    int idx[JHS_MAX];
+    jhs_iter(&all, idx);
+    sor_match_t sorted[JHS_MAX];
+    int n = all.n;
+    for (int i = 0; i < n; i++) sorted[i] = all.e[idx[i]];
+    /* Stream.sorted(): stable (insertion sort is stable and n is tiny) */
+    for (int i = 1; i < n; i++) {
+        sor_match_t key = sorted[i];
+        int j = i - 1;
+        while (j >= 0 && match_cmp(&sorted[j], &key) > 0) {
+            sorted[j + 1] = sorted[j];
+            j--;
+        }
+        sorted[j + 1] = key;
+    }
+    /* L248-250: distinctByKey(matchingBC): first = best, second distinct BC = second best */
+    const sor_match_t *best = &sorted[0], *second = NULL;
+    for (int i = 1; i < n; i++)
+        if (sorted[i].matching_bc != best->matching_bc) {
+            second = &sorted[i];
+            break;
+        }
+    res->n_matches = n;
+    if (best->ed > max_ed) return 0;            /* L251 */
+    if (second && best->ed >= second->ed) return 0; /* L252 */
+    res->found = 1;
+    res->bc = best->matching_bc;
+    res->ed = best->ed;
+    res->ed_sec = second ? second->ed : 2147483647; /* L288 */
+    res->offset = best->offset;
+    res->ins_minus_del = best->ins - best->dels; /* OneMatch.getOffsetForReadEnd L533 */
+    if (!five_prime) {
+        res->bc_start = adapterpos - 1 + best->offset;                        /* L275 */
+        res->bc_end = res->bc_start - (bc_len - 1) - res->ins_minus_del;      /* L278 */
+    } else {
+        res->bc_start = adapterpos + 1 + best->offset;                        /* L274 */
+        res->bc_end = res->bc_start + (bc_len - 1) + res->ins_minus_del;      /* L279 */
+    }
+    return 1;
+}

@@ -1,0 +1,474 @@
+// smi_bc.hip -- cell-barcode matching kernels for gfx950 (CDNA4), hand-written HIP.
+//
+// What the reference does per read (FJ!nanoporereadscanner/analyzers/Parser.java:L195-315,
+// BarcodeMatchTester.java:L198-374): for each of 5 window offsets, probe the 16-mer and every sequence
+// reachable by one "mutation cycle" (48 substitutions, 60 insertions, 15 deletions, in a fixed order) in a
+// hash set of barcodes; the first hit per (offset, level) wins; then a best/second rule over the merged set.
+//
+// MI355X mapping: the hash set becomes a 3-level bit pyramid over the 2^32 key universe (smi_internal.h);
+// one 64-lane wavefront owns one read at a time and its lanes ARE the enumeration order (lane e of round A
+// is mutant e, lane e of round B is mutant 64+e, lane 63 of round B is the un-mutated window), so the
+// reference's "first hit wins" is a ballot + count-trailing-zeros.  All 10 probe rounds of a read
+// (5 offsets x 2) are issued level by level, giving 10 independent gathers in flight per wave and level.
+// Integer/bitwise work only: no MFMA, no LDS (the pyramid's top level lives in L2, the window batch in
+// registers).
+#include <hipcub/hipcub.hpp>
+
+#include "smi_internal.h"
+
+namespace smi {
+
+// ---------------------------------------------------------------------------------------------------------
+// pyramid build
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ l0,
+                           uint32_t *__restrict__ l1, uint32_t *__restrict__ fine) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t k = keys[i];
+        atomicOr(&fine[k >> 5], 1u << (k & 31));
+        uint32_t i1 = k >> kG1;
+        atomicOr(&l1[i1 >> 5], 1u << (i1 & 31));
+        uint32_t i0 = k >> kG0;
+        atomicOr(&l0[i0 >> 5], 1u << (i0 & 31));
+    }
+}
+
+// popcount of every 256-key block of the fine bitmap (8 words, read as two 16-B vectors)
+__global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restrict__ counts) {
+    size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (b >= kRankEntries) return;
+    uint4 a = fine[2 * b], c = fine[2 * b + 1];
+    counts[b] = __popc(a.x) + __popc(a.y) + __popc(a.z) + __popc(a.w) + __popc(c.x) + __popc(c.y) + __popc(c.z) +
+                __popc(c.w);
+}
+
+int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s) {
+    SMI_HIP(hipMemsetAsync(ctx->l0, 0, kL0Words * 4, s));
+    SMI_HIP(hipMemsetAsync(ctx->l1, 0, kL1Words * 4, s));
+    SMI_HIP(hipMemsetAsync(ctx->fine, 0, kFineWords * 4, s));
+    if (n) {
+        unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
+        hipLaunchKernelGGL(k_set_bits, dim3(grid), dim3(256), 0, s, d_keys, n, ctx->l0, ctx->l1, ctx->fine);
+        SMI_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_block_counts, dim3((unsigned)(kRankEntries / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const uint4 *>(ctx->fine), ctx->block_counts);
+    SMI_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->block_counts, ctx->rank, (int)kRankEntries, s));
+    void *tmp = nullptr;
+    SMI_HIP(hipMalloc(&tmp, tmp_bytes));
+    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ctx->block_counts, ctx->rank, (int)kRankEntries, s);
+    if (e != hipSuccess) {
+        (void)hipFree(tmp);
+        return hip_fail(e, "hipcub::DeviceScan::ExclusiveSum");
+    }
+    // distinct keys = rank[last] + counts[last]
+    uint32_t last[2] = {0, 0};
+    SMI_HIP(hipMemcpyAsync(&last[0], ctx->rank + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    SMI_HIP(hipFree(tmp));
+    ctx->n_keys = (size_t)last[0] + last[1];
+    return SMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K-WIN: window extraction (Parser.java:L205-221: substring + 2-bit packing, without the reverse complement,
+// which the matcher applies).  One thread per read; 24-25 scattered bytes per read.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t base_code(uint8_t c, bool &is_n) {
+    // BASE_TO_TWOBIT_ARRAY, NucleicAcidTwoBitPerBase.java:L78-87
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'G': case 'g': return 1;
+    case 'C': case 'c': return 2;
+    case 'T': case 't': return 3;
+    default: is_n = true; return 0;
+    }
+}
+
+__global__ void k_extract_windows(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
+                                  const int32_t *__restrict__ adapter_end, size_t n, int five_prime,
+                                  smi_bc_window *__restrict__ out) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t beg = offsets[i];
+    const int64_t len = (int64_t)(offsets[i + 1] - beg);
+    const int64_t ae = adapter_end[i];
+    const int W = five_prime ? SMI_WIN_BASES_5P : SMI_WIN_BASES_3P;
+    // first window base, 1-based stranded coordinate
+    const int64_t first = five_prime ? ae - 1 : ae - 22;
+    smi_bc_window w;
+    w.bases = 0;
+    w.nmask = 0;
+    w.flags = 0;
+    // every substring() of the five offsets must lie inside the read, else the reference throws
+    bool ok = ae > 0 && first >= 1 && first + W - 1 <= len;
+    if (ok) {
+        const uint8_t *p = reads + beg + (first - 1);
+        uint64_t b = 0;
+        uint32_t nm = 0;
+        for (int j = 0; j < W; j++) {
+            bool is_n = false;
+            uint32_t c = base_code(p[j], is_n);
+            b = (b << 2) | c;
+            nm |= (uint32_t)is_n << j;
+        }
+        w.bases = b;
+        w.nmask = nm;
+        w.flags = SMI_WIN_VALID;
+    }
+    out[i] = w;
+}
+
+int launch_extract_windows(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offsets, const int32_t *d_ae, size_t n,
+                           int five_prime, smi_bc_window *d_win, hipStream_t s) {
+    if (!n) return SMI_OK;
+    hipLaunchKernelGGL(k_extract_windows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_reads, d_offsets, d_ae,
+                       n, five_prime, d_win);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K-BC1: ed <= 1 matcher
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t revcomp16(uint32_t w) {
+    // reverse the 16 2-bit groups and complement (REVERSE_COMP_ARRAY {3,2,1,0}: complement = 3 - code)
+    uint32_t r = __brev(w);
+    r = ((r >> 1) & 0x55555555u) | ((r & 0x55555555u) << 1);
+    return ~r;
+}
+
+__device__ __forceinline__ uint32_t lowmask(int nbits) {  // nbits in [0, 32]
+    return nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u);
+}
+
+// Per-offset key material derived from the window record (wave-uniform).
+struct OffsetKey {
+    uint32_t key;      // un-mutated 16-mer in barcode orientation
+    uint32_t del_base; // 2-bit code appended by a level-1 "deletion" (post[1], BarcodeMatchTester.java:L329)
+    bool usable;       // false: N-poisoned 5' window -> no probe can hit
+};
+
+__device__ __forceinline__ OffsetKey make_key(uint64_t bases, uint32_t nmask, int o, bool five_prime) {
+    OffsetKey k;
+    if (!five_prime) {
+        // window = base indices 6+o .. 21+o of the 24-base record (stranded orientation)
+        const int j0 = 6 + o;
+        uint32_t w = (uint32_t)(bases >> (2 * (24 - 16 - j0)));
+        uint32_t nm = (nmask >> j0) & 0xFFFFu;
+        if (nm) {
+            // getLongHashForSeq ORs (long)-2 for a non-ACGT char (L185) and reverseComplement keeps only the low
+            // 32 bits (L477-484): every base before the LAST N reads as T, the N itself as C.
+            int i = 31 - __clz(nm);  // window index of the last N
+            uint32_t keep = lowmask(30 - 2 * i);
+            w = (w & keep) | (0xFFFFFFFFu << (31 - 2 * i));
+        }
+        k.key = revcomp16(w);
+        k.usable = true;
+        // post = revcomp(substring(bcStart-5, bcStart)) -> post[1] = complement of stranded[bcStart] = window base 0
+        // taken from the 4-bit string: N stays N and BYTE_TO_2BITLONG_ARRAY[0][15] = 0 (L92-98)
+        uint32_t b0 = (uint32_t)(bases >> (2 * (24 - 1 - j0))) & 3u;
+        k.del_base = ((nmask >> j0) & 1u) ? 0u : (3u - b0);
+    } else {
+        // window = base indices 2+o .. 17+o of the 25-base record; post[1] = index 18+o
+        const int j0 = 2 + o;
+        k.key = (uint32_t)(bases >> (2 * (25 - 16 - j0)));
+        k.usable = ((nmask >> j0) & 0xFFFFu) == 0;
+        const int jp = 18 + o;
+        uint32_t bp = (uint32_t)(bases >> (2 * (25 - 1 - jp))) & 3u;
+        k.del_base = ((nmask >> jp) & 1u) ? 0u : bp;
+    }
+    return k;
+}
+
+// Lane-constant description of the mutant a lane generates in one round.
+//   e = 8*p + r : p = position 0..15; r = 0..2 substitutions (ascending base, current base skipped,
+//   BarcodeMatchTester.java:L259-260), r = 3..6 insertions of A,G,C,T after p (L286, SET_BITS order),
+//   r = 7 deletion of p (L330).  Position 15 has substitutions only (L234).  e == 127: the window itself.
+struct LaneMut {
+    int s;           // 30 - 2p : bit offset of base p
+    uint32_t lm_s;   // lowmask(s)
+    uint32_t lm_s2;  // lowmask(s + 2)
+    int r;
+    bool valid;
+    bool exact;
+};
+
+__device__ __forceinline__ LaneMut make_lane(int e) {
+    LaneMut m;
+    const int p = (e >> 3) & 15;
+    m.r = e & 7;
+    m.s = 30 - 2 * p;
+    m.lm_s = lowmask(m.s);
+    m.lm_s2 = lowmask(m.s + 2);
+    m.exact = (e == 127);
+    m.valid = (e < 123) || m.exact;
+    return m;
+}
+
+// Returns the mutant; ok=false where the reference's 64-bit value cannot equal a 32-bit barcode.
+__device__ __forceinline__ uint32_t mutate(const LaneMut &m, uint32_t K, uint32_t del_base, bool &ok) {
+    ok = m.valid;
+    if (m.exact) return K;
+    const uint32_t cur = (K >> m.s) & 3u;
+    // substitution: getLongHashReplaceByteDeg L228-233
+    const uint32_t j = (uint32_t)m.r;
+    const uint32_t b = j + (j >= cur ? 1u : 0u);
+    const uint32_t sub = K ^ ((cur ^ b) << m.s);
+    // insertion: getLongHashInsertByteDeg L300-309; at p == 14 the Java shift count 64 wraps to 0 and the dropped
+    // last base survives in bits 62..63, so the value is a barcode only when that base is A
+    const uint32_t x = (uint32_t)(m.r - 3) & 3u;
+    const int xs = m.s >= 2 ? m.s - 2 : 0;
+    const uint32_t ins = (K & ~m.lm_s) | ((K & m.lm_s) >> 2) | (x << xs);
+    // deletion: getLongHashdeleteByte L321-327
+    const uint32_t del = (K & ~m.lm_s2) | ((K & m.lm_s) << 2) | del_base;
+    if (m.r >= 3 && m.r <= 6 && m.s == 2 && (K & 3u) != 0u) ok = false;
+    return m.r < 3 ? sub : (m.r < 7 ? ins : del);
+}
+
+// which kind of mutant is enumeration index e: ins - del contribution (OneMatch.getOffsetForReadEnd, L533;
+// insertions() bumps nDeletions, deletions() bumps nInsertions: BarcodeMatchTester.java:L289,L346)
+__device__ __forceinline__ int ins_minus_del_of(int e) {
+    const int r = e & 7;
+    return r < 3 ? 0 : (r < 7 ? -1 : 1);
+}
+
+// java.util.HashSet<OneMatch> iteration order + Stream.sorted() + distinctByKey (Parser.java:L244-252).
+// Candidate slot i = 2*q + level for the q-th tested offset (order 0,-1,+1,-2,+2), i.e. slots are already in
+// HashSet insertion order; `present` marks the filled ones.  HashMap: index = spread(hash) & (cap-1), cap 16,
+// doubled when size > 0.75 cap or (below 64 buckets) when a node is appended to a bin already holding >= 8
+// nodes; bins keep insertion order.  OneMatch.hashCode = (int)(readSeq ^ readSeq >>> 32) = the 32-bit window key
+// (BarcodeMatchTester.java:L443); OneMatch.compareTo = (ed, offset == 0 first) (L449-461).
+__device__ __forceinline__ void pick_best(const uint32_t (&bc)[10], const uint32_t (&rs)[10], const int (&imd)[10],
+                                          uint32_t present, int max_ed, smi_bc_result &res) {
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+    const int n = __popc(present);
+    res.bc = 0;
+    res.ed_sec = 2147483647;
+    res.found = 0;
+    res.ed = 0;
+    res.offset = 0;
+    res.ins_minus_del = 0;
+    res.n_matches = (uint32_t)n;
+    if (n == 0) return;
+    uint32_t h[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) h[i] = rs[i] ^ (rs[i] >> 16);
+    int cap = 16;
+    if (n >= 9) {  // the only way the table can grow with <= 10 elements: >= 8 nodes already in the target bin
+        int size = 0;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            if (!((present >> i) & 1u)) continue;
+            int in_bin = 0;
+#pragma unroll
+            for (int k = 0; k < i; k++)
+                in_bin += (((present >> k) & 1u) && ((h[k] ^ h[i]) & (uint32_t)(cap - 1)) == 0) ? 1 : 0;
+            size++;
+            if (in_bin >= 8 && cap < 64) cap <<= 1;
+            if (size > (cap * 3) / 4) cap <<= 1;
+        }
+    }
+    // total order: (ed, offset != 0, bin, insertion index)
+    uint32_t key[10];
+    uint32_t best_key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        key[i] = ((uint32_t)(i & 1) << 20) | ((i >> 1) != 0 ? (1u << 16) : 0u) | ((h[i] & (uint32_t)(cap - 1)) << 8) |
+                 (uint32_t)i;
+        if (!((present >> i) & 1u)) key[i] = 0xFFFFFFFFu;
+        best_key = min(best_key, key[i]);
+    }
+    uint32_t best_bc = 0;
+    int best_imd = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        if (key[i] == best_key) {
+            best_bc = bc[i];
+            best_imd = imd[i];
+        }
+    uint32_t second_key = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+        if (key[i] != 0xFFFFFFFFu && bc[i] != best_bc) second_key = min(second_key, key[i]);
+    const int best_ed = (int)(best_key >> 20);
+    const int second_ed = (int)(second_key >> 20);
+    const bool has_second = second_key != 0xFFFFFFFFu;
+    if (best_ed > max_ed) return;                      // L251
+    if (has_second && best_ed >= second_ed) return;    // L252
+    res.found = 1;
+    res.bc = best_bc;
+    res.ed = (int8_t)best_ed;
+    res.ed_sec = has_second ? second_ed : 2147483647;  // L288
+    res.offset = (int8_t)OFFS[(best_key & 0xFF) >> 1];
+    res.ins_minus_del = (int8_t)best_imd;
+}
+
+__device__ __forceinline__ uint32_t bit_of(const uint32_t *__restrict__ words, uint32_t idx) {
+    return (words[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+template <int MAX_ED>
+__global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
+                                                      Pyramid P, smi_bc_result *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const LaneMut mA = make_lane(lane);
+    const LaneMut mB = make_lane(lane == 63 ? 127 : 64 + lane);
+    const bool fp = five_prime != 0;
+
+    for (size_t base = wave * 64; base < n; base += n_waves * 64) {
+        // coalesced 16-B/lane load of 64 window records
+        smi_bc_window my;
+        my.bases = 0;
+        my.nmask = 0;
+        my.flags = 0;
+        if (base + lane < n) my = win[base + lane];
+        smi_bc_result my_res;
+        my_res.bc = 0;
+        my_res.ed_sec = 2147483647;
+        my_res.found = -1;
+        my_res.ed = 0;
+        my_res.offset = 0;
+        my_res.ins_minus_del = 0;
+        my_res.n_matches = 0;
+        const int cnt = (int)min((size_t)64, n - base);
+        for (int r = 0; r < cnt; r++) {
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my.bases, r);
+            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(my.bases >> 32), r);
+            const uint32_t nmask = __builtin_amdgcn_readlane(my.nmask, r);
+            const uint32_t flags = __builtin_amdgcn_readlane(my.flags, r);
+            if (!(flags & SMI_WIN_VALID)) continue;  // wave-uniform; result stays found = -1
+            const uint64_t bases = ((uint64_t)hi << 32) | lo;
+
+            // offsets in the reference's order 0,-1,+1,-2,+2 (Parser.java:L203)
+            constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+            OffsetKey ok[5];
+            uint32_t mut[10];
+            bool live[10];
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                ok[q] = make_key(bases, nmask, OFFS[q], fp);
+                bool va, vb;
+                mut[2 * q] = mutate(mA, ok[q].key, ok[q].del_base, va);
+                mut[2 * q + 1] = mutate(mB, ok[q].key, ok[q].del_base, vb);
+                if (MAX_ED == 0) {
+                    va = false;
+                    vb = vb && mB.exact;
+                }
+                live[2 * q] = va && ok[q].usable;
+                live[2 * q + 1] = vb && ok[q].usable;
+            }
+            // level 0 of the pyramid: 10 independent gathers
+            uint32_t w0[10];
+#pragma unroll
+            for (int t = 0; t < 10; t++) w0[t] = P.l0[(mut[t] >> kG0) >> 5];
+#pragma unroll
+            for (int t = 0; t < 10; t++) live[t] = live[t] && ((w0[t] >> ((mut[t] >> kG0) & 31)) & 1u);
+            // level 1: lanes that are out read word 0 (one shared line)
+            uint32_t w1[10];
+#pragma unroll
+            for (int t = 0; t < 10; t++) w1[t] = P.l1[live[t] ? ((mut[t] >> kG1) >> 5) : 0u];
+#pragma unroll
+            for (int t = 0; t < 10; t++) live[t] = live[t] && ((w1[t] >> ((mut[t] >> kG1) & 31)) & 1u);
+            // exact level
+            uint32_t w2[10];
+#pragma unroll
+            for (int t = 0; t < 10; t++) w2[t] = P.fine[live[t] ? (mut[t] >> 5) : 0u];
+#pragma unroll
+            for (int t = 0; t < 10; t++) live[t] = live[t] && ((w2[t] >> (mut[t] & 31)) & 1u);
+
+            uint32_t c_bc[10], c_rs[10];
+            int c_imd[10];
+            uint32_t present = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const unsigned long long ba = __ballot(live[2 * q]);
+                const unsigned long long bb = __ballot(live[2 * q + 1]);
+                c_rs[2 * q] = c_rs[2 * q + 1] = ok[q].key;
+                // exact match (BarcodeMatchTester.java:L204-206)
+                c_bc[2 * q] = ok[q].key;
+                c_imd[2 * q] = 0;
+                present |= (uint32_t)(bb >> 63) << (2 * q);
+                // first hit in enumeration order = the only level-1 OneMatch the HashSet keeps
+                const unsigned long long bb1 = bb & 0x7FFFFFFFFFFFFFFFull;
+                const int e = ba ? __builtin_ctzll(ba) : 64 + __builtin_ctzll(bb1 | (1ull << 63));
+                bool dummy;
+                c_bc[2 * q + 1] = mutate(make_lane(e), ok[q].key, ok[q].del_base, dummy);
+                c_imd[2 * q + 1] = ins_minus_del_of(e);
+                present |= (uint32_t)((ba | bb1) != 0) << (2 * q + 1);
+            }
+            smi_bc_result res;
+            pick_best(c_bc, c_rs, c_imd, present, MAX_ED, res);
+            if (lane == r) my_res = res;
+        }
+        if (base + lane < n) out[base + lane] = my_res;
+    }
+}
+
+int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_ed, int five_prime,
+                    smi_bc_result *d_out, hipStream_t s) {
+    if (!n) return SMI_OK;
+    Pyramid P = pyramid_of(ctx);
+    const size_t n_waves = (n + 63) / 64;
+    const unsigned grid = (unsigned)std::min<size_t>((n_waves + 3) / 4, 256 * 64);
+    if (ctx->timing) SMI_HIP(hipEventRecord(ctx->ev0, s));
+    if (max_ed == 0)
+        hipLaunchKernelGGL(k_bc_match_ed1<0>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else
+        hipLaunchKernelGGL(k_bc_match_ed1<1>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    SMI_HIP(hipGetLastError());
+    if (ctx->timing) {
+        SMI_HIP(hipEventRecord(ctx->ev1, s));
+        ctx->ev_valid = true;
+    }
+    return SMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K-HIST: pass-1 exact membership + histogram (UsedCellBCListGenerator.java:L207-229).  One thread per read:
+// coalesced key/flag loads, one pyramid walk, one atomic per accepted read.  hist is indexed by the key's rank
+// in ascending key order (rank[] + popcount inside the 256-key block), so the vector summed across GPUs is dense.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_hist(const uint32_t *__restrict__ keys, const uint8_t *__restrict__ pass, size_t n, Pyramid P,
+                       uint32_t *__restrict__ hist) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (pass && !pass[i]) continue;
+        const uint32_t k = keys[i];
+        if (!bit_of(P.l0, k >> kG0)) continue;
+        if (!bit_of(P.l1, k >> kG1)) continue;
+        const uint32_t blk = k >> 8;
+        const uint32_t *w = P.fine + (size_t)blk * 8;
+        const uint32_t wi = (k >> 5) & 7u;
+        const uint32_t word = w[wi];
+        if (!((word >> (k & 31)) & 1u)) continue;
+        uint32_t ord = P.rank[blk] + __popc(word & ((1u << (k & 31)) - 1u));
+        for (uint32_t j = 0; j < wi; j++) ord += __popc(w[j]);
+        atomicAdd(&hist[ord], 1u);
+    }
+}
+
+int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
+                hipStream_t s) {
+    if (!n) return SMI_OK;
+    Pyramid P = pyramid_of(ctx);
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    if (ctx->timing) SMI_HIP(hipEventRecord(ctx->ev0, s));
+    hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, d_keys, d_pass, n, P, d_hist);
+    SMI_HIP(hipGetLastError());
+    if (ctx->timing) {
+        SMI_HIP(hipEventRecord(ctx->ev1, s));
+        ctx->ev_valid = true;
+    }
+    return SMI_OK;
+}
+
+}  // namespace smi

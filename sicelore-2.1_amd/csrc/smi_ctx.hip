@@ -1,0 +1,249 @@
+// smi_ctx.hip -- context, error reporting and the extern "C" boundary of libsicelore_mi (see include/sicelore_mi.h).
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "smi_internal.h"
+
+namespace smi {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string &msg) { g_last_error = msg; }
+
+int hip_fail(hipError_t e, const char *what) {
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return SMI_ERR_HIP;
+}
+
+Pyramid pyramid_of(const smi_ctx *ctx) {
+    Pyramid p;
+    p.l0 = ctx->l0;
+    p.l1 = ctx->l1;
+    p.fine = ctx->fine;
+    p.rank = ctx->rank;
+    return p;
+}
+
+static int ensure_stage(smi_ctx *ctx, size_t in_bytes, size_t out_bytes) {
+    if (in_bytes > ctx->stage_in_bytes) {
+        if (ctx->stage_in) SMI_HIP(hipFree(ctx->stage_in));
+        ctx->stage_in = nullptr;
+        ctx->stage_in_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->stage_in, in_bytes));
+        ctx->stage_in_bytes = in_bytes;
+    }
+    if (out_bytes > ctx->stage_out_bytes) {
+        if (ctx->stage_out) SMI_HIP(hipFree(ctx->stage_out));
+        ctx->stage_out = nullptr;
+        ctx->stage_out_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->stage_out, out_bytes));
+        ctx->stage_out_bytes = out_bytes;
+    }
+    return SMI_OK;
+}
+
+static int bind(const smi_ctx *ctx) {
+    if (!ctx) {
+        set_error("null context");
+        return SMI_ERR_INVALID;
+    }
+    SMI_HIP(hipSetDevice(ctx->device));
+    return SMI_OK;
+}
+
+}  // namespace smi
+
+using namespace smi;
+
+extern "C" {
+
+const char *smi_last_error(void) { return g_last_error.c_str(); }
+
+const char *smi_version(void) { return "sicelore-mi 0.1 (gfx950)"; }
+
+int smi_ctx_create(int device, smi_ctx **out) {
+    if (!out) {
+        set_error("smi_ctx_create: out is null");
+        return SMI_ERR_INVALID;
+    }
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        set_error("smi_ctx_create: no HIP device visible (this library has no CPU fallback)");
+        return SMI_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) {
+        set_error("smi_ctx_create: device ordinal out of range");
+        return SMI_ERR_INVALID;
+    }
+    SMI_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SMI_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("smi_ctx_create: device is ") + prop.gcnArchName + ", this build targets gfx950 only");
+        return SMI_ERR_NO_DEVICE;
+    }
+    smi_ctx *ctx = new smi_ctx();
+    ctx->device = device;
+    auto fail = [&](int rc) {
+        smi_ctx_destroy(ctx);
+        return rc;
+    };
+#define SMI_TRY(call)                                     \
+    do {                                                  \
+        hipError_t e2 = (call);                           \
+        if (e2 != hipSuccess) return fail(hip_fail(e2, #call)); \
+    } while (0)
+    SMI_TRY(hipMalloc((void **)&ctx->l0, kL0Words * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->l1, kL1Words * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->fine, kFineWords * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->rank, kRankEntries * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->block_counts, kRankEntries * 4));
+    SMI_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SMI_TRY(hipEventCreate(&ctx->ev0));
+    SMI_TRY(hipEventCreate(&ctx->ev1));
+#undef SMI_TRY
+    *out = ctx;
+    return SMI_OK;
+}
+
+int smi_ctx_destroy(smi_ctx *ctx) {
+    if (!ctx) return SMI_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->l0);
+    (void)hipFree(ctx->l1);
+    (void)hipFree(ctx->fine);
+    (void)hipFree(ctx->rank);
+    (void)hipFree(ctx->block_counts);
+    (void)hipFree(ctx->stage_in);
+    (void)hipFree(ctx->stage_out);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SMI_OK;
+}
+
+int smi_ctx_device(const smi_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int smi_set_timing(smi_ctx *ctx, int enabled) {
+    if (!ctx) {
+        set_error("null context");
+        return SMI_ERR_INVALID;
+    }
+    ctx->timing = enabled != 0;
+    ctx->ev_valid = false;
+    return SMI_OK;
+}
+
+int smi_last_kernel_ms(smi_ctx *ctx, float *ms) {
+    if (!ctx || !ms) {
+        set_error("smi_last_kernel_ms: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *ms = -1.0f;
+    if (!ctx->ev_valid) return SMI_OK;
+    if (int rc = bind(ctx)) return rc;
+    SMI_HIP(hipEventSynchronize(ctx->ev1));
+    SMI_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return SMI_OK;
+}
+
+int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, int mode, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if ((!d_keys && n) || (mode != SMI_SET_USED_LIST && mode != SMI_SET_WHITELIST)) {
+        set_error("smi_set_barcode_set_device: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    ctx->set_mode = -1;
+    if (int rc = launch_build_pyramid(ctx, d_keys, n, (hipStream_t)stream)) return rc;
+    ctx->set_mode = mode;
+    return SMI_OK;
+}
+
+int smi_set_barcode_set(smi_ctx *ctx, const uint64_t *keys, size_t n, int mode) {
+    if (int rc = bind(ctx)) return rc;
+    if (!keys && n) {
+        set_error("smi_set_barcode_set: keys is null");
+        return SMI_ERR_INVALID;
+    }
+    std::vector<uint32_t> k32(n);
+    for (size_t i = 0; i < n; i++) {
+        if (keys[i] >> 32) {
+            set_error("smi_set_barcode_set: key does not fit 16 nt (N in a barcode, or cell_bc_length != 16)");
+            return SMI_ERR_INVALID;
+        }
+        k32[i] = (uint32_t)keys[i];
+    }
+    if (int rc = ensure_stage(ctx, std::max<size_t>(n * 4, 16), 0)) return rc;
+    if (n) SMI_HIP(hipMemcpyAsync(ctx->stage_in, k32.data(), n * 4, hipMemcpyHostToDevice, ctx->stream));
+    SMI_HIP(hipStreamSynchronize(ctx->stream));
+    return smi_set_barcode_set_device(ctx, (const uint32_t *)ctx->stage_in, n, mode, ctx->stream);
+}
+
+static int check_match_args(smi_ctx *ctx, const void *in, const void *out, size_t n, int max_ed) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!in || !out)) {
+        set_error("smi_bc_match: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    if (max_ed < 0 || max_ed > 1) {
+        set_error("smi_bc_match: bcEditDistance must be 0 or 1 in this build (2 is not implemented on the device yet)");
+        return SMI_ERR_INVALID;
+    }
+    if (ctx->set_mode < 0) {
+        set_error("smi_bc_match: no barcode set loaded (call smi_set_barcode_set first)");
+        return SMI_ERR_STATE;
+    }
+    return SMI_OK;
+}
+
+int smi_bc_match_device(smi_ctx *ctx, const smi_bc_window *d_windows, size_t n, int max_ed, int five_prime,
+                        smi_bc_result *d_out, void *stream) {
+    if (int rc = check_match_args(ctx, d_windows, d_out, n, max_ed)) return rc;
+    return launch_bc_match(ctx, d_windows, n, max_ed, five_prime, d_out, (hipStream_t)stream);
+}
+
+int smi_bc_match_batch(smi_ctx *ctx, const smi_bc_window *windows, size_t n, int max_ed, int five_prime,
+                       smi_bc_result *out) {
+    if (int rc = check_match_args(ctx, windows, out, n, max_ed)) return rc;
+    if (!n) return SMI_OK;
+    if (int rc = ensure_stage(ctx, n * sizeof(smi_bc_window), n * sizeof(smi_bc_result))) return rc;
+    SMI_HIP(hipMemcpyAsync(ctx->stage_in, windows, n * sizeof(smi_bc_window), hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = launch_bc_match(ctx, (const smi_bc_window *)ctx->stage_in, n, max_ed, five_prime,
+                                 (smi_bc_result *)ctx->stage_out, ctx->stream))
+        return rc;
+    SMI_HIP(hipMemcpyAsync(out, ctx->stage_out, n * sizeof(smi_bc_result), hipMemcpyDeviceToHost, ctx->stream));
+    SMI_HIP(hipStreamSynchronize(ctx->stream));
+    return SMI_OK;
+}
+
+int smi_extract_windows_device(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets,
+                               const int32_t *d_adapter_end, size_t n, int five_prime, smi_bc_window *d_windows,
+                               void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_reads || !d_offsets || !d_adapter_end || !d_windows)) {
+        set_error("smi_extract_windows_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_extract_windows(ctx, d_reads, d_offsets, d_adapter_end, n, five_prime, d_windows, (hipStream_t)stream);
+}
+
+int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
+                    void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_keys || !d_hist)) {
+        set_error("smi_hist_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    if (ctx->set_mode < 0) {
+        set_error("smi_hist_device: no barcode set loaded");
+        return SMI_ERR_STATE;
+    }
+    return launch_hist(ctx, d_keys, d_pass, n, d_hist, (hipStream_t)stream);
+}
+
+}  // extern "C"

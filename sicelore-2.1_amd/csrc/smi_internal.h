@@ -1,0 +1,73 @@
+// smi_internal.h -- shared declarations of libsicelore_mi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+#include "sicelore_mi.h"
+
+namespace smi {
+
+void set_error(const std::string &msg);
+int hip_fail(hipError_t e, const char *what);
+
+#define SMI_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return smi::hip_fail(e__, #call); \
+    } while (0)
+
+// Membership pyramid over the 2^32 universe of 16-mers (A=0 G=1 C=2 T=3, first base most significant).
+//   l0  : 1 bit per 2^G0 consecutive keys  (2^(32-G0) bits)  -- sized to stay resident in one XCD's 4 MiB L2
+//   l1  : 1 bit per 2^G1 consecutive keys  (2^(32-G1) bits)  -- Infinity-Cache resident
+//   fine: 1 bit per key                    (2^32 bits = 512 MiB, HBM)
+// A probe walks l0 -> l1 -> fine and stops at the first clear bit, so it is exact; consecutive keys share
+// a bit, so the mutants of one window that keep its leading bases hit the same 128-B line.
+// rank[k] = number of set keys below (k << 8): ordinal(key) = rank[key >> 8] + popcount of the fine bits
+// of that 256-key block below key  (pass-1 histogram index).
+constexpr int kG0 = 8;
+constexpr int kG1 = 5;
+constexpr size_t kL0Words = (size_t(1) << (32 - kG0)) / 32;
+constexpr size_t kL1Words = (size_t(1) << (32 - kG1)) / 32;
+constexpr size_t kFineWords = (size_t(1) << 32) / 32;
+constexpr size_t kRankEntries = size_t(1) << 24;
+
+struct Pyramid {
+    const uint32_t *l0;
+    const uint32_t *l1;
+    const uint32_t *fine;
+    const uint32_t *rank;
+};
+
+}  // namespace smi
+
+struct smi_ctx {
+    int device = -1;
+    uint32_t *l0 = nullptr;
+    uint32_t *l1 = nullptr;
+    uint32_t *fine = nullptr;
+    uint32_t *rank = nullptr;
+    uint32_t *block_counts = nullptr;  // scratch for the rank scan
+    size_t n_keys = 0;                 // distinct keys loaded
+    int set_mode = -1;
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    // staging buffers of the *_batch entry points (grown on demand)
+    void *stage_in = nullptr;
+    void *stage_out = nullptr;
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    hipStream_t stream = nullptr;  // private stream of the *_batch entry points
+};
+
+namespace smi {
+Pyramid pyramid_of(const smi_ctx *ctx);
+int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_ed, int five_prime,
+                    smi_bc_result *d_out, hipStream_t s);
+int launch_extract_windows(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, const int32_t *d_ae,
+                           size_t n, int five_prime, smi_bc_window *d_win, hipStream_t s);
+int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s);
+int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
+                hipStream_t s);
+}  // namespace smi

@@ -1,0 +1,160 @@
+"""ctypes binding of libsicelore_mi.so (C ABI: include/sicelore_mi.h).
+
+PyTorch is used by callers only for device memory and streams; tensors cross this boundary as raw
+``data_ptr()`` integers.  Nothing here computes: a missing library is a hard error.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# mirrors of the C structs (include/sicelore_mi.h)
+BC_WINDOW_DTYPE = np.dtype([("bases", "<u8"), ("nmask", "<u4"), ("flags", "<u4")])
+BC_RESULT_DTYPE = np.dtype(
+    [("bc", "<u4"), ("ed_sec", "<i4"), ("found", "i1"), ("ed", "i1"), ("offset", "i1"), ("ins_minus_del", "i1"),
+     ("n_matches", "<u4")]
+)
+assert BC_WINDOW_DTYPE.itemsize == 16 and BC_RESULT_DTYPE.itemsize == 16
+
+SET_USED_LIST = 0
+SET_WHITELIST = 1
+
+# every symbol include/sicelore_mi.h declares (tests check the export table against this list)
+EXPORTS = [
+    "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
+    "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
+    "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing",
+]
+
+
+class SmiError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libsicelore_mi.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Load the HIP library; raises SmiError when it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise SmiError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
+    lib = ctypes.CDLL(path)
+    vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.smi_last_error.restype = ctypes.c_char_p
+    lib.smi_version.restype = ctypes.c_char_p
+    lib.smi_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.smi_ctx_destroy.argtypes = [vp]
+    lib.smi_ctx_device.argtypes = [vp]
+    lib.smi_set_barcode_set.argtypes = [vp, vp, sz, ci]
+    lib.smi_set_barcode_set_device.argtypes = [vp, vp, sz, ci, vp]
+    lib.smi_bc_match_batch.argtypes = [vp, vp, sz, ci, ci, vp]
+    lib.smi_bc_match_device.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+    lib.smi_extract_windows_device.argtypes = [vp, vp, vp, vp, sz, ci, vp, vp]
+    lib.smi_hist_device.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.smi_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.smi_set_timing.argtypes = [vp, ci]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is not ctypes.c_char_p:
+            fn.restype = ci
+    _LIB = lib
+    return lib
+
+
+def _ptr(t):
+    """raw address of a torch tensor / numpy array / None"""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return ctypes.c_void_p(t.data_ptr())
+    return ctypes.c_void_p(t.ctypes.data)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+
+        stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+
+
+class Context:
+    """One per GPU.  Stands where the reference keeps ``hashMapForBCfinding`` + a ``Parser`` worker
+    (FJ!nanoporereadscanner/analyzers/Parser.java:L70-78)."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        self._check(self._lib.smi_ctx_create(int(device), ctypes.byref(h)))
+        self._h = h
+        self.device = int(device)
+        self.n_keys = 0
+
+    def _check(self, rc):
+        if rc != 0:
+            raise SmiError(f"libsicelore_mi error {rc}: {self._lib.smi_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smi_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- barcode set -------------------------------------------------------------------------------------
+    def set_barcode_set(self, keys, mode=SET_USED_LIST):
+        """keys: iterable of 2-bit packed 16-mers (host).  Builds the device membership pyramid."""
+        k = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64))
+        self._check(self._lib.smi_set_barcode_set(self._h, _ptr(k), k.size, int(mode)))
+        self.n_keys = int(np.unique(k).size)
+
+    def set_barcode_set_device(self, d_keys_u32, mode=SET_USED_LIST, stream=None):
+        """d_keys_u32: device tensor of int32/uint32 keys."""
+        self._check(self._lib.smi_set_barcode_set_device(self._h, _ptr(d_keys_u32), d_keys_u32.numel(), int(mode),
+                                                         _stream_ptr(stream)))
+
+    # ---- matcher -----------------------------------------------------------------------------------------
+    def bc_match(self, windows, max_ed=1, five_prime=False):
+        """Host buffers in, host buffers out (numpy structured arrays)."""
+        w = np.ascontiguousarray(windows, dtype=BC_WINDOW_DTYPE)
+        out = np.zeros(w.size, dtype=BC_RESULT_DTYPE)
+        self._check(self._lib.smi_bc_match_batch(self._h, _ptr(w), w.size, int(max_ed), int(bool(five_prime)),
+                                                 _ptr(out)))
+        return out
+
+    def bc_match_device(self, d_windows, d_out, n, max_ed=1, five_prime=False, stream=None):
+        """d_windows: device int64 tensor [n, 2] (16-B records); d_out: device int32 tensor [n, 4]."""
+        self._check(self._lib.smi_bc_match_device(self._h, _ptr(d_windows), int(n), int(max_ed),
+                                                  int(bool(five_prime)), _ptr(d_out), _stream_ptr(stream)))
+
+    def extract_windows_device(self, d_reads, d_offsets, d_adapter_end, d_windows, n, five_prime=False, stream=None):
+        self._check(self._lib.smi_extract_windows_device(self._h, _ptr(d_reads), _ptr(d_offsets), _ptr(d_adapter_end),
+                                                         int(n), int(bool(five_prime)), _ptr(d_windows),
+                                                         _stream_ptr(stream)))
+
+    def hist_device(self, d_keys_u32, d_pass_u8, d_hist_u32, n, stream=None):
+        self._check(self._lib.smi_hist_device(self._h, _ptr(d_keys_u32), _ptr(d_pass_u8), int(n), _ptr(d_hist_u32),
+                                              _stream_ptr(stream)))
+
+    # ---- timing ------------------------------------------------------------------------------------------
+    def set_timing(self, enabled=True):
+        self._check(self._lib.smi_set_timing(self._h, int(bool(enabled))))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float(-1.0)
+        self._check(self._lib.smi_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,139 @@
+"""Seeded synthetic inputs: whitelist, used-barcode list with log-normal cell sizes and
+Nanopore-error-profile barcode regions.  The reference has no generator and its test data are absent
+(/root/reference/.MISSING_LARGE_BLOBS), so every measured number names the seed and version below.
+
+Written with torch ops only so that the same code builds 10^7 windows on the GPU in milliseconds and small
+cases on the CPU for the oracle comparison.  Generator, not product: nothing here assigns barcodes.
+"""
+import torch
+
+GENERATOR_VERSION = "synth-1"
+
+# Jar/config.xml:111-118 (3' adapter, complete form) and :155 (TSO)
+ADAPTER_3P_COMPLETE = "CTACACGACGCTCTTCCGATCT"
+ADAPTER_3P_SHORT = "CTTCCGATCT"
+TSO = "AACGCAGAGTACATGG"
+
+_CODE = {"A": 0, "G": 1, "C": 2, "T": 3}
+
+
+def _codes(s, device):
+    return torch.tensor([_CODE[c] for c in s], dtype=torch.int64, device=device)
+
+
+def _rc(codes):
+    """reverse complement along the last dim (complement = 3 - code)"""
+    return 3 - torch.flip(codes, dims=[-1])
+
+
+def _gen(seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    return g
+
+
+def make_whitelist(n, seed=1, device="cpu"):
+    """n distinct pseudo-random 16-mers as sorted int64 keys (stand-in for 3M-february-2018.txt.gz)."""
+    g = _gen(seed, device)
+    keys = torch.empty(0, dtype=torch.int64, device=device)
+    while keys.numel() < n:
+        m = int((n - keys.numel()) * 1.05) + 1024
+        new = torch.randint(0, 1 << 32, (m,), generator=g, device=device, dtype=torch.int64)
+        keys = torch.unique(torch.cat([keys, new]))
+    if keys.numel() > n:
+        # drop a seeded random subset so the result is not biased towards small keys
+        perm = torch.randperm(keys.numel(), generator=g, device=device)[:n]
+        keys = torch.sort(keys[perm]).values
+    return keys
+
+
+def pick_used(whitelist, n_cells, seed=2):
+    g = _gen(seed, whitelist.device)
+    idx = torch.randperm(whitelist.numel(), generator=g, device=whitelist.device)[:n_cells]
+    return whitelist[idx]
+
+
+def keys_to_codes(keys, k=16):
+    shifts = torch.arange(k - 1, -1, -1, device=keys.device, dtype=torch.int64) * 2
+    return (keys.unsqueeze(-1) >> shifts) & 3
+
+
+def gen_bc_region(n, used_keys, seed=3, device=None, err=0.063, frac=(0.4, 0.3, 0.3), five_prime=False, jitter=0.1,
+                  n_rate=0.0, width=128):
+    """Simulate the barcode end of n reads through a sub/ins/del channel.
+
+    Returns a dict:
+      codes  uint8 [n, width]   the read region in stranded orientation (2-bit codes, 4 = N)
+      ae     int32 [n]          adapter end AE (1-based, as Parser.assignBarcode reads it), with +-1 jitter
+      truth  int64 [n]          the barcode that was put in
+      umi    int64 [n]          the 12-nt UMI that was put in (2-bit packed)
+    """
+    device = device or used_keys.device
+    g = _gen(seed, device)
+    n_cells = used_keys.numel()
+    # log-normal cell sizes (gives the knee SURVEY 8d asks for)
+    w = torch.exp(torch.randn(n_cells, generator=g, device=device))
+    cell = torch.multinomial(w, n, replacement=True, generator=g)
+    truth = used_keys.to(device)[cell]
+    bc = keys_to_codes(truth, 16)
+    umi = torch.randint(0, 4, (n, 12), generator=g, device=device, dtype=torch.int64)
+    umi_key = (umi << (torch.arange(11, -1, -1, device=device, dtype=torch.int64) * 2)).sum(-1)
+    if not five_prime:
+        cdna = torch.randint(0, 4, (n, 20), generator=g, device=device, dtype=torch.int64)
+        polya = torch.zeros((n, 12), dtype=torch.int64, device=device)
+        ad = _rc(_codes(ADAPTER_3P_COMPLETE, device)).expand(n, -1)
+        src = torch.cat([cdna, polya, _rc(umi), _rc(bc), ad], dim=1)
+        anchor = 20 + 12 + 12 + 16  # source index of the first adapter base
+    else:
+        pre = torch.randint(0, 4, (n, 6), generator=g, device=device, dtype=torch.int64)
+        ad = _codes(ADAPTER_3P_COMPLETE, device).expand(n, -1)
+        cdna = torch.randint(0, 4, (n, 30), generator=g, device=device, dtype=torch.int64)
+        src = torch.cat([pre, ad, bc, umi, cdna], dim=1)
+        anchor = 6 + 22  # source index of the first barcode base
+    S = src.shape[1]
+    p_sub, p_ins, p_del = (err * f for f in frac)
+    u = torch.rand((n, S), generator=g, device=device)
+    is_del = u < p_del
+    is_sub = (u >= p_del) & (u < p_del + p_sub)
+    sub_base = (src + torch.randint(1, 4, (n, S), generator=g, device=device, dtype=torch.int64)) & 3
+    base = torch.where(is_sub, sub_base, src)
+    has_ins = torch.rand((n, S), generator=g, device=device) < p_ins
+    ins_base = torch.randint(0, 4, (n, S), generator=g, device=device, dtype=torch.int64)
+    kept = (~is_del).to(torch.int64)
+    cnt = kept + has_ins.to(torch.int64)
+    start = torch.cumsum(cnt, dim=1) - cnt
+    out = torch.randint(0, 4, (n, width + 2), generator=g, device=device, dtype=torch.int64)
+    dump = width + 1  # writes of absent elements land in a scratch column
+    pos_base = torch.where(is_del, torch.full_like(start, dump), start).clamp_(max=dump)
+    out.scatter_(1, pos_base, base)
+    pos_ins = torch.where(has_ins, start + kept, torch.full_like(start, dump)).clamp_(max=dump)
+    out.scatter_(1, pos_ins, ins_base)
+    out = out[:, :width]
+    a0 = start[:, anchor]  # 0-based output index of the first base emitted from the anchor onwards
+    ae = a0 + 1 if not five_prime else a0  # 3': AE = first adapter(rc) base; 5': AE = last adapter base
+    j = torch.rand((n,), generator=g, device=device)
+    ae = ae + (j < jitter / 2).to(torch.int64) - ((j >= jitter / 2) & (j < jitter)).to(torch.int64)
+    if n_rate > 0:
+        is_n = torch.rand((n, width), generator=g, device=device) < n_rate
+        out = torch.where(is_n, torch.full_like(out, 4), out)
+    return {"codes": out.to(torch.uint8), "ae": ae.to(torch.int32), "truth": truth, "umi": umi_key}
+
+
+def pack_windows(codes, ae, five_prime=False):
+    """The packing half of Parser.lambda$assignBarcode$4 done with torch ops (used to feed the matcher directly
+    when reads are synthesised on the device): -> int64 [n, 2] = smi_bc_window records."""
+    n, width = codes.shape
+    W = 25 if five_prime else 24
+    first = (ae.to(torch.int64) - 1) if five_prime else (ae.to(torch.int64) - 22)  # 1-based
+    valid = (ae > 0) & (first >= 1) & (first + W - 1 <= width)
+    idx = (first - 1).clamp(0, width - W).unsqueeze(1) + torch.arange(W, device=codes.device)
+    win = torch.gather(codes.to(torch.int64), 1, idx)
+    is_n = win > 3
+    c = torch.where(is_n, torch.zeros_like(win), win)
+    shifts = torch.arange(W - 1, -1, -1, device=codes.device, dtype=torch.int64) * 2
+    bases = (c << shifts).sum(1)
+    nmask = (is_n.to(torch.int64) << torch.arange(W, device=codes.device, dtype=torch.int64)).sum(1)
+    bases = torch.where(valid, bases, torch.zeros_like(bases))
+    nmask = torch.where(valid, nmask, torch.zeros_like(nmask))
+    word1 = nmask | (valid.to(torch.int64) << 32)
+    return torch.stack([bases, word1], dim=1).contiguous()

@@ -1,0 +1,86 @@
+"""CPU checks of the drop-in boundary: the library builds for gfx950, loads, exports every symbol that
+include/sicelore_mi.h declares, the struct layouts agree, and without a GPU it fails loudly (no fallback)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import __graft_entry__ as graft
+
+HEADER = os.path.join(graft.ROOT, "include", "sicelore_mi.h")
+
+
+@pytest.fixture(scope="module")
+def built():
+    graft.build()
+    return graft.load_package()
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(smi_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = built.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 10
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in sicelore_mi.h but not exported"
+    from sicelore_amd import lib as libmod
+
+    assert sorted(libmod.EXPORTS) == declared
+
+
+def test_code_object_targets_gfx950(built):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", built.library_path()],
+                         capture_output=True, text=True).stdout
+    assert "gfx950" in out
+
+
+def test_struct_layout_matches_header(built, tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sicelore_mi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(smi_bc_window),offsetof(smi_bc_window,nmask),offsetof(smi_bc_window,flags),"
+                   "sizeof(smi_bc_result),offsetof(smi_bc_result,ed_sec),offsetof(smi_bc_result,found),"
+                   "offsetof(smi_bc_result,ins_minus_del),offsetof(smi_bc_result,n_matches));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    w, r = built.BC_WINDOW_DTYPE, built.BC_RESULT_DTYPE
+    assert got == [w.itemsize, w.fields["nmask"][1], w.fields["flags"][1], r.itemsize, r.fields["ed_sec"][1],
+                   r.fields["found"][1], r.fields["ins_minus_del"][1], r.fields["n_matches"][1]]
+
+
+def test_no_gpu_fails_loudly(built):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(built.SmiError, match="no HIP device|hip"):
+        built.Context(0)
+
+
+def test_missing_library_is_an_error(built, monkeypatch):
+    from sicelore_amd import lib as libmod
+
+    monkeypatch.setattr(libmod, "_LIB", None)
+    monkeypatch.setattr(libmod, "library_path", lambda: "/nonexistent/libsicelore_mi.so")
+    with pytest.raises(built.SmiError, match="missing"):
+        libmod.load_library()
+
+
+def test_synth_generator_is_seeded(synth):
+    wl = synth.make_whitelist(5000, seed=5)
+    assert wl.numel() == 5000 and int(wl.unique().numel()) == 5000
+    assert (synth.make_whitelist(5000, seed=5) == wl).all()
+    used = synth.pick_used(wl, 50, seed=6)
+    a = synth.gen_bc_region(1000, used, seed=7)
+    b = synth.gen_bc_region(1000, used, seed=7)
+    assert (a["codes"] == b["codes"]).all() and (a["ae"] == b["ae"]).all()
+    w = synth.pack_windows(a["codes"], a["ae"])
+    assert w.shape == (1000, 2) and bool(((w[:, 1] >> 32) & 1).all())
