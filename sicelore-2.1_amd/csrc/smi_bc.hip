@@ -313,6 +313,13 @@ __device__ __forceinline__ uint32_t bit_of(const uint32_t *__restrict__ words, u
     return (words[idx >> 5] >> (idx & 31)) & 1u;
 }
 
+// Work split inside a wavefront (64 reads per batch):
+//   phase 1 (lane = read)   : every lane derives the five window keys of ITS read (N handling, reverse complement)
+//   phase 2 (lane = mutant) : for r = 0..63 the keys of read r are broadcast (v_readlane) and the 64 lanes probe the
+//                             124 sequences of each offset; per offset the ballot is folded into one byte
+//                             {exact hit, index+1 of the first level-1 hit} which is written back to lane r
+//   phase 3 (lane = read)   : every lane runs the HashSet-order / best-second rule for ITS read and stores 16 B
+// so only the probes themselves are wave-serial; the scalar unit sees ~10 instructions per offset.
 template <int MAX_ED>
 __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
@@ -322,93 +329,110 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
     const LaneMut mA = make_lane(lane);
     const LaneMut mB = make_lane(lane == 63 ? 127 : 64 + lane);
     const bool fp = five_prime != 0;
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};  // the reference's order (Parser.java:L203)
 
     for (size_t base = wave * 64; base < n; base += n_waves * 64) {
-        // coalesced 16-B/lane load of 64 window records
+        // ---- phase 1: coalesced 16-B/lane load, per-lane key derivation ---------------------------------
         smi_bc_window my;
         my.bases = 0;
         my.nmask = 0;
         my.flags = 0;
         if (base + lane < n) my = win[base + lane];
-        smi_bc_result my_res;
-        my_res.bc = 0;
-        my_res.ed_sec = 2147483647;
-        my_res.found = -1;
-        my_res.ed = 0;
-        my_res.offset = 0;
-        my_res.ins_minus_del = 0;
-        my_res.n_matches = 0;
+        uint32_t key[5];
+        uint32_t packed = (my.flags & SMI_WIN_VALID) ? (1u << 15) : 0u;  // [1:0]..[9:8] del bases, [14:10] usable
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const OffsetKey k = make_key(my.bases, my.nmask, OFFS[q], fp);
+            key[q] = k.key;
+            packed |= k.del_base << (2 * q);
+            packed |= (k.usable ? 1u : 0u) << (10 + q);
+        }
+        // ---- phase 2: probes, one read at a time ---------------------------------------------------------
+        uint32_t sum_lo = 0, sum_hi = 0;
         const int cnt = (int)min((size_t)64, n - base);
         for (int r = 0; r < cnt; r++) {
-            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)my.bases, r);
-            const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(my.bases >> 32), r);
-            const uint32_t nmask = __builtin_amdgcn_readlane(my.nmask, r);
-            const uint32_t flags = __builtin_amdgcn_readlane(my.flags, r);
-            if (!(flags & SMI_WIN_VALID)) continue;  // wave-uniform; result stays found = -1
-            const uint64_t bases = ((uint64_t)hi << 32) | lo;
-
-            // offsets in the reference's order 0,-1,+1,-2,+2 (Parser.java:L203)
-            constexpr int OFFS[5] = {0, -1, 1, -2, 2};
-            OffsetKey ok[5];
+            const uint32_t pk = __builtin_amdgcn_readlane(packed, r);
+            if (!(pk & (1u << 15))) continue;  // wave-uniform
+            uint32_t K[5];
             uint32_t mut[10];
-            bool live[10];
+            uint32_t live[10];  // 0 / 0xFFFFFFFF lane masks: everything below is branch-free VALU
 #pragma unroll
             for (int q = 0; q < 5; q++) {
-                ok[q] = make_key(bases, nmask, OFFS[q], fp);
+                K[q] = __builtin_amdgcn_readlane(key[q], r);
+                const uint32_t db = (pk >> (2 * q)) & 3u;
+                const bool usable = (pk >> (10 + q)) & 1u;
                 bool va, vb;
-                mut[2 * q] = mutate(mA, ok[q].key, ok[q].del_base, va);
-                mut[2 * q + 1] = mutate(mB, ok[q].key, ok[q].del_base, vb);
+                mut[2 * q] = mutate(mA, K[q], db, va);
+                mut[2 * q + 1] = mutate(mB, K[q], db, vb);
                 if (MAX_ED == 0) {
                     va = false;
                     vb = vb && mB.exact;
                 }
-                live[2 * q] = va && ok[q].usable;
-                live[2 * q + 1] = vb && ok[q].usable;
+                live[2 * q] = (va && usable) ? 0xFFFFFFFFu : 0u;
+                live[2 * q + 1] = (vb && usable) ? 0xFFFFFFFFu : 0u;
             }
             // level 0 of the pyramid: 10 independent gathers
-            uint32_t w0[10];
+            uint32_t w[10];
 #pragma unroll
-            for (int t = 0; t < 10; t++) w0[t] = P.l0[(mut[t] >> kG0) >> 5];
+            for (int t = 0; t < 10; t++) w[t] = P.l0[mut[t] >> (kG0 + 5)];
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] = live[t] && ((w0[t] >> ((mut[t] >> kG0) & 31)) & 1u);
+            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> ((mut[t] >> kG0) & 31u)) & 1u);
             // level 1: lanes that are out read word 0 (one shared line)
-            uint32_t w1[10];
 #pragma unroll
-            for (int t = 0; t < 10; t++) w1[t] = P.l1[live[t] ? ((mut[t] >> kG1) >> 5) : 0u];
+            for (int t = 0; t < 10; t++) w[t] = P.l1[(mut[t] >> (kG1 + 5)) & live[t]];
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] = live[t] && ((w1[t] >> ((mut[t] >> kG1) & 31)) & 1u);
+            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> ((mut[t] >> kG1) & 31u)) & 1u);
             // exact level
-            uint32_t w2[10];
 #pragma unroll
-            for (int t = 0; t < 10; t++) w2[t] = P.fine[live[t] ? (mut[t] >> 5) : 0u];
+            for (int t = 0; t < 10; t++) w[t] = P.fine[(mut[t] >> 5) & live[t]];
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] = live[t] && ((w2[t] >> (mut[t] & 31)) & 1u);
+            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> (mut[t] & 31u)) & 1u);
 
-            uint32_t c_bc[10], c_rs[10];
-            int c_imd[10];
-            uint32_t present = 0;
+            uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int q = 0; q < 5; q++) {
-                const unsigned long long ba = __ballot(live[2 * q]);
-                const unsigned long long bb = __ballot(live[2 * q + 1]);
-                c_rs[2 * q] = c_rs[2 * q + 1] = ok[q].key;
-                // exact match (BarcodeMatchTester.java:L204-206)
-                c_bc[2 * q] = ok[q].key;
-                c_imd[2 * q] = 0;
-                present |= (uint32_t)(bb >> 63) << (2 * q);
-                // first hit in enumeration order = the only level-1 OneMatch the HashSet keeps
+                const unsigned long long ba = __ballot(live[2 * q] != 0u);
+                const unsigned long long bb = __ballot(live[2 * q + 1] != 0u);
+                // first hit in enumeration order = the only level-1 OneMatch the HashSet keeps.  Bit 63 of bb is the
+                // exact probe (lane 63 of round B).
                 const unsigned long long bb1 = bb & 0x7FFFFFFFFFFFFFFFull;
-                const int e = ba ? __builtin_ctzll(ba) : 64 + __builtin_ctzll(bb1 | (1ull << 63));
-                bool dummy;
-                c_bc[2 * q + 1] = mutate(make_lane(e), ok[q].key, ok[q].del_base, dummy);
-                c_imd[2 * q + 1] = ins_minus_del_of(e);
-                present |= (uint32_t)((ba | bb1) != 0) << (2 * q + 1);
+                const uint32_t ib = (uint32_t)__builtin_ctzll(bb1 | (1ull << 63));  // 63 = none
+                uint32_t code = ba ? (uint32_t)__builtin_ctzll(ba) + 1u : (ib < 63u ? ib + 65u : 0u);
+                code |= (uint32_t)(bb >> 63) << 7;  // exact match (BarcodeMatchTester.java:L204-206)
+                if (q < 4)
+                    lo |= code << (8 * q);
+                else
+                    hi = code;
             }
-            smi_bc_result res;
-            pick_best(c_bc, c_rs, c_imd, present, MAX_ED, res);
-            if (lane == r) my_res = res;
+            const bool mine = lane == r;
+            sum_lo = mine ? lo : sum_lo;
+            sum_hi = mine ? hi : sum_hi;
         }
-        if (base + lane < n) out[base + lane] = my_res;
+        // ---- phase 3: per-lane epilogue ------------------------------------------------------------------
+        smi_bc_result res;
+        uint32_t c_bc[10], c_rs[10];
+        int c_imd[10];
+        uint32_t present = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const uint32_t code = q < 4 ? (sum_lo >> (8 * q)) & 0xFFu : sum_hi & 0xFFu;
+            const uint32_t db = (packed >> (2 * q)) & 3u;
+            c_rs[2 * q] = c_rs[2 * q + 1] = key[q];
+            c_bc[2 * q] = key[q];
+            c_imd[2 * q] = 0;
+            present |= (code >> 7) << (2 * q);
+            const int e = (int)(code & 0x7Fu) - 1;
+            bool dummy;
+            c_bc[2 * q + 1] = mutate(make_lane(e < 0 ? 0 : e), key[q], db, dummy);
+            c_imd[2 * q + 1] = ins_minus_del_of(e < 0 ? 0 : e);
+            present |= (e >= 0 ? 1u : 0u) << (2 * q + 1);
+        }
+        pick_best(c_bc, c_rs, c_imd, present, MAX_ED, res);
+        if (!(packed & (1u << 15))) {
+            res.found = -1;
+            res.n_matches = 0;
+        }
+        if (base + lane < n) out[base + lane] = res;
     }
 }
 

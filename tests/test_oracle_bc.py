@@ -231,3 +231,19 @@ def test_hashset_tie_order(sor):
             assert int(r["bc"]) == m["bc"] and int(r["offset"]) == m["offset"]
     # two different barcodes at the same ed are ambiguous -> almost always rejected; the assertion above is the point
     assert hits >= 0
+
+
+def test_golden_fixture(sor):
+    """tests/golden/bc_assign_v1.json (made by tests/golden/make_golden.py from the oracle; regression pin)"""
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bc_assign_v1.json")))
+    bset = sor.BarcodeSet(g["whitelist"])
+    for c in g["cases"]:
+        for i, read in enumerate(c["reads"]):
+            rc, r = sor.assign_barcode(bset, read, c["ae"][i], max_ed=c["max_ed"], five_prime=c["five_prime"])
+            assert rc == c["status"][i]
+            if rc == 1:
+                for f in ("bc", "ed", "ed_sec", "offset", "ins_minus_del", "bc_start", "bc_end"):
+                    assert int(r[f]) == c[f][i]
