@@ -48,6 +48,53 @@ int sor_bc_match(const sor_set *search, int64_t seq, int len, int ed, int skip_f
 int sor_assign_barcode(const sor_set *search, const char *stranded, int read_len, int adapterpos, int max_ed,
                        int test_plus_minus, int five_prime, int bc_len, sor_assign_t *res);
 
+
+/* ---- read scan (sor_scan.c) ------------------------------------------------------------------------------ */
+/* bit = ordinal of the flag in FJ!nanoporereadscanner/stats/ReadFlags$Flags (ReadFlags.java:L72-109); the
+ * reference's own long values come from a static counter and are not part of any output format */
+#define SOR_F_FAILED (1ull << 6)
+#define SOR_F_PASSED_FWD (1ull << 9)
+#define SOR_F_PASSED_REV (1ull << 10)
+#define SOR_F_POLY_T_5P (1ull << 12)
+#define SOR_F_POLY_A_3P (1ull << 13)
+#define SOR_F_POLY_A_NOT_FOUND (1ull << 14)
+#define SOR_F_POLY_T_5P_POLY_A_3P (1ull << 15)
+#define SOR_F_ADAPTER_5P (1ull << 16)
+#define SOR_F_ADAPTER_3P (1ull << 17)
+#define SOR_F_ADAPTER_SELECTED_DESP_BOTH (1ull << 20)
+#define SOR_F_READ_TOO_SHORT (1ull << 21)
+#define SOR_F_ADAPTER_5P_AND_3P (1ull << 22)
+
+typedef struct { /* shipped values: Jar/config.xml:21,55-59,95-105 */
+    int32_t min_read_length;        /* 200 */
+    int32_t polya_len;              /* 15 */
+    float polya_frac;               /* 0.75 */
+    int32_t window_polya;           /* 150 */
+    int32_t min_adapter_3p_matches; /* 8 */
+    int32_t min_mean_bc_qv;         /* 8 */
+    int32_t min_mean_read_qv;       /* 8 */
+} sor_scan_params;
+
+typedef struct {
+    uint64_t flags;
+    int32_t adapter_found, reverse;       /* reverse = 1: stranded read = reverse complement of the raw read */
+    int32_t polya_start, polya_end;       /* PS / PE, stranded 1-based */
+    int32_t adapter_start, adapter_end;   /* AS / AE, stranded 1-based */
+    int32_t scan_end;                     /* adapter end in scan orientation (1-based) */
+    int32_t adapter_nmis;                 /* getNerrorsNeedleman of the accepted alignment */
+    int32_t n_cand_fwd, n_cand_rev;       /* NW candidates per side (-1: no polyT on that side) */
+    int32_t pass1_ok;                     /* UsedCellBCListGenerator quality filter */
+    float mean_qv_bc, mean_qv_read;
+} sor_scan_result;
+
+int sor_find_polyt(const uint8_t *seq4, int n, int minlen, float minfrac, int window, int *begin1, int *end1);
+int sor_scan_read_3p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
+                     const sor_scan_params *par, sor_scan_result *out);
+int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offsets, size_t n, const char *adapter,
+                      int max_mm, const sor_scan_params *par, sor_scan_result *out, int32_t *status, int n_threads);
+int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
+                   int *ins, int *del, int *sub, float *end5);
+
 #ifdef __cplusplus
 }
 #endif

@@ -137,3 +137,78 @@ def assign_batch(bset, codes, ae, max_ed=1, test_pm=2, five_prime=False, n_threa
     if rc != 0:
         raise RuntimeError("sor_assign_batch_codes failed")
     return st, out
+
+
+# ---- read scan (sor_scan.c) ----------------------------------------------------------------------------------
+SCAN_PARAMS_DTYPE = np.dtype([("min_read_length", "<i4"), ("polya_len", "<i4"), ("polya_frac", "<f4"),
+                              ("window_polya", "<i4"), ("min_adapter_3p_matches", "<i4"), ("min_mean_bc_qv", "<i4"),
+                              ("min_mean_read_qv", "<i4")])
+SCAN_RESULT_DTYPE = np.dtype([("flags", "<u8"), ("adapter_found", "<i4"), ("reverse", "<i4"), ("polya_start", "<i4"),
+                              ("polya_end", "<i4"), ("adapter_start", "<i4"), ("adapter_end", "<i4"),
+                              ("scan_end", "<i4"), ("adapter_nmis", "<i4"), ("n_cand_fwd", "<i4"),
+                              ("n_cand_rev", "<i4"), ("pass1_ok", "<i4"), ("mean_qv_bc", "<f4"),
+                              ("mean_qv_read", "<f4")], align=True)
+assert SCAN_RESULT_DTYPE.itemsize == 64
+FLAG_BITS = {"FAILED": 6, "PASSED_FWD": 9, "PASSED_REV": 10, "POLY_T_5P": 12, "POLY_A_3P": 13, "POLY_A_NOT_FOUND": 14,
+             "POLY_T_5P_POLY_A_3P": 15, "ADAPTER_5P": 16, "ADAPTER_3P": 17, "ADAPTER_SELECTED_DESP_BOTH": 20,
+             "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22}
+
+
+def default_scan_params():
+    p = np.zeros(1, dtype=SCAN_PARAMS_DTYPE)
+    p[0] = (200, 15, 0.75, 150, 8, 8, 8)  # Jar/config.xml:21,95-105,55-59
+    return p
+
+
+def _scan_sigs():
+    L = lib()
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.sor_scan_read_3p.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ci, ctypes.c_char_p, ci, vp, vp]
+    L.sor_scan_batch_3p.argtypes = [vp, vp, vp, sz, ctypes.c_char_p, ci, vp, vp, vp, ci]
+    L.sor_find_polyt.argtypes = [vp, ci, ci, ctypes.c_float, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.sor_nw_strings.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p,
+                                 ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ci), ctypes.POINTER(ci),
+                                 ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_float)]
+    return L
+
+
+def scan_read_3p(read, qual, adapter, max_mm=3, params=None):
+    L = _scan_sigs()
+    p = default_scan_params() if params is None else params
+    r = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
+    rc = L.sor_scan_read_3p(read.encode(), qual.encode() if qual is not None else None, len(read), adapter.encode(),
+                            max_mm, p.ctypes.data, r.ctypes.data)
+    return rc, r[0]
+
+
+def scan_batch_3p(reads_ascii, quals_ascii, offsets, adapter, max_mm=3, params=None, n_threads=1):
+    """reads_ascii / quals_ascii: uint8 arrays (concatenated), offsets: uint64 [n+1]"""
+    L = _scan_sigs()
+    p = default_scan_params() if params is None else params
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = offsets.size - 1
+    out = np.zeros(n, dtype=SCAN_RESULT_DTYPE)
+    st = np.zeros(n, dtype=np.int32)
+    reads_ascii = np.ascontiguousarray(reads_ascii, dtype=np.uint8)
+    q = None if quals_ascii is None else np.ascontiguousarray(quals_ascii, dtype=np.uint8)
+    L.sor_scan_batch_3p(reads_ascii.ctypes.data, None if q is None else q.ctypes.data, offsets.ctypes.data, n,
+                        adapter.encode(), max_mm, p.ctypes.data, out.ctypes.data, st.ctypes.data, n_threads)
+    return st, out
+
+
+def find_polyt(codes4, minlen=15, minfrac=0.75, window=150):
+    L = _scan_sigs()
+    a = np.ascontiguousarray(codes4, dtype=np.uint8)
+    b, e = ctypes.c_int(0), ctypes.c_int(0)
+    rc = L.sor_find_polyt(a.ctypes.data, a.size, minlen, minfrac, window, ctypes.byref(b), ctypes.byref(e))
+    return (b.value, e.value) if rc == 1 else None
+
+
+def nw_strings(adapter, read_slice):
+    L = _scan_sigs()
+    a1, d, a2 = (ctypes.create_string_buffer(200) for _ in range(3))
+    ne, e5 = ctypes.c_float(0), ctypes.c_float(0)
+    i, dl, s = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    L.sor_nw_strings(adapter.encode(), read_slice.encode(), a1, d, a2, ctypes.byref(ne), ctypes.byref(i),
+                     ctypes.byref(dl), ctypes.byref(s), ctypes.byref(e5))
+    return a1.value.decode(), d.value.decode(), a2.value.decode(), ne.value, i.value, dl.value, s.value, e5.value

@@ -1,0 +1,444 @@
+/*
+ * sor_scan.c -- ORACLE (test infrastructure; see sor_bc.c for the rules).
+ *
+ * CPU restatement of the reference's 3' read scan: polyA/T finder, k-mer gated Needleman-Wunsch adapter scan,
+ * strand decision / adapter acceptance, and the pass-1 quality filter.  Citations as in sor_bc.c
+ * (FJ! = NanoporeBC_UMI_finder-2.1.jar, TB! = TwoFourBitNucAcidLibraryMaven-1.0.jar, Class.java:Lnn).
+ * PARITY UNPINNED by the reference (no tests/fixtures, no JVM in the image): pinned by hand-derived vectors and
+ * an independent Python model in tests/.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "sor.h"
+
+#define T4 8 /* NucleicAcidByteCodeBase.T */
+
+/* ---- 4-bit helpers ----------------------------------------------------------------------------------- */
+static int enc4(unsigned char c) {
+    int v = sor_fourbit_encode_char(c);
+    return v < 0 ? 15 : v; /* a char outside the IUPAC table would throw in the reference; FASTQ has ACGTN only */
+}
+
+/* ---- PolyATSearcher.findpolyAT (FJ!nanopore/analyzers/PolyATSearcher.java:L56-252) ------------------------ */
+/* seq: 4-bit codes of the sub-sequence (length n = window + minlen + 10).  Returns 1 and (begin,end) 1-based. */
+static int count_t(const uint8_t *seq, int start, int window) { /* lambda$findpolyAT$d2855ce0$1 L61-67 */
+    int r = 0;
+    for (int i = start; i < start + window; i++) r += seq[i] == T4;
+    return r;
+}
+
+int sor_find_polyt(const uint8_t *seq, int n, int minlen, float minfrac, int window, int *begin1, int *end1) {
+    float scores[4096];
+    if (window > 4096 || n < window + minlen) return -1;
+    float cur = 0.0f;
+    for (int i = 0; i < minlen; i++) /* L188-190 */
+        if (seq[i] == T4) cur += 1.0f;
+    for (int pos = 0; pos <= window - 1; pos++) { /* L194-200: pos = -1; while (pos < window-1) { pos++; ... } */
+        int d = 0;
+        if (seq[pos] == T4) d -= 1;          /* lambda$findpolyAT$0 L75-82 */
+        if (seq[pos + minlen] == T4) d += 1;
+        cur = cur + (float)d;
+        scores[pos] = cur / (float)minlen; /* entry (pos, fraction of [pos+1, pos+minlen]) */
+    }
+    int first = -1;
+    for (int pos = 0; pos < window; pos++) { /* L217-218 */
+        if (scores[pos] < minfrac) continue;                                  /* lambda$4: fails when value < min */
+        if (seq[pos] != T4) continue;                                         /* lambda$2 L98 */
+        if (count_t(seq, pos, 5) <= 2) continue;                              /* L101 */
+        first = pos;
+        break;
+    }
+    if (first < 0) return 0;
+    int start = first;
+    static const int INC[8] = {20, 15, 10, 5, 4, 3, 2, 1}; /* L223-230 */
+    for (int k = 0; k < 8; k++) {
+        int inc = INC[k];
+        /* lambda$1 L88-92: double compare against (double)minfrac - 0.1 */
+        while (start + inc < window && (double)scores[start + inc] >= (double)minfrac - 0.1) start += inc;
+    }
+    int endpos = start + minlen - 1; /* L231 */
+    /* lambda$findpolyAT$3 L122-175 */
+    for (;;) {
+        if (endpos <= 4) break;
+        int nts[5], tot = 0;
+        for (int i = 0; i < 5; i++) {
+            if (seq[endpos - i] == T4) tot++;
+            nts[i] = tot;
+        }
+        if (nts[0] != 0 && nts[1] >= 2 && nts[3] >= 3 && nts[4] >= 4) break;
+        endpos--;
+    }
+    while (n > endpos + 6 && count_t(seq, endpos + 1, 5) > 3) endpos += 5; /* L145-147 */
+    while (n > endpos + 4 && count_t(seq, endpos + 1, 3) > 1) endpos += 3; /* L156-158 */
+    while (endpos < n - 1 && seq[endpos + 1] == T4) endpos++;              /* L171-172 */
+    *begin1 = first + 1; /* L239 */
+    *end1 = endpos + 1;
+    return 1;
+}
+
+/* ---- Needleman-Wunsch (TB!nuc/alignment/needleman/{DynamicProgramming,NeedlemanWunsch,SequenceAlignment}.java) */
+#define NW_MAX 64
+typedef struct {
+    int len;                  /* number of alignment columns */
+    uint8_t a1[2 * NW_MAX];   /* template (seq1 = adapter), 0 = '-' */
+    uint8_t a2[2 * NW_MAX];   /* read (seq2), 0 = '-' */
+    char dots[2 * NW_MAX + 1];
+} nw_aln;
+
+/* NeedlemanScores(lead1,lead2,trail1,trail2,indel,mismatch,match) = (-4,-5,-5,-5,-5,-5,+5)
+ * (FJ!nanopore/analyzers/parameters/NeedlemanParameters.java:L36-38); trailing scores are never read. */
+typedef struct {
+    int lead1, lead2, indel, mismatch, match;
+} nw_scores;
+static const nw_scores SEARCH = {-4, -5, -5, -5, 5};
+
+static void nw_align(const uint8_t *s1, int n1, const uint8_t *s2, int n2, const nw_scores *sc, nw_aln *out) {
+    static _Thread_local int score[NW_MAX + 1][NW_MAX + 1];
+    static _Thread_local uint8_t dir[NW_MAX + 1][NW_MAX + 1]; /* 0 none, 1 diag, 2 up (row-1), 3 left (col-1) */
+    /* getInitialScore / getInitialPointer, NeedlemanWunsch.java:L106-122 */
+    score[0][0] = 0;
+    dir[0][0] = 0;
+    for (int c = 1; c <= n1; c++) {
+        score[0][c] = c * sc->lead2;
+        dir[0][c] = 3;
+    }
+    for (int r = 1; r <= n2; r++) {
+        score[r][0] = r * sc->lead1;
+        dir[r][0] = 2;
+    }
+    for (int r = 1; r <= n2; r++) /* fillIn L92-98, fillInCell NeedlemanWunsch.java:L55-80 */
+        for (int c = 1; c <= n1; c++) {
+            int row_space = score[r - 1][c] + sc->indel;
+            int col_space = score[r][c - 1] + sc->indel;
+            int diag = score[r - 1][c - 1] + ((s2[r - 1] & s1[c - 1]) != 0 ? sc->match : sc->mismatch);
+            if (row_space >= col_space) {
+                if (diag >= row_space) {
+                    score[r][c] = diag;
+                    dir[r][c] = 1;
+                } else {
+                    score[r][c] = row_space;
+                    dir[r][c] = 2;
+                }
+            } else {
+                if (diag >= col_space) {
+                    score[r][c] = diag;
+                    dir[r][c] = 1;
+                } else {
+                    score[r][c] = col_space;
+                    dir[r][c] = 3;
+                }
+            }
+        }
+    /* getTraceback, SequenceAlignment.java:L102-151 */
+    uint8_t t1[2 * NW_MAX], t2[2 * NW_MAX];
+    int k = 0, r = n2, c = n1;
+    while (dir[r][c] != 0) {
+        int d = dir[r][c];
+        t2[k] = (d == 1 || d == 2) ? s2[r - 1] : 0;
+        t1[k] = (d == 1 || d == 3) ? s1[c - 1] : 0;
+        k++;
+        if (d == 1) {
+            r--;
+            c--;
+        } else if (d == 2)
+            r--;
+        else
+            c--;
+    }
+    out->len = k;
+    for (int i = 0; i < k; i++) {
+        out->a1[i] = t1[k - 1 - i];
+        out->a2[i] = t2[k - 1 - i];
+        uint8_t b1 = out->a1[i], b2 = out->a2[i];
+        out->dots[i] = (b1 == 0 || b2 == 0) ? 'x' : ((b1 & b2) == 0 ? 'x' : '.');
+    }
+    out->dots[k] = 0;
+}
+
+/* Match.countErrorsInNeedleman (FJ!nanopore/analyzers/Match.java:L31-34) */
+static float count_errors(const nw_aln *a) {
+    int nx = 0, lead = 0;
+    for (int i = 0; i < a->len; i++) nx += a->dots[i] == 'x';
+    while (lead < a->len && a->a1[lead] == 0) lead++; /* count5pInsertionsInNeedleman L185-189 */
+    return (float)nx - 0.9f * (float)lead;
+}
+
+/* NeedlemanMatch (FJ!nanopore/analyzers/NeedlemanMatch.java) */
+typedef struct {
+    int ins, del, sub, nmis;
+} nm_counts;
+
+static nm_counts needleman_counts(const nw_aln *a) { /* countNeedlemanErrorsInRead L68-86 (byte arithmetic) */
+    nm_counts c = {0, 0, 0, 0};
+    for (int i = 0; i < a->len; i++)
+        if (a->dots[i] == 'x') {
+            if (a->a1[i] == 0)
+                c.ins++;
+            else if (a->a2[i] == 0)
+                c.del++;
+            else
+                c.sub++;
+        }
+    int i = a->len;
+    while (i > 0 && a->a2[i - 1] == 0) i--;
+    c.del = (int8_t)(c.del - (a->len - i));
+    c.nmis = c.ins + c.del + c.sub;
+    return c;
+}
+
+static float indels_mismatches_end_of_read(const nw_aln *a, int n) { /* countIndelsMismatchesEndOfRead L109-123 */
+    float ret = 0.0f;
+    int len = a->len;
+    int i = len - 1, k = i;
+    while (k >= len - n && i >= 0) {
+        if (a->dots[i] == 'x') {
+            if (k >= len - 2)
+                ret = (float)((double)ret + 1.2);
+            else
+                ret = ret + 1.0f;
+        }
+        if (a->a2[i] != 0) k--;
+        i--;
+    }
+    return ret;
+}
+
+static int has_n_3p_consecutive_matches(const nw_aln *a, int n) { /* Match.lambda$static$2 L41-50 */
+    int consec = 0;
+    for (int i = a->len - 1; i >= a->len - n; i--) {
+        if (i < 0) break; /* charAt would throw for an alignment shorter than n; cannot happen (len >= adapter length) */
+        if (a->dots[i] != '.') break;
+        consec++;
+    }
+    return consec == n;
+}
+
+/* NucleicAcidInmutableOneBytePerBase$Kmers.nKmersMatching_4mer
+ * (TB!nuc/encoding/onebyte/NucleicAcidInmutableOneBytePerBase.java:L533-543) */
+static int kmers4_matching(const uint8_t *read, int read_len, const uint8_t *ad, int ad_len, int pos1) {
+    int matches = 0;
+    int n_kmers = ad_len - 3;
+    for (int p = pos1 - 1, k = 0; p < read_len - 3 && k < n_kmers; p++, k++)
+        if ((read[p] & ad[k] & 15) && (read[p + 1] & ad[k + 1] & 15) && (read[p + 2] & ad[k + 2] & 15) &&
+            (read[p + 3] & ad[k + 3] & 15))
+            matches++;
+    return matches;
+}
+
+/* AdapterTSOanalyzer.scanForAdapterOrTSOseq with maxErrors = Optional.empty()
+ * (FJ!nanopore/analyzers/AdapterTSOanalyzer.java:L84-110) + $AdapterScanRslt.getPosForBestScore (L279-291) */
+typedef struct {
+    int n_all;       /* number of (nErrors, pos) entries */
+    float best;      /* least key */
+    int n_best;      /* positions sharing the least key, in scan order */
+    int best_pos[256];
+} scan_rslt;
+
+static void scan_adapter(const uint8_t *read, int read_len, int begin, int end, const uint8_t *ad, int ad_len,
+                         scan_rslt *res) {
+    res->n_all = 0;
+    res->n_best = 0;
+    res->best = 3.4028234663852886e+38f;
+    int last = read_len - ad_len < end ? read_len - ad_len : end;
+    for (int pos = begin; pos <= last; pos++) {
+        int n = kmers4_matching(read, read_len, ad, ad_len, pos);
+        if (n <= 1) continue;
+        nw_aln a;
+        nw_align(ad, ad_len, read + pos - 1, ad_len, &SEARCH, &a);
+        float ne = count_errors(&a);
+        res->n_all++;
+        if (ne < res->best) {
+            res->best = ne;
+            res->n_best = 0;
+        }
+        if (ne == res->best && res->n_best < 256) res->best_pos[res->n_best++] = pos;
+    }
+}
+
+/* PolyATadapterAnalyzerBase.createNeedlemanMatch (FJ!nanopore/analyzers/PolyATadapterAnalyzerBase.java:L237-253) */
+typedef struct {
+    int ok;
+    int start, end; /* scan coordinates, 1-based */
+    nw_aln aln;
+    nm_counts cnt;
+} adapter_match;
+
+static void create_needleman_match(int pos, const uint8_t *test, const uint8_t *ad, int ad_len, int max_mm,
+                                   adapter_match *m) {
+    nw_align(ad, ad_len, test + pos - 1, ad_len, &SEARCH, &m->aln);
+    m->cnt = needleman_counts(&m->aln);
+    m->ok = 1;
+    if (m->cnt.nmis > max_mm) {
+        /* AdapterParameters.MIN_3P_CONSEC_MATCHES_TO_OVERRIDE_PASS = 6 (FJ!parameters/AdapterParameters.java:L22) */
+        if (!has_n_3p_consecutive_matches(&m->aln, 6)) m->ok = 0;
+    }
+    m->start = pos;
+    m->end = pos + ad_len - 1 + m->cnt.ins - m->cnt.del; /* L251 */
+}
+
+/* FastqRecordExt.getMeanQV (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L57-59) */
+static int mean_qv(const char *qual, int qlen, int start1, int stop1, float *out) {
+    long long sum = 0;
+    int cnt = 0;
+    if (start1 - 1 < 0) return -1; /* IntStream.skip(negative) throws */
+    for (int i = start1 - 1; i < qlen && cnt < stop1 - start1 + 1; i++) {
+        sum += (unsigned char)qual[i] - 33;
+        cnt++;
+    }
+    if (cnt == 0) return -1; /* OptionalDouble.getAsDouble throws */
+    *out = (float)((double)sum / (double)cnt);
+    return 0;
+}
+
+/* PolyATadapterAnalyzer_3pBCUMI.search (FJ!nanoporereadscanner/analyzers/PolyATadapterAnalyzer_3pBCUMI.java:L45-114)
+ * + PolyATadapterAnalyzerBase.{searchpolyA L109-121, analyze L145-221, getMatchList L275-319}
+ * + pass-1 filter UsedCellBCListGenerator$Worker.lambda$call$0 (UsedCellBCListGenerator.java:L198-202).
+ * TSO scan (scanReadForTSOs) is not restated yet: it only sets the T= field and TSO_* flags. */
+int sor_scan_read_3p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
+                     const sor_scan_params *par, sor_scan_result *out) {
+    memset(out, 0, sizeof(*out));
+    if (len < par->min_read_length) { /* testReadLength L131-137 */
+        out->flags = SOR_F_READ_TOO_SHORT | SOR_F_FAILED;
+        return 0;
+    }
+    const int sub_n = par->window_polya + par->polya_len + 10; /* PolyATSearcher.java:L178-181 */
+    if (len < sub_n) return -1; /* substring / charAt would throw */
+    int ad_len = (int)strlen(adapter);
+    uint8_t ad[NW_MAX];
+    if (ad_len > NW_MAX) return -1;
+    for (int i = 0; i < ad_len; i++) ad[i] = (uint8_t)enc4((unsigned char)adapter[i]);
+    uint8_t fwd[512], rev[512];
+    if (sub_n > 512) return -1;
+    for (int i = 0; i < sub_n; i++) fwd[i] = (uint8_t)enc4((unsigned char)read[i]);
+    for (int i = 0; i < sub_n; i++) rev[i] = (uint8_t)sor_fourbit_complement(enc4((unsigned char)read[len - 1 - i]));
+    int fb = 0, fe = 0, rb = 0, re = 0;
+    int has_f = sor_find_polyt(fwd, sub_n, par->polya_len, par->polya_frac, par->window_polya, &fb, &fe) == 1;
+    int has_r = sor_find_polyt(rev, sub_n, par->polya_len, par->polya_frac, par->window_polya, &rb, &re) == 1;
+    if (!has_f && !has_r)
+        out->flags |= SOR_F_POLY_A_NOT_FOUND;
+    else if (has_f && !has_r)
+        out->flags |= SOR_F_POLY_T_5P;
+    else if (!has_f && has_r)
+        out->flags |= SOR_F_POLY_A_3P;
+    else
+        out->flags |= SOR_F_POLY_T_5P_POLY_A_3P;
+    scan_rslt sf, sr;
+    /* seqTilPolyAend = sub-sequence [1, polyTend]; scan 1 .. min(len - adapter, len - 12) (L49-61) */
+    if (has_f) scan_adapter(fwd, fe, 1, fe - 12, ad, ad_len, &sf);
+    if (has_r) scan_adapter(rev, re, 1, re - 12, ad, ad_len, &sr);
+    out->n_cand_fwd = has_f ? sf.n_all : -1;
+    out->n_cand_rev = has_r ? sr.n_all : -1;
+    int use_fwd = -1; /* Boolean useforward = null */
+    int f_nonempty = has_f && sf.n_all > 0, r_nonempty = has_r && sr.n_all > 0;
+    if (has_f || has_r) { /* analyze L145-163 */
+        if (f_nonempty && r_nonempty) {
+            if (fabsf(sf.best - sr.best) < 2.0f)
+                out->flags |= SOR_F_ADAPTER_5P_AND_3P;
+            else {
+                out->flags |= SOR_F_ADAPTER_SELECTED_DESP_BOTH;
+                use_fwd = sf.best < sr.best ? 1 : 0;
+            }
+        } else if (f_nonempty && !r_nonempty)
+            use_fwd = 1;
+        else if (!f_nonempty && r_nonempty)
+            use_fwd = 0;
+    }
+    if (use_fwd < 0) { /* adapterscanResult == null -> FAILED (L178-179) */
+        out->flags |= SOR_F_FAILED;
+        return 0;
+    }
+    const int pe = use_fwd ? fe : re, pb = use_fwd ? fb : rb;
+    out->polya_start = len - (pe - 1); /* setPolyAstartfromScanPosition(polyTend) ReadScanResult.java:L346 */
+    out->polya_end = len - (pb - 1);   /* setPolyAendfromScanPosition(polyTbegin) L356 */
+    const scan_rslt *s = use_fwd ? &sf : &sr;
+    const uint8_t *test = use_fwd ? fwd : rev;
+    /* getMatchList L275-319 */
+    adapter_match best;
+    int have = 0;
+    if (s->n_best == 1) {
+        create_needleman_match(s->best_pos[0], test, ad, ad_len, max_mm, &best);
+        have = best.ok;
+    } else {
+        float best_key = 0;
+        for (int i = 0; i < s->n_best; i++) {
+            adapter_match m;
+            create_needleman_match(s->best_pos[i], test, ad, ad_len, max_mm, &m);
+            if (!m.ok) continue;
+            float key = indels_mismatches_end_of_read(&m.aln, 5);
+            if (!have || key < best_key) { /* smallest key; inside a key group the first (lowest position) */
+                best = m;
+                best_key = key;
+                have = 1;
+            }
+        }
+    }
+    if (!have) {
+        out->flags |= SOR_F_FAILED; /* L217 */
+        return 0;
+    }
+    /* setAdapterMatch, 3' (ReadScanResult.java:L445-447) */
+    out->adapter_found = 1;
+    out->adapter_start = len - (best.start - 1);
+    out->adapter_end = len - (best.end - 1);
+    out->scan_end = best.end;
+    out->adapter_nmis = best.cnt.nmis;
+    out->flags |= use_fwd ? SOR_F_ADAPTER_5P : SOR_F_ADAPTER_3P;
+    out->flags |= use_fwd ? SOR_F_PASSED_REV : SOR_F_PASSED_FWD; /* L206-213 */
+    out->reverse = use_fwd ? 1 : 0;
+    /* pass-1 quality filter; note the UNSTRANDED quality string is indexed with stranded coordinates (L201) */
+    out->pass1_ok = 0;
+    if (qual) {
+        /* short-circuit && chain of lambda$call$0 (L198-202) */
+        float end_err = indels_mismatches_end_of_read(&best.aln, par->min_adapter_3p_matches);
+        if (end_err == 0.0f) {
+            float q_bc = 0, q_read = 0;
+            if (mean_qv(qual, len, out->adapter_end - 16, out->adapter_end - 1, &q_bc)) return -1;
+            out->mean_qv_bc = q_bc;
+            if (!(q_bc < (float)par->min_mean_bc_qv)) {
+                if (mean_qv(qual, len, 1, len, &q_read)) return -1;
+                out->mean_qv_read = q_read;
+                out->pass1_ok = !(q_read < (float)par->min_mean_read_qv);
+            }
+        }
+    }
+    return 0;
+}
+
+/* exposed for unit tests */
+int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
+                   int *ins, int *del, int *sub, float *end5) {
+    static const char DEC[16] = {'-', 'A', 'G', 'R', 'C', 'M', 'S', 'V', 'T', 'W', 'K', 'D', 'Y', 'H', 'B', 'N'};
+    uint8_t s1[NW_MAX], s2[NW_MAX];
+    int n1 = (int)strlen(adapter), n2 = (int)strlen(read_slice);
+    if (n1 > NW_MAX || n2 > NW_MAX) return -1;
+    for (int i = 0; i < n1; i++) s1[i] = (uint8_t)enc4((unsigned char)adapter[i]);
+    for (int i = 0; i < n2; i++) s2[i] = (uint8_t)enc4((unsigned char)read_slice[i]);
+    nw_aln a;
+    nw_align(s1, n1, s2, n2, &SEARCH, &a);
+    for (int i = 0; i < a.len; i++) {
+        a1[i] = DEC[a.a1[i]];
+        a2[i] = DEC[a.a2[i]];
+        dots[i] = a.dots[i];
+    }
+    a1[a.len] = a2[a.len] = dots[a.len] = 0;
+    *n_errors = count_errors(&a);
+    nm_counts c = needleman_counts(&a);
+    *ins = c.ins;
+    *del = c.del;
+    *sub = c.sub;
+    *end5 = indels_mismatches_end_of_read(&a, 5);
+    return a.len;
+}
+
+int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offsets, size_t n, const char *adapter,
+                      int max_mm, const sor_scan_params *par, sor_scan_result *out, int32_t *status, int n_threads) {
+#pragma omp parallel for schedule(dynamic, 256) num_threads(n_threads > 0 ? n_threads : 1)
+    for (long long i = 0; i < (long long)n; i++) {
+        int len = (int)(offsets[i + 1] - offsets[i]);
+        status[i] = sor_scan_read_3p(reads + offsets[i], quals ? quals + offsets[i] : NULL, len, adapter, max_mm, par,
+                                     &out[i]);
+    }
+    return 0;
+}

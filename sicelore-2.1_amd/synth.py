@@ -137,3 +137,133 @@ def pack_windows(codes, ae, five_prime=False):
     nmask = torch.where(valid, nmask, torch.zeros_like(nmask))
     word1 = nmask | (valid.to(torch.int64) << 32)
     return torch.stack([bases, word1], dim=1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole reads (both ends) for the scan stage
+# ---------------------------------------------------------------------------------------------------------------
+END_BASES = 208  # bases kept per read end on the device (175 scanned + room for the barcode windows)
+TSO_COMPLETE = "AAGCAGTGGTATCAACGCAGAGTACATGGG"
+
+
+def _channel(src, forced_del, g, err, frac, width):
+    """sub/ins/del channel; returns (out [n, width] left-aligned, total emitted length [n])"""
+    n, S = src.shape
+    device = src.device
+    p_sub, p_ins, p_del = (err * f for f in frac)
+    u = torch.rand((n, S), generator=g, device=device)
+    is_del = (u < p_del) | forced_del
+    is_sub = (u >= p_del) & (u < p_del + p_sub)
+    sub_base = (src + torch.randint(1, 4, (n, S), generator=g, device=device, dtype=torch.int64)) & 3
+    base = torch.where(is_sub, sub_base, src)
+    has_ins = (torch.rand((n, S), generator=g, device=device) < p_ins) & ~forced_del
+    ins_base = torch.randint(0, 4, (n, S), generator=g, device=device, dtype=torch.int64)
+    kept = (~is_del).to(torch.int64)
+    cnt = kept + has_ins.to(torch.int64)
+    start = torch.cumsum(cnt, dim=1) - cnt
+    total = cnt.sum(1)
+    out = torch.randint(0, 4, (n, width + 1), generator=g, device=device, dtype=torch.int64)
+    dump = width
+    out.scatter_(1, torch.where(is_del, torch.full_like(start, dump), start).clamp_(max=dump), base)
+    out.scatter_(1, torch.where(has_ins, start + kept, torch.full_like(start, dump)).clamp_(max=dump), ins_base)
+    return out[:, :width], total.clamp(max=width)
+
+
+def gen_reads(n, used_keys, seed=5, device=None, err=0.063, frac=(0.4, 0.3, 0.3), n_rate=0.0, max_mid=1500,
+              q_mean=12.0):
+    """n synthetic 3' reads, kept as their two END_BASES-long ends + the length of the (unmaterialised) middle.
+
+    read (transcript sense) = TSO + cDNA + polyA(20..60) + rc(UMI12) + rc(BC16) + rc(CTACACGACGCTCTTCCGATCT);
+    half of the reads are reverse-complemented.  Returns a dict of tensors:
+      head, tail  uint8 [n, END_BASES]  raw read's first / last bases (2-bit codes, 4 = N)
+      qhead, qtail uint8 [n, END_BASES] Phred+33 of those bases;  qmid uint8 [n] quality of every middle base
+      mid_len int64 [n]; length = 2*END_BASES + mid_len; reverse bool [n]; truth int64 [n]; umi int64 [n]
+    """
+    device = device or used_keys.device
+    g = _gen(seed, device)
+    E = END_BASES
+    n_cells = used_keys.numel()
+    w = torch.exp(torch.randn(n_cells, generator=g, device=device))
+    cell = torch.multinomial(w, n, replacement=True, generator=g)
+    truth = used_keys.to(device)[cell]
+    bc = keys_to_codes(truth, 16)
+    umi = torch.randint(0, 4, (n, 12), generator=g, device=device, dtype=torch.int64)
+    umi_key = (umi << (torch.arange(11, -1, -1, device=device, dtype=torch.int64) * 2)).sum(-1)
+    # barcode end (transcript sense, right-aligned at the read's 3' end)
+    pad = torch.randint(0, 4, (n, 160), generator=g, device=device, dtype=torch.int64)
+    polya = torch.zeros((n, 60), dtype=torch.int64, device=device)
+    ad = _rc(_codes(ADAPTER_3P_COMPLETE, device)).expand(n, -1)
+    src = torch.cat([pad, polya, _rc(umi), _rc(bc), ad], dim=1)
+    pa_len = torch.randint(20, 61, (n,), generator=g, device=device)
+    forced = torch.zeros(src.shape, dtype=torch.bool, device=device)
+    forced[:, 160:220] = torch.arange(60, device=device).unsqueeze(0) < (60 - pa_len).unsqueeze(1)
+    W = 320
+    out3, tot3 = _channel(src, forced, g, err, frac, W)
+    idx = (tot3 - E).clamp(min=0).unsqueeze(1) + torch.arange(E, device=device)
+    end3 = torch.gather(out3, 1, idx.clamp(max=W - 1))
+    # TSO end (left-aligned at the 5' end)
+    tso = _codes(TSO_COMPLETE, device).expand(n, -1)
+    cdna = torch.randint(0, 4, (n, 230), generator=g, device=device, dtype=torch.int64)
+    out5, _ = _channel(torch.cat([tso, cdna], dim=1), torch.zeros((n, 260), dtype=torch.bool, device=device), g, err,
+                       frac, W)
+    end5 = out5[:, :E]
+    if n_rate > 0:
+        end3 = torch.where(torch.rand((n, E), generator=g, device=device) < n_rate, torch.full_like(end3, 4), end3)
+        end5 = torch.where(torch.rand((n, E), generator=g, device=device) < n_rate, torch.full_like(end5, 4), end5)
+    reverse = torch.rand((n,), generator=g, device=device) < 0.5
+
+    def rc4(x):  # reverse complement keeping N (4)
+        y = torch.flip(x, dims=[1])
+        return torch.where(y > 3, y, 3 - y)
+
+    head = torch.where(reverse.unsqueeze(1), rc4(end3), end5)
+    tail = torch.where(reverse.unsqueeze(1), rc4(end5), end3)
+    q = lambda: (torch.randn((n, E), generator=g, device=device) * 3.0 + q_mean).round().clamp(2, 40).to(torch.uint8) + 33  # noqa: E731
+    mid_len = torch.randint(0, max_mid + 1, (n,), generator=g, device=device)
+    qmid = (torch.randn((n,), generator=g, device=device) * 2.0 + q_mean).round().clamp(2, 40).to(torch.uint8) + 33
+    return {"head": head.to(torch.uint8), "tail": tail.to(torch.uint8), "qhead": q(), "qtail": q(), "qmid": qmid,
+            "mid_len": mid_len, "reverse": reverse, "truth": truth, "umi": umi_key}
+
+
+def materialize(reads, i, seed=0):
+    """ASCII (read, qual) of read i for the oracle; the middle is seeded random sequence"""
+    import numpy as np
+
+    lut = np.frombuffer(b"AGCTN", dtype=np.uint8)
+    m = int(reads["mid_len"][i])
+    rng = np.random.default_rng(seed * 1_000_003 + i)
+    mid = lut[rng.integers(0, 4, m)]
+    seq = np.concatenate([lut[reads["head"][i].cpu().numpy()], mid, lut[reads["tail"][i].cpu().numpy()]])
+    qual = np.concatenate([reads["qhead"][i].cpu().numpy(), np.full(m, int(reads["qmid"][i]), dtype=np.uint8),
+                           reads["qtail"][i].cpu().numpy()])
+    return bytes(seq).decode(), bytes(qual).decode()
+
+
+_LUT24 = None
+
+
+def pack_ends(head, tail):
+    """-> int32 [28, 2n]: both scan-orientation ends of every read as four IUPAC bit-planes of END_BASES bits
+    (plane c, word w of end e at row 7*c + w, column e; e = 2*read for the head, 2*read+1 for the reverse
+    complement of the tail).  Bit p of a plane = bit c of the 4-bit code (A=1 G=2 C=4 T=8 N=15) of base p."""
+    device = head.device
+    n, E = head.shape
+    lut = torch.tensor([1, 2, 4, 8, 15], dtype=torch.int64, device=device)
+    fwd = lut[head.long()]
+    t = torch.flip(tail.long(), dims=[1])
+    t = torch.where(t > 3, t, 3 - t)
+    rev = lut[t]
+    ends = torch.stack([fwd, rev], dim=1).reshape(2 * n, E)  # [2n, E]
+    nw = (E + 31) // 32
+    padw = nw * 32 - E
+    if padw:
+        ends = torch.cat([ends, torch.zeros((2 * n, padw), dtype=torch.int64, device=device)], dim=1)
+    sh = torch.arange(32, device=device, dtype=torch.int64)
+    rows = []
+    for c in range(4):
+        bits = ((ends >> c) & 1).reshape(2 * n, nw, 32)
+        words = (bits << sh).sum(-1)  # [2n, nw] values < 2^32
+        rows.append(words.t())
+    planes = torch.cat(rows, dim=0)  # [4*nw, 2n]
+    planes = torch.where(planes >= (1 << 31), planes - (1 << 32), planes)
+    return planes.to(torch.int32).contiguous()
