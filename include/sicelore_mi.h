@@ -111,10 +111,90 @@ int smi_extract_windows_device(smi_ctx *ctx, const uint8_t *d_reads, const uint6
 
 /* Replaces UsedCellBCListGenerator$Worker's membership test + histogram increment
  * (FJ!nanoporereadscanner/analyzers/UsedCellBCListGenerator.java:L207-229): for every read with pass[i] != 0,
- * if keys[i] is in the loaded set, ++hist[ordinal(keys[i])].  Ordinals are positions in the key array given to
- * smi_set_barcode_set (first occurrence).  hist must hold n_set uint32 counters. */
+ * if keys[i] is in the loaded set, ++hist[ordinal(keys[i])].  ordinal(key) = rank of the key in ascending key order among the
+ * distinct keys given to smi_set_barcode_set.  hist must hold n_distinct uint32 counters. */
 int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
                     void *stream);
+
+
+/* ================================================================================================================
+ * Read scan (3' protocol): polyA/T finder + k-mer gated Needleman-Wunsch adapter scan + strand decision.
+ * Replaces PolyATadapterAnalyzer_3pBCUMI.search minus the TSO scan
+ * (FJ!nanoporereadscanner/analyzers/PolyATadapterAnalyzer_3pBCUMI.java:L45-68 ->
+ *  FJ!nanopore/analyzers/PolyATadapterAnalyzerBase.java:L109-319, PolyATSearcher.java:L56-252,
+ *  AdapterTSOanalyzer.java:L84-110) and, with qualities, the pass-1 filter of
+ * UsedCellBCListGenerator$Worker (UsedCellBCListGenerator.java:L198-202).
+ *
+ * Device read batch ("ends"): for read i the head (first SMI_END_BASES bases) is end 2i, the reverse complement of
+ * its last SMI_END_BASES bases is end 2i+1 -- the two orientations PolyATSearcher scans (L178-181).  An end is
+ * stored as four bit-planes (bit c of the reference's 4-bit IUPAC code A=1 G=2 C=4 T=8 N=15,
+ * TB!nuc/encoding/NucleicAcidByteCodeBase.java:L45-78) of SMI_PLANE_WORDS 32-bit words; word w of plane c of end e
+ * lives at ends[(c * SMI_PLANE_WORDS + w) * (2 n) + e], bit p%32 of word p/32 = base p.  Bases beyond the read are 0.
+ * ================================================================================================================ */
+#define SMI_END_BASES 224
+#define SMI_PLANE_WORDS 7
+#define SMI_ENDS_ROWS (4 * SMI_PLANE_WORDS)
+
+/* flag bits = ordinals of FJ!nanoporereadscanner/stats/ReadFlags$Flags (ReadFlags.java:L72-109) */
+#define SMI_F_FAILED (1u << 6)
+#define SMI_F_PASSED_FWD (1u << 9)
+#define SMI_F_PASSED_REV (1u << 10)
+#define SMI_F_POLY_T_5P (1u << 12)
+#define SMI_F_POLY_A_3P (1u << 13)
+#define SMI_F_POLY_A_NOT_FOUND (1u << 14)
+#define SMI_F_POLY_T_5P_POLY_A_3P (1u << 15)
+#define SMI_F_ADAPTER_5P (1u << 16)
+#define SMI_F_ADAPTER_3P (1u << 17)
+#define SMI_F_ADAPTER_SELECTED_DESP_BOTH (1u << 20)
+#define SMI_F_READ_TOO_SHORT (1u << 21)
+#define SMI_F_ADAPTER_5P_AND_3P (1u << 22)
+
+typedef struct {
+    int32_t min_read_length;        /* Jar/config.xml:21   200 */
+    int32_t polya_len;              /* :95  15 */
+    float polya_frac;               /* :97  0.75 */
+    int32_t window_polya;           /* :105 150 */
+    int32_t max_mismatches;         /* :115 maxNeedlemanMismatches 3 */
+    int32_t min_adapter_3p_matches; /* :59  8 */
+    int32_t min_mean_bc_qv;         /* :55  8 */
+    int32_t min_mean_read_qv;       /* :57  8 */
+    int32_t adapter_len;            /* 10 (pass 2, "CTTCCGATCT") or 22 (pass 1, complete adapter), Parser.java:L135 */
+    uint32_t adapter4[22];          /* 4-bit codes of the adapter */
+} smi_scan_config;
+
+typedef struct {
+    uint32_t flags;
+    int32_t adapter_start, adapter_end; /* AS / AE: stranded, 1-based (ReadScanResult.java:L445-447); 0 = none */
+    int32_t polya_start, polya_end;     /* PS / PE (ReadScanResult.java:L346,L356) */
+    int32_t scan_end;                   /* adapter end in scan orientation */
+    int16_t adapter_nmis;               /* NeedlemanMatch.getNerrorsNeedleman of the accepted alignment */
+    int8_t found;                       /* adapterFound() */
+    int8_t reverse;                     /* 1: stranded read = reverse complement of the raw read (PASSED_REV) */
+    int8_t pass1_ok;                    /* pass-1 quality filter passed (only when qualities were given) */
+    int8_t reserved;
+    int16_t pad;
+} smi_scan_result;
+
+/* fills cfg with the shipped config.xml values; pass = 1 (complete adapter) or 2 (short adapter) */
+int smi_scan_default_config(int pass, smi_scan_config *cfg);
+
+/* ASCII reads (concatenated, read i = [offsets[i], offsets[i+1])) -> ends / lengths (+ right-aligned tail qualities
+ * [n][SMI_END_BASES] and sum of (q-33) per read when quals != NULL).  The packing half of FastqRecordExt /
+ * NucleicAcidOneBytePerBase construction (PolyATSearcher.java:L178-181). */
+int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets,
+                         size_t n, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail, uint32_t *d_qsum,
+                         void *stream);
+
+/* d_qtail / d_qsum may be NULL (pass 2); d_windows may be NULL.  windows[i] is the smi_bc_window of read i (valid flag
+ * clear when no adapter was found), ready for smi_bc_match_device. */
+int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_len, const uint8_t *d_qtail,
+                    const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
+                    smi_bc_window *d_windows, void *stream);
+
+/* pass-1 histogram straight from scan output: for reads with pass1_ok, key = offset-0 barcode of the window
+ * (UsedCellBCListGenerator.java:L207-229); ++hist[ordinal(key)] when the key is in the loaded set */
+int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n,
+                            uint32_t *d_hist, void *stream);
 
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */

@@ -10,6 +10,8 @@ from . import codec  # noqa: F401
 from .lib import (  # noqa: F401
     BC_RESULT_DTYPE,
     BC_WINDOW_DTYPE,
+    SCAN_CONFIG_DTYPE,
+    SCAN_RESULT_DTYPE,
     Context,
     SmiError,
     library_path,

@@ -495,4 +495,37 @@ int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, siz
     return SMI_OK;
 }
 
+// pass-1 histogram from scan output: offset-0 key of the window (same make_key as the matcher: N emulation included)
+__global__ void k_hist_windows(const smi_bc_window *__restrict__ win, const smi_scan_result *__restrict__ scan, size_t n,
+                               Pyramid P, uint32_t *__restrict__ hist) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (!scan[i].pass1_ok) continue;
+        const smi_bc_window w = win[i];
+        if (!(w.flags & SMI_WIN_VALID)) continue;
+        const uint32_t k = make_key(w.bases, w.nmask, 0, false).key;
+        if (!bit_of(P.l0, k >> kG0)) continue;
+        if (!bit_of(P.l1, k >> kG1)) continue;
+        const uint32_t blk = k >> 8;
+        const uint32_t *wd = P.fine + (size_t)blk * 8;
+        const uint32_t wi = (k >> 5) & 7u;
+        const uint32_t word = wd[wi];
+        if (!((word >> (k & 31)) & 1u)) continue;
+        uint32_t ord = P.rank[blk] + __popc(word & ((1u << (k & 31)) - 1u));
+        for (uint32_t j = 0; j < wi; j++) ord += __popc(wd[j]);
+        atomicAdd(&hist[ord], 1u);
+    }
+}
+
+int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan_result *d_scan, size_t n,
+                        uint32_t *d_hist, hipStream_t s) {
+    if (!n) return SMI_OK;
+    Pyramid P = pyramid_of(ctx);
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_hist_windows, dim3(grid), dim3(256), 0, s, d_win, d_scan, n, P, d_hist);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
 }  // namespace smi

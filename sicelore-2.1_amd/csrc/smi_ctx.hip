@@ -246,4 +246,72 @@ int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass,
     return launch_hist(ctx, d_keys, d_pass, n, d_hist, (hipStream_t)stream);
 }
 
+
+int smi_scan_default_config(int pass, smi_scan_config *cfg) {
+    if (!cfg || (pass != 1 && pass != 2)) {
+        set_error("smi_scan_default_config: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->min_read_length = 200;
+    cfg->polya_len = 15;
+    cfg->polya_frac = 0.75f;
+    cfg->window_polya = 150;
+    cfg->max_mismatches = 3;
+    cfg->min_adapter_3p_matches = 8;
+    cfg->min_mean_bc_qv = 8;
+    cfg->min_mean_read_qv = 8;
+    // Jar/config.xml:111-113: sequence / sequence_complete of adapter_for3pBarcoding
+    const char *ad = pass == 1 ? "CTACACGACGCTCTTCCGATCT" : "CTTCCGATCT";
+    cfg->adapter_len = (int32_t)std::strlen(ad);
+    for (int i = 0; i < cfg->adapter_len; i++)
+        cfg->adapter4[i] = ad[i] == 'A' ? 1u : ad[i] == 'G' ? 2u : ad[i] == 'C' ? 4u : 8u;
+    return SMI_OK;
+}
+
+int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets,
+                         size_t n, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail, uint32_t *d_qsum,
+                         void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_reads || !d_offsets || !d_ends || !d_read_len || (d_quals && (!d_qtail || !d_qsum)))) {
+        set_error("smi_pack_ends_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_pack_ends(ctx, d_reads, d_quals, d_offsets, n, d_ends, d_read_len, d_qtail, d_qsum, (hipStream_t)stream);
+}
+
+int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_len, const uint8_t *d_qtail,
+                    const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
+                    smi_bc_window *d_windows, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (!cfg || (n && (!d_ends || !d_read_len || !d_out)) || ((d_qtail == nullptr) != (d_qsum == nullptr))) {
+        set_error("smi_scan_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    if (cfg->adapter_len != 10 && cfg->adapter_len != 22) {
+        set_error("smi_scan_device: adapter length must be 10 or 22 in this build (config.xml sequence / sequence_complete)");
+        return SMI_ERR_INVALID;
+    }
+    if (cfg->polya_len < 5 || cfg->polya_len > 30 || cfg->window_polya + cfg->polya_len + 10 > 175 ||
+        cfg->window_polya < 1) {
+        set_error("smi_scan_device: polyA window does not fit the 175-base scan region");
+        return SMI_ERR_INVALID;
+    }
+    return launch_scan(ctx, d_ends, d_read_len, d_qtail, d_qsum, n, cfg, d_out, d_windows, (hipStream_t)stream);
+}
+
+int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n,
+                            uint32_t *d_hist, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_windows || !d_scan || !d_hist)) {
+        set_error("smi_hist_windows_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    if (ctx->set_mode < 0) {
+        set_error("smi_hist_windows_device: no barcode set loaded");
+        return SMI_ERR_STATE;
+    }
+    return launch_hist_windows(ctx, d_windows, d_scan, n, d_hist, (hipStream_t)stream);
+}
+
 }  // extern "C"

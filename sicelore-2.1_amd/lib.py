@@ -16,7 +16,22 @@ BC_RESULT_DTYPE = np.dtype(
     [("bc", "<u4"), ("ed_sec", "<i4"), ("found", "i1"), ("ed", "i1"), ("offset", "i1"), ("ins_minus_del", "i1"),
      ("n_matches", "<u4")]
 )
-assert BC_WINDOW_DTYPE.itemsize == 16 and BC_RESULT_DTYPE.itemsize == 16
+SCAN_RESULT_DTYPE = np.dtype(
+    [("flags", "<u4"), ("adapter_start", "<i4"), ("adapter_end", "<i4"), ("polya_start", "<i4"), ("polya_end", "<i4"),
+     ("scan_end", "<i4"), ("adapter_nmis", "<i2"), ("found", "i1"), ("reverse", "i1"), ("pass1_ok", "i1"),
+     ("reserved", "i1"), ("pad", "<i2")]
+)
+SCAN_CONFIG_DTYPE = np.dtype(
+    [("min_read_length", "<i4"), ("polya_len", "<i4"), ("polya_frac", "<f4"), ("window_polya", "<i4"),
+     ("max_mismatches", "<i4"), ("min_adapter_3p_matches", "<i4"), ("min_mean_bc_qv", "<i4"),
+     ("min_mean_read_qv", "<i4"), ("adapter_len", "<i4"), ("adapter4", "<u4", (22,))]
+)
+END_BASES = 224
+ENDS_ROWS = 28
+FLAG_BITS = {"FAILED": 6, "PASSED_FWD": 9, "PASSED_REV": 10, "POLY_T_5P": 12, "POLY_A_3P": 13, "POLY_A_NOT_FOUND": 14,
+             "POLY_T_5P_POLY_A_3P": 15, "ADAPTER_5P": 16, "ADAPTER_3P": 17, "ADAPTER_SELECTED_DESP_BOTH": 20,
+             "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22}
+assert BC_WINDOW_DTYPE.itemsize == 16 and BC_RESULT_DTYPE.itemsize == 16 and SCAN_RESULT_DTYPE.itemsize == 32
 
 SET_USED_LIST = 0
 SET_WHITELIST = 1
@@ -25,7 +40,8 @@ SET_WHITELIST = 1
 EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
-    "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing",
+    "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
+    "smi_scan_device", "smi_hist_windows_device",
 ]
 
 
@@ -61,6 +77,10 @@ def load_library():
     lib.smi_bc_match_device.argtypes = [vp, vp, sz, ci, ci, vp, vp]
     lib.smi_extract_windows_device.argtypes = [vp, vp, vp, vp, sz, ci, vp, vp]
     lib.smi_hist_device.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.smi_scan_default_config.argtypes = [ci, vp]
+    lib.smi_pack_ends_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.smi_scan_device.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
+    lib.smi_hist_windows_device.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.smi_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.smi_set_timing.argtypes = [vp, ci]
     for name in EXPORTS:
@@ -149,6 +169,27 @@ class Context:
     def hist_device(self, d_keys_u32, d_pass_u8, d_hist_u32, n, stream=None):
         self._check(self._lib.smi_hist_device(self._h, _ptr(d_keys_u32), _ptr(d_pass_u8), int(n), _ptr(d_hist_u32),
                                               _stream_ptr(stream)))
+
+    # ---- read scan ---------------------------------------------------------------------------------------
+    def scan_config(self, pass_no=2):
+        """shipped config.xml values; pass 1 = complete adapter (22 nt), pass 2 = short adapter (10 nt)"""
+        cfg = np.zeros(1, dtype=SCAN_CONFIG_DTYPE)
+        self._check(self._lib.smi_scan_default_config(int(pass_no), _ptr(cfg)))
+        return cfg
+
+    def pack_ends_device(self, d_reads, d_quals, d_offsets, n, d_ends, d_len, d_qtail=None, d_qsum=None, stream=None):
+        self._check(self._lib.smi_pack_ends_device(self._h, _ptr(d_reads), _ptr(d_quals), _ptr(d_offsets), int(n),
+                                                   _ptr(d_ends), _ptr(d_len), _ptr(d_qtail), _ptr(d_qsum),
+                                                   _stream_ptr(stream)))
+
+    def scan_device(self, d_ends, d_len, n, cfg, d_out, d_windows=None, d_qtail=None, d_qsum=None, stream=None):
+        """d_ends int32 [28, 2n]; d_len int32 [n]; d_out int32 [n, 8] (32-B records); d_windows int64 [n, 2]"""
+        self._check(self._lib.smi_scan_device(self._h, _ptr(d_ends), _ptr(d_len), _ptr(d_qtail), _ptr(d_qsum), int(n),
+                                              _ptr(cfg), _ptr(d_out), _ptr(d_windows), _stream_ptr(stream)))
+
+    def hist_windows_device(self, d_windows, d_scan, n, d_hist, stream=None):
+        self._check(self._lib.smi_hist_windows_device(self._h, _ptr(d_windows), _ptr(d_scan), int(n), _ptr(d_hist),
+                                                      _stream_ptr(stream)))
 
     # ---- timing ------------------------------------------------------------------------------------------
     def set_timing(self, enabled=True):

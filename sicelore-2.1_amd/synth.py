@@ -142,7 +142,7 @@ def pack_windows(codes, ae, five_prime=False):
 # ---------------------------------------------------------------------------------------------------------------
 # whole reads (both ends) for the scan stage
 # ---------------------------------------------------------------------------------------------------------------
-END_BASES = 208  # bases kept per read end on the device (175 scanned + room for the barcode windows)
+END_BASES = 224  # bases kept per read end on the device (= SMI_END_BASES: 175 scanned + room for the barcode windows)
 TSO_COMPLETE = "AAGCAGTGGTATCAACGCAGAGTACATGGG"
 
 

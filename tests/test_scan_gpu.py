@@ -1,0 +1,155 @@
+"""GPU parity tests of the read scan (K-PACK, K-SCAN, pass-1 histogram) against the oracle, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+AD = {1: "CTACACGACGCTCTTCCGATCT", 2: "CTTCCGATCT"}
+FIELDS = ("adapter_start", "adapter_end", "polya_start", "polya_end", "scan_end", "adapter_nmis", "reverse")
+
+
+def _ascii_batch(synth, reads, n, short_every=0):
+    seqs, quals = [], []
+    for i in range(n):
+        s, q = synth.materialize(reads, i)
+        if short_every and i % short_every == 0:
+            s, q = s[:150], q[:150]
+        if short_every and i % short_every == 1:
+            k = 200 + (i % 23)  # shortest legal reads: the two ends overlap
+            s, q = s[:k // 2] + s[-(k - k // 2):], q[:k // 2] + q[-(k - k // 2):]
+        seqs.append(s)
+        quals.append(q)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    ra = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    qa = np.frombuffer("".join(quals).encode(), dtype=np.uint8)
+    return ra, qa, offs
+
+
+def _scan_gpu(pkg, ctx, ra, qa, offs, pass_no):
+    n = offs.size - 1
+    d_reads, d_quals = torch.from_numpy(ra.copy()).cuda(), torch.from_numpy(qa.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_ends = torch.zeros((28, 2 * n), dtype=torch.int32, device="cuda")
+    d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_qtail = torch.zeros((n, 224), dtype=torch.uint8, device="cuda")
+    d_qsum = torch.zeros(n, dtype=torch.int32, device="cuda")
+    ctx.pack_ends_device(d_reads, d_quals, d_offs, n, d_ends, d_len, d_qtail, d_qsum)
+    cfg = ctx.scan_config(pass_no)
+    d_out = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    d_win = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
+    ctx.scan_device(d_ends, d_len, n, cfg, d_out, d_win, d_qtail, d_qsum)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(pkg.SCAN_RESULT_DTYPE).reshape(-1)
+    return got, d_win, d_out, (d_ends, d_len)
+
+
+def _compare(got, st, exp, pass1):
+    assert (st == 0).all()
+    assert (got["reserved"] == 0).all()
+    bad = np.nonzero(got["flags"].astype(np.uint64) != exp["flags"])[0]
+    assert bad.size == 0, f"flags differ at {bad[:10]}: {got['flags'][bad[:5]]} vs {exp['flags'][bad[:5]]}"
+    assert (got["found"] == exp["adapter_found"]).all()
+    sel = exp["adapter_found"] == 1
+    for f in FIELDS:
+        bad = np.nonzero(got[f][sel].astype(np.int64) != exp[f][sel])[0]
+        assert bad.size == 0, f"{f} differs at {bad[:10]}"
+    # polyA coordinates are also set when a side was chosen but no alignment was accepted
+    for f in ("polya_start", "polya_end"):
+        assert (got[f].astype(np.int64) == exp[f]).all()
+    if pass1:
+        assert (got["pass1_ok"] == exp["pass1_ok"]).all()
+    return int(sel.sum())
+
+
+@pytest.mark.parametrize("pass_no", [2, 1])
+def test_scan_matches_oracle(pkg, synth, sor, gpu_ctx, pass_no):
+    wl = synth.make_whitelist(50_000, seed=201)
+    used = synth.pick_used(wl, 300, seed=202)
+    n = 6000
+    reads = synth.gen_reads(n, used, seed=203 + pass_no, n_rate=0.003)
+    ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
+    got, d_win, _, _ = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, pass_no)
+    st, exp = sor.scan_batch_3p(ra, qa, offs, AD[pass_no], n_threads=8)
+    n_found = _compare(got, st, exp, pass1=True)
+    assert n_found > 0.6 * n
+    if pass_no == 1:
+        assert exp["pass1_ok"].sum() > 0.05 * n
+
+
+def test_pack_ends_equals_torch_packer(pkg, synth, gpu_ctx):
+    wl = synth.make_whitelist(10_000, seed=211)
+    used = synth.pick_used(wl, 100, seed=212)
+    n = 500
+    reads = synth.gen_reads(n, used, seed=213, n_rate=0.01)
+    # make every read exactly head+tail (mid_len = 0) so that the torch packer sees the same bases
+    reads["mid_len"][:] = 0
+    ra, qa, offs = _ascii_batch(synth, reads, n)
+    _, _, _, (d_ends, d_len) = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, 2)
+    exp = synth.pack_ends(reads["head"], reads["tail"])
+    assert (d_ends.cpu() == exp).all()
+    assert (d_len.cpu() == 448).all()
+
+
+def test_scan_then_match_end_to_end(pkg, synth, sor, gpu_ctx):
+    """pass 2 on the device: K-SCAN windows -> K-BC1 == oracle scan -> oracle assignBarcode"""
+    wl = synth.make_whitelist(100_000, seed=221)
+    used = synth.pick_used(wl, 500, seed=222)
+    n = 5000
+    reads = synth.gen_reads(n, used, seed=223, n_rate=0.002)
+    ra, qa, offs = _ascii_batch(synth, reads, n, short_every=50)
+    got, d_win, _, _ = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, 2)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    d_res = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    gpu_ctx.bc_match_device(d_win, d_res, n, max_ed=1)
+    torch.cuda.synchronize()
+    res = d_res.cpu().numpy().view(pkg.BC_RESULT_DTYPE).reshape(-1)
+    st, exp = sor.scan_batch_3p(ra, qa, offs, AD[2], n_threads=8)
+    bset = sor.BarcodeSet(used.numpy())
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    n_assigned = n_right = 0
+    for i in range(n):
+        if not exp["adapter_found"][i]:
+            assert res["found"][i] == -1
+            continue
+        seq = bytes(ra[int(offs[i]):int(offs[i + 1])])
+        stranded = seq.translate(comp)[::-1] if exp["reverse"][i] else seq
+        rc, a = sor.assign_barcode(bset, stranded, int(exp["adapter_end"][i]), max_ed=1)
+        assert res["found"][i] == rc, i
+        if rc == 1:
+            n_assigned += 1
+            assert res["bc"][i] == np.uint32(a["bc"]) and res["ed"][i] == a["ed"] and res["ed_sec"][i] == a["ed_sec"]
+            assert res["offset"][i] == a["offset"] and res["ins_minus_del"][i] == a["ins_minus_del"]
+            n_right += int(a["bc"]) == int(reads["truth"][i])
+    assert n_assigned > 0.4 * n and n_right / n_assigned > 0.97
+
+
+def test_pass1_histogram(pkg, synth, sor, gpu_ctx):
+    """pass 1 on the device: scan with the complete adapter + quality filter + exact whitelist membership +
+    histogram == the same done with the oracle (UsedCellBCListGenerator.java:L198-229)"""
+    wl = synth.make_whitelist(200_000, seed=231)
+    used = synth.pick_used(wl, 200, seed=232)
+    n = 8000
+    reads = synth.gen_reads(n, used, seed=233, q_mean=14.0)
+    ra, qa, offs = _ascii_batch(synth, reads, n)
+    got, d_win, d_out, _ = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, 1)
+    gpu_ctx.set_barcode_set(wl.numpy().astype(np.uint64), mode=1)
+    d_hist = torch.zeros(wl.numel(), dtype=torch.int32, device="cuda")
+    gpu_ctx.hist_windows_device(d_win, d_out, n, d_hist)
+    torch.cuda.synchronize()
+    hist = d_hist.cpu().numpy()
+    st, exp = sor.scan_batch_3p(ra, qa, offs, AD[1], n_threads=8)
+    wl_sorted = np.sort(wl.numpy())
+    ref = np.zeros(wl.numel(), dtype=np.int64)
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    for i in np.nonzero(exp["pass1_ok"] == 1)[0]:
+        seq = bytes(ra[int(offs[i]):int(offs[i + 1])])
+        stranded = seq.translate(comp)[::-1] if exp["reverse"][i] else seq
+        ae = int(exp["adapter_end"][i])
+        key = sor.revcomp(sor.encode(stranded[ae - 17:ae - 1].decode()))
+        j = np.searchsorted(wl_sorted, key)
+        if j < wl_sorted.size and wl_sorted[j] == key:
+            ref[j] += 1
+    assert ref.sum() > 200
+    assert (hist == ref).all()
