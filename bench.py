@@ -23,6 +23,8 @@ import __graft_entry__ as graft  # noqa: E402
 
 # algorithmic bytes per read of the ed <= 1 matcher = 16 (window) + 16 (result) + 4 x 620 probes
 ALG_BYTES_PER_READ_BC1 = 2512
+# K-PA + K-AD scan: 2 x 175 bases (1 B/base as the reference holds them) + 32 B result
+ALG_BYTES_PER_READ_SCAN = 382
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -34,7 +36,7 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (configs[1]: 10 M)")
     ap.add_argument("--whitelist", type=int, default=3_600_000)
     ap.add_argument("--cells", type=int, default=5000)
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="reads of the same workload timed on the host")
+    ap.add_argument("--cpu-sample", type=int, default=200_000, help="reads of the same workload timed on the host")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -65,21 +67,35 @@ def main():
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
     ctx = pkg.Context(local_rank)
 
-    # ---- inputs (synthetic, seeded; built on the device, resident in HBM before the timed region) ----------
+    # ---- inputs (synthetic, seeded; built on the device in chunks, resident in HBM before the timed region) ----
     n = args.reads
     wl = synth.make_whitelist(args.whitelist, seed=1, device=dev)           # same list on every rank
     used = synth.pick_used(wl, args.cells, seed=2)
     ctx.set_barcode_set_device(wl.to(torch.int32), mode=1)                   # -g semantics: search set = whole list
-    reg = synth.gen_bc_region(n, used, seed=1000 + rank, device=dev)         # each rank has its own shard of reads
-    win = synth.pack_windows(reg["codes"], reg["ae"])
+    ends = torch.empty((28, 2 * n), dtype=torch.int32, device=dev)           # packed read ends (bit-planes)
+    lens = torch.empty(n, dtype=torch.int32, device=dev)
+    truth = torch.empty(n, dtype=torch.int64, device=dev)
+    chunk = 1_000_000
+    cpu_reads = None
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        rd = synth.gen_reads(m, used, seed=1000 + 97 * rank + c0 // chunk, device=dev)   # each rank its own reads
+        ends[:, 2 * c0:2 * (c0 + m)] = synth.pack_ends(rd["head"], rd["tail"])
+        lens[c0:c0 + m] = (2 * synth.END_BASES + rd["mid_len"]).to(torch.int32)
+        truth[c0:c0 + m] = rd["truth"]
+        if c0 == 0 and rank == 0:
+            k = min(args.cpu_sample, m)
+            cpu_reads = {key: (v[:k].cpu() if torch.is_tensor(v) else v) for key, v in rd.items()}
+        del rd
+    scan_cfg = ctx.scan_config(2)
+    scan_out = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    win = torch.zeros((n, 2), dtype=torch.int64, device=dev)
     out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
-    truth = reg["truth"]
-    cpu_codes = reg["codes"][: args.cpu_sample].cpu().numpy() if rank == 0 else None
-    cpu_ae = reg["ae"][: args.cpu_sample].cpu().numpy() if rank == 0 else None
-    del reg
     torch.cuda.synchronize()
 
     def step():
+        # pass 2 of scanfastq for one batch: polyA/adapter scan -> barcode windows -> ed<=1 match + best/second rule
+        ctx.scan_device(ends, lens, n, scan_cfg, scan_out, win)
         ctx.bc_match_device(win, out, n, max_ed=1, five_prime=False)
 
     def barrier():
@@ -91,14 +107,14 @@ def main():
         step()
     barrier()
     ctx.set_timing(True)
-    kernel_ms = []
+    scan_ms, match_ms = [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        # HIP events were recorded on the launch stream around the kernel; reading them synchronises that event
-        # only after the loop would lose all but the last, so collect per step (adds one event sync per step,
-        # inside the timed region -- conservative)
-        kernel_ms.append(ctx.last_kernel_ms())
+        # HIP events were recorded on the launch stream around each kernel; reading them waits for this step's
+        # kernels (one sync per step inside the timed region -- conservative)
+        scan_ms.append(ctx.kernel_ms(ctx.K_SCAN))
+        match_ms.append(ctx.kernel_ms(ctx.K_BC_MATCH))
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -119,15 +135,19 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n * world * args.steps / elapsed
-    k_ms = float(np.mean(kernel_ms))
-    achieved = ALG_BYTES_PER_READ_BC1 * n / (k_ms * 1e-3) / 1e9
+    k_scan, k_match = float(np.mean(scan_ms)), float(np.mean(match_ms))
+    # dominant kernel = the longer of the two; algorithmic bytes per read from SURVEY.md section 8d
+    dom = ("k_scan<10>", k_scan, ALG_BYTES_PER_READ_SCAN) if k_scan >= k_match else \
+          ("k_bc_match_ed1<1>", k_match, ALG_BYTES_PER_READ_BC1)
+    achieved = dom[2] * n / (dom[1] * 1e-3) / 1e9
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc):
         try:
-            traffic = json.load(open(pmc)).get("k_bc_match_ed1", {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get(dom[0].split("<")[0], {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    n_adapter = int(((scan_out[:, 6] >> 16) & 0xFF).eq(1).sum().item())
     res = {
         "metric": "Nanopore reads/sec BC-assigned at ed<=1, 3.6M whitelist",
         "value": value,
@@ -140,27 +160,32 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32",
-        "data": f"synthetic ({synth.GENERATOR_VERSION}, seeds wl=1 used=2 reads=1000+rank, err=6.3% 40/30/30 sub/ins/del)",
+        "data": f"synthetic ({synth.GENERATOR_VERSION}, seeds wl=1 used=2 reads=1000+97*rank+chunk, err=6.3% 40/30/30 sub/ins/del, "
+                "50% reverse strand, read length 448..1948)",
         "config": {
-            "workload": "configs[1]: 10M synthetic Nanopore reads, ed<=1 vs 3.6M whitelist (-g semantics), 3' protocol, "
-                        "5 offsets; timed = barcode window match + best/second rule (K-BC1) on HBM-resident windows",
+            "workload": "configs[1]: 10M synthetic Nanopore reads, ed<=1 vs 3.6M whitelist (-g semantics), 3' protocol; "
+                        "timed = pass 2 per read from packed read ends in HBM: polyA/T finder + k-mer gated NW adapter scan "
+                        "+ strand decision (K-SCAN) -> 5-offset barcode match + best/second rule (K-BC1); "
+                        "not in the step: FASTQ decode/packing, chimera split, TSO flagging, UMI stage",
             "reads_per_gpu": n,
             "whitelist": int(wl.numel()),
             "cells": args.cells,
+            "adapter_found_frac": n_adapter / n,
             "bc_assigned_frac": n_found / n,
             "bc_assigned_accuracy": acc,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_bc_match_ed1<1>",
+            "kernel": dom[0],
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "kernel_ms": k_ms,
-            "probes_per_s": 620.0 * n / (k_ms * 1e-3),
-            "alg_bytes_per_read": ALG_BYTES_PER_READ_BC1,
+            "kernel_ms": dom[1],
+            "alg_bytes_per_read": dom[2],
+            "kernels_ms": {"k_scan<10>": k_scan, "k_bc_match_ed1<1>": k_match},
+            "probes_per_s_bc1": 620.0 * n / (k_match * 1e-3),
         },
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -168,21 +193,44 @@ def main():
         sor.build()
         cores = os.cpu_count() or 1
         bset = sor.BarcodeSet(wl.cpu().numpy())
-        m = cpu_codes.shape[0]
+        m = int(cpu_reads["head"].shape[0])
+        seqs, quals = zip(*(synth.materialize(cpu_reads, i) for i in range(m)))
+        offs = np.zeros(m + 1, dtype=np.uint64)
+        offs[1:] = np.cumsum([len(s_) for s_ in seqs])
+        ra = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
         t0 = time.perf_counter()
-        st, exp = sor.assign_batch(bset, cpu_codes, cpu_ae, max_ed=1, n_threads=cores)
+        st, sc = sor.scan_batch_3p(ra, None, offs, synth.ADAPTER_3P_SHORT, n_threads=cores)
+        # stranded barcode regions for assignBarcode: reuse the oracle on windows cut out of the stranded read
+        codes = np.full((m, 64), 4, dtype=np.uint8)
+        ae = np.zeros(m, dtype=np.int32)
+        lut = np.full(256, 4, dtype=np.uint8)
+        for ch, v in ((b"A", 0), (b"G", 1), (b"C", 2), (b"T", 3)):
+            lut[ch[0]] = v
+        comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+        for i in range(m):
+            if not sc["adapter_found"][i]:
+                continue
+            seq = bytes(ra[int(offs[i]):int(offs[i + 1])])
+            stranded = seq.translate(comp)[::-1] if sc["reverse"][i] else seq
+            a = int(sc["adapter_end"][i])
+            lo = max(a - 30, 0)
+            seg = np.frombuffer(stranded[lo:a + 2], dtype=np.uint8)
+            codes[i, :seg.size] = lut[seg]
+            ae[i] = a - lo
+        st2, exp = sor.assign_batch(bset, codes, ae, max_ed=1, n_threads=cores)
         dt = time.perf_counter() - t0
-        # the sample doubles as an end-of-run parity spot check of the timed output buffer
         got = out[:m].cpu().numpy().view(pkg.BC_RESULT_DTYPE).reshape(-1)
-        same = bool((got["found"] == np.where(st < 0, -1, exp["found"])).all() and
-                    (got["bc"][exp["found"] == 1] == exp["bc"][exp["found"] == 1].astype(np.uint32)).all())
+        exp_found = np.where(sc["adapter_found"] == 1, np.where(st2 < 0, -1, exp["found"]), -1)
+        same = bool((got["found"] == exp_found).all() and
+                    (got["bc"][exp_found == 1] == exp["bc"][exp_found == 1].astype(np.uint32)).all())
         res["cpu_baseline"] = {
             "value": m / dt,
             "unit": "reads/s",
             "cores": cores,
             "kind": "port",
-            "sample": f"first {m} reads of rank 0's batch, oracle/sor_bc.c (C restatement, OpenMP x{cores}); "
-                      "the Java reference cannot run here (no JVM); README quotes 20.8k reads/s on 96 cores for the whole scan",
+            "sample": f"first {m} reads of rank 0's batch (materialised as ASCII), oracle/sor_scan.c + sor_bc.c "
+                      f"(C restatement, OpenMP x{cores}; includes a Python loop cutting the stranded windows); the Java "
+                      "reference cannot run here (no JVM); README quotes 20.8k reads/s on 96 cores for the whole scan",
             "seconds": dt,
             "matches_gpu": same,
         }

@@ -199,6 +199,9 @@ int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const 
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);
+/* same, per kernel: the last launch of that kernel since timing was enabled */
+enum { SMI_K_BC_MATCH = 0, SMI_K_SCAN = 1, SMI_K_HIST = 2, SMI_K_PACK = 3, SMI_K_COUNT = 4 };
+int smi_kernel_ms(smi_ctx *ctx, int kernel_id, float *ms);
 int smi_set_timing(smi_ctx *ctx, int enabled);
 
 #ifdef __cplusplus

@@ -442,16 +442,13 @@ int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_
     Pyramid P = pyramid_of(ctx);
     const size_t n_waves = (n + 63) / 64;
     const unsigned grid = (unsigned)std::min<size_t>((n_waves + 3) / 4, 256 * 64);
-    if (ctx->timing) SMI_HIP(hipEventRecord(ctx->ev0, s));
+    if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
     if (max_ed == 0)
         hipLaunchKernelGGL(k_bc_match_ed1<0>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else
         hipLaunchKernelGGL(k_bc_match_ed1<1>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     SMI_HIP(hipGetLastError());
-    if (ctx->timing) {
-        SMI_HIP(hipEventRecord(ctx->ev1, s));
-        ctx->ev_valid = true;
-    }
+    if (int rc = time_end(ctx, SMI_K_BC_MATCH, s)) return rc;
     return SMI_OK;
 }
 
@@ -485,13 +482,10 @@ int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, siz
     if (!n) return SMI_OK;
     Pyramid P = pyramid_of(ctx);
     const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
-    if (ctx->timing) SMI_HIP(hipEventRecord(ctx->ev0, s));
+    if (int rc = time_begin(ctx, SMI_K_HIST, s)) return rc;
     hipLaunchKernelGGL(k_hist, dim3(grid), dim3(256), 0, s, d_keys, d_pass, n, P, d_hist);
     SMI_HIP(hipGetLastError());
-    if (ctx->timing) {
-        SMI_HIP(hipEventRecord(ctx->ev1, s));
-        ctx->ev_valid = true;
-    }
+    if (int rc = time_end(ctx, SMI_K_HIST, s)) return rc;
     return SMI_OK;
 }
 

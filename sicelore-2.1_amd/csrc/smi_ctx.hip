@@ -16,6 +16,22 @@ int hip_fail(hipError_t e, const char *what) {
     return SMI_ERR_HIP;
 }
 
+int time_begin(smi_ctx *ctx, int kid, hipStream_t s) {
+    if (!ctx->timing) return SMI_OK;
+    SMI_HIP(hipEventRecord(ctx->kev[kid][0], s));
+    return SMI_OK;
+}
+
+int time_end(smi_ctx *ctx, int kid, hipStream_t s) {
+    if (!ctx->timing) return SMI_OK;
+    SMI_HIP(hipEventRecord(ctx->kev[kid][1], s));
+    ctx->kev_valid[kid] = true;
+    ctx->ev0 = ctx->kev[kid][0];
+    ctx->ev1 = ctx->kev[kid][1];
+    ctx->ev_valid = true;
+    return SMI_OK;
+}
+
 Pyramid pyramid_of(const smi_ctx *ctx) {
     Pyramid p;
     p.l0 = ctx->l0;
@@ -102,8 +118,10 @@ int smi_ctx_create(int device, smi_ctx **out) {
     SMI_TRY(hipMalloc((void **)&ctx->rank, kRankEntries * 4));
     SMI_TRY(hipMalloc((void **)&ctx->block_counts, kRankEntries * 4));
     SMI_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    SMI_TRY(hipEventCreate(&ctx->ev0));
-    SMI_TRY(hipEventCreate(&ctx->ev1));
+    for (int k = 0; k < SMI_K_COUNT; k++) {
+        SMI_TRY(hipEventCreate(&ctx->kev[k][0]));
+        SMI_TRY(hipEventCreate(&ctx->kev[k][1]));
+    }
 #undef SMI_TRY
     *out = ctx;
     return SMI_OK;
@@ -120,8 +138,10 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->block_counts);
     (void)hipFree(ctx->stage_in);
     (void)hipFree(ctx->stage_out);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < SMI_K_COUNT; k++) {
+        if (ctx->kev[k][0]) (void)hipEventDestroy(ctx->kev[k][0]);
+        if (ctx->kev[k][1]) (void)hipEventDestroy(ctx->kev[k][1]);
+    }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SMI_OK;
@@ -136,6 +156,7 @@ int smi_set_timing(smi_ctx *ctx, int enabled) {
     }
     ctx->timing = enabled != 0;
     ctx->ev_valid = false;
+    for (int k = 0; k < SMI_K_COUNT; k++) ctx->kev_valid[k] = false;
     return SMI_OK;
 }
 
@@ -149,6 +170,19 @@ int smi_last_kernel_ms(smi_ctx *ctx, float *ms) {
     if (int rc = bind(ctx)) return rc;
     SMI_HIP(hipEventSynchronize(ctx->ev1));
     SMI_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return SMI_OK;
+}
+
+int smi_kernel_ms(smi_ctx *ctx, int kernel_id, float *ms) {
+    if (!ctx || !ms || kernel_id < 0 || kernel_id >= SMI_K_COUNT) {
+        set_error("smi_kernel_ms: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    *ms = -1.0f;
+    if (!ctx->kev_valid[kernel_id]) return SMI_OK;
+    if (int rc = bind(ctx)) return rc;
+    SMI_HIP(hipEventSynchronize(ctx->kev[kernel_id][1]));
+    SMI_HIP(hipEventElapsedTime(ms, ctx->kev[kernel_id][0], ctx->kev[kernel_id][1]));
     return SMI_OK;
 }
 

@@ -52,8 +52,10 @@ struct smi_ctx {
     size_t n_keys = 0;                 // distinct keys loaded
     int set_mode = -1;
     bool timing = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the last timed kernel
     bool ev_valid = false;
+    hipEvent_t kev[SMI_K_COUNT][2] = {};       // per kernel id (smi_kernel_ms)
+    bool kev_valid[SMI_K_COUNT] = {};
     // staging buffers of the *_batch entry points (grown on demand)
     void *stage_in = nullptr;
     void *stage_out = nullptr;
@@ -62,6 +64,8 @@ struct smi_ctx {
 };
 
 namespace smi {
+int time_begin(smi_ctx *ctx, int kid, hipStream_t s);
+int time_end(smi_ctx *ctx, int kid, hipStream_t s);
 Pyramid pyramid_of(const smi_ctx *ctx);
 int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_ed, int five_prime,
                     smi_bc_result *d_out, hipStream_t s);

@@ -508,7 +508,7 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     for (int i = 0; i < 22; i++) P.adapter4[i] = i < ad ? cfg->adapter4[i] : 0u;
     const size_t n_ends = 2 * n;
     const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 16);
-    if (ctx->timing) SMI_HIP(hipEventRecord(ctx->ev0, s));
+    if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;
     if (ad == 10) {
         const size_t lds = 5 * kLdsWords * kBlock * 4 + 10 * (kBlock / 2) * 8;
         hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), lds, s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out, d_win);
@@ -517,10 +517,7 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
         hipLaunchKernelGGL(k_scan<22>, dim3(grid), dim3(kBlock), lds, s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out, d_win);
     }
     SMI_HIP(hipGetLastError());
-    if (ctx->timing) {
-        SMI_HIP(hipEventRecord(ctx->ev1, s));
-        ctx->ev_valid = true;
-    }
+    if (int rc = time_end(ctx, SMI_K_SCAN, s)) return rc;
     return SMI_OK;
 }
 

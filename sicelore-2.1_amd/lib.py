@@ -41,7 +41,7 @@ EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
-    "smi_scan_device", "smi_hist_windows_device",
+    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms",
 ]
 
 
@@ -83,6 +83,7 @@ def load_library():
     lib.smi_hist_windows_device.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.smi_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.smi_set_timing.argtypes = [vp, ci]
+    lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is not ctypes.c_char_p:
@@ -194,6 +195,13 @@ class Context:
     # ---- timing ------------------------------------------------------------------------------------------
     def set_timing(self, enabled=True):
         self._check(self._lib.smi_set_timing(self._h, int(bool(enabled))))
+
+    K_BC_MATCH, K_SCAN, K_HIST, K_PACK = 0, 1, 2, 3
+
+    def kernel_ms(self, kernel_id):
+        ms = ctypes.c_float(-1.0)
+        self._check(self._lib.smi_kernel_ms(self._h, int(kernel_id), ctypes.byref(ms)))
+        return float(ms.value)
 
     def last_kernel_ms(self):
         ms = ctypes.c_float(-1.0)
