@@ -196,6 +196,20 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
 int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n,
                             uint32_t *d_hist, void *stream);
 
+/* End of pass 1 on the host (no device work): low-count filter, collision merge, low-depth cut and rank of the
+ * used-barcode list = UsedCellBCListGenerator$UsedBarcodesListData.finalizeData
+ * (FJ!nanoporereadscanner/analyzers/UsedCellBCListGenerator.java:L379-425), BarcodeDatasetColissionTester
+ * (BarcodeDatasetColissionTester.java:L68-229) and the rank assignment of WorkerReadscanner.scan
+ * (FJ!nanoporereadscanner/WorkerReadscanner.java:L265-273).
+ * keys/counts: the non-zero entries of the (all-reduced) pass-1 histogram; record_count = number of 10,000-read
+ * chunks seen in pass 1 (the reference's cutoff uses the chunk count, L254,L391); merge_ed = mergeBCsED
+ * (defaults to --bcEditDistance); min_count_fold = 10, cells_fold_below_max = 500 (Jar/config.xml:61,27).
+ * Outputs (capacity n each): barcodes sorted by count descending (equal counts: ascending key -- canonical order,
+ * see DESIGN.md), their counts and 1-based ranks (the rk= field). */
+int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count,
+                           int merge_ed, int min_count_fold, int cells_fold_below_max, uint64_t *out_keys,
+                           uint32_t *out_counts, uint32_t *out_rank, size_t *n_out);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

@@ -95,6 +95,11 @@ int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offs
 int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
                    int *ins, int *del, int *sub, float *end5);
 
+/* ---- pass-1 finalize (sor_final.c) ---- */
+int sor_finalize_used_list(const int64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count, int merge_ed,
+                           int min_count_fold, int cells_fold_below_max, int64_t *out_keys, uint32_t *out_counts,
+                           uint32_t *out_rank, size_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

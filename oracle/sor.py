@@ -212,3 +212,21 @@ def nw_strings(adapter, read_slice):
     L.sor_nw_strings(adapter.encode(), read_slice.encode(), a1, d, a2, ctypes.byref(ne), ctypes.byref(i),
                      ctypes.byref(dl), ctypes.byref(s), ctypes.byref(e5))
     return a1.value.decode(), d.value.decode(), a2.value.decode(), ne.value, i.value, dl.value, s.value, e5.value
+
+
+# ---- pass-1 finalize (sor_final.c) ---------------------------------------------------------------------------
+def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10, cells_fold_below_max=500):
+    L = lib()
+    k = np.ascontiguousarray(keys, dtype=np.int64)
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    ok, oc, orank = np.zeros(k.size, np.int64), np.zeros(k.size, np.uint32), np.zeros(k.size, np.uint32)
+    n_out = ctypes.c_size_t(0)
+    L.sor_finalize_used_list.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.POINTER(ctypes.c_size_t)]
+    rc = L.sor_finalize_used_list(k.ctypes.data, c.ctypes.data, k.size, record_count, merge_ed, min_count_fold,
+                                  cells_fold_below_max, ok.ctypes.data, oc.ctypes.data, orank.ctypes.data,
+                                  ctypes.byref(n_out))
+    assert rc == 0
+    m = n_out.value
+    return ok[:m], oc[:m], orank[:m]

@@ -1,0 +1,208 @@
+// smi_host.hip -- host-side steps of the path that run once per pass, not per read (no device code here).
+//
+// smi_finalize_used_list: end of pass 1 --
+//   UsedCellBCListGenerator$UsedBarcodesListData.finalizeData  FJ!nanoporereadscanner/analyzers/UsedCellBCListGenerator.java:L379-425
+//   BarcodeDatasetColissionTester                               FJ!nanoporereadscanner/analyzers/BarcodeDatasetColissionTester.java:L68-229
+//   WorkerReadscanner.scan (rank)                               FJ!nanoporereadscanner/WorkerReadscanner.java:L265-273
+// Input is the all-reduced pass-1 histogram restricted to non-zero counters (a few 10^4 keys), so this is a small
+// host job; the mutation-cycle walk below is the collision-mode variant of BarcodeMatchTester (post sequence absent,
+// full matches skipped, descent on hit for substitutions / on miss for indels: BarcodeMatchTester.java:L268,L295,L351).
+//
+// Canonical order: equal-count ties are broken by ascending key (the reference's order there depends on thread
+// timing and on fastutil internals; DESIGN.md section "Pass-1 finalize").
+#include <algorithm>
+#include <cstring>
+#include <unordered_set>
+#include <vector>
+
+#include "smi_internal.h"
+
+namespace smi {
+
+namespace {
+
+// ---- 64-bit mutate ops with Java shift semantics (NucleicAcidTwoBitPerBase.java:L228-233,L300-309,L321-327) ------
+inline uint64_t shl(uint64_t v, int s) { return v << (s & 63); }
+inline uint64_t shr(uint64_t v, int s) { return v >> (s & 63); }
+
+inline void subs16(uint64_t seq, int pos, uint64_t out[4]) {
+    const int sh = (16 - (pos + 1)) << 1;
+    seq &= ~shl(3, sh);
+    for (uint64_t b = 0; b < 4; b++) out[b] = seq | shl(b, sh);
+}
+inline void ins16(uint64_t h, int pos, uint64_t out[4]) {
+    int sh = (16 - pos - 1) << 1;
+    const uint64_t upper = shl(shr(h, sh), sh);
+    sh = 64 - sh;
+    h = shl(h, sh);
+    h = shr(h, sh + 2);  // count 64 at pos 14 wraps to 0: the dropped base stays in bits 62..63
+    const int at = 2 * (16 - (pos + 1) - 1);
+    for (uint64_t b = 0; b < 4; b++) out[b] = upper | h | shl(b, at);  // A,G,C,T
+}
+inline uint64_t del16(uint64_t h, uint64_t append2, int pos) {
+    int sh = (16 - pos) << 1;
+    const uint64_t upper = shl(shr(h, sh), sh);
+    sh = 64 - sh;
+    h = shl(h, sh + 2);
+    h = shr(h, sh);
+    return upper | h | append2;
+}
+
+struct Item {
+    uint64_t seq;
+    int16_t prev, pos, level;
+};
+struct Hit {
+    uint64_t bc;
+    int ed;
+};
+
+// Matches of one barcode against the set, collision mode.  Returns the HashSet content: first hit per level.
+void collision_matches(const std::unordered_set<uint64_t> &set, uint64_t seq, int max_ed, std::vector<Hit> &hits) {
+    hits.clear();
+    std::unordered_set<uint32_t> tested;  // IntHashSet of (int)seq, only when ed >= 2 (NucTwoBitPerBaseEDtesterBase.java:L82-95)
+    const bool use_tested = max_ed >= 2;
+    auto is_tested = [&](uint64_t s) { return use_tested && tested.count((uint32_t)s) != 0; };
+    auto record = [&](uint64_t s, int level) {
+        // OneMatch.equals ignores the barcode (BarcodeMatchTester.java:L433-436): one entry per level
+        for (const Hit &h : hits)
+            if (h.ed == level) return;
+        hits.push_back({s, level});
+    };
+    auto probe = [&](uint64_t s) { return s != seq && set.count(s) != 0; };  // skipFullMatches (L368)
+    if (max_ed == 0) return;
+    std::vector<Item> dq;
+    dq.push_back({seq, -1, -1, 1});
+    while (!dq.empty()) {
+        Item cur = dq.back();
+        dq.pop_back();
+        cur.pos++;
+        if (cur.pos < 15) dq.push_back(cur);
+        if (cur.prev == cur.pos) continue;
+        auto descend = [&](uint64_t s) {
+            if (max_ed > cur.level) dq.push_back({s, cur.pos, -1, (int16_t)(cur.level + 1)});
+        };
+        uint64_t v[4];
+        subs16(cur.seq, cur.pos, v);
+        for (int k = 0; k < 4; k++) {
+            if (v[k] == cur.seq || is_tested(v[k])) continue;
+            const bool hit = probe(v[k]);
+            if (hit) {
+                record(v[k], cur.level);
+                descend(v[k]);  // substitutions descend on hit
+            }
+        }
+        if (cur.pos < 15) {
+            ins16(cur.seq, cur.pos, v);
+            for (int k = 0; k < 4; k++) {
+                if (is_tested(v[k])) continue;
+                const bool hit = probe(v[k]);
+                if (hit)
+                    record(v[k], cur.level);
+                else
+                    descend(v[k]);  // indels descend on miss
+            }
+            const uint64_t m0 = del16(cur.seq, 0, cur.pos);
+            for (uint64_t b = 0; b < 4; b++) {  // no post sequence: the four possible appended bases (L336-340)
+                const uint64_t s = m0 | b;
+                if (is_tested(s)) continue;
+                const bool hit = probe(s);
+                if (hit)
+                    record(s, cur.level);
+                else
+                    descend(s);
+            }
+        }
+        if (use_tested) tested.insert((uint32_t)cur.seq);
+    }
+}
+
+struct KC {
+    uint64_t key;
+    uint32_t count;
+};
+
+}  // namespace
+}  // namespace smi
+
+using namespace smi;
+
+extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count,
+                                      int merge_ed, int min_count_fold, int cells_fold_below_max, uint64_t *out_keys,
+                                      uint32_t *out_counts, uint32_t *out_rank, size_t *n_out) {
+    if (!n_out || (n && (!keys || !counts || !out_keys || !out_counts || !out_rank)) || merge_ed < 0 || merge_ed > 2 ||
+        min_count_fold <= 0 || cells_fold_below_max <= 0) {
+        set_error("smi_finalize_used_list: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    *n_out = 0;
+    const float cutoff = (2.0f * (float)record_count) / 5000000.0f;  // UsedCellBCListGenerator.java:L391
+    std::vector<KC> f;
+    for (size_t i = 0; i < n; i++)
+        if ((float)counts[i] > cutoff && counts[i] > 1) f.push_back({keys[i], counts[i]});  // L359-363
+    if (f.empty()) return SMI_OK;
+    std::sort(f.begin(), f.end(), [](const KC &a, const KC &b) { return a.key < b.key; });
+    std::unordered_set<uint64_t> set;
+    set.reserve(f.size() * 2);
+    for (const KC &e : f) set.insert(e.key);
+    auto index_of = [&](uint64_t k) -> long {
+        auto it = std::lower_bound(f.begin(), f.end(), k, [](const KC &a, uint64_t v) { return a.key < v; });
+        return (it != f.end() && it->key == k) ? (long)(it - f.begin()) : -1;
+    };
+    struct Coll {
+        size_t self;
+        std::vector<Hit> hits;
+    };
+    std::vector<Coll> cs;
+    std::vector<Hit> hits;
+    for (size_t i = 0; i < f.size(); i++) {
+        collision_matches(set, f[i].key, merge_ed, hits);
+        if (!hits.empty()) cs.push_back({i, hits});  // stored only when non-empty (BarcodeDatasetColissionTester.java:L240-241)
+    }
+    // entries by count of their key, descending; canonical tie: key ascending (L166-167)
+    std::vector<size_t> ord(cs.size());
+    for (size_t i = 0; i < ord.size(); i++) ord[i] = i;
+    std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+        const KC &x = f[cs[a].self], &y = f[cs[b].self];
+        return x.count != y.count ? x.count > y.count : x.key < y.key;
+    });
+    // java.util.HashMap<Long, Set<Long>> iteration order of toMergeMap (insertion = ord): buckets ascending at the
+    // final capacity, insertion order inside a bucket
+    size_t cap = 16;
+    while (ord.size() > (cap * 3) / 4) cap <<= 1;
+    std::vector<std::pair<uint32_t, size_t>> it(ord.size());
+    for (size_t i = 0; i < ord.size(); i++) {
+        const uint64_t k = f[cs[ord[i]].self].key;
+        uint32_t h = (uint32_t)(k ^ (k >> 32));
+        h ^= h >> 16;
+        it[i] = {h & (uint32_t)(cap - 1), i};
+    }
+    std::stable_sort(it.begin(), it.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    std::vector<uint8_t> alive(f.size(), 1);
+    for (const auto &e : it) {  // L188-195
+        const Coll &c = cs[ord[e.second]];
+        if (!alive[c.self]) continue;
+        const uint32_t cut = f[c.self].count / (uint32_t)min_count_fold;  // L168 integer division
+        for (const Hit &h : c.hits) {
+            if (h.ed > merge_ed) continue;
+            const long p = index_of(h.bc);
+            if (p >= 0 && f[p].count < cut) alive[p] = 0;  // L171-172, L194
+        }
+    }
+    uint32_t mx = 0;
+    for (size_t i = 0; i < f.size(); i++)
+        if (alive[i]) mx = std::max(mx, f[i].count);
+    const uint32_t min_counts = mx / (uint32_t)cells_fold_below_max;  // L198
+    std::vector<KC> fin;
+    for (size_t i = 0; i < f.size(); i++)
+        if (alive[i] && f[i].count >= min_counts) fin.push_back(f[i]);
+    std::sort(fin.begin(), fin.end(),
+              [](const KC &a, const KC &b) { return a.count != b.count ? a.count > b.count : a.key < b.key; });
+    for (size_t i = 0; i < fin.size(); i++) {
+        out_keys[i] = fin[i].key;
+        out_counts[i] = fin[i].count;
+        out_rank[i] = (uint32_t)(i + 1);  // WorkerReadscanner.java:L266-270
+    }
+    *n_out = fin.size();
+    return SMI_OK;
+}

@@ -41,7 +41,7 @@ EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
-    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms",
+    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list",
 ]
 
 
@@ -84,6 +84,7 @@ def load_library():
     lib.smi_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.smi_set_timing.argtypes = [vp, ci]
     lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
+    lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if fn.restype is not ctypes.c_char_p:
@@ -107,6 +108,21 @@ def _stream_ptr(stream):
 
         stream = torch.cuda.current_stream()
     return ctypes.c_void_p(stream.cuda_stream if hasattr(stream, "cuda_stream") else int(stream))
+
+
+def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10, cells_fold_below_max=500):
+    """End of pass 1 (host, no GPU): smi_finalize_used_list -> (keys, counts, ranks) sorted by count descending."""
+    lib = load_library()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    ok, oc, orank = np.zeros(k.size, np.uint64), np.zeros(k.size, np.uint32), np.zeros(k.size, np.uint32)
+    n_out = ctypes.c_size_t(0)
+    rc = lib.smi_finalize_used_list(_ptr(k), _ptr(c), k.size, int(record_count), int(merge_ed), int(min_count_fold),
+                                    int(cells_fold_below_max), _ptr(ok), _ptr(oc), _ptr(orank), ctypes.byref(n_out))
+    if rc != 0:
+        raise SmiError(f"smi_finalize_used_list error {rc}: {lib.smi_last_error().decode()}")
+    m = n_out.value
+    return ok[:m], oc[:m], orank[:m]
 
 
 class Context:
