@@ -210,11 +210,26 @@ int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t 
                            int merge_ed, int min_count_fold, int cells_fold_below_max, uint64_t *out_keys,
                            uint32_t *out_counts, uint32_t *out_rank, size_t *n_out);
 
+/* ================================================================================================================
+ * UMI pair distances of `assignumis`: replaces ClusteringEditDistanceBase.generateDistanceMatrix
+ * (FJ!clustering/ClusteringEditDistanceBase.java:L168-259; per pair calcEditDistances L297-350 + calcBestEditDistance
+ * L67-80 + apachemod/LevenshteinDistance.limitedCompare, threshold 4).
+ * windows[r]: 14 bases of read r as 4-bit codes (A=1 G=2 C=4 T=8 N=15), base k in bits [4k+3:4k]: the bases
+ * bcEnd .. bcEnd+13 (1-based bcEnd = barcode end on the tested read-name sequence, FastqRecordExt.java:L378), i.e. the
+ * three 12-mers getSubSequence(bcEnd+1+i, 12), i = -1,0,+1.
+ * Groups = (cell barcode, genomic region) sets of reads (UmiClustering.java:L105): group g owns reads
+ * [group_off[g], group_off[g+1]).  pair_off[g] = sum over earlier groups of n(n+1)/2, mat_off[g] = sum of n^2.
+ * out + mat_off[g] is the n x n byte matrix of group g: ed | pos1 << 4 | pos2 << 6, ed in 0..5 (5 = above the
+ * threshold), pos = PlusMinusOneEnum.getValue(): 0 MINUSONE, 1 ZERO, 2 PLUSONE; [v][i] holds the transposed copy. */
+int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off,
+                        const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
+                        uint64_t total_pairs, uint8_t *d_out, void *stream);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);
 /* same, per kernel: the last launch of that kernel since timing was enabled */
-enum { SMI_K_BC_MATCH = 0, SMI_K_SCAN = 1, SMI_K_HIST = 2, SMI_K_PACK = 3, SMI_K_COUNT = 4 };
+enum { SMI_K_BC_MATCH = 0, SMI_K_SCAN = 1, SMI_K_HIST = 2, SMI_K_PACK = 3, SMI_K_UMI = 4, SMI_K_COUNT = 5 };
 int smi_kernel_ms(smi_ctx *ctx, int kernel_id, float *ms);
 int smi_set_timing(smi_ctx *ctx, int enabled);
 

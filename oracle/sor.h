@@ -95,6 +95,12 @@ int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offs
 int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
                    int *ins, int *del, int *sub, float *end5);
 
+/* ---- UMI pair distances (sor_umi.c) ---- */
+int sor_umi_pair(const uint8_t *w1, const uint8_t *w2);
+void sor_umi_matrix(const uint8_t *windows, int n, uint8_t *out);
+int sor_umi_window_3p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14);
+int sor_limited_compare(const uint8_t *a, int n, const uint8_t *b, int m, int threshold);
+
 /* ---- pass-1 finalize (sor_final.c) ---- */
 int sor_finalize_used_list(const int64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count, int merge_ed,
                            int min_count_fold, int cells_fold_below_max, int64_t *out_keys, uint32_t *out_counts,

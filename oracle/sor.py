@@ -230,3 +230,40 @@ def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10
     assert rc == 0
     m = n_out.value
     return ok[:m], oc[:m], orank[:m]
+
+
+# ---- UMI pair distances (sor_umi.c) --------------------------------------------------------------------------
+def umi_pair(w1, w2):
+    a = np.ascontiguousarray(w1, dtype=np.uint8)
+    b = np.ascontiguousarray(w2, dtype=np.uint8)
+    L = lib()
+    L.sor_umi_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    return int(L.sor_umi_pair(a.ctypes.data, b.ctypes.data))
+
+
+def umi_matrix(windows):
+    """windows: uint8 [n, 14] 4-bit codes -> uint8 [n, n] packed (ed | pos1 << 4 | pos2 << 6)"""
+    w = np.ascontiguousarray(windows, dtype=np.uint8)
+    n = w.shape[0]
+    out = np.zeros((n, n), dtype=np.uint8)
+    L = lib()
+    L.sor_umi_matrix.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.sor_umi_matrix.restype = None
+    L.sor_umi_matrix(w.ctypes.data, n, out.ctypes.data)
+    return out
+
+
+def umi_window_3p(x, adapter_end, bc_end):
+    out = np.zeros(14, dtype=np.uint8)
+    L = lib()
+    L.sor_umi_window_3p.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rc = L.sor_umi_window_3p(x.encode(), len(x), adapter_end, bc_end, out.ctypes.data)
+    return None if rc else out
+
+
+def limited_compare(a, b, threshold=4):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    b = np.ascontiguousarray(b, dtype=np.uint8)
+    L = lib()
+    L.sor_limited_compare.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    return int(L.sor_limited_compare(a.ctypes.data, a.size, b.ctypes.data, b.size, threshold))

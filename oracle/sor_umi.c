@@ -1,0 +1,110 @@
+/*
+ * sor_umi.c -- ORACLE (test infrastructure; rules in sor_bc.c).
+ *
+ * UMI pair distances of assignumis:
+ *   ClusteringEditDistanceBase.lambda$static$7 (calcEditDistances)  FJ!clustering/ClusteringEditDistanceBase.java:L297-350
+ *   ClusteringEditDistanceBase.calcBestEditDistance                 L67-80   (POSITIONS order L57 = enum ordinal order
+ *                                                                   ZERO, PLUSONE, MINUSONE: PlusMinusOnePosData.java:L20-22)
+ *   $BestEditDistance packing                                        L425-449
+ *   apachemod/LevenshteinDistance.limitedCompare                     FJ!nanopore/analyzers/apachemod/LevenshteinDistance.java:L220-283
+ *   window position on the read-name sequence                        FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L378,
+ *                                                                   FJ!umifinder/reads/nanopore/OneNanoporeResult.java:L59-66
+ */
+#include <limits.h>
+#include <string.h>
+
+#include "sor.h"
+
+/* limitedCompare on byte arrays (4-bit codes compared for equality, so N only equals N), threshold 4 */
+static int limited_compare(const uint8_t *left, int n, const uint8_t *right, int m, int threshold) {
+    int pa[64], da[64];
+    int *p = pa, *d = da;
+    const int boundary = threshold + 1;
+    for (int i = 0; i < boundary && i <= n; i++) p[i] = i;
+    for (int i = boundary; i <= n; i++) p[i] = INT_MAX;
+    for (int i = 0; i <= n; i++) d[i] = INT_MAX;
+    for (int j = 1; j <= m; j++) {
+        const uint8_t rj = right[j - 1];
+        d[0] = j;
+        const int mn = j - threshold > 1 ? j - threshold : 1;
+        const int mx = j > INT_MAX - threshold ? n : (n < j + threshold ? n : j + threshold);
+        if (mn > 1) d[mn - 1] = INT_MAX;
+        int lower = INT_MAX;
+        for (int i = mn; i <= mx; i++) {
+            if (left[i - 1] == rj)
+                d[i] = p[i - 1];
+            else {
+                int a = d[i - 1] < p[i] ? d[i - 1] : p[i];
+                a = a < p[i - 1] ? a : p[i - 1];
+                d[i] = (int)(1u + (unsigned)a); /* Java int wrap-around */
+            }
+            if (d[i] < lower) lower = d[i];
+        }
+        if (lower > threshold) return -1;
+        int *t = p;
+        p = d;
+        d = t;
+    }
+    return p[n] <= threshold ? p[n] : -1;
+}
+
+/* w1, w2: 14 4-bit codes = bases bcEnd .. bcEnd+13 of the read-name sequence (1-based bcEnd), i.e. the three
+ * 12-mers getSubSequence(bcEnd+1+i, 12), i = -1,0,+1.  Returns ed | pos1.value << 4 | pos2.value << 6 with
+ * value 0 = MINUSONE, 1 = ZERO, 2 = PLUSONE. */
+int sor_umi_pair(const uint8_t *w1, const uint8_t *w2) {
+    int eds[3][3];
+    for (int i = -1; i < 2; i++)
+        for (int j = -1; j < 2; j++) {
+            const uint8_t *s1 = w1 + (i + 1), *s2 = w2 + (j + 1);
+            int ed;
+            if (memcmp(s1, s2, 12) == 0)
+                ed = 0; /* L332-333 */
+            else {
+                ed = limited_compare(s1, 12, s2, 12, 4); /* L341-343 */
+                if (ed == -1) ed = 5;
+            }
+            eds[i + 1][j + 1] = ed;
+        }
+    static const int ORDER[3] = {1, 2, 0}; /* values of ZERO, PLUSONE, MINUSONE in ordinal order */
+    int best = 127, b1 = 0, b2 = 0;       /* L67: (127, MINUSONE, MINUSONE) */
+    for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) {
+            int i = ORDER[a], v = ORDER[b];
+            if (eds[i][v] < best) { /* L73: strict */
+                best = eds[i][v];
+                b1 = i;
+                b2 = v;
+            }
+        }
+    return best | (b1 << 4) | (b2 << 6);
+}
+
+/* full n x n matrix as the reference fills it: [i][v] computed for v >= i, [v][i] = transposed copy (L213-216,L255) */
+void sor_umi_matrix(const uint8_t *windows, int n, uint8_t *out) {
+    for (int i = 0; i < n; i++)
+        for (int v = i; v < n; v++) {
+            int r = sor_umi_pair(windows + 14 * (size_t)i, windows + 14 * (size_t)v);
+            out[(size_t)i * n + v] = (uint8_t)r;
+            out[(size_t)v * n + i] = (uint8_t)((r & 15) | (((r >> 6) & 3) << 4) | (((r >> 4) & 3) << 6));
+        }
+}
+
+/* 3': x = the 43-base X= string (stranded[AE-40 .. AE+2]); the tested sequence is its reverse complement and the
+ * barcode ends at adapterend + nbasesOfAdapterSeqInReadname(3) - bcEnd on it.  Returns 0 and 14 codes, or -1 when
+ * the slice does not fit (the reference would throw from System.arraycopy). */
+int sor_umi_window_3p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14) {
+    int pos = adapter_end + 3 - bc_end; /* getStrandedShortSeqPosFromReadPos L378 */
+    if (pos < 1 || pos + 13 > xlen) return -1;
+    for (int k = 0; k < 14; k++) {
+        int p1 = pos + k;                 /* 1-based on revcomp(x) */
+        char c = x[xlen - p1];            /* revcomp index */
+        int code = sor_fourbit_encode_char((unsigned char)c);
+        if (code < 0) return -1;
+        out14[k] = (uint8_t)sor_fourbit_complement(code);
+    }
+    return 0;
+}
+
+int sor_limited_compare(const uint8_t *a, int n, const uint8_t *b, int m, int threshold) {
+    return limited_compare(a, n, b, m, threshold);
+}

@@ -348,4 +348,16 @@ int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const 
     return launch_hist_windows(ctx, d_windows, d_scan, n, d_hist, (hipStream_t)stream);
 }
 
+int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off,
+                        const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
+                        uint64_t total_pairs, uint8_t *d_out, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_groups && (!d_windows || !d_group_off || !d_pair_off || !d_mat_off || !d_out)) {
+        set_error("smi_umi_dist_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_umi_dist(ctx, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups, total_pairs, d_out,
+                           (hipStream_t)stream);
+}
+
 }  // extern "C"

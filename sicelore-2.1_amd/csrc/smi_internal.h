@@ -79,6 +79,8 @@ int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan
 int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, const uint8_t *d_qtail,
                 const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
                 smi_bc_window *d_win, hipStream_t s);
+int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
+                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s);
 int launch_pack_ends(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, size_t n,
                      uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s);
 }  // namespace smi

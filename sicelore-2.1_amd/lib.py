@@ -41,7 +41,7 @@ EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
-    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list",
+    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device",
 ]
 
 
@@ -84,6 +84,7 @@ def load_library():
     lib.smi_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.smi_set_timing.argtypes = [vp, ci]
     lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
+    lib.smi_umi_dist_device.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -208,11 +209,29 @@ class Context:
         self._check(self._lib.smi_hist_windows_device(self._h, _ptr(d_windows), _ptr(d_scan), int(n), _ptr(d_hist),
                                                       _stream_ptr(stream)))
 
+    # ---- UMI pair distances ------------------------------------------------------------------------------
+    @staticmethod
+    def umi_offsets(group_sizes):
+        """host helper: group sizes -> (group_off uint32, pair_off uint64, mat_off uint64) prefix arrays"""
+        n = np.asarray(group_sizes, dtype=np.uint64)
+        go = np.zeros(n.size + 1, dtype=np.uint32)
+        go[1:] = np.cumsum(n)
+        po = np.zeros(n.size + 1, dtype=np.uint64)
+        po[1:] = np.cumsum(n * (n + 1) // 2)
+        mo = np.zeros(n.size + 1, dtype=np.uint64)
+        mo[1:] = np.cumsum(n * n)
+        return go, po, mo
+
+    def umi_dist_device(self, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups, total_pairs, d_out, stream=None):
+        self._check(self._lib.smi_umi_dist_device(self._h, _ptr(d_windows), _ptr(d_group_off), _ptr(d_pair_off),
+                                                  _ptr(d_mat_off), int(n_groups), int(total_pairs), _ptr(d_out),
+                                                  _stream_ptr(stream)))
+
     # ---- timing ------------------------------------------------------------------------------------------
     def set_timing(self, enabled=True):
         self._check(self._lib.smi_set_timing(self._h, int(bool(enabled))))
 
-    K_BC_MATCH, K_SCAN, K_HIST, K_PACK = 0, 1, 2, 3
+    K_BC_MATCH, K_SCAN, K_HIST, K_PACK, K_UMI = 0, 1, 2, 3, 4
 
     def kernel_ms(self, kernel_id):
         ms = ctypes.c_float(-1.0)

@@ -1,0 +1,54 @@
+"""GPU parity: K-UMI pair-distance matrices == oracle, byte for byte."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_groups(seed, sizes):
+    rng = np.random.default_rng(seed)
+    ws = []
+    for n in sizes:
+        n_umi = max(1, n // 3)
+        umis = rng.choice([1, 2, 4, 8], size=(n_umi, 14)).astype(np.uint8)
+        for _ in range(n):
+            w = umis[rng.integers(n_umi)].copy()
+            for _ in range(rng.integers(0, 3)):
+                p = rng.integers(14)
+                op = rng.integers(3)
+                if op == 0:
+                    w[p] = rng.choice([1, 2, 4, 8, 15])
+                elif op == 1:
+                    w[p + 1:] = w[p:-1]
+                    w[p] = rng.choice([1, 2, 4, 8])
+                else:
+                    w[p:-1] = w[p + 1:]
+                    w[-1] = rng.choice([1, 2, 4, 8])
+            ws.append(w)
+    return np.array(ws, dtype=np.uint8)
+
+
+def _pack(ws):
+    out = np.zeros(ws.shape[0], dtype=np.uint64)
+    for k in range(14):
+        out |= ws[:, k].astype(np.uint64) << np.uint64(4 * k)
+    return out
+
+
+@pytest.mark.parametrize("sizes", [[2, 3, 1, 7, 64, 5, 130, 2, 2, 33], [400], [1] * 50 + [2] * 300])
+def test_umi_matrices_match_oracle(pkg, sor, gpu_ctx, sizes):
+    ws = _make_groups(len(sizes), sizes)
+    go, po, mo = gpu_ctx.umi_offsets(sizes)
+    d_w = torch.from_numpy(_pack(ws).view(np.int64)).cuda()
+    d_go = torch.from_numpy(go.view(np.int32)).cuda()
+    d_po = torch.from_numpy(po.view(np.int64)).cuda()
+    d_mo = torch.from_numpy(mo.view(np.int64)).cuda()
+    d_out = torch.full((int(mo[-1]),), 255, dtype=torch.uint8, device="cuda")
+    gpu_ctx.umi_dist_device(d_w, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for g, n in enumerate(sizes):
+        exp = sor.umi_matrix(ws[go[g]:go[g + 1]])
+        got = out[int(mo[g]):int(mo[g + 1])].reshape(n, n)
+        assert (got == exp).all(), g
