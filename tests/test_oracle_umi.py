@@ -95,4 +95,4 @@ def test_window_from_read_name(sor):
     rc = "".join(comp[c] for c in reversed(X))
     assert rc[:3] == "TCT" and rc[3:19] == "TCCGATCGTGCCAAGA"
     assert [CODE[c] for c in rc[18:32]] == list(w)
-    assert sor.umi_window_3p(X, 619, 592) is None  # slice would leave the 43-base string
+    assert sor.umi_window_3p(X, 619, 592) is not None and sor.umi_window_3p(X, 619, 591) is None  # slice would leave the 43-base string
