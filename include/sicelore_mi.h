@@ -60,7 +60,9 @@ typedef struct {
 #define SMI_WIN_BASES_5P 25
 
 /* ---- result of Parser.assignBarcode (Parser.java:L244-311) ----------------------------------------
- * found: 1 = barcode accepted (BC_FOUND), 0 = none/ambiguous, -1 = window invalid (reference would throw)
+ * found: 1 = barcode accepted (BC_FOUND), 0 = none/ambiguous, -1 = window invalid (reference would throw),
+ *        -2 = (ed 2 only) >= 11 matches share one HashSet bucket: the reference's tree bin orders them by
+ *        System.identityHashCode, so its own answer is not reproducible (needs >= 4 identical windows, i.e. homopolymers)
  * bc: matching barcode, 2-bit, first base most significant (16 nt -> 32 bits)
  * ed / ed_sec: editDistance and editDistanceSecondBest (INT32_MAX when there is no second barcode, L288)
  * offset: offsetFromPredicted of the best match; ins_minus_del: OneMatch.getOffsetForReadEnd (L533), so

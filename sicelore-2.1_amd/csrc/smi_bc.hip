@@ -320,6 +320,9 @@ __device__ __forceinline__ uint32_t bit_of(const uint32_t *__restrict__ words, u
 //                             {exact hit, index+1 of the first level-1 hit} which is written back to lane r
 //   phase 3 (lane = read)   : every lane runs the HashSet-order / best-second rule for ITS read and stores 16 B
 // so only the probes themselves are wave-serial; the scalar unit sees ~10 instructions per offset.
+int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int five_prime, smi_bc_result *d_out,
+                     hipStream_t s);
+
 template <int MAX_ED>
 __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
@@ -439,6 +442,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
 int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_ed, int five_prime,
                     smi_bc_result *d_out, hipStream_t s) {
     if (!n) return SMI_OK;
+    if (max_ed == 2) return launch_bc_match2(ctx, d_win, n, five_prime, d_out, s);
     Pyramid P = pyramid_of(ctx);
     const size_t n_waves = (n + 63) / 64;
     const unsigned grid = (unsigned)std::min<size_t>((n_waves + 3) / 4, 256 * 64);
@@ -519,6 +523,332 @@ int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan
     const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(k_hist_windows, dim3(grid), dim3(256), 0, s, d_win, d_scan, n, P, d_hist);
     SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K-BC2: ed <= 2 matcher.  Same contract as K-BC1, but the second mutation level follows the reference's
+// depth-first order and its dedup set (NucTwoBitPerBaseEDtesterBase.java:L82-95,L105-120, BarcodeMatchTester.java:
+// L218-241):
+//   * level-1 children c_e (the 123 mutants of K-BC1's enumeration) are CREATED unless (int)c_e is already in
+//     `tested`, i.e. equals the root (for positions >= 1) or an earlier-position child: created(e) <=>
+//     p_e == min position among children with the same low 32 bits (and not the root unless p_e == 0);
+//   * created children are expanded LIFO: by root position ascending, inside a position in reverse creation order;
+//     an item visits positions 0..15 except the one it was created at;
+//   * a level-2 mutant m is skipped when (int)m is the root, an item expanded earlier, or the item's own sequence
+//     after its first visited position; otherwise it is probed, and the first hit in this order is THE level-2 match.
+// A sequence is (low 32 bits, g) where g = bits 62..63 left behind by "insert after position 14" (Java shift wrap);
+// g != 0 can never equal a barcode but still takes part in the (int) dedup.
+// One wavefront per read; lanes are the 128 (position, kind) child slots of the item being expanded, so the DFS
+// order inside an item is again ballot + ctz, and items are walked in order with early exit on the first hit.
+// The dedup set is a 256-slot open-addressing table in LDS (per wave), value = expansion order of the sequence.
+// ---------------------------------------------------------------------------------------------------------
+struct Seq {
+    uint32_t low, g;
+};
+
+// child of s at position q, kind r (0..2 substitutions, 3..6 insertions A,G,C,T, 7 deletion appending del_base)
+__device__ __forceinline__ Seq child_of(Seq s, int q, int r, uint32_t del_base) {
+    const int sh = 30 - 2 * q;
+    const uint32_t lm = lowmask(sh), lm2 = lowmask(sh + 2);
+    Seq o = s;
+    if (r < 3) {
+        const uint32_t cur = (s.low >> sh) & 3u;
+        const uint32_t j = (uint32_t)r, b = j + (j >= cur ? 1u : 0u);
+        o.low = s.low ^ ((cur ^ b) << sh);
+    } else if (r < 7) {
+        const uint32_t x = (uint32_t)(r - 3);
+        const int xs = sh >= 2 ? sh - 2 : 0;
+        o.low = (s.low & ~lm) | ((s.low & lm) >> 2) | (x << xs);
+        if (q == 14) o.g = s.g | (s.low & 3u);  // getLongHashInsertByteDeg L303-305: shift count 64 wraps to 0
+    } else {
+        o.low = (s.low & ~lm2) | ((s.low & lm) << 2) | del_base;
+    }
+    return o;
+}
+
+__device__ __forceinline__ bool slot_valid(int q, int r) { return q < 15 || r < 3; }
+
+// post[k] (1-based, k = 1..5) as the 2-bit code appended by a deletion (BarcodeMatchTester.java:L329; N -> A)
+__device__ __forceinline__ uint32_t post_base(uint64_t bases, uint32_t nmask, int o, bool five_prime, int k) {
+    if (!five_prime) {
+        const int j = 6 + o - (k - 1);  // revcomp(substring(bcStart-5, bcStart)): Parser.java:L218
+        const uint32_t b = (uint32_t)(bases >> (2 * (24 - 1 - j))) & 3u;
+        return ((nmask >> j) & 1u) ? 0u : (3u - b);
+    }
+    const int j = 17 + o + k;  // substring(bcEnd, bcEnd + 5): Parser.java:L219
+    const uint32_t b = (uint32_t)(bases >> (2 * (25 - 1 - j))) & 3u;
+    return ((nmask >> j) & 1u) ? 0u : b;
+}
+
+__device__ __forceinline__ bool member(const Pyramid &P, uint32_t k) {
+    if (!bit_of(P.l0, k >> kG0)) return false;
+    if (!bit_of(P.l1, k >> kG1)) return false;
+    return bit_of(P.fine, k);
+}
+
+constexpr int kTabSlots = 256;
+constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+
+// 15-candidate version of pick_best: slot = 3*q + level (insertion order of offsets; order inside an offset is
+// irrelevant because compareTo separates different levels)
+__device__ __forceinline__ void pick_best15(const uint32_t (&bc)[15], const uint32_t (&rs)[5], const int (&imd)[15],
+                                            uint32_t present, int max_ed, smi_bc_result &res) {
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+    const int n = __popc(present);
+    res.bc = 0;
+    res.ed_sec = 2147483647;
+    res.found = 0;
+    res.ed = 0;
+    res.offset = 0;
+    res.ins_minus_del = 0;
+    res.n_matches = (uint32_t)n;
+    if (n == 0) return;
+    uint32_t h[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) h[q] = rs[q] ^ (rs[q] >> 16);
+    int cap = 16;
+    if (n >= 9) {  // HashMap growth: size > 0.75 cap, or a 9th node in one bin while cap < 64 (treeifyBin -> resize)
+        int size = 0;
+        for (int i = 0; i < 15; i++) {
+            if (!((present >> i) & 1u)) continue;
+            int in_bin = 0;
+            for (int k = 0; k < i; k++)
+                in_bin += (((present >> k) & 1u) && ((h[k / 3] ^ h[i / 3]) & (uint32_t)(cap - 1)) == 0) ? 1 : 0;
+            size++;
+            if (in_bin >= 8) {
+                if (cap < 64) {
+                    cap <<= 1;
+                } else {
+                    // a real tree bin: its iteration order depends on System.identityHashCode (HashMap.tieBreakOrder),
+                    // i.e. the reference itself is not reproducible here; flagged instead of guessed
+                    res.found = -2;
+                    return;
+                }
+            }
+            if (size > (cap * 3) / 4) cap <<= 1;
+        }
+    }
+    uint32_t best_key = 0xFFFFFFFFu, second_key = 0xFFFFFFFFu;
+    uint32_t key[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) {
+        const int q = i / 3, lvl = i % 3;
+        key[i] = ((uint32_t)lvl << 20) | (q != 0 ? (1u << 16) : 0u) | ((h[q] & (uint32_t)(cap - 1)) << 8) | (uint32_t)i;
+        if (!((present >> i) & 1u)) key[i] = 0xFFFFFFFFu;
+        best_key = min(best_key, key[i]);
+    }
+    uint32_t best_bc = 0;
+    int best_imd = 0;
+#pragma unroll
+    for (int i = 0; i < 15; i++)
+        if (key[i] == best_key) {
+            best_bc = bc[i];
+            best_imd = imd[i];
+        }
+#pragma unroll
+    for (int i = 0; i < 15; i++)
+        if (key[i] != 0xFFFFFFFFu && bc[i] != best_bc) second_key = min(second_key, key[i]);
+    const int best_ed = (int)(best_key >> 20), second_ed = (int)(second_key >> 20);
+    const bool has_second = second_key != 0xFFFFFFFFu;
+    if (best_ed > max_ed) return;
+    if (has_second && best_ed >= second_ed) return;
+    res.found = 1;
+    res.bc = best_bc;
+    res.ed = (int8_t)best_ed;
+    res.ed_sec = has_second ? second_ed : 2147483647;
+    res.offset = (int8_t)OFFS[(best_key & 0xFF) / 3];
+    res.ins_minus_del = (int8_t)best_imd;
+}
+
+__global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
+                                                      Pyramid P, smi_bc_result *__restrict__ out) {
+    __shared__ uint32_t s_keys[4][kTabSlots];
+    __shared__ uint32_t s_vals[4][kTabSlots];
+    __shared__ uint32_t s_low[4][128];
+    __shared__ uint32_t s_ord2e[4][128];
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    uint32_t *keys = s_keys[wv], *vals = s_vals[wv], *lows = s_low[wv], *ord2e = s_ord2e[wv];
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const bool fp = five_prime != 0;
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+
+    for (size_t rd = wave; rd < n; rd += n_waves) {
+        const smi_bc_window w = win[rd];  // wave-uniform (scalar loads)
+        smi_bc_result res;
+        res.bc = 0;
+        res.ed_sec = 2147483647;
+        res.found = -1;
+        res.ed = 0;
+        res.offset = 0;
+        res.ins_minus_del = 0;
+        res.n_matches = 0;
+        if (w.flags & SMI_WIN_VALID) {
+            uint32_t c_bc[15];
+            uint32_t c_rs[5];
+            int c_imd[15];
+            uint32_t present = 0;
+#pragma unroll 1
+            for (int q = 0; q < 5; q++) {
+                const OffsetKey ok = make_key(w.bases, w.nmask, OFFS[q], fp);
+                const uint32_t post1 = post_base(w.bases, w.nmask, OFFS[q], fp, 1);
+                const uint32_t post2 = post_base(w.bases, w.nmask, OFFS[q], fp, 2);
+                const uint32_t K = ok.key;
+                uint32_t bc0 = K, bc1 = 0, bc2 = 0;
+                int imd1 = 0, imd2 = 0;
+                bool hit0 = false, hit1 = false, hit2 = false;
+                if (ok.usable) {
+                    const Seq root = {K, 0u};
+                    // ---- level 1: the 123 children, two per lane (e = lane, 64 + lane) ------------------------
+                    Seq c[2];
+                    bool val[2];
+                    int pe[2], re[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int e = 64 * h + lane;
+                        pe[h] = e >> 3;
+                        re[h] = e & 7;
+                        val[h] = e < 123;
+                        c[h] = child_of(root, pe[h] & 15, re[h], post1);
+                        lows[e] = val[h] ? c[h].low : K;  // invalid slots mirror the root (never created)
+                    }
+                    // clear the table
+#pragma unroll
+                    for (int k = 0; k < kTabSlots / 64; k++) {
+                        keys[64 * k + lane] = kEmpty;
+                        vals[64 * k + lane] = 0xFFFFFFFFu;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // created(e): first position among equal sequences, and not the root except at position 0
+                    bool created[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        int pmin = 99;
+                        for (int f = 0; f < 123; f++) pmin = (lows[f] == c[h].low) ? min(pmin, f >> 3) : pmin;
+                        created[h] = val[h] && pe[h] == pmin && (c[h].low != K || pe[h] == 0);
+                    }
+                    const unsigned long long ca = __ballot(created[0]), cb = __ballot(created[1]);
+                    const int n_items = __popcll(ca) + __popcll(cb);
+                    // expansion order: positions ascending, reverse creation order inside a position
+                    uint32_t ord[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const unsigned long long mine = h == 0 ? ca : cb;
+                        const int base_bit = 8 * (pe[h] & 7);  // first lane of this position inside its ballot
+                        const int before = (h == 1 ? __popcll(ca) : 0) + __popcll(mine & ((1ull << base_bit) - 1ull));
+                        const unsigned long long sib = (mine >> base_bit) & 0xFFull;
+                        const int later = __popcll(sib >> (re[h] + 1));  // created siblings generated after me
+                        ord[h] = (uint32_t)(before + later);
+                        if (created[h]) ord2e[ord[h]] = (uint32_t)(64 * h + lane);
+                    }
+                    // dedup table: low 32 bits -> smallest expansion order; the all-T key equals the empty-slot
+                    // sentinel and is kept in a register instead
+                    uint32_t t_ord = 0xFFFFFFFFu;
+                    {
+                        uint32_t mine = 0xFFFFFFFFu;
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            if (created[h] && c[h].low == kEmpty) mine = min(mine, ord[h]);
+                        if (__ballot(mine != 0xFFFFFFFFu)) {
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) mine = min(mine, (uint32_t)__shfl_xor((int)mine, o));
+                            t_ord = mine;
+                        }
+                    }
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        if (created[h] && c[h].low != kEmpty) {
+                            uint32_t slot = (c[h].low * 2654435761u) >> 24;
+                            for (;;) {
+                                const uint32_t prev = atomicCAS(&keys[slot], kEmpty, c[h].low);
+                                if (prev == kEmpty || prev == c[h].low) {
+                                    atomicMin(&vals[slot], ord[h]);
+                                    break;
+                                }
+                                slot = (slot + 1) & (kTabSlots - 1);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // ---- probes of level 0 and 1 (only created children are ever probed) ----------------------
+                    hit0 = member(P, K);
+                    const bool h1a = created[0] && c[0].g == 0u && member(P, c[0].low);
+                    const bool h1b = created[1] && c[1].g == 0u && member(P, c[1].low);
+                    const unsigned long long ha = __ballot(h1a), hb = __ballot(h1b);
+                    if (ha | hb) {
+                        const int e = ha ? __builtin_ctzll(ha) : 64 + __builtin_ctzll(hb);
+                        hit1 = true;
+                        bc1 = child_of(root, e >> 3, e & 7, post1).low;
+                        imd1 = ins_minus_del_of(e);
+                    }
+                    // ---- level 2: expand the created children in order, early exit on the first hit ------------
+                    for (int t = 0; t < n_items && !hit2; t++) {
+                        const int e = (int)ord2e[t];
+                        const int pX = e >> 3, rX = e & 7;
+                        const Seq X = child_of(root, pX, rX, post1);
+                        const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;  // post[nDeletions + 1]
+                        const int q0 = pX == 0 ? 1 : 0;                              // first visited position
+#pragma unroll
+                        for (int h = 0; h < 2 && !hit2; h++) {
+                            const int slot = 64 * h + lane;
+                            const int qq = slot >> 3, rr = slot & 7;
+                            bool live = slot_valid(qq, rr) && qq != pX;
+                            const Seq m = child_of(X, qq, rr, delb);
+                            // dedup set: root, anything expanded before X, X itself after its first position
+                            live = live && m.low != K && !(m.low == X.low && qq > q0);
+                            if (live && m.low == kEmpty) {
+                                live = !(t_ord < (uint32_t)t);
+                            } else if (live) {
+                                uint32_t sl = (m.low * 2654435761u) >> 24;
+                                for (;;) {
+                                    const uint32_t kk = keys[sl];
+                                    if (kk == m.low) {
+                                        if (vals[sl] < (uint32_t)t) live = false;
+                                        break;
+                                    }
+                                    if (kk == kEmpty) break;
+                                    sl = (sl + 1) & (kTabSlots - 1);
+                                }
+                            }
+                            const bool hit = live && m.g == 0u && member(P, m.low);
+                            const unsigned long long hm = __ballot(hit);
+                            if (hm) {
+                                const int s2 = 64 * h + __builtin_ctzll(hm);
+                                hit2 = true;
+                                bc2 = child_of(X, s2 >> 3, s2 & 7, delb).low;
+                                imd2 = ins_minus_del_of(e) + ins_minus_del_of(s2);
+                            }
+                        }
+                    }
+                }
+                c_rs[q] = K;
+                c_bc[3 * q] = bc0;
+                c_bc[3 * q + 1] = bc1;
+                c_bc[3 * q + 2] = bc2;
+                c_imd[3 * q] = 0;
+                c_imd[3 * q + 1] = imd1;
+                c_imd[3 * q + 2] = imd2;
+                present |= (hit0 ? 1u : 0u) << (3 * q);
+                present |= (hit1 ? 1u : 0u) << (3 * q + 1);
+                present |= (hit2 ? 1u : 0u) << (3 * q + 2);
+            }
+            pick_best15(c_bc, c_rs, c_imd, present, 2, res);
+        }
+        if (lane == 0) out[rd] = res;
+    }
+}
+
+int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int five_prime, smi_bc_result *d_out,
+                     hipStream_t s) {
+    if (!n) return SMI_OK;
+    Pyramid P = pyramid_of(ctx);
+    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
+    if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
+    hipLaunchKernelGGL(k_bc_match_ed2, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    SMI_HIP(hipGetLastError());
+    if (int rc = time_end(ctx, SMI_K_BC_MATCH, s)) return rc;
     return SMI_OK;
 }
 

@@ -224,8 +224,8 @@ static int check_match_args(smi_ctx *ctx, const void *in, const void *out, size_
         set_error("smi_bc_match: null buffer");
         return SMI_ERR_INVALID;
     }
-    if (max_ed < 0 || max_ed > 1) {
-        set_error("smi_bc_match: bcEditDistance must be 0 or 1 in this build (2 is not implemented on the device yet)");
+    if (max_ed < 0 || max_ed > 2) {
+        set_error("smi_bc_match: bcEditDistance must be 0, 1 or 2");
         return SMI_ERR_INVALID;
     }
     if (ctx->set_mode < 0) {

@@ -9,7 +9,7 @@ FIELDS = ("bc", "ed", "ed_sec", "offset", "ins_minus_del")
 
 
 def _compare(pkg, got, st, exp):
-    exp_found = np.where(st < 0, -1, exp["found"])
+    exp_found = np.where(st < 0, st, exp["found"])  # -1: window outside the read, -2: tree bin (see sicelore_mi.h)
     bad = np.nonzero(got["found"] != exp_found)[0]
     assert bad.size == 0, f"found differs at {bad[:10]}: got {got['found'][bad[:10]]} exp {exp_found[bad[:10]]}"
     sel = exp_found == 1
@@ -189,3 +189,63 @@ def test_full_size_properties(pkg, synth, gpu_ctx):
     assert bool((srt[idx] == bc[found]).all())
     acc = float((bc[found] == reg["truth"][found]).float().mean())
     assert acc > 0.8
+
+
+@pytest.mark.parametrize("five_prime", [False, True])
+def test_ed2_used_list_mode(pkg, synth, sor, gpu_ctx, five_prime):
+    """BASELINE.json configs[2] shape: ed <= 2 against the used list (pass 2 of the two-pass mode)"""
+    wl = synth.make_whitelist(100_000, seed=301)
+    used = synth.pick_used(wl, 3000, seed=302)
+    n = 20_000
+    reg = synth.gen_bc_region(n, used, seed=303 + five_prime, five_prime=five_prime, n_rate=0.002, err=0.08)
+    win = synth.pack_windows(reg["codes"], reg["ae"], five_prime)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    got = _run_device(pkg, gpu_ctx, win, 2, five_prime)
+    st, exp = sor.assign_batch(sor.BarcodeSet(used.numpy()), reg["codes"].numpy(), reg["ae"].numpy(), max_ed=2,
+                               five_prime=five_prime, n_threads=8)
+    n_found = _compare(pkg, got, st, exp)
+    assert n_found > 0.6 * n
+    assert (exp["ed"][exp["found"] == 1] == 2).sum() > 200
+
+
+def test_ed2_dense_and_degenerate(pkg, synth, sor, gpu_ctx):
+    """ed <= 2 where the dedup set decides: dense neighbourhoods (many ed-1/ed-2 barcodes per window), homopolymer
+    and low-complexity windows (equal children at different positions), all-T keys (hash sentinel) and N bases"""
+    rng = np.random.default_rng(11)
+    wl = synth.make_whitelist(3000, seed=311)
+    used = synth.pick_used(wl, 300, seed=312)
+    n = 6000
+    reg = synth.gen_bc_region(n, used, seed=313, err=0.05, n_rate=0.01)
+    codes, ae = reg["codes"].clone(), reg["ae"].clone()
+    # low-complexity reads
+    codes[:200] = 3                                            # all T -> key 0xFFFFFFFF in 5' / all A after revcomp
+    codes[200:400] = 0                                         # all A -> all T after revcomp (3')
+    codes[400:600] = torch.tensor([0, 3], dtype=torch.uint8).repeat(64)[None, :]            # ATAT...
+    codes[600:800] = torch.tensor([2, 2, 1, 1], dtype=torch.uint8).repeat(32)[None, :]      # CCGG...
+    for i in range(800, 1200):                                                               # runs with one break
+        codes[i] = int(rng.integers(4))
+        codes[i, rng.integers(30, 90, size=3)] = torch.tensor(rng.integers(0, 4, size=3), dtype=torch.uint8)
+    keys = []
+    cn = codes.numpy()
+    for i in list(range(0, 1200, 7)) + list(range(1200, 2200, 5)):
+        for o in (-2, -1, 0, 1, 2):
+            a = int(ae[i]) - 16 + o - 1
+            if a < 0 or a + 16 > cn.shape[1]:
+                continue
+            k = 0
+            for c in cn[i, a:a + 16][::-1]:
+                k = (k << 2) | (3 - min(int(c), 3))
+            keys.append(k)
+    keys = np.array(keys, dtype=np.uint64)
+    nb1 = keys ^ (rng.integers(1, 4, keys.size).astype(np.uint64) << (2 * rng.integers(0, 16, keys.size)).astype(np.uint64))
+    nb2 = nb1 ^ (rng.integers(1, 4, keys.size).astype(np.uint64) << (2 * rng.integers(0, 16, keys.size)).astype(np.uint64))
+    allk = np.unique(np.concatenate([keys[::3], nb1, nb2, used.numpy().astype(np.uint64),
+                                     np.array([0xFFFFFFFF, 0, 0x33333333, 0xCCCCCCCC], dtype=np.uint64)]))
+    for five_prime in (False, True):
+        gpu_ctx.set_barcode_set(allk, mode=0)
+        win = synth.pack_windows(codes, ae, five_prime)
+        got = _run_device(pkg, gpu_ctx, win, 2, five_prime)
+        st, exp = sor.assign_batch(sor.BarcodeSet(allk.astype(np.int64)), cn, ae.numpy(), max_ed=2,
+                                   five_prime=five_prime, n_threads=8)
+        _compare(pkg, got, st, exp)
+        assert (exp["n_matches"] >= 4).sum() > 100
