@@ -21,8 +21,10 @@ namespace smi {
 // ---------------------------------------------------------------------------------------------------------
 // pyramid build
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t suffix_index(uint32_t k) { return ((k & 0x3FFFu) << 10) | (k >> 22); }
+
 __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ l0,
-                           uint32_t *__restrict__ l1, uint32_t *__restrict__ fine) {
+                           uint32_t *__restrict__ l0s, uint32_t *__restrict__ l1, uint32_t *__restrict__ fine) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -32,6 +34,8 @@ __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t
         atomicOr(&l1[i1 >> 5], 1u << (i1 & 31));
         uint32_t i0 = k >> kG0;
         atomicOr(&l0[i0 >> 5], 1u << (i0 & 31));
+        uint32_t is = suffix_index(k);
+        atomicOr(&l0s[is >> 5], 1u << (is & 31));
     }
 }
 
@@ -46,11 +50,12 @@ __global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restr
 
 int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s) {
     SMI_HIP(hipMemsetAsync(ctx->l0, 0, kL0Words * 4, s));
+    SMI_HIP(hipMemsetAsync(ctx->l0s, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l1, 0, kL1Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->fine, 0, kFineWords * 4, s));
     if (n) {
         unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_set_bits, dim3(grid), dim3(256), 0, s, d_keys, n, ctx->l0, ctx->l1, ctx->fine);
+        hipLaunchKernelGGL(k_set_bits, dim3(grid), dim3(256), 0, s, d_keys, n, ctx->l0, ctx->l0s, ctx->l1, ctx->fine);
         SMI_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_block_counts, dim3((unsigned)(kRankEntries / 256)), dim3(256), 0, s,
@@ -197,6 +202,7 @@ struct LaneMut {
     int r;
     bool valid;
     bool exact;
+    bool far;  // mutant changes the leading 7 bases: probe the suffix-major top level instead of the prefix one
 };
 
 __device__ __forceinline__ LaneMut make_lane(int e) {
@@ -208,6 +214,8 @@ __device__ __forceinline__ LaneMut make_lane(int e) {
     m.lm_s2 = lowmask(m.s + 2);
     m.exact = (e == 127);
     m.valid = (e < 123) || m.exact;
+    // substitution at p changes base p, insertion after p bases p+1.., deletion of p bases p..
+    m.far = !m.exact && (m.r < 3 ? p <= 6 : (m.r < 7 ? p <= 5 : p <= 6));
     return m;
 }
 
@@ -375,11 +383,23 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
                 live[2 * q + 1] = (vb && usable) ? 0xFFFFFFFFu : 0u;
             }
             // level 0 of the pyramid: 10 independent gathers
+            // (one prefix-ordered table would spread the 124 probes of an offset over ~54 lines; routing the mutants
+            // that change the leading bases to the suffix-major twin leaves 4 lines per offset -- smi_internal.h)
             uint32_t w[10];
+            const uint32_t *const topA = mA.far ? P.l0s : P.l0;
+            const uint32_t *const topB = mB.far ? P.l0s : P.l0;
 #pragma unroll
-            for (int t = 0; t < 10; t++) w[t] = P.l0[mut[t] >> (kG0 + 5)];
+            for (int t = 0; t < 10; t++) {
+                const bool far = (t & 1) ? mB.far : mA.far;
+                const uint32_t i0 = far ? suffix_index(mut[t]) : (mut[t] >> kG0);
+                w[t] = ((t & 1) ? topB : topA)[i0 >> 5];
+            }
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> ((mut[t] >> kG0) & 31u)) & 1u);
+            for (int t = 0; t < 10; t++) {
+                const bool far = (t & 1) ? mB.far : mA.far;
+                const uint32_t i0 = far ? suffix_index(mut[t]) : (mut[t] >> kG0);
+                live[t] &= 0u - ((w[t] >> (i0 & 31u)) & 1u);
+            }
             // level 1: lanes that are out read word 0 (one shared line)
 #pragma unroll
             for (int t = 0; t < 10; t++) w[t] = P.l1[(mut[t] >> (kG1 + 5)) & live[t]];

@@ -35,6 +35,7 @@ int time_end(smi_ctx *ctx, int kid, hipStream_t s) {
 Pyramid pyramid_of(const smi_ctx *ctx) {
     Pyramid p;
     p.l0 = ctx->l0;
+    p.l0s = ctx->l0s;
     p.l1 = ctx->l1;
     p.fine = ctx->fine;
     p.rank = ctx->rank;
@@ -113,6 +114,7 @@ int smi_ctx_create(int device, smi_ctx **out) {
         if (e2 != hipSuccess) return fail(hip_fail(e2, #call)); \
     } while (0)
     SMI_TRY(hipMalloc((void **)&ctx->l0, kL0Words * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->l0s, kL0Words * 4));
     SMI_TRY(hipMalloc((void **)&ctx->l1, kL1Words * 4));
     SMI_TRY(hipMalloc((void **)&ctx->fine, kFineWords * 4));
     SMI_TRY(hipMalloc((void **)&ctx->rank, kRankEntries * 4));
@@ -132,6 +134,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->l0);
+    (void)hipFree(ctx->l0s);
     (void)hipFree(ctx->l1);
     (void)hipFree(ctx->fine);
     (void)hipFree(ctx->rank);

@@ -24,6 +24,10 @@ int hip_fail(hipError_t e, const char *what);
 //   fine: 1 bit per key                    (2^32 bits = 512 MiB, HBM)
 // A probe walks l0 -> l1 -> fine and stops at the first clear bit, so it is exact; consecutive keys share
 // a bit, so the mutants of one window that keep its leading bases hit the same 128-B line.
+//   l0s : a second top level with the key's LAST 7 bases selecting the 128-B line and its first 5 bases the bit
+//         (bases 5..8 dropped), for the mutants that change the leading bases: all substitutions at positions
+//         0..6 share the window's line, all early insertions share the "shifted right" line and all early
+//         deletions the "shifted left" line -- 4 lines per offset instead of ~54 with one prefix-ordered table.
 // rank[k] = number of set keys below (k << 8): ordinal(key) = rank[key >> 8] + popcount of the fine bits
 // of that 256-key block below key  (pass-1 histogram index).
 constexpr int kG0 = 8;
@@ -35,6 +39,7 @@ constexpr size_t kRankEntries = size_t(1) << 24;
 
 struct Pyramid {
     const uint32_t *l0;
+    const uint32_t *l0s;  // suffix-major twin of l0 (same 2^24 bits): bit ((key & 0x3FFF) << 10 | key >> 22)
     const uint32_t *l1;
     const uint32_t *fine;
     const uint32_t *rank;
@@ -45,6 +50,7 @@ struct Pyramid {
 struct smi_ctx {
     int device = -1;
     uint32_t *l0 = nullptr;
+    uint32_t *l0s = nullptr;
     uint32_t *l1 = nullptr;
     uint32_t *fine = nullptr;
     uint32_t *rank = nullptr;

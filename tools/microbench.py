@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Secondary kernels' throughput on one MI355X (not the headline bench): K-BC2 (ed<=2, used-list mode),
+K-SCAN pass 1 (complete adapter + quality filter) + histogram, K-UMI.  Prints one JSON object."""
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+
+
+def timed(fn, reps=3):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    pkg = graft.load_package()
+    synth = importlib.import_module(graft.PKG_NAME + ".synth")
+    dev = torch.device("cuda:0")
+    ctx = pkg.Context(0)
+    res = {}
+    wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
+    used = synth.pick_used(wl, 5000, seed=2)
+    # ---- K-BC2 / K-BC1 in used-list mode -------------------------------------------------------------------
+    n = 2_000_000
+    reg = synth.gen_bc_region(n, used, seed=3, device=dev)
+    win = synth.pack_windows(reg["codes"], reg["ae"])
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
+    for ed in (1, 2):
+        dt = timed(lambda: ctx.bc_match_device(win, out, n, max_ed=ed))
+        found = ((out[:, 2] & 0xFF) == 1)
+        acc = float(((out[:, 0].to(torch.int64) & 0xFFFFFFFF)[found] == reg["truth"][found]).float().mean())
+        res[f"bc_match_ed{ed}_used_list_5k"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt,
+                                                "assigned_frac": float(found.float().mean()), "accuracy": acc}
+    ctx.set_barcode_set_device(wl.to(torch.int32), mode=1)
+    dt = timed(lambda: ctx.bc_match_device(win, out, n, max_ed=2))
+    res["bc_match_ed2_whitelist_3p6M"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt}
+    del reg, win, out
+    # ---- pass 1: scan (22-mer) + quality filter + histogram ---------------------------------------------------
+    n = 2_000_000
+    rd = synth.gen_reads(n, used, seed=5, device=dev, q_mean=14.0)
+    ends = synth.pack_ends(rd["head"], rd["tail"])
+    lens = (2 * synth.END_BASES + rd["mid_len"]).to(torch.int32)
+    qtail = rd["qtail"].contiguous()
+    qsum = (rd["qhead"].to(torch.int32).sum(1) + rd["qtail"].to(torch.int32).sum(1) - 33 * 2 * synth.END_BASES +
+            (rd["qmid"].to(torch.int32) - 33) * rd["mid_len"].to(torch.int32)).to(torch.int32)
+    cfg1 = ctx.scan_config(1)
+    so = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    win = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    hist = torch.zeros(wl.numel(), dtype=torch.int32, device=dev)
+
+    def pass1():
+        ctx.scan_device(ends, lens, n, cfg1, so, win, qtail, qsum)
+        ctx.hist_windows_device(win, so, n, hist)
+
+    dt = timed(pass1)
+    res["pass1_scan22_filter_hist"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt,
+                                       "pass1_ok_frac": float((((so[:, 7]) & 0xFF) == 1).float().mean())}
+    del rd, ends, so, win
+    # ---- K-UMI ------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(1)
+    sizes = np.minimum(rng.zipf(1.6, 400_000), 400).astype(np.int64) + 1
+    go, po, mo = ctx.umi_offsets(sizes)
+    n_reads = int(go[-1])
+    w = torch.randint(0, 4, (n_reads, 14), device=dev)
+    codes = torch.tensor([1, 2, 4, 8], device=dev)[w]
+    packed = (codes << (4 * torch.arange(14, device=dev))).sum(1)
+    d_go = torch.from_numpy(go.view(np.int32)).to(dev)
+    d_po = torch.from_numpy(po.view(np.int64)).to(dev)
+    d_mo = torch.from_numpy(mo.view(np.int64)).to(dev)
+    d_out = torch.zeros(int(mo[-1]), dtype=torch.uint8, device=dev)
+    dt = timed(lambda: ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out))
+    res["umi_dist"] = {"groups": int(len(sizes)), "reads": n_reads, "pairs": int(po[-1]), "ms": dt * 1e3,
+                       "pairs_per_s": int(po[-1]) / dt, "levenshtein_per_s": 9 * int(po[-1]) / dt}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
