@@ -121,8 +121,8 @@ int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass,
 
 /* ================================================================================================================
  * Read scan (3' protocol): polyA/T finder + k-mer gated Needleman-Wunsch adapter scan + strand decision.
- * Replaces PolyATadapterAnalyzer_3pBCUMI.search minus the TSO scan
- * (FJ!nanoporereadscanner/analyzers/PolyATadapterAnalyzer_3pBCUMI.java:L45-68 ->
+ * Replaces PolyATadapterAnalyzer_3pBCUMI.search incl. the TSO scan
+ * (FJ!nanoporereadscanner/analyzers/PolyATadapterAnalyzer_3pBCUMI.java:L45-190 ->
  *  FJ!nanopore/analyzers/PolyATadapterAnalyzerBase.java:L109-319, PolyATSearcher.java:L56-252,
  *  AdapterTSOanalyzer.java:L84-110) and, with qualities, the pass-1 filter of
  * UsedCellBCListGenerator$Worker (UsedCellBCListGenerator.java:L198-202).
@@ -150,6 +150,9 @@ int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass,
 #define SMI_F_ADAPTER_SELECTED_DESP_BOTH (1u << 20)
 #define SMI_F_READ_TOO_SHORT (1u << 21)
 #define SMI_F_ADAPTER_5P_AND_3P (1u << 22)
+#define SMI_F_TSO_5P (1u << 18)
+#define SMI_F_TSO_3P (1u << 19)
+#define SMI_F_TSO_5P_AND_3P (1u << 23)
 
 typedef struct {
     int32_t min_read_length;        /* Jar/config.xml:21   200 */
@@ -168,13 +171,14 @@ typedef struct {
     uint32_t flags;
     int32_t adapter_start, adapter_end; /* AS / AE: stranded, 1-based (ReadScanResult.java:L445-447); 0 = none */
     int32_t polya_start, polya_end;     /* PS / PE (ReadScanResult.java:L346,L356) */
-    int32_t scan_end;                   /* adapter end in scan orientation */
+    int16_t scan_end;                   /* adapter end in scan orientation */
+    int16_t tso_start;                  /* TSOresult.start (0 = null) */
     int16_t adapter_nmis;               /* NeedlemanMatch.getNerrorsNeedleman of the accepted alignment */
     int8_t found;                       /* adapterFound() */
     int8_t reverse;                     /* 1: stranded read = reverse complement of the raw read (PASSED_REV) */
     int8_t pass1_ok;                    /* pass-1 quality filter passed (only when qualities were given) */
     int8_t reserved;
-    int16_t pad;
+    int16_t tso_end;                    /* TSOresult.end (0 = null): the read name's T= field */
 } smi_scan_result;
 
 /* fills cfg with the shipped config.xml values; pass = 1 (complete adapter) or 2 (short adapter) */

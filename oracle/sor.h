@@ -52,7 +52,13 @@ int sor_assign_barcode(const sor_set *search, const char *stranded, int read_len
 /* ---- read scan (sor_scan.c) ------------------------------------------------------------------------------ */
 /* bit = ordinal of the flag in FJ!nanoporereadscanner/stats/ReadFlags$Flags (ReadFlags.java:L72-109); the
  * reference's own long values come from a static counter and are not part of any output format */
+#define SOR_F_PASSED_TOTAL (1ull << 5)
 #define SOR_F_FAILED (1ull << 6)
+#define SOR_F_PASSED_TOT_TSO (1ull << 11)
+#define SOR_F_TSO_5P (1ull << 18)
+#define SOR_F_TSO_3P (1ull << 19)
+#define SOR_F_TSO_5P_AND_3P (1ull << 23)
+#define SOR_F_TSO_5P_AND_3P_FAILED (1ull << 24)
 #define SOR_F_PASSED_FWD (1ull << 9)
 #define SOR_F_PASSED_REV (1ull << 10)
 #define SOR_F_POLY_T_5P (1ull << 12)
@@ -85,8 +91,10 @@ typedef struct {
     int32_t n_cand_fwd, n_cand_rev;       /* NW candidates per side (-1: no polyT on that side) */
     int32_t pass1_ok;                     /* UsedCellBCListGenerator quality filter */
     float mean_qv_bc, mean_qv_read;
+    int32_t tso_start, tso_end;           /* TSOresult.start / .end (0 = null); T= prints tso_end */
 } sor_scan_result;
 
+uint64_t sor_finalize_flag(uint64_t flags);
 int sor_find_polyt(const uint8_t *seq4, int n, int minlen, float minfrac, int window, int *begin1, int *end1);
 int sor_scan_read_3p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
                      const sor_scan_params *par, sor_scan_result *out);

@@ -236,25 +236,158 @@ typedef struct {
     int best_pos[256];
 } scan_rslt;
 
-static void scan_adapter(const uint8_t *read, int read_len, int begin, int end, const uint8_t *ad, int ad_len,
-                         scan_rslt *res) {
+/* Math.round(float): floor(a + 0.5f) */
+static int jround(float a) { return (int)floorf(a + 0.5f); }
+
+/* max_errors < 0: Optional.empty() */
+static void scan_adapter_max(const uint8_t *read, int read_len, int begin, int end, const uint8_t *ad, int ad_len,
+                             float max_errors, scan_rslt *res) {
     res->n_all = 0;
     res->n_best = 0;
     res->best = 3.4028234663852886e+38f;
     int last = read_len - ad_len < end ? read_len - ad_len : end;
-    for (int pos = begin; pos <= last; pos++) {
+    int delta = 1;
+    for (int pos = begin; pos <= last; pos += delta) {
+        delta = 1;
         int n = kmers4_matching(read, read_len, ad, ad_len, pos);
         if (n <= 1) continue;
         nw_aln a;
         nw_align(ad, ad_len, read + pos - 1, ad_len, &SEARCH, &a);
         float ne = count_errors(&a);
-        res->n_all++;
-        if (ne < res->best) {
-            res->best = ne;
-            res->n_best = 0;
+        if (max_errors < 0 || !((float)jround(ne) > max_errors)) { /* L97-98 */
+            res->n_all++;
+            if (ne < res->best) {
+                res->best = ne;
+                res->n_best = 0;
+            }
+            if (ne == res->best && res->n_best < 256) res->best_pos[res->n_best++] = pos;
         }
-        if (ne == res->best && res->n_best < 256) res->best_pos[res->n_best++] = pos;
+        if (max_errors >= 0 && max_errors < ne) { /* L100-104 */
+            delta = jround(ne - max_errors) - 1;
+            if (delta < 1) delta = 1;
+        }
     }
+}
+
+static void scan_adapter(const uint8_t *read, int read_len, int begin, int end, const uint8_t *ad, int ad_len,
+                         scan_rslt *res) {
+    scan_adapter_max(read, read_len, begin, end, ad, ad_len, -1.0f, res);
+}
+
+/* NeedlemanMatch.getNconsecutiveMatchesNeedleman L160-173: a run only counts once a non-'.' follows it */
+static int n_consecutive_matches(const nw_aln *a) {
+    int ret = 0, cur = 0;
+    for (int i = 0; i < a->len; i++) {
+        if (a->dots[i] == '.')
+            cur++;
+        else {
+            if (cur > ret) ret = cur;
+            cur = 0;
+        }
+    }
+    return ret;
+}
+
+/* getSumOfBestTwoMatchStretchesNeedleman L183-196: runs > 4 (closed by a non-'.'), sorted ASCENDING, first two summed */
+static int sum_best_two_stretches(const nw_aln *a) {
+    int runs[2 * NW_MAX], nr = 0, cur = 0;
+    for (int i = 0; i < a->len; i++) {
+        if (a->dots[i] == '.')
+            cur++;
+        else {
+            if (cur > 4) runs[nr++] = cur;
+            cur = 0;
+        }
+    }
+    for (int i = 1; i < nr; i++) {
+        int x = runs[i], j = i - 1;
+        while (j >= 0 && runs[j] > x) {
+            runs[j + 1] = runs[j];
+            j--;
+        }
+        runs[j + 1] = x;
+    }
+    int s = 0;
+    for (int i = 0; i < nr && i < 2; i++) s += runs[i];
+    return s;
+}
+
+/* PolyATadapterAnalyzerBase.scanForTSO L324-369 */
+typedef struct {
+    int present; /* Match != null */
+    int passed;
+    int nmis;
+    int end_scan; /* best position + len - 1 + ins - del, scan coordinates */
+    nw_aln aln;
+} tso_match;
+
+static void scan_for_tso(const uint8_t *seq, int seq_len, const uint8_t *tso, int tso_len, int max_mm, int scantil,
+                         tso_match *m) {
+    scan_rslt r;
+    m->present = 0;
+    m->passed = 0;
+    scan_adapter_max(seq, seq_len, 1, scantil, tso, tso_len, (float)max_mm, &r);
+    if (r.n_all == 0) return;
+    int pos = r.best_pos[0];
+    nw_align(tso, tso_len, seq + pos - 1, tso_len, &SEARCH, &m->aln); /* finalAlignment scores == search scores */
+    nm_counts c = needleman_counts(&m->aln);
+    m->present = 1;
+    m->nmis = c.nmis;
+    m->passed = c.nmis <= max_mm; /* L350 */
+    m->end_scan = pos + tso_len - 1 + c.ins - c.del;
+}
+
+/* PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190 */
+static void scan_read_for_tsos(const char *read, int len, const sor_scan_params *par, sor_scan_result *out) {
+    static const char TSO[] = "AACGCAGAGTACATGG"; /* Jar/config.xml:155 */
+    const int tso_len = 16, window = 90, max_mm = 5, min_consec = 8, min_two = 12; /* :157-166 */
+    (void)par;
+    const int n = window + tso_len + 10;
+    uint8_t tso[16], fwd[128], rev[128];
+    for (int i = 0; i < tso_len; i++) tso[i] = (uint8_t)enc4((unsigned char)TSO[i]);
+    for (int i = 0; i < n; i++) fwd[i] = (uint8_t)enc4((unsigned char)read[i]);
+    for (int i = 0; i < n; i++) rev[i] = (uint8_t)sor_fourbit_complement(enc4((unsigned char)read[len - 1 - i]));
+    tso_match f, r;
+    scan_for_tso(fwd, n, tso, tso_len, max_mm, window, &f);
+    scan_for_tso(rev, n, tso, tso_len, max_mm, window, &r);
+#define FOUND(m) ((m).present && (m).passed)
+    if (!FOUND(f) && !FOUND(r)) { /* L146-153: rescue by >= 8 consecutive matches */
+        if (f.present) f.passed = n_consecutive_matches(&f.aln) >= min_consec;
+        if (r.present) r.passed = n_consecutive_matches(&r.aln) >= min_consec;
+        if (!FOUND(f) && !FOUND(r)) { /* L155-162: rescue by the two stretches */
+            if (f.present) f.passed = sum_best_two_stretches(&f.aln) >= min_two;
+            if (r.present) r.passed = sum_best_two_stretches(&r.aln) >= min_two;
+        }
+    }
+    if (FOUND(f) && FOUND(r) && abs(f.nmis - r.nmis) > 3) { /* L167-172 */
+        if (f.nmis > r.nmis)
+            f.present = 0;
+        else
+            r.present = 0;
+    }
+    int ff = FOUND(f), rf = FOUND(r);
+#undef FOUND
+    /* L177-181: endPosRead = len - (end_scan - 1); TSO start/end = len - (endPosRead - 1) = end_scan */
+    if (ff) out->tso_start = f.end_scan;
+    if (rf) out->tso_end = r.end_scan;
+    if (ff && !rf)
+        out->flags |= SOR_F_TSO_5P;
+    else if (!ff && rf)
+        out->flags |= SOR_F_TSO_3P;
+    else if (ff && rf)
+        out->flags |= SOR_F_TSO_5P_AND_3P;
+}
+
+/* ReadFlags$Flags.finalizeFlag (FJ!nanoporereadscanner/stats/ReadFlags.java:L194-207) */
+uint64_t sor_finalize_flag(uint64_t f) {
+    if (!(f & SOR_F_PASSED_FWD) && !(f & SOR_F_PASSED_REV))
+        f |= SOR_F_FAILED;
+    else
+        f |= SOR_F_PASSED_TOTAL;
+    if (((f & SOR_F_PASSED_REV) && (f & SOR_F_TSO_3P)) || ((f & SOR_F_PASSED_FWD) && (f & SOR_F_TSO_5P)))
+        f |= SOR_F_PASSED_TOT_TSO;
+    if ((f & SOR_F_FAILED) && (f & SOR_F_TSO_5P_AND_3P)) f |= SOR_F_TSO_5P_AND_3P_FAILED;
+    return f;
 }
 
 /* PolyATadapterAnalyzerBase.createNeedlemanMatch (FJ!nanopore/analyzers/PolyATadapterAnalyzerBase.java:L237-253) */
@@ -296,8 +429,20 @@ static int mean_qv(const char *qual, int qlen, int start1, int stop1, float *out
  * + PolyATadapterAnalyzerBase.{searchpolyA L109-121, analyze L145-221, getMatchList L275-319}
  * + pass-1 filter UsedCellBCListGenerator$Worker.lambda$call$0 (UsedCellBCListGenerator.java:L198-202).
  * TSO scan (scanReadForTSOs) is not restated yet: it only sets the T= field and TSO_* flags. */
+static int scan_read_3p_core(const char *read, const char *qual, int len, const char *adapter, int max_mm,
+                             const sor_scan_params *par, sor_scan_result *out);
+
 int sor_scan_read_3p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
                      const sor_scan_params *par, sor_scan_result *out) {
+    int rc = scan_read_3p_core(read, qual, len, adapter, max_mm, par, out);
+    if (rc != 0) return rc;
+    /* search() L45-46 returns before the TSO scan for too-short reads; otherwise scanReadForTSOs always runs (L111) */
+    if (!(out->flags & SOR_F_READ_TOO_SHORT)) scan_read_for_tsos(read, len, par, out);
+    return 0;
+}
+
+static int scan_read_3p_core(const char *read, const char *qual, int len, const char *adapter, int max_mm,
+                             const sor_scan_params *par, sor_scan_result *out) {
     memset(out, 0, sizeof(*out));
     if (len < par->min_read_length) { /* testReadLength L131-137 */
         out->flags = SOR_F_READ_TOO_SHORT | SOR_F_FAILED;

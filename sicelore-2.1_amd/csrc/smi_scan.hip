@@ -155,6 +155,8 @@ struct FinalAln {
     int ins, del, sub, nmis;
     bool term6;
     float end5, endn;
+    int consec;   // NeedlemanMatch.getNconsecutiveMatchesNeedleman L160-173 (a run counts once a non-'.' follows it)
+    int best_two; // getSumOfBestTwoMatchStretchesNeedleman L183-196 (the two SMALLEST closed runs > 4)
 };
 
 // full DP with 2-bit moves in LDS + walk from the end (SequenceAlignment.getTraceback L102-151,
@@ -203,6 +205,24 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
     int ins = 0, del = 0, sub = 0, trail = 0, cb = 0, t = 0;
     bool trailing = true, term = true;
     float e5 = 0.0f, en = 0.0f;
+    // runs of '.', met in reverse: a run is closed (counts) iff an 'x' was met before it on the way back
+    int run = 0, consec = 0, s1 = 0, s2 = 0, n_runs = 0;
+    bool seen_x = false, run_closed = false;
+    auto close_run = [&]() {
+        if (run > 0 && run_closed) {
+            consec = max(consec, run);
+            if (run > 4) {
+                if (n_runs == 0 || run < s1) {
+                    s2 = s1;
+                    s1 = run;
+                } else if (n_runs == 1 || run < s2) {
+                    s2 = run;
+                }
+                n_runs++;
+            }
+        }
+        run = 0;
+    };
     while (r > 0 || c > 0) {
         int mv;
         if (r == 0)
@@ -222,6 +242,13 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
             trailing = false;
         if (t < 6 && x) term = false;
         if (x) {
+            close_run();
+            seen_x = true;
+        } else {
+            if (run == 0) run_closed = seen_x;
+            run++;
+        }
+        if (x) {
             if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
             if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
         }
@@ -235,6 +262,9 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
             c--;
         t++;
     }
+    close_run();
+    out.consec = consec;
+    out.best_two = (n_runs >= 1 ? s1 : 0) + (n_runs >= 2 ? s2 : 0);
     del = (int)(int8_t)(del - trail);
     out.ins = ins;
     out.del = del;
@@ -250,6 +280,84 @@ __device__ __forceinline__ void load_cols(const uint32_t *planes, int tid, const
                                           uint32_t (&col)[AD]) {
 #pragma unroll
     for (int c = 0; c < AD; c++) col[c] = match32(planes, tid, P.adapter4[c], pos1 - 1) & ((1u << AD) - 1u);
+}
+
+// TSO "AACGCAGAGTACATGG" (Jar/config.xml:155) as 4-bit codes A=1 G=2 C=4 T=8
+__device__ __forceinline__ uint32_t tso4(int i) {
+    // packed nibbles, base i in bits [4i+3:4i]
+    constexpr uint64_t TSO = 0x2281418212142411ull;  // A A C G C A G A G T A C A T G G  (low nibble first)
+    return (uint32_t)(TSO >> (4 * i)) & 15u;
+}
+__device__ __forceinline__ void load_cols_tso(const uint32_t *planes, int tid, int pos1, uint32_t (&col)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) col[c] = match32(planes, tid, tso4(c), pos1 - 1) & 0xFFFFu;
+}
+
+struct TsoMatch {
+    int present, passed, nmis, end_scan, consec, best_two;
+};
+
+// PolyATadapterAnalyzerBase.scanForTSO (L324-369) on this lane's end: AdapterTSOanalyzer.scanForAdapterOrTSOseq with
+// maxErrors = 5 (L84-110: candidates kept when Math.round(nErrors) <= 5, positions skipped by round(nErrors - 5) - 1
+// after a bad candidate), then the final alignment of the first best position.
+__device__ __forceinline__ int scan_tso_positions(const uint32_t *planes, int tid) {
+    float best = 3.4028234663852886e+38f;
+    int best_pos = 0, skip_until = 0;
+    const int last = 90;  // min(116 - 16, windowForTSOsearch = 90)
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {
+        const int b = ch * 64;
+        uint64_t any = 0, two = 0;
+        uint64_t m0 = match64(planes, tid, tso4(0), b), m1 = match64(planes, tid, tso4(1), b + 1),
+                 m2 = match64(planes, tid, tso4(2), b + 2);
+#pragma unroll
+        for (int i = 0; i + 3 < 16; i++) {
+            const uint64_t m3 = match64(planes, tid, tso4(i + 3), b + i + 3);
+            const uint64_t k = m0 & m1 & m2 & m3;
+            two |= any & k;
+            any |= k;
+            m0 = m1;
+            m1 = m2;
+            m2 = m3;
+        }
+        uint64_t cand = two;
+        const int hi = last - b;
+        cand = hi <= 0 ? 0 : (hi >= 64 ? cand : (cand & ((1ull << hi) - 1ull)));
+        while (cand) {
+            const int i = __builtin_ctzll(cand);
+            cand &= cand - 1;
+            const int pos = b + i + 1;
+            if (pos < skip_until) continue;  // jumped over by deltaPos
+            uint32_t col[16];
+            load_cols_tso(planes, tid, pos, col);
+            const float ne = nw_errors<16>(col);
+            if (!((float)(int)floorf(__fadd_rn(ne, 0.5f)) > 5.0f)) {  // Math.round(nErrors) <= maxErrors
+                if (ne < best) {
+                    best = ne;
+                    best_pos = pos;
+                }
+            }
+            if (5.0f < ne) {
+                int d = (int)floorf(__fadd_rn(__fsub_rn(ne, 5.0f), 0.5f)) - 1;
+                if (d < 1) d = 1;
+                skip_until = pos + d;
+            }
+        }
+    }
+    return best_pos;  // 0 = AdapterScanRslt empty
+}
+
+__device__ __forceinline__ void tso_final(const uint32_t *planes, uint64_t *dirs, int tid, int best_pos, TsoMatch &m) {
+    uint32_t col[16];
+    load_cols_tso(planes, tid, best_pos, col);
+    FinalAln a;
+    nw_final<16>(col, dirs, tid, 0, a);
+    m.present = 1;
+    m.nmis = a.nmis;
+    m.passed = a.nmis <= 5;
+    m.end_scan = best_pos + 15 + a.ins - a.del;
+    m.consec = a.consec;
+    m.best_two = a.best_two;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -377,6 +485,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
         res.reverse = 0;
         res.pass1_ok = 0;
         res.reserved = 0;
+        res.tso_start = 0;
+        res.tso_end = 0;
         smi_bc_window win;
         win.bases = 0;
         win.nmask = 0;
@@ -418,10 +528,10 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
             } else {
                 const int s_end = f_pos + AD - 1 + fa.ins - fa.del;  // L251
                 res.found = 1;
-                res.scan_end = s_end;
+                res.scan_end = (int16_t)s_end;
                 res.adapter_start = len - (f_pos - 1);  // ReadScanResult.java:L446-447
                 res.adapter_end = len - (s_end - 1);
-                res.adapter_nmis = fa.nmis;
+                res.adapter_nmis = (int16_t)fa.nmis;
                 res.reverse = use_fwd ? 1 : 0;
                 res.flags |= use_fwd ? (SMI_F_ADAPTER_5P | SMI_F_PASSED_REV) : (SMI_F_ADAPTER_3P | SMI_F_PASSED_FWD);
                 // barcode window: stranded[AE-22 .. AE+1] = reverse complement of scan[s_end-1 .. s_end+22]
@@ -473,6 +583,41 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
                 }
             }
         }
+        // ---- TSO scan on both ends (PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190) -------------------------------
+        TsoMatch tm = {0, 0, 0, 0, 0, 0};
+        const int tso_pos = (active && long_enough) ? scan_tso_positions(planes, tid) : 0;
+#pragma unroll
+        for (int sd = 0; sd < 2; sd++)  // the two lanes of a pair share one direction slot: one side at a time
+            if (side == sd && tso_pos) tso_final(planes, dirs, tid, tso_pos, tm);
+        {
+            TsoMatch o;
+            o.present = __shfl_xor(tm.present, 1);
+            o.passed = __shfl_xor(tm.passed, 1);
+            o.nmis = __shfl_xor(tm.nmis, 1);
+            o.end_scan = __shfl_xor(tm.end_scan, 1);
+            o.consec = __shfl_xor(tm.consec, 1);
+            o.best_two = __shfl_xor(tm.best_two, 1);
+            TsoMatch f = side == 0 ? tm : o, r = side == 0 ? o : tm;
+            auto found = [](const TsoMatch &x) { return x.present && x.passed; };
+            if (!found(f) && !found(r)) {  // L146-153: rescue by >= 8 consecutive matches (config.xml:161)
+                if (f.present) f.passed = f.consec >= 8;
+                if (r.present) r.passed = r.consec >= 8;
+                if (!found(f) && !found(r)) {  // L155-162: rescue by the two stretches >= 12 (config.xml:164)
+                    if (f.present) f.passed = f.best_two >= 12;
+                    if (r.present) r.passed = r.best_two >= 12;
+                }
+            }
+            if (found(f) && found(r) && abs(f.nmis - r.nmis) > 3) {  // L167-172
+                if (f.nmis > r.nmis)
+                    f.present = 0;
+                else
+                    r.present = 0;
+            }
+            const bool ff = found(f), rf = found(r);
+            res.tso_start = ff ? (int16_t)f.end_scan : (int16_t)0;  // TSOresult.start/.end = end of the match in scan
+            res.tso_end = rf ? (int16_t)r.end_scan : (int16_t)0;    // coordinates (L177-181)
+            if (long_enough) res.flags |= (ff && !rf) ? SMI_F_TSO_5P : (!ff && rf) ? SMI_F_TSO_3P : (ff && rf) ? SMI_F_TSO_5P_AND_3P : 0u;
+        }
         // one record per read: written by the chosen lane, else by the even lane
         const int partner_chosen = __shfl_xor((int)chosen, 1);
         if (active && (chosen || (side == 0 && !partner_chosen))) {
@@ -510,7 +655,7 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 16);
     if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;
     if (ad == 10) {
-        const size_t lds = 5 * kLdsWords * kBlock * 4 + 10 * (kBlock / 2) * 8;
+        const size_t lds = 5 * kLdsWords * kBlock * 4 + 16 * (kBlock / 2) * 8;  // 16 rows: the TSO alignment
         hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), lds, s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out, d_win);
     } else {
         const size_t lds = 5 * kLdsWords * kBlock * 4 + 22 * (kBlock / 2) * 8;

@@ -18,8 +18,8 @@ BC_RESULT_DTYPE = np.dtype(
 )
 SCAN_RESULT_DTYPE = np.dtype(
     [("flags", "<u4"), ("adapter_start", "<i4"), ("adapter_end", "<i4"), ("polya_start", "<i4"), ("polya_end", "<i4"),
-     ("scan_end", "<i4"), ("adapter_nmis", "<i2"), ("found", "i1"), ("reverse", "i1"), ("pass1_ok", "i1"),
-     ("reserved", "i1"), ("pad", "<i2")]
+     ("scan_end", "<i2"), ("tso_start", "<i2"), ("adapter_nmis", "<i2"), ("found", "i1"), ("reverse", "i1"),
+     ("pass1_ok", "i1"), ("reserved", "i1"), ("tso_end", "<i2")]
 )
 SCAN_CONFIG_DTYPE = np.dtype(
     [("min_read_length", "<i4"), ("polya_len", "<i4"), ("polya_frac", "<f4"), ("window_polya", "<i4"),
@@ -30,7 +30,7 @@ END_BASES = 224
 ENDS_ROWS = 28
 FLAG_BITS = {"FAILED": 6, "PASSED_FWD": 9, "PASSED_REV": 10, "POLY_T_5P": 12, "POLY_A_3P": 13, "POLY_A_NOT_FOUND": 14,
              "POLY_T_5P_POLY_A_3P": 15, "ADAPTER_5P": 16, "ADAPTER_3P": 17, "ADAPTER_SELECTED_DESP_BOTH": 20,
-             "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22}
+             "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22, "TSO_5P": 18, "TSO_3P": 19, "TSO_5P_AND_3P": 23}
 assert BC_WINDOW_DTYPE.itemsize == 16 and BC_RESULT_DTYPE.itemsize == 16 and SCAN_RESULT_DTYPE.itemsize == 32
 
 SET_USED_LIST = 0

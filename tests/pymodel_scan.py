@@ -176,23 +176,103 @@ def kmers_matching(read, ad, pos1):
     return m
 
 
-def scan_adapter(read, begin, end, ad):
+def jround(x):
+    """Math.round(float)"""
+    import math
+
+    return int(math.floor(float(f32(f32(x) + f32(0.5)))))
+
+
+def scan_adapter(read, begin, end, ad, max_errors=None):
+    """AdapterTSOanalyzer.scanForAdapterOrTSOseq L84-110"""
     rslt = {}
     pos = begin
     while pos <= min(len(read) - len(ad), end):
+        delta = 1
         if kmers_matching(read, ad, pos) > 1:
             ne = count_errors(needleman(ad, read[pos - 1:pos - 1 + len(ad)]))
-            rslt.setdefault(float(ne), []).append(pos)
-        pos += 1
+            if max_errors is None or not (jround(ne) > max_errors):
+                rslt.setdefault(float(ne), []).append(pos)
+            if max_errors is not None and max_errors < ne:
+                delta = max(1, jround(f32(ne - f32(max_errors))) - 1)
+        pos += delta
     return rslt
+
+
+def n_consecutive(pattern):
+    ret = cur = 0
+    for ch in pattern:
+        if ch == ".":
+            cur += 1
+        else:
+            ret, cur = max(ret, cur), 0
+    return ret
+
+
+def best_two(pattern):
+    runs, cur = [], 0
+    for ch in pattern:
+        if ch == ".":
+            cur += 1
+        else:
+            if cur > 4:
+                runs.append(cur)
+            cur = 0
+    return sum(sorted(runs)[:2])
+
+
+def scan_tsos(read):
+    """PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190 -> (flags set, tso_start, tso_end)"""
+    tso = enc("AACGCAGAGTACATGG")
+    L = len(read)
+    fwd = enc(read[:116])
+    rev = enc(revcomp_str(read[L - 116:]))
+
+    def one(seq):
+        r = scan_adapter(seq, 1, 90, tso, 5)
+        if not r:
+            return None
+        pos = r[min(r)][0]
+        nm = NeedlemanMatch(needleman(tso, seq[pos - 1:pos + 15]))
+        nm.passed = nm.nmis <= 5
+        nm.end_scan = pos + 15 + nm.ins - nm.dele
+        return nm
+
+    f, r = one(fwd), one(rev)
+    found = lambda m: m is not None and m.passed  # noqa: E731
+    if not found(f) and not found(r):
+        for m in (f, r):
+            if m is not None:
+                m.passed = n_consecutive(m.pattern) >= 8
+        if not found(f) and not found(r):
+            for m in (f, r):
+                if m is not None:
+                    m.passed = best_two(m.pattern) >= 12
+    if found(f) and found(r) and abs(f.nmis - r.nmis) > 3:
+        if f.nmis > r.nmis:
+            f = None
+        else:
+            r = None
+    ff, rf = found(f), found(r)
+    flags = set()
+    if ff and not rf:
+        flags.add("TSO_5P")
+    elif rf and not ff:
+        flags.add("TSO_3P")
+    elif ff and rf:
+        flags.add("TSO_5P_AND_3P")
+    return flags, (f.end_scan if ff else 0), (r.end_scan if rf else 0)
 
 
 def scan_read_3p(read, qual, adapter, max_mm=3, min_len=200, min_3p=8, min_bc_qv=8, min_read_qv=8):
     out = dict(flags=set(), adapter_found=0, pass1_ok=0)
     L = len(read)
+    out["tso_start"] = out["tso_end"] = 0
     if L < min_len:
         out["flags"] |= {"READ_TOO_SHORT", "FAILED"}
         return out
+    tf, out["tso_start"], out["tso_end"] = scan_tsos(read)
+    out["flags"] |= tf
     ad = enc(adapter)
     fwd = enc(read[:175])
     rev = enc(revcomp_str(read[L - 175:]))

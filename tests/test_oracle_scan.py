@@ -73,7 +73,7 @@ def test_scan_c_oracle_equals_python_model(sor, synth, adapter, n_reads):
     wl = synth.make_whitelist(5000, seed=81)
     used = synth.pick_used(wl, 50, seed=82)
     reads = synth.gen_reads(n_reads, used, seed=83, n_rate=0.004)
-    n_found = n_pass1 = 0
+    n_found = n_pass1 = n_tso = 0
     for i in range(n_reads):
         seq, qual = synth.materialize(reads, i)
         if i % 25 == 0:
@@ -87,6 +87,8 @@ def test_scan_c_oracle_equals_python_model(sor, synth, adapter, n_reads):
         flags = {k for k, b in sor.FLAG_BITS.items() if (int(r["flags"]) >> b) & 1}
         assert flags == m["flags"], (i, flags, m["flags"])
         assert int(r["adapter_found"]) == m["adapter_found"]
+        assert (int(r["tso_start"]), int(r["tso_end"])) == (m["tso_start"], m["tso_end"]), i
+        n_tso += bool(m["tso_start"] or m["tso_end"])
         if m["adapter_found"]:
             n_found += 1
             for f in ("adapter_start", "adapter_end", "polya_start", "polya_end", "reverse", "adapter_nmis", "pass1_ok"):
@@ -94,6 +96,7 @@ def test_scan_c_oracle_equals_python_model(sor, synth, adapter, n_reads):
             n_pass1 += m["pass1_ok"]
     assert n_found > n_reads * 0.6
     assert n_pass1 > 10
+    assert n_tso > n_reads * 0.5
 
 
 def test_scan_then_assign_recovers_barcodes(sor, synth):

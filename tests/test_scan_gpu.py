@@ -7,6 +7,7 @@ pytestmark = pytest.mark.gpu
 
 AD = {1: "CTACACGACGCTCTTCCGATCT", 2: "CTTCCGATCT"}
 FIELDS = ("adapter_start", "adapter_end", "polya_start", "polya_end", "scan_end", "adapter_nmis", "reverse")
+TSO_FIELDS = ("tso_start", "tso_end")
 
 
 def _ascii_batch(synth, reads, n, short_every=0):
@@ -58,6 +59,9 @@ def _compare(got, st, exp, pass1):
     # polyA coordinates are also set when a side was chosen but no alignment was accepted
     for f in ("polya_start", "polya_end"):
         assert (got[f].astype(np.int64) == exp[f]).all()
+    for f in TSO_FIELDS:
+        bad = np.nonzero(got[f].astype(np.int64) != exp[f])[0]
+        assert bad.size == 0, f"{f} differs at {bad[:10]}: {got[f][bad[:5]]} vs {exp[f][bad[:5]]}"
     if pass1:
         assert (got["pass1_ok"] == exp["pass1_ok"]).all()
     return int(sel.sum())
