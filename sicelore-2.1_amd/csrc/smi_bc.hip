@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         keys[64 * k + lane] = kEmpty;
                         vals[64 * k + lane] = 0xFFFFFFFFu;
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync();
                     // created(e): first position among equal sequences, and not the root except at position 0
                     bool created[2];
 #pragma unroll
@@ -791,7 +791,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                             }
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
+                    wave_sync();
                     // ---- probes of level 0 and 1 (only created children are ever probed) ----------------------
                     hit0 = member(P, K);
                     const bool h1a = created[0] && c[0].g == 0u && member(P, c[0].low);

@@ -37,6 +37,10 @@ constexpr size_t kL1Words = (size_t(1) << (32 - kG1)) / 32;
 constexpr size_t kFineWords = (size_t(1) << 32) / 32;
 constexpr size_t kRankEntries = size_t(1) << 24;
 
+// Hand-off of LDS data between lanes of ONE wavefront: LDS operations of a wave execute in order, so all that is
+// needed is that the compiler neither reorders memory operations across this point nor leaves them pending.
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 struct Pyramid {
     const uint32_t *l0;
     const uint32_t *l0s;  // suffix-major twin of l0 (same 2^24 bits): bit ((key & 0x3FFF) << 10 | key >> 22)

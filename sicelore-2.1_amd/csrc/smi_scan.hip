@@ -88,6 +88,11 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *tex, int tid, const S
     int first = -1;
     for (int pos = 0; pos < P.window; pos++) {
         const uint32_t x = get32(tex, tid, pos);
+        // every window of the entries pos .. pos+16 lies inside bits 1..31 of x: too few T's there -> none can pass
+        if (ML <= 15 && __popc(x >> 1) < P.thr_first) {
+            pos += 16;
+            continue;
+        }
         const int cnt = __popc((x >> 1) & wmask);                       // L199-200
         if (cnt >= P.thr_first && (x & 1u) && __popc(x & 31u) > 2) {    // L217-218, lambda$2 L98-101
             first = pos;
@@ -118,65 +123,54 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *tex, int tid, const S
     return true;
 }
 
-// ---- scan-phase Needleman-Wunsch with forward-carried statistics ----------------------------------------------
-// cell = score << 16 | nx << 8 | lead  (nx = number of 'x' columns on the traceback path, lead = leading template
-// gaps).  Scores (-4,-5,.,.,-5,-5,+5): NeedlemanParameters.java:L36-38.  Tie-breaks: NeedlemanWunsch.java:L55-80.
-template <int AD>
-__device__ __forceinline__ float nw_errors(const uint32_t (&col)[AD]) {
-    // col[c] bit r = read base r of the slice matches adapter base c
-    int prev[AD + 1], cur[AD + 1];
-#pragma unroll
-    for (int c = 0; c <= AD; c++) prev[c] = (-5 * c) * 65536 + (c << 8);  // row 0: c left moves = c x's
-    for (int r = 1; r <= AD; r++) {
-        cur[0] = (-4 * r) * 65536 + (r << 8) + r;  // column 0: r up moves
-#pragma unroll
-        for (int c = 1; c <= AD; c++) {
-            const int up = prev[c] - 5 * 65536 + (1 << 8);
-            const int left = cur[c - 1] - 5 * 65536 + (1 << 8);
-            const bool m = (col[c - 1] >> (r - 1)) & 1u;
-            const int diag = prev[c - 1] + (m ? 5 * 65536 : (-5 * 65536 + (1 << 8)));
-            const int su = up >> 16, sl = left >> 16, sd = diag >> 16;
-            int v;
-            if (su >= sl)
-                v = sd >= su ? diag : up;
-            else
-                v = sd >= sl ? diag : left;
-            cur[c] = v;
-        }
-#pragma unroll
-        for (int c = 0; c <= AD; c++) prev[c] = cur[c];
-    }
-    const int nx = (prev[AD] >> 8) & 0xFF, lead = prev[AD] & 0xFF;
-    // Match.countErrorsInNeedleman (Match.java:L31-34): (float)#x - 0.9f * (float)lead, two roundings
-    return __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));
-}
-
-struct FinalAln {
-    int ins, del, sub, nmis;
+// ---- Needleman-Wunsch with 2-bit moves in LDS and a walk from the end ---------------------------------------
+// Scores (-4,-5,.,.,-5,-5,+5): NeedlemanParameters.java:L36-38.  Tie-breaks: NeedlemanWunsch.java:L55-80.
+// The walk yields everything the reference reads off the alignment strings (SequenceAlignment.getTraceback L102-151):
+//   Match.countErrorsInNeedleman L31-34 (#x - 0.9f * leading template gaps), NeedlemanMatch.countNeedlemanErrorsInRead
+//   L68-86, countIndelsMismatchesEndOfRead L109-123, getNconsecutiveMatchesNeedleman L160-173,
+//   getSumOfBestTwoMatchStretchesNeedleman L183-196, Match.hasN3pConsecutiveMatchesInNeedleman L41-50.
+// move: 0 diag match, 1 diag mismatch, 2 up (template gap), 3 left (read gap).
+struct AlnStats {
+    float ne;         // countErrorsInNeedleman
+    float end5, endn; // countIndelsMismatchesEndOfRead(5) / (minAdapter3pMatches)
+    int nmis, ins, del;
+    int consec, best_two;
     bool term6;
-    float end5, endn;
-    int consec;   // NeedlemanMatch.getNconsecutiveMatchesNeedleman L160-173 (a run counts once a non-'.' follows it)
-    int best_two; // getSumOfBestTwoMatchStretchesNeedleman L183-196 (the two SMALLEST closed runs > 4)
 };
 
-// full DP with 2-bit moves in LDS + walk from the end (SequenceAlignment.getTraceback L102-151,
-// NeedlemanMatch.countNeedlemanErrorsInRead L68-86, countIndelsMismatchesEndOfRead L109-123,
-// Match.hasN3pConsecutiveMatchesInNeedleman L41-50).  move: 0 diag match, 1 diag mismatch, 2 up, 3 left.
-template <int AD>
-__device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *dirs, int tid, int n_end, FinalAln &out) {
-    int prev[AD + 1], cur[AD + 1];
+template <int N>
+struct MoveRow {
+    using type = uint64_t;
+};
+template <>
+struct MoveRow<10> {
+    using type = uint32_t;
+};
+template <>
+struct MoveRow<16> {
+    using type = uint32_t;
+};
+
+// col[c] bit r = read base r of the slice matches pattern base c; rows: [N][kBlock] in LDS, column `slot`
+// RowT is the kernel's row type for BOTH alignments it runs, so that every lane's slots keep one stride and the waves
+// of a block (which run independently) never touch each other's columns
+template <int N, typename RowT>
+__device__ __forceinline__ void nw_full(const uint32_t (&col)[N], RowT *rows, int slot, int n_end, AlnStats &out) {
+    using row_t = RowT;
+    static_assert(sizeof(RowT) * 8 >= 2 * N, "row type too narrow for the moves of one row");
+    int prev[N + 1], cur[N + 1];
 #pragma unroll
-    for (int c = 0; c <= AD; c++) prev[c] = -5 * c;
-    for (int r = 1; r <= AD; r++) {
+    for (int c = 0; c <= N; c++) prev[c] = -5 * c;
+    for (int r = 1; r <= N; r++) {
         cur[0] = -4 * r;
-        uint64_t row = 0;
+        row_t row = 0;
 #pragma unroll
-        for (int c = 1; c <= AD; c++) {
+        for (int c = 1; c <= N; c++) {
             const int up = prev[c] - 5, left = cur[c - 1] - 5;
             const bool m = (col[c - 1] >> (r - 1)) & 1u;
             const int diag = prev[c - 1] + (m ? 5 : -5);
             int v;
-            uint64_t mv;
+            row_t mv;
             if (up >= left) {
                 if (diag >= up) {
                     v = diag;
@@ -197,12 +191,12 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
             cur[c] = v;
             row |= mv << (2 * (c - 1));
         }
-        dirs[(r - 1) * (kBlock / 2) + (tid >> 1)] = row;  // one lane of each pair reaches this
+        rows[(r - 1) * kBlock + slot] = row;
 #pragma unroll
-        for (int c = 0; c <= AD; c++) prev[c] = cur[c];
+        for (int c = 0; c <= N; c++) prev[c] = cur[c];
     }
-    int r = AD, c = AD;
-    int ins = 0, del = 0, sub = 0, trail = 0, cb = 0, t = 0;
+    int r = N, c = N;
+    int ins = 0, del = 0, sub = 0, trail = 0, cb = 0, t = 0, nx = 0;
     bool trailing = true, term = true;
     float e5 = 0.0f, en = 0.0f;
     // runs of '.', met in reverse: a run is closed (counts) iff an 'x' was met before it on the way back
@@ -223,19 +217,14 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
         }
         run = 0;
     };
-    while (r > 0 || c > 0) {
-        int mv;
-        if (r == 0)
-            mv = 3;  // first row points left
-        else if (c == 0)
-            mv = 2;  // first column points up
-        else
-            mv = (int)((dirs[(r - 1) * (kBlock / 2) + (tid >> 1)] >> (2 * (c - 1))) & 3u);
+    while (r > 0 && c > 0) {
+        const int mv = (int)((rows[(r - 1) * kBlock + slot] >> (2 * (c - 1))) & 3u);
         const bool x = mv != 0;
         const bool read_gap = mv == 3;
         ins += mv == 2;
         del += read_gap;
         sub += mv == 1;
+        nx += x;
         if (trailing && read_gap)
             trail++;
         else
@@ -244,13 +233,11 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
         if (x) {
             close_run();
             seen_x = true;
+            if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+            if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
         } else {
             if (run == 0) run_closed = seen_x;
             run++;
-        }
-        if (x) {
-            if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
-            if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
         }
         if (!read_gap) cb++;
         if (mv <= 1) {
@@ -262,113 +249,123 @@ __device__ __forceinline__ void nw_final(const uint32_t (&col)[AD], uint64_t *di
             c--;
         t++;
     }
+    // the rest of the path runs along the first column (r up-moves = leading template gaps) or the first row
+    // (c left-moves = read gaps); every such column is an 'x'
+    const int lead = r;
+    if (r > 0 || c > 0) {
+        close_run();
+        seen_x = true;
+    }
+    for (; r > 0; r--) {  // up moves
+        ins++;
+        nx++;
+        if (t < 6) term = false;
+        if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+        if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+        trailing = false;
+        cb++;
+        t++;
+    }
+    for (; c > 0; c--) {  // left moves (read gaps)
+        del++;
+        nx++;
+        if (trailing) trail++;
+        if (t < 6) term = false;
+        if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+        if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+        t++;
+    }
     close_run();
-    out.consec = consec;
-    out.best_two = (n_runs >= 1 ? s1 : 0) + (n_runs >= 2 ? s2 : 0);
-    del = (int)(int8_t)(del - trail);
+    del = (int)(int8_t)(del - trail);  // trailing read gaps are not deletions (byte arithmetic, L84)
     out.ins = ins;
     out.del = del;
-    out.sub = sub;
     out.nmis = ins + del + sub;
     out.term6 = term && t >= 6;
     out.end5 = e5;
     out.endn = en;
+    out.consec = consec;
+    out.best_two = (n_runs >= 1 ? s1 : 0) + (n_runs >= 2 ? s2 : 0);
+    // Match.countErrorsInNeedleman: (float)#x - 0.9f * (float)lead, two roundings
+    out.ne = __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));
 }
 
-template <int AD>
-__device__ __forceinline__ void load_cols(const uint32_t *planes, int tid, const ScanParams &P, int pos1,
-                                          uint32_t (&col)[AD]) {
-#pragma unroll
-    for (int c = 0; c < AD; c++) col[c] = match32(planes, tid, P.adapter4[c], pos1 - 1) & ((1u << AD) - 1u);
-}
-
-// TSO "AACGCAGAGTACATGG" (Jar/config.xml:155) as 4-bit codes A=1 G=2 C=4 T=8
+// TSO "AACGCAGAGTACATGG" (Jar/config.xml:155) as 4-bit codes A=1 G=2 C=4 T=8, base i in bits [4i+3:4i]
 __device__ __forceinline__ uint32_t tso4(int i) {
-    // packed nibbles, base i in bits [4i+3:4i]
-    constexpr uint64_t TSO = 0x2281418212142411ull;  // A A C G C A G A G T A C A T G G  (low nibble first)
+    constexpr uint64_t TSO = 0x2281418212142411ull;
     return (uint32_t)(TSO >> (4 * i)) & 15u;
 }
-__device__ __forceinline__ void load_cols_tso(const uint32_t *planes, int tid, int pos1, uint32_t (&col)[16]) {
+
+// 4-mer gate (Kmers.nKmersMatching_4mer > 1) for 64 scan positions starting at bit b of the owner's planes
+template <int N, typename F>
+__device__ __forceinline__ uint64_t gate64(const uint32_t *planes, int owner, int b, F code) {
+    uint64_t any = 0, two = 0;
+    uint64_t m0 = match64(planes, owner, code(0), b), m1 = match64(planes, owner, code(1), b + 1),
+             m2 = match64(planes, owner, code(2), b + 2);
 #pragma unroll
-    for (int c = 0; c < 16; c++) col[c] = match32(planes, tid, tso4(c), pos1 - 1) & 0xFFFFu;
+    for (int i = 0; i + 3 < N; i++) {
+        const uint64_t m3 = match64(planes, owner, code(i + 3), b + i + 3);
+        const uint64_t k = m0 & m1 & m2 & m3;
+        two |= any & k;
+        any |= k;
+        m0 = m1;
+        m1 = m2;
+        m2 = m3;
+    }
+    return two;
 }
 
-struct TsoMatch {
-    int present, passed, nmis, end_scan, consec, best_two;
+__device__ __forceinline__ uint64_t keep_low(uint64_t m, int n_bits) {
+    return n_bits <= 0 ? 0ull : (n_bits >= 64 ? m : (m & ((1ull << n_bits) - 1ull)));
+}
+
+// k-th set bit (k < popcount) of a 64-bit mask
+__device__ __forceinline__ int kth_bit(uint64_t m, int k) {
+    for (; k > 0; k--) m &= m - 1;
+    return __builtin_ctzll(m);
+}
+
+// result of one aligned candidate, as the owner lane needs it (5 words per entry in LDS, odd stride)
+struct Entry {
+    float ne, end5, endn;
+    uint32_t a;  // nmis | ins << 8 | del(+128) << 16 | term6 << 24
+    uint32_t b;  // consec | best_two << 8 | pos << 16
 };
 
-// PolyATadapterAnalyzerBase.scanForTSO (L324-369) on this lane's end: AdapterTSOanalyzer.scanForAdapterOrTSOseq with
-// maxErrors = 5 (L84-110: candidates kept when Math.round(nErrors) <= 5, positions skipped by round(nErrors - 5) - 1
-// after a bad candidate), then the final alignment of the first best position.
-__device__ __forceinline__ int scan_tso_positions(const uint32_t *planes, int tid) {
-    float best = 3.4028234663852886e+38f;
-    int best_pos = 0, skip_until = 0;
-    const int last = 90;  // min(116 - 16, windowForTSOsearch = 90)
+// wave-wide exclusive prefix sum of one int per lane; returns the wave total through `total`
+__device__ __forceinline__ int wave_exscan(int v, int lane, int &total) {
+    int inc = v;
 #pragma unroll
-    for (int ch = 0; ch < 2; ch++) {
-        const int b = ch * 64;
-        uint64_t any = 0, two = 0;
-        uint64_t m0 = match64(planes, tid, tso4(0), b), m1 = match64(planes, tid, tso4(1), b + 1),
-                 m2 = match64(planes, tid, tso4(2), b + 2);
-#pragma unroll
-        for (int i = 0; i + 3 < 16; i++) {
-            const uint64_t m3 = match64(planes, tid, tso4(i + 3), b + i + 3);
-            const uint64_t k = m0 & m1 & m2 & m3;
-            two |= any & k;
-            any |= k;
-            m0 = m1;
-            m1 = m2;
-            m2 = m3;
-        }
-        uint64_t cand = two;
-        const int hi = last - b;
-        cand = hi <= 0 ? 0 : (hi >= 64 ? cand : (cand & ((1ull << hi) - 1ull)));
-        while (cand) {
-            const int i = __builtin_ctzll(cand);
-            cand &= cand - 1;
-            const int pos = b + i + 1;
-            if (pos < skip_until) continue;  // jumped over by deltaPos
-            uint32_t col[16];
-            load_cols_tso(planes, tid, pos, col);
-            const float ne = nw_errors<16>(col);
-            if (!((float)(int)floorf(__fadd_rn(ne, 0.5f)) > 5.0f)) {  // Math.round(nErrors) <= maxErrors
-                if (ne < best) {
-                    best = ne;
-                    best_pos = pos;
-                }
-            }
-            if (5.0f < ne) {
-                int d = (int)floorf(__fadd_rn(__fsub_rn(ne, 5.0f), 0.5f)) - 1;
-                if (d < 1) d = 1;
-                skip_until = pos + d;
-            }
-        }
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(inc, o);
+        if (lane >= o) inc += y;
     }
-    return best_pos;  // 0 = AdapterScanRslt empty
+    total = __shfl(inc, 63);
+    return inc - v;
 }
 
-__device__ __forceinline__ void tso_final(const uint32_t *planes, uint64_t *dirs, int tid, int best_pos, TsoMatch &m) {
-    uint32_t col[16];
-    load_cols_tso(planes, tid, best_pos, col);
-    FinalAln a;
-    nw_final<16>(col, dirs, tid, 0, a);
-    m.present = 1;
-    m.nmis = a.nmis;
-    m.passed = a.nmis <= 5;
-    m.end_scan = best_pos + 15 + a.ins - a.del;
-    m.consec = a.consec;
-    m.best_two = a.best_two;
-}
-
+// ---------------------------------------------------------------------------------------------------------------
+// One wavefront = 64 read ends = 32 reads (a block is four independent wavefronts: no block-level barrier).  Phases:
+//   A (lane = end)        stage planes, polyT finder, 4-mer gates of the adapter (positions up to polyT end) and of
+//                         the TSO (positions 1..90): candidate bit masks
+//   B (lane = candidate)  the wave's candidates are numbered through a prefix sum and aligned 64 at a time, so
+//                         Needleman-Wunsch always runs with full waves whatever the per-read candidate counts are
+//   C (lane = end)        owners fold their candidates' statistics in scan order (best score / first best, the TSO
+//                         skip rule), lanes 2i/2i+1 exchange for the strand decision and the TSO rules, one lane
+//                         writes the record and the barcode window
 // ---------------------------------------------------------------------------------------------------------------
 template <int AD>
 __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
                                                  const uint8_t *__restrict__ qtail, const uint32_t *__restrict__ qsum,
                                                  size_t n_reads, ScanParams P, smi_scan_result *__restrict__ out,
                                                  smi_bc_window *__restrict__ windows) {
-    extern __shared__ uint32_t lds[];
-    uint32_t *planes = lds;                                                   // [5][kLdsWords][kBlock]
-    uint64_t *dirs = reinterpret_cast<uint64_t *>(lds + 5 * kLdsWords * kBlock);  // [AD][kBlock / 2]
+    using row_t = typename MoveRow<AD>::type;  // wide enough for the TSO rows too (32 bits for AD = 10)
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    uint32_t *planes = lds;                                             // [5][kLdsWords][kBlock]
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(planes + 5 * kLdsWords * kBlock);  // [5][kBlock]
+    uint32_t *coff = reinterpret_cast<uint32_t *>(cmask + 5 * kBlock);  // [2][kBlock + 1] adapter / TSO offsets
+    uint32_t *ent = coff + 2 * (kBlock + 1) + 2;                        // [kBlock][5]
+    int *wave_tot = reinterpret_cast<int *>(ent + kBlock * 5);          // [4] (+4 pad: rows stay 8-byte aligned)
+    row_t *rows = reinterpret_cast<row_t *>(wave_tot + 8);              // [max(AD,16)][kBlock]
     const int tid = threadIdx.x;
     const size_t n_ends = 2 * n_reads;
     for (size_t e0 = (size_t)blockIdx.x * kBlock; e0 < n_ends; e0 += (size_t)gridDim.x * kBlock) {
@@ -376,7 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
         const bool active = e < n_ends;
         const size_t read = e >> 1;
         const int side = (int)(e & 1);  // 0 = head (forward scan), 1 = reverse-complemented tail
-        // ---- stage the bit-planes ---------------------------------------------------------------------------
+        // ---- phase A ---------------------------------------------------------------------------------------
         uint32_t ta[kLdsWords];
 #pragma unroll
         for (int w = 0; w < kLdsWords; w++) ta[w] = 0xFFFFFFFFu;
@@ -390,63 +387,154 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
                 ta[w] = c == 3 ? (ta[w] & v) : (ta[w] & ~v);
             }
 #pragma unroll
-        for (int w = 0; w < kLdsWords; w++) planes[(4 * kLdsWords + w) * kBlock + tid] = ta[w];  // exact T = T & ~A & ~G & ~C
-        // (each lane only ever reads its own column: no barrier needed)
+        for (int w = 0; w < kLdsWords; w++) planes[(4 * kLdsWords + w) * kBlock + tid] = ta[w];  // exact T
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         const uint32_t *tex = planes + 4 * kLdsWords * kBlock;
-
-        // ---- polyT + adapter scan on this end ----------------------------------------------------------------
         int pb = 0, pe = 0;
         const bool has_t = active && long_enough && find_polyt(tex, tid, P, pb, pe);
-        float best = 3.4028234663852886e+38f;
-        uint64_t bm[3] = {0, 0, 0};
-        int n_all = 0;
+        uint64_t am[3] = {0, 0, 0}, tm[2] = {0, 0};
         if (has_t) {
-            // scan positions 1 .. min(pe - AD, pe - 12)  (seqTilPolyAend has length pe; L49-61, L87)
+            // scan positions 1 .. min(pe - AD, pe - 12)  (seqTilPolyAend has length pe; L49-61, AdapterTSOanalyzer L87)
             const int last = min(pe - AD, pe - 12);
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                const int b = ch * 64;
-                uint64_t any = 0, two = 0;
-                uint64_t m0 = match64(planes, tid, P.adapter4[0], b), m1 = match64(planes, tid, P.adapter4[1], b + 1),
-                         m2 = match64(planes, tid, P.adapter4[2], b + 2);
+            for (int ch = 0; ch < 3; ch++)
+                am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return P.adapter4[i]; }), last - ch * 64);
+        }
+        if (active && long_enough) {
+            // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325)
 #pragma unroll
-                for (int i = 0; i + 3 < AD; i++) {
-                    const uint64_t m3 = match64(planes, tid, P.adapter4[i + 3], b + i + 3);
-                    const uint64_t k = m0 & m1 & m2 & m3;
-                    two |= any & k;
-                    any |= k;
-                    m0 = m1;
-                    m1 = m2;
-                    m2 = m3;
-                }
-                // bit i <-> pos = b + i + 1 ; keep 1 <= pos <= last
-                uint64_t cand = two;
-                const int hi = last - b;  // number of valid bits in this chunk
-                cand = hi <= 0 ? 0 : (hi >= 64 ? cand : (cand & ((1ull << hi) - 1ull)));
-                while (cand) {
-                    const int i = __builtin_ctzll(cand);
-                    cand &= cand - 1;
-                    uint32_t col[AD];
-                    load_cols<AD>(planes, tid, P, b + i + 1, col);
-                    const float ne = nw_errors<AD>(col);
-                    n_all++;
-                    if (ne < best) {
-                        best = ne;
-                        bm[0] = bm[1] = bm[2] = 0;
+            for (int ch = 0; ch < 2; ch++)
+                tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) cmask[ch * kBlock + tid] = am[ch];
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) cmask[(3 + ch) * kBlock + tid] = tm[ch];
+        const int n_ad = __popcll(am[0]) + __popcll(am[1]) + __popcll(am[2]);
+        const int n_ts = __popcll(tm[0]) + __popcll(tm[1]);
+        const int lane = tid & 63, wbase = tid & ~63;  // this wave's lanes are wbase .. wbase+63
+        int tot_ad, tot_ts;
+        const int off_ad = wave_exscan(n_ad, lane, tot_ad);
+        const int off_ts = wave_exscan(n_ts, lane, tot_ts);
+        coff[tid] = (uint32_t)off_ad;
+        coff[kBlock + 1 + tid] = (uint32_t)off_ts;
+        wave_sync();
+
+        // ---- phases B + C(fold): adapter candidates, then TSO candidates -----------------------------------------
+        // adapter fold state (AdapterScanRslt best key + getMatchList L275-319)
+        float a_best = 3.4028234663852886e+38f, a_key = 0.0f;
+        bool a_have = false;
+        int a_pos = 0, a_nmis = 0, a_ins = 0, a_del = 0;
+        float a_endn = 0.0f;
+        // TSO fold state (scanForAdapterOrTSOseq with maxErrors = 5, L96-104; scanForTSO takes the first best position)
+        float t_best = 3.4028234663852886e+38f;
+        int t_pos = 0, t_nmis = 0, t_ins = 0, t_del = 0, t_consec = 0, t_two = 0, t_skip = 0;
+#pragma unroll 1
+        for (int kind = 0; kind < 2; kind++) {
+            const uint32_t *offs = coff + kind * (kBlock + 1);
+            const int total = kind == 0 ? tot_ad : tot_ts;
+            const int my_off = kind == 0 ? off_ad : off_ts, my_n = kind == 0 ? n_ad : n_ts;
+            for (int base = 0; base < total; base += 64) {
+                const int en = base + lane;
+                if (en < total) {
+                    // owner: last lane of this wave with offs[lane] <= en
+                    int lo = 0, hi = 64;
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((int)offs[wbase + mid] <= en)
+                            lo = mid;
+                        else
+                            hi = mid;
                     }
-                    if (ne == best) bm[ch] |= 1ull << i;
+                    const int owner = wbase + lo;
+                    int k = en - (int)offs[owner];
+                    int pos = 0;
+                    const int nch = kind == 0 ? 3 : 2, ch0 = kind == 0 ? 0 : 3;
+                    for (int ch = 0; ch < nch; ch++) {
+                        const uint64_t m = cmask[(ch0 + ch) * kBlock + owner];
+                        const int c = __popcll(m);
+                        if (k < c) {
+                            pos = ch * 64 + kth_bit(m, k) + 1;
+                            break;
+                        }
+                        k -= c;
+                    }
+                    AlnStats st;
+                    if (kind == 0) {
+                        uint32_t col[AD];
+#pragma unroll
+                        for (int c = 0; c < AD; c++) col[c] = match32(planes, owner, P.adapter4[c], pos - 1) & ((1u << AD) - 1u);
+                        nw_full<AD, row_t>(col, rows, tid, P.min_3p, st);
+                    } else {
+                        uint32_t col[16];
+#pragma unroll
+                        for (int c = 0; c < 16; c++) col[c] = match32(planes, owner, tso4(c), pos - 1) & 0xFFFFu;
+                        nw_full<16, row_t>(col, rows, tid, 0, st);
+                    }
+                    uint32_t *o = ent + tid * 5;
+                    o[0] = __float_as_uint(st.ne);
+                    o[1] = __float_as_uint(st.end5);
+                    o[2] = __float_as_uint(st.endn);
+                    o[3] = (uint32_t)(st.nmis & 0xFF) | ((uint32_t)(st.ins & 0xFF) << 8) | ((uint32_t)((st.del + 128) & 0xFF) << 16) |
+                           ((uint32_t)st.term6 << 24);
+                    o[4] = (uint32_t)(st.consec & 0xFF) | ((uint32_t)(st.best_two & 0xFF) << 8) | ((uint32_t)pos << 16);
                 }
+                wave_sync();
+                // owners fold their entries of this tile, in scan order
+                const int f0 = max(my_off, base), f1 = min(my_off + my_n, base + 64);
+                for (int x = f0; x < f1; x++) {
+                    const uint32_t *o = ent + (wbase + x - base) * 5;
+                    const float ne = __uint_as_float(o[0]);
+                    const int nmis = (int)(o[3] & 0xFF), ins = (int)((o[3] >> 8) & 0xFF), del = (int)((o[3] >> 16) & 0xFF) - 128;
+                    const int pos = (int)(o[4] >> 16);
+                    if (kind == 0) {
+                        if (ne < a_best) {
+                            a_best = ne;
+                            a_have = false;
+                        }
+                        if (ne == a_best) {
+                            // createNeedlemanMatch L242-247: accepted with <= maxMM errors or 6 terminal matches
+                            const bool ok = nmis <= P.max_mm || ((o[3] >> 24) & 1u);
+                            const float key = __uint_as_float(o[1]);
+                            // several best positions: smallest countIndelsMismatchesEndOfRead(5), first of its group
+                            if (ok && (!a_have || key < a_key)) {
+                                a_have = true;
+                                a_key = key;
+                                a_pos = pos;
+                                a_nmis = nmis;
+                                a_ins = ins;
+                                a_del = del;
+                                a_endn = __uint_as_float(o[2]);
+                            }
+                        }
+                    } else if (pos >= t_skip) {  // positions jumped over by deltaPos are never aligned (L100-106)
+                        if (!((float)(int)floorf(__fadd_rn(ne, 0.5f)) > 5.0f) && ne < t_best) {  // Math.round(ne) <= 5
+                            t_best = ne;
+                            t_pos = pos;
+                            t_nmis = nmis;
+                            t_ins = ins;
+                            t_del = del;
+                            t_consec = (int)(o[4] & 0xFF);
+                            t_two = (int)((o[4] >> 8) & 0xFF);
+                        }
+                        if (5.0f < ne) {
+                            int d = (int)floorf(__fadd_rn(__fsub_rn(ne, 5.0f), 0.5f)) - 1;
+                            t_skip = pos + (d < 1 ? 1 : d);
+                        }
+                    }
+                }
+                wave_sync();
             }
         }
-        // ---- strand decision (PolyATadapterAnalyzerBase.analyze L145-163): lanes 2i and 2i+1 exchange -------------
+
+        // ---- phase C: strand decision (PolyATadapterAnalyzerBase.analyze L145-163): lanes 2i and 2i+1 exchange ----
         const int o_has_t = __shfl_xor((int)has_t, 1);
-        const int o_n_all = __shfl_xor(n_all, 1);
-        const float o_best = __shfl_xor(best, 1);
+        const int o_n_all = __shfl_xor(n_ad, 1);
+        const float o_best = __shfl_xor(a_best, 1);
         const bool f_has = side == 0 ? has_t : (bool)o_has_t, r_has = side == 0 ? (bool)o_has_t : has_t;
-        const int f_n = side == 0 ? n_all : o_n_all, r_n = side == 0 ? o_n_all : n_all;
-        const float f_best = side == 0 ? best : o_best, r_best = side == 0 ? o_best : best;
+        const int f_n = side == 0 ? n_ad : o_n_all, r_n = side == 0 ? o_n_all : n_ad;
+        const float f_best = side == 0 ? a_best : o_best, r_best = side == 0 ? o_best : a_best;
         uint32_t flags = 0;
         int use_fwd = -1;
         if (!long_enough) {
@@ -472,7 +560,6 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
         }
         const bool chosen = active && use_fwd >= 0 && side == (use_fwd ? 0 : 1);
 
-        // ---- accepted alignment (getMatchList L275-319, createNeedlemanMatch L237-253) ------------------------------
         smi_scan_result res;
         res.flags = flags;
         res.adapter_end = 0;
@@ -492,46 +579,18 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
         win.nmask = 0;
         win.flags = 0;
         if (chosen) {
-            const int n_best = __popcll(bm[0]) + __popcll(bm[1]) + __popcll(bm[2]);
-            bool have = false;
-            float best_key = 0.0f;
-            FinalAln fa;
-            int f_pos = 0;
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                uint64_t m = bm[ch];
-                while (m) {
-                    const int i = __builtin_ctzll(m);
-                    m &= m - 1;
-                    const int pos = ch * 64 + i + 1;
-                    uint32_t col[AD];
-                    load_cols<AD>(planes, tid, P, pos, col);
-                    FinalAln a;
-                    nw_final<AD>(col, dirs, tid, P.min_3p, a);
-                    // MIN_3P_CONSEC_MATCHES_TO_OVERRIDE_PASS = 6 (AdapterParameters.java:L22)
-                    const bool ok = a.nmis <= P.max_mm || a.term6;
-                    if (!ok) continue;
-                    // one offset: taken as is; several: smallest countIndelsMismatchesEndOfRead(5) group, first of it
-                    if (!have || (n_best > 1 && a.end5 < best_key)) {
-                        have = true;
-                        best_key = a.end5;
-                        fa = a;
-                        f_pos = pos;
-                    }
-                }
-            }
             // polyA coordinates are set as soon as a side is chosen (analyze L169-171)
             res.polya_start = len - (pe - 1);
             res.polya_end = len - (pb - 1);
-            if (!have) {
+            if (!a_have) {
                 res.flags |= SMI_F_FAILED;  // L217
             } else {
-                const int s_end = f_pos + AD - 1 + fa.ins - fa.del;  // L251
+                const int s_end = a_pos + AD - 1 + a_ins - a_del;  // createNeedlemanMatch L251
                 res.found = 1;
                 res.scan_end = (int16_t)s_end;
-                res.adapter_start = len - (f_pos - 1);  // ReadScanResult.java:L446-447
+                res.adapter_start = len - (a_pos - 1);  // ReadScanResult.java:L446-447
                 res.adapter_end = len - (s_end - 1);
-                res.adapter_nmis = (int16_t)fa.nmis;
+                res.adapter_nmis = (int16_t)a_nmis;
                 res.reverse = use_fwd ? 1 : 0;
                 res.flags |= use_fwd ? (SMI_F_ADAPTER_5P | SMI_F_PASSED_REV) : (SMI_F_ADAPTER_3P | SMI_F_PASSED_FWD);
                 // barcode window: stranded[AE-22 .. AE+1] = reverse complement of scan[s_end-1 .. s_end+22]
@@ -558,13 +617,12 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
                 }
                 // pass-1 quality filter (short-circuit && chain; the UNSTRANDED quality string is indexed with
                 // stranded coordinates, UsedCellBCListGenerator.java:L201)
-                if (qtail != nullptr && fa.endn == 0.0f) {
+                if (qtail != nullptr && a_endn == 0.0f) {
                     const int ae = res.adapter_end;
-                    // raw 1-based positions ae-16 .. ae-1 ; qtail is right-aligned: index = kEndBases - 1 - (len - p)
                     int sum = 0;
                     bool in_range = ae - 16 >= 1;
                     for (int p = ae - 16; p <= ae - 1; p++) {
-                        const int idx = kEndBases - 1 - (len - p);
+                        const int idx = kEndBases - 1 - (len - p);  // qtail is right-aligned
                         if (idx < 0 || idx >= kEndBases) {
                             in_range = false;
                             break;
@@ -583,28 +641,33 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
                 }
             }
         }
-        // ---- TSO scan on both ends (PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190) -------------------------------
-        TsoMatch tm = {0, 0, 0, 0, 0, 0};
-        const int tso_pos = (active && long_enough) ? scan_tso_positions(planes, tid) : 0;
-#pragma unroll
-        for (int sd = 0; sd < 2; sd++)  // the two lanes of a pair share one direction slot: one side at a time
-            if (side == sd && tso_pos) tso_final(planes, dirs, tid, tso_pos, tm);
+        // ---- TSO rules on both ends (PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190) ----------------------
         {
-            TsoMatch o;
-            o.present = __shfl_xor(tm.present, 1);
-            o.passed = __shfl_xor(tm.passed, 1);
-            o.nmis = __shfl_xor(tm.nmis, 1);
-            o.end_scan = __shfl_xor(tm.end_scan, 1);
-            o.consec = __shfl_xor(tm.consec, 1);
-            o.best_two = __shfl_xor(tm.best_two, 1);
-            TsoMatch f = side == 0 ? tm : o, r = side == 0 ? o : tm;
-            auto found = [](const TsoMatch &x) { return x.present && x.passed; };
+            struct Tm {
+                int present, passed, nmis, end_scan, consec, two;
+            };
+            Tm mine;
+            mine.present = t_pos != 0;
+            mine.nmis = t_nmis;
+            mine.passed = mine.present && t_nmis <= 5;  // scanForTSO L350
+            mine.end_scan = t_pos + 15 + t_ins - t_del;
+            mine.consec = t_consec;
+            mine.two = t_two;
+            Tm o;
+            o.present = __shfl_xor(mine.present, 1);
+            o.passed = __shfl_xor(mine.passed, 1);
+            o.nmis = __shfl_xor(mine.nmis, 1);
+            o.end_scan = __shfl_xor(mine.end_scan, 1);
+            o.consec = __shfl_xor(mine.consec, 1);
+            o.two = __shfl_xor(mine.two, 1);
+            Tm f = side == 0 ? mine : o, r = side == 0 ? o : mine;
+            auto found = [](const Tm &x) { return x.present && x.passed; };
             if (!found(f) && !found(r)) {  // L146-153: rescue by >= 8 consecutive matches (config.xml:161)
                 if (f.present) f.passed = f.consec >= 8;
                 if (r.present) r.passed = r.consec >= 8;
                 if (!found(f) && !found(r)) {  // L155-162: rescue by the two stretches >= 12 (config.xml:164)
-                    if (f.present) f.passed = f.best_two >= 12;
-                    if (r.present) r.passed = r.best_two >= 12;
+                    if (f.present) f.passed = f.two >= 12;
+                    if (r.present) r.passed = r.two >= 12;
                 }
             }
             if (found(f) && found(r) && abs(f.nmis - r.nmis) > 3) {  // L167-172
@@ -624,7 +687,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
             out[read] = res;
             if (windows) windows[read] = win;
         }
+        wave_sync();  // the next iteration overwrites this wave's columns
     }
+}
+
+template <int AD>
+static size_t scan_lds_bytes() {
+    constexpr int ROWS = AD > 16 ? AD : 16;
+    return (size_t)5 * kLdsWords * kBlock * 4 + (size_t)5 * kBlock * 8 + (size_t)(2 * (kBlock + 1) + 2) * 4 +
+           (size_t)kBlock * 5 * 4 + 8 * 4 + (size_t)ROWS * kBlock * sizeof(typename MoveRow<AD>::type);
 }
 
 static int thr_for(int len, float limit_f, bool use_double, double limit_d) {
@@ -655,11 +726,23 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 16);
     if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;
     if (ad == 10) {
-        const size_t lds = 5 * kLdsWords * kBlock * 4 + 16 * (kBlock / 2) * 8;  // 16 rows: the TSO alignment
-        hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), lds, s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out, d_win);
+        static bool attr10_set = false;
+        if (!attr10_set) {  // > 64 KiB of dynamic LDS needs the opt-in
+            SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<10>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes<10>()));
+            attr10_set = true;
+        }
+        hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), scan_lds_bytes<10>(), s, d_ends, d_len, d_qtail, d_qsum, n,
+                           P, d_out, d_win);
     } else {
-        const size_t lds = 5 * kLdsWords * kBlock * 4 + 22 * (kBlock / 2) * 8;
-        hipLaunchKernelGGL(k_scan<22>, dim3(grid), dim3(kBlock), lds, s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out, d_win);
+        static bool attr_set = false;
+        if (!attr_set) {
+            SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<22>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes<22>()));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_scan<22>, dim3(grid), dim3(kBlock), scan_lds_bytes<22>(), s, d_ends, d_len, d_qtail, d_qsum, n,
+                           P, d_out, d_win);
     }
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_SCAN, s)) return rc;
