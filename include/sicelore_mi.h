@@ -231,6 +231,15 @@ int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t 
                         const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
                         uint64_t total_pairs, uint8_t *d_out, void *stream);
 
+/* Read-name suffix of a scanned (and possibly barcode-assigned) read = FastqRecordExt.getRecordForWriting
+ * (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311): `<name>_{REV|FWD}_[PS=_PE=_][AE=_][T=_]
+ * [bc=_ed=_ed_sec=_bcStart=_bcEnd=_[rk=_]]X=<stranded[AE-40..AE+2]>_Q=<##.#>_<base-36 id>[ cellBC=<bc>]`, or
+ * `<name>_FAILED ` (host-side string formatting; 3' protocol).  raw_seq / raw_qual: the read as it came from the
+ * FASTQ; bc may be NULL; rank <= 0 omits rk=.  Returns the length written (>= 0) or a negative smi_status. */
+int smi_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int32_t len,
+                         const smi_scan_result *scan, const smi_bc_result *bc, int32_t rank, uint32_t read_id,
+                         char *out, size_t cap);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

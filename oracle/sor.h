@@ -103,6 +103,12 @@ int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offs
 int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
                    int *ins, int *del, int *sub, float *end5);
 
+/* ---- read-name writer (sor_name.c) ---- */
+int sor_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int len,
+                         const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, char *out,
+                         size_t cap);
+int sor_fmt_dec1(float f, char *out);
+
 /* ---- UMI pair distances (sor_umi.c) ---- */
 int sor_umi_pair(const uint8_t *w1, const uint8_t *w2);
 void sor_umi_matrix(const uint8_t *windows, int n, uint8_t *out);

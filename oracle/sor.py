@@ -267,3 +267,30 @@ def limited_compare(a, b, threshold=4):
     L = lib()
     L.sor_limited_compare.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
     return int(L.sor_limited_compare(a.ctypes.data, a.size, b.ctypes.data, b.size, threshold))
+
+
+# ---- read-name writer (sor_name.c) ---------------------------------------------------------------------------
+def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0):
+    """scan: SCAN_RESULT_DTYPE record, bc: ASSIGN_DTYPE record or None -> str, or None where the reference throws"""
+    L = lib()
+    L.sor_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+    sc = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
+    sc[0] = scan
+    out = ctypes.create_string_buffer(1200)
+    bp = None
+    if bc is not None:
+        b = np.zeros(1, dtype=ASSIGN_DTYPE)
+        b[0] = bc
+        bp = b.ctypes.data
+    n = L.sor_format_read_name(read_name.encode(), raw_seq.encode(), raw_qual.encode(), len(raw_seq), sc.ctypes.data, bp,
+                               int(rank), int(read_id), out, 1200)
+    return None if n < 0 else out.value.decode()
+
+
+def fmt_dec1(f):
+    L = lib()
+    L.sor_fmt_dec1.argtypes = [ctypes.c_float, ctypes.c_char_p]
+    out = ctypes.create_string_buffer(64)
+    L.sor_fmt_dec1(ctypes.c_float(f), out)
+    return out.value.decode()

@@ -41,7 +41,7 @@ EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
-    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device",
+    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
 ]
 
 
@@ -85,6 +85,8 @@ def load_library():
     lib.smi_set_timing.argtypes = [vp, ci]
     lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     lib.smi_umi_dist_device.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
+    lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
+                                         ctypes.c_int32, ctypes.c_uint32, ctypes.c_char_p, sz]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -124,6 +126,23 @@ def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10
         raise SmiError(f"smi_finalize_used_list error {rc}: {lib.smi_last_error().decode()}")
     m = n_out.value
     return ok[:m], oc[:m], orank[:m]
+
+
+def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0):
+    """smi_format_read_name; scan: SCAN_RESULT_DTYPE record, bc: BC_RESULT_DTYPE record or None -> str"""
+    lib = load_library()
+    sc = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
+    sc[0] = scan
+    b = None
+    if bc is not None:
+        b = np.zeros(1, dtype=BC_RESULT_DTYPE)
+        b[0] = bc
+    out = ctypes.create_string_buffer(1200)
+    n = lib.smi_format_read_name(read_name.encode(), raw_seq.encode(), raw_qual.encode(), len(raw_seq), _ptr(sc),
+                                 _ptr(b), int(rank), int(read_id), out, 1200)
+    if n < 0:
+        raise SmiError(f"smi_format_read_name error {n}: {lib.smi_last_error().decode()}")
+    return out.value.decode()
 
 
 class Context:
