@@ -27,8 +27,11 @@ namespace smi {
 
 constexpr int kEndBases = SMI_END_BASES;     // 208
 constexpr int kPlaneWords = SMI_PLANE_WORDS;  // 7
-constexpr int kLdsWords = 8;                  // per plane in LDS (word 7 = 0 so 64-bit fetches never run off)
+constexpr int kLdsWords = 7;                  // per plane in LDS; fetches past the plane read as 0
 constexpr int kBlock = 256;
+#ifndef SMI_SCAN_WAVES
+#define SMI_SCAN_WAVES 4  // waves per SIMD the register allocation of K-SCAN is held to (LDS: 40 KiB per block)
+#endif
 
 struct ScanParams {
     int min_read_length;
@@ -44,7 +47,7 @@ struct ScanParams {
 };
 
 // ---- LDS plane access -----------------------------------------------------------------------------------------
-// planes: [5][kLdsWords][kBlock] u32 (A, G, C, T, exact-T); the lane's column is `tid`
+// planes: [4][kLdsWords][kBlock] u32 (A, G, C, T bits of the 4-bit code); the lane's column is `tid`
 __device__ __forceinline__ uint64_t get64(const uint32_t *lds_plane, int tid, int bitpos) {
     // 64 bits starting at bitpos (0 <= bitpos < 224); words past the plane read as 0
     const int w = bitpos >> 5, s = bitpos & 31;
@@ -79,15 +82,20 @@ __device__ __forceinline__ uint32_t match32(const uint32_t *planes, int tid, uin
     return m;
 }
 
+// exact T (code 8, not N = 15): T plane without the A plane (the packer only emits A, G, C, T, N and '-')
+__device__ __forceinline__ uint32_t get32_t(const uint32_t *planes, int tid, int bitpos) {
+    return get32(planes + 3 * kLdsWords * kBlock, tid, bitpos) & ~get32(planes, tid, bitpos);
+}
+
 // ---- polyT finder (PolyATSearcher.java:L56-252) ---------------------------------------------------------------
-// tex: exact-T plane.  Entry `pos` of the reference's score list is the T fraction of bases [pos+1, pos+15].
-__device__ __forceinline__ bool find_polyt(const uint32_t *tex, int tid, const ScanParams &P, int &begin1, int &end1) {
+// Entry `pos` of the reference's score list is the T fraction of bases [pos+1, pos+15].
+__device__ __forceinline__ bool find_polyt(const uint32_t *planes, int tid, const ScanParams &P, int &begin1, int &end1) {
     const int ML = P.polya_len;
     const uint32_t wmask = (1u << ML) - 1u;
     const int n = P.window + ML + 10;  // sub-sequence length (175)
     int first = -1;
     for (int pos = 0; pos < P.window; pos++) {
-        const uint32_t x = get32(tex, tid, pos);
+        const uint32_t x = get32_t(planes, tid, pos);
         // every window of the entries pos .. pos+16 lies inside bits 1..31 of x: too few T's there -> none can pass
         if (ML <= 15 && __popc(x >> 1) < P.thr_first) {
             pos += 16;
@@ -105,19 +113,19 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *tex, int tid, const S
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int inc = INC[k];
-        while (start + inc < P.window && __popc((get32(tex, tid, start + inc) >> 1) & wmask) >= P.thr_adv) start += inc;
+        while (start + inc < P.window && __popc((get32_t(planes, tid, start + inc) >> 1) & wmask) >= P.thr_adv) start += inc;
     }
     int endpos = start + ML - 1;  // L231
     // lambda$findpolyAT$3 L122-142: walk back until T at endpos, >=2 T in the last 2, >=3 in 4, >=4 in 5
     while (endpos > 4) {
-        const uint32_t x = get32(tex, tid, endpos - 4);  // bit i = base endpos-4+i
+        const uint32_t x = get32_t(planes, tid, endpos - 4);  // bit i = base endpos-4+i
         const bool ok = ((x >> 4) & 1u) && __popc((x >> 3) & 3u) >= 2 && __popc((x >> 1) & 15u) >= 3 && __popc(x & 31u) >= 4;
         if (ok) break;
         endpos--;
     }
-    while (n > endpos + 6 && __popc(get32(tex, tid, endpos + 1) & 31u) > 3) endpos += 5;  // L145-147
-    while (n > endpos + 4 && __popc(get32(tex, tid, endpos + 1) & 7u) > 1) endpos += 3;   // L156-158
-    while (endpos < n - 1 && (get32(tex, tid, endpos + 1) & 1u)) endpos++;                // L171-172
+    while (n > endpos + 6 && __popc(get32_t(planes, tid, endpos + 1) & 31u) > 3) endpos += 5;  // L145-147
+    while (n > endpos + 4 && __popc(get32_t(planes, tid, endpos + 1) & 7u) > 1) endpos += 3;   // L156-158
+    while (endpos < n - 1 && (get32_t(planes, tid, endpos + 1) & 1u)) endpos++;                // L171-172
     begin1 = first + 1;
     end1 = endpos + 1;
     return true;
@@ -129,7 +137,6 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *tex, int tid, const S
 //   Match.countErrorsInNeedleman L31-34 (#x - 0.9f * leading template gaps), NeedlemanMatch.countNeedlemanErrorsInRead
 //   L68-86, countIndelsMismatchesEndOfRead L109-123, getNconsecutiveMatchesNeedleman L160-173,
 //   getSumOfBestTwoMatchStretchesNeedleman L183-196, Match.hasN3pConsecutiveMatchesInNeedleman L41-50.
-// move: 0 diag match, 1 diag mismatch, 2 up (template gap), 3 left (read gap).
 struct AlnStats {
     float ne;         // countErrorsInNeedleman
     float end5, endn; // countIndelsMismatchesEndOfRead(5) / (minAdapter3pMatches)
@@ -138,64 +145,51 @@ struct AlnStats {
     bool term6;
 };
 
+// col[c] bit r = read base r of the slice matches pattern base c.
+//
+// Fill: one cell = 7 VALU ops.  A cell is kept as U = 4*score + 2 + 20*r (r = row): with the move as a 2-bit tag in
+// the low bits (3 diag match, 2 diag mismatch, 1 up, 0 left) one v_max3_i32 over
+//     diag' = U[r-1][c-1] + 41*m     up' = U[r-1][c] - 1     left' = U[r][c-1] - 22
+// yields 4*best + tag + 20*r -- the tag order IS the reference's tie order (diag >= up >= left) -- and
+// (v & ~3) | 2 is the stored cell again.  The tags of a row are shifted into one register (v_alignbit), the rows
+// stay in registers (row loop fully unrolled), so the walk needs no LDS.
+// Walk: rows N..1 unrolled; inside a row only consecutive left moves loop.
 template <int N>
-struct MoveRow {
-    using type = uint64_t;
-};
-template <>
-struct MoveRow<10> {
-    using type = uint32_t;
-};
-template <>
-struct MoveRow<16> {
-    using type = uint32_t;
-};
-
-// col[c] bit r = read base r of the slice matches pattern base c; rows: [N][kBlock] in LDS, column `slot`
-// RowT is the kernel's row type for BOTH alignments it runs, so that every lane's slots keep one stride and the waves
-// of a block (which run independently) never touch each other's columns
-template <int N, typename RowT>
-__device__ __forceinline__ void nw_full(const uint32_t (&col)[N], RowT *rows, int slot, int n_end, AlnStats &out) {
-    using row_t = RowT;
-    static_assert(sizeof(RowT) * 8 >= 2 * N, "row type too narrow for the moves of one row");
-    int prev[N + 1], cur[N + 1];
+__device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, AlnStats &out) {
+    constexpr int NLO = N < 16 ? N : 16, NHI = N - NLO;
+    static_assert(N <= 32, "two 32-bit move words per row");
+    uint32_t mlo[N], mhi[NHI > 0 ? N : 1];
+    {
+        int U[N + 1];
 #pragma unroll
-    for (int c = 0; c <= N; c++) prev[c] = -5 * c;
-    for (int r = 1; r <= N; r++) {
-        cur[0] = -4 * r;
-        row_t row = 0;
+        for (int c = 0; c <= N; c++) U[c] = -20 * c + 2;
 #pragma unroll
-        for (int c = 1; c <= N; c++) {
-            const int up = prev[c] - 5, left = cur[c - 1] - 5;
-            const bool m = (col[c - 1] >> (r - 1)) & 1u;
-            const int diag = prev[c - 1] + (m ? 5 : -5);
-            int v;
-            row_t mv;
-            if (up >= left) {
-                if (diag >= up) {
-                    v = diag;
-                    mv = m ? 0 : 1;
-                } else {
-                    v = up;
-                    mv = 2;
-                }
-            } else {
-                if (diag >= left) {
-                    v = diag;
-                    mv = m ? 0 : 1;
-                } else {
-                    v = left;
-                    mv = 3;
-                }
+        for (int r = 1; r <= N; r++) {
+            int diag = U[0];
+            U[0] = 4 * r + 2;  // 4 * (-4r) + 2 + 20r
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int c = 1; c <= N; c++) {
+                int m, d;  // d = diag + 41 * match bit (asm: the compiler's own choice is and/cmp/cndmask/add)
+                asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(m) : "v"(col[c - 1]), "n"(r - 1));
+                asm("v_mad_u32_u24 %0, %1, 41, %2" : "=v"(d) : "v"(m), "v"(diag));
+                const int up = U[c] - 1, left = U[c - 1] - 22;
+                diag = U[c];
+                const int v = max(max(d, up), left);
+                U[c] = (v & ~3) | 2;
+                // {v, word} >> 2: the tag enters at the top.  Inline asm: as an intrinsic the chain is re-associated
+                // into 16 masks/shifts/ors per row and every v stays live until then
+                if (c <= 16)
+                    asm("v_alignbit_b32 %0, %1, %2, 2" : "=v"(lo) : "v"(v), "v"(lo));
+                else
+                    asm("v_alignbit_b32 %0, %1, %2, 2" : "=v"(hi) : "v"(v), "v"(hi));
             }
-            cur[c] = v;
-            row |= mv << (2 * (c - 1));
+            mlo[r - 1] = NLO < 16 ? lo >> (32 - 2 * NLO) : lo;
+            if (NHI > 0) mhi[r - 1] = hi >> (32 - 2 * (NHI > 0 ? NHI : 1));
+            __builtin_amdgcn_sched_barrier(0);  // keep rows apart: interleaving them only costs registers
         }
-        rows[(r - 1) * kBlock + slot] = row;
-#pragma unroll
-        for (int c = 0; c <= N; c++) prev[c] = cur[c];
     }
-    int r = N, c = N;
+    int c = N, lead = 0;
     int ins = 0, del = 0, sub = 0, trail = 0, cb = 0, t = 0, nx = 0;
     bool trailing = true, term = true;
     float e5 = 0.0f, en = 0.0f;
@@ -217,41 +211,42 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], RowT *rows, in
         }
         run = 0;
     };
-    while (r > 0 && c > 0) {
-        const int mv = (int)((rows[(r - 1) * kBlock + slot] >> (2 * (c - 1))) & 3u);
-        const bool x = mv != 0;
-        const bool read_gap = mv == 3;
-        ins += mv == 2;
-        del += read_gap;
-        sub += mv == 1;
-        nx += x;
-        if (trailing && read_gap)
-            trail++;
-        else
-            trailing = false;
-        if (t < 6 && x) term = false;
-        if (x) {
-            close_run();
-            seen_x = true;
-            if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
-            if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
-        } else {
-            if (run == 0) run_closed = seen_x;
-            run++;
+#pragma unroll
+    for (int R = N; R >= 1; R--) {
+        if (c > 0) {
+            int tag;
+            do {
+                tag = (int)(((NHI > 0 && c > 16) ? (mhi[R - 1] >> (2 * (c - 17))) : (mlo[R - 1] >> (2 * (c - 1)))) & 3u);
+                const bool x = tag != 3;
+                const bool read_gap = tag == 0;
+                ins += tag == 1;
+                del += read_gap;
+                sub += tag == 2;
+                nx += x;
+                if (trailing && read_gap)
+                    trail++;
+                else
+                    trailing = false;
+                if (t < 6 && x) term = false;
+                if (x) {
+                    close_run();
+                    seen_x = true;
+                    if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+                    if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+                } else {
+                    if (run == 0) run_closed = seen_x;
+                    run++;
+                }
+                if (!read_gap) cb++;
+                if (tag != 1) c--;
+                t++;
+            } while (tag == 0 && c > 0);
+            if (c == 0) lead = tag == 0 ? R : R - 1;  // rows still above the path when it reaches the first column
         }
-        if (!read_gap) cb++;
-        if (mv <= 1) {
-            r--;
-            c--;
-        } else if (mv == 2)
-            r--;
-        else
-            c--;
-        t++;
     }
-    // the rest of the path runs along the first column (r up-moves = leading template gaps) or the first row
+    // the rest of the path runs along the first column (`lead` up-moves = leading template gaps) or the first row
     // (c left-moves = read gaps); every such column is an 'x'
-    const int lead = r;
+    int r = lead;
     if (r > 0 || c > 0) {
         close_run();
         seen_x = true;
@@ -354,18 +349,15 @@ __device__ __forceinline__ int wave_exscan(int v, int lane, int &total) {
 //                         writes the record and the barcode window
 // ---------------------------------------------------------------------------------------------------------------
 template <int AD>
-__global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
+__global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
                                                  const uint8_t *__restrict__ qtail, const uint32_t *__restrict__ qsum,
                                                  size_t n_reads, ScanParams P, smi_scan_result *__restrict__ out,
                                                  smi_bc_window *__restrict__ windows) {
-    using row_t = typename MoveRow<AD>::type;  // wide enough for the TSO rows too (32 bits for AD = 10)
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t *planes = lds;                                             // [5][kLdsWords][kBlock]
-    uint64_t *cmask = reinterpret_cast<uint64_t *>(planes + 5 * kLdsWords * kBlock);  // [5][kBlock]
-    uint32_t *coff = reinterpret_cast<uint32_t *>(cmask + 5 * kBlock);  // [2][kBlock + 1] adapter / TSO offsets
-    uint32_t *ent = coff + 2 * (kBlock + 1) + 2;                        // [kBlock][5]
-    int *wave_tot = reinterpret_cast<int *>(ent + kBlock * 5);          // [4] (+4 pad: rows stay 8-byte aligned)
-    row_t *rows = reinterpret_cast<row_t *>(wave_tot + 8);              // [max(AD,16)][kBlock]
+    uint32_t *planes = lds;                                                           // [4][kLdsWords][kBlock]
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(planes + 4 * kLdsWords * kBlock);  // [3][kBlock] candidate bits
+    uint32_t *coff = reinterpret_cast<uint32_t *>(cmask + 3 * kBlock);                // [kBlock] candidate offsets
+    uint32_t *ent = coff + kBlock;                                                    // [kBlock][5]
     const int tid = threadIdx.x;
     const size_t n_ends = 2 * n_reads;
     for (size_t e0 = (size_t)blockIdx.x * kBlock; e0 < n_ends; e0 += (size_t)gridDim.x * kBlock) {
@@ -374,25 +366,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
         const size_t read = e >> 1;
         const int side = (int)(e & 1);  // 0 = head (forward scan), 1 = reverse-complemented tail
         // ---- phase A ---------------------------------------------------------------------------------------
-        uint32_t ta[kLdsWords];
-#pragma unroll
-        for (int w = 0; w < kLdsWords; w++) ta[w] = 0xFFFFFFFFu;
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int w = 0; w < kLdsWords; w++) {
-                uint32_t v = 0;
-                if (active && w < kPlaneWords) v = ends[(size_t)(c * kPlaneWords + w) * n_ends + e];
-                planes[(c * kLdsWords + w) * kBlock + tid] = v;
-                ta[w] = c == 3 ? (ta[w] & v) : (ta[w] & ~v);
-            }
-#pragma unroll
-        for (int w = 0; w < kLdsWords; w++) planes[(4 * kLdsWords + w) * kBlock + tid] = ta[w];  // exact T
+            for (int w = 0; w < kLdsWords; w++)
+                planes[(c * kLdsWords + w) * kBlock + tid] = active ? ends[(size_t)(c * kPlaneWords + w) * n_ends + e] : 0u;
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
-        const uint32_t *tex = planes + 4 * kLdsWords * kBlock;
         int pb = 0, pe = 0;
-        const bool has_t = active && long_enough && find_polyt(tex, tid, P, pb, pe);
+        const bool has_t = active && long_enough && find_polyt(planes, tid, P, pb, pe);
         uint64_t am[3] = {0, 0, 0}, tm[2] = {0, 0};
         if (has_t) {
             // scan positions 1 .. min(pe - AD, pe - 12)  (seqTilPolyAend has length pe; L49-61, AdapterTSOanalyzer L87)
@@ -407,19 +389,12 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
             for (int ch = 0; ch < 2; ch++)
                 tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
         }
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) cmask[ch * kBlock + tid] = am[ch];
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++) cmask[(3 + ch) * kBlock + tid] = tm[ch];
         const int n_ad = __popcll(am[0]) + __popcll(am[1]) + __popcll(am[2]);
         const int n_ts = __popcll(tm[0]) + __popcll(tm[1]);
         const int lane = tid & 63, wbase = tid & ~63;  // this wave's lanes are wbase .. wbase+63
         int tot_ad, tot_ts;
         const int off_ad = wave_exscan(n_ad, lane, tot_ad);
         const int off_ts = wave_exscan(n_ts, lane, tot_ts);
-        coff[tid] = (uint32_t)off_ad;
-        coff[kBlock + 1 + tid] = (uint32_t)off_ts;
-        wave_sync();
 
         // ---- phases B + C(fold): adapter candidates, then TSO candidates -----------------------------------------
         // adapter fold state (AdapterScanRslt best key + getMatchList L275-319)
@@ -432,7 +407,13 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
         int t_pos = 0, t_nmis = 0, t_ins = 0, t_del = 0, t_consec = 0, t_two = 0, t_skip = 0;
 #pragma unroll 1
         for (int kind = 0; kind < 2; kind++) {
-            const uint32_t *offs = coff + kind * (kBlock + 1);
+            // this kind's candidate masks and offsets go to LDS (the previous kind's are dead: wave_sync below)
+            cmask[0 * kBlock + tid] = kind == 0 ? am[0] : tm[0];
+            cmask[1 * kBlock + tid] = kind == 0 ? am[1] : tm[1];
+            cmask[2 * kBlock + tid] = kind == 0 ? am[2] : 0ull;
+            coff[tid] = (uint32_t)(kind == 0 ? off_ad : off_ts);
+            wave_sync();
+            const uint32_t *offs = coff;
             const int total = kind == 0 ? tot_ad : tot_ts;
             const int my_off = kind == 0 ? off_ad : off_ts, my_n = kind == 0 ? n_ad : n_ts;
             for (int base = 0; base < total; base += 64) {
@@ -450,9 +431,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
                     const int owner = wbase + lo;
                     int k = en - (int)offs[owner];
                     int pos = 0;
-                    const int nch = kind == 0 ? 3 : 2, ch0 = kind == 0 ? 0 : 3;
-                    for (int ch = 0; ch < nch; ch++) {
-                        const uint64_t m = cmask[(ch0 + ch) * kBlock + owner];
+                    for (int ch = 0; ch < 3; ch++) {
+                        const uint64_t m = cmask[ch * kBlock + owner];
                         const int c = __popcll(m);
                         if (k < c) {
                             pos = ch * 64 + kth_bit(m, k) + 1;
@@ -465,12 +445,12 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
                         uint32_t col[AD];
 #pragma unroll
                         for (int c = 0; c < AD; c++) col[c] = match32(planes, owner, P.adapter4[c], pos - 1) & ((1u << AD) - 1u);
-                        nw_full<AD, row_t>(col, rows, tid, P.min_3p, st);
+                        nw_full<AD>(col, P.min_3p, st);
                     } else {
                         uint32_t col[16];
 #pragma unroll
                         for (int c = 0; c < 16; c++) col[c] = match32(planes, owner, tso4(c), pos - 1) & 0xFFFFu;
-                        nw_full<16, row_t>(col, rows, tid, 0, st);
+                        nw_full<16>(col, 0, st);
                     }
                     uint32_t *o = ent + tid * 5;
                     o[0] = __float_as_uint(st.ne);
@@ -691,11 +671,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(const uint32_t *__restrict__ en
     }
 }
 
-template <int AD>
 static size_t scan_lds_bytes() {
-    constexpr int ROWS = AD > 16 ? AD : 16;
-    return (size_t)5 * kLdsWords * kBlock * 4 + (size_t)5 * kBlock * 8 + (size_t)(2 * (kBlock + 1) + 2) * 4 +
-           (size_t)kBlock * 5 * 4 + 8 * 4 + (size_t)ROWS * kBlock * sizeof(typename MoveRow<AD>::type);
+    return (size_t)4 * kLdsWords * kBlock * 4 + (size_t)3 * kBlock * 8 + (size_t)kBlock * 4 + (size_t)kBlock * 5 * 4;
 }
 
 static int thr_for(int len, float limit_f, bool use_double, double limit_d) {
@@ -729,19 +706,19 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
         static bool attr10_set = false;
         if (!attr10_set) {  // > 64 KiB of dynamic LDS needs the opt-in
             SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<10>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes<10>()));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes()));
             attr10_set = true;
         }
-        hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), scan_lds_bytes<10>(), s, d_ends, d_len, d_qtail, d_qsum, n,
+        hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n,
                            P, d_out, d_win);
     } else {
         static bool attr_set = false;
         if (!attr_set) {
             SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<22>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes<22>()));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes()));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_scan<22>, dim3(grid), dim3(kBlock), scan_lds_bytes<22>(), s, d_ends, d_len, d_qtail, d_qsum, n,
+        hipLaunchKernelGGL(k_scan<22>, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n,
                            P, d_out, d_win);
     }
     SMI_HIP(hipGetLastError());
