@@ -123,4 +123,34 @@ int sor_finalize_used_list(const int64_t *keys, const uint32_t *counts, size_t n
 #ifdef __cplusplus
 }
 #endif
+
+/* ---- chimera splitter (sor_chimera.c) ---------------------------------------------------------------------- */
+#define SOR_F_CHIMERIC_READS_SPLIT (1ull << 1)
+#define SOR_F_MULTI_CHIMERIC_READS_DISCARDED (1ull << 2)
+#define SOR_F_READS_AFTER_SPLIT (1ull << 4)
+/* ChimeraFindernew$SplitPosition$SplitReason ordinals (ChimeraFindernew.java:L364-370) */
+enum { SOR_SPLIT_REV_ADAPTER = 0, SOR_SPLIT_FWD_ADAPTER, SOR_SPLIT_RA_FA, SOR_SPLIT_RA_FT, SOR_SPLIT_RT_FA, SOR_SPLIT_RT_FT,
+       SOR_SPLIT_READSTART };
+typedef struct {
+    const char *tso_complete;     /* AAGCAGTGGTATCAACGCAGAGTACAT (config.xml:170) */
+    const char *adapter_complete; /* CTACACGACGCTCTTCCGATCT (config.xml:113) */
+    int32_t tso_max_errors;       /* 6 */
+    int32_t adapter_max_errors;   /* 5 */
+    int32_t internal_pat_len;     /* 15 */
+    float internal_pat_frac;      /* 0.70 */
+    int32_t window_polya;         /* 150 */
+    int32_t bc_umi_len;           /* 16 + 12 */
+} sor_chimera_params;
+typedef struct {
+    int32_t n_split;        /* 0..2 cut positions (0-based offsets into the read, String.substring semantics) */
+    int32_t pos[2];
+    int32_t reason[2];
+    int32_t multi_chimeric; /* > 2 split positions: MULTI_CHIMERIC_READS_DISCARDED | FAILED, read kept whole */
+    int32_t n_matches;      /* adapter / TSO matches that entered the split rules (diagnostic) */
+} sor_chimera_result;
+/* 0 ok, -1 where the reference would throw (substring range) */
+int sor_chimera_split(const char *read, int len, const sor_chimera_params *par, sor_chimera_result *out);
+/* name of fragment k (0-based, 0..n_split) of a split read; returns the length or -1 */
+int sor_chimera_fragment_name(const char *read_name, const sor_chimera_result *res, int fragment, char *out, size_t cap);
+
 #endif

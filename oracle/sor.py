@@ -294,3 +294,41 @@ def fmt_dec1(f):
     out = ctypes.create_string_buffer(64)
     L.sor_fmt_dec1(ctypes.c_float(f), out)
     return out.value.decode()
+
+
+# ---- chimera splitter (sor_chimera.c) ---------------------------------------------------------------------------
+class _ChimeraParams(ctypes.Structure):
+    _fields_ = [("tso_complete", ctypes.c_char_p), ("adapter_complete", ctypes.c_char_p), ("tso_max_errors", ctypes.c_int32),
+                ("adapter_max_errors", ctypes.c_int32), ("internal_pat_len", ctypes.c_int32),
+                ("internal_pat_frac", ctypes.c_float), ("window_polya", ctypes.c_int32), ("bc_umi_len", ctypes.c_int32)]
+
+
+class _ChimeraResult(ctypes.Structure):
+    _fields_ = [("n_split", ctypes.c_int32), ("pos", ctypes.c_int32 * 2), ("reason", ctypes.c_int32 * 2),
+                ("multi_chimeric", ctypes.c_int32), ("n_matches", ctypes.c_int32)]
+
+
+SPLIT_REASONS = ["REV_ADAPTER", "FWD_ADAPTER", "REV_ADAPTER_FWD_ADAPTER", "REV_ADAPTER_FWD_TSO", "REV_TSO_FWD_ADAPTER",
+                 "REV_TSO_FWD_TSO", "READSTART"]
+
+
+def chimera_params(tso="AAGCAGTGGTATCAACGCAGAGTACAT", adapter="CTACACGACGCTCTTCCGATCT", tso_max=6, adapter_max=5):
+    return _ChimeraParams(tso.encode(), adapter.encode(), tso_max, adapter_max, 15, 0.70, 150, 28)
+
+
+def chimera_split(read, params=None):
+    """-> (rc, [(reason name, pos)], multi_chimeric, n_matches, raw result)"""
+    L = lib()
+    p = chimera_params() if params is None else params
+    r = _ChimeraResult()
+    L.sor_chimera_split.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    rc = L.sor_chimera_split(read.encode(), len(read), ctypes.byref(p), ctypes.byref(r))
+    return rc, [(SPLIT_REASONS[r.reason[i]], r.pos[i]) for i in range(r.n_split)], bool(r.multi_chimeric), r.n_matches, r
+
+
+def chimera_fragment_name(name, raw_result, fragment):
+    L = lib()
+    L.sor_chimera_fragment_name.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t]
+    out = ctypes.create_string_buffer(len(name) + 64)
+    n = L.sor_chimera_fragment_name(name.encode(), ctypes.byref(raw_result), fragment, out, len(name) + 64)
+    return out.value.decode() if n >= 0 else None

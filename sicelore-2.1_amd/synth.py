@@ -267,3 +267,18 @@ def pack_ends(head, tail):
     planes = torch.cat(rows, dim=0)  # [4*nw, 2n]
     planes = torch.where(planes >= (1 << 31), planes - (1 << 32), planes)
     return planes.to(torch.int32).contiguous()
+
+
+def make_chimeras(reads, n, seed=9, parts=(1, 2, 2, 2, 3, 4)):
+    """n ASCII (read, qual, n_parts) made by concatenating 1..4 materialised reads of `reads` (ligation chimeras: the
+    junction carries the 3' adapter of one molecule next to the TSO / adapter of the next); host-side, tests only"""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    n_src = reads["head"].shape[0]
+    out = []
+    for _ in range(n):
+        k = int(parts[rng.integers(0, len(parts))])
+        seqs, quals = zip(*(materialize(reads, int(rng.integers(0, n_src))) for _ in range(k)))
+        out.append(("".join(seqs), "".join(quals), k))
+    return out
