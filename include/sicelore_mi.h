@@ -240,11 +240,68 @@ int smi_format_read_name(const char *read_name, const char *raw_seq, const char 
                          const smi_scan_result *scan, const smi_bc_result *bc, int32_t rank, uint32_t read_id,
                          char *out, size_t cap);
 
+/* ================================================================================================================
+ * Chimera splitter of pass 2 (3' barcoding): replaces ChimeraFindernew.findSplitPositions
+ * (FJ!nanoporereadscanner/analyzers/ChimeraFindernew.java:L107-332, called per record from Parser.call,
+ * Parser.java:L180) with PolyATadapterInternalSearcherBase.aTadapterScanBase
+ * (FJ!nanopore/analyzers/PolyATadapterInternalSearcherBase.java:L78-270).
+ * ================================================================================================================ */
+typedef struct {                  /* shipped values: Jar/config.xml */
+    const char *tso_complete;     /* :170 AAGCAGTGGTATCAACGCAGAGTACAT (27 bases in this build) */
+    const char *adapter_complete; /* :113 CTACACGACGCTCTTCCGATCT (22 bases in this build) */
+    int32_t tso_max_errors;       /* :172 6 */
+    int32_t adapter_max_errors;   /* :118 5 */
+    int32_t internal_pat_len;     /* :99  15 */
+    float internal_pat_frac;      /* :101 0.70 */
+    int32_t window_polya;         /* :105 150 */
+    int32_t bc_umi_len;           /* :189 + :264 = 16 + 12 */
+} smi_chimera_config;
+
+/* ChimeraFindernew$SplitPosition$SplitReason ordinals (ChimeraFindernew.java:L364-370); tags RA FA RA_FA RA_FT RT_FA RT_FT */
+enum { SMI_SPLIT_REV_ADAPTER = 0, SMI_SPLIT_FWD_ADAPTER = 1, SMI_SPLIT_RA_FA = 2, SMI_SPLIT_RA_FT = 3, SMI_SPLIT_RT_FA = 4,
+       SMI_SPLIT_RT_FT = 5 };
+#define SMI_CHIM_MULTI 1u    /* > 2 split positions: MULTI_CHIMERIC_READS_DISCARDED | FAILED, the read stays whole (L284-286) */
+#define SMI_CHIM_RANGE 2u    /* split positions out of order / outside the read: the reference throws from substring */
+#define SMI_CHIM_OVERFLOW 4u /* more than 64 internal matches in one read: result not computed, treat as an error */
+
+typedef struct {
+    int32_t pos[2];    /* cut offsets into the read (String.substring semantics): fragments [0,pos0) [pos0,pos1) [pos1,len) */
+    uint8_t n_split;   /* 0, 1 or 2 */
+    uint8_t reason[2]; /* SMI_SPLIT_* of each cut */
+    uint8_t flags;     /* SMI_CHIM_* */
+    int32_t n_matches; /* adapter / TSO matches that entered the split rules */
+} smi_chimera_result;
+
+int smi_chimera_default_config(smi_chimera_config *cfg);
+
+/* u32 words the plane buffer of smi_pack_reads_device needs for n reads holding total_bases bases in all */
+size_t smi_read_planes_words(uint64_t total_bases, size_t n);
+
+/* ASCII reads (read i = [offsets[i], offsets[i+1]), offsets[n] = total_bases) -> four IUPAC bit-planes per read:
+ * the NucleicAcidOneBytePerBase construction of ChimeraFindernew.java:L177 */
+int smi_pack_reads_device(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
+                          uint32_t *d_planes, void *stream);
+
+/* split positions of every read (reads shorter than 240 bases are never split, L169) */
+int smi_chimera_device(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
+                       const smi_chimera_config *cfg, smi_chimera_result *d_out, void *stream);
+
+/* The records after the split (L288-326) are consecutive slices of the same byte buffer, so splitting is a new offset
+ * array: d_frag_offsets [n_frag + 1] (capacity 3n + 1), d_frag_src [n_frag] (capacity 3n, may be NULL) =
+ * (source read << 2 | fragment index), *d_n_frag = number of records.  d_scratch: (n + 1023) / 1024 + 1 u32 words. */
+int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,
+                             uint32_t *d_scratch, uint64_t *d_n_frag, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
+                             void *stream);
+
+/* name of fragment k (0 .. n_split) of a split read: readName.replaceFirst(" ", "_" + tag + "sp" + (k+1) + " ")
+ * (L309,L323); returns the length written or a negative smi_status */
+int smi_chimera_fragment_name(const char *read_name, const smi_chimera_result *res, int fragment, char *out, size_t cap);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);
 /* same, per kernel: the last launch of that kernel since timing was enabled */
-enum { SMI_K_BC_MATCH = 0, SMI_K_SCAN = 1, SMI_K_HIST = 2, SMI_K_PACK = 3, SMI_K_UMI = 4, SMI_K_COUNT = 5 };
+enum { SMI_K_BC_MATCH = 0, SMI_K_SCAN = 1, SMI_K_HIST = 2, SMI_K_PACK = 3, SMI_K_UMI = 4, SMI_K_CHIMERA = 5, SMI_K_COUNT = 6 };
 int smi_kernel_ms(smi_ctx *ctx, int kernel_id, float *ms);
 int smi_set_timing(smi_ctx *ctx, int enabled);
 

@@ -10,6 +10,7 @@ from . import codec  # noqa: F401
 from .lib import (  # noqa: F401
     BC_RESULT_DTYPE,
     BC_WINDOW_DTYPE,
+    CHIMERA_RESULT_DTYPE,
     SCAN_CONFIG_DTYPE,
     SCAN_RESULT_DTYPE,
     Context,

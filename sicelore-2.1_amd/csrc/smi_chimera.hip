@@ -1,0 +1,744 @@
+// smi_chimera.hip -- K-PACKR + K-CHIM: the reference's chimera splitter (pass 2, 3' barcoding) on gfx950.
+//
+// Reference units (bytecode; citation form in DESIGN.md):
+//   ChimeraFindernew.findSplitPositions                FJ!nanoporereadscanner/analyzers/ChimeraFindernew.java:L107-332
+//   PolyATadapterInternalSearcherBase.aTscan / searchATend / adapterScan
+//                                                      FJ!nanopore/analyzers/PolyATadapterInternalSearcherBase.java:L78-270
+//   AdapterTSOanalyzer.scanForAdapterOrTSOseqKMERsForInternal  FJ!nanopore/analyzers/AdapterTSOanalyzer.java:L130-156
+//   $AdapterScanRslt.getPosbelowMaxMismatches / getPosForBestScore  (same file, L278-308)
+//
+// MI355X mapping.  K-PACKR turns every read into four IUPAC bit-planes (A, G, C, T bits of the 4-bit code), one
+// wavefront per read.  K-CHIM runs one wavefront per read on those planes:
+//   * internal TSO scan (both orientations): the 4-mer gate for 64 positions per lane (bit-parallel), then one
+//     27 x 27 Needleman-Wunsch per candidate with lane = candidate (error count only, smi_nw.h); the reference's
+//     position-skip rule is a scalar fold over the candidates in order
+//   * internal polyA / polyT windows: bit-sliced 14-base counters give the trigger positions for 64 positions per
+//     lane; the few triggers are walked in order (the walk is data-dependent), each followed by the 51-base
+//     adapter scan (gate in one register, 22 x 22 alignments with lane = position)
+//   * the split rules run on the handful of matches in LDS.
+// Integer / bitwise work: no MFMA.  Planes are read from global memory (they are touched a few times, L2-resident),
+// so the read length is not limited by LDS.
+#include <algorithm>
+#include <cstring>
+
+#include "smi_internal.h"
+#include "smi_nw.h"
+
+namespace smi {
+
+constexpr int kTsoLen = 27;  // tso_for3pBarcoding.sequence_complete (Jar/config.xml:170)
+constexpr int kAdLen = 22;   // adapter_for3pBarcoding.sequence_complete (Jar/config.xml:113)
+constexpr int kCap = 64;     // accepted TSO positions per orientation / matches per read kept in LDS
+constexpr int kPadWords = 5; // plane spacing: ceil(len / 32) data words + 4 zero words (gates and windows run past the end)
+
+struct ChimParams {
+    uint32_t tso4[2][kTsoLen];  // [0] complete TSO, [1] its reverse complement (4-bit codes)
+    uint32_t ad4[kAdLen];
+    int tso_max, ad_max;
+    int pat_len;   // internalpATlength (15)
+    int pat_thr;   // least count c with c / (float)pat_len >= internalFractionATInPolyAT
+    int off;       // windowSearchForPolyA + 70
+    int bc_umi;    // cell barcode + UMI length
+};
+
+// planes of one read: word w of plane c at p[c][w]
+struct ReadPlanes {
+    const uint32_t *p[4];
+};
+
+__host__ __device__ inline size_t plane_start(uint64_t base_offset, size_t r) { return (size_t)(base_offset >> 5) + kPadWords * r; }
+
+__device__ __forceinline__ uint64_t gget64(const uint32_t *pl, int bitpos) {
+    const int w = bitpos >> 5, s = bitpos & 31;
+    const uint64_t lo = ((uint64_t)pl[w + 1] << 32) | pl[w];
+    uint64_t r = lo >> s;
+    if (s) r |= (uint64_t)pl[w + 2] << (64 - s);
+    return r;
+}
+__device__ __forceinline__ uint32_t gget32(const uint32_t *pl, int bitpos) {
+    const int w = bitpos >> 5, s = bitpos & 31;
+    return (uint32_t)((((uint64_t)pl[w + 1] << 32) | pl[w]) >> s);
+}
+__device__ __forceinline__ uint64_t gmatch64(const ReadPlanes &rp, uint32_t a4, int bitpos) {
+    uint64_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if ((a4 >> c) & 1u) m |= gget64(rp.p[c], bitpos);
+    return m;
+}
+__device__ __forceinline__ uint32_t gmatch32(const ReadPlanes &rp, uint32_t a4, int bitpos) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if ((a4 >> c) & 1u) m |= gget32(rp.p[c], bitpos);
+    return m;
+}
+// exact A (code 1) / exact T (code 8): the packer emits A, G, C, T, N (all four bits) and nothing else
+__device__ __forceinline__ uint64_t gexact64(const ReadPlanes &rp, int is_t, int bitpos) {
+    return is_t ? (gget64(rp.p[3], bitpos) & ~gget64(rp.p[0], bitpos)) : (gget64(rp.p[0], bitpos) & ~gget64(rp.p[1], bitpos));
+}
+__device__ __forceinline__ uint32_t gexact_bit(const ReadPlanes &rp, int is_t, int idx) {
+    const int w = idx >> 5, s = idx & 31;
+    const uint32_t x = is_t ? (rp.p[3][w] & ~rp.p[0][w]) : (rp.p[0][w] & ~rp.p[1][w]);
+    return (x >> s) & 1u;
+}
+__device__ __forceinline__ uint32_t comp4(uint32_t b) {
+    return ((b & 1u) << 3) | ((b & 8u) >> 3) | ((b & 2u) << 1) | ((b & 4u) >> 1);
+}
+__device__ __forceinline__ uint64_t keep_low64(uint64_t m, int n_bits) {
+    return n_bits <= 0 ? 0ull : (n_bits >= 64 ? m : (m & ((1ull << n_bits) - 1ull)));
+}
+__device__ __forceinline__ int kth_bit64(uint64_t m, int k) {
+    for (; k > 0; k--) m &= m - 1;
+    return __builtin_ctzll(m);
+}
+__device__ __forceinline__ int wave_exscan_i(int v, int lane, int &total) {
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(inc, o);
+        if (lane >= o) inc += y;
+    }
+    total = __shfl(inc, 63);
+    return inc - v;
+}
+__device__ __forceinline__ int jround(float a) { return (int)floorf(__fadd_rn(a, 0.5f)); }  // Math.round(float)
+
+// ---------------------------------------------------------------------------------------------------------------
+// K-PACKR: ASCII reads -> bit-planes.  planes: [4][stride] u32; read r starts at word plane_start(offsets[r], r).
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t enc4c(uint8_t c) {
+    switch (c) {
+    case 'A': case 'a': return 1;
+    case 'G': case 'g': return 2;
+    case 'C': case 'c': return 4;
+    case 'T': case 't': return 8;
+    default: return 15;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
+                                                    size_t n, size_t stride, uint32_t *__restrict__ planes) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < n; r += n_waves) {
+        const uint64_t beg = offsets[r];
+        const int64_t len = (int64_t)(offsets[r + 1] - beg);
+        const size_t w0 = plane_start(beg, r);
+        const int64_t n_words = (len + 31) / 32 + kPadWords - 1;  // the pad words are written as zeros
+        for (int64_t base = 0; base < n_words * 32; base += 64) {
+            const int64_t p = base + lane;
+            const uint32_t code = p < len ? enc4c(reads[beg + p]) : 0u;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned long long b = __ballot((code >> c) & 1u);
+                if (lane == 0) {
+                    const int64_t w = base >> 5;
+                    planes[c * stride + w0 + w] = (uint32_t)b;
+                    if (w + 1 < n_words) planes[c * stride + w0 + w + 1] = (uint32_t)(b >> 32);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// K-CHIM
+// ---------------------------------------------------------------------------------------------------------------
+// 4-mer gate (Kmers.nKmersMatching >= need, need = 2) for 64 scan positions starting at bit b
+template <int N>
+__device__ __forceinline__ uint64_t ggate64_two(const ReadPlanes &rp, const uint32_t *code, int b) {
+    uint64_t any = 0, two = 0;
+    uint64_t m0 = gmatch64(rp, code[0], b), m1 = gmatch64(rp, code[1], b + 1), m2 = gmatch64(rp, code[2], b + 2);
+#pragma unroll
+    for (int i = 0; i + 3 < N; i++) {
+        const uint64_t m3 = gmatch64(rp, code[i + 3], b + i + 3);
+        const uint64_t k = m0 & m1 & m2 & m3;
+        two |= any & k;
+        any |= k;
+        m0 = m1;
+        m1 = m2;
+        m2 = m3;
+    }
+    return two;
+}
+
+struct MatchRec {  // ChimeraFindernew$AdapterTSOmatch
+    int begin;
+    int is_reverse;
+    int is_adapter;
+};
+
+// per-wave LDS
+struct WaveLds {
+    unsigned long long cmask[64];  // candidate bits of the current segment / orientation, one word per lane
+    int coff[64];                  // exclusive prefix of the candidate counts
+    int acc_pos[kCap];             // accepted TSO positions of the current orientation ...
+    float acc_ne[kCap];            // ... and their error counts
+    int srt_pos[kCap];
+    float srt_ne[kCap];
+    int m_begin[kCap];             // matches entering the split rules
+    int m_kind[kCap];              // bit 0 is_reverse, bit 1 is_adapter
+    int order[kCap];
+};
+
+// searchATend (PolyATadapterInternalSearcherBase.java:L233-270); every lane runs the same walk
+__device__ __forceinline__ int search_at_end(const ReadPlanes &rp, int len, int pos, int is_t, int cur, const ChimParams &P) {
+    const int ml = P.pat_len;
+    for (int pb = pos + 1; pb < len - P.off - ml - 1 && cur >= P.pat_thr; pb++) {
+        cur -= (int)gexact_bit(rp, is_t, pb);
+        cur += (int)gexact_bit(rp, is_t, pb + ml);
+        if (cur >= P.pat_thr) pos = pb;
+        if (!gexact_bit(rp, is_t, pb + ml - 1) && !gexact_bit(rp, is_t, pb + ml - 2)) break;
+    }
+    int end = pos + ml - 1;
+    for (;;) {
+        int score = 0;
+        for (int i = 0; i < 4; i++) score += (int)gexact_bit(rp, is_t, end - i);
+        if (score >= 2) break;
+        end -= 4;
+    }
+    while (!gexact_bit(rp, is_t, end)) end--;
+    return end;
+}
+
+// adapterScan (L159-221): read coordinate of the first accepted adapter match next to an internal polyA/T, 0 = none
+__device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, int at_end, int is_t, int lane,
+                                            const ChimParams &P) {
+    int start_range, end_range;
+    if (is_t) {
+        start_range = at_begin - P.bc_umi - 30 - 10;
+        end_range = start_range + 30 + 20;
+    } else {
+        end_range = at_end + P.bc_umi + 30 + 10;
+        start_range = end_range - 30 - 20;
+    }
+    constexpr int NPOS = 51 - kAdLen;  // scan positions 1 .. 29 (bits 0 .. 28)
+    // match bits of adapter base i against the sub-sequence (reverse-complemented when the stretch is polyA)
+    auto col_bits = [&](int i, int shift) -> uint32_t {
+        // bit k = sub[shift + k] matches adapter base i
+        if (is_t) return gmatch32(rp, P.ad4[i], start_range - 1 + shift);
+        // sub_rc[x] = comp(seq[end_range - 1 - x]): 32 read bases ending at end_range - 1 - shift, bit-reversed
+        return __brev(gmatch32(rp, comp4(P.ad4[i]), end_range - 32 - shift));
+    };
+    uint32_t any = 0, two = 0, three = 0;
+    {
+        uint32_t m0 = col_bits(0, 0), m1 = col_bits(1, 1), m2 = col_bits(2, 2);
+#pragma unroll
+        for (int i = 0; i + 3 < kAdLen; i++) {
+            const uint32_t m3 = col_bits(i + 3, i + 3);
+            const uint32_t k = m0 & m1 & m2 & m3;
+            three |= two & k;
+            two |= any & k;
+            any |= k;
+            m0 = m1;
+            m1 = m2;
+            m2 = m3;
+        }
+    }
+    const uint32_t gate = three & ((1u << NPOS) - 1u);  // minKmersMatching = 3 (L173)
+    if (gate == 0) return 0;
+    // lane l < 29 aligns scan position l + 1
+    float ne = 0.0f;
+    int nmis = 0;
+    if (lane < NPOS && ((gate >> lane) & 1u)) {
+        uint32_t col[kAdLen];
+#pragma unroll
+        for (int c = 0; c < kAdLen; c++) col[c] = col_bits(c, lane) & ((1u << kAdLen) - 1u);
+        AlnStats st;
+        nw_full<kAdLen>(col, 0, st);
+        ne = st.ne;
+        nmis = st.nmis;
+    }
+    const float maxe = (float)P.ad_max;
+    const int ok_l = !((float)jround(ne) > maxe) ? 1 : 0;
+    int delta_l = 1;
+    if (maxe < ne) {
+        delta_l = jround(__fsub_rn(ne, maxe)) - 1;
+        if (delta_l < 1) delta_l = 1;
+    }
+    // scanForAdapterOrTSOseqKMERsForInternal's position skip: scalar fold in scan order
+    uint32_t accepted = 0;
+    int skip = 0;
+    for (uint32_t g = gate; g; g &= g - 1) {
+        const int i = __builtin_ctz(g);
+        if (i + 1 < skip) continue;
+        if (__builtin_amdgcn_readlane(ok_l, i)) accepted |= 1u << i;
+        skip = i + 1 + __builtin_amdgcn_readlane(delta_l, i);
+    }
+    if (!accepted) return 0;
+    // getPosForBestScore(MAX_VALUE): positions sharing the least key, neighbours < 2 apart dropped (L180-183)
+    const bool mine = lane < NPOS && ((accepted >> lane) & 1u);
+    float best = mine ? ne : 3.4028234663852886e+38f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = fminf(best, __shfl_xor(best, o));
+    const uint32_t eq = (uint32_t)__ballot(mine && ne == best);
+    const uint32_t keep = eq & ~(eq << 1);
+    const uint32_t good = keep & (uint32_t)__ballot(nmis <= P.ad_max);  // L203
+    if (!good) return 0;
+    const int o1 = __builtin_ctz(good) + 1;
+    return is_t ? start_range + o1 - 1 : start_range + 51 - o1;  // L207 / L211
+}
+
+__global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
+                                                    const uint64_t *__restrict__ offsets, size_t n, ChimParams P,
+                                                    smi_chimera_result *__restrict__ out) {
+    __shared__ WaveLds lds_all[4];
+    WaveLds &L = lds_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < n; r += n_waves) {
+        const uint64_t beg = offsets[r];
+        const int len = (int)(offsets[r + 1] - beg);
+        smi_chimera_result res;
+        res.n_split = 0;
+        res.pos[0] = res.pos[1] = 0;
+        res.reason[0] = res.reason[1] = 0;
+        res.flags = 0;
+        res.n_matches = 0;
+        if (len < 2 * 70 + 100) {  // L169
+            if (lane == 0) out[r] = res;
+            continue;
+        }
+        ReadPlanes rp;
+        const size_t w0 = plane_start(beg, r);
+#pragma unroll
+        for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
+        int n_m = 0;        // matches in L.m_*
+        bool overflow = false;
+
+        // ---- internal TSO, both orientations (lambda$1 L107-125, lambda$5 L156-166) --------------------------
+        const int last = len - 70;  // min(len - 27, len - 70)
+#pragma unroll 1
+        for (int o = 0; o < 2; o++) {
+            int n_acc = 0;
+            int skip = 0;  // next position the reference's scan looks at
+            for (int p0 = 70; p0 <= last; p0 += 4096) {
+                // gate: lane = 64 positions p0 + 64*lane ...
+                const int pl = p0 + 64 * lane;
+                unsigned long long cm = 0;
+                if (pl <= last) cm = keep_low64(ggate64_two<kTsoLen>(rp, P.tso4[o], pl - 1), last - pl + 1);
+                L.cmask[lane] = cm;
+                int total;
+                const int my_off = wave_exscan_i(__popcll(cm), lane, total);
+                L.coff[lane] = my_off;
+                wave_sync();
+                for (int base = 0; base < total; base += 64) {
+                    const int en = base + lane;
+                    int pos = 0x7FFFFFFF;
+                    float ne = 0.0f;
+                    if (en < total) {
+                        int lo = 0, hi = 64;
+                        while (hi - lo > 1) {
+                            const int mid = (lo + hi) >> 1;
+                            if (L.coff[mid] <= en)
+                                lo = mid;
+                            else
+                                hi = mid;
+                        }
+                        pos = p0 + 64 * lo + kth_bit64(L.cmask[lo], en - L.coff[lo]);
+                        uint32_t col[kTsoLen];
+#pragma unroll
+                        for (int c = 0; c < kTsoLen; c++) col[c] = gmatch32(rp, P.tso4[o][c], pos - 1) & ((1u << kTsoLen) - 1u);
+                        ne = nw_errors<kTsoLen>(col);
+                    }
+                    const float maxe = (float)P.tso_max;
+                    int delta_l = 1;
+                    if (maxe < ne) {  // L146-150
+                        delta_l = jround(__fsub_rn(ne, maxe)) - 1;
+                        if (delta_l < 1) delta_l = 1;
+                    }
+                    const int ok_l = !(ne > maxe) ? 1 : 0;  // getPosbelowMaxMismatches: key <= max (L302)
+                    const int cnt = min(64, total - base);
+                    unsigned long long taken = 0;
+                    for (int i = 0; i < cnt; i++) {  // scalar fold, scan order
+                        const int p = __builtin_amdgcn_readlane(pos, i);
+                        if (p < skip) continue;
+                        if (__builtin_amdgcn_readlane(ok_l, i)) taken |= 1ull << i;
+                        skip = p + __builtin_amdgcn_readlane(delta_l, i);
+                    }
+                    if ((taken >> lane) & 1ull) {
+                        const int slot = n_acc + __popcll(taken & ((1ull << lane) - 1ull));
+                        if (slot < kCap) {
+                            L.acc_pos[slot] = pos;
+                            L.acc_ne[slot] = ne;
+                        }
+                    }
+                    n_acc += __popcll(taken);
+                }
+                wave_sync();
+            }
+            if (n_acc > kCap) {
+                overflow = true;
+                n_acc = kCap;
+            }
+            wave_sync();
+            // sort by (score, position): rank by counting (n_acc <= 64)
+            if (lane < n_acc) {
+                const float me = L.acc_ne[lane];
+                const int mp = L.acc_pos[lane];
+                int rank = 0;
+                for (int j = 0; j < n_acc; j++) {
+                    const float e = L.acc_ne[j];
+                    const int p = L.acc_pos[j];
+                    rank += (e < me || (e == me && p < mp)) ? 1 : 0;
+                }
+                L.srt_pos[rank] = mp;
+                L.srt_ne[rank] = me;
+            }
+            wave_sync();
+            // L115-123: entry i dropped when < 3 away from entry i-1 of the sorted list
+            int mypos = 0;
+            bool keep = false;
+            if (lane < n_acc) {
+                mypos = L.srt_pos[lane];
+                keep = lane == 0 || abs(mypos - L.srt_pos[lane - 1]) >= 3;
+            }
+            const unsigned long long kb = __ballot(keep);
+            const int idx = __popcll(kb & ((1ull << lane) - 1ull));
+            const int n_keep = __popcll(kb);
+            wave_sync();
+            const int begin = o ? mypos + kTsoLen - 1 : mypos;  // L161
+            if (keep) L.acc_pos[idx] = begin;
+            wave_sync();
+            // L163: begin > prev.getAndSet(begin) + 120, prev = previous list element
+            bool pass = false;
+            if (lane < n_keep) pass = lane == 0 || L.acc_pos[lane] > L.acc_pos[lane - 1] + 120;
+            const unsigned long long pb = __ballot(pass);
+            if (pass) {
+                const int slot = n_m + __popcll(pb & ((1ull << lane) - 1ull));
+                if (slot < kCap) {
+                    L.m_begin[slot] = L.acc_pos[lane];
+                    L.m_kind[slot] = o;
+                }
+            }
+            n_m += __popcll(pb);
+            wave_sync();
+        }
+
+        // ---- internal polyA / polyT + adapter (aTscan L92-136, adapterScan) --------------------------------------
+        // window count at pos = exact bases in [pos+1, pos+14] + the base at index off+13, which the reference's
+        // window update counts twice (L99-121)
+        const int first = P.off - 1, stop = len - P.off;  // pos in [first, stop)
+        if (first < stop) {
+            int end_cur[2] = {0, 0};                               // [0] A, [1] T
+            int fired[2] = {-1, -1};                               // last position that produced an ATposition
+            long long prev_start[2] = {-2147483648LL, -2147483648LL};  // prevA_Position / prevT_Position
+            const int extra[2] = {(int)gexact_bit(rp, 0, P.off + P.pat_len - 2), (int)gexact_bit(rp, 1, P.off + P.pat_len - 2)};
+            for (int p0 = first; p0 < stop; p0 += 4096) {
+                const int pl = p0 + 64 * lane;
+                unsigned long long trig[2] = {0, 0};
+                if (pl < stop && P.pat_thr <= 15) {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                        for (int k = 1; k < P.pat_len; k++) {  // bit-sliced sum of the 14 shifted planes
+                            const unsigned long long x = gexact64(rp, t, pl + k);
+                            const unsigned long long t0 = c0 & x;
+                            c0 ^= x;
+                            const unsigned long long t1 = c1 & t0;
+                            c1 ^= t0;
+                            const unsigned long long t2 = c2 & t1;
+                            c2 ^= t1;
+                            c3 ^= t2;
+                        }
+                        if (extra[t]) {
+                            const unsigned long long t0 = c0;
+                            c0 = ~c0;
+                            const unsigned long long t1 = c1 & t0;
+                            c1 ^= t0;
+                            const unsigned long long t2 = c2 & t1;
+                            c2 ^= t1;
+                            c3 ^= t2;
+                        }
+                        const unsigned long long cb[4] = {c0, c1, c2, c3};
+                        unsigned long long gt = 0, eq = ~0ull;
+                        for (int b = 3; b >= 0; b--) {  // count >= pat_thr
+                            if ((P.pat_thr >> b) & 1)
+                                eq &= cb[b];
+                            else
+                                gt |= eq & cb[b];
+                        }
+                        const unsigned long long e0 = gexact64(rp, t, pl), e1 = gexact64(rp, t, pl + 1);
+                        trig[t] = keep_low64((gt | eq) & e0 & e1, stop - pl);
+                    }
+                }
+                // walk the triggers in position order (T before A never collide: a base is one or the other)
+                for (;;) {
+                    int nxt[2];
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        // first trigger position > end_cur[t] in this segment
+                        unsigned long long m = trig[t];
+                        const int rel = max(end_cur[t], fired[t]) + 1 - pl;  // bits below rel are not eligible
+                        if (rel >= 64)
+                            m = 0;
+                        else if (rel > 0)
+                            m &= ~0ull << rel;
+                        const unsigned long long lanes = __ballot(m != 0);
+                        if (lanes) {
+                            const int l0 = __builtin_ctzll(lanes);
+                            const unsigned long long mm = ((unsigned long long)__builtin_amdgcn_readlane((int)(m >> 32), l0) << 32) |
+                                                          (uint32_t)__builtin_amdgcn_readlane((int)m, l0);
+                            nxt[t] = p0 + 64 * l0 + __builtin_ctzll(mm);
+                        } else
+                            nxt[t] = 0x7FFFFFFF;
+                    }
+                    if (nxt[0] == 0x7FFFFFFF && nxt[1] == 0x7FFFFFFF) break;
+                    const int t = nxt[1] < nxt[0] ? 1 : 0;
+                    const int pos = nxt[t];
+                    // currentInWindow at pos
+                    int cur = extra[t];
+                    {
+                        const unsigned long long x = gexact64(rp, t, pos + 1);
+                        cur += __popcll(x & ((1ull << (P.pat_len - 1)) - 1ull));
+                    }
+                    const int at_begin = pos + 1;
+                    const int at_end = search_at_end(rp, len, pos, t, cur, P) + 1;
+                    end_cur[t] = at_end;
+                    fired[t] = pos;
+                    const int start = adapter_scan(rp, at_begin, at_end, t, lane, P);
+                    if (start != 0) {  // lambda$7 L204-207
+                        const long long lim = prev_start[t] + 120;
+                        prev_start[t] = start;
+                        if ((long long)start > lim) {
+                            if (n_m < kCap && lane == 0) {
+                                L.m_begin[n_m] = start;
+                                L.m_kind[n_m] = 2 | (t == 0 ? 1 : 0);  // polyA stretch = reverse adapter
+                            }
+                            n_m++;
+                        }
+                    }
+                }
+            }
+        }
+        if (n_m > kCap) {
+            overflow = true;
+            n_m = kCap;
+        }
+        wave_sync();
+
+        // ---- split rules (L229-286) ----------------------------------------------------------------------------
+        // stable sort by begin: rank by counting
+        if (lane < n_m) {
+            const int mb = L.m_begin[lane];
+            int rank = 0;
+            for (int j = 0; j < n_m; j++) {
+                const int b = L.m_begin[j];
+                rank += (b < mb || (b == mb && j < lane)) ? 1 : 0;
+            }
+            L.order[rank] = lane;
+        }
+        wave_sync();
+        // The < 100 filter (L273-281) compares NEIGHBOURS of the unfiltered list, so it is applied while the list
+        // is produced: element i is dropped iff pos[i] - pos[i-1] < 100.
+        int n_kept = 0, kept_pos[3], kept_reason[3], prev_sp = 0;
+        bool have_prev_sp = false;
+        auto emit = [&](int reason, int pos) {
+            const bool drop = have_prev_sp && (pos - prev_sp < 100);
+            prev_sp = pos;
+            have_prev_sp = true;
+            if (!drop) {
+                if (n_kept < 3) {
+                    kept_pos[n_kept] = pos;
+                    kept_reason[n_kept] = reason;
+                }
+                n_kept++;
+            }
+        };
+        auto isolated = [&](int m) {
+            const int k = L.m_kind[m], b = L.m_begin[m];
+            emit((k & 1) ? SMI_SPLIT_REV_ADAPTER : SMI_SPLIT_FWD_ADAPTER, (k & 1) ? b + 25 : b - 25);  // lambda$10
+        };
+        if (n_m == 1) {
+            if (L.m_kind[0] & 2) isolated(0);
+        } else if (n_m > 1) {
+            int it = 0;
+            int prev = L.order[it++];
+            while (it < n_m && prev >= 0) {
+                const int cur = L.order[it++];
+                const int pk = L.m_kind[prev], ck = L.m_kind[cur];
+                const int pbeg = L.m_begin[prev], cbeg = L.m_begin[cur];
+                if (cbeg - pbeg > 160) {
+                    if (pk & 2) isolated(prev);
+                    prev = cur;
+                } else if ((pk & 1) && !(ck & 1)) {
+                    const int reason = (pk & 2) ? ((ck & 2) ? SMI_SPLIT_RA_FA : SMI_SPLIT_RA_FT)
+                                                : ((ck & 2) ? SMI_SPLIT_RT_FA : SMI_SPLIT_RT_FT);  // lambda$11
+                    emit(reason, pbeg + (cbeg - pbeg) / 2);
+                    prev = it < n_m ? L.order[it++] : -1;
+                } else
+                    prev = cur;
+                if (it >= n_m && prev >= 0 && (L.m_kind[prev] & 2)) isolated(prev);  // L263-264
+            }
+        }
+        res.n_matches = n_m;
+        if (n_kept > 2) {
+            res.flags |= SMI_CHIM_MULTI;  // MULTI_CHIMERIC_READS_DISCARDED | FAILED, read kept whole (L284-286)
+        } else {
+            res.n_split = n_kept;
+            int lastp = 0;
+            for (int i = 0; i < n_kept; i++) {
+                res.pos[i] = kept_pos[i];
+                res.reason[i] = (uint8_t)kept_reason[i];
+                if (kept_pos[i] < lastp || kept_pos[i] > len) res.flags |= SMI_CHIM_RANGE;  // substring would throw
+                lastp = kept_pos[i];
+            }
+        }
+        if (overflow) res.flags |= SMI_CHIM_OVERFLOW;
+        if (lane == 0) out[r] = res;
+        wave_sync();
+    }
+}
+
+// ---- fragment offsets: read i with k split positions becomes k + 1 consecutive records of the same byte buffer ----
+__global__ void k_frag_counts(const smi_chimera_result *__restrict__ chim, size_t n, uint32_t *__restrict__ block_sums) {
+    __shared__ uint32_t sh[256];
+    const size_t i = blockIdx.x * (size_t)1024 + threadIdx.x * 4;
+    uint32_t s = 0;
+    for (int k = 0; k < 4; k++)
+        if (i + k < n) s += 1u + (uint32_t)chim[i + k].n_split;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = sh[0];
+}
+
+__global__ void k_scan_block_sums(uint32_t *__restrict__ block_sums, size_t n_blocks, uint64_t *__restrict__ total) {
+    // one block: exclusive scan in place (n_blocks is ~ n / 1024)
+    __shared__ uint64_t carry;
+    __shared__ uint32_t sh[1024];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (size_t base = 0; base < n_blocks; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const uint32_t v = i < n_blocks ? block_sums[i] : 0u;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t y = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+            __syncthreads();
+            sh[threadIdx.x] += y;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = (uint32_t)(carry + sh[threadIdx.x] - v);
+        __syncthreads();
+        if (threadIdx.x == 0) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void k_frag_offsets(const smi_chimera_result *__restrict__ chim, const uint64_t *__restrict__ offsets, size_t n,
+                               const uint32_t *__restrict__ block_sums, uint64_t *__restrict__ frag_offsets,
+                               uint32_t *__restrict__ frag_src) {
+    __shared__ uint32_t sh[256];
+    const size_t i = blockIdx.x * (size_t)1024 + threadIdx.x * 4;
+    uint32_t cnt[4], s = 0;
+    for (int k = 0; k < 4; k++) {
+        cnt[k] = i + k < n ? 1u + (uint32_t)chim[i + k].n_split : 0u;
+        s += cnt[k];
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const uint32_t y = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += y;
+        __syncthreads();
+    }
+    uint64_t f = (uint64_t)block_sums[blockIdx.x] + sh[threadIdx.x] - s;
+    for (int k = 0; k < 4; k++) {
+        if (i + k >= n) break;
+        const smi_chimera_result c = chim[i + k];
+        const uint64_t beg = offsets[i + k];
+        for (uint32_t j = 0; j < cnt[k]; j++) {
+            frag_offsets[f] = j == 0 ? beg : beg + (uint64_t)c.pos[j - 1];
+            if (frag_src) frag_src[f] = (uint32_t)(((i + k) << 2) | j);
+            f++;
+        }
+        if (i + k == n - 1) frag_offsets[f] = offsets[n];
+    }
+}
+
+static int thr_count(int len, float frac) {
+    for (int k = 0; k <= len + 1; k++)
+        if (!((float)k / (float)len < frac)) return k;
+    return len + 2;
+}
+
+static uint32_t code_of(char c) {
+    switch (c) {
+    case 'A': case 'a': return 1;
+    case 'G': case 'g': return 2;
+    case 'C': case 'c': return 4;
+    case 'T': case 't': return 8;
+    default: return 15;
+    }
+}
+
+size_t read_planes_stride(uint64_t total_bases, size_t n) { return (size_t)(total_bases >> 5) + kPadWords * (n + 1) + 8; }
+
+int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
+                      uint32_t *d_planes, hipStream_t s) {
+    if (!n) return SMI_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, n, read_planes_stride(total_bases, n),
+                       d_planes);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
+                   const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s) {
+    if (!n) return SMI_OK;
+    if (std::strlen(cfg->tso_complete) != (size_t)kTsoLen || std::strlen(cfg->adapter_complete) != (size_t)kAdLen) {
+        set_error("smi_chimera_device: this build handles a 27-base complete TSO and a 22-base complete adapter "
+                  "(the shipped config.xml values)");
+        return SMI_ERR_INVALID;
+    }
+    if (cfg->internal_pat_len < 2 || cfg->internal_pat_len > 15) {
+        set_error("smi_chimera_device: internal_pat_len must be 2..15 (4-bit window counters)");
+        return SMI_ERR_INVALID;
+    }
+    ChimParams P;
+    for (int i = 0; i < kTsoLen; i++) {
+        P.tso4[0][i] = code_of(cfg->tso_complete[i]);
+        const uint32_t b = code_of(cfg->tso_complete[kTsoLen - 1 - i]);
+        P.tso4[1][i] = ((b & 1u) << 3) | ((b & 8u) >> 3) | ((b & 2u) << 1) | ((b & 4u) >> 1);
+    }
+    for (int i = 0; i < kAdLen; i++) P.ad4[i] = code_of(cfg->adapter_complete[i]);
+    P.tso_max = cfg->tso_max_errors;
+    P.ad_max = cfg->adapter_max_errors;
+    P.pat_len = cfg->internal_pat_len;
+    P.pat_thr = thr_count(cfg->internal_pat_len, cfg->internal_pat_frac);
+    P.off = cfg->window_polya + 70;
+    P.bc_umi = cfg->bc_umi_len;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 16);
+    if (int rc = time_begin(ctx, SMI_K_CHIMERA, s)) return rc;
+    hipLaunchKernelGGL(k_chimera, dim3(grid), dim3(256), 0, s, d_planes, read_planes_stride(total_bases, n), d_offsets, n, P,
+                       d_out);
+    SMI_HIP(hipGetLastError());
+    if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;
+    return SMI_OK;
+}
+
+int launch_split_offsets(smi_ctx *, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,
+                         uint32_t *d_scratch, uint64_t *d_total, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
+                         hipStream_t s) {
+    if (!n) return SMI_OK;
+    const size_t n_blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_frag_counts, dim3((unsigned)n_blocks), dim3(256), 0, s, d_chim, n, d_scratch);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, d_scratch, n_blocks, d_total);
+    hipLaunchKernelGGL(k_frag_offsets, dim3((unsigned)n_blocks), dim3(256), 0, s, d_chim, d_offsets, n, d_scratch,
+                       d_frag_offsets, d_frag_src);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+}  // namespace smi

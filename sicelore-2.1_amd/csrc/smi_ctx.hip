@@ -306,6 +306,55 @@ int smi_scan_default_config(int pass, smi_scan_config *cfg) {
     return SMI_OK;
 }
 
+int smi_chimera_default_config(smi_chimera_config *cfg) {
+    if (!cfg) {
+        set_error("smi_chimera_default_config: null argument");
+        return SMI_ERR_INVALID;
+    }
+    cfg->tso_complete = "AAGCAGTGGTATCAACGCAGAGTACAT";
+    cfg->adapter_complete = "CTACACGACGCTCTTCCGATCT";
+    cfg->tso_max_errors = 6;
+    cfg->adapter_max_errors = 5;
+    cfg->internal_pat_len = 15;
+    cfg->internal_pat_frac = 0.70f;
+    cfg->window_polya = 150;
+    cfg->bc_umi_len = 28;
+    return SMI_OK;
+}
+
+size_t smi_read_planes_words(uint64_t total_bases, size_t n) { return 4 * read_planes_stride(total_bases, n); }
+
+int smi_pack_reads_device(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
+                          uint32_t *d_planes, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_reads || !d_offsets || !d_planes)) {
+        set_error("smi_pack_reads_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_pack_reads(ctx, d_reads, d_offsets, n, total_bases, d_planes, (hipStream_t)stream);
+}
+
+int smi_chimera_device(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
+                       const smi_chimera_config *cfg, smi_chimera_result *d_out, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (!cfg || !cfg->tso_complete || !cfg->adapter_complete || (n && (!d_planes || !d_offsets || !d_out))) {
+        set_error("smi_chimera_device: null argument");
+        return SMI_ERR_INVALID;
+    }
+    return launch_chimera(ctx, d_planes, d_offsets, n, total_bases, cfg, d_out, (hipStream_t)stream);
+}
+
+int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,
+                             uint32_t *d_scratch, uint64_t *d_n_frag, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
+                             void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_chim || !d_offsets || !d_scratch || !d_n_frag || !d_frag_offsets)) {
+        set_error("smi_split_offsets_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_split_offsets(ctx, d_chim, d_offsets, n, d_scratch, d_n_frag, d_frag_offsets, d_frag_src, (hipStream_t)stream);
+}
+
 int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets,
                          size_t n, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail, uint32_t *d_qsum,
                          void *stream) {

@@ -325,3 +325,30 @@ extern "C" int smi_format_read_name(const char *read_name, const char *raw_seq, 
     std::memcpy(out, name.c_str(), name.size() + 1);
     return (int)name.size();
 }
+
+
+// fragment names of a split read (ChimeraFindernew.java:L309,L323)
+extern "C" int smi_chimera_fragment_name(const char *read_name, const smi_chimera_result *res, int fragment, char *out,
+                                         size_t cap) {
+    static const char *const TAGS[] = {"RA", "FA", "RA_FA", "RA_FT", "RT_FA", "RT_FT"};
+    if (!read_name || !res || !out || res->n_split == 0 || res->n_split > 2 || fragment < 0 || fragment > res->n_split) {
+        set_error("smi_chimera_fragment_name: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    // fragments before a cut carry that cut's tag, the last fragment the tag of the cut it starts at
+    const int cut = fragment < res->n_split ? fragment : res->n_split - 1;
+    if (res->reason[cut] > 5) {
+        set_error("smi_chimera_fragment_name: bad split reason");
+        return SMI_ERR_INVALID;
+    }
+    std::string name(read_name);
+    const size_t sp = name.find(' ');
+    if (sp != std::string::npos)  // String.replaceFirst(" ", ...): a name without a blank stays as it is
+        name.replace(sp, 1, std::string("_") + TAGS[res->reason[cut]] + "sp" + std::to_string(fragment + 1) + " ");
+    if (name.size() + 1 > cap) {
+        set_error("smi_chimera_fragment_name: output buffer too small");
+        return SMI_ERR_INVALID;
+    }
+    std::memcpy(out, name.c_str(), name.size() + 1);
+    return (int)name.size();
+}

@@ -1,0 +1,199 @@
+// smi_nw.h -- Needleman-Wunsch on gfx950 registers, shared by K-SCAN (smi_scan.hip) and K-CHIM (smi_chimera.hip).
+//
+// Reference units (bytecode; citation form in DESIGN.md):
+//   NeedlemanWunsch.fillInCell / init            TB!nuc/alignment/needleman/NeedlemanWunsch.java:L55-80,L106-122
+//   SequenceAlignment.getTraceback               TB!nuc/alignment/needleman/SequenceAlignment.java:L102-151
+//   Match.countErrorsInNeedleman, NeedlemanMatch FJ!nanopore/analyzers/{Match,NeedlemanMatch}.java
+#pragma once
+#include "smi_internal.h"
+
+namespace smi {
+
+// ---- Needleman-Wunsch with 2-bit moves in LDS and a walk from the end ---------------------------------------
+// Scores (-4,-5,.,.,-5,-5,+5): NeedlemanParameters.java:L36-38.  Tie-breaks: NeedlemanWunsch.java:L55-80.
+// The walk yields everything the reference reads off the alignment strings (SequenceAlignment.getTraceback L102-151):
+//   Match.countErrorsInNeedleman L31-34 (#x - 0.9f * leading template gaps), NeedlemanMatch.countNeedlemanErrorsInRead
+//   L68-86, countIndelsMismatchesEndOfRead L109-123, getNconsecutiveMatchesNeedleman L160-173,
+//   getSumOfBestTwoMatchStretchesNeedleman L183-196, Match.hasN3pConsecutiveMatchesInNeedleman L41-50.
+struct AlnStats {
+    float ne;         // countErrorsInNeedleman
+    float end5, endn; // countIndelsMismatchesEndOfRead(5) / (minAdapter3pMatches)
+    int nmis, ins, del;
+    int consec, best_two;
+    bool term6;
+};
+
+// col[c] bit r = read base r of the slice matches pattern base c.
+//
+// Fill: one cell = 7 VALU ops.  A cell is kept as U = 4*score + 2 + 20*r (r = row): with the move as a 2-bit tag in
+// the low bits (3 diag match, 2 diag mismatch, 1 up, 0 left) one v_max3_i32 over
+//     diag' = U[r-1][c-1] + 41*m     up' = U[r-1][c] - 1     left' = U[r][c-1] - 22
+// yields 4*best + tag + 20*r -- the tag order IS the reference's tie order (diag >= up >= left) -- and
+// (v & ~3) | 2 is the stored cell again.  The tags of a row are shifted into one register (v_alignbit), the rows
+// stay in registers (row loop fully unrolled), so the walk needs no LDS.
+// Walk: rows N..1 unrolled; inside a row only consecutive left moves loop.
+template <int N>
+__device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, AlnStats &out) {
+    constexpr int NLO = N < 16 ? N : 16, NHI = N - NLO;
+    static_assert(N <= 32, "two 32-bit move words per row");
+    uint32_t mlo[N], mhi[NHI > 0 ? N : 1];
+    {
+        int U[N + 1];
+#pragma unroll
+        for (int c = 0; c <= N; c++) U[c] = -20 * c + 2;
+#pragma unroll
+        for (int r = 1; r <= N; r++) {
+            int diag = U[0];
+            U[0] = 4 * r + 2;  // 4 * (-4r) + 2 + 20r
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int c = 1; c <= N; c++) {
+                int m, d;  // d = diag + 41 * match bit (asm: the compiler's own choice is and/cmp/cndmask/add)
+                asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(m) : "v"(col[c - 1]), "n"(r - 1));
+                asm("v_mad_u32_u24 %0, %1, 41, %2" : "=v"(d) : "v"(m), "v"(diag));
+                const int up = U[c] - 1, left = U[c - 1] - 22;
+                diag = U[c];
+                const int v = max(max(d, up), left);
+                U[c] = (v & ~3) | 2;
+                // {v, word} >> 2: the tag enters at the top.  Inline asm: as an intrinsic the chain is re-associated
+                // into 16 masks/shifts/ors per row and every v stays live until then
+                if (c <= 16)
+                    asm("v_alignbit_b32 %0, %1, %2, 2" : "=v"(lo) : "v"(v), "v"(lo));
+                else
+                    asm("v_alignbit_b32 %0, %1, %2, 2" : "=v"(hi) : "v"(v), "v"(hi));
+            }
+            mlo[r - 1] = NLO < 16 ? lo >> (32 - 2 * NLO) : lo;
+            if (NHI > 0) mhi[r - 1] = hi >> (32 - 2 * (NHI > 0 ? NHI : 1));
+            __builtin_amdgcn_sched_barrier(0);  // keep rows apart: interleaving them only costs registers
+        }
+    }
+    int c = N, lead = 0;
+    int ins = 0, del = 0, sub = 0, trail = 0, cb = 0, t = 0, nx = 0;
+    bool trailing = true, term = true;
+    float e5 = 0.0f, en = 0.0f;
+    // runs of '.', met in reverse: a run is closed (counts) iff an 'x' was met before it on the way back
+    int run = 0, consec = 0, s1 = 0, s2 = 0, n_runs = 0;
+    bool seen_x = false, run_closed = false;
+    auto close_run = [&]() {
+        if (run > 0 && run_closed) {
+            consec = max(consec, run);
+            if (run > 4) {
+                if (n_runs == 0 || run < s1) {
+                    s2 = s1;
+                    s1 = run;
+                } else if (n_runs == 1 || run < s2) {
+                    s2 = run;
+                }
+                n_runs++;
+            }
+        }
+        run = 0;
+    };
+#pragma unroll
+    for (int R = N; R >= 1; R--) {
+        if (c > 0) {
+            int tag;
+            do {
+                tag = (int)(((NHI > 0 && c > 16) ? (mhi[R - 1] >> (2 * (c - 17))) : (mlo[R - 1] >> (2 * (c - 1)))) & 3u);
+                const bool x = tag != 3;
+                const bool read_gap = tag == 0;
+                ins += tag == 1;
+                del += read_gap;
+                sub += tag == 2;
+                nx += x;
+                if (trailing && read_gap)
+                    trail++;
+                else
+                    trailing = false;
+                if (t < 6 && x) term = false;
+                if (x) {
+                    close_run();
+                    seen_x = true;
+                    if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+                    if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+                } else {
+                    if (run == 0) run_closed = seen_x;
+                    run++;
+                }
+                if (!read_gap) cb++;
+                if (tag != 1) c--;
+                t++;
+            } while (tag == 0 && c > 0);
+            if (c == 0) lead = tag == 0 ? R : R - 1;  // rows still above the path when it reaches the first column
+        }
+    }
+    // the rest of the path runs along the first column (`lead` up-moves = leading template gaps) or the first row
+    // (c left-moves = read gaps); every such column is an 'x'
+    int r = lead;
+    if (r > 0 || c > 0) {
+        close_run();
+        seen_x = true;
+    }
+    for (; r > 0; r--) {  // up moves
+        ins++;
+        nx++;
+        if (t < 6) term = false;
+        if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+        if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+        trailing = false;
+        cb++;
+        t++;
+    }
+    for (; c > 0; c--) {  // left moves (read gaps)
+        del++;
+        nx++;
+        if (trailing) trail++;
+        if (t < 6) term = false;
+        if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+        if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+        t++;
+    }
+    close_run();
+    del = (int)(int8_t)(del - trail);  // trailing read gaps are not deletions (byte arithmetic, L84)
+    out.ins = ins;
+    out.del = del;
+    out.nmis = ins + del + sub;
+    out.term6 = term && t >= 6;
+    out.end5 = e5;
+    out.endn = en;
+    out.consec = consec;
+    out.best_two = (n_runs >= 1 ? s1 : 0) + (n_runs >= 2 ? s2 : 0);
+    // Match.countErrorsInNeedleman: (float)#x - 0.9f * (float)lead, two roundings
+    out.ne = __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));
+}
+
+// Error count only (Match.countErrorsInNeedleman = #x - 0.9f * leading template gaps), no moves kept: the two
+// statistics ride in the low bits of the cell, below the score and the move tag, where they cannot influence the
+// max (the three candidates of a cell always differ in (score, tag)).
+//   cell = (4*score + 2 + 20*r) << 11 | q << 5 | lead      q = 32 + #up - #match on the best path
+// On an N x N alignment #x = N + #up - #match (#up = #left, #diag = N - #up), so one counter is enough; 6 VALU ops
+// per cell.
+template <int N>
+__device__ __forceinline__ float nw_errors(const uint32_t (&col)[N]) {
+    static_assert(N <= 27, "field widths: lead 5 bits, q 6 bits");
+    constexpr int SH = 11;
+    const uint32_t kmatch = (41u << SH) - 32u;  // diag with a match: +41 in the tagged score, q - 1
+    int U[N + 1];
+#pragma unroll
+    for (int c = 0; c <= N; c++) U[c] = ((-20 * c + 2) << SH) + (32 << 5);
+#pragma unroll
+    for (int r = 1; r <= N; r++) {
+        int diag = U[0];
+        U[0] = ((4 * r + 2) << SH) + ((32 + r) << 5) + r;
+#pragma unroll
+        for (int c = 1; c <= N; c++) {
+            int m, d;
+            asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(m) : "v"(col[c - 1]), "n"(r - 1));
+            asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(m), "s"(kmatch), "v"(diag));
+            const int up = U[c] - (1 << SH) + 32, left = U[c - 1] - (22 << SH);
+            diag = U[c];
+            const int v = max(max(d, up), left);
+            U[c] = (v & ~(3 << SH)) | (2 << SH);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const int lead = U[N] & 31, nx = N + ((U[N] >> 5) & 63) - 32;
+    return __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));
+}
+
+}  // namespace smi

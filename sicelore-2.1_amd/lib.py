@@ -26,12 +26,18 @@ SCAN_CONFIG_DTYPE = np.dtype(
      ("max_mismatches", "<i4"), ("min_adapter_3p_matches", "<i4"), ("min_mean_bc_qv", "<i4"),
      ("min_mean_read_qv", "<i4"), ("adapter_len", "<i4"), ("adapter4", "<u4", (22,))]
 )
+CHIMERA_RESULT_DTYPE = np.dtype([("pos", "<i4", (2,)), ("n_split", "u1"), ("reason", "u1", (2,)), ("flags", "u1"),
+                                 ("n_matches", "<i4")])
+SPLIT_REASONS = ["REV_ADAPTER", "FWD_ADAPTER", "REV_ADAPTER_FWD_ADAPTER", "REV_ADAPTER_FWD_TSO", "REV_TSO_FWD_ADAPTER",
+                 "REV_TSO_FWD_TSO"]
+CHIM_MULTI, CHIM_RANGE, CHIM_OVERFLOW = 1, 2, 4
 END_BASES = 224
 ENDS_ROWS = 28
 FLAG_BITS = {"FAILED": 6, "PASSED_FWD": 9, "PASSED_REV": 10, "POLY_T_5P": 12, "POLY_A_3P": 13, "POLY_A_NOT_FOUND": 14,
              "POLY_T_5P_POLY_A_3P": 15, "ADAPTER_5P": 16, "ADAPTER_3P": 17, "ADAPTER_SELECTED_DESP_BOTH": 20,
              "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22, "TSO_5P": 18, "TSO_3P": 19, "TSO_5P_AND_3P": 23}
 assert BC_WINDOW_DTYPE.itemsize == 16 and BC_RESULT_DTYPE.itemsize == 16 and SCAN_RESULT_DTYPE.itemsize == 32
+assert CHIMERA_RESULT_DTYPE.itemsize == 16
 
 SET_USED_LIST = 0
 SET_WHITELIST = 1
@@ -42,6 +48,8 @@ EXPORTS = [
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
     "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
+    "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
+    "smi_split_offsets_device", "smi_chimera_fragment_name",
 ]
 
 
@@ -85,6 +93,13 @@ def load_library():
     lib.smi_set_timing.argtypes = [vp, ci]
     lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     lib.smi_umi_dist_device.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
+    lib.smi_chimera_default_config.argtypes = [vp]
+    lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
+    lib.smi_read_planes_words.restype = sz
+    lib.smi_pack_reads_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp]
+    lib.smi_chimera_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp, vp]
+    lib.smi_split_offsets_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.smi_chimera_fragment_name.argtypes = [ctypes.c_char_p, vp, ci, ctypes.c_char_p, sz]
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ctypes.c_char_p, sz]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
@@ -142,6 +157,25 @@ def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_i
                                  _ptr(b), int(rank), int(read_id), out, 1200)
     if n < 0:
         raise SmiError(f"smi_format_read_name error {n}: {lib.smi_last_error().decode()}")
+    return out.value.decode()
+
+
+class ChimeraConfig(ctypes.Structure):
+    """smi_chimera_config"""
+    _fields_ = [("tso_complete", ctypes.c_char_p), ("adapter_complete", ctypes.c_char_p), ("tso_max_errors", ctypes.c_int32),
+                ("adapter_max_errors", ctypes.c_int32), ("internal_pat_len", ctypes.c_int32),
+                ("internal_pat_frac", ctypes.c_float), ("window_polya", ctypes.c_int32), ("bc_umi_len", ctypes.c_int32)]
+
+
+def chimera_fragment_name(read_name, result, fragment):
+    """smi_chimera_fragment_name; result: CHIMERA_RESULT_DTYPE record -> str"""
+    lib = load_library()
+    r = np.zeros(1, dtype=CHIMERA_RESULT_DTYPE)
+    r[0] = result
+    out = ctypes.create_string_buffer(len(read_name) + 64)
+    n = lib.smi_chimera_fragment_name(read_name.encode(), _ptr(r), int(fragment), out, len(read_name) + 64)
+    if n < 0:
+        raise SmiError(f"smi_chimera_fragment_name error {n}: {lib.smi_last_error().decode()}")
     return out.value.decode()
 
 
@@ -224,6 +258,30 @@ class Context:
         self._check(self._lib.smi_scan_device(self._h, _ptr(d_ends), _ptr(d_len), _ptr(d_qtail), _ptr(d_qsum), int(n),
                                               _ptr(cfg), _ptr(d_out), _ptr(d_windows), _stream_ptr(stream)))
 
+    # ---- chimera splitter ----------------------------------------------------------------------------------
+    def chimera_config(self):
+        cfg = ChimeraConfig()
+        self._check(self._lib.smi_chimera_default_config(ctypes.byref(cfg)))
+        return cfg
+
+    def read_planes_words(self, total_bases, n):
+        return int(self._lib.smi_read_planes_words(int(total_bases), int(n)))
+
+    def pack_reads_device(self, d_reads, d_offsets, n, total_bases, d_planes, stream=None):
+        """d_planes: int32 [read_planes_words(total_bases, n)]"""
+        self._check(self._lib.smi_pack_reads_device(self._h, _ptr(d_reads), _ptr(d_offsets), int(n), int(total_bases),
+                                                    _ptr(d_planes), _stream_ptr(stream)))
+
+    def chimera_device(self, d_planes, d_offsets, n, total_bases, cfg, d_out, stream=None):
+        """d_out: int32 [n, 4] (16-B smi_chimera_result records)"""
+        self._check(self._lib.smi_chimera_device(self._h, _ptr(d_planes), _ptr(d_offsets), int(n), int(total_bases),
+                                                 ctypes.addressof(cfg), _ptr(d_out), _stream_ptr(stream)))
+
+    def split_offsets_device(self, d_chim, d_offsets, n, d_scratch, d_n_frag, d_frag_offsets, d_frag_src=None, stream=None):
+        self._check(self._lib.smi_split_offsets_device(self._h, _ptr(d_chim), _ptr(d_offsets), int(n), _ptr(d_scratch),
+                                                       _ptr(d_n_frag), _ptr(d_frag_offsets), _ptr(d_frag_src),
+                                                       _stream_ptr(stream)))
+
     def hist_windows_device(self, d_windows, d_scan, n, d_hist, stream=None):
         self._check(self._lib.smi_hist_windows_device(self._h, _ptr(d_windows), _ptr(d_scan), int(n), _ptr(d_hist),
                                                       _stream_ptr(stream)))
@@ -250,7 +308,7 @@ class Context:
     def set_timing(self, enabled=True):
         self._check(self._lib.smi_set_timing(self._h, int(bool(enabled))))
 
-    K_BC_MATCH, K_SCAN, K_HIST, K_PACK, K_UMI = 0, 1, 2, 3, 4
+    K_BC_MATCH, K_SCAN, K_HIST, K_PACK, K_UMI, K_CHIMERA = 0, 1, 2, 3, 4, 5
 
     def kernel_ms(self, kernel_id):
         ms = ctypes.c_float(-1.0)

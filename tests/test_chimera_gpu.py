@@ -1,0 +1,109 @@
+"""K-PACKR + K-CHIM (chimera splitter) on the GPU == oracle, and the fragment offsets kernel."""
+import numpy as np
+import pytest
+
+import pymodel_chimera as pm
+
+
+def _run(pkg, ctx, seqs):
+    import torch
+
+    dev = torch.device("cuda:0")
+    n = len(seqs)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    total = int(offs[-1])
+    ra = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    d_reads = torch.from_numpy(ra.copy()).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_planes = torch.full((ctx.read_planes_words(total, n),), -1, dtype=torch.int32, device=dev)  # garbage-filled
+    ctx.pack_reads_device(d_reads, d_offs, n, total, d_planes)
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ctx.chimera_device(d_planes, d_offs, n, total, ctx.chimera_config(), d_out)
+    torch.cuda.synchronize()
+    res = d_out.cpu().numpy().view(pkg.CHIMERA_RESULT_DTYPE).reshape(-1)
+    return res, d_out, d_offs, offs
+
+
+def _compare(sor, seqs, res):
+    n_split = n_multi = 0
+    for i, s in enumerate(seqs):
+        rc, splits, multi, n_matches, _ = sor.chimera_split(s)
+        got = [(sor.SPLIT_REASONS[res["reason"][i][k]], int(res["pos"][i][k])) for k in range(res["n_split"][i])]
+        assert rc == 0 and not (res["flags"][i] & 6), i
+        assert got == splits and bool(res["flags"][i] & 1) == multi and res["n_matches"][i] == n_matches, (i, got, splits)
+        n_split += len(splits) > 0
+        n_multi += multi
+    return n_split, n_multi
+
+
+@pytest.mark.gpu
+def test_chimera_matches_oracle_on_synthetic_chimeras(pkg, sor, synth):
+    wl = synth.make_whitelist(20000, seed=81)
+    used = synth.pick_used(wl, 200, seed=82)
+    reads = synth.gen_reads(500, used, seed=83, n_rate=0.002)
+    chim = synth.make_chimeras(reads, 1500, seed=84)
+    seqs = [c[0] for c in chim]
+    rng = np.random.default_rng(5)
+    seqs += ["".join("ACGT"[k] for k in rng.integers(0, 4, L)) for L in (1, 100, 239, 240, 439, 440, 441, 500, 5000)]
+    seqs += ["A" * 700, "T" * 1000, "AT" * 400]
+    ctx = pkg.Context(0)
+    res, *_ = _run(pkg, ctx, seqs)
+    n_split, n_multi = _compare(sor, seqs, res)
+    assert n_split > 500 and n_multi > 50
+    # more than 64 internal TSO hits in one read (here: every position of an all-N read) is reported, not guessed
+    res, *_ = _run(pkg, ctx, ["N" * 600])
+    assert res["flags"][0] & pkg.lib.CHIM_OVERFLOW
+
+
+@pytest.mark.gpu
+def test_chimera_hand_built_reads_and_model(pkg, sor):
+    import random
+
+    from test_oracle_chimera import AD22, molecule, rc, rnd
+
+    rng = random.Random(17)
+    seqs = []
+    for _ in range(20):
+        a, b = molecule(rng), molecule(rng)
+        seqs += [a + b, rc(a) + b, a + rc(b), rc(a + b)]
+        core = AD22 + rnd(rng, 16) + rnd(rng, 12) + "T" * rng.randrange(16, 60)
+        seqs += [rnd(rng, 600) + core + rnd(rng, 600), rc(rnd(rng, 500) + core + rnd(rng, 700))]
+    ctx = pkg.Context(0)
+    res, *_ = _run(pkg, ctx, seqs)
+    _compare(sor, seqs, res)
+    for i in range(0, len(seqs), 7):  # the Python model on a subset (slow)
+        m_splits, m_multi, _ = pm.find_split_positions(seqs[i])
+        got = [(sor.SPLIT_REASONS[res["reason"][i][k]], int(res["pos"][i][k])) for k in range(res["n_split"][i])]
+        assert got == m_splits and bool(res["flags"][i] & 1) == m_multi
+
+
+@pytest.mark.gpu
+def test_split_offsets(pkg, sor, synth):
+    import torch
+
+    wl = synth.make_whitelist(5000, seed=91)
+    used = synth.pick_used(wl, 50, seed=92)
+    reads = synth.gen_reads(200, used, seed=93, max_mid=300)
+    seqs = [c[0] for c in synth.make_chimeras(reads, 3000, seed=94)]
+    ctx = pkg.Context(0)
+    res, d_out, d_offs, offs = _run(pkg, ctx, seqs)
+    n = len(seqs)
+    dev = d_out.device
+    d_scratch = torch.zeros((n + 1023) // 1024 + 1, dtype=torch.int32, device=dev)
+    d_nfrag = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_fo = torch.zeros(3 * n + 1, dtype=torch.int64, device=dev)
+    d_src = torch.zeros(3 * n, dtype=torch.int32, device=dev)
+    ctx.split_offsets_device(d_out, d_offs, n, d_scratch, d_nfrag, d_fo, d_src)
+    torch.cuda.synchronize()
+    exp_off, exp_src = [], []
+    for i in range(n):
+        cuts = [0] + [int(res["pos"][i][k]) for k in range(res["n_split"][i])]
+        for j, c in enumerate(cuts):
+            exp_off.append(int(offs[i]) + c)
+            exp_src.append((i << 2) | j)
+    exp_off.append(int(offs[n]))
+    nf = int(d_nfrag.item())
+    assert nf == len(exp_src) and nf > n
+    assert d_fo.cpu().numpy()[:nf + 1].tolist() == exp_off
+    assert d_src.cpu().numpy()[:nf].tolist() == exp_src

@@ -1,6 +1,8 @@
 """Chimera splitter (ChimeraFindernew.findSplitPositions): oracle == independent Python model; hand-built reads."""
 import random
 
+import numpy as np
+
 import pytest
 
 import pymodel_chimera as pm
@@ -80,3 +82,20 @@ def test_random_chimeras_oracle_equals_model(sor, synth):
         n_split += len(splits) > 0
         n_multi += multi
     assert n_split >= 15 and n_multi >= 1
+
+
+def test_product_fragment_names(pkg, sor):
+    from sicelore_amd import lib as libmod
+
+    for reasons in ([3], [0, 5], [4, 1]):
+        r = np.zeros(1, dtype=pkg.CHIMERA_RESULT_DTYPE)[0]
+        raw = sor._ChimeraResult()
+        raw.n_split = r["n_split"] = len(reasons)
+        for k, x in enumerate(reasons):
+            r["reason"][k] = raw.reason[k] = x
+            r["pos"][k] = raw.pos[k] = 300 * (k + 1)
+        for name in ("r7 runid=abc ch=1", "plain"):
+            for k in range(len(reasons) + 1):
+                assert libmod.chimera_fragment_name(name, r, k) == sor.chimera_fragment_name(name, raw, k)
+    with pytest.raises(libmod.SmiError):
+        libmod.chimera_fragment_name("x y", np.zeros(1, dtype=pkg.CHIMERA_RESULT_DTYPE)[0], 0)
