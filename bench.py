@@ -165,8 +165,8 @@ def main():
         "config": {
             "workload": "configs[1]: 10M synthetic Nanopore reads, ed<=1 vs 3.6M whitelist (-g semantics), 3' protocol; "
                         "timed = pass 2 per read from packed read ends in HBM: polyA/T finder + k-mer gated NW adapter scan "
-                        "+ strand decision (K-SCAN) -> 5-offset barcode match + best/second rule (K-BC1); "
-                        "not in the step: FASTQ decode/packing, chimera split, TSO flagging, UMI stage",
+                        "+ TSO scan + strand decision (K-SCAN) -> 5-offset barcode match + best/second rule (K-BC1); "
+                        "not in the step: FASTQ decode/packing, chimera split, UMI stage",
             "reads_per_gpu": n,
             "whitelist": int(wl.numel()),
             "cells": args.cells,

@@ -282,3 +282,24 @@ def make_chimeras(reads, n, seed=9, parts=(1, 2, 2, 2, 3, 4)):
         seqs, quals = zip(*(materialize(reads, int(rng.integers(0, n_src))) for _ in range(k)))
         out.append(("".join(seqs), "".join(quals), k))
     return out
+
+
+def materialize_device(reads, seed=0, chunk=262144):
+    """device-side twin of materialize() for whole batches: (ascii uint8 [total], offsets int64 [n + 1]); the middle
+    of every read is random sequence (not the same bytes materialize() draws)"""
+    dev = reads["head"].device
+    n = reads["head"].shape[0]
+    E = END_BASES
+    lens = 2 * E + reads["mid_len"].to(torch.int64)
+    offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offs[1:] = torch.cumsum(lens, 0)
+    total = int(offs[-1])
+    lut = torch.tensor(list(b"AGCTN"), dtype=torch.uint8, device=dev)
+    g = _gen(seed + 77, dev)
+    buf = lut[torch.randint(0, 4, (total,), generator=g, device=dev)]
+    ar = torch.arange(E, device=dev)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        buf[(offs[a:b, None] + ar).reshape(-1)] = lut[reads["head"][a:b].long()].reshape(-1)
+        buf[(offs[a + 1:b + 1, None] - E + ar).reshape(-1)] = lut[reads["tail"][a:b].long()].reshape(-1)
+    return buf, offs

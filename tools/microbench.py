@@ -85,6 +85,26 @@ def main():
     dt = timed(lambda: ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out))
     res["umi_dist"] = {"groups": int(len(sizes)), "reads": n_reads, "pairs": int(po[-1]), "ms": dt * 1e3,
                        "pairs_per_s": int(po[-1]) / dt, "levenshtein_per_s": 9 * int(po[-1]) / dt}
+    del packed, d_out
+    # ---- chimera splitter: K-PACKR + K-CHIM on whole reads; 10 % of the records are two molecules joined -----------
+    n = 1_000_000
+    rd = synth.gen_reads(n, used, seed=7, device=dev)
+    buf, offs = synth.materialize_device(rd)
+    keep = torch.ones(n + 1, dtype=torch.bool, device=dev)
+    keep[1:n][torch.rand(n - 1, device=dev) < 0.1] = False  # dropping an offset joins two neighbouring reads
+    offs = offs[keep].contiguous()
+    n = offs.numel() - 1
+    total = int(offs[-1])
+    planes = torch.zeros(ctx.read_planes_words(total, n), dtype=torch.int32, device=dev)
+    cres = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ccfg = ctx.chimera_config()
+    dt_pack = timed(lambda: ctx.pack_reads_device(buf, offs, n, total, planes))
+    dt = timed(lambda: ctx.chimera_device(planes, offs, n, total, ccfg, cres))
+    cr = cres.cpu().numpy().view(pkg.CHIMERA_RESULT_DTYPE).reshape(-1)
+    res["chimera"] = {"reads": n, "bases": total, "pack_ms": dt_pack * 1e3, "ms": dt * 1e3, "reads_per_s": n / dt,
+                      "bases_per_s": total / dt, "pack_GBps": total / dt_pack / 1e9,
+                      "split_frac": float((cr["n_split"] > 0).mean()), "multi_frac": float((cr["flags"] & 1).mean()),
+                      "overflow": int((cr["flags"] & 4).sum())}
     print(json.dumps(res))
 
 
