@@ -231,6 +231,40 @@ int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t 
                         const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
                         uint64_t total_pairs, uint8_t *d_out, void *stream);
 
+/* ================================================================================================================
+ * UMI clustering of `assignumis` on the K-UMI matrices (host): replaces the clusterer a (cell barcode, genomic region)
+ * group is handed to in UmiClustering$Submitter (FJ!umifinder/analyzers/clustering/UmiClustering$Submitter.java:L239-261):
+ * ClusterOneHierarchical (groups <= 100 reads: LingPipe complete link cut at umi_completelinkclusteringED,
+ * ClusterOneHierarchical.java:L66-217, lingpipe CompleteLinkClusterer.java:L146-237) or ClusterOne_MyClustering
+ * (larger groups, ClusterOne_MyClustering.java:L59-219), the fold-depth filter, centre selection
+ * (FJ!clustering/OneUmiCluster.java:L49-65) and the per-read values behind the tags U8 / U1 / U2
+ * (ClusterOneBase.java:L118-168).  Canonical order rules where the reference is not reproducible: DESIGN.md.
+ * ================================================================================================================ */
+typedef struct {
+    int32_t complete_link_ed;     /* umi_completelinkclusteringED, config.xml:270 (2) */
+    int32_t single_link_ed;       /* umi_singlelinkclusteringED, :272 (1) */
+    int32_t single_link_switch;   /* complexity_threshold_for_switch_to_single_link_clustering, :278 (3000) */
+    int32_t fold_depth_below_max; /* foldDepthBelowMaxDiscardForClustering (50) */
+    int32_t own_clusterer_above;  /* NRECORDS_SWITCH_TO_OWNCLUSTERING (100) */
+} smi_umi_cluster_config;
+
+typedef struct {
+    int32_t center;   /* group-local index of the cluster centre whose UMI the read takes (tag U8); -1 = not clustered */
+    int8_t offset;    /* -1, 0, +1: the centre's 12-mer is cut at this offset (getPostBCUMIseqOffset) */
+    int8_t ed;        /* tag U1: distance to the centre */
+    int8_t ed_second; /* tag U2: least distance to a read outside the cluster; -1 = tag absent */
+    int8_t pos2;      /* PlusMinusOneEnum value (0 MINUSONE, 1 ZERO, 2 PLUSONE) of the read's best position vs the centre */
+} smi_umi_assignment;
+
+int smi_umi_cluster_default_config(smi_umi_cluster_config *cfg);
+
+/* dist / mat_off / group_off: exactly the buffers of smi_umi_dist_device (copied to the host); mean_qv[r]: the read's
+ * mean quality (the Q= field of its name); out[r] / skipped[r] (may be NULL; 1 = UMI_CLUSTERING_SKIPPED_HIGHCOMPLEXITY)
+ * per read in group order; groups are independent and are spread over n_threads host threads. */
+int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_off, const uint32_t *group_off, uint32_t n_groups,
+                           const float *mean_qv, const smi_umi_cluster_config *cfg, smi_umi_assignment *out,
+                           uint8_t *skipped, int n_threads);
+
 /* Read-name suffix of a scanned (and possibly barcode-assigned) read = FastqRecordExt.getRecordForWriting
  * (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311): `<name>_{REV|FWD}_[PS=_PE=_][AE=_][T=_]
  * [bc=_ed=_ed_sec=_bcStart=_bcEnd=_[rk=_]]X=<stranded[AE-40..AE+2]>_Q=<##.#>_<base-36 id>[ cellBC=<bc>]`, or

@@ -153,4 +153,25 @@ int sor_chimera_split(const char *read, int len, const sor_chimera_params *par, 
 /* name of fragment k (0-based, 0..n_split) of a split read; returns the length or -1 */
 int sor_chimera_fragment_name(const char *read_name, const sor_chimera_result *res, int fragment, char *out, size_t cap);
 
+
+/* ---- UMI clustering of one (cell, region) group (sor_cluster.c) ---------------------------------------------- */
+typedef struct {                 /* shipped values: Jar/config.xml:270-278, UmiClustering.java:L52, UMIparameters.java:L118 */
+    int32_t complete_link_ed;    /* umi_completelinkclusteringED 2 */
+    int32_t single_link_ed;      /* umi_singlelinkclusteringED 1 */
+    int32_t single_link_switch;  /* complexity_threshold_for_switch_to_single_link_clustering 3000 */
+    int32_t fold_depth_below_max; /* foldDepthBelowMaxDiscardForClustering 50 */
+    int32_t own_clusterer_above; /* NRECORDS_SWITCH_TO_OWNCLUSTERING 100 */
+} sor_umi_cluster_params;
+typedef struct {
+    int32_t center;    /* group-local index of the cluster centre whose UMI the read takes, -1 = not clustered */
+    int8_t offset;     /* mean offset (-1, 0, +1) at which the centre's 12-mer is cut (getPostBCUMIseqOffset) */
+    int8_t ed;         /* UMI_ED: distance to the centre */
+    int8_t ed_second;  /* UMI_ED_SECOND_BEST_MATCH, -1 = tag absent */
+    int8_t pos2;       /* PlusMinusOneEnum value of the read's own best position vs the centre (predicted-pos flag) */
+} sor_umi_assignment;
+/* mat: n x n bytes ed | pos1 << 4 | pos2 << 6 (sor_umi_matrix layout); skipped_out (may be NULL): reads flagged
+ * UMI_CLUSTERING_SKIPPED_HIGHCOMPLEXITY by the fold-depth filter */
+int sor_umi_cluster_group(const uint8_t *mat, int32_t n, const float *mean_qv, const sor_umi_cluster_params *par,
+                          sor_umi_assignment *out, uint8_t *skipped_out);
+
 #endif

@@ -332,3 +332,29 @@ def chimera_fragment_name(name, raw_result, fragment):
     out = ctypes.create_string_buffer(len(name) + 64)
     n = L.sor_chimera_fragment_name(name.encode(), ctypes.byref(raw_result), fragment, out, len(name) + 64)
     return out.value.decode() if n >= 0 else None
+
+
+# ---- UMI clustering (sor_cluster.c) --------------------------------------------------------------------------------
+UMI_ASSIGNMENT_DTYPE = np.dtype([("center", "<i4"), ("offset", "i1"), ("ed", "i1"), ("ed_second", "i1"), ("pos2", "i1")])
+UMI_CLUSTER_PARAMS_DTYPE = np.dtype([("complete_link_ed", "<i4"), ("single_link_ed", "<i4"), ("single_link_switch", "<i4"),
+                                     ("fold_depth_below_max", "<i4"), ("own_clusterer_above", "<i4")])
+
+
+def umi_cluster_params(complete_ed=2, single_ed=1, single_switch=3000, fold=50, own_above=100):
+    p = np.zeros(1, dtype=UMI_CLUSTER_PARAMS_DTYPE)
+    p[0] = (complete_ed, single_ed, single_switch, fold, own_above)
+    return p
+
+
+def umi_cluster_group(mat, n, mean_qv, params=None):
+    """mat: uint8 [n*n] packed; -> (assignments structured array [n], skipped bool [n])"""
+    L = lib()
+    p = umi_cluster_params() if params is None else params
+    m = np.ascontiguousarray(mat, dtype=np.uint8)
+    q = np.ascontiguousarray(mean_qv, dtype=np.float32)
+    out = np.zeros(max(n, 1), dtype=UMI_ASSIGNMENT_DTYPE)
+    sk = np.zeros(max(n, 1), dtype=np.uint8)
+    L.sor_umi_cluster_group.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p]
+    L.sor_umi_cluster_group(m.ctypes.data, n, q.ctypes.data, p.ctypes.data, out.ctypes.data, sk.ctypes.data)
+    return out[:n], sk[:n].astype(bool)

@@ -1,0 +1,401 @@
+// smi_cluster.hip -- host-side UMI clustering of `assignumis` on the K-UMI distance matrices (no device code here).
+//
+// Reference units (bytecode; citation form in DESIGN.md; AL! = Jar/lib/lingpipe-4.1.2-JL1.0.jar):
+//   UmiClustering$Submitter.lambda$run$2            FJ!umifinder/analyzers/clustering/UmiClustering$Submitter.java:L239-261
+//   ClusterOneHierarchical.call                     FJ!umifinder/analyzers/clustering/ClusterOneHierarchical.java:L66-217
+//   ClusterOne_MyClustering.call / clusterLocal     FJ!umifinder/analyzers/clustering/ClusterOne_MyClustering.java:L59-219
+//   ClusterOneBase.setSamflagsAndStatsForClustered  FJ!umifinder/analyzers/clustering/ClusterOneBase.java:L118-168
+//   DistanceMatrix, OneUmiCluster                   FJ!clustering/{DistanceMatrix.java:L87-169,OneUmiCluster.java:L49-65}
+//   CompleteLinkClusterer, SingleLinkClusterer, Dendrogram.partitionDistance, BoundedPriorityQueue
+//                                                   AL!cluster/*.java, AL!util/BoundedPriorityQueue.java:L458-464
+//   fastutil 8.2.2 IntOpenHashSet / Int2ObjectOpenHashMap iteration order (jar not in the checkout; published layout)
+//
+// The reference is not reproducible on this step (parallel-stream arrival order, identity-hash HashSet<PairScore>);
+// the canonical rules are: group members in input order, PairScore sets in creation order, fastutil collections filled
+// in ascending index order (DESIGN.md "UMI clustering").
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <set>
+#include <thread>
+#include <vector>
+
+#include "smi_internal.h"
+
+namespace smi {
+namespace {
+
+struct Dist {
+    const uint8_t *m;
+    int n;
+    int ed(int i, int j) const { return m[(size_t)i * n + j] & 15; }
+    int pos1(int i, int j) const { return (m[(size_t)i * n + j] >> 4) & 3; }
+    int pos2(int i, int j) const { return (m[(size_t)i * n + j] >> 6) & 3; }
+};
+
+// iteration order of a fastutil open hash set / map that received `keys` in ascending order
+std::vector<int> fastutil_order(std::vector<int> keys) {
+    std::sort(keys.begin(), keys.end());
+    auto mix = [](uint32_t x) {
+        const uint32_t h = x * 0x9E3779B9u;
+        return h ^ (h >> 16);
+    };
+    size_t n = 32;
+    std::vector<int> tab(n + 1, 0);
+    bool zero = false;
+    size_t size = 0;
+    for (int k : keys) {
+        if (k == 0)
+            zero = true;
+        else {
+            size_t pos = mix((uint32_t)k) & (n - 1);
+            while (tab[pos] != 0) pos = (pos + 1) & (n - 1);
+            tab[pos] = k;
+        }
+        const size_t max_fill = std::min((size_t)std::ceil(n * 0.75), n - 1);
+        if (size++ >= max_fill) {
+            const size_t need = (size_t)std::ceil((size + 1) / 0.75);
+            size_t nn = 2;
+            while (nn < need) nn <<= 1;
+            std::vector<int> nt(nn + 1, 0);
+            for (size_t i = n; i-- > 0;) {  // entries move in descending slot order
+                if (tab[i] == 0) continue;
+                size_t pos = mix((uint32_t)tab[i]) & (nn - 1);
+                while (nt[pos] != 0) pos = (pos + 1) & (nn - 1);
+                nt[pos] = tab[i];
+            }
+            tab.swap(nt);
+            n = nn;
+        }
+    }
+    std::vector<int> out;
+    out.reserve(keys.size());
+    if (zero) out.push_back(0);
+    for (size_t pos = n; pos-- > 0;)
+        if (tab[pos] != 0) out.push_back(tab[pos]);
+    return out;
+}
+
+int choose_center(const Dist &D, const std::vector<int> &members, const float *qv) {
+    const std::vector<int> ord = fastutil_order(members);
+    if (ord.size() == 1) return ord[0];
+    if (ord.size() == 2) return qv[0] > qv[1] ? ord[0] : ord[1];  // reads 0 and 1 of the group (OneUmiCluster.java:L53)
+    long best = -1;
+    int center = ord[0];
+    for (int s : ord) {
+        long tot = 0;
+        for (int w : ord)
+            if (w != s) tot += (long)(int)std::pow((double)D.ed(s, w), 2.0);
+        if (best < 0 || tot < best) {
+            best = tot;
+            center = s;
+        }
+    }
+    return center;
+}
+
+// LingPipe complete link + cut: partition of 0..k-1 (distance d(a,b) = ED(nb[a], nb[b])) at max_distance
+std::vector<std::vector<int>> complete_link(const Dist &D, const std::vector<int> &nb, double max_distance) {
+    const int k = (int)nb.size();
+    struct Node {
+        int parent = -1, left = -1, right = -1;
+        double score = 0.0;
+    };
+    struct Pair {
+        int a, b;
+        double score;
+    };
+    std::vector<Node> nodes(k);
+    std::vector<Pair> pairs;
+    // queue order: score ascending, then id DESCENDING (BoundedPriorityQueue$EntryComparator)
+    auto cmp = [&](int x, int y) { return pairs[x].score != pairs[y].score ? pairs[x].score < pairs[y].score : x > y; };
+    std::set<int, decltype(cmp)> queue(cmp);
+    std::vector<std::vector<int>> index(k);  // node -> its pairs, creation order
+    auto offer = [&](int a, int b, double s) {
+        pairs.push_back({a, b, s});
+        const int id = (int)pairs.size() - 1;
+        queue.insert(id);
+        if ((int)index.size() <= std::max(a, b)) index.resize(std::max(a, b) + 1);
+        index[a].push_back(id);
+        index[b].push_back(id);
+    };
+    for (int i = 0; i < k; i++)
+        for (int j = i + 1; j < k; j++) offer(i, j, (double)D.ed(nb[i], nb[j]));
+    auto root_of = [&](int x) {
+        while (nodes[x].parent >= 0) x = nodes[x].parent;
+        return x;
+    };
+    std::vector<char> dead;
+    int root = 0;
+    while (!queue.empty()) {
+        const int nxt = *queue.begin();
+        queue.erase(queue.begin());
+        dead.resize(pairs.size(), 0);
+        dead[nxt] = 1;
+        const int d1 = root_of(pairs[nxt].a), d2 = root_of(pairs[nxt].b);
+        Node link;
+        link.left = d1;
+        link.right = d2;
+        link.score = pairs[nxt].score;
+        nodes.push_back(link);
+        const int d12 = (int)nodes.size() - 1;
+        nodes[d1].parent = nodes[d2].parent = d12;
+        root = d12;
+        index.resize(nodes.size());
+        std::map<int, double> buf;
+        for (int p : index[d1]) {
+            if (dead[p] && p != nxt) continue;
+            buf[pairs[p].a == d1 ? pairs[p].b : pairs[p].a] = pairs[p].score;
+            if (!dead[p]) {
+                queue.erase(p);
+                dead[p] = 1;
+            }
+        }
+        const std::vector<int> of_d2 = index[d2];
+        for (int p : of_d2) {
+            if (dead[p]) continue;
+            queue.erase(p);
+            dead[p] = 1;
+            const int d3 = pairs[p].a == d2 ? pairs[p].b : pairs[p].a;
+            auto it = buf.find(d3);
+            if (it == buf.end()) continue;
+            const double s = std::max(it->second, pairs[p].score);
+            offer(d12, d3, s);
+            dead.resize(pairs.size(), 0);
+        }
+    }
+    std::vector<std::vector<int>> out;
+    std::vector<int> stack{root};
+    while (!stack.empty()) {
+        const int cur = stack.back();
+        stack.pop_back();
+        if (nodes[cur].score <= max_distance) {
+            std::vector<int> mem, st{cur};
+            while (!st.empty()) {
+                const int x = st.back();
+                st.pop_back();
+                if (x < k)
+                    mem.push_back(x);
+                else {
+                    st.push_back(nodes[x].left);
+                    st.push_back(nodes[x].right);
+                }
+            }
+            out.push_back(mem);
+        } else {
+            stack.push_back(nodes[cur].left);
+            stack.push_back(nodes[cur].right);
+        }
+    }
+    return out;
+}
+
+std::vector<std::vector<int>> single_link(const Dist &D, const std::vector<int> &nb, double max_distance) {
+    const int k = (int)nb.size();
+    std::vector<int> parent(k);
+    for (int i = 0; i < k; i++) parent[i] = i;
+    auto find = [&](int x) {
+        while (parent[x] != x) x = parent[x] = parent[parent[x]];
+        return x;
+    };
+    for (int i = 0; i < k; i++)
+        for (int j = i + 1; j < k; j++)
+            if ((double)D.ed(nb[i], nb[j]) <= max_distance) parent[find(i)] = find(j);
+    std::map<int, std::vector<int>> g;
+    for (int i = 0; i < k; i++) g[find(i)].push_back(i);
+    std::vector<std::vector<int>> out;
+    for (auto &kv : g) out.push_back(kv.second);
+    return out;
+}
+
+struct Cluster {
+    std::vector<int> members;  // ascending
+    int center = -1;
+};
+
+void tag_members(const Dist &D, const Cluster &c, const std::vector<int> &who, size_t n_clusters,
+                 const std::vector<char> &skipped, smi_umi_assignment *out) {
+    long sum = 0;
+    int cnt = 0;
+    for (int v : c.members)
+        if (v != c.center) {
+            sum += D.pos1(c.center, v) - 1;
+            cnt++;
+        }
+    const int offset = (int)std::floor((double)sum / (double)cnt + 0.5);  // (int) Math.round(double)
+    std::vector<char> inside(D.n, 0);
+    for (int v : c.members) inside[v] = 1;
+    for (int idx : who) {
+        if (skipped[idx]) continue;
+        int sec = -1;
+        if (n_clusters > 1)
+            for (int m = 0; m < D.n; m++)
+                if (!inside[m] && (sec < 0 || D.ed(idx, m) < sec)) sec = D.ed(idx, m);
+        out[idx].center = c.center;
+        out[idx].offset = (int8_t)offset;
+        out[idx].ed = (int8_t)D.ed(c.center, idx);
+        out[idx].ed_second = (int8_t)sec;
+        out[idx].pos2 = (int8_t)D.pos2(c.center, idx);
+    }
+}
+
+// clusterLocal: owner key of every index that has a neighbour, -1 otherwise
+std::vector<int> cluster_local(const Dist &D, const std::vector<int> &indices, int ed) {
+    std::vector<int> owner(D.n, -1), count(D.n, 0), keys;
+    for (int a : indices) {
+        for (int b : indices) count[a] += D.ed(a, b) <= ed;
+        if (count[a] > 1) keys.push_back(a);
+    }
+    const std::vector<int> ord = fastutil_order(keys);
+    for (int c : keys) {
+        int best = -1;
+        for (int a : ord)
+            if (D.ed(a, c) <= ed && (best < 0 || count[a] > count[best])) best = a;
+        owner[c] = best;
+    }
+    return owner;
+}
+
+void cluster_one(const uint8_t *mat, int n, const float *qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *out,
+                 uint8_t *skipped_out) {
+    const Dist D{mat, n};
+    std::vector<char> skipped(std::max(n, 1), 0);
+    for (int i = 0; i < n; i++) out[i] = smi_umi_assignment{-1, 0, -1, -1, 0};
+    const int ced = cfg.complete_link_ed;
+    std::vector<Cluster> kept;
+    if (n > 1 && n <= cfg.own_clusterer_above) {
+        std::vector<int> nb;
+        for (int i = 0; i < n; i++) {
+            bool any = false;
+            for (int j = 0; j < n && !any; j++) any = i != j && D.ed(i, j) <= ced;
+            if (any) nb.push_back(i);
+        }
+        if (nb.size() > 1) {
+            auto parts = (int)nb.size() > cfg.single_link_switch ? single_link(D, nb, (double)cfg.single_link_ed)
+                                                                 : complete_link(D, nb, (double)ced);
+            size_t mx = 0;
+            for (auto &p : parts)
+                if (p.size() > 1) mx = std::max(mx, p.size());
+            for (auto &p : parts) {
+                if (p.size() <= 1) continue;
+                Cluster c;
+                for (int a : p) c.members.push_back(nb[a]);
+                std::sort(c.members.begin(), c.members.end());
+                if (c.members.size() * (size_t)cfg.fold_depth_below_max > mx)
+                    kept.push_back(c);
+                else
+                    for (int v : c.members) skipped[v] = 1;
+            }
+            for (auto &c : kept) c.center = choose_center(D, c.members, qv);
+            for (auto &c : kept) tag_members(D, c, fastutil_order(c.members), kept.size(), skipped, out);
+        }
+    } else if (n > 1) {
+        std::vector<int> all(n);
+        for (int i = 0; i < n; i++) all[i] = i;
+        auto group_by_owner = [&](const std::vector<int> &owner, const std::vector<int> &indices) {
+            std::map<int, size_t> slot;  // owner -> cluster, clusters listed by their smallest member
+            std::vector<Cluster> cl;
+            for (int i : indices) {
+                if (owner[i] < 0) continue;
+                auto it = slot.find(owner[i]);
+                if (it == slot.end()) {
+                    slot[owner[i]] = cl.size();
+                    cl.emplace_back();
+                    it = slot.find(owner[i]);
+                }
+                cl[it->second].members.push_back(i);
+            }
+            return cl;
+        };
+        std::vector<Cluster> first = group_by_owner(cluster_local(D, all, ced), all);
+        size_t mx = 0;
+        for (auto &c : first) mx = std::max(mx, c.members.size());
+        std::vector<char> clustered(n, 0);
+        for (auto &c : first) {
+            if (c.members.size() * (size_t)cfg.fold_depth_below_max > mx) {
+                c.center = choose_center(D, c.members, qv);
+                for (int v : c.members) clustered[v] = 1;
+                kept.push_back(c);
+            } else
+                for (int v : c.members) skipped[v] = 1;
+        }
+        std::vector<int> unclustered;
+        for (int i = 0; i < n; i++)
+            if (!clustered[i]) unclustered.push_back(i);
+        size_t n_removed = 0;
+        for (auto &c : kept) {  // removeOffCenter
+            std::vector<int> stay;
+            for (int s : c.members)
+                if (D.ed(s, c.center) > ced) {
+                    unclustered.push_back(s);
+                    n_removed++;
+                } else
+                    stay.push_back(s);
+            if (stay.size() != c.members.size()) {
+                c.members = stay;
+                c.center = choose_center(D, c.members, qv);
+            }
+        }
+        if (n_removed > 0) {
+            std::sort(unclustered.begin(), unclustered.end());
+            for (auto &c : group_by_owner(cluster_local(D, unclustered, ced), unclustered))
+                if (c.members.size() > 1) {
+                    c.center = choose_center(D, c.members, qv);
+                    kept.push_back(c);
+                }
+        }
+        for (auto &c : kept) {
+            if (c.members.size() <= 1) continue;
+            std::vector<int> filt;
+            for (int s : fastutil_order(c.members))
+                if (D.ed(s, c.center) <= ced) filt.push_back(s);
+            if (filt.size() > 1) tag_members(D, c, filt, kept.size(), skipped, out);
+        }
+    }
+    if (skipped_out)
+        for (int i = 0; i < n; i++) skipped_out[i] = (uint8_t)skipped[i];
+}
+
+}  // namespace
+}  // namespace smi
+
+using namespace smi;
+
+extern "C" int smi_umi_cluster_default_config(smi_umi_cluster_config *cfg) {
+    if (!cfg) {
+        set_error("smi_umi_cluster_default_config: null argument");
+        return SMI_ERR_INVALID;
+    }
+    cfg->complete_link_ed = 2;        // Jar/config.xml:270
+    cfg->single_link_ed = 1;          // :272
+    cfg->single_link_switch = 3000;   // :278
+    cfg->fold_depth_below_max = 50;   // UMIparameters.java:L118
+    cfg->own_clusterer_above = 100;   // UmiClustering.java:L52
+    return SMI_OK;
+}
+
+extern "C" int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_off, const uint32_t *group_off,
+                                      uint32_t n_groups, const float *mean_qv, const smi_umi_cluster_config *cfg,
+                                      smi_umi_assignment *out, uint8_t *skipped, int n_threads) {
+    if (!cfg || (n_groups && (!dist || !mat_off || !group_off || !mean_qv || !out)) || cfg->complete_link_ed < 0 ||
+        cfg->fold_depth_below_max <= 0) {
+        set_error("smi_umi_cluster_groups: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    const int nt = std::max(1, std::min(n_threads, 256));
+    auto work = [&](int t) {
+        for (uint32_t g = (uint32_t)t; g < n_groups; g += (uint32_t)nt) {
+            const uint32_t a = group_off[g], n = group_off[g + 1] - a;
+            cluster_one(dist + mat_off[g], (int)n, mean_qv + a, *cfg, out + a, skipped ? skipped + a : nullptr);
+        }
+    };
+    if (nt == 1)
+        work(0);
+    else {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+        for (auto &x : th) x.join();
+    }
+    return SMI_OK;
+}

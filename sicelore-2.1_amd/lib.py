@@ -49,7 +49,7 @@ EXPORTS = [
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
     "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
-    "smi_split_offsets_device", "smi_chimera_fragment_name",
+    "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
 ]
 
 
@@ -100,6 +100,8 @@ def load_library():
     lib.smi_chimera_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp, vp]
     lib.smi_split_offsets_device.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, vp]
     lib.smi_chimera_fragment_name.argtypes = [ctypes.c_char_p, vp, ci, ctypes.c_char_p, sz]
+    lib.smi_umi_cluster_default_config.argtypes = [vp]
+    lib.smi_umi_cluster_groups.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp, ci]
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ctypes.c_char_p, sz]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
@@ -158,6 +160,40 @@ def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_i
     if n < 0:
         raise SmiError(f"smi_format_read_name error {n}: {lib.smi_last_error().decode()}")
     return out.value.decode()
+
+
+UMI_ASSIGNMENT_DTYPE = np.dtype([("center", "<i4"), ("offset", "i1"), ("ed", "i1"), ("ed_second", "i1"), ("pos2", "i1")])
+UMI_CLUSTER_CONFIG_DTYPE = np.dtype([("complete_link_ed", "<i4"), ("single_link_ed", "<i4"), ("single_link_switch", "<i4"),
+                                     ("fold_depth_below_max", "<i4"), ("own_clusterer_above", "<i4")])
+
+
+def umi_cluster_config(**overrides):
+    """smi_umi_cluster_default_config (+ field overrides) -> 1-element structured array"""
+    lib = load_library()
+    cfg = np.zeros(1, dtype=UMI_CLUSTER_CONFIG_DTYPE)
+    if lib.smi_umi_cluster_default_config(_ptr(cfg)) != 0:
+        raise SmiError(lib.smi_last_error().decode())
+    for k, v in overrides.items():
+        cfg[k] = v
+    return cfg
+
+
+def umi_cluster_groups(dist, mat_off, group_off, mean_qv, cfg=None, n_threads=1):
+    """smi_umi_cluster_groups on host arrays -> (assignments [n_reads], skipped bool [n_reads])"""
+    lib = load_library()
+    cfg = umi_cluster_config() if cfg is None else cfg
+    dist = np.ascontiguousarray(dist, dtype=np.uint8)
+    mat_off = np.ascontiguousarray(mat_off, dtype=np.uint64)
+    group_off = np.ascontiguousarray(group_off, dtype=np.uint32)
+    qv = np.ascontiguousarray(mean_qv, dtype=np.float32)
+    n_reads = int(group_off[-1])
+    out = np.zeros(max(n_reads, 1), dtype=UMI_ASSIGNMENT_DTYPE)
+    sk = np.zeros(max(n_reads, 1), dtype=np.uint8)
+    rc = lib.smi_umi_cluster_groups(_ptr(dist), _ptr(mat_off), _ptr(group_off), group_off.size - 1, _ptr(qv), _ptr(cfg),
+                                    _ptr(out), _ptr(sk), int(n_threads))
+    if rc != 0:
+        raise SmiError(f"smi_umi_cluster_groups error {rc}: {lib.smi_last_error().decode()}")
+    return out[:n_reads], sk[:n_reads].astype(bool)
 
 
 class ChimeraConfig(ctypes.Structure):

@@ -52,3 +52,26 @@ def test_umi_matrices_match_oracle(pkg, sor, gpu_ctx, sizes):
         exp = sor.umi_matrix(ws[go[g]:go[g + 1]])
         got = out[int(mo[g]):int(mo[g + 1])].reshape(n, n)
         assert (got == exp).all(), g
+
+
+def test_umi_distances_then_clustering_end_to_end(pkg, sor, gpu_ctx):
+    """K-UMI matrices (device) -> host clustering (product) == oracle matrices -> oracle clustering, per group"""
+    from sicelore_amd import lib as libmod
+
+    sizes = [2, 3, 9, 40, 100, 101, 150, 7, 64, 1, 250]
+    ws = _make_groups(77, sizes)
+    go, po, mo = gpu_ctx.umi_offsets(sizes)
+    d_out = torch.zeros((int(mo[-1]),), dtype=torch.uint8, device="cuda")
+    gpu_ctx.umi_dist_device(torch.from_numpy(_pack(ws).view(np.int64)).cuda(), torch.from_numpy(go.view(np.int32)).cuda(),
+                            torch.from_numpy(po.view(np.int64)).cuda(), torch.from_numpy(mo.view(np.int64)).cuda(),
+                            len(sizes), int(po[-1]), d_out)
+    torch.cuda.synchronize()
+    qv = np.random.default_rng(5).uniform(8, 25, int(go[-1])).astype(np.float32)
+    got, got_sk = libmod.umi_cluster_groups(d_out.cpu().numpy(), mo, go, qv, n_threads=4)
+    n_clustered = 0
+    for g, n in enumerate(sizes):
+        a, b = int(go[g]), int(go[g + 1])
+        exp, exp_sk = sor.umi_cluster_group(sor.umi_matrix(ws[a:b]).reshape(-1), n, qv[a:b])
+        assert (got[a:b] == exp.astype(got.dtype)).all() and (got_sk[a:b] == exp_sk).all(), g
+        n_clustered += int((exp["center"] >= 0).sum())
+    assert n_clustered > 400
