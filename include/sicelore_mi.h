@@ -265,6 +265,26 @@ int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_off, const u
                            const float *mean_qv, const smi_umi_cluster_config *cfg, smi_umi_assignment *out,
                            uint8_t *skipped, int n_threads);
 
+/* ================================================================================================================
+ * Genomic-region grouping of `assignumis` (host): which reads of a chunk may share a UMI group.  Replaces
+ * ReadGrouper.groupSams / doClusteringOneStrand / ClusterList.refineClusters
+ * (FJ!umifinder/bamreaders/ReadGrouper.java:L82-260,L455-785): per strand, position-sorted reads are chained while
+ * consecutive gaps < max_dist, chains of > 2 reads become regions, regions are refined around their centre
+ * (Math.round((float) mean position)) and close neighbours merged.
+ * pos / has_pos / reverse: per read in BAM order (reverse = SAM flag 16; has_pos = positionOnGenomeForClustering
+ * present); region[i] = ordinal of the read's region in the final list or -1 (the reference's ids come from a static
+ * counter, only their equality matters); *n_done = leading reads of the chunk that are final -- with keep_data_end the
+ * regions within 3 * max_dist of the right-most position are held back and re-grouped with the next chunk (L171-184).
+ * ================================================================================================================ */
+int smi_region_group(const int32_t *pos, const uint8_t *has_pos, const uint8_t *reverse, int32_t n, int32_t max_dist,
+                     int keep_data_end, int32_t *region, int32_t *n_done);
+
+/* NanoporeRead$ReadScanData.getReferencePositionAtReadPosition (FJ!umifinder/reads/nanopore/NanoporeRead$ReadScanData.java:
+ * L133-153) on a BAM-encoded CIGAR (len << 4 | op, op = MIDNSHP=X): returns 1 and *out = reference position of the
+ * 1-based read position, 0 for Optional.absent, or a negative smi_status. */
+int smi_ref_position_at_read_position(const uint32_t *cigar, int32_t n_cigar, int32_t alignment_start, int32_t position,
+                                      int32_t *out);
+
 /* Read-name suffix of a scanned (and possibly barcode-assigned) read = FastqRecordExt.getRecordForWriting
  * (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311): `<name>_{REV|FWD}_[PS=_PE=_][AE=_][T=_]
  * [bc=_ed=_ed_sec=_bcStart=_bcEnd=_[rk=_]]X=<stranded[AE-40..AE+2]>_Q=<##.#>_<base-36 id>[ cellBC=<bc>]`, or

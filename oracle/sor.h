@@ -174,4 +174,15 @@ typedef struct {
 int sor_umi_cluster_group(const uint8_t *mat, int32_t n, const float *mean_qv, const sor_umi_cluster_params *par,
                           sor_umi_assignment *out, uint8_t *skipped_out);
 
+
+/* ---- genomic-region grouping (sor_group.c) ------------------------------------------------------------------- */
+/* pos / has_pos / reverse per read in BAM order (reverse = SAM flag 16); region[i] = ordinal of the read's region or
+ * -1; n_done = number of leading reads of the chunk that are final (the rest is re-grouped with the next chunk when
+ * keep_data_end is set).  max_dist = max_GenomeDistance_forGrouping (500). */
+int sor_region_group(const int32_t *pos, const uint8_t *has_pos, const uint8_t *reverse, int32_t n, int32_t max_dist,
+                     int keep_data_end, int32_t *region, int32_t *n_done);
+/* returns 1 and *out = reference position, or 0 (Optional.absent) */
+int sor_ref_position_at_read_position(const uint32_t *cigar, int n_cigar, int32_t alignment_start, int32_t position,
+                                      int32_t *out);
+
 #endif

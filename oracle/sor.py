@@ -358,3 +358,33 @@ def umi_cluster_group(mat, n, mean_qv, params=None):
                                         ctypes.c_void_p]
     L.sor_umi_cluster_group(m.ctypes.data, n, q.ctypes.data, p.ctypes.data, out.ctypes.data, sk.ctypes.data)
     return out[:n], sk[:n].astype(bool)
+
+
+# ---- genomic-region grouping (sor_group.c) ------------------------------------------------------------------------
+def region_group(pos, reverse, max_dist=500, keep_data_end=False):
+    """pos: list with None for absent; -> (region list, n_done)"""
+    L = lib()
+    n = len(pos)
+    p = np.array([0 if v is None else v for v in pos], dtype=np.int32)
+    h = np.array([v is not None for v in pos], dtype=np.uint8)
+    r = np.ascontiguousarray(reverse, dtype=np.uint8)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    nd = ctypes.c_int32(0)
+    L.sor_region_group.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int32, ctypes.c_int32, ctypes.c_int, ctypes.c_void_p,
+                                                           ctypes.c_void_p]
+    L.sor_region_group(p.ctypes.data, h.ctypes.data, r.ctypes.data, n, max_dist, int(keep_data_end), out.ctypes.data,
+                       ctypes.byref(nd))
+    return out[:n].tolist(), nd.value
+
+
+CIGAR_OPS = "MIDNSHP=X"
+
+
+def ref_position_at_read_position(cigar, alignment_start, position):
+    L = lib()
+    c = np.array([(ln << 4) | CIGAR_OPS.index(op) for op, ln in cigar], dtype=np.uint32)
+    out = ctypes.c_int32(0)
+    L.sor_ref_position_at_read_position.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int32,
+                                                    ctypes.c_void_p]
+    rc = L.sor_ref_position_at_read_position(c.ctypes.data, c.size, alignment_start, position, ctypes.byref(out))
+    return out.value if rc == 1 else None

@@ -399,3 +399,180 @@ extern "C" int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_o
     }
     return SMI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Genomic-region grouping of `assignumis` (which reads may share a UMI group):
+//   ReadGrouper.groupSams / doClusteringOneStrand   FJ!umifinder/bamreaders/ReadGrouper.java:L82-260
+//   ReadGrouper$Cluster, $ClusterList.refineClusters  (same file) L455-785
+//   NanoporeRead$ReadScanData.getReferencePositionAtReadPosition  FJ!umifinder/reads/nanopore/NanoporeRead$ReadScanData.java:L133-153
+// ---------------------------------------------------------------------------------------------------------------
+namespace smi {
+namespace {
+
+struct Rec {
+    int pos, read, index;
+    bool rev;
+};
+
+struct Region {
+    std::vector<const Rec *> reads;
+    bool cached = false;
+    int center_value = 0;
+    int center() {  // Math.round((float) mean), cached until the membership changes
+        if (!cached && !reads.empty()) {
+            double s = 0;
+            for (const Rec *r : reads) s += r->pos;
+            center_value = (int)std::floor((float)(s / (double)reads.size()) + 0.5f);
+            cached = true;
+        }
+        return center_value;
+    }
+    // members for which `off` holds leave and form a new region, ordered by position
+    template <typename F>
+    bool split_off(F off, Region &out) {
+        out = Region();
+        std::vector<const Rec *> stay;
+        for (const Rec *r : reads) (off(r) ? out.reads : stay).push_back(r);
+        if (out.reads.empty()) return false;
+        reads.swap(stay);
+        cached = false;
+        std::stable_sort(out.reads.begin(), out.reads.end(), [](const Rec *a, const Rec *b) { return a->pos < b->pos; });
+        return true;
+    }
+};
+
+void drop_empty(std::vector<Region> &v) {
+    v.erase(std::remove_if(v.begin(), v.end(), [](const Region &r) { return r.reads.empty(); }), v.end());
+}
+
+void sort_by_center(std::vector<Region> &v) {
+    drop_empty(v);
+    for (Region &r : v) r.center();
+    std::stable_sort(v.begin(), v.end(), [](const Region &a, const Region &b) { return a.center_value < b.center_value; });
+}
+
+void refine_regions(std::vector<Region> &v, int dist) {
+    size_t from = 0, to = v.size();
+    while (from < to) {
+        for (size_t i = from; i < to; i++) {
+            Region out;
+            int c = v[i].center();
+            if (v[i].split_off([&](const Rec *r) { return r->pos < c - dist; }, out)) v.push_back(out);
+            c = v[i].center();
+            if (v[i].split_off([&](const Rec *r) { return r->pos > c + dist; }, out)) v.push_back(out);
+        }
+        from = to;
+        to = v.size();
+    }
+    sort_by_center(v);
+    for (bool again = true; again;) {
+        again = false;
+        for (size_t i = 0; i + 1 < v.size(); i++) {
+            if (v[i].reads.empty()) continue;
+            Region &left = v[i], &right = v[i + 1];
+            if (right.center() - left.center() >= 2 * dist) continue;
+            const bool left_bigger = left.reads.size() > right.reads.size();
+            Region &from_r = left_bigger ? right : left, &to_r = left_bigger ? left : right;
+            const int tc = to_r.center_value;
+            std::vector<const Rec *> stay, move;
+            for (const Rec *r : from_r.reads) (std::abs(r->pos - tc) <= dist ? move : stay).push_back(r);
+            if (move.empty()) continue;
+            again = true;
+            to_r.reads.insert(to_r.reads.end(), move.begin(), move.end());
+            from_r.reads.swap(stay);
+            to_r.cached = from_r.cached = false;
+        }
+        drop_empty(v);
+    }
+    v.erase(std::remove_if(v.begin(), v.end(), [](const Region &r) { return r.reads.size() <= 1; }), v.end());
+}
+
+std::vector<Region> chain_strand(const std::vector<const Rec *> &s, int dist) {
+    std::vector<Region> out;
+    if (s.size() <= 1) return out;
+    Region cur;
+    if (s[1]->pos - s[0]->pos < dist) cur.reads.push_back(s[0]);
+    for (size_t i = 1; i < s.size(); i++) {
+        if (s[i]->pos - s[i - 1]->pos < dist)
+            cur.reads.push_back(s[i]);
+        else if (cur.reads.size() > 2) {  // a chain of <= 2 reads is not closed by a gap, it keeps growing (L247)
+            out.push_back(cur);
+            cur = Region();
+        }
+    }
+    if (cur.reads.size() > 2) out.push_back(cur);
+    refine_regions(out, dist);
+    return out;
+}
+
+}  // namespace
+}  // namespace smi
+
+extern "C" int smi_region_group(const int32_t *pos, const uint8_t *has_pos, const uint8_t *reverse, int32_t n,
+                                int32_t max_dist, int keep_data_end, int32_t *region, int32_t *n_done) {
+    if (n < 0 || max_dist <= 0 || !n_done || (n && (!pos || !has_pos || !reverse || !region))) {
+        set_error("smi_region_group: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    std::vector<Rec> data;
+    for (int i = 0; i < n; i++) {
+        region[i] = -1;
+        if (has_pos[i]) data.push_back(Rec{pos[i], i, (int)data.size(), reverse[i] != 0});
+    }
+    std::stable_sort(data.begin(), data.end(), [](const Rec &a, const Rec &b) { return a.pos < b.pos; });
+    std::vector<const Rec *> fwd, rev;
+    for (const Rec &r : data) (r.rev ? rev : fwd).push_back(&r);
+    std::vector<Region> all = chain_strand(fwd, max_dist), rv = chain_strand(rev, max_dist);
+    all.insert(all.end(), rv.begin(), rv.end());
+    sort_by_center(all);
+    int last_index = n - 1;
+    if (keep_data_end && !all.empty() && !data.empty()) {  // L171-184
+        const int most_right = data.back().pos;
+        while (!all.empty() && all.back().center() > most_right - 3 * max_dist) all.pop_back();
+        if (!all.empty()) {
+            last_index = 0;
+            for (const Rec *r : all.back().reads) last_index = std::max(last_index, r->index);
+            last_index = std::max(last_index, n / 3);
+        }
+    }
+    for (size_t k = 0; k < all.size(); k++)
+        for (const Rec *r : all[k].reads) region[r->read] = (int32_t)k;
+    *n_done = last_index + 1;
+    return SMI_OK;
+}
+
+extern "C" int smi_ref_position_at_read_position(const uint32_t *cigar, int32_t n_cigar, int32_t alignment_start,
+                                                 int32_t position, int32_t *out) {
+    if (!out || n_cigar < 0 || (n_cigar && !cigar)) {
+        set_error("smi_ref_position_at_read_position: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    if (position == 0) return 0;
+    int last_ref_end = 1, last_read_end = 1, read_at = 1, ref_at = alignment_start;
+    for (int i = 0; i < n_cigar; i++) {
+        const uint32_t op = cigar[i] & 15u;
+        const int len = (int)(cigar[i] >> 4);
+        switch (op) {
+        case 1: case 4: read_at += len; break;  // I, S
+        case 2: case 3: ref_at += len; break;   // D, N
+        case 0: case 7: case 8: {               // M, =, X: an alignment block
+            const int block_read = read_at, block_ref = ref_at;
+            read_at += len;
+            ref_at += len;
+            if (block_read + len - 1 < position) {
+                last_ref_end = block_ref + len - 1;
+                last_read_end = block_read + len - 1;
+                break;
+            }
+            *out = position < block_read ? block_ref - std::abs(block_ref - last_ref_end) / 2 : block_ref + position - block_read;
+            return 1;
+        }
+        default: break;  // H, P
+        }
+    }
+    if (position - last_read_end < 300) {
+        *out = last_ref_end;
+        return 1;
+    }
+    return 0;
+}

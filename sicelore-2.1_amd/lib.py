@@ -50,6 +50,7 @@ EXPORTS = [
     "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
+    "smi_region_group", "smi_ref_position_at_read_position",
 ]
 
 
@@ -102,6 +103,8 @@ def load_library():
     lib.smi_chimera_fragment_name.argtypes = [ctypes.c_char_p, vp, ci, ctypes.c_char_p, sz]
     lib.smi_umi_cluster_default_config.argtypes = [vp]
     lib.smi_umi_cluster_groups.argtypes = [vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp, ci]
+    lib.smi_region_group.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ci, vp, vp]
+    lib.smi_ref_position_at_read_position.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ctypes.c_char_p, sz]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
@@ -194,6 +197,32 @@ def umi_cluster_groups(dist, mat_off, group_off, mean_qv, cfg=None, n_threads=1)
     if rc != 0:
         raise SmiError(f"smi_umi_cluster_groups error {rc}: {lib.smi_last_error().decode()}")
     return out[:n_reads], sk[:n_reads].astype(bool)
+
+
+def region_group(pos, reverse, max_dist=500, keep_data_end=False):
+    """smi_region_group; pos: sequence with None for reads without a clustering position -> (region list, n_done)"""
+    lib = load_library()
+    n = len(pos)
+    p = np.array([0 if v is None else v for v in pos], dtype=np.int32)
+    h = np.array([v is not None for v in pos], dtype=np.uint8)
+    r = np.ascontiguousarray(np.asarray(reverse, dtype=bool), dtype=np.uint8)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    nd = ctypes.c_int32(0)
+    rc = lib.smi_region_group(_ptr(p), _ptr(h), _ptr(r), n, int(max_dist), int(keep_data_end), _ptr(out), ctypes.byref(nd))
+    if rc != 0:
+        raise SmiError(f"smi_region_group error {rc}: {lib.smi_last_error().decode()}")
+    return out[:n].tolist(), nd.value
+
+
+def ref_position_at_read_position(cigar, alignment_start, position):
+    """cigar: [(op char, length)] -> reference position or None"""
+    lib = load_library()
+    c = np.array([(ln << 4) | "MIDNSHP=X".index(op) for op, ln in cigar], dtype=np.uint32)
+    out = ctypes.c_int32(0)
+    rc = lib.smi_ref_position_at_read_position(_ptr(c), c.size, int(alignment_start), int(position), ctypes.byref(out))
+    if rc < 0:
+        raise SmiError(f"smi_ref_position_at_read_position error {rc}: {lib.smi_last_error().decode()}")
+    return out.value if rc == 1 else None
 
 
 class ChimeraConfig(ctypes.Structure):

@@ -1,0 +1,85 @@
+"""Genomic-region grouping (ReadGrouper) and the read->reference position helper: oracle == independent Python model
+(== product, below)."""
+import numpy as np
+import pytest
+
+import pymodel_group as pg
+
+
+def make_chunk(rng, n, n_loci, spread=200, far_frac=0.05):
+    loci = np.sort(rng.integers(10_000, 10_000 + 4000 * n_loci, n_loci))
+    pos, rev = [], []
+    for _ in range(n):
+        l = int(loci[rng.integers(0, n_loci)])
+        p = l + int(rng.normal(0, spread))
+        if rng.random() < far_frac:
+            p += int(rng.integers(-3000, 3000))
+        pos.append(None if rng.random() < 0.03 else p)
+        rev.append(bool(rng.random() < 0.5))
+    order = np.argsort([(-1 if p is None else p) for p in pos], kind="stable")  # BAM order ~ coordinate order
+    return [pos[i] for i in order], [rev[i] for i in order]
+
+
+def canon(region):
+    """region ids -> partition (set of frozensets), so that two numberings compare equal"""
+    groups = {}
+    for i, r in enumerate(region):
+        if r >= 0:
+            groups.setdefault(r, set()).add(i)
+    return {frozenset(g) for g in groups.values()}
+
+
+def check(sor, pos, rev, **kw):
+    r_o, done_o = sor.region_group(pos, rev, **kw)
+    r_m, done_m = pg.group_sams(pos, rev, **{("d" if k == "max_dist" else k): v for k, v in kw.items()})
+    assert r_o == r_m and done_o == done_m
+    from sicelore_amd import lib as libmod
+
+    r_p, done_p = libmod.region_group(pos, rev, **kw)
+    assert r_p == r_o and done_p == done_o
+    return r_o, done_o
+
+
+def test_simple_chains(sor, pkg):
+    # forward strand: one chain of 5 reads, a gap, one chain of 4 reads; the first read after a gap is never added
+    pos = [100, 150, 220, 300, 390, 2000, 2050, 2100, 2150]
+    r, done = check(sor, pos, [False] * 9)
+    assert canon(r) == {frozenset({0, 1, 2, 3, 4}), frozenset({6, 7, 8})} and r[5] == -1 and done == 9
+    # strands are grouped separately
+    r, _ = check(sor, pos[:5] * 2, [False] * 5 + [True] * 5)
+    assert canon(r) == {frozenset(range(5)), frozenset(range(5, 10))}
+    assert check(sor, [], [])[0] == [] and check(sor, [5], [False])[0] == [-1]
+
+
+def test_random_chunks(sor, pkg):
+    rng = np.random.default_rng(31)
+    n_regions = 0
+    for trial in range(60):
+        n = int(rng.integers(2, 400))
+        pos, rev = make_chunk(rng, n, int(rng.integers(1, 12)), spread=int(rng.choice([50, 200, 450])),
+                              far_frac=float(rng.choice([0.0, 0.05, 0.2])))
+        r, done = check(sor, pos, rev, keep_data_end=bool(trial % 2))
+        n_regions += len(canon(r))
+        assert 1 <= done <= n
+    assert n_regions > 200
+
+
+def test_reference_position_at_read_position(sor, pkg):
+    from sicelore_amd import lib as libmod
+
+    cig = [("S", 30), ("M", 100), ("N", 500), ("M", 50), ("I", 3), ("M", 20), ("D", 2), ("M", 40), ("S", 10)]
+    for position in (0, 1, 30, 31, 130, 131, 180, 181, 183, 184, 203, 204, 243, 244, 253, 400, 542, 543, 544, 900):
+        exp = pg.ref_position_at_read_position(cig, 1000, position)
+        assert sor.ref_position_at_read_position(cig, 1000, position) == exp
+        assert libmod.ref_position_at_read_position(cig, 1000, position) == exp
+    assert pg.ref_position_at_read_position(cig, 1000, 31) == 1000
+    assert pg.ref_position_at_read_position(cig, 1000, 131) == 1600  # first base after the 500-base skip
+    assert pg.ref_position_at_read_position(cig, 1000, 10) == 1000 - abs(1000 - 1) // 2  # before the first block
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        cig = [("MIDNS=X"[int(rng.integers(0, 7))], int(rng.integers(1, 80))) for _ in range(int(rng.integers(1, 9)))]
+        position = int(rng.integers(0, 500))
+        start = int(rng.integers(1, 10_000))
+        exp = pg.ref_position_at_read_position(cig, start, position)
+        assert sor.ref_position_at_read_position(cig, start, position) == exp
+        assert libmod.ref_position_at_read_position(cig, start, position) == exp
