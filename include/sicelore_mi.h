@@ -56,6 +56,7 @@ typedef struct {
     uint32_t flags;
 } smi_bc_window;
 #define SMI_WIN_VALID 1u
+#define SMI_WIN_5P 2u /* the record is a 25-base 5' window (set by smi_scan_device in 5' mode; informational) */
 #define SMI_WIN_BASES_3P 24
 #define SMI_WIN_BASES_5P 25
 
@@ -165,6 +166,9 @@ typedef struct {
     int32_t min_mean_read_qv;       /* :57  8 */
     int32_t adapter_len;            /* 10 (pass 2, "CTTCCGATCT") or 22 (pass 1, complete adapter), Parser.java:L135 */
     uint32_t adapter4[22];          /* 4-bit codes of the adapter */
+    int32_t five_prime;             /* 1: 5' barcoding, PolyATadapterAnalyzer_5pBCUMI.search (PolyATadapterAnalyzer_5pBCUMI.java:L43-76) */
+    int32_t dont_search_polya;      /* 5' only: --noPolyARequired (dontSearchPolyAFor5pBarcoding) */
+    int32_t adapter_search_window;  /* 5' only: AdapterSearchWindow, config.xml:134 (110) */
 } smi_scan_config;
 
 typedef struct {
@@ -183,13 +187,17 @@ typedef struct {
 
 /* fills cfg with the shipped config.xml values; pass = 1 (complete adapter) or 2 (short adapter) */
 int smi_scan_default_config(int pass, smi_scan_config *cfg);
+/* the same for 5' barcoding: fiveprimeadapter_for5pBarcoding (config.xml:122-135), max_mismatches =
+ * maxNeedlemanMismatches + 1 (Parser.java:L99), window 110 */
+int smi_scan_default_config_5p(int pass, int dont_search_polya, smi_scan_config *cfg);
 
 /* ASCII reads (concatenated, read i = [offsets[i], offsets[i+1])) -> ends / lengths (+ right-aligned tail qualities
- * [n][SMI_END_BASES] and sum of (q-33) per read when quals != NULL).  The packing half of FastqRecordExt /
+ * [n][SMI_END_BASES] and sum of (q-33) per read when quals != NULL; with five_prime the FIRST SMI_END_BASES qualities,
+ * left-aligned, because the pass-1 filter then reads positions near the read start).  The packing half of FastqRecordExt /
  * NucleicAcidOneBytePerBase construction (PolyATSearcher.java:L178-181). */
 int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets,
-                         size_t n, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail, uint32_t *d_qsum,
-                         void *stream);
+                         size_t n, int five_prime, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail,
+                         uint32_t *d_qsum, void *stream);
 
 /* d_qtail / d_qsum may be NULL (pass 2); d_windows may be NULL.  windows[i] is the smi_bc_window of read i (valid flag
  * clear when no adapter was found), ready for smi_bc_match_device. */

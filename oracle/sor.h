@@ -98,6 +98,9 @@ uint64_t sor_finalize_flag(uint64_t flags);
 int sor_find_polyt(const uint8_t *seq4, int n, int minlen, float minfrac, int window, int *begin1, int *end1);
 int sor_scan_read_3p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
                      const sor_scan_params *par, sor_scan_result *out);
+/* 5' barcoding (PolyATadapterAnalyzer_5pBCUMI): max_mm = maxNeedlemanMismatches + 1, window = AdapterSearchWindow */
+int sor_scan_read_5p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
+                     const sor_scan_params *par, int window, int dont_search_polya, sor_scan_result *out);
 int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offsets, size_t n, const char *adapter,
                       int max_mm, const sor_scan_params *par, sor_scan_result *out, int32_t *status, int n_threads);
 int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,

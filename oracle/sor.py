@@ -181,6 +181,18 @@ def scan_read_3p(read, qual, adapter, max_mm=3, params=None):
     return rc, r[0]
 
 
+def scan_read_5p(read, qual, adapter, max_mm=4, params=None, window=110, dont_search_polya=True):
+    """5' barcoding; max_mm = maxNeedlemanMismatches + 1 (Parser.java:L99)"""
+    L = _scan_sigs()
+    L.sor_scan_read_5p.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    p = default_scan_params() if params is None else params
+    r = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
+    rc = L.sor_scan_read_5p(read.encode(), qual.encode() if qual is not None else None, len(read), adapter.encode(),
+                            max_mm, p.ctypes.data, window, int(dont_search_polya), r.ctypes.data)
+    return rc, r[0]
+
+
 def scan_batch_3p(reads_ascii, quals_ascii, offsets, adapter, max_mm=3, params=None, n_threads=1):
     """reads_ascii / quals_ascii: uint8 arrays (concatenated), offsets: uint64 [n+1]"""
     L = _scan_sigs()

@@ -312,6 +312,128 @@ static int scan_read_3p_core(const char *read, const char *qual, int len, const 
     return 0;
 }
 
+/* PolyATadapterAnalyzer_5pBCUMI.search (FJ!nanoporereadscanner/analyzers/PolyATadapterAnalyzer_5pBCUMI.java:L43-76)
+ * + PolyATadapterAnalyzerBase.analyze for scantype != THREEP_BARCODE (L145-221) + Adapterresult.setAdapterMatch
+ * (ReadScanResult.java:L449-450: scan coordinates are kept as they are) + the pass-1 filter, which for 5' reads the
+ * same quality positions AE-16 .. AE-1 (UsedCellBCListGenerator.java:L201).
+ * max_mm: the caller passes maxNeedlemanMismatches + 1 as Parser.processOneRecord does (Parser.java:L99).
+ * window = AdapterSearchWindow (config.xml:134, 110); dont_search_polya = --noPolyARequired. */
+int sor_scan_read_5p(const char *read, const char *qual, int len, const char *adapter, int max_mm,
+                     const sor_scan_params *par, int window, int dont_search_polya, sor_scan_result *out) {
+    memset(out, 0, sizeof(*out));
+    if (len < par->min_read_length) {
+        out->flags = SOR_F_READ_TOO_SHORT | SOR_F_FAILED;
+        return 0;
+    }
+    int ad_len = (int)strlen(adapter);
+    uint8_t ad[NW_MAX];
+    if (ad_len > NW_MAX) return -1;
+    for (int i = 0; i < ad_len; i++) ad[i] = (uint8_t)enc4((unsigned char)adapter[i]);
+    int fb = 0, fe = 0, rb = 0, re = 0, has_f = 0, has_r = 0;
+    uint8_t buf[512];
+    if (!dont_search_polya) { /* searchpolyA L109-121 */
+        const int sub_n = par->window_polya + par->polya_len + 10;
+        if (len < sub_n || sub_n > 512) return -1;
+        for (int i = 0; i < sub_n; i++) buf[i] = (uint8_t)enc4((unsigned char)read[i]);
+        has_f = sor_find_polyt(buf, sub_n, par->polya_len, par->polya_frac, par->window_polya, &fb, &fe) == 1;
+        for (int i = 0; i < sub_n; i++) buf[i] = (uint8_t)sor_fourbit_complement(enc4((unsigned char)read[len - 1 - i]));
+        has_r = sor_find_polyt(buf, sub_n, par->polya_len, par->polya_frac, par->window_polya, &rb, &re) == 1;
+        if (!has_f && !has_r)
+            out->flags |= SOR_F_POLY_A_NOT_FOUND;
+        else if (has_f && !has_r)
+            out->flags |= SOR_F_POLY_T_5P;
+        else if (!has_f && has_r)
+            out->flags |= SOR_F_POLY_A_3P;
+        else
+            out->flags |= SOR_F_POLY_T_5P_POLY_A_3P;
+    }
+    /* L51-68: the 3' end is scanned when a polyT was found at the 5' end (the read is the reverse strand), the 5' end when
+     * a polyA was found at the 3' end */
+    const int end_n = window + ad_len + max_mm + 5;
+    if (len < end_n || end_n > 512) return -1; /* String.substring would throw */
+    uint8_t five[512], three[512];
+    for (int i = 0; i < end_n; i++) five[i] = (uint8_t)enc4((unsigned char)read[i]);
+    for (int i = 0; i < end_n; i++) three[i] = (uint8_t)sor_fourbit_complement(enc4((unsigned char)read[len - 1 - i]));
+    scan_rslt sf, sr;
+    const int scan_rev = has_f || dont_search_polya, scan_fwd = has_r || dont_search_polya;
+    if (scan_rev) scan_adapter(three, end_n, 1, window, ad, ad_len, &sr);
+    if (scan_fwd) scan_adapter(five, end_n, 1, window, ad, ad_len, &sf);
+    out->n_cand_fwd = scan_fwd ? sf.n_all : -1;
+    out->n_cand_rev = scan_rev ? sr.n_all : -1;
+    int use_fwd = -1;
+    const int f_nonempty = scan_fwd && sf.n_all > 0, r_nonempty = scan_rev && sr.n_all > 0;
+    if (scan_fwd || scan_rev) {
+        if (f_nonempty && r_nonempty) {
+            if (fabsf(sf.best - sr.best) < 2.0f)
+                out->flags |= SOR_F_ADAPTER_5P_AND_3P;
+            else {
+                out->flags |= SOR_F_ADAPTER_SELECTED_DESP_BOTH;
+                use_fwd = sf.best < sr.best ? 1 : 0;
+            }
+        } else if (f_nonempty)
+            use_fwd = 1;
+        else if (r_nonempty)
+            use_fwd = 0;
+    }
+    if (use_fwd < 0) {
+        out->flags |= SOR_F_FAILED;
+        return 0;
+    }
+    if (!dont_search_polya) { /* L169-172: 5' protocol takes the polyA of the OTHER end */
+        const int pe = use_fwd ? re : fe, pb = use_fwd ? rb : fb;
+        out->polya_start = len - (pe - 1);
+        out->polya_end = len - (pb - 1);
+    }
+    const scan_rslt *s = use_fwd ? &sf : &sr;
+    const uint8_t *test = use_fwd ? five : three; /* adapterscanResult.scannedSequence L193 */
+    adapter_match best;
+    int have = 0;
+    if (s->n_best == 1) {
+        create_needleman_match(s->best_pos[0], test, ad, ad_len, max_mm, &best);
+        have = best.ok;
+    } else {
+        float best_key = 0;
+        for (int i = 0; i < s->n_best; i++) {
+            adapter_match m;
+            create_needleman_match(s->best_pos[i], test, ad, ad_len, max_mm, &m);
+            if (!m.ok) continue;
+            float key = indels_mismatches_end_of_read(&m.aln, 5);
+            if (!have || key < best_key) {
+                best = m;
+                best_key = key;
+                have = 1;
+            }
+        }
+    }
+    if (!have) {
+        out->flags |= SOR_F_FAILED;
+        return 0;
+    }
+    out->adapter_found = 1;
+    out->adapter_start = best.start; /* ReadScanResult.java:L449-450 */
+    out->adapter_end = best.end;
+    out->scan_end = best.end;
+    out->adapter_nmis = best.cnt.nmis;
+    out->flags |= use_fwd ? SOR_F_ADAPTER_5P : SOR_F_ADAPTER_3P;
+    out->flags |= use_fwd ? SOR_F_PASSED_FWD : SOR_F_PASSED_REV; /* L206-213 with scantype != THREEP */
+    out->reverse = use_fwd ? 0 : 1;
+    out->pass1_ok = 0;
+    if (qual) {
+        float end_err = indels_mismatches_end_of_read(&best.aln, par->min_adapter_3p_matches);
+        if (end_err == 0.0f) {
+            float q_bc = 0, q_read = 0;
+            if (mean_qv(qual, len, out->adapter_end - 16, out->adapter_end - 1, &q_bc)) return -1;
+            out->mean_qv_bc = q_bc;
+            if (!(q_bc < (float)par->min_mean_bc_qv)) {
+                if (mean_qv(qual, len, 1, len, &q_read)) return -1;
+                out->mean_qv_read = q_read;
+                out->pass1_ok = !(q_read < (float)par->min_mean_read_qv);
+            }
+        }
+    }
+    return 0;
+}
+
 /* exposed for unit tests */
 int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
                    int *ins, int *del, int *sub, float *end5) {

@@ -522,7 +522,10 @@ __global__ void k_hist_windows(const smi_bc_window *__restrict__ win, const smi_
         if (!scan[i].pass1_ok) continue;
         const smi_bc_window w = win[i];
         if (!(w.flags & SMI_WIN_VALID)) continue;
-        const uint32_t k = make_key(w.bases, w.nmask, 0, false).key;
+        // 3': reverse complement of stranded[AE-16 .. AE-1]; 5': stranded[AE+1 .. AE+16] (UsedCellBCListGenerator.java:L210-221)
+        const OffsetKey ok = make_key(w.bases, w.nmask, 0, (w.flags & SMI_WIN_5P) != 0);
+        if (!ok.usable) continue;  // an N poisons the 5' key: never a whitelist member
+        const uint32_t k = ok.key;
         if (!bit_of(P.l0, k >> kG0)) continue;
         if (!bit_of(P.l1, k >> kG1)) continue;
         const uint32_t blk = k >> 8;

@@ -355,15 +355,25 @@ int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, con
     return launch_split_offsets(ctx, d_chim, d_offsets, n, d_scratch, d_n_frag, d_frag_offsets, d_frag_src, (hipStream_t)stream);
 }
 
+int smi_scan_default_config_5p(int pass, int dont_search_polya, smi_scan_config *cfg) {
+    if (int rc = smi_scan_default_config(pass, cfg)) return rc;  // same adapter sequences (config.xml:124,126)
+    cfg->max_mismatches += 1;                                      // Parser.java:L99
+    cfg->five_prime = 1;
+    cfg->dont_search_polya = dont_search_polya ? 1 : 0;
+    cfg->adapter_search_window = 110;
+    return SMI_OK;
+}
+
 int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets,
-                         size_t n, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail, uint32_t *d_qsum,
-                         void *stream) {
+                         size_t n, int five_prime, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail,
+                         uint32_t *d_qsum, void *stream) {
     if (int rc = bind(ctx)) return rc;
     if (n && (!d_reads || !d_offsets || !d_ends || !d_read_len || (d_quals && (!d_qtail || !d_qsum)))) {
         set_error("smi_pack_ends_device: null buffer");
         return SMI_ERR_INVALID;
     }
-    return launch_pack_ends(ctx, d_reads, d_quals, d_offsets, n, d_ends, d_read_len, d_qtail, d_qsum, (hipStream_t)stream);
+    return launch_pack_ends(ctx, d_reads, d_quals, d_offsets, n, five_prime, d_ends, d_read_len, d_qtail, d_qsum,
+                            (hipStream_t)stream);
 }
 
 int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_len, const uint8_t *d_qtail,
@@ -381,6 +391,11 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
     if (cfg->polya_len < 5 || cfg->polya_len > 30 || cfg->window_polya + cfg->polya_len + 10 > 175 ||
         cfg->window_polya < 1) {
         set_error("smi_scan_device: polyA window does not fit the 175-base scan region");
+        return SMI_ERR_INVALID;
+    }
+    if (cfg->five_prime && (cfg->adapter_search_window < 1 ||
+                            cfg->adapter_search_window + cfg->adapter_len + cfg->max_mismatches + 5 > 192)) {
+        set_error("smi_scan_device: 5' search window + adapter + mismatches + 5 must fit 192 bases");
         return SMI_ERR_INVALID;
     }
     return launch_scan(ctx, d_ends, d_read_len, d_qtail, d_qsum, n, cfg, d_out, d_windows, (hipStream_t)stream);

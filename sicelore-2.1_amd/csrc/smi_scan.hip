@@ -45,6 +45,9 @@ struct ScanParams {
     int min_bc_qv;       // 8
     int min_read_qv;     // 8
     uint32_t adapter4[22];  // 4-bit codes of the adapter, padded
+    int five_prime;      // 5' barcoding: PolyATadapterAnalyzer_5pBCUMI.search
+    int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
+    int window5;         // AdapterSearchWindow (110)
 };
 
 // ---- LDS plane access -----------------------------------------------------------------------------------------
@@ -222,17 +225,21 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         int pb = 0, pe = 0;
-        const bool has_t = active && long_enough && find_polyt(planes, tid, P, pb, pe);
+        const bool has_t = active && long_enough && !(P.five_prime && P.dont_polya) && find_polyt(planes, tid, P, pb, pe);
         uint64_t am[3] = {0, 0, 0}, tm[2] = {0, 0};
-        if (has_t) {
-            // scan positions 1 .. min(pe - AD, pe - 12)  (seqTilPolyAend has length pe; L49-61, AdapterTSOanalyzer L87)
-            const int last = min(pe - AD, pe - 12);
+        // 5' barcoding scans an end when the polyT was found at the OTHER end (or no polyA is asked for):
+        // PolyATadapterAnalyzer_5pBCUMI.java:L51-68
+        const bool scan5 = P.five_prime && active && long_enough && (P.dont_polya || __shfl_xor((int)has_t, 1));
+        if (P.five_prime ? scan5 : has_t) {
+            // 3': positions 1 .. min(pe - AD, pe - 12)  (seqTilPolyAend has length pe; L49-61, AdapterTSOanalyzer L87)
+            // 5': positions 1 .. AdapterSearchWindow of the first window + AD + maxMM + 5 bases
+            const int last = P.five_prime ? P.window5 : min(pe - AD, pe - 12);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
                 am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return P.adapter4[i]; }), last - ch * 64);
         }
-        if (active && long_enough) {
-            // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325)
+        if (active && long_enough && !P.five_prime) {
+            // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
 #pragma unroll
             for (int ch = 0; ch < 2; ch++)
                 tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
@@ -368,11 +375,13 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         if (!long_enough) {
             flags |= SMI_F_READ_TOO_SHORT | SMI_F_FAILED;
         } else {
-            flags |= (!f_has && !r_has) ? SMI_F_POLY_A_NOT_FOUND
-                     : (f_has && !r_has) ? SMI_F_POLY_T_5P
-                     : (!f_has && r_has) ? SMI_F_POLY_A_3P
-                                         : SMI_F_POLY_T_5P_POLY_A_3P;
-            const bool f_ne = f_has && f_n > 0, r_ne = r_has && r_n > 0;
+            if (!(P.five_prime && P.dont_polya))
+                flags |= (!f_has && !r_has) ? SMI_F_POLY_A_NOT_FOUND
+                         : (f_has && !r_has) ? SMI_F_POLY_T_5P
+                         : (!f_has && r_has) ? SMI_F_POLY_A_3P
+                                             : SMI_F_POLY_T_5P_POLY_A_3P;
+            // an end that was not scanned has no candidates, so "scan result present and not empty" is n > 0
+            const bool f_ne = f_n > 0, r_ne = r_n > 0;
             if (f_ne && r_ne) {
                 if (fabsf(__fsub_rn(f_best, r_best)) < 2.0f)
                     flags |= SMI_F_ADAPTER_5P_AND_3P;
@@ -406,42 +415,59 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         win.bases = 0;
         win.nmask = 0;
         win.flags = 0;
+        const int o_pe = __shfl_xor(pe, 1), o_pb = __shfl_xor(pb, 1);
         if (chosen) {
-            // polyA coordinates are set as soon as a side is chosen (analyze L169-171)
-            res.polya_start = len - (pe - 1);
-            res.polya_end = len - (pb - 1);
+            // polyA coordinates are set as soon as a side is chosen (analyze L169-171); 5' barcoding takes the polyT
+            // result of the other end, and none with --noPolyARequired
+            if (!P.five_prime) {
+                res.polya_start = len - (pe - 1);
+                res.polya_end = len - (pb - 1);
+            } else if (!P.dont_polya) {
+                res.polya_start = len - (o_pe - 1);
+                res.polya_end = len - (o_pb - 1);
+            }
             if (!a_have) {
                 res.flags |= SMI_F_FAILED;  // L217
             } else {
                 const int s_end = a_pos + AD - 1 + a_ins - a_del;  // createNeedlemanMatch L251
                 res.found = 1;
                 res.scan_end = (int16_t)s_end;
-                res.adapter_start = len - (a_pos - 1);  // ReadScanResult.java:L446-447
-                res.adapter_end = len - (s_end - 1);
                 res.adapter_nmis = (int16_t)a_nmis;
-                res.reverse = use_fwd ? 1 : 0;
-                res.flags |= use_fwd ? (SMI_F_ADAPTER_5P | SMI_F_PASSED_REV) : (SMI_F_ADAPTER_3P | SMI_F_PASSED_FWD);
-                // barcode window: stranded[AE-22 .. AE+1] = reverse complement of scan[s_end-1 .. s_end+22]
-                const int hi_sp = s_end + 22, lo_sp = s_end - 1;
+                if (!P.five_prime) {
+                    res.adapter_start = len - (a_pos - 1);  // ReadScanResult.java:L446-447
+                    res.adapter_end = len - (s_end - 1);
+                    res.reverse = use_fwd ? 1 : 0;
+                    res.flags |= use_fwd ? (SMI_F_ADAPTER_5P | SMI_F_PASSED_REV) : (SMI_F_ADAPTER_3P | SMI_F_PASSED_FWD);
+                } else {
+                    res.adapter_start = a_pos;  // L449-450: scan coordinates = stranded coordinates
+                    res.adapter_end = s_end;
+                    res.reverse = use_fwd ? 0 : 1;
+                    res.flags |= use_fwd ? (SMI_F_ADAPTER_5P | SMI_F_PASSED_FWD) : (SMI_F_ADAPTER_3P | SMI_F_PASSED_REV);
+                }
+                // barcode window.  3': stranded[AE-22 .. AE+1] = reverse complement of scan[s_end-1 .. s_end+22];
+                // 5': stranded[AE-1 .. AE+23] = scan[s_end-1 .. s_end+23] as it stands (Parser.java:L205-221)
+                const int n_win = P.five_prime ? SMI_WIN_BASES_5P : SMI_WIN_BASES_3P;
+                const int hi_sp = s_end - 2 + n_win, lo_sp = s_end - 1;
                 if (lo_sp >= 1 && hi_sp <= len && hi_sp <= kEndBases) {
                     uint64_t bases = 0;
                     uint32_t nmask = 0;
-#pragma unroll 4
-                    for (int j = 0; j < 24; j++) {
-                        const int bit = hi_sp - j - 1;  // scan position hi_sp - j, 0-based bit
+#pragma unroll 5
+                    for (int j = 0; j < 25; j++) {
+                        if (j >= n_win) break;
+                        const int bit = P.five_prime ? lo_sp + j - 1 : hi_sp - j - 1;  // 0-based scan index of window base j
                         const uint32_t a = get32(planes + 0 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t g = get32(planes + 1 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t c = get32(planes + 2 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t t = get32(planes + 3 * kLdsWords * kBlock, tid, bit) & 1u;
-                        // complement: A<->T, G<->C ; 2-bit code A0 G1 C2 T3
                         const uint32_t single = (a + g + c + t) == 1u;
-                        const uint32_t code = t ? 0u : (c ? 1u : (g ? 2u : 3u));
+                        // 2-bit code A0 G1 C2 T3; 3' takes the complement (A<->T, G<->C)
+                        const uint32_t code = P.five_prime ? (t ? 3u : (c ? 2u : (g ? 1u : 0u))) : (t ? 0u : (c ? 1u : (g ? 2u : 3u)));
                         bases = (bases << 2) | (single ? code : 0u);
                         nmask |= (single ? 0u : 1u) << j;
                     }
                     win.bases = bases;
                     win.nmask = nmask;
-                    win.flags = SMI_WIN_VALID;
+                    win.flags = SMI_WIN_VALID | (P.five_prime ? SMI_WIN_5P : 0u);
                 }
                 // pass-1 quality filter (short-circuit && chain; the UNSTRANDED quality string is indexed with
                 // stranded coordinates, UsedCellBCListGenerator.java:L201)
@@ -450,7 +476,8 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                     int sum = 0;
                     bool in_range = ae - 16 >= 1;
                     for (int p = ae - 16; p <= ae - 1; p++) {
-                        const int idx = kEndBases - 1 - (len - p);  // qtail is right-aligned
+                        // 3': the last kEndBases qualities, right-aligned; 5': the first kEndBases, left-aligned
+                        const int idx = P.five_prime ? p - 1 : kEndBases - 1 - (len - p);
                         if (idx < 0 || idx >= kEndBases) {
                             in_range = false;
                             break;
@@ -547,6 +574,9 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     P.min_read_qv = cfg->min_mean_read_qv;
     const int ad = cfg->adapter_len;
     for (int i = 0; i < 22; i++) P.adapter4[i] = i < ad ? cfg->adapter4[i] : 0u;
+    P.five_prime = cfg->five_prime;
+    P.dont_polya = cfg->dont_search_polya;
+    P.window5 = cfg->adapter_search_window;
     const size_t n_ends = 2 * n;
     const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 16);
     if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;
@@ -595,7 +625,7 @@ __device__ __forceinline__ uint32_t comp4(uint32_t b) {
 }
 
 __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ reads, const uint8_t *__restrict__ quals,
-                                                   const uint64_t *__restrict__ offsets, size_t n,
+                                                   const uint64_t *__restrict__ offsets, size_t n, int head_quals,
                                                    uint32_t *__restrict__ ends, int32_t *__restrict__ read_len,
                                                    uint8_t *__restrict__ qtail, uint32_t *__restrict__ qsum) {
     const int lane = threadIdx.x & 63;
@@ -613,8 +643,8 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
             if (lane == 0) qsum[r] = s;
             for (int i = lane; i < kEndBases; i += 64) {
-                const int64_t p = len - kEndBases + i;  // right-aligned
-                qtail[r * kEndBases + i] = p >= 0 ? quals[beg + p] : (uint8_t)33;
+                const int64_t p = head_quals ? i : len - kEndBases + i;  // 5': first bases, left-aligned; 3': last, right-aligned
+                qtail[r * kEndBases + i] = (p >= 0 && p < len) ? quals[beg + p] : (uint8_t)33;
             }
         }
         for (int side = 0; side < 2; side++) {
@@ -642,10 +672,11 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
 }
 
 int launch_pack_ends(smi_ctx *, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, size_t n,
-                     uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
+                     int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
     if (!n) return SMI_OK;
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_quals, d_offsets, n, d_ends, d_len, d_qtail, d_qsum);
+    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_quals, d_offsets, n, head_quals, d_ends, d_len, d_qtail,
+                       d_qsum);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

@@ -24,7 +24,8 @@ SCAN_RESULT_DTYPE = np.dtype(
 SCAN_CONFIG_DTYPE = np.dtype(
     [("min_read_length", "<i4"), ("polya_len", "<i4"), ("polya_frac", "<f4"), ("window_polya", "<i4"),
      ("max_mismatches", "<i4"), ("min_adapter_3p_matches", "<i4"), ("min_mean_bc_qv", "<i4"),
-     ("min_mean_read_qv", "<i4"), ("adapter_len", "<i4"), ("adapter4", "<u4", (22,))]
+     ("min_mean_read_qv", "<i4"), ("adapter_len", "<i4"), ("adapter4", "<u4", (22,)), ("five_prime", "<i4"),
+     ("dont_search_polya", "<i4"), ("adapter_search_window", "<i4")]
 )
 CHIMERA_RESULT_DTYPE = np.dtype([("pos", "<i4", (2,)), ("n_split", "u1"), ("reason", "u1", (2,)), ("flags", "u1"),
                                  ("n_matches", "<i4")])
@@ -50,7 +51,7 @@ EXPORTS = [
     "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
-    "smi_region_group", "smi_ref_position_at_read_position",
+    "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p",
 ]
 
 
@@ -87,7 +88,8 @@ def load_library():
     lib.smi_extract_windows_device.argtypes = [vp, vp, vp, vp, sz, ci, vp, vp]
     lib.smi_hist_device.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.smi_scan_default_config.argtypes = [ci, vp]
-    lib.smi_pack_ends_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp, vp, vp]
+    lib.smi_scan_default_config_5p.argtypes = [ci, ci, vp]
+    lib.smi_pack_ends_device.argtypes = [vp, vp, vp, vp, sz, ci, vp, vp, vp, vp, vp]
     lib.smi_scan_device.argtypes = [vp, vp, vp, vp, vp, sz, vp, vp, vp, vp]
     lib.smi_hist_windows_device.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.smi_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
@@ -313,10 +315,16 @@ class Context:
         self._check(self._lib.smi_scan_default_config(int(pass_no), _ptr(cfg)))
         return cfg
 
-    def pack_ends_device(self, d_reads, d_quals, d_offsets, n, d_ends, d_len, d_qtail=None, d_qsum=None, stream=None):
+    def pack_ends_device(self, d_reads, d_quals, d_offsets, n, d_ends, d_len, d_qtail=None, d_qsum=None, stream=None,
+                         five_prime=False):
         self._check(self._lib.smi_pack_ends_device(self._h, _ptr(d_reads), _ptr(d_quals), _ptr(d_offsets), int(n),
-                                                   _ptr(d_ends), _ptr(d_len), _ptr(d_qtail), _ptr(d_qsum),
+                                                   int(five_prime), _ptr(d_ends), _ptr(d_len), _ptr(d_qtail), _ptr(d_qsum),
                                                    _stream_ptr(stream)))
+
+    def scan_config_5p(self, pass_no=2, dont_search_polya=True):
+        cfg = np.zeros(1, dtype=SCAN_CONFIG_DTYPE)
+        self._check(self._lib.smi_scan_default_config_5p(int(pass_no), int(dont_search_polya), _ptr(cfg)))
+        return cfg
 
     def scan_device(self, d_ends, d_len, n, cfg, d_out, d_windows=None, d_qtail=None, d_qsum=None, stream=None):
         """d_ends int32 [28, 2n]; d_len int32 [n]; d_out int32 [n, 8] (32-B records); d_windows int64 [n, 2]"""

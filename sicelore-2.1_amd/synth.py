@@ -303,3 +303,58 @@ def materialize_device(reads, seed=0, chunk=262144):
         buf[(offs[a:b, None] + ar).reshape(-1)] = lut[reads["head"][a:b].long()].reshape(-1)
         buf[(offs[a + 1:b + 1, None] - E + ar).reshape(-1)] = lut[reads["tail"][a:b].long()].reshape(-1)
     return buf, offs
+
+
+# 5' barcoding (Jar/config.xml:124-141): adapter + BC16 + UMI + TSO at the 5' end, polyA + 3' adapter at the other end
+ADAPTER_5P_3PRIME = "AAGCAGTGGTATCAACGCAGAGTAC"
+TSO_5P = "TTTCTTATATGGG"
+
+
+def gen_reads_5p(n, used_keys, seed=6, device=None, err=0.063, frac=(0.4, 0.3, 0.3), n_rate=0.0, max_mid=1500, q_mean=12.0,
+                 umi_len=12):
+    """n synthetic 5'-protocol reads in the layout of gen_reads():
+    read (transcript sense) = CTACACGACGCTCTTCCGATCT + BC16 + UMI + TTTCTTATATGGG + cDNA + polyA(20..60) + rc(3' adapter);
+    half of the reads are reverse-complemented."""
+    device = device or used_keys.device
+    g = _gen(seed, device)
+    E = END_BASES
+    n_cells = used_keys.numel()
+    w = torch.exp(torch.randn(n_cells, generator=g, device=device))
+    cell = torch.multinomial(w, n, replacement=True, generator=g)
+    truth = used_keys.to(device)[cell]
+    bc = keys_to_codes(truth, 16)
+    umi = torch.randint(0, 4, (n, umi_len), generator=g, device=device, dtype=torch.int64)
+    umi_key = (umi << (torch.arange(umi_len - 1, -1, -1, device=device, dtype=torch.int64) * 2)).sum(-1)
+    W = 320
+    ad = _codes(ADAPTER_3P_COMPLETE, device).expand(n, -1)
+    tso = _codes(TSO_5P, device).expand(n, -1)
+    cdna = torch.randint(0, 4, (n, 230), generator=g, device=device, dtype=torch.int64)
+    src5 = torch.cat([ad, bc, umi, tso, cdna], dim=1)
+    out5, _ = _channel(src5, torch.zeros(src5.shape, dtype=torch.bool, device=device), g, err, frac, W)
+    end5 = out5[:, :E]
+    pad = torch.randint(0, 4, (n, 180), generator=g, device=device, dtype=torch.int64)
+    polya = torch.zeros((n, 60), dtype=torch.int64, device=device)
+    ad3 = _rc(_codes(ADAPTER_5P_3PRIME, device)).expand(n, -1)
+    src3 = torch.cat([pad, polya, ad3], dim=1)
+    pa_len = torch.randint(20, 61, (n,), generator=g, device=device)
+    forced = torch.zeros(src3.shape, dtype=torch.bool, device=device)
+    forced[:, 180:240] = torch.arange(60, device=device).unsqueeze(0) < (60 - pa_len).unsqueeze(1)
+    out3, tot3 = _channel(src3, forced, g, err, frac, W)
+    idx = (tot3 - E).clamp(min=0).unsqueeze(1) + torch.arange(E, device=device)
+    end3 = torch.gather(out3, 1, idx.clamp(max=W - 1))
+    if n_rate > 0:
+        end3 = torch.where(torch.rand((n, E), generator=g, device=device) < n_rate, torch.full_like(end3, 4), end3)
+        end5 = torch.where(torch.rand((n, E), generator=g, device=device) < n_rate, torch.full_like(end5, 4), end5)
+    reverse = torch.rand((n,), generator=g, device=device) < 0.5
+
+    def rc4(x):
+        y = torch.flip(x, dims=[1])
+        return torch.where(y > 3, y, 3 - y)
+
+    head = torch.where(reverse.unsqueeze(1), rc4(end3), end5)
+    tail = torch.where(reverse.unsqueeze(1), rc4(end5), end3)
+    q = lambda: (torch.randn((n, E), generator=g, device=device) * 3.0 + q_mean).round().clamp(2, 40).to(torch.uint8) + 33  # noqa: E731
+    mid_len = torch.randint(0, max_mid + 1, (n,), generator=g, device=device)
+    qmid = (torch.randn((n,), generator=g, device=device) * 2.0 + q_mean).round().clamp(2, 40).to(torch.uint8) + 33
+    return {"head": head.to(torch.uint8), "tail": tail.to(torch.uint8), "qhead": q(), "qtail": q(), "qmid": qmid,
+            "mid_len": mid_len, "reverse": reverse, "truth": truth, "umi": umi_key}

@@ -334,3 +334,82 @@ def scan_read_3p(read, qual, adapter, max_mm=3, min_len=200, min_3p=8, min_bc_qv
         out["pass1_ok"] = int(m.end_of_read(min_3p) == 0.0 and not (mean(ae - 16, ae - 1) < min_bc_qv)
                               and not (mean(1, L) < min_read_qv))
     return out
+
+
+def scan_read_5p(read, qual, adapter, max_mm=4, window=110, dont_search_polya=True, min_len=200, min_3p=8, min_bc_qv=8,
+                 min_read_qv=8):
+    """PolyATadapterAnalyzer_5pBCUMI.search L43-76 + analyze for 5' barcoding (scan coordinates kept as they are)"""
+    out = dict(flags=set(), adapter_found=0, pass1_ok=0, polya_start=0, polya_end=0)
+    L = len(read)
+    if L < min_len:
+        out["flags"] |= {"READ_TOO_SHORT", "FAILED"}
+        return out
+    ad = enc(adapter)
+    pf = pr = None
+    if not dont_search_polya:
+        pf, pr = find_polyt(enc(read[:175])), find_polyt(enc(revcomp_str(read[L - 175:])))
+        out["flags"].add("POLY_A_NOT_FOUND" if not pf and not pr else "POLY_T_5P" if pf and not pr else
+                         "POLY_A_3P" if pr and not pf else "POLY_T_5P_POLY_A_3P")
+    n_end = window + len(ad) + max_mm + 5
+    sr = sf = None
+    three = five = None
+    if pf is not None or dont_search_polya:
+        three = enc(revcomp_str(read[L - n_end:]))
+        sr = scan_adapter(three, 1, window, ad)
+    if pr is not None or dont_search_polya:
+        five = enc(read[:n_end])
+        sf = scan_adapter(five, 1, window, ad)
+    use_fwd = None
+    if sf is not None or sr is not None:
+        if sf and sr:
+            if abs(f32(min(sf)) - f32(min(sr))) >= 2.0:
+                out["flags"].add("ADAPTER_SELECTED_DESP_BOTH")
+                use_fwd = not (min(sf) >= min(sr))
+            else:
+                out["flags"].add("ADAPTER_5P_AND_3P")
+        elif sf and not sr:
+            use_fwd = True
+        elif not sf and sr:
+            use_fwd = False
+    if use_fwd is None:
+        out["flags"].add("FAILED")
+        return out
+    if not dont_search_polya:
+        p = pr if use_fwd else pf  # useforward == false selects the FORWARD polyT result for 5' (L170-171)
+        out["polya_start"], out["polya_end"] = L - (p[1] - 1), L - (p[0] - 1)
+    s = sf if use_fwd else sr
+    test = five if use_fwd else three
+    offsets = s[min(s)]
+
+    def create(pos):
+        nm = NeedlemanMatch(needleman(ad, test[pos - 1:pos - 1 + len(ad)]))
+        if nm.nmis > max_mm and not nm.has_3p_matches(6):
+            return None
+        nm.start, nm.end = pos, pos + len(ad) - 1 + nm.ins - nm.dele
+        return nm
+
+    if len(offsets) == 1:
+        m = create(offsets[0])
+        lst = [m] if m else []
+    else:
+        groups = {}
+        for o in offsets:
+            m = create(o)
+            if m:
+                groups.setdefault(float(m.end_of_read(5)), []).append(m)
+        lst = groups[min(groups)] if groups else []
+    if not lst:
+        out["flags"].add("FAILED")
+        return out
+    m = lst[0]
+    out["adapter_found"] = 1
+    out["adapter_start"], out["adapter_end"] = m.start, m.end
+    out["adapter_nmis"] = m.nmis
+    out["reverse"] = 0 if use_fwd else 1
+    out["flags"] |= {"ADAPTER_5P", "PASSED_FWD"} if use_fwd else {"ADAPTER_3P", "PASSED_REV"}
+    if qual is not None:
+        mean = lambda a, b: f32(np.mean([ord(c) - 33 for c in qual[a - 1:b]], dtype=np.float64))  # noqa: E731
+        ae = out["adapter_end"]
+        out["pass1_ok"] = int(m.end_of_read(min_3p) == 0.0 and not (mean(ae - 16, ae - 1) < min_bc_qv)
+                              and not (mean(1, L) < min_read_qv))
+    return out

@@ -119,3 +119,40 @@ def test_scan_then_assign_recovers_barcodes(sor, synth):
             tot += 1
             ok += int(a["bc"]) == int(reads["truth"][i])
     assert tot > 150 and ok / tot > 0.97
+
+
+def _cmp_5p(sor, seq, qual, dont):
+    rc, o = sor.scan_read_5p(seq, qual, AD10, max_mm=4, dont_search_polya=dont)
+    m = pms.scan_read_5p(seq, qual, AD10, max_mm=4, dont_search_polya=dont)
+    assert rc == 0
+    flags = {k for k, b in sor.FLAG_BITS.items() if (int(o["flags"]) >> b) & 1}
+    assert flags == m["flags"], (flags, m["flags"])
+    assert int(o["adapter_found"]) == m["adapter_found"]
+    assert (int(o["polya_start"]), int(o["polya_end"])) == (m["polya_start"], m["polya_end"])
+    if m["adapter_found"]:
+        assert (int(o["adapter_start"]), int(o["adapter_end"]), int(o["adapter_nmis"]), int(o["reverse"])) == \
+            (m["adapter_start"], m["adapter_end"], m["adapter_nmis"], m["reverse"])
+        assert int(o["pass1_ok"]) == m["pass1_ok"]
+    return o
+
+
+@pytest.mark.parametrize("dont", [True, False])
+def test_scan_5p_c_oracle_equals_python_model(sor, synth, dont):
+    wl = synth.make_whitelist(20000, seed=301)
+    used = synth.pick_used(wl, 100, seed=302)
+    reads = synth.gen_reads_5p(120, used, seed=303, n_rate=0.003)
+    n_found = n_rev = n_right = 0
+    for i in range(120):
+        seq, qual = synth.materialize(reads, i)
+        if i % 17 == 0:
+            seq, qual = seq[:180], qual[:180]  # too short
+        o = _cmp_5p(sor, seq, qual, dont)
+        if o["adapter_found"]:
+            n_found += 1
+            n_rev += int(o["reverse"])
+            n_right += int(o["reverse"]) == int(reads["reverse"][i])
+            # the barcode sits right behind the adapter on the stranded read
+            stranded = pms.revcomp_str(seq) if o["reverse"] else seq
+            ae = int(o["adapter_end"])
+            assert 10 <= ae <= 140 and len(stranded[ae:ae + 16]) == 16
+    assert n_found > 80 and 20 < n_rev < n_found - 20 and n_right > 0.95 * n_found

@@ -157,3 +157,60 @@ def test_pass1_histogram(pkg, synth, sor, gpu_ctx):
             ref[j] += 1
     assert ref.sum() > 200
     assert (hist == ref).all()
+
+
+@pytest.mark.parametrize("pass_no,dont", [(2, True), (2, False), (1, True)])
+def test_scan_5p_matches_oracle_and_assigns(pkg, synth, sor, gpu_ctx, pass_no, dont):
+    """5' barcoding: K-PACK (head qualities) -> K-SCAN in 5' mode == oracle, its 25-base windows -> K-BC1 == oracle"""
+    wl = synth.make_whitelist(50_000, seed=231)
+    used = synth.pick_used(wl, 300, seed=232)
+    n = 2500
+    reads = synth.gen_reads_5p(n, used, seed=233 + pass_no, n_rate=0.003, q_mean=14.0)
+    ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
+    d_reads, d_quals = torch.from_numpy(ra.copy()).cuda(), torch.from_numpy(qa.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_ends = torch.zeros((28, 2 * n), dtype=torch.int32, device="cuda")
+    d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_qh = torch.zeros((n, 224), dtype=torch.uint8, device="cuda")
+    d_qsum = torch.zeros(n, dtype=torch.int32, device="cuda")
+    gpu_ctx.pack_ends_device(d_reads, d_quals, d_offs, n, d_ends, d_len, d_qh, d_qsum, five_prime=True)
+    cfg = gpu_ctx.scan_config_5p(pass_no, dont)
+    d_out = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    d_win = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
+    gpu_ctx.scan_device(d_ends, d_len, n, cfg, d_out, d_win, d_qh, d_qsum)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    d_res = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    gpu_ctx.bc_match_device(d_win, d_res, n, max_ed=1, five_prime=True)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(pkg.SCAN_RESULT_DTYPE).reshape(-1)
+    res = d_res.cpu().numpy().view(pkg.BC_RESULT_DTYPE).reshape(-1)
+    bset = sor.BarcodeSet(used.numpy())
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    n_found = n_assigned = n_p1 = n_thrown = 0
+    for i in range(n):
+        seq = bytes(ra[int(offs[i]):int(offs[i + 1])]).decode()
+        qual = bytes(qa[int(offs[i]):int(offs[i + 1])]).decode()
+        rc, e = sor.scan_read_5p(seq, qual, AD[pass_no], max_mm=4, dont_search_polya=dont)
+        if rc != 0:  # the reference throws in getMeanQV (adapter end < 17): flagged, not guessed
+            assert got["reserved"][i] == 1
+            n_thrown += 1
+            continue
+        assert got["reserved"][i] == 0
+        assert int(got["flags"][i]) == int(e["flags"]), (i, hex(int(got["flags"][i])), hex(int(e["flags"])))
+        assert got["found"][i] == e["adapter_found"]
+        assert (got["polya_start"][i], got["polya_end"][i]) == (e["polya_start"], e["polya_end"])
+        if not e["adapter_found"]:
+            assert res["found"][i] == -1
+            continue
+        n_found += 1
+        for f in ("adapter_start", "adapter_end", "scan_end", "adapter_nmis", "reverse", "pass1_ok"):
+            assert int(got[f][i]) == int(e[f]), (i, f)
+        n_p1 += int(e["pass1_ok"])
+        stranded = seq.encode().translate(comp)[::-1] if e["reverse"] else seq.encode()
+        rc2, a = sor.assign_barcode(bset, stranded, int(e["adapter_end"]), max_ed=1, five_prime=True)
+        assert res["found"][i] == rc2, (i, res["found"][i], rc2)
+        if rc2 == 1:
+            n_assigned += 1
+            assert res["bc"][i] == np.uint32(a["bc"]) and res["ed"][i] == a["ed"] and res["ed_sec"][i] == a["ed_sec"]
+            assert res["offset"][i] == a["offset"] and res["ins_minus_del"][i] == a["ins_minus_del"]
+    assert n_found > 0.6 * n and n_assigned > 0.5 * n_found and n_p1 > 0.02 * n and n_thrown < 0.01 * n
