@@ -21,7 +21,7 @@ namespace smi {
 // ---------------------------------------------------------------------------------------------------------
 // pyramid build
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t suffix_index(uint32_t k) { return ((k & 0x3FFFu) << 10) | (k >> 22); }
+__device__ __forceinline__ uint32_t suffix_index(uint32_t k) { return ((k & 0x3FFFu) << (18 - kG0)) | (k >> (14 + kG0)); }
 
 __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ l0,
                            uint32_t *__restrict__ l0s, uint32_t *__restrict__ l1, uint32_t *__restrict__ fine) {
@@ -321,6 +321,54 @@ __device__ __forceinline__ uint32_t bit_of(const uint32_t *__restrict__ words, u
     return (words[idx >> 5] >> (idx & 31)) & 1u;
 }
 
+// Lane-constant masks for the mutant a lane generates (same enumeration as LaneMut / mutate, 14 VALU ops instead
+// of ~30): mutant = (K & keep) | ((K & low) >> 2 & m_ins) | ((K & low) << 2 & m_del) | ins_const | sub base | del base
+struct LaneMasks {
+    uint32_t keep, low, m_ins, m_del, ins_const, m_sub, m_db;
+    int s;            // bit offset of base p
+    uint32_t r;       // kind index (substitution rank for r < 3)
+    uint32_t p14_ins; // all-ones for "insert behind position 14" (the mutant is a barcode only when the last base is A)
+    uint32_t valid;   // all-ones when the lane generates a mutant in this round
+    uint32_t exact;   // all-ones for the lane that probes the window itself
+    bool far;
+};
+
+__device__ __forceinline__ LaneMasks make_masks(int e) {
+    LaneMasks m;
+    const LaneMut b = make_lane(e);
+    m.s = b.s;
+    m.r = (uint32_t)b.r;
+    m.far = b.far;
+    m.valid = b.valid ? 0xFFFFFFFFu : 0u;
+    m.exact = b.exact ? 0xFFFFFFFFu : 0u;
+    const bool is_sub = !b.exact && b.r < 3, is_ins = !b.exact && b.r >= 3 && b.r < 7, is_del = !b.exact && b.r == 7;
+    m.keep = b.exact ? 0xFFFFFFFFu : is_sub ? ~(3u << b.s) : is_ins ? ~b.lm_s : ~b.lm_s2;
+    m.low = (is_ins || is_del) ? b.lm_s : 0u;
+    m.m_ins = is_ins ? 0xFFFFFFFFu : 0u;
+    m.m_del = is_del ? 0xFFFFFFFFu : 0u;
+    const uint32_t x = (uint32_t)(b.r - 3) & 3u;
+    m.ins_const = is_ins ? (x << (b.s >= 2 ? b.s - 2 : 0)) : 0u;
+    m.m_sub = is_sub ? 0xFFFFFFFFu : 0u;
+    m.m_db = is_del ? 3u : 0u;
+    m.p14_ins = (is_ins && b.s == 2) ? 0xFFFFFFFFu : 0u;
+    return m;
+}
+
+// live = all-ones when the mutant has to be probed
+__device__ __forceinline__ uint32_t mutate2(const LaneMasks &m, uint32_t K, uint32_t del_base, uint32_t &live) {
+    const uint32_t cur = (K >> m.s) & 3u;
+    const uint32_t bsub = m.r + (m.r >= cur ? 1u : 0u);
+    const uint32_t lo = K & m.low;
+    uint32_t v = K & m.keep;
+    v |= (lo >> 2) & m.m_ins;
+    v |= (lo << 2) & m.m_del;
+    v |= m.ins_const;
+    v |= (bsub << m.s) & m.m_sub;
+    v |= del_base & m.m_db;
+    live = m.valid & ~(m.p14_ins & (0u - (uint32_t)((K & 3u) != 0u)));
+    return v;
+}
+
 // Work split inside a wavefront (64 reads per batch):
 //   phase 1 (lane = read)   : every lane derives the five window keys of ITS read (N handling, reverse complement)
 //   phase 2 (lane = mutant) : for r = 0..63 the keys of read r are broadcast (v_readlane) and the 64 lanes probe the
@@ -337,8 +385,11 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    const LaneMut mA = make_lane(lane);
-    const LaneMut mB = make_lane(lane == 63 ? 127 : 64 + lane);
+    const LaneMasks mA = make_masks(lane);
+    const LaneMasks mB = make_masks(lane == 63 ? 127 : 64 + lane);
+    // top level: prefix-major index = key >> kG0 = rotr(key, kG0) & mask, suffix-major = rotr(key, 14 + kG0) & mask
+    const uint32_t rotA = mA.far ? 14u + kG0 : (uint32_t)kG0, rotB = mB.far ? 14u + kG0 : (uint32_t)kG0;
+    constexpr uint32_t kTopMask = (1u << (32 - kG0)) - 1u;
     const bool fp = five_prime != 0;
     constexpr int OFFS[5] = {0, -1, 1, -2, 2};  // the reference's order (Parser.java:L203)
 
@@ -371,16 +422,11 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
             for (int q = 0; q < 5; q++) {
                 K[q] = __builtin_amdgcn_readlane(key[q], r);
                 const uint32_t db = (pk >> (2 * q)) & 3u;
-                const bool usable = (pk >> (10 + q)) & 1u;
-                bool va, vb;
-                mut[2 * q] = mutate(mA, K[q], db, va);
-                mut[2 * q + 1] = mutate(mB, K[q], db, vb);
-                if (MAX_ED == 0) {
-                    va = false;
-                    vb = vb && mB.exact;
-                }
-                live[2 * q] = (va && usable) ? 0xFFFFFFFFu : 0u;
-                live[2 * q + 1] = (vb && usable) ? 0xFFFFFFFFu : 0u;
+                const uint32_t usable = 0u - ((pk >> (10 + q)) & 1u);
+                mut[2 * q] = mutate2(mA, K[q], db, live[2 * q]);
+                mut[2 * q + 1] = mutate2(mB, K[q], db, live[2 * q + 1]);
+                live[2 * q] &= MAX_ED == 0 ? 0u : usable;
+                live[2 * q + 1] &= MAX_ED == 0 ? (usable & mB.exact) : usable;
             }
             // level 0 of the pyramid: 10 independent gathers
             // (one prefix-ordered table would spread the 124 probes of an offset over ~54 lines; routing the mutants
@@ -390,14 +436,12 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
             const uint32_t *const topB = mB.far ? P.l0s : P.l0;
 #pragma unroll
             for (int t = 0; t < 10; t++) {
-                const bool far = (t & 1) ? mB.far : mA.far;
-                const uint32_t i0 = far ? suffix_index(mut[t]) : (mut[t] >> kG0);
+                const uint32_t i0 = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? rotB : rotA) & kTopMask;
                 w[t] = ((t & 1) ? topB : topA)[i0 >> 5];
             }
 #pragma unroll
             for (int t = 0; t < 10; t++) {
-                const bool far = (t & 1) ? mB.far : mA.far;
-                const uint32_t i0 = far ? suffix_index(mut[t]) : (mut[t] >> kG0);
+                const uint32_t i0 = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? rotB : rotA);
                 live[t] &= 0u - ((w[t] >> (i0 & 31u)) & 1u);
             }
             // level 1: lanes that are out read word 0 (one shared line)

@@ -19,18 +19,19 @@ int hip_fail(hipError_t e, const char *what);
     } while (0)
 
 // Membership pyramid over the 2^32 universe of 16-mers (A=0 G=1 C=2 T=3, first base most significant).
-//   l0  : 1 bit per 2^G0 consecutive keys  (2^(32-G0) bits)  -- sized to stay resident in one XCD's 4 MiB L2
+//   l0  : 1 bit per 2^G0 consecutive keys  (2^(32-G0) bits = 4 MiB at G0 = 7; the size was chosen by measurement:
+//         a finer top level lets fewer of the 620 mutants through to the levels below)
 //   l1  : 1 bit per 2^G1 consecutive keys  (2^(32-G1) bits)  -- Infinity-Cache resident
 //   fine: 1 bit per key                    (2^32 bits = 512 MiB, HBM)
 // A probe walks l0 -> l1 -> fine and stops at the first clear bit, so it is exact; consecutive keys share
 // a bit, so the mutants of one window that keep its leading bases hit the same 128-B line.
-//   l0s : a second top level with the key's LAST 7 bases selecting the 128-B line and its first 5 bases the bit
-//         (bases 5..8 dropped), for the mutants that change the leading bases: all substitutions at positions
+//   l0s : a second top level with the key's LAST 7 bases (and its first bit) selecting the 128-B line and its first
+//         5.5 bases the bit (the bases between are dropped), for the mutants that change the leading bases: all substitutions at positions
 //         0..6 share the window's line, all early insertions share the "shifted right" line and all early
 //         deletions the "shifted left" line -- 4 lines per offset instead of ~54 with one prefix-ordered table.
 // rank[k] = number of set keys below (k << 8): ordinal(key) = rank[key >> 8] + popcount of the fine bits
 // of that 256-key block below key  (pass-1 histogram index).
-constexpr int kG0 = 8;
+constexpr int kG0 = 7;  // 4 MiB per top level: measured best (8: 9.6 ms, 7: 8.3 ms, 6: 9.6 ms per 10 M reads)
 constexpr int kG1 = 5;
 constexpr size_t kL0Words = (size_t(1) << (32 - kG0)) / 32;
 constexpr size_t kL1Words = (size_t(1) << (32 - kG1)) / 32;
