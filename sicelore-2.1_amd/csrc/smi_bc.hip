@@ -215,7 +215,10 @@ __device__ __forceinline__ LaneMut make_lane(int e) {
     m.exact = (e == 127);
     m.valid = (e < 123) || m.exact;
     // substitution at p changes base p, insertion after p bases p+1.., deletion of p bases p..
-    m.far = !m.exact && (m.r < 3 ? p <= 6 : (m.r < 7 ? p <= 5 : p <= 6));
+    // which mutants go to the suffix-major twin: measured (ms per 10 M reads) sub/ins/del <= 6/5/6: 8.4, 7/6/7: 7.5,
+    // 8/7/8: 7.3, 8/6/8: 7.4, 8/8/8: 8.5, 9/8/9: 9.0 -- positions 6..8 lie in the bits the twin drops, so their
+    // substitutions test the window's own bit there
+    m.far = !m.exact && (m.r < 3 ? p <= 8 : (m.r < 7 ? p <= 7 : p <= 8));
     return m;
 }
 
@@ -509,7 +512,7 @@ int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_
     if (max_ed == 2) return launch_bc_match2(ctx, d_win, n, five_prime, d_out, s);
     Pyramid P = pyramid_of(ctx);
     const size_t n_waves = (n + 63) / 64;
-    const unsigned grid = (unsigned)std::min<size_t>((n_waves + 3) / 4, 256 * 64);
+    const unsigned grid = (unsigned)((n_waves + 3) / 4);  // one batch of 64 reads per wave: measured 3 % faster than a capped grid
     if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
     if (max_ed == 0)
         hipLaunchKernelGGL(k_bc_match_ed1<0>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);

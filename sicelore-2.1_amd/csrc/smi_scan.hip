@@ -45,7 +45,6 @@ struct ScanParams {
     int min_bc_qv;       // 8
     int min_read_qv;     // 8
     uint32_t adapter4[22];  // 4-bit codes of the adapter, padded
-    int five_prime;      // 5' barcoding: PolyATadapterAnalyzer_5pBCUMI.search
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
 };
@@ -199,7 +198,7 @@ __device__ __forceinline__ int wave_exscan(int v, int lane, int &total) {
 //                         skip rule), lanes 2i/2i+1 exchange for the strand decision and the TSO rules, one lane
 //                         writes the record and the barcode window
 // ---------------------------------------------------------------------------------------------------------------
-template <int AD>
+template <int AD, bool FP>
 __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
                                                  const uint8_t *__restrict__ qtail, const uint32_t *__restrict__ qsum,
                                                  size_t n_reads, ScanParams P, smi_scan_result *__restrict__ out,
@@ -225,20 +224,20 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         int pb = 0, pe = 0;
-        const bool has_t = active && long_enough && !(P.five_prime && P.dont_polya) && find_polyt(planes, tid, P, pb, pe);
+        const bool has_t = active && long_enough && !(FP && P.dont_polya) && find_polyt(planes, tid, P, pb, pe);
         uint64_t am[3] = {0, 0, 0}, tm[2] = {0, 0};
         // 5' barcoding scans an end when the polyT was found at the OTHER end (or no polyA is asked for):
         // PolyATadapterAnalyzer_5pBCUMI.java:L51-68
-        const bool scan5 = P.five_prime && active && long_enough && (P.dont_polya || __shfl_xor((int)has_t, 1));
-        if (P.five_prime ? scan5 : has_t) {
+        const bool scan5 = FP && active && long_enough && (P.dont_polya || __shfl_xor((int)has_t, 1));
+        if (FP ? scan5 : has_t) {
             // 3': positions 1 .. min(pe - AD, pe - 12)  (seqTilPolyAend has length pe; L49-61, AdapterTSOanalyzer L87)
             // 5': positions 1 .. AdapterSearchWindow of the first window + AD + maxMM + 5 bases
-            const int last = P.five_prime ? P.window5 : min(pe - AD, pe - 12);
+            const int last = FP ? P.window5 : min(pe - AD, pe - 12);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
                 am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return P.adapter4[i]; }), last - ch * 64);
         }
-        if (active && long_enough && !P.five_prime) {
+        if (active && long_enough && !FP) {
             // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
 #pragma unroll
             for (int ch = 0; ch < 2; ch++)
@@ -375,7 +374,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         if (!long_enough) {
             flags |= SMI_F_READ_TOO_SHORT | SMI_F_FAILED;
         } else {
-            if (!(P.five_prime && P.dont_polya))
+            if (!(FP && P.dont_polya))
                 flags |= (!f_has && !r_has) ? SMI_F_POLY_A_NOT_FOUND
                          : (f_has && !r_has) ? SMI_F_POLY_T_5P
                          : (!f_has && r_has) ? SMI_F_POLY_A_3P
@@ -419,7 +418,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         if (chosen) {
             // polyA coordinates are set as soon as a side is chosen (analyze L169-171); 5' barcoding takes the polyT
             // result of the other end, and none with --noPolyARequired
-            if (!P.five_prime) {
+            if (!FP) {
                 res.polya_start = len - (pe - 1);
                 res.polya_end = len - (pb - 1);
             } else if (!P.dont_polya) {
@@ -433,7 +432,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 res.found = 1;
                 res.scan_end = (int16_t)s_end;
                 res.adapter_nmis = (int16_t)a_nmis;
-                if (!P.five_prime) {
+                if (!FP) {
                     res.adapter_start = len - (a_pos - 1);  // ReadScanResult.java:L446-447
                     res.adapter_end = len - (s_end - 1);
                     res.reverse = use_fwd ? 1 : 0;
@@ -446,7 +445,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 }
                 // barcode window.  3': stranded[AE-22 .. AE+1] = reverse complement of scan[s_end-1 .. s_end+22];
                 // 5': stranded[AE-1 .. AE+23] = scan[s_end-1 .. s_end+23] as it stands (Parser.java:L205-221)
-                const int n_win = P.five_prime ? SMI_WIN_BASES_5P : SMI_WIN_BASES_3P;
+                const int n_win = FP ? SMI_WIN_BASES_5P : SMI_WIN_BASES_3P;
                 const int hi_sp = s_end - 2 + n_win, lo_sp = s_end - 1;
                 if (lo_sp >= 1 && hi_sp <= len && hi_sp <= kEndBases) {
                     uint64_t bases = 0;
@@ -454,20 +453,20 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
 #pragma unroll 5
                     for (int j = 0; j < 25; j++) {
                         if (j >= n_win) break;
-                        const int bit = P.five_prime ? lo_sp + j - 1 : hi_sp - j - 1;  // 0-based scan index of window base j
+                        const int bit = FP ? lo_sp + j - 1 : hi_sp - j - 1;  // 0-based scan index of window base j
                         const uint32_t a = get32(planes + 0 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t g = get32(planes + 1 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t c = get32(planes + 2 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t t = get32(planes + 3 * kLdsWords * kBlock, tid, bit) & 1u;
                         const uint32_t single = (a + g + c + t) == 1u;
                         // 2-bit code A0 G1 C2 T3; 3' takes the complement (A<->T, G<->C)
-                        const uint32_t code = P.five_prime ? (t ? 3u : (c ? 2u : (g ? 1u : 0u))) : (t ? 0u : (c ? 1u : (g ? 2u : 3u)));
+                        const uint32_t code = FP ? (t ? 3u : (c ? 2u : (g ? 1u : 0u))) : (t ? 0u : (c ? 1u : (g ? 2u : 3u)));
                         bases = (bases << 2) | (single ? code : 0u);
                         nmask |= (single ? 0u : 1u) << j;
                     }
                     win.bases = bases;
                     win.nmask = nmask;
-                    win.flags = SMI_WIN_VALID | (P.five_prime ? SMI_WIN_5P : 0u);
+                    win.flags = SMI_WIN_VALID | (FP ? SMI_WIN_5P : 0u);
                 }
                 // pass-1 quality filter (short-circuit && chain; the UNSTRANDED quality string is indexed with
                 // stranded coordinates, UsedCellBCListGenerator.java:L201)
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                     bool in_range = ae - 16 >= 1;
                     for (int p = ae - 16; p <= ae - 1; p++) {
                         // 3': the last kEndBases qualities, right-aligned; 5': the first kEndBases, left-aligned
-                        const int idx = P.five_prime ? p - 1 : kEndBases - 1 - (len - p);
+                        const int idx = FP ? p - 1 : kEndBases - 1 - (len - p);
                         if (idx < 0 || idx >= kEndBases) {
                             in_range = false;
                             break;
@@ -574,30 +573,26 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     P.min_read_qv = cfg->min_mean_read_qv;
     const int ad = cfg->adapter_len;
     for (int i = 0; i < 22; i++) P.adapter4[i] = i < ad ? cfg->adapter4[i] : 0u;
-    P.five_prime = cfg->five_prime;
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
     const size_t n_ends = 2 * n;
-    const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 16);
+    const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 64);  // measured: x4 8.2, x16 7.5, x64 7.2, uncapped 7.7 ms
     if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;
+    // the dynamic LDS size (40 KiB) is below the 64 KiB that needs an opt-in
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out,
+                           d_win);
+    };
     if (ad == 10) {
-        static bool attr10_set = false;
-        if (!attr10_set) {  // > 64 KiB of dynamic LDS needs the opt-in
-            SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<10>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes()));
-            attr10_set = true;
-        }
-        hipLaunchKernelGGL(k_scan<10>, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n,
-                           P, d_out, d_win);
+        if (cfg->five_prime)
+            launch(k_scan<10, true>);
+        else
+            launch(k_scan<10, false>);
     } else {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan<22>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)scan_lds_bytes()));
-            attr_set = true;
-        }
-        hipLaunchKernelGGL(k_scan<22>, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n,
-                           P, d_out, d_win);
+        if (cfg->five_prime)
+            launch(k_scan<22, true>);
+        else
+            launch(k_scan<22, false>);
     }
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_SCAN, s)) return rc;
