@@ -744,6 +744,9 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const bool fp = five_prime != 0;
     constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+    // level-2 child slots of a lane: slot = 8 * position + kind, the same enumeration as level 1 (slots >= 123 unused)
+    LaneMasks mk[2] = {make_masks(lane), make_masks(64 + lane)};
+    if (64 + lane >= 123) mk[1].valid = 0u;
 
     for (size_t rd = wave; rd < n; rd += n_waves) {
         const smi_bc_window w = win[rd];  // wave-uniform (scalar loads)
@@ -854,38 +857,71 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         imd1 = ins_minus_del_of(e);
                     }
                     // ---- level 2: expand the created children in order, early exit on the first hit ------------
-                    for (int t = 0; t < n_items && !hit2; t++) {
-                        const int e = (int)ord2e[t];
-                        const int pX = e >> 3, rX = e & 7;
-                        const Seq X = child_of(root, pX, rX, post1);
-                        const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;  // post[nDeletions + 1]
-                        const int q0 = pX == 0 ? 1 : 0;                              // first visited position
+                    // kGroup items (2 * kGroup half-rounds of 64 mutants) are generated, looked up in the dedup table and
+                    // tested against the top level TOGETHER: the loads of a group are independent, so their latencies
+                    // overlap; the (rare) survivors of the top level are then walked in order, which keeps "first hit".
+                    constexpr int kGroup = 4;
+                    for (int t0 = 0; t0 < n_items && !hit2; t0 += kGroup) {
+                        uint32_t m_low[2 * kGroup], m_ok[2 * kGroup], w0[2 * kGroup];
 #pragma unroll
-                        for (int h = 0; h < 2 && !hit2; h++) {
-                            const int slot = 64 * h + lane;
-                            const int qq = slot >> 3, rr = slot & 7;
-                            bool live = slot_valid(qq, rr) && qq != pX;
-                            const Seq m = child_of(X, qq, rr, delb);
-                            // dedup set: root, anything expanded before X, X itself after its first position
-                            live = live && m.low != K && !(m.low == X.low && qq > q0);
-                            if (live && m.low == kEmpty) {
-                                live = !(t_ord < (uint32_t)t);
-                            } else if (live) {
-                                uint32_t sl = (m.low * 2654435761u) >> 24;
-                                for (;;) {
-                                    const uint32_t kk = keys[sl];
-                                    if (kk == m.low) {
-                                        if (vals[sl] < (uint32_t)t) live = false;
-                                        break;
-                                    }
-                                    if (kk == kEmpty) break;
-                                    sl = (sl + 1) & (kTabSlots - 1);
-                                }
+                        for (int g = 0; g < kGroup; g++) {
+                            const int t = t0 + g;
+                            const bool on = t < n_items;  // wave-uniform
+                            // the item being expanded is wave-uniform: keep it on the scalar unit
+                            const int e = __builtin_amdgcn_readfirstlane((int)ord2e[on ? t : 0]);
+                            const int pX = e >> 3, rX = e & 7;
+                            const Seq X = child_of(root, pX, rX, post1);
+                            const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;  // post[nDeletions + 1]
+                            const int q0 = pX == 0 ? 1 : 0;                              // first visited position
+                            const bool x_ok = on && X.g == 0u;  // a child of a g != 0 item can never equal a barcode
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                const int qq = (64 * h + lane) >> 3;
+                                uint32_t lv;
+                                Seq m;
+                                m.low = mutate2(mk[h], X.low, delb, lv);  // lv: valid slot and g == 0
+                                // dedup set: root, anything expanded before X, X itself after its first position
+                                bool live = x_ok && lv != 0u && qq != pX && m.low != K && !(m.low == X.low && qq > q0);
+                                m_low[2 * g + h] = m.low;
+                                m_ok[2 * g + h] = live ? 1u : 0u;
+                                w0[2 * g + h] = P.l0[live ? (m.low >> (kG0 + 5)) : 0u];
                             }
-                            const bool hit = live && m.g == 0u && member(P, m.low);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 2 * kGroup; i++) {
+                            if (hit2) break;
+                            bool pass = m_ok[i] && ((w0[i] >> ((m_low[i] >> kG0) & 31u)) & 1u);
+                            if (!__ballot(pass)) continue;  // wave-uniform: nearly always taken
+                            // Only a mutant that can be a barcode needs the dedup set ("expanded earlier" cannot change
+                            // the outcome of a probe that misses), so the LDS look-up runs on the few top-level survivors
+                            const int t = t0 + (i >> 1);
+                            if (pass) {
+                                const uint32_t ml = m_low[i];
+                                uint32_t ord_seen = 0xFFFFFFFFu;  // expansion order of an equal sequence, if any
+                                if (ml == kEmpty)
+                                    ord_seen = t_ord;
+                                else {
+                                    uint32_t sl = (ml * 2654435761u) >> 24;
+                                    for (;;) {
+                                        const uint32_t kk = keys[sl];
+                                        if (kk == ml) {
+                                            ord_seen = vals[sl];
+                                            break;
+                                        }
+                                        if (kk == kEmpty) break;
+                                        sl = (sl + 1) & (kTabSlots - 1);
+                                    }
+                                }
+                                pass = !(ord_seen < (uint32_t)t);
+                            }
+                            const bool hit = pass && bit_of(P.l1, m_low[i] >> kG1) && bit_of(P.fine, m_low[i]);
                             const unsigned long long hm = __ballot(hit);
                             if (hm) {
-                                const int s2 = 64 * h + __builtin_ctzll(hm);
+                                const int e = (int)ord2e[t];
+                                const int pX = e >> 3, rX = e & 7;
+                                const Seq X = child_of(root, pX, rX, post1);
+                                const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;
+                                const int s2 = 64 * (i & 1) + __builtin_ctzll(hm);
                                 hit2 = true;
                                 bc2 = child_of(X, s2 >> 3, s2 & 7, delb).low;
                                 imd2 = ins_minus_del_of(e) + ins_minus_del_of(s2);
