@@ -296,11 +296,12 @@ int smi_ref_position_at_read_position(const uint32_t *cigar, int32_t n_cigar, in
 /* Read-name suffix of a scanned (and possibly barcode-assigned) read = FastqRecordExt.getRecordForWriting
  * (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311): `<name>_{REV|FWD}_[PS=_PE=_][AE=_][T=_]
  * [bc=_ed=_ed_sec=_bcStart=_bcEnd=_[rk=_]]X=<stranded[AE-40..AE+2]>_Q=<##.#>_<base-36 id>[ cellBC=<bc>]`, or
- * `<name>_FAILED ` (host-side string formatting; 3' protocol).  raw_seq / raw_qual: the read as it came from the
+ * `<name>_FAILED ` (host-side string formatting; with five_prime X= is stranded[AE-2..AE+39] and the barcode lies behind
+ * the adapter).  raw_seq / raw_qual: the read as it came from the
  * FASTQ; bc may be NULL; rank <= 0 omits rk=.  Returns the length written (>= 0) or a negative smi_status. */
 int smi_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int32_t len,
                          const smi_scan_result *scan, const smi_bc_result *bc, int32_t rank, uint32_t read_id,
-                         char *out, size_t cap);
+                         int five_prime, char *out, size_t cap);
 
 /* ================================================================================================================
  * Chimera splitter of pass 2 (3' barcoding): replaces ChimeraFindernew.findSplitPositions
@@ -309,8 +310,8 @@ int smi_format_read_name(const char *read_name, const char *raw_seq, const char 
  * (FJ!nanopore/analyzers/PolyATadapterInternalSearcherBase.java:L78-270).
  * ================================================================================================================ */
 typedef struct {                  /* shipped values: Jar/config.xml */
-    const char *tso_complete;     /* :170 AAGCAGTGGTATCAACGCAGAGTACAT (27 bases in this build) */
-    const char *adapter_complete; /* :113 CTACACGACGCTCTTCCGATCT (22 bases in this build) */
+    const char *tso_complete;     /* :170 AAGCAGTGGTATCAACGCAGAGTACAT; this build: lengths 27 + 22 (3') or 22 + 25 (5') */
+    const char *adapter_complete; /* :113 CTACACGACGCTCTTCCGATCT */
     int32_t tso_max_errors;       /* :172 6 */
     int32_t adapter_max_errors;   /* :118 5 */
     int32_t internal_pat_len;     /* :99  15 */
@@ -335,6 +336,9 @@ typedef struct {
 } smi_chimera_result;
 
 int smi_chimera_default_config(smi_chimera_config *cfg);
+/* 5' barcoding (ChimeraFindernew.java:L75-81: the 5' adapter is searched like the TSO, the 3' adapter next to internal
+ * polyA/T, no barcode + UMI between them); only run when polyA is searched (Parser.java:L176) */
+int smi_chimera_default_config_5p(smi_chimera_config *cfg);
 
 /* u32 words the plane buffer of smi_pack_reads_device needs for n reads holding total_bases bases in all */
 size_t smi_read_planes_words(uint64_t total_bases, size_t n);

@@ -108,8 +108,8 @@ int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *
 
 /* ---- read-name writer (sor_name.c) ---- */
 int sor_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int len,
-                         const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, char *out,
-                         size_t cap);
+                         const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, int five_prime,
+                         char *out, size_t cap);
 int sor_fmt_dec1(float f, char *out);
 
 /* ---- UMI pair distances (sor_umi.c) ---- */

@@ -282,11 +282,12 @@ def limited_compare(a, b, threshold=4):
 
 
 # ---- read-name writer (sor_name.c) ---------------------------------------------------------------------------
-def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0):
+def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0, five_prime=False):
     """scan: SCAN_RESULT_DTYPE record, bc: ASSIGN_DTYPE record or None -> str, or None where the reference throws"""
     L = lib()
     L.sor_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
-                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_char_p, ctypes.c_size_t]
+                                       ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_char_p,
+                                       ctypes.c_size_t]
     sc = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
     sc[0] = scan
     out = ctypes.create_string_buffer(1200)
@@ -296,7 +297,7 @@ def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_i
         b[0] = bc
         bp = b.ctypes.data
     n = L.sor_format_read_name(read_name.encode(), raw_seq.encode(), raw_qual.encode(), len(raw_seq), sc.ctypes.data, bp,
-                               int(rank), int(read_id), out, 1200)
+                               int(rank), int(read_id), int(five_prime), out, 1200)
     return None if n < 0 else out.value.decode()
 
 
@@ -324,8 +325,8 @@ SPLIT_REASONS = ["REV_ADAPTER", "FWD_ADAPTER", "REV_ADAPTER_FWD_ADAPTER", "REV_A
                  "REV_TSO_FWD_TSO", "READSTART"]
 
 
-def chimera_params(tso="AAGCAGTGGTATCAACGCAGAGTACAT", adapter="CTACACGACGCTCTTCCGATCT", tso_max=6, adapter_max=5):
-    return _ChimeraParams(tso.encode(), adapter.encode(), tso_max, adapter_max, 15, 0.70, 150, 28)
+def chimera_params(tso="AAGCAGTGGTATCAACGCAGAGTACAT", adapter="CTACACGACGCTCTTCCGATCT", tso_max=6, adapter_max=5, bc_umi=28):
+    return _ChimeraParams(tso.encode(), adapter.encode(), tso_max, adapter_max, 15, 0.70, 150, bc_umi)
 
 
 def chimera_split(read, params=None):

@@ -51,8 +51,8 @@ static void to_base36(uint32_t v, char *out) {
 /* returns the length written, or -1 where the reference would throw (substring / skip out of range), -2 on overflow.
  * scan: oracle scan record; bc: oracle assign record (found==1) or NULL; rank <= 0: no rk= field. */
 int sor_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int len,
-                         const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, char *out,
-                         size_t cap) {
+                         const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id,
+                         int five_prime, char *out, size_t cap) {
     char buf[1024];
     char *p = buf;
     /* readName = getReadName().split(" ")[0]  (L220) */
@@ -82,7 +82,9 @@ int sor_format_read_name(const char *read_name, const char *raw_seq, const char 
         }
         int append = 0;
         if (scan->adapter_found) {
-            const int begin = scan->adapter_end - 40 - 1, end = scan->adapter_end + 2; /* L253-254 */
+            /* 3': stranded[AE-40 .. AE+2] (L253-254); 5': stranded[AE-2 .. AE+39] (L250-251), nbasesOfAdapterSeqInReadname = 3 */
+            const int begin = five_prime ? scan->adapter_end - 3 : scan->adapter_end - 40 - 1;
+            const int end = five_prime ? scan->adapter_end + 40 - 1 : scan->adapter_end + 2;
             if (begin >= 0) { /* else: passed = false and the name keeps no suffix (L257-259) */
                 if (end > len) return -1;     /* String.substring */
                 if (begin - 1 < 0) return -1; /* IntStream.skip(negative) in getMeanQV */

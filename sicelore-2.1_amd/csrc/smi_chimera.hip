@@ -26,14 +26,15 @@
 
 namespace smi {
 
-constexpr int kTsoLen = 27;  // tso_for3pBarcoding.sequence_complete (Jar/config.xml:170)
-constexpr int kAdLen = 22;   // adapter_for3pBarcoding.sequence_complete (Jar/config.xml:113)
+// The two pattern lengths are template parameters <TL, AL> of the kernel: <27, 22> for 3' barcoding (complete TSO /
+// complete adapter, Jar/config.xml:170,113) and <22, 25> for 5' barcoding (5' adapter / 3' adapter, config.xml:126,141).
+constexpr int kMaxPat = 27;
 constexpr int kCap = 64;     // accepted TSO positions per orientation / matches per read kept in LDS
 constexpr int kPadWords = 5; // plane spacing: ceil(len / 32) data words + 4 zero words (gates and windows run past the end)
 
 struct ChimParams {
-    uint32_t tso4[2][kTsoLen];  // [0] complete TSO, [1] its reverse complement (4-bit codes)
-    uint32_t ad4[kAdLen];
+    uint32_t tso4[2][kMaxPat];  // [0] the pattern searched in both orientations (complete TSO), [1] its reverse complement
+    uint32_t ad4[kMaxPat];      // the adapter searched next to internal polyA / polyT
     int tso_max, ad_max;
     int pat_len;   // internalpATlength (15)
     int pat_thr;   // least count c with c / (float)pat_len >= internalFractionATInPolyAT
@@ -146,14 +147,35 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------------
 // K-CHIM
 // ---------------------------------------------------------------------------------------------------------------
-// 4-mer gate (Kmers.nKmersMatching >= need, need = 2) for 64 scan positions starting at bit b
+// 128-bit window of each base plane starting at bit b: everything the gates of 64 scan positions need
+struct PlaneWin {
+    uint64_t lo[4], hi[4];
+};
+__device__ __forceinline__ PlaneWin load_window(const ReadPlanes &rp, int b) {
+    PlaneWin w;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        w.lo[c] = gget64(rp.p[c], b);
+        w.hi[c] = gget64(rp.p[c], b + 64);
+    }
+    return w;
+}
+// match bits of IUPAC code a4 at scan positions b+i .. b+i+63 (i < 64, compile-time)
+__device__ __forceinline__ uint64_t win_match(const PlaneWin &w, uint32_t a4, int i) {
+    uint64_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if ((a4 >> c) & 1u) m |= i == 0 ? w.lo[c] : ((w.lo[c] >> i) | (w.hi[c] << (64 - i)));
+    return m;
+}
+// 4-mer gate (Kmers.nKmersMatching >= 2) for 64 scan positions
 template <int N>
-__device__ __forceinline__ uint64_t ggate64_two(const ReadPlanes &rp, const uint32_t *code, int b) {
+__device__ __forceinline__ uint64_t gate_two(const PlaneWin &w, const uint32_t *code) {
     uint64_t any = 0, two = 0;
-    uint64_t m0 = gmatch64(rp, code[0], b), m1 = gmatch64(rp, code[1], b + 1), m2 = gmatch64(rp, code[2], b + 2);
+    uint64_t m0 = win_match(w, code[0], 0), m1 = win_match(w, code[1], 1), m2 = win_match(w, code[2], 2);
 #pragma unroll
     for (int i = 0; i + 3 < N; i++) {
-        const uint64_t m3 = gmatch64(rp, code[i + 3], b + i + 3);
+        const uint64_t m3 = win_match(w, code[i + 3], i + 3);
         const uint64_t k = m0 & m1 & m2 & m3;
         two |= any & k;
         any |= k;
@@ -172,10 +194,10 @@ struct MatchRec {  // ChimeraFindernew$AdapterTSOmatch
 
 // per-wave LDS
 struct WaveLds {
-    unsigned long long cmask[64];  // candidate bits of the current segment / orientation, one word per lane
-    int coff[64];                  // exclusive prefix of the candidate counts
-    int acc_pos[kCap];             // accepted TSO positions of the current orientation ...
-    float acc_ne[kCap];            // ... and their error counts
+    unsigned long long cmask[2][64];  // candidate bits of the current segment, per orientation, one word per lane
+    int coff[2][64];                  // exclusive prefix of the candidate counts (orientation 1 continues orientation 0)
+    int acc_pos[2][kCap];             // accepted TSO positions per orientation ...
+    float acc_ne[2][kCap];            // ... and their error counts
     int srt_pos[kCap];
     float srt_ne[kCap];
     int m_begin[kCap];             // matches entering the split rules
@@ -204,6 +226,7 @@ __device__ __forceinline__ int search_at_end(const ReadPlanes &rp, int len, int 
 }
 
 // adapterScan (L159-221): read coordinate of the first accepted adapter match next to an internal polyA/T, 0 = none
+template <int kAdLen>
 __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, int at_end, int is_t, int lane,
                                             const ChimParams &P) {
     int start_range, end_range;
@@ -281,6 +304,7 @@ __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, 
     return is_t ? start_range + o1 - 1 : start_range + 51 - o1;  // L207 / L211
 }
 
+template <int kTsoLen, int kAdLen>
 __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
                                                     const uint64_t *__restrict__ offsets, size_t n, ChimParams P,
                                                     smi_chimera_result *__restrict__ out) {
@@ -310,38 +334,59 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
         bool overflow = false;
 
         // ---- internal TSO, both orientations (lambda$1 L107-125, lambda$5 L156-166) --------------------------
+        // One candidate pool per segment: the forward-TSO candidates, then the reverse-complement ones, aligned 64 at
+        // a time whatever their orientation.  The column masks of a 27 x 27 alignment are just the four base planes of
+        // the read window (col[c] = plane of template base c), so a candidate costs 4 window fetches, not 27.
         const int last = len - 70;  // min(len - 27, len - 70)
-#pragma unroll 1
-        for (int o = 0; o < 2; o++) {
-            int n_acc = 0;
-            int skip = 0;  // next position the reference's scan looks at
+        int n_acc2[2] = {0, 0};
+        {
+            int skip[2] = {0, 0};  // next position the reference's scan looks at, per orientation
             for (int p0 = 70; p0 <= last; p0 += 4096) {
-                // gate: lane = 64 positions p0 + 64*lane ...
                 const int pl = p0 + 64 * lane;
-                unsigned long long cm = 0;
-                if (pl <= last) cm = keep_low64(ggate64_two<kTsoLen>(rp, P.tso4[o], pl - 1), last - pl + 1);
-                L.cmask[lane] = cm;
-                int total;
-                const int my_off = wave_exscan_i(__popcll(cm), lane, total);
-                L.coff[lane] = my_off;
+                unsigned long long cm[2] = {0, 0};
+                if (pl <= last) {
+                    const PlaneWin pw = load_window(rp, pl - 1);
+#pragma unroll
+                    for (int o = 0; o < 2; o++) cm[o] = keep_low64(gate_two<kTsoLen>(pw, P.tso4[o]), last - pl + 1);
+                }
+                int tot0, tot1;
+                const int off0 = wave_exscan_i(__popcll(cm[0]), lane, tot0);
+                const int off1 = wave_exscan_i(__popcll(cm[1]), lane, tot1) + tot0;
+                L.cmask[0][lane] = cm[0];
+                L.cmask[1][lane] = cm[1];
+                L.coff[0][lane] = off0;
+                L.coff[1][lane] = off1;
                 wave_sync();
+                const int total = tot0 + tot1;
                 for (int base = 0; base < total; base += 64) {
                     const int en = base + lane;
                     int pos = 0x7FFFFFFF;
                     float ne = 0.0f;
                     if (en < total) {
+                        const int o = en >= tot0 ? 1 : 0;
                         int lo = 0, hi = 64;
                         while (hi - lo > 1) {
                             const int mid = (lo + hi) >> 1;
-                            if (L.coff[mid] <= en)
+                            if (L.coff[o][mid] <= en)
                                 lo = mid;
                             else
                                 hi = mid;
                         }
-                        pos = p0 + 64 * lo + kth_bit64(L.cmask[lo], en - L.coff[lo]);
+                        pos = p0 + 64 * lo + kth_bit64(L.cmask[o][lo], en - L.coff[o][lo]);
+                        uint32_t W[4];
+#pragma unroll
+                        for (int c = 0; c < 4; c++) W[c] = gget32(rp.p[c], pos - 1) & ((1u << kTsoLen) - 1u);
                         uint32_t col[kTsoLen];
 #pragma unroll
-                        for (int c = 0; c < kTsoLen; c++) col[c] = gmatch32(rp, P.tso4[o][c], pos - 1) & ((1u << kTsoLen) - 1u);
+                        for (int c = 0; c < kTsoLen; c++) {
+                            uint32_t f = 0, r = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if ((P.tso4[0][c] >> k) & 1u) f |= W[k];
+                                if ((P.tso4[1][c] >> k) & 1u) r |= W[k];
+                            }
+                            col[c] = o ? r : f;
+                        }
                         ne = nw_errors<kTsoLen>(col);
                     }
                     const float maxe = (float)P.tso_max;
@@ -352,24 +397,32 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
                     }
                     const int ok_l = !(ne > maxe) ? 1 : 0;  // getPosbelowMaxMismatches: key <= max (L302)
                     const int cnt = min(64, total - base);
-                    unsigned long long taken = 0;
-                    for (int i = 0; i < cnt; i++) {  // scalar fold, scan order
+                    unsigned long long taken[2] = {0, 0};
+                    for (int i = 0; i < cnt; i++) {  // scalar fold, scan order inside each orientation
+                        const int o = base + i >= tot0 ? 1 : 0;
                         const int p = __builtin_amdgcn_readlane(pos, i);
-                        if (p < skip) continue;
-                        if (__builtin_amdgcn_readlane(ok_l, i)) taken |= 1ull << i;
-                        skip = p + __builtin_amdgcn_readlane(delta_l, i);
+                        if (p < skip[o]) continue;
+                        if (__builtin_amdgcn_readlane(ok_l, i)) taken[o] |= 1ull << i;
+                        skip[o] = p + __builtin_amdgcn_readlane(delta_l, i);
                     }
-                    if ((taken >> lane) & 1ull) {
-                        const int slot = n_acc + __popcll(taken & ((1ull << lane) - 1ull));
-                        if (slot < kCap) {
-                            L.acc_pos[slot] = pos;
-                            L.acc_ne[slot] = ne;
+#pragma unroll
+                    for (int o = 0; o < 2; o++) {
+                        if ((taken[o] >> lane) & 1ull) {
+                            const int slot = n_acc2[o] + __popcll(taken[o] & ((1ull << lane) - 1ull));
+                            if (slot < kCap) {
+                                L.acc_pos[o][slot] = pos;
+                                L.acc_ne[o][slot] = ne;
+                            }
                         }
+                        n_acc2[o] += __popcll(taken[o]);
                     }
-                    n_acc += __popcll(taken);
                 }
                 wave_sync();
             }
+        }
+#pragma unroll 1
+        for (int o = 0; o < 2; o++) {
+            int n_acc = n_acc2[o];
             if (n_acc > kCap) {
                 overflow = true;
                 n_acc = kCap;
@@ -377,12 +430,12 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
             wave_sync();
             // sort by (score, position): rank by counting (n_acc <= 64)
             if (lane < n_acc) {
-                const float me = L.acc_ne[lane];
-                const int mp = L.acc_pos[lane];
+                const float me = L.acc_ne[o][lane];
+                const int mp = L.acc_pos[o][lane];
                 int rank = 0;
                 for (int j = 0; j < n_acc; j++) {
-                    const float e = L.acc_ne[j];
-                    const int p = L.acc_pos[j];
+                    const float e = L.acc_ne[o][j];
+                    const int p = L.acc_pos[o][j];
                     rank += (e < me || (e == me && p < mp)) ? 1 : 0;
                 }
                 L.srt_pos[rank] = mp;
@@ -401,16 +454,16 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
             const int n_keep = __popcll(kb);
             wave_sync();
             const int begin = o ? mypos + kTsoLen - 1 : mypos;  // L161
-            if (keep) L.acc_pos[idx] = begin;
+            if (keep) L.acc_pos[o][idx] = begin;
             wave_sync();
             // L163: begin > prev.getAndSet(begin) + 120, prev = previous list element
             bool pass = false;
-            if (lane < n_keep) pass = lane == 0 || L.acc_pos[lane] > L.acc_pos[lane - 1] + 120;
+            if (lane < n_keep) pass = lane == 0 || L.acc_pos[o][lane] > L.acc_pos[o][lane - 1] + 120;
             const unsigned long long pb = __ballot(pass);
             if (pass) {
                 const int slot = n_m + __popcll(pb & ((1ull << lane) - 1ull));
                 if (slot < kCap) {
-                    L.m_begin[slot] = L.acc_pos[lane];
+                    L.m_begin[slot] = L.acc_pos[o][lane];
                     L.m_kind[slot] = o;
                 }
             }
@@ -499,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
                     const int at_end = search_at_end(rp, len, pos, t, cur, P) + 1;
                     end_cur[t] = at_end;
                     fired[t] = pos;
-                    const int start = adapter_scan(rp, at_begin, at_end, t, lane, P);
+                    const int start = adapter_scan<kAdLen>(rp, at_begin, at_end, t, lane, P);
                     if (start != 0) {  // lambda$7 L204-207
                         const long long lim = prev_start[t] + 120;
                         prev_start[t] = start;
@@ -697,22 +750,19 @@ int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offse
 int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
                    const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s) {
     if (!n) return SMI_OK;
-    if (std::strlen(cfg->tso_complete) != (size_t)kTsoLen || std::strlen(cfg->adapter_complete) != (size_t)kAdLen) {
-        set_error("smi_chimera_device: this build handles a 27-base complete TSO and a 22-base complete adapter "
-                  "(the shipped config.xml values)");
-        return SMI_ERR_INVALID;
-    }
-    if (cfg->internal_pat_len < 2 || cfg->internal_pat_len > 15) {
-        set_error("smi_chimera_device: internal_pat_len must be 2..15 (4-bit window counters)");
+    const int tl = (int)std::strlen(cfg->tso_complete), al = (int)std::strlen(cfg->adapter_complete);
+    if (!((tl == 27 && al == 22) || (tl == 22 && al == 25))) {
+        set_error("smi_chimera_device: this build handles pattern lengths 27 + 22 (3' barcoding) and 22 + 25 (5' barcoding), "
+                  "the shipped config.xml values");
         return SMI_ERR_INVALID;
     }
     ChimParams P;
-    for (int i = 0; i < kTsoLen; i++) {
+    for (int i = 0; i < tl; i++) {
         P.tso4[0][i] = code_of(cfg->tso_complete[i]);
-        const uint32_t b = code_of(cfg->tso_complete[kTsoLen - 1 - i]);
+        const uint32_t b = code_of(cfg->tso_complete[tl - 1 - i]);
         P.tso4[1][i] = ((b & 1u) << 3) | ((b & 8u) >> 3) | ((b & 2u) << 1) | ((b & 4u) >> 1);
     }
-    for (int i = 0; i < kAdLen; i++) P.ad4[i] = code_of(cfg->adapter_complete[i]);
+    for (int i = 0; i < al; i++) P.ad4[i] = code_of(cfg->adapter_complete[i]);
     P.tso_max = cfg->tso_max_errors;
     P.ad_max = cfg->adapter_max_errors;
     P.pat_len = cfg->internal_pat_len;
@@ -721,8 +771,12 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     P.bc_umi = cfg->bc_umi_len;
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 16);
     if (int rc = time_begin(ctx, SMI_K_CHIMERA, s)) return rc;
-    hipLaunchKernelGGL(k_chimera, dim3(grid), dim3(256), 0, s, d_planes, read_planes_stride(total_bases, n), d_offsets, n, P,
-                       d_out);
+    if (tl == 27)
+        hipLaunchKernelGGL((k_chimera<27, 22>), dim3(grid), dim3(256), 0, s, d_planes, read_planes_stride(total_bases, n),
+                           d_offsets, n, P, d_out);
+    else
+        hipLaunchKernelGGL((k_chimera<22, 25>), dim3(grid), dim3(256), 0, s, d_planes, read_planes_stride(total_bases, n),
+                           d_offsets, n, P, d_out);
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;
     return SMI_OK;

@@ -322,6 +322,18 @@ int smi_chimera_default_config(smi_chimera_config *cfg) {
     return SMI_OK;
 }
 
+int smi_chimera_default_config_5p(smi_chimera_config *cfg) {
+    if (int rc = smi_chimera_default_config(cfg)) return rc;
+    // ChimeraFindernew.<init> L75-78 for scantype != THREEP_BARCODE: the 5' adapter plays the TSO's part, the 3' adapter
+    // of the 5' protocol is searched next to internal polyA / polyT, and no barcode + UMI lies between them (hasBCUMI = false)
+    cfg->tso_complete = "CTACACGACGCTCTTCCGATCT";        // fiveprimeadapter_for5pBarcoding.sequence_complete, config.xml:126
+    cfg->adapter_complete = "AAGCAGTGGTATCAACGCAGAGTAC";  // threeprimeadapter_for5pBarcoding.sequence_complete, :141
+    cfg->tso_max_errors = 5;                               // :132
+    cfg->adapter_max_errors = 5;                           // :146
+    cfg->bc_umi_len = 0;
+    return SMI_OK;
+}
+
 size_t smi_read_planes_words(uint64_t total_bases, size_t n) { return 4 * read_planes_stride(total_bases, n); }
 
 int smi_pack_reads_device(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, size_t n, uint64_t total_bases,

@@ -268,7 +268,7 @@ char complement(char c) {  // FastqRecordExt.REVERSE_COMPLEMENT L72-95 (ACGTN su
 
 extern "C" int smi_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int32_t len,
                                     const smi_scan_result *scan, const smi_bc_result *bc, int32_t rank, uint32_t read_id,
-                                    char *out, size_t cap) {
+                                    int five_prime, char *out, size_t cap) {
     if (!read_name || !scan || !out || (len > 0 && (!raw_seq || !raw_qual))) {
         set_error("smi_format_read_name: null argument");
         return SMI_ERR_INVALID;
@@ -291,14 +291,17 @@ extern "C" int smi_format_read_name(const char *read_name, const char *raw_seq, 
         std::string bcs;
         if (has_bc) {
             bcs = kmer16(bc->bc);
-            const int bc_start = scan->adapter_end - 1 + bc->offset;      // Parser.java:L275
-            const int bc_end = bc_start - 15 - bc->ins_minus_del;         // L278
+            // Parser.java:L274-279: 3' barcodes end at the adapter, 5' barcodes start behind it
+            const int bc_start = five_prime ? scan->adapter_end + 1 + bc->offset : scan->adapter_end - 1 + bc->offset;
+            const int bc_end = five_prime ? bc_start + 15 + bc->ins_minus_del : bc_start - 15 - bc->ins_minus_del;
             add += "bc=" + bcs + "_ed=" + std::to_string((int)bc->ed) + "_ed_sec=" + std::to_string(bc->ed_sec) +
                    "_bcStart=" + std::to_string(bc_start) + "_bcEnd=" + std::to_string(bc_end) + "_";
             if (rank > 0) add += "rk=" + std::to_string(rank) + "_";
         }
         if (scan->found) {
-            const int begin = scan->adapter_end - 40 - 1, end = scan->adapter_end + 2;  // L253-254
+            // 3': stranded[AE-40 .. AE+2] (L253-254); 5': stranded[AE-2 .. AE+39] (L250-251)
+            const int begin = five_prime ? scan->adapter_end - 3 : scan->adapter_end - 40 - 1;
+            const int end = five_prime ? scan->adapter_end + 39 : scan->adapter_end + 2;
             if (begin >= 0) {
                 if (end > len || begin - 1 < 0) {
                     set_error("smi_format_read_name: X=/Q= range outside the read (the reference throws here)");

@@ -51,7 +51,7 @@ EXPORTS = [
     "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
-    "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p",
+    "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p",
 ]
 
 
@@ -97,6 +97,7 @@ def load_library():
     lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     lib.smi_umi_dist_device.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
     lib.smi_chimera_default_config.argtypes = [vp]
+    lib.smi_chimera_default_config_5p.argtypes = [vp]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
     lib.smi_pack_reads_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp]
@@ -108,7 +109,7 @@ def load_library():
     lib.smi_region_group.argtypes = [vp, vp, vp, ctypes.c_int32, ctypes.c_int32, ci, vp, vp]
     lib.smi_ref_position_at_read_position.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
-                                         ctypes.c_int32, ctypes.c_uint32, ctypes.c_char_p, sz]
+                                         ctypes.c_int32, ctypes.c_uint32, ci, ctypes.c_char_p, sz]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     for name in EXPORTS:
         fn = getattr(lib, name)
@@ -150,7 +151,7 @@ def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10
     return ok[:m], oc[:m], orank[:m]
 
 
-def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0):
+def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0, five_prime=False):
     """smi_format_read_name; scan: SCAN_RESULT_DTYPE record, bc: BC_RESULT_DTYPE record or None -> str"""
     lib = load_library()
     sc = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
@@ -161,7 +162,7 @@ def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_i
         b[0] = bc
     out = ctypes.create_string_buffer(1200)
     n = lib.smi_format_read_name(read_name.encode(), raw_seq.encode(), raw_qual.encode(), len(raw_seq), _ptr(sc),
-                                 _ptr(b), int(rank), int(read_id), out, 1200)
+                                 _ptr(b), int(rank), int(read_id), int(five_prime), out, 1200)
     if n < 0:
         raise SmiError(f"smi_format_read_name error {n}: {lib.smi_last_error().decode()}")
     return out.value.decode()
@@ -332,9 +333,10 @@ class Context:
                                               _ptr(cfg), _ptr(d_out), _ptr(d_windows), _stream_ptr(stream)))
 
     # ---- chimera splitter ----------------------------------------------------------------------------------
-    def chimera_config(self):
+    def chimera_config(self, five_prime=False):
         cfg = ChimeraConfig()
-        self._check(self._lib.smi_chimera_default_config(ctypes.byref(cfg)))
+        fn = self._lib.smi_chimera_default_config_5p if five_prime else self._lib.smi_chimera_default_config
+        self._check(fn(ctypes.byref(cfg)))
         return cfg
 
     def read_planes_words(self, total_bases, n):

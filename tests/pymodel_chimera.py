@@ -141,7 +141,7 @@ def adapter_scan(seq, at, ad, max_errors, bc_umi=28):
         at["matches"] = matches
 
 
-def find_split_positions(read, tso_complete=TSO_COMPLETE, adapter_complete=ADAPTER_COMPLETE, tso_max=6, ad_max=5):
+def find_split_positions(read, tso_complete=TSO_COMPLETE, adapter_complete=ADAPTER_COMPLETE, tso_max=6, ad_max=5, bc_umi=28):
     """-> (split positions [(reason, pos)], multi_chimeric flag, matches)"""
     if len(read) < 2 * 70 + 100:
         return [], False, []
@@ -153,7 +153,7 @@ def find_split_positions(read, tso_complete=TSO_COMPLETE, adapter_complete=ADAPT
     ad = enc(adapter_complete)
     ats = at_scan(seq)
     for at in ats:
-        adapter_scan(seq, at, ad, ad_max)
+        adapter_scan(seq, at, ad, ad_max, bc_umi)
     prev = {A: MIN_INT, T: MIN_INT}
     for at in ats:
         if at["matches"] is None:

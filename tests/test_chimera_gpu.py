@@ -5,7 +5,7 @@ import pytest
 import pymodel_chimera as pm
 
 
-def _run(pkg, ctx, seqs):
+def _run(pkg, ctx, seqs, five_prime=False):
     import torch
 
     dev = torch.device("cuda:0")
@@ -19,7 +19,7 @@ def _run(pkg, ctx, seqs):
     d_planes = torch.full((ctx.read_planes_words(total, n),), -1, dtype=torch.int32, device=dev)  # garbage-filled
     ctx.pack_reads_device(d_reads, d_offs, n, total, d_planes)
     d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
-    ctx.chimera_device(d_planes, d_offs, n, total, ctx.chimera_config(), d_out)
+    ctx.chimera_device(d_planes, d_offs, n, total, ctx.chimera_config(five_prime), d_out)
     torch.cuda.synchronize()
     res = d_out.cpu().numpy().view(pkg.CHIMERA_RESULT_DTYPE).reshape(-1)
     return res, d_out, d_offs, offs
@@ -107,3 +107,23 @@ def test_split_offsets(pkg, sor, synth):
     assert nf == len(exp_src) and nf > n
     assert d_fo.cpu().numpy()[:nf + 1].tolist() == exp_off
     assert d_src.cpu().numpy()[:nf].tolist() == exp_src
+
+
+@pytest.mark.gpu
+def test_chimera_5p_configuration(pkg, sor, synth):
+    wl = synth.make_whitelist(20000, seed=95)
+    used = synth.pick_used(wl, 200, seed=96)
+    reads = synth.gen_reads_5p(400, used, seed=97, n_rate=0.002)
+    seqs = [c[0] for c in synth.make_chimeras(reads, 1000, seed=98)]
+    ctx = pkg.Context(0)
+    res, *_ = _run(pkg, ctx, seqs, five_prime=True)
+    par = sor.chimera_params(tso="CTACACGACGCTCTTCCGATCT", adapter="AAGCAGTGGTATCAACGCAGAGTAC", tso_max=5, adapter_max=5,
+                             bc_umi=0)
+    n_split = 0
+    for i, s in enumerate(seqs):
+        rc, splits, multi, n_matches, _ = sor.chimera_split(s, par)
+        got = [(sor.SPLIT_REASONS[res["reason"][i][k]], int(res["pos"][i][k])) for k in range(res["n_split"][i])]
+        assert rc == 0 and not (res["flags"][i] & 6)
+        assert got == splits and bool(res["flags"][i] & 1) == multi and res["n_matches"][i] == n_matches, (i, got, splits)
+        n_split += len(splits) > 0
+    assert n_split > 300

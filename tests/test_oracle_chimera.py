@@ -99,3 +99,20 @@ def test_product_fragment_names(pkg, sor):
                 assert libmod.chimera_fragment_name(name, r, k) == sor.chimera_fragment_name(name, raw, k)
     with pytest.raises(libmod.SmiError):
         libmod.chimera_fragment_name("x y", np.zeros(1, dtype=pkg.CHIMERA_RESULT_DTYPE)[0], 0)
+
+
+def test_5p_configuration_oracle_equals_model(sor, synth):
+    """5' barcoding: the 5' adapter is searched like the TSO, the 3' adapter next to internal polyA/T, no BC + UMI gap"""
+    ad5, ad3 = "CTACACGACGCTCTTCCGATCT", "AAGCAGTGGTATCAACGCAGAGTAC"
+    wl = synth.make_whitelist(5000, seed=75)
+    used = synth.pick_used(wl, 50, seed=76)
+    reads = synth.gen_reads_5p(50, used, seed=77, max_mid=400)
+    chim = synth.make_chimeras(reads, 50, seed=78)
+    par = sor.chimera_params(tso=ad5, adapter=ad3, tso_max=5, adapter_max=5, bc_umi=0)
+    n_split = 0
+    for seq, _q, _k in chim:
+        rc_, splits, multi, n_matches, _ = sor.chimera_split(seq, par)
+        m_splits, m_multi, m_ms = pm.find_split_positions(seq, ad5, ad3, 5, 5, bc_umi=0)
+        assert rc_ == 0 and splits == m_splits and multi == m_multi and n_matches == len(m_ms)
+        n_split += len(splits) > 0
+    assert n_split >= 10

@@ -19,7 +19,7 @@ def model_dec1(f):
     return (ip if ip not in ("0", "-0") else ip.replace("0", "")) + "." + fp
 
 
-def model_name(name, seq, qual, flags, ps, pe, ae, tso_end, bc, rank, read_id):
+def model_name(name, seq, qual, flags, ps, pe, ae, tso_end, bc, rank, read_id, five_prime=False):
     base = name.split(" ")[0]
     rev, fwd = "PASSED_REV" in flags, "PASSED_FWD" in flags
     if not (rev or fwd):
@@ -36,7 +36,7 @@ def model_name(name, seq, qual, flags, ps, pe, ae, tso_end, bc, rank, read_id):
         if rank > 0:
             add += f"rk={rank}_"
     if ae:
-        begin, end = ae - 41, ae + 2
+        begin, end = (ae - 3, ae + 39) if five_prime else (ae - 41, ae + 2)
         if begin < 0:
             return base
         stranded = "".join(COMP[c] for c in reversed(seq)) if rev else seq
@@ -149,3 +149,46 @@ def test_product_oracle_model_on_scanned_reads(pkg, sor, synth):
         assert o == p == m, (i, o, p, m)
         n_failed += o.endswith("_FAILED ")
     assert n_bc > 100 and n_failed > 5
+
+
+def test_product_oracle_model_5p(pkg, sor, synth):
+    from sicelore_amd import lib as libmod
+
+    wl = synth.make_whitelist(20000, seed=411)
+    used = synth.pick_used(wl, 100, seed=412)
+    reads = synth.gen_reads_5p(200, used, seed=413)
+    bset = sor.BarcodeSet(used.numpy())
+    n_bc = 0
+    for i in range(200):
+        seq, qual = synth.materialize(reads, i)
+        rc, sc = sor.scan_read_5p(seq, qual, "CTTCCGATCT", max_mm=4, dont_search_polya=bool(i % 2))
+        if rc != 0:
+            continue
+        flags = {k for k, b in sor.FLAG_BITS.items() if (int(sc["flags"]) >> b) & 1}
+        a = None
+        if sc["adapter_found"]:
+            stranded = "".join(COMP[c] for c in reversed(seq)) if sc["reverse"] else seq
+            rc2, a_ = sor.assign_barcode(bset, stranded, int(sc["adapter_end"]), max_ed=1, five_prime=True)
+            if rc2 == 1:
+                a = a_
+        name = f"r{i} ch=5"
+        o = sor.format_read_name(name, seq, qual, sc, a, rank=i % 7, read_id=50000 + i, five_prime=True)
+        ps = np.zeros(1, dtype=pkg.SCAN_RESULT_DTYPE)[0]
+        ps["flags"] = int(sc["flags"]) & 0xFFFFFFFF
+        for f in ("polya_start", "polya_end", "adapter_start", "adapter_end", "scan_end", "adapter_nmis", "reverse",
+                  "tso_start", "tso_end"):
+            ps[f] = sc[f]
+        ps["found"] = sc["adapter_found"]
+        pb = mb = None
+        if a is not None:
+            pb = np.zeros(1, dtype=pkg.BC_RESULT_DTYPE)[0]
+            pb["bc"], pb["found"], pb["ed"], pb["ed_sec"] = int(a["bc"]) & 0xFFFFFFFF, 1, a["ed"], a["ed_sec"]
+            pb["offset"], pb["ins_minus_del"] = a["offset"], a["ins_minus_del"]
+            mb = dict(seq=sor.decode(int(a["bc"])), ed=int(a["ed"]), ed_sec=int(a["ed_sec"]), start=int(a["bc_start"]),
+                      end=int(a["bc_end"]))
+            n_bc += 1
+        p = libmod.format_read_name(name, seq, qual, ps, pb, rank=i % 7, read_id=50000 + i, five_prime=True)
+        m = model_name(name, seq, qual, flags, int(sc["polya_start"]), int(sc["polya_end"]),
+                       int(sc["adapter_end"]) if sc["adapter_found"] else 0, 0, mb, i % 7, 50000 + i, five_prime=True)
+        assert o == p == m, (i, o, p, m)
+    assert n_bc > 80

@@ -26,6 +26,7 @@ def timed(fn, reps=3):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else None  # e.g. "chimera": just that leg
     pkg = graft.load_package()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
     dev = torch.device("cuda:0")
@@ -33,6 +34,14 @@ def main():
     res = {}
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
+    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera}
+    for name, fn in legs.items():
+        if only in (None, name):
+            fn(pkg, synth, ctx, dev, wl, used, res)
+    print(json.dumps(res))
+
+
+def leg_bc(pkg, synth, ctx, dev, wl, used, res):
     # ---- K-BC2 / K-BC1 in used-list mode -------------------------------------------------------------------
     n = 2_000_000
     reg = synth.gen_bc_region(n, used, seed=3, device=dev)
@@ -48,8 +57,11 @@ def main():
     ctx.set_barcode_set_device(wl.to(torch.int32), mode=1)
     dt = timed(lambda: ctx.bc_match_device(win, out, n, max_ed=2))
     res["bc_match_ed2_whitelist_3p6M"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt}
-    del reg, win, out
+
+
+def leg_pass1(pkg, synth, ctx, dev, wl, used, res):
     # ---- pass 1: scan (22-mer) + quality filter + histogram ---------------------------------------------------
+    ctx.set_barcode_set_device(wl.to(torch.int32), mode=1)
     n = 2_000_000
     rd = synth.gen_reads(n, used, seed=5, device=dev, q_mean=14.0)
     ends = synth.pack_ends(rd["head"], rd["tail"])
@@ -69,7 +81,9 @@ def main():
     dt = timed(pass1)
     res["pass1_scan22_filter_hist"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt,
                                        "pass1_ok_frac": float((((so[:, 7]) & 0xFF) == 1).float().mean())}
-    del rd, ends, so, win
+
+
+def leg_umi(pkg, synth, ctx, dev, wl, used, res):
     # ---- K-UMI ------------------------------------------------------------------------------------------------
     rng = np.random.default_rng(1)
     sizes = np.minimum(rng.zipf(1.6, 400_000), 400).astype(np.int64) + 1
@@ -85,13 +99,17 @@ def main():
     dt = timed(lambda: ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out))
     res["umi_dist"] = {"groups": int(len(sizes)), "reads": n_reads, "pairs": int(po[-1]), "ms": dt * 1e3,
                        "pairs_per_s": int(po[-1]) / dt, "levenshtein_per_s": 9 * int(po[-1]) / dt}
-    del packed, d_out
+
+
+def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
     # ---- chimera splitter: K-PACKR + K-CHIM on whole reads; 10 % of the records are two molecules joined -----------
     n = 1_000_000
     rd = synth.gen_reads(n, used, seed=7, device=dev)
     buf, offs = synth.materialize_device(rd)
     keep = torch.ones(n + 1, dtype=torch.bool, device=dev)
-    keep[1:n][torch.rand(n - 1, device=dev) < 0.1] = False  # dropping an offset joins two neighbouring reads
+    g = torch.Generator(device=dev)
+    g.manual_seed(11)
+    keep[1:n][torch.rand(n - 1, device=dev, generator=g) < 0.1] = False  # dropping an offset joins two neighbouring reads
     offs = offs[keep].contiguous()
     n = offs.numel() - 1
     total = int(offs[-1])
@@ -105,7 +123,6 @@ def main():
                       "bases_per_s": total / dt, "pack_GBps": total / dt_pack / 1e9,
                       "split_frac": float((cr["n_split"] > 0).mean()), "multi_frac": float((cr["flags"] & 1).mean()),
                       "overflow": int((cr["flags"] & 4).sum())}
-    print(json.dumps(res))
 
 
 if __name__ == "__main__":

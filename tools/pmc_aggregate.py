@@ -11,7 +11,7 @@ import os
 import sys
 
 KERNELS = {"k_scan": "smi::k_scan", "k_bc_match_ed1": "smi::k_bc_match_ed1", "k_bc_match_ed2": "smi::k_bc_match_ed2",
-           "k_pack_ends": "smi::k_pack_ends", "k_umi_dist": "smi::k_umi_dist", "k_hist_windows": "smi::k_hist_windows"}
+           "k_pack_ends": "smi::k_pack_ends", "k_umi_dist": "smi::k_umi_dist", "k_hist_windows": "smi::k_hist_windows", "k_chimera": "smi::k_chimera", "k_pack_reads": "smi::k_pack_reads"}
 
 
 def main():
