@@ -108,16 +108,18 @@ __device__ __forceinline__ int jround(float a) { return (int)floorf(__fadd_rn(a,
 // ---------------------------------------------------------------------------------------------------------------
 // K-PACKR: ASCII reads -> bit-planes.  planes: [4][stride] u32; read r starts at word plane_start(offsets[r], r).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t enc4c(uint8_t c) {
-    switch (c) {
-    case 'A': case 'a': return 1;
-    case 'G': case 'g': return 2;
-    case 'C': case 'c': return 4;
-    case 'T': case 't': return 8;
-    default: return 15;
-    }
+__device__ __forceinline__ uint32_t enc4c(uint8_t ch) {
+    // branch-free (a switch here becomes a divergent jump chain per base): A/a 1, G/g 2, C/c 4, T/t 8, anything else N
+    const uint32_t c = (uint32_t)ch | 0x20u;
+    uint32_t r = 15u;
+    r = c == 'a' ? 1u : r;
+    r = c == 'g' ? 2u : r;
+    r = c == 'c' ? 4u : r;
+    r = c == 't' ? 8u : r;
+    return r;
 }
 
+// one wave per read, one lane per 32-base plane word: a wave reads 2 KiB of consecutive ASCII and writes four 256-B rows
 __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                                                     size_t n, size_t stride, uint32_t *__restrict__ planes) {
     const int lane = threadIdx.x & 63;
@@ -128,18 +130,28 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
         const size_t w0 = plane_start(beg, r);
         const int64_t n_words = (len + 31) / 32 + kPadWords - 1;  // the pad words are written as zeros
-        for (int64_t base = 0; base < n_words * 32; base += 64) {
-            const int64_t p = base + lane;
-            const uint32_t code = p < len ? enc4c(reads[beg + p]) : 0u;
+        const uint8_t *src = reads + beg;
+        for (int64_t w = lane; w < n_words; w += 64) {
+            uint32_t pl[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const unsigned long long b = __ballot((code >> c) & 1u);
-                if (lane == 0) {
-                    const int64_t w = base >> 5;
-                    planes[c * stride + w0 + w] = (uint32_t)b;
-                    if (w + 1 < n_words) planes[c * stride + w0 + w + 1] = (uint32_t)(b >> 32);
+            for (int k = 0; k < 4; k++) {
+                const int64_t p0 = 32 * w + 8 * k;
+                if (p0 >= len) break;
+                uint64_t piece = 0;
+                if (p0 + 8 <= len)
+                    __builtin_memcpy(&piece, src + p0, 8);
+                else
+                    for (int i = 0; i < (int)(len - p0); i++) piece |= (uint64_t)src[p0 + i] << (8 * i);
+                const int nb = (int)min((int64_t)8, len - p0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t code = i < nb ? enc4c((uint8_t)(piece >> (8 * i))) : 0u;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pl[c] |= ((code >> c) & 1u) << (8 * k + i);
                 }
             }
+#pragma unroll
+            for (int c = 0; c < 4; c++) planes[c * stride + w0 + w] = pl[c];
         }
     }
 }

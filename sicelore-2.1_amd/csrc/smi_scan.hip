@@ -601,67 +601,90 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
 
 // ---------------------------------------------------------------------------------------------------------------
 // K-PACK: ASCII reads -> scan-orientation bit-plane ends (+ read length, tail qualities, quality sum).
-// One wave per read: lanes stride over the read for the quality sum (coalesced), then build the planes with
-// ballots (lane = base position).
+// Bases: one lane per read end (below); qualities: one wave per read.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t enc4(uint8_t c) {
-    // NucleicAcidByteCodeBase.ENCODE_MATRIX (TB!nuc/encoding/NucleicAcidByteCodeBase.java:L45-78), ACGTN subset;
-    // every other character is treated as N
-    switch (c) {
-    case 'A': case 'a': return 1;
-    case 'G': case 'g': return 2;
-    case 'C': case 'c': return 4;
-    case 'T': case 't': return 8;
-    default: return 15;
-    }
+__device__ __forceinline__ uint32_t enc4(uint8_t ch) {
+    // branch-free (a switch here becomes a divergent jump chain per base): A/a 1, G/g 2, C/c 4, T/t 8, anything else N
+    const uint32_t c = (uint32_t)ch | 0x20u;
+    uint32_t r = 15u;
+    r = c == 'a' ? 1u : r;
+    r = c == 'g' ? 2u : r;
+    r = c == 'c' ? 4u : r;
+    r = c == 't' ? 8u : r;
+    return r;
 }
 __device__ __forceinline__ uint32_t comp4(uint32_t b) {
     return ((b & 1u) << 3) | ((b & 8u) >> 3) | ((b & 2u) << 1) | ((b & 4u) >> 1);
 }
 
-__global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ reads, const uint8_t *__restrict__ quals,
-                                                   const uint64_t *__restrict__ offsets, size_t n, int head_quals,
-                                                   uint32_t *__restrict__ ends, int32_t *__restrict__ read_len,
-                                                   uint8_t *__restrict__ qtail, uint32_t *__restrict__ qsum) {
+// one lane = one read end (lanes 2i / 2i+1 = head / reverse-complemented tail of read i): every lane walks its 224
+// bases in 8-byte pieces and builds the four plane words in registers, so the stores of a wave are 256-B rows of the
+// [plane-word][end] layout and no cross-lane operation is needed
+__global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
+                                                   size_t n, uint32_t *__restrict__ ends, int32_t *__restrict__ read_len) {
+    const size_t n_ends = 2 * n;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_ends; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = e >> 1;
+        const int side = (int)(e & 1);
+        const uint64_t beg = offsets[r];
+        const int64_t len = (int64_t)(offsets[r + 1] - beg);
+        if (side == 0) read_len[r] = (int32_t)len;
+        const uint8_t *src = reads + beg;
+#pragma unroll 1
+        for (int w = 0; w < kPlaneWords; w++) {
+            uint32_t pa = 0, pg = 0, pc = 0, pt = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {  // 8 bases per piece
+                const int p0 = 32 * w + 8 * k;  // scan positions p0 .. p0 + 7
+                if (p0 >= len) break;
+                uint64_t piece = 0;
+                const int64_t lo = side == 0 ? p0 : len - 8 - p0;  // first byte of the piece in the read
+                if (p0 + 8 <= len) {
+                    __builtin_memcpy(&piece, src + lo, 8);
+                    if (side) piece = __builtin_bswap64(piece);  // the tail is scanned backwards
+                } else {  // the read ends inside this piece
+                    for (int i = 0; i < (int)(len - p0); i++)
+                        piece |= (uint64_t)src[side == 0 ? p0 + i : len - 1 - p0 - i] << (8 * i);
+                }
+                const int nb = (int)min((int64_t)8, len - p0);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t code = i < nb ? enc4((uint8_t)(piece >> (8 * i))) : 0u;
+                    if (side) code = comp4(code);
+                    const int bit = 8 * k + i;
+                    pa |= (code & 1u) << bit;
+                    pg |= ((code >> 1) & 1u) << bit;
+                    pc |= ((code >> 2) & 1u) << bit;
+                    pt |= ((code >> 3) & 1u) << bit;
+                }
+            }
+            ends[(size_t)(0 * kPlaneWords + w) * n_ends + e] = pa;
+            ends[(size_t)(1 * kPlaneWords + w) * n_ends + e] = pg;
+            ends[(size_t)(2 * kPlaneWords + w) * n_ends + e] = pc;
+            ends[(size_t)(3 * kPlaneWords + w) * n_ends + e] = pt;
+        }
+    }
+}
+
+// qualities (pass 1 only): one wave per read sums the whole string (coalesced) and copies the 224 qualities the
+// pass-1 filter may look at (3': the last ones, right-aligned; 5': the first ones)
+__global__ __launch_bounds__(256) void k_pack_quals(const uint8_t *__restrict__ quals, const uint64_t *__restrict__ offsets,
+                                                    size_t n, int head_quals, uint8_t *__restrict__ qtail,
+                                                    uint32_t *__restrict__ qsum) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    const size_t n_ends = 2 * n;
     for (size_t r = wave; r < n; r += n_waves) {
         const uint64_t beg = offsets[r];
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
-        if (lane == 0) read_len[r] = (int32_t)len;
-        if (quals) {
-            uint32_t s = 0;
-            for (int64_t i = lane; i < len; i += 64) s += (uint32_t)quals[beg + i] - 33u;
+        uint32_t s = 0;
+        for (int64_t i = lane; i < len; i += 64) s += (uint32_t)quals[beg + i] - 33u;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) qsum[r] = s;
-            for (int i = lane; i < kEndBases; i += 64) {
-                const int64_t p = head_quals ? i : len - kEndBases + i;  // 5': first bases, left-aligned; 3': last, right-aligned
-                qtail[r * kEndBases + i] = (p >= 0 && p < len) ? quals[beg + p] : (uint8_t)33;
-            }
-        }
-        for (int side = 0; side < 2; side++) {
-            for (int w = 0; w < kPlaneWords; w += 2) {
-                // 64 base positions per step: position p = 32*w + lane
-                const int p = 32 * w + lane;
-                uint32_t code = 0;  // '-' (matches nothing) beyond the read / the stored end
-                if (p < kEndBases && p < len) {
-                    if (side == 0)
-                        code = enc4(reads[beg + p]);
-                    else
-                        code = comp4(enc4(reads[beg + (len - 1 - p)]));
-                }
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const unsigned long long b = __ballot((code >> c) & 1u);
-                    if (lane == 0) {
-                        ends[(size_t)(c * kPlaneWords + w) * n_ends + 2 * r + side] = (uint32_t)b;
-                        if (w + 1 < kPlaneWords) ends[(size_t)(c * kPlaneWords + w + 1) * n_ends + 2 * r + side] = (uint32_t)(b >> 32);
-                    }
-                }
-            }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) qsum[r] = s;
+        for (int i = lane; i < kEndBases; i += 64) {
+            const int64_t p = head_quals ? i : len - kEndBases + i;
+            qtail[r * kEndBases + i] = (p >= 0 && p < len) ? quals[beg + p] : (uint8_t)33;
         }
     }
 }
@@ -669,9 +692,12 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
 int launch_pack_ends(smi_ctx *, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, size_t n,
                      int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
     if (!n) return SMI_OK;
-    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_quals, d_offsets, n, head_quals, d_ends, d_len, d_qtail,
-                       d_qsum);
+    const unsigned grid = (unsigned)std::min<size_t>((2 * n + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, n, d_ends, d_len);
+    if (d_quals) {
+        const unsigned gq = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(k_pack_quals, dim3(gq), dim3(256), 0, s, d_quals, d_offsets, n, head_quals, d_qtail, d_qsum);
+    }
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

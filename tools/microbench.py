@@ -117,6 +117,16 @@ def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
     cres = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     ccfg = ctx.chimera_config()
     dt_pack = timed(lambda: ctx.pack_reads_device(buf, offs, n, total, planes))
+    # K-PACK (read ends for K-SCAN), without and with the quality string (pass 1 sums every quality)
+    ends = torch.zeros((28, 2 * n), dtype=torch.int32, device=dev)
+    lens = torch.zeros(n, dtype=torch.int32, device=dev)
+    dt_ends = timed(lambda: ctx.pack_ends_device(buf, None, offs, n, ends, lens))
+    qt = torch.zeros((n, 224), dtype=torch.uint8, device=dev)
+    qs = torch.zeros(n, dtype=torch.int32, device=dev)
+    dt_ends_q = timed(lambda: ctx.pack_ends_device(buf, buf, offs, n, ends, lens, qt, qs))
+    res["pack_ends"] = {"reads": n, "ms": dt_ends * 1e3, "reads_per_s": n / dt_ends, "with_quals_ms": dt_ends_q * 1e3,
+                        "with_quals_GBps": 2 * total / dt_ends_q / 1e9}
+    del ends, lens, qt, qs
     dt = timed(lambda: ctx.chimera_device(planes, offs, n, total, ccfg, cres))
     cr = cres.cpu().numpy().view(pkg.CHIMERA_RESULT_DTYPE).reshape(-1)
     res["chimera"] = {"reads": n, "bases": total, "pack_ms": dt_pack * 1e3, "ms": dt * 1e3, "reads_per_s": n / dt,
