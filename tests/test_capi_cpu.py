@@ -56,6 +56,39 @@ def test_struct_layout_matches_header(built, tmp_path):
                    r.fields["found"][1], r.fields["ins_minus_del"][1], r.fields["n_matches"][1]]
 
 
+def test_struct_layout_of_the_other_records(built, tmp_path):
+    from sicelore_amd import lib as libmod
+
+    src = tmp_path / "sz2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sicelore_mi.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(smi_scan_result),offsetof(smi_scan_result,scan_end),offsetof(smi_scan_result,found),"
+                   "offsetof(smi_scan_result,tso_end),sizeof(smi_scan_config),offsetof(smi_scan_config,adapter4),"
+                   "offsetof(smi_scan_config,adapter_search_window),sizeof(smi_chimera_result),offsetof(smi_chimera_result,flags),"
+                   "sizeof(smi_umi_assignment),offsetof(smi_umi_assignment,pos2),sizeof(smi_umi_cluster_config));return 0;}\n")
+    exe = tmp_path / "sz2"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    sr, sc, cr = built.SCAN_RESULT_DTYPE, built.SCAN_CONFIG_DTYPE, built.CHIMERA_RESULT_DTYPE
+    ua, uc = libmod.UMI_ASSIGNMENT_DTYPE, libmod.UMI_CLUSTER_CONFIG_DTYPE
+    assert got == [sr.itemsize, sr.fields["scan_end"][1], sr.fields["found"][1], sr.fields["tso_end"][1], sc.itemsize,
+                   sc.fields["adapter4"][1], sc.fields["adapter_search_window"][1], cr.itemsize, cr.fields["flags"][1],
+                   ua.itemsize, ua.fields["pos2"][1], uc.itemsize]
+
+
+def test_host_entry_points_reject_bad_arguments(built):
+    """host-side entry points need no GPU: they validate and report through smi_last_error"""
+    from sicelore_amd import lib as libmod
+
+    lib = built.load_library()
+    assert lib.smi_region_group(None, None, None, 5, 500, 0, None, None) < 0
+    assert b"smi_region_group" in lib.smi_last_error()
+    assert lib.smi_umi_cluster_groups(None, None, None, 3, None, None, None, None, 1) < 0
+    assert lib.smi_chimera_fragment_name(b"r x", None, 0, None, 0) < 0
+    assert libmod.region_group([], []) == ([], 0)
+    out, sk = libmod.umi_cluster_groups(np.zeros(0, np.uint8), [0], [0], np.zeros(0, np.float32))
+    assert out.size == 0 and sk.size == 0
+
+
 def test_no_gpu_fails_loudly(built):
     import torch
 
