@@ -448,22 +448,34 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 const int n_win = FP ? SMI_WIN_BASES_5P : SMI_WIN_BASES_3P;
                 const int hi_sp = s_end - 2 + n_win, lo_sp = s_end - 1;
                 if (lo_sp >= 1 && hi_sp <= len && hi_sp <= kEndBases) {
-                    uint64_t bases = 0;
-                    uint32_t nmask = 0;
-#pragma unroll 5
-                    for (int j = 0; j < 25; j++) {
-                        if (j >= n_win) break;
-                        const int bit = FP ? lo_sp + j - 1 : hi_sp - j - 1;  // 0-based scan index of window base j
-                        const uint32_t a = get32(planes + 0 * kLdsWords * kBlock, tid, bit) & 1u;
-                        const uint32_t g = get32(planes + 1 * kLdsWords * kBlock, tid, bit) & 1u;
-                        const uint32_t c = get32(planes + 2 * kLdsWords * kBlock, tid, bit) & 1u;
-                        const uint32_t t = get32(planes + 3 * kLdsWords * kBlock, tid, bit) & 1u;
-                        const uint32_t single = (a + g + c + t) == 1u;
-                        // 2-bit code A0 G1 C2 T3; 3' takes the complement (A<->T, G<->C)
-                        const uint32_t code = FP ? (t ? 3u : (c ? 2u : (g ? 1u : 0u))) : (t ? 0u : (c ? 1u : (g ? 2u : 3u)));
-                        bases = (bases << 2) | (single ? code : 0u);
-                        nmask |= (single ? 0u : 1u) << j;
+                    // bit-parallel on one 32-bit window per plane (bit i = scan position lo_sp + i): a base is kept when
+                    // exactly one plane has it (N and '-' go to the mask); 2-bit codes A0 G1 C2 T3, complemented for 3'
+                    const uint32_t wm = (1u << n_win) - 1u;
+                    const uint32_t va = get32(planes + 0 * kLdsWords * kBlock, tid, lo_sp - 1);
+                    const uint32_t vg = get32(planes + 1 * kLdsWords * kBlock, tid, lo_sp - 1);
+                    const uint32_t vc = get32(planes + 2 * kLdsWords * kBlock, tid, lo_sp - 1);
+                    const uint32_t vt = get32(planes + 3 * kLdsWords * kBlock, tid, lo_sp - 1);
+                    const uint32_t single = (va ^ vg ^ vc ^ vt) & ~((va & vg & (vc | vt)) | (vc & vt & (va | vg))) & wm;
+                    uint32_t hi = (FP ? (vc | vt) : (vg | va)) & single, lo = (FP ? (vg | vt) : (vc | va)) & single;
+                    uint32_t nmask = ~single & wm;
+                    // window base j sits at bit n_win-1-j of the 3' window (the reverse complement reads it backwards)
+                    // and at bit j of the 5' one; base 0 is the most significant 2-bit group of `bases`
+                    if (FP) {
+                        hi = __brev(hi) >> (32 - n_win);
+                        lo = __brev(lo) >> (32 - n_win);
+                    } else {
+                        nmask = __brev(nmask) >> (32 - n_win);
                     }
+                    auto spread = [](uint32_t x) {
+                        uint64_t v = x;
+                        v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+                        v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+                        v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+                        v = (v | (v << 2)) & 0x3333333333333333ull;
+                        v = (v | (v << 1)) & 0x5555555555555555ull;
+                        return v;
+                    };
+                    const uint64_t bases = (spread(hi) << 1) | spread(lo);
                     win.bases = bases;
                     win.nmask = nmask;
                     win.flags = SMI_WIN_VALID | (FP ? SMI_WIN_5P : 0u);
