@@ -363,6 +363,31 @@ int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, con
  * (L309,L323); returns the length written or a negative smi_status */
 int smi_chimera_fragment_name(const char *read_name, const smi_chimera_result *res, int fragment, char *out, size_t cap);
 
+/* ================================================================================================================
+ * FASTQ ingest (the caller side of the path): uncompressed FASTQ text resident on the device ->
+ * record index + the contiguous read / quality buffers the kernels above take.  Replaces the htsjdk FastqReader loop of
+ * FastqFileReader$OneFastqFileWorker (FJ!nanoporereadscanner/readerwriter/FastqFileReader.java:L138-167); gz inflate
+ * stays on the host.  FastqReader's checks are reported in *errors (the reference throws SAMException), never repaired.
+ * ================================================================================================================ */
+#define SMI_FQ_BAD_SEQ_HEADER 1u  /* a record's first line does not start with '@' */
+#define SMI_FQ_BAD_QUAL_HEADER 2u /* its third line does not start with '+' */
+#define SMI_FQ_LENGTH_MISMATCH 4u /* sequence and quality lines differ in length */
+#define SMI_FQ_TRUNCATED 8u       /* the text does not end on a record boundary (line count not a multiple of 4) */
+
+/* d_line_start: scratch, cap_lines >= number of lines + 1 (4 * records + 2 is always enough);
+ * per record r < *n_records: name = text[name_start .. +name_len) (without '@'), read = text[seq_start .. +seq_len),
+ * qualities = text[qual_start .. +seq_len); d_offsets[r] = sum of seq_len before r (cap_records + 1 entries), the
+ * `offsets` array of smi_pack_ends_device / smi_pack_reads_device once the reads are gathered.  Synchronises the stream. */
+int smi_fastq_index_device(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
+                           uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
+                           uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records,
+                           uint32_t *errors, void *stream);
+
+/* d_out[d_offsets[r] .. d_offsets[r+1]) = d_text[d_start[r] ..): call with seq_start for the reads, qual_start for the
+ * qualities */
+int smi_fastq_gather_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
+                            uint8_t *d_out, void *stream);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

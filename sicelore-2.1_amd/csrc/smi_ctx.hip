@@ -140,6 +140,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->rank);
     (void)hipFree(ctx->block_counts);
     (void)hipFree(ctx->stage_in);
+    (void)hipFree(ctx->scan_tmp);
     (void)hipFree(ctx->stage_out);
     for (int k = 0; k < SMI_K_COUNT; k++) {
         if (ctx->kev[k][0]) (void)hipEventDestroy(ctx->kev[k][0]);
@@ -304,6 +305,34 @@ int smi_scan_default_config(int pass, smi_scan_config *cfg) {
     for (int i = 0; i < cfg->adapter_len; i++)
         cfg->adapter4[i] = ad[i] == 'A' ? 1u : ad[i] == 'G' ? 2u : ad[i] == 'C' ? 4u : 8u;
     return SMI_OK;
+}
+
+int smi_fastq_index_device(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
+                           uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
+                           uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records,
+                           uint32_t *errors, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (!n_records || !errors || (n_bytes && (!d_text || !d_line_start || !d_name_start || !d_name_len || !d_seq_start ||
+                                              !d_seq_len || !d_qual_start || !d_offsets))) {
+        set_error("smi_fastq_index_device: null argument");
+        return SMI_ERR_INVALID;
+    }
+    if (n_bytes >= ((size_t)1 << 42) || cap_records >= ((size_t)1 << 31) - 2) {
+        set_error("smi_fastq_index_device: buffer too large for one call");
+        return SMI_ERR_INVALID;
+    }
+    return launch_fastq_index(ctx, d_text, n_bytes, d_line_start, cap_lines, d_name_start, d_name_len, d_seq_start, d_seq_len,
+                              d_qual_start, d_offsets, cap_records, n_records, errors, (hipStream_t)stream);
+}
+
+int smi_fastq_gather_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
+                            uint8_t *d_out, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_text || !d_start || !d_offsets || !d_out)) {
+        set_error("smi_fastq_gather_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_fastq_gather(ctx, d_text, d_start, d_offsets, n, d_out, (hipStream_t)stream);
 }
 
 int smi_chimera_default_config(smi_chimera_config *cfg) {

@@ -1,0 +1,193 @@
+// smi_fastq.hip -- K-FQ: FASTQ text resident in HBM -> record index and contiguous read / quality buffers.
+//
+// SURVEY section 8f.1 (the caller side of the path): replaces the htsjdk FastqReader loop of
+// FastqFileReader$OneFastqFileWorker (FJ!nanoporereadscanner/readerwriter/FastqFileReader.java:L138-167 submits one per
+// file; 10,000-record chunks, WorkerReadscanner.java:L186) for uncompressed text: gz inflate stays on the host.
+// htsjdk 4.1.3 FastqReader semantics kept: four lines per record, '@' and '+' headers, sequence and quality lines of
+// equal length, line ends "\n" or "\r\n"; a violation is reported through the error word, never repaired.
+//
+// MI355X mapping: newline positions are found by all lanes at once (16 bytes per lane, block-level counts, one
+// exclusive scan over the blocks, then a second sweep writes the start of every line); records are then four consecutive
+// line starts.  Byte work at HBM speed, no MFMA.
+#include <hipcub/hipcub.hpp>
+
+#include "smi_internal.h"
+
+namespace smi {
+
+constexpr int kFqBlock = 256;
+constexpr int kFqBytesPerThread = 16;
+constexpr int kFqTile = kFqBlock * kFqBytesPerThread;  // 4 KiB of text per block
+
+// newline flags of 16 bytes: bit k set when text[i0 + k] == '\n' (one 16-byte load; SWAR zero-byte test per dword)
+__device__ __forceinline__ uint32_t nl_mask16(const uint8_t *p, size_t i0, size_t n) {
+    if (i0 + kFqBytesPerThread <= n) {
+        uint32_t w[4];
+        __builtin_memcpy(w, p + i0, 16);
+        uint32_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t t = w[k] ^ 0x0A0A0A0Au;
+            const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 in every zero byte, exact
+            m |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu) << (4 * k);
+        }
+        return m;
+    }
+    uint32_t m = 0;
+    for (int k = 0; k < kFqBytesPerThread; k++) m |= (i0 + k < n && p[i0 + k] == '\n') ? (1u << k) : 0u;
+    return m;
+}
+__device__ __forceinline__ uint32_t count_nl16(const uint8_t *p, size_t i0, size_t n) { return __popc(nl_mask16(p, i0, n)); }
+
+__global__ __launch_bounds__(kFqBlock) void k_fq_count(const uint8_t *__restrict__ text, size_t n, uint32_t *__restrict__ block_counts) {
+    __shared__ uint32_t sh[kFqBlock];
+    const size_t i0 = (size_t)blockIdx.x * kFqTile + (size_t)threadIdx.x * kFqBytesPerThread;
+    sh[threadIdx.x] = count_nl16(text, i0, n);
+    __syncthreads();
+    for (int o = kFqBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = sh[0];
+}
+
+// line_start[L] = first byte of line L (line 0 starts at 0); block_base[b] = newlines before block b
+__global__ __launch_bounds__(kFqBlock) void k_fq_lines(const uint8_t *__restrict__ text, size_t n,
+                                                       const uint64_t *__restrict__ block_base, uint64_t *__restrict__ line_start,
+                                                       size_t cap_lines) {
+    __shared__ uint32_t sh[kFqBlock];
+    const size_t i0 = (size_t)blockIdx.x * kFqTile + (size_t)threadIdx.x * kFqBytesPerThread;
+    const uint32_t mine = count_nl16(text, i0, n);
+    sh[threadIdx.x] = mine;
+    __syncthreads();
+    for (int o = 1; o < kFqBlock; o <<= 1) {
+        const uint32_t y = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
+        __syncthreads();
+        sh[threadIdx.x] += y;
+        __syncthreads();
+    }
+    uint64_t line = block_base[blockIdx.x] + sh[threadIdx.x] - mine;  // newlines before my first byte
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cap_lines > 0) line_start[0] = 0;
+    for (uint32_t m = nl_mask16(text, i0, n); m; m &= m - 1) {
+        line++;
+        if (line < cap_lines) line_start[line] = i0 + (size_t)__builtin_ctz(m) + 1;
+    }
+}
+
+// record r = lines 4r .. 4r+3
+__global__ void k_fq_records(const uint8_t *__restrict__ text, size_t n_bytes, const uint64_t *__restrict__ line_start,
+                             uint64_t n_lines_complete, size_t n_rec, uint64_t *__restrict__ name_start,
+                             uint32_t *__restrict__ name_len, uint64_t *__restrict__ seq_start, uint32_t *__restrict__ seq_len,
+                             uint64_t *__restrict__ qual_start, uint32_t *__restrict__ err) {
+    const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (r >= n_rec) return;
+    auto line_end = [&](uint64_t L) -> uint64_t {  // one past the last character of line L (CR / LF stripped)
+        uint64_t e = L + 1 <= n_lines_complete ? line_start[L + 1] - 1 : n_bytes;  // the last line may lack its newline
+        if (e > line_start[L] && text[e - 1] == '\r') e--;
+        return e;
+    };
+    const uint64_t l0 = line_start[4 * r], l1 = line_start[4 * r + 1], l2 = line_start[4 * r + 2], l3 = line_start[4 * r + 3];
+    const uint64_t e0 = line_end(4 * r), e1 = line_end(4 * r + 1), e2 = line_end(4 * r + 2), e3 = line_end(4 * r + 3);
+    uint32_t bad = 0;
+    if (e0 == l0 || text[l0] != '@') bad |= SMI_FQ_BAD_SEQ_HEADER;
+    if (e2 == l2 || text[l2] != '+') bad |= SMI_FQ_BAD_QUAL_HEADER;
+    if (e1 - l1 != e3 - l3) bad |= SMI_FQ_LENGTH_MISMATCH;
+    if (bad) atomicOr(err, bad);
+    name_start[r] = l0 + 1;
+    name_len[r] = (uint32_t)(e0 > l0 ? e0 - l0 - 1 : 0);
+    seq_start[r] = l1;
+    seq_len[r] = (uint32_t)(e1 - l1);
+    qual_start[r] = l3;
+}
+
+// one wave per record: out[offsets[r] .. offsets[r+1]) = text[start[r] ..]
+__global__ __launch_bounds__(256) void k_fq_gather(const uint8_t *__restrict__ text, const uint64_t *__restrict__ start,
+                                                   const uint64_t *__restrict__ offsets, size_t n, uint8_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < n; r += n_waves) {
+        const uint64_t s = start[r], o = offsets[r], len = offsets[r + 1] - o;
+        for (uint64_t i = lane; i < len; i += 64) out[o + i] = text[s + i];
+    }
+}
+
+static int ensure_scan_tmp(smi_ctx *ctx, size_t bytes) {
+    if (bytes > ctx->scan_tmp_bytes) {
+        if (ctx->scan_tmp) SMI_HIP(hipFree(ctx->scan_tmp));
+        ctx->scan_tmp = nullptr;
+        ctx->scan_tmp_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->scan_tmp, bytes));
+        ctx->scan_tmp_bytes = bytes;
+    }
+    return SMI_OK;
+}
+
+int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
+                       uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
+                       uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records, uint32_t *errors,
+                       hipStream_t s) {
+    *n_records = 0;
+    *errors = 0;
+    if (!n_bytes) return SMI_OK;
+    const size_t n_blocks = (n_bytes + kFqTile - 1) / kFqTile;
+    // scratch: block counts (u32), block bases (u64), scalars, hipcub temp
+    size_t cub_a = 0, cub_b = 0;
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_a, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)n_blocks, s));
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)cap_records + 1, s));
+    const size_t off_counts = 0, off_base = (n_blocks * 4 + 255) & ~(size_t)255, off_scal = off_base + ((n_blocks * 8 + 255) & ~(size_t)255),
+                 off_cub = off_scal + 256, total = off_cub + std::max(cub_a, cub_b);
+    if (int rc = ensure_scan_tmp(ctx, total)) return rc;
+    uint8_t *tmp = (uint8_t *)ctx->scan_tmp;
+    uint32_t *counts = (uint32_t *)(tmp + off_counts);
+    uint64_t *bases = (uint64_t *)(tmp + off_base);
+    uint32_t *d_err = (uint32_t *)(tmp + off_scal);
+    SMI_HIP(hipMemsetAsync(d_err, 0, 16, s));
+    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts);
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_a, counts, bases, (int)n_blocks, s));
+    hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, bases, d_line_start, cap_lines);
+    // number of newlines = base of the last block + its count
+    uint64_t last_base = 0;
+    uint32_t last_count = 0;
+    SMI_HIP(hipMemcpyAsync(&last_base, bases + (n_blocks - 1), 8, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipMemcpyAsync(&last_count, counts + (n_blocks - 1), 4, hipMemcpyDeviceToHost, s));
+    uint8_t last_byte = 0;
+    SMI_HIP(hipMemcpyAsync(&last_byte, d_text + (n_bytes - 1), 1, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    const uint64_t n_newlines = last_base + last_count;
+    const uint64_t n_lines = n_newlines + (last_byte == '\n' ? 0 : 1);  // a last line without newline still counts
+    if (n_lines + 1 > cap_lines) {
+        set_error("smi_fastq_index_device: line buffer too small");
+        return SMI_ERR_INVALID;
+    }
+    uint32_t host_err = 0;
+    if (n_lines % 4 != 0) host_err |= SMI_FQ_TRUNCATED;  // htsjdk: "missing ... line" at end of file
+    const size_t n_rec = (size_t)(n_lines / 4);
+    if (n_rec > cap_records) {
+        set_error("smi_fastq_index_device: record buffers too small");
+        return SMI_ERR_INVALID;
+    }
+    if (n_rec) {
+        hipLaunchKernelGGL(k_fq_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, d_text, n_bytes, d_line_start,
+                           n_newlines, n_rec, d_name_start, d_name_len, d_seq_start, d_seq_len, d_qual_start, d_err);
+        SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_b, d_seq_len, d_offsets, (int)n_rec + 1, s));
+    } else
+        SMI_HIP(hipMemsetAsync(d_offsets, 0, 8, s));
+    uint32_t dev_err = 0;
+    SMI_HIP(hipMemcpyAsync(&dev_err, d_err, 4, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    *n_records = n_rec;
+    *errors = host_err | dev_err;
+    return SMI_OK;
+}
+
+int launch_fastq_gather(smi_ctx *, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
+                        uint8_t *d_out, hipStream_t s) {
+    if (!n) return SMI_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 64);
+    hipLaunchKernelGGL(k_fq_gather, dim3(grid), dim3(256), 0, s, d_text, d_start, d_offsets, n, d_out);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+}  // namespace smi

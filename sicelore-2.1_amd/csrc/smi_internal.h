@@ -72,6 +72,8 @@ struct smi_ctx {
     void *stage_out = nullptr;
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
     hipStream_t stream = nullptr;  // private stream of the *_batch entry points
+    void *scan_tmp = nullptr;      // scratch of the FASTQ indexer (block counts + hipcub temp storage)
+    size_t scan_tmp_bytes = 0;
 };
 
 namespace smi {
@@ -102,4 +104,10 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
 int launch_split_offsets(smi_ctx *ctx, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,
                          uint32_t *d_scratch, uint64_t *d_total, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
                          hipStream_t s);
+int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
+                       uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
+                       uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records, uint32_t *errors,
+                       hipStream_t s);
+int launch_fastq_gather(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
+                        uint8_t *d_out, hipStream_t s);
 }  // namespace smi

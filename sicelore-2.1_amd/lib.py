@@ -51,7 +51,7 @@ EXPORTS = [
     "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
-    "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p",
+    "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
 ]
 
 
@@ -97,6 +97,9 @@ def load_library():
     lib.smi_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     lib.smi_umi_dist_device.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
     lib.smi_chimera_default_config.argtypes = [vp]
+    lib.smi_fastq_index_device.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz),
+                                           ctypes.POINTER(ctypes.c_uint32), vp]
+    lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.smi_chimera_default_config_5p.argtypes = [vp]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
@@ -331,6 +334,23 @@ class Context:
         """d_ends int32 [28, 2n]; d_len int32 [n]; d_out int32 [n, 8] (32-B records); d_windows int64 [n, 2]"""
         self._check(self._lib.smi_scan_device(self._h, _ptr(d_ends), _ptr(d_len), _ptr(d_qtail), _ptr(d_qsum), int(n),
                                               _ptr(cfg), _ptr(d_out), _ptr(d_windows), _stream_ptr(stream)))
+
+    # ---- FASTQ ingest --------------------------------------------------------------------------------------
+    def fastq_index_device(self, d_text, n_bytes, d_line_start, d_name_start, d_name_len, d_seq_start, d_seq_len, d_qual_start,
+                           d_offsets, cap_records, stream=None):
+        """-> (n_records, error bits); buffers: int64 / int32 device tensors of capacity cap_records (+1 for offsets)"""
+        n_rec = ctypes.c_size_t(0)
+        err = ctypes.c_uint32(0)
+        self._check(self._lib.smi_fastq_index_device(self._h, _ptr(d_text), int(n_bytes), _ptr(d_line_start),
+                                                     int(d_line_start.numel()), _ptr(d_name_start), _ptr(d_name_len),
+                                                     _ptr(d_seq_start), _ptr(d_seq_len), _ptr(d_qual_start), _ptr(d_offsets),
+                                                     int(cap_records), ctypes.byref(n_rec), ctypes.byref(err),
+                                                     _stream_ptr(stream)))
+        return n_rec.value, err.value
+
+    def fastq_gather_device(self, d_text, d_start, d_offsets, n, d_out, stream=None):
+        self._check(self._lib.smi_fastq_gather_device(self._h, _ptr(d_text), _ptr(d_start), _ptr(d_offsets), int(n), _ptr(d_out),
+                                                      _stream_ptr(stream)))
 
     # ---- chimera splitter ----------------------------------------------------------------------------------
     def chimera_config(self, five_prime=False):

@@ -34,7 +34,7 @@ def main():
     res = {}
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
-    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera}
+    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq}
     for name, fn in legs.items():
         if only in (None, name):
             fn(pkg, synth, ctx, dev, wl, used, res)
@@ -133,6 +133,50 @@ def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
                       "bases_per_s": total / dt, "pack_GBps": total / dt_pack / 1e9,
                       "split_frac": float((cr["n_split"] > 0).mean()), "multi_frac": float((cr["flags"] & 1).mean()),
                       "overflow": int((cr["flags"] & 4).sum())}
+
+
+def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
+    # ---- K-FQ: FASTQ text -> record index -> contiguous reads; text built on the device from synthetic reads -----------
+    n = 500_000
+    rd = synth.gen_reads(n, used, seed=9, device=dev)
+    buf, offs = synth.materialize_device(rd)
+    lens = offs[1:] - offs[:-1]
+    # record = "@rNNNNNNNN\n" + seq + "\n+\n" + qual + "\n": 11 + len + 3 + len + 1 bytes
+    rec_len = 2 * lens + 15
+    rec_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rec_off[1:] = torch.cumsum(rec_len, 0)
+    total = int(rec_off[-1])
+    text = torch.full((total,), ord("I"), dtype=torch.uint8, device=dev)
+    idx = torch.arange(n, device=dev)
+    text[rec_off[:-1]] = ord("@")
+    text[rec_off[:-1] + 1] = ord("r")
+    for k in range(8):
+        text[rec_off[:-1] + 2 + k] = (48 + (idx // 10 ** (7 - k)) % 10).to(torch.uint8)
+    text[rec_off[:-1] + 10] = 10
+    text[rec_off[:-1] + 11 + lens] = 10
+    text[rec_off[:-1] + 12 + lens] = ord("+")
+    text[rec_off[:-1] + 13 + lens] = 10
+    text[rec_off[1:] - 1] = 10
+    pos = torch.arange(int(offs[-1]), device=dev) - torch.repeat_interleave(offs[:-1], lens) + \
+        torch.repeat_interleave(rec_off[:-1] + 11, lens)
+    text[pos] = buf
+    del pos
+    cap = n + 2
+    line = torch.zeros(4 * cap + 8, dtype=torch.int64, device=dev)
+    ns, ss, qs = (torch.zeros(cap, dtype=torch.int64, device=dev) for _ in range(3))
+    nl, sl = (torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(2))
+    o = torch.zeros(cap + 1, dtype=torch.int64, device=dev)
+    out = torch.zeros(int(offs[-1]), dtype=torch.uint8, device=dev)
+    state = {}
+
+    def run():
+        state["n"], state["err"] = ctx.fastq_index_device(text, total, line, ns, nl, ss, sl, qs, o, cap)
+        ctx.fastq_gather_device(text, ss, o, state["n"], out)
+
+    dt = timed(run)
+    assert state["n"] == n and state["err"] == 0 and bool((out == buf).all())
+    res["fastq_ingest"] = {"reads": n, "text_bytes": total, "ms": dt * 1e3, "text_GBps": total / dt / 1e9,
+                           "reads_per_s": n / dt}
 
 
 if __name__ == "__main__":
