@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference's `scanfastq` worker for one chunk of FASTQ text (WorkerReadscanner.scan ->
+Parser.call, FJ!nanoporereadscanner/WorkerReadscanner.java:L186-273, FJ!nanoporereadscanner/analyzers/Parser.java:L132-185):
+everything per read runs in the HIP library behind include/sicelore_mi.h; this module only strings the entry points
+together in the reference's order and formats the output records.  No CPU fallback: it needs a Context.
+
+pass 1 (UsedCellBCListGenerator): FASTQ text -> K-FQ -> K-PACK (+ qualities) -> K-SCAN (complete adapter, quality
+filter) -> histogram of whitelist members.
+pass 2 (Parser): FASTQ text -> K-FQ -> [K-PACKR -> K-CHIM -> fragment offsets] -> K-PACK -> K-SCAN -> K-BC1/K-BC2 ->
+read names (smi_format_read_name / smi_chimera_fragment_name on the host).
+"""
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+READS_AFTER_SPLIT = 1 << 4            # ReadFlags$Flags ordinals (ReadFlags.java:L72-109)
+MULTI_CHIMERIC_READS_DISCARDED = 1 << 2
+FAILED = 1 << 6
+
+
+class ReadScanner:
+    def __init__(self, ctx, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True):
+        self.ctx, self.max_ed, self.five_prime = ctx, int(max_ed), bool(five_prime)
+        self.dont_search_polya = bool(dont_search_polya)
+        # Parser.java:L176: chimeras are split in pass 2 unless --noPolyARequired
+        self.split_chimeras = bool(split_chimeras) and not (five_prime and dont_search_polya)
+        self.dev = torch.device("cuda", ctx.device)
+
+    # ---- FASTQ text -> contiguous reads / qualities -------------------------------------------------------------
+    def _ingest(self, text, want_quals):
+        t = torch.from_numpy(np.frombuffer(text, dtype=np.uint8).copy()).to(self.dev)
+        cap = text.count(b"\n") // 4 + 2
+        i64 = lambda n: torch.zeros(n, dtype=torch.int64, device=self.dev)  # noqa: E731
+        i32 = lambda n: torch.zeros(n, dtype=torch.int32, device=self.dev)  # noqa: E731
+        line, ns, ss, qs, offs, nl, sl = i64(4 * cap + 8), i64(cap), i64(cap), i64(cap), i64(cap + 1), i32(cap), i32(cap)
+        n, err = self.ctx.fastq_index_device(t, len(text), line, ns, nl, ss, sl, qs, offs, cap)
+        if err:
+            raise _lib.SmiError(f"malformed FASTQ (smi_fastq_index_device error bits {err})")  # the reference throws too
+        total = int(offs[n].item()) if n else 0
+        reads = torch.zeros(max(total, 1), dtype=torch.uint8, device=self.dev)
+        self.ctx.fastq_gather_device(t, ss, offs, n, reads)
+        quals = None
+        if want_quals:
+            quals = torch.zeros(max(total, 1), dtype=torch.uint8, device=self.dev)
+            self.ctx.fastq_gather_device(t, qs, offs, n, quals)
+        ns_h, nl_h = ns[:n].cpu().numpy(), nl[:n].cpu().numpy()
+        names = [text[int(a):int(a) + int(b)].decode() for a, b in zip(ns_h, nl_h)]
+        return n, total, reads, quals, offs[:n + 1].contiguous(), names
+
+    def _scan(self, reads, quals, offs, n, pass_no):
+        ends = torch.zeros((28, 2 * max(n, 1)), dtype=torch.int32, device=self.dev)
+        lens = torch.zeros(max(n, 1), dtype=torch.int32, device=self.dev)
+        qt = qsum = None
+        if quals is not None:
+            qt = torch.zeros((max(n, 1), 224), dtype=torch.uint8, device=self.dev)
+            qsum = torch.zeros(max(n, 1), dtype=torch.int32, device=self.dev)
+        self.ctx.pack_ends_device(reads, quals, offs, n, ends, lens, qt, qsum, five_prime=self.five_prime)
+        cfg = self.ctx.scan_config_5p(pass_no, self.dont_search_polya) if self.five_prime else self.ctx.scan_config(pass_no)
+        scan = torch.zeros((max(n, 1), 8), dtype=torch.int32, device=self.dev)
+        win = torch.zeros((max(n, 1), 2), dtype=torch.int64, device=self.dev)
+        self.ctx.scan_device(ends, lens, n, cfg, scan, win, qt, qsum)
+        return scan, win
+
+    # ---- pass 1 ----------------------------------------------------------------------------------------------------
+    def pass1_chunk(self, text, hist):
+        """adds this chunk's whitelist hits to `hist` (int32 device tensor, one counter per loaded barcode); -> n reads"""
+        n, _total, reads, quals, offs, _names = self._ingest(text, want_quals=True)
+        if n:
+            scan, win = self._scan(reads, quals, offs, n, pass_no=1)
+            self.ctx.hist_windows_device(win, scan, n, hist)
+        return n
+
+    # ---- pass 2 ----------------------------------------------------------------------------------------------------
+    def pass2_chunk(self, text, rank_of=None, first_read_id=0):
+        """-> list of dicts per output record (after the chimera split): name (as written by the reference), passed,
+        reverse, flags, source (index of the input record), fragment (0..2) and length of the record"""
+        n, total, reads, quals, offs, names = self._ingest(text, want_quals=True)
+        if n == 0:
+            return []
+        src = np.arange(n)
+        frag = np.zeros(n, dtype=np.int64)
+        chim = None
+        if self.split_chimeras:
+            planes = torch.zeros(self.ctx.read_planes_words(total, n), dtype=torch.int32, device=self.dev)
+            self.ctx.pack_reads_device(reads, offs, n, total, planes)
+            d_chim = torch.zeros((n, 4), dtype=torch.int32, device=self.dev)
+            self.ctx.chimera_device(planes, offs, n, total, self.ctx.chimera_config(self.five_prime), d_chim)
+            scratch = torch.zeros((n + 1023) // 1024 + 1, dtype=torch.int32, device=self.dev)
+            nfrag = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            foffs = torch.zeros(3 * n + 1, dtype=torch.int64, device=self.dev)
+            fsrc = torch.zeros(3 * n, dtype=torch.int32, device=self.dev)
+            self.ctx.split_offsets_device(d_chim, offs, n, scratch, nfrag, foffs, fsrc)
+            m = int(nfrag.item())
+            chim = d_chim.cpu().numpy().view(_lib.CHIMERA_RESULT_DTYPE).reshape(-1)
+            if (chim["flags"] & (_lib.CHIM_RANGE | _lib.CHIM_OVERFLOW)).any():
+                raise _lib.SmiError("chimera splitter: a read outside the supported range (SMI_CHIM_RANGE / SMI_CHIM_OVERFLOW)")
+            offs = foffs[:m + 1].contiguous()
+            fs = fsrc[:m].cpu().numpy()
+            src, frag, n_out = fs >> 2, fs & 3, m
+        else:
+            n_out = n
+        scan_d, win = self._scan(reads, quals, offs, n_out, pass_no=2)
+        res_d = torch.zeros((n_out, 4), dtype=torch.int32, device=self.dev)
+        self.ctx.bc_match_device(win, res_d, n_out, max_ed=self.max_ed, five_prime=self.five_prime)
+        torch.cuda.synchronize()
+        scan = scan_d.cpu().numpy().view(_lib.SCAN_RESULT_DTYPE).reshape(-1)[:n_out]
+        bc = res_d.cpu().numpy().view(_lib.BC_RESULT_DTYPE).reshape(-1)[:n_out]
+        o = offs.cpu().numpy()
+        rb, qb = reads.cpu().numpy(), quals.cpu().numpy()
+        out = []
+        for i in range(n_out):
+            r = int(src[i])
+            name, flags = names[r], int(scan["flags"][i])
+            if chim is not None:
+                if chim["n_split"][r]:
+                    name = _lib.chimera_fragment_name(name, chim[r], int(frag[i]))
+                    flags |= READS_AFTER_SPLIT
+                if chim["flags"][r] & _lib.CHIM_MULTI:
+                    flags |= MULTI_CHIMERIC_READS_DISCARDED | FAILED
+            seq = rb[int(o[i]):int(o[i + 1])].tobytes().decode()
+            qual = qb[int(o[i]):int(o[i + 1])].tobytes().decode()
+            b = bc[i] if bc["found"][i] == 1 else None
+            rk = 0
+            if b is not None and rank_of is not None:
+                rk = int(rank_of.get(int(b["bc"]), 0))
+            failed_multi = chim is not None and bool(chim["flags"][r] & _lib.CHIM_MULTI)
+            if failed_multi:  # Parser.processOneRecord L92: FAILED records are not scanned
+                full = name.split(" ")[0] + "_FAILED "
+                sc = np.zeros(1, dtype=_lib.SCAN_RESULT_DTYPE)[0]
+            else:
+                sc = scan[i]
+                full = _lib.format_read_name(name, seq, qual, sc, b, rank=rk, read_id=first_read_id + i,
+                                             five_prime=self.five_prime)
+            out.append(dict(name=full, passed=bool(int(sc["flags"]) & ((1 << 9) | (1 << 10))) and not failed_multi,
+                            reverse=bool(sc["reverse"]), flags=flags, source=r, fragment=int(frag[i]),
+                            length=int(o[i + 1]) - int(o[i])))
+        return out
