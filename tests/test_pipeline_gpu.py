@@ -87,3 +87,73 @@ def test_two_pass_flow(pkg, synth, sor, gpu_ctx):
     truth = reads["truth"].numpy()
     ok = sum(sor.encode(o["name"].split(" cellBC=")[1]) == int(truth[o["source"]]) for o in named)
     assert ok > 0.98 * len(named)
+
+
+def test_assignumis_flow_recovers_planted_umis(pkg, synth, sor, gpu_ctx):
+    """scanfastq names -> region grouping -> K-UMI -> clustering: reads of one molecule end with one UMI; every stage is
+    also run through the oracle on the same inputs"""
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    from sicelore_amd import lib as libmod
+
+    rng = np.random.default_rng(7)
+    wl = synth.make_whitelist(50_000, seed=271)
+    used = synth.pick_used(wl, 6, seed=272)
+    n_mol, copies = 60, 6
+    mol = synth.gen_reads(n_mol, used, seed=273, err=0.0, q_mean=20.0)          # error-free molecules ...
+    seqs, quals, mol_of = [], [], []
+    for m in range(n_mol):
+        s, q = synth.materialize(mol, m)
+        for _ in range(copies):                                                  # ... read several times with errors
+            t = list(s)
+            for p in rng.integers(0, len(t), max(1, len(t) // 40)):
+                t[p] = "ACGT"[rng.integers(0, 4)]
+            seqs.append("".join(t))
+            quals.append(q)
+            mol_of.append(m)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    rs = scanfastq.ReadScanner(gpu_ctx, max_ed=1, split_chimeras=False)
+    recs = rs.pass2_chunk(_fastq(seqs, quals))
+    names = [r["name"] for r in recs]
+    gene_of_mol = rng.integers(0, 8, n_mol)
+    positions = [int(100_000 + 20_000 * gene_of_mol[m] + rng.integers(-100, 100)) for m in mol_of]
+    strand = [bool(gene_of_mol[m] & 1) for m in mol_of]
+    tags = assignumis.assign_umis(gpu_ctx, names, positions, strand)
+    # planted UMI of a molecule (transcript sense); the tested sequence is the reverse complement of X=
+    n_tagged = n_right = 0
+    by_mol = {}
+    for i, t in enumerate(tags):
+        if t is None:
+            continue
+        n_tagged += 1
+        by_mol.setdefault(mol_of[i], set()).add(t["U8"])
+        n_right += t["U8"] == sor.decode(int(mol["umi"][mol_of[i]]), 12)
+    assert n_tagged > 0.6 * len(names) and n_right > 0.9 * n_tagged
+    assert sum(len(v) == 1 for v in by_mol.values()) > 0.85 * len(by_mol)
+    # the same flow through the oracle
+    info = [assignumis.parse_name(nm) for nm in names]
+    pos = [p if info[i] is not None else None for i, p in enumerate(positions)]
+    region, _ = sor.region_group(pos, strand)
+    assert region == libmod.region_group(pos, strand)[0]
+    groups = {}
+    for i, f in enumerate(info):
+        if f is None or region[i] < 0:
+            continue
+        w = sor.umi_window_3p(f["x"], f["ae"], f["bc_end"])
+        mine = assignumis.umi_window(f["x"], f["ae"], f["bc_end"])
+        assert (w is None) == (mine is None)
+        if w is None:
+            continue
+        assert list(w) == mine
+        groups.setdefault((f["cell"], region[i]), []).append((i, w))
+    for g in groups.values():
+        if len(g) < 2:
+            continue
+        idx = [i for i, _ in g]
+        ws = np.array([w for _, w in g], dtype=np.uint8)
+        asg, _ = sor.umi_cluster_group(sor.umi_matrix(ws).reshape(-1), len(g), np.array([info[i]["q"] for i in idx], np.float32))
+        for j, i in enumerate(idx):
+            if asg["center"][j] < 0:
+                assert tags[i] is None
+            else:
+                assert tags[i]["center"] == idx[int(asg["center"][j])] and tags[i]["U1"] == asg["ed"][j]
