@@ -27,17 +27,15 @@ __device__ __forceinline__ uint32_t eq_mask(uint64_t w, uint32_t c) {
     return m;
 }
 
-// Myers / Hyyro global edit distance of pattern (12 bits of the per-code masks shifted by pi) vs 12 text codes
-__device__ __forceinline__ int myers12(uint32_t mA, uint32_t mG, uint32_t mC, uint32_t mT, uint32_t mN, int pi, uint64_t text,
-                                       int tj) {
+// Myers / Hyyro global edit distance of the 12-base pattern that starts at base `pi` of read a against the 12 text
+// bases that start at base `tj` of read b.  eq[j] = pattern positions (14 bits, of read a) matching text base j of read b.
+__device__ __forceinline__ int myers12(const uint32_t (&eq)[14], int pi, int tj) {
     const uint32_t M = 0xFFFu, TOP = 0x800u;
     uint32_t Pv = M, Mv = 0;
     int score = 12;
 #pragma unroll
     for (int t = 0; t < 12; t++) {
-        const uint32_t c = (uint32_t)(text >> (4 * (tj + t))) & 15u;
-        uint32_t Eq = c == 1u ? mA : c == 2u ? mG : c == 4u ? mC : c == 8u ? mT : c == 15u ? mN : 0u;
-        Eq = (Eq >> pi) & M;
+        const uint32_t Eq = (eq[tj + t] >> pi) & M;
         const uint32_t Xv = Eq | Mv;
         const uint32_t Xh = ((((Eq & Pv) + Pv) ^ Pv) | Eq) & M;
         uint32_t Ph = (Mv | ~(Xh | Pv)) & M;
@@ -54,6 +52,13 @@ __device__ __forceinline__ int myers12(uint32_t mA, uint32_t mG, uint32_t mC, ui
 
 __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b) {
     const uint32_t mA = eq_mask(a, 1), mG = eq_mask(a, 2), mC = eq_mask(a, 4), mT = eq_mask(a, 8), mN = eq_mask(a, 15);
+    // match masks per text base, shared by the nine alignments (a code outside A, G, C, T, N matches nothing, as equals() would)
+    uint32_t eq[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) {
+        const uint32_t c = (uint32_t)(b >> (4 * j)) & 15u;
+        eq[j] = c == 1u ? mA : c == 2u ? mG : c == 4u ? mC : c == 8u ? mT : c == 15u ? mN : 0u;
+    }
     // calcBestEditDistance L67-80: start (127, MINUSONE, MINUSONE); visit values 1,2,0 x 1,2,0; strict <
     int best = 127, b1 = 0, b2 = 0;
     const int ORDER[3] = {1, 2, 0};
@@ -62,7 +67,7 @@ __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b) {
 #pragma unroll
         for (int y = 0; y < 3; y++) {
             const int i = ORDER[x], v = ORDER[y];
-            int d = myers12(mA, mG, mC, mT, mN, i, b, v);
+            int d = myers12(eq, i, v);
             d = d > 4 ? 5 : d;  // limitedCompare: -1 above the threshold, stored as 5 (L343)
             if (d < best) {
                 best = d;
@@ -77,16 +82,20 @@ __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ w
                                                   const uint64_t *__restrict__ pair_off, const uint64_t *__restrict__ mat_off,
                                                   uint32_t n_groups, uint64_t total_pairs, uint8_t *__restrict__ out) {
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total_pairs; t += (uint64_t)gridDim.x * blockDim.x) {
-        // group of this pair: last g with pair_off[g] <= t
+        // group of this pair: last g with pair_off[g] <= t.  The pairs of a wave are consecutive, so the binary search
+        // runs once for the wave's first pair (scalar) and every lane walks forward from there
+        const uint64_t t_first = __builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) * 0x100000000ull +
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
         uint32_t lo = 0, hi = n_groups;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (pair_off[mid] <= t)
+            if (pair_off[mid] <= t_first)
                 lo = mid;
             else
                 hi = mid;
         }
-        const uint32_t g = lo;
+        uint32_t g = lo;
+        while (g + 1 < n_groups && pair_off[g + 1] <= t) g++;
         const uint64_t local = t - pair_off[g];
         const uint32_t r0 = group_off[g];
         const uint64_t n = group_off[g + 1] - r0;
