@@ -870,7 +870,11 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                             // the item being expanded is wave-uniform: keep it on the scalar unit
                             const int e = __builtin_amdgcn_readfirstlane((int)ord2e[on ? t : 0]);
                             const int pX = e >> 3, rX = e & 7;
-                            const Seq X = child_of(root, pX, rX, post1);
+                            // the item is one of the level-1 children, whose low words are in LDS already; its g bits
+                            // are non-zero only for "insert behind position 14" (child_of)
+                            Seq X;
+                            X.low = (uint32_t)__builtin_amdgcn_readfirstlane((int)lows[e]);
+                            X.g = (rX >= 3 && rX <= 6 && pX == 14) ? (K & 3u) : 0u;
                             const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;  // post[nDeletions + 1]
                             const int q0 = pX == 0 ? 1 : 0;                              // first visited position
                             const bool x_ok = on && X.g == 0u;  // a child of a g != 0 item can never equal a barcode
@@ -887,11 +891,19 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                                 w0[2 * g + h] = P.l0[live ? (m.low >> (kG0 + 5)) : 0u];
                             }
                         }
+                        // top-level test of the whole group first: with a short used list nothing survives it
+                        uint32_t any_pass = 0;
+#pragma unroll
+                        for (int i = 0; i < 2 * kGroup; i++) {
+                            m_ok[i] &= (w0[i] >> ((m_low[i] >> kG0) & 31u)) & 1u;
+                            any_pass |= m_ok[i];
+                        }
+                        if (!__ballot(any_pass != 0u)) continue;
 #pragma unroll
                         for (int i = 0; i < 2 * kGroup; i++) {
                             if (hit2) break;
-                            bool pass = m_ok[i] && ((w0[i] >> ((m_low[i] >> kG0) & 31u)) & 1u);
-                            if (!__ballot(pass)) continue;  // wave-uniform: nearly always taken
+                            bool pass = m_ok[i] != 0u;
+                            if (!__ballot(pass)) continue;
                             // Only a mutant that can be a barcode needs the dedup set ("expanded earlier" cannot change
                             // the outcome of a probe that misses), so the LDS look-up runs on the few top-level survivors
                             const int t = t0 + (i >> 1);

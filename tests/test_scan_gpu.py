@@ -214,3 +214,27 @@ def test_scan_5p_matches_oracle_and_assigns(pkg, synth, sor, gpu_ctx, pass_no, d
             assert res["bc"][i] == np.uint32(a["bc"]) and res["ed"][i] == a["ed"] and res["ed_sec"][i] == a["ed_sec"]
             assert res["offset"][i] == a["offset"] and res["ins_minus_del"][i] == a["ins_minus_del"]
     assert n_found > 0.6 * n and n_assigned > 0.5 * n_found and n_p1 > 0.02 * n and n_thrown < 0.01 * n
+
+
+def test_scan_large_batch_matches_oracle(pkg, synth, sor, gpu_ctx):
+    """500 k reads built on the device, scanned by K-PACK + K-SCAN (pass 2) and by the oracle on all host cores"""
+    import os
+
+    dev = torch.device("cuda")
+    wl = synth.make_whitelist(100_000, seed=281, device=dev)
+    used = synth.pick_used(wl, 1000, seed=282)
+    n = 500_000
+    rd = synth.gen_reads(n, used, seed=283, device=dev, n_rate=0.001)
+    buf, offs = synth.materialize_device(rd)
+    d_ends = torch.zeros((28, 2 * n), dtype=torch.int32, device=dev)
+    d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+    gpu_ctx.pack_ends_device(buf, None, offs, n, d_ends, d_len)
+    assert (d_ends == synth.pack_ends(rd["head"], rd["tail"])).all()  # K-PACK == the torch packer the bench uses
+    d_out = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    gpu_ctx.scan_device(d_ends, d_len, n, gpu_ctx.scan_config(2), d_out)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(pkg.SCAN_RESULT_DTYPE).reshape(-1)
+    st, exp = sor.scan_batch_3p(buf.cpu().numpy(), None, offs.cpu().numpy().astype(np.uint64), AD[2],
+                                n_threads=min(64, os.cpu_count() or 8))
+    n_found = _compare(got, st, exp, pass1=False)
+    assert n_found > 0.9 * n
