@@ -217,20 +217,34 @@ struct WaveLds {
     int order[kCap];
 };
 
-// searchATend (PolyATadapterInternalSearcherBase.java:L233-270); every lane runs the same walk
+// searchATend (PolyATadapterInternalSearcherBase.java:L233-270); every lane runs the same walk.  The exact-base bits are
+// read through a 128-bit register window that is refilled every 48 positions, not bit by bit from memory.
 __device__ __forceinline__ int search_at_end(const ReadPlanes &rp, int len, int pos, int is_t, int cur, const ChimParams &P) {
-    const int ml = P.pat_len;
-    for (int pb = pos + 1; pb < len - P.off - ml - 1 && cur >= P.pat_thr; pb++) {
-        cur -= (int)gexact_bit(rp, is_t, pb);
-        cur += (int)gexact_bit(rp, is_t, pb + ml);
-        if (cur >= P.pat_thr) pos = pb;
-        if (!gexact_bit(rp, is_t, pb + ml - 1) && !gexact_bit(rp, is_t, pb + ml - 2)) break;
+    const int ml = P.pat_len;  // <= 15
+    const int lim = len - P.off - ml - 1;
+    int pb = pos + 1;
+    bool stop = !(pb < lim && cur >= P.pat_thr);
+    while (!stop) {
+        const uint64_t w0 = gexact64(rp, is_t, pb), w1 = gexact64(rp, is_t, pb + 64);  // bits pb .. pb+127
+        for (int j = 0; j < 48; j++, pb++) {
+            if (!(pb < lim && cur >= P.pat_thr)) {
+                stop = true;
+                break;
+            }
+            auto bit = [&](int k) -> int { return (int)((k < 64 ? (w0 >> k) : (w1 >> (k - 64))) & 1ull); };  // base at pb - j + k
+            cur -= bit(j);
+            cur += bit(j + ml);
+            if (cur >= P.pat_thr) pos = pb;
+            if (!bit(j + ml - 1) && !bit(j + ml - 2)) {
+                stop = true;
+                break;
+            }
+        }
     }
     int end = pos + ml - 1;
     for (;;) {
-        int score = 0;
-        for (int i = 0; i < 4; i++) score += (int)gexact_bit(rp, is_t, end - i);
-        if (score >= 2) break;
+        const uint32_t x = (uint32_t)(gexact64(rp, is_t, end - 3) & 15ull);  // bases end-3 .. end
+        if (__popc(x) >= 2) break;
         end -= 4;
     }
     while (!gexact_bit(rp, is_t, end)) end--;
@@ -496,11 +510,18 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
                 const int pl = p0 + 64 * lane;
                 unsigned long long trig[2] = {0, 0};
                 if (pl < stop && P.pat_thr <= 15) {
+                    // exact-A / exact-T bits of positions pl .. pl+127 from one 128-bit window per plane (the packer emits
+                    // A, G, C, T, N and nothing else: exact A = A & ~G, exact T = T & ~A)
+                    const PlaneWin pw = load_window(rp, pl);
+                    const uint64_t elo[2] = {pw.lo[0] & ~pw.lo[1], pw.lo[3] & ~pw.lo[0]};
+                    const uint64_t ehi[2] = {pw.hi[0] & ~pw.hi[1], pw.hi[3] & ~pw.hi[0]};
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
                         unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                        for (int k = 1; k < P.pat_len; k++) {  // bit-sliced sum of the 14 shifted planes
-                            const unsigned long long x = gexact64(rp, t, pl + k);
+#pragma unroll
+                        for (int k = 1; k < 15; k++) {  // bit-sliced sum of the shifted planes (pat_len - 1 of them)
+                            if (k >= P.pat_len) break;
+                            const unsigned long long x = (elo[t] >> k) | (ehi[t] << (64 - k));
                             const unsigned long long t0 = c0 & x;
                             c0 ^= x;
                             const unsigned long long t1 = c1 & t0;
@@ -520,14 +541,15 @@ __global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__
                         }
                         const unsigned long long cb[4] = {c0, c1, c2, c3};
                         unsigned long long gt = 0, eq = ~0ull;
+#pragma unroll
                         for (int b = 3; b >= 0; b--) {  // count >= pat_thr
                             if ((P.pat_thr >> b) & 1)
                                 eq &= cb[b];
                             else
                                 gt |= eq & cb[b];
                         }
-                        const unsigned long long e0 = gexact64(rp, t, pl), e1 = gexact64(rp, t, pl + 1);
-                        trig[t] = keep_low64((gt | eq) & e0 & e1, stop - pl);
+                        const unsigned long long e1 = (elo[t] >> 1) | (ehi[t] << 63);
+                        trig[t] = keep_low64((gt | eq) & elo[t] & e1, stop - pl);
                     }
                 }
                 // walk the triggers in position order (T before A never collide: a base is one or the other)
