@@ -331,7 +331,7 @@ __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, 
 }
 
 template <int kTsoLen, int kAdLen>
-__global__ __launch_bounds__(256, 2) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
+__global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
                                                     const uint64_t *__restrict__ offsets, size_t n, ChimParams P,
                                                     smi_chimera_result *__restrict__ out) {
     __shared__ WaveLds lds_all[4];
