@@ -388,6 +388,37 @@ int smi_fastq_index_device(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, 
 int smi_fastq_gather_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
                             uint8_t *d_out, void *stream);
 
+/* ================================================================================================================
+ * FASTQ record writer of pass 2 (the other side of the path): the records of a chunk as the
+ * reference writes them, assembled on the device into a `passed` and a `failed` byte stream.  Replaces
+ * FastqRecordExt.getRecordForWriting (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311) and the record
+ * loop of FastqWriterThreadPool$FastQoneFileThread.run (.../FastqWriterThreadPool.java:L300-306) with htsjdk's
+ * BasicFastqWriter layout ('@' name LF bases LF '+' quality header LF qualities LF).  File handling and gz stay on the host.
+ *   passed record: name = token before the first blank [+ fragment tag] + suffix (smi_format_read_name), bases = the
+ *     stranded read (reverse complement through FastqRecordExt.REVERSE_COMPLEMENT for PASSED_REV), qualities reversed
+ *     with it; with trim_fastq and an assigned barcode only [TSO end (5': barcode start + 30) .. polyA start];
+ *     read id = first_read_id + ordinal among the passed records of the call (GET_NEXT_READID per passed record)
+ *   failed record (also every fragment-less read flagged SMI_CHIM_MULTI): name token + "_FAILED ", raw bases / qualities
+ * d_text / d_line_start: the chunk and the line table smi_fastq_index_device filled; d_offsets: n_out + 1 offsets of the
+ * output records in d_reads / d_quals (the fragment offsets after a split); d_frag_src / d_chim: both NULL without the
+ * splitter, else per output record src << 2 | fragment and per input record the split result; d_rank may be NULL.
+ * Outputs: d_rec_off[i] = offset of record i in ITS stream, d_is_passed[i]; totals[0..2] = bytes passed, bytes failed,
+ * records passed (host); *errors = SMI_WR_* bits (host; any bit makes the call fail).  Synchronises the stream.
+ * ================================================================================================================ */
+typedef struct {
+    int32_t five_prime;
+    int32_t trim_fastq; /* -u / --trimFastq (NanoporeReadScannerMain.java:L240), default off */
+} smi_write_config;
+#define SMI_WR_NAME_RANGE 1u    /* the X= / Q= range of a passed read leaves the read: the reference throws */
+#define SMI_WR_NAME_TOO_LONG 2u /* a formatted name longer than 1016 bytes */
+#define SMI_WR_OVERFLOW 4u      /* cap_passed / cap_failed too small (nothing is written past a cap) */
+int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint8_t *d_reads,
+                           const uint8_t *d_quals, const uint64_t *d_offsets, const uint32_t *d_frag_src,
+                           const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc,
+                           const int32_t *d_rank, size_t n_out, uint32_t first_read_id, const smi_write_config *cfg,
+                           uint8_t *d_passed, size_t cap_passed, uint8_t *d_failed, size_t cap_failed, uint64_t *d_rec_off,
+                           uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

@@ -111,6 +111,9 @@ int sor_format_read_name(const char *read_name, const char *raw_seq, const char 
                          const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, int five_prime,
                          char *out, size_t cap);
 int sor_fmt_dec1(float f, char *out);
+int sor_fastq_record(const char *read_name, const char *qual_header, const char *raw_seq, const char *raw_qual, int len,
+                     const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, int five_prime,
+                     int trim_fastq, int force_failed, char *out, size_t cap, int *passed);
 
 /* ---- UMI pair distances (sor_umi.c) ---- */
 int sor_umi_pair(const uint8_t *w1, const uint8_t *w2);

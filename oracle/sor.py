@@ -301,6 +301,30 @@ def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_i
     return None if n < 0 else out.value.decode()
 
 
+def fastq_record(read_name, qual_header, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0, five_prime=False,
+                 trim_fastq=False, force_failed=False):
+    """the record as the pass-2 writer emits it -> (bytes, passed) or (None, passed) where the reference throws"""
+    L = lib()
+    L.sor_fastq_record.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+    sc = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
+    sc[0] = scan
+    bp = None
+    if bc is not None:
+        b = np.zeros(1, dtype=ASSIGN_DTYPE)
+        b[0] = bc
+        bp = b.ctypes.data
+    cap = 2 * len(raw_seq) + len(read_name) + len(qual_header) + 1400
+    out = ctypes.create_string_buffer(cap)
+    passed = ctypes.c_int(0)
+    seq = raw_seq if isinstance(raw_seq, bytes) else raw_seq.encode()
+    qual = raw_qual if isinstance(raw_qual, bytes) else raw_qual.encode()
+    n = L.sor_fastq_record(read_name.encode(), qual_header.encode(), seq, qual, len(seq), sc.ctypes.data, bp, int(rank),
+                           int(read_id), int(five_prime), int(trim_fastq), int(force_failed), out, cap, ctypes.byref(passed))
+    return (None if n < 0 else out.raw[:n]), bool(passed.value)
+
+
 def fmt_dec1(f):
     L = lib()
     L.sor_fmt_dec1.argtypes = [ctypes.c_float, ctypes.c_char_p]

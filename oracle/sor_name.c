@@ -12,6 +12,12 @@
 
 #include "sor.h"
 
+/* FastqRecordExt.REVERSE_COMPLEMENT (L72-104): zero except for these letters */
+static const char COMP[256] = {['A'] = 'T', ['a'] = 'T', ['G'] = 'C', ['g'] = 'C', ['C'] = 'G', ['c'] = 'G', ['T'] = 'A', ['t'] = 'A',
+                               ['N'] = 'N', ['n'] = 'N', ['H'] = 'D', ['h'] = 'D', ['R'] = 'Y', ['r'] = 'Y', ['Y'] = 'R', ['y'] = 'R',
+                               ['M'] = 'K', ['m'] = 'K', ['K'] = 'M', ['k'] = 'M', ['S'] = 'S', ['s'] = 'S', ['W'] = 'W', ['w'] = 'W',
+                               ['B'] = 'V', ['b'] = 'V', ['V'] = 'B', ['v'] = 'B', ['D'] = 'H', ['d'] = 'H'};
+
 /* DecimalFormat("##.#").format((double)f): HALF_EVEN on the exact value, no integer digit when |v| < 1 and a fraction
  * digit is printed, "0" when everything rounds away */
 static int fmt_dec1(float f, char *out) {
@@ -89,8 +95,6 @@ int sor_format_read_name(const char *read_name, const char *raw_seq, const char 
                 if (end > len) return -1;     /* String.substring */
                 if (begin - 1 < 0) return -1; /* IntStream.skip(negative) in getMeanQV */
                 a += sprintf(a, "X=");
-                static const char COMP[256] = {['A'] = 'T', ['C'] = 'G', ['G'] = 'C', ['T'] = 'A', ['N'] = 'N',
-                                               ['a'] = 'T', ['c'] = 'G', ['g'] = 'C', ['t'] = 'A', ['n'] = 'N'};
                 for (int i = begin; i < end; i++) /* stranded = reverse complement for PASSED_REV (L62-67) */
                     *a++ = rev ? COMP[(unsigned char)raw_seq[len - 1 - i]] : raw_seq[i];
                 *a++ = '_';
@@ -132,4 +136,64 @@ int sor_fmt_dec1(float f, char *out) {
     int n = fmt_dec1(f, out);
     out[n] = 0;
     return n;
+}
+
+/* The whole record as the pass-2 writer emits it: getRecordForWriting (L209-311) + htsjdk BasicFastqWriter.write
+ * ('@' name LF bases LF '+' quality header LF qualities LF; a null quality string prints as "null").
+ * read_name: the full name line (fragments: after ChimeraFindernew's replaceFirst); qual_header: text behind '+';
+ * force_failed: MULTI_CHIMERIC_READS_DISCARDED | FAILED records are never scanned (Parser.java:L92);
+ * trim_fastq: -u (L210-217, L301-304).  Returns the record length, -1 where the reference throws, -2 on overflow;
+ * *passed = 1 when the record goes to the `passed` file (FastqWriterThreadPool.java:L301). */
+int sor_fastq_record(const char *read_name, const char *qual_header, const char *raw_seq, const char *raw_qual, int len,
+                     const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, int five_prime,
+                     int trim_fastq, int force_failed, char *out, size_t cap, int *passed) {
+    sor_scan_result sc = *scan;
+    if (force_failed) sc.flags &= ~(uint64_t)(SOR_F_PASSED_FWD | SOR_F_PASSED_REV);
+    const int is_passed = (sc.flags & (SOR_F_PASSED_FWD | SOR_F_PASSED_REV)) != 0;
+    const int rev = (sc.flags & SOR_F_PASSED_REV) != 0;
+    *passed = is_passed;
+    char name[1200];
+    const int nl = sor_format_read_name(read_name, raw_seq, raw_qual, len, &sc, is_passed ? bc : NULL, rank, read_id, five_prime,
+                                        name, sizeof name);
+    if (nl < 0) return nl;
+    /* partOfSeqToWrite (L209-217) */
+    int cut_beg = 0, cut_end = len;
+    if (is_passed && trim_fastq && bc && bc->found == 1) {
+        const int begin = five_prime ? bc->bc_start + 30 : (sc.tso_end ? sc.tso_end : 1);
+        const int end = sc.polya_end ? sc.polya_start : len;
+        if (begin < end) {
+            if (begin - 1 < 0 || end > len) return -1; /* String.substring */
+            cut_beg = begin - 1;
+            cut_end = end;
+        }
+    }
+    /* quals stays null for a passed read whose name got no suffix (L221, L247-268) */
+    int quals_set = 1;
+    if (is_passed) {
+        const int b = five_prime ? sc.adapter_end - 3 : sc.adapter_end - 41;
+        quals_set = sc.adapter_found && b >= 0;
+    }
+    const size_t n_seq = (size_t)(cut_end - cut_beg), n_q = quals_set ? n_seq : 4;
+    const size_t hl = strlen(qual_header);
+    const size_t total = 1 + (size_t)nl + 1 + n_seq + 1 + 1 + hl + 1 + n_q + 1;
+    if (total + 1 > cap) return -2;
+    char *p = out;
+    *p++ = '@';
+    memcpy(p, name, (size_t)nl);
+    p += nl;
+    *p++ = '\n';
+    for (int i = cut_beg; i < cut_end; i++) *p++ = (is_passed && rev) ? COMP[(unsigned char)raw_seq[len - 1 - i]] : raw_seq[i];
+    *p++ = '\n';
+    *p++ = '+';
+    memcpy(p, qual_header, hl);
+    p += hl;
+    *p++ = '\n';
+    if (!quals_set) {
+        memcpy(p, "null", 4);
+        p += 4;
+    } else
+        for (int i = cut_beg; i < cut_end; i++) *p++ = (is_passed && rev) ? raw_qual[len - 1 - i] : raw_qual[i];
+    *p++ = '\n';
+    *p = 0;
+    return (int)(p - out);
 }

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "smi_internal.h"
+#include "smi_name.h"
 
 namespace smi {
 
@@ -212,60 +213,9 @@ extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *coun
 
 // ---------------------------------------------------------------------------------------------------------------
 // smi_format_read_name: the read-name suffix `assignumis` later parses = FastqRecordExt.getRecordForWriting
-// (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311).  Host-side string work on results that are
-// already back from the device; 3' protocol.
+// (FJ!nanoporereadscanner/readerwriter/FastqRecordExt.java:L209-311).  The formatting itself is smi_name.h, which the
+// device record writer (smi_write.hip) shares.
 // ---------------------------------------------------------------------------------------------------------------
-namespace {
-
-// new DecimalFormat("##.#").format((double) f): HALF_EVEN on the exact decimal value, at most one fraction digit,
-// no leading zero in front of a fraction ("##" = no mandatory integer digit)
-std::string format_dec1(float f) {
-    const double t = std::fabs((double)f) * 10.0;  // exact
-    const double fl = std::floor(t);
-    long long q = (long long)fl;
-    const double frac = t - fl;
-    if (frac > 0.5 || (frac == 0.5 && (q % 2) != 0)) q += 1;
-    std::string out;
-    if (f < 0 && q != 0) out += '-';
-    const long long ip = q / 10, tenth = q % 10;
-    if (tenth == 0) return out + std::to_string(ip);
-    if (ip != 0) out += std::to_string(ip);
-    return out + "." + std::to_string(tenth);
-}
-
-std::string base36(uint32_t v) {  // Integer.toString(id, 36), L524
-    if (v == 0) return "0";
-    std::string r;
-    while (v) {
-        const uint32_t d = v % 36;
-        r.insert(r.begin(), (char)(d < 10 ? '0' + d : 'a' + (d - 10)));
-        v /= 36;
-    }
-    return r;
-}
-
-std::string kmer16(uint32_t key) {
-    static const char B[4] = {'A', 'G', 'C', 'T'};  // TWOBIT_TO_BASE_ARRAY
-    std::string r(16, 'A');
-    for (int i = 15; i >= 0; i--) {
-        r[i] = B[key & 3u];
-        key >>= 2;
-    }
-    return r;
-}
-
-char complement(char c) {  // FastqRecordExt.REVERSE_COMPLEMENT L72-95 (ACGTN subset)
-    switch (c) {
-    case 'A': case 'a': return 'T';
-    case 'C': case 'c': return 'G';
-    case 'G': case 'g': return 'C';
-    case 'T': case 't': return 'A';
-    default: return 'N';
-    }
-}
-
-}  // namespace
-
 extern "C" int smi_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int32_t len,
                                     const smi_scan_result *scan, const smi_bc_result *bc, int32_t rank, uint32_t read_id,
                                     int five_prime, char *out, size_t cap) {
@@ -273,60 +223,22 @@ extern "C" int smi_format_read_name(const char *read_name, const char *raw_seq, 
         set_error("smi_format_read_name: null argument");
         return SMI_ERR_INVALID;
     }
-    std::string name(read_name);
-    const size_t sp = name.find(' ');
-    if (sp != std::string::npos) name.resize(sp);  // getReadName().split(" ")[0]
-    const bool fwd = scan->flags & SMI_F_PASSED_FWD, rev = scan->flags & SMI_F_PASSED_REV;
-    if (!fwd && !rev) {
-        name += "_FAILED ";  // L309
-    } else {
-        std::string add = rev ? "_REV_" : "_FWD_";
-        if (scan->polya_end != 0) {
-            add += "PS=" + std::to_string(scan->polya_start) + "_";
-            add += "PE=" + std::to_string(scan->polya_end) + "_";
-        }
-        if (scan->found) add += "AE=" + std::to_string(scan->adapter_end) + "_";
-        if (scan->tso_end != 0) add += "T=" + std::to_string(scan->tso_end) + "_";
-        const bool has_bc = bc && bc->found == 1;
-        std::string bcs;
-        if (has_bc) {
-            bcs = kmer16(bc->bc);
-            // Parser.java:L274-279: 3' barcodes end at the adapter, 5' barcodes start behind it
-            const int bc_start = five_prime ? scan->adapter_end + 1 + bc->offset : scan->adapter_end - 1 + bc->offset;
-            const int bc_end = five_prime ? bc_start + 15 + bc->ins_minus_del : bc_start - 15 - bc->ins_minus_del;
-            add += "bc=" + bcs + "_ed=" + std::to_string((int)bc->ed) + "_ed_sec=" + std::to_string(bc->ed_sec) +
-                   "_bcStart=" + std::to_string(bc_start) + "_bcEnd=" + std::to_string(bc_end) + "_";
-            if (rank > 0) add += "rk=" + std::to_string(rank) + "_";
-        }
-        if (scan->found) {
-            // 3': stranded[AE-40 .. AE+2] (L253-254); 5': stranded[AE-2 .. AE+39] (L250-251)
-            const int begin = five_prime ? scan->adapter_end - 3 : scan->adapter_end - 40 - 1;
-            const int end = five_prime ? scan->adapter_end + 39 : scan->adapter_end + 2;
-            if (begin >= 0) {
-                if (end > len || begin - 1 < 0) {
-                    set_error("smi_format_read_name: X=/Q= range outside the read (the reference throws here)");
-                    return SMI_ERR_INVALID;
-                }
-                add += "X=";
-                for (int i = begin; i < end; i++) add += rev ? complement(raw_seq[len - 1 - i]) : raw_seq[i];
-                add += "_Q=";
-                long long sum = 0;
-                int cnt = 0;
-                for (int i = begin - 1; i <= end - 1 && i < len; i++, cnt++)
-                    sum += (unsigned char)(rev ? raw_qual[len - 1 - i] : raw_qual[i]) - 33;
-                add += format_dec1((float)((double)sum / (double)cnt));
-                add += "_" + base36(read_id);
-                if (has_bc) add += " cellBC=" + bcs;
-                name += add;
-            }  // else: "Beginrange inconsistent" -- the name keeps no suffix (L257-259)
-        }
+    NameSink sink{out, 0, cap > 0 ? (int)std::min<size_t>(cap - 1, 1u << 30) : 0};
+    for (const char *c = read_name; *c && *c != ' '; c++) sink.put(*c);  // getReadName().split(" ")[0]
+    bool quals_set = false;
+    const int st = append_name_suffix(
+        sink, *scan, bc, rank, read_id, five_prime != 0, len, [&](int i) { return raw_seq[i]; },
+        [&](int i) { return raw_qual[i]; }, &quals_set);
+    if (st == NAME_RANGE) {
+        set_error("smi_format_read_name: X=/Q= range outside the read (the reference throws here)");
+        return SMI_ERR_INVALID;
     }
-    if (name.size() + 1 > cap) {
+    if (cap == 0 || sink.n > sink.cap) {
         set_error("smi_format_read_name: output buffer too small");
         return SMI_ERR_INVALID;
     }
-    std::memcpy(out, name.c_str(), name.size() + 1);
-    return (int)name.size();
+    out[sink.n] = 0;
+    return sink.n;
 }
 
 

@@ -52,6 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
+    "smi_fastq_write_device",
 ]
 
 
@@ -100,6 +101,8 @@ def load_library():
     lib.smi_fastq_index_device.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz),
                                            ctypes.POINTER(ctypes.c_uint32), vp]
     lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.smi_fastq_write_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ctypes.c_uint32, vp, vp, sz, vp, sz,
+                                           vp, vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), vp]
     lib.smi_chimera_default_config_5p.argtypes = [vp]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
@@ -351,6 +354,23 @@ class Context:
     def fastq_gather_device(self, d_text, d_start, d_offsets, n, d_out, stream=None):
         self._check(self._lib.smi_fastq_gather_device(self._h, _ptr(d_text), _ptr(d_start), _ptr(d_offsets), int(n), _ptr(d_out),
                                                       _stream_ptr(stream)))
+
+    def fastq_write_device(self, d_text, d_line_start, d_reads, d_quals, d_offsets, d_frag_src, d_chim, d_scan, d_bc, d_rank,
+                           n_out, first_read_id, d_passed, d_failed, d_rec_off, d_is_passed, five_prime=False,
+                           trim_fastq=False, stream=None):
+        """K-WRITE -> (bytes passed, bytes failed, records passed); raises SmiError with the SMI_WR_* bits"""
+        cfg = (ctypes.c_int32 * 2)(int(bool(five_prime)), int(bool(trim_fastq)))
+        totals = (ctypes.c_uint64 * 3)()
+        err = ctypes.c_uint32(0)
+        opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
+        rc = self._lib.smi_fastq_write_device(self._h, _ptr(d_text), _ptr(d_line_start), _ptr(d_reads), _ptr(d_quals),
+                                              _ptr(d_offsets), opt(d_frag_src), opt(d_chim), _ptr(d_scan), _ptr(d_bc),
+                                              opt(d_rank), int(n_out), int(first_read_id), ctypes.byref(cfg), _ptr(d_passed),
+                                              int(d_passed.numel()), _ptr(d_failed), int(d_failed.numel()), _ptr(d_rec_off),
+                                              _ptr(d_is_passed), totals, ctypes.byref(err), _stream_ptr(stream))
+        if rc != 0:
+            raise SmiError(f"smi_fastq_write_device: {self._lib.smi_last_error().decode()} (error bits {err.value})")
+        return int(totals[0]), int(totals[1]), int(totals[2])
 
     # ---- chimera splitter ----------------------------------------------------------------------------------
     def chimera_config(self, five_prime=False):

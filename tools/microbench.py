@@ -177,6 +177,34 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
     assert state["n"] == n and state["err"] == 0 and bool((out == buf).all())
     res["fastq_ingest"] = {"reads": n, "text_bytes": total, "ms": dt * 1e3, "text_GBps": total / dt / 1e9,
                            "reads_per_s": n / dt}
+    # ---- K-WRITE: scan + barcode results of the same chunk -> `passed` / `failed` FASTQ text on the device ---------
+    quals = torch.zeros(int(offs[-1]), dtype=torch.uint8, device=dev)
+    ctx.fastq_gather_device(text, qs, o, n, quals)
+    ends = torch.zeros((28, 2 * n), dtype=torch.int32, device=dev)
+    lens32 = torch.zeros(n, dtype=torch.int32, device=dev)
+    qt = torch.zeros((n, 224), dtype=torch.uint8, device=dev)
+    qsum = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.pack_ends_device(out, quals, o[:n + 1], n, ends, lens32, qt, qsum)
+    scan = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    win = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    ctx.scan_device(ends, lens32, n, ctx.scan_config(2), scan, win, qt, qsum)
+    bc = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
+    ctx.bc_match_device(win, bc, n, max_ed=1)
+    capw = 2 * int(offs[-1]) + total + 320 * n
+    out_p = torch.empty(capw, dtype=torch.uint8, device=dev)
+    out_f = torch.empty(capw, dtype=torch.uint8, device=dev)
+    rec_off_w = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    is_p = torch.zeros(n, dtype=torch.uint8, device=dev)
+
+    def write():
+        state["tot"] = ctx.fastq_write_device(text, line, out, quals, o[:n + 1], None, None, scan, bc, None, n, 1, out_p, out_f,
+                                              rec_off_w, is_p)
+
+    dtw = timed(write)
+    wb = state["tot"][0] + state["tot"][1]
+    res["fastq_write"] = {"reads": n, "passed": state["tot"][2], "out_bytes": wb, "ms": dtw * 1e3, "out_GBps": wb / dtw / 1e9,
+                          "reads_per_s": n / dtw}
 
 
 if __name__ == "__main__":
