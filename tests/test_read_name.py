@@ -192,3 +192,56 @@ def test_product_oracle_model_5p(pkg, sor, synth):
                        int(sc["adapter_end"]) if sc["adapter_found"] else 0, 0, mb, i % 7, 50000 + i, five_prime=True)
         assert o == p == m, (i, o, p, m)
     assert n_bc > 80
+
+
+def model_record(name, qhdr, seq, qual, flags, ps, pe, ae, tso_end, bc, rank, read_id, five_prime=False, trim=False):
+    """getRecordForWriting L209-311 + htsjdk BasicFastqWriter, in Python on top of model_name"""
+    rev, fwd = "PASSED_REV" in flags, "PASSED_FWD" in flags
+    nm = model_name(name, seq, qual, flags, ps, pe, ae, tso_end, bc, rank, read_id, five_prime)
+    if not (rev or fwd):
+        return f"@{nm}\n{seq}\n+{qhdr}\n{qual}\n", False
+    s = "".join(COMP[c] for c in reversed(seq)) if rev else seq
+    begin = (ae - 3) if five_prime else (ae - 41)
+    q = (qual[::-1] if rev else qual) if (ae and begin >= 0) else None
+    if trim and bc:
+        b = bc["start"] + 30 if five_prime else (tso_end or 1)
+        e = ps if pe else len(seq)
+        if b < e:
+            s, q = s[b - 1:e], q[b - 1:e]
+    return f"@{nm}\n{s}\n+{qhdr}\n{'null' if q is None else q}\n", True
+
+
+@pytest.mark.parametrize("trim", [False, True])
+def test_oracle_record_equals_model(sor, synth, trim):
+    wl = synth.make_whitelist(20000, seed=421)
+    used = synth.pick_used(wl, 100, seed=422)
+    reads = synth.gen_reads(150, used, seed=423, n_rate=0.002)
+    bset = sor.BarcodeSet(used.numpy())
+    n_passed = n_trimmed = 0
+    for i in range(150):
+        seq, qual = synth.materialize(reads, i)
+        if i % 50 == 7:
+            seq, qual = seq[:150], qual[:150]  # too short: FAILED
+        rc, sc = sor.scan_read_3p(seq, qual, "CTTCCGATCT")
+        assert rc == 0
+        flags = {k for k, b in sor.FLAG_BITS.items() if (int(sc["flags"]) >> b) & 1}
+        a = bc = None
+        if sc["adapter_found"]:
+            stranded = "".join(COMP[c] for c in reversed(seq)) if sc["reverse"] else seq
+            rc2, a_ = sor.assign_barcode(bset, stranded, int(sc["adapter_end"]), max_ed=1)
+            if rc2 == 1:
+                a = a_
+                bc = dict(seq=sor.decode(int(a["bc"]) & 0xFFFFFFFF, 16), ed=int(a["ed"]), ed_sec=int(a["ed_sec"]),
+                          start=int(a["bc_start"]), end=int(a["bc_end"]))
+        name, qh = f"r{i} ch=5", ("" if i % 3 else f"r{i}")
+        got, ok = sor.fastq_record(name, qh, seq, qual, sc, a, rank=i % 5, read_id=1000 + i, trim_fastq=trim)
+        exp, ok_m = model_record(name, qh, seq, qual, flags, int(sc["polya_start"]), int(sc["polya_end"]),
+                                 int(sc["adapter_end"]) if sc["adapter_found"] else 0, int(sc["tso_end"]), bc, i % 5, 1000 + i,
+                                 trim=trim)
+        assert got == exp.encode() and ok == ok_m
+        n_passed += ok
+        n_trimmed += ok and len(got) < 2 * len(seq)
+    assert n_passed > 120 and (n_trimmed > 40) == trim
+    # a read marked MULTI_CHIMERIC_READS_DISCARDED is written as FAILED with its raw bases whatever its scan says
+    got, ok = sor.fastq_record("x y", "", seq, qual, sc, a, force_failed=True)
+    assert not ok and got == f"@x_FAILED \n{seq}\n+\n{qual}\n".encode()
