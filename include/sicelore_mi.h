@@ -419,6 +419,34 @@ int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *
                            uint8_t *d_passed, size_t cap_passed, uint8_t *d_failed, size_t cap_failed, uint64_t *d_rec_off,
                            uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream);
 
+/* ================================================================================================================
+ * BAM ingest of `assignumis` (host): what BamReader (FJ!umifinder/bamreaders/BamReader.java:L82-158)
+ * gets from htsjdk's SamReader -- the BGZF container and the BAM record layout (SAM specification 4.1 / 4.2; htsjdk is an
+ * un-vendored jar dependency, the formats are restated from the specification).  Nothing here touches the device.
+ * ================================================================================================================ */
+/* size of the inflated data of the complete BGZF blocks in in[0 .. n_in); *consumed = bytes those blocks take */
+int smi_bgzf_uncompressed_size(const uint8_t *in, size_t n_in, size_t *n_out, size_t *n_blocks, size_t *consumed);
+/* inflates every complete block (CRC32 and ISIZE checked, as BlockCompressedInputStream does) on n_threads threads */
+int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, size_t *consumed,
+                     int n_threads);
+typedef struct {                /* one alignment record; offsets into the inflated stream */
+    uint64_t rec_off;           /* of its block_size word */
+    uint64_t name_off, cigar_off, seq_off, qual_off, aux_off;
+    uint32_t rec_len, aux_len;  /* rec_len includes the block_size word */
+    int32_t ref_id, pos;        /* pos is 0-based (SAMRecord.getAlignmentStart() = pos + 1) */
+    int32_t l_seq, next_ref_id, next_pos, tlen;
+    uint16_t flag, n_cigar;
+    uint8_t mapq, l_read_name;  /* l_read_name counts the terminating NUL */
+    uint8_t reserved[2];
+} smi_bam_record;
+/* magic, header text and reference dictionary; ref_* may be NULL / shorter than *n_ref (cap_ref entries are filled);
+ * *records_off = offset of the first alignment record */
+int smi_bam_header(const uint8_t *bam, size_t n, uint64_t *text_off, uint32_t *text_len, int32_t *n_ref, uint64_t *ref_name_off,
+                   uint32_t *ref_name_len, int32_t *ref_len, size_t cap_ref, uint64_t *records_off);
+/* records from offset `start` on; stops at cap records or in front of an incomplete record (*end_off) */
+int smi_bam_index_records(const uint8_t *bam, size_t n, uint64_t start, smi_bam_record *recs, size_t cap, size_t *n_recs,
+                          uint64_t *end_off);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

@@ -20,14 +20,57 @@ _COMP = {1: 8, 8: 1, 2: 4, 4: 2, 15: 15}
 _FIELD = {k: re.compile(r"_" + k + r"=([^_ ]+)") for k in ("AE", "bcEnd", "X", "Q")}
 
 
-def parse_name(name):
-    """fields of a scanfastq read name needed here; None when the read carries no barcode"""
-    m = {k: r.search(name) for k, r in _FIELD.items()}
-    cell = name.split(" cellBC=")
-    if len(cell) != 2 or any(v is None for v in m.values()):
+def _extract(sub, tag):
+    """FastqRecordExt.lambda$getScanDatFromReadName$4 (L397-408): text behind the first `tag` up to the next '_'"""
+    i = sub.find(tag)
+    if i < 0:
         return None
-    return dict(cell=cell[1].split()[0], ae=int(m["AE"].group(1)), bc_end=int(m["bcEnd"].group(1)), x=m["X"].group(1),
-                q=float(m["Q"].group(1)))
+    i += len(tag)
+    j = sub.find("_", i)
+    return sub[i:] if j < 0 else sub[i:j]
+
+
+def scan_data_from_name(name, bc_edit_limit=None):
+    """FastqRecordExt.getScanDatFromReadName (FastqRecordExt.java:L395-496): None when the name carries no _REV_ / _FWD_
+    marker; raises where the reference throws AdapterInfoNotFoundInReadException (no AE=).  The barcode fields are only
+    taken when ed <= bc_edit_limit (-b, L450-456)."""
+    k = name.find("_REV_")
+    rev = k >= 0
+    if not rev:
+        k = name.find("_FWD_")
+        if k < 0:
+            return None
+    sub = name[k + 4:]
+    ae = _extract(sub, "AE=")
+    if ae is None:
+        raise _lib.SmiError("adapter position (AE=) not found in read name: " + name)
+    d = dict(reverse=rev, ae=int(ae), ps=None, pe=None, tso=None, bc=None, x=_extract(sub, "X="), q=None)
+    for key, tag in (("ps", "PS="), ("pe", "PE="), ("tso", "T=")):
+        v = _extract(sub, tag)
+        if v is not None:
+            d[key] = int(v)
+    ed = _extract(sub, "ed=")
+    if ed is not None and (bc_edit_limit is None or int(ed) <= bc_edit_limit):
+        g = lambda t: _extract(sub, t)  # noqa: E731
+        d["bc"] = dict(seq=g("bc="), ed=int(ed), ed_sec=None if g("ed_sec=") is None else int(g("ed_sec=")),
+                       start=None if g("bcStart=") is None else int(g("bcStart=")),
+                       end=None if g("bcEnd=") is None else int(g("bcEnd=")), rank=None if g("rk=") is None else int(g("rk=")))
+    q = _extract(sub, "Q=")
+    if q is not None:
+        d["q"] = float(np.float32(q.split(" ")[0]))
+    return d
+
+
+def parse_name(name):
+    """fields of a scanfastq read name needed for the UMI step; None when the read carries no barcode.  The barcode is the
+    bc= field (an aligner keeps only the first token of the FASTQ name, so ` cellBC=` is not in a BAM)."""
+    try:
+        d = scan_data_from_name(name)
+    except _lib.SmiError:
+        return None
+    if d is None or d["bc"] is None or d["bc"]["seq"] is None or d["bc"]["end"] is None or d["x"] is None or d["q"] is None:
+        return None
+    return dict(cell=d["bc"]["seq"], ae=d["ae"], bc_end=d["bc"]["end"], x=d["x"].split(" ")[0], q=d["q"])
 
 
 def umi_window(x, adapter_end, bc_end):
@@ -51,8 +94,14 @@ def assign_umis(ctx, names, positions, reverse, max_dist=500, cluster_cfg=None, 
     ClusterOneBase.setSamflagsAndStatsForClustered; reads without barcode / position / neighbours get None"""
     n = len(names)
     info = [parse_name(nm) for nm in names]
-    pos = [p if info[i] is not None else None for i, p in enumerate(positions)]
+    # every read whose name carries scan data has a clustering position, barcode or not (generateReadScanData L86-92)
+    pos = [p if ("_REV_" in names[i] or "_FWD_" in names[i]) else None for i, p in enumerate(positions)]
     region, _ = _lib.region_group(pos, reverse, max_dist=max_dist, keep_data_end=False)
+    return _assign_in_regions(ctx, info, region, cluster_cfg, n_threads)
+
+
+def _assign_in_regions(ctx, info, region, cluster_cfg=None, n_threads=4):
+    n = len(info)
     wins = [umi_window(f["x"], f["ae"], f["bc_end"]) if f is not None else None for f in info]
     groups = {}
     for i in range(n):
@@ -85,3 +134,81 @@ def assign_umis(ctx, names, positions, reverse, max_dist=500, cluster_cfg=None, 
                       U1=int(a["ed"]), U2=None if a["ed_second"] < 0 else int(a["ed_second"]), region=region[i],
                       center=order[int(base[j]) + int(a["center"])])
     return out
+
+
+# ---- BAM input (BamReader.run, FJ!umifinder/bamreaders/BamReader.java:L106-158) ---------------------------------------------
+def load_bam(data, n_threads=4):
+    """BGZF bytes of a coordinate-sorted BAM -> (header text, [(reference, length)], inflated stream, record index)"""
+    raw = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    bam, used = _lib.bgzf_inflate(raw, n_threads=n_threads)
+    if used != raw.size:
+        raise _lib.SmiError("truncated BGZF stream")
+    text, refs, start = _lib.bam_header(bam)
+    recs, end = _lib.bam_index_records(bam, start, cap=max(1, (bam.size - start) // 36))
+    if end != bam.size:
+        raise _lib.SmiError("truncated BAM record")
+    return text, refs, bam, recs
+
+
+def read_name(bam, rec):
+    o, n = int(rec["name_off"]), int(rec["l_read_name"]) - 1
+    return bam[o:o + n].tobytes().decode()
+
+
+def clustering_position(bam, rec, scan, grouping_distance=100):
+    """NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116), 3' barcoding: reference position under
+    read position polyA start - distanceFromReadEndForGrouping; None for unmapped reads and positions outside the alignment"""
+    if scan is None or int(rec["flag"]) & 4:
+        return None
+    o = int(rec["cigar_off"])
+    cigar = bam[o:o + 4 * int(rec["n_cigar"])].view("<u4")
+    return _lib.ref_position_at_read_position_raw(cigar, int(rec["pos"]) + 1, scan["ps"] - grouping_distance)
+
+
+def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=None, cluster_cfg=None, n_threads=4):
+    """`assignumis` over a whole BAM -> (names, tags): tags[i] as assign_umis returns them, in BAM order.  Chunks as
+    BamReader.run cuts them: `chunk_size` records or the end of a chromosome; within a chromosome the regions near the
+    right edge are carried into the next chunk (ReadGrouper.groupSams keepDataEnd, smi_region_group)."""
+    _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
+    n = recs.size
+    names = [read_name(bam, r) for r in recs]
+    scans = [scan_data_from_name(nm, bc_edit_limit) for nm in names]
+    pos = [clustering_position(bam, recs[i], scans[i]) for i in range(n)]
+    rev = [bool(int(r["flag"]) & 16) for r in recs]
+    info = []
+    for d in scans:
+        ok = d is not None and d["bc"] is not None and d["bc"]["seq"] and d["bc"]["end"] is not None and d["x"] and d["q"] is not None
+        info.append(dict(cell=d["bc"]["seq"], ae=d["ae"], bc_end=d["bc"]["end"], x=d["x"], q=d["q"]) if ok else None)
+    tags = [None] * n
+    region_base = 0
+
+    def flush(cur, keep):
+        nonlocal region_base
+        region, n_done = _lib.region_group([pos[i] for i in cur], [rev[i] for i in cur], max_dist=max_dist, keep_data_end=keep)
+        done = cur[:n_done]
+        res = _assign_in_regions(ctx, [info[i] for i in done], region[:n_done], cluster_cfg, n_threads)
+        for i, t in zip(done, res):
+            if t is not None:
+                t["center"] = done[t["center"]]
+                t["region"] += region_base
+            tags[i] = t
+        region_base += (max(region[:n_done]) + 1) if n_done and max(region[:n_done]) >= 0 else 0
+        return cur[n_done:]
+
+    cur, counter, chrom = [], 0, None
+    for i in range(n):
+        ref = int(recs[i]["ref_id"])
+        if i == 0:
+            chrom, cur, counter = ref, [0], 1
+            continue
+        counter += 1
+        is_end = ref != chrom
+        if is_end:
+            chrom = ref
+        if counter >= chunk_size or is_end:
+            cur = flush(cur, keep=not is_end)
+            counter = 0
+        cur.append(i)
+    while cur:
+        cur = flush(cur, keep=False)
+    return names, tags

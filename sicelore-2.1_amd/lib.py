@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records",
 ]
 
 
@@ -101,6 +101,11 @@ def load_library():
     lib.smi_fastq_index_device.argtypes = [vp, vp, sz, vp, sz, vp, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz),
                                            ctypes.POINTER(ctypes.c_uint32), vp]
     lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    lib.smi_bgzf_uncompressed_size.argtypes = [vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.smi_bgzf_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ci]
+    lib.smi_bam_header.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
+                                   ctypes.POINTER(ctypes.c_int32), vp, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
+    lib.smi_bam_index_records.argtypes = [vp, sz, ctypes.c_uint64, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
     lib.smi_fastq_write_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ctypes.c_uint32, vp, vp, sz, vp, sz,
                                            vp, vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), vp]
     lib.smi_chimera_default_config_5p.argtypes = [vp]
@@ -234,6 +239,17 @@ def ref_position_at_read_position(cigar, alignment_start, position):
     return out.value if rc == 1 else None
 
 
+def ref_position_at_read_position_raw(cigar_u32, alignment_start, position):
+    """same on a BAM-encoded CIGAR (numpy uint32: len << 4 | op)"""
+    lib = load_library()
+    c = np.ascontiguousarray(cigar_u32, dtype=np.uint32)
+    out = ctypes.c_int32(0)
+    rc = lib.smi_ref_position_at_read_position(_ptr(c), c.size, int(alignment_start), int(position), ctypes.byref(out))
+    if rc < 0:
+        raise SmiError(f"smi_ref_position_at_read_position error {rc}: {lib.smi_last_error().decode()}")
+    return out.value if rc == 1 else None
+
+
 class ChimeraConfig(ctypes.Structure):
     """smi_chimera_config"""
     _fields_ = [("tso_complete", ctypes.c_char_p), ("adapter_complete", ctypes.c_char_p), ("tso_max_errors", ctypes.c_int32),
@@ -251,6 +267,54 @@ def chimera_fragment_name(read_name, result, fragment):
     if n < 0:
         raise SmiError(f"smi_chimera_fragment_name error {n}: {lib.smi_last_error().decode()}")
     return out.value.decode()
+
+
+BAM_RECORD_DTYPE = np.dtype([("rec_off", "<u8"), ("name_off", "<u8"), ("cigar_off", "<u8"), ("seq_off", "<u8"), ("qual_off", "<u8"),
+                             ("aux_off", "<u8"), ("rec_len", "<u4"), ("aux_len", "<u4"), ("ref_id", "<i4"), ("pos", "<i4"),
+                             ("l_seq", "<i4"), ("next_ref_id", "<i4"), ("next_pos", "<i4"), ("tlen", "<i4"), ("flag", "<u2"),
+                             ("n_cigar", "<u2"), ("mapq", "u1"), ("l_read_name", "u1"), ("reserved", "u1", (2,))])
+
+
+def bgzf_inflate(data, n_threads=4):
+    """inflated bytes of the complete BGZF blocks of `data` (numpy uint8) -> (numpy uint8, bytes consumed)"""
+    lib = load_library()
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    n_out, n_blk, used = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+    if lib.smi_bgzf_uncompressed_size(data.ctypes.data, data.size, ctypes.byref(n_out), ctypes.byref(n_blk), ctypes.byref(used)):
+        raise SmiError(lib.smi_last_error().decode())
+    out = np.empty(max(n_out.value, 1), dtype=np.uint8)
+    got = ctypes.c_size_t(0)
+    if lib.smi_bgzf_inflate(data.ctypes.data, data.size, out.ctypes.data, out.size, ctypes.byref(got), ctypes.byref(used),
+                            int(n_threads)):
+        raise SmiError(lib.smi_last_error().decode())
+    return out[:got.value], used.value
+
+
+def bam_header(bam):
+    """-> (header text, [(reference name, length)], offset of the first record)"""
+    lib = load_library()
+    t_off, t_len, n_ref, rec = ctypes.c_uint64(0), ctypes.c_uint32(0), ctypes.c_int32(0), ctypes.c_uint64(0)
+    if lib.smi_bam_header(bam.ctypes.data, bam.size, ctypes.byref(t_off), ctypes.byref(t_len), ctypes.byref(n_ref), None, None,
+                          None, 0, ctypes.byref(rec)):
+        raise SmiError(lib.smi_last_error().decode())
+    k = max(n_ref.value, 1)
+    no, nl, rl = np.zeros(k, dtype=np.uint64), np.zeros(k, dtype=np.uint32), np.zeros(k, dtype=np.int32)
+    if lib.smi_bam_header(bam.ctypes.data, bam.size, ctypes.byref(t_off), ctypes.byref(t_len), ctypes.byref(n_ref), no.ctypes.data,
+                          nl.ctypes.data, rl.ctypes.data, k, ctypes.byref(rec)):
+        raise SmiError(lib.smi_last_error().decode())
+    text = bam[t_off.value:t_off.value + t_len.value].tobytes().decode(errors="replace")
+    refs = [(bam[int(no[i]):int(no[i]) + int(nl[i])].tobytes().decode(), int(rl[i])) for i in range(n_ref.value)]
+    return text, refs, rec.value
+
+
+def bam_index_records(bam, start, cap):
+    """-> (BAM_RECORD_DTYPE array, offset behind the last complete record)"""
+    lib = load_library()
+    recs = np.zeros(max(cap, 1), dtype=BAM_RECORD_DTYPE)
+    n, end = ctypes.c_size_t(0), ctypes.c_uint64(0)
+    if lib.smi_bam_index_records(bam.ctypes.data, bam.size, int(start), recs.ctypes.data, int(cap), ctypes.byref(n), ctypes.byref(end)):
+        raise SmiError(lib.smi_last_error().decode())
+    return recs[:n.value], end.value
 
 
 class Context:

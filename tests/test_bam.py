@@ -1,0 +1,102 @@
+"""BAM ingest (host C++: smi_bgzf_inflate, smi_bam_header, smi_bam_index_records) against the independent Python model of
+the SAM specification in tests/bammodel.py; no GPU involved."""
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import bammodel
+
+
+def _records(rng, n):
+    recs, meta = [], []
+    pos = 1000
+    for i in range(n):
+        ref = 0 if i < n // 2 else 2
+        if i == n // 2:
+            pos = 50
+        pos += rng.randint(0, 300)
+        L = rng.randint(1, 400)
+        seq = "".join(rng.choice("ACGTN") for _ in range(L))
+        cigar = [("S", rng.randint(1, 9))] * rng.randint(0, 1) + [("M", L)] + [("I", 2), ("D", 3), ("N", 700), ("=", 4), ("X", 1)][:rng.randint(0, 5)]
+        aux = b"NMC\x03" + b"RGZgrp" + bytes([48 + i % 10]) + b"\0" if i % 3 else b""
+        name = f"r{i}_FWD_PS={100 + i}_PE={120 + i}_AE={160 + i}_X=ACGT_Q=20.5_{i:x}"
+        flag = rng.choice([0, 16, 4, 256, 2048 + 16])
+        qual = bytes(rng.randint(0, 60) for _ in range(L)) if i % 4 else None
+        recs.append(bammodel.bam_record(name, flag, ref if not flag & 4 else -1, pos if not flag & 4 else -1, rng.randint(0, 60),
+                                        cigar if not flag & 4 else [], seq, qual, aux))
+        meta.append((name, flag, cigar, seq))
+    return recs, meta
+
+
+def test_bgzf_and_record_index_equal_model(pkg):
+    from sicelore_amd import lib as libmod
+
+    rng = random.Random(5)
+    recs, _ = _records(rng, 700)
+    refs = [("chr1", 248956422), ("chrUn_KI270302v1", 2274), ("chr12", 133275309)]
+    text = "@HD\tVN:1.6\tSO:coordinate\n@SQ\tSN:chr1\tLN:248956422\n"
+    raw = bammodel.bam_bytes(text, refs, recs)
+    for block in (0xFF00, 777):  # many small blocks: records straddle block boundaries
+        z = bammodel.bgzf_compress(raw, block=block)
+        got, used = libmod.bgzf_inflate(np.frombuffer(z, dtype=np.uint8), n_threads=3)
+        assert used == len(z) and got.tobytes() == raw == bammodel.bgzf_decompress(z)
+    bam = np.frombuffer(raw, dtype=np.uint8)
+    t, r, start = libmod.bam_header(bam)
+    mt, mr, mrecs = bammodel.parse_bam(raw)
+    assert t == text == mt and r == refs == mr
+    idx, end = libmod.bam_index_records(bam, start, cap=len(recs) + 5)
+    assert end == len(raw) and idx.size == len(mrecs) == 700
+    for a, m in zip(idx, mrecs):
+        assert (int(a["rec_off"]), int(a["rec_len"])) == (m["off"], m["length"])
+        assert (int(a["ref_id"]), int(a["pos"]), int(a["flag"]), int(a["mapq"])) == (m["ref_id"], m["pos0"], m["flag"], m["mapq"])
+        assert raw[int(a["name_off"]):int(a["name_off"]) + int(a["l_read_name"]) - 1].decode() == m["name"]
+        cg = np.frombuffer(raw, dtype="<u4", count=int(a["n_cigar"]), offset=int(a["cigar_off"]))
+        assert [(bammodel.CIGAR_OPS[v & 15], int(v >> 4)) for v in cg] == m["cigar"]
+        assert int(a["l_seq"]) == len(m["seq"]) and raw[int(a["qual_off"]):int(a["qual_off"]) + int(a["l_seq"])] == m["qual"]
+        assert raw[int(a["aux_off"]):int(a["aux_off"]) + int(a["aux_len"])] == m["aux"]
+    # a capped call and a buffer that ends inside a record stop in front of it
+    part, e2 = libmod.bam_index_records(bam, start, cap=10)
+    assert part.size == 10 and e2 == int(idx[10]["rec_off"])
+    cut = int(idx[20]["rec_off"]) + 17
+    part, e3 = libmod.bam_index_records(bam[:cut], start, cap=100)
+    assert part.size == 20 and e3 == int(idx[20]["rec_off"])
+
+
+def test_bgzf_errors_and_partial_input(pkg):
+    from sicelore_amd import lib as libmod
+
+    raw = bytes(range(256)) * 300
+    z = bytearray(bammodel.bgzf_compress(raw, block=5000))
+    # a trailing incomplete block is not consumed
+    got, used = libmod.bgzf_inflate(np.frombuffer(bytes(z[:-9]), dtype=np.uint8))
+    assert used < len(z) - 9 and raw.startswith(got.tobytes()) and got.size >= len(raw) - 5000
+    bad = bytearray(z)
+    bad[40] ^= 0x55  # inside the first deflate stream: inflate error or CRC mismatch
+    with pytest.raises(libmod.SmiError):
+        libmod.bgzf_inflate(np.frombuffer(bytes(bad), dtype=np.uint8))
+    with pytest.raises(libmod.SmiError):
+        libmod.bgzf_inflate(np.frombuffer(b"\x1f\x8b\x08\x00" + bytes(30), dtype=np.uint8))  # plain gzip, no BC field
+    with pytest.raises(libmod.SmiError):
+        libmod.bam_header(np.frombuffer(b"BAM\2" + bytes(20), dtype=np.uint8))
+    short = bammodel.bam_bytes("", [], []) + struct.pack("<I", 8) + bytes(8)
+    with pytest.raises(libmod.SmiError):
+        libmod.bam_index_records(np.frombuffer(short, dtype=np.uint8), 12, cap=4)
+
+
+def test_scan_data_from_name_follows_reference_rules(pkg):
+    import importlib
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    from sicelore_amd import lib as libmod
+
+    nm = "a1b2_REV_PS=1361_PE=1390_AE=1430_T=44_bc=ACGTACGTACGTACGT_ed=1_ed_sec=2147483647_bcStart=1429_bcEnd=1414_rk=17_X=ACGTTTGACCA_Q=27.1_1z"
+    d = au.scan_data_from_name(nm)
+    assert d["reverse"] and (d["ps"], d["pe"], d["ae"], d["tso"]) == (1361, 1390, 1430, 44) and d["x"] == "ACGTTTGACCA"
+    assert d["bc"] == dict(seq="ACGTACGTACGTACGT", ed=1, ed_sec=2147483647, start=1429, end=1414, rank=17) and abs(d["q"] - 27.1) < 1e-6
+    assert au.scan_data_from_name(nm, bc_edit_limit=0)["bc"] is None          # -b 0: the ed=1 barcode is not taken (L450-456)
+    assert au.scan_data_from_name("plain_read_name") is None                   # no _REV_ / _FWD_ (L412-418)
+    with pytest.raises(libmod.SmiError):
+        au.scan_data_from_name("x_FWD_PS=3_PE=9_")                             # AdapterInfoNotFoundInReadException (L442-443)
+    assert au.parse_name(nm)["cell"] == "ACGTACGTACGTACGT" and au.parse_name("x_FWD_PS=3_PE=9_AE=40_X=AC_Q=9_1") is None

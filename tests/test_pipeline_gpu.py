@@ -132,7 +132,7 @@ def test_assignumis_flow_recovers_planted_umis(pkg, synth, sor, gpu_ctx):
     assert sum(len(v) == 1 for v in by_mol.values()) > 0.85 * len(by_mol)
     # the same flow through the oracle
     info = [assignumis.parse_name(nm) for nm in names]
-    pos = [p if info[i] is not None else None for i, p in enumerate(positions)]
+    pos = [p if ("_REV_" in names[i] or "_FWD_" in names[i]) else None for i, p in enumerate(positions)]  # generateReadScanData
     region, _ = sor.region_group(pos, strand)
     assert region == libmod.region_group(pos, strand)[0]
     groups = {}
@@ -157,3 +157,108 @@ def test_assignumis_flow_recovers_planted_umis(pkg, synth, sor, gpu_ctx):
                 assert tags[i] is None
             else:
                 assert tags[i]["center"] == idx[int(asg["center"][j])] and tags[i]["U1"] == asg["ed"][j]
+
+
+def test_assignumis_from_bam_chunks_equal_oracle(pkg, synth, sor, gpu_ctx):
+    """BGZF BAM -> host BAM index -> BamReader.run chunking (chromosome ends, chunk size, carried tail) -> region grouping
+    -> K-UMI -> clustering == the same flow with the oracle's region grouping / windows / distances / clustering"""
+    import bammodel
+
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+
+    rng = np.random.default_rng(17)
+    wl = synth.make_whitelist(50_000, seed=281)
+    used = synth.pick_used(wl, 5, seed=282)
+    n_mol, copies = 90, 5
+    mol = synth.gen_reads(n_mol, used, seed=283, err=0.0, q_mean=20.0)
+    seqs, quals, mol_of = [], [], []
+    for m in range(n_mol):
+        s, q = synth.materialize(mol, m)
+        for _ in range(copies):
+            t = list(s)
+            for p in rng.integers(0, len(t), max(1, len(t) // 40)):
+                t[p] = "ACGT"[rng.integers(0, 4)]
+            seqs.append("".join(t))
+            quals.append(q)
+            mol_of.append(m)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    rs = scanfastq.ReadScanner(gpu_ctx, max_ed=1, split_chimeras=False)
+    recs = rs.pass2_chunk(_fastq(seqs, quals))
+    # alignments: two chromosomes, genes 2.5 kb apart (closer than the 3 x 500 guard, so chunk cuts carry reads over)
+    gene = rng.integers(0, 12, n_mol)
+    rows = []
+    for i, r in enumerate(recs):
+        qname = r["name"].split(" ")[0]  # an aligner keeps the first token of the FASTQ name
+        d = assignumis.scan_data_from_name(qname) if "_FAILED" not in qname else None
+        m = mol_of[r["source"]]
+        chrom = int(gene[m] >= 6)
+        want = 20_000 + 2_500 * int(gene[m] % 6) + int(rng.integers(-120, 120))
+        L = r["length"]
+        if d is None:
+            rows.append((chrom, want, qname, 4 if i % 2 else 0, [("M", L)] if i % 2 == 0 else [], L))
+            continue
+        rp = d["ps"] - 100
+        lead = int(rng.integers(0, 20))  # soft clip in front: read position rp lies at reference pos0 + rp - lead
+        cigar = ([("S", lead)] if lead else []) + [("M", L - lead)]
+        rows.append((chrom, want - (rp - lead) + 1 - 1, qname, 16 if gene[m] & 1 else 0, cigar, L))
+    rows.sort(key=lambda t: (t[0], t[1]))
+    brecs = [bammodel.bam_record(nm, fl, ch if not fl & 4 else -1, p0, 30, cg, "A" * L) for ch, p0, nm, fl, cg, L in rows]
+    data = bammodel.bgzf_compress(bammodel.bam_bytes("@HD\tVN:1.6\tSO:coordinate\n", [("chr1", 10 ** 6), ("chr2", 10 ** 6)], brecs), block=4096)
+
+    names, tags = assignumis.assign_umis_bam(gpu_ctx, data, chunk_size=60)
+    assert names == [t[2] for t in rows]
+
+    # ---- the oracle flow over the same chunks -------------------------------------------------------------------------------
+    scans = [assignumis.scan_data_from_name(nm) if "_FAILED" not in nm else None for nm in names]
+    pos = []
+    for (ch, p0, nm, fl, cg, L), d in zip(rows, scans):
+        pos.append(None if d is None or fl & 4 else sor.ref_position_at_read_position(cg, p0 + 1, d["ps"] - 100))
+    rev = [bool(t[3] & 16) for t in rows]
+    exp = [None] * len(rows)
+
+    def flush(cur, keep):
+        region, n_done = sor.region_group([pos[i] for i in cur], [rev[i] for i in cur], keep_data_end=keep)
+        done = cur[:n_done]
+        groups = {}
+        for k, i in enumerate(done):
+            d = scans[i]
+            if d is None or d["bc"] is None or region[k] < 0:
+                continue
+            w = sor.umi_window_3p(d["x"], d["ae"], d["bc"]["end"])
+            if w is not None:
+                groups.setdefault((d["bc"]["seq"], region[k]), []).append((i, w))
+        for g in groups.values():
+            if len(g) < 2:
+                continue
+            idx = [i for i, _ in g]
+            asg, _ = sor.umi_cluster_group(sor.umi_matrix(np.array([w for _, w in g], dtype=np.uint8)).reshape(-1), len(g),
+                                           np.array([scans[i]["q"] for i in idx], np.float32))
+            for j, i in enumerate(idx):
+                if asg["center"][j] >= 0:
+                    exp[i] = (idx[int(asg["center"][j])], int(asg["ed"][j]))
+        return cur[n_done:]
+
+    eff_ref = [-1 if t[3] & 4 else t[0] for t in rows]  # SAMRecord.getReferenceName() of an unmapped record is "*"
+    cur, counter, chrom, n_flush = [0], 1, eff_ref[0], 0
+    for i in range(1, len(rows)):
+        counter += 1
+        is_end = eff_ref[i] != chrom
+        chrom = eff_ref[i]
+        if counter >= 60 or is_end:
+            cur = flush(cur, keep=not is_end)
+            counter, n_flush = 0, n_flush + 1
+        cur.append(i)
+    while cur:
+        cur = flush(cur, keep=False)
+    assert n_flush >= 6
+    got = [None if t is None else (t["center"], t["U1"]) for t in tags]
+    assert got == exp
+    n_tagged = sum(t is not None for t in tags)
+    assert n_tagged > 0.5 * len(rows)
+    # reads of one molecule end with one UMI
+    by_mol = {}
+    for (ch, p0, nm, fl, cg, L), t in zip(rows, tags):
+        if t is not None:
+            by_mol.setdefault(nm.split("_")[0], set())
+    assert len(by_mol) > 200
