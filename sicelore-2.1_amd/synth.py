@@ -358,3 +358,31 @@ def gen_reads_5p(n, used_keys, seed=6, device=None, err=0.063, frac=(0.4, 0.3, 0
     qmid = (torch.randn((n,), generator=g, device=device) * 2.0 + q_mean).round().clamp(2, 40).to(torch.uint8) + 33
     return {"head": head.to(torch.uint8), "tail": tail.to(torch.uint8), "qhead": q(), "qtail": q(), "qmid": qmid,
             "mid_len": mid_len, "reverse": reverse, "truth": truth, "umi": umi_key}
+
+
+def fastq_text_device(rd):
+    """FASTQ text of a read batch, built on the device: records "@rNNNNNNNN\n" bases "\n+\n" qualities "\n" (qualities 'I').
+    -> (text uint8 tensor, contiguous bases, offsets)"""
+    buf, offs = materialize_device(rd)
+    dev = buf.device
+    n = offs.numel() - 1
+    lens = offs[1:] - offs[:-1]
+    rec_len = 2 * lens + 15  # 11 + len + 3 + len + 1
+    rec_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rec_off[1:] = torch.cumsum(rec_len, 0)
+    total = int(rec_off[-1])
+    text = torch.full((total,), ord("I"), dtype=torch.uint8, device=dev)
+    idx = torch.arange(n, device=dev)
+    text[rec_off[:-1]] = ord("@")
+    text[rec_off[:-1] + 1] = ord("r")
+    for k in range(8):
+        text[rec_off[:-1] + 2 + k] = (48 + (idx // 10 ** (7 - k)) % 10).to(torch.uint8)
+    text[rec_off[:-1] + 10] = 10
+    text[rec_off[:-1] + 11 + lens] = 10
+    text[rec_off[:-1] + 12 + lens] = ord("+")
+    text[rec_off[:-1] + 13 + lens] = 10
+    text[rec_off[1:] - 1] = 10
+    pos = torch.arange(int(offs[-1]), device=dev) - torch.repeat_interleave(offs[:-1], lens) + \
+        torch.repeat_interleave(rec_off[:-1] + 11, lens)
+    text[pos] = buf
+    return text, buf, offs

@@ -139,28 +139,8 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
     # ---- K-FQ: FASTQ text -> record index -> contiguous reads; text built on the device from synthetic reads -----------
     n = 500_000
     rd = synth.gen_reads(n, used, seed=9, device=dev)
-    buf, offs = synth.materialize_device(rd)
-    lens = offs[1:] - offs[:-1]
-    # record = "@rNNNNNNNN\n" + seq + "\n+\n" + qual + "\n": 11 + len + 3 + len + 1 bytes
-    rec_len = 2 * lens + 15
-    rec_off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
-    rec_off[1:] = torch.cumsum(rec_len, 0)
-    total = int(rec_off[-1])
-    text = torch.full((total,), ord("I"), dtype=torch.uint8, device=dev)
-    idx = torch.arange(n, device=dev)
-    text[rec_off[:-1]] = ord("@")
-    text[rec_off[:-1] + 1] = ord("r")
-    for k in range(8):
-        text[rec_off[:-1] + 2 + k] = (48 + (idx // 10 ** (7 - k)) % 10).to(torch.uint8)
-    text[rec_off[:-1] + 10] = 10
-    text[rec_off[:-1] + 11 + lens] = 10
-    text[rec_off[:-1] + 12 + lens] = ord("+")
-    text[rec_off[:-1] + 13 + lens] = 10
-    text[rec_off[1:] - 1] = 10
-    pos = torch.arange(int(offs[-1]), device=dev) - torch.repeat_interleave(offs[:-1], lens) + \
-        torch.repeat_interleave(rec_off[:-1] + 11, lens)
-    text[pos] = buf
-    del pos
+    text, buf, offs = synth.fastq_text_device(rd)
+    total = int(text.numel())
     cap = n + 2
     line = torch.zeros(4 * cap + 8, dtype=torch.int64, device=dev)
     ns, ss, qs = (torch.zeros(cap, dtype=torch.int64, device=dev) for _ in range(3))
