@@ -283,7 +283,26 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
     // dword-aligned output positions g = (off & ~3) + 4 * (64 * it + lane); dwords that are not wholly this wave's (the two
     // ends of the record, shared with its neighbours, and the ends of the suffix K-WNAME writes) go out as bytes
     const uint64_t g0 = off & ~3ull, end = off + bytes, s0 = off + p_sfx, s1 = s0 + n_sfx;
+    // the long runs -- four bytes that all lie in the bases or in the qualities -- take one (unaligned) dword load per lane
+    // when that holds for the whole wave; everything else goes through `source`
+    const uint64_t seq_lo = off + p_seq, seq_hi = off + p_plus - 1, q_lo = off + p_q, q_hi = q_lo + (qset ? qlen : 0);
     for (uint64_t g = g0 + 4ull * lane; g < end; g += 256) {
+        const bool all_seq = g >= seq_lo && g + 4 <= seq_hi, all_q = g >= q_lo && g + 4 <= q_hi;
+        if (!__ballot(!(all_seq || all_q))) {
+            const uint64_t k = all_seq ? g - seq_lo : g - q_lo;
+            const uint8_t *b0 = all_seq ? seq0 : qual0;
+            uint32_t w;
+            if (rev) {
+                __builtin_memcpy(&w, b0 - (int64_t)k - 3, 4);  // source bytes k+3 .. k of the mirrored run
+                w = __builtin_bswap32(w);
+                if (all_seq)
+                    w = lut[256 + (w & 0xFF)] | (lut[256 + ((w >> 8) & 0xFF)] << 8) | (lut[256 + ((w >> 16) & 0xFF)] << 16) |
+                        (lut[256 + (w >> 24)] << 24);
+            } else
+                __builtin_memcpy(&w, b0 + k, 4);
+            *reinterpret_cast<uint32_t *>(out + g) = w;
+            continue;
+        }
         uint32_t c[4], tb[4];
         bool ok[4];
 #pragma unroll
