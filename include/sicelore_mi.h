@@ -429,6 +429,9 @@ int smi_bgzf_uncompressed_size(const uint8_t *in, size_t n_in, size_t *n_out, si
 /* inflates every complete block (CRC32 and ISIZE checked, as BlockCompressedInputStream does) on n_threads threads */
 int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, size_t *consumed,
                      int n_threads);
+/* plain (multi-member) gzip, the *.fastq.gz inputs of scanfastq (FastqFileReader.java:L138-150 via GZIPInputStream); out ==
+ * NULL: only the inflated size is returned in *n_out */
+int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out);
 typedef struct {                /* one alignment record; offsets into the inflated stream */
     uint64_t rec_off;           /* of its block_size word */
     uint64_t name_off, cigar_off, seq_off, qual_off, aux_off;

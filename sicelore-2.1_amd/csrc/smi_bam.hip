@@ -239,3 +239,64 @@ extern "C" int smi_bam_index_records(const uint8_t *bam, size_t n, uint64_t star
     *end_off = p;
     return SMI_OK;
 }
+
+// Plain gzip (RFC 1952, possibly several members, as `cat a.gz b.gz` or bgzip produce): the FASTQ inputs of `scanfastq`
+// (FastqFileReader opens *.gz through htsjdk's FastqReader / GZIPInputStream, FJ!nanoporereadscanner/readerwriter/
+// FastqFileReader.java:L138-150).  One stream is inherently serial; files are independent, so the caller inflates several
+// at once.  Two-call protocol: out == NULL returns the inflated size in *n_out.
+extern "C" int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out) {
+    if ((!in && n_in) || !n_out) {
+        set_error("smi_gz_inflate: null argument");
+        return SMI_ERR_INVALID;
+    }
+    z_stream zs;
+    std::memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 16) != Z_OK) {  // gzip wrapper
+        set_error("smi_gz_inflate: inflateInit2 failed");
+        return SMI_ERR_INVALID;
+    }
+    std::vector<uint8_t> sink(out ? 0 : (1u << 20));
+    size_t total = 0, off = 0;
+    int rc = Z_OK;
+    while (off < n_in) {
+        zs.next_in = const_cast<Bytef *>(in + off);
+        zs.avail_in = (uInt)std::min<size_t>(n_in - off, 1u << 30);
+        const size_t fed = zs.avail_in;
+        do {
+            if (out) {
+                zs.next_out = out + total;
+                zs.avail_out = (uInt)std::min<size_t>(cap_out - total, 1u << 30);
+            } else {
+                zs.next_out = sink.data();
+                zs.avail_out = (uInt)sink.size();
+            }
+            const size_t room = zs.avail_out;
+            rc = inflate(&zs, Z_NO_FLUSH);
+            total += room - zs.avail_out;
+            if (rc == Z_STREAM_END) break;
+            if (rc != Z_OK && rc != Z_BUF_ERROR) {
+                inflateEnd(&zs);
+                set_error(std::string("smi_gz_inflate: corrupt gzip data (") + (zs.msg ? zs.msg : "zlib error") + ")");
+                return SMI_ERR_INVALID;
+            }
+            if (out && total == cap_out && zs.avail_in) {
+                inflateEnd(&zs);
+                set_error("smi_gz_inflate: output buffer too small");
+                return SMI_ERR_INVALID;
+            }
+        } while (zs.avail_in);
+        off += fed - zs.avail_in;
+        if (rc == Z_STREAM_END) {
+            if (off < n_in) inflateReset(&zs);  // next member
+            rc = Z_OK;
+            if (off >= n_in) rc = Z_STREAM_END;
+        }
+    }
+    inflateEnd(&zs);
+    if (n_in && rc != Z_STREAM_END) {
+        set_error("smi_gz_inflate: truncated gzip stream");
+        return SMI_ERR_INVALID;
+    }
+    *n_out = total;
+    return SMI_OK;
+}

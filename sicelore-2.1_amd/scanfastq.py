@@ -19,6 +19,15 @@ MULTI_CHIMERIC_READS_DISCARDED = 1 << 2
 FAILED = 1 << 6
 
 
+def read_fastq_file(path):
+    """bytes of a FASTQ file; *.gz (plain or block gzip) is inflated by the library (smi_gz_inflate), as FastqFileReader
+    does through GZIPInputStream (FastqFileReader.java:L138-150)"""
+    raw = np.fromfile(path, dtype=np.uint8)
+    if str(path).lower().endswith(".gz"):
+        return _lib.gz_inflate(raw).tobytes()
+    return raw.tobytes()
+
+
 class ReadScanner:
     def __init__(self, ctx, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True):
         self.ctx, self.max_ed, self.five_prime = ctx, int(max_ed), bool(five_prime)

@@ -100,3 +100,22 @@ def test_scan_data_from_name_follows_reference_rules(pkg):
     with pytest.raises(libmod.SmiError):
         au.scan_data_from_name("x_FWD_PS=3_PE=9_")                             # AdapterInfoNotFoundInReadException (L442-443)
     assert au.parse_name(nm)["cell"] == "ACGTACGTACGTACGT" and au.parse_name("x_FWD_PS=3_PE=9_AE=40_X=AC_Q=9_1") is None
+
+
+def test_gz_inflate_multi_member_and_errors(pkg):
+    import gzip
+
+    from sicelore_amd import lib as libmod
+
+    a = (b"@r1\nACGT\n+\nIIII\n" * 30000)
+    b = b"@r2\nTTTT\n+\n5555\n" * 7
+    z = gzip.compress(a, 6) + gzip.compress(b"") + gzip.compress(b, 1)  # cat a.gz empty.gz b.gz
+    got = libmod.gz_inflate(np.frombuffer(z, dtype=np.uint8))
+    assert got.tobytes() == a + b
+    assert libmod.gz_inflate(np.frombuffer(bammodel.bgzf_compress(a), dtype=np.uint8)).tobytes() == a  # BGZF is gzip too
+    with pytest.raises(libmod.SmiError):
+        libmod.gz_inflate(np.frombuffer(z[:-5], dtype=np.uint8))  # truncated
+    bad = bytearray(z)
+    bad[len(bad) // 3] ^= 0xFF
+    with pytest.raises(libmod.SmiError):
+        libmod.gz_inflate(np.frombuffer(bytes(bad), dtype=np.uint8))

@@ -110,3 +110,60 @@ def test_records_equal_oracle_5p(pkg, synth, sor, gpu_ctx, trim):
     exp_p, exp_f, n_p = _oracle_records(sor, sor.BarcodeSet(used.numpy()), seqs, quals, 1, {}, 1, five_prime=True, trim=trim,
                                         split=False)
     assert got_p == exp_p and got_f == exp_f and info["n_passed"] == n_p and n_p > 120
+
+
+def test_large_batch_round_trip_properties(pkg, synth, gpu_ctx):
+    """200 k reads (no oracle at this size): the two streams re-read by K-FQ hold every record exactly once, with the same
+    number of bases; reverse complement preserves the A+T / G+C / N totals; qualities keep their byte histogram"""
+    import torch
+
+    n = 200_000
+    dev = torch.device("cuda", gpu_ctx.device)
+    wl = synth.make_whitelist(50_000, seed=971, device=dev)
+    used = synth.pick_used(wl, 300, seed=972)
+    gpu_ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
+    rd = synth.gen_reads(n, used, seed=973, device=dev)
+    text, bases, offs0 = synth.fastq_text_device(rd)
+    cap = n + 2
+    z64 = lambda k: torch.zeros(k, dtype=torch.int64, device=dev)  # noqa: E731
+    z32 = lambda k: torch.zeros(k, dtype=torch.int32, device=dev)  # noqa: E731
+    line, ns, ss, qs, offs, nl, sl = z64(4 * cap + 8), z64(cap), z64(cap), z64(cap), z64(cap + 1), z32(cap), z32(cap)
+    nr, err = gpu_ctx.fastq_index_device(text, text.numel(), line, ns, nl, ss, sl, qs, offs, cap)
+    assert (nr, err) == (n, 0)
+    total = int(offs[n])
+    reads = torch.zeros(total, dtype=torch.uint8, device=dev)
+    quals = torch.zeros(total, dtype=torch.uint8, device=dev)
+    gpu_ctx.fastq_gather_device(text, ss, offs, n, reads)
+    gpu_ctx.fastq_gather_device(text, qs, offs, n, quals)
+    ends = torch.zeros((28, 2 * n), dtype=torch.int32, device=dev)
+    lens, qsum = z32(n), z32(n)
+    qt = torch.zeros((n, 224), dtype=torch.uint8, device=dev)
+    gpu_ctx.pack_ends_device(reads, quals, offs[:n + 1], n, ends, lens, qt, qsum)
+    scan = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    win = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    gpu_ctx.scan_device(ends, lens, n, gpu_ctx.scan_config(2), scan, win, qt, qsum)
+    bc = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    gpu_ctx.bc_match_device(win, bc, n, max_ed=1)
+    capw = 2 * total + text.numel() + 320 * n
+    out_p, out_f = torch.empty(capw, dtype=torch.uint8, device=dev), torch.empty(capw, dtype=torch.uint8, device=dev)
+    rec_off, is_p = z64(n + 1), torch.zeros(n, dtype=torch.uint8, device=dev)
+    bp, bf, n_p = gpu_ctx.fastq_write_device(text, line, reads, quals, offs[:n + 1], None, None, scan, bc, None, n, 1, out_p, out_f,
+                                             rec_off, is_p)
+    assert n_p == int(is_p.sum()) and 0.9 * n < n_p < n
+    seq_total, hist_b, hist_q = 0, torch.zeros(256, dtype=torch.int64, device=dev), torch.zeros(256, dtype=torch.int64, device=dev)
+    for buf, nbytes, want in ((out_p, bp, n_p), (out_f, bf, n - n_p)):
+        k, e = gpu_ctx.fastq_index_device(buf, nbytes, line, ns, nl, ss, sl, qs, offs, cap)
+        assert (k, e) == (want, 0)
+        t = int(offs[k])
+        sb, sq = torch.zeros(max(t, 1), dtype=torch.uint8, device=dev), torch.zeros(max(t, 1), dtype=torch.uint8, device=dev)
+        gpu_ctx.fastq_gather_device(buf, ss, offs, k, sb)
+        gpu_ctx.fastq_gather_device(buf, qs, offs, k, sq)
+        seq_total += t
+        hist_b += torch.bincount(sb[:t].to(torch.int64), minlength=256)
+        hist_q += torch.bincount(sq[:t].to(torch.int64), minlength=256)
+    assert seq_total == total
+    h_in = torch.bincount(reads.to(torch.int64), minlength=256)
+    at = lambda h: int(h[ord("A")] + h[ord("T")])  # noqa: E731
+    gc = lambda h: int(h[ord("G")] + h[ord("C")])  # noqa: E731
+    assert at(hist_b) == at(h_in) and gc(hist_b) == gc(h_in) and int(hist_b[ord("N")]) == int(h_in[ord("N")])
+    assert bool((hist_q == torch.bincount(quals.to(torch.int64), minlength=256)).all())
