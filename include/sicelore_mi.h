@@ -432,6 +432,10 @@ int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_ou
 /* plain (multi-member) gzip, the *.fastq.gz inputs of scanfastq (FastqFileReader.java:L138-150 via GZIPInputStream); out ==
  * NULL: only the inflated size is returned in *n_out */
 int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out);
+/* BGZF writer under the output BAMs of assignumis (htsjdk BlockCompressedOutputStream under UmiFinderWorker$OneBamWriter):
+ * blocks of block_bytes (<= 0xFF00) input bytes + the EOF block; out == NULL: upper bound of the size in *n_out */
+int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, int level, int block_bytes,
+                     int n_threads);
 typedef struct {                /* one alignment record; offsets into the inflated stream */
     uint64_t rec_off;           /* of its block_size word */
     uint64_t name_off, cigar_off, seq_off, qual_off, aux_off;

@@ -58,6 +58,9 @@ def scan_data_from_name(name, bc_edit_limit=None):
     q = _extract(sub, "Q=")
     if q is not None:
         d["q"] = float(np.float32(q.split(" ")[0]))
+    last = sub.rfind("_")
+    # NumberToAndFromAscii.convertString (L492-494); a FASTQ-style name still carries ` cellBC=...` behind the id
+    d["read_id"] = int(sub[last + 1:].split(" ")[0], 36) if last < len(sub) - 1 else 0
     return d
 
 
@@ -122,11 +125,13 @@ def _assign_in_regions(ctx, info, region, cluster_cfg=None, n_threads=4):
                         len(sizes), int(po[-1]), d_out)
     torch.cuda.synchronize()
     qv = np.array([info[i]["q"] for i in order], dtype=np.float32)
-    asg, _skipped = _lib.umi_cluster_groups(d_out.cpu().numpy(), mo, go, qv, cluster_cfg, n_threads=n_threads)
+    asg, skipped = _lib.umi_cluster_groups(d_out.cpu().numpy(), mo, go, qv, cluster_cfg, n_threads=n_threads)
     base = np.repeat(go[:-1], sizes)
     for j, i in enumerate(order):
         a = asg[j]
         if a["center"] < 0:
+            if skipped is not None and skipped[j]:
+                out[i] = dict(skipped=True)  # UMI_CLUSTERING_SKIPPED_HIGHCOMPLEXITY | DONT_ASSIGN_UMI (ClusterOneBase L61)
             continue
         cw = wins[order[int(base[j]) + int(a["center"])]]
         off = int(a["offset"])
@@ -212,3 +217,155 @@ def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=N
     while cur:
         cur = flush(cur, keep=False)
     return names, tags
+
+
+# ---- BAM tags (ReadScanResult.writeSamFlags / writeBCSamFlags, ClusterOneBase.setSamflagsAndStatsForClustered,
+#      UmiFinderWorker.lambda$new$0 + $BamWriters.lambda$writeSams$2; tag names: Jar/config.xml:297-492) -------------------------
+def record_tag_sets(scan, umi, u7):
+    """the setAttribute calls the reference makes on one record, in its order: [(tag, value)], value int or str.
+    scan: scan_data_from_name; umi: entry of assign_umis (or None); u7: the read's own post-barcode 12-mer or None.
+    -> (calls, has_bc, umi_from_clustering)"""
+    c = []
+    if scan is None:
+        return c, False, False
+    if scan["pe"] is not None:                                   # polyAFound(): end != null (ReadScanResult L205-207)
+        c += [("PE", scan["pe"]), ("PS", scan["ps"])]
+    c.append(("AE", scan["ae"]))                                 # L209-210
+    if scan["reverse"]:
+        c.append(("RE", ""))                                     # L212-213
+    if scan["tso"] is not None:
+        c.append(("TE", scan["tso"]))                            # L215-216
+    bc = scan["bc"]
+    has_bc = bc is not None and bc["seq"] is not None            # barcodeFound(): barcodeseq != null
+    if has_bc:                                                   # L218-237
+        c.append(("BU", bc["seq"]))
+        if bc["start"] is not None:
+            c.append(("BV", str(bc["start"])))
+        if bc["end"] is not None:
+            c.append(("BE", str(bc["end"])))
+        c.append(("BW", bc["ed"]))
+        if bc["ed_sec"] is not None:
+            c.append(("BX", "N.A." if bc["ed_sec"] == 2147483647 else str(bc["ed_sec"])))
+        c.append(("SX", str(scan["read_id"])))
+        if bc["rank"] is not None:
+            c.append(("BH", str(bc["rank"])))
+        # writeBCSamFlags(sam, flags, false, false) L254-279
+        c += [("BC", bc["seq"]), ("BZ", "")]
+        if bc["start"] is not None:
+            c.append(("BB", str(bc["start"])))
+        if bc["end"] is not None:
+            c.append(("BF", str(bc["end"])))
+        c.append(("B1", bc["ed"]))
+        if bc["ed_sec"] is not None:
+            c.append(("B2", str(bc["ed_sec"])))
+        c.append(("BZ", bc["seq"]))
+        if bc["rank"] is not None:
+            c.append(("BH", str(bc["rank"])))
+    clustered = umi is not None and not umi.get("skipped")
+    if clustered:                                                # ClusterOneBase L145-164
+        c += [("U8", umi["U8"]), ("U7", umi["U7"]), ("UC", ""), ("U1", str(umi["U1"]))]
+        if umi["U2"] is not None:
+            c.append(("U2", str(umi["U2"])))
+    elif has_bc and u7 is not None:                              # UmiFinderWorker.lambda$new$0 L248-255
+        c.append(("U7", u7))
+        if not (umi is not None and umi.get("skipped")):         # $BamWriters L442-447: unless DONT_ASSIGN_UMI
+            c += [("U8", u7), ("UZ", "")]
+    return c, has_bc, clustered
+
+
+def _aux_bytes(tag, value):
+    """BinaryTagCodec: strings as Z, integers in the smallest type that holds them (c C s S i I)"""
+    t = tag.encode()
+    if isinstance(value, str):
+        return t + b"Z" + value.encode() + b"\0"
+    v = int(value)
+    for code, fmt, lo, hi in (("c", "<b", -128, 127), ("C", "<B", 0, 255), ("s", "<h", -32768, 32767), ("S", "<H", 0, 65535),
+                              ("i", "<i", -2 ** 31, 2 ** 31 - 1), ("I", "<I", 0, 2 ** 32 - 1)):
+        if lo <= v <= hi:
+            return t + code.encode() + np.array([v]).astype(fmt).tobytes()
+    raise ValueError("integer tag out of range")
+
+
+_AUX_SIZE = {ord("A"): 1, ord("c"): 1, ord("C"): 1, ord("s"): 2, ord("S"): 2, ord("i"): 4, ord("I"): 4, ord("f"): 4}
+
+
+def split_aux(aux):
+    """aux bytes of a BAM record -> [(tag str, raw bytes of the whole field)] in file order"""
+    out, p, n = [], 0, len(aux)
+    while p < n:
+        ty = aux[p + 2]
+        if ty in _AUX_SIZE:
+            q = p + 3 + _AUX_SIZE[ty]
+        elif ty in (ord("Z"), ord("H")):
+            q = aux.index(b"\0", p + 3) + 1
+        elif ty == ord("B"):
+            q = p + 8 + _AUX_SIZE[aux[p + 3]] * int(np.frombuffer(aux[p + 4:p + 8], dtype="<u4")[0])
+        else:
+            raise _lib.SmiError("unknown BAM aux type")
+        out.append((aux[p:p + 2].decode(), bytes(aux[p:q])))
+        p = q
+    return out
+
+
+def apply_tag_sets(fields, calls):
+    """SAMRecord.setAttribute on htsjdk's attribute list (SAMBinaryTagAndValue.insert): the list read from the file keeps its
+    order; a new tag goes in front of the first element whose binary tag (second char << 8 | first char) is greater, an
+    existing tag is replaced in place.  [restated from htsjdk 2.x, an un-vendored dependency: parity unpinned]"""
+    key = lambda t: (ord(t[1]) << 8) | ord(t[0])  # noqa: E731
+    fields = list(fields)
+    for tag, value in calls:
+        raw, k = _aux_bytes(tag, value), key(tag)
+        for j, (t, _) in enumerate(fields):
+            if k < key(t):
+                fields.insert(j, (tag, raw))
+                break
+            if k == key(t):
+                fields[j] = (tag, raw)
+                break
+        else:
+            fields.append((tag, raw))
+    return fields
+
+
+def _coordinate_key(rec, name):
+    """SAMRecordCoordinateComparator: reference index (unmapped last), start, strand, name, flags, mapq, mate, insert size"""
+    ref = int(rec["ref_id"])
+    return (ref if ref >= 0 else 1 << 30, int(rec["pos"]), bool(int(rec["flag"]) & 16), name, int(rec["flag"]), int(rec["mapq"]),
+            int(rec["next_ref_id"]) if int(rec["next_ref_id"]) >= 0 else 1 << 30, int(rec["next_pos"]), int(rec["tlen"]))
+
+
+def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, **kw):
+    """`assignumis` BAM in -> (bcfound BAM bytes, umifound BAM bytes, names, tags): the two BGZF streams the reference writes
+    (<out>.bam: every record with a cell barcode; <out>_umifound_.bam: those whose UMI comes from clustering), header copied,
+    records of a chunk in coordinate-comparator order with the tags of record_tag_sets added (GE needs the refFlat
+    annotator, which is not built)."""
+    _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
+    names, tags = assign_umis_bam(ctx, data, chunk_size=chunk_size, n_threads=n_threads, **kw)
+    scans = [scan_data_from_name(nm, kw.get("bc_edit_limit")) for nm in names]
+    header_end = int(recs[0]["rec_off"]) if recs.size else bam.size
+    out_bc, out_umi = [bam[:header_end].tobytes()], [bam[:header_end].tobytes()]
+    # BamReader cuts chunks; BamWriters sorts each written batch (L421): batches = the flushes of assign_umis_bam
+    order = sorted(range(recs.size), key=lambda i: _coordinate_key(recs[i], names[i]))
+    for i in order:
+        d, r = scans[i], recs[i]
+        u7 = None
+        if d is not None and d["bc"] is not None and d["bc"]["end"] is not None and d["x"]:
+            w = umi_window(d["x"], d["ae"], d["bc"]["end"])
+            u7 = None if w is None else "".join(_DEC[c] for c in w[1:13])
+        calls, has_bc, clustered = record_tag_sets(d, tags[i], u7)
+        if not has_bc:
+            continue
+        o = int(r["rec_off"])
+        fixed = bytearray(bam[o + 4:int(r["aux_off"])].tobytes())
+        if truncate_read_name:                                  # -w: readName.split("_")[0] (L431-432)
+            nm = names[i].split("_")[0].encode() + b"\0"
+            fixed = fixed[:32] + nm + fixed[32 + int(r["l_read_name"]):]
+            fixed[8] = len(nm)
+        aux = bam[int(r["aux_off"]):int(r["aux_off"]) + int(r["aux_len"])].tobytes()
+        body = bytes(fixed) + b"".join(raw for _, raw in apply_tag_sets(split_aux(aux), calls))
+        rec_bytes = np.array([len(body)], dtype="<u4").tobytes() + body
+        out_bc.append(rec_bytes)
+        if clustered:
+            out_umi.append(rec_bytes)
+    z = lambda parts: _lib.bgzf_deflate(b"".join(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
+    return z(out_bc), z(out_umi), names, tags

@@ -300,3 +300,82 @@ extern "C" int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size
     *n_out = total;
     return SMI_OK;
 }
+
+// BGZF writer: `in` cut into blocks of block_bytes (<= 0xFF00) uncompressed bytes, each deflated on its own (zlib level
+// `level`), plus the 28-byte empty EOF block.  Replaces htsjdk's BlockCompressedOutputStream under BAMFileWriter
+// (UmiFinderWorker$OneBamWriter); the compressed bytes depend on the deflate implementation and are not comparable with the
+// reference's, the inflated stream is.  Two-call protocol: out == NULL returns an upper bound of the size in *n_out.
+extern "C" int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, int level,
+                                int block_bytes, int n_threads) {
+    if ((!in && n_in) || !n_out || block_bytes < 1 || block_bytes > 0xFF00 || level < 0 || level > 9) {
+        set_error("smi_bgzf_deflate: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    const size_t n_blocks = (n_in + (size_t)block_bytes - 1) / (size_t)block_bytes;
+    const size_t slot = (size_t)block_bytes + 26 + 1024;  // deflate never grows a block of <= 0xFF00 bytes past this
+    if (!out) {
+        *n_out = n_blocks * slot + 28;
+        return SMI_OK;
+    }
+    std::vector<std::vector<uint8_t>> blk(n_blocks);
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        z_stream zs;
+        std::memset(&zs, 0, sizeof zs);
+        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+            bad = 1;
+            return;
+        }
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= n_blocks) break;
+            const size_t o = k * (size_t)block_bytes, n = std::min<size_t>((size_t)block_bytes, n_in - o);
+            std::vector<uint8_t> &b = blk[k];
+            b.resize(slot);
+            deflateReset(&zs);
+            zs.next_in = const_cast<Bytef *>(in + o);
+            zs.avail_in = (uInt)n;
+            zs.next_out = b.data() + 18;
+            zs.avail_out = (uInt)(slot - 26);
+            if (deflate(&zs, Z_FINISH) != Z_STREAM_END || 18 + zs.total_out + 8 > 0x10000) {
+                bad = 1;
+                break;
+            }
+            const uint32_t bsize = (uint32_t)(18 + zs.total_out + 8);
+            const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xFF),
+                                      (uint8_t)((bsize - 1) >> 8)};
+            std::memcpy(b.data(), head, 18);
+            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in + o, (uInt)n);
+            uint8_t *t = b.data() + 18 + zs.total_out;
+            for (int i = 0; i < 4; i++) t[i] = (uint8_t)(crc >> (8 * i));
+            for (int i = 0; i < 4; i++) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
+            b.resize(bsize);
+        }
+        deflateEnd(&zs);
+    };
+    const int nt = std::max(1, std::min<int>(n_threads, (int)std::max<size_t>(n_blocks, 1)));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(work);
+    work();
+    for (auto &t : pool) t.join();
+    if (bad.load()) {
+        set_error("smi_bgzf_deflate: deflate failed");
+        return SMI_ERR_INVALID;
+    }
+    static const uint8_t kEof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t total = 28;
+    for (const auto &b : blk) total += b.size();
+    if (total > cap_out) {
+        set_error("smi_bgzf_deflate: output buffer too small");
+        return SMI_ERR_INVALID;
+    }
+    size_t o = 0;
+    for (const auto &b : blk) {
+        std::memcpy(out + o, b.data(), b.size());
+        o += b.size();
+    }
+    std::memcpy(out + o, kEof, 28);
+    *n_out = total;
+    return SMI_OK;
+}

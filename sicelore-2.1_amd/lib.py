@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate",
 ]
 
 
@@ -103,6 +103,7 @@ def load_library():
     lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.smi_bgzf_uncompressed_size.argtypes = [vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.smi_bgzf_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ci]
+    lib.smi_bgzf_deflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ci, ci, ci]
     lib.smi_gz_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.smi_bam_header.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
                                    ctypes.POINTER(ctypes.c_int32), vp, vp, vp, sz, ctypes.POINTER(ctypes.c_uint64)]
@@ -289,6 +290,20 @@ def bgzf_inflate(data, n_threads=4):
                             int(n_threads)):
         raise SmiError(lib.smi_last_error().decode())
     return out[:got.value], used.value
+
+
+def bgzf_deflate(data, level=5, block_bytes=0xFF00, n_threads=4):
+    """BGZF-compressed bytes (numpy uint8) of `data`, EOF block included"""
+    lib = load_library()
+    data = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data, dtype=np.uint8)
+    n = ctypes.c_size_t(0)
+    if lib.smi_bgzf_deflate(data.ctypes.data, data.size, None, 0, ctypes.byref(n), int(level), int(block_bytes), int(n_threads)):
+        raise SmiError(lib.smi_last_error().decode())
+    out = np.empty(n.value, dtype=np.uint8)
+    if lib.smi_bgzf_deflate(data.ctypes.data, data.size, out.ctypes.data, out.size, ctypes.byref(n), int(level), int(block_bytes),
+                            int(n_threads)):
+        raise SmiError(lib.smi_last_error().decode())
+    return out[:n.value]
 
 
 def gz_inflate(data):

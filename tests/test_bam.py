@@ -119,3 +119,58 @@ def test_gz_inflate_multi_member_and_errors(pkg):
     bad[len(bad) // 3] ^= 0xFF
     with pytest.raises(libmod.SmiError):
         libmod.gz_inflate(np.frombuffer(bytes(bad), dtype=np.uint8))
+
+
+def _parse_aux(aux):
+    """independent reader of the aux types this project writes or passes through"""
+    out, p = [], 0
+    while p < len(aux):
+        tag, ty = aux[p:p + 2].decode(), chr(aux[p + 2])
+        p += 3
+        if ty == "Z":
+            q = aux.index(b"\0", p)
+            out.append((tag, ty, aux[p:q].decode()))
+            p = q + 1
+        else:
+            fmt = {"c": "<b", "C": "<B", "s": "<h", "S": "<H", "i": "<i", "I": "<I", "A": "<c", "f": "<f"}[ty]
+            out.append((tag, ty, struct.unpack_from(fmt, aux, p)[0]))
+            p += struct.calcsize(fmt)
+    return out
+
+
+def test_tag_sets_and_attribute_order(pkg):
+    import importlib
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    nm = "a_REV_PS=100_PE=130_AE=170_T=44_bc=ACGTACGTACGTACGT_ed=1_ed_sec=2147483647_bcStart=169_bcEnd=154_rk=17_X=ACGT_Q=27.1_1z"
+    d = au.scan_data_from_name(nm)
+    assert d["read_id"] == int("1z", 36)
+    calls, has_bc, clustered = au.record_tag_sets(d, dict(U8="AAAACCCCGGGG", U7="AAAACCCCGGGT", U1=1, U2=3), "AAAACCCCGGGT")
+    assert has_bc and clustered
+    # ReadScanResult.writeSamFlags L205-237, writeBCSamFlags L254-279, ClusterOneBase L145-164 -- in call order
+    assert calls == [("PE", 130), ("PS", 100), ("AE", 170), ("RE", ""), ("TE", 44), ("BU", "ACGTACGTACGTACGT"), ("BV", "169"),
+                     ("BE", "154"), ("BW", 1), ("BX", "N.A."), ("SX", "71"), ("BH", "17"), ("BC", "ACGTACGTACGTACGT"), ("BZ", ""),
+                     ("BB", "169"), ("BF", "154"), ("B1", 1), ("B2", "2147483647"), ("BZ", "ACGTACGTACGTACGT"), ("BH", "17"),
+                     ("U8", "AAAACCCCGGGG"), ("U7", "AAAACCCCGGGT"), ("UC", ""), ("U1", "1"), ("U2", "3")]
+    # no clustering result: U7 from the read, copied to U8 with UZ -- unless the group was skipped (DONT_ASSIGN_UMI)
+    c2, _, cl2 = au.record_tag_sets(d, None, "TTTTGGGGCCCC")
+    assert not cl2 and c2[-3:] == [("U7", "TTTTGGGGCCCC"), ("U8", "TTTTGGGGCCCC"), ("UZ", "")]
+    c3, _, _ = au.record_tag_sets(d, dict(skipped=True), "TTTTGGGGCCCC")
+    assert c3[-1] == ("U7", "TTTTGGGGCCCC")
+    d0 = au.scan_data_from_name("b_FWD_PS=5_PE=9_AE=40_X=AC_Q=9_1")
+    c4, has_bc4, _ = au.record_tag_sets(d0, None, None)
+    assert not has_bc4 and c4 == [("PE", 9), ("PS", 5), ("AE", 40)]
+    # attribute list: file order kept, new tags in front of the first greater binary tag (second char major), replacement in place
+    aux = b"NMC\x03" + b"ASi\x10\x00\x00\x00" + b"tpAP" + b"BZZold\0"
+    fields = au.apply_tag_sets(au.split_aux(aux), calls)
+    tags = [t for t, _ in fields]
+    assert tags == ["B1", "U1", "B2", "U2", "U7", "U8", "BB", "BC", "UC", "AE", "BE", "PE", "RE", "TE", "BF", "BH", "NM", "AS", "PS", "BU",
+                    "BV", "BW", "BX", "SX", "BZ", "tp", "BZ"]  # the walk stops at the greater `tp`: an unsorted input keeps its BZ
+    parsed = {}
+    for t, ty, v in _parse_aux(b"".join(r for _, r in fields)):
+        parsed.setdefault(t, (ty, v))
+    assert parsed["PE"] == ("C", 130) and parsed["AE"] == ("C", 170) and parsed["B1"] == ("c", 1) and parsed["TE"] == ("c", 44)
+    assert parsed["BZ"] == ("Z", "ACGTACGTACGTACGT") and parsed["RE"] == ("Z", "") and parsed["NM"] == ("C", 3) and parsed["tp"] == ("A", b"P")
+    # integer types follow BinaryTagCodec.getIntegerType
+    for v, ty in ((-1, "c"), (127, "c"), (128, "C"), (255, "C"), (256, "s"), (-129, "s"), (32768, "S"), (65536, "i"), (-40000, "i"), (2 ** 31, "I")):
+        assert chr(au._aux_bytes("XY", v)[2]) == ty

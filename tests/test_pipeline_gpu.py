@@ -262,3 +262,85 @@ def test_assignumis_from_bam_chunks_equal_oracle(pkg, synth, sor, gpu_ctx):
         if t is not None:
             by_mol.setdefault(nm.split("_")[0], set())
     assert len(by_mol) > 200
+
+
+def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
+    """BAM in -> the two output BAMs: records with a barcode only, fixed fields untouched, tag values = scan data of the name
+    + the UMI of the clustering (or the read's own 12-mer with UZ), umifound = the clustered subset"""
+    import bammodel
+    from test_bam import _parse_aux
+
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    rng = np.random.default_rng(23)
+    wl = synth.make_whitelist(50_000, seed=291)
+    used = synth.pick_used(wl, 4, seed=292)
+    n_mol, copies = 40, 4
+    mol = synth.gen_reads(n_mol, used, seed=293, err=0.0, q_mean=20.0)
+    seqs, quals, mol_of = [], [], []
+    for m in range(n_mol):
+        s, q = synth.materialize(mol, m)
+        for _ in range(copies):
+            t = list(s)
+            for p in rng.integers(0, len(t), max(1, len(t) // 40)):
+                t[p] = "ACGT"[rng.integers(0, 4)]
+            seqs.append("".join(t))
+            quals.append(q)
+            mol_of.append(m)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    recs = scanfastq.ReadScanner(gpu_ctx, max_ed=1, split_chimeras=False).pass2_chunk(_fastq(seqs, quals))
+    gene = rng.integers(0, 5, n_mol)
+    rows = []
+    for r in recs:
+        qname = r["name"].split(" ")[0]
+        d = assignumis.scan_data_from_name(qname) if "_FAILED" not in qname else None
+        m = mol_of[r["source"]]
+        want = 30_000 + 5_000 * int(gene[m]) + int(rng.integers(-100, 100))
+        if d is None:
+            rows.append((want, qname, 0, [("M", r["length"])], r["length"]))
+        else:
+            rows.append((want - (d["ps"] - 100), qname, 16 if gene[m] & 1 else 0, [("M", r["length"])], r["length"]))
+    rows.sort(key=lambda t: t[0])
+    aux_in = b"NMC\x02" + b"tpAP"
+    brecs = [bammodel.bam_record(nm, fl, 0, p0, 30, cg, "C" * L, aux=aux_in) for p0, nm, fl, cg, L in rows]
+    header = bammodel.bam_bytes("@HD\tVN:1.6\tSO:coordinate\n", [("chr1", 10 ** 6)], [])
+    data = bammodel.bgzf_compress(header + b"".join(brecs), block=8192)
+
+    z_bc, z_umi, names, tags = assignumis.write_tagged_bams(gpu_ctx, data)
+    raw_bc, raw_umi = bammodel.bgzf_decompress(z_bc), bammodel.bgzf_decompress(z_umi)
+    assert raw_bc.startswith(header) and raw_umi.startswith(header)
+    _, _, out_bc = bammodel.parse_bam(raw_bc)
+    _, _, out_umi = bammodel.parse_bam(raw_umi)
+    by_name = {nm: i for i, nm in enumerate(names)}
+    n_clustered = n_uz = 0
+    assert [o["pos0"] for o in out_bc] == sorted(o["pos0"] for o in out_bc)
+    for o in out_bc:
+        i = by_name[o["name"]]
+        d = assignumis.scan_data_from_name(o["name"])
+        assert d["bc"] is not None and (o["flag"], o["cigar"], o["seq"]) == (rows[i][2], rows[i][3], "C" * rows[i][4])
+        a = {}
+        for t, ty, v in _parse_aux(o["aux"]):
+            assert t not in a
+            a[t] = (ty, v)
+        assert a["NM"] == ("C", 2) and a["tp"] == ("A", b"P")
+        assert a["BC"] == ("Z", d["bc"]["seq"]) == a["BU"] == a["BZ"] and a["AE"][1] == d["ae"] and a["PS"][1] == d["ps"] and a["PE"][1] == d["pe"]
+        assert a["BB"] == ("Z", str(d["bc"]["start"])) == a["BV"] and a["BF"] == ("Z", str(d["bc"]["end"])) == a["BE"]
+        assert a["B1"][1] == d["bc"]["ed"] == a["BW"][1] and a["B2"] == ("Z", str(d["bc"]["ed_sec"])) and a["SX"] == ("Z", str(d["read_id"]))
+        assert ("RE" in a) == d["reverse"] and ("TE" in a) == (d["tso"] is not None)
+        t = tags[i]
+        w = assignumis.umi_window(d["x"], d["ae"], d["bc"]["end"])
+        own = None if w is None else "".join("AGCT"[{1: 0, 2: 1, 4: 2, 8: 3}[c]] if c != 15 else "N" for c in w[1:13])
+        if t is not None and not t.get("skipped"):
+            n_clustered += 1
+            assert a["U8"] == ("Z", t["U8"]) and a["U7"] == ("Z", t["U7"]) == ("Z", own) and a["UC"] == ("Z", "") and a["U1"] == ("Z", str(t["U1"]))
+            assert ("U2" in a) == (t["U2"] is not None) and "UZ" not in a
+        elif own is not None:
+            n_uz += 1
+            assert a["U8"] == ("Z", own) == a["U7"] and a["UZ"] == ("Z", "") and "UC" not in a
+    assert n_clustered > 60 and n_uz >= 1
+    assert [o["name"] for o in out_umi] == [o["name"] for o in out_bc if tags[by_name[o["name"]]] is not None and not tags[by_name[o["name"]]].get("skipped")]
+    assert sum(1 for nm in names if "_bc=" in nm) == len(out_bc)
+    # -w: read names cut at the first '_' (BamWriters L431-432), everything else unchanged
+    z_w, _, _, _ = assignumis.write_tagged_bams(gpu_ctx, data, truncate_read_name=True)
+    _, _, out_w = bammodel.parse_bam(bammodel.bgzf_decompress(z_w))
+    assert [o["name"] for o in out_w] == [o["name"].split("_")[0] for o in out_bc] and [o["aux"] for o in out_w] == [o["aux"] for o in out_bc]
