@@ -420,6 +420,46 @@ int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *
                            uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream);
 
 /* ================================================================================================================
+ * The per-chunk workers of `scanfastq` as one call each (what a JNI shim calls per FastqFileReader$ReadChunk): host
+ * FASTQ text in, results out; everything between the upload and the download runs on the device through the entry points
+ * above.  Replaces WorkerReadscanner.scan -> Parser.call for the chunk (FJ!nanoporereadscanner/WorkerReadscanner.java:
+ * L186-273, FJ!nanoporereadscanner/analyzers/Parser.java:L132-185), UsedCellBCListGenerator.call in pass 1
+ * (UsedCellBCListGenerator.java:L198-229) and the record loop of the writer thread (FastqWriterThreadPool.java:L300-306).
+ * One call at a time per context (private stream, grow-only device arena).
+ * ================================================================================================================ */
+typedef struct {
+    int32_t max_ed;              /* --bcEditDistance: 0, 1 or 2 */
+    int32_t five_prime;          /* -p */
+    int32_t dont_search_polya;   /* --noPolyARequired (5' only); also switches the chimera splitter off (Parser.java:L176) */
+    int32_t split_chimeras;      /* 1: ChimeraFindernew.findSplitPositions as in pass 2 */
+    int32_t trim_fastq;          /* -u */
+    int32_t want_results;        /* 1: per-record scan / barcode results are returned as well */
+    uint32_t first_read_id;      /* id of the first passed record of this chunk (READCOUNTER + 1) */
+    uint32_t reserved;
+    const uint64_t *rank_keys;   /* used list of pass 1, sorted ascending, or NULL (-g mode): rk= field */
+    const int32_t *rank_values;
+    size_t n_ranks;
+} smi_pass2_config;
+typedef struct {
+    const uint8_t *passed, *failed; /* FASTQ text of the two output files; owned by the context, valid until its next call */
+    size_t passed_bytes, failed_bytes;
+    size_t n_records_in, n_records_out, n_passed; /* out = after the chimera split; next first_read_id = first + n_passed */
+    const smi_scan_result *scan;    /* n_records_out entries when want_results, else NULL */
+    const smi_bc_result *bc;
+    uint32_t fastq_errors;          /* SMI_FQ_* (the call fails when non-zero) */
+    uint32_t reserved;
+} smi_pass2_output;
+/* page-locked host memory for the text handed to the workers (uploads at link speed); freed with smi_host_free */
+int smi_host_alloc(size_t bytes, void **out);
+int smi_host_free(void *p);
+int smi_pass2_default_config(smi_pass2_config *cfg);
+int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, const smi_pass2_config *cfg,
+                              smi_pass2_output *out);
+/* pass 1: adds the chunk's whitelist hits to d_hist (device, one u32 counter per key of the loaded set, mode 1) */
+int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
+                              uint32_t *d_hist, size_t *n_records, uint32_t *fastq_errors);
+
+/* ================================================================================================================
  * BAM ingest of `assignumis` (host): what BamReader (FJ!umifinder/bamreaders/BamReader.java:L82-158)
  * gets from htsjdk's SamReader -- the BGZF container and the BAM record layout (SAM specification 4.1 / 4.2; htsjdk is an
  * un-vendored jar dependency, the formats are restated from the specification).  Nothing here touches the device.

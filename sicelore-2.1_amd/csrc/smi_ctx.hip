@@ -141,6 +141,9 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->block_counts);
     (void)hipFree(ctx->stage_in);
     (void)hipFree(ctx->scan_tmp);
+    (void)hipFree(ctx->arena);
+    (void)hipHostFree(ctx->host_out[0]);
+    (void)hipHostFree(ctx->host_out[1]);
     (void)hipFree(ctx->stage_out);
     for (int k = 0; k < SMI_K_COUNT; k++) {
         if (ctx->kev[k][0]) (void)hipEventDestroy(ctx->kev[k][0]);

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <string>
+#include <vector>
 
 #include "sicelore_mi.h"
 
@@ -74,6 +75,12 @@ struct smi_ctx {
     hipStream_t stream = nullptr;  // private stream of the *_batch entry points
     void *scan_tmp = nullptr;      // scratch of the FASTQ indexer (block counts + hipcub temp storage)
     size_t scan_tmp_bytes = 0;
+    void *arena = nullptr;         // device memory of the chunk workers (smi_worker.hip), grow-only
+    size_t arena_bytes = 0;
+    uint8_t *host_out[2] = {nullptr, nullptr};  // pinned: passed / failed text of the last smi_scanfastq_pass2_chunk
+    size_t host_out_bytes[2] = {0, 0};
+    std::vector<smi_scan_result> host_scan;  // its per-record results when asked for
+    std::vector<smi_bc_result> host_bc;
 };
 
 namespace smi {

@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free",
 ]
 
 
@@ -103,6 +103,11 @@ def load_library():
     lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.smi_bgzf_uncompressed_size.argtypes = [vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.smi_bgzf_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ci]
+    lib.smi_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
+    lib.smi_host_free.argtypes = [vp]
+    lib.smi_pass2_default_config.argtypes = [vp]
+    lib.smi_scanfastq_pass2_chunk.argtypes = [vp, vp, sz, vp, vp]
+    lib.smi_scanfastq_pass1_chunk.argtypes = [vp, vp, sz, ci, ci, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32)]
     lib.smi_bgzf_deflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ci, ci, ci]
     lib.smi_gz_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.smi_bam_header.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
@@ -250,6 +255,38 @@ def ref_position_at_read_position_raw(cigar_u32, alignment_start, position):
     if rc < 0:
         raise SmiError(f"smi_ref_position_at_read_position error {rc}: {lib.smi_last_error().decode()}")
     return out.value if rc == 1 else None
+
+
+class PinnedBuffer:
+    """page-locked host bytes (smi_host_alloc) as a numpy uint8 array: .array; free with .close()"""
+
+    def __init__(self, n_bytes):
+        lib = load_library()
+        self._p = ctypes.c_void_p(0)
+        if lib.smi_host_alloc(int(n_bytes), ctypes.byref(self._p)):
+            raise SmiError(lib.smi_last_error().decode())
+        self.array = np.ctypeslib.as_array(ctypes.cast(self._p, ctypes.POINTER(ctypes.c_uint8)), shape=(int(n_bytes),))
+
+    def close(self):
+        if self._p:
+            load_library().smi_host_free(self._p)
+            self._p, self.array = ctypes.c_void_p(0), None
+
+
+class Pass2Config(ctypes.Structure):
+    """smi_pass2_config"""
+    _fields_ = [("max_ed", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("dont_search_polya", ctypes.c_int32),
+                ("split_chimeras", ctypes.c_int32), ("trim_fastq", ctypes.c_int32), ("want_results", ctypes.c_int32),
+                ("first_read_id", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("rank_keys", ctypes.c_void_p),
+                ("rank_values", ctypes.c_void_p), ("n_ranks", ctypes.c_size_t)]
+
+
+class Pass2Output(ctypes.Structure):
+    """smi_pass2_output"""
+    _fields_ = [("passed", ctypes.c_void_p), ("failed", ctypes.c_void_p), ("passed_bytes", ctypes.c_size_t),
+                ("failed_bytes", ctypes.c_size_t), ("n_records_in", ctypes.c_size_t), ("n_records_out", ctypes.c_size_t),
+                ("n_passed", ctypes.c_size_t), ("scan", ctypes.c_void_p), ("bc", ctypes.c_void_p), ("fastq_errors", ctypes.c_uint32),
+                ("reserved", ctypes.c_uint32)]
 
 
 class ChimeraConfig(ctypes.Structure):
@@ -464,6 +501,44 @@ class Context:
         if rc != 0:
             raise SmiError(f"smi_fastq_write_device: {self._lib.smi_last_error().decode()} (error bits {err.value})")
         return int(totals[0]), int(totals[1]), int(totals[2])
+
+    # ---- one native call per chunk (smi_worker.hip) ---------------------------------------------------------
+    def scanfastq_pass2_chunk(self, text, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True, trim_fastq=False,
+                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True):
+        """host FASTQ bytes (or a numpy uint8 array, e.g. PinnedBuffer.array) -> (passed, failed, info dict); everything in
+        between on the device.  copy=False returns numpy views of the context's pinned output buffers (valid until its next call)"""
+        cfg = Pass2Config()
+        self._check(self._lib.smi_pass2_default_config(ctypes.byref(cfg)))
+        cfg.max_ed, cfg.five_prime, cfg.dont_search_polya = int(max_ed), int(five_prime), int(dont_search_polya)
+        cfg.split_chimeras, cfg.trim_fastq, cfg.want_results, cfg.first_read_id = int(split_chimeras), int(trim_fastq), int(want_results), int(first_read_id)
+        keep = []
+        if rank_keys is not None and len(rank_keys):
+            k = np.ascontiguousarray(rank_keys, dtype=np.uint64)
+            v = np.ascontiguousarray(rank_values, dtype=np.int32)
+            keep += [k, v]
+            cfg.rank_keys, cfg.rank_values, cfg.n_ranks = k.ctypes.data, v.ctypes.data, k.size
+        buf = text if isinstance(text, np.ndarray) else np.frombuffer(text, dtype=np.uint8)
+        out = Pass2Output()
+        self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), ctypes.byref(out)))
+        if copy:
+            passed = ctypes.string_at(out.passed, out.passed_bytes) if out.passed_bytes else b""
+            failed = ctypes.string_at(out.failed, out.failed_bytes) if out.failed_bytes else b""
+        else:
+            view = lambda p, n: np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)) if n else np.zeros(0, np.uint8)  # noqa: E731
+            passed, failed = view(out.passed, out.passed_bytes), view(out.failed, out.failed_bytes)
+        info = dict(n_records_in=out.n_records_in, n_records_out=out.n_records_out, n_passed=out.n_passed)
+        if want_results and out.n_records_out:
+            info["scan"] = np.frombuffer(ctypes.string_at(out.scan, out.n_records_out * SCAN_RESULT_DTYPE.itemsize), dtype=SCAN_RESULT_DTYPE)
+            info["bc"] = np.frombuffer(ctypes.string_at(out.bc, out.n_records_out * BC_RESULT_DTYPE.itemsize), dtype=BC_RESULT_DTYPE)
+        return passed, failed, info
+
+    def scanfastq_pass1_chunk(self, text, d_hist, five_prime=False, dont_search_polya=False):
+        """adds the chunk's whitelist hits to d_hist (int32 device tensor, one counter per loaded key) -> n records"""
+        buf = np.frombuffer(text, dtype=np.uint8)
+        n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
+        self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
+                                                        _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
+        return n.value
 
     # ---- chimera splitter ----------------------------------------------------------------------------------
     def chimera_config(self, five_prime=False):

@@ -167,3 +167,42 @@ def test_large_batch_round_trip_properties(pkg, synth, gpu_ctx):
     gc = lambda h: int(h[ord("G")] + h[ord("C")])  # noqa: E731
     assert at(hist_b) == at(h_in) and gc(hist_b) == gc(h_in) and int(hist_b[ord("N")]) == int(h_in[ord("N")])
     assert bool((hist_q == torch.bincount(quals.to(torch.int64), minlength=256)).all())
+
+
+def test_native_chunk_workers_equal_the_chained_entry_points(pkg, synth, sor, gpu_ctx):
+    """smi_scanfastq_pass2_chunk / _pass1_chunk (one native call per chunk, host text in) == the same entry points chained
+    from Python (ReadScanner), which the tests above compare with the oracle"""
+    import torch
+
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    used, reads = _reads(synth, 300, 981)
+    chim = synth.make_chimeras(reads, 380, seed=984)
+    seqs, quals = [c[0] for c in chim] + ["ACGT" * 30], [c[1] for c in chim] + ["5" * 120]
+    keys = np.sort(used.numpy().astype(np.uint64))
+    ranks = (np.arange(keys.size) % 50 + 1).astype(np.int32)
+    text = _fastq(seqs, quals, qh=lambda i: "x" if i % 7 == 0 else "")
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    for kw in (dict(), dict(trim_fastq=True), dict(split_chimeras=False)):
+        rs = scanfastq.ReadScanner(gpu_ctx, max_ed=1, split_chimeras=kw.get("split_chimeras", True))
+        exp_p, exp_f, info = rs.pass2_write_chunk(text, rank_keys=keys, rank_values=ranks, first_read_id=500, trim_fastq=kw.get("trim_fastq", False))
+        got_p, got_f, ginfo = gpu_ctx.scanfastq_pass2_chunk(text, first_read_id=500, rank_keys=keys, rank_values=ranks, want_results=True, **kw)
+        assert got_p == exp_p and got_f == exp_f
+        assert (ginfo["n_records_in"], ginfo["n_records_out"], ginfo["n_passed"]) == (len(seqs), info["n_records"], info["n_passed"])
+        assert ginfo["bc"].tobytes() == info["bc"].tobytes() and ginfo["scan"].tobytes() == info["scan"].tobytes()
+    # a second, smaller chunk on the same context reuses the arena
+    small = _fastq(seqs[:20], quals[:20])
+    a, b, i2 = gpu_ctx.scanfastq_pass2_chunk(small)
+    e_p, e_f, _ = scanfastq.ReadScanner(gpu_ctx, max_ed=1).pass2_write_chunk(small)
+    assert a == e_p and b == e_f and i2["n_records_in"] == 20
+    with pytest.raises(pkg.SmiError):
+        gpu_ctx.scanfastq_pass2_chunk(b"@r1\nACGT\n-\nIIII\n")  # third line must start with '+': FastqReader throws
+    assert gpu_ctx.scanfastq_pass2_chunk(b"")[2]["n_records_in"] == 0
+    # pass 1
+    wl = synth.make_whitelist(30_000, seed=985)
+    wkeys = np.sort(np.unique(np.concatenate([wl.numpy().astype(np.uint64), keys])))
+    gpu_ctx.set_barcode_set(wkeys, mode=1)
+    h1 = torch.zeros(wkeys.size, dtype=torch.int32, device="cuda")
+    h2 = torch.zeros(wkeys.size, dtype=torch.int32, device="cuda")
+    n1 = scanfastq.ReadScanner(gpu_ctx).pass1_chunk(text, h1)
+    n2 = gpu_ctx.scanfastq_pass1_chunk(text, h2)
+    assert n1 == n2 == len(seqs) and bool((h1 == h2).all()) and int(h1.sum()) > 30

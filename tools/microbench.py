@@ -136,6 +136,8 @@ def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
 
 
 def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
+    from sicelore_amd import lib as libmod
+
     # ---- K-FQ: FASTQ text -> record index -> contiguous reads; text built on the device from synthetic reads -----------
     n = 500_000
     rd = synth.gen_reads(n, used, seed=9, device=dev)
@@ -183,6 +185,23 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
 
     dtw = timed(write)
     wb = state["tot"][0] + state["tot"][1]
+    # ---- the native chunk worker: host FASTQ text -> passed / failed text on the host (PCIe in both directions included) ----
+    pin = libmod.PinnedBuffer(total)
+    pin.array[:] = text.cpu().numpy()
+    ctx.scanfastq_pass2_chunk(pin.array, copy=False)  # warm-up: arena and pinned output buffers of this size
+    t0 = time.perf_counter()
+    pp, ff, inf = ctx.scanfastq_pass2_chunk(pin.array, copy=False)
+    dth = time.perf_counter() - t0
+    n_out_bytes = int(pp.size + ff.size)
+    t0 = time.perf_counter()
+    ctx.scanfastq_pass2_chunk(pin.array.copy(), copy=False)  # the same from pageable memory
+    dtp = time.perf_counter() - t0
+    pin.close()
+    res["pass2_chunk_host_to_host"] = {"reads": n, "text_in_bytes": total, "text_out_bytes": n_out_bytes,
+                                       "records_out": inf["n_records_out"], "ms": dth * 1e3, "reads_per_s": n / dth,
+                                       "pageable_input_ms": dtp * 1e3,
+                                       "note": "one smi_scanfastq_pass2_chunk call: H2D of the text (page-locked buffer from smi_host_alloc), "
+                                               "every kernel incl. the chimera splitter, D2H of both streams into the context's pinned buffers"}
     res["fastq_write"] = {"reads": n, "passed": state["tot"][2], "out_bytes": wb, "ms": dtw * 1e3, "out_GBps": wb / dtw / 1e9,
                           "reads_per_s": n / dtw}
 
