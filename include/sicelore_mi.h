@@ -459,6 +459,39 @@ int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes,
 int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
                               uint32_t *d_hist, size_t *n_records, uint32_t *fastq_errors);
 
+/* `assignumis` for one chunk of BamReader (the records between two cuts of BamReader.run): OneBatchExecutor.call +
+ * UmiClustering.cluster after ReadGrouper.groupSams (FJ!umifinder/OneBatchExecutor.java:L61-90,
+ * FJ!umifinder/analyzers/clustering/UmiClustering.java:L97-161, FJ!umifinder/bamreaders/ReadGrouper.java:L82-230), 3'
+ * barcoding: names parsed as FastqRecordExt.getScanDatFromReadName does, clustering position, region grouping, K-UMI,
+ * clustering.  names: the QNAMEs back to back, name i = names[name_off[i] .. name_off[i+1]); cigars: BAM-encoded ops of
+ * all records, record i = cigars[cigar_off[i] .. cigar_off[i+1]); flags / pos0 as in the BAM record.  out[i] for the first
+ * *n_done records is final; the others must be handed in again at the front of the next chunk (keep_data_end). */
+typedef struct {
+    int32_t max_dist;          /* max_GenomeDistance_forGrouping (500) */
+    int32_t grouping_distance; /* distanceFromReadEndForGrouping (100) */
+    int32_t bc_edit_limit;     /* -b: barcodes with a larger ed are ignored (FastqRecordExt.java:L450-456); -1 = no limit */
+    int32_t keep_data_end;     /* 1: more records of this chromosome follow (ReadGrouper.java:L171-184) */
+    int32_t n_threads;         /* host threads of the clustering */
+    int32_t reserved;
+    const smi_umi_cluster_config *cluster; /* NULL: shipped values */
+} smi_assignumis_config;
+#define SMI_UMI_HAS_BC 1u    /* the name carries a barcode (the record goes to the output BAM) */
+#define SMI_UMI_HAS_U7 2u    /* u7 valid: the read's own 12 bases behind the barcode */
+#define SMI_UMI_CLUSTERED 4u /* u8 / u1 / u2 / center valid: UMI from clustering (tags U8 U7 UC U1 [U2]) */
+#define SMI_UMI_SKIPPED 8u   /* UMI_CLUSTERING_SKIPPED_HIGHCOMPLEXITY | DONT_ASSIGN_UMI: no U8 at all */
+typedef struct {
+    int32_t region;  /* ordinal of the genomic region within the chunk, -1 none */
+    int32_t center;  /* chunk index of the read whose UMI was taken, -1 */
+    int8_t u1, u2;   /* tags U1 / U2 (-1: absent) */
+    uint8_t flags;   /* SMI_UMI_* */
+    uint8_t reserved;
+    char u8[12], u7[12];
+} smi_umi_tag;
+int smi_assignumis_default_config(smi_assignumis_config *cfg);
+int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint32_t *name_off, const uint16_t *flags, const int32_t *pos0,
+                         const uint32_t *cigars, const uint32_t *cigar_off, int32_t n, const smi_assignumis_config *cfg,
+                         smi_umi_tag *out, int32_t *n_done);
+
 /* ================================================================================================================
  * BAM ingest of `assignumis` (host): what BamReader (FJ!umifinder/bamreaders/BamReader.java:L82-158)
  * gets from htsjdk's SamReader -- the BGZF container and the BAM record layout (SAM specification 4.1 / 4.2; htsjdk is an

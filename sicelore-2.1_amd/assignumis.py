@@ -170,13 +170,15 @@ def clustering_position(bam, rec, scan, grouping_distance=100):
     return _lib.ref_position_at_read_position_raw(cigar, int(rec["pos"]) + 1, scan["ps"] - grouping_distance)
 
 
-def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=None, cluster_cfg=None, n_threads=4):
+def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=None, cluster_cfg=None, n_threads=4, native=False):
     """`assignumis` over a whole BAM -> (names, tags): tags[i] as assign_umis returns them, in BAM order.  Chunks as
     BamReader.run cuts them: `chunk_size` records or the end of a chromosome; within a chromosome the regions near the
     right edge are carried into the next chunk (ReadGrouper.groupSams keepDataEnd, smi_region_group)."""
     _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
     n = recs.size
     names = [read_name(bam, r) for r in recs]
+    if native:
+        return names, _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads)
     scans = [scan_data_from_name(nm, bc_edit_limit) for nm in names]
     pos = [clustering_position(bam, recs[i], scans[i]) for i in range(n)]
     rev = [bool(int(r["flag"]) & 16) for r in recs]
@@ -193,13 +195,21 @@ def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=N
         done = cur[:n_done]
         res = _assign_in_regions(ctx, [info[i] for i in done], region[:n_done], cluster_cfg, n_threads)
         for i, t in zip(done, res):
-            if t is not None:
+            if t is not None and not t.get("skipped"):
                 t["center"] = done[t["center"]]
                 t["region"] += region_base
             tags[i] = t
         region_base += (max(region[:n_done]) + 1) if n_done and max(region[:n_done]) >= 0 else 0
         return cur[n_done:]
 
+    _run_chunks(recs, chunk_size, flush)
+    return names, tags
+
+
+def _run_chunks(recs, chunk_size, flush):
+    """BamReader.run L106-147: a chunk ends after chunk_size records or with the chromosome; flush(cur, keep) returns the records
+    ReadGrouper holds back for the next chunk"""
+    n = recs.size
     cur, counter, chrom = [], 0, None
     for i in range(n):
         ref = int(recs[i]["ref_id"])
@@ -216,7 +226,32 @@ def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=N
         cur.append(i)
     while cur:
         cur = flush(cur, keep=False)
-    return names, tags
+
+
+def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads):
+    """the same through smi_assignumis_chunk: one native call per chunk (name parsing, positions, grouping, K-UMI, clustering)"""
+    tags = [None] * recs.size
+    cig = [bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4") for r in recs]
+    region_base = 0
+
+    def flush(cur, keep):
+        nonlocal region_base
+        out, n_done = ctx.assignumis_chunk([names[i] for i in cur], recs["flag"][cur], recs["pos"][cur], [cig[i] for i in cur],
+                                           keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads)
+        top = -1
+        for k in range(n_done):
+            t, i = out[k], cur[k]
+            top = max(top, int(t["region"]))
+            if t["flags"] & _lib.UMI_CLUSTERED:
+                tags[i] = dict(U8=t["u8"].decode(), U7=t["u7"].decode(), U1=int(t["u1"]), U2=None if t["u2"] < 0 else int(t["u2"]),
+                               region=int(t["region"]) + region_base, center=cur[int(t["center"])])
+            elif t["flags"] & _lib.UMI_SKIPPED:
+                tags[i] = dict(skipped=True)
+        region_base += top + 1
+        return cur[n_done:]
+
+    _run_chunks(recs, chunk_size, flush)
+    return tags
 
 
 # ---- BAM tags (ReadScanResult.writeSamFlags / writeBCSamFlags, ClusterOneBase.setSamflagsAndStatsForClustered,

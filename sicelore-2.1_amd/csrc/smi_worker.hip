@@ -8,7 +8,10 @@
 // same entry points the parity tests exercise one by one (include/sicelore_mi.h).  Device memory comes from a grow-only
 // arena owned by the context, so steady-state chunks allocate nothing.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "smi_internal.h"
@@ -299,5 +302,264 @@ extern "C" int smi_host_alloc(size_t bytes, void **out) {
 
 extern "C" int smi_host_free(void *p) {
     if (p) SMI_HIP(hipHostFree(p));
+    return SMI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// `assignumis`, one chunk of BamReader (records of one chromosome stretch): what OneBatchExecutor.call + UmiClustering.cluster do
+// with it (FJ!umifinder/OneBatchExecutor.java:L61-90, FJ!umifinder/analyzers/clustering/UmiClustering.java:L97-161) after
+// ReadGrouper.groupSams (FJ!umifinder/bamreaders/ReadGrouper.java:L82-230): parse the read names, clustering position, region
+// grouping, (cell barcode, region) groups in first-member order with members in input order, 14-base windows, K-UMI on the
+// device, clustering on host threads, the values behind U8 / U7 / U1 / U2 per record.  3' barcoding.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+
+// FastqRecordExt.lambda$getScanDatFromReadName$4 (L397-408): text behind the first `tag` up to the next '_'
+bool extract(const char *sub, size_t n, const char *tag, const char **val, size_t *len) {
+    const size_t tl = std::strlen(tag);
+    if (n < tl) return false;
+    for (size_t i = 0; i + tl <= n; i++)
+        if (std::memcmp(sub + i, tag, tl) == 0) {
+            size_t a = i + tl, b = a;
+            while (b < n && sub[b] != '_') b++;
+            *val = sub + a;
+            *len = b - a;
+            return true;
+        }
+    return false;
+}
+
+bool to_int(const char *v, size_t n, long *out) {  // Integer.parseInt
+    if (n == 0 || n > 11) return false;
+    char buf[16];
+    std::memcpy(buf, v, n);
+    buf[n] = 0;
+    char *end = nullptr;
+    const long x = std::strtol(buf, &end, 10);
+    if (end != buf + n) return false;
+    *out = x;
+    return true;
+}
+
+struct NameData {
+    bool present = false, has_bc = false;
+    long ae = 0, ps = 0, bc_end = 0;
+    bool has_ps = false, has_bc_end = false;
+    const char *bc = nullptr, *x = nullptr;
+    size_t bc_len = 0, x_len = 0;
+    float q = 0.0f;
+    bool has_q = false;
+};
+
+// FastqRecordExt.getScanDatFromReadName (L395-496), the fields this step needs; returns SMI_ERR_INVALID where the reference
+// throws AdapterInfoNotFoundInReadException / NumberFormatException
+int parse_name(const char *name, size_t n, int bc_edit_limit, NameData &d) {
+    d = NameData();
+    const char *mark = nullptr;
+    for (size_t i = 0; i + 5 <= n && !mark; i++)
+        if (std::memcmp(name + i, "_REV_", 5) == 0) mark = name + i;
+    if (!mark)
+        for (size_t i = 0; i + 5 <= n && !mark; i++)
+            if (std::memcmp(name + i, "_FWD_", 5) == 0) mark = name + i;
+    if (!mark) return SMI_OK;  // Optional.absent()
+    const char *sub = mark + 4;
+    const size_t sn = (size_t)(name + n - sub);
+    const char *v;
+    size_t l;
+    if (!extract(sub, sn, "AE=", &v, &l) || !to_int(v, l, &d.ae)) {
+        set_error("smi_assignumis_chunk: adapter position (AE=) not found in a read name (AdapterInfoNotFoundInReadException)");
+        return SMI_ERR_INVALID;
+    }
+    d.present = true;
+    if (extract(sub, sn, "PS=", &v, &l)) d.has_ps = to_int(v, l, &d.ps);
+    long ed = 0;
+    if (extract(sub, sn, "ed=", &v, &l) && to_int(v, l, &ed) && (bc_edit_limit < 0 || ed <= bc_edit_limit)) {
+        if (extract(sub, sn, "bc=", &v, &l)) {
+            d.bc = v;
+            d.bc_len = l;
+            d.has_bc = true;
+        }
+        if (extract(sub, sn, "bcEnd=", &v, &l)) d.has_bc_end = to_int(v, l, &d.bc_end);
+    }
+    if (extract(sub, sn, "X=", &v, &l)) {
+        d.x = v;
+        d.x_len = l;
+    }
+    if (extract(sub, sn, "Q=", &v, &l) && l < 30) {
+        char buf[32];
+        size_t k = 0;
+        while (k < l && v[k] != ' ') {
+            buf[k] = v[k];
+            k++;
+        }
+        buf[k] = 0;
+        d.q = std::strtof(buf, nullptr);  // Float.parseFloat
+        d.has_q = k > 0;
+    }
+    return SMI_OK;
+}
+
+inline uint32_t code4(char c) {
+    switch (c) {
+    case 'A': return 1;
+    case 'G': return 2;
+    case 'C': return 4;
+    case 'T': return 8;
+    default: return 15;
+    }
+}
+inline uint32_t comp4(uint32_t c) { return c == 1 ? 8 : c == 8 ? 1 : c == 2 ? 4 : c == 4 ? 2 : 15; }
+inline char dec4(uint32_t c) { return c == 1 ? 'A' : c == 2 ? 'G' : c == 4 ? 'C' : c == 8 ? 'T' : 'N'; }
+
+// the three 12-mers at offsets -1, 0, +1 behind the barcode on the reverse complement of X= (ClusteringEditDistanceBase L297-350,
+// getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378): 14 bases, 4-bit codes, base k in bits [4k+3:4k]
+bool umi_window(const NameData &d, uint64_t *packed) {
+    const long pos = d.ae + 3 - d.bc_end;
+    if (!d.x || pos < 1 || pos + 13 > (long)d.x_len) return false;
+    uint64_t w = 0;
+    for (int k = 0; k < 14; k++) w |= (uint64_t)comp4(code4(d.x[d.x_len - (size_t)(pos + k)])) << (4 * k);
+    *packed = w;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint32_t *name_off, const uint16_t *flags,
+                                    const int32_t *pos0, const uint32_t *cigars, const uint32_t *cigar_off, int32_t n,
+                                    const smi_assignumis_config *cfg, smi_umi_tag *out, int32_t *n_done) {
+    if (!ctx || !names || !name_off || !flags || !pos0 || !cigar_off || !cfg || !out || !n_done || n < 0) {
+        set_error("smi_assignumis_chunk: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *n_done = 0;
+    if (n == 0) return SMI_OK;
+    std::vector<NameData> nd((size_t)n);
+    std::vector<int32_t> cpos((size_t)n, 0);
+    std::vector<uint8_t> has_pos((size_t)n, 0), rev((size_t)n, 0);
+    for (int32_t i = 0; i < n; i++) {
+        SMI_RC(parse_name(names + name_off[i], name_off[i + 1] - name_off[i], cfg->bc_edit_limit, nd[i]));
+        rev[i] = (flags[i] & 16) ? 1 : 0;
+        // NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116), 3': reference position under read
+        // position polyA start - distanceFromReadEndForGrouping
+        if (nd[i].present && nd[i].has_ps && !(flags[i] & 4)) {
+            int32_t p = 0;
+            const int rc = smi_ref_position_at_read_position(cigars + cigar_off[i], (int32_t)(cigar_off[i + 1] - cigar_off[i]), pos0[i] + 1,
+                                                             (int32_t)nd[i].ps - cfg->grouping_distance, &p);
+            if (rc < 0) return rc;
+            if (rc == 1) {
+                has_pos[i] = 1;
+                cpos[i] = p;
+            }
+        }
+    }
+    std::vector<int32_t> region((size_t)n, -1);
+    SMI_RC(smi_region_group(cpos.data(), has_pos.data(), rev.data(), n, cfg->max_dist, cfg->keep_data_end, region.data(), n_done));
+    const int32_t nd_ = *n_done;
+    for (int32_t i = 0; i < n; i++) {
+        smi_umi_tag &t = out[i];
+        std::memset(&t, 0, sizeof t);
+        t.region = i < nd_ ? region[i] : -1;
+        t.center = -1;
+        t.u1 = t.u2 = -1;
+    }
+    // (cell barcode, region) groups in the order their first member appears, members in input order
+    std::unordered_map<std::string, uint32_t> index;
+    std::vector<std::vector<int32_t>> groups;
+    std::vector<uint64_t> win((size_t)n, 0);
+    for (int32_t i = 0; i < nd_; i++) {
+        const NameData &d = nd[i];
+        const bool bc_ok = d.present && d.has_bc && d.has_bc_end && d.x && d.has_q;
+        uint64_t w = 0;
+        const bool has_w = bc_ok && umi_window(d, &w);
+        if (d.present && d.has_bc) out[i].flags |= SMI_UMI_HAS_BC;
+        if (has_w) {
+            win[i] = w;
+            out[i].flags |= SMI_UMI_HAS_U7;
+            for (int k = 0; k < 12; k++) out[i].u7[k] = dec4((uint32_t)(w >> (4 * (k + 1))) & 15u);
+        }
+        if (!has_w || region[i] < 0) continue;
+        std::string key(d.bc, d.bc_len);
+        key += '#';
+        key += std::to_string(region[i]);
+        auto it = index.find(key);
+        if (it == index.end()) {
+            index.emplace(std::move(key), (uint32_t)groups.size());
+            groups.emplace_back(1, i);
+        } else
+            groups[it->second].push_back(i);
+    }
+    std::vector<int32_t> order;
+    std::vector<uint32_t> goff(1, 0);
+    std::vector<uint64_t> poff(1, 0), moff(1, 0);
+    for (const auto &g : groups) {
+        if (g.size() < 2) continue;  // UmiClustering.lambda$cluster$6
+        order.insert(order.end(), g.begin(), g.end());
+        const uint64_t k = g.size();
+        goff.push_back((uint32_t)order.size());
+        poff.push_back(poff.back() + k * (k + 1) / 2);
+        moff.push_back(moff.back() + k * k);
+    }
+    const uint32_t n_groups = (uint32_t)goff.size() - 1;
+    if (n_groups == 0) return SMI_OK;
+    const size_t m = order.size();
+    std::vector<uint64_t> wpk(m);
+    std::vector<float> qv(m);
+    for (size_t j = 0; j < m; j++) {
+        wpk[j] = win[order[j]];
+        qv[j] = nd[order[j]].q;
+    }
+    // ---- K-UMI ------------------------------------------------------------------------------------------------------------
+    SMI_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    SMI_RC(ensure_arena(ctx, pad(m * 8) + pad(goff.size() * 4) + 2 * pad(goff.size() * 8) + pad(moff.back()) + 1024));
+    Arena A(ctx);
+    uint64_t *d_w = A.take<uint64_t>(m);
+    uint32_t *d_go = A.take<uint32_t>(goff.size());
+    uint64_t *d_po = A.take<uint64_t>(goff.size()), *d_mo = A.take<uint64_t>(goff.size());
+    uint8_t *d_dist = A.take<uint8_t>(moff.back());
+    SMI_HIP(hipMemcpyAsync(d_w, wpk.data(), m * 8, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_go, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_po, poff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_mo, moff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
+    SMI_RC(smi_umi_dist_device(ctx, d_w, d_go, d_po, d_mo, n_groups, poff.back(), d_dist, s));
+    std::vector<uint8_t> dist(moff.back());
+    SMI_HIP(hipMemcpyAsync(dist.data(), d_dist, moff.back(), hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    // ---- clustering -------------------------------------------------------------------------------------------------------
+    std::vector<smi_umi_assignment> asg(m);
+    std::vector<uint8_t> skipped(m, 0);
+    smi_umi_cluster_config cc;
+    SMI_RC(smi_umi_cluster_default_config(&cc));
+    if (cfg->cluster) cc = *cfg->cluster;
+    SMI_RC(smi_umi_cluster_groups(dist.data(), moff.data(), goff.data(), n_groups, qv.data(), &cc, asg.data(), skipped.data(),
+                                  cfg->n_threads > 0 ? cfg->n_threads : 1));
+    for (uint32_t g = 0; g < n_groups; g++)
+        for (uint32_t j = goff[g]; j < goff[g + 1]; j++) {
+            smi_umi_tag &t = out[order[j]];
+            if (asg[j].center < 0) {
+                if (skipped[j]) t.flags |= SMI_UMI_SKIPPED;  // UMI_CLUSTERING_SKIPPED_HIGHCOMPLEXITY | DONT_ASSIGN_UMI
+                continue;
+            }
+            const int32_t c = order[goff[g] + (uint32_t)asg[j].center];
+            t.flags |= SMI_UMI_CLUSTERED;
+            t.center = c;
+            t.u1 = asg[j].ed;
+            t.u2 = asg[j].ed_second;
+            const uint64_t cw = win[c];
+            for (int k = 0; k < 12; k++) t.u8[k] = dec4((uint32_t)(cw >> (4 * (k + 1 + asg[j].offset))) & 15u);
+        }
+    return SMI_OK;
+}
+
+extern "C" int smi_assignumis_default_config(smi_assignumis_config *cfg) {
+    if (!cfg) {
+        set_error("smi_assignumis_default_config: null argument");
+        return SMI_ERR_INVALID;
+    }
+    std::memset(cfg, 0, sizeof *cfg);
+    cfg->max_dist = 500;           // max_GenomeDistance_forGrouping
+    cfg->grouping_distance = 100;  // distanceFromReadEndForGrouping
+    cfg->bc_edit_limit = -1;       // -b not given
+    cfg->n_threads = 4;
     return SMI_OK;
 }

@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library():
     lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.smi_bgzf_uncompressed_size.argtypes = [vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.smi_bgzf_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ci]
+    lib.smi_assignumis_default_config.argtypes = [vp]
+    lib.smi_assignumis_chunk.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, ctypes.POINTER(ctypes.c_int32)]
     lib.smi_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
     lib.smi_host_free.argtypes = [vp]
     lib.smi_pass2_default_config.argtypes = [vp]
@@ -255,6 +257,18 @@ def ref_position_at_read_position_raw(cigar_u32, alignment_start, position):
     if rc < 0:
         raise SmiError(f"smi_ref_position_at_read_position error {rc}: {lib.smi_last_error().decode()}")
     return out.value if rc == 1 else None
+
+
+UMI_TAG_DTYPE = np.dtype([("region", "<i4"), ("center", "<i4"), ("u1", "i1"), ("u2", "i1"), ("flags", "u1"), ("reserved", "u1"),
+                          ("u8", "S12"), ("u7", "S12")])
+UMI_HAS_BC, UMI_HAS_U7, UMI_CLUSTERED, UMI_SKIPPED = 1, 2, 4, 8
+
+
+class AssignUmisConfig(ctypes.Structure):
+    """smi_assignumis_config"""
+    _fields_ = [("max_dist", ctypes.c_int32), ("grouping_distance", ctypes.c_int32), ("bc_edit_limit", ctypes.c_int32),
+                ("keep_data_end", ctypes.c_int32), ("n_threads", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("cluster", ctypes.c_void_p)]
 
 
 class PinnedBuffer:
@@ -539,6 +553,30 @@ class Context:
         self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
                                                         _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
         return n.value
+
+    def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4):
+        """one BamReader chunk through the native worker -> (UMI_TAG_DTYPE array, n_done); names: list of QNAME strings,
+        cigars: list of numpy uint32 arrays (BAM encoding)"""
+        n = len(names)
+        enc = [nm.encode() for nm in names]
+        noff = np.zeros(n + 1, dtype=np.uint32)
+        noff[1:] = np.cumsum([len(e) for e in enc])
+        nbuf = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8)
+        coff = np.zeros(n + 1, dtype=np.uint32)
+        coff[1:] = np.cumsum([len(c) for c in cigars])
+        cbuf = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.uint32) for c in cigars] + [np.zeros(1, np.uint32)]))
+        fl = np.ascontiguousarray(flags, dtype=np.uint16)
+        p0 = np.ascontiguousarray(pos0, dtype=np.int32)
+        cfg = AssignUmisConfig()
+        self._check(self._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
+        cfg.max_dist, cfg.keep_data_end, cfg.n_threads = int(max_dist), int(keep_data_end), int(n_threads)
+        cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
+        out = np.zeros(max(n, 1), dtype=UMI_TAG_DTYPE)
+        nd = ctypes.c_int32(0)
+        self._check(self._lib.smi_assignumis_chunk(self._h, nbuf.ctypes.data, noff.ctypes.data, fl.ctypes.data, p0.ctypes.data,
+                                                   cbuf.ctypes.data, coff.ctypes.data, n, ctypes.byref(cfg), out.ctypes.data,
+                                                   ctypes.byref(nd)))
+        return out[:n], nd.value
 
     # ---- chimera splitter ----------------------------------------------------------------------------------
     def chimera_config(self, five_prime=False):

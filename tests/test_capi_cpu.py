@@ -117,3 +117,24 @@ def test_synth_generator_is_seeded(synth):
     assert (a["codes"] == b["codes"]).all() and (a["ae"] == b["ae"]).all()
     w = synth.pack_windows(a["codes"], a["ae"])
     assert w.shape == (1000, 2) and bool(((w[:, 1] >> 32) & 1).all())
+
+
+def test_struct_layouts_of_the_host_side_units(pkg, tmp_path):
+    """records of the BAM index, the UMI tags and the configs of the chunk workers: numpy / ctypes views == the C header"""
+    import ctypes
+
+    from sicelore_amd import lib as libmod
+
+    src = tmp_path / "t2.c"
+    src.write_text("#include <stdio.h>\n#include <stddef.h>\n#include \"sicelore_mi.h\"\nint main(){printf(\"%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n\","
+                   "sizeof(smi_bam_record),offsetof(smi_bam_record,rec_len),offsetof(smi_bam_record,flag),offsetof(smi_bam_record,l_read_name),"
+                   "sizeof(smi_umi_tag),offsetof(smi_umi_tag,flags),offsetof(smi_umi_tag,u7),"
+                   "sizeof(smi_pass2_config),offsetof(smi_pass2_config,rank_keys),sizeof(smi_pass2_output),offsetof(smi_pass2_output,fastq_errors),"
+                   "sizeof(smi_assignumis_config));return 0;}\n")
+    exe = tmp_path / "t2"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    br, ut = libmod.BAM_RECORD_DTYPE, libmod.UMI_TAG_DTYPE
+    assert got == [br.itemsize, br.fields["rec_len"][1], br.fields["flag"][1], br.fields["l_read_name"][1], ut.itemsize,
+                   ut.fields["flags"][1], ut.fields["u7"][1], ctypes.sizeof(libmod.Pass2Config), libmod.Pass2Config.rank_keys.offset,
+                   ctypes.sizeof(libmod.Pass2Output), libmod.Pass2Output.fastq_errors.offset, ctypes.sizeof(libmod.AssignUmisConfig)]

@@ -208,6 +208,10 @@ def test_assignumis_from_bam_chunks_equal_oracle(pkg, synth, sor, gpu_ctx):
 
     names, tags = assignumis.assign_umis_bam(gpu_ctx, data, chunk_size=60)
     assert names == [t[2] for t in rows]
+    # the native chunk worker (smi_assignumis_chunk: name parsing, positions, grouping, K-UMI, clustering in one call)
+    names_n, tags_n = assignumis.assign_umis_bam(gpu_ctx, data, chunk_size=60, native=True)
+    assert names_n == names and tags_n == tags
+    assert assignumis.assign_umis_bam(gpu_ctx, data, chunk_size=10_000, native=True)[1] == assignumis.assign_umis_bam(gpu_ctx, data, chunk_size=10_000)[1]
 
     # ---- the oracle flow over the same chunks -------------------------------------------------------------------------------
     scans = [assignumis.scan_data_from_name(nm) if "_FAILED" not in nm else None for nm in names]
