@@ -206,3 +206,24 @@ def test_native_chunk_workers_equal_the_chained_entry_points(pkg, synth, sor, gp
     n1 = scanfastq.ReadScanner(gpu_ctx).pass1_chunk(text, h1)
     n2 = gpu_ctx.scanfastq_pass1_chunk(text, h2)
     assert n1 == n2 == len(seqs) and bool((h1 == h2).all()) and int(h1.sum()) > 30
+
+
+def test_native_chunk_worker_5p_and_ed2(pkg, synth, sor, gpu_ctx):
+    """the native worker in the other configurations: 5' barcoding without polyA requirement, and ed <= 2 (K-BC2)"""
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    wl = synth.make_whitelist(20_000, seed=991)
+    used = synth.pick_used(wl, 120, seed=992)
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    r5 = synth.gen_reads_5p(150, used, seed=993)
+    text5 = _fastq(*zip(*(synth.materialize(r5, i) for i in range(150))))
+    exp = scanfastq.ReadScanner(gpu_ctx, max_ed=1, five_prime=True, dont_search_polya=True).pass2_write_chunk(text5)
+    got = gpu_ctx.scanfastq_pass2_chunk(text5, five_prime=True, dont_search_polya=True)
+    assert got[0] == exp[0] and got[1] == exp[1] and got[2]["n_passed"] == exp[2]["n_passed"] > 80
+    r3 = synth.gen_reads(200, used, seed=994, err=0.09)
+    text3 = _fastq(*zip(*(synth.materialize(r3, i) for i in range(200))))
+    for ed in (0, 2):
+        exp = scanfastq.ReadScanner(gpu_ctx, max_ed=ed).pass2_write_chunk(text3)
+        got = gpu_ctx.scanfastq_pass2_chunk(text3, max_ed=ed)
+        assert got[0] == exp[0] and got[1] == exp[1]
+    n_bc = {ed: gpu_ctx.scanfastq_pass2_chunk(text3, max_ed=ed)[0].count(b" cellBC=") for ed in (0, 1, 2)}
+    assert n_bc[0] < n_bc[1] < n_bc[2]
