@@ -30,8 +30,7 @@ __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t
     for (; i < n; i += stride) {
         uint32_t k = keys[i];
         atomicOr(&fine[k >> 5], 1u << (k & 31));
-        uint32_t i1 = k >> kG1;
-        atomicOr(&l1[i1 >> 5], 1u << (i1 & 31));
+        atomicOr(&l1[l1_word(k)], 1u << l1_bit(k));
         uint32_t i0 = k >> kG0;
         atomicOr(&l0[i0 >> 5], 1u << (i0 & 31));
         uint32_t is = suffix_index(k);
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
 #pragma unroll
             for (int t = 0; t < 10; t++) w[t] = P.l1[(mut[t] >> (kG1 + 5)) & live[t]];
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> ((mut[t] >> kG1) & 31u)) & 1u);
+            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> l1_bit(mut[t])) & 1u);
             // exact level
 #pragma unroll
             for (int t = 0; t < 10; t++) w[t] = P.fine[(mut[t] >> 5) & live[t]];
@@ -536,7 +535,7 @@ __global__ void k_hist(const uint32_t *__restrict__ keys, const uint8_t *__restr
         if (pass && !pass[i]) continue;
         const uint32_t k = keys[i];
         if (!bit_of(P.l0, k >> kG0)) continue;
-        if (!bit_of(P.l1, k >> kG1)) continue;
+        if (!((P.l1[l1_word(k)] >> l1_bit(k)) & 1u)) continue;
         const uint32_t blk = k >> 8;
         const uint32_t *w = P.fine + (size_t)blk * 8;
         const uint32_t wi = (k >> 5) & 7u;
@@ -574,7 +573,7 @@ __global__ void k_hist_windows(const smi_bc_window *__restrict__ win, const smi_
         if (!ok.usable) continue;  // an N poisons the 5' key: never a whitelist member
         const uint32_t k = ok.key;
         if (!bit_of(P.l0, k >> kG0)) continue;
-        if (!bit_of(P.l1, k >> kG1)) continue;
+        if (!((P.l1[l1_word(k)] >> l1_bit(k)) & 1u)) continue;
         const uint32_t blk = k >> 8;
         const uint32_t *wd = P.fine + (size_t)blk * 8;
         const uint32_t wi = (k >> 5) & 7u;
@@ -653,7 +652,7 @@ __device__ __forceinline__ uint32_t post_base(uint64_t bases, uint32_t nmask, in
 
 __device__ __forceinline__ bool member(const Pyramid &P, uint32_t k) {
     if (!bit_of(P.l0, k >> kG0)) return false;
-    if (!bit_of(P.l1, k >> kG1)) return false;
+    if (!((P.l1[l1_word(k)] >> l1_bit(k)) & 1u)) return false;
     return bit_of(P.fine, k);
 }
 
@@ -926,7 +925,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                                 }
                                 pass = !(ord_seen < (uint32_t)t);
                             }
-                            const bool hit = pass && bit_of(P.l1, m_low[i] >> kG1) && bit_of(P.fine, m_low[i]);
+                            const bool hit = pass && ((P.l1[l1_word(m_low[i])] >> l1_bit(m_low[i])) & 1u) && bit_of(P.fine, m_low[i]);
                             const unsigned long long hm = __ballot(hit);
                             if (hm) {
                                 const int e = (int)ord2e[t];

@@ -22,7 +22,10 @@ int hip_fail(hipError_t e, const char *what);
 // Membership pyramid over the 2^32 universe of 16-mers (A=0 G=1 C=2 T=3, first base most significant).
 //   l0  : 1 bit per 2^G0 consecutive keys  (2^(32-G0) bits = 4 MiB at G0 = 7; the size was chosen by measurement:
 //         a finer top level lets fewer of the 620 mutants through to the levels below)
-//   l1  : 1 bit per 2^G1 consecutive keys  (2^(32-G1) bits)  -- Infinity-Cache resident
+//   l1  : 2^(32-G1) bits, Infinity-Cache resident: word = key >> (G1 + 5) (1024 consecutive keys), bit = a 5-bit hash of the
+//         key's low 10 bits.  A probe that passed the top level has a barcode within 128 keys of it; with one bit per 32
+//         CONSECUTIVE keys that neighbour shared the probe's bit one time in four (27 % of the survivors went on to the
+//         exact level), hashed it does so one time in 32 (5.8 %)
 //   fine: 1 bit per key                    (2^32 bits = 512 MiB, HBM)
 // A probe walks l0 -> l1 -> fine and stops at the first clear bit, so it is exact; consecutive keys share
 // a bit, so the mutants of one window that keep its leading bases hit the same 128-B line.
@@ -42,6 +45,10 @@ constexpr size_t kRankEntries = size_t(1) << 24;
 // Hand-off of LDS data between lanes of ONE wavefront: LDS operations of a wave execute in order, so all that is
 // needed is that the compiler neither reorders memory operations across this point nor leaves them pending.
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// position of a key in l1
+__host__ __device__ inline uint32_t l1_word(uint32_t key) { return key >> (kG1 + 5); }
+__host__ __device__ inline uint32_t l1_bit(uint32_t key) { return (key ^ (key >> 5)) & 31u; }
 
 struct Pyramid {
     const uint32_t *l0;
