@@ -24,7 +24,8 @@ namespace smi {
 __device__ __forceinline__ uint32_t suffix_index(uint32_t k) { return ((k & 0x3FFFu) << (18 - kG0)) | (k >> (14 + kG0)); }
 
 __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ l0,
-                           uint32_t *__restrict__ l0s, uint32_t *__restrict__ l1, uint32_t *__restrict__ fine) {
+                           uint32_t *__restrict__ l0s, uint32_t *__restrict__ l1, uint32_t *__restrict__ fine,
+                           uint32_t *__restrict__ t2) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -35,6 +36,9 @@ __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t
         atomicOr(&l0[i0 >> 5], 1u << (i0 & 31));
         uint32_t is = suffix_index(k);
         atomicOr(&l0s[is >> 5], 1u << (is & 31));
+        atomicOr(&t2[t2_prefix_word(k)], 1u << (k & 31));
+        const uint32_t i2 = t2_twin_index(k);
+        atomicOr(&t2[kL0Words + (((is >> 10) << 5) | (i2 >> 5))], 1u << (i2 & 31));
     }
 }
 
@@ -51,10 +55,11 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     SMI_HIP(hipMemsetAsync(ctx->l0, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l0s, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l1, 0, kL1Words * 4, s));
+    SMI_HIP(hipMemsetAsync(ctx->t2, 0, 2 * kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->fine, 0, kFineWords * 4, s));
     if (n) {
         unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 4096);
-        hipLaunchKernelGGL(k_set_bits, dim3(grid), dim3(256), 0, s, d_keys, n, ctx->l0, ctx->l0s, ctx->l1, ctx->fine);
+        hipLaunchKernelGGL(k_set_bits, dim3(grid), dim3(256), 0, s, d_keys, n, ctx->l0, ctx->l0s, ctx->l1, ctx->fine, ctx->t2);
         SMI_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(k_block_counts, dim3((unsigned)(kRankEntries / 256)), dim3(256), 0, s,
@@ -371,32 +376,102 @@ __device__ __forceinline__ uint32_t mutate2(const LaneMasks &m, uint32_t K, uint
     return v;
 }
 
-// Work split inside a wavefront (64 reads per batch):
-//   phase 1 (lane = read)   : every lane derives the five window keys of ITS read (N handling, reverse complement)
-//   phase 2 (lane = mutant) : for r = 0..63 the keys of read r are broadcast (v_readlane) and the 64 lanes probe the
-//                             124 sequences of each offset; per offset the ballot is folded into one byte
-//                             {exact hit, index+1 of the first level-1 hit} which is written back to lane r
-//   phase 3 (lane = read)   : every lane runs the HashSet-order / best-second rule for ITS read and stores 16 B
-// so only the probes themselves are wave-serial; the scalar unit sees ~10 instructions per offset.
 int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int five_prime, smi_bc_result *d_out,
                      hipStream_t s);
 
+// Lane-constant description of the probe a lane makes in the two rounds of one offset.  The 124 sequences of an offset
+// are dealt to the lanes by KIND, so that a round needs two or three VALU operations per mutant, with the shifted
+// copies of the window coming from the scalar unit:
+//   round A: lanes 0..47 substitutions (position lane / 3, the base XORed with 1 + lane % 3), 48..62 deletions of
+//            position lane - 48, lane 63 the window itself:        mutant = bfi(keep, K, K << 2 | del_base) ^ flip
+//   round B: lanes 0..59 insertions (after position lane / 4, base lane % 4), 60..63 idle:
+//                                                                mutant = (bfi(keep, K, K >> 2) & clear) | put
+// The reference's enumeration index of a hit (what the HashSet rule needs) is recovered afterwards, for hits only.
+struct ProbeLanes {
+    uint32_t keepA, flipA, rotA, rot2A, tabA;  // tab: byte offset of the lane's table inside l0 | l0s (and inside t2)
+    uint32_t keepB, clearB, putB, rotB, rot2B, tabB;
+    uint32_t enumA;  // enumeration index e for deletion lanes; 8 * position for substitution lanes (rank added later)
+    uint32_t enumB;
+    int sA;          // bit offset of the substituted base (substitution lanes)
+    uint32_t subA;   // 1 + lane % 3 for substitution lanes, else 0
+};
+
+__device__ __forceinline__ ProbeLanes make_probe_lanes(int lane) {
+    ProbeLanes L;
+    {  // round A
+        const bool is_sub = lane < 48, is_del = lane >= 48 && lane < 63;
+        const int p = is_sub ? lane / 3 : (is_del ? lane - 48 : 0);
+        const int s = 30 - 2 * p;
+        const uint32_t d = (uint32_t)(lane % 3) + 1u;
+        L.keepA = is_del ? ~lowmask(s + 2) : 0xFFFFFFFFu;
+        L.flipA = is_sub ? d << s : 0u;
+        L.sA = s;
+        L.subA = is_sub ? d : 0u;
+        L.enumA = is_sub ? 8u * p : (is_del ? 8u * p + 7u : 127u);
+        const bool far = make_lane(is_sub ? 8 * p : (is_del ? 8 * p + 7 : 127)).far;
+        L.rotA = far ? 14u + kG0 : (uint32_t)kG0;
+        L.rot2A = far ? 14u : 0u;
+        L.tabA = far ? (uint32_t)(kL0Words * 4) : 0u;
+    }
+    {  // round B
+        const bool is_ins = lane < 60;
+        const int p = lane >> 2;
+        const int s = 30 - 2 * p;  // >= 2 for p <= 14
+        const uint32_t x = (uint32_t)lane & 3u;
+        L.keepB = is_ins ? ~lowmask(s) : 0xFFFFFFFFu;
+        L.clearB = is_ins ? ~(3u << (s - 2)) : 0xFFFFFFFFu;
+        L.putB = is_ins ? x << (s - 2) : 0u;
+        L.enumB = is_ins ? 8u * p + 3u + x : 255u;
+        const bool far = is_ins && make_lane(8 * p + 3).far;
+        L.rotB = far ? 14u + kG0 : (uint32_t)kG0;
+        L.rot2B = far ? 14u : 0u;
+        L.tabB = far ? (uint32_t)(kL0Words * 4) : 0u;
+    }
+    return L;
+}
+
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+
+// smallest enumeration index among the lanes of `hits` (wave-uniform; only reached for windows that have a level-1 hit)
+__device__ __forceinline__ uint32_t min_over(unsigned long long hits, uint32_t e, uint32_t m) {
+    while (hits) {
+        const int l = __builtin_ctzll(hits);
+        m = min(m, (uint32_t)__builtin_amdgcn_readlane(e, l));
+        hits &= hits - 1;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t load_at(const uint32_t *base, uint32_t byte_off) {
+    return *reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+// Work split inside a wavefront (64 reads per batch):
+//   phase 1 (lane = read)   : every lane derives the five window keys of ITS read (N handling, reverse complement)
+//   phase 2 (lane = mutant) : for r = 0..63 the keys of read r are broadcast (v_readlane) and the 64 lanes probe the
+//                             124 sequences of each offset; per offset the hit masks are folded into one byte
+//                             {exact hit, enumeration index + 1 of the first level-1 hit} which goes back to lane r
+//   phase 3 (lane = read)   : every lane runs the HashSet-order / best-second rule for ITS read and stores 16 B
+// Phase 2 is written for instruction count: a probe is a 32-bit byte offset against a uniform table base, a lane that a
+// level has ruled out reads word 0 of the next (offset & mask, mask = the sign-extended bit it just extracted).
+// Levels: top level (l0 | l0s), its second stage (t2: the same line, other key bits), the exact level.
 template <int MAX_ED>
 __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    const LaneMasks mA = make_masks(lane);
-    const LaneMasks mB = make_masks(lane == 63 ? 127 : 64 + lane);
-    // top level: prefix-major index = key >> kG0 = rotr(key, kG0) & mask, suffix-major = rotr(key, 14 + kG0) & mask
-    const uint32_t rotA = mA.far ? 14u + kG0 : (uint32_t)kG0, rotB = mB.far ? 14u + kG0 : (uint32_t)kG0;
-    constexpr uint32_t kTopMask = (1u << (32 - kG0)) - 1u;
+    const ProbeLanes L = make_probe_lanes(lane);
+    constexpr uint32_t kTopOffMask = (uint32_t)(kL0Words * 4 - 4);  // byte offset of a word of one top-level table
+    const unsigned long long exact_lane = 1ull << 63;
+    const unsigned long long lanesA = MAX_ED == 0 ? exact_lane : ~0ull;
+    const unsigned long long lanesB = MAX_ED == 0 ? 0ull : (1ull << 60) - 1ull;
+    const unsigned long long p14B = 0xFull << 56;  // "insert behind position 14": a barcode only when the last base is A
+    const unsigned long long subsA = (1ull << 48) - 1ull;
     const bool fp = five_prime != 0;
     constexpr int OFFS[5] = {0, -1, 1, -2, 2};  // the reference's order (Parser.java:L203)
 
     for (size_t base = wave * 64; base < n; base += n_waves * 64) {
-        // ---- phase 1: coalesced 16-B/lane load, per-lane key derivation ---------------------------------
         smi_bc_window my;
         my.bases = 0;
         my.nmask = 0;
@@ -411,63 +486,61 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
             packed |= k.del_base << (2 * q);
             packed |= (k.usable ? 1u : 0u) << (10 + q);
         }
-        // ---- phase 2: probes, one read at a time ---------------------------------------------------------
         uint32_t sum_lo = 0, sum_hi = 0;
         const int cnt = (int)min((size_t)64, n - base);
         for (int r = 0; r < cnt; r++) {
             const uint32_t pk = __builtin_amdgcn_readlane(packed, r);
             if (!(pk & (1u << 15))) continue;  // wave-uniform
             uint32_t K[5];
-            uint32_t mut[10];
-            uint32_t live[10];  // 0 / 0xFFFFFFFF lane masks: everything below is branch-free VALU
+            uint32_t mut[10], aux[10], live[10], w[10];  // aux: byte offset of the probe's line, then the stage-2 bit index
 #pragma unroll
             for (int q = 0; q < 5; q++) {
                 K[q] = __builtin_amdgcn_readlane(key[q], r);
                 const uint32_t db = (pk >> (2 * q)) & 3u;
-                const uint32_t usable = 0u - ((pk >> (10 + q)) & 1u);
-                mut[2 * q] = mutate2(mA, K[q], db, live[2 * q]);
-                mut[2 * q + 1] = mutate2(mB, K[q], db, live[2 * q + 1]);
-                live[2 * q] &= MAX_ED == 0 ? 0u : usable;
-                live[2 * q + 1] &= MAX_ED == 0 ? (usable & mB.exact) : usable;
-            }
-            // level 0 of the pyramid: 10 independent gathers
-            // (one prefix-ordered table would spread the 124 probes of an offset over ~54 lines; routing the mutants
-            // that change the leading bases to the suffix-major twin leaves 4 lines per offset -- smi_internal.h)
-            uint32_t w[10];
-            const uint32_t *const topA = mA.far ? P.l0s : P.l0;
-            const uint32_t *const topB = mB.far ? P.l0s : P.l0;
-#pragma unroll
-            for (int t = 0; t < 10; t++) {
-                const uint32_t i0 = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? rotB : rotA) & kTopMask;
-                w[t] = ((t & 1) ? topB : topA)[i0 >> 5];
+                mut[2 * q] = bfi(L.keepA, K[q], (K[q] << 2) | db) ^ L.flipA;
+                mut[2 * q + 1] = (bfi(L.keepB, K[q], K[q] >> 2) & L.clearB) | L.putB;
             }
 #pragma unroll
             for (int t = 0; t < 10; t++) {
-                const uint32_t i0 = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? rotB : rotA);
-                live[t] &= 0u - ((w[t] >> (i0 & 31u)) & 1u);
+                const uint32_t rot = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? L.rotB : L.rotA);  // bit index: low 5 bits
+                aux[t] = ((rot >> 3) & kTopOffMask) | ((t & 1) ? L.tabB : L.tabA);
+                w[t] = load_at(P.l0, aux[t]);
+                live[t] = rot;
             }
-            // level 1: lanes that are out read word 0 (one shared line)
 #pragma unroll
-            for (int t = 0; t < 10; t++) w[t] = P.l1[(mut[t] >> (kG1 + 5)) & live[t]];
+            for (int t = 0; t < 10; t++) live[t] = (uint32_t)__builtin_amdgcn_sbfe(w[t], live[t], 1);
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> l1_bit(mut[t])) & 1u);
-            // exact level
+            for (int t = 0; t < 10; t++) {
+                const uint32_t r2 = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? L.rot2B : L.rot2A);  // stage-2 index: low 10 bits
+                w[t] = load_at(P.t2, (((r2 >> 3) & 0x7Cu) | (aux[t] & ~0x7Cu)) & live[t]);
+                aux[t] = r2;
+            }
 #pragma unroll
-            for (int t = 0; t < 10; t++) w[t] = P.fine[(mut[t] >> 5) & live[t]];
+            for (int t = 0; t < 10; t++) live[t] &= (uint32_t)__builtin_amdgcn_sbfe(w[t], aux[t], 1);
 #pragma unroll
-            for (int t = 0; t < 10; t++) live[t] &= 0u - ((w[t] >> (mut[t] & 31u)) & 1u);
+            for (int t = 0; t < 10; t++) w[t] = load_at(P.fine, (mut[t] >> 3) & (live[t] & ~3u));
 
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int q = 0; q < 5; q++) {
-                const unsigned long long ba = __ballot(live[2 * q] != 0u);
-                const unsigned long long bb = __ballot(live[2 * q + 1] != 0u);
-                // first hit in enumeration order = the only level-1 OneMatch the HashSet keeps.  Bit 63 of bb is the
-                // exact probe (lane 63 of round B).
-                const unsigned long long bb1 = bb & 0x7FFFFFFFFFFFFFFFull;
-                const uint32_t ib = (uint32_t)__builtin_ctzll(bb1 | (1ull << 63));  // 63 = none
-                uint32_t code = ba ? (uint32_t)__builtin_ctzll(ba) + 1u : (ib < 63u ? ib + 65u : 0u);
-                code |= (uint32_t)(bb >> 63) << 7;  // exact match (BarcodeMatchTester.java:L204-206)
+                const bool usable = (pk >> (10 + q)) & 1u;
+                const unsigned long long liveA = usable ? lanesA : 0ull;
+                const unsigned long long liveB = usable ? ((K[q] & 3u) ? lanesB & ~p14B : lanesB) : 0ull;
+                const uint32_t fa = live[2 * q] & (uint32_t)__builtin_amdgcn_sbfe(w[2 * q], mut[2 * q], 1);
+                const uint32_t fb = live[2 * q + 1] & (uint32_t)__builtin_amdgcn_sbfe(w[2 * q + 1], mut[2 * q + 1], 1);
+                const unsigned long long ha = __ballot(fa != 0u) & liveA;
+                const unsigned long long hb = __ballot(fb != 0u) & liveB;
+                uint32_t code = (uint32_t)(ha >> 63) << 7;  // exact match (BarcodeMatchTester.java:L204-206)
+                const unsigned long long ha1 = ha & ~exact_lane;
+                if (ha1 | hb) {
+                    // first hit in the reference's enumeration order = the only level-1 OneMatch the HashSet keeps:
+                    // position-major; at one position the substitutions by ascending base (the current base skipped,
+                    // L259-260), then the insertions, then the deletion
+                    const uint32_t cur = (K[q] >> L.sA) & 3u;
+                    const uint32_t b = cur ^ L.subA;
+                    const uint32_t eA = L.enumA + (((ha1 & subsA) >> lane) & 1ull ? b - (b > cur ? 1u : 0u) : 0u);
+                    code |= min_over(hb, L.enumB, min_over(ha1, eA, 255u)) + 1u;
+                }
                 if (q < 4)
                     lo |= code << (8 * q);
                 else
@@ -477,7 +550,6 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
             sum_lo = mine ? lo : sum_lo;
             sum_hi = mine ? hi : sum_hi;
         }
-        // ---- phase 3: per-lane epilogue ------------------------------------------------------------------
         smi_bc_result res;
         uint32_t c_bc[10], c_rs[10];
         int c_imd[10];

@@ -39,6 +39,7 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.l1 = ctx->l1;
     p.fine = ctx->fine;
     p.rank = ctx->rank;
+    p.t2 = ctx->t2;
     return p;
 }
 
@@ -113,9 +114,10 @@ int smi_ctx_create(int device, smi_ctx **out) {
         hipError_t e2 = (call);                           \
         if (e2 != hipSuccess) return fail(hip_fail(e2, #call)); \
     } while (0)
-    SMI_TRY(hipMalloc((void **)&ctx->l0, kL0Words * 4));
-    SMI_TRY(hipMalloc((void **)&ctx->l0s, kL0Words * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->l0, 2 * kL0Words * 4));  // l0 | l0s: one allocation, K-BC1 addresses both from l0
+    ctx->l0s = ctx->l0 + kL0Words;
     SMI_TRY(hipMalloc((void **)&ctx->l1, kL1Words * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->t2, 2 * kL0Words * 4));
     SMI_TRY(hipMalloc((void **)&ctx->fine, kFineWords * 4));
     SMI_TRY(hipMalloc((void **)&ctx->rank, kRankEntries * 4));
     SMI_TRY(hipMalloc((void **)&ctx->block_counts, kRankEntries * 4));
@@ -134,8 +136,8 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->l0);
-    (void)hipFree(ctx->l0s);
     (void)hipFree(ctx->l1);
+    (void)hipFree(ctx->t2);
     (void)hipFree(ctx->fine);
     (void)hipFree(ctx->rank);
     (void)hipFree(ctx->block_counts);

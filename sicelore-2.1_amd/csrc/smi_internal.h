@@ -46,6 +46,13 @@ constexpr size_t kRankEntries = size_t(1) << 24;
 // needed is that the compiler neither reorders memory operations across this point nor leaves them pending.
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// Second stage of the top level (K-BC1): the SAME 128-B line as the key's l0 / l0s bit (prefix line key >> 17, twin line
+// of its last seven bases + first bit), but the bit inside the line is chosen by ten other bits of the key (prefix: the low
+// ten; twin: bits 14..23).  The survivors of the 124 probes of an offset therefore go on to a handful of lines next to the
+// ones they just read, not to 63 unrelated lines of l1.
+__host__ __device__ inline uint32_t t2_prefix_word(uint32_t key) { return ((key >> 17) << 5) | ((key & 1023u) >> 5); }
+__host__ __device__ inline uint32_t t2_twin_index(uint32_t key) { return (key >> 14) & 1023u; }
+
 // position of a key in l1
 __host__ __device__ inline uint32_t l1_word(uint32_t key) { return key >> (kG1 + 5); }
 __host__ __device__ inline uint32_t l1_bit(uint32_t key) { return (key ^ (key >> 5)) & 31u; }
@@ -56,6 +63,7 @@ struct Pyramid {
     const uint32_t *l1;
     const uint32_t *fine;
     const uint32_t *rank;
+    const uint32_t *t2;  // second stage of the top level for K-BC1: [prefix lines | twin lines], same lines as l0 / l0s
 };
 
 }  // namespace smi
@@ -65,6 +73,7 @@ struct smi_ctx {
     uint32_t *l0 = nullptr;
     uint32_t *l0s = nullptr;
     uint32_t *l1 = nullptr;
+    uint32_t *t2 = nullptr;
     uint32_t *fine = nullptr;
     uint32_t *rank = nullptr;
     uint32_t *block_counts = nullptr;  // scratch for the rank scan
