@@ -117,7 +117,7 @@ int smi_ctx_create(int device, smi_ctx **out) {
     SMI_TRY(hipMalloc((void **)&ctx->l0, 2 * kL0Words * 4));  // l0 | l0s: one allocation, K-BC1 addresses both from l0
     ctx->l0s = ctx->l0 + kL0Words;
     SMI_TRY(hipMalloc((void **)&ctx->l1, kL1Words * 4));
-    SMI_TRY(hipMalloc((void **)&ctx->t2, 2 * kL0Words * 4));
+    SMI_TRY(hipMalloc((void **)&ctx->t2, 4 * kL0Words * 4));
     SMI_TRY(hipMalloc((void **)&ctx->fine, kFineWords * 4));
     SMI_TRY(hipMalloc((void **)&ctx->rank, kRankEntries * 4));
     SMI_TRY(hipMalloc((void **)&ctx->block_counts, kRankEntries * 4));

@@ -46,12 +46,13 @@ constexpr size_t kRankEntries = size_t(1) << 24;
 // needed is that the compiler neither reorders memory operations across this point nor leaves them pending.
 __device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// Second stage of the top level (K-BC1): the SAME 128-B line as the key's l0 / l0s bit (prefix line key >> 17, twin line
-// of its last seven bases + first bit), but the bit inside the line is chosen by ten other bits of the key (prefix: the low
-// ten; twin: bits 14..23).  The survivors of the 124 probes of an offset therefore go on to a handful of lines next to the
-// ones they just read, not to 63 unrelated lines of l1.
-__host__ __device__ inline uint32_t t2_prefix_word(uint32_t key) { return ((key >> 17) << 5) | ((key & 1023u) >> 5); }
-__host__ __device__ inline uint32_t t2_twin_index(uint32_t key) { return (key >> 14) & 1023u; }
+// Two-stage top level of K-BC1 (`t2`, 16 MiB): the words of l0 | l0s interleaved with a second word each.  Entry j (8 B) =
+// { word j of l0 | l0s , stage-2 word j }: the stage-2 bit of a key sits at the same word position as its stage-1 bit and is
+// chosen by five OTHER bits of the key (prefix table: the low five, which the 128-key cell ignores; twin: bits 14..18, which
+// the twin drops).  A word position covers 4096 keys = 3.4 barcodes, so a probe that passes stage 1 by chance passes stage 2
+// one time in ten -- the selectivity of a separate level, from the same 8-byte load.
+__host__ __device__ inline uint32_t t2_prefix_bit(uint32_t key) { return key & 31u; }
+__host__ __device__ inline uint32_t t2_twin_bit(uint32_t key) { return (key >> 14) & 31u; }
 
 // position of a key in l1
 __host__ __device__ inline uint32_t l1_word(uint32_t key) { return key >> (kG1 + 5); }
@@ -63,7 +64,7 @@ struct Pyramid {
     const uint32_t *l1;
     const uint32_t *fine;
     const uint32_t *rank;
-    const uint32_t *t2;  // second stage of the top level for K-BC1: [prefix lines | twin lines], same lines as l0 / l0s
+    const uint32_t *t2;  // two-stage top level of K-BC1: entry j = {word j of l0 | l0s, stage-2 word j}
 };
 
 }  // namespace smi
