@@ -802,6 +802,7 @@ __device__ __forceinline__ void pick_best15(const uint32_t (&bc)[15], const uint
     res.ins_minus_del = (int8_t)best_imd;
 }
 
+template <bool kTwoStage>  // dense barcode sets (the whole whitelist): both stages of the top level from t2
 __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
     __shared__ uint32_t s_keys[4][kTabSlots];
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                     // overlap; the (rare) survivors of the top level are then walked in order, which keeps "first hit".
                     constexpr int kGroup = 4;
                     for (int t0 = 0; t0 < n_items && !hit2; t0 += kGroup) {
-                        uint32_t m_low[2 * kGroup], m_ok[2 * kGroup], w0[2 * kGroup];
+                        uint32_t m_low[2 * kGroup], m_ok[2 * kGroup], w0[2 * kGroup], w1[2 * kGroup];
 #pragma unroll
                         for (int g = 0; g < kGroup; g++) {
                             const int t = t0 + g;
@@ -959,14 +960,23 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                                 bool live = x_ok && lv != 0u && qq != pX && m.low != K && !(m.low == X.low && qq > q0);
                                 m_low[2 * g + h] = m.low;
                                 m_ok[2 * g + h] = live ? 1u : 0u;
-                                w0[2 * g + h] = P.l0[live ? (m.low >> (kG0 + 5)) : 0u];
+                                if (kTwoStage) {
+                                    // both stages of the top level from one 8-byte load (t2, prefix-major part): one probe in
+                                    // a hundred instead of one in ten goes on to the dedup table and the lower levels
+                                    const uint2 e2 = reinterpret_cast<const uint2 *>(P.t2)[live ? (m.low >> (kG0 + 5)) : 0u];
+                                    w0[2 * g + h] = e2.x;
+                                    w1[2 * g + h] = e2.y;
+                                } else {  // a used list of a few thousand barcodes: the 4 MiB l0 stays in L2 and lets almost nothing through
+                                    w0[2 * g + h] = P.l0[live ? (m.low >> (kG0 + 5)) : 0u];
+                                    w1[2 * g + h] = 0xFFFFFFFFu;
+                                }
                             }
                         }
                         // top-level test of the whole group first: with a short used list nothing survives it
                         uint32_t any_pass = 0;
 #pragma unroll
                         for (int i = 0; i < 2 * kGroup; i++) {
-                            m_ok[i] &= (w0[i] >> ((m_low[i] >> kG0) & 31u)) & 1u;
+                            m_ok[i] &= (w0[i] >> ((m_low[i] >> kG0) & 31u)) & (w1[i] >> t2_prefix_bit(m_low[i])) & 1u;
                             any_pass |= m_ok[i];
                         }
                         if (!__ballot(any_pass != 0u)) continue;
@@ -1035,7 +1045,11 @@ int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int fiv
     Pyramid P = pyramid_of(ctx);
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
     if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
-    hipLaunchKernelGGL(k_bc_match_ed2, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    // density of the top level: 2^25 cells; from ~1 % occupied cells on the second stage pays for its wider loads
+    if (ctx->n_keys > 300000)
+        hipLaunchKernelGGL(k_bc_match_ed2<true>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else
+        hipLaunchKernelGGL(k_bc_match_ed2<false>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_BC_MATCH, s)) return rc;
     return SMI_OK;
