@@ -210,6 +210,16 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
 int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n,
                             uint32_t *d_hist, void *stream);
 
+/* Pass-2 counters per barcode and edit distance = assignedBarcodes2ndPass[bc].addCountForEd(ed) (Parser.java:L305-311,
+ * Parser$BarcodeCounts L339-354): d_counts[3 * ordinal(bc) + ed] += 1 for every result with found == 1; ordinal = index of the
+ * barcode in the ascending key list of the loaded set (the index smi_hist_device uses), so the vector is dense and is summed
+ * across GPUs with one all-reduce.  d_counts: 3 * n_keys u32, zeroed by the caller before the first batch. */
+int smi_bc_counts_device(smi_ctx *ctx, const smi_bc_result *d_results, size_t n, uint32_t *d_counts, void *stream);
+/* BarcodesAssigned.tsv from those counters (ParseStatsHtmlPrinter.writeAssignedTSV, ParseStatsHtmlPrinter.java:L294-327);
+ * keys ascending as loaded; rows with equal counts by ascending key (the reference: HashMap order).  out == NULL: size only. */
+int smi_assigned_tsv(const uint64_t *keys, const uint32_t *counts, size_t n_keys, int max_ed, char *out, size_t cap,
+                     size_t *n_out);
+
 /* End of pass 1 on the host (no device work): low-count filter, collision merge, low-depth cut and rank of the
  * used-barcode list = UsedCellBCListGenerator$UsedBarcodesListData.finalizeData
  * (FJ!nanoporereadscanner/analyzers/UsedCellBCListGenerator.java:L379-425), BarcodeDatasetColissionTester

@@ -619,6 +619,37 @@ __global__ void k_hist(const uint32_t *__restrict__ keys, const uint8_t *__restr
     }
 }
 
+// K-CNT: assignedBarcodes2ndPass[bc].addCountForEd(ed) (Parser.java:L305-311, Parser$BarcodeCounts L339-354) for a batch of
+// pass-2 results: counts[3 * ordinal(bc) + ed] += 1 for every assigned read.  The assigned barcode is a member of the loaded
+// set, so its ordinal comes straight from rank[] + the popcount inside its 256-key block; the vector is dense and sums across
+// GPUs like the pass-1 histogram.
+__global__ void k_bc_counts(const smi_bc_result *__restrict__ res, size_t n, Pyramid P, uint32_t *__restrict__ counts) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const smi_bc_result r = res[i];
+        if (r.found != 1 || r.ed < 0 || r.ed > 2) continue;
+        const uint32_t k = r.bc;
+        const uint32_t blk = k >> 8;
+        const uint32_t *w = P.fine + (size_t)blk * 8;
+        const uint32_t wi = (k >> 5) & 7u;
+        const uint32_t word = w[wi];
+        if (!((word >> (k & 31)) & 1u)) continue;  // cannot happen for a result of this context's matcher
+        uint32_t ord = P.rank[blk] + __popc(word & ((1u << (k & 31)) - 1u));
+        for (uint32_t j = 0; j < wi; j++) ord += __popc(w[j]);
+        atomicAdd(&counts[3 * (size_t)ord + (uint32_t)r.ed], 1u);
+    }
+}
+
+int launch_bc_counts(smi_ctx *ctx, const smi_bc_result *d_res, size_t n, uint32_t *d_counts, hipStream_t s) {
+    if (!n) return SMI_OK;
+    Pyramid P = pyramid_of(ctx);
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_bc_counts, dim3(grid), dim3(256), 0, s, d_res, n, P, d_counts);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
 int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
                 hipStream_t s) {
     if (!n) return SMI_OK;

@@ -290,6 +290,19 @@ int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass,
 }
 
 
+int smi_bc_counts_device(smi_ctx *ctx, const smi_bc_result *d_results, size_t n, uint32_t *d_counts, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_results || !d_counts)) {
+        set_error("smi_bc_counts_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    if (ctx->set_mode < 0) {
+        set_error("smi_bc_counts_device: no barcode set loaded");
+        return SMI_ERR_STATE;
+    }
+    return launch_bc_counts(ctx, d_results, n, d_counts, (hipStream_t)stream);
+}
+
 int smi_scan_default_config(int pass, smi_scan_config *cfg) {
     if (!cfg || (pass != 1 && pass != 2)) {
         set_error("smi_scan_default_config: bad argument");

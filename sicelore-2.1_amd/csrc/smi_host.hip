@@ -267,3 +267,57 @@ extern "C" int smi_chimera_fragment_name(const char *read_name, const smi_chimer
     std::memcpy(out, name.c_str(), name.size() + 1);
     return (int)name.size();
 }
+
+// BarcodesAssigned.tsv (ParseStatsHtmlPrinter.writeAssignedTSV, FJ!nanoporereadscanner/stats/ParseStatsHtmlPrinter.java:
+// L294-327): header `Barcode\tn Reads with ED<=k match\tED=0 .. \tED=k`, one row per barcode that was assigned at least
+// once, sorted by its read count, descending; numbers through DecimalFormat("###,###,###,###") (L52; grouping commas).
+// The reference sorts the entries of a HashMap with a stable sort, so rows with equal counts come out in that map's
+// iteration order, which depends on the insertion history of a run; here they are ordered by ascending barcode key.
+extern "C" int smi_assigned_tsv(const uint64_t *keys, const uint32_t *counts, size_t n_keys, int max_ed, char *out, size_t cap,
+                                size_t *n_out) {
+    if (!n_out || max_ed < 0 || max_ed > 2 || (n_keys && (!keys || !counts))) {
+        set_error("smi_assigned_tsv: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    auto grouped = [](unsigned long long v) {
+        std::string d = std::to_string(v), r;
+        for (size_t i = 0; i < d.size(); i++) {
+            if (i && (d.size() - i) % 3 == 0) r += ',';
+            r += d[i];
+        }
+        return r;
+    };
+    std::vector<size_t> rows;
+    std::vector<unsigned long long> tot(n_keys, 0);
+    for (size_t i = 0; i < n_keys; i++) {
+        tot[i] = (unsigned long long)counts[3 * i] + counts[3 * i + 1] + counts[3 * i + 2];
+        if (tot[i]) rows.push_back(i);
+    }
+    std::stable_sort(rows.begin(), rows.end(), [&](size_t a, size_t b) { return tot[a] != tot[b] ? tot[a] > tot[b] : keys[a] < keys[b]; });
+    std::string text = "Barcode\tn Reads with ED<=" + std::to_string(max_ed) + " match";
+    for (int e = 0; e <= max_ed; e++) text += "\tED=" + std::to_string(e);
+    text += "\n";
+    static const char B[4] = {'A', 'G', 'C', 'T'};
+    for (size_t i : rows) {
+        char bc[17];
+        uint64_t k = keys[i];
+        for (int j = 15; j >= 0; j--) {
+            bc[j] = B[k & 3u];
+            k >>= 2;
+        }
+        bc[16] = 0;
+        text += bc;
+        text += '\t' + grouped(tot[i]);
+        for (int e = 0; e <= max_ed; e++) text += '\t' + (counts[3 * i + e] ? grouped(counts[3 * i + e]) : std::string("0"));
+        text += '\n';
+    }
+    *n_out = text.size();
+    if (out) {
+        if (text.size() > cap) {
+            set_error("smi_assigned_tsv: output buffer too small");
+            return SMI_ERR_INVALID;
+        }
+        std::memcpy(out, text.data(), text.size());
+    }
+    return SMI_OK;
+}

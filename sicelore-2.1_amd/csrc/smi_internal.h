@@ -111,6 +111,7 @@ int launch_extract_windows(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t 
 int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s);
 int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
                 hipStream_t s);
+int launch_bc_counts(smi_ctx *ctx, const smi_bc_result *d_res, size_t n, uint32_t *d_counts, hipStream_t s);
 int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan_result *d_scan, size_t n,
                         uint32_t *d_hist, hipStream_t s);
 int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, const uint8_t *d_qtail,

@@ -54,3 +54,17 @@ def pass1_finalize(hist, sorted_keys, record_count, merge_ed=1, min_count_fold=1
         b = buf.cpu().numpy()
         k, c, r = b[0].astype(np.uint64), b[1].astype(np.uint32), b[2].astype(np.uint32)
     return k, c, r
+
+
+def assigned_counts_tsv(counts, sorted_keys, max_ed=1, group=None):
+    """End of pass 2: sum the per-(barcode, ed) counters of smi_bc_counts_device over the ranks (the second, tiny exchange
+    of SURVEY 8e: `BarcodesAssigned.tsv` counters) and format the file on every rank.  counts: [n_keys, 3] int32/uint32
+    tensor (host or device)."""
+    import torch.distributed as dist
+
+    from . import lib as _lib
+
+    c = counts.to(torch.int32) if counts.dtype != torch.int32 else counts
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(c, op=dist.ReduceOp.SUM, group=group)
+    return _lib.assigned_tsv(sorted_keys, c.cpu().numpy().astype(np.uint32), max_ed=max_ed)

@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv",
 ]
 
 
@@ -103,6 +103,8 @@ def load_library():
     lib.smi_fastq_gather_device.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     lib.smi_bgzf_uncompressed_size.argtypes = [vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.smi_bgzf_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(sz), ci]
+    lib.smi_bc_counts_device.argtypes = [vp, vp, sz, vp, vp]
+    lib.smi_assigned_tsv.argtypes = [vp, vp, sz, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_assignumis_default_config.argtypes = [vp]
     lib.smi_assignumis_chunk.argtypes = [vp, vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, vp, ctypes.POINTER(ctypes.c_int32)]
     lib.smi_host_alloc.argtypes = [sz, ctypes.POINTER(vp)]
@@ -357,6 +359,20 @@ def bgzf_deflate(data, level=5, block_bytes=0xFF00, n_threads=4):
     return out[:n.value]
 
 
+def assigned_tsv(keys, counts, max_ed=1):
+    """BarcodesAssigned.tsv text from the per-(barcode, ed) counters of smi_bc_counts_device (counts: [n_keys, 3] uint32)"""
+    lib = load_library()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    c = np.ascontiguousarray(counts, dtype=np.uint32).reshape(-1)
+    n = ctypes.c_size_t(0)
+    if lib.smi_assigned_tsv(k.ctypes.data, c.ctypes.data, k.size, int(max_ed), None, 0, ctypes.byref(n)):
+        raise SmiError(lib.smi_last_error().decode())
+    out = ctypes.create_string_buffer(n.value + 1)
+    if lib.smi_assigned_tsv(k.ctypes.data, c.ctypes.data, k.size, int(max_ed), out, n.value, ctypes.byref(n)):
+        raise SmiError(lib.smi_last_error().decode())
+    return out.raw[:n.value].decode()
+
+
 def gz_inflate(data):
     """inflated bytes of a (multi-member) gzip stream, numpy uint8 in and out"""
     lib = load_library()
@@ -515,6 +531,10 @@ class Context:
         if rc != 0:
             raise SmiError(f"smi_fastq_write_device: {self._lib.smi_last_error().decode()} (error bits {err.value})")
         return int(totals[0]), int(totals[1]), int(totals[2])
+
+    def bc_counts_device(self, d_results, n, d_counts, stream=None):
+        """K-CNT: d_counts[3 * ordinal(bc) + ed] += 1 for the assigned reads of a batch"""
+        self._check(self._lib.smi_bc_counts_device(self._h, _ptr(d_results), int(n), _ptr(d_counts), _stream_ptr(stream)))
 
     # ---- one native call per chunk (smi_worker.hip) ---------------------------------------------------------
     def scanfastq_pass2_chunk(self, text, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True, trim_fastq=False,

@@ -249,3 +249,38 @@ def test_ed2_dense_and_degenerate(pkg, synth, sor, gpu_ctx):
                                    five_prime=five_prime, n_threads=8)
         _compare(pkg, got, st, exp)
         assert (exp["n_matches"] >= 4).sum() > 100
+
+
+def test_pass2_counters_per_barcode_and_ed(pkg, synth, gpu_ctx):
+    """K-CNT: counts[3 * ordinal(bc) + ed] over the results of a batch == numpy over the same results; accumulates"""
+    import torch
+
+    dev = torch.device("cuda", gpu_ctx.device)
+    wl = synth.make_whitelist(30_000, seed=71, device=dev)
+    used = synth.pick_used(wl, 400, seed=72)
+    keys = np.sort(used.cpu().numpy().astype(np.uint64))
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    n = 50_000
+    rd = synth.gen_reads(n, used, seed=73, device=dev)
+    ends = synth.pack_ends(rd["head"], rd["tail"])
+    lens = (2 * synth.END_BASES + rd["mid_len"]).to(torch.int32)
+    scan = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    win = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    gpu_ctx.scan_device(ends, lens, n, gpu_ctx.scan_config(2), scan, win)
+    counts = torch.zeros((keys.size, 3), dtype=torch.int32, device=dev)
+    exp = np.zeros((keys.size, 3), dtype=np.int64)
+    for ed in (2, 1):
+        res = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+        gpu_ctx.bc_match_device(win, res, n, max_ed=ed)
+        gpu_ctx.bc_counts_device(res, n, counts)
+        r = res.cpu().numpy().view(pkg.BC_RESULT_DTYPE).reshape(-1)
+        ok = r["found"] == 1
+        np.add.at(exp, (np.searchsorted(keys, r["bc"][ok].astype(np.uint64)), r["ed"][ok].astype(np.int64)), 1)
+    got = counts.cpu().numpy()
+    assert (got == exp).all() and exp[:, 0].sum() > 10_000 and exp[:, 1].sum() > 5_000 and exp[:, 2].sum() > 100
+    from sicelore_amd import lib as libmod
+
+    tsv = libmod.assigned_tsv(keys, got.astype(np.uint32), max_ed=2).splitlines()
+    assert tsv[0] == "Barcode\tn Reads with ED<=2 match\tED=0\tED=1\tED=2" and len(tsv) == 1 + int((exp.sum(1) > 0).sum())
+    tot = [int(l.split("\t")[1].replace(",", "")) for l in tsv[1:]]
+    assert tot == sorted(tot, reverse=True) and sum(tot) == exp.sum()

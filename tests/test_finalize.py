@@ -190,3 +190,68 @@ def test_two_rank_histogram_allreduce_and_finalize(pkg, tmp_path):
         r = np.load(tmp_path / f"r{rank}.npy")
         assert k.tolist() == ek.tolist() and c.tolist() == ec.tolist() and r.tolist() == er.tolist()
     assert ek.size > 50
+
+
+def _model_assigned_tsv(keys, counts, max_ed):
+    """ParseStatsHtmlPrinter.writeAssignedTSV (L294-327) in Python; equal counts in ascending key order (canonical)"""
+    rows = [(int(c.sum()), int(k), c) for k, c in zip(keys, counts) if c.sum()]
+    rows.sort(key=lambda t: (-t[0], t[1]))
+    out = ["Barcode\tn Reads with ED<=%d match" % max_ed + "".join("\tED=%d" % e for e in range(max_ed + 1))]
+    for tot, k, c in rows:
+        bc = "".join("AGCT"[(k >> (2 * (15 - j))) & 3] for j in range(16))
+        out.append(bc + "\t" + f"{tot:,}" + "".join("\t" + (f"{int(c[e]):,}" if c[e] else "0") for e in range(max_ed + 1)))
+    return "\n".join(out) + "\n"
+
+
+def test_assigned_tsv_equals_model(pkg):
+    from sicelore_amd import lib as libmod
+
+    rng = np.random.default_rng(3)
+    keys = np.sort(rng.choice(2 ** 32, 400, replace=False).astype(np.uint64))
+    counts = np.zeros((400, 3), dtype=np.uint32)
+    hot = rng.choice(400, 150, replace=False)
+    counts[hot, 0] = rng.integers(0, 3_000_000, 150)
+    counts[hot, 1] = rng.integers(0, 2000, 150)
+    counts[hot[:40], 2] = rng.integers(0, 30, 40)
+    counts[hot[5]] = counts[hot[6]]  # equal totals: ascending key
+    for max_ed in (0, 1, 2):
+        c = counts.copy()
+        c[:, max_ed + 1:] = 0
+        assert libmod.assigned_tsv(keys, c, max_ed) == _model_assigned_tsv(keys, c, max_ed)
+    assert libmod.assigned_tsv(keys[:0], counts[:0], 1) == "Barcode\tn Reads with ED<=1 match\tED=0\tED=1\n"
+    assert "\t1,234,567\t" in libmod.assigned_tsv(keys[:1], np.array([[1234567, 0, 0]], dtype=np.uint32), 1)
+
+
+def _counts_worker(rank, world, port, tmp):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    graft.load_package()
+    import importlib
+
+    dmod = importlib.import_module(graft.PKG_NAME + ".distributed")
+    rng = np.random.default_rng(11)
+    keys = np.sort(rng.choice(2 ** 32, 300, replace=False).astype(np.uint64))
+    total = rng.integers(0, 5000, (300, 3)).astype(np.int64)
+    part0 = np.random.default_rng(12).binomial(total, 0.4)
+    mine = part0 if rank == 0 else total - part0
+    text = dmod.assigned_counts_tsv(torch.from_numpy(mine.astype(np.int32)), keys, max_ed=2)
+    open(os.path.join(tmp, f"tsv{rank}.txt"), "w").write(text)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_assigned_counters(pkg, tmp_path):
+    """world_size 2 over gloo: the pass-2 counters summed over the ranks give the single-process BarcodesAssigned.tsv"""
+    import torch.multiprocessing as mp
+
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_counts_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(11)
+    keys = np.sort(rng.choice(2 ** 32, 300, replace=False).astype(np.uint64))
+    total = rng.integers(0, 5000, (300, 3)).astype(np.uint32)
+    exp = _model_assigned_tsv(keys, total, 2)
+    assert open(tmp_path / "tsv0.txt").read() == exp == open(tmp_path / "tsv1.txt").read()
