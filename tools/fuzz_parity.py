@@ -1,0 +1,86 @@
+"""Seed sweep of the GPU parity checks (run on the GPU box): the same comparisons as tests/ (-m gpu), over many seeds and
+set densities, to look for rare disagreements with the oracle.  usage: python tools/fuzz_parity.py [minutes]
+Prints one line per leg and seed; exits non-zero at the first mismatch."""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as graft  # noqa: E402
+
+COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
+FIELDS = ("bc", "ed", "ed_sec", "offset", "ins_minus_del")
+
+
+def check_bc(pkg, synth, sor, ctx, seed):
+    rng = np.random.default_rng(seed)
+    n_wl = int(rng.choice([2_000, 50_000, 400_000, 3_600_000]))
+    five = bool(seed & 1)
+    max_ed = int(rng.choice([0, 1, 1, 1, 2]))
+    wl = synth.make_whitelist(n_wl, seed=seed)
+    used = synth.pick_used(wl, min(3000, n_wl // 2), seed=seed + 1)
+    search = wl if rng.random() < 0.5 else used
+    n = 4000 if max_ed == 2 else 60_000
+    reg = synth.gen_bc_region(n, used, seed=seed + 2, five_prime=five, n_rate=float(rng.choice([0.0, 0.002, 0.02])))
+    win = synth.pack_windows(reg["codes"], reg["ae"], five)
+    keys = search.numpy().astype(np.uint64)
+    ctx.set_barcode_set(keys, mode=1 if search is wl else 0)
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    ctx.bc_match_device(win.cuda(), d_out, n, max_ed=max_ed, five_prime=five)
+    got = d_out.cpu().numpy().view(pkg.BC_RESULT_DTYPE).reshape(-1)
+    st, exp = sor.assign_batch(sor.BarcodeSet(search.numpy()), reg["codes"].numpy(), reg["ae"].numpy(), max_ed=max_ed, five_prime=five,
+                               n_threads=16)
+    exp_found = np.where(st < 0, st, exp["found"])
+    ok = (got["found"] == exp_found).all()
+    sel = exp_found == 1
+    for f in FIELDS:
+        ok = ok and (got[f][sel].astype(np.int64) == (exp[f][sel].astype(np.int64) & (0xFFFFFFFF if f == "bc" else -1))).all()
+    ok = ok and (got["n_matches"][st >= 0] == exp["n_matches"][st >= 0]).all()
+    return ok, f"bc seed={seed} wl={n_wl} set={'wl' if search is wl else 'used'} ed={max_ed} 5p={five} found={int(sel.sum())}"
+
+
+def check_records(pkg, synth, sor, ctx, seed):
+    import bammodel  # noqa: F401  (tests dir on the path)
+    from test_write_gpu import _fastq, _oracle_records
+
+    rng = np.random.default_rng(seed)
+    wl = synth.make_whitelist(20_000, seed=seed)
+    used = synth.pick_used(wl, 150, seed=seed + 1)
+    reads = synth.gen_reads(160, used, seed=seed + 2, n_rate=float(rng.choice([0.0, 0.003])), err=float(rng.choice([0.03, 0.063, 0.1])))
+    chim = synth.make_chimeras(reads, 200, seed=seed + 3)
+    seqs, quals = [c[0] for c in chim], [c[1] for c in chim]
+    ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    trim = bool(seed & 1)
+    got_p, got_f, info = ctx.scanfastq_pass2_chunk(_fastq(seqs, quals), first_read_id=7 + seed, trim_fastq=trim)
+    exp_p, exp_f, n_p = _oracle_records(sor, sor.BarcodeSet(used.numpy()), seqs, quals, 1, {}, 7 + seed, trim=trim)
+    return got_p == exp_p and got_f == exp_f and info["n_passed"] == n_p, f"records seed={seed} trim={trim} passed={n_p} out={info['n_records_out']}"
+
+
+def main():
+    minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
+    pkg = graft.load_package()
+    synth = importlib.import_module(graft.PKG_NAME + ".synth")
+    sor = graft.load_oracle()
+    sor.build()
+    ctx = pkg.Context(0)
+    t_end = time.time() + 60 * minutes
+    seed, n_ok = 1000, 0
+    while time.time() < t_end:
+        for leg in (check_bc, check_records):
+            ok, msg = leg(pkg, synth, sor, ctx, seed)
+            print(("ok   " if ok else "FAIL ") + msg, flush=True)
+            if not ok:
+                sys.exit(1)
+            n_ok += 1
+        seed += 7
+    print(f"fuzz: {n_ok} legs passed")
+
+
+if __name__ == "__main__":
+    main()
