@@ -109,6 +109,9 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *planes, int tid, cons
             first = pos;
             break;
         }
+        // the entry of a position can only pass when its own base is a T: go straight to the next T
+        const uint32_t rest = x >> 1;
+        pos += rest ? __builtin_ctz(rest) : 30;
     }
     if (first < 0) return false;
     int start = first;
