@@ -91,6 +91,9 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
     };
 #pragma unroll
     for (int R = N; R >= 1; R--) {
+        // every row above contributed one column and at least one step: cb = N - R and t >= N - R while row R is walked, so
+        // the "first 5 columns" / "first 6 steps" bookkeeping is dead code in the lower rows (R is a constant after unrolling)
+        const bool first5 = N - R < 5, first6 = N - R < 6;
         if (c > 0) {
             int tag;
             do {
@@ -105,11 +108,11 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
                     trail++;
                 else
                     trailing = false;
-                if (t < 6 && x) term = false;
+                if (first6 && t < 6 && x) term = false;
                 if (x) {
                     close_run();
                     seen_x = true;
-                    if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+                    if (first5 && cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
                     if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
                 } else {
                     if (run == 0) run_closed = seen_x;
