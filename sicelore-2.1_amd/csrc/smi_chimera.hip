@@ -296,7 +296,7 @@ __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, 
 #pragma unroll
         for (int c = 0; c < kAdLen; c++) col[c] = col_bits(c, lane) & ((1u << kAdLen) - 1u);
         AlnStats st;
-        nw_full<kAdLen>(col, 0, st);
+        nw_full<kAdLen, false, false>(col, 0, st);  // only ne and nmis are read
         ne = st.ne;
         nmis = st.nmis;
     }

@@ -32,7 +32,9 @@ struct AlnStats {
 // (v & ~3) | 2 is the stored cell again.  The tags of a row are shifted into one register (v_alignbit), the rows
 // stay in registers (row loop fully unrolled), so the walk needs no LDS.
 // Walk: rows N..1 unrolled; inside a row only consecutive left moves loop.
-template <int N>
+// kEnds: end5 / endn / term6 are wanted (the adapter fold); kRuns: consec / best_two are wanted (the TSO rules).  The walk
+// keeps only the bookkeeping of the statistics its caller reads.
+template <int N, bool kEnds = true, bool kRuns = true>
 __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, AlnStats &out) {
     constexpr int NLO = N < 16 ? N : 16, NHI = N - NLO;
     static_assert(N <= 32, "two 32-bit move words per row");
@@ -75,7 +77,7 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
     int run = 0, consec = 0, s1 = 0, s2 = 0, n_runs = 0;
     bool seen_x = false, run_closed = false;
     auto close_run = [&]() {
-        if (run > 0 && run_closed) {
+        if (kRuns && run > 0 && run_closed) {
             consec = max(consec, run);
             if (run > 4) {
                 if (n_runs == 0 || run < s1) {
@@ -108,15 +110,17 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
                     trail++;
                 else
                     trailing = false;
-                if (first6 && t < 6 && x) term = false;
+                if (kEnds && first6 && t < 6 && x) term = false;
                 if (x) {
                     close_run();
                     seen_x = true;
-                    if (first5 && cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
-                    if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+                    if (kEnds && first5 && cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+                    if (kEnds && cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
                 } else {
-                    if (run == 0) run_closed = seen_x;
-                    run++;
+                    if (kRuns) {
+                        if (run == 0) run_closed = seen_x;
+                        run++;
+                    }
                 }
                 if (!read_gap) cb++;
                 if (tag != 1) c--;
@@ -135,9 +139,9 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
     for (; r > 0; r--) {  // up moves
         ins++;
         nx++;
-        if (t < 6) term = false;
-        if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
-        if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+        if (kEnds && t < 6) term = false;
+        if (kEnds && cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+        if (kEnds && cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
         trailing = false;
         cb++;
         t++;
@@ -146,9 +150,9 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
         del++;
         nx++;
         if (trailing) trail++;
-        if (t < 6) term = false;
-        if (cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
-        if (cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
+        if (kEnds && t < 6) term = false;
+        if (kEnds && cb < 5) e5 = cb <= 1 ? (float)((double)e5 + 1.2) : __fadd_rn(e5, 1.0f);
+        if (kEnds && cb < n_end) en = cb <= 1 ? (float)((double)en + 1.2) : __fadd_rn(en, 1.0f);
         t++;
     }
     close_run();

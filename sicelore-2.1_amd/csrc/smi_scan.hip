@@ -302,12 +302,12 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                         uint32_t col[AD];
 #pragma unroll
                         for (int c = 0; c < AD; c++) col[c] = match32(planes, owner, P.adapter4[c], pos - 1) & ((1u << AD) - 1u);
-                        nw_full<AD>(col, P.min_3p, st);
+                        nw_full<AD, true, false>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
                     } else {
                         uint32_t col[16];
 #pragma unroll
                         for (int c = 0; c < 16; c++) col[c] = match32(planes, owner, tso4(c), pos - 1) & 0xFFFFu;
-                        nw_full<16>(col, 0, st);
+                        nw_full<16, false, true>(col, 0, st);  // the TSO rules read ne, nmis, ins, del, consec, best_two
                     }
                     uint32_t *o = ent + tid * 5;
                     o[0] = __float_as_uint(st.ne);
