@@ -114,24 +114,37 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *planes, int tid, cons
         pos += rest ? __builtin_ctz(rest) : 30;
     }
     if (first < 0) return false;
+    // From here on the walk stays around the run, so the exact-T bits are read through a 64-bit register window (two
+    // 64-bit plane fetches per refill) instead of two plane fetches per look.
+    int wbase = 0;
+    uint64_t wbits = 0;
+    auto refill = [&](int p) {
+        wbase = p;
+        wbits = get64(planes + 3 * kLdsWords * kBlock, tid, p) & ~get64(planes, tid, p);
+    };
+    auto look = [&](int p, bool backwards) -> uint32_t {  // 32 exact-T bits from position p on
+        if (p < wbase || p + 32 > wbase + 64) refill(backwards ? max(p - 31, 0) : p);
+        return (uint32_t)(wbits >> (p - wbase));
+    };
+    refill(first);
     int start = first;
     const int INC[8] = {20, 15, 10, 5, 4, 3, 2, 1};  // L223-230
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const int inc = INC[k];
-        while (start + inc < P.window && __popc((get32_t(planes, tid, start + inc) >> 1) & wmask) >= P.thr_adv) start += inc;
+        while (start + inc < P.window && __popc((look(start + inc, false) >> 1) & wmask) >= P.thr_adv) start += inc;
     }
     int endpos = start + ML - 1;  // L231
     // lambda$findpolyAT$3 L122-142: walk back until T at endpos, >=2 T in the last 2, >=3 in 4, >=4 in 5
     while (endpos > 4) {
-        const uint32_t x = get32_t(planes, tid, endpos - 4);  // bit i = base endpos-4+i
+        const uint32_t x = look(endpos - 4, true);  // bit i = base endpos-4+i
         const bool ok = ((x >> 4) & 1u) && __popc((x >> 3) & 3u) >= 2 && __popc((x >> 1) & 15u) >= 3 && __popc(x & 31u) >= 4;
         if (ok) break;
         endpos--;
     }
-    while (n > endpos + 6 && __popc(get32_t(planes, tid, endpos + 1) & 31u) > 3) endpos += 5;  // L145-147
-    while (n > endpos + 4 && __popc(get32_t(planes, tid, endpos + 1) & 7u) > 1) endpos += 3;   // L156-158
-    while (endpos < n - 1 && (get32_t(planes, tid, endpos + 1) & 1u)) endpos++;                // L171-172
+    while (n > endpos + 6 && __popc(look(endpos + 1, false) & 31u) > 3) endpos += 5;  // L145-147
+    while (n > endpos + 4 && __popc(look(endpos + 1, false) & 7u) > 1) endpos += 3;   // L156-158
+    while (endpos < n - 1 && (look(endpos + 1, false) & 1u)) endpos++;                // L171-172
     begin1 = first + 1;
     end1 = endpos + 1;
     return true;
