@@ -311,15 +311,23 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                         k -= c;
                     }
                     AlnStats st;
+                    // the column masks of the alignment are the four base planes of the read slice, selected per pattern
+                    // base: four window fetches per candidate, not one per pattern base
+                    uint32_t W[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) W[c] = get32(planes + c * kLdsWords * kBlock, owner, pos - 1);
+                    auto col_of = [&](uint32_t a4) -> uint32_t {
+                        return ((a4 & 1u) ? W[0] : 0u) | ((a4 & 2u) ? W[1] : 0u) | ((a4 & 4u) ? W[2] : 0u) | ((a4 & 8u) ? W[3] : 0u);
+                    };
                     if (kind == 0) {
                         uint32_t col[AD];
 #pragma unroll
-                        for (int c = 0; c < AD; c++) col[c] = match32(planes, owner, P.adapter4[c], pos - 1) & ((1u << AD) - 1u);
+                        for (int c = 0; c < AD; c++) col[c] = col_of(P.adapter4[c]) & ((1u << AD) - 1u);
                         nw_full<AD, true, false>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
                     } else {
                         uint32_t col[16];
 #pragma unroll
-                        for (int c = 0; c < 16; c++) col[c] = match32(planes, owner, tso4(c), pos - 1) & 0xFFFFu;
+                        for (int c = 0; c < 16; c++) col[c] = col_of(tso4(c)) & 0xFFFFu;
                         nw_full<16, false, true>(col, 0, st);  // the TSO rules read ne, nmis, ins, del, consec, best_two
                     }
                     uint32_t *o = ent + tid * 5;
