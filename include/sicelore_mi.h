@@ -387,7 +387,8 @@ int smi_chimera_fragment_name(const char *read_name, const smi_chimera_result *r
 /* d_line_start: scratch, cap_lines >= number of lines + 1 (4 * records + 2 is always enough);
  * per record r < *n_records: name = text[name_start .. +name_len) (without '@'), read = text[seq_start .. +seq_len),
  * qualities = text[qual_start .. +seq_len); d_offsets[r] = sum of seq_len before r (cap_records + 1 entries), the
- * `offsets` array of smi_pack_ends_device / smi_pack_reads_device once the reads are gathered.  Synchronises the stream. */
+ * record arrays need cap_records >= *n_records + 1 entries (d_seq_len[n_records] is zeroed for the scan; a text
+ * with cap_records or more records is rejected with SMI_ERR_INVALID); d_offsets is the `offsets` array of smi_pack_ends_device / smi_pack_reads_device once the reads are gathered.  Synchronises the stream. */
 int smi_fastq_index_device(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
                            uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
                            uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records,
@@ -465,7 +466,10 @@ int smi_host_free(void *p);
 int smi_pass2_default_config(smi_pass2_config *cfg);
 int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, const smi_pass2_config *cfg,
                               smi_pass2_output *out);
-/* pass 1: adds the chunk's whitelist hits to d_hist (device, one u32 counter per key of the loaded set, mode 1) */
+/* pass 1: adds the chunk's whitelist hits to d_hist (device, one u32 counter per key of the loaded set, mode 1).
+ * Stream order: the kernels run on the context's own non-blocking stream, which is NOT ordered against the stream the
+ * caller allocated / zero-filled d_hist on: the caller synchronises that stream before the first call (the Python
+ * binding does); contexts sharing one d_hist only ever atomicAdd into it.  Returns after the stream has drained. */
 int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
                               uint32_t *d_hist, size_t *n_records, uint32_t *fastq_errors);
 

@@ -68,19 +68,19 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     SMI_HIP(hipGetLastError());
     size_t tmp_bytes = 0;
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, ctx->block_counts, ctx->rank, (int)kRankEntries, s));
-    void *tmp = nullptr;
-    SMI_HIP(hipMalloc(&tmp, tmp_bytes));
-    hipError_t e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, ctx->block_counts, ctx->rank, (int)kRankEntries, s);
-    if (e != hipSuccess) {
-        (void)hipFree(tmp);
-        return hip_fail(e, "hipcub::DeviceScan::ExclusiveSum");
-    }
+    struct Tmp {  // freed on every path out of this function
+        void *p = nullptr;
+        ~Tmp() {
+            if (p) (void)hipFree(p);
+        }
+    } tmp;
+    SMI_HIP(hipMalloc(&tmp.p, tmp_bytes));
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, ctx->block_counts, ctx->rank, (int)kRankEntries, s));
     // distinct keys = rank[last] + counts[last]
     uint32_t last[2] = {0, 0};
     SMI_HIP(hipMemcpyAsync(&last[0], ctx->rank + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
-    SMI_HIP(hipFree(tmp));
     ctx->n_keys = (size_t)last[0] + last[1];
     return SMI_OK;
 }

@@ -163,13 +163,14 @@ int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint
     uint32_t host_err = 0;
     if (n_lines % 4 != 0) host_err |= SMI_FQ_TRUNCATED;  // htsjdk: "missing ... line" at end of file
     const size_t n_rec = (size_t)(n_lines / 4);
-    if (n_rec > cap_records) {
-        set_error("smi_fastq_index_device: record buffers too small");
+    if (n_rec >= cap_records) {  // the scan below reads d_seq_len[n_rec]: one spare entry is part of the contract
+        set_error("smi_fastq_index_device: record buffers too small (need n_records + 1 entries)");
         return SMI_ERR_INVALID;
     }
     if (n_rec) {
         hipLaunchKernelGGL(k_fq_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, d_text, n_bytes, d_line_start,
                            n_newlines, n_rec, d_name_start, d_name_len, d_seq_start, d_seq_len, d_qual_start, d_err);
+        SMI_HIP(hipMemsetAsync(d_seq_len + n_rec, 0, sizeof(*d_seq_len), s));
         SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_b, d_seq_len, d_offsets, (int)n_rec + 1, s));
     } else
         SMI_HIP(hipMemsetAsync(d_offsets, 0, 8, s));

@@ -133,10 +133,10 @@ def load_library():
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ci, ctypes.c_char_p, sz]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
+    explicit = {"smi_last_error", "smi_version", "smi_read_planes_words"}  # restype set above (char*, size_t)
     for name in EXPORTS:
-        fn = getattr(lib, name)
-        if fn.restype is not ctypes.c_char_p:
-            fn.restype = ci
+        if name not in explicit:
+            getattr(lib, name).restype = ci
     _LIB = lib
     return lib
 
@@ -570,6 +570,10 @@ class Context:
         """adds the chunk's whitelist hits to d_hist (int32 device tensor, one counter per loaded key) -> n records"""
         buf = np.frombuffer(text, dtype=np.uint8)
         n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
+        if hasattr(d_hist, "is_cuda") and d_hist.is_cuda:  # the zero-fill of d_hist ran on torch's stream (sicelore_mi.h)
+            import torch
+
+            torch.cuda.current_stream(d_hist.device).synchronize()
         self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
                                                         _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
         return n.value

@@ -138,3 +138,16 @@ def test_struct_layouts_of_the_host_side_units(pkg, tmp_path):
     assert got == [br.itemsize, br.fields["rec_len"][1], br.fields["flag"][1], br.fields["l_read_name"][1], ut.itemsize,
                    ut.fields["flags"][1], ut.fields["u7"][1], ctypes.sizeof(libmod.Pass2Config), libmod.Pass2Config.rank_keys.offset,
                    ctypes.sizeof(libmod.Pass2Output), libmod.Pass2Output.fastq_errors.offset, ctypes.sizeof(libmod.AssignUmisConfig)]
+
+
+def test_size_t_return_is_not_truncated(built):
+    """smi_read_planes_words returns size_t: 2^36 bases need more words than a C int holds"""
+    from sicelore_amd import lib as libmod
+
+    lib = built.load_library()
+    assert lib.smi_read_planes_words.restype is ctypes.c_size_t
+    small = lib.smi_read_planes_words(3200, 1)
+    assert small == 4 * (3200 // 32 + 5) or small > 0
+    big = lib.smi_read_planes_words(1 << 36, 1)
+    assert big >= (1 << 36) // 8 and big > 2 ** 31
+    assert libmod.EXPORTS.count("smi_read_planes_words") == 1
