@@ -106,6 +106,12 @@ int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offs
 int sor_nw_strings(const char *adapter, const char *read_slice, char *a1, char *dots, char *a2, float *n_errors,
                    int *ins, int *del, int *sub, float *end5);
 
+/* probes for tests/test_ref_exec.py: out9 = {alignment length, hasN3pConsecutiveMatches(6), nMismatchesInAlignment, substitutions,
+ * deletions, insertions, getNconsecutiveMatchesNeedleman, getSumOfBestTwoMatchStretchesNeedleman, getOffsetForReadEnd};
+ * out_f2 = {countErrorsInNeedleman, countIndelsMismatchesEndOfRead(5)}; last_row = bottom row of the score table */
+int sor_nw_stats(const char *adapter, const char *read_slice, int32_t *out9, float *out_f2, int32_t *last_row);
+int sor_kmers4_matching(const char *adapter, const char *read, int pos1);
+
 /* ---- read-name writer (sor_name.c) ---- */
 int sor_format_read_name(const char *read_name, const char *raw_seq, const char *raw_qual, int len,
                          const sor_scan_result *scan, const sor_assign_t *bc, int rank, uint32_t read_id, int five_prime,

@@ -470,3 +470,51 @@ int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offs
     }
     return 0;
 }
+
+/* ---- probes for tests/test_ref_exec.py: every alignment statistic of one (pattern, read slice) pair, and the 4-mer gate,
+ * so that each can be compared with the value the reference's own bytecode produced (tests/golden/ref_exec_nw.json) ---- */
+int sor_nw_stats(const char *adapter, const char *read_slice, int32_t *out9, float *out_f2, int32_t *last_row) {
+    uint8_t s1[NW_MAX], s2[NW_MAX];
+    int n1 = (int)strlen(adapter), n2 = (int)strlen(read_slice);
+    if (n1 > NW_MAX || n2 > NW_MAX) return -1;
+    for (int i = 0; i < n1; i++) s1[i] = (uint8_t)enc4((unsigned char)adapter[i]);
+    for (int i = 0; i < n2; i++) s2[i] = (uint8_t)enc4((unsigned char)read_slice[i]);
+    nw_aln a;
+    nw_align(s1, n1, s2, n2, &SEARCH, &a);
+    nm_counts c = needleman_counts(&a);
+    /* score of the alignment as SequenceAlignment.calcAlignmentScore sums it up is the bottom-right cell for these scores */
+    int sc[NW_MAX + 1][NW_MAX + 1];
+    for (int cc = 0; cc <= n1; cc++) sc[0][cc] = cc * SEARCH.lead2;
+    for (int r = 1; r <= n2; r++) {
+        sc[r][0] = r * SEARCH.lead1;
+        for (int cc = 1; cc <= n1; cc++) {
+            int up = sc[r - 1][cc] + SEARCH.indel, left = sc[r][cc - 1] + SEARCH.indel;
+            int diag = sc[r - 1][cc - 1] + ((s2[r - 1] & s1[cc - 1]) != 0 ? SEARCH.match : SEARCH.mismatch);
+            int m = up > left ? up : left;
+            sc[r][cc] = diag > m ? diag : m;
+        }
+    }
+    if (last_row)
+        for (int cc = 0; cc <= n1; cc++) last_row[cc] = sc[n2][cc];
+    out9[0] = a.len;
+    out9[1] = has_n_3p_consecutive_matches(&a, 6);
+    out9[2] = c.nmis;
+    out9[3] = c.sub;
+    out9[4] = c.del;
+    out9[5] = c.ins;
+    out9[6] = n_consecutive_matches(&a);
+    out9[7] = sum_best_two_stretches(&a);
+    out9[8] = c.ins - c.del;
+    out_f2[0] = count_errors(&a);
+    out_f2[1] = indels_mismatches_end_of_read(&a, 5);
+    return 0;
+}
+
+int sor_kmers4_matching(const char *adapter, const char *read, int pos1) {
+    uint8_t ad[NW_MAX], rd[4096];
+    int n1 = (int)strlen(adapter), n2 = (int)strlen(read);
+    if (n1 > NW_MAX || n2 > 4096) return -1;
+    for (int i = 0; i < n1; i++) ad[i] = (uint8_t)enc4((unsigned char)adapter[i]);
+    for (int i = 0; i < n2; i++) rd[i] = (uint8_t)enc4((unsigned char)read[i]);
+    return kmers4_matching(rd, n2, ad, n1, pos1);
+}

@@ -1,0 +1,197 @@
+"""The oracle against REFERENCE-EXECUTED vectors.
+
+tests/golden/ref_exec_*.json hold inputs and the outputs the reference's own class files produced for them when executed
+by tools/jvm_exec.py (a JVM bytecode interpreter written for this repository; generator: tools/make_ref_exec.py; the jars
+stay under /root/reference and are not needed to run these tests).  This is what pins oracle/ to the reference:
+every section names the class and method that ran and the JDK natives the interpreter supplied meanwhile.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
+        return json.load(f)
+
+
+def section(data, needle):
+    hits = [s for s in data["sections"] if needle in s["reference_method"] or needle in s["title"]]
+    assert len(hits) == 1, (needle, [s["reference_method"] for s in data["sections"]])
+    return hits[0]
+
+
+def s64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def u64(v):
+    return int(v) & 0xFFFFFFFFFFFFFFFF
+
+
+def test_fixture_files_describe_their_provenance():
+    for name in ("twobit", "onebyte", "nw", "lev", "polyat", "bcmatch"):
+        d = load(name)
+        assert "jvm_exec" in d["how"] and d["bytecode_steps"] > 0
+        for s in d["sections"]:
+            assert s["reference_class"].startswith("com/rw/") and s["cases"]
+            assert s["max_tier"] in ("A", "B", "C")
+            # nothing hash-ordered was iterated while these vectors were produced
+            assert not any("hash-iteration" in n["native"] for n in s["natives"])
+
+
+# ---- a-1 / a-2 ------------------------------------------------------------------------------------------------------
+def test_twobit_tables_and_codec(sor):
+    d = load("twobit")
+    tabs = {c["table"]: c["values"] for c in section(d, "<clinit>")["cases"]}
+    # A=0, G=1, C=2, T=3 and the complement table {3,2,1,0} (NucleicAcidTwoBitPerBase.java:L72-87)
+    assert tabs["REVERSE_COMP_ARRAY"] == [3, 2, 1, 0]
+    b2t = tabs["BASE_TO_TWOBIT_ARRAY"]
+    for ch, code in (("A", 0), ("G", 1), ("C", 2), ("T", 3), ("a", 0), ("g", 1), ("c", 2), ("t", 3)):
+        assert b2t[ord(ch)] == code
+    for c in section(d, "getLongHashForSeq")["cases"]:
+        if len(c["seq"]) <= 32:
+            assert u64(sor.encode(c["seq"])) == c["hash"], c["seq"]
+    for c in section(d, "longTwoBitToString")["cases"]:
+        assert sor.decode(s64(c["value"]), c["length"]) == c["string"]
+
+
+def test_twobit_mutate_ops(sor):
+    d = load("twobit")
+    for c in section(d, "getLongHashReplaceByteDeg")["cases"]:
+        assert [u64(x) for x in sor.replace_deg(s64(c["seq"]), c["pos"], c["length"])] == c["out"], c
+    for c in section(d, "getLongHashInsertByteDeg")["cases"]:
+        assert [u64(x) for x in sor.insert_deg(s64(c["seq"]), c["pos"], c["length"])] == c["out"], c
+    for c in section(d, "getLongHashdeleteByte")["cases"]:
+        assert u64(sor.delete_byte(s64(c["seq"]), c["base4"], c["pos"], c["length"])) == c["out"], c
+
+
+def test_twobit_reverse_complement_with_n_poison(sor):
+    for c in section(load("twobit"), "reverseComplement")["cases"]:
+        v = sor.encode(c["seq"])
+        assert u64(v) == c["sequence"], c["seq"]
+        assert u64(sor.revcomp(v, c["length"])) == c["rc_sequence"], c["seq"]
+        assert sor.decode(sor.revcomp(v, c["length"]), c["length"]) == c["rc_string"]
+
+
+# ---- a-3 / a-4 ------------------------------------------------------------------------------------------------------
+def test_fourbit_codec_and_kmer_gate(sor):
+    d = load("onebyte")
+    L = sor.lib()
+    for c in section(d, "getSubSequence")["cases"]:
+        codes = [L.sor_fourbit_encode_char(ord(ch)) for ch in c["seq"]]
+        assert codes == c["codes"], c["seq"]
+        assert [L.sor_fourbit_complement(b) for b in reversed(codes)] == c["rc_codes"]
+        assert codes[c["sub_start1"] - 1:c["sub_start1"] - 1 + c["sub_len"]] == c["sub_codes"]
+        assert codes == c["byte_at"]
+    L.sor_kmers4_matching.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int]
+    n = 0
+    for c in section(d, "nKmersMatching")["cases"]:
+        for k, want in enumerate(c["counts"]):
+            assert L.sor_kmers4_matching(c["adapter"].encode(), c["read"].encode(), c["first_pos1"] + k) == want, (c["adapter"], k)
+            n += 1
+    assert n > 500
+
+
+# ---- a-5 / a-6 ------------------------------------------------------------------------------------------------------
+def _nw_stats(sor, pattern, read_slice):
+    L = sor.lib()
+    L.sor_nw_stats.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    o9, f2, row = np.zeros(9, np.int32), np.zeros(2, np.float32), np.zeros(len(pattern) + 1, np.int32)
+    assert L.sor_nw_stats(pattern.encode(), read_slice.encode(), o9.ctypes.data, f2.ctypes.data, row.ctypes.data) == 0
+    return o9, f2, row
+
+
+def test_needleman_wunsch_alignment_and_statistics(sor):
+    cases = section(load("nw"), "fillInCell")["cases"]
+    assert len(cases) >= 60
+    for c in cases:
+        a1, dots, a2, n_err, ins, dele, sub, end5 = sor.nw_strings(c["pattern"], c["read_slice"])
+        assert [a1, dots, a2] == c["alignment"], c
+        o9, f2, row = _nw_stats(sor, c["pattern"], c["read_slice"])
+        assert row.tolist() == c["score_table_last_row"], c
+        assert np.float32(n_err) == np.float32(c["count_errors"]) == f2[0], c
+        assert int(o9[1]) == c["has_6_3p_matches"], c
+        assert int(o9[2]) == c["nm_nerrors"], c
+        assert [int(o9[3]), int(o9[4]), int(o9[5])] == c["nm_subs_del_ins"], c
+        assert np.float32(end5) == np.float32(c["nm_end_of_read_5"]) == f2[1], c
+        assert int(o9[6]) == c["nm_consecutive"], c
+        assert int(o9[7]) == c["nm_best_two"], c
+
+
+# ---- a-16 (inner) -------------------------------------------------------------------------------------------------------
+def test_limited_levenshtein(sor):
+    n = 0
+    for c in section(load("lev"), "limitedCompare")["cases"]:
+        if isinstance(c["out"], dict):
+            continue  # unequal lengths further apart than the threshold: the reference throws; the path only compares 12-mers
+        assert sor.limited_compare(c["a"], c["b"], c["threshold"]) == c["out"], c
+        n += 1
+    assert n >= 350
+
+
+# ---- a-7 ------------------------------------------------------------------------------------------------------------
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def test_polyt_finder(sor):
+    L = sor.lib()
+    n_found = 0
+    for c in section(load("polyat"), "findpolyAT")["cases"]:
+        read = c["read"]
+        if len(read) < 175:
+            assert all(isinstance(r, dict) and "throws" in r for r in c["forward_and_reverse"])
+            continue
+        fwd = [L.sor_fourbit_encode_char(ord(ch)) for ch in read[:175]]
+        rev = [L.sor_fourbit_encode_char(ord(_COMP[ch])) for ch in reversed(read[-175:])]
+        for codes, want in zip((fwd, rev), c["forward_and_reverse"]):
+            got = sor.find_polyt(np.array(codes, dtype=np.uint8))
+            if want is None:
+                assert got is None, (read, want, got)
+            else:
+                assert got == (want["begin"], want["end"]), (read, want, got)
+                n_found += 1
+    assert n_found >= 40
+
+
+# ---- a-11 -----------------------------------------------------------------------------------------------------------
+def _post_codes(sor, read, bc_start, bc_end, three_p):
+    L = sor.lib()
+    if three_p:  # new NucleicAcidOneBytePerBase(read.substring(bcStart-5, bcStart)).reverseComplement()  (Parser.java:L218)
+        s = read[bc_start - 5:bc_start]
+        return [L.sor_fourbit_complement(L.sor_fourbit_encode_char(ord(ch))) for ch in reversed(s)]
+    return [L.sor_fourbit_encode_char(ord(ch)) for ch in read[bc_end:bc_end + 5]]
+
+
+def test_barcode_match_tester_per_offset(sor):
+    """every (offset, level) hit of BarcodeMatchTester.call(): the set the reference's bytecode built == the oracle's"""
+    s = section(load("bcmatch"), "call:")
+    bset = sor.BarcodeSet(np.array([s64(k) for k in s["barcode_keys"]], dtype=np.int64))
+    n_hits, n_cases = 0, 0
+    for c in s["cases"]:
+        read, ae, ed, three_p = c["read"], c["adapter_pos"], c["ed"], c["three_prime"]
+        for off_s, want in c["matches"].items():
+            off = int(off_s)
+            if three_p:
+                bc_start, bc_end = ae - 16 + off, ae - 1 + off
+            else:
+                bc_start, bc_end = ae + 1 + off, ae + 16 + off
+            win = read[bc_start - 1:bc_end]
+            seq = sor.encode(win)
+            if three_p:
+                seq = sor.revcomp(seq, 16)
+            post = _post_codes(sor, read, bc_start, bc_end, three_p)
+            got, _ = sor.bc_match(bset, seq, ed, post4=post, offset=off)
+            got = sorted(({"read_seq": u64(m["read_seq"]), "bc": u64(m["matching_bc"]), "ed": int(m["ed"]), "subs": int(m["subs"]),
+                           "ins": int(m["ins"]), "dels": int(m["dels"]), "offset": int(m["offset"]),
+                           "offset_for_read_end": int(m["ins"]) - int(m["dels"])} for m in got),
+                         key=lambda r: (r["ed"], r["bc"], r["read_seq"]))
+            assert got == (want or []), (read, ae, ed, three_p, off, want, got)
+            n_hits += len(got)
+            n_cases += 1
+    assert n_cases >= 400 and n_hits >= 100

@@ -1,0 +1,434 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ref_exec_*.json: answers computed BY THE REFERENCE'S OWN BYTECODE.
+
+Build container only: needs /root/reference/Jar/*.jar (never copied, never shipped) and tools/jvm_exec.py, the bytecode
+interpreter written for this purpose (the image has no JVM).  Every fixture file records, per section, the class and
+method that was executed, its inputs and its outputs, and the JDK natives the interpreter had to supply while it ran
+(`natives`, with their tier: A = language level, B = java.lang value classes with specified behaviour, C = ordered
+containers / membership-only sets / ordered sequential streams; see tools/jvm_exec.py).  Hash-ordered iteration is never
+emulated: where a method iterates a HashMap / HashSet the case is run under several different iteration orders and kept
+only if all of them agree (`hash_orders_agree`), otherwise it is listed under `excluded`.
+
+usage: python tools/make_ref_exec.py [section ...]     (default: all sections)
+"""
+import json
+import os
+import random
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from jvm_exec import JVM, JArray, JBox, JObject, JavaThrow, Unsupported, f32  # noqa: E402
+import jvm_natives  # noqa: E402
+
+REF = "/root/reference/Jar/"
+JARS = [REF + "NanoporeBC_UMI_finder-2.1.jar", REF + "lib/TwoFourBitNucAcidLibraryMaven-1.0.jar",
+        REF + "lib/Aliasi_ClusteringLib-1.0.jar", REF + "lib/commons-lang3-3.17.0.jar"]
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+TB = "com/rw/nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase"
+OBI = "com/rw/nuc/encoding/onebyte/NucleicAcidInmutableOneBytePerBase"
+OB = "com/rw/nuc/encoding/onebyte/NucleicAcidOneBytePerBase"
+BCB = "com/rw/nuc/encoding/NucleicAcidByteCodeBase"
+NS = "com/rw/nuc/alignment/needleman/NeedlemanScores"
+NW = "com/rw/nuc/alignment/needleman/NeedlemanWunsch"
+MATCH = "com/rw/nanopore/analyzers/Match"
+NM = "com/rw/nanopore/analyzers/NeedlemanMatch"
+LEV = "com/rw/nanopore/analyzers/apachemod/LevenshteinDistance"
+BMT = "com/rw/nanoporereadscanner/analyzers/BarcodeMatchTester"
+PS = "com/rw/nanopore/analyzers/PolyATSearcher"
+
+
+def u64(v):
+    return v & 0xFFFFFFFFFFFFFFFF
+
+
+class Gen:
+    def __init__(self):
+        self.j = JVM(JARS)
+        self.t0 = time.time()
+
+    def natives(self):
+        used = sorted(self.j.natives_used)
+        return [{"native": k, "tier": jvm_natives.tier_of(k)} for k in used]
+
+    def section(self, title, cls, method):
+        self.j.natives_used.clear()
+        return {"reference_class": cls, "reference_method": method, "title": title, "cases": []}
+
+    def finish(self, sec):
+        sec["natives"] = self.natives()
+        sec["max_tier"] = max([n["tier"] for n in sec["natives"]] or ["A"])
+        return sec
+
+
+def rnd_seq(rng, n, alphabet="ACGT"):
+    return "".join(rng.choice(alphabet) for _ in range(n))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def gen_twobit(g):
+    """a-1 / a-2: NucleicAcidTwoBitPerBase -- <clinit> tables, getLongHashForSeq, mutate ops, reverseComplement"""
+    j = g.j
+    rng = random.Random(101)
+    out = {"jar": "TwoFourBitNucAcidLibraryMaven-1.0.jar", "sections": []}
+    s = g.section("static tables built by <clinit> (L72-136)", TB, "<clinit>")
+    jc = j.init_class(TB)
+    for name, v in sorted(jc.statics.items()):
+        if isinstance(v, JArray):
+            s["cases"].append({"table": name, "values": [[u64(x) for x in r.a] if isinstance(r, JArray) else (u64(r) if v.etype == "J" else r)
+                                                          for r in v.a]})
+    out["sections"].append(g.finish(s))
+
+    s = g.section("getLongHashForSeq(char[]) (L183-187), incl. non-ACGT characters", TB, "getLongHashForSeq:([C)J")
+    seqs = [rnd_seq(rng, 16) for _ in range(40)] + [rnd_seq(rng, n) for n in (1, 2, 8, 12, 15, 17, 24, 31, 32)]
+    seqs += ["ACGTNACGTACGTACG", "NNNNNNNNNNNNNNNN", "acgtacgtacgtacgt", "ACGTACGTACGTACGN", "NCGTACGTACGTACGT", "ACGTRYACGTACGTAC"]
+    for q in seqs:
+        s["cases"].append({"seq": q, "hash": u64(j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q)))})
+    out["sections"].append(g.finish(s))
+
+    s = g.section("longTwoBitToString(long, int) (L337-342)", TB, "longTwoBitToString:(JI)Ljava/lang/String;")
+    for _ in range(20):
+        n = rng.choice([16, 16, 16, 12, 10, 8, 20])
+        v = rng.getrandbits(2 * n)
+        s["cases"].append({"value": v, "length": n, "string": j.call_static(TB, "longTwoBitToString", "(JI)Ljava/lang/String;", v, n)})
+    out["sections"].append(g.finish(s))
+
+    for name, desc, title in (("getLongHashReplaceByteDeg", "(J[JII)V", "substitution variants (L228-233)"),
+                              ("getLongHashInsertByteDeg", "(J[JII)V", "insertion variants (L300-309), incl. pos = length-2 (shift count 64 wraps)")):
+        s = g.section(title, TB, f"{name}:{desc}")
+        for k in range(24):
+            n = 16 if k < 16 else rng.choice([12, 10, 14])
+            v = rng.getrandbits(2 * n)
+            for pos in range(n if "Replace" in name else n - 1):
+                res = j.long_array([0, 0, 0, 0])
+                j.call_static(TB, name, desc, v, res, pos, n)
+                s["cases"].append({"seq": v, "pos": pos, "length": n, "out": [u64(x) for x in res.a]})
+        out["sections"].append(g.finish(s))
+
+    s = g.section("deletion (L321-327): getLongHashdeleteByte(seq, 4-bit code of the appended base, pos, length)", TB, "getLongHashdeleteByte:(JBII)J")
+    for k in range(12):
+        n = 16 if k < 9 else 12
+        v = rng.getrandbits(2 * n)
+        for pos in range(n - 1):
+            for b4 in (1, 2, 4, 8, 15):
+                s["cases"].append({"seq": v, "base4": b4, "pos": pos, "length": n,
+                                   "out": u64(j.call_static(TB, "getLongHashdeleteByte", "(JBII)J", v, b4, pos, n))})
+    out["sections"].append(g.finish(s))
+
+    s = g.section("reverseComplement() (L477-484) on objects built from strings (N poisons the long, L185)", TB, "reverseComplement:()L...;")
+    for q in [rnd_seq(rng, 16) for _ in range(30)] + ["ACGTNACGTACGTACG", "NNNNNNNNNNNNNNNN", "ACGTACGTACGTACGN", "NCGTACGTACGTACGT"] + \
+            [rnd_seq(rng, 16, "ACGTN") for _ in range(10)] + [rnd_seq(rng, n) for n in (8, 10, 12, 14)]:
+        o = j.new(TB, "(Ljava/lang/String;)V", q)
+        r = j.call_virtual(o, "reverseComplement", f"()L{TB};")
+        s["cases"].append({"seq": q, "sequence": u64(o.f["sequence"]), "length": o.f["seqlength"], "rc_sequence": u64(r.f["sequence"]),
+                           "rc_string": j.call_virtual(r, "toString", "()Ljava/lang/String;")})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def gen_onebyte(g):
+    """a-3 / a-4: 4-bit IUPAC codec, reverse complement, sub-sequences, the 4-mer gate"""
+    j = g.j
+    rng = random.Random(202)
+    out = {"jar": "TwoFourBitNucAcidLibraryMaven-1.0.jar", "sections": []}
+    s = g.section("static tables of the byte codec (L41-133)", BCB, "<clinit>")
+    jc = j.init_class(BCB)
+    for name, v in sorted(jc.statics.items()):
+        if isinstance(v, JArray) and v.etype in ("B", "C", "I", "[B"):
+            s["cases"].append({"table": name, "values": [list(r.a) if isinstance(r, JArray) else r for r in v.a]})
+    out["sections"].append(g.finish(s))
+
+    s = g.section("encode / toString / reverseComplement / getSubSequence(start1, len) / getByteAt(1-based)", OBI, "<init>(CharSequence), reverseComplement, getSubSequence, getByteAt")
+    for q in [rnd_seq(rng, n, "ACGTN") for n in (5, 10, 22, 30, 43)] + ["ACGTRYKMSWBDHVN", "acgtn", "AAAAACCCCCGGGGGTTTTT"]:
+        o = j.new(OBI, "(Ljava/lang/CharSequence;)V", q)
+        codes = list(o.f["naData"].a)
+        n = len(q)
+        st, ln = 1 + n // 4, max(1, n // 2)
+        sub = j.call_virtual(o, "getSubSequence", f"(II)L{OBI};", st, ln)
+        byte_at = [j.call_virtual(o, "getByteAt", "(I)B", k) for k in range(1, n + 1)]
+        string = j.call_virtual(o, "toString", "()Ljava/lang/String;")
+        rc_copy = j.call_virtual(o, "reverseComplementCopy", f"()L{OBI};")
+        untouched = list(o.f["naData"].a) == codes
+        rc = j.call_virtual(o, "reverseComplement", f"()L{OBI};")     # works IN PLACE and returns this
+        s["cases"].append({"seq": q, "codes": codes, "string": string, "rc_codes": list(rc_copy.f["naData"].a),
+                           "copy_leaves_original": untouched, "reverse_complement_in_place": rc is o and list(o.f["naData"].a) == list(rc_copy.f["naData"].a),
+                           "sub_start1": st, "sub_len": ln, "sub_codes": list(sub.f["naData"].a), "byte_at": byte_at})
+    out["sections"].append(g.finish(s))
+
+    s = g.section("$Kmers.nKmersMatching(read, pos) with 4-mers (nKmersMatching_4mer L533-543)", OBI + "$Kmers", "nKmersMatching:(L...;I)I")
+    adapters = ["CTTCCGATCT", "CTACACGACGCTCTTCCGATCT", "AAGCAGTGGTATCAAC", "AAGCAGTGGTATCAACGCAGAGTACAT"]
+    for ad in adapters:
+        a = j.new(OBI, "(Ljava/lang/CharSequence;)V", ad)
+        k = j.new(OBI + "$Kmers", f"(L{OBI};I)V", a, 4)
+        for t in range(6):
+            # a read with a noisy copy of the adapter somewhere inside
+            noisy = "".join(c if rng.random() > 0.12 else rng.choice("ACGTN") for c in ad)
+            pre = rnd_seq(rng, rng.randrange(3, 12))
+            read = pre + noisy + rnd_seq(rng, 14 + len(ad))
+            r = j.new(OBI, "(Ljava/lang/CharSequence;)V", read)
+            counts = [j.call_virtual(k, "nKmersMatching", f"(L{OBI};I)I", r, p) for p in range(1, len(read) - len(ad) + 1)]
+            s["cases"].append({"adapter": ad, "read": read, "first_pos1": 1, "counts": counts})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def nw_align(j, adapter, read_slice, scores=(-4, -5, -5, -5, -5, -5, 5)):
+    a = j.new(OBI, "(Ljava/lang/CharSequence;)V", adapter)
+    b = j.new(OBI, "(Ljava/lang/CharSequence;)V", read_slice)
+    sc = j.new(NS, "(IIIIIII)V", *scores)
+    nw = j.new(NW, f"(L{OBI};L{OBI};L{NS};)V", a, b, sc)
+    strs = j.call_virtual(nw, "getAlignmentString", "()[Ljava/lang/String;")
+    return nw, list(strs.a), j.call_virtual(nw, "getAlignmentScore", "()I")
+
+
+def gen_nw(g):
+    """a-5 / a-6: Needleman-Wunsch with the scores of NeedlemanParameters$OneSet, alignment strings, error metrics"""
+    j = g.j
+    rng = random.Random(303)
+    out = {"jar": "TwoFourBitNucAcidLibraryMaven-1.0.jar + NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("NeedlemanWunsch(seq1 = pattern, seq2 = read slice, NeedlemanScores(-4,-5,-5,-5,-5,-5,+5)): getAlignmentString, "
+                  "getAlignmentScore, DynamicProgramming.getScoreTable; Match.countErrorsInNeedleman (L31-34), "
+                  "Match.hasN3pConsecutiveMatchesInNeedleman(nw, 6) (L41-50); NeedlemanMatch(match, pattern, read) statistics "
+                  "(L68-196)", NW, "fillInCell L55-80, getTraceback L102-151")
+    pats = ["CTTCCGATCT", "CTACACGACGCTCTTCCGATCT", "AAGCAGTGGTATCAAC", "AAGCAGTGGTATCAACGCAGAGTACAT", "TTTCTTATATGGG"]
+    cases = []
+    for p in pats:
+        for t in range(14 if len(p) <= 16 else 8):
+            mode = t % 7
+            x = list(p)
+            if mode == 0:
+                pass
+            else:
+                k = 0
+                while k < len(x):
+                    r = rng.random()
+                    if r < 0.06 * mode / 2:
+                        x[k] = rng.choice("ACGTN")
+                    elif r < 0.10 * mode / 2:
+                        del x[k]
+                        continue
+                    elif r < 0.14 * mode / 2:
+                        x.insert(k, rng.choice("ACGT"))
+                        k += 1
+                    k += 1
+            rs = "".join(x)
+            if mode == 6:
+                rs = rnd_seq(rng, len(p))
+            rs = (rs + rnd_seq(rng, len(p)))[:len(p)]  # the reference always aligns a slice of the pattern's length
+            cases.append((p, rs))
+    cases += [("CTTCCGATCT", "CTTCCGATCT"), ("CTTCCGATCT", "TTTTTTTTTT"), ("CTTCCGATCT", "NNNNNNNNNN"), ("CTTCCGATCT", "TCTAGCCTTC"),
+              ("CTTCCGATCT", "CTTCGATCTA"), ("CTTCCGATCT", "ACTTCCGATC"), ("CTTCCGATCT", "TTCCGATCTA")]
+    for p, rs in cases:
+        nw, strs, score = nw_align(j, p, rs)
+        tab = j.call_virtual(nw, "getScoreTable", "()[[I")
+        err = j.call_lambda(j.get_static(MATCH, "countErrorsInNeedleman"), [nw]).v
+        n3p = j.call_lambda(j.get_static(MATCH, "hasN3pConsecutiveMatchesInNeedleman"), [nw, JBox("java/lang/Integer", 6)]).v
+        o = j.new(NM, "(Ljava/lang/String;Ljava/lang/String;Ljava/lang/String;)V", strs[0], strs[1], strs[2])
+        c = {"pattern": p, "read_slice": rs, "alignment": strs, "score": score, "score_table_last_row": list(tab.a[-1].a),
+             "count_errors": err, "has_6_3p_matches": int(n3p),
+             "nm_nerrors": j.call_virtual(o, "getNerrorsNeedleman", "()I"),
+             "nm_subs_del_ins": [o.f["substitutionsNeedleman"], o.f["deletionsNeedleman"], o.f["insertionsNeedleman"]],
+             "nm_end_of_read_5": j.call_virtual(o, "countIndelsMismatchesEndOfRead", "(I)F", 5),
+             "nm_consecutive": j.call_virtual(o, "getNconsecutiveMatchesNeedleman", "()I"),
+             "nm_best_two": j.call_virtual(o, "getSumOfBestTwoMatchStretchesNeedleman", "()I"),
+             "nm_offset_for_read_end": j.call_virtual(o, "getOffsetForReadEnd", "()I")}
+        s["cases"].append(c)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def gen_lev(g):
+    """a-16 (inner): apachemod LevenshteinDistance.limitedCompare(byte[], byte[], threshold)"""
+    j = g.j
+    rng = random.Random(404)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("limitedCompare(left, right, threshold) on 4-bit coded 12-mers (L220-283); -1 = above the threshold", LEV, "limitedCompare:([B[BI)I")
+    codes = [1, 2, 4, 8]
+    for t in range(400):
+        n = 12 if t < 320 else rng.choice([5, 8, 10, 14])
+        a = [rng.choice(codes) for _ in range(n)]
+        b = list(a)
+        for _ in range(rng.choice([0, 1, 1, 2, 2, 3, 4, 5, 8])):
+            r = rng.random()
+            k = rng.randrange(len(b)) if b else 0
+            if r < 0.4 and b:
+                b[k] = rng.choice(codes + [15])
+            elif r < 0.7 and b:
+                del b[k]
+            else:
+                b.insert(k, rng.choice(codes))
+        if t < 320:
+            b = (b + [rng.choice(codes) for _ in range(n)])[:n]
+        th = 4 if t < 360 else rng.choice([1, 2, 3, 6])
+        try:
+            res = j.call_static(LEV, "limitedCompare", "([B[BI)I", j.byte_array(a), j.byte_array(b), th)
+        except JavaThrow as e:  # unequal lengths further apart than the threshold: the reference's own code throws
+            res = {"throws": e.obj.cls}
+        s["cases"].append({"a": a, "b": b, "threshold": th, "out": res})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N"}
+
+
+def revcomp_str(q):
+    return "".join(COMP[c] for c in reversed(q))
+
+
+def membership_set(keys):
+    """stands where the reference holds a fastutil LongOpenHashSet (jar absent): contains() only, no order"""
+    o = JObject("it/unimi/dsi/fastutil/longs/LongOpenHashSet")
+    o.native = set(keys)
+    return o
+
+
+def run_tester(j, read, ae, offset, wl, ed, three_p, length=16):
+    """what Parser.lambda$assignBarcode$4 (Parser.java:L205-242) does for one offset, through the reference's constructors"""
+    if three_p:
+        bc_start, bc_end = ae - length + offset, ae - 1 + offset
+    else:
+        bc_start, bc_end = ae + 1 + offset, ae + length + offset
+    bc = j.new(TB, "(Ljava/lang/String;)V", read[bc_start - 1:bc_end])
+    if three_p:
+        post = j.call_virtual(j.new(OB, "(Ljava/lang/CharSequence;)V", read[bc_start - 5:bc_start]), "reverseComplement", f"()L{OBI};")
+        bc = j.call_virtual(bc, "reverseComplement", f"()L{TB};")
+    else:
+        post = j.new(OB, "(Ljava/lang/CharSequence;)V", read[bc_end:bc_end + 5])
+    opt = j.call_native("java/util/Optional.of", [bc])
+    t = j.new(BMT, f"(Ljava/util/Optional;IZZLjava/util/Set;SIL{OBI};Z)V", opt, ed, 0, 1, wl, offset, length, post, 1)
+    m = j.call_virtual(t, "call", f"()L{BMT}$Matches;")
+    if m is None:
+        return None
+    res = []
+    for o, _ in m.native.items_in_insertion_order():
+        res.append({"read_seq": u64(o.f["readSeq"]), "bc": u64(o.f["matchingBC"]), "ed": o.f["editDistance"], "subs": o.f["substitutions"],
+                    "ins": o.f["insertions"], "dels": o.f["deletions"], "offset": o.f["offsetFromPredicted"],
+                    "offset_for_read_end": j.call_virtual(o, "getOffsetForReadEnd", "()I")})
+    return sorted(res, key=lambda r: (r["ed"], r["bc"], r["read_seq"]))
+
+
+def mutate(rng, q, n_err, with_n=False):
+    x = list(q)
+    for _ in range(n_err):
+        r = rng.random()
+        k = rng.randrange(len(x))
+        if r < 0.4:
+            x[k] = rng.choice("ACGT" + ("N" if with_n else ""))
+        elif r < 0.7:
+            del x[k]
+        else:
+            x.insert(k, rng.choice("ACGT"))
+    return "".join(x)
+
+
+def gen_bcmatch(g, n_ed1=60, n_ed2=6):
+    """a-11: BarcodeMatchTester.call() per offset, driven exactly as Parser.lambda$assignBarcode$4 drives it"""
+    j = g.j
+    rng = random.Random(505)
+    enc = lambda q: j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q))  # noqa: E731
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("BarcodeMatchTester(Optional.of(bc), ed, false, true, searchSet, offset, 16, postBCseq, true).call() for the five offsets "
+                  "0, -1, +1, -2, +2 of a stranded read (Parser.java:L205-242; doJob L198-247, substitutions L259-270, insertions "
+                  "L286-297, deletions L313-352, checkMatchWithTestSets).  `matches` = the CONTENT of the returned HashSet, sorted "
+                  "canonically here (its iteration order is not part of these vectors); null = call() returned null.  searchSet is a "
+                  "membership-only stand-in for the absent fastutil set.", BMT, "call:()L...$Matches;")
+    # barcode lists with near-duplicates so that 'first hit at a level wins' is exercised
+    base = [rnd_seq(rng, 16) for _ in range(30)]
+    near = []
+    for b in base[:12]:
+        for _ in range(3):
+            near.append(mutate(rng, b, 1)[:16].ljust(16, "A"))
+    bcs = sorted(set(base + near + ["A" * 16, "ACGT" * 4, "T" * 16]))
+    keys = [enc(b) for b in bcs]
+    wl = membership_set(keys)
+    s["barcodes"] = bcs
+    s["barcode_keys"] = [u64(k) for k in keys]
+    plan = [(1, True)] * n_ed1 + [(1, False)] * (n_ed1 // 2) + [(0, True)] * 6 + [(2, True)] * n_ed2 + [(2, False)] * (n_ed2 // 2)
+    for idx, (ed, three_p) in enumerate(plan):
+        b = rng.choice(bcs)
+        kind = idx % 6
+        n_err = [0, 1, 1, 2, 2, 3][kind]
+        left, right = rnd_seq(rng, 30), rnd_seq(rng, 30)
+        if three_p:
+            body = mutate(rng, revcomp_str(b), n_err, with_n=(idx % 11 == 0))
+            read = left + body + right          # adapter would start at AE: barcode occupies [AE-16, AE-1]
+            ae = len(left) + len(body) + 1 + rng.choice([0, 0, 0, -1, 1, 2, -2])
+        else:
+            body = mutate(rng, b, n_err, with_n=(idx % 11 == 0))
+            read = left + body + right          # adapter ends at AE: barcode occupies [AE+1, AE+16]
+            ae = len(left) + rng.choice([0, 0, 0, -1, 1, 2, -2])
+        if idx % 17 == 5:
+            read = read[:len(left)] + "A" * 24 + read[len(left) + 24:]   # homopolymer windows: identical mutants, dedup set at ed 2
+        per_offset = {}
+        for off in (0, -1, 1, -2, 2):
+            per_offset[str(off)] = run_tester(j, read, ae, off, wl, ed, three_p)
+        s["cases"].append({"read": read, "adapter_pos": ae, "ed": ed, "three_prime": three_p, "matches": per_offset})
+        if idx % 10 == 0:
+            print(f"  bcmatch {idx + 1}/{len(plan)}  {time.time() - g.t0:.0f}s", flush=True)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def gen_polyat(g):
+    """a-7: PolyATSearcher.findpolyAT"""
+    j = g.j
+    rng = random.Random(606)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("new PolyATSearcher(read, 15, 0.75f, 150).findpolyAT(reverse) (L56-252): polyT in the first 175 bases (reverse = false) / "
+                  "in the reverse complement of the last 175 (reverse = true); result null or (polyTbegin, polyTend, length of seqTilPolyAend)",
+                  PS, "findpolyAT:(Z)L...$PolyAscanResult;")
+
+    def run(read):
+        res = []
+        for rev in (0, 1):
+            o = j.new(PS, "(Ljava/lang/String;IFI)V", read, 15, f32(0.75), 150)
+            try:
+                r = j.call_virtual(o, "findpolyAT", f"(Z)L{PS}$PolyAscanResult;", rev)
+            except JavaThrow as e:  # reads shorter than the 175-base window: the callers test the read length first
+                res.append({"throws": e.obj.cls})
+                continue
+            res.append(None if r is None else {"begin": r.f["polyTbegin"], "end": r.f["polyTend"], "seq_til_end_len": len(r.f["seqTilPolyAend"].f["naData"].a)})
+        return res
+
+    for t in range(70):
+        kind = t % 7
+        tl = rng.randrange(8, 60)
+        run_t = "".join("T" if rng.random() > (0.0, 0.05, 0.12, 0.2, 0.3, 0.1, 0.1)[kind] else rng.choice("ACG") for _ in range(tl))
+        pre = rnd_seq(rng, rng.randrange(0, 140) if kind != 5 else rng.randrange(140, 175))
+        body = rnd_seq(rng, rng.randrange(150, 500))
+        tail_a = "".join("A" if rng.random() > 0.08 else rng.choice("CGT") for _ in range(rng.randrange(10, 50)))
+        read = pre + run_t + body + (tail_a + rnd_seq(rng, rng.randrange(20, 60)) if kind in (2, 4, 6) else "")
+        if kind == 6:
+            read = read[:rng.randrange(100, 170)]
+        s["cases"].append({"read": read, "forward_and_reverse": run(read)})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat}
+
+
+def main():
+    want = sys.argv[1:] or list(SECTIONS)
+    os.makedirs(OUT, exist_ok=True)
+    for name in want:
+        g = Gen()
+        t0 = time.time()
+        data = SECTIONS[name](g)
+        data["generated_by"] = "tools/make_ref_exec.py " + name
+        data["how"] = ("outputs computed by executing the reference's class files (jar named in `jar`) with tools/jvm_exec.py; "
+                       "inputs are seeded random / hand-picked; nothing here comes from oracle/ or from the HIP library")
+        data["bytecode_steps"] = g.j.steps
+        path = os.path.join(OUT, f"ref_exec_{name}.json")
+        with open(path, "w") as f:
+            json.dump(data, f, separators=(",", ":"))
+        n_cases = sum(len(s["cases"]) for s in data["sections"])
+        print(f"{name}: {n_cases} cases, {g.j.steps} bytecode steps, {time.time() - t0:.1f}s, {os.path.getsize(path) / 1024:.0f} KiB, "
+              f"max tier {max(s['max_tier'] for s in data['sections'])}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
