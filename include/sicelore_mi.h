@@ -138,22 +138,24 @@ int smi_hist_device(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass,
 #define SMI_PLANE_WORDS 7
 #define SMI_ENDS_ROWS (4 * SMI_PLANE_WORDS)
 
-/* flag bits = ordinals of FJ!nanoporereadscanner/stats/ReadFlags$Flags (ReadFlags.java:L72-109) */
-#define SMI_F_FAILED (1u << 6)
-#define SMI_F_PASSED_FWD (1u << 9)
-#define SMI_F_PASSED_REV (1u << 10)
-#define SMI_F_POLY_T_5P (1u << 12)
-#define SMI_F_POLY_A_3P (1u << 13)
-#define SMI_F_POLY_A_NOT_FOUND (1u << 14)
-#define SMI_F_POLY_T_5P_POLY_A_3P (1u << 15)
-#define SMI_F_ADAPTER_5P (1u << 16)
-#define SMI_F_ADAPTER_3P (1u << 17)
-#define SMI_F_ADAPTER_SELECTED_DESP_BOTH (1u << 20)
-#define SMI_F_READ_TOO_SHORT (1u << 21)
-#define SMI_F_ADAPTER_5P_AND_3P (1u << 22)
-#define SMI_F_TSO_5P (1u << 18)
-#define SMI_F_TSO_3P (1u << 19)
-#define SMI_F_TSO_5P_AND_3P (1u << 23)
+/* flag bits = ReadFlags$Flags.getValue() of FJ!nanoporereadscanner/stats/ReadFlags$Flags (ReadFlags.java:L72-109): FAILED = 0x20,
+ * PASSED_FWD = 0x100, ... (NOT the enum ordinals: ALL_READS_AFTER_SPLIT = -1 sits in between; values pinned by
+ * tests/golden/ref_exec_pass2_*.json `flag_values`, read from the reference's own enum) */
+#define SMI_F_FAILED (1u << 5)
+#define SMI_F_PASSED_FWD (1u << 8)
+#define SMI_F_PASSED_REV (1u << 9)
+#define SMI_F_POLY_T_5P (1u << 11)
+#define SMI_F_POLY_A_3P (1u << 12)
+#define SMI_F_POLY_A_NOT_FOUND (1u << 13)
+#define SMI_F_POLY_T_5P_POLY_A_3P (1u << 14)
+#define SMI_F_ADAPTER_5P (1u << 15)
+#define SMI_F_ADAPTER_3P (1u << 16)
+#define SMI_F_ADAPTER_SELECTED_DESP_BOTH (1u << 19)
+#define SMI_F_READ_TOO_SHORT (1u << 20)
+#define SMI_F_ADAPTER_5P_AND_3P (1u << 21)
+#define SMI_F_TSO_5P (1u << 17)
+#define SMI_F_TSO_3P (1u << 18)
+#define SMI_F_TSO_5P_AND_3P (1u << 22)
 
 typedef struct {
     int32_t min_read_length;        /* Jar/config.xml:21   200 */

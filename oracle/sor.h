@@ -50,26 +50,27 @@ int sor_assign_barcode(const sor_set *search, const char *stranded, int read_len
 
 
 /* ---- read scan (sor_scan.c) ------------------------------------------------------------------------------ */
-/* bit = ordinal of the flag in FJ!nanoporereadscanner/stats/ReadFlags$Flags (ReadFlags.java:L72-109); the
- * reference's own long values come from a static counter and are not part of any output format */
-#define SOR_F_PASSED_TOTAL (1ull << 5)
-#define SOR_F_FAILED (1ull << 6)
-#define SOR_F_PASSED_TOT_TSO (1ull << 11)
-#define SOR_F_TSO_5P (1ull << 18)
-#define SOR_F_TSO_3P (1ull << 19)
-#define SOR_F_TSO_5P_AND_3P (1ull << 23)
-#define SOR_F_TSO_5P_AND_3P_FAILED (1ull << 24)
-#define SOR_F_PASSED_FWD (1ull << 9)
-#define SOR_F_PASSED_REV (1ull << 10)
-#define SOR_F_POLY_T_5P (1ull << 12)
-#define SOR_F_POLY_A_3P (1ull << 13)
-#define SOR_F_POLY_A_NOT_FOUND (1ull << 14)
-#define SOR_F_POLY_T_5P_POLY_A_3P (1ull << 15)
-#define SOR_F_ADAPTER_5P (1ull << 16)
-#define SOR_F_ADAPTER_3P (1ull << 17)
-#define SOR_F_ADAPTER_SELECTED_DESP_BOTH (1ull << 20)
-#define SOR_F_READ_TOO_SHORT (1ull << 21)
-#define SOR_F_ADAPTER_5P_AND_3P (1ull << 22)
+/* bit values = ReadFlags$Flags.getValue() (FJ!nanoporereadscanner/stats/ReadFlags.java:L72-109: FAILED = 0x20, PASSED_FWD = 0x100,
+ * ...), pinned by tests/golden/ref_exec_pass2_*.json `flag_values` (read from the reference's own enum by tools/jvm_exec.py);
+ * not the ordinals: the all-ones ALL_READS_AFTER_SPLIT sits between bit 2 and bit 3 */
+#define SOR_F_PASSED_TOTAL (1ull << 4)
+#define SOR_F_FAILED (1ull << 5)
+#define SOR_F_PASSED_TOT_TSO (1ull << 10)
+#define SOR_F_TSO_5P (1ull << 17)
+#define SOR_F_TSO_3P (1ull << 18)
+#define SOR_F_TSO_5P_AND_3P (1ull << 22)
+#define SOR_F_TSO_5P_AND_3P_FAILED (1ull << 23)
+#define SOR_F_PASSED_FWD (1ull << 8)
+#define SOR_F_PASSED_REV (1ull << 9)
+#define SOR_F_POLY_T_5P (1ull << 11)
+#define SOR_F_POLY_A_3P (1ull << 12)
+#define SOR_F_POLY_A_NOT_FOUND (1ull << 13)
+#define SOR_F_POLY_T_5P_POLY_A_3P (1ull << 14)
+#define SOR_F_ADAPTER_5P (1ull << 15)
+#define SOR_F_ADAPTER_3P (1ull << 16)
+#define SOR_F_ADAPTER_SELECTED_DESP_BOTH (1ull << 19)
+#define SOR_F_READ_TOO_SHORT (1ull << 20)
+#define SOR_F_ADAPTER_5P_AND_3P (1ull << 21)
 
 typedef struct { /* shipped values: Jar/config.xml:21,55-59,95-105 */
     int32_t min_read_length;        /* 200 */
@@ -139,7 +140,7 @@ int sor_finalize_used_list(const int64_t *keys, const uint32_t *counts, size_t n
 /* ---- chimera splitter (sor_chimera.c) ---------------------------------------------------------------------- */
 #define SOR_F_CHIMERIC_READS_SPLIT (1ull << 1)
 #define SOR_F_MULTI_CHIMERIC_READS_DISCARDED (1ull << 2)
-#define SOR_F_READS_AFTER_SPLIT (1ull << 4)
+#define SOR_F_READS_AFTER_SPLIT (1ull << 3)
 /* ChimeraFindernew$SplitPosition$SplitReason ordinals (ChimeraFindernew.java:L364-370) */
 enum { SOR_SPLIT_REV_ADAPTER = 0, SOR_SPLIT_FWD_ADAPTER, SOR_SPLIT_RA_FA, SOR_SPLIT_RA_FT, SOR_SPLIT_RT_FA, SOR_SPLIT_RT_FT,
        SOR_SPLIT_READSTART };

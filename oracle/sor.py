@@ -149,9 +149,9 @@ SCAN_RESULT_DTYPE = np.dtype([("flags", "<u8"), ("adapter_found", "<i4"), ("reve
                               ("n_cand_rev", "<i4"), ("pass1_ok", "<i4"), ("mean_qv_bc", "<f4"),
                               ("mean_qv_read", "<f4"), ("tso_start", "<i4"), ("tso_end", "<i4")], align=True)
 assert SCAN_RESULT_DTYPE.itemsize == 72
-FLAG_BITS = {"FAILED": 6, "PASSED_FWD": 9, "PASSED_REV": 10, "POLY_T_5P": 12, "POLY_A_3P": 13, "POLY_A_NOT_FOUND": 14,
-             "POLY_T_5P_POLY_A_3P": 15, "ADAPTER_5P": 16, "ADAPTER_3P": 17, "ADAPTER_SELECTED_DESP_BOTH": 20,
-             "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22, "TSO_5P": 18, "TSO_3P": 19, "TSO_5P_AND_3P": 23}
+FLAG_BITS = {"FAILED": 5, "PASSED_FWD": 8, "PASSED_REV": 9, "POLY_T_5P": 11, "POLY_A_3P": 12, "POLY_A_NOT_FOUND": 13,
+             "POLY_T_5P_POLY_A_3P": 14, "ADAPTER_5P": 15, "ADAPTER_3P": 16, "ADAPTER_SELECTED_DESP_BOTH": 19,
+             "READ_TOO_SHORT": 20, "ADAPTER_5P_AND_3P": 21, "TSO_5P": 17, "TSO_3P": 18, "TSO_5P_AND_3P": 22}
 
 
 def default_scan_params():

@@ -474,7 +474,7 @@ int sor_scan_batch_3p(const char *reads, const char *quals, const uint64_t *offs
 /* ---- probes for tests/test_ref_exec.py: every alignment statistic of one (pattern, read slice) pair, and the 4-mer gate,
  * so that each can be compared with the value the reference's own bytecode produced (tests/golden/ref_exec_nw.json) ---- */
 int sor_nw_stats(const char *adapter, const char *read_slice, int32_t *out9, float *out_f2, int32_t *last_row) {
-    uint8_t s1[NW_MAX], s2[NW_MAX];
+    uint8_t s1[NW_MAX] = {0}, s2[NW_MAX] = {0};
     int n1 = (int)strlen(adapter), n2 = (int)strlen(read_slice);
     if (n1 > NW_MAX || n2 > NW_MAX) return -1;
     for (int i = 0; i < n1; i++) s1[i] = (uint8_t)enc4((unsigned char)adapter[i]);

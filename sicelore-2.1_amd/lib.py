@@ -34,9 +34,9 @@ SPLIT_REASONS = ["REV_ADAPTER", "FWD_ADAPTER", "REV_ADAPTER_FWD_ADAPTER", "REV_A
 CHIM_MULTI, CHIM_RANGE, CHIM_OVERFLOW = 1, 2, 4
 END_BASES = 224
 ENDS_ROWS = 28
-FLAG_BITS = {"FAILED": 6, "PASSED_FWD": 9, "PASSED_REV": 10, "POLY_T_5P": 12, "POLY_A_3P": 13, "POLY_A_NOT_FOUND": 14,
-             "POLY_T_5P_POLY_A_3P": 15, "ADAPTER_5P": 16, "ADAPTER_3P": 17, "ADAPTER_SELECTED_DESP_BOTH": 20,
-             "READ_TOO_SHORT": 21, "ADAPTER_5P_AND_3P": 22, "TSO_5P": 18, "TSO_3P": 19, "TSO_5P_AND_3P": 23}
+FLAG_BITS = {"FAILED": 5, "PASSED_FWD": 8, "PASSED_REV": 9, "POLY_T_5P": 11, "POLY_A_3P": 12, "POLY_A_NOT_FOUND": 13,
+             "POLY_T_5P_POLY_A_3P": 14, "ADAPTER_5P": 15, "ADAPTER_3P": 16, "ADAPTER_SELECTED_DESP_BOTH": 19,
+             "READ_TOO_SHORT": 20, "ADAPTER_5P_AND_3P": 21, "TSO_5P": 17, "TSO_3P": 18, "TSO_5P_AND_3P": 22}
 assert BC_WINDOW_DTYPE.itemsize == 16 and BC_RESULT_DTYPE.itemsize == 16 and SCAN_RESULT_DTYPE.itemsize == 32
 assert CHIMERA_RESULT_DTYPE.itemsize == 16
 

@@ -14,9 +14,9 @@ import torch
 
 from . import lib as _lib
 
-READS_AFTER_SPLIT = 1 << 4            # ReadFlags$Flags ordinals (ReadFlags.java:L72-109)
+READS_AFTER_SPLIT = 1 << 3            # ReadFlags$Flags.getValue() (ReadFlags.java:L72-109; sicelore_mi.h SMI_F_*)
 MULTI_CHIMERIC_READS_DISCARDED = 1 << 2
-FAILED = 1 << 6
+FAILED = 1 << 5
 
 
 def read_fastq_file(path):

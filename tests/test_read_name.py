@@ -94,7 +94,7 @@ def test_readme_read_name_examples(pkg, sor):
         raw_seq = "".join(COMP[x] for x in reversed(stranded)) if c["rev"] else stranded
         raw_qual = squal[::-1] if c["rev"] else squal
         scan = np.zeros(1, dtype=pkg.SCAN_RESULT_DTYPE)[0]
-        scan["flags"] = (1 << 10) if c["rev"] else (1 << 9)
+        scan["flags"] = (1 << sor.FLAG_BITS["PASSED_REV"]) if c["rev"] else (1 << sor.FLAG_BITS["PASSED_FWD"])
         scan["polya_start"], scan["polya_end"], scan["adapter_end"], scan["found"] = c["PS"], c["PE"], c["AE"], 1
         scan["reverse"], scan["tso_end"] = int(c["rev"]), c["T"]
         bc = np.zeros(1, dtype=pkg.BC_RESULT_DTYPE)[0]

@@ -195,3 +195,75 @@ def test_barcode_match_tester_per_offset(sor):
             n_hits += len(got)
             n_cases += 1
     assert n_cases >= 400 and n_hits >= 100
+
+
+# ---- whole records: a-4 ... a-11, a-15 through the reference's own pass 2 -----------------------------------------------
+_TR = bytes.maketrans(b"ACGTN", b"TGCAN")
+
+
+def _oracle_record(sor, bset, rank_of, sec, case, read_id):
+    """the oracle flow for one record, as tests/test_write_gpu.py chains it (no chimera splitting: the fixture driver calls
+    search / assignBarcode / getRecordForWriting directly)"""
+    five, ed = sec["five_prime"], sec["ed"]
+    s, q = case["seq"], case["qual"]
+    if five:
+        rc, sc = sor.scan_read_5p(s, q, "CTTCCGATCT", dont_search_polya=sec["dont_search_polya"])
+    else:
+        rc, sc = sor.scan_read_3p(s, q, "CTTCCGATCT")
+    assert rc == 0
+    a = None
+    if sc["adapter_found"]:
+        stranded = s.encode().translate(_TR)[::-1] if sc["reverse"] else s.encode()
+        rc2, a_ = sor.assign_barcode(bset, stranded, int(sc["adapter_end"]), max_ed=ed, five_prime=five)
+        if rc2 == 1:
+            a = a_
+    rk = rank_of.get(int(a["bc"]) & 0xFFFFFFFF, 0) if a is not None else 0
+    rec, ok = sor.fastq_record(case["name"], "", s, q, sc, a, rank=rk, read_id=read_id, five_prime=five)
+    return sc, a, rec, ok
+
+
+@pytest.mark.parametrize("name", ["pass2_3p", "pass2_5p", "pass2_5p_polya", "pass2_3p_ed2"])
+def test_pass2_records_equal_reference_bytecode(sor, name):
+    d = load(name)
+    sec = d["sections"][0]
+    keys = [sor.encode(b) for b in sec["barcodes"]]
+    bset = sor.BarcodeSet(np.array(keys, dtype=np.int64))
+    rank_of = {int(k) & 0xFFFFFFFF: r for k, r in zip(keys, sec["ranks"])}
+    n_passed = n_bc = n_checked = 0
+    for idx, c in enumerate(sec["cases"]):
+        want = c["result"]
+        if not c["hash_orders_agree"] or "throws" in want:
+            continue  # listed by test_pass2_exclusions_are_explained
+        sc, a, rec, ok = _oracle_record(sor, bset, rank_of, sec, c, idx + 1)
+        n_checked += 1
+        assert ok == want["passed"], (c["name"], want)
+        # the oracle models the scan-level flags (sor.FLAG_BITS); the barcode / statistics bits of the reference are not outputs
+        for fname, bit in sor.FLAG_BITS.items():
+            ref_name = {"ADAPTER_SELECTED_DESP_BOTH": "ADAPTER_SELECTED_DESP_ADAPTER_BOTH_SIDES"}.get(fname, fname)
+            assert (1 << bit) == sec["flag_values"][ref_name], fname            # same bit VALUES as ReadFlags$Flags.getValue()
+            assert bool(int(sc["flags"]) >> bit & 1) == bool(want["flag"] & sec["flag_values"][ref_name]), (c["name"], fname, hex(want["flag"]))
+        assert bool(sc["reverse"]) == (want["forward"] == "REVERSE"), c["name"]
+        if want["adapter"] is not None and want["adapter"][1] is not None:
+            assert [int(sc["adapter_start"]), int(sc["adapter_end"])] == want["adapter"], (c["name"], want)
+        if want["barcode"] is not None:
+            assert a is not None, (c["name"], want["barcode"])
+            assert sor.decode(int(a["bc"]), 16) == want["barcode"]["seq"]
+            assert [int(a["ed"]), int(a["ed_sec"]), int(a["bc_start"]), int(a["bc_end"])] == \
+                [want["barcode"]["ed"], want["barcode"]["ed_second"], want["barcode"]["start"], want["barcode"]["end"]], c["name"]
+            n_bc += 1
+        else:
+            assert a is None, (c["name"], a)
+        w = want["written"]
+        text = f"@{w['name']}\n{w['bases']}\n+{w['quality_header'] or ''}\n{w['qualities']}\n".encode()
+        assert rec == text, (c["name"], rec[:300], text[:300])
+        n_passed += ok
+    assert n_checked >= len(sec["cases"]) * 0.8 and n_passed >= 3 and n_bc >= 2
+
+
+def test_pass2_exclusions_are_explained():
+    """cases the vectors cannot decide are few and of two kinds only: the result depends on HashSet iteration order (not
+    emulated by the interpreter), or the reference itself throws"""
+    for name in ("pass2_3p", "pass2_5p", "pass2_5p_polya", "pass2_3p_ed2"):
+        sec = load(name)["sections"][0]
+        bad = [c for c in sec["cases"] if not c["hash_orders_agree"] or "throws" in c["result"]]
+        assert len(bad) <= max(2, len(sec["cases"]) // 5), (name, [(c["name"], c["result"].get("throws")) for c in bad])

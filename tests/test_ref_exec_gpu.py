@@ -1,0 +1,52 @@
+"""The HIP path against REFERENCE-EXECUTED vectors (tests/golden/ref_exec_pass2_*.json: whole records through the reference's
+own pass 2, executed from its class files by tools/jvm_exec.py; see tests/test_ref_exec.py for the oracle side).
+
+Every record goes through the C ABI's chunk worker (smi_scanfastq_pass2_chunk: FASTQ text in, passed / failed FASTQ text out,
+K-FQ -> K-PACK -> K-SCAN -> K-WIN/K-BC -> K-WRITE on the device) and must come out byte for byte as the reference's
+FastqRecordExt.getRecordForWriting wrote it.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_CODE = {"A": 0, "G": 1, "C": 2, "T": 3}
+
+
+def _key(bc):
+    v = 0
+    for ch in bc:
+        v = (v << 2) | _CODE[ch]
+    return v
+
+
+@pytest.mark.parametrize("name", ["pass2_3p", "pass2_5p", "pass2_5p_polya", "pass2_3p_ed2"])
+def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name):
+    with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
+        sec = json.load(f)["sections"][0]
+    keys = np.array([_key(b) for b in sec["barcodes"]], dtype=np.uint64)
+    ranks = np.array(sec["ranks"], dtype=np.int32)
+    order = np.argsort(keys)
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    n_checked = n_passed = n_bc = 0
+    for idx, c in enumerate(sec["cases"]):
+        want = c["result"]
+        if not c["hash_orders_agree"] or "throws" in want:
+            continue
+        text = f"@{c['name']}\n{c['seq']}\n+\n{c['qual']}\n".encode()
+        passed, failed, info = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=sec["ed"], five_prime=sec["five_prime"],
+                                                             dont_search_polya=sec["dont_search_polya"], split_chimeras=False,
+                                                             first_read_id=idx + 1, rank_keys=keys[order], rank_values=ranks[order])
+        w = want["written"]
+        exp = f"@{w['name']}\n{w['bases']}\n+{w['quality_header'] or ''}\n{w['qualities']}\n".encode()
+        got = passed if want["passed"] else failed
+        other = failed if want["passed"] else passed
+        assert got == exp, (c["name"], got[:400], exp[:400])
+        assert other == b""
+        n_checked += 1
+        n_passed += want["passed"]
+        n_bc += want["barcode"] is not None
+    assert n_checked >= len(sec["cases"]) * 0.8 and n_passed >= 3 and n_bc >= 2

@@ -40,6 +40,7 @@ class JavaThrow(Exception):
     def __init__(self, obj):
         Exception.__init__(self, getattr(obj, "cls", str(obj)))
         self.obj = obj
+        self.trace = []  # innermost first: the Java methods the exception passed through
 
 
 class JObject:
@@ -235,11 +236,13 @@ class JVM:
         self.intern = {}
         self.hash_order = None  # see jvm_natives.HashStore.cells_for_iteration
         self.hooks = {}  # "cls.name:desc" -> python callable(jvm, args) replacing a method (used for MISSING libraries only)
-        from jvm_natives import install, install_hash, install_streams  # noqa: E402
+        from jvm_natives import install, install_enumset, install_env, install_hash, install_streams  # noqa: E402
 
         install(self)
         install_streams(self)
         install_hash(self)
+        install_env(self)
+        install_enumset(self)
 
     # ---- classes ---------------------------------------------------------------------------------------------------
     def has_class(self, name):
@@ -327,6 +330,8 @@ class JVM:
         """resolution along the superclass chain, then default methods of interfaces; -> Method or native key or None"""
         n = cname
         seen_ifaces = []
+        if cname.startswith("[") and name == "clone":
+            return "[.clone"
         while n is not None:
             if n in self.index:
                 jc = self.load(n)
@@ -588,6 +593,10 @@ class JVM:
             raise Unsupported("call depth > 400")
         try:
             return self._run(m, args)
+        except JavaThrow as e:
+            if len(e.trace) < 30:
+                e.trace.append(f"{m.cls.name}.{m.name}")
+            raise
         finally:
             self.depth -= 1
 

@@ -141,6 +141,14 @@ def install(jvm):
     N["java/lang/String.toString"] = lambda j, s: s
     N["java/lang/String.toCharArray"] = lambda j, s: JArray("C", [ord(c) for c in s])
     N["java/lang/String.getBytes"] = lambda j, s, *a: JArray("B", [((b + 128) & 255) - 128 for b in s.encode("latin-1")])
+    def s_get_bytes_into(j, s, b, e, dst, d0):
+        if b < 0 or e > len(s) or b > e or d0 < 0 or d0 + (e - b) > len(dst.a):
+            j.throw("java/lang/StringIndexOutOfBoundsException")
+        for k in range(b, e):
+            dst.a[d0 + k - b] = ((ord(s[k]) + 128) & 255) - 128
+
+    N["java/lang/String.getBytes:(II[BI)V"] = s_get_bytes_into
+    N["java/lang/String.getChars:(II[CI)V"] = lambda j, s, b, e, dst, d0: dst.a.__setitem__(slice(d0, d0 + e - b), [ord(c) for c in s[b:e]])
     N["java/lang/String.indexOf:(I)I"] = lambda j, s, c: s.find(chr(c))
     N["java/lang/String.indexOf:(II)I"] = lambda j, s, c, f: s.find(chr(c), max(f, 0))
     N["java/lang/String.indexOf:(Ljava/lang/String;)I"] = lambda j, s, t: s.find(t)
@@ -168,7 +176,25 @@ def install(jvm):
     N["java/lang/String.valueOf:(Ljava/lang/Object;)Ljava/lang/String;"] = lambda j, v: j.to_jstring(v)
     N["java/lang/String.valueOf:([C)Ljava/lang/String;"] = lambda j, v: "".join(chr(c) for c in v.a)
     N["java/lang/String.copyValueOf:([C)Ljava/lang/String;"] = lambda j, v: "".join(chr(c) for c in v.a)
-    N["java/lang/String.chars"] = lambda j, s: (_ for _ in ()).throw(Unsupported("String.chars (streams)"))
+    def s_split(j, s, rx, limit=0):
+        import re
+
+        if limit != 0:
+            raise Unsupported("String.split with a limit")
+        if any(ch in rx for ch in ".$|()[{^?*+\\"):
+            simple = {"\\s+": r"\s+", "\\|": r"\|", "\\t": "\t", "\\.": r"\."}
+            if rx not in simple:
+                raise Unsupported(f"String.split regex {rx!r}")
+            parts = re.split(simple[rx], s)
+        else:
+            parts = s.split(rx) if rx else list(s)
+        if s == "":
+            return JArray("Ljava/lang/String;", [""])
+        while parts and parts[-1] == "":
+            parts.pop()
+        return JArray("Ljava/lang/String;", parts)
+
+    N["java/lang/String.split:(Ljava/lang/String;)[Ljava/lang/String;"] = s_split
     N["java/lang/CharSequence.length"] = lambda j, s: len(j.to_jstring(s))
     N["java/lang/CharSequence.charAt"] = lambda j, s, i: s_char_at(j, j.to_jstring(s), i)
     N["java/lang/CharSequence.toString"] = lambda j, s: j.to_jstring(s)
@@ -300,6 +326,21 @@ def install(jvm):
     N["java/lang/Long.toString:(J)Ljava/lang/String;"] = lambda j, v: str(v)
     N["java/lang/Float.toString:(F)Ljava/lang/String;"] = lambda j, v: float_to_string(v, True)
     N["java/lang/Double.toString:(D)Ljava/lang/String;"] = lambda j, v: float_to_string(v, False)
+    def to_radix(j, v, radix):
+        if not 2 <= radix <= 36:
+            radix = 10
+        digits = "0123456789abcdefghijklmnopqrstuvwxyz"
+        n, out = abs(v), ""
+        while True:
+            out = digits[n % radix] + out
+            n //= radix
+            if n == 0:
+                break
+        return ("-" if v < 0 else "") + out
+
+    N["java/lang/Integer.toString:(II)Ljava/lang/String;"] = to_radix
+    N["java/lang/Long.toString:(JI)Ljava/lang/String;"] = to_radix
+    N["java/lang/Integer.parseInt:(Ljava/lang/String;I)I"] = lambda j, s, r: int(s, r)
     N["java/lang/Integer.parseInt:(Ljava/lang/String;)I"] = lambda j, s: _parse_int(j, s, 32)
     N["java/lang/Long.parseLong:(Ljava/lang/String;)J"] = lambda j, s: _parse_int(j, s, 64)
     N["java/lang/Integer.valueOf:(Ljava/lang/String;)Ljava/lang/Integer;"] = lambda j, s: JBox("java/lang/Integer", _parse_int(j, s, 32))
@@ -831,6 +872,35 @@ def install_streams(jvm):
     N["java/util/stream/Collectors.joining:(Ljava/lang/CharSequence;)Ljava/util/stream/Collector;"] = \
         lambda j, sep: collector(lambda j_, items: j_.to_jstring(sep).join(j_.to_jstring(v) for v in items))
 
+    def grouping_by(j, keyf, *rest):
+        """groupingBy(classifier[, downstream]) -> java.util.HashMap: lists in encounter order; the map's own iteration order is
+        as for every hash container here (varied, not emulated)"""
+        down = rest[-1] if rest else None
+        if len(rest) == 2:
+            raise Unsupported("groupingBy with a map factory")
+
+        def run(j_, items):
+            m = j_.natives["java/util/HashMap.<new>"](j_)
+            for v in items:
+                k = call_fn(j_, keyf, v)
+                cell = m.native.find(k)
+                if cell is None:
+                    m.native.put(k, [v])
+                else:
+                    cell[1].append(v)
+            for cell in m.native.order:
+                cell[1] = _list(j_, cell[1]) if down is None else down.native(j_, cell[1])
+            return m
+
+        return collector(run)
+
+    def mapping(j, f, down):
+        return collector(lambda j_, items: down.native(j_, [call_fn(j_, f, v) for v in items]))
+
+    N["java/util/stream/Collectors.groupingBy"] = grouping_by
+    N["java/util/stream/Collectors.mapping"] = mapping
+    N["java/util/stream/Collectors.toUnmodifiableList"] = N["java/util/stream/Collectors.toList"]
+
     # ---- Optional
     for c, k in (("java/util/Optional", "ref"), ("java/util/OptionalInt", "int"), ("java/util/OptionalLong", "long"), ("java/util/OptionalDouble", "double")):
         N[f"{c}.isPresent"] = lambda j, o: 1 if o.native[0] is not None else 0
@@ -1096,6 +1166,12 @@ def install_hash(jvm):
         return None
 
     N["java/util/HashMap.putIfAbsent"] = put_if_absent
+    # ConcurrentHashMap used single-threaded: the same membership structure (its iteration order is likewise not emulated)
+    for k in list(N):
+        if k.startswith("java/util/HashMap."):
+            N["java/util/concurrent/ConcurrentHashMap" + k[len("java/util/HashMap"):]] = N[k]
+    N["java/util/concurrent/ConcurrentHashMap.<new>"] = new("java/util/concurrent/ConcurrentHashMap")
+    N["java/util/concurrent/ConcurrentHashMap.newKeySet"] = lambda j, *a: new("java/util/HashSet")(j)
     for iface, impl in (("java/util/Set", "java/util/HashSet"), ("java/util/Map", "java/util/HashMap")):
         for k in list(N):
             if k.startswith(impl + ".") and not k.endswith(("<new>", "<init>")):
@@ -1105,4 +1181,155 @@ def install_hash(jvm):
     jdk_super.update({"java/util/HashSet": "java/util/AbstractSet", "java/util/AbstractSet": "java/util/AbstractCollection",
                       "java/util/HashMap": "java/util/AbstractMap", "java/util/AbstractMap": "java/lang/Object"})
     jdk_ifaces["java/util/AbstractMap$SimpleEntry"] = ["java/util/Map$Entry"]
+    jdk_super["java/util/concurrent/ConcurrentHashMap"] = "java/util/AbstractMap"
+    jdk_ifaces["java/util/concurrent/ConcurrentHashMap"] = ["java/util/Map", "java/util/concurrent/ConcurrentMap"]
     jdk_ifaces.update({"java/util/HashSet": ["java/util/Set", "java/util/Collection", "java/lang/Iterable"], "java/util/HashMap": ["java/util/Map"]})
+
+
+# =====================================================================================================================
+# environment: things a driver has to answer for the JVM process (no bearing on the algorithms): runtime, clocks,
+# properties, atomics used as plain counters, DecimalFormat for the two patterns the reference uses
+# =====================================================================================================================
+def install_env(jvm):
+    N = jvm.natives
+
+    def inert(cls):
+        def f(j, *a):
+            o = JObject(cls)
+            o.native = {}
+            return o
+
+        return f
+
+    N["java/lang/Runtime.getRuntime"] = inert("java/lang/Runtime")
+    N["java/lang/Runtime.availableProcessors"] = lambda j, o: 8
+    N["java/lang/Runtime.maxMemory"] = lambda j, o: 1 << 34
+    N["java/lang/Runtime.totalMemory"] = lambda j, o: 1 << 33
+    N["java/lang/Runtime.freeMemory"] = lambda j, o: 1 << 32
+    N["java/lang/System.currentTimeMillis"] = lambda j: 0
+    N["java/lang/System.nanoTime"] = lambda j: 0
+    N["java/lang/System.getProperty"] = lambda j, k, *d: {"user.home": "/tmp", "user.dir": "/tmp", "line.separator": "\n", "file.separator": "/"}.get(k, d[0] if d else None)
+    N["java/lang/System.lineSeparator"] = lambda j: "\n"
+    N["java/lang/Thread.currentThread"] = inert("java/lang/Thread")
+    N["java/lang/Thread.getName"] = lambda j, o: "main"
+    N["java/lang/Thread.getId"] = lambda j, o: 1
+
+    for c, wrap in (("java/util/concurrent/atomic/AtomicInteger", i32), ("java/util/concurrent/atomic/AtomicLong", i64)):
+        def mk(cls):
+            def new(j):
+                o = JObject(cls)
+                o.native = [0]
+                return o
+
+            return new
+
+        N[f"{c}.<new>"] = mk(c)
+        N[f"{c}.<init>"] = lambda j, o, *a: o.native.__setitem__(0, a[0] if a else 0)
+        N[f"{c}.get"] = lambda j, o: o.native[0]
+        N[f"{c}.set"] = lambda j, o, v: o.native.__setitem__(0, v)
+        N[f"{c}.intValue"] = lambda j, o: i32(o.native[0])
+        N[f"{c}.longValue"] = lambda j, o: i64(o.native[0])
+        N[f"{c}.incrementAndGet"] = (lambda w: lambda j, o: (o.native.__setitem__(0, w(o.native[0] + 1)), o.native[0])[1])(wrap)
+        N[f"{c}.getAndIncrement"] = (lambda w: lambda j, o: (o.native[0], o.native.__setitem__(0, w(o.native[0] + 1)))[0])(wrap)
+        N[f"{c}.addAndGet"] = (lambda w: lambda j, o, d: (o.native.__setitem__(0, w(o.native[0] + d)), o.native[0])[1])(wrap)
+        N[f"{c}.getAndAdd"] = (lambda w: lambda j, o, d: (o.native[0], o.native.__setitem__(0, w(o.native[0] + d)))[0])(wrap)
+        N[f"{c}.decrementAndGet"] = (lambda w: lambda j, o: (o.native.__setitem__(0, w(o.native[0] - 1)), o.native[0])[1])(wrap)
+
+    # java.text.DecimalFormat: only patterns made of '#', '0', ',', '.'; RoundingMode.HALF_EVEN on the exact binary value
+    def df_new(j):
+        o = JObject("java/text/DecimalFormat")
+        o.native = {"pattern": "#"}
+        return o
+
+    def df_init(j, o, pattern="#", *a):
+        o.native["pattern"] = pattern  # checked when something is formatted with it
+
+    def df_format(j, o, v):
+        import decimal
+
+        pat = o.native["pattern"]
+        if any(ch not in "#0,." for ch in pat):
+            raise Unsupported(f"DecimalFormat pattern {pat!r}")
+        ip, _, fp = pat.partition(".")
+        max_frac, min_frac = len(fp), fp.count("0")
+        min_int = ip.replace(",", "").count("0")
+        grouping = len(ip) - ip.rfind(",") - 1 if "," in ip else 0
+        if isinstance(v, JBox):
+            v = v.v
+        d = decimal.Decimal(v)  # exact value of the double (a float argument was widened exactly)
+        q = d.quantize(decimal.Decimal(1).scaleb(-max_frac), rounding=decimal.ROUND_HALF_EVEN)
+        neg = q < 0
+        q = abs(q)
+        s = f"{q:f}"
+        i, _, f = s.partition(".")
+        f = f.rstrip("0")
+        f = f.ljust(min_frac, "0")
+        i = i.lstrip("0").rjust(min_int, "0")
+        if grouping and len(i) > grouping:
+            parts = []
+            while len(i) > grouping:
+                parts.insert(0, i[-grouping:])
+                i = i[:-grouping]
+            i = ",".join([i] + parts)
+        out = i + ("." + f if f else "")
+        if not out:
+            out = "0"
+        if neg and any(ch in "123456789" for ch in out):
+            out = "-" + out
+        return out
+
+    N["java/text/DecimalFormat.<new>"] = df_new
+    N["java/text/DecimalFormat.<init>"] = df_init
+    N["java/text/DecimalFormat.format:(D)Ljava/lang/String;"] = df_format
+    N["java/text/DecimalFormat.format:(J)Ljava/lang/String;"] = df_format
+    N["java/text/DecimalFormat.format:(Ljava/lang/Object;)Ljava/lang/String;"] = df_format   # Float / Double / Integer boxes
+    N["java/text/NumberFormat.format:(D)Ljava/lang/String;"] = df_format
+    N["java/text/NumberFormat.format:(J)Ljava/lang/String;"] = df_format
+    N["java/text/Format.format:(Ljava/lang/Object;)Ljava/lang/String;"] = df_format
+
+
+def install_enumset(jvm):
+    """java.util.EnumSet: iteration order is the natural order of the constants (specified), kept as an ordinal-sorted list"""
+    N = jvm.natives
+
+    def mk(items=()):
+        o = JObject("java/util/EnumSet")
+        o.native = sorted(set(items), key=lambda e: e.f["$ordinal"])
+        return o
+
+    def add(j, o, e):
+        if any(x is e for x in o.native):
+            return 0
+        o.native.append(e)
+        o.native.sort(key=lambda x: x.f["$ordinal"])
+        return 1
+
+    def remove(j, o, e):
+        for k, x in enumerate(o.native):
+            if x is e:
+                del o.native[k]
+                return 1
+        return 0
+
+    def all_of(j, cls):
+        vals = j.call_static(cls.native, "values", f"()[L{cls.native};")
+        return mk(vals.a)
+
+    N["java/util/EnumSet.noneOf"] = lambda j, cls: mk()
+    N["java/util/EnumSet.allOf"] = all_of
+    N["java/util/EnumSet.of"] = lambda j, *a: mk([x for x in a if not isinstance(x, JArray)] + [y for x in a if isinstance(x, JArray) for y in x.a])
+    N["java/util/EnumSet.copyOf"] = lambda j, c: mk(c.native)
+    N["java/util/EnumSet.clone"] = lambda j, o: mk(o.native)
+    N["java/util/EnumSet.add"] = add
+    N["java/util/EnumSet.remove"] = remove
+    N["java/util/EnumSet.contains"] = lambda j, o, e: 1 if any(x is e for x in o.native) else 0
+    N["java/util/EnumSet.size"] = lambda j, o: len(o.native)
+    N["java/util/EnumSet.isEmpty"] = lambda j, o: 0 if o.native else 1
+    N["java/util/EnumSet.clear"] = lambda j, o: o.native.clear()
+    N["java/util/EnumSet.addAll"] = lambda j, o, c: 1 if [add(j, o, e) for e in list(c.native)].count(1) else 0
+    N["java/util/EnumSet.iterator"] = N["java/util/ArrayList.iterator"]
+    N["java/util/EnumSet.stream"] = N["java/util/ArrayList.stream"]
+    N["java/util/EnumSet.forEach"] = N["java/util/ArrayList.forEach"]
+    ex = __import__("jvm_exec")
+    ex.JDK_SUPER["java/util/EnumSet"] = "java/util/AbstractSet"
+    ex.JDK_IFACES["java/util/EnumSet"] = ["java/util/Set", "java/util/Collection", "java/lang/Iterable"]

@@ -24,7 +24,8 @@ import jvm_natives  # noqa: E402
 
 REF = "/root/reference/Jar/"
 JARS = [REF + "NanoporeBC_UMI_finder-2.1.jar", REF + "lib/TwoFourBitNucAcidLibraryMaven-1.0.jar",
-        REF + "lib/Aliasi_ClusteringLib-1.0.jar", REF + "lib/commons-lang3-3.17.0.jar"]
+        REF + "lib/Aliasi_ClusteringLib-1.0.jar", REF + "lib/commons-lang3-3.17.0.jar", REF + "lib/htsjdk-4.1.3.jar",
+        REF + "lib/guava-33.3.1-jre.jar"]
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 TB = "com/rw/nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase"
@@ -407,8 +408,252 @@ def gen_polyat(g):
     out["sections"].append(g.finish(s))
     return out
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Whole records through the reference's pass 2: ChimeraFindernew.findSplitPositions -> PolyATadapterAnalyzer_{3p,5p}BCUMI.search
+# -> Parser.assignBarcode -> ReadFlags$Flags.finalizeFlag -> FastqRecordExt.getRecordForWriting, i.e. what Parser.call /
+# processOneRecord and the writer thread do per record (Parser.java:L92-124, L132-185; FastqWriterThreadPool.java:L300-306).
+# The driver below only builds the objects those methods take (parameters from Jar/config.xml through tools/ref_params.py,
+# the command-line fields NanoporeReadScannerMain sets, a barcode map) and calls them; statistics objects are left out.
+# ---------------------------------------------------------------------------------------------------------------------
+PAR = "com/rw/nanoporereadscanner/parameters/ParametersReadScannerApp"
+SCANTYPE = "com/rw/parameters/ParametersMainBase$SCANTYPE"
+GOPT = "com/google/common/base/Optional"
+MAIN = "com/rw/nanoporereadscanner/NanoporeReadScannerMain"
+FQR = "htsjdk/samtools/fastq/FastqRecord"
+FQX = "com/rw/nanoporereadscanner/readerwriter/FastqRecordExt"
+PARSER = "com/rw/nanoporereadscanner/analyzers/Parser"
+BCMAP = "com/rw/nanoporereadscanner/WorkerReadscanner$BarcodesMapForBCfinding"
+CRANK = "com/rw/nanoporereadscanner/WorkerReadscanner$CountsRank"
+KMERS = "com/rw/parameters/TSO_AdapterParameterBase$NucleicAcidInmutableOneBytePerBaseKmers"
+FLAGS = "com/rw/nanoporereadscanner/stats/ReadFlags$Flags"
+L2O = "it/unimi/dsi/fastutil/longs/Long2ObjectOpenHashMap"
 
-SECTIONS = {"twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat}
+
+def install_long2object(j):
+    """membership / lookup stand-in for the absent fastutil Long2ObjectOpenHashMap (superclass of BarcodesMapForBCfinding):
+    get / put / containsKey / keySet().contains; no iteration"""
+    N = j.natives
+
+    def store(o):
+        if o.native is None:
+            o.native = {}
+        return o.native
+
+    N[L2O + ".<init>"] = lambda jj, o, *a: store(o) and None
+    N[L2O + ".put:(JLjava/lang/Object;)Ljava/lang/Object;"] = lambda jj, o, k, v: store(o).__setitem__(k, v)
+    N[L2O + ".get:(J)Ljava/lang/Object;"] = lambda jj, o, k: store(o).get(k)
+    N[L2O + ".containsKey:(J)Z"] = lambda jj, o, k: 1 if k in store(o) else 0
+    N[L2O + ".size"] = lambda jj, o: len(store(o))
+
+    def key_set(jj, o):
+        ks = JObject("it/unimi/dsi/fastutil/longs/LongOpenHashSet")
+        ks.native = store(o).keys()  # live view: contains only
+        return ks
+
+    N[L2O + ".keySet"] = key_set
+    import jvm_exec
+
+    jvm_exec.JDK_SUPER[L2O] = "java/lang/Object"
+    jvm_exec.JDK_IFACES["it/unimi/dsi/fastutil/longs/LongOpenHashSet"] = ["java/util/Set", "it/unimi/dsi/fastutil/longs/LongSet"]
+
+
+class Pass2:
+    def __init__(self, g, five_prime, ed, dont_search_polya=False):
+        import ref_params
+
+        self.j = j = g.j
+        self.five = five_prime
+        install_long2object(j)
+        par, self.report = ref_params.load_config(j, PAR)
+        rs = par.f["readScannerParameters"]
+        rs.f["assignCellBCwithEditDistance"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JBox("java/lang/Integer", ed))
+        par.f["polyAT"].f["dontSearchPolyAFor5pBarcoding"] = 1 if dont_search_polya else 0   # -y (NanoporeReadScannerMain.java:L248)
+        par.f["scantype"] = j.get_static(SCANTYPE, "FIVEP_BARCODE" if five_prime else "THREEP_BARCODE")   # -h (L249)
+        for k in (("adapter_5p_for5pBarcoding", "adapter_3p_for5pBarcoding", "tso_for5pBarcoding") if five_prime else
+                  ("adapter_for3pBarcoding", "tso_for3pBarcoding")):
+            o = par.f[k]
+            j.invoke(j.find_method(o.cls, "validate", "()V"), [o])        # what ParametersReadScannerApp.validate() L107-130 calls
+        jc = j.load(MAIN)
+        jc.initialized = True          # the program's own static initialiser only builds the CLI option table
+        jc.statics["params"] = par     # PolyATadapterAnalyzer_* are constructed from NanoporeReadScannerMain.params (Parser.java:L96)
+        self.par = par
+        self.ap = par.f["adapter_5p_for5pBarcoding" if five_prime else "adapter_for3pBarcoding"]
+        self.max_mm = self.ap.f["maxNeedlemanMismatches"].v
+
+    def barcode_map(self, keys_ranks):
+        j = self.j
+        m = j.new_object(BCMAP)
+        m.native = {}
+        for k, rank in keys_ranks:
+            cr = j.new(CRANK, "(Ljava/lang/Integer;Ljava/lang/Integer;)V", JBox("java/lang/Integer", 1), JBox("java/lang/Integer", rank))
+            m.native[k] = cr
+        return m
+
+    def parser(self, bcmap):
+        j = self.j
+        p = j.new_object(PARSER)      # fields as Parser.<init> L70-78 assigns them; no chunk / statistics
+        p.f["parameters"] = self.par
+        p.f["hashMapForBCfinding"] = bcmap
+        p.f["assignedBarcodes2ndPass"] = j.natives["java/util/HashMap.<new>"](j)
+        p.f["pass"] = j.get_static(MAIN + "$Pass", "SECOND")
+        return p
+
+    def record(self, name, seq, qual):
+        j = self.j
+        rec = j.new(FQR, "(Ljava/lang/String;Ljava/lang/String;Ljava/lang/String;Ljava/lang/String;)V", name, seq, "", qual)
+        return j.new(FQX, f"(L{FQR};)V", rec)
+
+    def process(self, parser, fq, pass2=True):
+        """Parser.processOneRecord L92-114 without the statistics"""
+        j = self.j
+        failed = j.call_virtual(j.get_static(FLAGS, "FAILED"), "getValue", "()J")
+        sr = fq.f["scanResult"]
+        if (sr.f["flag"] & failed) == 0:
+            cls = "com/rw/nanoporereadscanner/analyzers/PolyATadapterAnalyzer_" + ("5pBCUMI" if self.five else "3pBCUMI")
+            pa = j.new(cls, f"(L{PAR};)V", self.par)
+            kmers = self.ap.f["bytesequence"] if pass2 else j.call_virtual(self.ap.f["bytesequence_complete"], "get", "()Ljava/lang/Object;")
+            j.call_virtual(pa, "search", f"(L{FQX};L{KMERS};I)V", fq, kmers, self.max_mm + (1 if self.five else 0))
+            if pass2 and j.call_virtual(sr, "adapterFound", "()Z"):
+                j.invoke(parser.cls and j.load(PARSER).methods[("assignBarcode", f"(L{FQX};)V")], [parser, fq])
+        sr.f["flag"] = j.call_static(FLAGS, "finalizeFlag", "(J)J", sr.f["flag"])
+        return fq
+
+    def describe(self, fq, read_id):
+        j = self.j
+        sr = fq.f["scanResult"]
+
+        def iv(o, k):
+            v = None if o is None else o.f.get(k)
+            if isinstance(v, JObject) and isinstance(v.native, tuple):   # java.util.Optional
+                v = v.native[0]
+            if isinstance(v, JObject) and "Optional" in v.cls:            # com.google.common.base.Optional
+                v = j.call_virtual(v, "orNull", "()Ljava/lang/Object;")
+            return None if v is None else (v.v if isinstance(v, JBox) else v)
+
+        ad, pa, tso, bc = sr.f["adapter_result"], sr.f["polyA_Result"], sr.f["tSOresult"], sr.f["barcode_Result"]
+        passed = bool(j.call_virtual(fq, "passed", "()Z"))
+        rec = j.call_virtual(fq, "getRecordForWriting", f"(Lcom/rw/parameters/ReadScannerParameters;ZLjava/lang/Integer;)L{FQR};",
+                             self.par.f["readScannerParameters"], 1 if self.five else 0, JBox("java/lang/Integer", read_id) if passed else None)
+        out = {"flag": u64(sr.f["flag"]), "forward": sr.f["forward"].f["$name"], "passed": passed,
+               "adapter": None if ad is None else [iv(ad, "start"), iv(ad, "end")],
+               "polya": None if pa is None else [iv(pa, "start"), iv(pa, "end")],
+               "tso": None if tso is None else [iv(tso, "start"), iv(tso, "end")],
+               "barcode": None,
+               "written": {"name": rec.f["readName"], "bases": rec.f["readString"], "quality_header": rec.f["qualityHeader"],
+                           "qualities": rec.f["baseQualityString"]}}
+        if bc is not None and bc.f.get("barcodeseq") is not None:
+            out["barcode"] = {"seq": j.call_virtual(bc.f["barcodeseq"], "toString", "()Ljava/lang/String;"), "ed": iv(bc, "editDistance"),
+                              "ed_second": iv(bc, "editDistanceSecondBest"), "start": iv(bc, "start"), "end": iv(bc, "end"), "rank": iv(bc, "rank")}
+        return out
+
+
+TSO = "AAGCAGTGGTATCAACGCAGAGTACATGGG"
+AD3 = "CTACACGACGCTCTTCCGATCT"
+
+
+def noisy(rng, q, rate):
+    out = []
+    for c in q:
+        r = rng.random()
+        if r < rate * 0.4:
+            out.append(rng.choice("ACGT"))
+        elif r < rate * 0.7:
+            continue
+        elif r < rate:
+            out.append(c)
+            out.append(rng.choice("ACGT"))
+        else:
+            out.append(c)
+    return "".join(out)
+
+
+def synth_read(rng, bcs, five_prime, kind):
+    """one synthetic read; kind varies error rate / strand / structure (SURVEY 8d layout)"""
+    bc, umi = rng.choice(bcs), rnd_seq(rng, 12)
+    cdna = rnd_seq(rng, rng.randrange(260, 700))
+    rate = (0.0, 0.02, 0.05, 0.08, 0.12)[kind % 5]
+    if five_prime:
+        mol = AD3 + bc + umi + "TTTCTTATATGGG" + cdna + ("A" * rng.randrange(18, 40) if kind % 3 else "") + rnd_seq(rng, rng.randrange(0, 30))
+    else:
+        mol = TSO + cdna + "A" * rng.randrange(18, 45) + revcomp_str(umi) + revcomp_str(bc) + revcomp_str(AD3)
+    if kind % 7 == 6:                       # no adapter at all
+        mol = rnd_seq(rng, len(mol))
+    mol = noisy(rng, mol, rate)
+    if kind % 11 == 10:
+        mol = mol[:rng.randrange(120, 199)]  # below minReadLength
+    if kind % 13 == 7:
+        k = rng.randrange(len(mol))
+        mol = mol[:k] + "N" + mol[k + 1:]
+    if rng.random() < 0.5:
+        mol = revcomp_str(mol)
+    qual = "".join(chr(33 + rng.randrange(3, 35)) for _ in mol)
+    return mol, qual, bc
+
+
+def gen_pass2(g, n_reads=36, five_prime=False, ed=1, seed=707, dont_search_polya=False, tag="3p"):
+    j = g.j
+    rng = random.Random(seed)
+    p2 = Pass2(g, five_prime, ed, dont_search_polya)
+    enc = lambda q: j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q))  # noqa: E731
+    bcs = sorted({rnd_seq(rng, 16) for _ in range(40)})
+    extra = [mutate(rng, b, 1)[:16].ljust(16, "C") for b in bcs[:10]]
+    bcs = sorted(set(bcs + extra))
+    ranks = {b: k + 1 for k, b in enumerate(bcs)}
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar (+ TwoFourBitNucAcidLibraryMaven-1.0.jar, htsjdk-4.1.3.jar, guava, commons-lang3 as shipped in Jar/lib)",
+           "sections": []}
+    s = g.section(f"pass 2 of scanfastq per record, {'5-prime' if five_prime else '3-prime'} barcoding, --bcEditDistance {ed}"
+                  + (", --noPolyARequired" if dont_search_polya else "") +
+                  ": PolyATadapterAnalyzer.search -> Parser.assignBarcode -> ReadFlags$Flags.finalizeFlag -> FastqRecordExt.getRecordForWriting "
+                  "(read id = 1 + index of the case for passed records).  Parameters: Jar/config.xml as shipped.  Each case ran under three different "
+                  "iteration orders of java.util.HashMap / HashSet; `hash_orders_agree` = all three gave this result.",
+                  PARSER, "processOneRecord L92-114 / assignBarcode L195-315 / getRecordForWriting L209-311")
+    s["barcodes"] = bcs
+    s["ranks"] = [ranks[b] for b in bcs]
+    s["five_prime"], s["ed"], s["dont_search_polya"] = five_prime, ed, dont_search_polya
+    s["config_report"] = p2.report
+    vals = j.call_static(FLAGS, "values", f"()[L{FLAGS};")
+    s["flag_values"] = {v.f["$name"]: u64(j.call_virtual(v, "getValue", "()J")) for v in vals.a}   # ReadFlags$Flags.getValue()
+    for idx in range(n_reads):
+        seq, qual, bc = synth_read(rng, bcs, five_prime, idx)
+        name = f"read{idx:04d} runid=abc ch={idx % 512}"
+        results = []
+        for order in ("insertion", "reverse", ("shuffle", idx + 1)):
+            j.hash_order = order
+            bcmap = p2.barcode_map([(enc(b), ranks[b]) for b in bcs])
+            parser = p2.parser(bcmap)
+            fq = p2.record(name, seq, qual)
+            try:
+                p2.process(parser, fq)
+                results.append(p2.describe(fq, idx + 1))
+            except JavaThrow as e:
+                results.append({"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:6]})
+        j.hash_order = None
+        agree = all(r == results[0] for r in results[1:])
+        s["cases"].append({"name": name, "seq": seq, "qual": qual, "planted_barcode": bc, "hash_orders_agree": agree, "result": results[0]})
+        if idx % 6 == 0:
+            print(f"  pass2[{tag}] {idx + 1}/{n_reads}  {time.time() - g.t0:.0f}s", flush=True)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def gen_pass2_3p(g):
+    return gen_pass2(g, 40, False, 1, 707, tag="3p")
+
+
+def gen_pass2_3p_ed2(g):
+    return gen_pass2(g, 8, False, 2, 717, tag="3p ed2")
+
+
+def gen_pass2_5p(g):
+    return gen_pass2(g, 30, True, 1, 727, dont_search_polya=True, tag="5p -y")
+
+
+def gen_pass2_5p_polya(g):
+    return gen_pass2(g, 14, True, 1, 737, dont_search_polya=False, tag="5p")
+
+
+SECTIONS = {"twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+            "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya}
 
 
 def main():
