@@ -477,8 +477,8 @@ int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes,
 
 /* `assignumis` for one chunk of BamReader (the records between two cuts of BamReader.run): OneBatchExecutor.call +
  * UmiClustering.cluster after ReadGrouper.groupSams (FJ!umifinder/OneBatchExecutor.java:L61-90,
- * FJ!umifinder/analyzers/clustering/UmiClustering.java:L97-161, FJ!umifinder/bamreaders/ReadGrouper.java:L82-230), 3'
- * barcoding: names parsed as FastqRecordExt.getScanDatFromReadName does, clustering position, region grouping, K-UMI,
+ * FJ!umifinder/analyzers/clustering/UmiClustering.java:L97-161, FJ!umifinder/bamreaders/ReadGrouper.java:L82-230), 3' or
+ * 5' barcoding (cfg->five_prime): names parsed as FastqRecordExt.getScanDatFromReadName does, clustering position, region grouping, K-UMI,
  * clustering.  names: the QNAMEs back to back, name i = names[name_off[i] .. name_off[i+1]); cigars: BAM-encoded ops of
  * all records, record i = cigars[cigar_off[i] .. cigar_off[i+1]); flags / pos0 as in the BAM record.  out[i] for the first
  * *n_done records is final; the others must be handed in again at the front of the next chunk (keep_data_end). */
@@ -488,7 +488,10 @@ typedef struct {
     int32_t bc_edit_limit;     /* -b: barcodes with a larger ed are ignored (FastqRecordExt.java:L450-456); -1 = no limit */
     int32_t keep_data_end;     /* 1: more records of this chromosome follow (ReadGrouper.java:L171-184) */
     int32_t n_threads;         /* host threads of the clustering */
-    int32_t reserved;
+    int32_t five_prime;        /* -p: 5' barcoding (UmiFinderMain.java:L249): X= read forwards, barcode end = bcEnd - AE + 3 on it
+                                  (ClusteringEditDistanceBase.java:L312-313, FastqRecordExt.java:L378); clustering position = reference
+                                  position under read position AE + cell_bc_length + umi_length + grouping_distance
+                                  (NanoporeRead$ReadScanData.java:L90-92) */
     const smi_umi_cluster_config *cluster; /* NULL: shipped values */
 } smi_assignumis_config;
 #define SMI_UMI_HAS_BC 1u    /* the name carries a barcode (the record goes to the output BAM) */

@@ -126,6 +126,7 @@ int sor_fastq_record(const char *read_name, const char *qual_header, const char 
 int sor_umi_pair(const uint8_t *w1, const uint8_t *w2);
 void sor_umi_matrix(const uint8_t *windows, int n, uint8_t *out);
 int sor_umi_window_3p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14);
+int sor_umi_window_5p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14);
 int sor_limited_compare(const uint8_t *a, int n, const uint8_t *b, int m, int threshold);
 
 /* ---- pass-1 finalize (sor_final.c) ---- */

@@ -273,6 +273,14 @@ def umi_window_3p(x, adapter_end, bc_end):
     return None if rc else out
 
 
+def umi_window_5p(x, adapter_end, bc_end):
+    out = np.zeros(14, dtype=np.uint8)
+    L = lib()
+    L.sor_umi_window_5p.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rc = L.sor_umi_window_5p(x.encode(), len(x), adapter_end, bc_end, out.ctypes.data)
+    return None if rc else out
+
+
 def limited_compare(a, b, threshold=4):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     b = np.ascontiguousarray(b, dtype=np.uint8)

@@ -105,6 +105,20 @@ int sor_umi_window_3p(const char *x, int xlen, int adapter_end, int bc_end, uint
     return 0;
 }
 
+/* 5' barcoding (ClusteringEditDistanceBase.java:L312-313: getSeq(), not getSeqRevComp(); bcEnd on the short sequence =
+ * bcEnd - adapterend + nbasesOfAdapterSeqInReadname, FastqRecordExt.java:L378 with is5pBarcoding): x = the X= string
+ * (stranded[AE-2 .. AE+39]) read forwards; the three 12-mers start at 1-based bcEnd' + 1 + {-1, 0, +1} (L322, L329). */
+int sor_umi_window_5p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14) {
+    int pos = bc_end - adapter_end + 3;
+    if (pos < 1 || pos + 13 > xlen) return -1;
+    for (int k = 0; k < 14; k++) {
+        int code = sor_fourbit_encode_char((unsigned char)x[pos - 1 + k]); /* 1-based pos + k on x */
+        if (code < 0) return -1;
+        out14[k] = (uint8_t)code;
+    }
+    return 0;
+}
+
 int sor_limited_compare(const uint8_t *a, int n, const uint8_t *b, int m, int threshold) {
     return limited_compare(a, n, b, m, threshold);
 }

@@ -1,7 +1,8 @@
 """Host-side mirror of the reference's `assignumis` worker for one chunk of aligned reads (UmiFinderWorker ->
 ReadGrouper.groupSams -> UmiClustering.cluster, FJ!umifinder/UmiFinderWorker.java, FJ!umifinder/bamreaders/ReadGrouper.java:L82-260,
 FJ!umifinder/analyzers/clustering/UmiClustering.java:L97-161): region grouping (host C++), UMI pair distances (K-UMI on
-the device), clustering (host C++), and the values of the tags U8 / U7 / U1 / U2.  3' barcoding.  No CPU fallback.
+the device), clustering (host C++), and the values of the tags U8 / U7 / U1 / U2.  3' barcoding by default, 5' barcoding with `five_prime=True` (the reference's `-p`,
+UmiFinderMain.java:L249).  No CPU fallback.
 
 Per read the caller supplies what the reference parses from the BAM record: the read name written by scanfastq
 (FastqRecordExt.getScanDatFromReadName, FastqRecordExt.java:L395-496: X=, AE=, bcEnd=, Q=, cellBC), the strand flag
@@ -76,9 +77,15 @@ def parse_name(name):
     return dict(cell=d["bc"]["seq"], ae=d["ae"], bc_end=d["bc"]["end"], x=d["x"].split(" ")[0], q=d["q"])
 
 
-def umi_window(x, adapter_end, bc_end):
-    """14 bases as 4-bit codes: the three 12-mers at offsets -1, 0, +1 behind the barcode on the reverse complement of X=
-    (ClusteringEditDistanceBase L297-350; getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378); None if out of range"""
+def umi_window(x, adapter_end, bc_end, five_prime=False):
+    """14 bases as 4-bit codes: the three 12-mers at offsets -1, 0, +1 behind the barcode (ClusteringEditDistanceBase L297-350;
+    getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378).  3': on the reverse complement of X= (getSeqRevComp), barcode end
+    = AE + 3 - bcEnd; 5': on X= itself (getSeq, L312-313), barcode end = bcEnd - AE + 3.  None if out of range"""
+    if five_prime:
+        pos = bc_end - adapter_end + 3
+        if pos < 1 or pos + 13 > len(x):
+            return None
+        return [_CODE.get(x[pos - 1 + k], 15) for k in range(14)]
     pos = adapter_end + 3 - bc_end
     if pos < 1 or pos + 13 > len(x):
         return None
@@ -92,7 +99,7 @@ def pack_window(w):
     return v
 
 
-def assign_umis(ctx, names, positions, reverse, max_dist=500, cluster_cfg=None, n_threads=4):
+def assign_umis(ctx, names, positions, reverse, max_dist=500, cluster_cfg=None, n_threads=4, five_prime=False):
     """-> list (one per read) of None or dict(U8, U7, U1, U2, region, center) -- the tag VALUES the reference writes in
     ClusterOneBase.setSamflagsAndStatsForClustered; reads without barcode / position / neighbours get None"""
     n = len(names)
@@ -100,12 +107,12 @@ def assign_umis(ctx, names, positions, reverse, max_dist=500, cluster_cfg=None, 
     # every read whose name carries scan data has a clustering position, barcode or not (generateReadScanData L86-92)
     pos = [p if ("_REV_" in names[i] or "_FWD_" in names[i]) else None for i, p in enumerate(positions)]
     region, _ = _lib.region_group(pos, reverse, max_dist=max_dist, keep_data_end=False)
-    return _assign_in_regions(ctx, info, region, cluster_cfg, n_threads)
+    return _assign_in_regions(ctx, info, region, cluster_cfg, n_threads, five_prime)
 
 
-def _assign_in_regions(ctx, info, region, cluster_cfg=None, n_threads=4):
+def _assign_in_regions(ctx, info, region, cluster_cfg=None, n_threads=4, five_prime=False):
     n = len(info)
-    wins = [umi_window(f["x"], f["ae"], f["bc_end"]) if f is not None else None for f in info]
+    wins = [umi_window(f["x"], f["ae"], f["bc_end"], five_prime) if f is not None else None for f in info]
     groups = {}
     for i in range(n):
         if info[i] is not None and region[i] >= 0 and wins[i] is not None:
@@ -160,17 +167,22 @@ def read_name(bam, rec):
     return bam[o:o + n].tobytes().decode()
 
 
-def clustering_position(bam, rec, scan, grouping_distance=100):
-    """NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116), 3' barcoding: reference position under
-    read position polyA start - distanceFromReadEndForGrouping; None for unmapped reads and positions outside the alignment"""
+def clustering_position(bam, rec, scan, grouping_distance=100, five_prime=False, bc_length=16, umi_length=12):
+    """NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116): reference position under read position
+    polyA start - distanceFromReadEndForGrouping (3') or adapter end + cell_bc_length + umi_length + that distance (5', L90);
+    None for unmapped reads and positions outside the alignment"""
     if scan is None or int(rec["flag"]) & 4:
         return None
+    if not five_prime and scan["ps"] is None:
+        return None  # the reference dereferences polyA_Result here: only reads scanned with --noPolyARequired lack it
     o = int(rec["cigar_off"])
     cigar = bam[o:o + 4 * int(rec["n_cigar"])].view("<u4")
-    return _lib.ref_position_at_read_position_raw(cigar, int(rec["pos"]) + 1, scan["ps"] - grouping_distance)
+    read_pos = scan["ae"] + bc_length + umi_length + grouping_distance if five_prime else scan["ps"] - grouping_distance
+    return _lib.ref_position_at_read_position_raw(cigar, int(rec["pos"]) + 1, read_pos)
 
 
-def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=None, cluster_cfg=None, n_threads=4, native=False):
+def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=None, cluster_cfg=None, n_threads=4, native=False,
+                    five_prime=False, batches=None):
     """`assignumis` over a whole BAM -> (names, tags): tags[i] as assign_umis returns them, in BAM order.  Chunks as
     BamReader.run cuts them: `chunk_size` records or the end of a chromosome; within a chromosome the regions near the
     right edge are carried into the next chunk (ReadGrouper.groupSams keepDataEnd, smi_region_group)."""
@@ -178,9 +190,9 @@ def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=N
     n = recs.size
     names = [read_name(bam, r) for r in recs]
     if native:
-        return names, _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads)
+        return names, _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads, five_prime, batches)
     scans = [scan_data_from_name(nm, bc_edit_limit) for nm in names]
-    pos = [clustering_position(bam, recs[i], scans[i]) for i in range(n)]
+    pos = [clustering_position(bam, recs[i], scans[i], five_prime=five_prime) for i in range(n)]
     rev = [bool(int(r["flag"]) & 16) for r in recs]
     info = []
     for d in scans:
@@ -193,7 +205,9 @@ def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=N
         nonlocal region_base
         region, n_done = _lib.region_group([pos[i] for i in cur], [rev[i] for i in cur], max_dist=max_dist, keep_data_end=keep)
         done = cur[:n_done]
-        res = _assign_in_regions(ctx, [info[i] for i in done], region[:n_done], cluster_cfg, n_threads)
+        if batches is not None:
+            batches.append(list(done))  # what one OneBatchExecutor hands to the writers (sorted per batch, $BamWriters L421)
+        res = _assign_in_regions(ctx, [info[i] for i in done], region[:n_done], cluster_cfg, n_threads, five_prime)
         for i, t in zip(done, res):
             if t is not None and not t.get("skipped"):
                 t["center"] = done[t["center"]]
@@ -228,7 +242,7 @@ def _run_chunks(recs, chunk_size, flush):
         cur = flush(cur, keep=False)
 
 
-def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads):
+def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads, five_prime=False, batches=None):
     """the same through smi_assignumis_chunk: one native call per chunk (name parsing, positions, grouping, K-UMI, clustering)"""
     tags = [None] * recs.size
     cig = [bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4") for r in recs]
@@ -237,7 +251,10 @@ def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit
     def flush(cur, keep):
         nonlocal region_base
         out, n_done = ctx.assignumis_chunk([names[i] for i in cur], recs["flag"][cur], recs["pos"][cur], [cig[i] for i in cur],
-                                           keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads)
+                                           keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
+                                           five_prime=five_prime)
+        if batches is not None:
+            batches.append(list(cur[:n_done]))
         top = -1
         for k in range(n_done):
             t, i = out[k], cur[k]
@@ -375,17 +392,20 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
     records of a chunk in coordinate-comparator order with the tags of record_tag_sets added (GE needs the refFlat
     annotator, which is not built)."""
     _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
-    names, tags = assign_umis_bam(ctx, data, chunk_size=chunk_size, n_threads=n_threads, **kw)
+    batches = []
+    names, tags = assign_umis_bam(ctx, data, chunk_size=chunk_size, n_threads=n_threads, batches=batches, **kw)
+    five_prime = bool(kw.get("five_prime", False))
     scans = [scan_data_from_name(nm, kw.get("bc_edit_limit")) for nm in names]
     header_end = int(recs[0]["rec_off"]) if recs.size else bam.size
     out_bc, out_umi = [bam[:header_end].tobytes()], [bam[:header_end].tobytes()]
-    # BamReader cuts chunks; BamWriters sorts each written batch (L421): batches = the flushes of assign_umis_bam
-    order = sorted(range(recs.size), key=lambda i: _coordinate_key(recs[i], names[i]))
+    # BamReader cuts chunks; BamWriters sorts each written BATCH with the coordinate comparator (L421), not the file: batches =
+    # the flushes of assign_umis_bam, in the order they complete
+    order = [i for b in batches for i in sorted(b, key=lambda k: _coordinate_key(recs[k], names[k]))]
     for i in order:
         d, r = scans[i], recs[i]
         u7 = None
         if d is not None and d["bc"] is not None and d["bc"]["end"] is not None and d["x"]:
-            w = umi_window(d["x"], d["ae"], d["bc"]["end"])
+            w = umi_window(d["x"], d["ae"], d["bc"]["end"], five_prime)
             u7 = None if w is None else "".join(_DEC[c] for c in w[1:13])
         calls, has_bc, clustered = record_tag_sets(d, tags[i], u7)
         if not has_bc:

@@ -413,11 +413,15 @@ inline char dec4(uint32_t c) { return c == 1 ? 'A' : c == 2 ? 'G' : c == 4 ? 'C'
 
 // the three 12-mers at offsets -1, 0, +1 behind the barcode on the reverse complement of X= (ClusteringEditDistanceBase L297-350,
 // getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378): 14 bases, 4-bit codes, base k in bits [4k+3:4k]
-bool umi_window(const NameData &d, uint64_t *packed) {
-    const long pos = d.ae + 3 - d.bc_end;
+// 5' barcoding: X= is read forwards (getSeq(), L312-313) and the barcode end on it is bcEnd - AE + 3 (L378 with is5pBarcoding)
+bool umi_window(const NameData &d, bool five_prime, uint64_t *packed) {
+    const long pos = five_prime ? d.bc_end - d.ae + 3 : d.ae + 3 - d.bc_end;
     if (!d.x || pos < 1 || pos + 13 > (long)d.x_len) return false;
     uint64_t w = 0;
-    for (int k = 0; k < 14; k++) w |= (uint64_t)comp4(code4(d.x[d.x_len - (size_t)(pos + k)])) << (4 * k);
+    for (int k = 0; k < 14; k++) {
+        const uint32_t c = five_prime ? code4(d.x[(size_t)(pos - 1 + k)]) : comp4(code4(d.x[d.x_len - (size_t)(pos + k)]));
+        w |= (uint64_t)c << (4 * k);
+    }
     *packed = w;
     return true;
 }
@@ -439,12 +443,14 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     for (int32_t i = 0; i < n; i++) {
         SMI_RC(parse_name(names + name_off[i], name_off[i + 1] - name_off[i], cfg->bc_edit_limit, nd[i]));
         rev[i] = (flags[i] & 16) ? 1 : 0;
-        // NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116), 3': reference position under read
-        // position polyA start - distanceFromReadEndForGrouping
-        if (nd[i].present && nd[i].has_ps && !(flags[i] & 4)) {
+        // NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116): reference position under read position
+        // polyA start - distanceFromReadEndForGrouping (3'), adapter end + cell_bc_length + umi_length + that distance (5')
+        const bool five = cfg->five_prime != 0;
+        if (nd[i].present && (five || nd[i].has_ps) && !(flags[i] & 4)) {
             int32_t p = 0;
+            const int32_t read_pos = five ? (int32_t)nd[i].ae + 16 + 12 + cfg->grouping_distance : (int32_t)nd[i].ps - cfg->grouping_distance;
             const int rc = smi_ref_position_at_read_position(cigars + cigar_off[i], (int32_t)(cigar_off[i + 1] - cigar_off[i]), pos0[i] + 1,
-                                                             (int32_t)nd[i].ps - cfg->grouping_distance, &p);
+                                                             read_pos, &p);
             if (rc < 0) return rc;
             if (rc == 1) {
                 has_pos[i] = 1;
@@ -470,7 +476,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
         const NameData &d = nd[i];
         const bool bc_ok = d.present && d.has_bc && d.has_bc_end && d.x && d.has_q;
         uint64_t w = 0;
-        const bool has_w = bc_ok && umi_window(d, &w);
+        const bool has_w = bc_ok && umi_window(d, cfg->five_prime != 0, &w);
         if (d.present && d.has_bc) out[i].flags |= SMI_UMI_HAS_BC;
         if (has_w) {
             win[i] = w;

@@ -269,7 +269,7 @@ UMI_HAS_BC, UMI_HAS_U7, UMI_CLUSTERED, UMI_SKIPPED = 1, 2, 4, 8
 class AssignUmisConfig(ctypes.Structure):
     """smi_assignumis_config"""
     _fields_ = [("max_dist", ctypes.c_int32), ("grouping_distance", ctypes.c_int32), ("bc_edit_limit", ctypes.c_int32),
-                ("keep_data_end", ctypes.c_int32), ("n_threads", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("keep_data_end", ctypes.c_int32), ("n_threads", ctypes.c_int32), ("five_prime", ctypes.c_int32),
                 ("cluster", ctypes.c_void_p)]
 
 
@@ -578,7 +578,8 @@ class Context:
                                                         _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
         return n.value
 
-    def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4):
+    def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
+                         five_prime=False):
         """one BamReader chunk through the native worker -> (UMI_TAG_DTYPE array, n_done); names: list of QNAME strings,
         cigars: list of numpy uint32 arrays (BAM encoding)"""
         n = len(names)
@@ -594,6 +595,7 @@ class Context:
         cfg = AssignUmisConfig()
         self._check(self._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
         cfg.max_dist, cfg.keep_data_end, cfg.n_threads = int(max_dist), int(keep_data_end), int(n_threads)
+        cfg.five_prime = int(bool(five_prime))
         cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
         out = np.zeros(max(n, 1), dtype=UMI_TAG_DTYPE)
         nd = ctypes.c_int32(0)

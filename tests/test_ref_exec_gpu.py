@@ -50,3 +50,39 @@ def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name):
         n_passed += want["passed"]
         n_bc += want["barcode"] is not None
     assert n_checked >= len(sec["cases"]) * 0.8 and n_passed >= 3 and n_bc >= 2
+
+
+@pytest.mark.parametrize("name", ["umi_3p", "umi_5p"])
+def test_k_umi_distances_equal_reference_bytecode(pkg, gpu_ctx, name):
+    """K-UMI on the windows the product cuts out of the read names == ClusteringEditDistanceBase.calcEditDistances executed from
+    the reference's class files (3' and 5' / -p)"""
+    import importlib
+
+    import torch
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
+        sec = json.load(f)["sections"][0]
+    five = sec["five_prime"]
+    wins = []
+    for nm in sec["names"]:
+        d = au.scan_data_from_name(nm["name"])
+        w = au.umi_window(d["x"], d["ae"], d["bc"]["end"], five)
+        assert w is not None
+        wins.append(au.pack_window(w))
+    n = len(wins)
+    dev = torch.device("cuda", gpu_ctx.device)
+    go, po, mo = gpu_ctx.umi_offsets([n])
+    d_out = torch.zeros(int(mo[-1]), dtype=torch.uint8, device=dev)
+    gpu_ctx.umi_dist_device(torch.from_numpy(np.array(wins, dtype=np.uint64).view(np.int64)).to(dev), torch.from_numpy(go.view(np.int32)).to(dev),
+                            torch.from_numpy(po.view(np.int64)).to(dev), torch.from_numpy(mo.view(np.int64)).to(dev), 1, int(po[-1]), d_out)
+    torch.cuda.synchronize()
+    m = d_out.cpu().numpy().reshape(n, n)
+    pos = {"MINUSONE": 0, "ZERO": 1, "PLUSONE": 2}
+    for c in sec["cases"]:
+        for (a, b), want in (((c["i"], c["j"]), c["distance"]), ((c["j"], c["i"]), c["reverse"])):
+            r = int(m[a, b])
+            if a > b:
+                # the reference fills [v][i] with the TRANSPOSED copy of [i][v] (L213-216), not with calcEditDistances(v, i)
+                want = {"ed": c["distance"]["ed"], "pos1": c["distance"]["pos2"], "pos2": c["distance"]["pos1"]}
+            assert (r & 15, (r >> 4) & 3, (r >> 6) & 3) == (want["ed"], pos[want["pos1"]], pos[want["pos2"]]), (a, b, want, r)

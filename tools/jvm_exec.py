@@ -989,7 +989,7 @@ class JVM:
                             r = None
                         elif isinstance(recv, JLambda) and mname == recv.sam:
                             r = self.call_lambda(recv, cargs)
-                        elif isinstance(recv, JObject) and recv.cls in ("$Comparator", "$Fn") and mname in ("compare", "apply", "test", "accept", "applyAsInt"):
+                        elif isinstance(recv, JObject) and recv.cls in ("$Comparator", "$Fn") and mname in ("compare", "apply", "test", "accept", "applyAsInt", "get"):
                             r = recv.native(*cargs)
                         else:
                             if nm == "invokespecial":

@@ -344,6 +344,19 @@ def install(jvm):
     N["java/lang/Integer.parseInt:(Ljava/lang/String;)I"] = lambda j, s: _parse_int(j, s, 32)
     N["java/lang/Long.parseLong:(Ljava/lang/String;)J"] = lambda j, s: _parse_int(j, s, 64)
     N["java/lang/Integer.valueOf:(Ljava/lang/String;)Ljava/lang/Integer;"] = lambda j, s: JBox("java/lang/Integer", _parse_int(j, s, 32))
+    def parse_float(j, t, single):
+        u = t.strip()
+        try:
+            if not u or any(ch not in "0123456789+-.eE" for ch in u.rstrip("fFdD")):
+                raise ValueError
+            v = float(u.rstrip("fFdD"))
+        except ValueError:
+            j.throw("java/lang/NumberFormatException", f'For input string: "{t}"')
+        return f32(v) if single else v      # decimal -> nearest double -> nearest float; exact for the short decimals in read names
+
+    N["java/lang/Float.parseFloat:(Ljava/lang/String;)F"] = lambda j, t: parse_float(j, t, True)
+    N["java/lang/Double.parseDouble:(Ljava/lang/String;)D"] = lambda j, t: parse_float(j, t, False)
+    N["java/lang/Float.valueOf:(Ljava/lang/String;)Ljava/lang/Float;"] = lambda j, t: JBox("java/lang/Float", parse_float(j, t, True))
     N["java/lang/Integer.bitCount"] = lambda j, v: bin(v & 0xFFFFFFFF).count("1")
     N["java/lang/Long.bitCount"] = lambda j, v: bin(v & 0xFFFFFFFFFFFFFFFF).count("1")
     N["java/lang/Long.toBinaryString"] = lambda j, v: bin(v & 0xFFFFFFFFFFFFFFFF)[2:]

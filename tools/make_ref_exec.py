@@ -651,9 +651,129 @@ def gen_pass2_5p(g):
 def gen_pass2_5p_polya(g):
     return gen_pass2(g, 14, True, 1, 737, dont_search_polya=False, tag="5p")
 
+# ---------------------------------------------------------------------------------------------------------------------
+# assignumis: read name -> scan data (FastqRecordExt.getScanDatFromReadName L395-496) -> UMI pair distance
+# (ClusteringEditDistanceBase.calcEditDistances = lambda$static$7 L297-350 + calcBestEditDistance L67-80), 3' and 5' (-p)
+# ---------------------------------------------------------------------------------------------------------------------
+UPAR = "com/rw/umifinder/parameters/ParametersBarcodeUMiFinderAppParams"
+CED = "com/rw/clustering/ClusteringEditDistanceBase"
+ONR = "com/rw/umifinder/reads/nanopore/OneNanoporeResult"
+NREAD = "com/rw/umifinder/reads/nanopore/NanoporeRead"
+RSD = "com/rw/umifinder/reads/nanopore/NanoporeRead$ReadScanData"
+
+
+class UmiSide:
+    def __init__(self, g, five_prime):
+        import ref_params
+
+        self.j = j = g.j
+        self.par, self.report = ref_params.load_config(j, UPAR)
+        self.par.f["scantype"] = j.get_static(SCANTYPE, "FIVEP_BARCODE" if five_prime else "THREEP_BARCODE")   # -p (UmiFinderMain.java:L249)
+        self.five = five_prime
+
+    def scan_data(self, name):
+        """NanoporeRead$ReadScanData.generateReadScanData L86 without the SAM record: the name is all it parses"""
+        j = self.j
+        sup = j.natives["java/util/function/Function.identity"](j)      # placeholder object; replaced below by a real supplier
+        sup.native = lambda *a: j.new(RSD)                                   # Supplier.get -> new ReadScanData()  (L86: ReadScanData::new)
+        opt = j.call_static(FQX, "getScanDatFromReadName", f"(Ljava/lang/String;L{UPAR};Ljava/util/function/Supplier;)L{GOPT};", name, self.par, sup)
+        return j.call_virtual(opt, "orNull", "()Ljava/lang/Object;")
+
+    def result_for(self, sd):
+        j = self.j
+        nr = j.new_object(NREAD)
+        nr.f["readScanData"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", sd)
+        o = j.new_object(ONR)
+        o.f["nanoporeRead"] = nr
+        return o
+
+    def distance(self, r1, r2):
+        j = self.j
+        f = j.get_static(CED, "calcEditDistances")
+        ced = j.call_lambda(f, [r1, r2, self.par])
+        b = ced.f["bestEditDistance"]
+        return {"ed": j.call_virtual(b, "getED", "()B"),
+                "pos1": j.call_virtual(b, "getPos1", "()Lcom/rw/clustering/PlusMinusOnePosData$PlusMinusOneEnum;").f["$name"],
+                "pos2": j.call_virtual(b, "getPos2", "()Lcom/rw/clustering/PlusMinusOnePosData$PlusMinusOneEnum;").f["$name"]}
+
+
+def fake_name(rng, k, five_prime, bc, umi, rev, ae, shift, ed=0):
+    """a read name in scanfastq's format around a given UMI (the barcode / adapter neighbourhood is synthetic)"""
+    ad3 = "AGA"                      # the three adapter bases the name carries (nbasesOfAdapterSeqInReadname)
+    if five_prime:
+        bc_start, bc_end = ae + 1 + shift, ae + 16 + shift
+        x = ("TCT" + rnd_seq(rng, shift) + bc + umi + rnd_seq(rng, 40))[:42] if shift >= 0 else ("TCT" + bc[-shift:] + umi + rnd_seq(rng, 40))[:42]
+        core = f"AE={ae}_bc={bc}_ed={ed}_bcStart={bc_start}_bcEnd={bc_end}"
+    else:
+        bc_start, bc_end = ae - 1 + shift, ae - 16 + shift
+        stranded = rnd_seq(rng, 40) + revcomp_str(umi) + revcomp_str(bc) + (rnd_seq(rng, -shift) if shift < 0 else "")
+        if shift > 0:
+            stranded = stranded[:-shift]
+        x = (stranded + ad3)[-43:]
+        core = f"PS={ae - 60}_PE={ae - 30}_AE={ae}_bc={bc}_ed={ed}_bcStart={bc_start}_bcEnd={bc_end}"
+    q = f"{10 + (k * 7) % 23}.{k % 10}" if k % 4 else f"{12 + k % 9}"
+    return f"read{k}_{'REV' if rev else 'FWD'}_{core}_rk={1 + k % 40}_X={x}_Q={q}_{k + 1:x}"
+
+
+def gen_umi(g, five_prime, seed, n_mol=14):
+    j = g.j
+    rng = random.Random(seed)
+    side = UmiSide(g, five_prime)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section(("5-prime (-p)" if five_prime else "3-prime") + " assignumis: FastqRecordExt.getScanDatFromReadName(name) (L395-496), then "
+                  "ClusteringEditDistanceBase.calcEditDistances (lambda$static$7, L297-350) for read pairs: 9 limited Levenshtein "
+                  "distances between the 12-mers at offsets -1 / 0 / +1 behind the barcode, best = first strict minimum in EnumSet order "
+                  "(calcBestEditDistance L67-80)", CED, "calcEditDistances / calcBestEditDistance")
+    s["five_prime"] = five_prime
+    bc = rnd_seq(rng, 16)
+    names = []
+    for m in range(n_mol):
+        umi = rnd_seq(rng, 12)
+        for r in range(rng.choice([1, 2, 3, 3, 4])):
+            u = umi if r == 0 else mutate(rng, umi, rng.choice([0, 1, 1, 2, 3]))[:12].ljust(12, "A")
+            names.append(fake_name(rng, len(names), five_prime, bc, u, rng.random() < 0.5, rng.randrange(300, 900), rng.choice([0, 0, 0, -1, 1])))
+    parsed, results = [], []
+    for nm in names:
+        sd = side.scan_data(nm)
+        ad, bcr = sd.f["adapter_result"], sd.f["barcode_Result"]
+
+        def iv(o, k):
+            v = None if o is None else o.f.get(k)
+            if isinstance(v, JObject) and isinstance(v.native, tuple):   # java.util.Optional
+                v = v.native[0]
+            if isinstance(v, JObject) and "Optional" in v.cls:            # com.google.common.base.Optional
+                v = j.call_virtual(v, "orNull", "()Ljava/lang/Object;")
+            if isinstance(v, JObject):
+                raise TypeError(f"{k}: {v.cls}")
+            return None if v is None else (v.v if isinstance(v, JBox) else v)
+
+        seq = sd.f["seq"]
+        parsed.append({"name": nm, "forward": sd.f["forward"].f["$name"], "adapter_end": iv(ad, "end"),
+                       "barcode": None if bcr is None else {"seq": j.call_virtual(bcr.f["barcodeseq"], "toString", "()Ljava/lang/String;"),
+                                                            "ed": iv(bcr, "editDistance"), "start": iv(bcr, "start"), "end": iv(bcr, "end"),
+                                                            "rank": iv(bcr, "rank")},
+                       "x_codes": None if seq is None else list(seq.f["naData"].a), "mean_qv": iv(sd, "mean_qv"), "read_id": sd.f["read_id"]})
+        results.append(side.result_for(sd))
+    s["names"] = parsed
+    for a in range(len(names)):
+        for b in range(a + 1, len(names)):
+            if (a * 31 + b) % 3 == 0 or abs(a - b) < 4:
+                s["cases"].append({"i": a, "j": b, "distance": side.distance(results[a], results[b]), "reverse": side.distance(results[b], results[a])})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def gen_umi_3p(g):
+    return gen_umi(g, False, 808)
+
+
+def gen_umi_5p(g):
+    return gen_umi(g, True, 818)
+
 
 SECTIONS = {"twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
-            "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya}
+            "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
+            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p}
 
 
 def main():
