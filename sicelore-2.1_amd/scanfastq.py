@@ -17,6 +17,7 @@ from . import lib as _lib
 READS_AFTER_SPLIT = 1 << 3            # ReadFlags$Flags.getValue() (ReadFlags.java:L72-109; sicelore_mi.h SMI_F_*)
 MULTI_CHIMERIC_READS_DISCARDED = 1 << 2
 FAILED = 1 << 5
+PASSED_ANY = (1 << _lib.FLAG_BITS["PASSED_FWD"]) | (1 << _lib.FLAG_BITS["PASSED_REV"])
 
 
 def read_fastq_file(path):
@@ -182,7 +183,7 @@ class ReadScanner:
                 sc = scan[i]
                 full = _lib.format_read_name(name, seq, qual, sc, b, rank=rk, read_id=first_read_id + i,
                                              five_prime=self.five_prime)
-            out.append(dict(name=full, passed=bool(int(sc["flags"]) & ((1 << 9) | (1 << 10))) and not failed_multi,
+            out.append(dict(name=full, passed=bool(int(sc["flags"]) & PASSED_ANY) and not failed_multi,
                             reverse=bool(sc["reverse"]), flags=flags, source=r, fragment=int(frag[i]),
                             length=int(o[i + 1]) - int(o[i])))
         return out

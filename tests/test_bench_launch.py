@@ -1,0 +1,33 @@
+"""bench.py --gpus N starts its own ranks (no torchrun around it) and runs the path's exchange: here with world size 2 under gloo
+on CPU tensors (`--exchange-only`: the launch, the pass-1 histogram all-reduce + finalize + broadcast, the BarcodesAssigned
+counters' all-reduce; no kernels).  On the GPU box the same launcher runs the real two-pass leg over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import __graft_entry__ as graft
+
+
+def _run(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(graft.ROOT, "bench.py")] + extra, capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_launches_two_ranks_itself_and_exchanges():
+    graft.build()
+    r = _run(["--gpus", "2", "--exchange-only", "--backend", "gloo", "--whitelist", "50000", "--cells", "300"])
+    assert r["n_gpus"] == 2 and r["backend"] == "gloo"
+    assert r["same_used_list_on_all_ranks"] is True and 100 <= r["used_list"] <= 300
+    # counters of rank 0 (1 per used barcode) + rank 1 (2 per used barcode) summed before the file is formatted
+    assert r["assigned_rows"] == r["used_list"] and r["first_row_total"] == 3
+
+
+def test_single_rank_exchange_only_needs_no_process_group():
+    r = _run(["--gpus", "1", "--exchange-only", "--whitelist", "20000", "--cells", "100"])
+    assert r["n_gpus"] == 1 and r["backend"] == "none" and r["first_row_total"] == 1
