@@ -19,6 +19,7 @@
 // Integer / bitwise work: no MFMA.  Planes are read from global memory (they are touched a few times, L2-resident),
 // so the read length is not limited by LDS.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "smi_internal.h"
@@ -40,6 +41,15 @@ struct ChimParams {
     int pat_thr;   // least count c with c / (float)pat_len >= internalFractionATInPolyAT
     int off;       // windowSearchForPolyA + 70
     int bc_umi;    // cell barcode + UMI length
+    // exact pre-filter of the alignments (myers_bound below): plane index (A 0, G 1, C 2, T 3) of the pattern bases in the order the
+    // bit-vector recurrence consumes them; prefilter = 0 when a pattern holds an IUPAC code other than A, G, C, T
+    int prefilter;   // K-CHIM-A runs first and leaves its verdicts in out[r].n_matches
+    int myers_ok;    // every pattern base is A / G / C / T: the bit-vector bound applies
+    int ablate;    // measurement builds only (SMI_CHIM_ABLATE): 1 no TSO scan, 2 no polyA/T scan, 4 pre-filter without the bit-vector pass, 8 gates only
+    int tso_lead_max, ad_lead_max;       // most leading template gaps an accepted alignment can have (1.1 * lead <= max errors)
+    uint8_t tso_fwd_idx[kMaxPat];        // orientation 0: TSO[m-1-j]
+    uint8_t tso_rev_idx[kMaxPat];        // orientation 1: complement of TSO[j] on the bit-reversed planes
+    uint8_t ad_idx[kMaxPat];             // adapter[m-1-j]
 };
 
 // planes of one read: word w of plane c at p[c][w]
@@ -198,6 +208,116 @@ __device__ __forceinline__ uint64_t gate_two(const PlaneWin &w, const uint32_t *
     return two;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Exact pre-filter of the Needleman-Wunsch acceptance tests.
+//
+// Both internal scans accept a position only when nErrors = #x - 0.9 * lead is at most max (AdapterTSOanalyzer.java:L143-144,
+// L302), #x = alignment columns that are not a match, lead = leading columns that hold a template gap (Match.java:L31-34).
+// Dropping the lead columns from the traceback leaves an alignment of the WHOLE pattern against the read slice without its
+// first `lead` bases that has #x - lead <= nErrors edit operations, so
+//        min over s <= lead_max of  Levenshtein(pattern, slice[s ..])  <=  nErrors,
+// and lead <= nErrors / 1.1 because every leading template gap is paid back by a read gap further on (both sequences are
+// m long).  A position whose bound exceeds max can therefore never be accepted -- whatever the position-skip rule lets the
+// scan visit -- and a read (or an internal polyA/T site) without any position under the bound has NO accepted match: the
+// alignments, whose exact error counts only matter for the skip distances in front of an accepted position, need not run.
+//
+// The bound is Myers' bit-vector edit distance (Hyyro's global form) with the roles swapped: the bit-vector runs over the
+// read slice REVERSED (prefixes of it = suffixes of the slice), the pattern is consumed base by base from its end, and the
+// match vector of a pattern base is simply the read's bit-plane of that base (an N in the read sets all four planes and
+// matches everything, as (a & b) != 0 does).  The last column's vertical deltas give D[i][m] for every prefix length i.
+// Sixteen instructions per pattern base, all of the 2-cycle forms (and / or / xor / add / not on VGPRs; written as one asm
+// block so that the compiler does not fuse them into three-operand forms, which issue at half the rate and drag their
+// neighbours along: profiles/r02/valu_peak.json).
+// ---------------------------------------------------------------------------------------------------------------
+#define SMI_MYERS_STEP(EQ)                                                                                          \
+    asm volatile("v_or_b32 %2, %5, %1\n\t"  /* Xv = Eq | Mv                  */                                      \
+                 "v_and_b32 %3, %5, %0\n\t" /* t  = Eq & Pv                  */                                      \
+                 "v_add_u32 %3, %3, %0\n\t" /* t += Pv                       */                                      \
+                 "v_xor_b32 %3, %3, %0\n\t" /* t ^= Pv                       */                                      \
+                 "v_or_b32 %3, %3, %5\n\t"  /* Xh = t | Eq                   */                                      \
+                 "v_or_b32 %4, %3, %0\n\t"  /* u  = Xh | Pv                  */                                      \
+                 "v_not_b32 %4, %4\n\t"     /* u  = ~u                       */                                      \
+                 "v_or_b32 %4, %1, %4\n\t"  /* Ph = Mv | u                   */                                      \
+                 "v_and_b32 %3, %0, %3\n\t" /* Mh = Pv & Xh                  */                                      \
+                 "v_add_u32 %4, %4, %4\n\t" /* Ph <<= 1                      */                                      \
+                 "v_or_b32 %4, 1, %4\n\t"   /* Ph |= 1  (D[0][j] = j)        */                                      \
+                 "v_add_u32 %3, %3, %3\n\t" /* Mh <<= 1                      */                                      \
+                 "v_or_b32 %0, %2, %4\n\t"  /* w  = Xv | Ph                  */                                      \
+                 "v_not_b32 %0, %0\n\t"     /* w  = ~w                       */                                      \
+                 "v_or_b32 %0, %3, %0\n\t"  /* Pv = Mh | w                   */                                      \
+                 "v_and_b32 %1, %4, %2\n\t" /* Mv = Ph & Xv                  */                                      \
+                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                           \
+                 : "v"(EQ))
+
+// V[b]: plane b of the read slice, bit-reversed into the low M bits (bit k = slice base M-1-k).  idx[j] (wave-uniform): plane of the
+// j-th pattern base consumed.  -> min over i in [M - lead_max, M] of D[i][M]
+template <int M>
+__device__ __forceinline__ int myers_bound(const uint32_t (&V)[4], const uint8_t *idx, int lead_max) {
+    uint32_t pv = 0xFFFFFFFFu, mv = 0u, t_xv, t_a, t_b;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        switch (idx[j]) {  // uniform: a scalar branch
+        case 0: SMI_MYERS_STEP(V[0]); break;
+        case 1: SMI_MYERS_STEP(V[1]); break;
+        case 2: SMI_MYERS_STEP(V[2]); break;
+        default: SMI_MYERS_STEP(V[3]); break;
+        }
+    }
+    const uint32_t mask = (1u << M) - 1u;
+    int d = M + __popc(pv & mask) - __popc(mv & mask);  // D[M][M]
+    int best = d;
+    for (int k = M - 1; k >= M - lead_max && k >= 0; k--) {  // D[k][M] = D[k+1][M] - (Pv - Mv)(row k+1 = bit k)
+        d -= (int)((pv >> k) & 1u) - (int)((mv >> k) & 1u);
+        best = min(best, d);
+    }
+    return best;
+}
+
+// The shipped patterns as compile-time constants (Jar/config.xml:170 complete TSO for 3' barcoding; :126 the 5' adapter for 5'
+// barcoding): with them the gates and the bit-vector bound of K-CHIM-A need no pattern look-ups at all.  PAT 0 = any pattern, read
+// from the kernel arguments.
+template <int PAT>
+struct PatSeq;
+template <>
+struct PatSeq<1> {
+    static constexpr const char *s = "AAGCAGTGGTATCAACGCAGAGTACAT";
+};
+template <>
+struct PatSeq<2> {
+    static constexpr const char *s = "CTACACGACGCTCTTCCGATCT";
+};
+__host__ __device__ constexpr int plane_c(char c) { return c == 'A' ? 0 : c == 'G' ? 1 : c == 'C' ? 2 : 3; }
+// plane of base j of the pattern searched in orientation o (1: the reverse complement)
+template <int PAT, int M>
+__host__ __device__ constexpr int gate_plane(int o, int j) {
+    return o == 0 ? plane_c(PatSeq<PAT>::s[j]) : 3 - plane_c(PatSeq<PAT>::s[M - 1 - j]);
+}
+// plane consumed at step j of myers_bound (see ChimParams::tso_fwd_idx / tso_rev_idx)
+template <int PAT, int M>
+__host__ __device__ constexpr int myers_plane(int o, int j) {
+    return o == 0 ? plane_c(PatSeq<PAT>::s[M - 1 - j]) : 3 - plane_c(PatSeq<PAT>::s[j]);
+}
+
+template <int M, int PAT, int ORI>
+__device__ __forceinline__ int myers_bound_ct(const uint32_t (&V)[4], int lead_max) {
+    uint32_t pv = 0xFFFFFFFFu, mv = 0u, t_xv, t_a, t_b;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const uint32_t eqv = V[(myers_plane<PAT, M>(ORI, j))];
+        SMI_MYERS_STEP(eqv);
+    }
+    const uint32_t mask = (1u << M) - 1u;
+    int d = M + __popc(pv & mask) - __popc(mv & mask);
+    int best = d;
+    for (int k = M - 1; k >= M - lead_max && k >= 0; k--) {
+        d -= (int)((pv >> k) & 1u) - (int)((mv >> k) & 1u);
+        best = min(best, d);
+    }
+    return best;
+}
+
 struct MatchRec {  // ChimeraFindernew$AdapterTSOmatch
     int begin;
     int is_reverse;
@@ -288,6 +408,22 @@ __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, 
     }
     const uint32_t gate = three & ((1u << NPOS) - 1u);  // minKmersMatching = 3 (L173)
     if (gate == 0) return 0;
+    if (P.myers_ok) {
+        // no scan position with an alignment that could be accepted (round(nErrors) <= max => Levenshtein bound <= max): the
+        // result list is empty whatever the skip rule visits (myers_bound)
+        bool hot = false;
+        if (lane < NPOS && ((gate >> lane) & 1u)) {
+            uint32_t V[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                // plane c of the sub-sequence at scan position lane + 1, bit k = sub[lane + k]
+                const uint32_t w = is_t ? gget32(rp.p[c], start_range - 1 + lane) : __brev(gget32(rp.p[3 - c], end_range - 32 - lane));
+                V[c] = __brev(w) >> (32 - kAdLen);
+            }
+            hot = myers_bound<kAdLen>(V, P.ad_idx, P.ad_lead_max) <= P.ad_max;
+        }
+        if (!__ballot(hot)) return 0;
+    }
     // lane l < 29 aligns scan position l + 1
     float ne = 0.0f;
     int nmis = 0;
@@ -330,16 +466,230 @@ __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, 
     return is_t ? start_range + o1 - 1 : start_range + 51 - o1;  // L207 / L211
 }
 
-template <int kTsoLen, int kAdLen>
-__global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
-                                                    const uint64_t *__restrict__ offsets, size_t n, ChimParams P,
-                                                    smi_chimera_result *__restrict__ out) {
+// ---------------------------------------------------------------------------------------------------------------
+// K-CHIM-A: the pre-filter pass of the internal TSO scan (myers_bound).  One wave per read, one lane per 32 scan positions:
+// the 4-mer gates of both orientations in 32-bit words (every lane busy for reads of >= 2 kb, 41 of 64 for 1.3 kb), the
+// gate-passing positions pooled per orientation through LDS and bounded 64 at a time.  Writes hot[r] = 1 when some position
+// could be accepted.  No Needleman-Wunsch here: ~1,300 instructions per read instead of ~17,000 per candidate batch.
+// ---------------------------------------------------------------------------------------------------------------
+struct FilterParams {  // what K-CHIM-A needs of ChimParams, bytes instead of words (kernel arguments live in SGPRs)
+    uint8_t gate_idx[2][kMaxPat];  // plane (A 0, G 1, C 2, T 3) of pattern base j, per orientation
+    uint8_t fwd_idx[kMaxPat], rev_idx[kMaxPat];
+    uint8_t tso4[2][kMaxPat];      // 4-bit codes of the pattern, per orientation (gates)
+    int tso_max, lead_max;
+    int myers_ok;                  // 0: a pattern base is not A / G / C / T -> every read counts as possible
+    int force_all;                 // measurement / cross-check: every read gets both verdicts (the kernels behind run on all reads)
+    int pat_len, pat_thr, off;     // internal polyA / polyT windows (aTscan)
+};
+#define SMI_CHIMA_TSO 1  /* K-CHIM-A verdicts left in out[r].n_matches: some position may hold an accepted internal TSO alignment */
+#define SMI_CHIMA_PAT 2  /* some position satisfies the local start condition of an internal polyA / polyT stretch */
+
+struct FilterLds {
+    uint32_t cmask[2][64];
+    int coff[2][64];
+};
+
+__device__ __forceinline__ int kth_bit32(uint32_t m, int k) {
+    for (; k > 0; k--) m &= m - 1;
+    return __builtin_ctz(m);
+}
+
+template <int kTsoLen, int PAT>
+__global__ __launch_bounds__(256) void k_chim_tso_filter(const uint32_t *__restrict__ planes, size_t stride,
+                                                         const uint64_t *__restrict__ offsets, size_t n, FilterParams P,
+                                                         smi_chimera_result *__restrict__ out, uint32_t *__restrict__ list,
+                                                         uint32_t *__restrict__ list_count) {
+    __shared__ FilterLds lds_all[4];
+    FilterLds &L = lds_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < n; r += n_waves) {
+        const uint64_t beg = offsets[r];
+        const int len = (int)(offsets[r + 1] - beg);
+        bool any_hot = false, any_pat = false;
+        if (len >= 2 * 70 + 100) {
+            ReadPlanes rp;
+            const size_t w0 = plane_start(beg, r);
+#pragma unroll
+            for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
+            const int last = len - 70;
+            const int pa_first = P.off - 1, pa_stop = len - P.off;  // aTscan positions (0-based) [pa_first, pa_stop)
+            int extra[2] = {0, 0};
+            if (pa_first < pa_stop && P.pat_thr <= 15) {
+                extra[0] = (int)gexact_bit(rp, 0, P.off + P.pat_len - 2);
+                extra[1] = (int)gexact_bit(rp, 1, P.off + P.pat_len - 2);
+            } else
+                any_pat = pa_first < pa_stop;  // thresholds the bit-sliced counter cannot hold: leave it to the big kernel
+            if (!P.myers_ok) any_hot = true;
+            if (P.force_all) any_hot = any_pat = true;
+            for (int p0 = 70; p0 <= last && !(any_hot && any_pat); p0 += 2048) {
+                const int pl = p0 + 32 * lane;  // first scan position of this lane (1-based); its bit is pl - 1
+                uint32_t cm[2] = {0, 0};
+                uint64_t Wk[4] = {0, 0, 0, 0};
+                if (pl <= last) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) Wk[c] = gget64(rp.p[c], pl - 1);
+                    const uint64_t(&W)[4] = Wk;
+#pragma unroll
+                    for (int o = 0; o < 2 && P.myers_ok; o++) {
+                        // m_j = match bits of pattern base j at scan positions pl .. pl+31; a 4-mer at i matches where m_i & m_i+1 & m_i+2 & m_i+3
+                        auto mj = [&](int j) -> uint32_t {
+                            if constexpr (PAT != 0) {
+                                return (uint32_t)(W[gate_plane<PAT, kTsoLen>(o, j)] >> j);
+                            } else {
+                                const uint32_t a4 = P.tso4[o][j];
+                                uint64_t x = 0;
+#pragma unroll
+                                for (int c = 0; c < 4; c++)
+                                    if ((a4 >> c) & 1u) x |= W[c];
+                                return (uint32_t)(x >> j);
+                            }
+                        };
+                        uint32_t any = 0, two = 0;
+                        const uint32_t m0 = mj(0), m1 = mj(1);
+                        uint32_t m_prev = mj(2);
+                        uint32_t p01 = m0 & m1, p12 = m1 & m_prev;
+#pragma unroll
+                        for (int i = 0; i + 3 < kTsoLen; i++) {
+                            const uint32_t m3 = mj(i + 3);
+                            const uint32_t p23 = m_prev & m3;
+                            const uint32_t k = p01 & p23;
+                            two |= any & k;
+                            any |= k;
+                            p01 = p12;
+                            p12 = p23;
+                            m_prev = m3;
+                        }
+                        const int nb = last - pl + 1;
+                        cm[o] = nb >= 32 ? two : (two & ((1u << nb) - 1u));
+                    }
+                }
+                // internal polyA / polyT: is the local start condition of aTscan (window count >= threshold, bases pos and pos + 1 exact)
+                // met anywhere?  (The big kernel walks the stretches in order; a read without any such position has none.)
+                if (!any_pat) {
+                    uint32_t trig = 0;
+                    if (pl <= last) {
+#pragma unroll
+                        for (int t = 0; t < 2; t++) {
+                            const uint64_t e = t ? (Wk[3] & ~Wk[0]) : (Wk[0] & ~Wk[1]);  // exact T / exact A from bit pl - 1
+                            uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+                            for (int k = 1; k < 15; k++) {
+                                if (k >= P.pat_len) break;
+                                const uint32_t x = (uint32_t)(e >> k);
+                                const uint32_t t0 = c0 & x;
+                                c0 ^= x;
+                                const uint32_t t1 = c1 & t0;
+                                c1 ^= t0;
+                                const uint32_t t2 = c2 & t1;
+                                c2 ^= t1;
+                                c3 ^= t2;
+                            }
+                            if (extra[t]) {
+                                const uint32_t t0 = c0;
+                                c0 = ~c0;
+                                const uint32_t t1 = c1 & t0;
+                                c1 ^= t0;
+                                const uint32_t t2 = c2 & t1;
+                                c2 ^= t1;
+                                c3 ^= t2;
+                            }
+                            const uint32_t cb[4] = {c0, c1, c2, c3};
+                            uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+                            for (int b = 3; b >= 0; b--) {
+                                if ((P.pat_thr >> b) & 1)
+                                    eq &= cb[b];
+                                else
+                                    gt |= eq & cb[b];
+                            }
+                            // positions q = pl - 1 + k (0-based) with first <= q < stop
+                            uint32_t m = (gt | eq) & (uint32_t)e & (uint32_t)(e >> 1);
+                            const int q0 = pl - 1;
+                            if (q0 < pa_first) m = pa_first - q0 >= 32 ? 0u : (m & (~0u << (pa_first - q0)));
+                            if (q0 + 32 > pa_stop) m = pa_stop - q0 <= 0 ? 0u : (m & ((1u << (pa_stop - q0)) - 1u));
+                            trig |= m;
+                        }
+                    }
+                    if (__ballot(trig != 0)) any_pat = true;
+                }
+#pragma unroll 1
+                for (int o = 0; o < 2 && !any_hot; o++) {
+                    int total;
+                    const int off = wave_exscan_i(__popc(cm[o]), lane, total);
+                    if (total == 0) continue;
+                    L.cmask[o][lane] = cm[o];
+                    L.coff[o][lane] = off;
+                    wave_sync();
+                    for (int base = 0; base < total && !any_hot; base += 64) {
+                        const int en = base + lane;
+                        const bool live = en < total;
+                        uint32_t V[4] = {0, 0, 0, 0};
+                        if (live) {
+                            int lo = 0, hi = 64;
+                            while (hi - lo > 1) {
+                                const int mid = (lo + hi) >> 1;
+                                if (L.coff[o][mid] <= en)
+                                    lo = mid;
+                                else
+                                    hi = mid;
+                            }
+                            const int pos = p0 + 32 * lo + kth_bit32(L.cmask[o][lo], en - L.coff[o][lo]);
+#pragma unroll
+                            for (int c = 0; c < 4; c++) V[c] = __brev(gget32(rp.p[c], pos - 1)) >> (32 - kTsoLen);
+                        }
+                        int b;
+                        if constexpr (PAT != 0)
+                            b = o ? myers_bound_ct<kTsoLen, PAT, 1>(V, P.lead_max) : myers_bound_ct<kTsoLen, PAT, 0>(V, P.lead_max);
+                        else
+                            b = myers_bound<kTsoLen>(V, o ? P.rev_idx : P.fwd_idx, P.lead_max);
+                        if (__ballot(live && b <= P.tso_max)) any_hot = true;
+                    }
+                    wave_sync();
+                }
+            }
+        }
+        // a read without any verdict is finished here (no internal match, no split); the others queue up for K-CHIM-B / -C
+        if (lane == 0) {
+            smi_chimera_result res;
+            res.n_split = 0;
+            res.pos[0] = res.pos[1] = 0;
+            res.reason[0] = res.reason[1] = 0;
+            res.flags = 0;
+            res.n_matches = (any_hot ? SMI_CHIMA_TSO : 0) | (any_pat ? SMI_CHIMA_PAT : 0);
+            out[r] = res;
+            if (res.n_matches) list[atomicAdd(list_count, 1u)] = (uint32_t)r;
+        }
+    }
+}
+
+// Matches of the exact internal-TSO scan of one queued read (K-CHIM-B -> K-CHIM-C), in the order the split rules take them
+struct TsoSlot {
+    int n;  // number of matches, > kCap: overflow
+    int begin[kCap];
+    int kind[kCap];
+};
+
+// K-CHIM-B (PART 1): the exact internal TSO scan of the queued reads with the TSO verdict -> TsoSlot.
+// K-CHIM-C (PART 2): internal polyA / polyT + adapter for the reads with that verdict, then the split rules on all matches of the
+// queued read -> out[r].  Two kernels instead of one so that each is register-allocated for its own part.
+template <int kTsoLen, int kAdLen, int PART>
+__global__ __launch_bounds__(256, PART == 1 ? 4 : 2) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
+                                                                   const uint64_t *__restrict__ offsets,
+                                                                   const uint32_t *__restrict__ list,
+                                                                   const uint32_t *__restrict__ list_count, ChimParams P,
+                                                                   TsoSlot *__restrict__ slots, smi_chimera_result *__restrict__ out) {
     __shared__ WaveLds lds_all[4];
     WaveLds &L = lds_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t r = wave; r < n; r += n_waves) {
+    const size_t n_list = *list_count;
+    for (size_t li = wave; li < n_list; li += n_waves) {
+        const size_t r = list[li];
+        const int verdict = out[r].n_matches;  // left by K-CHIM-A
+        if (PART == 1 && !(verdict & SMI_CHIMA_TSO)) continue;
         const uint64_t beg = offsets[r];
         const int len = (int)(offsets[r + 1] - beg);
         smi_chimera_result res;
@@ -348,11 +698,7 @@ __global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__
         res.reason[0] = res.reason[1] = 0;
         res.flags = 0;
         res.n_matches = 0;
-        if (len < 2 * 70 + 100) {  // L169
-            if (lane == 0) out[r] = res;
-            continue;
-        }
-        ReadPlanes rp;
+        ReadPlanes rp;  // (reads shorter than 2 * 70 + 100 never reach the queue, L169)
         const size_t w0 = plane_start(beg, r);
 #pragma unroll
         for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
@@ -365,7 +711,7 @@ __global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__
         // the read window (col[c] = plane of template base c), so a candidate costs 4 window fetches, not 27.
         const int last = len - 70;  // min(len - 27, len - 70)
         int n_acc2[2] = {0, 0};
-        {
+        if constexpr (PART == 1) {
             int skip[2] = {0, 0};  // next position the reference's scan looks at, per orientation
             for (int p0 = 70; p0 <= last; p0 += 4096) {
                 const int pl = p0 + 64 * lane;
@@ -445,7 +791,6 @@ __global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__
                 }
                 wave_sync();
             }
-        }
 #pragma unroll 1
         for (int o = 0; o < 2; o++) {
             int n_acc = n_acc2[o];
@@ -496,12 +841,34 @@ __global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__
             n_m += __popcll(pb);
             wave_sync();
         }
+            // hand the matches to K-CHIM-C
+            if (lane < min(n_m, kCap)) {
+                slots[li].begin[lane] = L.m_begin[lane];
+                slots[li].kind[lane] = L.m_kind[lane];
+            }
+            if (lane == 0) slots[li].n = overflow ? kCap + 1 : n_m;
+            wave_sync();
+            continue;
+        } else {
+            if (verdict & SMI_CHIMA_TSO) {
+                n_m = slots[li].n;
+                if (n_m > kCap) {
+                    overflow = true;
+                    n_m = kCap;
+                }
+                if (lane < n_m) {
+                    L.m_begin[lane] = slots[li].begin[lane];
+                    L.m_kind[lane] = slots[li].kind[lane];
+                }
+                wave_sync();
+            }
+        }
 
         // ---- internal polyA / polyT + adapter (aTscan L92-136, adapterScan) --------------------------------------
         // window count at pos = exact bases in [pos+1, pos+14] + the base at index off+13, which the reference's
         // window update counts twice (L99-121)
         const int first = P.off - 1, stop = len - P.off;  // pos in [first, stop)
-        if (first < stop) {
+        if (PART == 2 && first < stop && !(P.ablate & 2) && (verdict & SMI_CHIMA_PAT)) {
             int end_cur[2] = {0, 0};                               // [0] A, [1] T
             int fired[2] = {-1, -1};                               // last position that produced an ATposition
             long long prev_start[2] = {-2147483648LL, -2147483648LL};  // prevA_Position / prevT_Position
@@ -553,7 +920,7 @@ __global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__
                     }
                 }
                 // walk the triggers in position order (T before A never collide: a base is one or the other)
-                for (;;) {
+                for (; !(P.ablate & 64);) {
                     int nxt[2];
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
@@ -586,7 +953,7 @@ __global__ __launch_bounds__(256, 4) void k_chimera(const uint32_t *__restrict__
                     const int at_end = search_at_end(rp, len, pos, t, cur, P) + 1;
                     end_cur[t] = at_end;
                     fired[t] = pos;
-                    const int start = adapter_scan<kAdLen>(rp, at_begin, at_end, t, lane, P);
+                    const int start = (P.ablate & 32) ? 0 : adapter_scan<kAdLen>(rp, at_begin, at_end, t, lane, P);
                     if (start != 0) {  // lambda$7 L204-207
                         const long long lim = prev_start[t] + 120;
                         prev_start[t] = start;
@@ -803,15 +1170,98 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     P.pat_thr = thr_count(cfg->internal_pat_len, cfg->internal_pat_frac);
     P.off = cfg->window_polya + 70;
     P.bc_umi = cfg->bc_umi_len;
-    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 16);
+    auto plane_of = [](uint32_t code) { return code == 1 ? 0 : code == 2 ? 1 : code == 4 ? 2 : code == 8 ? 3 : -1; };
+    P.prefilter = 1;
+    P.myers_ok = 1;
+    for (int j = 0; j < tl; j++) {
+        const int f = plane_of(P.tso4[0][tl - 1 - j]), r = plane_of(P.tso4[0][j]);
+        if (f < 0 || r < 0) P.myers_ok = 0;
+        P.tso_fwd_idx[j] = (uint8_t)(f < 0 ? 0 : f);
+        P.tso_rev_idx[j] = (uint8_t)(r < 0 ? 0 : 3 - r);  // complement plane: A <-> T, G <-> C
+    }
+    for (int j = 0; j < al; j++) {
+        const int a = plane_of(P.ad4[al - 1 - j]);
+        if (a < 0) P.myers_ok = 0;
+        P.ad_idx[j] = (uint8_t)(a < 0 ? 0 : a);
+    }
+    P.ablate = getenv("SMI_CHIM_ABLATE") ? atoi(getenv("SMI_CHIM_ABLATE")) : 0;
+    const bool no_filter = getenv("SMI_CHIM_NO_PREFILTER") != nullptr;  // measurement / cross-check switch: every read takes the exact path
+    if (no_filter) P.myers_ok = 0;
+    // lead <= nErrors / 1.1 (see myers_bound); one more for safety -- a larger range only weakens the filter
+    P.tso_lead_max = std::min(tl, (int)(((float)P.tso_max + 0.5f) / 1.1f) + 1);
+    P.ad_lead_max = std::min(al, (int)(((float)P.ad_max + 0.5f) / 1.1f) + 1);
+    // queue of the reads K-CHIM-A could not clear, and the hand-over slots of K-CHIM-B: device scratch of the context, grow-only
+    const size_t list_bytes = (n + 64) * sizeof(uint32_t);
+    if (ctx->chim_list_bytes < list_bytes) {
+        if (ctx->chim_list) (void)hipFree(ctx->chim_list);
+        ctx->chim_list = nullptr;
+        ctx->chim_list_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->chim_list, list_bytes));
+        ctx->chim_list_bytes = list_bytes;
+    }
+    uint32_t *d_count = ctx->chim_list, *d_list = ctx->chim_list + 16;
+    SMI_HIP(hipMemsetAsync(d_count, 0, 64, s));
     if (int rc = time_begin(ctx, SMI_K_CHIMERA, s)) return rc;
-    if (tl == 27)
-        hipLaunchKernelGGL((k_chimera<27, 22>), dim3(grid), dim3(256), 0, s, d_planes, read_planes_stride(total_bases, n),
-                           d_offsets, n, P, d_out);
-    else
-        hipLaunchKernelGGL((k_chimera<22, 25>), dim3(grid), dim3(256), 0, s, d_planes, read_planes_stride(total_bases, n),
-                           d_offsets, n, P, d_out);
-    SMI_HIP(hipGetLastError());
+    FilterParams F;
+    std::memset(&F, 0, sizeof F);
+    for (int j = 0; j < tl; j++) {
+        F.gate_idx[0][j] = (uint8_t)std::max(0, plane_of(P.tso4[0][j]));
+        F.gate_idx[1][j] = (uint8_t)std::max(0, plane_of(P.tso4[1][j]));
+        F.fwd_idx[j] = P.tso_fwd_idx[j];
+        F.rev_idx[j] = P.tso_rev_idx[j];
+        F.tso4[0][j] = (uint8_t)P.tso4[0][j];
+        F.tso4[1][j] = (uint8_t)P.tso4[1][j];
+    }
+    F.tso_max = P.tso_max;
+    F.lead_max = P.tso_lead_max;
+    F.myers_ok = P.myers_ok;
+    F.force_all = no_filter ? 1 : 0;
+    F.pat_len = P.pat_len;
+    F.pat_thr = P.pat_thr;
+    F.off = P.off;
+    const size_t st = read_planes_stride(total_bases, n);
+    {
+        const unsigned gridA = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
+        const bool generic = getenv("SMI_CHIM_GENERIC") != nullptr || !P.myers_ok;
+        const bool shipped3 = tl == 27 && !std::strcmp(cfg->tso_complete, PatSeq<1>::s) && !generic;
+        const bool shipped5 = tl == 22 && !std::strcmp(cfg->tso_complete, PatSeq<2>::s) && !generic;
+        if (shipped3)
+            hipLaunchKernelGGL((k_chim_tso_filter<27, 1>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+        else if (shipped5)
+            hipLaunchKernelGGL((k_chim_tso_filter<22, 2>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+        else if (tl == 27)
+            hipLaunchKernelGGL((k_chim_tso_filter<27, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+        else
+            hipLaunchKernelGGL((k_chim_tso_filter<22, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+        SMI_HIP(hipGetLastError());
+    }
+    // the queue length decides the size of the hand-over slots (one small copy + sync per launch)
+    uint32_t n_list = 0;
+    SMI_HIP(hipMemcpyAsync(&n_list, d_count, 4, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    if (n_list) {
+        const size_t slot_bytes = (size_t)n_list * sizeof(TsoSlot);
+        if (ctx->chim_slot_bytes < slot_bytes) {
+            if (ctx->chim_slots) (void)hipFree(ctx->chim_slots);
+            ctx->chim_slots = nullptr;
+            ctx->chim_slot_bytes = 0;
+            const size_t want = slot_bytes + slot_bytes / 4;
+            SMI_HIP(hipMalloc(&ctx->chim_slots, want));
+            ctx->chim_slot_bytes = want;
+        }
+        TsoSlot *d_slots = static_cast<TsoSlot *>(ctx->chim_slots);
+        const unsigned grid = (unsigned)std::min<size_t>(((size_t)n_list + 3) / 4, 256 * 16);
+        if (!(P.ablate & 16)) {
+            if (tl == 27) {
+                hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
+            } else {
+                hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
+            }
+            SMI_HIP(hipGetLastError());
+        }
+    }
     if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;
     return SMI_OK;
 }

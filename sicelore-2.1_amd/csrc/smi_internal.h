@@ -92,6 +92,10 @@ struct smi_ctx {
     hipStream_t stream = nullptr;  // private stream of the *_batch entry points
     void *scan_tmp = nullptr;      // scratch of the FASTQ indexer (block counts + hipcub temp storage)
     size_t scan_tmp_bytes = 0;
+    uint32_t *chim_list = nullptr; // K-CHIM: queue of the reads the filter pass could not clear (+ its counter), grow-only
+    size_t chim_list_bytes = 0;
+    void *chim_slots = nullptr;    // K-CHIM: matches handed from the exact TSO scan to the rules kernel
+    size_t chim_slot_bytes = 0;
     void *arena = nullptr;         // device memory of the chunk workers (smi_worker.hip), grow-only
     size_t arena_bytes = 0;
     uint8_t *host_out[2] = {nullptr, nullptr};  // pinned: passed / failed text of the last smi_scanfastq_pass2_chunk

@@ -132,7 +132,8 @@ def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
     res["chimera"] = {"reads": n, "bases": total, "pack_ms": dt_pack * 1e3, "ms": dt * 1e3, "reads_per_s": n / dt,
                       "bases_per_s": total / dt, "pack_GBps": total / dt_pack / 1e9,
                       "split_frac": float((cr["n_split"] > 0).mean()), "multi_frac": float((cr["flags"] & 1).mean()),
-                      "overflow": int((cr["flags"] & 4).sum())}
+                      "overflow": int((cr["flags"] & 4).sum()),
+                      "n_matches_bit0_frac": float((cr["n_matches"] & 1).mean()), "n_matches_bit1_frac": float(((cr["n_matches"] >> 1) & 1).mean())}
 
 
 def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
