@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "smi_internal.h"
 #include "smi_nw.h"
@@ -1047,6 +1048,217 @@ __global__ __launch_bounds__(256, PART == 1 ? 4 : 2) void k_chimera(const uint32
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K-CHIM-S: the reads K-CHIM-B / -C flagged SMI_CHIM_OVERFLOW (more than kCap accepted positions or matches: TSO
+// concatemers, homopolymers, all-N reads) once more, with every list in global scratch sized by the read's length -- the
+// reference has no such cap (ChimeraFindernew.java:L107-332).  One wave per read, UNIFORM control flow: every lane runs the same
+// statements on the same values (the alignments of a batch excepted), lane 0 stores.  Rare reads; speed is not a concern here.
+// Scratch of read k of the queue: 7 * cap(k) words at scr[scr_off[k]], cap = length + 8.
+// ---------------------------------------------------------------------------------------------------------------
+template <int kTsoLen, int kAdLen>
+__global__ __launch_bounds__(64) void k_chimera_serial(const uint32_t *__restrict__ planes, size_t stride,
+                                                       const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list,
+                                                       uint32_t n_list, const uint64_t *__restrict__ scr_off, int32_t *__restrict__ scr,
+                                                       ChimParams P, smi_chimera_result *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    for (uint32_t li = blockIdx.x; li < n_list; li += gridDim.x) {
+        const size_t r = list[li];
+        const uint64_t beg = offsets[r];
+        const int len = (int)(offsets[r + 1] - beg);
+        const int cap = len + 8;
+        int32_t *ps_pos = scr + scr_off[li];
+        float *ps_ne = reinterpret_cast<float *>(ps_pos + cap);
+        int32_t *m_begin = ps_pos + 2 * cap, *m_kind = ps_pos + 3 * cap, *order = ps_pos + 4 * cap;  // cap entries each (matches are > 120 apart)
+        ReadPlanes rp;
+        const size_t w0 = plane_start(beg, r);
+#pragma unroll
+        for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
+        smi_chimera_result res;
+        res.n_split = 0;
+        res.pos[0] = res.pos[1] = 0;
+        res.reason[0] = res.reason[1] = 0;
+        res.flags = 0;
+        res.n_matches = 0;
+        int n_m = 0;
+        const int last = len - 70;
+        // ---- internal TSO, orientation by orientation (scanForAdapterOrTSOseqKMERsForInternal L130-156 as the scan runs it) ----
+        for (int o = 0; o < 2; o++) {
+            int n_ps = 0, delta = 1;
+            for (int pos = 70; pos <= last; pos += delta) {
+                delta = 1;
+                const PlaneWin pw = load_window(rp, pos - 1);
+                if (!(gate_two<kTsoLen>(pw, P.tso4[o]) & 1ull)) continue;  // bit 0 = this position (Kmers.nKmersMatching >= 2)
+                uint32_t W[4], col[kTsoLen];
+#pragma unroll
+                for (int c = 0; c < 4; c++) W[c] = gget32(rp.p[c], pos - 1) & ((1u << kTsoLen) - 1u);
+#pragma unroll
+                for (int c = 0; c < kTsoLen; c++) {
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if ((P.tso4[o][c] >> k) & 1u) m |= W[k];
+                    col[c] = m;
+                }
+                const float ne = nw_errors<kTsoLen>(col);
+                const float maxe = (float)P.tso_max;
+                if (!((float)jround(ne) > maxe) && !(ne > maxe)) {  // L143-144, then getPosbelowMaxMismatches (key <= max, L302)
+                    if (lane == 0) {
+                        ps_pos[n_ps] = pos;
+                        ps_ne[n_ps] = ne;
+                    }
+                    n_ps++;
+                }
+                if (maxe < ne) {  // L146-150
+                    delta = jround(__fsub_rn(ne, maxe)) - 1;
+                    if (delta < 1) delta = 1;
+                }
+            }
+            __threadfence_block();
+            wave_sync();
+            // stable sort by score (positions ascending inside one score): selection into `order`
+            if (lane == 0) {
+                for (int i = 0; i < n_ps; i++) {
+                    int rank = 0;
+                    for (int j = 0; j < n_ps; j++)
+                        rank += (ps_ne[j] < ps_ne[i] || (ps_ne[j] == ps_ne[i] && ps_pos[j] < ps_pos[i])) ? 1 : 0;
+                    order[rank] = ps_pos[i];
+                }
+            }
+            __threadfence_block();
+            wave_sync();
+            // L115-123: entry i dropped when < 3 away from entry i-1 of the sorted list; then begin > prev + 120 (L161-163)
+            long long prev = -2147483648LL;
+            int prev_sorted = 0;
+            for (int i = 0; i < n_ps; i++) {
+                const int pp = order[i];
+                const bool keep = i == 0 || abs(pp - prev_sorted) >= 3;
+                prev_sorted = pp;
+                if (!keep) continue;
+                const int begin = o ? pp + kTsoLen - 1 : pp;
+                const long long lim = prev + 120;
+                prev = begin;
+                if ((long long)begin > lim) {
+                    if (lane == 0) {
+                        m_begin[n_m] = begin;
+                        m_kind[n_m] = o;
+                    }
+                    n_m++;
+                }
+            }
+            wave_sync();
+        }
+        // ---- internal polyA / polyT + adapter (aTscan L92-136): one position at a time --------------------------------
+        const int first = P.off - 1, stop = len - P.off;
+        if (first < stop) {
+            int cur[2] = {0, 0};  // [0] A, [1] T: exact bases in the window
+            for (int i = first; i < first + P.pat_len && i < len; i++) {
+                cur[0] += (int)gexact_bit(rp, 0, i);
+                cur[1] += (int)gexact_bit(rp, 1, i);
+            }
+            int end_cur[2] = {0, 0};
+            long long prev_start[2] = {-2147483648LL, -2147483648LL};
+            for (int pos = first; pos < stop; pos++) {
+                for (int t = 0; t < 2; t++) {
+                    cur[t] -= (int)gexact_bit(rp, t, pos);
+                    cur[t] += (int)gexact_bit(rp, t, pos + P.pat_len - 1);
+                }
+                for (int w = 0; w < 2; w++) {  // T first (L123), then A (L129)
+                    const int t = w == 0 ? 1 : 0;
+                    if (cur[t] < P.pat_thr || pos <= end_cur[t] || !gexact_bit(rp, t, pos) || !gexact_bit(rp, t, pos + 1)) continue;
+                    const int at_begin = pos + 1;
+                    const int at_end = search_at_end(rp, len, pos, t, cur[t], P) + 1;
+                    end_cur[t] = at_end;
+                    const int start = adapter_scan<kAdLen>(rp, at_begin, at_end, t, lane, P);
+                    if (start == 0) continue;
+                    const long long lim = prev_start[t] + 120;
+                    prev_start[t] = start;
+                    if ((long long)start > lim) {
+                        if (lane == 0) {
+                            m_begin[n_m] = start;
+                            m_kind[n_m] = 2 | (t == 0 ? 1 : 0);
+                        }
+                        n_m++;
+                    }
+                }
+            }
+        }
+        __threadfence_block();
+        wave_sync();
+        // ---- split rules (L229-286) on the whole list -------------------------------------------------------------------
+        if (lane == 0) {
+            for (int i = 0; i < n_m; i++) {
+                int rank = 0;
+                for (int j = 0; j < n_m; j++) rank += (m_begin[j] < m_begin[i] || (m_begin[j] == m_begin[i] && j < i)) ? 1 : 0;
+                order[rank] = i;
+            }
+        }
+        __threadfence_block();
+        wave_sync();
+        int n_kept = 0, kept_pos[3], kept_reason[3], prev_sp = 0;
+        bool have_prev_sp = false;
+        auto emit = [&](int reason, int pos) {
+            const bool drop = have_prev_sp && (pos - prev_sp < 100);
+            prev_sp = pos;
+            have_prev_sp = true;
+            if (!drop) {
+                if (n_kept < 3) {
+                    kept_pos[n_kept] = pos;
+                    kept_reason[n_kept] = reason;
+                }
+                n_kept++;
+            }
+        };
+        auto isolated = [&](int m) {
+            const int k = m_kind[m], b = m_begin[m];
+            emit((k & 1) ? SMI_SPLIT_REV_ADAPTER : SMI_SPLIT_FWD_ADAPTER, (k & 1) ? b + 25 : b - 25);
+        };
+        if (n_m == 1) {
+            if (m_kind[0] & 2) isolated(0);
+        } else if (n_m > 1) {
+            int it = 0;
+            int prev = order[it++];
+            while (it < n_m && prev >= 0) {
+                const int cur = order[it++];
+                const int pk = m_kind[prev], ck = m_kind[cur];
+                const int pbeg = m_begin[prev], cbeg = m_begin[cur];
+                if (cbeg - pbeg > 160) {
+                    if (pk & 2) isolated(prev);
+                    prev = cur;
+                } else if ((pk & 1) && !(ck & 1)) {
+                    const int reason = (pk & 2) ? ((ck & 2) ? SMI_SPLIT_RA_FA : SMI_SPLIT_RA_FT) : ((ck & 2) ? SMI_SPLIT_RT_FA : SMI_SPLIT_RT_FT);
+                    emit(reason, pbeg + (cbeg - pbeg) / 2);
+                    prev = it < n_m ? order[it++] : -1;
+                } else
+                    prev = cur;
+                if (it >= n_m && prev >= 0 && (m_kind[prev] & 2)) isolated(prev);
+            }
+        }
+        res.n_matches = n_m;
+        if (n_kept > 2) {
+            res.flags |= SMI_CHIM_MULTI;
+        } else {
+            res.n_split = n_kept;
+            int lastp = 0;
+            for (int i = 0; i < n_kept; i++) {
+                res.pos[i] = kept_pos[i];
+                res.reason[i] = (uint8_t)kept_reason[i];
+                if (kept_pos[i] < lastp || kept_pos[i] > len) res.flags |= SMI_CHIM_RANGE;
+                lastp = kept_pos[i];
+            }
+        }
+        if (lane == 0) out[r] = res;
+        wave_sync();
+    }
+}
+
+// queue of the reads whose result carries SMI_CHIM_OVERFLOW
+__global__ void k_collect_overflow(const smi_chimera_result *__restrict__ out, const uint32_t *__restrict__ list,
+                                   const uint32_t *__restrict__ list_count, uint32_t *__restrict__ over, uint32_t *__restrict__ over_count) {
+    const uint32_t n = *list_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        if (out[list[i]].flags & SMI_CHIM_OVERFLOW) over[atomicAdd(over_count, 1u)] = list[i];
+}
+
 // ---- fragment offsets: read i with k split positions becomes k + 1 consecutive records of the same byte buffer ----
 __global__ void k_frag_counts(const smi_chimera_result *__restrict__ chim, size_t n, uint32_t *__restrict__ block_sums) {
     __shared__ uint32_t sh[256];
@@ -1191,7 +1403,7 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     P.tso_lead_max = std::min(tl, (int)(((float)P.tso_max + 0.5f) / 1.1f) + 1);
     P.ad_lead_max = std::min(al, (int)(((float)P.ad_max + 0.5f) / 1.1f) + 1);
     // queue of the reads K-CHIM-A could not clear, and the hand-over slots of K-CHIM-B: device scratch of the context, grow-only
-    const size_t list_bytes = (n + 64) * sizeof(uint32_t);
+    const size_t list_bytes = (2 * n + 64) * sizeof(uint32_t);
     if (ctx->chim_list_bytes < list_bytes) {
         if (ctx->chim_list) (void)hipFree(ctx->chim_list);
         ctx->chim_list = nullptr;
@@ -1260,6 +1472,46 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
             }
             SMI_HIP(hipGetLastError());
+            // reads with more than kCap accepted positions / matches: once more without the cap (K-CHIM-S).  The overflow queue sits
+            // behind the main queue in the same buffer (the main queue never uses more than n entries, the buffer holds 2 n + 64)
+            uint32_t *d_over_count = d_count + 1, *d_over = d_list + n;
+            hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over, d_over_count);
+            uint32_t n_over = 0;
+            SMI_HIP(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, s));
+            SMI_HIP(hipStreamSynchronize(s));
+            if (n_over) {
+                std::vector<uint32_t> over(n_over);
+                std::vector<uint64_t> offs(n + 1);
+                SMI_HIP(hipMemcpyAsync(over.data(), d_over, (size_t)n_over * 4, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipMemcpyAsync(offs.data(), d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipStreamSynchronize(s));
+                std::sort(over.begin(), over.end());  // the collection order is not deterministic; the results do not depend on it
+                std::vector<uint64_t> scr_off(n_over + 1, 0);
+                for (uint32_t i = 0; i < n_over; i++) scr_off[i + 1] = scr_off[i] + 7 * (offs[over[i] + 1] - offs[over[i]] + 8);
+                uint64_t *d_scr_off = nullptr;
+                int32_t *d_scr = nullptr;
+                uint32_t *d_over_sorted = nullptr;
+                SMI_HIP(hipMalloc(&d_scr_off, (n_over + 1) * 8));
+                hipError_t e = hipMalloc(&d_scr, scr_off[n_over] * 4);
+                if (e == hipSuccess) e = hipMalloc(&d_over_sorted, (size_t)n_over * 4);
+                if (e != hipSuccess) {
+                    (void)hipFree(d_scr_off);
+                    (void)hipFree(d_scr);
+                    return hip_fail(e, "hipMalloc (K-CHIM-S scratch)");
+                }
+                SMI_HIP(hipMemcpyAsync(d_scr_off, scr_off.data(), (n_over + 1) * 8, hipMemcpyHostToDevice, s));
+                SMI_HIP(hipMemcpyAsync(d_over_sorted, over.data(), (size_t)n_over * 4, hipMemcpyHostToDevice, s));
+                const unsigned gs = (unsigned)std::min<uint32_t>(n_over, 4096);
+                if (tl == 27)
+                    hipLaunchKernelGGL((k_chimera_serial<27, 22>), dim3(gs), dim3(64), 0, s, d_planes, st, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
+                else
+                    hipLaunchKernelGGL((k_chimera_serial<22, 25>), dim3(gs), dim3(64), 0, s, d_planes, st, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
+                hipError_t e2 = hipStreamSynchronize(s);
+                (void)hipFree(d_scr_off);
+                (void)hipFree(d_scr);
+                (void)hipFree(d_over_sorted);
+                if (e2 != hipSuccess) return hip_fail(e2, "k_chimera_serial");
+            }
         }
     }
     if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;

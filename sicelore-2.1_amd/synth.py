@@ -360,11 +360,20 @@ def gen_reads_5p(n, used_keys, seed=6, device=None, err=0.063, frac=(0.4, 0.3, 0
             "mid_len": mid_len, "reverse": reverse, "truth": truth, "umi": umi_key}
 
 
-def fastq_text_device(rd):
+def fastq_text_device(rd, chimera_frac=0.0, seed=11):
     """FASTQ text of a read batch, built on the device: records "@rNNNNNNNN\n" bases "\n+\n" qualities "\n" (qualities 'I').
+    chimera_frac > 0: that fraction of the record boundaries is dropped, i.e. two neighbouring molecules become ONE record (a
+    ligation chimera: 3' adapter of one next to the TSO of the next), as tools/microbench.py does for K-CHIM.
     -> (text uint8 tensor, contiguous bases, offsets)"""
     buf, offs = materialize_device(rd)
     dev = buf.device
+    if chimera_frac > 0:
+        n0 = offs.numel() - 1
+        keep = torch.ones(n0 + 1, dtype=torch.bool, device=dev)
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        keep[1:n0][torch.rand(n0 - 1, device=dev, generator=g) < chimera_frac] = False
+        offs = offs[keep].contiguous()
     n = offs.numel() - 1
     lens = offs[1:] - offs[:-1]
     rec_len = 2 * lens + 15  # 11 + len + 3 + len + 1

@@ -51,9 +51,43 @@ def test_chimera_matches_oracle_on_synthetic_chimeras(pkg, sor, synth):
     res, *_ = _run(pkg, ctx, seqs)
     n_split, n_multi = _compare(sor, seqs, res)
     assert n_split > 500 and n_multi > 50
-    # more than 64 internal TSO hits in one read (here: every position of an all-N read) is reported, not guessed
-    res, *_ = _run(pkg, ctx, ["N" * 600])
-    assert res["flags"][0] & pkg.lib.CHIM_OVERFLOW
+
+
+@pytest.mark.gpu
+def test_reads_with_more_than_64_internal_hits_are_computed_not_flagged(pkg, sor, synth):
+    """the reference has no cap on internal TSO / adapter hits (ChimeraFindernew.java:L107-332): all-N reads, TSO concatemers,
+    homopolymers and low-complexity reads go through K-CHIM-S and equal the oracle; a chunk that holds them does not fail"""
+    import random
+
+    rng = random.Random(23)
+    tso, tso_rc = "AAGCAGTGGTATCAACGCAGAGTACAT", "ATGTACTCTGCGTTGATACCACTGCTT"
+    rnd = lambda k: "".join(rng.choice("ACGT") for _ in range(k))  # noqa: E731
+    seqs = ["N" * 600, "N" * 2300,
+            rnd(150) + "".join(tso + rnd(rng.randrange(95, 140)) for _ in range(90)) + rnd(150),           # 90 spaced TSO copies
+            rnd(100) + "".join((tso if k % 2 else tso_rc) + rnd(130) for k in range(80)) + rnd(100),       # both orientations
+            rnd(200) + "".join(tso[:rng.randrange(20, 27)] + rnd(3) for _ in range(200)) + rnd(200),       # dense, overlapping hits
+            rnd(300) + ("A" * 40 + "CTACACGACGCTCTTCCGATCT"[::-1] + rnd(60)) * 30 + rnd(300),             # many polyA stretches
+            "ACGTN" * 500, "AAGCAGTGGTATCAACGCAGAGTACAT" * 60]
+    reads = synth.gen_reads(40, synth.pick_used(synth.make_whitelist(5000, seed=91), 20, seed=92), seed=93)
+    seqs += [synth.materialize(reads, i)[0] for i in range(40)]
+    ctx = pkg.Context(0)
+    res, *_ = _run(pkg, ctx, seqs)
+    assert not (res["flags"] & pkg.lib.CHIM_OVERFLOW).any()
+    n_big = 0
+    for i, s in enumerate(seqs):
+        rc, splits, multi, n_matches, _ = sor.chimera_split(s)
+        got = [(sor.SPLIT_REASONS[res["reason"][i][k]], int(res["pos"][i][k])) for k in range(res["n_split"][i])]
+        if rc != 0:
+            assert res["flags"][i] & pkg.lib.CHIM_RANGE, i   # the reference's substring would throw
+            continue
+        assert got == splits and bool(res["flags"][i] & 1) == multi and res["n_matches"][i] == n_matches, (i, got, splits, n_matches)
+        n_big += n_matches > 64
+    assert n_big >= 2
+    # the native chunk worker takes the same reads in its stride
+    text = "".join(f"@r{i} x\n{s}\n+\n{'5' * len(s)}\n" for i, s in enumerate(seqs) if not (res["flags"][i] & pkg.lib.CHIM_RANGE)).encode()
+    ctx.set_barcode_set(np.arange(100, dtype=np.uint64) * 977, mode=0)
+    passed, failed, info = ctx.scanfastq_pass2_chunk(text)
+    assert info["n_records_in"] >= 40 and info["n_records_out"] >= info["n_records_in"]
 
 
 @pytest.mark.gpu
