@@ -217,6 +217,13 @@ int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const 
  * barcode in the ascending key list of the loaded set (the index smi_hist_device uses), so the vector is dense and is summed
  * across GPUs with one all-reduce.  d_counts: 3 * n_keys u32, zeroed by the caller before the first batch. */
 int smi_bc_counts_device(smi_ctx *ctx, const smi_bc_result *d_results, size_t n, uint32_t *d_counts, void *stream);
+/* BarcodeList.tsv (ParseStatsHtmlPrinter.writesedBarcodesListTSV, FJ!nanoporereadscanner/stats/ParseStatsHtmlPrinter.java:L235-285) from the
+ * same inputs as smi_finalize_used_list: the used barcodes in rank order with their pass-1 counts and, per edit distance that occurs, the
+ * barcode each collides with -- `BC(count x)` when that one is in the used list too, `BC(count m)` when it was merged away.  no_whitelist:
+ * the run had no list of possible barcodes (rows with AAAAA / TTTTT are left out, UsedCellBCListGenerator.java:L419).  out == NULL: size only.
+ * Host only. */
+int smi_barcode_list_tsv(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count, int merge_ed, int min_count_fold,
+                         int cells_fold_below_max, int no_whitelist, char *out, size_t cap, size_t *n_out);
 /* BarcodesAssigned.tsv from those counters (ParseStatsHtmlPrinter.writeAssignedTSV, ParseStatsHtmlPrinter.java:L294-327);
  * keys ascending as loaded; rows with equal counts by ascending key (the reference: HashMap order).  out == NULL: size only. */
 int smi_assigned_tsv(const uint64_t *keys, const uint32_t *counts, size_t n_keys, int max_ed, char *out, size_t cap,

@@ -130,20 +130,20 @@ struct KC {
 
 using namespace smi;
 
-extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count,
-                                      int merge_ed, int min_count_fold, int cells_fold_below_max, uint64_t *out_keys,
-                                      uint32_t *out_counts, uint32_t *out_rank, size_t *n_out) {
-    if (!n_out || (n && (!keys || !counts || !out_keys || !out_counts || !out_rank)) || merge_ed < 0 || merge_ed > 2 ||
-        min_count_fold <= 0 || cells_fold_below_max <= 0) {
-        set_error("smi_finalize_used_list: bad argument");
-        return SMI_ERR_INVALID;
-    }
-    *n_out = 0;
+namespace {
+struct Finalized {
+    std::vector<KC> f;                       // after the low-count filter, ascending key
+    std::vector<std::vector<Hit>> coll;      // per entry of f: its collision matches (one per level at most), empty = none
+    std::vector<KC> fin;                     // the used list, by count descending (canonical tie: ascending key)
+};
+
+void finalize_core(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count, int merge_ed, int min_count_fold,
+                   int cells_fold_below_max, Finalized &R) {
     const float cutoff = (2.0f * (float)record_count) / 5000000.0f;  // UsedCellBCListGenerator.java:L391
-    std::vector<KC> f;
+    std::vector<KC> &f = R.f;
     for (size_t i = 0; i < n; i++)
         if ((float)counts[i] > cutoff && counts[i] > 1) f.push_back({keys[i], counts[i]});  // L359-363
-    if (f.empty()) return SMI_OK;
+    if (f.empty()) return;
     std::sort(f.begin(), f.end(), [](const KC &a, const KC &b) { return a.key < b.key; });
     std::unordered_set<uint64_t> set;
     set.reserve(f.size() * 2);
@@ -152,21 +152,20 @@ extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *coun
         auto it = std::lower_bound(f.begin(), f.end(), k, [](const KC &a, uint64_t v) { return a.key < v; });
         return (it != f.end() && it->key == k) ? (long)(it - f.begin()) : -1;
     };
-    struct Coll {
-        size_t self;
-        std::vector<Hit> hits;
-    };
-    std::vector<Coll> cs;
+    R.coll.assign(f.size(), {});
+    std::vector<size_t> cs;  // entries with collisions (stored only when non-empty, BarcodeDatasetColissionTester.java:L240-241)
     std::vector<Hit> hits;
     for (size_t i = 0; i < f.size(); i++) {
         collision_matches(set, f[i].key, merge_ed, hits);
-        if (!hits.empty()) cs.push_back({i, hits});  // stored only when non-empty (BarcodeDatasetColissionTester.java:L240-241)
+        if (!hits.empty()) {
+            R.coll[i] = hits;
+            cs.push_back(i);
+        }
     }
     // entries by count of their key, descending; canonical tie: key ascending (L166-167)
-    std::vector<size_t> ord(cs.size());
-    for (size_t i = 0; i < ord.size(); i++) ord[i] = i;
+    std::vector<size_t> ord(cs);
     std::sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
-        const KC &x = f[cs[a].self], &y = f[cs[b].self];
+        const KC &x = f[a], &y = f[b];
         return x.count != y.count ? x.count > y.count : x.key < y.key;
     });
     // java.util.HashMap<Long, Set<Long>> iteration order of toMergeMap (insertion = ord): buckets ascending at the
@@ -175,7 +174,7 @@ extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *coun
     while (ord.size() > (cap * 3) / 4) cap <<= 1;
     std::vector<std::pair<uint32_t, size_t>> it(ord.size());
     for (size_t i = 0; i < ord.size(); i++) {
-        const uint64_t k = f[cs[ord[i]].self].key;
+        const uint64_t k = f[ord[i]].key;
         uint32_t h = (uint32_t)(k ^ (k >> 32));
         h ^= h >> 16;
         it[i] = {h & (uint32_t)(cap - 1), i};
@@ -183,10 +182,10 @@ extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *coun
     std::stable_sort(it.begin(), it.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     std::vector<uint8_t> alive(f.size(), 1);
     for (const auto &e : it) {  // L188-195
-        const Coll &c = cs[ord[e.second]];
-        if (!alive[c.self]) continue;
-        const uint32_t cut = f[c.self].count / (uint32_t)min_count_fold;  // L168 integer division
-        for (const Hit &h : c.hits) {
+        const size_t self = ord[e.second];
+        if (!alive[self]) continue;
+        const uint32_t cut = f[self].count / (uint32_t)min_count_fold;  // L168 integer division
+        for (const Hit &h : R.coll[self]) {
             if (h.ed > merge_ed) continue;
             const long p = index_of(h.bc);
             if (p >= 0 && f[p].count < cut) alive[p] = 0;  // L171-172, L194
@@ -196,17 +195,104 @@ extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *coun
     for (size_t i = 0; i < f.size(); i++)
         if (alive[i]) mx = std::max(mx, f[i].count);
     const uint32_t min_counts = mx / (uint32_t)cells_fold_below_max;  // L198
-    std::vector<KC> fin;
     for (size_t i = 0; i < f.size(); i++)
-        if (alive[i] && f[i].count >= min_counts) fin.push_back(f[i]);
-    std::sort(fin.begin(), fin.end(),
+        if (alive[i] && f[i].count >= min_counts) R.fin.push_back(f[i]);
+    std::sort(R.fin.begin(), R.fin.end(),
               [](const KC &a, const KC &b) { return a.count != b.count ? a.count > b.count : a.key < b.key; });
-    for (size_t i = 0; i < fin.size(); i++) {
-        out_keys[i] = fin[i].key;
-        out_counts[i] = fin[i].count;
+}
+
+std::string bc_string(uint64_t key) {  // NucleicAcidTwoBitPerBase.toString of a 16-mer: A 0, G 1, C 2, T 3, first base in the high bits
+    std::string s(16, 'A');
+    for (int i = 0; i < 16; i++) s[i] = "AGCT"[(key >> (2 * (15 - i))) & 3];
+    return s;
+}
+}  // namespace
+
+extern "C" int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count,
+                                      int merge_ed, int min_count_fold, int cells_fold_below_max, uint64_t *out_keys,
+                                      uint32_t *out_counts, uint32_t *out_rank, size_t *n_out) {
+    if (!n_out || (n && (!keys || !counts || !out_keys || !out_counts || !out_rank)) || merge_ed < 0 || merge_ed > 2 ||
+        min_count_fold <= 0 || cells_fold_below_max <= 0) {
+        set_error("smi_finalize_used_list: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    *n_out = 0;
+    Finalized R;
+    finalize_core(keys, counts, n, record_count, merge_ed, min_count_fold, cells_fold_below_max, R);
+    for (size_t i = 0; i < R.fin.size(); i++) {
+        out_keys[i] = R.fin[i].key;
+        out_counts[i] = R.fin[i].count;
         out_rank[i] = (uint32_t)(i + 1);  // WorkerReadscanner.java:L266-270
     }
-    *n_out = fin.size();
+    *n_out = R.fin.size();
+    return SMI_OK;
+}
+
+// BarcodeList.tsv (ParseStatsHtmlPrinter.writesedBarcodesListTSV, FJ!nanoporereadscanner/stats/ParseStatsHtmlPrinter.java:L235-285) from the
+// same pass-1 counters: header "Barcode\tn Reads with full match" + one "BCs colliding at ED k" column per edit distance that occurs among
+// the collision matches (BarcodeDatasetColissionTester.getUnfilteredColissionData L126-144: a TreeMap over the distances); one row per used
+// barcode in rank order (LinkedHashMap filled by count descending, UsedCellBCListGenerator.java:L367-371); a collision cell lists the colliding
+// barcode as `BC(count x)` when it is itself in the used list and `BC(count m)` (its unfiltered count: merged away) otherwise (L257-263).
+// no_whitelist != 0: the run had no list of possible barcodes and rows whose barcode holds AAAAA or TTTTT are left out (L419).
+extern "C" int smi_barcode_list_tsv(const uint64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count, int merge_ed,
+                                    int min_count_fold, int cells_fold_below_max, int no_whitelist, char *out, size_t cap, size_t *n_out) {
+    if (!n_out || (n && (!keys || !counts)) || merge_ed < 0 || merge_ed > 2 || min_count_fold <= 0 || cells_fold_below_max <= 0) {
+        set_error("smi_barcode_list_tsv: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    Finalized R;
+    finalize_core(keys, counts, n, record_count, merge_ed, min_count_fold, cells_fold_below_max, R);
+    bool ed_seen[4] = {false, false, false, false};
+    for (const auto &h : R.coll)
+        for (const Hit &x : h)
+            if (x.ed >= 0 && x.ed < 4) ed_seen[x.ed] = true;
+    std::string txt = "Barcode\tn Reads with full match\t";
+    bool first = true;
+    for (int e = 0; e < 4; e++)
+        if (ed_seen[e]) {
+            if (!first) txt += "\t";
+            txt += "BCs colliding at ED " + std::to_string(e);
+            first = false;
+        }
+    txt += "\n";
+    auto idx_f = [&](uint64_t k) -> long {
+        auto it = std::lower_bound(R.f.begin(), R.f.end(), k, [](const KC &a, uint64_t v) { return a.key < v; });
+        return (it != R.f.end() && it->key == k) ? (long)(it - R.f.begin()) : -1;
+    };
+    std::unordered_set<uint64_t> used;
+    auto shown = [&](uint64_t k) {
+        if (!no_whitelist) return true;
+        const std::string b = bc_string(k);
+        return b.find("TTTTT") == std::string::npos && b.find("AAAAA") == std::string::npos;
+    };
+    for (const KC &e : R.fin)
+        if (shown(e.key)) used.insert(e.key);
+    for (const KC &e : R.fin) {
+        if (!shown(e.key)) continue;
+        txt += bc_string(e.key) + "\t" + std::to_string(e.count);
+        const long self = idx_f(e.key);
+        for (int ed = 0; ed < 4; ed++) {
+            if (!ed_seen[ed]) continue;
+            txt += "\t";
+            bool any = false;
+            for (const Hit &h : R.coll[(size_t)self]) {
+                if (h.ed != ed) continue;
+                if (any) txt += ",";
+                any = true;
+                const long p = idx_f(h.bc);
+                const uint32_t c = p >= 0 ? R.f[(size_t)p].count : 0;  // unfilteredUsedBarcodeMap count of the colliding barcode
+                txt += bc_string(h.bc) + "(" + std::to_string(c) + (used.count(h.bc) ? " x)" : " m)");
+            }
+        }
+        txt += "\n";
+    }
+    *n_out = txt.size();
+    if (!out) return SMI_OK;
+    if (cap < txt.size()) {
+        set_error("smi_barcode_list_tsv: output buffer too small");
+        return SMI_ERR_INVALID;
+    }
+    std::memcpy(out, txt.data(), txt.size());
     return SMI_OK;
 }
 

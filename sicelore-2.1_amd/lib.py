@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv",
 ]
 
 
@@ -132,6 +132,7 @@ def load_library():
     lib.smi_ref_position_at_read_position.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ci, ctypes.c_char_p, sz]
+    lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     explicit = {"smi_last_error", "smi_version", "smi_read_planes_words"}  # restype set above (char*, size_t)
     for name in EXPORTS:
@@ -171,6 +172,21 @@ def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10
         raise SmiError(f"smi_finalize_used_list error {rc}: {lib.smi_last_error().decode()}")
     m = n_out.value
     return ok[:m], oc[:m], orank[:m]
+
+
+def barcode_list_tsv(keys, counts, record_count, merge_ed=1, min_count_fold=10, cells_fold_below_max=500, no_whitelist=False):
+    """BarcodeList.tsv text (smi_barcode_list_tsv) from the pass-1 histogram (non-zero keys / counts, as for finalize_used_list)"""
+    lib = load_library()
+    k = np.ascontiguousarray(keys, dtype=np.uint64)
+    c = np.ascontiguousarray(counts, dtype=np.uint32)
+    n = ctypes.c_size_t(0)
+    args = (_ptr(k), _ptr(c), k.size, int(record_count), int(merge_ed), int(min_count_fold), int(cells_fold_below_max), int(no_whitelist))
+    if lib.smi_barcode_list_tsv(*args, None, 0, ctypes.byref(n)):
+        raise SmiError(lib.smi_last_error().decode())
+    out = ctypes.create_string_buffer(n.value + 1)
+    if lib.smi_barcode_list_tsv(*args, out, n.value, ctypes.byref(n)):
+        raise SmiError(lib.smi_last_error().decode())
+    return out.raw[:n.value].decode()
 
 
 def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0, five_prime=False):

@@ -46,7 +46,7 @@ class JHashMap:
                 yield e[1], e[2]
 
 
-def model_finalize(keys, counts, record_count, merge_ed, fold=10, below=500):
+def model_finalize(keys, counts, record_count, merge_ed, fold=10, below=500, details=None):
     f32 = np.float32
     cutoff = f32(f32(2.0) * f32(record_count)) / f32(5000000.0)
     cnt = {int(k): int(c) for k, c in zip(keys, counts) if f32(c) > cutoff and c > 1}
@@ -70,6 +70,8 @@ def model_finalize(keys, counts, record_count, merge_ed, fold=10, below=500):
                 alive.pop(x, None)
     mn = max(alive.values()) // below
     fin = sorted(((k, c) for k, c in alive.items() if c >= mn), key=lambda kc: (-kc[1], kc[0]))
+    if details is not None:
+        details.update(cnt=cnt, coll=coll)
     return [k for k, _ in fin], [c for _, c in fin], list(range(1, len(fin) + 1))
 
 
@@ -255,3 +257,42 @@ def test_two_rank_assigned_counters(pkg, tmp_path):
     total = rng.integers(0, 5000, (300, 3)).astype(np.uint32)
     exp = _model_assigned_tsv(keys, total, 2)
     assert open(tmp_path / "tsv0.txt").read() == exp == open(tmp_path / "tsv1.txt").read()
+
+
+def _bc_str(k):
+    return "".join("AGCT"[(k >> (2 * (15 - i))) & 3] for i in range(16))
+
+
+def model_barcode_list_tsv(keys, counts, record_count, merge_ed, no_whitelist=False):
+    """ParseStatsHtmlPrinter.writesedBarcodesListTSV (L235-285) on top of model_finalize"""
+    det = {}
+    fk, fc, _ = model_finalize(keys, counts, record_count, merge_ed, details=det)
+    if not det:
+        return "Barcode\tn Reads with full match\t\n"
+    cnt, coll = det["cnt"], det["coll"]
+    eds = sorted({m["ed"] for ms in coll.values() for m in ms})                      # TreeMap over the distances that occur
+    shown = [(k, c) for k, c in zip(fk, fc) if not (no_whitelist and ("TTTTT" in _bc_str(k) or "AAAAA" in _bc_str(k)))]
+    used = {k: c for k, c in shown}
+    out = ["Barcode\tn Reads with full match\t" + "\t".join(f"BCs colliding at ED {e}" for e in eds) + "\n"]
+    for k, c in shown:
+        row = f"{_bc_str(k)}\t{c}"
+        for e in eds:
+            row += "\t" + ",".join(f"{_bc_str(m['matching_bc'])}({used[m['matching_bc']]} x)" if m["matching_bc"] in used
+                                    else f"{_bc_str(m['matching_bc'])}({cnt[m['matching_bc']]} m)" for m in coll.get(k, []) if m["ed"] == e)
+        out.append(row + "\n")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("merge_ed", [1, 2])
+def test_barcode_list_tsv_equals_model(pkg, merge_ed):
+    from sicelore_amd import lib as libmod
+
+    for seed in (3, 4, 5):
+        keys, counts = make_case(seed, n_cells=90, deep=seed == 5)
+        for no_wl in (False, True):
+            got = libmod.barcode_list_tsv(keys, counts, 40, merge_ed=merge_ed, no_whitelist=no_wl)
+            exp = model_barcode_list_tsv(keys, counts, 40, merge_ed, no_whitelist=no_wl)
+            assert got == exp
+            rows = got.splitlines()
+            assert rows[0].startswith("Barcode\tn Reads with full match\t") and len(rows) > 40
+    assert " x)" in got or " m)" in got

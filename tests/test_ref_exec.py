@@ -312,3 +312,27 @@ def test_read_name_parser_equals_reference_bytecode(pkg, name):
         assert (d["bc"]["seq"], d["bc"]["ed"], d["bc"]["start"], d["bc"]["end"], d["bc"]["rank"]) == (b["seq"], b["ed"], b["start"], b["end"], b["rank"])
         assert [au._CODE[ch] for ch in d["x"]] == nm["x_codes"]
         assert np.float32(d["q"]) == np.float32(nm["mean_qv"]) and d["read_id"] == nm["read_id"]
+
+
+# ---- a-14: the chimera splitter ------------------------------------------------------------------------------------------
+def test_chimera_split_equals_reference_bytecode(sor):
+    sec = load("chimera_3p")["sections"][0]
+    fv = sec["flag_values"]
+    n_split = n_multi = 0
+    for c in sec["cases"]:
+        assert c["hash_orders_agree"] and isinstance(c["records"], list), c["name"]
+        rc, splits, multi, _n, raw = sor.chimera_split(c["seq"])
+        assert rc == 0
+        cuts = [0] + [p for _, p in splits] + [len(c["seq"])]
+        want = c["records"]
+        assert len(want) == len(cuts) - 1, (c["name"], splits, [w["name"] for w in want])
+        for k, w in enumerate(want):
+            name = sor.chimera_fragment_name(c["name"], raw, k) if splits else c["name"]
+            assert name == w["name"] and cuts[k + 1] - cuts[k] == w["length"], (c["name"], k, name, w)
+            assert c["seq"][cuts[k]:cuts[k] + 24] == w["bases_head"]
+            # flags the splitter leaves: READS_AFTER_SPLIT on fragments, MULTI_CHIMERIC_READS_DISCARDED | FAILED on reads kept whole
+            expect = fv["READS_AFTER_SPLIT"] if splits else ((fv["MULTI_CHIMERIC_READS_DISCARDED"] | fv["FAILED"]) if multi else 0)
+            assert w["flag"] == expect, (c["name"], hex(w["flag"]), hex(expect))
+        n_split += bool(splits)
+        n_multi += multi
+    assert n_split >= 8 and n_multi >= 1

@@ -86,3 +86,38 @@ def test_k_umi_distances_equal_reference_bytecode(pkg, gpu_ctx, name):
                 # the reference fills [v][i] with the TRANSPOSED copy of [i][v] (L213-216), not with calcEditDistances(v, i)
                 want = {"ed": c["distance"]["ed"], "pos1": c["distance"]["pos2"], "pos2": c["distance"]["pos1"]}
             assert (r & 15, (r >> 4) & 3, (r >> 6) & 3) == (want["ed"], pos[want["pos1"]], pos[want["pos2"]]), (a, b, want, r)
+
+
+def test_k_chim_equals_reference_bytecode(pkg, gpu_ctx):
+    """K-PACKR + K-CHIM-A/B/C (+ fragment names) == ChimeraFindernew.findSplitPositions executed from the reference's class files"""
+    import torch
+
+    with open(os.path.join(GOLD, "ref_exec_chimera_3p.json")) as f:
+        sec = json.load(f)["sections"][0]
+    seqs = [c["seq"] for c in sec["cases"]]
+    dev = torch.device("cuda", gpu_ctx.device)
+    n = len(seqs)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    total = int(offs[-1])
+    d_reads = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()).to(dev)
+    d_offs = torch.from_numpy(offs.astype(np.int64)).to(dev)
+    d_planes = torch.zeros(gpu_ctx.read_planes_words(total, n), dtype=torch.int32, device=dev)
+    gpu_ctx.pack_reads_device(d_reads, d_offs, n, total, d_planes)
+    d_out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    gpu_ctx.chimera_device(d_planes, d_offs, n, total, gpu_ctx.chimera_config(False), d_out)
+    torch.cuda.synchronize()
+    res = d_out.cpu().numpy().view(pkg.CHIMERA_RESULT_DTYPE).reshape(-1)
+    n_split = 0
+    for i, c in enumerate(sec["cases"]):
+        want = c["records"]
+        k = int(res["n_split"][i])
+        cuts = [0] + [int(res["pos"][i][j]) for j in range(k)] + [len(c["seq"])]
+        assert len(want) == k + 1, (c["name"], k, [w["name"] for w in want])
+        for j, w in enumerate(want):
+            name = pkg.lib.chimera_fragment_name(c["name"], res[i], j) if k else c["name"]
+            assert name == w["name"] and cuts[j + 1] - cuts[j] == w["length"], (c["name"], j, name, w["name"])
+        multi = bool(res["flags"][i] & pkg.lib.CHIM_MULTI)
+        assert multi == (len(want) == 1 and want[0]["flag"] != 0)
+        n_split += k > 0
+    assert n_split >= 8

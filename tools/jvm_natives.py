@@ -195,6 +195,13 @@ def install(jvm):
         return JArray("Ljava/lang/String;", parts)
 
     N["java/lang/String.split:(Ljava/lang/String;)[Ljava/lang/String;"] = s_split
+
+    def s_replace_first(j, s, rx, repl):
+        if any(ch in rx for ch in ".$|()[{^?*+\\") or any(ch in repl for ch in "$\\"):
+            raise Unsupported(f"String.replaceFirst regex {rx!r} / replacement {repl!r}")
+        return s.replace(rx, repl, 1)
+
+    N["java/lang/String.replaceFirst"] = s_replace_first
     N["java/lang/CharSequence.length"] = lambda j, s: len(j.to_jstring(s))
     N["java/lang/CharSequence.charAt"] = lambda j, s, i: s_char_at(j, j.to_jstring(s), i)
     N["java/lang/CharSequence.toString"] = lambda j, s: j.to_jstring(s)
@@ -961,6 +968,11 @@ def install_streams(jvm):
     N["java/util/Comparator.thenComparingInt"] = lambda j, c, n: then_comparing(j, c, n, "num")
     for k in [k for k in N if k.startswith("java/util/Comparator.") and "thenComparing" in k]:
         N["$Comparator." + k.split(".", 1)[1]] = N[k]
+    N["java/util/Collections.singleton"] = lambda j, v: _list(j, [v])          # one element: no order to speak of
+    N["java/util/Collections.singletonList"] = lambda j, v: _list(j, [v])
+    N["java/util/Collections.emptyList"] = lambda j: _list(j, [])
+    N["java/util/Collections.emptySet"] = lambda j: _list(j, [])
+    N["java/util/Collections.unmodifiableList"] = lambda j, c: c
     N["java/util/function/Function.identity"] = lambda j: fn_obj(lambda v: v)
 
     def list_sort(j, o, cmp):
@@ -1246,6 +1258,7 @@ def install_env(jvm):
         N[f"{c}.getAndIncrement"] = (lambda w: lambda j, o: (o.native[0], o.native.__setitem__(0, w(o.native[0] + 1)))[0])(wrap)
         N[f"{c}.addAndGet"] = (lambda w: lambda j, o, d: (o.native.__setitem__(0, w(o.native[0] + d)), o.native[0])[1])(wrap)
         N[f"{c}.getAndAdd"] = (lambda w: lambda j, o, d: (o.native[0], o.native.__setitem__(0, w(o.native[0] + d)))[0])(wrap)
+        N[f"{c}.getAndSet"] = lambda j, o, v: (o.native[0], o.native.__setitem__(0, v))[0]
         N[f"{c}.decrementAndGet"] = (lambda w: lambda j, o: (o.native.__setitem__(0, w(o.native[0] - 1)), o.native[0])[1])(wrap)
 
     # java.text.DecimalFormat: only patterns made of '#', '0', ',', '.'; RoundingMode.HALF_EVEN on the exact binary value

@@ -770,10 +770,81 @@ def gen_umi_3p(g):
 def gen_umi_5p(g):
     return gen_umi(g, True, 818)
 
+# ---------------------------------------------------------------------------------------------------------------------
+# a-14: ChimeraFindernew.findSplitPositions on whole records (pass 2, before the scan)
+# ---------------------------------------------------------------------------------------------------------------------
+CHIM = "com/rw/nanoporereadscanner/analyzers/ChimeraFindernew"
+NPSET = "com/rw/nanopore/analyzers/parameters/NeedlemanParameters$OneSet"
+RFLAGS = "com/rw/nanoporereadscanner/stats/ReadFlags"
+
+
+def gen_chimera(g, five_prime=False, seed=909, n_reads=26):
+    j = g.j
+    rng = random.Random(seed)
+    p2 = Pass2(g, five_prime, 1, dont_search_polya=False)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section(("5-prime" if five_prime else "3-prime") + " barcoding: new ChimeraFindernew(params, new NeedlemanParameters$OneSet())"
+                  ".findSplitPositions(record, readFlags, skip = false) (L107-332): the records it returns (names with the _<reason>sp<k> tag, bases) "
+                  "and the flag it leaves on each; each case under three iteration orders of the JDK hash containers", CHIM,
+                  "findSplitPositions:(L...FastqRecordExt;L...ReadFlags;Z)Ljava/util/Collection;")
+    s["five_prime"] = five_prime
+    bcs = [rnd_seq(rng, 16) for _ in range(12)]
+
+    def molecule(kind):
+        seq, _q, _b = synth_read(rng, bcs, five_prime, kind)
+        return seq
+
+    for idx in range(n_reads):
+        k = idx % 9
+        if k in (0, 1):
+            seq = molecule(idx)                                   # a single molecule
+        elif k in (2, 3, 4):
+            seq = molecule(idx) + molecule(idx + 1)               # ligation chimera of two
+        elif k == 5:
+            seq = molecule(idx) + molecule(idx + 1) + molecule(idx + 2)
+        elif k == 6:
+            seq = molecule(1) + molecule(2) + molecule(3) + molecule(4)   # too many split points -> MULTI, read kept whole
+        elif k == 7:
+            a = molecule(idx)
+            seq = a[:len(a) // 2] + "A" * 35 + revcomp_str(AD3) + rnd_seq(rng, 40) + TSO + a[len(a) // 2:]  # internal polyA + adapter + TSO
+        else:
+            seq = rnd_seq(rng, rng.randrange(150, 260))           # below 2 * 70 + 100
+        qual = "".join(chr(33 + rng.randrange(3, 35)) for _ in seq)
+        name = f"read{idx:04d} runid=abc ch={idx}"
+        results = []
+        for order in ("insertion", "reverse", ("shuffle", idx + 1)):
+            j.hash_order = order
+            fq = p2.record(name, seq, qual)
+            cf = j.new(CHIM, f"(L{PAR};L{NPSET};)V", p2.par, j.new(NPSET))
+            rf = j.new_object(RFLAGS)   # statistics object: its counters are not outputs of this path; atomics created, the rest left null
+            jc = j.load(RFLAGS)
+            for fname, fdesc in jc.instance_fields:
+                if fdesc in ("Ljava/util/concurrent/atomic/AtomicLong;", "Ljava/util/concurrent/atomic/AtomicInteger;"):
+                    rf.f[fname] = j.natives[fdesc[1:-1] + ".<new>"](j)
+            try:
+                coll = j.call_virtual(cf, "findSplitPositions", f"(L{FQX};L{RFLAGS};Z)Ljava/util/Collection;", fq, rf, 0)  # skip = !doSplitChimericReads (Parser.java:L180)
+                recs = [{"name": r.f["readName"], "length": len(r.f["readString"]), "bases_head": r.f["readString"][:24],
+                         "flag": u64(r.f["scanResult"].f["flag"])} for r in coll.native]
+                results.append(recs)
+            except JavaThrow as e:
+                results.append({"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:6]})
+        j.hash_order = None
+        s["cases"].append({"name": name, "seq": seq, "hash_orders_agree": all(r == results[0] for r in results[1:]), "records": results[0]})
+        if idx % 5 == 0:
+            print(f"  chimera {idx + 1}/{n_reads}  {time.time() - g.t0:.0f}s", flush=True)
+    vals = j.call_static(FLAGS, "values", f"()[L{FLAGS};")
+    s["flag_values"] = {v.f["$name"]: u64(j.call_virtual(v, "getValue", "()J")) for v in vals.a}
+    out["sections"].append(g.finish(s))
+    return out
+
+
+def gen_chimera_3p(g):
+    return gen_chimera(g, False, 909)
+
 
 SECTIONS = {"twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
-            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p}
+            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
 
 def main():
