@@ -201,11 +201,22 @@ int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_
                          size_t n, int five_prime, uint32_t *d_ends, int32_t *d_read_len, uint8_t *d_qtail,
                          uint32_t *d_qsum, void *stream);
 
+/* smi_scan_batch: the same from host buffers (ASCII bases, optional ASCII qualities, offsets[n_reads + 1]): upload, K-PACK, K-SCAN, download;
+ * out_windows may be NULL */
+int smi_scan_batch(smi_ctx *ctx, const uint8_t *bases, const uint8_t *quals, const uint64_t *offsets, size_t n_reads,
+                   const smi_scan_config *cfg, smi_scan_result *out, smi_bc_window *out_windows);
 /* d_qtail / d_qsum may be NULL (pass 2); d_windows may be NULL.  windows[i] is the smi_bc_window of read i (valid flag
  * clear when no adapter was found), ready for smi_bc_match_device. */
 int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_len, const uint8_t *d_qtail,
                     const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
                     smi_bc_window *d_windows, void *stream);
+
+/* The one exchange of the path for a single-process host that drives several GPUs -- the shape of the reference, one JVM:
+ * element-wise sum of the pass-1 histograms of n_ctx contexts, one per GPU, in place, over RCCL (xGMI).  d_hist[i]: n_counters u32 on the
+ * device of ctxs[i] (n_counters = number of loaded keys; every context holds the same barcode set).  Runs on the contexts' own streams and
+ * returns when all of them have drained; RCCL is dlopen-ed on first use.  The reference's threads add into one ConcurrentHashMap instead
+ * (UsedCellBCListGenerator.java:L224-229); multi-process hosts use their own collective (sicelore-2.1_amd/distributed.py). */
+int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, size_t n_counters);
 
 /* pass-1 histogram straight from scan output: for reads with pass1_ok, key = offset-0 barcode of the window
  * (UsedCellBCListGenerator.java:L207-229); ++hist[ordinal(key)] when the key is in the loaded set */
@@ -257,6 +268,9 @@ int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t 
 int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off,
                         const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
                         uint64_t total_pairs, uint8_t *d_out, void *stream);
+/* host buffers in and out: windows of all groups back to back, group g = reads [group_off[g], group_off[g+1]); out: the n x n matrices of
+ * the groups back to back (sum of n^2 bytes), layout as above */
+int smi_umi_dist_batch(smi_ctx *ctx, const uint64_t *windows, const uint32_t *group_off, uint32_t n_groups, uint8_t *out);
 
 /* ================================================================================================================
  * UMI clustering of `assignumis` on the K-UMI matrices (host): replaces the clusterer a (cell barcode, genomic region)

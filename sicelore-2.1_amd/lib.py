@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_scan_batch", "smi_umi_dist_batch",
 ]
 
 
@@ -132,6 +132,9 @@ def load_library():
     lib.smi_ref_position_at_read_position.argtypes = [vp, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, vp]
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ci, ctypes.c_char_p, sz]
+    lib.smi_hist_allreduce.argtypes = [vp, ci, vp, sz]
+    lib.smi_scan_batch.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+    lib.smi_umi_dist_batch.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     explicit = {"smi_last_error", "smi_version", "smi_read_planes_words"}  # restype set above (char*, size_t)
@@ -667,6 +670,27 @@ class Context:
                                                   _ptr(d_mat_off), int(n_groups), int(total_pairs), _ptr(d_out),
                                                   _stream_ptr(stream)))
 
+    # ---- host-buffer forms ---------------------------------------------------------------------------------
+    def scan_batch(self, bases, quals, offsets, cfg, want_windows=True):
+        """smi_scan_batch: numpy uint8 bases (+ qualities or None), uint64 offsets [n+1] -> (SCAN_RESULT_DTYPE [n], BC_WINDOW_DTYPE [n] or None)"""
+        b = np.ascontiguousarray(bases, dtype=np.uint8)
+        q = None if quals is None else np.ascontiguousarray(quals, dtype=np.uint8)
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        n = o.size - 1
+        out = np.zeros(max(n, 1), dtype=SCAN_RESULT_DTYPE)
+        win = np.zeros(max(n, 1), dtype=BC_WINDOW_DTYPE) if want_windows else None
+        self._check(self._lib.smi_scan_batch(self._h, _ptr(b), _ptr(q), _ptr(o), n, _ptr(cfg), _ptr(out), _ptr(win)))
+        return out[:n], (None if win is None else win[:n])
+
+    def umi_dist_batch(self, windows, group_off):
+        """smi_umi_dist_batch: packed windows (uint64) of all groups, group_off uint32 [n_groups + 1] -> the groups' matrices back to back"""
+        w = np.ascontiguousarray(windows, dtype=np.uint64)
+        go = np.ascontiguousarray(group_off, dtype=np.uint32)
+        sizes = np.diff(go.astype(np.int64))
+        out = np.zeros(max(int((sizes * sizes).sum()), 1), dtype=np.uint8)
+        self._check(self._lib.smi_umi_dist_batch(self._h, _ptr(w), _ptr(go), go.size - 1, _ptr(out)))
+        return out[:int((sizes * sizes).sum())]
+
     # ---- timing ------------------------------------------------------------------------------------------
     def set_timing(self, enabled=True):
         self._check(self._lib.smi_set_timing(self._h, int(bool(enabled))))
@@ -682,3 +706,14 @@ class Context:
         ms = ctypes.c_float(-1.0)
         self._check(self._lib.smi_last_kernel_ms(self._h, ctypes.byref(ms)))
         return float(ms.value)
+
+
+def hist_allreduce(contexts, d_hists):
+    """smi_hist_allreduce: in-place sum of the pass-1 histograms (device int32/uint32 tensors, one per context / GPU) over RCCL"""
+    lib = load_library()
+    n = len(contexts)
+    hs = (ctypes.c_void_p * n)(*[c._h for c in contexts])
+    ps = (ctypes.c_void_p * n)(*[ctypes.c_void_p(t.data_ptr()) for t in d_hists])
+    rc = lib.smi_hist_allreduce(hs, n, ps, int(d_hists[0].numel()))
+    if rc != 0:
+        raise SmiError(f"smi_hist_allreduce error {rc}: {lib.smi_last_error().decode()}")
