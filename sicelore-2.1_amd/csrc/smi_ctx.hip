@@ -131,16 +131,67 @@ int smi_ctx_create(int device, smi_ctx **out) {
     return SMI_OK;
 }
 
+// A worker lane: a context of its own (stream, arena, pinned output, timing) that READS the barcode set of `owner` instead of
+// holding the 616 MiB pyramid a second time.  The reference runs nCPU Parser workers over one hashMapForBCfinding
+// (FJ!nanoporereadscanner/WorkerReadscanner.java:L188-204); this is the same shape: one set, several workers whose transfers and
+// kernels overlap.  After the owner has loaded another set (pass 1 -> pass 2) the lanes call smi_ctx_lane_refresh.
+int smi_ctx_create_lane(smi_ctx *owner, smi_ctx **out) {
+    if (!owner || !out) {
+        set_error("smi_ctx_create_lane: null argument");
+        return SMI_ERR_INVALID;
+    }
+    if (owner->set_owner) {
+        set_error("smi_ctx_create_lane: the owner must be a full context, not a lane");
+        return SMI_ERR_INVALID;
+    }
+    *out = nullptr;
+    SMI_HIP(hipSetDevice(owner->device));
+    smi_ctx *ctx = new smi_ctx();
+    ctx->device = owner->device;
+    ctx->set_owner = owner;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int k = 0; k < SMI_K_COUNT && e == hipSuccess; k++) {
+        e = hipEventCreate(&ctx->kev[k][0]);
+        if (e == hipSuccess) e = hipEventCreate(&ctx->kev[k][1]);
+    }
+    if (e != hipSuccess) {
+        smi_ctx_destroy(ctx);
+        return hip_fail(e, "smi_ctx_create_lane");
+    }
+    *out = ctx;
+    return smi_ctx_lane_refresh(ctx);
+}
+
+int smi_ctx_lane_refresh(smi_ctx *lane) {
+    if (!lane || !lane->set_owner) {
+        set_error("smi_ctx_lane_refresh: not a lane");
+        return SMI_ERR_INVALID;
+    }
+    const smi_ctx *o = lane->set_owner;
+    lane->l0 = o->l0;
+    lane->l0s = o->l0s;
+    lane->l1 = o->l1;
+    lane->t2 = o->t2;
+    lane->fine = o->fine;
+    lane->rank = o->rank;
+    lane->block_counts = o->block_counts;
+    lane->n_keys = o->n_keys;
+    lane->set_mode = o->set_mode;
+    return SMI_OK;
+}
+
 int smi_ctx_destroy(smi_ctx *ctx) {
     if (!ctx) return SMI_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->l0);
-    (void)hipFree(ctx->l1);
-    (void)hipFree(ctx->t2);
-    (void)hipFree(ctx->fine);
-    (void)hipFree(ctx->rank);
-    (void)hipFree(ctx->block_counts);
+    if (!ctx->set_owner) {  // a lane borrows these
+        (void)hipFree(ctx->l0);
+        (void)hipFree(ctx->l1);
+        (void)hipFree(ctx->t2);
+        (void)hipFree(ctx->fine);
+        (void)hipFree(ctx->rank);
+        (void)hipFree(ctx->block_counts);
+    }
     (void)hipFree(ctx->stage_in);
     (void)hipFree(ctx->scan_tmp);
     (void)hipFree(ctx->arena);
@@ -198,6 +249,10 @@ int smi_kernel_ms(smi_ctx *ctx, int kernel_id, float *ms) {
 }
 
 int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, int mode, void *stream) {
+    if (ctx && ctx->set_owner) {
+        set_error("smi_set_barcode_set: a lane reads its owner's barcode set; load it on the owner and call smi_ctx_lane_refresh");
+        return SMI_ERR_STATE;
+    }
     if (int rc = bind(ctx)) return rc;
     if ((!d_keys && n) || (mode != SMI_SET_USED_LIST && mode != SMI_SET_WHITELIST)) {
         set_error("smi_set_barcode_set_device: bad argument");

@@ -92,6 +92,7 @@ struct smi_ctx {
     hipStream_t stream = nullptr;  // private stream of the *_batch entry points
     void *scan_tmp = nullptr;      // scratch of the FASTQ indexer (block counts + hipcub temp storage)
     size_t scan_tmp_bytes = 0;
+    const smi_ctx *set_owner = nullptr;  // worker lane (smi_ctx_create_lane): the pyramid pointers above belong to this context
     uint32_t *chim_list = nullptr; // K-CHIM: queue of the reads the filter pass could not clear (+ its counter), grow-only
     size_t chim_list_bytes = 0;
     void *chim_slots = nullptr;    // K-CHIM: matches handed from the exact TSO scan to the rules kernel

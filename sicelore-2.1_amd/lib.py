@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_scan_batch", "smi_umi_dist_batch",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
 ]
 
 
@@ -81,6 +81,8 @@ def load_library():
     lib.smi_version.restype = ctypes.c_char_p
     lib.smi_ctx_create.argtypes = [ci, ctypes.POINTER(vp)]
     lib.smi_ctx_destroy.argtypes = [vp]
+    lib.smi_ctx_create_lane.argtypes = [vp, ctypes.POINTER(vp)]
+    lib.smi_ctx_lane_refresh.argtypes = [vp]
     lib.smi_ctx_device.argtypes = [vp]
     lib.smi_set_barcode_set.argtypes = [vp, vp, sz, ci]
     lib.smi_set_barcode_set_device.argtypes = [vp, vp, sz, ci, vp]
@@ -436,13 +438,26 @@ class Context:
     """One per GPU.  Stands where the reference keeps ``hashMapForBCfinding`` + a ``Parser`` worker
     (FJ!nanoporereadscanner/analyzers/Parser.java:L70-78)."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _lane_of=None):
         self._lib = load_library()
         h = ctypes.c_void_p()
-        self._check(self._lib.smi_ctx_create(int(device), ctypes.byref(h)))
+        if _lane_of is None:
+            self._check(self._lib.smi_ctx_create(int(device), ctypes.byref(h)))
+        else:
+            self._check(self._lib.smi_ctx_create_lane(_lane_of._h, ctypes.byref(h)))
         self._h = h
         self.device = int(device)
-        self.n_keys = 0
+        self.n_keys = 0 if _lane_of is None else _lane_of.n_keys
+        self._owner = _lane_of
+
+    def lane(self):
+        """a worker lane of this context (smi_ctx_create_lane): own stream / arena / pinned buffers, this context's barcode set"""
+        return Context(self.device, _lane_of=self)
+
+    def refresh(self):
+        """lane: pick up the barcode set its owner has loaded since (smi_ctx_lane_refresh)"""
+        self._check(self._lib.smi_ctx_lane_refresh(self._h))
+        self.n_keys = self._owner.n_keys
 
     def _check(self, rc):
         if rc != 0:

@@ -201,10 +201,9 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
     # nCPU Parser workers: the transfers of one chunk overlap the kernels of another
     import threading
 
-    n_ctx, per_thread = 3, 3
-    extra = [pkg.Context(ctx.device) for _ in range(n_ctx - 1)]
-    for c in extra:
-        c.set_barcode_set_device(used.to(torch.int32), mode=0)
+    n_ctx, per_thread = int(os.environ.get("SMI_MB_LANES", "3")), 3
+    # worker LANES of the one context (smi_ctx_create_lane): own stream / arena / pinned buffers, the owner's barcode set
+    extra = [ctx.lane() for _ in range(n_ctx - 1)]
     ctxs = [ctx] + extra
     pins = [pin] + [libmod.PinnedBuffer(total) for _ in extra]
     for pb in pins[1:]:
@@ -226,9 +225,10 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
     for pb in pins[1:]:
         pb.close()
     pin.close()
-    res["pass2_chunk_host_to_host_3_contexts"] = {"reads": n * n_ctx * per_thread, "ms": dtm * 1e3,
-                                                  "reads_per_s": n * n_ctx * per_thread / dtm,
-                                                  "note": "3 host threads x 3 contexts on one GPU, 3 chunks each"}
+    res["pass2_chunk_host_to_host_lanes"] = {"lanes": n_ctx, "reads": n * n_ctx * per_thread, "ms": dtm * 1e3,
+                                             "reads_per_s": n * n_ctx * per_thread / dtm,
+                                             "GB_per_s_both_directions": (total + n_out_bytes) * n_ctx * per_thread / dtm / 1e9,
+                                             "note": f"{n_ctx} host threads, one worker lane each (one context, one barcode set) on one GPU, 3 chunks each"}
     res["pass2_chunk_host_to_host"] = {"reads": n, "text_in_bytes": total, "text_out_bytes": n_out_bytes,
                                        "records_out": inf["n_records_out"], "ms": dth * 1e3, "reads_per_s": n / dth,
                                        "pageable_input_ms": dtp * 1e3,
