@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 4 --warmup 1 --no-cpu-baseline --two-pass-reads 0 --e2e-reads 0 $*"
 PROG=${PROFILE_PROG:-$ROOT/bench.py}   # e.g. PROFILE_PROG=$PWD/tools/microbench.py tools/profile_gpu.sh tag chimera
 [ -n "${PROFILE_PROG:-}" ] && ARGS="$*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $PROG $ARGS > "$OUT/bench_trace.log" 2>&1
