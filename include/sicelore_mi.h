@@ -574,6 +574,29 @@ int smi_bam_header(const uint8_t *bam, size_t n, uint64_t *text_off, uint32_t *t
 int smi_bam_index_records(const uint8_t *bam, size_t n, uint64_t start, smi_bam_record *recs, size_t cap, size_t *n_recs,
                           uint64_t *end_off);
 
+/* ---- GE / GS / XF: the default gene tagger of assignumis (host only) ---------------------------------------------------------------------
+ * Replaces GennameTagger (FJ!umifinder/bamreaders/GennameTagger.java:L57-382, the DefaultTagger of config.xml:86-89) over picard-2.23.9
+ * RefFlatReader / Gene / LocusFunction and the htsjdk-4.1.3 OverlapDetector: called per record from OneNanoporeSeqAnalyzer.call L95-103,
+ * after writeSamFlags and before the UMI tags.
+ * smi_genes_load_refflat: the text of the --annotationFile (refFlat, 11 tab-separated columns) and the names of the BAM header's reference
+ * sequences (rows on other sequences are skipped, RefFlatReader.java:L87-88).  Genes the reference drops (transcripts of one name on two
+ * strands / chromosomes, a transcript twice, exon count that disagrees, empty or overlapping exons; a second gene with the interval and
+ * strand of an earlier one) are dropped, the "earlier" one being decided in the JDK's HashMap<String> iteration order like there. */
+typedef struct smi_genes smi_genes;
+int smi_genes_load_refflat(const char *text, size_t n_bytes, const char *const *ref_names, int n_refs, smi_genes **out);
+int smi_genes_free(smi_genes *g);
+int smi_genes_count(const smi_genes *g, size_t *n_genes, size_t *n_lines, size_t *n_skipped);
+/* n records (BAM fields: reference index, FLAG, 0-based POS, CIGAR operations `len << 4 | op` of record i at cigars[cigar_off[i] ..
+ * cigar_off[i + 1])).  Output: three strings per record, GE, GS, XF, back to back in `out`; string k of record i is
+ * out[out_off[3 i + k] .. out_off[3 i + k + 1]) (out_off: 3 n + 1 entries).  Empty GE = the reference sets GE and GS to null (removes them);
+ * empty XF = the reference's annotateGene threw and no tag was touched.  A multi-gene value lists the genes in the JDK's HashSet<Gene>
+ * iteration order.  out == NULL: sizes and offsets only. */
+int smi_gene_tag_chunk(const smi_genes *g, const int32_t *ref_id, const uint16_t *flags, const int32_t *pos0, const uint32_t *cigars,
+                       const uint32_t *cigar_off, int32_t n, char *out, size_t cap, uint32_t *out_off, size_t *n_out);
+/* the same for n records of an inflated BAM stream (smi_bgzf_inflate) by their index entries (smi_bam_index_records) */
+int smi_gene_tag_bam(const smi_genes *g, const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, char *out, size_t cap,
+                     uint32_t *out_off, size_t *n_out);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

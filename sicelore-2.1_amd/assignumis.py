@@ -273,9 +273,10 @@ def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit
 
 # ---- BAM tags (ReadScanResult.writeSamFlags / writeBCSamFlags, ClusterOneBase.setSamflagsAndStatsForClustered,
 #      UmiFinderWorker.lambda$new$0 + $BamWriters.lambda$writeSams$2; tag names: Jar/config.xml:297-492) -------------------------
-def record_tag_sets(scan, umi, u7):
-    """the setAttribute calls the reference makes on one record, in its order: [(tag, value)], value int or str.
-    scan: scan_data_from_name; umi: entry of assign_umis (or None); u7: the read's own post-barcode 12-mer or None.
+def record_tag_sets(scan, umi, u7, gene=None):
+    """the setAttribute calls the reference makes on one record, in its order: [(tag, value)], value int, str or None (= the tag is removed).
+    scan: scan_data_from_name; umi: entry of assign_umis (or None); u7: the read's own post-barcode 12-mer or None; gene: (GE, GS, XF) of
+    lib.GeneTagger for this record when an --annotationFile is given.
     -> (calls, has_bc, umi_from_clustering)"""
     c = []
     if scan is None:
@@ -313,6 +314,10 @@ def record_tag_sets(scan, umi, u7):
         c.append(("BZ", bc["seq"]))
         if bc["rank"] is not None:
             c.append(("BH", str(bc["rank"])))
+    if gene is not None and gene[2] is not None:                 # annotateGene (OneNanoporeSeqAnalyzer L98, GennameTagger.setGeneExons L108-119)
+        ge, gs, xf = gene
+        c.append(("XF", xf))
+        c += [("GE", ge), ("GS", gs)] if ge is not None and gs is not None else [("GE", None), ("GS", None)]
     clustered = umi is not None and not umi.get("skipped")
     if clustered:                                                # ClusterOneBase L145-164
         c += [("U8", umi["U8"]), ("U7", umi["U7"]), ("UC", ""), ("U1", str(umi["U1"]))]
@@ -326,7 +331,9 @@ def record_tag_sets(scan, umi, u7):
 
 
 def _aux_bytes(tag, value):
-    """BinaryTagCodec: strings as Z, integers in the smallest type that holds them (c C s S i I)"""
+    """htsjdk BinaryTagCodec.writeTag / getIntegerType (Jar/lib/htsjdk-4.1.3.jar!/htsjdk/samtools/BinaryTagCodec.class L123-180, read from the
+    class file): strings as Z; an integer as c in [-128, 127], C up to 255, s up to 32767 (and down to -32768), S up to 65535, i up to
+    2^31 - 1 (and down to -2^31), I above"""
     t = tag.encode()
     if isinstance(value, str):
         return t + b"Z" + value.encode() + b"\0"
@@ -360,12 +367,16 @@ def split_aux(aux):
 
 
 def apply_tag_sets(fields, calls):
-    """SAMRecord.setAttribute on htsjdk's attribute list (SAMBinaryTagAndValue.insert): the list read from the file keeps its
-    order; a new tag goes in front of the first element whose binary tag (second char << 8 | first char) is greater, an
-    existing tag is replaced in place.  [restated from htsjdk 2.x, an un-vendored dependency: parity unpinned]"""
+    """SAMRecord.setAttribute on htsjdk's attribute list = SAMBinaryTagAndValue.insert (Jar/lib/htsjdk-4.1.3.jar!/htsjdk/samtools/
+    SAMBinaryTagAndValue.class L207-228, read from the class file): the list read from the file keeps its order; a new tag goes in front of
+    the first element whose binary tag is greater, an existing tag is replaced in place, otherwise it is appended.  Binary tag =
+    (short)(second char << 8 | first char) (SAMTag.makeBinaryTag L124-127)."""
     key = lambda t: (ord(t[1]) << 8) | ord(t[0])  # noqa: E731
     fields = list(fields)
     for tag, value in calls:
+        if value is None:                                        # setAttribute(tag, null): SAMBinaryTagAndValue.remove
+            fields = [f for f in fields if f[0] != tag]
+            continue
         raw, k = _aux_bytes(tag, value), key(tag)
         for j, (t, _) in enumerate(fields):
             if k < key(t):
@@ -386,12 +397,17 @@ def _coordinate_key(rec, name):
             int(rec["next_ref_id"]) if int(rec["next_ref_id"]) >= 0 else 1 << 30, int(rec["next_pos"]), int(rec["tlen"]))
 
 
-def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, **kw):
+def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, **kw):
     """`assignumis` BAM in -> (bcfound BAM bytes, umifound BAM bytes, names, tags): the two BGZF streams the reference writes
     (<out>.bam: every record with a cell barcode; <out>_umifound_.bam: those whose UMI comes from clustering), header copied,
-    records of a chunk in coordinate-comparator order with the tags of record_tag_sets added (GE needs the refFlat
-    annotator, which is not built)."""
+    records of a chunk in coordinate-comparator order with the tags of record_tag_sets added; refflat = text of the --annotationFile
+    (GE / GS / XF through lib.GeneTagger), None = no annotation file given."""
     _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
+    gene_tags = None
+    if refflat is not None:
+        tagger = _lib.GeneTagger(refflat, [nm for nm, _ in _refs])
+        gene_tags = tagger.tag_bam(bam, recs)
+        tagger.close()
     batches = []
     names, tags = assign_umis_bam(ctx, data, chunk_size=chunk_size, n_threads=n_threads, batches=batches, **kw)
     five_prime = bool(kw.get("five_prime", False))
@@ -407,7 +423,7 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
         if d is not None and d["bc"] is not None and d["bc"]["end"] is not None and d["x"]:
             w = umi_window(d["x"], d["ae"], d["bc"]["end"], five_prime)
             u7 = None if w is None else "".join(_DEC[c] for c in w[1:13])
-        calls, has_bc, clustered = record_tag_sets(d, tags[i], u7)
+        calls, has_bc, clustered = record_tag_sets(d, tags[i], u7, None if gene_tags is None else gene_tags[i])
         if not has_bc:
             continue
         o = int(r["rec_off"])

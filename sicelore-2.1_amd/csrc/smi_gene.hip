@@ -1,0 +1,495 @@
+// smi_gene.hip -- the GE / GS / XF tags of `assignumis` (host; no device code): the reference's default gene tagger
+//   GennameTagger.setGeneExons and helpers        FJ!umifinder/bamreaders/GennameTagger.java:L73-366   (config.xml:86-89 DefaultTagger)
+//   TagReadBase.<init>                            DropseqLib-1.0.jar!/org/broadinstitute/dropseqrna/metrics/TagReadBase.java:L64-71
+//                                                 (ALLOW_MULTI_GENE_READS = true as GennameTagger constructs it, L65)
+//   RefFlatReader.load / makeGeneFromRefFlatLines  picard-2.23.9.jar!/picard/annotation/RefFlatReader.java:L70-190
+//   Gene / Gene$Transcript                        picard/annotation/Gene.java:L46-71, L102-205 (assignLocusFunctionForRange, inExon, utr)
+//   OverlapDetector.addLhs / getOverlaps          htsjdk-4.1.3.jar!/htsjdk/samtools/util/OverlapDetector.java:L69-89, L179-200
+//   Interval.hashCode / compareTo / intersects    htsjdk/samtools/util/Interval.java:L124-125, L184-195, L228-231
+//   SAMUtils.getAlignmentBlocks                   (M, =, X make a block; I, S advance the read; D, N the reference)
+// All of these are bytecode under /root/reference/Jar (read with tools/classfold.py).  Call site: OneNanoporeSeqAnalyzer.call L95-103
+// (after ReadScanResult.writeSamFlags, before the UMI tags).
+//
+// Several java.util.HashMap / HashSet objects sit on the way (genes by name, the overlap set, the per-gene function map, the exon-consistent
+// set), so the ORDER of the names in a multi-gene GE value ("A,B") and which of two genes with the same interval and strand survives
+// (Gene.equals compares interval + strand only) follow the JDK's hash iteration order.  That order is reproduced here from the objects' own
+// hashCode() (String.hashCode; Interval.hashCode = 31 * (31 * contig.hashCode() + start) + end): buckets ascending at the table's final
+// capacity, insertion order inside a bucket (bins long enough to be treeified -- 8 colliding keys -- are not expected in annotation data).
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "smi_internal.h"
+
+using namespace smi;
+
+namespace {
+
+inline int32_t jstring_hash(const std::string &s) {
+    uint32_t h = 0;
+    for (unsigned char c : s) h = 31u * h + c;
+    return (int32_t)h;
+}
+inline uint32_t spread(int32_t h) {
+    const uint32_t u = (uint32_t)h;
+    return u ^ (u >> 16);
+}
+// iteration order of a java.util.HashMap / HashSet that received `hashes` in this insertion order (no removals)
+std::vector<size_t> jhash_order(const std::vector<int32_t> &hashes) {
+    size_t cap = 16;
+    while (hashes.size() > (cap * 3) / 4) cap <<= 1;
+    std::vector<size_t> idx(hashes.size());
+    for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return (spread(hashes[a]) & (cap - 1)) < (spread(hashes[b]) & (cap - 1)); });
+    return idx;
+}
+
+enum LF { INTERGENIC = 0, INTRONIC = 1, UTR = 2, CODING = 3, RIBOSOMAL = 4 };  // LocusFunction ordinals
+const char *const LF_NAME[5] = {"INTERGENIC", "INTRONIC", "UTR", "CODING", "RIBOSOMAL"};
+// GennameTagger.LOCUS_FUNCTION_SCORES (L39-43); RIBOSOMAL has no score (never produced by assignLocusFunctionForRange)
+inline int lf_score(int f) { return f == CODING ? 4 : f == UTR ? 3 : f == INTRONIC ? 2 : 1; }
+
+struct Transcript {
+    std::string name;
+    int tx_start, tx_end, cds_start, cds_end;
+    std::vector<std::pair<int, int>> exons;  // 1-based inclusive, file order
+    bool in_exon(int locus) const {          // Gene$Transcript.inExon L200-205: stops at the first exon that starts behind the locus
+        for (const auto &e : exons) {
+            if (e.first > locus) return false;
+            if (locus >= e.first && locus <= e.second) return true;
+        }
+        return false;
+    }
+    bool utr(int locus) const { return locus < cds_start || locus > cds_end; }  // L196
+};
+
+struct Gene {
+    int contig;  // index into the reference names
+    int start, end;
+    bool negative;
+    std::string name;
+    std::vector<Transcript> tx;  // in the iteration order of Gene.transcripts (a HashMap<String, Transcript>)
+    int32_t hash;                // Interval.hashCode
+};
+
+struct Block {
+    int ref_start, length;
+};
+
+}  // namespace
+
+struct smi_genes {
+    std::vector<std::string> refs;
+    std::vector<int32_t> ref_hash;
+    std::vector<Gene> genes;                 // in the order the reference adds them to the OverlapDetector
+    std::vector<std::vector<int>> by_contig; // gene indices per contig, sorted by (start, end) -- the IntervalTree's in-order walk
+    size_t n_lines = 0, n_skipped_sequence = 0, n_skipped_genes = 0;
+};
+
+static bool same_gene(const Gene &a, const Gene &b) {  // Gene.equals = compareTo == 0: contig, start, end, strand (Gene.java:L61-71)
+    return a.contig == b.contig && a.start == b.start && a.end == b.end && a.negative == b.negative;
+}
+
+extern "C" int smi_genes_load_refflat(const char *text, size_t n_bytes, const char *const *ref_names, int n_refs, smi_genes **out) {
+    if (!out || (!text && n_bytes) || (n_refs && !ref_names) || n_refs < 0) {
+        set_error("smi_genes_load_refflat: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *out = nullptr;
+    smi_genes *G = new smi_genes();
+    std::unordered_map<std::string, int> ref_index;
+    for (int i = 0; i < n_refs; i++) {
+        G->refs.emplace_back(ref_names[i]);
+        G->ref_hash.push_back(jstring_hash(G->refs.back()));
+        ref_index.emplace(G->refs.back(), i);
+    }
+    // rows by gene name: HashMap<String, List<Row>> (RefFlatReader.java:L74-95)
+    struct Row {
+        std::vector<std::string> f;
+    };
+    std::vector<std::string> names;                // insertion order of the map's keys
+    std::unordered_map<std::string, size_t> slot;  // name -> index into names / rows
+    std::vector<std::vector<Row>> rows;
+    size_t p = 0;
+    size_t line_no = 0;
+    while (p < n_bytes) {
+        size_t e = p;
+        while (e < n_bytes && text[e] != '\n') e++;
+        size_t le = e;
+        if (le > p && text[le - 1] == '\r') le--;
+        std::string line(text + p, le - p);
+        p = e + 1;
+        line_no++;
+        if (line.empty() || line[0] == '#') continue;  // BasicInputParser: blank lines and comment lines are skipped
+        Row r;
+        size_t a = 0;
+        for (;;) {
+            size_t t = line.find('\t', a);
+            if (t == std::string::npos) {
+                r.f.push_back(line.substr(a));
+                break;
+            }
+            r.f.push_back(line.substr(a, t - a));
+            a = t + 1;
+        }
+        if (r.f.size() != 11) {
+            delete G;
+            set_error("smi_genes_load_refflat: wrong number of fields in the refFlat text at line " + std::to_string(line_no) +
+                      " (the reference throws AnnotationException here, RefFlatReader.java:L79-80)");
+            return SMI_ERR_INVALID;
+        }
+        G->n_lines++;
+        if (!ref_index.count(r.f[2])) {  // isSequenceRecognized L87-88
+            G->n_skipped_sequence++;
+            continue;
+        }
+        auto it = slot.find(r.f[0]);
+        if (it == slot.end()) {
+            slot.emplace(r.f[0], names.size());
+            names.push_back(r.f[0]);
+            rows.emplace_back();
+            rows.back().push_back(std::move(r));
+        } else
+            rows[it->second].push_back(std::move(r));
+    }
+    std::vector<int32_t> hs(names.size());
+    for (size_t i = 0; i < names.size(); i++) hs[i] = jstring_hash(names[i]);
+    auto to_int = [](const std::string &s, int *v) {
+        if (s.empty()) return false;
+        char *endp = nullptr;
+        long x = std::strtol(s.c_str(), &endp, 10);
+        if (*endp) return false;
+        *v = (int)x;
+        return true;
+    };
+    auto split_ints = [&](const std::string &s, std::vector<int> &v) {  // String.split(","): trailing empty strings dropped
+        v.clear();
+        size_t a = 0;
+        std::vector<std::string> parts;
+        for (;;) {
+            size_t t = s.find(',', a);
+            if (t == std::string::npos) {
+                parts.push_back(s.substr(a));
+                break;
+            }
+            parts.push_back(s.substr(a, t - a));
+            a = t + 1;
+        }
+        if (parts.size() > 1)  // "".split(",") is [""], but "1,2,".split(",") drops the trailing empty strings
+            while (!parts.empty() && parts.back().empty()) parts.pop_back();
+        for (const auto &x : parts) {
+            int k;
+            if (!to_int(x, &k)) return false;
+            v.push_back(k);
+        }
+        return true;
+    };
+    for (size_t gi : jhash_order(hs)) {  // refFlatLinesByGene.values() L102
+        const std::vector<Row> &R = rows[gi];
+        Gene g;
+        g.name = R[0].f[0];
+        const std::string strand = R[0].f[3], chrom = R[0].f[2];
+        g.negative = strand == "-";
+        g.contig = ref_index[chrom];
+        int st = 2147483647, en = -2147483647 - 1;
+        bool ok = true;
+        for (const Row &r : R) {
+            int a, b;
+            if (!to_int(r.f[4], &a) || !to_int(r.f[5], &b)) {
+                ok = false;
+                break;
+            }
+            st = std::min(st, a + 1);
+            en = std::max(en, b);
+        }
+        if (!ok) {  // NumberFormatException: not an AnnotationException, the reference dies; refuse the file
+            delete G;
+            set_error("smi_genes_load_refflat: non-numeric coordinate for gene " + g.name);
+            return SMI_ERR_INVALID;
+        }
+        g.start = st;
+        g.end = en;
+        std::vector<std::string> tnames;
+        std::vector<Transcript> txs;
+        for (const Row &r : R) {
+            if (r.f[3] != strand || r.f[2] != chrom) {  // L138-142: AnnotationException -> gene skipped (L108-109)
+                ok = false;
+                break;
+            }
+            if (std::find(tnames.begin(), tnames.end(), r.f[1]) != tnames.end()) {  // Gene.addTranscript L46-47
+                ok = false;
+                break;
+            }
+            Transcript t;
+            t.name = r.f[1];
+            int cnt, cs, ce, a, b;
+            std::vector<int> es, ee;
+            if (!to_int(r.f[8], &cnt) || !to_int(r.f[4], &a) || !to_int(r.f[5], &b) || !to_int(r.f[6], &cs) || !to_int(r.f[7], &ce) ||
+                !split_ints(r.f[9], es) || !split_ints(r.f[10], ee)) {
+                delete G;
+                set_error("smi_genes_load_refflat: non-numeric field for transcript " + r.f[1]);
+                return SMI_ERR_INVALID;
+            }
+            if (cnt != (int)es.size() || cnt != (int)ee.size()) {  // L164-168: AnnotationException
+                ok = false;
+                break;
+            }
+            t.tx_start = a + 1;
+            t.tx_end = b;
+            t.cds_start = cs + 1;
+            t.cds_end = ce;
+            for (int i = 0; i < cnt; i++) {
+                // L181-186: "Exon has 0 or negative extent", "Exons overlap" -- AnnotationException, the gene is skipped
+                if (es[i] + 1 > ee[i] || (i > 0 && t.exons.back().second >= es[i] + 1)) {
+                    ok = false;
+                    break;
+                }
+                t.exons.emplace_back(es[i] + 1, ee[i]);
+            }
+            if (!ok) break;
+            tnames.push_back(t.name);
+            txs.push_back(std::move(t));
+        }
+        if (!ok) {
+            G->n_skipped_genes++;
+            continue;
+        }
+        // Gene.iterator() = transcripts.values() of a HashMap<String, Transcript> (Gene.java:L57)
+        std::vector<int32_t> th(tnames.size());
+        for (size_t i = 0; i < tnames.size(); i++) th[i] = jstring_hash(tnames[i]);
+        for (size_t k : jhash_order(th)) g.tx.push_back(std::move(txs[k]));
+        g.hash = (int32_t)(31u * (31u * (uint32_t)G->ref_hash[(size_t)g.contig] + (uint32_t)g.start) + (uint32_t)g.end);
+        // OverlapDetector.addLhs L69-89: interval tree node per (start, end); a node's value is a set, and Gene.equals makes a second gene with
+        // the same interval and strand disappear in it (the first one added stays)
+        bool dup = false;
+        for (const Gene &o : G->genes)
+            if (same_gene(o, g)) {
+                dup = true;
+                break;
+            }
+        if (dup) {
+            G->n_skipped_genes++;
+            continue;
+        }
+        G->genes.push_back(std::move(g));
+    }
+    G->by_contig.assign((size_t)n_refs, {});
+    for (size_t i = 0; i < G->genes.size(); i++) G->by_contig[(size_t)G->genes[i].contig].push_back((int)i);
+    for (auto &v : G->by_contig)
+        std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
+            const Gene &x = G->genes[(size_t)a], &y = G->genes[(size_t)b];
+            return x.start != y.start ? x.start < y.start : x.end < y.end;
+        });
+    *out = G;
+    return SMI_OK;
+}
+
+extern "C" int smi_genes_free(smi_genes *g) {
+    delete g;
+    return SMI_OK;
+}
+
+extern "C" int smi_genes_count(const smi_genes *g, size_t *n_genes, size_t *n_lines, size_t *n_skipped) {
+    if (!g) {
+        set_error("smi_genes_count: null argument");
+        return SMI_ERR_INVALID;
+    }
+    if (n_genes) *n_genes = g->genes.size();
+    if (n_lines) *n_lines = g->n_lines;
+    if (n_skipped) *n_skipped = g->n_skipped_genes + g->n_skipped_sequence;
+    return SMI_OK;
+}
+
+namespace {
+
+// a HashSet<Gene> / HashMap<Gene, .> as the reference fills it: insertion order + hash -> iteration order
+struct GeneSet {
+    std::vector<int> ids;  // insertion order, distinct
+    void add(int g) {
+        if (std::find(ids.begin(), ids.end(), g) == ids.end()) ids.push_back(g);
+    }
+    std::vector<int> iter(const smi_genes &G) const {
+        std::vector<int32_t> h(ids.size());
+        for (size_t i = 0; i < ids.size(); i++) h[i] = G.genes[(size_t)ids[i]].hash;
+        std::vector<int> out;
+        for (size_t k : jhash_order(h)) out.push_back(ids[k]);
+        return out;
+    }
+};
+
+int top_scoring(const std::vector<int> &fs) {  // getTopScoringLocusFunction L346-354: first strictly greater score wins; -1 = null
+    int best = -1;
+    for (int f : fs)
+        if (best < 0 || lf_score(f) > lf_score(best)) best = f;
+    return best;
+}
+
+}  // namespace
+
+extern "C" int smi_gene_tag_chunk(const smi_genes *G, const int32_t *ref_id, const uint16_t *flags, const int32_t *pos0, const uint32_t *cigars,
+                                  const uint32_t *cigar_off, int32_t n, char *out, size_t cap, uint32_t *out_off, size_t *n_out) {
+    if (!G || !n_out || n < 0 || (n && (!ref_id || !flags || !pos0 || !cigar_off || !out_off))) {
+        set_error("smi_gene_tag_chunk: null argument");
+        return SMI_ERR_INVALID;
+    }
+    std::string txt;
+    std::vector<uint32_t> offs;
+    offs.reserve((size_t)3 * n + 1);
+    for (int32_t i = 0; i < n; i++) {
+        // alignment blocks (SAMUtils.getAlignmentBlocks) and the read's interval [alignmentStart, alignmentEnd]
+        std::vector<Block> blocks;
+        const bool unmapped = (flags[i] & 4) != 0 || ref_id[i] < 0;
+        int ref = pos0[i] + 1, aln_end = pos0[i];
+        if (!unmapped) {
+            for (uint32_t k = cigar_off[i]; k < cigar_off[i + 1]; k++) {
+                const int op = (int)(cigars[k] & 15u), len = (int)(cigars[k] >> 4);
+                if (op == 0 || op == 7 || op == 8) {  // M = X
+                    blocks.push_back({ref, len});
+                    ref += len;
+                } else if (op == 2 || op == 3)  // D N
+                    ref += len;
+            }
+            aln_end = ref - 1;
+        }
+        // geneOverlapDetector.getOverlaps(readInterval) L231: nodes in (start, end) order, into a HashSet
+        GeneSet overlapping;
+        if (!unmapped && ref_id[i] < (int32_t)G->by_contig.size() && aln_end >= pos0[i] + 1)
+            for (int gi : G->by_contig[(size_t)ref_id[i]]) {
+                const Gene &g = G->genes[(size_t)gi];
+                if (g.start > aln_end) break;
+                if (g.end >= pos0[i] + 1) overlapping.add(gi);
+            }
+        // map gene -> locus function of the read for that gene (getLocusFunctionForRead(rec, gene) L246-260), a HashMap<Gene, LocusFunction>
+        const std::vector<int> over_iter = overlapping.iter(*G);
+        GeneSet map_keys;
+        std::vector<int> map_val;
+        for (int gi : over_iter) {
+            const Gene &g = G->genes[(size_t)gi];
+            std::vector<int> block_fn;
+            for (const Block &b : blocks) {
+                std::vector<int> lf((size_t)b.length, INTERGENIC);  // getLocusFunctionsByBlock L358-366
+                for (const Transcript &t : g.tx) {
+                    const int lo = std::max(b.ref_start, t.tx_start), hi = std::min(t.tx_end, b.ref_start + b.length - 1);
+                    for (int p = lo; p <= hi; p++) {  // assignLocusFunctionForRange L151-165
+                        int &cur = lf[(size_t)(p - b.ref_start)];
+                        if (cur > CODING) continue;
+                        const int f = t.in_exon(p) ? (t.utr(p) ? UTR : CODING) : INTRONIC;
+                        if (f > cur) cur = f;
+                    }
+                }
+                block_fn.push_back(top_scoring(lf));
+            }
+            map_keys.add(gi);
+            map_val.push_back(top_scoring(block_fn));  // an empty block list gives null; the filter below then drops the gene
+        }
+        const std::vector<int> map_iter = map_keys.iter(*G);
+        auto fn_of = [&](int gi) {
+            for (size_t k = 0; k < map_keys.ids.size(); k++)
+                if (map_keys.ids[k] == gi) return map_val[k];
+            return -1;
+        };
+        // getConsistentExons(rec, map.keySet(), true) L158-185: per block the genes with an exon that intersects it
+        GeneSet exons_for_read;
+        for (const Block &b : blocks) {
+            GeneSet block_genes;
+            for (int gi : map_iter) {
+                const Gene &g = G->genes[(size_t)gi];
+                bool hit = false;
+                for (const Transcript &t : g.tx) {
+                    for (const auto &e : t.exons)
+                        if (e.first <= b.ref_start + b.length - 1 && b.ref_start <= e.second) {  // CoordMath.overlaps
+                            hit = true;
+                            break;
+                        }
+                    if (hit) break;
+                }
+                if (hit) block_genes.add(gi);
+            }
+            for (int gi : block_genes.iter(*G)) exons_for_read.add(gi);  // result.addAll(blockGenes)
+        }
+        // genes whose function is CODING or UTR (lambda$setGeneExons$1 L81-82)
+        std::vector<int> genes;
+        for (int gi : exons_for_read.iter(*G)) {
+            const int f = fn_of(gi);
+            if (f == CODING || f == UTR) genes.push_back(gi);
+        }
+        // f = getLocusFunction(map.values()) L312-316
+        int f = INTERGENIC;
+        if (!map_keys.ids.empty()) {
+            std::vector<int> vals;
+            for (int gi : map_iter) vals.push_back(fn_of(gi));
+            // a null entry cannot score: LOCUS_FUNCTION_SCORES.get(null) would throw inside annotateGene, which the caller swallows
+            // (OneNanoporeSeqAnalyzer.java:L100-102) -- only possible for a mapped read without a single M / = / X operation
+            bool has_null = false;
+            for (int v : vals) has_null |= v < 0;
+            if (has_null) {
+                offs.push_back((uint32_t)txt.size());
+                offs.push_back((uint32_t)txt.size());
+                offs.push_back((uint32_t)txt.size());
+                continue;  // no tag touched
+            }
+            f = top_scoring(vals);
+        }
+        // getGenesConsistentWithReadStrand L125-154
+        const bool neg_read = (flags[i] & 16) != 0;
+        std::vector<int> same, opposite;
+        for (int gi : genes) (G->genes[(size_t)gi].negative == neg_read ? same : opposite).push_back(gi);
+        (void)opposite;  // only counted in the reference's metrics; a read with opposite-strand genes only gets no GE
+        std::string ge, gs;
+        for (size_t k = 0; k < same.size(); k++) {
+            if (k) {
+                ge += ",";
+                gs += ",";
+            }
+            ge += G->genes[(size_t)same[k]].name;
+            gs += G->genes[(size_t)same[k]].negative ? "-" : "+";
+        }
+        offs.push_back((uint32_t)txt.size());
+        txt += ge;
+        offs.push_back((uint32_t)txt.size());
+        txt += gs;
+        offs.push_back((uint32_t)txt.size());
+        txt += LF_NAME[f];
+    }
+    offs.push_back((uint32_t)txt.size());
+    *n_out = txt.size();
+    if (out_off) std::memcpy(out_off, offs.data(), offs.size() * sizeof(uint32_t));
+    if (!out) return SMI_OK;
+    if (cap < txt.size()) {
+        set_error("smi_gene_tag_chunk: output buffer too small");
+        return SMI_ERR_INVALID;
+    }
+    std::memcpy(out, txt.data(), txt.size());
+    return SMI_OK;
+}
+
+// the same over an inflated BAM stream and its record index (smi_bam_index_records)
+extern "C" int smi_gene_tag_bam(const smi_genes *G, const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, char *out,
+                                size_t cap, uint32_t *out_off, size_t *n_out) {
+    if (!G || !n_out || n < 0 || (n && (!bam || !recs || !out_off))) {
+        set_error("smi_gene_tag_bam: null argument");
+        return SMI_ERR_INVALID;
+    }
+    std::vector<int32_t> rid((size_t)n), p0((size_t)n);
+    std::vector<uint16_t> fl((size_t)n);
+    std::vector<uint32_t> off((size_t)n + 1, 0), cg;
+    for (int32_t i = 0; i < n; i++) {
+        const smi_bam_record &r = recs[i];
+        if (r.cigar_off + 4ull * r.n_cigar > n_bam) {
+            set_error("smi_gene_tag_bam: record outside the stream");
+            return SMI_ERR_INVALID;
+        }
+        rid[(size_t)i] = r.ref_id;
+        p0[(size_t)i] = r.pos;
+        fl[(size_t)i] = r.flag;
+        const size_t at = cg.size();
+        cg.resize(at + r.n_cigar);
+        if (r.n_cigar) std::memcpy(cg.data() + at, bam + r.cigar_off, 4ull * r.n_cigar);
+        off[(size_t)i + 1] = (uint32_t)cg.size();
+    }
+    if (cg.empty()) cg.push_back(0);
+    return smi_gene_tag_chunk(G, rid.data(), fl.data(), p0.data(), cg.data(), off.data(), n, out, cap, out_off, n_out);
+}

@@ -53,6 +53,7 @@ EXPORTS = [
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
     "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
+    "smi_genes_load_refflat", "smi_genes_free", "smi_genes_count", "smi_gene_tag_chunk", "smi_gene_tag_bam",
 ]
 
 
@@ -137,6 +138,11 @@ def load_library():
     lib.smi_hist_allreduce.argtypes = [vp, ci, vp, sz]
     lib.smi_scan_batch.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     lib.smi_umi_dist_batch.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
+    lib.smi_genes_load_refflat.argtypes = [vp, sz, vp, ci, vp]
+    lib.smi_genes_free.argtypes = [vp]
+    lib.smi_genes_count.argtypes = [vp, vp, vp, vp]
+    lib.smi_gene_tag_chunk.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
+    lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     explicit = {"smi_last_error", "smi_version", "smi_read_planes_words"}  # restype set above (char*, size_t)
@@ -192,6 +198,71 @@ def barcode_list_tsv(keys, counts, record_count, merge_ed=1, min_count_fold=10, 
     if lib.smi_barcode_list_tsv(*args, out, n.value, ctypes.byref(n)):
         raise SmiError(lib.smi_last_error().decode())
     return out.raw[:n.value].decode()
+
+
+class GeneTagger:
+    """The --annotationFile of assignumis: refFlat genes on the BAM header's reference sequences (smi_genes_load_refflat), and the GE / GS /
+    XF values of records (smi_gene_tag_chunk) = GennameTagger.annotateGene (FJ!umifinder/bamreaders/GennameTagger.java:L73-121, L382)."""
+
+    CIGAR_OPS = "MIDNSHP=X"
+
+    def __init__(self, refflat_text, ref_names):
+        lib = load_library()
+        text = refflat_text.encode() if isinstance(refflat_text, str) else bytes(refflat_text)
+        names = [n.encode() if isinstance(n, str) else n for n in ref_names]
+        arr = (ctypes.c_char_p * max(len(names), 1))(*names)
+        h = ctypes.c_void_p()
+        if lib.smi_genes_load_refflat(text, len(text), arr, len(names), ctypes.byref(h)):
+            raise SmiError(lib.smi_last_error().decode())
+        self._h, self._lib = h, lib
+        a, b, c = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+        lib.smi_genes_count(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        self.n_genes, self.n_lines, self.n_skipped = a.value, b.value, c.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smi_genes_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def tag(self, ref_id, flags, pos0, cigars):
+        """cigars: per record a list of (op letter or code, length).  -> list of (GE, GS, XF); GE / GS None = removed; XF None = untouched"""
+        n = len(ref_id)
+        rid = np.ascontiguousarray(ref_id, dtype=np.int32)
+        fl = np.ascontiguousarray(flags, dtype=np.uint16)
+        p0 = np.ascontiguousarray(pos0, dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.uint32)
+        flat = []
+        for i, cg in enumerate(cigars):
+            for op, ln in cg:
+                flat.append(int(ln) << 4 | (self.CIGAR_OPS.index(op) if isinstance(op, str) else int(op)))
+            off[i + 1] = len(flat)
+        cg = np.asarray(flat if flat else [0], dtype=np.uint32)
+        return self.tag_arrays(rid, fl, p0, cg, off)
+
+    def tag_arrays(self, rid, fl, p0, cg, off):
+        return self._run(self._lib.smi_gene_tag_chunk, (self._h, _ptr(rid), _ptr(fl), _ptr(p0), _ptr(cg), _ptr(off), int(rid.size)), int(rid.size))
+
+    def tag_bam(self, bam, recs):
+        """bam: inflated stream (numpy uint8), recs: BAM_RECORD_DTYPE index entries"""
+        recs = np.ascontiguousarray(recs)
+        return self._run(self._lib.smi_gene_tag_bam, (self._h, _ptr(bam), bam.size, _ptr(recs), int(recs.size)), int(recs.size))
+
+    def _run(self, fn, args, n):
+        out_off = np.zeros(3 * n + 1, dtype=np.uint32)
+        need = ctypes.c_size_t(0)
+        if fn(*args, None, 0, _ptr(out_off), ctypes.byref(need)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        buf = ctypes.create_string_buffer(need.value + 1)
+        if fn(*args, buf, need.value, _ptr(out_off), ctypes.byref(need)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        raw = buf.raw
+        res = []
+        for i in range(n):
+            ge, gs, xf = (raw[out_off[3 * i + k]:out_off[3 * i + k + 1]].decode() for k in range(3))
+            res.append((ge or None, gs or None, xf or None))
+        return res
 
 
 def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0, five_prime=False):
