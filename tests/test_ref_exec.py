@@ -336,3 +336,48 @@ def test_chimera_split_equals_reference_bytecode(sor):
         n_split += bool(splits)
         n_multi += multi
     assert n_split >= 8 and n_multi >= 1
+
+
+# ---- GE / GS / XF (GennameTagger over picard's refFlat genes): model and product against the reference's bytecode ---------------
+def _gene_expectation(case):
+    """(GE, GS, XF) as lib.GeneTagger reports them, from the setAttribute calls the reference made"""
+    if "throws" in case:
+        assert case["set_attribute_before_throw"] == []
+        return (None, None, None)
+    calls = {t: v for t, v in case["set_attribute"]}
+    assert [t for t, _ in case["set_attribute"]] == ["XF", "GE", "GS"]  # the order record_tag_sets replays
+    assert (calls["GE"] is None) == (calls["GS"] is None)
+    return (calls["GE"], calls["GS"], calls["XF"])
+
+
+def test_gene_tags_equal_reference_bytecode(pkg):
+    import gzip
+
+    import genemodel
+    from sicelore_amd import lib
+
+    d = load("gene")
+    sec = d["sections"][0]
+    assert sec["max_tier"] == "D" and any("jdk table order" in n["native"] for n in sec["natives"])
+    text = gzip.open(os.path.join(GOLD, "chr12_head1500.refFlat.gz"), "rt").read()
+    lines = [ln for ln in text.split("\n") if ln][:sec["n_rows_of_sample"]] + sec["extra_rows"]
+    text = "\n".join(lines) + "\n"
+    refs = sec["ref_names"]
+    tree, n_genes = genemodel.load_refflat(text, refs)
+    assert sorted(g.name for nodes in tree.values() for _, node in nodes for g in node) == sec["genes_loaded"]
+    tagger = lib.GeneTagger(text, refs)
+    assert tagger.n_genes == len(sec["genes_loaded"]) == n_genes
+    cases = sec["cases"]
+    exp = [_gene_expectation(c) for c in cases]
+    model = [genemodel.tag(tree, c["ref"], c["flag"], c["pos0"], [tuple(x) for x in c["cigar"]]) for c in cases]
+    assert model == exp
+    got = tagger.tag([refs.index(c["ref"]) if c["ref"] is not None else -1 for c in cases], [c["flag"] for c in cases],
+                     [c["pos0"] for c in cases], [[tuple(x) for x in c["cigar"]] for c in cases])
+    assert got == exp
+    # the set covers every branch: each function, multi-gene values, opposite-strand-only, the swallowed exception, unmapped
+    xf = [e[2] for e in exp]
+    assert all(xf.count(k) >= 10 for k in ("INTERGENIC", "INTRONIC", "UTR", "CODING")) and xf.count(None) >= 10
+    assert sum(e[0] is not None and "," in e[0] for e in exp) >= 3
+    assert sum(e[0] is None and e[2] in ("UTR", "CODING") for e in exp) >= 10
+    assert sum("throws" in c for c in cases) == xf.count(None)
+    assert {c["throws"] for c in cases if "throws" in c} == {"java/lang/NullPointerException"}

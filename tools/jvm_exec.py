@@ -265,7 +265,7 @@ class JVM:
             if jc.super and self.has_class(jc.super):
                 self.init_class(jc.super)
             m = jc.methods.get(("<clinit>", "()V"))
-            if m is not None:
+            if m is not None and f"{name}.<clinit>:()V" not in self.hooks:
                 self.run(m, [])
         return jc
 
@@ -385,7 +385,10 @@ class JVM:
         if isinstance(target, str):
             return self.call_native(target, args)
         hook = self.hooks.get(f"{target.cls.name}.{target.name}:{target.desc}")
+        if hook is None:
+            hook = self.hooks.get(f"{target.cls.name}.*")
         if hook is not None:
+            self.natives_used.add(f"hook:{target.cls.name}.{target.name}")
             return hook(self, *args)
         return self.run(target, args)
 
@@ -424,6 +427,11 @@ class JVM:
                 return self._box_ret(self.call_lambda(recv, self._adapt(allargs[1:], pargs)), pret, lam)
             t = self.find_method(rc, lam.name, lam.desc)
             call = [recv] + self._adapt(allargs[1:], pargs)
+        elif kind == 8 and lam.owner not in self.index:  # constructor reference to a JDK class held as a native
+            o = self.call_native(f"{lam.owner}.<new>", [])
+            key = f"{lam.owner}.<init>:{lam.desc}"
+            self.call_native(key if key in self.natives else f"{lam.owner}.<init>", [o] + self._adapt(allargs, pargs))
+            return o
         elif kind == 8:  # newinvokespecial
             o = self.new_object(lam.owner)
             self.init_class(lam.owner)

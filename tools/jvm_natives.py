@@ -13,6 +13,8 @@ TIER_A = {"java/lang/Object.<init>:()V"}
 def tier_of(key):
     if key in TIER_A:
         return "A"
+    if key.startswith("$hash-iteration(jdk"):
+        return "D"
     if key.startswith(("java/util/", "it/unimi/", "org/eclipse/")):
         return "C"
     return "B"
@@ -159,6 +161,10 @@ def install(jvm):
     N["java/lang/String.startsWith:(Ljava/lang/String;)Z"] = lambda j, s, t: 1 if s.startswith(t) else 0
     N["java/lang/String.endsWith"] = lambda j, s, t: 1 if s.endswith(t) else 0
     N["java/lang/String.concat"] = lambda j, s, t: s + t
+    N["java/lang/String.intern"] = lambda j, s: s
+    # an opaque object: static initialisers may compile patterns the executed path never uses; any use of one is Unsupported
+    N["java/util/regex/Pattern.compile:(Ljava/lang/String;)Ljava/util/regex/Pattern;"] = lambda j, s: JObject("java/util/regex/Pattern")
+    N["java/lang/Boolean.parseBoolean:(Ljava/lang/String;)Z"] = lambda j, s: 1 if s is not None and s.lower() == "true" else 0
     N["java/lang/String.trim"] = lambda j, s: s.strip(" \t\n\r\x0b\x0c" + "".join(chr(c) for c in range(0, 33)))
     N["java/lang/String.toUpperCase:()Ljava/lang/String;"] = lambda j, s: s.upper()
     N["java/lang/String.toLowerCase:()Ljava/lang/String;"] = lambda j, s: s.lower()
@@ -373,6 +379,7 @@ def install(jvm):
     N["java/lang/Integer.MIN_VALUE"] = lambda j: -2 ** 31
     N["java/lang/Long.MAX_VALUE"] = lambda j: 2 ** 63 - 1
     N["java/lang/Float.MAX_VALUE"] = lambda j: f32(3.4028234663852886e38)
+    N["java/lang/Boolean.toString:(Z)Ljava/lang/String;"] = lambda j, v: "true" if v else "false"
     N["java/lang/Boolean.TRUE"] = lambda j: JBox("java/lang/Boolean", 1)
     N["java/lang/Boolean.FALSE"] = lambda j: JBox("java/lang/Boolean", 0)
     N["java/lang/Character.toUpperCase:(C)C"] = lambda j, c: ord(chr(c).upper()) if c < 128 else c
@@ -858,7 +865,7 @@ def install_streams(jvm):
         N[f"{c}.allMatch"] = lambda j, s, f: 1 if all(truth(call_fn(j, f, v)) for v in s.native) else 0
         N[f"{c}.noneMatch"] = lambda j, s, f: 0 if any(truth(call_fn(j, f, v)) for v in s.native) else 1
         N[f"{c}.findFirst"] = lambda j, s: optional(j, s.native[0] if s.native else None, kind_of(s))
-        N[f"{c}.findAny"] = lambda j, s: (_ for _ in ()).throw(Unsupported("findAny: the specification leaves the element open"))
+        N[f"{c}.findAny"] = lambda j, s: find_any(j, s)
         N[f"{c}.reduce"] = reduce_
         N[f"{c}.collect"] = collect
         N[f"{c}.toArray"] = lambda j, s, *a: JArray({"int": "I", "long": "J", "double": "D"}.get(kind_of(s), "Ljava/lang/Object;"), list(s.native))
@@ -879,6 +886,12 @@ def install_streams(jvm):
                 raise Unsupported("DoubleStream.sum over non-integral values (summation order unspecified)")
             t += v
         return t
+
+    def find_any(j, s):
+        """which element is open in the specification; the drivers only use sections whose caller asks isPresent() -- the note travels in
+        the fixture's native list so that a reader can check that"""
+        j.natives_used.add("$findAny(first element; valid only where the caller asks isPresent)")
+        return optional(j, s.native[0] if s.native else None, kind_of(s))
 
     # ---- Collectors (ordered results only)
     def collector(fn):
@@ -917,6 +930,34 @@ def install_streams(jvm):
     def mapping(j, f, down):
         return collector(lambda j_, items: down.native(j_, [call_fn(j_, f, v) for v in items]))
 
+    def to_map(j, keyf, valf, *rest):
+        """toMap(key, value[, merge[, mapFactory]]): accumulates with Map.merge in encounter order; a null value is a NullPointerException
+        (HashMap.merge / Objects.requireNonNull), a duplicate key without a merge function an IllegalStateException"""
+        merge = rest[0] if rest else None
+        factory = rest[1] if len(rest) > 1 else None
+
+        def run(j_, items):
+            m = call_fn(j_, factory) if factory is not None else j_.natives["java/util/HashMap.<new>"](j_)
+            for v in items:
+                k, val = call_fn(j_, keyf, v), call_fn(j_, valf, v)
+                if val is None:
+                    j_.throw("java/lang/NullPointerException")
+                cell = m.native.find(k)
+                if cell is None or cell[1] is None:
+                    m.native.put(k, val)
+                elif merge is None:
+                    j_.throw("java/lang/IllegalStateException", "Duplicate key")
+                else:
+                    nv = call_fn(j_, merge, cell[1], val)
+                    if nv is None:
+                        m.native.remove(k)
+                    else:
+                        cell[1] = nv
+            return m
+
+        return collector(run)
+
+    N["java/util/stream/Collectors.toMap"] = to_map
     N["java/util/stream/Collectors.groupingBy"] = grouping_by
     N["java/util/stream/Collectors.mapping"] = mapping
     N["java/util/stream/Collectors.toUnmodifiableList"] = N["java/util/stream/Collectors.toList"]
@@ -1009,6 +1050,9 @@ class HashStore:
         self.j = jvm
         self.buckets = {}   # hashCode -> [[key, value], ...]
         self.order = []     # [key, value] cells in insertion order (driver-side reading only)
+        self.cap0 = 16      # table size the first put allocates (jdk order only)
+        self.peak = 0       # largest size reached: the table never shrinks
+        self.identity = False
 
     def _hash(self, k):
         j = self.j
@@ -1031,6 +1075,7 @@ class HashStore:
             raise Unsupported("hashCode of " + k.cls)
         t = j.find_method(j.class_of(k), "hashCode", "()I")
         if t is None or isinstance(t, str) and t.startswith("java/lang/Object"):
+            self.identity = True
             return id(k) & 0x7FFFFFFF  # identity hash: membership by identity
         return j.invoke(t, [k])
 
@@ -1062,6 +1107,7 @@ class HashStore:
         cell = [k, v]
         self.buckets.setdefault(self._hash(k), []).append(cell)
         self.order.append(cell)
+        self.peak = max(self.peak, len(self.order))
         return None, True
 
     def remove(self, k):
@@ -1086,6 +1132,8 @@ class HashStore:
         mode = self.j.hash_order
         if mode is None:
             raise Unsupported(f"{what} of {cls}: hash-ordered iteration is not emulated (set jvm.hash_order to vary it)")
+        if mode == "jdk":
+            return self.cells_in_jdk_order(what, cls)
         self.j.natives_used.add("$hash-iteration(order varied, not emulated)")
         cells = list(self.order)
         if mode == "reverse":
@@ -1095,6 +1143,41 @@ class HashStore:
 
             random.Random(mode[1] * 1000003 + len(cells)).shuffle(cells)
         return cells
+
+
+def _cells_in_jdk_order(self, what, cls):
+    """Tier D, opt-in (jvm.hash_order = 'jdk'): the order java.util.HashMap (JDK 8 .. 21, the layout is part of its documented
+    implementation notes) walks its table in -- buckets ascending, bucket of a key = (h ^ h >>> 16) & (capacity - 1) with h the key's own
+    hashCode() as the bytecode / the value class defines it, capacity = the initial table size doubled while size exceeded 0.75 capacity,
+    nodes of a bucket in the order they were linked (insertion order; resize() splits keep it, remove() unlinks).  Refused for keys with
+    identity hashes and for bins long enough to be turned into trees (8 nodes at capacity >= 64), whose order this does not model."""
+    if self.identity:
+        raise Unsupported(f"{what} of {cls}: identity-hashed keys have no reproducible order")
+    self.j.natives_used.add("$hash-iteration(jdk table order from the keys' hashCode())")
+    cap = self.cap0
+    while self.peak > (cap * 3) // 4:
+        cap *= 2
+    keyed = []
+    per = {}
+    for cell in self.order:
+        h = self._hash(cell[0]) & 0xFFFFFFFF
+        b = (h ^ (h >> 16)) & (cap - 1)
+        per[b] = per.get(b, 0) + 1
+        keyed.append((b, cell))
+    if per and max(per.values()) >= 8:
+        raise Unsupported(f"{what} of {cls}: a bin of {max(per.values())} nodes may have been treeified")
+    keyed.sort(key=lambda t: t[0])
+    return [c for _, c in keyed]
+
+
+HashStore.cells_in_jdk_order = _cells_in_jdk_order
+
+
+def _table_size_for(n):
+    c = 1
+    while c < n:
+        c *= 2
+    return max(c, 1)
 
 
 def install_hash(jvm):
@@ -1111,11 +1194,19 @@ def install_hash(jvm):
     def init(j, o, *a):
         if o.native is None:
             o.native = HashStore(j)  # a jar class extending HashSet / HashMap
+        if a and isinstance(a[0], int):
+            o.native.cap0 = _table_size_for(a[0])  # HashMap(int): threshold = tableSizeFor(initialCapacity)
         if a and isinstance(a[0], JObject) and isinstance(a[0].native, list):
+            if o.cls.endswith("Set"):
+                o.native.cap0 = _table_size_for(max(int(f32(len(a[0].native) / f32(0.75))) + 1, 16))  # HashSet(Collection)
             for v in a[0].native:
                 o.native.put(v, True)
         elif a and isinstance(a[0], JObject) and isinstance(a[0].native, HashStore):
-            for k, v in a[0].native.items_in_insertion_order():
+            src = a[0].native
+            cells = src.cells_for_iteration("copy constructor", o.cls) if j.hash_order == "jdk" else [tuple(c) for c in src.order]
+            if o.cls.endswith("Set"):
+                o.native.cap0 = _table_size_for(max(int(f32(len(cells) / f32(0.75))) + 1, 16))
+            for k, v in cells:
                 o.native.put(k, v)
 
     def refuse(what):
@@ -1191,6 +1282,19 @@ def install_hash(jvm):
         return None
 
     N["java/util/HashMap.putIfAbsent"] = put_if_absent
+    # java.util.TreeMap used as a lookup table only (put / get / containsKey / size): same keyed store, iteration refused; get(null)
+    # throws as a TreeMap with natural ordering does
+    N["java/util/TreeMap.<new>"] = new("java/util/TreeMap")
+    N["java/util/TreeMap.<init>:()V"] = lambda j, o: None
+
+    def tree_get(j, o, k):
+        if k is None:
+            j.throw("java/lang/NullPointerException")
+        return (o.native.find(k) or [None, None])[1]
+
+    N["java/util/TreeMap.get"] = tree_get
+    N["java/util/TreeMap.put"] = lambda j, o, k, v: o.native.put(k, v)[0]
+    N["java/util/TreeMap.size"] = lambda j, o: len(o.native)
     # ConcurrentHashMap used single-threaded: the same membership structure (its iteration order is likewise not emulated)
     for k in list(N):
         if k.startswith("java/util/HashMap."):
@@ -1206,6 +1310,8 @@ def install_hash(jvm):
     jdk_super.update({"java/util/HashSet": "java/util/AbstractSet", "java/util/AbstractSet": "java/util/AbstractCollection",
                       "java/util/HashMap": "java/util/AbstractMap", "java/util/AbstractMap": "java/lang/Object"})
     jdk_ifaces["java/util/AbstractMap$SimpleEntry"] = ["java/util/Map$Entry"]
+    jdk_super["java/util/TreeMap"] = "java/util/AbstractMap"
+    jdk_ifaces["java/util/TreeMap"] = ["java/util/NavigableMap", "java/util/SortedMap", "java/util/Map"]
     jdk_super["java/util/concurrent/ConcurrentHashMap"] = "java/util/AbstractMap"
     jdk_ifaces["java/util/concurrent/ConcurrentHashMap"] = ["java/util/Map", "java/util/concurrent/ConcurrentMap"]
     jdk_ifaces.update({"java/util/HashSet": ["java/util/Set", "java/util/Collection", "java/lang/Iterable"], "java/util/HashMap": ["java/util/Map"]})

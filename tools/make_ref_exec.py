@@ -25,7 +25,7 @@ import jvm_natives  # noqa: E402
 REF = "/root/reference/Jar/"
 JARS = [REF + "NanoporeBC_UMI_finder-2.1.jar", REF + "lib/TwoFourBitNucAcidLibraryMaven-1.0.jar",
         REF + "lib/Aliasi_ClusteringLib-1.0.jar", REF + "lib/commons-lang3-3.17.0.jar", REF + "lib/htsjdk-4.1.3.jar",
-        REF + "lib/guava-33.3.1-jre.jar"]
+        REF + "lib/guava-33.3.1-jre.jar", REF + "lib/picard-2.23.9.jar", REF + "lib/DropseqLib-1.0.jar"]
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
 
 TB = "com/rw/nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase"
@@ -842,7 +842,190 @@ def gen_chimera_3p(g):
     return gen_chimera(g, False, 909)
 
 
-SECTIONS = {"twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+GT = "com/rw/umifinder/bamreaders/GennameTagger"
+RFR = "picard/annotation/RefFlatReader"
+TTP = "picard/util/TabbedTextFileWithHeaderParser"
+SAMREC = "htsjdk/samtools/SAMRecord"
+REFFLAT_COLUMNS = ["GENE_NAME", "TRANSCRIPT_NAME", "CHROMOSOME", "STRAND", "TX_START", "TX_END", "CDS_START", "CDS_END", "EXON_COUNT",
+                   "EXON_STARTS", "EXON_ENDS"]
+
+
+def install_gene_io(j, lines, ref_names):
+    """file / header stand-ins, all of them INPUT plumbing: the tab-separated rows of the annotation file reach RefFlatReader.load() as real
+    TabbedTextFileWithHeaderParser$Row objects (the class-file's own getField / getIntegerField run), the sequence dictionary answers
+    getSequence(name) != null for the given names, the logger is inert, and a SAMRecord is a bag of the five values GennameTagger asks for
+    (alignment blocks and end computed by htsjdk's own Cigar / SAMUtils bytecode from the CIGAR string)."""
+    def parser_init(jj, o, _file, labels):
+        m = jj.natives["java/util/HashMap.<new>"](jj)
+        for i, lab in enumerate(labels.a):
+            m.native.put(lab, JBox("java/lang/Integer", i))
+        o.f["columnLabelIndices"] = m
+        o.native = {"line": 0}
+
+    def parser_iter(jj, o):
+        rows = []
+        for ln in lines:
+            if not ln or ln.startswith("#"):
+                continue  # BasicInputParser skips blank lines and comments
+            parts = ln.split("\t")
+            arr = JArray("Ljava/lang/String;", parts)
+            rows.append(jj.new(TTP + "$Row", f"(L{TTP};[Ljava/lang/String;Ljava/lang/String;)V", o, arr, ln))
+        lst = JObject("java/util/ArrayList")
+        lst.native = rows
+        return jj.natives["java/util/ArrayList.iterator"](jj, lst)
+
+    def guava_stream(jj, it):
+        """com.google.common.collect.Streams.stream(Iterable) = a sequential stream over iterable.iterator() (the Iterable's own bytecode)"""
+        itr = jj.call_virtual(it, "iterator", "()Ljava/util/Iterator;")
+        lst = JObject("java/util/ArrayList")
+        lst.native = []
+        while jj.call_virtual(itr, "hasNext", "()Z"):
+            lst.native.append(jj.call_virtual(itr, "next", "()Ljava/lang/Object;"))
+        return jj.natives["java/util/ArrayList.stream"](jj, lst)
+
+    H = j.hooks  # these classes ARE in the jars: their file / header plumbing is replaced, nothing of the path under test
+    H["com/google/common/collect/Streams.stream:(Ljava/lang/Iterable;)Ljava/util/stream/Stream;"] = guava_stream
+    H["com/google/common/collect/Streams.<clinit>:()V"] = None
+    # GennameTagger.<clinit> builds LOCUS_FUNCTION_SCORES with io.vavr.collection.Stream.of(entries).collect(toMap(.., TreeMap::new)): a
+    # sequential ordered stream over the four entries (vavr is not among the jars executed)
+    j.natives["io/vavr/collection/Stream.of:([Ljava/lang/Object;)Lio/vavr/collection/Stream;"] = \
+        j.natives["java/util/stream/Stream.of:([Ljava/lang/Object;)Ljava/util/stream/Stream;"]
+    j.natives["io/vavr/collection/Stream.collect"] = j.natives["java/util/stream/Stream.collect"]
+    H[TTP + ".<init>:(Ljava/io/File;[Ljava/lang/String;)V"] = parser_init
+    H[TTP + ".iterator:()Lhtsjdk/samtools/util/CloseableIterator;"] = parser_iter
+    H[TTP + ".getCurrentLineNumber:()I"] = lambda jj, o: 0
+    H[TTP + ".close:()V"] = lambda jj, o: None
+    H["htsjdk/samtools/util/Log.<clinit>:()V"] = None
+    H["htsjdk/samtools/util/Log.*"] = lambda jj, *a: None
+    H["htsjdk/samtools/util/Log.getInstance:(Ljava/lang/Class;)Lhtsjdk/samtools/util/Log;"] = lambda jj, *a: JObject("htsjdk/samtools/util/Log")
+    names = set(ref_names)
+    H["htsjdk/samtools/SAMSequenceDictionary.getSequence:(Ljava/lang/String;)Lhtsjdk/samtools/SAMSequenceRecord;"] = (
+        lambda jj, o, nm: JObject("htsjdk/samtools/SAMSequenceRecord") if nm in names else None)
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".getReferenceName:()Ljava/lang/String;"] = lambda jj, o: o.native["ref"]
+    H[SAMREC + ".getAlignmentStart:()I"] = lambda jj, o: o.native["start"]
+    H[SAMREC + ".getAlignmentEnd:()I"] = lambda jj, o: o.native["end"]
+    H[SAMREC + ".getAlignmentBlocks:()Ljava/util/List;"] = lambda jj, o: o.native["blocks"]
+    H[SAMREC + ".getReadNegativeStrandFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 16 else 0
+    H[SAMREC + ".setAttribute:(Ljava/lang/String;Ljava/lang/Object;)V"] = lambda jj, o, t, v: o.native["calls"].append([t, v])
+
+
+def sam_record(j, ref, flag, pos0, cigar):
+    """unmapped: reference "*", start 0, no cigar (SAMRecord.NO_ALIGNMENT_*)"""
+    o = JObject(SAMREC)
+    if flag & 4 or ref is None:
+        lst = JObject("java/util/ArrayList")
+        lst.native = []
+        o.native = {"ref": "*", "start": 0, "end": 0, "blocks": lst, "flag": flag, "calls": []}  # getAlignmentEnd of an unmapped read: NO_ALIGNMENT_START
+        return o
+    text = "".join(f"{ln}{op}" for op, ln in cigar)
+    cg = j.call_static("htsjdk/samtools/TextCigarCodec", "decode", "(Ljava/lang/String;)Lhtsjdk/samtools/Cigar;", text)
+    blocks = j.call_static("htsjdk/samtools/SAMUtils", "getAlignmentBlocks", "(Lhtsjdk/samtools/Cigar;ILjava/lang/String;)Ljava/util/List;",
+                           cg, pos0 + 1, "read cigar")
+    ref_len = j.call_virtual(cg, "getReferenceLength", "()I")
+    o.native = {"ref": ref, "start": pos0 + 1, "end": pos0 + 1 + ref_len - 1, "blocks": blocks, "flag": flag, "calls": []}
+    return o
+
+
+def gene_reads(rng, rows, n):
+    """reads along transcripts (N between exons), around genes, across genes, unmapped, on an unknown contig"""
+    out = []
+    tx = [r for r in rows if r[2] == "chr12"]
+    for k in range(n):
+        r = tx[rng.randrange(len(tx))]
+        es = [int(x) + 1 for x in r[9].split(",") if x]
+        ee = [int(x) for x in r[10].split(",") if x]
+        flag = 16 if rng.random() < 0.5 else 0
+        kind = k % 7
+        if kind <= 2:
+            i = rng.randrange(len(es))
+            jx = min(len(es), i + rng.randrange(1, 5))
+            start = rng.randrange(es[i], ee[i] + 1)
+            cigar, p = ([("S", rng.randrange(1, 30))] if kind == 1 else []), start
+            for q in range(i, jx):
+                stop = ee[q] if q < jx - 1 else rng.randrange(max(p, es[q]), ee[q] + 1)
+                if q > i:
+                    cigar.append(("N", es[q] - p))
+                    p = es[q]
+                if stop - p + 1 > 0:
+                    cigar.append(("M", stop - p + 1))
+                    p = stop + 1
+            if not any(op == "M" for op, _ in cigar):
+                cigar.append(("M", 1))
+            out.append(("chr12", flag, start - 1, cigar))
+        elif kind == 3:
+            start = rng.randrange(max(1, es[0] - 3000), ee[-1] + 3000)
+            out.append(("chr12", flag, start - 1, [("M", rng.randrange(20, 900)), ("I", 3), ("D", rng.randrange(1, 40)), ("=", rng.randrange(1, 400)), ("X", 2)]))
+        elif kind == 4:
+            start = rng.randrange(max(1, es[0] - 20000), ee[-1])
+            out.append(("chr12", flag, start - 1, [("M", rng.randrange(500, 4000)), ("N", rng.randrange(100, 60000)), ("M", rng.randrange(100, 3000))]))
+        elif kind == 5:
+            out.append((None, flag | 4, -1, []) if rng.random() < 0.5 else ("chrUn", flag, rng.randrange(10 ** 6), [("M", 500)]))
+        else:
+            start = rng.randrange(es[0], ee[-1])
+            out.append(("chr12", flag, start - 1, [("S", 5), ("D", rng.randrange(1, 60))]))   # no aligned block at all
+    return out
+
+
+def gen_gene(g, n_rows=1500, n_reads=420, seed=1212):
+    import gzip
+
+    j = g.j
+    rng = random.Random(seed)
+    text = gzip.open(os.path.join(OUT, "chr12_head1500.refFlat.gz"), "rt").read()
+    lines = text.split("\n")[:n_rows]
+    extra = ["GOOD\tt1\tc1\t+\t100\t1000\t200\t900\t2\t100,600,\t300,1000,", "GOOD\tt2\tc1\t+\t150\t1200\t200\t900\t1\t150,\t1200,",
+             "TWOSTRANDS\tt3\tc1\t+\t5000\t6000\t5000\t6000\t1\t5000,\t6000,", "TWOSTRANDS\tt4\tc1\t-\t5000\t6000\t5000\t6000\t1\t5000,\t6000,",
+             "TWICE\tt5\tc1\t-\t7000\t8000\t7000\t8000\t1\t7000,\t8000,", "TWICE\tt5\tc1\t-\t7000\t8000\t7000\t8000\t1\t7000,\t8000,",
+             "COUNT\tt6\tc1\t+\t9000\t9500\t9000\t9500\t3\t9000,9200,\t9100,9500,", "OVERLAP\tt7\tc1\t+\t10000\t10500\t10000\t10500\t2\t10000,10100,\t10100,10500,",
+             "OVERLAP2\tt8\tc1\t+\t11000\t11500\t11000\t11500\t2\t11000,11099,\t11100,11500,", "EMPTY\tt9\tc1\t+\t12000\t12500\t12000\t12500\t1\t12100,\t12100,",
+             "ELSEWHERE\tt10\tc9\t+\t100\t1000\t100\t1000\t1\t100,\t1000,", "SAMEPLACE_A\tt11\tc1\t-\t20000\t21000\t20000\t21000\t1\t20000,\t21000,",
+             "SAMEPLACE_B\tt12\tc1\t-\t20000\t21000\t20500\t21000\t1\t20000,\t21000,", "ANTISENSE\tt13\tc1\t+\t20000\t21000\t21000\t21000\t1\t20000,\t21000,"]
+    lines = [ln for ln in lines if ln] + extra
+    refs = ["chr1", "chr12", "chrUn", "c1"]
+    install_gene_io(j, lines, refs)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar + picard-2.23.9.jar + htsjdk-4.1.3.jar", "sections": []}
+    s = g.section("RefFlatReader.load() over the rows of tests/golden/chr12_head1500.refFlat.gz plus the hand-made rows in `extra_rows`, then "
+                  "GennameTagger.annotateGene(record) (GennameTagger.java:L73-121, L382) with ALLOW_MULTI_GENE_READS = true as its constructor sets "
+                  "it (L65): the setAttribute calls it makes (value null = tag removed) or the exception it throws.  HashMap / HashSet iteration "
+                  "in java.util.HashMap table order from the keys' own hashCode() (tier D)", GT, "annotateGene:(Lhtsjdk/samtools/SAMRecord;)Lhtsjdk/samtools/SAMRecord;")
+    s["extra_rows"] = extra
+    s["ref_names"] = refs
+    s["n_rows_of_sample"] = len(lines) - len(extra)
+    j.hash_order = "jdk"
+    rdr = j.new(RFR, "(Ljava/io/File;Lhtsjdk/samtools/SAMSequenceDictionary;)V", None, JObject("htsjdk/samtools/SAMSequenceDictionary"))
+    det = j.call_virtual(rdr, "load", "()Lhtsjdk/samtools/util/OverlapDetector;")
+    print(f"  refFlat loaded by the reference's RefFlatReader.load(): {time.time() - g.t0:.0f}s", flush=True)
+    allg = j.call_virtual(det, "getAll", "()Ljava/util/Set;")
+    s["genes_loaded"] = sorted(o.f["name"] for o, _ in allg.native.items_in_insertion_order())
+    tagger = j.new_object(GT)
+    tagger.f.update({"TAG": "GE", "STRANDTAG": "GS", "FUNCTIONTAG": "XF", "ALLOW_MULTI_GENE_READS": 1, "geneOverlapDetector": det})
+    tagger.f["metrics"] = j.new(GT + "$ReadTaggingMetric", f"(L{GT};)V", tagger)
+    rows = [ln.split("\t") for ln in lines]
+    reads = gene_reads(rng, rows, n_reads)
+    reads += [("c1", f, p, cg) for f, p, cg in [(0, 40, [("M", 50)]), (0, 100, [("M", 50)]), (0, 250, [("M", 20)]), (0, 350, [("M", 20)]),
+              (16, 250, [("M", 20)]), (0, 1100, [("M", 50)]), (0, 1199, [("M", 50)]), (0, 1200, [("M", 50)]), (16, 20100, [("M", 50)]),
+              (0, 20100, [("M", 50)]), (0, 5100, [("M", 50)]), (0, 10090, [("M", 5)]), (0, 250, [("S", 10), ("D", 30)]),
+              (0, 11050, [("M", 100)]), (0, 250, [("M", 20), ("N", 19800), ("M", 100)]), (16, 250, [("M", 20), ("N", 19800), ("M", 100)])]]
+    for k, (ref, flag, pos0, cigar) in enumerate(reads):
+        rec = sam_record(j, ref, flag, pos0, cigar)
+        case = {"ref": ref, "flag": flag, "pos0": pos0, "cigar": [[op, ln] for op, ln in cigar]}
+        try:
+            j.call_virtual(tagger, "annotateGene", f"(L{SAMREC};)L{SAMREC};", rec)
+            case["set_attribute"] = rec.native["calls"]
+        except JavaThrow as e:
+            case["throws"] = e.obj.cls
+            case["set_attribute_before_throw"] = rec.native["calls"]
+        s["cases"].append(case)
+        if k % 60 == 0:
+            print(f"  gene {k + 1}/{len(reads)}  {time.time() - g.t0:.0f}s", flush=True)
+    j.hash_order = None
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
