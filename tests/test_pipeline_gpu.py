@@ -348,3 +348,21 @@ def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
     z_w, _, _, _ = assignumis.write_tagged_bams(gpu_ctx, data, truncate_read_name=True)
     _, _, out_w = bammodel.parse_bam(bammodel.bgzf_decompress(z_w))
     assert [o["name"] for o in out_w] == [o["name"].split("_")[0] for o in out_bc] and [o["aux"] for o in out_w] == [o["aux"] for o in out_bc]
+    # --annotationFile: GE / GS / XF from the refFlat genes (GennameTagger): reads of molecule group k sit around 30,000 + 5,000 k
+    refflat = "".join(f"G{k}\tT{k}\tchr1\t{'-' if k & 1 else '+'}\t{25_000 + 5_000 * k}\t{36_000 + 5_000 * k}\t{26_000 + 5_000 * k}\t"
+                      f"{35_000 + 5_000 * k}\t1\t{25_000 + 5_000 * k},\t{36_000 + 5_000 * k},\n" for k in range(0, 5, 2))
+    z_g, _, names_g, _ = assignumis.write_tagged_bams(gpu_ctx, data, refflat=refflat)
+    _, _, out_g = bammodel.parse_bam(bammodel.bgzf_decompress(z_g))
+    assert names_g == names and [o["name"] for o in out_g] == [o["name"] for o in out_bc]
+    import genemodel
+
+    tree, _ = genemodel.load_refflat(refflat, ["chr1"])
+    n_ge = 0
+    for o, o0 in zip(out_g, out_bc):
+        a = {t: v for t, _ty, v in _parse_aux(o["aux"])}
+        ge, gs, xf = genemodel.tag(tree, "chr1", o["flag"], o["pos0"], o["cigar"])
+        assert a["XF"] == xf and a.get("GE") == ge and a.get("GS") == gs
+        n_ge += ge is not None
+        rest = [(t, v) for t, _ty, v in _parse_aux(o["aux"]) if t not in ("XF", "GE", "GS")]
+        assert rest == [(t, v) for t, _ty, v in _parse_aux(o0["aux"])]
+    assert 20 < n_ge < len(out_g)
