@@ -365,7 +365,7 @@ enum { SMI_SPLIT_REV_ADAPTER = 0, SMI_SPLIT_FWD_ADAPTER = 1, SMI_SPLIT_RA_FA = 2
        SMI_SPLIT_RT_FT = 5 };
 #define SMI_CHIM_MULTI 1u    /* > 2 split positions: MULTI_CHIMERIC_READS_DISCARDED | FAILED, the read stays whole (L284-286) */
 #define SMI_CHIM_RANGE 2u    /* split positions out of order / outside the read: the reference throws from substring */
-#define SMI_CHIM_OVERFLOW 4u /* more than 64 internal matches in one read: result not computed, treat as an error */
+#define SMI_CHIM_OVERFLOW 4u /* (round 1: more than 64 internal matches; such reads now go through the serial kernel and this flag is never set) */
 
 typedef struct {
     int32_t pos[2];    /* cut offsets into the read (String.substring semantics): fragments [0,pos0) [pos0,pos1) [pos1,len) */

@@ -169,7 +169,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         SMI_HIP(hipStreamSynchronize(s));
         for (const auto &c : h_chim)
             if (c.flags & (SMI_CHIM_RANGE | SMI_CHIM_OVERFLOW)) {
-                set_error("smi_scanfastq_pass2_chunk: a read outside what the splitter supports (SMI_CHIM_RANGE / SMI_CHIM_OVERFLOW)");
+                set_error("smi_scanfastq_pass2_chunk: a read outside what the splitter supports (SMI_CHIM_RANGE: longer than the plane offsets can address)");
                 return SMI_ERR_INVALID;
             }
         m = (size_t)nf;
