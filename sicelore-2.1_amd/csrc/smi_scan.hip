@@ -44,7 +44,8 @@ struct ScanParams {
     int min_3p;          // minAdapter3pMatches (8)
     int min_bc_qv;       // 8
     int min_read_qv;     // 8
-    uint32_t adapter4[22];  // 4-bit codes of the adapter, padded
+    uint32_t adapter_nib[3];  // 4-bit codes of the adapter, eight per word, padded with 0 (three SGPRs instead of 22)
+    __host__ __device__ __forceinline__ uint32_t a4(int i) const { return (adapter_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
 };
@@ -156,6 +157,17 @@ __device__ __forceinline__ uint32_t tso4(int i) {
     return (uint32_t)(TSO >> (4 * i)) & 15u;
 }
 
+// The adapters the reference ships (Jar/config.xml:111-113: `sequence` "CTTCCGATCT" and `sequence_complete`
+// "CTACACGACGCTCTTCCGATCT" of adapter_for3pBarcoding / the 5' adapter) as compile-time 4-bit codes, base i in bits [4i+3:4i] of
+// word i / 8: a kernel compiled for one of them (SHIP = true) selects the column planes of an alignment and the gate planes by
+// constants instead of by uniform bit tests of ScanParams (80 SGPR select masks at AD = 10, spilled to VGPR lanes and read back per
+// use).  Any other adapter runs the generic kernels (SHIP = false).
+template <int AD>
+__host__ __device__ constexpr uint32_t shipped_a4(int i) {
+    constexpr const char *S = AD == 10 ? "CTTCCGATCT" : "CTACACGACGCTCTTCCGATCT";
+    return S[i] == 'A' ? 1u : S[i] == 'G' ? 2u : S[i] == 'C' ? 4u : 8u;
+}
+
 // 4-mer gate (Kmers.nKmersMatching_4mer > 1) for 64 scan positions starting at bit b of the owner's planes
 template <int N, typename F>
 __device__ __forceinline__ uint64_t gate64(const uint32_t *planes, int owner, int b, F code) {
@@ -214,7 +226,7 @@ __device__ __forceinline__ int wave_exscan(int v, int lane, int &total) {
 //                         skip rule), lanes 2i/2i+1 exchange for the strand decision and the TSO rules, one lane
 //                         writes the record and the barcode window
 // ---------------------------------------------------------------------------------------------------------------
-template <int AD, bool FP>
+template <int AD, bool FP, bool SHIP>
 __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
                                                  const uint8_t *__restrict__ qtail, const uint32_t *__restrict__ qsum,
                                                  size_t n_reads, ScanParams P, smi_scan_result *__restrict__ out,
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         int pb = 0, pe = 0;
         const bool has_t = active && long_enough && !(FP && P.dont_polya) && find_polyt(planes, tid, P, pb, pe);
-        uint64_t am[3] = {0, 0, 0}, tm[2] = {0, 0};
+        uint64_t am[3] = {0, 0, 0};
         // 5' barcoding scans an end when the polyT was found at the OTHER end (or no polyA is asked for):
         // PolyATadapterAnalyzer_5pBCUMI.java:L51-68
         const bool scan5 = FP && active && long_enough && (P.dont_polya || __shfl_xor((int)has_t, 1));
@@ -251,41 +263,54 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
             const int last = FP ? P.window5 : min(pe - AD, pe - 12);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
-                am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return P.adapter4[i]; }), last - ch * 64);
-        }
-        if (active && long_enough && !FP) {
-            // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++)
-                tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
+                am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return SHIP ? shipped_a4<AD>(i) : P.a4(i); }), last - ch * 64);
         }
         const int n_ad = __popcll(am[0]) + __popcll(am[1]) + __popcll(am[2]);
-        const int n_ts = __popcll(tm[0]) + __popcll(tm[1]);
         const int lane = tid & 63, wbase = tid & ~63;  // this wave's lanes are wbase .. wbase+63
-        int tot_ad, tot_ts;
-        const int off_ad = wave_exscan(n_ad, lane, tot_ad);
-        const int off_ts = wave_exscan(n_ts, lane, tot_ts);
+        int tot_ad;
+        // count (<= 192) and offset (<= 64 * 192) of a lane's candidates share a register while the alignments run
+        const uint32_t no_ad = (uint32_t)n_ad | ((uint32_t)wave_exscan(n_ad, lane, tot_ad) << 8);
+        const uint32_t pbe = (uint32_t)pb | ((uint32_t)pe << 16);
 
         // ---- phases B + C(fold): adapter candidates, then TSO candidates -----------------------------------------
         // adapter fold state (AdapterScanRslt best key + getMatchList L275-319)
+        // The fold state rides through the alignment loops in few registers: a_pack / t_pack = pos | nmis << 8 | ins << 16 | (del + 128) << 24
+        // (positions are <= 192), t_aux = consec | best_two << 8 | skip << 16
         float a_best = 3.4028234663852886e+38f, a_key = 0.0f;
         bool a_have = false;
-        int a_pos = 0, a_nmis = 0, a_ins = 0, a_del = 0;
+        uint32_t a_pack = 0;
         float a_endn = 0.0f;
         // TSO fold state (scanForAdapterOrTSOseq with maxErrors = 5, L96-104; scanForTSO takes the first best position)
         float t_best = 3.4028234663852886e+38f;
-        int t_pos = 0, t_nmis = 0, t_ins = 0, t_del = 0, t_consec = 0, t_two = 0, t_skip = 0;
+        uint32_t t_pack = 0, t_aux = 0;
 #pragma unroll 1
         for (int kind = 0; kind < 2; kind++) {
-            // this kind's candidate masks and offsets go to LDS (the previous kind's are dead: wave_sync below)
-            cmask[0 * kBlock + tid] = kind == 0 ? am[0] : tm[0];
-            cmask[1 * kBlock + tid] = kind == 0 ? am[1] : tm[1];
-            cmask[2 * kBlock + tid] = kind == 0 ? am[2] : 0ull;
-            coff[tid] = (uint32_t)(kind == 0 ? off_ad : off_ts);
+            // this kind's candidate masks and offsets go to LDS (the previous kind's are dead: wave_sync below).  The TSO gates are
+            // computed here, after the adapter alignments, so that their masks are not live across them.
+            uint32_t no = no_ad;
+            int total = tot_ad;
+            if (kind == 0) {
+                cmask[0 * kBlock + tid] = am[0];
+                cmask[1 * kBlock + tid] = am[1];
+                cmask[2 * kBlock + tid] = am[2];
+            } else {
+                uint64_t tm[2] = {0, 0};
+                if (active && long_enough && !FP) {
+                    // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+                        tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
+                }
+                const int n_ts = __popcll(tm[0]) + __popcll(tm[1]);
+                no = (uint32_t)n_ts | ((uint32_t)wave_exscan(n_ts, lane, total) << 8);
+                cmask[0 * kBlock + tid] = tm[0];
+                cmask[1 * kBlock + tid] = tm[1];
+                cmask[2 * kBlock + tid] = 0ull;
+            }
+            coff[tid] = no >> 8;
             wave_sync();
             const uint32_t *offs = coff;
-            const int total = kind == 0 ? tot_ad : tot_ts;
-            const int my_off = kind == 0 ? off_ad : off_ts, my_n = kind == 0 ? n_ad : n_ts;
+            const int my_off = (int)(no >> 8), my_n = (int)(no & 0xFFu);
             for (int base = 0; base < total; base += 64) {
                 const int en = base + lane;
                 if (en < total) {
@@ -322,7 +347,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                     if (kind == 0) {
                         uint32_t col[AD];
 #pragma unroll
-                        for (int c = 0; c < AD; c++) col[c] = col_of(P.adapter4[c]) & ((1u << AD) - 1u);
+                        for (int c = 0; c < AD; c++) col[c] = col_of(SHIP ? shipped_a4<AD>(c) : P.a4(c)) & ((1u << AD) - 1u);
                         nw_full<AD, true, false>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
                     } else {
                         uint32_t col[16];
@@ -344,8 +369,9 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 for (int x = f0; x < f1; x++) {
                     const uint32_t *o = ent + (wbase + x - base) * 5;
                     const float ne = __uint_as_float(o[0]);
-                    const int nmis = (int)(o[3] & 0xFF), ins = (int)((o[3] >> 8) & 0xFF), del = (int)((o[3] >> 16) & 0xFF) - 128;
+                    const int nmis = (int)(o[3] & 0xFF);
                     const int pos = (int)(o[4] >> 16);
+                    const uint32_t packed = (uint32_t)pos | (o[3] << 8);  // the term6 bit falls off the top
                     if (kind == 0) {
                         if (ne < a_best) {
                             a_best = ne;
@@ -359,26 +385,19 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                             if (ok && (!a_have || key < a_key)) {
                                 a_have = true;
                                 a_key = key;
-                                a_pos = pos;
-                                a_nmis = nmis;
-                                a_ins = ins;
-                                a_del = del;
+                                a_pack = packed;
                                 a_endn = __uint_as_float(o[2]);
                             }
                         }
-                    } else if (pos >= t_skip) {  // positions jumped over by deltaPos are never aligned (L100-106)
+                    } else if (pos >= (int)(t_aux >> 16)) {  // positions jumped over by deltaPos are never aligned (L100-106)
                         if (!((float)(int)floorf(__fadd_rn(ne, 0.5f)) > 5.0f) && ne < t_best) {  // Math.round(ne) <= 5
                             t_best = ne;
-                            t_pos = pos;
-                            t_nmis = nmis;
-                            t_ins = ins;
-                            t_del = del;
-                            t_consec = (int)(o[4] & 0xFF);
-                            t_two = (int)((o[4] >> 8) & 0xFF);
+                            t_pack = packed;
+                            t_aux = (t_aux & 0xFFFF0000u) | (o[4] & 0xFFFFu);
                         }
                         if (5.0f < ne) {
                             int d = (int)floorf(__fadd_rn(__fsub_rn(ne, 5.0f), 0.5f)) - 1;
-                            t_skip = pos + (d < 1 ? 1 : d);
+                            t_aux = (t_aux & 0xFFFFu) | ((uint32_t)(pos + (d < 1 ? 1 : d)) << 16);
                         }
                     }
                 }
@@ -388,10 +407,11 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
 
         // ---- phase C: strand decision (PolyATadapterAnalyzerBase.analyze L145-163): lanes 2i and 2i+1 exchange ----
         const int o_has_t = __shfl_xor((int)has_t, 1);
-        const int o_n_all = __shfl_xor(n_ad, 1);
+        const int n_ad_c = (int)(no_ad & 0xFFu);
+        const int o_n_all = __shfl_xor(n_ad_c, 1);
         const float o_best = __shfl_xor(a_best, 1);
         const bool f_has = side == 0 ? has_t : (bool)o_has_t, r_has = side == 0 ? (bool)o_has_t : has_t;
-        const int f_n = side == 0 ? n_ad : o_n_all, r_n = side == 0 ? o_n_all : n_ad;
+        const int f_n = side == 0 ? n_ad_c : o_n_all, r_n = side == 0 ? o_n_all : n_ad_c;
         const float f_best = side == 0 ? a_best : o_best, r_best = side == 0 ? o_best : a_best;
         uint32_t flags = 0;
         int use_fwd = -1;
@@ -419,6 +439,10 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
             if (use_fwd < 0) flags |= SMI_F_FAILED;
         }
         const bool chosen = active && use_fwd >= 0 && side == (use_fwd ? 0 : 1);
+        const int a_pos = (int)(a_pack & 0xFF), a_nmis = (int)((a_pack >> 8) & 0xFF), a_ins = (int)((a_pack >> 16) & 0xFF),
+                  a_del = (int)(a_pack >> 24) - 128;
+        const int t_pos = (int)(t_pack & 0xFF), t_nmis = (int)((t_pack >> 8) & 0xFF), t_ins = (int)((t_pack >> 16) & 0xFF),
+                  t_del = (int)(t_pack >> 24) - 128, t_consec = (int)(t_aux & 0xFF), t_two = (int)((t_aux >> 8) & 0xFF);
 
         smi_scan_result res;
         res.flags = flags;
@@ -438,13 +462,14 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         win.bases = 0;
         win.nmask = 0;
         win.flags = 0;
-        const int o_pe = __shfl_xor(pe, 1), o_pb = __shfl_xor(pb, 1);
+        const int pb_c = (int)(pbe & 0xFFFFu), pe_c = (int)(pbe >> 16);
+        const int o_pe = __shfl_xor(pe_c, 1), o_pb = __shfl_xor(pb_c, 1);
         if (chosen) {
             // polyA coordinates are set as soon as a side is chosen (analyze L169-171); 5' barcoding takes the polyT
             // result of the other end, and none with --noPolyARequired
             if (!FP) {
-                res.polya_start = len - (pe - 1);
-                res.polya_end = len - (pb - 1);
+                res.polya_start = len - (pe_c - 1);
+                res.polya_end = len - (pb_c - 1);
             } else if (!P.dont_polya) {
                 res.polya_start = len - (o_pe - 1);
                 res.polya_end = len - (o_pb - 1);
@@ -608,7 +633,8 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     P.min_bc_qv = cfg->min_mean_bc_qv;
     P.min_read_qv = cfg->min_mean_read_qv;
     const int ad = cfg->adapter_len;
-    for (int i = 0; i < 22; i++) P.adapter4[i] = i < ad ? cfg->adapter4[i] : 0u;
+    P.adapter_nib[0] = P.adapter_nib[1] = P.adapter_nib[2] = 0u;
+    for (int i = 0; i < 22 && i < ad; i++) P.adapter_nib[i >> 3] |= (cfg->adapter4[i] & 15u) << ((i & 7) * 4);
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
     const size_t n_ends = 2 * n;
@@ -619,16 +645,19 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out,
                            d_win);
     };
+    bool ship = ad == 10 || ad == 22;
+    for (int i = 0; ship && i < ad; i++) ship = P.a4(i) == (ad == 10 ? shipped_a4<10>(i) : shipped_a4<22>(i));
+    if (std::getenv("SMI_SCAN_GENERIC")) ship = false;  // tests run both builds against the oracle
     if (ad == 10) {
         if (cfg->five_prime)
-            launch(k_scan<10, true>);
+            ship ? launch(k_scan<10, true, true>) : launch(k_scan<10, true, false>);
         else
-            launch(k_scan<10, false>);
+            ship ? launch(k_scan<10, false, true>) : launch(k_scan<10, false, false>);
     } else {
         if (cfg->five_prime)
-            launch(k_scan<22, true>);
+            ship ? launch(k_scan<22, true, true>) : launch(k_scan<22, true, false>);
         else
-            launch(k_scan<22, false>);
+            ship ? launch(k_scan<22, false, true>) : launch(k_scan<22, false, false>);
     }
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_SCAN, s)) return rc;

@@ -67,8 +67,11 @@ def _compare(got, st, exp, pass1):
     return int(sel.sum())
 
 
-@pytest.mark.parametrize("pass_no", [2, 1])
-def test_scan_matches_oracle(pkg, synth, sor, gpu_ctx, pass_no):
+@pytest.mark.parametrize("pass_no,generic", [(2, False), (1, False), (2, True), (1, True)])
+def test_scan_matches_oracle(pkg, synth, sor, gpu_ctx, pass_no, generic, monkeypatch):
+    # generic: the kernels that take the adapter from ScanParams (any adapter) instead of the ones compiled for the shipped adapters
+    if generic:
+        monkeypatch.setenv("SMI_SCAN_GENERIC", "1")
     wl = synth.make_whitelist(50_000, seed=201)
     used = synth.pick_used(wl, 300, seed=202)
     n = 6000
@@ -159,9 +162,11 @@ def test_pass1_histogram(pkg, synth, sor, gpu_ctx):
     assert (hist == ref).all()
 
 
-@pytest.mark.parametrize("pass_no,dont", [(2, True), (2, False), (1, True)])
-def test_scan_5p_matches_oracle_and_assigns(pkg, synth, sor, gpu_ctx, pass_no, dont):
+@pytest.mark.parametrize("pass_no,dont,generic", [(2, True, False), (2, False, False), (1, True, False), (2, False, True)])
+def test_scan_5p_matches_oracle_and_assigns(pkg, synth, sor, gpu_ctx, pass_no, dont, generic, monkeypatch):
     """5' barcoding: K-PACK (head qualities) -> K-SCAN in 5' mode == oracle, its 25-base windows -> K-BC1 == oracle"""
+    if generic:
+        monkeypatch.setenv("SMI_SCAN_GENERIC", "1")
     wl = synth.make_whitelist(50_000, seed=231)
     used = synth.pick_used(wl, 300, seed=232)
     n = 2500
