@@ -93,7 +93,7 @@ def self_launch(args):
 
 def end_to_end_leg(ctx, synth, dev, used, n):
     """Whole pass 2 of `scanfastq` for one chunk, FASTQ text resident in HBM -> finished `passed` / `failed` FASTQ text in
-    HBM, every stage on the device: K-FQ (index + two gathers), K-PACKR + K-CHIM + fragment offsets, K-PACK, K-SCAN,
+    HBM, every stage on the device: K-FQ (record index; bases and qualities are read in place), K-PACKR + K-CHIM + fragment offsets, K-PACK, K-SCAN,
     K-BC1 (same 3.6 M whitelist as the step), K-WRITE.  10 % of the input records are ligation chimeras (two molecules in one
     record), so the splitter has real work.  Reported beside `value`, never part of it."""
     rd = synth.gen_reads(n, used, seed=77, device=dev)
@@ -107,14 +107,13 @@ def end_to_end_leg(ctx, synth, dev, used, n):
     u8 = lambda k: torch.zeros(k, dtype=torch.uint8, device=dev)  # noqa: E731
     line, ns, ss, qs, offs = i64(4 * cap + 8), i64(cap), i64(cap), i64(cap), i64(cap + 1)
     nl, sl = i32(cap), i32(cap)
-    reads, quals = u8(total_bases), u8(total_bases)
     planes = i32(ctx.read_planes_words(total_bases, n))
     d_chim = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     scratch, nfrag, foffs, fsrc = i32((n + 1023) // 1024 + 1), i64(1), i64(3 * n + 1), i32(3 * n)
     m_cap = 3 * n
     ends = torch.zeros((28, 2 * m_cap), dtype=torch.int32, device=dev)
-    lens, qsum = i32(m_cap), i32(m_cap)
-    qt = torch.zeros((m_cap, 224), dtype=torch.uint8, device=dev)
+    lens = i32(m_cap)
+    bstart, qstart = i64(m_cap), i64(m_cap)
     scan = torch.zeros((m_cap, 8), dtype=torch.int32, device=dev)
     win = torch.zeros((m_cap, 2), dtype=torch.int64, device=dev)
     bc = torch.zeros((m_cap, 4), dtype=torch.int32, device=dev)
@@ -127,17 +126,16 @@ def end_to_end_leg(ctx, synth, dev, used, n):
     def run():
         nr, err = ctx.fastq_index_device(text, total_text, line, ns, nl, ss, sl, qs, offs, cap)
         assert nr == n and err == 0
-        ctx.fastq_gather_device(text, ss, offs, n, reads)
-        ctx.fastq_gather_device(text, qs, offs, n, quals)
-        ctx.pack_reads_device(reads, offs, n, total_bases, planes)
+        ctx.pack_reads_text_device(text, ss, offs, n, total_bases, planes)   # bases and qualities are read in place: no gathers
         ctx.chimera_device(planes, offs, n, total_bases, chim_cfg, d_chim)
         ctx.split_offsets_device(d_chim, offs, n, scratch, nfrag, foffs, fsrc)
         m = int(nfrag.item())
-        ctx.pack_ends_device(reads, quals, foffs, m, ends, lens, qt, qsum)
-        ctx.scan_device(ends, lens, m, scan_cfg, scan, win, qt, qsum)
+        ctx.frag_text_starts_device(ss, qs, offs, foffs, fsrc, m, bstart, qstart)
+        ctx.pack_ends_text_device(text, bstart, foffs, m, ends, lens)     # pass 2 has no quality filter
+        ctx.scan_device(ends, lens, m, scan_cfg, scan, win)
         ctx.bc_match_device(win, bc, m, max_ed=1, five_prime=False)
-        state["tot"] = ctx.fastq_write_device(text, line, reads, quals, foffs, fsrc, d_chim, scan, bc, None, m, 1, out_p, out_f,
-                                              rec_off, is_p)
+        state["tot"] = ctx.fastq_write_device(text, line, bstart, qstart, foffs, fsrc, d_chim, scan, bc, None, m, 1, out_p, out_f,
+                                              rec_off, is_p, in_text=True)
         state["m"] = m
 
     run()

@@ -399,6 +399,22 @@ int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, con
                              uint32_t *d_scratch, uint64_t *d_n_frag, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
                              void *stream);
 
+/* ---- the same stages without gathered copies of the chunk: bases and qualities are read where the FASTQ text has them ------------------
+ * (K-FQ's two gathers move 2 x the bases of a chunk through HBM and back; the chunk workers use these instead.)
+ * d_seq_start / d_qual_start: per input record, from smi_fastq_index_device; d_offsets: its prefix array of read lengths, which stays the
+ * coordinate system of the planes, of the fragment offsets and of every length. */
+int smi_pack_reads_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_seq_start, const uint64_t *d_offsets, size_t n,
+                               uint64_t total_bases, uint32_t *d_planes, void *stream);
+/* text positions of the bases / qualities of the n_out output records: fragment f of input record d_frag_src[f] >> 2 begins
+ * d_frag_offsets[f] - d_offsets[src] bases into it; d_frag_src == NULL: output records = input records.  d_qual_out may be NULL. */
+int smi_frag_text_starts_device(smi_ctx *ctx, const uint64_t *d_seq_start, const uint64_t *d_qual_start, const uint64_t *d_offsets,
+                                const uint64_t *d_frag_offsets, const uint32_t *d_frag_src, size_t n_out, uint64_t *d_base_start,
+                                uint64_t *d_qual_out, void *stream);
+/* smi_pack_ends_device for pass 2 (no qualities): record i's bases begin at d_text[d_base_start[i]], its length is
+ * d_offsets[i + 1] - d_offsets[i] (the fragment offsets when the splitter ran) */
+int smi_pack_ends_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_base_start, const uint64_t *d_offsets, size_t n,
+                              uint32_t *d_ends, int32_t *d_read_len, void *stream);
+
 /* name of fragment k (0 .. n_split) of a split read: readName.replaceFirst(" ", "_" + tag + "sp" + (k+1) + " ")
  * (L309,L323); returns the length written or a negative smi_status */
 int smi_chimera_fragment_name(const char *read_name, const smi_chimera_result *res, int fragment, char *out, size_t cap);
@@ -459,6 +475,13 @@ int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *
                            const int32_t *d_rank, size_t n_out, uint32_t first_read_id, const smi_write_config *cfg,
                            uint8_t *d_passed, size_t cap_passed, uint8_t *d_failed, size_t cap_failed, uint64_t *d_rec_off,
                            uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream);
+/* smi_fastq_write_device with d_reads / d_quals replaced by the text positions of smi_frag_text_starts_device */
+int smi_fastq_write_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint64_t *d_base_start,
+                                const uint64_t *d_qual_start, const uint64_t *d_offsets, const uint32_t *d_frag_src,
+                                const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc,
+                                const int32_t *d_rank, size_t n_out, uint32_t first_read_id, const smi_write_config *cfg, uint8_t *d_passed,
+                                size_t cap_passed, uint8_t *d_failed, size_t cap_failed, uint64_t *d_rec_off, uint8_t *d_is_passed,
+                                uint64_t *totals, uint32_t *errors, void *stream);
 
 /* ================================================================================================================
  * The per-chunk workers of `scanfastq` as one call each (what a JNI shim calls per FastqFileReader$ReadChunk): host

@@ -132,7 +132,8 @@ __device__ __forceinline__ uint32_t enc4c(uint8_t ch) {
 
 // one wave per read, one lane per 32-base plane word: a wave reads 2 KiB of consecutive ASCII and writes four 256-B rows
 __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
-                                                    size_t n, size_t stride, uint32_t *__restrict__ planes) {
+                                                    const uint64_t *__restrict__ starts, size_t n, size_t stride,
+                                                    uint32_t *__restrict__ planes) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
         const size_t w0 = plane_start(beg, r);
         const int64_t n_words = (len + 31) / 32 + kPadWords - 1;  // the pad words are written as zeros
-        const uint8_t *src = reads + beg;
+        const uint8_t *src = reads + (starts ? starts[r] : beg);  // starts: the bases sit in the FASTQ text, not in a gathered copy
         for (int64_t w = lane; w < n_words; w += 64) {
             uint32_t pl[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1350,11 +1351,11 @@ static uint32_t code_of(char c) {
 
 size_t read_planes_stride(uint64_t total_bases, size_t n) { return (size_t)(total_bases >> 5) + kPadWords * (n + 1) + 8; }
 
-int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
-                      uint32_t *d_planes, hipStream_t s) {
+int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offsets, const uint64_t *d_starts, size_t n,
+                      uint64_t total_bases, uint32_t *d_planes, hipStream_t s) {
     if (!n) return SMI_OK;
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, n, read_planes_stride(total_bases, n),
+    hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, read_planes_stride(total_bases, n),
                        d_planes);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
@@ -1515,6 +1516,29 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         }
     }
     if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;
+    return SMI_OK;
+}
+
+// text positions of the bases and qualities of output record f (a fragment of input record frag_src[f] >> 2, or the record itself)
+__global__ __launch_bounds__(256) void k_frag_text_starts(const uint64_t *__restrict__ seq_start, const uint64_t *__restrict__ qual_start,
+                                                          const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ frag_offsets,
+                                                          const uint32_t *__restrict__ frag_src, size_t m, uint64_t *__restrict__ bstart,
+                                                          uint64_t *__restrict__ qstart) {
+    const size_t f = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (f >= m) return;
+    const size_t r = frag_src ? (size_t)(frag_src[f] >> 2) : f;
+    const uint64_t in_read = frag_src ? frag_offsets[f] - offsets[r] : 0;
+    bstart[f] = seq_start[r] + in_read;
+    if (qstart) qstart[f] = qual_start[r] + in_read;
+}
+
+int launch_frag_text_starts(smi_ctx *, const uint64_t *d_seq_start, const uint64_t *d_qual_start, const uint64_t *d_offsets,
+                            const uint64_t *d_frag_offsets, const uint32_t *d_frag_src, size_t m, uint64_t *d_bstart, uint64_t *d_qstart,
+                            hipStream_t s) {
+    if (!m) return SMI_OK;
+    hipLaunchKernelGGL(k_frag_text_starts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_seq_start, d_qual_start, d_offsets,
+                       d_frag_offsets, d_frag_src, m, d_bstart, d_qstart);
+    SMI_HIP(hipGetLastError());
     return SMI_OK;
 }
 

@@ -447,7 +447,7 @@ int smi_pack_reads_device(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *
         set_error("smi_pack_reads_device: null buffer");
         return SMI_ERR_INVALID;
     }
-    return launch_pack_reads(ctx, d_reads, d_offsets, n, total_bases, d_planes, (hipStream_t)stream);
+    return launch_pack_reads(ctx, d_reads, d_offsets, nullptr, n, total_bases, d_planes, (hipStream_t)stream);
 }
 
 int smi_chimera_device(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
@@ -488,8 +488,41 @@ int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_
         set_error("smi_pack_ends_device: null buffer");
         return SMI_ERR_INVALID;
     }
-    return launch_pack_ends(ctx, d_reads, d_quals, d_offsets, n, five_prime, d_ends, d_read_len, d_qtail, d_qsum,
+    return launch_pack_ends(ctx, d_reads, d_quals, d_offsets, nullptr, n, five_prime, d_ends, d_read_len, d_qtail, d_qsum,
                             (hipStream_t)stream);
+}
+
+// ---- the same packers reading the bases where the FASTQ text has them (no gathered copy of the chunk) ----------------------------------
+int smi_pack_reads_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_seq_start, const uint64_t *d_offsets, size_t n,
+                               uint64_t total_bases, uint32_t *d_planes, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_text || !d_seq_start || !d_offsets || !d_planes)) {
+        set_error("smi_pack_reads_text_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_pack_reads(ctx, d_text, d_offsets, d_seq_start, n, total_bases, d_planes, (hipStream_t)stream);
+}
+
+int smi_pack_ends_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_base_start, const uint64_t *d_offsets, size_t n,
+                              uint32_t *d_ends, int32_t *d_read_len, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n && (!d_text || !d_base_start || !d_offsets || !d_ends || !d_read_len)) {
+        set_error("smi_pack_ends_text_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_pack_ends(ctx, d_text, nullptr, d_offsets, d_base_start, n, 0, d_ends, d_read_len, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int smi_frag_text_starts_device(smi_ctx *ctx, const uint64_t *d_seq_start, const uint64_t *d_qual_start, const uint64_t *d_offsets,
+                                const uint64_t *d_frag_offsets, const uint32_t *d_frag_src, size_t n_out, uint64_t *d_base_start,
+                                uint64_t *d_qual_out, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_out && (!d_seq_start || !d_base_start || (d_qual_out && !d_qual_start) || (d_frag_src && (!d_offsets || !d_frag_offsets)))) {
+        set_error("smi_frag_text_starts_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_frag_text_starts(ctx, d_seq_start, d_qual_start, d_offsets, d_frag_offsets, d_frag_src, n_out, d_base_start, d_qual_out,
+                                   (hipStream_t)stream);
 }
 
 int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_len, const uint8_t *d_qtail,

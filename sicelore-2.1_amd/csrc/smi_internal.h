@@ -124,11 +124,14 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
                 smi_bc_window *d_win, hipStream_t s);
 int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
                     const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s);
-int launch_pack_ends(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, size_t n,
-                     int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s);
+int launch_pack_ends(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, const uint64_t *d_starts,
+                     size_t n, int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s);
+int launch_frag_text_starts(smi_ctx *ctx, const uint64_t *d_seq_start, const uint64_t *d_qual_start, const uint64_t *d_offsets,
+                            const uint64_t *d_frag_offsets, const uint32_t *d_frag_src, size_t m, uint64_t *d_bstart, uint64_t *d_qstart,
+                            hipStream_t s);
 size_t read_planes_stride(uint64_t total_bases, size_t n);
-int launch_pack_reads(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
-                      uint32_t *d_planes, hipStream_t s);
+int launch_pack_reads(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, const uint64_t *d_starts, size_t n,
+                      uint64_t total_bases, uint32_t *d_planes, hipStream_t s);
 int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
                    const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s);
 int launch_split_offsets(smi_ctx *ctx, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,

@@ -685,8 +685,11 @@ __device__ __forceinline__ uint32_t comp4(uint32_t b) {
 // one lane = one read end (lanes 2i / 2i+1 = head / reverse-complemented tail of read i): every lane walks its 224
 // bases in 8-byte pieces and builds the four plane words in registers, so the stores of a wave are 256-B rows of the
 // [plane-word][end] layout and no cross-lane operation is needed
+// starts != nullptr: record r's bases begin at reads[starts[r]] (reads = the FASTQ text itself, no gathered copy); lengths always come
+// from the offsets prefix array
 __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
-                                                   size_t n, uint32_t *__restrict__ ends, int32_t *__restrict__ read_len) {
+                                                   const uint64_t *__restrict__ starts, size_t n, uint32_t *__restrict__ ends,
+                                                   int32_t *__restrict__ read_len) {
     const size_t n_ends = 2 * n;
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_ends; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e >> 1;
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
         const uint64_t beg = offsets[r];
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
         if (side == 0) read_len[r] = (int32_t)len;
-        const uint8_t *src = reads + beg;
+        const uint8_t *src = reads + (starts ? starts[r] : beg);
 #pragma unroll 1
         for (int w = 0; w < kPlaneWords; w++) {
             uint32_t pa = 0, pg = 0, pc = 0, pt = 0;
@@ -754,11 +757,11 @@ __global__ __launch_bounds__(256) void k_pack_quals(const uint8_t *__restrict__ 
     }
 }
 
-int launch_pack_ends(smi_ctx *, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, size_t n,
-                     int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
+int launch_pack_ends(smi_ctx *, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, const uint64_t *d_starts,
+                     size_t n, int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
     if (!n) return SMI_OK;
     const unsigned grid = (unsigned)std::min<size_t>((2 * n + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, n, d_ends, d_len);
+    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, d_ends, d_len);
     if (d_quals) {
         const unsigned gq = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
         hipLaunchKernelGGL(k_pack_quals, dim3(gq), dim3(256), 0, s, d_quals, d_offsets, n, head_quals, d_qtail, d_qsum);

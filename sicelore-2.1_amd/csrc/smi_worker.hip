@@ -115,7 +115,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     const size_t bases_cap = n_bytes;
     const size_t planes_words = split ? smi_read_planes_words(bases_cap, cap) : 0;
     const size_t out_cap = 2 * bases_cap + n_bytes + 320 * m_cap + 64;
-    size_t need = pad(n_bytes) + pad((4 * cap + 8) * 8) + 4 * pad(cap * 8) + pad((cap + 1) * 8) + 2 * pad(cap * 4) + 2 * pad(bases_cap) +
+    size_t need = pad(n_bytes) + pad((4 * cap + 8) * 8) + 4 * pad(cap * 8) + pad((cap + 1) * 8) + 2 * pad(cap * 4) + 2 * pad(m_cap * 8) +
                   pad(planes_words * 4) + pad(cap * sizeof(smi_chimera_result)) + pad(((cap + 1023) / 1024 + 1) * 4) + pad(8) +
                   pad((3 * cap + 1) * 8) + pad(3 * cap * 4) + pad((size_t)SMI_ENDS_ROWS * 2 * m_cap * 4) + 2 * pad(m_cap * 4) +
                   pad(m_cap * (size_t)SMI_END_BASES) + pad(m_cap * sizeof(smi_scan_result)) + pad(m_cap * sizeof(smi_bc_window)) +
@@ -142,9 +142,8 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     uint64_t total = 0;
     SMI_HIP(hipMemcpyAsync(&total, d_offs + n, 8, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
-    uint8_t *d_reads = A.take<uint8_t>(bases_cap), *d_quals = A.take<uint8_t>(bases_cap);
-    SMI_RC(smi_fastq_gather_device(ctx, d_text, d_ss, d_offs, n, d_reads, s));
-    SMI_RC(smi_fastq_gather_device(ctx, d_text, d_qs, d_offs, n, d_quals, s));
+    // bases and qualities stay where the text has them: every consumer below takes per-record text positions (no gathered copies)
+    uint64_t *d_bstart = A.take<uint64_t>(m_cap), *d_qstart = A.take<uint64_t>(m_cap);
     // ---- chimera splitter ----------------------------------------------------------------------------------------------------
     size_t m = n;
     const uint64_t *d_rec_offs = d_offs;
@@ -159,7 +158,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         d_fsrc = A.take<uint32_t>(3 * cap);
         smi_chimera_config cc;
         SMI_RC(five ? smi_chimera_default_config_5p(&cc) : smi_chimera_default_config(&cc));
-        SMI_RC(smi_pack_reads_device(ctx, d_reads, d_offs, n, total, d_planes, s));
+        SMI_RC(smi_pack_reads_text_device(ctx, d_text, d_ss, d_offs, n, total, d_planes, s));
         SMI_RC(smi_chimera_device(ctx, d_planes, d_offs, n, total, &cc, d_chim, s));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
         uint64_t nf = 0;
@@ -179,15 +178,15 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     // ---- scan + barcode -------------------------------------------------------------------------------------------------------
     uint32_t *d_ends = A.take<uint32_t>((size_t)SMI_ENDS_ROWS * 2 * m_cap);
     int32_t *d_len = A.take<int32_t>(m_cap);
-    uint32_t *d_qsum = A.take<uint32_t>(m_cap);
-    uint8_t *d_qtail = A.take<uint8_t>(m_cap * (size_t)SMI_END_BASES);
     smi_scan_result *d_scan = A.take<smi_scan_result>(m_cap);
     smi_bc_window *d_win = A.take<smi_bc_window>(m_cap);
     smi_bc_result *d_bc = A.take<smi_bc_result>(m_cap);
     smi_scan_config sc;
     SMI_RC(five ? smi_scan_default_config_5p(2, cfg->dont_search_polya, &sc) : smi_scan_default_config(2, &sc));
-    SMI_RC(smi_pack_ends_device(ctx, d_reads, d_quals, d_rec_offs, m, five, d_ends, d_len, d_qtail, d_qsum, s));
-    SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, m, &sc, d_scan, d_win, s));
+    // no qualities here: the quality filter (pass1_ok) belongs to pass 1 (UsedCellBCListGenerator.java:L198-202)
+    SMI_RC(smi_frag_text_starts_device(ctx, d_ss, d_qs, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_bstart, d_qstart, s));
+    SMI_RC(smi_pack_ends_text_device(ctx, d_text, d_bstart, d_rec_offs, m, d_ends, d_len, s));
+    SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
     int32_t *d_rank = nullptr;
     if (cfg->rank_keys && cfg->n_ranks) {
@@ -207,9 +206,9 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     smi_write_config wc{cfg->five_prime, cfg->trim_fastq};
     uint64_t totals[3] = {0, 0, 0};
     uint32_t werr = 0;
-    SMI_RC(smi_fastq_write_device(ctx, d_text, d_line, d_reads, d_quals, d_rec_offs, split ? d_fsrc : nullptr, split ? d_chim : nullptr,
-                                  d_scan, d_bc, d_rank, m, cfg->first_read_id, &wc, d_passed, out_cap, d_failed, out_cap, d_roff, d_isp,
-                                  totals, &werr, s));
+    SMI_RC(smi_fastq_write_text_device(ctx, d_text, d_line, d_bstart, d_qstart, d_rec_offs, split ? d_fsrc : nullptr,
+                                       split ? d_chim : nullptr, d_scan, d_bc, d_rank, m, cfg->first_read_id, &wc, d_passed, out_cap, d_failed,
+                                       out_cap, d_roff, d_isp, totals, &werr, s));
     for (int k = 0; k < 2; k++)  // pinned, grow-only: the download runs at link speed and nothing is zero-filled
         if (ctx->host_out_bytes[k] < totals[k]) {
             if (ctx->host_out[k]) SMI_HIP(hipHostFree(ctx->host_out[k]));

@@ -27,6 +27,7 @@ struct WriteArgs {
     const uint8_t *text;
     const uint64_t *line_start;
     const uint8_t *reads, *quals;
+    const uint64_t *bstart, *qstart;  // non-null: record i's bases / qualities begin at text[bstart[i]] / text[qstart[i]] (reads, quals unused)
     const uint64_t *offsets;
     const uint32_t *frag_src;
     const smi_chimera_result *chim;
@@ -123,7 +124,7 @@ __device__ __forceinline__ int format_record_suffix(const WriteArgs &A, const Re
         *quals_set = true;
         return NAME_OK;
     }
-    const uint8_t *rd = A.reads + R.base, *ql = A.quals + R.base;
+    const uint8_t *rd = A.bstart ? A.text + A.bstart[i] : A.reads + R.base, *ql = A.bstart ? A.text + A.qstart[i] : A.quals + R.base;
     const smi_bc_result *b = A.bc[i].found == 1 ? A.bc + i : nullptr;
     return append_name_suffix(
         s, A.scan[i], b, A.rank ? A.rank[i] : 0, read_id, A.five_prime != 0, R.len, [&](int k) { return (char)rd[k]; },
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
         if (lane == 0) atomicOr(err, SMI_WR_OVERFLOW);
         return;
     }
-    const uint8_t *rd = A.reads + base, *ql = A.quals + base;
+    const uint8_t *rd = A.bstart ? A.text + A.bstart[i] : A.reads + base, *ql = A.bstart ? A.text + A.qstart[i] : A.quals + base;
     const uint8_t *tok = A.text + name_beg, *qh = A.text + qh_beg;
     const uint8_t *lit = reinterpret_cast<const uint8_t *>(literals);
     const uint8_t *lut = reinterpret_cast<const uint8_t *>(rc_lut);
@@ -328,12 +329,12 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
 
 using namespace smi;
 
-extern "C" int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint8_t *d_reads,
-                                      const uint8_t *d_quals, const uint64_t *d_offsets, const uint32_t *d_frag_src,
-                                      const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc,
-                                      const int32_t *d_rank, size_t n_out, uint32_t first_read_id, const smi_write_config *cfg,
-                                      uint8_t *d_passed, size_t cap_passed, uint8_t *d_failed, size_t cap_failed,
-                                      uint64_t *d_rec_off, uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream) {
+static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint8_t *d_reads, const uint8_t *d_quals,
+                      const uint64_t *d_bstart, const uint64_t *d_qstart, const uint64_t *d_offsets, const uint32_t *d_frag_src,
+                      const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc, const int32_t *d_rank,
+                      size_t n_out, uint32_t first_read_id, const smi_write_config *cfg, uint8_t *d_passed, size_t cap_passed,
+                      uint8_t *d_failed, size_t cap_failed, uint64_t *d_rec_off, uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors,
+                      void *stream) {
     if (!ctx || !cfg || !totals || !errors) {
         set_error("smi_fastq_write_device: null argument");
         return SMI_ERR_INVALID;
@@ -341,7 +342,7 @@ extern "C" int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const
     totals[0] = totals[1] = totals[2] = 0;
     *errors = 0;
     if (n_out == 0) return SMI_OK;
-    if (!d_text || !d_line_start || !d_reads || !d_quals || !d_offsets || !d_scan || !d_bc || !d_passed || !d_failed || !d_rec_off ||
+    if (!d_text || !d_line_start || (d_bstart ? !d_qstart : (!d_reads || !d_quals)) || !d_offsets || !d_scan || !d_bc || !d_passed || !d_failed || !d_rec_off ||
         !d_is_passed || ((d_frag_src == nullptr) != (d_chim == nullptr))) {
         set_error("smi_fastq_write_device: null argument");
         return SMI_ERR_INVALID;
@@ -373,7 +374,7 @@ extern "C" int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const
     SMI_HIP(hipMemsetAsync(lenp + n_out, 0, 8, s));
     SMI_HIP(hipMemsetAsync(lenf + n_out, 0, 8, s));
     SMI_HIP(hipMemsetAsync(cntp + n_out, 0, 8, s));
-    WriteArgs A{d_text, d_line_start, d_reads, d_quals, d_offsets, d_frag_src, d_chim, d_scan, d_bc, d_rank,
+    WriteArgs A{d_text, d_line_start, d_reads, d_quals, d_bstart, d_qstart, d_offsets, d_frag_src, d_chim, d_scan, d_bc, d_rank,
                 n_out,  first_read_id, cfg->five_prime, cfg->trim_fastq};
     const unsigned g = (unsigned)((n_out + 255) / 256);
     hipLaunchKernelGGL(k_write_len, dim3(g), dim3(256), 0, s, A, lenp, lenf, cntp, sfx, d_is_passed, d_err);
@@ -402,4 +403,36 @@ extern "C" int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const
         return SMI_ERR_INVALID;
     }
     return SMI_OK;
+}
+
+extern "C" int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint8_t *d_reads,
+                                      const uint8_t *d_quals, const uint64_t *d_offsets, const uint32_t *d_frag_src,
+                                      const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc,
+                                      const int32_t *d_rank, size_t n_out, uint32_t first_read_id, const smi_write_config *cfg,
+                                      uint8_t *d_passed, size_t cap_passed, uint8_t *d_failed, size_t cap_failed,
+                                      uint64_t *d_rec_off, uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream) {
+    if (!d_reads || !d_quals) {
+        if (n_out) {
+            set_error("smi_fastq_write_device: null argument");
+            return SMI_ERR_INVALID;
+        }
+    }
+    return write_core(ctx, d_text, d_line_start, d_reads, d_quals, nullptr, nullptr, d_offsets, d_frag_src, d_chim, d_scan, d_bc, d_rank, n_out,
+                      first_read_id, cfg, d_passed, cap_passed, d_failed, cap_failed, d_rec_off, d_is_passed, totals, errors, stream);
+}
+
+// the same writer taking bases and qualities where the FASTQ text has them: d_base_start / d_qual_start from smi_frag_text_starts_device
+extern "C" int smi_fastq_write_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint64_t *d_base_start,
+                                           const uint64_t *d_qual_start, const uint64_t *d_offsets, const uint32_t *d_frag_src,
+                                           const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc,
+                                           const int32_t *d_rank, size_t n_out, uint32_t first_read_id, const smi_write_config *cfg,
+                                           uint8_t *d_passed, size_t cap_passed, uint8_t *d_failed, size_t cap_failed,
+                                           uint64_t *d_rec_off, uint8_t *d_is_passed, uint64_t *totals, uint32_t *errors, void *stream) {
+    if (n_out && (!d_base_start || !d_qual_start)) {
+        set_error("smi_fastq_write_text_device: null argument");
+        return SMI_ERR_INVALID;
+    }
+    return write_core(ctx, d_text, d_line_start, nullptr, nullptr, d_base_start, d_qual_start, d_offsets, d_frag_src, d_chim, d_scan, d_bc,
+                      d_rank, n_out, first_read_id, cfg, d_passed, cap_passed, d_failed, cap_failed, d_rec_off, d_is_passed, totals, errors,
+                      stream);
 }

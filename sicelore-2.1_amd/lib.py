@@ -54,6 +54,7 @@ EXPORTS = [
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
     "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
     "smi_genes_load_refflat", "smi_genes_free", "smi_genes_count", "smi_gene_tag_chunk", "smi_gene_tag_bam",
+    "smi_pack_reads_text_device", "smi_pack_ends_text_device", "smi_frag_text_starts_device", "smi_fastq_write_text_device",
 ]
 
 
@@ -122,6 +123,10 @@ def load_library():
     lib.smi_bam_index_records.argtypes = [vp, sz, ctypes.c_uint64, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint64)]
     lib.smi_fastq_write_device.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ctypes.c_uint32, vp, vp, sz, vp, sz,
                                            vp, vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32), vp]
+    lib.smi_fastq_write_text_device.argtypes = lib.smi_fastq_write_device.argtypes
+    lib.smi_pack_reads_text_device.argtypes = [vp, vp, vp, vp, sz, ctypes.c_uint64, vp, vp]
+    lib.smi_pack_ends_text_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
+    lib.smi_frag_text_starts_device.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
     lib.smi_chimera_default_config_5p.argtypes = [vp]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
@@ -620,15 +625,32 @@ class Context:
         self._check(self._lib.smi_fastq_gather_device(self._h, _ptr(d_text), _ptr(d_start), _ptr(d_offsets), int(n), _ptr(d_out),
                                                       _stream_ptr(stream)))
 
+    def pack_reads_text_device(self, d_text, d_seq_start, d_offsets, n, total_bases, d_planes, stream=None):
+        """K-PACKR reading the bases where the FASTQ text has them (no gathered copy)"""
+        self._check(self._lib.smi_pack_reads_text_device(self._h, _ptr(d_text), _ptr(d_seq_start), _ptr(d_offsets), int(n), int(total_bases),
+                                                         _ptr(d_planes), _stream_ptr(stream)))
+
+    def frag_text_starts_device(self, d_seq_start, d_qual_start, d_offsets, d_frag_offsets, d_frag_src, n_out, d_base_start, d_qual_out,
+                                stream=None):
+        self._check(self._lib.smi_frag_text_starts_device(self._h, _ptr(d_seq_start), _ptr(d_qual_start), _ptr(d_offsets), _ptr(d_frag_offsets),
+                                                          _ptr(d_frag_src), int(n_out), _ptr(d_base_start), _ptr(d_qual_out),
+                                                          _stream_ptr(stream)))
+
+    def pack_ends_text_device(self, d_text, d_base_start, d_offsets, n, d_ends, d_len, stream=None):
+        self._check(self._lib.smi_pack_ends_text_device(self._h, _ptr(d_text), _ptr(d_base_start), _ptr(d_offsets), int(n), _ptr(d_ends),
+                                                        _ptr(d_len), _stream_ptr(stream)))
+
     def fastq_write_device(self, d_text, d_line_start, d_reads, d_quals, d_offsets, d_frag_src, d_chim, d_scan, d_bc, d_rank,
                            n_out, first_read_id, d_passed, d_failed, d_rec_off, d_is_passed, five_prime=False,
-                           trim_fastq=False, stream=None):
-        """K-WRITE -> (bytes passed, bytes failed, records passed); raises SmiError with the SMI_WR_* bits"""
+                           trim_fastq=False, stream=None, in_text=False):
+        """K-WRITE -> (bytes passed, bytes failed, records passed); raises SmiError with the SMI_WR_* bits.
+        in_text: d_reads / d_quals are the int64 text positions of frag_text_starts_device (smi_fastq_write_text_device)"""
         cfg = (ctypes.c_int32 * 2)(int(bool(five_prime)), int(bool(trim_fastq)))
         totals = (ctypes.c_uint64 * 3)()
         err = ctypes.c_uint32(0)
         opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
-        rc = self._lib.smi_fastq_write_device(self._h, _ptr(d_text), _ptr(d_line_start), _ptr(d_reads), _ptr(d_quals),
+        fn = self._lib.smi_fastq_write_text_device if in_text else self._lib.smi_fastq_write_device
+        rc = fn(self._h, _ptr(d_text), _ptr(d_line_start), _ptr(d_reads), _ptr(d_quals),
                                               _ptr(d_offsets), opt(d_frag_src), opt(d_chim), _ptr(d_scan), _ptr(d_bc),
                                               opt(d_rank), int(n_out), int(first_read_id), ctypes.byref(cfg), _ptr(d_passed),
                                               int(d_passed.numel()), _ptr(d_failed), int(d_failed.numel()), _ptr(d_rec_off),

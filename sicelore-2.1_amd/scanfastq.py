@@ -105,7 +105,7 @@ class ReadScanner:
                 raise _lib.SmiError("chimera splitter: a read outside the supported range (SMI_CHIM_RANGE / SMI_CHIM_OVERFLOW)")
             offs = foffs[:n_out + 1].contiguous()
             fsrc = fsrc[:n_out].contiguous()
-        scan_d, win = self._scan(reads, quals, offs, n_out, pass_no=2)
+        scan_d, win = self._scan(reads, None, offs, n_out, pass_no=2)  # the quality filter belongs to pass 1 (UsedCellBCListGenerator L198-202)
         res_d = torch.zeros((max(n_out, 1), 4), dtype=torch.int32, device=self.dev)
         self.ctx.bc_match_device(win, res_d, n_out, max_ed=self.max_ed, five_prime=self.five_prime)
         return n_out, offs, d_chim, fsrc, scan_d, res_d

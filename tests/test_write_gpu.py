@@ -150,6 +150,24 @@ def test_large_batch_round_trip_properties(pkg, synth, gpu_ctx):
     bp, bf, n_p = gpu_ctx.fastq_write_device(text, line, reads, quals, offs[:n + 1], None, None, scan, bc, None, n, 1, out_p, out_f,
                                              rec_off, is_p)
     assert n_p == int(is_p.sum()) and 0.9 * n < n_p < n
+    # the in-place entry points (bases and qualities read where the text has them, no gathers) give the same planes, ends and streams
+    ends2, lens2 = torch.zeros_like(ends), z32(n)
+    bstart, qstart = z64(n), z64(n)
+    gpu_ctx.frag_text_starts_device(ss, qs, offs, None, None, n, bstart, qstart)
+    assert bool((bstart == ss[:n]).all()) and bool((qstart == qs[:n]).all())
+    gpu_ctx.pack_ends_text_device(text, bstart, offs[:n + 1], n, ends2, lens2)
+    assert bool((ends2 == ends).all()) and bool((lens2 == lens).all())
+    pw = gpu_ctx.read_planes_words(total, n)
+    pl1, pl2 = z32(pw), z32(pw)
+    gpu_ctx.pack_reads_device(reads, offs[:n + 1], n, total, pl1)
+    gpu_ctx.pack_reads_text_device(text, ss, offs[:n + 1], n, total, pl2)
+    assert bool((pl1 == pl2).all())
+    out_p2, out_f2 = torch.empty(capw, dtype=torch.uint8, device=dev), torch.empty(capw, dtype=torch.uint8, device=dev)
+    rec_off2, is_p2 = z64(n + 1), torch.zeros(n, dtype=torch.uint8, device=dev)
+    tot2 = gpu_ctx.fastq_write_device(text, line, bstart, qstart, offs[:n + 1], None, None, scan, bc, None, n, 1, out_p2, out_f2, rec_off2,
+                                      is_p2, in_text=True)
+    assert tot2 == (bp, bf, n_p) and bool((out_p2[:bp] == out_p[:bp]).all()) and bool((out_f2[:bf] == out_f[:bf]).all())
+    assert bool((rec_off2 == rec_off).all()) and bool((is_p2 == is_p).all())
     seq_total, hist_b, hist_q = 0, torch.zeros(256, dtype=torch.int64, device=dev), torch.zeros(256, dtype=torch.int64, device=dev)
     for buf, nbytes, want in ((out_p, bp, n_p), (out_f, bf, n - n_p)):
         k, e = gpu_ctx.fastq_index_device(buf, nbytes, line, ns, nl, ss, sl, qs, offs, cap)
