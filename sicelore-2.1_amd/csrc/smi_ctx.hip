@@ -204,6 +204,9 @@ int smi_ctx_destroy(smi_ctx *ctx) {
         if (ctx->kev[k][0]) (void)hipEventDestroy(ctx->kev[k][0]);
         if (ctx->kev[k][1]) (void)hipEventDestroy(ctx->kev[k][1]);
     }
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SMI_OK;

@@ -90,6 +90,8 @@ struct smi_ctx {
     void *stage_out = nullptr;
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
     hipStream_t stream = nullptr;  // private stream of the *_batch entry points
+    hipStream_t side_stream = nullptr;  // created on first use: independent kernels of one call run beside the caller's stream (K-WNAME || K-WRITE)
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     void *scan_tmp = nullptr;      // scratch of the FASTQ indexer (block counts + hipcub temp storage)
     size_t scan_tmp_bytes = 0;
     const smi_ctx *set_owner = nullptr;  // worker lane (smi_ctx_create_lane): the pyramid pointers above belong to this context

@@ -183,18 +183,47 @@ __global__ void k_write_idlen(const WriteArgs A, const uint64_t *__restrict__ or
 
 // K-WNAME (thread = record): the suffix goes straight to its place in the output stream -- serial per record, parallel
 // over records (inside K-WRITE the other 63 lanes of the record's wave would wait for it)
-__global__ void k_write_name(WriteArgs A, const uint64_t *__restrict__ off_passed, const uint64_t *__restrict__ off_failed,
-                             const uint64_t *__restrict__ ord_passed, const uint32_t *__restrict__ sfx_len,
-                             uint8_t *__restrict__ out_passed, size_t cap_passed, uint8_t *__restrict__ out_failed, size_t cap_failed) {
-    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (i >= A.n) return;
-    const RecPlan R = plan_record(A, i);
-    const int n_sfx = (int)(sfx_len[i] & 0x7FFFFFFFu);
-    const uint64_t pos = (R.passed ? off_passed[i] : off_failed[i]) + 1 + R.name_tok_len;
-    if (pos + n_sfx > (R.passed ? cap_passed : cap_failed)) return;  // K-WRITE reports the overflow
-    NameSink s{reinterpret_cast<char *>(R.passed ? out_passed : out_failed) + pos, 0, n_sfx};
-    bool quals_set = true;
-    format_record_suffix(A, R, i, A.first_read_id + (uint32_t)ord_passed[i], s, &quals_set);
+constexpr int kNameBlock = 128;   // threads (= records) per block of K-WNAME
+constexpr int kNameStage = 260;   // bytes of LDS per record: 65 words, so equal byte offsets of neighbouring records fall into different banks
+__global__ __launch_bounds__(kNameBlock) void k_write_name(WriteArgs A, const uint64_t *__restrict__ off_passed,
+                                                           const uint64_t *__restrict__ off_failed, const uint64_t *__restrict__ ord_passed,
+                                                           const uint32_t *__restrict__ sfx_len, uint8_t *__restrict__ out_passed,
+                                                           size_t cap_passed, uint8_t *__restrict__ out_failed, size_t cap_failed) {
+    // The formatter is serial per record and emits single bytes: into global memory that is one 1-byte transaction per lane and character.
+    // Every thread therefore formats into its own row of LDS, then each wave copies the rows of its 64 records out, a row at a time with
+    // lane = byte, so that a store instruction covers 64 consecutive bytes of the stream.
+    __shared__ char stage[kNameBlock][kNameStage];
+    __shared__ uint64_t dst[kNameBlock];
+    __shared__ int cnt[kNameBlock];
+    const int t = threadIdx.x;
+    const size_t i = blockIdx.x * (size_t)kNameBlock + t;
+    int n_copy = 0;
+    uint64_t d = 0;
+    if (i < A.n) {
+        const RecPlan R = plan_record(A, i);
+        const int n_sfx = (int)(sfx_len[i] & 0x7FFFFFFFu);
+        const uint64_t pos = (R.passed ? off_passed[i] : off_failed[i]) + 1 + R.name_tok_len;
+        if (pos + n_sfx <= (R.passed ? cap_passed : cap_failed)) {  // otherwise K-WRITE reports the overflow
+            char *out = reinterpret_cast<char *>(R.passed ? out_passed : out_failed) + pos;
+            const bool staged = n_sfx <= kNameStage;
+            NameSink s{staged ? stage[t] : out, 0, n_sfx};
+            bool quals_set = true;
+            format_record_suffix(A, R, i, A.first_read_id + (uint32_t)ord_passed[i], s, &quals_set);
+            if (staged) {
+                n_copy = n_sfx;
+                d = (uint64_t)(uintptr_t)out;
+            }
+        }
+    }
+    cnt[t] = n_copy;
+    dst[t] = d;
+    __syncthreads();
+    const int lane = t & 63, w0 = t & ~63;
+    for (int r = w0; r < w0 + 64; r++) {
+        const int n = cnt[r];
+        char *o = reinterpret_cast<char *>((uintptr_t)dst[r]);
+        for (int k = lane; k < n; k += 64) o[k] = stage[r][k];
+    }
 }
 
 // K-WRITE: one wave per record copies everything but the suffix.  Every output byte is ONE load from a computed address
@@ -384,11 +413,23 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp_bytes, lenp, offp, (int)(n_out + 1), s));
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp_bytes, lenf, offf, (int)(n_out + 1), s));
-    hipLaunchKernelGGL(k_write_name, dim3(g), dim3(256), 0, s, A, offp, offf, ordp, sfx, d_passed, cap_passed, d_failed, cap_failed);
+    // K-WNAME (serial per record, latency-bound) and K-WRITE (wave per record, bandwidth-bound) write disjoint bytes and only read what is
+    // finished by now: they run side by side, K-WNAME on the context's side stream
+    if (!ctx->side_stream) {
+        SMI_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        SMI_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        SMI_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+    }
+    SMI_HIP(hipEventRecord(ctx->side_fork, s));
+    SMI_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    hipLaunchKernelGGL(k_write_name, dim3((unsigned)((n_out + kNameBlock - 1) / kNameBlock)), dim3(kNameBlock), 0, ctx->side_stream, A, offp, offf, ordp, sfx, d_passed, cap_passed, d_failed,
+                       cap_failed);
     SMI_HIP(hipGetLastError());
+    SMI_HIP(hipEventRecord(ctx->side_join, ctx->side_stream));
     hipLaunchKernelGGL(k_write, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, A, offp, offf, sfx, d_passed, cap_passed,
                        d_failed, cap_failed, d_rec_off, d_err);
     SMI_HIP(hipGetLastError());
+    SMI_HIP(hipStreamWaitEvent(s, ctx->side_join, 0));
     uint64_t h[3];
     SMI_HIP(hipMemcpyAsync(&h[0], offp + n_out, 8, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&h[1], offf + n_out, 8, hipMemcpyDeviceToHost, s));
