@@ -67,14 +67,25 @@ int ensure_arena(smi_ctx *ctx, size_t bytes) {
     return SMI_OK;
 }
 
-size_t count_lines(const uint8_t *text, size_t n) {
-    size_t lines = 0;
-    const uint8_t *p = text, *end = text + n;
-    while ((p = static_cast<const uint8_t *>(std::memchr(p, '\n', (size_t)(end - p)))) != nullptr) {
-        lines++;
-        p++;
-    }
-    return lines + ((n && text[n - 1] != '\n') ? 1 : 0);
+// The chunk's text goes to the front of the arena first and its lines are counted THERE: the buffers behind it are sized by the record
+// count, and counting on the host (memchr over ~1.2 GB) took longer than the upload.  *d_text stays valid when the arena grows afterwards.
+int upload_and_count(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, hipStream_t s, size_t *n_lines) {
+    if (int rc = ensure_arena(ctx, pad(n_bytes) + 4096)) return rc;
+    SMI_HIP(hipMemcpyAsync(ctx->arena, text, n_bytes, hipMemcpyHostToDevice, s));
+    return launch_count_lines(ctx, static_cast<const uint8_t *>(ctx->arena), n_bytes, n_lines, s);
+}
+// grow the arena to `bytes`, keeping its first keep_bytes (the uploaded text)
+int grow_arena_keep(smi_ctx *ctx, size_t bytes, size_t keep_bytes, hipStream_t s) {
+    if (ctx->arena_bytes >= bytes) return SMI_OK;
+    const size_t want = bytes + bytes / 4;
+    void *fresh = nullptr;
+    SMI_HIP(hipMalloc(&fresh, want));
+    SMI_HIP(hipMemcpyAsync(fresh, ctx->arena, keep_bytes, hipMemcpyDeviceToDevice, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    SMI_HIP(hipFree(ctx->arena));
+    ctx->arena = fresh;
+    ctx->arena_bytes = want;
+    return SMI_OK;
 }
 
 #define SMI_RC(call)                 \
@@ -109,7 +120,9 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     hipStream_t s = ctx->stream;
     const bool five = cfg->five_prime != 0;
     const bool split = cfg->split_chimeras && !(five && cfg->dont_search_polya);  // Parser.java:L176
-    const size_t cap = count_lines(text, n_bytes) / 4 + 2;  // records
+    size_t n_lines = 0;
+    if (int rc = upload_and_count(ctx, text, n_bytes, s, &n_lines)) return rc;
+    const size_t cap = n_lines / 4 + 2;  // records
     // worst-case sizes before anything is known about the chunk: bases + qualities <= text, fragments <= 3 per record
     const size_t m_cap = split ? 3 * cap : cap;
     const size_t bases_cap = n_bytes;
@@ -121,14 +134,13 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
                   pad(m_cap * (size_t)SMI_END_BASES) + pad(m_cap * sizeof(smi_scan_result)) + pad(m_cap * sizeof(smi_bc_window)) +
                   pad(m_cap * sizeof(smi_bc_result)) + pad(m_cap * 4) + pad(cfg->n_ranks * 8) + pad(cfg->n_ranks * 4) +
                   2 * pad(out_cap) + pad((m_cap + 1) * 8) + pad(m_cap) + 4096;
-    SMI_RC(ensure_arena(ctx, need));
+    SMI_RC(grow_arena_keep(ctx, need, n_bytes, s));
     Arena A(ctx);
-    uint8_t *d_text = A.take<uint8_t>(n_bytes);
+    uint8_t *d_text = A.take<uint8_t>(n_bytes);  // already there
     uint64_t *d_line = A.take<uint64_t>(4 * cap + 8);
     uint64_t *d_ns = A.take<uint64_t>(cap), *d_ss = A.take<uint64_t>(cap), *d_qs = A.take<uint64_t>(cap);
     uint64_t *d_offs = A.take<uint64_t>(cap + 1);
     uint32_t *d_nl = A.take<uint32_t>(cap), *d_sl = A.take<uint32_t>(cap);
-    SMI_HIP(hipMemcpyAsync(d_text, text, n_bytes, hipMemcpyHostToDevice, s));
     size_t n = 0;
     uint32_t fq_err = 0;
     SMI_RC(smi_fastq_index_device(ctx, d_text, n_bytes, d_line, 4 * cap + 8, d_ns, d_nl, d_ss, d_sl, d_qs, d_offs, cap, &n, &fq_err, s));
@@ -248,18 +260,19 @@ extern "C" int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size
     if (n_bytes == 0) return SMI_OK;
     SMI_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
-    const size_t cap = count_lines(text, n_bytes) / 4 + 2;
+    size_t n_lines = 0;
+    if (int rc = upload_and_count(ctx, text, n_bytes, s, &n_lines)) return rc;
+    const size_t cap = n_lines / 4 + 2;
     const size_t need = pad(n_bytes) + pad((4 * cap + 8) * 8) + 4 * pad(cap * 8) + pad((cap + 1) * 8) + 2 * pad(cap * 4) +
                         2 * pad(n_bytes) + pad((size_t)SMI_ENDS_ROWS * 2 * cap * 4) + 2 * pad(cap * 4) + pad(cap * (size_t)SMI_END_BASES) +
                         pad(cap * sizeof(smi_scan_result)) + pad(cap * sizeof(smi_bc_window)) + 4096;
-    SMI_RC(ensure_arena(ctx, need));
+    SMI_RC(grow_arena_keep(ctx, need, n_bytes, s));
     Arena A(ctx);
-    uint8_t *d_text = A.take<uint8_t>(n_bytes);
+    uint8_t *d_text = A.take<uint8_t>(n_bytes);  // already there
     uint64_t *d_line = A.take<uint64_t>(4 * cap + 8);
     uint64_t *d_ns = A.take<uint64_t>(cap), *d_ss = A.take<uint64_t>(cap), *d_qs = A.take<uint64_t>(cap);
     uint64_t *d_offs = A.take<uint64_t>(cap + 1);
     uint32_t *d_nl = A.take<uint32_t>(cap), *d_sl = A.take<uint32_t>(cap);
-    SMI_HIP(hipMemcpyAsync(d_text, text, n_bytes, hipMemcpyHostToDevice, s));
     size_t n = 0;
     uint32_t fq_err = 0;
     SMI_RC(smi_fastq_index_device(ctx, d_text, n_bytes, d_line, 4 * cap + 8, d_ns, d_nl, d_ss, d_sl, d_qs, d_offs, cap, &n, &fq_err, s));
