@@ -230,19 +230,13 @@ def two_pass_leg(pkg, synth, dev, dist, rank, world, wl, used, n, max_ed=1):
     text = text_d.cpu().numpy().tobytes()
     del rd, text_d, _buf
     ctx2.set_barcode_set(keys, mode=1)
-    rs = scanfastq.ReadScanner(ctx2, max_ed=max_ed)
     hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    chunk_reads = 0
-    # pass 1 in 10,000-read chunks as FastqFileReader cuts them (the chunk count is the reference's recordCount)
-    lines = text.split(b"\n")
-    n_chunks = 0
-    per = 4 * 50_000
-    for a in range(0, len(lines) - 1, per):
-        part = b"\n".join(lines[a:a + per]) + b"\n"
-        chunk_reads += rs.pass1_chunk(part, hist)
-        n_chunks += (min(per, len(lines) - 1 - a) // 4 + 9_999) // 10_000
+    # pass 1 through the native chunk worker (host text in, histogram increment on the device); the reference's recordCount is the
+    # number of 10,000-read chunks FastqFileReader cuts
+    chunk_reads = ctx2.scanfastq_pass1_chunk(text, hist)
+    n_chunks = (chunk_reads + 9_999) // 10_000
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     k, c, r = distributed.pass1_finalize(hist, keys, record_count=n_chunks)          # all-reduce (RCCL) + finalize + broadcast
@@ -281,7 +275,7 @@ def two_pass_leg(pkg, synth, dev, dist, rank, world, wl, used, n, max_ed=1):
            "same_used_list_on_all_ranks": same, "pass2_ms": (t4 - t3) * 1e3, "pass2_records_out": int(info["n_records_out"]),
            "pass2_passed": int(info["n_passed"]), "pass2_assigned": int(ok.sum()), "assigned_tsv_rows": len(rows) - 1,
            "assigned_tsv_total": sum(int(x.split("\t")[1].replace(",", "")) for x in rows[1:]),
-           "note": "pass 1 through the chained entry points, pass 2 through smi_scanfastq_pass2_chunk (host text in, text out, chimera "
+           "note": "pass 1 through smi_scanfastq_pass1_chunk, pass 2 through smi_scanfastq_pass2_chunk (host text in, text out, chimera "
                    "splitter on); the BarcodesAssigned counters are summed over the ranks before the file is formatted"}
     ctx2.close()
     return out

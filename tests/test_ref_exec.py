@@ -381,3 +381,56 @@ def test_gene_tags_equal_reference_bytecode(pkg):
     assert sum(e[0] is None and e[2] in ("UTR", "CODING") for e in exp) >= 10
     assert sum("throws" in c for c in cases) == xf.count(None)
     assert {c["throws"] for c in cases if "throws" in c} == {"java/lang/NullPointerException"}
+
+
+# ---- a-13: end of pass 1 (UsedBarcodesListData.finalizeData + BarcodeDatasetColissionTester) --------------------------------------
+def _finalize_cases():
+    sec = load("finalize")["sections"][0]
+    assert sec["parameters"] == {"mergeBCsEdit": 1, "minCountFold": 10, "cellsWithReadsnFoldBelowMaxToKeep": 500}
+    assert all(c["hash_orders_agree"] and "throws" not in c for c in sec["cases"])  # no case had to be dropped
+    return sec["cases"]
+
+
+def test_finalize_oracle_equals_reference_bytecode(sor):
+    for c in _finalize_cases():
+        keys = np.array(c["keys"], dtype=np.uint64)
+        cnt = np.array([x[1] for x in c["barcodes"]], dtype=np.uint32)
+        o = np.argsort(keys)
+        k, cc, r = sor.finalize_used_list(keys[o], cnt[o], c["record_count"], 1, 10, 500)
+        assert sorted([int(a), int(b)] for a, b in zip(k, cc)) == c["final"]
+        assert len(c["final"]) < len(c["keys"])  # something was filtered or merged in every case
+        # rank order = count descending; where the reference's own order does not depend on a hash order it is the TSV order
+        if c["tsv_order_agrees"] and c["with_whitelist"]:
+            assert [int(x) for x in cc] == [row[1] for row in c["tsv"]]
+
+
+def test_finalize_product_and_barcode_list_equal_reference_bytecode(pkg, sor):
+    from sicelore_amd import lib as libmod
+
+    dec = lambda k: sor.decode(int(k), 16)  # noqa: E731
+    n_dropped_rows = 0
+    for c in _finalize_cases():
+        keys = np.array(c["keys"], dtype=np.uint64)
+        cnt = np.array([x[1] for x in c["barcodes"]], dtype=np.uint32)
+        nz = np.argsort(keys)
+        k, cc, r = libmod.finalize_used_list(keys[nz], cnt[nz], c["record_count"], 1, 10, 500)
+        assert sorted([int(a), int(b)] for a, b in zip(k, cc)) == c["final"]
+        text = libmod.barcode_list_tsv(keys[nz], cnt[nz], c["record_count"], merge_ed=1, no_whitelist=not c["with_whitelist"])
+        rows = [ln.split("\t") for ln in text.splitlines()[1:]]
+        got = [[row[0], int(row[1])] for row in rows]
+        assert sorted(got) == sorted(c["tsv"])                     # usedBarcodesForTSV: the rows and their counts
+        if c["tsv_order_agrees"]:
+            assert got == c["tsv"]
+        n_dropped_rows += len(c["final"]) - len(c["tsv"])
+        # the collision columns: per used barcode the barcodes its BarcodeMatchTester reported, by edit distance
+        coll = {int(ed): {int(b): set(m) for b, m in per} for ed, per in c["collisions"].items()}
+        header = text.splitlines()[0].split("\t")
+        eds = [int(h.rsplit(" ", 1)[1]) for h in header[2:] if h]
+        assert eds == sorted(coll)
+        for row in rows:
+            key = sor.encode(row[0])
+            for col, ed in enumerate(eds):
+                cell = row[2 + col] if len(row) > 2 + col else ""
+                names = {x.split("(")[0] for x in cell.split(",") if x}
+                assert names == {dec(m) for m in coll[ed].get(key, set())}
+    assert n_dropped_rows > 0  # AAAAA / TTTTT rows left out when no list of possible barcodes was given

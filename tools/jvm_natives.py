@@ -909,11 +909,10 @@ def install_streams(jvm):
         """groupingBy(classifier[, downstream]) -> java.util.HashMap: lists in encounter order; the map's own iteration order is
         as for every hash container here (varied, not emulated)"""
         down = rest[-1] if rest else None
-        if len(rest) == 2:
-            raise Unsupported("groupingBy with a map factory")
+        factory = rest[0] if len(rest) == 2 else None   # groupingBy(classifier, mapFactory, downstream)
 
         def run(j_, items):
-            m = j_.natives["java/util/HashMap.<new>"](j_)
+            m = call_fn(j_, factory) if factory is not None else j_.natives["java/util/HashMap.<new>"](j_)
             for v in items:
                 k = call_fn(j_, keyf, v)
                 cell = m.native.find(k)
@@ -957,6 +956,27 @@ def install_streams(jvm):
 
         return collector(run)
 
+    def to_collection(j, sup):
+        def run(j_, items):
+            c = call_fn(j_, sup)
+            for v in items:
+                j_.call_virtual(c, "add", "(Ljava/lang/Object;)Z", v)
+            return c
+
+        return collector(run)
+
+    N["java/util/stream/Collectors.toCollection"] = to_collection
+
+    def to_set(j):
+        def run(j_, items):
+            c = j_.natives["java/util/HashSet.<new>"](j_)
+            for v in items:
+                c.native.put(v, True)
+            return c
+
+        return collector(run)
+
+    N["java/util/stream/Collectors.toSet"] = to_set
     N["java/util/stream/Collectors.toMap"] = to_map
     N["java/util/stream/Collectors.groupingBy"] = grouping_by
     N["java/util/stream/Collectors.mapping"] = mapping
@@ -1282,6 +1302,19 @@ def install_hash(jvm):
         return None
 
     N["java/util/HashMap.putIfAbsent"] = put_if_absent
+
+    # java.util.LinkedHashMap: the same keyed store, iterated in insertion order (specified, tier C)
+    class LinkedStore(HashStore):
+        def cells_for_iteration(self, what, cls):
+            return list(self.order)
+
+    def linked_new(j):
+        o = JObject("java/util/LinkedHashMap")
+        o.native = LinkedStore(j)
+        return o
+
+    N["java/util/LinkedHashMap.<new>"] = linked_new
+    N["java/util/LinkedHashMap.<init>"] = lambda j, o, *a: None
     # java.util.TreeMap used as a lookup table only (put / get / containsKey / size): same keyed store, iteration refused; get(null)
     # throws as a TreeMap with natural ordering does
     N["java/util/TreeMap.<new>"] = new("java/util/TreeMap")
@@ -1310,6 +1343,7 @@ def install_hash(jvm):
     jdk_super.update({"java/util/HashSet": "java/util/AbstractSet", "java/util/AbstractSet": "java/util/AbstractCollection",
                       "java/util/HashMap": "java/util/AbstractMap", "java/util/AbstractMap": "java/lang/Object"})
     jdk_ifaces["java/util/AbstractMap$SimpleEntry"] = ["java/util/Map$Entry"]
+    jdk_super["java/util/LinkedHashMap"] = "java/util/HashMap"
     jdk_super["java/util/TreeMap"] = "java/util/AbstractMap"
     jdk_ifaces["java/util/TreeMap"] = ["java/util/NavigableMap", "java/util/SortedMap", "java/util/Map"]
     jdk_super["java/util/concurrent/ConcurrentHashMap"] = "java/util/AbstractMap"

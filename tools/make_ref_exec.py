@@ -1025,7 +1025,246 @@ def gen_gene(g, n_rows=1500, n_reads=420, seed=1212):
     return out
 
 
-SECTIONS = {"gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+UBLD = "com/rw/nanoporereadscanner/analyzers/UsedCellBCListGenerator$UsedBarcodesListData"
+BDCT = "com/rw/nanoporereadscanner/analyzers/BarcodeDatasetColissionTester"
+L2OM = "it/unimi/dsi/fastutil/longs/Long2ObjectMap"
+L2OE = "it/unimi/dsi/fastutil/longs/Long2ObjectMap$Entry"
+LSET = "it/unimi/dsi/fastutil/longs/LongOpenHashSet"
+LES = "com/google/common/util/concurrent/ListeningExecutorService"
+
+
+def install_long2object_iterable(j):
+    """the absent fastutil Long2ObjectOpenHashMap as a keyed store that can ALSO be iterated -- in the varied orders of jvm.hash_order,
+    never in fastutil's own (the jar is missing): a case is kept only when every order gives the same answer"""
+    import jvm_exec
+    from jvm_natives import HashStore
+
+    N = j.natives
+
+    def st(o):
+        if o.native is None or isinstance(o.native, dict):
+            o.native = HashStore(j)
+        return o.native
+
+    box = lambda k: JBox("java/lang/Long", k)  # noqa: E731
+
+    def new_map(jj):
+        o = JObject(L2O)
+        o.native = HashStore(jj)
+        return o
+
+    def alist(items):
+        lst = JObject("java/util/ArrayList")
+        lst.native = list(items)
+        return lst
+
+    def entry(k, v):
+        e = JObject(L2OE)
+        e.native = [k, v]
+        return e
+
+    def cells(o, what):
+        return st(o).cells_for_iteration(what, L2O)
+
+    def key_set(jj, o):
+        ks = JObject(LSET)
+        ks.native = o          # live view
+        return ks
+
+    for c in (L2O, L2OM):
+        N[c + ".<new>"] = new_map
+        N[c + ".<init>"] = lambda jj, o, *a: None if st(o) is None else None
+        N[c + ".put:(JLjava/lang/Object;)Ljava/lang/Object;"] = lambda jj, o, k, v: st(o).put(box(k), v)[0]
+        N[c + ".get:(J)Ljava/lang/Object;"] = lambda jj, o, k: (st(o).find(box(k)) or [None, None])[1]
+        N[c + ".containsKey:(J)Z"] = lambda jj, o, k: 1 if st(o).find(box(k)) is not None else 0
+        N[c + ".remove:(J)Ljava/lang/Object;"] = lambda jj, o, k: (st(o).remove(box(k)) or [None, None])[1]
+        N[c + ".size"] = lambda jj, o: len(st(o))
+        N[c + ".isEmpty"] = lambda jj, o: 0 if len(st(o)) else 1
+        N[c + ".values"] = lambda jj, o: alist(cl[1] for cl in cells(o, "values"))
+        N[c + ".long2ObjectEntrySet"] = lambda jj, o: alist(entry(cl[0], cl[1]) for cl in cells(o, "long2ObjectEntrySet"))
+        N[c + ".keySet"] = key_set
+    N[LSET + ".contains:(J)Z"] = lambda jj, ks, k: 1 if st(ks.native).find(box(k)) is not None else 0
+    N[LSET + ".contains:(Ljava/lang/Object;)Z"] = lambda jj, ks, k: 1 if st(ks.native).find(k) is not None else 0
+    N[LSET + ".stream"] = lambda jj, ks: jj.natives["java/util/ArrayList.stream"](jj, alist(cl[0] for cl in cells(ks.native, "keySet().stream")))
+    N[LSET + ".size"] = lambda jj, ks: len(st(ks.native))
+    N[L2OE + ".getLongKey"] = lambda jj, e: e.native[0].v
+    N[L2OE + ".getKey"] = lambda jj, e: e.native[0]
+    N[L2OE + ".getValue"] = lambda jj, e: e.native[1]
+    N["it/unimi/dsi/fastutil/longs/Long2ObjectMaps.synchronize"] = lambda jj, m, *a: m
+    jvm_exec.JDK_SUPER[L2O] = "java/lang/Object"
+    jvm_exec.JDK_IFACES[L2O] = [L2OM, "java/util/Map"]
+    jvm_exec.JDK_IFACES[L2OE] = ["java/util/Map$Entry"]
+    jvm_exec.JDK_IFACES[LSET] = ["java/util/Set", "it/unimi/dsi/fastutil/longs/LongSet", "java/util/Collection"]
+
+
+def install_sync_executor(j):
+    """the thread pool of BarcodeDatasetColissionTester run on one thread: submit() calls the Callable at once, Futures.addCallback()
+    queues the callback, CountDownLatch.await() runs the queued callbacks (each of which submits the next barcode, L212-227, L240-243)
+    until the latch is released.  Submission order = the order of the reference's own deque."""
+    N, H = j.natives, j.hooks
+    pending = []
+    N["java/util/concurrent/Executors.newWorkStealingPool"] = lambda jj, *a: JObject("$Pool")
+    H["com/google/common/util/concurrent/MoreExecutors.<clinit>:()V"] = None
+    H["com/google/common/util/concurrent/Futures.<clinit>:()V"] = None
+    H["com/google/common/util/concurrent/MoreExecutors.listeningDecorator:(Ljava/util/concurrent/ExecutorService;)L" + LES + ";"] = \
+        lambda jj, p: JObject("$ListeningPool")
+    H["com/google/common/util/concurrent/MoreExecutors.directExecutor:()Ljava/util/concurrent/Executor;"] = lambda jj: None
+
+    def submit(jj, pool, callable_):
+        fut = JObject("$DoneFuture")
+        try:
+            fut.native = ("ok", jj.call_virtual(callable_, "call", "()Ljava/lang/Object;"))
+        except JavaThrow as e:
+            fut.native = ("err", e.obj)
+        return fut
+
+    N["$ListeningPool.submit"] = submit
+    N["$ListeningPool.shutdown"] = lambda jj, p: None
+    H["com/google/common/util/concurrent/Futures.addCallback:(Lcom/google/common/util/concurrent/ListenableFuture;"
+      "Lcom/google/common/util/concurrent/FutureCallback;Ljava/util/concurrent/Executor;)V"] = lambda jj, fut, cb, ex: pending.append((fut, cb))
+
+    def latch_new(jj):
+        o = JObject("java/util/concurrent/CountDownLatch")
+        o.native = [1]
+        return o
+
+    def run_one(jj):
+        fut, cb = pending.pop(0)
+        if fut.native[0] == "ok":
+            jj.call_virtual(cb, "onSuccess", "(Ljava/lang/Object;)V", fut.native[1])
+        else:
+            jj.call_virtual(cb, "onFailure", "(Ljava/lang/Throwable;)V", fut.native[1])
+
+    def latch_await(jj, o, *a):
+        while o.native[0] > 0:
+            if not pending:
+                raise Unsupported("CountDownLatch.await with nothing left to run")
+            run_one(jj)
+
+    def await_termination(jj, p, *a):
+        # the latch opens when the first worker finds the deque empty; the tasks still in flight finish (callbacks included, they run on the
+        # workers: directExecutor) before awaitTermination returns (L97-98)
+        while pending:
+            run_one(jj)
+        return 1
+
+    N["$ListeningPool.awaitTermination"] = await_termination
+
+    N["java/util/concurrent/CountDownLatch.<new>"] = latch_new
+    N["java/util/concurrent/CountDownLatch.<init>"] = lambda jj, o, n: o.native.__setitem__(0, n)
+    N["java/util/concurrent/CountDownLatch.await"] = latch_await
+    N["java/util/concurrent/CountDownLatch.countDown"] = lambda jj, o: o.native.__setitem__(0, max(0, o.native[0] - 1))
+    for k in list(N):
+        if k.startswith("java/util/ArrayDeque."):
+            N["java/util/concurrent/ConcurrentLinkedDeque" + k[len("java/util/ArrayDeque"):]] = N[k]
+    N["java/util/concurrent/ConcurrentLinkedDeque.remove:()Ljava/lang/Object;"] = N["java/util/ArrayDeque.removeFirst"]
+
+    def cld_new(jj):
+        o = JObject("java/util/concurrent/ConcurrentLinkedDeque")
+        o.native = []
+        return o
+
+    N["java/util/concurrent/ConcurrentLinkedDeque.<new>"] = cld_new
+    N["java/util/concurrent/TimeUnit.MINUTES"] = lambda jj: JObject("java/util/concurrent/TimeUnit")
+    import jvm_exec
+
+    jvm_exec.JDK_IFACES["$ListeningPool"] = [LES, "java/util/concurrent/ExecutorService"]
+    jvm_exec.JDK_IFACES["java/util/concurrent/ConcurrentLinkedDeque"] = ["java/util/Deque", "java/util/Queue", "java/util/Collection"]
+
+
+def gen_finalize(g, n_sets=14, seed=1313):
+    """a-13: the end of pass 1"""
+    import ref_params
+
+    j = g.j
+    rng = random.Random(seed)
+    install_long2object_iterable(j)
+    install_sync_executor(j)
+    par, _report = ref_params.load_config(j, PAR)
+    rs = par.f["readScannerParameters"]
+    # what ReadScannerParameters.validate_readScannerParameters L236-238 does with the shipped config (<mergeBCsED>null) and -e 1
+    rs.f["assignCellBCwithEditDistance"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JBox("java/lang/Integer", 1))
+    rs.f["mergeBCsEdit"] = JBox("java/lang/Integer", 1)
+    par.f["general"].f["nCPU"] = JBox("java/lang/Integer", 4)   # -t: only sizes the pool and the first wave of submissions (L72, L87)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("new UsedBarcodesListData(params); unfilteredUsedBarcodeMap := {barcode -> AtomicInteger(count)}; recordCount := n; "
+                  "finalizeData() (UsedCellBCListGenerator.java:L379-425): low-count filter (L359-363), BarcodeDatasetColissionTester "
+                  "(L68-229: one BarcodeMatchTester per barcode in collision mode, merge of the colliding barcodes, low-depth cut), and the "
+                  "printable list.  Outputs: finalColissionFilteredData as {barcode: count}, usedBarcodesForTSV as the ordered list it is. "
+                  "The fastutil map is a keyed store iterated in three different orders per case (`hash_orders_agree`); the thread pool "
+                  "runs on one thread", UBLD, "finalizeData:()V")
+    s["parameters"] = {"mergeBCsEdit": rs.f["mergeBCsEdit"].v if rs.f.get("mergeBCsEdit") is not None else None,
+                       "minCountFold": rs.f["minCountFold"].v, "cellsWithReadsnFoldBelowMaxToKeep": rs.f["cellsWithReadsnFoldBelowMaxToKeep"].v}
+    enc = lambda q: j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q))  # noqa: E731
+    for idx in range(n_sets):
+        n_cells = rng.randrange(6, 22)
+        cells = [rnd_seq(rng, 16) for _ in range(n_cells)]
+        counts = {}
+        big = rng.randrange(400, 4000)
+        for c in cells:
+            counts[c] = max(2, int(big * rng.random() ** 2) + rng.randrange(2, 12))
+        # sequencing-error children of some cells (ed 1: substitution, insertion, deletion), a few unrelated low-count barcodes,
+        # homopolymer barcodes (dropped from the TSV when no whitelist is given)
+        for c in cells[:max(2, n_cells // 2)]:
+            for _ in range(rng.randrange(1, 4)):
+                kind = rng.randrange(3)
+                p_ = rng.randrange(16)
+                if kind == 0:
+                    m = c[:p_] + rng.choice([b for b in "ACGT" if b != c[p_]]) + c[p_ + 1:]
+                elif kind == 1:
+                    m = (c[:p_] + rng.choice("ACGT") + c[p_:])[:16]
+                else:
+                    m = (c[:p_] + c[p_ + 1:] + rng.choice("ACGT"))[:16]
+                if m not in counts:
+                    counts[m] = rng.randrange(1, max(3, counts[c] // rng.randrange(3, 40)))
+        for _ in range(rng.randrange(2, 8)):
+            counts.setdefault(rnd_seq(rng, 16), rng.randrange(1, 6))
+        if idx % 3 == 0:
+            counts.setdefault("AAAAAAC" + rnd_seq(rng, 9), rng.randrange(20, 200))
+        record_count = rng.choice([1, 40, 2500, 12000, 60000])
+        items = list(counts.items())
+        results = []
+        # a list of possible barcodes was given (the TSV keeps every row) or not (rows with AAAAA / TTTTT are dropped, L418-420)
+        with_whitelist = idx % 2 == 0
+        rs.f["tenXbarcodeWhiteList"] = (j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JObject("java/lang/Object")) if with_whitelist
+                                        else j.call_static(GOPT, "absent", f"()L{GOPT};"))
+        for order in ("insertion", "reverse", ("shuffle", idx + 1)):
+            j.hash_order = order
+            ud = j.new(UBLD, f"(L{PAR};)V", par)
+            m = ud.f["unfilteredUsedBarcodeMap"]
+            for q, c in items:
+                ai = j.natives["java/util/concurrent/atomic/AtomicInteger.<new>"](j)
+                j.natives["java/util/concurrent/atomic/AtomicInteger.<init>"](j, ai, c)
+                m.native.put(JBox("java/lang/Long", enc(q)), ai)
+            rc = ud.f["recordCount"]
+            j.natives["java/util/concurrent/atomic/AtomicInteger.set"](j, rc, record_count)
+            try:
+                j.invoke(j.find_method(UBLD, "finalizeData", "()V"), [ud])
+                fin = ud.f["finalColissionFilteredData"]
+                final = sorted([u64(k.v), v.v] for k, v in fin.native.items_in_insertion_order())
+                tsv = ud.f["usedBarcodesForTSV"]
+                tsv_rows = [[k, v.v] for k, v in tsv.native] if isinstance(tsv.native, list) else [[k, v.v] for k, v in tsv.native.items_in_insertion_order()]
+                info = ud.f["infoOnCollidingBarcodesInUsedBCs"]   # TreeMap<ed, Map<barcode, List<colliding barcode>>> (L133)
+                coll = {}
+                for ed_box, per_bc in info.native.items_in_insertion_order():
+                    coll[str(ed_box.v)] = sorted([u64(k.v), sorted(u64(x.v) for x in lst.native)] for k, lst in per_bc.native.items_in_insertion_order())
+                results.append({"final": final, "tsv": tsv_rows, "collisions": coll})
+            except JavaThrow as e:
+                results.append({"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:6]})
+        j.hash_order = None
+        agree_final = all(r.get("final") == results[0].get("final") and r.get("throws") == results[0].get("throws") for r in results[1:])
+        agree_final = agree_final and all(r.get("collisions") == results[0].get("collisions") for r in results[1:])
+        agree_tsv = all(r.get("tsv") == results[0].get("tsv") for r in results[1:])
+        s["cases"].append({"barcodes": [[q, c] for q, c in items], "keys": [u64(enc(q)) for q, _ in items], "record_count": record_count, "with_whitelist": with_whitelist,
+                           "hash_orders_agree": agree_final, "tsv_order_agrees": agree_tsv, **results[0],
+                           **({} if agree_final else {"other_orders": results[1:]})})
+        print(f"  finalize {idx + 1}/{n_sets}  {time.time() - g.t0:.0f}s  agree={agree_final}/{agree_tsv}", flush=True)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
