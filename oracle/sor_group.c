@@ -44,10 +44,23 @@ static int cl_center(cl_t *c, const rec_t *d) { /* getCenter / setCenter L491,L6
     return c->center;
 }
 
-/* removeOffCenterLeft (side = -1) / Right (side = +1): moved members form a new cluster sorted by position */
+/* removeOffCenterLeft (side = -1) / Right (side = +1) = Cluster.removeOffCenter (lambda$new$5, L626-638): moved members form a new
+ * cluster sorted by position.  The centre is a cached field, and the reference (a) COUNTS the off-centre members with whatever centre is
+ * cached (possibly stale: a removal does not clear it), (b) only if that count is > 0 clears the cache, so that the filter pass that
+ * picks the members to move recomputes the centre from the list as it is now, and (c) leaves that value cached after the members have
+ * left.  Returns 1 when the reference creates a cluster (which may be empty when (a) and (b) disagree). */
 static int cl_split(cl_t *c, const rec_t *d, int side, int dist, cl_t *out) {
-    const int center = cl_center(c, d);
     memset(out, 0, sizeof(*out));
+    if (c->n == 0) return 0;
+    int center = cl_center(c, d);
+    int cnt = 0;
+    for (int i = 0; i < c->n; i++) {
+        const int p = d[c->m[i]].pos;
+        if (side < 0 ? p < center - dist : p > center + dist) cnt++;
+    }
+    if (cnt == 0) return 0;
+    c->has_center = 0; /* L633 */
+    center = cl_center(c, d);
     int k = 0;
     for (int i = 0; i < c->n; i++) {
         const int p = d[c->m[i]].pos;
@@ -56,9 +69,8 @@ static int cl_split(cl_t *c, const rec_t *d, int side, int dist, cl_t *out) {
         else
             c->m[k++] = c->m[i];
     }
-    if (out->n == 0) return 0;
-    c->n = k;
-    c->has_center = 0;
+    c->n = k; /* the centre stays cached at the value computed before the members left */
+    if (c->n == 0) c->has_center = 0; /* setCenter on an empty list leaves null; empty clusters are dropped before any use */
     for (int i = 1; i < out->n; i++) { /* stable insertion sort by position */
         int v = out->m[i], j = i - 1;
         while (j >= 0 && d[out->m[j]].pos > d[v].pos) {

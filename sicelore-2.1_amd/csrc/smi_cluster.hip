@@ -418,7 +418,7 @@ struct Region {
     std::vector<const Rec *> reads;
     bool cached = false;
     int center_value = 0;
-    int center() {  // Math.round((float) mean), cached until the membership changes
+    int center() {  // Math.round((float) mean) in a cached field: cleared by add / addAll / removeAll, NOT by removeOffCenter (see split_off)
         if (!cached && !reads.empty()) {
             double s = 0;
             for (const Rec *r : reads) s += r->pos;
@@ -427,15 +427,25 @@ struct Region {
         }
         return center_value;
     }
-    // members for which `off` holds leave and form a new region, ordered by position
-    template <typename F>
-    bool split_off(F off, Region &out) {
+    // Cluster.removeOffCenter (ReadGrouper$Cluster.lambda$new$5, L626-638) with side = -1 (left of centre - dist) or +1 (right of centre +
+    // dist).  The reference keeps the centre in a field that a removal does not clear, and works in two passes: it COUNTS the off-centre
+    // members against the cached centre (possibly the one from before an earlier removal); only when that count is positive it clears the
+    // field, so the pass that picks the members to move sees the centre of the list as it is now; the members then leave and the field
+    // keeps that value.  Returns true when the reference creates a new cluster -- which is empty when the two passes disagree.
+    bool split_off(int side, int dist, Region &out) {
         out = Region();
+        if (reads.empty()) return false;
+        auto off = [&](const Rec *r, int c) { return side < 0 ? r->pos < c - dist : r->pos > c + dist; };
+        const int counted_with = center();
+        size_t n_off = 0;
+        for (const Rec *r : reads) n_off += off(r, counted_with);
+        if (n_off == 0) return false;
+        cached = false;  // L633
+        const int c = center();
         std::vector<const Rec *> stay;
-        for (const Rec *r : reads) (off(r) ? out.reads : stay).push_back(r);
-        if (out.reads.empty()) return false;
-        reads.swap(stay);
-        cached = false;
+        for (const Rec *r : reads) (off(r, c) ? out.reads : stay).push_back(r);
+        reads.swap(stay);  // `cached` stays true: the field is not cleared when the members leave
+        if (reads.empty()) cached = false;
         std::stable_sort(out.reads.begin(), out.reads.end(), [](const Rec *a, const Rec *b) { return a->pos < b->pos; });
         return true;
     }
@@ -456,10 +466,8 @@ void refine_regions(std::vector<Region> &v, int dist) {
     while (from < to) {
         for (size_t i = from; i < to; i++) {
             Region out;
-            int c = v[i].center();
-            if (v[i].split_off([&](const Rec *r) { return r->pos < c - dist; }, out)) v.push_back(out);
-            c = v[i].center();
-            if (v[i].split_off([&](const Rec *r) { return r->pos > c + dist; }, out)) v.push_back(out);
+            if (v[i].split_off(-1, dist, out)) v.push_back(out);
+            if (v[i].split_off(+1, dist, out)) v.push_back(out);
         }
         from = to;
         to = v.size();

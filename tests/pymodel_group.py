@@ -29,10 +29,14 @@ class Cluster:
         return self.center
 
     def remove_off_center(self, pred):
-        out = [r for r in self.list if pred(r)]
-        if not out:
+        """lambda$new$5 L626-638, statement by statement: count with the predicate (the centre field may still hold the value from before an
+        earlier removal), clear the field only when something was counted, filter again (the predicate now recomputes the centre from the
+        list as it is), remove the members -- which does not touch the field"""
+        n_removed = sum(1 for r in self.list if pred(r))
+        if n_removed <= 0:
             return None
         self.center = None
+        out = [r for r in self.list if pred(r)]
         for r in out:
             self.list.remove(r)
         return Cluster(out)

@@ -434,3 +434,36 @@ def test_finalize_product_and_barcode_list_equal_reference_bytecode(pkg, sor):
                 names = {x.split("(")[0] for x in cell.split(",") if x}
                 assert names == {dec(m) for m in coll[ed].get(key, set())}
     assert n_dropped_rows > 0  # AAAAA / TTTTT rows left out when no list of possible barcodes was given
+
+
+# ---- a-18: genomic-region grouping (ReadGrouper.groupSams) ------------------------------------------------------------------------
+def _group_cases():
+    sec = load("group")["sections"][0]
+    cases = [c for c in sec["cases"] if c["reads"]]
+    assert all("throws" not in c for c in cases) and len(cases) > 90
+    assert all(c["returned_null"] and c.get("region") == [] for c in sec["cases"] if not c["reads"])  # empty chunk: groupSams returns null
+    return cases
+
+
+def _first_appearance(region):
+    ids = {}
+    return [(-1 if r < 0 else ids.setdefault(r, len(ids))) for r in region]
+
+
+def test_region_grouping_equals_reference_bytecode(pkg, sor):
+    import pymodel_group
+    from sicelore_amd import lib as libmod
+
+    n_carry = n_regions = 0
+    for c in _group_cases():
+        pos = [p for p, _ in c["reads"]]
+        rev = [bool(f & 16) for _, f in c["reads"]]
+        for fn in (lambda: sor.region_group(pos, rev, keep_data_end=c["keep_data_end"]),
+                   lambda: pymodel_group.group_sams(pos, rev, 500, c["keep_data_end"]),
+                   lambda: libmod.region_group(pos, rev, keep_data_end=c["keep_data_end"])):
+            region, n_done = fn()
+            assert _first_appearance(list(region)) == c["region"]
+            assert n_done == c["n_done"] and len(pos) - n_done == c["n_carried"]
+        n_carry += c["n_carried"] > 0
+        n_regions += max(c["region"]) + 1
+    assert n_carry >= 10 and n_regions > 400

@@ -517,6 +517,8 @@ def install(jvm):
         return f
 
     def list_init(j, o, *a):
+        if o.native is None:
+            o.native = []   # a jar class extending ArrayList
         if a and isinstance(a[0], JObject) and isinstance(a[0].native, list):
             o.native = list(a[0].native)
 
@@ -868,7 +870,7 @@ def install_streams(jvm):
         N[f"{c}.findAny"] = lambda j, s: find_any(j, s)
         N[f"{c}.reduce"] = reduce_
         N[f"{c}.collect"] = collect
-        N[f"{c}.toArray"] = lambda j, s, *a: JArray({"int": "I", "long": "J", "double": "D"}.get(kind_of(s), "Ljava/lang/Object;"), list(s.native))
+        N[f"{c}.toArray"] = lambda j, s, *a: stream_to_array(j, s, *a)
         N[f"{c}.iterator"] = lambda j, s: N["java/util/ArrayList.iterator"](j, _list(j, s.native))
     N["java/util/stream/Stream.max"] = lambda j, s, cmp: max_min(j, s, cmp, 1)
     N["java/util/stream/Stream.min"] = lambda j, s, cmp: max_min(j, s, cmp, -1)
@@ -886,6 +888,13 @@ def install_streams(jvm):
                 raise Unsupported("DoubleStream.sum over non-integral values (summation order unspecified)")
             t += v
         return t
+
+    def stream_to_array(j, s, *a):
+        if a:  # toArray(IntFunction<A[]> generator): the generator makes the (typed) array
+            arr = call_fn(j, a[0], len(s.native))
+            arr.a[:] = list(s.native)
+            return arr
+        return JArray({"int": "I", "long": "J", "double": "D"}.get(kind_of(s), "Ljava/lang/Object;"), list(s.native))
 
     def find_any(j, s):
         """which element is open in the specification; the drivers only use sections whose caller asks isPresent() -- the note travels in

@@ -1264,7 +1264,95 @@ def gen_finalize(g, n_sets=14, seed=1313):
     return out
 
 
-SECTIONS = {"finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+RGRP = "com/rw/umifinder/bamreaders/ReadGrouper"
+NREAD = "com/rw/umifinder/reads/nanopore/NanoporeRead"
+RSD = NREAD + "$ReadScanData"
+NCHUNK = "com/rw/umifinder/bamreaders/BamReader$NanoporeReadChunk"
+
+
+def gen_group(g, n_chunks=120, seed=1414):
+    """a-18: genomic-region grouping of one BamReader chunk"""
+    j = g.j
+    rng = random.Random(seed)
+    N, H = j.natives, j.hooks
+    put_log = []
+    N["java/util/concurrent/LinkedBlockingQueue.put"] = lambda jj, q, c: put_log.append(c)
+    N["java/util/concurrent/LinkedBlockingQueue.size"] = lambda jj, q: len(put_log)
+    import jvm_exec
+
+    jvm_exec.JDK_IFACES["java/util/concurrent/LinkedBlockingQueue"] = ["java/util/concurrent/BlockingQueue", "java/util/Queue", "java/util/Collection"]
+    for lv in ("DEBUG", "TRACE", "ALL", "INFO"):
+        N["org/apache/logging/log4j/Level." + lv] = (lambda name: (lambda jj: JObject("org/apache/logging/log4j/Level:" + name)))(lv)
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".getFlags:()I"] = lambda jj, o: o.native["flag"]
+
+    def parallel_sort(jj, arr):
+        """Arrays.parallelSort(Comparable[]): a stable merge sort by compareTo (below 8192 elements it IS Arrays.sort; above, sorted runs are
+        merged left-first)"""
+        import functools
+
+        arr.a.sort(key=functools.cmp_to_key(lambda a, b: jj.call_virtual(a, "compareTo", "(Ljava/lang/Object;)I", b)))
+
+    N["java/util/Arrays.parallelSort:([Ljava/lang/Comparable;)V"] = parallel_sort
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("new ReadGrouper().groupSams(chunk, queue, keepDataEnd) (ReadGrouper.java:L82-230; $Cluster, $ClusterList.refineClusters L455-785) "
+                  "with MAX_GENOME_DISTANCE_FOR_SAME_GENOMIC_REGION = 500 (setMaxGenomeDistance): per read the genomic region it was given "
+                  "(numbered here in order of first appearance; the reference's ids come from a global counter), the size of the chunk that "
+                  "was handed on and of the one carried to the next cycle.  A read = its clustering position (or none) and its strand flag",
+                  RGRP, "groupSams:(L...NanoporeReadChunk;Ljava/util/concurrent/BlockingQueue;Z)L...NanoporeReadChunk;")
+    j.call_static(RGRP, "setMaxGenomeDistance", "(I)V", 500)
+    grouper = j.new(RGRP, "()V")
+    for idx in range(n_chunks):
+        n = rng.choice([0, 1, 2, 3, 5, 12, 40, 90, 160, 300])
+        reads = []
+        base = rng.randrange(1000, 5000)
+        while len(reads) < n:                              # loci of 1..25 reads, coordinate-sorted like a BAM chunk
+            base += rng.choice([rng.randrange(0, 400), rng.randrange(400, 700), rng.randrange(700, 6000)])
+            spread = rng.choice([5, 60, 250, 600])
+            for p_ in sorted(rng.randrange(0, spread) for _ in range(min(rng.randrange(1, 26), n - len(reads)))):
+                reads.append([None if rng.random() < 0.06 else base + p_, 16 if rng.random() < 0.45 else 0])
+            base += spread
+        if idx % 5 == 0:
+            reads = [[(p if p is None else 2000 + (k // 9) * 3), f] for k, (p, f) in enumerate(reads)]   # dense ties
+        keep = idx % 2 == 0
+        chunk = j.new(NCHUNK, "(I)V", 1)
+        objs = []
+        for pos, flag in reads:
+            rd = j.new_object(NREAD)
+            sam = JObject(SAMREC)
+            sam.native = {"flag": flag}
+            rd.f["sam"] = sam
+            sd = j.new_object(RSD)
+            sd.f["positionOnGenomeForClustering"] = (j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JBox("java/lang/Integer", pos))
+                                                     if pos is not None else j.call_static(GOPT, "absent", f"()L{GOPT};"))
+            rd.f["readScanData"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", sd)
+            rd.f["genomicRegionNmber"] = j.call_static(GOPT, "absent", f"()L{GOPT};")
+            j.call_virtual(chunk, "add", "(Ljava/lang/Object;)Z", rd)
+            objs.append(rd)
+        del put_log[:]
+        q = JObject("java/util/concurrent/LinkedBlockingQueue")
+        case = {"reads": reads, "keep_data_end": keep}
+        try:
+            nxt = j.call_virtual(grouper, "groupSams", f"(L{NCHUNK};Ljava/util/concurrent/BlockingQueue;Z)L{NCHUNK};", chunk, q, 1 if keep else 0)
+            ids, regions = {}, []
+            for rd in objs:
+                o = rd.f["genomicRegionNmber"]
+                if j.call_virtual(o, "isPresent", "()Z"):
+                    v = j.call_virtual(o, "get", "()Ljava/lang/Object;").v
+                    regions.append(ids.setdefault(v, len(ids)))
+                else:
+                    regions.append(-1)
+            case.update({"region": regions, "returned_null": nxt is None, "n_done": len(put_log[0].native) if put_log else None,
+                         "n_carried": None if nxt is None else len(nxt.native)})
+        except JavaThrow as e:
+            case.update({"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:5]})
+        s["cases"].append(case)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
