@@ -467,3 +467,65 @@ def test_region_grouping_equals_reference_bytecode(pkg, sor):
         n_carry += c["n_carried"] > 0
         n_regions += max(c["region"]) + 1
     assert n_carry >= 10 and n_regions > 400
+
+
+# ---- a-17: UMI clustering of a (cell, region) group (ClusterOneHierarchical.call over LingPipe) --------------------------------------
+_DEC4 = {1: "A", 2: "G", 4: "C", 8: "T", 15: "N"}
+
+
+def _cluster_tags(sor, scan_data_from_name, names, cluster):
+    """the setAttribute calls of ClusterOneBase.setSamflagsAndStatsForClustered per read: windows -> pair matrix (oracle) -> `cluster`
+    (the oracle's sor_umi_cluster_group or the product's smi_umi_cluster_groups, both take the packed matrix)"""
+    scans = [scan_data_from_name(nm) for nm in names]
+    ws = [sor.umi_window_3p(d["x"], d["ae"], d["bc"]["end"]) for d in scans]
+    assert all(w is not None for w in ws)
+    mat = sor.umi_matrix(np.array(ws, dtype=np.uint8))
+    asg, skipped = cluster(mat.reshape(-1), len(names), np.array([d["q"] for d in scans], np.float32))
+    out = []
+    for i in range(len(names)):
+        a = asg[i]
+        if a["center"] < 0 or skipped[i]:
+            out.append([])
+            continue
+        cw, off = ws[int(a["center"])], int(a["offset"])
+        calls = [["U8", "".join(_DEC4[c] for c in cw[off + 1:off + 13])], ["U7", "".join(_DEC4[c] for c in ws[i][1:13])], ["UC", ""],
+                 ["U1", str(int(a["ed"]))]]
+        if a["ed_second"] >= 0:
+            calls.append(["U2", str(int(a["ed_second"]))])
+        out.append(calls)
+    return out
+
+
+def test_umi_clustering_equals_reference_bytecode(pkg, sor):
+    import importlib
+
+    from sicelore_amd import lib as libmod
+
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    sec = load("cluster")["sections"][0]
+    assert all(isinstance(c["set_attribute"], list) for c in sec["cases"])   # nothing threw
+    oracle = lambda m, n, q: sor.umi_cluster_group(m, n, q)  # noqa: E731
+    product = lambda m, n, q: libmod.umi_cluster_groups(m, [0, n * n], [0, n], q)  # noqa: E731
+    # groups whose answer does not depend on any hash order (eight orders gave the same): equal, read by read
+    kept = [c for c in sec["cases"] if c["hash_orders_agree"]]
+    assert len(kept) >= 25
+    n_reads = n_tagged = n_multi = 0
+    for c in kept:
+        exp = c["set_attribute"]
+        for cluster in (oracle, product):
+            assert _cluster_tags(sor, assignumis.scan_data_from_name, c["names"], cluster) == exp, c["names"]
+        n_reads += len(exp)
+        n_tagged += sum(1 for e in exp if e)
+        n_multi += len({e[0][1] for e in exp if e}) > 1
+    assert n_reads > 120 and n_tagged > 90 and n_multi >= 4
+    # groups where the reference's answer depends on the iteration order of a HashSet / fastutil set (ties between merges, between
+    # candidate centres, the two members of a 2-read cluster): oracle and product use one canonical order (DESIGN 2) and must agree with
+    # each other; their answer is one of the answers the reference gave under the orders that were tried, except where eight orders did
+    # not reach every alternative
+    dep = [c for c in sec["cases"] if not c["hash_orders_agree"]]
+    n_in = 0
+    for c in dep:
+        got = _cluster_tags(sor, assignumis.scan_data_from_name, c["names"], oracle)
+        assert got == _cluster_tags(sor, assignumis.scan_data_from_name, c["names"], product)
+        n_in += got in c["outcomes_over_orders"]
+    assert len(dep) >= 20 and n_in >= 0.85 * len(dep)

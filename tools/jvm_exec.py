@@ -236,13 +236,14 @@ class JVM:
         self.intern = {}
         self.hash_order = None  # see jvm_natives.HashStore.cells_for_iteration
         self.hooks = {}  # "cls.name:desc" -> python callable(jvm, args) replacing a method (used for MISSING libraries only)
-        from jvm_natives import install, install_enumset, install_env, install_hash, install_streams  # noqa: E402
+        from jvm_natives import install, install_enumset, install_env, install_hash, install_streams, install_treeset  # noqa: E402
 
         install(self)
         install_streams(self)
         install_hash(self)
         install_env(self)
         install_enumset(self)
+        install_treeset(self)
 
     # ---- classes ---------------------------------------------------------------------------------------------------
     def has_class(self, name):

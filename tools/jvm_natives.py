@@ -335,6 +335,16 @@ def install(jvm):
     N["java/lang/Long.compare"] = lambda j, a, b: (a > b) - (a < b)
     N["java/lang/Float.compare"] = lambda j, a, b: _fcompare(a, b)
     N["java/lang/Double.compare"] = lambda j, a, b: _fcompare(a, b)
+    N["java/lang/Integer.sum:(II)I"] = lambda j, a, b: i32(a + b)
+    N["java/lang/Integer.max:(II)I"] = lambda j, a, b: max(a, b)
+    N["java/lang/Integer.min:(II)I"] = lambda j, a, b: min(a, b)
+    N["java/lang/Long.sum:(JJ)J"] = lambda j, a, b: i64(a + b)
+    N["java/lang/Double.isNaN:(D)Z"] = lambda j, v: 1 if v != v else 0
+    N["java/lang/Double.isInfinite:(D)Z"] = lambda j, v: 1 if v in (math.inf, -math.inf) else 0
+    N["java/lang/Double.POSITIVE_INFINITY"] = lambda j: math.inf
+    N["java/lang/Double.NEGATIVE_INFINITY"] = lambda j: -math.inf
+    N["java/lang/Double.NaN"] = lambda j: math.nan
+    N["java/lang/Double.MAX_VALUE"] = lambda j: 1.7976931348623157e308
     N["java/lang/Integer.toString:(I)Ljava/lang/String;"] = lambda j, v: str(v)
     N["java/lang/Long.toString:(J)Ljava/lang/String;"] = lambda j, v: str(v)
     N["java/lang/Float.toString:(F)Ljava/lang/String;"] = lambda j, v: float_to_string(v, True)
@@ -1043,6 +1053,8 @@ def install_streams(jvm):
     N["java/util/Collections.emptyList"] = lambda j: _list(j, [])
     N["java/util/Collections.emptySet"] = lambda j: _list(j, [])
     N["java/util/Collections.unmodifiableList"] = lambda j, c: c
+    N["java/util/Collections.unmodifiableMap"] = lambda j, m: m
+    N["java/util/Collections.unmodifiableSet"] = lambda j, m: m
     N["java/util/function/Function.identity"] = lambda j: fn_obj(lambda v: v)
 
     def list_sort(j, o, cmp):
@@ -1079,6 +1091,8 @@ class HashStore:
         self.j = jvm
         self.buckets = {}   # hashCode -> [[key, value], ...]
         self.order = []     # [key, value] cells in insertion order (driver-side reading only)
+        jvm.store_serial = getattr(jvm, "store_serial", 0) + 1
+        self.serial = jvm.store_serial   # shuffled orders differ from container to container (a chain of two iterations must not cancel)
         self.cap0 = 16      # table size the first put allocates (jdk order only)
         self.peak = 0       # largest size reached: the table never shrinks
         self.identity = False
@@ -1170,7 +1184,7 @@ class HashStore:
         elif isinstance(mode, tuple):
             import random
 
-            random.Random(mode[1] * 1000003 + len(cells)).shuffle(cells)
+            random.Random(mode[1] * 1000003 + len(cells) + 7919 * self.serial).shuffle(cells)
         return cells
 
 
@@ -1252,6 +1266,23 @@ def install_hash(jvm):
         N[f"{c}.clear"] = lambda j, o: o.native.__init__(j)
         for it in ("parallelStream", "toString", "hashCode"):
             N[f"{c}.{it}"] = refuse(it)
+
+    def set_hash(j, o):
+        """AbstractSet.hashCode: the sum of the members' hash codes -- independent of any order"""
+        t = 0
+        for cell in o.native.order:
+            t = (t + o.native._hash(cell[0])) & 0xFFFFFFFF
+        return i32(t)
+
+    def set_equals(j, o, other):
+        if o is other:
+            return 1
+        if not isinstance(other, JObject) or not isinstance(other.native, HashStore) or len(other.native) != len(o.native):
+            return 0
+        return 1 if all(other.native.find(cell[0]) is not None for cell in o.native.order) else 0
+
+    N["java/util/HashSet.hashCode"] = set_hash
+    N["java/util/HashSet.equals"] = set_equals
 
     def _aslist(j, items):
         o = JObject("java/util/ArrayList")
@@ -1364,6 +1395,127 @@ def install_hash(jvm):
 # environment: things a driver has to answer for the JVM process (no bearing on the algorithms): runtime, clocks,
 # properties, atomics used as plain counters, DecimalFormat for the two patterns the reference uses
 # =====================================================================================================================
+def install_treeset(jvm):
+    """java.util.TreeSet (tier C: an ordered container): elements kept sorted by the comparator (or compareTo); an element that compares
+    equal to a member is not added -- the specified behaviour of a sorted set, independent of its tree"""
+    N = jvm.natives
+
+    def cmp(j, o, a, b):
+        c = o.native["cmp"]
+        if c is None:
+            if isinstance(a, JBox):
+                return (a.v > b.v) - (a.v < b.v)
+            if isinstance(a, str):
+                return N["java/lang/String.compareTo:(Ljava/lang/String;)I"](j, a, b)
+            return j.call_virtual(a, "compareTo", "(Ljava/lang/Object;)I", b)
+        return j.call_fn(j, c, a, b) if not (isinstance(c, JObject) and c.cls not in ("$Comparator", "$Fn") and not isinstance(c, JLambda)) \
+            else j.call_virtual(c, "compare", "(Ljava/lang/Object;Ljava/lang/Object;)I", a, b)
+
+    def find(j, o, v):
+        """-> (index, found) by binary search"""
+        items = o.native["items"]
+        lo, hi = 0, len(items)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            c = cmp(j, o, items[mid], v)
+            c = c.v if isinstance(c, JBox) else c
+            if c == 0:
+                return mid, True
+            if c < 0:
+                lo = mid + 1
+            else:
+                hi = mid
+        return lo, False
+
+    def new(j):
+        o = JObject("java/util/TreeSet")
+        o.native = {"items": [], "cmp": None}
+        return o
+
+    def init(j, o, *a):
+        if o.native is None:
+            o.native = {"items": [], "cmp": None}
+        if a and a[0] is not None:
+            if isinstance(a[0], JObject) and isinstance(a[0].native, list):
+                for v in a[0].native:
+                    add(j, o, v)
+            else:
+                o.native["cmp"] = a[0]
+
+    def add(j, o, v):
+        i, found = find(j, o, v)
+        if found:
+            return 0
+        o.native["items"].insert(i, v)
+        return 1
+
+    def remove(j, o, v):
+        i, found = find(j, o, v)
+        if found:
+            o.native["items"].pop(i)
+            return 1
+        return 0
+
+    def first(j, o):
+        if not o.native["items"]:
+            j.throw("java/util/NoSuchElementException")
+        return o.native["items"][0]
+
+    def last(j, o):
+        if not o.native["items"]:
+            j.throw("java/util/NoSuchElementException")
+        return o.native["items"][-1]
+
+    def as_list(j, items):
+        lst = JObject("java/util/ArrayList")
+        lst.native = list(items)
+        return lst
+
+    N["java/util/TreeSet.<new>"] = new
+    N["java/util/TreeSet.<init>"] = init
+    N["java/util/TreeSet.add"] = add
+    N["java/util/TreeSet.remove"] = remove
+    N["java/util/TreeSet.contains"] = lambda j, o, v: 1 if find(j, o, v)[1] else 0
+    N["java/util/TreeSet.first"] = first
+    N["java/util/TreeSet.last"] = last
+    N["java/util/TreeSet.size"] = lambda j, o: len(o.native["items"])
+    N["java/util/TreeSet.isEmpty"] = lambda j, o: 0 if o.native["items"] else 1
+    N["java/util/TreeSet.clear"] = lambda j, o: o.native["items"].clear()
+    def ts_iter(j, o):
+        it = JObject("$TreeSetIterator")
+        it.native = [o, 0, -1]
+        return it
+
+    def ts_next(j, it):
+        o, i, _ = it.native
+        if i >= len(o.native["items"]):
+            j.throw("java/util/NoSuchElementException")
+        it.native[1], it.native[2] = i + 1, i
+        return o.native["items"][i]
+
+    def ts_remove(j, it):
+        o, i, last = it.native
+        if last < 0:
+            j.throw("java/lang/IllegalStateException")
+        o.native["items"].pop(last)
+        it.native[1], it.native[2] = last, -1
+
+    N["java/util/TreeSet.iterator"] = ts_iter
+    N["$TreeSetIterator.hasNext"] = lambda j, it: 1 if it.native[1] < len(it.native[0].native["items"]) else 0
+    N["$TreeSetIterator.next"] = ts_next
+    N["$TreeSetIterator.remove"] = ts_remove
+    __import__("jvm_exec").JDK_IFACES["$TreeSetIterator"] = ["java/util/Iterator"]
+    N["java/util/TreeSet.stream"] = lambda j, o: N["java/util/ArrayList.stream"](j, as_list(j, o.native["items"]))
+    N["java/util/TreeSet.comparator"] = lambda j, o: o.native["cmp"]
+    for k in list(N):
+        if k.startswith("java/util/TreeSet.") and not k.endswith(("<new>", "<init>")):
+            N.setdefault("java/util/SortedSet" + k[len("java/util/TreeSet"):], N[k])
+    sup = __import__("jvm_exec").JDK_SUPER
+    ifs = __import__("jvm_exec").JDK_IFACES
+    sup["java/util/TreeSet"] = "java/util/AbstractSet"
+    ifs["java/util/TreeSet"] = ["java/util/NavigableSet", "java/util/SortedSet", "java/util/Set", "java/util/Collection"]
+
+
 def install_env(jvm):
     N = jvm.natives
 

@@ -1352,7 +1352,141 @@ def gen_group(g, n_chunks=120, seed=1414):
     return out
 
 
-SECTIONS = {"group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+COH = "com/rw/umifinder/analyzers/clustering/ClusterOneHierarchical"
+SSTAT = "com/rw/umifinder/scanstats/ScanStats"
+ORSS = "com/rw/umifinder/scanstats/OneReadScanStat"
+IPAIR = "org/apache/commons/lang3/tuple/ImmutablePair"
+
+
+def install_intset_iterable(j):
+    """the absent fastutil IntOpenHashSet (superclass of OneUmiCluster) as a set that can be iterated -- in the varied orders of
+    jvm.hash_order, never in fastutil's own"""
+    import jvm_exec
+    from jvm_natives import HashStore
+
+    N = j.natives
+    IOS = "it/unimi/dsi/fastutil/ints/IntOpenHashSet"
+    box = lambda v: v if isinstance(v, JBox) else JBox("java/lang/Integer", v)  # noqa: E731
+
+    def st(o):
+        if not isinstance(o.native, HashStore):
+            o.native = HashStore(j)
+        return o.native
+
+    def alist(items):
+        lst = JObject("java/util/ArrayList")
+        lst.native = list(items)
+        return lst
+
+    keys = lambda o, what: [c[0] for c in st(o).cells_for_iteration(what, IOS)]  # noqa: E731
+
+    def new(jj):
+        o = JObject(IOS)
+        o.native = HashStore(jj)
+        return o
+
+    def remove_all(jj, o, coll):
+        items = coll.native if isinstance(coll.native, list) else [c[0] for c in coll.native.order]
+        changed = 0
+        for v in list(items):
+            if st(o).remove(box(v)) is not None:
+                changed = 1
+        return changed
+
+    N[IOS + ".<new>"] = new
+    N[IOS + ".<init>"] = lambda jj, o, *a: None if st(o) is None else None
+    N[IOS + ".add"] = lambda jj, o, v: 1 if st(o).put(box(v), True)[1] else 0
+    N[IOS + ".contains"] = lambda jj, o, v: 1 if st(o).find(box(v)) is not None else 0
+    N[IOS + ".remove"] = lambda jj, o, v: 1 if st(o).remove(box(v)) is not None else 0
+    N[IOS + ".removeAll"] = remove_all
+    N[IOS + ".size"] = lambda jj, o: len(st(o))
+    N[IOS + ".isEmpty"] = lambda jj, o: 0 if len(st(o)) else 1
+    N[IOS + ".stream"] = lambda jj, o: jj.natives["java/util/ArrayList.stream"](jj, alist(keys(o, "stream")))
+    N[IOS + ".iterator"] = lambda jj, o: jj.natives["java/util/ArrayList.iterator"](jj, alist(keys(o, "iterator")))
+    N[IOS + ".forEach"] = lambda jj, o, f: [jj.call_fn(jj, f, k) for k in keys(o, "forEach")] and None
+    jvm_exec.JDK_SUPER[IOS] = "java/util/AbstractSet"
+    jvm_exec.JDK_IFACES[IOS] = ["java/util/Set", "java/util/Collection", "it/unimi/dsi/fastutil/ints/IntSet", "java/lang/Iterable"]
+
+
+def cluster_once(j, side, par, stats, names, order):
+    """one ClusterOneHierarchical.call() over the reads behind `names` under one iteration order -> per read its setAttribute calls"""
+    j.hash_order = order
+    reads = []
+    for nm in names:
+        sd = side.scan_data(nm)
+        r = side.result_for(sd)
+        sam = JObject(SAMREC)
+        sam.native = {"calls": []}
+        r.f["nanoporeRead"].f["sam"] = sam
+        r.f["oneReadScanStats"] = j.new(ORSS, "()V") if ("<init>", "()V") in j.load(ORSS).methods else j.new_object(ORSS)
+        reads.append(r)
+    lst = JObject("java/util/ArrayList")
+    lst.native = list(reads)
+    pair = j.call_static(IPAIR, "of", f"(Ljava/lang/Object;Ljava/lang/Object;)L{IPAIR};", JBox("java/lang/Boolean", 0), lst)
+    try:
+        c = j.new(COH, f"(L{UPAR};L{IPAIR};L{SSTAT};)V", par, pair, stats)
+        j.call_virtual(c, "call", f"()L{IPAIR};")
+        return [r.f["nanoporeRead"].f["sam"].native["calls"] for r in reads]
+    except JavaThrow as e:
+        return {"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:8]}
+    finally:
+        j.hash_order = None
+
+
+def gen_cluster(g, n_groups=70, seed=1515, five_prime=False):
+    """a-17: UMI clustering of one (cell, region) group"""
+    j = g.j
+    rng = random.Random(seed)
+    side = UmiSide(g, five_prime)
+    par = side.par
+    install_intset_iterable(j)
+    H = j.hooks
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".setAttribute:(Ljava/lang/String;Ljava/lang/Object;)V"] = lambda jj, o, t, v: o.native["calls"].append([t, v])
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar + Aliasi_ClusteringLib-1.0.jar", "sections": []}
+    s = g.section("new ClusterOneHierarchical(params, ImmutablePair.of(false, reads), scanStats).call() (ClusterOneHierarchical.java:L61-217) for the "
+                  "reads of one (cell, region) group: DistanceMatrix, LingPipe CompleteLinkClusterer / Dendrogram.partitionDistance, "
+                  "OneUmiCluster centre, ClusterOneBase.setSamflagsAndStatsForClustered: per read the setAttribute calls made on its record.  "
+                  "Each group under eight iteration orders of the hash containers (JDK sets and the stand-in for fastutil's IntOpenHashSet; the shuffled "
+                  "orders differ from container to container); kept when they agree", COH, "call:()L...ImmutablePair;")
+    # the statistics objects of the run: their counters are not outputs of this path -- atomics created, the per-flag tables inert
+    stats = j.new_object(SSTAT)
+    for fname, fdesc in j.load(SSTAT).instance_fields:
+        if fdesc in ("Ljava/util/concurrent/atomic/AtomicLong;", "Ljava/util/concurrent/atomic/AtomicInteger;"):
+            stats.f[fname] = j.natives[fdesc[1:-1] + ".<new>"](j)
+    ASS = "com/rw/umifinder/scanstats/AllSamScanStats"
+    H[ASS + ".<clinit>:()V"] = None
+    H[ASS + ".*"] = lambda jj, *a: None
+    stats.f["scanStatsForSams"] = JObject(ASS)
+    for idx in range(n_groups):
+        n_mol = rng.randrange(1, 5)
+        umis = [rnd_seq(rng, 12) for _ in range(n_mol)]
+        bc = rnd_seq(rng, 16)
+        names = []
+        k = 0
+        for u in umis:
+            for _ in range(rng.randrange(1, 6)):
+                uu = mutate(rng, u, rng.choice([0, 0, 0, 1, 1, 2]))[:12].ljust(12, "A")
+                names.append(fake_name(rng, 100 * idx + k, five_prime, bc, uu, rng.random() < 0.5, rng.randrange(120, 200), rng.choice([0, 0, 0, 1, -1])))
+                k += 1
+        results = [cluster_once(j, side, par, stats, names, order)
+                   for order in ("insertion", "reverse") + tuple(("shuffle", 977 * idx + 5 + 31 * t) for t in range(6))]
+        j.hash_order = None
+        distinct = []
+        for r in results:
+            if r not in distinct:
+                distinct.append(r)
+        case = {"names": names, "hash_orders_agree": len(distinct) == 1, "set_attribute": results[0]}
+        if len(distinct) > 1:
+            case["outcomes_over_orders"] = distinct   # what the reference writes depends on a hash order here: every answer that was seen
+        s["cases"].append(case)
+        print(f"  cluster {idx + 1}/{n_groups} n={len(names)} agree={s['cases'][-1]['hash_orders_agree']}  {time.time() - g.t0:.0f}s", flush=True)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
