@@ -529,3 +529,39 @@ def test_umi_clustering_equals_reference_bytecode(pkg, sor):
         assert got == _cluster_tags(sor, assignumis.scan_data_from_name, c["names"], product)
         n_in += got in c["outcomes_over_orders"]
     assert len(dep) >= 20 and n_in >= 0.85 * len(dep)
+
+
+# ---- a-12: the pass-1 worker (quality filter, barcode cut, membership, counter map) -------------------------------------------------
+def _pass1_batch(sec):
+    seqs = [c["seq"] for c in sec["cases"]]
+    quals = [c["qual"] for c in sec["cases"]]
+    offs = np.zeros(len(seqs) + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(q) for q in seqs])
+    return (np.frombuffer("".join(seqs).encode(), dtype=np.uint8), np.frombuffer("".join(quals).encode(), dtype=np.uint8), offs)
+
+
+def _pass1_histogram(sor, sec, ra, offs, pass1_ok, reverse, adapter_end):
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    wl = {sor.encode(q) for q in sec["whitelist"]}
+    hist = {}
+    for i in np.nonzero(np.asarray(pass1_ok) == 1)[0]:
+        seq = bytes(ra[int(offs[i]):int(offs[i + 1])])
+        stranded = seq.translate(comp)[::-1] if reverse[i] else seq
+        ae = int(adapter_end[i])
+        key = sor.revcomp(sor.encode(stranded[ae - 17:ae - 1].decode()))
+        if key in wl:
+            hist[key] = hist.get(key, 0) + 1
+    return sorted([int(k), v] for k, v in hist.items())
+
+
+def test_pass1_worker_equals_reference_bytecode(sor):
+    sec = load("pass1")["sections"][0]
+    assert sec["hash_orders_agree"] and all(c["scanned"] and "filter_throws" not in c for c in sec["cases"])
+    ra, qa, offs = _pass1_batch(sec)
+    st, exp = sor.scan_batch_3p(ra, qa, offs, "CTACACGACGCTCTTCCGATCT", n_threads=4)
+    assert (st == 0).all()
+    assert [bool(x) for x in exp["pass1_ok"]] == [c["filter"] for c in sec["cases"]]
+    assert 10 < int(exp["pass1_ok"].sum()) < len(sec["cases"]) - 10
+    hist = _pass1_histogram(sor, sec, ra, offs, exp["pass1_ok"], exp["reverse"], exp["adapter_end"])
+    assert hist == sec["histogram"] and sum(c for _, c in hist) < int(exp["pass1_ok"].sum())   # some planted barcodes are not possible ones
+    assert sec["record_count"] == 1   # recordCount counts chunks (L254), the unit of the 2 * recordCount / 5e6 cutoff

@@ -121,3 +121,40 @@ def test_k_chim_equals_reference_bytecode(pkg, gpu_ctx):
         assert multi == (len(want) == 1 and want[0]["flag"] != 0)
         n_split += k > 0
     assert n_split >= 8
+
+
+def test_pass1_chunk_worker_equals_reference_bytecode(pkg, gpu_ctx):
+    """smi_scanfastq_pass1_chunk (FASTQ text in, histogram increment on the device: K-FQ, K-PACK with qualities, K-SCAN<22> with the
+    quality filter, K-HIST) against UsedCellBCListGenerator$Worker.call executed from the reference's class files
+    (tests/golden/ref_exec_pass1.json): the counter map, and the per-record filter through the scan entry points"""
+    import torch
+
+    with open(os.path.join(GOLD, "ref_exec_pass1.json")) as f:
+        sec = json.load(f)["sections"][0]
+    assert sec["hash_orders_agree"]
+    keys = np.sort(np.array([_key(b) for b in sec["whitelist"]], dtype=np.uint64))
+    gpu_ctx.set_barcode_set(keys, mode=1)
+    text = "".join(f"@{c['name']}\n{c['seq']}\n+\n{c['qual']}\n" for c in sec["cases"]).encode()
+    hist = torch.zeros(keys.size, dtype=torch.int32, device="cuda")
+    assert gpu_ctx.scanfastq_pass1_chunk(text, hist) == len(sec["cases"])
+    h = hist.cpu().numpy()
+    got = sorted([int(keys[i]), int(h[i])] for i in np.nonzero(h)[0])
+    assert got == sec["histogram"] and len(got) >= 5
+    # the filter per record: pack with qualities -> K-SCAN pass 1 -> pass1_ok
+    seqs, quals = [c["seq"] for c in sec["cases"]], [c["qual"] for c in sec["cases"]]
+    n = len(seqs)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(q) for q in seqs])
+    d_reads = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()).cuda()
+    d_quals = torch.from_numpy(np.frombuffer("".join(quals).encode(), dtype=np.uint8).copy()).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    ends = torch.zeros((28, 2 * n), dtype=torch.int32, device="cuda")
+    lens, qsum = torch.zeros(n, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.int32, device="cuda")
+    qt = torch.zeros((n, 224), dtype=torch.uint8, device="cuda")
+    gpu_ctx.pack_ends_device(d_reads, d_quals, d_offs, n, ends, lens, qt, qsum)
+    out = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    win = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
+    gpu_ctx.scan_device(ends, lens, n, gpu_ctx.scan_config(1), out, win, qt, qsum)
+    torch.cuda.synchronize()
+    res = out.cpu().numpy().view(pkg.SCAN_RESULT_DTYPE).reshape(-1)
+    assert [bool(x) for x in res["pass1_ok"]] == [c["filter"] for c in sec["cases"]]

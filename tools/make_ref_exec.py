@@ -1486,7 +1486,95 @@ def gen_cluster(g, n_groups=70, seed=1515, five_prime=False):
     return out
 
 
-SECTIONS = {"cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+UCG = "com/rw/nanoporereadscanner/analyzers/UsedCellBCListGenerator"
+RCHUNK = "com/rw/nanoporereadscanner/readerwriter/FastqFileReader$ReadChunk"
+
+
+def gen_pass1(g, n_reads=60, seed=1616, five_prime=False):
+    """a-12: the pass-1 worker of scanfastq over one chunk"""
+    j = g.j
+    rng = random.Random(seed)
+    p2 = Pass2(g, five_prime, 1)
+    install_long2object_iterable(j)
+    par = p2.par
+    enc = lambda q: j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q))  # noqa: E731
+    bcs = sorted({rnd_seq(rng, 16) for _ in range(30)})
+    whitelist = bcs[:24] + [rnd_seq(rng, 16) for _ in range(10)]        # six of the planted barcodes are NOT possible barcodes
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("pass 1 of scanfastq over one chunk: PolyATadapterAnalyzer.search with the complete adapter (as pass 1 scans), then "
+                  "new UsedCellBCListGenerator$Worker(generator, chunk).call() (UsedCellBCListGenerator.java:L189-263): per record the "
+                  "quality filter lambda$call$0 (L198-202), then the barcode cut from the stranded read, its membership in the list of possible "
+                  "barcodes and the counter map.  Outputs: per record `filter`, and the final unfilteredUsedBarcodeMap", UCG + "$Worker", "call:()Ljava/lang/Object;")
+    s["whitelist"] = whitelist
+    s["five_prime"] = five_prime
+    reads = []
+    for idx in range(n_reads):
+        seq, qual, bc = synth_read(rng, bcs, five_prime, idx)
+        if idx % 4 == 1:   # low qualities over the barcode or over the whole read
+            qual = "".join(chr(33 + rng.randrange(2, 9)) for _ in qual)
+        elif idx % 4 == 2:
+            qual = "".join(chr(33 + rng.randrange(6, 14)) for _ in qual)
+        reads.append((f"read{idx:04d} runid=abc ch={idx % 512}", seq, qual, bc))
+
+    def run(order):
+        j.hash_order = order
+        gen = j.new_object(UCG)
+        gen.f["params"] = par
+        for fname, fdesc in j.load(UCG).instance_fields:
+            if fdesc == "Ljava/util/concurrent/atomic/AtomicInteger;":
+                gen.f[fname] = j.natives["java/util/concurrent/atomic/AtomicInteger.<new>"](j)
+        dbg = j.new_object(UCG + "$DebugInfo")
+        for fname, fdesc in j.load(UCG + "$DebugInfo").instance_fields:
+            if fdesc in ("Ljava/util/concurrent/atomic/AtomicInteger;", "Ljava/util/concurrent/atomic/AtomicLong;"):
+                dbg.f[fname] = j.natives[fdesc[1:-1] + ".<new>"](j)
+        gen.f["debugInfo"] = dbg
+        wl_map = j.natives[L2O + ".<new>"](j)
+        for q in whitelist:
+            wl_map.native.put(JBox("java/lang/Long", enc(q)), True)
+        gen.f["allPossibleBarcodes"] = j.natives[L2O + ".keySet"](j, wl_map)   # LongOpenHashSet stand-in: contains only
+        ud = j.new(UBLD, f"(L{PAR};)V", par)
+        gen.f["barcodesUsedData"] = ud
+        fqs, cases = [], []
+        for name, seq, qual, bc in reads:
+            fq = p2.record(name, seq, qual)
+            case = {"name": name, "seq": seq, "qual": qual, "planted_barcode": bc}
+            try:
+                p2.process(None, fq, pass2=False)
+                fqs.append(fq)
+                case["scanned"] = True
+            except JavaThrow as e:
+                case.update({"scanned": False, "throws": e.obj.cls})
+            cases.append(case)
+        lst = JObject("java/util/ArrayList")
+        lst.native = list(fqs)
+        chunk = j.new_object(RCHUNK)
+        chunk.f["fastqRecords"] = lst
+        w = j.new(UCG + "$Worker", f"(L{UCG};L{RCHUNK};)V", gen, chunk)
+        flt = j.find_method(UCG + "$Worker", "lambda$call$0", f"(L{FQX};)Z")
+        k = 0
+        for case in cases:
+            if case["scanned"]:
+                try:
+                    case["filter"] = bool(j.invoke(flt, [w, fqs[k]]))
+                except JavaThrow as e:
+                    case["filter_throws"] = e.obj.cls
+                k += 1
+        j.call_virtual(w, "call", "()Ljava/lang/Object;")
+        m = ud.f["unfilteredUsedBarcodeMap"]
+        hist = sorted([u64(kk.v), j.natives["java/util/concurrent/atomic/AtomicInteger.get"](j, v)] for kk, v in m.native.items_in_insertion_order())
+        rc = j.natives["java/util/concurrent/atomic/AtomicInteger.get"](j, ud.f["recordCount"])
+        j.hash_order = None
+        return cases, hist, rc
+
+    runs = [run(order) for order in ("insertion", "reverse", ("shuffle", 3))]
+    s["cases"], s["histogram"], s["record_count"] = runs[0]
+    s["hash_orders_agree"] = all(r == runs[0] for r in runs[1:])
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
