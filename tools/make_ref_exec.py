@@ -19,7 +19,7 @@ import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
-from jvm_exec import JVM, JArray, JBox, JObject, JavaThrow, Unsupported, f32  # noqa: E402
+from jvm_exec import JVM, JArray, JBox, JLambda, JObject, JavaThrow, Unsupported, f32  # noqa: E402
 import jvm_natives  # noqa: E402
 
 REF = "/root/reference/Jar/"
@@ -1034,8 +1034,8 @@ LSET = "it/unimi/dsi/fastutil/longs/LongOpenHashSet"
 LES = "com/google/common/util/concurrent/ListeningExecutorService"
 
 
-def install_long2object_iterable(j):
-    """the absent fastutil Long2ObjectOpenHashMap as a keyed store that can ALSO be iterated -- in the varied orders of jvm.hash_order,
+def _install_prim2object_iterable(j, map_cls, iface, entry_cls, keyset_cls, box_cls, key_desc, get_key_name, entry_set_name, maps_cls):
+    """an absent fastutil <prim>2ObjectOpenHashMap as a keyed store that can ALSO be iterated -- in the varied orders of jvm.hash_order,
     never in fastutil's own (the jar is missing): a case is kept only when every order gives the same answer"""
     import jvm_exec
     from jvm_natives import HashStore
@@ -1047,10 +1047,10 @@ def install_long2object_iterable(j):
             o.native = HashStore(j)
         return o.native
 
-    box = lambda k: JBox("java/lang/Long", k)  # noqa: E731
+    box = lambda k: k if isinstance(k, JBox) else JBox(box_cls, k)  # noqa: E731
 
     def new_map(jj):
-        o = JObject(L2O)
+        o = JObject(map_cls)
         o.native = HashStore(jj)
         return o
 
@@ -1060,42 +1060,84 @@ def install_long2object_iterable(j):
         return lst
 
     def entry(k, v):
-        e = JObject(L2OE)
+        e = JObject(entry_cls)
         e.native = [k, v]
         return e
 
     def cells(o, what):
-        return st(o).cells_for_iteration(what, L2O)
+        return st(o).cells_for_iteration(what, map_cls)
 
     def key_set(jj, o):
-        ks = JObject(LSET)
+        ks = JObject(keyset_cls)
         ks.native = o          # live view
         return ks
 
-    for c in (L2O, L2OM):
+    for c in (map_cls, iface):
         N[c + ".<new>"] = new_map
         N[c + ".<init>"] = lambda jj, o, *a: None if st(o) is None else None
-        N[c + ".put:(JLjava/lang/Object;)Ljava/lang/Object;"] = lambda jj, o, k, v: st(o).put(box(k), v)[0]
-        N[c + ".get:(J)Ljava/lang/Object;"] = lambda jj, o, k: (st(o).find(box(k)) or [None, None])[1]
-        N[c + ".containsKey:(J)Z"] = lambda jj, o, k: 1 if st(o).find(box(k)) is not None else 0
-        N[c + ".remove:(J)Ljava/lang/Object;"] = lambda jj, o, k: (st(o).remove(box(k)) or [None, None])[1]
+        N[c + f".put:({key_desc}Ljava/lang/Object;)Ljava/lang/Object;"] = lambda jj, o, k, v: st(o).put(box(k), v)[0]
+        N[c + f".get:({key_desc})Ljava/lang/Object;"] = lambda jj, o, k: (st(o).find(box(k)) or [None, None])[1]
+        N[c + f".containsKey:({key_desc})Z"] = lambda jj, o, k: 1 if st(o).find(box(k)) is not None else 0
+        N[c + f".remove:({key_desc})Ljava/lang/Object;"] = lambda jj, o, k: (st(o).remove(box(k)) or [None, None])[1]
         N[c + ".size"] = lambda jj, o: len(st(o))
         N[c + ".isEmpty"] = lambda jj, o: 0 if len(st(o)) else 1
         N[c + ".values"] = lambda jj, o: alist(cl[1] for cl in cells(o, "values"))
-        N[c + ".long2ObjectEntrySet"] = lambda jj, o: alist(entry(cl[0], cl[1]) for cl in cells(o, "long2ObjectEntrySet"))
+        N[c + "." + entry_set_name] = lambda jj, o: alist(entry(cl[0], cl[1]) for cl in cells(o, entry_set_name))
         N[c + ".keySet"] = key_set
-    N[LSET + ".contains:(J)Z"] = lambda jj, ks, k: 1 if st(ks.native).find(box(k)) is not None else 0
-    N[LSET + ".contains:(Ljava/lang/Object;)Z"] = lambda jj, ks, k: 1 if st(ks.native).find(k) is not None else 0
-    N[LSET + ".stream"] = lambda jj, ks: jj.natives["java/util/ArrayList.stream"](jj, alist(cl[0] for cl in cells(ks.native, "keySet().stream")))
-    N[LSET + ".size"] = lambda jj, ks: len(st(ks.native))
-    N[L2OE + ".getLongKey"] = lambda jj, e: e.native[0].v
-    N[L2OE + ".getKey"] = lambda jj, e: e.native[0]
-    N[L2OE + ".getValue"] = lambda jj, e: e.native[1]
-    N["it/unimi/dsi/fastutil/longs/Long2ObjectMaps.synchronize"] = lambda jj, m, *a: m
-    jvm_exec.JDK_SUPER[L2O] = "java/lang/Object"
-    jvm_exec.JDK_IFACES[L2O] = [L2OM, "java/util/Map"]
-    jvm_exec.JDK_IFACES[L2OE] = ["java/util/Map$Entry"]
+    N[keyset_cls + f".contains:({key_desc})Z"] = lambda jj, ks, k: 1 if st(ks.native).find(box(k)) is not None else 0
+    N[keyset_cls + ".contains:(Ljava/lang/Object;)Z"] = lambda jj, ks, k: 1 if st(ks.native).find(k) is not None else 0
+    N[keyset_cls + ".stream"] = lambda jj, ks: jj.natives["java/util/ArrayList.stream"](jj, alist(cl[0] for cl in cells(ks.native, "keySet().stream")))
+    N[keyset_cls + ".size"] = lambda jj, ks: len(st(ks.native))
+    N[entry_cls + "." + get_key_name] = lambda jj, e: e.native[0].v
+    N[entry_cls + ".getKey"] = lambda jj, e: e.native[0]
+    N[entry_cls + ".getValue"] = lambda jj, e: e.native[1]
+    N[maps_cls + ".synchronize"] = lambda jj, m, *a: m
+    jvm_exec.JDK_SUPER[map_cls] = "java/lang/Object"
+    jvm_exec.JDK_IFACES[map_cls] = [iface, "java/util/Map"]
+    jvm_exec.JDK_IFACES[entry_cls] = ["java/util/Map$Entry"]
+    jvm_exec.JDK_IFACES[keyset_cls] = ["java/util/Set", "java/util/Collection"]
+
+
+def install_long2object_iterable(j):
+    _install_prim2object_iterable(j, L2O, L2OM, L2OE, LSET, "java/lang/Long", "J", "getLongKey", "long2ObjectEntrySet",
+                                  "it/unimi/dsi/fastutil/longs/Long2ObjectMaps")
+    import jvm_exec
+
     jvm_exec.JDK_IFACES[LSET] = ["java/util/Set", "it/unimi/dsi/fastutil/longs/LongSet", "java/util/Collection"]
+
+
+def install_parallel_as_sequential(j):
+    """ClusterOne_MyClustering switches to parallel streams above 30 reads (L176-189).  Their terminal operations there are collects into
+    maps and sets, whose CONTENT does not depend on the encounter order; what is read out of those containers afterwards is iterated in the
+    varied orders like everything else.  So the parallel stream is run sequentially."""
+    N = j.natives
+    N["java/util/stream/Stream.parallel"] = lambda jj, st_: st_
+    N["java/util/stream/Collectors.groupingByConcurrent"] = N["java/util/stream/Collectors.groupingBy"]
+    for k in list(N):
+        if k.endswith(".stream") and not k.startswith("java/util/stream/"):
+            N[k[:-len(".stream")] + ".parallelStream"] = N[k]
+
+
+def install_async_as_sync(j):
+    """CompletableFuture.runAsync(runnable) of generateDistanceMatrixParalell (>= 70 reads: one task per matrix row, every task writes its
+    own row and the transposed cells) run at once on the calling thread; allOf(...).join() then has nothing to wait for"""
+    N = j.natives
+    CF = "java/util/concurrent/CompletableFuture"
+
+    def run_async(jj, runnable, *a):
+        jj.call_fn(jj, runnable) if isinstance(runnable, JLambda) else jj.call_virtual(runnable, "run", "()V")
+        return JObject(CF)
+
+    N[CF + ".runAsync"] = run_async
+    N[CF + ".allOf"] = lambda jj, arr: JObject(CF)
+    N[CF + ".join"] = lambda jj, f: None
+    N[CF + ".get"] = lambda jj, f: None
+
+
+def install_int2object_iterable(j):
+    fi = "it/unimi/dsi/fastutil/ints/"
+    _install_prim2object_iterable(j, fi + "Int2ObjectOpenHashMap", fi + "Int2ObjectMap", fi + "Int2ObjectMap$Entry", fi + "IntSet$View",
+                                  "java/lang/Integer", "I", "getIntKey", "int2ObjectEntrySet", fi + "Int2ObjectMaps")
 
 
 def install_sync_executor(j):
@@ -1409,8 +1451,13 @@ def install_intset_iterable(j):
     jvm_exec.JDK_IFACES[IOS] = ["java/util/Set", "java/util/Collection", "it/unimi/dsi/fastutil/ints/IntSet", "java/lang/Iterable"]
 
 
-def cluster_once(j, side, par, stats, names, order):
-    """one ClusterOneHierarchical.call() over the reads behind `names` under one iteration order -> per read its setAttribute calls"""
+COM = "com/rw/umifinder/analyzers/clustering/ClusterOne_MyClustering"
+
+
+def cluster_once(j, side, par, stats, names, order, cls=None):
+    """one ClusterOneHierarchical.call() (or ClusterOne_MyClustering.call()) over the reads behind `names` under one iteration order ->
+    per read its setAttribute calls"""
+    cls = cls or COH
     j.hash_order = order
     reads = []
     for nm in names:
@@ -1425,7 +1472,7 @@ def cluster_once(j, side, par, stats, names, order):
     lst.native = list(reads)
     pair = j.call_static(IPAIR, "of", f"(Ljava/lang/Object;Ljava/lang/Object;)L{IPAIR};", JBox("java/lang/Boolean", 0), lst)
     try:
-        c = j.new(COH, f"(L{UPAR};L{IPAIR};L{SSTAT};)V", par, pair, stats)
+        c = j.new(cls, f"(L{UPAR};L{IPAIR};L{SSTAT};)V", par, pair, stats)
         j.call_virtual(c, "call", f"()L{IPAIR};")
         return [r.f["nanoporeRead"].f["sam"].native["calls"] for r in reads]
     except JavaThrow as e:
@@ -1574,7 +1621,58 @@ def gen_pass1(g, n_reads=60, seed=1616, five_prime=False):
     return out
 
 
-SECTIONS = {"pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+def gen_cluster_own(g, seed=1717):
+    """a-17, the other clusterer: ClusterOne_MyClustering, which the dispatch of UmiClustering$Submitter.lambda$run$2 (L239-261) takes for
+    groups of more than 100 reads"""
+    j = g.j
+    rng = random.Random(seed)
+    side = UmiSide(g, False)
+    par = side.par
+    install_intset_iterable(j)
+    install_int2object_iterable(j)
+    install_parallel_as_sequential(j)
+    install_async_as_sync(j)
+    H = j.hooks
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".setAttribute:(Ljava/lang/String;Ljava/lang/Object;)V"] = lambda jj, o, t, v: o.native["calls"].append([t, v])
+    stats = j.new_object(SSTAT)
+    for fname, fdesc in j.load(SSTAT).instance_fields:
+        if fdesc in ("Ljava/util/concurrent/atomic/AtomicLong;", "Ljava/util/concurrent/atomic/AtomicInteger;"):
+            stats.f[fname] = j.natives[fdesc[1:-1] + ".<new>"](j)
+    ASS = "com/rw/umifinder/scanstats/AllSamScanStats"
+    H[ASS + ".<clinit>:()V"] = None
+    H[ASS + ".*"] = lambda jj, *a: None
+    stats.f["scanStatsForSams"] = JObject(ASS)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("new ClusterOne_MyClustering(params, ImmutablePair.of(false, reads), scanStats).call() (ClusterOne_MyClustering.java:L59-219): "
+                  "per read the setAttribute calls made on its record.  Groups of 30-45 reads (the class itself; the shipped dispatch only sends "
+                  "it groups above 100 reads) and one group of 104 reads (parallel distance matrix and parallel streams run on one thread).  "
+                  "Each group under several iteration orders of the hash containers; all answers seen are recorded", COM, "call:()L...ImmutablePair;")
+    sizes = [8, 31, 36, 44, 40, 33, 104]
+    for idx, n in enumerate(sizes):
+        umis = [rnd_seq(rng, 12) for _ in range(max(2, n // 5))]
+        bc = rnd_seq(rng, 16)
+        names = []
+        for k in range(n):
+            u = umis[min(int(rng.random() ** 2 * len(umis)), len(umis) - 1)]
+            uu = mutate(rng, u, rng.choice([0, 0, 0, 1, 1, 2]))[:12].ljust(12, "A")
+            names.append(fake_name(rng, 1000 * idx + k, False, bc, uu, rng.random() < 0.5, rng.randrange(120, 200), rng.choice([0, 0, 0, 1, -1])))
+        orders = ("insertion", "reverse") + tuple(("shuffle", 577 * idx + 3 + 31 * t) for t in range(1 if n > 100 else 4))
+        results = [cluster_once(j, side, par, stats, names, order, cls=COM) for order in orders]
+        distinct = []
+        for r in results:
+            if r not in distinct:
+                distinct.append(r)
+        case = {"names": names, "n_orders": len(orders), "hash_orders_agree": len(distinct) == 1, "set_attribute": results[0]}
+        if len(distinct) > 1:
+            case["outcomes_over_orders"] = distinct
+        s["cases"].append(case)
+        print(f"  own clusterer {idx + 1}/{len(sizes)} n={n} distinct={len(distinct)}  {time.time() - g.t0:.0f}s", flush=True)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
 
