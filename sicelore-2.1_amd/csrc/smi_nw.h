@@ -34,7 +34,22 @@ struct AlnStats {
 // Walk: rows N..1 unrolled; inside a row only consecutive left moves loop.
 // kEnds: end5 / endn / term6 are wanted (the adapter fold); kRuns: consec / best_two are wanted (the TSO rules).  The walk
 // keeps only the bookkeeping of the statistics its caller reads.
-template <int N, bool kEnds = true, bool kRuns = true>
+//
+// Band.  Every caller aligns a candidate that passed the reference's 4-mer gate (> 1 matching 4-mers on the main diagonal of the very
+// slice that is aligned), so at least 5 pattern bases match on the diagonal and the diagonal path scores >= 10 * 5 - 5N.  A path through
+// a cell d off the diagonal has >= d gaps before and >= d after it and <= N - d diagonal steps: <= 5(N - d) - 9d (leading template gaps
+// cost 4, every other gap 5).  For 14 d > 10 (N - 5) such a path is strictly worse than the diagonal, so no optimal path enters those
+// cells -- and neither can a tie: a predecessor that ties with the chosen one lies on an optimal path itself.  Cells of the band whose
+// best predecessor was cut off hold a smaller value than the reference's matrix, but they are not on an optimal path either; the cells
+// on optimal paths, the moves out of them and their tie order are the reference's.  nw_band<N, MIN_DIAG>() is the largest |r - c| kept.
+template <int N, int MIN_DIAG>
+__host__ __device__ constexpr int nw_band() {
+    int w = 0;
+    while (w + 1 < N && 14 * (w + 1) <= 10 * (N - MIN_DIAG)) w++;
+    return w;
+}
+
+template <int N, bool kEnds = true, bool kRuns = true, int W = N>
 __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, AlnStats &out) {
     constexpr int NLO = N < 16 ? N : 16, NHI = N - NLO;
     static_assert(N <= 32, "two 32-bit move words per row");
@@ -42,20 +57,28 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
     {
         int U[N + 1];
 #pragma unroll
-        for (int c = 0; c <= N; c++) U[c] = -20 * c + 2;
+        for (int c = 0; c <= N; c++) U[c] = -20 * c + 2;  // row 0 (columns beyond the band are never read)
 #pragma unroll
         for (int r = 1; r <= N; r++) {
-            int diag = U[0];
-            U[0] = 4 * r + 2;  // 4 * (-4r) + 2 + 20r
+            const int clo = r - W > 1 ? r - W : 1, chi = r + W < N ? r + W : N;
+            int diag = U[clo - 1];
+            if (r <= W) U[0] = 4 * r + 2;  // 4 * (-4r) + 2 + 20r
             uint32_t lo = 0, hi = 0;
 #pragma unroll
-            for (int c = 1; c <= N; c++) {
+            for (int c = clo; c <= chi; c++) {
                 int m, d;  // d = diag + 41 * match bit (asm: the compiler's own choice is and/cmp/cndmask/add)
                 asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(m) : "v"(col[c - 1]), "n"(r - 1));
                 asm("v_mad_u32_u24 %0, %1, 41, %2" : "=v"(d) : "v"(m), "v"(diag));
-                const int up = U[c] - 1, left = U[c - 1] - 22;
+                int v;
+                if (c - r == W) {  // the cell above lies outside the band
+                    v = max(d, U[c - 1] - 22);
+                } else if (r - c == W) {  // the cell to the left lies outside the band
+                    v = max(d, U[c] - 1);
+                } else {
+                    const int up = U[c] - 1, left = U[c - 1] - 22;
+                    v = max(max(d, up), left);
+                }
                 diag = U[c];
-                const int v = max(max(d, up), left);
                 U[c] = (v & ~3) | 2;
                 // {v, word} >> 2: the tag enters at the top.  Inline asm: as an intrinsic the chain is re-associated
                 // into 16 masks/shifts/ors per row and every v stays live until then
@@ -64,8 +87,10 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
                 else
                     asm("v_alignbit_b32 %0, %1, %2, 2" : "=v"(hi) : "v"(v), "v"(hi));
             }
-            mlo[r - 1] = NLO < 16 ? lo >> (32 - 2 * NLO) : lo;
-            if (NHI > 0) mhi[r - 1] = hi >> (32 - 2 * (NHI > 0 ? NHI : 1));
+            // the tag of column c belongs at bits 2(c-1) of lo / 2(c-17) of hi; the last one pushed sits at the top
+            const int cl = chi < 16 ? chi : 16;
+            mlo[r - 1] = cl < 16 ? lo >> (32 - 2 * cl) : lo;
+            if (NHI > 0) mhi[r - 1] = chi > 16 ? hi >> (32 - 2 * (chi > 16 ? chi - 16 : 1)) : 0u;
             __builtin_amdgcn_sched_barrier(0);  // keep rows apart: interleaving them only costs registers
         }
     }

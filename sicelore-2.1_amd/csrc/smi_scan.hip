@@ -231,6 +231,10 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                                                  const uint8_t *__restrict__ qtail, const uint32_t *__restrict__ qsum,
                                                  size_t n_reads, ScanParams P, smi_scan_result *__restrict__ out,
                                                  smi_bc_window *__restrict__ windows) {
+    // Every aligned candidate passed gate64 on the slice that is aligned (>= 2 matching 4-mers = >= 5 matching bases on the main diagonal),
+    // which bounds how far an optimal path can leave the diagonal (smi_nw.h "Band"): 3 cells for the 10-mer, 12 for the 22-mer, 7 for the
+    // TSO.  The kernels of the shipped adapters fill the band only; the generic kernels fill the whole matrix, and the parity tests run both.
+    constexpr int kBandAd = SHIP ? nw_band<AD, 5>() : AD, kBandTso = SHIP ? nw_band<16, 5>() : 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *planes = lds;                                                           // [4][kLdsWords][kBlock]
     uint64_t *cmask = reinterpret_cast<uint64_t *>(planes + 4 * kLdsWords * kBlock);  // [3][kBlock] candidate bits
@@ -348,12 +352,12 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                         uint32_t col[AD];
 #pragma unroll
                         for (int c = 0; c < AD; c++) col[c] = col_of(SHIP ? shipped_a4<AD>(c) : P.a4(c)) & ((1u << AD) - 1u);
-                        nw_full<AD, true, false>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
+                        nw_full<AD, true, false, kBandAd>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
                     } else {
                         uint32_t col[16];
 #pragma unroll
                         for (int c = 0; c < 16; c++) col[c] = col_of(tso4(c)) & 0xFFFFu;
-                        nw_full<16, false, true>(col, 0, st);  // the TSO rules read ne, nmis, ins, del, consec, best_two
+                        nw_full<16, false, true, kBandTso>(col, 0, st);  // the TSO rules read ne, nmis, ins, del, consec, best_two
                     }
                     uint32_t *o = ent + tid * 5;
                     o[0] = __float_as_uint(st.ne);
