@@ -434,7 +434,7 @@ __device__ __forceinline__ int adapter_scan(const ReadPlanes &rp, int at_begin, 
 #pragma unroll
         for (int c = 0; c < kAdLen; c++) col[c] = col_bits(c, lane) & ((1u << kAdLen) - 1u);
         AlnStats st;
-        nw_full<kAdLen, false, false>(col, 0, st);  // only ne and nmis are read
+        nw_full<kAdLen, false, false, nw_band<kAdLen, 6>()>(col, 0, st);  // only ne and nmis are read; the gate asked for 3 matching 4-mers = 6 diagonal matches
         ne = st.ne;
         nmis = st.nmis;
     }
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256, PART == 1 ? 4 : 2) void k_chimera(const uint32
                             }
                             col[c] = o ? r : f;
                         }
-                        ne = nw_errors<kTsoLen>(col);
+                        ne = nw_errors<kTsoLen, nw_band<kTsoLen, 5>()>(col);  // gate_two: >= 5 diagonal matches (smi_nw.h "Band")
                     }
                     const float maxe = (float)P.tso_max;
                     int delta_l = 1;

@@ -200,7 +200,7 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
 //   cell = (4*score + 2 + 20*r) << 11 | q << 5 | lead      q = 32 + #up - #match on the best path
 // On an N x N alignment #x = N + #up - #match (#up = #left, #diag = N - #up), so one counter is enough; 6 VALU ops
 // per cell.
-template <int N>
+template <int N, int W = N>
 __device__ __forceinline__ float nw_errors(const uint32_t (&col)[N]) {
     static_assert(N <= 27, "field widths: lead 5 bits, q 6 bits");
     constexpr int SH = 11;
@@ -210,16 +210,24 @@ __device__ __forceinline__ float nw_errors(const uint32_t (&col)[N]) {
     for (int c = 0; c <= N; c++) U[c] = ((-20 * c + 2) << SH) + (32 << 5);
 #pragma unroll
     for (int r = 1; r <= N; r++) {
-        int diag = U[0];
-        U[0] = ((4 * r + 2) << SH) + ((32 + r) << 5) + r;
+        const int clo = r - W > 1 ? r - W : 1, chi = r + W < N ? r + W : N;  // the band of nw_full
+        int diag = U[clo - 1];
+        if (r <= W) U[0] = ((4 * r + 2) << SH) + ((32 + r) << 5) + r;
 #pragma unroll
-        for (int c = 1; c <= N; c++) {
+        for (int c = clo; c <= chi; c++) {
             int m, d;
             asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(m) : "v"(col[c - 1]), "n"(r - 1));
             asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(m), "s"(kmatch), "v"(diag));
-            const int up = U[c] - (1 << SH) + 32, left = U[c - 1] - (22 << SH);
+            int v;
+            if (c - r == W) {
+                v = max(d, U[c - 1] - (22 << SH));
+            } else if (r - c == W) {
+                v = max(d, U[c] - (1 << SH) + 32);
+            } else {
+                const int up = U[c] - (1 << SH) + 32, left = U[c - 1] - (22 << SH);
+                v = max(max(d, up), left);
+            }
             diag = U[c];
-            const int v = max(max(d, up), left);
             U[c] = (v & ~(3 << SH)) | (2 << SH);
         }
         __builtin_amdgcn_sched_barrier(0);
