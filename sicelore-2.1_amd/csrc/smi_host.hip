@@ -312,9 +312,11 @@ extern "C" int smi_format_read_name(const char *read_name, const char *raw_seq, 
     NameSink sink{out, 0, cap > 0 ? (int)std::min<size_t>(cap - 1, 1u << 30) : 0};
     for (const char *c = read_name; *c && *c != ' '; c++) sink.put(*c);  // getReadName().split(" ")[0]
     bool quals_set = false;
+    const NameWindow w = name_window(*scan, five_prime != 0, len);
+    auto at = [&](const char *raw, int k) { return raw[w.rev ? w.lo + w.n_chars - 1 - k : w.lo + k]; };
     const int st = append_name_suffix(
-        sink, *scan, bc, rank, read_id, five_prime != 0, len, [&](int i) { return raw_seq[i]; },
-        [&](int i) { return raw_qual[i]; }, &quals_set);
+        sink, *scan, bc, rank, read_id, five_prime != 0, len, [&](int k) { return at(raw_seq, k); },
+        [&](int k) { return at(raw_qual, k); }, &quals_set);
     if (st == NAME_RANGE) {
         set_error("smi_format_read_name: X=/Q= range outside the read (the reference throws here)");
         return SMI_ERR_INVALID;

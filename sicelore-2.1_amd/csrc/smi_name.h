@@ -42,6 +42,29 @@ struct NameSink {
         } else
             put_u64((unsigned long long)v);
     }
+    // the same digits for a value that fits 32 bits (coordinates, counts): no 64-bit division, which a GPU lane emulates
+    SMI_HD void put_u32(uint32_t v) {
+        // digits from the top by constant divisors: no digit buffer (an indexed local array is scratch memory on the device)
+        bool started = false;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+        for (uint32_t div = 1000000000u; div >= 1u; div /= 10u) {
+            const uint32_t d = v / div;
+            v -= d * div;
+            if (d || started || div == 1u) {
+                put((char)('0' + (int)d));
+                started = true;
+            }
+        }
+    }
+    SMI_HD void put_i32(int v) {
+        if (v < 0) {
+            put('-');
+            put_u32(0u - (uint32_t)v);
+        } else
+            put_u32((uint32_t)v);
+    }
 };
 
 // FastqRecordExt.REVERSE_COMPLEMENT (L72-104): a char[254] that is zero except for these letters
@@ -77,24 +100,38 @@ SMI_HD void put_dec1(NameSink &s, float f) {
     if (frac > 0.5 || (frac == 0.5 && (q & 1))) q++;
     const long long ip = q / 10, tenth = q % 10;
     if (neg && q != 0) s.put('-');
+    auto put_ip = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        s.put_u32((uint32_t)ip);  // the device formats mean qualities only (< 256)
+#else
+        if (ip <= 0xFFFFFFFFll)
+            s.put_u32((uint32_t)ip);
+        else
+            s.put_u64((unsigned long long)ip);
+#endif
+    };
     if (tenth == 0)
-        s.put_u64((unsigned long long)ip);
+        put_ip();
     else {
-        if (ip != 0) s.put_u64((unsigned long long)ip);
+        if (ip != 0) put_ip();
         s.put('.');
         s.put((char)('0' + (int)tenth));
     }
 }
 
 SMI_HD void put_base36(NameSink &s, uint32_t v) {  // FastqRecordExt$NumberToAndFromAscii.convertInt = Integer.toString(id, 36), L524
-    char t[8];
-    int k = 0;
-    do {
-        const uint32_t d = v % 36u;
-        t[k++] = (char)(d < 10 ? '0' + d : 'a' + (d - 10));
-        v /= 36u;
-    } while (v);
-    while (k) s.put(t[--k]);
+    bool started = false;  // digits from the top, as in put_u32: 36^6 > 2^31, seven digits at most
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (uint32_t div = 2176782336u; div >= 1u; div /= 36u) {
+        const uint32_t d = v / div;
+        v -= d * div;
+        if (d || started || div == 1u) {
+            s.put((char)(d < 10 ? '0' + d : 'a' + (d - 10)));
+            started = true;
+        }
+    }
 }
 
 SMI_HD void put_kmer16(NameSink &s, uint32_t key) {  // TWOBIT_TO_BASE_ARRAY: A G C T
@@ -106,13 +143,43 @@ SMI_HD void put_kmer16(NameSink &s, uint32_t key) {  // TWOBIT_TO_BASE_ARRAY: A 
 
 enum { NAME_OK = 0, NAME_RANGE = 1 };  // NAME_RANGE: the X= / Q= range leaves the read (the reference throws from substring / skip)
 
+// The X= and Q= fields read one window of the STRANDED read: Q= averages stranded positions begin-1 .. end-1 (0-based), X= prints
+// begin .. end-1, i.e. the window without its first character.  3': stranded[AE-40 .. AE+2] (L253-254), 5': stranded[AE-2 .. AE+39]
+// (L250-251), so the window has 44 resp. 43 characters.  In the RAW read it is the contiguous range raw[lo .. lo + n_chars), read
+// backwards (and complemented, for the bases) when the read passed on the reverse strand.
+struct NameWindow {
+    bool has;     // the name carries X= / Q= (passed, adapter found, window inside the read)
+    int status;   // NAME_RANGE: the reference throws
+    bool rev;
+    int lo, n_chars;
+};
+constexpr int kNameWindowMax = 44;
+SMI_HD NameWindow name_window(const smi_scan_result &scan, bool five_prime, int len) {
+    NameWindow w{false, NAME_OK, false, 0, 0};
+    const bool fwd = scan.flags & SMI_F_PASSED_FWD, rev = scan.flags & SMI_F_PASSED_REV;
+    if ((!fwd && !rev) || !scan.found) return w;
+    const int begin = five_prime ? scan.adapter_end - 3 : scan.adapter_end - 40 - 1;
+    const int end = five_prime ? scan.adapter_end + 39 : scan.adapter_end + 2;
+    if (begin < 0) return w;  // L257-259
+    if (end > len || begin - 1 < 0) {
+        w.status = NAME_RANGE;
+        return w;
+    }
+    w.has = true;
+    w.rev = rev;
+    w.n_chars = end - begin + 1;
+    w.lo = rev ? len - end : begin - 1;
+    return w;
+}
+
 // Appends what getRecordForWriting puts behind `readName.split(" ")[0]` (L220; the caller has written that token).
-// seq_at(i) / qual_at(i): base / quality character i (0-based) of the RAW read of length len.
+// seq_w(k) / qual_w(k): character k (0 <= k < n_chars) of the window of name_window() in STRANDED order, the base not yet complemented
+// (host: raw[rev ? lo + n_chars - 1 - k : lo + k]; the device writer loads the window with a few wide loads before it formats).
 // Returns NAME_OK or NAME_RANGE; *stranded_ok = false in the "Beginrange inconsistent" case (L257-259: the name keeps no
 // suffix and the record is written with the stranded sequence and a null quality string).
 template <class SeqAt, class QualAt>
 SMI_HD int append_name_suffix(NameSink &s, const smi_scan_result &scan, const smi_bc_result *bc, int rank, uint32_t read_id,
-                              bool five_prime, int len, SeqAt seq_at, QualAt qual_at, bool *quals_set) {
+                              bool five_prime, int len, SeqAt seq_w, QualAt qual_w, bool *quals_set) {
     *quals_set = true;
     const bool fwd = scan.flags & SMI_F_PASSED_FWD, rev = scan.flags & SMI_F_PASSED_REV;
     if (!fwd && !rev) {
@@ -121,26 +188,24 @@ SMI_HD int append_name_suffix(NameSink &s, const smi_scan_result &scan, const sm
     }
     *quals_set = false;
     if (!scan.found) return NAME_OK;  // the suffix is only attached inside `if (adapterFound())` (L247-298)
-    // 3': stranded[AE-40 .. AE+2] (L253-254); 5': stranded[AE-2 .. AE+39] (L250-251)
-    const int begin = five_prime ? scan.adapter_end - 3 : scan.adapter_end - 40 - 1;
-    const int end = five_prime ? scan.adapter_end + 39 : scan.adapter_end + 2;
-    if (begin < 0) return NAME_OK;  // L257-259
-    if (end > len || begin - 1 < 0) return NAME_RANGE;
+    const NameWindow nw = name_window(scan, five_prime, len);
+    if (nw.status == NAME_RANGE) return NAME_RANGE;
+    if (!nw.has) return NAME_OK;  // L257-259
     *quals_set = true;
     s.puts(rev ? "_REV_" : "_FWD_");
     if (scan.polya_end != 0) {
         s.puts("PS=");
-        s.put_int(scan.polya_start);
+        s.put_i32(scan.polya_start);
         s.puts("_PE=");
-        s.put_int(scan.polya_end);
+        s.put_i32(scan.polya_end);
         s.put('_');
     }
     s.puts("AE=");
-    s.put_int(scan.adapter_end);
+    s.put_i32(scan.adapter_end);
     s.put('_');
     if (scan.tso_end != 0) {
         s.puts("T=");
-        s.put_int(scan.tso_end);
+        s.put_i32(scan.tso_end);
         s.put('_');
     }
     const bool has_bc = bc && bc->found == 1;
@@ -151,27 +216,35 @@ SMI_HD int append_name_suffix(NameSink &s, const smi_scan_result &scan, const sm
         s.puts("bc=");
         put_kmer16(s, bc->bc);
         s.puts("_ed=");
-        s.put_int(bc->ed);
+        s.put_i32(bc->ed);
         s.puts("_ed_sec=");
-        s.put_int(bc->ed_sec);
+        s.put_i32(bc->ed_sec);
         s.puts("_bcStart=");
-        s.put_int(bc_start);
+        s.put_i32(bc_start);
         s.puts("_bcEnd=");
-        s.put_int(bc_end);
+        s.put_i32(bc_end);
         s.put('_');
         if (rank > 0) {
             s.puts("rk=");
-            s.put_int(rank);
+            s.put_i32(rank);
             s.put('_');
         }
     }
     s.puts("X=");
-    for (int i = begin; i < end; i++) s.put(rev ? rc_char((unsigned char)seq_at(len - 1 - i)) : (char)seq_at(i));
+    // constant trip counts with a guard: unrolled on the device, where the window sits in registers
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 1; k < kNameWindowMax; k++)
+        if (k < nw.n_chars) s.put(rev ? rc_char((unsigned char)seq_w(k)) : (char)seq_w(k));
     s.puts("_Q=");
-    long long sum = 0;
-    int cnt = 0;
-    for (int i = begin - 1; i <= end - 1 && i < len; i++, cnt++) sum += (int)(unsigned char)(rev ? qual_at(len - 1 - i) : qual_at(i)) - 33;
-    put_dec1(s, (float)((double)sum / (double)cnt));
+    int sum = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < kNameWindowMax; k++)
+        if (k < nw.n_chars) sum += (int)(unsigned char)qual_w(k) - 33;
+    put_dec1(s, (float)((double)sum / (double)nw.n_chars));
     s.put('_');
     put_base36(s, read_id);
     if (has_bc) {

@@ -39,18 +39,21 @@ struct WriteArgs {
     int five_prime, trim;
 };
 
-// what a record consists of, derived the same way by K-WLEN and K-WRITE
-struct RecPlan {
-    size_t src;       // input record the name and '+' line come from
-    int frag;         // fragment number, -1: not split
-    uint64_t name_beg, name_tok_len;  // readName.split(" ")[0] in the text
-    bool name_had_blank;
-    uint64_t qh_beg, qh_len;          // text behind '+'
-    uint64_t base;    // offset of the (fragment's) raw read in reads / quals
-    int len;          // its length
-    bool passed, rev, forced_failed;
-    int cut_beg, cut_len;  // range of the stranded (passed) or raw (failed) sequence that is written, 0-based
+// What a record consists of: derived once, by K-WLEN, and handed to K-WNAME and K-WRITE as one 64-byte row (a wave of K-WRITE used to
+// walk frag_src -> line table -> name line -> offsets / scan / bc itself: five dependent round trips before its first copy).
+struct __attribute__((aligned(16))) RecPlan {
+    uint64_t name_beg;   // readName.split(" ")[0] in the text
+    uint64_t qh_beg;     // text behind '+'
+    uint64_t rd, ql;     // the (fragment's) raw bases / qualities: positions in `text` (bstart given) or in reads / quals
+    uint32_t name_tok_len, qh_len;
+    int32_t len;         // raw length
+    int32_t cut_beg, cut_len;  // range of the stranded (passed) or raw (failed) sequence that is written, 0-based
+    uint32_t src;        // input record the name and '+' line come from
+    int32_t frag;        // fragment number, -1: not split
+    uint32_t flags;      // kPassed | kRev | kForcedFailed | kHadBlank
 };
+static_assert(sizeof(RecPlan) == 64, "one plan row = four 16-byte loads");
+enum : uint32_t { kPassed = 1u, kRev = 2u, kForcedFailed = 4u, kHadBlank = 8u };
 
 __device__ __forceinline__ uint64_t line_end(const WriteArgs &A, uint64_t L) {
     uint64_t e = A.line_start[L + 1] - 1;
@@ -58,31 +61,54 @@ __device__ __forceinline__ uint64_t line_end(const WriteArgs &A, uint64_t L) {
     return e;
 }
 
+// first blank of text[beg, end) (or end): 16 characters per step while the loads stay in front of `safe` (a position inside the same
+// record), SWAR zero-byte test on x ^ "    "
+__device__ __forceinline__ uint64_t find_blank(const uint8_t *text, uint64_t beg, uint64_t end, uint64_t safe) {
+    uint64_t t = beg;
+    while (t < end && t + 16 <= safe) {
+        uint32_t w[4];
+        __builtin_memcpy(w, text + t, 16);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = w[k] ^ 0x20202020u;
+            const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
+            if (z) {
+                const uint64_t hit = t + 4 * k + (__builtin_ctz(z) >> 3);
+                return hit < end ? hit : end;
+            }
+        }
+        t += 16;
+    }
+    while (t < end && text[t] != ' ') t++;
+    return t < end ? t : end;
+}
+
 __device__ __forceinline__ RecPlan plan_record(const WriteArgs &A, size_t i) {
     RecPlan R;
     const uint32_t fs = A.frag_src ? A.frag_src[i] : (uint32_t)(i << 2);
-    R.src = A.frag_src ? (size_t)(fs >> 2) : i;
+    R.src = A.frag_src ? (fs >> 2) : (uint32_t)i;
     const smi_chimera_result *ch = A.chim ? A.chim + R.src : nullptr;
     R.frag = (ch && ch->n_split) ? (int)(fs & 3u) : -1;
-    R.forced_failed = ch && (ch->flags & SMI_CHIM_MULTI);  // MULTI_CHIMERIC_READS_DISCARDED | FAILED: never scanned (Parser.java:L92)
-    const uint64_t l0 = A.line_start[4 * R.src], e0 = line_end(A, 4 * R.src);
+    const bool forced_failed = ch && (ch->flags & SMI_CHIM_MULTI);  // MULTI_CHIMERIC_READS_DISCARDED | FAILED: never scanned (Parser.java:L92)
+    const uint64_t l0 = A.line_start[4 * (size_t)R.src], e0 = line_end(A, 4 * (size_t)R.src);
+    const uint64_t l2 = A.line_start[4 * (size_t)R.src + 2];
     R.name_beg = l0 + 1;
-    uint64_t t = R.name_beg;
-    while (t < e0 && A.text[t] != ' ') t++;
-    R.name_tok_len = t - R.name_beg;
-    R.name_had_blank = t < e0;
-    const uint64_t l2 = A.line_start[4 * R.src + 2];
+    const uint64_t t = find_blank(A.text, R.name_beg, e0, l2);
+    R.name_tok_len = (uint32_t)(t - R.name_beg);
     R.qh_beg = l2 + 1;
-    R.qh_len = line_end(A, 4 * R.src + 2) - R.qh_beg;
-    R.base = A.offsets[i];
-    R.len = (int)(A.offsets[i + 1] - A.offsets[i]);
+    R.qh_len = (uint32_t)(line_end(A, 4 * (size_t)R.src + 2) - R.qh_beg);
+    const uint64_t base = A.offsets[i];
+    R.rd = A.bstart ? A.bstart[i] : base;
+    R.ql = A.bstart ? A.qstart[i] : base;
+    R.len = (int)(A.offsets[i + 1] - base);
     const smi_scan_result &sc = A.scan[i];
-    R.passed = !R.forced_failed && (sc.flags & (SMI_F_PASSED_FWD | SMI_F_PASSED_REV));
-    R.rev = R.passed && (sc.flags & SMI_F_PASSED_REV);
+    const bool passed = !forced_failed && (sc.flags & (SMI_F_PASSED_FWD | SMI_F_PASSED_REV));
+    R.flags = (passed ? kPassed : 0u) | ((passed && (sc.flags & SMI_F_PASSED_REV)) ? kRev : 0u) | (forced_failed ? kForcedFailed : 0u) |
+              (t < e0 ? kHadBlank : 0u);
     R.cut_beg = 0;
     R.cut_len = R.len;
     const smi_bc_result &b = A.bc[i];
-    if (R.passed && A.trim && b.found == 1) {
+    if (passed && A.trim && b.found == 1) {
         // partOfSeqToWrite (L210-217): from the TSO end (5': 30 bases behind the barcode start) to the polyA start
         const int bc_start = sc.adapter_end + 1 + b.offset;
         const int beg = A.five_prime ? bc_start + 30 : (sc.tso_end != 0 ? sc.tso_end : 1);
@@ -106,29 +132,72 @@ __device__ __forceinline__ const char *split_tag(int reason) {  // ChimeraFinder
     }
 }
 
+// The characters behind X= and Q= (name_window of smi_name.h) in registers, in stranded order: a few wide loads that are in flight
+// together, instead of one dependent byte load per character from inside the formatter.
+struct WindowRegs {
+    uint32_t w[kNameWindowMax / 4];
+    __device__ __forceinline__ uint8_t at(int k) const { return (uint8_t)(w[k >> 2] >> (8 * (k & 3))); }  // k is a constant after unrolling
+};
+__device__ __forceinline__ WindowRegs load_window(const uint8_t *raw, const NameWindow &nw) {
+    constexpr int ND = kNameWindowMax / 4;
+    uint32_t v[ND];
+    const uint8_t *p = raw + nw.lo;
+#pragma unroll
+    for (int d = 0; d < ND; d++) {
+        v[d] = 0;
+        if (4 * d + 4 <= nw.n_chars)
+            __builtin_memcpy(&v[d], p + 4 * d, 4);
+        else
+            for (int k = 4 * d; k < nw.n_chars; k++) v[d] |= (uint32_t)p[k] << (8 * (k - 4 * d));
+    }
+    WindowRegs r;
+    if (!nw.rev) {
+#pragma unroll
+        for (int d = 0; d < ND; d++) r.w[d] = v[d];
+        return r;
+    }
+    // stranded character k = raw character n_chars - 1 - k: reverse all 44 bytes, then drop the 44 - n_chars bytes that came to the front
+    uint32_t t[ND + 1];
+#pragma unroll
+    for (int d = 0; d < ND; d++) t[d] = __builtin_bswap32(v[ND - 1 - d]);
+    t[ND] = 0;
+    const int drop = kNameWindowMax - nw.n_chars;  // 0 (3') or 1 (5')
+#pragma unroll
+    for (int d = 0; d < ND; d++) r.w[d] = drop == 0 ? t[d] : (drop == 1 ? __builtin_amdgcn_alignbyte(t[d + 1], t[d], 1) : 0u);
+    return r;
+}
+
 // what follows the name token: fragment tag + suffix; returns the status of append_name_suffix
 __device__ __forceinline__ int format_record_suffix(const WriteArgs &A, const RecPlan &R, size_t i, uint32_t read_id, NameSink &s,
                                                     bool *quals_set) {
-    if (R.frag >= 0 && R.name_had_blank) {
+    if (R.frag >= 0 && (R.flags & kHadBlank)) {
         // readName.replaceFirst(" ", "_" + tag + "sp" + (k + 1) + " "): fragments before a cut carry that cut's tag, the
         // last fragment the tag of the cut it starts at
         const smi_chimera_result &ch = A.chim[R.src];
         const int cut = R.frag < ch.n_split ? R.frag : ch.n_split - 1;
         s.put('_');
-        s.puts(split_tag(ch.reason[cut]));
+        s.puts(split_tag(cut == 0 ? ch.reason[0] : ch.reason[1]));  // (an indexed member of a struct held in registers would go through scratch)
         s.puts("sp");
-        s.put_int(R.frag + 1);
+        s.put_i32(R.frag + 1);
     }
-    if (R.forced_failed) {
+    if (R.flags & kForcedFailed) {
         s.puts("_FAILED ");
         *quals_set = true;
         return NAME_OK;
     }
-    const uint8_t *rd = A.bstart ? A.text + A.bstart[i] : A.reads + R.base, *ql = A.bstart ? A.text + A.qstart[i] : A.quals + R.base;
-    const smi_bc_result *b = A.bc[i].found == 1 ? A.bc + i : nullptr;
+    const smi_scan_result sc = A.scan[i];
+    const smi_bc_result bcr = A.bc[i];
+    const NameWindow nw = name_window(sc, A.five_prime != 0, R.len);
+    WindowRegs ws, wq;
+#pragma unroll
+    for (int d = 0; d < kNameWindowMax / 4; d++) ws.w[d] = wq.w[d] = 0;
+    if (nw.has && nw.n_chars >= kNameWindowMax - 1) {  // the two shipped layouts: 44 (3') and 43 (5') characters
+        ws = load_window((A.bstart ? A.text : A.reads) + R.rd, nw);
+        wq = load_window((A.bstart ? A.text : A.quals) + R.ql, nw);
+    }
     return append_name_suffix(
-        s, A.scan[i], b, A.rank ? A.rank[i] : 0, read_id, A.five_prime != 0, R.len, [&](int k) { return (char)rd[k]; },
-        [&](int k) { return (char)ql[k]; }, quals_set);
+        s, sc, &bcr /* has_bc = found == 1, tested inside */, A.rank ? A.rank[i] : 0, read_id, A.five_prime != 0, R.len, [&](int k) { return (char)ws.at(k); },
+        [&](int k) { return (char)wq.at(k); }, quals_set);
 }
 
 // '@' name LF bases LF '+' header LF qualities LF
@@ -136,12 +205,14 @@ __device__ __forceinline__ uint64_t record_bytes(const RecPlan &R, int name_len,
     return 1ull + name_len + 1 + R.cut_len + 1 + 1 + R.qh_len + 1 + (quals_set ? (uint64_t)R.cut_len : 4ull) + 1;
 }
 
-__global__ void k_write_len(WriteArgs A, uint64_t *__restrict__ len_passed, uint64_t *__restrict__ len_failed,
+__global__ void k_write_len(WriteArgs A, RecPlan *__restrict__ plan, uint64_t *__restrict__ len_passed, uint64_t *__restrict__ len_failed,
                             uint64_t *__restrict__ cnt_passed, uint32_t *__restrict__ sfx_len, uint8_t *__restrict__ is_passed,
                             uint32_t *__restrict__ err) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     const RecPlan R = plan_record(A, i);
+    plan[i] = R;
+    const bool passed = R.flags & kPassed;
     NameSink s{nullptr, 0, 0};  // counts only
     bool quals_set = true;
     // the base-36 id changes the length, and it is only known after the scan of the passed flags: K-WLEN therefore
@@ -150,11 +221,11 @@ __global__ void k_write_len(WriteArgs A, uint64_t *__restrict__ len_passed, uint
     if (st == NAME_RANGE) atomicOr(err, SMI_WR_NAME_RANGE);
     if (s.n + 8 > kSuffixCap) atomicOr(err, SMI_WR_NAME_TOO_LONG);
     const uint64_t bytes = record_bytes(R, (int)R.name_tok_len + s.n, quals_set);
-    len_passed[i] = R.passed ? bytes : 0;
-    len_failed[i] = R.passed ? 0 : bytes;
-    cnt_passed[i] = R.passed ? 1 : 0;
+    len_passed[i] = passed ? bytes : 0;
+    len_failed[i] = passed ? 0 : bytes;
+    cnt_passed[i] = passed ? 1 : 0;
     sfx_len[i] = (uint32_t)s.n | (quals_set ? 0x80000000u : 0u);
-    is_passed[i] = R.passed ? 1 : 0;
+    is_passed[i] = passed ? 1 : 0;
 }
 
 // width of Integer.toString(id, 36) minus the one digit K-WLEN counted for id 0
@@ -185,7 +256,7 @@ __global__ void k_write_idlen(const WriteArgs A, const uint64_t *__restrict__ or
 // over records (inside K-WRITE the other 63 lanes of the record's wave would wait for it)
 constexpr int kNameBlock = 128;   // threads (= records) per block of K-WNAME
 constexpr int kNameStage = 260;   // bytes of LDS per record: 65 words, so equal byte offsets of neighbouring records fall into different banks
-__global__ __launch_bounds__(kNameBlock) void k_write_name(WriteArgs A, const uint64_t *__restrict__ off_passed,
+__global__ __launch_bounds__(kNameBlock) void k_write_name(WriteArgs A, const RecPlan *__restrict__ plan, const uint64_t *__restrict__ off_passed,
                                                            const uint64_t *__restrict__ off_failed, const uint64_t *__restrict__ ord_passed,
                                                            const uint32_t *__restrict__ sfx_len, uint8_t *__restrict__ out_passed,
                                                            size_t cap_passed, uint8_t *__restrict__ out_failed, size_t cap_failed) {
@@ -200,11 +271,12 @@ __global__ __launch_bounds__(kNameBlock) void k_write_name(WriteArgs A, const ui
     int n_copy = 0;
     uint64_t d = 0;
     if (i < A.n) {
-        const RecPlan R = plan_record(A, i);
+        const RecPlan R = plan[i];
+        const bool passed = R.flags & kPassed;
         const int n_sfx = (int)(sfx_len[i] & 0x7FFFFFFFu);
-        const uint64_t pos = (R.passed ? off_passed[i] : off_failed[i]) + 1 + R.name_tok_len;
-        if (pos + n_sfx <= (R.passed ? cap_passed : cap_failed)) {  // otherwise K-WRITE reports the overflow
-            char *out = reinterpret_cast<char *>(R.passed ? out_passed : out_failed) + pos;
+        const uint64_t pos = (passed ? off_passed[i] : off_failed[i]) + 1 + R.name_tok_len;
+        if (pos + n_sfx <= (passed ? cap_passed : cap_failed)) {  // otherwise K-WRITE reports the overflow
+            char *out = reinterpret_cast<char *>(passed ? out_passed : out_failed) + pos;
             const bool staged = n_sfx <= kNameStage;
             NameSink s{staged ? stage[t] : out, 0, n_sfx};
             bool quals_set = true;
@@ -226,10 +298,24 @@ __global__ __launch_bounds__(kNameBlock) void k_write_name(WriteArgs A, const ui
     }
 }
 
-// K-WRITE: one wave per record copies everything but the suffix.  Every output byte is ONE load from a computed address
-// (text, reads, qualities or the literal table in LDS, through generic pointers) chosen with selects, so the four loads
-// of a lane are in flight together; four bytes per lane go out as one aligned dword.
-__global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__restrict__ off_passed,
+// reverse complement of four bases at once.  (c >> 1) & 7 separates A C G T N (0 1 3 2 7), so one v_perm_b32 against an 8-byte table
+// complements a dword and a second one against the identity table proves that all four characters were one of the five; anything
+// else (lower case, IUPAC codes, which FastqRecordExt.REVERSE_COMPLEMENT also maps, and the characters it maps to 0) takes the table in LDS.
+__device__ __forceinline__ bool rc4(uint32_t w, uint32_t &out) {
+    const uint32_t idx = (w >> 1) & 0x07070707u;
+    // byte j of {hi:lo} = the character with index j:   0 'A'  1 'C'  2 'T'  3 'G'  4 -  5 -  6 -  7 'N'
+    const uint32_t id_lo = 'A' | ('C' << 8) | ('T' << 16) | ((uint32_t)'G' << 24), id_hi = (uint32_t)'N' << 24;
+    const uint32_t rc_lo = 'T' | ('G' << 8) | ('A' << 16) | ((uint32_t)'C' << 24), rc_hi = (uint32_t)'N' << 24;
+    out = __builtin_amdgcn_perm(rc_hi, rc_lo, idx);
+    return __builtin_amdgcn_perm(id_hi, id_lo, idx) == w;
+}
+
+// K-WRITE: one wave per record copies everything but the suffix.  The two long runs of a record -- bases and qualities -- go out in
+// 16-byte pieces per lane: an unaligned 16-byte load from the text (mirrored, and complemented with v_perm_b32, for a read that passed
+// on the reverse strand) and an aligned 16-byte store, all loads of a record in flight before its first store.  What is left -- '@',
+// the name token, the line ends, the '+' line and the few bytes of each run in front of / behind its 16-byte aligned part -- is copied
+// a byte per lane from an address chosen with selects.
+__global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__restrict__ plan, const uint64_t *__restrict__ off_passed,
                                                const uint64_t *__restrict__ off_failed, const uint32_t *__restrict__ sfx_len,
                                                uint8_t *__restrict__ out_passed, size_t cap_passed, uint8_t *__restrict__ out_failed,
                                                size_t cap_failed, uint64_t *__restrict__ rec_off, uint32_t *__restrict__ err) {
@@ -242,38 +328,10 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
     const int lane = threadIdx.x & 63;
     const size_t i = blockIdx.x * (size_t)4 + (threadIdx.x >> 6);
     if (i >= A.n) return;
-    // ---- plan (wave-uniform values; the token end is searched 64 characters at a time) ---------------------------------
-    const uint32_t fs = A.frag_src ? A.frag_src[i] : 0u;
-    const size_t src = A.frag_src ? (size_t)(fs >> 2) : i;
-    const bool forced_failed = A.chim && (A.chim[src].flags & SMI_CHIM_MULTI);
-    const uint64_t name_beg = A.line_start[4 * src] + 1, e0 = line_end(A, 4 * src);
-    uint64_t t = name_beg;
-    for (;; t += 64) {
-        const bool stop = t + lane >= e0 || A.text[t + lane] == ' ';
-        const unsigned long long m = __ballot(stop);
-        if (m) {
-            t += __builtin_ctzll(m);
-            break;
-        }
-    }
-    const uint64_t tok_len = t - name_beg;
-    const uint64_t qh_beg = A.line_start[4 * src + 2] + 1, qh_len = line_end(A, 4 * src + 2) - qh_beg;
-    const uint64_t base = A.offsets[i];
-    const int len = (int)(A.offsets[i + 1] - base);
-    const smi_scan_result &sc = A.scan[i];
-    const bool passed = !forced_failed && (sc.flags & (SMI_F_PASSED_FWD | SMI_F_PASSED_REV));
-    const bool rev = passed && (sc.flags & SMI_F_PASSED_REV);
-    int cut_beg = 0, cut_len = len;
-    const smi_bc_result &b = A.bc[i];
-    if (passed && A.trim && b.found == 1) {  // same rule as plan_record
-        const int bc_start = sc.adapter_end + 1 + b.offset;
-        const int beg = A.five_prime ? bc_start + 30 : (sc.tso_end != 0 ? sc.tso_end : 1);
-        const int end = sc.polya_end != 0 ? sc.polya_start : len;
-        if (beg < end) {
-            cut_beg = min(max(beg - 1, 0), len);
-            cut_len = max(min(end, len) - cut_beg, 0);
-        }
-    }
+    const RecPlan R = plan[i];  // the same 64 bytes for every lane of the wave
+    const bool passed = R.flags & kPassed, rev = R.flags & kRev;
+    const uint64_t tok_len = R.name_tok_len, qh_len = R.qh_len;
+    const int len = R.len, cut_beg = R.cut_beg, cut_len = R.cut_len;
     const uint32_t sl = sfx_len[i];
     const bool qset = sl >> 31;
     const uint64_t n_sfx = sl & 0x7FFFFFFFu;
@@ -288,8 +346,8 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
         if (lane == 0) atomicOr(err, SMI_WR_OVERFLOW);
         return;
     }
-    const uint8_t *rd = A.bstart ? A.text + A.bstart[i] : A.reads + base, *ql = A.bstart ? A.text + A.qstart[i] : A.quals + base;
-    const uint8_t *tok = A.text + name_beg, *qh = A.text + qh_beg;
+    const uint8_t *rd = (A.bstart ? A.text : A.reads) + R.rd, *ql = (A.bstart ? A.text : A.quals) + R.ql;
+    const uint8_t *tok = A.text + R.name_beg, *qh = A.text + R.qh_beg;
     const uint8_t *lit = reinterpret_cast<const uint8_t *>(literals);
     const uint8_t *lut = reinterpret_cast<const uint8_t *>(rc_lut);
     // bases / qualities: position k of the written range is raw index cut_beg + k, or len - 1 - cut_beg - k when reversed
@@ -298,6 +356,59 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
     const uint8_t *qual0 = qset ? ql + (rev ? len - 1 - cut_beg : cut_beg) : lit + 3;
     const int64_t qstep = qset ? step : 1;
     const uint32_t rc_sel = rev ? 256u : 0u;
+    // ---- the 16-byte aligned inside of the two runs --------------------------------------------------------------------------------
+    // output addresses [lo, hi) of a run; its aligned part is [a0, a1) (empty: a0 = a1 = lo)
+    const uint64_t obase = (uint64_t)(uintptr_t)out;
+    const uint64_t seq_lo = off + p_seq, seq_hi = seq_lo + (uint64_t)cut_len, q_lo = off + p_q, q_hi = q_lo + (qset ? qlen : 0);
+    auto aligned_part = [&](uint64_t lo, uint64_t hi, uint64_t &a0, uint64_t &a1) {
+        a0 = ((obase + lo + 15) & ~15ull) - obase;
+        a1 = ((obase + hi) & ~15ull) - obase;
+        if (a0 >= a1) a0 = a1 = lo;
+    };
+    uint64_t sa0, sa1, qa0, qa1;
+    aligned_part(seq_lo, seq_hi, sa0, sa1);
+    aligned_part(q_lo, q_hi, qa0, qa1);
+    auto fetch16 = [&](const uint8_t *b0, uint64_t k, bool is_seq, uint32_t (&w)[4]) {  // run positions k .. k+15
+        if (!rev) {
+            __builtin_memcpy(w, b0 + k, 16);
+            return;
+        }
+        uint32_t v[4];
+        __builtin_memcpy(v, b0 - (int64_t)k - 15, 16);  // positions k+15 .. k
+#pragma unroll
+        for (int d = 0; d < 4; d++) w[d] = __builtin_bswap32(v[3 - d]);
+        if (is_seq) {
+            uint32_t c[4];
+            bool ok = true;
+#pragma unroll
+            for (int d = 0; d < 4; d++) ok = rc4(w[d], c[d]) && ok;
+            if (ok) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) w[d] = c[d];
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; d++)
+                    w[d] = lut[256 + (w[d] & 0xFF)] | (lut[256 + ((w[d] >> 8) & 0xFF)] << 8) | (lut[256 + ((w[d] >> 16) & 0xFF)] << 16) |
+                           (lut[256 + (w[d] >> 24)] << 24);
+            }
+        }
+    };
+    // two pieces per lane and run per turn: four independent loads in flight, then four stores
+    for (uint64_t g = 16ull * lane;; g += 2048) {
+        const uint64_t gs0 = sa0 + g, gs1 = gs0 + 1024, gq0 = qa0 + g, gq1 = gq0 + 1024;
+        const bool bs0 = gs0 < sa1, bs1 = gs1 < sa1, bq0 = gq0 < qa1, bq1 = gq1 < qa1;
+        if (!__ballot(bs0 || bq0)) break;
+        uint32_t ws0[4], ws1[4], wq0[4], wq1[4];
+        if (bs0) fetch16(seq0, gs0 - seq_lo, true, ws0);
+        if (bs1) fetch16(seq0, gs1 - seq_lo, true, ws1);
+        if (bq0) fetch16(qual0, gq0 - q_lo, false, wq0);
+        if (bq1) fetch16(qual0, gq1 - q_lo, false, wq1);
+        if (bs0) __builtin_memcpy(__builtin_assume_aligned(out + gs0, 16), ws0, 16);
+        if (bs1) __builtin_memcpy(__builtin_assume_aligned(out + gs1, 16), ws1, 16);
+        if (bq0) __builtin_memcpy(__builtin_assume_aligned(out + gq0, 16), wq0, 16);
+        if (bq1) __builtin_memcpy(__builtin_assume_aligned(out + gq1, 16), wq1, 16);
+    }
+    // ---- everything else, a byte per lane ---------------------------------------------------------------------------------------
     auto source = [&](uint64_t j, uint32_t &table) -> const uint8_t * {
         const uint8_t *p = lit + 1;  // LF: the byte that closes each of the four lines
         p = j == 0 ? lit : p;
@@ -310,46 +421,14 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const uint64_t *__re
         p = (j >= p_q && j - p_q < qlen) ? qual0 + qstep * (int64_t)(j - p_q) : p;
         return p;
     };
-    // dword-aligned output positions g = (off & ~3) + 4 * (64 * it + lane); dwords that are not wholly this wave's (the two
-    // ends of the record, shared with its neighbours, and the ends of the suffix K-WNAME writes) go out as bytes
-    const uint64_t g0 = off & ~3ull, end = off + bytes, s0 = off + p_sfx, s1 = s0 + n_sfx;
-    // the long runs -- four bytes that all lie in the bases or in the qualities -- take one (unaligned) dword load per lane
-    // when that holds for the whole wave; everything else goes through `source`
-    const uint64_t seq_lo = off + p_seq, seq_hi = off + p_plus - 1, q_lo = off + p_q, q_hi = q_lo + (qset ? qlen : 0);
-    for (uint64_t g = g0 + 4ull * lane; g < end; g += 256) {
-        const bool all_seq = g >= seq_lo && g + 4 <= seq_hi, all_q = g >= q_lo && g + 4 <= q_hi;
-        if (!__ballot(!(all_seq || all_q))) {
-            const uint64_t k = all_seq ? g - seq_lo : g - q_lo;
-            const uint8_t *b0 = all_seq ? seq0 : qual0;
-            uint32_t w;
-            if (rev) {
-                __builtin_memcpy(&w, b0 - (int64_t)k - 3, 4);  // source bytes k+3 .. k of the mirrored run
-                w = __builtin_bswap32(w);
-                if (all_seq)
-                    w = lut[256 + (w & 0xFF)] | (lut[256 + ((w >> 8) & 0xFF)] << 8) | (lut[256 + ((w >> 16) & 0xFF)] << 16) |
-                        (lut[256 + (w >> 24)] << 24);
-            } else
-                __builtin_memcpy(&w, b0 + k, 4);
-            *reinterpret_cast<uint32_t *>(out + g) = w;
-            continue;
-        }
-        uint32_t c[4], tb[4];
-        bool ok[4];
+    const uint64_t end = off + bytes, s0 = off + p_sfx, s1 = s0 + n_sfx;  // [s0, s1): the suffix K-WNAME writes
+    const uint64_t seg_lo[4] = {off, s1, sa1, qa1}, seg_hi[4] = {s0, sa0, qa0, end};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint64_t a = g + k;
-            ok[k] = a >= off && a < end && !(a >= s0 && a < s1);
-            const uint8_t *p = source(ok[k] ? a - off : 0, tb[k]);
-            c[k] = *p;
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) c[k] = lut[tb[k] + c[k]];
-        if (ok[0] && ok[1] && ok[2] && ok[3])
-            *reinterpret_cast<uint32_t *>(out + g) = c[0] | (c[1] << 8) | (c[2] << 16) | (c[3] << 24);
-        else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (ok[k]) out[g + k] = (uint8_t)c[k];
+    for (int sgm = 0; sgm < 4; sgm++) {
+        for (uint64_t a = seg_lo[sgm] + lane; a < seg_hi[sgm]; a += 64) {
+            uint32_t tb;
+            const uint8_t *p = source(a - off, tb);
+            out[a] = lut[tb + *p];
         }
     }
 }
@@ -378,12 +457,14 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
     }
     SMI_HIP(hipSetDevice(ctx->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
-    // scratch: 6 arrays of n_out + 1 u64 (3 lengths, 3 scanned), the error word, hipcub temp storage
+    // scratch: 6 arrays of n_out + 1 u64 (3 lengths, 3 scanned), the suffix lengths, the error word, the plan rows, hipcub temp storage
     size_t tmp_bytes = 0;
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (int)(n_out + 1), s));
     const size_t arr = (n_out + 1) * sizeof(uint64_t);
     const size_t sfx_bytes = ((n_out * sizeof(uint32_t) + 255) / 256) * 256;
-    const size_t need = 6 * arr + sfx_bytes + 256 + tmp_bytes;
+    const size_t plan_bytes = n_out * sizeof(RecPlan);
+    const size_t tmp_off = ((6 * arr + sfx_bytes + 256 + 255) / 256) * 256 + plan_bytes;
+    const size_t need = tmp_off + tmp_bytes;
     if (ctx->scan_tmp_bytes < need) {
         SMI_HIP(hipStreamSynchronize(s));
         if (ctx->scan_tmp) SMI_HIP(hipFree(ctx->scan_tmp));
@@ -397,7 +478,8 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
     uint64_t *offp = (uint64_t *)(base + 3 * arr), *offf = (uint64_t *)(base + 4 * arr), *ordp = (uint64_t *)(base + 5 * arr);
     uint32_t *sfx = (uint32_t *)(base + 6 * arr);
     uint32_t *d_err = (uint32_t *)(base + 6 * arr + sfx_bytes);
-    void *cub_tmp = base + 6 * arr + sfx_bytes + 256;
+    RecPlan *plan = (RecPlan *)(base + tmp_off - plan_bytes);  // 256-byte aligned
+    void *cub_tmp = base + tmp_off;
     SMI_HIP(hipMemsetAsync(d_err, 0, 4, s));
     // the extra last element makes the exclusive scans deliver the totals
     SMI_HIP(hipMemsetAsync(lenp + n_out, 0, 8, s));
@@ -406,7 +488,7 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
     WriteArgs A{d_text, d_line_start, d_reads, d_quals, d_bstart, d_qstart, d_offsets, d_frag_src, d_chim, d_scan, d_bc, d_rank,
                 n_out,  first_read_id, cfg->five_prime, cfg->trim_fastq};
     const unsigned g = (unsigned)((n_out + 255) / 256);
-    hipLaunchKernelGGL(k_write_len, dim3(g), dim3(256), 0, s, A, lenp, lenf, cntp, sfx, d_is_passed, d_err);
+    hipLaunchKernelGGL(k_write_len, dim3(g), dim3(256), 0, s, A, plan, lenp, lenf, cntp, sfx, d_is_passed, d_err);
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(cub_tmp, tmp_bytes, cntp, ordp, (int)(n_out + 1), s));
     hipLaunchKernelGGL(k_write_idlen, dim3(g), dim3(256), 0, s, A, ordp, lenp, sfx);
@@ -422,11 +504,11 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
     }
     SMI_HIP(hipEventRecord(ctx->side_fork, s));
     SMI_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-    hipLaunchKernelGGL(k_write_name, dim3((unsigned)((n_out + kNameBlock - 1) / kNameBlock)), dim3(kNameBlock), 0, ctx->side_stream, A, offp, offf, ordp, sfx, d_passed, cap_passed, d_failed,
+    hipLaunchKernelGGL(k_write_name, dim3((unsigned)((n_out + kNameBlock - 1) / kNameBlock)), dim3(kNameBlock), 0, ctx->side_stream, A, plan, offp, offf, ordp, sfx, d_passed, cap_passed, d_failed,
                        cap_failed);
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipEventRecord(ctx->side_join, ctx->side_stream));
-    hipLaunchKernelGGL(k_write, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, A, offp, offf, sfx, d_passed, cap_passed,
+    hipLaunchKernelGGL(k_write, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, s, A, plan, offp, offf, sfx, d_passed, cap_passed,
                        d_failed, cap_failed, d_rec_off, d_err);
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipStreamWaitEvent(s, ctx->side_join, 0));
