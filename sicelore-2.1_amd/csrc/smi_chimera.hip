@@ -119,52 +119,83 @@ __device__ __forceinline__ int jround(float a) { return (int)floorf(__fadd_rn(a,
 // ---------------------------------------------------------------------------------------------------------------
 // K-PACKR: ASCII reads -> bit-planes.  planes: [4][stride] u32; read r starts at word plane_start(offsets[r], r).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t enc4c(uint8_t ch) {
-    // branch-free (a switch here becomes a divergent jump chain per base): A/a 1, G/g 2, C/c 4, T/t 8, anything else N
-    const uint32_t c = (uint32_t)ch | 0x20u;
-    uint32_t r = 15u;
-    r = c == 'a' ? 1u : r;
-    r = c == 'g' ? 2u : r;
-    r = c == 'c' ? 4u : r;
-    r = c == 't' ? 8u : r;
-    return r;
-}
-
-// one wave per read, one lane per 32-base plane word: a wave reads 2 KiB of consecutive ASCII and writes four 256-B rows
+// one wave per read, one lane per 32-base plane word: a wave reads 2 KiB of consecutive ASCII and writes four 256-B rows.  The offsets of
+// the read after the next and the text of the next read are requested before the current one is encoded (the loop is otherwise three
+// dependent round trips per read: offsets, text, stores).
 __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                                                     const uint64_t *__restrict__ starts, size_t n, size_t stride,
-                                                    uint32_t *__restrict__ planes) {
+                                                    uint64_t total_bases, uint32_t *__restrict__ planes) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t r = wave; r < n; r += n_waves) {
-        const uint64_t beg = offsets[r];
-        const int64_t len = (int64_t)(offsets[r + 1] - beg);
-        const size_t w0 = plane_start(beg, r);
-        const int64_t n_words = (len + 31) / 32 + kPadWords - 1;  // the pad words are written as zeros
-        const uint8_t *src = reads + (starts ? starts[r] : beg);  // starts: the bases sit in the FASTQ text, not in a gathered copy
-        for (int64_t w = lane; w < n_words; w += 64) {
-            uint32_t pl[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int64_t p0 = 32 * w + 8 * k;
-                if (p0 >= len) break;
-                uint64_t piece = 0;
-                if (p0 + 8 <= len)
-                    __builtin_memcpy(&piece, src + p0, 8);
-                else
-                    for (int i = 0; i < (int)(len - p0); i++) piece |= (uint64_t)src[p0 + i] << (8 * i);
-                const int nb = (int)min((int64_t)8, len - p0);
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t code = i < nb ? enc4c((uint8_t)(piece >> (8 * i))) : 0u;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) pl[c] |= ((code >> c) & 1u) << (8 * k + i);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 4; c++) planes[c * stride + w0 + w] = pl[c];
+    struct Meta {
+        uint64_t beg, end, src;
+    };
+    auto load_meta = [&](size_t r) -> Meta {
+        Meta m{0, 0, 0};
+        if (r < n) {
+            m.beg = offsets[r];
+            m.end = offsets[r + 1];
+            m.src = starts ? starts[r] : m.beg;  // starts: the bases sit in the FASTQ text, not in a gathered copy
         }
+        return m;
+    };
+    // the 32 bases of word w: two 16-byte loads (a wave reads 2 KiB of consecutive text); the partial last word byte by byte
+    auto load_word = [&](const Meta &m, int64_t w, uint32_t (&v)[8]) {
+        const int64_t len = (int64_t)(m.end - m.beg), p0 = 32 * w;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[j] = 0;
+        // The last, partial word of a read takes the same two 16-byte loads when the bytes behind the read's end are known to exist:
+        // in the FASTQ text the line end, the '+' line and the read's own quality line follow (>= len + 3 bytes), in a gathered array
+        // the next reads do (up to total_bases).  encode_store drops the codes behind the end.  (A byte loop here -- counted or unrolled
+        // under `if (i < nb)` -- is compiled into dependent round trips and ~300 wave instructions per read on ONE lane, as much as the
+        // encoding of the whole read: 587 M instead of ~300 M VALU instructions per 0.9 M reads.)
+        const bool wide = p0 + 32 <= len || (p0 < len && (starts ? len >= 29 : m.beg + (uint64_t)p0 + 32 <= total_bases));
+        if (wide) {
+            __builtin_memcpy(v, reads + m.src + p0, 32);
+        } else {
+            for (int i = 0; i < (int)(len - p0); i++) {  // reads shorter than 29 bases, the last read of a gathered array
+                const uint32_t b = (uint32_t)reads[m.src + p0 + i] << (8 * (i & 3));
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] |= (i >> 2) == j ? b : 0u;
+            }
+        }
+    };
+    auto encode_store = [&](const Meta &m, size_t r, int64_t w, const uint32_t (&v)[8]) {
+        const int64_t len = (int64_t)(m.end - m.beg), p0 = 32 * w;
+        uint32_t pl[4] = {0, 0, 0, 0};
+        if (p0 < len) {
+            const int nb = (int)min((int64_t)32, len - p0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {  // four bases per enc4x4
+                uint32_t code = enc4x4<false>(v[j]);
+                if (4 * j + 4 > nb) code &= 4 * j >= nb ? 0u : (0xFFFFFFFFu >> (8 * (4 * j + 4 - nb)));  // nothing behind the read's end
+#pragma unroll
+                for (int c = 0; c < 4; c++) pl[c] |= plane_nibble(code, c) << (4 * j);
+            }
+        }
+        const size_t w0 = plane_start(m.beg, r);
+#pragma unroll
+        for (int c = 0; c < 4; c++) planes[c * stride + w0 + w] = pl[c];
+    };
+    Meta cur = load_meta(wave), nxt = load_meta(wave + n_waves);
+    uint32_t vcur[8];
+    load_word(cur, lane, vcur);
+    for (size_t r = wave; r < n; r += n_waves) {
+        uint32_t vnxt[8];
+        load_word(nxt, lane, vnxt);                       // (an empty Meta behind the last read: nothing is loaded)
+        const Meta nxt2 = load_meta(r + 2 * n_waves);
+        const int64_t n_words = ((int64_t)(cur.end - cur.beg) + 31) / 32 + kPadWords - 1;  // the pad words are written as zeros
+        if (lane < n_words) encode_store(cur, r, lane, vcur);
+        for (int64_t w = lane + 64; w < n_words; w += 64) {  // reads beyond 2048 bases
+            uint32_t v[8];
+            load_word(cur, w, v);
+            encode_store(cur, r, w, v);
+        }
+        cur = nxt;
+        nxt = nxt2;
+#pragma unroll
+        for (int j = 0; j < 8; j++) vcur[j] = vnxt[j];
     }
 }
 
@@ -1356,7 +1387,7 @@ int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offse
     if (!n) return SMI_OK;
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
     hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, read_planes_stride(total_bases, n),
-                       d_planes);
+                       total_bases, d_planes);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

@@ -6,7 +6,7 @@
 // htsjdk 4.1.3 FastqReader semantics kept: four lines per record, '@' and '+' headers, sequence and quality lines of
 // equal length, line ends "\n" or "\r\n"; a violation is reported through the error word, never repaired.
 //
-// MI355X mapping: newline positions are found by all lanes at once (16 bytes per lane, block-level counts, one
+// MI355X mapping: newline positions are found by all lanes at once (64 bytes per lane, block-level counts, one
 // exclusive scan over the blocks, then a second sweep writes the start of every line); records are then four consecutive
 // line starts.  Byte work at HBM speed, no MFMA.
 #include <hipcub/hipcub.hpp>
@@ -16,61 +16,80 @@
 namespace smi {
 
 constexpr int kFqBlock = 256;
-constexpr int kFqBytesPerThread = 16;
-constexpr int kFqTile = kFqBlock * kFqBytesPerThread;  // 4 KiB of text per block
+constexpr int kFqBytesPerThread = 64;
+constexpr int kFqTile = kFqBlock * kFqBytesPerThread;  // 16 KiB of text per block
 
-// newline flags of 16 bytes: bit k set when text[i0 + k] == '\n' (one 16-byte load; SWAR zero-byte test per dword)
-__device__ __forceinline__ uint32_t nl_mask16(const uint8_t *p, size_t i0, size_t n) {
-    if (i0 + kFqBytesPerThread <= n) {
-        uint32_t w[4];
-        __builtin_memcpy(w, p + i0, 16);
-        uint32_t m = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint32_t t = w[k] ^ 0x0A0A0A0Au;
-            const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 in every zero byte, exact
-            m |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu) << (4 * k);
-        }
-        return m;
-    }
+// newline flags of 16 bytes: bit k set when p[k] == '\n' (SWAR zero-byte test per dword)
+__device__ __forceinline__ uint32_t nl_mask16w(const uint32_t (&w)[4]) {
     uint32_t m = 0;
-    for (int k = 0; k < kFqBytesPerThread; k++) m |= (i0 + k < n && p[i0 + k] == '\n') ? (1u << k) : 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t t = w[k] ^ 0x0A0A0A0Au;
+        const uint32_t z = ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t | 0x7F7F7F7Fu);  // 0x80 in every zero byte, exact
+        m |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu) << (4 * k);
+    }
     return m;
 }
-__device__ __forceinline__ uint32_t count_nl16(const uint8_t *p, size_t i0, size_t n) { return __popc(nl_mask16(p, i0, n)); }
+// newline flags of the 64 bytes at i0: four 16-byte loads in flight together
+__device__ __forceinline__ uint64_t nl_mask64(const uint8_t *p, size_t i0, size_t n) {
+    if (i0 + kFqBytesPerThread <= n) {
+        uint32_t w[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) __builtin_memcpy(w[q], p + i0 + 16 * q, 16);
+        uint64_t m = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) m |= (uint64_t)nl_mask16w(w[q]) << (16 * q);
+        return m;
+    }
+    uint64_t m = 0;
+    for (int k = 0; k < kFqBytesPerThread; k++) m |= (i0 + k < n && p[i0 + k] == '\n') ? (1ull << k) : 0ull;
+    return m;
+}
+
+// sum over the block (every thread gets it): wave sums through shuffles, the four of them through LDS
+__device__ __forceinline__ uint32_t block_sum_and_prefix(uint32_t mine, uint32_t *wave_tot, uint32_t &before) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(inc, o);
+        if (lane >= o) inc += y;
+    }
+    if (lane == 63) wave_tot[wv] = inc;
+    __syncthreads();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kFqBlock / 64; k++) {
+        const uint32_t t = wave_tot[k];
+        base += k < wv ? t : 0u;
+        total += t;
+    }
+    before = base + inc - mine;
+    return total;
+}
 
 __global__ __launch_bounds__(kFqBlock) void k_fq_count(const uint8_t *__restrict__ text, size_t n, uint32_t *__restrict__ block_counts) {
-    __shared__ uint32_t sh[kFqBlock];
+    __shared__ uint32_t wave_tot[kFqBlock / 64];
     const size_t i0 = (size_t)blockIdx.x * kFqTile + (size_t)threadIdx.x * kFqBytesPerThread;
-    sh[threadIdx.x] = count_nl16(text, i0, n);
-    __syncthreads();
-    for (int o = kFqBlock / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) block_counts[blockIdx.x] = sh[0];
+    uint32_t before;
+    const uint32_t total = block_sum_and_prefix(i0 < n ? (uint32_t)__popcll(nl_mask64(text, i0, n)) : 0u, wave_tot, before);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
 
 // line_start[L] = first byte of line L (line 0 starts at 0); block_base[b] = newlines before block b
 __global__ __launch_bounds__(kFqBlock) void k_fq_lines(const uint8_t *__restrict__ text, size_t n,
                                                        const uint64_t *__restrict__ block_base, uint64_t *__restrict__ line_start,
                                                        size_t cap_lines) {
-    __shared__ uint32_t sh[kFqBlock];
+    __shared__ uint32_t wave_tot[kFqBlock / 64];
     const size_t i0 = (size_t)blockIdx.x * kFqTile + (size_t)threadIdx.x * kFqBytesPerThread;
-    const uint32_t mine = count_nl16(text, i0, n);
-    sh[threadIdx.x] = mine;
-    __syncthreads();
-    for (int o = 1; o < kFqBlock; o <<= 1) {
-        const uint32_t y = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0u;
-        __syncthreads();
-        sh[threadIdx.x] += y;
-        __syncthreads();
-    }
-    uint64_t line = block_base[blockIdx.x] + sh[threadIdx.x] - mine;  // newlines before my first byte
+    const uint64_t mask = i0 < n ? nl_mask64(text, i0, n) : 0ull;
+    uint32_t before;
+    block_sum_and_prefix((uint32_t)__popcll(mask), wave_tot, before);
+    uint64_t line = block_base[blockIdx.x] + before;  // newlines before my first byte
     if (blockIdx.x == 0 && threadIdx.x == 0 && cap_lines > 0) line_start[0] = 0;
-    for (uint32_t m = nl_mask16(text, i0, n); m; m &= m - 1) {
+    for (uint64_t m = mask; m; m &= m - 1) {
         line++;
-        if (line < cap_lines) line_start[line] = i0 + (size_t)__builtin_ctz(m) + 1;
+        if (line < cap_lines) line_start[line] = i0 + (size_t)__builtin_ctzll(m) + 1;
     }
 }
 
@@ -129,7 +148,7 @@ __global__ __launch_bounds__(kFqBlock) void k_fq_count_total(const uint8_t *__re
     uint32_t c = 0;
     for (size_t i0 = ((size_t)blockIdx.x * kFqBlock + threadIdx.x) * kFqBytesPerThread; i0 < n;
          i0 += (size_t)gridDim.x * kFqBlock * kFqBytesPerThread)
-        c += count_nl16(text, i0, n);
+        c += (uint32_t)__popcll(nl_mask64(text, i0, n));
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(total, (unsigned long long)c);
 }

@@ -672,20 +672,6 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
 // K-PACK: ASCII reads -> scan-orientation bit-plane ends (+ read length, tail qualities, quality sum).
 // Bases: one lane per read end (below); qualities: one wave per read.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t enc4(uint8_t ch) {
-    // branch-free (a switch here becomes a divergent jump chain per base): A/a 1, G/g 2, C/c 4, T/t 8, anything else N
-    const uint32_t c = (uint32_t)ch | 0x20u;
-    uint32_t r = 15u;
-    r = c == 'a' ? 1u : r;
-    r = c == 'g' ? 2u : r;
-    r = c == 'c' ? 4u : r;
-    r = c == 't' ? 8u : r;
-    return r;
-}
-__device__ __forceinline__ uint32_t comp4(uint32_t b) {
-    return ((b & 1u) << 3) | ((b & 8u) >> 3) | ((b & 2u) << 1) | ((b & 4u) >> 1);
-}
-
 // one lane = one read end (lanes 2i / 2i+1 = head / reverse-complemented tail of read i): every lane walks its 224
 // bases in 8-byte pieces and builds the four plane words in registers, so the stores of a wave are 256-B rows of the
 // [plane-word][end] layout and no cross-lane operation is needed
@@ -702,38 +688,42 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
         if (side == 0) read_len[r] = (int32_t)len;
         const uint8_t *src = reads + (starts ? starts[r] : beg);
+        // 16 bases per piece: one 16-byte load (unaligned), four enc4x4 -- the tail end is read backwards and complemented, which is a
+        // byte swap of the piece and the complement table
 #pragma unroll 1
         for (int w = 0; w < kPlaneWords; w++) {
-            uint32_t pa = 0, pg = 0, pc = 0, pt = 0;
+            uint32_t pl[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {  // 8 bases per piece
-                const int p0 = 32 * w + 8 * k;  // scan positions p0 .. p0 + 7
+            for (int k = 0; k < 2; k++) {
+                const int p0 = 32 * w + 16 * k;  // scan positions p0 .. p0 + 15
                 if (p0 >= len) break;
-                uint64_t piece = 0;
-                const int64_t lo = side == 0 ? p0 : len - 8 - p0;  // first byte of the piece in the read
-                if (p0 + 8 <= len) {
-                    __builtin_memcpy(&piece, src + lo, 8);
-                    if (side) piece = __builtin_bswap64(piece);  // the tail is scanned backwards
+                uint32_t v[4] = {0, 0, 0, 0};    // v[j] byte i = character at scan position p0 + 4j + i
+                if (p0 + 16 <= len) {
+                    if (side == 0) {
+                        __builtin_memcpy(v, src + p0, 16);
+                    } else {
+                        uint32_t t[4];
+                        __builtin_memcpy(t, src + (len - 16 - p0), 16);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) v[j] = __builtin_bswap32(t[3 - j]);
+                    }
                 } else {  // the read ends inside this piece
                     for (int i = 0; i < (int)(len - p0); i++)
-                        piece |= (uint64_t)src[side == 0 ? p0 + i : len - 1 - p0 - i] << (8 * i);
+                        v[i >> 2] |= (uint32_t)src[side == 0 ? p0 + i : len - 1 - p0 - i] << (8 * (i & 3));
                 }
-                const int nb = (int)min((int64_t)8, len - p0);
+                const int nb = (int)min((int64_t)16, len - p0);
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    uint32_t code = i < nb ? enc4((uint8_t)(piece >> (8 * i))) : 0u;
-                    if (side) code = comp4(code);
-                    const int bit = 8 * k + i;
-                    pa |= (code & 1u) << bit;
-                    pg |= ((code >> 1) & 1u) << bit;
-                    pc |= ((code >> 2) & 1u) << bit;
-                    pt |= ((code >> 3) & 1u) << bit;
+                for (int j = 0; j < 4; j++) {
+                    uint32_t code = side ? enc4x4<true>(v[j]) : enc4x4<false>(v[j]);
+                    if (4 * j + 4 > nb) code &= 4 * j >= nb ? 0u : (0xFFFFFFFFu >> (8 * (4 * j + 4 - nb)));
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pl[c] |= plane_nibble(code, c) << (16 * k + 4 * j);
                 }
             }
-            ends[(size_t)(0 * kPlaneWords + w) * n_ends + e] = pa;
-            ends[(size_t)(1 * kPlaneWords + w) * n_ends + e] = pg;
-            ends[(size_t)(2 * kPlaneWords + w) * n_ends + e] = pc;
-            ends[(size_t)(3 * kPlaneWords + w) * n_ends + e] = pt;
+            ends[(size_t)(0 * kPlaneWords + w) * n_ends + e] = pl[0];
+            ends[(size_t)(1 * kPlaneWords + w) * n_ends + e] = pl[1];
+            ends[(size_t)(2 * kPlaneWords + w) * n_ends + e] = pl[2];
+            ends[(size_t)(3 * kPlaneWords + w) * n_ends + e] = pl[3];
         }
     }
 }

@@ -328,14 +328,25 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
     const int lane = threadIdx.x & 63;
     const size_t i = blockIdx.x * (size_t)4 + (threadIdx.x >> 6);
     if (i >= A.n) return;
-    const RecPlan R = plan[i];  // the same 64 bytes for every lane of the wave
+    // the same 64 bytes for every lane of the wave: through v_readfirstlane into scalar registers, and with them everything derived
+    // from the plan (positions, lengths, segment bounds).  (A persistent form of this kernel -- waves that loop over records and request
+    // the next plan row early -- needs 99 VGPRs = 4 waves per SIMD and measured 1.17 ms against 1.08 ms for this one at 8 waves.)
+    RecPlan R;
+    {
+        uint32_t v[16];
+        __builtin_memcpy(v, plan + i, 64);
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = __builtin_amdgcn_readfirstlane(v[k]);
+        __builtin_memcpy(&R, v, 64);
+    }
+    const uint32_t sl = __builtin_amdgcn_readfirstlane(sfx_len[i]);
+    const uint64_t off_v = (R.flags & kPassed) ? off_passed[i] : off_failed[i];
+    const uint64_t off = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(off_v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)off_v);
     const bool passed = R.flags & kPassed, rev = R.flags & kRev;
     const uint64_t tok_len = R.name_tok_len, qh_len = R.qh_len;
     const int len = R.len, cut_beg = R.cut_beg, cut_len = R.cut_len;
-    const uint32_t sl = sfx_len[i];
     const bool qset = sl >> 31;
     const uint64_t n_sfx = sl & 0x7FFFFFFFu;
-    const uint64_t off = passed ? off_passed[i] : off_failed[i];
     const uint64_t qlen = qset ? (uint64_t)cut_len : 4ull;
     // '@' token suffix LF bases LF '+' header LF qualities LF
     const uint64_t p_sfx = 1ull + tok_len, p_seq = p_sfx + n_sfx + 1, p_plus = p_seq + cut_len + 1, p_qh = p_plus + 1,
@@ -393,22 +404,8 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
             }
         }
     };
-    // two pieces per lane and run per turn: four independent loads in flight, then four stores
-    for (uint64_t g = 16ull * lane;; g += 2048) {
-        const uint64_t gs0 = sa0 + g, gs1 = gs0 + 1024, gq0 = qa0 + g, gq1 = gq0 + 1024;
-        const bool bs0 = gs0 < sa1, bs1 = gs1 < sa1, bq0 = gq0 < qa1, bq1 = gq1 < qa1;
-        if (!__ballot(bs0 || bq0)) break;
-        uint32_t ws0[4], ws1[4], wq0[4], wq1[4];
-        if (bs0) fetch16(seq0, gs0 - seq_lo, true, ws0);
-        if (bs1) fetch16(seq0, gs1 - seq_lo, true, ws1);
-        if (bq0) fetch16(qual0, gq0 - q_lo, false, wq0);
-        if (bq1) fetch16(qual0, gq1 - q_lo, false, wq1);
-        if (bs0) __builtin_memcpy(__builtin_assume_aligned(out + gs0, 16), ws0, 16);
-        if (bs1) __builtin_memcpy(__builtin_assume_aligned(out + gs1, 16), ws1, 16);
-        if (bq0) __builtin_memcpy(__builtin_assume_aligned(out + gq0, 16), wq0, 16);
-        if (bq1) __builtin_memcpy(__builtin_assume_aligned(out + gq1, 16), wq1, 16);
-    }
-    // ---- everything else, a byte per lane ---------------------------------------------------------------------------------------
+    // ---- everything else, a byte per lane: '@' + token | LF + front of the bases | their end + LF + '+' line + front of the
+    // qualities | their end + LF (the suffix between the first two is K-WNAME's) -------------------------------------------------
     auto source = [&](uint64_t j, uint32_t &table) -> const uint8_t * {
         const uint8_t *p = lit + 1;  // LF: the byte that closes each of the four lines
         p = j == 0 ? lit : p;
@@ -422,14 +419,44 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
         return p;
     };
     const uint64_t end = off + bytes, s0 = off + p_sfx, s1 = s0 + n_sfx;  // [s0, s1): the suffix K-WNAME writes
-    const uint64_t seg_lo[4] = {off, s1, sa1, qa1}, seg_hi[4] = {s0, sa0, qa0, end};
+    const uint64_t n0 = s0 - off, n1 = sa0 - s1, n2 = qa0 - sa1, n3 = end - qa1, n_loose = n0 + n1 + n2 + n3;
+    auto loose_addr = [&](uint64_t u) -> uint64_t {  // u-th byte outside the aligned parts and the suffix
+        uint64_t a = off + u;
+        a = u >= n0 ? s1 + (u - n0) : a;
+        a = u >= n0 + n1 ? sa1 + (u - n0 - n1) : a;
+        a = u >= n0 + n1 + n2 ? qa1 + (u - n0 - n1 - n2) : a;
+        return a;
+    };
+    // One turn = per lane two 16-byte pieces of each run and three loose bytes: every load of the turn is issued before its first store,
+    // so a record of up to 2 KiB per run costs one round trip to memory after the plan row.
+    constexpr int kLoose = 3;
+    for (uint64_t turn = 0;; turn++) {
+        const uint64_t g = 16ull * lane + 2048 * turn;
+        const uint64_t gs0 = sa0 + g, gs1 = gs0 + 1024, gq0 = qa0 + g, gq1 = gq0 + 1024;
+        const bool bs0 = gs0 < sa1, bs1 = gs1 < sa1, bq0 = gq0 < qa1, bq1 = gq1 < qa1;
+        const uint64_t u0 = (uint64_t)lane + 64ull * kLoose * turn;
+        if (!__ballot(bs0 || bq0 || u0 < n_loose)) break;
+        uint32_t ws0[4], ws1[4], wq0[4], wq1[4];
+        if (bs0) fetch16(seq0, gs0 - seq_lo, true, ws0);
+        if (bs1) fetch16(seq0, gs1 - seq_lo, true, ws1);
+        if (bq0) fetch16(qual0, gq0 - q_lo, false, wq0);
+        if (bq1) fetch16(qual0, gq1 - q_lo, false, wq1);
+        uint64_t la[kLoose];
+        uint32_t lc[kLoose], ltb[kLoose];
 #pragma unroll
-    for (int sgm = 0; sgm < 4; sgm++) {
-        for (uint64_t a = seg_lo[sgm] + lane; a < seg_hi[sgm]; a += 64) {
-            uint32_t tb;
-            const uint8_t *p = source(a - off, tb);
-            out[a] = lut[tb + *p];
+        for (int j = 0; j < kLoose; j++) {
+            const uint64_t u = u0 + 64ull * j;
+            la[j] = u < n_loose ? loose_addr(u) : ~0ull;
+            const uint8_t *p = source(la[j] != ~0ull ? la[j] - off : 0, ltb[j]);
+            lc[j] = *p;
         }
+        if (bs0) __builtin_memcpy(__builtin_assume_aligned(out + gs0, 16), ws0, 16);
+        if (bs1) __builtin_memcpy(__builtin_assume_aligned(out + gs1, 16), ws1, 16);
+        if (bq0) __builtin_memcpy(__builtin_assume_aligned(out + gq0, 16), wq0, 16);
+        if (bq1) __builtin_memcpy(__builtin_assume_aligned(out + gq1, 16), wq1, 16);
+#pragma unroll
+        for (int j = 0; j < kLoose; j++)
+            if (la[j] != ~0ull) out[la[j]] = lut[ltb[j] + lc[j]];
     }
 }
 
