@@ -375,8 +375,11 @@ def config2(args, dist, rank, local_rank, world, dev):
         "roofline": {"bound": "valu-issue (HBM figures as the contract asks)", "kernel": "k_bc_match_ed2", "kernel_ms": k_bc2,
                      "launches_per_step": len(batches), "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                      "alg_bytes_per_read": ALG_BYTES_PER_READ_BC2, "traffic": None,
-                     "limiter": "integer VALU issue: ~60 wave-instructions per 64 mutants, ~56k mutants per read; the used list's top level "
-                                "stays in L2", "kernels_ms": {"k_bc_match_ed2": k_bc2, "k_scan<10>": state["ms_scan"]}}}))
+                     "note": "SURVEY 8d prices a read at ~56,000 probes x 4 B; against a short used list K-BC2 dismisses ~98 % of the level-1 "
+                             "items with one load each (the inverse one-step neighbourhood of the list, P.n1) and never enumerates their "
+                             "children, so `achieved` in algorithmic bytes can exceed the HBM peak: it measures probes answered, not bytes moved",
+                     "limiter": "integer VALU issue + LDS atomics of the per-offset set-up (123 level-1 children, dedup table, creation order); "
+                                "the level-2 work only runs for the items the filter lets through", "kernels_ms": {"k_bc_match_ed2": k_bc2, "k_scan<10>": state["ms_scan"]}}}))
 
 
 def main():

@@ -21,6 +21,7 @@ namespace smi {
 // ---------------------------------------------------------------------------------------------------------
 // pyramid build
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lowmask_h(int nbits) { return nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u); }  // nbits in [0, 32]
 __device__ __forceinline__ uint32_t suffix_index(uint32_t k) { return ((k & 0x3FFFu) << (18 - kG0)) | (k >> (14 + kG0)); }
 
 __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ l0,
@@ -40,6 +41,34 @@ __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t
         atomicOr(&t2[2 * (i0 >> 5) + 1], 1u << t2_prefix_bit(k));
         atomicOr(&t2[2 * (kL0Words + (is >> 5))], 1u << (is & 31));
         atomicOr(&t2[2 * (kL0Words + (is >> 5)) + 1], 1u << t2_twin_bit(k));
+    }
+}
+
+// K-BC2's item filter for short used lists.  A level-1 item X can only produce a level-2 hit if one mutation step of the reference's
+// enumeration leads from X to a barcode, i.e. if X lies in the INVERSE one-step neighbourhood of the list.  Per barcode w that is (a superset
+// of) 169 sequences: w itself; its 48 substitutions (symmetric); for "insert b behind position q, drop the last base" (q = 0..14) every X
+// = w without position q + 1, left-shifted, with ANY last base (60); for "delete position q, append the next read base" (q = 0..14) every
+// X = w with ANY base inserted at q, w's last base dropped (60; that w's last base equals the appended read base is not checked -- a
+// superset is all the filter needs).  Stored like l1: word = X >> 10, bit = 5-bit hash of the low 10 bits (16 MiB); 5 k barcodes set
+// 0.6 % of the bits, so 99 of 100 items are dismissed with one load instead of the 123 probes of their children.
+constexpr int kN1Slots = 169;
+constexpr size_t kN1MaxKeys = 65536;  // beyond this the table is too dense to dismiss anything (169 x keys of 2^27 bits)
+__global__ void k_set_n1(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ n1) {
+    const size_t total = n * kN1Slots;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t k = keys[i / kN1Slots];
+        const int slot = (int)(i % kN1Slots);
+        uint32_t x = k;
+        if (slot < 48) {
+            x = k ^ ((uint32_t)(slot % 3 + 1) << (30 - 2 * (slot / 3)));
+        } else if (slot < 108) {
+            const int j = slot - 48, p1 = 1 + j / 4, sh = 30 - 2 * p1;  // position that the insertion filled
+            x = (k & ~lowmask_h(sh + 2)) | ((k & lowmask_h(sh)) << 2) | (uint32_t)(j & 3);
+        } else if (slot < 168) {
+            const int j = slot - 108, q = j / 4, top = 32 - 2 * q;       // position that the deletion removed
+            x = (k & ~lowmask_h(top)) | ((uint32_t)(j & 3) << (30 - 2 * q)) | ((k & lowmask_h(top)) >> 2);
+        }
+        atomicOr(&n1[l1_word(x)], 1u << l1_bit(x));
     }
 }
 
@@ -80,6 +109,15 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     uint32_t last[2] = {0, 0};
     SMI_HIP(hipMemcpyAsync(&last[0], ctx->rank + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
+    ctx->n1_valid = false;
+    if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
+        if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, kL1Words * 4));
+        SMI_HIP(hipMemsetAsync(ctx->n1, 0, kL1Words * 4, s));
+        const unsigned g1 = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 64);
+        hipLaunchKernelGGL(k_set_n1, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1);
+        SMI_HIP(hipGetLastError());
+        ctx->n1_valid = true;
+    }
     SMI_HIP(hipStreamSynchronize(s));
     ctx->n_keys = (size_t)last[0] + last[1];
     return SMI_OK;
@@ -833,16 +871,20 @@ __device__ __forceinline__ void pick_best15(const uint32_t (&bc)[15], const uint
     res.ins_minus_del = (int8_t)best_imd;
 }
 
-template <bool kTwoStage>  // dense barcode sets (the whole whitelist): both stages of the top level from t2
+// kTwoStage: dense barcode sets (the whole whitelist): both stages of the top level from t2.  kFilter: short used lists: only the items
+// that P.n1 lets through are expanded (k_set_n1).
+template <bool kTwoStage, bool kFilter>
 __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
     __shared__ uint32_t s_keys[4][kTabSlots];
     __shared__ uint32_t s_vals[4][kTabSlots];
     __shared__ uint32_t s_low[4][128];
     __shared__ uint32_t s_ord2e[4][128];
+    __shared__ uint32_t s_pass[4][128];
+    __shared__ uint32_t s_vpos[4][kTabSlots];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
-    uint32_t *keys = s_keys[wv], *vals = s_vals[wv], *lows = s_low[wv], *ord2e = s_ord2e[wv];
+    uint32_t *keys = s_keys[wv], *vals = s_vals[wv], *lows = s_low[wv], *ord2e = s_ord2e[wv], *passf = s_pass[wv], *vpos = s_vpos[wv];
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const bool fp = five_prime != 0;
@@ -890,20 +932,50 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         c[h] = child_of(root, pe[h] & 15, re[h], post1);
                         lows[e] = val[h] ? c[h].low : K;  // invalid slots mirror the root (never created)
                     }
-                    // clear the table
+                    // clear the tables
 #pragma unroll
                     for (int k = 0; k < kTabSlots / 64; k++) {
                         keys[64 * k + lane] = kEmpty;
                         vals[64 * k + lane] = 0xFFFFFFFFu;
+                        vpos[64 * k + lane] = 0xFFFFFFFFu;
                     }
                     wave_sync();
-                    // created(e): first position among equal sequences, and not the root except at position 0
+                    // created(e): first position among equal sequences, and not the root except at position 0.  The first position of
+                    // a sequence comes out of the dedup table (slot of the sequence -> smallest position), not out of a comparison of
+                    // every child with every other one (123 LDS reads per child: two thirds of this kernel's instructions once the
+                    // item filter had removed the level-2 work).  The all-T key equals the empty-slot sentinel: wave reductions.
+                    uint32_t slot_of[2] = {0, 0};
+                    uint32_t t_pmin = 99u;
+                    {
+                        uint32_t mine = 99u;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (!val[h]) continue;
+                            if (c[h].low == kEmpty) {
+                                mine = min(mine, (uint32_t)pe[h]);
+                                continue;
+                            }
+                            uint32_t slot = (c[h].low * 2654435761u) >> 24;
+                            for (;;) {
+                                const uint32_t prev = atomicCAS(&keys[slot], kEmpty, c[h].low);
+                                if (prev == kEmpty || prev == c[h].low) break;
+                                slot = (slot + 1) & (kTabSlots - 1);
+                            }
+                            atomicMin(&vpos[slot], (uint32_t)pe[h]);
+                            slot_of[h] = slot;
+                        }
+                        if (__ballot(mine != 99u)) {
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) mine = min(mine, (uint32_t)__shfl_xor((int)mine, o));
+                            t_pmin = mine;
+                        }
+                    }
+                    wave_sync();
                     bool created[2];
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        int pmin = 99;
-                        for (int f = 0; f < 123; f++) pmin = (lows[f] == c[h].low) ? min(pmin, f >> 3) : pmin;
-                        created[h] = val[h] && pe[h] == pmin && (c[h].low != K || pe[h] == 0);
+                        const uint32_t pmin = !val[h] ? 99u : (c[h].low == kEmpty ? t_pmin : vpos[slot_of[h]]);
+                        created[h] = val[h] && (uint32_t)pe[h] == pmin && (c[h].low != K || pe[h] == 0);
                     }
                     const unsigned long long ca = __ballot(created[0]), cb = __ballot(created[1]);
                     const int n_items = __popcll(ca) + __popcll(cb);
@@ -919,8 +991,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         ord[h] = (uint32_t)(before + later);
                         if (created[h]) ord2e[ord[h]] = (uint32_t)(64 * h + lane);
                     }
-                    // dedup table: low 32 bits -> smallest expansion order; the all-T key equals the empty-slot
-                    // sentinel and is kept in a register instead
+                    // dedup table: low 32 bits -> smallest expansion order; the all-T key is kept in a register instead
                     uint32_t t_ord = 0xFFFFFFFFu;
                     {
                         uint32_t mine = 0xFFFFFFFFu;
@@ -934,20 +1005,24 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         }
                     }
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        if (created[h] && c[h].low != kEmpty) {
-                            uint32_t slot = (c[h].low * 2654435761u) >> 24;
-                            for (;;) {
-                                const uint32_t prev = atomicCAS(&keys[slot], kEmpty, c[h].low);
-                                if (prev == kEmpty || prev == c[h].low) {
-                                    atomicMin(&vals[slot], ord[h]);
-                                    break;
-                                }
-                                slot = (slot + 1) & (kTabSlots - 1);
-                            }
-                        }
+                    for (int h = 0; h < 2; h++)
+                        if (created[h] && c[h].low != kEmpty) atomicMin(&vals[slot_of[h]], ord[h]);
+                    // items worth expanding, as a bit mask over the expansion order
+                    unsigned long long pm0 = ~0ull, pm1 = ~0ull;
+                    if (kFilter) {
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            if (created[h])
+                                passf[ord[h]] = (c[h].g == 0u && ((P.n1[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u)) ? 1u : 0u;
                     }
                     wave_sync();
+                    if (kFilter) {
+                        pm0 = __ballot(lane < n_items && passf[lane] != 0u);
+                        pm1 = __ballot(64 + lane < n_items && passf[64 + lane] != 0u);
+                    } else {
+                        pm0 = n_items >= 64 ? ~0ull : ((1ull << n_items) - 1ull);
+                        pm1 = n_items <= 64 ? 0ull : (n_items >= 128 ? ~0ull : ((1ull << (n_items - 64)) - 1ull));
+                    }
                     // ---- probes of level 0 and 1 (only created children are ever probed) ----------------------
                     hit0 = member(P, K);
                     const bool h1a = created[0] && c[0].g == 0u && member(P, c[0].low);
@@ -964,12 +1039,24 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                     // tested against the top level TOGETHER: the loads of a group are independent, so their latencies
                     // overlap; the (rare) survivors of the top level are then walked in order, which keeps "first hit".
                     constexpr int kGroup = 4;
-                    for (int t0 = 0; t0 < n_items && !hit2; t0 += kGroup) {
+                    while ((pm0 | pm1) && !hit2) {
                         uint32_t m_low[2 * kGroup], m_ok[2 * kGroup], w0[2 * kGroup], w1[2 * kGroup];
+                        int t_sel[kGroup];  // the next kGroup items in expansion order (wave-uniform)
 #pragma unroll
                         for (int g = 0; g < kGroup; g++) {
-                            const int t = t0 + g;
-                            const bool on = t < n_items;  // wave-uniform
+                            if (pm0) {
+                                t_sel[g] = __builtin_ctzll(pm0);
+                                pm0 &= pm0 - 1;
+                            } else if (pm1) {
+                                t_sel[g] = 64 + __builtin_ctzll(pm1);
+                                pm1 &= pm1 - 1;
+                            } else
+                                t_sel[g] = -1;
+                        }
+#pragma unroll
+                        for (int g = 0; g < kGroup; g++) {
+                            const int t = t_sel[g];
+                            const bool on = t >= 0;  // wave-uniform
                             // the item being expanded is wave-uniform: keep it on the scalar unit
                             const int e = __builtin_amdgcn_readfirstlane((int)ord2e[on ? t : 0]);
                             const int pX = e >> 3, rX = e & 7;
@@ -1018,7 +1105,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                             if (!__ballot(pass)) continue;
                             // Only a mutant that can be a barcode needs the dedup set ("expanded earlier" cannot change
                             // the outcome of a probe that misses), so the LDS look-up runs on the few top-level survivors
-                            const int t = t0 + (i >> 1);
+                            const int t = t_sel[i >> 1];
                             if (pass) {
                                 const uint32_t ml = m_low[i];
                                 uint32_t ord_seen = 0xFFFFFFFFu;  // expansion order of an equal sequence, if any
@@ -1078,9 +1165,11 @@ int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int fiv
     if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
     // density of the top level: 2^25 cells; from ~1 % occupied cells on the second stage pays for its wider loads
     if (ctx->n_keys > 300000)
-        hipLaunchKernelGGL(k_bc_match_ed2<true>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+        hipLaunchKernelGGL((k_bc_match_ed2<true, false>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else if (P.n1)
+        hipLaunchKernelGGL((k_bc_match_ed2<false, true>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else
-        hipLaunchKernelGGL(k_bc_match_ed2<false>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+        hipLaunchKernelGGL((k_bc_match_ed2<false, false>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_BC_MATCH, s)) return rc;
     return SMI_OK;

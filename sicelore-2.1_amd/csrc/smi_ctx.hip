@@ -40,6 +40,7 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.fine = ctx->fine;
     p.rank = ctx->rank;
     p.t2 = ctx->t2;
+    p.n1 = ctx->n1_valid ? ctx->n1 : nullptr;
     return p;
 }
 
@@ -172,6 +173,8 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->l0s = o->l0s;
     lane->l1 = o->l1;
     lane->t2 = o->t2;
+    lane->n1 = o->n1;
+    lane->n1_valid = o->n1_valid;
     lane->fine = o->fine;
     lane->rank = o->rank;
     lane->block_counts = o->block_counts;
@@ -188,6 +191,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(ctx->l0);
         (void)hipFree(ctx->l1);
         (void)hipFree(ctx->t2);
+        (void)hipFree(ctx->n1);
         (void)hipFree(ctx->fine);
         (void)hipFree(ctx->rank);
         (void)hipFree(ctx->block_counts);
