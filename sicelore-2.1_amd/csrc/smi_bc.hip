@@ -51,24 +51,41 @@ __global__ void k_set_bits(const uint32_t *__restrict__ keys, size_t n, uint32_t
 // X = w with ANY base inserted at q, w's last base dropped (60; that w's last base equals the appended read base is not checked -- a
 // superset is all the filter needs).  Stored like l1: word = X >> 10, bit = 5-bit hash of the low 10 bits (16 MiB); 5 k barcodes set
 // 0.6 % of the bits, so 99 of 100 items are dismissed with one load instead of the 123 probes of their children.
+// A second table of the same layout holds the cells that TWO OR MORE different barcodes reach: when the window itself is a barcode
+// (the usual case at the true offset), every child of it has that barcode as a neighbour, but a level-2 mutant equal to the root is
+// never probed (it is in the dedup set), so such an item only matters if ANOTHER barcode is one step away from it.
 constexpr int kN1Slots = 169;
 constexpr size_t kN1MaxKeys = 65536;  // beyond this the table is too dense to dismiss anything (169 x keys of 2^27 bits)
-__global__ void k_set_n1(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ n1) {
+__device__ __forceinline__ uint32_t n1_member(uint32_t k, int slot) {
+    if (slot < 48) return k ^ ((uint32_t)(slot % 3 + 1) << (30 - 2 * (slot / 3)));
+    if (slot < 108) {
+        const int j = slot - 48, p1 = 1 + j / 4, sh = 30 - 2 * p1;  // position that the insertion filled
+        return (k & ~lowmask_h(sh + 2)) | ((k & lowmask_h(sh)) << 2) | (uint32_t)(j & 3);
+    }
+    if (slot < 168) {
+        const int j = slot - 108, q = j / 4, top = 32 - 2 * q;       // position that the deletion removed
+        return (k & ~lowmask_h(top)) | ((uint32_t)(j & 3) << (30 - 2 * q)) | ((k & lowmask_h(top)) >> 2);
+    }
+    return k;
+}
+__device__ __forceinline__ uint32_t n1_cell(uint32_t x) { return (l1_word(x) << 5) | l1_bit(x); }
+// pass 1: owner[cell] = smallest index of a barcode that reaches the cell, n1 bit set
+__global__ void k_set_n1(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ n1, uint32_t *__restrict__ owner) {
     const size_t total = n * kN1Slots;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const uint32_t k = keys[i / kN1Slots];
-        const int slot = (int)(i % kN1Slots);
-        uint32_t x = k;
-        if (slot < 48) {
-            x = k ^ ((uint32_t)(slot % 3 + 1) << (30 - 2 * (slot / 3)));
-        } else if (slot < 108) {
-            const int j = slot - 48, p1 = 1 + j / 4, sh = 30 - 2 * p1;  // position that the insertion filled
-            x = (k & ~lowmask_h(sh + 2)) | ((k & lowmask_h(sh)) << 2) | (uint32_t)(j & 3);
-        } else if (slot < 168) {
-            const int j = slot - 108, q = j / 4, top = 32 - 2 * q;       // position that the deletion removed
-            x = (k & ~lowmask_h(top)) | ((uint32_t)(j & 3) << (30 - 2 * q)) | ((k & lowmask_h(top)) >> 2);
-        }
-        atomicOr(&n1[l1_word(x)], 1u << l1_bit(x));
+        const uint32_t b = (uint32_t)(i / kN1Slots);
+        const uint32_t cell = n1_cell(n1_member(keys[b], (int)(i % kN1Slots)));
+        atomicOr(&n1[cell >> 5], 1u << (cell & 31));
+        atomicMin(&owner[cell], b);
+    }
+}
+// pass 2: a cell that a barcode other than its owner reaches is reached by two
+__global__ void k_set_n2(const uint32_t *__restrict__ keys, size_t n, const uint32_t *__restrict__ owner, uint32_t *__restrict__ n2) {
+    const size_t total = n * kN1Slots;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t b = (uint32_t)(i / kN1Slots);
+        const uint32_t cell = n1_cell(n1_member(keys[b], (int)(i % kN1Slots)));
+        if (owner[cell] != b) atomicOr(&n2[cell >> 5], 1u << (cell & 31));
     }
 }
 
@@ -111,11 +128,21 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     ctx->n1_valid = false;
     if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
-        if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, kL1Words * 4));
-        SMI_HIP(hipMemsetAsync(ctx->n1, 0, kL1Words * 4, s));
+        if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 2 * kL1Words * 4));
+        SMI_HIP(hipMemsetAsync(ctx->n1, 0, 2 * kL1Words * 4, s));
+        struct Owner {  // one u32 per cell (512 MiB), only while the tables are built
+            uint32_t *p = nullptr;
+            ~Owner() {
+                if (p) (void)hipFree(p);
+            }
+        } owner;
+        SMI_HIP(hipMalloc((void **)&owner.p, kL1Words * 32 * sizeof(uint32_t)));
+        SMI_HIP(hipMemsetAsync(owner.p, 0xFF, kL1Words * 32 * sizeof(uint32_t), s));
         const unsigned g1 = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 64);
-        hipLaunchKernelGGL(k_set_n1, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1);
+        hipLaunchKernelGGL(k_set_n1, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1, owner.p);
+        hipLaunchKernelGGL(k_set_n2, dim3(g1), dim3(256), 0, s, d_keys, n, owner.p, ctx->n1 + kL1Words);
         SMI_HIP(hipGetLastError());
+        SMI_HIP(hipStreamSynchronize(s));  // before `owner` is freed
         ctx->n1_valid = true;
     }
     SMI_HIP(hipStreamSynchronize(s));
@@ -1009,11 +1036,19 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         if (created[h] && c[h].low != kEmpty) atomicMin(&vals[slot_of[h]], ord[h]);
                     // items worth expanding, as a bit mask over the expansion order
                     unsigned long long pm0 = ~0ull, pm1 = ~0ull;
+                    hit0 = member(P, K);
                     if (kFilter) {
+                        // K a barcode: its children have K as a neighbour by construction (substitutions; insertion children through the
+                        // "base inserted, last dropped" members of K's neighbourhood or, behind position 14, as substitutions of the last
+                        // base; deletion children through "position removed, any last base" for positions >= 1) -- all but the child
+                        // that lost position 0 -- and K itself is never a level-2 hit, so they need a SECOND barcode in reach
 #pragma unroll
-                        for (int h = 0; h < 2; h++)
-                            if (created[h])
-                                passf[ord[h]] = (c[h].g == 0u && ((P.n1[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u)) ? 1u : 0u;
+                        for (int h = 0; h < 2; h++) {
+                            if (!created[h]) continue;
+                            const bool k_counts = hit0 && !(re[h] == 7 && pe[h] == 0);
+                            const uint32_t *tab = k_counts ? P.n2 : P.n1;
+                            passf[ord[h]] = (c[h].g == 0u && ((tab[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u)) ? 1u : 0u;
+                        }
                     }
                     wave_sync();
                     if (kFilter) {
@@ -1024,7 +1059,6 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         pm1 = n_items <= 64 ? 0ull : (n_items >= 128 ? ~0ull : ((1ull << (n_items - 64)) - 1ull));
                     }
                     // ---- probes of level 0 and 1 (only created children are ever probed) ----------------------
-                    hit0 = member(P, K);
                     const bool h1a = created[0] && c[0].g == 0u && member(P, c[0].low);
                     const bool h1b = created[1] && c[1].g == 0u && member(P, c[1].low);
                     const unsigned long long ha = __ballot(h1a), hb = __ballot(h1b);

@@ -41,6 +41,7 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.rank = ctx->rank;
     p.t2 = ctx->t2;
     p.n1 = ctx->n1_valid ? ctx->n1 : nullptr;
+    p.n2 = ctx->n1_valid ? ctx->n1 + kL1Words : nullptr;
     return p;
 }
 

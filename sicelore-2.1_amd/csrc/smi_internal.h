@@ -92,6 +92,7 @@ struct Pyramid {
     const uint32_t *rank;
     const uint32_t *t2;  // two-stage top level of K-BC1: entry j = {word j of l0 | l0s, stage-2 word j}
     const uint32_t *n1;  // K-BC2, short used lists only (else null): the sequences one mutation step away FROM which a barcode can be reached (l1 layout)
+    const uint32_t *n2;  // ... from which TWO OR MORE different barcodes can be reached (same layout)
 };
 
 }  // namespace smi
@@ -102,7 +103,7 @@ struct smi_ctx {
     uint32_t *l0s = nullptr;
     uint32_t *l1 = nullptr;
     uint32_t *t2 = nullptr;
-    uint32_t *n1 = nullptr;   // allocated with the first short barcode list (16 MiB)
+    uint32_t *n1 = nullptr;   // allocated with the first short barcode list (2 x 16 MiB: n1, then n2)
     bool n1_valid = false;    // describes the set that is loaded now
     uint32_t *fine = nullptr;
     uint32_t *rank = nullptr;
