@@ -89,6 +89,16 @@ __global__ void k_set_n2(const uint32_t *__restrict__ keys, size_t n, const uint
     }
 }
 
+// K-BC1's offset filter: the same inverse one-step neighbourhood, one exact bit per key (512 MiB).  An offset whose window K has its bit
+// clear has no barcode among K and its 123 mutants, so none of its 124 probes is made.
+__global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ nb) {
+    const size_t total = n * kN1Slots;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = n1_member(keys[i / kN1Slots], (int)(i % kN1Slots));
+        atomicOr(&nb[x >> 5], 1u << (x & 31));
+    }
+}
+
 // popcount of every 256-key block of the fine bitmap (8 words, read as two 16-B vectors)
 __global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restrict__ counts) {
     size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -126,6 +136,15 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     uint32_t last[2] = {0, 0};
     SMI_HIP(hipMemcpyAsync(&last[0], ctx->rank + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
+    ctx->nb_valid = false;
+    if (n > 0 && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
+        if (!ctx->nb) SMI_HIP(hipMalloc((void **)&ctx->nb, kFineWords * 4));
+        SMI_HIP(hipMemsetAsync(ctx->nb, 0, kFineWords * 4, s));
+        const unsigned gb = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 256);
+        hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, s, d_keys, n, ctx->nb);
+        SMI_HIP(hipGetLastError());
+        ctx->nb_valid = true;
+    }
     ctx->n1_valid = false;
     if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
         if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 2 * kL1Words * 4));
@@ -642,6 +661,141 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
     }
 }
 
+// K-BC1 behind the offset filter (P.nb).  Phase 1 also reads, per lane, the neighbourhood bit of its five windows; phase 2 then runs
+// per OFFSET: the reads of the batch whose window at that offset has a barcode in reach are taken five at a time (ten probe rounds in
+// flight, as before), all others cost nothing.  Against the 3.6 M whitelist the neighbourhood holds 14 % of all 16-mers, so a read keeps
+// 1.6 of its 5 offsets on average (its true one and a chance one now and then); against a used list only the true one.
+__global__ __launch_bounds__(256) void k_bc_match_ed1f(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
+                                                       Pyramid P, smi_bc_result *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const ProbeLanes L = make_probe_lanes(lane);
+    constexpr uint32_t kTopOffMask2 = (uint32_t)(kL0Words * 8 - 8);
+    const unsigned long long exact_lane = 1ull << 63;
+    const unsigned long long lanesA = ~0ull;
+    const unsigned long long lanesB = (1ull << 60) - 1ull;
+    const unsigned long long p14B = 0xFull << 56;
+    const unsigned long long subsA = (1ull << 48) - 1ull;
+    const bool fp = five_prime != 0;
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+    constexpr int kSlots = 5;  // (read, offset) pairs probed together
+
+    for (size_t base = wave * 64; base < n; base += n_waves * 64) {
+        smi_bc_window my;
+        my.bases = 0;
+        my.nmask = 0;
+        my.flags = 0;
+        if (base + lane < n) my = win[base + lane];
+        uint32_t key[5];
+        uint32_t packed = (my.flags & SMI_WIN_VALID) ? (1u << 15) : 0u;  // [1:0]..[9:8] del bases, [14:10] usable
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const OffsetKey k = make_key(my.bases, my.nmask, OFFS[q], fp);
+            key[q] = k.key;
+            packed |= k.del_base << (2 * q);
+            packed |= (k.usable ? 1u : 0u) << (10 + q);
+        }
+        // the neighbourhood bit of every usable window of this lane's read: five independent loads
+        uint32_t nbw[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) nbw[q] = P.nb[key[q] >> 5];
+        uint32_t near = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++)
+            near |= ((packed >> 15) & (packed >> (10 + q)) & (nbw[q] >> (key[q] & 31u)) & 1u) << q;
+
+        uint32_t sum_lo = 0, sum_hi = 0;
+#pragma unroll 1
+        for (int q = 0; q < 5; q++) {
+            unsigned long long todo = __ballot((near >> q) & 1u);
+            if (!todo) continue;
+            const uint32_t keyq = q == 0 ? key[0] : q == 1 ? key[1] : q == 2 ? key[2] : q == 3 ? key[3] : key[4];
+            const uint32_t dbq = (packed >> (2 * q)) & 3u;
+            while (todo) {
+                int rr[kSlots];
+                bool on[kSlots];
+#pragma unroll
+                for (int t = 0; t < kSlots; t++) {
+                    on[t] = todo != 0ull;
+                    rr[t] = on[t] ? __builtin_ctzll(todo) : 0;
+                    if (on[t]) todo &= todo - 1ull;
+                }
+                uint32_t K[kSlots], mut[2 * kSlots], live[2 * kSlots], w[2 * kSlots], w2[2 * kSlots];
+#pragma unroll
+                for (int t = 0; t < kSlots; t++) {
+                    K[t] = __builtin_amdgcn_readlane(keyq, rr[t]);
+                    const uint32_t db = __builtin_amdgcn_readlane(dbq, rr[t]);
+                    mut[2 * t] = bfi(L.keepA, K[t], (K[t] << 2) | db) ^ L.flipA;
+                    mut[2 * t + 1] = (bfi(L.keepB, K[t], K[t] >> 2) & L.clearB) | L.putB;
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * kSlots; t++) {
+                    const uint32_t rot = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? L.rotB : L.rotA);
+                    const uint2 e = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(P.t2) +
+                                                                      (((rot >> 2) & kTopOffMask2) | ((t & 1) ? L.tabB : L.tabA)));
+                    w[t] = e.x;
+                    w2[t] = e.y;
+                    live[t] = rot;
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * kSlots; t++) {
+                    const uint32_t r2 = __builtin_amdgcn_alignbit(mut[t], mut[t], (t & 1) ? L.rot2B : L.rot2A);
+                    live[t] = (uint32_t)__builtin_amdgcn_sbfe(w[t], live[t], 1) & (uint32_t)__builtin_amdgcn_sbfe(w2[t], r2, 1);
+                }
+#pragma unroll
+                for (int t = 0; t < 2 * kSlots; t++) w[t] = load_at(P.fine, (mut[t] >> 3) & (live[t] & ~3u));
+#pragma unroll
+                for (int t = 0; t < kSlots; t++) {
+                    const unsigned long long liveA = on[t] ? lanesA : 0ull;
+                    const unsigned long long liveB = on[t] ? ((K[t] & 3u) ? lanesB & ~p14B : lanesB) : 0ull;
+                    const uint32_t fa = live[2 * t] & (uint32_t)__builtin_amdgcn_sbfe(w[2 * t], mut[2 * t], 1);
+                    const uint32_t fb = live[2 * t + 1] & (uint32_t)__builtin_amdgcn_sbfe(w[2 * t + 1], mut[2 * t + 1], 1);
+                    const unsigned long long ha = __ballot(fa != 0u) & liveA;
+                    const unsigned long long hb = __ballot(fb != 0u) & liveB;
+                    uint32_t code = (uint32_t)(ha >> 63) << 7;  // exact match (BarcodeMatchTester.java:L204-206)
+                    const unsigned long long ha1 = ha & ~exact_lane;
+                    if (ha1 | hb) {  // first hit in the reference's enumeration order (see k_bc_match_ed1)
+                        const uint32_t cur = (K[t] >> L.sA) & 3u;
+                        const uint32_t b = cur ^ L.subA;
+                        const uint32_t eA = L.enumA + (((ha1 & subsA) >> lane) & 1ull ? b - (b > cur ? 1u : 0u) : 0u);
+                        code |= min_over(hb, L.enumB, min_over(ha1, eA, 255u)) + 1u;
+                    }
+                    const bool mine = on[t] && lane == rr[t];
+                    if (q < 4)
+                        sum_lo |= mine ? code << (8 * q) : 0u;
+                    else
+                        sum_hi = mine ? code : sum_hi;
+                }
+            }
+        }
+        smi_bc_result res;
+        uint32_t c_bc[10], c_rs[10];
+        int c_imd[10];
+        uint32_t present = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const uint32_t code = q < 4 ? (sum_lo >> (8 * q)) & 0xFFu : sum_hi & 0xFFu;
+            const uint32_t db = (packed >> (2 * q)) & 3u;
+            c_rs[2 * q] = c_rs[2 * q + 1] = key[q];
+            c_bc[2 * q] = key[q];
+            c_imd[2 * q] = 0;
+            present |= (code >> 7) << (2 * q);
+            const int e = (int)(code & 0x7Fu) - 1;
+            bool dummy;
+            c_bc[2 * q + 1] = mutate(make_lane(e < 0 ? 0 : e), key[q], db, dummy);
+            c_imd[2 * q + 1] = ins_minus_del_of(e < 0 ? 0 : e);
+            present |= (e >= 0 ? 1u : 0u) << (2 * q + 1);
+        }
+        pick_best(c_bc, c_rs, c_imd, present, 1, res);
+        if (!(packed & (1u << 15))) {
+            res.found = -1;
+            res.n_matches = 0;
+        }
+        if (base + lane < n) out[base + lane] = res;
+    }
+}
+
 int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_ed, int five_prime,
                     smi_bc_result *d_out, hipStream_t s) {
     if (!n) return SMI_OK;
@@ -652,6 +806,8 @@ int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_
     if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
     if (max_ed == 0)
         hipLaunchKernelGGL(k_bc_match_ed1<0>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else if (P.nb)
+        hipLaunchKernelGGL(k_bc_match_ed1f, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else
         hipLaunchKernelGGL(k_bc_match_ed1<1>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     SMI_HIP(hipGetLastError());

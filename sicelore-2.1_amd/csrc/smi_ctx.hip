@@ -42,6 +42,7 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.t2 = ctx->t2;
     p.n1 = ctx->n1_valid ? ctx->n1 : nullptr;
     p.n2 = ctx->n1_valid ? ctx->n1 + kL1Words : nullptr;
+    p.nb = ctx->nb_valid ? ctx->nb : nullptr;
     return p;
 }
 
@@ -176,6 +177,8 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->t2 = o->t2;
     lane->n1 = o->n1;
     lane->n1_valid = o->n1_valid;
+    lane->nb = o->nb;
+    lane->nb_valid = o->nb_valid;
     lane->fine = o->fine;
     lane->rank = o->rank;
     lane->block_counts = o->block_counts;
@@ -193,6 +196,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(ctx->l1);
         (void)hipFree(ctx->t2);
         (void)hipFree(ctx->n1);
+        (void)hipFree(ctx->nb);
         (void)hipFree(ctx->fine);
         (void)hipFree(ctx->rank);
         (void)hipFree(ctx->block_counts);

@@ -93,6 +93,7 @@ struct Pyramid {
     const uint32_t *t2;  // two-stage top level of K-BC1: entry j = {word j of l0 | l0s, stage-2 word j}
     const uint32_t *n1;  // K-BC2, short used lists only (else null): the sequences one mutation step away FROM which a barcode can be reached (l1 layout)
     const uint32_t *n2;  // ... from which TWO OR MORE different barcodes can be reached (same layout)
+    const uint32_t *nb;  // K-BC1's offset filter (else null): 1 bit per key, set for every sequence one mutation step away from a barcode (512 MiB)
 };
 
 }  // namespace smi
@@ -105,6 +106,8 @@ struct smi_ctx {
     uint32_t *t2 = nullptr;
     uint32_t *n1 = nullptr;   // allocated with the first short barcode list (2 x 16 MiB: n1, then n2)
     bool n1_valid = false;    // describes the set that is loaded now
+    uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
+    bool nb_valid = false;
     uint32_t *fine = nullptr;
     uint32_t *rank = nullptr;
     uint32_t *block_counts = nullptr;  // scratch for the rank scan
