@@ -507,7 +507,11 @@ def main():
     f_scan = kernel_fields("k_scan<10>", "k_scan", k_scan, ALG_BYTES_PER_READ_SCAN)
     f_bc1 = kernel_fields("k_bc_match_ed1<1>", "k_bc_match_ed1", k_match, ALG_BYTES_PER_READ_BC1)
     f_scan["limiter"] = "integer VALU issue (bit-parallel gates, Needleman-Wunsch cells): not hbm, not mfma"
-    f_bc1["limiter"] = "dependent 4/8-byte gathers into the barcode pyramid (L2 / Infinity Cache / HBM request rate)"
+    f_bc1["limiter"] = "dependent 4/8-byte gathers into the barcode pyramid and the offset filter (L2 / Infinity Cache / HBM request rate)"
+    f_bc1["note"] = ("SURVEY 8d prices a read at 620 probes x 4 B; K-BC1 asks an exact 512 MiB bitmap of the set's inverse one-step neighbourhood "
+                     "(P.nb) once per offset and makes the 124 probes only where a barcode is in reach (1.6 of 5 offsets per read against the "
+                     "3.6 M list), so `achieved` in algorithmic bytes can exceed the HBM peak: it counts probes answered, not bytes moved; "
+                     "`traffic` is what the counters saw")
     dom, oth = (f_scan, f_bc1) if k_scan >= k_match else (f_bc1, f_scan)
     n_adapter = int(((scan_out[:, 6] >> 16) & 0xFF).eq(1).sum().item())
     res = {

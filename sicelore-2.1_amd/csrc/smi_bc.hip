@@ -662,8 +662,8 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1(const smi_bc_window *__res
 }
 
 // K-BC1 behind the offset filter (P.nb).  Phase 1 also reads, per lane, the neighbourhood bit of its five windows; phase 2 then runs
-// per OFFSET: the reads of the batch whose window at that offset has a barcode in reach are taken five at a time (ten probe rounds in
-// flight, as before), all others cost nothing.  Against the 3.6 M whitelist the neighbourhood holds 14 % of all 16-mers, so a read keeps
+// per OFFSET: the reads of the batch whose window at that offset has a barcode in reach are taken four at a time (eight probe rounds in
+// flight), all others cost nothing.  Against the 3.6 M whitelist the neighbourhood holds 14 % of all 16-mers, so a read keeps
 // 1.6 of its 5 offsets on average (its true one and a chance one now and then); against a used list only the true one.
 __global__ __launch_bounds__(256) void k_bc_match_ed1f(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                        Pyramid P, smi_bc_result *__restrict__ out) {
@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1f(const smi_bc_window *__re
     const unsigned long long subsA = (1ull << 48) - 1ull;
     const bool fp = five_prime != 0;
     constexpr int OFFS[5] = {0, -1, 1, -2, 2};
-    constexpr int kSlots = 5;  // (read, offset) pairs probed together
+    constexpr int kSlots = 4;  // (read, offset) pairs probed together: 3 / 4 / 5 / 8 measured 2.71 / 2.68 / 2.71 / 2.81 ms per 10 M reads
 
     for (size_t base = wave * 64; base < n; base += n_waves * 64) {
         smi_bc_window my;
