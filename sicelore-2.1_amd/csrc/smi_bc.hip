@@ -149,19 +149,12 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
         if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 2 * kL1Words * 4));
         SMI_HIP(hipMemsetAsync(ctx->n1, 0, 2 * kL1Words * 4, s));
-        struct Owner {  // one u32 per cell (512 MiB), only while the tables are built
-            uint32_t *p = nullptr;
-            ~Owner() {
-                if (p) (void)hipFree(p);
-            }
-        } owner;
-        SMI_HIP(hipMalloc((void **)&owner.p, kL1Words * 32 * sizeof(uint32_t)));
-        SMI_HIP(hipMemsetAsync(owner.p, 0xFF, kL1Words * 32 * sizeof(uint32_t), s));
+        if (!ctx->n1_owner) SMI_HIP(hipMalloc((void **)&ctx->n1_owner, kL1Words * 32 * sizeof(uint32_t)));  // one u32 per cell
+        SMI_HIP(hipMemsetAsync(ctx->n1_owner, 0xFF, kL1Words * 32 * sizeof(uint32_t), s));
         const unsigned g1 = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 64);
-        hipLaunchKernelGGL(k_set_n1, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1, owner.p);
-        hipLaunchKernelGGL(k_set_n2, dim3(g1), dim3(256), 0, s, d_keys, n, owner.p, ctx->n1 + kL1Words);
+        hipLaunchKernelGGL(k_set_n1, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1, ctx->n1_owner);
+        hipLaunchKernelGGL(k_set_n2, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1_owner, ctx->n1 + kL1Words);
         SMI_HIP(hipGetLastError());
-        SMI_HIP(hipStreamSynchronize(s));  // before `owner` is freed
         ctx->n1_valid = true;
     }
     SMI_HIP(hipStreamSynchronize(s));

@@ -197,6 +197,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(ctx->t2);
         (void)hipFree(ctx->n1);
         (void)hipFree(ctx->nb);
+        (void)hipFree(ctx->n1_owner);
         (void)hipFree(ctx->fine);
         (void)hipFree(ctx->rank);
         (void)hipFree(ctx->block_counts);

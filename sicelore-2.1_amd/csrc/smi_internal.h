@@ -107,6 +107,7 @@ struct smi_ctx {
     uint32_t *n1 = nullptr;   // allocated with the first short barcode list (2 x 16 MiB: n1, then n2)
     bool n1_valid = false;    // describes the set that is loaded now
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
+    uint32_t *n1_owner = nullptr;  // scratch of the n2 build (one u32 per n1 cell, 512 MiB), kept: hipMalloc / hipFree of that size cost ~100 ms per set load
     bool nb_valid = false;
     uint32_t *fine = nullptr;
     uint32_t *rank = nullptr;
