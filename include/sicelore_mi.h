@@ -402,7 +402,9 @@ int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, con
 /* ---- the same stages without gathered copies of the chunk: bases and qualities are read where the FASTQ text has them ------------------
  * (K-FQ's two gathers move 2 x the bases of a chunk through HBM and back; the chunk workers use these instead.)
  * d_seq_start / d_qual_start: per input record, from smi_fastq_index_device; d_offsets: its prefix array of read lengths, which stays the
- * coordinate system of the planes, of the fragment offsets and of every length. */
+ * coordinate system of the planes, of the fragment offsets and of every length.  The packer reads the text in 16-byte pieces: behind the
+ * bases of a record of 29 or more bases up to 31 further bytes of d_text are read (and ignored) -- in a record that smi_fastq_index_device
+ * accepted those are its own line end, '+' line and quality line. */
 int smi_pack_reads_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_seq_start, const uint64_t *d_offsets, size_t n,
                                uint64_t total_bases, uint32_t *d_planes, void *stream);
 /* text positions of the bases / qualities of the n_out output records: fragment f of input record d_frag_src[f] >> 2 begins
