@@ -8,9 +8,12 @@
 // same entry points the parity tests exercise one by one (include/sicelore_mi.h).  Device memory comes from a grow-only
 // arena owned by the context, so steady-state chunks allocate nothing.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <chrono>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -449,29 +452,70 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     }
     *n_done = 0;
     if (n == 0) return SMI_OK;
+    // SMI_AU_TIMING=1: the host stages of this call on stderr (where the time of the second worker goes)
+    const bool timing = std::getenv("SMI_AU_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "smi_assignumis_chunk %-12s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     std::vector<NameData> nd((size_t)n);
     std::vector<int32_t> cpos((size_t)n, 0);
     std::vector<uint8_t> has_pos((size_t)n, 0), rev((size_t)n, 0);
-    for (int32_t i = 0; i < n; i++) {
-        SMI_RC(parse_name(names + name_off[i], name_off[i + 1] - name_off[i], cfg->bc_edit_limit, nd[i]));
-        rev[i] = (flags[i] & 16) ? 1 : 0;
-        // NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116): reference position under read position
-        // polyA start - distanceFromReadEndForGrouping (3'), adapter end + cell_bc_length + umi_length + that distance (5')
-        const bool five = cfg->five_prime != 0;
-        if (nd[i].present && (five || nd[i].has_ps) && !(flags[i] & 4)) {
-            int32_t p = 0;
-            const int32_t read_pos = five ? (int32_t)nd[i].ae + 16 + 12 + cfg->grouping_distance : (int32_t)nd[i].ps - cfg->grouping_distance;
-            const int rc = smi_ref_position_at_read_position(cigars + cigar_off[i], (int32_t)(cigar_off[i + 1] - cigar_off[i]), pos0[i] + 1,
-                                                             read_pos, &p);
-            if (rc < 0) return rc;
-            if (rc == 1) {
-                has_pos[i] = 1;
-                cpos[i] = p;
+    // names and clustering positions: independent per record, on cfg->n_threads host threads (the reference parses them inside its
+    // parallel stream, UmiFinderWorker)
+    {
+        const int nt = std::max(1, std::min(cfg->n_threads > 0 ? cfg->n_threads : 1, 64));
+        std::vector<int> rcs((size_t)nt, SMI_OK);
+        std::vector<std::string> msgs((size_t)nt);  // the error text is thread-local: carried back to the calling thread
+        auto work = [&](int t) {
+            const int32_t lo = (int32_t)((int64_t)n * t / nt), hi = (int32_t)((int64_t)n * (t + 1) / nt);
+            for (int32_t i = lo; i < hi; i++) {
+                int rc = parse_name(names + name_off[i], name_off[i + 1] - name_off[i], cfg->bc_edit_limit, nd[i]);
+                if (rc != SMI_OK) {
+                    rcs[t] = rc;
+                    msgs[t] = smi_last_error();
+                    return;
+                }
+                rev[i] = (flags[i] & 16) ? 1 : 0;
+                // NanoporeRead$ReadScanData.generateReadScanData / getGenomePosition (L86-116): reference position under read position
+                // polyA start - distanceFromReadEndForGrouping (3'), adapter end + cell_bc_length + umi_length + that distance (5')
+                const bool five = cfg->five_prime != 0;
+                if (nd[i].present && (five || nd[i].has_ps) && !(flags[i] & 4)) {
+                    int32_t p = 0;
+                    const int32_t read_pos = five ? (int32_t)nd[i].ae + 16 + 12 + cfg->grouping_distance : (int32_t)nd[i].ps - cfg->grouping_distance;
+                    rc = smi_ref_position_at_read_position(cigars + cigar_off[i], (int32_t)(cigar_off[i + 1] - cigar_off[i]), pos0[i] + 1, read_pos, &p);
+                    if (rc < 0) {
+                        rcs[t] = rc;
+                        msgs[t] = smi_last_error();
+                        return;
+                    }
+                    if (rc == 1) {
+                        has_pos[i] = 1;
+                        cpos[i] = p;
+                    }
+                }
             }
+        };
+        if (nt == 1 || n < 4096)
+            for (int t = 0; t < nt; t++) work(t);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
         }
+        for (int t = 0; t < nt; t++)
+            if (rcs[t] != SMI_OK) {
+                set_error(msgs[t]);
+                return rcs[t];
+            }
     }
+    lap("names");
     std::vector<int32_t> region((size_t)n, -1);
     SMI_RC(smi_region_group(cpos.data(), has_pos.data(), rev.data(), n, cfg->max_dist, cfg->keep_data_end, region.data(), n_done));
+    lap("regions");
     const int32_t nd_ = *n_done;
     for (int32_t i = 0; i < n; i++) {
         smi_umi_tag &t = out[i];
@@ -480,42 +524,100 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
         t.center = -1;
         t.u1 = t.u2 = -1;
     }
-    // (cell barcode, region) groups in the order their first member appears, members in input order
-    std::unordered_map<std::string, uint32_t> index;
-    std::vector<std::vector<int32_t>> groups;
+    // the reads' own UMI windows (U7): independent per record, on the host threads
     std::vector<uint64_t> win((size_t)n, 0);
-    for (int32_t i = 0; i < nd_; i++) {
-        const NameData &d = nd[i];
-        const bool bc_ok = d.present && d.has_bc && d.has_bc_end && d.x && d.has_q;
-        uint64_t w = 0;
-        const bool has_w = bc_ok && umi_window(d, cfg->five_prime != 0, &w);
-        if (d.present && d.has_bc) out[i].flags |= SMI_UMI_HAS_BC;
-        if (has_w) {
-            win[i] = w;
-            out[i].flags |= SMI_UMI_HAS_U7;
-            for (int k = 0; k < 12; k++) out[i].u7[k] = dec4((uint32_t)(w >> (4 * (k + 1))) & 15u);
+    std::vector<uint8_t> has_w((size_t)n, 0);
+    {
+        const int nt = std::max(1, std::min(cfg->n_threads > 0 ? cfg->n_threads : 1, 64));
+        auto work = [&](int t) {
+            const int32_t lo = (int32_t)((int64_t)nd_ * t / nt), hi = (int32_t)((int64_t)nd_ * (t + 1) / nt);
+            for (int32_t i = lo; i < hi; i++) {
+                const NameData &d = nd[i];
+                const bool bc_ok = d.present && d.has_bc && d.has_bc_end && d.x && d.has_q;
+                uint64_t w = 0;
+                const bool ok = bc_ok && umi_window(d, cfg->five_prime != 0, &w);
+                if (d.present && d.has_bc) out[i].flags |= SMI_UMI_HAS_BC;
+                if (ok) {
+                    win[i] = w;
+                    has_w[i] = 1;
+                    out[i].flags |= SMI_UMI_HAS_U7;
+                    for (int k = 0; k < 12; k++) out[i].u7[k] = dec4((uint32_t)(w >> (4 * (k + 1))) & 15u);
+                }
+            }
+        };
+        if (nt == 1 || nd_ < 4096)
+            for (int t = 0; t < nt; t++) work(t);
+        else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
         }
-        if (!has_w || region[i] < 0) continue;
-        std::string key(d.bc, d.bc_len);
-        key += '#';
-        key += std::to_string(region[i]);
-        auto it = index.find(key);
-        if (it == index.end()) {
-            index.emplace(std::move(key), (uint32_t)groups.size());
-            groups.emplace_back(1, i);
-        } else
-            groups[it->second].push_back(i);
     }
-    std::vector<int32_t> order;
+    // (cell barcode, region) groups in the order their first member appears, members in input order.  Key = the barcode's bytes (up to
+    // 16, the usual case, held in two words; longer ones through a string map) + region: one pass gives every record its group and every
+    // group its size, a second one fills the member lists of the groups that have two or more
+    struct GKey {
+        uint64_t a, b;
+        uint32_t region, len;
+        bool operator==(const GKey &o) const { return a == o.a && b == o.b && region == o.region && len == o.len; }
+    };
+    struct GHash {
+        size_t operator()(const GKey &k) const {
+            uint64_t h = k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull) * 0xC2B2AE3D27D4EB4Full ^ ((uint64_t)k.region << 8 | k.len) * 0x165667B19E3779F9ull;
+            return (size_t)(h ^ (h >> 29));
+        }
+    };
+    std::unordered_map<GKey, uint32_t, GHash> index;
+    index.reserve((size_t)nd_);
+    std::unordered_map<std::string, uint32_t> long_index;
+    std::vector<int32_t> gid((size_t)nd_, -1);
+    std::vector<uint32_t> gsize;
+    for (int32_t i = 0; i < nd_; i++) {
+        if (!has_w[i] || region[i] < 0) continue;
+        const NameData &d = nd[i];
+        uint32_t g;
+        if (d.bc_len <= 16) {
+            GKey k{0, 0, (uint32_t)region[i], (uint32_t)d.bc_len};
+            std::memcpy(&k.a, d.bc, std::min<size_t>(d.bc_len, 8));
+            if (d.bc_len > 8) std::memcpy(&k.b, d.bc + 8, d.bc_len - 8);
+            auto it = index.find(k);
+            if (it == index.end()) {
+                g = (uint32_t)gsize.size();
+                index.emplace(k, g);
+                gsize.push_back(0);
+            } else
+                g = it->second;
+        } else {
+            std::string key(d.bc, d.bc_len);
+            key += '#';
+            key += std::to_string(region[i]);
+            auto it = long_index.find(key);
+            if (it == long_index.end()) {
+                g = (uint32_t)gsize.size();
+                long_index.emplace(std::move(key), g);
+                gsize.push_back(0);
+            } else
+                g = it->second;
+        }
+        gid[i] = (int32_t)g;
+        gsize[g]++;
+    }
     std::vector<uint32_t> goff(1, 0);
     std::vector<uint64_t> poff(1, 0), moff(1, 0);
-    for (const auto &g : groups) {
-        if (g.size() < 2) continue;  // UmiClustering.lambda$cluster$6
-        order.insert(order.end(), g.begin(), g.end());
-        const uint64_t k = g.size();
-        goff.push_back((uint32_t)order.size());
+    std::vector<int32_t> slot(gsize.size(), -1);  // group -> its number among the groups that are clustered
+    for (size_t g = 0; g < gsize.size(); g++) {
+        if (gsize[g] < 2) continue;  // UmiClustering.lambda$cluster$6
+        slot[g] = (int32_t)goff.size() - 1;
+        const uint64_t k = gsize[g];
+        goff.push_back(goff.back() + (uint32_t)k);
         poff.push_back(poff.back() + k * (k + 1) / 2);
         moff.push_back(moff.back() + k * k);
+    }
+    std::vector<int32_t> order((size_t)goff.back());
+    {
+        std::vector<uint32_t> cursor(goff.begin(), goff.end() - 1);
+        for (int32_t i = 0; i < nd_; i++)
+            if (gid[i] >= 0 && slot[(size_t)gid[i]] >= 0) order[cursor[(size_t)slot[(size_t)gid[i]]]++] = i;
     }
     const uint32_t n_groups = (uint32_t)goff.size() - 1;
     if (n_groups == 0) return SMI_OK;
@@ -526,6 +628,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
         wpk[j] = win[order[j]];
         qv[j] = nd[order[j]].q;
     }
+    lap("groups");
     // ---- K-UMI ------------------------------------------------------------------------------------------------------------
     SMI_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
@@ -543,6 +646,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     std::vector<uint8_t> dist(moff.back());
     SMI_HIP(hipMemcpyAsync(dist.data(), d_dist, moff.back(), hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
+    lap("k-umi");
     // ---- clustering -------------------------------------------------------------------------------------------------------
     std::vector<smi_umi_assignment> asg(m);
     std::vector<uint8_t> skipped(m, 0);
@@ -551,6 +655,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     if (cfg->cluster) cc = *cfg->cluster;
     SMI_RC(smi_umi_cluster_groups(dist.data(), moff.data(), goff.data(), n_groups, qv.data(), &cc, asg.data(), skipped.data(),
                                   cfg->n_threads > 0 ? cfg->n_threads : 1));
+    lap("clustering");
     for (uint32_t g = 0; g < n_groups; g++)
         for (uint32_t j = goff[g]; j < goff[g + 1]; j++) {
             smi_umi_tag &t = out[order[j]];

@@ -34,7 +34,7 @@ def main():
     res = {}
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
-    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq}
+    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis}
     for name, fn in legs.items():
         if only in (None, name):
             fn(pkg, synth, ctx, dev, wl, used, res)
@@ -99,6 +99,60 @@ def leg_umi(pkg, synth, ctx, dev, wl, used, res):
     dt = timed(lambda: ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out))
     res["umi_dist"] = {"groups": int(len(sizes)), "reads": n_reads, "pairs": int(po[-1]), "ms": dt * 1e3,
                        "pairs_per_s": int(po[-1]) / dt, "levenshtein_per_s": 9 * int(po[-1]) / dt}
+
+
+def leg_assignumis(pkg, synth, ctx, dev, wl, used, res):
+    """the second worker end to end: smi_assignumis_chunk (names parsed as getScanDatFromReadName does, clustering positions, region
+    grouping, K-UMI, UMI clustering) on one BamReader chunk.  Names come out of a real pass 2 over synthetic molecules; every molecule is
+    then read `copies` times (same barcode and UMI window, an error now and then), aligned to one of `genes` loci."""
+    import ctypes
+    scanfastq = importlib.import_module(graft.PKG_NAME + ".scanfastq")
+    lib = importlib.import_module(graft.PKG_NAME + ".lib")
+    rng = np.random.default_rng(5)
+    n_mol, copies, genes = 20_000, 6, 2_000
+    ctx.set_barcode_set(used.cpu().numpy().astype(np.uint64), mode=0)
+    mol = synth.gen_reads(n_mol, used, seed=77, err=0.0, q_mean=20.0)
+    seqs, quals = zip(*(synth.materialize(mol, i) for i in range(n_mol)))
+    text = "".join(f"@m{i} ch=1\n{s}\n+\n{q}\n" for i, (s, q) in enumerate(zip(seqs, quals))).encode()
+    rs = scanfastq.ReadScanner(ctx, max_ed=1, split_chimeras=False)
+    recs = [r for r in rs.pass2_chunk(text) if "_FAILED" not in r["name"] and "bc=" in r["name"]]
+    gene = rng.integers(0, genes, len(recs))
+    rows = []
+    for m, r in enumerate(recs):
+        q = r["name"].split(" ")[0]
+        head, x_rest = q.split("_X=")
+        x, rest = x_rest.split("_", 1)
+        for c in range(copies):
+            xs = list(x)
+            if rng.random() < 0.3:  # a sequencing error inside the window
+                xs[int(rng.integers(0, len(xs)))] = "ACGT"[int(rng.integers(0, 4))]
+            nm = f"{head.replace('m', 'r%d_' % c, 1)}_X={''.join(xs)}_{rest}"
+            rows.append((int(gene[m]) * 5_000 + int(rng.integers(-100, 100)), nm, 16 if gene[m] & 1 else 0, r["length"]))
+    rows.sort(key=lambda t: t[0])
+    n = len(rows)
+    enc = [t[1].encode() for t in rows]
+    noff = np.zeros(n + 1, dtype=np.uint32)
+    noff[1:] = np.cumsum([len(e) for e in enc])
+    nbuf = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8)
+    coff = np.arange(n + 1, dtype=np.uint32)
+    cbuf = np.array([(t[3] << 4) | 0 for t in rows] + [0], dtype=np.uint32)  # one M operation per record
+    fl = np.array([t[2] for t in rows], dtype=np.uint16)
+    p0 = np.array([max(t[0], 0) + 1_000_000 for t in rows], dtype=np.int32)
+    out = np.zeros(n, dtype=lib.UMI_TAG_DTYPE)
+    nd = ctypes.c_int32(0)
+    for threads in (1, 16):
+        cfg = lib.AssignUmisConfig()
+        ctx._check(ctx._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
+        cfg.n_threads = threads
+
+        def call():
+            ctx._check(ctx._lib.smi_assignumis_chunk(ctx._h, nbuf.ctypes.data, noff.ctypes.data, fl.ctypes.data, p0.ctypes.data, cbuf.ctypes.data,
+                                                     coff.ctypes.data, n, ctypes.byref(cfg), out.ctypes.data, ctypes.byref(nd)))
+        dt = timed(call)
+        res[f"assignumis_chunk_{threads}_threads"] = {
+            "records": n, "molecules": len(recs), "copies": copies, "loci": genes, "ms": dt * 1e3, "records_per_s": n / dt,
+            "clustered": int((out["flags"] & 4 != 0).sum()), "with_region": int((out["region"] >= 0).sum()),
+            "note": "one smi_assignumis_chunk call, host arrays in, tags out (name parsing, region grouping and clustering on the host, K-UMI on the device)"}
 
 
 def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
