@@ -284,3 +284,57 @@ def test_pass2_counters_per_barcode_and_ed(pkg, synth, gpu_ctx):
     assert tsv[0] == "Barcode\tn Reads with ED<=2 match\tED=0\tED=1\tED=2" and len(tsv) == 1 + int((exp.sum(1) > 0).sum())
     tot = [int(l.split("\t")[1].replace(",", "")) for l in tsv[1:]]
     assert tot == sorted(tot, reverse=True) and sum(tot) == exp.sum()
+
+
+@pytest.mark.parametrize("case", ["ed1_whitelist", "ed1_used_list", "ed2_used_list", "ed1_adversarial"])
+def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
+    """K-BC1's offset filter and K-BC2's item filter (the inverse one-step neighbourhood of the barcode set, smi_bc.hip) against the same
+    kernels without them: byte-identical result records.  The switches are read when a set is loaded."""
+    import os
+    five_prime = False
+    if case == "ed1_whitelist":
+        wl = synth.make_whitelist(1_000_000, seed=61)
+        keys, max_ed, mode = wl.numpy().astype(np.uint64), 1, 1
+        reg = synth.gen_bc_region(150_000, synth.pick_used(wl, 3000, seed=62), seed=63, five_prime=five_prime, n_rate=0.002)
+    elif case == "ed1_used_list":
+        wl = synth.make_whitelist(200_000, seed=64)
+        used = synth.pick_used(wl, 4000, seed=65)
+        keys, max_ed, mode = used.numpy().astype(np.uint64), 1, 0
+        reg = synth.gen_bc_region(150_000, used, seed=66, five_prime=True)
+        five_prime = True
+    elif case == "ed2_used_list":
+        wl = synth.make_whitelist(200_000, seed=67)
+        used = synth.pick_used(wl, 4000, seed=68)
+        keys, max_ed, mode = used.numpy().astype(np.uint64), 2, 0
+        reg = synth.gen_bc_region(30_000, used, seed=69, five_prime=five_prime, n_rate=0.002)
+    else:
+        # barcodes that are one and two steps away from each other, homopolymers and short repeats: where different mutations of a
+        # window coincide and where a child of a barcode has a second barcode in reach
+        rng = np.random.default_rng(70)
+        base = rng.integers(0, 1 << 32, 300, dtype=np.uint64)
+        near = [int(b) ^ (int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 16)))) for b in base]
+        near2 = [n ^ (int(rng.integers(1, 4)) << (2 * int(rng.integers(0, 16)))) for n in near]
+        shifted = [((int(b) << 2) | int(rng.integers(0, 4))) & 0xFFFFFFFF for b in base] + [int(b) >> 2 for b in base]
+        homo = [0, 0xFFFFFFFF, 0x55555555, 0xAAAAAAAA, 0x33333333, 0xCCCCCCCC, 0x0F0F0F0F]
+        keys = np.unique(np.array(list(map(int, base)) + near + near2 + shifted + homo, dtype=np.uint64))
+        used = torch.from_numpy(keys.astype(np.int64))
+        max_ed, mode = 1, 0
+        reg = synth.gen_bc_region(60_000, used, seed=71, five_prime=five_prime, err=0.08)
+    win = synth.pack_windows(reg["codes"], reg["ae"], five_prime)
+    gpu_ctx.set_barcode_set(keys, mode=mode)
+    with_filter = _run_device(pkg, gpu_ctx, win, max_ed, five_prime)
+    got2 = None
+    if case == "ed1_adversarial":  # the same set through K-BC2 as well
+        got2 = _run_device(pkg, gpu_ctx, win, 2, five_prime)
+    monkeypatch.setenv("SMI_BC1_NO_FILTER", "1")
+    monkeypatch.setenv("SMI_BC2_NO_FILTER", "1")
+    gpu_ctx.set_barcode_set(keys, mode=mode)
+    without = _run_device(pkg, gpu_ctx, win, max_ed, five_prime)
+    assert (with_filter.view(np.uint8) == without.view(np.uint8)).all()
+    if got2 is not None:
+        assert (got2.view(np.uint8) == _run_device(pkg, gpu_ctx, win, 2, five_prime).view(np.uint8)).all()
+    assert int((with_filter["found"] == 1).sum()) > 1000
+    monkeypatch.delenv("SMI_BC1_NO_FILTER")
+    monkeypatch.delenv("SMI_BC2_NO_FILTER")
+    assert "SMI_BC1_NO_FILTER" not in os.environ
+    gpu_ctx.set_barcode_set(keys, mode=mode)  # leave the context with its filters on
