@@ -48,6 +48,7 @@ struct ScanParams {
     __host__ __device__ __forceinline__ uint32_t a4(int i) const { return (adapter_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
+    int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates
 };
 
 // ---- LDS plane access -----------------------------------------------------------------------------------------
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         int pb = 0, pe = 0;
-        const bool has_t = active && long_enough && !(FP && P.dont_polya) && find_polyt(planes, tid, P, pb, pe);
+        const bool has_t = active && long_enough && !(FP && P.dont_polya) && !(P.ablate & 4) && find_polyt(planes, tid, P, pb, pe);
         uint64_t am[3] = {0, 0, 0};
         // 5' barcoding scans an end when the polyT was found at the OTHER end (or no polyA is asked for):
         // PolyATadapterAnalyzer_5pBCUMI.java:L51-68
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 cmask[2 * kBlock + tid] = am[2];
             } else {
                 uint64_t tm[2] = {0, 0};
-                if (active && long_enough && !FP) {
+                if (active && long_enough && !FP && !(P.ablate & 8)) {
                     // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++)
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                         k -= c;
                     }
                     AlnStats st;
+                    st.ne = 9.0f, st.end5 = st.endn = 0.0f, st.nmis = 9, st.ins = st.del = st.consec = st.best_two = 0, st.term6 = false;
                     // the column masks of the alignment are the four base planes of the read slice, selected per pattern
                     // base: four window fetches per candidate, not one per pattern base
                     uint32_t W[4];
@@ -348,12 +350,12 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                     auto col_of = [&](uint32_t a4) -> uint32_t {
                         return ((a4 & 1u) ? W[0] : 0u) | ((a4 & 2u) ? W[1] : 0u) | ((a4 & 4u) ? W[2] : 0u) | ((a4 & 8u) ? W[3] : 0u);
                     };
-                    if (kind == 0) {
+                    if (kind == 0 && !(P.ablate & 2)) {
                         uint32_t col[AD];
 #pragma unroll
                         for (int c = 0; c < AD; c++) col[c] = col_of(SHIP ? shipped_a4<AD>(c) : P.a4(c)) & ((1u << AD) - 1u);
                         nw_full<AD, true, false, kBandAd>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
-                    } else {
+                    } else if (kind == 1 && !(P.ablate & 1)) {
                         uint32_t col[16];
 #pragma unroll
                         for (int c = 0; c < 16; c++) col[c] = col_of(tso4(c)) & 0xFFFFu;
@@ -641,6 +643,8 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     for (int i = 0; i < 22 && i < ad; i++) P.adapter_nib[i >> 3] |= (cfg->adapter4[i] & 15u) << ((i & 7) * 4);
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
+    const char *abl = std::getenv("SMI_SCAN_ABLATE");  // measurement only (tools/gpu_scan_ablate.sh): the results are wrong by construction
+    P.ablate = abl ? std::atoi(abl) : 0;
     const size_t n_ends = 2 * n;
     const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 64);  // measured: x4 8.2, x16 7.5, x64 7.2, uncapped 7.7 ms
     if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;
