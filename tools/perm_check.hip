@@ -1,4 +1,5 @@
-// v_perm_b32 operand order check: prints perm(hi, lo, sel) for sel = 0x07030201
+// v_perm_b32 / v_alignbyte_b32 operand order check (what enc4x4, rc4 and load_window rely on): prints perm(hi, lo, sel) for sel = 0x07030201
+// build and run on the GPU box: hipcc --offload-arch=gfx950 -O2 tools/perm_check.hip -o /tmp/perm_check && /tmp/perm_check
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(uint32_t *o) {
