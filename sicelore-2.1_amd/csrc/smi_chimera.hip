@@ -262,25 +262,7 @@ __device__ __forceinline__ uint64_t gate_two(const PlaneWin &w, const uint32_t *
 // block so that the compiler does not fuse them into three-operand forms, which issue at half the rate and drag their
 // neighbours along: profiles/r02/valu_peak.json).
 // ---------------------------------------------------------------------------------------------------------------
-#define SMI_MYERS_STEP(EQ)                                                                                          \
-    asm volatile("v_or_b32 %2, %5, %1\n\t"  /* Xv = Eq | Mv                  */                                      \
-                 "v_and_b32 %3, %5, %0\n\t" /* t  = Eq & Pv                  */                                      \
-                 "v_add_u32 %3, %3, %0\n\t" /* t += Pv                       */                                      \
-                 "v_xor_b32 %3, %3, %0\n\t" /* t ^= Pv                       */                                      \
-                 "v_or_b32 %3, %3, %5\n\t"  /* Xh = t | Eq                   */                                      \
-                 "v_or_b32 %4, %3, %0\n\t"  /* u  = Xh | Pv                  */                                      \
-                 "v_not_b32 %4, %4\n\t"     /* u  = ~u                       */                                      \
-                 "v_or_b32 %4, %1, %4\n\t"  /* Ph = Mv | u                   */                                      \
-                 "v_and_b32 %3, %0, %3\n\t" /* Mh = Pv & Xh                  */                                      \
-                 "v_add_u32 %4, %4, %4\n\t" /* Ph <<= 1                      */                                      \
-                 "v_or_b32 %4, 1, %4\n\t"   /* Ph |= 1  (D[0][j] = j)        */                                      \
-                 "v_add_u32 %3, %3, %3\n\t" /* Mh <<= 1                      */                                      \
-                 "v_or_b32 %0, %2, %4\n\t"  /* w  = Xv | Ph                  */                                      \
-                 "v_not_b32 %0, %0\n\t"     /* w  = ~w                       */                                      \
-                 "v_or_b32 %0, %3, %0\n\t"  /* Pv = Mh | w                   */                                      \
-                 "v_and_b32 %1, %4, %2\n\t" /* Mv = Ph & Xv                  */                                      \
-                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                           \
-                 : "v"(EQ))
+// (SMI_MYERS_STEP: smi_nw.h)
 
 // V[b]: plane b of the read slice, bit-reversed into the low M bits (bit k = slice base M-1-k).  idx[j] (wave-uniform): plane of the
 // j-th pattern base consumed.  -> min over i in [M - lead_max, M] of D[i][M]

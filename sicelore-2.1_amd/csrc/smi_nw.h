@@ -236,4 +236,50 @@ __device__ __forceinline__ float nw_errors(const uint32_t (&col)[N]) {
     return __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));
 }
 
+// ---- Myers / Hyyro bit-vector step shared by the exact pre-filters of K-CHIM-A and K-SCAN (derivation: smi_chimera.hip "Exact
+// pre-filter of the Needleman-Wunsch acceptance tests").  Sixteen two-cycle VALU operations per pattern base in one asm block.
+#define SMI_MYERS_STEP(EQ)                                                                                          \
+    asm volatile("v_or_b32 %2, %5, %1\n\t"  /* Xv = Eq | Mv                  */                                      \
+                 "v_and_b32 %3, %5, %0\n\t" /* t  = Eq & Pv                  */                                      \
+                 "v_add_u32 %3, %3, %0\n\t" /* t += Pv                       */                                      \
+                 "v_xor_b32 %3, %3, %0\n\t" /* t ^= Pv                       */                                      \
+                 "v_or_b32 %3, %3, %5\n\t"  /* Xh = t | Eq                   */                                      \
+                 "v_or_b32 %4, %3, %0\n\t"  /* u  = Xh | Pv                  */                                      \
+                 "v_not_b32 %4, %4\n\t"     /* u  = ~u                       */                                      \
+                 "v_or_b32 %4, %1, %4\n\t"  /* Ph = Mv | u                   */                                      \
+                 "v_and_b32 %3, %0, %3\n\t" /* Mh = Pv & Xh                  */                                      \
+                 "v_add_u32 %4, %4, %4\n\t" /* Ph <<= 1                      */                                      \
+                 "v_or_b32 %4, 1, %4\n\t"   /* Ph |= 1  (D[0][j] = j)        */                                      \
+                 "v_add_u32 %3, %3, %3\n\t" /* Mh <<= 1                      */                                      \
+                 "v_or_b32 %0, %2, %4\n\t"  /* w  = Xv | Ph                  */                                      \
+                 "v_not_b32 %0, %0\n\t"     /* w  = ~w                       */                                      \
+                 "v_or_b32 %0, %3, %0\n\t"  /* Pv = Mh | w                   */                                      \
+                 "v_and_b32 %1, %4, %2\n\t" /* Mv = Ph & Xv                  */                                      \
+                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                           \
+                 : "v"(EQ))
+
+
+// The bound for the 16-mer TSO of K-SCAN ("AACGCAGAGTACATGG", Jar/config.xml:155), pattern consumed from its end, planes as compile-time
+// constants: V[b] = plane b (A G C T) of the 16-base read slice bit-reversed into the low 16 bits.
+//   -> min over s <= lead_max of Levenshtein(TSO, slice[s ..]), a lower bound of Match.countErrorsInNeedleman whenever that is < lead_max + 0.5
+__device__ __forceinline__ int myers_bound_tso16(const uint32_t (&V)[4], int lead_max) {
+    constexpr int M = 16;
+    // planes of "AACGCAGAGTACATGG" read backwards: G G T A C A T G A G A C G C A A
+    constexpr int PL[M] = {1, 1, 3, 0, 2, 0, 3, 1, 0, 1, 0, 2, 1, 2, 0, 0};
+    uint32_t pv = 0xFFFFFFFFu, mv = 0u, t_xv, t_a, t_b;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const uint32_t eqv = V[PL[j]];
+        SMI_MYERS_STEP(eqv);
+    }
+    const uint32_t mask = (1u << M) - 1u;
+    int d = M + __popc(pv & mask) - __popc(mv & mask);  // D[M][M]
+    int best = d;
+    for (int k = M - 1; k >= M - lead_max && k >= 0; k--) {
+        d -= (int)((pv >> k) & 1u) - (int)((mv >> k) & 1u);
+        best = min(best, d);
+    }
+    return best;
+}
+
 }  // namespace smi

@@ -48,7 +48,7 @@ struct ScanParams {
     __host__ __device__ __forceinline__ uint32_t a4(int i) const { return (adapter_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
-    int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates
+    int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates, 16 no TSO pre-filter (results unchanged)
 };
 
 // ---- LDS plane access -----------------------------------------------------------------------------------------
@@ -305,6 +305,73 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++)
                         tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
+                }
+                if (SHIP && !(P.ablate & 16)) {
+                    // Exact pre-filter of the ISOLATED TSO candidates.  A candidate's alignment matters in two ways only: it may be
+                    // accepted (Math.round(ne) <= 5, AdapterTSOanalyzer L96-104), or its error count makes the scan jump over the next
+                    // candidates (delta = round(ne - 5) - 1 <= 26: an alignment of two 16-mers has at most 32 columns).  A candidate
+                    // without another candidate of its end among the next 26 positions can only matter by being accepted, and it
+                    // cannot be when the bit-vector bound min_s Levenshtein(TSO, slice[s ..]) (s <= 5 leading template gaps, which is
+                    // all an alignment with ne < 5.5 can have) exceeds 5 -- smi_nw.h myers_bound_tso16, 16 two-cycle operations per
+                    // pattern base instead of a 184-cell fill and a walk.  About a third of the TSO candidates go this way (the
+                    // chance hits on the end that has no TSO, and behind the true site on the end that has one); the generic
+                    // kernels align every candidate, and the parity suite runs both.
+                    auto shr128 = [](uint64_t &lo, uint64_t &hi, int k) {
+                        lo = (lo >> k) | (hi << (64 - k));
+                        hi >>= k;
+                    };
+                    uint64_t slo = tm[0], shi = tm[1];
+                    shr128(slo, shi, 1);  // a candidate 1 position further on
+#pragma unroll
+                    for (int k = 1; k <= 8; k <<= 1) {  // ... 1..2, 1..4, 1..8, 1..16
+                        uint64_t a = slo, b = shi;
+                        shr128(a, b, k);
+                        slo |= a;
+                        shi |= b;
+                    }
+                    {
+                        uint64_t a = slo, b = shi;
+                        shr128(a, b, 10);  // ... 1..26
+                        slo |= a;
+                        shi |= b;
+                    }
+                    const uint64_t iso0 = tm[0] & ~slo, iso1 = tm[1] & ~shi;
+                    int tot_iso;
+                    const int off_iso = wave_exscan(__popcll(iso0) + __popcll(iso1), lane, tot_iso);
+                    if (tot_iso) {  // wave-uniform
+                        cmask[0 * kBlock + tid] = iso0;
+                        cmask[1 * kBlock + tid] = iso1;
+                        coff[tid] = (uint32_t)off_iso;
+                        uint32_t *drop = ent + tid * 5;  // three words of dropped positions per end
+                        drop[0] = drop[1] = drop[2] = 0u;
+                        wave_sync();
+                        for (int base = 0; base < tot_iso; base += 64) {
+                            const int en = base + lane;
+                            if (en < tot_iso) {
+                                int lo = 0, hi = 64;
+                                while (hi - lo > 1) {
+                                    const int mid = (lo + hi) >> 1;
+                                    if ((int)coff[wbase + mid] <= en)
+                                        lo = mid;
+                                    else
+                                        hi = mid;
+                                }
+                                const int owner = wbase + lo;
+                                const int k = en - (int)coff[owner];
+                                const uint64_t mm = cmask[0 * kBlock + owner];
+                                const int c0 = __popcll(mm);
+                                const int bit = k < c0 ? kth_bit(mm, k) : 64 + kth_bit(cmask[1 * kBlock + owner], k - c0);  // scan position - 1
+                                uint32_t V[4];
+#pragma unroll
+                                for (int c = 0; c < 4; c++) V[c] = __brev(get32(planes + c * kLdsWords * kBlock, owner, bit)) >> 16;
+                                if (myers_bound_tso16(V, 5) > 5) atomicOr(&ent[owner * 5 + (bit >> 5)], 1u << (bit & 31));
+                            }
+                        }
+                        wave_sync();
+                        tm[0] &= ~((uint64_t)drop[0] | ((uint64_t)drop[1] << 32));
+                        tm[1] &= ~(uint64_t)drop[2];
+                        wave_sync();  // cmask / coff / ent are written again below
+                    }
                 }
                 const int n_ts = __popcll(tm[0]) + __popcll(tm[1]);
                 no = (uint32_t)n_ts | ((uint32_t)wave_exscan(n_ts, lane, total) << 8);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # where K-SCAN's time goes: the bench step with parts of the kernel switched off (results are wrong by construction)
 set -u
-for a in 0 1 2 4 8 3 15; do
+for a in 0 16 1 2 4 8 3 15; do
   SMI_SCAN_ABLATE=$a timeout -k 10 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --two-pass-reads 0 --e2e-reads 0 2>/dev/null | python -c "
 import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ablate $a', round(d['roofline']['kernels_ms']['k_scan<10>'],3), 'ms')"
 done
