@@ -268,7 +268,8 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
             const int last = FP ? P.window5 : min(pe - AD, pe - 12);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
-                am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return SHIP ? shipped_a4<AD>(i) : P.a4(i); }), last - ch * 64);
+                if (last > ch * 64)  // (the third chunk is needed by the few ends whose polyT ends beyond position 138: most waves skip it)
+                    am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return SHIP ? shipped_a4<AD>(i) : P.a4(i); }), last - ch * 64);
         }
         const int n_ad = __popcll(am[0]) + __popcll(am[1]) + __popcll(am[2]);
         const int lane = tid & 63, wbase = tid & ~63;  // this wave's lanes are wbase .. wbase+63
