@@ -99,6 +99,42 @@ __global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *
     }
 }
 
+// K-BC1's neighbourhood table: for every (barcode w, step) pair the sequence X = n1_member(w, step) together with the ONE mutation of the
+// reference's enumeration that leads from X back to w -- kind (0 X is w, 1 substitution, 2 insertion, 3 deletion), position, and the base
+// that the step writes (substitution: w's base there; insertion: the inserted base; deletion: the base it appends, which must be the
+// read's next base).  A window that the offset filter lets through is looked up here and its level-0 / level-1 matches are read off the
+// entries: no mutant is generated and no membership is probed.  Open addressing over 8-byte slots, linear probing, 1.6 slots per pair.
+__device__ __forceinline__ uint32_t nt_hash(uint32_t x) { return x * 0x9E3779B1u; }
+// first slot of the 8-slot bucket (one 64-byte line) of x; cap is a multiple of 8
+__device__ __forceinline__ uint32_t nt_slot(uint32_t x, uint32_t cap) { return (uint32_t)(((uint64_t)nt_hash(x) * (cap >> 3)) >> 32) << 3; }
+__global__ void k_set_nt(const uint32_t *__restrict__ keys, size_t n, unsigned long long *__restrict__ nt, uint32_t cap) {
+    const size_t total = n * kN1Slots;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t w = keys[i / kN1Slots];
+        const int slot = (int)(i % kN1Slots);
+        const uint32_t x = n1_member(w, slot);
+        uint32_t kind, pos, base;
+        if (slot < 48) {  // X = w with position pos changed: the step back substitutes w's base
+            kind = 1u, pos = (uint32_t)(slot / 3), base = (w >> (30 - 2 * pos)) & 3u;
+        } else if (slot < 108) {  // X = w without position p1: the step back inserts w[p1] behind position p1 - 1
+            const int p1 = 1 + (slot - 48) / 4;
+            kind = 2u, pos = (uint32_t)(p1 - 1), base = (w >> (30 - 2 * p1)) & 3u;
+        } else if (slot < 168) {  // X = w with a base inserted at q: the step back deletes position q and appends w's last base
+            kind = 3u, pos = (uint32_t)((slot - 108) / 4), base = w & 3u;
+        } else {
+            kind = 0u, pos = 0u, base = 0u;
+        }
+        const unsigned long long entry = (1ull << 40) | ((unsigned long long)x << 8) | (kind | (pos << 2) | (base << 6));
+        // first free slot of the bucket, else of the next one: a bucket that still has a free slot has never overflowed
+        uint32_t idx = nt_slot(x, cap);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&nt[idx], 0ull, entry);
+            if (old == 0ull || old == entry) break;
+            idx = idx + 1 == cap ? 0u : idx + 1;
+        }
+    }
+}
+
 // popcount of every 256-key block of the fine bitmap (8 words, read as two 16-B vectors)
 __global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restrict__ counts) {
     size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -137,6 +173,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     SMI_HIP(hipMemcpyAsync(&last[0], ctx->rank + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     ctx->nb_valid = false;
+    ctx->nt_cap = 0;
     if (n > 0 && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
         if (!ctx->nb) SMI_HIP(hipMalloc((void **)&ctx->nb, kFineWords * 4));
         SMI_HIP(hipMemsetAsync(ctx->nb, 0, kFineWords * 4, s));
@@ -144,6 +181,24 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
         hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, s, d_keys, n, ctx->nb);
         SMI_HIP(hipGetLastError());
         ctx->nb_valid = true;
+        ctx->nt_cap = 0;
+        if (!std::getenv("SMI_BC1_NO_TABLE")) {  // (the switch: the filtered kernel that enumerates the mutants of the flagged offsets)
+            const size_t pairs = n * (size_t)kN1Slots;
+            const size_t cap = (std::max<size_t>(4096, pairs + pairs / 2 + pairs / 10) + 7) & ~(size_t)7;
+            if (cap < 0xFFFFFFFFull) {
+                if (ctx->nt_alloc < cap) {
+                    if (ctx->nt) SMI_HIP(hipFree(ctx->nt));
+                    ctx->nt = nullptr;
+                    ctx->nt_alloc = 0;
+                    SMI_HIP(hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)));
+                    ctx->nt_alloc = cap;
+                }
+                SMI_HIP(hipMemsetAsync(ctx->nt, 0, cap * sizeof(uint64_t), s));
+                hipLaunchKernelGGL(k_set_nt, dim3(gb), dim3(256), 0, s, d_keys, n, reinterpret_cast<unsigned long long *>(ctx->nt), (uint32_t)cap);
+                SMI_HIP(hipGetLastError());
+                ctx->nt_cap = (uint32_t)cap;
+            }
+        }
     }
     ctx->n1_valid = false;
     if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
@@ -789,6 +844,96 @@ __global__ __launch_bounds__(256) void k_bc_match_ed1f(const smi_bc_window *__re
     }
 }
 
+// K-BC1 from the neighbourhood table (P.nt), two kernels.
+// k_bc_codes_ed1t: one lane = one (read, offset) pair, so that every look-up of the batch is in flight at once (with a lane per read the
+// five windows of a read were looked up one behind the other and a wave waited for its slowest lane: 2.5 ms, 1.5 of them waiting).  The
+// window's filter bit (P.nb) first; a window whose bit is set reads the 64-byte bucket of its sequence and every entry with that sequence
+// names one mutation of the reference's enumeration that turns the window into a barcode: the exact match (kind 0), or the enumeration
+// index 8 * position + kind slot of a level-1 match -- valid unless it is a deletion whose appended base is not the read's next base, or
+// the insertion behind position 14 of a window that does not end in A (the Java shift wrap, see `mutate`).  The smallest valid index is
+// the match the reference's HashSet keeps.  -> one byte per pair: exact << 7 | (index + 1).  No mutant is generated, no membership probed.
+// k_bc_pick_ed1t: one lane = one read: the HashSet-order / best-second rule over its five bytes.
+__global__ __launch_bounds__(256) void k_bc_codes_ed1t(const smi_bc_window *__restrict__ win, size_t n, int five_prime, Pyramid P,
+                                                       uint8_t *__restrict__ codes) {
+    const bool fp = five_prime != 0;
+    const size_t total = n * 5;
+    for (size_t j = blockIdx.x * (size_t)blockDim.x + threadIdx.x; j < total; j += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = j / 5;
+        const int q = (int)(j - 5 * i);
+        const int off = q == 0 ? 0 : (q == 1 ? -1 : (q == 2 ? 1 : (q == 3 ? -2 : 2)));  // the reference's order (Parser.java:L203)
+        const smi_bc_window my = win[i];
+        uint32_t code = 0;
+        if (my.flags & SMI_WIN_VALID) {
+            const OffsetKey k = make_key(my.bases, my.nmask, off, fp);
+            const uint32_t K = k.key;
+            if (k.usable && ((P.nb[K >> 5] >> (K & 31u)) & 1u)) {
+                uint32_t best = 255u;
+                uint32_t idx = nt_slot(K, P.nt_cap);
+                for (;;) {
+                    uint64_t e[8];
+                    __builtin_memcpy(e, P.nt + idx, 64);  // one bucket = one line
+                    bool open = false;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        open = open || e[t] == 0ull;
+                        if ((uint32_t)(e[t] >> 8) == K && (e[t] >> 40)) {
+                            const uint32_t kind = (uint32_t)e[t] & 3u, pos = ((uint32_t)e[t] >> 2) & 15u, base = ((uint32_t)e[t] >> 6) & 3u;
+                            if (kind == 0u) {
+                                code |= 0x80u;  // exact match (BarcodeMatchTester.java:L204-206)
+                            } else if (kind == 1u) {
+                                const uint32_t cur = (K >> (30 - 2 * pos)) & 3u;
+                                best = min(best, 8u * pos + base - (base > cur ? 1u : 0u));  // substitutions by ascending base, the current one skipped
+                            } else if (kind == 2u) {
+                                if (!(pos == 14u && (K & 3u) != 0u)) best = min(best, 8u * pos + 3u + base);
+                            } else {
+                                if (base == k.del_base) best = min(best, 8u * pos + 7u);
+                            }
+                        }
+                    }
+                    if (open) break;  // a bucket with a free slot has never overflowed into the next one
+                    idx = idx + 8 == P.nt_cap ? 0u : idx + 8;
+                }
+                if (best != 255u) code |= best + 1u;
+            }
+        }
+        codes[j] = (uint8_t)code;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bc_pick_ed1t(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
+                                                      const uint8_t *__restrict__ codes, smi_bc_result *__restrict__ out) {
+    const bool fp = five_prime != 0;
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const smi_bc_window my = win[i];
+        const bool valid = my.flags & SMI_WIN_VALID;
+        smi_bc_result res;
+        uint32_t c_bc[10], c_rs[10];
+        int c_imd[10];
+        uint32_t present = 0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const OffsetKey k = make_key(my.bases, my.nmask, OFFS[q], fp);
+            const uint32_t code = codes[5 * i + q];
+            c_rs[2 * q] = c_rs[2 * q + 1] = k.key;
+            c_bc[2 * q] = k.key;
+            c_imd[2 * q] = 0;
+            present |= (code >> 7) << (2 * q);
+            const int e = (int)(code & 0x7Fu) - 1;
+            bool dummy;
+            c_bc[2 * q + 1] = mutate(make_lane(e < 0 ? 0 : e), k.key, k.del_base, dummy);
+            c_imd[2 * q + 1] = ins_minus_del_of(e < 0 ? 0 : e);
+            present |= (e >= 0 ? 1u : 0u) << (2 * q + 1);
+        }
+        pick_best(c_bc, c_rs, c_imd, present, 1, res);
+        if (!valid) {
+            res.found = -1;
+            res.n_matches = 0;
+        }
+        out[i] = res;
+    }
+}
+
 int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_ed, int five_prime,
                     smi_bc_result *d_out, hipStream_t s) {
     if (!n) return SMI_OK;
@@ -796,9 +941,23 @@ int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_
     Pyramid P = pyramid_of(ctx);
     const size_t n_waves = (n + 63) / 64;
     const unsigned grid = (unsigned)((n_waves + 3) / 4);  // one batch of 64 reads per wave: measured 3 % faster than a capped grid
+    if (max_ed != 0 && P.nt && ctx->bc_codes_bytes < 5 * n) {  // one byte per (read, offset) between the two kernels of the table path
+        SMI_HIP(hipStreamSynchronize(s));
+        if (ctx->bc_codes) SMI_HIP(hipFree(ctx->bc_codes));
+        ctx->bc_codes = nullptr;
+        ctx->bc_codes_bytes = 0;
+        SMI_HIP(hipMalloc((void **)&ctx->bc_codes, 5 * n + 5 * n / 4));
+        ctx->bc_codes_bytes = 5 * n + 5 * n / 4;
+    }
     if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
     if (max_ed == 0)
         hipLaunchKernelGGL(k_bc_match_ed1<0>, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else if (P.nt) {
+        hipLaunchKernelGGL(k_bc_codes_ed1t, dim3((unsigned)std::min<size_t>((5 * n + 255) / 256, 256 * 256)), dim3(256), 0, s, d_win, n, five_prime, P,
+                           ctx->bc_codes);
+        hipLaunchKernelGGL(k_bc_pick_ed1t, dim3((unsigned)std::min<size_t>((n + 255) / 256, 256 * 64)), dim3(256), 0, s, d_win, n, five_prime,
+                           ctx->bc_codes, d_out);
+    }
     else if (P.nb)
         hipLaunchKernelGGL(k_bc_match_ed1f, dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else

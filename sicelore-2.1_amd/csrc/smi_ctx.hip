@@ -43,6 +43,8 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.n1 = ctx->n1_valid ? ctx->n1 : nullptr;
     p.n2 = ctx->n1_valid ? ctx->n1 + kL1Words : nullptr;
     p.nb = ctx->nb_valid ? ctx->nb : nullptr;
+    p.nt = ctx->nb_valid && ctx->nt_cap ? ctx->nt : nullptr;
+    p.nt_cap = ctx->nt_cap;
     return p;
 }
 
@@ -179,6 +181,8 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->n1_valid = o->n1_valid;
     lane->nb = o->nb;
     lane->nb_valid = o->nb_valid;
+    lane->nt = o->nt;
+    lane->nt_cap = o->nt_cap;
     lane->fine = o->fine;
     lane->rank = o->rank;
     lane->block_counts = o->block_counts;
@@ -197,11 +201,13 @@ int smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(ctx->t2);
         (void)hipFree(ctx->n1);
         (void)hipFree(ctx->nb);
+        (void)hipFree(ctx->nt);
         (void)hipFree(ctx->n1_owner);
         (void)hipFree(ctx->fine);
         (void)hipFree(ctx->rank);
         (void)hipFree(ctx->block_counts);
     }
+    (void)hipFree(ctx->bc_codes);
     (void)hipFree(ctx->stage_in);
     (void)hipFree(ctx->scan_tmp);
     (void)hipFree(ctx->arena);

@@ -94,6 +94,8 @@ struct Pyramid {
     const uint32_t *n1;  // K-BC2, short used lists only (else null): the sequences one mutation step away FROM which a barcode can be reached (l1 layout)
     const uint32_t *n2;  // ... from which TWO OR MORE different barcodes can be reached (same layout)
     const uint32_t *nb;  // K-BC1's offset filter (else null): 1 bit per key, set for every sequence one mutation step away from a barcode (512 MiB)
+    const uint64_t *nt;  // K-BC1's neighbourhood table (else null): open addressing, entry = 1 << 40 | sequence << 8 | the step that leads from it to a barcode
+    uint32_t nt_cap;     // its slots
 };
 
 }  // namespace smi
@@ -109,6 +111,11 @@ struct smi_ctx {
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
     uint32_t *n1_owner = nullptr;  // scratch of the n2 build (one u32 per n1 cell, 512 MiB), kept: hipMalloc / hipFree of that size cost ~100 ms per set load
     bool nb_valid = false;
+    uint64_t *nt = nullptr;   // grown on demand: 1.6 slots of 8 bytes per (barcode, step) pair, 7.8 GB for the 3.6 M list
+    size_t nt_alloc = 0;      // slots allocated
+    uint32_t nt_cap = 0;      // slots in use by the set that is loaded now (0: no table)
+    uint8_t *bc_codes = nullptr;  // K-BC1, table path: one byte per (read, offset) between its two kernels (grow-only, private to a context or lane)
+    size_t bc_codes_bytes = 0;
     uint32_t *fine = nullptr;
     uint32_t *rank = nullptr;
     uint32_t *block_counts = nullptr;  // scratch for the rank scan
