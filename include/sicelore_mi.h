@@ -92,7 +92,7 @@ int smi_ctx_create(int device, smi_ctx **out);
 int smi_ctx_destroy(smi_ctx *ctx);
 int smi_ctx_device(const smi_ctx *ctx);
 /* A worker lane of `owner`: a context with its own stream, device arena, pinned output buffers and timing that READS the owner's barcode
- * set instead of holding the 616 MiB membership pyramid and the 512 MiB neighbourhood bitmap again -- several host threads, one lane each, overlap their uploads, kernels and
+ * set instead of holding the 616 MiB membership pyramid and the neighbourhood bitmap and table (up to 8.3 GB for the whole whitelist) again -- several host threads, one lane each, overlap their uploads, kernels and
  * downloads on one GPU over ONE set, as the reference's nCPU Parser workers share one hashMapForBCfinding
  * (FJ!nanoporereadscanner/WorkerReadscanner.java:L188-204).  Every entry point takes a lane except smi_set_barcode_set*: load the set on the
  * owner (no lane busy meanwhile), then smi_ctx_lane_refresh each lane.  Destroy the lanes before the owner. */

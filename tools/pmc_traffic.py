@@ -13,6 +13,9 @@ src, reads = sys.argv[1], int(sys.argv[2])
 d = json.load(open(src))
 commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
 out = {"commit": commit, "source": src}
+if "k_bc_codes_ed1t" in d:  # K-BC1 on its table path is two kernels: their counters are added up under the old key
+    a, b = d["k_bc_codes_ed1t"], d["k_bc_pick_ed1t"]
+    d["k_bc_match_ed1"] = {c: {"mean_per_launch": a[c]["mean_per_launch"] + b[c]["mean_per_launch"]} for c in a if c in b}
 for key, fetch_scale in (("k_scan", 2.0), ("k_bc_match_ed1", 1.0)):
     k = d[key]
     out[key] = {
