@@ -509,9 +509,10 @@ def main():
     f_scan["limiter"] = "integer VALU issue (bit-parallel gates, Needleman-Wunsch cells): not hbm, not mfma"
     f_bc1["limiter"] = "dependent 4/8-byte gathers into the barcode pyramid and the offset filter (L2 / Infinity Cache / HBM request rate)"
     f_bc1["note"] = ("SURVEY 8d prices a read at 620 probes x 4 B; K-BC1 asks an exact 512 MiB bitmap of the set's inverse one-step neighbourhood "
-                     "(P.nb) once per offset and makes the 124 probes only where a barcode is in reach (1.6 of 5 offsets per read against the "
-                     "3.6 M list), so `achieved` in algorithmic bytes can exceed the HBM peak: it counts probes answered, not bytes moved; "
-                     "`traffic` is what the counters saw")
+                     "(P.nb) once per offset and, where a barcode is in reach (1.6 of 5 offsets per read against the 3.6 M list), reads the "
+                     "matching mutation steps off one bucket of a table of that neighbourhood (P.nt) instead of making the 124 probes, so "
+                     "`achieved` in algorithmic bytes exceeds the HBM peak: it counts probes answered, not bytes moved; `traffic` is what the "
+                     "counters saw; kernel_ms = k_bc_codes_ed1t + k_bc_pick_ed1t")
     dom, oth = (f_scan, f_bc1) if k_scan >= k_match else (f_bc1, f_scan)
     n_adapter = int(((scan_out[:, 6] >> 16) & 0xFF).eq(1).sum().item())
     res = {
