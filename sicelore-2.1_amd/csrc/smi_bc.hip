@@ -190,13 +190,20 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
                     if (ctx->nt) SMI_HIP(hipFree(ctx->nt));
                     ctx->nt = nullptr;
                     ctx->nt_alloc = 0;
-                    SMI_HIP(hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)));
-                    ctx->nt_alloc = cap;
+                    // 7.8 GB for the 3.6 M list: a device that cannot spare them runs the enumerating kernel behind the offset filter
+                    if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)) == hipSuccess)
+                        ctx->nt_alloc = cap;
+                    else {
+                        ctx->nt = nullptr;
+                        (void)hipGetLastError();
+                    }
                 }
-                SMI_HIP(hipMemsetAsync(ctx->nt, 0, cap * sizeof(uint64_t), s));
-                hipLaunchKernelGGL(k_set_nt, dim3(gb), dim3(256), 0, s, d_keys, n, reinterpret_cast<unsigned long long *>(ctx->nt), (uint32_t)cap);
-                SMI_HIP(hipGetLastError());
-                ctx->nt_cap = (uint32_t)cap;
+                if (ctx->nt_alloc >= cap) {
+                    SMI_HIP(hipMemsetAsync(ctx->nt, 0, cap * sizeof(uint64_t), s));
+                    hipLaunchKernelGGL(k_set_nt, dim3(gb), dim3(256), 0, s, d_keys, n, reinterpret_cast<unsigned long long *>(ctx->nt), (uint32_t)cap);
+                    SMI_HIP(hipGetLastError());
+                    ctx->nt_cap = (uint32_t)cap;
+                }
             }
         }
     }

@@ -689,11 +689,14 @@ struct TsoSlot {
 // K-CHIM-B (PART 1): the exact internal TSO scan of the queued reads with the TSO verdict -> TsoSlot.
 // K-CHIM-C (PART 2): internal polyA / polyT + adapter for the reads with that verdict, then the split rules on all matches of the
 // queued read -> out[r].  Two kernels instead of one so that each is register-allocated for its own part.
+#ifndef SMI_CHIM_B_WAVES
+#define SMI_CHIM_B_WAVES 4  // waves per SIMD K-CHIM-B is held to
+#endif
 #ifndef SMI_CHIM_C_WAVES
 #define SMI_CHIM_C_WAVES 4  // waves per SIMD K-CHIM-C is held to
 #endif
 template <int kTsoLen, int kAdLen, int PART>
-__global__ __launch_bounds__(256, PART == 1 ? 4 : SMI_CHIM_C_WAVES) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
+__global__ __launch_bounds__(256, PART == 1 ? SMI_CHIM_B_WAVES : SMI_CHIM_C_WAVES) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
                                                                    const uint64_t *__restrict__ offsets,
                                                                    const uint32_t *__restrict__ list,
                                                                    const uint32_t *__restrict__ list_count, ChimParams P,
