@@ -13,6 +13,7 @@ finalize -> pass 2 -> all-reduce of the BarcodesAssigned counters: the one excha
 `value_full_pass2` (the whole of pass 2 from FASTQ text in HBM, beside `value`, never part of it).
 
   --config 2: BASELINE configs[2] (ed <= 2, two-pass, reads streamed in 10 M batches; K-BC2 in `roofline`).
+  --config 4: BASELINE configs[4] (5' protocol --noPolyARequired, 737,280-key whitelist, ed <= 1; K-UMI leg in `umi`).
   --exchange-only: just the launch + the two exchanges on synthetic histograms (gloo on CPU tensors when no GPU is visible);
                    what tests/test_bench_launch.py runs on the CPU.
 """
@@ -67,7 +68,7 @@ def parse_args():
     ap.add_argument("--e2e-reads", type=int, default=500_000,
                     help="reads of the bounded end-to-end leg (FASTQ text -> passed/failed text), reported beside `value`; 0 = skip")
     ap.add_argument("--two-pass-reads", type=int, default=200_000, help="reads per rank of the two-pass leg with the RCCL exchange; 0 = skip")
-    ap.add_argument("--config", type=int, default=1, choices=(1, 2), help="BASELINE configs[1] (default) or configs[2] (ed<=2 two-pass)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4), help="BASELINE configs[1] (default), configs[2] (ed<=2 two-pass) or configs[4] (5' --noPolyARequired, 737K whitelist, UMI clustering)")
     ap.add_argument("--batch", type=int, default=10_000_000, help="--config 2: reads per batch resident in HBM")
     ap.add_argument("--exchange-only", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl with GPUs, gloo without)")
@@ -382,6 +383,104 @@ def config2(args, dist, rank, local_rank, world, dev):
                                 "the level-2 work only runs for the items the filter lets through", "kernels_ms": {"k_bc_match_ed2": k_bc2, "k_scan<10>": state["ms_scan"]}}}))
 
 
+def config4(args, dist, rank, local_rank, world, dev):
+    """BASELINE configs[4]: 5' protocol with --noPolyARequired (scanfastq -h -y), the 737K-august-2016 whitelist size (737,280 keys) as the
+    search set, ed <= 1, plus the UMI stage: per-(cell, region) UMI edit distances (K-UMI) and clustering (host, smi_umi_cluster_groups).
+    A step = pass 2 per read from packed read ends in HBM (K-SCAN in its 5' mode + K-BC1 on 5' windows); the UMI leg is timed beside it
+    on synthetic (cell, region) groups, as in tools/microbench.py (it runs on aligned reads, i.e. behind an external aligner)."""
+    pkg = graft.load_package()
+    synth = importlib.import_module(graft.PKG_NAME + ".synth")
+    ctx = pkg.Context(local_rank)
+    n = args.reads
+    wl = synth.make_whitelist(737_280, seed=401, device=dev)
+    used = synth.pick_used(wl, args.cells, seed=402)
+    ctx.set_barcode_set_device(wl.to(torch.int32), mode=1)
+    ends = torch.empty((28, 2 * n), dtype=torch.int32, device=dev)
+    lens = torch.empty(n, dtype=torch.int32, device=dev)
+    truth = torch.empty(n, dtype=torch.int64, device=dev)
+    chunk = 1_000_000
+    for c0 in range(0, n, chunk):
+        m = min(chunk, n - c0)
+        rd = synth.gen_reads_5p(m, used, seed=4000 + 97 * rank + c0 // chunk, device=dev)
+        ends[:, 2 * c0:2 * (c0 + m)] = synth.pack_ends(rd["head"], rd["tail"])
+        lens[c0:c0 + m] = (2 * synth.END_BASES + rd["mid_len"]).to(torch.int32)
+        truth[c0:c0 + m] = rd["truth"]
+        del rd
+    cfg = ctx.scan_config_5p(2, dont_search_polya=True)
+    scan_out = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    win = torch.zeros((n, 2), dtype=torch.int64, device=dev)
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.scan_device(ends, lens, n, cfg, scan_out, win)
+        ctx.bc_match_device(win, out, n, max_ed=1, five_prime=True)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.set_timing(True)
+    scan_ms, match_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        scan_ms.append(ctx.kernel_ms(ctx.K_SCAN))
+        match_ms.append(ctx.kernel_ms(ctx.K_BC_MATCH))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ctx.set_timing(False)
+    found = (out[:, 2] & 0xFF) == 1
+    n_found = int(found.sum().item())
+    acc = float(((out[:, 0].to(torch.int64) & 0xFFFFFFFF)[found] == truth[found]).float().mean().item())
+    # ---- UMI leg: Zipf-sized (cell, region) groups, K-UMI on the device, clustering on the host --------------------------------
+    rng = np.random.default_rng(1 + rank)
+    sizes = np.minimum(rng.zipf(1.6, 200_000), 400).astype(np.int64) + 1
+    go, po, mo = ctx.umi_offsets(sizes)
+    n_umi = int(go[-1])
+    w = torch.randint(0, 4, (n_umi, 14), device=dev)
+    packed = (torch.tensor([1, 2, 4, 8], device=dev)[w] << (4 * torch.arange(14, device=dev))).sum(1)
+    d_go, d_po, d_mo = (torch.from_numpy(a.view(np.int32 if a is go else np.int64)).to(dev) for a in (go, po, mo))
+    d_dist = torch.zeros(int(mo[-1]), dtype=torch.uint8, device=dev)
+    ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_dist)
+    torch.cuda.synchronize()
+    tu = time.perf_counter()
+    ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_dist)
+    torch.cuda.synchronize()
+    umi_ms = (time.perf_counter() - tu) * 1e3
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    k_scan, k_match = float(np.mean(scan_ms)), float(np.mean(match_ms))
+    dom_name, dom_ms, alg = ("k_scan<10, 5'>", k_scan, ALG_BYTES_PER_READ_SCAN) if k_scan >= k_match else ("k_bc_match_ed1 (5')", k_match, ALG_BYTES_PER_READ_BC1)
+    ach = alg * n / (dom_ms * 1e-3) / 1e9
+    print(json.dumps({
+        "metric": "Nanopore reads/sec BC-assigned at ed<=1, 5' protocol --noPolyARequired, 737K whitelist", "value": n * world * args.steps / elapsed,
+        "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+        "data": f"synthetic ({synth.GENERATOR_VERSION}, 5' reads, seeds wl=401 used=402 reads=4000+97*rank+chunk), packed read ends resident in HBM",
+        "config": {"workload": "configs[4]: 5' protocol, --noPolyARequired, ed<=1 vs the 737,280-key whitelist (-g semantics); timed = pass 2 per read "
+                               "from packed read ends in HBM (K-SCAN 5' mode + K-BC1 on 5' windows); the UMI stage (K-UMI + clustering) beside it in `umi`",
+                   "reads_per_gpu": n, "whitelist": int(wl.numel()), "cells": args.cells, "bc_assigned_frac": n_found / n, "bc_assigned_accuracy": acc},
+        "roofline": {"bound": "hbm" if dom_name.startswith("k_bc") else "valu-issue (HBM figures as the contract asks)", "kernel": dom_name, "kernel_ms": dom_ms,
+                     "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "alg_bytes_per_read": alg, "traffic": None,
+                     "kernels_ms": {"k_scan<10, 5'>": k_scan, "k_bc_match_ed1 (5')": k_match}},
+        "umi": {"groups": int(len(sizes)), "reads": n_umi, "pairs": int(po[-1]), "k_umi_ms": umi_ms, "pairs_per_s": int(po[-1]) / (umi_ms * 1e-3),
+                "levenshtein_per_s": 9 * int(po[-1]) / (umi_ms * 1e-3),
+                "note": "K-UMI over Zipf-sized (cell, region) groups; clustering and the BAM side: tools/microbench.py assignumis (5.4 M records/s per chunk call)"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -397,6 +496,8 @@ def main():
     dist, rank, local_rank, world = init_dist(args, dev)
     if args.config == 2:
         return config2(args, dist, rank, local_rank, world, dev)
+    if args.config == 4:
+        return config4(args, dist, rank, local_rank, world, dev)
 
     pkg = graft.load_package()
     synth = importlib.import_module(graft.PKG_NAME + ".synth")
