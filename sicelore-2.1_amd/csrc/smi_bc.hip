@@ -1351,6 +1351,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         if (created[h] && c[h].low != kEmpty) atomicMin(&vals[slot_of[h]], ord[h]);
                     // items worth expanding, as a bit mask over the expansion order
                     unsigned long long pm0 = ~0ull, pm1 = ~0ull;
+                    bool pass_h[2] = {created[0] && c[0].g == 0u, created[1] && c[1].g == 0u};  // this lane's items that are worth expanding
                     hit0 = member(P, K);
                     if (kFilter) {
                         // K a barcode: its children have K as a neighbour by construction (substitutions; insertion children through the
@@ -1362,7 +1363,8 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                             if (!created[h]) continue;
                             const bool k_counts = hit0 && !(re[h] == 7 && pe[h] == 0);
                             const uint32_t *tab = k_counts ? P.n2 : P.n1;
-                            passf[ord[h]] = (c[h].g == 0u && ((tab[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u)) ? 1u : 0u;
+                            pass_h[h] = c[h].g == 0u && ((tab[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u);
+                            passf[ord[h]] = pass_h[h] ? 1u : 0u;
                         }
                     }
                     wave_sync();
@@ -1387,6 +1389,80 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                     // kGroup items (2 * kGroup half-rounds of 64 mutants) are generated, looked up in the dedup table and
                     // tested against the top level TOGETHER: the loads of a group are independent, so their latencies
                     // overlap; the (rare) survivors of the top level are then walked in order, which keeps "first hit".
+                    if (P.nt != nullptr) {
+                        // Level 2 from the neighbourhood table (k_set_nt): an item X is not expanded into its 123 children; the bucket of
+                        // X lists every mutation that turns X into a barcode, and the rules of the expansion are applied to those few --
+                        // the position the item was created at is not visited, an insertion behind position 14 needs X to end in A, a
+                        // deletion appends the read's next base, the root / X itself behind its first position / a sequence that was
+                        // expanded earlier are in the dedup set.  Every lane does this for its own two items at once; the item that comes
+                        // first in the expansion order among those with a match is the one the serial expansion would have stopped at.
+                        auto ord_seen_of = [&](uint32_t ml) -> uint32_t {
+                            if (ml == kEmpty) return t_ord;
+                            uint32_t sl = (ml * 2654435761u) >> 24;
+                            for (;;) {
+                                const uint32_t kk = keys[sl];
+                                if (kk == ml) return vals[sl];
+                                if (kk == kEmpty) return 0xFFFFFFFFu;
+                                sl = (sl + 1) & (kTabSlots - 1);
+                            }
+                        };
+                        uint32_t cand = 0xFFFFFFFFu;  // ord << 8 | s2 of this lane's best item
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (!pass_h[h]) continue;
+                            const uint32_t X = c[h].low;
+                            const int pX = pe[h] & 15, rX = re[h];
+                            const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;  // post[nDeletions + 1]
+                            const int q0 = pX == 0 ? 1 : 0;
+                            uint32_t best = 255u;
+                            uint32_t idx = nt_slot(X, P.nt_cap);
+                            for (;;) {
+                                uint64_t en[8];
+                                __builtin_memcpy(en, P.nt + idx, 64);
+                                bool open = false;
+#pragma unroll
+                                for (int t8 = 0; t8 < 8; t8++) {
+                                    open = open || en[t8] == 0ull;
+                                    if ((uint32_t)(en[t8] >> 8) != X || !(en[t8] >> 40)) continue;
+                                    const uint32_t kind = (uint32_t)en[t8] & 3u, pos = ((uint32_t)en[t8] >> 2) & 15u, base = ((uint32_t)en[t8] >> 6) & 3u;
+                                    if (kind == 0u || (int)pos == pX) continue;  // X itself is no mutant of X; the item skips its own position
+                                    uint32_t r2;
+                                    if (kind == 1u) {
+                                        const uint32_t cur = (X >> (30 - 2 * pos)) & 3u;
+                                        r2 = base - (base > cur ? 1u : 0u);
+                                    } else if (kind == 2u) {
+                                        if (pos == 14u && (X & 3u) != 0u) continue;
+                                        r2 = 3u + base;
+                                    } else {
+                                        if (base != delb) continue;
+                                        r2 = 7u;
+                                    }
+                                    const Seq Xs = {X, 0u};
+                                    const uint32_t ml = child_of(Xs, (int)pos, (int)r2, delb).low;
+                                    if (ml == K || (ml == X && (int)pos > q0)) continue;  // the root, X itself after its first position
+                                    if (ord_seen_of(ml) < ord[h]) continue;                // a sequence that was expanded earlier
+                                    best = min(best, 8u * pos + r2);
+                                }
+                                if (open) break;
+                                idx = idx + 8 == P.nt_cap ? 0u : idx + 8;
+                            }
+                            if (best != 255u) cand = min(cand, (ord[h] << 8) | best);
+                        }
+                        uint32_t first_c = cand;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) first_c = min(first_c, (uint32_t)__shfl_xor((int)first_c, o));
+                        if (first_c != 0xFFFFFFFFu) {
+                            const int t = (int)(first_c >> 8), s2 = (int)(first_c & 0xFFu);
+                            const int e = (int)ord2e[t];
+                            const int pX = e >> 3, rX = e & 7;
+                            const Seq X = child_of(root, pX, rX, post1);
+                            const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;
+                            hit2 = true;
+                            bc2 = child_of(X, s2 >> 3, s2 & 7, delb).low;
+                            imd2 = ins_minus_del_of(e) + ins_minus_del_of(s2);
+                        }
+                        pm0 = pm1 = 0ull;  // nothing is left for the enumerating loop
+                    }
                     constexpr int kGroup = 4;
                     while ((pm0 | pm1) && !hit2) {
                         uint32_t m_low[2 * kGroup], m_ok[2 * kGroup], w0[2 * kGroup], w1[2 * kGroup];
@@ -1513,6 +1589,9 @@ int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int fiv
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
     if (int rc = time_begin(ctx, SMI_K_BC_MATCH, s)) return rc;
     // density of the top level: 2^25 cells; from ~1 % occupied cells on the second stage pays for its wider loads
+    // level 2 from the table pays when the table is small enough to stay in cache (a used list: 11 MB); against the whole whitelist the 550
+    // bucket reads of a read miss to HBM (measured 29 instead of 32 M reads/s), so dense sets keep the enumeration through the two-stage top level
+    if (std::getenv("SMI_BC2_NO_TABLE") || ctx->n_keys > 300000) P.nt = nullptr;
     if (ctx->n_keys > 300000)
         hipLaunchKernelGGL((k_bc_match_ed2<true, false>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else if (P.n1)

@@ -327,9 +327,12 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     if case == "ed1_adversarial":  # the same set through K-BC2 as well
         got2 = _run_device(pkg, gpu_ctx, win, 2, five_prime)
     monkeypatch.setenv("SMI_BC1_NO_TABLE", "1")  # K-BC1: offset filter, mutants of the flagged offsets enumerated (k_bc_match_ed1f)
+    monkeypatch.setenv("SMI_BC2_NO_TABLE", "1")  # K-BC2: level 2 by enumeration of the items the filter lets through (read at launch)
     gpu_ctx.set_barcode_set(keys, mode=mode)
     no_table = _run_device(pkg, gpu_ctx, win, max_ed, five_prime)
     assert (with_filter.view(np.uint8) == no_table.view(np.uint8)).all()
+    if got2 is not None:
+        assert (got2.view(np.uint8) == _run_device(pkg, gpu_ctx, win, 2, five_prime).view(np.uint8)).all()
     monkeypatch.setenv("SMI_BC1_NO_FILTER", "1")
     monkeypatch.setenv("SMI_BC2_NO_FILTER", "1")
     gpu_ctx.set_barcode_set(keys, mode=mode)
@@ -341,5 +344,6 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     monkeypatch.delenv("SMI_BC1_NO_FILTER")
     monkeypatch.delenv("SMI_BC2_NO_FILTER")
     monkeypatch.delenv("SMI_BC1_NO_TABLE")
+    monkeypatch.delenv("SMI_BC2_NO_TABLE")
     assert "SMI_BC1_NO_FILTER" not in os.environ
     gpu_ctx.set_barcode_set(keys, mode=mode)  # leave the context with its filters on
