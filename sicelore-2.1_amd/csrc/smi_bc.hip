@@ -99,6 +99,22 @@ __global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *
     }
 }
 
+// K-BC2's offset filter for short used lists: one exact bit per key for the inverse TWO-step neighbourhood (the inverse one-step
+// neighbourhood of every member of the inverse one-step neighbourhood: 169 x 169 sequences per barcode, a superset of everything from
+// which two mutations of the reference's enumeration reach the barcode, and of everything from which one or none does).  A window whose
+// bit is clear has no match at level 0, 1 or 2 and the whole per-offset machinery of K-BC2 -- the 123 children, their dedup table and
+// creation order -- is skipped for it.  The bitmap lives in the build scratch of the n2 table, which is idle once that is built.
+constexpr size_t kNb2MaxKeys = 32768;  // 169^2 x keys <= 2^30: at most a fifth of all 16-mers set
+__global__ void k_set_nb2(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ nb2) {
+    const size_t total = n * kN1Slots * kN1Slots;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / ((size_t)kN1Slots * kN1Slots);
+        const int s12 = (int)(i - b * kN1Slots * kN1Slots);
+        const uint32_t x = n1_member(n1_member(keys[b], s12 / kN1Slots), s12 % kN1Slots);
+        atomicOr(&nb2[x >> 5], 1u << (x & 31));
+    }
+}
+
 // K-BC1's neighbourhood table: for every (barcode w, step) pair the sequence X = n1_member(w, step) together with the ONE mutation of the
 // reference's enumeration that leads from X back to w -- kind (0 X is w, 1 substitution, 2 insertion, 3 deletion), position, and the base
 // that the step writes (substitution: w's base there; insertion: the inserted base; deletion: the base it appends, which must be the
@@ -208,6 +224,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
         }
     }
     ctx->n1_valid = false;
+    ctx->nb2_valid = false;
     if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
         if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 2 * kL1Words * 4));
         SMI_HIP(hipMemsetAsync(ctx->n1, 0, 2 * kL1Words * 4, s));
@@ -218,6 +235,15 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
         hipLaunchKernelGGL(k_set_n2, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1_owner, ctx->n1 + kL1Words);
         SMI_HIP(hipGetLastError());
         ctx->n1_valid = true;
+        ctx->nb2_valid = false;
+        if (n <= kNb2MaxKeys && !std::getenv("SMI_BC2_NO_OFFSET_FILTER")) {
+            // stream order: k_set_n2 has read the scratch as the owner array before it is cleared and filled as the two-step bitmap
+            SMI_HIP(hipMemsetAsync(ctx->n1_owner, 0, kFineWords * 4, s));
+            const unsigned g2 = (unsigned)std::min<size_t>((n * kN1Slots * kN1Slots + 255) / 256, 256 * 256);
+            hipLaunchKernelGGL(k_set_nb2, dim3(g2), dim3(256), 0, s, d_keys, n, ctx->n1_owner);
+            SMI_HIP(hipGetLastError());
+            ctx->nb2_valid = true;
+        }
     }
     SMI_HIP(hipStreamSynchronize(s));
     ctx->n_keys = (size_t)last[0] + last[1];
@@ -1250,6 +1276,20 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
             uint32_t c_rs[5];
             int c_imd[15];
             uint32_t present = 0;
+            // the two-step filter bits of the five windows: five independent loads in front of the per-offset loop (inside it they
+            // would be five dependent round trips per read)
+            uint32_t near2 = 31u;
+            if (kFilter && P.nb2 != nullptr) {
+                uint32_t wds[5], kys[5];
+#pragma unroll
+                for (int q = 0; q < 5; q++) {
+                    kys[q] = make_key(w.bases, w.nmask, OFFS[q], fp).key;
+                    wds[q] = P.nb2[kys[q] >> 5];
+                }
+                near2 = 0u;
+#pragma unroll
+                for (int q = 0; q < 5; q++) near2 |= ((wds[q] >> (kys[q] & 31u)) & 1u) << q;
+            }
 #pragma unroll 1
             for (int q = 0; q < 5; q++) {
                 const OffsetKey ok = make_key(w.bases, w.nmask, OFFS[q], fp);
@@ -1259,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                 uint32_t bc0 = K, bc1 = 0, bc2 = 0;
                 int imd1 = 0, imd2 = 0;
                 bool hit0 = false, hit1 = false, hit2 = false;
-                if (ok.usable) {
+                if (ok.usable && ((near2 >> q) & 1u)) {  // (a clear bit of the two-step filter: no match at any level)
                     const Seq root = {K, 0u};
                     // ---- level 1: the 123 children, two per lane (e = lane, 64 + lane) ------------------------
                     Seq c[2];

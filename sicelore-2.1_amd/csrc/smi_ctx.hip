@@ -42,6 +42,7 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.t2 = ctx->t2;
     p.n1 = ctx->n1_valid ? ctx->n1 : nullptr;
     p.n2 = ctx->n1_valid ? ctx->n1 + kL1Words : nullptr;
+    p.nb2 = ctx->n1_valid && ctx->nb2_valid ? ctx->n1_owner : nullptr;
     p.nb = ctx->nb_valid ? ctx->nb : nullptr;
     p.nt = ctx->nb_valid && ctx->nt_cap ? ctx->nt : nullptr;
     p.nt_cap = ctx->nt_cap;
@@ -179,6 +180,8 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->t2 = o->t2;
     lane->n1 = o->n1;
     lane->n1_valid = o->n1_valid;
+    lane->n1_owner = o->n1_owner;
+    lane->nb2_valid = o->nb2_valid;
     lane->nb = o->nb;
     lane->nb_valid = o->nb_valid;
     lane->nt = o->nt;

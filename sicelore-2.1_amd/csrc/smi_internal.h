@@ -93,6 +93,7 @@ struct Pyramid {
     const uint32_t *t2;  // two-stage top level of K-BC1: entry j = {word j of l0 | l0s, stage-2 word j}
     const uint32_t *n1;  // K-BC2, short used lists only (else null): the sequences one mutation step away FROM which a barcode can be reached (l1 layout)
     const uint32_t *n2;  // ... from which TWO OR MORE different barcodes can be reached (same layout)
+    const uint32_t *nb2; // K-BC2's offset filter for short used lists (else null): 1 bit per key, set for every sequence TWO steps away from a barcode
     const uint32_t *nb;  // K-BC1's offset filter (else null): 1 bit per key, set for every sequence one mutation step away from a barcode (512 MiB)
     const uint64_t *nt;  // K-BC1's neighbourhood table (else null): open addressing, entry = 1 << 40 | sequence << 8 | the step that leads from it to a barcode
     uint32_t nt_cap;     // its slots
@@ -108,6 +109,7 @@ struct smi_ctx {
     uint32_t *t2 = nullptr;
     uint32_t *n1 = nullptr;   // allocated with the first short barcode list (2 x 16 MiB: n1, then n2)
     bool n1_valid = false;    // describes the set that is loaded now
+    bool nb2_valid = false;   // the build scratch n1_owner holds the two-step neighbourhood bitmap of the set that is loaded now
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
     uint32_t *n1_owner = nullptr;  // scratch of the n2 build (one u32 per n1 cell, 512 MiB), kept: hipMalloc / hipFree of that size cost ~100 ms per set load
     bool nb_valid = false;

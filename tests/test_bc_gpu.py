@@ -335,6 +335,7 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
         assert (got2.view(np.uint8) == _run_device(pkg, gpu_ctx, win, 2, five_prime).view(np.uint8)).all()
     monkeypatch.setenv("SMI_BC1_NO_FILTER", "1")
     monkeypatch.setenv("SMI_BC2_NO_FILTER", "1")
+    monkeypatch.setenv("SMI_BC2_NO_OFFSET_FILTER", "1")
     gpu_ctx.set_barcode_set(keys, mode=mode)
     without = _run_device(pkg, gpu_ctx, win, max_ed, five_prime)
     assert (with_filter.view(np.uint8) == without.view(np.uint8)).all()
@@ -345,5 +346,6 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     monkeypatch.delenv("SMI_BC2_NO_FILTER")
     monkeypatch.delenv("SMI_BC1_NO_TABLE")
     monkeypatch.delenv("SMI_BC2_NO_TABLE")
+    monkeypatch.delenv("SMI_BC2_NO_OFFSET_FILTER")
     assert "SMI_BC1_NO_FILTER" not in os.environ
     gpu_ctx.set_barcode_set(keys, mode=mode)  # leave the context with its filters on
