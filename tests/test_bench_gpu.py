@@ -1,0 +1,51 @@
+"""bench.py end to end at small sizes on the GPU: the three configurations it runs (BASELINE configs[1], [2], [4]) produce one JSON line
+with the fields the driver's contract names, and the step's output equals the oracle where the line says so (`cpu_baseline.matches_gpu`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = p.stdout.strip().splitlines()[-1]
+    return json.loads(line)
+
+
+def _common(d, steps):
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == steps and d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+
+
+def test_bench_config1_small():
+    d = _run("--reads", "300000", "--whitelist", "400000", "--steps", "2", "--warmup", "1", "--cpu-sample", "20000", "--e2e-reads", "30000",
+             "--two-pass-reads", "20000")
+    _common(d, 2)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["matches_gpu"] is True
+    assert d["end_to_end"]["reads_per_s"] > 0 and d["value_full_pass2"] == d["end_to_end"]["reads_per_s"]
+    assert d["two_pass"]["same_used_list_on_all_ranks"] is True and d["two_pass"]["pass2_assigned"] > 0
+    assert set(d["roofline"]["kernels_ms"]) == {"k_scan<10>", "k_bc_match_ed1<1>"}
+
+
+def test_bench_config2_small():
+    d = _run("--config", "2", "--reads", "400000", "--batch", "200000", "--whitelist", "400000", "--steps", "2", "--warmup", "1")
+    _common(d, 2)
+    assert d["roofline"]["kernel"] == "k_bc_match_ed2" and d["config"]["used_list"] > 1000 and d["config"]["bc_assigned_frac"] > 0.5
+
+
+def test_bench_config4_small():
+    d = _run("--config", "4", "--reads", "300000", "--steps", "2", "--warmup", "1")
+    _common(d, 2)
+    assert d["config"]["whitelist"] == 737_280 and d["config"]["bc_assigned_frac"] > 0.4 and d["config"]["bc_assigned_accuracy"] > 0.9
+    assert d["umi"]["pairs_per_s"] > 0
