@@ -245,3 +245,63 @@ def test_native_chunk_worker_5p_and_ed2(pkg, synth, sor, gpu_ctx):
         assert got[0] == exp[0] and got[1] == exp[1]
     n_bc = {ed: gpu_ctx.scanfastq_pass2_chunk(text3, max_ed=ed)[0].count(b" cellBC=") for ed in (0, 1, 2)}
     assert n_bc[0] < n_bc[1] < n_bc[2]
+
+
+def test_tiny_reads_long_names_and_headers(pkg, synth, sor, gpu_ctx):
+    """the edges of the byte kernels: reads of 1 .. 70 bases (K-PACKR's partial last word with and without the wide load, K-WRITE records
+    whose runs have no 16-byte aligned inside), names of 1 .. 300 characters with and without a blank, quality headers of 0 .. 200
+    characters (several turns of K-WRITE's loose-byte loop), mixed with ordinary reads -- records equal the oracle's byte for byte, through
+    the chained entry points and through the native chunk worker"""
+    import random
+
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    rng = random.Random(77)
+    used, reads = _reads(synth, 40, 951)
+    base = [synth.materialize(reads, i) for i in range(40)]
+    seqs, quals, names, qhs = [], [], [], []
+    lengths = list(range(1, 71)) + [199, 200, 201, 224, 225, 447, 448, 449]
+    for j, n in enumerate(lengths):
+        seqs.append("".join(rng.choice("ACGTN") for _ in range(n)))
+        quals.append("".join(chr(33 + rng.randrange(40)) for _ in range(n)))
+    for s, q in base:
+        seqs.append(s)
+        quals.append(q)
+    for i in range(len(seqs)):
+        ln = rng.choice([1, 2, 15, 16, 17, 63, 64, 65, 120, 300])
+        tok = "".join(rng.choice("abcdefghijklmnopqrstuvwxyz0123456789-") for _ in range(ln))
+        names.append(tok if i % 3 == 0 else tok + " " + "x" * rng.choice([0, 1, 40, 150]))
+        qhs.append("" if i % 2 else "h" * rng.choice([1, 30, 200]))
+    text = "".join(f"@{nm}\n{s}\n+{h}\n{q}\n" for nm, s, h, q in zip(names, seqs, qhs, quals)).encode()
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    bset = sor.BarcodeSet(used.numpy())
+    # oracle records (no chimera splitting for the tiny reads: they are below the splitter's minimum length anyway)
+    passed, failed, rid = [], [], 1
+    for nm, s, h, q in zip(names, seqs, qhs, quals):
+        rc, splits, multi, _, raw = sor.chimera_split(s)
+        assert rc == 0
+        cuts = [0] + [p for _, p in splits] + [len(s)]
+        for k in range(len(cuts) - 1):
+            fs, fq = s[cuts[k]:cuts[k + 1]], q[cuts[k]:cuts[k + 1]]
+            fname = sor.chimera_fragment_name(nm, raw, k) if splits else nm
+            rc, sc = sor.scan_read_3p(fs, fq, "CTTCCGATCT")
+            assert rc == 0
+            a = None
+            if sc["adapter_found"] and not multi:
+                stranded = fs.encode().translate(COMP)[::-1] if sc["reverse"] else fs.encode()
+                rc2, a_ = sor.assign_barcode(bset, stranded, int(sc["adapter_end"]), max_ed=1)
+                if rc2 == 1:
+                    a = a_
+            rec, ok = sor.fastq_record(fname, h, fs, fq, sc, a, rank=0, read_id=rid, trim_fastq=False, force_failed=multi)
+            assert rec is not None
+            if ok:
+                passed.append(rec)
+                rid += 1
+            else:
+                failed.append(rec)
+    exp_p, exp_f = b"".join(passed), b"".join(failed)
+    rs = scanfastq.ReadScanner(gpu_ctx, max_ed=1)
+    got_p, got_f, info = rs.pass2_write_chunk(text)
+    assert got_f == exp_f
+    assert got_p == exp_p and info["n_passed"] == len(passed) > 20
+    nat_p, nat_f, ninfo = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=1)
+    assert bytes(nat_p) == exp_p and bytes(nat_f) == exp_f
