@@ -305,3 +305,23 @@ def test_tiny_reads_long_names_and_headers(pkg, synth, sor, gpu_ctx):
     assert got_p == exp_p and info["n_passed"] == len(passed) > 20
     nat_p, nat_f, ninfo = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=1)
     assert bytes(nat_p) == exp_p and bytes(nat_f) == exp_f
+
+
+def test_long_reads(pkg, synth, sor, gpu_ctx):
+    """reads of up to ~30 kb (several turns of every per-read loop: K-PACKR words, K-CHIM segments of 2048 / 4096 positions, K-WRITE runs)
+    equal the oracle's records, chained entry points and native chunk worker"""
+    scanfastq = importlib.import_module("sicelore_amd.scanfastq")
+    wl = synth.make_whitelist(20_000, seed=971)
+    used = synth.pick_used(wl, 50, seed=972)
+    reads = synth.gen_reads(24, used, seed=973, n_rate=0.001, max_mid=30_000)
+    sq = [synth.materialize(reads, i) for i in range(24)]
+    seqs, quals = [s for s, _ in sq], [q for _, q in sq]
+    assert max(len(s) for s in seqs) > 15_000
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    rs = scanfastq.ReadScanner(gpu_ctx, max_ed=1)
+    text = _fastq(seqs, quals)
+    got_p, got_f, info = rs.pass2_write_chunk(text)
+    exp_p, exp_f, n_p = _oracle_records(sor, sor.BarcodeSet(used.numpy()), seqs, quals, 1, {}, 1)
+    assert got_p == exp_p and got_f == exp_f and info["n_passed"] == n_p > 10
+    nat_p, nat_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=1)
+    assert bytes(nat_p) == exp_p and bytes(nat_f) == exp_f
