@@ -1,5 +1,5 @@
 """Seed sweep of the GPU parity checks (run on the GPU box): the same comparisons as tests/ (-m gpu), over many seeds and
-set densities, to look for rare disagreements with the oracle.  usage: python tools/fuzz_parity.py [minutes]
+set densities, to look for rare disagreements with the oracle.  usage: python tools/fuzz_parity.py [minutes] [first seed]
 Prints one line per leg and seed; exits non-zero at the first mismatch."""
 import importlib
 import os
@@ -70,7 +70,7 @@ def main():
     sor.build()
     ctx = pkg.Context(0)
     t_end = time.time() + 60 * minutes
-    seed, n_ok = 1000, 0
+    seed, n_ok = (int(sys.argv[2]) if len(sys.argv) > 2 else 1000), 0
     while time.time() < t_end:
         for leg in (check_bc, check_records):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
