@@ -343,9 +343,13 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
         assert (got2.view(np.uint8) == _run_device(pkg, gpu_ctx, win, 2, five_prime).view(np.uint8)).all()
     assert int((with_filter["found"] == 1).sum()) > 1000
     monkeypatch.delenv("SMI_BC1_NO_FILTER")
-    monkeypatch.delenv("SMI_BC2_NO_FILTER")
     monkeypatch.delenv("SMI_BC1_NO_TABLE")
     monkeypatch.delenv("SMI_BC2_NO_TABLE")
+    # K-BC2 without its filters but WITH the table (what a list of 65,537 .. 300,000 barcodes runs): every created item is looked up
+    if max_ed == 2 or got2 is not None:
+        gpu_ctx.set_barcode_set(keys, mode=mode)
+        assert (_run_device(pkg, gpu_ctx, win, 2, five_prime).view(np.uint8) == (with_filter if max_ed == 2 else got2).view(np.uint8)).all()
+    monkeypatch.delenv("SMI_BC2_NO_FILTER")
     monkeypatch.delenv("SMI_BC2_NO_OFFSET_FILTER")
     assert "SMI_BC1_NO_FILTER" not in os.environ
     gpu_ctx.set_barcode_set(keys, mode=mode)  # leave the context with its filters on
