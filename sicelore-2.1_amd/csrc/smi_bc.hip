@@ -1392,6 +1392,13 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                     // items worth expanding, as a bit mask over the expansion order
                     unsigned long long pm0 = ~0ull, pm1 = ~0ull;
                     bool pass_h[2] = {created[0] && c[0].g == 0u, created[1] && c[1].g == 0u};  // this lane's items that are worth expanding
+                    if (!kFilter && P.nt != nullptr && P.nb != nullptr) {
+                        // lists too long for the hashed item filter: the exact bitmap of K-BC1's offset filter answers the same question
+                        // (is any barcode one step away from this item?) before the item's bucket is read
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            pass_h[h] = pass_h[h] && ((P.nb[c[h].low >> 5] >> (c[h].low & 31u)) & 1u);
+                    }
                     hit0 = member(P, K);
                     if (kFilter) {
                         // K a barcode: its children have K as a neighbour by construction (substitutions; insertion children through the
@@ -1631,7 +1638,7 @@ int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int fiv
     // density of the top level: 2^25 cells; from ~1 % occupied cells on the second stage pays for its wider loads
     // level 2 from the table pays when the table is small enough to stay in cache (a used list: 11 MB); against the whole whitelist the 550
     // bucket reads of a read miss to HBM (measured 29 instead of 32 M reads/s), so dense sets keep the enumeration through the two-stage top level
-    if (std::getenv("SMI_BC2_NO_TABLE") || ctx->n_keys > 300000) P.nt = nullptr;
+    if (std::getenv("SMI_BC2_NO_TABLE") || (ctx->n_keys > 300000 && std::getenv("SMI_BC2_DENSE_ENUM"))) P.nt = nullptr;
     if (ctx->n_keys > 300000)
         hipLaunchKernelGGL((k_bc_match_ed2<true, false>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else if (P.n1)
