@@ -101,7 +101,12 @@ int smi_ctx_lane_refresh(smi_ctx *lane);
 
 /* Replaces the Set<Long> handed to BarcodeMatchTester (hashMapForBCfinding.keySet(), Parser.java:L234) and the
  * LongOpenHashSet of all possible barcodes used by pass 1 (NanoporeReadScannerMain.readBarcodesFile L480-503).
- * keys: n 16-nt barcodes, 2-bit packed in the low 32 bits.  Builds the HBM-resident membership pyramid. */
+ * keys: n 16-nt barcodes, 2-bit packed in the low 32 bits.  Builds the HBM-resident membership pyramid (616 MiB) and, from the set's
+ * inverse one-step neighbourhood (169 sequences per barcode), what lets the matchers skip the reference's mutant enumeration without
+ * changing a result: an exact bitmap of that neighbourhood (512 MiB) and a table of it with the mutation step back to the barcode in every
+ * entry (13.5 bytes per neighbour: 7.8 GB for 3.6 M barcodes, 11 MB for 5 k; left out when the device cannot spare it); for lists of up to
+ * 65,536 / 32,768 barcodes also the item filter and the two-step bitmap of the ed <= 2 matcher (32 MiB + a 512 MiB scratch).  3.6 M barcodes
+ * load in ~125 ms, a used list in < 1 ms.  Results never depend on these structures ("Switches"). */
 int smi_set_barcode_set(smi_ctx *ctx, const uint64_t *keys, size_t n, int mode);
 int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, int mode, void *stream);
 
