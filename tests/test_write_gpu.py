@@ -325,3 +325,42 @@ def test_long_reads(pkg, synth, sor, gpu_ctx):
     assert got_p == exp_p and got_f == exp_f and info["n_passed"] == n_p > 10
     nat_p, nat_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=1)
     assert bytes(nat_p) == exp_p and bytes(nat_f) == exp_f
+
+
+def test_worker_lanes_share_one_barcode_set(pkg, synth, sor, gpu_ctx):
+    """smi_ctx_create_lane / smi_ctx_lane_refresh: two lanes driven from two host threads at once give the records the owner gives (which
+    the tests above compare with the oracle), before and after the owner loads another set; K-BC1 takes its table path on the lanes too
+    (the neighbourhood bitmap and table belong to the owner, the byte buffer between its two kernels to the lane)"""
+    import threading
+
+    def texts(seed):
+        used, reads = _reads(synth, 120, seed)
+        chim = synth.make_chimeras(reads, 150, seed=seed + 5)
+        return used, _fastq([c[0] for c in chim], [c[1] for c in chim])
+
+    used_a, text_a = texts(981)
+    used_b, text_b = texts(991)
+    lanes = [gpu_ctx.lane(), gpu_ctx.lane()]
+    for which, used in enumerate((used_a, used_b)):
+        gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+        for ln in lanes:
+            ln.refresh()
+        want = [tuple(bytes(x) for x in gpu_ctx.scanfastq_pass2_chunk(t, max_ed=1)[:2]) for t in (text_a, text_b)]
+        got = [None, None]
+
+        def work(k):
+            for _ in range(3):  # several chunks per lane, the two lanes interleaving on the GPU
+                p, f, _info = lanes[k].scanfastq_pass2_chunk((text_a, text_b)[k], max_ed=1)
+                got[k] = (bytes(p), bytes(f))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert got[0] == want[0] and got[1] == want[1]
+        assert want[which][0].count(b"bc=") > 50  # the text whose molecules carry barcodes of the loaded list
+    # ed <= 2 on a lane as well (filters and table of the owner)
+    p2, f2, _ = lanes[0].scanfastq_pass2_chunk(text_b, max_ed=2)
+    q2, g2, _ = gpu_ctx.scanfastq_pass2_chunk(text_b, max_ed=2)
+    assert bytes(p2) == bytes(q2) and bytes(f2) == bytes(g2)
