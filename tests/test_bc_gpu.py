@@ -353,3 +353,19 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     monkeypatch.delenv("SMI_BC2_NO_OFFSET_FILTER")
     assert "SMI_BC1_NO_FILTER" not in os.environ
     gpu_ctx.set_barcode_set(keys, mode=mode)  # leave the context with its filters on
+
+
+@pytest.mark.parametrize("max_ed", [0, 1, 2])
+def test_empty_and_single_key_sets(pkg, synth, sor, gpu_ctx, max_ed):
+    """the two smallest barcode sets: none (every structure empty, no filter or table built) and one barcode"""
+    wl = synth.make_whitelist(1000, seed=81)
+    used = synth.pick_used(wl, 1, seed=82)
+    reg = synth.gen_bc_region(3000, used, seed=83)
+    win = synth.pack_windows(reg["codes"], reg["ae"], False)
+    gpu_ctx.set_barcode_set(np.zeros(0, dtype=np.uint64), mode=0)
+    got = _run_device(pkg, gpu_ctx, win, max_ed, False)
+    assert (got["found"][got["found"] >= 0] == 0).all() and (got["n_matches"] == 0).all()
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    got = _run_device(pkg, gpu_ctx, win, max_ed, False)
+    st, exp = sor.assign_batch(sor.BarcodeSet(used.numpy()), reg["codes"].numpy(), reg["ae"].numpy(), max_ed=max_ed, n_threads=8)
+    assert _compare(pkg, got, st, exp) > (500 if max_ed else 100)
