@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
         const uint8_t *src = reads + (starts ? starts[r] : beg);
         // 16 bases per piece: one 16-byte load (unaligned), four enc4x4 -- the tail end is read backwards and complemented, which is a
         // byte swap of the piece and the complement table
-#pragma unroll 1
+#pragma unroll
         for (int w = 0; w < kPlaneWords; w++) {
             uint32_t pl[4] = {0, 0, 0, 0};
 #pragma unroll
