@@ -762,6 +762,29 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
         const uint8_t *src = reads + (starts ? starts[r] : beg);
         // 16 bases per piece: one 16-byte load (unaligned), four enc4x4 -- the tail end is read backwards and complemented, which is a
         // byte swap of the piece and the complement table
+        if (len >= kEndBases) {
+            // the usual case, a read of 224 bases or more: its fourteen pieces are requested together (one round trip to the text instead
+            // of seven), then encoded
+            uint32_t vv[2 * kPlaneWords][4];
+#pragma unroll
+            for (int k = 0; k < 2 * kPlaneWords; k++)
+                __builtin_memcpy(vv[k], side == 0 ? src + 16 * k : src + (len - 16 - 16 * k), 16);
+#pragma unroll
+            for (int w = 0; w < kPlaneWords; w++) {
+                uint32_t pl[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t code = side ? enc4x4<true>(__builtin_bswap32(vv[2 * w + k][3 - j])) : enc4x4<false>(vv[2 * w + k][j]);
+#pragma unroll
+                        for (int c = 0; c < 4; c++) pl[c] |= plane_nibble(code, c) << (16 * k + 4 * j);
+                    }
+#pragma unroll
+                for (int c = 0; c < 4; c++) ends[(size_t)(c * kPlaneWords + w) * n_ends + e] = pl[c];
+            }
+            continue;
+        }
 #pragma unroll
         for (int w = 0; w < kPlaneWords; w++) {
             uint32_t pl[4] = {0, 0, 0, 0};
