@@ -834,14 +834,30 @@ __global__ __launch_bounds__(256) void k_pack_quals(const uint8_t *__restrict__ 
     for (size_t r = wave; r < n; r += n_waves) {
         const uint64_t beg = offsets[r];
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
+        // sum of the characters, 16 per lane and step (v_sad_u8 adds the four bytes of a dword), minus 33 per character
         uint32_t s = 0;
-        for (int64_t i = lane; i < len; i += 64) s += (uint32_t)quals[beg + i] - 33u;
+        const int64_t body = len & ~(int64_t)15;
+        for (int64_t i = 16 * (int64_t)lane; i < body; i += 1024) {
+            uint32_t w[4];
+            __builtin_memcpy(w, quals + beg + i, 16);
+#pragma unroll
+            for (int k = 0; k < 4; k++) s = __builtin_amdgcn_sad_u8(w[k], 0u, s);
+        }
+        if (lane < (int)(len - body)) s += (uint32_t)quals[beg + body + lane];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) qsum[r] = s;
-        for (int i = lane; i < kEndBases; i += 64) {
-            const int64_t p = head_quals ? i : len - kEndBases + i;
-            qtail[r * kEndBases + i] = (p >= 0 && p < len) ? quals[beg + p] : (uint8_t)33;
+        if (lane == 0) qsum[r] = s - 33u * (uint32_t)len;
+        if (len >= kEndBases) {  // the 224 qualities the filter may look at: fourteen lanes, 16 bytes each
+            if (lane < kEndBases / 16) {
+                uint32_t w[4];
+                __builtin_memcpy(w, quals + beg + (head_quals ? 0 : len - kEndBases) + 16 * lane, 16);
+                __builtin_memcpy(qtail + r * kEndBases + 16 * lane, w, 16);
+            }
+        } else {
+            for (int i = lane; i < kEndBases; i += 64) {
+                const int64_t p = head_quals ? i : len - kEndBases + i;
+                qtail[r * kEndBases + i] = (p >= 0 && p < len) ? quals[beg + p] : (uint8_t)33;
+            }
         }
     }
 }
