@@ -609,14 +609,21 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                     const int ae = res.adapter_end;
                     int sum = 0;
                     bool in_range = ae - 16 >= 1;
-                    for (int p = ae - 16; p <= ae - 1; p++) {
-                        // 3': the last kEndBases qualities, right-aligned; 5': the first kEndBases, left-aligned
-                        const int idx = FP ? p - 1 : kEndBases - 1 - (len - p);
-                        if (idx < 0 || idx >= kEndBases) {
-                            in_range = false;
-                            break;
+                    {
+                        // 3': the last kEndBases qualities, right-aligned; 5': the first kEndBases, left-aligned.  The sixteen
+                        // qualities are consecutive bytes of the tail: one 16-byte load summed with v_sad_u8 (a loop of sixteen
+                        // dependent byte loads per chosen lane before)
+                        const int p0 = ae - 16;
+                        const int idx0 = FP ? p0 - 1 : kEndBases - 1 - (len - p0);
+                        if (idx0 < 0 || idx0 + 15 >= kEndBases) in_range = false;
+                        if (in_range) {
+                            uint32_t w[4];
+                            __builtin_memcpy(w, qtail + (size_t)read * kEndBases + idx0, 16);
+                            uint32_t acc = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) acc = __builtin_amdgcn_sad_u8(w[k], 0u, acc);
+                            sum = (int)acc - 16 * 33;
                         }
-                        sum += (int)qtail[(size_t)read * kEndBases + idx] - 33;
                     }
                     if (in_range) {
                         const float q_bc = (float)((double)sum / 16.0);
