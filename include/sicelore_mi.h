@@ -227,8 +227,16 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
  * element-wise sum of the pass-1 histograms of n_ctx contexts, one per GPU, in place, over RCCL (xGMI).  d_hist[i]: n_counters u32 on the
  * device of ctxs[i] (n_counters = number of loaded keys; every context holds the same barcode set).  Runs on the contexts' own streams and
  * returns when all of them have drained; RCCL is dlopen-ed on first use.  The reference's threads add into one ConcurrentHashMap instead
- * (UsedCellBCListGenerator.java:L224-229); multi-process hosts use their own collective (sicelore-2.1_amd/distributed.py). */
+ * (UsedCellBCListGenerator.java:L224-229); multi-process hosts use their own collective (sicelore-2.1_amd/distributed.py).
+ * Stream order: a context's stream is NOT ordered against the stream that filled d_hist[i].  smi_hist_allreduce expects every producer
+ * stream to have been synchronised by the caller (smi_scanfastq_pass1_chunk returns drained, so its histograms qualify);
+ * smi_hist_allreduce_after takes the producer streams (hipStream_t as void*, one per context, NULL entry = the device's default stream) and
+ * orders each context's stream behind its producer with an event.  The calling thread's current HIP device is restored on return.  The
+ * communicators are created on the first call for a device list and kept (ncclCommInitAll is hundreds of ms on 8 GPUs);
+ * smi_hist_allreduce_release destroys them (call it before the contexts go when the process outlives them). */
 int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, size_t n_counters);
+int smi_hist_allreduce_after(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, size_t n_counters, void *const *producer_streams);
+int smi_hist_allreduce_release(void);
 
 /* pass-1 histogram straight from scan output: for reads with pass1_ok, key = offset-0 barcode of the window
  * (UsedCellBCListGenerator.java:L207-229); ++hist[ordinal(key)] when the key is in the loaded set */

@@ -1416,7 +1416,16 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         if (a < 0) P.myers_ok = 0;
         P.ad_idx[j] = (uint8_t)(a < 0 ? 0 : a);
     }
+    // SMI_CHIM_ABLATE (timing of the kernel's parts, wrong results by construction): measurement builds only (make MEASURE=1)
+#ifdef SMI_MEASURE
     P.ablate = getenv("SMI_CHIM_ABLATE") ? atoi(getenv("SMI_CHIM_ABLATE")) : 0;
+#else
+    P.ablate = 0;
+    if (getenv("SMI_CHIM_ABLATE") && atoi(getenv("SMI_CHIM_ABLATE")) != 0) {
+        set_error("smi_chimera_device: SMI_CHIM_ABLATE is set, which yields wrong results by construction; it is honoured by measurement builds only (make MEASURE=1)");
+        return SMI_ERR_INVALID;
+    }
+#endif
     const bool no_filter = getenv("SMI_CHIM_NO_PREFILTER") != nullptr;  // measurement / cross-check switch: every read takes the exact path
     if (no_filter) P.myers_ok = 0;
     // lead <= nErrors / 1.1 (see myers_bound); one more for safety -- a larger range only weakens the filter

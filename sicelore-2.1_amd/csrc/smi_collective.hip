@@ -61,7 +61,43 @@ int rccl_fail(int rc, const char *what) {
 }
 }  // namespace
 
-extern "C" int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, size_t n_counters) {
+namespace {
+// communicators are cached per device list: ncclCommInitAll costs hundreds of ms on 8 GPUs and a host calls the exchange once per
+// run at least (twice with the BarcodesAssigned counters); smi_hist_allreduce_release destroys them
+struct CommSet {
+    std::vector<int> devs;
+    std::vector<void *> comms;
+};
+std::vector<CommSet> g_comm_sets;
+std::mutex g_comm_mu;  // also serialises the collective itself: one RCCL group at a time per process
+
+struct DeviceRestore {  // the calling thread's current HIP device is left as it was found
+    int dev = -1;
+    DeviceRestore() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceRestore() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
+int comms_for(const std::vector<int> &devs, std::vector<void *> **out) {
+    for (auto &cs : g_comm_sets)
+        if (cs.devs == devs) {
+            *out = &cs.comms;
+            return SMI_OK;
+        }
+    CommSet cs;
+    cs.devs = devs;
+    cs.comms.assign(devs.size(), nullptr);
+    if (int rc = g_rccl.CommInitAll(cs.comms.data(), (int)devs.size(), devs.data())) {
+        for (void *c : cs.comms)  // a partial initialisation leaks nothing
+            if (c) (void)g_rccl.CommDestroy(c);
+        return rccl_fail(rc, "ncclCommInitAll");
+    }
+    g_comm_sets.push_back(std::move(cs));
+    *out = &g_comm_sets.back().comms;
+    return SMI_OK;
+}
+}  // namespace
+
+extern "C" int smi_hist_allreduce_after(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, size_t n_counters, void *const *producer_streams) {
     if (!ctxs || !d_hist || n_ctx <= 0) {
         set_error("smi_hist_allreduce: null argument");
         return SMI_ERR_INVALID;
@@ -81,8 +117,22 @@ extern "C" int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, 
     }
     if (n_counters == 0) return SMI_OK;
     if (int rc = load_rccl()) return rc;
-    std::vector<void *> comms((size_t)n_ctx, nullptr);
-    if (int rc = g_rccl.CommInitAll(comms.data(), n_ctx, devs.data())) return rccl_fail(rc, "ncclCommInitAll");
+    DeviceRestore restore;
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    std::vector<void *> *comms = nullptr;
+    if (int rc = comms_for(devs, &comms)) return rc;
+    // order every context's stream behind the stream that produced its histogram (an event on that stream; the default stream when the
+    // caller names it as 0 is a legal producer too)
+    if (producer_streams)
+        for (int i = 0; i < n_ctx; i++) {
+            SMI_HIP(hipSetDevice(devs[i]));
+            hipEvent_t ev = nullptr;
+            SMI_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            hipError_t e = hipEventRecord(ev, static_cast<hipStream_t>(producer_streams[i]));
+            if (e == hipSuccess) e = hipStreamWaitEvent(ctxs[i]->stream, ev, 0);
+            (void)hipEventDestroy(ev);  // released once the wait has been satisfied
+            if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent (smi_hist_allreduce)");
+        }
     int rc = g_rccl.GroupStart();
     for (int i = 0; i < n_ctx && rc == 0; i++) {
         hipError_t e = hipSetDevice(devs[i]);
@@ -90,7 +140,7 @@ extern "C" int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, 
             rc = -1;
             break;
         }
-        rc = g_rccl.AllReduce(d_hist[i], d_hist[i], n_counters, /*ncclUint32*/ 3, /*ncclSum*/ 0, comms[i], ctxs[i]->stream);
+        rc = g_rccl.AllReduce(d_hist[i], d_hist[i], n_counters, /*ncclUint32*/ 3, /*ncclSum*/ 0, (*comms)[i], ctxs[i]->stream);
     }
     const int rc_end = g_rccl.GroupEnd();
     int ret = SMI_OK;
@@ -100,9 +150,21 @@ extern "C" int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, 
         hipError_t e = hipStreamSynchronize(ctxs[i]->stream);
         if (e != hipSuccess && ret == SMI_OK) ret = hip_fail(e, "hipStreamSynchronize (smi_hist_allreduce)");
     }
-    for (void *c : comms)
-        if (c) (void)g_rccl.CommDestroy(c);
     return ret;
+}
+
+extern "C" int smi_hist_allreduce(smi_ctx **ctxs, int n_ctx, uint32_t **d_hist, size_t n_counters) {
+    return smi_hist_allreduce_after(ctxs, n_ctx, d_hist, n_counters, nullptr);
+}
+
+extern "C" int smi_hist_allreduce_release(void) {
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    DeviceRestore restore;
+    for (auto &cs : g_comm_sets)
+        for (void *c : cs.comms)
+            if (c && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c);
+    g_comm_sets.clear();
+    return SMI_OK;
 }
 
 // ---- host-buffer forms: upload, the device entry points, download ------------------------------------------------

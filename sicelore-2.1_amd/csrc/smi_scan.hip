@@ -718,8 +718,18 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     for (int i = 0; i < 22 && i < ad; i++) P.adapter_nib[i >> 3] |= (cfg->adapter4[i] & 15u) << ((i & 7) * 4);
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
-    const char *abl = std::getenv("SMI_SCAN_ABLATE");  // measurement only (tools/gpu_scan_ablate.sh): the results are wrong by construction
+    // SMI_SCAN_ABLATE switches parts of the kernel off to time them (tools/gpu_scan_ablate.sh): the results are wrong by construction, so
+    // only a measurement build (make MEASURE=1 -> -DSMI_MEASURE) honours it; the shipped library refuses to run with it set
+    const char *abl = std::getenv("SMI_SCAN_ABLATE");
+#ifdef SMI_MEASURE
     P.ablate = abl ? std::atoi(abl) : 0;
+#else
+    P.ablate = 0;
+    if (abl && std::atoi(abl) != 0) {
+        set_error("smi_scan_device: SMI_SCAN_ABLATE is set, which yields wrong results by construction; it is honoured by measurement builds only (make MEASURE=1)");
+        return SMI_ERR_INVALID;
+    }
+#endif
     const size_t n_ends = 2 * n;
     const unsigned grid = (unsigned)std::min<size_t>((n_ends + kBlock - 1) / kBlock, 256 * 64);  // measured: x4 8.2, x16 7.5, x64 7.2, uncapped 7.7 ms
     if (int rc = time_begin(ctx, SMI_K_SCAN, s)) return rc;

@@ -52,7 +52,7 @@ EXPORTS = [
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
-    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
+    "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_hist_allreduce_after", "smi_hist_allreduce_release", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
     "smi_genes_load_refflat", "smi_genes_free", "smi_genes_count", "smi_gene_tag_chunk", "smi_gene_tag_bam",
     "smi_pack_reads_text_device", "smi_pack_ends_text_device", "smi_frag_text_starts_device", "smi_fastq_write_text_device",
 ]
@@ -141,6 +141,8 @@ def load_library():
     lib.smi_format_read_name.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int32, vp, vp,
                                          ctypes.c_int32, ctypes.c_uint32, ci, ctypes.c_char_p, sz]
     lib.smi_hist_allreduce.argtypes = [vp, ci, vp, sz]
+    lib.smi_hist_allreduce_after.argtypes = [vp, ci, vp, sz, vp]
+    lib.smi_hist_allreduce_release.argtypes = []
     lib.smi_scan_batch.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     lib.smi_umi_dist_batch.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
     lib.smi_genes_load_refflat.argtypes = [vp, sz, vp, ci, vp]
@@ -817,11 +819,20 @@ class Context:
 
 
 def hist_allreduce(contexts, d_hists):
-    """smi_hist_allreduce: in-place sum of the pass-1 histograms (device int32/uint32 tensors, one per context / GPU) over RCCL"""
+    """smi_hist_allreduce_after: in-place sum of the pass-1 histograms (device int32/uint32 tensors, one per context / GPU) over RCCL;
+    every context's stream is ordered behind torch's current stream on the tensor's device (the stream that filled it)"""
+    import torch
+
     lib = load_library()
     n = len(contexts)
     hs = (ctypes.c_void_p * n)(*[c._h for c in contexts])
     ps = (ctypes.c_void_p * n)(*[ctypes.c_void_p(t.data_ptr()) for t in d_hists])
-    rc = lib.smi_hist_allreduce(hs, n, ps, int(d_hists[0].numel()))
+    ss = (ctypes.c_void_p * n)(*[ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream) for t in d_hists])
+    rc = lib.smi_hist_allreduce_after(hs, n, ps, int(d_hists[0].numel()), ss)
     if rc != 0:
         raise SmiError(f"smi_hist_allreduce error {rc}: {lib.smi_last_error().decode()}")
+
+
+def hist_allreduce_release():
+    """destroy the cached RCCL communicators (smi_hist_allreduce_release)"""
+    load_library().smi_hist_allreduce_release()

@@ -19,12 +19,19 @@ def test_hist_allreduce_over_rccl(pkg, synth):
         h = np.random.default_rng(10 + d).integers(0, 1000, n_keys).astype(np.int32)
         total += h
         hists.append(torch.from_numpy(h).to(f"cuda:{d}"))
-    torch.cuda.synchronize()
+    # no synchronize here: hist_allreduce orders every context's stream behind torch's stream on that device (smi_hist_allreduce_after)
+    dev_before = torch.cuda.current_device()
     libmod.hist_allreduce(ctxs, hists)
-    for h in hists:
+    assert torch.cuda.current_device() == dev_before
+    for d, h in enumerate(hists):
+        torch.cuda.synchronize(d)
         assert (h.cpu().numpy().astype(np.int64) == total).all()
+    libmod.hist_allreduce(ctxs, hists)          # the cached communicators serve the second exchange
+    for h in hists:
+        assert (h.cpu().numpy().astype(np.int64) == n_gpu * total).all()
     with pytest.raises(libmod.SmiError, match="one context per GPU"):
         libmod.hist_allreduce([ctxs[0], ctxs[0]], [hists[0], hists[0]])
+    libmod.hist_allreduce_release()
     for c in ctxs:
         c.close()
 
@@ -37,8 +44,9 @@ def test_hist_allreduce_two_gpus_sum(pkg):
     ctxs = [pkg.Context(0), pkg.Context(1)]
     a = torch.arange(1000, dtype=torch.int32, device="cuda:0")
     b = torch.full((1000,), 7, dtype=torch.int32, device="cuda:1")
-    torch.cuda.synchronize()
     libmod.hist_allreduce(ctxs, [a, b])
+    for d in range(2):
+        torch.cuda.synchronize(d)
     exp = np.arange(1000) + 7
     assert (a.cpu().numpy() == exp).all() and (b.cpu().numpy() == exp).all()
 
