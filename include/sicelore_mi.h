@@ -484,6 +484,7 @@ typedef struct {
 #define SMI_WR_NAME_RANGE 1u    /* the X= / Q= range of a passed read leaves the read: the reference throws */
 #define SMI_WR_NAME_TOO_LONG 2u /* a formatted name longer than 1016 bytes */
 #define SMI_WR_OVERFLOW 4u      /* cap_passed / cap_failed too small (nothing is written past a cap) */
+#define SMI_WR_QUAL_NEWLINE 8u  /* smi_fastq_write_host only: a line end inside a quality string the one-pass index had stepped over (reserved = 1) */
 int smi_fastq_write_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_line_start, const uint8_t *d_reads,
                            const uint8_t *d_quals, const uint64_t *d_offsets, const uint32_t *d_frag_src,
                            const smi_chimera_result *d_chim, const smi_scan_result *d_scan, const smi_bc_result *d_bc,
@@ -540,6 +541,90 @@ int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes,
  * binding does); contexts sharing one d_hist only ever atomicAdd into it.  Returns after the stream has drained. */
 int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
                               uint32_t *d_hist, size_t *n_records, uint32_t *fastq_errors);
+
+/* ================================================================================================================
+ * The packed boundary of `scanfastq` ("multi-file parallel decode and on-host trimming"): the host keeps the
+ * FASTQ text, ships the bases only -- four IUPAC bit-planes per read, 0.5 byte per base -- and gets DECISIONS back (split positions,
+ * scan result, barcode result, rank: ~80 bytes per record); the `passed` / `failed` text is then assembled on host threads from the text
+ * the host never gave away.  5 KB per read cross the link with the text workers above, 0.7 KB with these.  Output is byte-identical to
+ * smi_scanfastq_pass2_chunk (tests/test_packed_gpu.py); host code is AVX-512 (BW + VBMI) where the CPU has it, AVX2 or plain C++ otherwise.
+ * Replaces the same reference units as the text workers: FastqFileReader$ReadChunk -> Parser.call -> FastqWriterThreadPool$FastQoneFileThread.run
+ * (FJ!nanoporereadscanner/readerwriter/FastqWriterThreadPool.java:L300-306).
+ * ================================================================================================================ */
+typedef struct {            /* one FASTQ record of a chunk of text (positions into the text; line ends and a CR in front of them stripped) */
+    uint64_t name_start;    /* behind '@' */
+    uint64_t seq_start;
+    uint64_t plus_start;    /* behind '+' */
+    uint64_t qual_start;
+    uint32_t name_len, seq_len, plus_len, reserved;
+} smi_fastq_record;
+/* The record index smi_fastq_index_device builds, on n_threads host threads (htsjdk FastqReader rules, SMI_FQ_* in *errors, nothing
+ * repaired).  recs: cap_records entries, offsets: cap_records + 1 (prefix sums of seq_len = the coordinate system of planes, fragment
+ * offsets and every length, as on the device).  A text with more than cap_records records is rejected. */
+int smi_fastq_index_host(const uint8_t *text, size_t n_bytes, smi_fastq_record *recs, uint64_t *offsets, size_t cap_records,
+                         size_t *n_records, uint32_t *errors, int n_threads);
+/* K-PACKR on the host: planes in the layout of smi_pack_reads_device (smi_read_planes_words(offsets[n], n) u32 words, every word of it
+ * written) */
+int smi_pack_reads_host(const uint8_t *text, const smi_fastq_record *recs, const uint64_t *offsets, size_t n, uint32_t *planes,
+                        int n_threads);
+/* Index and planes in ONE pass over the text (what the chunk workers below use): every thread walks its share of the text once and
+ * writes its reads' planes into a segment of its own, so a read's place is no longer a function of its offset -- pstart[r] says where read
+ * r begins in a plane of the compact layout in which the device holds the segments back to back.  The quality lines are stepped over
+ * (their length is known): recs[r].reserved = 1 asks whoever reads the qualities later (smi_fastq_write_host, smi_pack_quals_host) to
+ * check them for hidden line ends, so a malformed chunk fails in the same cases as with the text workers.  Falls back to
+ * smi_fastq_index_host + smi_pack_reads_host (one segment, pstart = NULL) whenever the text is not plain well-formed FASTQ.
+ * planes: smi_packed_planes_words(n_bytes, n_threads) u32 words; pstart, recs: cap_records entries, offsets: cap_records + 1. */
+#define SMI_PACKED_MAX_SEGMENTS 256
+typedef struct {
+    const uint32_t *planes;   /* host: plane c of segment k = planes[c * stride + seg_host_word[k] .. + seg_words[k]) */
+    size_t stride;
+    const uint32_t *pstart;   /* n entries, or NULL: K-PACKR's layout (read r at plane_start(offsets[r], r), one segment) */
+    int32_t n_seg, reserved;
+    size_t total_words;       /* words per plane of the compact layout */
+    uint64_t seg_host_word[SMI_PACKED_MAX_SEGMENTS], seg_dev_word[SMI_PACKED_MAX_SEGMENTS], seg_words[SMI_PACKED_MAX_SEGMENTS];
+} smi_packed_reads;
+size_t smi_packed_planes_words(size_t n_bytes, int n_threads);
+int smi_fastq_index_pack_host(const uint8_t *text, size_t n_bytes, smi_fastq_record *recs, uint64_t *offsets, uint32_t *pstart,
+                              size_t cap_records, uint32_t *planes, size_t planes_words, smi_packed_reads *packed, size_t *n_records,
+                              uint32_t *errors, int n_threads);
+/* the quality side of pass 1 (K-PACK's k_pack_quals): qsum[r] = sum of (q - 33) over the read, qtail[r][SMI_END_BASES] = its last
+ * qualities right-aligned (five_prime: its first ones, left-aligned), '!' where the read is shorter */
+int smi_pack_quals_host(const uint8_t *text, const smi_fastq_record *recs, size_t n, int five_prime, uint8_t *qtail, uint32_t *qsum,
+                        int n_threads);
+/* what comes back from the device for a chunk; arrays are owned by the context (page-locked), valid until its next call */
+typedef struct {
+    size_t n_records_in, n_records_out;   /* out = after the chimera split */
+    const smi_chimera_result *chim;       /* n_records_in entries, NULL when the splitter did not run */
+    const uint64_t *frag_offsets;         /* n_records_out + 1: output record i = bases [frag_offsets[i], frag_offsets[i+1]) of the chunk */
+    const uint32_t *frag_src;             /* n_records_out: input record << 2 | fragment; NULL when the splitter did not run */
+    const smi_scan_result *scan;          /* n_records_out */
+    const smi_bc_result *bc;              /* n_records_out */
+    const int32_t *rank;                  /* n_records_out, NULL without a rank table */
+} smi_pass2_decisions;
+/* device side of pass 2 from packed reads: upload of planes + offsets (host memory, page-locked for link speed), K-CHIM, fragment
+ * offsets, read ends cut out of the planes (k_ends_from_planes), K-SCAN, K-BC, rank lookup, download of the decisions */
+int smi_scanfastq_pass2_packed(smi_ctx *ctx, const uint32_t *planes, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,
+                               smi_pass2_decisions *out);
+/* the same from the segments of smi_fastq_index_pack_host */
+int smi_scanfastq_pass2_packed_seg(smi_ctx *ctx, const smi_packed_reads *packed, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,
+                                   smi_pass2_decisions *out);
+/* K-WRITE on host threads: the records of smi_fastq_write_device from the host's text, its index and the decisions.  passed / failed:
+ * caller's buffers; totals[0..2] = bytes passed, bytes failed, records passed; *errors = SMI_WR_* (any bit fails the call). */
+int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record *recs, const uint64_t *offsets, const smi_pass2_decisions *dec,
+                         uint32_t first_read_id, const smi_write_config *cfg, uint8_t *passed, size_t cap_passed, uint8_t *failed,
+                         size_t cap_failed, uint64_t *totals, uint32_t *errors, int n_threads);
+/* the three steps as one call per chunk, same contract and same bytes as smi_scanfastq_pass2_chunk (out->scan / bc with want_results);
+ * n_threads host threads index, pack and write */
+int smi_scanfastq_pass2_chunk_packed(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, const smi_pass2_config *cfg, int n_threads,
+                                     smi_pass2_output *out);
+/* pass 1 likewise: index, planes, quality sums and tails on the host; ends cut from the planes, K-SCAN<22> + filter, K-HIST on the device */
+int smi_scanfastq_pass1_chunk_packed(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
+                                     uint32_t *d_hist, int n_threads, size_t *n_records, uint32_t *fastq_errors);
+/* read ends for smi_scan_device cut out of read planes: record i = bases [d_rec_offsets[i], d_rec_offsets[i+1]) of the chunk, inside input
+ * read d_frag_src[i] >> 2 (d_frag_src == NULL: record i = read i); same ends / lengths as smi_pack_ends_device gives from ASCII */
+int smi_ends_from_planes_device(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_read_offsets, size_t n_reads,
+                                uint64_t total_bases, const uint64_t *d_rec_offsets, const uint32_t *d_frag_src, size_t n_records, uint32_t *d_ends,
+                                int32_t *d_read_len, void *stream);
 
 /* `assignumis` for one chunk of BamReader (the records between two cuts of BamReader.run): OneBatchExecutor.call +
  * UmiClustering.cluster after ReadGrouper.groupSams (FJ!umifinder/OneBatchExecutor.java:L61-90,

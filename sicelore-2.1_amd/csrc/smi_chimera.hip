@@ -32,7 +32,7 @@ namespace smi {
 // complete adapter, Jar/config.xml:170,113) and <22, 25> for 5' barcoding (5' adapter / 3' adapter, config.xml:126,141).
 constexpr int kMaxPat = 27;
 constexpr int kCap = 64;     // accepted TSO positions per orientation / matches per read kept in LDS
-constexpr int kPadWords = 5; // plane spacing: ceil(len / 32) data words + 4 zero words (gates and windows run past the end)
+constexpr int kPadWords = kReadPadWords; // plane spacing: ceil(len / 32) data words + 4 zero words (gates and windows run past the end)
 
 struct ChimParams {
     uint32_t tso4[2][kMaxPat];  // [0] the pattern searched in both orientations (complete TSO), [1] its reverse complement
@@ -58,7 +58,6 @@ struct ReadPlanes {
     const uint32_t *p[4];
 };
 
-__host__ __device__ inline size_t plane_start(uint64_t base_offset, size_t r) { return (size_t)(base_offset >> 5) + kPadWords * r; }
 
 __device__ __forceinline__ uint64_t gget64(const uint32_t *pl, int bitpos) {
     const int w = bitpos >> 5, s = bitpos & 31;
@@ -510,7 +509,7 @@ __device__ __forceinline__ int kth_bit32(uint32_t m, int k) {
 }
 
 template <int kTsoLen, int PAT>
-__global__ __launch_bounds__(256) void k_chim_tso_filter(const uint32_t *__restrict__ planes, size_t stride,
+__global__ __launch_bounds__(256) void k_chim_tso_filter(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
                                                          const uint64_t *__restrict__ offsets, size_t n, FilterParams P,
                                                          smi_chimera_result *__restrict__ out, uint32_t *__restrict__ list,
                                                          uint32_t *__restrict__ list_count) {
@@ -525,7 +524,7 @@ __global__ __launch_bounds__(256) void k_chim_tso_filter(const uint32_t *__restr
         bool any_hot = false, any_pat = false;
         if (len >= 2 * 70 + 100) {
             ReadPlanes rp;
-            const size_t w0 = plane_start(beg, r);
+            const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);  // pstart: explicit word start per read (segmented host packer)
 #pragma unroll
             for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
             const int last = len - 70;
@@ -696,7 +695,7 @@ struct TsoSlot {
 #define SMI_CHIM_C_WAVES 4  // waves per SIMD K-CHIM-C is held to
 #endif
 template <int kTsoLen, int kAdLen, int PART>
-__global__ __launch_bounds__(256, PART == 1 ? SMI_CHIM_B_WAVES : SMI_CHIM_C_WAVES) void k_chimera(const uint32_t *__restrict__ planes, size_t stride,
+__global__ __launch_bounds__(256, PART == 1 ? SMI_CHIM_B_WAVES : SMI_CHIM_C_WAVES) void k_chimera(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
                                                                    const uint64_t *__restrict__ offsets,
                                                                    const uint32_t *__restrict__ list,
                                                                    const uint32_t *__restrict__ list_count, ChimParams P,
@@ -720,7 +719,7 @@ __global__ __launch_bounds__(256, PART == 1 ? SMI_CHIM_B_WAVES : SMI_CHIM_C_WAVE
         res.flags = 0;
         res.n_matches = 0;
         ReadPlanes rp;  // (reads shorter than 2 * 70 + 100 never reach the queue, L169)
-        const size_t w0 = plane_start(beg, r);
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);  // pstart: explicit word start per read (segmented host packer)
 #pragma unroll
         for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
         int n_m = 0;        // matches in L.m_*
@@ -1076,7 +1075,7 @@ __global__ __launch_bounds__(256, PART == 1 ? SMI_CHIM_B_WAVES : SMI_CHIM_C_WAVE
 // Scratch of read k of the queue: 7 * cap(k) words at scr[scr_off[k]], cap = length + 8.
 // ---------------------------------------------------------------------------------------------------------------
 template <int kTsoLen, int kAdLen>
-__global__ __launch_bounds__(64) void k_chimera_serial(const uint32_t *__restrict__ planes, size_t stride,
+__global__ __launch_bounds__(64) void k_chimera_serial(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
                                                        const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list,
                                                        uint32_t n_list, const uint64_t *__restrict__ scr_off, int32_t *__restrict__ scr,
                                                        ChimParams P, smi_chimera_result *__restrict__ out) {
@@ -1090,7 +1089,7 @@ __global__ __launch_bounds__(64) void k_chimera_serial(const uint32_t *__restric
         float *ps_ne = reinterpret_cast<float *>(ps_pos + cap);
         int32_t *m_begin = ps_pos + 2 * cap, *m_kind = ps_pos + 3 * cap, *order = ps_pos + 4 * cap;  // cap entries each (matches are > 120 apart)
         ReadPlanes rp;
-        const size_t w0 = plane_start(beg, r);
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);  // pstart: explicit word start per read (segmented host packer)
 #pragma unroll
         for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
         smi_chimera_result res;
@@ -1381,7 +1380,7 @@ int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offse
 }
 
 int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
-                   const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s) {
+                   const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s, const uint32_t *d_pstart, size_t stride_override) {
     if (!n) return SMI_OK;
     const int tl = (int)std::strlen(cfg->tso_complete), al = (int)std::strlen(cfg->adapter_complete);
     if (!((tl == 27 && al == 22) || (tl == 22 && al == 25))) {
@@ -1460,20 +1459,20 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     F.pat_len = P.pat_len;
     F.pat_thr = P.pat_thr;
     F.off = P.off;
-    const size_t st = read_planes_stride(total_bases, n);
+    const size_t st = stride_override ? stride_override : read_planes_stride(total_bases, n);
     {
         const unsigned gridA = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
         const bool generic = getenv("SMI_CHIM_GENERIC") != nullptr || !P.myers_ok;
         const bool shipped3 = tl == 27 && !std::strcmp(cfg->tso_complete, PatSeq<1>::s) && !generic;
         const bool shipped5 = tl == 22 && !std::strcmp(cfg->tso_complete, PatSeq<2>::s) && !generic;
         if (shipped3)
-            hipLaunchKernelGGL((k_chim_tso_filter<27, 1>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+            hipLaunchKernelGGL((k_chim_tso_filter<27, 1>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
         else if (shipped5)
-            hipLaunchKernelGGL((k_chim_tso_filter<22, 2>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+            hipLaunchKernelGGL((k_chim_tso_filter<22, 2>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
         else if (tl == 27)
-            hipLaunchKernelGGL((k_chim_tso_filter<27, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+            hipLaunchKernelGGL((k_chim_tso_filter<27, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
         else
-            hipLaunchKernelGGL((k_chim_tso_filter<22, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_offsets, n, F, d_out, d_list, d_count);
+            hipLaunchKernelGGL((k_chim_tso_filter<22, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
         SMI_HIP(hipGetLastError());
     }
     // the queue length decides the size of the hand-over slots (one small copy + sync per launch)
@@ -1494,11 +1493,11 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         const unsigned grid = (unsigned)std::min<size_t>(((size_t)n_list + 3) / 4, 256 * 16);
         if (!(P.ablate & 16)) {
             if (tl == 27) {
-                hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
-                hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
             } else {
-                hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
-                hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
             }
             SMI_HIP(hipGetLastError());
             // reads with more than kCap accepted positions / matches: once more without the cap (K-CHIM-S).  The overflow queue sits
@@ -1532,9 +1531,9 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 SMI_HIP(hipMemcpyAsync(d_over_sorted, over.data(), (size_t)n_over * 4, hipMemcpyHostToDevice, s));
                 const unsigned gs = (unsigned)std::min<uint32_t>(n_over, 4096);
                 if (tl == 27)
-                    hipLaunchKernelGGL((k_chimera_serial<27, 22>), dim3(gs), dim3(64), 0, s, d_planes, st, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
+                    hipLaunchKernelGGL((k_chimera_serial<27, 22>), dim3(gs), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
                 else
-                    hipLaunchKernelGGL((k_chimera_serial<22, 25>), dim3(gs), dim3(64), 0, s, d_planes, st, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
+                    hipLaunchKernelGGL((k_chimera_serial<22, 25>), dim3(gs), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
                 hipError_t e2 = hipStreamSynchronize(s);
                 (void)hipFree(d_scr_off);
                 (void)hipFree(d_scr);

@@ -49,6 +49,17 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     return p;
 }
 
+int ensure_host_buf(smi_ctx *ctx, int which, size_t bytes) {
+    if (ctx->host_buf_bytes[which] >= bytes) return SMI_OK;
+    if (ctx->host_buf[which]) SMI_HIP(hipHostFree(ctx->host_buf[which]));
+    ctx->host_buf[which] = nullptr;
+    ctx->host_buf_bytes[which] = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    SMI_HIP(hipHostMalloc(&ctx->host_buf[which], want, hipHostMallocDefault));
+    ctx->host_buf_bytes[which] = want;
+    return SMI_OK;
+}
+
 static int ensure_stage(smi_ctx *ctx, size_t in_bytes, size_t out_bytes) {
     if (in_bytes > ctx->stage_in_bytes) {
         if (ctx->stage_in) SMI_HIP(hipFree(ctx->stage_in));
@@ -218,6 +229,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->chim_slots);
     (void)hipHostFree(ctx->host_out[0]);
     (void)hipHostFree(ctx->host_out[1]);
+    for (void *hb : ctx->host_buf) (void)hipHostFree(hb);
     (void)hipFree(ctx->stage_out);
     for (int k = 0; k < SMI_K_COUNT; k++) {
         if (ctx->kev[k][0]) (void)hipEventDestroy(ctx->kev[k][0]);
@@ -533,6 +545,18 @@ int smi_pack_ends_text_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_
         return SMI_ERR_INVALID;
     }
     return launch_pack_ends(ctx, d_text, nullptr, d_offsets, d_base_start, n, 0, d_ends, d_read_len, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int smi_ends_from_planes_device(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_read_offsets, size_t n_reads,
+                                uint64_t total_bases, const uint64_t *d_rec_offsets, const uint32_t *d_frag_src, size_t n_records,
+                                uint32_t *d_ends, int32_t *d_read_len, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_records && (!d_planes || !d_read_offsets || !d_rec_offsets || !d_ends || !d_read_len)) {
+        set_error("smi_ends_from_planes_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_ends_from_planes(ctx, d_planes, read_planes_stride(total_bases, n_reads), d_read_offsets, d_rec_offsets, d_frag_src,
+                                   n_records, d_ends, d_read_len, (hipStream_t)stream);
 }
 
 int smi_frag_text_starts_device(smi_ctx *ctx, const uint64_t *d_seq_start, const uint64_t *d_qual_start, const uint64_t *d_offsets,

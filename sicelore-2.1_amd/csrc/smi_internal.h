@@ -148,6 +148,10 @@ struct smi_ctx {
     size_t host_out_bytes[2] = {0, 0};
     std::vector<smi_scan_result> host_scan;  // its per-record results when asked for
     std::vector<smi_bc_result> host_bc;
+    // packed chunk workers: page-locked, grow-only host buffers (index, offsets, planes, quality tails / sums, decisions)
+    enum { HB_RECS = 0, HB_OFFS, HB_PSTART, HB_PLANES, HB_QTAIL, HB_QSUM, HB_CHIM, HB_FOFFS, HB_FSRC, HB_SCAN, HB_BC, HB_RANK, HB_COUNT };
+    void *host_buf[HB_COUNT] = {};
+    size_t host_buf_bytes[HB_COUNT] = {};
 };
 
 namespace smi {
@@ -178,8 +182,10 @@ int launch_frag_text_starts(smi_ctx *ctx, const uint64_t *d_seq_start, const uin
 size_t read_planes_stride(uint64_t total_bases, size_t n);
 int launch_pack_reads(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, const uint64_t *d_starts, size_t n,
                       uint64_t total_bases, uint32_t *d_planes, hipStream_t s);
+// d_pstart != nullptr: read r starts at word d_pstart[r] of each plane and the planes are stride_override words apart (segmented host packer)
 int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
-                   const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s);
+                   const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s, const uint32_t *d_pstart = nullptr,
+                   size_t stride_override = 0);
 int launch_split_offsets(smi_ctx *ctx, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,
                          uint32_t *d_scratch, uint64_t *d_total, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
                          hipStream_t s);
@@ -189,4 +195,11 @@ int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint
                        hipStream_t s);
 int launch_fastq_gather(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
                         uint8_t *d_out, hipStream_t s);
+// read planes (K-PACKR / smi_pack_reads_host): [4][stride] u32; read r starts at word plane_start(offsets[r], r) of each plane and owns
+// ceil(len / 32) data words + 4 zero words (gates and windows run past the end)
+constexpr int kReadPadWords = 5;
+__host__ __device__ inline size_t plane_start(uint64_t base_offset, size_t r) { return (size_t)(base_offset >> 5) + kReadPadWords * r; }
+int launch_ends_from_planes(smi_ctx *ctx, const uint32_t *d_planes, size_t stride, const uint64_t *d_read_offsets, const uint64_t *d_rec_offsets,
+                            const uint32_t *d_frag_src, size_t m, uint32_t *d_ends, int32_t *d_len, hipStream_t s, const uint32_t *d_pstart = nullptr);
+int ensure_host_buf(smi_ctx *ctx, int which, size_t bytes);
 }  // namespace smi

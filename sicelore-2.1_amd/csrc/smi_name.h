@@ -91,7 +91,8 @@ SMI_HD char rc_char(unsigned char c) {
 
 // new DecimalFormat("##.#").format((double) f) (L36, L270): HALF_EVEN on the exact decimal value, at most one fraction
 // digit, no integer digit in front of a fraction when it is zero
-SMI_HD void put_dec1(NameSink &s, float f) {
+template <class Sink>
+SMI_HD void put_dec1(Sink &s, float f) {
     double t = (double)f * 10.0;  // exact: a 24-bit mantissa times 10 fits a double
     const bool neg = t < 0;
     if (neg) t = -t;
@@ -119,7 +120,8 @@ SMI_HD void put_dec1(NameSink &s, float f) {
     }
 }
 
-SMI_HD void put_base36(NameSink &s, uint32_t v) {  // FastqRecordExt$NumberToAndFromAscii.convertInt = Integer.toString(id, 36), L524
+template <class Sink>
+SMI_HD void put_base36(Sink &s, uint32_t v) {  // FastqRecordExt$NumberToAndFromAscii.convertInt = Integer.toString(id, 36), L524
     bool started = false;  // digits from the top, as in put_u32: 36^6 > 2^31, seven digits at most
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -134,7 +136,8 @@ SMI_HD void put_base36(NameSink &s, uint32_t v) {  // FastqRecordExt$NumberToAnd
     }
 }
 
-SMI_HD void put_kmer16(NameSink &s, uint32_t key) {  // TWOBIT_TO_BASE_ARRAY: A G C T
+template <class Sink>
+SMI_HD void put_kmer16(Sink &s, uint32_t key) {  // TWOBIT_TO_BASE_ARRAY: A G C T
     for (int i = 15; i >= 0; i--) {
         const uint32_t b = (key >> (2 * i)) & 3u;
         s.put(b == 0 ? 'A' : (b == 1 ? 'G' : (b == 2 ? 'C' : 'T')));
@@ -177,8 +180,8 @@ SMI_HD NameWindow name_window(const smi_scan_result &scan, bool five_prime, int 
 // (host: raw[rev ? lo + n_chars - 1 - k : lo + k]; the device writer loads the window with a few wide loads before it formats).
 // Returns NAME_OK or NAME_RANGE; *stranded_ok = false in the "Beginrange inconsistent" case (L257-259: the name keeps no
 // suffix and the record is written with the stranded sequence and a null quality string).
-template <class SeqAt, class QualAt>
-SMI_HD int append_name_suffix(NameSink &s, const smi_scan_result &scan, const smi_bc_result *bc, int rank, uint32_t read_id,
+template <class Sink, class SeqAt, class QualAt>
+SMI_HD int append_name_suffix(Sink &s, const smi_scan_result &scan, const smi_bc_result *bc, int rank, uint32_t read_id,
                               bool five_prime, int len, SeqAt seq_w, QualAt qual_w, bool *quals_set) {
     *quals_set = true;
     const bool fwd = scan.flags & SMI_F_PASSED_FWD, rev = scan.flags & SMI_F_PASSED_REV;

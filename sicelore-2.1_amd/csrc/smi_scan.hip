@@ -879,6 +879,63 @@ __global__ __launch_bounds__(256) void k_pack_quals(const uint8_t *__restrict__ 
     }
 }
 
+// K-PACK for the packed boundary: the read ends cut out of read PLANES (smi_pack_reads_host / K-PACKR) instead of ASCII.  One lane = one
+// end, as in k_pack_ends.  Record i = bases [rec_offsets[i], rec_offsets[i+1]) of the chunk inside read src (frag_src[i] >> 2, or i):
+// bit b of word w of a plane = base 32 w + b of the read, so the head is a 224-bit funnel shift out of each plane and the reverse-
+// complemented tail the same bits mirrored (v_bfrev) with the planes swapped A <-> T, G <-> C (N = all four bits stays N).
+__device__ __forceinline__ uint32_t plane_bits32(const uint32_t *pl, int64_t bitpos) {  // 32 bits from bit position bitpos >= 0
+    const int64_t w = bitpos >> 5;
+    const int sh = (int)(bitpos & 31);
+    const uint64_t two = ((uint64_t)pl[w + 1] << 32) | pl[w];
+    return (uint32_t)(two >> sh);
+}
+__global__ __launch_bounds__(256) void k_ends_from_planes(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+                                                          const uint64_t *__restrict__ read_offsets,
+                                                          const uint64_t *__restrict__ rec_offsets, const uint32_t *__restrict__ frag_src, size_t m,
+                                                          uint32_t *__restrict__ ends, int32_t *__restrict__ read_len) {
+    const size_t n_ends = 2 * m;
+    for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_ends; e += (size_t)gridDim.x * blockDim.x) {
+        const size_t i = e >> 1;
+        const int side = (int)(e & 1);
+        const size_t src = frag_src ? (size_t)(frag_src[i] >> 2) : i;
+        const uint64_t rbeg = read_offsets[src], beg = rec_offsets[i];
+        const int64_t len = (int64_t)(rec_offsets[i + 1] - beg);
+        const int64_t fb = (int64_t)(beg - rbeg);  // first base of the record inside its read
+        if (side == 0) read_len[i] = (int32_t)len;
+        const uint32_t *p0 = planes + (pstart ? (size_t)pstart[src] : plane_start(rbeg, src));
+#pragma unroll
+        for (int w = 0; w < kPlaneWords; w++) {
+            const int64_t nb = len - 32 * w;  // bases of this end word that exist
+            uint32_t pl[4] = {0, 0, 0, 0};
+            if (nb > 0) {
+                const uint32_t keep = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+                if (side == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pl[c] = plane_bits32(p0 + c * stride, fb + 32 * w) & keep;
+                } else {
+                    // scan position p = 32 w + b is read base fb + len - 1 - p: the 32 bases ending at fb + len - 1 - 32 w, mirrored; a partial
+                    // word starts at the record's first base and is shifted down after the mirror
+                    const int64_t q = nb >= 32 ? fb + len - 32 * (w + 1) : fb;
+                    const int down = nb >= 32 ? 0 : (int)(32 - nb);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pl[3 - c] = (__builtin_bitreverse32(plane_bits32(p0 + c * stride, q) & keep)) >> down;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) ends[(size_t)(c * kPlaneWords + w) * n_ends + e] = pl[c];
+        }
+    }
+}
+
+int launch_ends_from_planes(smi_ctx *, const uint32_t *d_planes, size_t stride, const uint64_t *d_read_offsets, const uint64_t *d_rec_offsets,
+                            const uint32_t *d_frag_src, size_t m, uint32_t *d_ends, int32_t *d_len, hipStream_t s, const uint32_t *d_pstart) {
+    if (!m) return SMI_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((2 * m + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(k_ends_from_planes, dim3(grid), dim3(256), 0, s, d_planes, stride, d_pstart, d_read_offsets, d_rec_offsets, d_frag_src, m, d_ends, d_len);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
 int launch_pack_ends(smi_ctx *, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, const uint64_t *d_starts,
                      size_t n, int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
     if (!n) return SMI_OK;

@@ -304,6 +304,312 @@ extern "C" int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size
     return SMI_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The packed boundary (include/sicelore_mi.h, "The packed boundary of scanfastq"): planes + offsets up, decisions down.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,
+                      smi_pass2_decisions *out);
+}
+extern "C" int smi_scanfastq_pass2_packed(smi_ctx *ctx, const uint32_t *planes, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,
+                                          smi_pass2_decisions *out) {
+    if (!ctx || !cfg || !out || (n && (!planes || !offsets))) {
+        set_error("smi_scanfastq_pass2_packed: null argument");
+        return SMI_ERR_INVALID;
+    }
+    smi_packed_reads pk;
+    std::memset(&pk, 0, offsetof(smi_packed_reads, seg_host_word));
+    if (n) {
+        pk.planes = planes;
+        pk.stride = smi_read_planes_words(offsets[n], n) / 4;
+        pk.n_seg = 1;
+        pk.total_words = pk.stride;
+        pk.seg_host_word[0] = pk.seg_dev_word[0] = 0;
+        pk.seg_words[0] = pk.stride;
+    }
+    return pass2_packed_core(ctx, &pk, offsets, n, cfg, out);
+}
+extern "C" int smi_scanfastq_pass2_packed_seg(smi_ctx *ctx, const smi_packed_reads *packed, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,
+                                              smi_pass2_decisions *out) {
+    if (!ctx || !cfg || !out || !packed || (n && (!packed->planes || !offsets || packed->n_seg < 1 || packed->n_seg > SMI_PACKED_MAX_SEGMENTS))) {
+        set_error("smi_scanfastq_pass2_packed_seg: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    return pass2_packed_core(ctx, packed, offsets, n, cfg, out);
+}
+
+namespace {
+// planes of a chunk into the arena, compact: the segments back to back in each of the four planes (+ pstart when the packer gave one)
+int upload_planes(smi_ctx *ctx, const smi_packed_reads *pk, size_t n, uint32_t *d_planes, uint32_t *d_pstart, hipStream_t s) {
+    for (int c = 0; c < 4; c++)
+        for (int k = 0; k < pk->n_seg; k++)
+            SMI_HIP(hipMemcpyAsync(d_planes + (size_t)c * pk->total_words + pk->seg_dev_word[k], pk->planes + (size_t)c * pk->stride + pk->seg_host_word[k],
+                                   (size_t)pk->seg_words[k] * 4, hipMemcpyHostToDevice, s));
+    if (pk->pstart) SMI_HIP(hipMemcpyAsync(d_pstart, pk->pstart, n * 4, hipMemcpyHostToDevice, s));
+    return SMI_OK;
+}
+
+int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,
+                      smi_pass2_decisions *out) {
+    std::memset(out, 0, sizeof *out);
+    if (n == 0) return SMI_OK;
+    SMI_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const bool five = cfg->five_prime != 0;
+    const bool split = cfg->split_chimeras && !(five && cfg->dont_search_polya);  // Parser.java:L176
+    const uint64_t total = offsets[n];
+    const size_t pstride = pk->total_words;  // words per plane on the device
+    const size_t planes_words = 4 * pstride;
+    const size_t m_cap = split ? 3 * n : n;
+    const size_t need = pad(planes_words * 4) + pad(n * 4) + pad((n + 1) * 8) + pad(n * sizeof(smi_chimera_result)) + pad(((n + 1023) / 1024 + 1) * 4) + pad(8) +
+                        pad((3 * n + 1) * 8) + pad(3 * n * 4) + pad((size_t)SMI_ENDS_ROWS * 2 * m_cap * 4) + pad(m_cap * 4) +
+                        pad(m_cap * sizeof(smi_scan_result)) + pad(m_cap * sizeof(smi_bc_window)) + pad(m_cap * sizeof(smi_bc_result)) +
+                        pad(m_cap * 4) + pad(cfg->n_ranks * 8) + pad(cfg->n_ranks * 4) + 4096;
+    SMI_RC(ensure_arena(ctx, need));
+    Arena A(ctx);
+    uint32_t *d_planes = A.take<uint32_t>(planes_words);
+    uint32_t *d_pstart = A.take<uint32_t>(n);
+    uint64_t *d_offs = A.take<uint64_t>(n + 1);
+    SMI_RC(upload_planes(ctx, pk, n, d_planes, d_pstart, s));
+    if (!pk->pstart) d_pstart = nullptr;
+    SMI_HIP(hipMemcpyAsync(d_offs, offsets, (n + 1) * 8, hipMemcpyHostToDevice, s));
+    size_t m = n;
+    const uint64_t *d_rec_offs = d_offs;
+    smi_chimera_result *d_chim = nullptr;
+    uint32_t *d_fsrc = nullptr;
+    uint64_t *d_foffs = nullptr;
+    if (split) {
+        d_chim = A.take<smi_chimera_result>(n);
+        uint32_t *d_scr = A.take<uint32_t>((n + 1023) / 1024 + 1);
+        uint64_t *d_nfrag = A.take<uint64_t>(1);
+        d_foffs = A.take<uint64_t>(3 * n + 1);
+        d_fsrc = A.take<uint32_t>(3 * n);
+        smi_chimera_config cc;
+        SMI_RC(five ? smi_chimera_default_config_5p(&cc) : smi_chimera_default_config(&cc));
+        SMI_RC(launch_chimera(ctx, d_planes, d_offs, n, total, &cc, d_chim, s, d_pstart, pstride));
+        SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_CHIM, n * sizeof(smi_chimera_result)));
+        smi_chimera_result *h_chim = static_cast<smi_chimera_result *>(ctx->host_buf[smi_ctx::HB_CHIM]);
+        uint64_t nf = 0;
+        SMI_HIP(hipMemcpyAsync(&nf, d_nfrag, 8, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipMemcpyAsync(h_chim, d_chim, n * sizeof(smi_chimera_result), hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n; i++)
+            if (h_chim[i].flags & (SMI_CHIM_RANGE | SMI_CHIM_OVERFLOW)) {
+                set_error("smi_scanfastq_pass2_packed: a read outside what the splitter supports (SMI_CHIM_RANGE: longer than the plane offsets can address)");
+                return SMI_ERR_INVALID;
+            }
+        m = (size_t)nf;
+        d_rec_offs = d_foffs;
+        out->chim = h_chim;
+    }
+    out->n_records_in = n;
+    out->n_records_out = m;
+    uint32_t *d_ends = A.take<uint32_t>((size_t)SMI_ENDS_ROWS * 2 * m_cap);
+    int32_t *d_len = A.take<int32_t>(m_cap);
+    smi_scan_result *d_scan = A.take<smi_scan_result>(m_cap);
+    smi_bc_window *d_win = A.take<smi_bc_window>(m_cap);
+    smi_bc_result *d_bc = A.take<smi_bc_result>(m_cap);
+    smi_scan_config sc;
+    SMI_RC(five ? smi_scan_default_config_5p(2, cfg->dont_search_polya, &sc) : smi_scan_default_config(2, &sc));
+    SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_ends, d_len, s, d_pstart));
+    SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
+    SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
+    int32_t *d_rank = nullptr;
+    if (cfg->rank_keys && cfg->n_ranks) {
+        d_rank = A.take<int32_t>(m_cap);
+        uint64_t *d_keys = A.take<uint64_t>(cfg->n_ranks);
+        int32_t *d_vals = A.take<int32_t>(cfg->n_ranks);
+        SMI_HIP(hipMemcpyAsync(d_keys, cfg->rank_keys, cfg->n_ranks * 8, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(d_vals, cfg->rank_values, cfg->n_ranks * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_rank_lookup, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_bc, m, d_keys, d_vals, cfg->n_ranks, d_rank);
+        SMI_HIP(hipGetLastError());
+    }
+    // decisions down: ~80 bytes per record
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_SCAN, m * sizeof(smi_scan_result)));
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_BC, m * sizeof(smi_bc_result)));
+    SMI_HIP(hipMemcpyAsync(ctx->host_buf[smi_ctx::HB_SCAN], d_scan, m * sizeof(smi_scan_result), hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipMemcpyAsync(ctx->host_buf[smi_ctx::HB_BC], d_bc, m * sizeof(smi_bc_result), hipMemcpyDeviceToHost, s));
+    if (d_rank) {
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_RANK, m * 4));
+        SMI_HIP(hipMemcpyAsync(ctx->host_buf[smi_ctx::HB_RANK], d_rank, m * 4, hipMemcpyDeviceToHost, s));
+        out->rank = static_cast<const int32_t *>(ctx->host_buf[smi_ctx::HB_RANK]);
+    }
+    if (split) {
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_FOFFS, (m + 1) * 8));
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_FSRC, m * 4));
+        SMI_HIP(hipMemcpyAsync(ctx->host_buf[smi_ctx::HB_FOFFS], d_foffs, (m + 1) * 8, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipMemcpyAsync(ctx->host_buf[smi_ctx::HB_FSRC], d_fsrc, m * 4, hipMemcpyDeviceToHost, s));
+        out->frag_offsets = static_cast<const uint64_t *>(ctx->host_buf[smi_ctx::HB_FOFFS]);
+        out->frag_src = static_cast<const uint32_t *>(ctx->host_buf[smi_ctx::HB_FSRC]);
+    } else
+        out->frag_offsets = offsets;  // the caller's array: output records = input records
+    SMI_HIP(hipStreamSynchronize(s));
+    out->scan = static_cast<const smi_scan_result *>(ctx->host_buf[smi_ctx::HB_SCAN]);
+    out->bc = static_cast<const smi_bc_result *>(ctx->host_buf[smi_ctx::HB_BC]);
+    return SMI_OK;
+}
+}  // namespace
+
+namespace {
+// host index + planes of a chunk (one pass over the text, smi_fastq_index_pack_host) into the context's page-locked buffers
+int index_and_pack(smi_ctx *ctx, const char *who, const uint8_t *text, size_t n_bytes, int n_threads, size_t *n_out, uint32_t *fq_err,
+                   smi_packed_reads *pk, double *ms) {
+    const auto t0 = std::chrono::steady_clock::now();
+    // a record has at least four line ends + '@' + '+' = 6 bytes (an empty read); the buffers are first sized for records of 64 bytes
+    // or more and only a chunk of tinier ones pays for the worst case
+    const size_t cap_worst = n_bytes / 6 + 2;
+    size_t cap_try = std::min(cap_worst, n_bytes / 64 + 1024);
+    size_t planes_words = smi_packed_planes_words(n_bytes, n_threads);
+    for (;;) {
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_RECS, cap_try * sizeof(smi_fastq_record)));
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_OFFS, (cap_try + 1) * 8));
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_PSTART, cap_try * 4));
+        SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_PLANES, planes_words * 4));
+        const int rc = smi_fastq_index_pack_host(text, n_bytes, static_cast<smi_fastq_record *>(ctx->host_buf[smi_ctx::HB_RECS]),
+                                                 static_cast<uint64_t *>(ctx->host_buf[smi_ctx::HB_OFFS]),
+                                                 static_cast<uint32_t *>(ctx->host_buf[smi_ctx::HB_PSTART]), cap_try,
+                                                 static_cast<uint32_t *>(ctx->host_buf[smi_ctx::HB_PLANES]), planes_words, pk, n_out, fq_err, n_threads);
+        if (rc == SMI_OK) break;
+        if (cap_try >= cap_worst) return rc;
+        cap_try = cap_worst;  // tiny records: once more with the worst-case capacities
+        planes_words = std::max(planes_words, 4 * read_planes_stride(n_bytes / 2, cap_worst));
+    }
+    if (*fq_err) {
+        set_error(std::string(who) + ": malformed FASTQ (see fastq_errors, SMI_FQ_*): htsjdk's FastqReader throws here");
+        return SMI_ERR_INVALID;
+    }
+    *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SMI_OK;
+}
+}  // namespace
+
+extern "C" int smi_scanfastq_pass2_chunk_packed(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, const smi_pass2_config *cfg, int n_threads,
+                                                smi_pass2_output *out) {
+    if (!ctx || !cfg || !out || (!text && n_bytes)) {
+        set_error("smi_scanfastq_pass2_chunk_packed: null argument");
+        return SMI_ERR_INVALID;
+    }
+    std::memset(out, 0, sizeof *out);
+    if (n_bytes == 0) return SMI_OK;
+    const bool timing = std::getenv("SMI_PK_TIMING") != nullptr;  // the stages of this call on stderr
+    double ms_index = 0;
+    size_t n = 0;
+    uint32_t fq_err = 0;
+    smi_packed_reads pk;
+    const int rc_ix = index_and_pack(ctx, "smi_scanfastq_pass2_chunk_packed", text, n_bytes, n_threads, &n, &fq_err, &pk, &ms_index);
+    out->n_records_in = n;
+    out->fastq_errors = fq_err;
+    if (rc_ix != SMI_OK) return rc_ix;
+    if (n == 0) return SMI_OK;
+    const smi_fastq_record *recs = static_cast<const smi_fastq_record *>(ctx->host_buf[smi_ctx::HB_RECS]);
+    const uint64_t *offs = static_cast<const uint64_t *>(ctx->host_buf[smi_ctx::HB_OFFS]);
+    const auto t0 = std::chrono::steady_clock::now();
+    smi_pass2_decisions dec;
+    SMI_RC(pass2_packed_core(ctx, &pk, offs, n, cfg, &dec));
+    const auto t1 = std::chrono::steady_clock::now();
+    out->n_records_out = dec.n_records_out;
+    // the records: never longer than the text they are cut from + a name suffix each
+    // (bases and qualities once; the name token and the '+' line once per fragment, at most three fragments per record)
+    const size_t out_cap = n_bytes + 320 * dec.n_records_out + (dec.frag_src ? 2 * (n_bytes - std::min<size_t>(n_bytes, 2 * (size_t)offs[n])) : 0) + 64;
+    for (int k = 0; k < 2; k++)
+        if (ctx->host_out_bytes[k] < out_cap) {
+            if (ctx->host_out[k]) SMI_HIP(hipHostFree(ctx->host_out[k]));
+            ctx->host_out[k] = nullptr;
+            ctx->host_out_bytes[k] = 0;
+            const size_t want = out_cap + out_cap / 4 + 4096;
+            SMI_HIP(hipHostMalloc((void **)&ctx->host_out[k], want, hipHostMallocDefault));
+            ctx->host_out_bytes[k] = want;
+        }
+    smi_write_config wc{cfg->five_prime, cfg->trim_fastq};
+    uint64_t totals[3] = {0, 0, 0};
+    uint32_t werr = 0;
+    const int rc_w = smi_fastq_write_host(text, recs, offs, &dec, cfg->first_read_id, &wc, ctx->host_out[0], ctx->host_out_bytes[0], ctx->host_out[1],
+                                          ctx->host_out_bytes[1], totals, &werr, n_threads);
+    if (rc_w != SMI_OK) {
+        if (werr & SMI_WR_QUAL_NEWLINE) {  // a line end inside a quality line that the one-pass index stepped over: what the exact index reports
+            out->fastq_errors = SMI_FQ_LENGTH_MISMATCH;
+            set_error("smi_scanfastq_pass2_chunk_packed: malformed FASTQ (a line end inside a quality string): htsjdk's FastqReader throws here");
+        }
+        return rc_w;
+    }
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "smi_scanfastq_pass2_chunk_packed: %zu reads  index+pack %.2f (%d segments)  device %.2f  write %.2f ms (%d threads)\n", n, ms_index,
+                pk.n_seg, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count(), n_threads);
+    }
+    if (cfg->want_results) {
+        ctx->host_scan.assign(dec.scan, dec.scan + dec.n_records_out);
+        ctx->host_bc.assign(dec.bc, dec.bc + dec.n_records_out);
+        out->scan = ctx->host_scan.data();
+        out->bc = ctx->host_bc.data();
+    }
+    out->passed = ctx->host_out[0];
+    out->failed = ctx->host_out[1];
+    out->passed_bytes = totals[0];
+    out->failed_bytes = totals[1];
+    out->n_passed = totals[2];
+    return SMI_OK;
+}
+
+extern "C" int smi_scanfastq_pass1_chunk_packed(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
+                                                uint32_t *d_hist, int n_threads, size_t *n_records, uint32_t *fastq_errors) {
+    if (!ctx || !d_hist || !n_records || (!text && n_bytes)) {
+        set_error("smi_scanfastq_pass1_chunk_packed: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *n_records = 0;
+    if (fastq_errors) *fastq_errors = 0;
+    if (n_bytes == 0) return SMI_OK;
+    size_t n = 0;
+    uint32_t fq_err = 0;
+    double ms_index = 0;
+    smi_packed_reads pk;
+    const int rc_ix = index_and_pack(ctx, "smi_scanfastq_pass1_chunk_packed", text, n_bytes, n_threads, &n, &fq_err, &pk, &ms_index);
+    *n_records = n;
+    if (fastq_errors) *fastq_errors = fq_err;
+    if (rc_ix != SMI_OK) return rc_ix;
+    if (n == 0) return SMI_OK;
+    const smi_fastq_record *recs = static_cast<const smi_fastq_record *>(ctx->host_buf[smi_ctx::HB_RECS]);
+    const uint64_t *offs = static_cast<const uint64_t *>(ctx->host_buf[smi_ctx::HB_OFFS]);
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_QTAIL, n * (size_t)SMI_END_BASES));
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_QSUM, n * 4));
+    uint8_t *h_qtail = static_cast<uint8_t *>(ctx->host_buf[smi_ctx::HB_QTAIL]);
+    uint32_t *h_qsum = static_cast<uint32_t *>(ctx->host_buf[smi_ctx::HB_QSUM]);
+    if (int rc = smi_pack_quals_host(text, recs, n, five_prime, h_qtail, h_qsum, n_threads)) {
+        if (fastq_errors && std::strstr(smi_last_error(), "line end inside")) *fastq_errors = SMI_FQ_LENGTH_MISMATCH;
+        return rc;
+    }
+    SMI_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t pstride = pk.total_words, planes_words = 4 * pstride;
+    const size_t need = pad(planes_words * 4) + pad(n * 4) + pad((n + 1) * 8) + pad((size_t)SMI_ENDS_ROWS * 2 * n * 4) + 2 * pad(n * 4) + pad(n * (size_t)SMI_END_BASES) +
+                        pad(n * sizeof(smi_scan_result)) + pad(n * sizeof(smi_bc_window)) + 4096;
+    SMI_RC(ensure_arena(ctx, need));
+    Arena A(ctx);
+    uint32_t *d_planes = A.take<uint32_t>(planes_words);
+    uint32_t *d_pstart = A.take<uint32_t>(n);
+    uint64_t *d_offs = A.take<uint64_t>(n + 1);
+    uint32_t *d_ends = A.take<uint32_t>((size_t)SMI_ENDS_ROWS * 2 * n);
+    int32_t *d_len = A.take<int32_t>(n);
+    uint32_t *d_qsum = A.take<uint32_t>(n);
+    uint8_t *d_qtail = A.take<uint8_t>(n * (size_t)SMI_END_BASES);
+    smi_scan_result *d_scan = A.take<smi_scan_result>(n);
+    smi_bc_window *d_win = A.take<smi_bc_window>(n);
+    SMI_RC(upload_planes(ctx, &pk, n, d_planes, d_pstart, s));
+    if (!pk.pstart) d_pstart = nullptr;
+    SMI_HIP(hipMemcpyAsync(d_offs, offs, (n + 1) * 8, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_qtail, h_qtail, n * (size_t)SMI_END_BASES, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_qsum, h_qsum, n * 4, hipMemcpyHostToDevice, s));
+    smi_scan_config sc;
+    SMI_RC(five_prime ? smi_scan_default_config_5p(1, dont_search_polya, &sc) : smi_scan_default_config(1, &sc));
+    SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_offs, nullptr, n, d_ends, d_len, s, d_pstart));
+    SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, n, &sc, d_scan, d_win, s));
+    SMI_RC(smi_hist_windows_device(ctx, d_win, d_scan, n, d_hist, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    return SMI_OK;
+}
+
 // Page-locked host memory for the text a caller hands to the chunk workers (a JNI shim reads the file straight into it, e.g.
 // through a direct ByteBuffer): the upload then runs at link speed instead of through the runtime's pageable staging.
 extern "C" int smi_host_alloc(size_t bytes, void **out) {

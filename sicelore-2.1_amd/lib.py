@@ -55,6 +55,9 @@ EXPORTS = [
     "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_hist_allreduce_after", "smi_hist_allreduce_release", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
     "smi_genes_load_refflat", "smi_genes_free", "smi_genes_count", "smi_gene_tag_chunk", "smi_gene_tag_bam",
     "smi_pack_reads_text_device", "smi_pack_ends_text_device", "smi_frag_text_starts_device", "smi_fastq_write_text_device",
+    "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
+    "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
+    "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg",
 ]
 
 
@@ -128,6 +131,19 @@ def load_library():
     lib.smi_pack_ends_text_device.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     lib.smi_frag_text_starts_device.argtypes = [vp, vp, vp, vp, vp, vp, sz, vp, vp, vp]
     lib.smi_chimera_default_config_5p.argtypes = [vp]
+    lib.smi_fastq_index_host.argtypes = [vp, sz, vp, vp, sz, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
+    lib.smi_pack_reads_host.argtypes = [vp, vp, vp, sz, vp, ci]
+    lib.smi_pack_quals_host.argtypes = [vp, vp, sz, ci, vp, vp, ci]
+    lib.smi_scanfastq_pass2_packed.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.smi_fastq_write_host.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp, vp, sz, vp, sz, ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_uint32), ci]
+    lib.smi_scanfastq_pass2_chunk_packed.argtypes = [vp, vp, sz, vp, ci, vp]
+    lib.smi_scanfastq_pass1_chunk_packed.argtypes = [vp, vp, sz, ci, ci, vp, ci, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32)]
+    lib.smi_ends_from_planes_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp, sz, vp, vp, vp]
+    lib.smi_packed_planes_words.argtypes = [sz, ci]
+    lib.smi_packed_planes_words.restype = sz
+    lib.smi_fastq_index_pack_host.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
+    lib.smi_scanfastq_pass2_packed_seg.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
     lib.smi_pack_reads_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp]
@@ -152,7 +168,7 @@ def load_library():
     lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
-    explicit = {"smi_last_error", "smi_version", "smi_read_planes_words"}  # restype set above (char*, size_t)
+    explicit = {"smi_last_error", "smi_version", "smi_read_planes_words", "smi_packed_planes_words"}  # restype set above (char*, size_t)
     for name in EXPORTS:
         if name not in explicit:
             getattr(lib, name).restype = ci
@@ -386,6 +402,132 @@ class PinnedBuffer:
         if self._p:
             load_library().smi_host_free(self._p)
             self._p, self.array = ctypes.c_void_p(0), None
+
+
+FASTQ_RECORD_DTYPE = np.dtype([("name_start", "<u8"), ("seq_start", "<u8"), ("plus_start", "<u8"), ("qual_start", "<u8"),
+                               ("name_len", "<u4"), ("seq_len", "<u4"), ("plus_len", "<u4"), ("reserved", "<u4")])
+assert FASTQ_RECORD_DTYPE.itemsize == 48
+
+
+class Pass2Decisions(ctypes.Structure):
+    """smi_pass2_decisions"""
+    _fields_ = [("n_records_in", ctypes.c_size_t), ("n_records_out", ctypes.c_size_t), ("chim", ctypes.c_void_p),
+                ("frag_offsets", ctypes.c_void_p), ("frag_src", ctypes.c_void_p), ("scan", ctypes.c_void_p), ("bc", ctypes.c_void_p),
+                ("rank", ctypes.c_void_p)]
+
+
+class PackedReads(ctypes.Structure):
+    """smi_packed_reads"""
+    _fields_ = [("planes", ctypes.c_void_p), ("stride", ctypes.c_size_t), ("pstart", ctypes.c_void_p), ("n_seg", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("total_words", ctypes.c_size_t), ("seg_host_word", ctypes.c_uint64 * 256),
+                ("seg_dev_word", ctypes.c_uint64 * 256), ("seg_words", ctypes.c_uint64 * 256)]
+
+
+def fastq_index_pack_host(text, n_threads=1, cap_records=None):
+    """smi_fastq_index_pack_host -> (recs, offsets, error bits, pstart or None, planes uint32 (host layout), PackedReads)"""
+    lib = load_library()
+    buf = _as_u8(text)
+    cap = int(cap_records) if cap_records is not None else buf.size // 6 + 2
+    recs = np.zeros(cap + 1, dtype=FASTQ_RECORD_DTYPE)
+    offs = np.zeros(cap + 2, dtype=np.uint64)
+    pstart = np.zeros(cap + 1, dtype=np.uint32)
+    words = max(int(lib.smi_packed_planes_words(buf.size, int(n_threads))), read_planes_words(buf.size // 2, cap))
+    planes = np.full(words, 0xDEADBEEF, dtype=np.uint32)
+    pk = PackedReads()
+    n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
+    rc = lib.smi_fastq_index_pack_host(buf.ctypes.data if buf.size else None, buf.size, recs.ctypes.data, offs.ctypes.data, pstart.ctypes.data, cap,
+                                       planes.ctypes.data, planes.size, ctypes.byref(pk), ctypes.byref(n), ctypes.byref(err), int(n_threads))
+    if rc != 0:
+        raise SmiError(f"smi_fastq_index_pack_host error {rc}: {lib.smi_last_error().decode()}")
+    return recs[:n.value], offs[:n.value + 1], err.value, (pstart[:n.value] if pk.pstart else None), planes, pk
+
+
+def _as_u8(text):
+    return text if isinstance(text, np.ndarray) else np.frombuffer(text, dtype=np.uint8)
+
+
+def fastq_index_host(text, n_threads=1, cap_records=None):
+    """smi_fastq_index_host -> (FASTQ_RECORD_DTYPE [n], offsets uint64 [n + 1], error bits)"""
+    lib = load_library()
+    buf = _as_u8(text)
+    cap = int(cap_records) if cap_records is not None else buf.size // 6 + 2
+    recs = np.zeros(cap + 1, dtype=FASTQ_RECORD_DTYPE)
+    offs = np.zeros(cap + 2, dtype=np.uint64)
+    n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
+    rc = lib.smi_fastq_index_host(buf.ctypes.data if buf.size else None, buf.size, recs.ctypes.data, offs.ctypes.data, cap, ctypes.byref(n),
+                                  ctypes.byref(err), int(n_threads))
+    if rc != 0:
+        raise SmiError(f"smi_fastq_index_host error {rc}: {lib.smi_last_error().decode()}")
+    return recs[:n.value], offs[:n.value + 1], err.value
+
+
+def read_planes_words(total_bases, n):
+    return int(load_library().smi_read_planes_words(int(total_bases), int(n)))
+
+
+def pack_reads_host(text, recs, offsets, n_threads=1):
+    """smi_pack_reads_host -> planes, uint32 [smi_read_planes_words(offsets[-1], n)]"""
+    lib = load_library()
+    buf = _as_u8(text)
+    n = int(recs.size)
+    recs = np.ascontiguousarray(recs, dtype=FASTQ_RECORD_DTYPE)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    planes = np.full(read_planes_words(int(offsets[n]) if n else 0, n), 0xDEADBEEF, dtype=np.uint32)  # every word must be overwritten
+    if lib.smi_pack_reads_host(buf.ctypes.data, recs.ctypes.data, offsets.ctypes.data, n, planes.ctypes.data, int(n_threads)):
+        raise SmiError(lib.smi_last_error().decode())
+    return planes
+
+
+def pack_quals_host(text, recs, five_prime=False, n_threads=1):
+    """smi_pack_quals_host -> (qtail uint8 [n, 224], qsum uint32 [n])"""
+    lib = load_library()
+    buf = _as_u8(text)
+    n = int(recs.size)
+    recs = np.ascontiguousarray(recs, dtype=FASTQ_RECORD_DTYPE)
+    qtail = np.zeros((max(n, 1), END_BASES), dtype=np.uint8)
+    qsum = np.zeros(max(n, 1), dtype=np.uint32)
+    if lib.smi_pack_quals_host(buf.ctypes.data, recs.ctypes.data, n, int(bool(five_prime)), qtail.ctypes.data, qsum.ctypes.data, int(n_threads)):
+        raise SmiError(lib.smi_last_error().decode())
+    return qtail[:n], qsum[:n]
+
+
+def fastq_write_host(text, recs, offsets, scan, bc, frag_offsets=None, frag_src=None, chim=None, rank=None, first_read_id=1,
+                     five_prime=False, trim_fastq=False, n_threads=1, cap=None):
+    """smi_fastq_write_host on numpy decisions (SCAN_RESULT_DTYPE / BC_RESULT_DTYPE per output record; frag_offsets / frag_src / chim as
+    smi_split_offsets_device gives them, or all None when the splitter did not run) -> (passed bytes, failed bytes, records passed)"""
+    lib = load_library()
+    buf = _as_u8(text)
+    recs = np.ascontiguousarray(recs, dtype=FASTQ_RECORD_DTYPE)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    scan = np.ascontiguousarray(scan, dtype=SCAN_RESULT_DTYPE)
+    bc = np.ascontiguousarray(bc, dtype=BC_RESULT_DTYPE)
+    m = int(scan.size)
+    keep = [buf, recs, offsets, scan, bc]
+    d = Pass2Decisions()
+    d.n_records_in, d.n_records_out = int(recs.size), m
+    d.scan, d.bc = scan.ctypes.data, bc.ctypes.data
+    if frag_src is not None:
+        fo = np.ascontiguousarray(frag_offsets, dtype=np.uint64)
+        fs = np.ascontiguousarray(frag_src, dtype=np.uint32)
+        ch = np.ascontiguousarray(chim, dtype=CHIMERA_RESULT_DTYPE)
+        keep += [fo, fs, ch]
+        d.frag_offsets, d.frag_src, d.chim = fo.ctypes.data, fs.ctypes.data, ch.ctypes.data
+    else:
+        d.frag_offsets = offsets.ctypes.data
+    if rank is not None:
+        rk = np.ascontiguousarray(rank, dtype=np.int32)
+        keep.append(rk)
+        d.rank = rk.ctypes.data
+    cap = int(cap) if cap is not None else 3 * buf.size + 400 * m + 64
+    out_p, out_f = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)
+    cfg = (ctypes.c_int32 * 2)(int(bool(five_prime)), int(bool(trim_fastq)))
+    totals = (ctypes.c_uint64 * 3)()
+    err = ctypes.c_uint32(0)
+    rc = lib.smi_fastq_write_host(buf.ctypes.data, recs.ctypes.data, offsets.ctypes.data, ctypes.byref(d), int(first_read_id), ctypes.byref(cfg),
+                                  out_p.ctypes.data, cap, out_f.ctypes.data, cap, totals, ctypes.byref(err), int(n_threads))
+    if rc != 0:
+        raise SmiError(f"smi_fastq_write_host: {lib.smi_last_error().decode()} (error bits {err.value})")
+    return out_p[:totals[0]].tobytes(), out_f[:totals[1]].tobytes(), int(totals[2])
 
 
 class Pass2Config(ctypes.Structure):
@@ -667,9 +809,11 @@ class Context:
 
     # ---- one native call per chunk (smi_worker.hip) ---------------------------------------------------------
     def scanfastq_pass2_chunk(self, text, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True, trim_fastq=False,
-                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True):
+                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True, packed=False, n_threads=4):
         """host FASTQ bytes (or a numpy uint8 array, e.g. PinnedBuffer.array) -> (passed, failed, info dict); everything in
-        between on the device.  copy=False returns numpy views of the context's pinned output buffers (valid until its next call)"""
+        between on the device.  copy=False returns numpy views of the context's pinned output buffers (valid until its next call).
+        packed=True: smi_scanfastq_pass2_chunk_packed -- the host indexes / packs / writes on n_threads threads, the link carries
+        bit-planes up and decisions down; same bytes out"""
         cfg = Pass2Config()
         self._check(self._lib.smi_pass2_default_config(ctypes.byref(cfg)))
         cfg.max_ed, cfg.five_prime, cfg.dont_search_polya = int(max_ed), int(five_prime), int(dont_search_polya)
@@ -682,7 +826,11 @@ class Context:
             cfg.rank_keys, cfg.rank_values, cfg.n_ranks = k.ctypes.data, v.ctypes.data, k.size
         buf = text if isinstance(text, np.ndarray) else np.frombuffer(text, dtype=np.uint8)
         out = Pass2Output()
-        self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), ctypes.byref(out)))
+        if packed:
+            self._check(self._lib.smi_scanfastq_pass2_chunk_packed(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), int(n_threads),
+                                                                   ctypes.byref(out)))
+        else:
+            self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), ctypes.byref(out)))
         if copy:
             passed = ctypes.string_at(out.passed, out.passed_bytes) if out.passed_bytes else b""
             failed = ctypes.string_at(out.failed, out.failed_bytes) if out.failed_bytes else b""
@@ -695,17 +843,28 @@ class Context:
             info["bc"] = np.frombuffer(ctypes.string_at(out.bc, out.n_records_out * BC_RESULT_DTYPE.itemsize), dtype=BC_RESULT_DTYPE)
         return passed, failed, info
 
-    def scanfastq_pass1_chunk(self, text, d_hist, five_prime=False, dont_search_polya=False):
+    def scanfastq_pass1_chunk(self, text, d_hist, five_prime=False, dont_search_polya=False, packed=False, n_threads=4):
         """adds the chunk's whitelist hits to d_hist (int32 device tensor, one counter per loaded key) -> n records"""
-        buf = np.frombuffer(text, dtype=np.uint8)
+        buf = _as_u8(text)
         n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
         if hasattr(d_hist, "is_cuda") and d_hist.is_cuda:  # the zero-fill of d_hist ran on torch's stream (sicelore_mi.h)
             import torch
 
             torch.cuda.current_stream(d_hist.device).synchronize()
-        self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
-                                                        _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
+        if packed:
+            self._check(self._lib.smi_scanfastq_pass1_chunk_packed(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
+                                                                   _ptr(d_hist), int(n_threads), ctypes.byref(n), ctypes.byref(err)))
+        else:
+            self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
+                                                            _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
         return n.value
+
+    def ends_from_planes_device(self, d_planes, d_read_offsets, n_reads, total_bases, d_rec_offsets, d_frag_src, n_records, d_ends, d_len,
+                                stream=None):
+        """K-PACK from read planes (smi_ends_from_planes_device)"""
+        self._check(self._lib.smi_ends_from_planes_device(self._h, _ptr(d_planes), _ptr(d_read_offsets), int(n_reads), int(total_bases),
+                                                          _ptr(d_rec_offsets), _ptr(d_frag_src), int(n_records), _ptr(d_ends), _ptr(d_len),
+                                                          _stream_ptr(stream)))
 
     def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
                          five_prime=False):

@@ -23,8 +23,10 @@ def _key(bc):
     return v
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["text", "packed"])
 @pytest.mark.parametrize("name", ["pass2_3p", "pass2_5p", "pass2_5p_polya", "pass2_3p_ed2"])
-def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name):
+def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name, packed):
+    """packed: smi_scanfastq_pass2_chunk_packed (bit-planes up, decisions down, records written on the host) instead of the text worker"""
     with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
         sec = json.load(f)["sections"][0]
     keys = np.array([_key(b) for b in sec["barcodes"]], dtype=np.uint64)
@@ -39,7 +41,8 @@ def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name):
         text = f"@{c['name']}\n{c['seq']}\n+\n{c['qual']}\n".encode()
         passed, failed, info = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=sec["ed"], five_prime=sec["five_prime"],
                                                              dont_search_polya=sec["dont_search_polya"], split_chimeras=False,
-                                                             first_read_id=idx + 1, rank_keys=keys[order], rank_values=ranks[order])
+                                                             first_read_id=idx + 1, rank_keys=keys[order], rank_values=ranks[order],
+                                                             packed=packed, n_threads=2)
         w = want["written"]
         exp = f"@{w['name']}\n{w['bases']}\n+{w['quality_header'] or ''}\n{w['qualities']}\n".encode()
         got = passed if want["passed"] else failed
@@ -140,6 +143,9 @@ def test_pass1_chunk_worker_equals_reference_bytecode(pkg, gpu_ctx):
     h = hist.cpu().numpy()
     got = sorted([int(keys[i]), int(h[i])] for i in np.nonzero(h)[0])
     assert got == sec["histogram"] and len(got) >= 5
+    hist2 = torch.zeros(keys.size, dtype=torch.int32, device="cuda")    # the packed worker: planes, quality tails and sums from the host
+    assert gpu_ctx.scanfastq_pass1_chunk(text, hist2, packed=True, n_threads=2) == len(sec["cases"])
+    assert (hist2.cpu().numpy() == h).all()
     # the filter per record: pack with qualities -> K-SCAN pass 1 -> pass1_ok
     seqs, quals = [c["seq"] for c in sec["cases"]], [c["qual"] for c in sec["cases"]]
     n = len(seqs)

@@ -34,7 +34,8 @@ def main():
     res = {}
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
-    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis}
+    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis,
+            "packed": leg_packed}
     for name, fn in legs.items():
         if only in (None, name):
             fn(pkg, synth, ctx, dev, wl, used, res)
@@ -290,6 +291,66 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
                                                "every kernel incl. the chimera splitter, D2H of both streams into the context's pinned buffers"}
     res["fastq_write"] = {"reads": n, "passed": state["tot"][2], "out_bytes": wb, "ms": dtw * 1e3, "out_GBps": wb / dtw / 1e9,
                           "reads_per_s": n / dtw}
+
+
+def leg_packed(pkg, synth, ctx, dev, wl, used, res):
+    """host text -> host text through the PACKED boundary (smi_scanfastq_pass2_chunk_packed: index / bit-planes / records on host threads,
+    0.7 KB per read over the link instead of 5 KB), one lane with T threads and several lanes sharing the box's host cores"""
+    import threading
+
+    from sicelore_amd import lib as libmod
+
+    n = int(os.environ.get("SMI_MB_READS", "500000"))
+    rd = synth.gen_reads(n, used, seed=9, device=dev)
+    text, buf, offs = synth.fastq_text_device(rd)
+    total = int(text.numel())
+    del rd, buf
+    ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
+    pin = libmod.PinnedBuffer(total)
+    pin.array[:] = text.cpu().numpy()
+    del text
+    cores = len(os.sched_getaffinity(0))
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        quota = None
+    out = {"reads_per_chunk": n, "text_bytes": total, "host_cpus_visible": cores, "host_cpu_quota": quota, "runs": []}
+    pt, ft, _ = ctx.scanfastq_pass2_chunk(pin.array, copy=True)                       # the text worker: the bytes to match
+    pp, fp, info = ctx.scanfastq_pass2_chunk(pin.array, copy=True, packed=True, n_threads=16)
+    out["equals_text_worker"] = bool(pt == pp and ft == fp)
+    out["text_out_bytes"] = len(pp) + len(fp)
+    os.environ["SMI_PK_TIMING"] = "1"
+    ctx.scanfastq_pass2_chunk(pin.array, copy=False, packed=True, n_threads=16)      # stages of one call on stderr
+    del os.environ["SMI_PK_TIMING"]
+    for lanes, threads in ((1, 16), (1, 32), (2, 8), (2, 16), (4, 4), (4, 8), (8, 2), (8, 4), (16, 1), (16, 2)):
+        ctxs = [ctx] + [ctx.lane() for _ in range(lanes - 1)]
+        pins = [pin] + [libmod.PinnedBuffer(total) for _ in range(lanes - 1)]
+        for pb in pins[1:]:
+            pb.array[:] = pin.array
+        for c, pb in zip(ctxs, pins):
+            c.scanfastq_pass2_chunk(pb.array, copy=False, packed=True, n_threads=threads)   # warm-up: arena, pinned buffers
+        per = 3
+
+        def worker(c, pb):
+            for _ in range(per):
+                c.scanfastq_pass2_chunk(pb.array, copy=False, packed=True, n_threads=threads)
+
+        th = [threading.Thread(target=worker, args=(c, pb)) for c, pb in zip(ctxs, pins)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        out["runs"].append({"lanes": lanes, "threads_per_lane": threads, "reads_per_s": n * lanes * per / dt, "ms_per_chunk": dt / per * 1e3})
+        for c in ctxs[1:]:
+            c.close()
+        for pb in pins[1:]:
+            pb.close()
+    pin.close()
+    out["best"] = max(out["runs"], key=lambda r: r["reads_per_s"])
+    res["pass2_chunk_packed_host_to_host"] = out
 
 
 if __name__ == "__main__":
