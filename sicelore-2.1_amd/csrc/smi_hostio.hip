@@ -17,6 +17,8 @@
 #include <immintrin.h>
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -218,7 +220,9 @@ extern "C" int smi_fastq_index_host(const uint8_t *text, size_t n_bytes, smi_fas
         // speculative split: thread t parses from a guessed record start behind t * n / T up to the next thread's guess, into its own
         // vector; accepted only when every thread arrives exactly at its successor's start
         std::vector<size_t> start((size_t)nt + 1, n_bytes);
-        std::vector<std::vector<smi_fastq_record>> part((size_t)nt);
+        // (one cache line pair per thread: the vector headers are written with every record, neighbours must not share a line)
+        struct alignas(128) Part : std::vector<smi_fastq_record> {};
+        std::vector<Part> part((size_t)nt);
         std::vector<uint32_t> bad((size_t)nt, 0);
         std::vector<size_t> reached((size_t)nt, 0);
         std::vector<uint8_t> truncated((size_t)nt, 0);
@@ -360,7 +364,8 @@ __attribute__((target("avx2"))) inline void planes64_avx2(const uint8_t *p, int 
 
 __attribute__((target("avx512f,avx512bw"))) inline void planes64_avx512(const uint8_t *p, int nb, uint64_t (&pl)[4]) {
     const __mmask64 keep = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
-    const __m512i v = _mm512_and_si512(_mm512_maskz_loadu_epi8(keep, p), _mm512_set1_epi8((char)0xDF));
+    // (a masked byte load costs several times a plain one on Zen 4 / 5: only the last, partial block of a read takes it)
+    const __m512i v = _mm512_and_si512(nb >= 64 ? _mm512_loadu_si512(p) : _mm512_maskz_loadu_epi8(keep, p), _mm512_set1_epi8((char)0xDF));
     const __mmask64 a = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('A'));
     const __mmask64 g = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('G'));
     const __mmask64 c = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('C'));
@@ -444,7 +449,7 @@ extern "C" int smi_pack_reads_host(const uint8_t *text, const smi_fastq_record *
 // ---------------------------------------------------------------------------------------------------------------------------
 namespace {
 
-struct FusedThread {
+struct alignas(128) FusedThread {  // written with every record: no two threads' state in one cache line
     std::vector<smi_fastq_record> recs;
     std::vector<uint32_t> wstart;  // word offset of the read inside the thread's segment
     size_t words = 0, reached = 0, bases = 0;
@@ -476,7 +481,7 @@ __attribute__((target("avx2"))) inline void block64_avx2(const uint8_t *p, size_
 }
 __attribute__((target("avx512f,avx512bw"))) inline void block64_avx512(const uint8_t *p, size_t avail, uint64_t (&pl)[4], uint64_t *nl) {
     const __mmask64 keep = avail >= 64 ? ~0ull : ((1ull << avail) - 1ull);
-    const __m512i raw = _mm512_maskz_loadu_epi8(keep, p);
+    const __m512i raw = avail >= 64 ? _mm512_loadu_si512(p) : _mm512_maskz_loadu_epi8(keep, p);  // masked byte loads are slow on Zen 4 / 5
     *nl = _mm512_cmpeq_epi8_mask(raw, _mm512_set1_epi8('\n'));
     const __m512i v = _mm512_and_si512(raw, _mm512_set1_epi8((char)0xDF));
     const __mmask64 a = _mm512_cmpeq_epi8_mask(v, _mm512_set1_epi8('A'));
@@ -515,6 +520,13 @@ __attribute__((target("avx512f,avx512bw"))) inline void block64_avx512(const uin
                 if (lw + (b >> 5) + 2 + kReadPadWords > seg_cap) { T.ok = false; break; }                                                 \
                 uint64_t pl[4], nlm;                                                                                                      \
                 BLOCK64(text + at, n - at, pl, &nlm);                                                                                     \
+                if (__builtin_expect(nlm == 0 && n - at >= 64, 1)) {                                                                      \
+                    /* the usual block: 64 bases, no line end.  A BRANCH, not arithmetic on the mask: the address of the next block must  \
+                       not wait for this block's compare, or every cache miss of the line is taken one after the other */                 \
+                    for (int c = 0; c < 4; c++) std::memcpy(seg + (size_t)c * stride + lw + (b >> 5), &pl[c], 8);                         \
+                    b += 64;                                                                                                              \
+                    continue;                                                                                                             \
+                }                                                                                                                         \
                 const size_t avail = n - at < 64 ? n - at : 64;                                                                           \
                 const int nb = nlm ? (int)__builtin_ctzll(nlm) : (int)avail;                                                              \
                 const uint64_t keep = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);                                                           \
@@ -562,6 +574,9 @@ __attribute__((target("avx512f,avx512bw"))) inline void block64_avx512(const uin
                 next = n;                                                                                                                 \
             else { T.ok = false; break; }                                                                                                 \
             if (l3 >= n) { T.ok = false; break; } /* a line that starts at the end of the text does not exist */                          \
+            /* the next record's first lines: its name and the head of its bases (the hardware prefetcher lost the stream at the jump) */  \
+            { const size_t ahead = len + 192 < 4096 ? len + 192 : 4096; /* its bases are about as long as this record's */                \
+              for (size_t o = 0; o < ahead; o += 64) _mm_prefetch(reinterpret_cast<const char *>(text + (next + o < n ? next + o : n - 1)), _MM_HINT_T0); } \
             r.qual_start = l3;                                                                                                            \
             r.reserved = 1; /* the quality line has not been looked at: whoever reads it checks it for line ends */                       \
             T.recs.push_back(r);                                                                                                          \
@@ -1013,7 +1028,7 @@ inline bool copy_run(const uint8_t *src, size_t n, uint8_t *out, int level, bool
     return check && std::memchr(src, '\n', n) != nullptr;
 }
 
-struct ThreadOut {
+struct alignas(128) ThreadOut {  // (aligned: neighbouring threads' state must not share a cache line)
     std::vector<char> sfx;          // suffixes of this thread's records, back to back
     std::vector<uint32_t> sfx_off;  // per record (+1)
     std::vector<uint64_t> bytes;    // record length
@@ -1046,8 +1061,14 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
     std::vector<ThreadOut> TO((size_t)nt);
     std::vector<uint64_t> n_passed((size_t)nt + 1, 0), base_p((size_t)nt + 1, 0), base_f((size_t)nt + 1, 0);
     std::atomic<uint32_t> err{0};
+    const bool timing = std::getenv("SMI_PK_TIMING") != nullptr;
+    double t_phase[4] = {0, 0, 0, 0};
+    auto stamp = [&](int t, int k) {
+        if (timing && t == 0) t_phase[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
     Team::run(nt, [&](int t, Team &team) {
         const size_t lo = m * (size_t)t / (size_t)nt, hi = m * (size_t)(t + 1) / (size_t)nt;
+        stamp(t, 0);
         // 1. passed records of my range -> read ids (GET_NEXT_READID per passed record, in record order)
         uint64_t np = 0;
         for (size_t i = lo; i < hi; i++) np += record_passed(J, i) ? 1 : 0;
@@ -1055,6 +1076,7 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
         team.barrier();
         uint64_t ord = 0;
         for (int u = 1; u <= t; u++) ord += n_passed[u];
+        stamp(t, 1);
         // 2. suffixes and record lengths
         ThreadOut &O = TO[t];
         O.sfx.resize((hi - lo) * 192 + kSuffixCapHost + 64);
@@ -1114,6 +1136,7 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
         base_f[t + 1] = O.tot[1];
         if (O.err) err.fetch_or(O.err);
         team.barrier();
+        stamp(t, 2);
         if (err.load()) return;
         uint64_t off_p = 0, off_f = 0, all_p = 0, all_f = 0;
         for (int u = 1; u <= nt; u++) {
@@ -1185,7 +1208,11 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
         }
         if (qual_nl) err.fetch_or(SMI_WR_QUAL_NEWLINE);
         if (level == 2) _mm_sfence();  // the streamed stores are visible before the team is joined
+        stamp(t, 3);
     });
+    if (timing)
+        fprintf(stderr, "smi_fastq_write_host (thread 0 of %d): passed count %.2f  suffixes %.2f  records %.2f ms\n", nt, t_phase[1] - t_phase[0],
+                t_phase[2] - t_phase[1], t_phase[3] - t_phase[2]);
     uint64_t all_p = 0, all_f = 0, all_n = 0;
     for (int u = 1; u <= nt; u++) {
         all_p += base_p[u];

@@ -44,6 +44,18 @@ struct NameSink {
     }
     // the same digits for a value that fits 32 bits (coordinates, counts): no 64-bit division, which a GPU lane emulates
     SMI_HD void put_u32(uint32_t v) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+        {   // host: as many steps as the number has digits (the constant-divisor form below always takes ten)
+            char t[10];
+            int k = 0;
+            do {
+                t[k++] = (char)('0' + (int)(v % 10u));
+                v /= 10u;
+            } while (v);
+            while (k) put(t[--k]);
+            return;
+        }
+#endif
         // digits from the top by constant divisors: no digit buffer (an indexed local array is scratch memory on the device)
         bool started = false;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -68,7 +80,7 @@ struct NameSink {
 };
 
 // FastqRecordExt.REVERSE_COMPLEMENT (L72-104): a char[254] that is zero except for these letters
-SMI_HD char rc_char(unsigned char c) {
+SMI_HD char rc_char_switch(unsigned char c) {
     switch (c) {
     case 'A': case 'a': return 'T';
     case 'G': case 'g': return 'C';
@@ -87,6 +99,23 @@ SMI_HD char rc_char(unsigned char c) {
     case 'D': case 'd': return 'H';
     default: return 0;
     }
+}
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+struct RcHostTable {  // host: one table look-up per character
+    char t[256];
+    RcHostTable() {
+        for (int i = 0; i < 256; i++) t[i] = rc_char_switch((unsigned char)i);
+    }
+};
+static const RcHostTable g_rc_host_table;
+#endif
+SMI_HD char rc_char(unsigned char c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return rc_char_switch(c);
+#else
+    return g_rc_host_table.t[c];
+#endif
 }
 
 // new DecimalFormat("##.#").format((double) f) (L36, L270): HALF_EVEN on the exact decimal value, at most one fraction
@@ -122,6 +151,19 @@ SMI_HD void put_dec1(Sink &s, float f) {
 
 template <class Sink>
 SMI_HD void put_base36(Sink &s, uint32_t v) {  // FastqRecordExt$NumberToAndFromAscii.convertInt = Integer.toString(id, 36), L524
+#if !defined(__HIP_DEVICE_COMPILE__)
+    {
+        char t[8];
+        int k = 0;
+        do {
+            const uint32_t d = v % 36u;
+            t[k++] = (char)(d < 10 ? '0' + d : 'a' + (d - 10));
+            v /= 36u;
+        } while (v);
+        while (k) s.put(t[--k]);
+        return;
+    }
+#endif
     bool started = false;  // digits from the top, as in put_u32: 36^6 > 2^31, seven digits at most
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
