@@ -867,7 +867,7 @@ class Context:
                                                           _stream_ptr(stream)))
 
     def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
-                         five_prime=False):
+                         five_prime=False, cluster_cfg=None):
         """one BamReader chunk through the native worker -> (UMI_TAG_DTYPE array, n_done); names: list of QNAME strings,
         cigars: list of numpy uint32 arrays (BAM encoding)"""
         n = len(names)
@@ -885,6 +885,9 @@ class Context:
         cfg.max_dist, cfg.keep_data_end, cfg.n_threads = int(max_dist), int(keep_data_end), int(n_threads)
         cfg.five_prime = int(bool(five_prime))
         cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
+        if cluster_cfg is not None:  # umi_cluster_config(...) record: the clusterer's knobs (shipped values otherwise)
+            cluster_cfg = np.ascontiguousarray(cluster_cfg, dtype=UMI_CLUSTER_CONFIG_DTYPE)
+            cfg.cluster = cluster_cfg.ctypes.data
         out = np.zeros(max(n, 1), dtype=UMI_TAG_DTYPE)
         nd = ctypes.c_int32(0)
         self._check(self._lib.smi_assignumis_chunk(self._h, nbuf.ctypes.data, noff.ctypes.data, fl.ctypes.data, p0.ctypes.data,

@@ -208,6 +208,34 @@ def test_ed2_used_list_mode(pkg, synth, sor, gpu_ctx, five_prime):
     assert (exp["ed"][exp["found"] == 1] == 2).sum() > 200
 
 
+@pytest.mark.parametrize("five_prime", [False, True])
+@pytest.mark.parametrize("n_wl", [100_000, 400_000, 3_600_000])
+def test_ed2_long_lists_equal_oracle(pkg, synth, sor, gpu_ctx, n_wl, five_prime):
+    """K-BC2 against the oracle where the search set is the WHOLE list (-g semantics) and longer than 65,536 keys: the path through the
+    neighbourhood table behind P.nb (no item filter, no two-step bitmap), and -- with SMI_BC2_DENSE_ENUM on lists above 300 k keys -- the
+    kernel that enumerates instead; 4,000 reads per case, windows with N bases among them"""
+    import os
+
+    wl = synth.make_whitelist(n_wl, seed=331 + n_wl % 97)
+    used = synth.pick_used(wl, 3000, seed=332)
+    n = 4000
+    reg = synth.gen_bc_region(n, used, seed=333 + five_prime, five_prime=five_prime, n_rate=0.002, err=0.08)
+    win = synth.pack_windows(reg["codes"], reg["ae"], five_prime)
+    gpu_ctx.set_barcode_set(wl.numpy().astype(np.uint64), mode=1)
+    st, exp = sor.assign_batch(sor.BarcodeSet(wl.numpy()), reg["codes"].numpy(), reg["ae"].numpy(), max_ed=2, five_prime=five_prime,
+                               n_threads=16)
+    got = _run_device(pkg, gpu_ctx, win, 2, five_prime)
+    n_found = _compare(pkg, got, st, exp)
+    assert n_found > 0.3 * n and (exp["ed"][exp["found"] == 1] == 2).sum() > 50
+    if n_wl > 300_000:
+        os.environ["SMI_BC2_DENSE_ENUM"] = "1"
+        try:
+            got2 = _run_device(pkg, gpu_ctx, win, 2, five_prime)
+        finally:
+            del os.environ["SMI_BC2_DENSE_ENUM"]
+        assert got2.tobytes() == got.tobytes()
+
+
 def test_ed2_dense_and_degenerate(pkg, synth, sor, gpu_ctx):
     """ed <= 2 where the dedup set decides: dense neighbourhoods (many ed-1/ed-2 barcodes per window), homopolymer
     and low-complexity windows (equal children at different positions), all-T keys (hash sentinel) and N bases"""

@@ -75,3 +75,69 @@ def test_umi_distances_then_clustering_end_to_end(pkg, sor, gpu_ctx):
         assert (got[a:b] == exp.astype(got.dtype)).all() and (got_sk[a:b] == exp_sk).all(), g
         n_clustered += int((exp["center"] >= 0).sum())
     assert n_clustered > 400
+
+
+def _name_with_window(i, w, q, bc="ACGTACGTACGTACGT"):
+    """a pass-2 read name whose UMI window (3': reverse complement of X= from AE + 3 - bcEnd on) is the 14 codes of w"""
+    comp = {1: "T", 2: "C", 4: "G", 8: "A", 15: "N"}     # the letter whose complement has code c
+    x = ["A"] * 43
+    for k in range(14):
+        x[24 - k] = comp[int(w[k])]
+    return f"r{i}_FWD_PS=700_PE=730_AE=743_bc={bc}_ed=0_ed_sec=3_bcStart=742_bcEnd=727_X={''.join(x)}_Q={q}_{i:x} cellBC={bc}"
+
+
+@pytest.mark.parametrize("n,own_above", [(101, 100), (1000, 100), (3300, 4000), (20000, 100)])
+def test_assignumis_chunk_large_groups_equal_oracle(pkg, sor, gpu_ctx, n, own_above):
+    """one (cell, region) group of n reads through smi_assignumis_chunk against the oracle's clusterer on the same matrix: just above the
+    switch to ClusterOne_MyClustering (101), well inside it (1000, 20000: a 400 MB matrix), and -- with the switch moved up -- the
+    hierarchical path with more than 3000 neighbour reads, where the reference changes from complete link to single link"""
+    from sicelore_amd import lib as libmod
+
+    rng = np.random.default_rng(n)
+    n_umi = max(3, n // 12)
+    ws = _make_groups(n, [n])                              # n reads around n // 3 UMIs with up to two edits each
+    if n >= 3000:                                          # fewer, deeper molecules: clusters of very different depth (the fold filter)
+        base = _make_groups(n + 1, [n_umi])
+        pick = np.minimum(rng.zipf(1.4, n) - 1, n_umi - 1)
+        ws = base[pick].copy()
+        noisy = rng.random(n) < 0.3
+        ws[noisy, rng.integers(0, 14, int(noisy.sum()))] = rng.choice([1, 2, 4, 8], int(noisy.sum()))
+    qs = [f"{v:.1f}".rstrip("0").rstrip(".") for v in rng.uniform(8, 25, n)]
+    names = [_name_with_window(i, ws[i], qs[i]) for i in range(n)]
+    flags = np.zeros(n, dtype=np.uint16)
+    pos0 = (100_000 + rng.integers(0, 50, n)).astype(np.int32)
+    order = np.argsort(pos0, kind="stable")               # a coordinate-sorted chunk
+    names, ws, qs, pos0 = [names[i] for i in order], ws[order], [qs[i] for i in order], pos0[order]
+    cigars = [np.array([1000 << 4], dtype=np.uint32)] * n
+    ccfg = libmod.umi_cluster_config(own_clusterer_above=own_above)
+    tags, n_done = gpu_ctx.assignumis_chunk(names, flags, pos0, cigars, n_threads=8, cluster_cfg=ccfg)
+    assert n_done == n and (tags["region"] == tags["region"][0]).all() and tags["region"][0] >= 0
+    # the matrix: the oracle's for the sizes it finishes in seconds, K-UMI's otherwise (checked against the oracle on sampled pairs)
+    if n <= 1000:
+        mat = sor.umi_matrix(ws).reshape(-1)
+    else:
+        mat = gpu_ctx.umi_dist_batch(_pack(ws), np.array([0, n], dtype=np.uint32))
+        for a, b in rng.integers(0, n, (1500, 2)):
+            a, b = int(min(a, b)), int(max(a, b))                                            # ([v][i] holds the transposed copy)
+            assert int(mat[a * n + b]) == int(sor.umi_pair(ws[a], ws[b]))
+    qv = np.array([float(q) for q in qs], dtype=np.float32)
+    exp, exp_sk = sor.umi_cluster_group(mat, n, qv, sor.umi_cluster_params(own_above=own_above))
+    dec = {1: "A", 2: "G", 4: "C", 8: "T", 15: "N"}
+    n_clustered = 0
+    for j in range(n):
+        t = tags[j]
+        if exp["center"][j] < 0:
+            assert not (t["flags"] & libmod.UMI_CLUSTERED), j
+            assert bool(t["flags"] & libmod.UMI_SKIPPED) == bool(exp_sk[j]), j
+            continue
+        n_clustered += 1
+        c = int(exp["center"][j])
+        assert t["flags"] & libmod.UMI_CLUSTERED and t["center"] == c and t["u1"] == exp["ed"][j] and t["u2"] == exp["ed_second"][j], j
+        off = int(exp["offset"][j])
+        assert t["u8"].decode() == "".join(dec[int(ws[c][k + 1 + off])] for k in range(12)), j
+        assert t["u7"].decode() == "".join(dec[int(ws[j][k + 1])] for k in range(12))
+    assert n_clustered > 0.5 * n
+    if n == 3300:   # more than 3000 reads have a neighbour within ed 2: the reference's switch to single-link clustering was taken
+        m2 = (np.asarray(mat).reshape(n, n) & 15) <= 2
+        np.fill_diagonal(m2, False)
+        assert int(m2.any(axis=1).sum()) > 3000
