@@ -326,6 +326,12 @@ int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_off, const u
                            const float *mean_qv, const smi_umi_cluster_config *cfg, smi_umi_assignment *out,
                            uint8_t *skipped, int n_threads);
 
+/* The same on the device for groups of up to 100 reads (K-UCLUST, one wavefront per group: ClusterOneHierarchical over LingPipe's
+ * complete-link queue order); groups of more than min(own_clusterer_above, 100) reads are left "not clustered" for the caller to hand to
+ * smi_umi_cluster_groups.  Buffers as smi_umi_dist_device leaves them; d_out / d_skipped per read in group order. */
+int smi_umi_cluster_groups_device(smi_ctx *ctx, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups,
+                                  const float *d_mean_qv, const smi_umi_cluster_config *cfg, smi_umi_assignment *d_out, uint8_t *d_skipped, void *stream);
+
 /* ================================================================================================================
  * Genomic-region grouping of `assignumis` (host): which reads of a chunk may share a UMI group.  Replaces
  * ReadGrouper.groupSams / doClusteringOneStrand / ClusterList.refineClusters

@@ -225,6 +225,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->stage_in);
     (void)hipFree(ctx->scan_tmp);
     (void)hipFree(ctx->arena);
+    (void)hipFree(ctx->umi_dist);
     (void)hipFree(ctx->chim_list);
     (void)hipFree(ctx->chim_slots);
     (void)hipHostFree(ctx->host_out[0]);

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "smi_internal.h"
+#include "smi_umi_stage.h"
 
 using namespace smi;
 
@@ -749,13 +750,13 @@ bool umi_window(const NameData &d, bool five_prime, uint64_t *packed) {
 
 }  // namespace
 
-extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint32_t *name_off, const uint16_t *flags,
-                                    const int32_t *pos0, const uint32_t *cigars, const uint32_t *cigar_off, int32_t n,
-                                    const smi_assignumis_config *cfg, smi_umi_tag *out, int32_t *n_done) {
-    if (!ctx || !names || !name_off || !flags || !pos0 || !cigar_off || !cfg || !out || !n_done || n < 0) {
-        set_error("smi_assignumis_chunk: null argument");
-        return SMI_ERR_INVALID;
-    }
+namespace {
+// The chunk on host threads, K-UMI alone on the device (rounds 1 and 2): the path of record for anything the device parser does not
+// evaluate itself (UP_NONSTD: barcodes that are not 16 letters of ACGT, exotic number formats) and for SMI_AU_HOST=1, which the tests
+// use to hold the device stage to it.
+int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_off, const uint16_t *flags,
+                          const int32_t *pos0, const uint32_t *cigars, const uint32_t *cigar_off, int32_t n,
+                          const smi_assignumis_config *cfg, smi_umi_tag *out, int32_t *n_done) {
     *n_done = 0;
     if (n == 0) return SMI_OK;
     // SMI_AU_TIMING=1: the host stages of this call on stderr (where the time of the second worker goes)
@@ -977,6 +978,178 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
             const uint64_t cw = win[c];
             for (int k = 0; k < 12; k++) t.u8[k] = dec4((uint32_t)(cw >> (4 * (k + 1 + asg[j].offset))) & 15u);
         }
+    return SMI_OK;
+}
+
+// region grouping of a chunk from K-UPARSE's records: smi_region_group (exact, sequential per strand)
+int regions_from_parsed(const UmiParsed *P, int32_t n, const smi_assignumis_config *cfg, std::vector<int32_t> &region, int32_t *n_done) {
+    std::vector<int32_t> cpos((size_t)n);
+    std::vector<uint8_t> has_pos((size_t)n), rev((size_t)n);
+    for (int32_t i = 0; i < n; i++) {
+        cpos[i] = P[i].cpos;
+        has_pos[i] = (P[i].flags & UP_HAS_POS) ? 1 : 0;
+        rev[i] = (P[i].flags & UP_REV) ? 1 : 0;
+    }
+    region.assign((size_t)n, -1);
+    return smi_region_group(cpos.data(), has_pos.data(), rev.data(), n, cfg->max_dist, cfg->keep_data_end, region.data(), n_done);
+}
+}  // namespace
+
+extern "C" int smi_umi_cluster_groups_device(smi_ctx *ctx, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups,
+                                             const float *d_mean_qv, const smi_umi_cluster_config *cfg, smi_umi_assignment *d_out, uint8_t *d_skipped, void *stream) {
+    if (!ctx || !cfg || (n_groups && (!d_dist || !d_mat_off || !d_group_off || !d_mean_qv || !d_out || !d_skipped)) || cfg->complete_link_ed < 0 ||
+        cfg->fold_depth_below_max <= 0) {
+        set_error("smi_umi_cluster_groups_device: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    SMI_HIP(hipSetDevice(ctx->device));
+    int dev_max = std::min(cfg->own_clusterer_above, kUmiClusterDeviceMax);
+    if (cfg->single_link_switch < dev_max) dev_max = cfg->single_link_switch;
+    return launch_umi_cluster(ctx, d_dist, d_mat_off, d_group_off, n_groups, d_mean_qv, *cfg, dev_max, d_out, d_skipped, static_cast<hipStream_t>(stream));
+}
+
+// `assignumis` for one chunk, the UMI stage on the device (smi_umi_stage.hip): K-UPARSE -> [host: region grouping] -> key sort ->
+// K-UMI -> K-UCLUST (groups of up to 100 reads; larger groups: their matrix comes back and ClusterOne_MyClustering runs on the host) ->
+// K-UTAG.  Same results as the host path, record by record (tests/test_umi_stage_gpu.py).
+extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint32_t *name_off, const uint16_t *flags,
+                                    const int32_t *pos0, const uint32_t *cigars, const uint32_t *cigar_off, int32_t n,
+                                    const smi_assignumis_config *cfg, smi_umi_tag *out, int32_t *n_done) {
+    if (!ctx || !names || !name_off || !flags || !pos0 || !cigar_off || !cfg || !out || !n_done || n < 0) {
+        set_error("smi_assignumis_chunk: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *n_done = 0;
+    if (n == 0) return SMI_OK;
+    smi_umi_cluster_config cc;
+    SMI_RC(smi_umi_cluster_default_config(&cc));
+    if (cfg->cluster) cc = *cfg->cluster;
+    if (std::getenv("SMI_AU_HOST")) return assignumis_chunk_host(ctx, names, name_off, flags, pos0, cigars, cigar_off, n, cfg, out, n_done);
+    const bool timing = std::getenv("SMI_AU_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "smi_assignumis_chunk(device) %-12s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    SMI_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const size_t N = (size_t)n, name_bytes = name_off[n], n_cig = cigar_off[n];
+    const size_t tmp_bytes = umi_group_scratch_bytes(n + 2);
+    const size_t G = N / 2 + 2;
+    const size_t fixed = pad(name_bytes + 16) + 2 * pad((N + 1) * 4) + pad(N * 2) + pad(N * 4) + pad((n_cig + 1) * 4) + pad(N * sizeof(UmiParsed)) + pad(N * 4) +
+                         3 * pad((N + 2) * 8) + 4 * pad((N + 2) * 4) + pad(16) + 4 * pad((N + 2) * 4) + 4 * pad((N + 2) * 8) + pad(G * 4) + pad(N * 4) + 2 * pad(G * 8) +
+                         pad(N * 8) + pad(N * 4) + pad(tmp_bytes) + pad(N * sizeof(smi_umi_assignment)) + pad(N) + pad(N * sizeof(smi_umi_tag)) + 8192;
+    SMI_RC(ensure_arena(ctx, fixed));
+    Arena A(ctx);
+    char *d_names = A.take<char>(name_bytes + 16);
+    uint32_t *d_noff = A.take<uint32_t>(N + 1), *d_coff = A.take<uint32_t>(N + 1);
+    uint16_t *d_flags = A.take<uint16_t>(N);
+    int32_t *d_pos0 = A.take<int32_t>(N);
+    uint32_t *d_cig = A.take<uint32_t>(n_cig + 1);
+    UmiParsed *d_parsed = A.take<UmiParsed>(N);
+    int32_t *d_region = A.take<int32_t>(N);
+    UmiGroupBuffers B;
+    B.keys = A.take<uint64_t>(N + 2);
+    B.keys_sorted = A.take<uint64_t>(N + 2);
+    B.run_keys = A.take<uint64_t>(N + 2);
+    B.idx = A.take<uint32_t>(N + 2);
+    B.idx_sorted = A.take<uint32_t>(N + 2);
+    B.run_len = A.take<uint32_t>(N + 2);
+    B.run_start = A.take<uint32_t>(N + 2);
+    B.n_runs = A.take<uint32_t>(4);
+    B.gsize = A.take<uint32_t>(N + 2);
+    B.gkept = A.take<uint32_t>(N + 2);
+    B.gslot = A.take<uint32_t>(N + 2);
+    B.goff_run = A.take<uint32_t>(N + 2);
+    B.gpairs = A.take<uint64_t>(N + 2);
+    B.gmat = A.take<uint64_t>(N + 2);
+    B.poff_run = A.take<uint64_t>(N + 2);
+    B.moff_run = A.take<uint64_t>(N + 2);
+    B.group_off = A.take<uint32_t>(G);
+    B.order = A.take<uint32_t>(N);
+    B.pair_off = A.take<uint64_t>(G);
+    B.mat_off = A.take<uint64_t>(G);
+    B.wpk = A.take<uint64_t>(N);
+    B.qv = A.take<float>(N);
+    B.tmp = A.take<uint8_t>(tmp_bytes);
+    B.tmp_bytes = tmp_bytes;
+    smi_umi_assignment *d_asg = A.take<smi_umi_assignment>(N);
+    uint8_t *d_skipped = A.take<uint8_t>(N);
+    smi_umi_tag *d_tags = A.take<smi_umi_tag>(N);
+    SMI_HIP(hipMemcpyAsync(d_names, names, name_bytes, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_noff, name_off, (N + 1) * 4, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_coff, cigar_off, (N + 1) * 4, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_flags, flags, N * 2, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_pos0, pos0, N * 4, hipMemcpyHostToDevice, s));
+    if (n_cig) SMI_HIP(hipMemcpyAsync(d_cig, cigars, n_cig * 4, hipMemcpyHostToDevice, s));
+    SMI_RC(launch_umi_parse(ctx, d_names, d_noff, d_flags, d_pos0, d_cig, d_coff, n, cfg->five_prime != 0, cfg->grouping_distance, cfg->bc_edit_limit, d_parsed, s));
+    std::vector<UmiParsed> parsed(N);
+    SMI_HIP(hipMemcpyAsync(parsed.data(), d_parsed, N * sizeof(UmiParsed), hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    lap("parse");
+    for (size_t i = 0; i < N; i++)
+        if (parsed[i].flags & (UP_NONSTD | UP_ERROR))  // the host path reads such a name itself (and reports AE= missing as the reference does)
+            return assignumis_chunk_host(ctx, names, name_off, flags, pos0, cigars, cigar_off, n, cfg, out, n_done);
+    std::vector<int32_t> region;
+    SMI_RC(regions_from_parsed(parsed.data(), n, cfg, region, n_done));
+    lap("regions");
+    SMI_HIP(hipMemcpyAsync(d_region, region.data(), N * 4, hipMemcpyHostToDevice, s));
+    uint64_t totals[4];
+    SMI_RC(launch_umi_groups(ctx, d_parsed, d_region, n, *n_done, B, totals, s));
+    const uint32_t n_groups = (uint32_t)totals[0], m = (uint32_t)totals[1];
+    lap("groups");
+    if (n_groups) {
+        // the matrices: a grow-only buffer of the context beside the arena
+        if (ctx->umi_dist_bytes < totals[3]) {
+            SMI_HIP(hipStreamSynchronize(s));
+            if (ctx->umi_dist) SMI_HIP(hipFree(ctx->umi_dist));
+            ctx->umi_dist = nullptr;
+            ctx->umi_dist_bytes = 0;
+            const size_t want = (size_t)totals[3] + (size_t)totals[3] / 4 + 4096;
+            SMI_HIP(hipMalloc(&ctx->umi_dist, want));
+            ctx->umi_dist_bytes = want;
+        }
+        uint8_t *d_dist = static_cast<uint8_t *>(ctx->umi_dist);
+        SMI_RC(smi_umi_dist_device(ctx, B.wpk, B.group_off, B.pair_off, B.mat_off, n_groups, totals[2], d_dist, s));
+        int dev_max = std::min(cc.own_clusterer_above, kUmiClusterDeviceMax);
+        if (cc.single_link_switch < dev_max) dev_max = cc.single_link_switch;  // (never with the shipped values: the switch sits at 3000)
+        SMI_RC(launch_umi_cluster(ctx, d_dist, B.mat_off, B.group_off, n_groups, B.qv, cc, dev_max, d_asg, d_skipped, s));
+        // groups the kernel left alone: their matrix comes back, the host clusters them, the assignments go up again
+        std::vector<uint32_t> goff((size_t)n_groups + 1);
+        SMI_HIP(hipMemcpyAsync(goff.data(), B.group_off, ((size_t)n_groups + 1) * 4, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        lap("k-umi+clust");
+        std::vector<uint32_t> big;
+        for (uint32_t g = 0; g < n_groups; g++)
+            if ((int)(goff[g + 1] - goff[g]) > dev_max) big.push_back(g);
+        if (!big.empty()) {
+            std::vector<uint64_t> moff((size_t)n_groups + 1);
+            SMI_HIP(hipMemcpyAsync(moff.data(), B.mat_off, ((size_t)n_groups + 1) * 8, hipMemcpyDeviceToHost, s));
+            SMI_HIP(hipStreamSynchronize(s));
+            for (uint32_t g : big) {
+                const uint32_t k = goff[g + 1] - goff[g];
+                std::vector<uint8_t> mat((size_t)k * k);
+                std::vector<float> qv(k);
+                std::vector<smi_umi_assignment> asg(k);
+                std::vector<uint8_t> sk(k, 0);
+                SMI_HIP(hipMemcpyAsync(mat.data(), d_dist + moff[g], (size_t)k * k, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipMemcpyAsync(qv.data(), B.qv + goff[g], (size_t)k * 4, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipStreamSynchronize(s));
+                const uint64_t zero64 = 0;
+                const uint32_t one_group[2] = {0, k};
+                SMI_RC(smi_umi_cluster_groups(mat.data(), &zero64, one_group, 1, qv.data(), &cc, asg.data(), sk.data(), cfg->n_threads > 0 ? cfg->n_threads : 1));
+                SMI_HIP(hipMemcpyAsync(d_asg + goff[g], asg.data(), (size_t)k * sizeof(smi_umi_assignment), hipMemcpyHostToDevice, s));
+                SMI_HIP(hipMemcpyAsync(d_skipped + goff[g], sk.data(), k, hipMemcpyHostToDevice, s));
+                SMI_HIP(hipStreamSynchronize(s));
+            }
+            lap("big groups");
+        }
+    }
+    SMI_RC(launch_umi_tags(ctx, d_parsed, d_region, n, *n_done, B, n_groups, m, d_asg, d_skipped, d_tags, s));
+    SMI_HIP(hipMemcpyAsync(out, d_tags, N * sizeof(smi_umi_tag), hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    lap("tags");
     return SMI_OK;
 }
 

@@ -57,7 +57,7 @@ EXPORTS = [
     "smi_pack_reads_text_device", "smi_pack_ends_text_device", "smi_frag_text_starts_device", "smi_fastq_write_text_device",
     "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
-    "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg",
+    "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library():
     lib.smi_packed_planes_words.restype = sz
     lib.smi_fastq_index_pack_host.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
     lib.smi_scanfastq_pass2_packed_seg.argtypes = [vp, vp, vp, sz, vp, vp]
+    lib.smi_umi_cluster_groups_device.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
     lib.smi_pack_reads_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp]
@@ -941,6 +942,12 @@ class Context:
         self._check(self._lib.smi_umi_dist_device(self._h, _ptr(d_windows), _ptr(d_group_off), _ptr(d_pair_off),
                                                   _ptr(d_mat_off), int(n_groups), int(total_pairs), _ptr(d_out),
                                                   _stream_ptr(stream)))
+
+    def umi_cluster_groups_device(self, d_dist, d_mat_off, d_group_off, n_groups, d_qv, d_out, d_skipped, cfg=None, stream=None):
+        """K-UCLUST: d_out int64-viewable [n_reads] of 8-byte smi_umi_assignment records, d_skipped uint8 [n_reads]"""
+        cfg = umi_cluster_config() if cfg is None else cfg
+        self._check(self._lib.smi_umi_cluster_groups_device(self._h, _ptr(d_dist), _ptr(d_mat_off), _ptr(d_group_off), int(n_groups), _ptr(d_qv),
+                                                            _ptr(cfg), _ptr(d_out), _ptr(d_skipped), _stream_ptr(stream)))
 
     # ---- host-buffer forms ---------------------------------------------------------------------------------
     def scan_batch(self, bases, quals, offsets, cfg, want_windows=True):

@@ -226,7 +226,8 @@ def test_ed2_long_lists_equal_oracle(pkg, synth, sor, gpu_ctx, n_wl, five_prime)
                                n_threads=16)
     got = _run_device(pkg, gpu_ctx, win, 2, five_prime)
     n_found = _compare(pkg, got, st, exp)
-    assert n_found > 0.3 * n and (exp["ed"][exp["found"] == 1] == 2).sum() > 50
+    # (against the whole 3.6 M list most windows have several barcodes within two edits: few reads are assigned, which is the point)
+    assert n_found > 100 and (exp["n_matches"] >= 2).sum() > 100
     if n_wl > 300_000:
         os.environ["SMI_BC2_DENSE_ENUM"] = "1"
         try:

@@ -141,19 +141,54 @@ def leg_assignumis(pkg, synth, ctx, dev, wl, used, res):
     p0 = np.array([max(t[0], 0) + 1_000_000 for t in rows], dtype=np.int32)
     out = np.zeros(n, dtype=lib.UMI_TAG_DTYPE)
     nd = ctypes.c_int32(0)
-    for threads in (1, 16):
+    import threading
+
+    def make_call(c, o, ndv, threads):
         cfg = lib.AssignUmisConfig()
-        ctx._check(ctx._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
+        c._check(c._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
         cfg.n_threads = threads
 
         def call():
-            ctx._check(ctx._lib.smi_assignumis_chunk(ctx._h, nbuf.ctypes.data, noff.ctypes.data, fl.ctypes.data, p0.ctypes.data, cbuf.ctypes.data,
-                                                     coff.ctypes.data, n, ctypes.byref(cfg), out.ctypes.data, ctypes.byref(nd)))
-        dt = timed(call)
-        res[f"assignumis_chunk_{threads}_threads"] = {
-            "records": n, "molecules": len(recs), "copies": copies, "loci": genes, "ms": dt * 1e3, "records_per_s": n / dt,
-            "clustered": int((out["flags"] & 4 != 0).sum()), "with_region": int((out["region"] >= 0).sum()),
-            "note": "one smi_assignumis_chunk call, host arrays in, tags out (name parsing, region grouping and clustering on the host, K-UMI on the device)"}
+            c._check(c._lib.smi_assignumis_chunk(c._h, nbuf.ctypes.data, noff.ctypes.data, fl.ctypes.data, p0.ctypes.data, cbuf.ctypes.data,
+                                                 coff.ctypes.data, n, ctypes.byref(cfg), o.ctypes.data, ctypes.byref(ndv)))
+        return call
+
+    base = {"records": n, "molecules": len(recs), "copies": copies, "loci": genes}
+    for label, env in (("host_path", "1"), ("device_stage", None)):
+        if env:
+            os.environ["SMI_AU_HOST"] = env
+        for threads in (1, 16):
+            dt = timed(make_call(ctx, out, nd, threads))
+            res[f"assignumis_chunk_{label}_{threads}_threads"] = dict(base, ms=dt * 1e3, records_per_s=n / dt, clustered=int((out["flags"] & 4 != 0).sum()),
+                                                                     with_region=int((out["region"] >= 0).sum()))
+        os.environ.pop("SMI_AU_HOST", None)
+    res["assignumis_chunk_device_stage_1_threads"]["note"] = ("one smi_assignumis_chunk call: names / flags / positions / CIGARs up, K-UPARSE, region grouping on "
+                                                              "the host (two threads), key sort, K-UMI, K-UCLUST, K-UTAG, tags down")
+    # several chunks side by side on worker lanes of the one GPU (UmiFinderWorker runs several OneBatchExecutors the same way)
+    runs = []
+    for lanes in (1, 2, 4, 8, 16):
+        ctxs = [ctx] + [ctx.lane() for _ in range(lanes - 1)]
+        outs = [np.zeros(n, dtype=lib.UMI_TAG_DTYPE) for _ in ctxs]
+        calls = [make_call(c, o, ctypes.c_int32(0), 2) for c, o in zip(ctxs, outs)]
+        for f in calls:
+            f()
+        per = 6
+
+        def worker(f):
+            for _ in range(per):
+                f()
+        th = [threading.Thread(target=worker, args=(f,)) for f in calls]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        same = all(o.tobytes() == outs[0].tobytes() for o in outs)
+        runs.append({"lanes": lanes, "records_per_s": n * lanes * per / dt, "ms_per_chunk": dt / per * 1e3, "same_tags_on_every_lane": same})
+        for c in ctxs[1:]:
+            c.close()
+    res["assignumis_device_stage_lanes"] = {"records_per_chunk": n, "runs": runs, "best": max(runs, key=lambda r: r["records_per_s"])}
 
 
 def leg_chimera(pkg, synth, ctx, dev, wl, used, res):
