@@ -40,13 +40,6 @@ struct NameView {
     __device__ __forceinline__ char at(int i) const { return i < staged ? lds[i] : glob[i]; }
 };
 
-// first occurrence of a 5-character marker
-__device__ __forceinline__ int find5(const NameView &v, int from, const char *m) {
-    for (int i = from; i + 5 <= v.len; i++)
-        if (v.at(i) == m[0] && v.at(i + 1) == m[1] && v.at(i + 2) == m[2] && v.at(i + 3) == m[3] && v.at(i + 4) == m[4]) return i;
-    return -1;
-}
-
 // Integer.parseInt of v[a, b): digits with an optional sign, at most 10 digits; *nonstd is set for anything the host's parser might read
 // differently (leading blanks, '+', overflow) so that the chunk takes the host path instead
 __device__ __forceinline__ bool parse_int(const NameView &v, int a, int b, long *out, bool *nonstd) {
@@ -152,22 +145,72 @@ __global__ __launch_bounds__(64) void k_umi_parse(const char *__restrict__ names
     NameView v{flat ? stage + (a - base) : stage + lane * (kNameStage + 4), names + a, nlen, flat ? nlen : min(nlen, kNameStage)};
     const uint16_t fl = flags[i];
     if (fl & 16) P.flags |= UP_REV;
-    int mark = find5(v, 0, "_REV_");
-    if (mark < 0) mark = find5(v, 0, "_FWD_");
+    // The characters go through a rolling 64-bit window (one LDS read per position): the first `_REV_`, else the first `_FWD_`, in pass
+    // one; the first occurrence of every tag behind it in pass two.  (Comparing every position against every pattern character by
+    // character cost thirteen reads per position.)
+    auto pat = [](const char *t, int n) {
+        uint64_t w = 0;
+        for (int k = 0; k < n; k++) w = (w << 8) | (uint8_t)t[k];
+        return w;
+    };
+    const uint64_t kRev = pat("_REV_", 5), kFwd = pat("_FWD_", 5), kM5 = 0xFFFFFFFFFFull, kM3 = 0xFFFFFFull, kM2 = 0xFFFFull, kM6 = 0xFFFFFFFFFFFFull;
+    // (the staged characters are read a dword at a time: a quarter of the LDS instructions of byte reads)
+    struct ByteStream {
+        const NameView &v;
+        const uint32_t *w32;
+        uint32_t cur;
+        int abs, k;
+        bool fast;
+        __device__ ByteStream(const NameView &nv, const char *stage_base, bool flat, int from) : v(nv), w32(reinterpret_cast<const uint32_t *>(stage_base)), cur(0), abs(0), k(from), fast(flat) {
+            if (fast) {
+                abs = (int)(nv.lds - stage_base) + from;
+                cur = w32[abs >> 2];
+            }
+        }
+        __device__ __forceinline__ uint8_t next() {
+            if (!fast) return (uint8_t)v.at(k++);
+            const uint8_t b = (uint8_t)(cur >> (8 * (abs & 3)));
+            abs++;
+            k++;
+            if ((abs & 3) == 0) cur = w32[abs >> 2];
+            return b;
+        }
+    };
+    int m_rev = -1, m_fwd = -1;
+    {
+        uint64_t w = 0;
+        ByteStream bs(v, stage, flat, 0);
+        for (int k = 0; k < v.len && m_rev < 0; k++) {
+            w = (w << 8) | bs.next();
+            if (k >= 4) {
+                if ((w & kM5) == kRev) m_rev = k - 4;
+                if ((w & kM5) == kFwd && m_fwd < 0) m_fwd = k - 4;
+            }
+        }
+    }
+    const int mark = m_rev >= 0 ? m_rev : m_fwd;
     if (mark >= 0) {
         const int s0 = mark + 4;  // `sub` of the reference: from the marker's closing '_' on
-        // one pass: the first occurrence of every tag and the end of its value (the next '_' or the end of the name)
         int p_ae = -1, p_ps = -1, p_ed = -1, p_bc = -1, p_bce = -1, p_x = -1, p_q = -1;
+        const uint64_t kAE = pat("AE=", 3), kPS = pat("PS=", 3), kED = pat("ed=", 3), kBC = pat("bc=", 3), kX = pat("X=", 2), kQ = pat("Q=", 2),
+                       kBCE = pat("bcEnd=", 6);
+        uint64_t w = 0;
+        ByteStream bs(v, stage, flat, s0);
         for (int k = s0; k < v.len; k++) {
-            const char c = v.at(k);
-            const char c1 = k + 1 < v.len ? v.at(k + 1) : '\0', c2 = k + 2 < v.len ? v.at(k + 2) : '\0';
-            if (c == 'A' && c1 == 'E' && c2 == '=' && p_ae < 0) p_ae = k + 3;
-            if (c == 'P' && c1 == 'S' && c2 == '=' && p_ps < 0) p_ps = k + 3;
-            if (c == 'e' && c1 == 'd' && c2 == '=' && p_ed < 0) p_ed = k + 3;
-            if (c == 'b' && c1 == 'c' && c2 == '=' && p_bc < 0) p_bc = k + 3;
-            if (c == 'X' && c1 == '=' && p_x < 0) p_x = k + 2;
-            if (c == 'Q' && c1 == '=' && p_q < 0) p_q = k + 2;
-            if (c == 'b' && c1 == 'c' && c2 == 'E' && p_bce < 0 && k + 6 <= v.len && v.at(k + 3) == 'n' && v.at(k + 4) == 'd' && v.at(k + 5) == '=') p_bce = k + 6;
+            w = (w << 8) | bs.next();
+            const int have = k - s0 + 1;  // characters of `sub` in the window
+            if (have >= 2) {
+                if ((w & kM2) == kX && p_x < 0) p_x = k + 1;
+                if ((w & kM2) == kQ && p_q < 0) p_q = k + 1;
+            }
+            if (have >= 3) {
+                const uint64_t t = w & kM3;
+                if (t == kAE && p_ae < 0) p_ae = k + 1;
+                if (t == kPS && p_ps < 0) p_ps = k + 1;
+                if (t == kED && p_ed < 0) p_ed = k + 1;
+                if (t == kBC && p_bc < 0) p_bc = k + 1;
+            }
+            if (have >= 6 && (w & kM6) == kBCE && p_bce < 0) p_bce = k + 1;
         }
         auto value_end = [&](int from) {
             int b = from;
@@ -320,19 +363,22 @@ __global__ void k_umi_fill_groups(const uint32_t *__restrict__ run_len, const ui
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int kClustMax = kUmiClusterDeviceMax;   // NRECORDS_SWITCH_TO_OWNCLUSTERING: larger groups go to ClusterOne_MyClustering (host)
 
+template <int KMAX>
 struct ClustLds {
-    uint8_t score[kClustMax * kClustMax];
-    uint16_t id[kClustMax * kClustMax];
-    int16_t nb[kClustMax];       // group-local read index of element e
-    int16_t label[kClustMax];    // slot of the cluster element e belongs to
-    int32_t cnum[kClustMax];     // cluster number of a slot (elements 0..k-1, merged clusters k, k+1, ...: creation order)
-    uint8_t alive[kClustMax];
-    int16_t csize[kClustMax];
-    int16_t members[kClustMax];  // of the cluster being tagged, ascending
-    int16_t ord[kClustMax];      // ... in fastutil iteration order
-    int32_t tab[260], tab2[260]; // fastutil open-addressing tables
-    uint8_t inside[kClustMax];
-    uint8_t skipped[kClustMax];
+    static constexpr int TAB = KMAX <= 24 ? 33 : 260;  // fastutil's table never grows beyond 32 slots for up to 24 keys
+    uint8_t mat[KMAX * KMAX];    // the group's distance matrix (ed | pos1 << 4 | pos2 << 6), staged once
+    uint8_t score[KMAX * KMAX];
+    uint16_t id[KMAX * KMAX];
+    int16_t nb[KMAX];       // group-local read index of element e
+    int16_t label[KMAX];    // slot of the cluster element e belongs to
+    int32_t cnum[KMAX];     // cluster number of a slot (elements 0..k-1, merged clusters k, k+1, ...: creation order)
+    uint8_t alive[KMAX];
+    int16_t csize[KMAX];
+    int16_t members[KMAX];  // of the cluster being tagged, ascending
+    int16_t ord[KMAX];      // ... in fastutil iteration order
+    int32_t tab[TAB], tab2[TAB]; // fastutil open-addressing tables
+    uint8_t inside[KMAX];
+    uint8_t skipped[KMAX];
 };
 
 // iteration order of a fastutil IntOpenHashSet that received `keys` (ascending) one by one: fastutil_order of smi_cluster.hip, serial
@@ -395,24 +441,36 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(64) void k_umi_cluster(const uint8_t *__restrict__ dist, const uint64_t *__restrict__ mat_off, const uint32_t *__restrict__ group_off,
-                                                    uint32_t n_groups, const float *__restrict__ qv_all, smi_umi_cluster_config cfg, int dev_max,
-                                                    smi_umi_assignment *__restrict__ out_all, uint8_t *__restrict__ skipped_all) {
-    __shared__ ClustLds L;
-    const int lane = threadIdx.x;
-    const uint32_t g = blockIdx.x;
+// KMAX: largest group this instantiation takes (its LDS is sized for it); WAVES groups per block, one wave each.  Two instantiations run
+// over the same group list: <16, 4> takes the groups of up to 16 reads (the bulk: ~1.6 KB of LDS per group, many waves per CU), <100, 1> the rest
+template <int KMAX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_umi_cluster(const uint8_t *__restrict__ dist, const uint64_t *__restrict__ mat_off, const uint32_t *__restrict__ group_off,
+                                                            uint32_t n_groups, const float *__restrict__ qv_all, smi_umi_cluster_config cfg, int dev_max, int n_above,
+                                                            smi_umi_assignment *__restrict__ out_all, uint8_t *__restrict__ skipped_all) {
+    __shared__ ClustLds<KMAX> L_all[WAVES];
+    ClustLds<KMAX> &L = L_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (g >= n_groups) return;
     const uint32_t a0 = group_off[g];
     const int n = (int)(group_off[g + 1] - a0);
+    if (n <= n_above || (KMAX < kClustMax && n > KMAX)) return;  // the other instantiation's group
     smi_umi_assignment *out = out_all + a0;
     uint8_t *skipped_out = skipped_all + a0;
     for (int i = lane; i < n; i += 64) {
         out[i] = smi_umi_assignment{-1, 0, -1, -1, 0};
         skipped_out[i] = 0;
     }
-    if (n < 2 || n > dev_max || n > kClustMax) return;  // larger groups: ClusterOne_MyClustering on the host
-    const uint8_t *M = dist + mat_off[g];
-    auto ed = [&](int i, int j) { return (int)(M[(size_t)i * n + j] & 15u); };
+    if (n < 2 || n > dev_max || n > KMAX) return;  // larger groups stay "not clustered": ClusterOne_MyClustering on the host
+    // the matrix into LDS: every distance is read many times (neighbour test, queue, centre, second-best), each of them a dependent
+    // global load before this copy existed
+    {
+        const uint8_t *Mg = dist + mat_off[g];
+        for (int p = lane; p < n * n; p += 64) L.mat[p] = Mg[p];
+    }
+    wave_sync();
+    const uint8_t *M = L.mat;
+    auto ed = [&](int i, int j) { return (int)(M[i * n + j] & 15u); };
     const int ced = cfg.complete_link_ed;
     // ---- reads with a neighbour (DistanceMatrix.java:L87-88), ascending -----------------------------------------------------------
     int k = 0;
@@ -535,6 +593,7 @@ __global__ __launch_bounds__(64) void k_umi_cluster(const uint8_t *__restrict__ 
                 if (L.label[e] == s) L.members[o++] = L.nb[e];  // ascending (nb is)
             fastutil_order_dev(L.members, m, L.tab, L.tab2, L.ord);
         }
+        wave_sync();
         for (int i = lane; i < n; i += 64) L.inside[i] = 0;
         wave_sync();
         for (int j = lane; j < m; j += 64) L.inside[L.members[j]] = 1;
@@ -562,7 +621,7 @@ __global__ __launch_bounds__(64) void k_umi_cluster(const uint8_t *__restrict__ 
         int sum = 0;
         for (int j = lane; j < m; j += 64) {
             const int vv = L.members[j];
-            if (vv != center) sum += (int)((M[(size_t)center * n + vv] >> 4) & 3u) - 1;
+            if (vv != center) sum += (int)((M[center * n + vv] >> 4) & 3u) - 1;
         }
         sum = wave_sum_i(sum);
         const int offset = (int)floor((double)sum / (double)(m - 1) + 0.5);
@@ -572,7 +631,7 @@ __global__ __launch_bounds__(64) void k_umi_cluster(const uint8_t *__restrict__ 
             if (n_kept > 1)
                 for (int w = 0; w < n; w++)
                     if (!L.inside[w] && (sec < 0 || ed(idx, w) < sec)) sec = ed(idx, w);
-            const uint8_t cm = M[(size_t)center * n + idx];
+            const uint8_t cm = M[center * n + idx];
             out[idx] = smi_umi_assignment{center, (int8_t)offset, (int8_t)(cm & 15u), (int8_t)sec, (int8_t)((cm >> 6) & 3u)};
         }
         wave_sync();
@@ -699,7 +758,9 @@ int launch_umi_groups(smi_ctx *, const UmiParsed *d_parsed, const int32_t *d_reg
 int launch_umi_cluster(smi_ctx *, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups, const float *d_qv,
                        const smi_umi_cluster_config &cfg, int dev_max, smi_umi_assignment *d_asg, uint8_t *d_skipped, hipStream_t s) {
     if (!n_groups) return SMI_OK;
-    hipLaunchKernelGGL(k_umi_cluster, dim3(n_groups), dim3(64), 0, s, d_dist, d_mat_off, d_group_off, n_groups, d_qv, cfg, dev_max, d_asg, d_skipped);
+    hipLaunchKernelGGL((k_umi_cluster<16, 4>), dim3((n_groups + 3) / 4), dim3(256), 0, s, d_dist, d_mat_off, d_group_off, n_groups, d_qv, cfg, dev_max, 0, d_asg, d_skipped);
+    hipLaunchKernelGGL((k_umi_cluster<kClustMax, 1>), dim3(n_groups), dim3(64), 0, s, d_dist, d_mat_off, d_group_off, n_groups, d_qv, cfg, dev_max, 16, d_asg,
+                       d_skipped);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

@@ -1,0 +1,214 @@
+"""`scanfastq -d <dir> -o <dir> --bcEditDistance k --compress` file to file: what quickrun-2.1.sh:35 runs, on one GPU.
+
+A directory of *.fastq / *.fastq.gz in, `<out>/passed/<base>_passed.fastq.gz` and `<out>/failed/<base>_failed.fastq.gz` per input file
+(FastqWriterThreadPool.java:L242-257), `BarcodeList.tsv` and `BarcodesAssigned.tsv` out; both passes of the default flow:
+
+  inflate (host threads, zlib)  ->  pass 1 per chunk on worker lanes (packed boundary, shared histogram)  ->  finalize / rank (host)
+  ->  pass 2 per chunk on the lanes (packed boundary: bit-planes up, decisions down, records written by host threads)
+  ->  gzip of every chunk's `passed` / `failed` text as one gzip member each (host threads), members appended in chunk order.
+
+The reference parallelises over input files (README.md:155) with one JVM; here a pool of host threads takes chunks, each thread owning
+one worker lane of the GPU (smi_ctx_create_lane) -- zlib and the native workers release the GIL, so the pool scales like the
+reference's thread pool does.  Read ids (GET_NEXT_READID, a process-wide counter in the reference, so their order is not reproducible
+there) are given per chunk from the number of records in front of it.  Nothing here computes on the CPU what the device path computes.
+"""
+import os
+import time
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def _inflate(path):
+    with open(path, "rb") as f:
+        raw = f.read()
+    if path.endswith(".gz"):
+        d = zlib.decompressobj(31)
+        parts = []
+        while raw:  # multi-member files
+            parts.append(d.decompress(raw))
+            raw = d.unused_data
+            if not d.eof:
+                break
+            d = zlib.decompressobj(31)
+        raw = b"".join(parts)
+    return np.frombuffer(raw, dtype=np.uint8)
+
+
+def write_synthetic_dir(synth, out_dir, n_files, reads_per_file, used, device, seed=9000, chimera_frac=0.05, gz_level=1, pool=None, q_lo=35, q_hi=64):
+    """test / bench input: n_files `*.fastq.gz` of reads_per_file synthetic reads each (generator of synth.py), qualities drawn uniformly
+    per base (constant qualities would flatter every gzip step) -> total reads"""
+    os.makedirs(out_dir, exist_ok=True)
+    own = pool is None
+    pool = pool or ThreadPoolExecutor(16)
+    futs, total = [], 0
+    for fi in range(n_files):
+        rd = synth.gen_reads(reads_per_file, used, seed=seed + fi, device=device, q_mean=20.0)
+        text, _b, offs = synth.fastq_text_device(rd, chimera_frac=chimera_frac, seed=seed + 7 * fi)
+        g = torch.Generator(device=text.device)
+        g.manual_seed(seed + 13 * fi)
+        is_q = text == ord("I")          # the generator's quality placeholder (no base or header character is 'I')
+        text[is_q] = torch.randint(q_lo, q_hi, (int(is_q.sum()),), device=text.device, generator=g, dtype=torch.int32).to(torch.uint8)
+        total += int(offs.numel()) - 1
+        data = text.cpu().numpy()
+        del rd, text, _b, is_q
+        futs.append(pool.submit(lambda d=data, k=fi: open(os.path.join(out_dir, f"synth_{k:04d}.fastq.gz"), "wb").write(_gzip_member(memoryview(d), gz_level))))
+    for f in futs:
+        f.result()
+    if own:
+        pool.shutdown()
+    return total
+
+
+def _cut_chunks(text, reads_per_chunk):
+    """byte ranges of `text` holding reads_per_chunk records each (4 lines per record)"""
+    n = int(text.size)
+    if n == 0:
+        return []
+    nl = np.flatnonzero(text == 10)
+    n_lines = nl.size + (0 if text[-1] == 10 else 1)
+    n_rec = n_lines // 4
+    cuts, start = [], 0
+    for r in range(reads_per_chunk, n_rec, reads_per_chunk):
+        end = int(nl[4 * r - 1]) + 1
+        cuts.append((start, end))
+        start = end
+    cuts.append((start, n))
+    return cuts
+
+
+def _gzip_member(data, level):
+    c = zlib.compressobj(level, zlib.DEFLATED, 31)
+    return c.compress(data) + c.flush()
+
+
+def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
+        dont_search_polya=False, host_threads_per_call=1, compress=True):
+    """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
+    (sorted uint64), loaded for pass 1."""
+    t_all = time.perf_counter()
+    files = sorted(f for f in os.listdir(in_dir) if f.endswith((".fastq", ".fq", ".fastq.gz", ".fq.gz")))
+    if not files:
+        raise _lib.SmiError(f"no FASTQ files in {in_dir}")
+    os.makedirs(os.path.join(out_dir, "passed"), exist_ok=True)
+    os.makedirs(os.path.join(out_dir, "failed"), exist_ok=True)
+    pool = ThreadPoolExecutor(n_workers)
+    # ---- inflate ---------------------------------------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    def load(f):
+        t = _inflate(os.path.join(in_dir, f))
+        return t, _cut_chunks(t, reads_per_chunk)
+
+    loaded = list(pool.map(load, files))
+    texts = [t for t, _ in loaded]
+    t_inflate = time.perf_counter() - t0
+    chunks = []  # (file index, chunk index in file, byte range)
+    for fi, (_, cuts) in enumerate(loaded):
+        for ci, rng in enumerate(cuts):
+            chunks.append((fi, ci, rng))
+    lanes = [ctx] + [ctx.lane() for _ in range(n_workers - 1)]
+    free = list(range(n_workers))
+
+    def with_lane(fn):
+        def call(*a):
+            k = free.pop()
+            try:
+                return fn(lanes[k], *a)
+            finally:
+                free.append(k)
+        return call
+
+    dev = torch.device("cuda", ctx.device)
+    keys = np.ascontiguousarray(whitelist_keys, dtype=np.uint64)
+    # ---- pass 1 ----------------------------------------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
+    for ln in lanes[1:]:
+        ln.refresh()
+    hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def p1(lane, fi, ci, rng):
+        return lane.scanfastq_pass1_chunk(texts[fi][rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=True,
+                                          n_threads=host_threads_per_call)
+
+    n_rec = list(pool.map(lambda c: with_lane(p1)(*c), chunks))
+    torch.cuda.synchronize()
+    t_pass1 = time.perf_counter() - t0
+    # ---- finalize ----------------------------------------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    # the reference's recordCount: the 10,000-read chunks FastqFileReader cuts, per input file (UsedCellBCListGenerator.java:L254)
+    per_file = {}
+    for (fi, _, _), m in zip(chunks, n_rec):
+        per_file[fi] = per_file.get(fi, 0) + m
+    record_count = sum((m + 9_999) // 10_000 for m in per_file.values())
+    h = hist.cpu().numpy()
+    nz = np.nonzero(h)[0]
+    k, c, r = _lib.finalize_used_list(keys[nz], h[nz].astype(np.uint32), record_count, max_ed, 10, 500)
+    with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
+        f.write(_lib.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, max_ed))
+    order = np.argsort(k)
+    rk_keys, rk_vals = k[order], r[order].astype(np.int32)
+    ctx.set_barcode_set(k, mode=_lib.SET_USED_LIST)
+    for ln in lanes[1:]:
+        ln.refresh()
+    t_finalize = time.perf_counter() - t0
+    # ---- pass 2 + gzip -------------------------------------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    first_id = np.concatenate([[0], np.cumsum(n_rec)])[:-1] + 1
+
+    def p2(lane, j):
+        fi, ci, rng = chunks[j]
+        passed, failed, info = lane.scanfastq_pass2_chunk(texts[fi][rng[0]:rng[1]], max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya,
+                                                          first_read_id=int(first_id[j]), rank_keys=rk_keys, rank_values=rk_vals, want_results=True, copy=False,
+                                                          packed=True, n_threads=host_threads_per_call)
+        bc = info["bc"] if info["n_records_out"] else np.zeros(0, dtype=_lib.BC_RESULT_DTYPE)
+        ok = bc["found"] == 1
+        cnt = np.zeros((k.size, 3), dtype=np.int64)
+        if ok.any():
+            np.add.at(cnt, (np.searchsorted(rk_keys, bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)), 1)
+        if compress:
+            zp, zf = _gzip_member(memoryview(passed), gz_level), _gzip_member(memoryview(failed), gz_level)
+        else:
+            zp, zf = bytes(passed), bytes(failed)
+        return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(passed.size), int(failed.size)
+
+    results = list(pool.map(lambda j: with_lane(p2)(j), range(len(chunks))))
+    t_pass2 = time.perf_counter() - t0
+    # ---- files -----------------------------------------------------------------------------------------------------------------------------
+    t0 = time.perf_counter()
+    counts = np.zeros((k.size, 3), dtype=np.int64)
+    ext = ".fastq.gz" if compress else ".fastq"
+    by_file = {}
+    for (fi, ci, _), res in zip(chunks, results):
+        by_file.setdefault(fi, []).append(res)
+        counts += res[4]
+
+    def write_file(fi):
+        base = files[fi]
+        for suf in (".gz", ".fastq", ".fq"):
+            if base.endswith(suf):
+                base = base[:-len(suf)]
+        with open(os.path.join(out_dir, "passed", base + "_passed" + ext), "wb") as fp, open(os.path.join(out_dir, "failed", base + "_failed" + ext), "wb") as ff:
+            for res in by_file.get(fi, []):
+                fp.write(res[0])
+                ff.write(res[1])
+
+    list(pool.map(write_file, range(len(files))))
+    with open(os.path.join(out_dir, "BarcodesAssigned.tsv"), "w") as f:
+        f.write(_lib.assigned_tsv(rk_keys, counts.astype(np.uint32), max_ed=max_ed))
+    t_write = time.perf_counter() - t0
+    for ln in lanes[1:]:
+        ln.close()
+    pool.shutdown()
+    n_reads = int(sum(n_rec))
+    wall = time.perf_counter() - t_all
+    return {"files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
+            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(t.size for t in texts)),
+            "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
+            "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_s": t_inflate, "pass1_s": t_pass1, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
+            "write_files_s": t_write, "workers": n_workers, "gz_level": gz_level if compress else None}

@@ -31,3 +31,17 @@ def test_bench_launches_two_ranks_itself_and_exchanges():
 def test_single_rank_exchange_only_needs_no_process_group():
     r = _run(["--gpus", "1", "--exchange-only", "--whitelist", "20000", "--cells", "100"])
     assert r["n_gpus"] == 1 and r["backend"] == "none" and r["first_row_total"] == 1
+
+
+def test_strong_scaling_split_sums_to_the_one_rank_run():
+    """--total-reads: the same 200,000 reads (20 chunks with global seeds) on one rank and sharded over two: the all-reduced histogram, the
+    used list after finalize and its ranks are identical (BASELINE configs[3]'s split, distributed.shard_range)"""
+    common = ["--exchange-only", "--backend", "gloo", "--whitelist", "50000", "--cells", "300", "--total-reads", "200000"]
+    one = _run(["--gpus", "1"] + common)
+    two = _run(["--gpus", "2"] + common)
+    three = _run(["--gpus", "3"] + common)
+    assert one["scaling"] == two["scaling"] == "strong" and one["total_reads"] == 200_000
+    assert one["hist_sum"] == two["hist_sum"] == three["hist_sum"] > 90_000
+    assert one["used_list"] == two["used_list"] == three["used_list"] > 100
+    assert one["used_list_digest"] == two["used_list_digest"] == three["used_list_digest"]
+    assert two["same_used_list_on_all_ranks"] is True and three["same_used_list_on_all_ranks"] is True

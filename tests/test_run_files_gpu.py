@@ -1,0 +1,65 @@
+"""File to file (sicelore-2.1_amd/run_files.py = `scanfastq -d <dir> -o <dir> --bcEditDistance 1 --compress`, both passes): the records
+in `<out>/passed/*_passed.fastq.gz` / `<out>/failed/*_failed.fastq.gz` equal the chunk worker's records over the same reads after the
+canonicalisation SURVEY 8c prescribes (sort by original read name, strip the base-36 read id, whose order the reference does not
+reproduce either); BarcodeList.tsv and BarcodesAssigned.tsv equal the single-call results."""
+import gzip
+import importlib
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+_ID = re.compile(rb"(_Q=[0-9.]+)_[0-9a-z]+")
+
+
+def _canon(text):
+    lines = text.split(b"\n")
+    assert lines[-1] == b""
+    recs = []
+    for k in range(0, len(lines) - 1, 4):
+        name = _ID.sub(rb"\1_", lines[k], count=1)
+        recs.append((name, lines[k + 1], lines[k + 2], lines[k + 3]))
+    return sorted(recs)
+
+
+def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path):
+    from sicelore_amd import lib as libmod
+
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    dev = torch.device("cuda", gpu_ctx.device)
+    wl = synth.make_whitelist(60_000, seed=801, device=dev)
+    used = synth.pick_used(wl, 60, seed=802)
+    keys = np.sort(wl.cpu().numpy().astype(np.uint64))
+    in_dir, out_dir = str(tmp_path / "in"), str(tmp_path / "out")
+    n = run_files.write_synthetic_dir(synth, in_dir, 6, 2500, used, dev, seed=810, chimera_frac=0.08)
+    info = run_files.run(gpu_ctx, in_dir, out_dir, max_ed=1, n_workers=4, reads_per_chunk=1000, whitelist_keys=keys)
+    assert info["reads"] == n and info["files"] == 6 and info["chunks"] >= 12 and info["passed"] > 0.8 * n
+    # the same reads through single calls of the chunk workers (text form), file by file
+    texts = [gzip.open(os.path.join(in_dir, f)).read() for f in sorted(os.listdir(in_dir))]
+    gpu_ctx.set_barcode_set(keys, mode=1)
+    hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
+    n_rec = [gpu_ctx.scanfastq_pass1_chunk(t, hist) for t in texts]
+    h = hist.cpu().numpy()
+    nz = np.nonzero(h)[0]
+    record_count = sum((m + 9_999) // 10_000 for m in n_rec)      # FastqFileReader's 10,000-read chunks per file
+    k, c, r = libmod.finalize_used_list(keys[nz], h[nz].astype(np.uint32), record_count, 1, 10, 500)
+    assert info["used_list"] == k.size and 40 <= k.size <= 70
+    assert open(os.path.join(out_dir, "BarcodeList.tsv")).read() == libmod.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, 1)
+    order = np.argsort(k)
+    gpu_ctx.set_barcode_set(k, mode=0)
+    counts = np.zeros((k.size, 3), dtype=np.int64)
+    for fi, t in enumerate(texts):
+        p, f, inf = gpu_ctx.scanfastq_pass2_chunk(t, max_ed=1, rank_keys=k[order], rank_values=r[order].astype(np.int32), want_results=True)
+        base = f"synth_{fi:04d}"
+        got_p = gzip.open(os.path.join(out_dir, "passed", base + "_passed.fastq.gz")).read()
+        got_f = gzip.open(os.path.join(out_dir, "failed", base + "_failed.fastq.gz")).read()
+        assert _canon(got_p) == _canon(p) and _canon(got_f) == _canon(f)
+        assert got_p.count(b"_rk=") > 1000
+        bc = inf["bc"]
+        ok = bc["found"] == 1
+        np.add.at(counts, (np.searchsorted(k[order], bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)), 1)
+    assert open(os.path.join(out_dir, "BarcodesAssigned.tsv")).read() == libmod.assigned_tsv(k[order], counts.astype(np.uint32), max_ed=1)
+    assert info["assigned"] == int(counts.sum())
