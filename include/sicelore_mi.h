@@ -534,6 +534,7 @@ typedef struct {
     const smi_bc_result *bc;
     uint32_t fastq_errors;          /* SMI_FQ_* (the call fails when non-zero) */
     uint32_t reserved;
+    const void *stats;              /* smi_scan_stats of this chunk (packed worker with want_results; NULL otherwise); owned by the context */
 } smi_pass2_output;
 /* page-locked host memory for the text handed to the workers (uploads at link speed); freed with smi_host_free */
 int smi_host_alloc(size_t bytes, void **out);
@@ -607,6 +608,24 @@ typedef struct {
     const smi_bc_result *bc;              /* n_records_out */
     const int32_t *rank;                  /* n_records_out, NULL without a rank table */
 } smi_pass2_decisions;
+/* ---- scan statistics: the counters ReadScanner.html renders and stats.pojo stores, as text ------------------------------------
+ * smi_record_flags: the reference's whole 64-bit flag word of a record (ReadFlags$Flags values) from the scan result (whose low bits it
+ * already is), the barcode result (BC_FOUND, BC_FOUND_ED*, BC_ED_DIFF*, BC_OFFSET*: Parser.assignBarcode), the splitter (READS_AFTER_SPLIT;
+ * MULTI_CHIMERIC_READS_DISCARDED | FAILED) and ReadFlags$Flags.finalizeFlag (ReadFlags.java:L194-207); equal to the `flag` of every record
+ * of tests/golden/ref_exec_pass2_*.json.  smi_scan_stats_add: ReadFlags.addForCounting + the read-length sums of Parser.processOneRecord
+ * (Parser.java:L114-118) over the records of one chunk; smi_scan_stats_merge: ReadFlags.mergeStats (what `mergestats` sums);
+ * smi_scan_stats_tsv: the text of ReadFlags.print (description TAB count TAB percent TAB "of <reference>").  The HTML page, stats.pojo
+ * (Java serialisation) and the QV histograms are not built. */
+#define SMI_N_READ_FLAGS 37
+typedef struct {
+    uint64_t counts[SMI_N_READ_FLAGS];  /* ReadFlags.countsMap in enum order */
+    uint64_t sum_len_passed, sum_len_failed, n_reads_split;
+} smi_scan_stats;
+uint64_t smi_record_flags(const smi_scan_result *scan, const smi_bc_result *bc, int from_split, int multi_chimeric);
+int smi_scan_stats_add(smi_scan_stats *st, const smi_pass2_decisions *dec);
+int smi_scan_stats_merge(smi_scan_stats *dst, const smi_scan_stats *src);
+int smi_scan_stats_tsv(const smi_scan_stats *st, char *out, size_t cap, size_t *n_out);
+
 /* device side of pass 2 from packed reads: upload of planes + offsets (host memory, page-locked for link speed), K-CHIM, fragment
  * offsets, read ends cut out of the planes (k_ends_from_planes), K-SCAN, K-BC, rank lookup, download of the decisions */
 int smi_scanfastq_pass2_packed(smi_ctx *ctx, const uint32_t *planes, const uint64_t *offsets, size_t n, const smi_pass2_config *cfg,

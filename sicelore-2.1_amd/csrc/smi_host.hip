@@ -409,3 +409,177 @@ extern "C" int smi_assigned_tsv(const uint64_t *keys, const uint32_t *counts, si
     }
     return SMI_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Scan statistics: the counters behind ReadScanner.html / stats.pojo, as text.
+//   ReadFlags$Flags (values, descriptions, print rules)         FJ!nanoporereadscanner/stats/ReadFlags.java:L70-165
+//   ReadFlags$Flags.finalizeFlag                                ReadFlags.java:L194-207
+//   ReadFlags.addForCounting / mergeStats / generateStatDataForPrinting / print        ReadFlags.java:L229-313
+//   Parser.processOneRecord (what is counted, the read-length sums)                     FJ!nanoporereadscanner/analyzers/Parser.java:L92-124
+//   Parser.assignBarcode flag bits (BC_FOUND*, BC_ED_DIFF*, BC_OFFSET*), pinned by the `flag` of every record of
+//   tests/golden/ref_exec_pass2_*.json (the reference's own flag word, 92 records)
+//   ChimeraFindernew (READS_AFTER_SPLIT on fragments, nReadsSplit, MULTI_CHIMERIC_READS_DISCARDED | FAILED)   ChimeraFindernew.java:L284-325
+// Not built: the HTML page itself (a Velocity template over these numbers), stats.pojo (Java object serialisation) and the QV histograms.
+// ---------------------------------------------------------------------------------------------------------------------------
+namespace {
+struct FlagDef {
+    const char *name, *description;
+    int bit;          // value = 1 << bit; -1: ALL_READS_AFTER_SPLIT (every bit)
+    bool print, only_nonzero;
+    int ref;          // index of refForPercentage, -1 none
+};
+// enum order = ReadFlags$Flags.values()
+const FlagDef kFlags[SMI_N_READ_FLAGS] = {
+    {"ALL_READS", "All Reads", 0, true, false, -1},
+    {"CHIMERIC_READS_SPLIT", "Chimeric reads split", 1, true, true, 0},
+    {"MULTI_CHIMERIC_READS_DISCARDED", "Multi Chimeric reads discarded n>3", 2, true, true, 0},
+    {"ALL_READS_AFTER_SPLIT", "Reads after chimera split", -1, true, false, -1},
+    {"READS_AFTER_SPLIT", "Reads from split chimeric", 3, true, true, 3},
+    {"PASSED_TOTAL", "Passed (Adapter found)", 4, true, false, 3},
+    {"FAILED", "Adapter NOT found", 5, false, false, 3},
+    {"MEAN_LENGTH_PASSED", "Mean read length pA and Adapter found", 6, true, false, -1},
+    {"MEAN_LENGTH_FAILED", "Mean read length pA and Adapter NOT found", 7, true, false, -1},
+    {"PASSED_FWD", "Passed forward", 8, true, false, 3},
+    {"PASSED_REV", "Passed reverse", 9, true, false, 3},
+    {"PASSED_TOT_TSO", "Passed total, found TSO other end", 10, true, true, 5},
+    {"POLY_T_5P", "PolyT found only at 5\"", 11, true, true, 3},
+    {"POLY_A_3P", "PolyA found only at 3\"", 12, true, true, 3},
+    {"POLY_A_NOT_FOUND", "PolyA not found", 13, true, true, 3},
+    {"POLY_T_5P_POLY_A_3P", "PolyT 5\" and PolyA at 3\"", 14, true, true, 3},
+    {"ADAPTER_5P", "Adapter at 5\"(3\" for 5p barcoding)", 15, true, false, 3},
+    {"ADAPTER_3P", "Adapter at 3\"(5\" for 5p barcoding)", 16, true, false, 3},
+    {"TSO_5P", "TSO at 5\"", 17, true, true, 3},
+    {"TSO_3P", "TSO at 3\"", 18, true, true, 3},
+    {"ADAPTER_SELECTED_DESP_ADAPTER_BOTH_SIDES", "Adapter selected despite Adapter both ends", 19, false, false, 3},
+    {"READ_TOO_SHORT", "Read too short", 20, true, false, 3},
+    {"ADAPTER_5P_AND_3P", "Adapter at 5\" and 3\"", 21, true, false, 3},
+    {"TSO_5P_AND_3P", "TSO at 5\" and 3\"", 22, true, true, 3},
+    {"TSO_5P_AND_3P_FAILED", "TSO at 5\" and 3\" failed", 23, true, true, 3},
+    {"BC_FOUND", "Barcode found", 24, true, true, 5},
+    {"BC_FOUND_NO_SECONDARY_MATCH", "Barcode found no secondary at <= ED + 2", 25, true, true, 5},
+    {"BC_FOUND_ED0", "Barcode found ED= 0", 26, true, true, 25},
+    {"BC_FOUND_ED1", "Barcode found ED= 1", 27, true, true, 25},
+    {"BC_FOUND_ED2", "Barcode found ED= 2", 28, true, true, 25},
+    {"BC_FOUND_ED3", "Barcode found ED= 3", 29, true, true, 25},
+    {"BC_ED_DIFF_ABOVE2", "Barcode secondary match ED diff > 2", 30, true, true, 25},
+    {"BC_ED_DIFF1", "Barcode secondary match ED diff 1", 31, true, true, 25},
+    {"BC_ED_DIFF2", "Barcode secondary match ED diff 2", 32, true, true, 25},
+    {"BC_OFFSET0", "Barcode offset from predicted pos=0", 33, true, true, 25},
+    {"BC_OFFSET1", "Barcode offset from predicted pos=+/-1", 34, true, true, 25},
+    {"BC_OFFSET2", "Barcode offset from predicted pos=+/-2", 35, true, true, 25},
+};
+enum { F_ALL = 0, F_CHIM_SPLIT = 1, F_AFTER_SPLIT_ALL = 3, F_READS_AFTER_SPLIT = 4, F_PASSED_TOTAL = 5, F_FAILED = 6, F_MEAN_P = 7, F_MEAN_F = 8 };
+}  // namespace
+
+extern "C" uint64_t smi_record_flags(const smi_scan_result *scan, const smi_bc_result *bc, int from_split, int multi_chimeric) {
+    if (multi_chimeric) return (1ull << 2) | (1ull << 5);  // never scanned (Parser.java:L92): MULTI_CHIMERIC_READS_DISCARDED | FAILED
+    uint64_t f = scan ? (uint64_t)scan->flags : 0;
+    if (from_split) f |= 1ull << 3;
+    if (bc && bc->found == 1 && scan && scan->found) {
+        f |= 1ull << 24;
+        if (bc->ed >= 0 && bc->ed <= 3) f |= 1ull << (26 + bc->ed);
+        const long long d = (long long)bc->ed_sec - (long long)bc->ed;
+        if (d > 2) f |= 1ull << 25;
+        f |= d == 1 ? 1ull << 31 : d == 2 ? 1ull << 32 : 1ull << 30;
+        const int o = bc->offset < 0 ? -bc->offset : bc->offset;
+        if (o <= 2) f |= 1ull << (33 + o);
+    }
+    // ReadFlags$Flags.finalizeFlag
+    const bool fwd = f & (1ull << 8), rev = f & (1ull << 9);
+    if (!fwd && !rev)
+        f |= 1ull << 5;
+    else
+        f |= 1ull << 4;
+    if ((rev && (f & (1ull << 18))) || (fwd && (f & (1ull << 17)))) f |= 1ull << 10;
+    if ((f & (1ull << 5)) && (f & (1ull << 22))) f |= 1ull << 23;
+    return f;
+}
+
+extern "C" int smi_scan_stats_add(smi_scan_stats *st, const smi_pass2_decisions *dec) {
+    if (!st || !dec || (dec->n_records_out && (!dec->scan || !dec->bc || !dec->frag_offsets))) {
+        set_error("smi_scan_stats_add: null argument");
+        return SMI_ERR_INVALID;
+    }
+    for (size_t i = 0; i < dec->n_records_out; i++) {
+        const uint32_t src = dec->frag_src ? (dec->frag_src[i] >> 2) : (uint32_t)i;
+        const smi_chimera_result *ch = dec->chim ? dec->chim + src : nullptr;
+        const bool multi = ch && (ch->flags & SMI_CHIM_MULTI), split = ch && ch->n_split > 0 && !multi;
+        const uint64_t f = smi_record_flags(dec->scan + i, dec->bc + i, split, multi);
+        const uint64_t len = dec->frag_offsets[i + 1] - dec->frag_offsets[i];
+        for (int k = 0; k < SMI_N_READ_FLAGS; k++)  // ReadFlags.addForCounting
+            if (kFlags[k].bit < 0 || (f & (1ull << kFlags[k].bit))) st->counts[k]++;
+        ((f & (1ull << 4)) ? st->sum_len_passed : st->sum_len_failed) += len;
+        if (split && (!dec->frag_src || (dec->frag_src[i] & 3u) == 0)) st->n_reads_split++;  // once per split read (ChimeraFindernew.java:L288)
+    }
+    return SMI_OK;
+}
+
+extern "C" int smi_scan_stats_merge(smi_scan_stats *dst, const smi_scan_stats *src) {  // ReadFlags.mergeStats (the `mergestats` sub-command's sum)
+    if (!dst || !src) {
+        set_error("smi_scan_stats_merge: null argument");
+        return SMI_ERR_INVALID;
+    }
+    for (int k = 0; k < SMI_N_READ_FLAGS; k++) dst->counts[k] += src->counts[k];
+    dst->sum_len_passed += src->sum_len_passed;
+    dst->sum_len_failed += src->sum_len_failed;
+    dst->n_reads_split += src->n_reads_split;
+    return SMI_OK;
+}
+
+// ReadFlags.print: "=======  Scan Stats =======" and one line `description TAB count TAB percent TAB of <reference>` per printed flag
+extern "C" int smi_scan_stats_tsv(const smi_scan_stats *st, char *out, size_t cap, size_t *n_out) {
+    if (!st || !n_out) {
+        set_error("smi_scan_stats_tsv: null argument");
+        return SMI_ERR_INVALID;
+    }
+    uint64_t c[SMI_N_READ_FLAGS];
+    for (int k = 0; k < SMI_N_READ_FLAGS; k++) c[k] = st->counts[k];
+    // generateStatDataForPrinting L283-286 (int arithmetic of the reference)
+    c[F_ALL] = c[F_AFTER_SPLIT_ALL] - (c[F_READS_AFTER_SPLIT] - st->n_reads_split);
+    c[F_CHIM_SPLIT] = st->n_reads_split;
+    c[F_MEAN_P] = c[F_PASSED_TOTAL] ? st->sum_len_passed / c[F_PASSED_TOTAL] : 0;  // (the reference divides by zero here: ArithmeticException)
+    c[F_MEAN_F] = c[F_FAILED] ? st->sum_len_failed / c[F_FAILED] : 0;
+    auto grouped = [](unsigned long long v) {
+        std::string d = std::to_string(v), r;
+        for (size_t i = 0; i < d.size(); i++) {
+            if (i && (d.size() - i) % 3 == 0) r += ',';
+            r += d[i];
+        }
+        return r;
+    };
+    auto percent = [](float ratio) {  // DecimalFormat("###.0 %"): x 100, one fraction digit, HALF_EVEN, no integer digit when it is zero
+        if (ratio != ratio) return std::string("NaN");
+        double t = (double)ratio * 100.0 * 10.0;
+        if (t > 1e18) return std::string("\xE2\x88\x9E %");
+        unsigned long long q = (unsigned long long)t;
+        const double frac = t - (double)q;
+        if (frac > 0.5 || (frac == 0.5 && (q & 1))) q++;
+        std::string r = q / 10 ? std::to_string(q / 10) : std::string();
+        r += '.';
+        r += (char)('0' + (int)(q % 10));
+        return r + " %";
+    };
+    std::string text = "=======  Scan Stats =======\n\n";
+    for (int k = 0; k < SMI_N_READ_FLAGS; k++) {
+        const FlagDef &f = kFlags[k];
+        if (!f.print || (f.only_nonzero && c[k] == 0)) continue;
+        text += f.description;
+        text += '\t' + grouped(c[k]) + '\t';
+        if (f.ref >= 0) {
+            text += percent((float)(int)c[k] / (float)(int)c[f.ref]);
+            text += std::string("\tof ") + kFlags[f.ref].description;
+        } else
+            text += '\t';
+        text += '\n';
+    }
+    *n_out = text.size();
+    if (out) {
+        if (text.size() > cap) {
+            set_error("smi_scan_stats_tsv: output buffer too small");
+            return SMI_ERR_INVALID;
+        }
+        std::memcpy(out, text.data(), text.size());
+    }
+    return SMI_OK;
+}

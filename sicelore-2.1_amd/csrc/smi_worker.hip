@@ -544,6 +544,9 @@ extern "C" int smi_scanfastq_pass2_chunk_packed(smi_ctx *ctx, const uint8_t *tex
         ctx->host_bc.assign(dec.bc, dec.bc + dec.n_records_out);
         out->scan = ctx->host_scan.data();
         out->bc = ctx->host_bc.data();
+        std::memset(&ctx->host_stats, 0, sizeof ctx->host_stats);  // ReadFlags.addForCounting over the chunk (the counters behind ReadScanner.html)
+        SMI_RC(smi_scan_stats_add(&ctx->host_stats, &dec));
+        out->stats = &ctx->host_stats;
     }
     out->passed = ctx->host_out[0];
     out->failed = ctx->host_out[1];

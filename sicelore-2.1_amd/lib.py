@@ -58,6 +58,7 @@ EXPORTS = [
     "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
+    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv",
 ]
 
 
@@ -145,6 +146,11 @@ def load_library():
     lib.smi_fastq_index_pack_host.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
     lib.smi_scanfastq_pass2_packed_seg.argtypes = [vp, vp, vp, sz, vp, vp]
     lib.smi_umi_cluster_groups_device.argtypes = [vp, vp, vp, vp, ctypes.c_uint32, vp, vp, vp, vp, vp]
+    lib.smi_record_flags.argtypes = [vp, vp, ci, ci]
+    lib.smi_record_flags.restype = ctypes.c_uint64
+    lib.smi_scan_stats_add.argtypes = [vp, vp]
+    lib.smi_scan_stats_merge.argtypes = [vp, vp]
+    lib.smi_scan_stats_tsv.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     lib.smi_read_planes_words.argtypes = [ctypes.c_uint64, sz]
     lib.smi_read_planes_words.restype = sz
     lib.smi_pack_reads_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp]
@@ -169,7 +175,7 @@ def load_library():
     lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
-    explicit = {"smi_last_error", "smi_version", "smi_read_planes_words", "smi_packed_planes_words"}  # restype set above (char*, size_t)
+    explicit = {"smi_last_error", "smi_version", "smi_read_planes_words", "smi_packed_planes_words", "smi_record_flags"}  # restype set above (char*, size_t)
     for name in EXPORTS:
         if name not in explicit:
             getattr(lib, name).restype = ci
@@ -410,6 +416,41 @@ FASTQ_RECORD_DTYPE = np.dtype([("name_start", "<u8"), ("seq_start", "<u8"), ("pl
 assert FASTQ_RECORD_DTYPE.itemsize == 48
 
 
+N_READ_FLAGS = 37
+N_SCAN_STATS = N_READ_FLAGS + 3   # smi_scan_stats as a uint64 vector: the 37 counters, sum_len_passed, sum_len_failed, n_reads_split
+READ_FLAG_NAMES = ["ALL_READS", "CHIMERIC_READS_SPLIT", "MULTI_CHIMERIC_READS_DISCARDED", "ALL_READS_AFTER_SPLIT", "READS_AFTER_SPLIT", "PASSED_TOTAL", "FAILED",
+                   "MEAN_LENGTH_PASSED", "MEAN_LENGTH_FAILED", "PASSED_FWD", "PASSED_REV", "PASSED_TOT_TSO", "POLY_T_5P", "POLY_A_3P", "POLY_A_NOT_FOUND",
+                   "POLY_T_5P_POLY_A_3P", "ADAPTER_5P", "ADAPTER_3P", "TSO_5P", "TSO_3P", "ADAPTER_SELECTED_DESP_ADAPTER_BOTH_SIDES", "READ_TOO_SHORT",
+                   "ADAPTER_5P_AND_3P", "TSO_5P_AND_3P", "TSO_5P_AND_3P_FAILED", "BC_FOUND", "BC_FOUND_NO_SECONDARY_MATCH", "BC_FOUND_ED0", "BC_FOUND_ED1",
+                   "BC_FOUND_ED2", "BC_FOUND_ED3", "BC_ED_DIFF_ABOVE2", "BC_ED_DIFF1", "BC_ED_DIFF2", "BC_OFFSET0", "BC_OFFSET1", "BC_OFFSET2"]
+
+
+def record_flags(scan, bc=None, from_split=False, multi_chimeric=False):
+    """smi_record_flags: the reference's 64-bit flag word of one record (SCAN_RESULT_DTYPE / BC_RESULT_DTYPE records)"""
+    lib = load_library()
+    sc = np.zeros(1, dtype=SCAN_RESULT_DTYPE)
+    sc[0] = scan
+    b = None
+    if bc is not None:
+        b = np.zeros(1, dtype=BC_RESULT_DTYPE)
+        b[0] = bc
+    return int(lib.smi_record_flags(_ptr(sc), _ptr(b), int(from_split), int(multi_chimeric)))
+
+
+def scan_stats_tsv(stats):
+    """smi_scan_stats_tsv: the text of ReadFlags.print from a smi_scan_stats vector (uint64 [40]; vectors of several chunks / runs add up)"""
+    lib = load_library()
+    st = np.ascontiguousarray(stats, dtype=np.uint64)
+    assert st.size == N_SCAN_STATS
+    n = ctypes.c_size_t(0)
+    if lib.smi_scan_stats_tsv(st.ctypes.data, None, 0, ctypes.byref(n)):
+        raise SmiError(lib.smi_last_error().decode())
+    out = ctypes.create_string_buffer(n.value + 1)
+    if lib.smi_scan_stats_tsv(st.ctypes.data, out, n.value, ctypes.byref(n)):
+        raise SmiError(lib.smi_last_error().decode())
+    return out.raw[:n.value].decode()
+
+
 class Pass2Decisions(ctypes.Structure):
     """smi_pass2_decisions"""
     _fields_ = [("n_records_in", ctypes.c_size_t), ("n_records_out", ctypes.c_size_t), ("chim", ctypes.c_void_p),
@@ -544,7 +585,7 @@ class Pass2Output(ctypes.Structure):
     _fields_ = [("passed", ctypes.c_void_p), ("failed", ctypes.c_void_p), ("passed_bytes", ctypes.c_size_t),
                 ("failed_bytes", ctypes.c_size_t), ("n_records_in", ctypes.c_size_t), ("n_records_out", ctypes.c_size_t),
                 ("n_passed", ctypes.c_size_t), ("scan", ctypes.c_void_p), ("bc", ctypes.c_void_p), ("fastq_errors", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32)]
+                ("reserved", ctypes.c_uint32), ("stats", ctypes.c_void_p)]
 
 
 class ChimeraConfig(ctypes.Structure):
@@ -839,6 +880,8 @@ class Context:
             view = lambda p, n: np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)) if n else np.zeros(0, np.uint8)  # noqa: E731
             passed, failed = view(out.passed, out.passed_bytes), view(out.failed, out.failed_bytes)
         info = dict(n_records_in=out.n_records_in, n_records_out=out.n_records_out, n_passed=out.n_passed)
+        if want_results and out.stats:
+            info["stats"] = np.frombuffer(ctypes.string_at(out.stats, 8 * N_SCAN_STATS), dtype=np.uint64).copy()
         if want_results and out.n_records_out:
             info["scan"] = np.frombuffer(ctypes.string_at(out.scan, out.n_records_out * SCAN_RESULT_DTYPE.itemsize), dtype=SCAN_RESULT_DTYPE)
             info["bc"] = np.frombuffer(ctypes.string_at(out.bc, out.n_records_out * BC_RESULT_DTYPE.itemsize), dtype=BC_RESULT_DTYPE)

@@ -64,6 +64,25 @@ def write_synthetic_dir(synth, out_dir, n_files, reads_per_file, used, device, s
     return total
 
 
+def write_stats(out_dir, stats):
+    with open(os.path.join(out_dir, "ReadScanner.tsv"), "w") as f:
+        f.write(_lib.scan_stats_tsv(stats))
+    with open(os.path.join(out_dir, "stats.tsv"), "w") as f:
+        names = _lib.READ_FLAG_NAMES + ["sum_len_passed", "sum_len_failed", "n_reads_split"]
+        f.write("".join(f"{nm}\t{int(v)}\n" for nm, v in zip(names, stats)))
+
+
+def merge_stats(run_dirs, out_dir):
+    """`mergestats` (Jar/config.xml:33, ReadFlags.mergeStats): the statistics of several scanfastq runs added up -> <out_dir>/ReadScanner.tsv, stats.tsv"""
+    total = np.zeros(_lib.N_SCAN_STATS, dtype=np.uint64)
+    for d in run_dirs:
+        rows = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(d, "stats.tsv"))]
+        total += np.array([int(r[1]) for r in rows], dtype=np.uint64)
+    os.makedirs(out_dir, exist_ok=True)
+    write_stats(out_dir, total)
+    return total
+
+
 def _cut_chunks(text, reads_per_chunk):
     """byte ranges of `text` holding reads_per_chunk records each (4 lines per record)"""
     n = int(text.size)
@@ -175,7 +194,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             zp, zf = _gzip_member(memoryview(passed), gz_level), _gzip_member(memoryview(failed), gz_level)
         else:
             zp, zf = bytes(passed), bytes(failed)
-        return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(passed.size), int(failed.size)
+        return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(passed.size), int(failed.size), info.get("stats")
 
     results = list(pool.map(lambda j: with_lane(p2)(j), range(len(chunks))))
     t_pass2 = time.perf_counter() - t0
@@ -201,6 +220,13 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     list(pool.map(write_file, range(len(files))))
     with open(os.path.join(out_dir, "BarcodesAssigned.tsv"), "w") as f:
         f.write(_lib.assigned_tsv(rk_keys, counts.astype(np.uint32), max_ed=max_ed))
+    # the counters ReadScanner.html renders (ReadFlags.print) and, beside them, the raw vector `merge_stats` adds up (the reference keeps
+    # them in stats.pojo for its `mergestats` sub-command)
+    stats = np.zeros(_lib.N_SCAN_STATS, dtype=np.uint64)
+    for res in results:
+        if res[7] is not None:
+            stats += res[7]
+    write_stats(out_dir, stats)
     t_write = time.perf_counter() - t0
     for ln in lanes[1:]:
         ln.close()

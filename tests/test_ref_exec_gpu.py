@@ -43,6 +43,13 @@ def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name, packe
                                                              dont_search_polya=sec["dont_search_polya"], split_chimeras=False,
                                                              first_read_id=idx + 1, rank_keys=keys[order], rank_values=ranks[order],
                                                              packed=packed, n_threads=2)
+        if packed:   # the reference's whole flag word from the results the device sent back (smi_record_flags; the counters behind ReadScanner.html)
+            _p, _f, inf = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=sec["ed"], five_prime=sec["five_prime"], dont_search_polya=sec["dont_search_polya"],
+                                                        split_chimeras=False, first_read_id=idx + 1, rank_keys=keys[order], rank_values=ranks[order],
+                                                        packed=True, n_threads=1, want_results=True)
+            assert pkg.lib.record_flags(inf["scan"][0], inf["bc"][0]) == want["flag"], (c["name"], hex(want["flag"]))
+            st = inf["stats"]
+            assert int(st[3]) == 1 and int(st[5]) == int(want["passed"]) and int(st[25]) == int(want["barcode"] is not None)
         w = want["written"]
         exp = f"@{w['name']}\n{w['bases']}\n+{w['quality_header'] or ''}\n{w['qualities']}\n".encode()
         got = passed if want["passed"] else failed

@@ -63,3 +63,12 @@ def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path):
         np.add.at(counts, (np.searchsorted(k[order], bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)), 1)
     assert open(os.path.join(out_dir, "BarcodesAssigned.tsv")).read() == libmod.assigned_tsv(k[order], counts.astype(np.uint32), max_ed=1)
     assert info["assigned"] == int(counts.sum())
+    # the statistics file: the counters of ReadFlags.print, consistent with the records that were written; mergestats adds runs up
+    rows = {ln.split("\t")[0]: ln.split("\t")[1:] for ln in open(os.path.join(out_dir, "ReadScanner.tsv")).read().split("\n")[2:] if ln}
+    num = lambda key: int(rows[key][0].replace(",", ""))  # noqa: E731
+    assert num("All Reads") == n and num("Reads after chimera split") == info["records_out"] and num("Passed (Adapter found)") == info["passed"]
+    assert num("Barcode found") == info["assigned"] and num("Chimeric reads split") > 50
+    assert num("Passed forward") + num("Passed reverse") == info["passed"]
+    total = run_files.merge_stats([out_dir, out_dir], str(tmp_path / "merged"))
+    merged = open(str(tmp_path / "merged" / "ReadScanner.tsv")).read()
+    assert f"All Reads\t{2 * n:,}" in merged and int(total[3]) == 2 * info["records_out"]
