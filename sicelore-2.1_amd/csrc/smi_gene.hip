@@ -37,13 +37,24 @@ inline uint32_t spread(int32_t h) {
     const uint32_t u = (uint32_t)h;
     return u ^ (u >> 16);
 }
-// iteration order of a java.util.HashMap / HashSet that received `hashes` in this insertion order (no removals)
+// iteration order of a java.util.HashMap / HashSet created with the default constructor that received `hashes` in this insertion order
+// (no removals): table of 16 doubling when the size passes 3/4 of it, bins in insertion order, bins visited in ascending index.  The model
+// ends where the JDK leaves it: a bin that reaches 8 entries is turned into a red-black tree (or, under 64 slots, forces a resize) and
+// its iteration order then depends on the tree's shape (ties by System.identityHashCode) -- such a map is REFUSED here (g_jhash_unmodelled,
+// checked by the callers), as tools/jvm_natives.py refuses it when the fixtures are made.  Whether the JDK's order is modelled correctly
+// below that point rests on the published HashMap source, not on a JVM run (DESIGN.md "Oracle": parity of hash-ordered outputs unpinned).
+thread_local bool g_jhash_unmodelled = false;
 std::vector<size_t> jhash_order(const std::vector<int32_t> &hashes) {
     size_t cap = 16;
     while (hashes.size() > (cap * 3) / 4) cap <<= 1;
     std::vector<size_t> idx(hashes.size());
     for (size_t i = 0; i < idx.size(); i++) idx[i] = i;
     std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return (spread(hashes[a]) & (cap - 1)) < (spread(hashes[b]) & (cap - 1)); });
+    size_t run = 0;
+    for (size_t i = 0; i < idx.size(); i++) {
+        run = (i && (spread(hashes[idx[i]]) & (cap - 1)) == (spread(hashes[idx[i - 1]]) & (cap - 1))) ? run + 1 : 1;
+        if (run >= 8) g_jhash_unmodelled = true;  // TREEIFY_THRESHOLD
+    }
     return idx;
 }
 
@@ -283,6 +294,13 @@ extern "C" int smi_genes_load_refflat(const char *text, size_t n_bytes, const ch
             const Gene &x = G->genes[(size_t)a], &y = G->genes[(size_t)b];
             return x.start != y.start ? x.start < y.start : x.end < y.end;
         });
+    if (g_jhash_unmodelled) {
+        g_jhash_unmodelled = false;
+        delete G;
+        set_error("smi_genes_load_refflat: a java.util.HashMap bin of the reference would hold 8 or more entries here (gene names / transcript names with "
+                  "colliding hashes): its iteration order is a tree's, which this library does not model");
+        return SMI_ERR_INVALID;
+    }
     *out = G;
     return SMI_OK;
 }
@@ -455,6 +473,11 @@ extern "C" int smi_gene_tag_chunk(const smi_genes *G, const int32_t *ref_id, con
         txt += LF_NAME[f];
     }
     offs.push_back((uint32_t)txt.size());
+    if (g_jhash_unmodelled) {  // a HashSet<Gene> bin of 8 or more genes (never seen: a record overlaps a handful of genes)
+        g_jhash_unmodelled = false;
+        set_error("smi_gene_tag_chunk: a HashSet<Gene> of the reference would hold a tree bin here: its iteration order is not modelled");
+        return SMI_ERR_INVALID;
+    }
     *n_out = txt.size();
     if (out_off) std::memcpy(out_off, offs.data(), offs.size() * sizeof(uint32_t));
     if (!out) return SMI_OK;

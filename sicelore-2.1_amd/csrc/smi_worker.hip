@@ -45,6 +45,15 @@ __global__ void k_rank_lookup(const smi_bc_result *__restrict__ bc, size_t n, co
     rank[i] = r;
 }
 
+// a read the splitter discarded whole (MULTI_CHIMERIC_READS_DISCARDED) is never scanned by the reference (Parser.java:L92): its record goes
+// to `failed` as it is and must not count as an assigned barcode anywhere (per-barcode counters, statistics, rank)
+__global__ void k_drop_discarded(smi_bc_result *__restrict__ bc, const uint32_t *__restrict__ frag_src,
+                                 const smi_chimera_result *__restrict__ chim, size_t n) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (chim[frag_src[i] >> 2].flags & SMI_CHIM_MULTI) bc[i].found = 0;
+}
+
 struct Arena {
     smi_ctx *ctx;
     size_t used = 0;
@@ -204,6 +213,10 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     SMI_RC(smi_pack_ends_text_device(ctx, d_text, d_bstart, d_rec_offs, m, d_ends, d_len, s));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
+    if (split && m) {
+        hipLaunchKernelGGL(k_drop_discarded, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_bc, d_fsrc, d_chim, m);
+        SMI_HIP(hipGetLastError());
+    }
     int32_t *d_rank = nullptr;
     if (cfg->rank_keys && cfg->n_ranks) {
         d_rank = A.take<int32_t>(m_cap);
@@ -416,6 +429,10 @@ int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *
     SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_ends, d_len, s, d_pstart));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
+    if (split && m) {
+        hipLaunchKernelGGL(k_drop_discarded, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_bc, d_fsrc, d_chim, m);
+        SMI_HIP(hipGetLastError());
+    }
     int32_t *d_rank = nullptr;
     if (cfg->rank_keys && cfg->n_ranks) {
         d_rank = A.take<int32_t>(m_cap);

@@ -108,6 +108,11 @@ class ReadScanner:
         scan_d, win = self._scan(reads, None, offs, n_out, pass_no=2)  # the quality filter belongs to pass 1 (UsedCellBCListGenerator L198-202)
         res_d = torch.zeros((max(n_out, 1), 4), dtype=torch.int32, device=self.dev)
         self.ctx.bc_match_device(win, res_d, n_out, max_ed=self.max_ed, five_prime=self.five_prime)
+        if fsrc is not None and n_out:
+            # a read the splitter discarded whole is never scanned by the reference (Parser.java:L92): no barcode for its record, as the
+            # chunk workers' k_drop_discarded has it
+            multi = (flags[(fsrc >> 2).to(torch.int64)] & _lib.CHIM_MULTI) != 0
+            res_d.view(torch.uint8).view(-1, 16)[:n_out, 8][multi] = 0
         return n_out, offs, d_chim, fsrc, scan_d, res_d
 
     def pass2_write_chunk(self, text, rank_keys=None, rank_values=None, first_read_id=1, trim_fastq=False):

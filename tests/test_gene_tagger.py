@@ -146,3 +146,26 @@ def test_tags_enter_the_record_in_reference_order(pkg):
     assert [t for t, _ in out] == ["XF", "NM"]  # in front of GS, the first larger binary tag ("SG" > "FX")
     calls3, _, _ = assignumis.record_tag_sets(scan, None, None, gene=(None, None, None))
     assert not any(t in ("XF", "GE", "GS") for t, _ in calls3)
+
+
+def test_loader_refuses_a_map_whose_bin_would_be_a_tree(pkg):
+    """java.util.HashMap turns a bin of 8 entries into a red-black tree (ordered by hash, then identityHashCode): the iteration order of such a
+    map is not modelled, so the loader refuses the annotation instead of guessing (as tools/jvm_natives.py does when the fixtures are made)"""
+    from sicelore_amd import lib as libmod
+
+    def jhash(s):
+        h = 0
+        for ch in s:
+            h = (31 * h + ord(ch)) & 0xFFFFFFFF
+        return h
+
+    # nine gene names whose spread hashes fall into one bin of a 16-slot table ("Aa" / "BB" blocks hash alike: equal full hashes)
+    names = []
+    for k in range(512):
+        nm = "".join("Aa" if (k >> b) & 1 else "BB" for b in range(9))
+        names.append(nm)
+    assert len({jhash(n) for n in names[:9]}) == 1
+    rows = "".join(f"{nm}\tT{i}\tchr1\t+\t{1000 * i}\t{1000 * i + 500}\t{1000 * i}\t{1000 * i + 500}\t1\t{1000 * i},\t{1000 * i + 500},\n" for i, nm in enumerate(names[:9]))
+    with pytest.raises(libmod.SmiError, match="tree"):
+        libmod.GeneTagger(rows, ["chr1"])
+    libmod.GeneTagger(rows.split("\n", 2)[2], ["chr1"])          # seven of them: modelled
