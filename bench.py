@@ -492,7 +492,7 @@ def two_pass_leg(pkg, synth, dev, dist, rank, world, wl, used, n, max_ed=1):
     planted = set(used.cpu().numpy().astype(np.uint64).tolist())
     out = {"reads_per_rank": n, "ranks": world, "pass1_reads": chunk_reads, "pass1_ms": (t1 - t0) * 1e3,
            "exchange_finalize_broadcast_ms": (t2 - t1) * 1e3, "allreduce_ms": allreduce_ms, "allreduce_bytes": int(keys.size * 4),
-           "backend": "nccl (RCCL)" if dist is not None else "none (1 rank)", "used_list": int(k.size),
+           "backend": (dist.get_backend() if dist is not None else "none (1 rank)"), "used_list": int(k.size),
            "used_list_planted_frac": float(np.mean([int(x) in planted for x in k])) if k.size else 0.0,
            "same_used_list_on_all_ranks": same, "pass2_ms": (t4 - t3) * 1e3, "pass2_records_out": int(info["n_records_out"]),
            "pass2_passed": int(info["n_passed"]), "pass2_assigned": int(ok.sum()), "assigned_tsv_rows": len(rows) - 1,
@@ -778,6 +778,10 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible (the hot path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    if os.environ.get("SMI_BENCH_SHARE_GPU"):
+        # rehearsal of the N-rank launch on a box with fewer GPUs than ranks (use with --backend gloo: RCCL refuses two ranks on one
+        # device): rank r runs on device r mod device_count.  Not a measurement mode.
+        os.environ["LOCAL_RANK"] = str(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -868,11 +872,12 @@ def main():
     found = (out[:n, 2] & 0xFF) == 1
     n_found = int(found.sum().item())
     acc = float(((out[:n, 0].to(torch.int64) & 0xFFFFFFFF)[found] == truth[:n][found]).float().mean().item()) if n_found else 0.0
-    n_all = n * world
-    if strong and dist is not None:
-        t = torch.tensor([n], dtype=torch.int64, device=dev)
+    n_all, found_all = n * world, n_found
+    if dist is not None:
+        # job-wide counts (outside the timed region): reads in all (strong scaling: the shards differ by at most one chunk) and assigned reads
+        t = torch.tensor([n, n_found], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        n_all = int(t.item())
+        n_all, found_all = int(t[0].item()), int(t[1].item())
     elif strong:
         n_all = n
 
@@ -935,6 +940,7 @@ def main():
             "adapter_found_frac": n_adapter / max(n, 1),
             "bc_assigned_frac": n_found / max(n, 1),
             "bc_assigned_accuracy": acc,
+            "bc_assigned_total": found_all,
         },
         "roofline": dict({"bound": "hbm" if dom is f_bc1 else "valu-issue (the HBM figures are what the contract asks for; the binding resource "
                                    "of this kernel is integer VALU issue, in `valu_issue`)"}, **dom,

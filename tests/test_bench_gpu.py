@@ -11,8 +11,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*args):
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _run(*args, env=None):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, **(env or {})))
     assert p.returncode == 0, p.stderr[-2000:]
     line = p.stdout.strip().splitlines()[-1]
     return json.loads(line)
@@ -49,3 +50,22 @@ def test_bench_config4_small():
     _common(d, 2)
     assert d["config"]["whitelist"] == 737_280 and d["config"]["bc_assigned_frac"] > 0.4 and d["config"]["bc_assigned_accuracy"] > 0.9
     assert d["umi"]["pairs_per_s"] > 0
+
+
+def test_bench_two_ranks_on_one_gpu_weak_and_strong():
+    """the N-rank launch (bench.py starts its ranks itself), sharding, barriers, max-over-ranks timing and both exchanges of the two-pass leg
+    on the GPU with two ranks that share the box's one device (SMI_BENCH_SHARE_GPU, gloo: RCCL refuses two ranks on one device) --
+    a rehearsal of the driver's multi-GPU run, not a measurement"""
+    small = ["--whitelist", "400000", "--steps", "2", "--warmup", "1", "--e2e-reads", "0", "--umi-molecules", "0", "--h2h-reads", "0",
+             "--f2f-reads", "0", "--two-pass-reads", "20000"]
+    two = ["--gpus", "2", "--backend", "gloo"]
+    env = {"SMI_BENCH_SHARE_GPU": "1"}
+    w = _run("--reads", "200000", *small, *two, env=env)
+    assert w["n_gpus"] == 2 and w["scaling"] == "weak" and w["config"]["reads_total"] == 400_000 and w["value"] > 0
+    assert w["two_pass"]["ranks"] == 2 and w["two_pass"]["same_used_list_on_all_ranks"] is True and w["two_pass"]["backend"] == "gloo"
+    assert w["two_pass"]["assigned_tsv_total"] >= w["two_pass"]["pass2_assigned"]          # counters summed over both ranks
+    st = _run("--total-reads", "2000000", *small, *two, env=env)
+    assert st["n_gpus"] == 2 and st["scaling"] == "strong" and st["config"]["reads_total"] == 2_000_000 and st["config"]["reads_per_gpu"] == 1_000_000
+    one = _run("--total-reads", "2000000", *small)
+    # the same reads whatever the world size: the number of assigned reads of the whole job is identical
+    assert one["scaling"] == "strong" and one["config"]["bc_assigned_total"] == st["config"]["bc_assigned_total"] > 1_000_000
