@@ -282,12 +282,21 @@ def umi_stage_leg(pkg, synth, ctx, used, n_mol, copies=6, genes_per=10):
                       "(groups <= 100 reads; larger ones on the host), K-UTAG; host arrays in, tags out"}
 
 
-def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=8, threads=4):
+def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=2, threads=None):
     """pass 2 of one chunk from host FASTQ text to host `passed` / `failed` text through the PACKED boundary (bit-planes up, decisions down,
     records written by host threads): what a JNI host obtains, PCIe and host cores included.  Never part of `value`."""
     import threading
 
     lib = importlib.import_module(graft.PKG_NAME + ".lib")
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        quota = None
+    if threads is None:
+        # two lanes, each with as many host threads as the process may run at once: one lane's host stages overlap the other's device side
+        # (tools/microbench.py packed sweeps lanes x threads: profiles/r03/microbench_packed.json)
+        threads = max(1, min(int(quota) if quota else 16, len(os.sched_getaffinity(0))))
     ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
     rd = synth.gen_reads(n, used, seed=9, device=dev)
     text = synth.fastq_text_device(rd)[0]
@@ -316,16 +325,11 @@ def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=8, threads=4):
         c.close()
     for pb in pins:
         pb.close()
-    try:
-        q = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
-    except Exception:
-        quota = None
     return {"reads_per_chunk": n, "lanes": lanes, "host_threads_per_lane": threads, "reads_per_s": n * lanes * per / dt, "ms_per_chunk": dt / per * 1e3,
             "text_in_bytes": total, "text_out_bytes": out_bytes, "link_bytes_per_read": "~0.7 KB up (bit-planes), ~80 B down (decisions)",
             "host_cpus_visible": len(os.sched_getaffinity(0)), "host_cpu_quota": quota,
             "note": "smi_scanfastq_pass2_chunk_packed on worker lanes of one GPU; host-bound (index, planes and records are written by the host's "
-                    "cores): ~1 M reads/s per core on this box, against 14.5 M reads/s for the text worker, which the link bounds"}
+                    "cores): ~1.2 M reads/s per core on this box, against 14.5 M reads/s for the text worker, which the link bounds"}
 
 
 def file_to_file_leg(pkg, synth, ctx, dev, wl, used, n_reads, scratch=None, n_files=64, workers=16):

@@ -21,6 +21,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -862,8 +864,113 @@ inline HostPlan plan_record_host(const WriteJob &J, size_t i) {  // plan_record 
     return R;
 }
 
+// The writer's own sink: the scratch behind it always has room for the longest suffix there is (< 300 characters: every field is a
+// bounded integer, 16 + 16 barcode letters, 43 window letters), so nothing is checked per character; integers two digits per step, barcodes
+// four letters per step.  Same interface as NameSink, so it runs through the same append_name_suffix as the device writer.
+struct DigitPairs {
+    char t[200];
+    DigitPairs() {
+        for (int i = 0; i < 100; i++) t[2 * i] = (char)('0' + i / 10), t[2 * i + 1] = (char)('0' + i % 10);
+    }
+};
+const DigitPairs g_digit_pairs;
+struct KmerQuads {  // TWOBIT_TO_BASE_ARRAY (A G C T), four bases per byte of the key, first base in the top bits
+    uint32_t t[256];
+    KmerQuads() {
+        const char L[4] = {'A', 'G', 'C', 'T'};
+        for (int b = 0; b < 256; b++) {
+            char c[4] = {L[(b >> 6) & 3], L[(b >> 4) & 3], L[(b >> 2) & 3], L[b & 3]};
+            std::memcpy(&t[b], c, 4);
+        }
+    }
+};
+const KmerQuads g_kmer_quads;
+
+struct HostSink {
+    static constexpr bool kFastKmer = true;
+    char *p;
+    int n;
+    inline void put(char c) { p[n++] = c; }
+    inline void puts(const char *s) {
+        const size_t k = __builtin_strlen(s);  // a constant for the literals this is called with
+        std::memcpy(p + n, s, k);
+        n += (int)k;
+    }
+    inline void put_u32(uint32_t v) {
+        if (v < 10u) {
+            p[n++] = (char)('0' + v);
+            return;
+        }
+        char t[10];
+        int k = 10;
+        while (v >= 100u) {
+            const uint32_t q = v / 100u, r = v - q * 100u;
+            k -= 2;
+            std::memcpy(t + k, g_digit_pairs.t + 2 * r, 2);
+            v = q;
+        }
+        if (v >= 10u) {
+            k -= 2;
+            std::memcpy(t + k, g_digit_pairs.t + 2 * v, 2);
+        } else
+            t[--k] = (char)('0' + v);
+        std::memcpy(p + n, t + k, 10 - k);
+        n += 10 - k;
+    }
+    inline void put_i32(int v) {
+        if (v < 0) {
+            p[n++] = '-';
+            put_u32(0u - (uint32_t)v);
+        } else
+            put_u32((uint32_t)v);
+    }
+    inline void put_u64(unsigned long long v) {
+        char t[20];
+        int k = 20;
+        do {
+            t[--k] = (char)('0' + (int)(v % 10));
+            v /= 10;
+        } while (v);
+        std::memcpy(p + n, t + k, 20 - k);
+        n += 20 - k;
+    }
+    inline void put_kmer16(uint32_t key) {
+        for (int b = 3; b >= 0; b--) {
+            std::memcpy(p + n, &g_kmer_quads.t[(key >> (8 * b)) & 0xFFu], 4);
+            n += 4;
+        }
+    }
+};
+
+// the X= / Q= window of a record, read where the text has it: X= is the window without its first stranded character, Q= sums all of it
+struct HostSeqWindow {
+    static constexpr bool kBulk = true;
+    const uint8_t *raw;  // the fragment's bases
+    inline char operator()(int) const { return 0; }  // (never used: bulk_x below)
+    template <class Sink>
+    inline void bulk_x(Sink &s, const NameWindow &nw) const {
+        const int m = nw.n_chars - 1;
+        char *o = s.p + s.n;
+        if (!nw.rev)
+            std::memcpy(o, raw + nw.lo + 1, (size_t)m);
+        else  // stranded character k = complement of raw[lo + n_chars - 1 - k], k = 1 .. n_chars - 1
+            for (int j = 0; j < m; j++) o[j] = rc_char(raw[nw.lo + m - 1 - j]);
+        s.n += m;
+    }
+};
+struct HostQualWindow {
+    static constexpr bool kBulk = true;
+    const uint8_t *raw;
+    inline char operator()(int) const { return 0; }
+    inline int bulk_sum(const NameWindow &nw) const {
+        int sum = 0;
+        for (int k = 0; k < nw.n_chars; k++) sum += raw[nw.lo + k];
+        return sum - 33 * nw.n_chars;
+    }
+};
+
 // fragment tag + suffix (format_record_suffix of smi_write.hip)
-inline int format_suffix_host(const WriteJob &J, const HostPlan &R, size_t i, uint32_t read_id, NameSink &s, bool *quals_set) {
+inline int format_suffix_host(const WriteJob &J, const HostPlan &R, size_t i, uint32_t read_id, HostSink &s, bool *quals_set) {
     const smi_pass2_decisions &D = *J.dec;
     if (R.frag >= 0 && R.had_blank) {
         const smi_chimera_result &ch = D.chim[R.src];
@@ -879,10 +986,8 @@ inline int format_suffix_host(const WriteJob &J, const HostPlan &R, size_t i, ui
         return NAME_OK;
     }
     const smi_scan_result &sc = D.scan[i];
-    const NameWindow nw = name_window(sc, J.five_prime != 0, R.len);
-    const uint8_t *rd = J.text + R.rd, *ql = J.text + R.ql;
-    auto seq_w = [&](int k) { return (char)rd[nw.rev ? nw.lo + nw.n_chars - 1 - k : nw.lo + k]; };
-    auto qual_w = [&](int k) { return (char)ql[nw.rev ? nw.lo + nw.n_chars - 1 - k : nw.lo + k]; };
+    const HostSeqWindow seq_w{J.text + R.rd};
+    const HostQualWindow qual_w{J.text + R.ql};
     return append_name_suffix(s, sc, &D.bc[i], D.rank ? D.rank[i] : 0, read_id, J.five_prime != 0, R.len, seq_w, qual_w, quals_set);
 }
 
@@ -1035,7 +1140,35 @@ struct alignas(128) ThreadOut {  // (aligned: neighbouring threads' state must n
     std::vector<uint8_t> flags;     // 1 passed, 2 quals_set
     uint64_t tot[2] = {0, 0};       // bytes passed / failed
     uint32_t err = 0;
+    // grow-only: a chunk worker calls the writer once per chunk with about the same record count, and a fresh 20 MB vector per thread and
+    // call is 20 MB of zero-fill and page faults per thread and call
+    void reset(size_t n_rec) {
+        if (sfx.size() < n_rec * 192 + kSuffixCapHost + 64) sfx.resize(n_rec * 192 + kSuffixCapHost + 64);
+        if (sfx_off.size() < n_rec + 1) sfx_off.resize(n_rec + 1);
+        if (bytes.size() < n_rec) bytes.resize(n_rec);
+        if (flags.size() < n_rec) flags.resize(n_rec);
+        tot[0] = tot[1] = 0;
+        err = 0;
+    }
 };
+
+// per-thread scratch kept between calls (several lanes may write at once: each call takes its own set)
+struct ScratchPool {
+    std::mutex mu;
+    std::vector<std::unique_ptr<ThreadOut>> idle;
+    std::unique_ptr<ThreadOut> take() {
+        std::lock_guard<std::mutex> g(mu);
+        if (idle.empty()) return std::unique_ptr<ThreadOut>(new ThreadOut());
+        std::unique_ptr<ThreadOut> t = std::move(idle.back());
+        idle.pop_back();
+        return t;
+    }
+    void give(std::unique_ptr<ThreadOut> t) {
+        std::lock_guard<std::mutex> g(mu);
+        if (idle.size() < 256) idle.push_back(std::move(t));
+    }
+};
+ScratchPool g_scratch;
 
 }  // namespace
 
@@ -1058,7 +1191,14 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
     const WriteJob J{text, recs, offsets, dec, first_read_id, cfg->five_prime, cfg->trim_fastq};
     const int nt = clamp_threads(n_threads, m, 128);
     const int level = simd_level();
-    std::vector<ThreadOut> TO((size_t)nt);
+    std::vector<std::unique_ptr<ThreadOut>> TO((size_t)nt);
+    for (auto &t : TO) t = g_scratch.take();
+    struct GiveBack {
+        std::vector<std::unique_ptr<ThreadOut>> &v;
+        ~GiveBack() {
+            for (auto &t : v) g_scratch.give(std::move(t));
+        }
+    } give_back{TO};
     std::vector<uint64_t> n_passed((size_t)nt + 1, 0), base_p((size_t)nt + 1, 0), base_f((size_t)nt + 1, 0);
     std::atomic<uint32_t> err{0};
     const bool timing = std::getenv("SMI_PK_TIMING") != nullptr;
@@ -1078,11 +1218,8 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
         for (int u = 1; u <= t; u++) ord += n_passed[u];
         stamp(t, 1);
         // 2. suffixes and record lengths
-        ThreadOut &O = TO[t];
-        O.sfx.resize((hi - lo) * 192 + kSuffixCapHost + 64);
-        O.sfx_off.resize(hi - lo + 1);
-        O.bytes.resize(hi - lo);
-        O.flags.resize(hi - lo);
+        ThreadOut &O = *TO[t];
+        O.reset(hi - lo);
         size_t at = 0;
         constexpr size_t kAheadFmt = 6;  // the formatter reads ~3 cache lines per record that nothing else has touched: ask for them early
         for (size_t i = lo; i < hi; i++) {
@@ -1104,7 +1241,7 @@ extern "C" int smi_fastq_write_host(const uint8_t *text, const smi_fastq_record 
             }
             const HostPlan R = plan_record_host(J, i);
             if (at + kSuffixCapHost + 64 > O.sfx.size()) O.sfx.resize(O.sfx.size() * 2 + kSuffixCapHost);
-            NameSink s{O.sfx.data() + at, 0, kSuffixCapHost};
+            HostSink s{O.sfx.data() + at, 0};
             bool quals_set = true;
             const int st = format_suffix_host(J, R, i, first_read_id + (uint32_t)ord, s, &quals_set);
             if (st == NAME_RANGE) O.err |= SMI_WR_NAME_RANGE;

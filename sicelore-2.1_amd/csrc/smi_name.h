@@ -5,6 +5,7 @@
 // library calls, so the same code runs in a kernel.
 #pragma once
 #include <cstdint>
+#include <type_traits>
 
 #include "sicelore_mi.h"
 
@@ -118,6 +119,17 @@ SMI_HD char rc_char(unsigned char c) {
 #endif
 }
 
+// Optional bulk hooks a host sink / window may offer (the device formats character by character out of registers): a sink that
+// declares `kFastKmer` has put_kmer16(key); a window functor that declares `kBulk` has bulk_x(sink, window) / bulk_sum(window)
+template <class T, class = void>
+struct has_fast_kmer : std::false_type {};
+template <class T>
+struct has_fast_kmer<T, std::void_t<decltype(T::kFastKmer)>> : std::true_type {};
+template <class T, class = void>
+struct has_bulk : std::false_type {};
+template <class T>
+struct has_bulk<T, std::void_t<decltype(T::kBulk)>> : std::true_type {};
+
 // new DecimalFormat("##.#").format((double) f) (L36, L270): HALF_EVEN on the exact decimal value, at most one fraction
 // digit, no integer digit in front of a fraction when it is zero
 template <class Sink>
@@ -180,6 +192,10 @@ SMI_HD void put_base36(Sink &s, uint32_t v) {  // FastqRecordExt$NumberToAndFrom
 
 template <class Sink>
 SMI_HD void put_kmer16(Sink &s, uint32_t key) {  // TWOBIT_TO_BASE_ARRAY: A G C T
+    if constexpr (has_fast_kmer<Sink>::value) {
+        s.put_kmer16(key);
+        return;
+    }
     for (int i = 15; i >= 0; i--) {
         const uint32_t b = (key >> (2 * i)) & 3u;
         s.put(b == 0 ? 'A' : (b == 1 ? 'G' : (b == 2 ? 'C' : 'T')));
@@ -277,18 +293,26 @@ SMI_HD int append_name_suffix(Sink &s, const smi_scan_result &scan, const smi_bc
     }
     s.puts("X=");
     // constant trip counts with a guard: unrolled on the device, where the window sits in registers
+    if constexpr (has_bulk<SeqAt>::value)
+        seq_w.bulk_x(s, nw);
+    else {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 1; k < kNameWindowMax; k++)
-        if (k < nw.n_chars) s.put(rev ? rc_char((unsigned char)seq_w(k)) : (char)seq_w(k));
+        for (int k = 1; k < kNameWindowMax; k++)
+            if (k < nw.n_chars) s.put(rev ? rc_char((unsigned char)seq_w(k)) : (char)seq_w(k));
+    }
     s.puts("_Q=");
     int sum = 0;
+    if constexpr (has_bulk<QualAt>::value)
+        sum = qual_w.bulk_sum(nw);
+    else {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
 #endif
-    for (int k = 0; k < kNameWindowMax; k++)
-        if (k < nw.n_chars) sum += (int)(unsigned char)qual_w(k) - 33;
+        for (int k = 0; k < kNameWindowMax; k++)
+            if (k < nw.n_chars) sum += (int)(unsigned char)qual_w(k) - 33;
+    }
     put_dec1(s, (float)((double)sum / (double)nw.n_chars));
     s.put('_');
     put_base36(s, read_id);

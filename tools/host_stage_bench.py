@@ -69,7 +69,7 @@ def main():
     pstart_buf = np.zeros(nrec + 8, dtype=np.uint32)
     fw = int(L.smi_packed_planes_words(total, 32))
     fused_np = np.zeros(fw, dtype=np.uint32)
-    for nt in (1, 4, 8, 12, 16, 24, 32):
+    for nt in [int(x) for x in os.environ.get("SMI_HSB_THREADS", "1,4,8,12,16,24,32").split(",")]:
         r = {}
         r["index_pack_one_pass_ms"] = best(lambda: L.smi_fastq_index_pack_host(text_np.ctypes.data, total, recs_buf.ctypes.data, offs_buf.ctypes.data,
                                                                                 pstart_buf.ctypes.data, nrec + 4, fused_np.ctypes.data, fw, ctypes.byref(pk),
