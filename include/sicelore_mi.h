@@ -697,6 +697,14 @@ int smi_bgzf_uncompressed_size(const uint8_t *in, size_t n_in, size_t *n_out, si
 /* inflates every complete block (CRC32 and ISIZE checked, as BlockCompressedInputStream does) on n_threads threads */
 int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, size_t *consumed,
                      int n_threads);
+/* K-DEFLATE: the `--compress` writer of scanfastq (FastqWriterThreadPool.java:L242-257: a GZIPOutputStream per passed / failed file;
+ * quickrun-2.1.sh:35) on the device.  d_in[0 .. n_bytes) (device) -> d_out (device, at least smi_deflate_bound(n_bytes) bytes): ONE gzip
+ * member (RFC 1952; raw_deflate != 0: the bare RFC 1951 stream) that any inflater reads back to the input: dynamic-Huffman blocks of
+ * 64 KiB, literals only, each closed by an empty stored block, CRC-32 and ISIZE in the trailer.  Concatenated members are a valid .gz
+ * file.  d_total (device, two 8-byte words): [0] = bytes written, [1] = error flags (0 = none).  Asynchronous on `stream`. */
+size_t smi_deflate_bound(size_t n_bytes);
+int smi_gzip_device(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *d_out, size_t out_cap, uint64_t *d_total, int raw_deflate,
+                    void *stream);
 /* plain (multi-member) gzip, the *.fastq.gz inputs of scanfastq (FastqFileReader.java:L138-150 via GZIPInputStream); out ==
  * NULL: only the inflated size is returned in *n_out */
 int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out);

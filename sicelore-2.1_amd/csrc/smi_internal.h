@@ -153,6 +153,8 @@ struct smi_ctx {
     smi_scan_stats host_stats = {};  // scan statistics of the last packed pass-2 chunk (want_results)
     void *umi_dist = nullptr;      // K-UMI matrices of the device UMI stage (smi_assignumis_chunk), grow-only
     size_t umi_dist_bytes = 0;
+    void *deflate_scratch = nullptr;  // K-DEFLATE: block slots, sizes, offsets, scan storage (grow-only)
+    size_t deflate_scratch_bytes = 0;
     void *host_buf[HB_COUNT] = {};
     size_t host_buf_bytes[HB_COUNT] = {};
 };
@@ -205,4 +207,10 @@ __host__ __device__ inline size_t plane_start(uint64_t base_offset, size_t r) { 
 int launch_ends_from_planes(smi_ctx *ctx, const uint32_t *d_planes, size_t stride, const uint64_t *d_read_offsets, const uint64_t *d_rec_offsets,
                             const uint32_t *d_frag_src, size_t m, uint32_t *d_ends, int32_t *d_len, hipStream_t s, const uint32_t *d_pstart = nullptr);
 int ensure_host_buf(smi_ctx *ctx, int which, size_t bytes);
+// K-DEFLATE (smi_deflate.hip): d_in -> one gzip member / raw deflate stream in d_out; d_total[0] = its size, d_total[1] = error flags (device)
+size_t deflate_bound(size_t n_bytes);
+size_t deflate_scratch_bytes(size_t n_bytes);
+int launch_deflate(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *d_out, size_t out_cap, uint8_t *d_scratch, uint64_t *d_total, int gzip,
+                   hipStream_t s);
+int ensure_deflate_scratch(smi_ctx *ctx, size_t n_bytes);
 }  // namespace smi

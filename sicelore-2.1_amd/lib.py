@@ -58,7 +58,7 @@ EXPORTS = [
     "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
-    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv",
+    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device",
 ]
 
 
@@ -141,6 +141,9 @@ def load_library():
     lib.smi_scanfastq_pass2_chunk_packed.argtypes = [vp, vp, sz, vp, ci, vp]
     lib.smi_scanfastq_pass1_chunk_packed.argtypes = [vp, vp, sz, ci, ci, vp, ci, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32)]
     lib.smi_ends_from_planes_device.argtypes = [vp, vp, vp, sz, ctypes.c_uint64, vp, vp, sz, vp, vp, vp]
+    lib.smi_deflate_bound.argtypes = [sz]
+    lib.smi_deflate_bound.restype = sz
+    lib.smi_gzip_device.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_int, vp]
     lib.smi_packed_planes_words.argtypes = [sz, ci]
     lib.smi_packed_planes_words.restype = sz
     lib.smi_fastq_index_pack_host.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
@@ -909,6 +912,22 @@ class Context:
         self._check(self._lib.smi_ends_from_planes_device(self._h, _ptr(d_planes), _ptr(d_read_offsets), int(n_reads), int(total_bases),
                                                           _ptr(d_rec_offsets), _ptr(d_frag_src), int(n_records), _ptr(d_ends), _ptr(d_len),
                                                           _stream_ptr(stream)))
+
+    def gzip_device(self, d_in, n_bytes=None, raw_deflate=False, d_out=None, stream=None):
+        """K-DEFLATE (smi_gzip_device): a uint8 device tensor -> one gzip member (or raw deflate stream) as a uint8 device tensor view"""
+        import torch
+
+        n = int(d_in.numel() if n_bytes is None else n_bytes)
+        cap = int(self._lib.smi_deflate_bound(n))
+        if d_out is None:
+            d_out = torch.empty(cap, dtype=torch.uint8, device=d_in.device)
+        total = torch.zeros(2, dtype=torch.int64, device=d_in.device)
+        self._check(self._lib.smi_gzip_device(self._h, _ptr(d_in), n, _ptr(d_out), int(d_out.numel()), _ptr(total), 1 if raw_deflate else 0,
+                                              _stream_ptr(stream)))
+        t = total.cpu()
+        if int(t[1]):
+            raise SmiError(f"smi_gzip_device: error flags {int(t[1])}")
+        return d_out[:int(t[0])]
 
     def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
                          five_prime=False, cluster_cfg=None):

@@ -1,0 +1,81 @@
+"""K-DEFLATE (smi_gzip_device, the `--compress` writer of scanfastq on the device): every member inflates back to the input with an independent
+inflater (zlib / gzip of the Python standard library, which also checks the CRC-32 and ISIZE of the trailer) -- the encode -> decode round
+trip is the parity property of a compressor; sizes around the 64 KiB block boundary, empty input, one symbol, all 256 byte values,
+incompressible input, a frequency profile whose optimal code is deeper than 15 bits, FASTQ text at the size of a pass-2 chunk."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _roundtrip(ctx, data, raw=False):
+    dev = torch.device("cuda", ctx.device)
+    d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).to(dev) if len(data) else torch.zeros(0, dtype=torch.uint8, device=dev)
+    out = ctx.gzip_device(d_in, len(data), raw_deflate=raw).cpu().numpy().tobytes()
+    if raw:
+        back = zlib.decompress(out, wbits=-15)
+    else:
+        assert out[:4] == b"\x1f\x8b\x08\x00"
+        back = gzip.decompress(out)
+        assert int.from_bytes(out[-8:-4], "little") == zlib.crc32(data) and int.from_bytes(out[-4:], "little") == len(data) & 0xFFFFFFFF
+    assert back == data
+    return out
+
+
+def _fastq(n, seed):
+    g = np.random.default_rng(seed)
+    recs = []
+    for i in range(n):
+        m = int(g.integers(300, 1800))
+        seq = g.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=m).tobytes()
+        qual = (33 + np.clip(g.normal(18, 7, size=m), 1, 50).astype(np.uint8)).tobytes()
+        recs.append(b"@%08x-aaaa-bbbb read=%d ch=%d_FWD_PS=%d_AE=%d_bc=ACGTACGTACGTACGT_ed=1\n" % (i * 2654435761 % 2 ** 32, i, i % 512, m - 60, m - 20) + seq + b"\n+\n" + qual + b"\n")
+    return b"".join(recs)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 4095, 65535, 65536, 65537, 131072, 200001])
+def test_sizes_around_the_block_boundaries(gpu_ctx, n):
+    g = np.random.default_rng(n)
+    data = g.choice(np.frombuffer(b"ACGTN\n!5?I", dtype=np.uint8), size=n, p=[.22, .22, .22, .22, .02, .02, .02, .02, .02, .02]).tobytes()
+    out = _roundtrip(gpu_ctx, data)
+    _roundtrip(gpu_ctx, data, raw=True)
+    if n >= 4095:
+        assert len(out) < 0.45 * n        # four letters dominate: close to 2.5 bits per byte
+
+
+def test_one_symbol_all_symbols_and_incompressible_input(gpu_ctx):
+    _roundtrip(gpu_ctx, b"A" * 70_000)
+    _roundtrip(gpu_ctx, bytes(range(256)) * 300)
+    rnd = np.random.default_rng(1).integers(0, 256, size=300_000, dtype=np.uint8).tobytes()
+    out = _roundtrip(gpu_ctx, rnd)
+    assert len(out) < len(rnd) * 1.01 + 1024       # a Huffman code over uniform bytes costs 8 bits each: no blow-up
+
+
+def test_code_deeper_than_fifteen_bits_is_flattened(gpu_ctx):
+    # Fibonacci frequencies: the minimum-redundancy code of 24 such symbols is 23 bits deep; deflate allows 15
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    assert sum(fib) < 65536 + 60_000
+    blk = b"".join(bytes([65 + k]) * f for k, f in enumerate(fib))[:65536]
+    g = np.random.default_rng(3)
+    data = bytes(g.permutation(np.frombuffer(blk, dtype=np.uint8)))
+    _roundtrip(gpu_ctx, data)
+    _roundtrip(gpu_ctx, data + b"tail of another block" * 100)
+
+
+def test_fastq_chunk_and_concatenated_members(gpu_ctx):
+    a, b = _fastq(6000, 11), _fastq(50, 12)
+    za, zb = _roundtrip(gpu_ctx, a), _roundtrip(gpu_ctx, b)
+    assert gzip.decompress(za + zb) == a + b                   # members of one .gz file (one per chunk)
+    ref = len(zlib.compress(a, 6))
+    assert len(za) < 1.25 * ref                                # literals only: within a quarter of zlib level 6 on FASTQ text
+    # an unaligned input pointer (a view into a larger device buffer)
+    dev = torch.device("cuda", gpu_ctx.device)
+    big = torch.from_numpy(np.frombuffer(b"xyz" + a, dtype=np.uint8).copy()).to(dev)
+    out = gpu_ctx.gzip_device(big[3:], len(a)).cpu().numpy().tobytes()
+    assert gzip.decompress(out) == a

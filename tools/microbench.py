@@ -35,7 +35,7 @@ def main():
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
     legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis,
-            "packed": leg_packed}
+            "packed": leg_packed, "deflate": leg_deflate}
     for name, fn in legs.items():
         if only in (None, name):
             fn(pkg, synth, ctx, dev, wl, used, res)
@@ -326,6 +326,43 @@ def leg_fastq(pkg, synth, ctx, dev, wl, used, res):
                                                "every kernel incl. the chimera splitter, D2H of both streams into the context's pinned buffers"}
     res["fastq_write"] = {"reads": n, "passed": state["tot"][2], "out_bytes": wb, "ms": dtw * 1e3, "out_GBps": wb / dtw / 1e9,
                           "reads_per_s": n / dtw}
+
+
+def leg_deflate(pkg, synth, ctx, dev, wl, used, res):
+    """K-DEFLATE on the FASTQ text of a pass-2 chunk (qualities drawn uniformly from 29 values per base, as run_files.write_synthetic_dir
+    does): GB/s of text, size against zlib level 6 and level 1 on a 64 MB sample of the same text"""
+    import zlib
+
+    n = int(os.environ.get("SMI_MB_READS", "500000"))
+    rd = synth.gen_reads(n, used, seed=9, device=dev, q_mean=20.0)
+    text = synth.fastq_text_device(rd)[0]
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    is_q = text == ord("I")
+    text[is_q] = torch.randint(35, 64, (int(is_q.sum()),), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+    del rd, is_q
+    total = int(text.numel())
+    d_out = torch.empty(int(ctx._lib.smi_deflate_bound(total)), dtype=torch.uint8, device=dev)
+    state = {}
+
+    def run():
+        state["z"] = ctx.gzip_device(text, total, d_out=d_out)
+
+    dt = timed(run, reps=5)
+    z = state["z"]
+    sample = text[:64 << 20].cpu().numpy().tobytes()
+    zs = ctx.gzip_device(text[:64 << 20].contiguous(), len(sample)).cpu().numpy().tobytes()
+    assert zlib.decompress(zs, wbits=31) == sample
+    t0 = time.perf_counter()
+    z6 = len(zlib.compress(sample, 6))
+    t6 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    z1 = len(zlib.compress(sample, 1))
+    t1 = time.perf_counter() - t0
+    res["gzip_device"] = {"text_bytes": total, "member_bytes": int(z.numel()), "ratio": total / int(z.numel()), "ms": dt * 1e3, "text_GBps": total / dt / 1e9,
+                          "sample_bytes": len(sample), "sample_member_bytes": len(zs), "sample_zlib6_bytes": z6, "sample_zlib1_bytes": z1,
+                          "size_vs_zlib6": len(zs) / z6, "zlib6_MBps_one_thread": len(sample) / t6 / 1e6, "zlib1_MBps_one_thread": len(sample) / t1 / 1e6,
+                          "note": "one call incl. the 16-byte read-back of size and flags; literals-only dynamic Huffman blocks of 64 KiB"}
 
 
 def leg_packed(pkg, synth, ctx, dev, wl, used, res):
