@@ -334,7 +334,7 @@ def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=2, threads=None):
 
 def file_to_file_leg(pkg, synth, ctx, dev, wl, used, n_reads, scratch=None, n_files=64, workers=16):
     """`scanfastq -d <dir> -o <dir> --bcEditDistance 1 --compress` (quickrun-2.1.sh:35) on n_files synthetic *.fastq.gz, both passes, gzip
-    level 6 out, wall clock from the first byte read to the last byte written (inputs in the page cache).  The README's figure for the
+    out (K-DEFLATE on the device; beside it a quarter of the files with zlib level 6 on the host), wall clock from the first byte read to the last byte written (inputs in the page cache).  The README's figure for the
     Java reference: 20.8 k reads/s on 96 cores (README.md:106)."""
     import shutil
     import tempfile
@@ -347,15 +347,25 @@ def file_to_file_leg(pkg, synth, ctx, dev, wl, used, n_reads, scratch=None, n_fi
         n = run_files.write_synthetic_dir(synth, in_dir, n_files, max(1, n_reads // n_files), used, dev, seed=9000, chimera_frac=0.05)
         t_gen = time.perf_counter() - t0
         keys = np.sort(wl.cpu().numpy().astype(np.uint64))
-        info = run_files.run(ctx, in_dir, out_dir, max_ed=1, n_workers=workers, reads_per_chunk=100_000, gz_level=6, whitelist_keys=keys)
+        info = run_files.run(ctx, in_dir, out_dir, max_ed=1, n_workers=workers, reads_per_chunk=100_000, whitelist_keys=keys, gz="device")
         info["gz_in_bytes"] = sum(os.path.getsize(os.path.join(in_dir, f)) for f in os.listdir(in_dir))
         info["generate_inputs_s"] = t_gen
         info["scratch"] = "/dev/shm (RAM)" if base.startswith("/dev/shm") else base
         info["host_cpus_visible"] = len(os.sched_getaffinity(0))
         info["reference_readme_reads_per_s"] = 20_800
-        info["note"] = ("inflate -> pass 1 (packed boundary, whole whitelist) -> finalize / rank -> pass 2 (packed boundary, used list) -> gzip level 6 of the "
-                        "passed / failed text -> files + BarcodeList.tsv + BarcodesAssigned.tsv; %d worker threads, one GPU lane each; qualities "
-                        "uniform per base (incompressible, as real ones nearly are)" % workers)
+        info["note"] = ("inflate (host zlib) with pass 1 of every inflated file behind it (text worker, whole whitelist) -> finalize / rank -> pass 2 (text worker, used list; records written "
+                        "in HBM and deflated there by K-DEFLATE, one gzip member per chunk and stream) -> files + BarcodeList.tsv + BarcodesAssigned.tsv + "
+                        "ReadScanner.tsv; %d worker threads, one GPU lane each; qualities uniform per base (incompressible, as real ones nearly are)" % workers)
+        # the same run with the output deflated by zlib level 6 on the host's threads (what round 2 could do): smaller sample, it is 5 - 10 x slower
+        shutil.rmtree(out_dir, ignore_errors=True)
+        keep = sorted(os.listdir(in_dir))[: max(1, n_files // 4)]
+        sub = os.path.join(base, "in_zlib")
+        os.makedirs(sub)
+        for f in keep:
+            os.link(os.path.join(in_dir, f), os.path.join(sub, f))
+        z = run_files.run(ctx, sub, out_dir, max_ed=1, n_workers=workers, reads_per_chunk=100_000, gz_level=6, whitelist_keys=keys, gz="zlib")
+        info["host_zlib6"] = {k: z[k] for k in ("files", "reads", "wall_s", "reads_per_s", "inflate_and_pass1_s", "pass2_and_gzip_s", "gz_out_bytes",
+                                                 "text_out_bytes")}
         assert info["reads"] == n
         return info
     finally:

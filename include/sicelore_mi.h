@@ -521,7 +521,8 @@ typedef struct {
     int32_t trim_fastq;          /* -u */
     int32_t want_results;        /* 1: per-record scan / barcode results are returned as well */
     uint32_t first_read_id;      /* id of the first passed record of this chunk (READCOUNTER + 1) */
-    uint32_t reserved;
+    uint32_t compress;           /* --compress: 1 = `passed` / `failed` come back as ONE gzip member each (K-DEFLATE, smi_gzip_device) instead of
+                                  * text; the members of a file's chunks, written one after the other, are its .fastq.gz.  Text worker only */
     const uint64_t *rank_keys;   /* used list of pass 1, sorted ascending, or NULL (-g mode): rk= field */
     const int32_t *rank_values;
     size_t n_ranks;
@@ -535,6 +536,7 @@ typedef struct {
     uint32_t fastq_errors;          /* SMI_FQ_* (the call fails when non-zero) */
     uint32_t reserved;
     const void *stats;              /* smi_scan_stats of this chunk (packed worker with want_results; NULL otherwise); owned by the context */
+    size_t passed_text_bytes, failed_text_bytes; /* size of the FASTQ text (= passed_bytes / failed_bytes unless cfg->compress) */
 } smi_pass2_output;
 /* page-locked host memory for the text handed to the workers (uploads at link speed); freed with smi_host_free */
 int smi_host_alloc(size_t bytes, void **out);

@@ -518,8 +518,8 @@ int launch_deflate(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *d
     return SMI_OK;
 }
 
-int ensure_deflate_scratch(smi_ctx *ctx, size_t n_bytes) {
-    const size_t want = deflate_scratch_bytes(n_bytes);
+int ensure_deflate_scratch(smi_ctx *ctx, size_t n_bytes, size_t extra_bytes) {
+    const size_t want = deflate_scratch_bytes(n_bytes) + extra_bytes;
     if (ctx->deflate_scratch_bytes >= want) return SMI_OK;
     if (ctx->deflate_scratch) SMI_HIP(hipFree(ctx->deflate_scratch));
     ctx->deflate_scratch = nullptr;
@@ -528,6 +528,20 @@ int ensure_deflate_scratch(smi_ctx *ctx, size_t n_bytes) {
     SMI_HIP(hipMalloc(&ctx->deflate_scratch, grown));
     ctx->deflate_scratch_bytes = grown;
     return SMI_OK;
+}
+
+int deflate_pair(smi_ctx *ctx, const uint8_t *d_a, size_t na, const uint8_t *d_b, size_t nb, uint8_t **d_za, uint8_t **d_zb, uint64_t **d_totals,
+                 hipStream_t s) {
+    const size_t ca = (deflate_bound(na) + 255) & ~(size_t)255, cb = (deflate_bound(nb) + 255) & ~(size_t)255;
+    const size_t work = (deflate_scratch_bytes(std::max(na, nb)) + 255) & ~(size_t)255;
+    if (int rc = ensure_deflate_scratch(ctx, std::max(na, nb), ca + cb + 1024)) return rc;
+    uint8_t *base = static_cast<uint8_t *>(ctx->deflate_scratch);
+    *d_za = base + work;
+    *d_zb = base + work + ca;
+    *d_totals = reinterpret_cast<uint64_t *>(base + work + ca + cb);
+    // the two members share the block slots: same stream, one after the other
+    if (int rc = launch_deflate(ctx, d_a, na, *d_za, ca, base, *d_totals, 1, s)) return rc;
+    return launch_deflate(ctx, d_b, nb, *d_zb, cb, base, *d_totals + 2, 1, s);
 }
 
 }  // namespace smi
@@ -542,7 +556,7 @@ extern "C" int smi_gzip_device(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes
         return SMI_ERR_INVALID;
     }
     SMI_HIP(hipSetDevice(ctx->device));
-    if (int rc = ensure_deflate_scratch(ctx, n_bytes)) return rc;
+    if (int rc = ensure_deflate_scratch(ctx, n_bytes, 0)) return rc;
     return launch_deflate(ctx, d_in, n_bytes, d_out, out_cap, static_cast<uint8_t *>(ctx->deflate_scratch), d_total, raw_deflate ? 0 : 1,
                           (hipStream_t)stream);
 }

@@ -212,5 +212,8 @@ size_t deflate_bound(size_t n_bytes);
 size_t deflate_scratch_bytes(size_t n_bytes);
 int launch_deflate(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *d_out, size_t out_cap, uint8_t *d_scratch, uint64_t *d_total, int gzip,
                    hipStream_t s);
-int ensure_deflate_scratch(smi_ctx *ctx, size_t n_bytes);
+int ensure_deflate_scratch(smi_ctx *ctx, size_t n_bytes, size_t extra_bytes = 0);
+// two buffers -> two gzip members in the context's deflate scratch (behind the block slots); d_totals: [size a, flags a, size b, flags b]
+int deflate_pair(smi_ctx *ctx, const uint8_t *d_a, size_t na, const uint8_t *d_b, size_t nb, uint8_t **d_za, uint8_t **d_zb, uint64_t **d_totals,
+                 hipStream_t s);
 }  // namespace smi

@@ -174,6 +174,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     const uint64_t *d_rec_offs = d_offs;
     smi_chimera_result *d_chim = nullptr;
     uint32_t *d_fsrc = nullptr;
+    std::vector<smi_chimera_result> h_chim;
     if (split) {
         uint32_t *d_planes = A.take<uint32_t>(planes_words);
         d_chim = A.take<smi_chimera_result>(cap);
@@ -187,7 +188,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         SMI_RC(smi_chimera_device(ctx, d_planes, d_offs, n, total, &cc, d_chim, s));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
         uint64_t nf = 0;
-        std::vector<smi_chimera_result> h_chim(n);
+        h_chim.resize(n);
         SMI_HIP(hipMemcpyAsync(&nf, d_nfrag, 8, hipMemcpyDeviceToHost, s));
         SMI_HIP(hipMemcpyAsync(h_chim.data(), d_chim, n * sizeof(smi_chimera_result), hipMemcpyDeviceToHost, s));
         SMI_HIP(hipStreamSynchronize(s));
@@ -238,17 +239,38 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     SMI_RC(smi_fastq_write_text_device(ctx, d_text, d_line, d_bstart, d_qstart, d_rec_offs, split ? d_fsrc : nullptr,
                                        split ? d_chim : nullptr, d_scan, d_bc, d_rank, m, cfg->first_read_id, &wc, d_passed, out_cap, d_failed,
                                        out_cap, d_roff, d_isp, totals, &werr, s));
+    out->passed_text_bytes = totals[0];
+    out->failed_text_bytes = totals[1];
+    const uint8_t *d_src[2] = {d_passed, d_failed};
+    uint64_t down[2] = {totals[0], totals[1]};
+    if (cfg->compress) {
+        // --compress: the two texts become one gzip member each where they lie; only the members cross the link
+        uint8_t *d_z[2] = {nullptr, nullptr};
+        uint64_t *d_zt = nullptr;
+        SMI_RC(deflate_pair(ctx, d_passed, totals[0], d_failed, totals[1], &d_z[0], &d_z[1], &d_zt, s));
+        uint64_t zt[4] = {0, 0, 0, 0};
+        SMI_HIP(hipMemcpyAsync(zt, d_zt, sizeof zt, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        if (zt[1] | zt[3]) {
+            set_error("smi_scanfastq_pass2_chunk: K-DEFLATE reported an error (a block outgrew its slot)");
+            return SMI_ERR_INVALID;
+        }
+        d_src[0] = d_z[0];
+        d_src[1] = d_z[1];
+        down[0] = zt[0];
+        down[1] = zt[2];
+    }
     for (int k = 0; k < 2; k++)  // pinned, grow-only: the download runs at link speed and nothing is zero-filled
-        if (ctx->host_out_bytes[k] < totals[k]) {
+        if (ctx->host_out_bytes[k] < down[k]) {
             if (ctx->host_out[k]) SMI_HIP(hipHostFree(ctx->host_out[k]));
             ctx->host_out[k] = nullptr;
             ctx->host_out_bytes[k] = 0;
-            const size_t want = totals[k] + totals[k] / 4 + 4096;
+            const size_t want = down[k] + down[k] / 4 + 4096;
             SMI_HIP(hipHostMalloc((void **)&ctx->host_out[k], want, hipHostMallocDefault));
             ctx->host_out_bytes[k] = want;
         }
-    if (totals[0]) SMI_HIP(hipMemcpyAsync(ctx->host_out[0], d_passed, totals[0], hipMemcpyDeviceToHost, s));
-    if (totals[1]) SMI_HIP(hipMemcpyAsync(ctx->host_out[1], d_failed, totals[1], hipMemcpyDeviceToHost, s));
+    if (down[0]) SMI_HIP(hipMemcpyAsync(ctx->host_out[0], d_src[0], down[0], hipMemcpyDeviceToHost, s));
+    if (down[1]) SMI_HIP(hipMemcpyAsync(ctx->host_out[1], d_src[1], down[1], hipMemcpyDeviceToHost, s));
     if (cfg->want_results) {
         ctx->host_scan.resize(m);
         ctx->host_bc.resize(m);
@@ -257,11 +279,35 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         out->scan = ctx->host_scan.data();
         out->bc = ctx->host_bc.data();
     }
+    std::vector<uint64_t> h_foffs;
+    std::vector<uint32_t> h_fsrc;
+    if (cfg->want_results) {  // what the statistics need beside scan / bc: where each output record came from
+        h_foffs.resize(m + 1);
+        SMI_HIP(hipMemcpyAsync(h_foffs.data(), d_rec_offs, (m + 1) * 8, hipMemcpyDeviceToHost, s));
+        if (split) {
+            h_fsrc.resize(m);
+            SMI_HIP(hipMemcpyAsync(h_fsrc.data(), d_fsrc, m * 4, hipMemcpyDeviceToHost, s));
+        }
+    }
     SMI_HIP(hipStreamSynchronize(s));
+    if (cfg->want_results) {
+        smi_pass2_decisions dec;
+        std::memset(&dec, 0, sizeof dec);
+        dec.n_records_in = n;
+        dec.n_records_out = m;
+        dec.chim = split ? h_chim.data() : nullptr;
+        dec.frag_offsets = h_foffs.data();
+        dec.frag_src = split ? h_fsrc.data() : nullptr;
+        dec.scan = ctx->host_scan.data();
+        dec.bc = ctx->host_bc.data();
+        std::memset(&ctx->host_stats, 0, sizeof ctx->host_stats);  // ReadFlags.addForCounting over the chunk
+        SMI_RC(smi_scan_stats_add(&ctx->host_stats, &dec));
+        out->stats = &ctx->host_stats;
+    }
     out->passed = ctx->host_out[0];
     out->failed = ctx->host_out[1];
-    out->passed_bytes = totals[0];
-    out->failed_bytes = totals[1];
+    out->passed_bytes = down[0];
+    out->failed_bytes = down[1];
     out->n_passed = totals[2];
     return SMI_OK;
 }
@@ -509,6 +555,10 @@ extern "C" int smi_scanfastq_pass2_chunk_packed(smi_ctx *ctx, const uint8_t *tex
         return SMI_ERR_INVALID;
     }
     std::memset(out, 0, sizeof *out);
+    if (cfg->compress) {
+        set_error("smi_scanfastq_pass2_chunk_packed: compress is an option of the text worker (the packed worker's records are written by the host)");
+        return SMI_ERR_INVALID;
+    }
     if (n_bytes == 0) return SMI_OK;
     const bool timing = std::getenv("SMI_PK_TIMING") != nullptr;  // the stages of this call on stderr
     double ms_index = 0;
@@ -567,8 +617,8 @@ extern "C" int smi_scanfastq_pass2_chunk_packed(smi_ctx *ctx, const uint8_t *tex
     }
     out->passed = ctx->host_out[0];
     out->failed = ctx->host_out[1];
-    out->passed_bytes = totals[0];
-    out->failed_bytes = totals[1];
+    out->passed_bytes = out->passed_text_bytes = totals[0];
+    out->failed_bytes = out->failed_text_bytes = totals[1];
     out->n_passed = totals[2];
     return SMI_OK;
 }

@@ -579,7 +579,7 @@ class Pass2Config(ctypes.Structure):
     """smi_pass2_config"""
     _fields_ = [("max_ed", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("dont_search_polya", ctypes.c_int32),
                 ("split_chimeras", ctypes.c_int32), ("trim_fastq", ctypes.c_int32), ("want_results", ctypes.c_int32),
-                ("first_read_id", ctypes.c_uint32), ("reserved", ctypes.c_uint32), ("rank_keys", ctypes.c_void_p),
+                ("first_read_id", ctypes.c_uint32), ("compress", ctypes.c_uint32), ("rank_keys", ctypes.c_void_p),
                 ("rank_values", ctypes.c_void_p), ("n_ranks", ctypes.c_size_t)]
 
 
@@ -588,7 +588,8 @@ class Pass2Output(ctypes.Structure):
     _fields_ = [("passed", ctypes.c_void_p), ("failed", ctypes.c_void_p), ("passed_bytes", ctypes.c_size_t),
                 ("failed_bytes", ctypes.c_size_t), ("n_records_in", ctypes.c_size_t), ("n_records_out", ctypes.c_size_t),
                 ("n_passed", ctypes.c_size_t), ("scan", ctypes.c_void_p), ("bc", ctypes.c_void_p), ("fastq_errors", ctypes.c_uint32),
-                ("reserved", ctypes.c_uint32), ("stats", ctypes.c_void_p)]
+                ("reserved", ctypes.c_uint32), ("stats", ctypes.c_void_p), ("passed_text_bytes", ctypes.c_size_t),
+                ("failed_text_bytes", ctypes.c_size_t)]
 
 
 class ChimeraConfig(ctypes.Structure):
@@ -854,15 +855,17 @@ class Context:
 
     # ---- one native call per chunk (smi_worker.hip) ---------------------------------------------------------
     def scanfastq_pass2_chunk(self, text, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True, trim_fastq=False,
-                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True, packed=False, n_threads=4):
+                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True, packed=False, n_threads=4, compress=False):
         """host FASTQ bytes (or a numpy uint8 array, e.g. PinnedBuffer.array) -> (passed, failed, info dict); everything in
         between on the device.  copy=False returns numpy views of the context's pinned output buffers (valid until its next call).
         packed=True: smi_scanfastq_pass2_chunk_packed -- the host indexes / packs / writes on n_threads threads, the link carries
-        bit-planes up and decisions down; same bytes out"""
+        bit-planes up and decisions down; same bytes out.  compress=True (text worker): `passed` / `failed` are one gzip member each (K-DEFLATE);
+        info["passed_text_bytes"] / ["failed_text_bytes"] give the sizes of the text"""
         cfg = Pass2Config()
         self._check(self._lib.smi_pass2_default_config(ctypes.byref(cfg)))
         cfg.max_ed, cfg.five_prime, cfg.dont_search_polya = int(max_ed), int(five_prime), int(dont_search_polya)
         cfg.split_chimeras, cfg.trim_fastq, cfg.want_results, cfg.first_read_id = int(split_chimeras), int(trim_fastq), int(want_results), int(first_read_id)
+        cfg.compress = 1 if compress else 0
         keep = []
         if rank_keys is not None and len(rank_keys):
             k = np.ascontiguousarray(rank_keys, dtype=np.uint64)
@@ -882,7 +885,8 @@ class Context:
         else:
             view = lambda p, n: np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_uint8)), shape=(n,)) if n else np.zeros(0, np.uint8)  # noqa: E731
             passed, failed = view(out.passed, out.passed_bytes), view(out.failed, out.failed_bytes)
-        info = dict(n_records_in=out.n_records_in, n_records_out=out.n_records_out, n_passed=out.n_passed)
+        info = dict(n_records_in=out.n_records_in, n_records_out=out.n_records_out, n_passed=out.n_passed, passed_text_bytes=out.passed_text_bytes,
+                    failed_text_bytes=out.failed_text_bytes)
         if want_results and out.stats:
             info["stats"] = np.frombuffer(ctypes.string_at(out.stats, 8 * N_SCAN_STATS), dtype=np.uint64).copy()
         if want_results and out.n_records_out:

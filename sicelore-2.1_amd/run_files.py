@@ -106,9 +106,14 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device"):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
-    (sorted uint64), loaded for pass 1."""
+    (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
+    and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
+    "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads."""
+    if gz not in ("device", "zlib"):
+        raise ValueError("gz: 'device' or 'zlib'")
+    on_device = compress and gz == "device"
     t_all = time.perf_counter()
     files = sorted(f for f in os.listdir(in_dir) if f.endswith((".fastq", ".fq", ".fastq.gz", ".fq.gz")))
     if not files:
@@ -116,19 +121,6 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     os.makedirs(os.path.join(out_dir, "passed"), exist_ok=True)
     os.makedirs(os.path.join(out_dir, "failed"), exist_ok=True)
     pool = ThreadPoolExecutor(n_workers)
-    # ---- inflate ---------------------------------------------------------------------------------------------------------------------
-    t0 = time.perf_counter()
-    def load(f):
-        t = _inflate(os.path.join(in_dir, f))
-        return t, _cut_chunks(t, reads_per_chunk)
-
-    loaded = list(pool.map(load, files))
-    texts = [t for t, _ in loaded]
-    t_inflate = time.perf_counter() - t0
-    chunks = []  # (file index, chunk index in file, byte range)
-    for fi, (_, cuts) in enumerate(loaded):
-        for ci, rng in enumerate(cuts):
-            chunks.append((fi, ci, rng))
     lanes = [ctx] + [ctx.lane() for _ in range(n_workers - 1)]
     free = list(range(n_workers))
 
@@ -143,21 +135,36 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
 
     dev = torch.device("cuda", ctx.device)
     keys = np.ascontiguousarray(whitelist_keys, dtype=np.uint64)
-    # ---- pass 1 ----------------------------------------------------------------------------------------------------------------------
+    # ---- inflate + pass 1: a file's chunks go to the device as soon as the file is inflated (the host inflates the next one meanwhile) -----
     t0 = time.perf_counter()
     ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
     for ln in lanes[1:]:
         ln.refresh()
     hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
+    cpu_inflate = [0.0] * len(files)
 
-    def p1(lane, fi, ci, rng):
-        return lane.scanfastq_pass1_chunk(texts[fi][rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=True,
-                                          n_threads=host_threads_per_call)
+    def p1(lane, text, rng):
+        # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
+        return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
 
-    n_rec = list(pool.map(lambda c: with_lane(p1)(*c), chunks))
+    def load_and_count(fi):
+        t1 = time.perf_counter()
+        t = _inflate(os.path.join(in_dir, files[fi]))
+        cuts = _cut_chunks(t, reads_per_chunk)
+        cpu_inflate[fi] = time.perf_counter() - t1
+        return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
+
+    loaded = list(pool.map(load_and_count, range(len(files))))
     torch.cuda.synchronize()
+    texts = [t for t, _, _ in loaded]
+    chunks, n_rec = [], []  # (file index, chunk index in file, byte range); records per chunk
+    for fi, (_, cuts, recs) in enumerate(loaded):
+        for ci, rng in enumerate(cuts):
+            chunks.append((fi, ci, rng))
+        n_rec += recs
     t_pass1 = time.perf_counter() - t0
+    t_inflate = float(sum(cpu_inflate))
     # ---- finalize ----------------------------------------------------------------------------------------------------------------------
     t0 = time.perf_counter()
     # the reference's recordCount: the 10,000-read chunks FastqFileReader cuts, per input file (UsedCellBCListGenerator.java:L254)
@@ -184,17 +191,19 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         fi, ci, rng = chunks[j]
         passed, failed, info = lane.scanfastq_pass2_chunk(texts[fi][rng[0]:rng[1]], max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya,
                                                           first_read_id=int(first_id[j]), rank_keys=rk_keys, rank_values=rk_vals, want_results=True, copy=False,
-                                                          packed=True, n_threads=host_threads_per_call)
+                                                          packed=not on_device, n_threads=host_threads_per_call, compress=on_device)
         bc = info["bc"] if info["n_records_out"] else np.zeros(0, dtype=_lib.BC_RESULT_DTYPE)
         ok = bc["found"] == 1
         cnt = np.zeros((k.size, 3), dtype=np.int64)
         if ok.any():
             np.add.at(cnt, (np.searchsorted(rk_keys, bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)), 1)
-        if compress:
+        if on_device:
+            zp, zf = bytes(passed), bytes(failed)      # gzip members already
+        elif compress:
             zp, zf = _gzip_member(memoryview(passed), gz_level), _gzip_member(memoryview(failed), gz_level)
         else:
             zp, zf = bytes(passed), bytes(failed)
-        return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(passed.size), int(failed.size), info.get("stats")
+        return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(info["passed_text_bytes"]), int(info["failed_text_bytes"]), info.get("stats")
 
     results = list(pool.map(lambda j: with_lane(p2)(j), range(len(chunks))))
     t_pass2 = time.perf_counter() - t0
@@ -236,5 +245,5 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     return {"files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
             "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(t.size for t in texts)),
             "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
-            "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_s": t_inflate, "pass1_s": t_pass1, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
-            "write_files_s": t_write, "workers": n_workers, "gz_level": gz_level if compress else None}
+            "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
+            "write_files_s": t_write, "workers": n_workers, "gz": (gz if compress else None), "gz_level": gz_level if compress and not on_device else None}

@@ -79,3 +79,29 @@ def test_fastq_chunk_and_concatenated_members(gpu_ctx):
     big = torch.from_numpy(np.frombuffer(b"xyz" + a, dtype=np.uint8).copy()).to(dev)
     out = gpu_ctx.gzip_device(big[3:], len(a)).cpu().numpy().tobytes()
     assert gzip.decompress(out) == a
+
+
+def test_text_worker_with_compress_returns_the_members_of_its_text(pkg, synth, gpu_ctx):
+    """smi_scanfastq_pass2_chunk with cfg.compress: `passed` / `failed` inflate to exactly the text the same call returns without it; the
+    statistics of the chunk are those of the packed worker; the packed worker refuses the option"""
+    wl = synth.make_whitelist(20_000, seed=77)
+    used = synth.pick_used(wl, 150, seed=78)
+    reads = synth.gen_reads(700, used, seed=79, n_rate=0.002)
+    chim = synth.make_chimeras(reads, 900, seed=80)
+    text = "".join(f"@read{i} runid=x ch={i % 9}\n{c[0]}\n+\n{c[1]}\n" for i, c in enumerate(chim)).encode()
+    keys = np.sort(used.numpy().astype(np.uint64))
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    kw = dict(rank_keys=keys, rank_values=(np.arange(keys.size) % 40 + 1).astype(np.int32), first_read_id=36 ** 3, want_results=True)
+    p, f, info = gpu_ctx.scanfastq_pass2_chunk(text, **kw)
+    zp, zf, zinfo = gpu_ctx.scanfastq_pass2_chunk(text, compress=True, **kw)
+    assert gzip.decompress(bytes(zp)) == bytes(p) and gzip.decompress(bytes(zf)) == bytes(f)
+    assert (zinfo["passed_text_bytes"], zinfo["failed_text_bytes"]) == (len(p), len(f)) == (info["passed_text_bytes"], info["failed_text_bytes"])
+    assert len(zp) < 0.6 * len(p) and zinfo["n_passed"] == info["n_passed"]
+    pk = gpu_ctx.scanfastq_pass2_chunk(text, packed=True, n_threads=2, **kw)[2]
+    assert (info["stats"] == pk["stats"]).all() and (zinfo["stats"] == pk["stats"]).all() and int(pk["stats"][3]) == info["n_records_out"] > 900
+    with pytest.raises(pkg.SmiError):
+        gpu_ctx.scanfastq_pass2_chunk(text, packed=True, compress=True)
+    # an empty stream is still a member (a chunk whose records all passed)
+    allp = "".join(f"@r{i}\n{c[0]}\n+\n{c[1]}\n" for i, c in enumerate(chim[:1])).encode()
+    zp1, zf1, i1 = gpu_ctx.scanfastq_pass2_chunk(allp, compress=True)
+    assert gzip.decompress(bytes(zp1) + bytes(zf1)) is not None and (i1["passed_text_bytes"] == 0 or i1["failed_text_bytes"] == 0)
