@@ -11,14 +11,15 @@
 // blocks of a member are deflated independently and then just concatenated.  A member ends with the empty final block 03 00.
 //
 // One workgroup (256 threads) per block:
-//   pass A  the block's bytes -> symbol histogram (16 privatised copies in LDS) and the CRC-32 of each thread's 256-byte segment
+//   pass A  the block's bytes -> symbol histogram (16 privatised copies in LDS) and the CRC-32 of each 64-byte run (a thread owns runs
+//           tid, tid + 256, ...: a wave reads 4 KiB in one piece, and each run is one piece of the bit stream)
 //   tree    used symbols compacted and sorted by frequency (bitonic, LDS), code lengths by the in-place minimum-redundancy algorithm of
 //           Moffat & Katajainen (one lane; 60 - 90 used symbols for FASTQ), frequencies halved and the tree rebuilt while a length exceeds
 //           15; canonical codes, bit-reversed for the LSB-first stream
 //   header  HLIT = 257 codes, HDIST = 1 (length 0: no distances), code lengths run-length coded with a FIXED complete code-length code
 //           (sixteen-plus-two symbols, 4 or 5 bits), so no second tree is built
-//   pass B  bits per thread, exclusive scan -> every thread's bit offset in the block's slot
-//   pass C  codes packed into a 64-bit accumulator, whole words stored, the two boundary words of a thread OR-ed in atomically
+//   pass B  bits per run, exclusive scan -> every run's bit offset in the block's slot
+//   pass C  codes packed into a 64-bit accumulator, whole words stored, the two boundary words of a run OR-ed in atomically
 // then a scan of the block sizes and a copy kernel make the member contiguous behind its 10-byte header, and one lane writes the trailer.
 // CRC-32 of a concatenation is linear in the CRCs of its parts: crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P, so every thread
 // multiplies its segment's CRC by x^(8 * bytes behind it) and the workgroups XOR their sums into one word.
@@ -33,7 +34,8 @@ namespace {
 
 constexpr int kDeflateBlock = 65536;                                  // input bytes per deflate block
 constexpr int kDefThreads = 256;
-constexpr int kSeg = kDeflateBlock / kDefThreads;                     // 256 bytes per thread
+constexpr int kRun = 64;                                              // bytes per run: a thread owns runs tid, tid + 256, tid + 512, tid + 768
+constexpr int kRunsPerThread = kDeflateBlock / kRun / kDefThreads;    // 4
 constexpr int kSlotBytes = kDeflateBlock + kDeflateBlock / 4 + 1024;  // worst case is < 9.1 bits per byte + header; checked
 constexpr int kSyms = 257;                                            // literals + end-of-block (no length codes are used)
 constexpr uint32_t kCrcPoly = 0xEDB88320u;
@@ -49,7 +51,7 @@ __host__ __device__ constexpr uint32_t gf_mul(uint32_t a, uint32_t b) {
 }
 struct PowTables {
     uint32_t x2n[40];    // x^(8 * 2^k) mod P
-    uint32_t seg[256];   // x^(8 * 256 * k) mod P
+    uint32_t run[1024];  // x^(8 * 64 * k) mod P
 };
 constexpr PowTables make_pow_tables() {
     PowTables t{};
@@ -60,9 +62,9 @@ constexpr PowTables make_pow_tables() {
         p = gf_mul(p, p);
     }
     uint32_t s = 1u << 31;  // x^0
-    for (int k = 0; k < 256; k++) {
-        t.seg[k] = s;
-        s = gf_mul(s, t.x2n[8]);  // * x^(8 * 256)
+    for (int k = 0; k < 1024; k++) {
+        t.run[k] = s;
+        s = gf_mul(s, t.x2n[6]);  // * x^(8 * 64)
     }
     return t;
 }
@@ -106,26 +108,21 @@ constexpr ClCode make_cl_code() {
 }
 __constant__ ClCode c_cl = make_cl_code();
 
-struct BitBuf {  // LSB-first bit writer into 32-bit words of LDS (header and trailer: a few hundred bits, one lane)
-    uint32_t *w;
-    uint32_t n;
-    __device__ __forceinline__ void put(uint32_t v, int bits) {
-        const uint32_t at = n >> 5, sh = n & 31u;
-        w[at] |= v << sh;
-        if (sh + (uint32_t)bits > 32u) w[at + 1] |= v >> (32u - sh);
-        n += (uint32_t)bits;
-    }
-};
-
 struct DeflateLds {
-    uint32_t hist[16][260];
-    uint32_t sfreq[512];   // sorted: frequency
-    uint16_t ssym[512];    //         symbol
+    union {
+        uint32_t hist[8][264];  // pass A: privatised histograms
+        uint32_t tail[1024];    // pass C: the bits a run leaves in its last, partial word (the next run's owner stores that word)
+    };
+    uint32_t ufreq[260];   // used symbols, unsorted
+    uint16_t usym[260];
+    uint32_t sfreq[260];   // sorted ascending by (frequency, symbol)
+    uint16_t ssym[260];
     uint32_t tree[260];    // Moffat-Katajainen work array -> code lengths of the sorted symbols
     uint32_t code[260];    // per symbol: reversed code | length << 16
     uint32_t crc_tab[256];
-    uint32_t hdr[96];      // header bits (<= 57 + 258 * 12 bits in the worst case = 395 bytes; 96 words = 384 bytes is the practical bound, checked)
-    uint32_t wave_sum[4];
+    uint32_t hdr[64];      // header bits: 74 + at most 258 tokens of 5 bits = 1364 bits
+    uint32_t nz[10];       // bit s: position s of the code-length sequence (257 literal / length codes, 1 distance code) is non-zero
+    uint32_t wave_sum[4][4];
     uint32_t n_used, hdr_bits, blk_shift, bl_count[16], next_code[16];
 };
 
@@ -140,73 +137,100 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
     const uint8_t *src = in + b0;
     uint32_t *slot = reinterpret_cast<uint32_t *>(slots + (uint64_t)blockIdx.x * kSlotBytes);
     // ---- tables, zeroes -------------------------------------------------------------------------------------------------------
-    for (int i = tid; i < 16 * 260; i += kDefThreads) (&L.hist[0][0])[i] = 0;
+    for (int i = tid; i < 8 * 264; i += kDefThreads) (&L.hist[0][0])[i] = 0;
     {
         uint32_t c = (uint32_t)tid;
         for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
         L.crc_tab[tid] = c;
     }
-    for (int i = tid; i < 96; i += kDefThreads) L.hdr[i] = 0;
-    for (int i = tid; i < 512; i += kDefThreads) {
-        L.sfreq[i] = 0xFFFFFFFFu;
-        L.ssym[i] = 0xFFFFu;
-    }
+    if (tid < 64) L.hdr[tid] = 0;
     if (tid < 16) L.bl_count[tid] = 0;
     if (tid == 0) {
         L.n_used = 0;
         L.blk_shift = x_pow_bytes(n_bytes - (b0 + blen));  // x^(8 * bytes behind this block)
     }
     __syncthreads();
-    // ---- pass A: histogram + CRC of my segment ---------------------------------------------------------------------------------
-    const uint32_t s0 = (uint32_t)tid * kSeg, s1 = min(s0 + (uint32_t)kSeg, blen);
-    uint32_t crc = 0xFFFFFFFFu;
+    // ---- pass A: histogram + CRC of my runs ---------------------------------------------------------------------------------------
+    // Run q = j * 256 + tid covers bytes [64 q, 64 q + 64) of the block: the 64 lanes of a wave read one contiguous 4 KiB per j (four
+    // 16-byte loads per lane whose lines the wave shares), and every run is a contiguous piece of the bit stream with one offset.
+    const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
+    auto run_begin = [&](int j) { return ((uint32_t)j * kDefThreads + (uint32_t)tid) * kRun; };
+    auto for_run_bytes = [&](int j, auto &&f) {  // f(byte) over run j of this thread, in order
+        const uint32_t r0 = run_begin(j);
+        if (r0 >= blen) return;
+        if (r0 + kRun <= blen && aligned) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(src + r0);
+            const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+            const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) f((w[k] >> (8 * q)) & 0xFFu);
+        } else {
+            const uint32_t r1 = min(r0 + (uint32_t)kRun, blen);
+            for (uint32_t i = r0; i < r1; i++) f((uint32_t)src[i]);
+        }
+    };
     {
-        uint32_t *h = L.hist[tid & 15];
-        const bool aligned = ((reinterpret_cast<uintptr_t>(src) & 15u) == 0);
-        if (s0 + kSeg <= blen && aligned) {
-            const uint4 *p = reinterpret_cast<const uint4 *>(src + s0);
-            for (int k = 0; k < kSeg / 16; k++) {
-                const uint4 v = p[k];
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t *h = L.hist[tid & 7];
+        uint32_t part = 0;
+        auto fold = [&](int j, uint32_t crc) {  // CRC of run j times x^(8 * bytes of this block behind it)
+            const uint32_t r1 = min(run_begin(j) + (uint32_t)kRun, blen);
+            const uint32_t behind = blen - r1;
+            const uint32_t f = (behind % (uint32_t)kRun == 0) ? c_pow.run[behind / kRun] : x_pow_bytes(behind);
+            part ^= gf_mul(f, ~crc);
+        };
+#pragma unroll 1
+        for (int j = 0; j < kRunsPerThread; j += 2) {
+            if (run_begin(j) >= blen) break;
+            if (aligned && run_begin(j + 1) + kRun <= blen) {
+                // two full runs at once: their CRC chains (a table look-up per byte, each waiting for the one before) overlap
+                const uint4 *p = reinterpret_cast<const uint4 *>(src + run_begin(j)), *q4 = reinterpret_cast<const uint4 *>(src + run_begin(j + 1));
+                uint32_t ca = 0xFFFFFFFFu, cb = 0xFFFFFFFFu;
 #pragma unroll
-                for (int j = 0; j < 4; j++)
+                for (int k = 0; k < 4; k++) {
+                    const uint4 va = p[k], vb = q4[k];
+                    const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t c = (w[j] >> (8 * q)) & 0xFFu;
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const uint32_t a = (wa[i] >> (8 * q)) & 0xFFu, b = (wb[i] >> (8 * q)) & 0xFFu;
+                            atomicAdd(&h[a], 1u);
+                            atomicAdd(&h[b], 1u);
+                            ca = L.crc_tab[(ca ^ a) & 0xFFu] ^ (ca >> 8);
+                            cb = L.crc_tab[(cb ^ b) & 0xFFu] ^ (cb >> 8);
+                        }
+                }
+                fold(j, ca);
+                fold(j + 1, cb);
+            } else {
+                for (int jj = j; jj < j + 2; jj++) {
+                    if (run_begin(jj) >= blen) break;
+                    uint32_t crc = 0xFFFFFFFFu;
+                    for_run_bytes(jj, [&](uint32_t c) {
                         atomicAdd(&h[c], 1u);
                         crc = L.crc_tab[(crc ^ c) & 0xFFu] ^ (crc >> 8);
-                    }
-            }
-        } else {
-            for (uint32_t i = s0; i < s1; i++) {
-                const uint32_t c = src[i];
-                atomicAdd(&h[c], 1u);
-                crc = L.crc_tab[(crc ^ c) & 0xFFu] ^ (crc >> 8);
+                    });
+                    fold(jj, crc);
+                }
             }
         }
-    }
-    crc = s1 > s0 ? ~crc : 0u;  // CRC-32 of the segment (0 for an empty one)
-    {
-        // bytes of this block behind my segment: whole segments for a full block (table), anything for the last one
-        const uint32_t behind = blen - s1;
-        const uint32_t f = (behind % (uint32_t)(kSeg) == 0 && s1 > s0) ? c_pow.seg[behind / kSeg] : x_pow_bytes(behind);
-        uint32_t part = s1 > s0 ? gf_mul(gf_mul(f, L.blk_shift), crc) : 0u;
+        part = gf_mul(L.blk_shift, part);
 #pragma unroll
         for (int o = 32; o; o >>= 1) part ^= __shfl_xor(part, o);
-        if (lane == 0) L.wave_sum[wave] = part;
+        if (lane == 0) L.wave_sum[0][wave] = part;
     }
     __syncthreads();
-    if (tid == 0) atomicXor(crc_acc, L.wave_sum[0] ^ L.wave_sum[1] ^ L.wave_sum[2] ^ L.wave_sum[3]);
-    // ---- symbol frequencies -> sorted list of the used ones --------------------------------------------------------------------
-    uint32_t f_mine = 0;
-    for (int k = 0; k < 16; k++) f_mine += L.hist[k][tid];
+    if (tid == 0) atomicXor(crc_acc, L.wave_sum[0][0] ^ L.wave_sum[0][1] ^ L.wave_sum[0][2] ^ L.wave_sum[0][3]);
+    // ---- symbol frequencies -> list of the used ones, sorted by rank counting ------------------------------------------------------
     {
-        // compact (order does not matter: the sort follows)
-        const bool used = f_mine != 0;
-        if (used) {
+        uint32_t f_mine = 0;
+        for (int k = 0; k < 8; k++) f_mine += L.hist[k][tid];
+        if (f_mine) {
             const uint32_t at = atomicAdd(&L.n_used, 1u);
-            L.sfreq[at] = f_mine;
-            L.ssym[at] = (uint16_t)tid;
+            L.ufreq[at] = f_mine;
+            L.usym[at] = (uint16_t)tid;
         }
         L.code[tid] = 0;
         if (tid == 0) L.code[256] = 0;
@@ -214,29 +238,22 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
     __syncthreads();
     if (tid == 0) {  // end-of-block, once
         const uint32_t at = L.n_used++;
-        L.sfreq[at] = 1u;
-        L.ssym[at] = 256;
+        L.ufreq[at] = 1u;
+        L.usym[at] = 256;
     }
     __syncthreads();
     const uint32_t n_used = L.n_used;  // >= 2: a block holds at least one byte
-    // bitonic sort of 512 (freq, sym) pairs, ascending by frequency then symbol (the unused slots hold the maximum)
-    for (uint32_t k = 2; k <= 512; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = (uint32_t)tid; i < 512; i += kDefThreads) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const uint64_t a = ((uint64_t)L.sfreq[i] << 16) | L.ssym[i], b = ((uint64_t)L.sfreq[x] << 16) | L.ssym[x];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) {
-                        L.sfreq[i] = (uint32_t)(b >> 16);
-                        L.ssym[i] = (uint16_t)b;
-                        L.sfreq[x] = (uint32_t)(a >> 16);
-                        L.ssym[x] = (uint16_t)a;
-                    }
-                }
-            }
-            __syncthreads();
+    for (uint32_t i = (uint32_t)tid; i < n_used; i += kDefThreads) {
+        const uint32_t fi = L.ufreq[i], si = L.usym[i];
+        uint32_t rank = 0;
+        for (uint32_t k = 0; k < n_used; k++) {
+            const uint32_t fk = L.ufreq[k], sk = L.usym[k];
+            rank += (fk < fi || (fk == fi && sk < si)) ? 1u : 0u;
         }
+        L.sfreq[rank] = fi;
+        L.ssym[rank] = (uint16_t)si;
+    }
+    __syncthreads();
     // ---- code lengths (one lane): Moffat & Katajainen, "In-place calculation of minimum-redundancy codes" ----------------------
     if (tid == 0) {
         const int n = (int)n_used;
@@ -309,61 +326,118 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
         }
     }
     __syncthreads();
-    // ---- header (one lane) -----------------------------------------------------------------------------------------------------------
-    if (tid == 0) {
-        BitBuf B{L.hdr, 0};
-        B.put(0u, 1);   // BFINAL = 0
-        B.put(2u, 2);   // BTYPE = 10, dynamic Huffman
-        B.put(0u, 5);   // HLIT: 257 literal / length codes
-        B.put(0u, 5);   // HDIST: 1 distance code
-        B.put(15u, 4);  // HCLEN: all 19 code-length codes
-        const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-        for (int k = 0; k < 19; k++) B.put((uint32_t)c_cl.len[order[k]], 3);
-        // 257 literal / length code lengths + the one distance code (length 0: "no distance codes", RFC 1951 3.2.7)
-        int s = 0;
-        while (s < kSyms + 1) {
-            const uint32_t len = s < kSyms ? (L.code[s] >> 16) : 0u;
-            if (len == 0) {
-                int run = 1;
-                while (s + run < kSyms + 1 && (s + run < kSyms ? (L.code[s + run] >> 16) : 0u) == 0u && run < 138) run++;
-                if (run >= 11) {
-                    B.put(c_cl.code[18], c_cl.len[18]);
-                    B.put((uint32_t)(run - 11), 7);
-                } else if (run >= 3) {
-                    B.put(c_cl.code[17], c_cl.len[17]);
-                    B.put((uint32_t)(run - 3), 3);
-                } else {
-                    run = 1;
-                    B.put(c_cl.code[0], c_cl.len[0]);
-                }
-                s += run;
-            } else {
-                B.put(c_cl.code[len], c_cl.len[len]);
-                s++;
-            }
-            if (B.n > 96 * 32 - 64) {  // (cannot happen: 257 lengths cost <= 5 bits each + 57 = 1342 bits)
-                atomicOr(err, 2u);
-                break;
-            }
+    // ---- header: every position of the code-length sequence finds its token(s) and their place by itself ---------------------------
+    // positions 0..255 = the literals (thread = position), 256 = end-of-block (always used), 257 = the one distance code (length 0)
+    {
+        const uint32_t my_len = L.code[tid] >> 16;
+        const uint64_t m = __ballot(my_len != 0);
+        if (lane == 0) {
+            L.nz[2 * wave] = (uint32_t)m;
+            L.nz[2 * wave + 1] = (uint32_t)(m >> 32);
         }
-        L.hdr_bits = B.n;
-    }
-    __syncthreads();
-    // ---- pass B: bits per thread, exclusive scan ---------------------------------------------------------------------------------
-    uint32_t my_bits = 0;
-    for (uint32_t i = s0; i < s1; i++) my_bits += L.code[src[i]] >> 16;
-    uint32_t inc = my_bits;
+        if (tid == 0) {
+            L.nz[8] = 1u;  // 256: used; 257: zero
+            L.nz[9] = 0u;
+        }
+        __syncthreads();
+        // zero runs: a run starts where the position before is used; as the serial greedy coder would, it is cut into pieces of 138
+        // (symbol 18), then one piece of 11..137 (18) or 3..10 (17), or one or two single zeros
+        uint32_t bits = 0, run = 0;
+        if (my_len)
+            bits = c_cl.len[my_len];
+        else if (tid == 0 || ((L.nz[(tid - 1) >> 5] >> ((tid - 1) & 31)) & 1u)) {
+            // next used position behind tid (256 is always one)
+            uint32_t p = (uint32_t)tid + 1;
+            for (;;) {
+                const uint32_t w = L.nz[p >> 5] >> (p & 31u);
+                if (w) {
+                    p += (uint32_t)__builtin_ctz(w);
+                    break;
+                }
+                p = (p | 31u) + 1u;
+            }
+            run = p - (uint32_t)tid;
+            const uint32_t k = run / 138u, r = run % 138u;
+            bits = k * (c_cl.len[18] + 7u) + (r >= 11u ? c_cl.len[18] + 7u : r >= 3u ? c_cl.len[17] + 3u : r * c_cl.len[0]);
+        }
+        uint32_t inc = bits;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(inc, o);
-        if (lane >= o) inc += y;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(inc, o);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) L.wave_sum[1][wave] = inc;
+        __syncthreads();
+        uint32_t at = 74u + inc - bits;  // 3 + 5 + 5 + 4 + 19 * 3 bits come first
+        for (int w = 0; w < wave; w++) at += L.wave_sum[1][w];
+        auto put = [&](uint32_t v, uint32_t nb) {
+            const uint32_t w = at >> 5, sh = at & 31u;
+            atomicOr(&L.hdr[w], v << sh);
+            if (sh + nb > 32u) atomicOr(&L.hdr[w + 1], v >> (32u - sh));
+            at += nb;
+        };
+        if (my_len)
+            put(c_cl.code[my_len], c_cl.len[my_len]);
+        else if (run) {
+            uint32_t r = run;
+            for (; r >= 138u; r -= 138u) {
+                put(c_cl.code[18], c_cl.len[18]);
+                put(127u, 7);
+            }
+            if (r >= 11u) {
+                put(c_cl.code[18], c_cl.len[18]);
+                put(r - 11u, 7);
+            } else if (r >= 3u) {
+                put(c_cl.code[17], c_cl.len[17]);
+                put(r - 3u, 3);
+            } else
+                for (; r; r--) put(c_cl.code[0], c_cl.len[0]);
+        }
+        if (tid == 0) {
+            at = 0;
+            put(0u, 1);   // BFINAL = 0
+            put(2u, 2);   // BTYPE = 10, dynamic Huffman
+            put(0u, 5);   // HLIT: 257 literal / length codes
+            put(0u, 5);   // HDIST: 1 distance code
+            put(15u, 4);  // HCLEN: all 19 code-length codes
+            const int order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            for (int k = 0; k < 19; k++) put((uint32_t)c_cl.len[order[k]], 3);
+            // behind the 256 literal positions: end-of-block (used) and the distance code (a zero run of one)
+            at = 74u + L.wave_sum[1][0] + L.wave_sum[1][1] + L.wave_sum[1][2] + L.wave_sum[1][3];
+            const uint32_t le = L.code[256] >> 16;
+            put(c_cl.code[le], c_cl.len[le]);
+            put(c_cl.code[0], c_cl.len[0]);
+            L.hdr_bits = at;
+        }
     }
-    if (lane == 63) L.wave_sum[wave] = inc;
     __syncthreads();
-    uint32_t before = L.hdr_bits;
-    for (int w = 0; w < wave; w++) before += L.wave_sum[w];
-    const uint32_t my_off = before + inc - my_bits;
-    const uint32_t data_end = L.hdr_bits + L.wave_sum[0] + L.wave_sum[1] + L.wave_sum[2] + L.wave_sum[3];
+    // ---- pass B: bits per run, exclusive scan over the runs in stream order (run q = j * 256 + tid) ---------------------------------
+    uint32_t run_bits[kRunsPerThread], run_off[kRunsPerThread];
+#pragma unroll
+    for (int j = 0; j < kRunsPerThread; j++) {
+        uint32_t b = 0;
+        for_run_bytes(j, [&](uint32_t c) { b += L.code[c] >> 16; });
+        run_bits[j] = b;
+        uint32_t inc = b;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(inc, o);
+            if (lane >= o) inc += y;
+        }
+        run_off[j] = inc - b;  // exclusive within the wave
+        if (lane == 63) L.wave_sum[j][wave] = inc;
+    }
+    __syncthreads();
+    uint32_t data_end = L.hdr_bits;
+#pragma unroll
+    for (int j = 0; j < kRunsPerThread; j++) {
+        uint32_t before = data_end;
+        for (int w = 0; w < 4; w++) {
+            if (w < wave) before += L.wave_sum[j][w];
+            data_end += L.wave_sum[j][w];
+        }
+        run_off[j] += before;
+    }
     const uint32_t eob = L.code[256];
     // trailer: end-of-block, then BFINAL = 0 / BTYPE = 00, padding to the byte, LEN = 0, NLEN = 0xFFFF
     const uint32_t after_eob = data_end + (eob >> 16) + 3u;
@@ -375,34 +449,32 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
         }
         return;  // (uniform)
     }
-    // ---- zero the words two writers share: the first word of every thread's run, and the trailer's words ---------------------------
-    // header words are stored whole by their owner below, except the last (partial) one, which thread 0's first bits share
-    if (s1 > s0) slot[my_off >> 5] = 0u;
-    if (tid == 0) {
-        const uint32_t w0 = data_end >> 5, w1 = (total_bytes + 3u) >> 2;
-        for (uint32_t w = w0; w <= w1; w++) slot[w] = 0u;
-        slot[L.hdr_bits >> 5] = 0u;
-    }
-    __syncthreads();
-    // header: whole words plain, the last partial word OR-ed (it is thread 0's first word, or the trailer's if the block is tiny)
+    // header: its whole words; the last, partial one goes out with the first run's first word
     {
         const uint32_t hw = L.hdr_bits >> 5;
         for (uint32_t w = (uint32_t)tid; w < hw; w += kDefThreads) slot[w] = L.hdr[w];
-        if (tid == 0 && (L.hdr_bits & 31u)) atomicOr(&slot[hw], L.hdr[hw]);
     }
     // ---- pass C: the codes -------------------------------------------------------------------------------------------------------------
-    if (s1 > s0) {
-        uint32_t w = my_off >> 5;
-        uint32_t nb = my_off & 31u;
+    // A run is at least 64 bits, so it begins in one word, fills some, and ends in another.  Whole words are stored as they fill up; the
+    // word a run begins in is kept back and stored after the barrier together with the bits the run before it left there (L.tail), so no
+    // word has two writers and nothing has to be zeroed or OR-ed in.  Two codes (<= 30 bits) are joined before they enter the 64-bit
+    // accumulator: one long shift and one overflow test per pair.
+    uint32_t head[kRunsPerThread];
+#pragma unroll
+    for (int j = 0; j < kRunsPerThread; j++) {
+        head[j] = 0;
+        if (!run_bits[j]) continue;
+        uint32_t w = run_off[j] >> 5;
+        uint32_t nb = run_off[j] & 31u;
         uint64_t acc = 0;
         bool first = true;
-        for (uint32_t i = s0; i < s1; i++) {
-            const uint32_t e = L.code[src[i]];
-            acc |= (uint64_t)(e & 0xFFFFu) << nb;
-            nb += e >> 16;
+        uint32_t pend = 0, pend_len = 0xFFFFFFFFu;  // first code of a pair
+        auto push = [&](uint32_t bits, uint32_t len) {
+            acc |= (uint64_t)bits << nb;
+            nb += len;
             if (nb >= 32u) {
                 if (first) {
-                    atomicOr(&slot[w], (uint32_t)acc);
+                    head[j] = (uint32_t)acc;
                     first = false;
                 } else
                     slot[w] = (uint32_t)acc;
@@ -410,21 +482,53 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
                 acc >>= 32;
                 nb -= 32u;
             }
-        }
-        if (nb) atomicOr(&slot[w], (uint32_t)acc);  // the next thread's first word (zeroed above), or the trailer's
-    }
-    if (tid == 0) {
-        uint32_t at = data_end;
-        auto put = [&](uint32_t v, uint32_t bits) {
-            const uint32_t w = at >> 5, sh = at & 31u;
-            atomicOr(&slot[w], v << sh);
-            if (sh + bits > 32u) atomicOr(&slot[w + 1], v >> (32u - sh));
-            at += bits;
         };
-        put(eob & 0xFFFFu, eob >> 16);
-        put(0u, 3);
-        at = (at + 7u) & ~7u;
-        put(0xFFFF0000u, 32);  // LEN = 0x0000, NLEN = 0xFFFF (little endian)
+        for_run_bytes(j, [&](uint32_t c) {
+            const uint32_t e = L.code[c];
+            if (pend_len == 0xFFFFFFFFu) {
+                pend = e & 0xFFFFu;
+                pend_len = e >> 16;
+            } else {
+                push(pend | ((e & 0xFFFFu) << pend_len), pend_len + (e >> 16));
+                pend_len = 0xFFFFFFFFu;
+            }
+        });
+        if (pend_len != 0xFFFFFFFFu) push(pend, pend_len);  // (a run of odd length: the end of the input)
+        L.tail[j * kDefThreads + tid] = (uint32_t)acc;        // nb < 32 bits, the rest is zero
+    }
+    __syncthreads();
+    const uint32_t hdr_tail = (L.hdr_bits & 31u) ? L.hdr[L.hdr_bits >> 5] : 0u;
+#pragma unroll
+    for (int j = 0; j < kRunsPerThread; j++)
+        if (run_bits[j]) {
+            const uint32_t q = (uint32_t)j * kDefThreads + (uint32_t)tid;
+            const uint32_t before = q ? L.tail[q - 1] : hdr_tail;
+            if ((run_off[j] & 31u) + run_bits[j] >= 32u)
+                slot[run_off[j] >> 5] = head[j] | before;
+            else
+                L.tail[q] |= before;  // a run that stays inside its first word (only the short last run of the input can): hand everything on
+        }
+    __syncthreads();
+    if (tid == 0) {
+        // the last run's leftover bits, end-of-block, the empty stored block
+        const uint32_t n_runs = (blen + kRun - 1) / kRun;
+        uint64_t acc = L.tail[n_runs - 1];
+        uint32_t nb = data_end & 31u, w = data_end >> 5;
+        auto push = [&](uint32_t bits, uint32_t len) {
+            acc |= (uint64_t)bits << nb;
+            nb += len;
+            if (nb >= 32u) {
+                slot[w++] = (uint32_t)acc;
+                acc >>= 32;
+                nb -= 32u;
+            }
+        };
+        push(eob & 0xFFFFu, eob >> 16);
+        push(0u, 3);
+        if (nb & 7u) push(0u, 8u - (nb & 7u));
+        push(0u, 16);       // LEN = 0x0000
+        push(0xFFFFu, 16);  // NLEN = 0xFFFF
+        if (nb) slot[w] = (uint32_t)acc;
         block_bytes[blockIdx.x] = total_bytes;
     }
 }
