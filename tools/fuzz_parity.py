@@ -62,6 +62,65 @@ def check_records(pkg, synth, sor, ctx, seed):
     return got_p == exp_p and got_f == exp_f and info["n_passed"] == n_p, f"records seed={seed} trim={trim} passed={n_p} out={info['n_records_out']}"
 
 
+def check_packed(pkg, synth, sor, ctx, seed):
+    """round 3: the packed boundary (host index / planes / writer in a random SIMD form on 1..5 threads) == the oracle's records; its
+    statistics == the text worker's; the text worker with cfg.compress returns members that inflate to the same text"""
+    import gzip
+
+    from test_write_gpu import _fastq, _oracle_records
+
+    rng = np.random.default_rng(seed)
+    wl = synth.make_whitelist(20_000, seed=seed)
+    used = synth.pick_used(wl, 150, seed=seed + 1)
+    reads = synth.gen_reads(160, used, seed=seed + 2, n_rate=float(rng.choice([0.0, 0.003])), err=float(rng.choice([0.03, 0.063, 0.1])))
+    chim = synth.make_chimeras(reads, 220, seed=seed + 3)
+    seqs, quals = [c[0] for c in chim], [c[1] for c in chim]
+    ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    trim = bool(seed & 2)
+    text = _fastq(seqs, quals)
+    os.environ["SMI_HOST_SIMD"] = str(int(rng.integers(0, 3)))
+    try:
+        got_p, got_f, info = ctx.scanfastq_pass2_chunk(text, first_read_id=7 + seed, trim_fastq=trim, packed=True, n_threads=int(rng.integers(1, 6)),
+                                                       want_results=True)
+    finally:
+        del os.environ["SMI_HOST_SIMD"]
+    exp_p, exp_f, n_p = _oracle_records(sor, sor.BarcodeSet(used.numpy()), seqs, quals, 1, {}, 7 + seed, trim=trim)
+    ok = got_p == exp_p and got_f == exp_f and info["n_passed"] == n_p
+    zp, zf, zinfo = ctx.scanfastq_pass2_chunk(text, first_read_id=7 + seed, trim_fastq=trim, compress=True, want_results=True)
+    ok = ok and gzip.decompress(bytes(zp)) == exp_p and gzip.decompress(bytes(zf)) == exp_f and bool((zinfo["stats"] == info["stats"]).all())
+    return ok, f"packed seed={seed} trim={trim} passed={n_p} out={info['n_records_out']} member={len(zp)}"
+
+
+def check_umi_stage(pkg, synth, sor, ctx, seed):
+    """round 3: smi_assignumis_chunk with the stage on the device == the host stage of round 2 (which tests/ hold to the oracle), 3' / 5'"""
+    from test_umi_stage_gpu import _both_paths, _chunk
+
+    rng = np.random.default_rng(seed)
+    five = bool(seed & 1)
+    names, flags, pos0, cigars = _chunk(pkg, synth, ctx, int(rng.integers(200, 900)), int(rng.integers(2, 9)), int(rng.integers(5, 120)), seed, five)
+    kw = dict(five_prime=five, n_threads=int(rng.integers(1, 5)), keep_data_end=bool(rng.random() < 0.3))
+    if rng.random() < 0.3:
+        kw["bc_edit_limit"] = int(rng.integers(0, 2))
+    tags, n_done = _both_paths(ctx, names, flags, pos0, cigars, **kw)          # asserts equality
+    return True, f"umi_stage seed={seed} 5p={five} records={len(names)} done={n_done} clustered={int((tags['flags'] & 1 != 0).sum())}"
+
+
+def check_deflate(pkg, synth, sor, ctx, seed):
+    """round 3: K-DEFLATE round trip on random lengths and alphabets (zlib is the inflater)"""
+    import zlib
+
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([0, 1, 63, 64, 65, 4096, 65535, 65536, 65537, int(rng.integers(1, 3_000_000))]))
+    k = int(rng.choice([1, 2, 4, 5, 16, 64, 256]))
+    alpha = rng.choice(256, size=k, replace=False).astype(np.uint8)
+    p = rng.dirichlet(np.full(k, float(rng.choice([0.05, 0.5, 5.0]))))
+    data = rng.choice(alpha, size=n, p=p).tobytes()
+    d_in = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda() if n else torch.zeros(0, dtype=torch.uint8, device="cuda")
+    out = ctx.gzip_device(d_in, n).cpu().numpy().tobytes()
+    back = zlib.decompress(out, wbits=31)
+    return back == data, f"deflate seed={seed} n={n} alphabet={k} member={len(out)}"
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     pkg = graft.load_package()
@@ -72,7 +131,8 @@ def main():
     t_end = time.time() + 60 * minutes
     seed, n_ok = (int(sys.argv[2]) if len(sys.argv) > 2 else 1000), 0
     while time.time() < t_end:
-        for leg in (check_bc, check_records):
+        for leg in ([check_bc, check_records] if os.environ.get("SMI_FUZZ_LEGS") == "r2" else [check_packed, check_umi_stage, check_deflate]
+                    if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_bc, check_records, check_packed, check_umi_stage, check_deflate]):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
             print(("ok   " if ok else "FAIL ") + msg, flush=True)
             if not ok:
