@@ -244,21 +244,36 @@ def umi_stage_leg(pkg, synth, ctx, used, n_mol, copies=6, genes_per=10):
     fl = np.array([t[2] for t in rows], dtype=np.uint16)
     p0 = np.array([max(t[0], 0) + 1_000_000 for t in rows], dtype=np.int32)
 
+    def pinned(a):
+        """a copy of the array in page-locked memory (smi_host_alloc), as the host hands its chunk over: uploads at link speed and side by side
+        on several lanes (pageable memory goes through the runtime's one staging path)"""
+        pb = lib.PinnedBuffer(max(a.nbytes, 1))
+        v = pb.array[:a.nbytes].view(a.dtype)
+        v[:] = a.reshape(-1)
+        return pb, v
+
+    keep_pinned = []
+
     def make_call(c, o):
         cfg = lib.AssignUmisConfig()
         c._check(c._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
         cfg.n_threads = 2
         nd = ctypes.c_int32(0)
+        arrs = [pinned(a) for a in (nbuf, noff, fl, p0, cbuf, coff)]      # every lane's own chunk buffers
+        keep_pinned.extend(pb for pb, _ in arrs)
+        a_n, a_no, a_f, a_p, a_c, a_co = (v for _, v in arrs)
 
         def call():
-            c._check(c._lib.smi_assignumis_chunk(c._h, nbuf.ctypes.data, noff.ctypes.data, fl.ctypes.data, p0.ctypes.data, cbuf.ctypes.data, coff.ctypes.data,
+            c._check(c._lib.smi_assignumis_chunk(c._h, a_n.ctypes.data, a_no.ctypes.data, a_f.ctypes.data, a_p.ctypes.data, a_c.ctypes.data, a_co.ctypes.data,
                                                  n, ctypes.byref(cfg), o.ctypes.data, ctypes.byref(nd)))
         return call
 
     runs, first = [], None
-    for lanes in (1, 4, 8):
+    for lanes in (1, 4, 8, 16):
         ctxs = [ctx] + [ctx.lane() for _ in range(lanes - 1)]
-        outs = [np.zeros(n, dtype=lib.UMI_TAG_DTYPE) for _ in ctxs]
+        out_pins = [lib.PinnedBuffer(n * lib.UMI_TAG_DTYPE.itemsize) for _ in ctxs]
+        keep_pinned.extend(out_pins)
+        outs = [pb.array.view(lib.UMI_TAG_DTYPE) for pb in out_pins]
         calls = [make_call(c, o) for c, o in zip(ctxs, outs)]
         for f in calls:
             f()
@@ -270,16 +285,19 @@ def umi_stage_leg(pkg, synth, ctx, used, n_mol, copies=6, genes_per=10):
         for t in th:
             t.join()
         dt = time.perf_counter() - t0
-        first = outs[0] if first is None else first
+        first = outs[0].copy() if first is None else first
         runs.append({"lanes": lanes, "records_per_s": n * lanes * per / dt, "ms_per_chunk": dt / per * 1e3,
                      "same_tags_on_every_lane": all(o.tobytes() == first.tobytes() for o in outs)})
         for c in ctxs[1:]:
             c.close()
+        for pb in keep_pinned:
+            pb.close()
+        keep_pinned.clear()
     best = max(runs, key=lambda r: r["records_per_s"])
     return {"records_per_chunk": n, "molecules": len(names), "copies": copies, "loci": genes, "clustered": int((first["flags"] & 4 != 0).sum()),
             "with_region": int((first["region"] >= 0).sum()), "runs": runs, "records_per_s": best["records_per_s"], "lanes_at_best": best["lanes"],
-            "stages": "K-UPARSE (names, UMI windows, clustering positions), region grouping (host, per strand), key sort, K-UMI, K-UCLUST "
-                      "(groups <= 100 reads; larger ones on the host), K-UTAG; host arrays in, tags out"}
+            "stages": "K-UPARSE (names, UMI windows, clustering positions), region grouping (sort on the device, chains and their refinement on the host), key sort, K-UMI, K-UCLUST "
+                      "(groups <= 100 reads; larger ones on the host), K-UTAG; host arrays (page-locked) in, tags out"}
 
 
 def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=2, threads=None):

@@ -412,20 +412,45 @@ extern "C" int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_o
 namespace smi {
 namespace {
 
-struct Rec {
-    int pos, read, index;
-    bool rev;
+// One strand of a chunk, sorted by position (stable in BAM order): the members of a region are indices into these arrays.
+struct Strand {
+    std::vector<int> pos, read, index;  // clustering position, record number, rank among the chunk's reads that have a position
+    std::vector<int64_t> psum;          // psum[k] = pos[0] + ... + pos[k - 1]
 };
 
+// A region's members are either a contiguous piece [lo, hi) of its strand (what a chain is when it is built, and what most regions still are
+// when everything is over: nothing per member is stored, the centre comes from the prefix sums and the two "is anyone off-centre" questions
+// look at the two ends) or, once a region has been split, merged or built across a gap, an explicit list in insertion order.
 struct Region {
-    std::vector<const Rec *> reads;
+    const Strand *st = nullptr;
+    int lo = 0, hi = 0;
+    bool is_list = false;
+    std::vector<int> list;
     bool cached = false;
     int center_value = 0;
+    size_t size() const { return is_list ? list.size() : (size_t)(hi - lo); }
+    bool empty() const { return size() == 0; }
+    void materialize() {
+        if (is_list) return;
+        list.resize((size_t)(hi - lo));
+        for (int k = lo; k < hi; k++) list[(size_t)(k - lo)] = k;
+        is_list = true;
+    }
+    template <class F>
+    void for_each(F &&f) const {
+        if (is_list)
+            for (int k : list) f(k);
+        else
+            for (int k = lo; k < hi; k++) f(k);
+    }
     int center() {  // Math.round((float) mean) in a cached field: cleared by add / addAll / removeAll, NOT by removeOffCenter (see split_off)
-        if (!cached && !reads.empty()) {
-            double s = 0;
-            for (const Rec *r : reads) s += r->pos;
-            center_value = (int)std::floor((float)(s / (double)reads.size()) + 0.5f);
+        if (!cached && !empty()) {
+            double s = 0;  // (the sum of the positions is an integer below 2^53: exact in a double in any order)
+            if (is_list)
+                for (int k : list) s += st->pos[(size_t)k];
+            else
+                s = (double)(st->psum[(size_t)hi] - st->psum[(size_t)lo]);
+            center_value = (int)std::floor((float)(s / (double)size()) + 0.5f);
             cached = true;
         }
         return center_value;
@@ -437,25 +462,33 @@ struct Region {
     // keeps that value.  Returns true when the reference creates a new cluster -- which is empty when the two passes disagree.
     bool split_off(int side, int dist, Region &out) {
         out = Region();
-        if (reads.empty()) return false;
-        auto off = [&](const Rec *r, int c) { return side < 0 ? r->pos < c - dist : r->pos > c + dist; };
+        out.st = st;
+        if (empty()) return false;
         const int counted_with = center();
+        if (!is_list) {  // sorted piece: the off-centre members, if any, include its first (side < 0) or last (side > 0) one
+            const bool any = side < 0 ? st->pos[(size_t)lo] < counted_with - dist : st->pos[(size_t)hi - 1] > counted_with + dist;
+            if (!any) return false;
+            materialize();
+        }
+        const std::vector<int> &P = st->pos;
+        auto off = [&](int k, int c) { return side < 0 ? P[(size_t)k] < c - dist : P[(size_t)k] > c + dist; };
         size_t n_off = 0;
-        for (const Rec *r : reads) n_off += off(r, counted_with);
+        for (int k : list) n_off += off(k, counted_with);
         if (n_off == 0) return false;
         cached = false;  // L633
         const int c = center();
-        std::vector<const Rec *> stay;
-        for (const Rec *r : reads) (off(r, c) ? out.reads : stay).push_back(r);
-        reads.swap(stay);  // `cached` stays true: the field is not cleared when the members leave
-        if (reads.empty()) cached = false;
-        std::stable_sort(out.reads.begin(), out.reads.end(), [](const Rec *a, const Rec *b) { return a->pos < b->pos; });
+        std::vector<int> stay;
+        out.is_list = true;
+        for (int k : list) (off(k, c) ? out.list : stay).push_back(k);
+        list.swap(stay);  // `cached` stays true: the field is not cleared when the members leave
+        if (list.empty()) cached = false;
+        std::stable_sort(out.list.begin(), out.list.end(), [&](int x, int y) { return P[(size_t)x] < P[(size_t)y]; });
         return true;
     }
 };
 
 void drop_empty(std::vector<Region> &v) {
-    v.erase(std::remove_if(v.begin(), v.end(), [](const Region &r) { return r.reads.empty(); }), v.end());
+    v.erase(std::remove_if(v.begin(), v.end(), [](const Region &r) { return r.empty(); }), v.end());
 }
 
 void sort_by_center(std::vector<Region> &v) {
@@ -479,52 +512,116 @@ void refine_regions(std::vector<Region> &v, int dist) {
     for (bool again = true; again;) {
         again = false;
         for (size_t i = 0; i + 1 < v.size(); i++) {
-            if (v[i].reads.empty()) continue;
+            if (v[i].empty()) continue;
             Region &left = v[i], &right = v[i + 1];
             if (right.center() - left.center() >= 2 * dist) continue;
-            const bool left_bigger = left.reads.size() > right.reads.size();
+            const bool left_bigger = left.size() > right.size();
             Region &from_r = left_bigger ? right : left, &to_r = left_bigger ? left : right;
             const int tc = to_r.center_value;
-            std::vector<const Rec *> stay, move;
-            for (const Rec *r : from_r.reads) (std::abs(r->pos - tc) <= dist ? move : stay).push_back(r);
+            const std::vector<int> &P = from_r.st->pos;
+            if (!from_r.is_list) {  // sorted piece: does anyone lie within dist of the other centre at all?
+                const auto b = P.begin() + from_r.lo, e = P.begin() + from_r.hi;
+                const auto it = std::lower_bound(b, e, tc - dist);
+                if (it == e || *it > tc + dist) continue;
+                from_r.materialize();
+            }
+            std::vector<int> stay, move;
+            for (int k : from_r.list) (std::abs(P[(size_t)k] - tc) <= dist ? move : stay).push_back(k);
             if (move.empty()) continue;
             again = true;
-            to_r.reads.insert(to_r.reads.end(), move.begin(), move.end());
-            from_r.reads.swap(stay);
+            to_r.materialize();
+            to_r.list.insert(to_r.list.end(), move.begin(), move.end());
+            from_r.list.swap(stay);
             to_r.cached = from_r.cached = false;
         }
         drop_empty(v);
     }
-    v.erase(std::remove_if(v.begin(), v.end(), [](const Region &r) { return r.reads.size() <= 1; }), v.end());
+    v.erase(std::remove_if(v.begin(), v.end(), [](const Region &r) { return r.size() <= 1; }), v.end());
 }
 
-std::vector<Region> chain_strand(const std::vector<const Rec *> &s, int dist) {
+std::vector<Region> chain_strand(const Strand &s, int dist) {
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<Region> out;
-    if (s.size() <= 1) return out;
+    const size_t n = s.pos.size();
+    if (n <= 1) return out;
     Region cur;
-    if (s[1]->pos - s[0]->pos < dist) cur.reads.push_back(s[0]);
-    for (size_t i = 1; i < s.size(); i++) {
-        if (s[i]->pos - s[i - 1]->pos < dist)
-            cur.reads.push_back(s[i]);
-        else if (cur.reads.size() > 2) {  // a chain of <= 2 reads is not closed by a gap, it keeps growing (L247)
+    cur.st = &s;
+    auto add = [&](int i) {
+        if (cur.is_list)
+            cur.list.push_back(i);
+        else if (cur.hi == cur.lo) {
+            cur.lo = i;
+            cur.hi = i + 1;
+        } else if (i == cur.hi)
+            cur.hi++;
+        else {  // a chain of <= 2 reads that went on behind a gap: the read at the gap is not a member
+            cur.materialize();
+            cur.list.push_back(i);
+        }
+    };
+    if (s.pos[1] - s.pos[0] < dist) add(0);
+    for (size_t i = 1; i < n; i++) {
+        if (s.pos[i] - s.pos[i - 1] < dist)
+            add((int)i);
+        else if (cur.size() > 2) {  // a chain of <= 2 reads is not closed by a gap, it keeps growing (L247)
             out.push_back(cur);
             cur = Region();
+            cur.st = &s;
         }
     }
-    if (cur.reads.size() > 2) out.push_back(cur);
+    if (cur.size() > 2) out.push_back(cur);
+    const bool timing = std::getenv("SMI_RG_TIMING") != nullptr;
+    const auto t1 = std::chrono::steady_clock::now();
+    const size_t n_chains = out.size();
     refine_regions(out, dist);
+    if (timing)
+        fprintf(stderr, "  strand of %zu reads: chains %.3f ms (%zu), refinement %.3f ms (%zu regions)\n", n,
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), n_chains,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count(), out.size());
     return out;
 }
 
-}  // namespace
-}  // namespace smi
-
-extern "C" int smi_region_group(const int32_t *pos, const uint8_t *has_pos, const uint8_t *reverse, int32_t n,
-                                int32_t max_dist, int keep_data_end, int32_t *region, int32_t *n_done) {
-    if (n < 0 || max_dist <= 0 || !n_done || (n && (!pos || !has_pos || !reverse || !region))) {
-        set_error("smi_region_group: bad argument");
-        return SMI_ERR_INVALID;
+// everything behind the sort: chains and their refinement per strand, the regions of both strands in centre order, the cut of the chunk
+template <class Lap>
+int region_group_tail(Strand *strand, int32_t n, size_t n_pos, int most_right, int32_t max_dist, int keep_data_end, int32_t *region, int32_t *n_done,
+                      Lap &&rg_lap) {
+    // the two strands are independent (doClusteringOneStrand per strand, L113-121); a second thread only pays on very large chunks (a chunk
+    // of 120 k reads is 0.2 ms of work per strand once the regions are pieces of the sorted strand: less than starting a thread costs)
+    std::vector<Region> all, rv;
+    if (n_pos > 2000000) {
+        std::thread other([&] { rv = chain_strand(strand[1], max_dist); });
+        all = chain_strand(strand[0], max_dist);
+        other.join();
+    } else {
+        all = chain_strand(strand[0], max_dist);
+        rv = chain_strand(strand[1], max_dist);
     }
+    rg_lap("strands");
+    all.insert(all.end(), rv.begin(), rv.end());
+    sort_by_center(all);
+    rg_lap("merge");
+    int last_index = n - 1;
+    if (keep_data_end && !all.empty() && n_pos) {  // L171-184
+        while (!all.empty() && all.back().center() > most_right - 3 * max_dist) all.pop_back();
+        if (!all.empty()) {
+            last_index = 0;
+            const Region &last = all.back();
+            last.for_each([&](int k) { last_index = std::max(last_index, last.st->index[(size_t)k]); });
+            last_index = std::max(last_index, n / 3);
+        }
+    }
+    for (size_t k = 0; k < all.size(); k++) {
+        const Region &r = all[k];
+        r.for_each([&](int m) { region[r.st->read[(size_t)m]] = (int32_t)k; });
+    }
+    *n_done = last_index + 1;
+    rg_lap("assign");
+    return SMI_OK;
+}
+
+// pos_of(i), has_pos_of(i), rev_of(i): the chunk's records wherever the caller keeps them
+template <class PosOf, class HasOf, class RevOf>
+int region_group_impl(int32_t n, PosOf pos_of, HasOf has_pos_of, RevOf rev_of, int32_t max_dist, int keep_data_end, int32_t *region, int32_t *n_done) {
     const bool rg_timing = std::getenv("SMI_RG_TIMING") != nullptr;
     auto rg_t0 = std::chrono::steady_clock::now();
     auto rg_lap = [&](const char *what) {
@@ -534,16 +631,16 @@ extern "C" int smi_region_group(const int32_t *pos, const uint8_t *has_pos, cons
         rg_t0 = now;
     };
     // Arrays.parallelSort by position, stable (ReadGrouper.java:L128): a least-significant-digit radix sort of (biased position, rank in
-    // BAM order) pairs -- three 11-bit passes, passes whose digit is the same for every record skipped (std::stable_sort took a third of
-    // this function on a 120 k-record chunk) -- and the records laid out in sorted order afterwards
+    // BAM order) pairs -- three 11-bit passes, passes whose digit is the same for every record skipped -- and the two strands laid out in
+    // sorted order afterwards
     std::vector<uint64_t> keys;
     keys.reserve((size_t)n);
     std::vector<int32_t> read_of;  // rank among the reads with a position -> record
     read_of.reserve((size_t)n);
     for (int i = 0; i < n; i++) {
         region[i] = -1;
-        if (has_pos[i]) {
-            keys.push_back(((uint64_t)((uint32_t)pos[i] ^ 0x80000000u) << 32) | (uint32_t)read_of.size());
+        if (has_pos_of(i)) {
+            keys.push_back(((uint64_t)((uint32_t)pos_of(i) ^ 0x80000000u) << 32) | (uint32_t)read_of.size());
             read_of.push_back(i);
         }
     }
@@ -564,46 +661,103 @@ extern "C" int smi_region_group(const int32_t *pos, const uint8_t *has_pos, cons
         if (src != keys.data()) std::memcpy(keys.data(), src, keys.size() * 8);
     } else
         std::sort(keys.begin(), keys.end());  // (position, rank) pairs are distinct: the order is the stable order by position
-    std::vector<Rec> data(keys.size());
+    Strand strand[2];  // forward, reverse
+    for (Strand &t : strand) {
+        t.pos.reserve(keys.size());
+        t.read.reserve(keys.size());
+        t.index.reserve(keys.size());
+        t.psum.reserve(keys.size() + 1);
+        t.psum.push_back(0);
+    }
+    int most_right = 0;
     for (size_t k = 0; k < keys.size(); k++) {
         const int idx = (int)(uint32_t)keys[k];
         const int i = read_of[(size_t)idx];
-        data[k] = Rec{pos[i], i, idx, reverse[i] != 0};
+        const int p = (int)((uint32_t)(keys[k] >> 32) ^ 0x80000000u);
+        Strand &t = strand[rev_of(i) ? 1 : 0];
+        t.pos.push_back(p);
+        t.read.push_back(i);
+        t.index.push_back(idx);
+        t.psum.push_back(t.psum.back() + p);
+        most_right = p;
     }
     rg_lap("sort");
-    std::vector<const Rec *> fwd, rev;
-    fwd.reserve(data.size());
-    rev.reserve(data.size());
-    for (const Rec &r : data) (r.rev ? rev : fwd).push_back(&r);
-    // the two strands are independent (doClusteringOneStrand per strand, L113-121): one thread each on a large chunk
-    std::vector<Region> all, rv;
-    if (data.size() > 20000) {
-        std::thread other([&] { rv = chain_strand(rev, max_dist); });
-        all = chain_strand(fwd, max_dist);
-        other.join();
-    } else {
-        all = chain_strand(fwd, max_dist);
-        rv = chain_strand(rev, max_dist);
-    }
-    rg_lap("strands");
-    all.insert(all.end(), rv.begin(), rv.end());
-    sort_by_center(all);
-    rg_lap("merge");
-    int last_index = n - 1;
-    if (keep_data_end && !all.empty() && !data.empty()) {  // L171-184
-        const int most_right = data.back().pos;
-        while (!all.empty() && all.back().center() > most_right - 3 * max_dist) all.pop_back();
-        if (!all.empty()) {
-            last_index = 0;
-            for (const Rec *r : all.back().reads) last_index = std::max(last_index, r->index);
-            last_index = std::max(last_index, n / 3);
+    return region_group_tail(strand, n, keys.size(), most_right, max_dist, keep_data_end, region, n_done, rg_lap);
+}
+
+}  // namespace
+
+// the same grouping from keys the device has sorted (smi_umi_stage.hip, k_umi_region_keys): key = biased position << 32 | record << 1 | strand,
+// n_pos of them; has_bits: one bit per record, set where the record has a position (ranks among those are what `n_done` counts in)
+// The strands' arrays live in a workspace the context keeps between calls: a chunk of 300 k reads is ~10 MB of them, which malloc would map and
+// unmap on every call -- page faults, and an unmap interrupts every thread of the process, which is what kept several lanes from scaling.
+struct RegionWork {
+    Strand strand[2];
+    std::vector<uint32_t> rank_before;
+};
+void region_work_free(void *w) { delete static_cast<RegionWork *>(w); }
+
+int region_group_from_sorted(void **work, const uint64_t *keys, size_t n_pos, int32_t n, const uint64_t *has_bits, int32_t max_dist, int keep_data_end,
+                             int32_t *region, int32_t *n_done) {
+    const bool rg_timing = std::getenv("SMI_RG_TIMING") != nullptr;
+    auto rg_t0 = std::chrono::steady_clock::now();
+    auto rg_lap = [&](const char *what) {
+        if (!rg_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "smi_region_group %-10s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - rg_t0).count());
+        rg_t0 = now;
+    };
+    if (!*work) *work = new RegionWork();
+    RegionWork &W = *static_cast<RegionWork *>(*work);
+    std::fill(region, region + n, -1);
+    std::vector<uint32_t> &rank_before = W.rank_before;  // records with a position in front of each 64-record word
+    if (keep_data_end) {
+        rank_before.resize(((size_t)n + 63) / 64 + 1);
+        uint32_t acc = 0;
+        for (size_t w = 0; w < rank_before.size(); w++) {
+            rank_before[w] = acc;
+            if (w * 64 < (size_t)n) acc += (uint32_t)__builtin_popcountll(has_bits[w]);
         }
     }
-    for (size_t k = 0; k < all.size(); k++)
-        for (const Rec *r : all[k].reads) region[r->read] = (int32_t)k;
-    *n_done = last_index + 1;
-    rg_lap("assign");
-    return SMI_OK;
+    Strand *strand = W.strand;
+    for (int k = 0; k < 2; k++) {
+        Strand &t = strand[k];
+        t.pos.clear();
+        t.read.clear();
+        t.index.clear();
+        t.psum.clear();
+        t.pos.reserve(n_pos);
+        t.read.reserve(n_pos);
+        if (keep_data_end) t.index.reserve(n_pos);
+        t.psum.reserve(n_pos + 1);
+        t.psum.push_back(0);
+    }
+    int most_right = 0;
+    for (size_t k = 0; k < n_pos; k++) {
+        const uint64_t key = keys[k];
+        const int p = (int)((uint32_t)(key >> 32) ^ 0x80000000u);
+        const int i = (int)((uint32_t)key >> 1);
+        Strand &t = strand[key & 1u];
+        t.pos.push_back(p);
+        t.read.push_back(i);
+        if (keep_data_end) t.index.push_back((int)(rank_before[(size_t)i >> 6] + (uint32_t)__builtin_popcountll(has_bits[(size_t)i >> 6] & ((1ull << (i & 63)) - 1ull))));
+        t.psum.push_back(t.psum.back() + p);
+        most_right = p;
+    }
+    rg_lap("strands in");
+    return region_group_tail(strand, n, n_pos, most_right, max_dist, keep_data_end, region, n_done, rg_lap);
+}
+}  // namespace smi
+
+extern "C" int smi_region_group(const int32_t *pos, const uint8_t *has_pos, const uint8_t *reverse, int32_t n,
+                                int32_t max_dist, int keep_data_end, int32_t *region, int32_t *n_done) {
+    if (n < 0 || max_dist <= 0 || !n_done || (n && (!pos || !has_pos || !reverse || !region))) {
+        set_error("smi_region_group: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    return smi::region_group_impl(
+        n, [&](int i) { return pos[i]; }, [&](int i) { return has_pos[i] != 0; }, [&](int i) { return reverse[i] != 0; }, max_dist, keep_data_end, region,
+        n_done);
 }
 
 extern "C" int smi_ref_position_at_read_position(const uint32_t *cigar, int32_t n_cigar, int32_t alignment_start,

@@ -227,6 +227,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->arena);
     (void)hipFree(ctx->umi_dist);
     (void)hipFree(ctx->deflate_scratch);
+    region_work_free(ctx->region_work);
     (void)hipFree(ctx->chim_list);
     (void)hipFree(ctx->chim_slots);
     (void)hipHostFree(ctx->host_out[0]);

@@ -149,10 +149,11 @@ struct smi_ctx {
     std::vector<smi_scan_result> host_scan;  // its per-record results when asked for
     std::vector<smi_bc_result> host_bc;
     // packed chunk workers: page-locked, grow-only host buffers (index, offsets, planes, quality tails / sums, decisions)
-    enum { HB_RECS = 0, HB_OFFS, HB_PSTART, HB_PLANES, HB_QTAIL, HB_QSUM, HB_CHIM, HB_FOFFS, HB_FSRC, HB_SCAN, HB_BC, HB_RANK, HB_COUNT };
+    enum { HB_RECS = 0, HB_OFFS, HB_PSTART, HB_PLANES, HB_QTAIL, HB_QSUM, HB_CHIM, HB_FOFFS, HB_FSRC, HB_SCAN, HB_BC, HB_RANK, HB_RKEYS, HB_RBITS, HB_REGION, HB_COUNT };
     smi_scan_stats host_stats = {};  // scan statistics of the last packed pass-2 chunk (want_results)
     void *umi_dist = nullptr;      // K-UMI matrices of the device UMI stage (smi_assignumis_chunk), grow-only
     size_t umi_dist_bytes = 0;
+    void *region_work = nullptr;      // host scratch of the region grouping (smi_cluster.hip), kept between calls
     void *deflate_scratch = nullptr;  // K-DEFLATE: block slots, sizes, offsets, scan storage (grow-only)
     size_t deflate_scratch_bytes = 0;
     void *host_buf[HB_COUNT] = {};
@@ -207,6 +208,15 @@ __host__ __device__ inline size_t plane_start(uint64_t base_offset, size_t r) { 
 int launch_ends_from_planes(smi_ctx *ctx, const uint32_t *d_planes, size_t stride, const uint64_t *d_read_offsets, const uint64_t *d_rec_offsets,
                             const uint32_t *d_frag_src, size_t m, uint32_t *d_ends, int32_t *d_len, hipStream_t s, const uint32_t *d_pstart = nullptr);
 int ensure_host_buf(smi_ctx *ctx, int which, size_t bytes);
+// smi_region_group from keys sorted on the device (smi_cluster.hip)
+int region_group_from_sorted(void **work, const uint64_t *keys, size_t n_pos, int32_t n, const uint64_t *has_bits, int32_t max_dist, int keep_data_end,
+                             int32_t *region, int32_t *n_done);  // *work: scratch kept between calls (ctx->region_work)
+void region_work_free(void *work);
+int region_group_from_sorted(void **work, const uint64_t *keys, size_t n_pos, int32_t n, const uint64_t *has_bits, int32_t max_dist, int keep_data_end,
+                             int32_t *region, int32_t *n_done);  // *work: scratch kept between calls (ctx->region_work)
+void region_work_free(void *work);
+int region_group_strided(const void *recs, size_t stride, size_t pos_off, size_t flags_off, uint32_t has_pos_bit, uint32_t rev_bit, int32_t n,
+                         int32_t max_dist, int keep_data_end, int32_t *region, int32_t *n_done);
 // K-DEFLATE (smi_deflate.hip): d_in -> one gzip member / raw deflate stream in d_out; d_total[0] = its size, d_total[1] = error flags (device)
 size_t deflate_bound(size_t n_bytes);
 size_t deflate_scratch_bytes(size_t n_bytes);

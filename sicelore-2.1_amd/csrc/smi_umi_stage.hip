@@ -701,6 +701,36 @@ int launch_umi_parse(smi_ctx *, const char *d_names, const uint32_t *d_name_off,
     return SMI_OK;
 }
 
+// sort keys of the region grouping (ReadGrouper sorts the chunk's reads by clustering position, stable in BAM order): biased position in the
+// upper half, record number and strand below it; records without a position sort to the end.  Also: how many have a position, whether any
+// name needs the host parser, and one bit per record "has a position" (the host asks for ranks among those in one rare case).
+__global__ __launch_bounds__(256) void k_umi_region_keys(const UmiParsed *__restrict__ P, int n, uint64_t *__restrict__ keys, uint32_t *__restrict__ counters,
+                                                         uint64_t *__restrict__ has_bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = i < n ? P[i].flags : 0u;
+    const bool has = (f & UP_HAS_POS) != 0;
+    if (i < n)
+        keys[i] = has ? ((uint64_t)((uint32_t)P[i].cpos ^ 0x80000000u) << 32) | ((uint64_t)(uint32_t)i << 1) | ((f & UP_REV) ? 1u : 0u) : ~0ull;
+    const uint64_t m = __ballot(has);
+    const uint64_t bad = __ballot((f & (UP_NONSTD | UP_ERROR)) != 0);
+    if ((threadIdx.x & 63) == 0) {
+        if (i < n) has_bits[i >> 6] = m;
+        if (m) atomicAdd(&counters[0], (uint32_t)__popcll(m));
+        if (bad) atomicOr(&counters[1], 1u);
+    }
+}
+
+// -> B.keys_sorted[0 .. n): the keys in ascending order; d_counters[0] = records with a position, [1] = some name needs the host parser
+int launch_umi_region_keys(smi_ctx *, const UmiParsed *d_parsed, int n, UmiGroupBuffers &B, uint32_t *d_counters, uint64_t *d_has_bits, hipStream_t s) {
+    if (!n) return SMI_OK;
+    SMI_HIP(hipMemsetAsync(d_counters, 0, 8, s));
+    hipLaunchKernelGGL(k_umi_region_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_parsed, n, B.keys, d_counters, d_has_bits);
+    size_t tmp = B.tmp_bytes;
+    SMI_HIP(hipcub::DeviceRadixSort::SortKeys(B.tmp, tmp, B.keys, B.keys_sorted, n, 0, 64, s));
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
 size_t umi_group_scratch_bytes(int n) {
     size_t sort_tmp = 0, rle_tmp = 0, scan32 = 0, scan64 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_tmp, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, n);

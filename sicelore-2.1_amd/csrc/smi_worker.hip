@@ -1051,18 +1051,6 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
     return SMI_OK;
 }
 
-// region grouping of a chunk from K-UPARSE's records: smi_region_group (exact, sequential per strand)
-int regions_from_parsed(const UmiParsed *P, int32_t n, const smi_assignumis_config *cfg, std::vector<int32_t> &region, int32_t *n_done) {
-    std::vector<int32_t> cpos((size_t)n);
-    std::vector<uint8_t> has_pos((size_t)n), rev((size_t)n);
-    for (int32_t i = 0; i < n; i++) {
-        cpos[i] = P[i].cpos;
-        has_pos[i] = (P[i].flags & UP_HAS_POS) ? 1 : 0;
-        rev[i] = (P[i].flags & UP_REV) ? 1 : 0;
-    }
-    region.assign((size_t)n, -1);
-    return smi_region_group(cpos.data(), has_pos.data(), rev.data(), n, cfg->max_dist, cfg->keep_data_end, region.data(), n_done);
-}
 }  // namespace
 
 extern "C" int smi_umi_cluster_groups_device(smi_ctx *ctx, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups,
@@ -1108,7 +1096,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     const size_t tmp_bytes = umi_group_scratch_bytes(n + 2);
     const size_t G = N / 2 + 2;
     const size_t fixed = pad(name_bytes + 16) + 2 * pad((N + 1) * 4) + pad(N * 2) + pad(N * 4) + pad((n_cig + 1) * 4) + pad(N * sizeof(UmiParsed)) + pad(N * 4) +
-                         3 * pad((N + 2) * 8) + 4 * pad((N + 2) * 4) + pad(16) + 4 * pad((N + 2) * 4) + 4 * pad((N + 2) * 8) + pad(G * 4) + pad(N * 4) + 2 * pad(G * 8) +
+                         3 * pad((N + 2) * 8) + 4 * pad((N + 2) * 4) + pad(16) + pad(16) + pad((N / 64 + 2) * 8) + 4 * pad((N + 2) * 4) + 4 * pad((N + 2) * 8) + pad(G * 4) + pad(N * 4) + 2 * pad(G * 8) +
                          pad(N * 8) + pad(N * 4) + pad(tmp_bytes) + pad(N * sizeof(smi_umi_assignment)) + pad(N) + pad(N * sizeof(smi_umi_tag)) + 8192;
     SMI_RC(ensure_arena(ctx, fixed));
     Arena A(ctx);
@@ -1119,6 +1107,8 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     uint32_t *d_cig = A.take<uint32_t>(n_cig + 1);
     UmiParsed *d_parsed = A.take<UmiParsed>(N);
     int32_t *d_region = A.take<int32_t>(N);
+    uint32_t *d_rcount = A.take<uint32_t>(4);
+    uint64_t *d_rbits = A.take<uint64_t>((N + 63) / 64 + 1);
     UmiGroupBuffers B;
     B.keys = A.take<uint64_t>(N + 2);
     B.keys_sorted = A.take<uint64_t>(N + 2);
@@ -1154,17 +1144,27 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     SMI_HIP(hipMemcpyAsync(d_pos0, pos0, N * 4, hipMemcpyHostToDevice, s));
     if (n_cig) SMI_HIP(hipMemcpyAsync(d_cig, cigars, n_cig * 4, hipMemcpyHostToDevice, s));
     SMI_RC(launch_umi_parse(ctx, d_names, d_noff, d_flags, d_pos0, d_cig, d_coff, n, cfg->five_prime != 0, cfg->grouping_distance, cfg->bc_edit_limit, d_parsed, s));
-    std::vector<UmiParsed> parsed(N);
-    SMI_HIP(hipMemcpyAsync(parsed.data(), d_parsed, N * sizeof(UmiParsed), hipMemcpyDeviceToHost, s));
+    // region grouping: the sort by clustering position runs on the device; the sorted keys (8 bytes per read with a position) come down, the
+    // chains and their refinement -- a sequential sweep with the reference's own quirks -- run on the host, the region numbers go up
+    const size_t n_words = (N + 63) / 64;
+    SMI_RC(launch_umi_region_keys(ctx, d_parsed, n, B, d_rcount, d_rbits, s));
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_RKEYS, N * 8 + 16));
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_RBITS, n_words * 8 + 16));
+    SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_REGION, N * 4));
+    uint64_t *h_keys = static_cast<uint64_t *>(ctx->host_buf[smi_ctx::HB_RKEYS]);
+    uint64_t *h_bits = static_cast<uint64_t *>(ctx->host_buf[smi_ctx::HB_RBITS]);
+    int32_t *h_region = static_cast<int32_t *>(ctx->host_buf[smi_ctx::HB_REGION]);
+    uint32_t *h_rcount = reinterpret_cast<uint32_t *>(h_bits + n_words);
+    SMI_HIP(hipMemcpyAsync(h_rcount, d_rcount, 8, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipMemcpyAsync(h_keys, B.keys_sorted, N * 8, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipMemcpyAsync(h_bits, d_rbits, n_words * 8, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
-    lap("parse");
-    for (size_t i = 0; i < N; i++)
-        if (parsed[i].flags & (UP_NONSTD | UP_ERROR))  // the host path reads such a name itself (and reports AE= missing as the reference does)
-            return assignumis_chunk_host(ctx, names, name_off, flags, pos0, cigars, cigar_off, n, cfg, out, n_done);
-    std::vector<int32_t> region;
-    SMI_RC(regions_from_parsed(parsed.data(), n, cfg, region, n_done));
+    lap("parse+sort");
+    if (h_rcount[1])  // a name the device parser does not evaluate: the host path reads it itself (and reports AE= missing as the reference does)
+        return assignumis_chunk_host(ctx, names, name_off, flags, pos0, cigars, cigar_off, n, cfg, out, n_done);
+    SMI_RC(region_group_from_sorted(&ctx->region_work, h_keys, h_rcount[0], n, h_bits, cfg->max_dist, cfg->keep_data_end, h_region, n_done));
     lap("regions");
-    SMI_HIP(hipMemcpyAsync(d_region, region.data(), N * 4, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(d_region, h_region, N * 4, hipMemcpyHostToDevice, s));
     uint64_t totals[4];
     SMI_RC(launch_umi_groups(ctx, d_parsed, d_region, n, *n_done, B, totals, s));
     const uint32_t n_groups = (uint32_t)totals[0], m = (uint32_t)totals[1];

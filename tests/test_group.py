@@ -64,6 +64,29 @@ def test_random_chunks(sor, pkg):
     assert n_regions > 200
 
 
+def test_large_chunks_product_equals_oracle(sor, pkg):
+    """the product's grouping (regions as pieces of the sorted strand until something touches them; radix sort above 2048 reads) against the
+    oracle on chunks large enough for every path: dense loci that split and merge, sparse ones that never do, ties, both keep_data_end forms"""
+    from sicelore_amd import lib as libmod
+
+    rng = np.random.default_rng(77)
+    n_split = 0
+    for trial in range(40):
+        n = int(rng.choice([2100, 3000, 6000, 25_000]))
+        pos, rev = make_chunk(rng, n, int(rng.choice([3, 20, 200, 1500])), spread=int(rng.choice([20, 200, 450, 900])),
+                              far_frac=float(rng.choice([0.0, 0.05, 0.2])))
+        if trial % 5 == 0:   # heavy ties: few distinct positions
+            pos = [None if p is None else (p // 300) * 300 for p in pos]
+            order = np.argsort([(-1 if p is None else p) for p in pos], kind="stable")
+            pos, rev = [pos[i] for i in order], [rev[i] for i in order]
+        kw = dict(max_dist=int(rng.choice([100, 500, 500, 2000])), keep_data_end=bool(trial & 1))
+        r_o, done_o = sor.region_group(pos, rev, **kw)
+        r_p, done_p = libmod.region_group(pos, rev, **kw)
+        assert r_p == r_o and done_p == done_o, trial
+        n_split += len(canon(r_o))
+    assert n_split > 2000
+
+
 def test_reference_position_at_read_position(sor, pkg):
     from sicelore_amd import lib as libmod
 
