@@ -110,7 +110,7 @@ __constant__ ClCode c_cl = make_cl_code();
 
 struct DeflateLds {
     union {
-        uint32_t hist[8][264];  // pass A: privatised histograms
+        uint32_t hist[8][260];  // pass A: privatised histograms (260 = 8 * 32 + 4: a symbol sits in eight different banks in the eight copies)
         uint32_t tail[1024];    // pass C: the bits a run leaves in its last, partial word (the next run's owner stores that word)
     };
     uint32_t ufreq[260];   // used symbols, unsorted
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
     const uint8_t *src = in + b0;
     uint32_t *slot = reinterpret_cast<uint32_t *>(slots + (uint64_t)blockIdx.x * kSlotBytes);
     // ---- tables, zeroes -------------------------------------------------------------------------------------------------------
-    for (int i = tid; i < 8 * 264; i += kDefThreads) (&L.hist[0][0])[i] = 0;
+    for (int i = tid; i < 8 * 260; i += kDefThreads) (&L.hist[0][0])[i] = 0;
     {
         uint32_t c = (uint32_t)tid;
         for (int k = 0; k < 8; k++) c = (c & 1u) ? (c >> 1) ^ kCrcPoly : c >> 1;
