@@ -300,9 +300,10 @@ def umi_stage_leg(pkg, synth, ctx, used, n_mol, copies=6, genes_per=10):
                       "(groups <= 100 reads; larger ones on the host), K-UTAG; host arrays (page-locked) in, tags out"}
 
 
-def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=2, threads=None):
+def host_to_host_leg(pkg, synth, ctx, dev, used, n):
     """pass 2 of one chunk from host FASTQ text to host `passed` / `failed` text through the PACKED boundary (bit-planes up, decisions down,
-    records written by host threads): what a JNI host obtains, PCIe and host cores included.  Never part of `value`."""
+    records written by host threads): what a JNI host obtains, PCIe and host cores included.  Never part of `value`.  Three ways to spend the
+    host's cores (lanes x threads per lane) are run, the best is reported (all of them are in `runs`)."""
     import threading
 
     lib = importlib.import_module(graft.PKG_NAME + ".lib")
@@ -311,43 +312,45 @@ def host_to_host_leg(pkg, synth, ctx, dev, used, n, lanes=2, threads=None):
         quota = None if q[0] == "max" else float(q[0]) / float(q[1])
     except Exception:
         quota = None
-    if threads is None:
-        # two lanes, each with as many host threads as the process may run at once: one lane's host stages overlap the other's device side
-        # (tools/microbench.py packed sweeps lanes x threads: profiles/r03/microbench_packed.json)
-        threads = max(1, min(int(quota) if quota else 16, len(os.sched_getaffinity(0))))
+    cpus = max(1, min(int(quota) if quota else 16, len(os.sched_getaffinity(0))))
     ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
     rd = synth.gen_reads(n, used, seed=9, device=dev)
     text = synth.fastq_text_device(rd)[0]
     total = int(text.numel())
-    pin = lib.PinnedBuffer(total)
-    pin.array[:] = text.cpu().numpy()
+    host_text = text.cpu().numpy()
     del rd, text
-    ctxs = [ctx] + [ctx.lane() for _ in range(lanes - 1)]
-    pins = [pin] + [lib.PinnedBuffer(total) for _ in range(lanes - 1)]
-    for pb in pins[1:]:
-        pb.array[:] = pin.array
-    out_bytes = 0
-    for c, pb in zip(ctxs, pins):
-        p, f, _ = c.scanfastq_pass2_chunk(pb.array, copy=False, packed=True, n_threads=threads)   # warm-up: arena, pinned buffers
-        out_bytes = int(p.size + f.size)
-    per = 3
-    th = [threading.Thread(target=lambda c=c, pb=pb: [c.scanfastq_pass2_chunk(pb.array, copy=False, packed=True, n_threads=threads) for _ in range(per)])
-          for c, pb in zip(ctxs, pins)]
-    t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    dt = time.perf_counter() - t0
+    max_lanes = 8
+    ctxs = [ctx] + [ctx.lane() for _ in range(max_lanes - 1)]
+    pins = [lib.PinnedBuffer(total) for _ in range(max_lanes)]
+    for pb in pins:
+        pb.array[:] = host_text
+    runs, out_bytes = [], 0
+    # (lanes, threads): one lane's host stages overlap another's device side; more lanes with fewer threads each need no barrier between threads
+    for lanes, threads in ((2, cpus), (4, max(1, cpus // 2)), (8, max(1, cpus // 4))):
+        for c, pb in zip(ctxs[:lanes], pins):
+            p, f, _ = c.scanfastq_pass2_chunk(pb.array, copy=False, packed=True, n_threads=threads)   # warm-up: arena, pinned buffers
+            out_bytes = int(p.size + f.size)
+        per = 3
+        th = [threading.Thread(target=lambda c=c, pb=pb, threads=threads: [c.scanfastq_pass2_chunk(pb.array, copy=False, packed=True, n_threads=threads)
+                                                                             for _ in range(per)]) for c, pb in zip(ctxs[:lanes], pins)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        dt = time.perf_counter() - t0
+        runs.append({"lanes": lanes, "host_threads_per_lane": threads, "reads_per_s": n * lanes * per / dt, "ms_per_chunk": dt / per * 1e3})
     for c in ctxs[1:]:
         c.close()
     for pb in pins:
         pb.close()
-    return {"reads_per_chunk": n, "lanes": lanes, "host_threads_per_lane": threads, "reads_per_s": n * lanes * per / dt, "ms_per_chunk": dt / per * 1e3,
+    best = max(runs, key=lambda r: r["reads_per_s"])
+    return {"reads_per_chunk": n, "lanes": best["lanes"], "host_threads_per_lane": best["host_threads_per_lane"], "reads_per_s": best["reads_per_s"],
+            "ms_per_chunk": best["ms_per_chunk"], "runs": runs,
             "text_in_bytes": total, "text_out_bytes": out_bytes, "link_bytes_per_read": "~0.7 KB up (bit-planes), ~80 B down (decisions)",
             "host_cpus_visible": len(os.sched_getaffinity(0)), "host_cpu_quota": quota,
             "note": "smi_scanfastq_pass2_chunk_packed on worker lanes of one GPU; host-bound (index, planes and records are written by the host's "
-                    "cores): ~1.2 M reads/s per core on this box, against 14.5 M reads/s for the text worker, which the link bounds"}
+                    "cores): ~1 M reads/s per core on this box, against 14.5 M reads/s for the text worker, which the link bounds"}
 
 
 def file_to_file_leg(pkg, synth, ctx, dev, wl, used, n_reads, scratch=None, n_files=64, workers=16):
