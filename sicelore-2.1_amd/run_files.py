@@ -23,9 +23,13 @@ import torch
 from . import lib as _lib
 
 
-def _inflate(path):
+def _inflate(path, pinned=False):
+    """-> (uint8 array of the file's text, owner).  pinned: the text lands in page-locked memory (smi_host_alloc), from which the chunk
+    workers upload at link speed and side by side on several lanes (pageable memory goes through the runtime's one staging path);
+    owner.close() frees it"""
     with open(path, "rb") as f:
         raw = f.read()
+    parts = [raw]
     if path.endswith(".gz"):
         d = zlib.decompressobj(31)
         parts = []
@@ -35,8 +39,15 @@ def _inflate(path):
             if not d.eof:
                 break
             d = zlib.decompressobj(31)
-        raw = b"".join(parts)
-    return np.frombuffer(raw, dtype=np.uint8)
+    if not pinned:
+        return np.frombuffer(parts[0] if len(parts) == 1 else b"".join(parts), dtype=np.uint8), None
+    total = sum(len(p) for p in parts)
+    pb = _lib.PinnedBuffer(max(total, 1))
+    at = 0
+    for p in parts:
+        pb.array[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
+        at += len(p)
+    return pb.array[:total], pb
 
 
 def write_synthetic_dir(synth, out_dir, n_files, reads_per_file, used, device, seed=9000, chimera_frac=0.05, gz_level=1, pool=None, q_lo=35, q_hi=64):
@@ -106,7 +117,7 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device"):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
@@ -143,6 +154,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     cpu_inflate = [0.0] * len(files)
+    owners = [None] * len(files)
 
     def p1(lane, text, rng):
         # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
@@ -150,7 +162,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
 
     def load_and_count(fi):
         t1 = time.perf_counter()
-        t = _inflate(os.path.join(in_dir, files[fi]))
+        t, owner = _inflate(os.path.join(in_dir, files[fi]), pinned=pinned_text)
+        owners[fi] = owner
         cuts = _cut_chunks(t, reads_per_chunk)
         cpu_inflate[fi] = time.perf_counter() - t1
         return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
@@ -240,6 +253,9 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     for ln in lanes[1:]:
         ln.close()
     pool.shutdown()
+    for o in owners:
+        if o is not None:
+            o.close()
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
     return {"files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
