@@ -699,6 +699,22 @@ int smi_bgzf_uncompressed_size(const uint8_t *in, size_t n_in, size_t *n_out, si
 /* inflates every complete block (CRC32 and ISIZE checked, as BlockCompressedInputStream does) on n_threads threads */
 int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, size_t *consumed,
                      int n_threads);
+/* K-INFLATE: the *.fastq.gz inputs of scanfastq (FastqFileReader.java:L138-150: a GZIPInputStream per file; README.md:155: the reference
+ * parallelises over input files) inflated on the device, one wavefront per file (the lanes decode the bit positions of a step speculatively).
+ * d_in: the files' bytes on the device, file i at in_off (a multiple of 4), in_len bytes; 1 KiB of readable bytes behind the last file.
+ * File i's text goes to d_out + out_off, at most out_cap bytes (single-member files say their size in their last four bytes).  Multi-member
+ * files, stored / fixed / dynamic blocks and the optional header fields are handled; CRC-32 and ISIZE of every member are checked.
+ * results[i].status: 0 = inflated and verified; anything else (malformed or unusual input, out_cap too small, > 1024 members): the caller
+ * inflates that file with smi_gz_inflate.  Synchronous (the results are on the host when it returns). */
+typedef struct {
+    uint64_t in_off, in_len, out_off, out_cap;
+} smi_inflate_stream;
+typedef struct {
+    uint64_t out_len;
+    uint32_t status, n_members;
+} smi_inflate_result;
+int smi_gz_inflate_device(smi_ctx *ctx, const uint8_t *d_in, const smi_inflate_stream *streams, int n_streams, uint8_t *d_out,
+                          smi_inflate_result *results, void *stream);
 /* K-DEFLATE: the `--compress` writer of scanfastq (FastqWriterThreadPool.java:L242-257: a GZIPOutputStream per passed / failed file;
  * quickrun-2.1.sh:35) on the device.  d_in[0 .. n_bytes) (device) -> d_out (device, at least smi_deflate_bound(n_bytes) bytes): ONE gzip
  * member (RFC 1952; raw_deflate != 0: the bare RFC 1951 stream) that any inflater reads back to the input: dynamic-Huffman blocks of

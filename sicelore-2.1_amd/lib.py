@@ -58,7 +58,7 @@ EXPORTS = [
     "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
-    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device",
+    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library():
     lib.smi_deflate_bound.argtypes = [sz]
     lib.smi_deflate_bound.restype = sz
     lib.smi_gzip_device.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_int, vp]
+    lib.smi_gz_inflate_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
     lib.smi_packed_planes_words.argtypes = [sz, ci]
     lib.smi_packed_planes_words.restype = sz
     lib.smi_fastq_index_pack_host.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
@@ -916,6 +917,36 @@ class Context:
         self._check(self._lib.smi_ends_from_planes_device(self._h, _ptr(d_planes), _ptr(d_read_offsets), int(n_reads), int(total_bases),
                                                           _ptr(d_rec_offsets), _ptr(d_frag_src), int(n_records), _ptr(d_ends), _ptr(d_len),
                                                           _stream_ptr(stream)))
+
+    def gz_inflate_device(self, files, out_caps=None):
+        """K-INFLATE (smi_gz_inflate_device): a list of gzip files (bytes / uint8 arrays) -> (uint8 device tensor with all texts, offsets, lengths,
+        statuses); file i's text is out[offsets[i] : offsets[i] + lengths[i]] when statuses[i] == 0.  out_caps: capacity per file (default: the
+        ISIZE field at the end of the file, which is the text's size for a single-member file below 4 GB)"""
+        import torch
+
+        n = len(files)
+        arrs = [np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else f for f in files]
+        in_off, at = [], 0
+        for a in arrs:
+            in_off.append(at)
+            at = (at + a.size + 511) & ~511
+        host = np.zeros(at + 1024, dtype=np.uint8)
+        for a, o in zip(arrs, in_off):
+            host[o:o + a.size] = a
+        if out_caps is None:
+            out_caps = [int.from_bytes(a[-4:].tobytes(), "little") if a.size >= 18 else 0 for a in arrs]
+        out_off, at = [], 0
+        for c in out_caps:
+            out_off.append(at)
+            at = (at + int(c) + 255) & ~255
+        dev = torch.device("cuda", self.device)
+        d_in = torch.from_numpy(host).to(dev)
+        d_out = torch.empty(max(at, 1), dtype=torch.uint8, device=dev)
+        S = np.zeros((n, 4), dtype=np.uint64)
+        S[:, 0], S[:, 1], S[:, 2], S[:, 3] = in_off, [a.size for a in arrs], out_off, out_caps
+        R = np.zeros(n, dtype=np.dtype([("out_len", "<u8"), ("status", "<u4"), ("n_members", "<u4")]))
+        self._check(self._lib.smi_gz_inflate_device(self._h, _ptr(d_in), S.ctypes.data, n, _ptr(d_out), R.ctypes.data, None))
+        return d_out, np.array(out_off, dtype=np.int64), R["out_len"].astype(np.int64), R["status"].copy(), R["n_members"].copy()
 
     def gzip_device(self, d_in, n_bytes=None, raw_deflate=False, d_out=None, stream=None):
         """K-DEFLATE (smi_gzip_device): a uint8 device tensor -> one gzip member (or raw deflate stream) as a uint8 device tensor view"""

@@ -35,7 +35,7 @@ def main():
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
     legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis,
-            "packed": leg_packed, "deflate": leg_deflate}
+            "packed": leg_packed, "deflate": leg_deflate, "inflate": leg_inflate}
     for name, fn in legs.items():
         if only in (None, name):
             fn(pkg, synth, ctx, dev, wl, used, res)
@@ -363,6 +363,65 @@ def leg_deflate(pkg, synth, ctx, dev, wl, used, res):
                           "sample_bytes": len(sample), "sample_member_bytes": len(zs), "sample_zlib6_bytes": z6, "sample_zlib1_bytes": z1,
                           "size_vs_zlib6": len(zs) / z6, "zlib6_MBps_one_thread": len(sample) / t6 / 1e6, "zlib1_MBps_one_thread": len(sample) / t1 / 1e6,
                           "note": "one call incl. the 16-byte read-back of size and flags; literals-only dynamic Huffman blocks of 64 KiB"}
+
+
+def leg_inflate(pkg, synth, ctx, dev, wl, used, res):
+    """K-INFLATE: 64 gzip files of FASTQ text (zlib level 6 and level 1, qualities uniform over 29 values per base) resident in HBM -> their
+    text in HBM; against zlib on one host thread"""
+    import ctypes
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    n = int(os.environ.get("SMI_MB_READS", "500000"))
+    n_files = int(os.environ.get("SMI_MB_FILES", "64"))
+    rd = synth.gen_reads(n, used, seed=9, device=dev, q_mean=20.0)
+    text = synth.fastq_text_device(rd)[0]
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    is_q = text == ord("I")
+    text[is_q] = torch.randint(35, 64, (int(is_q.sum()),), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+    host = text.cpu().numpy()
+    del rd, is_q, text
+    cuts = np.linspace(0, host.size, n_files + 1).astype(np.int64)
+    parts = [host[cuts[i]:cuts[i + 1]] for i in range(n_files)]
+    for level in (6, 1):
+        def gz(a, level=level):
+            c = zlib.compressobj(level, zlib.DEFLATED, 31)
+            return c.compress(memoryview(a)) + c.flush()
+
+        with ThreadPoolExecutor(16) as pool:
+            files = list(pool.map(gz, parts))
+        t0 = time.perf_counter()
+        zlib.decompress(files[0], wbits=31)
+        t_zlib = time.perf_counter() - t0
+        in_off, at = [], 0
+        for f in files:
+            in_off.append(at)
+            at = (at + len(f) + 511) & ~511
+        hbuf = np.zeros(at + 1024, dtype=np.uint8)
+        for f, o in zip(files, in_off):
+            hbuf[o:o + len(f)] = np.frombuffer(f, dtype=np.uint8)
+        d_in = torch.from_numpy(hbuf).to(dev)
+        out_off, at = [], 0
+        for p in parts:
+            out_off.append(at)
+            at = (at + p.size + 255) & ~255
+        d_out = torch.zeros(at, dtype=torch.uint8, device=dev)
+        S = np.zeros((n_files, 4), dtype=np.uint64)
+        S[:, 0], S[:, 1], S[:, 2], S[:, 3] = in_off, [len(f) for f in files], out_off, [p.size for p in parts]
+        R = np.zeros(n_files, dtype=np.dtype([("out_len", "<u8"), ("status", "<u4"), ("n_members", "<u4")]))
+
+        def run():
+            ctx._check(ctx._lib.smi_gz_inflate_device(ctx._h, d_in.data_ptr(), S.ctypes.data, n_files, d_out.data_ptr(), R.ctypes.data, None))
+
+        dt = timed(run, reps=3)
+        assert (R["status"] == 0).all(), R["status"]
+        got = d_out.cpu().numpy()
+        assert all((got[o:o + p.size] == p).all() for o, p in zip(out_off, parts))
+        res[f"gz_inflate_device_level{level}"] = {"files": n_files, "gz_bytes": int(sum(len(f) for f in files)), "text_bytes": int(host.size), "ms": dt * 1e3,
+                                                  "text_GBps": host.size / dt / 1e9, "text_MBps_per_file": host.size / dt / 1e6 / n_files,
+                                                  "zlib_one_thread_text_MBps": parts[0].size / t_zlib / 1e6,
+                                                  "note": "one call: kernel, CRC-32 check of every member, results on the host"}
 
 
 def leg_packed(pkg, synth, ctx, dev, wl, used, res):
