@@ -26,10 +26,10 @@ enum { TK_LIT = 0, TK_MATCH = 1, TK_EOB = 2, TK_BAD = 3 };
 
 struct InfLds {
     uint8_t window[kWin];
-    uint16_t ll[1 << kLlBits];
-    uint16_t lls[kLlSubMax * kLlSub];
-    uint16_t dt[1 << kDBits];
-    uint16_t dts[kDSubMax * kDSub];
+    uint32_t ll[1 << kLlBits];
+    uint32_t lls[kLlSubMax * kLlSub];
+    uint32_t dt[1 << kDBits];
+    uint32_t dts[kDSubMax * kDSub];
     uint32_t inbuf[kInWords + 4];
     uint8_t lens[320];
     uint16_t code_of[320];
@@ -41,10 +41,26 @@ struct InfLds {
     uint64_t hdr_bitpos;         // bit position behind the block header
 };
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+// A table entry says everything about its symbol, so that a token costs one look-up per code (two for a code longer than the primary index):
+//   bits 0-3 code length (0: no such code), bits 4-7 extra bits, bits 8-9 kind (0 literal, 1 length or distance, 2 end of block,
+//   3 "continue in second-level table `value`"), bits 16-30 value (literal byte, length base, distance base, table number)
+enum { EK_LIT = 0, EK_BASE = 1, EK_EOB = 2, EK_SUB = 3 };
+__device__ __forceinline__ uint32_t entry_of(uint32_t sym, uint32_t len, bool dist_table) {
+    if (dist_table) {
+        if (sym > 29u) return 0u;  // codes 30 and 31 of the fixed code never occur in a valid stream
+        const uint32_t e = sym < 4u ? 0u : (sym >> 1) - 1u;
+        const uint32_t base = sym < 4u ? 1u + sym : 1u + ((2u + (sym & 1u)) << e);
+        return len | (e << 4) | (EK_BASE << 8) | (base << 16);
+    }
+    if (sym < 256u) return len | (EK_LIT << 8) | (sym << 16);
+    if (sym == 256u) return len | (EK_EOB << 8);
+    if (sym > 285u) return 0u;
+    const uint32_t li = sym - 257u;
+    if (li == 28u) return len | (EK_BASE << 8) | (258u << 16);
+    const uint32_t e = li < 8u ? 0u : (li >> 2) - 1u;
+    const uint32_t base = li < 8u ? 3u + li : 3u + ((4u + (li & 3u)) << e);
+    return len | (e << 4) | (EK_BASE << 8) | (base << 16);
+}
 
 // serial bit reader over global memory (block headers, gzip headers: one lane)
 struct BitReader {
@@ -64,10 +80,10 @@ struct BitReader {
 };
 
 // canonical Huffman decode tables from code lengths lens[0 .. n): primary table of 2^P entries, second-level tables of 2^(15 - P).
-// entry: bits 0-3 code length (0 = no code), bits 4-12 symbol; bit 15 set: bits 4-14 = second-level table to continue in.
+// (entries: entry_of above; a second-level entry keeps the WHOLE code length).
 // Returns false for an over-subscribed code or one that is incomplete in a way inflate does not accept.
 template <int P>
-__device__ bool build_table(InfLds &L, const uint8_t *lens, int n, uint16_t *prim, uint16_t *sub, int sub_max, uint32_t *n_sub_out, int lane, bool dist_table) {
+__device__ bool build_table(InfLds &L, const uint8_t *lens, int n, uint32_t *prim, uint32_t *sub, int sub_max, uint32_t *n_sub_out, int lane, bool dist_table) {
     constexpr int SUB = 1 << (15 - P);
     for (int i = lane; i < (1 << P); i += 64) prim[i] = 0;
     for (int i = lane; i < sub_max * SUB; i += 64) sub[i] = 0;
@@ -104,12 +120,12 @@ __device__ bool build_table(InfLds &L, const uint8_t *lens, int n, uint16_t *pri
             L.code_of[s] = (uint16_t)rev;
             if (len > (uint32_t)P) {
                 const uint32_t pre = rev & ((1u << P) - 1u);
-                if (!(prim[pre] & 0x8000u)) {
+                if (((prim[pre] >> 8) & 3u) != EK_SUB) {
                     if (n_sub >= (uint32_t)sub_max) {
                         ok = 0;
                         break;
                     }
-                    prim[pre] = (uint16_t)(0x8000u | (n_sub << 4));
+                    prim[pre] = (uint32_t)P | (EK_SUB << 8) | (n_sub << 16);
                     n_sub++;
                 }
             }
@@ -123,11 +139,11 @@ __device__ bool build_table(InfLds &L, const uint8_t *lens, int n, uint16_t *pri
         const uint32_t len = lens[s];
         if (!len) continue;
         const uint32_t rev = L.code_of[s];
-        const uint16_t e = (uint16_t)(len | ((uint32_t)s << 4));
+        const uint32_t e = entry_of((uint32_t)s, len, dist_table);
         if (len <= (uint32_t)P) {
             for (uint32_t k = rev; k < (1u << P); k += 1u << len) prim[k] = e;
         } else {
-            const uint32_t t = (prim[rev & ((1u << P) - 1u)] >> 4) & 0x7FFu;
+            const uint32_t t = prim[rev & ((1u << P) - 1u)] >> 16;
             for (uint32_t k = rev >> P; k < (uint32_t)SUB; k += 1u << (len - P)) sub[t * SUB + k] = e;
         }
     }
@@ -135,48 +151,36 @@ __device__ bool build_table(InfLds &L, const uint8_t *lens, int n, uint16_t *pri
     return true;
 }
 
-struct Token {
-    uint32_t kind, bits, out_len, info;  // info: literal byte, or length | distance << 9
-};
-
-__device__ __forceinline__ Token decode_token(const InfLds &L, uint64_t x) {
-    Token t;
-    t.kind = TK_BAD;
-    t.bits = 1;
-    t.out_len = 0;
-    t.info = 0;
+// a token as one word: bits 0-5 its length in bits (1 .. 48), bits 6-7 kind, bits 8-16 output length (0 .. 258); and its info word
+// (literal byte, or length | distance << 9)
+__device__ __forceinline__ void decode_token(const InfLds &L, uint64_t x, uint32_t &tok, uint32_t &info) {
+    tok = 1u | (TK_BAD << 6);
+    info = 0;
     uint32_t e = L.ll[x & ((1u << kLlBits) - 1u)];
-    if (e & 0x8000u) e = L.lls[((e >> 4) & 0x7FFu) * kLlSub + ((x >> kLlBits) & (kLlSub - 1))];
-    const uint32_t len = e & 15u, sym = (e >> 4) & 0x1FFu;
-    if (!len) return t;
-    if (sym < 256u) {
-        t.kind = TK_LIT;
-        t.bits = len;
-        t.out_len = 1;
-        t.info = sym;
-        return t;
+    if (((e >> 8) & 3u) == EK_SUB && (e & 15u)) e = L.lls[(e >> 16) * kLlSub + ((x >> kLlBits) & (kLlSub - 1))];
+    const uint32_t len = e & 15u, kind = (e >> 8) & 3u;
+    if (!len || kind == EK_SUB) return;
+    if (kind == EK_LIT) {
+        tok = len | (TK_LIT << 6) | (1u << 8);
+        info = e >> 16;
+        return;
     }
-    if (sym == 256u) {
-        t.kind = TK_EOB;
-        t.bits = len;
-        return t;
+    if (kind == EK_EOB) {
+        tok = len | (TK_EOB << 6);
+        return;
     }
-    if (sym > 285u) return t;
-    const uint32_t li = sym - 257u, le = c_len_extra[li];
-    const uint32_t length = c_len_base[li] + ((uint32_t)(x >> len) & ((1u << le) - 1u));
+    const uint32_t le = (e >> 4) & 15u;
+    const uint32_t length = (e >> 16) + ((uint32_t)(x >> len) & ((1u << le) - 1u));
     const uint32_t used = len + le;
     const uint64_t y = x >> used;
     uint32_t d = L.dt[y & ((1u << kDBits) - 1u)];
-    if (d & 0x8000u) d = L.dts[((d >> 4) & 0x7FFu) * kDSub + ((y >> kDBits) & (kDSub - 1))];
-    const uint32_t dlen = d & 15u, dsym = (d >> 4) & 0x1FFu;
-    if (!dlen || dsym > 29u) return t;
-    const uint32_t de = c_dist_extra[dsym];
-    const uint32_t dist = c_dist_base[dsym] + ((uint32_t)(y >> dlen) & ((1u << de) - 1u));
-    t.kind = TK_MATCH;
-    t.bits = used + dlen + de;
-    t.out_len = length;
-    t.info = length | (dist << 9);
-    return t;
+    if (((d >> 8) & 3u) == EK_SUB && (d & 15u)) d = L.dts[(d >> 16) * kDSub + ((y >> kDBits) & (kDSub - 1))];
+    const uint32_t dlen = d & 15u;
+    if (!dlen || ((d >> 8) & 3u) != EK_BASE) return;
+    const uint32_t de = (d >> 4) & 15u;
+    const uint32_t dist = (d >> 16) + ((uint32_t)(y >> dlen) & ((1u << de) - 1u));
+    tok = (used + dlen + de) | (TK_MATCH << 6) | (length << 8);
+    info = length | (dist << 9);
 }
 
 }  // namespace
@@ -409,20 +413,27 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in, 
                 const uint32_t wi = o >> 5, sh = o & 31u;
                 const uint64_t lo = (uint64_t)L.inbuf[wi] | ((uint64_t)L.inbuf[wi + 1] << 32);
                 const uint64_t x = sh ? (lo >> sh) | ((uint64_t)L.inbuf[wi + 2] << (64u - sh)) : lo;
-                const Token t = decode_token(L, x);
-                // the chain of true token starts
+                uint32_t tok, info;
+                decode_token(L, x, tok, info);
+                // the chain of true token starts; the walk also numbers the tokens and adds up their output (rank | offset << 8 per token lane)
                 uint64_t valid = 0;
-                uint32_t cur = 0;
+                uint32_t cur = 0, n_tok = 0, total_out = 0, place = 0;
                 int ended = 0;  // 1: end of block, 2: bad code
                 while (cur < 64u) {
-                    valid |= 1ull << cur;
-                    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)t.kind, (int)cur);
-                    const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)t.bits, (int)cur);
+                    const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)cur);
+                    const uint32_t k = (tk >> 6) & 3u;
                     if (k == TK_BAD) {
                         ended = 2;
                         break;
                     }
-                    cur += nb;
+                    valid |= 1ull << cur;
+                    {
+                        const uint32_t pv = __builtin_amdgcn_readfirstlane(n_tok | (total_out << 8)), pl = __builtin_amdgcn_readfirstlane(cur);
+                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(place) : "s"(pv), "s"(pl) : "m0");
+                    }
+                    n_tok++;
+                    total_out += tk >> 8;
+                    cur += tk & 63u;
                     if (k == TK_EOB) {
                         ended = 1;
                         break;
@@ -436,20 +447,9 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in, 
                     status = INF_TRUNCATED;
                     break;
                 }
-                const bool mine = (valid >> lane) & 1ull;
-                const uint32_t rank = (uint32_t)__popcll(valid & ((1ull << lane) - 1ull));
-                const uint32_t n_tok = (uint32_t)__popcll(valid);
-                const uint32_t olen = mine ? t.out_len : 0u;
-                uint32_t inc = olen;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(inc, d);
-                    if (lane >= d) inc += y;
-                }
-                const uint32_t total_out = __shfl(inc, 63);
-                if (mine) {
-                    L.t_off[rank] = inc - olen;
-                    L.t_info[rank] = t.info | (t.kind == TK_MATCH ? 0x80000000u : 0u);
+                if ((valid >> lane) & 1ull) {
+                    L.t_off[place & 0xFFu] = place >> 8;
+                    L.t_info[place & 0xFFu] = info | (((tok >> 6) & 3u) == TK_MATCH ? 0x80000000u : 0u);
                 }
                 if (lane == 0) L.t_off[n_tok] = total_out;
                 wave_sync();
