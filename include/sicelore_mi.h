@@ -542,6 +542,7 @@ typedef struct {
 int smi_host_alloc(size_t bytes, void **out);
 int smi_host_free(void *p);
 int smi_pass2_default_config(smi_pass2_config *cfg);
+/* text: host memory (page-locked: link speed) or DEVICE memory (the output of smi_gz_inflate_device: the text never visits the host) */
 int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, const smi_pass2_config *cfg,
                               smi_pass2_output *out);
 /* pass 1: adds the chunk's whitelist hits to d_hist (device, one u32 counter per key of the loaded set, mode 1).

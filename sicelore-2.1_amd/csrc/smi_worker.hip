@@ -84,7 +84,7 @@ int ensure_arena(smi_ctx *ctx, size_t bytes) {
 // count, and counting on the host (memchr over ~1.2 GB) took longer than the upload.  *d_text stays valid when the arena grows afterwards.
 int upload_and_count(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, hipStream_t s, size_t *n_lines) {
     if (int rc = ensure_arena(ctx, pad(n_bytes) + 4096)) return rc;
-    SMI_HIP(hipMemcpyAsync(ctx->arena, text, n_bytes, hipMemcpyHostToDevice, s));
+    SMI_HIP(hipMemcpyAsync(ctx->arena, text, n_bytes, hipMemcpyDefault, s));  // host text, or text that is on the device already (K-INFLATE)
     return launch_count_lines(ctx, static_cast<const uint8_t *>(ctx->arena), n_bytes, n_lines, s);
 }
 // grow the arena to `bytes`, keeping its first keep_bytes (the uploaded text)

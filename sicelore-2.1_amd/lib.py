@@ -873,13 +873,18 @@ class Context:
             v = np.ascontiguousarray(rank_values, dtype=np.int32)
             keep += [k, v]
             cfg.rank_keys, cfg.rank_values, cfg.n_ranks = k.ctypes.data, v.ctypes.data, k.size
-        buf = text if isinstance(text, np.ndarray) else np.frombuffer(text, dtype=np.uint8)
         out = Pass2Output()
-        if packed:
-            self._check(self._lib.smi_scanfastq_pass2_chunk_packed(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), int(n_threads),
-                                                                   ctypes.byref(out)))
+        if hasattr(text, "is_cuda"):   # a uint8 device tensor (K-INFLATE's output): text worker only
+            if packed or not text.is_cuda:
+                raise SmiError("scanfastq_pass2_chunk: a tensor argument must be a device tensor, and only the text worker takes one")
+            self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, text.data_ptr(), int(text.numel()), ctypes.byref(cfg), ctypes.byref(out)))
         else:
-            self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), ctypes.byref(out)))
+            buf = text if isinstance(text, np.ndarray) else np.frombuffer(text, dtype=np.uint8)
+            if packed:
+                self._check(self._lib.smi_scanfastq_pass2_chunk_packed(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), int(n_threads),
+                                                                       ctypes.byref(out)))
+            else:
+                self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), ctypes.byref(out)))
         if copy:
             passed = ctypes.string_at(out.passed, out.passed_bytes) if out.passed_bytes else b""
             failed = ctypes.string_at(out.failed, out.failed_bytes) if out.failed_bytes else b""
@@ -897,12 +902,18 @@ class Context:
 
     def scanfastq_pass1_chunk(self, text, d_hist, five_prime=False, dont_search_polya=False, packed=False, n_threads=4):
         """adds the chunk's whitelist hits to d_hist (int32 device tensor, one counter per loaded key) -> n records"""
-        buf = _as_u8(text)
         n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
         if hasattr(d_hist, "is_cuda") and d_hist.is_cuda:  # the zero-fill of d_hist ran on torch's stream (sicelore_mi.h)
             import torch
 
             torch.cuda.current_stream(d_hist.device).synchronize()
+        if hasattr(text, "is_cuda"):   # a uint8 device tensor (K-INFLATE's output): text worker only
+            if packed or not text.is_cuda:
+                raise SmiError("scanfastq_pass1_chunk: a tensor argument must be a device tensor, and only the text worker takes one")
+            self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, text.data_ptr(), int(text.numel()), int(five_prime), int(dont_search_polya),
+                                                            _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
+            return n.value
+        buf = _as_u8(text)
         if packed:
             self._check(self._lib.smi_scanfastq_pass1_chunk_packed(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
                                                                    _ptr(d_hist), int(n_threads), ctypes.byref(n), ctypes.byref(err)))

@@ -117,13 +117,15 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto"):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
     "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads."""
     if gz not in ("device", "zlib"):
         raise ValueError("gz: 'device' or 'zlib'")
+    if inflate not in ("auto", "device", "host"):
+        raise ValueError("inflate: 'auto' (the device from 128 *.gz files on: one wavefront per file is slower than a host thread, many are not), 'device' or 'host'")
     on_device = compress and gz == "device"
     t_all = time.perf_counter()
     files = sorted(f for f in os.listdir(in_dir) if f.endswith((".fastq", ".fq", ".fastq.gz", ".fq.gz")))
@@ -168,7 +170,46 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         cpu_inflate[fi] = time.perf_counter() - t1
         return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
 
-    loaded = list(pool.map(load_and_count, range(len(files))))
+    def device_cuts(t):
+        """byte ranges of reads_per_chunk records each in a text that is on the device"""
+        n = int(t.numel())
+        if n == 0:
+            return []
+        nl = torch.nonzero(t == 10).flatten()
+        n_lines = int(nl.numel()) + (0 if int(t[-1]) == 10 else 1)
+        n_rec_ = n_lines // 4
+        idx = torch.arange(reads_per_chunk, n_rec_, reads_per_chunk, device=t.device) * 4 - 1
+        ends = (nl[idx] + 1).cpu().tolist() if idx.numel() else []
+        return [(a, b) for a, b in zip([0] + ends, ends + [n])]
+
+    n_on_device = 0
+    use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= 128))  # (the packed worker wants host text)
+    if use_device:
+        # K-INFLATE: every *.gz file of the directory in one call, one wavefront per file; the text stays in HBM and the chunk workers take it
+        # from there.  A file the kernel hands back (unusual or damaged) goes through zlib on the host like the others did before.
+        t1 = time.perf_counter()
+        gz_files = [fi for fi, f in enumerate(files) if f.endswith(".gz")]
+        raws = {fi: np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in gz_files}
+        on_dev = {}
+        if gz_files:
+            d_out, offs, lens, status, _ = ctx.gz_inflate_device([raws[fi] for fi in gz_files])
+            for j, fi in enumerate(gz_files):
+                if int(status[j]) == 0:
+                    on_dev[fi] = d_out[int(offs[j]):int(offs[j]) + int(lens[j])]
+        n_on_device = len(on_dev)
+        t_dev_inflate = time.perf_counter() - t1
+
+        def load_and_count_dev(fi):
+            if fi in on_dev:
+                t = on_dev[fi]
+                cuts = device_cuts(t)
+                return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
+            return load_and_count(fi)
+
+        loaded = list(pool.map(load_and_count_dev, range(len(files))))
+        cpu_inflate[0] += t_dev_inflate
+    else:
+        loaded = list(pool.map(load_and_count, range(len(files))))
     torch.cuda.synchronize()
     texts = [t for t, _, _ in loaded]
     chunks, n_rec = [], []  # (file index, chunk index in file, byte range); records per chunk
@@ -259,7 +300,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
     return {"files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
-            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(t.size for t in texts)),
+            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(int(t.numel()) if hasattr(t, "numel") else int(t.size) for t in texts)), "files_inflated_on_device": n_on_device,
             "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
             "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
             "write_files_s": t_write, "workers": n_workers, "gz": (gz if compress else None), "gz_level": gz_level if compress and not on_device else None}

@@ -25,8 +25,8 @@ def _canon(text):
     return sorted(recs)
 
 
-@pytest.mark.parametrize("gz", ["device", "zlib"])
-def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz):
+@pytest.mark.parametrize("gz,inflate", [("device", "host"), ("zlib", "host"), ("device", "device")])
+def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, inflate):
     from sicelore_amd import lib as libmod
 
     run_files = importlib.import_module("sicelore_amd.run_files")
@@ -36,7 +36,8 @@ def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz):
     keys = np.sort(wl.cpu().numpy().astype(np.uint64))
     in_dir, out_dir = str(tmp_path / "in"), str(tmp_path / "out")
     n = run_files.write_synthetic_dir(synth, in_dir, 6, 2500, used, dev, seed=810, chimera_frac=0.08)
-    info = run_files.run(gpu_ctx, in_dir, out_dir, max_ed=1, n_workers=4, reads_per_chunk=1000, whitelist_keys=keys, gz=gz)
+    info = run_files.run(gpu_ctx, in_dir, out_dir, max_ed=1, n_workers=4, reads_per_chunk=1000, whitelist_keys=keys, gz=gz, inflate=inflate)
+    assert info["files_inflated_on_device"] == (6 if inflate == "device" else 0)
     assert info["gz"] == gz and info["gz_out_bytes"] < 0.7 * info["text_out_bytes"]
     assert info["reads"] == n and info["files"] == 6 and info["chunks"] >= 12 and info["passed"] > 0.8 * n
     # the same reads through single calls of the chunk workers (text form), file by file
