@@ -117,7 +117,7 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto"):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
@@ -125,7 +125,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     if gz not in ("device", "zlib"):
         raise ValueError("gz: 'device' or 'zlib'")
     if inflate not in ("auto", "device", "host"):
-        raise ValueError("inflate: 'auto' (the device from 128 *.gz files on: one wavefront per file is slower than a host thread, many are not), 'device' or 'host'")
+        raise ValueError("inflate: 'auto' (the device takes a share from 1024 *.gz files on: one wavefront per file is much slower than a host thread, a thousand at once are not), 'device' or 'host'")
     on_device = compress and gz == "device"
     t_all = time.perf_counter()
     files = sorted(f for f in os.listdir(in_dir) if f.endswith((".fastq", ".fq", ".fastq.gz", ".fq.gz")))
@@ -178,36 +178,54 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         nl = torch.nonzero(t == 10).flatten()
         n_lines = int(nl.numel()) + (0 if int(t[-1]) == 10 else 1)
         n_rec_ = n_lines // 4
+        if n_rec_ <= reads_per_chunk:
+            return [(0, n)]
         idx = torch.arange(reads_per_chunk, n_rec_, reads_per_chunk, device=t.device) * 4 - 1
         ends = (nl[idx] + 1).cpu().tolist() if idx.numel() else []
         return [(a, b) for a, b in zip([0] + ends, ends + [n])]
 
     n_on_device = 0
-    use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= 128))  # (the packed worker wants host text)
+    use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= 1024))  # (the packed worker wants host text)
     if use_device:
-        # K-INFLATE: every *.gz file of the directory in one call, one wavefront per file; the text stays in HBM and the chunk workers take it
-        # from there.  A file the kernel hands back (unusual or damaged) goes through zlib on the host like the others did before.
-        t1 = time.perf_counter()
-        gz_files = [fi for fi, f in enumerate(files) if f.endswith(".gz")]
-        raws = {fi: np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in gz_files}
-        on_dev = {}
-        if gz_files:
-            d_out, offs, lens, status, _ = ctx.gz_inflate_device([raws[fi] for fi in gz_files])
-            for j, fi in enumerate(gz_files):
-                if int(status[j]) == 0:
-                    on_dev[fi] = d_out[int(offs[j]):int(offs[j]) + int(lens[j])]
-        n_on_device = len(on_dev)
-        t_dev_inflate = time.perf_counter() - t1
+        # K-INFLATE beside the host: the device takes a share of the *.gz files in one call (one wavefront per file; a file is as fast as any
+        # other however many run, so its share costs the time of ONE file as long as it fits the device at once), the host's threads inflate
+        # the rest with zlib meanwhile.  The device's texts stay in HBM and the chunk workers take them from there.  A file the kernel hands
+        # back (unusual or damaged) goes through zlib on the host like the others.
+        import threading
 
-        def load_and_count_dev(fi):
+        gz_files = [fi for fi, f in enumerate(files) if f.endswith(".gz")]
+        share = gz_files if inflate == "device" else gz_files[len(gz_files) - min(512, int(len(gz_files) * device_share)):]
+        on_dev = {}
+        t_dev = [0.0]
+
+        def device_part():
+            t1 = time.perf_counter()
+            raws = [np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in share]
+            if raws:
+                d_out, offs, lens, status, _ = lanes[-1].gz_inflate_device(raws)
+                for j, fi in enumerate(share):
+                    if int(status[j]) == 0:
+                        on_dev[fi] = d_out[int(offs[j]):int(offs[j]) + int(lens[j])]
+            t_dev[0] = time.perf_counter() - t1
+
+        th = threading.Thread(target=device_part)
+        th.start()
+        in_share = set(share)
+        host_first = [fi for fi in range(len(files)) if fi not in in_share]
+        part1 = dict(zip(host_first, pool.map(load_and_count, host_first)))
+        th.join()
+        n_on_device = len(on_dev)
+
+        def count_dev(fi):
             if fi in on_dev:
                 t = on_dev[fi]
                 cuts = device_cuts(t)
                 return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
             return load_and_count(fi)
 
-        loaded = list(pool.map(load_and_count_dev, range(len(files))))
-        cpu_inflate[0] += t_dev_inflate
+        part2 = dict(zip(share, pool.map(count_dev, share)))
+        loaded = [part1[fi] if fi in part1 else part2[fi] for fi in range(len(files))]
+        cpu_inflate[0] += t_dev[0]
     else:
         loaded = list(pool.map(load_and_count, range(len(files))))
     torch.cuda.synchronize()
