@@ -429,7 +429,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in, 
                     valid |= 1ull << cur;
                     {
                         const uint32_t pv = __builtin_amdgcn_readfirstlane(n_tok | (total_out << 8)), pl = __builtin_amdgcn_readfirstlane(cur);
-                        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(place) : "s"(pv), "s"(pl) : "m0");
+                        uint32_t m0_keep;
+                        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(place), "=&s"(m0_keep) : "s"(pv), "s"(pl));
                     }
                     n_tok++;
                     total_out += tk >> 8;
