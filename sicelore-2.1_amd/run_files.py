@@ -202,7 +202,11 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             t1 = time.perf_counter()
             raws = [np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in share]
             if raws:
-                d_out, offs, lens, status, _ = lanes[-1].gz_inflate_device(raws)
+                k_lane = free.pop()           # a lane of its own while the host's threads work with the others
+                try:
+                    d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(raws)
+                finally:
+                    free.append(k_lane)
                 for j, fi in enumerate(share):
                     if int(status[j]) == 0:
                         on_dev[fi] = d_out[int(offs[j]):int(offs[j]) + int(lens[j])]

@@ -121,6 +121,33 @@ def check_deflate(pkg, synth, sor, ctx, seed):
     return back == data, f"deflate seed={seed} n={n} alphabet={k} member={len(out)}"
 
 
+def check_inflate(pkg, synth, sor, ctx, seed):
+    """round 3: K-INFLATE on what zlib makes of random data at a random level / strategy / window, several files and members per call"""
+    import zlib
+
+    rng = np.random.default_rng(seed)
+    files, texts = [], []
+    for _ in range(int(rng.integers(1, 9))):
+        members, text = [], b""
+        for _m in range(int(rng.choice([1, 1, 1, 2, 5]))):
+            n = int(rng.choice([0, 1, 100, 70_000, int(rng.integers(1, 400_000))]))
+            k = int(rng.choice([1, 4, 5, 30, 256]))
+            alpha = rng.choice(256, size=k, replace=False).astype(np.uint8)
+            data = rng.choice(alpha, size=n, p=rng.dirichlet(np.full(k, float(rng.choice([0.05, 0.5, 5.0]))))).tobytes()
+            if rng.random() < 0.4 and n > 1000:                       # repeats at long and short distances
+                data = data[:n // 3] * 2 + data[n // 3:] + bytes([data[0]]) * int(rng.integers(1, 600))
+            c = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, 16 + int(rng.integers(9, 16)), int(rng.integers(1, 10)),
+                                 int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])))
+            members.append(c.compress(data) + c.flush())
+            text += data
+        files.append(b"".join(members))
+        texts.append(text)
+    out, offs, lens, status, _ = ctx.gz_inflate_device(files, [len(t) for t in texts])
+    host = out.cpu().numpy()
+    ok = all(int(status[i]) == 0 and int(lens[i]) == len(t) and host[offs[i]:offs[i] + lens[i]].tobytes() == t for i, t in enumerate(texts))
+    return ok, f"inflate seed={seed} files={len(files)} bytes={sum(len(t) for t in texts)}"
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     pkg = graft.load_package()
@@ -131,8 +158,8 @@ def main():
     t_end = time.time() + 60 * minutes
     seed, n_ok = (int(sys.argv[2]) if len(sys.argv) > 2 else 1000), 0
     while time.time() < t_end:
-        for leg in ([check_bc, check_records] if os.environ.get("SMI_FUZZ_LEGS") == "r2" else [check_packed, check_umi_stage, check_deflate]
-                    if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_bc, check_records, check_packed, check_umi_stage, check_deflate]):
+        for leg in ([check_bc, check_records] if os.environ.get("SMI_FUZZ_LEGS") == "r2" else [check_packed, check_umi_stage, check_deflate, check_inflate]
+                    if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate]):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
             print(("ok   " if ok else "FAIL ") + msg, flush=True)
             if not ok:
