@@ -29,6 +29,25 @@
 namespace smi {
 namespace {
 
+// threads the loops INSIDE one group may use (set per worker thread of smi_umi_cluster_groups: a call with fewer groups than threads -- the one
+// large group a chunk worker hands over -- gives the spare threads to the group's n^2 loops)
+thread_local int g_inner_threads = 1;
+template <class F>
+void parallel_for(size_t n, size_t min_per_thread, F &&f) {  // f(begin, end) over [0, n) in contiguous pieces
+    const int nt = (int)std::min<size_t>((size_t)g_inner_threads, std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
+    if (nt <= 1) {
+        f((size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;  // (a fresh thread starts with g_inner_threads = 1: loops nested inside f stay serial)
+    for (int t = 1; t < nt; t++) th.emplace_back([&, t] { f(n * (size_t)t / (size_t)nt, n * (size_t)(t + 1) / (size_t)nt); });
+    const int keep = g_inner_threads;
+    g_inner_threads = 1;
+    f((size_t)0, n / (size_t)nt);
+    g_inner_threads = keep;
+    for (auto &x : th) x.join();
+}
+
 struct Dist {
     const uint8_t *m;
     int n;
@@ -84,17 +103,24 @@ int choose_center(const Dist &D, const std::vector<int> &members, const float *q
     const std::vector<int> ord = fastutil_order(members);
     if (ord.size() == 1) return ord[0];
     if (ord.size() == 2) return qv[0] > qv[1] ? ord[0] : ord[1];  // reads 0 and 1 of the group (OneUmiCluster.java:L53)
+    // total squared distance of every member; the first minimum in iteration order wins
+    std::vector<long> tot(ord.size(), 0);
+    parallel_for(ord.size(), 64, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const int s = ord[i];
+            long t = 0;
+            for (int w : ord)
+                if (w != s) t += (long)(int)std::pow((double)D.ed(s, w), 2.0);
+            tot[i] = t;
+        }
+    });
     long best = -1;
     int center = ord[0];
-    for (int s : ord) {
-        long tot = 0;
-        for (int w : ord)
-            if (w != s) tot += (long)(int)std::pow((double)D.ed(s, w), 2.0);
-        if (best < 0 || tot < best) {
-            best = tot;
-            center = s;
+    for (size_t i = 0; i < ord.size(); i++)
+        if (best < 0 || tot[i] < best) {
+            best = tot[i];
+            center = ord[i];
         }
-    }
     return center;
 }
 
@@ -229,34 +255,46 @@ void tag_members(const Dist &D, const Cluster &c, const std::vector<int> &who, s
     const int offset = (int)std::floor((double)sum / (double)cnt + 0.5);  // (int) Math.round(double)
     std::vector<char> inside(D.n, 0);
     for (int v : c.members) inside[v] = 1;
-    for (int idx : who) {
-        if (skipped[idx]) continue;
-        int sec = -1;
-        if (n_clusters > 1)
-            for (int m = 0; m < D.n; m++)
-                if (!inside[m] && (sec < 0 || D.ed(idx, m) < sec)) sec = D.ed(idx, m);
-        out[idx].center = c.center;
-        out[idx].offset = (int8_t)offset;
-        out[idx].ed = (int8_t)D.ed(c.center, idx);
-        out[idx].ed_second = (int8_t)sec;
-        out[idx].pos2 = (int8_t)D.pos2(c.center, idx);
-    }
+    parallel_for(who.size(), 64, [&](size_t lo, size_t hi) {  // (every member writes its own record)
+        for (size_t i = lo; i < hi; i++) {
+            const int idx = who[i];
+            if (skipped[idx]) continue;
+            int sec = -1;
+            if (n_clusters > 1)
+                for (int m = 0; m < D.n; m++)
+                    if (!inside[m] && (sec < 0 || D.ed(idx, m) < sec)) sec = D.ed(idx, m);
+            out[idx].center = c.center;
+            out[idx].offset = (int8_t)offset;
+            out[idx].ed = (int8_t)D.ed(c.center, idx);
+            out[idx].ed_second = (int8_t)sec;
+            out[idx].pos2 = (int8_t)D.pos2(c.center, idx);
+        }
+    });
 }
 
 // clusterLocal: owner key of every index that has a neighbour, -1 otherwise
 std::vector<int> cluster_local(const Dist &D, const std::vector<int> &indices, int ed) {
     std::vector<int> owner(D.n, -1), count(D.n, 0), keys;
-    for (int a : indices) {
-        for (int b : indices) count[a] += D.ed(a, b) <= ed;
+    parallel_for(indices.size(), 64, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const int a = indices[i];
+            int c = 0;
+            for (int b : indices) c += D.ed(a, b) <= ed;
+            count[a] = c;
+        }
+    });
+    for (int a : indices)
         if (count[a] > 1) keys.push_back(a);
-    }
     const std::vector<int> ord = fastutil_order(keys);
-    for (int c : keys) {
-        int best = -1;
-        for (int a : ord)
-            if (D.ed(a, c) <= ed && (best < 0 || count[a] > count[best])) best = a;
-        owner[c] = best;
-    }
+    parallel_for(keys.size(), 64, [&](size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const int c = keys[i];
+            int best = -1;
+            for (int a : ord)
+                if (D.ed(a, c) <= ed && (best < 0 || count[a] > count[best])) best = a;
+            owner[c] = best;
+        }
+    });
     return owner;
 }
 
@@ -348,13 +386,16 @@ void cluster_one(const uint8_t *mat, int n, const float *qv, const smi_umi_clust
                     kept.push_back(c);
                 }
         }
-        for (auto &c : kept) {
-            if (c.members.size() <= 1) continue;
-            std::vector<int> filt;
-            for (int s : fastutil_order(c.members))
-                if (D.ed(s, c.center) <= ced) filt.push_back(s);
-            if (filt.size() > 1) tag_members(D, c, filt, kept.size(), skipped, out);
-        }
+        parallel_for(kept.size(), 1, [&](size_t lo, size_t hi) {  // (clusters are disjoint: every read's record has one writer)
+            for (size_t k = lo; k < hi; k++) {
+                const Cluster &c = kept[k];
+                if (c.members.size() <= 1) continue;
+                std::vector<int> filt;
+                for (int s : fastutil_order(c.members))
+                    if (D.ed(s, c.center) <= ced) filt.push_back(s);
+                if (filt.size() > 1) tag_members(D, c, filt, kept.size(), skipped, out);
+            }
+        });
     }
     if (skipped_out)
         for (int i = 0; i < n; i++) skipped_out[i] = (uint8_t)skipped[i];
@@ -386,8 +427,11 @@ extern "C" int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_o
         set_error("smi_umi_cluster_groups: bad argument");
         return SMI_ERR_INVALID;
     }
-    const int nt = std::max(1, std::min(n_threads, 256));
+    const int nt_all = std::max(1, std::min(n_threads, 256));
+    const int nt = (int)std::min<uint32_t>((uint32_t)nt_all, std::max<uint32_t>(n_groups, 1u));  // one thread per group at most ...
+    const int inner = std::max(1, nt_all / nt);                                                    // ... the rest work inside the groups
     auto work = [&](int t) {
+        g_inner_threads = inner;
         for (uint32_t g = (uint32_t)t; g < n_groups; g += (uint32_t)nt) {
             const uint32_t a = group_off[g], n = group_off[g + 1] - a;
             cluster_one(dist + mat_off[g], (int)n, mean_qv + a, *cfg, out + a, skipped ? skipped + a : nullptr);
