@@ -903,6 +903,30 @@ __global__ __launch_bounds__(256) void k_ends_from_planes(const uint32_t *__rest
         const int64_t fb = (int64_t)(beg - rbeg);  // first base of the record inside its read
         if (side == 0) read_len[i] = (int32_t)len;
         const uint32_t *p0 = planes + (pstart ? (size_t)pstart[src] : plane_start(rbeg, src));
+        if (len >= 32 * kPlaneWords) {
+            // whole end: the 224 bases sit in eight consecutive words of each plane -- two 16-byte loads per plane instead of fourteen
+            // 4-byte ones (a lane's addresses are its own: the loads of a wave do not coalesce, so their number is what costs)
+            struct __attribute__((aligned(4))) W4 {
+                uint32_t x, y, z, w;
+            };
+            const int64_t b0 = side == 0 ? fb : fb + len - 32 * kPlaneWords;  // first base of the end inside the read
+            const uint32_t *q0 = p0 + (b0 >> 5);
+            const int sh = (int)(b0 & 31);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const W4 lo = *reinterpret_cast<const W4 *>(q0 + c * stride), hi = *reinterpret_cast<const W4 *>(q0 + c * stride + 4);
+                const uint32_t r[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+                for (int w = 0; w < kPlaneWords; w++) {
+                    if (side == 0)
+                        ends[(size_t)(c * kPlaneWords + w) * n_ends + e] = (uint32_t)((((uint64_t)r[w + 1] << 32) | r[w]) >> sh);
+                    else  // scan position 32 w + b = base b0 + 223 - 32 w - b: the word at 6 - w mirrored, planes swapped
+                        ends[(size_t)((3 - c) * kPlaneWords + w) * n_ends + e] =
+                            __builtin_bitreverse32((uint32_t)((((uint64_t)r[7 - w] << 32) | r[6 - w]) >> sh));
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int w = 0; w < kPlaneWords; w++) {
             const int64_t nb = len - 32 * w;  // bases of this end word that exist
