@@ -731,6 +731,10 @@ int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out,
  * blocks of block_bytes (<= 0xFF00) input bytes + the EOF block; out == NULL: upper bound of the size in *n_out */
 int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, int level, int block_bytes,
                      int n_threads);
+/* the same writer with the blocks deflated on the device (K-DEFLATE: dynamic-Huffman blocks of literals; 61,440 input bytes per block, so
+ * that a block of any content stays below the 64 KiB BGZF allows): in may be host or device memory, out is host (or device) memory of at
+ * least the bound the call with out == NULL returns.  Every BGZF reader (htsjdk, samtools, smi_bgzf_inflate) reads the result. */
+int smi_bgzf_deflate_device(smi_ctx *ctx, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out);
 typedef struct {                /* one alignment record; offsets into the inflated stream */
     uint64_t rec_off;           /* of its block_size word */
     uint64_t name_off, cigar_off, seq_off, qual_off, aux_off;

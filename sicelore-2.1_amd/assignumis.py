@@ -397,11 +397,12 @@ def _coordinate_key(rec, name):
             int(rec["next_ref_id"]) if int(rec["next_ref_id"]) >= 0 else 1 << 30, int(rec["next_pos"]), int(rec["tlen"]))
 
 
-def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, **kw):
+def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device", **kw):
     """`assignumis` BAM in -> (bcfound BAM bytes, umifound BAM bytes, names, tags): the two BGZF streams the reference writes
     (<out>.bam: every record with a cell barcode; <out>_umifound_.bam: those whose UMI comes from clustering), header copied,
     records of a chunk in coordinate-comparator order with the tags of record_tag_sets added; refflat = text of the --annotationFile
-    (GE / GS / XF through lib.GeneTagger), None = no annotation file given."""
+    (GE / GS / XF through lib.GeneTagger), None = no annotation file given.  bgzf: "device" = the BGZF blocks are deflated by K-DEFLATE
+    (smi_bgzf_deflate_device), "zlib" = by zlib at compress_level on n_threads host threads; the inflated streams are the same."""
     _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
     gene_tags = None
     if refflat is not None:
@@ -438,5 +439,8 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
         out_bc.append(rec_bytes)
         if clustered:
             out_umi.append(rec_bytes)
-    z = lambda parts: _lib.bgzf_deflate(b"".join(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
+    if bgzf == "device":
+        z = lambda parts: ctx.bgzf_deflate_device(b"".join(parts)).tobytes()  # noqa: E731
+    else:
+        z = lambda parts: _lib.bgzf_deflate(b"".join(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
     return z(out_bc), z(out_umi), names, tags

@@ -127,13 +127,15 @@ struct DeflateLds {
 };
 
 // ---- one deflate block per workgroup ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *__restrict__ in, uint64_t n_bytes, uint8_t *__restrict__ slots,
+// block_in: input bytes per block (<= kDeflateBlock, a multiple of 64).  block_crc != nullptr (BGZF): every block's own CRC-32 goes there
+// instead of into the member's accumulator.
+__global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *__restrict__ in, uint64_t n_bytes, uint32_t block_in, uint8_t *__restrict__ slots,
                                                                 uint32_t *__restrict__ block_bytes, uint32_t *__restrict__ crc_acc,
-                                                                uint32_t *__restrict__ err) {
+                                                                uint32_t *__restrict__ err, uint32_t *__restrict__ block_crc) {
     __shared__ DeflateLds L;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint64_t b0 = (uint64_t)blockIdx.x * kDeflateBlock;
-    const uint32_t blen = (uint32_t)min((uint64_t)kDeflateBlock, n_bytes - b0);
+    const uint64_t b0 = (uint64_t)blockIdx.x * block_in;
+    const uint32_t blen = (uint32_t)min((uint64_t)block_in, n_bytes - b0);
     const uint8_t *src = in + b0;
     uint32_t *slot = reinterpret_cast<uint32_t *>(slots + (uint64_t)blockIdx.x * kSlotBytes);
     // ---- tables, zeroes -------------------------------------------------------------------------------------------------------
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
     if (tid < 16) L.bl_count[tid] = 0;
     if (tid == 0) {
         L.n_used = 0;
-        L.blk_shift = x_pow_bytes(n_bytes - (b0 + blen));  // x^(8 * bytes behind this block)
+        L.blk_shift = block_crc ? (1u << 31) : x_pow_bytes(n_bytes - (b0 + blen));  // x^(8 * bytes behind this block); BGZF: the block's own CRC
     }
     __syncthreads();
     // ---- pass A: histogram + CRC of my runs ---------------------------------------------------------------------------------------
@@ -222,7 +224,13 @@ __global__ __launch_bounds__(kDefThreads) void k_deflate_blocks(const uint8_t *_
         if (lane == 0) L.wave_sum[0][wave] = part;
     }
     __syncthreads();
-    if (tid == 0) atomicXor(crc_acc, L.wave_sum[0][0] ^ L.wave_sum[0][1] ^ L.wave_sum[0][2] ^ L.wave_sum[0][3]);
+    if (tid == 0) {
+        const uint32_t c = L.wave_sum[0][0] ^ L.wave_sum[0][1] ^ L.wave_sum[0][2] ^ L.wave_sum[0][3];
+        if (block_crc)
+            block_crc[blockIdx.x] = c;
+        else
+            atomicXor(crc_acc, c);
+    }
     // ---- symbol frequencies -> list of the used ones, sorted by rank counting ------------------------------------------------------
     {
         uint32_t f_mine = 0;
@@ -551,6 +559,35 @@ __global__ __launch_bounds__(256) void k_deflate_gather(const uint8_t *__restric
     if (threadIdx.x < n - done) d[done + threadIdx.x] = s[done + threadIdx.x];
 }
 
+// BGZF: block b = [18-byte header with BSIZE][its deflate data][03 00][CRC-32][ISIZE]; offs = exclusive scan of (block_bytes + 28); the
+// 28-byte end-of-file block behind the last one
+__global__ __launch_bounds__(256) void k_bgzf_gather(const uint8_t *__restrict__ slots, const uint32_t *__restrict__ block_bytes, const uint64_t *__restrict__ offs,
+                                                     const uint32_t *__restrict__ block_crc, uint64_t n_bytes, uint32_t block_in, uint32_t n_blocks,
+                                                     uint8_t *__restrict__ out, uint64_t *__restrict__ total) {
+    const uint32_t b = blockIdx.x;
+    const uint8_t *s = slots + (uint64_t)b * kSlotBytes;
+    const uint32_t n = block_bytes[b];
+    uint8_t *d = out + offs[b] + 28ull * b;
+    const uint32_t bsize = 18u + n + 2u + 8u;
+    if (threadIdx.x == 0) {
+        const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1u) & 0xFFu), (uint8_t)((bsize - 1u) >> 8)};
+        for (int i = 0; i < 18; i++) d[i] = head[i];
+        uint8_t *t = d + 18 + n;
+        t[0] = 0x03;  // the empty final block of the member
+        t[1] = 0x00;
+        const uint32_t crc = block_crc[b];
+        const uint32_t isize = (uint32_t)min((uint64_t)block_in, n_bytes - (uint64_t)b * block_in);
+        for (int i = 0; i < 4; i++) t[2 + i] = (uint8_t)(crc >> (8 * i));
+        for (int i = 0; i < 4; i++) t[6 + i] = (uint8_t)(isize >> (8 * i));
+        if (b + 1 == n_blocks) {
+            const uint8_t eof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 28; i++) t[10 + i] = eof[i];
+            total[0] = (uint64_t)(t + 38 - out);
+        }
+    }
+    for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) d[18 + k] = s[k];
+}
+
 __global__ void k_deflate_finish(uint8_t *__restrict__ out, const uint64_t *__restrict__ offs, const uint32_t *__restrict__ block_bytes,
                                  uint32_t n_blocks, const uint32_t *__restrict__ state, uint64_t n_bytes, int gzip, uint64_t *__restrict__ total) {
     if (threadIdx.x || blockIdx.x) return;
@@ -611,7 +648,8 @@ int launch_deflate(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *d
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint64_t *)nullptr, (int)std::max<size_t>(n_blocks, 1));
     SMI_HIP(hipMemsetAsync(d_state, 0, 8, s));
     if (n_blocks) {
-        hipLaunchKernelGGL(k_deflate_blocks, dim3((unsigned)n_blocks), dim3(kDefThreads), 0, s, d_in, (uint64_t)n_bytes, slots, d_bb, d_state, d_state + 1);
+        hipLaunchKernelGGL(k_deflate_blocks, dim3((unsigned)n_blocks), dim3(kDefThreads), 0, s, d_in, (uint64_t)n_bytes, (uint32_t)kDeflateBlock, slots, d_bb, d_state,
+                           d_state + 1, (uint32_t *)nullptr);
         SMI_HIP(hipGetLastError());
         SMI_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp, scan_tmp, d_bb, d_offs, (int)n_blocks, s));
         hipLaunchKernelGGL(k_deflate_gather, dim3((unsigned)n_blocks), dim3(256), 0, s, slots, d_bb, d_offs, d_out, gzip ? 10u : 0u);
@@ -651,6 +689,76 @@ int deflate_pair(smi_ctx *ctx, const uint8_t *d_a, size_t na, const uint8_t *d_b
 }  // namespace smi
 
 extern "C" size_t smi_deflate_bound(size_t n_bytes) { return smi::deflate_bound(n_bytes); }
+
+// BGZF on the device: see sicelore_mi.h
+extern "C" int smi_bgzf_deflate_device(smi_ctx *ctx, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out) {
+    using namespace smi;
+    constexpr uint32_t kBgzfIn = 0xF000;  // 61,440 input bytes per block: a Huffman-only block of any content stays below the 64 KiB a BGZF block may have
+    if ((!in && n_in) || !n_out || !ctx) {
+        set_error("smi_bgzf_deflate_device: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    const size_t n_blocks = (n_in + kBgzfIn - 1) / kBgzfIn;
+    const size_t bound = n_in + n_in / 8 + n_blocks * (600 + 28) + 28 + 64;
+    if (!out) {
+        *n_out = bound;
+        return SMI_OK;
+    }
+    static const uint8_t kEof[28] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (n_blocks == 0) {
+        if (cap_out < 28) {
+            set_error("smi_bgzf_deflate_device: output buffer too small");
+            return SMI_ERR_INVALID;
+        }
+        std::memcpy(out, kEof, 28);
+        *n_out = 28;
+        return SMI_OK;
+    }
+    if (cap_out < bound) {
+        set_error("smi_bgzf_deflate_device: output buffer below the bound (call with out == NULL for it)");
+        return SMI_ERR_INVALID;
+    }
+    SMI_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // scratch: block slots | sizes | offsets | scan storage | state | CRCs | input | output
+    size_t scan_tmp = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint64_t *)nullptr, (int)n_blocks);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_bb = al(n_blocks * (size_t)kSlotBytes), o_offs = o_bb + al(n_blocks * 4), o_tmp = o_offs + al((n_blocks + 1) * 8), o_state = o_tmp + al(scan_tmp),
+                 o_crc = o_state + 256, o_in = o_crc + al(n_blocks * 4), o_out = o_in + al(n_in + 64), end = o_out + al(bound);
+    if (ctx->deflate_scratch_bytes < end) {
+        if (ctx->deflate_scratch) SMI_HIP(hipFree(ctx->deflate_scratch));
+        ctx->deflate_scratch = nullptr;
+        ctx->deflate_scratch_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->deflate_scratch, end + end / 4));
+        ctx->deflate_scratch_bytes = end + end / 4;
+    }
+    uint8_t *base = static_cast<uint8_t *>(ctx->deflate_scratch);
+    uint32_t *d_bb = reinterpret_cast<uint32_t *>(base + o_bb), *d_state = reinterpret_cast<uint32_t *>(base + o_state), *d_crc = reinterpret_cast<uint32_t *>(base + o_crc);
+    uint64_t *d_offs = reinterpret_cast<uint64_t *>(base + o_offs);
+    uint8_t *d_in = base + o_in, *d_out = base + o_out;
+    SMI_HIP(hipMemcpyAsync(d_in, in, n_in, hipMemcpyDefault, s));
+    SMI_HIP(hipMemsetAsync(d_state, 0, 64, s));
+    hipLaunchKernelGGL(k_deflate_blocks, dim3((unsigned)n_blocks), dim3(kDefThreads), 0, s, d_in, (uint64_t)n_in, kBgzfIn, base, d_bb, d_state, d_state + 1, d_crc);
+    size_t tmp = scan_tmp;
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(base + o_tmp, tmp, d_bb, d_offs, (int)n_blocks, s));
+    hipLaunchKernelGGL(k_bgzf_gather, dim3((unsigned)n_blocks), dim3(256), 0, s, base, d_bb, d_offs, d_crc, (uint64_t)n_in, kBgzfIn, (uint32_t)n_blocks, d_out,
+                       reinterpret_cast<uint64_t *>(d_state + 4));
+    SMI_HIP(hipGetLastError());
+    uint64_t h_state[4] = {0, 0, 0, 0};
+    SMI_HIP(hipMemcpyAsync(h_state, d_state, 32, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    const uint32_t flags = (uint32_t)(h_state[0] >> 32);  // d_state[1]
+    const uint64_t total = h_state[2];                     // d_state[4..5]
+    if (flags || total > cap_out) {
+        set_error("smi_bgzf_deflate_device: a block outgrew its slot, or the output buffer is too small");
+        return SMI_ERR_INVALID;
+    }
+    SMI_HIP(hipMemcpyAsync(out, d_out, total, hipMemcpyDefault, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    *n_out = total;
+    return SMI_OK;
+}
 
 extern "C" int smi_gzip_device(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *d_out, size_t out_cap, uint64_t *d_total, int raw_deflate,
                                void *stream) {

@@ -58,7 +58,7 @@ EXPORTS = [
     "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
-    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device",
+    "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
 ]
 
 
@@ -145,6 +145,7 @@ def load_library():
     lib.smi_deflate_bound.restype = sz
     lib.smi_gzip_device.argtypes = [vp, vp, sz, vp, sz, vp, ctypes.c_int, vp]
     lib.smi_gz_inflate_device.argtypes = [vp, vp, vp, ctypes.c_int, vp, vp, vp]
+    lib.smi_bgzf_deflate_device.argtypes = [vp, vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.smi_packed_planes_words.argtypes = [sz, ci]
     lib.smi_packed_planes_words.restype = sz
     lib.smi_fastq_index_pack_host.argtypes = [vp, sz, vp, vp, vp, sz, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32), ci]
@@ -928,6 +929,15 @@ class Context:
         self._check(self._lib.smi_ends_from_planes_device(self._h, _ptr(d_planes), _ptr(d_read_offsets), int(n_reads), int(total_bases),
                                                           _ptr(d_rec_offsets), _ptr(d_frag_src), int(n_records), _ptr(d_ends), _ptr(d_len),
                                                           _stream_ptr(stream)))
+
+    def bgzf_deflate_device(self, data):
+        """smi_bgzf_deflate_device: bytes / uint8 array -> the BGZF stream (numpy uint8), blocks deflated on the device"""
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = ctypes.c_size_t(0)
+        self._check(self._lib.smi_bgzf_deflate_device(self._h, a.ctypes.data if a.size else None, a.size, None, 0, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.uint8)
+        self._check(self._lib.smi_bgzf_deflate_device(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, out.size, ctypes.byref(n)))
+        return out[:n.value]
 
     def gz_inflate_device(self, files, out_caps=None):
         """K-INFLATE (smi_gz_inflate_device): a list of gzip files (bytes / uint8 arrays) -> (uint8 device tensor with all texts, offsets, lengths,

@@ -105,3 +105,34 @@ def test_text_worker_with_compress_returns_the_members_of_its_text(pkg, synth, g
     allp = "".join(f"@r{i}\n{c[0]}\n+\n{c[1]}\n" for i, c in enumerate(chim[:1])).encode()
     zp1, zf1, i1 = gpu_ctx.scanfastq_pass2_chunk(allp, compress=True)
     assert gzip.decompress(bytes(zp1) + bytes(zf1)) is not None and (i1["passed_text_bytes"] == 0 or i1["failed_text_bytes"] == 0)
+
+
+def test_bgzf_blocks_made_on_the_device(pkg, gpu_ctx):
+    """smi_bgzf_deflate_device (the BGZF writer under assignumis' output BAMs with K-DEFLATE inside): the stream inflates back through Python's
+    gzip (a BGZF file is a multi-member gzip file), through the library's own BGZF reader, block by block through the BSIZE fields; blocks
+    stay below 64 KiB whatever the content; the empty stream is the 28-byte end-of-file block"""
+    from sicelore_amd import lib as libmod
+
+    g = np.random.default_rng(4)
+    bam_like = b"".join(int(g.integers(200, 400)).to_bytes(4, "little") + bytes(g.integers(0, 40, size=int(g.integers(200, 400)), dtype=np.uint8)) +
+                        b"read%06d_FWD_PS=12_AE=99_bc=ACGTACGTACGTACGT\0" % i for i in range(3000))
+    rnd = g.integers(0, 256, size=200_000, dtype=np.uint8).tobytes()
+    eof = bytes([31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 66, 67, 2, 0, 27, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0])
+    for data in (bam_like, rnd, b"x", b"A" * 61_440, b"B" * 61_441, b""):
+        z = gpu_ctx.bgzf_deflate_device(data).tobytes()
+        assert z.endswith(eof)
+        assert gzip.decompress(z) == data
+        back, used = libmod.bgzf_inflate(np.frombuffer(z, dtype=np.uint8), n_threads=2)
+        assert back.tobytes() == data and used == len(z)
+        at, total = 0, 0
+        while at < len(z):
+            assert z[at:at + 4] == b"\x1f\x8b\x08\x04" and z[at + 12:at + 16] == b"BC\x02\x00"
+            bsize = int.from_bytes(z[at + 16:at + 18], "little") + 1
+            assert bsize <= 65536
+            isize = int.from_bytes(z[at + bsize - 4:at + bsize], "little")
+            assert isize <= 61_440 and zlib.crc32(data[total:total + isize]) == int.from_bytes(z[at + bsize - 8:at + bsize - 4], "little")
+            total += isize
+            at += bsize
+        assert at == len(z) and total == len(data)
+    assert gpu_ctx.bgzf_deflate_device(b"").tobytes() == eof
+    assert len(gpu_ctx.bgzf_deflate_device(bam_like)) < 0.8 * len(bam_like)
