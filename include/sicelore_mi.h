@@ -705,7 +705,7 @@ int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_ou
  * d_in: the files' bytes on the device, file i at in_off (a multiple of 4), in_len bytes; 1 KiB of readable bytes behind the last file.
  * File i's text goes to d_out + out_off, at most out_cap bytes (single-member files say their size in their last four bytes).  Multi-member
  * files, stored / fixed / dynamic blocks and the optional header fields are handled; CRC-32 and ISIZE of every member are checked.
- * results[i].status: 0 = inflated and verified; anything else (malformed or unusual input, out_cap too small, > 1024 members): the caller
+ * results[i].status: 0 = inflated and verified; anything else (malformed or unusual input, out_cap too small, > 256 members): the caller
  * inflates that file with smi_gz_inflate.  Synchronous (the results are on the host when it returns). */
 typedef struct {
     uint64_t in_off, in_len, out_off, out_cap;

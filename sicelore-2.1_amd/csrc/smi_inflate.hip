@@ -638,7 +638,7 @@ extern "C" int smi_gz_inflate_device(smi_ctx *ctx, const uint8_t *d_in, const sm
         }
     SMI_HIP(hipSetDevice(ctx->device));
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
-    constexpr int kMaxMembers = 1024;
+    constexpr int kMaxMembers = 256;  // per file (a file of this pipeline has one member per 100 k-read chunk)
     InfStream *d_S = nullptr;
     InfResult *d_R = nullptr;
     InfMember *d_M = nullptr;
