@@ -11,7 +11,7 @@
 // blocks of a member are deflated independently and then just concatenated.  A member ends with the empty final block 03 00.
 //
 // One workgroup (256 threads) per block:
-//   pass A  the block's bytes -> symbol histogram (16 privatised copies in LDS) and the CRC-32 of each 64-byte run (a thread owns runs
+//   pass A  the block's bytes -> symbol histogram (8 privatised copies in LDS) and the CRC-32 of each 64-byte run (a thread owns runs
 //           tid, tid + 256, ...: a wave reads 4 KiB in one piece, and each run is one piece of the bit stream)
 //   tree    used symbols compacted and sorted by frequency (bitonic, LDS), code lengths by the in-place minimum-redundancy algorithm of
 //           Moffat & Katajainen (one lane; 60 - 90 used symbols for FASTQ), frequencies halved and the tree rebuilt while a length exceeds

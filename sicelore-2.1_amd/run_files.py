@@ -3,9 +3,10 @@
 A directory of *.fastq / *.fastq.gz in, `<out>/passed/<base>_passed.fastq.gz` and `<out>/failed/<base>_failed.fastq.gz` per input file
 (FastqWriterThreadPool.java:L242-257), `BarcodeList.tsv` and `BarcodesAssigned.tsv` out; both passes of the default flow:
 
-  inflate (host threads, zlib)  ->  pass 1 per chunk on worker lanes (packed boundary, shared histogram)  ->  finalize / rank (host)
-  ->  pass 2 per chunk on the lanes (packed boundary: bit-planes up, decisions down, records written by host threads)
-  ->  gzip of every chunk's `passed` / `failed` text as one gzip member each (host threads), members appended in chunk order.
+  per file: inflate (zlib on a host thread; from 1024 files on a share of the files by K-INFLATE on the device)  ->  pass 1 of its chunks on
+  a worker lane (text worker, shared histogram)  ->  finalize / rank (host)  ->  pass 2 per chunk on the lanes (text worker: the records
+  are written in HBM and K-DEFLATE turns `passed` and `failed` into one gzip member each there; gz="zlib": packed boundary, records
+  written by host threads, zlib on the worker threads)  ->  members appended in chunk order, TSVs, statistics.
 
 The reference parallelises over input files (README.md:155) with one JVM; here a pool of host threads takes chunks, each thread owning
 one worker lane of the GPU (smi_ctx_create_lane) -- zlib and the native workers release the GIL, so the pool scales like the
