@@ -415,29 +415,36 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in, 
                 const uint64_t x = sh ? (lo >> sh) | ((uint64_t)L.inbuf[wi + 2] << (64u - sh)) : lo;
                 uint32_t tok, info;
                 decode_token(L, x, tok, info);
-                // the chain of true token starts; the walk also numbers the tokens and adds up their output (rank | offset << 8 per token lane)
-                uint64_t valid = 0;
-                uint32_t cur = 0, n_tok = 0, total_out = 0, place = 0;
+                // The chain of true token starts.  Six scalar instructions per hop, written out (the compiler unrolled the C form sixty-four
+                // times at forty instructions a hop, and a single wave issues one instruction per four cycles): read the step of the token
+                // at `cur`, mark the lane, advance.  A token that ends the walk (end of block, bad code) carries a step of 64 or more.
+                const uint32_t kind = (tok >> 6) & 3u;
+                const uint32_t step = kind == TK_BAD ? 127u : kind == TK_EOB ? (tok & 63u) | 64u : tok & 63u;
+                uint64_t valid;
+                uint32_t cur, t_s;
+                asm volatile(
+                    "s_mov_b64 %[valid], 0\n\t"
+                    "s_mov_b32 %[cur], 0\n"
+                    "1:\n\t"
+                    "s_nop 3\n\t"  // (a lane select written by the scalar unit needs four wait states before v_readlane reads it)
+                    "v_readlane_b32 %[t], %[step], %[cur]\n\t"
+                    "s_bitset1_b64 %[valid], %[cur]\n\t"
+                    "s_add_u32 %[cur], %[cur], %[t]\n\t"
+                    "s_cmp_lt_u32 %[cur], 64\n\t"
+                    "s_cbranch_scc1 1b"
+                    : [valid] "=&s"(valid), [cur] "=&s"(cur), [t] "=&s"(t_s)
+                    : [step] "v"(step)
+                    : "scc");
                 int ended = 0;  // 1: end of block, 2: bad code
-                while (cur < 64u) {
-                    const uint32_t tk = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)cur);
-                    const uint32_t k = (tk >> 6) & 3u;
-                    if (k == TK_BAD) {
+                {
+                    const uint32_t last = 63u - (uint32_t)__builtin_clzll(valid);
+                    const uint32_t tl = (uint32_t)__builtin_amdgcn_readlane((int)tok, (int)last);
+                    const uint32_t kl = (tl >> 6) & 3u;
+                    if (kl == TK_BAD)
                         ended = 2;
-                        break;
-                    }
-                    valid |= 1ull << cur;
-                    {
-                        const uint32_t pv = __builtin_amdgcn_readfirstlane(n_tok | (total_out << 8)), pl = __builtin_amdgcn_readfirstlane(cur);
-                        uint32_t m0_keep;
-                        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(place), "=&s"(m0_keep) : "s"(pv), "s"(pl));
-                    }
-                    n_tok++;
-                    total_out += tk >> 8;
-                    cur += tk & 63u;
-                    if (k == TK_EOB) {
+                    else if (kl == TK_EOB) {
                         ended = 1;
-                        break;
+                        cur = last + (tl & 63u);
                     }
                 }
                 if (ended == 2) {
@@ -448,9 +455,21 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in, 
                     status = INF_TRUNCATED;
                     break;
                 }
-                if ((valid >> lane) & 1ull) {
-                    L.t_off[place & 0xFFu] = place >> 8;
-                    L.t_info[place & 0xFFu] = info | (((tok >> 6) & 3u) == TK_MATCH ? 0x80000000u : 0u);
+                // the tokens numbered and their output added up: rank among the marked lanes, inclusive scan of the output lengths
+                const bool mine = (valid >> lane) & 1ull;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(valid >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)valid, 0u));
+                const uint32_t n_tok = (uint32_t)__popcll(valid);
+                const uint32_t olen = mine ? tok >> 8 : 0u;
+                uint32_t inc = olen;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(inc, d);
+                    if (lane >= d) inc += y;
+                }
+                const uint32_t total_out = __shfl(inc, 63);
+                if (mine) {
+                    L.t_off[rank] = inc - olen;
+                    L.t_info[rank] = info | (kind == TK_MATCH ? 0x80000000u : 0u);
                 }
                 if (lane == 0) L.t_off[n_tok] = total_out;
                 wave_sync();
