@@ -118,11 +118,19 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
-    "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads."""
+    "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads.
+    With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
+    exchanges are the pass-1 histogram (one all-reduce, then the same finalize on every rank), the records in front of each rank (read ids),
+    and the counters behind the two TSVs and the statistics, which rank 0 writes.  Every rank writes the output files of its own inputs; the
+    result is the single-process run's, byte for byte."""
+    import torch.distributed as dist
+
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank, world = (dist.get_rank(group), dist.get_world_size(group)) if multi else (0, 1)
     if gz not in ("device", "zlib"):
         raise ValueError("gz: 'device' or 'zlib'")
     if inflate not in ("auto", "device", "host"):
@@ -132,6 +140,11 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     files = sorted(f for f in os.listdir(in_dir) if f.endswith((".fastq", ".fq", ".fastq.gz", ".fq.gz")))
     if not files:
         raise _lib.SmiError(f"no FASTQ files in {in_dir}")
+    if multi:
+        from . import distributed as _dist
+
+        lo_f, hi_f = _dist.shard_range(len(files), rank, world)
+        files = files[lo_f:hi_f]          # (a rank without files still takes part in the exchanges)
     os.makedirs(os.path.join(out_dir, "passed"), exist_ok=True)
     os.makedirs(os.path.join(out_dir, "failed"), exist_ok=True)
     pool = ThreadPoolExecutor(n_workers)
@@ -249,11 +262,21 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     for (fi, _, _), m in zip(chunks, n_rec):
         per_file[fi] = per_file.get(fi, 0) + m
     record_count = sum((m + 9_999) // 10_000 for m in per_file.values())
+    ids_in_front = 0
+    if multi:
+        # one all-reduce of the dense histogram (RCCL on the device tensor), the chunk counts with it; records in front of this rank's files
+        hist, record_count = _dist.allreduce_histogram(hist, record_count, group)
+        xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")   # (gloo in the tests: small tensors on the host)
+        mine = torch.tensor([int(sum(n_rec))], dtype=torch.int64, device=xdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine, group=group)
+        ids_in_front = int(sum(int(t.item()) for t in every[:rank]))
     h = hist.cpu().numpy()
     nz = np.nonzero(h)[0]
     k, c, r = _lib.finalize_used_list(keys[nz], h[nz].astype(np.uint32), record_count, max_ed, 10, 500)
-    with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
-        f.write(_lib.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, max_ed))
+    if rank == 0:
+        with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
+            f.write(_lib.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, max_ed))
     order = np.argsort(k)
     rk_keys, rk_vals = k[order], r[order].astype(np.int32)
     ctx.set_barcode_set(k, mode=_lib.SET_USED_LIST)
@@ -262,7 +285,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     t_finalize = time.perf_counter() - t0
     # ---- pass 2 + gzip -------------------------------------------------------------------------------------------------------------------
     t0 = time.perf_counter()
-    first_id = np.concatenate([[0], np.cumsum(n_rec)])[:-1] + 1
+    first_id = np.concatenate([[0], np.cumsum(n_rec)])[:-1] + 1 + ids_in_front
 
     def p2(lane, j):
         fi, ci, rng = chunks[j]
@@ -304,15 +327,23 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                 ff.write(res[1])
 
     list(pool.map(write_file, range(len(files))))
-    with open(os.path.join(out_dir, "BarcodesAssigned.tsv"), "w") as f:
-        f.write(_lib.assigned_tsv(rk_keys, counts.astype(np.uint32), max_ed=max_ed))
-    # the counters ReadScanner.html renders (ReadFlags.print) and, beside them, the raw vector `merge_stats` adds up (the reference keeps
-    # them in stats.pojo for its `mergestats` sub-command)
     stats = np.zeros(_lib.N_SCAN_STATS, dtype=np.uint64)
     for res in results:
         if res[7] is not None:
             stats += res[7]
-    write_stats(out_dir, stats)
+    if multi:  # the counters behind BarcodesAssigned.tsv and the statistics, summed over the ranks
+        xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        t_counts = torch.from_numpy(counts.astype(np.int64)).to(xdev)
+        t_stats = torch.from_numpy(stats.astype(np.int64)).to(xdev)
+        dist.all_reduce(t_counts, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(t_stats, op=dist.ReduceOp.SUM, group=group)
+        counts, stats = t_counts.cpu().numpy(), t_stats.cpu().numpy().astype(np.uint64)
+    if rank == 0:
+        with open(os.path.join(out_dir, "BarcodesAssigned.tsv"), "w") as f:
+            f.write(_lib.assigned_tsv(rk_keys, counts.astype(np.uint32), max_ed=max_ed))
+        # the counters ReadScanner.html renders (ReadFlags.print) and, beside them, the raw vector `merge_stats` adds up (the reference keeps
+        # them in stats.pojo for its `mergestats` sub-command)
+        write_stats(out_dir, stats)
     t_write = time.perf_counter() - t0
     for ln in lanes[1:]:
         ln.close()
@@ -322,7 +353,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             o.close()
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
-    return {"files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
+    return {"rank": rank, "ranks": world, "files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
             "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(int(t.numel()) if hasattr(t, "numel") else int(t.size) for t in texts)), "files_inflated_on_device": n_on_device,
             "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
             "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
