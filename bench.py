@@ -85,6 +85,9 @@ def parse_args():
     ap.add_argument("--single-process-gpus", type=int, default=0,
                     help="two-pass leg: ONE process drives this many GPUs (a context each, host threads) and sums the pass-1 histograms with "
                          "smi_hist_allreduce (RCCL inside the library) -- the shape of a JVM host; 0 = off (one process per GPU, torch.distributed)")
+    ap.add_argument("--pack-kernel", action="store_true",
+                    help="build the step's packed read ends with K-PACK (smi_pack_ends_device) from ASCII reads materialised on the device, instead of "
+                         "the generator's own torch packer (same ends; outside the timed region either way)")
     ap.add_argument("--exchange-only", action="store_true")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default: nccl with GPUs, gloo without)")
     return ap.parse_args()
@@ -857,8 +860,18 @@ def main():
     c0 = 0
     for cid, m in zip(chunk_ids, chunk_sizes):
         rd = synth.gen_reads(m, used, seed=seed_of(cid), device=dev)
-        ends[:, 2 * c0:2 * (c0 + m)] = synth.pack_ends(rd["head"], rd["tail"])
-        lens[c0:c0 + m] = (2 * synth.END_BASES + rd["mid_len"]).to(torch.int32)
+        if args.pack_kernel:
+            ascii_, offs_ = synth.materialize_device(rd, seed=seed_of(cid))
+            e_ = torch.zeros((28, 2 * m), dtype=torch.int32, device=dev)
+            l_ = torch.zeros(m, dtype=torch.int32, device=dev)
+            ctx.pack_ends_device(ascii_, None, offs_, m, e_, l_)
+            torch.cuda.synchronize()
+            ends[:, 2 * c0:2 * (c0 + m)] = e_
+            lens[c0:c0 + m] = l_
+            del ascii_, offs_, e_, l_
+        else:
+            ends[:, 2 * c0:2 * (c0 + m)] = synth.pack_ends(rd["head"], rd["tail"])
+            lens[c0:c0 + m] = (2 * synth.END_BASES + rd["mid_len"]).to(torch.int32)
         truth[c0:c0 + m] = rd["truth"]
         if c0 == 0 and rank == 0:
             k = min(args.cpu_sample, m)
@@ -976,6 +989,7 @@ def main():
             "bc_assigned_frac": n_found / max(n, 1),
             "bc_assigned_accuracy": acc,
             "bc_assigned_total": found_all,
+            "ends_packed_by": "K-PACK (smi_pack_ends_device) from ASCII reads" if args.pack_kernel else "the generator's torch packer (same bit-planes; --pack-kernel uses K-PACK)",
         },
         "roofline": dict({"bound": "hbm" if dom is f_bc1 else "valu-issue (the HBM figures are what the contract asks for; the binding resource "
                                    "of this kernel is integer VALU issue, in `valu_issue`)"}, **dom,

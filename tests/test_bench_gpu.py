@@ -39,6 +39,16 @@ def test_bench_config1_small():
     assert set(d["roofline"]["kernels_ms"]) == {"k_scan<10>", "k_bc_match_ed1<1>"}
 
 
+def test_bench_pack_kernel_gives_the_same_step():
+    """--pack-kernel: the step's inputs built by K-PACK from ASCII reads instead of the generator's packer -> the same assignments"""
+    common = ("--reads", "200000", "--whitelist", "400000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--e2e-reads", "0", "--two-pass-reads", "0",
+              "--umi-molecules", "0", "--h2h-reads", "0", "--f2f-reads", "0")
+    a, b = _run(*common), _run(*common, "--pack-kernel")
+    assert "K-PACK" in b["config"]["ends_packed_by"] and "torch" in a["config"]["ends_packed_by"]
+    for key in ("bc_assigned_total", "adapter_found_frac", "bc_assigned_accuracy"):
+        assert a["config"][key] == b["config"][key], key
+
+
 def test_bench_config2_small():
     d = _run("--config", "2", "--reads", "400000", "--batch", "200000", "--whitelist", "400000", "--steps", "2", "--warmup", "1")
     _common(d, 2)
