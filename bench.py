@@ -65,8 +65,8 @@ def valu_peaks():
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (200 x 5 ms: a second of the step for whoever watches the GPU from outside)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU per step (configs[1]: 10 M)")
     ap.add_argument("--whitelist", type=int, default=3_600_000)
     ap.add_argument("--cells", type=int, default=5000)
