@@ -443,19 +443,19 @@ const FlagDef kFlags[SMI_N_READ_FLAGS] = {
     {"PASSED_FWD", "Passed forward", 8, true, false, 3},
     {"PASSED_REV", "Passed reverse", 9, true, false, 3},
     {"PASSED_TOT_TSO", "Passed total, found TSO other end", 10, true, true, 5},
-    {"POLY_T_5P", "PolyT found only at 5\"", 11, true, true, 3},
-    {"POLY_A_3P", "PolyA found only at 3\"", 12, true, true, 3},
+    {"POLY_T_5P", "PolyT found only at 5\\'", 11, true, true, 3},
+    {"POLY_A_3P", "PolyA found only at 3\\'", 12, true, true, 3},
     {"POLY_A_NOT_FOUND", "PolyA not found", 13, true, true, 3},
-    {"POLY_T_5P_POLY_A_3P", "PolyT 5\" and PolyA at 3\"", 14, true, true, 3},
-    {"ADAPTER_5P", "Adapter at 5\"(3\" for 5p barcoding)", 15, true, false, 3},
-    {"ADAPTER_3P", "Adapter at 3\"(5\" for 5p barcoding)", 16, true, false, 3},
-    {"TSO_5P", "TSO at 5\"", 17, true, true, 3},
-    {"TSO_3P", "TSO at 3\"", 18, true, true, 3},
+    {"POLY_T_5P_POLY_A_3P", "PolyT 5\\' and PolyA at 3\\'", 14, true, true, 3},
+    {"ADAPTER_5P", "Adapter at 5\\'(3\\' for 5p barcoding)", 15, true, false, 3},
+    {"ADAPTER_3P", "Adapter at 3\\'(5\\' for 5p barcoding)", 16, true, false, 3},
+    {"TSO_5P", "TSO at 5\\'", 17, true, true, 3},
+    {"TSO_3P", "TSO at 3\\'", 18, true, true, 3},
     {"ADAPTER_SELECTED_DESP_ADAPTER_BOTH_SIDES", "Adapter selected despite Adapter both ends", 19, false, false, 3},
     {"READ_TOO_SHORT", "Read too short", 20, true, false, 3},
-    {"ADAPTER_5P_AND_3P", "Adapter at 5\" and 3\"", 21, true, false, 3},
-    {"TSO_5P_AND_3P", "TSO at 5\" and 3\"", 22, true, true, 3},
-    {"TSO_5P_AND_3P_FAILED", "TSO at 5\" and 3\" failed", 23, true, true, 3},
+    {"ADAPTER_5P_AND_3P", "Adapter at 5\\' and 3\\'", 21, true, false, 3},
+    {"TSO_5P_AND_3P", "TSO at 5\\' and 3\\'", 22, true, true, 3},
+    {"TSO_5P_AND_3P_FAILED", "TSO at 5\\' and 3\\' failed", 23, true, true, 3},
     {"BC_FOUND", "Barcode found", 24, true, true, 5},
     {"BC_FOUND_NO_SECONDARY_MATCH", "Barcode found no secondary at <= ED + 2", 25, true, true, 5},
     {"BC_FOUND_ED0", "Barcode found ED= 0", 26, true, true, 25},

@@ -86,11 +86,33 @@ def test_stats_text_follows_the_print_rules(libmod):
     assert rows["Passed (Adapter found)"] == ["1,100,000", _percent(1_100_000, 1_234_567), "of Reads after chimera split"]
     assert "Adapter NOT found" not in rows                                 # FAILED is not printed (print = false)
     assert rows["Mean read length pA and Adapter found"] == ["1,234", "", ""] and rows["Mean read length pA and Adapter NOT found"] == ["999", "", ""]
-    assert rows["Adapter at 3\"(5\" for 5p barcoding)"] == ["0", ".0 %", "of Reads after chimera split"]      # printed although zero
-    assert "TSO at 5\"" not in rows and "Barcode found ED= 2" not in rows                                        # printOnlyIfNonZero
+    assert rows["Adapter at 3\\'(5\\' for 5p barcoding)"] == ["0", ".0 %", "of Reads after chimera split"]      # printed although zero
+    assert "TSO at 5\\'" not in rows and "Barcode found ED= 2" not in rows                                        # printOnlyIfNonZero
     assert rows["Barcode found"] == ["800,000", _percent(800_000, 1_100_000), "of Passed (Adapter found)"]
     assert rows["Barcode found ED= 1"] == ["300,000", "37.5 %", "of Barcode found"]
     assert rows["Barcode offset from predicted pos=+/-2"] == ["1", ".0 %", "of Barcode found"]
     # merging is addition (ReadFlags.mergeStats); the derived rows are recomputed from the sums
     twice = libmod.scan_stats_tsv(st * np.uint64(2))
     assert f"{2 * all_reads:,}" in twice and "Mean read length pA and Adapter found\t1,234" in twice
+
+
+def test_stats_text_equals_the_reference_print(libmod):
+    """smi_scan_stats_tsv against what the reference's own ReadFlags.print wrote (tests/golden/ref_exec_stats_print.json: its bytecode executed on
+    sets of 3 .. 20,000 flag words with read lengths, the sums added as Parser.call adds them): the same text, character for character.  With
+    no failed (or no passed) read at all the reference's print throws an ArithmeticException -- its mean read length is an integer division by
+    the count; the product writes 0 there."""
+    sec = json.load(open(os.path.join(GOLD, "ref_exec_stats_print.json")))["sections"][0]
+    n_equal = 0
+    for c in sec["cases"]:
+        st = np.zeros(libmod.N_SCAN_STATS, dtype=np.uint64)
+        for k, nm in enumerate(libmod.READ_FLAG_NAMES):
+            st[k] = c["n_records"] if nm == "ALL_READS_AFTER_SPLIT" else c["counts"][nm]
+        st[37], st[38], st[39] = c["sum_len_passed"], c["sum_len_failed"], c["n_reads_split"]
+        text = libmod.scan_stats_tsv(st)
+        if c["throws"]:
+            assert c["throws"] == "java/lang/ArithmeticException" and (c["counts"]["FAILED"] == 0 or c["counts"]["PASSED_TOTAL"] == 0)
+            assert "Mean read length pA and Adapter NOT found\t0\t" in text
+            continue
+        assert text == c["text"], c["n_records"]
+        n_equal += 1
+    assert n_equal >= 7

@@ -1355,6 +1355,21 @@ def install_hash(jvm):
 
     N["java/util/LinkedHashMap.<new>"] = linked_new
     N["java/util/LinkedHashMap.<init>"] = lambda j, o, *a: None
+    # java.util.EnumMap: the same keyed store, iterated in the order of the enum constants (specified: "natural order of its keys", tier C)
+    class EnumStore(HashStore):
+        def cells_for_iteration(self, what, cls):
+            return sorted(self.order, key=lambda c: c[0].f["$ordinal"])
+
+    def enum_map_new(j):
+        o = JObject("java/util/EnumMap")
+        o.native = EnumStore(j)
+        return o
+
+    N["java/util/EnumMap.<new>"] = enum_map_new
+    N["java/util/EnumMap.<init>"] = lambda j, o, *a: None
+    for k in list(N):
+        if k.startswith("java/util/HashMap.") and not k.endswith(("<new>", "<init>")):
+            N["java/util/EnumMap" + k[len("java/util/HashMap"):]] = N[k]
     # java.util.TreeMap used as a lookup table only (put / get / containsKey / size): same keyed store, iteration refused; get(null)
     # throws as a TreeMap with natural ordering does
     N["java/util/TreeMap.<new>"] = new("java/util/TreeMap")
@@ -1562,7 +1577,7 @@ def install_env(jvm):
         N[f"{c}.getAndSet"] = lambda j, o, v: (o.native[0], o.native.__setitem__(0, v))[0]
         N[f"{c}.decrementAndGet"] = (lambda w: lambda j, o: (o.native.__setitem__(0, w(o.native[0] - 1)), o.native[0])[1])(wrap)
 
-    # java.text.DecimalFormat: only patterns made of '#', '0', ',', '.'; RoundingMode.HALF_EVEN on the exact binary value
+    # java.text.DecimalFormat: only patterns made of '#', '0', ',', '.' (+ a ' %' suffix); RoundingMode.HALF_EVEN on the exact binary value
     def df_new(j):
         o = JObject("java/text/DecimalFormat")
         o.native = {"pattern": "#"}
@@ -1575,8 +1590,15 @@ def install_env(jvm):
         import decimal
 
         pat = o.native["pattern"]
-        if any(ch not in "#0,." for ch in pat):
-            raise Unsupported(f"DecimalFormat pattern {pat!r}")
+        # a suffix of literal blanks and one '%' (the value is multiplied by 100 in double arithmetic first, as DecimalFormat does: `number *= multiplier`)
+        suffix = ""
+        while pat and pat[-1] in " %":
+            suffix = pat[-1] + suffix
+            pat = pat[:-1]
+        if suffix.count("%") > 1 or any(ch not in "#0,." for ch in pat):
+            raise Unsupported(f"DecimalFormat pattern {o.native['pattern']!r}")
+        if "%" in suffix:
+            v = (v.v if isinstance(v, JBox) else v) * 100.0
         ip, _, fp = pat.partition(".")
         max_frac, min_frac = len(fp), fp.count("0")
         min_int = ip.replace(",", "").count("0")
@@ -1603,7 +1625,7 @@ def install_env(jvm):
             out = "0"
         if neg and any(ch in "123456789" for ch in out):
             out = "-" + out
-        return out
+        return out + suffix
 
     N["java/text/DecimalFormat.<new>"] = df_new
     N["java/text/DecimalFormat.<init>"] = df_init

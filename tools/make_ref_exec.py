@@ -652,6 +652,60 @@ def gen_pass2_5p_polya(g):
     return gen_pass2(g, 14, True, 1, 737, dont_search_polya=False, tag="5p")
 
 # ---------------------------------------------------------------------------------------------------------------------
+# scan statistics: ReadFlags.addForCounting per record + the two read-length sums as Parser.call adds them (Parser.java:L115-118), then
+# ReadFlags.print(PrintStream) -- the text of the table ReadScanner.html shows, for sets of flag words drawn from the flags the reference
+# itself gave the records of ref_exec_pass2_*.json (+ the split / multi-chimeric bits) at random multiplicities
+# ---------------------------------------------------------------------------------------------------------------------
+def gen_stats_print(g):
+    j = g.j
+    rng = random.Random(4242)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    s = g.section("new ReadFlags(); per record addForCounting(flag, readLength) and sumReadLengthPassed / sumReadLengthFailed.addAndGet(readLength) "
+                  "by PASSED_TOTAL (Parser.call L115-118); nReadsSplit.addAndGet; print(PrintStream): every string handed to the stream", RFLAGS,
+                  "print:(Ljava/io/PrintStream;)V")
+    pool = []
+    fv = None
+    for name in ("pass2_3p", "pass2_5p", "pass2_5p_polya", "pass2_3p_ed2"):
+        d = json.load(open(os.path.join(OUT, f"ref_exec_{name}.json")))
+        fv = d["sections"][0]["flag_values"]
+        pool += [int(c["result"]["flag"]) for c in d["sections"][0]["cases"] if "flag" in c["result"]]
+    s["flag_values"] = fv
+    captured = []
+    j.natives["java/io/PrintStream.println"] = lambda jj, o, *a: captured.append((a[0] if a else "") + "\n")
+    j.natives["java/io/PrintStream.print"] = lambda jj, o, *a: captured.append(a[0] if a else "")
+    for case in range(8):
+        rf = j.new(RFLAGS)
+        n = [3, 40, 500, 5000, 1, 77, 1234, 20000][case]
+        recs = []
+        for _ in range(n):
+            f = rng.choice(pool)
+            if rng.random() < 0.1:
+                f |= fv["READS_AFTER_SPLIT"]
+            if rng.random() < 0.01:
+                f = fv["MULTI_CHIMERIC_READS_DISCARDED"] | fv["FAILED"]
+            ln = rng.randrange(150, 4000)
+            recs.append([f, ln])
+            j.call_virtual(rf, "addForCounting", "(JI)V", f, ln)
+            j.call_virtual(rf.f["sumReadLengthPassed" if f & fv["PASSED_TOTAL"] else "sumReadLengthFailed"], "addAndGet", "(J)J", ln)
+        n_split = sum(1 for f, _ in recs if f & fv["READS_AFTER_SPLIT"]) // 2
+        j.call_virtual(rf.f["nReadsSplit"], "addAndGet", "(I)I", n_split)
+        del captured[:]
+        ps = JObject("java/io/PrintStream")
+        ps.native = []
+        throws = None
+        try:
+            j.call_virtual(rf, "print", "(Ljava/io/PrintStream;)V", ps)
+        except JavaThrow as e:          # e.g. no failed read at all: the mean read length is an integer division by the count
+            throws = e.obj.cls if hasattr(e, "obj") else str(e)
+        s["cases"].append({"throws": throws, "records": recs if n <= 500 else None, "seed_note": "records drawn with random.Random(4242) in tools/make_ref_exec.py::gen_stats_print",
+                           "counts": {nm: sum(1 for f, _ in recs if f & v) for nm, v in fv.items()}, "n_records": n,
+                           "sum_len_passed": sum(l for f, l in recs if f & fv["PASSED_TOTAL"]), "sum_len_failed": sum(l for f, l in recs if not f & fv["PASSED_TOTAL"]),
+                           "n_reads_split": n_split, "text": "".join(captured)})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # assignumis: read name -> scan data (FastqRecordExt.getScanDatFromReadName L395-496) -> UMI pair distance
 # (ClusteringEditDistanceBase.calcEditDistances = lambda$static$7 L297-350 + calcBestEditDistance L67-80), 3' and 5' (-p)
 # ---------------------------------------------------------------------------------------------------------------------
@@ -1674,7 +1728,7 @@ def gen_cluster_own(g, seed=1717):
 
 SECTIONS = {"cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
-            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p}
+            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
 
 
 def main():
