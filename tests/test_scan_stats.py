@@ -116,3 +116,13 @@ def test_stats_text_equals_the_reference_print(libmod):
         assert text == c["text"], c["n_records"]
         n_equal += 1
     assert n_equal >= 7
+    # ReadFlags.mergeStats (the `mergestats` sub-command): three of the sets merged by the reference, printed by the reference
+    total = np.zeros(libmod.N_SCAN_STATS, dtype=np.uint64)
+    for k in sec["merged"]["cases"]:
+        c = sec["cases"][k]
+        for i, nm in enumerate(libmod.READ_FLAG_NAMES):
+            total[i] += c["n_records"] if nm == "ALL_READS_AFTER_SPLIT" else c["counts"][nm]
+        total[37] += c["sum_len_passed"]
+        total[38] += c["sum_len_failed"]
+        total[39] += c["n_reads_split"]
+    assert libmod.scan_stats_tsv(total) == sec["merged"]["text"]

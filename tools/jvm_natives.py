@@ -1370,10 +1370,29 @@ def install_hash(jvm):
     for k in list(N):
         if k.startswith("java/util/HashMap.") and not k.endswith(("<new>", "<init>")):
             N["java/util/EnumMap" + k[len("java/util/HashMap"):]] = N[k]
-    # java.util.TreeMap used as a lookup table only (put / get / containsKey / size): same keyed store, iteration refused; get(null)
-    # throws as a TreeMap with natural ordering does
-    N["java/util/TreeMap.<new>"] = new("java/util/TreeMap")
+    # java.util.TreeMap: the same keyed store; get(null) throws as a TreeMap with natural ordering does
+    # (iteration: ascending natural order of boxed-number or String keys, which is all the reference puts into one -- specified order, tier C)
+    class TreeStore(HashStore):
+        def cells_for_iteration(self, what, cls):
+            def key(c):
+                k = c[0]
+                if isinstance(k, JBox):
+                    return k.v
+                if isinstance(k, str):
+                    return k
+                raise Unsupported(f"{what} of a TreeMap with keys of {getattr(k, 'cls', type(k))}")
+            return sorted(self.order, key=key)
+
+    def tree_new(j):
+        o = JObject("java/util/TreeMap")
+        o.native = TreeStore(j)
+        return o
+
+    N["java/util/TreeMap.<new>"] = tree_new
     N["java/util/TreeMap.<init>:()V"] = lambda j, o: None
+    for k in ("entrySet", "keySet", "values", "forEach", "containsKey", "getOrDefault", "putIfAbsent", "computeIfAbsent", "isEmpty"):
+        if "java/util/HashMap." + k in N:
+            N["java/util/TreeMap." + k] = N["java/util/HashMap." + k]
 
     def tree_get(j, o, k):
         if k is None:

@@ -673,8 +673,10 @@ def gen_stats_print(g):
     captured = []
     j.natives["java/io/PrintStream.println"] = lambda jj, o, *a: captured.append((a[0] if a else "") + "\n")
     j.natives["java/io/PrintStream.print"] = lambda jj, o, *a: captured.append(a[0] if a else "")
+    kept = {}
     for case in range(8):
         rf = j.new(RFLAGS)
+        kept[case] = rf
         n = [3, 40, 500, 5000, 1, 77, 1234, 20000][case]
         recs = []
         for _ in range(n):
@@ -701,6 +703,15 @@ def gen_stats_print(g):
                            "counts": {nm: sum(1 for f, _ in recs if f & v) for nm, v in fv.items()}, "n_records": n,
                            "sum_len_passed": sum(l for f, l in recs if f & fv["PASSED_TOTAL"]), "sum_len_failed": sum(l for f, l in recs if not f & fv["PASSED_TOTAL"]),
                            "n_reads_split": n_split, "text": "".join(captured)})
+    # ReadFlags.mergeStats (the `mergestats` sub-command's sum): an empty ReadFlags that merges the sets of cases 1, 2 and 5, then prints
+    merged = j.new(RFLAGS)
+    for k in (1, 2, 5):
+        j.call_virtual(merged, "mergeStats", "(L" + RFLAGS + ";)V", kept[k])
+    del captured[:]
+    ps = JObject("java/io/PrintStream")
+    ps.native = []
+    j.call_virtual(merged, "print", "(Ljava/io/PrintStream;)V", ps)
+    s["merged"] = {"cases": [1, 2, 5], "text": "".join(captured)}
     out["sections"].append(g.finish(s))
     return out
 
