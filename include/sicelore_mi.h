@@ -776,6 +776,31 @@ int smi_gene_tag_chunk(const smi_genes *g, const int32_t *ref_id, const uint16_t
 int smi_gene_tag_bam(const smi_genes *g, const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, char *out, size_t cap,
                      uint32_t *out_off, size_t *n_out);
 
+/* ---- <out>.genecounts.tsv / <out>.UMIdepths.tsv of assignumis (host only) -----------------------------------------------------------------
+ * Replaces GeneCounts (FJ!umifinder/scanstats/GeneCounts.java:L58-652).
+ * smi_gene_counts_add = updateGeneCounts (L375-491) for the n records of one written batch, called where $BamWriters.lambda$writeSams$2
+ * calls it (UmiFinderWorker.java:L453-454: records that carry a BC and, after the U7 -> U8 fill, a U8 tag).  Per record: gene = the name the
+ * record counts for (first entry of its GE value split at ','; the reference draws one at random when there are several, L439), NULL =
+ * no GE value (the pointer array itself may be NULL); region = genomicRegionNmber of ReadGrouper (< 0: none); cell_bc / umi = 2-bit codes of
+ * the BC and U8 strings (NucleicAcidTwoBitPerBase(String).getSequence()); has_bc_umi = both tags present; flag / mapq = the BAM fields;
+ * first_cigar / last_cigar = first and last CIGAR operation `len << 4 | op` (0xFFFFFFFF in first_cigar: no CIGAR); nth_record = a record of
+ * the same read name went through the analyzer before this one (OneNanoporeSeqAnalyzer.java:L74-80).
+ * smi_gene_counts_merge = mergeGeneCounts (L540-592).  smi_gene_counts_tsv = printCountTable (L307-357): header TAB cells, one row per gene,
+ * cells by their number of UMIs (descending), genes by theirs; smi_umi_depths_tsv = printUmisPerCellTable (L256-284).  Rows the reference
+ * leaves in ConcurrentHashMap order (equal totals) are by ascending key.  out == NULL: size only. */
+typedef struct smi_gene_counts smi_gene_counts;
+int smi_gene_counts_create(smi_gene_counts **out);
+int smi_gene_counts_free(smi_gene_counts *gc);
+int smi_gene_counts_add(smi_gene_counts *gc, size_t n, const char *const *gene, const int64_t *region, const uint64_t *cell_bc,
+                        const uint64_t *umi, const uint8_t *has_bc_umi, const uint16_t *flag, const uint8_t *mapq,
+                        const uint32_t *first_cigar, const uint32_t *last_cigar, const uint8_t *nth_record, int five_prime);
+int smi_gene_counts_merge(smi_gene_counts *dst, const smi_gene_counts *src);
+/* recordsWithGene, recordsWithGeneSkippedClipping, number of genes / (gene, cell, UMI) / (region, cell, UMI) entries; any pointer may be NULL */
+int smi_gene_counts_info(const smi_gene_counts *gc, int64_t *records_with_gene, int64_t *records_skipped_clipping, size_t *n_genes,
+                         size_t *n_gene_entries, size_t *n_region_entries);
+int smi_gene_counts_tsv(const smi_gene_counts *gc, int bc_length, char *out, size_t cap, size_t *n_out);
+int smi_umi_depths_tsv(const smi_gene_counts *gc, char *out, size_t cap, size_t *n_out);
+
 /* device-time of the dominant kernel of the last *_device call on this context, measured with HIP events on the
  * stream the kernel was launched on; valid after the stream has been synchronised.  ms <= 0: not available. */
 int smi_last_kernel_ms(smi_ctx *ctx, float *ms);

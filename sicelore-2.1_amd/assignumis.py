@@ -182,15 +182,16 @@ def clustering_position(bam, rec, scan, grouping_distance=100, five_prime=False,
 
 
 def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=None, cluster_cfg=None, n_threads=4, native=False,
-                    five_prime=False, batches=None):
+                    five_prime=False, batches=None, regions=None):
     """`assignumis` over a whole BAM -> (names, tags): tags[i] as assign_umis returns them, in BAM order.  Chunks as
     BamReader.run cuts them: `chunk_size` records or the end of a chromosome; within a chromosome the regions near the
-    right edge are carried into the next chunk (ReadGrouper.groupSams keepDataEnd, smi_region_group)."""
+    right edge are carried into the next chunk (ReadGrouper.groupSams keepDataEnd, smi_region_group).  batches / regions: optional lists that
+    receive the record indices of every flush and {record index: run-wide region number} (genomicRegionNmber) of the grouped records."""
     _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
     n = recs.size
     names = [read_name(bam, r) for r in recs]
     if native:
-        return names, _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads, five_prime, batches)
+        return names, _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads, five_prime, batches, regions)
     scans = [scan_data_from_name(nm, bc_edit_limit) for nm in names]
     pos = [clustering_position(bam, recs[i], scans[i], five_prime=five_prime) for i in range(n)]
     rev = [bool(int(r["flag"]) & 16) for r in recs]
@@ -213,6 +214,8 @@ def assign_umis_bam(ctx, data, chunk_size=250_000, max_dist=500, bc_edit_limit=N
                 t["center"] = done[t["center"]]
                 t["region"] += region_base
             tags[i] = t
+        if regions is not None:
+            regions.update({i: region[k] + region_base for k, i in enumerate(done) if region[k] >= 0})
         region_base += (max(region[:n_done]) + 1) if n_done and max(region[:n_done]) >= 0 else 0
         return cur[n_done:]
 
@@ -242,7 +245,7 @@ def _run_chunks(recs, chunk_size, flush):
         cur = flush(cur, keep=False)
 
 
-def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads, five_prime=False, batches=None):
+def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit_limit, n_threads, five_prime=False, batches=None, regions=None):
     """the same through smi_assignumis_chunk: one native call per chunk (name parsing, positions, grouping, K-UMI, clustering)"""
     tags = [None] * recs.size
     cig = [bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4") for r in recs]
@@ -259,6 +262,8 @@ def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit
         for k in range(n_done):
             t, i = out[k], cur[k]
             top = max(top, int(t["region"]))
+            if regions is not None and int(t["region"]) >= 0:
+                regions[i] = int(t["region"]) + region_base
             if t["flags"] & _lib.UMI_CLUSTERED:
                 tags[i] = dict(U8=t["u8"].decode(), U7=t["u7"].decode(), U1=int(t["u1"]), U2=None if t["u2"] < 0 else int(t["u2"]),
                                region=int(t["region"]) + region_base, center=cur[int(t["center"])])
@@ -397,20 +402,40 @@ def _coordinate_key(rec, name):
             int(rec["next_ref_id"]) if int(rec["next_ref_id"]) >= 0 else 1 << 30, int(rec["next_pos"]), int(rec["tlen"]))
 
 
-def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device", **kw):
+def _java_split(text, sep):
+    """String.split(sep) for a literal separator: trailing empty strings are dropped, the empty string gives [""]"""
+    if text == "":
+        return [""]
+    parts = text.split(sep)
+    while parts and parts[-1] == "":
+        parts.pop()
+    return parts
+
+
+def _count_columns(rows, five_prime):
+    """rows of one written batch -> the columns of lib.GeneCounts.add"""
+    cols = list(zip(*rows))
+    return dict(gene=cols[0], region=cols[1], cell_bc=cols[2], umi=cols[3], has_bc_umi=cols[4], flag=cols[5], mapq=cols[6], first_cigar=cols[7],
+                last_cigar=cols[8], nth_record=cols[9], five_prime=five_prime)
+
+
+def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device",
+                      gene_counts=None, **kw):
     """`assignumis` BAM in -> (bcfound BAM bytes, umifound BAM bytes, names, tags): the two BGZF streams the reference writes
     (<out>.bam: every record with a cell barcode; <out>_umifound_.bam: those whose UMI comes from clustering), header copied,
     records of a chunk in coordinate-comparator order with the tags of record_tag_sets added; refflat = text of the --annotationFile
     (GE / GS / XF through lib.GeneTagger), None = no annotation file given.  bgzf: "device" = the BGZF blocks are deflated by K-DEFLATE
-    (smi_bgzf_deflate_device), "zlib" = by zlib at compress_level on n_threads host threads; the inflated streams are the same."""
+    (smi_bgzf_deflate_device), "zlib" = by zlib at compress_level on n_threads host threads; the inflated streams are the same.
+    gene_counts: a lib.GeneCounts that receives every written record that ends up with a U8 tag, batch by batch
+    (GeneCounts.updateGeneCounts from $BamWriters.lambda$writeSams$2 L453-454) -- what <out>.genecounts.tsv / <out>.UMIdepths.tsv print."""
     _text, _refs, bam, recs = load_bam(data, n_threads=n_threads)
     gene_tags = None
     if refflat is not None:
         tagger = _lib.GeneTagger(refflat, [nm for nm, _ in _refs])
         gene_tags = tagger.tag_bam(bam, recs)
         tagger.close()
-    batches = []
-    names, tags = assign_umis_bam(ctx, data, chunk_size=chunk_size, n_threads=n_threads, batches=batches, **kw)
+    batches, regions = [], ({} if gene_counts is not None else None)
+    names, tags = assign_umis_bam(ctx, data, chunk_size=chunk_size, n_threads=n_threads, batches=batches, regions=regions, **kw)
     five_prime = bool(kw.get("five_prime", False))
     scans = [scan_data_from_name(nm, kw.get("bc_edit_limit")) for nm in names]
     header_end = int(recs[0]["rec_off"]) if recs.size else bam.size
@@ -418,6 +443,14 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
     # BamReader cuts chunks; BamWriters sorts each written BATCH with the coordinate comparator (L421), not the file: batches =
     # the flushes of assign_umis_bam, in the order they complete
     order = [i for b in batches for i in sorted(b, key=lambda k: _coordinate_key(recs[k], names[k]))]
+    nth = {}
+    if gene_counts is not None:                                 # OneNanoporeSeqAnalyzer.call L74-80: a record of this read name was analysed before
+        seen = set()
+        for b in batches:
+            for i in b:
+                nth[i] = names[i] in seen
+                seen.add(names[i])
+    rows = []                                                   # in write order: UMIcounts.increment does not commute with its nth-record form
     for i in order:
         d, r = scans[i], recs[i]
         u7 = None
@@ -434,13 +467,43 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
             fixed = fixed[:32] + nm + fixed[32 + int(r["l_read_name"]):]
             fixed[8] = len(nm)
         aux = bam[int(r["aux_off"]):int(r["aux_off"]) + int(r["aux_len"])].tobytes()
-        body = bytes(fixed) + b"".join(raw for _, raw in apply_tag_sets(split_aux(aux), calls))
+        fields = apply_tag_sets(split_aux(aux), calls)
+        body = bytes(fixed) + b"".join(raw for _, raw in fields)
         rec_bytes = np.array([len(body)], dtype="<u4").tobytes() + body
         out_bc.append(rec_bytes)
         if clustered:
             out_umi.append(rec_bytes)
+        if gene_counts is not None:
+            f = {t: raw for t, raw in fields if t in ("GE", "U8", "BC")}
+            z = lambda t: f[t][3:-1].decode() if t in f and f[t][2:3] == b"Z" else None  # noqa: E731
+            ge, u8, bc = z("GE"), z("U8"), z("BC")
+            cg = bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4")
+            gene = None if ge is None else (_java_split(ge, ",") or [None])[0]
+            rows.append((gene, regions.get(i, -1), _lib.two_bit_code(bc) if bc else 0, _lib.two_bit_code(u8) if u8 else 0,
+                         1 if bc is not None and u8 is not None else 0, int(r["flag"]), int(r["mapq"]),
+                         int(cg[0]) if cg.size else 0xFFFFFFFF, int(cg[-1]) if cg.size else 0, 1 if nth[i] else 0))
+    if gene_counts is not None and rows:
+        gene_counts.add(**_count_columns(rows, five_prime))
     if bgzf == "device":
         z = lambda parts: ctx.bgzf_deflate_device(b"".join(parts)).tobytes()  # noqa: E731
     else:
         z = lambda parts: _lib.bgzf_deflate(b"".join(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
     return z(out_bc), z(out_umi), names, tags
+
+
+def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, **kw):
+    """`assignumis -i in.bam -o out`: writes <out>.bam, <out>_umifound_.bam, <out>.genecounts.tsv and <out>.UMIdepths.tsv
+    (UmiFinderWorker.java:L142-143, L188-189) -> dict of what was written.  kw: as write_tagged_bams (refflat = text of --annotationFile)."""
+    with open(in_bam, "rb") as f:
+        data = f.read()
+    gc = _lib.GeneCounts()
+    bc_bam, umi_bam, names, tags = write_tagged_bams(ctx, data, gene_counts=gc, **kw)
+    texts = {".bam": bc_bam, "_umifound_.bam": umi_bam, ".genecounts.tsv": gc.genecounts_tsv(bc_length).encode(),
+             ".UMIdepths.tsv": gc.umi_depths_tsv().encode()}
+    for suffix, body in texts.items():
+        with open(out_prefix + suffix, "wb") as f:
+            f.write(body)
+    info = gc.info()
+    gc.close()
+    return dict(records=len(names), clustered=sum(1 for t in tags if t is not None and not t.get("skipped")), **info,
+                files={out_prefix + k: len(v) for k, v in texts.items()})

@@ -59,6 +59,8 @@ EXPORTS = [
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
+    "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
+    "smi_gene_counts_tsv", "smi_umi_depths_tsv",
 ]
 
 
@@ -179,6 +181,13 @@ def load_library():
     lib.smi_gene_tag_chunk.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
+    lib.smi_gene_counts_create.argtypes = [ctypes.POINTER(vp)]
+    lib.smi_gene_counts_free.argtypes = [vp]
+    lib.smi_gene_counts_add.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
+    lib.smi_gene_counts_merge.argtypes = [vp, vp]
+    lib.smi_gene_counts_info.argtypes = [vp, vp, vp, vp, vp, vp]
+    lib.smi_gene_counts_tsv.argtypes = [vp, ci, vp, sz, ctypes.POINTER(sz)]
+    lib.smi_umi_depths_tsv.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     lib.smi_finalize_used_list.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, vp, vp, vp, ctypes.POINTER(sz)]
     explicit = {"smi_last_error", "smi_version", "smi_read_planes_words", "smi_packed_planes_words", "smi_record_flags"}  # restype set above (char*, size_t)
     for name in EXPORTS:
@@ -298,6 +307,74 @@ class GeneTagger:
             ge, gs, xf = (raw[out_off[3 * i + k]:out_off[3 * i + k + 1]].decode() for k in range(3))
             res.append((ge or None, gs or None, xf or None))
         return res
+
+
+def two_bit_code(seq):
+    """NucleicAcidTwoBitPerBase(String).getSequence() (TB!nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase.java:L183-187, L448-450): two bits per
+    base, first base most significant; any other character ORs in the table's fill value -2 like there"""
+    v = 0
+    for ch in seq:
+        c = {"A": 0, "a": 0, "G": 1, "g": 1, "C": 2, "c": 2, "T": 3, "t": 3}.get(ch, -2)
+        v = ((v << 2) | (c & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF
+    return v
+
+
+class GeneCounts:
+    """The counters behind <out>.genecounts.tsv and <out>.UMIdepths.tsv (smi_gene_counts_*) = GeneCounts
+    (FJ!umifinder/scanstats/GeneCounts.java): add() per written batch, the two texts at the end of the run."""
+
+    def __init__(self):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        if self._lib.smi_gene_counts_create(ctypes.byref(h)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smi_gene_counts_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def add(self, gene, region, cell_bc, umi, has_bc_umi, flag, mapq, first_cigar, last_cigar, nth_record, five_prime=False):
+        """gene: per record a str or None; region: int (< 0 none); cell_bc / umi: 2-bit codes (two_bit_code); first_cigar / last_cigar:
+        `len << 4 | op` (0xFFFFFFFF in first_cigar: no CIGAR)"""
+        n = len(region)
+        names = [None if g is None else (g.encode() if isinstance(g, str) else g) for g in gene]
+        arr = (ctypes.c_char_p * max(n, 1))(*names)
+        a = lambda x, t: np.ascontiguousarray(x, dtype=t)  # noqa: E731
+        cols = [a(region, np.int64), a(cell_bc, np.uint64), a(umi, np.uint64), a(has_bc_umi, np.uint8), a(flag, np.uint16), a(mapq, np.uint8),
+                a(first_cigar, np.uint32), a(last_cigar, np.uint32), a(nth_record, np.uint8)]
+        if any(c.size != n for c in cols) or len(names) != n:
+            raise SmiError("GeneCounts.add: columns of different lengths")
+        if self._lib.smi_gene_counts_add(self._h, n, arr, *[_ptr(c) for c in cols], int(bool(five_prime))):
+            raise SmiError(self._lib.smi_last_error().decode())
+
+    def merge(self, other):
+        if self._lib.smi_gene_counts_merge(self._h, other._h):
+            raise SmiError(self._lib.smi_last_error().decode())
+
+    def info(self):
+        a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+        c, d, e = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._lib.smi_gene_counts_info(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d), ctypes.byref(e))
+        return dict(records_with_gene=a.value, records_skipped_clipping=b.value, genes=c.value, gene_entries=d.value, region_entries=e.value)
+
+    def _text(self, fn, *args):
+        need = ctypes.c_size_t(0)
+        if fn(self._h, *args, None, 0, ctypes.byref(need)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        buf = ctypes.create_string_buffer(need.value + 1)
+        if fn(self._h, *args, buf, need.value, ctypes.byref(need)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        return buf.raw[:need.value].decode()
+
+    def genecounts_tsv(self, bc_length=16):
+        return self._text(self._lib.smi_gene_counts_tsv, int(bc_length))
+
+    def umi_depths_tsv(self):
+        return self._text(self._lib.smi_umi_depths_tsv)
 
 
 def format_read_name(read_name, raw_seq, raw_qual, scan, bc=None, rank=0, read_id=0, five_prime=False):

@@ -274,8 +274,11 @@ def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
     import bammodel
     from test_bam import _parse_aux
 
+    import os
+
     scanfastq = importlib.import_module("sicelore_amd.scanfastq")
     assignumis = importlib.import_module("sicelore_amd.assignumis")
+    libmod = importlib.import_module("sicelore_amd.lib")
     rng = np.random.default_rng(23)
     wl = synth.make_whitelist(50_000, seed=291)
     used = synth.pick_used(wl, 4, seed=292)
@@ -366,3 +369,31 @@ def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
         rest = [(t, v) for t, _ty, v in _parse_aux(o["aux"]) if t not in ("XF", "GE", "GS")]
         assert rest == [(t, v) for t, _ty, v in _parse_aux(o0["aux"])]
     assert 20 < n_ge < len(out_g)
+    # <out>.genecounts.tsv / <out>.UMIdepths.tsv: the counters fed by the writer = the test's GeneCounts model over the written records
+    from test_gene_counts import Model
+
+    regions = {}
+    assignumis.assign_umis_bam(gpu_ctx, data, regions=regions)
+    gc = libmod.GeneCounts()
+    z_c, _, _, _ = assignumis.write_tagged_bams(gpu_ctx, data, refflat=refflat, gene_counts=gc)
+    assert z_c == z_g
+    model, mrecs = Model(), []
+    for o in out_g:
+        a = {t: v for t, _ty, v in _parse_aux(o["aux"])}
+        ge = a.get("GE")
+        mrecs.append({"gene": None if ge is None else ge.split(",")[0], "region": regions.get(by_name[o["name"]]), "bc": a.get("BC"), "u8": a.get("U8"),
+                      "flag": o["flag"], "mapq": 30, "cigar": "".join(f"{ln}{op}" for op, ln in o["cigar"]), "nth": 0})
+    model.add(mrecs, False)
+    assert (gc.genecounts_tsv(16), gc.umi_depths_tsv()) == model.texts(libmod.two_bit_code)
+    info = gc.info()
+    assert info["records_with_gene"] == model.with_gene > 20 and info["region_entries"] == len(model.regions) >= n_mol // 2
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "in.bam"), "wb") as f:
+            f.write(data)
+        res = assignumis.assignumis_files(gpu_ctx, os.path.join(td, "in.bam"), os.path.join(td, "out"), refflat=refflat)
+        assert open(os.path.join(td, "out.bam"), "rb").read() == z_g
+        assert open(os.path.join(td, "out.genecounts.tsv")).read() == gc.genecounts_tsv(16)
+        assert open(os.path.join(td, "out.UMIdepths.tsv")).read() == gc.umi_depths_tsv()
+        assert os.path.getsize(os.path.join(td, "out_umifound_.bam")) > 100 and res["records"] == len(names)

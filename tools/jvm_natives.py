@@ -924,6 +924,11 @@ def install_streams(jvm):
     N["java/util/stream/Collectors.joining:(Ljava/lang/CharSequence;)Ljava/util/stream/Collector;"] = \
         lambda j, sep: collector(lambda j_, items: j_.to_jstring(sep).join(j_.to_jstring(v) for v in items))
 
+    N["java/util/stream/Collectors.joining:(Ljava/lang/CharSequence;Ljava/lang/CharSequence;Ljava/lang/CharSequence;)Ljava/util/stream/Collector;"] = \
+        lambda j, sep, pre, suf: collector(lambda j_, items: j_.to_jstring(pre) + j_.to_jstring(sep).join(j_.to_jstring(v) for v in items) + j_.to_jstring(suf))
+    N["java/util/stream/Collectors.summingInt"] = \
+        lambda j, f: collector(lambda j_, items: JBox("java/lang/Integer", i32(sum(call_fn(j_, f, v) for v in items))))
+
     def grouping_by(j, keyf, *rest):
         """groupingBy(classifier[, downstream]) -> java.util.HashMap: lists in encounter order; the map's own iteration order is
         as for every hash container here (varied, not emulated)"""

@@ -1737,7 +1737,176 @@ def gen_cluster_own(g, seed=1717):
     return out
 
 
-SECTIONS = {"cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+# assignumis: <out>.genecounts.tsv / <out>.UMIdepths.tsv (GeneCounts.updateGeneCounts L375-491, printCountTable L307-357,
+# printUmisPerCellTable L256-284, mergeGeneCounts L540-592)
+# ---------------------------------------------------------------------------------------------------------------------
+GCNT = "com/rw/umifinder/scanstats/GeneCounts"
+ORSTAT = "com/rw/umifinder/scanstats/OneReadScanStat"
+
+
+def install_genecounts_io(j, files):
+    """INPUT / OUTPUT plumbing of the GeneCounts fixture: a SAMRecord is a bag of the six values updateGeneCounts asks for (its Cigar is
+    htsjdk's own, decoded from text by TextCigarCodec); File / FileOutputStream / BufferedOutputStream / PrintStream collect what is appended
+    into files[path]; System.gc and the Runtime memory figures (printed to stdout only) are inert"""
+    H, N = j.hooks, j.natives
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".getReadUnmappedFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 4 else 0
+    H[SAMREC + ".isSecondaryOrSupplementary:()Z"] = lambda jj, o: 1 if o.native["flag"] & 0x900 else 0
+    H[SAMREC + ".getMappingQuality:()I"] = lambda jj, o: o.native["mapq"]
+    H[SAMREC + ".getCigar:()Lhtsjdk/samtools/Cigar;"] = lambda jj, o: o.native["cigar"]
+    H[SAMREC + ".getReadNegativeStrandFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 16 else 0
+    H[SAMREC + ".getStringAttribute:(Ljava/lang/String;)Ljava/lang/String;"] = lambda jj, o, t: o.native["attrs"].get(t)
+    H[ORSTAT + ".incrementRecordsForReadsUsedInGeneCounts:()V"] = lambda jj, o: o.native.__setitem__(0, o.native[0] + 1)
+
+    def file_init(jj, o, *a):
+        o.native = a[0] if len(a) == 1 else a[0].native + "/" + a[1]
+
+    for c in ("java/io/File", "java/io/FileOutputStream", "java/io/BufferedOutputStream", "java/io/PrintStream"):
+        N[c + ".<new>"] = (lambda cc: lambda jj: JObject(cc))(c)
+    N["java/io/File.<init>"] = file_init
+    N["java/io/File.getPath"] = lambda jj, o: o.native
+    N["java/io/FileOutputStream.<init>"] = lambda jj, o, f, *a: setattr(o, "native", files.setdefault(f.native if isinstance(f, JObject) else f, []))
+    N["java/io/BufferedOutputStream.<init>"] = lambda jj, o, inner, *a: setattr(o, "native", inner.native)
+    N["java/io/PrintStream.<init>"] = lambda jj, o, inner, *a: setattr(o, "native", inner.native)
+
+    def ps_append(jj, o, text, *a):
+        o.native.append(jj.to_jstring(text))
+        return o
+
+    N["java/io/PrintStream.append"] = ps_append
+    N["java/io/PrintStream.flush"] = lambda jj, o: None
+    N["java/io/PrintStream.close"] = lambda jj, o: None
+    N["java/lang/System.gc"] = lambda jj: None
+    rt = JObject("java/lang/Runtime")
+    N["java/lang/Runtime.getRuntime"] = lambda jj: rt
+    for m in ("freeMemory", "totalMemory", "maxMemory"):
+        N["java/lang/Runtime." + m] = lambda jj, o: 0
+
+
+def gen_genecounts(g, seed=1818):
+    j = g.j
+    rng = random.Random(seed)
+    files = {}
+    install_long2object_iterable(j)
+    install_parallel_as_sequential(j)
+    install_genecounts_io(j, files)
+    N = j.natives
+    for c in (L2O, L2OM):                                 # Long2ObjectFunction / Map defaults the stand-in did not need before
+        N[c + ".putIfAbsent:(JLjava/lang/Object;)Ljava/lang/Object;"] = \
+            lambda jj, o, k, v: (lambda cell: cell[1] if cell is not None and cell[1] is not None else (o.native.put(JBox("java/lang/Long", k), v), None)[1])(o.native.find(JBox("java/lang/Long", k)))
+        N[c + ".entrySet"] = N[c + ".long2ObjectEntrySet"]
+        N[c + ".containsKey:(Ljava/lang/Object;)Z"] = lambda jj, o, k: 1 if o.native.find(k) is not None else 0
+        N[c + ".get:(Ljava/lang/Object;)Ljava/lang/Object;"] = lambda jj, o, k: (o.native.find(k) or [None, None])[1]
+        N[c + ".put:(Ljava/lang/Object;Ljava/lang/Object;)Ljava/lang/Object;"] = lambda jj, o, k, v: o.native.put(k, v)[0]
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar + TwoFourBitNucAcidLibraryMaven-1.0.jar + htsjdk-4.1.3.jar (Cigar)", "sections": []}
+    s = g.section("new GeneCounts(); updateGeneCounts(result, params, null) per record (GeneCounts.java:L375-491: the record's flag / mapping "
+                  "quality / CIGAR clip test, BC and U8 attributes, geneNames, genomicRegionNmber, isNthRecordForRead), then printCountTable(file, "
+                  "params, null) and printUmisPerCellTable(file, params): the text appended to each file.  Every case under six iteration orders of "
+                  "the hash containers (ConcurrentHashMap, the stand-in for fastutil's Long2ObjectOpenHashMap; parallel streams run sequentially): "
+                  "`texts` lists the distinct outcomes -- rows of equal totals come in container order", GCNT,
+                  "updateGeneCounts:(L...OneNanoporeResult;L...ParametersBarcodeUMiFinderAppParams;L...AllReadsScanStats;)V")
+    orders = ("insertion", "reverse") + tuple(("shuffle", 1009 * k + 3) for k in range(4))
+
+    def draw_molecules(n, cells, n_genes, n_regions):
+        mols = []                                           # (gene index or None, region or None, cell, umi)
+        for _ in range(n):
+            gi = rng.randrange(n_genes) if rng.random() < 0.8 else None
+            mols.append((gi, rng.randrange(n_regions) if rng.random() < 0.9 else None, rng.choice(cells), rnd_seq(rng, 12)))
+        return mols
+
+    def draw_records(n_rec, mols, genes):
+        recs = []
+        for k in range(n_rec):
+            gi, reg, cell, umi = rng.choice(mols)
+            flag = (16 if rng.random() < 0.5 else 0) | (4 if rng.random() < 0.03 else 0) | (0x100 if rng.random() < 0.04 else 0) | \
+                   (0x800 if rng.random() < 0.04 else 0)
+            clip_l = rng.choice([0, 0, 0, 20, 150, 151, 400])
+            clip_r = rng.choice([0, 0, 0, 20, 150, 151, 400])
+            cig = (f"{clip_l}{rng.choice('SH')}" if clip_l else "") + f"{rng.randrange(50, 900)}M" + (f"{clip_r}{rng.choice('SH')}" if clip_r else "")
+            has_bc, has_umi = rng.random() < 0.95, rng.random() < 0.93
+            recs.append({"gene": None if gi is None else genes[gi], "region": reg, "bc": cell if has_bc else None, "u8": umi if has_umi else None,
+                         "flag": flag, "mapq": rng.choice([0, 1, 30, 60, 60, 60]), "cigar": cig, "nth": 1 if rng.random() < 0.12 else 0})
+        return recs
+
+    def fill(recs, par):
+        gc = j.new(GCNT, "()V")
+        stats_calls = [0]
+        for r in recs:
+            sam = JObject(SAMREC)
+            cg = j.call_static("htsjdk/samtools/TextCigarCodec", "decode", "(Ljava/lang/String;)Lhtsjdk/samtools/Cigar;", r["cigar"])
+            sam.native = {"flag": r["flag"], "mapq": r["mapq"], "cigar": cg, "attrs": {k: v for k, v in (("BC", r["bc"]), ("U8", r["u8"])) if v is not None}}
+            nr = j.new_object(NREAD)
+            nr.f["sam"] = sam
+            nr.f["geneNames"] = None if r["gene"] is None else JArray("Ljava/lang/String;", [r["gene"]])
+            nr.f["genomicRegionNmber"] = (j.call_static(GOPT, "absent", f"()L{GOPT};") if r["region"] is None else
+                                          j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JBox("java/lang/Long", r["region"])))
+            o = j.new_object(ONR)
+            o.f["nanoporeRead"] = nr
+            o.f["isNthRecordForRead"] = r["nth"]
+            st = JObject(ORSTAT)
+            st.native = stats_calls
+            o.f["oneReadScanStats"] = st
+            j.call_virtual(gc, "updateGeneCounts", f"(L{ONR};L{UPAR};Lcom/rw/umifinder/scanstats/AllReadsScanStats;)V", o, par, None)
+        return gc, stats_calls[0]
+
+    def tables(gc, par):
+        files.clear()
+        fa, fb = JObject("java/io/File"), JObject("java/io/File")
+        fa.native, fb.native = "out.genecounts.tsv", "out.UMIdepths.tsv"
+        j.call_virtual(gc, "printCountTable", f"(Ljava/io/File;L{UPAR};Lcom/rw/umifinder/scanstats/AllReadsScanStats;)V", fa, par, None)
+        j.call_virtual(gc, "printUmisPerCellTable", f"(Ljava/io/File;L{UPAR};)V", fb, par)
+        return {"genecounts": "".join(files["out.genecounts.tsv"]), "umidepths": "".join(files["out.UMIdepths.tsv"]),
+                "recordsWithGene": gc.f["recordsWithGene"], "recordsWithGeneSkippedClipping": gc.f["recordsWithGeneSkippedClipping"]}
+
+    for case, five_prime in enumerate([False, False, True, False, True, False]):
+        side = UmiSide(g, five_prime)
+        par = side.par
+        n_rec = [12, 60, 60, 400, 400, 1500][case]
+        n_cells, n_genes, n_regions = [(2, 2, 3), (4, 5, 8), (4, 5, 8), (12, 20, 40), (12, 20, 40), (30, 40, 100)][case]
+        cells = [rnd_seq(rng, 16) for _ in range(n_cells)]
+        genes = [f"GENE{k}" if k % 3 else f"Gm{k}.{k % 7}" for k in range(n_genes)]
+        recs = draw_records(n_rec, draw_molecules(max(2, n_rec // 3), cells, n_genes, n_regions), genes)
+        texts = []
+        for order in (orders if case < 3 else orders[:3]):
+            j.hash_order = order
+            try:
+                gc, n_calls = fill(recs, par)
+                t = tables(gc, par)
+                t["incrementRecordsForReadsUsedInGeneCounts"] = n_calls
+                if t not in texts:
+                    texts.append(t)
+            finally:
+                j.hash_order = None
+        s["cases"].append({"five_prime": five_prime, "records": recs, "texts": texts})
+        print(f"  genecounts case {case}: {n_rec} records, {len(texts)} distinct outcome(s)  {time.time() - g.t0:.0f}s", flush=True)
+    # GeneCounts.mergeGeneCounts(List.of(a, b, c)) (L540-592): three objects filled from record sets over the same molecules (so genes, cells
+    # and UMIs recur), then the two tables of the merged object
+    side = UmiSide(g, False)
+    par = side.par
+    cells = [rnd_seq(rng, 16) for _ in range(5)]
+    genes = [f"GENE{k}" for k in range(6)]
+    mols = draw_molecules(40, cells, 6, 10)
+    parts = [draw_records(n, mols, genes) for n in (120, 80, 150)]
+    texts = []
+    for order in orders:
+        j.hash_order = order
+        try:
+            lst = JObject("java/util/ArrayList")
+            lst.native = [fill(p, par)[0] for p in parts]
+            merged = j.call_static(GCNT, "mergeGeneCounts", f"(Ljava/util/List;)L{GCNT};", lst)
+            t = tables(merged, par)
+            if t not in texts:
+                texts.append(t)
+        finally:
+            j.hash_order = None
+    s["merged"] = {"five_prime": False, "parts": parts, "texts": texts}
+    print(f"  genecounts merged: {len(texts)} distinct outcome(s)  {time.time() - g.t0:.0f}s", flush=True)
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
 
