@@ -727,6 +727,12 @@ int smi_gzip_device(smi_ctx *ctx, const uint8_t *d_in, size_t n_bytes, uint8_t *
 /* plain (multi-member) gzip, the *.fastq.gz inputs of scanfastq (FastqFileReader.java:L138-150 via GZIPInputStream); out ==
  * NULL: only the inflated size is returned in *n_out */
 int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out);
+/* the same member by member, for a caller that does not know the inflated size (only a single-member file says it, in its last four
+ * bytes): members from *in_pos on are appended at out + *out_pos while they fit in cap_out.  SMI_OK: the input is used up; 1: the member at
+ * *in_pos needs more room (both positions stay in front of it; the caller grows the buffer and calls again); < 0: malformed input.  The
+ * decoder is the library's own (smi_inflate_host.hip: 64-bit bit buffer, two literals per table entry, CRC-32 by carry-less multiplication);
+ * CRC-32 and ISIZE of every member are checked. */
+int smi_gz_inflate_into(const uint8_t *in, size_t n_in, size_t *in_pos, uint8_t *out, size_t cap_out, size_t *out_pos);
 /* BGZF writer under the output BAMs of assignumis (htsjdk BlockCompressedOutputStream under UmiFinderWorker$OneBamWriter):
  * blocks of block_bytes (<= 0xFF00) input bytes + the EOF block; out == NULL: upper bound of the size in *n_out */
 int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, int level, int block_bytes,

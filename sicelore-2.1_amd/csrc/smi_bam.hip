@@ -97,32 +97,19 @@ extern "C" int smi_bgzf_inflate(const uint8_t *in, size_t n_in, uint8_t *out, si
     std::atomic<size_t> next{0};
     std::atomic<int> bad{-1};
     auto work = [&]() {
-        z_stream zs;
-        std::memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, -15) != Z_OK) {
-            bad = 0;
-            return;
-        }
         for (;;) {
             const size_t k = next.fetch_add(1);
             if (k >= blocks.size() || bad.load() >= 0) break;
             const Block &b = blocks[k];
             const uint8_t *payload = in + b.off + 12 + b.xlen;
             const size_t n_payload = b.bsize - 12 - b.xlen - 8;
-            inflateReset(&zs);
-            zs.next_in = const_cast<Bytef *>(payload);
-            zs.avail_in = (uInt)n_payload;
-            zs.next_out = out + b.out_off;
-            zs.avail_out = b.isize;
-            const int rc = inflate(&zs, Z_FINISH);
-            const bool ok = (rc == Z_STREAM_END) && zs.total_out == b.isize &&
-                            (uint32_t)crc32(crc32(0L, Z_NULL, 0), out + b.out_off, b.isize) == rd32(in + b.off + b.bsize - 8);
+            const bool ok = host_inflate_exact(payload, n_payload, out + b.out_off, b.isize) == 0 &&
+                            host_crc32(0, out + b.out_off, b.isize) == rd32(in + b.off + b.bsize - 8);
             if (!ok) {
                 bad = (int)k;
                 break;
             }
         }
-        inflateEnd(&zs);
     };
     const int nt = std::max(1, std::min<int>(n_threads, (int)blocks.size()));
     std::vector<std::thread> pool;
@@ -244,10 +231,28 @@ extern "C" int smi_bam_index_records(const uint8_t *bam, size_t n, uint64_t star
 // (FastqFileReader opens *.gz through htsjdk's FastqReader / GZIPInputStream, FJ!nanoporereadscanner/readerwriter/
 // FastqFileReader.java:L138-150).  One stream is inherently serial; files are independent, so the caller inflates several
 // at once.  Two-call protocol: out == NULL returns the inflated size in *n_out.
+extern "C" int smi_gz_inflate_into(const uint8_t *in, size_t n_in, size_t *in_pos, uint8_t *out, size_t cap_out, size_t *out_pos) {
+    if ((!in && n_in) || !in_pos || !out_pos || (!out && cap_out) || *in_pos > n_in || *out_pos > cap_out) {
+        set_error("smi_gz_inflate_into: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    return host_gunzip(in, n_in, in_pos, out, cap_out, out_pos);
+}
+
 extern "C" int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out) {
     if ((!in && n_in) || !n_out) {
         set_error("smi_gz_inflate: null argument");
         return SMI_ERR_INVALID;
+    }
+    if (out) {  // the library's own decoder (smi_inflate_host.hip); the size query below keeps zlib
+        size_t in_pos = 0, out_pos = 0;
+        const int rc = host_gunzip(in, n_in, &in_pos, out, cap_out, &out_pos);
+        if (rc == 1) {
+            set_error("smi_gz_inflate: output buffer too small");
+            return SMI_ERR_INVALID;
+        }
+        *n_out = out_pos;
+        return rc;
     }
     z_stream zs;
     std::memset(&zs, 0, sizeof zs);

@@ -13,6 +13,13 @@ namespace smi {
 void set_error(const std::string &msg);
 int hip_fail(hipError_t e, const char *what);
 
+// smi_inflate_host.hip: the host's DEFLATE decoder and CRC-32
+uint32_t host_crc32(uint32_t crc, const uint8_t *p, size_t n);                                   // zlib's crc32()
+int host_inflate_exact(const uint8_t *in, size_t n_in, uint8_t *out, size_t n_out);               // 0 = the stream filled out[0 .. n_out)
+// members of a gzip stream from *in_pos on, appended at *out_pos while they fit in cap: SMI_OK = input used up, 1 = the member at *in_pos
+// needs more room than cap - *out_pos (both positions stay at that member), SMI_ERR_INVALID = malformed (error text set)
+int host_gunzip(const uint8_t *in, size_t n_in, size_t *in_pos, uint8_t *out, size_t cap, size_t *out_pos);
+
 #define SMI_HIP(call)                                        \
     do {                                                     \
         hipError_t e__ = (call);                             \

@@ -60,7 +60,7 @@ EXPORTS = [
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
-    "smi_gene_counts_tsv", "smi_umi_depths_tsv",
+    "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into",
 ]
 
 
@@ -181,6 +181,7 @@ def load_library():
     lib.smi_gene_tag_chunk.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
+    lib.smi_gz_inflate_into.argtypes = [vp, sz, ctypes.POINTER(sz), vp, sz, ctypes.POINTER(sz)]
     lib.smi_gene_counts_create.argtypes = [ctypes.POINTER(vp)]
     lib.smi_gene_counts_free.argtypes = [vp]
     lib.smi_gene_counts_add.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
@@ -739,17 +740,30 @@ def assigned_tsv(keys, counts, max_ed=1):
     return out.raw[:n.value].decode()
 
 
-def gz_inflate(data):
-    """inflated bytes of a (multi-member) gzip stream, numpy uint8 in and out"""
+def gz_inflate(data, alloc=None):
+    """inflated bytes of a (multi-member) gzip stream, numpy uint8 in and out (smi_gz_inflate_into: the library's own decoder on the calling
+    thread; the GIL is released meanwhile).  alloc(n) -> (uint8 array of n bytes, owner): where the text should land (e.g. page-locked
+    memory); returns (text, owner) then."""
     lib = load_library()
     data = np.ascontiguousarray(data, dtype=np.uint8)
-    n = ctypes.c_size_t(0)
-    if lib.smi_gz_inflate(data.ctypes.data, data.size, None, 0, ctypes.byref(n)):
-        raise SmiError(lib.smi_last_error().decode())
-    out = np.empty(max(n.value, 1), dtype=np.uint8)
-    if lib.smi_gz_inflate(data.ctypes.data, data.size, out.ctypes.data, out.size, ctypes.byref(n)):
-        raise SmiError(lib.smi_last_error().decode())
-    return out[:n.value]
+    make = alloc or (lambda n: (np.empty(n, dtype=np.uint8), None))
+    # a single-member file says its size (mod 2^32) in its last four bytes; a file of several members gets room for the usual ratio first
+    hint = int.from_bytes(data[-4:].tobytes(), "little") if data.size >= 18 else 0
+    cap = max(hint if hint >= data.size // 2 else 4 * data.size, 64)
+    out, owner = make(cap)
+    ip, op = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    while True:
+        rc = lib.smi_gz_inflate_into(data.ctypes.data, data.size, ctypes.byref(ip), out.ctypes.data, out.size, ctypes.byref(op))
+        if rc == 0:
+            break
+        if rc != 1:
+            raise SmiError(lib.smi_last_error().decode())
+        bigger, owner2 = make(2 * out.size + (64 << 10))
+        bigger[:op.value] = out[:op.value]
+        if owner is not None:
+            owner.close()
+        out, owner = bigger, owner2
+    return out[:op.value] if alloc is None else (out[:op.value], owner)
 
 
 def bam_header(bam):

@@ -28,27 +28,21 @@ def _inflate(path, pinned=False):
     """-> (uint8 array of the file's text, owner).  pinned: the text lands in page-locked memory (smi_host_alloc), from which the chunk
     workers upload at link speed and side by side on several lanes (pageable memory goes through the runtime's one staging path);
     owner.close() frees it"""
-    with open(path, "rb") as f:
-        raw = f.read()
-    parts = [raw]
-    if path.endswith(".gz"):
-        d = zlib.decompressobj(31)
-        parts = []
-        while raw:  # multi-member files
-            parts.append(d.decompress(raw))
-            raw = d.unused_data
-            if not d.eof:
-                break
-            d = zlib.decompressobj(31)
+    raw = np.fromfile(path, dtype=np.uint8)
+    if not path.endswith(".gz"):
+        if not pinned:
+            return raw, None
+        pb = _lib.PinnedBuffer(max(raw.size, 1))
+        pb.array[:raw.size] = raw
+        return pb.array[:raw.size], pb
     if not pinned:
-        return np.frombuffer(parts[0] if len(parts) == 1 else b"".join(parts), dtype=np.uint8), None
-    total = sum(len(p) for p in parts)
-    pb = _lib.PinnedBuffer(max(total, 1))
-    at = 0
-    for p in parts:
-        pb.array[at:at + len(p)] = np.frombuffer(p, dtype=np.uint8)
-        at += len(p)
-    return pb.array[:total], pb
+        return _lib.gz_inflate(raw), None
+
+    def alloc(n):
+        pb = _lib.PinnedBuffer(max(n, 1))
+        return pb.array, pb
+
+    return _lib.gz_inflate(raw, alloc=alloc)
 
 
 def write_synthetic_dir(synth, out_dir, n_files, reads_per_file, used, device, seed=9000, chimera_frac=0.05, gz_level=1, pool=None, q_lo=35, q_hi=64):

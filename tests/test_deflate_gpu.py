@@ -3,6 +3,7 @@ inflater (zlib / gzip of the Python standard library, which also checks the CRC-
 trip is the parity property of a compressor; sizes around the 64 KiB block boundary, empty input, one symbol, all 256 byte values,
 incompressible input, a frequency profile whose optimal code is deeper than 15 bits, FASTQ text at the size of a pass-2 chunk."""
 import gzip
+import importlib
 import zlib
 
 import numpy as np
@@ -72,6 +73,8 @@ def test_fastq_chunk_and_concatenated_members(gpu_ctx):
     a, b = _fastq(6000, 11), _fastq(50, 12)
     za, zb = _roundtrip(gpu_ctx, a), _roundtrip(gpu_ctx, b)
     assert gzip.decompress(za + zb) == a + b                   # members of one .gz file (one per chunk)
+    libmod = importlib.import_module("sicelore_amd.lib")       # and through the library's own host decoder (two-literal table entries)
+    assert libmod.gz_inflate(np.frombuffer(za + zb, dtype=np.uint8)).tobytes() == a + b
     ref = len(zlib.compress(a, 6))
     assert len(za) < 1.25 * ref                                # literals only: within a quarter of zlib level 6 on FASTQ text
     # an unaligned input pointer (a view into a larger device buffer)
