@@ -436,6 +436,54 @@ def test_finalize_product_and_barcode_list_equal_reference_bytecode(pkg, sor):
     assert n_dropped_rows > 0  # AAAAA / TTTTT rows left out when no list of possible barcodes was given
 
 
+def test_tsv_texts_equal_the_reference_writers(pkg, sor):
+    """BarcodeList.tsv and BarcodesAssigned.tsv character for character against ParseStatsHtmlPrinter.writesedBarcodesListTSV / writeAssignedTSV
+    executed on the same data (header, `BC(count x)` / `BC(count m)` cells, the grouped numbers of DecimalFormat("###,###,###,###")); where the
+    reference's row order is a hash order (equal counts) the lines are compared as a multiset and the counts must still fall"""
+    from sicelore_amd import lib as libmod
+
+    n_exact_list = n_exact_assigned = 0
+    for c in _finalize_cases():
+        keys = np.array(c["keys"], dtype=np.uint64)
+        cnt = np.array([x[1] for x in c["barcodes"]], dtype=np.uint32)
+        nz = np.argsort(keys)
+        text = libmod.barcode_list_tsv(keys[nz], cnt[nz], c["record_count"], merge_ed=1, no_whitelist=not c["with_whitelist"])
+        ref = c["barcode_list_text"]
+        canon = lambda t: sorted("\t".join([f[0], f[1]] + [",".join(sorted(x.split(","))) for x in f[2:]]) for f in (ln.split("\t") for ln in t.splitlines()[1:]))  # noqa: E731
+        assert text.splitlines()[0] == ref.splitlines()[0] and canon(text) == canon(ref)
+        for other, _ in c["texts_under_other_orders"]:
+            assert canon(other) == canon(ref)             # what varies in the reference itself is the order only
+        if c["tsv_order_agrees"] and all(o[0] == ref for o in c["texts_under_other_orders"]):
+            assert text == ref
+            n_exact_list += 1
+        got_counts = [int(ln.split("\t")[1]) for ln in text.splitlines()[1:]]
+        assert got_counts == sorted(got_counts, reverse=True)
+        # BarcodesAssigned.tsv from the dense counter vector smi_bc_counts_device fills (3 counters per key of the loaded set)
+        a_keys = np.array(sorted(k for k, _, _ in c["assigned"]), dtype=np.uint64)
+        dense = np.zeros(3 * a_keys.size, dtype=np.uint32)
+        for k, n0, n1 in c["assigned"]:
+            i = int(np.searchsorted(a_keys, np.uint64(k)))
+            dense[3 * i], dense[3 * i + 1] = n0, n1
+        got = libmod.assigned_tsv(a_keys, dense, max_ed=1)
+        ref_a = c["assigned_text"]
+        assert got.splitlines()[0] == ref_a.splitlines()[0] and sorted(got.splitlines()) == sorted(ref_a.splitlines())
+        def runs(t):                                        # the lines grouped by their total, groups in file order
+            out = []
+            for ln in t.splitlines()[1:]:
+                tot = ln.split("\t")[1]
+                if out and out[-1][0] == tot:
+                    out[-1][1].add(ln)
+                else:
+                    out.append((tot, {ln}))
+            return out
+
+        assert runs(got) == runs(ref_a) and got.endswith("\n") == ref_a.endswith("\n")
+        n_exact_assigned += sum(1 for _, g in runs(got) if len(g) == 1)
+        tot = [int(ln.split("\t")[1].replace(",", "")) for ln in got.splitlines()[1:]]
+        assert tot == sorted(tot, reverse=True)
+    assert n_exact_list >= 4 and n_exact_assigned >= 50
+
+
 # ---- a-18: genomic-region grouping (ReadGrouper.groupSams) ------------------------------------------------------------------------
 def _group_cases():
     sec = load("group")["sections"][0]

@@ -1288,8 +1288,14 @@ def gen_finalize(g, n_sets=14, seed=1313):
     rng = random.Random(seed)
     install_long2object_iterable(j)
     install_sync_executor(j)
+    files = {}
+    install_file_sink(j, files)
+    PSHP = "com/rw/nanoporereadscanner/stats/ParseStatsHtmlPrinter"
+    BCNT = "com/rw/nanoporereadscanner/analyzers/Parser$BarcodeCounts"
     par, _report = ref_params.load_config(j, PAR)
     rs = par.f["readScannerParameters"]
+    wt = "com/rw/parameters/ReadScannerParameters$WHAT_TODO"
+    rs.f["what_todo"] = j.natives["java/util/EnumSet.of"](j, j.get_static(wt, "FIND_BARCODES"))   # the run's mode (-g ...)
     # what ReadScannerParameters.validate_readScannerParameters L236-238 does with the shipped config (<mergeBCsED>null) and -e 1
     rs.f["assignCellBCwithEditDistance"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JBox("java/lang/Integer", 1))
     rs.f["mergeBCsEdit"] = JBox("java/lang/Integer", 1)
@@ -1356,15 +1362,51 @@ def gen_finalize(g, n_sets=14, seed=1313):
                 coll = {}
                 for ed_box, per_bc in info.native.items_in_insertion_order():
                     coll[str(ed_box.v)] = sorted([u64(k.v), sorted(u64(x.v) for x in lst.native)] for k, lst in per_bc.native.items_in_insertion_order())
-                results.append({"final": final, "tsv": tsv_rows, "collisions": coll})
+                # BarcodeList.tsv: ParseStatsHtmlPrinter.writesedBarcodesListTSV(file, data, params) (L235-285), every string handed to the writer
+                files.clear()
+                fo = JObject("java/io/File")
+                fo.native = "BarcodeList.tsv"
+                j.call_static(PSHP, "writesedBarcodesListTSV", f"(Ljava/io/File;L{UBLD};L{PAR};)V", fo, ud, par)
+                # BarcodesAssigned.tsv: writeAssignedTSV(params, {barcode -> Parser$BarcodeCounts}, file) (L294-327) over pass-2 counters drawn
+                # for the barcodes of the final list (addCountForEd per assigned read)
+                amap = j.natives["java/util/HashMap.<new>"](j)
+                arng = random.Random(1000 * idx + 7)
+                assigned = []
+                for key, _cnt in final:
+                    n0, n1 = arng.choice([0, 1, 3, 900, 1000, 12345, 2000000]), arng.choice([0, 0, 2, 999, 1001])
+                    if n0 + n1 == 0:
+                        continue
+                    bc = j.new(BCNT, "()V")
+                    if n0 > 50 or n1 > 50:   # large counters set directly (the loop of addCountForEd calls would only add bytecode steps)
+                        for ed, n in ((0, n0), (1, n1)):
+                            if n:
+                                ai = j.natives["java/util/concurrent/atomic/AtomicInteger.<new>"](j)
+                                j.natives["java/util/concurrent/atomic/AtomicInteger.<init>"](j, ai, n)
+                                j.call_virtual(bc.f["edCounts"], "put", "(Ljava/lang/Object;Ljava/lang/Object;)Ljava/lang/Object;", JBox("java/lang/Integer", ed), ai)
+                        j.natives["java/util/concurrent/atomic/AtomicInteger.set"](j, bc.f["counts"], n0 + n1)
+                    else:
+                        for ed, n in ((0, n0), (1, n1)):
+                            for _ in range(n):
+                                j.call_virtual(bc, "addCountForEd", "(I)V", ed)
+                    amap.native.put(JBox("java/lang/Long", key if key < 1 << 63 else key - (1 << 64)), bc)
+                    assigned.append([key, n0, n1])
+                fa = JObject("java/io/File")
+                fa.native = "BarcodesAssigned.tsv"
+                j.call_static(PSHP, "writeAssignedTSV", f"(L{PAR};Ljava/util/Map;Ljava/io/File;)V", par, amap, fa)
+                results.append({"final": final, "tsv": tsv_rows, "collisions": coll, "barcode_list_text": "".join(files["BarcodeList.tsv"]),
+                                "assigned": assigned, "assigned_text": "".join(files["BarcodesAssigned.tsv"])})
             except JavaThrow as e:
                 results.append({"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:6]})
         j.hash_order = None
         agree_final = all(r.get("final") == results[0].get("final") and r.get("throws") == results[0].get("throws") for r in results[1:])
         agree_final = agree_final and all(r.get("collisions") == results[0].get("collisions") for r in results[1:])
         agree_tsv = all(r.get("tsv") == results[0].get("tsv") for r in results[1:])
+        texts = [[r.get("barcode_list_text"), r.get("assigned_text")] for r in results]
+        for r in results[1:]:
+            r.pop("assigned", None)
         s["cases"].append({"barcodes": [[q, c] for q, c in items], "keys": [u64(enc(q)) for q, _ in items], "record_count": record_count, "with_whitelist": with_whitelist,
                            "hash_orders_agree": agree_final, "tsv_order_agrees": agree_tsv, **results[0],
+                           "texts_under_other_orders": [t for t in texts[1:] if t != texts[0]],
                            **({} if agree_final else {"other_orders": results[1:]})})
         print(f"  finalize {idx + 1}/{n_sets}  {time.time() - g.t0:.0f}s  agree={agree_final}/{agree_tsv}", flush=True)
     out["sections"].append(g.finish(s))
@@ -1747,10 +1789,10 @@ ORSTAT = "com/rw/umifinder/scanstats/OneReadScanStat"
 
 def install_genecounts_io(j, files):
     """INPUT / OUTPUT plumbing of the GeneCounts fixture: a SAMRecord is a bag of the six values updateGeneCounts asks for (its Cigar is
-    htsjdk's own, decoded from text by TextCigarCodec); File / FileOutputStream / BufferedOutputStream / PrintStream collect what is appended
-    into files[path]; System.gc and the Runtime memory figures (printed to stdout only) are inert"""
-    H, N = j.hooks, j.natives
+    htsjdk's own, decoded from text by TextCigarCodec); the file classes are those of install_file_sink"""
+    H = j.hooks
     H[SAMREC + ".<clinit>:()V"] = None
+    install_file_sink(j, files)
     H[SAMREC + ".getReadUnmappedFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 4 else 0
     H[SAMREC + ".isSecondaryOrSupplementary:()Z"] = lambda jj, o: 1 if o.native["flag"] & 0x900 else 0
     H[SAMREC + ".getMappingQuality:()I"] = lambda jj, o: o.native["mapq"]
@@ -1758,6 +1800,12 @@ def install_genecounts_io(j, files):
     H[SAMREC + ".getReadNegativeStrandFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 16 else 0
     H[SAMREC + ".getStringAttribute:(Ljava/lang/String;)Ljava/lang/String;"] = lambda jj, o, t: o.native["attrs"].get(t)
     H[ORSTAT + ".incrementRecordsForReadsUsedInGeneCounts:()V"] = lambda jj, o: o.native.__setitem__(0, o.native[0] + 1)
+
+
+def install_file_sink(j, files):
+    """OUTPUT plumbing: File / FileOutputStream / BufferedOutputStream / PrintStream / FileWriter / BufferedWriter collect what is written
+    into files[path] (a list of strings); System.gc and the Runtime memory figures (printed to stdout only) are inert"""
+    N = j.natives
 
     def file_init(jj, o, *a):
         o.native = a[0] if len(a) == 1 else a[0].native + "/" + a[1]
@@ -1774,6 +1822,15 @@ def install_genecounts_io(j, files):
         o.native.append(jj.to_jstring(text))
         return o
 
+    for c in ("java/io/FileWriter", "java/io/BufferedWriter"):
+        N[c + ".<new>"] = (lambda cc: lambda jj: JObject(cc))(c)
+    N["java/io/FileWriter.<init>"] = lambda jj, o, f, *a: setattr(o, "native", files.setdefault(f.native if isinstance(f, JObject) else f, []))
+    N["java/io/BufferedWriter.<init>"] = lambda jj, o, inner, *a: setattr(o, "native", inner.native)
+    N["java/io/BufferedWriter.write:(Ljava/lang/String;)V"] = lambda jj, o, text: o.native.append(jj.to_jstring(text))
+    N["java/io/Writer.write:(Ljava/lang/String;)V"] = N["java/io/BufferedWriter.write:(Ljava/lang/String;)V"]
+    N["java/io/BufferedWriter.newLine"] = lambda jj, o: o.native.append("\n")
+    N["java/io/BufferedWriter.close"] = lambda jj, o: None
+    N["java/io/BufferedWriter.flush"] = lambda jj, o: None
     N["java/io/PrintStream.append"] = ps_append
     N["java/io/PrintStream.flush"] = lambda jj, o: None
     N["java/io/PrintStream.close"] = lambda jj, o: None
