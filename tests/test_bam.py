@@ -174,3 +174,36 @@ def test_tag_sets_and_attribute_order(pkg):
     # integer types follow BinaryTagCodec.getIntegerType
     for v, ty in ((-1, "c"), (127, "c"), (128, "C"), (255, "C"), (256, "s"), (-129, "s"), (32768, "S"), (65536, "i"), (-40000, "i"), (2 ** 31, "I")):
         assert chr(au._aux_bytes("XY", v)[2]) == ty
+
+
+def test_tag_sets_equal_the_reference_calls(pkg):
+    """the setAttribute calls of ReadScanResult.writeSamFlags + writeBCSamFlags and the U7 value of OneNanoporeResult.getPostBCUMIseq, executed
+    from the reference's class files on 178 read names (tests/golden/ref_exec_samtags.json), against record_tag_sets / umi_window"""
+    import importlib
+    import json
+    import os
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec_samtags.json")))
+    n = n_none = n_u7 = 0
+    for sec in gold["sections"]:
+        five = sec["five_prime"]
+        for c in sec["cases"]:
+            assert "throws" not in c
+            d = au.scan_data_from_name(c["name"])
+            if "calls" not in c:
+                assert c["scan_data"] is None and d is None, c["name"]
+                n_none += 1
+                continue
+            calls, has_bc, clustered = au.record_tag_sets(d, None, None)
+            assert not clustered
+            want = [(t, int(v) if ty == "int" else v) for t, v, ty in c["calls"]]
+            assert calls == want and [type(v) for _, v in calls] == [type(v) for _, v in want], c["name"]
+            assert has_bc == ("u7" in c)
+            if has_bc:
+                w = au.umi_window(d["x"], d["ae"], d["bc"]["end"], five) if d["bc"]["end"] is not None and d["x"] else None
+                u7 = None if w is None else "".join("AGCT"[{1: 0, 2: 1, 4: 2, 8: 3}[x]] if x != 15 else "N" for x in w[1:13])
+                assert u7 == c["u7"], c["name"]
+                n_u7 += 1
+            n += 1
+    assert n >= 150 and n_none >= 6 and n_u7 >= 130

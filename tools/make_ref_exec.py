@@ -1963,7 +1963,70 @@ def gen_genecounts(g, seed=1818):
     return out
 
 
-SECTIONS = {"genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+# ---------------------------------------------------------------------------------------------------------------------
+# assignumis: the tags of one record before clustering (OneNanoporeSeqAnalyzer.call L95, L146; UmiFinderWorker.lambda$new$0 L248-255)
+# ---------------------------------------------------------------------------------------------------------------------
+OTAGS = "com/rw/umifinder/flags/OutputSAMtags"
+
+
+def gen_samtags(g, seed=1919):
+    j = g.j
+    rng = random.Random(seed)
+    H = j.hooks
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".setAttribute:(Ljava/lang/String;Ljava/lang/Object;)V"] = lambda jj, o, t, v: o.native["calls"].append([t, v])
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    for five_prime, files in ((False, ("pass2_3p", "pass2_3p_ed2")), (True, ("pass2_5p", "pass2_5p_polya"))):
+        side = UmiSide(g, five_prime)
+        par = side.par
+        s = g.section(("5-prime (-p)" if five_prime else "3-prime") + " assignumis, per read name: NanoporeRead$ReadScanData.generateReadScanData's "
+                      "parse (FastqRecordExt.getScanDatFromReadName), then what OneNanoporeSeqAnalyzer.call does with it: writeSamFlags(sam, "
+                      "params.samFlags) (ReadScanResult.java:L205-237) and writeBCSamFlags(sam, params.samFlags, false, false) (L254-279) -> the "
+                      "setAttribute calls in order (tag, value; a boxed Integer is a number, a String a string); and "
+                      "OneNanoporeResult.getPostBCUMIseq(result, params) = the U7 value UmiFinderWorker.lambda$new$0 sets for a read with a "
+                      "barcode that clustering left without a UMI.  Names: the records the reference's own pass 2 wrote "
+                      "(ref_exec_pass2_*.json, up to the blank) and synthetic ones around them", RSD,
+                      "writeSamFlags:(Lhtsjdk/samtools/SAMRecord;L...OutputSAMtags;)V")
+        names = []
+        for f in files:
+            d = json.load(open(os.path.join(OUT, f"ref_exec_{f}.json")))
+            names += [c["result"]["written"]["name"].split(" ")[0] for c in d["sections"][0]["cases"] if "written" in c["result"]]
+        for k in range(40):
+            bc, umi = rnd_seq(rng, 16), rnd_seq(rng, 12)
+            names.append(fake_name(rng, 500 + k, five_prime, bc, umi, rng.random() < 0.5, rng.randrange(60, 300), rng.choice([0, 0, 1, -1, 2, -2]), ed=rng.choice([0, 1, 2])))
+        names += ["plain_read_name", "x_FWD_AE=40_X=ACGT_Q=9_1", "y_REV_PS=5_PE=9_AE=40_T=12_X=ACGTACGT_Q=11.5_2b"]
+        for nm in names:
+            case = {"name": nm}
+            try:
+                sd = side.scan_data(nm)
+                if sd is None:
+                    case["scan_data"] = None
+                else:
+                    sam = JObject(SAMREC)
+                    sam.native = {"calls": []}
+                    j.call_virtual(sd, "writeSamFlags", f"(L{SAMREC};L{OTAGS};)V", sam, par.f["samFlags"])
+                    n_first = len(sam.native["calls"])
+                    j.call_virtual(sd, "writeBCSamFlags", f"(L{SAMREC};L{OTAGS};ZZ)V", sam, par.f["samFlags"], 0, 0)
+                    box = lambda v: v.v if isinstance(v, JBox) else v  # noqa: E731
+                    case["calls"] = [[t, box(v), "int" if isinstance(v, JBox) else "str"] for t, v in sam.native["calls"]]
+                    case["n_calls_writeSamFlags"] = n_first
+                    r = side.result_for(sd)
+                    r.f["nanoporeRead"].f["sam"] = sam
+                    if j.call_virtual(sd, "barcodeFound", "()Z"):
+                        opt = j.call_static(ONR, "getPostBCUMIseq", f"(L{ONR};L{UPAR};)Ljava/util/Optional;", r, par)
+                        present = j.call_virtual(opt, "isPresent", "()Z")
+                        case["u7"] = j.to_jstring(j.call_virtual(j.call_virtual(opt, "get", "()Ljava/lang/Object;"), "toString", "()Ljava/lang/String;")) if present else None
+            except JavaThrow as e:
+                case["throws"] = e.obj.cls
+                case["message"] = e.obj.f.get("message")
+            s["cases"].append(case)
+        s["five_prime"] = five_prime
+        out["sections"].append(g.finish(s))
+        print(f"  samtags {'5p' if five_prime else '3p'}: {len(names)} names  {time.time() - g.t0:.0f}s", flush=True)
+    return out
+
+
+SECTIONS = {"samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
 
