@@ -106,3 +106,43 @@ def test_reference_position_at_read_position(sor, pkg):
         exp = pg.ref_position_at_read_position(cig, start, position)
         assert sor.ref_position_at_read_position(cig, start, position) == exp
         assert libmod.ref_position_at_read_position(cig, start, position) == exp
+
+
+def test_clustering_position_equals_reference_bytecode(sor, pkg):
+    """NanoporeRead$ReadScanData.generateReadScanData executed on 320 (name, flag, CIGAR) records (tests/golden/ref_exec_clusterpos.json): the
+    position a read is grouped by -- product (assignumis.clustering_position over smi_ref_position_at_read_position), oracle and the test's
+    model.  Where the reference dereferences a missing polyA result (3' names without PS) it throws; the product has no position there."""
+    import importlib
+    import json
+    import os
+    import re
+
+    from sicelore_amd import lib as libmod
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec_clusterpos.json")))
+    n_pos = n_none = n_throw = 0
+    for sec in gold["sections"]:
+        five, dist = sec["five_prime"], sec["distanceFromReadEndForGrouping"]
+        for c in sec["cases"]:
+            cig = [(op, int(ln)) for ln, op in re.findall(r"(\d+)([MIDNSHP=X])", c["cigar"])]
+            raw = np.array([(ln << 4) | "MIDNSHP=X".index(op) for op, ln in cig], dtype=np.uint32)
+            bam = raw.view(np.uint8)
+            rec = dict(flag=c["flag"], cigar_off=0, n_cigar=raw.size, pos=c["pos0"])
+            d = au.scan_data_from_name(c["name"])
+            got = au.clustering_position(bam, rec, d, grouping_distance=dist, five_prime=five)
+            if "throws" in c:
+                assert c["throws"] == "java/lang/NullPointerException" and got is None and d is not None and d["ps"] is None and not five
+                n_throw += 1
+                continue
+            if not c["scan_data"]:
+                assert d is None and got is None
+                continue
+            assert got == c["position"], (c["name"], c["cigar"], got, c["position"])
+            if not c["flag"] & 4:
+                read_pos = d["ae"] + 16 + 12 + dist if five else d["ps"] - dist
+                assert sor.ref_position_at_read_position(cig, c["pos0"] + 1, read_pos) == c["position"]
+                assert pg.ref_position_at_read_position(cig, c["pos0"] + 1, read_pos) == c["position"]
+            n_pos += got is not None
+            n_none += got is None
+    assert n_pos > 250 and n_none > 25 and n_throw >= 4

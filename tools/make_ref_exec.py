@@ -2026,7 +2026,75 @@ def gen_samtags(g, seed=1919):
     return out
 
 
-SECTIONS = {"samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+def gen_clusterpos(g, seed=2020):
+    """a-18 input: the genome position a read is grouped by"""
+    j = g.j
+    rng = random.Random(seed)
+    H = j.hooks
+    H[SAMREC + ".<clinit>:()V"] = None
+    H[SAMREC + ".getReadName:()Ljava/lang/String;"] = lambda jj, o: o.native["name"]
+    H[SAMREC + ".getReadUnmappedFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 4 else 0
+    H[SAMREC + ".getAlignmentBlocks:()Ljava/util/List;"] = lambda jj, o: o.native["blocks"]
+    DS = "com/rw/umifinder/scanstats/DebugStats"
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar + htsjdk-4.1.3.jar (TextCigarCodec, SAMUtils.getAlignmentBlocks, CoordMath)", "sections": []}
+    for five_prime in (False, True):
+        side = UmiSide(g, five_prime)
+        par = side.par
+        s = g.section(("5-prime (-p)" if five_prime else "3-prime") + " NanoporeRead$ReadScanData.generateReadScanData(sam, params) (NanoporeRead$ReadScanData.java:"
+                      "L86-153): name parse, read position = polyA start - distanceFromReadEndForGrouping (3') or adapter end + cell_bc_length + "
+                      "umi_length + that distance (5'), getReferencePositionAtReadPosition over the record's alignment blocks -> "
+                      "positionOnGenomeForClustering (null = absent).  The SAM record is a stand-in holding name, flag and the alignment blocks "
+                      "htsjdk's own SAMUtils.getAlignmentBlocks makes from the CIGAR text", RSD,
+                      "generateReadScanData:(Lhtsjdk/samtools/SAMRecord;L...ParametersBarcodeUMiFinderAppParams;)Lcom/google/common/base/Optional;")
+        for k in range(160):
+            bc, umi = rnd_seq(rng, 16), rnd_seq(rng, 12)
+            ae = rng.randrange(30, 600)
+            nm = fake_name(rng, k, five_prime, bc, umi, rng.random() < 0.5, ae, rng.choice([0, 0, 1, -1]))
+            if k % 23 == 5:
+                nm = "noscan_read_%d" % k
+            if k % 29 == 7 and not five_prime:
+                nm = f"nopolya{k}_FWD_AE={ae}_X=ACGTACGTAC_Q=9_1"        # a 3' name without PS / PE (--noPolyARequired)
+            ops = []
+            if rng.random() < 0.6:
+                ops.append((rng.choice("SH"), rng.randrange(1, 500)))
+            for b in range(rng.randrange(1, 7)):
+                ops.append((rng.choice("M=X"), rng.randrange(1, 400)))
+                if b < 5 and rng.random() < 0.8:
+                    ops.append((rng.choice("IDN"), rng.randrange(1, 60) if rng.random() < 0.7 else rng.randrange(100, 3000)))
+            while ops and ops[-1][0] in "IDN":
+                ops.pop()
+            if rng.random() < 0.5:
+                ops.append(("S", rng.randrange(1, 700)))
+            flag = (16 if rng.random() < 0.5 else 0) | (4 if k % 17 == 3 else 0)
+            pos0 = rng.randrange(0, 5_000_000)
+            text = "".join(f"{ln}{op}" for op, ln in ops)
+            sam = JObject(SAMREC)
+            if flag & 4:
+                lst = JObject("java/util/ArrayList")
+                lst.native = []
+                sam.native = {"name": nm, "flag": flag, "blocks": lst}
+            else:
+                cg = j.call_static("htsjdk/samtools/TextCigarCodec", "decode", "(Ljava/lang/String;)Lhtsjdk/samtools/Cigar;", text)
+                sam.native = {"name": nm, "flag": flag, "blocks": j.call_static("htsjdk/samtools/SAMUtils", "getAlignmentBlocks",
+                                                                                "(Lhtsjdk/samtools/Cigar;ILjava/lang/String;)Ljava/util/List;", cg, pos0 + 1, "read cigar")}
+            case = {"name": nm, "flag": flag, "pos0": pos0, "cigar": text}
+            try:
+                opt = j.call_static(RSD, "generateReadScanData", f"(L{SAMREC};L{UPAR};)L{GOPT};", sam, par)
+                sd = j.call_virtual(opt, "orNull", "()Ljava/lang/Object;")
+                case["scan_data"] = sd is not None
+                if sd is not None:
+                    p = j.call_virtual(sd.f["positionOnGenomeForClustering"], "orNull", "()Ljava/lang/Object;")
+                    case["position"] = None if p is None else p.v
+            except JavaThrow as e:
+                case["throws"] = e.obj.cls
+            s["cases"].append(case)
+        s["five_prime"] = five_prime
+        s["distanceFromReadEndForGrouping"] = par.f["barcodes"].f["distanceFromReadEndForGrouping"].v
+        out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
 
