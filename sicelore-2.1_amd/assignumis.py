@@ -396,10 +396,12 @@ def apply_tag_sets(fields, calls):
 
 
 def _coordinate_key(rec, name):
-    """SAMRecordCoordinateComparator: reference index (unmapped last), start, strand, name, flags, mapq, mate, insert size"""
+    """htsjdk SAMRecordCoordinateComparator.compare (SAMRecordCoordinateComparator.java:L48-105): reference index with -1 last -- two records
+    without a reference are not compared by position --, alignment start, strand (forward first), name, flags, mapping quality, then the mate's
+    reference index, the mate's start and the insert size as plain integers (a mate index of -1 sorts FIRST there)"""
     ref = int(rec["ref_id"])
-    return (ref if ref >= 0 else 1 << 30, int(rec["pos"]), bool(int(rec["flag"]) & 16), name, int(rec["flag"]), int(rec["mapq"]),
-            int(rec["next_ref_id"]) if int(rec["next_ref_id"]) >= 0 else 1 << 30, int(rec["next_pos"]), int(rec["tlen"]))
+    return (ref if ref >= 0 else 1 << 30, int(rec["pos"]) if ref >= 0 else 0, bool(int(rec["flag"]) & 16), name, int(rec["flag"]), int(rec["mapq"]),
+            int(rec["next_ref_id"]), int(rec["next_pos"]), int(rec["tlen"]))
 
 
 def _java_split(text, sep):

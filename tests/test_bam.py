@@ -207,3 +207,23 @@ def test_tag_sets_equal_the_reference_calls(pkg):
                 n_u7 += 1
             n += 1
     assert n >= 150 and n_none >= 6 and n_u7 >= 130
+
+
+def test_batch_order_equals_the_coordinate_comparator(pkg):
+    """the order in which a batch is written: a stable sort by htsjdk's SAMRecordCoordinateComparator, executed comparison by comparison
+    (tests/golden/ref_exec_bamorder.json), against sorted(key=_coordinate_key)"""
+    import importlib
+    import json
+    import os
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_exec_bamorder.json")))
+    n = 0
+    for c in gold["sections"][0]["cases"]:
+        recs = [dict(ref_id=r["ref"], pos=r["pos0"], flag=r["flag"], mapq=r["mapq"], next_ref_id=r["mate_ref"], next_pos=r["mate_pos0"], tlen=r["tlen"])
+                for r in c["records"]]
+        names = [r["name"] for r in c["records"]]
+        got = sorted(range(len(recs)), key=lambda k: au._coordinate_key(recs[k], names[k]))
+        assert got == c["order"]
+        n += len(recs)
+    assert n > 1000

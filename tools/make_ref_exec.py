@@ -2094,7 +2094,60 @@ def gen_clusterpos(g, seed=2020):
     return out
 
 
-SECTIONS = {"clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+def gen_bamorder(g, seed=2121):
+    """the order of the records of one written batch"""
+    import functools
+
+    j = g.j
+    rng = random.Random(seed)
+    H = j.hooks
+    H[SAMREC + ".<clinit>:()V"] = None
+    box = lambda v: JBox("java/lang/Integer", v)  # noqa: E731
+    hdr = JObject("htsjdk/samtools/SAMFileHeader")
+    H[SAMREC + ".getHeader:()Lhtsjdk/samtools/SAMFileHeader;"] = lambda jj, o: hdr
+    H[SAMREC + ".getReferenceIndex:()Ljava/lang/Integer;"] = lambda jj, o: box(o.native["ref"])
+    H[SAMREC + ".getAlignmentStart:()I"] = lambda jj, o: o.native["pos0"] + 1
+    H[SAMREC + ".getReadNegativeStrandFlag:()Z"] = lambda jj, o: 1 if o.native["flag"] & 16 else 0
+    H[SAMREC + ".getReadName:()Ljava/lang/String;"] = lambda jj, o: o.native["name"]
+    H[SAMREC + ".getFlags:()I"] = lambda jj, o: o.native["flag"]
+    H[SAMREC + ".getMappingQuality:()I"] = lambda jj, o: o.native["mapq"]
+    H[SAMREC + ".getMateReferenceIndex:()Ljava/lang/Integer;"] = lambda jj, o: box(o.native["mate_ref"])
+    H[SAMREC + ".getMateAlignmentStart:()I"] = lambda jj, o: o.native["mate_pos0"] + 1
+    H[SAMREC + ".getInferredInsertSize:()I"] = lambda jj, o: o.native["tlen"]
+    CMP = "htsjdk/samtools/SAMRecordCoordinateComparator"
+    out = {"jar": "htsjdk-4.1.3.jar", "sections": []}
+    s = g.section("Arrays.stream(results).sorted(SAMRecordCoordinateComparator::compare) of UmiFinderWorker$BamWriters.writeSams (L421): a stable sort "
+                  "of one batch with htsjdk's SAMRecordCoordinateComparator.compare (SAMRecordCoordinateComparator.java:L48-105) executed for every "
+                  "comparison.  Records are stand-ins holding the nine values the comparator reads; drawn with many ties", CMP,
+                  "compare:(Lhtsjdk/samtools/SAMRecord;Lhtsjdk/samtools/SAMRecord;)I")
+    cmpo = j.new(CMP, "()V")
+    for case in range(8):
+        n = [6, 40, 40, 120, 120, 120, 300, 300][case]
+        names = [f"r{k}_{rng.choice(['FWD', 'REV'])}_x" for k in range(max(3, n // 4))]
+        recs = []
+        for _ in range(n):
+            unm = rng.random() < 0.1
+            recs.append({"ref": -1 if unm else rng.randrange(0, 3), "pos0": -1 if unm and rng.random() < 0.7 else rng.randrange(0, 12), "flag": rng.choice([0, 16, 0, 16, 256, 272, 2048, 2064, 4, 20]),
+                         "name": rng.choice(names), "mapq": rng.choice([0, 30, 60]), "mate_ref": rng.choice([-1, -1, 0, 2]), "mate_pos0": rng.choice([-1, 5, 900]),
+                         "tlen": rng.choice([0, 0, -350, 350])})
+        objs = []
+        for r in recs:
+            o = JObject(SAMREC)
+            o.native = r
+            objs.append(o)
+        n_cmp = [0]
+
+        def cmp(a, b):
+            n_cmp[0] += 1
+            return j.call_virtual(cmpo, "compare", f"(L{SAMREC};L{SAMREC};)I", objs[a], objs[b])
+
+        order = sorted(range(n), key=functools.cmp_to_key(cmp))     # Python's sort is stable like Stream.sorted
+        s["cases"].append({"records": recs, "order": order, "comparisons": n_cmp[0]})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
 
