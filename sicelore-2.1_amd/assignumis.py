@@ -371,28 +371,39 @@ def split_aux(aux):
     return out
 
 
+_INT_FMT = {ord("c"): "<i1", ord("C"): "<u1", ord("s"): "<i2", ord("S"): "<u2", ord("i"): "<i4", ord("I"): "<u4"}
+
+
+def _as_htsjdk_writes(tag, raw):
+    """a field read from the input as htsjdk writes it back: an integer in the smallest type that holds it (BinaryTagCodec.readSingleValue
+    L316-346 boxes it, writeTag re-picks the type with getIntegerType L153-180); a hex string (H) comes back as a byte array (B:c); the rest
+    unchanged"""
+    ty = raw[2]
+    if ty in _INT_FMT:
+        return _aux_bytes(tag, int(np.frombuffer(raw[3:], dtype=_INT_FMT[ty])[0]))
+    if ty == ord("H"):
+        data = bytes.fromhex(raw[3:-1].decode())
+        return raw[:2] + b"Bc" + np.array([len(data)], dtype="<u4").tobytes() + data
+    return raw
+
+
 def apply_tag_sets(fields, calls):
-    """SAMRecord.setAttribute on htsjdk's attribute list = SAMBinaryTagAndValue.insert (Jar/lib/htsjdk-4.1.3.jar!/htsjdk/samtools/
-    SAMBinaryTagAndValue.class L207-228, read from the class file): the list read from the file keeps its order; a new tag goes in front of
-    the first element whose binary tag is greater, an existing tag is replaced in place, otherwise it is appended.  Binary tag =
-    (short)(second char << 8 | first char) (SAMTag.makeBinaryTag L124-127)."""
+    """The attribute list of a record that htsjdk reads, tags and writes.  BinaryTagCodec.readTags (Jar/lib/htsjdk-4.1.3.jar!/htsjdk/samtools/
+    BinaryTagCodec.class L271-305) builds the list through SAMBinaryTagAndValue.insert (L207-228), so it is ORDERED BY BINARY TAG from the
+    moment it is decoded -- binary tag = (short)(second char << 8 | first char), SAMTag.makeBinaryTag L124-127 -- and a tag that occurs twice
+    keeps its last value; SAMRecord.setAttribute (L1583-1602) inserts / replaces in that order and removes on null.  Every record goes through
+    setAttribute here, so every written record has its tags in that order.  fields: [(tag, raw field bytes)] of the input record ->
+    [(tag, raw bytes)] as written.  (Executed: tests/golden/ref_exec_auxorder.json.)"""
     key = lambda t: (ord(t[1]) << 8) | ord(t[0])  # noqa: E731
-    fields = list(fields)
+    cur = {}
+    for tag, raw in fields:
+        cur[tag] = _as_htsjdk_writes(tag, raw)
     for tag, value in calls:
         if value is None:                                        # setAttribute(tag, null): SAMBinaryTagAndValue.remove
-            fields = [f for f in fields if f[0] != tag]
-            continue
-        raw, k = _aux_bytes(tag, value), key(tag)
-        for j, (t, _) in enumerate(fields):
-            if k < key(t):
-                fields.insert(j, (tag, raw))
-                break
-            if k == key(t):
-                fields[j] = (tag, raw)
-                break
+            cur.pop(tag, None)
         else:
-            fields.append((tag, raw))
-    return fields
+            cur[tag] = _aux_bytes(tag, value)
+    return sorted(cur.items(), key=lambda kv: key(kv[0]))
 
 
 def _coordinate_key(rec, name):

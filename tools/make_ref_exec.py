@@ -2147,7 +2147,111 @@ def gen_bamorder(g, seed=2121):
     return out
 
 
-SECTIONS = {"bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+def install_bytebuffer(j):
+    """java.nio.ByteBuffer over a byte[] (little endian, as BinaryTagCodec.readTags sets it): the relative reads htsjdk's tag reader uses"""
+    import struct
+
+    N = j.natives
+    BB = "java/nio/ByteBuffer"
+
+    def wrap(jj, arr, off, ln):
+        o = JObject(BB)
+        o.native = {"b": bytes((v & 0xFF) for v in arr.a), "pos": off, "lim": off + ln, "mark": None}
+        return o
+
+    def take(o, n):
+        st = o.native
+        if st["pos"] + n > st["lim"]:
+            raise JavaThrow(JObject("java/nio/BufferUnderflowException"), [])
+        v = st["b"][st["pos"]:st["pos"] + n]
+        st["pos"] += n
+        return v
+
+    def get_bytes(jj, o, dst):
+        v = take(o, len(dst.a))
+        dst.a[:] = [x - 256 if x > 127 else x for x in v]
+        return o
+
+    N[BB + ".wrap:([BII)Ljava/nio/ByteBuffer;"] = wrap
+    N[BB + ".order:(Ljava/nio/ByteOrder;)Ljava/nio/ByteBuffer;"] = lambda jj, o, order: o
+    N["java/nio/ByteOrder.LITTLE_ENDIAN"] = lambda jj: JObject("java/nio/ByteOrder")
+    N[BB + ".hasRemaining"] = lambda jj, o: 1 if o.native["pos"] < o.native["lim"] else 0
+    N[BB + ".get:()B"] = lambda jj, o: struct.unpack("<b", take(o, 1))[0]
+    N[BB + ".get:([B)Ljava/nio/ByteBuffer;"] = get_bytes
+    N[BB + ".getShort:()S"] = lambda jj, o: struct.unpack("<h", take(o, 2))[0]
+    N[BB + ".getInt:()I"] = lambda jj, o: struct.unpack("<i", take(o, 4))[0]
+    N[BB + ".getFloat:()F"] = lambda jj, o: f32(struct.unpack("<f", take(o, 4))[0])
+    N[BB + ".mark"] = lambda jj, o: (o.native.__setitem__("mark", o.native["pos"]), o)[1]
+    N[BB + ".reset"] = lambda jj, o: (o.native.__setitem__("pos", o.native["mark"]), o)[1]
+    N[BB + ".position:()I"] = lambda jj, o: o.native["pos"]
+
+
+def gen_auxorder(g, seed=2222):
+    """the attribute list of a record that is read from a BAM, tagged and written again"""
+    import struct
+
+    j = g.j
+    rng = random.Random(seed)
+    install_bytebuffer(j)
+    H = j.hooks
+    H[SAMREC + ".<clinit>:()V"] = None
+    BTC, TAV, STAG = "htsjdk/samtools/BinaryTagCodec", "htsjdk/samtools/SAMBinaryTagAndValue", "htsjdk/samtools/SAMTag"
+    H["htsjdk/samtools/util/Log.<clinit>:()V"] = None
+    H["htsjdk/samtools/util/Log.*"] = lambda jj, *a: None
+    H["htsjdk/samtools/util/Log.getInstance:(Ljava/lang/Class;)Lhtsjdk/samtools/util/Log;"] = lambda jj, *a: JObject("htsjdk/samtools/util/Log")
+    out = {"jar": "htsjdk-4.1.3.jar", "sections": []}
+    s = g.section("BinaryTagCodec.readTags(aux bytes, 0, n, SILENT) (BinaryTagCodec.java:L271-305: the list is built through SAMBinaryTagAndValue.insert, "
+                  "i.e. ordered by binary tag while it is read, a repeated tag replacing the earlier one), then SAMRecord.setAttribute(tag, value) "
+                  "per call (SAMRecord.java:L1531-1602; value null = remove), then the list as BAMRecordCodec would write it: [tag, value, the type "
+                  "character BinaryTagCodec.getTagValueType picks].  The record is an otherwise empty SAMRecord object", BTC,
+                  "readTags:([BIILhtsjdk/samtools/ValidationStringency;)Lhtsjdk/samtools/SAMBinaryTagAndValue;")
+    silent = j.get_static("htsjdk/samtools/ValidationStringency", "SILENT")
+    pool = ["NM", "ms", "AS", "nn", "tp", "cm", "s1", "s2", "de", "rl", "SA", "MD", "GE", "GS", "XF", "BC", "U8", "zz", "AA", "B1", "ts"]
+    new_tags = ["PE", "PS", "AE", "RE", "TE", "BU", "BV", "BE", "BW", "BX", "SX", "BH", "BC", "BZ", "BB", "BF", "B1", "B2", "BZ", "BH", "XF", "GE", "GS",
+                "U8", "U7", "UC", "U1", "U2", "UZ"]
+    for case in range(60):
+        aux, given = b"", []
+        for t in rng.sample(pool, rng.randrange(0, 9)) + ([rng.choice(pool)] if case % 7 == 3 else []):
+            kind = rng.choice("cCsSiIZAf")
+            if kind in "cCsSiI":
+                lo, hi = {"c": (-128, 127), "C": (0, 255), "s": (-32768, 32767), "S": (0, 65535), "i": (-2 ** 31, 2 ** 31 - 1), "I": (0, 2 ** 32 - 1)}[kind]
+                v = rng.choice([lo, hi, 0, 1, 3, 100, 200, 300, 40000, 70000, rng.randrange(lo, hi + 1)])
+                v = min(max(v, lo), hi)
+                aux += t.encode() + kind.encode() + struct.pack("<" + {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I"}[kind], v)
+            elif kind == "Z":
+                v = rng.choice(["", "chr1,100,+,50M,60,0;", "GENE1", "CODING"])
+                aux += t.encode() + b"Z" + v.encode() + b"\0"
+            elif kind == "A":
+                v = rng.choice("PSI")
+                aux += t.encode() + b"A" + v.encode()
+            else:
+                v = rng.choice([0.0, 0.5, 0.0123])
+                aux += t.encode() + b"f" + struct.pack("<f", v)
+            given.append([t, kind, v])
+        calls = []
+        for t in new_tags:
+            if rng.random() < 0.55:
+                calls.append([t, rng.choice([None, "", "ACGT", "17"]) if t in ("GE", "GS") else rng.choice(["", "ACGTACGTACGTACGT", "12", 0, 1, 130, 611, 70000, -3])])
+        rec = j.new_object(SAMREC)
+        arr = j.byte_array([b - 256 if b > 127 else b for b in aux])
+        head = j.call_static(BTC, "readTags", f"([BIILhtsjdk/samtools/ValidationStringency;)L{TAV};", arr, 0, len(aux), silent) if aux else None
+        rec.f["mAttributes"] = head
+        for t, v in calls:
+            j.call_virtual(rec, "setAttribute", "(Ljava/lang/String;Ljava/lang/Object;)V", t, JBox("java/lang/Integer", v) if isinstance(v, int) else v)
+        final = []
+        node = rec.f["mAttributes"]
+        while node is not None:
+            tag = j.to_jstring(j.call_static(STAG, "makeStringTag", "(S)Ljava/lang/String;", node.f["tag"]))
+            val = node.f["value"]
+            ty = chr(j.call_static(BTC, "getTagValueType", "(Ljava/lang/Object;)C", val))
+            final.append([tag, val.v if isinstance(val, JBox) else val, ty])
+            node = node.f["next"]
+        s["cases"].append({"aux_hex": aux.hex(), "aux": given, "calls": calls, "final": final})
+    out["sections"].append(g.finish(s))
+    return out
+
+
+SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
 
