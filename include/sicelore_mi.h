@@ -782,6 +782,34 @@ int smi_gene_tag_chunk(const smi_genes *g, const int32_t *ref_id, const uint16_t
 int smi_gene_tag_bam(const smi_genes *g, const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, char *out, size_t cap,
                      uint32_t *out_off, size_t *n_out);
 
+/* ---- the writer half of assignumis (host only) --------------------------------------------------------------------------------------------
+ * smi_bam_write_batch: one batch of records (the records one OneBatchExecutor hands to UmiFinderWorker$BamWriters.writeSams,
+ * FJ!umifinder/UmiFinderWorker.java:L408-495) -> the uncompressed BAM records of <out>.bam (out_bc: every record with a cell barcode) and
+ * <out>_umifound_.bam (out_umi: those whose UMI comes from clustering), in the order the reference writes them (a stable sort of the batch by
+ * htsjdk's SAMRecordCoordinateComparator, L421).  Per record: the tags of ReadScanResult.writeSamFlags / writeBCSamFlags from the scan data
+ * in the read name, GennameTagger's XF / GE / GS (gene / gene_off as smi_gene_tag_bam returns them for ALL records of `recs`, or NULL), the
+ * clustering's U8 U7 UC U1 U2 or the U7 -> U8 + UZ fill (tags[i] of smi_assignumis_chunk, indexed like recs), merged into the record's
+ * attribute list as htsjdk keeps it (ordered by binary tag, a repeated tag keeping its last value, integers in the smallest type).
+ * batch: indices into recs; order_out (n_batch entries or NULL) receives them in write order.  out_bc == NULL: sizes only.
+ * gc != NULL: GeneCounts.updateGeneCounts for every written record that ends up with U8, in write order (region / nth_record indexed like
+ * recs, meanings as smi_gene_counts_add).  smi_bam_chunk_inputs gathers the names / CIGARs / flags / positions of records idx[0 .. n) in
+ * the layout smi_assignumis_chunk takes (names == NULL: sizes only). */
+typedef struct {
+    int32_t bc_edit_limit;      /* -b (FastqRecordExt.java:L450-456); -1 = no limit */
+    int32_t truncate_read_name; /* -w: read name cut at its first '_' (L431-432) */
+    int32_t five_prime;         /* -p: which end's clip GeneCounts looks at */
+    int32_t n_threads;
+} smi_bam_write_config;
+int smi_bam_write_default_config(smi_bam_write_config *cfg);
+typedef struct smi_gene_counts smi_gene_counts;
+int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, const int32_t *batch, int32_t n_batch,
+                        const smi_umi_tag *tags, const char *gene, const uint32_t *gene_off, const smi_bam_write_config *cfg,
+                        uint8_t *out_bc, size_t cap_bc, size_t *n_bc, uint8_t *out_umi, size_t cap_umi, size_t *n_umi, int32_t *order_out,
+                        smi_gene_counts *gc, const int64_t *region, const uint8_t *nth_record);
+int smi_bam_chunk_inputs(const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, const int32_t *idx, int32_t n, char *names,
+                         uint32_t *name_off, uint32_t *cigars, uint32_t *cigar_off, uint16_t *flags, int32_t *pos0, size_t *n_name_bytes,
+                         size_t *n_cigar_ops);
+
 /* ---- <out>.genecounts.tsv / <out>.UMIdepths.tsv of assignumis (host only) -----------------------------------------------------------------
  * Replaces GeneCounts (FJ!umifinder/scanstats/GeneCounts.java:L58-652).
  * smi_gene_counts_add = updateGeneCounts (L375-491) for the n records of one written batch, called where $BamWriters.lambda$writeSams$2
@@ -794,7 +822,6 @@ int smi_gene_tag_bam(const smi_genes *g, const uint8_t *bam, size_t n_bam, const
  * smi_gene_counts_merge = mergeGeneCounts (L540-592).  smi_gene_counts_tsv = printCountTable (L307-357): header TAB cells, one row per gene,
  * cells by their number of UMIs (descending), genes by theirs; smi_umi_depths_tsv = printUmisPerCellTable (L256-284).  Rows the reference
  * leaves in ConcurrentHashMap order (equal totals) are by ascending key.  out == NULL: size only. */
-typedef struct smi_gene_counts smi_gene_counts;
 int smi_gene_counts_create(smi_gene_counts **out);
 int smi_gene_counts_free(smi_gene_counts *gc);
 int smi_gene_counts_add(smi_gene_counts *gc, size_t n, const char *const *gene, const int64_t *region, const uint64_t *cell_bc,

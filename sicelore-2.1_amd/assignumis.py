@@ -432,6 +432,42 @@ def _count_columns(rows, five_prime):
                 last_cigar=cols[8], nth_record=cols[9], five_prime=five_prime)
 
 
+def tagged_record(bam, r, name, scan, umi, gene=None, five_prime=False, truncate_read_name=False):
+    """one record of the output: (BAM record bytes incl. its block_size word, from clustering?, attribute fields) or None when the read has no
+    cell barcode (it is not written).  scan: scan_data_from_name(name); umi: the record's entry of assign_umis / None; gene: (GE, GS, XF) or None"""
+    u7 = None
+    if scan is not None and scan["bc"] is not None and scan["bc"]["end"] is not None and scan["x"]:
+        w = umi_window(scan["x"], scan["ae"], scan["bc"]["end"], five_prime)
+        u7 = None if w is None else "".join(_DEC[c] for c in w[1:13])
+    calls, has_bc, clustered = record_tag_sets(scan, umi, u7, gene)
+    if not has_bc:
+        return None
+    o = int(r["rec_off"])
+    fixed = bytearray(bam[o + 4:int(r["aux_off"])].tobytes())
+    if truncate_read_name:                                  # -w: readName.split("_")[0] (L431-432)
+        nm = name.split("_")[0].encode() + b"\0"
+        fixed = fixed[:32] + nm + fixed[32 + int(r["l_read_name"]):]
+        fixed[8] = len(nm)
+    aux = bam[int(r["aux_off"]):int(r["aux_off"]) + int(r["aux_len"])].tobytes()
+    fields = apply_tag_sets(split_aux(aux), calls)
+    body = bytes(fixed) + b"".join(raw for _, raw in fields)
+    return np.array([len(body)], dtype="<u4").tobytes() + body, clustered, fields
+
+
+def gene_count_row(bam, r, fields, region, nth):
+    """the columns of lib.GeneCounts.add for one written record, or None when it carries no U8 (updateGeneCounts is only called for records
+    with the UMI attribute, UmiFinderWorker.java:L453)"""
+    f = {t: raw for t, raw in fields if t in ("GE", "U8", "BC")}
+    z = lambda t: f[t][3:-1].decode() if t in f and f[t][2:3] == b"Z" else None  # noqa: E731
+    ge, u8, bc = z("GE"), z("U8"), z("BC")
+    if u8 is None:
+        return None
+    cg = bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4")
+    gene = None if ge is None else (_java_split(ge, ",") or [None])[0]
+    return (gene, region, _lib.two_bit_code(bc) if bc else 0, _lib.two_bit_code(u8), 1 if bc is not None else 0, int(r["flag"]), int(r["mapq"]),
+            int(cg[0]) if cg.size else 0xFFFFFFFF, int(cg[-1]) if cg.size else 0, 1 if nth else 0)
+
+
 def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device",
                       gene_counts=None, **kw):
     """`assignumis` BAM in -> (bcfound BAM bytes, umifound BAM bytes, names, tags): the two BGZF streams the reference writes
@@ -465,36 +501,17 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
                 seen.add(names[i])
     rows = []                                                   # in write order: UMIcounts.increment does not commute with its nth-record form
     for i in order:
-        d, r = scans[i], recs[i]
-        u7 = None
-        if d is not None and d["bc"] is not None and d["bc"]["end"] is not None and d["x"]:
-            w = umi_window(d["x"], d["ae"], d["bc"]["end"], five_prime)
-            u7 = None if w is None else "".join(_DEC[c] for c in w[1:13])
-        calls, has_bc, clustered = record_tag_sets(d, tags[i], u7, None if gene_tags is None else gene_tags[i])
-        if not has_bc:
+        res = tagged_record(bam, recs[i], names[i], scans[i], tags[i], None if gene_tags is None else gene_tags[i], five_prime, truncate_read_name)
+        if res is None:
             continue
-        o = int(r["rec_off"])
-        fixed = bytearray(bam[o + 4:int(r["aux_off"])].tobytes())
-        if truncate_read_name:                                  # -w: readName.split("_")[0] (L431-432)
-            nm = names[i].split("_")[0].encode() + b"\0"
-            fixed = fixed[:32] + nm + fixed[32 + int(r["l_read_name"]):]
-            fixed[8] = len(nm)
-        aux = bam[int(r["aux_off"]):int(r["aux_off"]) + int(r["aux_len"])].tobytes()
-        fields = apply_tag_sets(split_aux(aux), calls)
-        body = bytes(fixed) + b"".join(raw for _, raw in fields)
-        rec_bytes = np.array([len(body)], dtype="<u4").tobytes() + body
+        rec_bytes, clustered, fields = res
         out_bc.append(rec_bytes)
         if clustered:
             out_umi.append(rec_bytes)
         if gene_counts is not None:
-            f = {t: raw for t, raw in fields if t in ("GE", "U8", "BC")}
-            z = lambda t: f[t][3:-1].decode() if t in f and f[t][2:3] == b"Z" else None  # noqa: E731
-            ge, u8, bc = z("GE"), z("U8"), z("BC")
-            cg = bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4")
-            gene = None if ge is None else (_java_split(ge, ",") or [None])[0]
-            rows.append((gene, regions.get(i, -1), _lib.two_bit_code(bc) if bc else 0, _lib.two_bit_code(u8) if u8 else 0,
-                         1 if bc is not None and u8 is not None else 0, int(r["flag"]), int(r["mapq"]),
-                         int(cg[0]) if cg.size else 0xFFFFFFFF, int(cg[-1]) if cg.size else 0, 1 if nth[i] else 0))
+            row = gene_count_row(bam, recs[i], fields, regions.get(i, -1), nth[i])
+            if row is not None:
+                rows.append(row)
     if gene_counts is not None and rows:
         gene_counts.add(**_count_columns(rows, five_prime))
     if bgzf == "device":
@@ -502,6 +519,87 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
     else:
         z = lambda parts: _lib.bgzf_deflate(b"".join(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
     return z(out_bc), z(out_umi), names, tags
+
+
+def chunk_bounds(ref_ids, chunk_size):
+    """BamReader.run L106-147 as positions: [(index in front of which a flush happens, keep)] -- after chunk_size records (the first chunk
+    holds chunk_size - 1: the reader's counter starts at 1) or in front of the first record of another chromosome (keep = False)"""
+    ref = np.asarray(ref_ids)
+    out, n = [], int(ref.size)
+    if n == 0:
+        return out
+    change = (np.flatnonzero(ref[1:] != ref[:-1]) + 1).tolist()
+    step, i0, ci = max(int(chunk_size), 1), -1, 0        # i0: the last flush position (the reader's counter is 1 at the first record)
+    while True:
+        by_count = max(i0 + step, 1)
+        while ci < len(change) and change[ci] <= i0:
+            ci += 1
+        nxt = change[ci] if ci < len(change) else n
+        at = min(by_count, nxt)
+        if at >= n:
+            return out
+        out.append((at, at != nxt))
+        i0 = at
+
+
+def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device",
+                             gene_counts=None, max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None):
+    """write_tagged_bams with no per-record work in Python: BGZF inflate + record index (host threads), per BamReader chunk
+    smi_bam_chunk_inputs -> smi_assignumis_chunk (device), smi_gene_tag_bam, per written batch smi_bam_write_batch (host threads), BGZF by
+    K-DEFLATE.  -> (bcfound BAM bytes, umifound BAM bytes, info dict).  The same bytes as write_tagged_bams."""
+    _text, refs, bam, recs = load_bam(data, n_threads=n_threads)
+    n = int(recs.size)
+    gene = None
+    if refflat is not None:
+        tagger = _lib.GeneTagger(refflat, [nm for nm, _ in refs])
+        gene = tagger.tag_bam_raw(bam, recs)
+        tagger.close()
+    header_end = int(recs[0]["rec_off"]) if n else bam.size
+    parts_bc, parts_umi = [bam[:header_end]], [bam[:header_end]]
+    tags = np.zeros(max(n, 1), dtype=_lib.UMI_TAG_DTYPE)
+    region = np.full(max(n, 1), -1, dtype=np.int64)
+    nth = np.zeros(max(n, 1), dtype=np.uint8)
+    if gene_counts is not None and n:       # a record of this read name went through the analyzer before (BAM order)
+        nm_len = recs["l_read_name"].astype(np.int64) - 1
+        keys = [bam[int(o):int(o) + int(k)].tobytes() for o, k in zip(recs["name_off"], nm_len)]
+        seen = set()
+        for i, k in enumerate(keys):
+            nth[i] = k in seen
+            seen.add(k)
+    region_base, n_clustered, n_batches = 0, 0, 0
+    cur = np.zeros(0, dtype=np.int32)
+
+    def flush(cur, keep):
+        nonlocal region_base, n_clustered, n_batches
+        inp = _lib.bam_chunk_inputs(bam, recs, cur)
+        out, n_done = ctx.assignumis_chunk_raw(inp, keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
+                                               five_prime=five_prime, cluster_cfg=cluster_cfg)
+        done = cur[:n_done]
+        tags[done] = out[:n_done]
+        reg = out["region"][:n_done].astype(np.int64)
+        region[done] = np.where(reg >= 0, reg + region_base, -1)
+        region_base += int(reg.max()) + 1 if n_done and reg.max() >= 0 else 0
+        n_clustered += int(((out["flags"][:n_done] & _lib.UMI_CLUSTERED) != 0).sum())
+        bc, umi, _order = _lib.bam_write_batch(bam, recs, done, tags, gene=gene, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate_read_name,
+                                               five_prime=five_prime, n_threads=n_threads, gene_counts=gene_counts, region=region, nth_record=nth)
+        parts_bc.append(bc)
+        parts_umi.append(umi)
+        n_batches += 1
+        return cur[n_done:]
+
+    start = 0
+    for at, keep in chunk_bounds(recs["ref_id"], chunk_size) if n else []:
+        cur = flush(np.concatenate([cur, np.arange(start, at, dtype=np.int32)]), keep)
+        start = at
+    if n:
+        cur = np.concatenate([cur, np.arange(start, n, dtype=np.int32)])
+        while cur.size:
+            cur = flush(cur, False)
+    if bgzf == "device":
+        z = lambda parts: ctx.bgzf_deflate_device(np.concatenate(parts)).tobytes()  # noqa: E731
+    else:
+        z = lambda parts: _lib.bgzf_deflate(np.concatenate(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
+    return z(parts_bc), z(parts_umi), dict(records=n, clustered=n_clustered, batches=n_batches, tags=tags, region=region)
 
 
 def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, **kw):

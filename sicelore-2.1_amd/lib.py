@@ -61,6 +61,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into",
+    "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs",
 ]
 
 
@@ -182,6 +183,10 @@ def load_library():
     lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_gz_inflate_into.argtypes = [vp, sz, ctypes.POINTER(sz), vp, sz, ctypes.POINTER(sz)]
+    lib.smi_bam_write_default_config.argtypes = [vp]
+    lib.smi_bam_write_batch.argtypes = [vp, sz, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz), vp, sz, ctypes.POINTER(sz), vp,
+                                        vp, vp, vp]
+    lib.smi_bam_chunk_inputs.argtypes = [vp, sz, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.smi_gene_counts_create.argtypes = [ctypes.POINTER(vp)]
     lib.smi_gene_counts_free.argtypes = [vp]
     lib.smi_gene_counts_add.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
@@ -294,6 +299,20 @@ class GeneTagger:
         recs = np.ascontiguousarray(recs)
         return self._run(self._lib.smi_gene_tag_bam, (self._h, _ptr(bam), bam.size, _ptr(recs), int(recs.size)), int(recs.size))
 
+    def tag_bam_raw(self, bam, recs):
+        """-> (bytes buffer, uint32 offsets [3 n + 1]): GE, GS, XF of record i at offsets 3 i .. 3 i + 3 (what smi_bam_write_batch takes)"""
+        recs = np.ascontiguousarray(recs)
+        n = int(recs.size)
+        out_off = np.zeros(3 * n + 1, dtype=np.uint32)
+        need = ctypes.c_size_t(0)
+        args = (self._h, _ptr(bam), bam.size, _ptr(recs), n)
+        if self._lib.smi_gene_tag_bam(*args, None, 0, _ptr(out_off), ctypes.byref(need)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        buf = np.zeros(need.value + 1, dtype=np.uint8)
+        if self._lib.smi_gene_tag_bam(*args, _ptr(buf), need.value, _ptr(out_off), ctypes.byref(need)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        return buf, out_off
+
     def _run(self, fn, args, n):
         out_off = np.zeros(3 * n + 1, dtype=np.uint32)
         need = ctypes.c_size_t(0)
@@ -308,6 +327,58 @@ class GeneTagger:
             ge, gs, xf = (raw[out_off[3 * i + k]:out_off[3 * i + k + 1]].decode() for k in range(3))
             res.append((ge or None, gs or None, xf or None))
         return res
+
+
+class BamWriteConfig(ctypes.Structure):
+    _fields_ = [("bc_edit_limit", ctypes.c_int32), ("truncate_read_name", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("n_threads", ctypes.c_int32)]
+
+
+def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, truncate_read_name=False, five_prime=False, n_threads=4,
+                    gene_counts=None, region=None, nth_record=None):
+    """smi_bam_write_batch: the records `batch` (indices into recs) of an inflated BAM -> (bytes of <out>.bam, bytes of <out>_umifound_.bam,
+    write order).  tags: UMI_TAG_DTYPE array indexed like recs; gene: (buffer, offsets) of GeneTagger.tag_bam_raw or None; gene_counts: a
+    GeneCounts fed in write order (region int64 / nth_record uint8 indexed like recs)."""
+    lib = load_library()
+    recs = np.ascontiguousarray(recs)
+    batch = np.ascontiguousarray(batch, dtype=np.int32)
+    tags = np.ascontiguousarray(tags, dtype=UMI_TAG_DTYPE)
+    cfg = BamWriteConfig()
+    lib.smi_bam_write_default_config(ctypes.byref(cfg))
+    cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
+    cfg.truncate_read_name, cfg.five_prime, cfg.n_threads = int(bool(truncate_read_name)), int(bool(five_prime)), int(n_threads)
+    gbuf, goff = (None, None) if gene is None else gene
+    if gene_counts is not None:
+        region = np.ascontiguousarray(region, dtype=np.int64)
+        nth_record = np.ascontiguousarray(nth_record, dtype=np.uint8)
+    cap = int(recs["rec_len"][batch].sum()) + 420 * int(batch.size) + 64          # every tag this step can add is below 420 bytes per record
+    out_bc, out_umi = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)
+    order = np.zeros(max(batch.size, 1), dtype=np.int32)
+    nb, nu = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    rc = lib.smi_bam_write_batch(_ptr(bam), bam.size, _ptr(recs), _ptr(batch), int(batch.size), _ptr(tags), _ptr(gbuf), _ptr(goff), ctypes.byref(cfg),
+                                 _ptr(out_bc), cap, ctypes.byref(nb), _ptr(out_umi), cap, ctypes.byref(nu), _ptr(order),
+                                 None if gene_counts is None else gene_counts._h, _ptr(region) if gene_counts is not None else None,
+                                 _ptr(nth_record) if gene_counts is not None else None)
+    if rc:
+        raise SmiError(lib.smi_last_error().decode())
+    return out_bc[:nb.value], out_umi[:nu.value], order[:batch.size]
+
+
+def bam_chunk_inputs(bam, recs, idx):
+    """names / CIGARs / flags / positions of records idx in the layout smi_assignumis_chunk takes -> dict of arrays"""
+    lib = load_library()
+    recs = np.ascontiguousarray(recs)
+    idx = np.ascontiguousarray(idx, dtype=np.int32)
+    n = int(idx.size)
+    a, b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    if lib.smi_bam_chunk_inputs(_ptr(bam), bam.size, _ptr(recs), _ptr(idx), n, None, None, None, None, None, None, ctypes.byref(a), ctypes.byref(b)):
+        raise SmiError(lib.smi_last_error().decode())
+    names, noff = np.zeros(a.value + 1, dtype=np.uint8), np.zeros(n + 1, dtype=np.uint32)
+    cig, coff = np.zeros(b.value + 1, dtype=np.uint32), np.zeros(n + 1, dtype=np.uint32)
+    fl, p0 = np.zeros(max(n, 1), dtype=np.uint16), np.zeros(max(n, 1), dtype=np.int32)
+    if lib.smi_bam_chunk_inputs(_ptr(bam), bam.size, _ptr(recs), _ptr(idx), n, _ptr(names), _ptr(noff), _ptr(cig), _ptr(coff), _ptr(fl), _ptr(p0),
+                                ctypes.byref(a), ctypes.byref(b)):
+        raise SmiError(lib.smi_last_error().decode())
+    return dict(names=names, name_off=noff, cigars=cig, cigar_off=coff, flags=fl, pos0=p0, n=n)
 
 
 def two_bit_code(seq):
@@ -1075,6 +1146,24 @@ class Context:
         if int(t[1]):
             raise SmiError(f"smi_gzip_device: error flags {int(t[1])}")
         return d_out[:int(t[0])]
+
+    def assignumis_chunk_raw(self, inp, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4, five_prime=False, cluster_cfg=None):
+        """the same on the buffers of bam_chunk_inputs -> (UMI_TAG_DTYPE array, n_done)"""
+        n = inp["n"]
+        cfg = AssignUmisConfig()
+        self._check(self._lib.smi_assignumis_default_config(ctypes.byref(cfg)))
+        cfg.max_dist, cfg.keep_data_end, cfg.n_threads = int(max_dist), int(keep_data_end), int(n_threads)
+        cfg.five_prime = int(bool(five_prime))
+        cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
+        if cluster_cfg is not None:
+            cluster_cfg = np.ascontiguousarray(cluster_cfg, dtype=UMI_CLUSTER_CONFIG_DTYPE)
+            cfg.cluster = cluster_cfg.ctypes.data
+        out = np.zeros(max(n, 1), dtype=UMI_TAG_DTYPE)
+        nd = ctypes.c_int32(0)
+        self._check(self._lib.smi_assignumis_chunk(self._h, inp["names"].ctypes.data, inp["name_off"].ctypes.data, inp["flags"].ctypes.data,
+                                                   inp["pos0"].ctypes.data, inp["cigars"].ctypes.data, inp["cigar_off"].ctypes.data, n,
+                                                   ctypes.byref(cfg), out.ctypes.data, ctypes.byref(nd)))
+        return out[:n], nd.value
 
     def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
                          five_prime=False, cluster_cfg=None):

@@ -258,3 +258,107 @@ def test_attribute_list_equals_htsjdk_executed(pkg):
         n_retyped += sum(1 for t, _, ty in c["final"] if t in kinds and kinds[t] in "cCsSiI" and kinds[t] != ty and t not in dict(c["calls"]))
         n += len(want)
     assert n > 600 and n_retyped > 40
+
+
+def _write_batch_case(libmod, au, seed, five_prime=False, truncate=False, bc_edit_limit=None):
+    """a BAM of mixed records + synthetic clustering results -> (native bytes, Python-mirror bytes, gene-count texts of both)"""
+    import json
+    import os
+
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sec = json.load(open(os.path.join(gold_dir, "ref_exec_samtags.json")))["sections"][1 if five_prime else 0]
+    names_pool = [c["name"] for c in sec["cases"]]
+    aux_pool = [bytes.fromhex(c["aux_hex"]) for c in json.load(open(os.path.join(gold_dir, "ref_exec_auxorder.json")))["sections"][0]["cases"]]
+    rng = np.random.default_rng(seed)
+    n = 400
+    rows = []
+    for k in range(n):
+        nm = names_pool[int(rng.integers(0, len(names_pool)))]
+        if rng.random() < 0.5:
+            nm = nm.replace("read", f"r{int(rng.integers(0, 30))}x", 1)          # repeated names: ties down to flags / mate fields
+        unm = rng.random() < 0.06
+        ref = -1 if unm else int(rng.integers(0, 2))
+        flag = int(rng.choice([0, 16, 256, 272, 2048, 2064])) | (4 if unm else 0)
+        cig = [] if unm else ([("S", int(rng.integers(1, 400)))] if rng.random() < 0.5 else []) + [("M", int(rng.integers(20, 300)))] + \
+            ([("H", int(rng.integers(100, 300)))] if rng.random() < 0.3 else [])
+        L = sum(ln for op, ln in cig if op in "MIS=X") or 10
+        rows.append((ref, -1 if unm else int(rng.integers(0, 40)), nm, flag, cig, L, aux_pool[int(rng.integers(0, len(aux_pool)))],
+                     int(rng.choice([0, 20, 60]))))
+    brecs = [bammodel.bam_record(nm, fl, ref, p0, mq, cg, "C" * L, aux=aux) for ref, p0, nm, fl, cg, L, aux, mq in rows]
+    header = bammodel.bam_bytes("@HD\tVN:1.6\tSO:unsorted\n", [("chr1", 10 ** 6), ("chr2", 10 ** 6)], [])
+    data = bammodel.bgzf_compress(header + b"".join(brecs), block=8192)
+    _text, _refs, bam, recs = au.load_bam(data, n_threads=2)
+    assert recs.size == n
+    names = [au.read_name(bam, r) for r in recs]
+    scans = [au.scan_data_from_name(nm, bc_edit_limit) for nm in names]
+    tags = np.zeros(n, dtype=libmod.UMI_TAG_DTYPE)
+    umis = [None] * n
+    for i, d in enumerate(scans):
+        u7 = None
+        if d is not None and d["bc"] is not None and d["bc"]["seq"] is not None:
+            tags[i]["flags"] |= libmod.UMI_HAS_BC
+            if d["bc"]["end"] is not None and d["x"]:
+                w = au.umi_window(d["x"], d["ae"], d["bc"]["end"], five_prime)
+                u7 = None if w is None else "".join("AGCT"[{1: 0, 2: 1, 4: 2, 8: 3}[c]] if c != 15 else "N" for c in w[1:13])
+        if u7 is not None:
+            tags[i]["flags"] |= libmod.UMI_HAS_U7
+            tags[i]["u7"] = u7.encode()
+            kind = rng.random()
+            if kind < 0.5:
+                u8 = "".join("ACGT"[int(x)] for x in rng.integers(0, 4, 12))
+                u2 = int(rng.integers(-1, 4))
+                tags[i]["flags"] |= libmod.UMI_CLUSTERED
+                tags[i]["u8"], tags[i]["u1"], tags[i]["u2"] = u8.encode(), int(rng.integers(0, 3)), u2
+                umis[i] = dict(U8=u8, U7=u7, U1=int(tags[i]["u1"]), U2=None if u2 < 0 else u2)
+            elif kind < 0.6:
+                tags[i]["flags"] |= libmod.UMI_SKIPPED
+                umis[i] = dict(skipped=True)
+    gene_list = []
+    for i in range(n):
+        k = rng.random()
+        gene_list.append((None, None, None) if k < 0.1 else (None, None, "INTERGENIC") if k < 0.3 else
+                         (rng.choice(["G1", "G2,G3", "G4", ",", "G5,,"]), rng.choice(["+", "-", "+,-"]), "CODING"))
+    off, buf = [0], b""
+    for ge, gs, xf in gene_list:
+        for v in (ge, gs, xf):
+            buf += (v or "").encode()
+            off.append(len(buf))
+    gene_raw = (np.frombuffer(buf + b"\0", dtype=np.uint8).copy(), np.array(off, dtype=np.uint32))
+    region = rng.integers(-1, 30, n).astype(np.int64)
+    nth = (rng.random(n) < 0.15).astype(np.uint8)
+    batch = rng.permutation(n).astype(np.int32)[: n - 7]                        # a batch is a subset, in whatever order it was collected
+    gc1, gc2 = libmod.GeneCounts(), libmod.GeneCounts()
+    bc, umi, order = libmod.bam_write_batch(bam, recs, batch, tags, gene=gene_raw, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate,
+                                            five_prime=five_prime, n_threads=3, gene_counts=gc1, region=region, nth_record=nth)
+    exp_order = sorted(batch.tolist(), key=lambda k: au._coordinate_key(recs[k], names[k]))
+    exp_bc, exp_umi, grows = [], [], []
+    for i in exp_order:
+        res = au.tagged_record(bam, recs[i], names[i], scans[i], umis[i], gene_list[i], five_prime, truncate)
+        if res is None:
+            continue
+        exp_bc.append(res[0])
+        if res[1]:
+            exp_umi.append(res[0])
+        row = au.gene_count_row(bam, recs[i], res[2], int(region[i]), int(nth[i]))
+        if row is not None:
+            grows.append(row)
+    if grows:
+        gc2.add(**au._count_columns(grows, five_prime))
+    assert order.tolist() == exp_order
+    return bc.tobytes(), b"".join(exp_bc), umi.tobytes(), b"".join(exp_umi), (gc1.genecounts_tsv(), gc1.umi_depths_tsv(), gc1.info()), \
+        (gc2.genecounts_tsv(), gc2.umi_depths_tsv(), gc2.info())
+
+
+@pytest.mark.parametrize("five_prime,truncate,limit", [(False, False, None), (True, False, None), (False, True, None), (False, False, 0)])
+def test_native_batch_writer_equals_the_python_mirror(pkg, five_prime, truncate, limit):
+    """smi_bam_write_batch (host threads) against tagged_record / _coordinate_key / gene_count_row, the mirror the reference-executed
+    fixtures pin: same order, same bytes in both outputs, same gene-count tables"""
+    import importlib
+
+    from sicelore_amd import lib as libmod
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    for seed in (1, 2):
+        bc, exp_bc, umi, exp_umi, g1, g2 = _write_batch_case(libmod, au, seed, five_prime, truncate, limit)
+        assert bc == exp_bc and umi == exp_umi and len(bc) > 50_000 and 0 < len(umi) < len(bc)
+        assert g1 == g2 and g1[2]["gene_entries"] > 5 and g1[2]["records_skipped_clipping"] > 0

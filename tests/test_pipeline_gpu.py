@@ -397,3 +397,12 @@ def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
         assert open(os.path.join(td, "out.genecounts.tsv")).read() == gc.genecounts_tsv(16)
         assert open(os.path.join(td, "out.UMIdepths.tsv")).read() == gc.umi_depths_tsv()
         assert os.path.getsize(os.path.join(td, "out_umifound_.bam")) > 100 and res["records"] == len(names)
+    # the native pipeline (no per-record Python: smi_bam_chunk_inputs -> smi_assignumis_chunk -> smi_bam_write_batch): the same streams and tables
+    for kw in (dict(), dict(refflat=refflat), dict(truncate_read_name=True), dict(chunk_size=37)):
+        gc_n, gc_p = libmod.GeneCounts(), libmod.GeneCounts()
+        nb, nu, info = assignumis.write_tagged_bams_native(gpu_ctx, data, gene_counts=gc_n, **kw)
+        pb, pu, _, _ = assignumis.write_tagged_bams(gpu_ctx, data, gene_counts=gc_p, native=True, **kw)
+        assert bammodel.bgzf_decompress(nb) == bammodel.bgzf_decompress(pb) and bammodel.bgzf_decompress(nu) == bammodel.bgzf_decompress(pu)
+        assert (gc_n.genecounts_tsv(16), gc_n.umi_depths_tsv(), gc_n.info()) == (gc_p.genecounts_tsv(16), gc_p.umi_depths_tsv(), gc_p.info())
+        assert info["records"] == len(names) and info["clustered"] == n_clustered and (info["batches"] > 3) == ("chunk_size" in kw)
+    assert bammodel.bgzf_decompress(assignumis.write_tagged_bams_native(gpu_ctx, data)[0]) == raw_bc
