@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=10_000_000, help="--config 2: reads per batch resident in HBM")
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: this many reads in ALL, sharded over the ranks (configs[3]: 100000000 with --gpus 8)")
     ap.add_argument("--umi-molecules", type=int, default=50_000, help="molecules of the UMI-stage leg (each read six times); 0 = skip")
+    ap.add_argument("--assignumis-file-records", type=int, default=100_000,
+                    help="records of the BAM -> tagged BAM leg (assignumis_file_to_file; 0 = off; needs the UMI leg)")
     ap.add_argument("--h2h-reads", type=int, default=500_000, help="reads per chunk of the host-to-host leg (packed boundary); 0 = skip")
     ap.add_argument("--f2f-reads", type=int, default=2_000_000, help="reads of the file-to-file leg (64 *.fastq.gz, both passes, gzip out); 0 = skip")
     ap.add_argument("--f2f-dir", default=None, help="scratch directory of the file-to-file leg (default: a temporary directory under /dev/shm or /tmp)")
@@ -237,6 +239,7 @@ def umi_stage_leg(pkg, synth, ctx, used, n_mol, copies=6, genes_per=10):
                 xs[int(rng.integers(0, len(xs)))] = "ACGT"[int(rng.integers(0, 4))]
             rows.append((int(gene[m]) * 5_000 + int(rng.integers(-100, 100)), f"{head.replace('m', 'r%d_' % c, 1)}_X={''.join(xs)}_{rest}", 16 if gene[m] & 1 else 0))
     rows.sort(key=lambda t: t[0])
+    umi_stage_leg.rows = rows          # the same records as a BAM file: assignumis_file_leg
     n = len(rows)
     enc = [t[1].encode() for t in rows]
     noff = np.zeros(n + 1, dtype=np.uint32)
@@ -301,6 +304,36 @@ def umi_stage_leg(pkg, synth, ctx, used, n_mol, copies=6, genes_per=10):
             "with_region": int((first["region"] >= 0).sum()), "runs": runs, "records_per_s": best["records_per_s"], "lanes_at_best": best["lanes"],
             "stages": "K-UPARSE (names, UMI windows, clustering positions), region grouping (sort on the device, chains and their refinement on the host), key sort, K-UMI, K-UCLUST "
                       "(groups <= 100 reads; larger ones on the host), K-UTAG; host arrays (page-locked) in, tags out"}
+
+
+def assignumis_file_leg(pkg, synth, ctx, rows, n_threads):
+    """`assignumis` BAM -> tagged BAMs + gene-count tables with no per-record Python (assignumis.write_tagged_bams_native): BGZF inflate and
+    record index on host threads, BamReader's chunks through smi_assignumis_chunk (device), the writer (tags, htsjdk's attribute order,
+    coordinate-comparator order per batch, gene counts) on host threads, BGZF by K-DEFLATE.  Input: the records of the UMI leg as a BAM with
+    1,200-base reads and minimap2's aux fields, BGZF-compressed by the host at level 1.  Never part of `value`."""
+    lib = importlib.import_module(graft.PKG_NAME + ".lib")
+    au = importlib.import_module(graft.PKG_NAME + ".assignumis")
+    rows = [(max(p, 0) + 1_000_000, nm, fl) for p, nm, fl in rows]
+    t0 = time.perf_counter()
+    raw = synth.bam_from_rows(rows)
+    data = lib.bgzf_deflate(raw, level=1, n_threads=n_threads).tobytes()
+    gen_s = time.perf_counter() - t0
+    gc = lib.GeneCounts()
+    au.write_tagged_bams_native(ctx, data, n_threads=n_threads, chunk_size=250_000)       # warm-up (allocations, first launches)
+    best = None
+    for _ in range(2):
+        gc.close()
+        gc = lib.GeneCounts()
+        z_bc, z_umi, info = au.write_tagged_bams_native(ctx, data, n_threads=n_threads, chunk_size=250_000, gene_counts=gc)
+        if best is None or info["wall_s"] < best[2]["wall_s"]:
+            best = (len(z_bc), len(z_umi), info)
+    n_bc, n_umi, info = best
+    res = {"records": info["records"], "clustered": info["clustered"], "batches": info["batches"], "wall_s": info["wall_s"],
+           "records_per_s": info["records"] / info["wall_s"], "seconds": info["seconds"], "bam_in_bytes": len(data), "bam_inflated_bytes": info["bam_bytes"],
+           "bam_out_bytes": n_bc, "umifound_out_bytes": n_umi, "gene_count_entries": gc.info()["region_entries"], "host_threads": n_threads,
+           "generate_input_s": gen_s, "note": "chunk size 250,000 records as shipped (config.xml:78); the whole input is one chromosome"}
+    gc.close()
+    return res
 
 
 def host_to_host_leg(pkg, synth, ctx, dev, used, n):
@@ -1010,6 +1043,9 @@ def main():
         res["umi_stage"] = umi_stage_leg(pkg, synth, ctx, used, args.umi_molecules)
         r_umi = res["umi_stage"]["records_per_s"]
         res["value_bc_umi"] = n / (ms_per_step * 1e-3 + n_found / r_umi)
+        if args.assignumis_file_records > 0:
+            rows = umi_stage_leg.rows[:args.assignumis_file_records]
+            res["assignumis_file_to_file"] = assignumis_file_leg(pkg, synth, ctx, rows, n_threads=16)
     if world == 1 and args.h2h_reads > 0:
         res["host_to_host"] = host_to_host_leg(pkg, synth, ctx, dev, used, args.h2h_reads)
         res["value_host_to_host"] = res["host_to_host"]["reads_per_s"]

@@ -547,13 +547,20 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
     """write_tagged_bams with no per-record work in Python: BGZF inflate + record index (host threads), per BamReader chunk
     smi_bam_chunk_inputs -> smi_assignumis_chunk (device), smi_gene_tag_bam, per written batch smi_bam_write_batch (host threads), BGZF by
     K-DEFLATE.  -> (bcfound BAM bytes, umifound BAM bytes, info dict).  The same bytes as write_tagged_bams."""
+    import time
+
+    t0 = time.perf_counter()
+    secs = dict(inflate_index=0.0, gene_tagger=0.0, chunk_inputs=0.0, umi_stage=0.0, write_batch=0.0, bgzf=0.0)
     _text, refs, bam, recs = load_bam(data, n_threads=n_threads)
+    secs["inflate_index"] = time.perf_counter() - t0
     n = int(recs.size)
     gene = None
     if refflat is not None:
+        t1 = time.perf_counter()
         tagger = _lib.GeneTagger(refflat, [nm for nm, _ in refs])
         gene = tagger.tag_bam_raw(bam, recs)
         tagger.close()
+        secs["gene_tagger"] = time.perf_counter() - t1
     header_end = int(recs[0]["rec_off"]) if n else bam.size
     parts_bc, parts_umi = [bam[:header_end]], [bam[:header_end]]
     tags = np.zeros(max(n, 1), dtype=_lib.UMI_TAG_DTYPE)
@@ -571,9 +578,14 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
 
     def flush(cur, keep):
         nonlocal region_base, n_clustered, n_batches
+        t1 = time.perf_counter()
         inp = _lib.bam_chunk_inputs(bam, recs, cur)
+        t2 = time.perf_counter()
         out, n_done = ctx.assignumis_chunk_raw(inp, keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
                                                five_prime=five_prime, cluster_cfg=cluster_cfg)
+        t3 = time.perf_counter()
+        secs["chunk_inputs"] += t2 - t1
+        secs["umi_stage"] += t3 - t2
         done = cur[:n_done]
         tags[done] = out[:n_done]
         reg = out["region"][:n_done].astype(np.int64)
@@ -585,6 +597,7 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         parts_bc.append(bc)
         parts_umi.append(umi)
         n_batches += 1
+        secs["write_batch"] += time.perf_counter() - t3
         return cur[n_done:]
 
     start = 0
@@ -599,7 +612,11 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         z = lambda parts: ctx.bgzf_deflate_device(np.concatenate(parts)).tobytes()  # noqa: E731
     else:
         z = lambda parts: _lib.bgzf_deflate(np.concatenate(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
-    return z(parts_bc), z(parts_umi), dict(records=n, clustered=n_clustered, batches=n_batches, tags=tags, region=region)
+    t1 = time.perf_counter()
+    z_bc, z_umi = z(parts_bc), z(parts_umi)
+    secs["bgzf"] = time.perf_counter() - t1
+    return z_bc, z_umi, dict(records=n, clustered=n_clustered, batches=n_batches, tags=tags, region=region, seconds=secs,
+                             wall_s=time.perf_counter() - t0, bam_bytes=int(bam.size))
 
 
 def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, **kw):

@@ -395,3 +395,31 @@ def fastq_text_device(rd, chimera_frac=0.0, seed=11):
         torch.repeat_interleave(rec_off[:-1] + 11, lens)
     text[pos] = buf
     return text, buf, offs
+
+
+def bam_from_rows(rows, ref_names=("chr1",), read_len=1200, seed=0):
+    """test / bench input: an uncompressed BAM stream (SAM specification 4.2) of mapped records -- rows: (0-based position, read name, FLAG)
+    on the first reference, one `read_len`M operation, random bases and qualities, the aux fields minimap2 writes (NM ms AS nn tp cm s1 s2
+    de rl, in its order).  -> bytes"""
+    import struct
+
+    rng = np.random.default_rng(seed)
+    text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{r}\tLN:250000000\n" for r in ref_names)
+    out = [b"BAM\1", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(ref_names))]
+    for r in ref_names:
+        out.append(struct.pack("<i", len(r) + 1) + r.encode() + b"\0" + struct.pack("<i", 250000000))
+    seq = rng.integers(0, 256, (read_len + 1) // 2, dtype=np.uint8).tobytes()      # packed 4-bit bases: any nibble is a valid code
+    qual = rng.integers(2, 50, read_len, dtype=np.uint8).tobytes()
+    cigar = struct.pack("<I", (read_len << 4) | 0)
+    for pos, name, flag in rows:
+        nm = name.encode() + b"\0"
+        aux = (b"NMi" + struct.pack("<i", int(rng.integers(0, 90))) + b"msi" + struct.pack("<i", 900) + b"ASi" + struct.pack("<i", 880) + b"nni\0\0\0\0" +
+               b"tpAP" + b"cmi" + struct.pack("<i", 120) + b"s1i" + struct.pack("<i", 700) + b"s2i\0\0\0\0" + b"def" + struct.pack("<f", 0.05) + b"rli\0\0\0\0")
+        b, e = 0, pos + read_len - 1                                          # reg2bin (SAM specification 5.3)
+        for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+            if pos >> shift == e >> shift:
+                b = base + (pos >> shift)
+                break
+        body = struct.pack("<iiBBHHHiiii", 0, int(pos), len(nm), 60, b & 0xFFFF, 1, int(flag), read_len, -1, -1, 0) + nm + cigar + seq + qual + aux
+        out.append(struct.pack("<i", len(body)) + body)
+    return b"".join(out)
