@@ -403,6 +403,8 @@ def bam_from_rows(rows, ref_names=("chr1",), read_len=1200, seed=0):
     de rl, in its order).  -> bytes"""
     import struct
 
+    import numpy as np
+
     rng = np.random.default_rng(seed)
     text = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{r}\tLN:250000000\n" for r in ref_names)
     out = [b"BAM\1", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(ref_names))]
