@@ -809,6 +809,8 @@ int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_bam_record *
 int smi_bam_chunk_inputs(const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, const int32_t *idx, int32_t n, char *names,
                          uint32_t *name_off, uint32_t *cigars, uint32_t *cigar_off, uint16_t *flags, int32_t *pos0, size_t *n_name_bytes,
                          size_t *n_cigar_ops);
+/* nth[i] = 1 when a record of the same read name comes earlier in recs (isNthRecordForRead, OneNanoporeSeqAnalyzer.java:L74-80) */
+int smi_bam_name_seen(const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, uint8_t *nth);
 
 /* ---- <out>.genecounts.tsv / <out>.UMIdepths.tsv of assignumis (host only) -----------------------------------------------------------------
  * Replaces GeneCounts (FJ!umifinder/scanstats/GeneCounts.java:L58-652).

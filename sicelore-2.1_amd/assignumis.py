@@ -565,14 +565,7 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
     parts_bc, parts_umi = [bam[:header_end]], [bam[:header_end]]
     tags = np.zeros(max(n, 1), dtype=_lib.UMI_TAG_DTYPE)
     region = np.full(max(n, 1), -1, dtype=np.int64)
-    nth = np.zeros(max(n, 1), dtype=np.uint8)
-    if gene_counts is not None and n:       # a record of this read name went through the analyzer before (BAM order)
-        nm_len = recs["l_read_name"].astype(np.int64) - 1
-        keys = [bam[int(o):int(o) + int(k)].tobytes() for o, k in zip(recs["name_off"], nm_len)]
-        seen = set()
-        for i, k in enumerate(keys):
-            nth[i] = k in seen
-            seen.add(k)
+    nth = _lib.bam_name_seen(bam, recs) if gene_counts is not None and n else np.zeros(max(n, 1), dtype=np.uint8)
     region_base, n_clustered, n_batches = 0, 0, 0
     cur = np.zeros(0, dtype=np.int32)
 

@@ -19,7 +19,9 @@
 #include <atomic>
 #include <cstring>
 #include <string>
+#include <string_view>
 #include <thread>
+#include <unordered_set>
 #include <vector>
 
 #include "smi_internal.h"
@@ -592,5 +594,26 @@ extern "C" int smi_bam_chunk_inputs(const uint8_t *bam, size_t n_bam, const smi_
     }
     *n_name_bytes = nb;
     *n_cigar_ops = nc;
+    return SMI_OK;
+}
+
+// nth[i] = 1 when a record with the same read name comes earlier in recs (OneNanoporeSeqAnalyzer.call L74-80: the read's statistics object
+// exists already, so this is a further record of the read -- isNthRecordForRead)
+extern "C" int smi_bam_name_seen(const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, uint8_t *nth) {
+    if (!bam || !recs || !nth || n < 0) {
+        set_error("smi_bam_name_seen: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    std::unordered_set<std::string_view> seen;
+    seen.reserve((size_t)n * 2);
+    for (int32_t i = 0; i < n; i++) {
+        const smi_bam_record &r = recs[i];
+        if (r.name_off + r.l_read_name > n_bam) {
+            set_error("smi_bam_name_seen: a record index entry points outside the BAM buffer");
+            return SMI_ERR_INVALID;
+        }
+        const std::string_view nm((const char *)bam + r.name_off, r.l_read_name ? r.l_read_name - 1u : 0u);
+        nth[i] = seen.insert(nm).second ? 0 : 1;
+    }
     return SMI_OK;
 }

@@ -61,7 +61,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into",
-    "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs",
+    "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen",
 ]
 
 
@@ -361,6 +361,17 @@ def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, trunc
     if rc:
         raise SmiError(lib.smi_last_error().decode())
     return out_bc[:nb.value], out_umi[:nu.value], order[:batch.size]
+
+
+def bam_name_seen(bam, recs):
+    """uint8 per record: a record of the same read name comes earlier (smi_bam_name_seen)"""
+    lib = load_library()
+    recs = np.ascontiguousarray(recs)
+    out = np.zeros(max(int(recs.size), 1), dtype=np.uint8)
+    lib.smi_bam_name_seen.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
+    if lib.smi_bam_name_seen(_ptr(bam), bam.size, _ptr(recs), int(recs.size), _ptr(out)):
+        raise SmiError(lib.smi_last_error().decode())
+    return out
 
 
 def bam_chunk_inputs(bam, recs, idx):

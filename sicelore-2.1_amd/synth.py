@@ -410,10 +410,13 @@ def bam_from_rows(rows, ref_names=("chr1",), read_len=1200, seed=0):
     out = [b"BAM\1", struct.pack("<i", len(text)), text.encode(), struct.pack("<i", len(ref_names))]
     for r in ref_names:
         out.append(struct.pack("<i", len(r) + 1) + r.encode() + b"\0" + struct.pack("<i", 250000000))
-    seq = rng.integers(0, 256, (read_len + 1) // 2, dtype=np.uint8).tobytes()      # packed 4-bit bases: any nibble is a valid code
-    qual = rng.integers(2, 50, read_len, dtype=np.uint8).tobytes()
+    half = (read_len + 1) // 2
+    codes = np.array([1, 2, 4, 8], dtype=np.uint8)                                   # A C G T as 4-bit codes, two per byte
+    pairs = codes[rng.integers(0, 4, (len(rows), half))] << 4 | codes[rng.integers(0, 4, (len(rows), half))]
+    quals = rng.integers(2, 50, (len(rows), read_len), dtype=np.uint8)
     cigar = struct.pack("<I", (read_len << 4) | 0)
-    for pos, name, flag in rows:
+    for k, (pos, name, flag) in enumerate(rows):
+        seq, qual = pairs[k].tobytes(), quals[k].tobytes()
         nm = name.encode() + b"\0"
         aux = (b"NMi" + struct.pack("<i", int(rng.integers(0, 90))) + b"msi" + struct.pack("<i", 900) + b"ASi" + struct.pack("<i", 880) + b"nni\0\0\0\0" +
                b"tpAP" + b"cmi" + struct.pack("<i", 120) + b"s1i" + struct.pack("<i", 700) + b"s2i\0\0\0\0" + b"def" + struct.pack("<f", 0.05) + b"rli\0\0\0\0")
