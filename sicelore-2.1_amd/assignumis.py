@@ -546,7 +546,7 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
                              gene_counts=None, max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None):
     """write_tagged_bams with no per-record work in Python: BGZF inflate + record index (host threads), per BamReader chunk
     smi_bam_chunk_inputs -> smi_assignumis_chunk (device), smi_gene_tag_bam, per written batch smi_bam_write_batch (host threads), BGZF by
-    K-DEFLATE.  -> (bcfound BAM bytes, umifound BAM bytes, info dict).  The same bytes as write_tagged_bams."""
+    K-DEFLATE.  -> (bcfound BAM, umifound BAM -- numpy uint8 arrays --, info dict).  The same bytes as write_tagged_bams."""
     import time
 
     t0 = time.perf_counter()
@@ -562,7 +562,11 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         tagger.close()
         secs["gene_tagger"] = time.perf_counter() - t1
     header_end = int(recs[0]["rec_off"]) if n else bam.size
-    parts_bc, parts_umi = [bam[:header_end]], [bam[:header_end]]
+    cap = header_end + (_lib.bam_write_bound(recs) if n else 0)
+    buf_bc, buf_umi = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)     # both outputs are written in place, batch behind batch
+    buf_bc[:header_end] = bam[:header_end]
+    buf_umi[:header_end] = bam[:header_end]
+    at_bc = at_umi = header_end
     tags = np.zeros(max(n, 1), dtype=_lib.UMI_TAG_DTYPE)
     region = np.full(max(n, 1), -1, dtype=np.int64)
     nth = _lib.bam_name_seen(bam, recs) if gene_counts is not None and n else np.zeros(max(n, 1), dtype=np.uint8)
@@ -570,7 +574,7 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
     cur = np.zeros(0, dtype=np.int32)
 
     def flush(cur, keep):
-        nonlocal region_base, n_clustered, n_batches
+        nonlocal region_base, n_clustered, n_batches, at_bc, at_umi
         t1 = time.perf_counter()
         inp = _lib.bam_chunk_inputs(bam, recs, cur)
         t2 = time.perf_counter()
@@ -586,9 +590,10 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         region_base += int(reg.max()) + 1 if n_done and reg.max() >= 0 else 0
         n_clustered += int(((out["flags"][:n_done] & _lib.UMI_CLUSTERED) != 0).sum())
         bc, umi, _order = _lib.bam_write_batch(bam, recs, done, tags, gene=gene, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate_read_name,
-                                               five_prime=five_prime, n_threads=n_threads, gene_counts=gene_counts, region=region, nth_record=nth)
-        parts_bc.append(bc)
-        parts_umi.append(umi)
+                                               five_prime=five_prime, n_threads=n_threads, gene_counts=gene_counts, region=region, nth_record=nth,
+                                               out_bc=buf_bc[at_bc:], out_umi=buf_umi[at_umi:])
+        at_bc += bc.size
+        at_umi += umi.size
         n_batches += 1
         secs["write_batch"] += time.perf_counter() - t3
         return cur[n_done:]
@@ -602,29 +607,35 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         while cur.size:
             cur = flush(cur, False)
     if bgzf == "device":
-        z = lambda parts: ctx.bgzf_deflate_device(np.concatenate(parts)).tobytes()  # noqa: E731
+        z = lambda a: ctx.bgzf_deflate_device(a)  # noqa: E731
     else:
-        z = lambda parts: _lib.bgzf_deflate(np.concatenate(parts), level=compress_level, n_threads=n_threads).tobytes()  # noqa: E731
+        z = lambda a: _lib.bgzf_deflate(a, level=compress_level, n_threads=n_threads)  # noqa: E731
     t1 = time.perf_counter()
-    z_bc, z_umi = z(parts_bc), z(parts_umi)
+    z_bc, z_umi = z(buf_bc[:at_bc]), z(buf_umi[:at_umi])                                 # numpy uint8 arrays (bytes(...) / tofile)
     secs["bgzf"] = time.perf_counter() - t1
     return z_bc, z_umi, dict(records=n, clustered=n_clustered, batches=n_batches, tags=tags, region=region, seconds=secs,
                              wall_s=time.perf_counter() - t0, bam_bytes=int(bam.size))
 
 
-def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, **kw):
+def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, native=True, **kw):
     """`assignumis -i in.bam -o out`: writes <out>.bam, <out>_umifound_.bam, <out>.genecounts.tsv and <out>.UMIdepths.tsv
-    (UmiFinderWorker.java:L142-143, L188-189) -> dict of what was written.  kw: as write_tagged_bams (refflat = text of --annotationFile)."""
+    (UmiFinderWorker.java:L142-143, L188-189) -> dict of what was written.  native: through write_tagged_bams_native (host threads + device,
+    no per-record Python) or through the Python mirror write_tagged_bams; the files are the same.  kw: as those (refflat = text of
+    --annotationFile)."""
     with open(in_bam, "rb") as f:
         data = f.read()
     gc = _lib.GeneCounts()
-    bc_bam, umi_bam, names, tags = write_tagged_bams(ctx, data, gene_counts=gc, **kw)
+    if native:
+        bc_bam, umi_bam, info = write_tagged_bams_native(ctx, data, gene_counts=gc, **kw)
+        n_records, n_clustered = info["records"], info["clustered"]
+    else:
+        bc_bam, umi_bam, names, tags = write_tagged_bams(ctx, data, gene_counts=gc, **kw)
+        n_records, n_clustered = len(names), sum(1 for t in tags if t is not None and not t.get("skipped"))
     texts = {".bam": bc_bam, "_umifound_.bam": umi_bam, ".genecounts.tsv": gc.genecounts_tsv(bc_length).encode(),
              ".UMIdepths.tsv": gc.umi_depths_tsv().encode()}
     for suffix, body in texts.items():
         with open(out_prefix + suffix, "wb") as f:
-            f.write(body)
+            f.write(bytes(body) if isinstance(body, np.ndarray) and body.size < (1 << 20) else body)
     info = gc.info()
     gc.close()
-    return dict(records=len(names), clustered=sum(1 for t in tags if t is not None and not t.get("skipped")), **info,
-                files={out_prefix + k: len(v) for k, v in texts.items()})
+    return dict(records=n_records, clustered=n_clustered, **info, files={out_prefix + k: len(v) for k, v in texts.items()})

@@ -333,11 +333,18 @@ class BamWriteConfig(ctypes.Structure):
     _fields_ = [("bc_edit_limit", ctypes.c_int32), ("truncate_read_name", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("n_threads", ctypes.c_int32)]
 
 
+def bam_write_bound(recs, batch=None):
+    """upper bound of the bytes smi_bam_write_batch writes for these records (every tag this step can add is below 420 bytes per record)"""
+    ln = recs["rec_len"] if batch is None else recs["rec_len"][batch]
+    return int(ln.sum()) + 420 * int(ln.size) + 64
+
+
 def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, truncate_read_name=False, five_prime=False, n_threads=4,
-                    gene_counts=None, region=None, nth_record=None):
+                    gene_counts=None, region=None, nth_record=None, out_bc=None, out_umi=None):
     """smi_bam_write_batch: the records `batch` (indices into recs) of an inflated BAM -> (bytes of <out>.bam, bytes of <out>_umifound_.bam,
     write order).  tags: UMI_TAG_DTYPE array indexed like recs; gene: (buffer, offsets) of GeneTagger.tag_bam_raw or None; gene_counts: a
-    GeneCounts fed in write order (region int64 / nth_record uint8 indexed like recs)."""
+    GeneCounts fed in write order (region int64 / nth_record uint8 indexed like recs).  out_bc / out_umi: uint8 arrays to write into (the
+    returned arrays are views of them)."""
     lib = load_library()
     recs = np.ascontiguousarray(recs)
     batch = np.ascontiguousarray(batch, dtype=np.int32)
@@ -350,12 +357,13 @@ def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, trunc
     if gene_counts is not None:
         region = np.ascontiguousarray(region, dtype=np.int64)
         nth_record = np.ascontiguousarray(nth_record, dtype=np.uint8)
-    cap = int(recs["rec_len"][batch].sum()) + 420 * int(batch.size) + 64          # every tag this step can add is below 420 bytes per record
-    out_bc, out_umi = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)
+    if out_bc is None:
+        cap = bam_write_bound(recs, batch)
+        out_bc, out_umi = np.empty(cap, dtype=np.uint8), np.empty(cap, dtype=np.uint8)
     order = np.zeros(max(batch.size, 1), dtype=np.int32)
     nb, nu = ctypes.c_size_t(0), ctypes.c_size_t(0)
     rc = lib.smi_bam_write_batch(_ptr(bam), bam.size, _ptr(recs), _ptr(batch), int(batch.size), _ptr(tags), _ptr(gbuf), _ptr(goff), ctypes.byref(cfg),
-                                 _ptr(out_bc), cap, ctypes.byref(nb), _ptr(out_umi), cap, ctypes.byref(nu), _ptr(order),
+                                 _ptr(out_bc), out_bc.size, ctypes.byref(nb), _ptr(out_umi), out_umi.size, ctypes.byref(nu), _ptr(order),
                                  None if gene_counts is None else gene_counts._h, _ptr(region) if gene_counts is not None else None,
                                  _ptr(nth_record) if gene_counts is not None else None)
     if rc:
