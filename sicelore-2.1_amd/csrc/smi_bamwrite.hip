@@ -364,6 +364,10 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
         const size_t lo = (size_t)n_batch * (size_t)t / (size_t)nt, hi = (size_t)n_batch * (size_t)(t + 1) / (size_t)nt;
         Attributes at;
         ScanName d;
+        size_t bound = 64;
+        for (size_t k = lo; k < hi; k++) bound += (size_t)recs[order[k]].rec_len + 420;
+        pc.bc.reserve(bound);  // no re-allocation while the piece grows
+        pc.umi.reserve(bound);
         for (size_t k = lo; k < hi; k++) {
             const int32_t i = order[k];
             const smi_bam_record &r = recs[i];
@@ -525,12 +529,21 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
         set_error("smi_bam_write_batch: output buffer too small");
         return SMI_ERR_INVALID;
     }
-    size_t ab = 0, au = 0;
-    for (const Piece &pc : pieces) {
-        if (out_bc) std::memcpy(out_bc + ab, pc.bc.data(), pc.bc.size());
-        if (out_umi) std::memcpy(out_umi + au, pc.umi.data(), pc.umi.size());
-        ab += pc.bc.size();
-        au += pc.umi.size();
+    {  // every thread copies its own piece to its place (the pages of a fresh output buffer are touched in parallel, too)
+        std::vector<size_t> ab((size_t)nt + 1, 0), au((size_t)nt + 1, 0);
+        for (int t = 0; t < nt; t++) {
+            ab[(size_t)t + 1] = ab[(size_t)t] + pieces[(size_t)t].bc.size();
+            au[(size_t)t + 1] = au[(size_t)t] + pieces[(size_t)t].umi.size();
+        }
+        auto place = [&](int t) {
+            const Piece &pc = pieces[(size_t)t];
+            if (out_bc) std::memcpy(out_bc + ab[(size_t)t], pc.bc.data(), pc.bc.size());
+            if (out_umi) std::memcpy(out_umi + au[(size_t)t], pc.umi.data(), pc.umi.size());
+        };
+        std::vector<std::thread> copiers;
+        for (int t = 1; t < nt; t++) copiers.emplace_back(place, t);
+        place(0);
+        for (auto &t : copiers) t.join();
     }
     if (gc && tr && out_bc) {  // counted once, with the bytes (a size query does not count)
         std::vector<const char *> g(tr);
