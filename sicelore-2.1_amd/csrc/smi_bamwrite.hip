@@ -325,7 +325,8 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
     }
     for (int32_t k = 0; k < n_batch; k++) {
         const smi_bam_record &r = recs[batch[k]];
-        if (r.aux_off + r.aux_len > n_bam || r.name_off + r.l_read_name > n_bam || r.cigar_off + 4ull * r.n_cigar > n_bam) {
+        if (r.aux_off + r.aux_len > n_bam || r.name_off + r.l_read_name > n_bam || r.cigar_off + 4ull * r.n_cigar > n_bam ||
+            r.name_off != r.rec_off + 36 || r.aux_off < r.name_off + r.l_read_name + 4ull * r.n_cigar) {  // the layout smi_bam_index_records reports
             set_error("smi_bam_write_batch: a record index entry points outside the BAM buffer");
             return SMI_ERR_INVALID;
         }
