@@ -112,11 +112,13 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None, resident_bytes=96 << 30):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
     "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads.
+    resident_bytes: with gz="device" a file's text is uploaded ONCE, when it has been inflated, and stays in HBM for both passes (the chunk
+    workers take device pointers) until this many bytes are held; files beyond that are uploaded per pass from the host as before.
     With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
     exchanges are the pass-1 histogram (one all-reduce, then the same finalize on every rank), the records in front of each rank (read ids),
     and the counters behind the two TSVs and the statistics, which rank 0 writes.  Every rank writes the output files of its own inputs; the
@@ -170,12 +172,22 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
         return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
 
+    held = [0]
+
     def load_and_count(fi):
         t1 = time.perf_counter()
         t, owner = _inflate(os.path.join(in_dir, files[fi]), pinned=pinned_text)
         owners[fi] = owner
-        cuts = _cut_chunks(t, reads_per_chunk)
         cpu_inflate[fi] = time.perf_counter() - t1
+        if on_device and held[0] + t.size <= resident_bytes:
+            held[0] += t.size                                 # (threads race for the last bytes of the budget; it is a soft limit)
+            td = torch.from_numpy(t).to(dev)                  # one upload; both passes read it from HBM
+            if owner is not None:
+                owner.close()
+                owners[fi] = None
+            cuts = device_cuts(td)
+            return td, cuts, [with_lane(p1)(td, rng) for rng in cuts]
+        cuts = _cut_chunks(t, reads_per_chunk)
         return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
 
     def device_cuts(t):
@@ -348,7 +360,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
     return {"rank": rank, "ranks": world, "files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
-            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(int(t.numel()) if hasattr(t, "numel") else int(t.size) for t in texts)), "files_inflated_on_device": n_on_device,
+            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(int(t.numel()) if hasattr(t, "numel") else int(t.size) for t in texts)), "files_inflated_on_device": n_on_device, "text_resident_bytes": int(held[0]),
             "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
             "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
             "write_files_s": t_write, "workers": n_workers, "gz": (gz if compress else None), "gz_level": gz_level if compress and not on_device else None}

@@ -25,8 +25,8 @@ def _canon(text):
     return sorted(recs)
 
 
-@pytest.mark.parametrize("gz,inflate", [("device", "host"), ("zlib", "host"), ("device", "device")])
-def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, inflate):
+@pytest.mark.parametrize("gz,inflate,resident", [("device", "host", 96 << 30), ("zlib", "host", 0), ("device", "device", 0), ("device", "host", 12_000_000)])
+def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, inflate, resident):
     from sicelore_amd import lib as libmod
 
     run_files = importlib.import_module("sicelore_amd.run_files")
@@ -36,8 +36,14 @@ def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, in
     keys = np.sort(wl.cpu().numpy().astype(np.uint64))
     in_dir, out_dir = str(tmp_path / "in"), str(tmp_path / "out")
     n = run_files.write_synthetic_dir(synth, in_dir, 6, 2500, used, dev, seed=810, chimera_frac=0.08)
-    info = run_files.run(gpu_ctx, in_dir, out_dir, max_ed=1, n_workers=4, reads_per_chunk=1000, whitelist_keys=keys, gz=gz, inflate=inflate)
+    info = run_files.run(gpu_ctx, in_dir, out_dir, max_ed=1, n_workers=4, reads_per_chunk=1000, whitelist_keys=keys, gz=gz, inflate=inflate,
+                         resident_bytes=resident)
     assert info["files_inflated_on_device"] == (6 if inflate == "device" else 0)
+    # the text of host-inflated files stays in HBM between the passes while the budget lasts (all of it / none / about two files of six)
+    if inflate == "host" and gz == "device":
+        assert (info["text_resident_bytes"] == info["text_in_bytes"]) if resident > (1 << 30) else (0 < info["text_resident_bytes"] < 0.7 * info["text_in_bytes"])
+    else:
+        assert info["text_resident_bytes"] == 0
     assert info["gz"] == gz and info["gz_out_bytes"] < 0.7 * info["text_out_bytes"]
     assert info["reads"] == n and info["files"] == 6 and info["chunks"] >= 12 and info["passed"] > 0.8 * n
     # the same reads through single calls of the chunk workers (text form), file by file
