@@ -303,12 +303,12 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         cnt = np.zeros((k.size, 3), dtype=np.int64)
         if ok.any():
             np.add.at(cnt, (np.searchsorted(rk_keys, bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)), 1)
-        if on_device:
-            zp, zf = bytes(passed), bytes(failed)      # gzip members already
-        elif compress:
+        if compress and not on_device:
             zp, zf = _gzip_member(memoryview(passed), gz_level), _gzip_member(memoryview(failed), gz_level)
         else:
-            zp, zf = bytes(passed), bytes(failed)
+            # (gzip members already with gz="device")  the lane's buffers are reused by its next call: a copy, made by numpy, which lets
+            # the other worker threads run meanwhile (bytes() would hold the interpreter lock for the whole memcpy)
+            zp, zf = np.array(passed, dtype=np.uint8, copy=True), np.array(failed, dtype=np.uint8, copy=True)
         return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(info["passed_text_bytes"]), int(info["failed_text_bytes"]), info.get("stats")
 
     results = list(pool.map(lambda j: with_lane(p2)(j), range(len(chunks))))
