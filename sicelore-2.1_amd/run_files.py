@@ -173,15 +173,35 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
 
     held = [0]
+    import threading
+
+    staging = threading.local()          # one page-locked buffer per worker thread, reused from file to file
+    staged = []
+
+    def stage_alloc(n):
+        """where a file that will live in HBM is inflated to: the thread's page-locked buffer (uploads from it run at link speed and side by side
+        on all threads; pageable memory goes through the runtime's one staging path)"""
+        pb = getattr(staging, "pb", None)
+        if pb is None or pb.array.size < n:
+            # (an outgrown buffer is freed with the others at the end of pass 1: gz_inflate still copies out of it when it grows)
+            pb = _lib.PinnedBuffer(max(int(n * 1.25), 1 << 20))
+            staging.pb = pb
+            staged.append(pb)
+        return pb.array[:n], None
 
     def load_and_count(fi):
         t1 = time.perf_counter()
-        t, owner = _inflate(os.path.join(in_dir, files[fi]), pinned=pinned_text)
+        path = os.path.join(in_dir, files[fi])
+        resident = on_device and held[0] + 3 * os.path.getsize(path) <= resident_bytes     # (a soft limit: the threads race for its last bytes)
+        if resident and path.endswith(".gz"):
+            t, owner = _lib.gz_inflate(np.fromfile(path, dtype=np.uint8), alloc=stage_alloc)
+        else:
+            t, owner = _inflate(path, pinned=pinned_text)
         owners[fi] = owner
         cpu_inflate[fi] = time.perf_counter() - t1
-        if on_device and held[0] + t.size <= resident_bytes:
-            held[0] += t.size                                 # (threads race for the last bytes of the budget; it is a soft limit)
-            td = torch.from_numpy(t).to(dev)                  # one upload; both passes read it from HBM
+        if resident:
+            held[0] += t.size
+            td = torch.from_numpy(t).to(dev)                  # one upload; both passes read the text from HBM
             if owner is not None:
                 owner.close()
                 owners[fi] = None
@@ -253,6 +273,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     else:
         loaded = list(pool.map(load_and_count, range(len(files))))
     torch.cuda.synchronize()
+    for pb in staged:
+        pb.close()
     texts = [t for t, _, _ in loaded]
     chunks, n_rec = [], []  # (file index, chunk index in file, byte range); records per chunk
     for fi, (_, cuts, recs) in enumerate(loaded):
