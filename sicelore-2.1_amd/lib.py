@@ -187,6 +187,7 @@ def load_library():
     lib.smi_bam_write_batch.argtypes = [vp, sz, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, sz, ctypes.POINTER(sz), vp, sz, ctypes.POINTER(sz), vp,
                                         vp, vp, vp]
     lib.smi_bam_chunk_inputs.argtypes = [vp, sz, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+    lib.smi_bam_name_seen.argtypes = [vp, sz, vp, ctypes.c_int32, vp]
     lib.smi_gene_counts_create.argtypes = [ctypes.POINTER(vp)]
     lib.smi_gene_counts_free.argtypes = [vp]
     lib.smi_gene_counts_add.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
@@ -376,7 +377,6 @@ def bam_name_seen(bam, recs):
     lib = load_library()
     recs = np.ascontiguousarray(recs)
     out = np.zeros(max(int(recs.size), 1), dtype=np.uint8)
-    lib.smi_bam_name_seen.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p]
     if lib.smi_bam_name_seen(_ptr(bam), bam.size, _ptr(recs), int(recs.size), _ptr(out)):
         raise SmiError(lib.smi_last_error().decode())
     return out
