@@ -389,7 +389,7 @@ def host_to_host_leg(pkg, synth, ctx, dev, used, n):
                     "cores): ~1 M reads/s per core on this box, against 14.5 M reads/s for the text worker, which the link bounds"}
 
 
-def file_to_file_leg(pkg, synth, ctx, dev, wl, used, n_reads, scratch=None, n_files=64, workers=16):
+def file_to_file_leg(pkg, synth, ctx, dev, wl, used, n_reads, scratch=None, n_files=64, workers=int(os.environ.get("SMI_BENCH_F2F_WORKERS", "16"))):
     """`scanfastq -d <dir> -o <dir> --bcEditDistance 1 --compress` (quickrun-2.1.sh:35) on n_files synthetic *.fastq.gz, both passes, gzip
     out (K-DEFLATE on the device; beside it a quarter of the files with zlib level 6 on the host), wall clock from the first byte read to the last byte written (inputs in the page cache).  The README's figure for the
     Java reference: 20.8 k reads/s on 96 cores (README.md:106)."""
