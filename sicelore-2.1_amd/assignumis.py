@@ -617,6 +617,154 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
                              wall_s=time.perf_counter() - t0, bam_bytes=int(bam.size))
 
 
+_BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+
+
+def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
+                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16):
+    """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes, never held as a
+    whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
+    chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
+    device and appended to <out>.bam / <out>_umifound_.bam; the records ReadGrouper holds back and the unfinished chunk go in front of the
+    next segment.  Writes the four files of assignumis_files; the inflated streams and the tables equal the whole-file run's.  -> info dict"""
+    import time
+
+    t_all = time.perf_counter()
+    gc, names_seen = _lib.GeneCounts(), _lib.NameSet()
+    f_in = open(in_bam, "rb")
+    f_bc, f_umi = open(out_prefix + ".bam", "wb"), open(out_prefix + "_umifound_.bam", "wb")
+    comp_tail = np.zeros(0, dtype=np.uint8)        # compressed bytes of an incomplete block
+    pend = np.zeros(0, dtype=np.uint8)             # inflated bytes not consumed yet: pending records (+ a partial record)
+    nth_pend = np.zeros(0, dtype=np.uint8)
+    header, tagger, refs = None, None, None
+    i0, g0, prev_ref = -1, 0, None                 # global position of the last flush, global index of pend's first record, reference of the record in front
+    region_base = n_records = n_clustered = n_batches = 0
+    cur_n = 0                                      # how many of pend's leading records belong to the chunk being collected
+    step = max(int(chunk_size), 1)
+    secs = dict(read_inflate=0.0, index=0.0, umi_stage=0.0, write_batch=0.0, bgzf_write=0.0)
+
+    def emit(bc, umi):
+        t1 = time.perf_counter()
+        for fh, a in ((f_bc, bc), (f_umi, umi)):
+            if a.size:
+                z = ctx.bgzf_deflate_device(a)
+                fh.write(z[:-28])                   # without the end-of-file block: more batches follow
+        secs["bgzf_write"] += time.perf_counter() - t1
+
+    eof = False
+    while not eof or pend.size:
+        t1 = time.perf_counter()
+        raw = np.fromfile(f_in, dtype=np.uint8, count=int(segment_bytes)) if not eof else np.zeros(0, dtype=np.uint8)
+        if raw.size < segment_bytes:
+            eof = True
+        comp = np.concatenate([comp_tail, raw]) if comp_tail.size else raw
+        fresh = np.zeros(0, dtype=np.uint8)
+        if comp.size:
+            fresh, used = _lib.bgzf_inflate(comp, n_threads=n_threads)
+            comp_tail = comp[used:].copy()
+            if eof and comp_tail.size:
+                raise _lib.SmiError("truncated BGZF stream")
+        bam = np.concatenate([pend, fresh]) if pend.size else fresh
+        secs["read_inflate"] += time.perf_counter() - t1
+        start = 0
+        if header is None:
+            try:
+                _text, refs, start = _lib.bam_header(bam)
+            except _lib.SmiError:
+                if eof:
+                    raise
+                pend = bam                           # the header is not complete yet: read on
+                continue
+            header = bam[:start].copy()
+            emit(header, header)
+            if refflat is not None:
+                tagger = _lib.GeneTagger(refflat, [nm for nm, _ in refs])
+        t1 = time.perf_counter()
+        recs, end = _lib.bam_index_records(bam, start, cap=max(1, (bam.size - start) // 36))
+        if eof and end != bam.size:
+            raise _lib.SmiError("truncated BAM record")
+        m = int(recs.size)
+        nth = np.zeros(max(m, 1), dtype=np.uint8)
+        nth[:nth_pend.size] = nth_pend
+        names_seen.seen(bam, recs, nth_pend.size, nth)
+        gene = tagger.tag_bam_raw(bam, recs) if tagger is not None and m else None
+        secs["index"] += time.perf_counter() - t1
+        tags = np.zeros(max(m, 1), dtype=_lib.UMI_TAG_DTYPE)
+        region = np.full(max(m, 1), -1, dtype=np.int64)
+        ref = recs["ref_id"].astype(np.int64)
+        # the flush positions among this segment's records (local index k = global g0 + k): by count (i0 + step) or at a change of chromosome
+        change = np.flatnonzero(ref[1:] != ref[:-1]) + 1 if m > 1 else np.zeros(0, dtype=np.int64)
+        if m and prev_ref is not None and cur_n == 0 and g0 > 0 and int(ref[0]) != prev_ref:
+            change = np.concatenate([[0], change])
+        change = [int(c) for c in change if c >= cur_n]      # (changes inside the chunk being collected were flushed when they were met)
+        cur = np.arange(0, cur_n, dtype=np.int32)          # local indices of the chunk being collected (they lead pend)
+        k = cur_n                                          # next local record to append
+
+        def flush(cur, keep):
+            nonlocal region_base, n_records, n_clustered, n_batches
+            t2 = time.perf_counter()
+            inp = _lib.bam_chunk_inputs(bam, recs, cur)
+            out, n_done = ctx.assignumis_chunk_raw(inp, keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
+                                                   five_prime=five_prime, cluster_cfg=cluster_cfg)
+            t3 = time.perf_counter()
+            done = cur[:n_done]
+            tags[done] = out[:n_done]
+            reg = out["region"][:n_done].astype(np.int64)
+            region[done] = np.where(reg >= 0, reg + region_base, -1)
+            region_base += int(reg.max()) + 1 if n_done and reg.max() >= 0 else 0
+            n_clustered += int(((out["flags"][:n_done] & _lib.UMI_CLUSTERED) != 0).sum())
+            bc, umi, _o = _lib.bam_write_batch(bam, recs, done, tags, gene=gene, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate_read_name,
+                                               five_prime=five_prime, n_threads=n_threads, gene_counts=gc, region=region, nth_record=nth)
+            t4 = time.perf_counter()
+            secs["umi_stage"] += t3 - t2
+            secs["write_batch"] += t4 - t3
+            emit(bc, umi)
+            n_records += n_done
+            n_batches += 1
+            return cur[n_done:]
+
+        ci = 0
+        while True:
+            by_count = max(i0 + step, 1) - g0                # local position of the next flush by count
+            while ci < len(change) and g0 + change[ci] <= i0:
+                ci += 1
+            nxt = change[ci] if ci < len(change) else m
+            at = min(by_count, nxt)
+            if at >= m:
+                break
+            cur = flush(np.concatenate([cur, np.arange(k, at, dtype=np.int32)]), keep=(at != nxt))
+            i0, k = g0 + at, at
+        cur = np.concatenate([cur, np.arange(k, m, dtype=np.int32)])
+        if eof:
+            while cur.size:
+                cur = flush(cur, False)
+            pend = np.zeros(0, dtype=np.uint8)
+            break
+        # what stays for the next segment: the chunk being collected (contiguous records) and the bytes behind the last complete record
+        first = int(cur[0]) if cur.size else m
+        off = int(recs[first]["rec_off"]) if first < m else int(end)
+        pend = bam[off:].copy()
+        nth_pend = nth[first:m].copy()
+        cur_n = int(cur.size)
+        if m:
+            prev_ref = int(ref[m - 1])
+        g0 += first
+    for fh in (f_bc, f_umi):
+        fh.write(_BGZF_EOF)
+        fh.close()
+    f_in.close()
+    with open(out_prefix + ".genecounts.tsv", "w") as f:
+        f.write(gc.genecounts_tsv(bc_length))
+    with open(out_prefix + ".UMIdepths.tsv", "w") as f:
+        f.write(gc.umi_depths_tsv())
+    info = gc.info()
+    gc.close()
+    names_seen.close()
+    if tagger is not None:
+        tagger.close()
+    return dict(records=n_records, clustered=n_clustered, batches=n_batches, seconds=secs, wall_s=time.perf_counter() - t_all, **info)
+
+
 def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, native=True, **kw):
     """`assignumis -i in.bam -o out`: writes <out>.bam, <out>_umifound_.bam, <out>.genecounts.tsv and <out>.UMIdepths.tsv
     (UmiFinderWorker.java:L142-143, L188-189) -> dict of what was written.  native: through write_tagged_bams_native (host threads + device,

@@ -631,3 +631,36 @@ extern "C" int smi_bam_name_seen(const uint8_t *bam, size_t n_bam, const smi_bam
     }
     return SMI_OK;
 }
+
+// the same over a stream of segments: the set of read names seen so far lives in a handle; records [from, n) of this segment are looked up and
+// added (records in front of `from` were handed in with an earlier segment)
+struct smi_name_set {
+    std::unordered_set<std::string> names;
+};
+extern "C" int smi_name_set_create(smi_name_set **out) {
+    if (!out) {
+        set_error("smi_name_set_create: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *out = new smi_name_set();
+    return SMI_OK;
+}
+extern "C" int smi_name_set_free(smi_name_set *s) {
+    delete s;
+    return SMI_OK;
+}
+extern "C" int smi_name_set_seen(smi_name_set *set, const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t from, int32_t n, uint8_t *nth) {
+    if (!set || !bam || !recs || !nth || from < 0 || n < from) {
+        set_error("smi_name_set_seen: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    for (int32_t i = from; i < n; i++) {
+        const smi_bam_record &r = recs[i];
+        if (r.name_off + r.l_read_name > n_bam) {
+            set_error("smi_name_set_seen: a record index entry points outside the BAM buffer");
+            return SMI_ERR_INVALID;
+        }
+        nth[i] = set->names.emplace((const char *)bam + r.name_off, r.l_read_name ? r.l_read_name - 1u : 0u).second ? 0 : 1;
+    }
+    return SMI_OK;
+}

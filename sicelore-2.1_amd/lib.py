@@ -61,7 +61,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into",
-    "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen",
+    "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen", "smi_name_set_create", "smi_name_set_free", "smi_name_set_seen",
 ]
 
 
@@ -188,6 +188,9 @@ def load_library():
                                         vp, vp, vp]
     lib.smi_bam_chunk_inputs.argtypes = [vp, sz, vp, vp, ctypes.c_int32, vp, vp, vp, vp, vp, vp, ctypes.POINTER(sz), ctypes.POINTER(sz)]
     lib.smi_bam_name_seen.argtypes = [vp, sz, vp, ctypes.c_int32, vp]
+    lib.smi_name_set_create.argtypes = [ctypes.POINTER(vp)]
+    lib.smi_name_set_free.argtypes = [vp]
+    lib.smi_name_set_seen.argtypes = [vp, vp, sz, vp, ctypes.c_int32, ctypes.c_int32, vp]
     lib.smi_gene_counts_create.argtypes = [ctypes.POINTER(vp)]
     lib.smi_gene_counts_free.argtypes = [vp]
     lib.smi_gene_counts_add.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
@@ -380,6 +383,29 @@ def bam_name_seen(bam, recs):
     if lib.smi_bam_name_seen(_ptr(bam), bam.size, _ptr(recs), int(recs.size), _ptr(out)):
         raise SmiError(lib.smi_last_error().decode())
     return out
+
+
+class NameSet:
+    """the read names seen so far in a BAM that is read in segments (smi_name_set_*)"""
+
+    def __init__(self):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        if self._lib.smi_name_set_create(ctypes.byref(self._h)):
+            raise SmiError(self._lib.smi_last_error().decode())
+
+    def seen(self, bam, recs, start, nth):
+        """nth[start:] of this segment's records filled (1 = the name came earlier), names added"""
+        recs = np.ascontiguousarray(recs)
+        if self._lib.smi_name_set_seen(self._h, _ptr(bam), bam.size, _ptr(recs), int(start), int(recs.size), _ptr(nth)):
+            raise SmiError(self._lib.smi_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smi_name_set_free(self._h)
+            self._h = None
+
+    __del__ = close
 
 
 def bam_chunk_inputs(bam, recs, idx):

@@ -406,3 +406,15 @@ def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
         assert (gc_n.genecounts_tsv(16), gc_n.umi_depths_tsv(), gc_n.info()) == (gc_p.genecounts_tsv(16), gc_p.umi_depths_tsv(), gc_p.info())
         assert info["records"] == len(names) and info["clustered"] >= n_clustered and (info["batches"] > 3) == ("chunk_size" in kw)
     assert bammodel.bgzf_decompress(bytes(assignumis.write_tagged_bams_native(gpu_ctx, data)[0])) == raw_bc
+    # the same file read in segments (a BAM of any size): BGZF blocks, records and BamReader's chunks all straddle the segment borders
+    with tempfile.TemporaryDirectory() as td:
+        with open(os.path.join(td, "in.bam"), "wb") as f:
+            f.write(data)
+        for seg, kw in ((2_500, dict(chunk_size=37)), (20_000, dict(refflat=refflat)), (7_777, dict(chunk_size=61, truncate_read_name=True)), (1 << 20, dict())):
+            gc_w = libmod.GeneCounts()
+            wb, wu, _info = assignumis.write_tagged_bams_native(gpu_ctx, data, gene_counts=gc_w, **kw)
+            res = assignumis.assignumis_stream(gpu_ctx, os.path.join(td, "in.bam"), os.path.join(td, "s"), segment_bytes=seg, **kw)
+            assert bammodel.bgzf_decompress(open(os.path.join(td, "s.bam"), "rb").read()) == bammodel.bgzf_decompress(bytes(wb)), (seg, kw)
+            assert bammodel.bgzf_decompress(open(os.path.join(td, "s_umifound_.bam"), "rb").read()) == bammodel.bgzf_decompress(bytes(wu))
+            assert open(os.path.join(td, "s.genecounts.tsv")).read() == gc_w.genecounts_tsv(16) and open(os.path.join(td, "s.UMIdepths.tsv")).read() == gc_w.umi_depths_tsv()
+            assert res["records"] == len(names) and res["batches"] == _info["batches"]
