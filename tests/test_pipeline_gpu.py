@@ -418,3 +418,18 @@ def test_tagged_bam_output(pkg, synth, sor, gpu_ctx):
             assert bammodel.bgzf_decompress(open(os.path.join(td, "s_umifound_.bam"), "rb").read()) == bammodel.bgzf_decompress(bytes(wu))
             assert open(os.path.join(td, "s.genecounts.tsv")).read() == gc_w.genecounts_tsv(16) and open(os.path.join(td, "s.UMIdepths.tsv")).read() == gc_w.umi_depths_tsv()
             assert res["records"] == len(names) and res["batches"] == _info["batches"]
+        # three chromosomes (the end of a chromosome closes a chunk whatever its size) and an unmapped tail
+        third = len(rows) // 3
+        brecs3 = [bammodel.bam_record(nm, fl | (4 if k >= len(rows) - 5 else 0), -1 if k >= len(rows) - 5 else min(k // third, 2), -1 if k >= len(rows) - 5 else p0,
+                                      30, [] if k >= len(rows) - 5 else cg, "C" * L, aux=aux_in) for k, (p0, nm, fl, cg, L) in enumerate(rows)]
+        header3 = bammodel.bam_bytes("@HD\tVN:1.6\tSO:coordinate\n", [("chr1", 10 ** 6), ("chr2", 10 ** 6), ("chr3", 10 ** 6)], [])
+        data3 = bammodel.bgzf_compress(header3 + b"".join(brecs3), block=4096)
+        with open(os.path.join(td, "in3.bam"), "wb") as f:
+            f.write(data3)
+        for seg, kw in ((3_000, dict(chunk_size=25)), (11_000, dict()), (1 << 20, dict(chunk_size=25))):
+            gc_w = libmod.GeneCounts()
+            wb, wu, _info = assignumis.write_tagged_bams_native(gpu_ctx, data3, gene_counts=gc_w, **kw)
+            res = assignumis.assignumis_stream(gpu_ctx, os.path.join(td, "in3.bam"), os.path.join(td, "s3"), segment_bytes=seg, **kw)
+            assert bammodel.bgzf_decompress(open(os.path.join(td, "s3.bam"), "rb").read()) == bammodel.bgzf_decompress(bytes(wb)), (seg, kw)
+            assert bammodel.bgzf_decompress(open(os.path.join(td, "s3_umifound_.bam"), "rb").read()) == bammodel.bgzf_decompress(bytes(wu))
+            assert open(os.path.join(td, "s3.UMIdepths.tsv")).read() == gc_w.umi_depths_tsv() and res["batches"] == _info["batches"] >= 3
