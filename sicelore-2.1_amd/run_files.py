@@ -112,13 +112,16 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None, resident_bytes=96 << 30):
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None, resident_bytes=96 << 30,
+        host_text_bytes=256 << 30):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
     "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads.
     resident_bytes: with gz="device" a file's text is uploaded ONCE, when it has been inflated, and stays in HBM for both passes (the chunk
     workers take device pointers) until this many bytes are held; files beyond that are uploaded per pass from the host as before.
+    host_text_bytes: how much inflated text may wait in host memory between the passes; the text of files beyond that is dropped after pass 1
+    and inflated again in pass 2 (the reference reads every file twice, NanoporeReadScannerMain.java:L306) -- a run of any size.
     With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
     exchanges are the pass-1 histogram (one all-reduce, then the same finalize on every rank), the records in front of each rank (read ids),
     and the counters behind the two TSVs and the statistics, which rank 0 writes.  Every rank writes the output files of its own inputs; the
@@ -172,7 +175,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
         return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
 
-    held = [0]
+    held, held_host = [0], [0]
     import threading
 
     staging = threading.local()          # one page-locked buffer per worker thread, reused from file to file
@@ -208,7 +211,14 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             cuts = device_cuts(td)
             return td, cuts, [with_lane(p1)(td, rng) for rng in cuts]
         cuts = _cut_chunks(t, reads_per_chunk)
-        return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
+        recs_ = [with_lane(p1)(t, rng) for rng in cuts]
+        if held_host[0] + t.size > host_text_bytes:           # no room to keep it: pass 2 inflates the file again
+            if owner is not None:
+                owner.close()
+                owners[fi] = None
+            return None, cuts, recs_
+        held_host[0] += t.size
+        return t, cuts, recs_
 
     def device_cuts(t):
         """byte ranges of reads_per_chunk records each in a text that is on the device"""
@@ -315,9 +325,35 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     t0 = time.perf_counter()
     first_id = np.concatenate([[0], np.cumsum(n_rec)])[:-1] + 1 + ids_in_front
 
+    again, again_lock = {}, threading.Lock()     # file index -> [text, chunks still to come] for files whose text was dropped after pass 1
+    chunks_of = {}
+    for fi_, _, _ in chunks:
+        chunks_of[fi_] = chunks_of.get(fi_, 0) + 1
+
+    def text_of(fi):
+        if texts[fi] is not None:
+            return texts[fi]
+        with again_lock:
+            ent = again.get(fi)
+            if ent is None:
+                ent = again[fi] = [None, chunks_of[fi], threading.Lock()]
+        with ent[2]:
+            if ent[0] is None:
+                ent[0] = _inflate(os.path.join(in_dir, files[fi]))[0]
+        return ent[0]
+
+    def text_done(fi):
+        if texts[fi] is None:
+            with again_lock:
+                ent = again[fi]
+                ent[1] -= 1
+                if ent[1] == 0:
+                    del again[fi]
+
     def p2(lane, j):
         fi, ci, rng = chunks[j]
-        passed, failed, info = lane.scanfastq_pass2_chunk(texts[fi][rng[0]:rng[1]], max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya,
+        text_j = text_of(fi)[rng[0]:rng[1]]
+        passed, failed, info = lane.scanfastq_pass2_chunk(text_j, max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya,
                                                           first_read_id=int(first_id[j]), rank_keys=rk_keys, rank_values=rk_vals, want_results=True, copy=False,
                                                           packed=not on_device, n_threads=host_threads_per_call, compress=on_device)
         bc = info["bc"] if info["n_records_out"] else np.zeros(0, dtype=_lib.BC_RESULT_DTYPE)
@@ -331,6 +367,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             # (gzip members already with gz="device")  the lane's buffers are reused by its next call: a copy, made by numpy, which lets
             # the other worker threads run meanwhile (bytes() would hold the interpreter lock for the whole memcpy)
             zp, zf = np.array(passed, dtype=np.uint8, copy=True), np.array(failed, dtype=np.uint8, copy=True)
+        text_done(fi)
         return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(info["passed_text_bytes"]), int(info["failed_text_bytes"]), info.get("stats")
 
     results = list(pool.map(lambda j: with_lane(p2)(j), range(len(chunks))))
@@ -382,7 +419,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
     return {"rank": rank, "ranks": world, "files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
-            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(int(t.numel()) if hasattr(t, "numel") else int(t.size) for t in texts)), "files_inflated_on_device": n_on_device, "text_resident_bytes": int(held[0]),
+            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(rng[1] - rng[0] for _, _, rng in chunks)), "files_inflated_twice": sum(1 for t in texts if t is None), "files_inflated_on_device": n_on_device, "text_resident_bytes": int(held[0]),
             "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
             "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
             "write_files_s": t_write, "workers": n_workers, "gz": (gz if compress else None), "gz_level": gz_level if compress and not on_device else None}
