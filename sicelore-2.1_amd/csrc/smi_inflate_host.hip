@@ -136,8 +136,9 @@ constexpr int LIT_CAP = (1 << LP) + 2048, DIST_CAP = (1 << DP) + 1024;
 // literal / length entry:  LIT: bits 0-7 code bits consumed, 8-15 first literal, 16-23 second literal (TWO)
 //                          EXC | EOB: end of block, bits 0-7 code bits
 //                          EXC: subtable, bits 0-7 = LP, 8-23 start index, 24-27 subtable bits
-//                          else a length: bits 0-7 code bits, 8-15 extra bits, 16-24 base length;  0 = no code
-// distance entry:          bits 0-7 code bits, 8-15 extra bits (0x80 | subtable bits for a subtable), 16-31 base distance / subtable start
+//                          else a length: bits 0-7 code bits + extra bits, 8-15 extra bits, 16-24 base length;  0 = no code
+// distance entry:          bits 0-7 code bits + extra bits, 8-15 extra bits (0x80 | subtable bits for a subtable), 16-31 base distance / subtable start
+// (the extra bits are read out of the buffer before ONE shift drops code and extra bits together: one shift less in the dependency chain)
 struct Tables {
     uint32_t lit[LIT_CAP];
     uint32_t dist[DIST_CAP];
@@ -223,11 +224,11 @@ inline uint32_t litlen_entry(int sym, int len) {
     if (sym < 256) return LIT | ((uint32_t)sym << 8) | (uint32_t)len;
     if (sym == 256) return EXC | EOB | (uint32_t)len;
     if (sym > 285) return 0;  // 286, 287: not valid in data (they take part in the code)
-    return ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 8) | (uint32_t)len;
+    return ((uint32_t)kLenBase[sym - 257] << 16) | ((uint32_t)kLenExtra[sym - 257] << 8) | (uint32_t)(len + kLenExtra[sym - 257]);
 }
 inline uint32_t dist_entry(int sym, int len) {
     if (sym > 29) return 0;
-    return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 8) | (uint32_t)len;
+    return ((uint32_t)kDistBase[sym] << 16) | ((uint32_t)kDistExtra[sym] << 8) | (uint32_t)(len + kDistExtra[sym]);
 }
 
 // pairs of literals in the primary table: slot i starts with a literal of l1 < LP bits; when the slot of the bits behind it is a
@@ -379,18 +380,14 @@ __attribute__((always_inline)) inline int decode_block_body(Bits &b, const Table
     uint8_t *out = out_pos;
     const uint32_t *lt = t.lit, *dt = t.dist;
     for (;;) {
-        // ---- fast: >= 16 input bytes and >= 280 output bytes of room
-        while (b.in_end - b.in >= 16 && out_end - out >= 280) {
+        // ---- fast: >= 16 input bytes and >= 280 output bytes of room.  The entry of the NEXT symbol is looked up before a match is copied
+        //      (and after a run of literals), so that the table load overlaps the copy; `e` is carried from one turn to the next
+        if (b.in_end - b.in >= 16 && out_end - out >= 280) {
             b.refill_fast();
             uint32_t e = lt[b.buf & ((1u << LP) - 1)];
-            if (e & LIT) {
-                uint16_t w = (uint16_t)(e >> 8);
-                std::memcpy(out, &w, 2);
-                out += 1 + ((e >> 30) & 1);
-                b.drop((int)(e & 0xFF));
-                e = lt[b.buf & ((1u << LP) - 1)];
+            for (;;) {
                 if (e & LIT) {
-                    w = (uint16_t)(e >> 8);
+                    uint16_t w = (uint16_t)(e >> 8);
                     std::memcpy(out, &w, 2);
                     out += 1 + ((e >> 30) & 1);
                     b.drop((int)(e & 0xFF));
@@ -400,61 +397,84 @@ __attribute__((always_inline)) inline int decode_block_body(Bits &b, const Table
                         std::memcpy(out, &w, 2);
                         out += 1 + ((e >> 30) & 1);
                         b.drop((int)(e & 0xFF));
-                        continue;
+                        e = lt[b.buf & ((1u << LP) - 1)];
+                        if (e & LIT) {
+                            w = (uint16_t)(e >> 8);
+                            std::memcpy(out, &w, 2);
+                            out += 1 + ((e >> 30) & 1);
+                            b.drop((int)(e & 0xFF));
+                            if (!(b.in_end - b.in >= 16 && out_end - out >= 280)) break;
+                            b.refill_fast();
+                            e = lt[b.buf & ((1u << LP) - 1)];
+                            continue;
+                        }
                     }
                 }
-            }
-            // not a literal: at least 56 - 22 = 34 bits are left
-            if (e & EXC) {
-                if (e & EOB) {
-                    b.drop((int)(e & 0xFF));
-                    out_pos = out;
-                    return INF_OK;
+                // not a literal: at least 56 - 22 = 34 bits are left
+                uint32_t len, dist;
+                if (e & EXC) {
+                    if (e & EOB) {
+                        b.drop((int)(e & 0xFF));
+                        out_pos = out;
+                        return INF_OK;
+                    }
+                    e = lt[((e >> 8) & 0xFFFF) + ((b.buf >> LP) & ((1u << ((e >> 24) & 15)) - 1))];
+                    if (e & LIT) {
+                        *out++ = (uint8_t)(e >> 8);
+                        b.drop((int)(e & 0xFF));
+                        if (!(b.in_end - b.in >= 16 && out_end - out >= 280)) break;
+                        b.refill_fast();
+                        e = lt[b.buf & ((1u << LP) - 1)];
+                        continue;
+                    }
+                    if (e & EXC) {  // end of block behind a long code
+                        b.drop((int)(e & 0xFF));
+                        out_pos = out;
+                        return INF_OK;
+                    }
                 }
-                e = lt[((e >> 8) & 0xFFFF) + ((b.buf >> LP) & ((1u << ((e >> 24) & 15)) - 1))];
-                if (e & LIT) {
-                    *out++ = (uint8_t)(e >> 8);
-                    b.drop((int)(e & 0xFF));
-                    continue;
+                if (!(e & 0xFF)) return INF_BAD;
+                {
+                    const int tot = (int)(e & 0xFF), xb = (int)((e >> 8) & 0xFF);
+                    len = (e >> 16) + ((uint32_t)(b.buf >> (tot - xb)) & ((1u << xb) - 1));
+                    b.drop(tot);
                 }
-                if (e & EXC) {  // end of block behind a long code
-                    b.drop((int)(e & 0xFF));
-                    out_pos = out;
-                    return INF_OK;
+                if (b.cnt < 28) b.refill_fast();  // a distance takes up to 15 + 13 bits
+                uint32_t d = dt[b.buf & ((1u << DP) - 1)];
+                if (d & 0x8000) d = dt[(d >> 16) + ((b.buf >> DP) & ((1u << ((d >> 8) & 0x7F)) - 1))];
+                if (!(d & 0xFF)) return INF_BAD;
+                {
+                    const int tot = (int)(d & 0xFF), db = (int)((d >> 8) & 0xFF);
+                    dist = (d >> 16) + ((uint32_t)(b.buf >> (tot - db)) & ((1u << db) - 1));
+                    b.drop(tot);
                 }
-            }
-            if (!(e & 0xFF)) return INF_BAD;
-            b.drop((int)(e & 0xFF));
-            const int xb = (int)((e >> 8) & 0xFF);
-            const uint32_t len = (e >> 16) + b.peek(xb);
-            b.drop(xb);
-            if (b.cnt < 28) b.refill_fast();  // a distance takes up to 15 + 13 bits
-            uint32_t d = dt[b.buf & ((1u << DP) - 1)];
-            if (d & 0x8000) d = dt[(d >> 16) + ((b.buf >> DP) & ((1u << ((d >> 8) & 0x7F)) - 1))];
-            if (!(d & 0xFF)) return INF_BAD;
-            b.drop((int)(d & 0xFF));
-            const int db = (int)((d >> 8) & 0xFF);
-            const uint32_t dist = (d >> 16) + b.peek(db);
-            b.drop(db);
-            if (dist > (uint32_t)(out - out_start)) return INF_BAD;
-            if (dist >= 8) {  // the usual case: eight bytes at a time, the first eight at once
-                const uint8_t *src = out - dist;
-                uint64_t v;
-                std::memcpy(&v, src, 8);
-                std::memcpy(out, &v, 8);
-                if (len > 8) {
-                    uint8_t *dst = out + 8, *end = out + len;
-                    src += 8;
-                    do {
-                        std::memcpy(&v, src, 8);
-                        std::memcpy(dst, &v, 8);
+                if (dist > (uint32_t)(out - out_start)) return INF_BAD;
+                uint8_t *const dst0 = out;
+                out += len;
+                const bool more = b.in_end - b.in >= 16 && out_end - out >= 280;
+                if (more) {  // the next symbol's entry, in flight while the match is copied
+                    b.refill_fast();
+                    e = lt[b.buf & ((1u << LP) - 1)];
+                }
+                if (dist >= 8) {  // the usual case: eight bytes at a time, the first eight at once
+                    const uint8_t *src = dst0 - dist;
+                    uint64_t v;
+                    std::memcpy(&v, src, 8);
+                    std::memcpy(dst0, &v, 8);
+                    if (len > 8) {
+                        uint8_t *dst = dst0 + 8, *end = dst0 + len;
                         src += 8;
-                        dst += 8;
-                    } while (dst < end);
-                }
-            } else
-                copy_match(out, dist, len);
-            out += len;
+                        do {
+                            std::memcpy(&v, src, 8);
+                            std::memcpy(dst, &v, 8);
+                            src += 8;
+                            dst += 8;
+                        } while (dst < end);
+                    }
+                } else
+                    copy_match(dst0, dist, len);
+                if (!more) break;
+            }
         }
         // ---- careful: one symbol
         b.refill_safe();
@@ -476,18 +496,16 @@ __attribute__((always_inline)) inline int decode_block_body(Bits &b, const Table
             return b.overrun * 8 > b.cnt ? INF_TRUNCATED : INF_OK;
         } else {
             if (!(e & 0xFF)) return INF_BAD;
-            b.drop((int)(e & 0xFF));
-            const int xb = (int)((e >> 8) & 0xFF);
-            const uint32_t len = (e >> 16) + b.peek(xb);
-            b.drop(xb);
+            const int tot = (int)(e & 0xFF), xb = (int)((e >> 8) & 0xFF);
+            const uint32_t len = (e >> 16) + ((uint32_t)(b.buf >> (tot - xb)) & ((1u << xb) - 1));
+            b.drop(tot);
             b.refill_safe();
             uint32_t d = dt[b.buf & ((1u << DP) - 1)];
             if (d & 0x8000) d = dt[(d >> 16) + ((b.buf >> DP) & ((1u << ((d >> 8) & 0x7F)) - 1))];
             if (!(d & 0xFF)) return INF_BAD;
-            b.drop((int)(d & 0xFF));
-            const int db = (int)((d >> 8) & 0xFF);
-            const uint32_t dist = (d >> 16) + b.peek(db);
-            b.drop(db);
+            const int dtot = (int)(d & 0xFF), db = (int)((d >> 8) & 0xFF);
+            const uint32_t dist = (d >> 16) + ((uint32_t)(b.buf >> (dtot - db)) & ((1u << db) - 1));
+            b.drop(dtot);
             if (dist > (uint32_t)(out - out_start)) return INF_BAD;
             if ((size_t)(out_end - out) < len) {
                 out_pos = out;
