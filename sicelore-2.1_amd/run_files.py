@@ -163,20 +163,30 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     keys = np.ascontiguousarray(whitelist_keys, dtype=np.uint64)
     # ---- inflate + pass 1: a file's chunks go to the device as soon as the file is inflated (the host inflates the next one meanwhile) -----
     t0 = time.perf_counter()
-    ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
-    for ln in lanes[1:]:
-        ln.refresh()
+    import threading
+
+    set_ready = threading.Event()
     hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+
+    def load_set():
+        """the possible barcodes on the device (125 ms for 3.6 M of them); the worker threads inflate their first files meanwhile"""
+        try:
+            ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
+            for ln in lanes[1:]:
+                ln.refresh()
+            torch.cuda.synchronize()
+        finally:
+            set_ready.set()                      # (on an error the workers' calls fail instead of waiting for ever)
+
     cpu_inflate = [0.0] * len(files)
     owners = [None] * len(files)
 
     def p1(lane, text, rng):
         # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
+        set_ready.wait()
         return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
 
     held, held_host = [0], [0]
-    import threading
 
     staging = threading.local()          # one page-locked buffer per worker thread, reused from file to file
     staged = []
@@ -237,11 +247,11 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     n_on_device = 0
     use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= 1024))  # (the packed worker wants host text)
     if use_device:
+        load_set()
         # K-INFLATE beside the host: the device takes a share of the *.gz files in one call (one wavefront per file; a file is as fast as any
         # other however many run, so its share costs the time of ONE file as long as it fits the device at once), the host's threads inflate
         # the rest with zlib meanwhile.  The device's texts stay in HBM and the chunk workers take them from there.  A file the kernel hands
         # back (unusual or damaged) goes through zlib on the host like the others.
-        import threading
 
         gz_files = [fi for fi, f in enumerate(files) if f.endswith(".gz")]
         share = gz_files if inflate == "device" else gz_files[len(gz_files) - min(512, int(len(gz_files) * device_share)):]
@@ -281,7 +291,9 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         loaded = [part1[fi] if fi in part1 else part2[fi] for fi in range(len(files))]
         cpu_inflate[0] += t_dev[0]
     else:
-        loaded = list(pool.map(load_and_count, range(len(files))))
+        futs = [pool.submit(load_and_count, fi) for fi in range(len(files))]
+        load_set()
+        loaded = [f.result() for f in futs]
     torch.cuda.synchronize()
     for pb in staged:
         pb.close()
