@@ -148,6 +148,42 @@ def check_inflate(pkg, synth, sor, ctx, seed):
     return ok, f"inflate seed={seed} files={len(files)} bytes={sum(len(t) for t in texts)}"
 
 
+def check_host_inflate(pkg, synth, sor, ctx, seed):
+    """round 3: the host's own gzip decoder (smi_gz_inflate_into) on the same kind of files, and the BGZF reader over it"""
+    import zlib
+
+    lib = importlib.import_module(graft.PKG_NAME + ".lib")
+    rng = np.random.default_rng(seed)
+    members, text = [], b""
+    for _m in range(int(rng.choice([1, 1, 2, 6]))):
+        n = int(rng.choice([0, 1, 100, 70_000, int(rng.integers(1, 900_000))]))
+        k = int(rng.choice([1, 4, 5, 30, 256]))
+        alpha = rng.choice(256, size=k, replace=False).astype(np.uint8)
+        data = rng.choice(alpha, size=n, p=rng.dirichlet(np.full(k, float(rng.choice([0.05, 0.5, 5.0]))))).tobytes()
+        if rng.random() < 0.5 and n > 1000:
+            data = data[:n // 3] * 2 + data[n // 3:] + bytes([data[0]]) * int(rng.integers(1, 600))
+        c = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, 16 + int(rng.integers(9, 16)), int(rng.integers(1, 10)),
+                             int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])))
+        members.append(c.compress(data) + c.flush())
+        text += data
+    got = lib.gz_inflate(np.frombuffer(b"".join(members), dtype=np.uint8)).tobytes()
+    z = lib.bgzf_deflate(text, level=int(rng.integers(0, 10)), n_threads=3)
+    back, used = lib.bgzf_inflate(z, n_threads=3)
+    return got == text and back.tobytes() == text and used == z.size, f"host_inflate seed={seed} members={len(members)} bytes={len(text)}"
+
+
+def check_bam_writer(pkg, synth, sor, ctx, seed):
+    """round 3: smi_bam_write_batch against the Python mirror that the reference-executed fixtures pin (tests/test_bam.py's generator)"""
+    import test_bam
+
+    lib = importlib.import_module(graft.PKG_NAME + ".lib")
+    au = importlib.import_module(graft.PKG_NAME + ".assignumis")
+    rng = np.random.default_rng(seed)
+    five, trunc, lim = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), [None, 0, 1][int(rng.integers(0, 3))]
+    bc, exp_bc, umi, exp_umi, g1, g2 = test_bam._write_batch_case(lib, au, seed, five, trunc, lim)
+    return bc == exp_bc and umi == exp_umi and g1 == g2, f"bam_writer seed={seed} five_prime={five} -w={trunc} -b={lim} bytes={len(bc)}"
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     pkg = graft.load_package()
@@ -159,7 +195,8 @@ def main():
     seed, n_ok = (int(sys.argv[2]) if len(sys.argv) > 2 else 1000), 0
     while time.time() < t_end:
         for leg in ([check_bc, check_records] if os.environ.get("SMI_FUZZ_LEGS") == "r2" else [check_packed, check_umi_stage, check_deflate, check_inflate]
-                    if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate]):
+                    if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_host_inflate, check_bam_writer] if os.environ.get("SMI_FUZZ_LEGS") == "host"
+                    else [check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate, check_host_inflate, check_bam_writer]):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
             print(("ok   " if ok else "FAIL ") + msg, flush=True)
             if not ok:
