@@ -398,8 +398,8 @@ def fastq_text_device(rd, chimera_frac=0.0, seed=11):
 
 
 def bam_from_rows(rows, ref_names=("chr1",), read_len=1200, seed=0):
-    """test / bench input: an uncompressed BAM stream (SAM specification 4.2) of mapped records -- rows: (0-based position, read name, FLAG)
-    on the first reference, one `read_len`M operation, random bases and qualities, the aux fields minimap2 writes (NM ms AS nn tp cm s1 s2
+    """test / bench input: an uncompressed BAM stream (SAM specification 4.2) of mapped records -- rows: (0-based position, read name, FLAG
+    [, reference index]) (on the first reference when no index is given), one `read_len`M operation, random bases and qualities, the aux fields minimap2 writes (NM ms AS nn tp cm s1 s2
     de rl, in its order).  -> bytes"""
     import struct
 
@@ -415,7 +415,9 @@ def bam_from_rows(rows, ref_names=("chr1",), read_len=1200, seed=0):
     pairs = codes[rng.integers(0, 4, (len(rows), half))] << 4 | codes[rng.integers(0, 4, (len(rows), half))]
     quals = rng.integers(2, 50, (len(rows), read_len), dtype=np.uint8)
     cigar = struct.pack("<I", (read_len << 4) | 0)
-    for k, (pos, name, flag) in enumerate(rows):
+    for k, row in enumerate(rows):
+        pos, name, flag = row[:3]
+        ref = row[3] if len(row) > 3 else 0
         seq, qual = pairs[k].tobytes(), quals[k].tobytes()
         nm = name.encode() + b"\0"
         aux = (b"NMi" + struct.pack("<i", int(rng.integers(0, 90))) + b"msi" + struct.pack("<i", 900) + b"ASi" + struct.pack("<i", 880) + b"nni\0\0\0\0" +
@@ -425,6 +427,6 @@ def bam_from_rows(rows, ref_names=("chr1",), read_len=1200, seed=0):
             if pos >> shift == e >> shift:
                 b = base + (pos >> shift)
                 break
-        body = struct.pack("<iiBBHHHiiii", 0, int(pos), len(nm), 60, b & 0xFFFF, 1, int(flag), read_len, -1, -1, 0) + nm + cigar + seq + qual + aux
+        body = struct.pack("<iiBBHHHiiii", int(ref), int(pos), len(nm), 60, b & 0xFFFF, 1, int(flag), read_len, -1, -1, 0) + nm + cigar + seq + qual + aux
         out.append(struct.pack("<i", len(body)) + body)
     return b"".join(out)
