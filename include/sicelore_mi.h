@@ -811,7 +811,8 @@ int smi_bam_chunk_inputs(const uint8_t *bam, size_t n_bam, const smi_bam_record 
                          size_t *n_cigar_ops);
 /* nth[i] = 1 when a record of the same read name comes earlier in recs (isNthRecordForRead, OneNanoporeSeqAnalyzer.java:L74-80) */
 int smi_bam_name_seen(const uint8_t *bam, size_t n_bam, const smi_bam_record *recs, int32_t n, uint8_t *nth);
-/* the same for a BAM that is read in segments: the names seen so far live in the handle; records [from, n) of this segment are looked up and added */
+/* the same for a BAM that is read in segments: the names seen so far live in the handle (as 64-bit hashes, like the reference's statsForReads
+ * keys); records [from, n) of this segment are looked up and added */
 typedef struct smi_name_set smi_name_set;
 int smi_name_set_create(smi_name_set **out);
 int smi_name_set_free(smi_name_set *set);

@@ -635,8 +635,18 @@ extern "C" int smi_bam_name_seen(const uint8_t *bam, size_t n_bam, const smi_bam
 // the same over a stream of segments: the set of read names seen so far lives in a handle; records [from, n) of this segment are looked up and
 // added (records in front of `from` were handed in with an earlier segment)
 struct smi_name_set {
-    std::unordered_set<std::string> names;
+    std::unordered_set<uint64_t> hashes;  // the reference keys its per-read statistics by a 64-bit hash of the name as well
+                                          // (AllReadsScanStats.getLongHashFromString, OneNanoporeResult.java:L192)
 };
+namespace {
+inline uint64_t name_hash(const uint8_t *p, size_t n) {  // 64-bit FNV-1a with a final avalanche
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < n; i++) h = (h ^ p[i]) * 0x100000001b3ull;
+    h ^= h >> 32;
+    h *= 0xd6e8feb86659fd93ull;
+    return h ^ (h >> 32);
+}
+}  // namespace
 extern "C" int smi_name_set_create(smi_name_set **out) {
     if (!out) {
         set_error("smi_name_set_create: null argument");
@@ -654,13 +664,14 @@ extern "C" int smi_name_set_seen(smi_name_set *set, const uint8_t *bam, size_t n
         set_error("smi_name_set_seen: bad argument");
         return SMI_ERR_INVALID;
     }
+    set->hashes.reserve(set->hashes.size() + (size_t)(n - from));
     for (int32_t i = from; i < n; i++) {
         const smi_bam_record &r = recs[i];
         if (r.name_off + r.l_read_name > n_bam) {
             set_error("smi_name_set_seen: a record index entry points outside the BAM buffer");
             return SMI_ERR_INVALID;
         }
-        nth[i] = set->names.emplace((const char *)bam + r.name_off, r.l_read_name ? r.l_read_name - 1u : 0u).second ? 0 : 1;
+        nth[i] = set->hashes.insert(name_hash(bam + r.name_off, r.l_read_name ? r.l_read_name - 1u : 0u)).second ? 0 : 1;
     }
     return SMI_OK;
 }

@@ -813,19 +813,23 @@ BAM_RECORD_DTYPE = np.dtype([("rec_off", "<u8"), ("name_off", "<u8"), ("cigar_of
                              ("n_cigar", "<u2"), ("mapq", "u1"), ("l_read_name", "u1"), ("reserved", "u1", (2,))])
 
 
-def bgzf_inflate(data, n_threads=4):
-    """inflated bytes of the complete BGZF blocks of `data` (numpy uint8) -> (numpy uint8, bytes consumed)"""
+def bgzf_inflate(data, n_threads=4, front=None):
+    """inflated bytes of the complete BGZF blocks of `data` (numpy uint8) -> (numpy uint8, bytes consumed).  front: bytes to put in front of
+    the inflated data in the SAME buffer (a stream's pending tail) -- the blocks are inflated straight behind them"""
     lib = load_library()
     data = np.ascontiguousarray(data, dtype=np.uint8)
     n_out, n_blk, used = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
     if lib.smi_bgzf_uncompressed_size(data.ctypes.data, data.size, ctypes.byref(n_out), ctypes.byref(n_blk), ctypes.byref(used)):
         raise SmiError(lib.smi_last_error().decode())
-    out = np.empty(max(n_out.value, 1), dtype=np.uint8)
+    n_front = 0 if front is None else int(front.size)
+    out = np.empty(max(n_front + n_out.value, 1), dtype=np.uint8)
+    if n_front:
+        out[:n_front] = front
     got = ctypes.c_size_t(0)
-    if lib.smi_bgzf_inflate(data.ctypes.data, data.size, out.ctypes.data, out.size, ctypes.byref(got), ctypes.byref(used),
+    if lib.smi_bgzf_inflate(data.ctypes.data, data.size, out[n_front:].ctypes.data, out.size - n_front, ctypes.byref(got), ctypes.byref(used),
                             int(n_threads)):
         raise SmiError(lib.smi_last_error().decode())
-    return out[:got.value], used.value
+    return out[:n_front + got.value], used.value
 
 
 def bgzf_deflate(data, level=5, block_bytes=0xFF00, n_threads=4):

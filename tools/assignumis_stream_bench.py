@@ -35,7 +35,7 @@ def main():
         gen_s = time.perf_counter() - t0
         del raw
         res = {"records": len(big), "bam_file_bytes": int(z.size), "generate_s": gen_s, "runs": []}
-        for seg in (64 << 20, 256 << 20, 1 << 40):
+        for seg in (256 << 20, 1 << 30, 1 << 40):
             info = au.assignumis_stream(ctx, path, os.path.join(td, "out"), segment_bytes=seg, n_threads=16)
             res["runs"].append({"segment_bytes": seg if seg < (1 << 39) else "whole file", "records_per_s": info["records"] / info["wall_s"], "wall_s": info["wall_s"],
                                 "batches": info["batches"], "clustered": info["clustered"], "seconds": info["seconds"],
