@@ -643,11 +643,21 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
     step = max(int(chunk_size), 1)
     secs = dict(read_inflate=0.0, index=0.0, umi_stage=0.0, write_batch=0.0, bgzf_write=0.0)
 
+    stage = {}                                     # page-locked buffers reused from batch to batch: records of both outputs, their BGZF streams
+
+    def staged(key, n):
+        pb = stage.get(key)
+        if pb is None or pb.array.size < n:
+            if pb is not None:
+                pb.close()
+            pb = stage[key] = _lib.PinnedBuffer(int(n * 1.2) + (1 << 20))
+        return pb.array
+
     def emit(bc, umi):
         t1 = time.perf_counter()
-        for fh, a in ((f_bc, bc), (f_umi, umi)):
+        for key, fh, a in (("z_bc", f_bc, bc), ("z_umi", f_umi, umi)):
             if a.size:
-                z = ctx.bgzf_deflate_device(a)
+                z = ctx.bgzf_deflate_device(a, out=staged(key, ctx.bgzf_device_bound(a.size)))
                 fh.write(z[:-28])                   # without the end-of-file block: more batches follow
         secs["bgzf_write"] += time.perf_counter() - t1
 
@@ -712,8 +722,10 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
             region[done] = np.where(reg >= 0, reg + region_base, -1)
             region_base += int(reg.max()) + 1 if n_done and reg.max() >= 0 else 0
             n_clustered += int(((out["flags"][:n_done] & _lib.UMI_CLUSTERED) != 0).sum())
+            bound = _lib.bam_write_bound(recs, done)
             bc, umi, _o = _lib.bam_write_batch(bam, recs, done, tags, gene=gene, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate_read_name,
-                                               five_prime=five_prime, n_threads=n_threads, gene_counts=gc, region=region, nth_record=nth)
+                                               five_prime=five_prime, n_threads=n_threads, gene_counts=gc, region=region, nth_record=nth,
+                                               out_bc=staged("bc", bound), out_umi=staged("umi", bound))
             t4 = time.perf_counter()
             secs["umi_stage"] += t3 - t2
             secs["write_batch"] += t4 - t3
@@ -752,6 +764,8 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
         fh.write(_BGZF_EOF)
         fh.close()
     f_in.close()
+    for pb in stage.values():
+        pb.close()
     with open(out_prefix + ".genecounts.tsv", "w") as f:
         f.write(gc.genecounts_tsv(bc_length))
     with open(out_prefix + ".UMIdepths.tsv", "w") as f:

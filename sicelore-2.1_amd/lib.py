@@ -1141,14 +1141,22 @@ class Context:
                                                           _ptr(d_rec_offsets), _ptr(d_frag_src), int(n_records), _ptr(d_ends), _ptr(d_len),
                                                           _stream_ptr(stream)))
 
-    def bgzf_deflate_device(self, data):
-        """smi_bgzf_deflate_device: bytes / uint8 array -> the BGZF stream (numpy uint8), blocks deflated on the device"""
+    def bgzf_deflate_device(self, data, out=None):
+        """smi_bgzf_deflate_device: bytes / uint8 array -> the BGZF stream (numpy uint8), blocks deflated on the device.  out: a uint8 array to
+        write into (e.g. page-locked memory that is reused from call to call; a view of it is returned) -- it must hold bgzf_device_bound(n)"""
         a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
         n = ctypes.c_size_t(0)
         self._check(self._lib.smi_bgzf_deflate_device(self._h, a.ctypes.data if a.size else None, a.size, None, 0, ctypes.byref(n)))
-        out = np.empty(n.value, dtype=np.uint8)
+        if out is None or out.size < n.value:
+            out = np.empty(n.value, dtype=np.uint8)
         self._check(self._lib.smi_bgzf_deflate_device(self._h, a.ctypes.data if a.size else None, a.size, out.ctypes.data, out.size, ctypes.byref(n)))
         return out[:n.value]
+
+    @staticmethod
+    def bgzf_device_bound(n_bytes):
+        """bytes smi_bgzf_deflate_device may write for n_bytes of input (its own bound: blocks of 61,440 input bytes)"""
+        n = int(n_bytes)
+        return n + n // 8 + ((n + 0xF000 - 1) // 0xF000) * 628 + 92
 
     def gz_inflate_device(self, files, out_caps=None):
         """K-INFLATE (smi_gz_inflate_device): a list of gzip files (bytes / uint8 arrays) -> (uint8 device tensor with all texts, offsets, lengths,
