@@ -654,11 +654,19 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
         return pb.array
 
     def emit(bc, umi):
+        import threading
+
         t1 = time.perf_counter()
+        writers = []
         for key, fh, a in (("z_bc", f_bc, bc), ("z_umi", f_umi, umi)):
             if a.size:
                 z = ctx.bgzf_deflate_device(a, out=staged(key, ctx.bgzf_device_bound(a.size)))
-                fh.write(z[:-28])                   # without the end-of-file block: more batches follow
+                # without the end-of-file block: more batches follow.  The file is written by a thread of its own while the other output
+                # is deflated (a write to the page cache is a memcpy by one core)
+                writers.append(threading.Thread(target=fh.write, args=(z[:-28],)))
+                writers[-1].start()
+        for w in writers:
+            w.join()
         secs["bgzf_write"] += time.perf_counter() - t1
 
     eof = False
