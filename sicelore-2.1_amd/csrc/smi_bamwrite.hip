@@ -16,7 +16,6 @@
 // The Python mirror of the same rules (assignumis.py: record_tag_sets / apply_tag_sets / _coordinate_key) is what the reference-executed
 // fixtures pin (ref_exec_samtags / auxorder / bamorder); tests hold this file to it byte for byte.
 #include <algorithm>
-#include <atomic>
 #include <cstring>
 #include <string>
 #include <string_view>

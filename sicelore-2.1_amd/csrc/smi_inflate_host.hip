@@ -16,7 +16,6 @@
 #include <cstring>
 #include <mutex>
 #include <string>
-#include <vector>
 
 #include "smi_internal.h"
 
