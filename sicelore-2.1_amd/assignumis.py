@@ -633,7 +633,6 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
     gc, names_seen = _lib.GeneCounts(), _lib.NameSet()
     f_in = open(in_bam, "rb")
     f_bc, f_umi = open(out_prefix + ".bam", "wb"), open(out_prefix + "_umifound_.bam", "wb")
-    comp_tail = np.zeros(0, dtype=np.uint8)        # compressed bytes of an incomplete block
     pend = np.zeros(0, dtype=np.uint8)             # inflated bytes not consumed yet: pending records (+ a partial record)
     nth_pend = np.zeros(0, dtype=np.uint8)
     header, tagger, refs = None, None, None
@@ -669,19 +668,43 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
             w.join()
         secs["bgzf_write"] += time.perf_counter() - t1
 
+    # a reader thread reads and inflates the next segment while this one is processed; it leaves room in front of the inflated bytes for the
+    # pending tail, which only the consumer knows
+    import queue
+    import threading
+
+    room_hint = [256 << 20]
+    segments = queue.Queue(maxsize=1)
+
+    def reader():
+        tail = np.zeros(0, dtype=np.uint8)
+        try:
+            while True:
+                raw = np.fromfile(f_in, dtype=np.uint8, count=int(segment_bytes))
+                last = raw.size < segment_bytes
+                comp = np.concatenate([tail, raw]) if tail.size else raw
+                buf, room, used = _lib.bgzf_inflate(comp, n_threads=n_threads, room=room_hint[0]) if comp.size else (np.zeros(0, dtype=np.uint8), 0, 0)
+                tail = comp[used:].copy()
+                if last and tail.size:
+                    raise _lib.SmiError("truncated BGZF stream")
+                segments.put((buf, room, last, None))
+                if last:
+                    return
+        except BaseException as e:  # noqa: BLE001 -- handed to the consumer
+            segments.put((None, 0, True, e))
+
+    threading.Thread(target=reader, daemon=True).start()
     eof = False
     while not eof or pend.size:
         t1 = time.perf_counter()
-        raw = np.fromfile(f_in, dtype=np.uint8, count=int(segment_bytes)) if not eof else np.zeros(0, dtype=np.uint8)
-        if raw.size < segment_bytes:
-            eof = True
-        comp = np.concatenate([comp_tail, raw]) if comp_tail.size else raw
-        bam = pend
-        if comp.size:
-            bam, used = _lib.bgzf_inflate(comp, n_threads=n_threads, front=pend)      # inflated straight behind the pending bytes
-            comp_tail = comp[used:].copy()
-            if eof and comp_tail.size:
-                raise _lib.SmiError("truncated BGZF stream")
+        buf, room, eof, err = segments.get() if not eof else (np.zeros(0, dtype=np.uint8), 0, True, None)
+        if err is not None:
+            raise err
+        if pend.size <= room:
+            buf[room - pend.size:room] = pend
+            bam = buf[room - pend.size:]
+        else:
+            bam = np.concatenate([pend, buf[room:]])
         secs["read_inflate"] += time.perf_counter() - t1
         start = 0
         if header is None:
@@ -763,6 +786,7 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size
         first = int(cur[0]) if cur.size else m
         off = int(recs[first]["rec_off"]) if first < m else int(end)
         pend = bam[off:].copy()
+        room_hint[0] = max(256 << 20, int(pend.size * 1.5))
         nth_pend = nth[first:m].copy()
         cur_n = int(cur.size)
         if m:

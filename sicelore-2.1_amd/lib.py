@@ -813,22 +813,26 @@ BAM_RECORD_DTYPE = np.dtype([("rec_off", "<u8"), ("name_off", "<u8"), ("cigar_of
                              ("n_cigar", "<u2"), ("mapq", "u1"), ("l_read_name", "u1"), ("reserved", "u1", (2,))])
 
 
-def bgzf_inflate(data, n_threads=4, front=None):
+def bgzf_inflate(data, n_threads=4, front=None, room=0):
     """inflated bytes of the complete BGZF blocks of `data` (numpy uint8) -> (numpy uint8, bytes consumed).  front: bytes to put in front of
-    the inflated data in the SAME buffer (a stream's pending tail) -- the blocks are inflated straight behind them"""
+    the inflated data in the SAME buffer (a stream's pending tail) -- the blocks are inflated straight behind them.  room > 0: that many
+    spare bytes are left in front instead and (whole buffer, offset of the inflated data, bytes consumed) is returned, for a reader thread
+    that inflates ahead of the consumer who knows the pending bytes."""
     lib = load_library()
     data = np.ascontiguousarray(data, dtype=np.uint8)
     n_out, n_blk, used = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
     if lib.smi_bgzf_uncompressed_size(data.ctypes.data, data.size, ctypes.byref(n_out), ctypes.byref(n_blk), ctypes.byref(used)):
         raise SmiError(lib.smi_last_error().decode())
-    n_front = 0 if front is None else int(front.size)
+    n_front = int(room) if room else (0 if front is None else int(front.size))
     out = np.empty(max(n_front + n_out.value, 1), dtype=np.uint8)
-    if n_front:
+    if n_front and not room:
         out[:n_front] = front
     got = ctypes.c_size_t(0)
     if lib.smi_bgzf_inflate(data.ctypes.data, data.size, out[n_front:].ctypes.data, out.size - n_front, ctypes.byref(got), ctypes.byref(used),
                             int(n_threads)):
         raise SmiError(lib.smi_last_error().decode())
+    if room:
+        return out[:n_front + got.value], n_front, used.value
     return out[:n_front + got.value], used.value
 
 
