@@ -620,9 +620,9 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
-def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=1 << 30, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
+def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
                       max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16):
-    """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (1 GiB: a few of BamReader's chunks), never held as a
+    """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (read and inflated by a thread of their own, one segment ahead), never held as a
     whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
     chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
     device and appended to <out>.bam / <out>_umifound_.bam; the records ReadGrouper holds back and the unfinished chunk go in front of the
