@@ -32,15 +32,13 @@ namespace {
 // FastqRecordExt.lambda$getScanDatFromReadName$4 (L397-408): text behind the first `tag` up to the next '_'
 bool extract(const char *sub, size_t n, const char *tag, const char **val, size_t *len) {
     const size_t tl = std::strlen(tag);
-    for (size_t i = 0; i + tl <= n; i++)
-        if (std::memcmp(sub + i, tag, tl) == 0) {
-            size_t a = i + tl, b = a;
-            while (b < n && sub[b] != '_') b++;
-            *val = sub + a;
-            *len = b - a;
-            return true;
-        }
-    return false;
+    const char *hit = (const char *)memmem(sub, n, tag, tl);
+    if (!hit) return false;
+    const char *a = hit + tl, *end = sub + n;
+    const char *b = (const char *)std::memchr(a, '_', (size_t)(end - a));
+    *val = a;
+    *len = (size_t)((b ? b : end) - a);
+    return true;
 }
 
 bool to_long(const char *v, size_t n, int base, long *out) {
@@ -69,13 +67,9 @@ struct ScanName {
 // the whole of getScanDatFromReadName that the tags need; false = the reference throws (no AE=, a number that does not parse)
 bool parse_scan_name(const char *name, size_t n, int bc_edit_limit, ScanName &d, std::string &err) {
     d = ScanName();
-    const char *mark = nullptr;
-    for (size_t i = 0; i + 5 <= n && !mark; i++)
-        if (std::memcmp(name + i, "_REV_", 5) == 0) mark = name + i;
+    const char *mark = (const char *)memmem(name, n, "_REV_", 5);
     d.reverse = mark != nullptr;
-    if (!mark)
-        for (size_t i = 0; i + 5 <= n && !mark; i++)
-            if (std::memcmp(name + i, "_FWD_", 5) == 0) mark = name + i;
+    if (!mark) mark = (const char *)memmem(name, n, "_FWD_", 5);
     if (!mark) return true;  // Optional.absent()
     const char *sub = mark + 4;
     const size_t sn = (size_t)(name + n - sub);
