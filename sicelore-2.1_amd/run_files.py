@@ -113,13 +113,16 @@ def _gzip_member(data, level):
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
         dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None, resident_bytes=96 << 30,
-        host_text_bytes=256 << 30):
+        host_text_bytes=256 << 30, inflate_auto_from=1024):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
     "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads.
     resident_bytes: with gz="device" a file's text is uploaded ONCE, when it has been inflated, and stays in HBM for both passes (the chunk
     workers take device pointers) until this many bytes are held; files beyond that are uploaded per pass from the host as before.
+    inflate: "host" = the library's decoder on the worker threads; "device" = K-INFLATE for every *.gz file, 512 per round; "auto" = both,
+    working one queue of files from its two ends, from inflate_auto_from files on (a round on the device costs the time of ONE file however
+    many run in it, so it pays for many files of moderate size: a flow cell's thousands of 4,000-read files), the host alone below that.
     host_text_bytes: how much inflated text may wait in host memory between the passes; the text of files beyond that is dropped after pass 1
     and inflated again in pass 2 (the reference reads every file twice, NanoporeReadScannerMain.java:L306) -- a run of any size.
     With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
@@ -147,8 +150,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     os.makedirs(os.path.join(out_dir, "passed"), exist_ok=True)
     os.makedirs(os.path.join(out_dir, "failed"), exist_ok=True)
     pool = ThreadPoolExecutor(n_workers)
-    lanes = [ctx] + [ctx.lane() for _ in range(n_workers - 1)]
-    free = list(range(n_workers))
+    lanes = [ctx] + [ctx.lane() for _ in range(n_workers)]     # one per worker thread, and one for the thread that drives K-INFLATE
+    free = list(range(n_workers + 1))
 
     def with_lane(fn):
         def call(*a):
@@ -245,50 +248,70 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         return [(a, b) for a, b in zip([0] + ends, ends + [n])]
 
     n_on_device = 0
-    use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= 1024))  # (the packed worker wants host text)
+    use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= inflate_auto_from))  # (the packed worker wants host text)
     if use_device:
-        load_set()
-        # K-INFLATE beside the host: the device takes a share of the *.gz files in one call (one wavefront per file; a file is as fast as any
-        # other however many run, so its share costs the time of ONE file as long as it fits the device at once), the host's threads inflate
-        # the rest with zlib meanwhile.  The device's texts stay in HBM and the chunk workers take them from there.  A file the kernel hands
-        # back (unusual or damaged) goes through zlib on the host like the others.
+        # K-INFLATE beside the host, both working one queue of *.gz files from its two ends: the host's worker threads take files from the
+        # front, one after the other; the device takes up to 512 from the back per round (one wavefront per file; a file is as fast as any
+        # other however many run, so a round costs the time of its largest file), round after round until the queue is empty.  The
+        # device's texts stay in HBM and the chunk workers take them from there.  A file the kernel hands back (unusual or damaged) goes
+        # through the host's decoder like the others.  inflate="device": the host's threads leave the *.gz files to the device.
+        import collections
 
-        gz_files = [fi for fi, f in enumerate(files) if f.endswith(".gz")]
-        share = gz_files if inflate == "device" else gz_files[len(gz_files) - min(512, int(len(gz_files) * device_share)):]
-        on_dev = {}
-        t_dev = [0.0]
+        todo = collections.deque(fi for fi, f in enumerate(files) if f.endswith(".gz"))
+        plain = [fi for fi, f in enumerate(files) if not f.endswith(".gz")]
+        todo_lock = threading.Lock()
+        results = {}
+        t_dev, n_rounds = [0.0], [0]
+        per_round = max(1, min(512, int(len(todo) * device_share))) if inflate == "auto" else 512
+
+        def count_dev(fi, t):
+            cuts = device_cuts(t)
+            return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
 
         def device_part():
-            t1 = time.perf_counter()
-            raws = [np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in share]
-            if raws:
-                k_lane = free.pop()           # a lane of its own while the host's threads work with the others
-                try:
+            k_lane = free.pop()               # a lane of its own while the host's threads work with the others
+            pending = []
+            try:
+                while True:
+                    with todo_lock:
+                        mine = [todo.pop() for _ in range(min(per_round, len(todo)))]
+                    if not mine:
+                        break
+                    t1 = time.perf_counter()
+                    raws = [np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in mine]
                     d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(raws)
-                finally:
-                    free.append(k_lane)
-                for j, fi in enumerate(share):
-                    if int(status[j]) == 0:
-                        on_dev[fi] = d_out[int(offs[j]):int(offs[j]) + int(lens[j])]
-            t_dev[0] = time.perf_counter() - t1
+                    t_dev[0] += time.perf_counter() - t1
+                    n_rounds[0] += 1
+                    for j, fi in enumerate(mine):
+                        if int(status[j]) == 0:
+                            pending.append((fi, pool.submit(count_dev, fi, d_out[int(offs[j]):int(offs[j]) + int(lens[j])]), True))
+                        else:
+                            pending.append((fi, pool.submit(load_and_count, fi), False))
+            finally:
+                free.append(k_lane)
+            return pending
 
-        th = threading.Thread(target=device_part)
-        th.start()
-        in_share = set(share)
-        host_first = [fi for fi in range(len(files)) if fi not in in_share]
-        part1 = dict(zip(host_first, pool.map(load_and_count, host_first)))
-        th.join()
-        n_on_device = len(on_dev)
+        def host_part():
+            """one of the host's worker threads: files from the front of the queue until it is empty"""
+            while True:
+                with todo_lock:
+                    if not todo:
+                        return
+                    fi = todo.popleft()
+                results[fi] = load_and_count(fi)
 
-        def count_dev(fi):
-            if fi in on_dev:
-                t = on_dev[fi]
-                cuts = device_cuts(t)
-                return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
-            return load_and_count(fi)
-
-        part2 = dict(zip(share, pool.map(count_dev, share)))
-        loaded = [part1[fi] if fi in part1 else part2[fi] for fi in range(len(files))]
+        dev_future = ThreadPoolExecutor(1).submit(device_part)
+        host_futs = [pool.submit(host_part) for _ in range(max(n_workers - 2, 1))] if inflate == "auto" else []
+        plain_futs = [(fi, pool.submit(load_and_count, fi)) for fi in plain]
+        load_set()
+        for f in host_futs:
+            f.result()
+        for fi, f in plain_futs:
+            results[fi] = f.result()
+        for fi, f, on_dev_ in dev_future.result():
+            results[fi] = f.result()
+            n_on_device += 1 if on_dev_ else 0
+        loaded = [results[fi] for fi in range(len(files))]
         cpu_inflate[0] += t_dev[0]
     else:
         futs = [pool.submit(load_and_count, fi) for fi in range(len(files))]

@@ -26,7 +26,7 @@ def _canon(text):
 
 
 @pytest.mark.parametrize("gz,inflate,resident,host_budget", [("device", "host", 96 << 30, 1 << 40), ("zlib", "host", 0, 1 << 40), ("device", "device", 0, 1 << 40),
-                                                             ("device", "host", 12_000_000, 1 << 40), ("device", "host", 11_000_000, 13_000_000), ("zlib", "host", 0, 0)])
+                                                             ("device", "host", 12_000_000, 1 << 40), ("device", "host", 11_000_000, 13_000_000), ("zlib", "host", 0, 0), ("device", "auto", 96 << 30, 1 << 40)])
 def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, inflate, resident, host_budget):
     from sicelore_amd import lib as libmod
 
@@ -38,12 +38,15 @@ def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, in
     in_dir, out_dir = str(tmp_path / "in"), str(tmp_path / "out")
     n = run_files.write_synthetic_dir(synth, in_dir, 6, 2500, used, dev, seed=810, chimera_frac=0.08)
     info = run_files.run(gpu_ctx, in_dir, out_dir, max_ed=1, n_workers=4, reads_per_chunk=1000, whitelist_keys=keys, gz=gz, inflate=inflate,
-                         resident_bytes=resident, host_text_bytes=host_budget)
-    assert info["files_inflated_on_device"] == (6 if inflate == "device" else 0)
+                         resident_bytes=resident, host_text_bytes=host_budget, inflate_auto_from=4, device_share=0.34)
+    # "auto": host threads and the device work the queue of files from its two ends (rounds of two files here)
+    assert info["files_inflated_on_device"] == (6 if inflate == "device" else 0) or (inflate == "auto" and 2 <= info["files_inflated_on_device"] <= 6)
     # files whose text found no room between the passes are inflated again in pass 2 (none / some / all of the six)
     assert info["files_inflated_twice"] == (6 if host_budget == 0 else 0) or (host_budget == 13_000_000 and 1 <= info["files_inflated_twice"] <= 4)
     # the text of host-inflated files stays in HBM between the passes while the budget lasts (all of it / none / about two files of six)
-    if inflate == "host" and gz == "device":
+    if inflate == "auto":
+        assert 0 < info["text_resident_bytes"] <= info["text_in_bytes"]
+    elif inflate == "host" and gz == "device":
         # (a soft limit: the worker threads race for the budget's last bytes)
         assert (info["text_resident_bytes"] == info["text_in_bytes"]) if resident > (1 << 30) else (0 < info["text_resident_bytes"] < info["text_in_bytes"]), \
             (info["text_resident_bytes"], info["text_in_bytes"])
