@@ -375,6 +375,29 @@ def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, trunc
     return out_bc[:nb.value], out_umi[:nu.value], order[:batch.size]
 
 
+def pack_gz_paths(paths, buffer=None):
+    """the files of one K-INFLATE round read straight into one host buffer at the 512-byte aligned offsets the kernel wants (1 KiB of zeros
+    behind the last) -> dict for Context.gz_inflate_device(packed=...).  buffer: a uint8 array to use (e.g. page-locked, reused from round to
+    round) when it is large enough."""
+    sizes = [os.path.getsize(p) for p in paths]
+    in_off, at = [], 0
+    for n in sizes:
+        in_off.append(at)
+        at = (at + n + 511) & ~511
+    total = at + 1024
+    host = buffer[:total] if buffer is not None and buffer.size >= total else np.empty(total, dtype=np.uint8)
+    out_caps = []
+    for p, o, n in zip(paths, in_off, sizes):
+        with open(p, "rb") as f:
+            got = f.readinto(memoryview(host[o:o + n]))
+        if got != n:
+            raise SmiError(f"short read of {p}")
+        host[o + n:((o + n + 511) & ~511)] = 0
+        out_caps.append(int.from_bytes(host[o + n - 4:o + n].tobytes(), "little") if n >= 18 else 0)
+    host[at:total] = 0
+    return dict(host=host, in_off=in_off, sizes=sizes, out_caps=out_caps)
+
+
 def bam_name_seen(bam, recs):
     """uint8 per record: a record of the same read name comes earlier (smi_bam_name_seen)"""
     lib = load_library()
@@ -1162,23 +1185,29 @@ class Context:
         n = int(n_bytes)
         return n + n // 8 + ((n + 0xF000 - 1) // 0xF000) * 628 + 92
 
-    def gz_inflate_device(self, files, out_caps=None):
+    def gz_inflate_device(self, files=None, out_caps=None, packed=None):
         """K-INFLATE (smi_gz_inflate_device): a list of gzip files (bytes / uint8 arrays) -> (uint8 device tensor with all texts, offsets, lengths,
         statuses); file i's text is out[offsets[i] : offsets[i] + lengths[i]] when statuses[i] == 0.  out_caps: capacity per file (default: the
-        ISIZE field at the end of the file, which is the text's size for a single-member file below 4 GB)"""
+        ISIZE field at the end of the file, which is the text's size for a single-member file below 4 GB).  packed: what pack_gz_paths made of
+        the files (read and laid out by another thread while the device was busy), instead of `files`"""
         import torch
 
-        n = len(files)
-        arrs = [np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else f for f in files]
-        in_off, at = [], 0
-        for a in arrs:
-            in_off.append(at)
-            at = (at + a.size + 511) & ~511
-        host = np.zeros(at + 1024, dtype=np.uint8)
-        for a, o in zip(arrs, in_off):
-            host[o:o + a.size] = a
-        if out_caps is None:
-            out_caps = [int.from_bytes(a[-4:].tobytes(), "little") if a.size >= 18 else 0 for a in arrs]
+        if packed is None:
+            arrs = [np.frombuffer(f, dtype=np.uint8) if not isinstance(f, np.ndarray) else f for f in files]
+            in_off, at = [], 0
+            for a in arrs:
+                in_off.append(at)
+                at = (at + a.size + 511) & ~511
+            host = np.zeros(at + 1024, dtype=np.uint8)
+            for a, o in zip(arrs, in_off):
+                host[o:o + a.size] = a
+            sizes = [a.size for a in arrs]
+            if out_caps is None:
+                out_caps = [int.from_bytes(a[-4:].tobytes(), "little") if a.size >= 18 else 0 for a in arrs]
+        else:
+            host, in_off, sizes = packed["host"], packed["in_off"], packed["sizes"]
+            out_caps = packed["out_caps"] if out_caps is None else out_caps
+        n = len(sizes)
         out_off, at = [], 0
         for c in out_caps:
             out_off.append(at)
@@ -1187,7 +1216,7 @@ class Context:
         d_in = torch.from_numpy(host).to(dev)
         d_out = torch.empty(max(at, 1), dtype=torch.uint8, device=dev)
         S = np.zeros((n, 4), dtype=np.uint64)
-        S[:, 0], S[:, 1], S[:, 2], S[:, 3] = in_off, [a.size for a in arrs], out_off, out_caps
+        S[:, 0], S[:, 1], S[:, 2], S[:, 3] = in_off, sizes, out_off, out_caps
         R = np.zeros(n, dtype=np.dtype([("out_len", "<u8"), ("status", "<u4"), ("n_members", "<u4")]))
         self._check(self._lib.smi_gz_inflate_device(self._h, _ptr(d_in), S.ctypes.data, n, _ptr(d_out), R.ctypes.data, None))
         return d_out, np.array(out_off, dtype=np.int64), R["out_len"].astype(np.int64), R["status"].copy(), R["n_members"].copy()

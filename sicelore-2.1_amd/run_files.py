@@ -271,24 +271,48 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         def device_part():
             k_lane = free.pop()               # a lane of its own while the host's threads work with the others
             pending = []
+            slots = [None, None]              # two page-locked buffers: one is read into while the device works on the other
+
+            def take():
+                # a round costs the device the time of one file (about what the host's threads need for 1.5 rounds' worth of files): near the
+                # end of the queue the rest is left to the host, or its threads would idle while the device finishes
+                with todo_lock:
+                    if inflate == "auto" and len(todo) < int(2.5 * per_round) and inflate_auto_from > 8:
+                        return []
+                    return [todo.pop() for _ in range(min(per_round, len(todo)))]
+
+            def prepare(mine, k):
+                paths = [os.path.join(in_dir, files[fi]) for fi in mine]
+                need = sum(((os.path.getsize(p_) + 511) & ~511) for p_ in paths) + 1024
+                if slots[k] is None or slots[k].array.size < need:
+                    if slots[k] is not None:
+                        slots[k].close()
+                    slots[k] = _lib.PinnedBuffer(int(need * 1.25))
+                return _lib.pack_gz_paths(paths, buffer=slots[k].array)
+
             try:
-                while True:
-                    with todo_lock:
-                        mine = [todo.pop() for _ in range(min(per_round, len(todo)))]
-                    if not mine:
-                        break
-                    t1 = time.perf_counter()
-                    raws = [np.fromfile(os.path.join(in_dir, files[fi]), dtype=np.uint8) for fi in mine]
-                    d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(raws)
-                    t_dev[0] += time.perf_counter() - t1
-                    n_rounds[0] += 1
-                    for j, fi in enumerate(mine):
-                        if int(status[j]) == 0:
-                            pending.append((fi, pool.submit(count_dev, fi, d_out[int(offs[j]):int(offs[j]) + int(lens[j])]), True))
-                        else:
-                            pending.append((fi, pool.submit(load_and_count, fi), False))
+                with ThreadPoolExecutor(1) as prefetch:
+                    mine, k = take(), 0
+                    nxt = prefetch.submit(prepare, mine, k) if mine else None
+                    while mine:
+                        t1 = time.perf_counter()
+                        packed = nxt.result()
+                        following = take()            # the next round is read and laid out while this one runs on the device
+                        nxt = prefetch.submit(prepare, following, 1 - k) if following else None
+                        d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(packed=packed)
+                        t_dev[0] += time.perf_counter() - t1
+                        n_rounds[0] += 1
+                        for j, fi in enumerate(mine):
+                            if int(status[j]) == 0:
+                                pending.append((fi, pool.submit(count_dev, fi, d_out[int(offs[j]):int(offs[j]) + int(lens[j])]), True))
+                            else:
+                                pending.append((fi, pool.submit(load_and_count, fi), False))
+                        mine, k = following, 1 - k
             finally:
                 free.append(k_lane)
+                for pb in slots:
+                    if pb is not None:
+                        pb.close()
             return pending
 
         def host_part():
