@@ -248,6 +248,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         return [(a, b) for a, b in zip([0] + ends, ends + [n])]
 
     n_on_device = 0
+    dev_detail = []          # per K-INFLATE round: files, seconds waiting for the files to be read, seconds of upload + kernel + results
     use_device = on_device and (inflate == "device" or (inflate == "auto" and sum(f.endswith(".gz") for f in files) >= inflate_auto_from))  # (the packed worker wants host text)
     if use_device:
         # K-INFLATE beside the host, both working one queue of *.gz files from its two ends: the host's worker threads take files from the
@@ -297,10 +298,12 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                     while mine:
                         t1 = time.perf_counter()
                         packed = nxt.result()
+                        t2 = time.perf_counter()
                         following = take()            # the next round is read and laid out while this one runs on the device
                         nxt = prefetch.submit(prepare, following, 1 - k) if following else None
                         d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(packed=packed)
                         t_dev[0] += time.perf_counter() - t1
+                        dev_detail.append((len(mine), round(t2 - t1, 3), round(time.perf_counter() - t2, 3)))
                         n_rounds[0] += 1
                         for j, fi in enumerate(mine):
                             if int(status[j]) == 0:
@@ -478,7 +481,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
     return {"rank": rank, "ranks": world, "files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
-            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(rng[1] - rng[0] for _, _, rng in chunks)), "files_inflated_twice": sum(1 for t in texts if t is None), "files_inflated_on_device": n_on_device, "text_resident_bytes": int(held[0]),
+            "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(rng[1] - rng[0] for _, _, rng in chunks)), "files_inflated_twice": sum(1 for t in texts if t is None), "files_inflated_on_device": n_on_device, "device_inflate_rounds": dev_detail, "text_resident_bytes": int(held[0]),
             "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
             "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
             "write_files_s": t_write, "workers": n_workers, "gz": (gz if compress else None), "gz_level": gz_level if compress and not on_device else None}

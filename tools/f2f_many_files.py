@@ -36,11 +36,11 @@ def main():
         res["generate_inputs_s"] = time.perf_counter() - t0
         res["reads"] = n
         res["gz_in_bytes"] = sum(os.path.getsize(os.path.join(in_dir, f)) for f in os.listdir(in_dir))
-        for mode, kw in (("host", {}), ("auto", {"device_share": 0.25}), ("auto", {"device_share": 0.5}), ("host", {})):
+        for mode, kw in (("host", {}), ("auto", {"device_share": 0.125}), ("auto", {"device_share": 0.25}), ("host", {})):
             shutil.rmtree(out_dir, ignore_errors=True)
             info = run_files.run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, whitelist_keys=keys, gz="device", inflate=mode, **kw)
             res["runs"].append({"inflate": mode, **kw, **{k: info[k] for k in ("reads_per_s", "wall_s", "inflate_and_pass1_s", "inflate_thread_seconds", "pass2_and_gzip_s",
-                                                                                "write_files_s", "files_inflated_on_device", "text_in_bytes", "text_resident_bytes", "assigned")}})
+                                                                                "write_files_s", "files_inflated_on_device", "device_inflate_rounds", "text_in_bytes", "text_resident_bytes", "assigned")}})
             print(json.dumps(res["runs"][-1]), file=sys.stderr, flush=True)
         res["same_assigned"] = len({r["assigned"] for r in res["runs"]}) == 1
         print(json.dumps(res))
