@@ -1218,6 +1218,7 @@ class Context:
         S = np.zeros((n, 4), dtype=np.uint64)
         S[:, 0], S[:, 1], S[:, 2], S[:, 3] = in_off, sizes, out_off, out_caps
         R = np.zeros(n, dtype=np.dtype([("out_len", "<u8"), ("status", "<u4"), ("n_members", "<u4")]))
+        torch.cuda.current_stream().synchronize()      # the upload (on the caller's torch stream) before the context's own stream reads it
         self._check(self._lib.smi_gz_inflate_device(self._h, _ptr(d_in), S.ctypes.data, n, _ptr(d_out), R.ctypes.data, None))
         return d_out, np.array(out_off, dtype=np.int64), R["out_len"].astype(np.int64), R["status"].copy(), R["n_members"].copy()
 

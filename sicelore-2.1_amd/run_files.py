@@ -194,6 +194,14 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     staging = threading.local()          # one page-locked buffer per worker thread, reused from file to file
     staged = []
 
+    def side_stream():
+        """the calling thread's own torch stream: uploads and the line-end search must not run on the default stream, which waits for every
+        other stream of the device -- a K-INFLATE round (a second) included"""
+        st = getattr(staging, "stream", None)
+        if st is None:
+            st = staging.stream = torch.cuda.Stream(dev)
+        return st
+
     def stage_alloc(n):
         """where a file that will live in HBM is inflated to: the thread's page-locked buffer (uploads from it run at link speed and side by side
         on all threads; pageable memory goes through the runtime's one staging path)"""
@@ -217,11 +225,13 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         cpu_inflate[fi] = time.perf_counter() - t1
         if resident:
             held[0] += t.size
-            td = torch.from_numpy(t).to(dev)                  # one upload; both passes read the text from HBM
+            with torch.cuda.stream(side_stream()):
+                td = torch.from_numpy(t).to(dev)              # one upload; both passes read the text from HBM
+                cuts = device_cuts(td)
+                side_stream().synchronize()
             if owner is not None:
                 owner.close()
                 owners[fi] = None
-            cuts = device_cuts(td)
             return td, cuts, [with_lane(p1)(td, rng) for rng in cuts]
         cuts = _cut_chunks(t, reads_per_chunk)
         recs_ = [with_lane(p1)(t, rng) for rng in cuts]
@@ -266,7 +276,9 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         per_round = max(1, min(512, int(len(todo) * device_share))) if inflate == "auto" else 512
 
         def count_dev(fi, t):
-            cuts = device_cuts(t)
+            with torch.cuda.stream(side_stream()):
+                cuts = device_cuts(t)
+                side_stream().synchronize()
             return t, cuts, [with_lane(p1)(t, rng) for rng in cuts]
 
         def device_part():
@@ -301,7 +313,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                         t2 = time.perf_counter()
                         following = take()            # the next round is read and laid out while this one runs on the device
                         nxt = prefetch.submit(prepare, following, 1 - k) if following else None
-                        d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(packed=packed)
+                        with torch.cuda.stream(side_stream()):
+                            d_out, offs, lens, status, _ = lanes[k_lane].gz_inflate_device(packed=packed)
                         t_dev[0] += time.perf_counter() - t1
                         dev_detail.append((len(mine), round(t2 - t1, 3), round(time.perf_counter() - t2, 3)))
                         n_rounds[0] += 1
