@@ -112,7 +112,7 @@ def _gzip_member(data, level):
 
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
-        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="auto", device_share=0.4, group=None, resident_bytes=96 << 30,
+        dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="host", device_share=0.25, group=None, resident_bytes=96 << 30,
         host_text_bytes=256 << 30, inflate_auto_from=1024):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
@@ -120,9 +120,11 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     "zlib": the packed worker's host-written records through zlib at gz_level on the worker threads.
     resident_bytes: with gz="device" a file's text is uploaded ONCE, when it has been inflated, and stays in HBM for both passes (the chunk
     workers take device pointers) until this many bytes are held; files beyond that are uploaded per pass from the host as before.
-    inflate: "host" = the library's decoder on the worker threads; "device" = K-INFLATE for every *.gz file, 512 per round; "auto" = both,
-    working one queue of files from its two ends, from inflate_auto_from files on (a round on the device costs the time of ONE file however
-    many run in it, so it pays for many files of moderate size: a flow cell's thousands of 4,000-read files), the host alone below that.
+    inflate: "host" (default) = the library's decoder on the worker threads; "device" = K-INFLATE for every *.gz file, 512 per round;
+    "auto" = both, working one queue of files from its two ends, from inflate_auto_from files on (a round on the device costs the time of ONE
+    file however many run in it).  Measured on 2,048 files of 4,000 reads (profiles/r03/f2f_many_files.json): the host alone 3.0 - 3.1 s for
+    inflate + pass 1, host + device 4.2 - 4.3 s -- with the library's own decoder on sixteen cores the device's rounds no longer pay, they
+    hold LDS that pass 1 wants; "auto" is kept for hosts with fewer cores per GPU.
     host_text_bytes: how much inflated text may wait in host memory between the passes; the text of files beyond that is dropped after pass 1
     and inflated again in pass 2 (the reference reads every file twice, NanoporeReadScannerMain.java:L306) -- a run of any size.
     With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
