@@ -362,3 +362,31 @@ def test_native_batch_writer_equals_the_python_mirror(pkg, five_prime, truncate,
         bc, exp_bc, umi, exp_umi, g1, g2 = _write_batch_case(libmod, au, seed, five_prime, truncate, limit)
         assert bc == exp_bc and umi == exp_umi and len(bc) > 50_000 and 0 < len(umi) < len(bc)
         assert g1 == g2 and g1[2]["gene_entries"] > 5 and g1[2]["records_skipped_clipping"] > 0
+
+
+def test_chunk_bounds_equal_the_reader_loop(pkg):
+    """BamReader.run's cuts as positions (assignumis.chunk_bounds, what the native and the streamed pipeline use) against the record-by-record
+    loop that mirrors the reference (assignumis._run_chunks): chunk sizes 1 - 11, up to four chromosomes, empty and one-record inputs"""
+    import importlib
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    rng = np.random.default_rng(3)
+    n_cases = 0
+    for t in range(400):
+        n = int(rng.integers(0, 70))
+        ref = np.sort(rng.integers(0, 4, n))
+        if t % 9 == 0 and n > 3:
+            ref[-2:] = -1                                             # an unmapped tail is one more "chromosome"
+        cs = int(rng.integers(1, 12))
+        recs = np.zeros(n, dtype=[("ref_id", "<i4")])
+        recs["ref_id"] = ref
+        got = []
+
+        def flush(cur, keep):
+            got.append((cur[-1] + 1, keep))
+            return []
+
+        au._run_chunks(recs, cs, flush)
+        assert (got[:-1] if n else got) == au.chunk_bounds(ref, cs), (t, n, cs)     # (the loop's last flush is the end of the file)
+        n_cases += 1
+    assert n_cases == 400
