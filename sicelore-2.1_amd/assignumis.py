@@ -617,6 +617,30 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
                              wall_s=time.perf_counter() - t0, bam_bytes=int(bam.size))
 
 
+def segment_cuts(ref, cur_n, g0, i0, prev_ref, step):
+    """BamReader.run's cuts among the records of one segment of a streamed BAM.  ref: reference index of the segment's records (local index
+    k = global index g0 + k); the first cur_n of them are already in the chunk being collected; i0: global position of the last cut (-1:
+    none yet); prev_ref: reference of the record in front of the segment (None at the start of the file); step: chunk size.
+    -> ([(local position in front of which the chunk is closed, keep)], i0 afterwards): closed after `step` records, or in front of the first
+    record of another chromosome (keep = False: nothing is held back for the next chunk)"""
+    m = int(len(ref))
+    change = (np.flatnonzero(ref[1:] != ref[:-1]) + 1).tolist() if m > 1 else []
+    if m and prev_ref is not None and cur_n == 0 and g0 > 0 and int(ref[0]) != prev_ref:
+        change = [0] + change
+    change = [c for c in change if c >= cur_n]             # (changes inside the chunk being collected were cut when they were met)
+    cuts, ci = [], 0
+    while True:
+        by_count = max(i0 + step, 1) - g0
+        while ci < len(change) and g0 + change[ci] <= i0:
+            ci += 1
+        nxt = change[ci] if ci < len(change) else m
+        at = min(by_count, nxt)
+        if at >= m:
+            return cuts, i0
+        cuts.append((at, at != nxt))
+        i0 = g0 + at
+
+
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
@@ -732,11 +756,7 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
         tags = np.zeros(max(m, 1), dtype=_lib.UMI_TAG_DTYPE)
         region = np.full(max(m, 1), -1, dtype=np.int64)
         ref = recs["ref_id"].astype(np.int64)
-        # the flush positions among this segment's records (local index k = global g0 + k): by count (i0 + step) or at a change of chromosome
-        change = np.flatnonzero(ref[1:] != ref[:-1]) + 1 if m > 1 else np.zeros(0, dtype=np.int64)
-        if m and prev_ref is not None and cur_n == 0 and g0 > 0 and int(ref[0]) != prev_ref:
-            change = np.concatenate([[0], change])
-        change = [int(c) for c in change if c >= cur_n]      # (changes inside the chunk being collected were flushed when they were met)
+        cuts, i0 = segment_cuts(ref, cur_n, g0, i0, prev_ref, step)
         cur = np.arange(0, cur_n, dtype=np.int32)          # local indices of the chunk being collected (they lead pend)
         k = cur_n                                          # next local record to append
 
@@ -765,17 +785,9 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             n_batches += 1
             return cur[n_done:]
 
-        ci = 0
-        while True:
-            by_count = max(i0 + step, 1) - g0                # local position of the next flush by count
-            while ci < len(change) and g0 + change[ci] <= i0:
-                ci += 1
-            nxt = change[ci] if ci < len(change) else m
-            at = min(by_count, nxt)
-            if at >= m:
-                break
-            cur = flush(np.concatenate([cur, np.arange(k, at, dtype=np.int32)]), keep=(at != nxt))
-            i0, k = g0 + at, at
+        for at, keep in cuts:
+            cur = flush(np.concatenate([cur, np.arange(k, at, dtype=np.int32)]), keep=keep)
+            k = at
         cur = np.concatenate([cur, np.arange(k, m, dtype=np.int32)])
         if eof:
             while cur.size:

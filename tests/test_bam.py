@@ -390,3 +390,40 @@ def test_chunk_bounds_equal_the_reader_loop(pkg):
         assert (got[:-1] if n else got) == au.chunk_bounds(ref, cs), (t, n, cs)     # (the loop's last flush is the end of the file)
         n_cases += 1
     assert n_cases == 400
+
+
+def test_segment_cuts_of_a_streamed_bam_equal_the_whole_file_cuts(pkg):
+    """assignumis_stream's cut positions (segment_cuts, segment after segment, with whatever the grouping holds back carried over) against
+    chunk_bounds on the whole file"""
+    import importlib
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    rng = np.random.default_rng(4)
+    for t in range(300):
+        n = int(rng.integers(1, 120))
+        ref = np.sort(rng.integers(0, 4, n)).astype(np.int64)
+        step = int(rng.integers(1, 15))
+        want = au.chunk_bounds(ref, step)
+        got = []
+        g0, i0, prev_ref, cur_n, pos = 0, -1, None, 0, 0          # pos: global index of the first record not yet read
+        while pos < n or cur_n:
+            take = int(rng.integers(0, 25))                       # records the next segment adds (0: a segment that ends inside a record)
+            hi = min(n, pos + take)
+            seg = ref[g0:hi]                                      # pending records + the new ones
+            cuts, i0 = au.segment_cuts(seg, cur_n, g0, i0, prev_ref, step)
+            k_first = 0                                           # local index of the first record that is still pending after the cuts
+            for at, keep in cuts:
+                got.append((g0 + at, keep))
+                held = int(rng.integers(0, at - k_first + 1)) if keep else 0      # what the grouping holds back for the next chunk
+                k_first = at - held
+            if hi == n and pos >= n:
+                break
+            m = len(seg)
+            if m:
+                prev_ref = int(seg[m - 1])
+            cur_n = m - k_first
+            g0 += k_first
+            pos = hi
+            if pos >= n:                                          # the end of the file: what is pending is flushed, no further cut positions
+                break
+        assert got == want, (t, n, step, got, want)
