@@ -79,6 +79,8 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=10_000_000, help="--config 2: reads per batch resident in HBM")
     ap.add_argument("--total-reads", type=int, default=0, help="strong scaling: this many reads in ALL, sharded over the ranks (configs[3]: 100000000 with --gpus 8)")
     ap.add_argument("--umi-molecules", type=int, default=50_000, help="molecules of the UMI-stage leg (each read six times); 0 = skip")
+    ap.add_argument("--overlap", action="store_true",
+                    help="run the timed steps as a two-stage pipeline: K-BC1 of a step on a second stream while K-SCAN of the next step runs")
     ap.add_argument("--assignumis-file-records", type=int, default=100_000,
                     help="records of the BAM -> tagged BAM leg (assignumis_file_to_file; 0 = off; needs the UMI leg)")
     ap.add_argument("--h2h-reads", type=int, default=500_000, help="reads per chunk of the host-to-host leg (packed boundary); 0 = skip")
@@ -931,18 +933,51 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.set_timing(True)
     scan_ms, match_ms = [], []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # HIP events were recorded on the launch stream around each kernel; reading them waits for this step's
-        # kernels (one sync per step inside the timed region -- conservative)
-        if n:
-            scan_ms.append(ctx.kernel_ms(ctx.K_SCAN))
-            match_ms.append(ctx.kernel_ms(ctx.K_BC_MATCH))
-    barrier()
-    t1 = time.perf_counter()
+    if args.overlap and n:
+        # the same steps as a two-stage pipeline: K-SCAN of step k + 1 on one stream while K-BC1 of step k runs on another (two window
+        # buffers, events between the stages).  Kernel durations: events around each launch on its own stream, read after the loop
+        s_scan, s_bc = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        wins = [win, torch.zeros_like(win)]
+        scanned = [torch.cuda.Event() for _ in range(2)]
+        matched = [None, None]
+        marks = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            b = k & 1
+            with torch.cuda.stream(s_scan):
+                if matched[b] is not None:
+                    s_scan.wait_event(matched[b])            # K-BC1 of step k - 2 has read this window buffer
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                ctx.scan_device(ends, lens, n, scan_cfg, scan_out, wins[b])
+                a1.record()
+                scanned[b] = a1
+            with torch.cuda.stream(s_bc):
+                s_bc.wait_event(scanned[b])
+                b0, b1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                b0.record()
+                ctx.bc_match_device(wins[b], out, n, max_ed=1, five_prime=False)
+                b1.record()
+                matched[b] = b1
+            marks.append((a0, a1, b0, b1))
+        barrier()
+        t1 = time.perf_counter()
+        scan_ms = [a0.elapsed_time(a1) for a0, a1, _, _ in marks]
+        match_ms = [b0.elapsed_time(b1) for _, _, b0, b1 in marks]
+    else:
+        ctx.set_timing(True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            # HIP events were recorded on the launch stream around each kernel; reading them waits for this step's
+            # kernels (one sync per step inside the timed region -- conservative)
+            if n:
+                scan_ms.append(ctx.kernel_ms(ctx.K_SCAN))
+                match_ms.append(ctx.kernel_ms(ctx.K_BC_MATCH))
+        barrier()
+        t1 = time.perf_counter()
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
