@@ -49,6 +49,16 @@ def test_bench_pack_kernel_gives_the_same_step():
         assert a["config"][key] == b["config"][key], key
 
 
+def test_bench_overlap_gives_the_same_assignments():
+    """--overlap: the steps as a two-stage pipeline on two streams (two window buffers, events between the stages) -> the same assignments"""
+    common = ("--reads", "200000", "--whitelist", "400000", "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--e2e-reads", "0", "--two-pass-reads", "0",
+              "--umi-molecules", "0", "--h2h-reads", "0", "--f2f-reads", "0")
+    a, b = _run(*common), _run(*common, "--overlap")
+    for key in ("bc_assigned_total", "adapter_found_frac", "bc_assigned_accuracy"):
+        assert a["config"][key] == b["config"][key], key
+    assert b["steps"] == 5 and b["value"] > 0 and len(b["roofline"]["kernels_ms"]) == 2
+
+
 def test_bench_config2_small():
     d = _run("--config", "2", "--reads", "400000", "--batch", "200000", "--whitelist", "400000", "--steps", "2", "--warmup", "1")
     _common(d, 2)
