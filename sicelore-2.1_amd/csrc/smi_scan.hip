@@ -688,7 +688,12 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
 }
 
 static size_t scan_lds_bytes() {
-    return (size_t)4 * kLdsWords * kBlock * 4 + (size_t)3 * kBlock * 8 + (size_t)kBlock * 4 + (size_t)kBlock * 5 * 4;
+    size_t bytes = (size_t)4 * kLdsWords * kBlock * 4 + (size_t)3 * kBlock * 8 + (size_t)kBlock * 4 + (size_t)kBlock * 5 * 4;
+#ifdef SMI_MEASURE
+    // measurement builds only: extra (unused) LDS per block, to hold K-SCAN to fewer blocks per CU when another kernel should run beside it
+    if (const char *pad = std::getenv("SMI_SCAN_LDS_PAD")) bytes += (size_t)std::atoi(pad);
+#endif
+    return bytes;
 }
 
 static int thr_for(int len, float limit_f, bool use_double, double limit_d) {
