@@ -210,6 +210,7 @@ JDK_IFACES = {
     "java/util/LinkedList": ["java/util/List", "java/util/Collection", "java/lang/Iterable", "java/util/Deque", "java/util/Queue"],
     "java/util/ArrayDeque": ["java/util/Deque", "java/util/Queue", "java/util/Collection", "java/lang/Iterable"],
     "java/lang/String": ["java/lang/CharSequence", "java/lang/Comparable"],
+    "java/lang/StringBuilder": ["java/lang/CharSequence", "java/lang/Appendable"],
     "java/lang/Integer": ["java/lang/Comparable"], "java/lang/Long": ["java/lang/Comparable"], "java/lang/Float": ["java/lang/Comparable"],
     "java/lang/Double": ["java/lang/Comparable"],
 }

@@ -595,6 +595,8 @@ def install(jvm):
     def to_array(j, o, a=None):
         if a is None:
             return JArray("Ljava/lang/Object;", list(o.native))
+        if isinstance(a, JLambda):       # Collection.toArray(IntFunction) (a default method since Java 11): toArray(generator.apply(0))
+            a = j.call_fn(j, a, 0)
         if len(a.a) < len(o.native):
             return JArray(a.etype, list(o.native))
         a.a[:len(o.native)] = o.native

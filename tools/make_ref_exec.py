@@ -750,6 +750,7 @@ class UmiSide:
         nr.f["readScanData"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", sd)
         o = j.new_object(ONR)
         o.f["nanoporeRead"] = nr
+        o.f["userObject"] = j.natives["java/util/Optional.empty"](j)   # the field's initialiser (the constructor is not run)
         return o
 
     def distance(self, r1, r2):
