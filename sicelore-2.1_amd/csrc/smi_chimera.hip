@@ -19,6 +19,7 @@
 // Integer / bitwise work: no MFMA.  Planes are read from global memory (they are touched a few times, L2-resident),
 // so the read length is not limited by LDS.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1270,6 +1271,399 @@ __global__ __launch_bounds__(64) void k_chimera_serial(const uint32_t *__restric
     }
 }
 
+// =================================================================================================================
+// K-CHIM-B, second generation (round 4): SELECT -> ALIGN -> FOLD.
+//
+// The exact internal TSO scan of one read is a chain: the scan visits the gated positions in order, aligns each one it
+// visits, and a rejected alignment with nErrors > max makes it skip delta = round(nErrors - max) - 1 positions
+// (AdapterTSOanalyzer.java:L146-150).  The first generation (k_chimera<.., 1>) therefore aligned EVERY gated position
+// of a queued read (~70 per read, one wave per read, 2 batches at half-filled lanes).  Almost all of that work cannot
+// matter:
+//   * only a position whose Levenshtein bound (myers_bound) is <= max can be ACCEPTED ("hot");
+//   * a gated position c only ever influences whether positions in (c, c + delta(c)) are visited, and
+//     delta(c) < kDmax for every gated position (below);
+// so the accepted set is decided by the hot positions and, transitively, by the gated positions less than kDmax in
+// front of a position that matters ("needed": the backward closure).  A gated position with nothing needed inside
+// (c, c + kDmax) is dropped without changing what the scan accepts: the first needed position behind such a gap is
+// visited whatever happened before it, because a skip from a position p lands at most at p + kDmax - 1.
+//
+// delta < kDmax.  A gated position has >= 5 pattern bases matching on the diagonal (two 4-mers), so the optimal
+// alignment scores at least the diagonal's 5*5 - 5*(N-5).  With m matches, x mismatches and g gaps per sequence
+// (m + x + g = N) a path scores at most 5m - 5x - 9g (a leading template gap costs 4, every other gap 5), hence
+// 10m - 4g >= 50, and #x = x + 2g = N - m + g <= N - 5 + 0.6g with g <= (N - 5) / 1.4: #x <= 31 for N = 27, 24 for
+// N = 22, and delta = round(#x - 0.9 lead - max) - 1 <= 30.  kDmax = 32; K-CHIM-B-FOLD still checks every delta it
+// computes and hands the read to the serial kernel if one ever reached kDmax.
+//
+//   k_chimb_select  one wave per queued read: 4-mer gates (lane = 32 positions), the bound for every gated position,
+//                   the closure from the right, the needed positions appended to a global queue
+//   k_chimb_align   one LANE per queued position, all lanes busy: 27 x 27 banded alignment, error count only
+//   k_chimb_fold    one wave per queued read: the skip rule over its needed positions, the accepted ones sorted and
+//                   filtered as before -> TsoSlot
+// =================================================================================================================
+constexpr int kDmax = 32;
+constexpr int kSelCap = 512;  // gated positions per orientation of one read held in LDS; more: the serial kernel takes the read
+
+struct BHead {  // per queue slot: where the read's needed positions sit in the global queue (orientation 0 first)
+    uint32_t first, n0, n1, flags;  // flags 1: over capacity -> serial kernel
+};
+
+struct SelLds {
+    uint32_t cmask[2][64];
+    int coff[2][64];
+    int cpos[2][kSelCap];
+    uint8_t cflag[2][kSelCap];  // bit 0 hot, bit 1 needed
+};
+
+// 4-mer gate (>= 2 matching 4-mers on the diagonal) of pattern orientation O for the 32 scan positions whose window is W
+template <int kTsoLen, int PAT, int O>
+__device__ __forceinline__ uint32_t tso_gate32(const uint64_t (&W)[4], const FilterParams &P) {
+    auto mj = [&](int j) -> uint32_t {
+        if constexpr (PAT != 0) {
+            return (uint32_t)(W[gate_plane<PAT, kTsoLen>(O, j)] >> j);
+        } else {
+            const uint32_t a4 = P.tso4[O][j];
+            uint64_t x = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if ((a4 >> c) & 1u) x |= W[c];
+            return (uint32_t)(x >> j);
+        }
+    };
+    uint32_t any = 0, two = 0;
+    const uint32_t m0 = mj(0), m1 = mj(1);
+    uint32_t m_prev = mj(2);
+    uint32_t p01 = m0 & m1, p12 = m1 & m_prev;
+#pragma unroll
+    for (int i = 0; i + 3 < kTsoLen; i++) {
+        const uint32_t m3 = mj(i + 3);
+        const uint32_t p23 = m_prev & m3;
+        const uint32_t k = p01 & p23;
+        two |= any & k;
+        any |= k;
+        p01 = p12;
+        p12 = p23;
+        m_prev = m3;
+    }
+    return two;
+}
+
+// the gated positions of one orientation in this 2048-position segment: bound each, append (position, hot) to the LDS list
+template <int kTsoLen, int PAT, int O>
+__device__ __forceinline__ void select_orient(SelLds &L, const ReadPlanes &rp, const FilterParams &P, int p0, int lane, uint32_t cm, int &n_c) {
+    int total;
+    const int off = wave_exscan_i(__popc(cm), lane, total);
+    if (total == 0) return;
+    L.cmask[O][lane] = cm;
+    L.coff[O][lane] = off;
+    wave_sync();
+    for (int base = 0; base < total; base += 64) {
+        const int en = base + lane;
+        const bool live = en < total;
+        uint32_t V[4] = {0, 0, 0, 0};
+        int pos = 0;
+        if (live) {
+            int lo = 0, hi = 64;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (L.coff[O][mid] <= en)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            pos = p0 + 32 * lo + kth_bit32(L.cmask[O][lo], en - L.coff[O][lo]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) V[c] = __brev(gget32(rp.p[c], pos - 1)) >> (32 - kTsoLen);
+        }
+        bool hot = live;
+        if (P.myers_ok) {  // (a pattern with IUPAC codes has no bound: every gated position counts as hot, i.e. everything is aligned)
+            int b;
+            if constexpr (PAT != 0)
+                b = myers_bound_ct<kTsoLen, PAT, O>(V, P.lead_max);
+            else
+                b = myers_bound<kTsoLen>(V, O ? P.rev_idx : P.fwd_idx, P.lead_max);
+            hot = live && b <= P.tso_max;
+        }
+        const int slot = n_c + en;
+        if (live && slot < kSelCap) {
+            L.cpos[O][slot] = pos;
+            L.cflag[O][slot] = hot ? 1 : 0;
+        }
+    }
+    n_c += total;
+    wave_sync();
+}
+
+template <int kTsoLen, int PAT>
+__global__ __launch_bounds__(256) void k_chimb_select(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+                                                      const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list,
+                                                      const uint32_t *__restrict__ list_count, FilterParams P,
+                                                      const smi_chimera_result *__restrict__ out, BHead *__restrict__ heads,
+                                                      uint64_t *__restrict__ cand_abs, uint32_t *__restrict__ gcount, uint32_t cap) {
+    __shared__ SelLds lds_all[4];
+    SelLds &L = lds_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_list = *list_count;
+    for (size_t li = wave; li < n_list; li += n_waves) {
+        const size_t r = list[li];
+        if (!(out[r].n_matches & SMI_CHIMA_TSO)) continue;  // K-CHIM-A's verdict
+        const uint64_t beg = offsets[r];
+        const int len = (int)(offsets[r + 1] - beg);
+        ReadPlanes rp;
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
+#pragma unroll
+        for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
+        const int last = len - 70;
+        int n_c[2] = {0, 0};
+        for (int p0 = 70; p0 <= last; p0 += 2048) {
+            const int pl = p0 + 32 * lane;
+            uint32_t cm0 = 0, cm1 = 0;
+            if (pl <= last) {
+                uint64_t W[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) W[c] = gget64(rp.p[c], pl - 1);
+                const int nb = last - pl + 1;
+                const uint32_t keep = nb >= 32 ? 0xFFFFFFFFu : ((1u << nb) - 1u);
+                cm0 = tso_gate32<kTsoLen, PAT, 0>(W, P) & keep;
+                cm1 = tso_gate32<kTsoLen, PAT, 1>(W, P) & keep;
+            }
+            select_orient<kTsoLen, PAT, 0>(L, rp, P, p0, lane, cm0, n_c[0]);
+            select_orient<kTsoLen, PAT, 1>(L, rp, P, p0, lane, cm1, n_c[1]);
+        }
+        BHead h;
+        h.first = h.n0 = h.n1 = h.flags = 0;
+        if (n_c[0] > kSelCap || n_c[1] > kSelCap) {
+            h.flags = 1;
+            if (lane == 0) heads[li] = h;
+            continue;
+        }
+        // closure from the right, 64 gated positions at a time: needed = hot, or something needed lies less than kDmax behind
+        uint32_t n_need[2] = {0, 0};
+#pragma unroll 1
+        for (int o = 0; o < 2; o++) {
+            long long next_needed = 1LL << 40;
+            for (int hi = n_c[o]; hi > 0;) {
+                const int lo = hi > 64 ? hi - 64 : 0;
+                const int i = lo + lane;
+                const bool live = i < hi;
+                const int pos_i = live ? L.cpos[o][i] : 0;
+                const bool hot_i = live && (L.cflag[o][i] & 1);
+                unsigned long long N = __ballot(hot_i);
+                bool need_i = hot_i;
+                for (;;) {
+                    const unsigned long long above = lane == 63 ? 0ull : ((N >> (lane + 1)) << (lane + 1));
+                    const int j = above ? __builtin_ctzll(above) : -1;
+                    const int pj_in = __shfl(pos_i, j < 0 ? 0 : j);
+                    const long long pj = j >= 0 ? (long long)pj_in : next_needed;
+                    need_i = live && (hot_i || pj - (long long)pos_i < kDmax);
+                    const unsigned long long N2 = __ballot(need_i);
+                    if (N2 == N) break;
+                    N = N2;
+                }
+                if (live) L.cflag[o][i] = (uint8_t)((hot_i ? 1 : 0) | (need_i ? 2 : 0));
+                if (N) next_needed = __shfl(pos_i, __builtin_ctzll(N));
+                n_need[o] += (uint32_t)__popcll(N);
+                hi = lo;
+            }
+        }
+        wave_sync();
+        const uint32_t total = n_need[0] + n_need[1];
+        uint32_t first = 0;
+        if (total) {
+            if (lane == 0) first = atomicAdd(gcount, total);
+            first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+        }
+        if ((unsigned long long)first + total > cap) {
+            h.flags = 1;
+            if (lane == 0) heads[li] = h;
+            continue;
+        }
+        const uint64_t bit_base = (uint64_t)w0 * 32u;
+#pragma unroll 1
+        for (int o = 0; o < 2; o++) {
+            uint32_t run = first + (o ? n_need[0] : 0u);
+            for (int lo = 0; lo < n_c[o]; lo += 64) {
+                const int i = lo + lane;
+                const bool need = i < n_c[o] && (L.cflag[o][i] & 2);
+                const unsigned long long nb = __ballot(need);
+                if (need) cand_abs[run + __popcll(nb & ((1ull << lane) - 1ull))] = (bit_base + (uint64_t)(L.cpos[o][i] - 1)) | ((uint64_t)o << 63);
+                run += (uint32_t)__popcll(nb);
+            }
+        }
+        h.first = first;
+        h.n0 = n_need[0];
+        h.n1 = n_need[1];
+        if (lane == 0) heads[li] = h;
+        wave_sync();
+    }
+}
+
+// one lane per queued position
+template <int kTsoLen>
+__global__ __launch_bounds__(256, SMI_CHIM_B_WAVES) void k_chimb_align(const uint32_t *__restrict__ planes, size_t stride, const uint64_t *__restrict__ cand_abs,
+                                                                         const uint32_t *__restrict__ gcount, uint32_t cap, ChimParams P,
+                                                                         float *__restrict__ cand_ne) {
+    const uint32_t total = min(*gcount, cap);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const uint64_t a = cand_abs[e];
+        const int o = (int)(a >> 63);
+        const uint64_t bit = a & 0x7FFFFFFFFFFFFFFFull;
+        const size_t w = (size_t)(bit >> 5);
+        const int sh = (int)(bit & 31u);
+        uint32_t W[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t *pl = planes + c * stride + w;
+            W[c] = (uint32_t)((((uint64_t)pl[1] << 32) | pl[0]) >> sh) & ((1u << kTsoLen) - 1u);
+        }
+        uint32_t col[kTsoLen];
+#pragma unroll
+        for (int c = 0; c < kTsoLen; c++) {
+            uint32_t f = 0, r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if ((P.tso4[0][c] >> k) & 1u) f |= W[k];
+                if ((P.tso4[1][c] >> k) & 1u) r |= W[k];
+            }
+            col[c] = o ? r : f;
+        }
+        cand_ne[e] = nw_errors<kTsoLen, nw_band<kTsoLen, 5>()>(col);
+    }
+}
+
+struct FoldLds {
+    int acc_pos[2][kCap];
+    float acc_ne[2][kCap];
+    int srt_pos[kCap];
+    float srt_ne[kCap];
+    int m_begin[kCap];
+    int m_kind[kCap];
+};
+
+template <int kTsoLen>
+__global__ __launch_bounds__(256) void k_chimb_fold(const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count, int tso_max,
+                                                    const smi_chimera_result *__restrict__ out, const BHead *__restrict__ heads,
+                                                    const uint64_t *__restrict__ cand_abs, const float *__restrict__ cand_ne,
+                                                    TsoSlot *__restrict__ slots) {
+    __shared__ FoldLds lds_all[4];
+    FoldLds &L = lds_all[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_list = *list_count;
+    for (size_t li = wave; li < n_list; li += n_waves) {
+        const size_t r = list[li];
+        if (!(out[r].n_matches & SMI_CHIMA_TSO)) continue;
+        const BHead h = heads[li];
+        if (h.flags & 1u) {
+            if (lane == 0) slots[li].n = kCap + 1;
+            continue;
+        }
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(offsets[r], r);
+        const uint64_t bit_base = (uint64_t)w0 * 32u;
+        int n_m = 0;
+        bool overflow = false;
+        int n_acc2[2] = {0, 0};
+        const float maxe = (float)tso_max;
+#pragma unroll 1
+        for (int o = 0; o < 2; o++) {
+            const int n = (int)(o ? h.n1 : h.n0);
+            const uint32_t e0 = h.first + (o ? h.n0 : 0u);
+            int skip = 0;  // next position the reference's scan looks at
+            for (int k = 0; k < n; k += 64) {
+                const int e = k + lane;
+                int pos = 0x7FFFFFFF;
+                float ne = 0.0f;
+                if (e < n) {
+                    pos = (int)((cand_abs[e0 + e] & 0x7FFFFFFFFFFFFFFFull) - bit_base) + 1;
+                    ne = cand_ne[e0 + e];
+                }
+                int delta_l = 1;
+                if (maxe < ne) {  // L146-150
+                    delta_l = jround(__fsub_rn(ne, maxe)) - 1;
+                    if (delta_l < 1) delta_l = 1;
+                }
+                if (__ballot(e < n && delta_l >= kDmax)) overflow = true;  // (never seen; the closure of k_chimb_select rests on it)
+                const int ok_l = !(ne > maxe) ? 1 : 0;  // getPosbelowMaxMismatches: key <= max (L302)
+                const int cnt = min(64, n - k);
+                unsigned long long taken = 0;
+                for (int i = 0; i < cnt; i++) {  // scalar fold in scan order
+                    const int p = __builtin_amdgcn_readlane(pos, i);
+                    if (p < skip) continue;
+                    if (__builtin_amdgcn_readlane(ok_l, i)) taken |= 1ull << i;
+                    skip = p + __builtin_amdgcn_readlane(delta_l, i);
+                }
+                if ((taken >> lane) & 1ull) {
+                    const int slot = n_acc2[o] + __popcll(taken & ((1ull << lane) - 1ull));
+                    if (slot < kCap) {
+                        L.acc_pos[o][slot] = pos;
+                        L.acc_ne[o][slot] = ne;
+                    }
+                }
+                n_acc2[o] += __popcll(taken);
+            }
+        }
+#pragma unroll 1
+        for (int o = 0; o < 2; o++) {
+            int n_acc = n_acc2[o];
+            if (n_acc > kCap) {
+                overflow = true;
+                n_acc = kCap;
+            }
+            wave_sync();
+            // sort by (score, position): rank by counting (n_acc <= 64)
+            if (lane < n_acc) {
+                const float me = L.acc_ne[o][lane];
+                const int mp = L.acc_pos[o][lane];
+                int rank = 0;
+                for (int j = 0; j < n_acc; j++) {
+                    const float e = L.acc_ne[o][j];
+                    const int p = L.acc_pos[o][j];
+                    rank += (e < me || (e == me && p < mp)) ? 1 : 0;
+                }
+                L.srt_pos[rank] = mp;
+                L.srt_ne[rank] = me;
+            }
+            wave_sync();
+            // L115-123: entry i dropped when < 3 away from entry i-1 of the sorted list
+            int mypos = 0;
+            bool keep = false;
+            if (lane < n_acc) {
+                mypos = L.srt_pos[lane];
+                keep = lane == 0 || abs(mypos - L.srt_pos[lane - 1]) >= 3;
+            }
+            const unsigned long long kb = __ballot(keep);
+            const int idx = __popcll(kb & ((1ull << lane) - 1ull));
+            const int n_keep = __popcll(kb);
+            wave_sync();
+            const int begin = o ? mypos + kTsoLen - 1 : mypos;  // L161
+            if (keep) L.acc_pos[o][idx] = begin;
+            wave_sync();
+            // L163: begin > prev.getAndSet(begin) + 120, prev = previous list element
+            bool pass = false;
+            if (lane < n_keep) pass = lane == 0 || L.acc_pos[o][lane] > L.acc_pos[o][lane - 1] + 120;
+            const unsigned long long pb = __ballot(pass);
+            if (pass) {
+                const int slot = n_m + __popcll(pb & ((1ull << lane) - 1ull));
+                if (slot < kCap) {
+                    L.m_begin[slot] = L.acc_pos[o][lane];
+                    L.m_kind[slot] = o;
+                }
+            }
+            n_m += __popcll(pb);
+            wave_sync();
+        }
+        if (lane < min(n_m, kCap)) {
+            slots[li].begin[lane] = L.m_begin[lane];
+            slots[li].kind[lane] = L.m_kind[lane];
+        }
+        if (lane == 0) slots[li].n = (overflow || n_m > kCap) ? kCap + 1 : n_m;
+        wave_sync();
+    }
+}
+
 // queue of the reads whose result carries SMI_CHIM_OVERFLOW
 __global__ void k_collect_overflow(const smi_chimera_result *__restrict__ out, const uint32_t *__restrict__ list,
                                    const uint32_t *__restrict__ list_count, uint32_t *__restrict__ over, uint32_t *__restrict__ over_count) {
@@ -1479,6 +1873,20 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     uint32_t n_list = 0;
     SMI_HIP(hipMemcpyAsync(&n_list, d_count, 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
+#ifdef SMI_MEASURE
+    if (getenv("SMI_CHIM_STATS")) {  // how many reads K-CHIM-A queues, and for what
+        std::vector<smi_chimera_result> h(n);
+        SMI_HIP(hipMemcpy(h.data(), d_out, n * sizeof(smi_chimera_result), hipMemcpyDeviceToHost));
+        size_t n_tso = 0, n_pat = 0, n_both = 0;
+        for (size_t i = 0; i < n; i++) {
+            const int v = h[i].n_matches;
+            n_tso += (v & SMI_CHIMA_TSO) != 0;
+            n_pat += (v & SMI_CHIMA_PAT) != 0;
+            n_both += v == (SMI_CHIMA_TSO | SMI_CHIMA_PAT);
+        }
+        fprintf(stderr, "[chim stats] reads %zu queued %u tso %zu pat %zu both %zu\n", n, n_list, n_tso, n_pat, n_both);
+    }
+#endif
     if (n_list) {
         const size_t slot_bytes = (size_t)n_list * sizeof(TsoSlot);
         if (ctx->chim_slot_bytes < slot_bytes) {
@@ -1492,11 +1900,50 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         TsoSlot *d_slots = static_cast<TsoSlot *>(ctx->chim_slots);
         const unsigned grid = (unsigned)std::min<size_t>(((size_t)n_list + 3) / 4, 256 * 16);
         if (!(P.ablate & 16)) {
+            const bool v1 = getenv("SMI_CHIM_V1") != nullptr;  // cross-check switch: the first-generation exact TSO scan (one wave per read aligns every gated position)
+            if (!v1) {
+                // K-CHIM-B second generation: heads | queue of positions (u64) | error counts (f32)
+                const size_t cap = std::max<size_t>((size_t)n_list * 48, (size_t)1 << 16);
+                const size_t heads_bytes = ((size_t)n_list * sizeof(BHead) + 255) & ~(size_t)255;
+                const size_t work_bytes = heads_bytes + cap * 12;
+                if (ctx->chim_work_bytes < work_bytes) {
+                    if (ctx->chim_work) (void)hipFree(ctx->chim_work);
+                    ctx->chim_work = nullptr;
+                    ctx->chim_work_bytes = 0;
+                    const size_t want = work_bytes + work_bytes / 4;
+                    SMI_HIP(hipMalloc(&ctx->chim_work, want));
+                    ctx->chim_work_bytes = want;
+                }
+                BHead *d_heads = static_cast<BHead *>(ctx->chim_work);
+                uint64_t *d_cand = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->chim_work) + heads_bytes);
+                float *d_ne = reinterpret_cast<float *>(d_cand + cap);
+                uint32_t *d_gcount = d_count + 2;  // zeroed with the queue counters above
+                const bool generic = getenv("SMI_CHIM_GENERIC") != nullptr || !P.myers_ok;
+                const bool shipped3 = tl == 27 && !std::strcmp(cfg->tso_complete, PatSeq<1>::s) && !generic;
+                const bool shipped5 = tl == 22 && !std::strcmp(cfg->tso_complete, PatSeq<2>::s) && !generic;
+                const unsigned grid_al = 256 * 8;
+                if (shipped3)
+                    hipLaunchKernelGGL((k_chimb_select<27, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                else if (shipped5)
+                    hipLaunchKernelGGL((k_chimb_select<22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                else if (tl == 27)
+                    hipLaunchKernelGGL((k_chimb_select<27, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                else
+                    hipLaunchKernelGGL((k_chimb_select<22, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                if (tl == 27) {
+                    hipLaunchKernelGGL((k_chimb_align<27>), dim3(grid_al), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
+                    hipLaunchKernelGGL((k_chimb_fold<27>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots);
+                } else {
+                    hipLaunchKernelGGL((k_chimb_align<22>), dim3(grid_al), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
+                    hipLaunchKernelGGL((k_chimb_fold<22>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots);
+                }
+                SMI_HIP(hipGetLastError());
+            }
             if (tl == 27) {
-                hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                if (v1) hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
                 hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
             } else {
-                hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                if (v1) hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
                 hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
             }
             SMI_HIP(hipGetLastError());

@@ -149,6 +149,8 @@ struct smi_ctx {
     size_t chim_list_bytes = 0;
     void *chim_slots = nullptr;    // K-CHIM: matches handed from the exact TSO scan to the rules kernel
     size_t chim_slot_bytes = 0;
+    void *chim_work = nullptr;     // K-CHIM second generation: per-read heads, the global queue of positions to align, their error counts (grow-only)
+    size_t chim_work_bytes = 0;
     void *arena = nullptr;         // device memory of the chunk workers (smi_worker.hip), grow-only
     size_t arena_bytes = 0;
     uint8_t *host_out[2] = {nullptr, nullptr};  // pinned: passed / failed text of the last smi_scanfastq_pass2_chunk

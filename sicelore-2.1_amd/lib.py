@@ -70,7 +70,9 @@ class SmiError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "libsicelore_mi.so")
+    """the shipped library; SMI_LIBRARY names a measurement / experiment build instead (csrc/Makefile: MEASURE=1, VARIANT=...),
+    which the tests and the bench never set"""
+    return os.environ.get("SMI_LIBRARY") or os.path.join(_HERE, "csrc", "libsicelore_mi.so")
 
 
 _LIB = None

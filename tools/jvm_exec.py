@@ -137,7 +137,7 @@ def default_value(d):
 
 
 class Method:
-    __slots__ = ("cls", "acc", "name", "desc", "args", "ret", "max_locals", "code", "exc", "lines", "nargs_slots", "ops")
+    __slots__ = ("cls", "acc", "name", "desc", "args", "ret", "max_locals", "code", "exc", "lines", "nargs_slots", "ops", "hit")
 
     def __init__(self, jc, m):
         self.cls = jc
@@ -146,6 +146,7 @@ class Method:
         self.code = None
         self.ops = None
         self.exc, self.lines = [], {}
+        self.hit = None     # bytearray over the code's pcs: 1 = this instruction was executed (coverage, see JVM.coverage)
         for an, data in attrs:
             if an == "Code":
                 self.code = data
@@ -482,6 +483,20 @@ class JVM:
             exc.append((s, e, h, cf.cname(ct) if ct else None))
         m.max_locals = max_locals
         m.exc = exc
+        # LineNumberTable of the Code attribute: pc -> source line (coverage by source line, JVM.coverage)
+        lnt = []
+        n_attr = struct.unpack_from(">H", data, p)[0]
+        p += 2
+        for _ in range(n_attr):
+            ni, alen = struct.unpack_from(">HI", data, p)
+            p += 6
+            if cf.utf(ni) == "LineNumberTable":
+                cnt = struct.unpack_from(">H", data, p)[0]
+                lnt += [struct.unpack_from(">HH", data, p + 2 + 4 * k) for k in range(cnt)]
+            p += alen
+        lnt.sort()
+        m.lines = lnt
+        m.hit = bytearray(clen)
         ops = {}
         pc, n = 0, len(code)
         while pc < n:
@@ -624,12 +639,14 @@ class JVM:
         st = []
         push, pop = st.append, st.pop
         ops = m.ops
+        hit = m.hit
         pc = 0
         while True:
             self.steps += 1
             if self.steps > self.max_steps:
                 raise Unsupported("step budget exhausted")
             nm, arg, nxt = ops[pc]
+            hit[pc] = 1
             try:
                 # ---- loads / stores / constants
                 if nm in ("iload", "aload", "fload"):
@@ -1072,6 +1089,40 @@ class JVM:
         return int(v)
 
     # ---- statics / misc --------------------------------------------------------------------------------------------
+    # ---- coverage ---------------------------------------------------------------------------------------------------
+    def coverage(self, class_names):
+        """{class: {"method:desc": {"lines": [source lines of the method], "hit": [those with an executed instruction],
+        "instr": n instructions, "instr_hit": n executed}}} for the named classes of the jars (a class that was never
+        loaded is loaded and decoded here so that its lines count as present).  Lines come from each method's
+        LineNumberTable; an instruction belongs to the entry with the greatest start pc <= its pc."""
+        import bisect
+        rep = {}
+        for cname in class_names:
+            if not self.has_class(cname):
+                continue
+            jc = self.load(cname)
+            cm = {}
+            for (name, desc), m in jc.methods.items():
+                if m.code is None:
+                    continue
+                if m.ops is None:
+                    self._decode(m)
+                if not m.lines:
+                    continue
+                starts = [pc for pc, _ in m.lines]
+                present, hit = set(), set()
+                n_hit = 0
+                for pc in m.ops:
+                    k = bisect.bisect_right(starts, pc) - 1
+                    ln = m.lines[max(k, 0)][1]
+                    present.add(ln)
+                    if m.hit[pc]:
+                        hit.add(ln)
+                        n_hit += 1
+                cm[f"{name}:{desc}"] = {"lines": sorted(present), "hit": sorted(hit), "instr": len(m.ops), "instr_hit": n_hit}
+            rep[cname] = cm
+        return rep
+
     def get_static(self, cname, fname):
         n = cname
         while n is not None:

@@ -9,7 +9,13 @@ containers / membership-only sets / ordered sequential streams; see tools/jvm_ex
 emulated: where a method iterates a HashMap / HashSet the case is run under several different iteration orders and kept
 only if all of them agree (`hash_orders_agree`), otherwise it is listed under `excluded`.
 
-usage: python tools/make_ref_exec.py [section ...]     (default: all sections)
+usage: python tools/make_ref_exec.py [--jobs N] [section ...]     (default: all sections; N processes, one section each)
+       python tools/make_ref_exec.py --coverage               merge tests/golden/coverage/*.json -> tests/golden/ref_exec_coverage.json
+
+Coverage: while a section runs, the interpreter marks every executed instruction (tools/jvm_exec.py, JVM.coverage); the
+section's hits on the hot-path classes (COVERAGE_CLASSES: SURVEY 8a) are written to tests/golden/coverage/<section>.json,
+and `--coverage` folds them with each method's LineNumberTable into lines present / lines executed / lines never reached
+(with the reason from tools/coverage_notes.json where one was written down).
 """
 import json
 import os
@@ -26,7 +32,39 @@ REF = "/root/reference/Jar/"
 JARS = [REF + "NanoporeBC_UMI_finder-2.1.jar", REF + "lib/TwoFourBitNucAcidLibraryMaven-1.0.jar",
         REF + "lib/Aliasi_ClusteringLib-1.0.jar", REF + "lib/commons-lang3-3.17.0.jar", REF + "lib/htsjdk-4.1.3.jar",
         REF + "lib/guava-33.3.1-jre.jar", REF + "lib/picard-2.23.9.jar", REF + "lib/DropseqLib-1.0.jar"]
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("REF_EXEC_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")   # committed fixtures that later sections take their inputs from
+COV_DIR = os.path.join(OUT, "coverage")
+
+# the classes of SURVEY 8a (rows a-1 .. a-18) + the 8f callers either side whose bytecode the fixtures execute
+_FJ = "com/rw/"
+COVERAGE_CLASSES = [_FJ + c for c in (
+    "nanoporereadscanner/analyzers/Parser", "nanoporereadscanner/analyzers/BarcodeMatchTester",
+    "nanoporereadscanner/analyzers/BarcodeMatchTester$Matches", "nanoporereadscanner/analyzers/BarcodeMatchTester$Matches$OneMatch",
+    "nuc/encoding/TwoBit/ed/NucTwoBitPerBaseEDtesterBase", "nuc/encoding/TwoBit/LongSeqMutated",
+    "nanoporereadscanner/analyzers/PolyATadapterAnalyzer_3pBCUMI", "nanoporereadscanner/analyzers/PolyATadapterAnalyzer_5pBCUMI",
+    "nanopore/analyzers/PolyATadapterAnalyzerBase", "nanopore/analyzers/PolyATSearcher", "nanopore/analyzers/PolyATSearcher$PolyAscanResult",
+    "nanopore/analyzers/AdapterTSOanalyzer", "nanopore/analyzers/AdapterTSOanalyzer$AdapterScanRslt",
+    "nanopore/analyzers/Match", "nanopore/analyzers/NeedlemanMatch", "nanopore/analyzers/apachemod/LevenshteinDistance",
+    "nanoporereadscanner/analyzers/ChimeraFindernew", "nanoporereadscanner/analyzers/ChimeraFindernew$AdapterTSOmatch",
+    "nanoporereadscanner/analyzers/ChimeraFindernew$SplitPosition", "nanopore/analyzers/PolyATadapterInternalSearcherBase",
+    "nanopore/analyzers/PolyATadapterInternalSearcherBase$ATposition",
+    "nanoporereadscanner/analyzers/UsedCellBCListGenerator$Worker", "nanoporereadscanner/analyzers/UsedCellBCListGenerator$UsedBarcodesListData",
+    "nanoporereadscanner/analyzers/BarcodeDatasetColissionTester",
+    "nanoporereadscanner/readerwriter/FastqRecordExt", "nanoporereadscanner/readerwriter/ReadScanResult",
+    "nanoporereadscanner/stats/ReadFlags", "nanoporereadscanner/stats/ReadFlags$Flags",
+    "clustering/ClusteringEditDistanceBase", "clustering/DistanceMatrix", "clustering/OneUmiCluster",
+    "umifinder/analyzers/clustering/ClusterOneBase", "umifinder/analyzers/clustering/ClusterOneHierarchical",
+    "umifinder/analyzers/clustering/ClusterOne_MyClustering", "umifinder/analyzers/clustering/UmiClustering",
+    "umifinder/bamreaders/ReadGrouper", "umifinder/bamreaders/ReadGrouper$Cluster", "umifinder/bamreaders/ReadGrouper$ClusterList",
+    "umifinder/bamreaders/ReadGrouper$NanoporeReadWithOrderedPosition", "umifinder/bamreaders/GennameTagger",
+    "umifinder/reads/nanopore/NanoporeRead", "umifinder/reads/nanopore/NanoporeRead$ReadScanData", "umifinder/scanstats/GeneCounts",
+    "nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase", "nuc/encoding/onebyte/NucleicAcidInmutableOneBytePerBase",
+    "nuc/encoding/onebyte/NucleicAcidInmutableOneBytePerBase$Kmers", "nuc/encoding/NucleicAcidByteCodeBase",
+    "nuc/alignment/needleman/NeedlemanWunsch", "nuc/alignment/needleman/DynamicProgramming", "nuc/alignment/needleman/SequenceAlignment",
+)] + ["com/aliasi/cluster/CompleteLinkClusterer", "com/aliasi/cluster/SingleLinkClusterer", "com/aliasi/cluster/AbstractHierarchicalClusterer",
+      "com/aliasi/cluster/Dendrogram", "com/aliasi/cluster/LinkDendrogram", "com/aliasi/cluster/LeafDendrogram",
+      "com/aliasi/util/BoundedPriorityQueue"]
 
 TB = "com/rw/nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase"
 OBI = "com/rw/nuc/encoding/onebyte/NucleicAcidInmutableOneBytePerBase"
@@ -62,6 +100,30 @@ class Gen:
         sec["natives"] = self.natives()
         sec["max_tier"] = max([n["tier"] for n in sec["natives"]] or ["A"])
         return sec
+
+    def hits(self):
+        """{class: {"method:desc": hex of the executed-instruction bitmap}} for the hot-path classes this JVM loaded"""
+        out = {}
+        for cname in COVERAGE_CLASSES:
+            jc = self.j.classes.get(cname)
+            if jc is None:
+                continue
+            cm = {f"{n}:{d}": m.hit.hex() for (n, d), m in jc.methods.items() if m.hit is not None and any(m.hit)}
+            if cm:
+                out[cname] = cm
+        return out
+
+
+def merge_hits(dst, src):
+    for cname, cm in src.items():
+        d = dst.setdefault(cname, {})
+        for mk, hx in cm.items():
+            if mk in d:
+                a, b = bytes.fromhex(d[mk]), bytes.fromhex(hx)
+                d[mk] = bytes(x | y for x, y in zip(a, b)).hex()
+            else:
+                d[mk] = hx
+    return dst
 
 
 def rnd_seq(rng, n, alphabet="ACGT"):
@@ -652,6 +714,255 @@ def gen_pass2_5p_polya(g):
     return gen_pass2(g, 14, True, 1, 737, dont_search_polya=False, tag="5p")
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Whole chunks through Parser.call ITSELF (round 4): ReadChunk of five records -> ChimeraFindernew.findSplitPositions ->
+# processOneRecord per fragment (search, assignBarcode, finalizeFlag, the chunk's statistics) -> getRecordForWriting.
+# 100 chunks = 500 input reads per configuration, the reads built to reach the branches SURVEY 8a names (`kind`).
+# The chunks of a section are independent: with WIDE_JOBS > 1 they are spread over processes (one JVM each); a read is a
+# function of (seed, its index) only, so the fixture does not depend on how the chunks were dealt.
+# ---------------------------------------------------------------------------------------------------------------------
+RCHUNK = "com/rw/nanoporereadscanner/readerwriter/FastqFileReader$ReadChunk"
+WHAT_TODO = "com/rw/parameters/ReadScannerParameters$WHAT_TODO"
+WIDE_KINDS = ["clean", "err2", "err5", "err8", "err12", "random", "length_edge", "n_in_barcode", "both_sides", "terminal6", "junction_indel",
+              "ambiguous_bc", "tso_damaged", "no_tso", "short_polya", "no_polya", "chimera2", "chimera3", "chimera4", "internal_site",
+              "adapter_truncated", "low_complexity", "t_rich_umi", "err15"]
+TSO16 = "AACGCAGAGTACATGG"
+
+
+def wide_barcodes(seed):
+    """60 random 16-mers + for ten of them a partner two substitutions away (a read half way between the two is ed 1 from both:
+    best.ed == second.ed, Parser.java:L252) + for five a partner one deletion away"""
+    rng = random.Random(seed)
+    base = sorted({rnd_seq(rng, 16) for _ in range(60)})
+    pairs = []
+    for b in base[:10]:
+        i, k = rng.sample(range(16), 2)
+        m = list(b)
+        for q in (i, k):
+            m[q] = rng.choice([c for c in "ACGT" if c != m[q]])
+        pairs.append((b, "".join(m), i, k))
+    indel = []
+    for b in base[10:15]:
+        i = rng.randrange(2, 14)
+        indel.append(b[:i] + b[i + 1:] + rng.choice("ACGT"))
+    bcs = sorted(set(base + [p[1] for p in pairs] + indel))
+    return bcs, pairs
+
+
+def wide_read(seed, idx, bcs, pairs, five_prime, can_split):
+    """input read idx of a wide section: (name, bases, qualities, kind)"""
+    rng = random.Random(seed * 1000003 + idx)
+    kind = WIDE_KINDS[idx % len(WIDE_KINDS)]
+    variant = idx // len(WIDE_KINDS)
+    rate = {"clean": 0.0, "err2": 0.02, "err5": 0.05, "err8": 0.08, "err12": 0.12, "err15": 0.15}.get(kind, (0.0, 0.02, 0.04)[variant % 3])
+
+    def molecule(bc=None, umi=None, tso=TSO, ad=AD3, pa=None, cdna=None, junction=""):
+        bc = bc or rng.choice(bcs)
+        umi = umi or rnd_seq(rng, 12)
+        cdna = cdna if cdna is not None else rnd_seq(rng, rng.randrange(110, 360))
+        pa = pa if pa is not None else "A" * rng.randrange(18, 45)
+        if five_prime:   # adapter - BC - UMI - TSO tail - cDNA [- polyA - rc(3' adapter)]
+            return ad + junction + bc + umi + "TTTCTTATATGGG" + cdna + pa + (revcomp_str("AAGCAGTGGTATCAACGCAGAGTAC") if variant % 2 else rnd_seq(rng, rng.randrange(0, 25)))
+        return tso + cdna + pa + revcomp_str(umi) + revcomp_str(bc) + revcomp_str(junction) + revcomp_str(ad)
+
+    if kind in ("clean", "err2", "err5", "err8", "err12", "err15"):
+        mol = molecule()
+    elif kind == "random":
+        mol = rnd_seq(rng, rng.randrange(200, 600))
+    elif kind == "length_edge":     # minReadLength 200 (PolyATadapterAnalyzerBase.java:L131-137), the splitter's 2 * 70 + 100 (ChimeraFindernew.java:L169)
+        want = (199, 200, 201, 239, 240, 241)[variant % 6]
+        mol = molecule(cdna=rnd_seq(rng, 300))
+        mol = mol[:want] if five_prime else mol[-want:]
+    elif kind == "n_in_barcode":
+        bc = list(rng.choice(bcs))
+        for _ in range(1 + variant % 2):
+            bc[rng.randrange(16)] = "N"
+        mol = molecule(bc="".join(bc))
+        if variant % 3 == 2:
+            k = rng.randrange(len(mol))
+            mol = mol[:k] + "N" + mol[k + 1:]
+    elif kind == "both_sides":      # adapter structure at both ends: |delta| < 2 fails, else the side with fewer errors (L145-221)
+        m1 = molecule(cdna=rnd_seq(rng, 150))
+        if five_prime:
+            head = AD3 + rng.choice(bcs) + rnd_seq(rng, 12) + "TTTCTTATATGGG"
+            mol = noisy(rng, head, (0.0, 0.03, 0.1)[variant % 3]) + rnd_seq(rng, 200) + revcomp_str(noisy(rng, head, (0.0, 0.1, 0.03)[variant % 3]))
+        else:
+            tail = "A" * rng.randrange(20, 40) + revcomp_str(rnd_seq(rng, 12)) + revcomp_str(rng.choice(bcs)) + revcomp_str(AD3)
+            mol = revcomp_str(noisy(rng, tail, (0.0, 0.03, 0.1)[variant % 3])) + rnd_seq(rng, 200) + noisy(rng, tail, (0.0, 0.1, 0.03)[variant % 3])
+        del m1
+    elif kind == "terminal6":       # > maxNeedlemanMismatches errors but the last 6 alignment columns match (MIN_3P_CONSEC_MATCHES_TO_OVERRIDE_PASS)
+        n_bad = 4 + variant % 2
+        lo = len(AD3) - 10 if not five_prime else len(AD3) - 12
+        ad = list(AD3)
+        for q in range(lo, lo + n_bad):
+            ad[q] = rng.choice([c for c in "ACGT" if c != ad[q]])
+        mol = molecule(ad="".join(ad))
+    elif kind == "junction_indel":  # a base too many / too few between adapter and barcode: the offset +-1 / +-2 windows win
+        v = variant % 4
+        if v == 0:
+            mol = molecule(junction=rng.choice("ACGT"))
+        elif v == 1:
+            mol = molecule(junction=rnd_seq(rng, 2))
+        elif v == 2:
+            mol = molecule(ad=AD3[:-1])
+        else:
+            mol = molecule(ad=AD3[:-2])
+    elif kind == "ambiguous_bc":    # one substitution away from two listed barcodes: best.ed == second.ed -> no barcode
+        a, b, i, k = pairs[variant % len(pairs)]
+        m = list(a)
+        m[i] = b[i]
+        mol = molecule(bc="".join(m))
+    elif kind == "tso_damaged":     # TSO with > 5 errors: the rescues by 8 consecutive matches / two stretches >= 12 (L122-190)
+        t = list(TSO)
+        i0 = TSO.index(TSO16)
+        keep = (range(i0 + 3, i0 + 12), range(i0, i0 + 7), list(range(i0, i0 + 6)) + list(range(i0 + 9, i0 + 16)), range(i0 + 8, i0 + 16))[variant % 4]
+        for q in range(len(t)):
+            if q not in keep:
+                t[q] = rng.choice([c for c in "ACGT" if c != t[q]])
+        mol = molecule(tso="".join(t))
+    elif kind == "no_tso":
+        mol = molecule(tso="")
+    elif kind == "short_polya":
+        mol = molecule(pa="A" * (8 + variant % 7))
+    elif kind == "no_polya":
+        mol = molecule(pa="")
+    elif kind in ("chimera2", "chimera3", "chimera4"):
+        k = int(kind[-1])
+        parts = [molecule(cdna=rnd_seq(rng, rng.randrange(110, 220))) for _ in range(k)]
+        for q in range(k):
+            if (variant >> q) & 1:
+                parts[q] = revcomp_str(parts[q])
+        mol = "".join(parts)
+    elif kind == "internal_site":   # internal polyA + adapter (+ TSO) inside one long cDNA
+        a = rnd_seq(rng, 330)
+        site = "A" * (25 + variant % 15) + revcomp_str(rnd_seq(rng, 12)) + revcomp_str(rng.choice(bcs)) + revcomp_str(AD3)
+        if variant % 2:
+            site += rnd_seq(rng, 30) + TSO
+        if variant % 4 >= 2:
+            site = revcomp_str(site)
+        mol = molecule(cdna=a[:160] + site + a[160:])
+    elif kind == "adapter_truncated":
+        mol = molecule()
+        cut = 3 + variant % 9
+        mol = mol[cut:] if five_prime else mol[:-cut]
+    elif kind == "low_complexity":
+        unit = (("A", "AT", "AAG", "ACGT", "T")[variant % 5])
+        mol = molecule(cdna=(unit * 400)[:rng.randrange(150, 320)])
+    else:                           # t_rich_umi
+        mol = molecule(umi="A" * (6 + variant % 6) + rnd_seq(rng, 6 - variant % 6))   # rc(umi) next to the polyA: T/A-rich window at the barcode side
+    mol = noisy(rng, mol, rate)
+    if kind == "length_edge":       # the edge lengths exactly, noise or not
+        want = (199, 200, 201, 239, 240, 241)[variant % 6]
+        while len(mol) < want:
+            mol = (mol + "C") if five_prime else ("C" + mol)
+        mol = mol[:want] if five_prime else mol[-want:]
+    if rng.random() < 0.5:
+        mol = revcomp_str(mol)
+    qual = "".join(chr(33 + rng.randrange(3, 35)) for _ in mol)
+    return f"w{idx:04d} runid=r4 ch={idx % 512}", mol, qual, kind
+
+
+def wide_chunk(g, p2, bc_keys_ranks, reads, first_id):
+    """Parser.call on one ReadChunk, once per hash order -> (records per order)"""
+    j = g.j
+    results = []
+    for order in ("insertion", "reverse"):
+        j.hash_order = order
+        bcmap = p2.barcode_map(bc_keys_ranks)
+        al = j.natives["java/util/ArrayList.<new>"](j)
+        for name, seq, qual, _kind in reads:
+            al.native.append(p2.record(name, seq, qual))
+        chunk = j.new(RCHUNK, "(Ljava/util/Optional;ZLjava/util/List;)V", j.natives["java/util/Optional.empty"](j), 0, al)
+        parser = j.new(PARSER, f"(L{RCHUNK};L{PAR};L{BCMAP};Ljava/util/Map;L{MAIN}$Pass;)V", chunk, p2.par, bcmap,
+                       j.natives["java/util/HashMap.<new>"](j), j.get_static(MAIN + "$Pass", "SECOND"))
+        try:
+            out = j.call_virtual(parser, "call", f"()L{RCHUNK};")
+            recs, rid = [], first_id
+            for fq in out.f["fastqRecords"].native:
+                passed = bool(j.call_virtual(fq, "passed", "()Z"))
+                recs.append(p2.describe(fq, rid))
+                rid += passed
+            rf = chunk.f["stats"].f["readflags"]
+            results.append({"records": recs, "sum_read_length_passed": rf.f["sumReadLengthPassed"].native[0] if hasattr(rf.f["sumReadLengthPassed"], "native") and isinstance(rf.f["sumReadLengthPassed"].native, list) else None})
+        except JavaThrow as e:
+            results.append({"throws": e.obj.cls, "message": e.obj.f.get("message"), "in": e.trace[:6]})
+    j.hash_order = None
+    return results
+
+
+def _wide_worker(args):
+    five_prime, ed, dont_search_polya, seed, chunk_ids, per_chunk = args
+    g = Gen()
+    j = g.j
+    p2 = Pass2(g, five_prime, ed, dont_search_polya)
+    rs = p2.par.f["readScannerParameters"]
+    j.call_virtual(rs.f["what_todo"], "add", "(Ljava/lang/Object;)Z", j.get_static(WHAT_TODO, "FIND_BARCODES"))   # -b (ReadScannerParameters.java:L291)
+    bcs, pairs = wide_barcodes(seed)
+    enc = lambda q: j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q))  # noqa: E731
+    keys_ranks = [(enc(b), k + 1) for k, b in enumerate(bcs)]
+    can_split = not dont_search_polya
+    cases = []
+    for c in chunk_ids:
+        reads = [wide_read(seed, c * per_chunk + k, bcs, pairs, five_prime, can_split) for k in range(per_chunk)]
+        res = wide_chunk(g, p2, keys_ranks, reads, first_id=1000 * c + 1)
+        cases.append({"chunk": c, "first_read_id": 1000 * c + 1, "reads": [{"name": n, "seq": s, "qual": q, "kind": k} for n, s, q, k in reads],
+                      "hash_orders_agree": all(r == res[0] for r in res[1:]), "result": res[0]})
+        print(f"  pass2w chunk {c} done  {time.time() - g.t0:.0f}s", flush=True)
+    vals = j.call_static(FLAGS, "values", f"()[L{FLAGS};")
+    flag_values = {v.f["$name"]: u64(j.call_virtual(v, "getValue", "()J")) for v in vals.a}
+    return cases, sorted(j.natives_used), g.hits(), j.steps, flag_values, p2.report
+
+
+def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5):
+    jobs = max(1, int(os.environ.get("WIDE_JOBS", "1")))
+    ids = list(range(n_chunks))
+    blocks = [ids[k::jobs] for k in range(jobs)]
+    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk) for b in blocks if b]
+    if len(args) == 1:
+        parts = [_wide_worker(args[0])]
+    else:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(len(args)) as pool:
+            parts = pool.map(_wide_worker, args)
+    cases = sorted((c for p in parts for c in p[0]), key=lambda c: c["chunk"])
+    natives = sorted(set(n for p in parts for n in p[1]))
+    hits = {}
+    for p in parts:
+        merge_hits(hits, p[2])
+    bcs, _pairs = wide_barcodes(seed)
+    s = {"reference_class": PARSER, "reference_method": "call L132-185 (-> ChimeraFindernew.findSplitPositions, processOneRecord L92-124, assignBarcode L195-315) / "
+         "FastqRecordExt.getRecordForWriting L209-311",
+         "title": f"pass 2 of scanfastq per CHUNK through Parser.call itself, {'5-prime' if five_prime else '3-prime'} barcoding, --bcEditDistance {ed}"
+                  + (", --noPolyARequired" if dont_search_polya else "") + ": a FastqFileReader$ReadChunk of the five reads of a case -> the records Parser.call leaves in "
+                  "chunk.fastqRecords (fragments of split reads included), each described as in ref_exec_pass2_*.json; passed records take read ids first_read_id, "
+                  "first_read_id + 1, ... in list order.  Parameters: Jar/config.xml as shipped + what_todo = {FIND_BARCODES}.  Each chunk ran under two iteration orders "
+                  "of java.util.HashMap / HashSet; `hash_orders_agree` = both gave this result.",
+         "cases": cases, "barcodes": bcs, "ranks": list(range(1, len(bcs) + 1)), "five_prime": five_prime, "ed": ed, "dont_search_polya": dont_search_polya,
+         "split_chimeras": not dont_search_polya, "kinds": WIDE_KINDS, "flag_values": parts[0][4], "config_report": parts[0][5],
+         "natives": [{"native": k, "tier": jvm_natives.tier_of(k)} for k in natives]}
+    s["max_tier"] = max([n["tier"] for n in s["natives"]] or ["A"])
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar (+ TwoFourBitNucAcidLibraryMaven-1.0.jar, htsjdk-4.1.3.jar, guava, commons-lang3 as shipped in Jar/lib)",
+           "sections": [s], "_steps": sum(p[3] for p in parts), "_hits": hits}
+    return out
+
+
+def gen_pass2w_3p(g):
+    return gen_pass2w(g, False, 1, False, 4101)
+
+
+def gen_pass2w_3p_ed2(g):
+    return gen_pass2w(g, False, 2, False, 4102)
+
+
+def gen_pass2w_5p(g):
+    return gen_pass2w(g, True, 1, True, 4103)
+
+
+def gen_pass2w_5p_polya(g):
+    return gen_pass2w(g, True, 1, False, 4104)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # scan statistics: ReadFlags.addForCounting per record + the two read-length sums as Parser.call adds them (Parser.java:L115-118), then
 # ReadFlags.print(PrintStream) -- the text of the table ReadScanner.html shows, for sets of flag words drawn from the flags the reference
 # itself gave the records of ref_exec_pass2_*.json (+ the split / multi-chimeric bits) at random multiplicities
@@ -666,7 +977,7 @@ def gen_stats_print(g):
     pool = []
     fv = None
     for name in ("pass2_3p", "pass2_5p", "pass2_5p_polya", "pass2_3p_ed2"):
-        d = json.load(open(os.path.join(OUT, f"ref_exec_{name}.json")))
+        d = json.load(open(os.path.join(GOLD, f"ref_exec_{name}.json")))
         fv = d["sections"][0]["flag_values"]
         pool += [int(c["result"]["flag"]) for c in d["sections"][0]["cases"] if "flag" in c["result"]]
     s["flag_values"] = fv
@@ -1039,7 +1350,7 @@ def gen_gene(g, n_rows=1500, n_reads=420, seed=1212):
 
     j = g.j
     rng = random.Random(seed)
-    text = gzip.open(os.path.join(OUT, "chr12_head1500.refFlat.gz"), "rt").read()
+    text = gzip.open(os.path.join(GOLD, "chr12_head1500.refFlat.gz"), "rt").read()
     lines = text.split("\n")[:n_rows]
     extra = ["GOOD\tt1\tc1\t+\t100\t1000\t200\t900\t2\t100,600,\t300,1000,", "GOOD\tt2\tc1\t+\t150\t1200\t200\t900\t1\t150,\t1200,",
              "TWOSTRANDS\tt3\tc1\t+\t5000\t6000\t5000\t6000\t1\t5000,\t6000,", "TWOSTRANDS\tt4\tc1\t-\t5000\t6000\t5000\t6000\t1\t5000,\t6000,",
@@ -1990,7 +2301,7 @@ def gen_samtags(g, seed=1919):
                       "writeSamFlags:(Lhtsjdk/samtools/SAMRecord;L...OutputSAMtags;)V")
         names = []
         for f in files:
-            d = json.load(open(os.path.join(OUT, f"ref_exec_{f}.json")))
+            d = json.load(open(os.path.join(GOLD, f"ref_exec_{f}.json")))
             names += [c["result"]["written"]["name"].split(" ")[0] for c in d["sections"][0]["cases"] if "written" in c["result"]]
         for k in range(40):
             bc, umi = rnd_seq(rng, 16), rnd_seq(rng, 12)
@@ -2254,26 +2565,162 @@ def gen_auxorder(g, seed=2222):
 
 SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
-            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print}
+            "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
+            "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya}
+
+
+def run_section(name):
+    g = Gen()
+    t0 = time.time()
+    data = SECTIONS[name](g)
+    data["generated_by"] = "tools/make_ref_exec.py " + name
+    data["how"] = ("outputs computed by executing the reference's class files (jar named in `jar`) with tools/jvm_exec.py; "
+                   "inputs are seeded random / hand-picked; nothing here comes from oracle/ or from the HIP library")
+    data["bytecode_steps"] = data.pop("_steps", 0) + g.j.steps
+    hits = merge_hits(data.pop("_hits", {}), g.hits())
+    path = os.path.join(OUT, f"ref_exec_{name}.json")
+    with open(path, "w") as f:
+        json.dump(data, f, separators=(",", ":"))
+    os.makedirs(COV_DIR, exist_ok=True)
+    with open(os.path.join(COV_DIR, f"{name}.json"), "w") as f:
+        json.dump({"section": name, "hits": hits}, f, separators=(",", ":"), sort_keys=True)
+    n_cases = sum(len(s["cases"]) for s in data["sections"])
+    print(f"{name}: {n_cases} cases, {data['bytecode_steps']} bytecode steps, {time.time() - t0:.1f}s, {os.path.getsize(path) / 1024:.0f} KiB, "
+          f"max tier {max(s['max_tier'] for s in data['sections'])}", flush=True)
+    return name
+
+
+def _ranges(lines):
+    out, lines = [], sorted(lines)
+    for ln in lines:
+        if out and ln == out[-1][1] + 1:
+            out[-1][1] = ln
+        else:
+            out.append([ln, ln])
+    return [f"L{a}" if a == b else f"L{a}-{b}" for a, b in out]
+
+
+def merge_coverage():
+    """tests/golden/coverage/*.json + every method's LineNumberTable -> tests/golden/ref_exec_coverage.json"""
+    import bisect
+    import glob
+
+    hits, sections = {}, []
+    for path in sorted(glob.glob(os.path.join(COV_DIR, "*.json"))):
+        with open(path) as f:
+            d = json.load(f)
+        sections.append(d["section"])
+        merge_hits(hits, d["hits"])
+    notes_path = os.path.join(HERE, "coverage_notes.json")
+    notes = json.load(open(notes_path)) if os.path.exists(notes_path) else {}
+    j = JVM(JARS)
+    rep, tot = {}, {"lines": 0, "hit": 0, "annotated": 0, "instr": 0, "instr_hit": 0}
+    for cname in COVERAGE_CLASSES:
+        if not j.has_class(cname):
+            continue
+        jc = j.load(cname)
+        cnotes = notes.get(cname.split("/")[-1], {})
+
+        def reason(ln, mname):
+            for key, why in cnotes.items():
+                if key == mname:
+                    return why
+                if key.startswith("L"):
+                    a, _, b = key[1:].partition("-")
+                    if int(a) <= ln <= int(b or a):
+                        return why
+            return None
+
+        cm, csum = {}, {"lines": 0, "hit": 0, "annotated": 0}
+        cl_present, cl_hit, line_methods = set(), set(), {}
+        for (name, desc), m in jc.methods.items():
+            if m.code is None:
+                continue
+            if m.ops is None:
+                j._decode(m)
+            if not m.lines:
+                continue
+            hx = hits.get(cname, {}).get(f"{name}:{desc}")
+            hit = bytes.fromhex(hx) if hx else bytes(len(m.hit))
+            starts = [pc for pc, _ in m.lines]
+            present, got, n_hit = set(), set(), 0
+            for pc in m.ops:
+                ln = m.lines[max(bisect.bisect_right(starts, pc) - 1, 0)][1]
+                present.add(ln)
+                if hit[pc]:
+                    got.add(ln)
+                    n_hit += 1
+            cl_present |= present
+            cl_hit |= got
+            for ln in present:
+                line_methods.setdefault(ln, set()).add(name)
+            tot["instr"] += len(m.ops)
+            tot["instr_hit"] += n_hit
+            missed = sorted(present - got)
+            e = {"lines": _ranges(present), "n_lines": len(present), "n_hit": len(got), "instr": len(m.ops), "instr_hit": n_hit}
+            if missed:
+                e["never_reached"] = _ranges(missed)
+                why = {}
+                for ln in missed:
+                    r = reason(ln, name)
+                    if r:
+                        why.setdefault(r, []).append(ln)
+                if why:
+                    e["reasons"] = {r: _ranges(v) for r, v in why.items()}
+                e["unexplained"] = _ranges([ln for ln in missed if not reason(ln, name)])
+            cm[f"{name}:{desc}"] = e
+        # a source line can belong to several methods (lambdas): count it once per class
+        missed = cl_present - cl_hit
+        ann = {ln for ln in missed if any(reason(ln, mn) for mn in line_methods[ln])}
+        csum = {"lines": len(cl_present), "hit": len(cl_hit), "annotated": len(ann), "unexplained": _ranges(missed - ann),
+                "pct_hit": round(100.0 * len(cl_hit) / max(1, len(cl_present)), 1),
+                "pct_hit_or_annotated": round(100.0 * (len(cl_hit) + len(ann)) / max(1, len(cl_present)), 1)}
+        for k in ("lines", "hit", "annotated"):
+            tot[k] += csum[k]
+        rep[cname] = {"summary": csum, "methods": cm}
+    tot["pct_hit"] = round(100.0 * tot["hit"] / max(1, tot["lines"]), 1)
+    tot["pct_hit_or_annotated"] = round(100.0 * (tot["hit"] + tot["annotated"]) / max(1, tot["lines"]), 1)
+    out = {"generated_by": "tools/make_ref_exec.py --coverage", "sections_merged": sections,
+           "how": "an instruction counts as executed if the interpreter ran it in any section; a source line (LineNumberTable) counts as executed "
+                  "if one of its instructions did; `annotated` = never reached, with a reason in tools/coverage_notes.json",
+           "total": tot, "classes": rep}
+    with open(os.path.join(OUT, "ref_exec_coverage.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=False)
+    print(f"coverage: {tot['hit']}/{tot['lines']} lines executed ({tot['pct_hit']} %), + {tot['annotated']} annotated = {tot['pct_hit_or_annotated']} %; "
+          f"{tot['instr_hit']}/{tot['instr']} instructions")
+    for cname, e in rep.items():
+        sm = e["summary"]
+        print(f"  {cname.split('/')[-1]:45s} {sm['hit']:4d}/{sm['lines']:4d} {sm['pct_hit']:5.1f} %  (+{sm['annotated']} annotated)  unexplained: {' '.join(sm['unexplained'][:12])}")
 
 
 def main():
-    want = sys.argv[1:] or list(SECTIONS)
+    args = sys.argv[1:]
+    jobs = 1
+    if "--jobs" in args:
+        k = args.index("--jobs")
+        jobs = int(args[k + 1])
+        del args[k:k + 2]
+    if args == ["--coverage"]:
+        return merge_coverage()
+    want = args or list(SECTIONS)
+    unknown = [w for w in want if w not in SECTIONS]
+    if unknown:
+        sys.exit(f"unknown section(s): {unknown}; known: {sorted(SECTIONS)}")
     os.makedirs(OUT, exist_ok=True)
-    for name in want:
-        g = Gen()
-        t0 = time.time()
-        data = SECTIONS[name](g)
-        data["generated_by"] = "tools/make_ref_exec.py " + name
-        data["how"] = ("outputs computed by executing the reference's class files (jar named in `jar`) with tools/jvm_exec.py; "
-                       "inputs are seeded random / hand-picked; nothing here comes from oracle/ or from the HIP library")
-        data["bytecode_steps"] = g.j.steps
-        path = os.path.join(OUT, f"ref_exec_{name}.json")
-        with open(path, "w") as f:
-            json.dump(data, f, separators=(",", ":"))
-        n_cases = sum(len(s["cases"]) for s in data["sections"])
-        print(f"{name}: {n_cases} cases, {g.j.steps} bytecode steps, {time.time() - t0:.1f}s, {os.path.getsize(path) / 1024:.0f} KiB, "
-              f"max tier {max(s['max_tier'] for s in data['sections'])}", flush=True)
+    if jobs <= 1 or len(want) == 1:
+        if jobs > 1:
+            os.environ["WIDE_JOBS"] = str(jobs)   # one section: the chunks of a pass2w_* section are spread over the processes instead
+        for name in want:
+            run_section(name)
+        return
+    import multiprocessing as mp
+
+    # longest sections first so that the pool drains evenly
+    weight = {"cluster_own": 100, "pass2_3p_ed2": 30, "chimera_3p": 25, "finalize": 10, "cluster": 10, "group": 8}
+    want = sorted(want, key=lambda n: -weight.get(n, 1))
+    with mp.get_context("fork").Pool(jobs, maxtasksperchild=1) as pool:
+        for name in pool.imap_unordered(run_section, want):
+            pass
 
 
 if __name__ == "__main__":
