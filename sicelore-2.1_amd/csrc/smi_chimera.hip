@@ -1301,6 +1301,7 @@ __global__ __launch_bounds__(64) void k_chimera_serial(const uint32_t *__restric
 //                   filtered as before -> TsoSlot
 // =================================================================================================================
 constexpr int kDmax = 32;
+constexpr int kSubQ = 64;   // regions of the position queue (k_chimb_select2)
 constexpr int kSelCap = 512;  // gated positions per orientation of one read held in LDS; more: the serial kernel takes the read
 
 struct BHead {  // per queue slot: where the read's needed positions sit in the global queue (orientation 0 first)
@@ -1398,7 +1399,7 @@ __global__ __launch_bounds__(256) void k_chimb_select(const uint32_t *__restrict
                                                       const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list,
                                                       const uint32_t *__restrict__ list_count, FilterParams P,
                                                       const smi_chimera_result *__restrict__ out, BHead *__restrict__ heads,
-                                                      uint64_t *__restrict__ cand_abs, uint32_t *__restrict__ gcount, uint32_t cap) {
+                                                      uint64_t *__restrict__ cand_abs, uint32_t *__restrict__ gcount, uint32_t cap, uint32_t *__restrict__ dbg) {
     __shared__ SelLds lds_all[4];
     SelLds &L = lds_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
@@ -1435,7 +1436,10 @@ __global__ __launch_bounds__(256) void k_chimb_select(const uint32_t *__restrict
         h.first = h.n0 = h.n1 = h.flags = 0;
         if (n_c[0] > kSelCap || n_c[1] > kSelCap) {
             h.flags = 1;
-            if (lane == 0) heads[li] = h;
+            if (lane == 0) {
+                heads[li] = h;
+                atomicAdd(dbg + 5, 1u);
+            }
             continue;
         }
         // closure from the right, 64 gated positions at a time: needed = hot, or something needed lies less than kDmax behind
@@ -1476,7 +1480,10 @@ __global__ __launch_bounds__(256) void k_chimb_select(const uint32_t *__restrict
         }
         if ((unsigned long long)first + total > cap) {
             h.flags = 1;
-            if (lane == 0) heads[li] = h;
+            if (lane == 0) {
+                heads[li] = h;
+                atomicAdd(dbg + 6, 1u);
+            }
             continue;
         }
         const uint64_t bit_base = (uint64_t)w0 * 32u;
@@ -1504,8 +1511,11 @@ template <int kTsoLen>
 __global__ __launch_bounds__(256, SMI_CHIM_B_WAVES) void k_chimb_align(const uint32_t *__restrict__ planes, size_t stride, const uint64_t *__restrict__ cand_abs,
                                                                          const uint32_t *__restrict__ gcount, uint32_t cap, ChimParams P,
                                                                          float *__restrict__ cand_ne) {
-    const uint32_t total = min(*gcount, cap);
-    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    // gridDim.y regions of cap / gridDim.y entries, a counter each (1: one queue)
+    const uint32_t sub_cap = cap / gridDim.y, sub_base = blockIdx.y * sub_cap;
+    const uint32_t total = min(gcount[blockIdx.y], sub_cap);
+    for (uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
+        const uint32_t e = sub_base + e0;
         const uint64_t a = cand_abs[e];
         const int o = (int)(a >> 63);
         const uint64_t bit = a & 0x7FFFFFFFFFFFFFFFull;
@@ -1546,7 +1556,7 @@ __global__ __launch_bounds__(256) void k_chimb_fold(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count, int tso_max,
                                                     const smi_chimera_result *__restrict__ out, const BHead *__restrict__ heads,
                                                     const uint64_t *__restrict__ cand_abs, const float *__restrict__ cand_ne,
-                                                    TsoSlot *__restrict__ slots) {
+                                                    TsoSlot *__restrict__ slots, uint32_t *__restrict__ dbg) {
     __shared__ FoldLds lds_all[4];
     FoldLds &L = lds_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
@@ -1659,9 +1669,826 @@ __global__ __launch_bounds__(256) void k_chimb_fold(const uint32_t *__restrict__
             slots[li].begin[lane] = L.m_begin[lane];
             slots[li].kind[lane] = L.m_kind[lane];
         }
-        if (lane == 0) slots[li].n = (overflow || n_m > kCap) ? kCap + 1 : n_m;
+        if (lane == 0) {
+            slots[li].n = (overflow || n_m > kCap) ? kCap + 1 : n_m;
+            if (overflow || n_m > kCap) atomicAdd(dbg + 7, 1u);
+        }
         wave_sync();
     }
+}
+
+// =================================================================================================================
+// K-CHIM-C, second generation (round 4).  The first generation walked the internal polyA / polyT stretches of ONE read
+// per wave (a serial, data-dependent walk: 17 of 64 lanes active, 38 % of the wave cycles waiting).  The walk is serial
+// per read but the reads are independent, so the unit of the walk is now a LANE:
+//   k_chimc_trig   wave per queued read, lane per 32 positions: the start condition of aTscan as bit masks (bit-sliced
+//                  window counters) -> two words per plane word
+//   k_chimc_walk   LANE per queued read: aTscan's walk over its trigger bits, searchATend -> stretch records
+//   k_chimc_gate   lane per stretch: the 51-base window's 3 x 4-mer gate, the Levenshtein bound of the gated positions;
+//                  the positions of a stretch with a possible match are queued
+//   k_chimc_align  lane per queued position: the kAdLen x kAdLen alignment (error count + mismatches)
+//   k_chimc_rules  lane per queued read: position-skip fold and best-score choice per stretch, the > 120 filter, the
+//                  matches of the TSO scan (TsoSlot), the split rules -> smi_chimera_result
+// Per-lane lists are capped (kStPerRead stretches, kMatchCap matches); a read over a cap gets SMI_CHIM_OVERFLOW and goes
+// through the serial kernel, which has no caps.
+// =================================================================================================================
+constexpr int kStPerRead = 16;
+constexpr int kMatchCap = 64;  // = kCap of the first generation
+
+struct Stretch {
+    uint32_t li;        // queue slot of the read
+    int t;              // 0 polyA, 1 polyT
+    int at_begin, at_end;
+};
+struct StretchRes {     // k_chimc_gate -> k_chimc_rules
+    uint32_t gate;      // gated scan positions (bit i = position i + 1), 0: no match possible
+    uint32_t first;     // first entry of the stretch in the alignment queue
+};
+struct AdEntry {
+    uint32_t s;         // stretch
+    uint32_t i;         // scan position - 1
+};
+
+// start condition of aTscan for the 32 positions q = 32 w .. 32 w + 31 of a read (0-based; L92-136): window count >= threshold,
+// bases q and q + 1 exact.  E: exact-base bits from bit 32 w on (64 of them).
+__device__ __forceinline__ uint32_t at_triggers32(uint64_t e, int extra, int pat_len, int pat_thr, int q0, int first, int stop) {
+    uint32_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma unroll
+    for (int k = 1; k < 15; k++) {  // bit-sliced sum of the shifted planes (pat_len - 1 of them)
+        if (k >= pat_len) break;
+        const uint32_t x = (uint32_t)(e >> k);
+        const uint32_t t0 = c0 & x;
+        c0 ^= x;
+        const uint32_t t1 = c1 & t0;
+        c1 ^= t0;
+        const uint32_t t2 = c2 & t1;
+        c2 ^= t1;
+        c3 ^= t2;
+    }
+    if (extra) {  // the base at index off + 13, which the reference's window update counts twice (L99-121)
+        const uint32_t t0 = c0;
+        c0 = ~c0;
+        const uint32_t t1 = c1 & t0;
+        c1 ^= t0;
+        const uint32_t t2 = c2 & t1;
+        c2 ^= t1;
+        c3 ^= t2;
+    }
+    const uint32_t cb[4] = {c0, c1, c2, c3};
+    uint32_t gt = 0, eq = ~0u;
+#pragma unroll
+    for (int b = 3; b >= 0; b--) {
+        if ((pat_thr >> b) & 1)
+            eq &= cb[b];
+        else
+            gt |= eq & cb[b];
+    }
+    uint32_t m = (gt | eq) & (uint32_t)e & (uint32_t)(e >> 1);
+    if (q0 < first) m = first - q0 >= 32 ? 0u : (m & (~0u << (first - q0)));
+    if (q0 + 32 > stop) m = stop - q0 <= 0 ? 0u : (m & ((1u << (stop - q0)) - 1u));
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_chimc_trig(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+                                                    const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list,
+                                                    const uint32_t *__restrict__ list_count, ChimParams P,
+                                                    const smi_chimera_result *__restrict__ out, uint32_t *__restrict__ trig) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_list = *list_count;
+    for (size_t li = wave; li < n_list; li += n_waves) {
+        const size_t r = list[li];
+        if (!(out[r].n_matches & SMI_CHIMA_PAT)) continue;
+        const uint64_t beg = offsets[r];
+        const int len = (int)(offsets[r + 1] - beg);
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
+        const uint32_t *pa = planes + w0, *pg = planes + stride + w0, *pt = planes + 3 * stride + w0;
+        const int first = P.off - 1, stop = len - P.off;
+        const int xb = P.off + P.pat_len - 2;
+        const uint32_t xa = pa[xb >> 5], xg = pg[xb >> 5], xt = pt[xb >> 5];
+        const int extra_a = (int)(((xa & ~xg) >> (xb & 31)) & 1u), extra_t = (int)(((xt & ~xa) >> (xb & 31)) & 1u);
+        const int n_words = (len + 31) >> 5;
+        for (int w = lane; w < n_words; w += 64) {
+            uint32_t ma = 0, mt = 0;
+            if (P.pat_thr <= 15 && 32 * w < stop && 32 * w + 32 > first) {
+                const uint64_t A = ((uint64_t)pa[w + 1] << 32) | pa[w], G = ((uint64_t)pg[w + 1] << 32) | pg[w], T = ((uint64_t)pt[w + 1] << 32) | pt[w];
+                ma = at_triggers32(A & ~G, extra_a, P.pat_len, P.pat_thr, 32 * w, first, stop);
+                mt = at_triggers32(T & ~A, extra_t, P.pat_len, P.pat_thr, 32 * w, first, stop);
+            }
+            trig[w0 + w] = ma;
+            trig[stride + w0 + w] = mt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_chimc_walk(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+                                                   const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list,
+                                                   const uint32_t *__restrict__ list_count, ChimParams P,
+                                                   const smi_chimera_result *__restrict__ out, const uint32_t *__restrict__ trig,
+                                                   Stretch *__restrict__ st, uint32_t *__restrict__ st_count, uint32_t st_cap,
+                                                   uint32_t *__restrict__ read_st, uint8_t *__restrict__ read_nst, uint32_t *__restrict__ dbg) {
+    const size_t n_list = *list_count;
+    const size_t li = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    const size_t r = list[li];
+    if (!(out[r].n_matches & SMI_CHIMA_PAT)) {
+        read_nst[li] = 0;
+        return;
+    }
+    const uint64_t beg = offsets[r];
+    const int len = (int)(offsets[r + 1] - beg);
+    ReadPlanes rp;
+    const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
+#pragma unroll
+    for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
+    const int first = P.off - 1, stop = len - P.off;
+    int n_st = 0;
+    bool over = false;
+    if (first < stop) {
+        const int extra[2] = {(int)gexact_bit(rp, 0, P.off + P.pat_len - 2), (int)gexact_bit(rp, 1, P.off + P.pat_len - 2)};
+        int end_cur[2] = {0, 0}, fired[2] = {-1, -1};
+        auto next_trig = [&](int t, int from) -> int {  // first trigger position >= from
+            if (from < first) from = first;
+            const uint32_t *tw = trig + (size_t)t * stride + w0;
+            // eight words per round trip (the words behind the read's end are zero pads / other reads' words inside the buffer: the
+            // position test below drops what lies beyond `stop`)
+            for (int w = from >> 5; 32 * w < stop; w += 8) {
+                uint32_t m[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) m[k] = tw[w + k];
+                if (w == (from >> 5)) m[0] &= ~0u << (from & 31);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    if (m[k]) {
+                        const int q = 32 * (w + k) + __builtin_ctz(m[k]);
+                        return q < stop ? q : 0x7FFFFFFF;
+                    }
+                }
+            }
+            return 0x7FFFFFFF;
+        };
+        for (;;) {
+            const int n0 = next_trig(0, max(end_cur[0], fired[0]) + 1), n1 = next_trig(1, max(end_cur[1], fired[1]) + 1);
+            if (n0 == 0x7FFFFFFF && n1 == 0x7FFFFFFF) break;
+            const int t = n1 < n0 ? 1 : 0;
+            const int pos = t ? n1 : n0;
+            int cur = extra[t];
+            cur += __popcll(gexact64(rp, t, pos + 1) & ((1ull << (P.pat_len - 1)) - 1ull));
+            const int at_end = search_at_end(rp, len, pos, t, cur, P) + 1;
+            end_cur[t] = at_end;
+            fired[t] = pos;
+            if (n_st < kStPerRead) {
+                const uint32_t idx = atomicAdd(st_count, 1u);
+                if (idx < st_cap) {
+                    Stretch x;
+                    x.li = (uint32_t)li;
+                    x.t = t;
+                    x.at_begin = pos + 1;
+                    x.at_end = at_end;
+                    st[idx] = x;
+                    read_st[li * kStPerRead + n_st] = idx;
+                    n_st++;
+                } else {
+                    if (!over) atomicAdd(dbg + 1, 1u);
+                    over = true;
+                }
+            } else {
+                if (!over) atomicAdd(dbg + 0, 1u);
+                over = true;
+            }
+        }
+    }
+    read_nst[li] = (uint8_t)(over ? 255 : n_st);
+}
+
+template <int kAdLen>
+struct AdWindow {  // the 51-base window next to a stretch (adapterScan L159-221), per lane
+    ReadPlanes rp;
+    int start_range, end_range, is_t;
+    __device__ __forceinline__ void set(const uint32_t *planes, size_t stride, size_t w0, const Stretch &x, const ChimParams &P) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) rp.p[c] = planes + c * stride + w0;
+        is_t = x.t;
+        if (is_t) {
+            start_range = x.at_begin - P.bc_umi - 30 - 10;
+            end_range = start_range + 30 + 20;
+        } else {
+            end_range = x.at_end + P.bc_umi + 30 + 10;
+            start_range = end_range - 30 - 20;
+        }
+    }
+    // bit k = sub[shift + k] matches adapter base i (the sub-sequence is reverse-complemented when the stretch is polyA)
+    __device__ __forceinline__ uint32_t col_bits(const ChimParams &P, int i, int shift) const {
+        if (is_t) return gmatch32(rp, P.ad4[i], start_range - 1 + shift);
+        return __brev(gmatch32(rp, comp4(P.ad4[i]), end_range - 32 - shift));
+    }
+};
+
+template <int kAdLen>
+__global__ __launch_bounds__(256) void k_chimc_gate(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+                                                    const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list, ChimParams P,
+                                                    const Stretch *__restrict__ st, const uint32_t *__restrict__ st_count, uint32_t st_cap,
+                                                    StretchRes *__restrict__ sres, AdEntry *__restrict__ entries, uint32_t *__restrict__ n_entries,
+                                                    uint32_t entry_cap, uint32_t *__restrict__ dbg) {
+    constexpr int NPOS = 51 - kAdLen;
+    const uint32_t n_st = min(*st_count, st_cap);
+    for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < n_st; s += gridDim.x * blockDim.x) {
+        const Stretch x = st[s];
+        const size_t r = list[x.li];
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(offsets[r], r);
+        AdWindow<kAdLen> W;
+        W.set(planes, stride, w0, x, P);
+        uint32_t any = 0, two = 0, three = 0;
+        {
+            uint32_t m0 = W.col_bits(P, 0, 0), m1 = W.col_bits(P, 1, 1), m2 = W.col_bits(P, 2, 2);
+#pragma unroll
+            for (int i = 0; i + 3 < kAdLen; i++) {
+                const uint32_t m3 = W.col_bits(P, i + 3, i + 3);
+                const uint32_t k = m0 & m1 & m2 & m3;
+                three |= two & k;
+                two |= any & k;
+                any |= k;
+                m0 = m1;
+                m1 = m2;
+                m2 = m3;
+            }
+        }
+        uint32_t gate = three & ((1u << NPOS) - 1u);  // minKmersMatching = 3 (L173)
+        if (gate && P.myers_ok) {
+            // no scan position with an alignment that could be accepted: the result list is empty whatever the skip rule visits
+            bool hot = false;
+            for (uint32_t g = gate; g && !hot; g &= g - 1) {
+                const int i = __builtin_ctz(g);
+                uint32_t V[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t w = W.is_t ? gget32(W.rp.p[c], W.start_range - 1 + i) : __brev(gget32(W.rp.p[3 - c], W.end_range - 32 - i));
+                    V[c] = __brev(w) >> (32 - kAdLen);
+                }
+                hot = myers_bound<kAdLen>(V, P.ad_idx, P.ad_lead_max) <= P.ad_max;
+            }
+            if (!hot) gate = 0;
+        }
+        StretchRes res;
+        res.gate = gate;
+        res.first = 0;
+        if (gate) {
+            const uint32_t n = (uint32_t)__popc(gate);
+            const uint32_t first = atomicAdd(n_entries, n);
+            if ((unsigned long long)first + n > entry_cap) {
+                res.gate = 0xFFFFFFFFu;  // out of queue space: the read goes to the serial kernel
+                atomicAdd(dbg + 2, 1u);
+            } else {
+                res.first = first;
+                uint32_t k = 0;
+                for (uint32_t g = gate; g; g &= g - 1) {
+                    AdEntry e;
+                    e.s = s;
+                    e.i = (uint32_t)__builtin_ctz(g);
+                    entries[first + k++] = e;
+                }
+            }
+        }
+        sres[s] = res;
+    }
+}
+
+template <int kAdLen>
+__global__ __launch_bounds__(256, SMI_CHIM_C_WAVES) void k_chimc_align(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+                                                                         const uint64_t *__restrict__ offsets, const uint32_t *__restrict__ list, ChimParams P,
+                                                                         const Stretch *__restrict__ st, const AdEntry *__restrict__ entries,
+                                                                         const uint32_t *__restrict__ n_entries, uint32_t entry_cap,
+                                                                         float *__restrict__ e_ne, int *__restrict__ e_nmis) {
+    const uint32_t n = min(*n_entries, entry_cap);
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const AdEntry a = entries[e];
+        const Stretch x = st[a.s];
+        const size_t r = list[x.li];
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(offsets[r], r);
+        AdWindow<kAdLen> W;
+        W.set(planes, stride, w0, x, P);
+        uint32_t col[kAdLen];
+#pragma unroll
+        for (int c = 0; c < kAdLen; c++) col[c] = W.col_bits(P, c, (int)a.i) & ((1u << kAdLen) - 1u);
+        AlnStats sa;
+        nw_full<kAdLen, false, false, nw_band<kAdLen, 6>()>(col, 0, sa);  // the gate asked for 3 matching 4-mers = 6 diagonal matches
+        e_ne[e] = sa.ne;
+        e_nmis[e] = sa.nmis;
+    }
+}
+
+struct RulesLds {  // per lane: [slot][lane]; a match is begin << 2 | kind (bit 0 is_reverse, bit 1 is_adapter)
+    int m[kMatchCap][64];
+};
+
+__global__ __launch_bounds__(64) void k_chimc_rules(const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets,
+                                                    const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count, ChimParams P,
+                                                    const TsoSlot *__restrict__ slots, const Stretch *__restrict__ st,
+                                                    const StretchRes *__restrict__ sres, const uint32_t *__restrict__ read_st,
+                                                    const uint8_t *__restrict__ read_nst, const float *__restrict__ e_ne,
+                                                    const int *__restrict__ e_nmis, smi_chimera_result *__restrict__ out, uint32_t *__restrict__ dbg) {
+    __shared__ RulesLds L;
+    const int lane = threadIdx.x;
+    const size_t n_list = *list_count;
+    const size_t li = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (li >= n_list) return;
+    const size_t r = list[li];
+    const int verdict = out[r].n_matches;  // left by K-CHIM-A
+    const int len = (int)(offsets[r + 1] - offsets[r]);
+    int n_m = 0;
+    bool overflow = false;
+    auto push = [&](int begin, int kind) {
+        if (n_m < kMatchCap)
+            L.m[n_m][lane] = (begin << 2) | kind;
+        else
+            overflow = true;
+        n_m++;
+    };
+    if (verdict & SMI_CHIMA_TSO) {
+        const int n = slots[li].n;
+        if (n > kCap) {
+            overflow = true;
+            atomicAdd(dbg + 4, 1u);
+        } else
+            for (int k = 0; k < n; k++) push(slots[li].begin[k], slots[li].kind[k]);
+    }
+    if (verdict & SMI_CHIMA_PAT) {
+        const int nst = read_nst[li];
+        if (nst == 255) overflow = true;
+        long long prev_start[2] = {-2147483648LL, -2147483648LL};  // prevA_Position / prevT_Position
+        const float maxe = (float)P.ad_max;
+        for (int k = 0; k < nst && nst != 255; k++) {
+            const uint32_t s = read_st[li * kStPerRead + k];
+            const StretchRes sr = sres[s];
+            if (sr.gate == 0) continue;
+            if (sr.gate == 0xFFFFFFFFu) {
+                overflow = true;
+                continue;
+            }
+            const Stretch x = st[s];
+            // scanForAdapterOrTSOseqKMERsForInternal's position skip, in scan order
+            uint32_t accepted = 0;
+            int skip = 0, q = 0;
+            float best = 3.4028234663852886e+38f;
+            for (uint32_t g = sr.gate; g; g &= g - 1, q++) {
+                const int i = __builtin_ctz(g);
+                if (i + 1 < skip) continue;
+                const float ne = e_ne[sr.first + q];
+                if (!((float)jround(ne) > maxe)) {
+                    accepted |= 1u << i;
+                    best = fminf(best, ne);
+                }
+                int delta = 1;
+                if (maxe < ne) {
+                    delta = jround(__fsub_rn(ne, maxe)) - 1;
+                    if (delta < 1) delta = 1;
+                }
+                skip = i + 1 + delta;
+            }
+            if (!accepted) continue;
+            // getPosForBestScore(MAX_VALUE): positions sharing the least key, neighbours < 2 apart dropped (L180-183); then nmis <= max (L203)
+            uint32_t eq = 0, okm = 0;
+            q = 0;
+            for (uint32_t g = sr.gate; g; g &= g - 1, q++) {
+                const int i = __builtin_ctz(g);
+                if (!((accepted >> i) & 1u)) continue;
+                if (e_ne[sr.first + q] == best) eq |= 1u << i;
+                if (e_nmis[sr.first + q] <= P.ad_max) okm |= 1u << i;
+            }
+            const uint32_t keep = eq & ~(eq << 1);
+            const uint32_t good = keep & okm;
+            if (!good) continue;
+            const int o1 = __builtin_ctz(good) + 1;
+            int start_range;
+            if (x.t)
+                start_range = x.at_begin - P.bc_umi - 30 - 10;
+            else
+                start_range = x.at_end + P.bc_umi + 30 + 10 - 30 - 20;
+            const int start = x.t ? start_range + o1 - 1 : start_range + 51 - o1;  // L207 / L211
+            if (start != 0) {  // lambda$7 L204-207
+                const long long lim = prev_start[x.t] + 120;
+                prev_start[x.t] = start;
+                if ((long long)start > lim) push(start, 2 | (x.t == 0 ? 1 : 0));  // polyA stretch = reverse adapter
+            }
+        }
+    }
+    if (n_m > kMatchCap) {  // (overflow is set: the serial kernel redoes the read)
+        n_m = kMatchCap;
+        atomicAdd(dbg + 3, 1u);
+    }
+    // ---- split rules (L229-286) ----------------------------------------------------------------------------
+    for (int i = 1; i < n_m; i++) {  // stable sort by begin (insertion: the lists are a handful of entries)
+        const int v = L.m[i][lane];
+        int j = i - 1;
+        while (j >= 0 && (L.m[j][lane] >> 2) > (v >> 2)) {
+            L.m[j + 1][lane] = L.m[j][lane];
+            j--;
+        }
+        L.m[j + 1][lane] = v;
+    }
+    int n_kept = 0, kept_pos[3] = {0, 0, 0}, kept_reason[3] = {0, 0, 0}, prev_sp = 0;
+    bool have_prev_sp = false;
+    auto emit = [&](int reason, int pos) {  // the < 100 filter (L273-281) compares neighbours of the unfiltered list
+        const bool drop = have_prev_sp && (pos - prev_sp < 100);
+        prev_sp = pos;
+        have_prev_sp = true;
+        if (!drop) {
+            if (n_kept == 0) { kept_pos[0] = pos; kept_reason[0] = reason; }
+            else if (n_kept == 1) { kept_pos[1] = pos; kept_reason[1] = reason; }
+            else if (n_kept == 2) { kept_pos[2] = pos; kept_reason[2] = reason; }
+            n_kept++;
+        }
+    };
+    auto isolated = [&](int m) {
+        const int k = L.m[m][lane] & 3, b = L.m[m][lane] >> 2;
+        emit((k & 1) ? SMI_SPLIT_REV_ADAPTER : SMI_SPLIT_FWD_ADAPTER, (k & 1) ? b + 25 : b - 25);  // lambda$10
+    };
+    if (n_m == 1) {
+        if (L.m[0][lane] & 2) isolated(0);
+    } else if (n_m > 1) {
+        int it = 0;
+        int prev = it++;
+        while (it < n_m && prev >= 0) {
+            const int cur = it++;
+            const int pk = L.m[prev][lane] & 3, ck = L.m[cur][lane] & 3;
+            const int pbeg = L.m[prev][lane] >> 2, cbeg = L.m[cur][lane] >> 2;
+            if (cbeg - pbeg > 160) {
+                if (pk & 2) isolated(prev);
+                prev = cur;
+            } else if ((pk & 1) && !(ck & 1)) {
+                const int reason = (pk & 2) ? ((ck & 2) ? SMI_SPLIT_RA_FA : SMI_SPLIT_RA_FT)
+                                            : ((ck & 2) ? SMI_SPLIT_RT_FA : SMI_SPLIT_RT_FT);  // lambda$11
+                emit(reason, pbeg + (cbeg - pbeg) / 2);
+                prev = it < n_m ? it++ : -1;
+            } else
+                prev = cur;
+            if (it >= n_m && prev >= 0 && (L.m[prev][lane] & 2)) isolated(prev);  // L263-264
+        }
+    }
+    smi_chimera_result res;
+    res.n_split = 0;
+    res.pos[0] = res.pos[1] = 0;
+    res.reason[0] = res.reason[1] = 0;
+    res.flags = 0;
+    res.n_matches = n_m;
+    if (n_kept > 2) {
+        res.flags |= SMI_CHIM_MULTI;  // MULTI_CHIMERIC_READS_DISCARDED | FAILED, read kept whole (L284-286)
+    } else {
+        res.n_split = n_kept;
+        int lastp = 0;
+        for (int i = 0; i < n_kept; i++) {
+            const int kp = i == 0 ? kept_pos[0] : kept_pos[1];
+            res.pos[i] = kp;
+            res.reason[i] = (uint8_t)(i == 0 ? kept_reason[0] : kept_reason[1]);
+            if (kp < lastp || kp > len) res.flags |= SMI_CHIM_RANGE;  // substring would throw
+            lastp = kp;
+        }
+    }
+    if (overflow) {  // over one of this pipeline's caps: the first-generation kernels redo the read from K-CHIM-A's verdict
+        res.flags = SMI_CHIM_OVERFLOW;
+        res.n_split = 0;
+        res.n_matches = verdict;
+    }
+    out[r] = res;
+}
+
+// =================================================================================================================
+// K-CHIM-A, second generation (round 4): the read-level filter over the FLAT plane stream.
+//
+// The first generation gave every read a wave (lane = 32 positions: 41 of 64 lanes busy for a 1.3 kb read) and bounded the
+// gated positions of one read and one orientation at a time (two half-empty batches per read).  Here a workgroup takes a
+// TILE of 256 consecutive plane words whatever reads they belong to (`own`: read of every plane word): every lane computes
+// the gates and the polyA / polyT start condition of its 32 positions, the gated positions of the whole tile are pooled per
+// orientation and bounded 256 at a time with all lanes busy.  Besides the verdict per read it leaves what the later stages
+// would otherwise compute again: the gate words (`cand`), the positions under the bound (`hotw`), the trigger words (`trig`).
+// =================================================================================================================
+constexpr int kFlatList = 2048;  // gated positions of one orientation in a tile that are bounded one by one; a tile with more (poly-N, homopolymers)
+                                 // counts all of them as possible -- that only adds alignments later
+
+struct FlatLds {
+    uint32_t pw[4][260];          // the tile's plane words (+ the first of the next tile)
+    uint32_t cmask[2][256];
+    uint32_t hot[2][256];
+    uint16_t clist[2][kFlatList]; // thread << 5 | bit
+    int wsum[2][4];
+};
+
+__global__ __launch_bounds__(256) void k_chim_owner(const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets, size_t n,
+                                                    uint32_t *__restrict__ own) {
+    const int lane = threadIdx.x & 63;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
+    const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave; r < n; r += n_waves) {
+        const uint64_t beg = offsets[r];
+        const int len = (int)(offsets[r + 1] - beg);
+        const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
+        const int n_words = (len + 31) >> 5;
+        for (int w = lane; w < n_words; w += 64) own[w0 + w] = (uint32_t)r;
+    }
+}
+
+template <int kTsoLen, int PAT>
+__global__ __launch_bounds__(256) void k_chima_flat(const uint32_t *__restrict__ planes, size_t stride, size_t n_tiles, const uint32_t *__restrict__ own,
+                                                    const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets, FilterParams P,
+                                                    uint32_t *__restrict__ cand, uint32_t *__restrict__ hotw, uint32_t *__restrict__ trig,
+                                                    uint32_t *__restrict__ verd) {
+    __shared__ FlatLds L;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (size_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const size_t w = tile * 256 + tid;
+        const uint32_t r = w < stride ? own[w] : 0xFFFFFFFFu;
+        uint32_t cm[2] = {0, 0}, ma = 0, mt = 0;
+        uint32_t lo4[4] = {0, 0, 0, 0}, hi4[4] = {0, 0, 0, 0};
+        if (w < stride) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                lo4[c] = planes[c * stride + w];
+                hi4[c] = planes[c * stride + w + 1];
+            }
+        }
+        if (r != 0xFFFFFFFFu) {
+            const uint64_t beg = offsets[r];
+            const int len = (int)(offsets[r + 1] - beg);
+            const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
+            const int q0 = 32 * (int)(w - w0);
+            if (len >= 2 * 70 + 100) {
+                uint64_t W[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) W[c] = ((uint64_t)hi4[c] << 32) | lo4[c];
+                // scan positions q0 + 1 + k, 70 <= position <= len - 70
+                const int klo = max(0, 69 - q0), khi = min(31, len - 70 - 1 - q0);
+                if (klo <= khi) {
+                    const uint32_t keep = (0xFFFFFFFFu << klo) & (0xFFFFFFFFu >> (31 - khi));
+                    cm[0] = tso_gate32<kTsoLen, PAT, 0>(W, P) & keep;
+                    cm[1] = tso_gate32<kTsoLen, PAT, 1>(W, P) & keep;
+                }
+                const int first = P.off - 1, stop = len - P.off;
+                if (first < stop) {
+                    if (P.pat_thr <= 15) {
+                        if (q0 < stop && q0 + 32 > first) {
+                            const int xb = P.off + P.pat_len - 2;
+                            const size_t xw = w0 + (size_t)(xb >> 5);
+                            const uint32_t xa = planes[xw], xg = planes[stride + xw], xt = planes[3 * stride + xw];
+                            const int extra_a = (int)(((xa & ~xg) >> (xb & 31)) & 1u), extra_t = (int)(((xt & ~xa) >> (xb & 31)) & 1u);
+                            ma = at_triggers32(W[0] & ~W[1], extra_a, P.pat_len, P.pat_thr, q0, first, stop);
+                            mt = at_triggers32(W[3] & ~W[0], extra_t, P.pat_len, P.pat_thr, q0, first, stop);
+                            if (ma | mt) atomicOr(verd + r, (uint32_t)SMI_CHIMA_PAT);
+                        }
+                    } else if (q0 == 0)
+                        atomicOr(verd + r, (uint32_t)SMI_CHIMA_PAT);  // thresholds the bit-sliced counter cannot hold: the walk finds no trigger
+                }
+                if (q0 == 0 && P.force_all) atomicOr(verd + r, (uint32_t)(SMI_CHIMA_TSO | SMI_CHIMA_PAT));
+            }
+        }
+        if (w < stride) {
+            cand[w] = cm[0];
+            cand[stride + w] = cm[1];
+            trig[w] = ma;
+            trig[stride + w] = mt;
+        }
+        // ---- pool the gated positions of the tile per orientation
+#pragma unroll
+        for (int c = 0; c < 4; c++) L.pw[c][tid] = lo4[c];
+        if (tid == 255) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) L.pw[c][256] = hi4[c];
+        }
+        int off[2], tot_w[2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            off[o] = wave_exscan_i(__popc(cm[o]), lane, tot_w[o]);
+            if (lane == 0) L.wsum[o][wv] = tot_w[o];
+            L.cmask[o][tid] = cm[o];
+            L.hot[o][tid] = P.myers_ok ? 0u : cm[o];  // no bound for this pattern: every gated position counts as possible
+        }
+        __syncthreads();
+        int total[2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            int base = 0, t = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k < wv) base += L.wsum[o][k];
+                t += L.wsum[o][k];
+            }
+            total[o] = t;
+            off[o] += base;
+            if (t > kFlatList)
+                L.hot[o][tid] = cm[o];
+            else {
+                int i = off[o];
+                for (uint32_t g = cm[o]; g; g &= g - 1) L.clist[o][i++] = (uint16_t)((tid << 5) | __builtin_ctz(g));
+            }
+        }
+        __syncthreads();
+        if (P.myers_ok) {
+#pragma unroll
+            for (int o = 0; o < 2; o++) {
+                if (total[o] > kFlatList) continue;
+                for (int base = 0; base < total[o]; base += 256) {
+                    if (base + (wv << 6) >= total[o]) break;  // nothing for this wave
+                    const int e = base + tid;
+                    const bool live = e < total[o];
+                    uint32_t V[4] = {0, 0, 0, 0};
+                    int t = 0, k = 0;
+                    if (live) {
+                        const int x = L.clist[o][e];
+                        t = x >> 5;
+                        k = x & 31;
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const uint64_t x64 = ((uint64_t)L.pw[c][t + 1] << 32) | L.pw[c][t];
+                            V[c] = __brev((uint32_t)(x64 >> k)) >> (32 - kTsoLen);
+                        }
+                    }
+                    int b;
+                    if constexpr (PAT != 0)
+                        b = o ? myers_bound_ct<kTsoLen, PAT, 1>(V, P.lead_max) : myers_bound_ct<kTsoLen, PAT, 0>(V, P.lead_max);
+                    else
+                        b = myers_bound<kTsoLen>(V, o ? P.rev_idx : P.fwd_idx, P.lead_max);
+                    if (live && b <= P.tso_max) atomicOr(&L.hot[o][t], 1u << k);
+                }
+            }
+        }
+        __syncthreads();
+        if (w < stride) {
+            const uint32_t h0 = L.hot[0][tid], h1 = L.hot[1][tid];
+            hotw[w] = h0;
+            hotw[stride + w] = h1;
+            if ((h0 | h1) && r != 0xFFFFFFFFu) atomicOr(verd + r, (uint32_t)SMI_CHIMA_TSO);
+        }
+        __syncthreads();
+    }
+}
+
+// verdicts -> results of the cleared reads + the queue of the others (one atomic per 1024 reads: the queue counter is a single address)
+__global__ __launch_bounds__(1024) void k_chima_finish(const uint32_t *__restrict__ verd, size_t n, smi_chimera_result *__restrict__ out,
+                                                       uint32_t *__restrict__ list, uint32_t *__restrict__ list_count) {
+    __shared__ uint32_t wcnt[16], wbase[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (size_t r0 = blockIdx.x * (size_t)1024; r0 < n; r0 += (size_t)gridDim.x * 1024) {
+        const size_t r = r0 + threadIdx.x;
+        const uint32_t v = r < n ? verd[r] : 0u;
+        if (r < n) {
+            smi_chimera_result res;
+            res.n_split = 0;
+            res.pos[0] = res.pos[1] = 0;
+            res.reason[0] = res.reason[1] = 0;
+            res.flags = 0;
+            res.n_matches = (int)v;
+            out[r] = res;
+        }
+        const unsigned long long q = __ballot(v != 0);
+        if (lane == 0) wcnt[wv] = (uint32_t)__popcll(q);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int k = 0; k < 16; k++) {
+                wbase[k] = t;
+                t += wcnt[k];
+            }
+            const uint32_t b = t ? atomicAdd(list_count, t) : 0u;
+            for (int k = 0; k < 16; k++) wbase[k] += b;
+        }
+        __syncthreads();
+        if (v) list[wbase[wv] + __popcll(q & ((1ull << lane) - 1ull))] = (uint32_t)r;
+        __syncthreads();
+    }
+}
+
+// K-CHIM-B SELECT on the words K-CHIM-A (second generation) left: a wave per queued read (sixteen reads per workgroup), a lane per
+// plane word.  The closure: a gated position is needed if it is under the bound or something needed lies less than kDmax = 32
+// positions behind it, i.e. in the same or the next word -- every lane smears its own needed bits and those of the lane above 31
+// positions down and takes the gated ones; repeated until no lane changes (the chains are a few positions long).  The positions
+// are appended to the global queue in scan order; the sixteen reads of a workgroup reserve their room with ONE atomic on one of
+// kSubQ counters (a counter per read would be 10^5 atomics on one address, which serialise).
+__device__ __forceinline__ uint32_t closure_step(uint32_t c, uint32_t hh, uint32_t carry_top, int lane) {
+    uint32_t x = hh;
+    for (;;) {
+        const uint32_t up = __shfl_down(x, 1);
+        uint64_t y = ((uint64_t)(lane == 63 ? carry_top : up) << 32) | x;
+        y |= y >> 1;
+        y |= y >> 2;
+        y |= y >> 4;
+        y |= y >> 8;
+        y |= y >> 16;
+        const uint32_t x2 = hh | (c & (uint32_t)y);
+        const bool changed = x2 != x;
+        x = x2;
+        if (!__ballot(changed)) break;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(1024) void k_chimb_select2(size_t stride, const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets,
+                                                        const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_count,
+                                                        const smi_chimera_result *__restrict__ out, const uint32_t *__restrict__ cand,
+                                                        const uint32_t *__restrict__ hotw, BHead *__restrict__ heads, uint64_t *__restrict__ cand_abs,
+                                                        uint32_t *__restrict__ gcounts, uint32_t cap, uint32_t *__restrict__ dbg) {
+    static_assert(kDmax == 32, "the smear below covers 31 positions");
+    __shared__ uint32_t wtot[16], wbase[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t n_list = *list_count;
+    const size_t li = blockIdx.x * (size_t)16 + wv;
+    const uint32_t sq = blockIdx.x & (kSubQ - 1);
+    const uint32_t sub_cap = cap / kSubQ, sub_base = sq * sub_cap;
+    bool active = li < n_list;
+    size_t r = 0, w0 = 0;
+    int nw = 0;
+    if (active) {
+        r = list[li];
+        active = (out[r].n_matches & SMI_CHIMA_TSO) != 0;
+    }
+    if (active) {
+        const uint64_t beg = offsets[r];
+        nw = ((int)(offsets[r + 1] - beg) + 31) >> 5;
+        w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
+    }
+    const uint64_t bit_base = (uint64_t)w0 * 32u;
+    // ---- count
+    uint32_t nd[2] = {0, 0}, n_need[2] = {0, 0};
+    int offl[2] = {0, 0};
+    if (active && nw <= 64) {  // reads up to 2048 bases: the needed words stay in registers
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const uint32_t c = lane < nw ? cand[(size_t)o * stride + w0 + lane] : 0u;
+            const uint32_t hh = lane < nw ? hotw[(size_t)o * stride + w0 + lane] : 0u;
+            nd[o] = closure_step(c, hh, 0u, lane);
+            int tot;
+            offl[o] = wave_exscan_i(__popc(nd[o]), lane, tot);
+            n_need[o] = (uint32_t)tot;
+        }
+    } else if (active) {  // longer reads: 64 words at a time from the right, the lowest needed word of the chunk above carried along
+        for (int o = 0; o < 2; o++) {
+            uint32_t carry = 0;
+            for (int ch = ((nw + 63) >> 6) - 1; ch >= 0; ch--) {
+                const int w = 64 * ch + lane;
+                const uint32_t c = w < nw ? cand[(size_t)o * stride + w0 + w] : 0u;
+                const uint32_t hh = w < nw ? hotw[(size_t)o * stride + w0 + w] : 0u;
+                const uint32_t x = closure_step(c, hh, carry, lane);
+                carry = __shfl(x, 0);
+                int tot;
+                (void)wave_exscan_i(__popc(x), lane, tot);
+                n_need[o] += (uint32_t)tot;
+            }
+        }
+    }
+    // ---- one reservation per workgroup
+    const uint32_t total = n_need[0] + n_need[1];
+    if (lane == 0) wtot[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int k = 0; k < 16; k++) {
+            wbase[k] = t;
+            t += wtot[k];
+        }
+        const uint32_t b = t ? atomicAdd(gcounts + sq, t) : 0u;
+        for (int k = 0; k < 16; k++) wbase[k] = (unsigned long long)b + wbase[k] + wtot[k] > sub_cap ? 0xFFFFFFFFu : sub_base + b + wbase[k];
+    }
+    __syncthreads();
+    if (!active) return;
+    BHead h;
+    h.first = h.n0 = h.n1 = h.flags = 0;
+    const uint32_t first = wbase[wv];
+    if (first == 0xFFFFFFFFu) {  // out of queue room: the first-generation kernels take the read
+        h.flags = 1;
+        if (lane == 0) {
+            heads[li] = h;
+            atomicAdd(dbg + 6, 1u);
+        }
+        return;
+    }
+    // ---- write, in scan order
+    if (nw <= 64) {
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            uint32_t idx = first + (o ? n_need[0] : 0u) + (uint32_t)offl[o];
+            for (uint32_t g = nd[o]; g; g &= g - 1) cand_abs[idx++] = (bit_base + (uint64_t)(32 * lane + __builtin_ctz(g))) | ((uint64_t)o << 63);
+        }
+    } else {
+        for (int o = 0; o < 2; o++) {
+            uint32_t carry = 0, below = n_need[o];  // needed positions in the chunks below the current one
+            const uint32_t run = first + (o ? n_need[0] : 0u);
+            for (int ch = ((nw + 63) >> 6) - 1; ch >= 0; ch--) {
+                const int w = 64 * ch + lane;
+                const uint32_t c = w < nw ? cand[(size_t)o * stride + w0 + w] : 0u;
+                const uint32_t hh = w < nw ? hotw[(size_t)o * stride + w0 + w] : 0u;
+                const uint32_t x = closure_step(c, hh, carry, lane);
+                carry = __shfl(x, 0);
+                int tot;
+                const int ol = wave_exscan_i(__popc(x), lane, tot);
+                below -= (uint32_t)tot;
+                uint32_t idx = run + below + (uint32_t)ol;
+                for (uint32_t g = x; g; g &= g - 1) cand_abs[idx++] = (bit_base + (uint64_t)(32 * w + __builtin_ctz(g))) | ((uint64_t)o << 63);
+            }
+        }
+    }
+    h.first = first;
+    h.n0 = n_need[0];
+    h.n1 = n_need[1];
+    if (lane == 0) heads[li] = h;
 }
 
 // queue of the reads whose result carries SMI_CHIM_OVERFLOW
@@ -1854,11 +2681,45 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     F.pat_thr = P.pat_thr;
     F.off = P.off;
     const size_t st = stride_override ? stride_override : read_planes_stride(total_bases, n);
-    {
+    const bool v1 = getenv("SMI_CHIM_V1") != nullptr;        // cross-check switch: the first-generation kernels throughout (one wave per read)
+    const bool a1 = v1 || getenv("SMI_CHIM_A1") != nullptr;  // cross-check switch: first-generation filter + the wave-per-read select / trigger kernels
+    const bool generic = getenv("SMI_CHIM_GENERIC") != nullptr || !P.myers_ok;
+    const bool shipped3 = tl == 27 && !std::strcmp(cfg->tso_complete, PatSeq<1>::s) && !generic;
+    const bool shipped5 = tl == 22 && !std::strcmp(cfg->tso_complete, PatSeq<2>::s) && !generic;
+    uint32_t *d_cand_w = nullptr, *d_hot_w = nullptr, *d_trig_w = nullptr;
+    if (!a1) {
+        // flat scratch: own[st] | cand[2 st] | hot[2 st] | trig[2 st] | verd[n]
+        const size_t flat_bytes = (7 * st + n + 64) * sizeof(uint32_t);
+        if (ctx->chim_flat_bytes < flat_bytes) {
+            if (ctx->chim_flat) (void)hipFree(ctx->chim_flat);
+            ctx->chim_flat = nullptr;
+            ctx->chim_flat_bytes = 0;
+            const size_t want = flat_bytes + flat_bytes / 8;
+            SMI_HIP(hipMalloc(&ctx->chim_flat, want));
+            ctx->chim_flat_bytes = want;
+        }
+        uint32_t *d_own = static_cast<uint32_t *>(ctx->chim_flat);
+        d_cand_w = d_own + st;
+        d_hot_w = d_cand_w + 2 * st;
+        d_trig_w = d_hot_w + 2 * st;
+        uint32_t *d_verd = d_trig_w + 2 * st;
+        SMI_HIP(hipMemsetAsync(d_own, 0xFF, st * sizeof(uint32_t), s));
+        SMI_HIP(hipMemsetAsync(d_verd, 0, n * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_chim_owner, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, s, d_pstart, d_offsets, n, d_own);
+        const size_t n_tiles = (st + 255) / 256;
+        const unsigned gridF = (unsigned)std::min<size_t>(n_tiles, 256 * 8);
+        if (shipped3)
+            hipLaunchKernelGGL((k_chima_flat<27, 1>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+        else if (shipped5)
+            hipLaunchKernelGGL((k_chima_flat<22, 2>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+        else if (tl == 27)
+            hipLaunchKernelGGL((k_chima_flat<27, 0>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+        else
+            hipLaunchKernelGGL((k_chima_flat<22, 0>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+        hipLaunchKernelGGL(k_chima_finish, dim3((unsigned)std::min<size_t>((n + 1023) / 1024, 256 * 8)), dim3(1024), 0, s, d_verd, n, d_out, d_list, d_count);
+        SMI_HIP(hipGetLastError());
+    } else {
         const unsigned gridA = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
-        const bool generic = getenv("SMI_CHIM_GENERIC") != nullptr || !P.myers_ok;
-        const bool shipped3 = tl == 27 && !std::strcmp(cfg->tso_complete, PatSeq<1>::s) && !generic;
-        const bool shipped5 = tl == 22 && !std::strcmp(cfg->tso_complete, PatSeq<2>::s) && !generic;
         if (shipped3)
             hipLaunchKernelGGL((k_chim_tso_filter<27, 1>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
         else if (shipped5)
@@ -1900,50 +2761,93 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         TsoSlot *d_slots = static_cast<TsoSlot *>(ctx->chim_slots);
         const unsigned grid = (unsigned)std::min<size_t>(((size_t)n_list + 3) / 4, 256 * 16);
         if (!(P.ablate & 16)) {
-            const bool v1 = getenv("SMI_CHIM_V1") != nullptr;  // cross-check switch: the first-generation exact TSO scan (one wave per read aligns every gated position)
             if (!v1) {
-                // K-CHIM-B second generation: heads | queue of positions (u64) | error counts (f32)
-                const size_t cap = std::max<size_t>((size_t)n_list * 48, (size_t)1 << 16);
-                const size_t heads_bytes = ((size_t)n_list * sizeof(BHead) + 255) & ~(size_t)255;
-                const size_t work_bytes = heads_bytes + cap * 12;
-                if (ctx->chim_work_bytes < work_bytes) {
+                // scratch of the second-generation pipelines, one grow-only buffer:
+                //   B: heads | queue of positions (u64) | error counts (f32)
+                //   C: trigger words (2 x stride) | stretches | their results | per-read stretch lists | alignment queue | its results
+                auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+                const size_t cap = (std::max<size_t>((size_t)n_list * 48, (size_t)1 << 16) + kSubQ - 1) / kSubQ * kSubQ;
+                const size_t st_cap = std::max<size_t>((size_t)n_list * 4, (size_t)1 << 12);
+                const size_t e_cap = std::max<size_t>((size_t)n_list * 8, (size_t)1 << 12);
+                size_t off = 0;
+                auto take = [&](size_t bytes) { const size_t o = off; off += up(bytes); return o; };
+                const size_t o_bcnt = take(kSubQ * 4);
+                const size_t o_heads = take((size_t)n_list * sizeof(BHead)), o_cand = take(cap * 8), o_ne = take(cap * 4);
+                const size_t o_trig = take(a1 ? 2 * st * 4 : 0), o_st = take(st_cap * sizeof(Stretch)), o_sres = take(st_cap * sizeof(StretchRes));
+                const size_t o_rst = take((size_t)n_list * kStPerRead * 4), o_rn = take(n_list), o_ent = take(e_cap * sizeof(AdEntry));
+                const size_t o_ene = take(e_cap * 4), o_enm = take(e_cap * 4);
+                if (ctx->chim_work_bytes < off) {
                     if (ctx->chim_work) (void)hipFree(ctx->chim_work);
                     ctx->chim_work = nullptr;
                     ctx->chim_work_bytes = 0;
-                    const size_t want = work_bytes + work_bytes / 4;
+                    const size_t want = off + off / 4;
                     SMI_HIP(hipMalloc(&ctx->chim_work, want));
                     ctx->chim_work_bytes = want;
                 }
-                BHead *d_heads = static_cast<BHead *>(ctx->chim_work);
-                uint64_t *d_cand = reinterpret_cast<uint64_t *>(static_cast<char *>(ctx->chim_work) + heads_bytes);
-                float *d_ne = reinterpret_cast<float *>(d_cand + cap);
-                uint32_t *d_gcount = d_count + 2;  // zeroed with the queue counters above
-                const bool generic = getenv("SMI_CHIM_GENERIC") != nullptr || !P.myers_ok;
-                const bool shipped3 = tl == 27 && !std::strcmp(cfg->tso_complete, PatSeq<1>::s) && !generic;
-                const bool shipped5 = tl == 22 && !std::strcmp(cfg->tso_complete, PatSeq<2>::s) && !generic;
-                const unsigned grid_al = 256 * 8;
-                if (shipped3)
-                    hipLaunchKernelGGL((k_chimb_select<27, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                char *wk = static_cast<char *>(ctx->chim_work);
+                BHead *d_heads = reinterpret_cast<BHead *>(wk + o_heads);
+                uint64_t *d_cand = reinterpret_cast<uint64_t *>(wk + o_cand);
+                float *d_ne = reinterpret_cast<float *>(wk + o_ne);
+                uint32_t *d_trig = a1 ? reinterpret_cast<uint32_t *>(wk + o_trig) : d_trig_w;
+                Stretch *d_st = reinterpret_cast<Stretch *>(wk + o_st);
+                StretchRes *d_sres = reinterpret_cast<StretchRes *>(wk + o_sres);
+                uint32_t *d_rst = reinterpret_cast<uint32_t *>(wk + o_rst);
+                uint8_t *d_rn = reinterpret_cast<uint8_t *>(wk + o_rn);
+                AdEntry *d_ent = reinterpret_cast<AdEntry *>(wk + o_ent);
+                float *d_ene = reinterpret_cast<float *>(wk + o_ene);
+                int *d_enm = reinterpret_cast<int *>(wk + o_enm);
+                uint32_t *d_gcount = a1 ? d_count + 2 : reinterpret_cast<uint32_t *>(wk + o_bcnt);  // (second generation: kSubQ counters)
+                if (!a1) SMI_HIP(hipMemsetAsync(d_gcount, 0, kSubQ * 4, s));
+                uint32_t *d_stcount = d_count + 3, *d_ecount = d_count + 4;  // zeroed with the queue counters above
+                uint32_t *d_dbg = d_count + 8;  // why reads went to the serial kernel: 0 stretches per read, 1 stretch queue, 2 alignment queue, 3 matches per read, 4 TSO slot, 5 gated positions per read, 6 position queue, 7 accepted positions
+                const unsigned grid_flat = 256 * 8;
+                const unsigned grid_lane = (unsigned)(((size_t)n_list + 63) / 64);
+                // ---- B: select -> align -> fold
+                if (!a1)
+                    hipLaunchKernelGGL(k_chimb_select2, dim3((unsigned)(((size_t)n_list + 15) / 16)), dim3(1024), 0, s, st, d_pstart, d_offsets, d_list, d_count, d_out, d_cand_w, d_hot_w, d_heads, d_cand, d_gcount,
+                                       (uint32_t)cap, d_dbg);
+                else if (shipped3)
+                    hipLaunchKernelGGL((k_chimb_select<27, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
                 else if (shipped5)
-                    hipLaunchKernelGGL((k_chimb_select<22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                    hipLaunchKernelGGL((k_chimb_select<22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
                 else if (tl == 27)
-                    hipLaunchKernelGGL((k_chimb_select<27, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                    hipLaunchKernelGGL((k_chimb_select<27, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
                 else
-                    hipLaunchKernelGGL((k_chimb_select<22, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap);
+                    hipLaunchKernelGGL((k_chimb_select<22, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
+                // ---- C: triggers -> walk (independent of B: the two could overlap; they are short)
+                if (a1) hipLaunchKernelGGL(k_chimc_trig, dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig);
+                hipLaunchKernelGGL(k_chimc_walk, dim3(grid_lane), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig, d_st, d_stcount,
+                                   (uint32_t)st_cap, d_rst, d_rn, d_dbg);
                 if (tl == 27) {
-                    hipLaunchKernelGGL((k_chimb_align<27>), dim3(grid_al), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
-                    hipLaunchKernelGGL((k_chimb_fold<27>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots);
+                    hipLaunchKernelGGL((k_chimb_align<27>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
+                    hipLaunchKernelGGL((k_chimb_fold<27>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg);
+                    hipLaunchKernelGGL((k_chimc_gate<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
+                                       d_ent, d_ecount, (uint32_t)e_cap, d_dbg);
+                    hipLaunchKernelGGL((k_chimc_align<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm);
                 } else {
-                    hipLaunchKernelGGL((k_chimb_align<22>), dim3(grid_al), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
-                    hipLaunchKernelGGL((k_chimb_fold<22>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots);
+                    hipLaunchKernelGGL((k_chimb_align<22>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
+                    hipLaunchKernelGGL((k_chimb_fold<22>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg);
+                    hipLaunchKernelGGL((k_chimc_gate<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
+                                       d_ent, d_ecount, (uint32_t)e_cap, d_dbg);
+                    hipLaunchKernelGGL((k_chimc_align<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm);
                 }
-                SMI_HIP(hipGetLastError());
-            }
-            if (tl == 27) {
-                if (v1) hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg);
+                // second chance for the reads over a cap of the lane-per-read kernels (one in 10^5): the first-generation kernels, one wave per read,
+                // with their caps of 64; what is over those too goes to the serial kernel below
+                uint32_t *d_over2_count = d_count + 5, *d_over2 = d_list + n;
+                hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over2, d_over2_count);
+                if (tl == 27) {
+                    hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
+                    hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
+                } else {
+                    hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
+                    hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
+                }
+            } else if (tl == 27) {
+                hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
                 hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
             } else {
-                if (v1) hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
                 hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
             }
             SMI_HIP(hipGetLastError());
@@ -1954,6 +2858,14 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
             uint32_t n_over = 0;
             SMI_HIP(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, s));
             SMI_HIP(hipStreamSynchronize(s));
+#ifdef SMI_MEASURE
+            if (getenv("SMI_CHIM_STATS")) {
+                uint32_t h[16];
+                SMI_HIP(hipMemcpy(h, d_count, 64, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[chim stats] queue %u over %u positions %u stretches %u ad-entries %u | caps hit: st/read %u st-queue %u ad-queue %u matches %u slot %u gated %u pos-queue %u accepted %u\n",
+                        h[0], h[1], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+            }
+#endif
             if (n_over) {
                 std::vector<uint32_t> over(n_over);
                 std::vector<uint64_t> offs(n + 1);

@@ -151,6 +151,8 @@ struct smi_ctx {
     size_t chim_slot_bytes = 0;
     void *chim_work = nullptr;     // K-CHIM second generation: per-read heads, the global queue of positions to align, their error counts (grow-only)
     size_t chim_work_bytes = 0;
+    void *chim_flat = nullptr;     // K-CHIM-A second generation: owner of every plane word, gate / bound / trigger words, verdicts (grow-only)
+    size_t chim_flat_bytes = 0;
     void *arena = nullptr;         // device memory of the chunk workers (smi_worker.hip), grow-only
     size_t arena_bytes = 0;
     uint8_t *host_out[2] = {nullptr, nullptr};  // pinned: passed / failed text of the last smi_scanfastq_pass2_chunk

@@ -40,14 +40,15 @@ def main():
     res = {}
 
     def run(env, n_sub=None):
-        for k in ("SMI_CHIM_V1", "SMI_CHIM_NO_PREFILTER", "SMI_CHIM_GENERIC"):
+        for k in ("SMI_CHIM_V1", "SMI_CHIM_A1", "SMI_CHIM_NO_PREFILTER", "SMI_CHIM_GENERIC"):
             os.environ.pop(k, None)
         for k in env:
             os.environ[k] = "1"
         m = n if n_sub is None else n_sub
         out = torch.zeros((m, 4), dtype=torch.int32, device=dev)
         tot = int(offs[m])
-        ctx.chimera_device(planes, offs[:m + 1].contiguous(), m, tot, cfg, out)   # the planes of the first m reads are the same words
+        for _ in range(4):   # (the first launches after an idle spell run at a lower clock)
+            ctx.chimera_device(planes, offs[:m + 1].contiguous(), m, tot, cfg, out)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(3):
@@ -60,10 +61,15 @@ def main():
     res["reads"] = n
     res["default_ms"], res["v1_ms"] = ta, tb
     res["default_equals_v1"] = bool((a == b).all())
-    m = min(n, 100_000)
-    c, tc = run(["SMI_CHIM_NO_PREFILTER", "SMI_CHIM_V1"], m)
-    res["no_prefilter_reads"] = m
-    res["default_equals_no_prefilter"] = bool((a[:m] == c).all())
+    c, tc = run(["SMI_CHIM_NO_PREFILTER", "SMI_CHIM_V1"])
+    res["no_prefilter_v1_ms"] = tc
+    res["default_equals_no_prefilter"] = bool((a == c).all())
+    c2, tc2 = run(["SMI_CHIM_NO_PREFILTER"])
+    res["no_prefilter_ms"] = tc2
+    res["default_equals_no_prefilter_v2"] = bool((a == c2).all())
+    a1, ta1 = run(["SMI_CHIM_A1"])
+    res["a1_ms"] = ta1
+    res["default_equals_a1"] = bool((a == a1).all())
     d, td = run(["SMI_CHIM_GENERIC"])
     res["generic_ms"] = td
     res["default_equals_generic"] = bool((a == d).all())
@@ -75,7 +81,7 @@ def main():
         res["first_diff"] = [int(x) for x in bad[:10]]
         res["diff_rows"] = {int(i): [a[i].tolist(), b[i].tolist()] for i in bad[:5]}
     print(json.dumps(res))
-    ok = res["default_equals_v1"] and res["default_equals_no_prefilter"] and res["default_equals_generic"]
+    ok = res["default_equals_v1"] and res["default_equals_no_prefilter"] and res["default_equals_no_prefilter_v2"] and res["default_equals_generic"] and res["default_equals_a1"]
     sys.exit(0 if ok else 1)
 
 
