@@ -1480,6 +1480,7 @@ __global__ __launch_bounds__(256) void k_chimb_select(const uint32_t *__restrict
         }
         if ((unsigned long long)first + total > cap) {
             h.flags = 1;
+            for (unsigned long long e = (unsigned long long)first + lane; e < cap; e += 64) cand_abs[e] = ~0ull;  // nothing of this read is queued: mark the room it took
             if (lane == 0) {
                 heads[li] = h;
                 atomicAdd(dbg + 6, 1u);
@@ -1517,6 +1518,7 @@ __global__ __launch_bounds__(256, SMI_CHIM_B_WAVES) void k_chimb_align(const uin
     for (uint32_t e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < total; e0 += gridDim.x * blockDim.x) {
         const uint32_t e = sub_base + e0;
         const uint64_t a = cand_abs[e];
+        if (a == ~0ull) continue;  // room that was reserved by reads which then did not fit (k_chimb_select*)
         const int o = (int)(a >> 63);
         const uint64_t bit = a & 0x7FFFFFFFFFFFFFFFull;
         const size_t w = (size_t)(bit >> 5);
@@ -1937,8 +1939,14 @@ __global__ __launch_bounds__(256) void k_chimc_gate(const uint32_t *__restrict__
             const uint32_t n = (uint32_t)__popc(gate);
             const uint32_t first = atomicAdd(n_entries, n);
             if ((unsigned long long)first + n > entry_cap) {
-                res.gate = 0xFFFFFFFFu;  // out of queue space: the read goes to the serial kernel
+                res.gate = 0xFFFFFFFFu;  // out of queue space: the first-generation kernels take the read
                 atomicAdd(dbg + 2, 1u);
+                for (unsigned long long e = first; e < entry_cap; e++) {  // mark the room it took
+                    AdEntry x;
+                    x.s = 0xFFFFFFFFu;
+                    x.i = 0;
+                    entries[e] = x;
+                }
             } else {
                 res.first = first;
                 uint32_t k = 0;
@@ -1963,6 +1971,7 @@ __global__ __launch_bounds__(256, SMI_CHIM_C_WAVES) void k_chimc_align(const uin
     const uint32_t n = min(*n_entries, entry_cap);
     for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
         const AdEntry a = entries[e];
+        if (a.s == 0xFFFFFFFFu) continue;  // room reserved by a stretch that did not fit
         const Stretch x = st[a.s];
         const size_t r = list[x.li];
         const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(offsets[r], r);
@@ -2204,7 +2213,7 @@ __global__ __launch_bounds__(256) void k_chima_flat(const uint32_t *__restrict__
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 lo4[c] = planes[c * stride + w];
-                hi4[c] = planes[c * stride + w + 1];
+                hi4[c] = w + 1 < stride ? planes[c * stride + w + 1] : 0u;  // (the last plane ends with the buffer)
             }
         }
         if (r != 0xFFFFFFFFu) {
@@ -2438,6 +2447,7 @@ __global__ __launch_bounds__(1024) void k_chimb_select2(size_t stride, const uin
     const uint32_t total = n_need[0] + n_need[1];
     if (lane == 0) wtot[wv] = total;
     __syncthreads();
+    __shared__ uint32_t hole_lo, hole_hi;
     if (threadIdx.x == 0) {
         uint32_t t = 0;
         for (int k = 0; k < 16; k++) {
@@ -2445,9 +2455,15 @@ __global__ __launch_bounds__(1024) void k_chimb_select2(size_t stride, const uin
             t += wtot[k];
         }
         const uint32_t b = t ? atomicAdd(gcounts + sq, t) : 0u;
-        for (int k = 0; k < 16; k++) wbase[k] = (unsigned long long)b + wbase[k] + wtot[k] > sub_cap ? 0xFFFFFFFFu : sub_base + b + wbase[k];
+        const bool fits = (unsigned long long)b + t <= sub_cap;
+        for (int k = 0; k < 16; k++) wbase[k] = fits ? sub_base + b + wbase[k] : 0xFFFFFFFFu;
+        // the reservation of a workgroup that does not fit is given up as a whole; what it took of the region is marked so that the
+        // alignment kernel passes over it
+        hole_lo = fits ? 0u : min(b, sub_cap);
+        hole_hi = fits ? 0u : sub_cap;
     }
     __syncthreads();
+    for (uint32_t e = hole_lo + threadIdx.x; e < hole_hi; e += 1024) cand_abs[sub_base + e] = ~0ull;
     if (!active) return;
     BHead h;
     h.first = h.n0 = h.n1 = h.flags = 0;
@@ -2600,6 +2616,19 @@ int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offse
     return SMI_OK;
 }
 
+// SMI_CHIM_SYNC=1 (debugging): wait for every kernel of the splitter and name the one that failed
+static bool chim_sync_on() {
+    static const bool on = getenv("SMI_CHIM_SYNC") != nullptr;
+    return on;
+}
+#define SMI_CHIM_CHECK(NAME)                                                                                   \
+    do {                                                                                                       \
+        if (chim_sync_on()) {                                                                                    \
+            const hipError_t e_ = hipStreamSynchronize(s);                                                     \
+            if (e_ != hipSuccess) return hip_fail(e_, "K-CHIM kernel " NAME);                                  \
+        }                                                                                                      \
+    } while (0)
+
 int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_offsets, size_t n, uint64_t total_bases,
                    const smi_chimera_config *cfg, smi_chimera_result *d_out, hipStream_t s, const uint32_t *d_pstart, size_t stride_override) {
     if (!n) return SMI_OK;
@@ -2705,29 +2734,29 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         uint32_t *d_verd = d_trig_w + 2 * st;
         SMI_HIP(hipMemsetAsync(d_own, 0xFF, st * sizeof(uint32_t), s));
         SMI_HIP(hipMemsetAsync(d_verd, 0, n * sizeof(uint32_t), s));
-        hipLaunchKernelGGL(k_chim_owner, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, s, d_pstart, d_offsets, n, d_own);
+        { hipLaunchKernelGGL(k_chim_owner, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, s, d_pstart, d_offsets, n, d_own); SMI_CHIM_CHECK("k_chim_owner"); }
         const size_t n_tiles = (st + 255) / 256;
         const unsigned gridF = (unsigned)std::min<size_t>(n_tiles, 256 * 8);
         if (shipped3)
-            hipLaunchKernelGGL((k_chima_flat<27, 1>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+            { hipLaunchKernelGGL((k_chima_flat<27, 1>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd); SMI_CHIM_CHECK("k_chima_flat"); }
         else if (shipped5)
-            hipLaunchKernelGGL((k_chima_flat<22, 2>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+            { hipLaunchKernelGGL((k_chima_flat<22, 2>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd); SMI_CHIM_CHECK("k_chima_flat"); }
         else if (tl == 27)
-            hipLaunchKernelGGL((k_chima_flat<27, 0>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
+            { hipLaunchKernelGGL((k_chima_flat<27, 0>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd); SMI_CHIM_CHECK("k_chima_flat"); }
         else
-            hipLaunchKernelGGL((k_chima_flat<22, 0>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd);
-        hipLaunchKernelGGL(k_chima_finish, dim3((unsigned)std::min<size_t>((n + 1023) / 1024, 256 * 8)), dim3(1024), 0, s, d_verd, n, d_out, d_list, d_count);
+            { hipLaunchKernelGGL((k_chima_flat<22, 0>), dim3(gridF), dim3(256), 0, s, d_planes, st, n_tiles, d_own, d_pstart, d_offsets, F, d_cand_w, d_hot_w, d_trig_w, d_verd); SMI_CHIM_CHECK("k_chima_flat"); }
+        { hipLaunchKernelGGL(k_chima_finish, dim3((unsigned)std::min<size_t>((n + 1023) / 1024, 256 * 8)), dim3(1024), 0, s, d_verd, n, d_out, d_list, d_count); SMI_CHIM_CHECK("k_chima_finish"); }
         SMI_HIP(hipGetLastError());
     } else {
         const unsigned gridA = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
         if (shipped3)
-            hipLaunchKernelGGL((k_chim_tso_filter<27, 1>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
+            { hipLaunchKernelGGL((k_chim_tso_filter<27, 1>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count); SMI_CHIM_CHECK("k_chim_tso_filter"); }
         else if (shipped5)
-            hipLaunchKernelGGL((k_chim_tso_filter<22, 2>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
+            { hipLaunchKernelGGL((k_chim_tso_filter<22, 2>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count); SMI_CHIM_CHECK("k_chim_tso_filter"); }
         else if (tl == 27)
-            hipLaunchKernelGGL((k_chim_tso_filter<27, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
+            { hipLaunchKernelGGL((k_chim_tso_filter<27, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count); SMI_CHIM_CHECK("k_chim_tso_filter"); }
         else
-            hipLaunchKernelGGL((k_chim_tso_filter<22, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count);
+            { hipLaunchKernelGGL((k_chim_tso_filter<22, 0>), dim3(gridA), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, n, F, d_out, d_list, d_count); SMI_CHIM_CHECK("k_chim_tso_filter"); }
         SMI_HIP(hipGetLastError());
     }
     // the queue length decides the size of the hand-over slots (one small copy + sync per launch)
@@ -2804,57 +2833,57 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 const unsigned grid_lane = (unsigned)(((size_t)n_list + 63) / 64);
                 // ---- B: select -> align -> fold
                 if (!a1)
-                    hipLaunchKernelGGL(k_chimb_select2, dim3((unsigned)(((size_t)n_list + 15) / 16)), dim3(1024), 0, s, st, d_pstart, d_offsets, d_list, d_count, d_out, d_cand_w, d_hot_w, d_heads, d_cand, d_gcount,
-                                       (uint32_t)cap, d_dbg);
+                    { hipLaunchKernelGGL(k_chimb_select2, dim3((unsigned)(((size_t)n_list + 15) / 16)), dim3(1024), 0, s, st, d_pstart, d_offsets, d_list, d_count, d_out, d_cand_w, d_hot_w, d_heads, d_cand, d_gcount,
+                                       (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select2"); }
                 else if (shipped3)
-                    hipLaunchKernelGGL((k_chimb_select<27, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
+                    { hipLaunchKernelGGL((k_chimb_select<27, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select"); }
                 else if (shipped5)
-                    hipLaunchKernelGGL((k_chimb_select<22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
+                    { hipLaunchKernelGGL((k_chimb_select<22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select"); }
                 else if (tl == 27)
-                    hipLaunchKernelGGL((k_chimb_select<27, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
+                    { hipLaunchKernelGGL((k_chimb_select<27, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select"); }
                 else
-                    hipLaunchKernelGGL((k_chimb_select<22, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg);
+                    { hipLaunchKernelGGL((k_chimb_select<22, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select"); }
                 // ---- C: triggers -> walk (independent of B: the two could overlap; they are short)
-                if (a1) hipLaunchKernelGGL(k_chimc_trig, dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig);
-                hipLaunchKernelGGL(k_chimc_walk, dim3(grid_lane), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig, d_st, d_stcount,
-                                   (uint32_t)st_cap, d_rst, d_rn, d_dbg);
+                if (a1) { hipLaunchKernelGGL(k_chimc_trig, dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig); SMI_CHIM_CHECK("k_chimc_trig"); }
+                { hipLaunchKernelGGL(k_chimc_walk, dim3(grid_lane), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig, d_st, d_stcount,
+                                   (uint32_t)st_cap, d_rst, d_rn, d_dbg); SMI_CHIM_CHECK("k_chimc_walk"); }
                 if (tl == 27) {
-                    hipLaunchKernelGGL((k_chimb_align<27>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
-                    hipLaunchKernelGGL((k_chimb_fold<27>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg);
-                    hipLaunchKernelGGL((k_chimc_gate<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
-                                       d_ent, d_ecount, (uint32_t)e_cap, d_dbg);
-                    hipLaunchKernelGGL((k_chimc_align<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm);
+                    { hipLaunchKernelGGL((k_chimb_align<27>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne); SMI_CHIM_CHECK("k_chimb_align"); }
+                    { hipLaunchKernelGGL((k_chimb_fold<27>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg); SMI_CHIM_CHECK("k_chimb_fold"); }
+                    { hipLaunchKernelGGL((k_chimc_gate<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
+                                       d_ent, d_ecount, (uint32_t)e_cap, d_dbg); SMI_CHIM_CHECK("k_chimc_gate"); }
+                    { hipLaunchKernelGGL((k_chimc_align<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm); SMI_CHIM_CHECK("k_chimc_align"); }
                 } else {
-                    hipLaunchKernelGGL((k_chimb_align<22>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne);
-                    hipLaunchKernelGGL((k_chimb_fold<22>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg);
-                    hipLaunchKernelGGL((k_chimc_gate<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
-                                       d_ent, d_ecount, (uint32_t)e_cap, d_dbg);
-                    hipLaunchKernelGGL((k_chimc_align<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm);
+                    { hipLaunchKernelGGL((k_chimb_align<22>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne); SMI_CHIM_CHECK("k_chimb_align"); }
+                    { hipLaunchKernelGGL((k_chimb_fold<22>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg); SMI_CHIM_CHECK("k_chimb_fold"); }
+                    { hipLaunchKernelGGL((k_chimc_gate<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
+                                       d_ent, d_ecount, (uint32_t)e_cap, d_dbg); SMI_CHIM_CHECK("k_chimc_gate"); }
+                    { hipLaunchKernelGGL((k_chimc_align<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm); SMI_CHIM_CHECK("k_chimc_align"); }
                 }
-                hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg);
+                { hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg); SMI_CHIM_CHECK("k_chimc_rules"); }
                 // second chance for the reads over a cap of the lane-per-read kernels (one in 10^5): the first-generation kernels, one wave per read,
                 // with their caps of 64; what is over those too goes to the serial kernel below
                 uint32_t *d_over2_count = d_count + 5, *d_over2 = d_list + n;
-                hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over2, d_over2_count);
+                { hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over2, d_over2_count); SMI_CHIM_CHECK("k_collect_overflow"); }
                 if (tl == 27) {
-                    hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
-                    hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
+                    { hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
+                    { hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
                 } else {
-                    hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
-                    hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out);
+                    { hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
+                    { hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
                 }
             } else if (tl == 27) {
-                hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
-                hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                { hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
+                { hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
             } else {
-                hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
-                hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out);
+                { hipLaunchKernelGGL((k_chimera<22, 25, 1>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
+                { hipLaunchKernelGGL((k_chimera<22, 25, 2>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
             }
             SMI_HIP(hipGetLastError());
             // reads with more than kCap accepted positions / matches: once more without the cap (K-CHIM-S).  The overflow queue sits
             // behind the main queue in the same buffer (the main queue never uses more than n entries, the buffer holds 2 n + 64)
             uint32_t *d_over_count = d_count + 1, *d_over = d_list + n;
-            hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over, d_over_count);
+            { hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over, d_over_count); SMI_CHIM_CHECK("k_collect_overflow"); }
             uint32_t n_over = 0;
             SMI_HIP(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, s));
             SMI_HIP(hipStreamSynchronize(s));
@@ -2890,9 +2919,9 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 SMI_HIP(hipMemcpyAsync(d_over_sorted, over.data(), (size_t)n_over * 4, hipMemcpyHostToDevice, s));
                 const unsigned gs = (unsigned)std::min<uint32_t>(n_over, 4096);
                 if (tl == 27)
-                    hipLaunchKernelGGL((k_chimera_serial<27, 22>), dim3(gs), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
+                    { hipLaunchKernelGGL((k_chimera_serial<27, 22>), dim3(gs), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out); SMI_CHIM_CHECK("k_chimera_serial"); }
                 else
-                    hipLaunchKernelGGL((k_chimera_serial<22, 25>), dim3(gs), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out);
+                    { hipLaunchKernelGGL((k_chimera_serial<22, 25>), dim3(gs), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_over_sorted, n_over, d_scr_off, d_scr, P, d_out); SMI_CHIM_CHECK("k_chimera_serial"); }
                 hipError_t e2 = hipStreamSynchronize(s);
                 (void)hipFree(d_scr_off);
                 (void)hipFree(d_scr);
@@ -2922,8 +2951,8 @@ int launch_frag_text_starts(smi_ctx *, const uint64_t *d_seq_start, const uint64
                             const uint64_t *d_frag_offsets, const uint32_t *d_frag_src, size_t m, uint64_t *d_bstart, uint64_t *d_qstart,
                             hipStream_t s) {
     if (!m) return SMI_OK;
-    hipLaunchKernelGGL(k_frag_text_starts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_seq_start, d_qual_start, d_offsets,
-                       d_frag_offsets, d_frag_src, m, d_bstart, d_qstart);
+    { hipLaunchKernelGGL(k_frag_text_starts, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_seq_start, d_qual_start, d_offsets,
+                       d_frag_offsets, d_frag_src, m, d_bstart, d_qstart); SMI_CHIM_CHECK("k_frag_text_starts"); }
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }
@@ -2933,10 +2962,10 @@ int launch_split_offsets(smi_ctx *, const smi_chimera_result *d_chim, const uint
                          hipStream_t s) {
     if (!n) return SMI_OK;
     const size_t n_blocks = (n + 1023) / 1024;
-    hipLaunchKernelGGL(k_frag_counts, dim3((unsigned)n_blocks), dim3(256), 0, s, d_chim, n, d_scratch);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, d_scratch, n_blocks, d_total);
-    hipLaunchKernelGGL(k_frag_offsets, dim3((unsigned)n_blocks), dim3(256), 0, s, d_chim, d_offsets, n, d_scratch,
-                       d_frag_offsets, d_frag_src);
+    { hipLaunchKernelGGL(k_frag_counts, dim3((unsigned)n_blocks), dim3(256), 0, s, d_chim, n, d_scratch); SMI_CHIM_CHECK("k_frag_counts"); }
+    { hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, d_scratch, n_blocks, d_total); SMI_CHIM_CHECK("k_scan_block_sums"); }
+    { hipLaunchKernelGGL(k_frag_offsets, dim3((unsigned)n_blocks), dim3(256), 0, s, d_chim, d_offsets, n, d_scratch,
+                       d_frag_offsets, d_frag_src); SMI_CHIM_CHECK("k_frag_offsets"); }
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

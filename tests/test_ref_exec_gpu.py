@@ -62,6 +62,40 @@ def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name, packe
     assert n_checked >= len(sec["cases"]) * 0.8 and n_passed >= 3 and n_bc >= 2
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["text", "packed"])
+@pytest.mark.parametrize("name", ["pass2w_3p", "pass2w_3p_ed2", "pass2w_5p", "pass2w_5p_polya"])
+def test_chunk_worker_equals_parser_call(pkg, gpu_ctx, name, packed):
+    """whole chunks (five reads) through the chunk workers with the chimera splitter on, against the records the reference's
+    Parser.call left in the chunk (tests/golden/ref_exec_pass2w_*.json: >= 500 input reads per configuration, fragments of split
+    reads, multi-chimeric reads, failed reads): the passed and the failed text byte for byte"""
+    with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
+        sec = json.load(f)["sections"][0]
+    keys = np.array([_key(b) for b in sec["barcodes"]], dtype=np.uint64)
+    ranks = np.array(sec["ranks"], dtype=np.int32)
+    order = np.argsort(keys)
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    n_in = n_out = n_passed = 0
+    for c in sec["cases"]:
+        if not c["hash_orders_agree"] or "throws" in c["result"]:
+            continue
+        text = "".join(f"@{r['name']}\n{r['seq']}\n+\n{r['qual']}\n" for r in c["reads"]).encode()
+        passed, failed, info = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=sec["ed"], five_prime=sec["five_prime"], dont_search_polya=sec["dont_search_polya"],
+                                                             split_chimeras=sec["split_chimeras"], first_read_id=c["first_read_id"],
+                                                             rank_keys=keys[order], rank_values=ranks[order], packed=packed, n_threads=2)
+        exp_p, exp_f = [], []
+        for w in c["result"]["records"]:
+            wr = w["written"]
+            (exp_p if w["passed"] else exp_f).append(f"@{wr['name']}\n{wr['bases']}\n+{wr['quality_header'] or ''}\n{wr['qualities']}\n")
+        assert passed == "".join(exp_p).encode(), (c["chunk"], passed[:300])
+        assert failed == "".join(exp_f).encode(), (c["chunk"], failed[:300])
+        n_in += len(c["reads"])
+        n_out += len(c["result"]["records"])
+        n_passed += len(exp_p)
+    assert n_in >= 450 and n_passed >= 300
+    if sec["split_chimeras"]:
+        assert n_out >= n_in + 30   # fragments of split reads
+
+
 @pytest.mark.parametrize("name", ["umi_3p", "umi_5p"])
 def test_k_umi_distances_equal_reference_bytecode(pkg, gpu_ctx, name):
     """K-UMI on the windows the product cuts out of the read names == ClusteringEditDistanceBase.calcEditDistances executed from

@@ -592,6 +592,15 @@ def install(jvm):
         N[f"{c}.getFirst"] = lambda j, o: o.native[0] if o.native else no_such(j)
         N[f"{c}.getLast"] = lambda j, o: o.native[-1] if o.native else no_such(j)
         N[f"{c}.contains"] = lambda j, o, v: 1 if any(_eq(j, v, e) for e in o.native) else 0
+    def list_remove_all(j, o, coll):
+        """AbstractCollection.removeAll: every element e of the list for which coll.contains(e) (coll: an ordered list here; contains = equals())"""
+        if not isinstance(coll.native, list):
+            raise Unsupported(f"removeAll({coll.cls}): only ordered collections")
+        keep = [e for e in o.native if not any(_eq(j, e, x) for x in coll.native)]   # contains(e) tests o.equals(e) with o = e, the list element, as argument: x.equals(e)
+        changed = len(keep) != len(o.native)
+        o.native[:] = keep
+        return 1 if changed else 0
+
     def to_array(j, o, a=None):
         if a is None:
             return JArray("Ljava/lang/Object;", list(o.native))
@@ -614,6 +623,7 @@ def install(jvm):
         N[f"{c}.remove:(Ljava/lang/Object;)Z"] = list_remove_obj
         N[f"{c}.addAll:(Ljava/util/Collection;)Z"] = lambda j, o, c2: (o.native.extend(c2.native), 1 if c2.native else 0)[1]
         N[f"{c}.indexOf"] = lambda j, o, v: next((k for k, e in enumerate(o.native) if _eq(j, v, e)), -1)
+        N[f"{c}.removeAll"] = list_remove_all
     # interface views of the same objects
     for iface, impl in (("java/util/List", "java/util/ArrayList"), ("java/util/Collection", "java/util/ArrayList"),
                         ("java/util/Deque", "java/util/ArrayDeque"), ("java/util/Queue", "java/util/ArrayDeque")):

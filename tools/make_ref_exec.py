@@ -890,19 +890,23 @@ def wide_chunk(g, p2, bc_keys_ranks, reads, first_id):
 
 
 def _wide_worker(args):
-    five_prime, ed, dont_search_polya, seed, chunk_ids, per_chunk = args
+    five_prime, ed, dont_search_polya, seed, chunk_ids, per_chunk = args[:6]
+    trim, reader = (args[6], args[7]) if len(args) > 6 else (False, None)
+    reader = reader or wide_read
     g = Gen()
     j = g.j
     p2 = Pass2(g, five_prime, ed, dont_search_polya)
     rs = p2.par.f["readScannerParameters"]
     j.call_virtual(rs.f["what_todo"], "add", "(Ljava/lang/Object;)Z", j.get_static(WHAT_TODO, "FIND_BARCODES"))   # -b (ReadScannerParameters.java:L291)
+    if trim:
+        rs.f["trimFastq"] = 1                                                                                       # -u (NanoporeReadScannerMain.java cli_otions)
     bcs, pairs = wide_barcodes(seed)
     enc = lambda q: j.call_static(TB, "getLongHashForSeq", "([C)J", j.char_array(q))  # noqa: E731
     keys_ranks = [(enc(b), k + 1) for k, b in enumerate(bcs)]
     can_split = not dont_search_polya
     cases = []
     for c in chunk_ids:
-        reads = [wide_read(seed, c * per_chunk + k, bcs, pairs, five_prime, can_split) for k in range(per_chunk)]
+        reads = [reader(seed, c * per_chunk + k, bcs, pairs, five_prime, can_split) for k in range(per_chunk)]
         res = wide_chunk(g, p2, keys_ranks, reads, first_id=1000 * c + 1)
         cases.append({"chunk": c, "first_read_id": 1000 * c + 1, "reads": [{"name": n, "seq": s, "qual": q, "kind": k} for n, s, q, k in reads],
                       "hash_orders_agree": all(r == res[0] for r in res[1:]), "result": res[0]})
@@ -912,11 +916,11 @@ def _wide_worker(args):
     return cases, sorted(j.natives_used), g.hits(), j.steps, flag_values, p2.report
 
 
-def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5):
+def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5, trim=False, reader=None, note=""):
     jobs = max(1, int(os.environ.get("WIDE_JOBS", "1")))
     ids = list(range(n_chunks))
     blocks = [ids[k::jobs] for k in range(jobs)]
-    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk) for b in blocks if b]
+    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk, trim, reader) for b in blocks if b]
     if len(args) == 1:
         parts = [_wide_worker(args[0])]
     else:
@@ -933,17 +937,74 @@ def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chu
     s = {"reference_class": PARSER, "reference_method": "call L132-185 (-> ChimeraFindernew.findSplitPositions, processOneRecord L92-124, assignBarcode L195-315) / "
          "FastqRecordExt.getRecordForWriting L209-311",
          "title": f"pass 2 of scanfastq per CHUNK through Parser.call itself, {'5-prime' if five_prime else '3-prime'} barcoding, --bcEditDistance {ed}"
-                  + (", --noPolyARequired" if dont_search_polya else "") + ": a FastqFileReader$ReadChunk of the five reads of a case -> the records Parser.call leaves in "
+                  + (", --noPolyARequired" if dont_search_polya else "") + (", --trimfastq" if trim else "") + note + ": a FastqFileReader$ReadChunk of the five reads of a case -> the records Parser.call leaves in "
                   "chunk.fastqRecords (fragments of split reads included), each described as in ref_exec_pass2_*.json; passed records take read ids first_read_id, "
                   "first_read_id + 1, ... in list order.  Parameters: Jar/config.xml as shipped + what_todo = {FIND_BARCODES}.  Each chunk ran under two iteration orders "
                   "of java.util.HashMap / HashSet; `hash_orders_agree` = both gave this result.",
          "cases": cases, "barcodes": bcs, "ranks": list(range(1, len(bcs) + 1)), "five_prime": five_prime, "ed": ed, "dont_search_polya": dont_search_polya,
-         "split_chimeras": not dont_search_polya, "kinds": WIDE_KINDS, "flag_values": parts[0][4], "config_report": parts[0][5],
+         "split_chimeras": not dont_search_polya, "trim_fastq": bool(trim), "kinds": sorted({r["kind"] for c in cases for r in c["reads"]}) if reader else WIDE_KINDS,
+         "flag_values": parts[0][4], "config_report": parts[0][5],
          "natives": [{"native": k, "tier": jvm_natives.tier_of(k)} for k in natives]}
     s["max_tier"] = max([n["tier"] for n in s["natives"]] or ["A"])
     out = {"jar": "NanoporeBC_UMI_finder-2.1.jar (+ TwoFourBitNucAcidLibraryMaven-1.0.jar, htsjdk-4.1.3.jar, guava, commons-lang3 as shipped in Jar/lib)",
            "sections": [s], "_steps": sum(p[3] for p in parts), "_hits": hits}
     return out
+
+
+X_KINDS = ["close_splits", "close_splits_rev", "internal_adapter_6err", "internal_adapter_7err", "internal_adapter_8err"]
+
+
+def targeted_read(seed, idx, bcs, pairs, five_prime, can_split):
+    """reads built for single branches of the splitter that the wide set does not reach (3' barcoding)"""
+    rng = random.Random(seed * 1000003 + idx)
+    kind = X_KINDS[idx % len(X_KINDS)]
+    variant = idx // len(X_KINDS)
+
+    def molecule(cdna_len, tso=TSO):
+        return tso + rnd_seq(rng, cdna_len) + "A" * rng.randrange(22, 40) + revcomp_str(rnd_seq(rng, 12)) + revcomp_str(rng.choice(bcs)) + revcomp_str(AD3)
+
+    if kind.startswith("close_splits"):
+        # junction (polyA + adapter | TSO: a pair, split at its middle) and, 40 - 90 bases behind it, the start of a reverse molecule
+        # (adapter + barcode + UMI + polyT: an isolated forward adapter, split 25 bases in front of it): two split positions less than
+        # 100 apart, the second is removed (ChimeraFindernew.java:L273-281)
+        gap = 10 + 10 * (variant % 6)
+        site = AD3 + rng.choice(bcs) + rnd_seq(rng, 12) + "T" * rng.randrange(24, 36)
+        mol = molecule(330) + TSO + rnd_seq(rng, gap) + site + rnd_seq(rng, 420)
+        if kind.endswith("rev"):
+            mol = revcomp_str(mol)
+    else:
+        # internal polyA + adapter whose final alignment has more errors than maxCompleteSeqNeedlemanMismatches (PolyATadapterInternalSearcherBase.java:L203-204)
+        n_err = int(kind[-4])
+        ad = list(AD3)
+        keep = set(range(0, 4)) | set(range(9, 13)) | set(range(18, 22))      # three 4-mers stay (the k-mer gate wants three)
+        pos = [q for q in range(len(ad)) if q not in keep]
+        rng.shuffle(pos)
+        for q in pos[:n_err]:
+            ad[q] = rng.choice([c for c in "ACGT" if c != ad[q]])
+        a = rnd_seq(rng, 600)
+        site = "A" * (28 + variant % 10) + revcomp_str(rnd_seq(rng, 12)) + revcomp_str(rng.choice(bcs)) + revcomp_str("".join(ad))
+        if variant % 2:
+            site = revcomp_str(site)
+        mol = TSO + a[:300] + site + a[300:] + "A" * 30 + revcomp_str(rnd_seq(rng, 12)) + revcomp_str(rng.choice(bcs)) + revcomp_str(AD3)
+    if rng.random() < 0.5 and not kind.startswith("close_splits"):
+        mol = revcomp_str(mol)
+    qual = "".join(chr(33 + rng.randrange(3, 35)) for _ in mol)
+    return f"x{idx:04d} runid=r4 ch={idx % 512}", mol, qual, kind
+
+
+def gen_pass2x_3p(g):
+    """supplement to pass2w_3p: (0) reads aimed at branches of the splitter the wide set misses, (1) the wide reads of chunks 0 .. 23 with --trimfastq"""
+    a = gen_pass2w(g, False, 1, False, 4201, n_chunks=12, per_chunk=5, reader=targeted_read, note=", reads aimed at single branches of ChimeraFindernew / PolyATadapterInternalSearcherBase")
+    b = gen_pass2w(g, False, 1, False, 4101, n_chunks=24, per_chunk=5, trim=True)
+    a["sections"] += b["sections"]
+    a["_steps"] += b["_steps"]
+    merge_hits(a["_hits"], b["_hits"])
+    return a
+
+
+def gen_pass2x_5p(g):
+    """the wide 5' reads of chunks 0 .. 23 with --trimfastq (FastqRecordExt.getRecordForWriting L210-217, L303-304, the 5' arm)"""
+    return gen_pass2w(g, True, 1, True, 4103, n_chunks=24, per_chunk=5, trim=True)
 
 
 def gen_pass2w_3p(g):
@@ -1732,7 +1793,55 @@ RSD = NREAD + "$ReadScanData"
 NCHUNK = "com/rw/umifinder/bamreaders/BamReader$NanoporeReadChunk"
 
 
-def gen_group(g, n_chunks=120, seed=1414):
+def merge_back_designs(seed=1424, n=48):
+    """chunks built so that ClusterList.refineClusters moves reads BACK (ReadGrouper.java:L765-775): a chain whose far-left group is cut
+    off as off-centre, which shifts the centre of the rest towards a small right group that was cut off too and now lies within 500 of
+    it (and the mirror image, and both strands)"""
+    rng = random.Random(seed)
+    out = []
+    for k in range(n):
+        base = rng.randrange(2000, 9000)
+        n_left, n_mid, n_right = rng.randrange(4, 6), rng.randrange(12, 17), rng.randrange(2, 4)
+        far = rng.randrange(1340, 1396)
+        pos = [0 + rng.randrange(0, 6) for _ in range(n_left)] + [rng.randrange(440, 470)] + [900 + rng.randrange(0, 8) for _ in range(n_mid)] + \
+              [far + rng.randrange(0, 5) for _ in range(n_right)]
+        if k % 2:
+            pos = [1400 - p_ for p_ in pos]          # mirror image: the small group on the left
+        flag = 16 if k % 4 >= 2 else 0
+        reads = [[base + p_, flag] for p_ in sorted(pos)]
+        if k % 3 == 0:                               # a second locus on the other strand, and a read without a position
+            reads += [[base + 5000 + 3 * q, 16 - flag] for q in range(5)] + [[None, 0]]
+            reads.sort(key=lambda r: (r[0] is None, r[0] or 0))
+        out.append((reads, k % 2 == 0))
+    # The reads a cluster loses as off-centre never come back: the centre it is compared with afterwards is the stale one of the
+    # removal pass.  What does move is a cluster exactly 500 from the centre of a larger one: 500 apart ends a chain (< 500 chains)
+    # but "within 500 of the centre" (<=) takes the reads over -- a larger cluster with all its reads on one position (or rounding
+    # to it) and a smaller one 500 further on; the emptied cluster is then passed over and dropped (L759-761, L780)
+    for k in range(24):
+        p = rng.randrange(3000, 9000)
+        n_x, n_y = rng.randrange(5, 9), rng.randrange(3, 5)
+        side = 1 if k % 2 == 0 else -1
+        x = [p] * n_x
+        if k % 3 == 1:
+            x = [p - side] + [p] * n_x          # mean within half a base of p: Math.round((float) mean) is still p
+        y = [p + side * 500] * n_y
+        if k % 4 == 3:
+            y += [p + side * (500 + rng.randrange(1, 40))]   # one read beyond: it stays behind alone and its cluster is dropped (L783)
+        if k % 6 == 5:
+            y = [p + side * 501] * n_y                       # one base too far: nothing moves
+        flag = 16 if k % 4 >= 2 else 0
+        reads = [[q, flag] for q in sorted(x + y)]
+        if k % 5 == 0:
+            reads += [[p + 4000 + 7 * q, flag] for q in range(4)]
+        out.append((reads, k % 2 == 1))
+    return out
+
+
+def gen_group2(g):
+    return gen_group(g, designed=merge_back_designs())
+
+
+def gen_group(g, n_chunks=120, seed=1414, designed=None):
     """a-18: genomic-region grouping of one BamReader chunk"""
     j = g.j
     rng = random.Random(seed)
@@ -1764,8 +1873,8 @@ def gen_group(g, n_chunks=120, seed=1414):
                   RGRP, "groupSams:(L...NanoporeReadChunk;Ljava/util/concurrent/BlockingQueue;Z)L...NanoporeReadChunk;")
     j.call_static(RGRP, "setMaxGenomeDistance", "(I)V", 500)
     grouper = j.new(RGRP, "()V")
-    for idx in range(n_chunks):
-        n = rng.choice([0, 1, 2, 3, 5, 12, 40, 90, 160, 300])
+    for idx in range(len(designed) if designed else n_chunks):
+        n = 0 if designed else rng.choice([0, 1, 2, 3, 5, 12, 40, 90, 160, 300])
         reads = []
         base = rng.randrange(1000, 5000)
         while len(reads) < n:                              # loci of 1..25 reads, coordinate-sorted like a BAM chunk
@@ -1777,6 +1886,8 @@ def gen_group(g, n_chunks=120, seed=1414):
         if idx % 5 == 0:
             reads = [[(p if p is None else 2000 + (k // 9) * 3), f] for k, (p, f) in enumerate(reads)]   # dense ties
         keep = idx % 2 == 0
+        if designed:
+            reads, keep = designed[idx]
         chunk = j.new(NCHUNK, "(I)V", 1)
         objs = []
         for pos, flag in reads:
@@ -2040,7 +2151,31 @@ def gen_pass1(g, n_reads=60, seed=1616, five_prime=False):
     return out
 
 
-def gen_cluster_own(g, seed=1717):
+def own_designs(seed=1727):
+    """groups above 100 reads built for the two branches of ClusterOne_MyClustering.call no random group reached:
+    (0) a cluster more than 50 x smaller than the largest one is discarded (foldDepthBelowMaxDiscardForClustering, L79-82): 104 reads of
+        one UMI and 2 of another;
+    (1) members farther than 2 from the centre are ejected and clustered once more with the unclustered reads (L102-112): 40 reads of U,
+        60 of U' (one substitution away) and 3 of M, two substitutions from U and three from U' -- the owner key is a U read (largest
+        neighbourhood), the centre a U' read (least sum of squares), M is 3 from it"""
+    rng = random.Random(seed)
+    u = rnd_seq(rng, 12)
+    other = "".join({"A": "C", "C": "G", "G": "T", "T": "A"}[c] for c in u)
+    g0 = [u] * 96 + [mutate(rng, u, 1)[:12].ljust(12, "A") for _ in range(8)] + [other] * 2
+    u1 = list(u)
+    u1[3] = {"A": "C", "C": "G", "G": "T", "T": "A"}[u1[3]]
+    m = list(u)
+    for q in (7, 9):
+        m[q] = {"A": "G", "C": "T", "G": "A", "T": "C"}[m[q]]
+    g1 = [u] * 40 + ["".join(u1)] * 60 + ["".join(m)] * 3
+    return [g0, g1]
+
+
+def gen_cluster_own2(g):
+    return gen_cluster_own(g, seed=1727, designed=own_designs())
+
+
+def gen_cluster_own(g, seed=1717, designed=None):
     """a-17, the other clusterer: ClusterOne_MyClustering, which the dispatch of UmiClustering$Submitter.lambda$run$2 (L239-261) takes for
     groups of more than 100 reads"""
     j = g.j
@@ -2067,16 +2202,19 @@ def gen_cluster_own(g, seed=1717):
                   "per read the setAttribute calls made on its record.  Groups of 30-45 reads (the class itself; the shipped dispatch only sends "
                   "it groups above 100 reads) and one group of 104 reads (parallel distance matrix and parallel streams run on one thread).  "
                   "Each group under several iteration orders of the hash containers; all answers seen are recorded", COM, "call:()L...ImmutablePair;")
-    sizes = [8, 31, 36, 44, 40, 33, 104]
+    sizes = [len(d) for d in designed] if designed else [8, 31, 36, 44, 40, 33, 104]
     for idx, n in enumerate(sizes):
         umis = [rnd_seq(rng, 12) for _ in range(max(2, n // 5))]
         bc = rnd_seq(rng, 16)
         names = []
         for k in range(n):
+            if designed:
+                names.append(fake_name(rng, 1000 * idx + k, False, bc, designed[idx][k], rng.random() < 0.5, rng.randrange(120, 200), 0))
+                continue
             u = umis[min(int(rng.random() ** 2 * len(umis)), len(umis) - 1)]
             uu = mutate(rng, u, rng.choice([0, 0, 0, 1, 1, 2]))[:12].ljust(12, "A")
             names.append(fake_name(rng, 1000 * idx + k, False, bc, uu, rng.random() < 0.5, rng.randrange(120, 200), rng.choice([0, 0, 0, 1, -1])))
-        orders = ("insertion", "reverse") + tuple(("shuffle", 577 * idx + 3 + 31 * t) for t in range(1 if n > 100 else 4))
+        orders = ("insertion", "reverse") + (() if designed else tuple(("shuffle", 577 * idx + 3 + 31 * t) for t in range(1 if n > 100 else 4)))
         results = [cluster_once(j, side, par, stats, names, order, cls=COM) for order in orders]
         distinct = []
         for r in results:
@@ -2566,7 +2704,8 @@ def gen_auxorder(g, seed=2222):
 SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
-            "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya}
+            "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
+            "pass2x_3p": gen_pass2x_3p, "pass2x_5p": gen_pass2x_5p, "group2": gen_group2, "cluster_own2": gen_cluster_own2}
 
 
 def run_section(name):
