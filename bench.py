@@ -62,6 +62,17 @@ def valu_peaks():
         return {"two_cycle_forms": 256 * 4 * 2.4 / 2, "four_cycle_forms": 256 * 4 * 2.4 / 4, "source": "nominal 2.4 GHz (profiles/r02/valu_peak.json missing)"}
 
 
+def host_cpu_quota():
+    """CPUs this process may use: the cgroup quota (cpu.max) where there is one, else the affinity mask"""
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            return max(1, int(round(int(q[0]) / int(q[1]))))
+    except Exception:
+        pass
+    return len(os.sched_getaffinity(0))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -161,16 +172,32 @@ def end_to_end_leg(ctx, synth, dev, used, n):
                                               rec_off, is_p, in_text=True)
         state["m"] = m
 
-    run()
+    for _ in range(3):
+        run()
     torch.cuda.synchronize()
-    reps = 3
+    reps = 20
     t0 = time.perf_counter()
     for _ in range(reps):
         run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    # the stages with HIP events of their own (library timing switch), one more pass; K-CHIM = the splitter's whole launch sequence
+    ctx.set_timing(True)
+    run()
+    torch.cuda.synchronize()
+    stage_ms = {"K-CHIM (filter + select/align/fold + walk/gate/align/rules)": ctx.kernel_ms(ctx.K_CHIMERA), "K-SCAN": ctx.kernel_ms(ctx.K_SCAN),
+                "K-BC1": ctx.kernel_ms(ctx.K_BC_MATCH)}
+    ctx.set_timing(False)
+    moved = total_text + state["tot"][0] + state["tot"][1]
+    ach = moved / dt / 1e9
     return {"reads": n, "chimeric_input_frac": 0.10, "records_out": state["m"], "passed": state["tot"][2], "text_in_bytes": total_text,
-            "text_out_bytes": state["tot"][0] + state["tot"][1], "ms": dt * 1e3, "reads_per_s": n / dt,
+            "text_out_bytes": state["tot"][0] + state["tot"][1], "ms": dt * 1e3, "reads_per_s": n / dt, "repetitions": reps,
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "basis": "FASTQ text in + passed / failed text out per chunk (the least a text-to-text pass must move) over the whole chunk's time",
+                         "stage_ms": stage_ms,
+                         "limiter": "the splitter's filter (K-CHIM-A: 4-mer gates + a Levenshtein bound for every gated position of every read) is integer VALU "
+                                    "issue; the rest of the chunk is a dozen short kernels and two host read-backs (queue length, fragment count)",
+                         "kernel_trace": "profiles/r04/e2e_kernel_stats.csv"},
             "stages": "K-FQ, K-PACKR, K-CHIM, fragment offsets, K-PACK, K-SCAN, K-BC1 (3.6M whitelist), K-WRITE; FASTQ text in HBM -> "
                       "passed/failed FASTQ text in HBM; host work between the launches included"}
 
@@ -1089,7 +1116,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         sor = graft.load_oracle()
         sor.build()
-        cores = os.cpu_count() or 1
+        cores = host_cpu_quota()     # OpenMP threads = the CPUs the cgroup grants (the box shows 256, the pool grants 16)
         bset = sor.BarcodeSet(wl.cpu().numpy())
         m = int(cpu_reads["head"].shape[0])
         seqs, quals = zip(*(synth.materialize(cpu_reads, i) for i in range(m)))
@@ -1127,6 +1154,7 @@ def main():
             "value": m / dt,
             "unit": "reads/s",
             "cores": cores,
+            "cpus_visible": os.cpu_count(),
             "kind": "port",
             "sample": f"first {m} reads of rank 0's batch (materialised as ASCII), oracle/sor_scan.c + sor_bc.c "
                       f"(C restatement, OpenMP x{cores}; timed = the two batch calls, not the Python glue between them); the Java "

@@ -1,0 +1,254 @@
+"""The jar's command line in front of the library.
+
+    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar scanfastq  -d <dir> -o <dir> --bcEditDistance k [--compress] [--ncpu N] [-h] [-y] [-a file]
+    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w]
+
+become   python sicelore-2.1_amd scanfastq ... / assignumis ...   (the directory is runnable: __main__.py; a `java` wrapper that drops
+`-jar`, `-Xmx..` and the jar's name makes /root/reference/quickrun-2.1.sh:35,42 run unchanged, tests/test_cli_gpu.py does exactly that).
+
+Reference units: option tables NanoporeReadScannerMain.cli_otions (NanoporeReadScannerMain.java:L336-469) and UmiFinderMain (L298-447);
+config discovery OneProgramMainBase.checkCfgFilePath (cwd, then the application's directory; -c names a file for assignumis);
+exit code 0, or 1 after a message (WorkerReadscanner.java:L376-378).
+
+config.xml: the library's kernels are built for the shipped values of the knobs that shape the algorithm (pattern sequences and lengths,
+thresholds, windows); those are CHECKED against the file and a different value stops the run with the knob's name -- nothing is silently
+ignored.  The knobs that are run-time parameters of the library are taken from the file: sam_records_chunk_size,
+max_GenomeDistance_forGrouping, fileWithAllPossibleTenXbarcodes.  Options the product has no path for (Illumina-guided modes, random
+barcodes, the file watcher) are refused by name.
+"""
+import gzip
+import os
+import sys
+import xml.etree.ElementTree as ET
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# knob (path under <Parameters>) -> the value the library is built with (Jar/config.xml as shipped: SURVEY 5)
+BUILT_IN = {
+    "readscanner/minReadLength": "200", "readscanner/cellsWithReadsnFoldBelowMaxToKeep": "500", "readscanner/testPlusMinusPos": "2",
+    "readscanner/pa_start_prefix": "PS=", "readscanner/pa_end_prefix": "PE=", "readscanner/adapter_pos_prefix": "AE=",
+    "readscanner/tso_pos_prefix": "T=", "readscanner/seq_prefix": "X=", "readscanner/qv_prefix": "Q=",
+    "readscanner/minMeanBCqv": "8", "readscanner/minMeanReadqv": "8", "readscanner/minAdapter3pMatches": "8", "readscanner/minCountFold": "10",
+    "readscanner/nbasesOfAdapterSeqInReadname": "3", "readscanner/runningasdemon": "false",
+    "barcodeUMIFinder/gene_name_attribute": "GE", "barcodeUMIFinder/tagGeneNameFunction": "DefaultTagger",
+    "polyAT/polyATlength": "15", "polyAT/fractionATInPolyAT": "0.75", "polyAT/internalpATlength": "15", "polyAT/internalFractionATInPolyAT": "0.70",
+    "polyAT/windowSearchForPolyA": "150",
+    "adapter_for3pBarcoding/sequence": "CTTCCGATCT", "adapter_for3pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
+    "adapter_for3pBarcoding/maxNeedlemanMismatches": "3", "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
+    "fiveprimeadapter_for5pBarcoding/sequence": "CTTCCGATCT", "fiveprimeadapter_for5pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
+    "fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches": "3", "fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
+    "fiveprimeadapter_for5pBarcoding/AdapterSearchWindow": "110",
+    "threeprimeadapter_for5pBarcoding/sequence": "AACGCAGAGTAC", "threeprimeadapter_for5pBarcoding/sequence_complete": "AAGCAGTGGTATCAACGCAGAGTAC",
+    "threeprimeadapter_for5pBarcoding/maxNeedlemanMismatches": "3", "threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
+    "tso_for3pBarcoding/sequence": "AACGCAGAGTACATGG", "tso_for3pBarcoding/maxNeedlemanMismatches": "5",
+    "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": "8", "tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches": "12",
+    "tso_for3pBarcoding/windowForTSOsearch": "90", "tso_for3pBarcoding/offsetTSOend": "1",
+    "tso_for3pBarcoding/sequence_complete": "AAGCAGTGGTATCAACGCAGAGTACAT", "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "6",
+    "tso_for5pBarcoding/sequence": "AACGCAGAGTACATGG", "tso_for5pBarcoding/maxNeedlemanMismatches": "5",
+    "barcodes/cell_bc_length": "16", "barcodes/distance_from_read_end_for_grouping": "100",
+    "umis/umi_length": "12", "umis/umi_completelinkclusteringED": "2", "umis/umi_singlelinkclusteringED": "1",
+}
+RUN_TIME = ("barcodeUMIFinder/sam_records_chunk_size", "barcodes/max_GenomeDistance_forGrouping", "readscanner/fileWithAllPossibleTenXbarcodes",
+            "readscanner/mergeBCsED")
+
+
+class CliError(Exception):
+    pass
+
+
+def find_config(explicit=None):
+    """-c file, else ./config.xml, else the application's directory (OneProgramMainBase.checkCfgFilePath)"""
+    for p in ([explicit] if explicit else []) + [os.path.join(os.getcwd(), "config.xml"), os.path.join(_HERE, "config.xml")]:
+        if p and os.path.isfile(p):
+            return p
+    if explicit:
+        raise CliError(f"config file {explicit} not found")
+    return None
+
+
+def read_config(path):
+    """-> {"section/knob": text} of the leaves two levels under <Parameters>; the knobs the library is built for are checked"""
+    knobs = {}
+    if path is None:
+        return knobs          # no file anywhere: the built-in values are the shipped file's
+    try:
+        root = ET.parse(path).getroot()
+    except ET.ParseError as e:
+        raise CliError(f"{path}: not well-formed XML ({e})")
+    for sec in root:
+        for leaf in sec:
+            if len(leaf) == 0 and leaf.text is not None:
+                knobs[f"{sec.tag}/{leaf.tag}"] = leaf.text.strip()
+    bad = [(k, knobs[k], v) for k, v in BUILT_IN.items() if k in knobs and _norm(knobs[k]) != _norm(v)]
+    if bad:
+        lines = "\n".join(f"  {k} = {got!r} (this build: {want!r})" for k, got, want in bad)
+        raise CliError(f"{path}: knobs with values this build of libsicelore_mi.so does not implement:\n{lines}\n"
+                       "(the kernels are compiled for the shipped config.xml; see sicelore-2.1_amd/cli.py BUILT_IN)")
+    return knobs
+
+
+def _norm(v):
+    try:
+        return repr(float(v))
+    except ValueError:
+        return v.strip()
+
+
+_CODE = {ord("A"): 0, ord("G"): 1, ord("C"): 2, ord("T"): 3}
+
+
+def read_barcode_file(path, length=16):
+    """one barcode per line, everything from the first '-' dropped, gz or plain (NanoporeReadScannerMain.readBarcodesFile L480-503)
+    -> sorted unique uint64 keys (2 bits per base, A 0 G 1 C 2 T 3, first base most significant)"""
+    op = gzip.open if path.endswith(".gz") else open
+    keys = []
+    with op(path, "rb") as f:
+        for ln, line in enumerate(f, 1):
+            s = line.split(b"-", 1)[0].strip().upper()
+            if not s:
+                continue
+            if len(s) != length or any(c not in _CODE for c in s):
+                raise CliError(f"{path}:{ln}: not a {length}-base A/C/G/T barcode: {line[:40]!r}")
+            v = 0
+            for c in s:
+                v = (v << 2) | _CODE[c]
+            keys.append(v)
+    if not keys:
+        raise CliError(f"{path}: no barcodes")
+    return np.unique(np.array(keys, dtype=np.uint64))
+
+
+def _parse(argv, spec, refused):
+    """commons-cli style: spec {canonical: (short, long, takes value)}; refused {option: why}"""
+    by_opt = {}
+    for name, (sh, lg, has) in spec.items():
+        by_opt["-" + sh] = (name, has)
+        by_opt["--" + lg] = (name, has)
+    out, i = {}, 0
+    while i < len(argv):
+        a = argv[i]
+        if a in refused:
+            raise CliError(f"option {a}: {refused[a]}")
+        if a not in by_opt:
+            raise CliError(f"unknown option {a!r}")
+        name, has = by_opt[a]
+        if has:
+            if i + 1 >= len(argv):
+                raise CliError(f"option {a} needs a value")
+            out[name] = argv[i + 1]
+            i += 2
+        else:
+            out[name] = True
+            i += 1
+    return out
+
+
+SCAN_SPEC = {"inDir": ("d", "inDir", True), "outDir": ("o", "outDir", True), "bcEditDistance": ("b", "bcEditDistance", True),
+             "compress": ("c", "compress", False), "ncpu": ("t", "ncpu", True), "fivePbc": ("h", "fivePbc", False),
+             "noPolyARequired": ("y", "noPolyARequired", False), "bcWhitelist": ("a", "bcWhitelist", True), "logFile": ("l", "logFile", True)}
+SCAN_REFUSED = {o: why for opts, why in (
+    (("-g", "--cellRangerBCs"), "a supplied used-barcode list (pass 1 skipped) has no path in this build"),
+    (("-e", "--randomBarcode"), "random barcodes (a specificity experiment of the reference) are not built"),
+    (("-f", "--fractionAT", "-p", "--polyAlength", "-w", "--windowAT"), "the polyA finder is compiled for the shipped config.xml values (15 / 0.75 / 150)"),
+    (("-k", "--skipNfastqs", "-z", "--onlyNfastqs", "-n", "--nonrecursive", "-v", "--pattern"), "file selection options are not built: every *.fastq[.gz] of the directory is taken"),
+    (("-s", "--dontwrite"), "not built"), (("-u", "--trimfastq"), "the file-to-file driver writes untrimmed records (the chunk workers do trim: smi_pass2_config.trim_fastq)"))
+    for o in opts}
+UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "outfile", True), "annotationFile": ("a", "annotationFile", True),
+            "config": ("c", "config", True), "chunksize": ("v", "chunksize", True), "fivePbc": ("p", "fivePbc", False),
+            "splitReadName": ("w", "splitReadName", False), "logFile": ("l", "logFile", True), "ncpu": ("t", "ncpu", True)}
+UMI_REFUSED = {o: why for opts, why in (
+    (("-k", "--inFile10x", "-g", "--ONTgene", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
+    (("-e", "--randomBarcode", "-f", "--randomUMI"), "random barcodes / UMIs (a specificity experiment of the reference) are not built"),
+    (("-s", "--noclustering"), "not built"), (("-b", "--bcedit", "-u", "--umiedit"), "the clustering distances are the shipped config.xml's (2 / 1)"))
+    for o in opts}
+
+
+def _context():
+    from . import lib
+    return lib.Context(int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def scanfastq(argv):
+    o = _parse(argv, SCAN_SPEC, SCAN_REFUSED)
+    for need in ("inDir", "outDir", "bcEditDistance"):
+        if need not in o:
+            raise CliError(f"Missing required option: {SCAN_SPEC[need][1]}")
+    try:
+        ed = int(o["bcEditDistance"])
+    except ValueError:
+        raise CliError(f"--bcEditDistance {o['bcEditDistance']!r}: not a number")
+    if ed not in (0, 1, 2):
+        raise CliError("--bcEditDistance: this build matches at edit distance 0, 1 or 2")
+    knobs = read_config(find_config())
+    if knobs.get("readscanner/mergeBCsED", "null") not in ("null", "", str(ed)):
+        raise CliError("readscanner/mergeBCsED: only null (= the barcode edit distance) is built")
+    if not os.path.isdir(o["inDir"]):
+        raise CliError(f"input directory {o['inDir']} does not exist")
+    wl_name = o.get("bcWhitelist") or knobs.get("readscanner/fileWithAllPossibleTenXbarcodes", "3M-february-2018.txt.gz")
+    if wl_name == "none":
+        raise CliError("-a none (every 16-mer is a possible barcode) is not built")
+    wl = next((p for p in (wl_name, os.path.join(os.getcwd(), wl_name), os.path.join(_HERE, wl_name)) if os.path.isfile(p)), None)
+    if wl is None:
+        raise CliError(f"file with all possible barcodes {wl_name!r} not found (looked in the working directory and in {_HERE}); "
+                       "-a <file> names it (ReadScannerParameters.java:L247)")
+    keys = read_barcode_file(wl)
+    from . import run_files
+    ctx = _context()
+    ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
+    info = run_files.run(ctx, o["inDir"], o["outDir"], max_ed=ed, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
+                         dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")))
+    print(f"DONE -- {info.get('reads', 0)} reads, {info.get('passed', 0)} passed, {info.get('assigned', 0)} barcode-assigned, "
+          f"{info.get('wall_s', 0.0):.1f} s")
+    return 0
+
+
+def assignumis(argv):
+    o = _parse(argv, UMI_SPEC, UMI_REFUSED)
+    for need in ("inFileNanopore", "outfile"):
+        if need not in o:
+            raise CliError(f"Missing required option: {UMI_SPEC[need][1]}")
+    knobs = read_config(find_config(o.get("config")))
+    if not os.path.isfile(o["inFileNanopore"]):
+        raise CliError(f"input BAM {o['inFileNanopore']} does not exist")
+    if "annotationFile" in o and not os.path.isfile(o["annotationFile"]):
+        raise CliError(f"annotation file {o['annotationFile']} does not exist")
+    out = o["outfile"]
+    prefix = out[:-4] if out.endswith(".bam") else out          # <out>.bam, <out>_umifound_.bam, <out>.genecounts.tsv, <out>.UMIdepths.tsv
+    chunk = int(o.get("chunksize") or knobs.get("barcodeUMIFinder/sam_records_chunk_size", 250000))
+    max_dist = int(knobs.get("barcodes/max_GenomeDistance_forGrouping", 500))
+    from . import assignumis as au
+    refflat = None
+    if "annotationFile" in o:          # refFlat text, gz or plain (picard's RefFlatReader through IOUtil)
+        with (gzip.open if o["annotationFile"].endswith(".gz") else open)(o["annotationFile"], "rt") as f:
+            refflat = f.read()
+    ctx = _context()
+    ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
+    info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
+                                refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")))
+    print(f"DONE -- {info.get('n_records', 0)} records, {info.get('n_clustered', 0)} in UMI clusters")
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    try:
+        if not argv or argv[0] in ("-h", "--help", "help"):
+            print(__doc__)
+            return 0
+        sub, rest = argv[0], argv[1:]
+        if sub == "scanfastq":
+            return scanfastq(rest)
+        if sub == "assignumis":
+            return assignumis(rest)
+        raise CliError(f"sub-command {sub!r}: this build has scanfastq and assignumis (tagbamwithread, mergestats, illuminaparser: SURVEY 2, out of scope)")
+    except CliError as e:
+        print(f"ERROR: {e}", file=sys.stderr)
+        return 1
+    except Exception as e:      # a failed batch: message, exit code 1 (WorkerReadscanner.java:L376-378); the library has no fallback to try
+        from . import lib
+        if isinstance(e, (lib.SmiError, OSError, ValueError)):
+            print(f"ERROR: {type(e).__name__}: {e}", file=sys.stderr)
+            return 1
+        raise

@@ -2862,9 +2862,25 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 }
                 { hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg); SMI_CHIM_CHECK("k_chimc_rules"); }
                 // second chance for the reads over a cap of the lane-per-read kernels (one in 10^5): the first-generation kernels, one wave per read,
-                // with their caps of 64; what is over those too goes to the serial kernel below
+                // with their caps of 64; what is over those too goes to the serial kernel below.  Their number is read back first: the usual
+                // chunk has none, and then neither these kernels nor the serial pass are launched at all
                 uint32_t *d_over2_count = d_count + 5, *d_over2 = d_list + n;
                 { hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over2, d_over2_count); SMI_CHIM_CHECK("k_collect_overflow"); }
+                uint32_t n_over2 = 0;
+                SMI_HIP(hipMemcpyAsync(&n_over2, d_over2_count, 4, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipStreamSynchronize(s));
+#ifdef SMI_MEASURE
+                if (getenv("SMI_CHIM_STATS")) {
+                    uint32_t h[16];
+                    SMI_HIP(hipMemcpy(h, d_count, 64, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[chim stats] queue %u second chance %u stretches %u ad-entries %u | caps hit: st/read %u st-queue %u ad-queue %u matches %u slot %u gated %u pos-queue %u accepted %u\n",
+                            h[0], h[5], h[3], h[4], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
+                }
+#endif
+                if (n_over2 == 0) {
+                    if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;
+                    return SMI_OK;
+                }
                 if (tl == 27) {
                     { hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
                     { hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }

@@ -1,0 +1,116 @@
+"""The jar's command line in front of the library (sicelore-2.1_amd/cli.py): lines 35 and 42 of the reference's quickrun-2.1.sh run as
+they stand, with `java` bound to a wrapper that drops `-jar`, `-Xmx..` and the jar's name and starts `python sicelore-2.1_amd`.  Only
+the two command strings are quoted here; the mapping step between them (minimap2 / samtools in the reference) is replaced by a BAM
+built from the passed reads with synthetic positions."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# /root/reference/quickrun-2.1.sh:35 and :42, verbatim
+STEP1 = "$java -jar -Xmx4G Jar/NanoporeBC_UMI_finder-2.1.jar scanfastq -d $fastqdir -o $readscandir --bcEditDistance 1 --compress "
+STEP3 = "$java -jar  -Xmx4G Jar/NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore ${mappingdir}passed.bam -o ${umidir}passedParsed.bam --annotationFile Data/gencode.v38.chr12.refFlat"
+
+
+def _wrapper(tmp_path):
+    w = tmp_path / "java"
+    w.write_text("#!/bin/bash\n# stands where `java` stands in quickrun-2.1.sh: the JVM's own options and the jar's name go, the sub-command and its options stay\n"
+                 "args=()\nfor a in \"$@\"; do case \"$a\" in -jar|-Xmx*|-Xms*|*.jar) ;; *) args+=(\"$a\");; esac; done\n"
+                 f"exec {sys.executable} {ROOT}/sicelore-2.1_amd \"${{args[@]}}\"\n")
+    w.chmod(0o755)
+    return str(w)
+
+
+def _run(cmd, env, cwd):
+    return subprocess.run(["bash", "-c", cmd], env=env, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def test_cli_refuses_what_it_does_not_implement(tmp_path):
+    """no GPU needed up to the point where the options are understood: unknown / unbuilt options, missing inputs and config.xml knobs this
+    build does not implement end with a message and exit code 1 (the jar: System.exit(1))"""
+    env = dict(os.environ, java=_wrapper(tmp_path))
+    (tmp_path / "in").mkdir()
+    for cmd, needle in (("$java -jar x.jar scanfastq -d in -o out", "bcEditDistance"),
+                        ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --cellRangerBCs list.txt", "cellRangerBCs"),
+                        ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --frobnicate", "unknown option"),
+                        ("$java -jar x.jar scanfastq -d nowhere -o out --bcEditDistance 1", "does not exist"),
+                        ("$java -jar x.jar assignumis -o out.bam", "inFileNanopore"),
+                        ("$java -jar x.jar tagbamwithread --inBam a.bam", "sub-command")):
+        r = _run(cmd, env, str(tmp_path))
+        assert r.returncode == 1 and needle in r.stderr, (cmd, r.returncode, r.stderr[-300:])
+    (tmp_path / "config.xml").write_text("<Parameters><polyAT><polyATlength>18</polyATlength></polyAT></Parameters>")
+    r = _run("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1", env, str(tmp_path))
+    assert r.returncode == 1 and "polyAT/polyATlength" in r.stderr
+
+
+@pytest.mark.gpu
+def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
+    import importlib
+
+    import torch
+
+    import bammodel
+    from test_bam import _parse_aux
+
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    dev = torch.device("cuda", 0)
+    wl = synth.make_whitelist(30_000, seed=4401, device=dev)
+    used = synth.pick_used(wl, 40, seed=4402)
+    work = tmp_path / "run"
+    (work / "Data").mkdir(parents=True)
+    fastqdir, readscandir, mappingdir, umidir = str(work / "fastq") + "/", str(work / "scan") + "/", str(work / "map") + "/", str(work / "umi") + "/"
+    for d in (mappingdir, umidir):
+        os.makedirs(d)
+    n = run_files.write_synthetic_dir(synth, fastqdir, 3, 1500, used, dev, seed=4410, chimera_frac=0.05)
+    # the application directory's barcode file (config.xml:37), found in the working directory
+    keys = np.sort(wl.cpu().numpy().astype(np.uint64))
+    with gzip.open(work / "3M-february-2018.txt.gz", "wt") as f:
+        for k in keys:
+            f.write("".join("AGCT"[(int(k) >> (2 * (15 - i))) & 3] for i in range(16)) + "-1\n")
+    # the shipped knobs, written out: the file is found in the working directory and every knob checks out
+    (work / "config.xml").write_text("<Parameters><readscanner><minReadLength>200</minReadLength><testPlusMinusPos>2</testPlusMinusPos>"
+                                     "<fileWithAllPossibleTenXbarcodes>3M-february-2018.txt.gz</fileWithAllPossibleTenXbarcodes></readscanner>"
+                                     "<barcodeUMIFinder><sam_records_chunk_size>250000</sam_records_chunk_size></barcodeUMIFinder>"
+                                     "<polyAT><polyATlength>15</polyATlength><fractionATInPolyAT>0.75</fractionATInPolyAT></polyAT></Parameters>")
+    env = dict(os.environ, java=_wrapper(tmp_path), fastqdir=fastqdir, readscandir=readscandir, mappingdir=mappingdir, umidir=umidir)
+    r = _run(STEP1, env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    passed = sorted(os.listdir(readscandir + "passed"))
+    assert len(passed) == 3 and all(p.endswith("_passed.fastq.gz") for p in passed)
+    assert os.path.isfile(readscandir + "BarcodesAssigned.tsv") and os.path.isfile(readscandir + "BarcodeList.tsv")
+    names, lens = [], []
+    for p in passed:
+        lines = gzip.open(readscandir + "passed/" + p).read().split(b"\n")
+        names += [ln[1:].split(b" ")[0].decode() for ln in lines[0::4] if ln]
+        lens += [len(ln) for ln in lines[1::4]]
+    assert len(names) > 0.8 * n and sum("_bc=" in nm for nm in names) > 0.5 * n
+    # "mapping": every passed read at a synthetic position of one of eight loci
+    rng = np.random.default_rng(5)
+    rows = sorted((int(20_000 + 4_000 * (i % 8) + rng.integers(0, 60)), nm, 16 if (i % 8) & 1 else 0, L) for i, (nm, L) in enumerate(zip(names, lens)))
+    recs = [bammodel.bam_record(nm, fl, 0, p0, 30, [("M", L)], "C" * L) for p0, nm, fl, L in rows]
+    header = bammodel.bam_bytes("@HD\tVN:1.6\tSO:coordinate\n", [("chr12", 10 ** 8)], [])
+    with open(mappingdir + "passed.bam", "wb") as f:
+        f.write(bammodel.bgzf_compress(header + b"".join(recs), block=16384))
+    (work / "Data" / "gencode.v38.chr12.refFlat").write_text("".join(
+        f"GENE{g}\tTX{g}\tchr12\t+\t{19_000 + 4_000 * g}\t{22_500 + 4_000 * g}\t{19_100 + 4_000 * g}\t{22_400 + 4_000 * g}\t1\t{19_000 + 4_000 * g},\t{22_500 + 4_000 * g},\n"
+        for g in range(8)))
+    r = _run(STEP3, env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for suffix in ("passedParsed.bam", "passedParsed_umifound_.bam", "passedParsed.genecounts.tsv", "passedParsed.UMIdepths.tsv"):
+        assert os.path.getsize(umidir + suffix) > 0, suffix
+    _, _, out = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "passedParsed.bam", "rb").read()))
+    assert len(out) > 0.5 * n
+    n_u8 = n_ge = 0
+    for o in out:
+        tags = {t: v for t, _ty, v in _parse_aux(o["aux"])}
+        d = assignumis.scan_data_from_name(o["name"])
+        bc = tags["BC"].decode() if isinstance(tags["BC"], bytes) else tags["BC"]
+        assert bc == d["bc"]["seq"]
+        n_u8 += "U8" in tags
+        n_ge += "GE" in tags
+    assert n_u8 > 0.9 * len(out) and n_ge > 0.3 * len(out)

@@ -15,7 +15,10 @@ KERNELS = {"k_scan": "smi::k_scan", "k_bc_match_ed1": "smi::k_bc_match_ed1", "k_
            "k_chim_filter": "smi::k_chim_tso_filter", "k_chimera_B": "smi::k_chimera<27, 22, 1>", "k_chimera_C": "smi::k_chimera<27, 22, 2>",
            "k_write": "smi::k_write(", "k_write_name": "smi::k_write_name", "k_fq_lines": "smi::k_fq_lines",
            "k_deflate_blocks": "k_deflate_blocks", "k_deflate_gather": "k_deflate_gather", "k_umi_parse": "smi::k_umi_parse", "k_umi_cluster": "smi::k_umi_cluster",
-           "k_ends_from_planes": "smi::k_ends_from_planes", "k_inflate": "smi::k_inflate("}
+           "k_ends_from_planes": "smi::k_ends_from_planes", "k_inflate": "smi::k_inflate(",
+           "k_chima_flat": "smi::k_chima_flat", "k_chima_finish": "smi::k_chima_finish", "k_chim_owner": "smi::k_chim_owner", "k_chimb_select2": "smi::k_chimb_select2",
+           "k_chimb_align": "smi::k_chimb_align", "k_chimb_fold": "smi::k_chimb_fold", "k_chimc_walk": "smi::k_chimc_walk", "k_chimc_gate": "smi::k_chimc_gate",
+           "k_chimc_align": "smi::k_chimc_align", "k_chimc_rules": "smi::k_chimc_rules", "k_umi_cluster_own": "smi::k_umi_own"}
 
 
 def main():
