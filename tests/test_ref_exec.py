@@ -271,6 +271,7 @@ def test_pass2_exclusions_are_explained():
 
 # ---- whole CHUNKS through Parser.call itself (round 4): split -> search -> assignBarcode -> statistics -> getRecordForWriting --
 WIDE = ["pass2w_3p", "pass2w_3p_ed2", "pass2w_5p", "pass2w_5p_polya"]
+WIDE_X = ["pass2x_3p", "pass2x_5p"]   # reads aimed at single branches of the splitter; the wide reads once more with --trimfastq
 
 
 def oracle_chunk(sor, bset, rank_of, sec, case):
@@ -304,18 +305,14 @@ def oracle_chunk(sor, bset, rank_of, sec, case):
                 if rc2 == 1:
                     a = a_
             rk = rank_of.get(int(a["bc"]) & 0xFFFFFFFF, 0) if a is not None else 0
-            rec, ok = sor.fastq_record(fname, "", fs, fq, sc, a, rank=rk, read_id=rid, five_prime=five, force_failed=multi)
+            rec, ok = sor.fastq_record(fname, "", fs, fq, sc, a, rank=rk, read_id=rid, five_prime=five, force_failed=multi,
+                                       trim_fastq=sec.get("trim_fastq", False))
             out.append((sc, a, rec, ok, multi))
             rid += ok
     return out
 
 
-@pytest.mark.parametrize("name", WIDE)
-def test_pass2_chunks_equal_reference_bytecode(sor, name):
-    """>= 500 input reads per configuration, five to a chunk, through the reference's Parser.call (tools/make_ref_exec.py gen_pass2w):
-    every record it leaves -- fragments of split reads, multi-chimeric reads kept whole, failed reads -- byte for byte, with the
-    barcode call and the scan-level flag bits"""
-    sec = load(name)["sections"][0]
+def _check_chunk_section(sor, sec):
     keys = [sor.encode(b) for b in sec["barcodes"]]
     bset = sor.BarcodeSet(np.array(keys, dtype=np.int64))
     rank_of = {int(k) & 0xFFFFFFFF: r for k, r in zip(keys, sec["ranks"])}
@@ -348,10 +345,32 @@ def test_pass2_chunks_equal_reference_bytecode(sor, name):
             n_rec += 1
             n_passed += ok
         kinds |= {r["kind"] for r in c["reads"]}
-    assert n_in >= 500 and n_skipped <= len(sec["cases"]) // 10, (n_in, n_skipped)
+    assert n_skipped <= max(1, len(sec["cases"]) // 10), (n_in, n_skipped)
+    return n_in, n_rec, n_passed, n_bc, kinds, n_skipped
+
+
+@pytest.mark.parametrize("name", WIDE)
+def test_pass2_chunks_equal_reference_bytecode(sor, name):
+    """>= 500 input reads per configuration, five to a chunk, through the reference's Parser.call (tools/make_ref_exec.py gen_pass2w):
+    every record it leaves -- fragments of split reads, multi-chimeric reads kept whole, failed reads -- byte for byte, with the
+    barcode call and the scan-level flag bits"""
+    sec = load(name)["sections"][0]
+    n_in, n_rec, n_passed, n_bc, kinds, n_skipped = _check_chunk_section(sor, sec)
+    assert n_in >= 500
     assert n_rec >= 450 and n_passed >= 300 and n_bc >= 250 and len(kinds) == len(sec["kinds"])
     if sec["split_chimeras"]:
         assert n_rec > n_in - 5 * n_skipped   # fragments were made
+
+
+@pytest.mark.parametrize("name", WIDE_X)
+def test_pass2_targeted_and_trimmed_chunks_equal_reference_bytecode(sor, name):
+    """pass2x_*: (3' only) reads built for the branches of the splitter the wide set misses -- two split positions less than 100 apart,
+    internal adapters with too many errors -- and the first 24 wide chunks again with --trimfastq (FastqRecordExt.java:L210-217, L303-304)"""
+    secs = load(name)["sections"]
+    assert any(s_.get("trim_fastq") for s_ in secs)
+    for sec in secs:
+        n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
+        assert n_in >= 50 and n_passed >= 30 and n_bc >= 20
 
 
 # ---- a-16: read name -> scan data -> UMI pair distance, 3' and 5' (-p) ---------------------------------------------------
@@ -684,6 +703,18 @@ def test_own_clusterer_equals_reference_bytecode(pkg, sor):
     if not os.path.exists(os.path.join(GOLD, "ref_exec_cluster_own.json")):
         pytest.skip("fixture not generated")
     assignumis = importlib.import_module("sicelore_amd.assignumis")
+    # round 4, cluster_own2: two groups above 100 reads built for the branches no random group reached -- a cluster more than 50 x smaller than
+    # the largest is discarded (ClusterOne_MyClustering.java:L79-82), members farther than 2 from the centre are ejected and clustered again
+    # with the unclustered reads (L102-112)
+    sec2 = load("cluster_own2")["sections"][0]
+    assert len(sec2["cases"]) == 2 and all(c["hash_orders_agree"] and len(c["names"]) > 100 for c in sec2["cases"])
+    for c in sec2["cases"]:
+        o2 = lambda m, n, q: sor.umi_cluster_group(m, n, q, sor.umi_cluster_params())  # noqa: E731   (the shipped switch: above 100 reads)
+        p2 = lambda m, n, q: libmod.umi_cluster_groups(m, [0, n * n], [0, n], q, cfg=libmod.umi_cluster_config())  # noqa: E731
+        got2 = _cluster_tags(sor, assignumis.scan_data_from_name, c["names"], o2)
+        assert got2 == c["set_attribute"], len(c["names"])
+        assert got2 == _cluster_tags(sor, assignumis.scan_data_from_name, c["names"], p2)
+    assert any(t == [] for t in sec2["cases"][0]["set_attribute"])        # the reads of the discarded small cluster get no tags
     sec = load("cluster_own")["sections"][0]
     assert all(isinstance(c["set_attribute"], list) for c in sec["cases"])   # nothing threw
     oracle = lambda m, n, q: sor.umi_cluster_group(m, n, q, sor.umi_cluster_params(own_above=0))  # noqa: E731
@@ -723,6 +754,26 @@ def _pass1_histogram(sor, sec, ra, offs, pass1_ok, reverse, adapter_end):
         if key in wl:
             hist[key] = hist.get(key, 0) + 1
     return sorted([int(k), v] for k, v in hist.items())
+
+
+def test_pass1_worker_5p_equals_reference_bytecode(sor):
+    """pass 1 in 5' mode (UsedCellBCListGenerator.java:L213-215: the barcode BEHIND the adapter, no reverse complement): filter and
+    counter map of 32 reads"""
+    sec = load("pass1_5p")["sections"][0]
+    assert sec["five_prime"] and sec["hash_orders_agree"] and all(c["scanned"] and "filter_throws" not in c for c in sec["cases"])
+    wl = {sor.encode(q) for q in sec["whitelist"]}
+    hist, n_ok = {}, 0
+    for c in sec["cases"]:
+        rc, sc = sor.scan_read_5p(c["seq"], c["qual"], "CTACACGACGCTCTTCCGATCT", dont_search_polya=False)
+        assert rc == 0 and bool(sc["pass1_ok"]) == c["filter"], c["name"]
+        if sc["pass1_ok"]:
+            n_ok += 1
+            st = c["seq"].encode().translate(_TR)[::-1] if sc["reverse"] else c["seq"].encode()
+            ae = int(sc["adapter_end"])
+            key = sor.encode(st[ae:ae + 16].decode())
+            if key in wl:
+                hist[key] = hist.get(key, 0) + 1
+    assert n_ok >= 4 and sorted([int(k), v] for k, v in hist.items()) == sec["histogram"]
 
 
 def test_pass1_worker_equals_reference_bytecode(sor):
