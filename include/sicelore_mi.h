@@ -836,6 +836,16 @@ int smi_gene_counts_add(smi_gene_counts *gc, size_t n, const char *const *gene, 
                         const uint64_t *umi, const uint8_t *has_bc_umi, const uint16_t *flag, const uint8_t *mapq,
                         const uint32_t *first_cigar, const uint32_t *last_cigar, const uint8_t *nth_record, int five_prime);
 int smi_gene_counts_merge(smi_gene_counts *dst, const smi_gene_counts *src);
+/* A run split over ranks / GPUs by chromosome ("no collective, only a final merge of gene counts"; BamReader.java:L130-135 cuts
+ * chunks at chromosome ends, README.md:607 asks for region-complete batches): smi_gene_counts_dump / _load carry a shard's tables between
+ * processes; smi_gene_counts_merge_shard folds a LATER shard into an earlier one so that the tables are those of one process over both --
+ * counters of a (gene, cell, UMI) key held by both are added (plain increments commute); where the later counter carries UMIcounts'
+ * "further alignment" bits the order of the increments would matter: such keys are left alone and counted in *n_order_dependent (may be
+ * NULL).  Region numbers of the shards must differ (each shard numbers from its own base).  NOT mergeGeneCounts (that is
+ * smi_gene_counts_merge, whose add() combines counters with ANDs, for `mergestats`). */
+int smi_gene_counts_dump(const smi_gene_counts *gc, uint8_t *out, size_t cap, size_t *n_out);
+int smi_gene_counts_load(const uint8_t *data, size_t n, smi_gene_counts **out);
+int smi_gene_counts_merge_shard(smi_gene_counts *dst, const smi_gene_counts *later, size_t *n_order_dependent);
 /* recordsWithGene, recordsWithGeneSkippedClipping, number of genes / (gene, cell, UMI) / (region, cell, UMI) entries; any pointer may be NULL */
 int smi_gene_counts_info(const smi_gene_counts *gc, int64_t *records_with_gene, int64_t *records_skipped_clipping, size_t *n_genes,
                          size_t *n_gene_entries, size_t *n_region_entries);

@@ -8,6 +8,7 @@ Per read the caller supplies what the reference parses from the BAM record: the 
 (FastqRecordExt.getScanDatFromReadName, FastqRecordExt.java:L395-496: X=, AE=, bcEnd=, Q=, cellBC), the strand flag
 and the clustering position (NanoporeRead$ReadScanData.getGenomePosition; smi_ref_position_at_read_position).
 """
+import os
 import re
 
 import numpy as np
@@ -644,24 +645,116 @@ def segment_cuts(ref, cur_n, g0, i0, prev_ref, step):
 _BGZF_EOF = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
 
 
+def bai_ref_extents(bai_path):
+    """samtools' / htsjdk's BAM index -> per reference (first virtual offset, virtual offset behind its last record) or None (no records):
+    the metadata pseudo-bin 37450 where the writer left one, else the least chunk start / largest chunk end over the reference's bins"""
+    return bai_ref_extents_bytes(open(bai_path, "rb").read(), bai_path)
+
+
+def bai_ref_extents_bytes(b, what="BAM index"):
+    import struct
+
+    if b[:4] != b"BAI\x01":
+        raise _lib.SmiError(f"{what}: not a BAM index")
+    n_ref, at = struct.unpack_from("<i", b, 4)[0], 8
+    out = []
+    for _ in range(n_ref):
+        n_bin = struct.unpack_from("<i", b, at)[0]
+        at += 4
+        lo, hi, meta = None, None, None
+        for _b in range(n_bin):
+            bin_id, n_chunk = struct.unpack_from("<Ii", b, at)
+            at += 8
+            for c in range(n_chunk):
+                cb, ce = struct.unpack_from("<QQ", b, at)
+                at += 16
+                if bin_id == 37450:
+                    if c == 0:
+                        meta = (cb, ce)
+                    continue
+                lo = cb if lo is None else min(lo, cb)
+                hi = ce if hi is None else max(hi, ce)
+        n_intv = struct.unpack_from("<i", b, at)[0]
+        at += 4 + 8 * n_intv
+        out.append(meta if meta is not None and meta[1] > meta[0] else (None if lo is None else (lo, hi)))
+    return out
+
+
+def plan_shards(extents, world):
+    """whole references dealt to the ranks in file order, balanced by compressed bytes -> per rank (first virtual offset or None = the file's
+    first record, end virtual offset or None = end of file: the unmapped tail goes with the last reference).  With fewer references than
+    ranks the first ranks get one each and the others nothing: (0, 0)."""
+    refs = [e for e in extents if e is not None]
+    m = max(1, min(world, len(refs)))
+    size = [max(1, (e[1] >> 16) - (e[0] >> 16)) for e in refs]
+    total, starts, acc, k = sum(size), [0], 0, 0
+    for r in range(1, m):                 # rank r starts at the first reference whose preceding bytes reach r / m of the whole
+        while k < len(refs) - (m - r) and (acc < total * r / m or k < r):
+            acc += size[k]
+            k += 1
+        k = max(k, starts[-1] + 1)
+        starts.append(k)
+    out = []
+    for r in range(world):
+        if r >= m:
+            out.append((0, 0))
+        else:
+            out.append((None if r == 0 else refs[starts[r]][0], None if r == m - 1 else refs[starts[r + 1]][0]))
+    return out
+
+
 def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
-                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16):
+                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None):
     """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (read and inflated by a thread of their own, one segment ahead), never held as a
     whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
     chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
     device and appended to <out>.bam / <out>_umifound_.bam; the records ReadGrouper holds back and the unfinished chunk go in front of the
-    next segment.  Writes the four files of assignumis_files; the inflated streams and the tables equal the whole-file run's.  -> info dict"""
+    next segment.  Writes the four files of assignumis_files; the inflated streams and the tables equal the whole-file run's.  -> info dict
+
+    Several GPUs ("partition by chromosome ... no collective, only a final merge of gene counts"): with torch.distributed
+    initialised (one process per GPU; `group`) -- or shard=(rank, world) without it -- the references of the BAM are dealt to the ranks as whole
+    chromosomes in file order, balanced by compressed bytes, from <in_bam>.bai (samtools index, as quickrun-2.1.sh:39 leaves it).  Every rank
+    reads only its byte range, runs the same pipeline on it and writes <out>.bam.shard<r> / <out>_umifound_.bam.shard<r>; rank 0 then strings
+    the shards together (BGZF streams concatenate) and merges the gene tables (smi_gene_counts_merge_shard).  What stays the same as in one
+    process: the (cell, region) groups, the tags of every record, the order of the records, both tables.  What may differ: where the batches
+    are cut (BamReader's record counter starts anew on every rank, BamReader.java:L106-158; a batch is a unit of writing only), region NUMBERS
+    (equal regions, other ids: every rank numbers from rank << 40), and -- for a read with alignments on chromosomes of two ranks -- the
+    "further alignment" bit of UMIcounts in the later rank (it sees the name for the first time)."""
     import time
 
     t_all = time.perf_counter()
+    rank, world, dist = 0, 1, None
+    if shard is not None:
+        rank, world = int(shard[0]), int(shard[1])
+    else:
+        try:
+            import torch.distributed as dist_mod
+            if dist_mod.is_available() and dist_mod.is_initialized() and dist_mod.get_world_size(group) > 1:
+                dist, rank, world = dist_mod, dist_mod.get_rank(group), dist_mod.get_world_size(group)
+        except ImportError:
+            pass
     gc, names_seen = _lib.GeneCounts(), _lib.NameSet()
     f_in = open(in_bam, "rb")
-    f_bc, f_umi = open(out_prefix + ".bam", "wb"), open(out_prefix + "_umifound_.bam", "wb")
+    v_begin = v_end = None                          # this rank's range of the file in virtual offsets (None: from the first record / to the end)
     pend = np.zeros(0, dtype=np.uint8)             # inflated bytes not consumed yet: pending records (+ a partial record)
+    if world > 1:
+        bai = next((p_ for p_ in (in_bam + ".bai", in_bam[:-4] + ".bai") if os.path.isfile(p_)), None)
+        if bai is None:
+            raise _lib.SmiError(f"assignumis over {world} ranks needs the BAM index ({in_bam}.bai: samtools index) to deal whole chromosomes to the ranks")
+        v_begin, v_end = plan_shards(bai_ref_extents(bai), world)[rank]
+        if rank > 0 and (v_begin, v_end) != (0, 0):
+            # the header comes from the file's start; it leads this rank's stream (and is not written again: rank 0 wrote it)
+            head = np.fromfile(f_in, dtype=np.uint8, count=4 << 20)
+            hb, _used = _lib.bgzf_inflate(head, n_threads=1)
+            _t, _r, hlen = _lib.bam_header(hb)
+            pend = hb[:hlen].copy()
+    suffix = f".shard{rank}" if world > 1 else ""
+    f_bc, f_umi = open(out_prefix + ".bam" + suffix, "wb"), open(out_prefix + "_umifound_.bam" + suffix, "wb")
     nth_pend = np.zeros(0, dtype=np.uint8)
     header, tagger, refs = None, None, None
     i0, g0, prev_ref = -1, 0, None                 # global position of the last flush, global index of pend's first record, reference of the record in front
     region_base = n_records = n_clustered = n_batches = 0
+    region_base = rank << 40                       # region numbers only matter for equality: every rank numbers from its own base
     cur_n = 0                                      # how many of pend's leading records belong to the chunk being collected
     step = max(int(chunk_size), 1)
     secs = dict(read_inflate=0.0, index=0.0, umi_stage=0.0, write_batch=0.0, bgzf_write=0.0)
@@ -703,14 +796,37 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
     def reader():
         tail = np.zeros(0, dtype=np.uint8)
         try:
+            if (v_begin, v_end) == (0, 0):          # more ranks than chromosomes: nothing for this one
+                segments.put((np.zeros(0, dtype=np.uint8), 0, True, None))
+                return
+            skip = 0                                # bytes of the first inflated block in front of this rank's first record
+            if v_begin is not None:
+                f_in.seek(v_begin >> 16)
+                skip = v_begin & 0xFFFF
+            left = None if v_end is None else (v_end >> 16) - f_in.tell()   # compressed bytes of whole blocks still to read
             while True:
-                raw = np.fromfile(f_in, dtype=np.uint8, count=int(segment_bytes))
-                last = raw.size < segment_bytes
+                want = int(segment_bytes) if left is None else min(int(segment_bytes), left)
+                raw = np.fromfile(f_in, dtype=np.uint8, count=want)
+                if left is not None:
+                    left -= raw.size
+                last = raw.size < segment_bytes if left is None else left == 0
                 comp = np.concatenate([tail, raw]) if tail.size else raw
                 buf, room, used = _lib.bgzf_inflate(comp, n_threads=n_threads, room=room_hint[0]) if comp.size else (np.zeros(0, dtype=np.uint8), 0, 0)
                 tail = comp[used:].copy()
                 if last and tail.size:
                     raise _lib.SmiError("truncated BGZF stream")
+                if skip:
+                    room += skip                     # (the block at v_begin holds the end of the previous chromosome in front of it)
+                    skip = 0
+                if last and v_end is not None and (v_end & 0xFFFF):
+                    # the block the range ends in: its first bytes are this rank's last record(s), the rest is the next rank's
+                    hdr = np.fromfile(f_in, dtype=np.uint8, count=18)
+                    if hdr.size < 18 or hdr[12] != 66 or hdr[13] != 67:
+                        raise _lib.SmiError("BGZF block without a leading BC field at a shard border")
+                    bsize = int(hdr[16]) | (int(hdr[17]) << 8)
+                    blk = np.concatenate([hdr, np.fromfile(f_in, dtype=np.uint8, count=bsize + 1 - 18)])
+                    tb, _u = _lib.bgzf_inflate(blk, n_threads=1)
+                    buf = np.concatenate([buf, tb[:v_end & 0xFFFF]])
                 segments.put((buf, room, last, None))
                 if last:
                     return
@@ -740,7 +856,8 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
                 pend = bam                           # the header is not complete yet: read on
                 continue
             header = bam[:start].copy()
-            emit(header, header)
+            if rank == 0:
+                emit(header, header)
             if refflat is not None:
                 tagger = _lib.GeneTagger(refflat, [nm for nm, _ in refs])
         t1 = time.perf_counter()
@@ -805,11 +922,49 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             prev_ref = int(ref[m - 1])
         g0 += first
     for fh in (f_bc, f_umi):
-        fh.write(_BGZF_EOF)
+        if world == 1:
+            fh.write(_BGZF_EOF)
         fh.close()
     f_in.close()
     for pb in stage.values():
         pb.close()
+    order_dependent = 0
+    if world > 1:
+        # the one exchange of a sharded run: every rank's gene tables (and counts) to rank 0, which strings the output shards together
+        mine = (gc.dump(), n_records, n_clustered, n_batches)
+        if dist is not None:
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0, group=group)
+        else:
+            parts = None                          # shard=(rank, world) without a process group: the caller merges (merge_shards)
+            with open(out_prefix + f".genecounts.shard{rank}", "wb") as f:
+                f.write(mine[0])
+        if dist is not None and rank == 0:
+            for q in range(1, world):
+                later = _lib.GeneCounts.load(parts[q][0])
+                order_dependent += gc.merge_shard(later)
+                later.close()
+            n_records, n_clustered, n_batches = (sum(p_[k] for p_ in parts) for k in (1, 2, 3))
+            for name in (".bam", "_umifound_.bam"):
+                with open(out_prefix + name, "wb") as dst:
+                    for q in range(world):
+                        with open(out_prefix + name + f".shard{q}", "rb") as src:
+                            while True:
+                                blk = src.read(64 << 20)
+                                if not blk:
+                                    break
+                                dst.write(blk)
+                        os.remove(out_prefix + name + f".shard{q}")
+                    dst.write(_BGZF_EOF)
+        if dist is not None:
+            dist.barrier(group=group)
+        if rank != 0 or dist is None:
+            info = gc.info()
+            gc.close()
+            names_seen.close()
+            if tagger is not None:
+                tagger.close()
+            return dict(records=n_records, clustered=n_clustered, batches=n_batches, seconds=secs, wall_s=time.perf_counter() - t_all, rank=rank, world=world, **info)
     with open(out_prefix + ".genecounts.tsv", "w") as f:
         f.write(gc.genecounts_tsv(bc_length))
     with open(out_prefix + ".UMIdepths.tsv", "w") as f:
@@ -819,7 +974,8 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
     names_seen.close()
     if tagger is not None:
         tagger.close()
-    return dict(records=n_records, clustered=n_clustered, batches=n_batches, seconds=secs, wall_s=time.perf_counter() - t_all, **info)
+    return dict(records=n_records, clustered=n_clustered, batches=n_batches, seconds=secs, wall_s=time.perf_counter() - t_all, rank=rank, world=world,
+                gene_keys_order_dependent=order_dependent, **info)
 
 
 def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, native=True, **kw):

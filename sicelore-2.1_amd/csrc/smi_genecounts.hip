@@ -193,6 +193,144 @@ extern "C" int smi_gene_counts_merge(smi_gene_counts *dst, const smi_gene_counts
     return SMI_OK;
 }
 
+// ---- shards of one run (assignumis split by chromosome over ranks / GPUs) ------------------------------------------------------
+// dump / load: the object as bytes (it crosses process borders); merge_shard: the tables of a LATER shard folded into an earlier one so that
+// the result is what one process would have counted over both.  That is not mergeGeneCounts (its add() is an AND of the counters, see
+// above): counters of one (gene, cell, UMI) key that both shards hold -- the same gene name on chromosomes of two shards -- are ADDED, as
+// consecutive increments do; if the later shard's counter carries the "further alignment" bits the order of the increments matters and
+// the call reports the key in *n_order_dependent instead of guessing.  Region numbers must not collide (each shard numbers its regions
+// from its own base).
+extern "C" int smi_gene_counts_dump(const smi_gene_counts *gc, uint8_t *out, size_t cap, size_t *n_out) {
+    if (!gc || !n_out) {
+        set_error("smi_gene_counts_dump: null argument");
+        return SMI_ERR_INVALID;
+    }
+    std::string b;
+    auto put = [&](const void *p, size_t n) { b.append(static_cast<const char *>(p), n); };
+    auto put64 = [&](uint64_t v) { put(&v, 8); };
+    put("SMIGC001", 8);
+    put64((uint64_t)gc->records_with_gene);
+    put64((uint64_t)gc->records_skipped_clipping);
+    put64(gc->gene_names.size());
+    for (const auto &nm : gc->gene_names) {
+        put64(nm.size());
+        put(nm.data(), nm.size());
+    }
+    for (const Table *t : {&gc->genes, &gc->regions}) {
+        put64(t->size());
+        for (const auto &e : *t) {
+            put64(e.first.group);
+            put64(e.first.cell);
+            put64(e.first.umi);
+            put64((uint64_t)(uint32_t)e.second);
+        }
+    }
+    *n_out = b.size();
+    if (out) {
+        if (b.size() > cap) {
+            set_error("smi_gene_counts_dump: output buffer too small");
+            return SMI_ERR_INVALID;
+        }
+        std::memcpy(out, b.data(), b.size());
+    }
+    return SMI_OK;
+}
+
+extern "C" int smi_gene_counts_load(const uint8_t *data, size_t n, smi_gene_counts **out) {
+    if (!data || !out) {
+        set_error("smi_gene_counts_load: null argument");
+        return SMI_ERR_INVALID;
+    }
+    size_t at = 0;
+    bool ok = n >= 8 && !std::memcmp(data, "SMIGC001", 8);
+    at = 8;
+    auto get64 = [&](uint64_t &v) {
+        if (!ok || at + 8 > n) {
+            ok = false;
+            v = 0;
+            return;
+        }
+        std::memcpy(&v, data + at, 8);
+        at += 8;
+    };
+    smi_gene_counts *gc = new smi_gene_counts();
+    uint64_t v = 0, cnt = 0;
+    get64(v);
+    gc->records_with_gene = (int64_t)v;
+    get64(v);
+    gc->records_skipped_clipping = (int64_t)v;
+    get64(cnt);
+    for (uint64_t i = 0; ok && i < cnt; i++) {
+        uint64_t len = 0;
+        get64(len);
+        if (!ok || len > n - at) {
+            ok = false;
+            break;
+        }
+        gc->gene_names.emplace_back(reinterpret_cast<const char *>(data + at), (size_t)len);
+        gc->gene_index.emplace(gc->gene_names.back(), (uint32_t)i);
+        at += (size_t)len;
+    }
+    for (Table *t : {&gc->genes, &gc->regions}) {
+        get64(cnt);
+        for (uint64_t i = 0; ok && i < cnt; i++) {
+            Key k{0, 0, 0};
+            uint64_t c = 0;
+            get64(k.group);
+            get64(k.cell);
+            get64(k.umi);
+            get64(c);
+            if (ok && t == &gc->genes && k.group >= gc->gene_names.size()) ok = false;
+            if (ok) t->emplace(k, (int32_t)(uint32_t)c);
+        }
+    }
+    if (!ok || at != n) {
+        delete gc;
+        set_error("smi_gene_counts_load: not a dump of smi_gene_counts_dump (or truncated)");
+        return SMI_ERR_INVALID;
+    }
+    *out = gc;
+    return SMI_OK;
+}
+
+extern "C" int smi_gene_counts_merge_shard(smi_gene_counts *dst, const smi_gene_counts *later, size_t *n_order_dependent) {
+    if (!dst || !later) {
+        set_error("smi_gene_counts_merge_shard: null argument");
+        return SMI_ERR_INVALID;
+    }
+    size_t bad = 0;
+    for (const auto &e : later->genes) {
+        const std::string &name = later->gene_names[(size_t)e.first.group];
+        auto it = dst->gene_index.find(name);
+        uint32_t g;
+        if (it == dst->gene_index.end()) {
+            g = (uint32_t)dst->gene_names.size();
+            dst->gene_names.push_back(name);
+            dst->gene_index.emplace(name, g);
+        } else
+            g = it->second;
+        const Key k{g, e.first.cell, e.first.umi};
+        auto f = dst->genes.find(k);
+        if (f == dst->genes.end())
+            dst->genes.emplace(k, e.second);
+        else if ((e.second & 61440) == 0 && (((f->second & 4095) + (e.second & 4095)) & ~4095) == 0)
+            f->second = (int32_t)((uint32_t)f->second + (uint32_t)e.second);  // plain increments commute: the count goes up by the later shard's
+        else
+            bad++;
+    }
+    for (const auto &e : later->regions) {
+        if (dst->regions.count(e.first)) {
+            set_error("smi_gene_counts_merge_shard: both shards hold region " + std::to_string(e.first.group) + " (give every shard its own region base)");
+            return SMI_ERR_INVALID;
+        }
+    }
+    for (const auto &e : later->regions) dst->regions.emplace(e.first, e.second);
+    dst->records_with_gene += later->records_with_gene;
+    dst->records_skipped_clipping += later->records_skipped_clipping;
+    if (n_order_dependent) *n_order_dependent = bad;
+    return SMI_OK;
+}
+
 extern "C" int smi_gene_counts_info(const smi_gene_counts *gc, int64_t *records_with_gene, int64_t *records_skipped_clipping, size_t *n_genes,
                                     size_t *n_gene_entries, size_t *n_region_entries) {
     if (!gc) {

@@ -60,7 +60,7 @@ EXPORTS = [
     "smi_packed_planes_words", "smi_fastq_index_pack_host", "smi_scanfastq_pass2_packed_seg", "smi_umi_cluster_groups_device",
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
-    "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into",
+    "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into", "smi_gene_counts_dump", "smi_gene_counts_load", "smi_gene_counts_merge_shard",
     "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen", "smi_name_set_create", "smi_name_set_free", "smi_name_set_seen",
 ]
 
@@ -197,6 +197,9 @@ def load_library():
     lib.smi_gene_counts_free.argtypes = [vp]
     lib.smi_gene_counts_add.argtypes = [vp, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci]
     lib.smi_gene_counts_merge.argtypes = [vp, vp]
+    lib.smi_gene_counts_dump.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
+    lib.smi_gene_counts_load.argtypes = [vp, sz, ctypes.POINTER(vp)]
+    lib.smi_gene_counts_merge_shard.argtypes = [vp, vp, ctypes.POINTER(sz)]
     lib.smi_gene_counts_info.argtypes = [vp, vp, vp, vp, vp, vp]
     lib.smi_gene_counts_tsv.argtypes = [vp, ci, vp, sz, ctypes.POINTER(sz)]
     lib.smi_umi_depths_tsv.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
@@ -496,6 +499,34 @@ class GeneCounts:
     def merge(self, other):
         if self._lib.smi_gene_counts_merge(self._h, other._h):
             raise SmiError(self._lib.smi_last_error().decode())
+
+    def dump(self):
+        """-> bytes (smi_gene_counts_dump): the tables, to be carried to another process"""
+        n = ctypes.c_size_t(0)
+        if self._lib.smi_gene_counts_dump(self._h, None, 0, ctypes.byref(n)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        if self._lib.smi_gene_counts_dump(self._h, buf, n.value, ctypes.byref(n)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        return buf.raw[:n.value]
+
+    @classmethod
+    def load(cls, data):
+        self = cls.__new__(cls)
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        b = bytes(data)
+        if self._lib.smi_gene_counts_load(b, len(b), ctypes.byref(self._h)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        return self
+
+    def merge_shard(self, later):
+        """fold the tables of a later shard of the same run (assignumis split by chromosome) into this one -> keys whose merge would depend on
+        the order of the increments (left alone; 0 for reads whose alignments stay within one shard)"""
+        bad = ctypes.c_size_t(0)
+        if self._lib.smi_gene_counts_merge_shard(self._h, later._h, ctypes.byref(bad)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        return int(bad.value)
 
     def info(self):
         a, b = ctypes.c_int64(0), ctypes.c_int64(0)

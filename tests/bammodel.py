@@ -89,3 +89,63 @@ def parse_bam(bam):
                          aux=bam[q:p + 4 + bs], off=p, length=bs + 4))
         p += 4 + bs
     return text, refs, recs
+
+
+# ---- a BAM index (.bai) for a BGZF stream made by bgzf_compress: what `samtools index` leaves beside passed.bam (quickrun-2.1.sh:39) ----
+def bgzf_block_offsets(data, block=0xFF00):
+    """compressed offset of every block of bgzf_compress(data, block)"""
+    offs, at = [], 0
+    for i in range(0, len(data), block):
+        offs.append(at)
+        at += len(bgzf_block(data[i:i + block]))
+    return offs
+
+
+def virtual_offset(pos, block, block_offsets):
+    return (block_offsets[pos // block] << 16) | (pos % block) if pos // block < len(block_offsets) else None
+
+
+def reg2bin(beg, end):
+    end -= 1
+    for shift, base in ((14, 4681), (17, 585), (20, 73), (23, 9), (26, 1)):
+        if beg >> shift == end >> shift:
+            return base + (beg >> shift)
+    return 0
+
+
+def bai_bytes(n_ref, records, meta=True):
+    """records: (ref_id, pos0, end0, virtual offset of the record, virtual offset behind it) in file order -> the bytes of a .bai
+    (bins with one chunk per record run, a 16 kb linear index, and -- meta -- samtools' pseudo-bin 37450 with the reference's extent)"""
+    per_ref = [dict() for _ in range(n_ref)]
+    ext = [None] * n_ref
+    lin = [dict() for _ in range(n_ref)]
+    for ref, p0, e0, vb, ve in records:
+        if ref < 0:
+            continue
+        b = reg2bin(p0, max(e0, p0 + 1))
+        ch = per_ref[ref].setdefault(b, [])
+        if ch and ch[-1][1] == vb:
+            ch[-1][1] = ve
+        else:
+            ch.append([vb, ve])
+        ext[ref] = (vb, ve) if ext[ref] is None else (min(ext[ref][0], vb), max(ext[ref][1], ve))
+        for w in range(p0 >> 14, (max(e0, p0 + 1) - 1 >> 14) + 1):
+            lin[ref].setdefault(w, vb)
+    out = [b"BAI\x01", struct.pack("<i", n_ref)]
+    for ref in range(n_ref):
+        bins = dict(per_ref[ref])
+        n_bin = len(bins) + (1 if meta and ext[ref] is not None else 0)
+        out.append(struct.pack("<i", n_bin))
+        for b, chunks in sorted(bins.items()):
+            out.append(struct.pack("<Ii", b, len(chunks)))
+            for vb, ve in chunks:
+                out.append(struct.pack("<QQ", vb, ve))
+        if meta and ext[ref] is not None:
+            out.append(struct.pack("<Ii", 37450, 2) + struct.pack("<QQ", ext[ref][0], ext[ref][1]) + struct.pack("<QQ", sum(1 for r in records if r[0] == ref), 0))
+        n_intv = (max(lin[ref]) + 1) if lin[ref] else 0
+        out.append(struct.pack("<i", n_intv))
+        last = 0
+        for w in range(n_intv):
+            last = lin[ref].get(w, last)
+            out.append(struct.pack("<Q", last))
+    return b"".join(out)

@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 _ID = re.compile(rb"(_Q=[0-9.]+)_[0-9a-z]+")
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _canon(text):
     lines = text.split(b"\n")
     assert lines[-1] == b""
@@ -108,7 +116,7 @@ def test_two_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path):
     a = run_files.run(gpu_ctx, in_dir, one, max_ed=1, n_workers=3, reads_per_chunk=1000, whitelist_keys=keys, gz="device")
     np.save(str(tmp_path / "keys.npy"), keys)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29731",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(root, "tests", "_run_files_rank.py"), in_dir, two, str(tmp_path / "keys.npy")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert p.returncode == 0, p.stderr[-3000:]
