@@ -501,7 +501,8 @@ __global__ __launch_bounds__(64) void k_inflate(const uint8_t *__restrict__ in, 
                         } else {
                             const uint32_t dist = (info >> 9) & 0xFFFFu, k = b - L.t_off[lo_t];
                             const uint64_t d0 = out_pos + L.t_off[lo_t];  // where the match's first byte goes
-                            if (dist > d0 || dist > (uint32_t)kWin) {
+                            // (a distance may not reach in front of its own member: zlib and the host decoder refuse it as "too far back")
+                            if (dist > d0 - member_out_start || dist > (uint32_t)kWin) {
                                 bad_dist = true;
                                 done = true;
                             } else {

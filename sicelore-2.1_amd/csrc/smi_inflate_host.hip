@@ -607,7 +607,10 @@ int host_gunzip(const uint8_t *in, size_t n_in, size_t *in_pos, uint8_t *out, si
     while (at < n_in) {
         const size_t h = gzip_header(in + at, n_in - at);
         if (!h) {
-            set_error(at ? "smi_gz_inflate: bytes behind the last member are not a gzip member" : "smi_gz_inflate: not a gzip stream");
+            // Behind a complete member: java.util.zip.GZIPInputStream (which the reference reads *.fastq.gz through) swallows a failed read of
+            // the next header and reports end of stream, and gzip / zlib pass over padding the same way -- the stream ends here.
+            if (at > 0) break;
+            set_error("smi_gz_inflate: not a gzip stream");
             return SMI_ERR_INVALID;
         }
         size_t used = 0, made = 0;

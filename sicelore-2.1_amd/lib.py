@@ -398,7 +398,8 @@ def pack_gz_paths(paths, buffer=None):
         if got != n:
             raise SmiError(f"short read of {p}")
         host[o + n:((o + n + 511) & ~511)] = 0
-        out_caps.append(int.from_bytes(host[o + n - 4:o + n].tobytes(), "little") if n >= 18 else 0)
+        isize = int.from_bytes(host[o + n - 4:o + n].tobytes(), "little") if n >= 18 else 0
+        out_caps.append(isize if isize <= 1032 * n else 0)   # (more than DEFLATE can expand to: not an ISIZE -- capacity 0 sends the file to the host decoder)
     host[at:total] = 0
     return dict(host=host, in_off=in_off, sizes=sizes, out_caps=out_caps)
 
@@ -929,6 +930,8 @@ def gz_inflate(data, alloc=None):
     make = alloc or (lambda n: (np.empty(n, dtype=np.uint8), None))
     # a single-member file says its size (mod 2^32) in its last four bytes; a file of several members gets room for the usual ratio first
     hint = int.from_bytes(data[-4:].tobytes(), "little") if data.size >= 18 else 0
+    if hint > 1032 * data.size:          # more than DEFLATE can expand to: the last bytes are not a member's ISIZE (padding behind the last member)
+        hint = 0
     cap = max(hint if hint >= data.size // 2 else 4 * data.size, 64)
     out, owner = make(cap)
     ip, op = ctypes.c_size_t(0), ctypes.c_size_t(0)
@@ -1237,6 +1240,7 @@ class Context:
             sizes = [a.size for a in arrs]
             if out_caps is None:
                 out_caps = [int.from_bytes(a[-4:].tobytes(), "little") if a.size >= 18 else 0 for a in arrs]
+                out_caps = [c if c <= 1032 * a.size else 0 for c, a in zip(out_caps, arrs)]   # an untrusted field: never more than DEFLATE can expand to
         else:
             host, in_off, sizes = packed["host"], packed["in_off"], packed["sizes"]
             out_caps = packed["out_caps"] if out_caps is None else out_caps

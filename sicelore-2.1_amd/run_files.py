@@ -126,7 +126,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     inflate + pass 1, host + device 4.2 - 4.3 s -- with the library's own decoder on sixteen cores the device's rounds no longer pay, they
     hold LDS that pass 1 wants; "auto" is kept for hosts with fewer cores per GPU.
     host_text_bytes: how much inflated text may wait in host memory between the passes; the text of files beyond that is dropped after pass 1
-    and inflated again in pass 2 (the reference reads every file twice, NanoporeReadScannerMain.java:L306) -- a run of any size.
+    and inflated again in pass 2 (the reference reads every file twice, NanoporeReadScannerMain.java:L306) -- a run of any size (the output side too: a chunk's members go to their file as soon as the file's earlier chunks are written).
     With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
     exchanges are the pass-1 histogram (one all-reduce, then the same finalize on every rank), the records in front of each rank (read ids),
     and the counters behind the two TSVs and the statistics, which rank 0 writes.  Every rank writes the output files of its own inputs; the
@@ -354,7 +354,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             results[fi] = f.result()
             n_on_device += 1 if on_dev_ else 0
         loaded = [results[fi] for fi in range(len(files))]
-        cpu_inflate[0] += t_dev[0]
+        if files:
+            cpu_inflate[0] += t_dev[0]
     else:
         futs = [pool.submit(load_and_count, fi) for fi in range(len(files))]
         load_set()
@@ -427,6 +428,41 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                 if ent[1] == 0:
                     del again[fi]
 
+    # The chunks of pass 2 run on the worker threads in (file, chunk) order; a chunk's members are written to its file's two outputs as soon as
+    # every earlier chunk of that file has been written, and dropped -- at most a few chunks per worker wait in memory, whatever the size of
+    # the run (the reference streams records to a writer thread per input file, FastqWriterThreadPool.java:L209).  The per-barcode counters
+    # go into ONE table under a lock.
+    counts = np.zeros((k.size, 3), dtype=np.int64)
+    counts_lock = threading.Lock()
+    ext = ".fastq.gz" if compress else ".fastq"
+    out_state = {}                                 # file index -> [lock, next chunk to write, {chunk: (passed, failed)}, handles or None]
+    for fi_ in chunks_of:
+        out_state[fi_] = [threading.Lock(), 0, {}, None]
+
+    def out_names(fi):
+        base = files[fi]
+        for suf in (".gz", ".fastq", ".fq"):
+            if base.endswith(suf):
+                base = base[:-len(suf)]
+        return os.path.join(out_dir, "passed", base + "_passed" + ext), os.path.join(out_dir, "failed", base + "_failed" + ext)
+
+    def deliver(fi, ci, zp, zf):
+        st = out_state[fi]
+        with st[0]:
+            st[2][ci] = (zp, zf)
+            while st[1] in st[2]:
+                a, b = st[2].pop(st[1])
+                if st[3] is None:
+                    pn, fn = out_names(fi)
+                    st[3] = (open(pn, "wb"), open(fn, "wb"))
+                st[3][0].write(a)
+                st[3][1].write(b)
+                st[1] += 1
+            if st[1] == chunks_of[fi] and st[3] is not None:
+                st[3][0].close()
+                st[3][1].close()
+                st[3] = ()
+
     def p2(lane, j):
         fi, ci, rng = chunks[j]
         text_j = text_of(fi)[rng[0]:rng[1]]
@@ -435,9 +471,10 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                                                           packed=not on_device, n_threads=host_threads_per_call, compress=on_device)
         bc = info["bc"] if info["n_records_out"] else np.zeros(0, dtype=_lib.BC_RESULT_DTYPE)
         ok = bc["found"] == 1
-        cnt = np.zeros((k.size, 3), dtype=np.int64)
         if ok.any():
-            np.add.at(cnt, (np.searchsorted(rk_keys, bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)), 1)
+            rows, eds = np.searchsorted(rk_keys, bc["bc"][ok].astype(np.uint64)), bc["ed"][ok].astype(np.int64)
+            with counts_lock:
+                np.add.at(counts, (rows, eds), 1)
         if compress and not on_device:
             zp, zf = _gzip_member(memoryview(passed), gz_level), _gzip_member(memoryview(failed), gz_level)
         else:
@@ -445,34 +482,22 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             # the other worker threads run meanwhile (bytes() would hold the interpreter lock for the whole memcpy)
             zp, zf = np.array(passed, dtype=np.uint8, copy=True), np.array(failed, dtype=np.uint8, copy=True)
         text_done(fi)
-        return zp, zf, int(info["n_records_out"]), int(info["n_passed"]), cnt, int(info["passed_text_bytes"]), int(info["failed_text_bytes"]), info.get("stats")
+        n_z = len(zp) + len(zf)
+        deliver(fi, ci, zp, zf)
+        return n_z, int(info["n_records_out"]), int(info["n_passed"]), int(info["passed_text_bytes"]), int(info["failed_text_bytes"]), info.get("stats")
 
     results = list(pool.map(lambda j: with_lane(p2)(j), range(len(chunks))))
     t_pass2 = time.perf_counter() - t0
-    # ---- files -----------------------------------------------------------------------------------------------------------------------------
+    # ---- files of inputs without a record (no chunk): empty outputs, as the reference's writer threads leave them -------------------------
     t0 = time.perf_counter()
-    counts = np.zeros((k.size, 3), dtype=np.int64)
-    ext = ".fastq.gz" if compress else ".fastq"
-    by_file = {}
-    for (fi, ci, _), res in zip(chunks, results):
-        by_file.setdefault(fi, []).append(res)
-        counts += res[4]
-
-    def write_file(fi):
-        base = files[fi]
-        for suf in (".gz", ".fastq", ".fq"):
-            if base.endswith(suf):
-                base = base[:-len(suf)]
-        with open(os.path.join(out_dir, "passed", base + "_passed" + ext), "wb") as fp, open(os.path.join(out_dir, "failed", base + "_failed" + ext), "wb") as ff:
-            for res in by_file.get(fi, []):
-                fp.write(res[0])
-                ff.write(res[1])
-
-    list(pool.map(write_file, range(len(files))))
+    for fi in range(len(files)):
+        if fi not in out_state:
+            for nm in out_names(fi):
+                open(nm, "wb").close()
     stats = np.zeros(_lib.N_SCAN_STATS, dtype=np.uint64)
     for res in results:
-        if res[7] is not None:
-            stats += res[7]
+        if res[5] is not None:
+            stats += res[5]
     if multi:  # the counters behind BarcodesAssigned.tsv and the statistics, summed over the ranks
         xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
         t_counts = torch.from_numpy(counts.astype(np.int64)).to(xdev)
@@ -495,8 +520,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             o.close()
     n_reads = int(sum(n_rec))
     wall = time.perf_counter() - t_all
-    return {"rank": rank, "ranks": world, "files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[2] for r_ in results), "passed": sum(r_[3] for r_ in results),
+    return {"rank": rank, "ranks": world, "files": len(files), "chunks": len(chunks), "reads": n_reads, "records_out": sum(r_[1] for r_ in results), "passed": sum(r_[2] for r_ in results),
             "assigned": int(counts.sum()), "used_list": int(k.size), "text_in_bytes": int(sum(rng[1] - rng[0] for _, _, rng in chunks)), "files_inflated_twice": sum(1 for t in texts if t is None), "files_inflated_on_device": n_on_device, "device_inflate_rounds": dev_detail, "text_resident_bytes": int(held[0]),
-            "text_out_bytes": sum(r_[5] + r_[6] for r_ in results), "gz_out_bytes": sum(len(r_[0]) + len(r_[1]) for r_ in results) if compress else None,
+            "text_out_bytes": sum(r_[3] + r_[4] for r_ in results), "gz_out_bytes": sum(r_[0] for r_ in results) if compress else None,
             "wall_s": wall, "reads_per_s": n_reads / wall, "inflate_and_pass1_s": t_pass1, "inflate_thread_seconds": t_inflate, "finalize_s": t_finalize, "pass2_and_gzip_s": t_pass2,
             "write_files_s": t_write, "workers": n_workers, "gz": (gz if compress else None), "gz_level": gz_level if compress and not on_device else None}
