@@ -1,4 +1,5 @@
-// smi_cluster.hip -- host-side UMI clustering of `assignumis` on the K-UMI distance matrices (no device code here).
+// smi_cluster.hip -- UMI clustering of `assignumis` on the K-UMI distance matrices: the host clusterers, and ClusterOne_MyClustering for
+// groups above 100 reads with its n^2 loops on the device (umi_cluster_own_device below).
 //
 // Reference units (bytecode; citation form in DESIGN.md; AL! = Jar/lib/lingpipe-4.1.2-JL1.0.jar):
 //   UmiClustering$Submitter.lambda$run$2            FJ!umifinder/analyzers/clustering/UmiClustering$Submitter.java:L239-261
@@ -418,6 +419,389 @@ extern "C" int smi_umi_cluster_default_config(smi_umi_cluster_config *cfg) {
     cfg->own_clusterer_above = 100;   // UmiClustering.java:L52
     return SMI_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// ClusterOne_MyClustering for a group above 100 reads with the matrix left in HBM (round 4).
+//
+// What is n^2 in it runs on the device over the matrix K-UMI left there: the neighbour counts, the owner arg-max, the squared-distance
+// sums of the centre choice, the least distance to a read outside the cluster (tag U2).  What is O(n) and order-bound stays on the
+// host between the launches: the fastutil iteration orders (a simulation of the table's insert / rehash history, sequential by
+// nature), the grouping by owner, the fold-depth rule, the ejection of members off their centre.  A few thousand bytes cross the link
+// per step instead of the n^2-byte matrix (64 MB for 8,000 reads) -- and the host's sixteen threads no longer walk it.
+// Every rule is the one of cluster_one() above; the two are compared on the same groups (tests/test_umi_stage_gpu.py).
+// ---------------------------------------------------------------------------------------------------------------
+#define SMI_OWN_RC(call)              \
+    do {                              \
+        const int rc__ = (call);      \
+        if (rc__ != SMI_OK) return rc__; \
+    } while (0)
+
+namespace smi {
+namespace {
+
+// count[i] = how many b of idx[0 .. n_idx) have ed(idx[i], b) <= ced (the read itself included: ed = 0).  One wave per row.
+__global__ __launch_bounds__(256) void k_umi_own_count(const uint8_t *__restrict__ m, int n, const int *__restrict__ idx, int n_idx, int ced,
+                                                       int *__restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < n_idx; i += n_waves) {
+        const uint8_t *row = m + (size_t)(idx ? idx[i] : i) * n;
+        int c = 0;
+        if (!idx) {  // every read of the group: the row as it lies, eight cells per load (a byte per lane and round trip is latency, not bandwidth)
+            for (int k = 8 * lane; k < n_idx; k += 512) {
+                if (k + 8 <= n_idx) {
+                    uint64_t v;
+                    __builtin_memcpy(&v, row + k, 8);
+#pragma unroll
+                    for (int b = 0; b < 8; b++) c += (int)((v >> (8 * b)) & 15u) <= ced ? 1 : 0;
+                } else
+                    for (int b = k; b < n_idx; b++) c += (row[b] & 15) <= ced ? 1 : 0;
+            }
+        } else {
+#pragma unroll 4
+            for (int k = lane; k < n_idx; k += 64) c += (row[idx[k]] & 15) <= ced ? 1 : 0;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+        if (lane == 0) count[i] = c;
+    }
+}
+
+// owner[i] for key i (keys in fastutil iteration order `ord`, their counts in cnt): the first a in that order with ed(a, key) <= ced and the
+// largest count (Stream.max keeps the first of equals).  One wave per key; the row of the key is read (ed is symmetric).
+__global__ __launch_bounds__(256) void k_umi_own_owner(const uint8_t *__restrict__ m, int n, const int *__restrict__ ord, const int *__restrict__ cnt,
+                                                       int n_keys, int ced, int *__restrict__ owner) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < n_keys; i += n_waves) {
+        const uint8_t *row = m + (size_t)ord[i] * n;
+        long long best = -1;  // count << 32 | (0x7FFFFFFF - position): larger = better count, then earlier position
+#pragma unroll 4
+        for (int p = lane; p < n_keys; p += 64)
+            if ((row[ord[p]] & 15) <= ced) {
+                const long long v = ((long long)cnt[p] << 32) | (long long)(0x7FFFFFFF - p);
+                best = v > best ? v : best;
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long y = __shfl_xor(best, o);
+            best = y > best ? y : best;
+        }
+        if (lane == 0) owner[i] = best < 0 ? -1 : ord[0x7FFFFFFF - (int)(best & 0x7FFFFFFFLL)];
+    }
+}
+
+// tot[i] = sum over the members w != s of ed(s, w)^2 for member i of its cluster (members listed cluster after cluster; c_off the offsets)
+__global__ __launch_bounds__(256) void k_umi_own_sums(const uint8_t *__restrict__ m, int n, const int *__restrict__ mem, const int *__restrict__ c_of,
+                                                      const int *__restrict__ c_off, int n_mem, long long *__restrict__ tot) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < n_mem; i += n_waves) {
+        const int c = c_of[i], s = mem[i];
+        const uint8_t *row = m + (size_t)s * n;
+        long long t = 0;
+#pragma unroll 4
+        for (int k = c_off[c] + lane; k < c_off[c + 1]; k += 64) {
+            const int w = mem[k];
+            const int e = row[w] & 15;
+            if (w != s) t += (long long)(e * e);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) tot[i] = t;
+    }
+}
+
+// cell[i] = matrix byte (a[i], b[i])
+__global__ void k_umi_own_gather(const uint8_t *__restrict__ m, int n, const int *__restrict__ a, const int *__restrict__ b, int k, uint8_t *__restrict__ cell) {
+    const int i = (int)(blockIdx.x * (size_t)blockDim.x + threadIdx.x);
+    if (i < k) cell[i] = m[(size_t)a[i] * n + b[i]];
+}
+
+// tags of the reads in `who` (ClusterOneBase.setSamflagsAndStatsForClustered): centre, offset, ed / pos2 to the centre, and the least distance to
+// a read outside the read's cluster (cid[m] != its own; -1 when there is one cluster only).  One wave per read.
+__global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict__ m, int n, const int *__restrict__ who, int n_who, const int *__restrict__ cid,
+                                                      const int *__restrict__ center, const int *__restrict__ offset, int n_clusters,
+                                                      smi_umi_assignment *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int i = wave; i < n_who; i += n_waves) {
+        const int idx = who[i], c = cid[idx];
+        const uint8_t *row = m + (size_t)idx * n;
+        int sec = 127;
+        if (n_clusters > 1)
+            for (int k = 8 * lane; k < n; k += 512) {
+                if (k + 8 <= n) {
+                    uint64_t v;
+                    __builtin_memcpy(&v, row + k, 8);
+                    int id[8];
+                    __builtin_memcpy(id, cid + k, 32);
+#pragma unroll
+                    for (int b = 0; b < 8; b++)
+                        if (id[b] != c) sec = min(sec, (int)((v >> (8 * b)) & 15u));
+                } else
+                    for (int b = k; b < n; b++)
+                        if (cid[b] != c) sec = min(sec, (int)(row[b] & 15));
+            }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sec = min(sec, __shfl_xor(sec, o));
+        if (lane == 0) {
+            const uint8_t cell = m[(size_t)center[c] * n + idx];
+            smi_umi_assignment a;
+            a.center = center[c];
+            a.offset = (int8_t)offset[c];
+            a.ed = (int8_t)(cell & 15);
+            a.ed_second = (int8_t)(n_clusters > 1 && sec != 127 ? sec : -1);
+            a.pos2 = (int8_t)((cell >> 6) & 3);
+            out[idx] = a;
+        }
+    }
+}
+
+struct OwnScratch {  // device scratch of one call, carved out of a grow-only buffer of the context
+    int *i0 = nullptr, *i1 = nullptr, *i2 = nullptr, *i3 = nullptr;
+    long long *l0 = nullptr;
+    uint8_t *b0 = nullptr;
+};
+
+}  // namespace
+
+int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const float *d_qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *d_out,
+                           uint8_t *d_skipped, hipStream_t s) {
+    const int ced = cfg.complete_link_ed;
+    OwnScratch S;
+    {
+        const size_t words = (size_t)n + 64;   // per array, padded
+        const size_t need = words * (4 * 4 + 8 + 1) + 256;
+        if (ctx->umi_own_bytes < need) {
+            if (ctx->umi_own) (void)hipFree(ctx->umi_own);
+            ctx->umi_own = nullptr;
+            ctx->umi_own_bytes = 0;
+            SMI_HIP(hipMalloc(&ctx->umi_own, need + need / 2));
+            ctx->umi_own_bytes = need + need / 2;
+        }
+        char *p = static_cast<char *>(ctx->umi_own);
+        S.l0 = reinterpret_cast<long long *>(p);
+        p += words * 8;
+        S.i0 = reinterpret_cast<int *>(p);
+        S.i1 = S.i0 + words;
+        S.i2 = S.i1 + words;
+        S.i3 = S.i2 + words;
+        S.b0 = reinterpret_cast<uint8_t *>(S.i3 + words);
+    }
+    const unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 3) / 4, 256 * 16);
+    std::vector<smi_umi_assignment> none((size_t)n, smi_umi_assignment{-1, 0, -1, -1, 0});
+    SMI_HIP(hipMemcpyAsync(d_out, none.data(), (size_t)n * sizeof(smi_umi_assignment), hipMemcpyHostToDevice, s));
+    float qv01[2] = {0.0f, 0.0f};
+    SMI_HIP(hipMemcpyAsync(qv01, d_qv, (n >= 2 ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, s));
+    std::vector<char> skipped((size_t)n, 0);
+
+    // clusterLocal (L175-219) over `indices` (ascending): owner key of every index that is a key, -1 otherwise
+    auto cluster_local_dev = [&](const std::vector<int> &indices, std::vector<int> &owner) -> int {
+        owner.assign((size_t)n, -1);
+        const int k = (int)indices.size();
+        if (k == 0) return SMI_OK;
+        std::vector<int> count((size_t)k);
+        const bool identity = k == n;   // (indices are ascending and distinct: all n of them = 0 .. n-1)
+        if (!identity) SMI_HIP(hipMemcpyAsync(S.i0, indices.data(), (size_t)k * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_own_count, dim3(grid), dim3(256), 0, s, d_mat, n, identity ? (const int *)nullptr : S.i0, k, ced, S.i1);
+        SMI_HIP(hipMemcpyAsync(count.data(), S.i1, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        std::vector<int> keys, cnt_of((size_t)n, 0);
+        for (int i = 0; i < k; i++) {
+            cnt_of[(size_t)indices[(size_t)i]] = count[(size_t)i];
+            if (count[(size_t)i] > 1) keys.push_back(indices[(size_t)i]);
+        }
+        if (keys.empty()) return SMI_OK;
+        const std::vector<int> ord = fastutil_order(keys);
+        std::vector<int> cnt_ord(ord.size()), own(ord.size());
+        for (size_t i = 0; i < ord.size(); i++) cnt_ord[i] = cnt_of[(size_t)ord[i]];
+        SMI_HIP(hipMemcpyAsync(S.i0, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i1, cnt_ord.data(), ord.size() * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_own_owner, dim3(grid), dim3(256), 0, s, d_mat, n, S.i0, S.i1, (int)ord.size(), ced, S.i2);
+        SMI_HIP(hipMemcpyAsync(own.data(), S.i2, ord.size() * 4, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < ord.size(); i++) owner[(size_t)ord[i]] = own[i];
+        return SMI_OK;
+    };
+    auto group_by_owner = [&](const std::vector<int> &owner, const std::vector<int> &indices) {
+        std::map<int, size_t> slot;  // owner -> cluster, clusters listed by their smallest member
+        std::vector<Cluster> cl;
+        for (int i : indices) {
+            if (owner[(size_t)i] < 0) continue;
+            auto it = slot.find(owner[(size_t)i]);
+            if (it == slot.end()) {
+                slot[owner[(size_t)i]] = cl.size();
+                cl.emplace_back();
+                it = slot.find(owner[(size_t)i]);
+            }
+            cl[it->second].members.push_back(i);
+        }
+        return cl;
+    };
+    // setClusterCenterNotPreGrouped (OneUmiCluster.java:L49-65) for the clusters `which` of `cl`: one launch for all of them
+    auto centers_dev = [&](std::vector<Cluster> &cl, const std::vector<size_t> &which) -> int {
+        std::vector<int> mem, c_of, c_off{0};
+        std::vector<std::vector<int>> ords;
+        for (size_t w = 0; w < which.size(); w++) {
+            ords.push_back(fastutil_order(cl[which[w]].members));
+            for (int v : ords.back()) {
+                mem.push_back(v);
+                c_of.push_back((int)w);
+            }
+            c_off.push_back((int)mem.size());
+        }
+        if (mem.empty()) return SMI_OK;
+        std::vector<long long> tot(mem.size());
+        SMI_HIP(hipMemcpyAsync(S.i0, mem.data(), mem.size() * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i1, c_of.data(), c_of.size() * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i2, c_off.data(), c_off.size() * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_own_sums, dim3(grid), dim3(256), 0, s, d_mat, n, S.i0, S.i1, S.i2, (int)mem.size(), S.l0);
+        SMI_HIP(hipMemcpyAsync(tot.data(), S.l0, mem.size() * 8, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        for (size_t w = 0; w < which.size(); w++) {
+            const std::vector<int> &ord = ords[w];
+            Cluster &c = cl[which[w]];
+            if (ord.size() == 1)
+                c.center = ord[0];
+            else if (ord.size() == 2)
+                c.center = qv01[0] > qv01[1] ? ord[0] : ord[1];  // reads 0 and 1 of the GROUP (OneUmiCluster.java:L53)
+            else {
+                long long best = -1;
+                c.center = ord[0];
+                for (size_t i = 0; i < ord.size(); i++) {
+                    const long long t = tot[(size_t)c_off[w] + i];
+                    if (best < 0 || t < best) {  // the first minimum in iteration order
+                        best = t;
+                        c.center = ord[i];
+                    }
+                }
+            }
+        }
+        return SMI_OK;
+    };
+    // matrix cells (centre of its cluster, member) for every member of the clusters `which`
+    auto cells_to_center = [&](const std::vector<Cluster> &cl, const std::vector<size_t> &which, std::vector<std::vector<uint8_t>> &cells) -> int {
+        std::vector<int> a, b;
+        for (size_t w : which)
+            for (int v : cl[w].members) {
+                a.push_back(cl[w].center);
+                b.push_back(v);
+            }
+        cells.assign(which.size(), {});
+        if (a.empty()) return SMI_OK;
+        std::vector<uint8_t> flat(a.size());
+        SMI_HIP(hipMemcpyAsync(S.i0, a.data(), a.size() * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i1, b.data(), b.size() * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_own_gather, dim3((unsigned)((a.size() + 255) / 256)), dim3(256), 0, s, d_mat, n, S.i0, S.i1, (int)a.size(), S.b0);
+        SMI_HIP(hipMemcpyAsync(flat.data(), S.b0, a.size(), hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        size_t at = 0;
+        for (size_t k = 0; k < which.size(); k++) {
+            cells[k].assign(flat.begin() + (long)at, flat.begin() + (long)(at + cl[which[k]].members.size()));
+            at += cl[which[k]].members.size();
+        }
+        return SMI_OK;
+    };
+
+    std::vector<int> all((size_t)n), owner;
+    for (int i = 0; i < n; i++) all[(size_t)i] = i;
+    SMI_OWN_RC(cluster_local_dev(all, owner));
+    std::vector<Cluster> first = group_by_owner(owner, all), kept;
+    size_t mx = 0;
+    for (auto &c : first) mx = std::max(mx, c.members.size());
+    std::vector<char> clustered((size_t)n, 0);
+    for (auto &c : first) {
+        if (c.members.size() * (size_t)cfg.fold_depth_below_max > mx) {
+            for (int v : c.members) clustered[(size_t)v] = 1;
+            kept.push_back(c);
+        } else
+            for (int v : c.members) skipped[(size_t)v] = 1;
+    }
+    std::vector<size_t> every(kept.size());
+    for (size_t k = 0; k < kept.size(); k++) every[k] = k;
+    SMI_OWN_RC(centers_dev(kept, every));
+    std::vector<int> unclustered;
+    for (int i = 0; i < n; i++)
+        if (!clustered[(size_t)i]) unclustered.push_back(i);
+    // removeOffCenter (L90-100): members farther than ced from their centre leave; a cluster that lost some gets a new centre
+    std::vector<std::vector<uint8_t>> cells;
+    SMI_OWN_RC(cells_to_center(kept, every, cells));
+    size_t n_removed = 0;
+    std::vector<size_t> changed;
+    for (size_t k = 0; k < kept.size(); k++) {
+        std::vector<int> stay;
+        for (size_t i = 0; i < kept[k].members.size(); i++) {
+            if ((cells[k][i] & 15) > ced) {
+                unclustered.push_back(kept[k].members[i]);
+                n_removed++;
+            } else
+                stay.push_back(kept[k].members[i]);
+        }
+        if (stay.size() != kept[k].members.size()) {
+            kept[k].members = stay;
+            changed.push_back(k);
+        }
+    }
+    if (!changed.empty()) SMI_OWN_RC(centers_dev(kept, changed));
+    if (n_removed > 0) {  // L102-112: the ejected and the unclustered reads once more
+        std::sort(unclustered.begin(), unclustered.end());
+        SMI_OWN_RC(cluster_local_dev(unclustered, owner));
+        std::vector<Cluster> more = group_by_owner(owner, unclustered);
+        std::vector<size_t> fresh;
+        for (auto &c : more)
+            if (c.members.size() > 1) {
+                fresh.push_back(kept.size());
+                kept.push_back(c);
+            }
+        if (!fresh.empty()) SMI_OWN_RC(centers_dev(kept, fresh));
+    }
+    // tags: the members within ced of the (final) centre, if more than one is left (L131-160)
+    std::vector<size_t> tagged;
+    for (size_t k = 0; k < kept.size(); k++)
+        if (kept[k].members.size() > 1) tagged.push_back(k);
+    SMI_OWN_RC(cells_to_center(kept, tagged, cells));
+    std::vector<int> who, cid((size_t)n, -1), center(kept.size(), 0), offset(kept.size(), 0);
+    for (size_t t = 0; t < tagged.size(); t++) {
+        const Cluster &c = kept[tagged[t]];
+        std::vector<int> filt;
+        long sum = 0;
+        int cnt = 0;
+        for (size_t i = 0; i < c.members.size(); i++) {
+            const int v = c.members[i];
+            if ((cells[t][i] & 15) <= ced) filt.push_back(v);
+            if (v != c.center) {  // offset over ALL members of the cluster (tag_members), pos1 of the cell (centre, member)
+                sum += ((cells[t][i] >> 4) & 3) - 1;
+                cnt++;
+            }
+        }
+        if (filt.size() <= 1) continue;
+        for (int v : c.members) cid[(size_t)v] = (int)tagged[t];
+        center[tagged[t]] = c.center;
+        offset[tagged[t]] = (int)std::floor((double)sum / (double)cnt + 0.5);  // (int) Math.round(double)
+        for (int v : filt)
+            if (!skipped[(size_t)v]) who.push_back(v);
+    }
+    // `inside` of tag_members is the cluster's member list whether it is tagged or not: clusters that stay untagged still count as "inside"
+    // for nobody, so only the tagged clusters' members carry an id; reads of untagged clusters are "outside" for everybody, as on the host
+    if (!who.empty()) {
+        SMI_HIP(hipMemcpyAsync(S.i0, who.data(), who.size() * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i1, cid.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i2, center.data(), center.size() * 4, hipMemcpyHostToDevice, s));
+        SMI_HIP(hipMemcpyAsync(S.i3, offset.data(), offset.size() * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_own_tags, dim3(grid), dim3(256), 0, s, d_mat, n, S.i0, (int)who.size(), S.i1, S.i2, S.i3, (int)kept.size(), d_out);
+    }
+    if (d_skipped) {
+        std::vector<uint8_t> sk((size_t)n);
+        for (int i = 0; i < n; i++) sk[(size_t)i] = (uint8_t)skipped[(size_t)i];
+        SMI_HIP(hipMemcpyAsync(d_skipped, sk.data(), (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    SMI_HIP(hipStreamSynchronize(s));
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+}  // namespace smi
 
 extern "C" int smi_umi_cluster_groups(const uint8_t *dist, const uint64_t *mat_off, const uint32_t *group_off,
                                       uint32_t n_groups, const float *mean_qv, const smi_umi_cluster_config *cfg,

@@ -232,6 +232,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->chim_slots);
     (void)hipFree(ctx->chim_work);
     (void)hipFree(ctx->chim_flat);
+    (void)hipFree(ctx->umi_own);
     (void)hipHostFree(ctx->host_out[0]);
     (void)hipHostFree(ctx->host_out[1]);
     for (void *hb : ctx->host_buf) (void)hipHostFree(hb);

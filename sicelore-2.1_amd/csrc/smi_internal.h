@@ -151,6 +151,8 @@ struct smi_ctx {
     size_t chim_slot_bytes = 0;
     void *chim_work = nullptr;     // K-CHIM second generation: per-read heads, the global queue of positions to align, their error counts (grow-only)
     size_t chim_work_bytes = 0;
+    void *umi_own = nullptr;       // ClusterOne_MyClustering on the device: index / count / sum scratch of one large group (grow-only)
+    size_t umi_own_bytes = 0;
     void *chim_flat = nullptr;     // K-CHIM-A second generation: owner of every plane word, gate / bound / trigger words, verdicts (grow-only)
     size_t chim_flat_bytes = 0;
     void *arena = nullptr;         // device memory of the chunk workers (smi_worker.hip), grow-only
@@ -172,6 +174,9 @@ struct smi_ctx {
 };
 
 namespace smi {
+// ClusterOne_MyClustering of one group above 100 reads on the matrix in HBM (smi_cluster.hip)
+int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const float *d_qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *d_out,
+                           uint8_t *d_skipped, hipStream_t s);
 int time_begin(smi_ctx *ctx, int kid, hipStream_t s);
 int time_end(smi_ctx *ctx, int kid, hipStream_t s);
 Pyramid pyramid_of(const smi_ctx *ctx);

@@ -1197,8 +1197,14 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
             std::vector<uint64_t> moff((size_t)n_groups + 1);
             SMI_HIP(hipMemcpyAsync(moff.data(), B.mat_off, ((size_t)n_groups + 1) * 8, hipMemcpyDeviceToHost, s));
             SMI_HIP(hipStreamSynchronize(s));
+            const bool own_on_host = getenv("SMI_AU_OWN_HOST") != nullptr;  // cross-check switch: the host clusterer for every large group
             for (uint32_t g : big) {
                 const uint32_t k = goff[g + 1] - goff[g];
+                if ((int)k > cc.own_clusterer_above && !own_on_host) {
+                    // ClusterOne_MyClustering: its n^2 loops on the device over the matrix where it lies (smi_cluster.hip)
+                    SMI_RC(umi_cluster_own_device(ctx, d_dist + moff[g], (int)k, B.qv + goff[g], cc, d_asg + goff[g], d_skipped + goff[g], s));
+                    continue;
+                }
                 std::vector<uint8_t> mat((size_t)k * k);
                 std::vector<float> qv(k);
                 std::vector<smi_umi_assignment> asg(k);
