@@ -18,6 +18,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_e
 cd "$ROOT"
 f=$(find gpurun_out/prof_e2e -name "*kernel_stats.csv" | head -1)
 (head -1 "$f"; grep "smi::" "$f") > gpurun_out/e2e_kernel_stats.csv
+python3 tools/e2e_timeline.py gpurun_out/prof_e2e gpurun_out/e2e_timeline.json
 find gpurun_out/prof_e2e -name "*.csv" -size +1M -delete
 python3 - <<'PY'
 import csv
@@ -26,3 +27,7 @@ for row in csv.DictReader(open("gpurun_out/e2e_kernel_stats.csv")):
     print(f'{nm:46s} calls {row["Calls"]:>3s} avg {float(row["AverageNs"])/1e6:7.3f} min {float(row["MinNs"])/1e6:7.3f} ms')
 PY
 tail -c 1500 gpurun_out/prof_e2e.log | grep -o '"end_to_end": {.*' | cut -c1-1200
+# the device clusterer of large UMI groups: one 8,000-read group, device against host
+SMI_AU_TIMING=1 timeout -k 10 300 python tools/own_cluster_bench.py 8000 > gpurun_out/own_cluster_8000.json 2> gpurun_out/own_cluster_8000.err; echo "own rc=$?"; cat gpurun_out/own_cluster_8000.json
+# the splitter's microbench line itself (no profiler attached)
+timeout -k 10 300 python tools/microbench.py chimera > gpurun_out/microbench_chimera.json 2> gpurun_out/microbench_chimera.err; echo "mb rc=$?"; cut -c1-600 gpurun_out/microbench_chimera.json
