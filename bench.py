@@ -229,6 +229,8 @@ def roofline_entry(name, key, ms, alg_bytes_per_unit, units, tj):
                  counters_from=e.get("source"), counters_commit=e.get("commit", tj.get("commit")))
     else:
         d.update(achieved=ach_alg, frac=ach_alg / HBM_PEAK_GBS, basis="algorithmic bytes (SURVEY 8d)")
+        if traffic:
+            d.update(counters_from=e.get("source"), counters_commit=e.get("commit", tj.get("commit")))
     vi = e.get("valu_insts_per_launch")
     if vi and e.get("reads_per_launch"):
         vp = valu_peaks()
@@ -1089,6 +1091,8 @@ def main():
         "roofline": dict({"bound": "hbm" if dom is f_bc1 else "valu-issue (the HBM figures are what the contract asks for; the binding resource "
                                    "of this kernel is integer VALU issue, in `valu_issue`)"}, **dom,
                          **{"kernels_ms": {"k_scan<10>": k_scan, "k_bc_match_ed1<1>": k_match}, "other": {oth["kernel"]: oth},
+                            "kernel_trace": "profiles/r04/step_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5` with every side "
+                                            "leg off: AverageNs of k_scan<10> is kernel_ms)",
                             "probes_per_s_bc1": 620.0 * n / (k_match * 1e-3)}),
     }
     if two_pass is not None:

@@ -58,14 +58,33 @@ struct Dist {
 };
 
 // iteration order of a fastutil open hash set / map that received `keys` in ascending order
-std::vector<int> fastutil_order(std::vector<int> keys) {
-    std::sort(keys.begin(), keys.end());
+std::vector<int> fastutil_order(const std::vector<int> &keys_in) {
+    std::vector<int> sorted_copy;
+    if (!std::is_sorted(keys_in.begin(), keys_in.end())) {
+        sorted_copy = keys_in;
+        std::sort(sorted_copy.begin(), sorted_copy.end());
+    }
+    const std::vector<int> &keys = sorted_copy.empty() ? keys_in : sorted_copy;
     auto mix = [](uint32_t x) {
         const uint32_t h = x * 0x9E3779B9u;
         return h ^ (h >> 16);
     };
-    size_t n = 32;
-    std::vector<int> tab(n + 1, 0);
+    auto max_fill_of = [](size_t n) { return std::min((size_t)std::ceil(n * 0.75), n - 1); };
+    // the tables of a rehash are kept by the thread: a call per cluster of a large group would otherwise allocate them every time
+    static thread_local std::vector<int> tab_v, nt_v, live_v;
+    // The entries of a table in descending slot order, without a branch per slot: whether a slot is taken is a coin toss to the predictor
+    // (the table is 40 - 75 % full), and that misprediction per slot -- not the probing -- was most of the time of this function.
+    auto entries_descending = [](const int *t, size_t n, int *dst) -> size_t {
+        size_t w = 0;
+        for (size_t i = n; i-- > 0;) {
+            dst[w] = t[i];
+            w += t[i] != 0;
+        }
+        return w;
+    };
+    size_t n = 32, max_fill = max_fill_of(n);
+    tab_v.assign(n + 1, 0);
+    int *tab = tab_v.data();
     bool zero = false;
     size_t size = 0;
     for (int k : keys) {
@@ -76,27 +95,31 @@ std::vector<int> fastutil_order(std::vector<int> keys) {
             while (tab[pos] != 0) pos = (pos + 1) & (n - 1);
             tab[pos] = k;
         }
-        const size_t max_fill = std::min((size_t)std::ceil(n * 0.75), n - 1);
         if (size++ >= max_fill) {
             const size_t need = (size_t)std::ceil((size + 1) / 0.75);
             size_t nn = 2;
             while (nn < need) nn <<= 1;
-            std::vector<int> nt(nn + 1, 0);
-            for (size_t i = n; i-- > 0;) {  // entries move in descending slot order
-                if (tab[i] == 0) continue;
-                size_t pos = mix((uint32_t)tab[i]) & (nn - 1);
+            nt_v.assign(nn + 1, 0);
+            int *nt = nt_v.data();
+            live_v.resize(n + 1);
+            const size_t n_live = entries_descending(tab, n, live_v.data());
+            for (size_t i = 0; i < n_live; i++) {  // entries move in descending slot order
+                const int k2 = live_v[i];
+                size_t pos = mix((uint32_t)k2) & (nn - 1);
                 while (nt[pos] != 0) pos = (pos + 1) & (nn - 1);
-                nt[pos] = tab[i];
+                nt[pos] = k2;
             }
-            tab.swap(nt);
+            tab_v.swap(nt_v);
+            tab = tab_v.data();
             n = nn;
+            max_fill = max_fill_of(n);
         }
     }
-    std::vector<int> out;
-    out.reserve(keys.size());
-    if (zero) out.push_back(0);
-    for (size_t pos = n; pos-- > 0;)
-        if (tab[pos] != 0) out.push_back(tab[pos]);
+    std::vector<int> out(n + 2);
+    const size_t z = zero ? 1 : 0;
+    if (zero) out[0] = 0;
+    const size_t n_out = entries_descending(tab, n, out.data() + z);
+    out.resize(z + n_out);
     return out;
 }
 
@@ -439,9 +462,11 @@ extern "C" int smi_umi_cluster_default_config(smi_umi_cluster_config *cfg) {
 namespace smi {
 namespace {
 
-// count[i] = how many b of idx[0 .. n_idx) have ed(idx[i], b) <= ced (the read itself included: ed = 0).  One wave per row.
+// count[i] = how many b of idx[0 .. n_idx) have ed(idx[i], b) <= ced (the read itself included: ed = 0).  One wave per row.  `init` (first
+// call of a group): the row's assignment record starts as "not clustered", its cluster number as -1, its tag flag as 0.
 __global__ __launch_bounds__(256) void k_umi_own_count(const uint8_t *__restrict__ m, int n, const int *__restrict__ idx, int n_idx, int ced,
-                                                       int *__restrict__ count) {
+                                                       int *__restrict__ count, smi_umi_assignment *__restrict__ init, int *__restrict__ init_cid,
+                                                       uint8_t *__restrict__ init_flag) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
     for (int i = wave; i < n_idx; i += n_waves) {
@@ -463,25 +488,46 @@ __global__ __launch_bounds__(256) void k_umi_own_count(const uint8_t *__restrict
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-        if (lane == 0) count[i] = c;
+        if (lane == 0) {
+            count[i] = c;
+            if (init) {
+                init[i] = smi_umi_assignment{-1, 0, -1, -1, 0};
+                init_cid[i] = -1;
+                init_flag[i] = 0;
+            }
+        }
     }
 }
 
-// owner[i] for key i (keys in fastutil iteration order `ord`, their counts in cnt): the first a in that order with ed(a, key) <= ced and the
-// largest count (Stream.max keeps the first of equals).  One wave per key; the row of the key is read (ed is symmetric).
-__global__ __launch_bounds__(256) void k_umi_own_owner(const uint8_t *__restrict__ m, int n, const int *__restrict__ ord, const int *__restrict__ cnt,
+// owner[i] for key ord[i] (keys in fastutil iteration order): the first a in that order with ed(a, key) <= ced and the largest count
+// (Stream.max keeps the first of equals).  The candidates are looked at in COLUMN order -- the key's row as it lies, eight cells per load --
+// with rc[b] = {position of read b in the iteration order or -1 when b is no key, its count}: the arg-max over (count, -position) does not
+// care in which order it sees them.  (Walking the positions and gathering row[ord[p]] was 0.58 ms for 8,000 keys: a byte per lane from a
+// random place of the row.)  One wave per key; ed is symmetric.
+__global__ __launch_bounds__(256) void k_umi_own_owner(const uint8_t *__restrict__ m, int n, const int *__restrict__ ord, const int2 *__restrict__ rc,
                                                        int n_keys, int ced, int *__restrict__ owner) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
     for (int i = wave; i < n_keys; i += n_waves) {
         const uint8_t *row = m + (size_t)ord[i] * n;
         long long best = -1;  // count << 32 | (0x7FFFFFFF - position): larger = better count, then earlier position
-#pragma unroll 4
-        for (int p = lane; p < n_keys; p += 64)
-            if ((row[ord[p]] & 15) <= ced) {
-                const long long v = ((long long)cnt[p] << 32) | (long long)(0x7FFFFFFF - p);
+        auto look = [&](int b, int e) {
+            if (e > ced) return;  // (a row has a handful of cells within ced: rc is read for those only)
+            const int2 x = rc[b];
+            if (x.x >= 0) {
+                const long long v = ((long long)x.y << 32) | (long long)(0x7FFFFFFF - x.x);
                 best = v > best ? v : best;
             }
+        };
+        for (int k = 8 * lane; k < n; k += 512) {
+            if (k + 8 <= n) {
+                uint64_t v;
+                __builtin_memcpy(&v, row + k, 8);
+#pragma unroll
+                for (int b = 0; b < 8; b++) look(k + b, (int)((v >> (8 * b)) & 15u));
+            } else
+                for (int b = k; b < n; b++) look(b, row[b] & 15);
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const long long y = __shfl_xor(best, o);
@@ -512,21 +558,95 @@ __global__ __launch_bounds__(256) void k_umi_own_sums(const uint8_t *__restrict_
     }
 }
 
-// cell[i] = matrix byte (a[i], b[i])
-__global__ void k_umi_own_gather(const uint8_t *__restrict__ m, int n, const int *__restrict__ a, const int *__restrict__ b, int k, uint8_t *__restrict__ cell) {
-    const int i = (int)(blockIdx.x * (size_t)blockDim.x + threadIdx.x);
-    if (i < k) cell[i] = m[(size_t)a[i] * n + b[i]];
+// setClusterCenterNotPreGrouped (OneUmiCluster.java:L49-65) for the listed clusters (members in fastutil iteration order): one member: itself;
+// two: by the quality of reads 0 and 1 of the GROUP (L53); else the first minimum of tot in list order.  center[gid[c]] is written: the
+// device keeps the centre of every cluster of the call under its number.  One wave per cluster.
+__global__ __launch_bounds__(256) void k_umi_own_pick(const long long *__restrict__ tot, const int *__restrict__ mem, const int *__restrict__ c_off,
+                                                      const int *__restrict__ gid, int n_cl, const float *__restrict__ qv, int n,
+                                                      int *__restrict__ center) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int c = wave; c < n_cl; c += n_waves) {
+        const int a = c_off[c], b = c_off[c + 1], sz = b - a;
+        if (sz <= 0) continue;
+        int ctr;
+        if (sz == 1)
+            ctr = mem[a];
+        else if (sz == 2)
+            ctr = (n >= 2 && qv[0] > qv[1]) ? mem[a] : mem[a + 1];
+        else {
+            unsigned long long best = ~0ull;  // tot << 32 | position: smallest total, then the earliest position
+            for (int k = a + lane; k < b; k += 64) {
+                const unsigned long long v = ((unsigned long long)tot[k] << 32) | (unsigned)(k - a);
+                best = v < best ? v : best;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long y = __shfl_xor(best, o);
+                best = y < best ? y : best;
+            }
+            ctr = mem[a + (int)(best & 0xFFFFFFFFull)];
+        }
+        if (lane == 0) center[gid[c]] = ctr;
+    }
 }
 
-// tags of the reads in `who` (ClusterOneBase.setSamflagsAndStatsForClustered): centre, offset, ed / pos2 to the centre, and the least distance to
+// cell[i] = matrix byte (centre of member i's cluster, member i)
+__global__ void k_umi_own_cells(const uint8_t *__restrict__ m, int n, const int *__restrict__ mem, const int *__restrict__ c_of, const int *__restrict__ gid,
+                                const int *__restrict__ center, int n_mem, uint8_t *__restrict__ cell) {
+    const int i = (int)(blockIdx.x * (size_t)blockDim.x + threadIdx.x);
+    if (i < n_mem) cell[i] = m[(size_t)center[gid[c_of[i]]] * n + mem[i]];
+}
+
+// What the host clusterer's last loop decides per cluster with more than one member (cluster_one / tag_members): the members within ced of
+// the (final) centre are tagged if there is more than one of them; the offset is the rounded mean of pos1 - 1 over ALL members but the centre.
+// A tagged cluster's members carry its number in cid (everybody else keeps -1: "outside" for every read), flag marks the reads that get tags.
+// One wave per cluster.
+__global__ __launch_bounds__(256) void k_umi_own_decide(const uint8_t *__restrict__ m, int n, const int *__restrict__ mem, const int *__restrict__ c_off,
+                                                        const int *__restrict__ gid, int n_cl, const int *__restrict__ center, int ced,
+                                                        const uint8_t *__restrict__ skipped, int *__restrict__ cid, int *__restrict__ offset,
+                                                        uint8_t *__restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
+    for (int c = wave; c < n_cl; c += n_waves) {
+        const int a = c_off[c], b = c_off[c + 1], g = gid[c], ctr = center[g];
+        const uint8_t *row = m + (size_t)ctr * n;
+        int sum = 0, cnt = 0, filt = 0;
+        for (int k = a + lane; k < b; k += 64) {
+            const int v = mem[k];
+            const int cell = row[v];
+            filt += (cell & 15) <= ced ? 1 : 0;
+            if (v != ctr) {
+                sum += ((cell >> 4) & 3) - 1;
+                cnt++;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            sum += __shfl_xor(sum, o);
+            cnt += __shfl_xor(cnt, o);
+            filt += __shfl_xor(filt, o);
+        }
+        if (filt <= 1) continue;  // (wave-uniform)
+        if (lane == 0) offset[g] = (int)floor((double)sum / (double)cnt + 0.5);  // (int) Math.round(double)
+        for (int k = a + lane; k < b; k += 64) {
+            const int v = mem[k];
+            cid[v] = g;
+            flag[v] = ((row[v] & 15) <= ced && !skipped[v]) ? 1 : 0;
+        }
+    }
+}
+
+// tags of the flagged reads (ClusterOneBase.setSamflagsAndStatsForClustered): centre, offset, ed / pos2 to the centre, and the least distance to
 // a read outside the read's cluster (cid[m] != its own; -1 when there is one cluster only).  One wave per read.
-__global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict__ m, int n, const int *__restrict__ who, int n_who, const int *__restrict__ cid,
+__global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict__ m, int n, const uint8_t *__restrict__ flag, const int *__restrict__ cid,
                                                       const int *__restrict__ center, const int *__restrict__ offset, int n_clusters,
                                                       smi_umi_assignment *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
-    for (int i = wave; i < n_who; i += n_waves) {
-        const int idx = who[i], c = cid[idx];
+    for (int idx = wave; idx < n; idx += n_waves) {
+        if (!flag[idx]) continue;
+        const int c = cid[idx];
         const uint8_t *row = m + (size_t)idx * n;
         int sec = 127;
         if (n_clusters > 1)
@@ -558,10 +678,27 @@ __global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict_
     }
 }
 
-struct OwnScratch {  // device scratch of one call, carved out of a grow-only buffer of the context
-    int *i0 = nullptr, *i1 = nullptr, *i2 = nullptr, *i3 = nullptr;
-    long long *l0 = nullptr;
-    uint8_t *b0 = nullptr;
+// bump allocator over one buffer (device scratch / pinned host memory): every step of a call takes fresh room, so nothing that a queued
+// copy or kernel still reads is written again
+struct Arena {
+    char *p = nullptr;
+    size_t cap = 0, at = 0;
+    char *take(size_t bytes) {
+        at = (at + 63) & ~(size_t)63;
+        char *r = p + at;
+        at += bytes;
+        return at <= cap ? r : nullptr;
+    }
+};
+
+// the arrays one step sends up, side by side in pinned memory and at the same offsets on the device: one copy per step
+struct UpBlock {
+    char *h = nullptr, *d = nullptr;
+    size_t bytes = 0;
+    template <class T>
+    T *host(size_t off) const { return reinterpret_cast<T *>(h + off); }
+    template <class T>
+    T *dev(size_t off) const { return reinterpret_cast<T *>(d + off); }
 };
 
 }  // namespace
@@ -569,144 +706,184 @@ struct OwnScratch {  // device scratch of one call, carved out of a grow-only bu
 int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const float *d_qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *d_out,
                            uint8_t *d_skipped, hipStream_t s) {
     const int ced = cfg.complete_link_ed;
-    OwnScratch S;
-    {
-        const size_t words = (size_t)n + 64;   // per array, padded
-        const size_t need = words * (4 * 4 + 8 + 1) + 256;
-        if (ctx->umi_own_bytes < need) {
-            if (ctx->umi_own) (void)hipFree(ctx->umi_own);
-            ctx->umi_own = nullptr;
-            ctx->umi_own_bytes = 0;
-            SMI_HIP(hipMalloc(&ctx->umi_own, need + need / 2));
-            ctx->umi_own_bytes = need + need / 2;
-        }
-        char *p = static_cast<char *>(ctx->umi_own);
-        S.l0 = reinterpret_cast<long long *>(p);
-        p += words * 8;
-        S.i0 = reinterpret_cast<int *>(p);
-        S.i1 = S.i0 + words;
-        S.i2 = S.i1 + words;
-        S.i3 = S.i2 + words;
-        S.b0 = reinterpret_cast<uint8_t *>(S.i3 + words);
+    // Room: every array of a step has at most n + 2 entries of at most 8 bytes, and a call takes fewer than 48 of them on either side.
+    const size_t room = 48 * ((size_t)n + 64) * 8;
+    if (ctx->umi_own_bytes < room) {
+        if (ctx->umi_own) (void)hipFree(ctx->umi_own);
+        ctx->umi_own = nullptr;
+        ctx->umi_own_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->umi_own, room + room / 4));
+        ctx->umi_own_bytes = room + room / 4;
     }
+    SMI_OWN_RC(ensure_host_buf(ctx, smi_ctx::HB_OWN, room));
+    Arena D{static_cast<char *>(ctx->umi_own), room, 0}, H{static_cast<char *>(ctx->host_buf[smi_ctx::HB_OWN]), room, 0};
+    bool short_of_room = false;
+    auto up = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    auto block = [&](size_t bytes) {
+        UpBlock B;
+        B.h = H.take(bytes);
+        B.d = D.take(bytes);
+        B.bytes = bytes;
+        if (!B.h || !B.d) short_of_room = true;
+        return B;
+    };
+    auto dev_only = [&](size_t bytes) {
+        char *r = D.take(bytes);
+        if (!r) short_of_room = true;
+        return r;
+    };
+    auto host_only = [&](size_t bytes) {
+        char *r = H.take(bytes);
+        if (!r) short_of_room = true;
+        return r;
+    };
+#define SMI_OWN_ROOM()                                                               \
+    do {                                                                             \
+        if (short_of_room) {                                                         \
+            set_error("umi_cluster_own_device: scratch accounting (internal error)"); \
+            return SMI_ERR_INVALID;                                                  \
+        }                                                                            \
+    } while (0)
+    static const bool timing = getenv("SMI_AU_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "    own clusterer %-44s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t - t_prev).count());
+        t_prev = t;
+    };
     const unsigned grid = (unsigned)std::min<size_t>(((size_t)n + 3) / 4, 256 * 16);
-    std::vector<smi_umi_assignment> none((size_t)n, smi_umi_assignment{-1, 0, -1, -1, 0});
-    SMI_HIP(hipMemcpyAsync(d_out, none.data(), (size_t)n * sizeof(smi_umi_assignment), hipMemcpyHostToDevice, s));
-    float qv01[2] = {0.0f, 0.0f};
-    SMI_HIP(hipMemcpyAsync(qv01, d_qv, (n >= 2 ? 2 : 1) * sizeof(float), hipMemcpyDeviceToHost, s));
     std::vector<char> skipped((size_t)n, 0);
+    // per cluster number (there are fewer clusters than reads): centre, offset; per read: cluster number, "gets tags"
+    int *d_center = reinterpret_cast<int *>(dev_only(((size_t)n + 1) * 4)), *d_offset = reinterpret_cast<int *>(dev_only(((size_t)n + 1) * 4));
+    int *d_cid = reinterpret_cast<int *>(dev_only(((size_t)n + 8) * 4));
+    uint8_t *d_flag = reinterpret_cast<uint8_t *>(dev_only((size_t)n + 8));
+    SMI_OWN_ROOM();
 
     // clusterLocal (L175-219) over `indices` (ascending): owner key of every index that is a key, -1 otherwise
+    bool first_call = true;
+    std::vector<int> keys;
     auto cluster_local_dev = [&](const std::vector<int> &indices, std::vector<int> &owner) -> int {
         owner.assign((size_t)n, -1);
         const int k = (int)indices.size();
         if (k == 0) return SMI_OK;
-        std::vector<int> count((size_t)k);
         const bool identity = k == n;   // (indices are ascending and distinct: all n of them = 0 .. n-1)
-        if (!identity) SMI_HIP(hipMemcpyAsync(S.i0, indices.data(), (size_t)k * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_own_count, dim3(grid), dim3(256), 0, s, d_mat, n, identity ? (const int *)nullptr : S.i0, k, ced, S.i1);
-        SMI_HIP(hipMemcpyAsync(count.data(), S.i1, (size_t)k * 4, hipMemcpyDeviceToHost, s));
-        SMI_HIP(hipStreamSynchronize(s));
-        std::vector<int> keys, cnt_of((size_t)n, 0);
-        for (int i = 0; i < k; i++) {
-            cnt_of[(size_t)indices[(size_t)i]] = count[(size_t)i];
-            if (count[(size_t)i] > 1) keys.push_back(indices[(size_t)i]);
+        const int *d_idx = nullptr;
+        if (!identity) {
+            const UpBlock B = block((size_t)k * 4);
+            SMI_OWN_ROOM();
+            std::memcpy(B.h, indices.data(), (size_t)k * 4);
+            SMI_HIP(hipMemcpyAsync(B.d, B.h, B.bytes, hipMemcpyHostToDevice, s));
+            d_idx = B.dev<int>(0);
         }
+        int *h_count = reinterpret_cast<int *>(host_only((size_t)k * 4)), *d_count = reinterpret_cast<int *>(dev_only((size_t)k * 4));
+        SMI_OWN_ROOM();
+        const bool init = first_call && identity;
+        hipLaunchKernelGGL(k_umi_own_count, dim3(grid), dim3(256), 0, s, d_mat, n, d_idx, k, ced, d_count, init ? d_out : (smi_umi_assignment *)nullptr,
+                           init ? d_cid : (int *)nullptr, init ? d_flag : (uint8_t *)nullptr);
+        SMI_HIP(hipMemcpyAsync(h_count, d_count, (size_t)k * 4, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        lap("neighbour counts");
+        keys.clear();
+        for (int i = 0; i < k; i++)
+            if (h_count[i] > 1) keys.push_back(indices[(size_t)i]);
         if (keys.empty()) return SMI_OK;
         const std::vector<int> ord = fastutil_order(keys);
-        std::vector<int> cnt_ord(ord.size()), own(ord.size());
-        for (size_t i = 0; i < ord.size(); i++) cnt_ord[i] = cnt_of[(size_t)ord[i]];
-        SMI_HIP(hipMemcpyAsync(S.i0, ord.data(), ord.size() * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i1, cnt_ord.data(), ord.size() * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_own_owner, dim3(grid), dim3(256), 0, s, d_mat, n, S.i0, S.i1, (int)ord.size(), ced, S.i2);
-        SMI_HIP(hipMemcpyAsync(own.data(), S.i2, ord.size() * 4, hipMemcpyDeviceToHost, s));
+        // up: ord[n_keys] | rc[n] = {position in ord or -1, count}
+        const size_t o_rc = up(ord.size() * 4);
+        const UpBlock B = block(o_rc + (size_t)n * 8);
+        int *h_own = reinterpret_cast<int *>(host_only(ord.size() * 4)), *d_own = reinterpret_cast<int *>(dev_only(ord.size() * 4));
+        SMI_OWN_ROOM();
+        int *h_ord = B.host<int>(0);
+        int2 *h_rc = B.host<int2>(o_rc);
+        for (int i = 0; i < n; i++) h_rc[i] = int2{-1, 0};
+        for (int i = 0; i < k; i++) h_rc[(size_t)indices[(size_t)i]].y = h_count[i];
+        for (size_t i = 0; i < ord.size(); i++) {
+            h_ord[i] = ord[i];
+            h_rc[(size_t)ord[i]].x = (int)i;
+        }
+        lap("keys in iteration order (host)");
+        SMI_HIP(hipMemcpyAsync(B.d, B.h, B.bytes, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_umi_own_owner, dim3(grid), dim3(256), 0, s, d_mat, n, B.dev<int>(0), B.dev<int2>(o_rc), (int)ord.size(), ced, d_own);
+        SMI_HIP(hipMemcpyAsync(h_own, d_own, ord.size() * 4, hipMemcpyDeviceToHost, s));
         SMI_HIP(hipStreamSynchronize(s));
-        for (size_t i = 0; i < ord.size(); i++) owner[(size_t)ord[i]] = own[i];
+        for (size_t i = 0; i < ord.size(); i++) owner[(size_t)ord[i]] = h_own[i];
+        lap("owners");
         return SMI_OK;
     };
+    std::vector<int> slot((size_t)n);
     auto group_by_owner = [&](const std::vector<int> &owner, const std::vector<int> &indices) {
-        std::map<int, size_t> slot;  // owner -> cluster, clusters listed by their smallest member
+        std::fill(slot.begin(), slot.end(), -1);  // owner -> cluster, clusters listed by their smallest member
         std::vector<Cluster> cl;
         for (int i : indices) {
-            if (owner[(size_t)i] < 0) continue;
-            auto it = slot.find(owner[(size_t)i]);
-            if (it == slot.end()) {
-                slot[owner[(size_t)i]] = cl.size();
+            const int o = owner[(size_t)i];
+            if (o < 0) continue;
+            if (slot[(size_t)o] < 0) {
+                slot[(size_t)o] = (int)cl.size();
                 cl.emplace_back();
-                it = slot.find(owner[(size_t)i]);
             }
-            cl[it->second].members.push_back(i);
+            cl[(size_t)slot[(size_t)o]].members.push_back(i);
         }
         return cl;
     };
-    // setClusterCenterNotPreGrouped (OneUmiCluster.java:L49-65) for the clusters `which` of `cl`: one launch for all of them
-    auto centers_dev = [&](std::vector<Cluster> &cl, const std::vector<size_t> &which) -> int {
-        std::vector<int> mem, c_of, c_off{0};
-        std::vector<std::vector<int>> ords;
+    // The clusters `which` of `cl` as flat arrays on the device (one copy): mem (members cluster after cluster, in fastutil iteration order when
+    // asked), c_of (a member's place in `which`), c_off (offsets into mem), gid (the cluster's number in `cl`)
+    struct Listed {
+        int *d_mem = nullptr, *d_c_of = nullptr, *d_c_off = nullptr, *d_gid = nullptr;
+        int *h_mem = nullptr;
+        int n_mem = 0, n_cl = 0;
+    };
+    auto list_clusters = [&](const std::vector<Cluster> &cl, const std::vector<size_t> &which, bool iteration_order, Listed &L) -> int {
+        size_t total = 0;
+        for (size_t w : which) total += cl[w].members.size();
+        L.n_mem = (int)total;
+        L.n_cl = (int)which.size();
+        if (total == 0) return SMI_OK;
+        const size_t o_c_of = up(total * 4), o_c_off = o_c_of + up(total * 4), o_gid = o_c_off + up((which.size() + 1) * 4);
+        const UpBlock B = block(o_gid + up((which.size() + 1) * 4));
+        SMI_OWN_ROOM();
+        L.h_mem = B.host<int>(0);
+        int *h_c_of = B.host<int>(o_c_of), *h_c_off = B.host<int>(o_c_off), *h_gid = B.host<int>(o_gid);
+        size_t at = 0;
         for (size_t w = 0; w < which.size(); w++) {
-            ords.push_back(fastutil_order(cl[which[w]].members));
-            for (int v : ords.back()) {
-                mem.push_back(v);
-                c_of.push_back((int)w);
-            }
-            c_off.push_back((int)mem.size());
-        }
-        if (mem.empty()) return SMI_OK;
-        std::vector<long long> tot(mem.size());
-        SMI_HIP(hipMemcpyAsync(S.i0, mem.data(), mem.size() * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i1, c_of.data(), c_of.size() * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i2, c_off.data(), c_off.size() * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_own_sums, dim3(grid), dim3(256), 0, s, d_mat, n, S.i0, S.i1, S.i2, (int)mem.size(), S.l0);
-        SMI_HIP(hipMemcpyAsync(tot.data(), S.l0, mem.size() * 8, hipMemcpyDeviceToHost, s));
-        SMI_HIP(hipStreamSynchronize(s));
-        for (size_t w = 0; w < which.size(); w++) {
-            const std::vector<int> &ord = ords[w];
-            Cluster &c = cl[which[w]];
-            if (ord.size() == 1)
-                c.center = ord[0];
-            else if (ord.size() == 2)
-                c.center = qv01[0] > qv01[1] ? ord[0] : ord[1];  // reads 0 and 1 of the GROUP (OneUmiCluster.java:L53)
-            else {
-                long long best = -1;
-                c.center = ord[0];
-                for (size_t i = 0; i < ord.size(); i++) {
-                    const long long t = tot[(size_t)c_off[w] + i];
-                    if (best < 0 || t < best) {  // the first minimum in iteration order
-                        best = t;
-                        c.center = ord[i];
-                    }
+            h_c_off[w] = (int)at;
+            h_gid[w] = (int)which[w];
+            const std::vector<int> &mm = cl[which[w]].members;
+            if (iteration_order && mm.size() > 1) {
+                for (int v : fastutil_order(mm)) {
+                    L.h_mem[at] = v;
+                    h_c_of[at++] = (int)w;
                 }
-            }
+            } else
+                for (int v : mm) {
+                    L.h_mem[at] = v;
+                    h_c_of[at++] = (int)w;
+                }
         }
+        h_c_off[which.size()] = (int)at;
+        SMI_HIP(hipMemcpyAsync(B.d, B.h, B.bytes, hipMemcpyHostToDevice, s));
+        L.d_mem = B.dev<int>(0);
+        L.d_c_of = B.dev<int>(o_c_of);
+        L.d_c_off = B.dev<int>(o_c_off);
+        L.d_gid = B.dev<int>(o_gid);
         return SMI_OK;
     };
-    // matrix cells (centre of its cluster, member) for every member of the clusters `which`
-    auto cells_to_center = [&](const std::vector<Cluster> &cl, const std::vector<size_t> &which, std::vector<std::vector<uint8_t>> &cells) -> int {
-        std::vector<int> a, b;
-        for (size_t w : which)
-            for (int v : cl[w].members) {
-                a.push_back(cl[w].center);
-                b.push_back(v);
-            }
-        cells.assign(which.size(), {});
-        if (a.empty()) return SMI_OK;
-        std::vector<uint8_t> flat(a.size());
-        SMI_HIP(hipMemcpyAsync(S.i0, a.data(), a.size() * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i1, b.data(), b.size() * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_own_gather, dim3((unsigned)((a.size() + 255) / 256)), dim3(256), 0, s, d_mat, n, S.i0, S.i1, (int)a.size(), S.b0);
-        SMI_HIP(hipMemcpyAsync(flat.data(), S.b0, a.size(), hipMemcpyDeviceToHost, s));
-        SMI_HIP(hipStreamSynchronize(s));
-        size_t at = 0;
-        for (size_t k = 0; k < which.size(); k++) {
-            cells[k].assign(flat.begin() + (long)at, flat.begin() + (long)(at + cl[which[k]].members.size()));
-            at += cl[which[k]].members.size();
-        }
+    // setClusterCenterNotPreGrouped for the clusters `which` of `cl`: queued, the centres stay on the device (d_center[cluster number])
+    auto centers_dev = [&](const std::vector<Cluster> &cl, const std::vector<size_t> &which, Listed &L) -> int {
+        SMI_OWN_RC(list_clusters(cl, which, true, L));
+        if (L.n_mem == 0) return SMI_OK;
+        long long *d_tot = reinterpret_cast<long long *>(dev_only(((size_t)L.n_mem + 1) * 8));
+        SMI_OWN_ROOM();
+        hipLaunchKernelGGL(k_umi_own_sums, dim3(grid), dim3(256), 0, s, d_mat, n, L.d_mem, L.d_c_of, L.d_c_off, L.n_mem, d_tot);
+        hipLaunchKernelGGL(k_umi_own_pick, dim3((unsigned)std::min<size_t>(((size_t)L.n_cl + 3) / 4, 256 * 16)), dim3(256), 0, s, d_tot, L.d_mem, L.d_c_off,
+                           L.d_gid, L.n_cl, d_qv, n, d_center);
         return SMI_OK;
     };
 
     std::vector<int> all((size_t)n), owner;
     for (int i = 0; i < n; i++) all[(size_t)i] = i;
     SMI_OWN_RC(cluster_local_dev(all, owner));
+    first_call = false;
     std::vector<Cluster> first = group_by_owner(owner, all), kept;
     size_t mx = 0;
     for (auto &c : first) mx = std::max(mx, c.members.size());
@@ -714,91 +891,100 @@ int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const floa
     for (auto &c : first) {
         if (c.members.size() * (size_t)cfg.fold_depth_below_max > mx) {
             for (int v : c.members) clustered[(size_t)v] = 1;
-            kept.push_back(c);
+            kept.push_back(std::move(c));
         } else
             for (int v : c.members) skipped[(size_t)v] = 1;
     }
     std::vector<size_t> every(kept.size());
     for (size_t k = 0; k < kept.size(); k++) every[k] = k;
-    SMI_OWN_RC(centers_dev(kept, every));
-    std::vector<int> unclustered;
+    Listed L1;
+    SMI_OWN_RC(centers_dev(kept, every, L1));
+    // removeOffCenter (L90-100): members farther than ced from their centre leave; a cluster that lost some gets a new centre
+    uint8_t *h_cell = nullptr;
+    if (L1.n_mem) {
+        h_cell = reinterpret_cast<uint8_t *>(host_only((size_t)L1.n_mem));
+        uint8_t *d_cell = reinterpret_cast<uint8_t *>(dev_only((size_t)L1.n_mem));
+        SMI_OWN_ROOM();
+        hipLaunchKernelGGL(k_umi_own_cells, dim3((unsigned)((L1.n_mem + 255) / 256)), dim3(256), 0, s, d_mat, n, L1.d_mem, L1.d_c_of, L1.d_gid, d_center, L1.n_mem,
+                           d_cell);
+        SMI_HIP(hipMemcpyAsync(h_cell, d_cell, (size_t)L1.n_mem, hipMemcpyDeviceToHost, s));
+    }
+    std::vector<int> unclustered;  // (while the device works)
     for (int i = 0; i < n; i++)
         if (!clustered[(size_t)i]) unclustered.push_back(i);
-    // removeOffCenter (L90-100): members farther than ced from their centre leave; a cluster that lost some gets a new centre
-    std::vector<std::vector<uint8_t>> cells;
-    SMI_OWN_RC(cells_to_center(kept, every, cells));
+    lap("clusters, fold depth, member orders (host)");
     size_t n_removed = 0;
     std::vector<size_t> changed;
-    for (size_t k = 0; k < kept.size(); k++) {
-        std::vector<int> stay;
-        for (size_t i = 0; i < kept[k].members.size(); i++) {
-            if ((cells[k][i] & 15) > ced) {
-                unclustered.push_back(kept[k].members[i]);
-                n_removed++;
-            } else
-                stay.push_back(kept[k].members[i]);
-        }
-        if (stay.size() != kept[k].members.size()) {
-            kept[k].members = stay;
-            changed.push_back(k);
-        }
+    if (L1.n_mem) {
+        SMI_HIP(hipStreamSynchronize(s));
+        lap("centres, distances to them");
+        std::vector<uint8_t> far((size_t)n, 0);
+        bool any_far = false;
+        for (int i = 0; i < L1.n_mem; i++)
+            if ((h_cell[i] & 15) > ced) {
+                far[(size_t)L1.h_mem[i]] = 1;
+                any_far = true;
+            }
+        if (any_far)
+            for (size_t k = 0; k < kept.size(); k++) {
+                std::vector<int> &mm = kept[k].members;
+                size_t w = 0;
+                for (size_t i = 0; i < mm.size(); i++) {
+                    if (far[(size_t)mm[i]]) {
+                        unclustered.push_back(mm[i]);
+                        n_removed++;
+                    } else
+                        mm[w++] = mm[i];
+                }
+                if (w != mm.size()) {
+                    mm.resize(w);
+                    changed.push_back(k);
+                }
+            }
     }
-    if (!changed.empty()) SMI_OWN_RC(centers_dev(kept, changed));
+    Listed L2, L3, L4;
+    if (!changed.empty()) SMI_OWN_RC(centers_dev(kept, changed, L2));
     if (n_removed > 0) {  // L102-112: the ejected and the unclustered reads once more
         std::sort(unclustered.begin(), unclustered.end());
+        lap("members off their centre (host)");
         SMI_OWN_RC(cluster_local_dev(unclustered, owner));
         std::vector<Cluster> more = group_by_owner(owner, unclustered);
         std::vector<size_t> fresh;
         for (auto &c : more)
             if (c.members.size() > 1) {
                 fresh.push_back(kept.size());
-                kept.push_back(c);
+                kept.push_back(std::move(c));
             }
-        if (!fresh.empty()) SMI_OWN_RC(centers_dev(kept, fresh));
+        if (!fresh.empty()) SMI_OWN_RC(centers_dev(kept, fresh, L3));
     }
-    // tags: the members within ced of the (final) centre, if more than one is left (L131-160)
+    // tags: the members within ced of the (final) centre, if more than one is left (L131-160) -- decided and written on the device
     std::vector<size_t> tagged;
     for (size_t k = 0; k < kept.size(); k++)
         if (kept[k].members.size() > 1) tagged.push_back(k);
-    SMI_OWN_RC(cells_to_center(kept, tagged, cells));
-    std::vector<int> who, cid((size_t)n, -1), center(kept.size(), 0), offset(kept.size(), 0);
-    for (size_t t = 0; t < tagged.size(); t++) {
-        const Cluster &c = kept[tagged[t]];
-        std::vector<int> filt;
-        long sum = 0;
-        int cnt = 0;
-        for (size_t i = 0; i < c.members.size(); i++) {
-            const int v = c.members[i];
-            if ((cells[t][i] & 15) <= ced) filt.push_back(v);
-            if (v != c.center) {  // offset over ALL members of the cluster (tag_members), pos1 of the cell (centre, member)
-                sum += ((cells[t][i] >> 4) & 3) - 1;
-                cnt++;
-            }
+    uint8_t *d_sk = d_skipped;
+    {
+        const UpBlock B = block((size_t)n);
+        SMI_OWN_ROOM();
+        for (int i = 0; i < n; i++) B.h[i] = skipped[(size_t)i];
+        if (d_sk)
+            SMI_HIP(hipMemcpyAsync(d_sk, B.h, (size_t)n, hipMemcpyHostToDevice, s));
+        else {
+            SMI_HIP(hipMemcpyAsync(B.d, B.h, (size_t)n, hipMemcpyHostToDevice, s));
+            d_sk = B.dev<uint8_t>(0);
         }
-        if (filt.size() <= 1) continue;
-        for (int v : c.members) cid[(size_t)v] = (int)tagged[t];
-        center[tagged[t]] = c.center;
-        offset[tagged[t]] = (int)std::floor((double)sum / (double)cnt + 0.5);  // (int) Math.round(double)
-        for (int v : filt)
-            if (!skipped[(size_t)v]) who.push_back(v);
     }
-    // `inside` of tag_members is the cluster's member list whether it is tagged or not: clusters that stay untagged still count as "inside"
-    // for nobody, so only the tagged clusters' members carry an id; reads of untagged clusters are "outside" for everybody, as on the host
-    if (!who.empty()) {
-        SMI_HIP(hipMemcpyAsync(S.i0, who.data(), who.size() * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i1, cid.data(), (size_t)n * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i2, center.data(), center.size() * 4, hipMemcpyHostToDevice, s));
-        SMI_HIP(hipMemcpyAsync(S.i3, offset.data(), offset.size() * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_own_tags, dim3(grid), dim3(256), 0, s, d_mat, n, S.i0, (int)who.size(), S.i1, S.i2, S.i3, (int)kept.size(), d_out);
+    if (!tagged.empty()) {
+        SMI_OWN_RC(list_clusters(kept, tagged, false, L4));
+        hipLaunchKernelGGL(k_umi_own_decide, dim3((unsigned)std::min<size_t>(((size_t)L4.n_cl + 3) / 4, 256 * 16)), dim3(256), 0, s, d_mat, n, L4.d_mem, L4.d_c_off,
+                           L4.d_gid, L4.n_cl, d_center, ced, d_sk, d_cid, d_offset, d_flag);
+        hipLaunchKernelGGL(k_umi_own_tags, dim3(grid), dim3(256), 0, s, d_mat, n, d_flag, d_cid, d_center, d_offset, (int)kept.size(), d_out);
     }
-    if (d_skipped) {
-        std::vector<uint8_t> sk((size_t)n);
-        for (int i = 0; i < n; i++) sk[(size_t)i] = (uint8_t)skipped[(size_t)i];
-        SMI_HIP(hipMemcpyAsync(d_skipped, sk.data(), (size_t)n, hipMemcpyHostToDevice, s));
-    }
-    SMI_HIP(hipStreamSynchronize(s));
+    lap("final lists (host)");
+    SMI_HIP(hipStreamSynchronize(s));  // (the pinned arrays of this call are free again)
     SMI_HIP(hipGetLastError());
+    lap("tags");
     return SMI_OK;
+#undef SMI_OWN_ROOM
 }
 
 }  // namespace smi

@@ -162,7 +162,7 @@ struct smi_ctx {
     std::vector<smi_scan_result> host_scan;  // its per-record results when asked for
     std::vector<smi_bc_result> host_bc;
     // packed chunk workers: page-locked, grow-only host buffers (index, offsets, planes, quality tails / sums, decisions)
-    enum { HB_RECS = 0, HB_OFFS, HB_PSTART, HB_PLANES, HB_QTAIL, HB_QSUM, HB_CHIM, HB_FOFFS, HB_FSRC, HB_SCAN, HB_BC, HB_RANK, HB_RKEYS, HB_RBITS, HB_REGION, HB_COUNT };
+    enum { HB_RECS = 0, HB_OFFS, HB_PSTART, HB_PLANES, HB_QTAIL, HB_QSUM, HB_CHIM, HB_FOFFS, HB_FSRC, HB_SCAN, HB_BC, HB_RANK, HB_RKEYS, HB_RBITS, HB_REGION, HB_OWN, HB_COUNT };
     smi_scan_stats host_stats = {};  // scan statistics of the last packed pass-2 chunk (want_results)
     void *umi_dist = nullptr;      // K-UMI matrices of the device UMI stage (smi_assignumis_chunk), grow-only
     size_t umi_dist_bytes = 0;

@@ -44,6 +44,7 @@ for src, units in zip(args[0::2], args[1::2]):
         if key == "k_scan" and "cfg2" in src:
             name = "k_scan_cfg2_mean_of_22_and_10"   # both instantiations match the pattern in the configs[2] run
         out[name] = entry(d[key], units, fetch_scale, src)
-out["commit"] = out.get("commit", commit)
+out.pop("source", None)   # every kernel entry names its own source file and commit
+out["commit"] = commit
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out))
