@@ -2183,17 +2183,21 @@ struct FlatLds {
     int wsum[2][4];
 };
 
-__global__ __launch_bounds__(256) void k_chim_owner(const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets, size_t n,
+__global__ __launch_bounds__(256) void k_chim_owner(const uint32_t *__restrict__ pstart, const uint64_t *__restrict__ offsets, size_t n, size_t stride,
                                                     uint32_t *__restrict__ own) {
     const int lane = threadIdx.x & 63;
     const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6;
     const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     for (size_t r = wave; r < n; r += n_waves) {
-        const uint64_t beg = offsets[r];
-        const int len = (int)(offsets[r + 1] - beg);
+        const uint64_t beg = offsets[r], end = offsets[r + 1];
+        const int len = (int)(end - beg);
         const size_t w0 = pstart ? (size_t)pstart[r] : plane_start(beg, r);
         const int n_words = (len + 31) >> 5;
-        for (int w = lane; w < n_words; w += 64) own[w0 + w] = (uint32_t)r;
+        // Without explicit word starts the reads tile the planes (read r + 1 starts where the pad words of read r end): the wave also marks its
+        // pad words -- and the last read the rest of the plane -- as nobody's, so the array needs no fill in front of this kernel (a 75 MB
+        // memset per chunk of 0.45 M reads).  With explicit starts the caller has filled it.
+        const size_t w1 = pstart ? w0 + (size_t)n_words : (r + 1 < n ? plane_start(end, r + 1) : stride);
+        for (size_t w = lane; w0 + w < w1; w += 64) own[w0 + w] = w < (size_t)n_words ? (uint32_t)r : 0xFFFFFFFFu;
     }
 }
 
@@ -2732,9 +2736,9 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
         d_hot_w = d_cand_w + 2 * st;
         d_trig_w = d_hot_w + 2 * st;
         uint32_t *d_verd = d_trig_w + 2 * st;
-        SMI_HIP(hipMemsetAsync(d_own, 0xFF, st * sizeof(uint32_t), s));
+        if (d_pstart || n == 0) SMI_HIP(hipMemsetAsync(d_own, 0xFF, st * sizeof(uint32_t), s));
         SMI_HIP(hipMemsetAsync(d_verd, 0, n * sizeof(uint32_t), s));
-        { hipLaunchKernelGGL(k_chim_owner, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, s, d_pstart, d_offsets, n, d_own); SMI_CHIM_CHECK("k_chim_owner"); }
+        { hipLaunchKernelGGL(k_chim_owner, dim3((unsigned)std::min<size_t>((n + 3) / 4, 256 * 32)), dim3(256), 0, s, d_pstart, d_offsets, n, st, d_own); SMI_CHIM_CHECK("k_chim_owner"); }
         const size_t n_tiles = (st + 255) / 256;
         const unsigned gridF = (unsigned)std::min<size_t>(n_tiles, 256 * 8);
         if (shipped3)
@@ -2862,13 +2866,11 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 }
                 { hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg); SMI_CHIM_CHECK("k_chimc_rules"); }
                 // second chance for the reads over a cap of the lane-per-read kernels (one in 10^5): the first-generation kernels, one wave per read,
-                // with their caps of 64; what is over those too goes to the serial kernel below.  Their number is read back first: the usual
-                // chunk has none, and then neither these kernels nor the serial pass are launched at all
+                // with their caps of 64; what is over those too goes to the serial kernel below.  The usual chunk has none: the two kernels then
+                // find an empty list (they take its length from the device, 64 workgroups each: ~ 10 us together) -- reading the length back
+                // first, to skip them, cost a round trip to the host of ~ 45 us per chunk
                 uint32_t *d_over2_count = d_count + 5, *d_over2 = d_list + n;
                 { hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over2, d_over2_count); SMI_CHIM_CHECK("k_collect_overflow"); }
-                uint32_t n_over2 = 0;
-                SMI_HIP(hipMemcpyAsync(&n_over2, d_over2_count, 4, hipMemcpyDeviceToHost, s));
-                SMI_HIP(hipStreamSynchronize(s));
 #ifdef SMI_MEASURE
                 if (getenv("SMI_CHIM_STATS")) {
                     uint32_t h[16];
@@ -2877,10 +2879,6 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                             h[0], h[5], h[3], h[4], h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15]);
                 }
 #endif
-                if (n_over2 == 0) {
-                    if (int rc = time_end(ctx, SMI_K_CHIMERA, s)) return rc;
-                    return SMI_OK;
-                }
                 if (tl == 27) {
                     { hipLaunchKernelGGL((k_chimera<27, 22, 1>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }
                     { hipLaunchKernelGGL((k_chimera<27, 22, 2>), dim3(64), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_over2, d_over2_count, P, d_slots, d_out); SMI_CHIM_CHECK("k_chimera"); }

@@ -93,13 +93,71 @@ __global__ __launch_bounds__(kFqBlock) void k_fq_lines(const uint8_t *__restrict
     }
 }
 
+// ---- the line index with ONE sweep over the text (round 4): the count sweep also leaves every thread's 64 newline flags (one bit per byte of
+// text, 1/8 of its size), and the sweep that writes the line starts reads those instead of the text again: 1.2 GB + 2 x 0.15 GB through HBM
+// instead of 2 x 1.2 GB.  (Tried first: a true single sweep, tiles publishing their counts and looking back over their predecessors' --
+// with 16 KiB tiles arriving every 3 ns and a look-back step of ~1 us every tile walks the whole resident window, 150 M device-scope loads
+// per chunk: 7 ms instead of 0.4.)
+__global__ __launch_bounds__(kFqBlock) void k_fq_count_masks(const uint8_t *__restrict__ text, size_t n, uint32_t *__restrict__ block_counts,
+                                                             uint64_t *__restrict__ masks) {
+    __shared__ uint32_t wave_tot[kFqBlock / 64];
+    const size_t t = (size_t)blockIdx.x * kFqBlock + threadIdx.x, i0 = t * kFqBytesPerThread;
+    const uint64_t mask = i0 < n ? nl_mask64(text, i0, n) : 0ull;
+    masks[t] = mask;
+    uint32_t before;
+    const uint32_t total = block_sum_and_prefix((uint32_t)__popcll(mask), wave_tot, before);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(kFqBlock) void k_fq_lines_masks(const uint64_t *__restrict__ masks, const uint64_t *__restrict__ block_base,
+                                                             uint64_t *__restrict__ line_start, size_t cap_lines) {
+    __shared__ uint32_t wave_tot[kFqBlock / 64];
+    const size_t t = (size_t)blockIdx.x * kFqBlock + threadIdx.x, i0 = t * kFqBytesPerThread;
+    const uint64_t mask = masks[t];
+    uint32_t before;
+    block_sum_and_prefix((uint32_t)__popcll(mask), wave_tot, before);
+    uint64_t line = block_base[blockIdx.x] + before;  // newlines before my first byte
+    if (blockIdx.x == 0 && threadIdx.x == 0 && cap_lines > 0) line_start[0] = 0;
+    for (uint64_t m = mask; m; m &= m - 1) {
+        line++;
+        if (line < cap_lines) line_start[line] = i0 + (size_t)__builtin_ctzll(m) + 1;
+    }
+}
+
+// what the host used to compute between the two halves of the index, on the device: the record kernel and the length scan are queued
+// right behind the line sweep, and the host reads these words once, at the end of the call
+struct FqTotals {
+    uint64_t n_newlines, n_lines, n_rec;  // n_rec = 0 when the buffers are too small (`overflow` says which)
+    uint32_t err, overflow;               // err: SMI_FQ_* of the record kernel; overflow: 1 line buffer, 2 record buffers
+};
+__global__ void k_fq_totals(const uint8_t *__restrict__ text, size_t n_bytes, size_t n_blocks, const uint64_t *__restrict__ block_base,
+                            const uint32_t *__restrict__ block_counts, size_t cap_lines, size_t cap_records, FqTotals *__restrict__ t) {
+    if (blockIdx.x || threadIdx.x) return;
+    const uint64_t nl = block_base[n_blocks - 1] + block_counts[n_blocks - 1];
+    const uint64_t lines = nl + (text[n_bytes - 1] == '\n' ? 0 : 1);  // a last line without newline still counts
+    uint64_t rec = lines / 4;
+    uint32_t over = 0;
+    if (lines + 1 > cap_lines) over |= 1u;
+    if (rec >= cap_records) over |= 2u;  // the length scan reads d_seq_len[n_rec]: one spare entry is part of the contract
+    if (over) rec = 0;
+    t->n_newlines = nl;
+    t->n_lines = lines;
+    t->n_rec = rec;
+    t->overflow = over;
+}
+
 // record r = lines 4r .. 4r+3
 __global__ void k_fq_records(const uint8_t *__restrict__ text, size_t n_bytes, const uint64_t *__restrict__ line_start,
-                             uint64_t n_lines_complete, size_t n_rec, uint64_t *__restrict__ name_start,
+                             FqTotals *__restrict__ tot, size_t cap_records, uint64_t *__restrict__ name_start,
                              uint32_t *__restrict__ name_len, uint64_t *__restrict__ seq_start, uint32_t *__restrict__ seq_len,
-                             uint64_t *__restrict__ qual_start, uint32_t *__restrict__ err) {
+                             uint64_t *__restrict__ qual_start) {
     const size_t r = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-    if (r >= n_rec) return;
+    const uint64_t n_lines_complete = tot->n_newlines;
+    const size_t n_rec = (size_t)tot->n_rec;
+    uint32_t *err = &tot->err;
+    if (r >= n_rec) {
+        if (r < cap_records) seq_len[r] = 0;  // (the length scan runs over the whole capacity: offsets[n_rec ..] = total bases)
+        return;
+    }
     auto line_end = [&](uint64_t L) -> uint64_t {  // one past the last character of line L (CR / LF stripped)
         uint64_t e = L + 1 <= n_lines_complete ? line_start[L + 1] - 1 : n_bytes;  // the last line may lack its newline
         if (e > line_start[L] && text[e - 1] == '\r') e--;
@@ -178,55 +236,56 @@ int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint
     *n_records = 0;
     *errors = 0;
     if (!n_bytes) return SMI_OK;
+    if (cap_records == 0) {
+        set_error("smi_fastq_index_device: record buffers too small (need n_records + 1 entries)");
+        return SMI_ERR_INVALID;
+    }
     const size_t n_blocks = (n_bytes + kFqTile - 1) / kFqTile;
-    // scratch: block counts (u32), block bases (u64), scalars, hipcub temp
+    // scratch: block counts (u32), block bases (u64), scalars, the newline flags (a u64 per thread of the sweep), hipcub temp
     size_t cub_a = 0, cub_b = 0;
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_a, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)n_blocks, s));
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)cap_records + 1, s));
+    const bool two_sweeps = getenv("SMI_FQ_TWO_SWEEPS") != nullptr;  // cross-check switch (read per call): the line starts from a second sweep over the text
     const size_t off_counts = 0, off_base = (n_blocks * 4 + 255) & ~(size_t)255, off_scal = off_base + ((n_blocks * 8 + 255) & ~(size_t)255),
-                 off_cub = off_scal + 256, total = off_cub + std::max(cub_a, cub_b);
+                 off_masks = off_scal + 256, off_cub = off_masks + (two_sweeps ? 0 : n_blocks * kFqBlock * 8), total = off_cub + std::max(cub_a, cub_b);
     if (int rc = ensure_scan_tmp(ctx, total)) return rc;
     uint8_t *tmp = (uint8_t *)ctx->scan_tmp;
     uint32_t *counts = (uint32_t *)(tmp + off_counts);
     uint64_t *bases = (uint64_t *)(tmp + off_base);
-    uint32_t *d_err = (uint32_t *)(tmp + off_scal);
-    SMI_HIP(hipMemsetAsync(d_err, 0, 16, s));
-    hipLaunchKernelGGL(k_fq_count, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts);
+    FqTotals *d_tot = (FqTotals *)(tmp + off_scal);
+    uint64_t *masks = (uint64_t *)(tmp + off_masks);
+    SMI_HIP(hipMemsetAsync(d_tot, 0, sizeof(FqTotals), s));
+    if (two_sweeps)
+        hipLaunchKernelGGL(k_fq_count, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts);
+    else
+        hipLaunchKernelGGL(k_fq_count_masks, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts, masks);
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_a, counts, bases, (int)n_blocks, s));
-    hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, bases, d_line_start, cap_lines);
-    // number of newlines = base of the last block + its count
-    uint64_t last_base = 0;
-    uint32_t last_count = 0;
-    SMI_HIP(hipMemcpyAsync(&last_base, bases + (n_blocks - 1), 8, hipMemcpyDeviceToHost, s));
-    SMI_HIP(hipMemcpyAsync(&last_count, counts + (n_blocks - 1), 4, hipMemcpyDeviceToHost, s));
-    uint8_t last_byte = 0;
-    SMI_HIP(hipMemcpyAsync(&last_byte, d_text + (n_bytes - 1), 1, hipMemcpyDeviceToHost, s));
+    if (two_sweeps)
+        hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, bases, d_line_start, cap_lines);
+    else
+        hipLaunchKernelGGL(k_fq_lines_masks, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, masks, bases, d_line_start, cap_lines);
+    hipLaunchKernelGGL(k_fq_totals, dim3(1), dim3(1), 0, s, d_text, n_bytes, n_blocks, (const uint64_t *)bases, (const uint32_t *)counts, cap_lines, cap_records,
+                       d_tot);
+    // records and lengths for as many records as the text turns out to have (the kernel reads the totals on the device; entries behind the
+    // last record get length 0), offsets over the whole capacity: nothing here waits for the host
+    hipLaunchKernelGGL(k_fq_records, dim3((unsigned)((cap_records + 255) / 256)), dim3(256), 0, s, d_text, n_bytes, d_line_start, d_tot, cap_records,
+                       d_name_start, d_name_len, d_seq_start, d_seq_len, d_qual_start);
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_b, d_seq_len, d_offsets, (int)cap_records, s));
+    FqTotals h;
+    SMI_HIP(hipMemcpyAsync(&h, d_tot, sizeof h, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
-    const uint64_t n_newlines = last_base + last_count;
-    const uint64_t n_lines = n_newlines + (last_byte == '\n' ? 0 : 1);  // a last line without newline still counts
-    if (n_lines + 1 > cap_lines) {
+    if (h.overflow & 1u) {
         set_error("smi_fastq_index_device: line buffer too small");
         return SMI_ERR_INVALID;
     }
-    uint32_t host_err = 0;
-    if (n_lines % 4 != 0) host_err |= SMI_FQ_TRUNCATED;  // htsjdk: "missing ... line" at end of file
-    const size_t n_rec = (size_t)(n_lines / 4);
-    if (n_rec >= cap_records) {  // the scan below reads d_seq_len[n_rec]: one spare entry is part of the contract
+    if (h.overflow & 2u) {
         set_error("smi_fastq_index_device: record buffers too small (need n_records + 1 entries)");
         return SMI_ERR_INVALID;
     }
-    if (n_rec) {
-        hipLaunchKernelGGL(k_fq_records, dim3((unsigned)((n_rec + 255) / 256)), dim3(256), 0, s, d_text, n_bytes, d_line_start,
-                           n_newlines, n_rec, d_name_start, d_name_len, d_seq_start, d_seq_len, d_qual_start, d_err);
-        SMI_HIP(hipMemsetAsync(d_seq_len + n_rec, 0, sizeof(*d_seq_len), s));
-        SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_b, d_seq_len, d_offsets, (int)n_rec + 1, s));
-    } else
-        SMI_HIP(hipMemsetAsync(d_offsets, 0, 8, s));
-    uint32_t dev_err = 0;
-    SMI_HIP(hipMemcpyAsync(&dev_err, d_err, 4, hipMemcpyDeviceToHost, s));
-    SMI_HIP(hipStreamSynchronize(s));
-    *n_records = n_rec;
-    *errors = host_err | dev_err;
+    uint32_t host_err = 0;
+    if (h.n_lines % 4 != 0) host_err |= SMI_FQ_TRUNCATED;  // htsjdk: "missing ... line" at end of file
+    *n_records = (size_t)h.n_rec;
+    *errors = host_err | h.err;
     return SMI_OK;
 }
 

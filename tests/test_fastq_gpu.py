@@ -61,6 +61,30 @@ def test_fastq_index_and_gather(pkg, gpu_ctx, crlf, final_newline):
     assert bytes(d_quals.cpu().numpy()).decode() == "".join(r[2] for r in recs)
 
 
+def test_fastq_index_one_sweep_equals_two_sweeps(pkg, gpu_ctx, monkeypatch):
+    """the line index from one sweep over the text (the count sweep keeps the newline flags, the line starts come from those) against the two
+    sweeps it replaced (SMI_FQ_TWO_SWEEPS), on a text of ~5,400 blocks with short and long lines mixed; and the capacity checks that moved
+    to the device"""
+    rng = np.random.default_rng(77)
+    recs, text = _records(60_000, rng)
+    assert len(text) > 80_000_000
+    n1, e1, _t, b1 = _index(gpu_ctx, text)
+    monkeypatch.setenv("SMI_FQ_TWO_SWEEPS", "1")
+    n2, e2, _t, b2 = _index(gpu_ctx, text)
+    monkeypatch.delenv("SMI_FQ_TWO_SWEEPS")
+    assert (n1, e1) == (n2, e2) == (len(recs), 0)
+    n_lines = 4 * n1
+    assert torch.equal(b1["line"][:n_lines + 1], b2["line"][:n_lines + 1])
+    for k in ("name_start", "name_len", "seq_start", "seq_len", "qual_start"):
+        assert torch.equal(b1[k][:n1], b2[k][:n1]), k
+    assert torch.equal(b1["offsets"][:n1 + 1], b2["offsets"][:n1 + 1])
+    assert int(b1["offsets"][n1]) == sum(len(r[1]) for r in recs)
+    for bad_cap in (n1, n1 // 2):   # record buffers need n_records + 1 entries
+        with pytest.raises(pkg.SmiError, match="too small"):
+            _index(gpu_ctx, text, cap=bad_cap)
+    assert _index(gpu_ctx, text, cap=n1 + 1)[:2] == (n1, 0)
+
+
 def test_fastq_errors_are_reported(pkg, gpu_ctx):
     ok = b"@r1\nACGT\n+\nIIII\n@r2\nAC\n+\nII\n"
     assert _index(gpu_ctx, ok)[:2] == (2, 0)

@@ -18,10 +18,10 @@ def main():
                 continue
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm))
     rows.sort()
-    # a repetition starts at k_fq_count
+    # a repetition starts at the line index's first kernel
     starts = [i for i, r in enumerate(rows) if "k_fq_count" in r[2]]
     if not starts:
-        raise SystemExit("no k_fq_count dispatch in the trace")
+        raise SystemExit("no line-index dispatch in the trace")
     a = starts[-1]
     b = max(i for i, r in enumerate(rows) if i >= a and ("k_write(" in r[2] or "k_write_name" in r[2])) + 1
     t0 = rows[a][0]
