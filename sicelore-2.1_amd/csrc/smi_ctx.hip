@@ -233,6 +233,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->chim_work);
     (void)hipFree(ctx->chim_flat);
     (void)hipFree(ctx->umi_own);
+    (void)hipFree(ctx->umi_plan);
     (void)hipHostFree(ctx->host_out[0]);
     (void)hipHostFree(ctx->host_out[1]);
     for (void *hb : ctx->host_buf) (void)hipHostFree(hb);

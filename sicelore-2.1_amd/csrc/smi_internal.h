@@ -153,6 +153,8 @@ struct smi_ctx {
     size_t chim_work_bytes = 0;
     void *umi_own = nullptr;       // ClusterOne_MyClustering on the device: index / count / sum scratch of one large group (grow-only)
     size_t umi_own_bytes = 0;
+    void *umi_plan = nullptr;      // K-UMI: per group its pairs in the flat kernel / tiles in the tiled one, and their prefix sums (grow-only)
+    size_t umi_plan_bytes = 0;
     void *chim_flat = nullptr;     // K-CHIM-A second generation: owner of every plane word, gate / bound / trigger words, verdicts (grow-only)
     size_t chim_flat_bytes = 0;
     void *arena = nullptr;         // device memory of the chunk workers (smi_worker.hip), grow-only

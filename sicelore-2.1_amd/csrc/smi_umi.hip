@@ -12,18 +12,35 @@
 // distance is Myers' bit-parallel global edit distance on 12-bit vectors -- the banded DP of the reference returns
 // exactly min(Levenshtein, "> 4"), which is what the bit-vector algorithm's last-row score gives.  Integer/bitwise
 // only: no MFMA, no LDS.
+#include <hipcub/hipcub.hpp>
+
 #include "smi_internal.h"
 
 namespace smi {
 
-// bit k of the result = nibble k of w equals code c (k = 0..13)
-__device__ __forceinline__ uint32_t eq_mask(uint64_t w, uint32_t c) {
-    uint64_t x = w ^ (0x1111111111111111ull * c);
-    // nibble == 0  <=>  (((x & 0x7..7) + 0x7..7) | x) has bit 3 clear
-    uint64_t z = ~((((x & 0x7777777777777777ull) + 0x7777777777777777ull) | x)) & 0x8888888888888888ull;
-    uint32_t m = 0;
+// The window's four code bits as 14-bit planes: plane c, bit k = bit c of nibble k.  Every fourth bit of a dword is drawn together in three
+// or-shift steps (8 nibbles of the low dword, 6 of the high one); the masks "nibble == A / G / C / T / N" are then a dozen logic operations on
+// the planes.  (The first version tested each code with a SWAR compare and moved its 14 flag bits one by one: 350 operations per pair of
+// 2,200.)
+__device__ __forceinline__ uint32_t every_fourth_bit(uint32_t t) {  // bits 0, 4, .., 28 -> bits 0 .. 7
+    t = (t | (t >> 3)) & 0x03030303u;
+    t = (t | (t >> 6)) & 0x000F000Fu;
+    return (t | (t >> 12)) & 0xFFu;
+}
+struct EqMasks {
+    uint32_t a, g, c, t, n;
+};
+__device__ __forceinline__ EqMasks eq_masks(uint64_t w) {
+    const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+    uint32_t p[4];
 #pragma unroll
-    for (int k = 0; k < 14; k++) m |= (uint32_t)((z >> (4 * k + 3)) & 1ull) << k;
+    for (int c = 0; c < 4; c++) p[c] = every_fourth_bit((lo >> c) & 0x11111111u) | (every_fourth_bit((hi >> c) & 0x00111111u) << 8);
+    EqMasks m;
+    m.a = p[0] & ~(p[1] | p[2] | p[3]);  // code 1
+    m.g = p[1] & ~(p[0] | p[2] | p[3]);  // code 2
+    m.c = p[2] & ~(p[0] | p[1] | p[3]);  // code 4
+    m.t = p[3] & ~(p[0] | p[1] | p[2]);  // code 8
+    m.n = p[0] & p[1] & p[2] & p[3];     // code 15
     return m;
 }
 
@@ -51,7 +68,8 @@ __device__ __forceinline__ int myers12(const uint32_t (&eq)[14], int pi, int tj)
 }
 
 __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b) {
-    const uint32_t mA = eq_mask(a, 1), mG = eq_mask(a, 2), mC = eq_mask(a, 4), mT = eq_mask(a, 8), mN = eq_mask(a, 15);
+    const EqMasks ma = eq_masks(a);
+    const uint32_t mA = ma.a, mG = ma.g, mC = ma.c, mT = ma.t, mN = ma.n;
     // match masks per text base, shared by the nine alignments (a code outside A, G, C, T, N matches nothing, as equals() would)
     uint32_t eq[14];
 #pragma unroll
@@ -78,32 +96,76 @@ __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b) {
     return (uint32_t)best | ((uint32_t)b1 << 4) | ((uint32_t)b2 << 6);
 }
 
+// ---- two mappings of pairs to lanes ---------------------------------------------------------------------------------------------------
+// A pair (i, v) is stored twice: m[i][v] and, with its offsets swapped, m[v][i].  With one lane per pair in row-major order (the flat kernel)
+// the first store of a wave is 64 consecutive bytes, the second 64 bytes a row apart: every one of them dirties a 128-byte line of L2 by one
+// byte, the rest of that line is written by other workgroups -- on other XCDs, with their own L2 -- much later, and the line goes out to HBM
+// many times: 5.8 x the matrix bytes (profiles/r03/umi_pmc.json).  Groups above 64 reads (which hold nearly all matrix bytes: they grow
+// with n^2) are therefore cut into 64 x 64 tiles, a workgroup per tile, a wave per 8 x 8 block of it: the eight results of a row of the block
+// travel to one lane (three shuffles) and leave as one 8-byte store, and so do the eight of a column for the mirrored copy.  Both copies of
+// the tile's 64-byte row pieces are complete when the workgroup ends, in ONE L2.  Blocks that the diagonal or the matrix edge cuts store
+// byte by byte, lanes below the diagonal idle there (the reference computes i <= v only, and its tie-break is not symmetric).  Small groups
+// keep the flat mapping: a tile over a 3-read group would be 98 % idle lanes.
+constexpr int kUmiTileMin = 64;   // groups above this many reads are tiled
+constexpr int kUmiTile = 64;
+
+struct UmiPlan {
+    uint64_t small_pairs, tiles;
+};
+struct UmiPlanAdd {
+    __host__ __device__ UmiPlan operator()(const UmiPlan &a, const UmiPlan &b) const { return UmiPlan{a.small_pairs + b.small_pairs, a.tiles + b.tiles}; }
+};
+
+// plan[g] = what group g contributes to the two kernels (plan[n_groups] = nothing: the exclusive scan leaves the totals there)
+__global__ void k_umi_plan(const uint32_t *__restrict__ group_off, uint32_t n_groups, UmiPlan *__restrict__ plan) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    UmiPlan p{0, 0};
+    if (g < n_groups) {
+        const uint64_t n = group_off[g + 1] - group_off[g];
+        if (n > (uint64_t)kUmiTileMin) {
+            const uint64_t nb = (n + 4 * kUmiTile - 1) / (4 * kUmiTile);  // macro-tiles of 4 x 4 tiles (k_umi_dist_tiles)
+            p.tiles = nb * (nb + 1) / 2;
+        } else
+            p.small_pairs = n * (n + 1) / 2;
+    }
+    plan[g] = p;
+}
+
+// row i of an upper triangle of side n (rows have n, n-1, ... entries) that holds entry `local`: first(i) = i*n - i*(i-1)/2
+__device__ __forceinline__ uint64_t tri_row(uint64_t n, uint64_t local) {
+    uint64_t i = (uint64_t)(((double)(2 * n + 1) - sqrt((double)(2 * n + 1) * (double)(2 * n + 1) - 8.0 * (double)local)) * 0.5);
+    if (i >= n) i = n - 1;
+    while (i > 0 && i * n - i * (i - 1) / 2 > local) i--;
+    while ((i + 1) * n - (i + 1) * i / 2 <= local) i++;
+    return i;
+}
+
+// the flat kernel: one lane per pair (i <= v) of the groups of at most kUmiTileMin reads, pairs of all those groups in one index space
+// (plan[g].small_pairs = pairs in front of group g; a tiled group has none, so "the last g with plan[g].small_pairs <= t" never lands on one)
 __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ windows, const uint32_t *__restrict__ group_off,
-                                                  const uint64_t *__restrict__ pair_off, const uint64_t *__restrict__ mat_off,
-                                                  uint32_t n_groups, uint64_t total_pairs, uint8_t *__restrict__ out) {
+                                                  const UmiPlan *__restrict__ plan, const uint64_t *__restrict__ mat_off,
+                                                  uint32_t n_groups, uint8_t *__restrict__ out) {
+    const uint64_t total_pairs = plan[n_groups].small_pairs;
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total_pairs; t += (uint64_t)gridDim.x * blockDim.x) {
-        // group of this pair: last g with pair_off[g] <= t.  The pairs of a wave are consecutive, so the binary search
+        // group of this pair: last g with off[g] <= t.  The pairs of a wave are consecutive, so the binary search
         // runs once for the wave's first pair (scalar) and every lane walks forward from there
         const uint64_t t_first = __builtin_amdgcn_readfirstlane((uint32_t)(t >> 32)) * 0x100000000ull +
                                  (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)t);
         uint32_t lo = 0, hi = n_groups;
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (pair_off[mid] <= t_first)
+            if (plan[mid].small_pairs <= t_first)
                 lo = mid;
             else
                 hi = mid;
         }
         uint32_t g = lo;
-        while (g + 1 < n_groups && pair_off[g + 1] <= t) g++;
-        const uint64_t local = t - pair_off[g];
+        while (g + 1 < n_groups && plan[g + 1].small_pairs <= t) g++;
+        const uint64_t local = t - plan[g].small_pairs;
         const uint32_t r0 = group_off[g];
         const uint64_t n = group_off[g + 1] - r0;
-        // row i of the upper triangle (rows have n, n-1, ... entries): first(i) = i*n - i*(i-1)/2
-        uint64_t i = (uint64_t)(((double)(2 * n + 1) - sqrt((double)(2 * n + 1) * (double)(2 * n + 1) - 8.0 * (double)local)) * 0.5);
-        if (i >= n) i = n - 1;
-        while (i > 0 && i * n - i * (i - 1) / 2 > local) i--;
-        while ((i + 1) * n - (i + 1) * i / 2 <= local) i++;
+        const uint64_t i = tri_row(n, local);
         const uint64_t v = i + (local - (i * n - i * (i - 1) / 2));
         const uint32_t r = umi_pair(windows[r0 + i], windows[r0 + v]);
         uint8_t *m = out + mat_off[g];
@@ -113,13 +175,136 @@ __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ w
     }
 }
 
+// the tiled kernel: a workgroup per 256 x 256 macro-tile (mi <= mv) of a group above kUmiTileMin reads; it goes through the macro-tile's
+// 4 x 4 tiles of 64 x 64 one after the other, a wave per 8 x 8 block of the tile, lane = (di, dv).  A tile's results are collected in LDS --
+// A = m[i0 ..][v0 ..], B = the mirrored m[v0 ..][i0 ..] (one and the same array for a tile on the diagonal, where a cell (a, a) ends up with
+// the mirrored value, as the two stores of the flat kernel leave it) -- and leave as 16-byte pieces of rows when the tile is done: every
+// store instruction of a wave covers whole 64-byte row pieces.  Macro-tiles are taken from a counter: they hold between 1 and 16 tiles.
+// What is left of the write amplification (profiles/r04/umi_pmc.json: 1.5 x the matrix bytes, from 5.8 x): a row of the matrix starts at
+// any byte (n is not a multiple of 64), so the first and last 64-byte block of a row piece is shared with the tile beside it, which writes
+// its part 160 us later (256 threads) -- L2 has written the block back by then.  Eight waves per workgroup halve that distance and merge
+// more (1.37 x) but run 10 % slower (56.8 against 51.5 ms per 0.94 G pairs: fewer waves per SIMD, a barrier per 80 us); whole 256-byte row
+// pieces per store would need the mirrored copy of a macro-tile in LDS (64 KB).  SMI_UMI_TILE_THREADS=512 builds the other variant.
+constexpr int kUmiLdsRow = kUmiTile + 16;  // bytes per staged row (80: rows start 16-byte aligned, neighbouring rows in different banks)
+constexpr int kUmiMacro = 4;               // tiles per macro-tile edge
+#ifndef SMI_UMI_TILE_THREADS
+#define SMI_UMI_TILE_THREADS 256
+#endif
+constexpr int kUmiTileThreads = SMI_UMI_TILE_THREADS;
+
+__global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64_t *__restrict__ windows, const uint32_t *__restrict__ group_off,
+                                                                    const UmiPlan *__restrict__ plan, const uint64_t *__restrict__ mat_off,
+                                                                    uint32_t n_groups, uint32_t *__restrict__ next_unit, uint8_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[2][kUmiTile][kUmiLdsRow];
+    __shared__ uint32_t s_unit;
+    const uint64_t total_units = plan[n_groups].tiles;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int di = lane >> 3, dv = lane & 7;
+    for (;;) {
+        if (threadIdx.x == 0) s_unit = atomicAdd(next_unit, 1u);
+        __syncthreads();
+        const uint64_t unit = s_unit;
+        __syncthreads();  // (s_unit is written again at the top of the next turn)
+        if (unit >= total_units) return;
+        uint32_t lo = 0, hi = n_groups;  // last g with plan[g].tiles <= unit (uniform)
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (plan[mid].tiles <= unit)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const uint32_t g = lo;
+        const uint64_t local = unit - plan[g].tiles;
+        const uint32_t r0 = group_off[g];
+        const uint64_t n = group_off[g + 1] - r0;
+        const uint64_t nbm = (n + kUmiMacro * kUmiTile - 1) / (kUmiMacro * kUmiTile);
+        const uint64_t mi = tri_row(nbm, local), mv = mi + (local - (mi * nbm - mi * (mi - 1) / 2));
+        uint8_t *m = out + mat_off[g];
+        const uint64_t *win = windows + r0;
+        for (int tt = 0; tt < kUmiMacro * kUmiMacro; tt++) {
+            const uint64_t bi = kUmiMacro * mi + tt / kUmiMacro, bv = kUmiMacro * mv + tt % kUmiMacro;
+            const uint64_t i0 = bi * kUmiTile, v0 = bv * kUmiTile;
+            if (i0 >= n || v0 >= n || bi > bv) continue;  // (uniform)
+            uint8_t(*A)[kUmiLdsRow] = stage[0];
+            uint8_t(*B)[kUmiLdsRow] = stage[bi == bv ? 0 : 1];
+            int live = 0;  // blocks of this tile that hold pairs, dealt to the eight waves in turn
+            for (int sb = 0; sb < 64; sb++) {
+                const int si = sb >> 3, sv = sb & 7;
+                const uint64_t bi0 = i0 + 8 * si, bv0 = v0 + 8 * sv;  // the block's first row / column
+                if (bi0 >= n || bv0 >= n || bv0 + 7 < bi0) continue;  // outside the matrix, or wholly below the diagonal
+                if ((live++ & (kUmiTileThreads / 64 - 1)) != wv) continue;
+                const uint64_t i = bi0 + di, v = bv0 + dv;
+                const bool valid = i < n && v < n && i <= v;
+                uint32_t r = 0;
+                if (valid) r = umi_pair(win[i], win[v]);
+                const uint32_t rt = (r & 15u) | (((r >> 6) & 3u) << 4) | (((r >> 4) & 3u) << 6);  // getTransposedEditDistance L133, L213-216
+                const bool whole = bi0 + 7 < bv0 && bv0 + 7 < n;  // every lane holds a pair above the diagonal
+                if (whole) {
+                    // a row of the block -> lane dv = 0 of that row
+                    uint32_t x = r | ((uint32_t)__shfl_down((int)r, 1) << 8);
+                    x |= (uint32_t)__shfl_down((int)x, 2) << 16;
+                    const uint32_t xh = (uint32_t)__shfl_down((int)x, 4);
+                    // a column of the block (the mirrored copy's row piece) -> lane di = 0 of that column
+                    uint32_t y = rt | ((uint32_t)__shfl_down((int)rt, 8) << 8);
+                    y |= (uint32_t)__shfl_down((int)y, 16) << 16;
+                    const uint32_t yh = (uint32_t)__shfl_down((int)y, 32);
+                    if (dv == 0) *reinterpret_cast<uint2 *>(&A[8 * si + di][8 * sv]) = make_uint2(x, xh);
+                    if (di == 0) *reinterpret_cast<uint2 *>(&B[8 * sv + dv][8 * si]) = make_uint2(y, yh);
+                } else if (valid) {
+                    A[8 * si + di][8 * sv + dv] = (uint8_t)r;
+                    B[8 * sv + dv][8 * si + di] = (uint8_t)rt;  // (the same cell when i == v: the mirrored value stays)
+                }
+            }
+            __syncthreads();
+            // out: region A = rows i0 .., columns v0 ..; region B (tiles off the diagonal) = rows v0 .., columns i0 ..: threads 0 .. 255 take A,
+            // the others B, thread = (row, 16-byte piece)
+            for (int reg = threadIdx.x >> 8; reg < 2; reg += kUmiTileThreads / 256) {
+                const int row = (threadIdx.x & 255) >> 2, piece = threadIdx.x & 3;
+                const uint64_t rr = (reg ? v0 : i0) + row, c0 = (reg ? i0 : v0) + 16 * piece, c_end = min((reg ? i0 : v0) + (uint64_t)kUmiTile, n);
+                if (!(reg == 1 && bi == bv) && rr < n && c0 < c_end) {
+                    const uint8_t *src = &stage[reg][row][16 * piece];
+                    uint8_t *dst = m + rr * n + c0;
+                    if (c0 + 16 <= c_end) {
+                        uint4 q = *reinterpret_cast<const uint4 *>(src);
+                        __builtin_memcpy(dst, &q, 16);
+                    } else
+                        for (int k = 0; k < (int)(c_end - c0); k++) dst[k] = src[k];
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
                     const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s) {
-    if (!total_pairs) return SMI_OK;
-    const unsigned grid = (unsigned)std::min<uint64_t>((total_pairs + 255) / 256, 256ull * 64);
+    (void)d_pair_off;  // (the flat index space of round 1; the two kernels take theirs from the plan below)
+    if (!total_pairs || !n_groups) return SMI_OK;
+    // plan: per group its pairs in the flat kernel or its tiles in the tiled one, prefix sums of both in one scan
+    size_t cub_bytes = 0;
+    SMI_HIP(hipcub::DeviceScan::ExclusiveScan(nullptr, cub_bytes, (UmiPlan *)nullptr, (UmiPlan *)nullptr, UmiPlanAdd(), UmiPlan{0, 0}, (int)n_groups + 1, s));
+    const size_t arr = (((size_t)n_groups + 1) * sizeof(UmiPlan) + 255) & ~(size_t)255;
+    const size_t need = 2 * arr + 256 + cub_bytes;
+    if (ctx->umi_plan_bytes < need) {
+        if (ctx->umi_plan) (void)hipFree(ctx->umi_plan);
+        ctx->umi_plan = nullptr;
+        ctx->umi_plan_bytes = 0;
+        SMI_HIP(hipMalloc(&ctx->umi_plan, need + need / 4));
+        ctx->umi_plan_bytes = need + need / 4;
+    }
+    char *base = static_cast<char *>(ctx->umi_plan);
+    UmiPlan *d_cnt = reinterpret_cast<UmiPlan *>(base), *d_plan = reinterpret_cast<UmiPlan *>(base + arr);
+    uint32_t *d_next = reinterpret_cast<uint32_t *>(base + 2 * arr);
     if (int rc = time_begin(ctx, SMI_K_UMI, s)) return rc;
-    hipLaunchKernelGGL(k_umi_dist, dim3(grid), dim3(256), 0, s, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups,
-                       total_pairs, d_out);
+    SMI_HIP(hipMemsetAsync(d_next, 0, 4, s));
+    hipLaunchKernelGGL(k_umi_plan, dim3((n_groups + 1 + 255) / 256), dim3(256), 0, s, d_group_off, n_groups, d_cnt);
+    SMI_HIP(hipcub::DeviceScan::ExclusiveScan(base + 2 * arr + 256, cub_bytes, d_cnt, d_plan, UmiPlanAdd(), UmiPlan{0, 0}, (int)n_groups + 1, s));
+    // the grids from what the host knows: all pairs bound the flat kernel's; a tiled group has at least 2,145 pairs per macro-tile (65 reads)
+    const unsigned grid = (unsigned)std::min<uint64_t>((total_pairs + 255) / 256, 256ull * 64);
+    const unsigned grid_t = (unsigned)std::min<uint64_t>(total_pairs / 2145 + 1, 256ull * 2048 / kUmiTileThreads);
+    hipLaunchKernelGGL(k_umi_dist, dim3(grid), dim3(256), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_out);
+    hipLaunchKernelGGL(k_umi_dist_tiles, dim3(grid_t), dim3(kUmiTileThreads), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_next, d_out);
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_UMI, s)) return rc;
     return SMI_OK;

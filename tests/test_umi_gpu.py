@@ -36,7 +36,9 @@ def _pack(ws):
     return out
 
 
-@pytest.mark.parametrize("sizes", [[2, 3, 1, 7, 64, 5, 130, 2, 2, 33], [400], [1] * 50 + [2] * 300])
+# (groups above 64 reads are computed tile by tile, 8 x 8 blocks with 8-byte stores where a block is whole: sizes on both sides of every edge)
+@pytest.mark.parametrize("sizes", [[2, 3, 1, 7, 64, 5, 130, 2, 2, 33], [400], [1] * 50 + [2] * 300,
+                                   [65, 3, 66, 71, 72, 73, 1, 127, 128, 129, 64, 63, 191, 192, 193], [257, 2, 321]])
 def test_umi_matrices_match_oracle(pkg, sor, gpu_ctx, sizes):
     ws = _make_groups(len(sizes), sizes)
     go, po, mo = gpu_ctx.umi_offsets(sizes)

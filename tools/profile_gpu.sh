@@ -21,6 +21,6 @@ for grp in "${GROUPS_[@]}"; do
 done
 cd "$ROOT"
 python3 tools/pmc_aggregate.py "$OUT" "$ROOT/gpurun_out/summary_$TAG" "$TAG"
-tail -2 "$OUT"/bench_trace.log "$OUT"/pmc_FETCH_SIZE.log
+tail -n 2 "$OUT"/bench_trace.log "$OUT"/pmc_FETCH_SIZE.log
 # raw per-dispatch CSVs are large (torch kernel names): keep the summaries only
 find "$OUT" -name "*.csv" -size +1M -delete
