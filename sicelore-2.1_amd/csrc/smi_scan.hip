@@ -34,6 +34,15 @@ constexpr int kBlock = 256;
 #define SMI_SCAN_WAVES 4  // waves per SIMD the register allocation of K-SCAN is held to (LDS: 40 KiB per block)
 #endif
 
+// SMI_SCAN_ABLATE's switches are compiled into measurement builds only.  (They used to be run-time tests of a field that is 0 in the shipped
+// library; two more of them -- uniform, never taken -- made the 22-mer kernel lose the records of reads with no side chosen: a kernel at 128
+// VGPRs with spilled SGPRs is not the place for code that does nothing.)
+#ifdef SMI_MEASURE
+#define SMI_ABLATED(bit) ((P.ablate & (bit)) != 0)
+#else
+#define SMI_ABLATED(bit) false
+#endif
+
 struct ScanParams {
     int min_read_length;
     int polya_len;       // 15
@@ -48,7 +57,8 @@ struct ScanParams {
     __host__ __device__ __forceinline__ uint32_t a4(int i) const { return (adapter_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
-    int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates, 16 no TSO pre-filter (results unchanged)
+    int finder_bits;     // the bit-parallel polyT finder applies (polya_len 15, thresholds 12 / 10, window <= 160); the generic kernels keep the loop
+    int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates, 16 no TSO pre-filter (results unchanged), 32 finder: first loop only, 64 no adapter gates, 128 no folds
 };
 
 // ---- LDS plane access -----------------------------------------------------------------------------------------
@@ -116,6 +126,13 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *planes, int tid, cons
         pos += rest ? __builtin_ctz(rest) : 30;
     }
     if (first < 0) return false;
+#ifdef SMI_MEASURE
+    if (SMI_ABLATED(32)) {  // timing only: the first loop alone
+        begin1 = first + 1;
+        end1 = first + ML;
+        return true;
+    }
+#endif
     // From here on the walk stays around the run, so the exact-T bits are read through a 64-bit register window (two
     // 64-bit plane fetches per refill) instead of two plane fetches per look.
     int wbase = 0;
@@ -147,6 +164,142 @@ __device__ __forceinline__ bool find_polyt(const uint32_t *planes, int tid, cons
     while (n > endpos + 6 && __popc(look(endpos + 1, false) & 31u) > 3) endpos += 5;  // L145-147
     while (n > endpos + 4 && __popc(look(endpos + 1, false) & 7u) > 1) endpos += 3;   // L156-158
     while (endpos < n - 1 && (look(endpos + 1, false) & 1u)) endpos++;                // L171-172
+    begin1 = first + 1;
+    end1 = endpos + 1;
+    return true;
+}
+
+// ---- the same finder, bit-parallel over positions (round 4) ----------------------------------------------------------------------------------
+// The loop above costs a wave 1,620 VALU instructions of K-SCAN's 6,480 (profiles/r04/k_scan_budget.json): ~ 16 turns of a loop whose body
+// fetches two planes at a run-time offset, for the 32 ends of a wave that have no polyT at all, then the increments of the extension one
+// probe at a time.  Everything it asks is a window count over the exact-T bits, and those can be had for ALL positions at once: the lane
+// keeps its 224 exact-T bits in seven registers, adds five shifted copies with bit-sliced adders (the number of T's in [q, q + 5) for every
+// q: three planes), three shifted copies of that sum (T's in [q, q + 15): four planes), and the loop's conditions become masks:
+//     entry(pos)  = T[pos] & (>= 3 T's in [pos, pos + 5)) & (>= thr_first T's in [pos + 1, pos + 16))        first = lowest set bit below `window`
+//     go(p)       = p < window & (>= thr_adv T's in [p + 1, p + 16))                                          the extension's probe
+//     back(e)     = T[e] & T[e - 1] & (two of T[e - 2], T[e - 3], T[e - 4])                                   the walk back: highest set bit <= end
+// (back: with T[e] and T[e - 1] set, ">= 3 T's in the last four" is "one of T[e-2], T[e-3]", ">= 4 in the last five" is "two of T[e-2 .. e-4]",
+// which implies it.)  For polya_len = 15 with the thresholds 12 and 10 the shipped fractions give; anything else takes the loop above.
+// The generic kernels keep the loop, so the parity suite (shipped against generic against the oracle) compares the two finders as well.
+__device__ __forceinline__ void full_add(uint32_t a, uint32_t b, uint32_t c, uint32_t &sum, uint32_t &carry) {
+    sum = a ^ b ^ c;
+    carry = (a & b) | (c & (a ^ b));
+}
+// 64 bits from bit position p of a 192-bit mask kept in the lane's own three 64-bit slots of the candidate-mask area ([slot][lane]: the four
+// waves of a block run independently, so a lane may only touch the columns of its own wave); bits past the mask read as 0
+__device__ __forceinline__ uint64_t mask64(const uint64_t *m, int tid, int p) {
+    const int q = p >> 6, sh = p & 63;
+    const uint64_t a = q < 3 ? m[q * kBlock + tid] : 0ull, b = q + 1 < 3 ? m[(q + 1) * kBlock + tid] : 0ull;
+    uint64_t r = a >> sh;
+    if (sh) r |= b << (64 - sh);
+    return r;
+}
+__device__ __forceinline__ bool find_polyt_bits(const uint32_t *planes, uint64_t *go_lds, int tid, const ScanParams &P, const uint32_t (&tw)[8], int &begin1,
+                                                int &end1) {
+    constexpr int ML = 15;
+    const int n = P.window + ML + 10;
+    // T's in [q, q + 5) for every q: planes c5[0..2], seven words (the eighth reads as 0)
+    uint32_t c5[3][8];
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        const uint32_t s1 = __builtin_amdgcn_alignbit(tw[k + 1], tw[k], 1), s2 = __builtin_amdgcn_alignbit(tw[k + 1], tw[k], 2),
+                       s3 = __builtin_amdgcn_alignbit(tw[k + 1], tw[k], 3), s4 = __builtin_amdgcn_alignbit(tw[k + 1], tw[k], 4);
+        uint32_t x, k1, k2;
+        full_add(tw[k], s1, s2, x, k1);
+        full_add(x, s3, s4, c5[0][k], k2);
+        c5[1][k] = k1 ^ k2;
+        c5[2][k] = k1 & k2;
+    }
+    c5[0][7] = c5[1][7] = c5[2][7] = 0u;
+    // T's in [q, q + 15) = the three five-counts at q, q + 5, q + 10: >= 12 and >= 10 as masks, six words (+ a zero word)
+    uint32_t ge12[7], ge10[7];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        uint32_t b[3], c[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            b[j] = __builtin_amdgcn_alignbit(c5[j][k + 1], c5[j][k], 5);
+            c[j] = __builtin_amdgcn_alignbit(c5[j][k + 1], c5[j][k], 10);
+        }
+        uint32_t r0, k0, t1, k1a, t2, k2a, r2, k2b;
+        full_add(c5[0][k], b[0], c[0], r0, k0);
+        full_add(c5[1][k], b[1], c[1], t1, k1a);
+        const uint32_t r1 = t1 ^ k0, k1b = t1 & k0;
+        full_add(c5[2][k], b[2], c[2], t2, k2a);
+        full_add(t2, k1a, k1b, r2, k2b);
+        const uint32_t r3 = k2a | k2b;  // (the count is at most 15: the two carries never come together)
+        (void)r0;
+        ge12[k] = r3 & r2;
+        ge10[k] = r3 & (r2 | r1);
+    }
+    ge12[6] = ge10[6] = 0u;
+    // entry positions; the extension's probe mask goes to LDS (it is read at run-time offsets)
+    int first = -1;
+    uint32_t gom[6];
+#pragma unroll
+    for (int k = 5; k >= 0; k--) {
+        const int keep = P.window - 32 * k;  // positions below `window` (uniform)
+        const uint32_t below = keep >= 32 ? 0xFFFFFFFFu : (keep <= 0 ? 0u : ((1u << keep) - 1u));
+        const uint32_t entry = __builtin_amdgcn_alignbit(ge12[k + 1], ge12[k], 1) & tw[k] & (c5[2][k] | (c5[1][k] & c5[0][k])) & below;
+        gom[k] = __builtin_amdgcn_alignbit(ge10[k + 1], ge10[k], 1) & below;
+        if (entry) first = 32 * k + __builtin_ctz(entry);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) go_lds[q * kBlock + tid] = ((uint64_t)gom[2 * q + 1] << 32) | gom[2 * q];
+    if (first < 0) return false;
+    int start = first;
+    {
+        int wbase = first;
+        uint64_t gw = mask64(go_lds, tid, first);
+        auto go = [&](int p) -> bool {  // start <= p <= start + 20, and start only grows: the window is taken from `start`
+            if (p >= wbase + 64) {
+                wbase = start;
+                gw = mask64(go_lds, tid, start);
+            }
+            return (gw >> (p - wbase)) & 1ull;
+        };
+        const int INC[8] = {20, 15, 10, 5, 4, 3, 2, 1};  // L223-230
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            while (go(start + INC[k])) start += INC[k];
+    }
+    int endpos = start + ML - 1;  // L231
+    {
+        // lambda$findpolyAT$3 L122-142: the last position <= endpos (and > 4) that passes; 4 when there is none
+        int e = 4;
+        bool found = false;
+#pragma unroll
+        for (int k = 5; k >= 0; k--) {
+            const uint32_t lo = k ? tw[k - 1] : 0u;
+            const uint32_t l1 = __builtin_amdgcn_alignbit(tw[k], lo, 31), l2 = __builtin_amdgcn_alignbit(tw[k], lo, 30), l3 = __builtin_amdgcn_alignbit(tw[k], lo, 29),
+                           l4 = __builtin_amdgcn_alignbit(tw[k], lo, 28);
+            uint32_t back = tw[k] & l1 & ((l2 & l3) | (l4 & (l2 ^ l3)));
+            if (k == 0) back &= ~31u;
+            const int rel = endpos - 32 * k;
+            const uint32_t upto = rel >= 31 ? 0xFFFFFFFFu : (rel < 0 ? 0u : ((2u << rel) - 1u));
+            back &= upto;
+            if (!found && back) {
+                e = 32 * k + 31 - __builtin_clz(back);
+                found = true;
+            }
+        }
+        endpos = e;
+    }
+    // the three forward steps look at a handful of positions: the exact-T bits through a 64-bit register window, as in the loop above
+    int wbase = 0;
+    uint64_t wbits = 0;
+    auto look = [&](int p) -> uint32_t {  // 32 exact-T bits from position p on
+        if (p < wbase || p + 32 > wbase + 64) {
+            wbase = p;
+            wbits = get64(planes + 3 * kLdsWords * kBlock, tid, p) & ~get64(planes, tid, p);
+        }
+        return (uint32_t)(wbits >> (p - wbase));
+    };
+    wbase = endpos + 1;
+    wbits = get64(planes + 3 * kLdsWords * kBlock, tid, wbase) & ~get64(planes, tid, wbase);
+    while (n > endpos + 6 && __popc(look(endpos + 1) & 31u) > 3) endpos += 5;  // L145-147
+    while (n > endpos + 4 && __popc(look(endpos + 1) & 7u) > 1) endpos += 3;   // L156-158
+    while (endpos < n - 1 && (look(endpos + 1) & 1u)) endpos++;                // L171-172
     begin1 = first + 1;
     end1 = endpos + 1;
     return true;
@@ -249,15 +402,26 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
         const size_t read = e >> 1;
         const int side = (int)(e & 1);  // 0 = head (forward scan), 1 = reverse-complemented tail
         // ---- phase A ---------------------------------------------------------------------------------------
+        uint32_t tw[8];  // exact T (the T plane without the A plane) of the lane's end: the bit-parallel finder works on these registers
+        {
+            uint32_t pa[kLdsWords];
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+            for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int w = 0; w < kLdsWords; w++)
-                planes[(c * kLdsWords + w) * kBlock + tid] = active ? ends[(size_t)(c * kPlaneWords + w) * n_ends + e] : 0u;
+                for (int w = 0; w < kLdsWords; w++) {
+                    const uint32_t v = active ? ends[(size_t)(c * kPlaneWords + w) * n_ends + e] : 0u;
+                    planes[(c * kLdsWords + w) * kBlock + tid] = v;
+                    if (c == 0) pa[w] = v;
+                    if (c == 3) tw[w] = v & ~pa[w];
+                }
+            tw[7] = 0u;
+        }
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         int pb = 0, pe = 0;
-        const bool has_t = active && long_enough && !(FP && P.dont_polya) && !(P.ablate & 4) && find_polyt(planes, tid, P, pb, pe);
+        bool has_t = false;
+        if (active && long_enough && !(FP && P.dont_polya) && !SMI_ABLATED(4))
+            has_t = (SHIP && P.finder_bits) ? find_polyt_bits(planes, cmask, tid, P, tw, pb, pe) : find_polyt(planes, tid, P, pb, pe);
         uint64_t am[3] = {0, 0, 0};
         // 5' barcoding scans an end when the polyT was found at the OTHER end (or no polyA is asked for):
         // PolyATadapterAnalyzer_5pBCUMI.java:L51-68
@@ -268,7 +432,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
             const int last = FP ? P.window5 : min(pe - AD, pe - 12);
 #pragma unroll
             for (int ch = 0; ch < 3; ch++)
-                if (last > ch * 64)  // (the third chunk is needed by the few ends whose polyT ends beyond position 138: most waves skip it)
+                if (last > ch * 64 && !SMI_ABLATED(64))  // (the third chunk is needed by the few ends whose polyT ends beyond position 138: most waves skip it)
                     am[ch] = keep_low(gate64<AD>(planes, tid, ch * 64, [&](int i) { return SHIP ? shipped_a4<AD>(i) : P.a4(i); }), last - ch * 64);
         }
         const int n_ad = __popcll(am[0]) + __popcll(am[1]) + __popcll(am[2]);
@@ -301,13 +465,13 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 cmask[2 * kBlock + tid] = am[2];
             } else {
                 uint64_t tm[2] = {0, 0};
-                if (active && long_enough && !FP && !(P.ablate & 8)) {
+                if (active && long_enough && !FP && !SMI_ABLATED(8)) {
                     // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++)
                         tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
                 }
-                if (SHIP && !(P.ablate & 16)) {
+                if (SHIP && !SMI_ABLATED(16)) {
                     // Exact pre-filter of the ISOLATED TSO candidates.  A candidate's alignment matters in two ways only: it may be
                     // accepted (Math.round(ne) <= 5, AdapterTSOanalyzer L96-104), or its error count makes the scan jump over the next
                     // candidates (delta = round(ne - 5) - 1 <= 26: an alignment of two 16-mers has at most 32 columns).  A candidate
@@ -418,12 +582,12 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                     auto col_of = [&](uint32_t a4) -> uint32_t {
                         return ((a4 & 1u) ? W[0] : 0u) | ((a4 & 2u) ? W[1] : 0u) | ((a4 & 4u) ? W[2] : 0u) | ((a4 & 8u) ? W[3] : 0u);
                     };
-                    if (kind == 0 && !(P.ablate & 2)) {
+                    if (kind == 0 && !SMI_ABLATED(2)) {
                         uint32_t col[AD];
 #pragma unroll
                         for (int c = 0; c < AD; c++) col[c] = col_of(SHIP ? shipped_a4<AD>(c) : P.a4(c)) & ((1u << AD) - 1u);
                         nw_full<AD, true, false, kBandAd>(col, P.min_3p, st);  // the adapter fold reads ne, nmis, ins, del, end5, endn, term6
-                    } else if (kind == 1 && !(P.ablate & 1)) {
+                    } else if (kind == 1 && !SMI_ABLATED(1)) {
                         uint32_t col[16];
 #pragma unroll
                         for (int c = 0; c < 16; c++) col[c] = col_of(tso4(c)) & 0xFFFFu;
@@ -439,7 +603,7 @@ __global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t 
                 }
                 wave_sync();
                 // owners fold their entries of this tile, in scan order
-                const int f0 = max(my_off, base), f1 = min(my_off + my_n, base + 64);
+                const int f0 = max(my_off, base), f1 = SMI_ABLATED(128) ? f0 : min(my_off + my_n, base + 64);
                 for (int x = f0; x < f1; x++) {
                     const uint32_t *o = ent + (wbase + x - base) * 5;
                     const float ne = __uint_as_float(o[0]);
@@ -723,6 +887,8 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     for (int i = 0; i < 22 && i < ad; i++) P.adapter_nib[i >> 3] |= (cfg->adapter4[i] & 15u) << ((i & 7) * 4);
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
+    // the bit-parallel finder is built for the shipped window length and the thresholds the shipped fractions give; SMI_SCAN_FINDER_LOOP: cross-check switch
+    P.finder_bits = cfg->polya_len == 15 && P.thr_first == 12 && P.thr_adv == 10 && cfg->window_polya >= 1 && cfg->window_polya <= 160 && !std::getenv("SMI_SCAN_FINDER_LOOP");
     // SMI_SCAN_ABLATE switches parts of the kernel off to time them (tools/gpu_scan_ablate.sh): the results are wrong by construction, so
     // only a measurement build (make MEASURE=1 -> -DSMI_MEASURE) honours it; the shipped library refuses to run with it set
     const char *abl = std::getenv("SMI_SCAN_ABLATE");

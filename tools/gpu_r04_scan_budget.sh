@@ -9,7 +9,7 @@ mkdir -p gpurun_out/scanb
 export SMI_LIBRARY=$ROOT/sicelore-2.1_amd/csrc/libsicelore_mi_measure.so
 OFF="--steps 3 --warmup 1 --no-cpu-baseline --two-pass-reads 0 --e2e-reads 0 --umi-molecules 0 --h2h-reads 0 --f2f-reads 0 --assignumis-file-records 0"
 cd /tmp
-for a in 0 1 2 4 8 16 9 15; do
+for a in ${ABLATES:-0 1 2 4 8 16 9 15}; do
   export SMI_SCAN_ABLATE=$a
   rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/scanb/t$a" -- python3 $ROOT/bench.py $OFF > "$ROOT/gpurun_out/scanb/t$a.log" 2>&1
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d "$ROOT/gpurun_out/scanb/p$a" -- python3 $ROOT/bench.py $OFF > "$ROOT/gpurun_out/scanb/p$a.log" 2>&1
@@ -19,7 +19,8 @@ cd "$ROOT"
 python3 - <<'PY'
 import csv, glob, json
 out = {}
-for a in (0, 1, 2, 4, 8, 16, 9, 15):
+import os
+for a in [int(x) for x in os.environ.get("ABLATES", "0 1 2 4 8 16 9 15").split()]:
     e = {}
     for f in glob.glob(f"gpurun_out/scanb/t{a}/**/*kernel_stats.csv", recursive=True):
         for row in csv.DictReader(open(f)):
