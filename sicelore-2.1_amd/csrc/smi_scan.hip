@@ -33,6 +33,14 @@ constexpr int kBlock = 256;
 #ifndef SMI_SCAN_WAVES
 #define SMI_SCAN_WAVES 4  // waves per SIMD the register allocation of K-SCAN is held to (LDS: 40 KiB per block)
 #endif
+// ... for the kernels of the shipped 10-mer (pass 2: the 3' one keeps one loop-invariant value in scratch, stored in the prologue).  The others get
+// the registers they need to hold everything: at 128 VGPRs the 22-mer kernels spill 13 - 47 values, and a value spilled INSIDE a divergent region is
+// stored for the lanes active there only -- a lane that sat the region out reads back whatever its scratch slot held.  That is how two never-taken
+// branches made the 22-mer kernel drop the records of reads with no side chosen (the even lane's `side` and `read` came back from scratch: NOTES R4.5).
+template <int AD, bool SHIP>
+constexpr int scan_waves() {
+    return SHIP ? (AD == 10 ? SMI_SCAN_WAVES : 3) : 2;
+}
 
 // SMI_SCAN_ABLATE's switches are compiled into measurement builds only.  (They used to be run-time tests of a field that is 0 in the shipped
 // library; two more of them -- uniform, never taken -- made the 22-mer kernel lose the records of reads with no side chosen: a kernel at 128
@@ -381,7 +389,7 @@ __device__ __forceinline__ int wave_exscan(int v, int lane, int &total) {
 //                         writes the record and the barcode window
 // ---------------------------------------------------------------------------------------------------------------
 template <int AD, bool FP, bool SHIP>
-__global__ __launch_bounds__(kBlock, SMI_SCAN_WAVES) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
+__global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const uint32_t *__restrict__ ends, const int32_t *__restrict__ read_len,
                                                  const uint8_t *__restrict__ qtail, const uint32_t *__restrict__ qsum,
                                                  size_t n_reads, ScanParams P, smi_scan_result *__restrict__ out,
                                                  smi_bc_window *__restrict__ windows) {
