@@ -695,8 +695,11 @@ struct TsoSlot {
 #ifndef SMI_CHIM_C_WAVES
 #define SMI_CHIM_C_WAVES 4  // waves per SIMD K-CHIM-C is held to
 #endif
+// The first-generation kernel (today: the second-chance path and the cross-check reference) is held to two waves per SIMD, its TSO part to one: at 128 VGPRs it spilled
+// a hundred values, and a VGPR spilled inside a divergent region is saved for the lanes active there only (NOTES R4.5) -- room to keep everything
+// in registers is worth more here than occupancy.
 template <int kTsoLen, int kAdLen, int PART>
-__global__ __launch_bounds__(256, PART == 1 ? SMI_CHIM_B_WAVES : SMI_CHIM_C_WAVES) void k_chimera(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
+__global__ __launch_bounds__(256, PART == 1 ? 1 : 2) void k_chimera(const uint32_t *__restrict__ planes, size_t stride, const uint32_t *__restrict__ pstart,
                                                                    const uint64_t *__restrict__ offsets,
                                                                    const uint32_t *__restrict__ list,
                                                                    const uint32_t *__restrict__ list_count, ChimParams P,
