@@ -2,7 +2,8 @@
 # round 4: the traces and counters the bench line cites, on the build it describes
 #   profiles/r04/step_*      the timed step alone (K-SCAN + K-BC1, 10 M reads, every side leg off): kernel trace + counters
 #   profiles/r04/chimera_*   the splitter's microbench leg (0.9 M reads): kernel trace + counters
-#   profiles/r04/e2e_*       the bench's end-to-end leg alone: kernel trace
+#   profiles/r04/umi_*       K-UMI's microbench leg: kernel trace + counters
+#   profiles/r04/e2e_*       the bench's end-to-end leg alone: kernel trace, timeline, traffic counters
 set -u
 ulimit -c 0
 mkdir -p gpurun_out
@@ -11,22 +12,35 @@ PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IN
   timeout -k 10 900 bash tools/profile_gpu.sh r04step --steps 5 --warmup 2 $OFF 2>&1 | tail -3
 PROFILE_PROG=$PWD/tools/microbench.py PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES;SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU" \
   timeout -k 10 900 bash tools/profile_gpu.sh r04chimera chimera 2>&1 | tail -3
+# K-UMI: the microbench leg, kernel trace + write counters -> gpurun_out/summary_r04umi/
+PROFILE_PROG=$PWD/tools/microbench.py PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+  timeout -k 10 900 bash tools/profile_gpu.sh r04umi umi 2>&1 | tail -n 3 | cut -c1-400
+timeout -k 10 300 python tools/microbench.py umi > gpurun_out/microbench_umi.json 2> gpurun_out/microbench_umi.err; echo "umi mb rc=$?"
+# the end-to-end leg alone: kernel trace + timeline, then FETCH_SIZE / WRITE_SIZE per kernel
+bash tools/gpu_r04_part.sh e2e
 export TMPDIR=/tmp
 ROOT=$(pwd)
-cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/gpurun_out/prof_e2e" -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --two-pass-reads 0 $OFF > "$ROOT/gpurun_out/prof_e2e.log" 2>&1
-cd "$ROOT"
-f=$(find gpurun_out/prof_e2e -name "*kernel_stats.csv" | head -1)
-(head -1 "$f"; grep "smi::" "$f") > gpurun_out/e2e_kernel_stats.csv
-python3 tools/e2e_timeline.py gpurun_out/prof_e2e gpurun_out/e2e_timeline.json
-find gpurun_out/prof_e2e -name "*.csv" -size +1M -delete
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d "$ROOT/gpurun_out/prof_e2e_pmc/$c" -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --two-pass-reads 0 $OFF > "$ROOT/gpurun_out/prof_e2e_pmc_$c.log" 2>&1) || echo "pass $c failed"
+done
 python3 - <<'PY'
-import csv
-for row in csv.DictReader(open("gpurun_out/e2e_kernel_stats.csv")):
-    nm = row["Name"].split("(")[0][-44:]
-    print(f'{nm:46s} calls {row["Calls"]:>3s} avg {float(row["AverageNs"])/1e6:7.3f} min {float(row["MinNs"])/1e6:7.3f} ms')
+import csv, glob, json, collections
+res = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob(f"gpurun_out/prof_e2e_pmc/{c}/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != c or "smi::" not in r["Kernel_Name"]:
+                continue
+            nm = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("smi::", "")
+            acc[nm].append(float(r["Counter_Value"]))
+    for nm, v in acc.items():
+        v = v[len(v) // 2:]     # the later dispatches: the timed repetitions
+        res[nm][c + "_KB_per_launch"] = sum(v) / len(v)
+        res[nm]["launches"] = len(v)
+json.dump(res, open("gpurun_out/e2e_pmc.json", "w"), indent=1)
 PY
-tail -c 1500 gpurun_out/prof_e2e.log | grep -o '"end_to_end": {.*' | cut -c1-1200
+find gpurun_out/prof_e2e_pmc -name "*.csv" -size +1M -delete
 # the device clusterer of large UMI groups: one 8,000-read group, device against host
 SMI_AU_TIMING=1 timeout -k 10 300 python tools/own_cluster_bench.py 8000 > gpurun_out/own_cluster_8000.json 2> gpurun_out/own_cluster_8000.err; echo "own rc=$?"; cat gpurun_out/own_cluster_8000.json
 # the splitter's microbench line itself (no profiler attached)
