@@ -165,9 +165,28 @@ UMI_REFUSED = {o: why for opts, why in (
     for o in opts}
 
 
+def _join_ranks():
+    """Started once per GPU (torchrun / torch.distributed.run: WORLD_SIZE, RANK, LOCAL_RANK, MASTER_* in the environment), the command joins the
+    process group: `scanfastq` then deals the files to the ranks and sums the pass-1 histogram over them, `assignumis` deals whole chromosomes
+    (run_files.py, assignumis.py).  Backend: RCCL ("nccl") with a GPU per rank; SMI_DIST_BACKEND=gloo for ranks that share a device."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return False
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return False
+    backend = os.environ.get("SMI_DIST_BACKEND") or ("nccl" if torch.cuda.device_count() >= int(os.environ.get("LOCAL_WORLD_SIZE", os.environ["WORLD_SIZE"])) else "gloo")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    dist.init_process_group(backend=backend)
+    return True
+
+
 def _context():
+    import torch
+
     from . import lib
-    return lib.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    return lib.Context(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
 
 
 def scanfastq(argv):
@@ -238,10 +257,14 @@ def main(argv=None):
             print(__doc__)
             return 0
         sub, rest = argv[0], argv[1:]
-        if sub == "scanfastq":
-            return scanfastq(rest)
-        if sub == "assignumis":
-            return assignumis(rest)
+        if sub in ("scanfastq", "assignumis"):
+            joined = _join_ranks()
+            try:
+                return scanfastq(rest) if sub == "scanfastq" else assignumis(rest)
+            finally:
+                if joined:
+                    import torch.distributed as dist
+                    dist.destroy_process_group()
         raise CliError(f"sub-command {sub!r}: this build has scanfastq and assignumis (tagbamwithread, mergestats, illuminaparser: SURVEY 2, out of scope)")
     except CliError as e:
         print(f"ERROR: {e}", file=sys.stderr)

@@ -42,9 +42,8 @@ def test_bai_extents_and_shard_plan(pkg):
     assert [s for s in five if s != (0, 0)] == three and len(five) == 5
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,meta", [(2, True), (3, False)])
-def test_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, world, meta):
+def _make_inputs(pkg, synth, gpu_ctx, tmp_path, meta):
+    """a three-chromosome BAM of names from a real pass 2 (+ four unmapped records), its .bai, a refFlat with twelve genes per chromosome"""
     scanfastq = importlib.import_module("sicelore_amd.scanfastq")
     assignumis = importlib.import_module("sicelore_amd.assignumis")
     rng = np.random.default_rng(71)
@@ -96,6 +95,14 @@ def test_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, worl
             for g in range(12):
                 a = 29_500 + 4_000 * g
                 f.write(f"G{c}_{g}\tT{c}_{g}\tchr{c + 1}\t+\t{a}\t{a + 3000}\t{a}\t{a + 3000}\t1\t{a},\t{a + 3000},\n")
+    return in_bam, refflat, rows, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,meta", [(2, True), (3, False)])
+def test_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, world, meta):
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    in_bam, refflat, rows, tail = _make_inputs(pkg, synth, gpu_ctx, tmp_path, meta)
     one = str(tmp_path / "one")
     a = assignumis.assignumis_stream(gpu_ctx, in_bam, one, segment_bytes=9_000, chunk_size=90, n_threads=2, refflat=open(refflat).read())
     many = str(tmp_path / "many")
@@ -120,3 +127,24 @@ def test_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, worl
     for name in (".genecounts.tsv", ".UMIdepths.tsv"):
         assert open(many + name).read() == open(one + name).read(), name
     assert a["clustered"] > 50 and open(one + ".genecounts.tsv").read().count("\n") > 10
+
+
+@pytest.mark.gpu
+def test_command_line_under_torchrun_equals_one_process(pkg, synth, gpu_ctx, tmp_path):
+    """the jar's `assignumis` line started once per rank (torch.distributed.run, two ranks on the box's one GPU, gloo): cli.py joins the process
+    group it finds in the environment, the ranks take their chromosomes, rank 0 leaves the files one process leaves"""
+    in_bam, refflat, rows, tail = _make_inputs(pkg, synth, gpu_ctx, tmp_path, True)
+    pkg_dir = os.path.join(ROOT, "sicelore-2.1_amd")
+    args = ["assignumis", "--inFileNanopore", in_bam, "--annotationFile", refflat]
+    env = dict(os.environ, OMP_NUM_THREADS="2", SMI_DIST_BACKEND="gloo")
+    one = subprocess.run([sys.executable, pkg_dir] + args + ["-o", str(tmp_path / "cli_one.bam")], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                          pkg_dir] + args + ["-o", str(tmp_path / "cli_two.bam")], capture_output=True, text=True, timeout=600, cwd=str(tmp_path), env=env)
+    assert two.returncode == 0, two.stderr[-3000:]
+    for suffix in (".bam", "_umifound_.bam"):
+        a, b = (bammodel.bgzf_decompress(open(str(tmp_path / f"cli_{k}") + suffix, "rb").read()) for k in ("one", "two"))
+        assert a == b and len(a) > 10_000, suffix
+    for suffix in (".genecounts.tsv", ".UMIdepths.tsv"):
+        assert open(str(tmp_path / "cli_one") + suffix).read() == open(str(tmp_path / "cli_two") + suffix).read(), suffix
+    assert not any(".shard" in f for f in os.listdir(tmp_path))
