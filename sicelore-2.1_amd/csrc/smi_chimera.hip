@@ -2768,8 +2768,12 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
     }
     // the queue length decides the size of the hand-over slots (one small copy + sync per launch)
     uint32_t n_list = 0;
-    SMI_HIP(hipMemcpyAsync(&n_list, d_count, 4, hipMemcpyDeviceToHost, s));
-    SMI_HIP(hipStreamSynchronize(s));
+    {
+        uint32_t *pw = static_cast<uint32_t *>(pin_words(ctx));
+        SMI_HIP(hipMemcpyAsync(pw ? pw : &n_list, d_count, 4, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        if (pw) n_list = *pw;
+    }
 #ifdef SMI_MEASURE
     if (getenv("SMI_CHIM_STATS")) {  // how many reads K-CHIM-A queues, and for what
         std::vector<smi_chimera_result> h(n);
@@ -2902,8 +2906,12 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
             uint32_t *d_over_count = d_count + 1, *d_over = d_list + n;
             { hipLaunchKernelGGL(k_collect_overflow, dim3(64), dim3(256), 0, s, d_out, d_list, d_count, d_over, d_over_count); SMI_CHIM_CHECK("k_collect_overflow"); }
             uint32_t n_over = 0;
-            SMI_HIP(hipMemcpyAsync(&n_over, d_over_count, 4, hipMemcpyDeviceToHost, s));
-            SMI_HIP(hipStreamSynchronize(s));
+            {
+                uint32_t *pw = static_cast<uint32_t *>(pin_words(ctx));
+                SMI_HIP(hipMemcpyAsync(pw ? pw : &n_over, d_over_count, 4, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipStreamSynchronize(s));
+                if (pw) n_over = *pw;
+            }
 #ifdef SMI_MEASURE
             if (getenv("SMI_CHIM_STATS")) {
                 uint32_t h[16];

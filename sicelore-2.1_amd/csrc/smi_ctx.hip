@@ -49,6 +49,11 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     return p;
 }
 
+void *pin_words(smi_ctx *ctx) {
+    if (!ctx->pin_words && hipHostMalloc(&ctx->pin_words, 4096, hipHostMallocDefault) != hipSuccess) ctx->pin_words = nullptr;
+    return ctx->pin_words;
+}
+
 int ensure_host_buf(smi_ctx *ctx, int which, size_t bytes) {
     if (ctx->host_buf_bytes[which] >= bytes) return SMI_OK;
     if (ctx->host_buf[which]) SMI_HIP(hipHostFree(ctx->host_buf[which]));
@@ -234,6 +239,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
     (void)hipFree(ctx->chim_flat);
     (void)hipFree(ctx->umi_own);
     (void)hipFree(ctx->umi_plan);
+    if (ctx->pin_words) (void)hipHostFree(ctx->pin_words);
     (void)hipHostFree(ctx->host_out[0]);
     (void)hipHostFree(ctx->host_out[1]);
     for (void *hb : ctx->host_buf) (void)hipHostFree(hb);

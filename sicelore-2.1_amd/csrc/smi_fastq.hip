@@ -272,8 +272,12 @@ int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint
                        d_name_start, d_name_len, d_seq_start, d_seq_len, d_qual_start);
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_b, d_seq_len, d_offsets, (int)cap_records, s));
     FqTotals h;
-    SMI_HIP(hipMemcpyAsync(&h, d_tot, sizeof h, hipMemcpyDeviceToHost, s));
-    SMI_HIP(hipStreamSynchronize(s));
+    {
+        FqTotals *pw = static_cast<FqTotals *>(pin_words(ctx));
+        SMI_HIP(hipMemcpyAsync(pw ? pw : &h, d_tot, sizeof h, hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipStreamSynchronize(s));
+        if (pw) h = *pw;
+    }
     if (h.overflow & 1u) {
         set_error("smi_fastq_index_device: line buffer too small");
         return SMI_ERR_INVALID;

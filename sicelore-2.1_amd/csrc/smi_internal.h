@@ -153,6 +153,7 @@ struct smi_ctx {
     size_t chim_work_bytes = 0;
     void *umi_own = nullptr;       // ClusterOne_MyClustering on the device: index / count / sum scratch of one large group (grow-only)
     size_t umi_own_bytes = 0;
+    void *pin_words = nullptr;     // 4 KiB of page-locked host memory for read-backs of a few words (pin_words() in smi_ctx.hip)
     void *umi_plan = nullptr;      // K-UMI: per group its pairs in the flat kernel / tiles in the tiled one, and their prefix sums (grow-only)
     size_t umi_plan_bytes = 0;
     void *chim_flat = nullptr;     // K-CHIM-A second generation: owner of every plane word, gate / bound / trigger words, verdicts (grow-only)
@@ -226,6 +227,9 @@ __host__ __device__ inline size_t plane_start(uint64_t base_offset, size_t r) { 
 int launch_ends_from_planes(smi_ctx *ctx, const uint32_t *d_planes, size_t stride, const uint64_t *d_read_offsets, const uint64_t *d_rec_offsets,
                             const uint32_t *d_frag_src, size_t m, uint32_t *d_ends, int32_t *d_len, hipStream_t s, const uint32_t *d_pstart = nullptr);
 int ensure_host_buf(smi_ctx *ctx, int which, size_t bytes);
+// 4 KiB of page-locked host memory of the context for reading a few words back (a copy into pageable memory is staged by the runtime and
+// blocks for about twice as long); valid until the next call that uses it, i.e. read it before calling on -- nullptr if the allocation failed
+void *pin_words(smi_ctx *ctx);
 // smi_region_group from keys sorted on the device (smi_cluster.hip)
 int region_group_from_sorted(void **work, const uint64_t *keys, size_t n_pos, int32_t n, const uint64_t *has_bits, int32_t max_dist, int keep_data_end,
                              int32_t *region, int32_t *n_done);  // *work: scratch kept between calls (ctx->region_work)

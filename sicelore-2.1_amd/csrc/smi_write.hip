@@ -539,15 +539,18 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
                        d_failed, cap_failed, d_rec_off, d_err);
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipStreamWaitEvent(s, ctx->side_join, 0));
-    uint64_t h[3];
+    uint64_t h_stack[4];
+    uint64_t *h = static_cast<uint64_t *>(pin_words(ctx));  // (four words: page-locked, or the stack if there is none)
+    if (!h) h = h_stack;
     SMI_HIP(hipMemcpyAsync(&h[0], offp + n_out, 8, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&h[1], offf + n_out, 8, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&h[2], ordp + n_out, 8, hipMemcpyDeviceToHost, s));
-    SMI_HIP(hipMemcpyAsync(errors, d_err, 4, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipMemcpyAsync(&h[3], d_err, 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
     totals[0] = h[0];
     totals[1] = h[1];
     totals[2] = h[2];
+    *errors = (uint32_t)h[3];
     if (*errors) {
         set_error("smi_fastq_write_device: see *errors (SMI_WR_*)");
         return SMI_ERR_INVALID;
