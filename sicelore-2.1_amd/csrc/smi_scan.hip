@@ -65,7 +65,7 @@ struct ScanParams {
     __host__ __device__ __forceinline__ uint32_t a4(int i) const { return (adapter_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
-    int finder_bits;     // the bit-parallel polyT finder applies (polya_len 15, thresholds 12 / 10, window <= 160); the generic kernels keep the loop
+    int finder_bits;     // host side only: the bit-parallel polyT finder applies (polya_len 15, thresholds 12 / 10, window <= 160) -- otherwise the generic kernels run
     int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates, 16 no TSO pre-filter (results unchanged), 32 finder: first loop only, 64 no adapter gates, 128 no folds
 };
 
@@ -410,26 +410,30 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
         const size_t read = e >> 1;
         const int side = (int)(e & 1);  // 0 = head (forward scan), 1 = reverse-complemented tail
         // ---- phase A ---------------------------------------------------------------------------------------
-        uint32_t tw[8];  // exact T (the T plane without the A plane) of the lane's end: the bit-parallel finder works on these registers
-        {
-            uint32_t pa[kLdsWords];
 #pragma unroll
-            for (int c = 0; c < 4; c++)
+        for (int c = 0; c < 4; c++)
 #pragma unroll
-                for (int w = 0; w < kLdsWords; w++) {
-                    const uint32_t v = active ? ends[(size_t)(c * kPlaneWords + w) * n_ends + e] : 0u;
-                    planes[(c * kLdsWords + w) * kBlock + tid] = v;
-                    if (c == 0) pa[w] = v;
-                    if (c == 3) tw[w] = v & ~pa[w];
-                }
-            tw[7] = 0u;
-        }
+            for (int w = 0; w < kLdsWords; w++)
+                planes[(c * kLdsWords + w) * kBlock + tid] = active ? ends[(size_t)(c * kPlaneWords + w) * n_ends + e] : 0u;
         const int len = active ? read_len[read] : 0;
         const bool long_enough = len >= P.min_read_length;  // testReadLength L131-137
         int pb = 0, pe = 0;
         bool has_t = false;
-        if (active && long_enough && !(FP && P.dont_polya) && !SMI_ABLATED(4))
-            has_t = (SHIP && P.finder_bits) ? find_polyt_bits(planes, cmask, tid, P, tw, pb, pe) : find_polyt(planes, tid, P, pb, pe);
+        if (active && long_enough && !(FP && P.dont_polya) && !SMI_ABLATED(4)) {
+            if (SHIP) {  // (the kernels of the shipped adapters carry the bit-parallel finder only -- both finders inlined pushed the 5' kernel past 64 KB of code and cost it 13 %; launch_scan sends parameters it is not built for to the generic kernels)
+                // exact T (the T plane without the A plane) of the lane's end, read back from its LDS columns: only the path that runs the finder pays
+                // for them
+                // (the empty asm keeps the loads, and with them the branch-free front of the finder, INSIDE this branch: hoisted above it -- the compiler
+                // did -- they run for every wave of the 5' --noPolyARequired kernel, which never takes the branch: 1.44 -> 1.63 ms per 10 M reads)
+                asm volatile("" ::: "memory");
+                uint32_t tw[8];
+#pragma unroll
+                for (int w = 0; w < kLdsWords; w++) tw[w] = planes[(3 * kLdsWords + w) * kBlock + tid] & ~planes[w * kBlock + tid];
+                tw[7] = 0u;
+                has_t = find_polyt_bits(planes, cmask, tid, P, tw, pb, pe);
+            } else
+                has_t = find_polyt(planes, tid, P, pb, pe);
+        }
         uint64_t am[3] = {0, 0, 0};
         // 5' barcoding scans an end when the polyT was found at the OTHER end (or no polyA is asked for):
         // PolyATadapterAnalyzer_5pBCUMI.java:L51-68
@@ -895,7 +899,8 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     for (int i = 0; i < 22 && i < ad; i++) P.adapter_nib[i >> 3] |= (cfg->adapter4[i] & 15u) << ((i & 7) * 4);
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
-    // the bit-parallel finder is built for the shipped window length and the thresholds the shipped fractions give; SMI_SCAN_FINDER_LOOP: cross-check switch
+    // the kernels of the shipped adapters carry the bit-parallel finder, built for the shipped window length and the thresholds the shipped fractions give;
+    // SMI_SCAN_FINDER_LOOP: cross-check switch (the generic kernels, which keep the loop)
     P.finder_bits = cfg->polya_len == 15 && P.thr_first == 12 && P.thr_adv == 10 && cfg->window_polya >= 1 && cfg->window_polya <= 160 && !std::getenv("SMI_SCAN_FINDER_LOOP");
     // SMI_SCAN_ABLATE switches parts of the kernel off to time them (tools/gpu_scan_ablate.sh): the results are wrong by construction, so
     // only a measurement build (make MEASURE=1 -> -DSMI_MEASURE) honours it; the shipped library refuses to run with it set
@@ -917,7 +922,7 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), scan_lds_bytes(), s, d_ends, d_len, d_qtail, d_qsum, n, P, d_out,
                            d_win);
     };
-    bool ship = ad == 10 || ad == 22;
+    bool ship = (ad == 10 || ad == 22) && P.finder_bits;
     for (int i = 0; ship && i < ad; i++) ship = P.a4(i) == (ad == 10 ? shipped_a4<10>(i) : shipped_a4<22>(i));
     if (std::getenv("SMI_SCAN_GENERIC")) ship = false;  // tests run both builds against the oracle
     if (ad == 10) {
