@@ -379,13 +379,18 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
     uint64_t sa0, sa1, qa0, qa1;
     aligned_part(seq_lo, seq_hi, sa0, sa1);
     aligned_part(q_lo, q_hi, qa0, qa1);
-    auto fetch16 = [&](const uint8_t *b0, uint64_t k, bool is_seq, uint32_t (&w)[4]) {  // run positions k .. k+15
-        if (!rev) {
-            __builtin_memcpy(w, b0 + k, 16);
-            return;
-        }
-        uint32_t v[4];
-        __builtin_memcpy(v, b0 - (int64_t)k - 15, 16);  // positions k+15 .. k
+    // run positions k .. k+15 in two steps: the load as the text has the bytes (forwards, or the 16 bytes that end at position k of a reversed
+    // run), and -- after every load of the turn has been issued -- the mirroring and the complement.  (As one step the complement's validity test
+    // sat between the loads: a record on the reverse strand waited for each of its sequence pieces before it asked for the next.)
+    auto load16 = [&](const uint8_t *b0, uint64_t k, uint32_t (&v)[4]) {
+        if (!rev)
+            __builtin_memcpy(v, b0 + k, 16);
+        else
+            __builtin_memcpy(v, b0 - (int64_t)k - 15, 16);  // positions k+15 .. k
+    };
+    auto finish16 = [&](bool is_seq, uint32_t (&w)[4]) {
+        if (!rev) return;
+        uint32_t v[4] = {w[0], w[1], w[2], w[3]};
 #pragma unroll
         for (int d = 0; d < 4; d++) w[d] = __builtin_bswap32(v[3 - d]);
         if (is_seq) {
@@ -437,10 +442,10 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
         const uint64_t u0 = (uint64_t)lane + 64ull * kLoose * turn;
         if (!__ballot(bs0 || bq0 || u0 < n_loose)) break;
         uint32_t ws0[4], ws1[4], wq0[4], wq1[4];
-        if (bs0) fetch16(seq0, gs0 - seq_lo, true, ws0);
-        if (bs1) fetch16(seq0, gs1 - seq_lo, true, ws1);
-        if (bq0) fetch16(qual0, gq0 - q_lo, false, wq0);
-        if (bq1) fetch16(qual0, gq1 - q_lo, false, wq1);
+        if (bs0) load16(seq0, gs0 - seq_lo, ws0);
+        if (bs1) load16(seq0, gs1 - seq_lo, ws1);
+        if (bq0) load16(qual0, gq0 - q_lo, wq0);
+        if (bq1) load16(qual0, gq1 - q_lo, wq1);
         uint64_t la[kLoose];
         uint32_t lc[kLoose], ltb[kLoose];
 #pragma unroll
@@ -450,6 +455,10 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
             const uint8_t *p = source(la[j] != ~0ull ? la[j] - off : 0, ltb[j]);
             lc[j] = *p;
         }
+        if (bs0) finish16(true, ws0);
+        if (bs1) finish16(true, ws1);
+        if (bq0) finish16(false, wq0);
+        if (bq1) finish16(false, wq1);
         if (bs0) __builtin_memcpy(__builtin_assume_aligned(out + gs0, 16), ws0, 16);
         if (bs1) __builtin_memcpy(__builtin_assume_aligned(out + gs1, 16), ws1, 16);
         if (bq0) __builtin_memcpy(__builtin_assume_aligned(out + gq0, 16), wq0, 16);
