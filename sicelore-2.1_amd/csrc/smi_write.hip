@@ -319,12 +319,8 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
                                                const uint64_t *__restrict__ off_failed, const uint32_t *__restrict__ sfx_len,
                                                uint8_t *__restrict__ out_passed, size_t cap_passed, uint8_t *__restrict__ out_failed,
                                                size_t cap_failed, uint64_t *__restrict__ rec_off, uint32_t *__restrict__ err) {
-    __shared__ char rc_lut[512];  // [0..255] identity, [256..511] FastqRecordExt.REVERSE_COMPLEMENT
-    __shared__ char literals[8];  // "@\n+null"
-    rc_lut[threadIdx.x] = (char)threadIdx.x;
-    rc_lut[256 + threadIdx.x] = rc_char((unsigned char)threadIdx.x);
-    if (threadIdx.x < 7) literals[threadIdx.x] = "@\n+null"[threadIdx.x];
-    __syncthreads();
+    // (No table in LDS: a block is four records, and filling 512 bytes of LDS behind a barrier before the first load of a record was a fixed cost per
+    // four records.  The complement of a dword is two v_perm_b32; a character outside A C G T N takes FastqRecordExt.REVERSE_COMPLEMENT's switch.)
     const int lane = threadIdx.x & 63;
     const size_t i = blockIdx.x * (size_t)4 + (threadIdx.x >> 6);
     if (i >= A.n) return;
@@ -359,8 +355,8 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
     }
     const uint8_t *rd = (A.bstart ? A.text : A.reads) + R.rd, *ql = (A.bstart ? A.text : A.quals) + R.ql;
     const uint8_t *tok = A.text + R.name_beg, *qh = A.text + R.qh_beg;
-    const uint8_t *lit = reinterpret_cast<const uint8_t *>(literals);
-    const uint8_t *lut = reinterpret_cast<const uint8_t *>(rc_lut);
+    static __device__ const uint8_t kLiterals[8] = {'@', '\n', '+', 'n', 'u', 'l', 'l', 0};
+    const uint8_t *lit = kLiterals;
     // bases / qualities: position k of the written range is raw index cut_beg + k, or len - 1 - cut_beg - k when reversed
     const int64_t step = rev ? -1 : 1;
     const uint8_t *seq0 = rd + (rev ? len - 1 - cut_beg : cut_beg);
@@ -404,8 +400,8 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
             } else {
 #pragma unroll
                 for (int d = 0; d < 4; d++)
-                    w[d] = lut[256 + (w[d] & 0xFF)] | (lut[256 + ((w[d] >> 8) & 0xFF)] << 8) | (lut[256 + ((w[d] >> 16) & 0xFF)] << 16) |
-                           (lut[256 + (w[d] >> 24)] << 24);
+                    w[d] = (uint32_t)(uint8_t)rc_char((unsigned char)(w[d] & 0xFF)) | ((uint32_t)(uint8_t)rc_char((unsigned char)((w[d] >> 8) & 0xFF)) << 8) |
+                           ((uint32_t)(uint8_t)rc_char((unsigned char)((w[d] >> 16) & 0xFF)) << 16) | ((uint32_t)(uint8_t)rc_char((unsigned char)(w[d] >> 24)) << 24);
             }
         }
     };
@@ -465,7 +461,14 @@ __global__ __launch_bounds__(256) void k_write(WriteArgs A, const RecPlan *__res
         if (bq1) __builtin_memcpy(__builtin_assume_aligned(out + gq1, 16), wq1, 16);
 #pragma unroll
         for (int j = 0; j < kLoose; j++)
-            if (la[j] != ~0ull) out[la[j]] = lut[ltb[j] + lc[j]];
+            if (la[j] != ~0ull) {
+                uint32_t ch = lc[j];
+                if (ltb[j]) {  // a base of a reversed record
+                    uint32_t c4;
+                    ch = rc4(ch * 0x01010101u, c4) ? (c4 & 0xFFu) : (uint32_t)(uint8_t)rc_char((unsigned char)ch);
+                }
+                out[la[j]] = (uint8_t)ch;
+            }
     }
 }
 
