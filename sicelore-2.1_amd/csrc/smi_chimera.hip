@@ -122,6 +122,10 @@ __device__ __forceinline__ int jround(float a) { return (int)floorf(__fadd_rn(a,
 // one wave per read, one lane per 32-base plane word: a wave reads 2 KiB of consecutive ASCII and writes four 256-B rows.  The offsets of
 // the read after the next and the text of the next read are requested before the current one is encoded (the loop is otherwise three
 // dependent round trips per read: offsets, text, stores).
+// kStarts: the bases sit in the FASTQ text (starts[r]), not in a gathered copy (offsets[r]).  A template parameter, not a test of the pointer:
+// as `starts ? starts[r] : beg` the source position depended on a value just asked for, and the wait the compiler put in front of that
+// select sat in the middle of the loop -- behind the text loads of the next read, which were meant to be in flight while this one is encoded.
+template <bool kStarts>
 __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                                                     const uint64_t *__restrict__ starts, size_t n, size_t stride,
                                                     uint64_t total_bases, uint32_t *__restrict__ planes) {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
         if (r < n) {
             m.beg = offsets[r];
             m.end = offsets[r + 1];
-            m.src = starts ? starts[r] : m.beg;  // starts: the bases sit in the FASTQ text, not in a gathered copy
+            m.src = kStarts ? starts[r] : m.beg;
         }
         return m;
     };
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
         // the next reads do (up to total_bases).  encode_store drops the codes behind the end.  (A byte loop here -- counted or unrolled
         // under `if (i < nb)` -- is compiled into dependent round trips and ~300 wave instructions per read on ONE lane, as much as the
         // encoding of the whole read: 587 M instead of ~300 M VALU instructions per 0.9 M reads.)
-        const bool wide = p0 + 32 <= len || (p0 < len && (starts ? len >= 29 : m.beg + (uint64_t)p0 + 32 <= total_bases));
+        const bool wide = p0 + 32 <= len || (p0 < len && (kStarts ? len >= 29 : m.beg + (uint64_t)p0 + 32 <= total_bases));
         if (wide) {
             __builtin_memcpy(v, reads + m.src + p0, 32);
         } else {
@@ -2617,7 +2621,7 @@ int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offse
                       uint64_t total_bases, uint32_t *d_planes, hipStream_t s) {
     if (!n) return SMI_OK;
     const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_pack_reads, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, read_planes_stride(total_bases, n),
+    hipLaunchKernelGGL(d_starts ? k_pack_reads<true> : k_pack_reads<false>, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, read_planes_stride(total_bases, n),
                        total_bases, d_planes);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
