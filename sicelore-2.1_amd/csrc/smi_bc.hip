@@ -894,12 +894,23 @@ __global__ __launch_bounds__(256) void k_bc_codes_ed1t(const smi_bc_window *__re
         const size_t i = j / 5;
         const int q = (int)(j - 5 * i);
         const int off = q == 0 ? 0 : (q == 1 ? -1 : (q == 2 ? 1 : (q == 3 ? -2 : 2)));  // the reference's order (Parser.java:L203)
-        const smi_bc_window my = win[i];
+        // the window as ONE 16-byte load (as `win[i]` the flags word was fetched and tested first, the bases behind that wait: a fourth
+        // dependent round trip in front of the filter bit, the bucket and the store)
+        smi_bc_window my;
+        {
+            const uint4 raw = *reinterpret_cast<const uint4 *>(win + i);
+            my.bases = ((uint64_t)raw.y << 32) | raw.x;
+            my.nmask = raw.z;
+            my.flags = raw.w;
+        }
         uint32_t code = 0;
-        if (my.flags & SMI_WIN_VALID) {
+        {
+            // key and filter word for every lane, valid window or not (any 32-bit key lies inside the 512 MiB bitmap): nothing but the window's
+            // own load stands in front of the probe
             const OffsetKey k = make_key(my.bases, my.nmask, off, fp);
             const uint32_t K = k.key;
-            if (k.usable && ((P.nb[K >> 5] >> (K & 31u)) & 1u)) {
+            const uint32_t word = P.nb[K >> 5];
+            if ((my.flags & SMI_WIN_VALID) && k.usable && ((word >> (K & 31u)) & 1u)) {
                 uint32_t best = 255u;
                 uint32_t idx = nt_slot(K, P.nt_cap);
                 for (;;) {
