@@ -950,6 +950,9 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
 // [plane-word][end] layout and no cross-lane operation is needed
 // starts != nullptr: record r's bases begin at reads[starts[r]] (reads = the FASTQ text itself, no gathered copy); lengths always come
 // from the offsets prefix array
+// (kStarts: the bases sit in the FASTQ text at starts[r] -- a template parameter, so that the load of starts[r] is issued beside the one of the
+// offsets instead of behind a test that waits for them)
+template <bool kStarts>
 __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
                                                    const uint64_t *__restrict__ starts, size_t n, uint32_t *__restrict__ ends,
                                                    int32_t *__restrict__ read_len) {
@@ -957,10 +960,11 @@ __global__ __launch_bounds__(256) void k_pack_ends(const uint8_t *__restrict__ r
     for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n_ends; e += (size_t)gridDim.x * blockDim.x) {
         const size_t r = e >> 1;
         const int side = (int)(e & 1);
+        const uint64_t at = kStarts ? starts[r] : 0;
         const uint64_t beg = offsets[r];
         const int64_t len = (int64_t)(offsets[r + 1] - beg);
         if (side == 0) read_len[r] = (int32_t)len;
-        const uint8_t *src = reads + (starts ? starts[r] : beg);
+        const uint8_t *src = reads + (kStarts ? at : beg);
         // 16 bases per piece: one 16-byte load (unaligned), four enc4x4 -- the tail end is read backwards and complemented, which is a
         // byte swap of the piece and the complement table
         if (len >= kEndBases) {
@@ -1148,7 +1152,7 @@ int launch_pack_ends(smi_ctx *, const uint8_t *d_reads, const uint8_t *d_quals, 
                      size_t n, int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s) {
     if (!n) return SMI_OK;
     const unsigned grid = (unsigned)std::min<size_t>((2 * n + 255) / 256, 256 * 64);
-    hipLaunchKernelGGL(k_pack_ends, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, d_ends, d_len);
+    hipLaunchKernelGGL(d_starts ? k_pack_ends<true> : k_pack_ends<false>, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, d_ends, d_len);
     if (d_quals) {
         const unsigned gq = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
         hipLaunchKernelGGL(k_pack_quals, dim3(gq), dim3(256), 0, s, d_quals, d_offsets, n, head_quals, d_qtail, d_qsum);
