@@ -196,7 +196,7 @@ def end_to_end_leg(ctx, synth, dev, used, n):
                          "basis": "FASTQ text in + passed / failed text out per chunk (the least a text-to-text pass must move) over the whole chunk's time",
                          "stage_ms": stage_ms,
                          "limiter": "the splitter's filter (K-CHIM-A: 4-mer gates + a Levenshtein bound for every gated position of every read) is integer VALU "
-                                    "issue; the rest of the chunk is a dozen short kernels and two host read-backs (queue length, fragment count)",
+                                    "issue; then the writer (K-WRITE beside K-WNAME), K-FQ's sweep, K-PACKR; six short host waits between the library calls",
                          "kernel_trace": "profiles/r04/e2e_kernel_stats.csv"},
             "stages": "K-FQ, K-PACKR, K-CHIM, fragment offsets, K-PACK, K-SCAN, K-BC1 (3.6M whitelist), K-WRITE; FASTQ text in HBM -> "
                       "passed/failed FASTQ text in HBM; host work between the launches included"}
