@@ -1,7 +1,8 @@
 #!/bin/bash
 # round 4: one part of the GPU work in one call -- usage: gpu_r04_part.sh <part> ...
 #   tests <pytest paths ...>   the named GPU tests (-x -q -m gpu)
-#   cross                      the splitter's generations against each other (tools/chim_crosscheck.py, 0.27 M 5' and 0.9 M 3' reads)
+#   cross                      the splitter's generations against each other (tools/chim_crosscheck.py, 0.27 M 5' and 0.9 M 3' reads), K-SCAN's shipped
+#                              kernels against its generic ones (tools/scan_crosscheck.py, 2 M reads in each of four modes)
 #   fuzz [minutes]             tools/fuzz_parity.py, legs bc + records
 #   step                       the bench's timed step and its end-to-end leg, no other leg
 #   e2e                        kernel trace of the end-to-end leg -> gpurun_out/e2e_kernel_stats.csv, e2e_timeline.json
@@ -23,7 +24,8 @@ while [ $# -gt 0 ]; do
       tail -6 gpurun_out/r04_part_tests.log | cut -c1-400; [ $rc -eq 0 ] || exit $rc ;;
     cross)
       timeout -k 10 300 python tools/chim_crosscheck.py 300000 5p 2> gpurun_out/chim_cross5.err | cut -c1-700 || exit 1
-      timeout -k 10 300 python tools/chim_crosscheck.py 1000000 2> gpurun_out/chim_cross3.err | cut -c1-700 || exit 1 ;;
+      timeout -k 10 300 python tools/chim_crosscheck.py 1000000 2> gpurun_out/chim_cross3.err | cut -c1-700 || exit 1
+      timeout -k 10 600 python tools/scan_crosscheck.py 2000000 2> gpurun_out/scan_cross.err | cut -c1-700 || exit 1 ;;
     fuzz)
       minutes=1.5
       if [ $# -gt 0 ] && [[ $1 =~ ^[0-9.]+$ ]]; then minutes=$1; shift; fi
