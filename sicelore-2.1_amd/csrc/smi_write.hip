@@ -167,6 +167,60 @@ __device__ __forceinline__ WindowRegs load_window(const uint8_t *raw, const Name
     return r;
 }
 
+// reverse complement of four bases at once.  (c >> 1) & 7 separates A C G T N (0 1 3 2 7), so one v_perm_b32 against an 8-byte table
+// complements a dword and a second one against the identity table proves that all four characters were one of the five; anything
+// else (lower case, IUPAC codes, which FastqRecordExt.REVERSE_COMPLEMENT also maps, and the characters it maps to 0) takes the table in LDS.
+__device__ __forceinline__ bool rc4(uint32_t w, uint32_t &out) {
+    const uint32_t idx = (w >> 1) & 0x07070707u;
+    // byte j of {hi:lo} = the character with index j:   0 'A'  1 'C'  2 'T'  3 'G'  4 -  5 -  6 -  7 'N'
+    const uint32_t id_lo = 'A' | ('C' << 8) | ('T' << 16) | ((uint32_t)'G' << 24), id_hi = (uint32_t)'N' << 24;
+    const uint32_t rc_lo = 'T' | ('G' << 8) | ('A' << 16) | ((uint32_t)'C' << 24), rc_hi = (uint32_t)'N' << 24;
+    out = __builtin_amdgcn_perm(rc_hi, rc_lo, idx);
+    return __builtin_amdgcn_perm(id_hi, id_lo, idx) == w;
+}
+
+// the complement of a dword that holds something else than A C G T N (or pad bytes): FastqRecordExt.REVERSE_COMPLEMENT's switch per byte, kept out
+// of line -- inlined per character of the X= window (43 times 30 cases) it was a good part of K-WNAME's 44,000 instructions
+__device__ __noinline__ uint32_t rc_dword_switch(uint32_t w) {
+    return (uint32_t)(uint8_t)rc_char((unsigned char)(w & 0xFF)) | ((uint32_t)(uint8_t)rc_char((unsigned char)((w >> 8) & 0xFF)) << 8) |
+           ((uint32_t)(uint8_t)rc_char((unsigned char)((w >> 16) & 0xFF)) << 16) | ((uint32_t)(uint8_t)rc_char((unsigned char)(w >> 24)) << 24);
+}
+
+// The X= / Q= windows as the formatter's bulk hooks (smi_name.h has_bulk): the window sits in eleven registers in stranded order; X= is the
+// window without its first character, complemented -- a dword at a time -- for a read that passed on the reverse strand; Q= sums all of it.
+struct DevSeqWindow {
+    static constexpr bool kBulk = true;
+    WindowRegs w;
+    __device__ __forceinline__ char operator()(int) const { return 0; }  // (never used: bulk_x below)
+    template <class Sink>
+    __device__ __forceinline__ void bulk_x(Sink &s, const NameWindow &nw) const {
+        constexpr int ND = kNameWindowMax / 4;
+        uint32_t c[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            c[d] = w.w[d];
+            if (nw.rev) {
+                uint32_t o;
+                c[d] = (4 * d + 4 <= nw.n_chars && rc4(c[d], o)) ? o : rc_dword_switch(c[d]);
+            }
+        }
+#pragma unroll
+        for (int k = 1; k < kNameWindowMax; k++)
+            if (k < nw.n_chars) s.put((char)(uint8_t)(c[k >> 2] >> (8 * (k & 3))));
+    }
+};
+struct DevQualWindow {
+    static constexpr bool kBulk = true;
+    WindowRegs w;
+    __device__ __forceinline__ char operator()(int) const { return 0; }
+    __device__ __forceinline__ int bulk_sum(const NameWindow &nw) const {  // (bytes behind the window are 0)
+        uint32_t acc = 0;
+#pragma unroll
+        for (int d = 0; d < kNameWindowMax / 4; d++) acc = __builtin_amdgcn_sad_u8(w.w[d], 0u, acc);
+        return (int)acc - 33 * nw.n_chars;
+    }
+};
+
 // what follows the name token: fragment tag + suffix; returns the status of append_name_suffix
 __device__ __forceinline__ int format_record_suffix(const WriteArgs &A, const RecPlan &R, size_t i, uint32_t read_id, NameSink &s,
                                                     bool *quals_set) {
@@ -188,16 +242,15 @@ __device__ __forceinline__ int format_record_suffix(const WriteArgs &A, const Re
     const smi_scan_result sc = A.scan[i];
     const smi_bc_result bcr = A.bc[i];
     const NameWindow nw = name_window(sc, A.five_prime != 0, R.len);
-    WindowRegs ws, wq;
+    DevSeqWindow ws;
+    DevQualWindow wq;
 #pragma unroll
-    for (int d = 0; d < kNameWindowMax / 4; d++) ws.w[d] = wq.w[d] = 0;
+    for (int d = 0; d < kNameWindowMax / 4; d++) ws.w.w[d] = wq.w.w[d] = 0;
     if (nw.has && nw.n_chars >= kNameWindowMax - 1) {  // the two shipped layouts: 44 (3') and 43 (5') characters
-        ws = load_window((A.bstart ? A.text : A.reads) + R.rd, nw);
-        wq = load_window((A.bstart ? A.text : A.quals) + R.ql, nw);
+        ws.w = load_window((A.bstart ? A.text : A.reads) + R.rd, nw);
+        wq.w = load_window((A.bstart ? A.text : A.quals) + R.ql, nw);
     }
-    return append_name_suffix(
-        s, sc, &bcr /* has_bc = found == 1, tested inside */, A.rank ? A.rank[i] : 0, read_id, A.five_prime != 0, R.len, [&](int k) { return (char)ws.at(k); },
-        [&](int k) { return (char)wq.at(k); }, quals_set);
+    return append_name_suffix(s, sc, &bcr /* has_bc = found == 1, tested inside */, A.rank ? A.rank[i] : 0, read_id, A.five_prime != 0, R.len, ws, wq, quals_set);
 }
 
 // '@' name LF bases LF '+' header LF qualities LF
@@ -296,18 +349,6 @@ __global__ __launch_bounds__(kNameBlock) void k_write_name(WriteArgs A, const Re
         char *o = reinterpret_cast<char *>((uintptr_t)dst[r]);
         for (int k = lane; k < n; k += 64) o[k] = stage[r][k];
     }
-}
-
-// reverse complement of four bases at once.  (c >> 1) & 7 separates A C G T N (0 1 3 2 7), so one v_perm_b32 against an 8-byte table
-// complements a dword and a second one against the identity table proves that all four characters were one of the five; anything
-// else (lower case, IUPAC codes, which FastqRecordExt.REVERSE_COMPLEMENT also maps, and the characters it maps to 0) takes the table in LDS.
-__device__ __forceinline__ bool rc4(uint32_t w, uint32_t &out) {
-    const uint32_t idx = (w >> 1) & 0x07070707u;
-    // byte j of {hi:lo} = the character with index j:   0 'A'  1 'C'  2 'T'  3 'G'  4 -  5 -  6 -  7 'N'
-    const uint32_t id_lo = 'A' | ('C' << 8) | ('T' << 16) | ((uint32_t)'G' << 24), id_hi = (uint32_t)'N' << 24;
-    const uint32_t rc_lo = 'T' | ('G' << 8) | ('A' << 16) | ((uint32_t)'C' << 24), rc_hi = (uint32_t)'N' << 24;
-    out = __builtin_amdgcn_perm(rc_hi, rc_lo, idx);
-    return __builtin_amdgcn_perm(id_hi, id_lo, idx) == w;
 }
 
 // K-WRITE: one wave per record copies everything but the suffix.  The two long runs of a record -- bases and qualities -- go out in
