@@ -85,6 +85,50 @@ def test_scan_matches_oracle(pkg, synth, sor, gpu_ctx, pass_no, generic, monkeyp
         assert exp["pass1_ok"].sum() > 0.05 * n
 
 
+def _t_rich_reads(n, seed):
+    """reads whose two ends are crowded with T / A runs of every kind: long and short, clean and dirty, with N inside, cut by the 150-base window, several per
+    end, runs that end where the extension's increments land -- the shapes the polyT finder's loops and its bit-parallel form must agree on"""
+    rng = np.random.default_rng(seed)
+
+    def end(base):  # 208 characters rich in `base`
+        out = rng.choice(list("ACGT"), 208).tolist()
+        for _ in range(int(rng.integers(1, 5))):
+            at, ln = int(rng.integers(0, 200)), int(rng.choice([5, 9, 12, 14, 15, 16, 17, 20, 25, 30, 35, 45, 60, 90, 130, 200]))
+            dirt = float(rng.choice([0.0, 0.0, 0.05, 0.1, 0.2, 0.3]))
+            for k in range(at, min(208, at + ln)):
+                out[k] = base if rng.random() >= dirt else str(rng.choice(list("ACGN" if base == "T" else "TCGN")))
+        if rng.random() < 0.3:  # a run that stops right at / behind the search window
+            a = int(rng.integers(120, 150))
+            for k in range(a, min(208, a + int(rng.integers(10, 50)))):
+                out[k] = base
+        return "".join(out)
+
+    seqs = []
+    for _ in range(n):
+        mid = "".join(rng.choice(list("ACGT"), int(rng.integers(0, 300))).tolist())
+        head = end("T") if rng.random() < 0.7 else end("A")
+        tail = end("A") if rng.random() < 0.7 else end("T")   # (the tail is scanned reverse-complemented: A runs there are T runs to the finder)
+        seqs.append(head + mid + tail)
+    quals = ["".join(chr(33 + int(q)) for q in rng.integers(5, 35, len(s))) for s in seqs]
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return np.frombuffer("".join(seqs).encode(), dtype=np.uint8), np.frombuffer("".join(quals).encode(), dtype=np.uint8), offs
+
+
+@pytest.mark.parametrize("pass_no,generic", [(2, False), (1, False), (2, True)])
+def test_polyt_finder_on_t_rich_ends(pkg, sor, gpu_ctx, pass_no, generic, monkeypatch):
+    """the bit-parallel finder of the shipped kernels (and the loop of the generic ones) against the oracle on ends built to stress it"""
+    if generic:
+        monkeypatch.setenv("SMI_SCAN_GENERIC", "1")
+    n = 20_000
+    ra, qa, offs = _t_rich_reads(n, seed=900 + pass_no)
+    got, _, _, _ = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, pass_no)
+    st, exp = sor.scan_batch_3p(ra, qa, offs, AD[pass_no], n_threads=8)
+    _compare(got, st, exp, pass1=True)
+    has = (exp["polya_end"] != 0).sum()
+    assert has > 0.3 * n or (exp["flags"] != exp["flags"][0]).any()   # (the finder found runs in a good part of the reads)
+
+
 def test_pack_ends_equals_torch_packer(pkg, synth, gpu_ctx):
     wl = synth.make_whitelist(10_000, seed=211)
     used = synth.pick_used(wl, 100, seed=212)
