@@ -129,6 +129,43 @@ def test_polyt_finder_on_t_rich_ends(pkg, sor, gpu_ctx, pass_no, generic, monkey
     assert has > 0.3 * n or (exp["flags"] != exp["flags"][0]).any()   # (the finder found runs in a good part of the reads)
 
 
+@pytest.mark.parametrize("generic", [False, True])
+def test_polyt_finder_on_t_rich_ends_5p(pkg, sor, gpu_ctx, generic, monkeypatch):
+    """the same ends through the 5' kernels with the polyA search on (an end is scanned when the polyT sits at the OTHER end): flags, polyA
+    coordinates and the adapter fields against the oracle, read by read"""
+    if generic:
+        monkeypatch.setenv("SMI_SCAN_GENERIC", "1")
+    n = 3000
+    ra, qa, offs = _t_rich_reads(n, seed=950)
+    d_reads, d_quals = torch.from_numpy(ra.copy()).cuda(), torch.from_numpy(qa.copy()).cuda()
+    d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
+    d_ends = torch.zeros((28, 2 * n), dtype=torch.int32, device="cuda")
+    d_len = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_qh = torch.zeros((n, 224), dtype=torch.uint8, device="cuda")
+    d_qsum = torch.zeros(n, dtype=torch.int32, device="cuda")
+    gpu_ctx.pack_ends_device(d_reads, d_quals, d_offs, n, d_ends, d_len, d_qh, d_qsum, five_prime=True)
+    d_out = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    gpu_ctx.scan_device(d_ends, d_len, n, gpu_ctx.scan_config_5p(2, False), d_out, None, d_qh, d_qsum)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(pkg.SCAN_RESULT_DTYPE).reshape(-1)
+    n_polya = 0
+    for i in range(n):
+        seq = bytes(ra[int(offs[i]):int(offs[i + 1])]).decode()
+        qual = bytes(qa[int(offs[i]):int(offs[i + 1])]).decode()
+        rc, e = sor.scan_read_5p(seq, qual, AD[2], max_mm=4, dont_search_polya=False)
+        if rc != 0:
+            assert got["reserved"][i] == 1
+            continue
+        assert int(got["flags"][i]) == int(e["flags"]), (i, hex(int(got["flags"][i])), hex(int(e["flags"])))
+        assert got["found"][i] == e["adapter_found"]
+        assert (got["polya_start"][i], got["polya_end"][i]) == (e["polya_start"], e["polya_end"]), i
+        n_polya += int(e["polya_end"] != 0)
+        if e["adapter_found"]:
+            for f in ("adapter_start", "adapter_end", "scan_end", "adapter_nmis", "reverse"):
+                assert int(got[f][i]) == int(e[f]), (i, f)
+    assert n_polya > 0
+
+
 def test_pack_ends_equals_torch_packer(pkg, synth, gpu_ctx):
     wl = synth.make_whitelist(10_000, seed=211)
     used = synth.pick_used(wl, 100, seed=212)
