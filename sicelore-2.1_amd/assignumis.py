@@ -741,12 +741,20 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
         bai = next((p_ for p_ in (in_bam + ".bai", in_bam[:-4] + ".bai") if os.path.isfile(p_)), None)
         if bai is None:
             raise _lib.SmiError(f"assignumis over {world} ranks needs the BAM index ({in_bam}.bai: samtools index) to deal whole chromosomes to the ranks")
-        v_begin, v_end = plan_shards(bai_ref_extents(bai), world)[rank]
+        extents = bai_ref_extents(bai)
+        size = os.path.getsize(in_bam)
+        far = max((e[1] >> 16 for e in extents if e is not None), default=0)
+        if far > size:
+            raise _lib.SmiError(f"{bai}: the index points behind the end of {in_bam} (block at {far}, file of {size} bytes): stale index or truncated BAM")
+        head = np.fromfile(f_in, dtype=np.uint8, count=4 << 20)
+        hb, _used = _lib.bgzf_inflate(head, n_threads=1)
+        _t, h_refs, hlen = _lib.bam_header(hb)
+        if len(h_refs) != len(extents):
+            raise _lib.SmiError(f"{bai}: index of {len(extents)} references, header of {in_bam} has {len(h_refs)}: not this file's index")
+        f_in.seek(0)
+        v_begin, v_end = plan_shards(extents, world)[rank]
         if rank > 0 and (v_begin, v_end) != (0, 0):
             # the header comes from the file's start; it leads this rank's stream (and is not written again: rank 0 wrote it)
-            head = np.fromfile(f_in, dtype=np.uint8, count=4 << 20)
-            hb, _used = _lib.bgzf_inflate(head, n_threads=1)
-            _t, _r, hlen = _lib.bam_header(hb)
             pend = hb[:hlen].copy()
     suffix = f".shard{rank}" if world > 1 else ""
     f_bc, f_umi = open(out_prefix + ".bam" + suffix, "wb"), open(out_prefix + "_umifound_.bam" + suffix, "wb")
@@ -796,9 +804,6 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
     def reader():
         tail = np.zeros(0, dtype=np.uint8)
         try:
-            if (v_begin, v_end) == (0, 0):          # more ranks than chromosomes: nothing for this one
-                segments.put((np.zeros(0, dtype=np.uint8), 0, True, None))
-                return
             skip = 0                                # bytes of the first inflated block in front of this rank's first record
             if v_begin is not None:
                 f_in.seek(v_begin >> 16)
@@ -808,6 +813,9 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
                 want = int(segment_bytes) if left is None else min(int(segment_bytes), left)
                 raw = np.fromfile(f_in, dtype=np.uint8, count=want)
                 if left is not None:
+                    if raw.size < want:              # the index promises bytes the file does not have (stale .bai, truncated BAM)
+                        raise _lib.SmiError(f"{in_bam}: truncated BGZF stream / the BAM index does not match the file "
+                                            f"({want - raw.size} bytes short of virtual offset {v_end})")
                     left -= raw.size
                 last = raw.size < segment_bytes if left is None else left == 0
                 comp = np.concatenate([tail, raw]) if tail.size else raw
@@ -833,8 +841,12 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
         except BaseException as e:  # noqa: BLE001 -- handed to the consumer
             segments.put((None, 0, True, e))
 
-    threading.Thread(target=reader, daemon=True).start()
-    eof = False
+    # more ranks than chromosomes with reads: this rank has no range.  It writes two empty shards and goes straight to the exchange
+    # (no header is read, so nothing may ask for one)
+    idle = world > 1 and (v_begin, v_end) == (0, 0)
+    if not idle:
+        threading.Thread(target=reader, daemon=True).start()
+    eof = idle
     while not eof or pend.size:
         t1 = time.perf_counter()
         buf, room, eof, err = segments.get() if not eof else (np.zeros(0, dtype=np.uint8), 0, True, None)
@@ -936,26 +948,12 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             parts = [None] * world if rank == 0 else None
             dist.gather_object(mine, parts, dst=0, group=group)
         else:
-            parts = None                          # shard=(rank, world) without a process group: the caller merges (merge_shards)
+            parts = None                          # shard=(rank, world) without a process group: the caller merges (merge_shards below)
             with open(out_prefix + f".genecounts.shard{rank}", "wb") as f:
                 f.write(mine[0])
         if dist is not None and rank == 0:
-            for q in range(1, world):
-                later = _lib.GeneCounts.load(parts[q][0])
-                order_dependent += gc.merge_shard(later)
-                later.close()
+            order_dependent = _string_shards(out_prefix, world, gc, [p_[0] for p_ in parts[1:]])
             n_records, n_clustered, n_batches = (sum(p_[k] for p_ in parts) for k in (1, 2, 3))
-            for name in (".bam", "_umifound_.bam"):
-                with open(out_prefix + name, "wb") as dst:
-                    for q in range(world):
-                        with open(out_prefix + name + f".shard{q}", "rb") as src:
-                            while True:
-                                blk = src.read(64 << 20)
-                                if not blk:
-                                    break
-                                dst.write(blk)
-                        os.remove(out_prefix + name + f".shard{q}")
-                    dst.write(_BGZF_EOF)
         if dist is not None:
             dist.barrier(group=group)
         if rank != 0 or dist is None:
@@ -976,6 +974,54 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
         tagger.close()
     return dict(records=n_records, clustered=n_clustered, batches=n_batches, seconds=secs, wall_s=time.perf_counter() - t_all, rank=rank, world=world,
                 gene_keys_order_dependent=order_dependent, **info)
+
+
+def _string_shards(out_prefix, world, gc, later_dumps):
+    """rank 0's end of a sharded run: the gene tables of ranks 1 .. world-1 (dumps) merged into gc in rank order, the BAM shards of both
+    outputs strung together in rank order (BGZF streams concatenate) + the end-of-file block, the shard files removed -> number of
+    (gene, cell, UMI) keys whose counters depend on the order of the records and were NOT added (smi_gene_counts_merge_shard)"""
+    order_dependent = 0
+    for dump in later_dumps:
+        later = _lib.GeneCounts.load(dump)
+        order_dependent += gc.merge_shard(later)
+        later.close()
+    for name in (".bam", "_umifound_.bam"):
+        with open(out_prefix + name, "wb") as dst:
+            for q in range(world):
+                with open(out_prefix + name + f".shard{q}", "rb") as src:
+                    while True:
+                        blk = src.read(64 << 20)
+                        if not blk:
+                            break
+                        dst.write(blk)
+                os.remove(out_prefix + name + f".shard{q}")
+            dst.write(_BGZF_EOF)
+    return order_dependent
+
+
+def merge_shards(out_prefix, world, bc_length=16):
+    """what follows `world` runs of assignumis_stream(..., shard=(r, world)) that had no process group between them (one job per GPU of a
+    scheduler, say): <out>.bam / <out>_umifound_.bam from the shard files, <out>.genecounts.tsv / <out>.UMIdepths.tsv from the
+    <out>.genecounts.shard<r> dumps; the shard files are removed.  The files equal those of the torch.distributed run and of one process
+    (assignumis_stream's docstring says what may differ) -> dict(gene_keys_order_dependent=...)"""
+    dumps = []
+    for q in range(world):
+        for name in (".bam", "_umifound_.bam", ".genecounts"):
+            if not os.path.isfile(out_prefix + name + f".shard{q}"):
+                raise _lib.SmiError(f"merge_shards: {out_prefix}{name}.shard{q} is missing (rank {q} of {world} has not finished)")
+        with open(out_prefix + f".genecounts.shard{q}", "rb") as f:
+            dumps.append(f.read())
+    gc = _lib.GeneCounts.load(dumps[0])
+    order_dependent = _string_shards(out_prefix, world, gc, dumps[1:])
+    with open(out_prefix + ".genecounts.tsv", "w") as f:
+        f.write(gc.genecounts_tsv(bc_length))
+    with open(out_prefix + ".UMIdepths.tsv", "w") as f:
+        f.write(gc.umi_depths_tsv())
+    info = gc.info()
+    gc.close()
+    for q in range(world):
+        os.remove(out_prefix + f".genecounts.shard{q}")
+    return dict(gene_keys_order_dependent=order_dependent, **info)
 
 
 def assignumis_files(ctx, in_bam, out_prefix, bc_length=16, native=True, **kw):

@@ -246,7 +246,14 @@ def assignumis(argv):
     ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
                                 refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")))
-    print(f"DONE -- {info.get('n_records', 0)} records, {info.get('n_clustered', 0)} in UMI clusters")
+    if info.get("rank", 0) == 0:       # rank 0 holds the whole run's counts (assignumis_stream gathers them)
+        print(f"DONE -- {info['records']} records, {info['clustered']} in UMI clusters")
+        bad = int(info.get("gene_keys_order_dependent", 0))
+        if bad:
+            # reads with alignments on chromosomes of two ranks: their (gene, cell, UMI) counters depend on which alignment is seen first,
+            # so the later rank's were left out of genecounts.tsv / UMIdepths.tsv; one process has no such keys
+            print(f"WARNING: {bad} (gene, cell, UMI) keys of reads aligned on chromosomes of different ranks were counted on the first rank only: "
+                  f"{prefix}.genecounts.tsv / .UMIdepths.tsv can differ from a single-process run in those keys (the BAMs do not)", file=sys.stderr)
     return 0
 
 

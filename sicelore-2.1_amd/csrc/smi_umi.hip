@@ -44,56 +44,120 @@ __device__ __forceinline__ EqMasks eq_masks(uint64_t w) {
     return m;
 }
 
-// Myers / Hyyro global edit distance of the 12-base pattern that starts at base `pi` of read a against the 12 text
-// bases that start at base `tj` of read b.  eq[j] = pattern positions (14 bits, of read a) matching text base j of read b.
-__device__ __forceinline__ int myers12(const uint32_t (&eq)[14], int pi, int tj) {
-    const uint32_t M = 0xFFFu, TOP = 0x800u;
-    uint32_t Pv = M, Mv = 0;
-    int score = 12;
-#pragma unroll
-    for (int t = 0; t < 12; t++) {
-        const uint32_t Eq = (eq[tj + t] >> pi) & M;
-        const uint32_t Xv = Eq | Mv;
-        const uint32_t Xh = ((((Eq & Pv) + Pv) ^ Pv) | Eq) & M;
-        uint32_t Ph = (Mv | ~(Xh | Pv)) & M;
-        uint32_t Mh = Pv & Xh;
-        score += (Ph & TOP) ? 1 : 0;
-        score -= (Mh & TOP) ? 1 : 0;
-        Ph = ((Ph << 1) | 1u) & M;  // global distance: the boundary row grows by one per text character
-        Mh = (Mh << 1) & M;
-        Pv = (Mh | ~(Xv | Ph)) & M;
-        Mv = Ph & Xv;
-    }
-    return score;
+// ---- the nine distances of a pair (round 5) ----------------------------------------------------------------------------------------------
+// Round 4's form ran nine separate 12-bit Myers recurrences, 19 compiler-chosen instructions per step, nearly all three-operand forms
+// (v_bitop3, v_and_or, v_lshl_or: four issue cycles each, profiles/r02/valu_peak.json): 2,090 instructions = ~ 8,400 issue cycles per pair.
+// Three changes, none of which alters a result:
+//   * TWO recurrences per register: 12-bit fields at bits 0 .. 11 and 16 .. 27.  The only operation that crosses bit positions upwards is
+//     the addition (Eq & Pv) + Pv; its carry out of a field stops at bit 12 / 28 as long as Pv is zero there, so one extra AND per step
+//     (Pv &= 0x0FFF0FFF) keeps the fields apart.  The "+1 per text base" of the boundary row is OR 0x00010001 (and that also overwrites
+//     whatever the shift moved from the low field's guard bits into bit 16).  Nine distances = five runs: (i = 0, 1) x v for v = 0, 1, 2;
+//     (i = 2) x (v = 0, 1); (i = 2, v = 2).
+//   * the distance is read off the last column at the end, D[12][12] = 12 + popcount(Pv) - popcount(Mv), instead of being followed step
+//     by step (two extractions and two adds per step and field).
+//   * the step is ONE asm block of seventeen two-operand instructions (and / or / xor / add / not on VGPRs and literals): those issue in two
+//     cycles instead of four, but only in unbroken runs -- a single three-operand form among them drags the rest to four cycles.  Five runs
+//     of 12 x 17 instructions = 2,040 issue cycles.
+// The match masks: eq[j] = positions of read a equal to base j of read b is a 5-way select per text base -- ~ 100 compare / select
+// instructions per pair in round 4 (v_cndmask is the slowest VALU instruction of this chip).  Now every lane keeps a 16-entry table
+// indexed by the 4-bit code in LDS ([code][thread]: conflict-free, no other lane ever touches the column, so no barrier): the five live
+// entries are written per pair ALREADY in the packed forms the runs consume, codes that match nothing stay zero from the kernel's start.
+#ifndef SMI_UMI_TILE_THREADS
+#define SMI_UMI_TILE_THREADS 256
+#endif
+constexpr int kUmiEqCols = SMI_UMI_TILE_THREADS > 256 ? SMI_UMI_TILE_THREADS : 256;  // a column per thread of the larger workgroup
+struct UmiEqTable {
+    uint2 e[16][kUmiEqCols];  // .x: fields (eq & 0xFFF, (eq >> 1) & 0xFFF) = pattern offsets 0 and 1; .y: (eq >> 2) in both fields = pattern offset 2
+};
+
+#define SMI_MYERS2_STEP(EQ)                                                                                         \
+    asm volatile("v_or_b32 %2, %5, %1\n\t"          /* Xv = Eq | Mv                                        */        \
+                 "v_and_b32 %3, %5, %0\n\t"         /* t  = Eq & Pv                                        */        \
+                 "v_add_u32 %3, %3, %0\n\t"         /* t += Pv       (carry stops at bit 12 / 28)          */        \
+                 "v_xor_b32 %3, %3, %0\n\t"         /* t ^= Pv                                             */        \
+                 "v_or_b32 %3, %3, %5\n\t"          /* Xh = t | Eq                                         */        \
+                 "v_or_b32 %4, %3, %0\n\t"          /* u  = Xh | Pv                                        */        \
+                 "v_not_b32 %4, %4\n\t"             /* u  = ~u                                             */        \
+                 "v_or_b32 %4, %1, %4\n\t"          /* Ph = Mv | u                                         */        \
+                 "v_and_b32 %3, %0, %3\n\t"         /* Mh = Pv & Xh  (clean: Pv is)                        */        \
+                 "v_add_u32 %4, %4, %4\n\t"         /* Ph <<= 1                                            */        \
+                 "v_or_b32 %4, 0x10001, %4\n\t"     /* Ph |= 1 in both fields (D[0][j] = j)                */        \
+                 "v_add_u32 %3, %3, %3\n\t"         /* Mh <<= 1                                            */        \
+                 "v_or_b32 %0, %2, %4\n\t"          /* w  = Xv | Ph                                        */        \
+                 "v_not_b32 %0, %0\n\t"             /* w  = ~w                                             */        \
+                 "v_or_b32 %0, %3, %0\n\t"          /* Pv = Mh | w                                         */        \
+                 "v_and_b32 %0, 0xfff0fff, %0\n\t"  /* the guard bits of Pv stay zero                      */        \
+                 "v_and_b32 %1, %4, %2\n\t"         /* Mv = Ph & Xv  (clean: Xv is)                        */        \
+                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                           \
+                 : "v"(EQ))
+
+// min(distance, 5) of both fields << 12, ready to take the enumeration rank and the offsets in the low bits
+__device__ __forceinline__ void myers2_scores(uint32_t pv, uint32_t mv, uint32_t &lo, uint32_t &hi) {
+    const int dl = 12 + __popc(pv & 0xFFFu) - __popc(mv & 0xFFFu);
+    const int dh = 12 + __popc(pv >> 16) - __popc(mv >> 16);
+    lo = (uint32_t)min(dl, 5) << 12;  // limitedCompare: -1 above the threshold 4, stored as 5 (L343)
+    hi = (uint32_t)min(dh, 5) << 12;
 }
 
-__device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b) {
+// calcBestEditDistance L67-80 visits (i, v) in the order (1,2,0) x (1,2,0) and keeps the first strict minimum: the least of
+// distance << 12 | rank << 8 | i << 4 | v << 6
+__host__ __device__ constexpr uint32_t umi_rank_code(int i, int v) {
+    const int ri = i == 1 ? 0 : i == 2 ? 1 : 2, rv = v == 1 ? 0 : v == 2 ? 1 : 2;
+    return (uint32_t)((3 * ri + rv) << 8) | (uint32_t)(i << 4) | (uint32_t)(v << 6);
+}
+
+__device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable &T, int tid) {
     const EqMasks ma = eq_masks(a);
-    const uint32_t mA = ma.a, mG = ma.g, mC = ma.c, mT = ma.t, mN = ma.n;
-    // match masks per text base, shared by the nine alignments (a code outside A, G, C, T, N matches nothing, as equals() would)
-    uint32_t eq[14];
+    {
+        const uint32_t m5[5] = {ma.a, ma.g, ma.c, ma.t, ma.n};
+        const int code[5] = {1, 2, 4, 8, 15};
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const uint32_t m = m5[k], f2 = m >> 2;  // (14 bits: m >> 2 has 12)
+            T.e[code[k]][tid] = make_uint2((m & 0xFFFu) | ((m << 15) & 0x0FFF0000u), f2 | (f2 << 16));
+        }
+    }
+    uint32_t e01[14], f22[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) {
         const uint32_t c = (uint32_t)(b >> (4 * j)) & 15u;
-        eq[j] = c == 1u ? mA : c == 2u ? mG : c == 4u ? mC : c == 8u ? mT : c == 15u ? mN : 0u;
+        const uint2 x = T.e[c][tid];
+        e01[j] = x.x;
+        f22[j] = x.y;
     }
-    // calcBestEditDistance L67-80: start (127, MINUSONE, MINUSONE); visit values 1,2,0 x 1,2,0; strict <
-    int best = 127, b1 = 0, b2 = 0;
-    const int ORDER[3] = {1, 2, 0};
+    uint32_t g[12];  // run 3: pattern offset 2 against text offsets 0 (low field) and 1 (high field)
 #pragma unroll
-    for (int x = 0; x < 3; x++)
+    for (int t = 0; t < 12; t++) g[t] = (f22[t] & 0xFFFFu) | (f22[t + 1] & 0xFFFF0000u);
+    uint32_t key = 0xFFFFFFFFu, lo, hi, t_xv, t_a, t_b;
 #pragma unroll
-        for (int y = 0; y < 3; y++) {
-            const int i = ORDER[x], v = ORDER[y];
-            int d = myers12(eq, i, v);
-            d = d > 4 ? 5 : d;  // limitedCompare: -1 above the threshold, stored as 5 (L343)
-            if (d < best) {
-                best = d;
-                b1 = i;
-                b2 = v;
-            }
-        }
-    return (uint32_t)best | ((uint32_t)b1 << 4) | ((uint32_t)b2 << 6);
+    for (int v = 0; v < 3; v++) {  // pattern offsets 0 / 1 against text offset v
+        uint32_t pv = 0x0FFF0FFFu, mv = 0u;
+#pragma unroll
+        for (int t = 0; t < 12; t++) SMI_MYERS2_STEP(e01[v + t]);
+        myers2_scores(pv, mv, lo, hi);
+        key = min(key, min(lo | umi_rank_code(0, v), hi | umi_rank_code(1, v)));
+    }
+    {
+        uint32_t pv = 0x0FFF0FFFu, mv = 0u;
+#pragma unroll
+        for (int t = 0; t < 12; t++) SMI_MYERS2_STEP(g[t]);
+        myers2_scores(pv, mv, lo, hi);
+        key = min(key, min(lo | umi_rank_code(2, 0), hi | umi_rank_code(2, 1)));
+    }
+    {
+        uint32_t pv = 0x0FFF0FFFu, mv = 0u;
+#pragma unroll
+        for (int t = 0; t < 12; t++) SMI_MYERS2_STEP(f22[2 + t]);  // (both fields hold the same problem)
+        myers2_scores(pv, mv, lo, hi);
+        key = min(key, lo | umi_rank_code(2, 2));
+    }
+    return (key >> 12) | (key & 0xF0u);
+}
+
+// every lane's column of the table: the codes that match nothing (everything but A, G, C, T, N) are zero and stay zero
+__device__ __forceinline__ void umi_table_init(UmiEqTable &T, int tid) {
+#pragma unroll
+    for (int c = 0; c < 16; c++) T.e[c][tid] = make_uint2(0u, 0u);
 }
 
 // ---- two mappings of pairs to lanes ---------------------------------------------------------------------------------------------------
@@ -146,6 +210,8 @@ __device__ __forceinline__ uint64_t tri_row(uint64_t n, uint64_t local) {
 __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ windows, const uint32_t *__restrict__ group_off,
                                                   const UmiPlan *__restrict__ plan, const uint64_t *__restrict__ mat_off,
                                                   uint32_t n_groups, uint8_t *__restrict__ out) {
+    __shared__ UmiEqTable T;
+    umi_table_init(T, threadIdx.x);
     const uint64_t total_pairs = plan[n_groups].small_pairs;
     for (uint64_t t = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; t < total_pairs; t += (uint64_t)gridDim.x * blockDim.x) {
         // group of this pair: last g with off[g] <= t.  The pairs of a wave are consecutive, so the binary search
@@ -167,7 +233,7 @@ __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ w
         const uint64_t n = group_off[g + 1] - r0;
         const uint64_t i = tri_row(n, local);
         const uint64_t v = i + (local - (i * n - i * (i - 1) / 2));
-        const uint32_t r = umi_pair(windows[r0 + i], windows[r0 + v]);
+        const uint32_t r = umi_pair(windows[r0 + i], windows[r0 + v], T, threadIdx.x);
         uint8_t *m = out + mat_off[g];
         m[i * n + v] = (uint8_t)r;
         // transposed copy for the lower triangle (getTransposedEditDistance L133, L213-216): offsets swapped
@@ -197,6 +263,9 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
                                                                     uint32_t n_groups, uint32_t *__restrict__ next_unit, uint8_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][kUmiTile][kUmiLdsRow];
     __shared__ uint32_t s_unit;
+    __shared__ UmiEqTable T;
+    static_assert(kUmiTileThreads <= kUmiEqCols, "a column of the table per thread");
+    umi_table_init(T, threadIdx.x);
     const uint64_t total_units = plan[n_groups].tiles;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int di = lane >> 3, dv = lane & 7;
@@ -237,7 +306,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
                 const uint64_t i = bi0 + di, v = bv0 + dv;
                 const bool valid = i < n && v < n && i <= v;
                 uint32_t r = 0;
-                if (valid) r = umi_pair(win[i], win[v]);
+                if (valid) r = umi_pair(win[i], win[v], T, threadIdx.x);
                 const uint32_t rt = (r & 15u) | (((r >> 6) & 3u) << 4) | (((r >> 4) & 3u) << 6);  // getTransposedEditDistance L133, L213-216
                 const bool whole = bi0 + 7 < bv0 && bv0 + 7 < n;  // every lane holds a pair above the diagonal
                 if (whole) {

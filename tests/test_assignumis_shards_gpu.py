@@ -99,7 +99,7 @@ def _make_inputs(pkg, synth, gpu_ctx, tmp_path, meta):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,meta", [(2, True), (3, False)])
+@pytest.mark.parametrize("world,meta", [(2, True), (3, False), (4, True)])     # 4: more ranks than chromosomes, rank 3 has no range
 def test_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, world, meta):
     assignumis = importlib.import_module("sicelore_amd.assignumis")
     in_bam, refflat, rows, tail = _make_inputs(pkg, synth, gpu_ctx, tmp_path, meta)
@@ -112,7 +112,8 @@ def test_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, worl
     assert p.returncode == 0, p.stderr[-3000:]
     infos = [json.load(open(many + f".info_rank{r}.json")) for r in range(world)]
     assert infos[0]["records"] == a["records"] == len(rows) + len(tail) and infos[0]["gene_keys_order_dependent"] == 0
-    assert all(i["records"] > 0 for i in infos[1:]) and sum(i["records"] for i in infos[1:]) < a["records"]      # every rank had a share of its own
+    assert all(i["records"] > 0 for i in infos[1:3]) and sum(i["records"] for i in infos[1:]) < a["records"]      # every rank had a share of its own
+    assert all(i["records"] == 0 for i in infos[3:])                                                           # ... or none, and said so
     for name in (".bam", "_umifound_.bam"):
         got, want = bammodel.bgzf_decompress(open(many + name, "rb").read()), bammodel.bgzf_decompress(open(one + name, "rb").read())
         if got != want:
@@ -148,3 +149,50 @@ def test_command_line_under_torchrun_equals_one_process(pkg, synth, gpu_ctx, tmp
     for suffix in (".genecounts.tsv", ".UMIdepths.tsv"):
         assert open(str(tmp_path / "cli_one") + suffix).read() == open(str(tmp_path / "cli_two") + suffix).read(), suffix
     assert not any(".shard" in f for f in os.listdir(tmp_path))
+
+
+@pytest.mark.gpu
+def test_shards_without_a_process_group_then_merge_shards(pkg, synth, gpu_ctx, tmp_path):
+    """shard=(rank, world) runs one after the other (a scheduler's jobs, no torch.distributed between them), merge_shards afterwards: the
+    single process's files; three shards of a three-chromosome BAM, then five (two of them without a range)"""
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    in_bam, refflat, rows, tail = _make_inputs(pkg, synth, gpu_ctx, tmp_path, False)
+    text = open(refflat).read()
+    one = str(tmp_path / "one")
+    a = assignumis.assignumis_stream(gpu_ctx, in_bam, one, segment_bytes=9_000, chunk_size=90, n_threads=2, refflat=text)
+    for world in (3, 5):
+        many = str(tmp_path / f"many{world}")
+        infos = [assignumis.assignumis_stream(gpu_ctx, in_bam, many, segment_bytes=9_000, chunk_size=90, n_threads=2, refflat=text, shard=(r, world))
+                 for r in range(world)]
+        assert sum(i["records"] for i in infos) == a["records"] and [i["records"] for i in infos[3:]] == [0] * (world - 3)
+        with pytest.raises(pkg.SmiError, match="missing"):
+            assignumis.merge_shards(many, world + 1)
+        m = assignumis.merge_shards(many, world)
+        assert m["gene_keys_order_dependent"] == 0
+        for name in (".bam", "_umifound_.bam"):
+            assert bammodel.bgzf_decompress(open(many + name, "rb").read()) == bammodel.bgzf_decompress(open(one + name, "rb").read()), name
+        for name in (".genecounts.tsv", ".UMIdepths.tsv"):
+            assert open(many + name).read() == open(one + name).read(), name
+    assert not any(".shard" in f for f in os.listdir(tmp_path))
+
+
+@pytest.mark.gpu
+def test_stale_or_foreign_index_is_refused(pkg, synth, gpu_ctx, tmp_path):
+    """a BAM shorter than its index says (truncated file, stale .bai) and an index of another reference count stop the run with a message
+    instead of a reader that waits for bytes that never come"""
+    assignumis = importlib.import_module("sicelore_amd.assignumis")
+    in_bam, refflat, rows, tail = _make_inputs(pkg, synth, gpu_ctx, tmp_path, True)
+    whole = open(in_bam, "rb").read()
+    ext = assignumis.bai_ref_extents(in_bam + ".bai")
+    cut = str(tmp_path / "cut.bam")
+    with open(cut, "wb") as f:                       # ends inside the second chromosome: rank 0's range is whole, the index points behind the end
+        f.write(whole[:(ext[1][0] >> 16) + 100])
+    os.link(in_bam + ".bai", cut + ".bai")
+    with pytest.raises(pkg.SmiError, match="behind the end|truncated"):
+        assignumis.assignumis_stream(gpu_ctx, cut, str(tmp_path / "o1"), n_threads=2, shard=(0, 2))
+    other = str(tmp_path / "other.bam")
+    os.link(in_bam, other)
+    with open(other + ".bai", "wb") as f:
+        f.write(bammodel.bai_bytes(2, [], meta=False))
+    with pytest.raises(pkg.SmiError, match="not this file's index"):
+        assignumis.assignumis_stream(gpu_ctx, other, str(tmp_path / "o2"), n_threads=2, shard=(1, 2))
