@@ -50,51 +50,73 @@ __device__ __forceinline__ EqMasks eq_masks(uint64_t w) {
 // Three changes, none of which alters a result:
 //   * TWO recurrences per register: 12-bit fields at bits 0 .. 11 and 16 .. 27.  The only operation that crosses bit positions upwards is
 //     the addition (Eq & Pv) + Pv; its carry out of a field stops at bit 12 / 28 as long as Pv is zero there, so one extra AND per step
-//     (Pv &= 0x0FFF0FFF) keeps the fields apart.  The "+1 per text base" of the boundary row is OR 0x00010001 (and that also overwrites
-//     whatever the shift moved from the low field's guard bits into bit 16).  Nine distances = five runs: (i = 0, 1) x v for v = 0, 1, 2;
+//     (Pv &= 0x0FFF0FFF) keeps the fields apart (Eq and Mv may hold anything in the guard bits).  The "+1 per text base" of the boundary
+//     row is OR 0x00010001 (and that also overwrites whatever the shift moved from the low field's guard bits into bit 16).  Nine distances = five runs: (i = 0, 1) x v for v = 0, 1, 2;
 //     (i = 2) x (v = 0, 1); (i = 2, v = 2).
 //   * the distance is read off the last column at the end, D[12][12] = 12 + popcount(Pv) - popcount(Mv), instead of being followed step
 //     by step (two extractions and two adds per step and field).
-//   * the step is ONE asm block of seventeen two-operand instructions (and / or / xor / add / not on VGPRs and literals): those issue in two
-//     cycles instead of four, but only in unbroken runs -- a single three-operand form among them drags the rest to four cycles.  Five runs
-//     of 12 x 17 instructions = 2,040 issue cycles.
+//   * a step is one asm block of seventeen two-operand instructions (and / or / xor / add / not on VGPRs and literals): those issue in two
+//     cycles instead of four as long as they come in long runs.  Five runs of 12 x 17 instructions = 2,040 issue cycles; the ~ 450
+//     instructions around them (masks, look-ups, scores, the tile's shuffles) are four-cycle forms: 1,800 cycles.  Measured: 4,340 cycles
+//     per wave of pairs, 89 % of that issue bound.
 // The match masks: eq[j] = positions of read a equal to base j of read b is a 5-way select per text base -- ~ 100 compare / select
 // instructions per pair in round 4 (v_cndmask is the slowest VALU instruction of this chip).  Now every lane keeps a 16-entry table
 // indexed by the 4-bit code in LDS ([code][thread]: conflict-free, no other lane ever touches the column, so no barrier): the five live
-// entries are written per pair ALREADY in the packed forms the runs consume, codes that match nothing stay zero from the kernel's start.
+// entries are written per pair already in the packed form the runs consume, codes that match nothing stay zero from the kernel's start.
 #ifndef SMI_UMI_TILE_THREADS
 #define SMI_UMI_TILE_THREADS 256
 #endif
 constexpr int kUmiEqCols = SMI_UMI_TILE_THREADS > 256 ? SMI_UMI_TILE_THREADS : 256;  // a column per thread of the larger workgroup
 struct UmiEqTable {
-    uint2 e[16][kUmiEqCols];  // .x: fields (eq & 0xFFF, (eq >> 1) & 0xFFF) = pattern offsets 0 and 1; .y: (eq >> 2) in both fields = pattern offset 2
+    // entry = m | m << 15 for the 14-bit mask m: bits 0 .. 11 = m[0 .. 11] (pattern offset 0), bits 16 .. 27 = m[1 .. 12] (offset 1); what
+    // lands in the guard bits 12 .. 15 / 28 .. 31 is harmless in an Eq word (it never reaches Pv, and the scores mask it off Mv);
+    // entry >> 2 has m[2 .. 13] (offset 2) in its low field
+    uint32_t e[16][kUmiEqCols];
 };
 
-#define SMI_MYERS2_STEP(EQ)                                                                                         \
-    asm volatile("v_or_b32 %2, %5, %1\n\t"          /* Xv = Eq | Mv                                        */        \
-                 "v_and_b32 %3, %5, %0\n\t"         /* t  = Eq & Pv                                        */        \
-                 "v_add_u32 %3, %3, %0\n\t"         /* t += Pv       (carry stops at bit 12 / 28)          */        \
-                 "v_xor_b32 %3, %3, %0\n\t"         /* t ^= Pv                                             */        \
-                 "v_or_b32 %3, %3, %5\n\t"          /* Xh = t | Eq                                         */        \
-                 "v_or_b32 %4, %3, %0\n\t"          /* u  = Xh | Pv                                        */        \
-                 "v_not_b32 %4, %4\n\t"             /* u  = ~u                                             */        \
-                 "v_or_b32 %4, %1, %4\n\t"          /* Ph = Mv | u                                         */        \
-                 "v_and_b32 %3, %0, %3\n\t"         /* Mh = Pv & Xh  (clean: Pv is)                        */        \
-                 "v_add_u32 %4, %4, %4\n\t"         /* Ph <<= 1                                            */        \
-                 "v_or_b32 %4, 0x10001, %4\n\t"     /* Ph |= 1 in both fields (D[0][j] = j)                */        \
-                 "v_add_u32 %3, %3, %3\n\t"         /* Mh <<= 1                                            */        \
-                 "v_or_b32 %0, %2, %4\n\t"          /* w  = Xv | Ph                                        */        \
-                 "v_not_b32 %0, %0\n\t"             /* w  = ~w                                             */        \
-                 "v_or_b32 %0, %3, %0\n\t"          /* Pv = Mh | w                                         */        \
-                 "v_and_b32 %0, 0xfff0fff, %0\n\t"  /* the guard bits of Pv stay zero                      */        \
-                 "v_and_b32 %1, %4, %2\n\t"         /* Mv = Ph & Xv  (clean: Xv is)                        */        \
-                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                           \
-                 : "v"(EQ))
+#define SMI_M2_STEP(E)                                                                    \
+    "v_or_b32 %2, " E ", %1\n\t"       /* Xv = Eq | Mv                                  */ \
+    "v_and_b32 %3, " E ", %0\n\t"      /* t  = Eq & Pv                                  */ \
+    "v_add_u32 %3, %3, %0\n\t"         /* t += Pv       (carry stops at bit 12 / 28)    */ \
+    "v_xor_b32 %3, %3, %0\n\t"         /* t ^= Pv                                       */ \
+    "v_or_b32 %3, %3, " E "\n\t"       /* Xh = t | Eq                                   */ \
+    "v_or_b32 %4, %3, %0\n\t"          /* u  = Xh | Pv                                  */ \
+    "v_not_b32 %4, %4\n\t"             /* u  = ~u                                       */ \
+    "v_or_b32 %4, %1, %4\n\t"          /* Ph = Mv | u                                   */ \
+    "v_and_b32 %3, %0, %3\n\t"         /* Mh = Pv & Xh  (clean: Pv is)                  */ \
+    "v_add_u32 %4, %4, %4\n\t"         /* Ph <<= 1                                      */ \
+    "v_or_b32 %4, 0x10001, %4\n\t"     /* Ph |= 1 in both fields (D[0][j] = j)          */ \
+    "v_add_u32 %3, %3, %3\n\t"         /* Mh <<= 1                                      */ \
+    "v_or_b32 %0, %2, %4\n\t"          /* w  = Xv | Ph                                  */ \
+    "v_not_b32 %0, %0\n\t"             /* w  = ~w                                       */ \
+    "v_or_b32 %0, %3, %0\n\t"          /* Pv = Mh | w                                   */ \
+    "v_and_b32 %0, 0xfff0fff, %0\n\t"  /* the guard bits of Pv stay zero                */ \
+    "v_and_b32 %1, %4, %2\n\t"         /* Mv = Ph & Xv  (clean: Xv is)                  */
+// A statement per step (the default) lets the compiler put the waits for the table look-ups and a three-operand instruction of the next
+// run's masks between the steps; twelve steps in ONE statement keep the run pure and were SLOWER (27.5 against 25.9 ms: every look-up must
+// have arrived before the first step, and what the compiler would have slipped in runs afterwards in a block of its own) -- an odd
+// instruction per seventeen does not cost the two-cycle rate, a block of them does (NOTES R5.1).
+#ifdef SMI_UMI_RUN_MONO  // measurement variant (make VARIANT=mono EXTRA=-DSMI_UMI_RUN_MONO): 27.5 ms against 25.9 per 0.94 G pairs
+#define SMI_MYERS2_RUN(E, O)                                                                                                      \
+    asm volatile(SMI_M2_STEP("%5") SMI_M2_STEP("%6") SMI_M2_STEP("%7") SMI_M2_STEP("%8") SMI_M2_STEP("%9") SMI_M2_STEP("%10")      \
+                     SMI_M2_STEP("%11") SMI_M2_STEP("%12") SMI_M2_STEP("%13") SMI_M2_STEP("%14") SMI_M2_STEP("%15") SMI_M2_STEP("%16") \
+                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                                         \
+                 : "v"(E[O]), "v"(E[O + 1]), "v"(E[O + 2]), "v"(E[O + 3]), "v"(E[O + 4]), "v"(E[O + 5]), "v"(E[O + 6]), "v"(E[O + 7]), \
+                   "v"(E[O + 8]), "v"(E[O + 9]), "v"(E[O + 10]), "v"(E[O + 11]))
+#else
+#define SMI_MYERS2_ONE(X) asm volatile(SMI_M2_STEP("%5") : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b) : "v"(X))
+#define SMI_MYERS2_RUN(E, O)                                                                                                     \
+    do {                                                                                                                         \
+        SMI_MYERS2_ONE(E[O]); SMI_MYERS2_ONE(E[O + 1]); SMI_MYERS2_ONE(E[O + 2]); SMI_MYERS2_ONE(E[O + 3]); SMI_MYERS2_ONE(E[O + 4]);     \
+        SMI_MYERS2_ONE(E[O + 5]); SMI_MYERS2_ONE(E[O + 6]); SMI_MYERS2_ONE(E[O + 7]); SMI_MYERS2_ONE(E[O + 8]); SMI_MYERS2_ONE(E[O + 9]); \
+        SMI_MYERS2_ONE(E[O + 10]); SMI_MYERS2_ONE(E[O + 11]);                                                                    \
+    } while (0)
+#endif
 
 // min(distance, 5) of both fields << 12, ready to take the enumeration rank and the offsets in the low bits
 __device__ __forceinline__ void myers2_scores(uint32_t pv, uint32_t mv, uint32_t &lo, uint32_t &hi) {
     const int dl = 12 + __popc(pv & 0xFFFu) - __popc(mv & 0xFFFu);
-    const int dh = 12 + __popc(pv >> 16) - __popc(mv >> 16);
+    const int dh = 12 + __popc(pv >> 16) - __popc((mv >> 16) & 0xFFFu);  // (Pv's guard bits are zero, Mv's are not)
     lo = (uint32_t)min(dl, 5) << 12;  // limitedCompare: -1 above the threshold 4, stored as 5 (L343)
     hi = (uint32_t)min(dh, 5) << 12;
 }
@@ -108,46 +130,36 @@ __host__ __device__ constexpr uint32_t umi_rank_code(int i, int v) {
 
 __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable &T, int tid) {
     const EqMasks ma = eq_masks(a);
-    {
-        const uint32_t m5[5] = {ma.a, ma.g, ma.c, ma.t, ma.n};
-        const int code[5] = {1, 2, 4, 8, 15};
+    T.e[1][tid] = ma.a | (ma.a << 15);
+    T.e[2][tid] = ma.g | (ma.g << 15);
+    T.e[4][tid] = ma.c | (ma.c << 15);
+    T.e[8][tid] = ma.t | (ma.t << 15);
+    T.e[15][tid] = ma.n | (ma.n << 15);
+    uint32_t w[14], w2[14];
 #pragma unroll
-        for (int k = 0; k < 5; k++) {
-            const uint32_t m = m5[k], f2 = m >> 2;  // (14 bits: m >> 2 has 12)
-            T.e[code[k]][tid] = make_uint2((m & 0xFFFu) | ((m << 15) & 0x0FFF0000u), f2 | (f2 << 16));
-        }
-    }
-    uint32_t e01[14], f22[14];
+    for (int j = 0; j < 14; j++) w[j] = T.e[(uint32_t)(b >> (4 * j)) & 15u][tid];
 #pragma unroll
-    for (int j = 0; j < 14; j++) {
-        const uint32_t c = (uint32_t)(b >> (4 * j)) & 15u;
-        const uint2 x = T.e[c][tid];
-        e01[j] = x.x;
-        f22[j] = x.y;
-    }
-    uint32_t g[12];  // run 3: pattern offset 2 against text offsets 0 (low field) and 1 (high field)
+    for (int j = 0; j < 14; j++) w2[j] = w[j] >> 2;
+    uint32_t g[12];  // run 3: pattern offset 2 against text offsets 0 (low field) and 1 (high field): the low halves of w2[t] and w2[t + 1]
 #pragma unroll
-    for (int t = 0; t < 12; t++) g[t] = (f22[t] & 0xFFFFu) | (f22[t + 1] & 0xFFFF0000u);
+    for (int t = 0; t < 12; t++) g[t] = __builtin_amdgcn_perm(w2[t + 1], w2[t], 0x05040100u);
     uint32_t key = 0xFFFFFFFFu, lo, hi, t_xv, t_a, t_b;
 #pragma unroll
     for (int v = 0; v < 3; v++) {  // pattern offsets 0 / 1 against text offset v
         uint32_t pv = 0x0FFF0FFFu, mv = 0u;
-#pragma unroll
-        for (int t = 0; t < 12; t++) SMI_MYERS2_STEP(e01[v + t]);
+        SMI_MYERS2_RUN(w, v);
         myers2_scores(pv, mv, lo, hi);
         key = min(key, min(lo | umi_rank_code(0, v), hi | umi_rank_code(1, v)));
     }
     {
         uint32_t pv = 0x0FFF0FFFu, mv = 0u;
-#pragma unroll
-        for (int t = 0; t < 12; t++) SMI_MYERS2_STEP(g[t]);
+        SMI_MYERS2_RUN(g, 0);
         myers2_scores(pv, mv, lo, hi);
         key = min(key, min(lo | umi_rank_code(2, 0), hi | umi_rank_code(2, 1)));
     }
     {
         uint32_t pv = 0x0FFF0FFFu, mv = 0u;
-#pragma unroll
-        for (int t = 0; t < 12; t++) SMI_MYERS2_STEP(f22[2 + t]);  // (both fields hold the same problem)
+        SMI_MYERS2_RUN(w2, 2);  // (the high field holds leftovers: its result is not read)
         myers2_scores(pv, mv, lo, hi);
         key = min(key, lo | umi_rank_code(2, 2));
     }
@@ -157,7 +169,7 @@ __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable 
 // every lane's column of the table: the codes that match nothing (everything but A, G, C, T, N) are zero and stay zero
 __device__ __forceinline__ void umi_table_init(UmiEqTable &T, int tid) {
 #pragma unroll
-    for (int c = 0; c < 16; c++) T.e[c][tid] = make_uint2(0u, 0u);
+    for (int c = 0; c < 16; c++) T.e[c][tid] = 0u;
 }
 
 // ---- two mappings of pairs to lanes ---------------------------------------------------------------------------------------------------
