@@ -60,7 +60,7 @@ __device__ __forceinline__ EqMasks eq_masks(uint64_t w) {
 //     instructions around them (masks, look-ups, scores, the tile's shuffles) are four-cycle forms: 1,800 cycles.  Measured: 4,340 cycles
 //     per wave of pairs, 89 % of that issue bound.
 // The match masks: eq[j] = positions of read a equal to base j of read b is a 5-way select per text base -- ~ 100 compare / select
-// instructions per pair in round 4 (v_cndmask is the slowest VALU instruction of this chip).  Now every lane keeps a 16-entry table
+// instructions per pair in round 4.  Now every lane keeps a 16-entry table
 // indexed by the 4-bit code in LDS ([code][thread]: conflict-free, no other lane ever touches the column, so no barrier): the five live
 // entries are written per pair already in the packed form the runs consume, codes that match nothing stay zero from the kernel's start.
 #ifndef SMI_UMI_TILE_THREADS

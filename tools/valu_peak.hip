@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -216,6 +217,22 @@ DEF_KERNEL(dep1, "ONE dependent chain of 2-cycle forms", ROW_DEP, 8, 0)
 DEF_KERNEL(dep2, "TWO dependent chains of 2-cycle forms, interleaved", ROW_DEP2, 8, 0)
 DEF_KERNEL(dep1_vop3, "ONE dependent chain of 4-cycle forms", ROW_DEP_MAX3, 8, 0)
 
+// ---- round 5: what does a select cost?  v_cndmask_b32 alone reads 18.6 cycles above; is that the instruction, its VCC operand, or the stream?
+#define T_CND64(k) "v_cndmask_b32_e64 %" #k ", %" #k ", %8, s[40:41]\n\t"
+#define ROW_CND1_MAX7 "v_cndmask_b32 %0, %0, %8, vcc\n\t" T_MAX3(1) T_MAX3(2) T_MAX3(3) T_MAX3(4) T_MAX3(5) T_MAX3(6) T_MAX3(7)
+#define ROW_CND1_AND7 "v_cndmask_b32 %0, %0, %8, vcc\n\t" T_AND(1) T_AND(2) T_AND(3) T_AND(4) T_AND(5) T_AND(6) T_AND(7)
+#define ROW_CND2_MAX6 "v_cndmask_b32 %0, %0, %8, vcc\n\t" T_MAX3(1) T_MAX3(2) T_MAX3(3) "v_cndmask_b32 %4, %4, %8, vcc\n\t" T_MAX3(5) T_MAX3(6) T_MAX3(7)
+#define ROW_CMP_CND "v_cmp_lt_u32 vcc, %0, %8\n\t" T_MAX3(1) T_MAX3(2) "v_cndmask_b32 %0, %0, %9, vcc\n\t" T_MAX3(3) T_MAX3(4) T_MAX3(5) T_MAX3(6)
+#define ROW_CMP64_CND64 "v_cmp_lt_u32 s[40:41], %0, %8\n\t" T_MAX3(1) T_MAX3(2) "v_cndmask_b32_e64 %0, %0, %9, s[40:41]\n\t" T_MAX3(3) T_MAX3(4) T_MAX3(5) T_MAX3(6)
+#define ROW_MAX8 T_MAX3(0) T_MAX3(1) T_MAX3(2) T_MAX3(3) T_MAX3(4) T_MAX3(5) T_MAX3(6) T_MAX3(7)
+DEF_KERNEL(cnd_e64, "r5: v_cndmask_b32_e64 v,v,v,s[40:41]", ROWOF(T_CND64), 8, 0)
+DEF_KERNEL(cnd1_max7, "r5: 1 v_cndmask (vcc) + 7 v_max3 per row (rate counts all 8)", ROW_CND1_MAX7, 8, 0)
+DEF_KERNEL(cnd1_and7, "r5: 1 v_cndmask (vcc) + 7 v_and per row (rate counts all 8)", ROW_CND1_AND7, 8, 0)
+DEF_KERNEL(cnd2_max6, "r5: 2 v_cndmask (vcc) + 6 v_max3 per row (rate counts all 8)", ROW_CND2_MAX6, 8, 0)
+DEF_KERNEL(cmp_cnd, "r5: v_cmp vcc .. v_cndmask vcc + 6 v_max3 per row (rate counts all 8)", ROW_CMP_CND, 8, 0)
+DEF_KERNEL(cmp64_cnd64, "r5: v_cmp s[] .. v_cndmask_e64 s[] + 6 v_max3 per row (rate counts all 8)", ROW_CMP64_CND64, 8, 0)
+DEF_KERNEL(max8, "r5: 8 v_max3 per row (reference for the rows above)", ROW_MAX8, 8, 0)
+
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 8000;
     hipDeviceProp_t prop;
@@ -236,7 +253,9 @@ int main(int argc, char **argv) {
     double best_int = 0.0, best_vop3 = 0.0;
     std::string best_name;
     bool first = true;
+    const char *only = argc > 2 ? argv[2] : nullptr;  // run the entries whose name holds this text (e.g. "r5:")
     for (const Entry &en : registry()) {
+        if (only && !strstr(en.name, only)) continue;
         for (int wi = 0; wi < 4; ++wi) {
             const int W = waves_per_simd[wi];
             const size_t lds = (160 * 1024 / W) & ~(size_t)1023;  // W blocks fill a CU's LDS, a (W+1)-th does not fit
