@@ -1,7 +1,8 @@
 """The jar's command line in front of the library.
 
-    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar scanfastq  -d <dir> -o <dir> --bcEditDistance k [--compress] [--ncpu N] [-h] [-y] [-a file]
-    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w]
+    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar scanfastq  -d <dir[,dir..]> -o <dir> --bcEditDistance k [--compress] [--ncpu N] [-h] [-y] [-a file]
+                                                                [-g usedBarcodes] [-n] [-v regex] [-k skip] [-z only] [-s] [-u]
+    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w] [-b ed] [-u ed]
 
 become   python sicelore-2.1_amd scanfastq ... / assignumis ...   (the directory is runnable: __main__.py; a `java` wrapper that drops
 `-jar`, `-Xmx..` and the jar's name makes /root/reference/quickrun-2.1.sh:35,42 run unchanged, tests/test_cli_gpu.py does exactly that).
@@ -14,7 +15,7 @@ config.xml: the library's kernels are built for the shipped values of the knobs 
 thresholds, windows); those are CHECKED against the file and a different value stops the run with the knob's name -- nothing is silently
 ignored.  The knobs that are run-time parameters of the library are taken from the file: sam_records_chunk_size,
 max_GenomeDistance_forGrouping, fileWithAllPossibleTenXbarcodes.  Options the product has no path for (Illumina-guided modes, random
-barcodes, the file watcher) are refused by name.
+barcodes, the file watcher, other polyA windows than the shipped ones, -a none, assignumis -s) are refused by name.
 """
 import gzip
 import os
@@ -147,21 +148,26 @@ def _parse(argv, spec, refused):
 
 SCAN_SPEC = {"inDir": ("d", "inDir", True), "outDir": ("o", "outDir", True), "bcEditDistance": ("b", "bcEditDistance", True),
              "compress": ("c", "compress", False), "ncpu": ("t", "ncpu", True), "fivePbc": ("h", "fivePbc", False),
-             "noPolyARequired": ("y", "noPolyARequired", False), "bcWhitelist": ("a", "bcWhitelist", True), "logFile": ("l", "logFile", True)}
+             "noPolyARequired": ("y", "noPolyARequired", False), "bcWhitelist": ("a", "bcWhitelist", True), "logFile": ("l", "logFile", True),
+             # NanoporeReadScannerMain.java:L138-146, L180-183 (file selection), L211-213 (-s), L239-240 (-u), L245-246 (-g)
+             "cellRangerBCs": ("g", "cellRangerBCs", True), "skipNfastqs": ("k", "skipNfastqs", True), "onlyNfastqs": ("z", "onlyNfastqs", True),
+             "nonrecursive": ("n", "nonrecursive", False), "pattern": ("v", "pattern", True), "dontwrite": ("s", "dontwrite", False),
+             "trimfastq": ("u", "trimfastq", False)}
 SCAN_REFUSED = {o: why for opts, why in (
-    (("-g", "--cellRangerBCs"), "a supplied used-barcode list (pass 1 skipped) has no path in this build"),
     (("-e", "--randomBarcode"), "random barcodes (a specificity experiment of the reference) are not built"),
     (("-f", "--fractionAT", "-p", "--polyAlength", "-w", "--windowAT"), "the polyA finder is compiled for the shipped config.xml values (15 / 0.75 / 150)"),
-    (("-k", "--skipNfastqs", "-z", "--onlyNfastqs", "-n", "--nonrecursive", "-v", "--pattern"), "file selection options are not built: every *.fastq[.gz] of the directory is taken"),
-    (("-s", "--dontwrite"), "not built"), (("-u", "--trimfastq"), "the file-to-file driver writes untrimmed records (the chunk workers do trim: smi_pass2_config.trim_fastq)"))
+    (("-i",), "Use either -i or -d: only -d <directories> is built"))
     for o in opts}
 UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "outfile", True), "annotationFile": ("a", "annotationFile", True),
             "config": ("c", "config", True), "chunksize": ("v", "chunksize", True), "fivePbc": ("p", "fivePbc", False),
-            "splitReadName": ("w", "splitReadName", False), "logFile": ("l", "logFile", True), "ncpu": ("t", "ncpu", True)}
+            "splitReadName": ("w", "splitReadName", False), "logFile": ("l", "logFile", True), "ncpu": ("t", "ncpu", True),
+            # -b: barcodes whose ed in the read name is larger are ignored (UmiFinderMain.java:L181-182, FastqRecordExt.java:L450-456);
+            # -u: read by the Illumina-guided UMI analyzer only (IlluminaUMIanalyzer) -- accepted, checked to be a number, without effect here
+            "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True)}
 UMI_REFUSED = {o: why for opts, why in (
     (("-k", "--inFile10x", "-g", "--ONTgene", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
     (("-e", "--randomBarcode", "-f", "--randomUMI"), "random barcodes / UMIs (a specificity experiment of the reference) are not built"),
-    (("-s", "--noclustering"), "not built"), (("-b", "--bcedit", "-u", "--umiedit"), "the clustering distances are the shipped config.xml's (2 / 1)"))
+    (("-s", "--noclustering"), "not built"),)
     for o in opts}
 
 
@@ -203,21 +209,60 @@ def scanfastq(argv):
     knobs = read_config(find_config())
     if knobs.get("readscanner/mergeBCsED", "null") not in ("null", "", str(ed)):
         raise CliError("readscanner/mergeBCsED: only null (= the barcode edit distance) is built")
-    if not os.path.isdir(o["inDir"]):
-        raise CliError(f"input directory {o['inDir']} does not exist")
-    wl_name = o.get("bcWhitelist") or knobs.get("readscanner/fileWithAllPossibleTenXbarcodes", "3M-february-2018.txt.gz")
-    if wl_name == "none":
-        raise CliError("-a none (every 16-mer is a possible barcode) is not built")
-    wl = next((p for p in (wl_name, os.path.join(os.getcwd(), wl_name), os.path.join(_HERE, wl_name)) if os.path.isfile(p)), None)
-    if wl is None:
-        raise CliError(f"file with all possible barcodes {wl_name!r} not found (looked in the working directory and in {_HERE}); "
-                       "-a <file> names it (ReadScannerParameters.java:L247)")
-    keys = read_barcode_file(wl)
+    for d in [d for d in o["inDir"].split(",") if d]:            # -d takes a comma-separated list (FileTools.java:L52)
+        if not os.path.isdir(d):
+            raise CliError(f"input directory {d} does not exist")
+    def number(name):
+        try:
+            v = int(o[name])
+        except ValueError:
+            raise CliError(f"--{name} {o[name]!r}: not a number")
+        if v < 0:
+            raise CliError(f"--{name} {v}: negative")
+        return v
+
+    skip = number("skipNfastqs") if "skipNfastqs" in o else 0
+    only = number("onlyNfastqs") if "onlyNfastqs" in o else None
     from . import run_files
+    used = None
+    if "cellRangerBCs" in o:
+        # -g: pass 1 is skipped and this list is searched (L300-302).  A file that does not exist is a warning in the reference, which then
+        # runs both passes (ReadScannerParameters.java:L277-279); the whitelist is not needed with it (L246)
+        if os.path.isfile(o["cellRangerBCs"]):
+            used = read_barcode_file(o["cellRangerBCs"])
+            print(f"Using Barcodes from: {o['cellRangerBCs']}\nCellranger list of barcodes was supplied --> skipping 1st pass (Search for used barcodes)")
+        else:
+            print(f"Warning: File with CellRanger barcodes {o['cellRangerBCs']} not found. Despite being provided in command line. "
+                  "Searching Barcodes without CellRanger data", file=sys.stderr)
+    keys = None
+    if used is None:
+        wl_name = o.get("bcWhitelist") or knobs.get("readscanner/fileWithAllPossibleTenXbarcodes", "3M-february-2018.txt.gz")
+        if wl_name.lower() in ("none", "null"):
+            raise CliError("-a none (every 16-mer is a possible barcode) is not built")
+        wl = next((p for p in (wl_name, os.path.join(os.getcwd(), wl_name), os.path.join(_HERE, wl_name)) if os.path.isfile(p)), None)
+        if wl is None:
+            raise CliError(f"file with all possible barcodes {wl_name!r} not found (looked in the working directory and in {_HERE}); "
+                           "-a <file> names it (ReadScannerParameters.java:L247)")
+        keys = read_barcode_file(wl)
+    if o["outDir"] != "null":              # (-o null: statistics only, NanoporeReadScannerMain.java:L216)
+        parent = os.path.dirname(os.path.abspath(o["outDir"]))
+        if not os.path.isdir(parent):
+            raise CliError(f"parent directory of output directory {o['outDir']} must exist")
+    else:
+        raise CliError("-o null (no output directory at all) is not built: -s keeps the statistics and TSVs and writes no FASTQ")
+    if skip:
+        print(f"skipping first {skip} fastq files as specified in command line")
+    if only is not None:
+        print(f"using only {only} fastq files as specified in command line")
+    if "dontwrite" in o:
+        print("Stats only, Won't write fastqs")
     ctx = _context()
     ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
     info = run_files.run(ctx, o["inDir"], o["outDir"], max_ed=ed, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
-                         dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")))
+                         dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")),
+                         recursive="nonrecursive" not in o, pattern=o.get("pattern", run_files.FASTQ_PATTERN), skip_files=skip, only_files=only,
+                         used_keys=used, write_fastqs="dontwrite" not in o, trim_fastq="trimfastq" in o)
+    print(f"{info.get('files', 0)} Files found")
     print(f"DONE -- {info.get('reads', 0)} reads, {info.get('passed', 0)} passed, {info.get('assigned', 0)} barcode-assigned, "
           f"{info.get('wall_s', 0.0):.1f} s")
     return 0
@@ -242,10 +287,19 @@ def assignumis(argv):
     if "annotationFile" in o:          # refFlat text, gz or plain (picard's RefFlatReader through IOUtil)
         with (gzip.open if o["annotationFile"].endswith(".gz") else open)(o["annotationFile"], "rt") as f:
             refflat = f.read()
+    bc_limit = None
+    for name in ("bcedit", "umiedit"):
+        if name in o:
+            try:
+                v = int(o[name])
+            except ValueError:
+                raise CliError(f"--{name} {o[name]!r}: not a number")
+            if name == "bcedit":
+                bc_limit = v
     ctx = _context()
     ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
-                                refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")))
+                                refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit)
     if info.get("rank", 0) == 0:       # rank 0 holds the whole run's counts (assignumis_stream gathers them)
         print(f"DONE -- {info['records']} records, {info['clustered']} in UMI clusters")
         bad = int(info.get("gene_keys_order_dependent", 0))

@@ -45,6 +45,37 @@ def _inflate(path, pinned=False):
     return _lib.gz_inflate(raw, alloc=alloc)
 
 
+FASTQ_PATTERN = r".{1,}\.fastq(\.gz)?"     # ParametersReadScannerApp$Files.fastqFilenamePattern (ParametersReadScannerApp.java:L203)
+
+
+def find_fastqs(in_dirs, recursive=True, pattern=FASTQ_PATTERN, skip=0, limit=None):
+    """the input files as the reference finds them (FileTools.getInfiles, FileTools.java:L37-59 + FoundFiles.initialize L81-82): `in_dirs` is a
+    comma-separated list of directories, each walked (all levels, or only the directory itself with -n; links followed), the regular files of
+    all of them ordered by FILE NAME (Path.getFileName().compareTo: the directory plays no part; equal names keep the walk's order, which is
+    the file system's there and the sorted one here), kept when the WHOLE path matches `pattern` (String.matches; -v), then the first `skip`
+    dropped (-k) and at most `limit` taken (-z) -> list of paths"""
+    import re
+
+    found = []
+    for d in str(in_dirs).split(","):
+        if not d:
+            continue
+        if not os.path.isdir(d):
+            raise _lib.SmiError(f"Error did not find input files: {d}")
+        if recursive:
+            for root, dirs, names in os.walk(d, followlinks=True):
+                dirs.sort()
+                found += [os.path.join(root, n) for n in sorted(names)]
+        else:
+            found += [os.path.join(d, n) for n in sorted(os.listdir(d))]
+    found = [f for f in found if os.path.isfile(f)]
+    found.sort(key=os.path.basename)                      # (stable: equal names stay in walk order)
+    rx = re.compile(pattern) if pattern is not None else None
+    found = [f for f in found if rx is None or rx.fullmatch(f)]
+    found = found[int(skip):]
+    return found if limit is None else found[:int(limit)]
+
+
 def write_synthetic_dir(synth, out_dir, n_files, reads_per_file, used, device, seed=9000, chimera_frac=0.05, gz_level=1, pool=None, q_lo=35, q_hi=64):
     """test / bench input: n_files `*.fastq.gz` of reads_per_file synthetic reads each (generator of synth.py), qualities drawn uniformly
     per base (constant qualities would flatter every gzip step) -> total reads"""
@@ -113,7 +144,8 @@ def _gzip_member(data, level):
 
 def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
         dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="host", device_share=0.25, group=None, resident_bytes=96 << 30,
-        host_text_bytes=256 << 30, inflate_auto_from=1024):
+        host_text_bytes=256 << 30, inflate_auto_from=1024, recursive=True, pattern=r".{1,}\.(fastq|fq)(\.gz)?", skip_files=0, only_files=None,
+        used_keys=None, write_fastqs=True, trim_fastq=False):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
@@ -130,7 +162,13 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     With torch.distributed initialised (one process per GPU) the directory's files are dealt to the ranks in contiguous runs; the only
     exchanges are the pass-1 histogram (one all-reduce, then the same finalize on every rank), the records in front of each rank (read ids),
     and the counters behind the two TSVs and the statistics, which rank 0 writes.  Every rank writes the output files of its own inputs; the
-    result is the single-process run's, byte for byte."""
+    result is the single-process run's, byte for byte.
+    in_dir / recursive / pattern / skip_files / only_files: find_fastqs (-d, -n, -v, -k, -z; the command line passes the reference's own
+    default pattern, a direct caller also gets *.fq).  used_keys (-g <file>, NanoporeReadScannerMain.java:L300-302): the barcodes in use are
+    SUPPLIED -- pass 1 is skipped, the files are only inflated and counted, every barcode has rank 0 (no rk= in the names,
+    WorkerReadscanner$BarcodesMapForBCfinding.getMapFromCellRangerData L437) and no BarcodeList.tsv is written (pass 1 writes it).
+    write_fastqs=False (-s, L211-213): statistics and TSVs only.  trim_fastq (-u): records cut as FastqRecordExt.getRecordForWriting does
+    with trimFastq."""
     import torch.distributed as dist
 
     multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -141,16 +179,19 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         raise ValueError("inflate: 'auto' (the device takes a share from 1024 *.gz files on: one wavefront per file is much slower than a host thread, a thousand at once are not), 'device' or 'host'")
     on_device = compress and gz == "device"
     t_all = time.perf_counter()
-    files = sorted(f for f in os.listdir(in_dir) if f.endswith((".fastq", ".fq", ".fastq.gz", ".fq.gz")))
+    files = find_fastqs(in_dir, recursive=recursive, pattern=pattern, skip=skip_files, limit=only_files)     # full paths
     if not files:
-        raise _lib.SmiError(f"no FASTQ files in {in_dir}")
+        raise _lib.SmiError(f"NO INPUT FILES FOUND in {in_dir}")
+    given = used_keys is not None
     if multi:
         from . import distributed as _dist
 
         lo_f, hi_f = _dist.shard_range(len(files), rank, world)
         files = files[lo_f:hi_f]          # (a rank without files still takes part in the exchanges)
-    os.makedirs(os.path.join(out_dir, "passed"), exist_ok=True)
-    os.makedirs(os.path.join(out_dir, "failed"), exist_ok=True)
+    os.makedirs(out_dir, exist_ok=True)
+    if write_fastqs:
+        os.makedirs(os.path.join(out_dir, "passed"), exist_ok=True)
+        os.makedirs(os.path.join(out_dir, "failed"), exist_ok=True)
     pool = ThreadPoolExecutor(n_workers)
     lanes = [ctx] + [ctx.lane() for _ in range(n_workers)]     # one per worker thread, and one for the thread that drives K-INFLATE
     free = list(range(n_workers + 1))
@@ -165,7 +206,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         return call
 
     dev = torch.device("cuda", ctx.device)
-    keys = np.ascontiguousarray(whitelist_keys, dtype=np.uint64)
+    keys = np.unique(np.ascontiguousarray(used_keys, dtype=np.uint64)) if given else np.ascontiguousarray(whitelist_keys, dtype=np.uint64)
     # ---- inflate + pass 1: a file's chunks go to the device as soon as the file is inflated (the host inflates the next one meanwhile) -----
     t0 = time.perf_counter()
     import threading
@@ -176,10 +217,11 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     def load_set():
         """the possible barcodes on the device (125 ms for 3.6 M of them); the worker threads inflate their first files meanwhile"""
         try:
-            ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
-            for ln in lanes[1:]:
-                ln.refresh()
-            torch.cuda.synchronize()
+            if not given:                       # (a supplied list is loaded once, as the used list, after the files are read)
+                ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
+                for ln in lanes[1:]:
+                    ln.refresh()
+                torch.cuda.synchronize()
         finally:
             set_ready.set()                      # (on an error the workers' calls fail instead of waiting for ever)
 
@@ -187,6 +229,13 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     owners = [None] * len(files)
 
     def p1(lane, text, rng):
+        if given:                               # -g: no pass 1, only the chunk's record count (lines / 4, as the chunk cutter counts them)
+            part = text[rng[0]:rng[1]]
+            if part.numel() if hasattr(part, "numel") else part.size:
+                lines = int((part == 10).sum()) + (0 if int(part[-1]) == 10 else 1)
+            else:
+                lines = 0
+            return lines // 4
         # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
         set_ready.wait()
         return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
@@ -217,7 +266,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
 
     def load_and_count(fi):
         t1 = time.perf_counter()
-        path = os.path.join(in_dir, files[fi])
+        path = files[fi]
         resident = on_device and held[0] + 3 * os.path.getsize(path) <= resident_bytes     # (a soft limit: the threads race for its last bytes)
         if resident and path.endswith(".gz"):
             t, owner = _lib.gz_inflate(np.fromfile(path, dtype=np.uint8), alloc=stage_alloc)
@@ -297,7 +346,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                     return [todo.pop() for _ in range(min(per_round, len(todo)))]
 
             def prepare(mine, k):
-                paths = [os.path.join(in_dir, files[fi]) for fi in mine]
+                paths = [files[fi] for fi in mine]
                 need = sum(((os.path.getsize(p_) + 511) & ~511) for p_ in paths) + 1024
                 if slots[k] is None or slots[k].array.size < need:
                     if slots[k] is not None:
@@ -381,21 +430,26 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     ids_in_front = 0
     if multi:
         # one all-reduce of the dense histogram (RCCL on the device tensor), the chunk counts with it; records in front of this rank's files
-        hist, record_count = _dist.allreduce_histogram(hist, record_count, group)
+        if not given:
+            hist, record_count = _dist.allreduce_histogram(hist, record_count, group)
         xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")   # (gloo in the tests: small tensors on the host)
         mine = torch.tensor([int(sum(n_rec))], dtype=torch.int64, device=xdev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine, group=group)
         ids_in_front = int(sum(int(t.item()) for t in every[:rank]))
-    h = hist.cpu().numpy()
-    nz = np.nonzero(h)[0]
-    k, c, r = _lib.finalize_used_list(keys[nz], h[nz].astype(np.uint32), record_count, max_ed, 10, 500)
-    if rank == 0:
-        with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
-            f.write(_lib.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, max_ed))
-    order = np.argsort(k)
-    rk_keys, rk_vals = k[order], r[order].astype(np.int32)
-    ctx.set_barcode_set(k, mode=_lib.SET_USED_LIST)
+    if given:
+        # the supplied list IS the search set: counts and ranks 0 (CountsRank(0, 0)); the reference runs no collision merge on it
+        k, rk_keys, rk_vals = keys, keys, None
+    else:
+        h = hist.cpu().numpy()
+        nz = np.nonzero(h)[0]
+        k, c, r = _lib.finalize_used_list(keys[nz], h[nz].astype(np.uint32), record_count, max_ed, 10, 500)
+        if rank == 0:
+            with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
+                f.write(_lib.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, max_ed))
+        order = np.argsort(k)
+        rk_keys, rk_vals = k[order], r[order].astype(np.int32)
+    ctx.set_barcode_set(k, mode=_lib.SET_WHITELIST if given else _lib.SET_USED_LIST)
     for ln in lanes[1:]:
         ln.refresh()
     t_finalize = time.perf_counter() - t0
@@ -417,7 +471,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
                 ent = again[fi] = [None, chunks_of[fi], threading.Lock()]
         with ent[2]:
             if ent[0] is None:
-                ent[0] = _inflate(os.path.join(in_dir, files[fi]))[0]
+                ent[0] = _inflate(files[fi])[0]
         return ent[0]
 
     def text_done(fi):
@@ -440,13 +494,15 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         out_state[fi_] = [threading.Lock(), 0, {}, None]
 
     def out_names(fi):
-        base = files[fi]
+        base = os.path.basename(files[fi])
         for suf in (".gz", ".fastq", ".fq"):
             if base.endswith(suf):
                 base = base[:-len(suf)]
         return os.path.join(out_dir, "passed", base + "_passed" + ext), os.path.join(out_dir, "failed", base + "_failed" + ext)
 
     def deliver(fi, ci, zp, zf):
+        if not write_fastqs:
+            return
         st = out_state[fi]
         with st[0]:
             st[2][ci] = (zp, zf)
@@ -466,8 +522,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     def p2(lane, j):
         fi, ci, rng = chunks[j]
         text_j = text_of(fi)[rng[0]:rng[1]]
-        passed, failed, info = lane.scanfastq_pass2_chunk(text_j, max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya,
-                                                          first_read_id=int(first_id[j]), rank_keys=rk_keys, rank_values=rk_vals, want_results=True, copy=False,
+        passed, failed, info = lane.scanfastq_pass2_chunk(text_j, max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya, trim_fastq=trim_fastq,
+                                                          first_read_id=int(first_id[j]), rank_keys=None if given else rk_keys, rank_values=rk_vals, want_results=True, copy=False,
                                                           packed=not on_device, n_threads=host_threads_per_call, compress=on_device)
         bc = info["bc"] if info["n_records_out"] else np.zeros(0, dtype=_lib.BC_RESULT_DTYPE)
         ok = bc["found"] == 1
@@ -491,7 +547,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     # ---- files of inputs without a record (no chunk): empty outputs, as the reference's writer threads leave them -------------------------
     t0 = time.perf_counter()
     for fi in range(len(files)):
-        if fi not in out_state:
+        if fi not in out_state and write_fastqs:
             for nm in out_names(fi):
                 open(nm, "wb").close()
     stats = np.zeros(_lib.N_SCAN_STATS, dtype=np.uint64)

@@ -35,7 +35,10 @@ def test_cli_refuses_what_it_does_not_implement(tmp_path):
     env = dict(os.environ, java=_wrapper(tmp_path))
     (tmp_path / "in").mkdir()
     for cmd, needle in (("$java -jar x.jar scanfastq -d in -o out", "bcEditDistance"),
-                        ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --cellRangerBCs list.txt", "cellRangerBCs"),
+                        ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --randomBarcode", "randomBarcode"),
+                        ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 -k some", "not a number"),
+                        ("$java -jar x.jar scanfastq -d in,nowhere -o out --bcEditDistance 1", "nowhere does not exist"),
+                        ("$java -jar x.jar assignumis -i in.bam -o out.bam --noclustering", "noclustering"),
                         ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --frobnicate", "unknown option"),
                         ("$java -jar x.jar scanfastq -d nowhere -o out --bcEditDistance 1", "does not exist"),
                         ("$java -jar x.jar assignumis -o out.bam", "inFileNanopore"),
@@ -45,6 +48,30 @@ def test_cli_refuses_what_it_does_not_implement(tmp_path):
     (tmp_path / "config.xml").write_text("<Parameters><polyAT><polyATlength>18</polyATlength></polyAT></Parameters>")
     r = _run("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1", env, str(tmp_path))
     assert r.returncode == 1 and "polyAT/polyATlength" in r.stderr
+
+
+def test_find_fastqs_orders_by_file_name_and_filters(pkg, tmp_path):
+    """FileTools.getInfiles + FoundFiles.initialize: comma-separated directories, all levels unless -n, ordered by FILE NAME (not by path),
+    the whole path against the pattern, then skip / limit"""
+    import importlib
+
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    a, b = tmp_path / "a", tmp_path / "b"
+    (a / "deep" / "er").mkdir(parents=True)
+    b.mkdir()
+    for p_ in (a / "r3.fastq", a / "deep" / "r1.fastq.gz", a / "deep" / "er" / "r5.fastq", b / "r2.fastq", b / "r4.fq", a / "notes.txt", a / "r6.fastq.bak"):
+        p_.write_bytes(b"")
+    both = f"{a},{b}"
+    base = lambda fs: [os.path.basename(f) for f in fs]  # noqa: E731
+    assert base(run_files.find_fastqs(both)) == ["r1.fastq.gz", "r2.fastq", "r3.fastq", "r5.fastq"]          # r4.fq, notes.txt, *.bak: not the pattern
+    assert base(run_files.find_fastqs(both, recursive=False)) == ["r2.fastq", "r3.fastq"]
+    assert base(run_files.find_fastqs(both, skip=1, limit=2)) == ["r2.fastq", "r3.fastq"]
+    assert base(run_files.find_fastqs(both, pattern=r".*/deep/.*")) == ["r1.fastq.gz", "r5.fastq"]             # (the whole path is matched)
+    assert base(run_files.find_fastqs(both, pattern=None)) == ["notes.txt", "r1.fastq.gz", "r2.fastq", "r3.fastq", "r4.fq", "r5.fastq", "r6.fastq.bak"]
+    assert run_files.find_fastqs(str(b), skip=5) == []
+    from sicelore_amd import lib as libmod
+    with pytest.raises(libmod.SmiError, match="did not find"):
+        run_files.find_fastqs(str(tmp_path / "nowhere"))
 
 
 @pytest.mark.gpu
@@ -114,3 +141,17 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
         n_u8 += "U8" in tags
         n_ge += "GE" in tags
     assert n_u8 > 0.9 * len(out) and n_ge > 0.3 * len(out)
+    # ---- the other options of the two sub-commands, parsed and acted on (tests/test_run_files_gpu.py holds their results to the default run's)
+    listed = [ln.split("\t")[0] for ln in open(readscandir + "BarcodesAssigned.tsv").read().split("\n")[1:] if ln]
+    (work / "used.txt").write_text("".join(b_ + "-1\n" for b_ in listed))
+    r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan2 --bcEditDistance 1 -g used.txt -s -n -k 1 -z 2 -u -v '.*synth_.*'", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "2 Files found" in r.stdout and "skipping 1st pass" in r.stdout and "Won't write fastqs" in r.stdout
+    assert sorted(os.listdir(str(work / "scan2"))) == ["BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    r = _run(STEP3.replace("passedParsed.bam", "limited.bam") + " -b 0 -u 1", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, _, lim = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "limited.bam", "rb").read()))
+    n_bc = lambda recs: sum(any(t == "BC" for t, _ty, _v in _parse_aux(o_["aux"])) for o_ in recs)  # noqa: E731
+    exact = sum("_ed=0_" in o_["name"] for o_ in out)
+    assert 0 < exact < len(out) and n_bc(lim) == exact and n_bc(out) == len(out)       # -b 0: only the barcodes read without an error count
+

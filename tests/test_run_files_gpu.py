@@ -130,3 +130,61 @@ def test_two_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path):
             assert open(os.path.join(one, sub, f), "rb").read() == open(os.path.join(two, sub, f), "rb").read(), f
     for f in ("BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"):
         assert open(os.path.join(one, f)).read() == open(os.path.join(two, f)).read(), f
+
+
+def test_supplied_barcode_list_dontwrite_trim_and_file_selection(pkg, synth, gpu_ctx, tmp_path):
+    """-g (pass 1 skipped, the supplied list searched, rank 0 = no rk=), -s (no FASTQ written, same tables), -u (trimmed records), and the file
+    selection options, against the default run of the same directory"""
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    dev = torch.device("cuda", gpu_ctx.device)
+    wl = synth.make_whitelist(60_000, seed=821, device=dev)
+    used = synth.pick_used(wl, 50, seed=822)
+    keys = np.sort(wl.cpu().numpy().astype(np.uint64))
+    in_dir = str(tmp_path / "in")
+    n = run_files.write_synthetic_dir(synth, in_dir, 4, 1500, used, dev, seed=830, chimera_frac=0.05)
+    os.makedirs(os.path.join(in_dir, "sub"))
+    os.rename(os.path.join(in_dir, "synth_0003.fastq.gz"), os.path.join(in_dir, "sub", "synth_0003.fastq.gz"))
+    kw = dict(max_ed=1, n_workers=3, reads_per_chunk=700, whitelist_keys=keys, pattern=run_files.FASTQ_PATTERN)
+    d0 = str(tmp_path / "default")
+    a = run_files.run(gpu_ctx, in_dir, d0, **kw)
+    assert a["files"] == 4 and a["reads"] == n                                  # the sub-directory's file is found (recursive by default)
+    rows = [ln.split("\t") for ln in open(os.path.join(d0, "BarcodesAssigned.tsv")).read().split("\n")[1:] if ln]
+    code = {"A": 0, "G": 1, "C": 2, "T": 3}
+    listed = np.array(sorted(sum(code[c] << (2 * (15 - i)) for i, c in enumerate(r_[0])) for r_ in rows), dtype=np.uint64)
+    assert listed.size == a["used_list"]
+    # -g with the list pass 1 arrived at: the same records, without the rank field
+    d1 = str(tmp_path / "given")
+    b = run_files.run(gpu_ctx, in_dir, d1, used_keys=listed, **kw)
+    assert b["reads"] == n and b["used_list"] == listed.size and b["assigned"] == a["assigned"] and not os.path.exists(os.path.join(d1, "BarcodeList.tsv"))
+    rk = re.compile(rb"_rk=[0-9]+")
+    for sub, suf in (("passed", "_passed.fastq.gz"), ("failed", "_failed.fastq.gz")):
+        for fi in range(4):
+            x = gzip.open(os.path.join(d0, sub, f"synth_{fi:04d}{suf}")).read()
+            y = gzip.open(os.path.join(d1, sub, f"synth_{fi:04d}{suf}")).read()
+            assert b"_rk=" not in y and rk.sub(b"", x) == y, (sub, fi)
+    assert open(os.path.join(d1, "BarcodesAssigned.tsv")).read() == open(os.path.join(d0, "BarcodesAssigned.tsv")).read()
+    assert open(os.path.join(d1, "ReadScanner.tsv")).read() == open(os.path.join(d0, "ReadScanner.tsv")).read()
+    # -s: statistics and tables only
+    d2 = str(tmp_path / "dontwrite")
+    c = run_files.run(gpu_ctx, in_dir, d2, write_fastqs=False, **kw)
+    assert c["assigned"] == a["assigned"] and sorted(os.listdir(d2)) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    for nm in ("BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv"):
+        assert open(os.path.join(d2, nm)).read() == open(os.path.join(d0, nm)).read(), nm
+    # -u: the same records by name, every trimmed read a piece of the untrimmed one
+    d3 = str(tmp_path / "trim")
+    run_files.run(gpu_ctx, in_dir, d3, trim_fastq=True, **kw)
+    x = gzip.open(os.path.join(d0, "passed", "synth_0001_passed.fastq.gz")).read().split(b"\n")
+    y = gzip.open(os.path.join(d3, "passed", "synth_0001_passed.fastq.gz")).read().split(b"\n")
+    assert x[0::4] == y[0::4] and len(x) > 1000
+    shorter = 0
+    for full, cut, fq, cq in zip(x[1::4], y[1::4], x[3::4], y[3::4]):
+        assert cut in full and len(cq) == len(cut) and cq in fq
+        shorter += len(cut) < len(full)
+    assert shorter > 0.5 * (len(x) // 4)
+    # file selection: -n, -k / -z in file-name order, -v
+    e = run_files.run(gpu_ctx, in_dir, str(tmp_path / "flat"), recursive=False, **kw)
+    assert e["files"] == 3 and sorted(os.listdir(str(tmp_path / "flat" / "passed"))) == [f"synth_{k:04d}_passed.fastq.gz" for k in range(3)]
+    f_ = run_files.run(gpu_ctx, in_dir, str(tmp_path / "some"), skip_files=1, only_files=2, **kw)
+    assert f_["files"] == 2 and sorted(os.listdir(str(tmp_path / "some" / "passed"))) == [f"synth_{k:04d}_passed.fastq.gz" for k in (1, 2)]
+    g = run_files.run(gpu_ctx, in_dir, str(tmp_path / "pat"), **dict(kw, pattern=r".*/sub/.*\.fastq\.gz"))
+    assert g["files"] == 1 and os.listdir(str(tmp_path / "pat" / "passed")) == ["synth_0003_passed.fastq.gz"]
