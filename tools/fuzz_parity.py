@@ -105,6 +105,45 @@ def check_umi_stage(pkg, synth, sor, ctx, seed):
     return True, f"umi_stage seed={seed} 5p={five} records={len(names)} done={n_done} clustered={int((tags['flags'] & 1 != 0).sum())}"
 
 
+def check_umi_pairs(pkg, synth, sor, ctx, seed):
+    """K-UMI alone (round 5: two Myers recurrences per register, match masks from an LDS table): matrices of groups on both sides of every
+    tile edge against the oracle's, windows with close and distant UMIs, with and without N"""
+    rng = np.random.default_rng(seed)
+    sizes = [int(x) for x in rng.choice([1, 2, 3, 7, 31, 63, 64, 65, 66, 127, 128, 129, 200, 257, 300], size=int(rng.integers(3, 9)))]
+    codes = [1, 2, 4, 8] if seed % 3 else [1, 2, 4, 8, 15, 15]     # the window packers know A, G, C, T and N (anything else) -- no other code exists
+    ws = []
+    for n in sizes:
+        n_umi = max(1, n // int(rng.choice([2, 3, 10])))
+        umis = rng.choice([1, 2, 4, 8] if seed % 5 else [1, 2], size=(n_umi, 14)).astype(np.uint8)     # (two-letter UMIs: many near ties)
+        for _ in range(n):
+            w = umis[rng.integers(n_umi)].copy()
+            for _ in range(int(rng.integers(0, 5))):
+                p_, op = int(rng.integers(14)), int(rng.integers(3))
+                if op == 0:
+                    w[p_] = rng.choice(codes)
+                elif op == 1:
+                    w[p_ + 1:] = w[p_:-1]
+                    w[p_] = rng.choice(codes)
+                else:
+                    w[p_:-1] = w[p_ + 1:]
+                    w[-1] = rng.choice(codes)
+            ws.append(w)
+    ws = np.array(ws, dtype=np.uint8)
+    packed = np.zeros(ws.shape[0], dtype=np.uint64)
+    for k in range(14):
+        packed |= ws[:, k].astype(np.uint64) << np.uint64(4 * k)
+    go, po, mo = ctx.umi_offsets(sizes)
+    d_out = torch.full((int(mo[-1]),), 255, dtype=torch.uint8, device="cuda")
+    ctx.umi_dist_device(torch.from_numpy(packed.view(np.int64)).cuda(), torch.from_numpy(go.view(np.int32)).cuda(), torch.from_numpy(po.view(np.int64)).cuda(),
+                        torch.from_numpy(mo.view(np.int64)).cuda(), len(sizes), int(po[-1]), d_out)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    ok = True
+    for g, n in enumerate(sizes):
+        ok = ok and bool((out[int(mo[g]):int(mo[g + 1])].reshape(n, n) == sor.umi_matrix(ws[go[g]:go[g + 1]])).all())
+    return ok, f"umi_pairs seed={seed} groups={sizes} pairs={int(po[-1])}"
+
+
 def check_deflate(pkg, synth, sor, ctx, seed):
     """round 3: K-DEFLATE round trip on random lengths and alphabets (zlib is the inflater)"""
     import zlib
@@ -196,7 +235,8 @@ def main():
     while time.time() < t_end:
         for leg in ([check_bc, check_records] if os.environ.get("SMI_FUZZ_LEGS") == "r2" else [check_packed, check_umi_stage, check_deflate, check_inflate]
                     if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_host_inflate, check_bam_writer] if os.environ.get("SMI_FUZZ_LEGS") == "host"
-                    else [check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate, check_host_inflate, check_bam_writer]):
+                    else [check_umi_pairs, check_umi_stage] if os.environ.get("SMI_FUZZ_LEGS") == "umi"
+                    else [check_umi_pairs, check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate, check_host_inflate, check_bam_writer]):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
             print(("ok   " if ok else "FAIL ") + msg, flush=True)
             if not ok:
