@@ -2846,6 +2846,20 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                 uint32_t *d_dbg = d_count + 8;  // why reads went to the serial kernel: 0 stretches per read, 1 stretch queue, 2 alignment queue, 3 matches per read, 4 TSO slot, 5 gated positions per read, 6 position queue, 7 accepted positions
                 const unsigned grid_flat = 256 * 8;
                 const unsigned grid_lane = (unsigned)(((size_t)n_list + 63) / 64);
+                // B (select -> align -> fold) and C (walk -> gate -> align) share nothing but the filter's words and the queue: C runs on the
+                // context's side stream beside B -- both are chains of short kernels that leave most of the chip idle (C's walk is a lane per
+                // queued read: under one wave per SIMD) -- and the rules kernel waits for both.  SMI_CHIM_SYNC keeps everything on one stream.
+                const bool use_side = !chim_sync_on();
+                if (use_side && !ctx->side_stream) {
+                    SMI_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+                    SMI_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+                    SMI_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+                }
+                hipStream_t sc = use_side ? ctx->side_stream : s;
+                if (use_side) {
+                    SMI_HIP(hipEventRecord(ctx->side_fork, s));
+                    SMI_HIP(hipStreamWaitEvent(sc, ctx->side_fork, 0));
+                }
                 // ---- B: select -> align -> fold
                 if (!a1)
                     { hipLaunchKernelGGL(k_chimb_select2, dim3((unsigned)(((size_t)n_list + 15) / 16)), dim3(1024), 0, s, st, d_pstart, d_offsets, d_list, d_count, d_out, d_cand_w, d_hot_w, d_heads, d_cand, d_gcount,
@@ -2858,22 +2872,27 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                     { hipLaunchKernelGGL((k_chimb_select<27, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select"); }
                 else
                     { hipLaunchKernelGGL((k_chimb_select<22, 0>), dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, F, d_out, d_heads, d_cand, d_gcount, (uint32_t)cap, d_dbg); SMI_CHIM_CHECK("k_chimb_select"); }
-                // ---- C: triggers -> walk (independent of B: the two could overlap; they are short)
-                if (a1) { hipLaunchKernelGGL(k_chimc_trig, dim3(grid), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig); SMI_CHIM_CHECK("k_chimc_trig"); }
-                { hipLaunchKernelGGL(k_chimc_walk, dim3(grid_lane), dim3(64), 0, s, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig, d_st, d_stcount,
+                // ---- C: triggers -> walk
+                if (a1) { hipLaunchKernelGGL(k_chimc_trig, dim3(grid), dim3(256), 0, sc, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig); SMI_CHIM_CHECK("k_chimc_trig"); }
+                { hipLaunchKernelGGL(k_chimc_walk, dim3(grid_lane), dim3(64), 0, sc, d_planes, st, d_pstart, d_offsets, d_list, d_count, P, d_out, d_trig, d_st, d_stcount,
                                    (uint32_t)st_cap, d_rst, d_rn, d_dbg); SMI_CHIM_CHECK("k_chimc_walk"); }
                 if (tl == 27) {
                     { hipLaunchKernelGGL((k_chimb_align<27>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne); SMI_CHIM_CHECK("k_chimb_align"); }
                     { hipLaunchKernelGGL((k_chimb_fold<27>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg); SMI_CHIM_CHECK("k_chimb_fold"); }
-                    { hipLaunchKernelGGL((k_chimc_gate<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
+                    { hipLaunchKernelGGL((k_chimc_gate<22>), dim3(grid_flat), dim3(256), 0, sc, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
                                        d_ent, d_ecount, (uint32_t)e_cap, d_dbg); SMI_CHIM_CHECK("k_chimc_gate"); }
-                    { hipLaunchKernelGGL((k_chimc_align<22>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm); SMI_CHIM_CHECK("k_chimc_align"); }
+                    { hipLaunchKernelGGL((k_chimc_align<22>), dim3(grid_flat), dim3(256), 0, sc, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm); SMI_CHIM_CHECK("k_chimc_align"); }
                 } else {
                     { hipLaunchKernelGGL((k_chimb_align<22>), a1 ? dim3(grid_flat) : dim3(32, kSubQ), dim3(256), 0, s, d_planes, st, d_cand, d_gcount, (uint32_t)cap, P, d_ne); SMI_CHIM_CHECK("k_chimb_align"); }
                     { hipLaunchKernelGGL((k_chimb_fold<22>), dim3(grid), dim3(256), 0, s, d_pstart, d_offsets, d_list, d_count, P.tso_max, d_out, d_heads, d_cand, d_ne, d_slots, d_dbg); SMI_CHIM_CHECK("k_chimb_fold"); }
-                    { hipLaunchKernelGGL((k_chimc_gate<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
+                    { hipLaunchKernelGGL((k_chimc_gate<25>), dim3(grid_flat), dim3(256), 0, sc, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_stcount, (uint32_t)st_cap, d_sres,
                                        d_ent, d_ecount, (uint32_t)e_cap, d_dbg); SMI_CHIM_CHECK("k_chimc_gate"); }
-                    { hipLaunchKernelGGL((k_chimc_align<25>), dim3(grid_flat), dim3(256), 0, s, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm); SMI_CHIM_CHECK("k_chimc_align"); }
+                    { hipLaunchKernelGGL((k_chimc_align<25>), dim3(grid_flat), dim3(256), 0, sc, d_planes, st, d_pstart, d_offsets, d_list, P, d_st, d_ent, d_ecount, (uint32_t)e_cap, d_ene, d_enm); SMI_CHIM_CHECK("k_chimc_align"); }
+                }
+                if (use_side) {
+                    SMI_HIP(hipGetLastError());
+                    SMI_HIP(hipEventRecord(ctx->side_join, sc));
+                    SMI_HIP(hipStreamWaitEvent(s, ctx->side_join, 0));
                 }
                 { hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg); SMI_CHIM_CHECK("k_chimc_rules"); }
                 // second chance for the reads over a cap of the lane-per-read kernels (one in 10^5): the first-generation kernels, one wave per read,
