@@ -704,7 +704,7 @@ def plan_shards(extents, world):
 
 
 def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
-                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None):
+                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None, no_clustering=False):
     """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (read and inflated by a thread of their own, one segment ahead), never held as a
     whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
     chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
@@ -719,7 +719,12 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
     process: the (cell, region) groups, the tags of every record, the order of the records, both tables.  What may differ: where the batches
     are cut (BamReader's record counter starts anew on every rank, BamReader.java:L106-158; a batch is a unit of writing only), region NUMBERS
     (equal regions, other ids: every rank numbers from rank << 40), and -- for a read with alignments on chromosomes of two ranks -- the
-    "further alignment" bit of UMIcounts in the later rank (it sees the name for the first time)."""
+    "further alignment" bit of UMIcounts in the later rank (it sees the name for the first time).
+
+    no_clustering (-s, UmiFinderMain.java:L268-269): OneBatchExecutor.call skips UmiClustering.cluster (L83) and the call-back skips the U7 fill
+    of barcoded records (UmiFinderWorker$FutCallBack.onSuccess L209-214), so no record gets U7 / U8 / UC / UZ / U1 / U2; regions, scan tags,
+    BC and gene tags are as always (ReadGrouper runs in the reader).  The stage still runs -- its regions and hold-back counts are needed --
+    and its UMI results are dropped."""
     import time
 
     t_all = time.perf_counter()
@@ -897,6 +902,8 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
                                                    five_prime=five_prime, cluster_cfg=cluster_cfg)
             t3 = time.perf_counter()
             done = cur[:n_done]
+            if no_clustering:
+                out["flags"] &= _lib.UMI_HAS_BC
             tags[done] = out[:n_done]
             reg = out["region"][:n_done].astype(np.int64)
             region[done] = np.where(reg >= 0, reg + region_base, -1)

@@ -2,7 +2,7 @@
 
     java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar scanfastq  -d <dir[,dir..]> -o <dir> --bcEditDistance k [--compress] [--ncpu N] [-h] [-y] [-a file]
                                                                 [-g usedBarcodes] [-n] [-v regex] [-k skip] [-z only] [-s] [-u]
-    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w] [-b ed] [-u ed]
+    java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w] [-b ed] [-u ed] [-s]
 
 become   python sicelore-2.1_amd scanfastq ... / assignumis ...   (the directory is runnable: __main__.py; a `java` wrapper that drops
 `-jar`, `-Xmx..` and the jar's name makes /root/reference/quickrun-2.1.sh:35,42 run unchanged, tests/test_cli_gpu.py does exactly that).
@@ -15,7 +15,7 @@ config.xml: the library's kernels are built for the shipped values of the knobs 
 thresholds, windows); those are CHECKED against the file and a different value stops the run with the knob's name -- nothing is silently
 ignored.  The knobs that are run-time parameters of the library are taken from the file: sam_records_chunk_size,
 max_GenomeDistance_forGrouping, fileWithAllPossibleTenXbarcodes.  Options the product has no path for (Illumina-guided modes, random
-barcodes, the file watcher, other polyA windows than the shipped ones, -a none, assignumis -s) are refused by name.
+barcodes, the file watcher, other polyA windows than the shipped ones, -a none) are refused by name.
 """
 import gzip
 import os
@@ -163,11 +163,12 @@ UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "o
             "splitReadName": ("w", "splitReadName", False), "logFile": ("l", "logFile", True), "ncpu": ("t", "ncpu", True),
             # -b: barcodes whose ed in the read name is larger are ignored (UmiFinderMain.java:L181-182, FastqRecordExt.java:L450-456);
             # -u: read by the Illumina-guided UMI analyzer only (IlluminaUMIanalyzer) -- accepted, checked to be a number, without effect here
-            "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True)}
+            "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True), "noclustering": ("s", "noclustering", False)}
 UMI_REFUSED = {o: why for opts, why in (
-    (("-k", "--inFile10x", "-g", "--ONTgene", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
+    (("-k", "--inFile10x", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
+    (("-g", "--ONTgene"), "the gene name attribute of this build is GE (config.xml gene_name_attribute; UmiFinderMain.java:L239-246)"),
     (("-e", "--randomBarcode", "-f", "--randomUMI"), "random barcodes / UMIs (a specificity experiment of the reference) are not built"),
-    (("-s", "--noclustering"), "not built"),)
+    )
     for o in opts}
 
 
@@ -299,7 +300,8 @@ def assignumis(argv):
     ctx = _context()
     ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
-                                refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit)
+                                refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit,
+                                no_clustering="noclustering" in o)
     if info.get("rank", 0) == 0:       # rank 0 holds the whole run's counts (assignumis_stream gathers them)
         print(f"DONE -- {info['records']} records, {info['clustered']} in UMI clusters")
         bad = int(info.get("gene_keys_order_dependent", 0))

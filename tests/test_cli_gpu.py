@@ -38,7 +38,7 @@ def test_cli_refuses_what_it_does_not_implement(tmp_path):
                         ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --randomBarcode", "randomBarcode"),
                         ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 -k some", "not a number"),
                         ("$java -jar x.jar scanfastq -d in,nowhere -o out --bcEditDistance 1", "nowhere does not exist"),
-                        ("$java -jar x.jar assignumis -i in.bam -o out.bam --noclustering", "noclustering"),
+                        ("$java -jar x.jar assignumis -i in.bam -o out.bam --randomUMI", "randomUMI"),
                         ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --frobnicate", "unknown option"),
                         ("$java -jar x.jar scanfastq -d nowhere -o out --bcEditDistance 1", "does not exist"),
                         ("$java -jar x.jar assignumis -o out.bam", "inFileNanopore"),
@@ -154,4 +154,13 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     n_bc = lambda recs: sum(any(t == "BC" for t, _ty, _v in _parse_aux(o_["aux"])) for o_ in recs)  # noqa: E731
     exact = sum("_ed=0_" in o_["name"] for o_ in out)
     assert 0 < exact < len(out) and n_bc(lim) == exact and n_bc(out) == len(out)       # -b 0: only the barcodes read without an error count
+    r = _run(STEP3.replace("passedParsed.bam", "unclustered.bam") + " -s", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, _, unc = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "unclustered.bam", "rb").read()))
+    tags_of = lambda o_: {t: v for t, _ty, v in _parse_aux(o_["aux"])}  # noqa: E731
+    assert len(unc) == len(out) and [o_["name"] for o_ in unc] == [o_["name"] for o_ in out]
+    for a_, b_ in zip(unc, out):          # -s: no UMI tag of any kind, every other tag as in the clustered run
+        ta, tb = tags_of(a_), tags_of(b_)
+        assert not ({"U7", "U8", "UC", "UZ", "U1", "U2"} & set(ta)) and ta == {t: v for t, v in tb.items() if t not in ("U7", "U8", "UC", "UZ", "U1", "U2")}
+    assert os.path.getsize(umidir + "unclustered_umifound_.bam") < os.path.getsize(umidir + "passedParsed_umifound_.bam")
 
