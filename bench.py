@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=500_000,
                     help="reads of the bounded end-to-end leg (FASTQ text -> passed/failed text), reported beside `value`; 0 = skip")
+    ap.add_argument("--e2e-lanes", default="1,2,3", help="worker lanes the end-to-end leg is run on, one run per count (a profile wants 1)")
     ap.add_argument("--two-pass-reads", type=int, default=200_000, help="reads per rank of the two-pass leg with the RCCL exchange; 0 = skip")
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4), help="BASELINE configs[1] (default), configs[2] (ed<=2 two-pass) or configs[4] (5' --noPolyARequired, 737K whitelist, UMI clustering)")
     ap.add_argument("--batch", type=int, default=10_000_000, help="--config 2: reads per batch resident in HBM")
@@ -234,7 +235,7 @@ def end_to_end_leg(ctx, synth, dev, used, n, lane_counts=(1, 2, 3)):
                          "limiter": "the splitter's filter (K-CHIM-A: 4-mer gates + a Levenshtein bound for every gated position of every read) is integer VALU "
                                     "issue; then the writer (K-WRITE beside K-WNAME), K-FQ's sweep, K-PACKR; with one lane also six short host waits "
                                     "between the library calls",
-                         "kernel_trace": "profiles/r04/e2e_kernel_stats.csv"},
+                         "kernel_trace": "profiles/r05/e2e_kernel_stats.csv (one lane)"},
             "stages": "K-FQ, K-PACKR, K-CHIM, fragment offsets, K-PACK, K-SCAN, K-BC1 (3.6M whitelist), K-WRITE; FASTQ text in HBM -> "
                       "passed/failed FASTQ text in HBM; host work between the launches included"}
 
@@ -1128,7 +1129,7 @@ def main():
         "roofline": dict({"bound": "hbm" if dom is f_bc1 else "valu-issue (the HBM figures are what the contract asks for; the binding resource "
                                    "of this kernel is integer VALU issue, in `valu_issue`)"}, **dom,
                          **{"kernels_ms": {"k_scan<10>": k_scan, "k_bc_match_ed1<1>": k_match}, "other": {oth["kernel"]: oth},
-                            "kernel_trace": "profiles/r04/step_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5` with every side "
+                            "kernel_trace": "profiles/r05/step_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5` with every side "
                                             "leg off: AverageNs of k_scan<10> is kernel_ms)",
                             "probes_per_s_bc1": 620.0 * n / (k_match * 1e-3)}),
     }
@@ -1138,7 +1139,7 @@ def main():
         res["two_pass_single_process"] = two_pass_single_process(pkg, synth, wl, used, max(args.two_pass_reads, 50_000),
                                                                  min(args.single_process_gpus, torch.cuda.device_count()))
     if world == 1 and args.e2e_reads > 0:
-        res["end_to_end"] = end_to_end_leg(ctx, synth, dev, used, args.e2e_reads)
+        res["end_to_end"] = end_to_end_leg(ctx, synth, dev, used, args.e2e_reads, lane_counts=tuple(int(x) for x in args.e2e_lanes.split(",")))
         # the number that corresponds to "pass 2" as the reference runs it: FASTQ text in HBM -> passed / failed text in HBM,
         # chimera splitter, K-PACK and the writer included (beside `value`, never part of it)
         res["value_full_pass2"] = res["end_to_end"]["reads_per_s"]

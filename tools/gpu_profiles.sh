@@ -1,27 +1,28 @@
 #!/bin/bash
-# round 4: the traces and counters the bench line cites, on the build it describes
-#   profiles/r04/step_*      the timed step alone (K-SCAN + K-BC1, 10 M reads, every side leg off): kernel trace + counters
-#   profiles/r04/chimera_*   the splitter's microbench leg (0.9 M reads): kernel trace + counters
-#   profiles/r04/umi_*       K-UMI's microbench leg: kernel trace + counters
-#   profiles/r04/e2e_*       the bench's end-to-end leg alone: kernel trace, timeline, traffic counters
+# the traces and counters the bench line cites, on the build it describes
+#   profiles/$TAG/step_*      the timed step alone (K-SCAN + K-BC1, 10 M reads, every side leg off): kernel trace + counters
+#   profiles/$TAG/chimera_*   the splitter's microbench leg (0.9 M reads): kernel trace + counters
+#   profiles/$TAG/umi_*       K-UMI's microbench leg: kernel trace + counters
+#   profiles/$TAG/e2e_*       the bench's end-to-end leg alone: kernel trace, timeline, traffic counters
 set -u
+TAG=${TAG:-r05}   # the round the outputs are named after (profiles/$TAG/ once copied there)
 ulimit -c 0
 mkdir -p gpurun_out
 OFF="--umi-molecules 0 --h2h-reads 0 --f2f-reads 0 --assignumis-file-records 0"
 PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD;TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" \
-  timeout -k 10 900 bash tools/profile_gpu.sh r04step --steps 5 --warmup 2 $OFF 2>&1 | tail -3
+  timeout -k 10 900 bash tools/profile_gpu.sh ${TAG}step --steps 5 --warmup 2 $OFF 2>&1 | tail -3
 PROFILE_PROG=$PWD/tools/microbench.py PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES;SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_INST_CYCLES_VMEM SQ_THREAD_CYCLES_VALU" \
-  timeout -k 10 900 bash tools/profile_gpu.sh r04chimera chimera 2>&1 | tail -3
-# K-UMI: the microbench leg, kernel trace + write counters -> gpurun_out/summary_r04umi/
-PROFILE_PROG=$PWD/tools/microbench.py PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
-  timeout -k 10 900 bash tools/profile_gpu.sh r04umi umi 2>&1 | tail -n 3 | cut -c1-400
+  timeout -k 10 900 bash tools/profile_gpu.sh ${TAG}chimera chimera 2>&1 | tail -3
+# K-UMI: the microbench leg, kernel trace + write counters -> gpurun_out/summary_${TAG}umi/
+PROFILE_PROG=$PWD/tools/microbench.py PMC_GROUPS="FETCH_SIZE;WRITE_SIZE;SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD;SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES;SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY;SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
+  timeout -k 10 900 bash tools/profile_gpu.sh ${TAG}umi umi 2>&1 | tail -n 3 | cut -c1-400
 timeout -k 10 300 python tools/microbench.py umi > gpurun_out/microbench_umi.json 2> gpurun_out/microbench_umi.err; echo "umi mb rc=$?"
 # the end-to-end leg alone: kernel trace + timeline, then FETCH_SIZE / WRITE_SIZE per kernel
-bash tools/gpu_r04_part.sh e2e
+bash tools/gpu_part.sh e2e
 export TMPDIR=/tmp
 ROOT=$(pwd)
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d "$ROOT/gpurun_out/prof_e2e_pmc/$c" -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --two-pass-reads 0 $OFF > "$ROOT/gpurun_out/prof_e2e_pmc_$c.log" 2>&1) || echo "pass $c failed"
+  (cd /tmp && rocprofv3 --pmc $c --output-format csv -d "$ROOT/gpurun_out/prof_e2e_pmc/$c" -- python3 $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --two-pass-reads 0 --e2e-lanes 1 $OFF > "$ROOT/gpurun_out/prof_e2e_pmc_$c.log" 2>&1) || echo "pass $c failed"
 done
 python3 - <<'PY'
 import csv, glob, json, collections
