@@ -62,7 +62,8 @@ __device__ __forceinline__ EqMasks eq_masks(uint64_t w) {
 // The match masks: eq[j] = positions of read a equal to base j of read b is a 5-way select per text base -- ~ 100 compare / select
 // instructions per pair in round 4.  Now every lane keeps a 16-entry table
 // indexed by the 4-bit code in LDS ([code][thread]: conflict-free, no other lane ever touches the column, so no barrier): the five live
-// entries are written per pair already in the packed form the runs consume, codes that match nothing stay zero from the kernel's start.
+// entries are written per pair already in the packed form the runs consume, codes that match nothing stay zero from the kernel's start
+// (the flat kernel; the tiled kernel shares one table per tile row: UmiRowTable).
 #ifndef SMI_UMI_TILE_THREADS
 #define SMI_UMI_TILE_THREADS 256
 #endif
@@ -113,12 +114,10 @@ struct UmiEqTable {
     } while (0)
 #endif
 
-// min(distance, 5) of both fields << 12, ready to take the enumeration rank and the offsets in the low bits
+// distance << 12 of both fields, ready to take the enumeration rank and the offsets in the low bits (the clamp to 5 comes once, at the end)
 __device__ __forceinline__ void myers2_scores(uint32_t pv, uint32_t mv, uint32_t &lo, uint32_t &hi) {
-    const int dl = 12 + __popc(pv & 0xFFFu) - __popc(mv & 0xFFFu);
-    const int dh = 12 + __popc(pv >> 16) - __popc((mv >> 16) & 0xFFFu);  // (Pv's guard bits are zero, Mv's are not)
-    lo = (uint32_t)min(dl, 5) << 12;  // limitedCompare: -1 above the threshold 4, stored as 5 (L343)
-    hi = (uint32_t)min(dh, 5) << 12;
+    lo = (uint32_t)(__popc(pv & 0xFFFu) + 12 - __popc(mv & 0xFFFu)) << 12;
+    hi = (uint32_t)(__popc(pv >> 16) + 12 - __popc((mv >> 16) & 0xFFFu)) << 12;  // (Pv's guard bits are zero, Mv's are not)
 }
 
 // calcBestEditDistance L67-80 visits (i, v) in the order (1,2,0) x (1,2,0) and keeps the first strict minimum: the least of
@@ -128,16 +127,9 @@ __host__ __device__ constexpr uint32_t umi_rank_code(int i, int v) {
     return (uint32_t)((3 * ri + rv) << 8) | (uint32_t)(i << 4) | (uint32_t)(v << 6);
 }
 
-__device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable &T, int tid) {
-    const EqMasks ma = eq_masks(a);
-    T.e[1][tid] = ma.a | (ma.a << 15);
-    T.e[2][tid] = ma.g | (ma.g << 15);
-    T.e[4][tid] = ma.c | (ma.c << 15);
-    T.e[8][tid] = ma.t | (ma.t << 15);
-    T.e[15][tid] = ma.n | (ma.n << 15);
-    uint32_t w[14], w2[14];
-#pragma unroll
-    for (int j = 0; j < 14; j++) w[j] = T.e[(uint32_t)(b >> (4 * j)) & 15u][tid];
+// the five runs on the fourteen looked-up words of a pair: w[j] = table entry of read a for the code of base j of read b
+__device__ __forceinline__ uint32_t umi_pair_runs(const uint32_t (&w)[14]) {
+    uint32_t w2[14];
 #pragma unroll
     for (int j = 0; j < 14; j++) w2[j] = w[j] >> 2;
     uint32_t g[12];  // run 3: pattern offset 2 against text offsets 0 (low field) and 1 (high field): the low halves of w2[t] and w2[t + 1]
@@ -163,7 +155,51 @@ __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable 
         myers2_scores(pv, mv, lo, hi);
         key = min(key, lo | umi_rank_code(2, 2));
     }
+    // limitedCompare: -1 above the threshold 4, stored as 5 (L343).  Distances of 5 and more are all 5 to the strict-minimum scan, so when
+    // the least is one of them the first pair visited keeps its place: (i, v) = (1, 1)
+    key = min(key, (5u << 12) | umi_rank_code(1, 1));
     return (key >> 12) | (key & 0xF0u);
+}
+
+__device__ __forceinline__ uint32_t umi_word(uint32_t m) { return m | (m << 15); }  // a table entry from a 14-bit mask (UmiEqTable)
+
+// the flat kernel's pair: every lane writes the five live entries of its own column and looks its words up there
+__device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable &T, int tid) {
+    const EqMasks ma = eq_masks(a);
+    T.e[1][tid] = umi_word(ma.a);
+    T.e[2][tid] = umi_word(ma.g);
+    T.e[4][tid] = umi_word(ma.c);
+    T.e[8][tid] = umi_word(ma.t);
+    T.e[15][tid] = umi_word(ma.n);
+    uint32_t w[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) w[j] = T.e[(uint32_t)(b >> (4 * j)) & 15u][tid];
+    return umi_pair_runs(w);
+}
+
+// the tiled kernel's: the 64 rows of a tile share their read a with the 64 columns of that row, so the entries of a row are written ONCE per
+// tile row (by 64 threads, before the tile's pairs start) into a [row][code] table -- the masks of read a were 75 of the ~ 450 instructions
+// around the runs when every pair recomputed them.  Rows are 17 words apart: the eight rows a wave reads at once start in different banks.
+constexpr int kUmiTileMin = 64;   // groups above this many reads are tiled
+constexpr int kUmiTile = 64;
+struct UmiRowTable {
+    uint32_t e[kUmiTile][17];
+};
+__device__ __forceinline__ void umi_row_fill(UmiRowTable &R, int row, uint64_t a) {
+    const EqMasks ma = eq_masks(a);
+#pragma unroll
+    for (int c = 0; c < 16; c++) R.e[row][c] = 0u;  // codes that match nothing
+    R.e[row][1] = umi_word(ma.a);
+    R.e[row][2] = umi_word(ma.g);
+    R.e[row][4] = umi_word(ma.c);
+    R.e[row][8] = umi_word(ma.t);
+    R.e[row][15] = umi_word(ma.n);
+}
+__device__ __forceinline__ uint32_t umi_pair_row(const UmiRowTable &R, int row, uint64_t b) {
+    uint32_t w[14];
+#pragma unroll
+    for (int j = 0; j < 14; j++) w[j] = R.e[row][(uint32_t)(b >> (4 * j)) & 15u];
+    return umi_pair_runs(w);
 }
 
 // every lane's column of the table: the codes that match nothing (everything but A, G, C, T, N) are zero and stay zero
@@ -182,8 +218,6 @@ __device__ __forceinline__ void umi_table_init(UmiEqTable &T, int tid) {
 // the tile's 64-byte row pieces are complete when the workgroup ends, in ONE L2.  Blocks that the diagonal or the matrix edge cuts store
 // byte by byte, lanes below the diagonal idle there (the reference computes i <= v only, and its tie-break is not symmetric).  Small groups
 // keep the flat mapping: a tile over a 3-read group would be 98 % idle lanes.
-constexpr int kUmiTileMin = 64;   // groups above this many reads are tiled
-constexpr int kUmiTile = 64;
 
 struct UmiPlan {
     uint64_t small_pairs, tiles;
@@ -275,9 +309,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
                                                                     uint32_t n_groups, uint32_t *__restrict__ next_unit, uint8_t *__restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][kUmiTile][kUmiLdsRow];
     __shared__ uint32_t s_unit;
-    __shared__ UmiEqTable T;
-    static_assert(kUmiTileThreads <= kUmiEqCols, "a column of the table per thread");
-    umi_table_init(T, threadIdx.x);
+    __shared__ UmiRowTable R;
     const uint64_t total_units = plan[n_groups].tiles;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int di = lane >> 3, dv = lane & 7;
@@ -303,12 +335,19 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
         const uint64_t mi = tri_row(nbm, local), mv = mi + (local - (mi * nbm - mi * (mi - 1) / 2));
         uint8_t *m = out + mat_off[g];
         const uint64_t *win = windows + r0;
+        uint64_t rows_of = ~0ull;  // first row of the tile row the table holds
         for (int tt = 0; tt < kUmiMacro * kUmiMacro; tt++) {
             const uint64_t bi = kUmiMacro * mi + tt / kUmiMacro, bv = kUmiMacro * mv + tt % kUmiMacro;
             const uint64_t i0 = bi * kUmiTile, v0 = bv * kUmiTile;
             if (i0 >= n || v0 >= n || bi > bv) continue;  // (uniform)
             uint8_t(*A)[kUmiLdsRow] = stage[0];
             uint8_t(*B)[kUmiLdsRow] = stage[bi == bv ? 0 : 1];
+            if (i0 != rows_of) {  // (uniform) the four tiles of a macro-tile row share their reads a: their table is built once
+                // nobody reads the table any more: every wave has passed the barrier behind the previous tile's pairs
+                if (threadIdx.x < kUmiTile && i0 + threadIdx.x < n) umi_row_fill(R, (int)threadIdx.x, win[i0 + threadIdx.x]);
+                rows_of = i0;
+                __syncthreads();
+            }
             int live = 0;  // blocks of this tile that hold pairs, dealt to the eight waves in turn
             for (int sb = 0; sb < 64; sb++) {
                 const int si = sb >> 3, sv = sb & 7;
@@ -318,7 +357,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
                 const uint64_t i = bi0 + di, v = bv0 + dv;
                 const bool valid = i < n && v < n && i <= v;
                 uint32_t r = 0;
-                if (valid) r = umi_pair(win[i], win[v], T, threadIdx.x);
+                if (valid) r = umi_pair_row(R, 8 * si + di, win[v]);
                 const uint32_t rt = (r & 15u) | (((r >> 6) & 3u) << 4) | (((r >> 4) & 3u) << 6);  // getTransposedEditDistance L133, L213-216
                 const bool whole = bi0 + 7 < bv0 && bv0 + 7 < n;  // every lane holds a pair above the diagonal
                 if (whole) {
