@@ -962,7 +962,8 @@ def bam_header(bam):
                           nl.ctypes.data, rl.ctypes.data, k, ctypes.byref(rec)):
         raise SmiError(lib.smi_last_error().decode())
     text = bam[t_off.value:t_off.value + t_len.value].tobytes().decode(errors="replace")
-    refs = [(bam[int(no[i]):int(no[i]) + int(nl[i])].tobytes().decode(), int(rl[i])) for i in range(n_ref.value)]
+    # (names as htsjdk reads them: one char per byte -- a damaged name is still a name, not a decoding error)
+    refs = [(bam[int(no[i]):int(no[i]) + int(nl[i])].tobytes().decode("latin-1"), int(rl[i])) for i in range(n_ref.value)]
     return text, refs, rec.value
 
 

@@ -1,0 +1,206 @@
+"""Malformed input through the host-side parsers of the library: every call ends in a result or an SmiError, never in a crash.
+
+What reaches these entry points comes from files a user hands over -- *.fastq(.gz), a BAM and its index, a refFlat annotation -- or, for the
+gene-count dumps, from another rank.  The reference leans on htsjdk / picard for all of it (FastqReader, SamReader, RefFlatReader: they
+throw); here the parsers are the library's own, so they get the mutations: bytes flipped, lengths and offsets overwritten with extreme
+values, the input cut short.  The same test runs under AddressSanitizer against a host-instrumented build of the library
+(`tools/asan/run_host.sh`: `make VARIANT=hostasan ...`, the runtime preloaded), where an out-of-bounds READ stops the process as well.
+No GPU: nothing here touches a device."""
+import gzip
+import importlib
+import struct
+
+import numpy as np
+import pytest
+
+import os
+
+import bammodel
+
+SCALE = int(os.environ.get("SMI_HOST_FUZZ_SCALE", "1"))     # more damaged copies per seed input (tools/asan/run_host.sh runs the deep form)
+
+
+def _mutations(rng, data, n, header_bytes=0):
+    """n (x SCALE) damaged copies of `data` (bytes): flips, extreme 32-bit values at random and at 4-aligned offsets, truncations, a doubled tail"""
+    n *= SCALE
+    out = []
+    b = np.frombuffer(data, dtype=np.uint8)
+    for k in range(n):
+        m = b.copy()
+        kind = k % 6
+        if kind == 0:                                   # a few flipped bytes
+            for p in rng.integers(0, m.size, int(rng.integers(1, 6))):
+                m[p] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:                                 # an extreme little-endian word somewhere
+            p = int(rng.integers(0, max(1, m.size - 4)))
+            m[p:p + 4] = np.frombuffer(struct.pack("<I", int(rng.choice([0, 1, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0xFFFF, m.size, m.size * 2]))), dtype=np.uint8)
+        elif kind == 2:                                 # cut short
+            m = m[:int(rng.integers(header_bytes // 2, m.size))]
+        elif kind == 3:                                 # the same in the leading structure (where the lengths live)
+            p = int(rng.integers(0, max(1, min(m.size, max(header_bytes, 64)) - 4))) & ~3
+            m[p:p + 4] = np.frombuffer(struct.pack("<i", int(rng.choice([-1, -2, 0x7FFFFFFF, 1 << 20, 0]))), dtype=np.uint8)
+        elif kind == 4:                                 # random bytes over a stretch
+            p = int(rng.integers(0, m.size))
+            q = min(m.size, p + int(rng.integers(1, 64)))
+            m[p:q] = rng.integers(0, 256, q - p, dtype=np.uint8)
+        else:                                           # garbage behind the end
+            m = np.concatenate([m, rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8)])
+        out.append(m)
+    return out
+
+
+def _bam_case(rng, n=60):
+    names = [f"r{k}_REV_PS=20_PE=45_AE={int(rng.integers(60, 90))}_T=7_bc=ACGTACGTACGTACGT_ed={k % 3}_ed_sec=4_bcStart=46_bcEnd=61_rk=3_"
+             f"X={''.join('ACGT'[int(x)] for x in rng.integers(0, 4, 43))}_Q=11.2_1z" if k % 4 else f"plain{k}" for k in range(n)]
+    recs = []
+    for k, nm in enumerate(names):
+        L = int(rng.integers(30, 200))
+        cig = ([("S", 5)] if k % 3 == 0 else []) + [("M", L - 5 if k % 3 == 0 else L)]
+        recs.append(bammodel.bam_record(nm, int(rng.choice([0, 16, 256])), int(rng.integers(0, 2)), 100 + 7 * k, 30, cig, "C" * L,
+                                        aux=b"NMC\x03ASs\x10\x00" if k % 2 else b""))
+    header = bammodel.bam_bytes("@HD\tVN:1.6\tSO:coordinate\n", [("chr1", 10 ** 6), ("chr2", 10 ** 6)], [])
+    return header, header + b"".join(recs)
+
+
+def test_bam_parsers_survive_damaged_streams(pkg):
+    """inflated BAM bytes with damage in the header, the record lengths, the names, CIGARs and aux fields: header, record index, chunk
+    inputs, name set, gene tagger over the records and the batch writer"""
+    libmod = importlib.import_module("sicelore_amd.lib")
+    rng = np.random.default_rng(11)
+    header, data = _bam_case(rng)
+    refflat = "".join(f"G{g}\tT{g}\tchr1\t+\t{50 + 200 * g}\t{240 + 200 * g}\t{60 + 200 * g}\t{230 + 200 * g}\t2\t{50 + 200 * g},{150 + 200 * g},\t"
+                      f"{100 + 200 * g},{240 + 200 * g},\n" for g in range(5))
+    tagger = libmod.GeneTagger(refflat, ["chr1", "chr2"])
+    n_ok = n_err = 0
+    for m in [np.frombuffer(data, dtype=np.uint8).copy()] + _mutations(rng, data, 600, header_bytes=len(header)):
+        try:
+            _text, refs, start = libmod.bam_header(m)
+            recs, end = libmod.bam_index_records(m, start, cap=max(1, (m.size - start) // 36))
+            if recs.size:
+                idx = np.arange(recs.size, dtype=np.int32)
+                libmod.bam_chunk_inputs(m, recs, idx)
+                libmod.bam_name_seen(m, recs)
+                gene = tagger.tag_bam_raw(m, recs)
+                tags = np.zeros(recs.size, dtype=libmod.UMI_TAG_DTYPE)
+                tags["flags"] = rng.integers(0, 16, recs.size)
+                tags["u7"] = b"ACGTACGTACGT"
+                tags["u8"] = b"TTTTACGTACGT"
+                gc = libmod.GeneCounts()
+                libmod.bam_write_batch(m, recs, idx, tags, gene=gene, n_threads=2, gene_counts=gc, region=np.zeros(recs.size, dtype=np.int64),
+                                       nth_record=np.zeros(recs.size, dtype=np.uint8))
+                gc.genecounts_tsv(16)
+                gc.close()
+            n_ok += 1
+        except libmod.SmiError:
+            n_err += 1
+    tagger.close()
+    assert n_ok > 50 and n_err > 50, (n_ok, n_err)           # both outcomes occur; what must not occur is a crash
+
+
+def test_bgzf_and_gzip_containers_survive_damage(pkg):
+    libmod = importlib.import_module("sicelore_amd.lib")
+    rng = np.random.default_rng(12)
+    _h, data = _bam_case(rng, 40)
+    z = bammodel.bgzf_compress(data, block=2048)
+    n_err = 0
+    for m in _mutations(rng, z, 300, header_bytes=18):
+        try:
+            libmod.bgzf_inflate(m, n_threads=2)
+        except libmod.SmiError:
+            n_err += 1
+    g = gzip.compress(data, 6)
+    for m in _mutations(rng, g, 300, header_bytes=10):
+        try:
+            libmod.gz_inflate(m)
+        except libmod.SmiError:
+            n_err += 1
+    assert n_err > 200
+
+
+def test_fastq_host_index_survives_damaged_text(pkg):
+    """the host's FASTQ index + plane packer (one pass, guessed thread splits) and the quality packer on damaged text: line ends lost or
+    doubled, '@' / '+' markers overwritten, lengths that no longer agree, the text cut inside a record"""
+    libmod = importlib.import_module("sicelore_amd.lib")
+    rng = np.random.default_rng(13)
+    recs = []
+    for k in range(300):
+        L = int(rng.integers(1, 400))
+        recs.append(f"@r{k} ch={k}\n{''.join('ACGTN'[int(x)] for x in rng.integers(0, 5, L))}\n+\n{''.join(chr(int(q)) for q in rng.integers(33, 74, L))}\n")
+    text = "".join(recs).encode()
+    n_ok = n_err = 0
+    for m in [np.frombuffer(text, dtype=np.uint8).copy()] + _mutations(rng, text, 400):
+        for threads in (1, 5):
+            try:
+                out = libmod.fastq_index_pack_host(m, n_threads=threads)
+                r2, offs, err = libmod.fastq_index_host(m, n_threads=threads)
+                # malformed text is REPORTED (SMI_FQ_* bits: the chunk workers turn them into an error).  The one-pass form steps over the quality
+                # lines (their length is known) and leaves a line end hidden inside one to whoever reads the qualities: the quality packer
+                assert err != 0 or out[2] == 0
+                late = False
+                if out[0].size and not out[2]:
+                    try:
+                        libmod.pack_quals_host(m, out[0], n_threads=threads)
+                    except libmod.SmiError:
+                        late = True
+                assert (out[2] != 0 or late) == (err != 0), (out[2], late, err)
+                if r2.size and not err:
+                    libmod.pack_reads_host(m, r2, offs, n_threads=threads)
+                n_ok += err == 0
+                n_err += err != 0
+            except libmod.SmiError:
+                n_err += 1
+    assert n_ok > 20 and n_err > 20, (n_ok, n_err)
+
+
+def test_refflat_and_dumps_survive_damage(pkg):
+    """the annotation parser (GennameTagger's RefFlatReader stand-in) and the gene-count dumps that travel between ranks"""
+    libmod = importlib.import_module("sicelore_amd.lib")
+    rng = np.random.default_rng(14)
+    refflat = "".join(f"G{g}\tT{g}\tchr{1 + g % 2}\t{'+-'[g % 2]}\t{50 + 200 * g}\t{240 + 200 * g}\t{60 + 200 * g}\t{230 + 200 * g}\t2\t"
+                      f"{50 + 200 * g},{150 + 200 * g},\t{100 + 200 * g},{240 + 200 * g},\n" for g in range(40)).encode()
+    n_err = 0
+    for m in _mutations(rng, refflat, 300):
+        try:
+            t = libmod.GeneTagger(bytes(m).decode("latin-1"), ["chr1", "chr2"])
+            t.tag(np.array([0, 1, 0], dtype=np.int32), np.array([0, 16, 0], dtype=np.uint16), np.array([60, 500, 10 ** 6], dtype=np.int32),
+                  [[(0, 50)], [(0, 30), (3, 200), (0, 30)], [(0, 10)]])
+            t.close()
+        except libmod.SmiError:
+            n_err += 1
+    gc = libmod.GeneCounts()
+    for k in range(200):
+        gc.add([f"G{k % 7}"], np.array([k % 5], dtype=np.int64), np.array([k * 977 % 4096], dtype=np.uint64), np.array([k * 31 % 65536], dtype=np.uint64),
+               np.array([1], dtype=np.uint8), np.array([0], dtype=np.uint16), np.array([30], dtype=np.uint8), np.array([(50 << 4)], dtype=np.uint32),
+               np.array([(50 << 4)], dtype=np.uint32), np.array([0], dtype=np.uint8))
+    dump = gc.dump()
+    gc.close()
+    for m in _mutations(rng, bytes(dump), 300, header_bytes=32):
+        try:
+            other = libmod.GeneCounts.load(bytes(m))
+            base = libmod.GeneCounts.load(bytes(dump))
+            base.merge_shard(other)
+            base.genecounts_tsv(16)
+            base.umi_depths_tsv()
+            other.close()
+            base.close()
+        except libmod.SmiError:
+            n_err += 1
+    assert n_err > 50
+
+
+def test_bam_index_parser_refuses_damage(pkg):
+    au = importlib.import_module("sicelore_amd.assignumis")
+    libmod = importlib.import_module("sicelore_amd.lib")
+    rng = np.random.default_rng(15)
+    idx = [(k % 3, 100 * k, 100 * k + 50, (k * 300) << 16, (k * 300 + 200) << 16) for k in range(30)]
+    idx.sort()
+    bai = bammodel.bai_bytes(3, idx, meta=True)
+    assert len(au.bai_ref_extents_bytes(bai)) == 3
+    n_err = 0
+    for m in _mutations(rng, bai, 300, header_bytes=8):
+        try:
+            ext = au.bai_ref_extents_bytes(bytes(m))
+            au.plan_shards(ext, 3)
+        except (libmod.SmiError, struct.error):
+            n_err += 1
+    assert n_err > 30
