@@ -242,6 +242,14 @@ int smi_hist_allreduce_release(void);
  * (UsedCellBCListGenerator.java:L207-229); ++hist[ordinal(key)] when the key is in the loaded set */
 int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n,
                             uint32_t *d_hist, void *stream);
+/* pass 1 WITHOUT a list of possible barcodes (`-a none`: ReadScannerParameters.generateUsedBarcodesWithoutWhitelist,
+ * NanoporeReadScannerMain.java:L132-133; the membership predicate of UsedCellBCListGenerator$Worker.call is "true", L255-256): the barcode of
+ * every read with pass1_ok is APPENDED to d_keys as the reference's long (a 5' barcode with an N: bits 63..32 set, ref_exec_pass1_nowl_5p.json);
+ * *d_count (device, u64, zeroed by the caller) counts every append, entries beyond cap are dropped (the caller checks count <= cap).
+ * smi_count_keys_device turns the list of a pass into distinct keys (ascending) and counts: the input of smi_finalize_used_list. */
+int smi_pass1_keys_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n, uint64_t *d_keys, size_t cap,
+                          uint64_t *d_count, void *stream);
+int smi_count_keys_device(smi_ctx *ctx, const uint64_t *d_keys, size_t n, uint64_t *d_unique, uint32_t *d_counts, uint64_t *d_n_unique, void *stream);
 
 /* Pass-2 counters per barcode and edit distance = assignedBarcodes2ndPass[bc].addCountForEd(ed) (Parser.java:L305-311,
  * Parser$BarcodeCounts L339-354): d_counts[3 * ordinal(bc) + ed] += 1 for every result with found == 1; ordinal = index of the
@@ -551,6 +559,9 @@ int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes,
  * binding does); contexts sharing one d_hist only ever atomicAdd into it.  Returns after the stream has drained. */
 int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
                               uint32_t *d_hist, size_t *n_records, uint32_t *fastq_errors);
+/* the same chunk without a list of possible barcodes: keys appended to d_keys / *d_count as smi_pass1_keys_device does (no barcode set needed) */
+int smi_scanfastq_pass1_chunk_keys(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
+                                   uint64_t *d_keys, size_t cap_keys, uint64_t *d_count, size_t *n_records, uint32_t *fastq_errors);
 
 /* ================================================================================================================
  * The packed boundary of `scanfastq` ("multi-file parallel decode and on-host trimming"): the host keeps the

@@ -15,7 +15,7 @@ config.xml: the library's kernels are built for the shipped values of the knobs 
 thresholds, windows); those are CHECKED against the file and a different value stops the run with the knob's name -- nothing is silently
 ignored.  The knobs that are run-time parameters of the library are taken from the file: sam_records_chunk_size,
 max_GenomeDistance_forGrouping, fileWithAllPossibleTenXbarcodes.  Options the product has no path for (Illumina-guided modes, random
-barcodes, the file watcher, other polyA windows than the shipped ones, -a none) are refused by name.
+barcodes, the file watcher, other polyA windows than the shipped ones) are refused by name.
 """
 import gzip
 import os
@@ -238,13 +238,12 @@ def scanfastq(argv):
     keys = None
     if used is None:
         wl_name = o.get("bcWhitelist") or knobs.get("readscanner/fileWithAllPossibleTenXbarcodes", "3M-february-2018.txt.gz")
-        if wl_name.lower() in ("none", "null"):
-            raise CliError("-a none (every 16-mer is a possible barcode) is not built")
-        wl = next((p for p in (wl_name, os.path.join(os.getcwd(), wl_name), os.path.join(_HERE, wl_name)) if os.path.isfile(p)), None)
+        wl = "" if wl_name in ("none", "None", "null", "Null") else next((p for p in (wl_name, os.path.join(os.getcwd(), wl_name), os.path.join(_HERE, wl_name)) if os.path.isfile(p)), None)
         if wl is None:
             raise CliError(f"file with all possible barcodes {wl_name!r} not found (looked in the working directory and in {_HERE}); "
                            "-a <file> names it (ReadScannerParameters.java:L247)")
-        keys = read_barcode_file(wl)
+        # -a none / null (L132-133): no list of possible barcodes, pass 1 counts every barcode it cuts
+        keys = read_barcode_file(wl) if wl else None
     if o["outDir"] != "null":              # (-o null: statistics only, NanoporeReadScannerMain.java:L216)
         parent = os.path.dirname(os.path.abspath(o["outDir"]))
         if not os.path.isdir(parent):

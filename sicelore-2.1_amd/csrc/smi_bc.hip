@@ -1115,6 +1115,78 @@ int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan
     return SMI_OK;
 }
 
+// pass 1 without a list of possible barcodes (`-a none`, generateUsedBarcodesWithoutWhitelist: the membership predicate is "true",
+// UsedCellBCListGenerator.java:L255-256): the barcode of every read that passes the quality filter is counted, so the chunk leaves its KEYS
+// (appended to a list; sorted and counted at the end of the pass, launch_count_keys) instead of increments of a dense histogram.
+// The key is the reference's long: a 3' barcode goes through reverseComplement, which keeps the low 32 bits (an N comes out as "T .. T C",
+// make_key); a 5' barcode does not, so an N leaves its -2 in the long: bits 63 .. 32 all set, below them the same "T .. T C" pattern
+// (tests/golden/ref_exec_pass1_nowl_5p.json has five of them).
+__global__ void k_keys_windows(const smi_bc_window *__restrict__ win, const smi_scan_result *__restrict__ scan, size_t n,
+                               uint64_t *__restrict__ keys, unsigned long long cap, unsigned long long *__restrict__ count) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        if (!scan[i].pass1_ok) continue;
+        const smi_bc_window w = win[i];
+        if (!(w.flags & SMI_WIN_VALID)) continue;
+        const bool fp = (w.flags & SMI_WIN_5P) != 0;
+        const OffsetKey ok = make_key(w.bases, w.nmask, 0, fp);
+        uint64_t k = ok.key;
+        if (!ok.usable) {  // 5' window with an N (make_key: base indices 2 .. 17 of the 25-base record)
+            const uint32_t nm = (w.nmask >> 2) & 0xFFFFu;
+            const int last = 31 - __clz(nm);  // window index of the last N
+            const uint32_t low = (ok.key & lowmask(30 - 2 * last)) | (0xFFFFFFFFu << (31 - 2 * last));
+            k = 0xFFFFFFFF00000000ull | low;
+        }
+        const unsigned long long at = atomicAdd(count, 1ull);  // (the order of the list is of no consequence: it is sorted before it is counted)
+        if (at < cap) keys[at] = k;
+    }
+}
+
+int launch_keys_windows(smi_ctx *, const smi_bc_window *d_win, const smi_scan_result *d_scan, size_t n, uint64_t *d_keys, size_t cap,
+                        unsigned long long *d_count, hipStream_t s) {
+    if (!n) return SMI_OK;
+    const unsigned grid = (unsigned)std::min<size_t>((n + 255) / 256, 256 * 32);
+    hipLaunchKernelGGL(k_keys_windows, dim3(grid), dim3(256), 0, s, d_win, d_scan, n, d_keys, (unsigned long long)cap, d_count);
+    SMI_HIP(hipGetLastError());
+    return SMI_OK;
+}
+
+// the key list of a whole pass -> its distinct keys (ascending) and their counts: radix sort + run-length encoding (hipcub), once per run
+int launch_count_keys(smi_ctx *, const uint64_t *d_keys, size_t n, uint64_t *d_unique, uint32_t *d_counts, uint64_t *d_n_unique, hipStream_t s) {
+    if (!n) {
+        SMI_HIP(hipMemsetAsync(d_n_unique, 0, 8, s));
+        return SMI_OK;
+    }
+    if (n > 0x7FFFFFFFull) {
+        set_error("smi_count_keys_device: more than 2^31 - 1 keys in one call");
+        return SMI_ERR_INVALID;
+    }
+    size_t t_sort = 0, t_rle = 0;
+    uint64_t *d_sorted = nullptr;
+    int *d_runs = nullptr;
+    void *d_tmp = nullptr;
+    SMI_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, d_keys, d_sorted, (int)n, 0, 64, s));
+    SMI_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, t_rle, d_sorted, d_unique, d_counts, d_runs, (int)n, s));
+    const size_t tmp_bytes = std::max(t_sort, t_rle);
+    SMI_HIP(hipMalloc((void **)&d_sorted, n * 8));
+    hipError_t e = hipMalloc(&d_tmp, tmp_bytes + 16);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_runs, 16);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortKeys(d_tmp, t_sort, d_keys, d_sorted, (int)n, 0, 64, s);
+    if (e == hipSuccess) e = hipcub::DeviceRunLengthEncode::Encode(d_tmp, t_rle, d_sorted, d_unique, d_counts, d_runs, (int)n, s);
+    int h_runs = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_runs, d_runs, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    const uint64_t runs64 = (uint64_t)h_runs;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_n_unique, &runs64, 8, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_sorted);
+    (void)hipFree(d_tmp);
+    (void)hipFree(d_runs);
+    if (e != hipSuccess) return hip_fail(e, "smi_count_keys_device");
+    return SMI_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K-BC2: ed <= 2 matcher.  Same contract as K-BC1, but the second mutation level follows the reference's
 // depth-first order and its dedup set (NucTwoBitPerBaseEDtesterBase.java:L82-95,L105-120, BarcodeMatchTester.java:

@@ -623,6 +623,25 @@ int smi_hist_windows_device(smi_ctx *ctx, const smi_bc_window *d_windows, const 
     return launch_hist_windows(ctx, d_windows, d_scan, n, d_hist, (hipStream_t)stream);
 }
 
+int smi_pass1_keys_device(smi_ctx *ctx, const smi_bc_window *d_windows, const smi_scan_result *d_scan, size_t n, uint64_t *d_keys, size_t cap,
+                          uint64_t *d_count, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (!d_count || (n && (!d_windows || !d_scan || !d_keys))) {
+        set_error("smi_pass1_keys_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_keys_windows(ctx, d_windows, d_scan, n, d_keys, cap, reinterpret_cast<unsigned long long *>(d_count), (hipStream_t)stream);
+}
+
+int smi_count_keys_device(smi_ctx *ctx, const uint64_t *d_keys, size_t n, uint64_t *d_unique, uint32_t *d_counts, uint64_t *d_n_unique, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (!d_n_unique || (n && (!d_keys || !d_unique || !d_counts))) {
+        set_error("smi_count_keys_device: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    return launch_count_keys(ctx, d_keys, n, d_unique, d_counts, d_n_unique, (hipStream_t)stream);
+}
+
 int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off,
                         const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
                         uint64_t total_pairs, uint8_t *d_out, void *stream) {

@@ -193,6 +193,9 @@ int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, siz
 int launch_bc_counts(smi_ctx *ctx, const smi_bc_result *d_res, size_t n, uint32_t *d_counts, hipStream_t s);
 int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan_result *d_scan, size_t n,
                         uint32_t *d_hist, hipStream_t s);
+int launch_keys_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan_result *d_scan, size_t n, uint64_t *d_keys, size_t cap,
+                        unsigned long long *d_count, hipStream_t s);
+int launch_count_keys(smi_ctx *ctx, const uint64_t *d_keys, size_t n, uint64_t *d_unique, uint32_t *d_counts, uint64_t *d_n_unique, hipStream_t s);
 int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, const uint8_t *d_qtail,
                 const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
                 smi_bc_window *d_win, hipStream_t s);

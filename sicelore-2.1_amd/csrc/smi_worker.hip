@@ -312,12 +312,34 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     return SMI_OK;
 }
 
+namespace {
+// pass 1 of one chunk; the barcodes of the reads that pass the filter go into the dense histogram of the loaded list (d_hist) or, without a
+// list of possible barcodes, as keys onto a list (d_keys / cap / d_count)
+int pass1_chunk_core(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya, uint32_t *d_hist, uint64_t *d_keys,
+                     size_t cap_keys, uint64_t *d_count, size_t *n_records, uint32_t *fastq_errors);
+}  // namespace
+
 extern "C" int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
                                          uint32_t *d_hist, size_t *n_records, uint32_t *fastq_errors) {
     if (!ctx || !d_hist || !n_records || (!text && n_bytes)) {
         set_error("smi_scanfastq_pass1_chunk: null argument");
         return SMI_ERR_INVALID;
     }
+    return pass1_chunk_core(ctx, text, n_bytes, five_prime, dont_search_polya, d_hist, nullptr, 0, nullptr, n_records, fastq_errors);
+}
+
+extern "C" int smi_scanfastq_pass1_chunk_keys(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya,
+                                              uint64_t *d_keys, size_t cap_keys, uint64_t *d_count, size_t *n_records, uint32_t *fastq_errors) {
+    if (!ctx || !d_keys || !d_count || !n_records || (!text && n_bytes)) {
+        set_error("smi_scanfastq_pass1_chunk_keys: null argument");
+        return SMI_ERR_INVALID;
+    }
+    return pass1_chunk_core(ctx, text, n_bytes, five_prime, dont_search_polya, nullptr, d_keys, cap_keys, d_count, n_records, fastq_errors);
+}
+
+namespace {
+int pass1_chunk_core(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five_prime, int dont_search_polya, uint32_t *d_hist, uint64_t *d_keys,
+                     size_t cap_keys, uint64_t *d_count, size_t *n_records, uint32_t *fastq_errors) {
     *n_records = 0;
     if (fastq_errors) *fastq_errors = 0;
     if (n_bytes == 0) return SMI_OK;
@@ -359,10 +381,14 @@ extern "C" int smi_scanfastq_pass1_chunk(smi_ctx *ctx, const uint8_t *text, size
     SMI_RC(five_prime ? smi_scan_default_config_5p(1, dont_search_polya, &sc) : smi_scan_default_config(1, &sc));
     SMI_RC(smi_pack_ends_device(ctx, d_reads, d_quals, d_offs, n, five_prime, d_ends, d_len, d_qtail, d_qsum, s));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, n, &sc, d_scan, d_win, s));
-    SMI_RC(smi_hist_windows_device(ctx, d_win, d_scan, n, d_hist, s));
+    if (d_hist)
+        SMI_RC(smi_hist_windows_device(ctx, d_win, d_scan, n, d_hist, s));
+    else
+        SMI_RC(smi_pass1_keys_device(ctx, d_win, d_scan, n, d_keys, cap_keys, d_count, s));
     SMI_HIP(hipStreamSynchronize(s));
     return SMI_OK;
 }
+}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // The packed boundary (include/sicelore_mi.h, "The packed boundary of scanfastq"): planes + offsets up, decisions down.

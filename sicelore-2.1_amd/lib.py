@@ -48,7 +48,7 @@ EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
-    "smi_scan_device", "smi_hist_windows_device", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
+    "smi_scan_device", "smi_hist_windows_device", "smi_pass1_keys_device", "smi_count_keys_device", "smi_scanfastq_pass1_chunk_keys", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
@@ -125,6 +125,9 @@ def load_library():
     lib.smi_pass2_default_config.argtypes = [vp]
     lib.smi_scanfastq_pass2_chunk.argtypes = [vp, vp, sz, vp, vp]
     lib.smi_scanfastq_pass1_chunk.argtypes = [vp, vp, sz, ci, ci, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32)]
+    lib.smi_scanfastq_pass1_chunk_keys.argtypes = [vp, vp, sz, ci, ci, vp, sz, vp, ctypes.POINTER(sz), ctypes.POINTER(ctypes.c_uint32)]
+    lib.smi_pass1_keys_device.argtypes = [vp, vp, vp, sz, vp, sz, vp, vp]
+    lib.smi_count_keys_device.argtypes = [vp, vp, sz, vp, vp, vp, vp]
     lib.smi_bgzf_deflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz), ci, ci, ci]
     lib.smi_gz_inflate.argtypes = [vp, sz, vp, sz, ctypes.POINTER(sz)]
     lib.smi_bam_header.argtypes = [vp, sz, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint32),
@@ -1197,6 +1200,42 @@ class Context:
             self._check(self._lib.smi_scanfastq_pass1_chunk(self._h, buf.ctypes.data, buf.size, int(five_prime), int(dont_search_polya),
                                                             _ptr(d_hist), ctypes.byref(n), ctypes.byref(err)))
         return n.value
+
+    def scanfastq_pass1_chunk_keys(self, text, d_keys, d_count, five_prime=False, dont_search_polya=False):
+        """pass 1 of a chunk WITHOUT a list of possible barcodes (`-a none`): the barcode of every read that passes the filter is appended to
+        d_keys (int64 device tensor; the reference's long) and counted in d_count (int64 device tensor of one element, zeroed by the caller and
+        shared by the chunks of a pass) -> n records.  text: host bytes / numpy uint8 or a uint8 device tensor"""
+        import torch
+
+        n, err = ctypes.c_size_t(0), ctypes.c_uint32(0)
+        torch.cuda.current_stream(d_keys.device).synchronize()      # (d_count was zeroed on torch's stream: sicelore_mi.h, smi_scanfastq_pass1_chunk)
+        if hasattr(text, "is_cuda"):
+            ptr, nb = text.data_ptr(), int(text.numel())
+        else:
+            buf = _as_u8(text)
+            ptr, nb = buf.ctypes.data, buf.size
+        self._check(self._lib.smi_scanfastq_pass1_chunk_keys(self._h, ptr, nb, int(five_prime), int(dont_search_polya), _ptr(d_keys), int(d_keys.numel()),
+                                                             _ptr(d_count), ctypes.byref(n), ctypes.byref(err)))
+        return n.value
+
+    def pass1_keys_device(self, d_windows, d_scan, n, d_keys, d_count, stream=None):
+        self._check(self._lib.smi_pass1_keys_device(self._h, _ptr(d_windows), _ptr(d_scan), int(n), _ptr(d_keys), int(d_keys.numel()), _ptr(d_count),
+                                                    _stream_ptr(stream)))
+
+    def count_keys_device(self, d_keys, n):
+        """the key list of a pass -> (distinct keys ascending, their counts) as numpy uint64 / uint32 (smi_count_keys_device: radix sort + run lengths)"""
+        import torch
+
+        n = int(n)
+        if n == 0:
+            return np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32)
+        uniq = torch.empty(n, dtype=torch.int64, device=d_keys.device)
+        cnt = torch.empty(n, dtype=torch.int32, device=d_keys.device)
+        nu = torch.zeros(1, dtype=torch.int64, device=d_keys.device)
+        torch.cuda.current_stream(d_keys.device).synchronize()
+        self._check(self._lib.smi_count_keys_device(self._h, _ptr(d_keys), n, _ptr(uniq), _ptr(cnt), _ptr(nu), None))
+        m = int(nu.item())
+        return uniq[:m].cpu().numpy().view(np.uint64), cnt[:m].cpu().numpy().view(np.uint32)
 
     def ends_from_planes_device(self, d_planes, d_read_offsets, n_reads, total_bases, d_rec_offsets, d_frag_src, n_records, d_ends, d_len,
                                 stream=None):

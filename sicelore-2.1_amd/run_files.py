@@ -167,6 +167,8 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     default pattern, a direct caller also gets *.fq).  used_keys (-g <file>, NanoporeReadScannerMain.java:L300-302): the barcodes in use are
     SUPPLIED -- pass 1 is skipped, the files are only inflated and counted, every barcode has rank 0 (no rk= in the names,
     WorkerReadscanner$BarcodesMapForBCfinding.getMapFromCellRangerData L437) and no BarcodeList.tsv is written (pass 1 writes it).
+    whitelist_keys=None without used_keys (-a none, NanoporeReadScannerMain.java:L132-133): there is no list of possible barcodes -- pass 1 counts
+    every barcode it cuts (lists of keys, sorted and counted on the device at the end of the pass), `BarcodeList.tsv` leaves out rows with AAAAA / TTTTT.
     write_fastqs=False (-s, L211-213): statistics and TSVs only.  trim_fastq (-u): records cut as FastqRecordExt.getRecordForWriting does
     with trimFastq."""
     import torch.distributed as dist
@@ -183,6 +185,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     if not files:
         raise _lib.SmiError(f"NO INPUT FILES FOUND in {in_dir}")
     given = used_keys is not None
+    nowl = not given and whitelist_keys is None      # -a none: no list of possible barcodes, every barcode seen in pass 1 is counted
     if multi:
         from . import distributed as _dist
 
@@ -206,18 +209,20 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         return call
 
     dev = torch.device("cuda", ctx.device)
-    keys = np.unique(np.ascontiguousarray(used_keys, dtype=np.uint64)) if given else np.ascontiguousarray(whitelist_keys, dtype=np.uint64)
+    keys = (np.unique(np.ascontiguousarray(used_keys, dtype=np.uint64)) if given else
+            np.zeros(0, dtype=np.uint64) if nowl else np.ascontiguousarray(whitelist_keys, dtype=np.uint64))
     # ---- inflate + pass 1: a file's chunks go to the device as soon as the file is inflated (the host inflates the next one meanwhile) -----
     t0 = time.perf_counter()
     import threading
 
     set_ready = threading.Event()
     hist = torch.zeros(keys.size, dtype=torch.int32, device=dev)
+    key_lists, key_bufs, key_lock = threading.local(), [], threading.Lock()      # -a none: per worker thread a list of the barcodes its chunks left
 
     def load_set():
         """the possible barcodes on the device (125 ms for 3.6 M of them); the worker threads inflate their first files meanwhile"""
         try:
-            if not given:                       # (a supplied list is loaded once, as the used list, after the files are read)
+            if not given and not nowl:          # (a supplied list is loaded once, as the used list, after the files are read; -a none has none)
                 ctx.set_barcode_set(keys, mode=_lib.SET_WHITELIST)
                 for ln in lanes[1:]:
                     ln.refresh()
@@ -236,6 +241,20 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
             else:
                 lines = 0
             return lines // 4
+        if nowl:                                # -a none: the chunk's barcodes as keys onto this thread's list (counted after the pass)
+            buf = getattr(key_lists, "cur", None)
+            if buf is None or buf[2] + reads_per_chunk > buf[0].numel():
+                buf = [torch.empty(max(4 * reads_per_chunk, 1 << 20), dtype=torch.int64, device=dev), torch.zeros(1, dtype=torch.int64, device=dev), 0]
+                key_lists.cur = buf
+                with key_lock:
+                    key_bufs.append(buf)
+            n_ = lane.scanfastq_pass1_chunk_keys(text[rng[0]:rng[1]], buf[0][buf[2]:], buf[1], five_prime=five_prime, dont_search_polya=dont_search_polya)
+            got = int(buf[1].item())
+            buf[1].zero_()
+            if got > buf[0].numel() - buf[2]:
+                raise _lib.SmiError("pass 1 (-a none): a chunk held more records than reads_per_chunk")
+            buf[2] += got
+            return n_
         # the text worker: index, planes, scan and histogram all on the device, so the host's threads stay with the inflating
         set_ready.wait()
         return lane.scanfastq_pass1_chunk(text[rng[0]:rng[1]], hist, five_prime=five_prime, dont_search_polya=dont_search_polya, packed=False)
@@ -430,7 +449,7 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
     ids_in_front = 0
     if multi:
         # one all-reduce of the dense histogram (RCCL on the device tensor), the chunk counts with it; records in front of this rank's files
-        if not given:
+        if not given and not nowl:
             hist, record_count = _dist.allreduce_histogram(hist, record_count, group)
         xdev = dev if dist.get_backend(group) == "nccl" else torch.device("cpu")   # (gloo in the tests: small tensors on the host)
         mine = torch.tensor([int(sum(n_rec))], dtype=torch.int64, device=xdev)
@@ -441,12 +460,33 @@ def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, g
         # the supplied list IS the search set: counts and ranks 0 (CountsRank(0, 0)); the reference runs no collision merge on it
         k, rk_keys, rk_vals = keys, keys, None
     else:
-        h = hist.cpu().numpy()
-        nz = np.nonzero(h)[0]
-        k, c, r = _lib.finalize_used_list(keys[nz], h[nz].astype(np.uint32), record_count, max_ed, 10, 500)
+        if nowl:
+            # every barcode seen, sorted and counted on the device; the ranks' tables added up on the host
+            parts = [b[0][:b[2]] for b in key_bufs if b[2]]
+            all_keys = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=dev)
+            hk, hc = ctx.count_keys_device(all_keys, int(all_keys.numel()))
+            del all_keys, parts
+            key_bufs.clear()
+            if multi:
+                every = [None] * world
+                dist.all_gather_object(every, (hk, hc, record_count), group=group)
+                cat_k, cat_c = np.concatenate([e[0] for e in every]), np.concatenate([e[1] for e in every]).astype(np.uint64)
+                hk, inv = np.unique(cat_k, return_inverse=True)
+                hc = np.bincount(inv, weights=cat_c.astype(np.float64), minlength=hk.size).astype(np.uint32)
+                record_count = int(sum(e[2] for e in every))
+        else:
+            h = hist.cpu().numpy()
+            nz = np.nonzero(h)[0]
+            hk, hc = keys[nz], h[nz].astype(np.uint32)
+        k, c, r = _lib.finalize_used_list(hk, hc, record_count, max_ed, 10, 500)
         if rank == 0:
             with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
-                f.write(_lib.barcode_list_tsv(keys[nz], h[nz].astype(np.uint32), record_count, max_ed))
+                f.write(_lib.barcode_list_tsv(hk, hc, record_count, max_ed, no_whitelist=nowl))
+        if nowl and k.size and int(k.max()) >> 32:
+            # a 5' barcode that was cut with an N in it is a long with its upper half set (UsedCellBCListGenerator.java:L219; NOTES R5.10): it can
+            # only ever equal a window with the same N, which the matcher does not probe -- such an entry stays in the TSVs and leaves the search set
+            keep = (k >> np.uint64(32)) == 0
+            k, c, r = k[keep], c[keep], r[keep]
         order = np.argsort(k)
         rk_keys, rk_vals = k[order], r[order].astype(np.int32)
     ctx.set_barcode_set(k, mode=_lib.SET_WHITELIST if given else _lib.SET_USED_LIST)

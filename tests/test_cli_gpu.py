@@ -148,6 +148,10 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert "2 Files found" in r.stdout and "skipping 1st pass" in r.stdout and "Won't write fastqs" in r.stdout
     assert sorted(os.listdir(str(work / "scan2"))) == ["BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan3 --bcEditDistance 1 -a none -s", env, str(work))   # no list of possible barcodes
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert sorted(os.listdir(str(work / "scan3"))) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    assert len(open(str(work / "scan3" / "BarcodesAssigned.tsv")).read().split("\n")) > 20
     r = _run(STEP3.replace("passedParsed.bam", "limited.bam") + " -b 0 -u 1", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     _, _, lim = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "limited.bam", "rb").read()))

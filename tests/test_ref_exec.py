@@ -776,6 +776,30 @@ def test_pass1_worker_5p_equals_reference_bytecode(sor):
     assert n_ok >= 4 and sorted([int(k), v] for k, v in hist.items()) == sec["histogram"]
 
 
+@pytest.mark.parametrize("name,five_prime", [("pass1_nowl", False), ("pass1_nowl_5p", True)])
+def test_pass1_worker_without_whitelist_equals_reference_bytecode(sor, name, five_prime):
+    """`-a none` (allPossibleBarcodes == null, UsedCellBCListGenerator.java:L255-256): every barcode cut from a read that passes the filter is
+    counted, under the reference's long.  Reads with an N inside the barcode: the 3' key goes through reverseComplement and comes out as a clean
+    16-mer ("T .. T C" up to the N), the 5' key keeps the -2 of getLongHashForSeq -- bits 63 .. 32 set"""
+    sec = load(name)["sections"][0]
+    assert sec["whitelist"] is None and sec["five_prime"] == five_prime and sec["hash_orders_agree"] and sec["record_count"] == 1
+    hist, n_with_n = {}, 0
+    for c in sec["cases"]:
+        assert c["scanned"] and "filter_throws" not in c
+        rc, sc = (sor.scan_read_5p(c["seq"], c["qual"], "CTACACGACGCTCTTCCGATCT", dont_search_polya=False) if five_prime
+                  else sor.scan_read_3p(c["seq"], c["qual"], "CTACACGACGCTCTTCCGATCT"))
+        assert rc == 0 and bool(sc["pass1_ok"]) == c["filter"], c["name"]
+        if sc["pass1_ok"]:
+            st = c["seq"].encode().translate(_TR)[::-1] if sc["reverse"] else c["seq"].encode()
+            ae = int(sc["adapter_end"])
+            w = st[ae:ae + 16].decode() if five_prime else st[ae - 17:ae - 1].decode()
+            n_with_n += "N" in w
+            key = (sor.encode(w) if five_prime else sor.revcomp(sor.encode(w))) & 0xFFFFFFFFFFFFFFFF
+            hist[key] = hist.get(key, 0) + 1
+    assert sorted([int(k), v] for k, v in hist.items()) == sec["histogram"] and n_with_n >= 5
+    assert (max(k for k, _ in sec["histogram"]) >> 32 == 0xFFFFFFFF) == five_prime
+
+
 def test_pass1_worker_equals_reference_bytecode(sor):
     sec = load("pass1")["sections"][0]
     assert sec["hash_orders_agree"] and all(c["scanned"] and "filter_throws" not in c for c in sec["cases"])

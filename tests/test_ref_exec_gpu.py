@@ -210,3 +210,40 @@ def test_pass1_chunk_worker_equals_reference_bytecode(pkg, gpu_ctx):
     torch.cuda.synchronize()
     res = out.cpu().numpy().view(pkg.SCAN_RESULT_DTYPE).reshape(-1)
     assert [bool(x) for x in res["pass1_ok"]] == [c["filter"] for c in sec["cases"]]
+
+
+@pytest.mark.parametrize("name,five_prime", [("pass1_nowl", False), ("pass1_nowl_5p", True)])
+def test_pass1_chunk_worker_without_whitelist_equals_reference_bytecode(pkg, gpu_ctx, name, five_prime):
+    """`-a none`: smi_scanfastq_pass1_chunk_keys (the barcode of every read that passes the filter appended to a key list) + smi_count_keys_device
+    (sorted, counted) against UsedCellBCListGenerator$Worker.call executed with allPossibleBarcodes == null -- reads with an N inside the
+    barcode included: a clean 16-mer for 3' (reverseComplement keeps the low 32 bits), a long with its upper half set for 5'"""
+    import torch
+
+    with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
+        sec = json.load(f)["sections"][0]
+    assert sec["hash_orders_agree"] and sec["whitelist"] is None and sec["five_prime"] == five_prime
+    text = "".join(f"@{c['name']}\n{c['seq']}\n+\n{c['qual']}\n" for c in sec["cases"]).encode()
+    d_keys = torch.zeros(len(sec["cases"]) + 8, dtype=torch.int64, device="cuda")
+    d_count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    # (the 5' fixture was executed with the polyA search on, as quickrun's 5' line without -y runs)
+    assert gpu_ctx.scanfastq_pass1_chunk_keys(text, d_keys, d_count, five_prime=five_prime, dont_search_polya=False) == len(sec["cases"])
+    m = int(d_count.item())
+    assert m == sum(c for _, c in sec["histogram"]) == sum(1 for c in sec["cases"] if c.get("filter"))
+    uk, uc = gpu_ctx.count_keys_device(d_keys[:m], m)
+    assert [[int(k), int(c)] for k, c in zip(uk, uc)] == sec["histogram"]
+    assert bool(int(uk.max()) >> 32) == five_prime
+
+
+def test_count_keys_device_equals_numpy(pkg, gpu_ctx):
+    import torch
+
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 2, 1000, 300_000):
+        k = rng.integers(0, 500, n).astype(np.uint64) * np.uint64(7919) if n else np.zeros(0, dtype=np.uint64)
+        if n > 10:
+            k[::17] |= np.uint64(0xFFFFFFFF00000000)
+        d = torch.from_numpy(k.view(np.int64).copy()).cuda()
+        uk, uc = gpu_ctx.count_keys_device(d, n)
+        ek, ec = np.unique(k, return_counts=True)
+        assert (uk == ek).all() and (uc == ec).all() and uk.size == ek.size
+

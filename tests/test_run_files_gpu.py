@@ -188,3 +188,42 @@ def test_supplied_barcode_list_dontwrite_trim_and_file_selection(pkg, synth, gpu
     assert f_["files"] == 2 and sorted(os.listdir(str(tmp_path / "some" / "passed"))) == [f"synth_{k:04d}_passed.fastq.gz" for k in (1, 2)]
     g = run_files.run(gpu_ctx, in_dir, str(tmp_path / "pat"), **dict(kw, pattern=r".*/sub/.*\.fastq\.gz"))
     assert g["files"] == 1 and os.listdir(str(tmp_path / "pat" / "passed")) == ["synth_0003_passed.fastq.gz"]
+
+
+def test_run_without_a_list_of_possible_barcodes(pkg, synth, gpu_ctx, tmp_path):
+    """`-a none`: pass 1 counts every barcode it cuts (key lists per worker thread, sorted and counted on the device), finalize works on that
+    table, `BarcodeList.tsv` is the no-whitelist form; against the same steps called one by one (chunk keys -> numpy counts -> finalize) and
+    against the run WITH the whitelist, whose used list it must contain"""
+    from sicelore_amd import lib as libmod
+
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    dev = torch.device("cuda", gpu_ctx.device)
+    wl = synth.make_whitelist(60_000, seed=841, device=dev)
+    used = synth.pick_used(wl, 40, seed=842)
+    keys = np.sort(wl.cpu().numpy().astype(np.uint64))
+    in_dir = str(tmp_path / "in")
+    n = run_files.write_synthetic_dir(synth, in_dir, 3, 4000, used, dev, seed=850, chimera_frac=0.05)
+    kw = dict(max_ed=1, n_workers=3, reads_per_chunk=900)
+    a = run_files.run(gpu_ctx, in_dir, str(tmp_path / "wl"), whitelist_keys=keys, **kw)
+    b = run_files.run(gpu_ctx, in_dir, str(tmp_path / "nowl"), whitelist_keys=None, **kw)
+    assert b["reads"] == n == a["reads"]
+    # the steps one by one
+    texts = [gzip.open(os.path.join(in_dir, f)).read() for f in sorted(os.listdir(in_dir))]
+    d_keys = torch.zeros(n + 8, dtype=torch.int64, device=dev)
+    d_count = torch.zeros(1, dtype=torch.int64, device=dev)
+    at = 0
+    for t in texts:
+        assert 3000 < gpu_ctx.scanfastq_pass1_chunk_keys(t, d_keys[at:], d_count) <= 4000      # (records: 5 % of the reads were joined in pairs)
+        at += int(d_count.item())
+        d_count.zero_()
+    hk, hc = np.unique(d_keys[:at].cpu().numpy().view(np.uint64), return_counts=True)
+    record_count = 3                                                       # under 4,000 records per file: one 10,000-read chunk each
+    k, c, r = libmod.finalize_used_list(hk, hc.astype(np.uint32), record_count, 1, 10, 500)
+    assert b["used_list"] == k.size
+    assert open(os.path.join(str(tmp_path / "nowl"), "BarcodeList.tsv")).read() == libmod.barcode_list_tsv(hk, hc.astype(np.uint32), record_count, 1, no_whitelist=True)
+    # without the list more barcodes are counted (every erroneous one too), and what the list-guided pass 1 kept is among them
+    wl_rows = {ln.split("\t")[0] for ln in open(os.path.join(str(tmp_path / "wl"), "BarcodesAssigned.tsv")).read().split("\n")[1:] if ln}
+    nowl_rows = {ln.split("\t")[0] for ln in open(os.path.join(str(tmp_path / "nowl"), "BarcodesAssigned.tsv")).read().split("\n")[1:] if ln}
+    assert hk.size > 2 * a["used_list"] and len(wl_rows & nowl_rows) >= 0.9 * len(wl_rows)
+    assert b["assigned"] > 0.8 * a["assigned"] and len(os.listdir(str(tmp_path / "nowl" / "passed"))) == 3
+

@@ -2068,8 +2068,10 @@ UCG = "com/rw/nanoporereadscanner/analyzers/UsedCellBCListGenerator"
 RCHUNK = "com/rw/nanoporereadscanner/readerwriter/FastqFileReader$ReadChunk"
 
 
-def gen_pass1(g, n_reads=60, seed=1616, five_prime=False):
-    """a-12: the pass-1 worker of scanfastq over one chunk"""
+def gen_pass1(g, n_reads=60, seed=1616, five_prime=False, no_whitelist=False):
+    """a-12: the pass-1 worker of scanfastq over one chunk.  no_whitelist: `-a none` (generateUsedBarcodesWithoutWhitelist): allPossibleBarcodes is
+    null, every barcode cut from a read that passes the filter is counted (UsedCellBCListGenerator.java:L255-256) -- every third read gets an N
+    inside its barcode, so the map also shows what key such a barcode is counted under"""
     j = g.j
     rng = random.Random(seed)
     p2 = Pass2(g, five_prime, 1)
@@ -2083,11 +2085,18 @@ def gen_pass1(g, n_reads=60, seed=1616, five_prime=False):
                   "new UsedCellBCListGenerator$Worker(generator, chunk).call() (UsedCellBCListGenerator.java:L189-263): per record the "
                   "quality filter lambda$call$0 (L198-202), then the barcode cut from the stranded read, its membership in the list of possible "
                   "barcodes and the counter map.  Outputs: per record `filter`, and the final unfilteredUsedBarcodeMap", UCG + "$Worker", "call:()Ljava/lang/Object;")
-    s["whitelist"] = whitelist
+    s["whitelist"] = None if no_whitelist else whitelist
     s["five_prime"] = five_prime
     reads = []
     for idx in range(n_reads):
         seq, qual, bc = synth_read(rng, bcs, five_prime, idx)
+        if no_whitelist and (idx % 3 == 0 or (five_prime and idx % 3 == 1)):          # an N inside the barcode, wherever the (possibly damaged, possibly reversed) copy still stands
+            for probe in (bc, revcomp_str(bc)):
+                at = seq.find(probe)
+                if at >= 0:
+                    k = at + rng.randrange(16)
+                    seq = seq[:k] + "N" + seq[k + 1:]
+                    break
         if idx % 4 == 1:   # low qualities over the barcode or over the whole read
             qual = "".join(chr(33 + rng.randrange(2, 9)) for _ in qual)
         elif idx % 4 == 2:
@@ -2109,7 +2118,7 @@ def gen_pass1(g, n_reads=60, seed=1616, five_prime=False):
         wl_map = j.natives[L2O + ".<new>"](j)
         for q in whitelist:
             wl_map.native.put(JBox("java/lang/Long", enc(q)), True)
-        gen.f["allPossibleBarcodes"] = j.natives[L2O + ".keySet"](j, wl_map)   # LongOpenHashSet stand-in: contains only
+        gen.f["allPossibleBarcodes"] = None if no_whitelist else j.natives[L2O + ".keySet"](j, wl_map)   # LongOpenHashSet stand-in: contains only
         ud = j.new(UBLD, f"(L{PAR};)V", par)
         gen.f["barcodesUsedData"] = ud
         fqs, cases = [], []
@@ -2706,7 +2715,8 @@ SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": ge
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
             "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
             "pass2x_3p": gen_pass2x_3p, "pass2x_5p": gen_pass2x_5p, "group2": gen_group2, "cluster_own2": gen_cluster_own2,
-            "pass1_5p": lambda g: gen_pass1(g, 32, 1626, five_prime=True)}
+            "pass1_5p": lambda g: gen_pass1(g, 32, 1626, five_prime=True),
+            "pass1_nowl": lambda g: gen_pass1(g, 60, 1636, no_whitelist=True), "pass1_nowl_5p": lambda g: gen_pass1(g, 66, 1646, five_prime=True, no_whitelist=True)}
 
 
 def run_section(name):
