@@ -1123,23 +1123,35 @@ int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan
 // (tests/golden/ref_exec_pass1_nowl_5p.json has five of them).
 __global__ void k_keys_windows(const smi_bc_window *__restrict__ win, const smi_scan_result *__restrict__ scan, size_t n,
                                uint64_t *__restrict__ keys, unsigned long long cap, unsigned long long *__restrict__ count) {
-    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        if (!scan[i].pass1_ok) continue;
-        const smi_bc_window w = win[i];
-        if (!(w.flags & SMI_WIN_VALID)) continue;
-        const bool fp = (w.flags & SMI_WIN_5P) != 0;
-        const OffsetKey ok = make_key(w.bases, w.nmask, 0, fp);
-        uint64_t k = ok.key;
-        if (!ok.usable) {  // 5' window with an N (make_key: base indices 2 .. 17 of the 25-base record)
-            const uint32_t nm = (w.nmask >> 2) & 0xFFFFu;
-            const int last = 31 - __clz(nm);  // window index of the last N
-            const uint32_t low = (ok.key & lowmask(30 - 2 * last)) | (0xFFFFFFFFu << (31 - 2 * last));
-            k = 0xFFFFFFFF00000000ull | low;
+    // (every lane of a wave takes part in every turn: the append is one atomic per wave, not one per read -- atomics on a single address serialise)
+    for (size_t i0 = blockIdx.x * (size_t)blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += stride) {
+        const size_t i = i0 + lane;
+        bool have = false;
+        uint64_t k = 0;
+        if (i < n && scan[i].pass1_ok) {
+            const smi_bc_window w = win[i];
+            if (w.flags & SMI_WIN_VALID) {
+                const bool fp = (w.flags & SMI_WIN_5P) != 0;
+                const OffsetKey ok = make_key(w.bases, w.nmask, 0, fp);
+                k = ok.key;
+                if (!ok.usable) {  // 5' window with an N (make_key: base indices 2 .. 17 of the 25-base record)
+                    const uint32_t nm = (w.nmask >> 2) & 0xFFFFu;
+                    const int last = 31 - __clz(nm);  // window index of the last N
+                    const uint32_t low = (ok.key & lowmask(30 - 2 * last)) | (0xFFFFFFFFu << (31 - 2 * last));
+                    k = 0xFFFFFFFF00000000ull | low;
+                }
+                have = true;
+            }
         }
-        const unsigned long long at = atomicAdd(count, 1ull);  // (the order of the list is of no consequence: it is sorted before it is counted)
-        if (at < cap) keys[at] = k;
+        const unsigned long long m = __ballot(have);
+        if (!m) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(count, (unsigned long long)__popcll(m));  // (the order of the list is of no consequence: it is sorted before it is counted)
+        base = __shfl(base, 0);
+        const unsigned long long at = base + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
+        if (have && at < cap) keys[at] = k;
     }
 }
 
