@@ -15,12 +15,14 @@ import __graft_entry__ as graft  # noqa: E402
 
 def main():
     in_dir, out_dir, keys_file = sys.argv[1:4]
+    mode = sys.argv[4] if len(sys.argv) > 4 else "whitelist"      # whitelist (default two-pass) | none (-a none) | given (-g: keys_file is the list)
     dist.init_process_group(backend="gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     pkg = graft.load_package()
     run_files = importlib.import_module(graft.PKG_NAME + ".run_files")
     ctx = pkg.Context(0)
     keys = np.load(keys_file)
-    info = run_files.run(ctx, in_dir, out_dir, max_ed=1, n_workers=3, reads_per_chunk=1000, whitelist_keys=keys, gz="device")
+    kw = dict(whitelist_keys=keys) if mode == "whitelist" else dict(whitelist_keys=None) if mode == "none" else dict(whitelist_keys=None, used_keys=keys)
+    info = run_files.run(ctx, in_dir, out_dir, max_ed=1, n_workers=3, reads_per_chunk=1000, gz="device", **kw)
     with open(os.path.join(out_dir, f"info_rank{dist.get_rank()}.json"), "w") as f:
         json.dump({k: v for k, v in info.items() if isinstance(v, (int, float, str)) or v is None}, f)
     dist.barrier()

@@ -99,7 +99,8 @@ def test_directory_run_equals_chunk_worker(pkg, synth, gpu_ctx, tmp_path, gz, in
     assert f"All Reads\t{2 * n:,}" in merged and int(total[3]) == 2 * info["records_out"]
 
 
-def test_two_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path):
+@pytest.mark.parametrize("mode", ["whitelist", "none", "given"])
+def test_two_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path, mode):
     """run_files under torch.distributed (two ranks sharing the box's GPU, gloo): files dealt to the ranks, one histogram all-reduce, read ids
     continued across the ranks, counters and statistics summed -- every output file and TSV equals the single-process run's, byte for byte"""
     import json
@@ -113,11 +114,15 @@ def test_two_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path):
     keys = np.sort(wl.cpu().numpy().astype(np.uint64))
     in_dir, one, two = str(tmp_path / "in"), str(tmp_path / "one"), str(tmp_path / "two")
     n = run_files.write_synthetic_dir(synth, in_dir, 5, 1800, used, dev, seed=820, chimera_frac=0.08)
-    a = run_files.run(gpu_ctx, in_dir, one, max_ed=1, n_workers=3, reads_per_chunk=1000, whitelist_keys=keys, gz="device")
+    # mode: the default two-pass run | -a none (the ranks' key tables are gathered and added up) | -g (a supplied list: no pass-1 exchange at all)
+    if mode == "given":
+        keys = np.sort(used.cpu().numpy().astype(np.uint64))
+    kw = dict(whitelist_keys=keys) if mode == "whitelist" else dict(whitelist_keys=None) if mode == "none" else dict(whitelist_keys=None, used_keys=keys)
+    a = run_files.run(gpu_ctx, in_dir, one, max_ed=1, n_workers=3, reads_per_chunk=1000, gz="device", **kw)
     np.save(str(tmp_path / "keys.npy"), keys)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(root, "tests", "_run_files_rank.py"), in_dir, two, str(tmp_path / "keys.npy")]
+           os.path.join(root, "tests", "_run_files_rank.py"), in_dir, two, str(tmp_path / "keys.npy"), mode]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="4"))
     assert p.returncode == 0, p.stderr[-3000:]
     infos = [json.load(open(os.path.join(two, f"info_rank{r}.json"))) for r in (0, 1)]
@@ -128,7 +133,7 @@ def test_two_ranks_write_what_one_process_writes(pkg, synth, gpu_ctx, tmp_path):
         assert names == sorted(os.listdir(os.path.join(two, sub))) and len(names) == 5
         for f in names:
             assert open(os.path.join(one, sub, f), "rb").read() == open(os.path.join(two, sub, f), "rb").read(), f
-    for f in ("BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"):
+    for f in ("BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv") + (() if mode == "given" else ("BarcodeList.tsv",)):
         assert open(os.path.join(one, f)).read() == open(os.path.join(two, f)).read(), f
 
 
