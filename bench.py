@@ -241,6 +241,45 @@ def end_to_end_leg(ctx, synth, dev, used, n, lane_counts=(1, 2, 3)):
 
 
 
+def hbm_probe(dev):
+    """What this GPU's memory system delivers, measured beside the 8 TB/s of the data sheet (SURVEY 8d asks for the copy rate next to the peak):
+    a device-to-device copy of 2 GiB (read + write) and dependent-free random 4-byte gathers into a 512 MiB table
+    (the size of K-BC1's offset filter) and into an 8 GiB one (the size of its neighbourhood table) -- the ceiling a kernel of random sector reads
+    can reach, whatever its arithmetic.  torch kernels, timed with events; a few hundred milliseconds in all."""
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e-3
+
+    out = {}
+    try:
+        n = 1 << 29                                          # 2 GiB of int32
+        a = torch.empty(n, dtype=torch.int32, device=dev).fill_(1)
+        b = torch.empty_like(a)
+        t = timed(lambda: b.copy_(a))
+        out["copy_GBps"] = 2 * 4 * n / t / 1e9
+        del b
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        m = 1 << 26                                          # 64 M gathers per call
+        for name, words in (("gather_512MiB", 1 << 27), ("gather_8GiB", 1 << 31)):
+            table = a[:words] if words <= n else torch.empty(words, dtype=torch.int32, device=dev).fill_(1)
+            idx = torch.randint(0, words, (m,), device=dev, generator=g, dtype=torch.int64)
+            t = timed(lambda: torch.take(table, idx), reps=3)
+            out[name + "_G_per_s"] = m / t / 1e9
+            del idx, table
+        out["note"] = ("torch copy_ / take; the gathers are independent 4-byte reads at random addresses (one 64-B sector each), 64 M per call")
+    except RuntimeError as e:                                # (not enough free memory beside the bench's own buffers: the probe is optional)
+        out["error"] = str(e)[:200]
+    return out
+
+
 def pmc_table():
     """profiles/pmc_traffic.json: HBM bytes per launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic.py)"""
     try:
@@ -1089,6 +1128,13 @@ def main():
                      "(P.nb) once per offset and, where a barcode is in reach (1.6 of 5 offsets per read against the 3.6 M list), reads the "
                      "matching mutation steps off one bucket of a table of that neighbourhood (P.nt) instead of making the 124 probes: the "
                      "algorithmic figure counts probes answered, not bytes moved, so `frac` is the counter traffic over the HBM peak")
+    probe = hbm_probe(dev) if world == 1 else None
+    if probe and "gather_512MiB_G_per_s" in probe and tj and "k_bc_match_ed1" in tj and tj["k_bc_match_ed1"].get("l2_misses_per_launch"):
+        # K-BC1 against what random sector reads can reach on this GPU: its L2 misses per second beside the measured gather rates
+        miss_rate = tj["k_bc_match_ed1"]["l2_misses_per_launch"] * (n / tj["k_bc_match_ed1"]["reads_per_launch"]) / (k_match * 1e-3) / 1e9
+        f_bc1["random_access"] = {"l2_misses_G_per_s": miss_rate, "measured_gather_512MiB_G_per_s": probe["gather_512MiB_G_per_s"],
+                                  "measured_gather_8GiB_G_per_s": probe["gather_8GiB_G_per_s"],
+                                  "frac_of_512MiB_gather_rate": miss_rate / probe["gather_512MiB_G_per_s"]}
     dom, oth = (f_scan, f_bc1) if k_scan >= k_match else (f_bc1, f_scan)
     n_adapter = int(((scan_out[:n, 6] >> 16) & 0xFF).eq(1).sum().item())
     res = {
@@ -1133,6 +1179,8 @@ def main():
                                             "leg off: AverageNs of k_scan<10> is kernel_ms)",
                             "probes_per_s_bc1": 620.0 * n / (k_match * 1e-3)}),
     }
+    if probe:
+        res["hbm_measured"] = probe
     if two_pass is not None:
         res["two_pass"] = two_pass
     if world == 1 and args.single_process_gpus > 0:
