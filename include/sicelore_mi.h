@@ -91,6 +91,11 @@ const char *smi_version(void);
 int smi_ctx_create(int device, smi_ctx **out);
 int smi_ctx_destroy(smi_ctx *ctx);
 int smi_ctx_device(const smi_ctx *ctx);
+/* `scanfastq -p <polyAlength> -f <fractionAT> -w <windowAT>` (NanoporeReadScannerMain.java:L227-234): the polyA / polyT finder of the per-chunk
+ * workers of this context (smi_scanfastq_pass{1,2}_chunk[_packed], _keys) runs with these values instead of config.xml's 15 / 0.75 / 150 (0 keeps
+ * the shipped one); the chimera splitter's distance from the read ends follows the window.  Lanes take the values of their owner when they are
+ * created or refreshed.  Limits of this build (175 scanned bases per end): 5 <= length <= 30, window + length + 10 <= 175. */
+int smi_ctx_set_polya(smi_ctx *ctx, int polya_len, float polya_frac, int window_polya);
 /* A worker lane of `owner`: a context with its own stream, device arena, pinned output buffers and timing that READS the owner's barcode
  * set instead of holding the 616 MiB membership pyramid and the neighbourhood bitmap and table (up to 8.3 GB for the whole whitelist) again -- several host threads, one lane each, overlap their uploads, kernels and
  * downloads on one GPU over ONE set, as the reference's nCPU Parser workers share one hashMapForBCfinding

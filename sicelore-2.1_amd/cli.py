@@ -1,7 +1,7 @@
 """The jar's command line in front of the library.
 
     java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar scanfastq  -d <dir[,dir..]> -o <dir> --bcEditDistance k [--compress] [--ncpu N] [-h] [-y] [-a file]
-                                                                [-g usedBarcodes] [-n] [-v regex] [-k skip] [-z only] [-s] [-u]
+                                                                [-g usedBarcodes] [-n] [-v regex] [-k skip] [-z only] [-s] [-u] [-p len] [-f frac] [-w window]
     java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w] [-b ed] [-u ed] [-s]
 
 become   python sicelore-2.1_amd scanfastq ... / assignumis ...   (the directory is runnable: __main__.py; a `java` wrapper that drops
@@ -15,7 +15,7 @@ config.xml: the library's kernels are built for the shipped values of the knobs 
 thresholds, windows); those are CHECKED against the file and a different value stops the run with the knob's name -- nothing is silently
 ignored.  The knobs that are run-time parameters of the library are taken from the file: sam_records_chunk_size,
 max_GenomeDistance_forGrouping, fileWithAllPossibleTenXbarcodes.  Options the product has no path for (Illumina-guided modes, random
-barcodes, the file watcher, other polyA windows than the shipped ones) are refused by name.
+barcodes, the file watcher) are refused by name.
 """
 import gzip
 import os
@@ -34,8 +34,7 @@ BUILT_IN = {
     "readscanner/minMeanBCqv": "8", "readscanner/minMeanReadqv": "8", "readscanner/minAdapter3pMatches": "8", "readscanner/minCountFold": "10",
     "readscanner/nbasesOfAdapterSeqInReadname": "3", "readscanner/runningasdemon": "false",
     "barcodeUMIFinder/gene_name_attribute": "GE", "barcodeUMIFinder/tagGeneNameFunction": "DefaultTagger",
-    "polyAT/polyATlength": "15", "polyAT/fractionATInPolyAT": "0.75", "polyAT/internalpATlength": "15", "polyAT/internalFractionATInPolyAT": "0.70",
-    "polyAT/windowSearchForPolyA": "150",
+    "polyAT/internalpATlength": "15", "polyAT/internalFractionATInPolyAT": "0.70",
     "adapter_for3pBarcoding/sequence": "CTTCCGATCT", "adapter_for3pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
     "adapter_for3pBarcoding/maxNeedlemanMismatches": "3", "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
     "fiveprimeadapter_for5pBarcoding/sequence": "CTTCCGATCT", "fiveprimeadapter_for5pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
@@ -52,7 +51,7 @@ BUILT_IN = {
     "umis/umi_length": "12", "umis/umi_completelinkclusteringED": "2", "umis/umi_singlelinkclusteringED": "1",
 }
 RUN_TIME = ("barcodeUMIFinder/sam_records_chunk_size", "barcodes/max_GenomeDistance_forGrouping", "readscanner/fileWithAllPossibleTenXbarcodes",
-            "readscanner/mergeBCsED")
+            "readscanner/mergeBCsED", "polyAT/polyATlength", "polyAT/fractionATInPolyAT", "polyAT/windowSearchForPolyA")
 
 
 class CliError(Exception):
@@ -152,10 +151,11 @@ SCAN_SPEC = {"inDir": ("d", "inDir", True), "outDir": ("o", "outDir", True), "bc
              # NanoporeReadScannerMain.java:L138-146, L180-183 (file selection), L211-213 (-s), L239-240 (-u), L245-246 (-g)
              "cellRangerBCs": ("g", "cellRangerBCs", True), "skipNfastqs": ("k", "skipNfastqs", True), "onlyNfastqs": ("z", "onlyNfastqs", True),
              "nonrecursive": ("n", "nonrecursive", False), "pattern": ("v", "pattern", True), "dontwrite": ("s", "dontwrite", False),
-             "trimfastq": ("u", "trimfastq", False)}
+             "trimfastq": ("u", "trimfastq", False),
+             # the polyA finder's window (L227-234); config.xml's polyAT values where the command line has none
+             "polyAlength": ("p", "polyAlength", True), "fractionAT": ("f", "fractionAT", True), "windowAT": ("w", "windowAT", True)}
 SCAN_REFUSED = {o: why for opts, why in (
     (("-e", "--randomBarcode"), "random barcodes (a specificity experiment of the reference) are not built"),
-    (("-f", "--fractionAT", "-p", "--polyAlength", "-w", "--windowAT"), "the polyA finder is compiled for the shipped config.xml values (15 / 0.75 / 150)"),
     (("-i",), "Use either -i or -d: only -d <directories> is built"))
     for o in opts}
 UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "outfile", True), "annotationFile": ("a", "annotationFile", True),
@@ -210,6 +210,13 @@ def scanfastq(argv):
     knobs = read_config(find_config())
     if knobs.get("readscanner/mergeBCsED", "null") not in ("null", "", str(ed)):
         raise CliError("readscanner/mergeBCsED: only null (= the barcode edit distance) is built")
+    try:
+        polya = (int(o.get("polyAlength") or knobs.get("polyAT/polyATlength", 15)), float(o.get("fractionAT") or knobs.get("polyAT/fractionATInPolyAT", 0.75)),
+                 int(o.get("windowAT") or knobs.get("polyAT/windowSearchForPolyA", 150)))
+    except ValueError:
+        raise CliError("-p / -w take whole numbers, -f a fraction (polyAT/polyATlength, fractionATInPolyAT, windowSearchForPolyA in config.xml)")
+    if polya == (15, 0.75, 150):
+        polya = None                       # the shipped window: the kernels compiled for it
     for d in [d for d in o["inDir"].split(",") if d]:            # -d takes a comma-separated list (FileTools.java:L52)
         if not os.path.isdir(d):
             raise CliError(f"input directory {d} does not exist")
@@ -258,7 +265,7 @@ def scanfastq(argv):
         print("Stats only, Won't write fastqs")
     ctx = _context()
     ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
-    info = run_files.run(ctx, o["inDir"], o["outDir"], max_ed=ed, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
+    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
                          dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")),
                          recursive="nonrecursive" not in o, pattern=o.get("pattern", run_files.FASTQ_PATTERN), skip_files=skip, only_files=only,
                          used_keys=used, write_fastqs="dontwrite" not in o, trim_fastq="trimfastq" in o)

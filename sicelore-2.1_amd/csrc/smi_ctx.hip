@@ -207,6 +207,9 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->block_counts = o->block_counts;
     lane->n_keys = o->n_keys;
     lane->set_mode = o->set_mode;
+    lane->polya_len = o->polya_len;
+    lane->polya_frac = o->polya_frac;
+    lane->polya_window = o->polya_window;
     return SMI_OK;
 }
 
@@ -257,6 +260,22 @@ int smi_ctx_destroy(smi_ctx *ctx) {
 }
 
 int smi_ctx_device(const smi_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int smi_ctx_set_polya(smi_ctx *ctx, int polya_len, float polya_frac, int window_polya) {
+    if (!ctx) {
+        set_error("null context");
+        return SMI_ERR_INVALID;
+    }
+    const int len = polya_len > 0 ? polya_len : 15, win = window_polya > 0 ? window_polya : 150;
+    if (len < 5 || len > 30 || win + len + 10 > 175 || (polya_frac != 0.0f && !(polya_frac > 0.0f && polya_frac <= 1.0f))) {
+        set_error("smi_ctx_set_polya: this build scans 175 bases of each read end: 5 <= polyA length <= 30, window + length + 10 <= 175, 0 < fraction <= 1");
+        return SMI_ERR_INVALID;
+    }
+    ctx->polya_len = polya_len > 0 ? polya_len : 0;
+    ctx->polya_frac = polya_frac;
+    ctx->polya_window = window_polya > 0 ? window_polya : 0;
+    return SMI_OK;
+}
 
 int smi_set_timing(smi_ctx *ctx, int enabled) {
     if (!ctx) {

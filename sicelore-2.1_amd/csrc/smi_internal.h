@@ -116,6 +116,8 @@ struct smi_ctx {
     uint32_t *t2 = nullptr;
     uint32_t *n1 = nullptr;   // allocated with the first short barcode list (2 x 16 MiB: n1, then n2)
     bool n1_valid = false;    // describes the set that is loaded now
+    int polya_len = 0, polya_window = 0;  // smi_ctx_set_polya: the chunk workers' polyA finder parameters (0: the shipped config.xml values)
+    float polya_frac = 0.0f;
     bool nb2_valid = false;   // the build scratch n1_owner holds the two-step neighbourhood bitmap of the set that is loaded now
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
     uint32_t *n1_owner = nullptr;  // scratch of the n2 build (one u32 per n1 cell, 512 MiB), kept: hipMalloc / hipFree of that size cost ~100 ms per set load

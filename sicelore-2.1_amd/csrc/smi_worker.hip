@@ -101,6 +101,16 @@ int grow_arena_keep(smi_ctx *ctx, size_t bytes, size_t keep_bytes, hipStream_t s
     return SMI_OK;
 }
 
+// -p / -f / -w of scanfastq (smi_ctx_set_polya): the chunk workers' configurations are the shipped ones with these three fields replaced
+inline void apply_polya(const smi_ctx *ctx, smi_scan_config &sc) {
+    if (ctx->polya_len) sc.polya_len = ctx->polya_len;
+    if (ctx->polya_frac != 0.0f) sc.polya_frac = ctx->polya_frac;
+    if (ctx->polya_window) sc.window_polya = ctx->polya_window;
+}
+inline void apply_polya(const smi_ctx *ctx, smi_chimera_config &cc) {
+    if (ctx->polya_window) cc.window_polya = ctx->polya_window;  // (the splitter keeps away from the read ends by windowSearchForPolyA + 70)
+}
+
 #define SMI_RC(call)                 \
     do {                             \
         const int rc__ = (call);     \
@@ -184,6 +194,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         d_fsrc = A.take<uint32_t>(3 * cap);
         smi_chimera_config cc;
         SMI_RC(five ? smi_chimera_default_config_5p(&cc) : smi_chimera_default_config(&cc));
+        apply_polya(ctx, cc);
         SMI_RC(smi_pack_reads_text_device(ctx, d_text, d_ss, d_offs, n, total, d_planes, s));
         SMI_RC(smi_chimera_device(ctx, d_planes, d_offs, n, total, &cc, d_chim, s));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
@@ -209,6 +220,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     smi_bc_result *d_bc = A.take<smi_bc_result>(m_cap);
     smi_scan_config sc;
     SMI_RC(five ? smi_scan_default_config_5p(2, cfg->dont_search_polya, &sc) : smi_scan_default_config(2, &sc));
+    apply_polya(ctx, sc);
     // no qualities here: the quality filter (pass1_ok) belongs to pass 1 (UsedCellBCListGenerator.java:L198-202)
     SMI_RC(smi_frag_text_starts_device(ctx, d_ss, d_qs, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_bstart, d_qstart, s));
     SMI_RC(smi_pack_ends_text_device(ctx, d_text, d_bstart, d_rec_offs, m, d_ends, d_len, s));
@@ -379,6 +391,7 @@ int pass1_chunk_core(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five
     smi_bc_window *d_win = A.take<smi_bc_window>(cap);
     smi_scan_config sc;
     SMI_RC(five_prime ? smi_scan_default_config_5p(1, dont_search_polya, &sc) : smi_scan_default_config(1, &sc));
+    apply_polya(ctx, sc);
     SMI_RC(smi_pack_ends_device(ctx, d_reads, d_quals, d_offs, n, five_prime, d_ends, d_len, d_qtail, d_qsum, s));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, n, &sc, d_scan, d_win, s));
     if (d_hist)
@@ -472,6 +485,7 @@ int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *
         d_fsrc = A.take<uint32_t>(3 * n);
         smi_chimera_config cc;
         SMI_RC(five ? smi_chimera_default_config_5p(&cc) : smi_chimera_default_config(&cc));
+        apply_polya(ctx, cc);
         SMI_RC(launch_chimera(ctx, d_planes, d_offs, n, total, &cc, d_chim, s, d_pstart, pstride));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
         SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_CHIM, n * sizeof(smi_chimera_result)));
@@ -498,6 +512,7 @@ int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *
     smi_bc_result *d_bc = A.take<smi_bc_result>(m_cap);
     smi_scan_config sc;
     SMI_RC(five ? smi_scan_default_config_5p(2, cfg->dont_search_polya, &sc) : smi_scan_default_config(2, &sc));
+    apply_polya(ctx, sc);
     SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_ends, d_len, s, d_pstart));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
@@ -700,6 +715,7 @@ extern "C" int smi_scanfastq_pass1_chunk_packed(smi_ctx *ctx, const uint8_t *tex
     SMI_HIP(hipMemcpyAsync(d_qsum, h_qsum, n * 4, hipMemcpyHostToDevice, s));
     smi_scan_config sc;
     SMI_RC(five_prime ? smi_scan_default_config_5p(1, dont_search_polya, &sc) : smi_scan_default_config(1, &sc));
+    apply_polya(ctx, sc);
     SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_offs, nullptr, n, d_ends, d_len, s, d_pstart));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, n, &sc, d_scan, d_win, s));
     SMI_RC(smi_hist_windows_device(ctx, d_win, d_scan, n, d_hist, s));

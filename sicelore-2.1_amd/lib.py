@@ -48,7 +48,7 @@ EXPORTS = [
     "smi_last_error", "smi_version", "smi_ctx_create", "smi_ctx_destroy", "smi_ctx_device", "smi_set_barcode_set",
     "smi_set_barcode_set_device", "smi_bc_match_batch", "smi_bc_match_device", "smi_extract_windows_device",
     "smi_hist_device", "smi_last_kernel_ms", "smi_set_timing", "smi_scan_default_config", "smi_pack_ends_device",
-    "smi_scan_device", "smi_hist_windows_device", "smi_pass1_keys_device", "smi_count_keys_device", "smi_scanfastq_pass1_chunk_keys", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
+    "smi_ctx_set_polya", "smi_scan_device", "smi_hist_windows_device", "smi_pass1_keys_device", "smi_count_keys_device", "smi_scanfastq_pass1_chunk_keys", "smi_kernel_ms", "smi_finalize_used_list", "smi_umi_dist_device", "smi_format_read_name",
     "smi_chimera_default_config", "smi_read_planes_words", "smi_pack_reads_device", "smi_chimera_device",
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
@@ -95,6 +95,7 @@ def load_library():
     lib.smi_ctx_create_lane.argtypes = [vp, ctypes.POINTER(vp)]
     lib.smi_ctx_lane_refresh.argtypes = [vp]
     lib.smi_ctx_device.argtypes = [vp]
+    lib.smi_ctx_set_polya.argtypes = [vp, ci, ctypes.c_float, ci]
     lib.smi_set_barcode_set.argtypes = [vp, vp, sz, ci]
     lib.smi_set_barcode_set_device.argtypes = [vp, vp, sz, ci, vp]
     lib.smi_bc_match_batch.argtypes = [vp, vp, sz, ci, ci, vp]
@@ -999,6 +1000,11 @@ class Context:
     def lane(self):
         """a worker lane of this context (smi_ctx_create_lane): own stream / arena / pinned buffers, this context's barcode set"""
         return Context(self.device, _lane_of=self)
+
+    def set_polya(self, polya_len=0, polya_frac=0.0, window_polya=0):
+        """-p / -f / -w of scanfastq for this context's chunk workers (smi_ctx_set_polya; 0 keeps the shipped value); lanes created or
+        refreshed afterwards take them over"""
+        self._check(self._lib.smi_ctx_set_polya(self._h, int(polya_len), float(polya_frac), int(window_polya)))
 
     def refresh(self):
         """lane: pick up the barcode set its owner has loaded since (smi_ctx_lane_refresh)"""

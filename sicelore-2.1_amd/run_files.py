@@ -142,7 +142,19 @@ def _gzip_member(data, level):
     return c.compress(data) + c.flush()
 
 
-def run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
+def run(ctx, in_dir, out_dir, *args, polya=None, **kw):
+    """`_run` (below: everything about the run) with the polyA finder's parameters of `scanfastq -p <length> -f <fraction> -w <window>` set on the
+    context for its duration (smi_ctx_set_polya; None / zeros: config.xml's 15 / 0.75 / 150)"""
+    if polya is not None:
+        ctx.set_polya(*polya)
+    try:
+        return _run(ctx, in_dir, out_dir, *args, **kw)
+    finally:
+        if polya is not None:
+            ctx.set_polya()
+
+
+def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
         dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="host", device_share=0.25, group=None, resident_bytes=96 << 30,
         host_text_bytes=256 << 30, inflate_auto_from=1024, recursive=True, pattern=r".{1,}\.(fastq|fq)(\.gz)?", skip_files=0, only_files=None,
         used_keys=None, write_fastqs=True, trim_fastq=False):

@@ -45,9 +45,12 @@ def test_cli_refuses_what_it_does_not_implement(tmp_path):
                         ("$java -jar x.jar tagbamwithread --inBam a.bam", "sub-command")):
         r = _run(cmd, env, str(tmp_path))
         assert r.returncode == 1 and needle in r.stderr, (cmd, r.returncode, r.stderr[-300:])
-    (tmp_path / "config.xml").write_text("<Parameters><polyAT><polyATlength>18</polyATlength></polyAT></Parameters>")
+    (tmp_path / "config.xml").write_text("<Parameters><polyAT><internalpATlength>18</internalpATlength></polyAT></Parameters>")
     r = _run("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1", env, str(tmp_path))
-    assert r.returncode == 1 and "polyAT/polyATlength" in r.stderr
+    assert r.returncode == 1 and "polyAT/internalpATlength" in r.stderr
+    (tmp_path / "config.xml").write_text("<Parameters><polyAT><polyATlength>18</polyATlength></polyAT></Parameters>")     # a run-time knob since round 5
+    r = _run("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 -p twelve", env, str(tmp_path))
+    assert r.returncode == 1 and "whole numbers" in r.stderr
 
 
 def test_find_fastqs_orders_by_file_name_and_filters(pkg, tmp_path):
@@ -152,6 +155,12 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     assert sorted(os.listdir(str(work / "scan3"))) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
     assert len(open(str(work / "scan3" / "BarcodesAssigned.tsv")).read().split("\n")) > 20
+    # -p / -f / -w: another polyA window through both passes (the kernels with the finder as a loop); out of the build's range: a message, exit code 1
+    r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan4 --bcEditDistance 1 -p 12 -f 0.8 -w 120 -z 1", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(os.listdir(str(work / "scan4" / "passed"))) == 1 and os.path.getsize(str(work / "scan4" / "BarcodesAssigned.tsv")) > 100
+    r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan5 --bcEditDistance 1 -p 40", env, str(work))
+    assert r.returncode == 1 and "polyA length" in r.stderr, r.stderr[-500:]
     r = _run(STEP3.replace("passedParsed.bam", "limited.bam") + " -b 0 -u 1", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     _, _, lim = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "limited.bam", "rb").read()))

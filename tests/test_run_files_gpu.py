@@ -232,3 +232,36 @@ def test_run_without_a_list_of_possible_barcodes(pkg, synth, gpu_ctx, tmp_path):
     assert hk.size > 2 * a["used_list"] and len(wl_rows & nowl_rows) >= 0.9 * len(wl_rows)
     assert b["assigned"] > 0.8 * a["assigned"] and len(os.listdir(str(tmp_path / "nowl" / "passed"))) == 3
 
+
+def test_other_polya_window_through_the_chunk_workers(pkg, synth, sor, gpu_ctx, tmp_path):
+    """-p / -f / -w (smi_ctx_set_polya): the text worker and the packed worker of pass 2 with another polyA window write the records the oracle
+    writes with the same parameters (scan + barcode + names), and the context goes back to the shipped window afterwards"""
+    from test_write_gpu import _fastq, _oracle_records
+
+    wl = synth.make_whitelist(20_000, seed=861)
+    used = synth.pick_used(wl, 100, seed=862)
+    reads = synth.gen_reads(400, used, seed=863, n_rate=0.002)
+    seqs, quals = zip(*(synth.materialize(reads, i) for i in range(400)))
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    text = _fastq(list(seqs), list(quals))
+    base_p, base_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False)
+    base_p = bytes(base_p)
+    differs = 0
+    for polya in ((12, 0.8, 100), (20, 0.7, 140)):
+        par = sor.default_scan_params()
+        par["polya_len"], par["polya_frac"], par["window_polya"] = polya
+        gpu_ctx.set_polya(*polya)
+        try:
+            got_p, got_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False)
+            got_p, got_f = bytes(got_p), bytes(got_f)
+            pk_p, pk_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False, packed=True, n_threads=2)
+            assert bytes(pk_p) == got_p and bytes(pk_f) == got_f
+        finally:
+            gpu_ctx.set_polya()
+        exp_p, exp_f, _n = _oracle_records(sor, sor.BarcodeSet(used.numpy()), list(seqs), list(quals), 1, {}, 1, split=False, scan_params=par)
+        assert got_p == exp_p and got_f == exp_f
+        differs += got_p != base_p
+    assert differs >= 1                                        # (another window does change what is found)
+    again, _f, _ = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False)
+    assert bytes(again) == base_p
+

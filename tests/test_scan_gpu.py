@@ -28,7 +28,7 @@ def _ascii_batch(synth, reads, n, short_every=0):
     return ra, qa, offs
 
 
-def _scan_gpu(pkg, ctx, ra, qa, offs, pass_no):
+def _scan_gpu(pkg, ctx, ra, qa, offs, pass_no, polya=None):
     n = offs.size - 1
     d_reads, d_quals = torch.from_numpy(ra.copy()).cuda(), torch.from_numpy(qa.copy()).cuda()
     d_offs = torch.from_numpy(offs.astype(np.int64)).cuda()
@@ -38,6 +38,8 @@ def _scan_gpu(pkg, ctx, ra, qa, offs, pass_no):
     d_qsum = torch.zeros(n, dtype=torch.int32, device="cuda")
     ctx.pack_ends_device(d_reads, d_quals, d_offs, n, d_ends, d_len, d_qtail, d_qsum)
     cfg = ctx.scan_config(pass_no)
+    if polya is not None:      # -p / -f / -w of scanfastq: other polyA windows than the shipped 15 / 0.75 / 150
+        cfg["polya_len"], cfg["polya_frac"], cfg["window_polya"] = polya
     d_out = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
     d_win = torch.zeros((n, 2), dtype=torch.int64, device="cuda")
     ctx.scan_device(d_ends, d_len, n, cfg, d_out, d_win, d_qtail, d_qsum)
@@ -127,6 +129,28 @@ def test_polyt_finder_on_t_rich_ends(pkg, sor, gpu_ctx, pass_no, generic, monkey
     _compare(got, st, exp, pass1=True)
     has = (exp["polya_end"] != 0).sum()
     assert has > 0.3 * n or (exp["flags"] != exp["flags"][0]).any()   # (the finder found runs in a good part of the reads)
+
+
+@pytest.mark.parametrize("polya", [(12, 0.8, 100), (20, 0.7, 140), (15, 0.75, 120), (10, 0.9, 150), (15, 0.6, 150), (18, 0.75, 147), (30, 0.75, 135), (5, 1.0, 60)])
+def test_other_polya_windows_equal_oracle(pkg, synth, sor, gpu_ctx, polya):
+    """`scanfastq -p <length> -f <fraction> -w <window>` (NanoporeReadScannerMain.java:L227-234): the finder with other parameters than the
+    shipped ones (the kernels with the finder as a loop take them; launch_scan picks them by itself) against the oracle with the same
+    parameters, on ordinary reads and on ends crowded with T / A runs"""
+    par = sor.default_scan_params()
+    par["polya_len"], par["polya_frac"], par["window_polya"] = polya
+    wl = synth.make_whitelist(50_000, seed=231)
+    used = synth.pick_used(wl, 300, seed=232)
+    n = 3000
+    reads = synth.gen_reads(n, used, seed=233, n_rate=0.003)
+    ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
+    for pass_no in (2, 1):
+        got, _, _, _ = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, pass_no, polya=polya)
+        st, exp = sor.scan_batch_3p(ra, qa, offs, AD[pass_no], params=par, n_threads=8)
+        assert _compare(got, st, exp, pass1=True) > 0.3 * n
+    ra, qa, offs = _t_rich_reads(6000, seed=940)
+    got, _, _, _ = _scan_gpu(pkg, gpu_ctx, ra, qa, offs, 2, polya=polya)
+    st, exp = sor.scan_batch_3p(ra, qa, offs, AD[2], params=par, n_threads=8)
+    _compare(got, st, exp, pass1=True)
 
 
 @pytest.mark.parametrize("generic", [False, True])

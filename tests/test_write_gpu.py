@@ -15,7 +15,7 @@ def _fastq(seqs, quals, eol="\n", qh=lambda i: ""):
 
 
 def _oracle_records(sor, bset, seqs, quals, max_ed, rank_of, first_id, five_prime=False, trim=False, split=True, qh=lambda i: "",
-                    noname_blank=False):
+                    noname_blank=False, scan_params=None):
     passed, failed = [], []
     rid = first_id
     for i, (s, q) in enumerate(zip(seqs, quals)):
@@ -31,7 +31,7 @@ def _oracle_records(sor, bset, seqs, quals, max_ed, rank_of, first_id, five_prim
             if five_prime:
                 rc, sc = sor.scan_read_5p(fs, fq, "CTTCCGATCT")
             else:
-                rc, sc = sor.scan_read_3p(fs, fq, "CTTCCGATCT")
+                rc, sc = sor.scan_read_3p(fs, fq, "CTTCCGATCT", params=scan_params)
             assert rc == 0
             a = None
             if sc["adapter_found"] and not multi:
