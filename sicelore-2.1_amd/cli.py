@@ -1,7 +1,7 @@
 """The jar's command line in front of the library.
 
     java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar scanfastq  -d <dir[,dir..]> -o <dir> --bcEditDistance k [--compress] [--ncpu N] [-h] [-y] [-a file]
-                                                                [-g usedBarcodes] [-n] [-v regex] [-k skip] [-z only] [-s] [-u] [-p len] [-f frac] [-w window]
+                                                                [-g usedBarcodes] [-n] [-v regex] [-k skip] [-z only] [-s] [-u] [-p len] [-f frac] [-w window]   (--polyAlength --frac-f --windowAT)
     java -jar [-Xmx..] NanoporeBC_UMI_finder-2.1.jar assignumis --inFileNanopore <bam> -o <bam> [--annotationFile refFlat] [-v n] [-p] [-w] [-b ed] [-u ed] [-s]
 
 become   python sicelore-2.1_amd scanfastq ... / assignumis ...   (the directory is runnable: __main__.py; a `java` wrapper that drops
@@ -153,17 +153,18 @@ SCAN_SPEC = {"inDir": ("d", "inDir", True), "outDir": ("o", "outDir", True), "bc
              "nonrecursive": ("n", "nonrecursive", False), "pattern": ("v", "pattern", True), "dontwrite": ("s", "dontwrite", False),
              "trimfastq": ("u", "trimfastq", False),
              # the polyA finder's window (L227-234); config.xml's polyAT values where the command line has none
-             "polyAlength": ("p", "polyAlength", True), "fractionAT": ("f", "fractionAT", True), "windowAT": ("w", "windowAT", True)}
+             "polyAlength": ("p", "polyAlength", True), "fractionAT": ("f", "frac-f", True), "windowAT": ("w", "windowAT", True)}
 SCAN_REFUSED = {o: why for opts, why in (
     (("-e", "--randomBarcode"), "random barcodes (a specificity experiment of the reference) are not built"),
     (("-i",), "Use either -i or -d: only -d <directories> is built"))
     for o in opts}
 UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "outfile", True), "annotationFile": ("a", "annotationFile", True),
             "config": ("c", "config", True), "chunksize": ("v", "chunksize", True), "fivePbc": ("p", "fivePbc", False),
-            "splitReadName": ("w", "splitReadName", False), "logFile": ("l", "logFile", True), "ncpu": ("t", "ncpu", True),
+            "splitReadName": ("w", "splitReadNameAtUnderscore", False), "logFile": ("l", "logFile", True), "ncpu": ("t", "ncpu", True),
             # -b: barcodes whose ed in the read name is larger are ignored (UmiFinderMain.java:L181-182, FastqRecordExt.java:L450-456);
             # -u: read by the Illumina-guided UMI analyzer only (IlluminaUMIanalyzer) -- accepted, checked to be a number, without effect here
-            "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True), "noclustering": ("s", "noclustering", False)}
+            "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True), "noclustering": ("s", "noclustering", False),
+            "debug": ("d", "debug", False)}   # (-d: stepwise execution of the reference, UmiFinderMain.java:L178-179: accepted, without effect)
 UMI_REFUSED = {o: why for opts, why in (
     (("-k", "--inFile10x", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
     (("-g", "--ONTgene"), "the gene name attribute of this build is GE (config.xml gene_name_attribute; UmiFinderMain.java:L239-246)"),
@@ -194,6 +195,20 @@ def _context():
 
     from . import lib
     return lib.Context(int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count()))
+
+
+def _ncpu(o):
+    """worker threads: -t / --ncpu (scanfastq; NanoporeReadScannerMain.java:L221), else what the JVM would call availableProcessors() -- the
+    `java` stand-in hands over -XX:ActiveProcessorCount=N (sicelore-nf/main.nf:83) as SMI_ACTIVE_PROCESSORS -- capped at the 16 lanes a GPU is given"""
+    for v in (o.get("ncpu"), os.environ.get("SMI_ACTIVE_PROCESSORS")):
+        if v:
+            try:
+                n = int(v)
+            except ValueError:
+                raise CliError(f"--ncpu / -XX:ActiveProcessorCount {v!r}: not a number")
+            if n > 0:
+                return n
+    return min(16, len(os.sched_getaffinity(0)))
 
 
 def scanfastq(argv):
@@ -264,7 +279,7 @@ def scanfastq(argv):
     if "dontwrite" in o:
         print("Stats only, Won't write fastqs")
     ctx = _context()
-    ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
+    ncpu = _ncpu(o)
     info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
                          dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")),
                          recursive="nonrecursive" not in o, pattern=o.get("pattern", run_files.FASTQ_PATTERN), skip_files=skip, only_files=only,
@@ -304,7 +319,7 @@ def assignumis(argv):
             if name == "bcedit":
                 bc_limit = v
     ctx = _context()
-    ncpu = int(o.get("ncpu", 0)) or min(16, len(os.sched_getaffinity(0)))
+    ncpu = _ncpu(o)
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
                                 refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit,
                                 no_clustering="noclustering" in o)

@@ -17,12 +17,9 @@ STEP3 = "$java -jar  -Xmx4G Jar/NanoporeBC_UMI_finder-2.1.jar assignumis --inFil
 
 
 def _wrapper(tmp_path):
-    w = tmp_path / "java"
-    w.write_text("#!/bin/bash\n# stands where `java` stands in quickrun-2.1.sh: the JVM's own options and the jar's name go, the sub-command and its options stay\n"
-                 "args=()\nfor a in \"$@\"; do case \"$a\" in -jar|-Xmx*|-Xms*|*.jar) ;; *) args+=(\"$a\");; esac; done\n"
-                 f"exec {sys.executable} {ROOT}/sicelore-2.1_amd \"${{args[@]}}\"\n")
-    w.chmod(0o755)
-    return str(w)
+    """the product's `java` stand-in (sicelore-2.1_amd/bin/java) with this interpreter"""
+    os.environ["PYTHON"] = sys.executable
+    return "bash " + os.path.join(ROOT, "sicelore-2.1_amd", "bin", "java")      # (`$java` is expanded unquoted in the scripts; no reliance on the mode bits of a snapshot)
 
 
 def _run(cmd, env, cwd):
@@ -161,6 +158,19 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     assert len(os.listdir(str(work / "scan4" / "passed"))) == 1 and os.path.getsize(str(work / "scan4" / "BarcodesAssigned.tsv")) > 100
     r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan5 --bcEditDistance 1 -p 40", env, str(work))
     assert r.returncode == 1 and "polyA length" in r.stderr, r.stderr[-500:]
+    # ---- sicelore-nf/main.nf:32 and :83 as they stand ($params.* filled in as nextflow.config would): --ncpu, -XX:ActiveProcessorCount, the long option of -f
+    nf = dict(env, PJ=env["java"], PX="-Xmx4g", PN="Jar/NanoporeBC_UMI_finder-2.1.jar")
+    r = _run("$PJ -jar $PX $PN scanfastq -d $fastqdir -o ./passed_nf --ncpu 4 --bcEditDistance 1 --compress", nf, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    for p in passed:       # the run of quickrun's line, file by file (the reads' ids, ranks and names do not depend on the thread count)
+        assert gzip.open(str(work / "passed_nf" / "passed" / p)).read() == gzip.open(readscandir + "passed/" + p).read(), p
+    r = _run("$PJ -jar $PX -XX:ActiveProcessorCount=4 $PN assignumis --inFileNanopore ${mappingdir}passed.bam -o passedParsed_nf.bam --annotationFile Data/gencode.v38.chr12.refFlat", nf, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, _, out_nf = bammodel.parse_bam(bammodel.bgzf_decompress(open(str(work / "passedParsed_nf.bam"), "rb").read()))
+    assert [(o_["name"], o_["aux"]) for o_ in out_nf] == [(o_["name"], o_["aux"]) for o_ in out]
+    r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan6 --bcEditDistance 1 --polyAlength 12 --frac-f 0.8 --windowAT 120 -z 1 -s", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(str(work / "scan6" / "BarcodesAssigned.tsv")).read() == open(str(work / "scan4" / "BarcodesAssigned.tsv")).read()
     r = _run(STEP3.replace("passedParsed.bam", "limited.bam") + " -b 0 -u 1", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     _, _, lim = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "limited.bam", "rb").read()))

@@ -35,7 +35,7 @@ def u64(v):
 
 
 def test_fixture_files_describe_their_provenance():
-    for name in ("twobit", "onebyte", "nw", "lev", "polyat", "bcmatch"):
+    for name in ("twobit", "onebyte", "nw", "lev", "polyat", "polyat_params", "bcmatch"):
         d = load(name)
         assert "jvm_exec" in d["how"] and d["bytecode_steps"] > 0
         for s in d["sections"]:
@@ -157,6 +157,34 @@ def test_polyt_finder(sor):
                 assert got == (want["begin"], want["end"]), (read, want, got)
                 n_found += 1
     assert n_found >= 40
+
+
+def test_polyt_finder_other_parameters(sor):
+    """`scanfastq -p / -f / -w`: the oracle's finder with other lengths, fractions and windows == PolyATSearcher executed with the same ones
+    (ref_exec_polyat_params.json: eight parameter sets, the ones the kernels are compared with the oracle on)"""
+    L = sor.lib()
+    n_found, n_none, n_sets = 0, 0, 0
+    for s in load("polyat_params")["sections"]:
+        ml, frac, win = s["polya_len"], s["polya_frac"], s["window_polya"]
+        sub_n = win + ml + 10
+        n_sets += 1
+        for c in s["cases"]:
+            read = c["read"]
+            if len(read) < sub_n:
+                assert all(isinstance(r, dict) and "throws" in r for r in c["forward_and_reverse"])
+                continue
+            fwd = [L.sor_fourbit_encode_char(ord(ch)) for ch in read[:sub_n]]
+            rev = [L.sor_fourbit_encode_char(ord(_COMP[ch])) for ch in reversed(read[-sub_n:])]
+            for codes, want in zip((fwd, rev), c["forward_and_reverse"]):
+                got = sor.find_polyt(np.array(codes, dtype=np.uint8), minlen=ml, minfrac=frac, window=win)
+                if want is None:
+                    assert got is None, (ml, frac, win, read, want, got)
+                    n_none += 1
+                else:
+                    assert got == (want["begin"], want["end"]), (ml, frac, win, read, want, got)
+                    assert want["seq_til_end_len"] == want["end"]
+                    n_found += 1
+    assert n_sets == 8 and n_found >= 250 and n_none >= 40
 
 
 # ---- a-11 -----------------------------------------------------------------------------------------------------------

@@ -470,6 +470,43 @@ def gen_polyat(g):
     out["sections"].append(g.finish(s))
     return out
 
+
+POLYA_PARAM_SETS = ((12, 0.8, 100), (20, 0.7, 140), (15, 0.75, 120), (10, 0.9, 150), (15, 0.6, 150), (18, 0.75, 147), (30, 0.75, 135), (5, 1.0, 60))
+
+
+def gen_polyat_params(g):
+    """a-7 under `scanfastq -p <length> -f <fraction> -w <window>` (NanoporeReadScannerMain.java:L227-234): the finder with other parameters than
+    config.xml's 15 / 0.75 / 150 -- the sets tests/test_scan_gpu.py::test_other_polya_windows_equal_oracle runs the kernels with"""
+    j = g.j
+    rng = random.Random(616)
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
+    for ml, frac, win in POLYA_PARAM_SETS:
+        s = g.section(f"new PolyATSearcher(read, {ml}, {frac}f, {win}).findpolyAT(reverse) (L56-252): polyT in the first window + length + 10 bases (reverse = false) / "
+                      "in the reverse complement of the last ones (reverse = true); result null or (polyTbegin, polyTend, length of seqTilPolyAend)",
+                      PS, "findpolyAT:(Z)L...$PolyAscanResult;")
+        s["polya_len"], s["polya_frac"], s["window_polya"] = ml, frac, win
+        sub_n = win + ml + 10
+        for t in range(36):
+            kind = t % 6
+            tl = rng.randrange(max(4, ml // 2), 4 * ml)
+            run_t = "".join("T" if rng.random() > (0.0, 0.05, 0.12, 0.2, 0.3, 0.1)[kind] else rng.choice("ACG") for _ in range(tl))
+            pre = rnd_seq(rng, rng.randrange(0, max(1, win - 10)) if kind != 5 else rng.randrange(max(1, win - 10), sub_n))
+            body = rnd_seq(rng, rng.randrange(sub_n, 2 * sub_n + 100))
+            tail_a = "".join("A" if rng.random() > 0.08 else rng.choice("CGT") for _ in range(rng.randrange(ml - 3, 4 * ml)))
+            read = pre + run_t + body + (tail_a + rnd_seq(rng, rng.randrange(10, 60)) if kind in (2, 4) else "")
+            res = []
+            for rev in (0, 1):
+                o = j.new(PS, "(Ljava/lang/String;IFI)V", read, ml, f32(frac), win)
+                try:
+                    r = j.call_virtual(o, "findpolyAT", f"(Z)L{PS}$PolyAscanResult;", rev)
+                except JavaThrow as e:
+                    res.append({"throws": e.obj.cls})
+                    continue
+                res.append(None if r is None else {"begin": r.f["polyTbegin"], "end": r.f["polyTend"], "seq_til_end_len": len(r.f["seqTilPolyAend"].f["naData"].a)})
+            s["cases"].append({"read": read, "forward_and_reverse": res})
+        out["sections"].append(g.finish(s))
+    return out
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Whole records through the reference's pass 2: ChimeraFindernew.findSplitPositions -> PolyATadapterAnalyzer_{3p,5p}BCUMI.search
 # -> Parser.assignBarcode -> ReadFlags$Flags.finalizeFlag -> FastqRecordExt.getRecordForWriting, i.e. what Parser.call /
@@ -2710,7 +2747,7 @@ def gen_auxorder(g, seed=2222):
     return out
 
 
-SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat,
+SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
             "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
