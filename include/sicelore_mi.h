@@ -815,6 +815,8 @@ typedef struct {
     int32_t truncate_read_name; /* -w: read name cut at its first '_' (L431-432) */
     int32_t five_prime;         /* -p: which end's clip GeneCounts looks at */
     int32_t n_threads;
+    char gene_tag[4];           /* -g / config.xml gene_name_attribute (UmiFinderMain.java:L239-246): the two-letter attribute GennameTagger writes the gene name
+                                 * under (TagReadBase.TAG; GS and XF stay) and GeneCounts reads it from (OneNanoporeResult.java:L522); "GE" by default */
 } smi_bam_write_config;
 int smi_bam_write_default_config(smi_bam_write_config *cfg);
 typedef struct smi_gene_counts smi_gene_counts;

@@ -279,7 +279,7 @@ def _assign_umis_bam_native(ctx, bam, recs, names, chunk_size, max_dist, bc_edit
 
 # ---- BAM tags (ReadScanResult.writeSamFlags / writeBCSamFlags, ClusterOneBase.setSamflagsAndStatsForClustered,
 #      UmiFinderWorker.lambda$new$0 + $BamWriters.lambda$writeSams$2; tag names: Jar/config.xml:297-492) -------------------------
-def record_tag_sets(scan, umi, u7, gene=None):
+def record_tag_sets(scan, umi, u7, gene=None, gene_tag="GE"):
     """the setAttribute calls the reference makes on one record, in its order: [(tag, value)], value int, str or None (= the tag is removed).
     scan: scan_data_from_name; umi: entry of assign_umis (or None); u7: the read's own post-barcode 12-mer or None; gene: (GE, GS, XF) of
     lib.GeneTagger for this record when an --annotationFile is given.
@@ -323,7 +323,7 @@ def record_tag_sets(scan, umi, u7, gene=None):
     if gene is not None and gene[2] is not None:                 # annotateGene (OneNanoporeSeqAnalyzer L98, GennameTagger.setGeneExons L108-119)
         ge, gs, xf = gene
         c.append(("XF", xf))
-        c += [("GE", ge), ("GS", gs)] if ge is not None and gs is not None else [("GE", None), ("GS", None)]
+        c += [(gene_tag, ge), ("GS", gs)] if ge is not None and gs is not None else [(gene_tag, None), ("GS", None)]
     clustered = umi is not None and not umi.get("skipped")
     if clustered:                                                # ClusterOneBase L145-164
         c += [("U8", umi["U8"]), ("U7", umi["U7"]), ("UC", ""), ("U1", str(umi["U1"]))]
@@ -433,14 +433,14 @@ def _count_columns(rows, five_prime):
                 last_cigar=cols[8], nth_record=cols[9], five_prime=five_prime)
 
 
-def tagged_record(bam, r, name, scan, umi, gene=None, five_prime=False, truncate_read_name=False):
+def tagged_record(bam, r, name, scan, umi, gene=None, five_prime=False, truncate_read_name=False, gene_tag="GE"):
     """one record of the output: (BAM record bytes incl. its block_size word, from clustering?, attribute fields) or None when the read has no
     cell barcode (it is not written).  scan: scan_data_from_name(name); umi: the record's entry of assign_umis / None; gene: (GE, GS, XF) or None"""
     u7 = None
     if scan is not None and scan["bc"] is not None and scan["bc"]["end"] is not None and scan["x"]:
         w = umi_window(scan["x"], scan["ae"], scan["bc"]["end"], five_prime)
         u7 = None if w is None else "".join(_DEC[c] for c in w[1:13])
-    calls, has_bc, clustered = record_tag_sets(scan, umi, u7, gene)
+    calls, has_bc, clustered = record_tag_sets(scan, umi, u7, gene, gene_tag)
     if not has_bc:
         return None
     o = int(r["rec_off"])
@@ -455,12 +455,12 @@ def tagged_record(bam, r, name, scan, umi, gene=None, five_prime=False, truncate
     return np.array([len(body)], dtype="<u4").tobytes() + body, clustered, fields
 
 
-def gene_count_row(bam, r, fields, region, nth):
+def gene_count_row(bam, r, fields, region, nth, gene_tag="GE"):
     """the columns of lib.GeneCounts.add for one written record, or None when it carries no U8 (updateGeneCounts is only called for records
     with the UMI attribute, UmiFinderWorker.java:L453)"""
-    f = {t: raw for t, raw in fields if t in ("GE", "U8", "BC")}
+    f = {t: raw for t, raw in fields if t in (gene_tag, "U8", "BC")}
     z = lambda t: f[t][3:-1].decode() if t in f and f[t][2:3] == b"Z" else None  # noqa: E731
-    ge, u8, bc = z("GE"), z("U8"), z("BC")
+    ge, u8, bc = z(gene_tag), z("U8"), z("BC")
     if u8 is None:
         return None
     cg = bam[int(r["cigar_off"]):int(r["cigar_off"]) + 4 * int(r["n_cigar"])].view("<u4")
@@ -470,7 +470,7 @@ def gene_count_row(bam, r, fields, region, nth):
 
 
 def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device",
-                      gene_counts=None, **kw):
+                      gene_counts=None, gene_tag="GE", **kw):
     """`assignumis` BAM in -> (bcfound BAM bytes, umifound BAM bytes, names, tags): the two BGZF streams the reference writes
     (<out>.bam: every record with a cell barcode; <out>_umifound_.bam: those whose UMI comes from clustering), header copied,
     records of a chunk in coordinate-comparator order with the tags of record_tag_sets added; refflat = text of the --annotationFile
@@ -502,7 +502,7 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
                 seen.add(names[i])
     rows = []                                                   # in write order: UMIcounts.increment does not commute with its nth-record form
     for i in order:
-        res = tagged_record(bam, recs[i], names[i], scans[i], tags[i], None if gene_tags is None else gene_tags[i], five_prime, truncate_read_name)
+        res = tagged_record(bam, recs[i], names[i], scans[i], tags[i], None if gene_tags is None else gene_tags[i], five_prime, truncate_read_name, gene_tag)
         if res is None:
             continue
         rec_bytes, clustered, fields = res
@@ -510,7 +510,7 @@ def write_tagged_bams(ctx, data, chunk_size=250_000, truncate_read_name=False, c
         if clustered:
             out_umi.append(rec_bytes)
         if gene_counts is not None:
-            row = gene_count_row(bam, recs[i], fields, regions.get(i, -1), nth[i])
+            row = gene_count_row(bam, recs[i], fields, regions.get(i, -1), nth[i], gene_tag)
             if row is not None:
                 rows.append(row)
     if gene_counts is not None and rows:
@@ -544,7 +544,7 @@ def chunk_bounds(ref_ids, chunk_size):
 
 
 def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device",
-                             gene_counts=None, max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None):
+                             gene_counts=None, max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, gene_tag="GE"):
     """write_tagged_bams with no per-record work in Python: BGZF inflate + record index (host threads), per BamReader chunk
     smi_bam_chunk_inputs -> smi_assignumis_chunk (device), smi_gene_tag_bam, per written batch smi_bam_write_batch (host threads), BGZF by
     K-DEFLATE.  -> (bcfound BAM, umifound BAM -- numpy uint8 arrays --, info dict).  The same bytes as write_tagged_bams."""
@@ -592,7 +592,7 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         n_clustered += int(((out["flags"][:n_done] & _lib.UMI_CLUSTERED) != 0).sum())
         bc, umi, _order = _lib.bam_write_batch(bam, recs, done, tags, gene=gene, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate_read_name,
                                                five_prime=five_prime, n_threads=n_threads, gene_counts=gene_counts, region=region, nth_record=nth,
-                                               out_bc=buf_bc[at_bc:], out_umi=buf_umi[at_umi:])
+                                               out_bc=buf_bc[at_bc:], out_umi=buf_umi[at_umi:], gene_tag=gene_tag)
         at_bc += bc.size
         at_umi += umi.size
         n_batches += 1
@@ -704,7 +704,8 @@ def plan_shards(extents, world):
 
 
 def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
-                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None, no_clustering=False):
+                      max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None, no_clustering=False,
+                      gene_tag="GE"):
     """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (read and inflated by a thread of their own, one segment ahead), never held as a
     whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
     chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
@@ -912,7 +913,7 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             bound = _lib.bam_write_bound(recs, done)
             bc, umi, _o = _lib.bam_write_batch(bam, recs, done, tags, gene=gene, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate_read_name,
                                                five_prime=five_prime, n_threads=n_threads, gene_counts=gc, region=region, nth_record=nth,
-                                               out_bc=staged("bc", bound), out_umi=staged("umi", bound))
+                                               out_bc=staged("bc", bound), out_umi=staged("umi", bound), gene_tag=gene_tag)
             t4 = time.perf_counter()
             secs["umi_stage"] += t3 - t2
             secs["write_batch"] += t4 - t3

@@ -33,7 +33,7 @@ BUILT_IN = {
     "readscanner/tso_pos_prefix": "T=", "readscanner/seq_prefix": "X=", "readscanner/qv_prefix": "Q=",
     "readscanner/minMeanBCqv": "8", "readscanner/minMeanReadqv": "8", "readscanner/minAdapter3pMatches": "8", "readscanner/minCountFold": "10",
     "readscanner/nbasesOfAdapterSeqInReadname": "3", "readscanner/runningasdemon": "false",
-    "barcodeUMIFinder/gene_name_attribute": "GE", "barcodeUMIFinder/tagGeneNameFunction": "DefaultTagger",
+    "barcodeUMIFinder/tagGeneNameFunction": "DefaultTagger",
     "polyAT/internalpATlength": "15", "polyAT/internalFractionATInPolyAT": "0.70",
     "adapter_for3pBarcoding/sequence": "CTTCCGATCT", "adapter_for3pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
     "adapter_for3pBarcoding/maxNeedlemanMismatches": "3", "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
@@ -51,7 +51,8 @@ BUILT_IN = {
     "umis/umi_length": "12", "umis/umi_completelinkclusteringED": "2", "umis/umi_singlelinkclusteringED": "1",
 }
 RUN_TIME = ("barcodeUMIFinder/sam_records_chunk_size", "barcodes/max_GenomeDistance_forGrouping", "readscanner/fileWithAllPossibleTenXbarcodes",
-            "readscanner/mergeBCsED", "polyAT/polyATlength", "polyAT/fractionATInPolyAT", "polyAT/windowSearchForPolyA")
+            "readscanner/mergeBCsED", "polyAT/polyATlength", "polyAT/fractionATInPolyAT", "polyAT/windowSearchForPolyA",
+            "barcodeUMIFinder/gene_name_attribute")
 
 
 class CliError(Exception):
@@ -164,10 +165,11 @@ UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "o
             # -b: barcodes whose ed in the read name is larger are ignored (UmiFinderMain.java:L181-182, FastqRecordExt.java:L450-456);
             # -u: read by the Illumina-guided UMI analyzer only (IlluminaUMIanalyzer) -- accepted, checked to be a number, without effect here
             "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True), "noclustering": ("s", "noclustering", False),
-            "debug": ("d", "debug", False)}   # (-d: stepwise execution of the reference, UmiFinderMain.java:L178-179: accepted, without effect)
+            "debug": ("d", "debug", False),
+            # -g: the two-letter attribute the gene name is written under and counted from (UmiFinderMain.java:L239-246; config.xml gene_name_attribute)
+            "ONTgene": ("g", "ONTgene", True)}   # (-d: stepwise execution of the reference, UmiFinderMain.java:L178-179: accepted, without effect)
 UMI_REFUSED = {o: why for opts, why in (
     (("-k", "--inFile10x", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
-    (("-g", "--ONTgene"), "the gene name attribute of this build is GE (config.xml gene_name_attribute; UmiFinderMain.java:L239-246)"),
     (("-e", "--randomBarcode", "-f", "--randomUMI"), "random barcodes / UMIs (a specificity experiment of the reference) are not built"),
     )
     for o in opts}
@@ -296,8 +298,24 @@ def assignumis(argv):
         if need not in o:
             raise CliError(f"Missing required option: {UMI_SPEC[need][1]}")
     knobs = read_config(find_config(o.get("config")))
+    gene_tag = knobs.get("barcodeUMIFinder/gene_name_attribute", "GE")
+    if "ONTgene" in o:
+        gene_tag = o["ONTgene"]
+        if len(gene_tag) != 2 or not gene_tag.isalpha() or not gene_tag.isascii():
+            raise CliError("!!!!!!!!   -g option should have two letters !!!!!!!!!!!!")     # (the reference prints its help under this line and exits with 1)
+    elif "annotationFile" in o and (len(gene_tag) != 2 or not gene_tag.isascii() or not gene_tag.isalpha()):
+        raise CliError("Annotation file supplied but gene name attribute undefined or incorrect in config.xml (the reference goes on without genes and gene counts: "
+                       "not built)")
     if not os.path.isfile(o["inFileNanopore"]):
         raise CliError(f"input BAM {o['inFileNanopore']} does not exist")
+    if "annotationFile" in o:
+        st = o["annotationFile"]
+        base = st[:-3] if st.endswith(".gz") else st
+        if not (base.endswith(".gtf") or base.lower().endswith(".refflat")):
+            raise CliError(f"Annotation file name is {st} file name should end with .gtf or .refFlat")       # (UmiFinderMain.java:L255-256)
+        if base.endswith(".gtf"):
+            raise CliError(f"annotation file {st}: a GTF is not read by this build; gtfToGenePred -genePredExt -geneNameAsName2 makes the refFlat "
+                           "(reference README, section IsoformMatrix)")
     if "annotationFile" in o and not os.path.isfile(o["annotationFile"]):
         raise CliError(f"annotation file {o['annotationFile']} does not exist")
     out = o["outfile"]
@@ -322,7 +340,7 @@ def assignumis(argv):
     ncpu = _ncpu(o)
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
                                 refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit,
-                                no_clustering="noclustering" in o)
+                                no_clustering="noclustering" in o, gene_tag=gene_tag)
     if info.get("rank", 0) == 0:       # rank 0 holds the whole run's counts (assignumis_stream gathers them)
         print(f"DONE -- {info['records']} records, {info['clustered']} in UMI clusters")
         bad = int(info.get("gene_keys_order_dependent", 0))

@@ -23,6 +23,8 @@
 #include <unordered_set>
 #include <vector>
 
+#include <cctype>
+
 #include "smi_internal.h"
 
 using namespace smi;
@@ -304,6 +306,8 @@ extern "C" int smi_bam_write_default_config(smi_bam_write_config *cfg) {
     std::memset(cfg, 0, sizeof *cfg);
     cfg->bc_edit_limit = -1;
     cfg->n_threads = 4;
+    cfg->gene_tag[0] = 'G';
+    cfg->gene_tag[1] = 'E';
     return SMI_OK;
 }
 
@@ -314,6 +318,12 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
     if (!bam || !recs || (!batch && n_batch) || !tags || !cfg || !n_bc || !n_umi || n_batch < 0 || (gene && !gene_off) ||
         (gc && (!region || !nth_record))) {
         set_error("smi_bam_write_batch: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    // -g: two letters (UmiFinderMain.java:L241; all zero = a caller that zeroed the structure itself: GE)
+    char gene_tag[3] = {cfg->gene_tag[0] ? cfg->gene_tag[0] : 'G', cfg->gene_tag[0] ? cfg->gene_tag[1] : 'E', 0};
+    if (!std::isalpha((unsigned char)gene_tag[0]) || !std::isalpha((unsigned char)gene_tag[1]) || cfg->gene_tag[2]) {
+        set_error("smi_bam_write_batch: the gene name attribute (-g) should have two letters");
         return SMI_ERR_INVALID;
     }
     for (int32_t k = 0; k < n_batch; k++) {
@@ -405,10 +415,10 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
                 if (xf_n) {
                     at.set(aux_str("XF", xf, xf_n));
                     if (ge_n && gs_n) {
-                        at.set(aux_str("GE", ge, ge_n));
+                        at.set(aux_str(gene_tag, ge, ge_n));
                         at.set(aux_str("GS", gs, gs_n));
                     } else {
-                        at.remove("GE");
+                        at.remove(gene_tag);
                         at.remove("GS");
                     }
                 }
@@ -459,7 +469,7 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
             if (clustered) pc.umi += rec;
             // ---- GeneCounts.updateGeneCounts (L453-454): records that carry U8 now
             if (gc) {
-                const Field *fu = at.find("U8"), *fb = at.find("BC"), *fg = at.find("GE");
+                const Field *fu = at.find("U8"), *fb = at.find("BC"), *fg = at.find(gene_tag);
                 auto z = [](const Field *f, const char **s, size_t *n) {
                     if (!f || f->raw[2] != 'Z') return false;
                     *s = f->raw.data() + 3;

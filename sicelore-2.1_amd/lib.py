@@ -343,7 +343,8 @@ class GeneTagger:
 
 
 class BamWriteConfig(ctypes.Structure):
-    _fields_ = [("bc_edit_limit", ctypes.c_int32), ("truncate_read_name", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("n_threads", ctypes.c_int32)]
+    _fields_ = [("bc_edit_limit", ctypes.c_int32), ("truncate_read_name", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("n_threads", ctypes.c_int32),
+                ("gene_tag", ctypes.c_char * 4)]
 
 
 def bam_write_bound(recs, batch=None):
@@ -353,11 +354,11 @@ def bam_write_bound(recs, batch=None):
 
 
 def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, truncate_read_name=False, five_prime=False, n_threads=4,
-                    gene_counts=None, region=None, nth_record=None, out_bc=None, out_umi=None):
+                    gene_counts=None, region=None, nth_record=None, out_bc=None, out_umi=None, gene_tag="GE"):
     """smi_bam_write_batch: the records `batch` (indices into recs) of an inflated BAM -> (bytes of <out>.bam, bytes of <out>_umifound_.bam,
     write order).  tags: UMI_TAG_DTYPE array indexed like recs; gene: (buffer, offsets) of GeneTagger.tag_bam_raw or None; gene_counts: a
     GeneCounts fed in write order (region int64 / nth_record uint8 indexed like recs).  out_bc / out_umi: uint8 arrays to write into (the
-    returned arrays are views of them)."""
+    returned arrays are views of them).  gene_tag: -g, the attribute the gene name is written under and counted from (two letters)."""
     lib = load_library()
     recs = np.ascontiguousarray(recs)
     batch = np.ascontiguousarray(batch, dtype=np.int32)
@@ -366,6 +367,9 @@ def bam_write_batch(bam, recs, batch, tags, gene=None, bc_edit_limit=None, trunc
     lib.smi_bam_write_default_config(ctypes.byref(cfg))
     cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
     cfg.truncate_read_name, cfg.five_prime, cfg.n_threads = int(bool(truncate_read_name)), int(bool(five_prime)), int(n_threads)
+    if len(gene_tag.encode()) > 3:
+        raise SmiError("smi_bam_write_batch: the gene name attribute (-g) should have two letters")
+    cfg.gene_tag = gene_tag.encode()
     gbuf, goff = (None, None) if gene is None else gene
     if gene_counts is not None:
         region = np.ascontiguousarray(region, dtype=np.int64)

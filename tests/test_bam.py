@@ -260,7 +260,7 @@ def test_attribute_list_equals_htsjdk_executed(pkg):
     assert n > 600 and n_retyped > 40
 
 
-def _write_batch_case(libmod, au, seed, five_prime=False, truncate=False, bc_edit_limit=None):
+def _write_batch_case(libmod, au, seed, five_prime=False, truncate=False, bc_edit_limit=None, gene_tag="GE", carried=()):
     """a BAM of mixed records + synthetic clustering results -> (native bytes, Python-mirror bytes, gene-count texts of both)"""
     import json
     import os
@@ -282,8 +282,11 @@ def _write_batch_case(libmod, au, seed, five_prime=False, truncate=False, bc_edi
         cig = [] if unm else ([("S", int(rng.integers(1, 400)))] if rng.random() < 0.5 else []) + [("M", int(rng.integers(20, 300)))] + \
             ([("H", int(rng.integers(100, 300)))] if rng.random() < 0.3 else [])
         L = sum(ln for op, ln in cig if op in "MIS=X") or 10
-        rows.append((ref, -1 if unm else int(rng.integers(0, 40)), nm, flag, cig, L, aux_pool[int(rng.integers(0, len(aux_pool)))],
-                     int(rng.choice([0, 20, 60]))))
+        aux = aux_pool[int(rng.integers(0, len(aux_pool)))]
+        for t in carried:                  # attributes the input already carries (a gene tag of an earlier tool under GE / under the -g attribute)
+            if rng.random() < 0.5 and t.encode() not in (aux[k2:k2 + 2] for k2 in range(len(aux))):
+                aux += t.encode() + b"Z" + f"OLD{k % 7}".encode() + b"\0"
+        rows.append((ref, -1 if unm else int(rng.integers(0, 40)), nm, flag, cig, L, aux, int(rng.choice([0, 20, 60]))))
     brecs = [bammodel.bam_record(nm, fl, ref, p0, mq, cg, "C" * L, aux=aux) for ref, p0, nm, fl, cg, L, aux, mq in rows]
     header = bammodel.bam_bytes("@HD\tVN:1.6\tSO:unsorted\n", [("chr1", 10 ** 6), ("chr2", 10 ** 6)], [])
     data = bammodel.bgzf_compress(header + b"".join(brecs), block=8192)
@@ -329,17 +332,17 @@ def _write_batch_case(libmod, au, seed, five_prime=False, truncate=False, bc_edi
     batch = rng.permutation(n).astype(np.int32)[: n - 7]                        # a batch is a subset, in whatever order it was collected
     gc1, gc2 = libmod.GeneCounts(), libmod.GeneCounts()
     bc, umi, order = libmod.bam_write_batch(bam, recs, batch, tags, gene=gene_raw, bc_edit_limit=bc_edit_limit, truncate_read_name=truncate,
-                                            five_prime=five_prime, n_threads=3, gene_counts=gc1, region=region, nth_record=nth)
+                                            five_prime=five_prime, n_threads=3, gene_counts=gc1, region=region, nth_record=nth, gene_tag=gene_tag)
     exp_order = sorted(batch.tolist(), key=lambda k: au._coordinate_key(recs[k], names[k]))
     exp_bc, exp_umi, grows = [], [], []
     for i in exp_order:
-        res = au.tagged_record(bam, recs[i], names[i], scans[i], umis[i], gene_list[i], five_prime, truncate)
+        res = au.tagged_record(bam, recs[i], names[i], scans[i], umis[i], gene_list[i], five_prime, truncate, gene_tag)
         if res is None:
             continue
         exp_bc.append(res[0])
         if res[1]:
             exp_umi.append(res[0])
-        row = au.gene_count_row(bam, recs[i], res[2], int(region[i]), int(nth[i]))
+        row = au.gene_count_row(bam, recs[i], res[2], int(region[i]), int(nth[i]), gene_tag)
         if row is not None:
             grows.append(row)
     if grows:
@@ -362,6 +365,25 @@ def test_native_batch_writer_equals_the_python_mirror(pkg, five_prime, truncate,
         bc, exp_bc, umi, exp_umi, g1, g2 = _write_batch_case(libmod, au, seed, five_prime, truncate, limit)
         assert bc == exp_bc and umi == exp_umi and len(bc) > 50_000 and 0 < len(umi) < len(bc)
         assert g1 == g2 and g1[2]["gene_entries"] > 5 and g1[2]["records_skipped_clipping"] > 0
+
+
+def test_gene_attribute_other_than_ge(pkg):
+    """`assignumis -g XG` (UmiFinderMain.java:L239-246 -> TagReadBase.TAG, OneNanoporeResult.java:L522): the gene name goes under XG and is counted from XG; GS and XF
+    stay; a GE the input carries is neither touched nor counted.  Native writer == Python mirror, and against the default run only the tag differs."""
+    import importlib
+
+    from sicelore_amd import lib as libmod
+
+    au = importlib.import_module("sicelore_amd.assignumis")
+    bc, exp_bc, umi, exp_umi, g1, g2 = _write_batch_case(libmod, au, 5, gene_tag="XG", carried=("GE", "XG"))
+    assert bc == exp_bc and umi == exp_umi and g1 == g2 and g1[2]["gene_entries"] > 5
+    assert b"XGZG" in bc and b"GEZOLD" in bc and b"GEZG" not in bc and b"XGZOLD" in bc      # (XGZOLD: records without an XF keep what they carried)
+    d_bc, d_exp, _u, _ue, d1, d2 = _write_batch_case(libmod, au, 5, carried=("GE", "XG"))
+    assert d_bc == d_exp and d1 == d2 and b"GEZG" in d_bc and b"XGZOLD" in d_bc
+    assert len(d_bc) != 0 and g1[0] != "" and sorted(g1[0].split("\n")[0].split("\t")) == sorted(d1[0].split("\n")[0].split("\t"))
+    for bad in ("G", "G1", "GEN"):
+        with pytest.raises(libmod.SmiError, match="two letters"):
+            _write_batch_case(libmod, au, 5, gene_tag=bad)
 
 
 def test_chunk_bounds_equal_the_reader_loop(pkg):

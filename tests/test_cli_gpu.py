@@ -39,6 +39,7 @@ def test_cli_refuses_what_it_does_not_implement(tmp_path):
                         ("$java -jar x.jar scanfastq -d in -o out --bcEditDistance 1 --frobnicate", "unknown option"),
                         ("$java -jar x.jar scanfastq -d nowhere -o out --bcEditDistance 1", "does not exist"),
                         ("$java -jar x.jar assignumis -o out.bam", "inFileNanopore"),
+                        ("$java -jar x.jar assignumis -i in/x.bam -o out.bam -g G1", "two letters"),
                         ("$java -jar x.jar tagbamwithread --inBam a.bam", "sub-command")):
         r = _run(cmd, env, str(tmp_path))
         assert r.returncode == 1 and needle in r.stderr, (cmd, r.returncode, r.stderr[-300:])
@@ -171,6 +172,17 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan6 --bcEditDistance 1 --polyAlength 12 --frac-f 0.8 --windowAT 120 -z 1 -s", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     assert open(str(work / "scan6" / "BarcodesAssigned.tsv")).read() == open(str(work / "scan4" / "BarcodesAssigned.tsv")).read()
+    # -g XG: the gene name under another attribute; the tables are the default run's
+    r = _run(STEP3.replace("passedParsed.bam", "xg.bam") + " -g XG", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, _, xg = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "xg.bam", "rb").read()))
+    assert len(xg) == len(out)
+    for a_, b_ in zip(xg, out):
+        ta, tb = {t: v for t, _ty, v in _parse_aux(a_["aux"])}, {t: v for t, _ty, v in _parse_aux(b_["aux"])}
+        assert "GE" not in ta and ta.get("XG") == tb.get("GE") and {t: v for t, v in ta.items() if t != "XG"} == {t: v for t, v in tb.items() if t != "GE"}
+    assert open(umidir + "xg.genecounts.tsv").read() == open(umidir + "passedParsed.genecounts.tsv").read()
+    r = _run(STEP3.replace("passedParsed.bam", "bad.bam") + " -g G1", env, str(work))
+    assert r.returncode == 1 and "two letters" in r.stderr
     r = _run(STEP3.replace("passedParsed.bam", "limited.bam") + " -b 0 -u 1", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     _, _, lim = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "limited.bam", "rb").read()))

@@ -223,6 +223,39 @@ def check_bam_writer(pkg, synth, sor, ctx, seed):
     return bc == exp_bc and umi == exp_umi and g1 == g2, f"bam_writer seed={seed} five_prime={five} -w={trunc} -b={lim} bytes={len(bc)}"
 
 
+def check_scan_params(pkg, synth, sor, ctx, seed):
+    """round 5: K-SCAN with a random polyA window of `scanfastq -p / -f / -w` (smi_ctx_set_polya's range: 5 <= length <= 30, window + length + 10 <= 175)
+    against the oracle with the same parameters, on ordinary reads (both passes) and on ends crowded with T / A runs"""
+    from test_scan_gpu import AD, _ascii_batch, _compare, _scan_gpu, _t_rich_reads
+
+    rng = np.random.default_rng(seed)
+    ml = int(rng.integers(5, 31))
+    win = int(rng.integers(20, 175 - ml - 10 + 1))
+    frac = float(rng.choice([0.5, 0.6, 0.7, 0.75, 0.8, 0.9, 1.0, round(float(rng.uniform(0.4, 1.0)), 3)]))
+    polya = (ml, frac, win)
+    par = sor.default_scan_params()
+    par["polya_len"], par["polya_frac"], par["window_polya"] = polya
+    wl = synth.make_whitelist(20_000, seed=seed)
+    used = synth.pick_used(wl, 200, seed=seed + 1)
+    n = 2000
+    reads = synth.gen_reads(n, used, seed=seed + 2, n_rate=float(rng.choice([0.0, 0.003])), err=float(rng.choice([0.03, 0.063, 0.1])))
+    ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
+    found = 0
+    try:
+        for pass_no in (2, 1):
+            got, _, _, _ = _scan_gpu(pkg, ctx, ra, qa, offs, pass_no, polya=polya)
+            st, exp = sor.scan_batch_3p(ra, qa, offs, AD[pass_no], params=par, n_threads=16)
+            found += _compare(got, st, exp, pass1=True)
+        ra, qa, offs = _t_rich_reads(3000, seed=seed + 3)
+        got, _, _, _ = _scan_gpu(pkg, ctx, ra, qa, offs, 2, polya=polya)
+        st, exp = sor.scan_batch_3p(ra, qa, offs, AD[2], params=par, n_threads=16)
+        _compare(got, st, exp, pass1=True)
+        ok = True
+    except AssertionError as e:
+        return False, f"scan_params seed={seed} polya={polya}: {e}"
+    return ok, f"scan_params seed={seed} polya={polya} found={found}"
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     pkg = graft.load_package()
@@ -236,7 +269,8 @@ def main():
         for leg in ([check_bc, check_records] if os.environ.get("SMI_FUZZ_LEGS") == "r2" else [check_packed, check_umi_stage, check_deflate, check_inflate]
                     if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_host_inflate, check_bam_writer] if os.environ.get("SMI_FUZZ_LEGS") == "host"
                     else [check_umi_pairs, check_umi_stage] if os.environ.get("SMI_FUZZ_LEGS") == "umi"
-                    else [check_umi_pairs, check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate, check_host_inflate, check_bam_writer]):
+                    else [check_scan_params] if os.environ.get("SMI_FUZZ_LEGS") == "scan"
+                    else [check_umi_pairs, check_scan_params, check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate, check_host_inflate, check_bam_writer]):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
             print(("ok   " if ok else "FAIL ") + msg, flush=True)
             if not ok:
