@@ -785,8 +785,18 @@ int smi_bam_index_records(const uint8_t *bam, size_t n, uint64_t start, smi_bam_
  * strand of an earlier one) are dropped, the "earlier" one being decided in the JDK's HashMap<String> iteration order like there. */
 typedef struct smi_genes smi_genes;
 int smi_genes_load_refflat(const char *text, size_t n_bytes, const char *const *ref_names, int n_refs, smi_genes **out);
+/* smi_genes_load_gtf: the same from a GTF annotation (README.md:727; GeneAnnotationReader.loadAnnotationsFile picks by the file name): DropseqLib's GTFReader /
+ * GTFParser / GeneFromGTFBuilder -- genes by gene_name (records of the highest gene_version), a gene's extent = the extent of all its records, transcripts by
+ * transcript_id from their exon / CDS features, kept by transcript_name; a line the reference's STRICT parser rejects (no gene_id / gene_name, no
+ * transcript_name / transcript_id on a feature that is not `gene`, ',' in a gene name, an attribute without a value) is an error here as it ends the run
+ * there; genes the LENIENT reader skips (strand / chromosome / gene_id disagreement, a `gene` feature of another extent, a transcript without exons, a
+ * transcript name twice, empty or overlapping exons, no transcript) are skipped.  Multi-gene values follow GeneFromGTF.hashCode. */
+int smi_genes_load_gtf(const char *text, size_t n_bytes, const char *const *ref_names, int n_refs, smi_genes **out);
 int smi_genes_free(smi_genes *g);
 int smi_genes_count(const smi_genes *g, size_t *n_genes, size_t *n_lines, size_t *n_skipped);
+/* the loaded model as text, a line per gene in the order the reference adds them to the OverlapDetector: name, contig, start, end (1-based, inclusive), strand,
+ * then its transcripts in the order Gene.iterator() walks them, `name|txStart|txEnd|cdsStart|cdsEnd|exonStart-exonEnd,...` joined by ';' (out == NULL: size only) */
+int smi_genes_dump(const smi_genes *g, char *out, size_t cap, size_t *n_out);
 /* n records (BAM fields: reference index, FLAG, 0-based POS, CIGAR operations `len << 4 | op` of record i at cigars[cigar_off[i] ..
  * cigar_off[i + 1])).  Output: three strings per record, GE, GS, XF, back to back in `out`; string k of record i is
  * out[out_off[3 i + k] .. out_off[3 i + k + 1]) (out_off: 3 n + 1 entries).  Empty GE = the reference sets GE and GS to null (removes them);

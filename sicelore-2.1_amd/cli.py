@@ -313,9 +313,6 @@ def assignumis(argv):
         base = st[:-3] if st.endswith(".gz") else st
         if not (base.endswith(".gtf") or base.lower().endswith(".refflat")):
             raise CliError(f"Annotation file name is {st} file name should end with .gtf or .refFlat")       # (UmiFinderMain.java:L255-256)
-        if base.endswith(".gtf"):
-            raise CliError(f"annotation file {st}: a GTF is not read by this build; gtfToGenePred -genePredExt -geneNameAsName2 makes the refFlat "
-                           "(reference README, section IsoformMatrix)")
     if "annotationFile" in o and not os.path.isfile(o["annotationFile"]):
         raise CliError(f"annotation file {o['annotationFile']} does not exist")
     out = o["outfile"]
@@ -327,6 +324,9 @@ def assignumis(argv):
     if "annotationFile" in o:          # refFlat text, gz or plain (picard's RefFlatReader through IOUtil)
         with (gzip.open if o["annotationFile"].endswith(".gz") else open)(o["annotationFile"], "rt") as f:
             refflat = f.read()
+        if (o["annotationFile"][:-3] if o["annotationFile"].endswith(".gz") else o["annotationFile"]).endswith(".gtf"):
+            from . import lib as _l
+            refflat = _l.GtfText(refflat)          # GeneAnnotationReader.loadAnnotationsFile L50-51: the GTF reader by the file's name
     bc_limit = None
     for name in ("bcedit", "umiedit"):
         if name in o:

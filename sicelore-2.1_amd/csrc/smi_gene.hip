@@ -104,6 +104,26 @@ static bool same_gene(const Gene &a, const Gene &b) {  // Gene.equals = compareT
     return a.contig == b.contig && a.start == b.start && a.end == b.end && a.negative == b.negative;
 }
 
+// the loaders' common end: the genes of a contig in the IntervalTree's in-order walk; a map the JDK would have treeified is refused
+static int finish_genes(smi_genes *G, int n_refs, const char *who, smi_genes **out) {
+    G->by_contig.assign((size_t)n_refs, {});
+    for (size_t i = 0; i < G->genes.size(); i++) G->by_contig[(size_t)G->genes[i].contig].push_back((int)i);
+    for (auto &v : G->by_contig)
+        std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
+            const Gene &x = G->genes[(size_t)a], &y = G->genes[(size_t)b];
+            return x.start != y.start ? x.start < y.start : x.end < y.end;
+        });
+    if (g_jhash_unmodelled) {
+        g_jhash_unmodelled = false;
+        delete G;
+        set_error(std::string(who) + ": a java.util.HashMap bin of the reference would hold 8 or more entries here (gene names / transcript names with "
+                  "colliding hashes): its iteration order is a tree's, which this library does not model");
+        return SMI_ERR_INVALID;
+    }
+    *out = G;
+    return SMI_OK;
+}
+
 extern "C" int smi_genes_load_refflat(const char *text, size_t n_bytes, const char *const *ref_names, int n_refs, smi_genes **out) {
     if (!out || (!text && n_bytes) || (n_refs && !ref_names) || n_refs < 0) {
         set_error("smi_genes_load_refflat: null argument");
@@ -287,22 +307,265 @@ extern "C" int smi_genes_load_refflat(const char *text, size_t n_bytes, const ch
         }
         G->genes.push_back(std::move(g));
     }
-    G->by_contig.assign((size_t)n_refs, {});
-    for (size_t i = 0; i < G->genes.size(); i++) G->by_contig[(size_t)G->genes[i].contig].push_back((int)i);
-    for (auto &v : G->by_contig)
-        std::stable_sort(v.begin(), v.end(), [&](int a, int b) {
-            const Gene &x = G->genes[(size_t)a], &y = G->genes[(size_t)b];
-            return x.start != y.start ? x.start < y.start : x.end < y.end;
-        });
-    if (g_jhash_unmodelled) {
-        g_jhash_unmodelled = false;
-        delete G;
-        set_error("smi_genes_load_refflat: a java.util.HashMap bin of the reference would hold 8 or more entries here (gene names / transcript names with "
-                  "colliding hashes): its iteration order is a tree's, which this library does not model");
+    return finish_genes(G, n_refs, "smi_genes_load_refflat", out);
+}
+
+// ---- the same model from a GTF (README.md:727 "path to refflat or GTF file"; GeneAnnotationReader.loadAnnotationsFile L46-55 picks by the file name) ----
+//   GTFReader.load / $FilteringGTFParser        DropseqLib-1.0.jar!/org/broadinstitute/dropseqrna/annotation/GTFReader.java:L78-134
+//   GTFParser.next / parseLine                  .../GTFParser.java:L83-137   (STRICT: an invalid line is an AnnotationException nobody catches)
+//   GTFRecord.validate                          .../GTFRecord.java:L146-158
+//   AnnotationUtils.parseOptionalFields         .../AnnotationUtils.java:L376-389
+//   GeneFromGTFBuilder                          .../GeneFromGTFBuilder.java:L47-222 (genes by gene_name, highest gene_version, transcripts by transcript_id)
+//   GeneFromGTF.addTranscript / equals / hashCode  .../GeneFromGTF.java:L81-113
+// What differs from the refFlat model downstream: a gene's extent is the extent of ALL its records (not of its transcripts), transcripts are kept by
+// transcript_name in the gene's own HashMap, and GeneFromGTF.hashCode = 31 * Interval.hashCode + name.hashCode with equals over start, end, name,
+// contig and gene_id -- so two genes of one interval and strand both stay, and the order of a multi-gene value follows the other hash.
+namespace {
+
+bool java_parse_int(const std::string &s, int *v) {  // Integer.parseInt: optional sign, decimal digits, int range
+    size_t i = 0;
+    bool neg = false;
+    if (!s.empty() && (s[0] == '-' || s[0] == '+')) {
+        neg = s[0] == '-';
+        i = 1;
+    }
+    if (i >= s.size()) return false;
+    long long x = 0;
+    for (; i < s.size(); i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        x = x * 10 + (s[i] - '0');
+        if (x > 2147483648ll) return false;
+    }
+    if (neg) x = -x;
+    if (x > 2147483647ll || x < -2147483648ll) return false;
+    *v = (int)x;
+    return true;
+}
+
+// String.split(one literal character): the pieces, trailing empty strings dropped (a string without the character is one piece, even if empty)
+std::vector<std::string> java_split(const std::string &s, char c) {
+    std::vector<std::string> parts;
+    size_t a = 0;
+    for (;;) {
+        const size_t t = s.find(c, a);
+        if (t == std::string::npos) {
+            parts.push_back(s.substr(a));
+            break;
+        }
+        parts.push_back(s.substr(a, t - a));
+        a = t + 1;
+    }
+    if (parts.size() > 1)
+        while (!parts.empty() && parts.back().empty()) parts.pop_back();
+    return parts;
+}
+
+struct GtfRecord {
+    std::string chrom, feature, gene_id, gene_name, tx_name, tx_id;
+    bool has_gene_id = false, has_gene_name = false, has_tx_name = false, has_tx_id = false, has_version = false;
+    int start = 0, end = 0, version = 0;
+    bool negative = false;
+};
+
+}  // namespace
+
+extern "C" int smi_genes_load_gtf(const char *text, size_t n_bytes, const char *const *ref_names, int n_refs, smi_genes **out) {
+    if (!out || (!text && n_bytes) || (n_refs && !ref_names) || n_refs < 0) {
+        set_error("smi_genes_load_gtf: null argument");
         return SMI_ERR_INVALID;
     }
-    *out = G;
-    return SMI_OK;
+    *out = nullptr;
+    smi_genes *G = new smi_genes();
+    std::unordered_map<std::string, int> ref_index;
+    for (int i = 0; i < n_refs; i++) {
+        G->refs.emplace_back(ref_names[i]);
+        G->ref_hash.push_back(jstring_hash(G->refs.back()));
+        ref_index.emplace(G->refs.back(), i);
+    }
+    auto fail = [&](const std::string &why) {
+        delete G;
+        set_error("smi_genes_load_gtf: " + why);
+        return SMI_ERR_INVALID;
+    };
+    // ---- the records, gathered by gene name in file order (gatherByGeneName L208: a HashMap<String, List<GTFRecord>>)
+    std::vector<std::string> names;
+    std::unordered_map<std::string, size_t> slot;
+    std::vector<std::vector<GtfRecord>> rows;
+    size_t p = 0, line_no = 0;
+    while (p < n_bytes) {
+        size_t e = p;
+        while (e < n_bytes && text[e] != '\n') e++;
+        size_t le = e;
+        if (le > p && text[le - 1] == '\r') le--;
+        const std::string line(text + p, le - p);
+        p = e + 1;
+        line_no++;
+        if (line.empty() || line[0] == '#') continue;  // BasicInputParser: blank lines and comment lines are skipped
+        std::vector<std::string> f;
+        {
+            size_t a = 0;
+            for (;;) {
+                const size_t t = line.find('\t', a);
+                if (t == std::string::npos) {
+                    f.push_back(line.substr(a));
+                    break;
+                }
+                f.push_back(line.substr(a, t - a));
+                a = t + 1;
+            }
+        }
+        const std::string at = " at line " + std::to_string(line_no);
+        if (f.size() != 9) return fail("wrong number of fields in the GTF text" + at + " (AnnotationException, GTFParser.java:L84-86)");
+        G->n_lines++;
+        GtfRecord r;
+        // AnnotationUtils.parseOptionalFields: split(";"), quotes removed, trimmed, empty pieces skipped, split(" "): key = piece 0, value = piece 1
+        for (std::string piece : java_split(f[8], ';')) {
+            piece.erase(std::remove(piece.begin(), piece.end(), '"'), piece.end());
+            size_t a = 0, b = piece.size();
+            while (a < b && (unsigned char)piece[a] <= ' ') a++;  // String.trim
+            while (b > a && (unsigned char)piece[b - 1] <= ' ') b--;
+            piece = piece.substr(a, b - a);
+            if (piece.empty()) continue;
+            const std::vector<std::string> z = java_split(piece, ' ');
+            if (z.size() < 2) return fail("attribute '" + piece + "' without a value" + at + " (ArrayIndexOutOfBoundsException in AnnotationUtils.parseOptionalFields L386)");
+            const std::string &k = z[0], &v = z[1];
+            if (k == "gene_name") r.gene_name = v, r.has_gene_name = true;
+            else if (k == "gene_id") r.gene_id = v, r.has_gene_id = true;
+            else if (k == "transcript_name") r.tx_name = v, r.has_tx_name = true;
+            else if (k == "transcript_id") r.tx_id = v, r.has_tx_id = true;
+            else if (k == "gene_version") {
+                if (!java_parse_int(v, &r.version)) return fail("gene_version '" + v + "' is not a number" + at + " (NumberFormatException, GTFParser.java:L130)");
+                r.has_version = true;
+            }
+        }
+        r.chrom = f[0];
+        r.feature = f[2];
+        if (!java_parse_int(f[3], &r.start) || !java_parse_int(f[4], &r.end))
+            return fail("start / end is not a number" + at + " (NumberFormatException, GTFParser.java:L117-118)");
+        r.negative = f[6] == "-";
+        // GTFRecord.validate under ValidationStringency.STRICT ($FilteringGTFParser L121): the AnnotationException leaves GTFReader.load uncaught
+        std::string problems;
+        if (!r.has_gene_id) problems += " Missing gene_id;";
+        if (!r.has_gene_name) problems += " Missing gene_name;";
+        if (r.feature != "gene") {
+            if (!r.has_tx_name) problems += " Missing transcript_name;";
+            if (!r.has_tx_id) problems += " Missing transcript_id;";
+        }
+        if (r.has_gene_name && r.gene_name.find(',') != std::string::npos) problems += " Reserved character ',' in gene name [" + r.gene_name + "];";
+        if (!problems.empty()) return fail("Invalid GTF line" + at + ":" + problems + " (the reference stops here: GTFParser.java:L90-97)");
+        if (!ref_index.count(r.chrom)) {  // $FilteringGTFParser.filterOut L126-131: behind the validation
+            G->n_skipped_sequence++;
+            continue;
+        }
+        auto it = slot.find(r.gene_name);
+        if (it == slot.end()) {
+            slot.emplace(r.gene_name, names.size());
+            names.push_back(r.gene_name);
+            rows.emplace_back();
+            rows.back().push_back(std::move(r));
+        } else
+            rows[it->second].push_back(std::move(r));
+    }
+    std::vector<int32_t> hs(names.size());
+    for (size_t i = 0; i < names.size(); i++) hs[i] = jstring_hash(names[i]);
+    for (size_t gi : jhash_order(hs)) {  // gatheredByGene.values().iterator() L49
+        // makeGeneFromMultiVersionGTFRecords L72-76: the records of the highest gene_version (none = Integer.MIN_VALUE), in file order
+        long long top = -2147483648ll;
+        for (const GtfRecord &r : rows[gi]) top = std::max(top, r.has_version ? (long long)r.version : -2147483648ll);
+        std::vector<const GtfRecord *> R;
+        for (const GtfRecord &r : rows[gi])
+            if ((r.has_version ? (long long)r.version : -2147483648ll) == top) R.push_back(&r);
+        // makeGeneFromGTFRecords L99-128; every AnnotationException from here on is caught by GTFReader.load L96-100 (LENIENT): the gene is skipped
+        const GtfRecord &one = *R[0];
+        Gene g;
+        g.name = one.gene_name;
+        g.negative = one.negative;
+        g.contig = ref_index[one.chrom];
+        int st = 2147483647, en = -2147483647 - 1;
+        bool ok = true;
+        std::vector<std::string> gene_ids;
+        for (const GtfRecord *r : R) {
+            st = std::min(st, r->start);
+            en = std::max(en, r->end);
+            if (std::find(gene_ids.begin(), gene_ids.end(), r->gene_id) == gene_ids.end()) gene_ids.push_back(r->gene_id);
+            if (r->chrom != one.chrom) ok = false;  // "Chromosome disagreement" L116-117
+        }
+        g.start = st;
+        g.end = en;
+        for (const GtfRecord *r : R) {  // validateGTFRecord L195-204
+            if (r->negative != g.negative) ok = false;                                     // "Strand disagreement"
+            if (r->feature == "gene" && (r->start != g.start || r->end != g.end)) ok = false;  // "gene GTFRecord(..) != GeneFromGTF(..)"
+        }
+        if (gene_ids.size() > 1) ok = false;  // "Multiple gene IDs" L125-126
+        // transcripts: the records that are not `gene` features by transcript_id (a HashMap<String, List>: L84, L217), its entries in hash order
+        std::vector<std::string> tids;
+        std::vector<std::vector<const GtfRecord *>> trecs;
+        if (ok)
+            for (const GtfRecord *r : R) {
+                if (r->feature == "gene") continue;  // $GeneAnnotationFilter L250
+                size_t k = 0;
+                while (k < tids.size() && tids[k] != r->tx_id) k++;
+                if (k == tids.size()) {
+                    tids.push_back(r->tx_id);
+                    trecs.emplace_back();
+                }
+                trecs[k].push_back(r);
+            }
+        std::vector<std::string> tnames;
+        std::vector<Transcript> txs;
+        if (ok) {
+            std::vector<int32_t> ih(tids.size());
+            for (size_t i = 0; i < tids.size(); i++) ih[i] = jstring_hash(tids[i]);
+            for (size_t k : jhash_order(ih)) {  // addTranscriptToGeneFromGTFRecords L137-188
+                const std::vector<const GtfRecord *> &T = trecs[k];
+                Transcript t;
+                t.name = T[0]->tx_name;
+                int ts = 2147483647, te = -2147483647 - 1, cs = 2147483647, ce = -2147483647 - 1;
+                for (const GtfRecord *r : T) {
+                    if (r->feature == "exon") {
+                        t.exons.emplace_back(r->start, r->end);
+                        ts = std::min(ts, r->start);
+                        te = std::max(te, r->end);
+                    }
+                    if (r->feature == "CDS") {
+                        cs = std::min(cs, r->start);
+                        ce = std::max(ce, r->end);
+                    }
+                }
+                std::stable_sort(t.exons.begin(), t.exons.end());  // Collections.sort over $Exon.compareTo (start, then end)
+                if (t.exons.empty()) {                             // "<gene>:<transcript> has no exons" L170-171
+                    ok = false;
+                    break;
+                }
+                t.tx_start = ts;
+                t.tx_end = te;
+                t.cds_start = cs == 2147483647 ? ts : cs;
+                t.cds_end = ce == -2147483647 - 1 ? te : ce;
+                if (std::find(tnames.begin(), tnames.end(), t.name) != tnames.end()) {  // GeneFromGTF.addTranscript L81-82: "appears more than once"
+                    ok = false;
+                    break;
+                }
+                for (size_t i = 0; i < t.exons.size(); i++)
+                    if (t.exons[i].first > t.exons[i].second || (i > 0 && t.exons[i - 1].second >= t.exons[i].first)) ok = false;  // L180-183
+                if (!ok) break;
+                tnames.push_back(t.name);
+                txs.push_back(std::move(t));
+            }
+        }
+        if (ok && txs.empty()) ok = false;  // "No transcript in GTF for gene" L92-93
+        if (!ok) {
+            G->n_skipped_genes++;
+            continue;
+        }
+        // GeneFromGTF.iterator() = its own transcripts.values() (a HashMap<String, TranscriptFromGTF> by transcript name, filled in the order above)
+        std::vector<int32_t> th(tnames.size());
+        for (size_t i = 0; i < tnames.size(); i++) th[i] = jstring_hash(tnames[i]);
+        for (size_t k : jhash_order(th)) g.tx.push_back(std::move(txs[k]));
+        const uint32_t ih = 31u * (31u * (uint32_t)G->ref_hash[(size_t)g.contig] + (uint32_t)g.start) + (uint32_t)g.end;
+        g.hash = (int32_t)(31u * ih + (uint32_t)jstring_hash(g.name));  // GeneFromGTF.hashCode L109-113
+        G->genes.push_back(std::move(g));  // (GeneFromGTF.equals includes the name, and the names are distinct: nothing disappears in the OverlapDetector)
+    }
+    return finish_genes(G, n_refs, "smi_genes_load_gtf", out);
 }
 
 extern "C" int smi_genes_free(smi_genes *g) {
@@ -318,6 +581,32 @@ extern "C" int smi_genes_count(const smi_genes *g, size_t *n_genes, size_t *n_li
     if (n_genes) *n_genes = g->genes.size();
     if (n_lines) *n_lines = g->n_lines;
     if (n_skipped) *n_skipped = g->n_skipped_genes + g->n_skipped_sequence;
+    return SMI_OK;
+}
+
+extern "C" int smi_genes_dump(const smi_genes *g, char *out, size_t cap, size_t *n_out) {
+    if (!g || !n_out) {
+        set_error("smi_genes_dump: null argument");
+        return SMI_ERR_INVALID;
+    }
+    std::string txt;
+    for (const Gene &x : g->genes) {
+        txt += x.name + "\t" + g->refs[(size_t)x.contig] + "\t" + std::to_string(x.start) + "\t" + std::to_string(x.end) + "\t" + (x.negative ? "-" : "+") + "\t";
+        for (size_t k = 0; k < x.tx.size(); k++) {
+            const Transcript &t = x.tx[k];
+            txt += (k ? ";" : "") + t.name + "|" + std::to_string(t.tx_start) + "|" + std::to_string(t.tx_end) + "|" + std::to_string(t.cds_start) + "|" +
+                   std::to_string(t.cds_end) + "|";
+            for (size_t i = 0; i < t.exons.size(); i++) txt += (i ? "," : "") + std::to_string(t.exons[i].first) + "-" + std::to_string(t.exons[i].second);
+        }
+        txt += "\n";
+    }
+    *n_out = txt.size();
+    if (!out) return SMI_OK;
+    if (cap < txt.size()) {
+        set_error("smi_genes_dump: output buffer too small");
+        return SMI_ERR_INVALID;
+    }
+    std::memcpy(out, txt.data(), txt.size());
     return SMI_OK;
 }
 

@@ -53,7 +53,7 @@ EXPORTS = [
     "smi_split_offsets_device", "smi_chimera_fragment_name", "smi_umi_cluster_default_config", "smi_umi_cluster_groups",
     "smi_region_group", "smi_ref_position_at_read_position", "smi_scan_default_config_5p", "smi_chimera_default_config_5p", "smi_fastq_index_device", "smi_fastq_gather_device",
     "smi_fastq_write_device", "smi_bgzf_uncompressed_size", "smi_bgzf_inflate", "smi_bam_header", "smi_bam_index_records", "smi_gz_inflate", "smi_bgzf_deflate", "smi_pass2_default_config", "smi_scanfastq_pass2_chunk", "smi_scanfastq_pass1_chunk", "smi_host_alloc", "smi_host_free", "smi_assignumis_default_config", "smi_assignumis_chunk", "smi_bc_counts_device", "smi_assigned_tsv", "smi_barcode_list_tsv", "smi_hist_allreduce", "smi_hist_allreduce_after", "smi_hist_allreduce_release", "smi_ctx_create_lane", "smi_ctx_lane_refresh", "smi_scan_batch", "smi_umi_dist_batch",
-    "smi_genes_load_refflat", "smi_genes_free", "smi_genes_count", "smi_gene_tag_chunk", "smi_gene_tag_bam",
+    "smi_genes_load_refflat", "smi_genes_load_gtf", "smi_genes_free", "smi_genes_count", "smi_genes_dump", "smi_gene_tag_chunk", "smi_gene_tag_bam",
     "smi_pack_reads_text_device", "smi_pack_ends_text_device", "smi_frag_text_starts_device", "smi_fastq_write_text_device",
     "smi_fastq_index_host", "smi_pack_reads_host", "smi_pack_quals_host", "smi_scanfastq_pass2_packed", "smi_fastq_write_host",
     "smi_scanfastq_pass2_chunk_packed", "smi_scanfastq_pass1_chunk_packed", "smi_ends_from_planes_device",
@@ -183,8 +183,10 @@ def load_library():
     lib.smi_scan_batch.argtypes = [vp, vp, vp, vp, sz, vp, vp, vp]
     lib.smi_umi_dist_batch.argtypes = [vp, vp, vp, ctypes.c_uint32, vp]
     lib.smi_genes_load_refflat.argtypes = [vp, sz, vp, ci, vp]
+    lib.smi_genes_load_gtf.argtypes = [vp, sz, vp, ci, vp]
     lib.smi_genes_free.argtypes = [vp]
     lib.smi_genes_count.argtypes = [vp, vp, vp, vp]
+    lib.smi_genes_dump.argtypes = [vp, vp, sz, ctypes.POINTER(sz)]
     lib.smi_gene_tag_chunk.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_gene_tag_bam.argtypes = [vp, vp, sz, vp, ctypes.c_int32, vp, sz, vp, ctypes.POINTER(sz)]
     lib.smi_barcode_list_tsv.argtypes = [vp, vp, sz, ctypes.c_uint32, ci, ci, ci, ci, vp, sz, ctypes.POINTER(sz)]
@@ -263,9 +265,15 @@ def barcode_list_tsv(keys, counts, record_count, merge_ed=1, min_count_fold=10, 
     return out.raw[:n.value].decode()
 
 
+class GtfText(str):
+    """the text of a GTF annotation, where the `refflat=` arguments of assignumis.py / GeneTagger take the text of a refFlat file (the reference picks
+    the reader by the file's name: GeneAnnotationReader.loadAnnotationsFile L46-55)"""
+
+
 class GeneTagger:
-    """The --annotationFile of assignumis: refFlat genes on the BAM header's reference sequences (smi_genes_load_refflat), and the GE / GS /
-    XF values of records (smi_gene_tag_chunk) = GennameTagger.annotateGene (FJ!umifinder/bamreaders/GennameTagger.java:L73-121, L382)."""
+    """The --annotationFile of assignumis: refFlat (or GTF: a GtfText) genes on the BAM header's reference sequences (smi_genes_load_refflat /
+    smi_genes_load_gtf), and the GE / GS / XF values of records (smi_gene_tag_chunk) = GennameTagger.annotateGene
+    (FJ!umifinder/bamreaders/GennameTagger.java:L73-121, L382)."""
 
     CIGAR_OPS = "MIDNSHP=X"
 
@@ -275,12 +283,34 @@ class GeneTagger:
         names = [n.encode() if isinstance(n, str) else n for n in ref_names]
         arr = (ctypes.c_char_p * max(len(names), 1))(*names)
         h = ctypes.c_void_p()
-        if lib.smi_genes_load_refflat(text, len(text), arr, len(names), ctypes.byref(h)):
+        load = lib.smi_genes_load_gtf if isinstance(refflat_text, GtfText) else lib.smi_genes_load_refflat
+        if load(text, len(text), arr, len(names), ctypes.byref(h)):
             raise SmiError(lib.smi_last_error().decode())
         self._h, self._lib = h, lib
         a, b, c = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_size_t(0)
         lib.smi_genes_count(h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
         self.n_genes, self.n_lines, self.n_skipped = a.value, b.value, c.value
+
+    def dump(self):
+        """the loaded genes (smi_genes_dump): [{name, contig, start, end, negative, transcripts: [{name, tx, cds, exons}]}] in the order the reference adds
+        them to its OverlapDetector, transcripts in the order Gene.iterator() walks them"""
+        n = ctypes.c_size_t(0)
+        if self._lib.smi_genes_dump(self._h, None, 0, ctypes.byref(n)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        if self._lib.smi_genes_dump(self._h, buf, n.value, ctypes.byref(n)):
+            raise SmiError(self._lib.smi_last_error().decode())
+        out = []
+        for ln in buf.raw[:n.value].decode("latin-1").split("\n"):
+            if not ln:
+                continue
+            name, contig, st, en, strand, txs = ln.split("\t")
+            tl = []
+            for t in txs.split(";"):
+                tn, a, b, c, d, ex = t.split("|")
+                tl.append({"name": tn, "tx": [int(a), int(b)], "cds": [int(c), int(d)], "exons": [[int(v) for v in e.split("-")] for e in ex.split(",")]})
+            out.append({"name": name, "contig": contig, "start": int(st), "end": int(en), "negative": strand == "-", "transcripts_in_iteration_order": tl})
+        return out
 
     def close(self):
         if getattr(self, "_h", None):

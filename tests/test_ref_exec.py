@@ -308,6 +308,12 @@ def oracle_chunk(sor, bset, rank_of, sec, case):
     par = None
     if five:
         par = sor.chimera_params(tso="CTACACGACGCTCTTCCGATCT", adapter="AAGCAGTGGTATCAACGCAGAGTAC", tso_max=5, adapter_max=5, bc_umi=0)
+    scan_par = None
+    if sec.get("polya"):       # -p / -f / -w: the finder's parameters; the splitter keeps windowSearchForPolyA + 70 away from the read ends
+        scan_par = sor.default_scan_params()
+        scan_par["polya_len"], scan_par["polya_frac"], scan_par["window_polya"] = sec["polya"]
+        par = par if par is not None else sor.chimera_params()
+        par.window_polya = int(sec["polya"][2])
     out, rid = [], case["first_read_id"]
     for rd in case["reads"]:
         s, q, name = rd["seq"], rd["qual"], rd["name"]
@@ -322,9 +328,9 @@ def oracle_chunk(sor, bset, rank_of, sec, case):
             # (no qualities for the scan: they only feed pass 1's filter, whose window AE - 16 .. AE - 1 the reference itself cannot
             # take when a 5' adapter ends before base 17 -- pass 2 never looks at it)
             if five:
-                rc, sc = sor.scan_read_5p(fs, None, "CTTCCGATCT", dont_search_polya=sec["dont_search_polya"])
+                rc, sc = sor.scan_read_5p(fs, None, "CTTCCGATCT", dont_search_polya=sec["dont_search_polya"], params=scan_par)
             else:
-                rc, sc = sor.scan_read_3p(fs, None, "CTTCCGATCT")
+                rc, sc = sor.scan_read_3p(fs, None, "CTTCCGATCT", params=scan_par)
             assert rc == 0
             a = None
             if sc["adapter_found"] and not multi:
@@ -399,6 +405,20 @@ def test_pass2_targeted_and_trimmed_chunks_equal_reference_bytecode(sor, name):
     for sec in secs:
         n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
         assert n_in >= 50 and n_passed >= 30 and n_bc >= 20
+
+
+def test_pass2_chunks_under_other_polya_parameters_equal_reference_bytecode(sor):
+    """pass2p: the wide reads through Parser.call with `-p 12 -f 0.8 -w 120` (3') and `-p 20 -f 0.7 -w 140` (5', polyA search on) as
+    NanoporeReadScannerMain.java:L228-234 stores them: the oracle with the same parameters writes the same records; and the parameters matter
+    (with the shipped window some records come out differently)"""
+    secs = load("pass2p")["sections"]
+    assert [s_["polya"] for s_ in secs] == [[12, 0.8, 120], [20, 0.7, 140]]
+    for sec in secs:
+        n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
+        assert n_in >= 150 and n_passed >= 80 and n_bc >= 60
+        shipped = dict(sec, polya=None)
+        with pytest.raises(AssertionError):
+            _check_chunk_section(sor, shipped)
 
 
 # ---- a-16: read name -> scan data -> UMI pair distance, 3' and 5' (-p) ---------------------------------------------------

@@ -208,6 +208,26 @@ def install(jvm):
         return s.replace(rx, repl, 1)
 
     N["java/lang/String.replaceFirst"] = s_replace_first
+
+    def s_replace_all(j, s, rx, repl):
+        """String.replaceAll for patterns without a regex metacharacter (a literal) and replacements without $ / backslash"""
+        if any(ch in rx for ch in ".$|()[{^?*+\\") or any(ch in repl for ch in "$\\") or rx == "":
+            raise Unsupported(f"String.replaceAll regex {rx!r} / replacement {repl!r}")
+        return s.replace(rx, repl)
+
+    N["java/lang/String.replaceAll"] = s_replace_all
+
+    def s_format(j, fmt, args):
+        """String.format with %s / %d / %n only (messages of exceptions and logs)"""
+        import re as _re
+
+        vals = [j.to_jstring(a) if not isinstance(a, JBox) else str(a.v) for a in args.a]
+        if _re.sub(r"%[sdn%]", "", fmt).count("%"):
+            raise Unsupported(f"String.format {fmt!r}")
+        it = iter(vals)
+        return _re.sub(r"%[sdn%]", lambda m_: "\n" if m_.group() == "%n" else "%" if m_.group() == "%%" else next(it), fmt)
+
+    N["java/lang/String.format:(Ljava/lang/String;[Ljava/lang/Object;)Ljava/lang/String;"] = s_format
     N["java/lang/CharSequence.length"] = lambda j, s: len(j.to_jstring(s))
     N["java/lang/CharSequence.charAt"] = lambda j, s, i: s_char_at(j, j.to_jstring(s), i)
     N["java/lang/CharSequence.toString"] = lambda j, s: j.to_jstring(s)
@@ -367,6 +387,8 @@ def install(jvm):
     N["java/lang/Integer.parseInt:(Ljava/lang/String;)I"] = lambda j, s: _parse_int(j, s, 32)
     N["java/lang/Long.parseLong:(Ljava/lang/String;)J"] = lambda j, s: _parse_int(j, s, 64)
     N["java/lang/Integer.valueOf:(Ljava/lang/String;)Ljava/lang/Integer;"] = lambda j, s: JBox("java/lang/Integer", _parse_int(j, s, 32))
+    N["java/lang/Integer.<init>:(Ljava/lang/String;)V"] = lambda j, _u, s: JBox("java/lang/Integer", _parse_int(j, s, 32))   # new Integer("12")
+    N["java/lang/Integer.<init>:(I)V"] = lambda j, _u, v: JBox("java/lang/Integer", v)
     def parse_float(j, t, single):
         u = t.strip()
         try:

@@ -929,10 +929,16 @@ def wide_chunk(g, p2, bc_keys_ranks, reads, first_id):
 def _wide_worker(args):
     five_prime, ed, dont_search_polya, seed, chunk_ids, per_chunk = args[:6]
     trim, reader = (args[6], args[7]) if len(args) > 6 else (False, None)
+    polya = args[8] if len(args) > 8 else None
     reader = reader or wide_read
     g = Gen()
     j = g.j
     p2 = Pass2(g, five_prime, ed, dont_search_polya)
+    if polya is not None:      # -p / -f / -w as NanoporeReadScannerMain.java:L228-234 stores them (boxed, in params.polyAT)
+        pat = p2.par.f["polyAT"]
+        pat.f["polyATlength"] = JBox("java/lang/Integer", int(polya[0]))
+        pat.f["fractionATInPolyAT"] = JBox("java/lang/Float", f32(polya[1]))
+        pat.f["windowSearchForPolyA"] = JBox("java/lang/Integer", int(polya[2]))
     rs = p2.par.f["readScannerParameters"]
     j.call_virtual(rs.f["what_todo"], "add", "(Ljava/lang/Object;)Z", j.get_static(WHAT_TODO, "FIND_BARCODES"))   # -b (ReadScannerParameters.java:L291)
     if trim:
@@ -953,11 +959,11 @@ def _wide_worker(args):
     return cases, sorted(j.natives_used), g.hits(), j.steps, flag_values, p2.report
 
 
-def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5, trim=False, reader=None, note=""):
+def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5, trim=False, reader=None, note="", polya=None):
     jobs = max(1, int(os.environ.get("WIDE_JOBS", "1")))
     ids = list(range(n_chunks))
     blocks = [ids[k::jobs] for k in range(jobs)]
-    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk, trim, reader) for b in blocks if b]
+    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk, trim, reader, polya) for b in blocks if b]
     if len(args) == 1:
         parts = [_wide_worker(args[0])]
     else:
@@ -979,7 +985,7 @@ def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chu
                   "first_read_id + 1, ... in list order.  Parameters: Jar/config.xml as shipped + what_todo = {FIND_BARCODES}.  Each chunk ran under two iteration orders "
                   "of java.util.HashMap / HashSet; `hash_orders_agree` = both gave this result.",
          "cases": cases, "barcodes": bcs, "ranks": list(range(1, len(bcs) + 1)), "five_prime": five_prime, "ed": ed, "dont_search_polya": dont_search_polya,
-         "split_chimeras": not dont_search_polya, "trim_fastq": bool(trim), "kinds": sorted({r["kind"] for c in cases for r in c["reads"]}) if reader else WIDE_KINDS,
+         "split_chimeras": not dont_search_polya, "trim_fastq": bool(trim), "polya": None if polya is None else [int(polya[0]), float(polya[1]), int(polya[2])], "kinds": sorted({r["kind"] for c in cases for r in c["reads"]}) if reader else WIDE_KINDS,
          "flag_values": parts[0][4], "config_report": parts[0][5],
          "natives": [{"native": k, "tier": jvm_natives.tier_of(k)} for k in natives]}
     s["max_tier"] = max([n["tier"] for n in s["natives"]] or ["A"])
@@ -1046,6 +1052,17 @@ def gen_pass2x_5p(g):
 
 def gen_pass2w_3p(g):
     return gen_pass2w(g, False, 1, False, 4101)
+
+
+def gen_pass2p(g):
+    """the wide reads under `scanfastq -p / -f / -w` (NanoporeReadScannerMain.java:L228-234): 3' with -p 12 -f 0.8 -w 120 (40 chunks), 5' with the polyA search on and
+    -p 20 -f 0.7 -w 140 (30 chunks) -- the finder's parameters and, through windowSearchForPolyA, how far the splitter keeps from the read ends"""
+    a = gen_pass2w(g, False, 1, False, 4101, n_chunks=40, per_chunk=5, polya=(12, 0.8, 120), note=", -p 12 -f 0.8 -w 120")
+    b = gen_pass2w(g, True, 1, False, 4104, n_chunks=30, per_chunk=5, polya=(20, 0.7, 140), note=", -p 20 -f 0.7 -w 140")
+    a["sections"] += b["sections"]
+    a["_steps"] += b["_steps"]
+    merge_hits(a["_hits"], b["_hits"])
+    return a
 
 
 def gen_pass2w_3p_ed2(g):
@@ -1497,6 +1514,187 @@ def gen_gene(g, n_rows=1500, n_reads=420, seed=1212):
             print(f"  gene {k + 1}/{len(reads)}  {time.time() - g.t0:.0f}s", flush=True)
     j.hash_order = None
     out["sections"].append(g.finish(s))
+    return out
+
+
+GTFR = "org/broadinstitute/dropseqrna/annotation/GTFReader"
+
+
+def gtf_lines_from_refflat(rows, rng):
+    """GENCODE-shaped GTF lines (gene, transcript, exon, CDS) for refFlat rows; the gene record spans its transcripts"""
+    by_gene = {}
+    for r in rows:
+        by_gene.setdefault(r[0], []).append(r)
+    out = []
+    for k, (name, rs) in enumerate(by_gene.items()):
+        if len({(r[2], r[3]) for r in rs}) != 1:
+            continue                       # (a name on two chromosomes / strands: the hand-made lines below cover those rules)
+        chrom, strand = rs[0][2], rs[0][3]
+        gid = f"ENSG{k:08d}.{1 + k % 4}"
+        gs, ge = min(int(r[4]) + 1 for r in rs), max(int(r[5]) for r in rs)
+        ga = f'gene_id "{gid}"; gene_type "protein_coding"; gene_name "{name}"; level 2;'
+        out.append("\t".join([chrom, "HAVANA", "gene", str(gs), str(ge), ".", strand, ".", ga]))
+        for q, r in enumerate(rs):
+            tid, tname = f"ENST{k:06d}{q:02d}.1", r[1]
+            ta = f'gene_id "{gid}"; transcript_id "{tid}"; gene_type "protein_coding"; gene_name "{name}"; transcript_name "{tname}"; tag "basic";'
+            out.append("\t".join([chrom, "HAVANA", "transcript", str(int(r[4]) + 1), r[5], ".", strand, ".", ta]))
+            es = [int(x) + 1 for x in r[9].split(",") if x]
+            ee = [int(x) for x in r[10].split(",") if x]
+            order = list(range(len(es)))
+            if strand == "-":
+                order.reverse()            # GENCODE lists the exons of a minus-strand transcript from its 5' end: the builder sorts them
+            cs, ce = int(r[6]) + 1, int(r[7])
+            for i in order:
+                out.append("\t".join([chrom, "HAVANA", "exon", str(es[i]), str(ee[i]), ".", strand, ".", ta + f' exon_number {i + 1};']))
+                lo, hi = max(es[i], cs), min(ee[i], ce)
+                if cs <= ce and lo <= hi:
+                    out.append("\t".join([chrom, "HAVANA", "CDS", str(lo), str(hi), ".", strand, "0", ta]))
+            if rng.random() < 0.2:
+                out.append("\t".join([chrom, "HAVANA", "UTR", str(es[0]), str(min(ee[0], es[0] + 10)), ".", strand, ".", ta]))
+    return out
+
+
+def gen_gene_gtf(g, n_rows=420, n_reads=300, seed=1222):
+    """--annotationFile <x.gtf>: GTFReader.load (DropseqLib: GTFParser, GTFRecord.validate, GeneFromGTFBuilder, GeneFromGTF) and GennameTagger over its genes"""
+    import gzip
+
+    j = g.j
+    rng = random.Random(seed)
+    text = gzip.open(os.path.join(GOLD, "chr12_head1500.refFlat.gz"), "rt").read()
+    rows = [ln.split("\t") for ln in text.split("\n")[:n_rows] if ln]
+    lines = ["##description: made from tests/golden/chr12_head1500.refFlat.gz", "##provider: tools/make_ref_exec.py", ""] + gtf_lines_from_refflat(rows, rng)
+
+    def feat(chrom, kind, a, b, strand, attrs):
+        return "\t".join([chrom, "hand", kind, str(a), str(b), ".", strand, ".", attrs])
+
+    def at(gid, name, tid=None, tname=None, more=""):
+        s_ = f'gene_id "{gid}"; gene_name "{name}";'
+        if tid is not None:
+            s_ += f' transcript_id "{tid}";'
+        if tname is not None:
+            s_ += f' transcript_name "{tname}";'
+        return s_ + more
+
+    extra = [
+        # GOOD: two transcripts, the gene record wider than both (extent = all records); exons given out of order; a CDS inside t1 only
+        feat("c1", "gene", 90, 1300, "+", at("g1", "GOOD")), feat("c1", "transcript", 101, 1000, "+", at("g1", "GOOD", "i1", "t1")),
+        feat("c1", "exon", 601, 1000, "+", at("g1", "GOOD", "i1", "t1")), feat("c1", "exon", 101, 300, "+", at("g1", "GOOD", "i1", "t1")),
+        feat("c1", "CDS", 201, 300, "+", at("g1", "GOOD", "i1", "t1")), feat("c1", "CDS", 601, 900, "+", at("g1", "GOOD", "i1", "t1")),
+        feat("c1", "exon", 151, 1200, "+", at("g1", "GOOD", "i2", "t2")),
+        # a gene without a gene record: extent from its features; the stop codon widens it beyond the exons
+        feat("c1", "exon", 3001, 3500, "-", at("g2", "NOGENEREC", "i3", "t3")), feat("c1", "stop_codon", 2990, 2992, "-", at("g2", "NOGENEREC", "i3", "t3")),
+        # rules that make the LENIENT reader skip a gene
+        feat("c1", "exon", 5001, 6000, "+", at("g3", "TWOSTRANDS", "i4", "t4")), feat("c1", "exon", 5001, 6000, "-", at("g3", "TWOSTRANDS", "i5", "t5")),
+        feat("c1", "exon", 7001, 8000, "-", at("g4", "TWOCHROMS", "i6", "t6")), feat("chr1", "exon", 7001, 8000, "-", at("g4", "TWOCHROMS", "i7", "t7")),
+        feat("c1", "gene", 9001, 9400, "+", at("g5", "GENERECSHORT")), feat("c1", "exon", 9001, 9500, "+", at("g5", "GENERECSHORT", "i8", "t8")),
+        feat("c1", "exon", 10001, 10100, "+", at("g6", "TWOIDS", "i9", "t9")), feat("c1", "exon", 10201, 10300, "+", at("g6b", "TWOIDS", "i9", "t9")),
+        feat("c1", "transcript", 11001, 11500, "+", at("g7", "NOEXONS", "i10", "t10")), feat("c1", "CDS", 11001, 11100, "+", at("g7", "NOEXONS", "i10", "t10")),
+        feat("c1", "exon", 12001, 12100, "+", at("g8", "TXNAMETWICE", "i11", "t11")), feat("c1", "exon", 12201, 12300, "+", at("g8", "TXNAMETWICE", "i12", "t11")),
+        feat("c1", "exon", 13001, 13100, "+", at("g9", "OVERLAP", "i13", "t13")), feat("c1", "exon", 13100, 13200, "+", at("g9", "OVERLAP", "i13", "t13")),
+        feat("c1", "exon", 14100, 14001, "+", at("g10", "NEGEXTENT", "i14", "t14")),
+        feat("c1", "gene", 15001, 15500, "+", at("g11", "ONLYGENEREC")),
+        feat("c9", "exon", 101, 1000, "+", at("g12", "ELSEWHERE", "i15", "t15")),
+        # two genes of one interval and strand both stay (GeneFromGTF.equals has the name); a third on the other strand
+        feat("c1", "exon", 20001, 21000, "-", at("g13", "SAMEPLACE_A", "i16", "t16")), feat("c1", "exon", 20001, 21000, "-", at("g14", "SAMEPLACE_B", "i17", "t17")),
+        feat("c1", "CDS", 20501, 21000, "-", at("g14", "SAMEPLACE_B", "i17", "t17")), feat("c1", "exon", 20001, 21000, "+", at("g15", "ANTISENSE", "i18", "t18")),
+        # gene versions: only the records of the highest version count (Ensembl's gene_version attribute)
+        feat("c1", "exon", 30001, 30500, "+", at("g16", "VERSIONED", "i19", "t19", ' gene_version "3";')), feat("c1", "exon", 31001, 31500, "+", at("g16", "VERSIONED", "i20", "t20", ' gene_version "12";')),
+        feat("c1", "exon", 32001, 32200, "+", at("g16", "VERSIONED", "i21", "t21")),
+        # the attribute parser: a value with a blank keeps its first word; two blanks leave an empty value
+        feat("c1", "exon", 40001, 40500, "+", 'gene_id "g17"; gene_name "BLANK NAME"; transcript_id "i22"; transcript_name "t22 x"; note  "two blanks";'),
+    ]
+    lines += extra
+    refs = ["chr1", "chr12", "chrUn", "c1"]
+    install_gene_io(j, lines, refs)
+    H = j.hooks
+
+    def guava_stream_it(jj, itr):
+        lst = JObject("java/util/ArrayList")
+        lst.native = []
+        while jj.call_virtual(itr, "hasNext", "()Z"):
+            lst.native.append(jj.call_virtual(itr, "next", "()Ljava/lang/Object;"))
+        return jj.natives["java/util/ArrayList.stream"](jj, lst)
+
+    H["com/google/common/collect/Streams.stream:(Ljava/util/Iterator;)Ljava/util/stream/Stream;"] = guava_stream_it
+    H["htsjdk/samtools/util/ProgressLogger.<init>:(Lhtsjdk/samtools/util/Log;ILjava/lang/String;Ljava/lang/String;)V"] = lambda jj, o, *a: None
+    H["htsjdk/samtools/util/AbstractProgressLogger.record:(Ljava/lang/String;I)Z"] = lambda jj, o, *a: 0      # (logging only)
+    H["htsjdk/samtools/util/CloserUtil.close:(Ljava/lang/Object;)V"] = lambda jj, *a: None
+    out = {"jar": "NanoporeBC_UMI_finder-2.1.jar + DropseqLib-1.0.jar + picard-2.23.9.jar + htsjdk-4.1.3.jar", "sections": []}
+    s = g.section("GTFReader.load() (DropseqLib: $FilteringGTFParser over GTFParser STRICT, GeneFromGTFBuilder) over GTF lines made from the first rows of "
+                  "tests/golden/chr12_head1500.refFlat.gz (gene / transcript / exon / CDS / UTR features, GENCODE attribute order) plus the hand-made lines in "
+                  "`extra_lines`, then GennameTagger.annotateGene(record) as in ref_exec_gene.json.  HashMap / HashSet iteration in java.util.HashMap table "
+                  "order from the keys' own hashCode() (tier D)", GT, "annotateGene:(Lhtsjdk/samtools/SAMRecord;)Lhtsjdk/samtools/SAMRecord;")
+    s["gtf_lines"] = lines
+    s["extra_lines"] = extra
+    s["ref_names"] = refs
+    j.hash_order = "jdk"
+    rdr = j.new(GTFR, "(Ljava/io/File;Lhtsjdk/samtools/SAMSequenceDictionary;)V", None, JObject("htsjdk/samtools/SAMSequenceDictionary"))
+    det = j.call_virtual(rdr, "load", "()Lhtsjdk/samtools/util/OverlapDetector;")
+    print(f"  GTF loaded by the reference's GTFReader.load(): {time.time() - g.t0:.0f}s", flush=True)
+    allg = j.call_virtual(det, "getAll", "()Ljava/util/Set;")
+    genes = []
+    for o, _ in allg.native.items_in_insertion_order():
+        txs = []
+        itr = j.call_virtual(o, "iterator", "()Ljava/util/Iterator;")
+        while j.call_virtual(itr, "hasNext", "()Z"):
+            t = j.call_virtual(itr, "next", "()Ljava/lang/Object;")
+            txs.append({"name": t.f["name"], "tx": [t.f["transcriptionStart"], t.f["transcriptionEnd"]], "cds": [t.f["codingStart"], t.f["codingEnd"]],
+                        "exons": [[e.f["start"], e.f["end"]] for e in t.f["exons"].a]})
+        genes.append({"name": o.f["name"], "contig": o.f["contig"], "start": o.f["start"], "end": o.f["end"], "negative": bool(o.f["negativeStrand"]),
+                      "transcripts_in_iteration_order": txs})
+    s["genes_loaded"] = sorted(genes, key=lambda d: d["name"])
+    tagger = j.new_object(GT)
+    tagger.f.update({"TAG": "GE", "STRANDTAG": "GS", "FUNCTIONTAG": "XF", "ALLOW_MULTI_GENE_READS": 1, "geneOverlapDetector": det})
+    tagger.f["metrics"] = j.new(GT + "$ReadTaggingMetric", f"(L{GT};)V", tagger)
+    reads = gene_reads(rng, rows, n_reads)
+    reads += [("c1", f, p, cg) for f, p, cg in [(0, 40, [("M", 50)]), (0, 95, [("M", 4)]), (0, 100, [("M", 50)]), (0, 250, [("M", 20)]), (0, 350, [("M", 20)]),
+              (16, 250, [("M", 20)]), (0, 1100, [("M", 50)]), (0, 1199, [("M", 50)]), (0, 1200, [("M", 50)]), (0, 1250, [("M", 100)]), (16, 2985, [("M", 10)]),
+              (16, 3100, [("M", 50)]), (16, 20100, [("M", 50)]), (0, 20100, [("M", 50)]), (16, 20600, [("M", 50)]), (0, 5100, [("M", 50)]), (0, 9100, [("M", 50)]),
+              (0, 10050, [("M", 20)]), (0, 11050, [("M", 20)]), (0, 12050, [("M", 20)]), (0, 13050, [("M", 100)]), (0, 15100, [("M", 100)]),
+              (0, 30100, [("M", 100)]), (0, 31100, [("M", 100)]), (0, 32050, [("M", 100)]), (0, 40100, [("M", 100)]),
+              (0, 250, [("M", 20), ("N", 19800), ("M", 100)]), (16, 250, [("M", 20), ("N", 19800), ("M", 100)]), (16, 3100, [("M", 50), ("N", 16900), ("M", 100)])]]
+    for k, (ref, flag, pos0, cigar) in enumerate(reads):
+        rec = sam_record(j, ref, flag, pos0, cigar)
+        case = {"ref": ref, "flag": flag, "pos0": pos0, "cigar": [[op, ln] for op, ln in cigar]}
+        try:
+            j.call_virtual(tagger, "annotateGene", f"(L{SAMREC};)L{SAMREC};", rec)
+            case["set_attribute"] = rec.native["calls"]
+        except JavaThrow as e:
+            case["throws"] = e.obj.cls
+            case["set_attribute_before_throw"] = rec.native["calls"]
+        s["cases"].append(case)
+        if k % 60 == 0:
+            print(f"  gene_gtf {k + 1}/{len(reads)}  {time.time() - g.t0:.0f}s", flush=True)
+    out["sections"].append(g.finish(s))
+    # ---- lines the STRICT parser rejects: each one alone behind a valid line -> the exception GTFReader.load ends with
+    s2 = g.section("GTFReader.load() over one valid line and ONE offending line: the exception it ends with (GTFParser.next L84-97 under ValidationStringency.STRICT, "
+                   "AnnotationUtils.parseOptionalFields L386, Integer.parseInt) -- nothing catches it on the way up to UmiFinderWorker", GTFR,
+                   "load:()Lhtsjdk/samtools/util/OverlapDetector;")
+    ok_line = feat("c1", "exon", 101, 300, "+", at("g1", "GOOD", "i1", "t1"))
+    bad = {"no_gene_id": feat("c1", "exon", 1, 9, "+", 'gene_name "X"; transcript_id "i"; transcript_name "t";'),
+           "no_gene_name": feat("c1", "exon", 1, 9, "+", 'gene_id "g"; transcript_id "i"; transcript_name "t";'),
+           "no_transcript_name": feat("c1", "exon", 1, 9, "+", 'gene_id "g"; gene_name "X"; transcript_id "i";'),
+           "no_transcript_id": feat("c1", "exon", 1, 9, "+", 'gene_id "g"; gene_name "X"; transcript_name "t";'),
+           "gene_record_without_transcript_is_fine": feat("c1", "gene", 101, 300, "+", 'gene_id "g1"; gene_name "GOOD";'),
+           "comma_in_gene_name": feat("c1", "exon", 1, 9, "+", at("g", "A,B", "i", "t")),
+           "attribute_without_value": feat("c1", "exon", 1, 9, "+", at("g", "X", "i", "t") + " basic;"),
+           "semicolon_inside_quotes": feat("c1", "exon", 1, 9, "+", at("g", "X", "i", "t") + ' note "a;b";'),
+           "eight_fields": "\t".join(["c1", "hand", "exon", "1", "9", ".", "+", "."]),
+           "start_not_a_number": feat("c1", "exon", "1e3", 2000, "+", at("g", "X", "i", "t")),
+           "gene_version_not_a_number": feat("c1", "exon", 1, 9, "+", at("g", "X", "i", "t", ' gene_version "v2";')),
+           "invalid_line_on_unknown_contig": feat("c9", "exon", 1, 9, "+", 'gene_name "X"; transcript_id "i"; transcript_name "t";')}
+    for name, ln in bad.items():
+        install_gene_io(j, [ok_line, ln], refs)
+        case = {"what": name, "line": ln}
+        try:
+            d2 = j.call_virtual(j.new(GTFR, "(Ljava/io/File;Lhtsjdk/samtools/SAMSequenceDictionary;)V", None, JObject("htsjdk/samtools/SAMSequenceDictionary")),
+                                "load", "()Lhtsjdk/samtools/util/OverlapDetector;")
+            case["genes_loaded"] = sorted(o.f["name"] for o, _ in j.call_virtual(d2, "getAll", "()Ljava/util/Set;").native.items_in_insertion_order())
+        except JavaThrow as e:
+            case["throws"] = e.obj.cls
+        s2["cases"].append(case)
+    j.hash_order = None
+    out["sections"].append(g.finish(s2))
     return out
 
 
@@ -2747,11 +2945,11 @@ def gen_auxorder(g, seed=2222):
     return out
 
 
-SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
+SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
             "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
-            "pass2x_3p": gen_pass2x_3p, "pass2x_5p": gen_pass2x_5p, "group2": gen_group2, "cluster_own2": gen_cluster_own2,
+            "pass2x_3p": gen_pass2x_3p, "pass2x_5p": gen_pass2x_5p, "pass2p": gen_pass2p, "group2": gen_group2, "cluster_own2": gen_cluster_own2,
             "pass1_5p": lambda g: gen_pass1(g, 32, 1626, five_prime=True),
             "pass1_nowl": lambda g: gen_pass1(g, 60, 1636, no_whitelist=True), "pass1_nowl_5p": lambda g: gen_pass1(g, 66, 1646, five_prime=True, no_whitelist=True)}
 
