@@ -183,6 +183,22 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     assert open(umidir + "xg.genecounts.tsv").read() == open(umidir + "passedParsed.genecounts.tsv").read()
     r = _run(STEP3.replace("passedParsed.bam", "bad.bam") + " -g G1", env, str(work))
     assert r.returncode == 1 and "two letters" in r.stderr
+    # --annotationFile <x.gtf> (README.md:727): the same eight genes as a GTF -> the same tags and tables as the refFlat run
+    with open(str(work / "Data" / "genes.gtf"), "w") as f:
+        f.write("##format: gtf\n")
+        for g in range(8):
+            a = f'gene_id "E{g}.1"; gene_type "protein_coding"; gene_name "GENE{g}";'
+            t = a + f' transcript_id "T{g}.1"; transcript_name "TX{g}";'
+            lo, hi = 19_001 + 4_000 * g, 22_500 + 4_000 * g
+            f.write(f"chr12\tsrc\tgene\t{lo}\t{hi}\t.\t+\t.\t{a}\nchr12\tsrc\ttranscript\t{lo}\t{hi}\t.\t+\t.\t{t}\n"
+                    f"chr12\tsrc\texon\t{lo}\t{hi}\t.\t+\t.\t{t}\nchr12\tsrc\tCDS\t{lo + 100}\t{hi - 100}\t.\t+\t0\t{t}\n")
+    r = _run(STEP3.replace("passedParsed.bam", "gtf.bam").replace("Data/gencode.v38.chr12.refFlat", "Data/genes.gtf"), env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, _, via_gtf = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "gtf.bam", "rb").read()))
+    assert [(o_["name"], o_["aux"]) for o_ in via_gtf] == [(o_["name"], o_["aux"]) for o_ in out]
+    assert open(umidir + "gtf.genecounts.tsv").read() == open(umidir + "passedParsed.genecounts.tsv").read()
+    r = _run(STEP3.replace("passedParsed.bam", "bad.bam").replace("Data/gencode.v38.chr12.refFlat", "Data/genes.txt"), env, str(work))
+    assert r.returncode == 1 and "should end with .gtf or .refFlat" in r.stderr
     r = _run(STEP3.replace("passedParsed.bam", "limited.bam") + " -b 0 -u 1", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     _, _, lim = bammodel.parse_bam(bammodel.bgzf_decompress(open(umidir + "limited.bam", "rb").read()))

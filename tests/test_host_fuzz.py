@@ -167,6 +167,24 @@ def test_refflat_and_dumps_survive_damage(pkg):
             t.close()
         except libmod.SmiError:
             n_err += 1
+    # the same through the GTF reader (smi_genes_load_gtf): gene / transcript / exon / CDS lines with GENCODE-shaped attributes
+    gtf = "".join(
+        f'chr{1 + g % 2}\tsrc\tgene\t{51 + 200 * g}\t{240 + 200 * g}\t.\t{"+-"[g % 2]}\t.\tgene_id "E{g}.1"; gene_name "G{g}"; level 2;\n' +
+        "".join(f'chr{1 + g % 2}\tsrc\t{ft}\t{a + 200 * g}\t{b + 200 * g}\t.\t{"+-"[g % 2]}\t.\tgene_id "E{g}.1"; transcript_id "T{g}.1"; gene_name "G{g}"; '
+                f'transcript_name "G{g}-201"; tag "basic";\n' for ft, a, b in (("transcript", 51, 240), ("exon", 51, 100), ("CDS", 61, 100), ("exon", 151, 240)))
+        for g in range(40)).encode()
+    n_gtf_err = n_gtf_ok = 0
+    for m in [np.frombuffer(gtf, dtype=np.uint8)] + _mutations(rng, gtf, 300):
+        try:
+            t = libmod.GeneTagger(libmod.GtfText(bytes(m).decode("latin-1")), ["chr1", "chr2"])
+            t.tag(np.array([0, 1, 0], dtype=np.int32), np.array([0, 16, 0], dtype=np.uint16), np.array([60, 500, 10 ** 6], dtype=np.int32),
+                  [[(0, 50)], [(0, 30), (3, 200), (0, 30)], [(0, 10)]])
+            t.dump()
+            t.close()
+            n_gtf_ok += 1
+        except libmod.SmiError:
+            n_gtf_err += 1
+    assert n_gtf_ok >= 1 and n_gtf_err > 20, (n_gtf_ok, n_gtf_err)
     gc = libmod.GeneCounts()
     for k in range(200):
         gc.add([f"G{k % 7}"], np.array([k % 5], dtype=np.int64), np.array([k * 977 % 4096], dtype=np.uint64), np.array([k * 31 % 65536], dtype=np.uint64),

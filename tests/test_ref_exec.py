@@ -535,6 +535,54 @@ def test_gene_tags_equal_reference_bytecode(pkg):
     assert {c["throws"] for c in cases if "throws" in c} == {"java/lang/NullPointerException"}
 
 
+def test_gtf_gene_model_and_tags_equal_reference_bytecode(pkg):
+    """--annotationFile <x.gtf>: smi_genes_load_gtf against GTFReader.load executed from DropseqLib's class files (ref_exec_gene_gtf.json): the genes kept
+    and skipped, every gene's extent, its transcripts in GeneFromGTF.iterator() order with their exons and coding ranges, then GennameTagger's tags over
+    those genes; and the lines the reference's STRICT parser ends the run on are errors here"""
+    from sicelore_amd import lib
+
+    d = load("gene_gtf")
+    sec = d["sections"][0]
+    assert sec["max_tier"] == "D"
+    text = "\n".join(sec["gtf_lines"]) + "\n"
+    refs = sec["ref_names"]
+    tagger = lib.GeneTagger(lib.GtfText(text), refs)
+    model = sorted(tagger.dump(), key=lambda g_: g_["name"])
+    assert [g_["name"] for g_ in model] == [g_["name"] for g_ in sec["genes_loaded"]]
+    assert model == sec["genes_loaded"]
+    names = {g_["name"] for g_ in model}
+    assert {"GOOD", "NOGENEREC", "SAMEPLACE_A", "SAMEPLACE_B", "ANTISENSE", "VERSIONED", "BLANK"} <= names
+    assert not ({"TWOSTRANDS", "TWOCHROMS", "GENERECSHORT", "TWOIDS", "NOEXONS", "TXNAMETWICE", "OVERLAP", "NEGEXTENT", "ONLYGENEREC", "ELSEWHERE"} & names)
+    by = {g_["name"]: g_ for g_ in model}
+    assert (by["GOOD"]["start"], by["GOOD"]["end"]) == (90, 1300) and (by["NOGENEREC"]["start"], by["NOGENEREC"]["end"]) == (2990, 3500)
+    assert [t["name"] for t in by["VERSIONED"]["transcripts_in_iteration_order"]] == ["t20"] and by["BLANK"]["transcripts_in_iteration_order"][0]["name"] == "t22"
+    assert sum(len(g_["transcripts_in_iteration_order"]) > 1 for g_ in model) >= 20
+    cases = sec["cases"]
+    exp = [_gene_expectation(c) for c in cases]
+    got = tagger.tag([refs.index(c["ref"]) if c["ref"] is not None else -1 for c in cases], [c["flag"] for c in cases],
+                     [c["pos0"] for c in cases], [[tuple(x) for x in c["cigar"]] for c in cases])
+    assert got == exp
+    xf = [e[2] for e in exp]
+    assert all(xf.count(k) >= 8 for k in ("INTERGENIC", "INTRONIC", "UTR", "CODING")) and xf.count(None) >= 5
+    assert sum(e[0] is not None and "," in e[0] for e in exp) >= 2
+    # lines the reference stops on (nothing catches the exception on the way up) / lines it takes
+    sec2 = d["sections"][1]
+    n_thrown = 0
+    for c in sec2["cases"]:
+        two = "\n".join(sec2_line for sec2_line in (_GTF_OK_LINE, c["line"])) + "\n"
+        if "throws" in c:
+            with pytest.raises(lib.SmiError):
+                lib.GeneTagger(lib.GtfText(two), refs)
+            n_thrown += 1
+        else:
+            t2 = lib.GeneTagger(lib.GtfText(two), refs)
+            assert sorted(g_["name"] for g_ in t2.dump()) == c["genes_loaded"], c["what"]
+    assert n_thrown >= 9 and n_thrown < len(sec2["cases"])
+
+
+_GTF_OK_LINE = "c1\thand\texon\t101\t300\t.\t+\t.\t" + 'gene_id "g1"; gene_name "GOOD"; transcript_id "i1"; transcript_name "t1";'
+
+
 # ---- a-13: end of pass 1 (UsedBarcodesListData.finalizeData + BarcodeDatasetColissionTester) --------------------------------------
 def _finalize_cases():
     sec = load("finalize")["sections"][0]
