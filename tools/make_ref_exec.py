@@ -64,7 +64,11 @@ COVERAGE_CLASSES = [_FJ + c for c in (
     "nuc/alignment/needleman/NeedlemanWunsch", "nuc/alignment/needleman/DynamicProgramming", "nuc/alignment/needleman/SequenceAlignment",
 )] + ["com/aliasi/cluster/CompleteLinkClusterer", "com/aliasi/cluster/SingleLinkClusterer", "com/aliasi/cluster/AbstractHierarchicalClusterer",
       "com/aliasi/cluster/Dendrogram", "com/aliasi/cluster/LinkDendrogram", "com/aliasi/cluster/LeafDendrogram",
-      "com/aliasi/util/BoundedPriorityQueue"]
+      "com/aliasi/util/BoundedPriorityQueue"] + [
+      # --annotationFile <x.gtf> (round 5): DropseqLib's GTF reader under GennameTagger
+      "org/broadinstitute/dropseqrna/annotation/" + c for c in ("GTFReader", "GTFReader$FilteringGTFParser", "GTFParser", "GTFRecord", "GeneFromGTFBuilder",
+                                                               "GeneFromGTFBuilder$Exon", "GeneFromGTFBuilder$GeneAnnotationFilter", "GeneFromGTF",
+                                                               "GeneFromGTF$TranscriptFromGTF", "AnnotationUtils")]
 
 TB = "com/rw/nuc/encoding/TwoBit/NucleicAcidTwoBitPerBase"
 OBI = "com/rw/nuc/encoding/onebyte/NucleicAcidInmutableOneBytePerBase"
