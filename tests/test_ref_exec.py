@@ -551,8 +551,8 @@ def test_gtf_gene_model_and_tags_equal_reference_bytecode(pkg):
     assert [g_["name"] for g_ in model] == [g_["name"] for g_ in sec["genes_loaded"]]
     assert model == sec["genes_loaded"]
     names = {g_["name"] for g_ in model}
-    assert {"GOOD", "NOGENEREC", "SAMEPLACE_A", "SAMEPLACE_B", "ANTISENSE", "VERSIONED", "BLANK"} <= names
-    assert not ({"TWOSTRANDS", "TWOCHROMS", "GENERECSHORT", "TWOIDS", "NOEXONS", "TXNAMETWICE", "OVERLAP", "NEGEXTENT", "ONLYGENEREC", "ELSEWHERE"} & names)
+    assert {"GOOD", "NOGENEREC", "SAMEPLACE_A", "SAMEPLACE_B", "ANTISENSE", "VERSIONED", "BLANK", "EMPTYPIECE"} <= names
+    assert not ({"TWOSTRANDS", "TWOCHROMS", "GENERECSHORT", "TWOIDS", "NOEXONS", "TXNAMETWICE", "OVERLAP", "NEGEXTENT", "ONLYGENEREC", "ELSEWHERE", "SAMESTART"} & names)
     by = {g_["name"]: g_ for g_ in model}
     assert (by["GOOD"]["start"], by["GOOD"]["end"]) == (90, 1300) and (by["NOGENEREC"]["start"], by["NOGENEREC"]["end"]) == (2990, 3500)
     assert [t["name"] for t in by["VERSIONED"]["transcripts_in_iteration_order"]] == ["t20"] and by["BLANK"]["transcripts_in_iteration_order"][0]["name"] == "t22"

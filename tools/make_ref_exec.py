@@ -1606,6 +1606,10 @@ def gen_gene_gtf(g, n_rows=420, n_reads=300, seed=1222):
         feat("c1", "exon", 32001, 32200, "+", at("g16", "VERSIONED", "i21", "t21")),
         # the attribute parser: a value with a blank keeps its first word; two blanks leave an empty value
         feat("c1", "exon", 40001, 40500, "+", 'gene_id "g17"; gene_name "BLANK NAME"; transcript_id "i22"; transcript_name "t22 x"; note  "two blanks";'),
+        # an empty piece between two ';' and a blank behind the last one are passed over (AnnotationUtils L381-382)
+        feat("c1", "exon", 41001, 41500, "-", 'gene_id "g18"; ; gene_name "EMPTYPIECE"; transcript_id "i23"; transcript_name "t23"; '),
+        # two exons of one start: $Exon.compareTo goes on to the ends (L239), the builder then finds them overlapping
+        feat("c1", "exon", 42001, 42100, "+", at("g19", "SAMESTART", "i24", "t24")), feat("c1", "exon", 42001, 42200, "+", at("g19", "SAMESTART", "i24", "t24")),
     ]
     lines += extra
     refs = ["chr1", "chr12", "chrUn", "c1"]
@@ -1655,7 +1659,7 @@ def gen_gene_gtf(g, n_rows=420, n_reads=300, seed=1222):
               (16, 250, [("M", 20)]), (0, 1100, [("M", 50)]), (0, 1199, [("M", 50)]), (0, 1200, [("M", 50)]), (0, 1250, [("M", 100)]), (16, 2985, [("M", 10)]),
               (16, 3100, [("M", 50)]), (16, 20100, [("M", 50)]), (0, 20100, [("M", 50)]), (16, 20600, [("M", 50)]), (0, 5100, [("M", 50)]), (0, 9100, [("M", 50)]),
               (0, 10050, [("M", 20)]), (0, 11050, [("M", 20)]), (0, 12050, [("M", 20)]), (0, 13050, [("M", 100)]), (0, 15100, [("M", 100)]),
-              (0, 30100, [("M", 100)]), (0, 31100, [("M", 100)]), (0, 32050, [("M", 100)]), (0, 40100, [("M", 100)]),
+              (0, 30100, [("M", 100)]), (0, 31100, [("M", 100)]), (0, 32050, [("M", 100)]), (0, 40100, [("M", 100)]), (16, 41100, [("M", 100)]), (0, 42050, [("M", 20)]),
               (0, 250, [("M", 20), ("N", 19800), ("M", 100)]), (16, 250, [("M", 20), ("N", 19800), ("M", 100)]), (16, 3100, [("M", 50), ("N", 16900), ("M", 100)])]]
     for k, (ref, flag, pos0, cigar) in enumerate(reads):
         rec = sam_record(j, ref, flag, pos0, cigar)
