@@ -85,7 +85,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--e2e-reads", type=int, default=500_000,
                     help="reads of the bounded end-to-end leg (FASTQ text -> passed/failed text), reported beside `value`; 0 = skip")
-    ap.add_argument("--e2e-lanes", default="1,2,3", help="worker lanes the end-to-end leg is run on, one run per count (a profile wants 1)")
+    ap.add_argument("--e2e-lanes", default="1,2,4", help="worker lanes the end-to-end leg is run on, one run per count (a profile wants 1)")
     ap.add_argument("--two-pass-reads", type=int, default=200_000, help="reads per rank of the two-pass leg with the RCCL exchange; 0 = skip")
     ap.add_argument("--config", type=int, default=1, choices=(1, 2, 4), help="BASELINE configs[1] (default), configs[2] (ed<=2 two-pass) or configs[4] (5' --noPolyARequired, 737K whitelist, UMI clustering)")
     ap.add_argument("--batch", type=int, default=10_000_000, help="--config 2: reads per batch resident in HBM")
