@@ -327,6 +327,24 @@ def test_long_reads(pkg, synth, sor, gpu_ctx):
     assert bytes(nat_p) == exp_p and bytes(nat_f) == exp_f
 
 
+def test_very_long_reads(pkg, synth, sor, gpu_ctx):
+    """ultra-long reads (a few hundred kb to over a megabase, as a genomic or concatemer-rich run can hold) among ordinary ones: text worker and packed worker
+    write the oracle's records; nothing in the per-read loops (32-bit plane offsets, 2048-base segments, the writer's runs) is bound to cDNA lengths"""
+    wl = synth.make_whitelist(20_000, seed=981)
+    used = synth.pick_used(wl, 50, seed=982)
+    reads = synth.gen_reads(10, used, seed=983, n_rate=0.001, max_mid=1_400_000)
+    sq = [synth.materialize(reads, i) for i in range(10)]
+    seqs, quals = [s_ for s_, _ in sq], [q for _, q in sq]
+    assert max(len(s_) for s_ in seqs) > 700_000 and sum(len(s_) > 100_000 for s_ in seqs) >= 3
+    gpu_ctx.set_barcode_set(used.numpy().astype(np.uint64), mode=0)
+    text = _fastq(seqs, quals)
+    exp_p, exp_f, n_p = _oracle_records(sor, sor.BarcodeSet(used.numpy()), seqs, quals, 1, {}, 1)
+    nat_p, nat_f, info = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=1)
+    assert bytes(nat_p) == exp_p and bytes(nat_f) == exp_f and info["n_passed"] == n_p
+    pk_p, pk_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, max_ed=1, packed=True, n_threads=3)
+    assert bytes(pk_p) == exp_p and bytes(pk_f) == exp_f
+
+
 def test_worker_lanes_share_one_barcode_set(pkg, synth, sor, gpu_ctx):
     """smi_ctx_create_lane / smi_ctx_lane_refresh: two lanes driven from two host threads at once give the records the owner gives (which
     the tests above compare with the oracle), before and after the owner loads another set; K-BC1 takes its table path on the lanes too
