@@ -310,7 +310,7 @@ def assignumis(argv):
         raise CliError(f"input BAM {o['inFileNanopore']} does not exist")
     if "annotationFile" in o:
         st = o["annotationFile"]
-        base = st[:-3] if st.endswith(".gz") else st
+        base = st[:-3] if st.endswith(".gz") else st[:-4] if st.endswith(".bz2") else st       # (GeneAnnotationReader.loadAnnotationsFile L47-48 strips both)
         if not (base.endswith(".gtf") or base.lower().endswith(".refflat")):
             raise CliError(f"Annotation file name is {st} file name should end with .gtf or .refFlat")       # (UmiFinderMain.java:L255-256)
     if "annotationFile" in o and not os.path.isfile(o["annotationFile"]):
@@ -322,9 +322,11 @@ def assignumis(argv):
     from . import assignumis as au
     refflat = None
     if "annotationFile" in o:          # refFlat text, gz or plain (picard's RefFlatReader through IOUtil)
-        with (gzip.open if o["annotationFile"].endswith(".gz") else open)(o["annotationFile"], "rt") as f:
+        import bz2
+        an = o["annotationFile"]
+        with (gzip.open if an.endswith(".gz") else bz2.open if an.endswith(".bz2") else open)(an, "rt") as f:
             refflat = f.read()
-        if (o["annotationFile"][:-3] if o["annotationFile"].endswith(".gz") else o["annotationFile"]).endswith(".gtf"):
+        if (an[:-3] if an.endswith(".gz") else an[:-4] if an.endswith(".bz2") else an).endswith(".gtf"):
             from . import lib as _l
             refflat = _l.GtfText(refflat)          # GeneAnnotationReader.loadAnnotationsFile L50-51: the GTF reader by the file's name
     bc_limit = None
