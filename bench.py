@@ -1123,11 +1123,14 @@ def main():
     f_scan = roofline_entry("k_scan<10>", "k_scan", k_scan, ALG_BYTES_PER_READ_SCAN, n, tj)
     f_bc1 = roofline_entry("k_bc_match_ed1<1> (k_bc_codes_ed1t + k_bc_pick_ed1t)", "k_bc_match_ed1", k_match, ALG_BYTES_PER_READ_BC1, n, tj)
     f_scan["limiter"] = "integer VALU issue (bit-parallel gates, Needleman-Wunsch cells): not hbm, not mfma"
-    f_bc1["limiter"] = "dependent 4/8-byte gathers into the offset filter and the neighbourhood table (L2 / Infinity Cache / HBM request rate)"
-    f_bc1["note"] = ("SURVEY 8d prices a read at 620 probes x 4 B; K-BC1 asks an exact 512 MiB bitmap of the set's inverse one-step neighbourhood "
-                     "(P.nb) once per offset and, where a barcode is in reach (1.6 of 5 offsets per read against the 3.6 M list), reads the "
-                     "matching mutation steps off one bucket of a table of that neighbourhood (P.nt) instead of making the 124 probes: the "
-                     "algorithmic figure counts probes answered, not bytes moved, so `frac` is the counter traffic over the HBM peak")
+    f_bc1["limiter"] = ("dependent gathers into the offset filter and the neighbourhood table (L2 / Infinity Cache / HBM request rate) together with "
+                        "integer VALU issue (the keys, the bucket's eight entries): since round 5's layout neither alone")
+    f_bc1["note"] = ("SURVEY 8d prices a read at 620 probes x 4 B; K-BC1 asks an exact bitmap of the set's inverse one-step neighbourhood once per "
+                     "offset -- laid out by the 12 bases the five windows of a read share (P.nb5, 2.5 GiB), so the five bits of a read are three "
+                     "64-byte sectors instead of five -- and, where a barcode is in reach (1.6 of 5 offsets per read against the 3.6 M list), reads "
+                     "the matching mutation steps off one bucket of a table of that neighbourhood (P.nt, three slots per entry: a second bucket "
+                     "is rare) instead of making the 124 probes: the algorithmic figure counts probes answered, not bytes moved, so `frac` is "
+                     "the counter traffic over the HBM peak")
     probe = hbm_probe(dev) if world == 1 else None
     if probe and "gather_512MiB_G_per_s" in probe and tj and "k_bc_match_ed1" in tj and tj["k_bc_match_ed1"].get("l2_misses_per_launch"):
         # K-BC1 against what random sector reads can reach on this GPU: its L2 misses per second beside the measured gather rates

@@ -91,11 +91,36 @@ __global__ void k_set_n2(const uint32_t *__restrict__ keys, size_t n, const uint
 
 // K-BC1's offset filter: the same inverse one-step neighbourhood, one exact bit per key (512 MiB).  An offset whose window K has its bit
 // clear has no barcode among K and its 123 mutants, so none of its 124 probes is made.
-__global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ nb) {
+//
+// nb5: the same bits where the five probes of a read are neighbours.  The windows of the five offsets (-2 .. 2) are one 20-base stretch cut at five
+// places, so they share their 12 middle bases: in the key of offset d (d = the offset for 3' barcoding, where the key is the reverse complement, and
+// minus the offset for 5') that core sits at base positions 2 + d .. 13 + d, with 2 + d flank bases in front of it and 2 - d behind.  nb5 is indexed by
+// the core first: 40 words per core, eight words (256 bits, one per value of the four flank bases) for each d.  A read's five filter bits then lie in
+// 160 consecutive bytes -- three 64-byte sectors -- instead of five random sectors of the 512 MiB bitmap.  A window with an N has an unrelated key (the
+// emulation in make_key) and simply lands elsewhere: every (d, key) pair has its own bit, so the test is nb's for any key.  2.5 GiB.
+constexpr size_t kNb5Words = ((size_t)1 << 24) * 40;
+__device__ __forceinline__ uint32_t nb5_bit_index(uint32_t key, int d, uint32_t &word) {
+    const int sh = 2 * (2 - d);                                             // bits of the flank behind the core: 8, 6, 4, 2, 0
+    const uint32_t core = (key >> sh) & 0xFFFFFFu;
+    const uint32_t low = (1u << sh) - 1u;
+    const uint32_t flank = ((key >> 24) & ~low & 0xFFu) | (key & low);      // the 2 + d leading bases above the 2 - d trailing ones
+    word = core * 40u + (uint32_t)(d + 2) * 8u + (flank >> 5);
+    return flank & 31u;
+}
+
+__global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ nb, uint32_t *__restrict__ nb5) {
     const size_t total = n * kN1Slots;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t x = n1_member(keys[i / kN1Slots], (int)(i % kN1Slots));
         atomicOr(&nb[x >> 5], 1u << (x & 31));
+        if (nb5) {
+#pragma unroll
+            for (int d = -2; d <= 2; d++) {
+                uint32_t w;
+                const uint32_t b = nb5_bit_index(x, d, w);
+                atomicOr(&nb5[w], 1u << b);
+            }
+        }
     }
 }
 
@@ -189,29 +214,52 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     SMI_HIP(hipMemcpyAsync(&last[0], ctx->rank + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     SMI_HIP(hipMemcpyAsync(&last[1], ctx->block_counts + (kRankEntries - 1), 4, hipMemcpyDeviceToHost, s));
     ctx->nb_valid = false;
+    ctx->nb5_valid = false;
     ctx->nt_cap = 0;
     if (n > 0 && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
         if (!ctx->nb) SMI_HIP(hipMalloc((void **)&ctx->nb, kFineWords * 4));
         SMI_HIP(hipMemsetAsync(ctx->nb, 0, kFineWords * 4, s));
         const unsigned gb = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 256);
-        hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, s, d_keys, n, ctx->nb);
+        // nb5 goes with the table path only (its kernel is the one that reads it); a device that cannot spare 2.5 GiB keeps the plain bitmap
+        ctx->nb5_valid = false;
+        const bool want_nb5 = !std::getenv("SMI_BC1_NO_TABLE") && !std::getenv("SMI_BC1_NO_NB5");  // (the second switch: cross-checks of the two layouts)
+        if (want_nb5 && !ctx->nb5 && hipMalloc((void **)&ctx->nb5, kNb5Words * 4) != hipSuccess) {
+            ctx->nb5 = nullptr;
+            (void)hipGetLastError();
+        }
+        if (want_nb5 && ctx->nb5) SMI_HIP(hipMemsetAsync(ctx->nb5, 0, kNb5Words * 4, s));
+        hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, s, d_keys, n, ctx->nb, want_nb5 ? ctx->nb5 : nullptr);
         SMI_HIP(hipGetLastError());
         ctx->nb_valid = true;
+        ctx->nb5_valid = want_nb5 && ctx->nb5 != nullptr;
         ctx->nt_cap = 0;
         if (!std::getenv("SMI_BC1_NO_TABLE")) {  // (the switch: the filtered kernel that enumerates the mutants of the flagged offsets)
             const size_t pairs = n * (size_t)kN1Slots;
-            const size_t cap = (std::max<size_t>(4096, pairs + pairs / 2 + pairs / 10) + 7) & ~(size_t)7;
+            // Slots per pair.  A look-up walks on to the next bucket when its own is full, and a WAVE walks on when one of its ~ 20 look-ups does: at
+            // 1.6 slots per pair (five entries per eight-slot bucket on average) 13 % of the buckets are full and nearly every wave paid a second bucket
+            // (a dependent miss and ~ 200 instructions: 458 VALU instructions per wave where one bucket takes ~ 320); at 3 slots per pair 0.6 % are and one
+            // wave in nine does.  14.6 GB for the 3.6 M list (7.8 GB at 1.6, which a device short of memory still gets; without either: the enumerating
+            // kernel behind the offset filter).
+            auto cap_at = [&](size_t tenths) { return (std::max<size_t>(4096, pairs * tenths / 10) + 7) & ~(size_t)7; };
+            size_t cap = cap_at(30);
+            if (cap >= 0xFFFFFFFFull) cap = cap_at(16);
             if (cap < 0xFFFFFFFFull) {
                 if (ctx->nt_alloc < cap) {
                     if (ctx->nt) SMI_HIP(hipFree(ctx->nt));
                     ctx->nt = nullptr;
                     ctx->nt_alloc = 0;
-                    // 7.8 GB for the 3.6 M list: a device that cannot spare them runs the enumerating kernel behind the offset filter
                     if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)) == hipSuccess)
                         ctx->nt_alloc = cap;
                     else {
                         ctx->nt = nullptr;
                         (void)hipGetLastError();
+                        cap = cap_at(16);
+                        if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)) == hipSuccess)
+                            ctx->nt_alloc = cap;
+                        else {
+                            ctx->nt = nullptr;
+                            (void)hipGetLastError();
+                        }
                     }
                 }
                 if (ctx->nt_alloc >= cap) {
@@ -909,8 +957,14 @@ __global__ __launch_bounds__(256) void k_bc_codes_ed1t(const smi_bc_window *__re
             // own load stands in front of the probe
             const OffsetKey k = make_key(my.bases, my.nmask, off, fp);
             const uint32_t K = k.key;
-            const uint32_t word = P.nb[K >> 5];
-            if ((my.flags & SMI_WIN_VALID) && k.usable && ((word >> (K & 31u)) & 1u)) {
+            uint32_t word, wbit = K & 31u;
+            if (P.nb5) {  // (wave-uniform) the five lanes of a read ask for neighbouring words: three sectors per read instead of five
+                uint32_t wi;
+                wbit = nb5_bit_index(K, fp ? -off : off, wi);
+                word = P.nb5[wi];
+            } else
+                word = P.nb[K >> 5];
+            if ((my.flags & SMI_WIN_VALID) && k.usable && ((word >> wbit) & 1u)) {
                 uint32_t best = 255u;
                 uint32_t idx = nt_slot(K, P.nt_cap);
                 for (;;) {

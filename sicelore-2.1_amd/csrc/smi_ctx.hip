@@ -44,6 +44,7 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.n2 = ctx->n1_valid ? ctx->n1 + kL1Words : nullptr;
     p.nb2 = ctx->n1_valid && ctx->nb2_valid ? ctx->n1_owner : nullptr;
     p.nb = ctx->nb_valid ? ctx->nb : nullptr;
+    p.nb5 = ctx->nb_valid && ctx->nb5_valid ? ctx->nb5 : nullptr;
     p.nt = ctx->nb_valid && ctx->nt_cap ? ctx->nt : nullptr;
     p.nt_cap = ctx->nt_cap;
     return p;
@@ -200,6 +201,8 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->nb2_valid = o->nb2_valid;
     lane->nb = o->nb;
     lane->nb_valid = o->nb_valid;
+    lane->nb5 = o->nb5;
+    lane->nb5_valid = o->nb5_valid;
     lane->nt = o->nt;
     lane->nt_cap = o->nt_cap;
     lane->fine = o->fine;
@@ -223,6 +226,7 @@ int smi_ctx_destroy(smi_ctx *ctx) {
         (void)hipFree(ctx->t2);
         (void)hipFree(ctx->n1);
         (void)hipFree(ctx->nb);
+        (void)hipFree(ctx->nb5);
         (void)hipFree(ctx->nt);
         (void)hipFree(ctx->n1_owner);
         (void)hipFree(ctx->fine);

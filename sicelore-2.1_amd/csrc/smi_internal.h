@@ -102,6 +102,7 @@ struct Pyramid {
     const uint32_t *n2;  // ... from which TWO OR MORE different barcodes can be reached (same layout)
     const uint32_t *nb2; // K-BC2's offset filter for short used lists (else null): 1 bit per key, set for every sequence TWO steps away from a barcode
     const uint32_t *nb;  // K-BC1's offset filter (else null): 1 bit per key, set for every sequence one mutation step away from a barcode (512 MiB)
+    const uint32_t *nb5; // the same filter laid out by the 12 bases the five offsets' windows share (else null; smi_bc.hip "nb5"): the five bits of a read in 160 consecutive bytes
     const uint64_t *nt;  // K-BC1's neighbourhood table (else null): open addressing, entry = 1 << 40 | sequence << 8 | the step that leads from it to a barcode
     uint32_t nt_cap;     // its slots
 };
@@ -120,6 +121,8 @@ struct smi_ctx {
     float polya_frac = 0.0f;
     bool nb2_valid = false;   // the build scratch n1_owner holds the two-step neighbourhood bitmap of the set that is loaded now
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
+    uint32_t *nb5 = nullptr;  // allocated with the first neighbourhood table (2.5 GiB); nb5_valid: describes the set that is loaded now
+    bool nb5_valid = false;
     uint32_t *n1_owner = nullptr;  // scratch of the n2 build (one u32 per n1 cell, 512 MiB), kept: hipMalloc / hipFree of that size cost ~100 ms per set load
     bool nb_valid = false;
     uint64_t *nt = nullptr;   // grown on demand: 1.6 slots of 8 bytes per (barcode, step) pair, 7.8 GB for the 3.6 M list

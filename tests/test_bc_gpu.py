@@ -355,6 +355,10 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     got2 = None
     if case == "ed1_adversarial":  # the same set through K-BC2 as well
         got2 = _run_device(pkg, gpu_ctx, win, 2, five_prime)
+    monkeypatch.setenv("SMI_BC1_NO_NB5", "1")    # K-BC1's table path with the plain 512 MiB filter bitmap instead of the one laid out by the shared core (nb5)
+    gpu_ctx.set_barcode_set(keys, mode=mode)
+    assert (with_filter.view(np.uint8) == _run_device(pkg, gpu_ctx, win, max_ed, five_prime).view(np.uint8)).all()
+    monkeypatch.delenv("SMI_BC1_NO_NB5")
     monkeypatch.setenv("SMI_BC1_NO_TABLE", "1")  # K-BC1: offset filter, mutants of the flagged offsets enumerated (k_bc_match_ed1f)
     monkeypatch.setenv("SMI_BC2_NO_TABLE", "1")  # K-BC2: level 2 by enumeration of the items the filter lets through (read at launch)
     gpu_ctx.set_barcode_set(keys, mode=mode)
