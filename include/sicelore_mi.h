@@ -81,7 +81,10 @@ typedef struct {
 
 typedef enum {
     SMI_SET_USED_LIST = 0, /* pass-2 search set = used-barcode list (WorkerReadscanner$BarcodesMapForBCfinding) */
-    SMI_SET_WHITELIST = 1  /* -g/--cellRangerBCs: search set = the whole list (NanoporeReadScannerMain.java:L300-302) */
+    SMI_SET_WHITELIST = 1, /* -g/--cellRangerBCs: search set = the whole list (NanoporeReadScannerMain.java:L300-302) */
+    SMI_SET_MEMBERSHIP = 2 /* the list of all possible barcodes as pass 1 uses it (UsedCellBCListGenerator.java:L207-229: exact membership + histogram): the
+                            * pyramid only, none of the matchers' neighbourhood structures (3.6 M barcodes: ~ 10 ms instead of ~ 300).  A matcher call on
+                            * such a set still answers, through the pyramid kernels */
 } smi_set_mode;
 
 const char *smi_last_error(void);
@@ -110,8 +113,9 @@ int smi_ctx_lane_refresh(smi_ctx *lane);
  * inverse one-step neighbourhood (169 sequences per barcode), what lets the matchers skip the reference's mutant enumeration without
  * changing a result: an exact bitmap of that neighbourhood (512 MiB) and a table of it with the mutation step back to the barcode in every
  * entry (13.5 bytes per neighbour: 7.8 GB for 3.6 M barcodes, 11 MB for 5 k; left out when the device cannot spare it); for lists of up to
- * 65,536 / 32,768 barcodes also the item filter and the two-step bitmap of the ed <= 2 matcher (32 MiB + a 512 MiB scratch).  3.6 M barcodes
- * load in ~125 ms, a used list in < 1 ms.  Results never depend on these structures ("Switches"). */
+ * 65,536 / 32,768 barcodes also the item filter and the two-step bitmap of the ed <= 2 matcher (32 MiB + a 512 MiB scratch).  Round 5: the neighbourhood bitmap
+ * a second time in the layout that makes a read's five probes neighbours (2.5 GiB) and the table at three slots per entry (14.6 GB for 3.6 M barcodes).  3.6 M barcodes
+ * load in ~300 ms (SMI_SET_MEMBERSHIP: ~10 ms), a used list in a few ms.  Results never depend on these structures ("Switches"). */
 int smi_set_barcode_set(smi_ctx *ctx, const uint64_t *keys, size_t n, int mode);
 int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, int mode, void *stream);
 

@@ -185,7 +185,7 @@ __global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restr
                 __popc(c.w);
 }
 
-int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s) {
+int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s, bool membership_only) {
     SMI_HIP(hipMemsetAsync(ctx->l0, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l0s, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l1, 0, kL1Words * 4, s));
@@ -216,7 +216,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     ctx->nb_valid = false;
     ctx->nb5_valid = false;
     ctx->nt_cap = 0;
-    if (n > 0 && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
+    if (n > 0 && !membership_only && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
         if (!ctx->nb) SMI_HIP(hipMalloc((void **)&ctx->nb, kFineWords * 4));
         SMI_HIP(hipMemsetAsync(ctx->nb, 0, kFineWords * 4, s));
         const unsigned gb = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 256);
@@ -273,7 +273,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     }
     ctx->n1_valid = false;
     ctx->nb2_valid = false;
-    if (n > 0 && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
+    if (n > 0 && !membership_only && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
         if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 2 * kL1Words * 4));
         SMI_HIP(hipMemsetAsync(ctx->n1, 0, 2 * kL1Words * 4, s));
         if (!ctx->n1_owner) SMI_HIP(hipMalloc((void **)&ctx->n1_owner, kL1Words * 32 * sizeof(uint32_t)));  // one u32 per cell

@@ -324,12 +324,12 @@ int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, i
         return SMI_ERR_STATE;
     }
     if (int rc = bind(ctx)) return rc;
-    if ((!d_keys && n) || (mode != SMI_SET_USED_LIST && mode != SMI_SET_WHITELIST)) {
+    if ((!d_keys && n) || (mode != SMI_SET_USED_LIST && mode != SMI_SET_WHITELIST && mode != SMI_SET_MEMBERSHIP)) {
         set_error("smi_set_barcode_set_device: bad argument");
         return SMI_ERR_INVALID;
     }
     ctx->set_mode = -1;
-    if (int rc = launch_build_pyramid(ctx, d_keys, n, (hipStream_t)stream)) return rc;
+    if (int rc = launch_build_pyramid(ctx, d_keys, n, (hipStream_t)stream, mode == SMI_SET_MEMBERSHIP)) return rc;
     ctx->set_mode = mode;
     return SMI_OK;
 }

@@ -192,7 +192,7 @@ int launch_bc_match(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int max_
                     smi_bc_result *d_out, hipStream_t s);
 int launch_extract_windows(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t *d_offsets, const int32_t *d_ae,
                            size_t n, int five_prime, smi_bc_window *d_win, hipStream_t s);
-int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s);
+int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s, bool membership_only = false);
 int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
                 hipStream_t s);
 int launch_bc_counts(smi_ctx *ctx, const smi_bc_result *d_res, size_t n, uint32_t *d_counts, hipStream_t s);

@@ -42,6 +42,7 @@ assert CHIMERA_RESULT_DTYPE.itemsize == 16
 
 SET_USED_LIST = 0
 SET_WHITELIST = 1
+SET_MEMBERSHIP = 2   # the list of all possible barcodes for pass 1 only: membership pyramid, no matcher structures (smi_set_mode)
 
 # every symbol include/sicelore_mi.h declares (tests check the export table against this list)
 EXPORTS = [

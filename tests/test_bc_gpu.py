@@ -388,6 +388,25 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     gpu_ctx.set_barcode_set(keys, mode=mode)  # leave the context with its filters on
 
 
+def test_membership_only_set_answers_like_the_full_one(pkg, synth, gpu_ctx):
+    """SMI_SET_MEMBERSHIP (what pass 1 loads: the pyramid, none of the matchers' neighbourhood structures): a matcher call on it goes through the pyramid
+    kernels and gives the full set's results; the pass-1 histogram is the same"""
+    from sicelore_amd import lib as libmod
+
+    wl = synth.make_whitelist(300_000, seed=91)
+    used = synth.pick_used(wl, 2000, seed=92)
+    reg = synth.gen_bc_region(40_000, used, seed=93, n_rate=0.002)
+    win = synth.pack_windows(reg["codes"], reg["ae"], False)
+    keys = wl.numpy().astype(np.uint64)
+    gpu_ctx.set_barcode_set(keys, mode=libmod.SET_WHITELIST)
+    full = {ed: _run_device(pkg, gpu_ctx, win, ed, False) for ed in (0, 1)}
+    gpu_ctx.set_barcode_set(keys, mode=libmod.SET_MEMBERSHIP)
+    for ed in (0, 1):
+        assert (_run_device(pkg, gpu_ctx, win, ed, False).view(np.uint8) == full[ed].view(np.uint8)).all()
+    assert int((full[1]["found"] == 1).sum()) > 10_000
+    gpu_ctx.set_barcode_set(keys, mode=libmod.SET_WHITELIST)
+
+
 @pytest.mark.parametrize("max_ed", [0, 1, 2])
 def test_empty_and_single_key_sets(pkg, synth, sor, gpu_ctx, max_ed):
     """the two smallest barcode sets: none (every structure empty, no filter or table built) and one barcode"""
