@@ -100,7 +100,7 @@ int smi_ctx_device(const smi_ctx *ctx);
  * created or refreshed.  Limits of this build (175 scanned bases per end): 5 <= length <= 30, window + length + 10 <= 175. */
 int smi_ctx_set_polya(smi_ctx *ctx, int polya_len, float polya_frac, int window_polya);
 /* A worker lane of `owner`: a context with its own stream, device arena, pinned output buffers and timing that READS the owner's barcode
- * set instead of holding the 616 MiB membership pyramid and the neighbourhood bitmap and table (up to 8.3 GB for the whole whitelist) again -- several host threads, one lane each, overlap their uploads, kernels and
+ * set instead of holding the 616 MiB membership pyramid and the neighbourhood bitmaps and table (up to 18 GB for the whole whitelist) again -- several host threads, one lane each, overlap their uploads, kernels and
  * downloads on one GPU over ONE set, as the reference's nCPU Parser workers share one hashMapForBCfinding
  * (FJ!nanoporereadscanner/WorkerReadscanner.java:L188-204).  Every entry point takes a lane except smi_set_barcode_set*: load the set on the
  * owner (no lane busy meanwhile), then smi_ctx_lane_refresh each lane.  Destroy the lanes before the owner. */
@@ -112,7 +112,7 @@ int smi_ctx_lane_refresh(smi_ctx *lane);
  * keys: n 16-nt barcodes, 2-bit packed in the low 32 bits.  Builds the HBM-resident membership pyramid (616 MiB) and, from the set's
  * inverse one-step neighbourhood (169 sequences per barcode), what lets the matchers skip the reference's mutant enumeration without
  * changing a result: an exact bitmap of that neighbourhood (512 MiB) and a table of it with the mutation step back to the barcode in every
- * entry (13.5 bytes per neighbour: 7.8 GB for 3.6 M barcodes, 11 MB for 5 k; left out when the device cannot spare it); for lists of up to
+ * entry (three eight-byte slots per neighbour: 14.6 GB for 3.6 M barcodes, 20 MB for 5 k; 1.6 slots or none at all where the device cannot spare them); for lists of up to
  * 65,536 / 32,768 barcodes also the item filter and the two-step bitmap of the ed <= 2 matcher (32 MiB + a 512 MiB scratch).  Round 5: the neighbourhood bitmap
  * a second time in the layout that makes a read's five probes neighbours (2.5 GiB) and the table at three slots per entry (14.6 GB for 3.6 M barcodes).  3.6 M barcodes
  * load in ~300 ms (SMI_SET_MEMBERSHIP: ~10 ms), a used list in a few ms.  Results never depend on these structures ("Switches"). */
