@@ -203,6 +203,74 @@ __global__ __launch_bounds__(256) void k_pack_reads(const uint8_t *__restrict__ 
     }
 }
 
+// K-PACKR, flat (round 5): a thread per PLANE WORD instead of a wave per read.  The planes tile the word axis (read r owns words plane_start(offsets[r], r) ..
+// plane_start(offsets[r + 1], r + 1): its data words, then four or five zero words), so word g belongs to the last read whose start is <= g: a binary search over
+// the offsets (once per wave, for its first word; the lanes step on from there), then the word's 32 characters as two 16-byte loads, the encoder, four stores.
+// Every lane has a word whatever the read lengths are -- a wave per read kept 42 of 64 lanes busy on 1,300-base reads and paid a round trip per read for its
+// offsets.  The words between a read's data and the next read are written as zeros (all of them; the wave kernel left the fifth one alone, nobody reads it).
+template <bool kStarts>
+__global__ __launch_bounds__(256) void k_pack_reads_flat(const uint8_t *__restrict__ reads, const uint64_t *__restrict__ offsets,
+                                                         const uint64_t *__restrict__ starts, size_t n, size_t stride, uint64_t total_bases,
+                                                         uint32_t *__restrict__ planes) {
+    const size_t n_words_all = plane_start(total_bases, n);  // behind the last read's words: not written (as before)
+    // every wave takes a CONTIGUOUS run of 64-word tiles: one binary search for its first word (uniform: scalar loads), then the lanes step from read to read as
+    // their words move on (a tile spans one or two reads of ordinary length, a dozen of the shortest) -- no search, and no far jump, per tile
+    const size_t n_tiles = (n_words_all + 63) / 64;
+    const size_t wave = (blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6, n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t per = (n_tiles + n_waves - 1) / n_waves;
+    const size_t t_begin = wave * per, t_end = min(n_tiles, t_begin + per);
+    if (t_begin >= t_end) return;
+    size_t r;
+    {
+        const size_t g0 = t_begin * 64;
+        size_t lo = 0, hi = n;
+        while (hi - lo > 1) {
+            const size_t mid = (lo + hi) >> 1;
+            if (plane_start(offsets[mid], mid) <= g0)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        r = lo;
+    }
+    for (size_t t = t_begin; t < t_end; t++) {
+        const size_t g = t * 64 + (threadIdx.x & 63);
+        if (g >= n_words_all) break;
+        while (r + 1 < n && plane_start(offsets[r + 1], r + 1) <= g) r++;
+        const uint64_t beg = offsets[r], end = offsets[r + 1];
+        const int64_t len = (int64_t)(end - beg), w = (int64_t)g - (int64_t)plane_start(beg, r), p0 = 32 * w;
+        if (w < 0) continue;  // (offsets[0] > 31: words in front of the first read belong to nobody)
+        uint32_t pl[4] = {0, 0, 0, 0};
+        if (p0 < len) {
+            const uint64_t src = (kStarts ? starts[r] : beg) + (uint64_t)p0;
+            uint32_t v[8];
+            // the partial last word takes the same two loads when the bytes behind the read's end exist (k_pack_reads has the argument)
+            const bool wide = p0 + 32 <= len || (kStarts ? len >= 29 : beg + (uint64_t)p0 + 32 <= total_bases);
+            if (wide) {
+                __builtin_memcpy(v, reads + src, 32);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v[k] = 0;
+                for (int i = 0; i < (int)(len - p0); i++) {
+                    const uint32_t b = (uint32_t)reads[src + i] << (8 * (i & 3));
+#pragma unroll
+                    for (int k = 0; k < 8; k++) v[k] |= (i >> 2) == k ? b : 0u;
+                }
+            }
+            const int nb = (int)min((int64_t)32, len - p0);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t code = enc4x4<false>(v[k]);
+                if (4 * k + 4 > nb) code &= 4 * k >= nb ? 0u : (0xFFFFFFFFu >> (8 * (4 * k + 4 - nb)));
+#pragma unroll
+                for (int c = 0; c < 4; c++) pl[c] |= plane_nibble(code, c) << (4 * k);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) planes[c * stride + g] = pl[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // K-CHIM
 // ---------------------------------------------------------------------------------------------------------------
@@ -2620,9 +2688,19 @@ size_t read_planes_stride(uint64_t total_bases, size_t n) { return (size_t)(tota
 int launch_pack_reads(smi_ctx *, const uint8_t *d_reads, const uint64_t *d_offsets, const uint64_t *d_starts, size_t n,
                       uint64_t total_bases, uint32_t *d_planes, hipStream_t s) {
     if (!n) return SMI_OK;
-    const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(d_starts ? k_pack_reads<true> : k_pack_reads<false>, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, read_planes_stride(total_bases, n),
-                       total_bases, d_planes);
+    const bool by_wave = getenv("SMI_PACKR_WAVE") != nullptr;  // the wave-per-read kernel of rounds 2 - 4 (cross-checks)
+    if (by_wave) {
+        const unsigned grid = (unsigned)std::min<size_t>((n + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(d_starts ? k_pack_reads<true> : k_pack_reads<false>, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n, read_planes_stride(total_bases, n),
+                           total_bases, d_planes);
+    } else {
+        const size_t words = plane_start(total_bases, n);
+        // 4,096 workgroups: measured (0.9 M reads: 512 / 1,024 / 2,048 / 4,096 / 16,384 / 65,536 workgroups -> 1.02 / 0.77 / 0.65 / 0.62 / 0.65 / 0.86 ms; a wave's one
+        // binary search wants a long run of tiles behind it, the memory system wants enough waves)
+        const unsigned grid = (unsigned)std::min<size_t>((words + 255) / 256, 4096);
+        hipLaunchKernelGGL(d_starts ? k_pack_reads_flat<true> : k_pack_reads_flat<false>, dim3(grid), dim3(256), 0, s, d_reads, d_offsets, d_starts, n,
+                           read_planes_stride(total_bases, n), total_bases, d_planes);
+    }
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

@@ -161,3 +161,48 @@ def test_chimera_5p_configuration(pkg, sor, synth):
         assert got == splits and bool(res["flags"][i] & 1) == multi and res["n_matches"][i] == n_matches, (i, got, splits)
         n_split += len(splits) > 0
     assert n_split > 300
+
+
+def test_flat_read_packer_equals_the_wave_per_read_one(pkg, synth, monkeypatch):
+    """K-PACKR as a thread per plane word (round 5) against the wave-per-read kernel (SMI_PACKR_WAVE) on reads of every length class -- empty, 1 .. 40 bases, around
+    the 32-base word and 2048-base wave borders, tens of kilobases -- from a gathered array and from FASTQ text: the same planes word for word"""
+    import torch
+
+    from sicelore_amd import lib as libmod
+
+    ctx = pkg.Context(0)
+    rng = np.random.default_rng(77)
+    lens = np.concatenate([np.arange(0, 70), rng.integers(1, 3000, 600), np.array([2047, 2048, 2049, 4096, 4097, 31, 32, 33, 63, 64, 65, 30_000, 70_001]),
+                           rng.integers(200, 2000, 400)])
+    rng.shuffle(lens)
+    n = lens.size
+    seqs = ["".join(rng.choice(list("ACGTN"), int(k), p=[0.245, 0.245, 0.245, 0.245, 0.02])) for k in lens]
+    offs = np.zeros(n + 1, dtype=np.int64)
+    offs[1:] = np.cumsum(lens)
+    total = int(offs[-1])
+    d_reads = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy()).cuda()
+    d_offs = torch.from_numpy(offs).cuda()
+    words = ctx.read_planes_words(total, n)
+    # the same reads as FASTQ text (names, '+' lines, qualities between them)
+    text, starts, at = [], [], 0
+    for i, q in enumerate(seqs):
+        head = f"@r{i} x\n"
+        starts.append(at + len(head))
+        rec = head + q + "\n+\n" + "I" * len(q) + "\n"
+        text.append(rec)
+        at += len(rec)
+    d_text = torch.from_numpy(np.frombuffer("".join(text).encode(), dtype=np.uint8).copy()).cuda()
+    d_starts = torch.from_numpy(np.array(starts, dtype=np.int64)).cuda()
+    got = {}
+    for mode in ("flat", "wave"):
+        if mode == "wave":
+            monkeypatch.setenv("SMI_PACKR_WAVE", "1")
+        a = torch.zeros(words, dtype=torch.int32, device="cuda")
+        b = torch.zeros(words, dtype=torch.int32, device="cuda")
+        ctx.pack_reads_device(d_reads, d_offs, n, total, a)
+        ctx.pack_reads_text_device(d_text, d_starts, d_offs, n, total, b)
+        torch.cuda.synchronize()
+        got[mode] = (a.cpu().numpy(), b.cpu().numpy())
+    monkeypatch.delenv("SMI_PACKR_WAVE")
+    assert (got["flat"][0] == got["wave"][0]).all() and (got["flat"][1] == got["wave"][1]).all() and (got["flat"][0] == got["flat"][1]).all()
+    assert int((got["flat"][0] != 0).sum()) > total // 64
