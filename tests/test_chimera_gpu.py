@@ -163,6 +163,7 @@ def test_chimera_5p_configuration(pkg, sor, synth):
     assert n_split > 300
 
 
+@pytest.mark.gpu
 def test_flat_read_packer_equals_the_wave_per_read_one(pkg, synth, monkeypatch):
     """K-PACKR as a thread per plane word (round 5) against the wave-per-read kernel (SMI_PACKR_WAVE) on reads of every length class -- empty, 1 .. 40 bases, around
     the 32-base word and 2048-base wave borders, tens of kilobases -- from a gathered array and from FASTQ text: the same planes word for word"""
