@@ -99,6 +99,59 @@ int smi_ctx_device(const smi_ctx *ctx);
  * the shipped one); the chimera splitter's distance from the read ends follows the window.  Lanes take the values of their owner when they are
  * created or refreshed.  Limits of this build (175 scanned bases per end): 5 <= length <= 30, window + length + 10 <= 175. */
 int smi_ctx_set_polya(smi_ctx *ctx, int polya_len, float polya_frac, int window_polya);
+
+/* The knobs of Jar/config.xml that shape the per-read algorithms, as RUN-TIME parameters of a context (round 6): what
+ * ParametersReadScannerApp / ParametersBarcodeUMiFinderAppParams hold after JAXB has read the file (FJ!nanoporereadscanner/parameters/
+ * ParametersReadScannerApp.java:L84-130, FJ!parameters/{ReadScannerParameters,PolyATparameters,AdapterParameters,Adapter5p_5pBC_Parameters,
+ * Adapter3p_5pBC_Parameters,TSOparameters_3pBarcoding,UMIparameters}.java).  Every chunk worker of the context (smi_scanfastq_pass{1,2}_chunk[_packed],
+ * _keys) builds its scan / splitter configuration from these instead of the shipped values; lanes take their owner's when they are created
+ * or refreshed.  Where each knob acts (reference unit -> kernel):
+ *   min_read_length               PolyATadapterAnalyzerBase.java:L109-118 (READ_TOO_SHORT)                              K-SCAN
+ *   min_mean_bc_qv / _read_qv / min_adapter_3p_matches   UsedCellBCListGenerator$Worker.java:L198-202 (pass 1 only)       K-SCAN
+ *   polya_len / polya_frac / window_polya                PolyATSearcher.java:L56-252 (also -p -f -w: smi_ctx_set_polya wins) K-SCAN, K-CHIM
+ *   internal_pat_len / internal_pat_frac                 PolyATadapterInternalSearcherBase.java:L78-270                   K-CHIM
+ *   adapter3p / adapter3p_complete / adapter3p_max_mm    Parser.java:L134-136 (pass 2: sequence, pass 1: sequence_complete; both with
+ *                                                        maxNeedlemanMismatches)                                           K-SCAN
+ *   adapter3p_complete_max_mm, tso_complete, tso_complete_max_mm   ChimeraFindernew.java:L74-81 (3' barcoding)              K-CHIM
+ *   adapter5p*, adapter5p_window                         PolyATadapterAnalyzer_5pBCUMI.java:L43-76; max mismatches + 1 (Parser.java:L99) K-SCAN
+ *   adapter5p_complete + _max_mm, adapter3p5_complete + _max_mm    ChimeraFindernew.java:L75-78 (5' barcoding)              K-CHIM
+ *   umi_length                                           ChimeraFindernew.java:L74 (cell_bc_length + umi_length between polyA and adapter) K-CHIM;
+ *                                                        the UMI stage takes it from smi_assignumis_config
+ * Limits of this build (checked by smi_ctx_set_knobs, message names the knob): sequence 10 bases, sequence_complete 22, the complete TSO 27,
+ * the complete 3' adapter of 5' barcoding 25, A / C / G / T only; the polyA limits of smi_ctx_set_polya; 8 <= umi_length <= 12;
+ * counts and mismatch limits 0 .. 30.  Compiled in (no knob): the TSO of the read scan (tso_for3pBarcoding sequence, maxNeedlemanMismatches,
+ * minTSO_*, windowForTSOsearch), testPlusMinusPos = 2, cell_bc_length = 16, the read-name prefixes, nbasesOfAdapterSeqInReadname = 3. */
+typedef struct {
+    int32_t min_read_length;          /* readscanner/minReadLength                              config.xml:21   200 */
+    int32_t min_mean_bc_qv;           /* readscanner/minMeanBCqv                                :55   8 */
+    int32_t min_mean_read_qv;         /* readscanner/minMeanReadqv                              :57   8 */
+    int32_t min_adapter_3p_matches;   /* readscanner/minAdapter3pMatches                        :59   8 */
+    int32_t polya_len;                /* polyAT/polyATlength                                    :95   15 */
+    float polya_frac;                 /* polyAT/fractionATInPolyAT                              :97   0.75 */
+    int32_t window_polya;             /* polyAT/windowSearchForPolyA                            :105  150 */
+    int32_t internal_pat_len;         /* polyAT/internalpATlength                               :99   15 */
+    float internal_pat_frac;          /* polyAT/internalFractionATInPolyAT                      :101  0.70 */
+    char adapter3p[32];               /* adapter_for3pBarcoding/sequence                        :111  CTTCCGATCT */
+    char adapter3p_complete[32];      /* adapter_for3pBarcoding/sequence_complete               :113  CTACACGACGCTCTTCCGATCT */
+    int32_t adapter3p_max_mm;         /* adapter_for3pBarcoding/maxNeedlemanMismatches          :115  3 */
+    int32_t adapter3p_complete_max_mm;/* adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches :118 5 */
+    char adapter5p[32];               /* fiveprimeadapter_for5pBarcoding/sequence               :124  CTTCCGATCT */
+    char adapter5p_complete[32];      /* fiveprimeadapter_for5pBarcoding/sequence_complete      :126  CTACACGACGCTCTTCCGATCT */
+    int32_t adapter5p_max_mm;         /* fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches :129  3 */
+    int32_t adapter5p_complete_max_mm;/* .../maxCompleteSeqNeedlemanMismatches                  :132  5 */
+    int32_t adapter5p_window;         /* .../AdapterSearchWindow                                :134  110 */
+    char adapter3p5_complete[32];     /* threeprimeadapter_for5pBarcoding/sequence_complete     :141  AAGCAGTGGTATCAACGCAGAGTAC */
+    int32_t adapter3p5_complete_max_mm;/* .../maxCompleteSeqNeedlemanMismatches                 :146  5 */
+    char tso_complete[32];            /* tso_for3pBarcoding/sequence_complete                   :170  AAGCAGTGGTATCAACGCAGAGTACAT */
+    int32_t tso_complete_max_mm;      /* tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches   :172  6 */
+    int32_t umi_length;               /* umis/umi_length                                        :264  12 */
+    int32_t reserved[7];
+} smi_run_knobs;
+/* the shipped config.xml */
+int smi_run_knobs_default(smi_run_knobs *knobs);
+/* knobs == NULL: back to the shipped values.  SMI_ERR_INVALID (smi_last_error names the knob) for a value this build has no kernel for. */
+int smi_ctx_set_knobs(smi_ctx *ctx, const smi_run_knobs *knobs);
+int smi_ctx_get_knobs(const smi_ctx *ctx, smi_run_knobs *knobs);
 /* A worker lane of `owner`: a context with its own stream, device arena, pinned output buffers and timing that READS the owner's barcode
  * set instead of holding the 616 MiB membership pyramid and the neighbourhood bitmaps and table (up to 18 GB for the whole whitelist) again -- several host threads, one lane each, overlap their uploads, kernels and
  * downloads on one GPU over ONE set, as the reference's nCPU Parser workers share one hashMapForBCfinding
@@ -297,7 +350,8 @@ int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t 
  * L67-80 + apachemod/LevenshteinDistance.limitedCompare, threshold 4).
  * windows[r]: 14 bases of read r as 4-bit codes (A=1 G=2 C=4 T=8 N=15), base k in bits [4k+3:4k]: the bases
  * bcEnd .. bcEnd+13 (1-based bcEnd = barcode end on the tested read-name sequence, FastqRecordExt.java:L378), i.e. the
- * three 12-mers getSubSequence(bcEnd+1+i, 12), i = -1,0,+1.
+ * three 12-mers getSubSequence(bcEnd+1+i, 12), i = -1,0,+1.  With another umis/umi_length L on the context (smi_ctx_set_knobs; 8 .. 12): L + 2
+ * bases, the three L-mers (ClusteringEditDistanceBase.java:L316-329 cut params.umis.umi_length bases).
  * Groups = (cell barcode, genomic region) sets of reads (UmiClustering.java:L105): group g owns reads
  * [group_off[g], group_off[g+1]).  pair_off[g] = sum over earlier groups of n(n+1)/2, mat_off[g] = sum of n^2.
  * out + mat_off[g] is the n x n byte matrix of group g: ed | pos1 << 4 | pos2 << 6, ed in 0..5 (5 = above the
@@ -415,6 +469,12 @@ int smi_chimera_default_config(smi_chimera_config *cfg);
 /* 5' barcoding (ChimeraFindernew.java:L75-81: the 5' adapter is searched like the TSO, the 3' adapter next to internal
  * polyA/T, no barcode + UMI between them); only run when polyA is searched (Parser.java:L176) */
 int smi_chimera_default_config_5p(smi_chimera_config *cfg);
+/* The configurations the chunk workers of a context derive from its knobs (smi_ctx_set_knobs; knobs == NULL: the shipped file), for callers of
+ * the per-stage entry points: pass 1 scans with sequence_complete, pass 2 with sequence, 5' barcoding with maxNeedlemanMismatches + 1
+ * (Parser.java:L99,L134-136); the splitter's patterns and limits by protocol (ChimeraFindernew.java:L74-81).  The strings of the splitter's
+ * configuration point into *knobs (or into constants when knobs == NULL). */
+int smi_scan_config_from_knobs(const smi_run_knobs *knobs, int pass, int five_prime, int dont_search_polya, smi_scan_config *cfg);
+int smi_chimera_config_from_knobs(const smi_run_knobs *knobs, int five_prime, smi_chimera_config *cfg);
 
 /* u32 words the plane buffer of smi_pack_reads_device needs for n reads holding total_bases bases in all */
 size_t smi_read_planes_words(uint64_t total_bases, size_t n);
@@ -691,6 +751,9 @@ typedef struct {
                                   (ClusteringEditDistanceBase.java:L312-313, FastqRecordExt.java:L378); clustering position = reference
                                   position under read position AE + cell_bc_length + umi_length + grouping_distance
                                   (NanoporeRead$ReadScanData.java:L90-92) */
+    int32_t umi_length;        /* umis/umi_length (config.xml:264): 8 .. 12 in this build; 0 = the context's knob (smi_ctx_set_knobs), 12 without one.
+                                  The UMI windows are umi_length + 2 bases (the umi_length-mers at offsets -1 / 0 / +1 behind the barcode,
+                                  ClusteringEditDistanceBase.java:L316-329), U8 / U7 umi_length characters (OneNanoporeResult.java:L111) */
     const smi_umi_cluster_config *cluster; /* NULL: shipped values */
 } smi_assignumis_config;
 #define SMI_UMI_HAS_BC 1u    /* the name carries a barcode (the record goes to the output BAM) */
@@ -703,7 +766,7 @@ typedef struct {
     int8_t u1, u2;   /* tags U1 / U2 (-1: absent) */
     uint8_t flags;   /* SMI_UMI_* */
     uint8_t reserved;
-    char u8[12], u7[12];
+    char u8[12], u7[12]; /* umi_length characters, zero bytes behind them when umi_length < 12 */
 } smi_umi_tag;
 int smi_assignumis_default_config(smi_assignumis_config *cfg);
 int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint32_t *name_off, const uint16_t *flags, const int32_t *pos0,

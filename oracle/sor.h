@@ -128,6 +128,11 @@ void sor_umi_matrix(const uint8_t *windows, int n, uint8_t *out);
 int sor_umi_window_3p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14);
 int sor_umi_window_5p(const char *x, int xlen, int adapter_end, int bc_end, uint8_t *out14);
 int sor_limited_compare(const uint8_t *a, int n, const uint8_t *b, int m, int threshold);
+/* umis/umi_length other than 12 (config.xml:264): windows of umi_len + 2 codes */
+int sor_umi_pair_len(const uint8_t *w1, const uint8_t *w2, int umi_len);
+void sor_umi_matrix_len(const uint8_t *windows, int n, int umi_len, uint8_t *out);
+int sor_umi_window_3p_len(const char *x, int xlen, int adapter_end, int bc_end, int umi_len, uint8_t *out);
+int sor_umi_window_5p_len(const char *x, int xlen, int adapter_end, int bc_end, int umi_len, uint8_t *out);
 
 /* ---- pass-1 finalize (sor_final.c) ---- */
 int sor_finalize_used_list(const int64_t *keys, const uint32_t *counts, size_t n, uint32_t record_count, int merge_ed,

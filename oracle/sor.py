@@ -245,39 +245,42 @@ def finalize_used_list(keys, counts, record_count, merge_ed=1, min_count_fold=10
 
 
 # ---- UMI pair distances (sor_umi.c) --------------------------------------------------------------------------
-def umi_pair(w1, w2):
+def umi_pair(w1, w2, umi_len=12):
+    """w1, w2: umi_len + 2 4-bit codes each (umis/umi_length, config.xml:264: 12 as shipped)"""
     a = np.ascontiguousarray(w1, dtype=np.uint8)
     b = np.ascontiguousarray(w2, dtype=np.uint8)
+    assert a.size >= umi_len + 2 and b.size >= umi_len + 2
     L = lib()
-    L.sor_umi_pair.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    return int(L.sor_umi_pair(a.ctypes.data, b.ctypes.data))
+    L.sor_umi_pair_len.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    return int(L.sor_umi_pair_len(a.ctypes.data, b.ctypes.data, umi_len))
 
 
-def umi_matrix(windows):
-    """windows: uint8 [n, 14] 4-bit codes -> uint8 [n, n] packed (ed | pos1 << 4 | pos2 << 6)"""
+def umi_matrix(windows, umi_len=12):
+    """windows: uint8 [n, umi_len + 2] 4-bit codes -> uint8 [n, n] packed (ed | pos1 << 4 | pos2 << 6)"""
     w = np.ascontiguousarray(windows, dtype=np.uint8)
     n = w.shape[0]
+    assert n == 0 or w.shape[1] == umi_len + 2
     out = np.zeros((n, n), dtype=np.uint8)
     L = lib()
-    L.sor_umi_matrix.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
-    L.sor_umi_matrix.restype = None
-    L.sor_umi_matrix(w.ctypes.data, n, out.ctypes.data)
+    L.sor_umi_matrix_len.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.sor_umi_matrix_len.restype = None
+    L.sor_umi_matrix_len(w.ctypes.data, n, umi_len, out.ctypes.data)
     return out
 
 
-def umi_window_3p(x, adapter_end, bc_end):
-    out = np.zeros(14, dtype=np.uint8)
+def umi_window_3p(x, adapter_end, bc_end, umi_len=12):
+    out = np.zeros(umi_len + 2, dtype=np.uint8)
     L = lib()
-    L.sor_umi_window_3p.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    rc = L.sor_umi_window_3p(x.encode(), len(x), adapter_end, bc_end, out.ctypes.data)
+    L.sor_umi_window_3p_len.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rc = L.sor_umi_window_3p_len(x.encode(), len(x), adapter_end, bc_end, umi_len, out.ctypes.data)
     return None if rc else out
 
 
-def umi_window_5p(x, adapter_end, bc_end):
-    out = np.zeros(14, dtype=np.uint8)
+def umi_window_5p(x, adapter_end, bc_end, umi_len=12):
+    out = np.zeros(umi_len + 2, dtype=np.uint8)
     L = lib()
-    L.sor_umi_window_5p.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-    rc = L.sor_umi_window_5p(x.encode(), len(x), adapter_end, bc_end, out.ctypes.data)
+    L.sor_umi_window_5p_len.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    rc = L.sor_umi_window_5p_len(x.encode(), len(x), adapter_end, bc_end, umi_len, out.ctypes.data)
     return None if rc else out
 
 

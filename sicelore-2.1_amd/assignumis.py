@@ -78,19 +78,19 @@ def parse_name(name):
     return dict(cell=d["bc"]["seq"], ae=d["ae"], bc_end=d["bc"]["end"], x=d["x"].split(" ")[0], q=d["q"])
 
 
-def umi_window(x, adapter_end, bc_end, five_prime=False):
-    """14 bases as 4-bit codes: the three 12-mers at offsets -1, 0, +1 behind the barcode (ClusteringEditDistanceBase L297-350;
-    getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378).  3': on the reverse complement of X= (getSeqRevComp), barcode end
-    = AE + 3 - bcEnd; 5': on X= itself (getSeq, L312-313), barcode end = bcEnd - AE + 3.  None if out of range"""
+def umi_window(x, adapter_end, bc_end, five_prime=False, umi_len=12):
+    """umi_len + 2 bases (14 with the shipped umis/umi_length) as 4-bit codes: the three umi_len-mers at offsets -1, 0, +1 behind the barcode
+    (ClusteringEditDistanceBase L297-350; getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378).  3': on the reverse complement of X=
+    (getSeqRevComp), barcode end = AE + 3 - bcEnd; 5': on X= itself (getSeq, L312-313), barcode end = bcEnd - AE + 3.  None if out of range"""
     if five_prime:
         pos = bc_end - adapter_end + 3
-        if pos < 1 or pos + 13 > len(x):
+        if pos < 1 or pos + umi_len + 1 > len(x):
             return None
-        return [_CODE.get(x[pos - 1 + k], 15) for k in range(14)]
+        return [_CODE.get(x[pos - 1 + k], 15) for k in range(umi_len + 2)]
     pos = adapter_end + 3 - bc_end
-    if pos < 1 or pos + 13 > len(x):
+    if pos < 1 or pos + umi_len + 1 > len(x):
         return None
-    return [_COMP[_CODE.get(x[len(x) - (pos + k)], 15)] for k in range(14)]
+    return [_COMP[_CODE.get(x[len(x) - (pos + k)], 15)] for k in range(umi_len + 2)]
 
 
 def pack_window(w):
@@ -544,7 +544,8 @@ def chunk_bounds(ref_ids, chunk_size):
 
 
 def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=False, compress_level=5, n_threads=4, refflat=None, bgzf="device",
-                             gene_counts=None, max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, gene_tag="GE"):
+                             gene_counts=None, max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, gene_tag="GE", umi_length=0,
+                             grouping_distance=None):
     """write_tagged_bams with no per-record work in Python: BGZF inflate + record index (host threads), per BamReader chunk
     smi_bam_chunk_inputs -> smi_assignumis_chunk (device), smi_gene_tag_bam, per written batch smi_bam_write_batch (host threads), BGZF by
     K-DEFLATE.  -> (bcfound BAM, umifound BAM -- numpy uint8 arrays --, info dict).  The same bytes as write_tagged_bams."""
@@ -580,7 +581,7 @@ def write_tagged_bams_native(ctx, data, chunk_size=250_000, truncate_read_name=F
         inp = _lib.bam_chunk_inputs(bam, recs, cur)
         t2 = time.perf_counter()
         out, n_done = ctx.assignumis_chunk_raw(inp, keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
-                                               five_prime=five_prime, cluster_cfg=cluster_cfg)
+                                               five_prime=five_prime, cluster_cfg=cluster_cfg, umi_length=umi_length, grouping_distance=grouping_distance)
         t3 = time.perf_counter()
         secs["chunk_inputs"] += t2 - t1
         secs["umi_stage"] += t3 - t2
@@ -705,7 +706,7 @@ def plan_shards(extents, world):
 
 def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
                       max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None, no_clustering=False,
-                      gene_tag="GE"):
+                      gene_tag="GE", umi_length=0, grouping_distance=None):
     """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (read and inflated by a thread of their own, one segment ahead), never held as a
     whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
     chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
@@ -900,7 +901,7 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             t2 = time.perf_counter()
             inp = _lib.bam_chunk_inputs(bam, recs, cur)
             out, n_done = ctx.assignumis_chunk_raw(inp, keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
-                                                   five_prime=five_prime, cluster_cfg=cluster_cfg)
+                                                   five_prime=five_prime, cluster_cfg=cluster_cfg, umi_length=umi_length, grouping_distance=grouping_distance)
             t3 = time.perf_counter()
             done = cur[:n_done]
             if no_clustering:

@@ -11,11 +11,11 @@ Reference units: option tables NanoporeReadScannerMain.cli_otions (NanoporeReadS
 config discovery OneProgramMainBase.checkCfgFilePath (cwd, then the application's directory; -c names a file for assignumis);
 exit code 0, or 1 after a message (WorkerReadscanner.java:L376-378).
 
-config.xml: the library's kernels are built for the shipped values of the knobs that shape the algorithm (pattern sequences and lengths,
-thresholds, windows); those are CHECKED against the file and a different value stops the run with the knob's name -- nothing is silently
-ignored.  The knobs that are run-time parameters of the library are taken from the file: sam_records_chunk_size,
-max_GenomeDistance_forGrouping, fileWithAllPossibleTenXbarcodes.  Options the product has no path for (Illumina-guided modes, random
-barcodes, the file watcher) are refused by name.
+config.xml (round 6): the file's knobs are taken at RUN TIME -- thresholds, windows, adapter / complete TSO sequences and mismatch limits, the
+finalize folds, mergeBCsED, umi_length and the clustering distances go to the library as smi_run_knobs / call arguments (lib.KNOB_FIELDS,
+HOST_KNOBS_* below).  Only what is genuinely compiled in (COMPILED_IN: the TSO of the read scan, testPlusMinusPos, cell_bc_length, the read-name
+grammar) is CHECKED against the file, and a different value stops the run with the knob's name -- nothing is silently ignored.  Options the
+product has no path for (Illumina-guided modes, the file watcher) are refused by name.
 """
 import gzip
 import os
@@ -26,33 +26,40 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-# knob (path under <Parameters>) -> the value the library is built with (Jar/config.xml as shipped: SURVEY 5)
-BUILT_IN = {
-    "readscanner/minReadLength": "200", "readscanner/cellsWithReadsnFoldBelowMaxToKeep": "500", "readscanner/testPlusMinusPos": "2",
-    "readscanner/pa_start_prefix": "PS=", "readscanner/pa_end_prefix": "PE=", "readscanner/adapter_pos_prefix": "AE=",
+# config.xml, round 6: the knobs that shape the per-read algorithms are RUN-TIME parameters of the library (smi_run_knobs,
+# lib.KNOB_FIELDS) or of its host-side steps (HOST_KNOBS below); a value the library has no kernel for is refused BY THE LIBRARY with the knob's
+# name (smi_ctx_set_knobs: sequence lengths, 8 <= umi_length <= 12, ...).
+#
+# COMPILED_IN: what is genuinely fixed in this build -- knob (path under <Parameters>) -> the shipped value the kernels are compiled for; any other
+# value stops the run with the knob's name (nothing is silently ignored):
+#   * the TSO of the READ SCAN (K-SCAN's gate / alignment columns / acceptance rules are compile-time: PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs)
+#   * testPlusMinusPos (five windows per read: the layout of smi_bc_window and of K-BC1's filter), cell_bc_length (32-bit keys)
+#   * the read-name grammar (prefixes, nbasesOfAdapterSeqInReadname: smi_name.h and K-UPARSE), runningasdemon, tagGeneNameFunction
+COMPILED_IN = {
+    "readscanner/testPlusMinusPos": "2", "readscanner/pa_start_prefix": "PS=", "readscanner/pa_end_prefix": "PE=", "readscanner/adapter_pos_prefix": "AE=",
     "readscanner/tso_pos_prefix": "T=", "readscanner/seq_prefix": "X=", "readscanner/qv_prefix": "Q=",
-    "readscanner/minMeanBCqv": "8", "readscanner/minMeanReadqv": "8", "readscanner/minAdapter3pMatches": "8", "readscanner/minCountFold": "10",
     "readscanner/nbasesOfAdapterSeqInReadname": "3", "readscanner/runningasdemon": "false",
     "barcodeUMIFinder/tagGeneNameFunction": "DefaultTagger",
-    "polyAT/internalpATlength": "15", "polyAT/internalFractionATInPolyAT": "0.70",
-    "adapter_for3pBarcoding/sequence": "CTTCCGATCT", "adapter_for3pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
-    "adapter_for3pBarcoding/maxNeedlemanMismatches": "3", "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
-    "fiveprimeadapter_for5pBarcoding/sequence": "CTTCCGATCT", "fiveprimeadapter_for5pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGATCT",
-    "fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches": "3", "fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
-    "fiveprimeadapter_for5pBarcoding/AdapterSearchWindow": "110",
-    "threeprimeadapter_for5pBarcoding/sequence": "AACGCAGAGTAC", "threeprimeadapter_for5pBarcoding/sequence_complete": "AAGCAGTGGTATCAACGCAGAGTAC",
-    "threeprimeadapter_for5pBarcoding/maxNeedlemanMismatches": "3", "threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "5",
     "tso_for3pBarcoding/sequence": "AACGCAGAGTACATGG", "tso_for3pBarcoding/maxNeedlemanMismatches": "5",
     "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": "8", "tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches": "12",
-    "tso_for3pBarcoding/windowForTSOsearch": "90", "tso_for3pBarcoding/offsetTSOend": "1",
-    "tso_for3pBarcoding/sequence_complete": "AAGCAGTGGTATCAACGCAGAGTACAT", "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "6",
-    "tso_for5pBarcoding/sequence": "AACGCAGAGTACATGG", "tso_for5pBarcoding/maxNeedlemanMismatches": "5",
-    "barcodes/cell_bc_length": "16", "barcodes/distance_from_read_end_for_grouping": "100",
-    "umis/umi_length": "12", "umis/umi_completelinkclusteringED": "2", "umis/umi_singlelinkclusteringED": "1",
+    "tso_for3pBarcoding/windowForTSOsearch": "90",
+    "barcodes/cell_bc_length": "16",
 }
-RUN_TIME = ("barcodeUMIFinder/sam_records_chunk_size", "barcodes/max_GenomeDistance_forGrouping", "readscanner/fileWithAllPossibleTenXbarcodes",
-            "readscanner/mergeBCsED", "polyAT/polyATlength", "polyAT/fractionATInPolyAT", "polyAT/windowSearchForPolyA",
-            "barcodeUMIFinder/gene_name_attribute")
+# knobs of the shipped file that NO unit of the path reads (checked over the bytecode: no getfield outside print() / the Illumina-guided analyzers):
+# accepted with any value, as the reference accepts them.  threeprimeadapter_for5pBarcoding's `sequence` / maxNeedlemanMismatches: only its
+# sequence_complete is used (ChimeraFindernew.java:L75); tso_for5pBarcoding: the 5' analyzer has no TSO scan; offsetTSOend, internalMinPolyATlengthForReporting:
+# never read; maxComplexityForUMIclustering / pregroup_for_clustering_threshold: the pre-grouping arm is dead code
+NO_EFFECT = ("threeprimeadapter_for5pBarcoding/sequence", "threeprimeadapter_for5pBarcoding/maxNeedlemanMismatches", "tso_for5pBarcoding/sequence",
+             "tso_for5pBarcoding/maxNeedlemanMismatches", "tso_for3pBarcoding/offsetTSOend", "polyAT/internalMinPolyATlengthForReporting",
+             "umis/pregroup_for_clustering_threshold")
+# host-side knobs: name -> (keyword of run_files.run / assignumis_stream, converter)
+HOST_KNOBS_SCAN = {"readscanner/minCountFold": ("min_count_fold", int), "readscanner/cellsWithReadsnFoldBelowMaxToKeep": ("cells_fold_below_max", int)}
+HOST_KNOBS_UMI = {"umis/umi_length": ("umi_length", int), "umis/umi_completelinkclusteringED": ("complete_link_ed", int),
+                  "umis/umi_singlelinkclusteringED": ("single_link_ed", int),
+                  "umis/complexity_threshold_for_switch_to_single_link_clustering": ("single_link_switch", int),
+                  "barcodes/distance_from_read_end_for_grouping": ("grouping_distance", int),
+                  "barcodes/max_GenomeDistance_forGrouping": ("max_dist", int), "barcodeUMIFinder/sam_records_chunk_size": ("chunk_size", int)}
+RUN_TIME = ("readscanner/fileWithAllPossibleTenXbarcodes", "readscanner/mergeBCsED", "barcodeUMIFinder/gene_name_attribute")
 
 
 class CliError(Exception):
@@ -82,12 +89,44 @@ def read_config(path):
         for leaf in sec:
             if len(leaf) == 0 and leaf.text is not None:
                 knobs[f"{sec.tag}/{leaf.tag}"] = leaf.text.strip()
-    bad = [(k, knobs[k], v) for k, v in BUILT_IN.items() if k in knobs and _norm(knobs[k]) != _norm(v)]
+    bad = [(k, knobs[k], v) for k, v in COMPILED_IN.items() if k in knobs and _norm(knobs[k]) != _norm(v)]
     if bad:
         lines = "\n".join(f"  {k} = {got!r} (this build: {want!r})" for k, got, want in bad)
-        raise CliError(f"{path}: knobs with values this build of libsicelore_mi.so does not implement:\n{lines}\n"
-                       "(the kernels are compiled for the shipped config.xml; see sicelore-2.1_amd/cli.py BUILT_IN)")
+        raise CliError(f"{path}: knobs that are compiled into this build of libsicelore_mi.so:\n{lines}\n"
+                       "(see sicelore-2.1_amd/cli.py COMPILED_IN; every other knob of the file is taken at run time)")
     return knobs
+
+
+def run_knobs_from(knobs, path="config.xml", polya=None):
+    """config.xml's elements -> smi_run_knobs (lib.RunKnobs); None when the file changes none of them (the kernels compiled for the shipped values
+    then run).  polya: the (length, fraction, window) the run uses -- command line over config.xml -- which then replace the file's.  A value the
+    library has no kernel for is refused with the knob's name (the checks of smi_ctx_set_knobs, made here without a device)."""
+    from . import lib
+    over = {}
+    for name, field in lib.KNOB_FIELDS.items():
+        if name in knobs:
+            over[name] = knobs[name]
+    if not over:
+        return None
+    try:
+        k = lib.run_knobs(**over)
+        if polya is not None:
+            k.polya_len, k.polya_frac, k.window_polya = polya
+        lib.check_run_knobs(k)
+    except (ValueError, lib.SmiError) as e:
+        raise CliError(f"{path}: {e}")
+    return None if k.as_dict() == lib.run_knobs().as_dict() else k
+
+
+def host_knobs_from(knobs, table, path="config.xml"):
+    out = {}
+    for name, (kw, conv) in table.items():
+        if name in knobs:
+            try:
+                out[kw] = conv(knobs[name])
+            except ValueError:
+                raise CliError(f"{path}: {name} = {knobs[name]!r}: not a number")
+    return out
 
 
 def _norm(v):
@@ -224,15 +263,35 @@ def scanfastq(argv):
         raise CliError(f"--bcEditDistance {o['bcEditDistance']!r}: not a number")
     if ed not in (0, 1, 2):
         raise CliError("--bcEditDistance: this build matches at edit distance 0, 1 or 2")
-    knobs = read_config(find_config())
-    if knobs.get("readscanner/mergeBCsED", "null") not in ("null", "", str(ed)):
-        raise CliError("readscanner/mergeBCsED: only null (= the barcode edit distance) is built")
+    cfg_path = find_config()
+    knobs = read_config(cfg_path)
+    host_kw = host_knobs_from(knobs, HOST_KNOBS_SCAN, cfg_path)
+    for kw in ("min_count_fold", "cells_fold_below_max"):
+        if host_kw.get(kw, 1) <= 0:
+            raise CliError(f"{cfg_path}: readscanner/{'minCountFold' if kw == 'min_count_fold' else 'cellsWithReadsnFoldBelowMaxToKeep'} must be positive")
+    # mergeBCsED: null / absent = the barcode edit distance (ReadScannerParameters.validate_readScannerParameters L236-238); a smaller value than
+    # --bcEditDistance is a warning in the reference (L239-240), and here
+    merge_txt = knobs.get("readscanner/mergeBCsED", "null")
+    merge_ed = ed
+    if merge_txt not in ("null", ""):
+        try:
+            merge_ed = int(merge_txt)
+        except ValueError:
+            merge_ed = ed          # (JAXB leaves the Integer null on an unparsable text: the default applies)
+        if not 0 <= merge_ed <= 2:
+            raise CliError(f"{cfg_path}: readscanner/mergeBCsED = {merge_ed}: this build merges colliding barcodes at edit distance 0, 1 or 2")
+        if ed > merge_ed:
+            print(f"Edit distance for generating table of used barcodes <mergeBCsED> in config.xml ({merge_ed}) is smaller than edit distance for final "
+                  f"barcode assignment ({ed}) - SHOULD BE AVOIDED", file=sys.stderr)
     try:
         polya = (int(o.get("polyAlength") or knobs.get("polyAT/polyATlength", 15)), float(o.get("fractionAT") or knobs.get("polyAT/fractionATInPolyAT", 0.75)),
                  int(o.get("windowAT") or knobs.get("polyAT/windowSearchForPolyA", 150)))
     except ValueError:
         raise CliError("-p / -w take whole numbers, -f a fraction (polyAT/polyATlength, fractionATInPolyAT, windowSearchForPolyA in config.xml)")
-    if polya == (15, 0.75, 150):
+    run_knobs = run_knobs_from(knobs, cfg_path, polya)
+    if run_knobs is not None:              # the window the run uses (command line over config.xml) is part of the knobs the context gets
+        polya = None
+    elif polya == (15, 0.75, 150):
         polya = None                       # the shipped window: the kernels compiled for it
     for d in [d for d in o["inDir"].split(",") if d]:            # -d takes a comma-separated list (FileTools.java:L52)
         if not os.path.isdir(d):
@@ -282,7 +341,13 @@ def scanfastq(argv):
         print("Stats only, Won't write fastqs")
     ctx = _context()
     ncpu = _ncpu(o)
-    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
+    if run_knobs is not None:
+        from . import lib as _lib
+        try:
+            ctx.set_knobs(run_knobs)
+        except _lib.SmiError as e:
+            raise CliError(f"{cfg_path}: {e}")
+    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, merge_ed=merge_ed, **host_kw, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
                          dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")),
                          recursive="nonrecursive" not in o, pattern=o.get("pattern", run_files.FASTQ_PATTERN), skip_files=skip, only_files=only,
                          used_keys=used, write_fastqs="dontwrite" not in o, trim_fastq="trimfastq" in o)
@@ -297,7 +362,17 @@ def assignumis(argv):
     for need in ("inFileNanopore", "outfile"):
         if need not in o:
             raise CliError(f"Missing required option: {UMI_SPEC[need][1]}")
-    knobs = read_config(find_config(o.get("config")))
+    cfg_path = find_config(o.get("config"))
+    knobs = read_config(cfg_path)
+    hk = host_knobs_from(knobs, HOST_KNOBS_UMI, cfg_path)
+    umi_length = hk.get("umi_length", 12)
+    if not 8 <= umi_length <= 12:
+        raise CliError(f"{cfg_path}: umis/umi_length = {umi_length}: this build has kernels for UMIs of 8 .. 12 bases")
+    cluster_over = {k: hk[k] for k in ("complete_link_ed", "single_link_ed", "single_link_switch") if k in hk}
+    for k, v in cluster_over.items():
+        if v < 0 or (k != "single_link_switch" and v > 5):
+            raise CliError(f"{cfg_path}: umis/{'umi_completelinkclusteringED' if k == 'complete_link_ed' else 'umi_singlelinkclusteringED' if k == 'single_link_ed' else 'complexity_threshold_for_switch_to_single_link_clustering'} = {v}: "
+                           "the UMI distances are Levenshtein distances cut at 4 (0 .. 5 make sense here)")
     gene_tag = knobs.get("barcodeUMIFinder/gene_name_attribute", "GE")
     if "ONTgene" in o:
         gene_tag = o["ONTgene"]
@@ -317,9 +392,14 @@ def assignumis(argv):
         raise CliError(f"annotation file {o['annotationFile']} does not exist")
     out = o["outfile"]
     prefix = out[:-4] if out.endswith(".bam") else out          # <out>.bam, <out>_umifound_.bam, <out>.genecounts.tsv, <out>.UMIdepths.tsv
-    chunk = int(o.get("chunksize") or knobs.get("barcodeUMIFinder/sam_records_chunk_size", 250000))
-    max_dist = int(knobs.get("barcodes/max_GenomeDistance_forGrouping", 500))
+    try:
+        chunk = int(o.get("chunksize") or hk.get("chunk_size", 250000))
+    except ValueError:
+        raise CliError(f"--chunksize {o.get('chunksize')!r}: not a number")
+    max_dist = hk.get("max_dist", 500)
     from . import assignumis as au
+    from . import lib as _lib
+    cluster_cfg = _lib.umi_cluster_config(**cluster_over) if cluster_over else None
     refflat = None
     if "annotationFile" in o:          # refFlat text, gz or plain (picard's RefFlatReader through IOUtil)
         import bz2
@@ -342,7 +422,8 @@ def assignumis(argv):
     ncpu = _ncpu(o)
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
                                 refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit,
-                                no_clustering="noclustering" in o, gene_tag=gene_tag)
+                                no_clustering="noclustering" in o, gene_tag=gene_tag, umi_length=umi_length, cluster_cfg=cluster_cfg,
+                                grouping_distance=hk.get("grouping_distance"))
     if info.get("rank", 0) == 0:       # rank 0 holds the whole run's counts (assignumis_stream gathers them)
         print(f"DONE -- {info['records']} records, {info['clustered']} in UMI clusters")
         bad = int(info.get("gene_keys_order_dependent", 0))

@@ -428,15 +428,15 @@ extern "C" int smi_bam_write_batch(const uint8_t *bam, size_t n_bam, const smi_b
             const smi_umi_tag &u = tags[i];
             const bool clustered = (u.flags & SMI_UMI_CLUSTERED) != 0;
             if (clustered) {
-                at.set(aux_str("U8", u.u8, 12));
-                at.set(aux_str("U7", u.u7, 12));
+                at.set(aux_str("U8", u.u8, strnlen(u.u8, 12)));
+                at.set(aux_str("U7", u.u7, strnlen(u.u7, 12)));
                 at.set(aux_str("UC", "", 0));
                 at.set(aux_str("U1", std::to_string((int)u.u1)));
                 if (u.u2 >= 0) at.set(aux_str("U2", std::to_string((int)u.u2)));
             } else if (u.flags & SMI_UMI_HAS_U7) {
-                at.set(aux_str("U7", u.u7, 12));
+                at.set(aux_str("U7", u.u7, strnlen(u.u7, 12)));
                 if (!(u.flags & SMI_UMI_SKIPPED)) {
-                    at.set(aux_str("U8", u.u7, 12));
+                    at.set(aux_str("U8", u.u7, strnlen(u.u7, 12)));
                     at.set(aux_str("UZ", "", 0));
                 }
             }

@@ -1,5 +1,6 @@
 // smi_ctx.hip -- context, error reporting and the extern "C" boundary of libsicelore_mi (see include/sicelore_mi.h).
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -213,6 +214,8 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->polya_len = o->polya_len;
     lane->polya_frac = o->polya_frac;
     lane->polya_window = o->polya_window;
+    lane->knobs = o->knobs;
+    lane->knobs_set = o->knobs_set;
     return SMI_OK;
 }
 
@@ -430,27 +433,201 @@ int smi_bc_counts_device(smi_ctx *ctx, const smi_bc_result *d_results, size_t n,
     return launch_bc_counts(ctx, d_results, n, d_counts, (hipStream_t)stream);
 }
 
-int smi_scan_default_config(int pass, smi_scan_config *cfg) {
-    if (!cfg || (pass != 1 && pass != 2)) {
-        set_error("smi_scan_default_config: bad argument");
+// ---- config.xml's knobs (smi_run_knobs) ---------------------------------------------------------------------------------------------------
+int smi_run_knobs_default(smi_run_knobs *k) {
+    if (!k) {
+        set_error("smi_run_knobs_default: null argument");
         return SMI_ERR_INVALID;
     }
+    std::memset(k, 0, sizeof(*k));
+    k->min_read_length = 200;  // Jar/config.xml:21
+    k->min_mean_bc_qv = 8;     // :55
+    k->min_mean_read_qv = 8;   // :57
+    k->min_adapter_3p_matches = 8;  // :59
+    k->polya_len = 15;         // :95
+    k->polya_frac = 0.75f;     // :97
+    k->window_polya = 150;     // :105
+    k->internal_pat_len = 15;  // :99
+    k->internal_pat_frac = 0.70f;  // :101
+    std::strcpy(k->adapter3p, "CTTCCGATCT");                       // :111
+    std::strcpy(k->adapter3p_complete, "CTACACGACGCTCTTCCGATCT");  // :113
+    k->adapter3p_max_mm = 3;                                       // :115
+    k->adapter3p_complete_max_mm = 5;                              // :118
+    std::strcpy(k->adapter5p, "CTTCCGATCT");                       // :124
+    std::strcpy(k->adapter5p_complete, "CTACACGACGCTCTTCCGATCT");  // :126
+    k->adapter5p_max_mm = 3;                                       // :129
+    k->adapter5p_complete_max_mm = 5;                              // :132
+    k->adapter5p_window = 110;                                     // :134
+    std::strcpy(k->adapter3p5_complete, "AAGCAGTGGTATCAACGCAGAGTAC");  // :141
+    k->adapter3p5_complete_max_mm = 5;                             // :146
+    std::strcpy(k->tso_complete, "AAGCAGTGGTATCAACGCAGAGTACAT");   // :170
+    k->tso_complete_max_mm = 6;                                    // :172
+    k->umi_length = 12;                                            // :264
+    return SMI_OK;
+}
+
+namespace {
+const smi_run_knobs &shipped_knobs() {
+    static const smi_run_knobs k = [] {
+        smi_run_knobs v;
+        smi_run_knobs_default(&v);
+        return v;
+    }();
+    return k;
+}
+
+// the limits of this build, knob by knob (the message names config.xml's element)
+int check_knobs(const smi_run_knobs &k) {
+    auto seq_ok = [](const char *s, size_t cap, int want) {
+        size_t n = 0;
+        while (n < cap && s[n]) n++;
+        if (n != (size_t)want) return false;
+        for (size_t i = 0; i < n; i++)
+            if (s[i] != 'A' && s[i] != 'C' && s[i] != 'G' && s[i] != 'T') return false;
+        return true;
+    };
+    struct {
+        const char *name;
+        const char *s;
+        int want;
+    } seqs[] = {{"adapter_for3pBarcoding/sequence", k.adapter3p, 10},
+                {"adapter_for3pBarcoding/sequence_complete", k.adapter3p_complete, 22},
+                {"fiveprimeadapter_for5pBarcoding/sequence", k.adapter5p, 10},
+                {"fiveprimeadapter_for5pBarcoding/sequence_complete", k.adapter5p_complete, 22},
+                {"threeprimeadapter_for5pBarcoding/sequence_complete", k.adapter3p5_complete, 25},
+                {"tso_for3pBarcoding/sequence_complete", k.tso_complete, 27}};
+    for (const auto &q : seqs)
+        if (!seq_ok(q.s, 32, q.want)) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "smi_ctx_set_knobs: %s: this build has kernels for %d bases of A / C / G / T here (the length of the shipped sequence)", q.name, q.want);
+            set_error(msg);
+            return SMI_ERR_INVALID;
+        }
+    struct {
+        const char *name;
+        int v, lo, hi;
+    } ints[] = {{"readscanner/minReadLength", k.min_read_length, 0, 1 << 30},
+                {"readscanner/minMeanBCqv", k.min_mean_bc_qv, 0, 93},
+                {"readscanner/minMeanReadqv", k.min_mean_read_qv, 0, 93},
+                {"readscanner/minAdapter3pMatches", k.min_adapter_3p_matches, 0, 22},
+                {"polyAT/polyATlength", k.polya_len, 5, 30},
+                {"polyAT/internalpATlength", k.internal_pat_len, 2, 15},
+                {"adapter_for3pBarcoding/maxNeedlemanMismatches", k.adapter3p_max_mm, 0, 30},
+                {"adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches", k.adapter3p_complete_max_mm, 0, 30},
+                {"fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches", k.adapter5p_max_mm, 0, 29},
+                {"fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches", k.adapter5p_complete_max_mm, 0, 30},
+                {"threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches", k.adapter3p5_complete_max_mm, 0, 30},
+                {"tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches", k.tso_complete_max_mm, 0, 30},
+                {"umis/umi_length", k.umi_length, 8, 12}};
+    for (const auto &q : ints)
+        if (q.v < q.lo || q.v > q.hi) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "smi_ctx_set_knobs: %s = %d: this build takes %d .. %d", q.name, q.v, q.lo, q.hi);
+            set_error(msg);
+            return SMI_ERR_INVALID;
+        }
+    if (k.window_polya < 1 || k.window_polya + k.polya_len + 10 > 175) {
+        set_error("smi_ctx_set_knobs: polyAT/windowSearchForPolyA + polyATlength + 10 must fit the 175 scanned bases of a read end");
+        return SMI_ERR_INVALID;
+    }
+    if (!(k.polya_frac > 0.0f && k.polya_frac <= 1.0f) || !(k.internal_pat_frac > 0.0f && k.internal_pat_frac <= 1.0f)) {
+        set_error("smi_ctx_set_knobs: polyAT/fractionATInPolyAT and internalFractionATInPolyAT must lie in (0, 1]");
+        return SMI_ERR_INVALID;
+    }
+    // 5' barcoding: the adapter is searched in the first AdapterSearchWindow + adapter + mismatches + 5 bases (PolyATadapterAnalyzer_5pBCUMI.java:L49-61); pass 1 scans the 22-mer
+    if (k.adapter5p_window < 1 || k.adapter5p_window + 22 + k.adapter5p_max_mm + 1 + 5 > 192) {
+        set_error("smi_ctx_set_knobs: fiveprimeadapter_for5pBarcoding/AdapterSearchWindow + 22 + maxNeedlemanMismatches + 6 must fit 192 bases");
+        return SMI_ERR_INVALID;
+    }
+    return SMI_OK;
+}
+}  // namespace
+
+int smi_ctx_set_knobs(smi_ctx *ctx, const smi_run_knobs *knobs) {
+    if (!ctx) {
+        set_error("null context");
+        return SMI_ERR_INVALID;
+    }
+    if (!knobs) {
+        ctx->knobs_set = false;
+        return SMI_OK;
+    }
+    if (int rc = check_knobs(*knobs)) return rc;
+    ctx->knobs = *knobs;
+    ctx->knobs_set = true;
+    return SMI_OK;
+}
+
+int smi_ctx_get_knobs(const smi_ctx *ctx, smi_run_knobs *knobs) {
+    if (!ctx || !knobs) {
+        set_error("smi_ctx_get_knobs: null argument");
+        return SMI_ERR_INVALID;
+    }
+    *knobs = ctx->knobs_set ? ctx->knobs : shipped_knobs();
+    return SMI_OK;
+}
+
+int smi_scan_config_from_knobs(const smi_run_knobs *knobs, int pass, int five_prime, int dont_search_polya, smi_scan_config *cfg) {
+    if (!cfg || (pass != 1 && pass != 2)) {
+        set_error("smi_scan_config_from_knobs: bad argument");
+        return SMI_ERR_INVALID;
+    }
+    if (knobs)
+        if (int rc = check_knobs(*knobs)) return rc;
+    const smi_run_knobs &k = knobs ? *knobs : shipped_knobs();
     std::memset(cfg, 0, sizeof(*cfg));
-    cfg->min_read_length = 200;
-    cfg->polya_len = 15;
-    cfg->polya_frac = 0.75f;
-    cfg->window_polya = 150;
-    cfg->max_mismatches = 3;
-    cfg->min_adapter_3p_matches = 8;
-    cfg->min_mean_bc_qv = 8;
-    cfg->min_mean_read_qv = 8;
-    // Jar/config.xml:111-113: sequence / sequence_complete of adapter_for3pBarcoding
-    const char *ad = pass == 1 ? "CTACACGACGCTCTTCCGATCT" : "CTTCCGATCT";
+    cfg->min_read_length = k.min_read_length;
+    cfg->polya_len = k.polya_len;
+    cfg->polya_frac = k.polya_frac;
+    cfg->window_polya = k.window_polya;
+    // Parser.java:L134-136: the adapter of the protocol; pass 2 scans `sequence`, pass 1 (no barcode map yet) `sequence_complete`, both with
+    // maxNeedlemanMismatches; 5' barcoding allows one more (L99)
+    cfg->max_mismatches = five_prime ? k.adapter5p_max_mm + 1 : k.adapter3p_max_mm;
+    cfg->min_adapter_3p_matches = k.min_adapter_3p_matches;
+    cfg->min_mean_bc_qv = k.min_mean_bc_qv;
+    cfg->min_mean_read_qv = k.min_mean_read_qv;
+    const char *ad = five_prime ? (pass == 1 ? k.adapter5p_complete : k.adapter5p) : (pass == 1 ? k.adapter3p_complete : k.adapter3p);
     cfg->adapter_len = (int32_t)std::strlen(ad);
     for (int i = 0; i < cfg->adapter_len; i++)
         cfg->adapter4[i] = ad[i] == 'A' ? 1u : ad[i] == 'G' ? 2u : ad[i] == 'C' ? 4u : 8u;
+    if (five_prime) {
+        cfg->five_prime = 1;
+        cfg->dont_search_polya = dont_search_polya ? 1 : 0;
+        cfg->adapter_search_window = k.adapter5p_window;
+    }
     return SMI_OK;
 }
+
+int smi_chimera_config_from_knobs(const smi_run_knobs *knobs, int five_prime, smi_chimera_config *cfg) {
+    if (!cfg) {
+        set_error("smi_chimera_config_from_knobs: null argument");
+        return SMI_ERR_INVALID;
+    }
+    if (knobs)
+        if (int rc = check_knobs(*knobs)) return rc;
+    const smi_run_knobs &k = knobs ? *knobs : shipped_knobs();
+    cfg->internal_pat_len = k.internal_pat_len;
+    cfg->internal_pat_frac = k.internal_pat_frac;
+    cfg->window_polya = k.window_polya;
+    if (!five_prime) {
+        cfg->tso_complete = k.tso_complete;
+        cfg->adapter_complete = k.adapter3p_complete;
+        cfg->tso_max_errors = k.tso_complete_max_mm;
+        cfg->adapter_max_errors = k.adapter3p_complete_max_mm;
+        cfg->bc_umi_len = 16 + k.umi_length;  // ChimeraFindernew.java:L74: umi_length + cell_bc_length
+    } else {
+        // ChimeraFindernew.<init> L75-78 for scantype != THREEP_BARCODE: the 5' adapter plays the TSO's part, the 3' adapter
+        // of the 5' protocol is searched next to internal polyA / polyT, and no barcode + UMI lies between them (hasBCUMI = false)
+        cfg->tso_complete = k.adapter5p_complete;
+        cfg->adapter_complete = k.adapter3p5_complete;
+        cfg->tso_max_errors = k.adapter5p_complete_max_mm;
+        cfg->adapter_max_errors = k.adapter3p5_complete_max_mm;
+        cfg->bc_umi_len = 0;
+    }
+    return SMI_OK;
+}
+
+int smi_scan_default_config(int pass, smi_scan_config *cfg) { return smi_scan_config_from_knobs(nullptr, pass, 0, 0, cfg); }
 
 int smi_fastq_index_device(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
                            uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
@@ -480,33 +657,9 @@ int smi_fastq_gather_device(smi_ctx *ctx, const uint8_t *d_text, const uint64_t 
     return launch_fastq_gather(ctx, d_text, d_start, d_offsets, n, d_out, (hipStream_t)stream);
 }
 
-int smi_chimera_default_config(smi_chimera_config *cfg) {
-    if (!cfg) {
-        set_error("smi_chimera_default_config: null argument");
-        return SMI_ERR_INVALID;
-    }
-    cfg->tso_complete = "AAGCAGTGGTATCAACGCAGAGTACAT";
-    cfg->adapter_complete = "CTACACGACGCTCTTCCGATCT";
-    cfg->tso_max_errors = 6;
-    cfg->adapter_max_errors = 5;
-    cfg->internal_pat_len = 15;
-    cfg->internal_pat_frac = 0.70f;
-    cfg->window_polya = 150;
-    cfg->bc_umi_len = 28;
-    return SMI_OK;
-}
+int smi_chimera_default_config(smi_chimera_config *cfg) { return smi_chimera_config_from_knobs(nullptr, 0, cfg); }
 
-int smi_chimera_default_config_5p(smi_chimera_config *cfg) {
-    if (int rc = smi_chimera_default_config(cfg)) return rc;
-    // ChimeraFindernew.<init> L75-78 for scantype != THREEP_BARCODE: the 5' adapter plays the TSO's part, the 3' adapter
-    // of the 5' protocol is searched next to internal polyA / polyT, and no barcode + UMI lies between them (hasBCUMI = false)
-    cfg->tso_complete = "CTACACGACGCTCTTCCGATCT";        // fiveprimeadapter_for5pBarcoding.sequence_complete, config.xml:126
-    cfg->adapter_complete = "AAGCAGTGGTATCAACGCAGAGTAC";  // threeprimeadapter_for5pBarcoding.sequence_complete, :141
-    cfg->tso_max_errors = 5;                               // :132
-    cfg->adapter_max_errors = 5;                           // :146
-    cfg->bc_umi_len = 0;
-    return SMI_OK;
-}
+int smi_chimera_default_config_5p(smi_chimera_config *cfg) { return smi_chimera_config_from_knobs(nullptr, 1, cfg); }
 
 size_t smi_read_planes_words(uint64_t total_bases, size_t n) { return 4 * read_planes_stride(total_bases, n); }
 
@@ -542,12 +695,7 @@ int smi_split_offsets_device(smi_ctx *ctx, const smi_chimera_result *d_chim, con
 }
 
 int smi_scan_default_config_5p(int pass, int dont_search_polya, smi_scan_config *cfg) {
-    if (int rc = smi_scan_default_config(pass, cfg)) return rc;  // same adapter sequences (config.xml:124,126)
-    cfg->max_mismatches += 1;                                      // Parser.java:L99
-    cfg->five_prime = 1;
-    cfg->dont_search_polya = dont_search_polya ? 1 : 0;
-    cfg->adapter_search_window = 110;
-    return SMI_OK;
+    return smi_scan_config_from_knobs(nullptr, pass, 1, dont_search_polya, cfg);
 }
 
 int smi_pack_ends_device(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets,
@@ -629,6 +777,24 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
         set_error("smi_scan_device: 5' search window + adapter + mismatches + 5 must fit 192 bases");
         return SMI_ERR_INVALID;
     }
+    {
+        // The reference cuts window + length + 10 bases off each read end before it looks for polyA / polyT (PolyATSearcher.java:L178-181) and
+        // AdapterSearchWindow + adapter + mismatches + 5 in 5' barcoding (PolyATadapterAnalyzer_5pBCUMI.java:L49-61): a read that passes
+        // minReadLength and is shorter than that ends its run with a StringIndexOutOfBoundsException.  With the shipped 200 no read can; a
+        // smaller minReadLength is refused here instead of guessing what such reads should become.
+        int need = 0;
+        if (!cfg->five_prime || !cfg->dont_search_polya) need = cfg->window_polya + cfg->polya_len + 10;
+        if (cfg->five_prime) need = std::max(need, cfg->adapter_search_window + cfg->adapter_len + cfg->max_mismatches + 5);
+        if (cfg->min_read_length < need) {
+            char msg[320];
+            std::snprintf(msg, sizeof msg,
+                          "smi_scan_device: readscanner/minReadLength = %d, but %d bases are cut off each read end (windowSearchForPolyA + polyATlength + 10, "
+                          "5': AdapterSearchWindow + adapter + mismatches + 5): the reference ends with an exception on the first read of %d .. %d bases",
+                          cfg->min_read_length, need, cfg->min_read_length, need - 1);
+            set_error(msg);
+            return SMI_ERR_INVALID;
+        }
+    }
     return launch_scan(ctx, d_ends, d_read_len, d_qtail, d_qsum, n, cfg, d_out, d_windows, (hipStream_t)stream);
 }
 
@@ -674,7 +840,23 @@ int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t 
         return SMI_ERR_INVALID;
     }
     return launch_umi_dist(ctx, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups, total_pairs, d_out,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, ctx_umi_length(ctx));
 }
 
 }  // extern "C"
+
+namespace smi {
+int worker_scan_config(const smi_ctx *ctx, int pass, int five_prime, int dont_search_polya, smi_scan_config *sc) {
+    if (int rc = smi_scan_config_from_knobs(ctx->knobs_set ? &ctx->knobs : nullptr, pass, five_prime, dont_search_polya, sc)) return rc;
+    // -p / -f / -w of the command line win over config.xml (NanoporeReadScannerMain.java:L227-234)
+    if (ctx->polya_len) sc->polya_len = ctx->polya_len;
+    if (ctx->polya_frac != 0.0f) sc->polya_frac = ctx->polya_frac;
+    if (ctx->polya_window) sc->window_polya = ctx->polya_window;
+    return SMI_OK;
+}
+int worker_chimera_config(const smi_ctx *ctx, int five_prime, smi_chimera_config *cc) {
+    if (int rc = smi_chimera_config_from_knobs(ctx->knobs_set ? &ctx->knobs : nullptr, five_prime, cc)) return rc;
+    if (ctx->polya_window) cc->window_polya = ctx->polya_window;  // (the splitter keeps away from the read ends by windowSearchForPolyA + 70)
+    return SMI_OK;
+}
+}  // namespace smi

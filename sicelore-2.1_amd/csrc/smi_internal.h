@@ -119,6 +119,8 @@ struct smi_ctx {
     bool n1_valid = false;    // describes the set that is loaded now
     int polya_len = 0, polya_window = 0;  // smi_ctx_set_polya: the chunk workers' polyA finder parameters (0: the shipped config.xml values)
     float polya_frac = 0.0f;
+    smi_run_knobs knobs = {};  // smi_ctx_set_knobs: config.xml's knobs for the chunk workers of this context (knobs_set false: the shipped file)
+    bool knobs_set = false;
     bool nb2_valid = false;   // the build scratch n1_owner holds the two-step neighbourhood bitmap of the set that is loaded now
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
     uint32_t *nb5 = nullptr;  // allocated with the first neighbourhood table (2.5 GiB); nb5_valid: describes the set that is loaded now
@@ -182,6 +184,10 @@ struct smi_ctx {
 };
 
 namespace smi {
+// the configurations a chunk worker of `ctx` runs with: its knobs (smi_ctx_set_knobs), then -p / -f / -w (smi_ctx_set_polya); the splitter's
+// strings point into the context (smi_ctx.hip)
+int worker_scan_config(const smi_ctx *ctx, int pass, int five_prime, int dont_search_polya, smi_scan_config *sc);
+int worker_chimera_config(const smi_ctx *ctx, int five_prime, smi_chimera_config *cc);
 // ClusterOne_MyClustering of one group above 100 reads on the matrix in HBM (smi_cluster.hip)
 int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const float *d_qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *d_out,
                            uint8_t *d_skipped, hipStream_t s);
@@ -205,7 +211,9 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
                 const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
                 smi_bc_window *d_win, hipStream_t s);
 int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
-                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s);
+                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s, int umi_len = 12);
+// umis/umi_length of a context's knobs (12 without knobs)
+inline int ctx_umi_length(const smi_ctx *ctx) { return ctx->knobs_set ? ctx->knobs.umi_length : 12; }
 int launch_pack_ends(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, const uint64_t *d_starts,
                      size_t n, int head_quals, uint32_t *d_ends, int32_t *d_len, uint8_t *d_qtail, uint32_t *d_qsum, hipStream_t s);
 int launch_count_lines(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, size_t *n_lines, hipStream_t s);

@@ -13,6 +13,7 @@
 // exactly min(Levenshtein, "> 4"), which is what the bit-vector algorithm's last-row score gives.  Integer/bitwise
 // only: no MFMA, no LDS.
 #include <hipcub/hipcub.hpp>
+#include <type_traits>
 
 #include "smi_internal.h"
 
@@ -97,27 +98,22 @@ struct UmiEqTable {
 // run's masks between the steps; twelve steps in ONE statement keep the run pure and were SLOWER (27.5 against 25.9 ms: every look-up must
 // have arrived before the first step, and what the compiler would have slipped in runs afterwards in a block of its own) -- an odd
 // instruction per seventeen does not cost the two-cycle rate, a block of them does (NOTES R5.1).
-#ifdef SMI_UMI_RUN_MONO  // measurement variant (make VARIANT=mono EXTRA=-DSMI_UMI_RUN_MONO): 27.5 ms against 25.9 per 0.94 G pairs
-#define SMI_MYERS2_RUN(E, O)                                                                                                      \
-    asm volatile(SMI_M2_STEP("%5") SMI_M2_STEP("%6") SMI_M2_STEP("%7") SMI_M2_STEP("%8") SMI_M2_STEP("%9") SMI_M2_STEP("%10")      \
-                     SMI_M2_STEP("%11") SMI_M2_STEP("%12") SMI_M2_STEP("%13") SMI_M2_STEP("%14") SMI_M2_STEP("%15") SMI_M2_STEP("%16") \
-                 : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b)                                                         \
-                 : "v"(E[O]), "v"(E[O + 1]), "v"(E[O + 2]), "v"(E[O + 3]), "v"(E[O + 4]), "v"(E[O + 5]), "v"(E[O + 6]), "v"(E[O + 7]), \
-                   "v"(E[O + 8]), "v"(E[O + 9]), "v"(E[O + 10]), "v"(E[O + 11]))
-#else
 #define SMI_MYERS2_ONE(X) asm volatile(SMI_M2_STEP("%5") : "+v"(pv), "+v"(mv), "=&v"(t_xv), "=&v"(t_a), "=&v"(t_b) : "v"(X))
-#define SMI_MYERS2_RUN(E, O)                                                                                                     \
-    do {                                                                                                                         \
-        SMI_MYERS2_ONE(E[O]); SMI_MYERS2_ONE(E[O + 1]); SMI_MYERS2_ONE(E[O + 2]); SMI_MYERS2_ONE(E[O + 3]); SMI_MYERS2_ONE(E[O + 4]);     \
-        SMI_MYERS2_ONE(E[O + 5]); SMI_MYERS2_ONE(E[O + 6]); SMI_MYERS2_ONE(E[O + 7]); SMI_MYERS2_ONE(E[O + 8]); SMI_MYERS2_ONE(E[O + 9]); \
-        SMI_MYERS2_ONE(E[O + 10]); SMI_MYERS2_ONE(E[O + 11]);                                                                    \
+// one run = UL steps (UL = umi_length, config.xml:264: 12 as shipped, 10 for the 10x v2 chemistry; 8 .. 12 built), fully unrolled so that E[O + k] are registers.
+// (Round 5 also measured the twelve steps as ONE asm statement: 27.5 against 25.9 ms per 0.94 G pairs, NOTES R5.1 -- not kept.)
+#define SMI_MYERS2_RUN(E, O)                                    \
+    do {                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < UL; k_++) SMI_MYERS2_ONE(E[(O) + k_]); \
     } while (0)
-#endif
 
 // distance << 12 of both fields, ready to take the enumeration rank and the offsets in the low bits (the clamp to 5 comes once, at the end)
+// (a pattern of UL < 12 bases lives in the low UL bits of its field: nothing in the recurrence moves information downwards, so the rows above
+// the pattern's last -- whatever the table holds there -- change no bit below them, and the last column is read off rows 0 .. UL - 1 only)
+template <int UL>
 __device__ __forceinline__ void myers2_scores(uint32_t pv, uint32_t mv, uint32_t &lo, uint32_t &hi) {
-    lo = (uint32_t)(__popc(pv & 0xFFFu) + 12 - __popc(mv & 0xFFFu)) << 12;
-    hi = (uint32_t)(__popc(pv >> 16) + 12 - __popc((mv >> 16) & 0xFFFu)) << 12;  // (Pv's guard bits are zero, Mv's are not)
+    constexpr uint32_t M = (1u << UL) - 1u;
+    lo = (uint32_t)(__popc(pv & M) + UL - __popc(mv & M)) << 12;
+    hi = (uint32_t)(__popc((pv >> 16) & M) + UL - __popc((mv >> 16) & M)) << 12;  // (Pv's guard bits are zero, Mv's are not)
 }
 
 // calcBestEditDistance L67-80 visits (i, v) in the order (1,2,0) x (1,2,0) and keeps the first strict minimum: the least of
@@ -127,32 +123,34 @@ __host__ __device__ constexpr uint32_t umi_rank_code(int i, int v) {
     return (uint32_t)((3 * ri + rv) << 8) | (uint32_t)(i << 4) | (uint32_t)(v << 6);
 }
 
-// the five runs on the fourteen looked-up words of a pair: w[j] = table entry of read a for the code of base j of read b
-__device__ __forceinline__ uint32_t umi_pair_runs(const uint32_t (&w)[14]) {
-    uint32_t w2[14];
+// the five runs on the UL + 2 looked-up words of a pair: w[j] = table entry of read a for the code of base j of read b
+template <int UL>
+__device__ __forceinline__ uint32_t umi_pair_runs(const uint32_t (&w)[UL + 2]) {
+    constexpr uint32_t kInit = ((1u << UL) - 1u) * 0x00010001u;  // Pv = D[i][0] - D[i-1][0] = +1 over the pattern's UL rows, both fields
+    uint32_t w2[UL + 2];
 #pragma unroll
-    for (int j = 0; j < 14; j++) w2[j] = w[j] >> 2;
-    uint32_t g[12];  // run 3: pattern offset 2 against text offsets 0 (low field) and 1 (high field): the low halves of w2[t] and w2[t + 1]
+    for (int j = 0; j < UL + 2; j++) w2[j] = w[j] >> 2;
+    uint32_t g[UL];  // run 3: pattern offset 2 against text offsets 0 (low field) and 1 (high field): the low halves of w2[t] and w2[t + 1]
 #pragma unroll
-    for (int t = 0; t < 12; t++) g[t] = __builtin_amdgcn_perm(w2[t + 1], w2[t], 0x05040100u);
+    for (int t = 0; t < UL; t++) g[t] = __builtin_amdgcn_perm(w2[t + 1], w2[t], 0x05040100u);
     uint32_t key = 0xFFFFFFFFu, lo, hi, t_xv, t_a, t_b;
 #pragma unroll
     for (int v = 0; v < 3; v++) {  // pattern offsets 0 / 1 against text offset v
-        uint32_t pv = 0x0FFF0FFFu, mv = 0u;
+        uint32_t pv = kInit, mv = 0u;
         SMI_MYERS2_RUN(w, v);
-        myers2_scores(pv, mv, lo, hi);
+        myers2_scores<UL>(pv, mv, lo, hi);
         key = min(key, min(lo | umi_rank_code(0, v), hi | umi_rank_code(1, v)));
     }
     {
-        uint32_t pv = 0x0FFF0FFFu, mv = 0u;
+        uint32_t pv = kInit, mv = 0u;
         SMI_MYERS2_RUN(g, 0);
-        myers2_scores(pv, mv, lo, hi);
+        myers2_scores<UL>(pv, mv, lo, hi);
         key = min(key, min(lo | umi_rank_code(2, 0), hi | umi_rank_code(2, 1)));
     }
     {
-        uint32_t pv = 0x0FFF0FFFu, mv = 0u;
+        uint32_t pv = kInit, mv = 0u;
         SMI_MYERS2_RUN(w2, 2);  // (the high field holds leftovers: its result is not read)
-        myers2_scores(pv, mv, lo, hi);
+        myers2_scores<UL>(pv, mv, lo, hi);
         key = min(key, lo | umi_rank_code(2, 2));
     }
     // limitedCompare: -1 above the threshold 4, stored as 5 (L343).  Distances of 5 and more are all 5 to the strict-minimum scan, so when
@@ -164,6 +162,7 @@ __device__ __forceinline__ uint32_t umi_pair_runs(const uint32_t (&w)[14]) {
 __device__ __forceinline__ uint32_t umi_word(uint32_t m) { return m | (m << 15); }  // a table entry from a 14-bit mask (UmiEqTable)
 
 // the flat kernel's pair: every lane writes the five live entries of its own column and looks its words up there
+template <int UL>
 __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable &T, int tid) {
     const EqMasks ma = eq_masks(a);
     T.e[1][tid] = umi_word(ma.a);
@@ -171,10 +170,10 @@ __device__ __forceinline__ uint32_t umi_pair(uint64_t a, uint64_t b, UmiEqTable 
     T.e[4][tid] = umi_word(ma.c);
     T.e[8][tid] = umi_word(ma.t);
     T.e[15][tid] = umi_word(ma.n);
-    uint32_t w[14];
+    uint32_t w[UL + 2];
 #pragma unroll
-    for (int j = 0; j < 14; j++) w[j] = T.e[(uint32_t)(b >> (4 * j)) & 15u][tid];
-    return umi_pair_runs(w);
+    for (int j = 0; j < UL + 2; j++) w[j] = T.e[(uint32_t)(b >> (4 * j)) & 15u][tid];
+    return umi_pair_runs<UL>(w);
 }
 
 // the tiled kernel's: the 64 rows of a tile share their read a with the 64 columns of that row, so the entries of a row are written ONCE per
@@ -195,11 +194,12 @@ __device__ __forceinline__ void umi_row_fill(UmiRowTable &R, int row, uint64_t a
     R.e[row][8] = umi_word(ma.t);
     R.e[row][15] = umi_word(ma.n);
 }
+template <int UL>
 __device__ __forceinline__ uint32_t umi_pair_row(const UmiRowTable &R, int row, uint64_t b) {
-    uint32_t w[14];
+    uint32_t w[UL + 2];
 #pragma unroll
-    for (int j = 0; j < 14; j++) w[j] = R.e[row][(uint32_t)(b >> (4 * j)) & 15u];
-    return umi_pair_runs(w);
+    for (int j = 0; j < UL + 2; j++) w[j] = R.e[row][(uint32_t)(b >> (4 * j)) & 15u];
+    return umi_pair_runs<UL>(w);
 }
 
 // every lane's column of the table: the codes that match nothing (everything but A, G, C, T, N) are zero and stay zero
@@ -253,6 +253,7 @@ __device__ __forceinline__ uint64_t tri_row(uint64_t n, uint64_t local) {
 
 // the flat kernel: one lane per pair (i <= v) of the groups of at most kUmiTileMin reads, pairs of all those groups in one index space
 // (plan[g].small_pairs = pairs in front of group g; a tiled group has none, so "the last g with plan[g].small_pairs <= t" never lands on one)
+template <int UL>
 __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ windows, const uint32_t *__restrict__ group_off,
                                                   const UmiPlan *__restrict__ plan, const uint64_t *__restrict__ mat_off,
                                                   uint32_t n_groups, uint8_t *__restrict__ out) {
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_umi_dist(const uint64_t *__restrict__ w
         const uint64_t n = group_off[g + 1] - r0;
         const uint64_t i = tri_row(n, local);
         const uint64_t v = i + (local - (i * n - i * (i - 1) / 2));
-        const uint32_t r = umi_pair(windows[r0 + i], windows[r0 + v], T, threadIdx.x);
+        const uint32_t r = umi_pair<UL>(windows[r0 + i], windows[r0 + v], T, threadIdx.x);
         uint8_t *m = out + mat_off[g];
         m[i * n + v] = (uint8_t)r;
         // transposed copy for the lower triangle (getTransposedEditDistance L133, L213-216): offsets swapped
@@ -304,6 +305,7 @@ constexpr int kUmiMacro = 4;               // tiles per macro-tile edge
 #endif
 constexpr int kUmiTileThreads = SMI_UMI_TILE_THREADS;
 
+template <int UL>
 __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64_t *__restrict__ windows, const uint32_t *__restrict__ group_off,
                                                                     const UmiPlan *__restrict__ plan, const uint64_t *__restrict__ mat_off,
                                                                     uint32_t n_groups, uint32_t *__restrict__ next_unit, uint8_t *__restrict__ out) {
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
                 const uint64_t i = bi0 + di, v = bv0 + dv;
                 const bool valid = i < n && v < n && i <= v;
                 uint32_t r = 0;
-                if (valid) r = umi_pair_row(R, 8 * si + di, win[v]);
+                if (valid) r = umi_pair_row<UL>(R, 8 * si + di, win[v]);
                 const uint32_t rt = (r & 15u) | (((r >> 6) & 3u) << 4) | (((r >> 4) & 3u) << 6);  // getTransposedEditDistance L133, L213-216
                 const bool whole = bi0 + 7 < bv0 && bv0 + 7 < n;  // every lane holds a pair above the diagonal
                 if (whole) {
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
 }
 
 int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
-                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s) {
+                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s, int umi_len) {
     (void)d_pair_off;  // (the flat index space of round 1; the two kernels take theirs from the plan below)
     if (!total_pairs || !n_groups) return SMI_OK;
     // plan: per group its pairs in the flat kernel or its tiles in the tiled one, prefix sums of both in one scan
@@ -423,8 +425,19 @@ int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_g
     // the grids from what the host knows: all pairs bound the flat kernel's; a tiled group has at least 2,145 pairs per macro-tile (65 reads)
     const unsigned grid = (unsigned)std::min<uint64_t>((total_pairs + 255) / 256, 256ull * 64);
     const unsigned grid_t = (unsigned)std::min<uint64_t>(total_pairs / 2145 + 1, 256ull * 2048 / kUmiTileThreads);
-    hipLaunchKernelGGL(k_umi_dist, dim3(grid), dim3(256), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_out);
-    hipLaunchKernelGGL(k_umi_dist_tiles, dim3(grid_t), dim3(kUmiTileThreads), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_next, d_out);
+    auto launch = [&](auto ul) {
+        constexpr int UL = decltype(ul)::value;
+        hipLaunchKernelGGL(k_umi_dist<UL>, dim3(grid), dim3(256), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_out);
+        hipLaunchKernelGGL(k_umi_dist_tiles<UL>, dim3(grid_t), dim3(kUmiTileThreads), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_next, d_out);
+    };
+    switch (umi_len) {  // umis/umi_length (config.xml:264)
+    case 12: launch(std::integral_constant<int, 12>()); break;
+    case 11: launch(std::integral_constant<int, 11>()); break;
+    case 10: launch(std::integral_constant<int, 10>()); break;
+    case 9: launch(std::integral_constant<int, 9>()); break;
+    case 8: launch(std::integral_constant<int, 8>()); break;
+    default: set_error("smi_umi_dist_device: umi_length must be 8 .. 12 in this build"); return SMI_ERR_INVALID;
+    }
     SMI_HIP(hipGetLastError());
     if (int rc = time_end(ctx, SMI_K_UMI, s)) return rc;
     return SMI_OK;

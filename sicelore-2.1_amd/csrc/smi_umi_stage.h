@@ -27,7 +27,7 @@ struct UmiGroupBuffers {  // device scratch of the grouping step; capacities for
 };
 
 int launch_umi_parse(smi_ctx *ctx, const char *d_names, const uint32_t *d_name_off, const uint16_t *d_flags, const int32_t *d_pos0, const uint32_t *d_cigars,
-                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, UmiParsed *d_out, hipStream_t s);
+                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, int umi_len, UmiParsed *d_out, hipStream_t s);
 size_t umi_group_scratch_bytes(int n);
 int launch_umi_region_keys(smi_ctx *ctx, const UmiParsed *d_parsed, int n, UmiGroupBuffers &B, uint32_t *d_counters, uint64_t *d_has_bits, hipStream_t s);
 int launch_umi_groups(smi_ctx *ctx, const UmiParsed *d_parsed, const int32_t *d_region, int n, int n_done, UmiGroupBuffers &B, uint64_t *totals, hipStream_t s);
@@ -35,7 +35,7 @@ int launch_umi_groups(smi_ctx *ctx, const UmiParsed *d_parsed, const int32_t *d_
 int launch_umi_cluster(smi_ctx *ctx, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups, const float *d_qv,
                        const smi_umi_cluster_config &cfg, int dev_max, smi_umi_assignment *d_asg, uint8_t *d_skipped, hipStream_t s);
 int launch_umi_tags(smi_ctx *ctx, const UmiParsed *d_parsed, const int32_t *d_region, int n, int n_done, const UmiGroupBuffers &B, uint32_t n_groups, uint32_t m,
-                    const smi_umi_assignment *d_asg, const uint8_t *d_skipped, smi_umi_tag *d_tags, hipStream_t s);
+                    const smi_umi_assignment *d_asg, const uint8_t *d_skipped, int umi_len, smi_umi_tag *d_tags, hipStream_t s);
 constexpr int kUmiClusterDeviceMax = 100;
 
 }  // namespace smi

@@ -108,7 +108,7 @@ __device__ __forceinline__ bool ref_position(const uint32_t *cigar, int n_cigar,
 __global__ __launch_bounds__(64) void k_umi_parse(const char *__restrict__ names, const uint32_t *__restrict__ name_off, const uint16_t *__restrict__ flags,
                                                   const int32_t *__restrict__ pos0, const uint32_t *__restrict__ cigars,
                                                   const uint32_t *__restrict__ cigar_off, int n, int five, int grouping_distance, int bc_edit_limit,
-                                                  UmiParsed *__restrict__ out) {
+                                                  int umi_len, UmiParsed *__restrict__ out) {
     // The names of the wave's 64 records are consecutive in memory: one coalesced copy of that byte range into LDS (16 bytes per lane and
     // step), every lane then reads its own name from there.  (Staging row by row -- 64 rows x 4 dependent rounds -- made this kernel
     // latency-bound: 0.83 ms per 120 k records.)  A block of unusually long names falls back to rows of kNameStage characters.
@@ -277,9 +277,9 @@ __global__ __launch_bounds__(64) void k_umi_parse(const char *__restrict__ names
             if (has_bc && has_bc_end && p_x >= 0 && has_q) {
                 const int xe = value_end(p_x), x_len = xe - p_x;
                 const long pos = five ? bc_end - ae + 3 : ae + 3 - bc_end;
-                if (pos >= 1 && pos + 13 <= (long)x_len) {
+                if (pos >= 1 && pos + umi_len + 1 <= (long)x_len) {   // umi_len + 2 bases: the umi_length-mers at offsets -1 / 0 / +1
                     uint64_t w = 0;
-                    for (int k = 0; k < 14; k++) {
+                    for (int k = 0; k < umi_len + 2; k++) {
                         const uint32_t c = five ? ucode4(v.at(p_x + (int)(pos - 1 + k))) : ucomp4(ucode4(v.at(p_x + x_len - (int)(pos + k))));
                         w |= (uint64_t)c << (4 * k);
                     }
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64) void k_umi_parse(const char *__restrict__ names
             }
             // clustering position
             if ((five || has_ps) && !(fl & 4)) {
-                const int read_pos = five ? (int)ae + 16 + 12 + grouping_distance : (int)ps - grouping_distance;
+                const int read_pos = five ? (int)ae + 16 + umi_len + grouping_distance : (int)ps - grouping_distance;
                 int p = 0;
                 if (ref_position(cigars + cigar_off[i], (int)(cigar_off[i + 1] - cigar_off[i]), pos0[i] + 1, read_pos, &p)) {
                     P.flags |= UP_HAS_POS;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_umi_cluster(const uint8_t *__res
 // ---------------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ char udec4(uint32_t c) { return c == 1 ? 'A' : c == 2 ? 'G' : c == 4 ? 'C' : c == 8 ? 'T' : 'N'; }
 
-__global__ void k_umi_tag_base(const UmiParsed *__restrict__ parsed, const int32_t *__restrict__ region, int n, int n_done, smi_umi_tag *__restrict__ tags) {
+__global__ void k_umi_tag_base(const UmiParsed *__restrict__ parsed, const int32_t *__restrict__ region, int n, int n_done, int umi_len, smi_umi_tag *__restrict__ tags) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     smi_umi_tag t;
@@ -656,14 +656,14 @@ __global__ void k_umi_tag_base(const UmiParsed *__restrict__ parsed, const int32
         if ((P.flags & UP_PRESENT) && (P.flags & UP_HAS_BC)) t.flags |= SMI_UMI_HAS_BC;
         if (P.flags & UP_HAS_W) {
             t.flags |= SMI_UMI_HAS_U7;
-            for (int k = 0; k < 12; k++) t.u7[k] = udec4((uint32_t)(P.win >> (4 * (k + 1))) & 15u);
+            for (int k = 0; k < umi_len; k++) t.u7[k] = udec4((uint32_t)(P.win >> (4 * (k + 1))) & 15u);
         }
     }
     tags[i] = t;
 }
 
 __global__ void k_umi_tag_groups(const uint32_t *__restrict__ group_off, uint32_t n_groups, const uint32_t *__restrict__ order, const uint64_t *__restrict__ wpk,
-                                 const smi_umi_assignment *__restrict__ asg, const uint8_t *__restrict__ skipped, uint32_t m, smi_umi_tag *__restrict__ tags) {
+                                 const smi_umi_assignment *__restrict__ asg, const uint8_t *__restrict__ skipped, uint32_t m, int umi_len, smi_umi_tag *__restrict__ tags) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= m) return;
     uint32_t lo = 0, hi = n_groups;  // group of member j
@@ -686,17 +686,17 @@ __global__ void k_umi_tag_groups(const uint32_t *__restrict__ group_off, uint32_
     t.u1 = a.ed;
     t.u2 = a.ed_second;
     const uint64_t cw = wpk[g0 + (uint32_t)a.center];
-    for (int k = 0; k < 12; k++) t.u8[k] = udec4((uint32_t)(cw >> (4 * (k + 1 + a.offset))) & 15u);
+    for (int k = 0; k < umi_len; k++) t.u8[k] = udec4((uint32_t)(cw >> (4 * (k + 1 + a.offset))) & 15u);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // launches
 // ---------------------------------------------------------------------------------------------------------------------------
 int launch_umi_parse(smi_ctx *, const char *d_names, const uint32_t *d_name_off, const uint16_t *d_flags, const int32_t *d_pos0, const uint32_t *d_cigars,
-                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, UmiParsed *d_out, hipStream_t s) {
+                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, int umi_len, UmiParsed *d_out, hipStream_t s) {
     if (!n) return SMI_OK;
     hipLaunchKernelGGL(k_umi_parse, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_names, d_name_off, d_flags, d_pos0, d_cigars, d_cigar_off, n, five,
-                       grouping_distance, bc_edit_limit, d_out);
+                       grouping_distance, bc_edit_limit, umi_len, d_out);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }
@@ -796,10 +796,10 @@ int launch_umi_cluster(smi_ctx *, const uint8_t *d_dist, const uint64_t *d_mat_o
 }
 
 int launch_umi_tags(smi_ctx *, const UmiParsed *d_parsed, const int32_t *d_region, int n, int n_done, const UmiGroupBuffers &B, uint32_t n_groups, uint32_t m,
-                    const smi_umi_assignment *d_asg, const uint8_t *d_skipped, smi_umi_tag *d_tags, hipStream_t s) {
+                    const smi_umi_assignment *d_asg, const uint8_t *d_skipped, int umi_len, smi_umi_tag *d_tags, hipStream_t s) {
     if (!n) return SMI_OK;
-    hipLaunchKernelGGL(k_umi_tag_base, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_parsed, d_region, n, n_done, d_tags);
-    if (m) hipLaunchKernelGGL(k_umi_tag_groups, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, B.group_off, n_groups, B.order, B.wpk, d_asg, d_skipped, m, d_tags);
+    hipLaunchKernelGGL(k_umi_tag_base, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_parsed, d_region, n, n_done, umi_len, d_tags);
+    if (m) hipLaunchKernelGGL(k_umi_tag_groups, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, B.group_off, n_groups, B.order, B.wpk, d_asg, d_skipped, m, umi_len, d_tags);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

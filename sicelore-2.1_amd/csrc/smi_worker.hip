@@ -101,15 +101,6 @@ int grow_arena_keep(smi_ctx *ctx, size_t bytes, size_t keep_bytes, hipStream_t s
     return SMI_OK;
 }
 
-// -p / -f / -w of scanfastq (smi_ctx_set_polya): the chunk workers' configurations are the shipped ones with these three fields replaced
-inline void apply_polya(const smi_ctx *ctx, smi_scan_config &sc) {
-    if (ctx->polya_len) sc.polya_len = ctx->polya_len;
-    if (ctx->polya_frac != 0.0f) sc.polya_frac = ctx->polya_frac;
-    if (ctx->polya_window) sc.window_polya = ctx->polya_window;
-}
-inline void apply_polya(const smi_ctx *ctx, smi_chimera_config &cc) {
-    if (ctx->polya_window) cc.window_polya = ctx->polya_window;  // (the splitter keeps away from the read ends by windowSearchForPolyA + 70)
-}
 
 #define SMI_RC(call)                 \
     do {                             \
@@ -193,8 +184,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         uint64_t *d_foffs = A.take<uint64_t>(3 * cap + 1);
         d_fsrc = A.take<uint32_t>(3 * cap);
         smi_chimera_config cc;
-        SMI_RC(five ? smi_chimera_default_config_5p(&cc) : smi_chimera_default_config(&cc));
-        apply_polya(ctx, cc);
+        SMI_RC(worker_chimera_config(ctx, five, &cc));
         SMI_RC(smi_pack_reads_text_device(ctx, d_text, d_ss, d_offs, n, total, d_planes, s));
         SMI_RC(smi_chimera_device(ctx, d_planes, d_offs, n, total, &cc, d_chim, s));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
@@ -219,8 +209,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     smi_bc_window *d_win = A.take<smi_bc_window>(m_cap);
     smi_bc_result *d_bc = A.take<smi_bc_result>(m_cap);
     smi_scan_config sc;
-    SMI_RC(five ? smi_scan_default_config_5p(2, cfg->dont_search_polya, &sc) : smi_scan_default_config(2, &sc));
-    apply_polya(ctx, sc);
+    SMI_RC(worker_scan_config(ctx, 2, five, cfg->dont_search_polya, &sc));
     // no qualities here: the quality filter (pass1_ok) belongs to pass 1 (UsedCellBCListGenerator.java:L198-202)
     SMI_RC(smi_frag_text_starts_device(ctx, d_ss, d_qs, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_bstart, d_qstart, s));
     SMI_RC(smi_pack_ends_text_device(ctx, d_text, d_bstart, d_rec_offs, m, d_ends, d_len, s));
@@ -390,8 +379,7 @@ int pass1_chunk_core(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five
     smi_scan_result *d_scan = A.take<smi_scan_result>(cap);
     smi_bc_window *d_win = A.take<smi_bc_window>(cap);
     smi_scan_config sc;
-    SMI_RC(five_prime ? smi_scan_default_config_5p(1, dont_search_polya, &sc) : smi_scan_default_config(1, &sc));
-    apply_polya(ctx, sc);
+    SMI_RC(worker_scan_config(ctx, 1, five_prime, dont_search_polya, &sc));
     SMI_RC(smi_pack_ends_device(ctx, d_reads, d_quals, d_offs, n, five_prime, d_ends, d_len, d_qtail, d_qsum, s));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, n, &sc, d_scan, d_win, s));
     if (d_hist)
@@ -484,8 +472,7 @@ int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *
         d_foffs = A.take<uint64_t>(3 * n + 1);
         d_fsrc = A.take<uint32_t>(3 * n);
         smi_chimera_config cc;
-        SMI_RC(five ? smi_chimera_default_config_5p(&cc) : smi_chimera_default_config(&cc));
-        apply_polya(ctx, cc);
+        SMI_RC(worker_chimera_config(ctx, five, &cc));
         SMI_RC(launch_chimera(ctx, d_planes, d_offs, n, total, &cc, d_chim, s, d_pstart, pstride));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
         SMI_RC(ensure_host_buf(ctx, smi_ctx::HB_CHIM, n * sizeof(smi_chimera_result)));
@@ -511,8 +498,7 @@ int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *
     smi_bc_window *d_win = A.take<smi_bc_window>(m_cap);
     smi_bc_result *d_bc = A.take<smi_bc_result>(m_cap);
     smi_scan_config sc;
-    SMI_RC(five ? smi_scan_default_config_5p(2, cfg->dont_search_polya, &sc) : smi_scan_default_config(2, &sc));
-    apply_polya(ctx, sc);
+    SMI_RC(worker_scan_config(ctx, 2, five, cfg->dont_search_polya, &sc));
     SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_ends, d_len, s, d_pstart));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
@@ -714,8 +700,7 @@ extern "C" int smi_scanfastq_pass1_chunk_packed(smi_ctx *ctx, const uint8_t *tex
     SMI_HIP(hipMemcpyAsync(d_qtail, h_qtail, n * (size_t)SMI_END_BASES, hipMemcpyHostToDevice, s));
     SMI_HIP(hipMemcpyAsync(d_qsum, h_qsum, n * 4, hipMemcpyHostToDevice, s));
     smi_scan_config sc;
-    SMI_RC(five_prime ? smi_scan_default_config_5p(1, dont_search_polya, &sc) : smi_scan_default_config(1, &sc));
-    apply_polya(ctx, sc);
+    SMI_RC(worker_scan_config(ctx, 1, five_prime, dont_search_polya, &sc));
     SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_offs, nullptr, n, d_ends, d_len, s, d_pstart));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, d_qtail, d_qsum, n, &sc, d_scan, d_win, s));
     SMI_RC(smi_hist_windows_device(ctx, d_win, d_scan, n, d_hist, s));
@@ -845,14 +830,14 @@ inline uint32_t code4(char c) {
 inline uint32_t comp4(uint32_t c) { return c == 1 ? 8 : c == 8 ? 1 : c == 2 ? 4 : c == 4 ? 2 : 15; }
 inline char dec4(uint32_t c) { return c == 1 ? 'A' : c == 2 ? 'G' : c == 4 ? 'C' : c == 8 ? 'T' : 'N'; }
 
-// the three 12-mers at offsets -1, 0, +1 behind the barcode on the reverse complement of X= (ClusteringEditDistanceBase L297-350,
-// getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378): 14 bases, 4-bit codes, base k in bits [4k+3:4k]
+// the three umi_length-mers (12 as shipped) at offsets -1, 0, +1 behind the barcode on the reverse complement of X= (ClusteringEditDistanceBase L297-350,
+// getStrandedShortSeqPosFromReadPos FastqRecordExt.java:L378): umi_length + 2 bases, 4-bit codes, base k in bits [4k+3:4k]
 // 5' barcoding: X= is read forwards (getSeq(), L312-313) and the barcode end on it is bcEnd - AE + 3 (L378 with is5pBarcoding)
-bool umi_window(const NameData &d, bool five_prime, uint64_t *packed) {
+bool umi_window(const NameData &d, bool five_prime, int umi_len, uint64_t *packed) {
     const long pos = five_prime ? d.bc_end - d.ae + 3 : d.ae + 3 - d.bc_end;
-    if (!d.x || pos < 1 || pos + 13 > (long)d.x_len) return false;
+    if (!d.x || pos < 1 || pos + umi_len + 1 > (long)d.x_len) return false;
     uint64_t w = 0;
-    for (int k = 0; k < 14; k++) {
+    for (int k = 0; k < umi_len + 2; k++) {
         const uint32_t c = five_prime ? code4(d.x[(size_t)(pos - 1 + k)]) : comp4(code4(d.x[d.x_len - (size_t)(pos + k)]));
         w |= (uint64_t)c << (4 * k);
     }
@@ -863,6 +848,9 @@ bool umi_window(const NameData &d, bool five_prime, uint64_t *packed) {
 }  // namespace
 
 namespace {
+// umis/umi_length of a chunk: the configuration's, else the context's knob, else 12
+int chunk_umi_length(const smi_ctx *ctx, const smi_assignumis_config *cfg) { return cfg->umi_length > 0 ? cfg->umi_length : ctx_umi_length(ctx); }
+
 // The chunk on host threads, K-UMI alone on the device (rounds 1 and 2): the path of record for anything the device parser does not
 // evaluate itself (UP_NONSTD: barcodes that are not 16 letters of ACGT, exotic number formats) and for SMI_AU_HOST=1, which the tests
 // use to hold the device stage to it.
@@ -871,6 +859,7 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
                           const smi_assignumis_config *cfg, smi_umi_tag *out, int32_t *n_done) {
     *n_done = 0;
     if (n == 0) return SMI_OK;
+    const int UL = chunk_umi_length(ctx, cfg);
     // SMI_AU_TIMING=1: the host stages of this call on stderr (where the time of the second worker goes)
     const bool timing = std::getenv("SMI_AU_TIMING") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
@@ -904,7 +893,7 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
                 const bool five = cfg->five_prime != 0;
                 if (nd[i].present && (five || nd[i].has_ps) && !(flags[i] & 4)) {
                     int32_t p = 0;
-                    const int32_t read_pos = five ? (int32_t)nd[i].ae + 16 + 12 + cfg->grouping_distance : (int32_t)nd[i].ps - cfg->grouping_distance;
+                    const int32_t read_pos = five ? (int32_t)nd[i].ae + 16 + UL + cfg->grouping_distance : (int32_t)nd[i].ps - cfg->grouping_distance;
                     rc = smi_ref_position_at_read_position(cigars + cigar_off[i], (int32_t)(cigar_off[i + 1] - cigar_off[i]), pos0[i] + 1, read_pos, &p);
                     if (rc < 0) {
                         rcs[t] = rc;
@@ -954,13 +943,13 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
                 const NameData &d = nd[i];
                 const bool bc_ok = d.present && d.has_bc && d.has_bc_end && d.x && d.has_q;
                 uint64_t w = 0;
-                const bool ok = bc_ok && umi_window(d, cfg->five_prime != 0, &w);
+                const bool ok = bc_ok && umi_window(d, cfg->five_prime != 0, UL, &w);
                 if (d.present && d.has_bc) out[i].flags |= SMI_UMI_HAS_BC;
                 if (ok) {
                     win[i] = w;
                     has_w[i] = 1;
                     out[i].flags |= SMI_UMI_HAS_U7;
-                    for (int k = 0; k < 12; k++) out[i].u7[k] = dec4((uint32_t)(w >> (4 * (k + 1))) & 15u);
+                    for (int k = 0; k < UL; k++) out[i].u7[k] = dec4((uint32_t)(w >> (4 * (k + 1))) & 15u);
                 }
             }
         };
@@ -1061,7 +1050,7 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
     SMI_HIP(hipMemcpyAsync(d_go, goff.data(), goff.size() * 4, hipMemcpyHostToDevice, s));
     SMI_HIP(hipMemcpyAsync(d_po, poff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
     SMI_HIP(hipMemcpyAsync(d_mo, moff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
-    SMI_RC(smi_umi_dist_device(ctx, d_w, d_go, d_po, d_mo, n_groups, poff.back(), d_dist, s));
+    SMI_RC(launch_umi_dist(ctx, d_w, d_go, d_po, d_mo, n_groups, poff.back(), d_dist, s, UL));
     std::vector<uint8_t> dist(moff.back());
     SMI_HIP(hipMemcpyAsync(dist.data(), d_dist, moff.back(), hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
@@ -1088,7 +1077,7 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
             t.u1 = asg[j].ed;
             t.u2 = asg[j].ed_second;
             const uint64_t cw = win[c];
-            for (int k = 0; k < 12; k++) t.u8[k] = dec4((uint32_t)(cw >> (4 * (k + 1 + asg[j].offset))) & 15u);
+            for (int k = 0; k < UL; k++) t.u8[k] = dec4((uint32_t)(cw >> (4 * (k + 1 + asg[j].offset))) & 15u);
         }
     return SMI_OK;
 }
@@ -1120,6 +1109,11 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     }
     *n_done = 0;
     if (n == 0) return SMI_OK;
+    const int UL = chunk_umi_length(ctx, cfg);
+    if (UL < 8 || UL > 12) {
+        set_error("smi_assignumis_chunk: umis/umi_length must be 8 .. 12 in this build");
+        return SMI_ERR_INVALID;
+    }
     smi_umi_cluster_config cc;
     SMI_RC(smi_umi_cluster_default_config(&cc));
     if (cfg->cluster) cc = *cfg->cluster;
@@ -1185,7 +1179,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     SMI_HIP(hipMemcpyAsync(d_flags, flags, N * 2, hipMemcpyHostToDevice, s));
     SMI_HIP(hipMemcpyAsync(d_pos0, pos0, N * 4, hipMemcpyHostToDevice, s));
     if (n_cig) SMI_HIP(hipMemcpyAsync(d_cig, cigars, n_cig * 4, hipMemcpyHostToDevice, s));
-    SMI_RC(launch_umi_parse(ctx, d_names, d_noff, d_flags, d_pos0, d_cig, d_coff, n, cfg->five_prime != 0, cfg->grouping_distance, cfg->bc_edit_limit, d_parsed, s));
+    SMI_RC(launch_umi_parse(ctx, d_names, d_noff, d_flags, d_pos0, d_cig, d_coff, n, cfg->five_prime != 0, cfg->grouping_distance, cfg->bc_edit_limit, UL, d_parsed, s));
     // region grouping: the sort by clustering position runs on the device; the sorted keys (8 bytes per read with a position) come down, the
     // chains and their refinement -- a sequential sweep with the reference's own quirks -- run on the host, the region numbers go up
     const size_t n_words = (N + 63) / 64;
@@ -1223,7 +1217,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
             ctx->umi_dist_bytes = want;
         }
         uint8_t *d_dist = static_cast<uint8_t *>(ctx->umi_dist);
-        SMI_RC(smi_umi_dist_device(ctx, B.wpk, B.group_off, B.pair_off, B.mat_off, n_groups, totals[2], d_dist, s));
+        SMI_RC(launch_umi_dist(ctx, B.wpk, B.group_off, B.pair_off, B.mat_off, n_groups, totals[2], d_dist, s, UL));
         int dev_max = std::min(cc.own_clusterer_above, kUmiClusterDeviceMax);
         if (cc.single_link_switch < dev_max) dev_max = cc.single_link_switch;  // (never with the shipped values: the switch sits at 3000)
         SMI_RC(launch_umi_cluster(ctx, d_dist, B.mat_off, B.group_off, n_groups, B.qv, cc, dev_max, d_asg, d_skipped, s));
@@ -1264,7 +1258,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
             lap("big groups");
         }
     }
-    SMI_RC(launch_umi_tags(ctx, d_parsed, d_region, n, *n_done, B, n_groups, m, d_asg, d_skipped, d_tags, s));
+    SMI_RC(launch_umi_tags(ctx, d_parsed, d_region, n, *n_done, B, n_groups, m, d_asg, d_skipped, UL, d_tags, s));
     SMI_HIP(hipMemcpyAsync(out, d_tags, N * sizeof(smi_umi_tag), hipMemcpyDeviceToHost, s));
     SMI_HIP(hipStreamSynchronize(s));
     lap("tags");

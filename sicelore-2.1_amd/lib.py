@@ -62,6 +62,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into", "smi_gene_counts_dump", "smi_gene_counts_load", "smi_gene_counts_merge_shard",
+    "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
     "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen", "smi_name_set_create", "smi_name_set_free", "smi_name_set_seen",
 ]
 
@@ -97,6 +98,11 @@ def load_library():
     lib.smi_ctx_lane_refresh.argtypes = [vp]
     lib.smi_ctx_device.argtypes = [vp]
     lib.smi_ctx_set_polya.argtypes = [vp, ci, ctypes.c_float, ci]
+    lib.smi_run_knobs_default.argtypes = [vp]
+    lib.smi_ctx_set_knobs.argtypes = [vp, vp]
+    lib.smi_ctx_get_knobs.argtypes = [vp, vp]
+    lib.smi_scan_config_from_knobs.argtypes = [vp, ci, ci, ci, vp]
+    lib.smi_chimera_config_from_knobs.argtypes = [vp, ci, vp]
     lib.smi_set_barcode_set.argtypes = [vp, vp, sz, ci]
     lib.smi_set_barcode_set_device.argtypes = [vp, vp, sz, ci, vp]
     lib.smi_bc_match_batch.argtypes = [vp, vp, sz, ci, ci, vp]
@@ -687,7 +693,7 @@ class AssignUmisConfig(ctypes.Structure):
     """smi_assignumis_config"""
     _fields_ = [("max_dist", ctypes.c_int32), ("grouping_distance", ctypes.c_int32), ("bc_edit_limit", ctypes.c_int32),
                 ("keep_data_end", ctypes.c_int32), ("n_threads", ctypes.c_int32), ("five_prime", ctypes.c_int32),
-                ("cluster", ctypes.c_void_p)]
+                ("umi_length", ctypes.c_int32), ("cluster", ctypes.c_void_p)]
 
 
 class PinnedBuffer:
@@ -1016,6 +1022,77 @@ def bam_index_records(bam, start, cap):
     return recs[:n.value], end.value
 
 
+class RunKnobs(ctypes.Structure):
+    """smi_run_knobs: the knobs of Jar/config.xml the library takes at run time (include/sicelore_mi.h)"""
+    _fields_ = [("min_read_length", ctypes.c_int32), ("min_mean_bc_qv", ctypes.c_int32), ("min_mean_read_qv", ctypes.c_int32),
+                ("min_adapter_3p_matches", ctypes.c_int32), ("polya_len", ctypes.c_int32), ("polya_frac", ctypes.c_float),
+                ("window_polya", ctypes.c_int32), ("internal_pat_len", ctypes.c_int32), ("internal_pat_frac", ctypes.c_float),
+                ("adapter3p", ctypes.c_char * 32), ("adapter3p_complete", ctypes.c_char * 32), ("adapter3p_max_mm", ctypes.c_int32),
+                ("adapter3p_complete_max_mm", ctypes.c_int32), ("adapter5p", ctypes.c_char * 32), ("adapter5p_complete", ctypes.c_char * 32),
+                ("adapter5p_max_mm", ctypes.c_int32), ("adapter5p_complete_max_mm", ctypes.c_int32), ("adapter5p_window", ctypes.c_int32),
+                ("adapter3p5_complete", ctypes.c_char * 32), ("adapter3p5_complete_max_mm", ctypes.c_int32), ("tso_complete", ctypes.c_char * 32),
+                ("tso_complete_max_mm", ctypes.c_int32), ("umi_length", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_[:-1]:
+            v = getattr(self, name)
+            out[name] = v.decode() if isinstance(v, bytes) else v
+        return out
+
+
+# config.xml element ("section/knob" under <Parameters>) -> field of smi_run_knobs
+KNOB_FIELDS = {
+    "readscanner/minReadLength": "min_read_length", "readscanner/minMeanBCqv": "min_mean_bc_qv", "readscanner/minMeanReadqv": "min_mean_read_qv",
+    "readscanner/minAdapter3pMatches": "min_adapter_3p_matches",
+    "polyAT/polyATlength": "polya_len", "polyAT/fractionATInPolyAT": "polya_frac", "polyAT/windowSearchForPolyA": "window_polya",
+    "polyAT/internalpATlength": "internal_pat_len", "polyAT/internalFractionATInPolyAT": "internal_pat_frac",
+    "adapter_for3pBarcoding/sequence": "adapter3p", "adapter_for3pBarcoding/sequence_complete": "adapter3p_complete",
+    "adapter_for3pBarcoding/maxNeedlemanMismatches": "adapter3p_max_mm", "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter3p_complete_max_mm",
+    "fiveprimeadapter_for5pBarcoding/sequence": "adapter5p", "fiveprimeadapter_for5pBarcoding/sequence_complete": "adapter5p_complete",
+    "fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches": "adapter5p_max_mm",
+    "fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter5p_complete_max_mm",
+    "fiveprimeadapter_for5pBarcoding/AdapterSearchWindow": "adapter5p_window",
+    "threeprimeadapter_for5pBarcoding/sequence_complete": "adapter3p5_complete",
+    "threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter3p5_complete_max_mm",
+    "tso_for3pBarcoding/sequence_complete": "tso_complete", "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "tso_complete_max_mm",
+    "umis/umi_length": "umi_length",
+}
+
+
+def run_knobs(**overrides):
+    """smi_run_knobs with the shipped config.xml values, fields replaced by name (RunKnobs) or by config.xml element (KNOB_FIELDS)"""
+    k = RunKnobs()
+    lib = load_library()
+    if lib.smi_run_knobs_default(ctypes.byref(k)):
+        raise SmiError(lib.smi_last_error().decode())
+    kinds = dict(RunKnobs._fields_)
+    for name, v in overrides.items():
+        f = KNOB_FIELDS.get(name, name)
+        if f not in kinds or f == "reserved":
+            raise SmiError(f"no run-time knob {name!r}")
+        t = kinds[f]
+        if t is ctypes.c_float or t is ctypes.c_int32:
+            try:
+                setattr(k, f, float(v) if t is ctypes.c_float else int(v))
+            except ValueError:
+                raise SmiError(f"{name} = {v!r}: not a number")
+        else:
+            b = v.encode() if isinstance(v, str) else bytes(v)
+            if len(b) > 31:
+                raise SmiError(f"{name}: sequence of {len(b)} bases (this build: up to 27)")
+            setattr(k, f, b)
+    return k
+
+
+def check_run_knobs(knobs):
+    """the limits of this build, without a device (what smi_ctx_set_knobs checks): SmiError names the knob"""
+    lib = load_library()
+    cfg = np.zeros(1, dtype=SCAN_CONFIG_DTYPE)
+    if lib.smi_scan_config_from_knobs(ctypes.byref(knobs), 2, 0, 0, _ptr(cfg)):
+        raise SmiError(lib.smi_last_error().decode())
+
+
 class Context:
     """One per GPU.  Stands where the reference keeps ``hashMapForBCfinding`` + a ``Parser`` worker
     (FJ!nanoporereadscanner/analyzers/Parser.java:L70-78)."""
@@ -1040,6 +1117,16 @@ class Context:
         """-p / -f / -w of scanfastq for this context's chunk workers (smi_ctx_set_polya; 0 keeps the shipped value); lanes created or
         refreshed afterwards take them over"""
         self._check(self._lib.smi_ctx_set_polya(self._h, int(polya_len), float(polya_frac), int(window_polya)))
+
+    def set_knobs(self, knobs=None):
+        """config.xml's knobs for this context's chunk workers (smi_ctx_set_knobs; None: the shipped file); lanes created or refreshed
+        afterwards take them over.  SmiError names the knob this build has no kernel for."""
+        self._check(self._lib.smi_ctx_set_knobs(self._h, ctypes.byref(knobs) if knobs is not None else None))
+
+    def get_knobs(self):
+        k = RunKnobs()
+        self._check(self._lib.smi_ctx_get_knobs(self._h, ctypes.byref(k)))
+        return k
 
     def refresh(self):
         """lane: pick up the barcode set its owner has loaded since (smi_ctx_lane_refresh)"""
@@ -1097,10 +1184,12 @@ class Context:
                                               _stream_ptr(stream)))
 
     # ---- read scan ---------------------------------------------------------------------------------------
-    def scan_config(self, pass_no=2):
-        """shipped config.xml values; pass 1 = complete adapter (22 nt), pass 2 = short adapter (10 nt)"""
+    def scan_config(self, pass_no=2, knobs=None, five_prime=False, dont_search_polya=False):
+        """shipped config.xml values, or what the chunk workers derive from `knobs` (smi_scan_config_from_knobs); pass 1 = complete adapter
+        (22 nt), pass 2 = short adapter (10 nt)"""
         cfg = np.zeros(1, dtype=SCAN_CONFIG_DTYPE)
-        self._check(self._lib.smi_scan_default_config(int(pass_no), _ptr(cfg)))
+        self._check(self._lib.smi_scan_config_from_knobs(ctypes.byref(knobs) if knobs is not None else None, int(pass_no), int(five_prime),
+                                                         int(dont_search_polya), _ptr(cfg)))
         return cfg
 
     def pack_ends_device(self, d_reads, d_quals, d_offsets, n, d_ends, d_len, d_qtail=None, d_qsum=None, stream=None,
@@ -1356,7 +1445,8 @@ class Context:
             raise SmiError(f"smi_gzip_device: error flags {int(t[1])}")
         return d_out[:int(t[0])]
 
-    def assignumis_chunk_raw(self, inp, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4, five_prime=False, cluster_cfg=None):
+    def assignumis_chunk_raw(self, inp, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4, five_prime=False, cluster_cfg=None,
+                             umi_length=0, grouping_distance=None):
         """the same on the buffers of bam_chunk_inputs -> (UMI_TAG_DTYPE array, n_done)"""
         n = inp["n"]
         cfg = AssignUmisConfig()
@@ -1364,6 +1454,9 @@ class Context:
         cfg.max_dist, cfg.keep_data_end, cfg.n_threads = int(max_dist), int(keep_data_end), int(n_threads)
         cfg.five_prime = int(bool(five_prime))
         cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
+        cfg.umi_length = int(umi_length)               # umis/umi_length (0: the context's knob, 12 without one)
+        if grouping_distance is not None:              # barcodes/distance_from_read_end_for_grouping
+            cfg.grouping_distance = int(grouping_distance)
         if cluster_cfg is not None:
             cluster_cfg = np.ascontiguousarray(cluster_cfg, dtype=UMI_CLUSTER_CONFIG_DTYPE)
             cfg.cluster = cluster_cfg.ctypes.data
@@ -1375,7 +1468,7 @@ class Context:
         return out[:n], nd.value
 
     def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
-                         five_prime=False, cluster_cfg=None):
+                         five_prime=False, cluster_cfg=None, umi_length=0, grouping_distance=None):
         """one BamReader chunk through the native worker -> (UMI_TAG_DTYPE array, n_done); names: list of QNAME strings,
         cigars: list of numpy uint32 arrays (BAM encoding)"""
         n = len(names)
@@ -1393,6 +1486,9 @@ class Context:
         cfg.max_dist, cfg.keep_data_end, cfg.n_threads = int(max_dist), int(keep_data_end), int(n_threads)
         cfg.five_prime = int(bool(five_prime))
         cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
+        cfg.umi_length = int(umi_length)               # umis/umi_length (0: the context's knob, 12 without one)
+        if grouping_distance is not None:              # barcodes/distance_from_read_end_for_grouping
+            cfg.grouping_distance = int(grouping_distance)
         if cluster_cfg is not None:  # umi_cluster_config(...) record: the clusterer's knobs (shipped values otherwise)
             cluster_cfg = np.ascontiguousarray(cluster_cfg, dtype=UMI_CLUSTER_CONFIG_DTYPE)
             cfg.cluster = cluster_cfg.ctypes.data
@@ -1404,10 +1500,11 @@ class Context:
         return out[:n], nd.value
 
     # ---- chimera splitter ----------------------------------------------------------------------------------
-    def chimera_config(self, five_prime=False):
+    def chimera_config(self, five_prime=False, knobs=None):
+        """the splitter's configuration: shipped, or from `knobs` (its strings then point into that object: it is kept alive on the result)"""
         cfg = ChimeraConfig()
-        fn = self._lib.smi_chimera_default_config_5p if five_prime else self._lib.smi_chimera_default_config
-        self._check(fn(ctypes.byref(cfg)))
+        self._check(self._lib.smi_chimera_config_from_knobs(ctypes.byref(knobs) if knobs is not None else None, int(five_prime), ctypes.byref(cfg)))
+        cfg._knobs = knobs
         return cfg
 
     def read_planes_words(self, total_bases, n):

@@ -48,6 +48,33 @@ def _inflate(path, pinned=False):
 FASTQ_PATTERN = r".{1,}\.fastq(\.gz)?"     # ParametersReadScannerApp$Files.fastqFilenamePattern (ParametersReadScannerApp.java:L203)
 
 
+def out_base_ext(name):
+    """(base, extension) of an input file's two outputs `<base>_passed.<extension>` / `<base>_failed.<extension>` as the reference's writer thread
+    names them (FastqWriterThreadPool$FastQoneFileThread.init L242-250: commons-io getBaseName / getExtension, a final `gz` taken together with the
+    extension in front of it): the INPUT's extension, whatever --compress says about the content"""
+    base, dot, ext = name.rpartition(".")
+    if not dot:
+        base, ext = name, ""
+    if ext.lower() == "gz":
+        b2, dot2, e2 = base.rpartition(".")
+        if not dot2:
+            b2, e2 = base, ""
+        base, ext = b2, e2 + "." + ext
+    return base, ext
+
+
+def check_output_names(files):
+    """two inputs whose outputs would be the same two files (the same file name in two directories of a -d list or of a recursive walk): the
+    reference opens both writers on one path and the chunks of the two inputs overwrite each other; here the run stops before it starts"""
+    seen = {}
+    for f in files:
+        key = out_base_ext(os.path.basename(f))
+        if key in seen:
+            raise _lib.SmiError(f"input files {seen[key]} and {f} have the same name: both would be written to passed/{key[0]}_passed.{key[1]} and "
+                                f"failed/{key[0]}_failed.{key[1]} (the reference's writer threads would overwrite each other's records); rename one of them or run the directories separately")
+        seen[key] = f
+
+
 def find_fastqs(in_dirs, recursive=True, pattern=FASTQ_PATTERN, skip=0, limit=None):
     """the input files as the reference finds them (FileTools.getInfiles, FileTools.java:L37-59 + FoundFiles.initialize L81-82): `in_dirs` is a
     comma-separated list of directories, each walked (all levels, or only the directory itself with -n; links followed), the regular files of
@@ -157,7 +184,7 @@ def run(ctx, in_dir, out_dir, *args, polya=None, **kw):
 def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
         dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="host", device_share=0.25, group=None, resident_bytes=96 << 30,
         host_text_bytes=256 << 30, inflate_auto_from=1024, recursive=True, pattern=r".{1,}\.(fastq|fq)(\.gz)?", skip_files=0, only_files=None,
-        used_keys=None, write_fastqs=True, trim_fastq=False):
+        used_keys=None, write_fastqs=True, trim_fastq=False, merge_ed=None, min_count_fold=10, cells_fold_below_max=500):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
@@ -196,6 +223,8 @@ def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, 
     files = find_fastqs(in_dir, recursive=recursive, pattern=pattern, skip=skip_files, limit=only_files)     # full paths
     if not files:
         raise _lib.SmiError(f"NO INPUT FILES FOUND in {in_dir}")
+    if write_fastqs:
+        check_output_names(files)          # over ALL files, before they are dealt to the ranks
     given = used_keys is not None
     nowl = not given and whitelist_keys is None      # -a none: no list of possible barcodes, every barcode seen in pass 1 is counted
     if multi:
@@ -490,10 +519,13 @@ def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, 
             h = hist.cpu().numpy()
             nz = np.nonzero(h)[0]
             hk, hc = keys[nz], h[nz].astype(np.uint32)
-        k, c, r = _lib.finalize_used_list(hk, hc, record_count, max_ed, 10, 500)
+        # config.xml: mergeBCsED (null = --bcEditDistance), minCountFold, cellsWithReadsnFoldBelowMaxToKeep (UsedCellBCListGenerator.java:L397-402,
+        # BarcodeDatasetColissionTester.java:L68-229)
+        m_ed = max_ed if merge_ed is None else int(merge_ed)
+        k, c, r = _lib.finalize_used_list(hk, hc, record_count, m_ed, min_count_fold, cells_fold_below_max)
         if rank == 0:
             with open(os.path.join(out_dir, "BarcodeList.tsv"), "w") as f:
-                f.write(_lib.barcode_list_tsv(hk, hc, record_count, max_ed, no_whitelist=nowl))
+                f.write(_lib.barcode_list_tsv(hk, hc, record_count, m_ed, min_count_fold, cells_fold_below_max, no_whitelist=nowl))
         if nowl and k.size and int(k.max()) >> 32:
             # a 5' barcode that was cut with an N in it is a long with its upper half set (UsedCellBCListGenerator.java:L219; NOTES R5.10): it can
             # only ever equal a window with the same N, which the matcher does not probe -- such an entry stays in the TSVs and leaves the search set
@@ -540,17 +572,13 @@ def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, 
     # go into ONE table under a lock.
     counts = np.zeros((k.size, 3), dtype=np.int64)
     counts_lock = threading.Lock()
-    ext = ".fastq.gz" if compress else ".fastq"
     out_state = {}                                 # file index -> [lock, next chunk to write, {chunk: (passed, failed)}, handles or None]
     for fi_ in chunks_of:
         out_state[fi_] = [threading.Lock(), 0, {}, None]
 
     def out_names(fi):
-        base = os.path.basename(files[fi])
-        for suf in (".gz", ".fastq", ".fq"):
-            if base.endswith(suf):
-                base = base[:-len(suf)]
-        return os.path.join(out_dir, "passed", base + "_passed" + ext), os.path.join(out_dir, "failed", base + "_failed" + ext)
+        base, ext = out_base_ext(os.path.basename(files[fi]))
+        return os.path.join(out_dir, "passed", f"{base}_passed.{ext}"), os.path.join(out_dir, "failed", f"{base}_failed.{ext}")
 
     def deliver(fi, ci, zp, zf):
         if not write_fastqs:

@@ -170,11 +170,12 @@ def _channel(src, forced_del, g, err, frac, width):
 
 
 def gen_reads(n, used_keys, seed=5, device=None, err=0.063, frac=(0.4, 0.3, 0.3), n_rate=0.0, max_mid=1500,
-              q_mean=12.0):
+              q_mean=12.0, adapter_complete=ADAPTER_3P_COMPLETE, tso_complete=None, umi_len=12):
     """n synthetic 3' reads, kept as their two END_BASES-long ends + the length of the (unmaterialised) middle.
 
     read (transcript sense) = TSO + cDNA + polyA(20..60) + rc(UMI12) + rc(BC16) + rc(CTACACGACGCTCTTCCGATCT);
-    half of the reads are reverse-complemented.  Returns a dict of tensors:
+    half of the reads are reverse-complemented.  adapter_complete / tso_complete / umi_len: other config.xml sequences and UMI lengths (the
+    defaults leave every seeded batch as it was).  Returns a dict of tensors:
       head, tail  uint8 [n, END_BASES]  raw read's first / last bases (2-bit codes, 4 = N)
       qhead, qtail uint8 [n, END_BASES] Phred+33 of those bases;  qmid uint8 [n] quality of every middle base
       mid_len int64 [n]; length = 2*END_BASES + mid_len; reverse bool [n]; truth int64 [n]; umi int64 [n]
@@ -187,12 +188,12 @@ def gen_reads(n, used_keys, seed=5, device=None, err=0.063, frac=(0.4, 0.3, 0.3)
     cell = torch.multinomial(w, n, replacement=True, generator=g)
     truth = used_keys.to(device)[cell]
     bc = keys_to_codes(truth, 16)
-    umi = torch.randint(0, 4, (n, 12), generator=g, device=device, dtype=torch.int64)
-    umi_key = (umi << (torch.arange(11, -1, -1, device=device, dtype=torch.int64) * 2)).sum(-1)
+    umi = torch.randint(0, 4, (n, umi_len), generator=g, device=device, dtype=torch.int64)
+    umi_key = (umi << (torch.arange(umi_len - 1, -1, -1, device=device, dtype=torch.int64) * 2)).sum(-1)
     # barcode end (transcript sense, right-aligned at the read's 3' end)
     pad = torch.randint(0, 4, (n, 160), generator=g, device=device, dtype=torch.int64)
     polya = torch.zeros((n, 60), dtype=torch.int64, device=device)
-    ad = _rc(_codes(ADAPTER_3P_COMPLETE, device)).expand(n, -1)
+    ad = _rc(_codes(adapter_complete, device)).expand(n, -1)
     src = torch.cat([pad, polya, _rc(umi), _rc(bc), ad], dim=1)
     pa_len = torch.randint(20, 61, (n,), generator=g, device=device)
     forced = torch.zeros(src.shape, dtype=torch.bool, device=device)
@@ -202,8 +203,8 @@ def gen_reads(n, used_keys, seed=5, device=None, err=0.063, frac=(0.4, 0.3, 0.3)
     idx = (tot3 - E).clamp(min=0).unsqueeze(1) + torch.arange(E, device=device)
     end3 = torch.gather(out3, 1, idx.clamp(max=W - 1))
     # TSO end (left-aligned at the 5' end)
-    tso = _codes(TSO_COMPLETE, device).expand(n, -1)
-    cdna = torch.randint(0, 4, (n, 230), generator=g, device=device, dtype=torch.int64)
+    tso = _codes(tso_complete or TSO_COMPLETE, device).expand(n, -1)
+    cdna = torch.randint(0, 4, (n, 260 - tso.shape[1]), generator=g, device=device, dtype=torch.int64)
     out5, _ = _channel(torch.cat([tso, cdna], dim=1), torch.zeros((n, 260), dtype=torch.bool, device=device), g, err,
                        frac, W)
     end5 = out5[:, :E]

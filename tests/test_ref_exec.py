@@ -427,29 +427,36 @@ _POS = {"MINUSONE": 0, "ZERO": 1, "PLUSONE": 2}
 
 def _umi_windows(sor, sec):
     win = []
+    ul = sec.get("umi_length", 12)
     for nm in sec["names"]:
         b = nm["barcode"]
         x = "".join({1: "A", 2: "G", 4: "C", 8: "T", 15: "N"}[c] for c in nm["x_codes"])
         f = sor.umi_window_5p if sec["five_prime"] else sor.umi_window_3p
-        win.append(f(x, nm["adapter_end"], b["end"]))
+        win.append(f(x, nm["adapter_end"], b["end"], ul))
     return win
 
 
-@pytest.mark.parametrize("name", ["umi_3p", "umi_5p"])
+# (umi_*_len10, round 6: the reference's classes run with <umi_length>10</umi_length> -- a knob of config.xml the product takes at run time)
+@pytest.mark.parametrize("name", ["umi_3p", "umi_5p", "umi_3p_len10", "umi_5p_len10"])
 def test_umi_pair_distances_equal_reference_bytecode(sor, name):
     sec = load(name)["sections"][0]
+    ul = sec.get("umi_length", 12)
     win = _umi_windows(sor, sec)
-    assert all(w is not None for w in win)
+    assert all(w is not None and len(w) == ul + 2 for w in win)
+    dec = {1: "A", 2: "G", 4: "C", 8: "T", 15: "N"}
+    for w, nm in zip(win, sec["names"]):
+        if "post_bc_umi" in nm:     # OneNanoporeResult.getPostBCUMIseqOffset(-1 / 0 / +1): what U7 (offset 0) and a centre's U8 are cut from
+            assert ["".join(dec[int(c)] for c in w[1 + off:1 + off + ul]) for off in (-1, 0, 1)] == nm["post_bc_umi"]
     seen = set()
     for c in sec["cases"]:
         for (a, b), want in (((c["i"], c["j"]), c["distance"]), ((c["j"], c["i"]), c["reverse"])):
-            r = sor.umi_pair(win[a], win[b])
+            r = sor.umi_pair(win[a], win[b], ul)
             assert (r & 15, (r >> 4) & 3, (r >> 6) & 3) == (want["ed"], _POS[want["pos1"]], _POS[want["pos2"]]), (a, b, want)
             seen.add(want["ed"])
     assert seen == {0, 1, 2, 3, 4, 5}
 
 
-@pytest.mark.parametrize("name", ["umi_3p", "umi_5p"])
+@pytest.mark.parametrize("name", ["umi_3p", "umi_5p", "umi_3p_len10", "umi_5p_len10"])
 def test_read_name_parser_equals_reference_bytecode(pkg, name):
     """the product's host-side name parser (assignumis.scan_data_from_name = FastqRecordExt.getScanDatFromReadName) and its UMI
     window against what the reference's bytecode parsed out of the same names"""

@@ -106,10 +106,11 @@ def _chunk_section_through_worker(gpu_ctx, sec, packed, wide):
         assert n_out >= n_in + 30   # fragments of split reads
 
 
-@pytest.mark.parametrize("name", ["umi_3p", "umi_5p"])
+@pytest.mark.parametrize("name", ["umi_3p", "umi_5p", "umi_3p_len10", "umi_5p_len10"])
 def test_k_umi_distances_equal_reference_bytecode(pkg, gpu_ctx, name):
     """K-UMI on the windows the product cuts out of the read names == ClusteringEditDistanceBase.calcEditDistances executed from
-    the reference's class files (3' and 5' / -p)"""
+    the reference's class files (3' and 5' / -p; *_len10: with <umi_length>10</umi_length> in config.xml -- the knob on the context,
+    smi_ctx_set_knobs), and the U7 the UMI stage writes for every read == OneNanoporeResult.getPostBCUMIseqOffset(read, 0)"""
     import importlib
 
     import torch
@@ -118,19 +119,41 @@ def test_k_umi_distances_equal_reference_bytecode(pkg, gpu_ctx, name):
     with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
         sec = json.load(f)["sections"][0]
     five = sec["five_prime"]
+    ul = sec.get("umi_length", 12)
     wins = []
     for nm in sec["names"]:
         d = au.scan_data_from_name(nm["name"])
-        w = au.umi_window(d["x"], d["ae"], d["bc"]["end"], five)
+        w = au.umi_window(d["x"], d["ae"], d["bc"]["end"], five, ul)
         assert w is not None
         wins.append(au.pack_window(w))
     n = len(wins)
     dev = torch.device("cuda", gpu_ctx.device)
     go, po, mo = gpu_ctx.umi_offsets([n])
     d_out = torch.zeros(int(mo[-1]), dtype=torch.uint8, device=dev)
-    gpu_ctx.umi_dist_device(torch.from_numpy(np.array(wins, dtype=np.uint64).view(np.int64)).to(dev), torch.from_numpy(go.view(np.int32)).to(dev),
-                            torch.from_numpy(po.view(np.int64)).to(dev), torch.from_numpy(mo.view(np.int64)).to(dev), 1, int(po[-1]), d_out)
-    torch.cuda.synchronize()
+    if ul != 12:
+        gpu_ctx.set_knobs(pkg.lib.run_knobs(umi_length=ul))
+    try:
+        gpu_ctx.umi_dist_device(torch.from_numpy(np.array(wins, dtype=np.uint64).view(np.int64)).to(dev), torch.from_numpy(go.view(np.int32)).to(dev),
+                                torch.from_numpy(po.view(np.int64)).to(dev), torch.from_numpy(mo.view(np.int64)).to(dev), 1, int(po[-1]), d_out)
+        torch.cuda.synchronize()
+        if ul != 12:
+            # the whole stage on these names (device path and host path): U7 = the reference's getPostBCUMIseqOffset(read, 0), umi_length characters
+            names = [nm["name"] for nm in sec["names"]]
+            cig = [np.array([(1200 << 4) | 0], dtype=np.uint32)] * n
+            for host in (False, True):
+                if host:
+                    os.environ["SMI_AU_HOST"] = "1"
+                try:
+                    for kw in (dict(), dict(umi_length=ul)):     # the context's knob / the chunk configuration's field
+                        tags, n_done = gpu_ctx.assignumis_chunk(names, np.zeros(n, np.uint16), np.arange(n, dtype=np.int32) * 7, cig, five_prime=five, **kw)
+                        assert n_done == n
+                        for t, nm in zip(tags, sec["names"]):
+                            assert t["flags"] & pkg.lib.UMI_HAS_U7 and t["u7"].decode() == nm["post_bc_umi"][1], (host, kw, nm["name"])
+                finally:
+                    os.environ.pop("SMI_AU_HOST", None)
+    finally:
+        if ul != 12:
+            gpu_ctx.set_knobs(None)
     m = d_out.cpu().numpy().reshape(n, n)
     pos = {"MINUSONE": 0, "ZERO": 1, "PLUSONE": 2}
     for c in sec["cases"]:

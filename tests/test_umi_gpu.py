@@ -143,3 +143,106 @@ def test_assignumis_chunk_large_groups_equal_oracle(pkg, sor, gpu_ctx, n, own_ab
         m2 = (np.asarray(mat).reshape(n, n) & 15) <= 2
         np.fill_diagonal(m2, False)
         assert int(m2.any(axis=1).sum()) > 3000
+
+
+# ---- umis/umi_length other than 12 (config.xml:264; smi_ctx_set_knobs, round 6) ---------------------------------------------------------------
+@pytest.mark.parametrize("ul", [8, 9, 10, 11])
+def test_umi_matrices_of_other_umi_lengths_match_oracle(pkg, sor, gpu_ctx, ul):
+    """K-UMI<UL>: flat kernel (small groups) and tiled kernel (groups above 64 reads) against the oracle's matrices of umi_length-mers; the
+    windows carry garbage in the nibbles above their umi_length + 2 bases (nothing may read them)"""
+    from sicelore_amd import lib as libmod
+
+    sizes = [2, 3, 1, 7, 64, 5, 130, 2, 33, 65, 257]
+    ws = _make_groups(100 + ul, sizes)[:, :ul + 2]
+    packed = _pack(np.concatenate([ws, np.zeros((ws.shape[0], 12 - ul), np.uint8)], axis=1))
+    packed |= np.random.default_rng(ul).integers(0, 1 << 62, packed.size, dtype=np.uint64) & ~np.uint64((1 << (4 * (ul + 2))) - 1)   # garbage above the window
+    go, po, mo = gpu_ctx.umi_offsets(sizes)
+    d_out = torch.full((int(mo[-1]),), 255, dtype=torch.uint8, device="cuda")
+    gpu_ctx.set_knobs(libmod.run_knobs(umi_length=ul))
+    try:
+        gpu_ctx.umi_dist_device(torch.from_numpy(packed.view(np.int64)).cuda(), torch.from_numpy(go.view(np.int32)).cuda(), torch.from_numpy(po.view(np.int64)).cuda(),
+                                torch.from_numpy(mo.view(np.int64)).cuda(), len(sizes), int(po[-1]), d_out)
+        torch.cuda.synchronize()
+    finally:
+        gpu_ctx.set_knobs(None)
+    out = d_out.cpu().numpy()
+    seen = set()
+    for g, n in enumerate(sizes):
+        exp = sor.umi_matrix(ws[go[g]:go[g + 1]], ul)
+        got = out[int(mo[g]):int(mo[g + 1])].reshape(n, n)
+        assert (got == exp).all(), (ul, g)
+        seen |= set((exp & 15).reshape(-1).tolist())
+    assert seen == {0, 1, 2, 3, 4, 5}
+    # and the same windows read as 12-mers give other matrices (the length is not decoration)
+    d12 = torch.full((int(mo[-1]),), 255, dtype=torch.uint8, device="cuda")
+    gpu_ctx.umi_dist_device(torch.from_numpy(packed.view(np.int64)).cuda(), torch.from_numpy(go.view(np.int32)).cuda(), torch.from_numpy(po.view(np.int64)).cuda(),
+                            torch.from_numpy(mo.view(np.int64)).cuda(), len(sizes), int(po[-1]), d12)
+    torch.cuda.synchronize()
+    assert (d12.cpu().numpy() != out).any()
+
+
+def _name_with_window_len(i, w, q, ul, five, bc="ACGTACGTACGTACGT"):
+    """a pass-2 read name whose UMI window holds the ul + 2 codes of w: 3' on the reverse complement of X= from AE + 3 - bcEnd on, 5' on X= from
+    bcEnd - AE + 3 on"""
+    dec = {1: "A", 2: "G", 4: "C", 8: "T", 15: "N"}
+    comp = {1: "T", 2: "C", 4: "G", 8: "A", 15: "N"}
+    if five:
+        x = ["A"] * 42
+        for k in range(ul + 2):
+            x[18 + k] = dec[int(w[k])]                      # bcEnd - AE + 3 = 19 (1-based) with AE = 50, bcEnd = 66
+        return f"r{i}_FWD_AE=50_bc={bc}_ed=0_bcStart=51_bcEnd=66_X={''.join(x)}_Q={q}_{i:x} cellBC={bc}"
+    x = ["A"] * 43
+    for k in range(ul + 2):
+        x[24 - k] = comp[int(w[k])]
+    return f"r{i}_FWD_PS=700_PE=730_AE=743_bc={bc}_ed=0_ed_sec=3_bcStart=742_bcEnd=727_X={''.join(x)}_Q={q}_{i:x} cellBC={bc}"
+
+
+@pytest.mark.parametrize("ul,five,host", [(10, False, False), (10, True, False), (10, False, True), (8, False, False), (11, True, False)])
+def test_assignumis_chunk_with_other_umi_lengths_equals_oracle(pkg, sor, gpu_ctx, ul, five, host, monkeypatch):
+    """the whole UMI stage (K-UPARSE windows of umi_length + 2 bases, K-UMI<UL>, K-UCLUST / the own clusterer, K-UTAG's umi_length characters) for
+    groups of 2 .. 300 reads of one cell against the oracle's matrices and clusterer; 5': the clustering position is the reference position under
+    AE + 16 + umi_length + 100 (NanoporeRead$ReadScanData.java:L90)"""
+    from sicelore_amd import lib as libmod
+
+    if host:
+        monkeypatch.setenv("SMI_AU_HOST", "1")
+    rng = np.random.default_rng(1000 + ul + five)
+    sizes = [3, 4, 9, 40, 100, 130, 300, 7]              # (a region needs more than two reads: ReadGrouper.java:L171-184)
+    ws_all, names, pos0 = [], [], []
+    for g, n in enumerate(sizes):
+        ws = _make_groups(50 + g + ul, [n])[:, :ul + 2]
+        qs = [f"{v:.1f}".rstrip("0").rstrip(".") for v in rng.uniform(8, 25, n)]
+        offs = np.zeros(n, dtype=np.int64)                    # one position per group (ReadGrouper's off-centre rules are not the subject here)
+        for i in range(n):
+            names.append(_name_with_window_len(len(names), ws[i], qs[i], ul, five))
+            pos0.append(100_000 + 5_000 * g + int(offs[i]))
+        ws_all.append((ws, np.array([float(q) for q in qs], dtype=np.float32)))
+    n = len(names)
+    cigars = [np.array([1000 << 4], dtype=np.uint32)] * n
+    tags, n_done = gpu_ctx.assignumis_chunk(names, np.zeros(n, np.uint16), np.array(pos0, dtype=np.int32), cigars, n_threads=4, five_prime=five, umi_length=ul)
+    assert n_done == n
+    dec = {1: "A", 2: "G", 4: "C", 8: "T", 15: "N"}
+    ws_flat = np.concatenate([w for w, _ in ws_all])
+    qv_flat = np.concatenate([q for _, q in ws_all])
+    n_clustered = n_grouped = 0
+    for j in range(n):
+        assert tags["u7"][j].decode() == "".join(dec[int(c)] for c in ws_flat[j][1:1 + ul]), j
+    # the groups as ReadGrouper cut them (one cell: a group = a region; the read that opens a new chain can stay without a region), members in input order
+    for reg in sorted(set(int(r) for r in tags["region"] if r >= 0)):
+        mem = np.nonzero(tags["region"] == reg)[0]
+        m = mem.size
+        if m < 2:
+            continue
+        n_grouped += m
+        ws, qv = ws_flat[mem], qv_flat[mem]
+        exp, exp_sk = sor.umi_cluster_group(sor.umi_matrix(ws, ul).reshape(-1), m, qv)
+        for j in range(m):
+            t = tags[mem[j]]
+            if exp["center"][j] < 0:
+                assert not (t["flags"] & libmod.UMI_CLUSTERED), (reg, j)
+                continue
+            n_clustered += 1
+            c, off = int(exp["center"][j]), int(exp["offset"][j])
+            assert t["flags"] & libmod.UMI_CLUSTERED and t["center"] == mem[c] and t["u1"] == exp["ed"][j] and t["u2"] == exp["ed_second"][j], (reg, j)
+            assert t["u8"].decode() == "".join(dec[int(ws[c][k + 1 + off])] for k in range(ul)), (reg, j)
+    assert n_grouped > 0.95 * n and n_clustered > 300

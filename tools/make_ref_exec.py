@@ -1211,22 +1211,28 @@ def fake_name(rng, k, five_prime, bc, umi, rev, ae, shift, ed=0):
     return f"read{k}_{'REV' if rev else 'FWD'}_{core}_rk={1 + k % 40}_X={x}_Q={q}_{k + 1:x}"
 
 
-def gen_umi(g, five_prime, seed, n_mol=14):
+def gen_umi(g, five_prime, seed, n_mol=14, umi_len=12):
     j = g.j
     rng = random.Random(seed)
     side = UmiSide(g, five_prime)
+    if umi_len != 12:                  # <umi_length> of config.xml's <umis> (UMIparameters.umi_length: a primitive int, set by JAXB from the element)
+        side.par.f["umis"].f["umi_length"] = umi_len
     out = {"jar": "NanoporeBC_UMI_finder-2.1.jar", "sections": []}
     s = g.section(("5-prime (-p)" if five_prime else "3-prime") + " assignumis: FastqRecordExt.getScanDatFromReadName(name) (L395-496), then "
                   "ClusteringEditDistanceBase.calcEditDistances (lambda$static$7, L297-350) for read pairs: 9 limited Levenshtein "
                   "distances between the 12-mers at offsets -1 / 0 / +1 behind the barcode, best = first strict minimum in EnumSet order "
                   "(calcBestEditDistance L67-80)", CED, "calcEditDistances / calcBestEditDistance")
     s["five_prime"] = five_prime
+    s["umi_length"] = umi_len
+    if umi_len != 12:
+        s["title"] += f".  config.xml with <umi_length>{umi_len}</umi_length>: the {umi_len}-mers; `post_bc_umi` = OneNanoporeResult.getPostBCUMIseqOffset(read, params, offset) " \
+                      "for offset -1 / 0 / +1 (L107-113: what U7 -- offset 0 -- and a centre's U8 are cut from)"
     bc = rnd_seq(rng, 16)
     names = []
     for m in range(n_mol):
-        umi = rnd_seq(rng, 12)
+        umi = rnd_seq(rng, umi_len)
         for r in range(rng.choice([1, 2, 3, 3, 4])):
-            u = umi if r == 0 else mutate(rng, umi, rng.choice([0, 1, 1, 2, 3]))[:12].ljust(12, "A")
+            u = umi if r == 0 else mutate(rng, umi, rng.choice([0, 1, 1, 2, 3]))[:umi_len].ljust(umi_len, "A")
             names.append(fake_name(rng, len(names), five_prime, bc, u, rng.random() < 0.5, rng.randrange(300, 900), rng.choice([0, 0, 0, -1, 1])))
     parsed, results = [], []
     for nm in names:
@@ -1250,6 +1256,13 @@ def gen_umi(g, five_prime, seed, n_mol=14):
                                                             "rank": iv(bcr, "rank")},
                        "x_codes": None if seq is None else list(seq.f["naData"].a), "mean_qv": iv(sd, "mean_qv"), "read_id": sd.f["read_id"]})
         results.append(side.result_for(sd))
+        if umi_len != 12:
+            post = []
+            for off in (-1, 0, 1):
+                o = j.call_static(ONR, "getPostBCUMIseqOffset", f"(L{ONR};L{UPAR};I)Ljava/util/Optional;", results[-1], side.par, off)
+                v = o.native[0] if isinstance(o.native, tuple) else None
+                post.append(None if v is None else j.call_virtual(v, "toString", "()Ljava/lang/String;"))
+            parsed[-1]["post_bc_umi"] = post
     s["names"] = parsed
     for a in range(len(names)):
         for b in range(a + 1, len(names)):
@@ -1265,6 +1278,15 @@ def gen_umi_3p(g):
 
 def gen_umi_5p(g):
     return gen_umi(g, True, 818)
+
+
+def gen_umi_3p_len10(g):
+    """round 6: umis/umi_length = 10 (10x 3' v2 / 5' v1-v2 chemistry), a value of config.xml the product takes at run time"""
+    return gen_umi(g, False, 828, umi_len=10)
+
+
+def gen_umi_5p_len10(g):
+    return gen_umi(g, True, 838, umi_len=10)
 
 # ---------------------------------------------------------------------------------------------------------------------
 # a-14: ChimeraFindernew.findSplitPositions on whole records (pass 2, before the scan)
@@ -2953,7 +2975,7 @@ def gen_auxorder(g, seed=2222):
     return out
 
 
-SECTIONS = {"auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
+SECTIONS = {"umi_3p_len10": gen_umi_3p_len10, "umi_5p_len10": gen_umi_5p_len10, "auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
             "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
