@@ -171,6 +171,12 @@ int smi_ctx_lane_refresh(smi_ctx *lane);
  * load in ~300 ms (SMI_SET_MEMBERSHIP: ~10 ms), a used list in a few ms.  Results never depend on these structures ("Switches"). */
 int smi_set_barcode_set(smi_ctx *ctx, const uint64_t *keys, size_t n, int mode);
 int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, int mode, void *stream);
+/* What the last smi_set_barcode_set[_device] of this context built (round 6: the one-time cost behind the matchers, for `bench.py`'s set_build_ms /
+ * set_hbm_bytes and for cross-checks of the build kernels): out[0] distinct keys, out[1] bytes of device memory the structures of the loaded set
+ * occupy (pyramid + nb + nb5 + nt + n1 / n2 / nb2 as far as they are valid for this set), out[2] wall time of the build in microseconds (launch to
+ * drained stream), out[3] bits set in nb, out[4] bits set in nb5, out[5] an order-sensitive digest of nb5 (sum of popcount(word) * (index mod 2^20 + 1)),
+ * out[6] slots of nt, out[7] entries in nt.  With digests != 0 the counting kernels run (a few ms for the whole whitelist); 0 leaves out[3..7] zero. */
+int smi_set_stats(smi_ctx *ctx, uint64_t out[8], int digests);
 
 /* Replaces BarcodeMatchTester.call for the 5 offsets + the best/second rule of Parser.assignBarcode
  * (BarcodeMatchTester.java:L198-374, Parser.java:L203-311).  max_ed in {0,1,2}; five_prime = 1 for -h/--fivePbc. */

@@ -9,8 +9,10 @@
  * Shipped parameters: Jar/config.xml:99-101 (internal polyA/T 15 bases, fraction 0.70), :105 (window 150),
  * :113,:118 (complete adapter CTACACGACGCTCTTCCGATCT, 5 errors), :170-172 (complete TSO, 6 errors),
  * :189,:264 (16-base barcode + 12-base UMI).
- * PARITY UNPINNED by the reference (no tests/fixtures, no JVM in the image): pinned by an independent Python model
- * and hand-built reads in tests/.
+ * PARITY UNPINNED by the reference (no tests/fixtures, no JVM in the image; status of all oracle files: sor_bc.c).  Held by
+ * executed-bytecode fixtures -- ref_exec_chimera_3p.json (findSplitPositions on whole records), ref_exec_pass2w_*.json,
+ * pass2x_* (reads aimed at single branches), pass2p (other polyA windows), pass2k (other config.xml knobs) through Parser.call --
+ * an independent Python model (tests/pymodel_chimera.py) and hand-built reads in tests/.
  */
 #include <stdio.h>
 #include <stdlib.h>

@@ -19,7 +19,9 @@
  * The reference is NOT reproducible on this step: group members arrive in the order of a parallel
  * stream, LingPipe iterates HashSet<PairScore> by identity hash, and parallel collectors fill the fastutil maps.
  * Canonical rules used here and in the product: members in input order; PairScore sets in creation order; fastutil
- * collections filled in ascending index order.  PARITY UNPINNED (no reference tests, no JVM).
+ * collections filled in ascending index order.  PARITY UNPINNED (no reference tests, no JVM; sor_bc.c has the status of all
+ * oracle files).  Held by ref_exec_cluster.json (70 groups under eight hash orders), ref_exec_cluster_own{,2}.json (ClusterOne_MyClustering);
+ * NOT pinned: centres of 1- and 2-read clusters and owners on size ties (fastutil iteration order).
  */
 #include <math.h>
 #include <stdlib.h>

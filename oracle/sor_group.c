@@ -8,7 +8,9 @@
  *   NanoporeRead$ReadScanData.getReferencePositionAtReadPosition   FJ!umifinder/reads/nanopore/NanoporeRead$ReadScanData.java:L133-153
  *   (alignment blocks as htsjdk 4.1.3 SAMUtils.getAlignmentBlocks builds them from the CIGAR)
  * Region ids: the reference numbers clusters from a static counter; only equality matters, ids here are the ordinal of
- * the cluster in the final list.  PARITY UNPINNED (no reference tests, no JVM).
+ * the cluster in the final list.  PARITY UNPINNED (no reference tests, no JVM; sor_bc.c has the status of all
+ * oracle files).  Held by ref_exec_group.json (120 chunks) and ref_exec_group2.json (merge-back designs; the reference's own NullPointerException on
+ * seven of them is recorded there), ref_exec_clusterpos.json (the grouping position of 320 records).
  */
 #include <math.h>
 #include <stdlib.h>

@@ -3,7 +3,7 @@
  *
  * 4-bit codec helpers, Needleman-Wunsch + traceback, the NeedlemanMatch statistics, the 4-mer gate and
  * AdapterTSOanalyzer.scanForAdapterOrTSOseq.  Citations: FJ! = NanoporeBC_UMI_finder-2.1.jar,
- * TB! = TwoFourBitNucAcidLibraryMaven-1.0.jar, Class.java:Lnn.  PARITY UNPINNED (see sor_scan.c).
+ * TB! = TwoFourBitNucAcidLibraryMaven-1.0.jar, Class.java:Lnn.  PARITY UNPINNED (see sor_bc.c; held by ref_exec_nw.json: alignments, statistics, tie-breaks).
  */
 #ifndef SOR_NW_H
 #define SOR_NW_H

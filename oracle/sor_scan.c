@@ -4,8 +4,10 @@
  * CPU restatement of the reference's 3' read scan: polyA/T finder, k-mer gated Needleman-Wunsch adapter scan,
  * strand decision / adapter acceptance, and the pass-1 quality filter.  Citations as in sor_bc.c
  * (FJ! = NanoporeBC_UMI_finder-2.1.jar, TB! = TwoFourBitNucAcidLibraryMaven-1.0.jar, Class.java:Lnn).
- * PARITY UNPINNED by the reference (no tests/fixtures, no JVM in the image): pinned by hand-derived vectors and
- * an independent Python model in tests/.
+ * PARITY UNPINNED by the reference (no tests/fixtures, no JVM in the image; status of all oracle files: sor_bc.c).  Held by
+ * executed-bytecode fixtures -- ref_exec_polyat{,_params}.json (the finder, shipped and other windows), ref_exec_nw.json,
+ * ref_exec_onebyte.json (4-mer gate), ref_exec_pass1*.json (the pass-1 filter), ref_exec_pass2*_*.json (search + rules inside whole
+ * records / chunks; pass2k: other config.xml knobs) -- hand-derived vectors and an independent Python model (tests/pymodel_scan.py).
  */
 #include <math.h>
 #include <stdlib.h>

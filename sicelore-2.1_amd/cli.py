@@ -347,7 +347,7 @@ def scanfastq(argv):
             ctx.set_knobs(run_knobs)
         except _lib.SmiError as e:
             raise CliError(f"{cfg_path}: {e}")
-    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, merge_ed=merge_ed, **host_kw, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
+    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, merge_ed=merge_ed, command_line="scanfastq " + " ".join(argv), **host_kw, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
                          dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")),
                          recursive="nonrecursive" not in o, pattern=o.get("pattern", run_files.FASTQ_PATTERN), skip_files=skip, only_files=only,
                          used_keys=used, write_fastqs="dontwrite" not in o, trim_fastq="trimfastq" in o)

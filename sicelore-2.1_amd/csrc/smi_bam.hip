@@ -6,7 +6,10 @@
 // absent from /root/reference; the formats are restated from the published specification.  Blocks are independent, so
 // they are inflated on n_threads host threads (zlib); records are length-prefixed, so their index is one sequential
 // pass (it runs at memory speed; nothing here belongs on the device).
-#include <zlib.h>
+#include <dlfcn.h>
+#include <zlib.h>  // types and constants only: libz is NOT linked -- smi_bgzf_deflate (the host-side BGZF writer with zlib's levels, a legacy path) looks it up with
+                   // dlopen on its first call, so that loading libsicelore_mi.so (a JNI System.loadLibrary) needs no libz; everything else inflates and
+                   // deflates with the library's own code (smi_inflate_host.hip, smi_deflate.hip)
 
 #include <atomic>
 #include <cstring>
@@ -244,7 +247,7 @@ extern "C" int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size
         set_error("smi_gz_inflate: null argument");
         return SMI_ERR_INVALID;
     }
-    if (out) {  // the library's own decoder (smi_inflate_host.hip); the size query below keeps zlib
+    if (out) {  // the library's own decoder (smi_inflate_host.hip)
         size_t in_pos = 0, out_pos = 0;
         const int rc = host_gunzip(in, n_in, &in_pos, out, cap_out, &out_pos);
         if (rc == 1) {
@@ -254,67 +257,60 @@ extern "C" int smi_gz_inflate(const uint8_t *in, size_t n_in, uint8_t *out, size
         *n_out = out_pos;
         return rc;
     }
-    z_stream zs;
-    std::memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, 15 + 16) != Z_OK) {  // gzip wrapper
-        set_error("smi_gz_inflate: inflateInit2 failed");
-        return SMI_ERR_INVALID;
-    }
-    std::vector<uint8_t> sink(out ? 0 : (1u << 20));
-    size_t total = 0, off = 0;
-    int rc = Z_OK;
-    while (off < n_in) {
-        zs.next_in = const_cast<Bytef *>(in + off);
-        zs.avail_in = (uInt)std::min<size_t>(n_in - off, 1u << 30);
-        const size_t fed = zs.avail_in;
-        do {
-            if (out) {
-                zs.next_out = out + total;
-                zs.avail_out = (uInt)std::min<size_t>(cap_out - total, 1u << 30);
-            } else {
-                zs.next_out = sink.data();
-                zs.avail_out = (uInt)sink.size();
-            }
-            const size_t room = zs.avail_out;
-            rc = inflate(&zs, Z_NO_FLUSH);
-            total += room - zs.avail_out;
-            if (rc == Z_STREAM_END) break;
-            if (rc != Z_OK && rc != Z_BUF_ERROR) {
-                inflateEnd(&zs);
-                set_error(std::string("smi_gz_inflate: corrupt gzip data (") + (zs.msg ? zs.msg : "zlib error") + ")");
-                return SMI_ERR_INVALID;
-            }
-            if (out && total == cap_out && zs.avail_in) {
-                inflateEnd(&zs);
-                set_error("smi_gz_inflate: output buffer too small");
-                return SMI_ERR_INVALID;
-            }
-        } while (zs.avail_in);
-        off += fed - zs.avail_in;
-        if (rc == Z_STREAM_END) {
-            if (off < n_in) inflateReset(&zs);  // next member
-            rc = Z_OK;
-            if (off >= n_in) rc = Z_STREAM_END;
+    // size query (out == NULL): the same decoder into a scratch buffer that is doubled until the stream fits (round 6: no zlib here any more)
+    std::vector<uint8_t> sink(std::max<size_t>(4 * n_in + (1u << 16), 1u << 20));
+    for (;;) {
+        size_t in_pos = 0, out_pos = 0;
+        const int rc = host_gunzip(in, n_in, &in_pos, sink.data(), sink.size(), &out_pos);
+        if (rc == 1) {  // output buffer too small
+            sink.resize(sink.size() * 2);
+            continue;
         }
+        if (rc != SMI_OK) return rc;
+        *n_out = out_pos;
+        return SMI_OK;
     }
-    inflateEnd(&zs);
-    if (n_in && rc != Z_STREAM_END) {
-        set_error("smi_gz_inflate: truncated gzip stream");
-        return SMI_ERR_INVALID;
-    }
-    *n_out = total;
-    return SMI_OK;
 }
 
 // BGZF writer: `in` cut into blocks of block_bytes (<= 0xFF00) uncompressed bytes, each deflated on its own (zlib level
 // `level`), plus the 28-byte empty EOF block.  Replaces htsjdk's BlockCompressedOutputStream under BAMFileWriter
 // (UmiFinderWorker$OneBamWriter); the compressed bytes depend on the deflate implementation and are not comparable with the
 // reference's, the inflated stream is.  Two-call protocol: out == NULL returns an upper bound of the size in *n_out.
+namespace {
+struct ZlibApi {
+    int (*deflateInit2_)(z_streamp, int, int, int, int, int, const char *, int) = nullptr;
+    int (*deflate)(z_streamp, int) = nullptr;
+    int (*deflateReset)(z_streamp) = nullptr;
+    int (*deflateEnd)(z_streamp) = nullptr;
+    bool ok = false;
+};
+const ZlibApi &zlib_api() {
+    static const ZlibApi api = [] {
+        ZlibApi a;
+        void *h = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libz.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return a;
+        a.deflateInit2_ = reinterpret_cast<decltype(a.deflateInit2_)>(dlsym(h, "deflateInit2_"));
+        a.deflate = reinterpret_cast<decltype(a.deflate)>(dlsym(h, "deflate"));
+        a.deflateReset = reinterpret_cast<decltype(a.deflateReset)>(dlsym(h, "deflateReset"));
+        a.deflateEnd = reinterpret_cast<decltype(a.deflateEnd)>(dlsym(h, "deflateEnd"));
+        a.ok = a.deflateInit2_ && a.deflate && a.deflateReset && a.deflateEnd;
+        return a;
+    }();
+    return api;
+}
+}  // namespace
+
 extern "C" int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *n_out, int level,
                                 int block_bytes, int n_threads) {
     if ((!in && n_in) || !n_out || block_bytes < 1 || block_bytes > 0xFF00 || level < 0 || level > 9) {
         set_error("smi_bgzf_deflate: bad argument");
         return SMI_ERR_INVALID;
+    }
+    const ZlibApi &Z = zlib_api();
+    if (out && !Z.ok) {
+        set_error("smi_bgzf_deflate: libz.so.1 not found (this host-side writer is the only entry point that uses zlib; smi_bgzf_deflate_device needs none)");
+        return SMI_ERR_STATE;
     }
     const size_t n_blocks = (n_in + (size_t)block_bytes - 1) / (size_t)block_bytes;
     const size_t slot = (size_t)block_bytes + 26 + 1024;  // deflate never grows a block of <= 0xFF00 bytes past this
@@ -328,7 +324,7 @@ extern "C" int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, si
     auto work = [&]() {
         z_stream zs;
         std::memset(&zs, 0, sizeof zs);
-        if (deflateInit2(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+        if (Z.deflateInit2_(&zs, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY, ZLIB_VERSION, (int)sizeof(z_stream)) != Z_OK) {
             bad = 1;
             return;
         }
@@ -338,12 +334,12 @@ extern "C" int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, si
             const size_t o = k * (size_t)block_bytes, n = std::min<size_t>((size_t)block_bytes, n_in - o);
             std::vector<uint8_t> &b = blk[k];
             b.resize(slot);
-            deflateReset(&zs);
+            Z.deflateReset(&zs);
             zs.next_in = const_cast<Bytef *>(in + o);
             zs.avail_in = (uInt)n;
             zs.next_out = b.data() + 18;
             zs.avail_out = (uInt)(slot - 26);
-            if (deflate(&zs, Z_FINISH) != Z_STREAM_END || 18 + zs.total_out + 8 > 0x10000) {
+            if (Z.deflate(&zs, Z_FINISH) != Z_STREAM_END || 18 + zs.total_out + 8 > 0x10000) {
                 bad = 1;
                 break;
             }
@@ -351,13 +347,13 @@ extern "C" int smi_bgzf_deflate(const uint8_t *in, size_t n_in, uint8_t *out, si
             const uint8_t head[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xFF),
                                       (uint8_t)((bsize - 1) >> 8)};
             std::memcpy(b.data(), head, 18);
-            const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), in + o, (uInt)n);
+            const uint32_t crc = host_crc32(0, in + o, n);
             uint8_t *t = b.data() + 18 + zs.total_out;
             for (int i = 0; i < 4; i++) t[i] = (uint8_t)(crc >> (8 * i));
             for (int i = 0; i < 4; i++) t[4 + i] = (uint8_t)((uint32_t)n >> (8 * i));
             b.resize(bsize);
         }
-        deflateEnd(&zs);
+        Z.deflateEnd(&zs);
     };
     const int nt = std::max(1, std::min<int>(n_threads, (int)std::max<size_t>(n_blocks, 1)));
     std::vector<std::thread> pool;

@@ -12,6 +12,8 @@
 // (5 offsets x 2) are issued level by level, giving 10 independent gathers in flight per wave and level.
 // Integer/bitwise work only: no MFMA, no LDS (the pyramid's top level lives in L2, the window batch in
 // registers).
+#include <chrono>
+
 #include <hipcub/hipcub.hpp>
 
 #include "smi_internal.h"
@@ -113,7 +115,7 @@ __global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t x = n1_member(keys[i / kN1Slots], (int)(i % kN1Slots));
         atomicOr(&nb[x >> 5], 1u << (x & 31));
-        if (nb5) {
+        if (nb5) {  // (round 5's form: five more scattered atomics per member; kept behind SMI_BC1_NB5_ATOMIC as the cross-check of k_nb5_from_nb)
 #pragma unroll
             for (int d = -2; d <= 2; d++) {
                 uint32_t w;
@@ -122,6 +124,74 @@ __global__ void k_set_nb(const uint32_t *__restrict__ keys, size_t n, uint32_t *
             }
         }
     }
+}
+
+// nb5 DERIVED from nb (round 6): the same bits in another order, so the 2.5 GiB are a streaming transposition of the 512 MiB bitmap instead of five
+// scattered atomics per neighbourhood member (k_set_nb took 133 ms for the 3.6 M list, 100 of them for nb5).  With key = [lead: 2 + d bases][core: 12][trail: 2 - d]
+// and flank = lead << 2 (2 - d) | trail, bit (flank & 31) of nb5 word core * 40 + (d + 2) * 8 + (flank >> 5) is bit (key & 31) of nb word key >> 5:
+//   d = -2  no lead: the eight words of a core are the eight consecutive nb words core * 8 ..                       (copy)
+//   d = -1  one lead base: word j = nb word (j >> 1) << 25 | core << 1 | (j & 1)                                     (copy)
+//   d =  0  two lead bases: word j = the half-word of core in nb word lead << 23 | core >> 1 for lead = 2 j, 2 j + 1  (2 x 2 half-words)
+//   d =  1  three: nibble m of word j = nibble (core & 7) of nb word (8 j + m) << 21 | core >> 3                     (8 x 8 nibbles per 8 cores)
+//   d =  2  four: bit b of word j = bit (core & 31) of nb word (32 j + b) << 19 | core >> 5                          (32 x 32 bits per 32 cores)
+// A workgroup takes 512 consecutive cores: its inputs are 5 x 16 KiB in pieces of at least one 64-byte line (d = 2: 256 lead rows x 64 bytes), its output
+// is 80 KiB contiguous; an item = (32 cores, d, j) gathers its <= 32 input words and leaves 32 output words in LDS, which then goes out in 16-byte pieces.
+constexpr int kNb5TileCores = 512;
+constexpr int kNb5TileWords = kNb5TileCores * 40;  // 20,480 words = 80 KiB of LDS
+__global__ __launch_bounds__(256) void k_nb5_from_nb(const uint32_t *__restrict__ nb, uint32_t *__restrict__ nb5) {
+    extern __shared__ uint32_t tile[];  // [core in tile][40]
+    const uint32_t c0 = blockIdx.x * (uint32_t)kNb5TileCores;
+    for (int item = threadIdx.x; item < (kNb5TileCores / 32) * 40; item += blockDim.x) {
+        const int dj = item % 40, g = item / 40;  // consecutive lanes: consecutive words of a core's forty (LDS banks), the same 32 cores
+        const int d = dj >> 3, j = dj & 7;         // d here = offset + 2
+        const uint32_t c5 = (c0 >> 5) + (uint32_t)g;  // cores c5 * 32 .. + 31
+        uint32_t *out = tile + (size_t)g * 32 * 40 + dj;
+        if (d == 0) {
+#pragma unroll 8
+            for (int i = 0; i < 32; i++) out[i * 40] = nb[((size_t)c5 * 32 + i) * 8 + j];
+        } else if (d == 1) {
+            const size_t base = ((size_t)(j >> 1) << 25) + (size_t)c5 * 64 + (j & 1);
+#pragma unroll 8
+            for (int i = 0; i < 32; i++) out[i * 40] = nb[base + 2 * i];
+        } else if (d == 2) {
+            const size_t b0 = ((size_t)(2 * j) << 23) + (size_t)c5 * 16, b1 = ((size_t)(2 * j + 1) << 23) + (size_t)c5 * 16;
+#pragma unroll 4
+            for (int p = 0; p < 16; p++) {
+                const uint32_t lo = nb[b0 + p], hi = nb[b1 + p];
+                out[(2 * p) * 40] = (lo & 0xFFFFu) | (hi << 16);
+                out[(2 * p + 1) * 40] = (lo >> 16) | (hi & 0xFFFF0000u);
+            }
+        } else if (d == 3) {
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) {  // eight cores per input word
+                uint32_t in[8];
+#pragma unroll
+                for (int m = 0; m < 8; m++) in[m] = nb[((size_t)(8 * j + m) << 21) + (size_t)c5 * 4 + q];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    uint32_t w = 0;
+#pragma unroll
+                    for (int m = 0; m < 8; m++) w |= ((in[m] >> (4 * i)) & 15u) << (4 * m);
+                    out[(8 * q + i) * 40] = w;
+                }
+            }
+        } else {
+            uint32_t in[32];
+#pragma unroll
+            for (int b = 0; b < 32; b++) in[b] = nb[((size_t)(32 * j + b) << 19) + c5];
+#pragma unroll 4
+            for (int i = 0; i < 32; i++) {
+                uint32_t w = 0;
+#pragma unroll
+                for (int b = 0; b < 32; b++) w |= ((in[b] >> i) & 1u) << b;
+                out[i * 40] = w;
+            }
+        }
+    }
+    __syncthreads();
+    uint4 *dst = reinterpret_cast<uint4 *>(nb5 + (size_t)c0 * 40);
+    const uint4 *src = reinterpret_cast<const uint4 *>(tile);
+    for (int k = threadIdx.x; k < kNb5TileWords / 4; k += blockDim.x) dst[k] = src[k];
 }
 
 // K-BC2's offset filter for short used lists: one exact bit per key for the inverse TWO-step neighbourhood (the inverse one-step
@@ -176,6 +246,42 @@ __global__ void k_set_nt(const uint32_t *__restrict__ keys, size_t n, unsigned l
     }
 }
 
+// The same table with the slot of an entry handed out by a COUNTER per bucket (round 6): one 32-bit atomicAdd into a 4-byte-per-bucket array (0.9 GB for
+// the 3.6 M list) and a plain 8-byte store, instead of a 64-bit compare-and-swap on the 14.6 GB table itself (k_set_nt: 62.7 ms for 608 M entries, 9.7 G/s;
+// the same number of 32-bit atomics on the 512 MiB bitmap run at 28 G/s).  A bucket's slots fill in counter order and an entry whose bucket is full goes to
+// the next bucket, so "a bucket with a free slot has never overflowed" holds as before; which slot of a bucket an entry sits in was never defined (it
+// depended on the order the threads arrived).  Needs DISTINCT barcodes (the compare-and-swap build drops an entry it meets again): the caller checks.
+__global__ void k_set_nt_counted(const uint32_t *__restrict__ keys, size_t n, unsigned long long *__restrict__ nt, uint32_t *__restrict__ cnt, uint32_t cap) {
+    const size_t total = n * kN1Slots;
+    const uint32_t n_buckets = cap >> 3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t w = keys[i / kN1Slots];
+        const int slot = (int)(i % kN1Slots);
+        const uint32_t x = n1_member(w, slot);
+        uint32_t kind, pos, base;
+        if (slot < 48) {
+            kind = 1u, pos = (uint32_t)(slot / 3), base = (w >> (30 - 2 * pos)) & 3u;
+        } else if (slot < 108) {
+            const int p1 = 1 + (slot - 48) / 4;
+            kind = 2u, pos = (uint32_t)(p1 - 1), base = (w >> (30 - 2 * p1)) & 3u;
+        } else if (slot < 168) {
+            kind = 3u, pos = (uint32_t)((slot - 108) / 4), base = w & 3u;
+        } else {
+            kind = 0u, pos = 0u, base = 0u;
+        }
+        const unsigned long long entry = (1ull << 40) | ((unsigned long long)x << 8) | (kind | (pos << 2) | (base << 6));
+        uint32_t b = nt_slot(x, cap) >> 3;
+        for (;;) {
+            const uint32_t k = atomicAdd(&cnt[b], 1u);
+            if (k < 8u) {
+                nt[(size_t)b * 8 + k] = entry;
+                break;
+            }
+            b = b + 1 == n_buckets ? 0u : b + 1;
+        }
+    }
+}
+
 // popcount of every 256-key block of the fine bitmap (8 words, read as two 16-B vectors)
 __global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restrict__ counts) {
     size_t b = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -185,7 +291,51 @@ __global__ void k_block_counts(const uint4 *__restrict__ fine, uint32_t *__restr
                 __popc(c.w);
 }
 
+// bits set / an order-sensitive digest of a bitmap, entries of the table: what smi_set_stats reports (cross-check of the build kernels)
+__global__ void k_bits_digest(const uint32_t *__restrict__ w, size_t n_words, unsigned long long *__restrict__ out) {
+    unsigned long long bits = 0, dig = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long p = (unsigned long long)__popc(w[i]);
+        bits += p;
+        dig += p * ((i & 0xFFFFFu) + 1u);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        bits += __shfl_xor(bits, o);
+        dig += __shfl_xor(dig, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], bits);
+        atomicAdd(&out[1], dig);
+    }
+}
+__global__ void k_nt_entries(const uint64_t *__restrict__ nt, size_t cap, unsigned long long *__restrict__ out) {
+    unsigned long long cnt = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < cap; i += (size_t)gridDim.x * blockDim.x) cnt += nt[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, cnt);
+}
+int launch_set_digests(smi_ctx *ctx, uint64_t *out5, hipStream_t s) {
+    unsigned long long *d = nullptr;
+    SMI_HIP(hipMalloc((void **)&d, 5 * 8));
+    SMI_HIP(hipMemsetAsync(d, 0, 5 * 8, s));
+    if (ctx->nb_valid) hipLaunchKernelGGL(k_bits_digest, dim3(4096), dim3(256), 0, s, ctx->nb, kFineWords, d);
+    if (ctx->nb5_valid) hipLaunchKernelGGL(k_bits_digest, dim3(4096), dim3(256), 0, s, ctx->nb5, kNb5Words, d + 2);
+    if (ctx->nt_cap) hipLaunchKernelGGL(k_nt_entries, dim3(4096), dim3(256), 0, s, ctx->nt, (size_t)ctx->nt_cap, d + 4);
+    unsigned long long h[5];
+    hipError_t e = hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    SMI_HIP(e);
+    out5[0] = h[0];  // bits of nb
+    out5[1] = h[2];  // bits of nb5
+    out5[2] = h[3];  // digest of nb5
+    out5[3] = ctx->nt_cap;
+    out5[4] = h[4];
+    return SMI_OK;
+}
+
 int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s, bool membership_only) {
+    const auto t_build0 = std::chrono::steady_clock::now();
     SMI_HIP(hipMemsetAsync(ctx->l0, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l0s, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l1, 0, kL1Words * 4, s));
@@ -218,7 +368,6 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     ctx->nt_cap = 0;
     if (n > 0 && !membership_only && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
         if (!ctx->nb) SMI_HIP(hipMalloc((void **)&ctx->nb, kFineWords * 4));
-        SMI_HIP(hipMemsetAsync(ctx->nb, 0, kFineWords * 4, s));
         const unsigned gb = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 256);
         // nb5 goes with the table path only (its kernel is the one that reads it); a device that cannot spare 2.5 GiB keeps the plain bitmap
         ctx->nb5_valid = false;
@@ -227,9 +376,52 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
             ctx->nb5 = nullptr;
             (void)hipGetLastError();
         }
-        if (want_nb5 && ctx->nb5) SMI_HIP(hipMemsetAsync(ctx->nb5, 0, kNb5Words * 4, s));
-        hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, s, d_keys, n, ctx->nb, want_nb5 ? ctx->nb5 : nullptr);
-        SMI_HIP(hipGetLastError());
+        // Round 6: the bitmap chain (nb, then nb5 from it) and the table are independent and bound by different things (atomics on 512 MiB against
+        // atomics / stores over gigabytes): the chain runs on the context's side stream beside the table's kernel.  SMI_SET_ONE_STREAM: one after the other.
+        hipStream_t sb = s;
+        const bool two_streams = !std::getenv("SMI_SET_ONE_STREAM") && !std::getenv("SMI_BC1_NO_TABLE");
+        if (two_streams) {
+            if (!ctx->side_stream) {
+                SMI_HIP(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+                SMI_HIP(hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+                SMI_HIP(hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+            }
+            SMI_HIP(hipEventRecord(ctx->side_fork, s));
+            SMI_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+            sb = ctx->side_stream;
+        }
+        // from here to the join an error must not leave the side stream running on buffers the caller may free: every exit waits for it
+        auto join = [&]() -> int {
+            if (!two_streams) return SMI_OK;
+            if (hipEventRecord(ctx->side_join, ctx->side_stream) != hipSuccess || hipStreamWaitEvent(s, ctx->side_join, 0) != hipSuccess) {
+                (void)hipStreamSynchronize(ctx->side_stream);
+                return hip_fail(hipGetLastError(), "smi_set_barcode_set (side stream)");
+            }
+            return SMI_OK;
+        };
+#define SMI_SET_HIP(call)                                \
+    do {                                                 \
+        const hipError_t e_ = (call);                    \
+        if (e_ != hipSuccess) {                          \
+            (void)hipStreamSynchronize(ctx->side_stream ? ctx->side_stream : s); \
+            return hip_fail(e_, #call);                  \
+        }                                                \
+    } while (0)
+        SMI_SET_HIP(hipMemsetAsync(ctx->nb, 0, kFineWords * 4, sb));
+        const bool nb5_atomic = std::getenv("SMI_BC1_NB5_ATOMIC") != nullptr;  // cross-check switch: nb5 by scattered atomics (round 5) instead of the transposition
+        if (want_nb5 && ctx->nb5 && nb5_atomic) SMI_SET_HIP(hipMemsetAsync(ctx->nb5, 0, kNb5Words * 4, sb));
+        hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, sb, d_keys, n, ctx->nb, want_nb5 && nb5_atomic ? ctx->nb5 : nullptr);
+        SMI_SET_HIP(hipGetLastError());
+        if (want_nb5 && ctx->nb5 && !nb5_atomic) {
+            static const bool lds_ok = [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_nb5_from_nb), hipFuncAttributeMaxDynamicSharedMemorySize, kNb5TileWords * 4) == hipSuccess; }();
+            if (!lds_ok) {
+                (void)hipStreamSynchronize(sb);
+                set_error("smi_set_barcode_set: 80 KiB of LDS per workgroup refused (k_nb5_from_nb)");
+                return SMI_ERR_HIP;
+            }
+            hipLaunchKernelGGL(k_nb5_from_nb, dim3((unsigned)(((size_t)1 << 24) / kNb5TileCores)), dim3(256), kNb5TileWords * 4, sb, ctx->nb, ctx->nb5);  // (every word of nb5 is written: no memset)
+            SMI_SET_HIP(hipGetLastError());
+        }
         ctx->nb_valid = true;
         ctx->nb5_valid = want_nb5 && ctx->nb5 != nullptr;
         ctx->nt_cap = 0;
@@ -244,32 +436,50 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
             size_t cap = cap_at(30);
             if (cap >= 0xFFFFFFFFull) cap = cap_at(16);
             if (cap < 0xFFFFFFFFull) {
+                // (advisor, round 5) a table that was allocated at the 1.6-slot size because the 3-slot one did not fit is KEPT for lists of that size:
+                // no free + failing malloc + malloc on every later load
+                if (ctx->nt_alloc < cap && ctx->nt_alloc >= cap_at(16) && ctx->nt_small_only) cap = cap_at(16);
                 if (ctx->nt_alloc < cap) {
-                    if (ctx->nt) SMI_HIP(hipFree(ctx->nt));
+                    (void)hipStreamSynchronize(sb);  // (hipFree synchronises the device anyway)
+                    if (ctx->nt) SMI_SET_HIP(hipFree(ctx->nt));
                     ctx->nt = nullptr;
                     ctx->nt_alloc = 0;
-                    if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)) == hipSuccess)
+                    ctx->nt_small_only = false;
+                    // (+ cap / 8 counters of four bytes behind the table: the scratch of k_set_nt_counted, 6 % of the table)
+                    if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t) + (cap >> 3) * sizeof(uint32_t)) == hipSuccess)
                         ctx->nt_alloc = cap;
                     else {
                         ctx->nt = nullptr;
                         (void)hipGetLastError();
                         cap = cap_at(16);
-                        if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t)) == hipSuccess)
+                        if (hipMalloc((void **)&ctx->nt, cap * sizeof(uint64_t) + (cap >> 3) * sizeof(uint32_t)) == hipSuccess) {
                             ctx->nt_alloc = cap;
-                        else {
+                            ctx->nt_small_only = true;
+                        } else {
                             ctx->nt = nullptr;
                             (void)hipGetLastError();
                         }
                     }
                 }
                 if (ctx->nt_alloc >= cap) {
-                    SMI_HIP(hipMemsetAsync(ctx->nt, 0, cap * sizeof(uint64_t), s));
-                    hipLaunchKernelGGL(k_set_nt, dim3(gb), dim3(256), 0, s, d_keys, n, reinterpret_cast<unsigned long long *>(ctx->nt), (uint32_t)cap);
-                    SMI_HIP(hipGetLastError());
+                    SMI_SET_HIP(hipMemsetAsync(ctx->nt, 0, cap * sizeof(uint64_t), s));
+                    // distinct barcodes (the usual case): slots by per-bucket counters; else the compare-and-swap build, which drops repeated entries
+                    SMI_SET_HIP(hipStreamSynchronize(s));  // (`last` has arrived: the number of distinct keys)
+                    const bool distinct = (size_t)last[0] + last[1] == n;
+                    // (the counters live behind the table's nt_alloc slots: allocated with it, idle between builds)
+                    uint32_t *cnt = distinct && !std::getenv("SMI_SET_NT_CAS") ? reinterpret_cast<uint32_t *>(ctx->nt + ctx->nt_alloc) : nullptr;
+                    if (cnt) {
+                        SMI_SET_HIP(hipMemsetAsync(cnt, 0, (cap >> 3) * sizeof(uint32_t), s));
+                        hipLaunchKernelGGL(k_set_nt_counted, dim3(gb), dim3(256), 0, s, d_keys, n, reinterpret_cast<unsigned long long *>(ctx->nt), cnt, (uint32_t)cap);
+                    } else
+                        hipLaunchKernelGGL(k_set_nt, dim3(gb), dim3(256), 0, s, d_keys, n, reinterpret_cast<unsigned long long *>(ctx->nt), (uint32_t)cap);
+                    SMI_SET_HIP(hipGetLastError());
                     ctx->nt_cap = (uint32_t)cap;
                 }
             }
         }
+        if (int rc = join()) return rc;
+#undef SMI_SET_HIP
     }
     ctx->n1_valid = false;
     ctx->nb2_valid = false;
@@ -295,6 +505,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     }
     SMI_HIP(hipStreamSynchronize(s));
     ctx->n_keys = (size_t)last[0] + last[1];
+    ctx->set_build_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build0).count();
     return SMI_OK;
 }
 

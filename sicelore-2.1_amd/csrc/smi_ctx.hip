@@ -337,6 +337,36 @@ int smi_set_barcode_set_device(smi_ctx *ctx, const uint32_t *d_keys, size_t n, i
     return SMI_OK;
 }
 
+int smi_set_stats(smi_ctx *ctx, uint64_t out[8], int digests) {
+    if (int rc = bind(ctx)) return rc;
+    if (!out) {
+        set_error("smi_set_stats: null argument");
+        return SMI_ERR_INVALID;
+    }
+    const smi_ctx *o = ctx->set_owner ? ctx->set_owner : ctx;
+    if (o->set_mode < 0) {
+        set_error("smi_set_stats: no barcode set loaded");
+        return SMI_ERR_STATE;
+    }
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = o->n_keys;
+    // the membership pyramid: l0 + l0s, l1, t2, fine, rank + block counts; then what is valid for the loaded set
+    uint64_t bytes = (2 * kL0Words + kL1Words + 4 * kL0Words + kFineWords) * 4ull + 2ull * kRankEntries * 4;
+    if (o->nb_valid) bytes += kFineWords * 4ull;
+    if (o->nb5_valid) bytes += ((uint64_t)1 << 24) * 40 * 4;
+    if (o->nt_cap) bytes += (uint64_t)o->nt_alloc * 8 + (o->nt_alloc >> 3) * 4;  // (the table as allocated, with the build's bucket counters behind it)
+    if (o->n1_valid) bytes += 2ull * kL1Words * 4;
+    if (o->nb2_valid) bytes += kFineWords * 4ull;
+    out[1] = bytes;
+    out[2] = o->set_build_us;
+    if (digests) {
+        uint64_t d5[5];
+        if (int rc = launch_set_digests(const_cast<smi_ctx *>(o), d5, ctx->stream)) return rc;
+        for (int i = 0; i < 5; i++) out[3 + i] = d5[i];
+    }
+    return SMI_OK;
+}
+
 int smi_set_barcode_set(smi_ctx *ctx, const uint64_t *keys, size_t n, int mode) {
     if (int rc = bind(ctx)) return rc;
     if (!keys && n) {

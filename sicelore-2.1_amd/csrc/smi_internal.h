@@ -129,6 +129,7 @@ struct smi_ctx {
     bool nb_valid = false;
     uint64_t *nt = nullptr;   // grown on demand: 1.6 slots of 8 bytes per (barcode, step) pair, 7.8 GB for the 3.6 M list
     size_t nt_alloc = 0;      // slots allocated
+    bool nt_small_only = false;  // the 3-slot table did not fit this device: lists of that size keep the 1.6-slot one (no retry per load)
     uint32_t nt_cap = 0;      // slots in use by the set that is loaded now (0: no table)
     uint8_t *bc_codes = nullptr;  // K-BC1, table path: one byte per (read, offset) between its two kernels (grow-only, private to a context or lane)
     size_t bc_codes_bytes = 0;
@@ -136,6 +137,7 @@ struct smi_ctx {
     uint32_t *rank = nullptr;
     uint32_t *block_counts = nullptr;  // scratch for the rank scan
     size_t n_keys = 0;                 // distinct keys loaded
+    uint64_t set_build_us = 0;         // wall time of the last launch_build_pyramid (smi_set_stats)
     int set_mode = -1;
     bool timing = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // around the last timed kernel
@@ -201,6 +203,7 @@ int launch_extract_windows(smi_ctx *ctx, const uint8_t *d_reads, const uint64_t 
 int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s, bool membership_only = false);
 int launch_hist(smi_ctx *ctx, const uint32_t *d_keys, const uint8_t *d_pass, size_t n, uint32_t *d_hist,
                 hipStream_t s);
+int launch_set_digests(smi_ctx *ctx, uint64_t *out5, hipStream_t s);  // bits of nb / nb5, digest of nb5, slots / entries of nt
 int launch_bc_counts(smi_ctx *ctx, const smi_bc_result *d_res, size_t n, uint32_t *d_counts, hipStream_t s);
 int launch_hist_windows(smi_ctx *ctx, const smi_bc_window *d_win, const smi_scan_result *d_scan, size_t n,
                         uint32_t *d_hist, hipStream_t s);

@@ -62,7 +62,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into", "smi_gene_counts_dump", "smi_gene_counts_load", "smi_gene_counts_merge_shard",
-    "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
+    "smi_set_stats", "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
     "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen", "smi_name_set_create", "smi_name_set_free", "smi_name_set_seen",
 ]
 
@@ -98,6 +98,7 @@ def load_library():
     lib.smi_ctx_lane_refresh.argtypes = [vp]
     lib.smi_ctx_device.argtypes = [vp]
     lib.smi_ctx_set_polya.argtypes = [vp, ci, ctypes.c_float, ci]
+    lib.smi_set_stats.argtypes = [vp, vp, ci]
     lib.smi_run_knobs_default.argtypes = [vp]
     lib.smi_ctx_set_knobs.argtypes = [vp, vp]
     lib.smi_ctx_get_knobs.argtypes = [vp, vp]
@@ -1154,6 +1155,15 @@ class Context:
         k = np.ascontiguousarray(np.asarray(keys, dtype=np.uint64))
         self._check(self._lib.smi_set_barcode_set(self._h, _ptr(k), k.size, int(mode)))
         self.n_keys = int(np.unique(k).size)
+
+    def set_stats(self, digests=False):
+        """smi_set_stats: what the last set_barcode_set built -> dict(keys, hbm_bytes, build_ms[, nb_bits, nb5_bits, nb5_digest, nt_slots, nt_entries])"""
+        out = np.zeros(8, dtype=np.uint64)
+        self._check(self._lib.smi_set_stats(self._h, out.ctypes.data, int(bool(digests))))
+        d = dict(keys=int(out[0]), hbm_bytes=int(out[1]), build_ms=float(out[2]) / 1e3)
+        if digests:
+            d.update(nb_bits=int(out[3]), nb5_bits=int(out[4]), nb5_digest=int(out[5]), nt_slots=int(out[6]), nt_entries=int(out[7]))
+        return d
 
     def set_barcode_set_device(self, d_keys_u32, mode=SET_USED_LIST, stream=None):
         """d_keys_u32: device tensor of int32/uint32 keys."""

@@ -128,12 +128,54 @@ def write_synthetic_dir(synth, out_dir, n_files, reads_per_file, used, device, s
     return total
 
 
-def write_stats(out_dir, stats):
+def stats_html(tsv_text, command_line=None, assigned_tsv=None):
+    """ReadScanner.html (/root/reference/README.md:388, sicelore-nf/main.nf:24 declares it an output of the scan step): ONE static page
+    over the numbers ReadScanner.tsv holds -- the rows of ReadFlags.print (description, reads, percent, of what) as a table with a bar per row --
+    and, when BarcodesAssigned.tsv was written, the assigned reads by edit distance.  The reference renders the same counters through a Velocity
+    template with Google charts loaded from the network (ParseStatsHtmlPrinter.java:L311-326); this page is self-contained (no script, no
+    network), its layout is this build's own; the QV histograms of QVstats and stats.pojo (Java serialisation) are not built."""
+    import html
+
+    rows = [ln.split("\t") for ln in tsv_text.split("\n") if ln.strip()]
+    most = max([int(r[1]) for r in rows if len(r) > 1 and r[1].isdigit()] or [1]) or 1
+    out = ["<!DOCTYPE html>", "<html><head><meta charset=\"utf-8\"><title>Nanopore read scan stats</title>",
+           "<style>body{font-family:sans-serif;margin:2em}table{border-collapse:collapse}td,th{padding:2px 10px;border-bottom:1px solid #ddd;text-align:left}"
+           "td.n{text-align:right;font-variant-numeric:tabular-nums}div.bar{background:#4a7ab8;height:0.8em}</style></head><body>",
+           "<h1>Nanopore read scan stats</h1>"]
+    if command_line:
+        out.append("<p><b>Command line:</b> <code>" + html.escape(command_line) + "</code></p>")
+    out.append("<table><tr><th></th><th>n reads</th><th>percent</th><th></th><th></th></tr>")
+    for r in rows:
+        if len(r) == 1:        # a heading line of ReadFlags.print
+            out.append(f"<tr><th colspan=\"5\">{html.escape(r[0].strip('= '))}</th></tr>")
+            continue
+        r = r + [""] * (4 - len(r))
+        width = 300 * int(r[1]) // most if r[1].isdigit() else 0
+        out.append(f"<tr><td>{html.escape(r[0])}</td><td class=\"n\">{html.escape(r[1])}</td><td class=\"n\">{html.escape(r[2])}</td><td>{html.escape(r[3])}</td>"
+                   f"<td><div class=\"bar\" style=\"width:{width}px\"></div></td></tr>")
+    out.append("</table>")
+    if assigned_tsv:
+        lines = [ln.split("\t") for ln in assigned_tsv.split("\n") if ln.strip()]
+        if len(lines) > 1:
+            head, body = lines[0], lines[1:]
+            out.append(f"<h2>Barcodes assigned in pass 2: {len(body)} barcodes</h2><table><tr>" + "".join(f"<th>{html.escape(h)}</th>" for h in head[1:]) + "</tr><tr>")
+            for c in range(1, len(head)):
+                out.append(f"<td class=\"n\">{sum(int(b[c]) for b in body if len(b) > c and b[c].lstrip('-').isdigit())}</td>")
+            out.append("</tr></table>")
+    out.append("</body></html>")
+    return "\n".join(out) + "\n"
+
+
+def write_stats(out_dir, stats, command_line=None):
+    tsv = _lib.scan_stats_tsv(stats)
     with open(os.path.join(out_dir, "ReadScanner.tsv"), "w") as f:
-        f.write(_lib.scan_stats_tsv(stats))
+        f.write(tsv)
     with open(os.path.join(out_dir, "stats.tsv"), "w") as f:
         names = _lib.READ_FLAG_NAMES + ["sum_len_passed", "sum_len_failed", "n_reads_split"]
         f.write("".join(f"{nm}\t{int(v)}\n" for nm, v in zip(names, stats)))
+    assigned = os.path.join(out_dir, "BarcodesAssigned.tsv")
+    with open(os.path.join(out_dir, "ReadScanner.html"), "w") as f:
+        f.write(stats_html(tsv, command_line, open(assigned).read() if os.path.isfile(assigned) else None))
 
 
 def merge_stats(run_dirs, out_dir):
@@ -184,7 +226,7 @@ def run(ctx, in_dir, out_dir, *args, polya=None, **kw):
 def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,
         dont_search_polya=False, host_threads_per_call=1, compress=True, gz="device", pinned_text=False, inflate="host", device_share=0.25, group=None, resident_bytes=96 << 30,
         host_text_bytes=256 << 30, inflate_auto_from=1024, recursive=True, pattern=r".{1,}\.(fastq|fq)(\.gz)?", skip_files=0, only_files=None,
-        used_keys=None, write_fastqs=True, trim_fastq=False, merge_ed=None, min_count_fold=10, cells_fold_below_max=500):
+        used_keys=None, write_fastqs=True, trim_fastq=False, merge_ed=None, min_count_fold=10, cells_fold_below_max=500, command_line=None):
     """-> dict of counts and wall-clock times.  ctx: a Context (its lanes are created here); whitelist_keys: the possible barcodes
     (sorted uint64), loaded for pass 1.  gz: who deflates the output with --compress -- "device": the text worker writes the records in HBM
     and K-DEFLATE turns them into one gzip member per chunk there (dynamic Huffman, literals only: about 8 % larger files than zlib level 6);
@@ -646,7 +688,7 @@ def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, 
             f.write(_lib.assigned_tsv(rk_keys, counts.astype(np.uint32), max_ed=max_ed))
         # the counters ReadScanner.html renders (ReadFlags.print) and, beside them, the raw vector `merge_stats` adds up (the reference keeps
         # them in stats.pojo for its `mergestats` sub-command)
-        write_stats(out_dir, stats)
+        write_stats(out_dir, stats, command_line)
     t_write = time.perf_counter() - t0
     for ln in lanes[1:]:
         ln.close()

@@ -421,3 +421,26 @@ def test_empty_and_single_key_sets(pkg, synth, sor, gpu_ctx, max_ed):
     got = _run_device(pkg, gpu_ctx, win, max_ed, False)
     st, exp = sor.assign_batch(sor.BarcodeSet(used.numpy()), reg["codes"].numpy(), reg["ae"].numpy(), max_ed=max_ed, n_threads=8)
     assert _compare(pkg, got, st, exp) > (500 if max_ed else 100)
+
+
+@pytest.mark.parametrize("n_keys", [3_600_000, 5_000, 1])
+def test_nb5_by_transposition_equals_nb5_by_atomics(pkg, synth, gpu_ctx, monkeypatch, n_keys):
+    """round 6: the 2.5 GiB offset filter `nb5` is DERIVED from the 512 MiB bitmap `nb` by a streaming transposition (k_nb5_from_nb) instead of five
+    scattered atomics per neighbourhood member (round 5's k_set_nb, still there behind SMI_BC1_NB5_ATOMIC): both builds leave the same bits -- same
+    count, same order-sensitive digest -- and nb5 holds five bits (one per offset) for every bit of nb; the table holds one entry per (barcode, step)"""
+    wl = synth.make_whitelist(max(n_keys, 16), seed=71)[:n_keys]
+    keys = wl.numpy().astype(np.uint64)
+    gpu_ctx.set_barcode_set(keys, mode=1)
+    a = gpu_ctx.set_stats(digests=True)
+    monkeypatch.setenv("SMI_BC1_NB5_ATOMIC", "1")
+    gpu_ctx.set_barcode_set(keys, mode=1)
+    b = gpu_ctx.set_stats(digests=True)
+    monkeypatch.delenv("SMI_BC1_NB5_ATOMIC")
+    assert a["keys"] == b["keys"] == n_keys
+    assert a["nb_bits"] == b["nb_bits"] > 100 * n_keys
+    assert a["nb5_bits"] == b["nb5_bits"] == 5 * a["nb_bits"]
+    assert a["nb5_digest"] == b["nb5_digest"] != 0
+    assert a["nt_entries"] == b["nt_entries"] and a["nt_slots"] >= a["nt_entries"] >= a["nb_bits"]
+    assert a["hbm_bytes"] == b["hbm_bytes"] > (1 << 29) and a["build_ms"] > 0
+    if n_keys == 3_600_000:
+        print(f"set build: transposed {a['build_ms']:.1f} ms, atomics {b['build_ms']:.1f} ms, {a['hbm_bytes'] / 1e9:.2f} GB")

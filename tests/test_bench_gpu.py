@@ -34,7 +34,12 @@ def test_bench_config1_small():
              "--two-pass-reads", "20000")
     _common(d, 2)
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["matches_gpu"] is True
-    assert d["end_to_end"]["reads_per_s"] > 0 and d["value_full_pass2"] == d["end_to_end"]["reads_per_s"]
+    assert d["end_to_end"]["reads_per_s"] > 0 and d["value_full_pass2"] == d["end_to_end"]["reads_per_s"] == d["end_to_end"]["reads_per_s_one_lane"]
+    assert d["value_full_pass2_lanes"] == d["end_to_end"]["reads_per_s_best_lanes"] >= 0.9 * d["value_full_pass2"]
+    # the one-time set build beside the step: its time (warm / with allocations), the HBM it occupies, and the batch as a job of its own
+    assert 0 < d["set_build_ms"] <= d["set_build_cold_ms"] * 1.5 and d["set_hbm_bytes"] > (1 << 30)
+    assert 0 < d["value_one_shot"] < d["value"]
+    assert d["two_pass"]["collective"]["ranks_counted"] == 1
     assert d["two_pass"]["same_used_list_on_all_ranks"] is True and d["two_pass"]["pass2_assigned"] > 0
     assert set(d["roofline"]["kernels_ms"]) == {"k_scan<10>", "k_bc_match_ed1<1>"}
 

@@ -28,6 +28,17 @@ def test_bench_launches_two_ranks_itself_and_exchanges():
     assert r["assigned_rows"] == r["used_list"] and r["first_row_total"] == 3
 
 
+def test_bench_launches_eight_ranks_and_counts_them():
+    """the driver's first 8-GPU run rehearsed as far as a CPU box can: eight ranks (gloo), the process group reports 8, a collective sums over 8
+    ranks, every rank holds the same used list, and each rank took its share of the host's CPU quota"""
+    r = _run(["--gpus", "8", "--exchange-only", "--backend", "gloo", "--whitelist", "50000", "--cells", "300"])
+    assert r["n_gpus"] == 8 and r["backend"] == "gloo"
+    c = r["collective"]
+    assert c["backend"] == "gloo" and c["world_size"] == 8 and c["ranks_counted"] == 8
+    assert c["host_threads_per_rank"] >= 1
+    assert r["same_used_list_on_all_ranks"] is True and r["first_row_total"] == sum(range(1, 9))
+
+
 def test_single_rank_exchange_only_needs_no_process_group():
     r = _run(["--gpus", "1", "--exchange-only", "--whitelist", "20000", "--cells", "100"])
     assert r["n_gpus"] == 1 and r["backend"] == "none" and r["first_row_total"] == 1

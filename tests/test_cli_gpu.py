@@ -148,10 +148,10 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
     r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan2 --bcEditDistance 1 -g used.txt -s -n -k 1 -z 2 -u -v '.*synth_.*'", env, str(work))
     assert r.returncode == 0, r.stderr[-2000:]
     assert "2 Files found" in r.stdout and "skipping 1st pass" in r.stdout and "Won't write fastqs" in r.stdout
-    assert sorted(os.listdir(str(work / "scan2"))) == ["BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    assert sorted(os.listdir(str(work / "scan2"))) == ["BarcodesAssigned.tsv", "ReadScanner.html", "ReadScanner.tsv", "stats.tsv"]
     r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan3 --bcEditDistance 1 -a none -s", env, str(work))   # no list of possible barcodes
     assert r.returncode == 0, r.stderr[-2000:]
-    assert sorted(os.listdir(str(work / "scan3"))) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    assert sorted(os.listdir(str(work / "scan3"))) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.html", "ReadScanner.tsv", "stats.tsv"]
     assert len(open(str(work / "scan3" / "BarcodesAssigned.tsv")).read().split("\n")) > 20
     # -p / -f / -w: another polyA window through both passes (the kernels with the finder as a loop); out of the build's range: a message, exit code 1
     r = _run("$java -jar Jar/x.jar scanfastq -d $fastqdir -o ${readscandir}../scan4 --bcEditDistance 1 -p 12 -f 0.8 -w 120 -z 1", env, str(work))
@@ -215,3 +215,100 @@ def test_quickrun_lines_35_and_42_run_verbatim(pkg, synth, tmp_path):
         assert not ({"U7", "U8", "UC", "UZ", "U1", "U2"} & set(ta)) and ta == {t: v for t, v in tb.items() if t not in ("U7", "U8", "UC", "UZ", "U1", "U2")}
     assert os.path.getsize(umidir + "unclustered_umifound_.bam") < os.path.getsize(umidir + "passedParsed_umifound_.bam")
 
+
+
+@pytest.mark.gpu
+def test_config_xml_knobs_through_the_command_line(pkg, synth, tmp_path):
+    """round 6: a config.xml with OTHER values -- the README's printed defaults minMeanBCqv / minMeanReadqv 10 and minCountFold 20
+    (/root/reference/README.md:480-489), fewer adapter mismatches, a longer minimal read; then umi_length 10 for assignumis -- is honoured by both
+    sub-commands: the run equals run_files.run / assignumis_stream called with the same knobs, and differs from the shipped file's run"""
+    import importlib
+
+    import torch
+
+    import bammodel
+    from test_bam import _parse_aux
+
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    lib = importlib.import_module("sicelore_amd.lib")
+    dev = torch.device("cuda", 0)
+    wl = synth.make_whitelist(30_000, seed=4501, device=dev)
+    used = synth.pick_used(wl, 40, seed=4502)
+    work = tmp_path / "run"
+    work.mkdir()
+    fastqdir = str(work / "fastq") + "/"
+    n = run_files.write_synthetic_dir(synth, fastqdir, 2, 1500, used, dev, seed=4510, chimera_frac=0.05, q_lo=38, q_hi=50)
+    keys = np.sort(wl.cpu().numpy().astype(np.uint64))
+    with gzip.open(work / "3M-february-2018.txt.gz", "wt") as f:
+        for k in keys:
+            f.write("".join("AGCT"[(int(k) >> (2 * (15 - i))) & 3] for i in range(16)) + "-1\n")
+    env = dict(os.environ, java=_wrapper(tmp_path), fastqdir=fastqdir)
+    cmd = "$java -jar Jar/x.jar scanfastq -d $fastqdir -o {out} --bcEditDistance 1 --compress"
+    r = _run(cmd.format(out="shipped"), env, str(work))            # no config.xml in the working directory: the shipped values
+    assert r.returncode == 0, r.stderr[-2000:]
+    body = ("<readscanner><minReadLength>500</minReadLength><minMeanBCqv>10</minMeanBCqv><minMeanReadqv>10</minMeanReadqv><minCountFold>20</minCountFold>"
+            "<cellsWithReadsnFoldBelowMaxToKeep>100</cellsWithReadsnFoldBelowMaxToKeep><mergeBCsED>2</mergeBCsED></readscanner>"
+            "<adapter_for3pBarcoding><maxNeedlemanMismatches>2</maxNeedlemanMismatches><maxCompleteSeqNeedlemanMismatches>4</maxCompleteSeqNeedlemanMismatches></adapter_for3pBarcoding>"
+            "<tso_for3pBarcoding><maxCompleteSeqNeedlemanMismatches>5</maxCompleteSeqNeedlemanMismatches></tso_for3pBarcoding>")
+    (work / "config.xml").write_text("<Parameters>" + body + "</Parameters>")
+    r = _run(cmd.format(out="knobs"), env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    # the same run through the library calls, knobs handed over directly
+    ctx = lib.Context(0)
+    ctx.set_knobs(lib.run_knobs(min_read_length=500, min_mean_bc_qv=10, min_mean_read_qv=10, adapter3p_max_mm=2, adapter3p_complete_max_mm=4, tso_complete_max_mm=5))
+    run_files.run(ctx, fastqdir, str(work / "direct"), max_ed=1, n_workers=4, whitelist_keys=keys, compress=True, merge_ed=2, min_count_fold=20, cells_fold_below_max=100)
+    ctx.close()
+    differs = 0
+    for sub in ("BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv"):
+        a, b, c = (open(str(work / d / sub)).read() for d in ("knobs", "direct", "shipped"))
+        assert a == b, sub
+        differs += a != c
+    assert differs == 3
+    for sub in ("passed", "failed"):
+        names = sorted(os.listdir(str(work / "knobs" / sub)))
+        assert names == sorted(os.listdir(str(work / "direct" / sub))) and len(names) == 2
+        for nm in names:     # (the reads' ids, ranks and names do not depend on the thread count)
+            assert gzip.open(str(work / "knobs" / sub / nm)).read() == gzip.open(str(work / "direct" / sub / nm)).read(), (sub, nm)
+    # a knob that is compiled in: refused by name, nothing run
+    (work / "config.xml").write_text("<Parameters><readscanner><testPlusMinusPos>3</testPlusMinusPos></readscanner></Parameters>")
+    r = _run(cmd.format(out="refused"), env, str(work))
+    assert r.returncode == 1 and "readscanner/testPlusMinusPos" in r.stderr and not os.path.exists(str(work / "refused"))
+    # minReadLength below the bases the reference cuts off every read end: stopped with the knob's name (the reference dies on the first read in between)
+    (work / "config.xml").write_text("<Parameters><readscanner><minReadLength>120</minReadLength></readscanner></Parameters>")
+    r = _run(cmd.format(out="tooshort"), env, str(work))
+    assert r.returncode == 1 and "readscanner/minReadLength" in r.stderr, r.stderr[-600:]
+    # ---- assignumis with <umi_length>10</umi_length>: U8 / U7 are 10 characters, the first ten of the shipped run's U7 (the same window, cut shorter)
+    names, lens = [], []
+    for p in sorted(os.listdir(str(work / "shipped" / "passed"))):
+        lines = gzip.open(str(work / "shipped" / "passed" / p)).read().split(b"\n")
+        names += [ln[1:].split(b" ")[0].decode() for ln in lines[0::4] if ln]
+        lens += [len(ln) for ln in lines[1::4]]
+    rng = np.random.default_rng(7)
+    rows = sorted((int(20_000 + 4_000 * (i % 6) + rng.integers(0, 60)), nm, 16 if (i % 6) & 1 else 0, L) for i, (nm, L) in enumerate(zip(names, lens)))
+    recs = [bammodel.bam_record(nm, fl, 0, p0, 30, [("M", L)], "C" * L) for p0, nm, fl, L in rows]
+    header = bammodel.bam_bytes("@HD\tVN:1.6\tSO:coordinate\n", [("chr12", 10 ** 8)], [])
+    with open(str(work / "passed.bam"), "wb") as f:
+        f.write(bammodel.bgzf_compress(header + b"".join(recs), block=16384))
+    (work / "config.xml").unlink()
+    r = _run("$java -jar Jar/x.jar assignumis --inFileNanopore passed.bam -o u12.bam", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    (work / "cfg10.xml").write_text("<Parameters><umis><umi_length>10</umi_length><umi_completelinkclusteringED>1</umi_completelinkclusteringED></umis></Parameters>")
+    r = _run("$java -jar Jar/x.jar assignumis --inFileNanopore passed.bam -o u10.bam -c cfg10.xml", env, str(work))
+    assert r.returncode == 0, r.stderr[-2000:]
+    _, _, o12 = bammodel.parse_bam(bammodel.bgzf_decompress(open(str(work / "u12.bam"), "rb").read()))
+    _, _, o10 = bammodel.parse_bam(bammodel.bgzf_decompress(open(str(work / "u10.bam"), "rb").read()))
+    assert [o["name"] for o in o10] == [o["name"] for o in o12] and len(o10) > 0.5 * n
+    n_u8 = 0
+    for a_, b_ in zip(o10, o12):
+        ta, tb = {t: v for t, _ty, v in _parse_aux(a_["aux"])}, {t: v for t, _ty, v in _parse_aux(b_["aux"])}
+        txt = lambda v: v.decode() if isinstance(v, bytes) else v  # noqa: E731
+        assert ("U7" in ta) == ("U7" in tb)
+        if "U7" in ta:
+            assert len(txt(ta["U7"])) == 10 and txt(tb["U7"])[:10] == txt(ta["U7"])
+        if "U8" in ta:
+            assert len(txt(ta["U8"])) == 10
+            n_u8 += 1
+    assert n_u8 > 0.8 * len(o10)
+    (work / "cfg16.xml").write_text("<Parameters><umis><umi_length>16</umi_length></umis></Parameters>")
+    r = _run("$java -jar Jar/x.jar assignumis --inFileNanopore passed.bam -o u16.bam -c cfg16.xml", env, str(work))
+    assert r.returncode == 1 and "umis/umi_length" in r.stderr

@@ -302,13 +302,45 @@ WIDE = ["pass2w_3p", "pass2w_3p_ed2", "pass2w_5p", "pass2w_5p_polya"]
 WIDE_X = ["pass2x_3p", "pass2x_5p"]   # reads aimed at single branches of the splitter; the wide reads once more with --trimfastq
 
 
+def knob_values(sec):
+    """config.xml's values a section ran under: the shipped file with the section's `knobs` over it (None: as shipped), by the library's field names"""
+    v = dict(min_read_length=200, min_mean_bc_qv=8, min_mean_read_qv=8, min_adapter_3p_matches=8, polya_len=15, polya_frac=0.75, window_polya=150,
+             internal_pat_len=15, internal_pat_frac=0.70, adapter3p="CTTCCGATCT", adapter3p_complete="CTACACGACGCTCTTCCGATCT", adapter3p_max_mm=3,
+             adapter3p_complete_max_mm=5, adapter5p="CTTCCGATCT", adapter5p_complete="CTACACGACGCTCTTCCGATCT", adapter5p_max_mm=3, adapter5p_complete_max_mm=5,
+             adapter5p_window=110, adapter3p5_complete="AAGCAGTGGTATCAACGCAGAGTAC", adapter3p5_complete_max_mm=5, tso_complete="AAGCAGTGGTATCAACGCAGAGTACAT",
+             tso_complete_max_mm=6, umi_length=12)
+    names = {"readscanner/minReadLength": "min_read_length", "readscanner/minMeanBCqv": "min_mean_bc_qv", "readscanner/minMeanReadqv": "min_mean_read_qv",
+             "readscanner/minAdapter3pMatches": "min_adapter_3p_matches", "polyAT/polyATlength": "polya_len", "polyAT/fractionATInPolyAT": "polya_frac",
+             "polyAT/windowSearchForPolyA": "window_polya", "polyAT/internalpATlength": "internal_pat_len", "polyAT/internalFractionATInPolyAT": "internal_pat_frac",
+             "adapter_for3pBarcoding/sequence": "adapter3p", "adapter_for3pBarcoding/sequence_complete": "adapter3p_complete",
+             "adapter_for3pBarcoding/maxNeedlemanMismatches": "adapter3p_max_mm", "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter3p_complete_max_mm",
+             "fiveprimeadapter_for5pBarcoding/sequence": "adapter5p", "fiveprimeadapter_for5pBarcoding/sequence_complete": "adapter5p_complete",
+             "fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches": "adapter5p_max_mm", "fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter5p_complete_max_mm",
+             "fiveprimeadapter_for5pBarcoding/AdapterSearchWindow": "adapter5p_window", "threeprimeadapter_for5pBarcoding/sequence_complete": "adapter3p5_complete",
+             "threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter3p5_complete_max_mm", "tso_for3pBarcoding/sequence_complete": "tso_complete",
+             "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "tso_complete_max_mm", "umis/umi_length": "umi_length"}
+    for k, text in (sec.get("knobs") or {}).items():
+        f = names[k]
+        v[f] = type(v[f])(text)
+    return v
+
+
 def oracle_chunk(sor, bset, rank_of, sec, case):
     """the oracle flow for one ReadChunk, as Parser.call runs it: [(scan, assignment, record bytes, passed, fragment name)] in list order"""
     five, ed = sec["five_prime"], sec["ed"]
     par = None
+    kv = knob_values(sec)
     if five:
-        par = sor.chimera_params(tso="CTACACGACGCTCTTCCGATCT", adapter="AAGCAGTGGTATCAACGCAGAGTAC", tso_max=5, adapter_max=5, bc_umi=0)
+        par = sor.chimera_params(tso=kv["adapter5p_complete"], adapter=kv["adapter3p5_complete"], tso_max=kv["adapter5p_complete_max_mm"],
+                                 adapter_max=kv["adapter3p5_complete_max_mm"], bc_umi=0)
+    elif sec.get("knobs"):
+        par = sor.chimera_params(tso=kv["tso_complete"], adapter=kv["adapter3p_complete"], tso_max=kv["tso_complete_max_mm"], adapter_max=kv["adapter3p_complete_max_mm"],
+                                 bc_umi=16 + kv["umi_length"])
     scan_par = None
+    if sec.get("knobs"):       # config.xml with other knob values (round 6): the scan's and the splitter's parameters from them
+        scan_par = sor.default_scan_params()
+        scan_par["min_read_length"], scan_par["polya_len"], scan_par["polya_frac"], scan_par["window_polya"] = kv["min_read_length"], kv["polya_len"], kv["polya_frac"], kv["window_polya"]
+        par.internal_pat_len, par.internal_pat_frac, par.window_polya = kv["internal_pat_len"], kv["internal_pat_frac"], kv["window_polya"]
     if sec.get("polya"):       # -p / -f / -w: the finder's parameters; the splitter keeps windowSearchForPolyA + 70 away from the read ends
         scan_par = sor.default_scan_params()
         scan_par["polya_len"], scan_par["polya_frac"], scan_par["window_polya"] = sec["polya"]
@@ -327,10 +359,11 @@ def oracle_chunk(sor, bset, rank_of, sec, case):
             fname = sor.chimera_fragment_name(name, raw, k) if splits else name
             # (no qualities for the scan: they only feed pass 1's filter, whose window AE - 16 .. AE - 1 the reference itself cannot
             # take when a 5' adapter ends before base 17 -- pass 2 never looks at it)
-            if five:
-                rc, sc = sor.scan_read_5p(fs, None, "CTTCCGATCT", dont_search_polya=sec["dont_search_polya"], params=scan_par)
+            if five:       # (maxNeedlemanMismatches + 1: Parser.java:L99)
+                rc, sc = sor.scan_read_5p(fs, None, kv["adapter5p"], max_mm=kv["adapter5p_max_mm"] + 1, window=kv["adapter5p_window"],
+                                          dont_search_polya=sec["dont_search_polya"], params=scan_par)
             else:
-                rc, sc = sor.scan_read_3p(fs, None, "CTTCCGATCT", params=scan_par)
+                rc, sc = sor.scan_read_3p(fs, None, kv["adapter3p"], max_mm=kv["adapter3p_max_mm"], params=scan_par)
             assert rc == 0
             a = None
             if sc["adapter_found"] and not multi:
@@ -405,6 +438,19 @@ def test_pass2_targeted_and_trimmed_chunks_equal_reference_bytecode(sor, name):
     for sec in secs:
         n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
         assert n_in >= 50 and n_passed >= 30 and n_bc >= 20
+
+
+def test_pass2_chunks_under_other_config_knobs_equal_reference_bytecode(sor):
+    """pass2k (round 6): the wide reads through the reference's Parser.call started with OTHER VALUES of config.xml's knobs -- mismatch limits of the
+    adapters and of the splitter's complete sequences, minReadLength, the internal polyA window, umi_length 10, AdapterSearchWindow (5'), another
+    adapter / complete TSO sequence: the oracle with the same values writes the same records; with the shipped values it does not"""
+    secs = load("pass2k")["sections"]
+    assert len(secs) == 3 and all(s_["knobs"] for s_ in secs)
+    for sec in secs:
+        n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
+        assert n_in >= 150 and n_rec >= 140 and n_passed >= 40 and n_bc >= 30, (sec["knobs"], n_in, n_rec, n_passed, n_bc)
+        with pytest.raises(AssertionError):
+            _check_chunk_section(sor, dict(sec, knobs=None))
 
 
 def test_pass2_chunks_under_other_polya_parameters_equal_reference_bytecode(sor):

@@ -172,7 +172,7 @@ def test_supplied_barcode_list_dontwrite_trim_and_file_selection(pkg, synth, gpu
     # -s: statistics and tables only
     d2 = str(tmp_path / "dontwrite")
     c = run_files.run(gpu_ctx, in_dir, d2, write_fastqs=False, **kw)
-    assert c["assigned"] == a["assigned"] and sorted(os.listdir(d2)) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv", "stats.tsv"]
+    assert c["assigned"] == a["assigned"] and sorted(os.listdir(d2)) == ["BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.html", "ReadScanner.tsv", "stats.tsv"]
     for nm in ("BarcodeList.tsv", "BarcodesAssigned.tsv", "ReadScanner.tsv"):
         assert open(os.path.join(d2, nm)).read() == open(os.path.join(d0, nm)).read(), nm
     # -u: the same records by name, every trimmed read a piece of the untrimmed one

@@ -126,3 +126,29 @@ def test_stats_text_equals_the_reference_print(libmod):
         total[38] += c["sum_len_failed"]
         total[39] += c["n_reads_split"]
     assert libmod.scan_stats_tsv(total) == sec["merged"]["text"]
+
+
+def test_html_page_over_the_statistics(libmod, pkg, tmp_path):
+    """ReadScanner.html (README.md:388, sicelore-nf/main.nf:24): a static page over ReadScanner.tsv's rows and BarcodesAssigned.tsv's counts --
+    every row of the table with its numbers, the command line escaped, no script and no network reference"""
+    import importlib
+    import re
+
+    run_files = importlib.import_module("sicelore_amd.run_files")
+    stats = np.zeros(libmod.N_SCAN_STATS, dtype=np.uint64)
+    stats[:libmod.SMI_N_READ_FLAGS if hasattr(libmod, "SMI_N_READ_FLAGS") else 37] = np.arange(37, dtype=np.uint64) * 13 + 5
+    stats[37:] = (123456, 65432, 17)
+    (tmp_path / "BarcodesAssigned.tsv").write_text("barcode\ted0\ted1\nACGTACGTACGTACGT\t7\t2\nTTTTACGTACGTACGT\t1\t0\n")
+    run_files.write_stats(str(tmp_path), stats, command_line='scanfastq -d "in <x>" -o out & more')
+    page = (tmp_path / "ReadScanner.html").read_text()
+    tsv = (tmp_path / "ReadScanner.tsv").read_text()
+    assert page.startswith("<!DOCTYPE html>") and "<script" not in page and "http" not in page
+    assert "scanfastq -d &quot;in &lt;x&gt;&quot; -o out &amp; more" in page
+    rows = [ln.split("\t") for ln in tsv.split("\n") if ln.strip()]
+    assert len(rows) > 10
+    import html as _html
+    for r in rows:
+        if len(r) > 1:
+            assert f"<td>{_html.escape(r[0])}</td><td class=\"n\">{r[1]}</td>" in page, r
+    assert "2 barcodes" in page and re.search(r'<td class="n">8</td>\s*<td class="n">2</td>', page)
+    assert (tmp_path / "stats.tsv").exists()

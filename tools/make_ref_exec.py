@@ -560,14 +560,41 @@ def install_long2object(j):
     jvm_exec.JDK_IFACES["it/unimi/dsi/fastutil/longs/LongOpenHashSet"] = ["java/util/Set", "it/unimi/dsi/fastutil/longs/LongSet"]
 
 
+def config_with(knobs):
+    """a copy of the reference's Jar/config.xml (scratch, /tmp) with the texts of the elements `section/knob` replaced -> its path.  The file the
+    reference would be started with; nothing of it is kept (the fixture records the replaced knobs only)."""
+    import tempfile
+    import xml.etree.ElementTree as ET
+
+    tree = ET.parse(REF + "config.xml")
+    root = tree.getroot()
+    for name, text in knobs.items():
+        sec, leaf = name.split("/")
+        el = root.find(sec).find(leaf)
+        if el is None:
+            raise KeyError(name)
+        el.text = str(text)
+    fd, path = tempfile.mkstemp(suffix=".xml", prefix="ref_config_")
+    os.close(fd)
+    tree.write(path)
+    return path
+
+
 class Pass2:
-    def __init__(self, g, five_prime, ed, dont_search_polya=False):
+    def __init__(self, g, five_prime, ed, dont_search_polya=False, knobs=None):
         import ref_params
 
         self.j = j = g.j
         self.five = five_prime
         install_long2object(j)
-        par, self.report = ref_params.load_config(j, PAR)
+        if knobs:
+            path = config_with(knobs)
+            try:
+                par, self.report = ref_params.load_config(j, PAR, path)
+            finally:
+                os.unlink(path)
+        else:
+            par, self.report = ref_params.load_config(j, PAR)
         rs = par.f["readScannerParameters"]
         rs.f["assignCellBCwithEditDistance"] = j.call_static(GOPT, "of", f"(Ljava/lang/Object;)L{GOPT};", JBox("java/lang/Integer", ed))
         par.f["polyAT"].f["dontSearchPolyAFor5pBarcoding"] = 1 if dont_search_polya else 0   # -y (NanoporeReadScannerMain.java:L248)
@@ -934,10 +961,11 @@ def _wide_worker(args):
     five_prime, ed, dont_search_polya, seed, chunk_ids, per_chunk = args[:6]
     trim, reader = (args[6], args[7]) if len(args) > 6 else (False, None)
     polya = args[8] if len(args) > 8 else None
+    knobs = args[9] if len(args) > 9 else None
     reader = reader or wide_read
     g = Gen()
     j = g.j
-    p2 = Pass2(g, five_prime, ed, dont_search_polya)
+    p2 = Pass2(g, five_prime, ed, dont_search_polya, knobs=knobs)
     if polya is not None:      # -p / -f / -w as NanoporeReadScannerMain.java:L228-234 stores them (boxed, in params.polyAT)
         pat = p2.par.f["polyAT"]
         pat.f["polyATlength"] = JBox("java/lang/Integer", int(polya[0]))
@@ -963,11 +991,11 @@ def _wide_worker(args):
     return cases, sorted(j.natives_used), g.hits(), j.steps, flag_values, p2.report
 
 
-def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5, trim=False, reader=None, note="", polya=None):
+def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chunk=5, trim=False, reader=None, note="", polya=None, knobs=None):
     jobs = max(1, int(os.environ.get("WIDE_JOBS", "1")))
     ids = list(range(n_chunks))
     blocks = [ids[k::jobs] for k in range(jobs)]
-    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk, trim, reader, polya) for b in blocks if b]
+    args = [(five_prime, ed, dont_search_polya, seed, b, per_chunk, trim, reader, polya, knobs) for b in blocks if b]
     if len(args) == 1:
         parts = [_wide_worker(args[0])]
     else:
@@ -989,7 +1017,8 @@ def gen_pass2w(g, five_prime, ed, dont_search_polya, seed, n_chunks=100, per_chu
                   "first_read_id + 1, ... in list order.  Parameters: Jar/config.xml as shipped + what_todo = {FIND_BARCODES}.  Each chunk ran under two iteration orders "
                   "of java.util.HashMap / HashSet; `hash_orders_agree` = both gave this result.",
          "cases": cases, "barcodes": bcs, "ranks": list(range(1, len(bcs) + 1)), "five_prime": five_prime, "ed": ed, "dont_search_polya": dont_search_polya,
-         "split_chimeras": not dont_search_polya, "trim_fastq": bool(trim), "polya": None if polya is None else [int(polya[0]), float(polya[1]), int(polya[2])], "kinds": sorted({r["kind"] for c in cases for r in c["reads"]}) if reader else WIDE_KINDS,
+         "split_chimeras": not dont_search_polya, "trim_fastq": bool(trim), "polya": None if polya is None else [int(polya[0]), float(polya[1]), int(polya[2])],
+         "knobs": None if not knobs else {k: str(v) for k, v in knobs.items()}, "kinds": sorted({r["kind"] for c in cases for r in c["reads"]}) if reader else WIDE_KINDS,
          "flag_values": parts[0][4], "config_report": parts[0][5],
          "natives": [{"native": k, "tier": jvm_natives.tier_of(k)} for k in natives]}
     s["max_tier"] = max([n["tier"] for n in s["natives"]] or ["A"])
@@ -1066,6 +1095,30 @@ def gen_pass2p(g):
     a["sections"] += b["sections"]
     a["_steps"] += b["_steps"]
     merge_hits(a["_hits"], b["_hits"])
+    return a
+
+
+def gen_pass2k(g):
+    """round 6: the wide reads through Parser.call under OTHER VALUES OF config.xml's knobs (the file the reference is started with, its elements
+    replaced; everything else as shipped) -- the knobs the product takes at run time (smi_run_knobs):
+    (0) 3': fewer allowed adapter mismatches, a longer minimal read, a stricter complete TSO / complete adapter in the splitter, another internal
+        polyA window, umi_length 10 (the barcode + UMI stretch between an internal polyA and its adapter);
+    (1) 5' with the polyA search on: another AdapterSearchWindow, other mismatch limits of both adapters;
+    (2) 3': another adapter sequence (two bases of the shipped one changed, in `sequence` and `sequence_complete`) with one more mismatch allowed"""
+    ka = {"adapter_for3pBarcoding/maxNeedlemanMismatches": 2, "adapter_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": 3, "readscanner/minReadLength": 300,
+          "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": 4, "polyAT/internalpATlength": 12, "polyAT/internalFractionATInPolyAT": 0.8, "umis/umi_length": 10}
+    kb = {"fiveprimeadapter_for5pBarcoding/AdapterSearchWindow": 40, "fiveprimeadapter_for5pBarcoding/maxNeedlemanMismatches": 1,
+          "fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": 2, "threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": 2,
+          "readscanner/minReadLength": 260}
+    kc = {"adapter_for3pBarcoding/sequence": "CTTCCGTTCA", "adapter_for3pBarcoding/sequence_complete": "CTACACGACGCTCTTCCGTTCA", "adapter_for3pBarcoding/maxNeedlemanMismatches": 4,
+          "tso_for3pBarcoding/sequence_complete": "AAGCAGTGGTATCAACGCAGAGTGAAT", "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": 7}
+    a = gen_pass2w(g, False, 1, False, 4101, n_chunks=40, per_chunk=5, knobs=ka, note=", config.xml with other knob values (see `knobs`)")
+    b = gen_pass2w(g, True, 1, False, 4104, n_chunks=30, per_chunk=5, knobs=kb, note=", config.xml with other knob values (see `knobs`)")
+    c = gen_pass2w(g, False, 1, False, 4101, n_chunks=30, per_chunk=5, knobs=kc, note=", config.xml with another adapter / complete TSO sequence (see `knobs`)")
+    for x in (b, c):
+        a["sections"] += x["sections"]
+        a["_steps"] += x["_steps"]
+        merge_hits(a["_hits"], x["_hits"])
     return a
 
 
@@ -2975,7 +3028,7 @@ def gen_auxorder(g, seed=2222):
     return out
 
 
-SECTIONS = {"umi_3p_len10": gen_umi_3p_len10, "umi_5p_len10": gen_umi_5p_len10, "auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
+SECTIONS = {"pass2k": gen_pass2k, "umi_3p_len10": gen_umi_3p_len10, "umi_5p_len10": gen_umi_5p_len10, "auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
             "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
