@@ -147,6 +147,13 @@ typedef struct {
     int32_t umi_length;               /* umis/umi_length                                        :264  12 */
     int32_t reserved[7];
 } smi_run_knobs;
+/* `scanfastq -e / --randomBarcode` (NanoporeReadScannerMain.java:L212-215; Parser.java:L212-215: "the read bc sequence gets replaced by a random sequence",
+ * /root/reference/README.md:176): the specificity experiment -- pass 2 of this context's chunk workers matches RANDOM sequences where the read's barcode
+ * windows stood, so every barcode it still assigns is a chance assignment.  seed != 0 switches it on, 0 off; lanes take their owner's when created or
+ * refreshed.  The reference draws five independent random 16-mers per read from an unseeded java.util.Random (not reproducible); here the 24 / 25 window
+ * bases of a read become one sequence drawn from (seed, read id), the five windows are cut from it as they are from a read -- each window is uniformly
+ * random, so the expected number of chance assignments is the reference's, and a run can be repeated. */
+int smi_ctx_set_random_barcodes(smi_ctx *ctx, uint64_t seed);
 /* the shipped config.xml */
 int smi_run_knobs_default(smi_run_knobs *knobs);
 /* knobs == NULL: back to the shipped values.  SMI_ERR_INVALID (smi_last_error names the knob) for a value this build has no kernel for. */
@@ -761,6 +768,8 @@ typedef struct {
                                   The UMI windows are umi_length + 2 bases (the umi_length-mers at offsets -1 / 0 / +1 behind the barcode,
                                   ClusteringEditDistanceBase.java:L316-329), U8 / U7 umi_length characters (OneNanoporeResult.java:L111) */
     const smi_umi_cluster_config *cluster; /* NULL: shipped values */
+    uint64_t random_umi_seed;  /* `assignumis -f / --randomUMI` (ClusteringEditDistanceBase.java:L308-310, L323, L330): != 0 replaces every read's UMI window by a
+                                  random one drawn from (seed, position of the record in the chunk) -- what still clusters is chance; 0 = off */
 } smi_assignumis_config;
 #define SMI_UMI_HAS_BC 1u    /* the name carries a barcode (the record goes to the output BAM) */
 #define SMI_UMI_HAS_U7 2u    /* u7 valid: the read's own 12 bases behind the barcode */

@@ -706,7 +706,7 @@ def plan_shards(extents, world):
 
 def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_size=250_000, truncate_read_name=False, n_threads=4, refflat=None,
                       max_dist=500, bc_edit_limit=None, five_prime=False, cluster_cfg=None, bc_length=16, group=None, shard=None, no_clustering=False,
-                      gene_tag="GE", umi_length=0, grouping_distance=None):
+                      gene_tag="GE", umi_length=0, grouping_distance=None, random_umi_seed=0, simulate=False):
     """`assignumis -i in.bam -o out` for a BAM of any size: the file is read in segments of about segment_bytes compressed bytes (read and inflated by a thread of their own, one segment ahead), never held as a
     whole -- inflate the segment's complete BGZF blocks behind the records still pending, index, cut BamReader's chunks (the counter and the
     chromosome carry over the segment borders), per chunk smi_assignumis_chunk + smi_bam_write_batch, each written batch BGZF-deflated on the
@@ -722,6 +722,10 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
     are cut (BamReader's record counter starts anew on every rank, BamReader.java:L106-158; a batch is a unit of writing only), region NUMBERS
     (equal regions, other ids: every rank numbers from rank << 40), and -- for a read with alignments on chromosomes of two ranks -- the
     "further alignment" bit of UMIcounts in the later rank (it sees the name for the first time).
+
+    simulate (-e / -f, the accuracy simulations: UmiFinderWorker$BamWriters.java:L294, L412): the run goes through every stage and writes NO file -- its
+    counts are the result; random_umi_seed (-f): every read's UMI window is a random one (smi_assignumis_config.random_umi_seed), so what still clusters is
+    chance.  One process only.
 
     no_clustering (-s, UmiFinderMain.java:L268-269): OneBatchExecutor.call skips UmiClustering.cluster (L83) and the call-back skips the U7 fill
     of barcoded records (UmiFinderWorker$FutCallBack.onSuccess L209-214), so no record gets U7 / U8 / UC / UZ / U1 / U2; regions, scan tags,
@@ -764,7 +768,9 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             # the header comes from the file's start; it leads this rank's stream (and is not written again: rank 0 wrote it)
             pend = hb[:hlen].copy()
     suffix = f".shard{rank}" if world > 1 else ""
-    f_bc, f_umi = open(out_prefix + ".bam" + suffix, "wb"), open(out_prefix + "_umifound_.bam" + suffix, "wb")
+    if simulate and world > 1:
+        raise _lib.SmiError("the accuracy simulations (-e / -f) run in one process")
+    f_bc, f_umi = (open(os.devnull, "wb"), open(os.devnull, "wb")) if simulate else (open(out_prefix + ".bam" + suffix, "wb"), open(out_prefix + "_umifound_.bam" + suffix, "wb"))
     nth_pend = np.zeros(0, dtype=np.uint8)
     header, tagger, refs = None, None, None
     i0, g0, prev_ref = -1, 0, None                 # global position of the last flush, global index of pend's first record, reference of the record in front
@@ -901,7 +907,8 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             t2 = time.perf_counter()
             inp = _lib.bam_chunk_inputs(bam, recs, cur)
             out, n_done = ctx.assignumis_chunk_raw(inp, keep_data_end=keep, max_dist=max_dist, bc_edit_limit=bc_edit_limit, n_threads=n_threads,
-                                                   five_prime=five_prime, cluster_cfg=cluster_cfg, umi_length=umi_length, grouping_distance=grouping_distance)
+                                                   five_prime=five_prime, cluster_cfg=cluster_cfg, umi_length=umi_length, grouping_distance=grouping_distance,
+                                                   random_umi_seed=random_umi_seed)
             t3 = time.perf_counter()
             done = cur[:n_done]
             if no_clustering:
@@ -972,10 +979,11 @@ def assignumis_stream(ctx, in_bam, out_prefix, segment_bytes=256 << 20, chunk_si
             if tagger is not None:
                 tagger.close()
             return dict(records=n_records, clustered=n_clustered, batches=n_batches, seconds=secs, wall_s=time.perf_counter() - t_all, rank=rank, world=world, **info)
-    with open(out_prefix + ".genecounts.tsv", "w") as f:
-        f.write(gc.genecounts_tsv(bc_length))
-    with open(out_prefix + ".UMIdepths.tsv", "w") as f:
-        f.write(gc.umi_depths_tsv())
+    if not simulate:
+        with open(out_prefix + ".genecounts.tsv", "w") as f:
+            f.write(gc.genecounts_tsv(bc_length))
+        with open(out_prefix + ".UMIdepths.tsv", "w") as f:
+            f.write(gc.umi_depths_tsv())
     info = gc.info()
     gc.close()
     names_seen.close()

@@ -114,7 +114,7 @@ def run_knobs_from(knobs, path="config.xml", polya=None):
             k.polya_len, k.polya_frac, k.window_polya = polya
         lib.check_run_knobs(k)
     except (ValueError, lib.SmiError) as e:
-        raise CliError(f"{path}: {e}")
+        raise CliError(f"{path}: {e}" + (" (-p / -f / -w of the command line stand for polyAT/polyATlength, fractionATInPolyAT, windowSearchForPolyA)" if "polyAT/" in str(e) else ""))
     return None if k.as_dict() == lib.run_knobs().as_dict() else k
 
 
@@ -192,11 +192,12 @@ SCAN_SPEC = {"inDir": ("d", "inDir", True), "outDir": ("o", "outDir", True), "bc
              "cellRangerBCs": ("g", "cellRangerBCs", True), "skipNfastqs": ("k", "skipNfastqs", True), "onlyNfastqs": ("z", "onlyNfastqs", True),
              "nonrecursive": ("n", "nonrecursive", False), "pattern": ("v", "pattern", True), "dontwrite": ("s", "dontwrite", False),
              "trimfastq": ("u", "trimfastq", False),
+             # -e: the specificity experiment (Parser.java:L212-215; /root/reference/README.md:176): random sequences in place of the reads' barcodes
+             "randomBarcode": ("e", "randomBarcode", False),
              # the polyA finder's window (L227-234); config.xml's polyAT values where the command line has none
              "polyAlength": ("p", "polyAlength", True), "fractionAT": ("f", "frac-f", True), "windowAT": ("w", "windowAT", True)}
 SCAN_REFUSED = {o: why for opts, why in (
-    (("-e", "--randomBarcode"), "random barcodes (a specificity experiment of the reference) are not built"),
-    (("-i",), "Use either -i or -d: only -d <directories> is built"))
+    (("-i",), "Use either -i or -d: only -d <directories> is built"),)
     for o in opts}
 UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "outfile", True), "annotationFile": ("a", "annotationFile", True),
             "config": ("c", "config", True), "chunksize": ("v", "chunksize", True), "fivePbc": ("p", "fivePbc", False),
@@ -205,11 +206,14 @@ UMI_SPEC = {"inFileNanopore": ("i", "inFileNanopore", True), "outfile": ("o", "o
             # -u: read by the Illumina-guided UMI analyzer only (IlluminaUMIanalyzer) -- accepted, checked to be a number, without effect here
             "bcedit": ("b", "bcedit", True), "umiedit": ("u", "umiedit", True), "noclustering": ("s", "noclustering", False),
             "debug": ("d", "debug", False),
+            # -e / -f: the accuracy simulations (UmiFinderMain.java:L212-215; UmiFinderWorker$BamWriters.java:L294, L412: no BAM is written under either).
+            # -f: every read's UMI is replaced by a random one before the pair distances (ClusteringEditDistanceBase.java:L308-310); -e replaces barcodes in the
+            # Illumina-guided analyzer only -- here it leaves the statistics-only run
+            "randomBarcode": ("e", "randomBarcode", False), "randomUMI": ("f", "randomUMI", False),
             # -g: the two-letter attribute the gene name is written under and counted from (UmiFinderMain.java:L239-246; config.xml gene_name_attribute)
             "ONTgene": ("g", "ONTgene", True)}   # (-d: stepwise execution of the reference, UmiFinderMain.java:L178-179: accepted, without effect)
 UMI_REFUSED = {o: why for opts, why in (
     (("-k", "--inFile10x", "-j", "-y", "-m", "-n", "-z", "--edBCbailout"), "Illumina-guided assignment is outside this build (SURVEY 2: OUT OF SCOPE)"),
-    (("-e", "--randomBarcode", "-f", "--randomUMI"), "random barcodes / UMIs (a specificity experiment of the reference) are not built"),
     )
     for o in opts}
 
@@ -347,7 +351,11 @@ def scanfastq(argv):
             ctx.set_knobs(run_knobs)
         except _lib.SmiError as e:
             raise CliError(f"{cfg_path}: {e}")
-    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, merge_ed=merge_ed, command_line="scanfastq " + " ".join(argv), **host_kw, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
+    rnd_seed = 0
+    if "randomBarcode" in o:      # the reference's java.util.Random is unseeded; here the run can be repeated (SMI_RANDOM_SEED, default 1)
+        rnd_seed = int(os.environ.get("SMI_RANDOM_SEED", "1")) or 1
+        print(f"Random barcode simulation: barcode sequences are replaced by random sequences during barcode assignment (seed {rnd_seed})")
+    info = run_files.run(ctx, o["inDir"], o["outDir"], polya=polya, max_ed=ed, merge_ed=merge_ed, random_barcode_seed=rnd_seed, command_line="scanfastq " + " ".join(argv), **host_kw, n_workers=ncpu, whitelist_keys=keys, five_prime=bool(o.get("fivePbc")),
                          dont_search_polya=bool(o.get("noPolyARequired")), compress=bool(o.get("compress")),
                          recursive="nonrecursive" not in o, pattern=o.get("pattern", run_files.FASTQ_PATTERN), skip_files=skip, only_files=only,
                          used_keys=used, write_fastqs="dontwrite" not in o, trim_fastq="trimfastq" in o)
@@ -418,12 +426,17 @@ def assignumis(argv):
                 raise CliError(f"--{name} {o[name]!r}: not a number")
             if name == "bcedit":
                 bc_limit = v
+    simulate = "randomBarcode" in o or "randomUMI" in o
+    rnd_umi = (int(os.environ.get("SMI_RANDOM_SEED", "1")) or 1) if "randomUMI" in o else 0
     ctx = _context()
     ncpu = _ncpu(o)
     info = au.assignumis_stream(ctx, o["inFileNanopore"], prefix, chunk_size=chunk, truncate_read_name=bool(o.get("splitReadName")), n_threads=ncpu,
                                 refflat=refflat, max_dist=max_dist, five_prime=bool(o.get("fivePbc")), bc_edit_limit=bc_limit,
                                 no_clustering="noclustering" in o, gene_tag=gene_tag, umi_length=umi_length, cluster_cfg=cluster_cfg,
-                                grouping_distance=hk.get("grouping_distance"))
+                                grouping_distance=hk.get("grouping_distance"), simulate=simulate, random_umi_seed=rnd_umi)
+    if simulate and info.get("rank", 0) == 0:
+        print(f"SIMULATION ({'random UMIs' if rnd_umi else 'random barcodes'}): no BAM written; {info['clustered']} of {info['records']} records ended up in UMI clusters"
+              + (f" by chance (seed {rnd_umi})" if rnd_umi else ""))
     if info.get("rank", 0) == 0:       # rank 0 holds the whole run's counts (assignumis_stream gathers them)
         print(f"DONE -- {info['records']} records, {info['clustered']} in UMI clusters")
         bad = int(info.get("gene_keys_order_dependent", 0))

@@ -216,6 +216,7 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->polya_window = o->polya_window;
     lane->knobs = o->knobs;
     lane->knobs_set = o->knobs_set;
+    lane->random_bc_seed = o->random_bc_seed;
     return SMI_OK;
 }
 
@@ -585,6 +586,15 @@ int smi_ctx_set_knobs(smi_ctx *ctx, const smi_run_knobs *knobs) {
     if (int rc = check_knobs(*knobs)) return rc;
     ctx->knobs = *knobs;
     ctx->knobs_set = true;
+    return SMI_OK;
+}
+
+int smi_ctx_set_random_barcodes(smi_ctx *ctx, uint64_t seed) {
+    if (!ctx) {
+        set_error("null context");
+        return SMI_ERR_INVALID;
+    }
+    ctx->random_bc_seed = seed;
     return SMI_OK;
 }
 

@@ -121,6 +121,7 @@ struct smi_ctx {
     float polya_frac = 0.0f;
     smi_run_knobs knobs = {};  // smi_ctx_set_knobs: config.xml's knobs for the chunk workers of this context (knobs_set false: the shipped file)
     bool knobs_set = false;
+    uint64_t random_bc_seed = 0;  // smi_ctx_set_random_barcodes (scanfastq -e): pass 2 matches random windows
     bool nb2_valid = false;   // the build scratch n1_owner holds the two-step neighbourhood bitmap of the set that is loaded now
     uint32_t *nb = nullptr;   // allocated with the first barcode set (512 MiB)
     uint32_t *nb5 = nullptr;  // allocated with the first neighbourhood table (2.5 GiB); nb5_valid: describes the set that is loaded now

@@ -27,7 +27,7 @@ struct UmiGroupBuffers {  // device scratch of the grouping step; capacities for
 };
 
 int launch_umi_parse(smi_ctx *ctx, const char *d_names, const uint32_t *d_name_off, const uint16_t *d_flags, const int32_t *d_pos0, const uint32_t *d_cigars,
-                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, int umi_len, UmiParsed *d_out, hipStream_t s);
+                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, int umi_len, uint64_t random_umi_seed, UmiParsed *d_out, hipStream_t s);
 size_t umi_group_scratch_bytes(int n);
 int launch_umi_region_keys(smi_ctx *ctx, const UmiParsed *d_parsed, int n, UmiGroupBuffers &B, uint32_t *d_counters, uint64_t *d_has_bits, hipStream_t s);
 int launch_umi_groups(smi_ctx *ctx, const UmiParsed *d_parsed, const int32_t *d_region, int n, int n_done, UmiGroupBuffers &B, uint64_t *totals, hipStream_t s);

@@ -108,7 +108,7 @@ __device__ __forceinline__ bool ref_position(const uint32_t *cigar, int n_cigar,
 __global__ __launch_bounds__(64) void k_umi_parse(const char *__restrict__ names, const uint32_t *__restrict__ name_off, const uint16_t *__restrict__ flags,
                                                   const int32_t *__restrict__ pos0, const uint32_t *__restrict__ cigars,
                                                   const uint32_t *__restrict__ cigar_off, int n, int five, int grouping_distance, int bc_edit_limit,
-                                                  int umi_len, UmiParsed *__restrict__ out) {
+                                                  int umi_len, uint64_t random_umi_seed, UmiParsed *__restrict__ out) {
     // The names of the wave's 64 records are consecutive in memory: one coalesced copy of that byte range into LDS (16 bytes per lane and
     // step), every lane then reads its own name from there.  (Staging row by row -- 64 rows x 4 dependent rounds -- made this kernel
     // latency-bound: 0.83 ms per 120 k records.)  A block of unusually long names falls back to rows of kNameStage characters.
@@ -282,6 +282,14 @@ __global__ __launch_bounds__(64) void k_umi_parse(const char *__restrict__ names
                     for (int k = 0; k < umi_len + 2; k++) {
                         const uint32_t c = five ? ucode4(v.at(p_x + (int)(pos - 1 + k))) : ucomp4(ucode4(v.at(p_x + x_len - (int)(pos + k))));
                         w |= (uint64_t)c << (4 * k);
+                    }
+                    if (random_umi_seed) {  // assignumis -f: a random window instead (random_umi_window of smi_worker.hip)
+                        uint64_t z = random_umi_seed + 0x9E3779B97F4A7C15ull * ((uint64_t)i + 1);
+                        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+                        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+                        z ^= z >> 31;
+                        w = 0;
+                        for (int k = 0; k < umi_len + 2; k++) w |= (uint64_t)(1u << ((z >> (2 * k)) & 3u)) << (4 * k);
                     }
                     P.win = w;
                     P.flags |= UP_HAS_W;
@@ -693,10 +701,10 @@ __global__ void k_umi_tag_groups(const uint32_t *__restrict__ group_off, uint32_
 // launches
 // ---------------------------------------------------------------------------------------------------------------------------
 int launch_umi_parse(smi_ctx *, const char *d_names, const uint32_t *d_name_off, const uint16_t *d_flags, const int32_t *d_pos0, const uint32_t *d_cigars,
-                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, int umi_len, UmiParsed *d_out, hipStream_t s) {
+                     const uint32_t *d_cigar_off, int n, int five, int grouping_distance, int bc_edit_limit, int umi_len, uint64_t random_umi_seed, UmiParsed *d_out, hipStream_t s) {
     if (!n) return SMI_OK;
     hipLaunchKernelGGL(k_umi_parse, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, d_names, d_name_off, d_flags, d_pos0, d_cigars, d_cigar_off, n, five,
-                       grouping_distance, bc_edit_limit, umi_len, d_out);
+                       grouping_distance, bc_edit_limit, umi_len, random_umi_seed, d_out);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

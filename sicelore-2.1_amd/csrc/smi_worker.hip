@@ -47,6 +47,23 @@ __global__ void k_rank_lookup(const smi_bc_result *__restrict__ bc, size_t n, co
 
 // a read the splitter discarded whole (MULTI_CHIMERIC_READS_DISCARDED) is never scanned by the reference (Parser.java:L92): its record goes
 // to `failed` as it is and must not count as an assigned barcode anywhere (per-barcode counters, statistics, rank)
+// scanfastq -e (smi_ctx_set_random_barcodes): the window bases of record i become a random sequence drawn from (seed, id of the record); N marks cleared.
+// splitmix64 of seed + id: every record its own value, the same in every run.
+__global__ void k_random_windows(smi_bc_window *__restrict__ win, size_t m, uint64_t seed, uint64_t first_id) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    smi_bc_window w = win[i];
+    if (!(w.flags & SMI_WIN_VALID)) return;
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (first_id + i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const int nb = (w.flags & SMI_WIN_5P) ? 25 : 24;
+    w.bases = z & ((1ull << (2 * nb)) - 1ull);
+    w.nmask = 0u;
+    win[i] = w;
+}
+
 __global__ void k_drop_discarded(smi_bc_result *__restrict__ bc, const uint32_t *__restrict__ frag_src,
                                  const smi_chimera_result *__restrict__ chim, size_t n) {
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -214,6 +231,10 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     SMI_RC(smi_frag_text_starts_device(ctx, d_ss, d_qs, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_bstart, d_qstart, s));
     SMI_RC(smi_pack_ends_text_device(ctx, d_text, d_bstart, d_rec_offs, m, d_ends, d_len, s));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
+    if (ctx->random_bc_seed && m) {  // scanfastq -e: the matcher sees random windows (ids: the chunk's first read id onwards)
+        hipLaunchKernelGGL(k_random_windows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_win, m, ctx->random_bc_seed, (uint64_t)cfg->first_read_id);
+        SMI_HIP(hipGetLastError());
+    }
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
     if (split && m) {
         hipLaunchKernelGGL(k_drop_discarded, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_bc, d_fsrc, d_chim, m);
@@ -501,6 +522,10 @@ int pass2_packed_core(smi_ctx *ctx, const smi_packed_reads *pk, const uint64_t *
     SMI_RC(worker_scan_config(ctx, 2, five, cfg->dont_search_polya, &sc));
     SMI_RC(launch_ends_from_planes(ctx, d_planes, pstride, d_offs, d_rec_offs, split ? d_fsrc : nullptr, m, d_ends, d_len, s, d_pstart));
     SMI_RC(smi_scan_device(ctx, d_ends, d_len, nullptr, nullptr, m, &sc, d_scan, d_win, s));
+    if (ctx->random_bc_seed && m) {  // scanfastq -e: the matcher sees random windows (ids: the chunk's first read id onwards)
+        hipLaunchKernelGGL(k_random_windows, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_win, m, ctx->random_bc_seed, (uint64_t)cfg->first_read_id);
+        SMI_HIP(hipGetLastError());
+    }
     SMI_RC(smi_bc_match_device(ctx, d_win, m, cfg->max_ed, five, d_bc, s));
     if (split && m) {
         hipLaunchKernelGGL(k_drop_discarded, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_bc, d_fsrc, d_chim, m);
@@ -848,6 +873,18 @@ bool umi_window(const NameData &d, bool five_prime, int umi_len, uint64_t *packe
 }  // namespace
 
 namespace {
+// assignumis -f: the UMI window of record i as a random sequence of umi_len + 2 bases (4-bit codes A G C T), from (seed, i): the same function on the
+// host path and in K-UPARSE (smi_umi_stage.hip)
+uint64_t random_umi_window(uint64_t seed, uint64_t i, int umi_len) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (i + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    uint64_t w = 0;
+    for (int k = 0; k < umi_len + 2; k++) w |= (uint64_t)(1u << ((z >> (2 * k)) & 3u)) << (4 * k);
+    return w;
+}
+
 // umis/umi_length of a chunk: the configuration's, else the context's knob, else 12
 int chunk_umi_length(const smi_ctx *ctx, const smi_assignumis_config *cfg) { return cfg->umi_length > 0 ? cfg->umi_length : ctx_umi_length(ctx); }
 
@@ -943,7 +980,8 @@ int assignumis_chunk_host(smi_ctx *ctx, const char *names, const uint32_t *name_
                 const NameData &d = nd[i];
                 const bool bc_ok = d.present && d.has_bc && d.has_bc_end && d.x && d.has_q;
                 uint64_t w = 0;
-                const bool ok = bc_ok && umi_window(d, cfg->five_prime != 0, UL, &w);
+                bool ok = bc_ok && umi_window(d, cfg->five_prime != 0, UL, &w);
+                if (ok && cfg->random_umi_seed) w = random_umi_window(cfg->random_umi_seed, (uint64_t)i, UL);
                 if (d.present && d.has_bc) out[i].flags |= SMI_UMI_HAS_BC;
                 if (ok) {
                     win[i] = w;
@@ -1179,7 +1217,7 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
     SMI_HIP(hipMemcpyAsync(d_flags, flags, N * 2, hipMemcpyHostToDevice, s));
     SMI_HIP(hipMemcpyAsync(d_pos0, pos0, N * 4, hipMemcpyHostToDevice, s));
     if (n_cig) SMI_HIP(hipMemcpyAsync(d_cig, cigars, n_cig * 4, hipMemcpyHostToDevice, s));
-    SMI_RC(launch_umi_parse(ctx, d_names, d_noff, d_flags, d_pos0, d_cig, d_coff, n, cfg->five_prime != 0, cfg->grouping_distance, cfg->bc_edit_limit, UL, d_parsed, s));
+    SMI_RC(launch_umi_parse(ctx, d_names, d_noff, d_flags, d_pos0, d_cig, d_coff, n, cfg->five_prime != 0, cfg->grouping_distance, cfg->bc_edit_limit, UL, cfg->random_umi_seed, d_parsed, s));
     // region grouping: the sort by clustering position runs on the device; the sorted keys (8 bytes per read with a position) come down, the
     // chains and their refinement -- a sequential sweep with the reference's own quirks -- run on the host, the region numbers go up
     const size_t n_words = (N + 63) / 64;

@@ -62,7 +62,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into", "smi_gene_counts_dump", "smi_gene_counts_load", "smi_gene_counts_merge_shard",
-    "smi_set_stats", "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
+    "smi_set_stats", "smi_ctx_set_random_barcodes", "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
     "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen", "smi_name_set_create", "smi_name_set_free", "smi_name_set_seen",
 ]
 
@@ -85,6 +85,10 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # torch first: its wheel carries a HIP runtime of its own (torch/lib/libamdhip64.so); a process that loads /opt/rocm's copy before it (this library
+    # is linked against libamdhip64.so.7) ends up with two runtimes and torch then finds no GPU.  Loaded in this order both share torch's.
+    import torch  # noqa: F401
+
     path = library_path()
     if not os.path.exists(path):
         raise SmiError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950)")
@@ -99,6 +103,7 @@ def load_library():
     lib.smi_ctx_device.argtypes = [vp]
     lib.smi_ctx_set_polya.argtypes = [vp, ci, ctypes.c_float, ci]
     lib.smi_set_stats.argtypes = [vp, vp, ci]
+    lib.smi_ctx_set_random_barcodes.argtypes = [vp, ctypes.c_uint64]
     lib.smi_run_knobs_default.argtypes = [vp]
     lib.smi_ctx_set_knobs.argtypes = [vp, vp]
     lib.smi_ctx_get_knobs.argtypes = [vp, vp]
@@ -694,7 +699,7 @@ class AssignUmisConfig(ctypes.Structure):
     """smi_assignumis_config"""
     _fields_ = [("max_dist", ctypes.c_int32), ("grouping_distance", ctypes.c_int32), ("bc_edit_limit", ctypes.c_int32),
                 ("keep_data_end", ctypes.c_int32), ("n_threads", ctypes.c_int32), ("five_prime", ctypes.c_int32),
-                ("umi_length", ctypes.c_int32), ("cluster", ctypes.c_void_p)]
+                ("umi_length", ctypes.c_int32), ("cluster", ctypes.c_void_p), ("random_umi_seed", ctypes.c_uint64)]
 
 
 class PinnedBuffer:
@@ -1119,6 +1124,10 @@ class Context:
         refreshed afterwards take them over"""
         self._check(self._lib.smi_ctx_set_polya(self._h, int(polya_len), float(polya_frac), int(window_polya)))
 
+    def set_random_barcodes(self, seed=0):
+        """scanfastq -e / --randomBarcode for this context's pass-2 chunk workers (smi_ctx_set_random_barcodes; 0 = off)"""
+        self._check(self._lib.smi_ctx_set_random_barcodes(self._h, int(seed)))
+
     def set_knobs(self, knobs=None):
         """config.xml's knobs for this context's chunk workers (smi_ctx_set_knobs; None: the shipped file); lanes created or refreshed
         afterwards take them over.  SmiError names the knob this build has no kernel for."""
@@ -1456,7 +1465,7 @@ class Context:
         return d_out[:int(t[0])]
 
     def assignumis_chunk_raw(self, inp, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4, five_prime=False, cluster_cfg=None,
-                             umi_length=0, grouping_distance=None):
+                             umi_length=0, grouping_distance=None, random_umi_seed=0):
         """the same on the buffers of bam_chunk_inputs -> (UMI_TAG_DTYPE array, n_done)"""
         n = inp["n"]
         cfg = AssignUmisConfig()
@@ -1465,6 +1474,7 @@ class Context:
         cfg.five_prime = int(bool(five_prime))
         cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
         cfg.umi_length = int(umi_length)               # umis/umi_length (0: the context's knob, 12 without one)
+        cfg.random_umi_seed = int(random_umi_seed)     # assignumis -f (0: off)
         if grouping_distance is not None:              # barcodes/distance_from_read_end_for_grouping
             cfg.grouping_distance = int(grouping_distance)
         if cluster_cfg is not None:
@@ -1478,7 +1488,7 @@ class Context:
         return out[:n], nd.value
 
     def assignumis_chunk(self, names, flags, pos0, cigars, keep_data_end=False, max_dist=500, bc_edit_limit=None, n_threads=4,
-                         five_prime=False, cluster_cfg=None, umi_length=0, grouping_distance=None):
+                         five_prime=False, cluster_cfg=None, umi_length=0, grouping_distance=None, random_umi_seed=0):
         """one BamReader chunk through the native worker -> (UMI_TAG_DTYPE array, n_done); names: list of QNAME strings,
         cigars: list of numpy uint32 arrays (BAM encoding)"""
         n = len(names)
@@ -1497,6 +1507,7 @@ class Context:
         cfg.five_prime = int(bool(five_prime))
         cfg.bc_edit_limit = -1 if bc_edit_limit is None else int(bc_edit_limit)
         cfg.umi_length = int(umi_length)               # umis/umi_length (0: the context's knob, 12 without one)
+        cfg.random_umi_seed = int(random_umi_seed)     # assignumis -f (0: off)
         if grouping_distance is not None:              # barcodes/distance_from_read_end_for_grouping
             cfg.grouping_distance = int(grouping_distance)
         if cluster_cfg is not None:  # umi_cluster_config(...) record: the clusterer's knobs (shipped values otherwise)

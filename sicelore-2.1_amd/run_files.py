@@ -211,16 +211,21 @@ def _gzip_member(data, level):
     return c.compress(data) + c.flush()
 
 
-def run(ctx, in_dir, out_dir, *args, polya=None, **kw):
+def run(ctx, in_dir, out_dir, *args, polya=None, random_barcode_seed=0, **kw):
     """`_run` (below: everything about the run) with the polyA finder's parameters of `scanfastq -p <length> -f <fraction> -w <window>` set on the
-    context for its duration (smi_ctx_set_polya; None / zeros: config.xml's 15 / 0.75 / 150)"""
+    context for its duration (smi_ctx_set_polya; None / zeros: config.xml's 15 / 0.75 / 150); random_barcode_seed != 0: `scanfastq -e`, pass 2
+    matches random sequences in place of the reads' barcode windows (smi_ctx_set_random_barcodes: what is still assigned is chance)"""
     if polya is not None:
         ctx.set_polya(*polya)
+    if random_barcode_seed:
+        ctx.set_random_barcodes(random_barcode_seed)
     try:
         return _run(ctx, in_dir, out_dir, *args, **kw)
     finally:
         if polya is not None:
             ctx.set_polya()
+        if random_barcode_seed:
+            ctx.set_random_barcodes(0)
 
 
 def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, gz_level=6, whitelist_keys=None, five_prime=False,

@@ -337,3 +337,114 @@ def test_knobs_outside_the_build_are_refused_by_name(pkg, gpu_ctx):
     gpu_ctx.scan_device(torch.zeros((28, 2), dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"), 1,
                         gpu_ctx.scan_config(2, knobs=lib.run_knobs(min_read_length=150), five_prime=True, dont_search_polya=True),
                         torch.zeros((1, 8), dtype=torch.int32, device="cuda"))        # 5' -y cuts 110 + 10 + 4 + 5 = 129 bases only
+
+
+# ---- the accuracy simulations: scanfastq -e (random barcodes), assignumis -f (random UMIs) ----------------------------------------------------------
+def _splitmix(seed, k):
+    z = (int(seed) + 0x9E3779B97F4A7C15 * (int(k) + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def test_random_barcode_simulation_through_the_chunk_workers(pkg, synth, sor, gpu_ctx):
+    """scanfastq -e (Parser.java:L212-215; README.md:176 "Specifity can be estimated by re-running the program with the -e option"): with
+    smi_ctx_set_random_barcodes the matcher of pass 2 sees random window bases drawn from (seed, read id) -- the barcode results of the text worker and
+    of the packed worker equal K-BC on exactly those windows (the ORACLE's assignment on them for a sample), almost nothing is assigned any more, the
+    same seed gives the same run, another seed another one, and seed 0 is the ordinary run again"""
+    from test_write_gpu import _fastq
+
+    lib = __import__("importlib").import_module("sicelore_amd.lib")
+    wl = synth.make_whitelist(20_000, seed=1301)
+    used = synth.pick_used(wl, 2000, seed=1302)
+    n = 3000
+    reads = synth.gen_reads(n, used, seed=1303, n_rate=0.002)
+    seqs, quals = zip(*(synth.materialize(reads, i) for i in range(n)))
+    text = _fastq(list(seqs), list(quals))
+    keys = used.numpy().astype(np.uint64)
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    _p, _f, base = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False, want_results=True, first_read_id=100)
+    base_bc = base["bc"].copy()
+    assert (base_bc["found"] == 1).sum() > 0.5 * n
+    # the windows K-SCAN leaves for these reads, and their random stand-ins
+    ra = np.frombuffer("".join(seqs).encode(), dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(s_) for s_ in seqs])
+    _scan, win = gpu_ctx.scan_batch(ra, None, offs, gpu_ctx.scan_config(2))
+    runs = {}
+    for seed in (7, 7, 8):
+        gpu_ctx.set_random_barcodes(seed)
+        try:
+            res = []
+            for packed in (False, True):
+                p_, f_, info = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False, want_results=True, first_read_id=100, packed=packed, n_threads=2)
+                res.append((bytes(p_), bytes(f_), info["bc"].copy()))
+            assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and (res[0][2] == res[1][2]).all()
+        finally:
+            gpu_ctx.set_random_barcodes(0)
+        rnd = win.copy()
+        for i in range(n):
+            if rnd["flags"][i] & 1:
+                rnd["bases"][i] = _splitmix(seed, 100 + i) & ((1 << 48) - 1)
+                rnd["nmask"][i] = 0
+        exp = gpu_ctx.bc_match(rnd, max_ed=1)
+        got = res[0][2]
+        for f in ("found", "bc", "ed", "ed_sec", "offset", "ins_minus_del"):
+            sel = rnd["flags"] & 1 == 1
+            assert (got[f][sel] == exp[f][sel]).all(), (seed, f)
+        runs.setdefault(seed, []).append(res[0])
+        n_chance = int((got["found"] == 1).sum())
+        assert n_chance < 0.1 * (base_bc["found"] == 1).sum()        # 2,000 barcodes x 124 x 5 of 4^16 sequences: a chance hit is rare
+    assert runs[7][0][0] == runs[7][1][0] and (runs[7][0][2] == runs[7][1][2]).all()      # the same seed: the same run
+    assert runs[7][0][0] != runs[8][0][0]
+    # a sample of the random windows against the oracle's Parser.assignBarcode on the same bases
+    bset = sor.BarcodeSet(used.numpy())
+    dec = "AGCT"
+    checked = 0
+    for i in range(0, n, 7):
+        if not (win["flags"][i] & 1):
+            continue
+        v = _splitmix(7, 100 + i) & ((1 << 48) - 1)
+        w24 = "".join(dec[(v >> (2 * (23 - j))) & 3] for j in range(24))      # stranded[AE-22 .. AE+1]
+        stranded = ("A" * 30 + w24 + "A" * 8).encode()
+        rc, a = sor.assign_barcode(bset, stranded, 30 + 22, max_ed=1)
+        g = runs[7][0][2][i]
+        assert (rc == 1) == (g["found"] == 1), i
+        if rc == 1:
+            assert int(g["bc"]) == int(a["bc"]) & 0xFFFFFFFF and g["ed"] == a["ed"]
+        checked += 1
+    assert checked > 300
+    _p2, _f2, again = gpu_ctx.scanfastq_pass2_chunk(text, split_chimeras=False, want_results=True, first_read_id=100)
+    assert (again["bc"] == base_bc).all()
+
+
+@pytest.mark.parametrize("five,ul", [(False, 12), (True, 10)])
+def test_random_umi_simulation_in_the_umi_stage(pkg, gpu_ctx, five, ul, monkeypatch):
+    """assignumis -f (ClusteringEditDistanceBase.java:L308-310): with smi_assignumis_config.random_umi_seed every read's UMI window is a random one drawn
+    from (seed, position in the chunk): U7 shows it, the device stage and the host path agree, and the deep molecules of the input no longer cluster"""
+    from test_umi_gpu import _make_groups, _name_with_window_len
+
+    lib = __import__("importlib").import_module("sicelore_amd.lib")
+    n = 600
+    ws = _make_groups(44, [n])[:, :ul + 2]
+    names = [_name_with_window_len(i, ws[i], "15", ul, five) for i in range(n)]
+    pos0 = np.full(n, 100_000, dtype=np.int32)
+    cig = [np.array([1000 << 4], dtype=np.uint32)] * n
+    real, _nd = gpu_ctx.assignumis_chunk(names, np.zeros(n, np.uint16), pos0, cig, five_prime=five, umi_length=ul)
+    assert ((real["flags"] & lib.UMI_CLUSTERED) != 0).sum() > 0.5 * n
+    dec = {0: "A", 1: "G", 2: "C", 3: "T"}
+    outs = []
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("SMI_AU_HOST", "1")
+        t, nd = gpu_ctx.assignumis_chunk(names, np.zeros(n, np.uint16), pos0, cig, five_prime=five, umi_length=ul, random_umi_seed=11)
+        assert nd == n
+        outs.append(t.copy())
+    monkeypatch.delenv("SMI_AU_HOST")
+    assert (outs[0] == outs[1]).all()
+    for i in range(n):
+        z = _splitmix(11, i)
+        want = "".join(dec[(z >> (2 * k)) & 3] for k in range(1, ul + 1))       # U7 = bases 1 .. umi_length of the window
+        assert outs[0]["u7"][i].decode() == want, i
+    # (600 random UMIs in ONE group: the pairs within two edits by chance are what the simulation is there to count -- fewer than the real molecules give)
+    assert ((outs[0]["flags"] & lib.UMI_CLUSTERED) != 0).sum() < ((real["flags"] & lib.UMI_CLUSTERED) != 0).sum()

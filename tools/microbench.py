@@ -34,10 +34,10 @@ def main():
     res = {}
     wl = synth.make_whitelist(3_600_000, seed=1, device=dev)
     used = synth.pick_used(wl, 5000, seed=2)
-    legs = {"bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis,
+    legs = {"bc2": leg_bc2, "bc": leg_bc, "pass1": leg_pass1, "umi": leg_umi, "chimera": leg_chimera, "fastq": leg_fastq, "assignumis": leg_assignumis,
             "packed": leg_packed, "deflate": leg_deflate, "inflate": leg_inflate}
     for name, fn in legs.items():
-        if only in (None, name):
+        if only == name or (only is None and name != "bc2"):
             fn(pkg, synth, ctx, dev, wl, used, res)
     print(json.dumps(res))
 
@@ -49,6 +49,8 @@ def leg_bc(pkg, synth, ctx, dev, wl, used, res):
     win = synth.pack_windows(reg["codes"], reg["ae"])
     out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
+    ctx.set_barcode_set_device(used.to(torch.int32), mode=0)          # (the second load: into structures that are allocated)
+    res["used_list_5k_set"] = ctx.set_stats()
     for ed in (1, 2):
         dt = timed(lambda: ctx.bc_match_device(win, out, n, max_ed=ed))
         found = ((out[:, 2] & 0xFF) == 1)
@@ -58,6 +60,17 @@ def leg_bc(pkg, synth, ctx, dev, wl, used, res):
     ctx.set_barcode_set_device(wl.to(torch.int32), mode=1)
     dt = timed(lambda: ctx.bc_match_device(win, out, n, max_ed=2))
     res["bc_match_ed2_whitelist_3p6M"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt}
+
+
+def leg_bc2(pkg, synth, ctx, dev, wl, used, res):
+    """K-BC2 alone against the 5 k used list (configs[2]'s dominant kernel): for counters (PROFILE_PROG=tools/microbench.py tools/profile_gpu.sh <tag> bc2)"""
+    n = 2_000_000
+    reg = synth.gen_bc_region(n, used, seed=3, device=dev)
+    win = synth.pack_windows(reg["codes"], reg["ae"])
+    out = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ctx.set_barcode_set_device(used.to(torch.int32), mode=0)
+    dt = timed(lambda: ctx.bc_match_device(win, out, n, max_ed=2))
+    res["bc_match_ed2_used_list_5k"] = {"reads": n, "ms": dt * 1e3, "reads_per_s": n / dt, "set": ctx.set_stats()}
 
 
 def leg_pass1(pkg, synth, ctx, dev, wl, used, res):
