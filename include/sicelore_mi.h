@@ -372,6 +372,15 @@ int smi_finalize_used_list(const uint64_t *keys, const uint32_t *counts, size_t 
 int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off,
                         const uint64_t *d_pair_off, const uint64_t *d_mat_off, uint32_t n_groups,
                         uint64_t total_pairs, uint8_t *d_out, void *stream);
+/* The same with the layout the chunk worker (smi_assignumis_chunk) gives its own matrices (round 6): a group of more than 64 reads has rows of
+ * smi_umi_padded_row(n) = n rounded up to 64 bytes, and every group starts on a 64-byte boundary -- mat_off[g] = sum over earlier groups of
+ * smi_umi_padded_bytes(n); cell [i][v] of group g = out[mat_off[g] + i * smi_umi_padded_row(n) + v].  Every 64-byte row piece a tile of the kernel writes
+ * is then one whole line; with dense rows (a row starts at any byte) the pieces' first and last lines were shared with the neighbouring tile and went out
+ * twice: 1.55 x the matrix bytes written (profiles/r05/umi_pmc.json), now about 1.0 x. */
+uint64_t smi_umi_padded_row(uint32_t n);
+uint64_t smi_umi_padded_bytes(uint32_t n);
+int smi_umi_dist_device_padded(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off, const uint64_t *d_mat_off,
+                               uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, void *stream);
 /* host buffers in and out: windows of all groups back to back, group g = reads [group_off[g], group_off[g+1]); out: the n x n matrices of
  * the groups back to back (sum of n^2 bytes), layout as above */
 int smi_umi_dist_batch(smi_ctx *ctx, const uint64_t *windows, const uint32_t *group_off, uint32_t n_groups, uint8_t *out);

@@ -464,13 +464,13 @@ namespace {
 
 // count[i] = how many b of idx[0 .. n_idx) have ed(idx[i], b) <= ced (the read itself included: ed = 0).  One wave per row.  `init` (first
 // call of a group): the row's assignment record starts as "not clustered", its cluster number as -1, its tag flag as 0.
-__global__ __launch_bounds__(256) void k_umi_own_count(const uint8_t *__restrict__ m, int n, const int *__restrict__ idx, int n_idx, int ced,
+__global__ __launch_bounds__(256) void k_umi_own_count(const uint8_t *__restrict__ m, int n, int ld, const int *__restrict__ idx, int n_idx, int ced,
                                                        int *__restrict__ count, smi_umi_assignment *__restrict__ init, int *__restrict__ init_cid,
                                                        uint8_t *__restrict__ init_flag) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
     for (int i = wave; i < n_idx; i += n_waves) {
-        const uint8_t *row = m + (size_t)(idx ? idx[i] : i) * n;
+        const uint8_t *row = m + (size_t)(idx ? idx[i] : i) * ld;
         int c = 0;
         if (!idx) {  // every read of the group: the row as it lies, eight cells per load (a byte per lane and round trip is latency, not bandwidth)
             for (int k = 8 * lane; k < n_idx; k += 512) {
@@ -504,12 +504,12 @@ __global__ __launch_bounds__(256) void k_umi_own_count(const uint8_t *__restrict
 // with rc[b] = {position of read b in the iteration order or -1 when b is no key, its count}: the arg-max over (count, -position) does not
 // care in which order it sees them.  (Walking the positions and gathering row[ord[p]] was 0.58 ms for 8,000 keys: a byte per lane from a
 // random place of the row.)  One wave per key; ed is symmetric.
-__global__ __launch_bounds__(256) void k_umi_own_owner(const uint8_t *__restrict__ m, int n, const int *__restrict__ ord, const int2 *__restrict__ rc,
+__global__ __launch_bounds__(256) void k_umi_own_owner(const uint8_t *__restrict__ m, int n, int ld, const int *__restrict__ ord, const int2 *__restrict__ rc,
                                                        int n_keys, int ced, int *__restrict__ owner) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
     for (int i = wave; i < n_keys; i += n_waves) {
-        const uint8_t *row = m + (size_t)ord[i] * n;
+        const uint8_t *row = m + (size_t)ord[i] * ld;
         long long best = -1;  // count << 32 | (0x7FFFFFFF - position): larger = better count, then earlier position
         auto look = [&](int b, int e) {
             if (e > ced) return;  // (a row has a handful of cells within ced: rc is read for those only)
@@ -538,13 +538,13 @@ __global__ __launch_bounds__(256) void k_umi_own_owner(const uint8_t *__restrict
 }
 
 // tot[i] = sum over the members w != s of ed(s, w)^2 for member i of its cluster (members listed cluster after cluster; c_off the offsets)
-__global__ __launch_bounds__(256) void k_umi_own_sums(const uint8_t *__restrict__ m, int n, const int *__restrict__ mem, const int *__restrict__ c_of,
+__global__ __launch_bounds__(256) void k_umi_own_sums(const uint8_t *__restrict__ m, int n, int ld, const int *__restrict__ mem, const int *__restrict__ c_of,
                                                       const int *__restrict__ c_off, int n_mem, long long *__restrict__ tot) {
     const int lane = threadIdx.x & 63;
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
     for (int i = wave; i < n_mem; i += n_waves) {
         const int c = c_of[i], s = mem[i];
-        const uint8_t *row = m + (size_t)s * n;
+        const uint8_t *row = m + (size_t)s * ld;
         long long t = 0;
 #pragma unroll 4
         for (int k = c_off[c] + lane; k < c_off[c + 1]; k += 64) {
@@ -592,17 +592,17 @@ __global__ __launch_bounds__(256) void k_umi_own_pick(const long long *__restric
 }
 
 // cell[i] = matrix byte (centre of member i's cluster, member i)
-__global__ void k_umi_own_cells(const uint8_t *__restrict__ m, int n, const int *__restrict__ mem, const int *__restrict__ c_of, const int *__restrict__ gid,
+__global__ void k_umi_own_cells(const uint8_t *__restrict__ m, int n, int ld, const int *__restrict__ mem, const int *__restrict__ c_of, const int *__restrict__ gid,
                                 const int *__restrict__ center, int n_mem, uint8_t *__restrict__ cell) {
     const int i = (int)(blockIdx.x * (size_t)blockDim.x + threadIdx.x);
-    if (i < n_mem) cell[i] = m[(size_t)center[gid[c_of[i]]] * n + mem[i]];
+    if (i < n_mem) cell[i] = m[(size_t)center[gid[c_of[i]]] * ld + mem[i]];
 }
 
 // What the host clusterer's last loop decides per cluster with more than one member (cluster_one / tag_members): the members within ced of
 // the (final) centre are tagged if there is more than one of them; the offset is the rounded mean of pos1 - 1 over ALL members but the centre.
 // A tagged cluster's members carry its number in cid (everybody else keeps -1: "outside" for every read), flag marks the reads that get tags.
 // One wave per cluster.
-__global__ __launch_bounds__(256) void k_umi_own_decide(const uint8_t *__restrict__ m, int n, const int *__restrict__ mem, const int *__restrict__ c_off,
+__global__ __launch_bounds__(256) void k_umi_own_decide(const uint8_t *__restrict__ m, int n, int ld, const int *__restrict__ mem, const int *__restrict__ c_off,
                                                         const int *__restrict__ gid, int n_cl, const int *__restrict__ center, int ced,
                                                         const uint8_t *__restrict__ skipped, int *__restrict__ cid, int *__restrict__ offset,
                                                         uint8_t *__restrict__ flag) {
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256) void k_umi_own_decide(const uint8_t *__restric
     const int wave = (int)((blockIdx.x * (size_t)blockDim.x + threadIdx.x) >> 6), n_waves = (int)(((size_t)gridDim.x * blockDim.x) >> 6);
     for (int c = wave; c < n_cl; c += n_waves) {
         const int a = c_off[c], b = c_off[c + 1], g = gid[c], ctr = center[g];
-        const uint8_t *row = m + (size_t)ctr * n;
+        const uint8_t *row = m + (size_t)ctr * ld;
         int sum = 0, cnt = 0, filt = 0;
         for (int k = a + lane; k < b; k += 64) {
             const int v = mem[k];
@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void k_umi_own_decide(const uint8_t *__restric
 
 // tags of the flagged reads (ClusterOneBase.setSamflagsAndStatsForClustered): centre, offset, ed / pos2 to the centre, and the least distance to
 // a read outside the read's cluster (cid[m] != its own; -1 when there is one cluster only).  One wave per read.
-__global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict__ m, int n, const uint8_t *__restrict__ flag, const int *__restrict__ cid,
+__global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict__ m, int n, int ld, const uint8_t *__restrict__ flag, const int *__restrict__ cid,
                                                       const int *__restrict__ center, const int *__restrict__ offset, int n_clusters,
                                                       smi_umi_assignment *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict_
     for (int idx = wave; idx < n; idx += n_waves) {
         if (!flag[idx]) continue;
         const int c = cid[idx];
-        const uint8_t *row = m + (size_t)idx * n;
+        const uint8_t *row = m + (size_t)idx * ld;
         int sec = 127;
         if (n_clusters > 1)
             for (int k = 8 * lane; k < n; k += 512) {
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(256) void k_umi_own_tags(const uint8_t *__restrict_
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sec = min(sec, __shfl_xor(sec, o));
         if (lane == 0) {
-            const uint8_t cell = m[(size_t)center[c] * n + idx];
+            const uint8_t cell = m[(size_t)center[c] * ld + idx];
             smi_umi_assignment a;
             a.center = center[c];
             a.offset = (int8_t)offset[c];
@@ -704,7 +704,8 @@ struct UpBlock {
 }  // namespace
 
 int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const float *d_qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *d_out,
-                           uint8_t *d_skipped, hipStream_t s) {
+                           uint8_t *d_skipped, hipStream_t s, int ld) {
+    if (ld <= 0) ld = n;  // row stride of the matrix (the chunk worker's matrices have rows padded to whole lines)
     const int ced = cfg.complete_link_ed;
     // Room: every array of a step has at most n + 2 entries of at most 8 bytes, and a call takes fewer than 48 of them on either side.
     const size_t room = 48 * ((size_t)n + 64) * 8;
@@ -779,7 +780,7 @@ int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const floa
         int *h_count = reinterpret_cast<int *>(host_only((size_t)k * 4)), *d_count = reinterpret_cast<int *>(dev_only((size_t)k * 4));
         SMI_OWN_ROOM();
         const bool init = first_call && identity;
-        hipLaunchKernelGGL(k_umi_own_count, dim3(grid), dim3(256), 0, s, d_mat, n, d_idx, k, ced, d_count, init ? d_out : (smi_umi_assignment *)nullptr,
+        hipLaunchKernelGGL(k_umi_own_count, dim3(grid), dim3(256), 0, s, d_mat, n, ld, d_idx, k, ced, d_count, init ? d_out : (smi_umi_assignment *)nullptr,
                            init ? d_cid : (int *)nullptr, init ? d_flag : (uint8_t *)nullptr);
         SMI_HIP(hipMemcpyAsync(h_count, d_count, (size_t)k * 4, hipMemcpyDeviceToHost, s));
         SMI_HIP(hipStreamSynchronize(s));
@@ -804,7 +805,7 @@ int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const floa
         }
         lap("keys in iteration order (host)");
         SMI_HIP(hipMemcpyAsync(B.d, B.h, B.bytes, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_umi_own_owner, dim3(grid), dim3(256), 0, s, d_mat, n, B.dev<int>(0), B.dev<int2>(o_rc), (int)ord.size(), ced, d_own);
+        hipLaunchKernelGGL(k_umi_own_owner, dim3(grid), dim3(256), 0, s, d_mat, n, ld, B.dev<int>(0), B.dev<int2>(o_rc), (int)ord.size(), ced, d_own);
         SMI_HIP(hipMemcpyAsync(h_own, d_own, ord.size() * 4, hipMemcpyDeviceToHost, s));
         SMI_HIP(hipStreamSynchronize(s));
         for (size_t i = 0; i < ord.size(); i++) owner[(size_t)ord[i]] = h_own[i];
@@ -874,7 +875,7 @@ int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const floa
         if (L.n_mem == 0) return SMI_OK;
         long long *d_tot = reinterpret_cast<long long *>(dev_only(((size_t)L.n_mem + 1) * 8));
         SMI_OWN_ROOM();
-        hipLaunchKernelGGL(k_umi_own_sums, dim3(grid), dim3(256), 0, s, d_mat, n, L.d_mem, L.d_c_of, L.d_c_off, L.n_mem, d_tot);
+        hipLaunchKernelGGL(k_umi_own_sums, dim3(grid), dim3(256), 0, s, d_mat, n, ld, L.d_mem, L.d_c_of, L.d_c_off, L.n_mem, d_tot);
         hipLaunchKernelGGL(k_umi_own_pick, dim3((unsigned)std::min<size_t>(((size_t)L.n_cl + 3) / 4, 256 * 16)), dim3(256), 0, s, d_tot, L.d_mem, L.d_c_off,
                            L.d_gid, L.n_cl, d_qv, n, d_center);
         return SMI_OK;
@@ -905,7 +906,7 @@ int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const floa
         h_cell = reinterpret_cast<uint8_t *>(host_only((size_t)L1.n_mem));
         uint8_t *d_cell = reinterpret_cast<uint8_t *>(dev_only((size_t)L1.n_mem));
         SMI_OWN_ROOM();
-        hipLaunchKernelGGL(k_umi_own_cells, dim3((unsigned)((L1.n_mem + 255) / 256)), dim3(256), 0, s, d_mat, n, L1.d_mem, L1.d_c_of, L1.d_gid, d_center, L1.n_mem,
+        hipLaunchKernelGGL(k_umi_own_cells, dim3((unsigned)((L1.n_mem + 255) / 256)), dim3(256), 0, s, d_mat, n, ld, L1.d_mem, L1.d_c_of, L1.d_gid, d_center, L1.n_mem,
                            d_cell);
         SMI_HIP(hipMemcpyAsync(h_cell, d_cell, (size_t)L1.n_mem, hipMemcpyDeviceToHost, s));
     }
@@ -975,9 +976,9 @@ int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const floa
     }
     if (!tagged.empty()) {
         SMI_OWN_RC(list_clusters(kept, tagged, false, L4));
-        hipLaunchKernelGGL(k_umi_own_decide, dim3((unsigned)std::min<size_t>(((size_t)L4.n_cl + 3) / 4, 256 * 16)), dim3(256), 0, s, d_mat, n, L4.d_mem, L4.d_c_off,
+        hipLaunchKernelGGL(k_umi_own_decide, dim3((unsigned)std::min<size_t>(((size_t)L4.n_cl + 3) / 4, 256 * 16)), dim3(256), 0, s, d_mat, n, ld, L4.d_mem, L4.d_c_off,
                            L4.d_gid, L4.n_cl, d_center, ced, d_sk, d_cid, d_offset, d_flag);
-        hipLaunchKernelGGL(k_umi_own_tags, dim3(grid), dim3(256), 0, s, d_mat, n, d_flag, d_cid, d_center, d_offset, (int)kept.size(), d_out);
+        hipLaunchKernelGGL(k_umi_own_tags, dim3(grid), dim3(256), 0, s, d_mat, n, ld, d_flag, d_cid, d_center, d_offset, (int)kept.size(), d_out);
     }
     lap("final lists (host)");
     SMI_HIP(hipStreamSynchronize(s));  // (the pinned arrays of this call are free again)

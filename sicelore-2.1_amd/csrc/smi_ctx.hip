@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "smi_internal.h"
+#include "smi_umi_stage.h"
 
 namespace smi {
 
@@ -869,6 +870,23 @@ int smi_count_keys_device(smi_ctx *ctx, const uint64_t *d_keys, size_t n, uint64
         return SMI_ERR_INVALID;
     }
     return launch_count_keys(ctx, d_keys, n, d_unique, d_counts, d_n_unique, (hipStream_t)stream);
+}
+
+uint64_t smi_umi_padded_row(uint32_t n) { return umi_ld(n, true); }
+uint64_t smi_umi_padded_bytes(uint32_t n) { return umi_mat_bytes(n, true); }
+
+int smi_umi_dist_device_padded(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off, const uint64_t *d_mat_off,
+                               uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, void *stream) {
+    if (int rc = bind(ctx)) return rc;
+    if (n_groups && (!d_windows || !d_group_off || !d_pair_off || !d_mat_off || !d_out)) {
+        set_error("smi_umi_dist_device_padded: null buffer");
+        return SMI_ERR_INVALID;
+    }
+    if ((reinterpret_cast<uintptr_t>(d_out) & 63u) != 0) {
+        set_error("smi_umi_dist_device_padded: the matrix buffer must start on a 64-byte boundary");
+        return SMI_ERR_INVALID;
+    }
+    return launch_umi_dist(ctx, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups, total_pairs, d_out, (hipStream_t)stream, ctx_umi_length(ctx), true);
 }
 
 int smi_umi_dist_device(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off,

@@ -193,7 +193,7 @@ int worker_scan_config(const smi_ctx *ctx, int pass, int five_prime, int dont_se
 int worker_chimera_config(const smi_ctx *ctx, int five_prime, smi_chimera_config *cc);
 // ClusterOne_MyClustering of one group above 100 reads on the matrix in HBM (smi_cluster.hip)
 int umi_cluster_own_device(smi_ctx *ctx, const uint8_t *d_mat, int n, const float *d_qv, const smi_umi_cluster_config &cfg, smi_umi_assignment *d_out,
-                           uint8_t *d_skipped, hipStream_t s);
+                           uint8_t *d_skipped, hipStream_t s, int ld = 0);  // ld: row stride of d_mat (0: n)
 int time_begin(smi_ctx *ctx, int kid, hipStream_t s);
 int time_end(smi_ctx *ctx, int kid, hipStream_t s);
 Pyramid pyramid_of(const smi_ctx *ctx);
@@ -215,7 +215,7 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
                 const uint32_t *d_qsum, size_t n, const smi_scan_config *cfg, smi_scan_result *d_out,
                 smi_bc_window *d_win, hipStream_t s);
 int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
-                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s, int umi_len = 12);
+                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s, int umi_len = 12, bool padded = false);
 // umis/umi_length of a context's knobs (12 without knobs)
 inline int ctx_umi_length(const smi_ctx *ctx) { return ctx->knobs_set ? ctx->knobs.umi_length : 12; }
 int launch_pack_ends(smi_ctx *ctx, const uint8_t *d_reads, const uint8_t *d_quals, const uint64_t *d_offsets, const uint64_t *d_starts,

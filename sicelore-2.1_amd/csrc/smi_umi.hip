@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "smi_internal.h"
+#include "smi_umi_stage.h"
 
 namespace smi {
 
@@ -308,7 +309,7 @@ constexpr int kUmiTileThreads = SMI_UMI_TILE_THREADS;
 template <int UL>
 __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64_t *__restrict__ windows, const uint32_t *__restrict__ group_off,
                                                                     const UmiPlan *__restrict__ plan, const uint64_t *__restrict__ mat_off,
-                                                                    uint32_t n_groups, uint32_t *__restrict__ next_unit, uint8_t *__restrict__ out) {
+                                                                    uint32_t n_groups, uint32_t *__restrict__ next_unit, uint8_t *__restrict__ out, int padded) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[2][kUmiTile][kUmiLdsRow];
     __shared__ uint32_t s_unit;
     __shared__ UmiRowTable R;
@@ -336,6 +337,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
         const uint64_t nbm = (n + kUmiMacro * kUmiTile - 1) / (kUmiMacro * kUmiTile);
         const uint64_t mi = tri_row(nbm, local), mv = mi + (local - (mi * nbm - mi * (mi - 1) / 2));
         uint8_t *m = out + mat_off[g];
+        const uint64_t ld = umi_ld(n, padded != 0);  // row stride: n, or n rounded up to whole 64-byte lines (smi_umi_stage.h)
         const uint64_t *win = windows + r0;
         uint64_t rows_of = ~0ull;  // first row of the tile row the table holds
         for (int tt = 0; tt < kUmiMacro * kUmiMacro; tt++) {
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
                 const uint64_t rr = (reg ? v0 : i0) + row, c0 = (reg ? i0 : v0) + 16 * piece, c_end = min((reg ? i0 : v0) + (uint64_t)kUmiTile, n);
                 if (!(reg == 1 && bi == bv) && rr < n && c0 < c_end) {
                     const uint8_t *src = &stage[reg][row][16 * piece];
-                    uint8_t *dst = m + rr * n + c0;
+                    uint8_t *dst = m + rr * ld + c0;
                     if (c0 + 16 <= c_end) {
                         uint4 q = *reinterpret_cast<const uint4 *>(src);
                         __builtin_memcpy(dst, &q, 16);
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(kUmiTileThreads) void k_umi_dist_tiles(const uint64
 }
 
 int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_group_off, const uint64_t *d_pair_off,
-                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s, int umi_len) {
+                    const uint64_t *d_mat_off, uint32_t n_groups, uint64_t total_pairs, uint8_t *d_out, hipStream_t s, int umi_len, bool padded) {
     (void)d_pair_off;  // (the flat index space of round 1; the two kernels take theirs from the plan below)
     if (!total_pairs || !n_groups) return SMI_OK;
     // plan: per group its pairs in the flat kernel or its tiles in the tiled one, prefix sums of both in one scan
@@ -428,7 +430,7 @@ int launch_umi_dist(smi_ctx *ctx, const uint64_t *d_windows, const uint32_t *d_g
     auto launch = [&](auto ul) {
         constexpr int UL = decltype(ul)::value;
         hipLaunchKernelGGL(k_umi_dist<UL>, dim3(grid), dim3(256), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_out);
-        hipLaunchKernelGGL(k_umi_dist_tiles<UL>, dim3(grid_t), dim3(kUmiTileThreads), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_next, d_out);
+        hipLaunchKernelGGL(k_umi_dist_tiles<UL>, dim3(grid_t), dim3(kUmiTileThreads), 0, s, d_windows, d_group_off, d_plan, d_mat_off, n_groups, d_next, d_out, padded ? 1 : 0);
     };
     switch (umi_len) {  // umis/umi_length (config.xml:264)
     case 12: launch(std::integral_constant<int, 12>()); break;

@@ -33,9 +33,15 @@ int launch_umi_region_keys(smi_ctx *ctx, const UmiParsed *d_parsed, int n, UmiGr
 int launch_umi_groups(smi_ctx *ctx, const UmiParsed *d_parsed, const int32_t *d_region, int n, int n_done, UmiGroupBuffers &B, uint64_t *totals, hipStream_t s);
 // groups of up to dev_max reads are clustered (ClusterOneHierarchical); larger ones are left untouched (all "not clustered") for the host
 int launch_umi_cluster(smi_ctx *ctx, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups, const float *d_qv,
-                       const smi_umi_cluster_config &cfg, int dev_max, smi_umi_assignment *d_asg, uint8_t *d_skipped, hipStream_t s);
+                       const smi_umi_cluster_config &cfg, int dev_max, smi_umi_assignment *d_asg, uint8_t *d_skipped, hipStream_t s, bool padded = false);
 int launch_umi_tags(smi_ctx *ctx, const UmiParsed *d_parsed, const int32_t *d_region, int n, int n_done, const UmiGroupBuffers &B, uint32_t n_groups, uint32_t m,
                     const smi_umi_assignment *d_asg, const uint8_t *d_skipped, int umi_len, smi_umi_tag *d_tags, hipStream_t s);
 constexpr int kUmiClusterDeviceMax = 100;
+// Row stride and size of a group's distance matrix.  Dense (the public contract of smi_umi_dist_device): n x n bytes.  Padded (round 6, the chunk worker's
+// own matrices): groups above 64 reads -- the ones the tiled kernel writes -- have rows of ld = n rounded up to 64 bytes and start on a 64-byte boundary, so
+// every 64-byte row piece of a tile is one whole line: a dense row starts at any byte, the first and last line of a piece were shared with the tile beside
+// it, written twice, and K-UMI's stores came to 1.55 x the matrix bytes (profiles/r05/umi_pmc.json).
+__host__ __device__ inline uint64_t umi_ld(uint64_t n, bool padded) { return padded && n > 64 ? (n + 63) & ~(uint64_t)63 : n; }
+__host__ __device__ inline uint64_t umi_mat_bytes(uint64_t n, bool padded) { return padded ? (umi_ld(n, true) * n + 63) & ~(uint64_t)63 : n * n; }
 
 }  // namespace smi

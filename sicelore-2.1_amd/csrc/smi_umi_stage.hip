@@ -331,7 +331,7 @@ __global__ void k_umi_group_sizes(const uint64_t *__restrict__ run_keys, const u
     const uint64_t k = ok ? run_len[r] : 0;
     gsize[r] = (uint32_t)k;
     gpairs[r] = k * (k + 1) / 2;
-    gmat[r] = k * k;
+    gmat[r] = ok ? umi_mat_bytes(k, true) : 0;  // (padded rows for the groups the tiled kernel writes: smi_umi_stage.h)
 }
 
 __global__ void k_umi_kept_flags(const uint32_t *__restrict__ gsize, uint32_t *__restrict__ gkept, int cap) {
@@ -454,7 +454,7 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 template <int KMAX, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_umi_cluster(const uint8_t *__restrict__ dist, const uint64_t *__restrict__ mat_off, const uint32_t *__restrict__ group_off,
                                                             uint32_t n_groups, const float *__restrict__ qv_all, smi_umi_cluster_config cfg, int dev_max, int n_above,
-                                                            smi_umi_assignment *__restrict__ out_all, uint8_t *__restrict__ skipped_all) {
+                                                            smi_umi_assignment *__restrict__ out_all, uint8_t *__restrict__ skipped_all, int padded) {
     __shared__ ClustLds<KMAX> L_all[WAVES];
     ClustLds<KMAX> &L = L_all[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
@@ -474,7 +474,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_umi_cluster(const uint8_t *__res
     // global load before this copy existed
     {
         const uint8_t *Mg = dist + mat_off[g];
-        for (int p = lane; p < n * n; p += 64) L.mat[p] = Mg[p];
+        const int ld = (int)umi_ld((uint64_t)n, padded != 0);  // (rows of a group above 64 reads may be padded to whole lines)
+        if (ld == n) {
+            for (int p = lane; p < n * n; p += 64) L.mat[p] = Mg[p];
+        } else {
+            for (int p = lane; p < n * n; p += 64) L.mat[p] = Mg[(p / n) * ld + p % n];
+        }
     }
     wave_sync();
     const uint8_t *M = L.mat;
@@ -794,11 +799,11 @@ int launch_umi_groups(smi_ctx *, const UmiParsed *d_parsed, const int32_t *d_reg
 }
 
 int launch_umi_cluster(smi_ctx *, const uint8_t *d_dist, const uint64_t *d_mat_off, const uint32_t *d_group_off, uint32_t n_groups, const float *d_qv,
-                       const smi_umi_cluster_config &cfg, int dev_max, smi_umi_assignment *d_asg, uint8_t *d_skipped, hipStream_t s) {
+                       const smi_umi_cluster_config &cfg, int dev_max, smi_umi_assignment *d_asg, uint8_t *d_skipped, hipStream_t s, bool padded) {
     if (!n_groups) return SMI_OK;
-    hipLaunchKernelGGL((k_umi_cluster<16, 4>), dim3((n_groups + 3) / 4), dim3(256), 0, s, d_dist, d_mat_off, d_group_off, n_groups, d_qv, cfg, dev_max, 0, d_asg, d_skipped);
+    hipLaunchKernelGGL((k_umi_cluster<16, 4>), dim3((n_groups + 3) / 4), dim3(256), 0, s, d_dist, d_mat_off, d_group_off, n_groups, d_qv, cfg, dev_max, 0, d_asg, d_skipped, padded ? 1 : 0);
     hipLaunchKernelGGL((k_umi_cluster<kClustMax, 1>), dim3(n_groups), dim3(64), 0, s, d_dist, d_mat_off, d_group_off, n_groups, d_qv, cfg, dev_max, 16, d_asg,
-                       d_skipped);
+                       d_skipped, padded ? 1 : 0);
     SMI_HIP(hipGetLastError());
     return SMI_OK;
 }

@@ -1255,10 +1255,10 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
             ctx->umi_dist_bytes = want;
         }
         uint8_t *d_dist = static_cast<uint8_t *>(ctx->umi_dist);
-        SMI_RC(launch_umi_dist(ctx, B.wpk, B.group_off, B.pair_off, B.mat_off, n_groups, totals[2], d_dist, s, UL));
+        SMI_RC(launch_umi_dist(ctx, B.wpk, B.group_off, B.pair_off, B.mat_off, n_groups, totals[2], d_dist, s, UL, true));  // rows padded to whole lines (smi_umi_stage.h)
         int dev_max = std::min(cc.own_clusterer_above, kUmiClusterDeviceMax);
         if (cc.single_link_switch < dev_max) dev_max = cc.single_link_switch;  // (never with the shipped values: the switch sits at 3000)
-        SMI_RC(launch_umi_cluster(ctx, d_dist, B.mat_off, B.group_off, n_groups, B.qv, cc, dev_max, d_asg, d_skipped, s));
+        SMI_RC(launch_umi_cluster(ctx, d_dist, B.mat_off, B.group_off, n_groups, B.qv, cc, dev_max, d_asg, d_skipped, s, true));
         // groups the kernel left alone: their matrix comes back, the host clusters them, the assignments go up again
         std::vector<uint32_t> goff((size_t)n_groups + 1);
         SMI_HIP(hipMemcpyAsync(goff.data(), B.group_off, ((size_t)n_groups + 1) * 4, hipMemcpyDeviceToHost, s));
@@ -1276,14 +1276,14 @@ extern "C" int smi_assignumis_chunk(smi_ctx *ctx, const char *names, const uint3
                 const uint32_t k = goff[g + 1] - goff[g];
                 if ((int)k > cc.own_clusterer_above && !own_on_host) {
                     // ClusterOne_MyClustering: its n^2 loops on the device over the matrix where it lies (smi_cluster.hip)
-                    SMI_RC(umi_cluster_own_device(ctx, d_dist + moff[g], (int)k, B.qv + goff[g], cc, d_asg + goff[g], d_skipped + goff[g], s));
+                    SMI_RC(umi_cluster_own_device(ctx, d_dist + moff[g], (int)k, B.qv + goff[g], cc, d_asg + goff[g], d_skipped + goff[g], s, (int)umi_ld(k, true)));
                     continue;
                 }
                 std::vector<uint8_t> mat((size_t)k * k);
                 std::vector<float> qv(k);
                 std::vector<smi_umi_assignment> asg(k);
                 std::vector<uint8_t> sk(k, 0);
-                SMI_HIP(hipMemcpyAsync(mat.data(), d_dist + moff[g], (size_t)k * k, hipMemcpyDeviceToHost, s));
+                SMI_HIP(hipMemcpy2DAsync(mat.data(), k, d_dist + moff[g], (size_t)umi_ld(k, true), k, k, hipMemcpyDeviceToHost, s));  // (rows of the padded matrix -> dense)
                 SMI_HIP(hipMemcpyAsync(qv.data(), B.qv + goff[g], (size_t)k * 4, hipMemcpyDeviceToHost, s));
                 SMI_HIP(hipStreamSynchronize(s));
                 const uint64_t zero64 = 0;

@@ -62,7 +62,7 @@ EXPORTS = [
     "smi_record_flags", "smi_scan_stats_add", "smi_scan_stats_merge", "smi_scan_stats_tsv", "smi_deflate_bound", "smi_gzip_device", "smi_gz_inflate_device", "smi_bgzf_deflate_device",
     "smi_gene_counts_create", "smi_gene_counts_free", "smi_gene_counts_add", "smi_gene_counts_merge", "smi_gene_counts_info",
     "smi_gene_counts_tsv", "smi_umi_depths_tsv", "smi_gz_inflate_into", "smi_gene_counts_dump", "smi_gene_counts_load", "smi_gene_counts_merge_shard",
-    "smi_set_stats", "smi_ctx_set_random_barcodes", "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
+    "smi_set_stats", "smi_umi_padded_row", "smi_umi_padded_bytes", "smi_umi_dist_device_padded", "smi_ctx_set_random_barcodes", "smi_run_knobs_default", "smi_ctx_set_knobs", "smi_ctx_get_knobs", "smi_scan_config_from_knobs", "smi_chimera_config_from_knobs",
     "smi_bam_write_default_config", "smi_bam_write_batch", "smi_bam_chunk_inputs", "smi_bam_name_seen", "smi_name_set_create", "smi_name_set_free", "smi_name_set_seen",
 ]
 
@@ -103,6 +103,11 @@ def load_library():
     lib.smi_ctx_device.argtypes = [vp]
     lib.smi_ctx_set_polya.argtypes = [vp, ci, ctypes.c_float, ci]
     lib.smi_set_stats.argtypes = [vp, vp, ci]
+    lib.smi_umi_padded_row.argtypes = [ctypes.c_uint32]
+    lib.smi_umi_padded_row.restype = ctypes.c_uint64
+    lib.smi_umi_padded_bytes.argtypes = [ctypes.c_uint32]
+    lib.smi_umi_padded_bytes.restype = ctypes.c_uint64
+    lib.smi_umi_dist_device_padded.argtypes = [vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_uint64, vp, vp]
     lib.smi_ctx_set_random_barcodes.argtypes = [vp, ctypes.c_uint64]
     lib.smi_run_knobs_default.argtypes = [vp]
     lib.smi_ctx_set_knobs.argtypes = [vp, vp]
@@ -1552,21 +1557,26 @@ class Context:
 
     # ---- UMI pair distances ------------------------------------------------------------------------------
     @staticmethod
-    def umi_offsets(group_sizes):
-        """host helper: group sizes -> (group_off uint32, pair_off uint64, mat_off uint64) prefix arrays"""
+    def umi_offsets(group_sizes, padded=False):
+        """host helper: group sizes -> (group_off uint32, pair_off uint64, mat_off uint64) prefix arrays; padded: the layout of
+        smi_umi_dist_device_padded (rows of a group above 64 reads rounded up to 64 bytes, every group on a 64-byte boundary)"""
         n = np.asarray(group_sizes, dtype=np.uint64)
         go = np.zeros(n.size + 1, dtype=np.uint32)
         go[1:] = np.cumsum(n)
         po = np.zeros(n.size + 1, dtype=np.uint64)
         po[1:] = np.cumsum(n * (n + 1) // 2)
         mo = np.zeros(n.size + 1, dtype=np.uint64)
-        mo[1:] = np.cumsum(n * n)
+        if padded:
+            ld = np.where(n > 64, (n + np.uint64(63)) & ~np.uint64(63), n)
+            mo[1:] = np.cumsum((ld * n + np.uint64(63)) & ~np.uint64(63))
+        else:
+            mo[1:] = np.cumsum(n * n)
         return go, po, mo
 
-    def umi_dist_device(self, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups, total_pairs, d_out, stream=None):
-        self._check(self._lib.smi_umi_dist_device(self._h, _ptr(d_windows), _ptr(d_group_off), _ptr(d_pair_off),
-                                                  _ptr(d_mat_off), int(n_groups), int(total_pairs), _ptr(d_out),
-                                                  _stream_ptr(stream)))
+    def umi_dist_device(self, d_windows, d_group_off, d_pair_off, d_mat_off, n_groups, total_pairs, d_out, stream=None, padded=False):
+        fn = self._lib.smi_umi_dist_device_padded if padded else self._lib.smi_umi_dist_device
+        self._check(fn(self._h, _ptr(d_windows), _ptr(d_group_off), _ptr(d_pair_off), _ptr(d_mat_off), int(n_groups), int(total_pairs), _ptr(d_out),
+                       _stream_ptr(stream)))
 
     def umi_cluster_groups_device(self, d_dist, d_mat_off, d_group_off, n_groups, d_qv, d_out, d_skipped, cfg=None, stream=None):
         """K-UCLUST: d_out int64-viewable [n_reads] of 8-byte smi_umi_assignment records, d_skipped uint8 [n_reads]"""

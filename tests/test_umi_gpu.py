@@ -246,3 +246,28 @@ def test_assignumis_chunk_with_other_umi_lengths_equals_oracle(pkg, sor, gpu_ctx
             assert t["flags"] & libmod.UMI_CLUSTERED and t["center"] == mem[c] and t["u1"] == exp["ed"][j] and t["u2"] == exp["ed_second"][j], (reg, j)
             assert t["u8"].decode() == "".join(dec[int(ws[c][k + 1 + off])] for k in range(ul)), (reg, j)
     assert n_grouped > 0.95 * n and n_clustered > 300
+
+
+@pytest.mark.parametrize("sizes", [[2, 3, 1, 7, 64, 5, 130, 2, 2, 33], [400], [65, 3, 66, 71, 127, 128, 129, 64, 63, 191, 192, 193], [257, 2, 321]])
+def test_padded_matrices_hold_the_dense_ones(pkg, sor, gpu_ctx, sizes):
+    """smi_umi_dist_device_padded (the layout of the chunk worker's own matrices: rows of a group above 64 reads rounded up to whole 64-byte lines, groups
+    on line boundaries): cell [i][v] at mat_off[g] + i * row + v equals the dense matrix's and the oracle's; nothing is written into the padding"""
+    from sicelore_amd import lib as libmod
+
+    ws = _make_groups(len(sizes) + 7, sizes)
+    go, po, mo = gpu_ctx.umi_offsets(sizes, padded=True)
+    L = libmod.load_library()
+    for n in sizes:
+        row, nbytes = int(L.smi_umi_padded_row(n)), int(L.smi_umi_padded_bytes(n))
+        assert row == (n if n <= 64 else (n + 63) // 64 * 64) and nbytes == (row * n + 63) // 64 * 64
+    assert all(int(x) % 64 == 0 for x in mo)
+    d_out = torch.full((int(mo[-1]),), 255, dtype=torch.uint8, device="cuda")
+    gpu_ctx.umi_dist_device(torch.from_numpy(_pack(ws).view(np.int64)).cuda(), torch.from_numpy(go.view(np.int32)).cuda(), torch.from_numpy(po.view(np.int64)).cuda(),
+                            torch.from_numpy(mo.view(np.int64)).cuda(), len(sizes), int(po[-1]), d_out, padded=True)
+    torch.cuda.synchronize()
+    out = d_out.cpu().numpy()
+    for g, n in enumerate(sizes):
+        row = n if n <= 64 else (n + 63) // 64 * 64
+        blk = out[int(mo[g]):int(mo[g]) + row * n].reshape(n, row)
+        assert (blk[:, :n] == sor.umi_matrix(ws[go[g]:go[g + 1]])).all(), g
+        assert (blk[:, n:] == 255).all() and (out[int(mo[g]) + row * n:int(mo[g + 1])] == 255).all(), g

@@ -101,7 +101,9 @@ def leg_umi(pkg, synth, ctx, dev, wl, used, res):
     # ---- K-UMI ------------------------------------------------------------------------------------------------
     rng = np.random.default_rng(1)
     sizes = np.minimum(rng.zipf(1.6, 400_000), 400).astype(np.int64) + 1
-    go, po, mo = ctx.umi_offsets(sizes)
+    # SMI_UMI_DENSE=1: the dense n x n layout of smi_umi_dist_device; default: the padded rows the chunk worker gives its own matrices (round 6)
+    padded = not os.environ.get("SMI_UMI_DENSE")
+    go, po, mo = ctx.umi_offsets(sizes, padded=padded)
     n_reads = int(go[-1])
     w = torch.randint(0, 4, (n_reads, 14), device=dev)
     codes = torch.tensor([1, 2, 4, 8], device=dev)[w]
@@ -110,8 +112,9 @@ def leg_umi(pkg, synth, ctx, dev, wl, used, res):
     d_po = torch.from_numpy(po.view(np.int64)).to(dev)
     d_mo = torch.from_numpy(mo.view(np.int64)).to(dev)
     d_out = torch.zeros(int(mo[-1]), dtype=torch.uint8, device=dev)
-    dt = timed(lambda: ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out))
-    res["umi_dist"] = {"groups": int(len(sizes)), "reads": n_reads, "pairs": int(po[-1]), "ms": dt * 1e3,
+    dt = timed(lambda: ctx.umi_dist_device(packed, d_go, d_po, d_mo, len(sizes), int(po[-1]), d_out, padded=padded))
+    res["umi_dist"] = {"groups": int(len(sizes)), "reads": n_reads, "pairs": int(po[-1]), "ms": dt * 1e3, "layout": "padded rows" if padded else "dense",
+                       "matrix_bytes": int((sizes.astype(np.int64) ** 2).sum()), "buffer_bytes": int(mo[-1]),
                        "pairs_per_s": int(po[-1]) / dt, "levenshtein_per_s": 9 * int(po[-1]) / dt}
 
 

@@ -11,7 +11,7 @@ import os
 import sys
 
 KERNELS = {"k_scan": "smi::k_scan", "k_bc_match_ed1": "smi::k_bc_match_ed1", "k_bc_codes_ed1t": "smi::k_bc_codes_ed1t", "k_bc_pick_ed1t": "smi::k_bc_pick_ed1t", "k_bc_match_ed2": "smi::k_bc_match_ed2",
-           "k_pack_ends": "smi::k_pack_ends", "k_umi_dist": "smi::k_umi_dist(", "k_umi_dist_tiles": "smi::k_umi_dist_tiles", "k_hist_windows": "smi::k_hist_windows", "k_chimera": "smi::k_chimera", "k_pack_reads": "smi::k_pack_reads",
+           "k_pack_ends": "smi::k_pack_ends", "k_umi_dist": "smi::k_umi_dist<", "k_umi_dist_tiles": "smi::k_umi_dist_tiles<", "k_hist_windows": "smi::k_hist_windows", "k_chimera": "smi::k_chimera", "k_pack_reads": "smi::k_pack_reads",
            "k_chim_filter": "smi::k_chim_tso_filter", "k_chimera_B": "smi::k_chimera<27, 22, 1>", "k_chimera_C": "smi::k_chimera<27, 22, 2>",
            "k_write": "smi::k_write(", "k_write_name": "smi::k_write_name", "k_fq_lines": "smi::k_fq_lines",
            "k_deflate_blocks": "k_deflate_blocks", "k_deflate_gather": "k_deflate_gather", "k_umi_parse": "smi::k_umi_parse", "k_umi_cluster": "smi::k_umi_cluster",
