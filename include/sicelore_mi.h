@@ -625,6 +625,11 @@ typedef struct {
     const uint64_t *rank_keys;   /* used list of pass 1, sorted ascending, or NULL (-g mode): rk= field */
     const int32_t *rank_values;
     size_t n_ranks;
+    uint32_t device_output;      /* 1 (text worker, not with want_results): nothing is downloaded -- out->passed / out->failed are DEVICE pointers into the
+                                  * context's arena (the text K-WRITE wrote, or K-DEFLATE's members with compress), valid until the context's next call.
+                                  * With text that is in device memory already (read in place, no copy) the whole chunk is one call with four waits for
+                                  * the host: line count, record index, fragment count, output sizes */
+    uint32_t reserved;
 } smi_pass2_config;
 typedef struct {
     const uint8_t *passed, *failed; /* FASTQ text of the two output files; owned by the context, valid until its next call */

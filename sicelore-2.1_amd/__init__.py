@@ -14,9 +14,10 @@ from .lib import (  # noqa: F401
     SCAN_CONFIG_DTYPE,
     SCAN_RESULT_DTYPE,
     Context,
+    DeviceSpan,
     SmiError,
     library_path,
     load_library,
 )
 
-__all__ = ["codec", "Context", "SmiError", "load_library", "library_path", "BC_WINDOW_DTYPE", "BC_RESULT_DTYPE"]
+__all__ = ["codec", "Context", "DeviceSpan", "SmiError", "load_library", "library_path", "BC_WINDOW_DTYPE", "BC_RESULT_DTYPE"]

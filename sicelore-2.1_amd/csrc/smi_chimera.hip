@@ -2938,6 +2938,9 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                     SMI_HIP(hipEventRecord(ctx->side_fork, s));
                     SMI_HIP(hipStreamWaitEvent(sc, ctx->side_fork, 0));
                 }
+                // (advisor, round 5) an error return between here and the join must not leave chain C running on arena buffers the caller reuses or
+                // frees: every such exit drains the side stream first
+                SideStreamGuard side_guard{sc, use_side};
                 // ---- B: select -> align -> fold
                 if (!a1)
                     { hipLaunchKernelGGL(k_chimb_select2, dim3((unsigned)(((size_t)n_list + 15) / 16)), dim3(1024), 0, s, st, d_pstart, d_offsets, d_list, d_count, d_out, d_cand_w, d_hot_w, d_heads, d_cand, d_gcount,
@@ -2971,6 +2974,7 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
                     SMI_HIP(hipGetLastError());
                     SMI_HIP(hipEventRecord(ctx->side_join, sc));
                     SMI_HIP(hipStreamWaitEvent(s, ctx->side_join, 0));
+                    side_guard.armed = false;  // s is ordered behind the side stream from here on
                 }
                 { hipLaunchKernelGGL(k_chimc_rules, dim3(grid_lane), dim3(64), 0, s, d_pstart, d_offsets, d_list, d_count, P, d_slots, d_st, d_sres, d_rst, d_rn, d_ene, d_enm, d_out, d_dbg); SMI_CHIM_CHECK("k_chimc_rules"); }
                 // second chance for the reads over a cap of the lane-per-read kernels (one in 10^5): the first-generation kernels, one wave per read,

@@ -499,13 +499,13 @@ int smi_run_knobs_default(smi_run_knobs *k) {
 }
 
 namespace {
-const smi_run_knobs &shipped_knobs() {
+const smi_run_knobs *shipped_knobs() {  // (a pointer: this file's definitions have C linkage)
     static const smi_run_knobs k = [] {
         smi_run_knobs v;
         smi_run_knobs_default(&v);
         return v;
     }();
-    return k;
+    return &k;
 }
 
 // the limits of this build, knob by knob (the message names config.xml's element)
@@ -604,7 +604,7 @@ int smi_ctx_get_knobs(const smi_ctx *ctx, smi_run_knobs *knobs) {
         set_error("smi_ctx_get_knobs: null argument");
         return SMI_ERR_INVALID;
     }
-    *knobs = ctx->knobs_set ? ctx->knobs : shipped_knobs();
+    *knobs = ctx->knobs_set ? ctx->knobs : *shipped_knobs();
     return SMI_OK;
 }
 
@@ -615,7 +615,7 @@ int smi_scan_config_from_knobs(const smi_run_knobs *knobs, int pass, int five_pr
     }
     if (knobs)
         if (int rc = check_knobs(*knobs)) return rc;
-    const smi_run_knobs &k = knobs ? *knobs : shipped_knobs();
+    const smi_run_knobs &k = knobs ? *knobs : *shipped_knobs();
     std::memset(cfg, 0, sizeof(*cfg));
     cfg->min_read_length = k.min_read_length;
     cfg->polya_len = k.polya_len;
@@ -646,7 +646,7 @@ int smi_chimera_config_from_knobs(const smi_run_knobs *knobs, int five_prime, sm
     }
     if (knobs)
         if (int rc = check_knobs(*knobs)) return rc;
-    const smi_run_knobs &k = knobs ? *knobs : shipped_knobs();
+    const smi_run_knobs &k = knobs ? *knobs : *shipped_knobs();
     cfg->internal_pat_len = k.internal_pat_len;
     cfg->internal_pat_frac = k.internal_pat_frac;
     cfg->window_polya = k.window_polya;

@@ -229,37 +229,98 @@ int launch_count_lines(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, size
     return SMI_OK;
 }
 
+// scratch of the index: block counts (u32), block bases (u64), scalars, the newline flags (a u64 per thread of the sweep), hipcub temp
+struct FqScratch {
+    size_t n_blocks, off_base, off_scal, off_masks, off_cub, total;
+};
+static FqScratch fq_scratch(size_t n_bytes, bool two_sweeps, size_t cub_bytes) {
+    FqScratch L;
+    L.n_blocks = (n_bytes + kFqTile - 1) / kFqTile;
+    L.off_base = (L.n_blocks * 4 + 255) & ~(size_t)255;
+    L.off_scal = L.off_base + ((L.n_blocks * 8 + 255) & ~(size_t)255);
+    L.off_masks = L.off_scal + 256;
+    L.off_cub = L.off_masks + (two_sweeps ? 0 : L.n_blocks * kFqBlock * 8);
+    L.total = L.off_cub + cub_bytes;
+    return L;
+}
+__global__ void k_fq_sweep_lines(const uint8_t *__restrict__ text, size_t n_bytes, size_t n_blocks, const uint64_t *__restrict__ block_base,
+                                 const uint32_t *__restrict__ block_counts, uint64_t *__restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    *out = block_base[n_blocks - 1] + block_counts[n_blocks - 1] + (text[n_bytes - 1] == '\n' ? 0 : 1);
+}
+
+// The first half of the index on its own: the ONE sweep over the text (newline flags, block counts, block bases, all left in the context's
+// scratch) and the number of lines for the host, which sizes the record buffers by it.  launch_fastq_index on the same text right afterwards
+// continues from the flags instead of reading the text again (the workers used to count the lines with a sweep of their own: a second
+// full read of the chunk).
+int launch_fastq_sweep(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, size_t *n_lines, hipStream_t s) {
+    *n_lines = 0;
+    ctx->fq_swept_text = nullptr;
+    if (!n_bytes) return SMI_OK;
+    if (getenv("SMI_FQ_TWO_SWEEPS") != nullptr) return launch_count_lines(ctx, d_text, n_bytes, n_lines, s);
+    const size_t n_blocks = (n_bytes + kFqTile - 1) / kFqTile;
+    // the record count is not known yet: hipcub's scratch for as many records as a text of this size can hold at most (8 bytes each)
+    const size_t max_rec = std::min<size_t>(n_bytes / 8 + 2, ((size_t)1 << 31) - 4);
+    size_t cub_a = 0, cub_b = 0;
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_a, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)n_blocks, s));
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)max_rec + 1, s));
+    const FqScratch L = fq_scratch(n_bytes, false, std::max(cub_a, cub_b));
+    if (int rc = ensure_scan_tmp(ctx, L.total)) return rc;
+    uint8_t *tmp = (uint8_t *)ctx->scan_tmp;
+    uint32_t *counts = (uint32_t *)tmp;
+    uint64_t *bases = (uint64_t *)(tmp + L.off_base);
+    uint64_t *d_lines = (uint64_t *)(tmp + L.off_scal + 128);
+    uint64_t *masks = (uint64_t *)(tmp + L.off_masks);
+    hipLaunchKernelGGL(k_fq_count_masks, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts, masks);
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + L.off_cub, cub_a, counts, bases, (int)n_blocks, s));
+    hipLaunchKernelGGL(k_fq_sweep_lines, dim3(1), dim3(1), 0, s, d_text, n_bytes, n_blocks, (const uint64_t *)bases, (const uint32_t *)counts, d_lines);
+    SMI_HIP(hipGetLastError());
+    uint64_t h = 0;
+    uint64_t *pw = static_cast<uint64_t *>(pin_words(ctx));
+    SMI_HIP(hipMemcpyAsync(pw ? pw : &h, d_lines, 8, hipMemcpyDeviceToHost, s));
+    SMI_HIP(hipStreamSynchronize(s));
+    if (pw) h = *pw;
+    *n_lines = (size_t)h;
+    ctx->fq_swept_text = d_text;
+    ctx->fq_swept_bytes = n_bytes;
+    return SMI_OK;
+}
+
 int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
                        uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
                        uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records, uint32_t *errors,
-                       hipStream_t s) {
+                       hipStream_t s, uint64_t *total_bases) {
     *n_records = 0;
     *errors = 0;
+    if (total_bases) *total_bases = 0;
     if (!n_bytes) return SMI_OK;
     if (cap_records == 0) {
         set_error("smi_fastq_index_device: record buffers too small (need n_records + 1 entries)");
         return SMI_ERR_INVALID;
     }
-    const size_t n_blocks = (n_bytes + kFqTile - 1) / kFqTile;
-    // scratch: block counts (u32), block bases (u64), scalars, the newline flags (a u64 per thread of the sweep), hipcub temp
     size_t cub_a = 0, cub_b = 0;
-    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_a, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)n_blocks, s));
+    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_a, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)((n_bytes + kFqTile - 1) / kFqTile), s));
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cub_b, (uint32_t *)nullptr, (uint64_t *)nullptr, (int)cap_records + 1, s));
     const bool two_sweeps = getenv("SMI_FQ_TWO_SWEEPS") != nullptr;  // cross-check switch (read per call): the line starts from a second sweep over the text
-    const size_t off_counts = 0, off_base = (n_blocks * 4 + 255) & ~(size_t)255, off_scal = off_base + ((n_blocks * 8 + 255) & ~(size_t)255),
-                 off_masks = off_scal + 256, off_cub = off_masks + (two_sweeps ? 0 : n_blocks * kFqBlock * 8), total = off_cub + std::max(cub_a, cub_b);
-    if (int rc = ensure_scan_tmp(ctx, total)) return rc;
+    const FqScratch L = fq_scratch(n_bytes, two_sweeps, std::max(cub_a, cub_b));
+    const size_t n_blocks = L.n_blocks, off_base = L.off_base, off_scal = L.off_scal, off_masks = L.off_masks, off_cub = L.off_cub;
+    // launch_fastq_sweep ran over this very text just before: its flags, counts and bases are in the scratch (unless the scratch has to grow now)
+    const bool swept = !two_sweeps && ctx->fq_swept_text == d_text && ctx->fq_swept_bytes == n_bytes && L.total <= ctx->scan_tmp_bytes;
+    ctx->fq_swept_text = nullptr;
+    if (int rc = ensure_scan_tmp(ctx, L.total)) return rc;
     uint8_t *tmp = (uint8_t *)ctx->scan_tmp;
-    uint32_t *counts = (uint32_t *)(tmp + off_counts);
+    uint32_t *counts = (uint32_t *)tmp;
     uint64_t *bases = (uint64_t *)(tmp + off_base);
     FqTotals *d_tot = (FqTotals *)(tmp + off_scal);
     uint64_t *masks = (uint64_t *)(tmp + off_masks);
     SMI_HIP(hipMemsetAsync(d_tot, 0, sizeof(FqTotals), s));
-    if (two_sweeps)
-        hipLaunchKernelGGL(k_fq_count, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts);
-    else
-        hipLaunchKernelGGL(k_fq_count_masks, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts, masks);
-    SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_a, counts, bases, (int)n_blocks, s));
+    if (!swept) {
+        if (two_sweeps)
+            hipLaunchKernelGGL(k_fq_count, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts);
+        else
+            hipLaunchKernelGGL(k_fq_count_masks, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, counts, masks);
+        SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_a, counts, bases, (int)n_blocks, s));
+    }
     if (two_sweeps)
         hipLaunchKernelGGL(k_fq_lines, dim3((unsigned)n_blocks), dim3(kFqBlock), 0, s, d_text, n_bytes, bases, d_line_start, cap_lines);
     else
@@ -273,10 +334,20 @@ int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp + off_cub, cub_b, d_seq_len, d_offsets, (int)cap_records, s));
     FqTotals h;
     {
-        FqTotals *pw = static_cast<FqTotals *>(pin_words(ctx));
-        SMI_HIP(hipMemcpyAsync(pw ? pw : &h, d_tot, sizeof h, hipMemcpyDeviceToHost, s));
+        // the sum of all sequence lengths rides on the same wait: lengths behind the last record are 0, so the last offset of the buffer is
+        // the total whatever the record count turns out to be (a text that fills the buffer to its last entry is refused below)
+        static_assert(sizeof(FqTotals) % 8 == 0 && sizeof(FqTotals) + 8 <= 256, "the total sits behind the scalars in the pinned words");
+        uint8_t *pw = static_cast<uint8_t *>(pin_words(ctx));
+        uint64_t tot = 0;
+        SMI_HIP(hipMemcpyAsync(pw ? (void *)pw : (void *)&h, d_tot, sizeof h, hipMemcpyDeviceToHost, s));
+        if (total_bases)
+            SMI_HIP(hipMemcpyAsync(pw ? (void *)(pw + sizeof h) : (void *)&tot, d_offsets + (cap_records - 1), 8, hipMemcpyDeviceToHost, s));
         SMI_HIP(hipStreamSynchronize(s));
-        if (pw) h = *pw;
+        if (pw) {
+            std::memcpy(&h, pw, sizeof h);
+            std::memcpy(&tot, pw + sizeof h, 8);
+        }
+        if (total_bases) *total_bases = tot;
     }
     if (h.overflow & 1u) {
         set_error("smi_fastq_index_device: line buffer too small");

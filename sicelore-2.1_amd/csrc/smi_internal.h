@@ -163,6 +163,8 @@ struct smi_ctx {
     size_t chim_work_bytes = 0;
     void *umi_own = nullptr;       // ClusterOne_MyClustering on the device: index / count / sum scratch of one large group (grow-only)
     size_t umi_own_bytes = 0;
+    const uint8_t *fq_swept_text = nullptr;  // launch_fastq_sweep's text while its flags are valid in scan_tmp (consumed by the next launch_fastq_index)
+    size_t fq_swept_bytes = 0;
     void *pin_words = nullptr;     // 4 KiB of page-locked host memory for read-backs of a few words (pin_words() in smi_ctx.hip)
     void *umi_plan = nullptr;      // K-UMI: per group its pairs in the flat kernel / tiles in the tiled one, and their prefix sums (grow-only)
     size_t umi_plan_bytes = 0;
@@ -187,6 +189,15 @@ struct smi_ctx {
 };
 
 namespace smi {
+// work forked onto a context's side stream: unless disarmed (the join is in place), leaving the scope waits for the side stream -- an error return between a
+// fork and its join does not leave kernels running on buffers the caller is about to reuse
+struct SideStreamGuard {
+    hipStream_t side;
+    bool armed;
+    ~SideStreamGuard() {
+        if (armed) (void)hipStreamSynchronize(side);
+    }
+};
 // the configurations a chunk worker of `ctx` runs with: its knobs (smi_ctx_set_knobs), then -p / -f / -w (smi_ctx_set_polya); the splitter's
 // strings point into the context (smi_ctx.hip)
 int worker_scan_config(const smi_ctx *ctx, int pass, int five_prime, int dont_search_polya, smi_scan_config *sc);
@@ -234,10 +245,11 @@ int launch_chimera(smi_ctx *ctx, const uint32_t *d_planes, const uint64_t *d_off
 int launch_split_offsets(smi_ctx *ctx, const smi_chimera_result *d_chim, const uint64_t *d_offsets, size_t n,
                          uint32_t *d_scratch, uint64_t *d_total, uint64_t *d_frag_offsets, uint32_t *d_frag_src,
                          hipStream_t s);
+int launch_fastq_sweep(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, size_t *n_lines, hipStream_t s);  // first half of the index + line count
 int launch_fastq_index(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, uint64_t *d_line_start, size_t cap_lines,
                        uint64_t *d_name_start, uint32_t *d_name_len, uint64_t *d_seq_start, uint32_t *d_seq_len,
                        uint64_t *d_qual_start, uint64_t *d_offsets, size_t cap_records, size_t *n_records, uint32_t *errors,
-                       hipStream_t s);
+                       hipStream_t s, uint64_t *total_bases = nullptr);  // total_bases: d_offsets[n_records], read back on the same wait
 int launch_fastq_gather(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_start, const uint64_t *d_offsets, size_t n,
                         uint8_t *d_out, hipStream_t s);
 // read planes (K-PACKR / smi_pack_reads_host): [4][stride] u32; read r starts at word plane_start(offsets[r], r) of each plane and owns

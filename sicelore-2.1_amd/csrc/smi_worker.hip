@@ -71,6 +71,13 @@ __global__ void k_drop_discarded(smi_bc_result *__restrict__ bc, const uint32_t 
     if (chim[frag_src[i] >> 2].flags & SMI_CHIM_MULTI) bc[i].found = 0;
 }
 
+// any read the splitter refused (SMI_CHIM_RANGE / SMI_CHIM_OVERFLOW)?  one word for the host instead of the chunk's results
+__global__ void k_chim_refused(const smi_chimera_result *__restrict__ chim, size_t n, uint64_t *__restrict__ flag) {
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    const bool bad = i < n && (chim[i].flags & (SMI_CHIM_RANGE | SMI_CHIM_OVERFLOW));
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr((unsigned long long *)flag, 1ull);
+}
+
 struct Arena {
     smi_ctx *ctx;
     size_t used = 0;
@@ -99,10 +106,21 @@ int ensure_arena(smi_ctx *ctx, size_t bytes) {
 
 // The chunk's text goes to the front of the arena first and its lines are counted THERE: the buffers behind it are sized by the record
 // count, and counting on the host (memchr over ~1.2 GB) took longer than the upload.  *d_text stays valid when the arena grows afterwards.
+// text that lies in device memory already (K-INFLATE's output, a caller's device buffer) is read where it is
+bool is_device_text(const uint8_t *text) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, text) != hipSuccess) {
+        (void)hipGetLastError();  // an ordinary host pointer: not an error of this call
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice;
+}
 int upload_and_count(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, hipStream_t s, size_t *n_lines) {
+    // the count is the first half of the record index (its one sweep over the text): launch_fastq_index continues from what it left
+    if (is_device_text(text)) return launch_fastq_sweep(ctx, text, n_bytes, n_lines, s);
     if (int rc = ensure_arena(ctx, pad(n_bytes) + 4096)) return rc;
-    SMI_HIP(hipMemcpyAsync(ctx->arena, text, n_bytes, hipMemcpyDefault, s));  // host text, or text that is on the device already (K-INFLATE)
-    return launch_count_lines(ctx, static_cast<const uint8_t *>(ctx->arena), n_bytes, n_lines, s);
+    SMI_HIP(hipMemcpyAsync(ctx->arena, text, n_bytes, hipMemcpyDefault, s));
+    return launch_fastq_sweep(ctx, static_cast<const uint8_t *>(ctx->arena), n_bytes, n_lines, s);
 }
 // grow the arena to `bytes`, keeping its first keep_bytes (the uploaded text)
 int grow_arena_keep(smi_ctx *ctx, size_t bytes, size_t keep_bytes, hipStream_t s) {
@@ -110,8 +128,9 @@ int grow_arena_keep(smi_ctx *ctx, size_t bytes, size_t keep_bytes, hipStream_t s
     const size_t want = bytes + bytes / 4;
     void *fresh = nullptr;
     SMI_HIP(hipMalloc(&fresh, want));
-    SMI_HIP(hipMemcpyAsync(fresh, ctx->arena, keep_bytes, hipMemcpyDeviceToDevice, s));
+    if (keep_bytes) SMI_HIP(hipMemcpyAsync(fresh, ctx->arena, keep_bytes, hipMemcpyDeviceToDevice, s));
     SMI_HIP(hipStreamSynchronize(s));
+    if (keep_bytes && ctx->fq_swept_text == ctx->arena) ctx->fq_swept_text = static_cast<const uint8_t *>(fresh);  // the swept text moved with the arena
     SMI_HIP(hipFree(ctx->arena));
     ctx->arena = fresh;
     ctx->arena_bytes = want;
@@ -151,8 +170,17 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     hipStream_t s = ctx->stream;
     const bool five = cfg->five_prime != 0;
     const bool split = cfg->split_chimeras && !(five && cfg->dont_search_polya);  // Parser.java:L176
+    const bool timing = std::getenv("SMI_WK_TIMING") != nullptr;  // the phases of this call (host clock, one line on stderr)
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_ph[6] = {0, 0, 0, 0, 0, 0};
+    auto phase = [&](int k) {
+        const auto now = std::chrono::steady_clock::now();
+        t_ph[k] += std::chrono::duration<double, std::milli>(now - t_prev).count();
+        t_prev = now;
+    };
     size_t n_lines = 0;
     if (int rc = upload_and_count(ctx, text, n_bytes, s, &n_lines)) return rc;
+    phase(0);
     const size_t cap = n_lines / 4 + 2;  // records
     // worst-case sizes before anything is known about the chunk: bases + qualities <= text, fragments <= 3 per record
     const size_t m_cap = split ? 3 * cap : cap;
@@ -165,16 +193,19 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
                   pad(m_cap * (size_t)SMI_END_BASES) + pad(m_cap * sizeof(smi_scan_result)) + pad(m_cap * sizeof(smi_bc_window)) +
                   pad(m_cap * sizeof(smi_bc_result)) + pad(m_cap * 4) + pad(cfg->n_ranks * 8) + pad(cfg->n_ranks * 4) +
                   2 * pad(out_cap) + pad((m_cap + 1) * 8) + pad(m_cap) + 4096;
-    SMI_RC(grow_arena_keep(ctx, need, n_bytes, s));
+    const bool in_place = is_device_text(text);
+    SMI_RC(grow_arena_keep(ctx, need, in_place ? 0 : n_bytes, s));
     Arena A(ctx);
-    uint8_t *d_text = A.take<uint8_t>(n_bytes);  // already there
+    const uint8_t *d_text = in_place ? text : A.take<uint8_t>(n_bytes);  // already there
     uint64_t *d_line = A.take<uint64_t>(4 * cap + 8);
     uint64_t *d_ns = A.take<uint64_t>(cap), *d_ss = A.take<uint64_t>(cap), *d_qs = A.take<uint64_t>(cap);
     uint64_t *d_offs = A.take<uint64_t>(cap + 1);
     uint32_t *d_nl = A.take<uint32_t>(cap), *d_sl = A.take<uint32_t>(cap);
     size_t n = 0;
     uint32_t fq_err = 0;
-    SMI_RC(smi_fastq_index_device(ctx, d_text, n_bytes, d_line, 4 * cap + 8, d_ns, d_nl, d_ss, d_sl, d_qs, d_offs, cap, &n, &fq_err, s));
+    uint64_t total = 0;  // all bases of the chunk: comes back on the index's own wait
+    SMI_RC(launch_fastq_index(ctx, d_text, n_bytes, d_line, 4 * cap + 8, d_ns, d_nl, d_ss, d_sl, d_qs, d_offs, cap, &n, &fq_err, s, &total));
+    phase(1);
     out->n_records_in = n;
     out->fastq_errors = fq_err;
     if (fq_err) {
@@ -182,9 +213,6 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         return SMI_ERR_INVALID;
     }
     if (n == 0) return SMI_OK;
-    uint64_t total = 0;
-    SMI_HIP(hipMemcpyAsync(&total, d_offs + n, 8, hipMemcpyDeviceToHost, s));
-    SMI_HIP(hipStreamSynchronize(s));
     // bases and qualities stay where the text has them: every consumer below takes per-record text positions (no gathered copies)
     uint64_t *d_bstart = A.take<uint64_t>(m_cap), *d_qstart = A.take<uint64_t>(m_cap);
     // ---- chimera splitter ----------------------------------------------------------------------------------------------------
@@ -197,7 +225,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         uint32_t *d_planes = A.take<uint32_t>(planes_words);
         d_chim = A.take<smi_chimera_result>(cap);
         uint32_t *d_scr = A.take<uint32_t>((cap + 1023) / 1024 + 1);
-        uint64_t *d_nfrag = A.take<uint64_t>(1);
+        uint64_t *d_nfrag = A.take<uint64_t>(2);  // [0] fragments, [1] != 0: a read the splitter refused
         uint64_t *d_foffs = A.take<uint64_t>(3 * cap + 1);
         d_fsrc = A.take<uint32_t>(3 * cap);
         smi_chimera_config cc;
@@ -205,19 +233,26 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         SMI_RC(smi_pack_reads_text_device(ctx, d_text, d_ss, d_offs, n, total, d_planes, s));
         SMI_RC(smi_chimera_device(ctx, d_planes, d_offs, n, total, &cc, d_chim, s));
         SMI_RC(smi_split_offsets_device(ctx, d_chim, d_offs, n, d_scr, d_nfrag, d_foffs, d_fsrc, s));
-        uint64_t nf = 0;
-        h_chim.resize(n);
-        SMI_HIP(hipMemcpyAsync(&nf, d_nfrag, 8, hipMemcpyDeviceToHost, s));
-        SMI_HIP(hipMemcpyAsync(h_chim.data(), d_chim, n * sizeof(smi_chimera_result), hipMemcpyDeviceToHost, s));
+        SMI_HIP(hipMemsetAsync(d_nfrag + 1, 0, 8, s));
+        hipLaunchKernelGGL(k_chim_refused, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_chim, n, d_nfrag + 1);
+        SMI_HIP(hipGetLastError());
+        uint64_t nf[2] = {0, 0};
+        uint64_t *pw = static_cast<uint64_t *>(pin_words(ctx));
+        SMI_HIP(hipMemcpyAsync(pw ? pw : nf, d_nfrag, 16, hipMemcpyDeviceToHost, s));
+        if (cfg->want_results) {  // the statistics count the split decisions; nothing else on the host reads them
+            h_chim.resize(n);
+            SMI_HIP(hipMemcpyAsync(h_chim.data(), d_chim, n * sizeof(smi_chimera_result), hipMemcpyDeviceToHost, s));
+        }
         SMI_HIP(hipStreamSynchronize(s));
-        for (const auto &c : h_chim)
-            if (c.flags & (SMI_CHIM_RANGE | SMI_CHIM_OVERFLOW)) {
-                set_error("smi_scanfastq_pass2_chunk: a read outside what the splitter supports (SMI_CHIM_RANGE: longer than the plane offsets can address)");
-                return SMI_ERR_INVALID;
-            }
-        m = (size_t)nf;
+        if (pw) std::memcpy(nf, pw, 16);
+        if (nf[1]) {
+            set_error("smi_scanfastq_pass2_chunk: a read outside what the splitter supports (SMI_CHIM_RANGE: longer than the plane offsets can address)");
+            return SMI_ERR_INVALID;
+        }
+        m = (size_t)nf[0];
         d_rec_offs = d_foffs;
     }
+    phase(2);
     out->n_records_out = m;
     // ---- scan + barcode -------------------------------------------------------------------------------------------------------
     uint32_t *d_ends = A.take<uint32_t>((size_t)SMI_ENDS_ROWS * 2 * m_cap);
@@ -261,6 +296,7 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
     SMI_RC(smi_fastq_write_text_device(ctx, d_text, d_line, d_bstart, d_qstart, d_rec_offs, split ? d_fsrc : nullptr,
                                        split ? d_chim : nullptr, d_scan, d_bc, d_rank, m, cfg->first_read_id, &wc, d_passed, out_cap, d_failed,
                                        out_cap, d_roff, d_isp, totals, &werr, s));
+    phase(3);
     out->passed_text_bytes = totals[0];
     out->failed_text_bytes = totals[1];
     const uint8_t *d_src[2] = {d_passed, d_failed};
@@ -281,6 +317,21 @@ extern "C" int smi_scanfastq_pass2_chunk(smi_ctx *ctx, const uint8_t *text, size
         d_src[1] = d_z[1];
         down[0] = zt[0];
         down[1] = zt[2];
+    }
+    if (cfg->device_output) {
+        // the caller reads the two texts (or gzip members) where K-WRITE / K-DEFLATE left them; the totals' wait above was the call's last
+        if (cfg->want_results) {
+            set_error("smi_scanfastq_pass2_chunk: device_output and want_results are two different callers (the per-record results are a host structure)");
+            return SMI_ERR_INVALID;
+        }
+        out->passed = d_src[0];
+        out->failed = d_src[1];
+        out->passed_bytes = down[0];
+        out->failed_bytes = down[1];
+        out->n_passed = totals[2];
+        if (timing)
+            std::fprintf(stderr, "pass2_chunk: sweep+count %.3f  index %.3f  split %.3f  ends..write %.3f ms (%zu records)\n", t_ph[0], t_ph[1], t_ph[2], t_ph[3], n);
+        return SMI_OK;
     }
     for (int k = 0; k < 2; k++)  // pinned, grow-only: the download runs at link speed and nothing is zero-filled
         if (ctx->host_out_bytes[k] < down[k]) {
@@ -373,16 +424,17 @@ int pass1_chunk_core(smi_ctx *ctx, const uint8_t *text, size_t n_bytes, int five
     const size_t need = pad(n_bytes) + pad((4 * cap + 8) * 8) + 4 * pad(cap * 8) + pad((cap + 1) * 8) + 2 * pad(cap * 4) +
                         2 * pad(n_bytes) + pad((size_t)SMI_ENDS_ROWS * 2 * cap * 4) + 2 * pad(cap * 4) + pad(cap * (size_t)SMI_END_BASES) +
                         pad(cap * sizeof(smi_scan_result)) + pad(cap * sizeof(smi_bc_window)) + 4096;
-    SMI_RC(grow_arena_keep(ctx, need, n_bytes, s));
+    const bool in_place = is_device_text(text);
+    SMI_RC(grow_arena_keep(ctx, need, in_place ? 0 : n_bytes, s));
     Arena A(ctx);
-    uint8_t *d_text = A.take<uint8_t>(n_bytes);  // already there
+    const uint8_t *d_text = in_place ? text : A.take<uint8_t>(n_bytes);  // already there
     uint64_t *d_line = A.take<uint64_t>(4 * cap + 8);
     uint64_t *d_ns = A.take<uint64_t>(cap), *d_ss = A.take<uint64_t>(cap), *d_qs = A.take<uint64_t>(cap);
     uint64_t *d_offs = A.take<uint64_t>(cap + 1);
     uint32_t *d_nl = A.take<uint32_t>(cap), *d_sl = A.take<uint32_t>(cap);
     size_t n = 0;
     uint32_t fq_err = 0;
-    SMI_RC(smi_fastq_index_device(ctx, d_text, n_bytes, d_line, 4 * cap + 8, d_ns, d_nl, d_ss, d_sl, d_qs, d_offs, cap, &n, &fq_err, s));
+    SMI_RC(launch_fastq_index(ctx, d_text, n_bytes, d_line, 4 * cap + 8, d_ns, d_nl, d_ss, d_sl, d_qs, d_offs, cap, &n, &fq_err, s));
     *n_records = n;
     if (fastq_errors) *fastq_errors = fq_err;
     if (fq_err) {
@@ -607,8 +659,8 @@ extern "C" int smi_scanfastq_pass2_chunk_packed(smi_ctx *ctx, const uint8_t *tex
         return SMI_ERR_INVALID;
     }
     std::memset(out, 0, sizeof *out);
-    if (cfg->compress) {
-        set_error("smi_scanfastq_pass2_chunk_packed: compress is an option of the text worker (the packed worker's records are written by the host)");
+    if (cfg->compress || cfg->device_output) {
+        set_error("smi_scanfastq_pass2_chunk_packed: compress and device_output are options of the text worker (the packed worker's records are written by the host)");
         return SMI_ERR_INVALID;
     }
     if (n_bytes == 0) return SMI_OK;

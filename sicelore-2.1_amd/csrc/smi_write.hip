@@ -584,6 +584,7 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
     }
     SMI_HIP(hipEventRecord(ctx->side_fork, s));
     SMI_HIP(hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    SideStreamGuard side_guard{ctx->side_stream, true};  // (an error return before the join drains the side stream: smi_internal.h)
     hipLaunchKernelGGL(k_write_name, dim3((unsigned)((n_out + kNameBlock - 1) / kNameBlock)), dim3(kNameBlock), 0, ctx->side_stream, A, plan, offp, offf, ordp, sfx, d_passed, cap_passed, d_failed,
                        cap_failed);
     SMI_HIP(hipGetLastError());
@@ -592,6 +593,7 @@ static int write_core(smi_ctx *ctx, const uint8_t *d_text, const uint64_t *d_lin
                        d_failed, cap_failed, d_rec_off, d_err);
     SMI_HIP(hipGetLastError());
     SMI_HIP(hipStreamWaitEvent(s, ctx->side_join, 0));
+    side_guard.armed = false;
     uint64_t h_stack[4];
     uint64_t *h = static_cast<uint64_t *>(pin_words(ctx));  // (four words: page-locked, or the stack if there is none)
     if (!h) h = h_stack;

@@ -884,12 +884,37 @@ def fastq_write_host(text, recs, offsets, scan, bc, frag_offsets=None, frag_src=
     return out_p[:totals[0]].tobytes(), out_f[:totals[1]].tobytes(), int(totals[2])
 
 
+class DeviceSpan:
+    """bytes in a context's device memory that the library still owns (smi_pass2_config.device_output): address and size; tensor() wraps them as a
+    uint8 torch view without copying (building the view costs more than the pointer, so it is made on request)"""
+    __slots__ = ("ptr", "nbytes", "device")
+
+    def __init__(self, ptr, nbytes, device):
+        self.ptr, self.nbytes, self.device = ptr, nbytes, device
+
+    def __len__(self):
+        return self.nbytes
+
+    @property
+    def __cuda_array_interface__(self):
+        return dict(shape=(self.nbytes,), typestr="|u1", data=(self.ptr, False), version=2)
+
+    def tensor(self):
+        import torch
+
+        dev = torch.device("cuda", self.device)
+        return torch.as_tensor(self, device=dev) if self.nbytes else torch.empty(0, dtype=torch.uint8, device=dev)
+
+    def tobytes(self):
+        return bytes(self.tensor().cpu().numpy())
+
+
 class Pass2Config(ctypes.Structure):
     """smi_pass2_config"""
     _fields_ = [("max_ed", ctypes.c_int32), ("five_prime", ctypes.c_int32), ("dont_search_polya", ctypes.c_int32),
                 ("split_chimeras", ctypes.c_int32), ("trim_fastq", ctypes.c_int32), ("want_results", ctypes.c_int32),
                 ("first_read_id", ctypes.c_uint32), ("compress", ctypes.c_uint32), ("rank_keys", ctypes.c_void_p),
-                ("rank_values", ctypes.c_void_p), ("n_ranks", ctypes.c_size_t)]
+                ("rank_values", ctypes.c_void_p), ("n_ranks", ctypes.c_size_t), ("device_output", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
 
 
 class Pass2Output(ctypes.Structure):
@@ -1289,17 +1314,21 @@ class Context:
 
     # ---- one native call per chunk (smi_worker.hip) ---------------------------------------------------------
     def scanfastq_pass2_chunk(self, text, max_ed=1, five_prime=False, dont_search_polya=False, split_chimeras=True, trim_fastq=False,
-                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True, packed=False, n_threads=4, compress=False):
+                              first_read_id=1, rank_keys=None, rank_values=None, want_results=False, copy=True, packed=False, n_threads=4, compress=False,
+                              device_output=False):
         """host FASTQ bytes (or a numpy uint8 array, e.g. PinnedBuffer.array) -> (passed, failed, info dict); everything in
         between on the device.  copy=False returns numpy views of the context's pinned output buffers (valid until its next call).
         packed=True: smi_scanfastq_pass2_chunk_packed -- the host indexes / packs / writes on n_threads threads, the link carries
         bit-planes up and decisions down; same bytes out.  compress=True (text worker): `passed` / `failed` are one gzip member each (K-DEFLATE);
-        info["passed_text_bytes"] / ["failed_text_bytes"] give the sizes of the text"""
+        info["passed_text_bytes"] / ["failed_text_bytes"] give the sizes of the text.  device_output=True (text worker): nothing is downloaded --
+        passed / failed stay on the DEVICE (copy=True: uint8 tensors of their own; copy=False: DeviceSpan = address + size inside the context's
+        arena, valid until its next call, .tensor() for a view); with a device tensor as `text` the chunk never touches the host"""
         cfg = Pass2Config()
         self._check(self._lib.smi_pass2_default_config(ctypes.byref(cfg)))
         cfg.max_ed, cfg.five_prime, cfg.dont_search_polya = int(max_ed), int(five_prime), int(dont_search_polya)
         cfg.split_chimeras, cfg.trim_fastq, cfg.want_results, cfg.first_read_id = int(split_chimeras), int(trim_fastq), int(want_results), int(first_read_id)
         cfg.compress = 1 if compress else 0
+        cfg.device_output = 1 if device_output else 0
         keep = []
         if rank_keys is not None and len(rank_keys):
             k = np.ascontiguousarray(rank_keys, dtype=np.uint64)
@@ -1318,7 +1347,9 @@ class Context:
                                                                        ctypes.byref(out)))
             else:
                 self._check(self._lib.smi_scanfastq_pass2_chunk(self._h, buf.ctypes.data, buf.size, ctypes.byref(cfg), ctypes.byref(out)))
-        if copy:
+        if device_output:
+            passed, failed = (self._device_bytes(out.passed, out.passed_bytes, copy), self._device_bytes(out.failed, out.failed_bytes, copy))
+        elif copy:
             passed = ctypes.string_at(out.passed, out.passed_bytes) if out.passed_bytes else b""
             failed = ctypes.string_at(out.failed, out.failed_bytes) if out.failed_bytes else b""
         else:
@@ -1332,6 +1363,18 @@ class Context:
             info["scan"] = np.frombuffer(ctypes.string_at(out.scan, out.n_records_out * SCAN_RESULT_DTYPE.itemsize), dtype=SCAN_RESULT_DTYPE)
             info["bc"] = np.frombuffer(ctypes.string_at(out.bc, out.n_records_out * BC_RESULT_DTYPE.itemsize), dtype=BC_RESULT_DTYPE)
         return passed, failed, info
+
+    def _device_bytes(self, ptr, n, copy):
+        """n bytes of the context's device memory: a DeviceSpan (address + size, valid until the context's next call; .tensor() is a torch view) or,
+        with copy, a uint8 tensor of their own"""
+        span = DeviceSpan(int(ptr or 0), int(n), self.device)
+        if not copy:
+            return span
+        import torch
+
+        c = span.tensor().clone()   # the worker's stream had drained when it returned; the copy is on torch's stream and must be over before the arena is reused
+        torch.cuda.current_stream(c.device).synchronize()
+        return c
 
     def scanfastq_pass1_chunk(self, text, d_hist, five_prime=False, dont_search_polya=False, packed=False, n_threads=4):
         """adds the chunk's whitelist hits to d_hist (int32 device tensor, one counter per loaded key) -> n records"""

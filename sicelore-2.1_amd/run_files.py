@@ -575,7 +575,8 @@ def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, 
                 f.write(_lib.barcode_list_tsv(hk, hc, record_count, m_ed, min_count_fold, cells_fold_below_max, no_whitelist=nowl))
         if nowl and k.size and int(k.max()) >> 32:
             # a 5' barcode that was cut with an N in it is a long with its upper half set (UsedCellBCListGenerator.java:L219; NOTES R5.10): it can
-            # only ever equal a window with the same N, which the matcher does not probe -- such an entry stays in the TSVs and leaves the search set
+            # only ever equal a window with the same N, which the matcher does not probe -- such an entry stays in BarcodeList.tsv (written above), leaves the search
+            # set, and can never be assigned, so BarcodesAssigned.tsv (rows with counts only) has no row for it either way
             keep = (k >> np.uint64(32)) == 0
             k, c, r = k[keep], c[keep], r[keep]
         order = np.argsort(k)
@@ -652,6 +653,10 @@ def _run(ctx, in_dir, out_dir, max_ed=1, n_workers=16, reads_per_chunk=100_000, 
         passed, failed, info = lane.scanfastq_pass2_chunk(text_j, max_ed=max_ed, five_prime=five_prime, dont_search_polya=dont_search_polya, trim_fastq=trim_fastq,
                                                           first_read_id=int(first_id[j]), rank_keys=None if given else rk_keys, rank_values=rk_vals, want_results=True, copy=False,
                                                           packed=not on_device, n_threads=host_threads_per_call, compress=on_device)
+        # (advisor, round 5) read ids are dealt from the record counts of the chunks in front: with -g those come from a line count, here from K-FQ's
+        # index -- a text on which the two disagree (stray blank lines) stops the run instead of shifting every later id
+        if int(info["n_records_in"]) != int(n_rec[j]):
+            raise _lib.SmiError(f"{files[fi]}, chunk {ci}: {int(info['n_records_in'])} FASTQ records indexed, {int(n_rec[j])} counted when the file was read")
         bc = info["bc"] if info["n_records_out"] else np.zeros(0, dtype=_lib.BC_RESULT_DTYPE)
         ok = bc["found"] == 1
         if ok.any():

@@ -226,6 +226,55 @@ def test_native_chunk_workers_equal_the_chained_entry_points(pkg, synth, sor, gp
     assert n1 == n2 == len(seqs) and bool((h1 == h2).all()) and int(h1.sum()) > 30
 
 
+def test_chunk_worker_device_text_in_place_and_device_output(pkg, synth, sor, gpu_ctx):
+    """the chunk as ONE call that never touches the host: a uint8 device tensor in (read where it lies, no copy into the arena), `passed` /
+    `failed` left on the device (device_output) == the host-text call; also with --compress (the members stay on the device), for a text
+    without a final newline, and on a context whose arena is reused by chunks of different sizes"""
+    import gzip
+
+    import torch
+
+    used, reads = _reads(synth, 260, 4411)
+    chim = synth.make_chimeras(reads, 300, seed=4412)
+    seqs, quals = [c[0] for c in chim], [c[1] for c in chim]
+    keys = np.sort(used.numpy().astype(np.uint64))
+    ranks = (np.arange(keys.size) % 50 + 1).astype(np.int32)
+    gpu_ctx.set_barcode_set(keys, mode=0)
+    for text in (_fastq(seqs, quals), _fastq(seqs[:41], quals[:41])[:-1], _fastq(seqs, quals, eol="\r\n")):
+        exp_p, exp_f, einfo = gpu_ctx.scanfastq_pass2_chunk(text, first_read_id=7, rank_keys=keys, rank_values=ranks)
+        d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+        before = d_text.clone()
+        for copy in (True, False):
+            got_p, got_f, info = gpu_ctx.scanfastq_pass2_chunk(d_text, first_read_id=7, rank_keys=keys, rank_values=ranks, device_output=True, copy=copy)
+            if not copy:   # address + size inside the context's arena
+                assert isinstance(got_p, pkg.DeviceSpan) and len(got_p) == len(exp_p) and len(got_f) == len(exp_f)
+                got_p, got_f = got_p.tensor(), got_f.tensor()
+            assert got_p.is_cuda and got_f.is_cuda and got_p.dtype == torch.uint8
+            assert bytes(got_p.cpu().numpy()) == exp_p and bytes(got_f.cpu().numpy()) == exp_f
+            assert {k: info[k] for k in ("n_records_in", "n_records_out", "n_passed")} == {k: einfo[k] for k in ("n_records_in", "n_records_out", "n_passed")}
+        assert torch.equal(d_text, before)   # read in place, never written
+        # host text in, device text out
+        got_p, got_f, _ = gpu_ctx.scanfastq_pass2_chunk(text, first_read_id=7, rank_keys=keys, rank_values=ranks, device_output=True)
+        assert bytes(got_p.cpu().numpy()) == exp_p and bytes(got_f.cpu().numpy()) == exp_f
+        z_p, z_f, zinfo = gpu_ctx.scanfastq_pass2_chunk(d_text, first_read_id=7, rank_keys=keys, rank_values=ranks, device_output=True, compress=True)
+        assert gzip.decompress(bytes(z_p.cpu().numpy())) == exp_p and gzip.decompress(bytes(z_f.cpu().numpy())) == exp_f
+        assert zinfo["passed_text_bytes"] == len(exp_p) and zinfo["failed_text_bytes"] == len(exp_f)
+    # pass 1 reads a device text in place as well
+    gpu_ctx.set_barcode_set(keys, mode=1)
+    text = _fastq(seqs, quals)
+    d_text = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    h1 = torch.zeros(keys.size, dtype=torch.int32, device="cuda")
+    h2 = torch.zeros(keys.size, dtype=torch.int32, device="cuda")
+    assert gpu_ctx.scanfastq_pass1_chunk(text, h1) == gpu_ctx.scanfastq_pass1_chunk(d_text, h2) == len(seqs)
+    assert bool((h1 == h2).all()) and int(h1.sum()) > 30
+    with pytest.raises(pkg.SmiError, match="want_results"):
+        gpu_ctx.scanfastq_pass2_chunk(text, device_output=True, want_results=True)
+    with pytest.raises(pkg.SmiError, match="text worker"):
+        gpu_ctx.scanfastq_pass2_chunk(text, device_output=True, packed=True)
+    with pytest.raises(pkg.SmiError):   # a malformed text in device memory fails as the host text does
+        gpu_ctx.scanfastq_pass2_chunk(torch.frombuffer(bytearray(b"@r1\nACGT\n-\nIIII\n"), dtype=torch.uint8).cuda(), device_output=True)
+
+
 def test_native_chunk_worker_5p_and_ed2(pkg, synth, sor, gpu_ctx):
     """the native worker in the other configurations: 5' barcoding without polyA requirement, and ed <= 2 (K-BC2)"""
     scanfastq = importlib.import_module("sicelore_amd.scanfastq")
