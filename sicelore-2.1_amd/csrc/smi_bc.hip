@@ -1774,8 +1774,13 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                             passf[ord[h]] = pass_h[h] ? 1u : 0u;
                         }
                     }
+                    if (!kFilter && P.nt != nullptr) {
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            if (created[h]) passf[ord[h]] = pass_h[h] ? 1u : 0u;
+                    }
                     wave_sync();
-                    if (kFilter) {
+                    if (kFilter || P.nt != nullptr) {  // the passing items as a mask over the expansion order
                         pm0 = __ballot(lane < n_items && passf[lane] != 0u);
                         pm1 = __ballot(64 + lane < n_items && passf[64 + lane] != 0u);
                     } else {
@@ -1813,47 +1818,67 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                                 sl = (sl + 1) & (kTabSlots - 1);
                             }
                         };
-                        uint32_t cand = 0xFFFFFFFFu;  // ord << 8 | s2 of this lane's best item
+                        // The passing items are few (a handful of the 123) and sit in arbitrary lanes: they are taken in expansion order, eight
+                        // per round, and a group of eight lanes reads one item's bucket -- one 8-byte entry per lane, 64 contiguous bytes per
+                        // group -- instead of every owning lane walking its eight entries while the rest of the wave idles.
+                        uint32_t cand = 0xFFFFFFFFu;  // ord << 8 | s2 of the best item this lane has seen
+                        unsigned long long r0 = pm0, r1 = pm1;  // (wave-uniform: ballots)
+                        const int grp = lane >> 3, sub = lane & 7;
+                        while (r0 | r1) {
+                            int my_t = -1;
 #pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            if (!pass_h[h]) continue;
-                            const uint32_t X = c[h].low;
-                            const int pX = pe[h] & 15, rX = re[h];
+                            for (int g8 = 0; g8 < 8; g8++) {
+                                int t = -1;
+                                if (r0) {
+                                    t = __builtin_ctzll(r0);
+                                    r0 &= r0 - 1;
+                                } else if (r1) {
+                                    t = 64 + __builtin_ctzll(r1);
+                                    r1 &= r1 - 1;
+                                }
+                                if (grp == g8) my_t = t;
+                            }
+                            bool live = my_t >= 0;
+                            const int e = (int)ord2e[live ? my_t : 0];
+                            const uint32_t X = lows[e];
+                            const int pX = (e >> 3) & 15, rX = e & 7;
                             const uint32_t delb = (rX >= 3 && rX <= 6) ? post2 : post1;  // post[nDeletions + 1]
                             const int q0 = pX == 0 ? 1 : 0;
                             uint32_t best = 255u;
-                            uint32_t idx = nt_slot(X, P.nt_cap);
+                            uint32_t bucket = nt_slot(X, P.nt_cap);
                             for (;;) {
-                                uint64_t en[8];
-                                __builtin_memcpy(en, P.nt + idx, 64);
-                                bool open = false;
-#pragma unroll
-                                for (int t8 = 0; t8 < 8; t8++) {
-                                    open = open || en[t8] == 0ull;
-                                    if ((uint32_t)(en[t8] >> 8) != X || !(en[t8] >> 40)) continue;
-                                    const uint32_t kind = (uint32_t)en[t8] & 3u, pos = ((uint32_t)en[t8] >> 2) & 15u, base = ((uint32_t)en[t8] >> 6) & 3u;
-                                    if (kind == 0u || (int)pos == pX) continue;  // X itself is no mutant of X; the item skips its own position
-                                    uint32_t r2;
+                                const uint64_t en = live ? P.nt[bucket + (uint32_t)sub] : 1ull;
+                                if (live && (uint32_t)(en >> 8) == X && (en >> 40)) {
+                                    const uint32_t kind = (uint32_t)en & 3u, pos = ((uint32_t)en >> 2) & 15u, base = ((uint32_t)en >> 6) & 3u;
+                                    // X itself is no mutant of X; the item skips its own position
+                                    bool use = kind != 0u && (int)pos != pX;
+                                    uint32_t r2 = 7u;
                                     if (kind == 1u) {
                                         const uint32_t cur = (X >> (30 - 2 * pos)) & 3u;
                                         r2 = base - (base > cur ? 1u : 0u);
                                     } else if (kind == 2u) {
-                                        if (pos == 14u && (X & 3u) != 0u) continue;
+                                        use = use && !(pos == 14u && (X & 3u) != 0u);
                                         r2 = 3u + base;
                                     } else {
-                                        if (base != delb) continue;
-                                        r2 = 7u;
+                                        use = use && base == delb;
                                     }
-                                    const Seq Xs = {X, 0u};
-                                    const uint32_t ml = child_of(Xs, (int)pos, (int)r2, delb).low;
-                                    if (ml == K || (ml == X && (int)pos > q0)) continue;  // the root, X itself after its first position
-                                    if (ord_seen_of(ml) < ord[h]) continue;                // a sequence that was expanded earlier
-                                    best = min(best, 8u * pos + r2);
+                                    if (use) {
+                                        const Seq Xs = {X, 0u};
+                                        const uint32_t ml = child_of(Xs, (int)pos, (int)r2, delb).low;
+                                        // the root, X itself after its first position, a sequence that was expanded earlier
+                                        if (!(ml == K || (ml == X && (int)pos > q0)) && !(ord_seen_of(ml) < (uint32_t)my_t)) best = min(best, 8u * pos + r2);
+                                    }
                                 }
-                                if (open) break;
-                                idx = idx + 8 == P.nt_cap ? 0u : idx + 8;
+                                // a bucket with a free entry ends the item's chain
+                                const unsigned long long z = __ballot(live && en == 0ull);
+                                if ((z >> (lane & 56)) & 0xFFull) live = false;
+                                if (!__ballot(live)) break;
+                                bucket = bucket + 8 == P.nt_cap ? 0u : bucket + 8;
                             }
-                            if (best != 255u) cand = min(cand, (ord[h] << 8) | best);
+                            best = min(best, (uint32_t)__shfl_xor((int)best, 1));
+                            best = min(best, (uint32_t)__shfl_xor((int)best, 2));
+                            best = min(best, (uint32_t)__shfl_xor((int)best, 4));
+                            if (my_t >= 0 && best != 255u) cand = min(cand, ((uint32_t)my_t << 8) | best);
                         }
                         uint32_t first_c = cand;
 #pragma unroll
