@@ -5,6 +5,8 @@
 //   SequenceAlignment.getTraceback               TB!nuc/alignment/needleman/SequenceAlignment.java:L102-151
 //   Match.countErrorsInNeedleman, NeedlemanMatch FJ!nanopore/analyzers/{Match,NeedlemanMatch}.java
 #pragma once
+#include <type_traits>
+
 #include "smi_internal.h"
 
 namespace smi {
@@ -47,6 +49,121 @@ __host__ __device__ constexpr int nw_band() {
     int w = 0;
     while (w + 1 < N && 14 * (w + 1) <= 10 * (N - MIN_DIAG)) w++;
     return w;
+}
+
+// ---- the walk, bit-parallel ------------------------------------------------------------------------------------
+// The path from (N, N) back to (0, 0) is at most 2N steps; step t is recorded as two bits in two masks (T1 T0: 11 match, 10 mismatch,
+// 01 up = a base of the read against a template gap, 00 left = a read gap) and every statistic the reference reads off its alignment
+// strings is a popcount, a count of trailing / leading bits or a short loop over runs of those masks.  The walk itself is one
+// find-highest-bit per row: the left moves of a row are the zero tags between the current column and the next non-zero tag below
+// it, so a row costs the same whatever the number of its left moves, and the rows need no inner loop.  (Until round 5 every step went
+// through ~40 operations of bookkeeping, and a row with left moves ran them once per move for the whole wave.)
+//   u = 2 * steps + 2 * column is unchanged by left and diagonal moves and grows by 2 on an up move: step index of a tag at column c2
+//   = (u - 2 c2) / 2.  Rows walked = non-left steps, so the rows still above the path when it reaches column 0 (`lead`) = N - popcount.
+template <int N>
+struct NwWalkWord {
+    using mask_t = typename std::conditional<(N <= 16), uint32_t, uint64_t>::type;
+};
+template <class W>
+__device__ __forceinline__ W nw_lowmask(int n) {  // n in [0, bits of W]
+    constexpr int B = (int)sizeof(W) * 8;
+    return n >= B ? ~(W)0 : (((W)1 << n) - (W)1);
+}
+__device__ __forceinline__ int nw_popc(uint32_t x) { return __popc(x); }
+__device__ __forceinline__ int nw_popc(uint64_t x) { return __popcll(x); }
+__device__ __forceinline__ int nw_ctz(uint32_t x) { return x ? __builtin_ctz(x) : 32; }
+__device__ __forceinline__ int nw_ctz(uint64_t x) { return x ? __builtin_ctzll(x) : 64; }
+__device__ __forceinline__ int nw_top(uint32_t x) { return 31 - __builtin_clz(x); }   // x != 0
+__device__ __forceinline__ int nw_top(uint64_t x) { return 63 - __builtin_clzll(x); }  // x != 0
+// position of the k-th set bit of x (k >= 1), or the width of the word when x has fewer
+template <class W>
+__device__ __forceinline__ int nw_kth_bit(W x, int k) {
+    for (int i = 1; i < k; i++) x &= x - (W)1;
+    return nw_ctz(x);
+}
+// float sum of the reference's end-of-read error weights: k12 times (float)((double)e + 1.2), then k10 times e + 1.0f (the x-columns that
+// lie over the first two read bases come first on the way back, countIndelsMismatchesEndOfRead L109-123)
+__device__ __forceinline__ float nw_end_errors(int k12, int k10) {
+    float e = 0.0f;
+    for (int i = 0; i < k12; i++) e = (float)((double)e + 1.2);
+    for (int i = 0; i < k10; i++) e = __fadd_rn(e, 1.0f);
+    return e;
+}
+
+template <int N, bool kEnds, bool kRuns, int NM>
+__device__ __forceinline__ void nw_walk_bits(const uint32_t (&mlo)[N], const uint32_t (&mhi)[NM], int n_end, AlnStats &out) {
+    using MW = typename NwWalkWord<N>::mask_t;  // a row's tags (2 bits per column) and the step masks (<= 2N steps)
+    constexpr int B = (int)sizeof(MW) * 8;
+    MW T0 = 0, T1 = 0;
+    int cc = 2 * N;  // 2 * current column
+    int u = 2 * N;
+#pragma unroll
+    for (int R = N; R >= 1; R--) {
+        if (cc > 0) {
+            MW z = mlo[R - 1];
+            if (N > 16) z |= (MW)mhi[R - 1] << (B / 2);
+            const MW below = z & nw_lowmask<MW>(cc);  // tags of the columns <= c
+            // the first non-left tag at or below the column (none: the rest of the row is left moves down to column 0)
+            const int pos = below ? (nw_top(below) & ~1) : -2;
+            const uint32_t tag = below ? (uint32_t)(below >> pos) & 3u : 0u;
+            const int cc2 = pos + 2;
+            const int t = ((u - cc2) >> 1) & (B - 1);
+            T0 |= (MW)(tag & 1u) << t;
+            T1 |= (MW)(tag >> 1) << t;
+            u += tag == 1u ? 2 : 0;
+            cc = cc2 - (int)(tag & 2u);  // diagonal moves leave the column, an up move stays in it
+        }
+    }
+    // the rest of the path runs along the first column (`lead` up moves = leading template gaps) or the first row (left moves)
+    const int lead = N - nw_popc((MW)(T0 | T1));
+    int t_end = (u - cc) >> 1;
+    T0 |= nw_lowmask<MW>(lead) << (t_end & (B - 1));
+    t_end += lead + (cc >> 1);
+    const MW valid = nw_lowmask<MW>(t_end);
+    const MW Mt = T0 & T1, I = T0 & ~T1, S = T1 & ~T0, D = valid & ~(T0 | T1), X = valid & ~Mt;
+    const int ins = nw_popc(I), sub = nw_popc(S), nx = nw_popc(X);
+    const int trail = nw_ctz((MW)~D);  // read gaps at the end of the read (the start of the walk) are not deletions
+    const int del = (int)(int8_t)(nw_popc(D) - trail);  // (byte arithmetic, L84)
+    out.ins = ins;
+    out.del = del;
+    out.nmis = ins + del + sub;
+    out.ne = __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));  // Match.countErrorsInNeedleman: two roundings
+    out.term6 = false;
+    out.end5 = out.endn = 0.0f;
+    out.consec = out.best_two = 0;
+    if (kEnds) {
+        out.term6 = (X & (MW)0x3F) == 0 && t_end >= 6;
+        // cb of a step = read bases consumed before it = non-left steps before it: "cb <= 1" are the steps up to the 2nd non-left one
+        const MW ND = T0 | T1;
+        const MW m12 = nw_lowmask<MW>(nw_kth_bit(ND, 2) + 1);
+        const MW m5 = nw_lowmask<MW>(nw_kth_bit(ND, 5) + 1);
+        const MW mn = n_end > 0 ? nw_lowmask<MW>(nw_kth_bit(ND, n_end) + 1) : (MW)0;
+        out.end5 = nw_end_errors(nw_popc((MW)(X & m12 & m5)), nw_popc((MW)(X & m5 & ~m12)));
+        out.endn = nw_end_errors(nw_popc((MW)(X & m12 & mn)), nw_popc((MW)(X & mn & ~m12)));
+    }
+    if (kRuns) {
+        // runs of matches in walk order; a run counts iff an 'x' was met before it, i.e. unless it starts the walk
+        MW m = Mt & (Mt + (MW)1);
+        int consec = 0, s1 = 0, s2 = 0, n_runs = 0;
+        while (m) {
+            const MW lowbit = m & (~m + (MW)1);
+            const MW nxt = m + lowbit;  // the carry runs through the lowest run
+            const int run = nw_ctz(nxt) - nw_ctz(m);
+            m &= nxt;
+            consec = max(consec, run);
+            if (run > 4) {  // getSumOfBestTwoMatchStretchesNeedleman L183-196 as it is written
+                if (n_runs == 0 || run < s1) {
+                    s2 = s1;
+                    s1 = run;
+                } else if (n_runs == 1 || run < s2) {
+                    s2 = run;
+                }
+                n_runs++;
+            }
+        }
+        out.consec = consec;
+        out.best_two = (n_runs >= 1 ? s1 : 0) + (n_runs >= 2 ? s2 : 0);
+    }
 }
 
 template <int N, bool kEnds = true, bool kRuns = true, int W = N>
@@ -94,6 +211,7 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
             __builtin_amdgcn_sched_barrier(0);  // keep rows apart: interleaving them only costs registers
         }
     }
+#ifdef SMI_NW_WALK_LOOP
     int c = N, lead = 0;
     int ins = 0, del = 0, sub = 0, trail = 0, cb = 0, t = 0, nx = 0;
     bool trailing = true, term = true;
@@ -192,6 +310,9 @@ __device__ __forceinline__ void nw_full(const uint32_t (&col)[N], int n_end, Aln
     out.best_two = (n_runs >= 1 ? s1 : 0) + (n_runs >= 2 ? s2 : 0);
     // Match.countErrorsInNeedleman: (float)#x - 0.9f * (float)lead, two roundings
     out.ne = __fsub_rn((float)nx, __fmul_rn(0.9f, (float)lead));
+#else
+    nw_walk_bits<N, kEnds, kRuns>(mlo, mhi, n_end, out);
+#endif
 }
 
 // Error count only (Match.countErrorsInNeedleman = #x - 0.9f * leading template gaps), no moves kept: the two
