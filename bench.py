@@ -219,7 +219,7 @@ def end_to_end_leg(ctx, synth, dev, used, n, lane_counts=(1, 2, 3)):
                          "limiter": "the splitter's filter (K-CHIM-A: 4-mer gates + a Levenshtein bound for every gated position of every read) is integer VALU "
                                     "issue; then the writer (K-WRITE beside K-WNAME), K-FQ's sweep, K-PACKR; with one lane also the four waits for "
                                     "the host inside the call (line count, record index, fragment count, output sizes)",
-                         "kernel_trace": "profiles/r05/e2e_kernel_stats.csv (one lane)"},
+                         "kernel_trace": "profiles/r06/e2e_kernel_stats.csv (one lane)"},
             "stages": "K-FQ, K-PACKR, K-CHIM, fragment offsets, K-PACK, K-SCAN, K-BC1 (3.6M whitelist), K-WRITE; FASTQ text in HBM -> "
                       "passed/failed FASTQ text in HBM; ONE library call per chunk (smi_scanfastq_pass2_chunk: device text read in place, device_output)"}
 
@@ -1185,7 +1185,7 @@ def main():
         "roofline": dict({"bound": "hbm" if dom is f_bc1 else "valu-issue (the HBM figures are what the contract asks for; the binding resource "
                                    "of this kernel is integer VALU issue, in `valu_issue`)"}, **dom,
                          **{"kernels_ms": {"k_scan<10>": k_scan, "k_bc_match_ed1<1>": k_match}, "other": {oth["kernel"]: oth},
-                            "kernel_trace": "profiles/r05/step_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5` with every side "
+                            "kernel_trace": "profiles/r06/step_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --steps 5` with every side "
                                             "leg off: AverageNs of k_scan<10> is kernel_ms)",
                             "probes_per_s_bc1": 620.0 * n / (k_match * 1e-3)}),
     }

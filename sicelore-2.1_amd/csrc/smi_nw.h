@@ -97,21 +97,44 @@ __device__ __forceinline__ void nw_walk_bits(const uint32_t (&mlo)[N], const uin
     MW T0 = 0, T1 = 0;
     int cc = 2 * N;  // 2 * current column
     int u = 2 * N;
+    if constexpr (N <= 16) {
+        // 32-bit rows.  sh = 32 - 2 * column: the row's tags shifted left by sh have the current column's tag on top, the leading zero bits
+        // (rounded down to a pair) are the left moves, and every quantity of the step is an add or a shift of them -- no selects.
+        int sh = 32 - 2 * N, up2 = 2 * N - 32;  // up2 = u - 32
 #pragma unroll
-    for (int R = N; R >= 1; R--) {
-        if (cc > 0) {
-            MW z = mlo[R - 1];
-            if (N > 16) z |= (MW)mhi[R - 1] << (B / 2);
-            const MW below = z & nw_lowmask<MW>(cc);  // tags of the columns <= c
-            // the first non-left tag at or below the column (none: the rest of the row is left moves down to column 0)
-            const int pos = below ? (nw_top(below) & ~1) : -2;
-            const uint32_t tag = below ? (uint32_t)(below >> pos) & 3u : 0u;
-            const int cc2 = pos + 2;
-            const int t = ((u - cc2) >> 1) & (B - 1);
-            T0 |= (MW)(tag & 1u) << t;
-            T1 |= (MW)(tag >> 1) << t;
-            u += tag == 1u ? 2 : 0;
-            cc = cc2 - (int)(tag & 2u);  // diagonal moves leave the column, an up move stays in it
+        for (int R = N; R >= 1; R--) {
+            if (sh < 32) {
+                const uint32_t y = mlo[R - 1] << sh;
+                const int k2 = __clz((int)y) & ~1;       // 2 * left moves (32: nothing but left moves down to column 0)
+                const int sh2 = min(sh + k2, 32);
+                const uint32_t tag = (y << (k2 & 31)) >> 30;  // y == 0: 0
+                const uint32_t lo = tag & 1u, hi = tag >> 1;
+                const int t = (up2 + sh2) >> 1;          // step index = (u - 2 * column of the tag) / 2
+                T0 |= lo << (t & 31);
+                T1 |= hi << (t & 31);
+                up2 += (int)((lo & ~hi) << 1);           // an up move
+                sh = sh2 + (int)(hi << 1);               // diagonal moves leave the column
+            }
+        }
+        cc = 32 - sh;
+        u = up2 + 32;
+    } else {
+#pragma unroll
+        for (int R = N; R >= 1; R--) {
+            if (cc > 0) {
+                MW z = mlo[R - 1];
+                z |= (MW)mhi[R - 1] << (B / 2);
+                const MW below = z & nw_lowmask<MW>(cc);  // tags of the columns <= c
+                // the first non-left tag at or below the column (none: the rest of the row is left moves down to column 0)
+                const int pos = below ? (nw_top(below) & ~1) : -2;
+                const uint32_t tag = below ? (uint32_t)(below >> pos) & 3u : 0u;
+                const int cc2 = pos + 2;
+                const int t = ((u - cc2) >> 1) & (B - 1);
+                T0 |= (MW)(tag & 1u) << t;
+                T1 |= (MW)(tag >> 1) << t;
+                u += tag == 1u ? 2 : 0;
+                cc = cc2 - (int)(tag & 2u);  // diagonal moves leave the column, an up move stays in it
+            }
         }
     }
     // the rest of the path runs along the first column (`lead` up moves = leading template gaps) or the first row (left moves)
