@@ -10,7 +10,7 @@
 #   own                        tools/own_cluster_bench.py 8000 with the clusterer's step timer -> gpurun_out/own_cluster_8000*.json
 # Parts run in the order given; the call stops at the first one that fails.
 set -u
-TAG=${TAG:-r05}   # the round the outputs are named after (profiles/$TAG/ once copied there)
+TAG=${TAG:-r06}   # the round the outputs are named after (profiles/$TAG/ once copied there)
 ulimit -c 0
 mkdir -p gpurun_out
 export TMPDIR=/tmp

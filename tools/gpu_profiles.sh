@@ -5,7 +5,7 @@
 #   profiles/$TAG/umi_*       K-UMI's microbench leg: kernel trace + counters
 #   profiles/$TAG/e2e_*       the bench's end-to-end leg alone: kernel trace, timeline, traffic counters
 set -u
-TAG=${TAG:-r05}   # the round the outputs are named after (profiles/$TAG/ once copied there)
+TAG=${TAG:-r06}   # the round the outputs are named after (profiles/$TAG/ once copied there)
 ulimit -c 0
 mkdir -p gpurun_out
 OFF="--umi-molecules 0 --h2h-reads 0 --f2f-reads 0 --assignumis-file-records 0"

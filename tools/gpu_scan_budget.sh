@@ -2,7 +2,7 @@
 # K-SCAN's instruction budget by region -- the step with parts of the kernel switched off (measurement build, wrong results by
 # construction): SQ_INSTS_VALU and the kernel's duration per variant -> gpurun_out/scan_budget.json
 set -u
-TAG=${TAG:-r05}   # the round the outputs are named after (profiles/$TAG/ once copied there)
+TAG=${TAG:-r06}   # the round the outputs are named after (profiles/$TAG/ once copied there)
 ulimit -c 0
 export TMPDIR=/tmp
 ROOT=$(pwd)
