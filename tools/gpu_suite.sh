@@ -1,7 +1,7 @@
 #!/bin/bash
 # the whole GPU suite, then the default bench line (no core files: a crashing torch process writes tens of GB)
 set -u
-TAG=${TAG:-r05}   # the round the outputs are named after (profiles/$TAG/ once copied there)
+TAG=${TAG:-r06}   # the round the outputs are named after (profiles/$TAG/ once copied there)
 ulimit -c 0
 mkdir -p gpurun_out
 timeout -k 10 1100 python -m pytest tests -x -q -m gpu "$@" > gpurun_out/${TAG}_gpu_tests.log 2>&1; echo "suite rc=$?"; tail -5 gpurun_out/${TAG}_gpu_tests.log
