@@ -1196,6 +1196,7 @@ def main():
     res["set_build_cold_ms"] = set_cold["build_ms"]
     res["set_hbm_bytes"] = set_warm["hbm_bytes"]
     res["value_one_shot"] = n * world / (set_cold["build_ms"] * 1e-3 + ms_per_step * 1e-3)
+    res["value_one_shot_warm_allocator"] = n * world / (set_warm["build_ms"] * 1e-3 + ms_per_step * 1e-3)   # (a second job of the same process: no hipMalloc)
     res["set_build_note"] = ("smi_set_barcode_set_device of the 3.6 M list: membership pyramid + nb (512 MiB, atomics) + nb5 (2.5 GiB, transposed from nb) on a side "
                              "stream beside nt (3 slots per neighbour + bucket counters); profiles/r06/set_build_kernel_stats.csv has the kernels; "
                              "set_build_cold_ms includes hipMalloc of set_hbm_bytes")

@@ -119,8 +119,10 @@ int smi_ctx_set_polya(smi_ctx *ctx, int polya_len, float polya_frac, int window_
  *                                                        the UMI stage takes it from smi_assignumis_config
  * Limits of this build (checked by smi_ctx_set_knobs, message names the knob): sequence 10 bases, sequence_complete 22, the complete TSO 27,
  * the complete 3' adapter of 5' barcoding 25, A / C / G / T only; the polyA limits of smi_ctx_set_polya; 8 <= umi_length <= 12;
- * counts and mismatch limits 0 .. 30.  Compiled in (no knob): the TSO of the read scan (tso_for3pBarcoding sequence, maxNeedlemanMismatches,
- * minTSO_*, windowForTSOsearch), testPlusMinusPos = 2, cell_bc_length = 16, the read-name prefixes, nbasesOfAdapterSeqInReadname = 3. */
+ * counts and mismatch limits 0 .. 30; the TSO of the read scan 16 bases, its window 16 .. 112.  A TSO, an adapter or a polyA window other than
+ * the shipped ones run K-SCAN's generic kernels (every candidate aligned over the full matrix, the finder as a loop), the shipped ones the
+ * kernels specialised for them; the results are the same function of the parameters (tests run both).  Compiled in (no knob):
+ * testPlusMinusPos = 2, cell_bc_length = 16, the read-name prefixes, nbasesOfAdapterSeqInReadname = 3. */
 typedef struct {
     int32_t min_read_length;          /* readscanner/minReadLength                              config.xml:21   200 */
     int32_t min_mean_bc_qv;           /* readscanner/minMeanBCqv                                :55   8 */
@@ -145,7 +147,12 @@ typedef struct {
     char tso_complete[32];            /* tso_for3pBarcoding/sequence_complete                   :170  AAGCAGTGGTATCAACGCAGAGTACAT */
     int32_t tso_complete_max_mm;      /* tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches   :172  6 */
     int32_t umi_length;               /* umis/umi_length                                        :264  12 */
-    int32_t reserved[7];
+    char tso_scan[20];                /* tso_for3pBarcoding/sequence                            :155  AACGCAGAGTACATGG (16 bases) */
+    int32_t tso_scan_max_mm;          /* tso_for3pBarcoding/maxNeedlemanMismatches              :157  5 */
+    int32_t tso_scan_min_consec;      /* tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches  :161  8 */
+    int32_t tso_scan_min_two_best;    /* tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches    :164  12 */
+    int32_t tso_scan_window;          /* tso_for3pBarcoding/windowForTSOsearch                  :166  90 */
+    int32_t reserved[6];
 } smi_run_knobs;
 /* `scanfastq -e / --randomBarcode` (NanoporeReadScannerMain.java:L212-215; Parser.java:L212-215: "the read bc sequence gets replaced by a random sequence",
  * /root/reference/README.md:176): the specificity experiment -- pass 2 of this context's chunk workers matches RANDOM sequences where the read's barcode
@@ -258,6 +265,13 @@ typedef struct {
     int32_t five_prime;             /* 1: 5' barcoding, PolyATadapterAnalyzer_5pBCUMI.search (PolyATadapterAnalyzer_5pBCUMI.java:L43-76) */
     int32_t dont_search_polya;      /* 5' only: --noPolyARequired (dontSearchPolyAFor5pBarcoding) */
     int32_t adapter_search_window;  /* 5' only: AdapterSearchWindow, config.xml:134 (110) */
+    /* the TSO scan of 3' barcoding (PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190, PolyATadapterAnalyzerBase.scanForTSO L324-369);
+     * tso_window == 0: the shipped parameters (a configuration built by hand before round 6 leaves these zero) */
+    uint32_t tso4[16];              /* 4-bit codes of tso_for3pBarcoding/sequence (16 bases), :155 */
+    int32_t tso_window;             /* windowForTSOsearch :166 (90); 16 .. 112 */
+    int32_t tso_max_mismatches;     /* maxNeedlemanMismatches :157 (5) */
+    int32_t tso_min_consec;         /* minTSO_NeedlemanConsecutiveMatches :161 (8) */
+    int32_t tso_min_two_best;       /* minTSO_TwoBestConsecutiveMatches :164 (12) */
 } smi_scan_config;
 
 typedef struct {

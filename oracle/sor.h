@@ -80,6 +80,12 @@ typedef struct { /* shipped values: Jar/config.xml:21,55-59,95-105 */
     int32_t min_adapter_3p_matches; /* 8 */
     int32_t min_mean_bc_qv;         /* 8 */
     int32_t min_mean_read_qv;       /* 8 */
+    /* the TSO of the read scan (tso_for3pBarcoding: Jar/config.xml:155-166); tso[0] == 0: the shipped values */
+    char tso[20];                   /* sequence: 16 bases, AACGCAGAGTACATGG */
+    int32_t tso_window;             /* windowForTSOsearch 90 */
+    int32_t tso_max_mm;             /* maxNeedlemanMismatches 5 */
+    int32_t tso_min_consec;         /* minTSO_NeedlemanConsecutiveMatches 8 */
+    int32_t tso_min_two;            /* minTSO_TwoBestConsecutiveMatches 12 */
 } sor_scan_params;
 
 typedef struct {

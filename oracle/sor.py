@@ -142,7 +142,8 @@ def assign_batch(bset, codes, ae, max_ed=1, test_pm=2, five_prime=False, n_threa
 # ---- read scan (sor_scan.c) ----------------------------------------------------------------------------------
 SCAN_PARAMS_DTYPE = np.dtype([("min_read_length", "<i4"), ("polya_len", "<i4"), ("polya_frac", "<f4"),
                               ("window_polya", "<i4"), ("min_adapter_3p_matches", "<i4"), ("min_mean_bc_qv", "<i4"),
-                              ("min_mean_read_qv", "<i4")])
+                              ("min_mean_read_qv", "<i4"), ("tso", "S20"), ("tso_window", "<i4"), ("tso_max_mm", "<i4"),
+                              ("tso_min_consec", "<i4"), ("tso_min_two", "<i4")])
 SCAN_RESULT_DTYPE = np.dtype([("flags", "<u8"), ("adapter_found", "<i4"), ("reverse", "<i4"), ("polya_start", "<i4"),
                               ("polya_end", "<i4"), ("adapter_start", "<i4"), ("adapter_end", "<i4"),
                               ("scan_end", "<i4"), ("adapter_nmis", "<i4"), ("n_cand_fwd", "<i4"),
@@ -156,7 +157,14 @@ FLAG_BITS = {"FAILED": 5, "PASSED_FWD": 8, "PASSED_REV": 9, "POLY_T_5P": 11, "PO
 
 def default_scan_params():
     p = np.zeros(1, dtype=SCAN_PARAMS_DTYPE)
-    p[0] = (200, 15, 0.75, 150, 8, 8, 8)  # Jar/config.xml:21,95-105,55-59
+    p[0] = (200, 15, 0.75, 150, 8, 8, 8, b"", 0, 0, 0, 0)  # Jar/config.xml:21,95-105,55-59; an empty `tso` = the shipped TSO parameters (:155-166)
+    return p
+
+
+def set_tso_params(p, sequence="AACGCAGAGTACATGG", window=90, max_mm=5, min_consec=8, min_two=12):
+    """the read scan's TSO parameters (tso_for3pBarcoding) on a scan-parameter record"""
+    p["tso"] = sequence.encode()
+    p["tso_window"], p["tso_max_mm"], p["tso_min_consec"], p["tso_min_two"] = window, max_mm, min_consec, min_two
     return p
 
 

@@ -102,11 +102,14 @@ static void scan_for_tso(const uint8_t *seq, int seq_len, const uint8_t *tso, in
 
 /* PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L122-190 */
 static void scan_read_for_tsos(const char *read, int len, const sor_scan_params *par, sor_scan_result *out) {
-    static const char TSO[] = "AACGCAGAGTACATGG"; /* Jar/config.xml:155 */
-    const int tso_len = 16, window = 90, max_mm = 5, min_consec = 8, min_two = 12; /* :157-166 */
-    (void)par;
+    /* TSOparameters_3pBarcoding: sequence, windowForTSOsearch, maxNeedlemanMismatches, minTSO_NeedlemanConsecutiveMatches,
+     * minTSO_TwoBestConsecutiveMatches (Jar/config.xml:155-166); the shipped values unless the caller's parameters carry others */
+    const int shipped = !par || par->tso[0] == 0;
+    const char *TSO = shipped ? "AACGCAGAGTACATGG" : par->tso;
+    const int tso_len = 16, window = shipped ? 90 : par->tso_window, max_mm = shipped ? 5 : par->tso_max_mm,
+              min_consec = shipped ? 8 : par->tso_min_consec, min_two = shipped ? 12 : par->tso_min_two;
     const int n = window + tso_len + 10;
-    uint8_t tso[16], fwd[128], rev[128];
+    uint8_t tso[16], fwd[256], rev[256];
     for (int i = 0; i < tso_len; i++) tso[i] = (uint8_t)enc4((unsigned char)TSO[i]);
     for (int i = 0; i < n; i++) fwd[i] = (uint8_t)enc4((unsigned char)read[i]);
     for (int i = 0; i < n; i++) rev[i] = (uint8_t)sor_fourbit_complement(enc4((unsigned char)read[len - 1 - i]));

@@ -13,7 +13,7 @@ exit code 0, or 1 after a message (WorkerReadscanner.java:L376-378).
 
 config.xml (round 6): the file's knobs are taken at RUN TIME -- thresholds, windows, adapter / complete TSO sequences and mismatch limits, the
 finalize folds, mergeBCsED, umi_length and the clustering distances go to the library as smi_run_knobs / call arguments (lib.KNOB_FIELDS,
-HOST_KNOBS_* below).  Only what is genuinely compiled in (COMPILED_IN: the TSO of the read scan, testPlusMinusPos, cell_bc_length, the read-name
+HOST_KNOBS_* below).  Only what is genuinely compiled in (COMPILED_IN: testPlusMinusPos, cell_bc_length, the read-name
 grammar) is CHECKED against the file, and a different value stops the run with the knob's name -- nothing is silently ignored.  Options the
 product has no path for (Illumina-guided modes, the file watcher) are refused by name.
 """
@@ -32,7 +32,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 #
 # COMPILED_IN: what is genuinely fixed in this build -- knob (path under <Parameters>) -> the shipped value the kernels are compiled for; any other
 # value stops the run with the knob's name (nothing is silently ignored):
-#   * the TSO of the READ SCAN (K-SCAN's gate / alignment columns / acceptance rules are compile-time: PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs)
 #   * testPlusMinusPos (five windows per read: the layout of smi_bc_window and of K-BC1's filter), cell_bc_length (32-bit keys)
 #   * the read-name grammar (prefixes, nbasesOfAdapterSeqInReadname: smi_name.h and K-UPARSE), runningasdemon, tagGeneNameFunction
 COMPILED_IN = {
@@ -40,9 +39,6 @@ COMPILED_IN = {
     "readscanner/tso_pos_prefix": "T=", "readscanner/seq_prefix": "X=", "readscanner/qv_prefix": "Q=",
     "readscanner/nbasesOfAdapterSeqInReadname": "3", "readscanner/runningasdemon": "false",
     "barcodeUMIFinder/tagGeneNameFunction": "DefaultTagger",
-    "tso_for3pBarcoding/sequence": "AACGCAGAGTACATGG", "tso_for3pBarcoding/maxNeedlemanMismatches": "5",
-    "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": "8", "tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches": "12",
-    "tso_for3pBarcoding/windowForTSOsearch": "90",
     "barcodes/cell_bc_length": "16",
 }
 # knobs of the shipped file that NO unit of the path reads (checked over the bytecode: no getfield outside print() / the Illumina-guided analyzers):

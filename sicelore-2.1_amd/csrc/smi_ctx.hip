@@ -495,6 +495,11 @@ int smi_run_knobs_default(smi_run_knobs *k) {
     std::strcpy(k->tso_complete, "AAGCAGTGGTATCAACGCAGAGTACAT");   // :170
     k->tso_complete_max_mm = 6;                                    // :172
     k->umi_length = 12;                                            // :264
+    std::strcpy(k->tso_scan, "AACGCAGAGTACATGG");                  // :155
+    k->tso_scan_max_mm = 5;                                        // :157
+    k->tso_scan_min_consec = 8;                                    // :161
+    k->tso_scan_min_two_best = 12;                                 // :164
+    k->tso_scan_window = 90;                                       // :166
     return SMI_OK;
 }
 
@@ -527,9 +532,10 @@ int check_knobs(const smi_run_knobs &k) {
                 {"fiveprimeadapter_for5pBarcoding/sequence", k.adapter5p, 10},
                 {"fiveprimeadapter_for5pBarcoding/sequence_complete", k.adapter5p_complete, 22},
                 {"threeprimeadapter_for5pBarcoding/sequence_complete", k.adapter3p5_complete, 25},
-                {"tso_for3pBarcoding/sequence_complete", k.tso_complete, 27}};
+                {"tso_for3pBarcoding/sequence_complete", k.tso_complete, 27},
+                {"tso_for3pBarcoding/sequence", k.tso_scan, 16}};
     for (const auto &q : seqs)
-        if (!seq_ok(q.s, 32, q.want)) {
+        if (!seq_ok(q.s, q.want == 16 ? 20 : 32, q.want)) {
             char msg[256];
             std::snprintf(msg, sizeof msg, "smi_ctx_set_knobs: %s: this build has kernels for %d bases of A / C / G / T here (the length of the shipped sequence)", q.name, q.want);
             set_error(msg);
@@ -550,7 +556,11 @@ int check_knobs(const smi_run_knobs &k) {
                 {"fiveprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches", k.adapter5p_complete_max_mm, 0, 30},
                 {"threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches", k.adapter3p5_complete_max_mm, 0, 30},
                 {"tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches", k.tso_complete_max_mm, 0, 30},
-                {"umis/umi_length", k.umi_length, 8, 12}};
+                {"umis/umi_length", k.umi_length, 8, 12},
+                {"tso_for3pBarcoding/maxNeedlemanMismatches", k.tso_scan_max_mm, 0, 30},
+                {"tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches", k.tso_scan_min_consec, 0, 32},
+                {"tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches", k.tso_scan_min_two_best, 0, 32},
+                {"tso_for3pBarcoding/windowForTSOsearch", k.tso_scan_window, 16, 112}};
     for (const auto &q : ints)
         if (q.v < q.lo || q.v > q.hi) {
             char msg[256];
@@ -636,6 +646,11 @@ int smi_scan_config_from_knobs(const smi_run_knobs *knobs, int pass, int five_pr
         cfg->dont_search_polya = dont_search_polya ? 1 : 0;
         cfg->adapter_search_window = k.adapter5p_window;
     }
+    for (int i = 0; i < 16; i++) cfg->tso4[i] = k.tso_scan[i] == 'A' ? 1u : k.tso_scan[i] == 'G' ? 2u : k.tso_scan[i] == 'C' ? 4u : 8u;
+    cfg->tso_window = k.tso_scan_window;
+    cfg->tso_max_mismatches = k.tso_scan_max_mm;
+    cfg->tso_min_consec = k.tso_scan_min_consec;
+    cfg->tso_min_two_best = k.tso_scan_min_two_best;
     return SMI_OK;
 }
 
@@ -684,6 +699,7 @@ int smi_fastq_index_device(smi_ctx *ctx, const uint8_t *d_text, size_t n_bytes, 
         set_error("smi_fastq_index_device: buffer too large for one call");
         return SMI_ERR_INVALID;
     }
+    ctx->fq_swept_text = nullptr;  // (a caller of this entry point has not swept: nothing a worker left behind is taken for this text's flags)
     return launch_fastq_index(ctx, d_text, n_bytes, d_line_start, cap_lines, d_name_start, d_name_len, d_seq_start, d_seq_len,
                               d_qual_start, d_offsets, cap_records, n_records, errors, (hipStream_t)stream);
 }
@@ -818,6 +834,15 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
         set_error("smi_scan_device: 5' search window + adapter + mismatches + 5 must fit 192 bases");
         return SMI_ERR_INVALID;
     }
+    if (cfg->tso_window != 0) {
+        bool ok = cfg->tso_window >= 16 && cfg->tso_window <= 112 && cfg->tso_max_mismatches >= 0 && cfg->tso_max_mismatches <= 30 && cfg->tso_min_consec >= 0 &&
+                  cfg->tso_min_two_best >= 0;
+        for (int i = 0; ok && i < 16; i++) ok = cfg->tso4[i] == 1u || cfg->tso4[i] == 2u || cfg->tso4[i] == 4u || cfg->tso4[i] == 8u;
+        if (!ok) {
+            set_error("smi_scan_device: the TSO of the read scan must be 16 bases of A / C / G / T, windowForTSOsearch 16 .. 112, the limits >= 0 (tso_window == 0: the shipped parameters)");
+            return SMI_ERR_INVALID;
+        }
+    }
     {
         // The reference cuts window + length + 10 bases off each read end before it looks for polyA / polyT (PolyATSearcher.java:L178-181) and
         // AdapterSearchWindow + adapter + mismatches + 5 in 5' barcoding (PolyATadapterAnalyzer_5pBCUMI.java:L49-61): a read that passes
@@ -826,6 +851,8 @@ int smi_scan_device(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_read_
         int need = 0;
         if (!cfg->five_prime || !cfg->dont_search_polya) need = cfg->window_polya + cfg->polya_len + 10;
         if (cfg->five_prime) need = std::max(need, cfg->adapter_search_window + cfg->adapter_len + cfg->max_mismatches + 5);
+        // 3' barcoding: windowForTSOsearch + 16 + 10 bases of each end for the TSO scan (PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs L128-131)
+        if (!cfg->five_prime && cfg->tso_window) need = std::max(need, cfg->tso_window + 26);
         if (cfg->min_read_length < need) {
             char msg[320];
             std::snprintf(msg, sizeof msg,

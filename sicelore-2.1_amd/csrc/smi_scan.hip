@@ -65,6 +65,9 @@ struct ScanParams {
     __host__ __device__ __forceinline__ uint32_t a4(int i) const { return (adapter_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int dont_polya;      // --noPolyARequired (dontSearchPolyAFor5pBarcoding)
     int window5;         // AdapterSearchWindow (110)
+    uint32_t tso_nib[2];  // 4-bit codes of the read scan's TSO (generic kernels; the shipped kernels carry tso4() as constants)
+    int tso_window, tso_max_mm, tso_min_consec, tso_min_two;  // 90, 5, 8, 12
+    __host__ __device__ __forceinline__ uint32_t t4(int i) const { return (tso_nib[i >> 3] >> ((i & 7) * 4)) & 15u; }
     int finder_bits;     // host side only: the bit-parallel polyT finder applies (polya_len 15, thresholds 12 / 10, window <= 160) -- otherwise the generic kernels run
     int ablate;          // measurement only (SMI_SCAN_ABLATE): 1 no TSO alignments, 2 no adapter alignments, 4 no polyT finder, 8 no TSO gates, 16 no TSO pre-filter (results unchanged), 32 finder: first loop only, 64 no adapter gates, 128 no folds
 };
@@ -314,7 +317,7 @@ __device__ __forceinline__ bool find_polyt_bits(const uint32_t *planes, uint64_t
 }
 
 // TSO "AACGCAGAGTACATGG" (Jar/config.xml:155) as 4-bit codes A=1 G=2 C=4 T=8, base i in bits [4i+3:4i]
-__device__ __forceinline__ uint32_t tso4(int i) {
+__host__ __device__ __forceinline__ uint32_t tso4(int i) {
     constexpr uint64_t TSO = 0x2281418212142411ull;
     return (uint32_t)(TSO >> (4 * i)) & 15u;
 }
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
                     // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++)
-                        tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [](int i) { return tso4(i); }), 90 - ch * 64);
+                        tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [&](int i) { return SHIP ? tso4(i) : P.t4(i); }), (SHIP ? 90 : P.tso_window) - ch * 64);
                 }
                 if (SHIP && !SMI_ABLATED(16)) {
                     // Exact pre-filter of the ISOLATED TSO candidates.  A candidate's alignment matters in two ways only: it may be
@@ -602,7 +605,7 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
                     } else if (kind == 1 && !SMI_ABLATED(1)) {
                         uint32_t col[16];
 #pragma unroll
-                        for (int c = 0; c < 16; c++) col[c] = col_of(tso4(c)) & 0xFFFFu;
+                        for (int c = 0; c < 16; c++) col[c] = col_of(SHIP ? tso4(c) : P.t4(c)) & 0xFFFFu;
                         nw_full<16, false, true, kBandTso>(col, 0, st);  // the TSO rules read ne, nmis, ins, del, consec, best_two
                     }
                     uint32_t *o = ent + tid * 5;
@@ -640,13 +643,14 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
                             }
                         }
                     } else if (pos >= (int)(t_aux >> 16)) {  // positions jumped over by deltaPos are never aligned (L100-106)
-                        if (!((float)(int)floorf(__fadd_rn(ne, 0.5f)) > 5.0f) && ne < t_best) {  // Math.round(ne) <= 5
+                        const float t_max = SHIP ? 5.0f : (float)P.tso_max_mm;  // maxErrors = maxNeedlemanMismatches of the TSO
+                        if (!((float)(int)floorf(__fadd_rn(ne, 0.5f)) > t_max) && ne < t_best) {  // Math.round(ne) <= maxErrors
                             t_best = ne;
                             t_pack = packed;
                             t_aux = (t_aux & 0xFFFF0000u) | (o[4] & 0xFFFFu);
                         }
-                        if (5.0f < ne) {
-                            int d = (int)floorf(__fadd_rn(__fsub_rn(ne, 5.0f), 0.5f)) - 1;
+                        if (t_max < ne) {
+                            int d = (int)floorf(__fadd_rn(__fsub_rn(ne, t_max), 0.5f)) - 1;
                             t_aux = (t_aux & 0xFFFFu) | ((uint32_t)(pos + (d < 1 ? 1 : d)) << 16);
                         }
                     }
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
             Tm mine;
             mine.present = t_pos != 0;
             mine.nmis = t_nmis;
-            mine.passed = mine.present && t_nmis <= 5;  // scanForTSO L350
+            mine.passed = mine.present && t_nmis <= (SHIP ? 5 : P.tso_max_mm);  // scanForTSO L350
             mine.end_scan = t_pos + 15 + t_ins - t_del;
             mine.consec = t_consec;
             mine.two = t_two;
@@ -835,11 +839,12 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
             Tm f = side == 0 ? mine : o, r = side == 0 ? o : mine;
             auto found = [](const Tm &x) { return x.present && x.passed; };
             if (!found(f) && !found(r)) {  // L146-153: rescue by >= 8 consecutive matches (config.xml:161)
-                if (f.present) f.passed = f.consec >= 8;
-                if (r.present) r.passed = r.consec >= 8;
+                const int min_consec = SHIP ? 8 : P.tso_min_consec, min_two = SHIP ? 12 : P.tso_min_two;
+                if (f.present) f.passed = f.consec >= min_consec;
+                if (r.present) r.passed = r.consec >= min_consec;
                 if (!found(f) && !found(r)) {  // L155-162: rescue by the two stretches >= 12 (config.xml:164)
-                    if (f.present) f.passed = f.two >= 12;
-                    if (r.present) r.passed = r.two >= 12;
+                    if (f.present) f.passed = f.two >= min_two;
+                    if (r.present) r.passed = r.two >= min_two;
                 }
             }
             if (found(f) && found(r) && abs(f.nmis - r.nmis) > 3) {  // L167-172
@@ -899,6 +904,14 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     for (int i = 0; i < 22 && i < ad; i++) P.adapter_nib[i >> 3] |= (cfg->adapter4[i] & 15u) << ((i & 7) * 4);
     P.dont_polya = cfg->dont_search_polya;
     P.window5 = cfg->adapter_search_window;
+    // the TSO of the read scan: tso_window == 0 (a configuration from before the knob) = the shipped parameters
+    const bool tso_given = cfg->tso_window != 0;
+    P.tso_nib[0] = P.tso_nib[1] = 0u;
+    for (int i = 0; i < 16; i++) P.tso_nib[i >> 3] |= ((tso_given ? cfg->tso4[i] : tso4(i)) & 15u) << ((i & 7) * 4);
+    P.tso_window = tso_given ? cfg->tso_window : 90;
+    P.tso_max_mm = tso_given ? cfg->tso_max_mismatches : 5;
+    P.tso_min_consec = tso_given ? cfg->tso_min_consec : 8;
+    P.tso_min_two = tso_given ? cfg->tso_min_two_best : 12;
     // the kernels of the shipped adapters carry the bit-parallel finder, built for the shipped window length and the thresholds the shipped fractions give;
     // SMI_SCAN_FINDER_LOOP: cross-check switch (the generic kernels, which keep the loop)
     P.finder_bits = cfg->polya_len == 15 && P.thr_first == 12 && P.thr_adv == 10 && cfg->window_polya >= 1 && cfg->window_polya <= 160 && !std::getenv("SMI_SCAN_FINDER_LOOP");
@@ -924,6 +937,9 @@ int launch_scan(smi_ctx *ctx, const uint32_t *d_ends, const int32_t *d_len, cons
     };
     bool ship = (ad == 10 || ad == 22) && P.finder_bits;
     for (int i = 0; ship && i < ad; i++) ship = P.a4(i) == (ad == 10 ? shipped_a4<10>(i) : shipped_a4<22>(i));
+    // (the shipped kernels carry the TSO, its window and its limits as constants, and the isolated-candidate pre-filter is derived for them)
+    ship = ship && P.tso_window == 90 && P.tso_max_mm == 5 && P.tso_min_consec == 8 && P.tso_min_two == 12;
+    for (int i = 0; ship && i < 16; i++) ship = P.t4(i) == tso4(i);
     if (std::getenv("SMI_SCAN_GENERIC")) ship = false;  // tests run both builds against the oracle
     if (ad == 10) {
         if (cfg->five_prime)

@@ -25,7 +25,8 @@ SCAN_CONFIG_DTYPE = np.dtype(
     [("min_read_length", "<i4"), ("polya_len", "<i4"), ("polya_frac", "<f4"), ("window_polya", "<i4"),
      ("max_mismatches", "<i4"), ("min_adapter_3p_matches", "<i4"), ("min_mean_bc_qv", "<i4"),
      ("min_mean_read_qv", "<i4"), ("adapter_len", "<i4"), ("adapter4", "<u4", (22,)), ("five_prime", "<i4"),
-     ("dont_search_polya", "<i4"), ("adapter_search_window", "<i4")]
+     ("dont_search_polya", "<i4"), ("adapter_search_window", "<i4"), ("tso4", "<u4", (16,)), ("tso_window", "<i4"),
+     ("tso_max_mismatches", "<i4"), ("tso_min_consec", "<i4"), ("tso_min_two_best", "<i4")]
 )
 CHIMERA_RESULT_DTYPE = np.dtype([("pos", "<i4", (2,)), ("n_split", "u1"), ("reason", "u1", (2,)), ("flags", "u1"),
                                  ("n_matches", "<i4")])
@@ -1067,7 +1068,9 @@ class RunKnobs(ctypes.Structure):
                 ("adapter3p_complete_max_mm", ctypes.c_int32), ("adapter5p", ctypes.c_char * 32), ("adapter5p_complete", ctypes.c_char * 32),
                 ("adapter5p_max_mm", ctypes.c_int32), ("adapter5p_complete_max_mm", ctypes.c_int32), ("adapter5p_window", ctypes.c_int32),
                 ("adapter3p5_complete", ctypes.c_char * 32), ("adapter3p5_complete_max_mm", ctypes.c_int32), ("tso_complete", ctypes.c_char * 32),
-                ("tso_complete_max_mm", ctypes.c_int32), ("umi_length", ctypes.c_int32), ("reserved", ctypes.c_int32 * 7)]
+                ("tso_complete_max_mm", ctypes.c_int32), ("umi_length", ctypes.c_int32), ("tso_scan", ctypes.c_char * 20),
+                ("tso_scan_max_mm", ctypes.c_int32), ("tso_scan_min_consec", ctypes.c_int32), ("tso_scan_min_two_best", ctypes.c_int32),
+                ("tso_scan_window", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
 
     def as_dict(self):
         out = {}
@@ -1093,6 +1096,9 @@ KNOB_FIELDS = {
     "threeprimeadapter_for5pBarcoding/maxCompleteSeqNeedlemanMismatches": "adapter3p5_complete_max_mm",
     "tso_for3pBarcoding/sequence_complete": "tso_complete", "tso_for3pBarcoding/maxCompleteSeqNeedlemanMismatches": "tso_complete_max_mm",
     "umis/umi_length": "umi_length",
+    "tso_for3pBarcoding/sequence": "tso_scan", "tso_for3pBarcoding/maxNeedlemanMismatches": "tso_scan_max_mm",
+    "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": "tso_scan_min_consec",
+    "tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches": "tso_scan_min_two_best", "tso_for3pBarcoding/windowForTSOsearch": "tso_scan_window",
 }
 
 
@@ -1115,8 +1121,8 @@ def run_knobs(**overrides):
                 raise SmiError(f"{name} = {v!r}: not a number")
         else:
             b = v.encode() if isinstance(v, str) else bytes(v)
-            if len(b) > 31:
-                raise SmiError(f"{name}: sequence of {len(b)} bases (this build: up to 27)")
+            if len(b) > ctypes.sizeof(t) - 1:
+                raise SmiError(f"{name}: sequence of {len(b)} bases (this build: up to {27 if ctypes.sizeof(t) == 32 else 16} here)")
             setattr(k, f, b)
     return k
 

@@ -35,6 +35,7 @@ def test_shipped_defaults_are_the_knob_defaults(cli, lib):
     assert (k["adapter5p"], k["adapter5p_complete"], k["adapter5p_max_mm"], k["adapter5p_complete_max_mm"], k["adapter5p_window"]) == ("CTTCCGATCT", "CTACACGACGCTCTTCCGATCT", 3, 5, 110)
     assert (k["adapter3p5_complete"], k["adapter3p5_complete_max_mm"], k["tso_complete"], k["tso_complete_max_mm"], k["umi_length"]) == \
         ("AAGCAGTGGTATCAACGCAGAGTAC", 5, "AAGCAGTGGTATCAACGCAGAGTACAT", 6, 12)
+    assert (k["tso_scan"], k["tso_scan_max_mm"], k["tso_scan_min_consec"], k["tso_scan_min_two_best"], k["tso_scan_window"]) == ("AACGCAGAGTACATGG", 5, 8, 12, 90)
 
 
 def test_the_reference_shipped_file_parses_to_the_defaults(cli, lib):
@@ -62,7 +63,9 @@ def test_run_time_knobs_reach_the_library_structure(cli, lib, tmp_path):
                              "<fiveprimeadapter_for5pBarcoding><AdapterSearchWindow>90</AdapterSearchWindow><maxNeedlemanMismatches>4</maxNeedlemanMismatches></fiveprimeadapter_for5pBarcoding>"
                              "<threeprimeadapter_for5pBarcoding><sequence>ACGT</sequence><maxCompleteSeqNeedlemanMismatches>7</maxCompleteSeqNeedlemanMismatches></threeprimeadapter_for5pBarcoding>"
                              "<tso_for3pBarcoding><sequence_complete>AAGCAGTGGTATCAACGCAGAGTGAAT</sequence_complete><maxCompleteSeqNeedlemanMismatches>8</maxCompleteSeqNeedlemanMismatches>"
-                             "<offsetTSOend>3</offsetTSOend></tso_for3pBarcoding>"
+                             "<offsetTSOend>3</offsetTSOend><sequence>AACGCAGAGTGAATGG</sequence><maxNeedlemanMismatches>4</maxNeedlemanMismatches>"
+                             "<minTSO_NeedlemanConsecutiveMatches>7</minTSO_NeedlemanConsecutiveMatches><minTSO_TwoBestConsecutiveMatches>11</minTSO_TwoBestConsecutiveMatches>"
+                             "<windowForTSOsearch>70</windowForTSOsearch></tso_for3pBarcoding>"
                              "<tso_for5pBarcoding><sequence>ACGTACGT</sequence></tso_for5pBarcoding>"
                              "<umis><umi_length>10</umi_length><umi_completelinkclusteringED>1</umi_completelinkclusteringED><umi_singlelinkclusteringED>0</umi_singlelinkclusteringED></umis>"
                              "<barcodes><distance_from_read_end_for_grouping>80</distance_from_read_end_for_grouping><max_GenomeDistance_forGrouping>300</max_GenomeDistance_forGrouping></barcodes>")
@@ -73,12 +76,16 @@ def test_run_time_knobs_reach_the_library_structure(cli, lib, tmp_path):
     assert (k["adapter3p"], k["adapter3p_complete"], k["adapter3p_max_mm"], k["adapter3p_complete_max_mm"]) == ("AAGAGACAGT", "GTCAGATGTGTATAAGAGACAG", 2, 4)
     assert (k["adapter5p_window"], k["adapter5p_max_mm"], k["adapter3p5_complete_max_mm"]) == (90, 4, 7)
     assert (k["tso_complete"], k["tso_complete_max_mm"], k["umi_length"]) == ("AAGCAGTGGTATCAACGCAGAGTGAAT", 8, 10)
+    assert (k["tso_scan"], k["tso_scan_max_mm"], k["tso_scan_min_consec"], k["tso_scan_min_two_best"], k["tso_scan_window"]) == ("AACGCAGAGTGAATGG", 4, 7, 11, 70)
     assert cli.host_knobs_from(knobs, cli.HOST_KNOBS_SCAN) == dict(min_count_fold=20, cells_fold_below_max=200)
     assert cli.host_knobs_from(knobs, cli.HOST_KNOBS_UMI) == dict(umi_length=10, complete_link_ed=1, single_link_ed=0, grouping_distance=80, max_dist=300)
     # what the chunk workers derive from them, pass by pass (Parser.java:L99,L134-136)
     cfg1 = np.zeros(1, dtype=lib.SCAN_CONFIG_DTYPE)
     lib.load_library().smi_scan_config_from_knobs(__import__("ctypes").byref(cli.run_knobs_from(knobs, path)), 1, 0, 0, cfg1.ctypes.data)
     assert (int(cfg1["adapter_len"][0]), int(cfg1["max_mismatches"][0]), int(cfg1["min_read_length"][0]), int(cfg1["min_mean_bc_qv"][0])) == (22, 2, 150, 10)
+    code = dict(A=1, G=2, C=4, T=8)   # the read scan's TSO as 4-bit codes, its window and limits
+    assert [int(x) for x in cfg1["tso4"][0]] == [code[c] for c in "AACGCAGAGTGAATGG"]
+    assert (int(cfg1["tso_window"][0]), int(cfg1["tso_max_mismatches"][0]), int(cfg1["tso_min_consec"][0]), int(cfg1["tso_min_two_best"][0])) == (70, 4, 7, 11)
     cfg5 = np.zeros(1, dtype=lib.SCAN_CONFIG_DTYPE)
     lib.load_library().smi_scan_config_from_knobs(__import__("ctypes").byref(cli.run_knobs_from(knobs, path)), 2, 1, 1, cfg5.ctypes.data)
     assert (int(cfg5["adapter_len"][0]), int(cfg5["max_mismatches"][0]), int(cfg5["adapter_search_window"][0]), int(cfg5["five_prime"][0]), int(cfg5["dont_search_polya"][0])) == (10, 5, 90, 1, 1)
@@ -87,8 +94,6 @@ def test_run_time_knobs_reach_the_library_structure(cli, lib, tmp_path):
 @pytest.mark.parametrize("body,needle", [
     ("<readscanner><testPlusMinusPos>3</testPlusMinusPos></readscanner>", "readscanner/testPlusMinusPos"),
     ("<barcodes><cell_bc_length>14</cell_bc_length></barcodes>", "barcodes/cell_bc_length"),
-    ("<tso_for3pBarcoding><sequence>AACGCAGAGTACATGGG</sequence></tso_for3pBarcoding>", "tso_for3pBarcoding/sequence"),
-    ("<tso_for3pBarcoding><windowForTSOsearch>100</windowForTSOsearch></tso_for3pBarcoding>", "tso_for3pBarcoding/windowForTSOsearch"),
     ("<readscanner><seq_prefix>SEQ=</seq_prefix></readscanner>", "readscanner/seq_prefix"),
     ("<readscanner><runningasdemon>true</runningasdemon></readscanner>", "readscanner/runningasdemon"),
 ])
@@ -103,6 +108,8 @@ def test_compiled_in_knobs_are_refused_by_name(cli, tmp_path, body, needle):
     ("<tso_for3pBarcoding><sequence_complete>AAGCAGTGGTATCAACGCAGAGTACATGG</sequence_complete></tso_for3pBarcoding>", "tso_for3pBarcoding/sequence_complete"),
     ("<polyAT><internalpATlength>18</internalpATlength></polyAT>", "polyAT/internalpATlength"),
     ("<umis><umi_length>16</umi_length></umis>", "umis/umi_length"),
+    ("<tso_for3pBarcoding><sequence>AACGCAGAGTACATGGG</sequence></tso_for3pBarcoding>", "tso_for3pBarcoding/sequence"),       # 17 bases: the build aligns 16
+    ("<tso_for3pBarcoding><windowForTSOsearch>130</windowForTSOsearch></tso_for3pBarcoding>", "tso_for3pBarcoding/windowForTSOsearch"),
     ("<readscanner><minReadLength>many</minReadLength></readscanner>", "readscanner/minReadLength"),
     ("<fiveprimeadapter_for5pBarcoding><AdapterSearchWindow>170</AdapterSearchWindow></fiveprimeadapter_for5pBarcoding>", "AdapterSearchWindow"),
 ])

@@ -35,6 +35,7 @@ def _oracle_scan_params(sor, k):
     par = sor.default_scan_params()
     par["min_read_length"], par["polya_len"], par["polya_frac"], par["window_polya"] = k.min_read_length, k.polya_len, k.polya_frac, k.window_polya
     par["min_adapter_3p_matches"], par["min_mean_bc_qv"], par["min_mean_read_qv"] = k.min_adapter_3p_matches, k.min_mean_bc_qv, k.min_mean_read_qv
+    sor.set_tso_params(par, k.tso_scan.decode(), k.tso_scan_window, k.tso_scan_max_mm, k.tso_scan_min_consec, k.tso_scan_min_two_best)
     return par
 
 
@@ -45,6 +46,10 @@ KNOB_SETS_3P = [
     dict(min_adapter_3p_matches=10, adapter3p_max_mm=4),
     dict(adapter3p=AD_OTHER[-10:], adapter3p_complete=AD_OTHER),
     dict(adapter3p=AD_OTHER[-10:], adapter3p_complete=AD_OTHER, adapter3p_max_mm=4, min_read_length=300, polya_len=12, polya_frac=0.8, window_polya=120),
+    # the TSO of the read scan (tso_for3pBarcoding: sequence, maxNeedlemanMismatches, the two rescue rules, windowForTSOsearch): the generic kernels
+    dict(tso_scan_max_mm=3), dict(tso_scan_max_mm=7, tso_scan_min_consec=6), dict(tso_scan_min_consec=11, tso_scan_min_two_best=9), dict(tso_scan_window=60),
+    dict(tso_scan_window=112, tso_scan_max_mm=4), dict(tso_scan=TSO_OTHER[-14:] + "GG", tso_complete=TSO_OTHER),
+    dict(tso_scan="ACGTTGCAAGGCTTAC", tso_scan_window=40, tso_scan_max_mm=6, tso_scan_min_consec=5, tso_scan_min_two_best=10, min_read_length=180),
 ]
 
 
@@ -58,7 +63,7 @@ def test_scan_knobs_3p_equal_oracle(pkg, synth, sor, gpu_ctx, over):
     wl = synth.make_whitelist(50_000, seed=1201)
     used = synth.pick_used(wl, 300, seed=1202)
     n = 3000
-    reads = synth.gen_reads(n, used, seed=1203, n_rate=0.003, adapter_complete=k.adapter3p_complete.decode())
+    reads = synth.gen_reads(n, used, seed=1203, n_rate=0.003, adapter_complete=k.adapter3p_complete.decode(), tso_complete=k.tso_complete.decode())
     ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
     found = {}
     for pass_no in (2, 1):
@@ -86,7 +91,8 @@ def test_scan_knobs_change_results(pkg, synth, sor, gpu_ctx):
     ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
     base = _scan_with(pkg, gpu_ctx, ra, qa, offs, gpu_ctx.scan_config(1))
     assert (base == _scan_with(pkg, gpu_ctx, ra, qa, offs, gpu_ctx.scan_config(1, knobs=lib.run_knobs()))).all()
-    for over in (dict(adapter3p_max_mm=1), dict(min_read_length=600), dict(min_mean_bc_qv=14), dict(min_adapter_3p_matches=12)):
+    for over in (dict(adapter3p_max_mm=1), dict(min_read_length=600), dict(min_mean_bc_qv=14), dict(min_adapter_3p_matches=12), dict(tso_scan_max_mm=2),
+                 dict(tso_scan_window=40), dict(tso_scan="AACGCAGAGTGAATGG")):
         other = _scan_with(pkg, gpu_ctx, ra, qa, offs, gpu_ctx.scan_config(1, knobs=lib.run_knobs(**over)))
         assert (other != base).any(), over
 
@@ -322,7 +328,9 @@ def test_knobs_outside_the_build_are_refused_by_name(pkg, gpu_ctx):
     lib = __import__("importlib").import_module("sicelore_amd.lib")
     for over, word in ((dict(adapter3p="CTTCCGATCTA"), "adapter_for3pBarcoding/sequence"), (dict(tso_complete="AAGCAGTGGTATCAACGCAGAGTACATGG"), "tso_for3pBarcoding/sequence_complete"),
                        (dict(umi_length=16), "umis/umi_length"), (dict(internal_pat_len=20), "polyAT/internalpATlength"), (dict(adapter3p="CTTCCGATCN"), "adapter_for3pBarcoding/sequence"),
-                       (dict(window_polya=170), "windowSearchForPolyA"), (dict(adapter5p_window=170), "AdapterSearchWindow")):
+                       (dict(window_polya=170), "windowSearchForPolyA"), (dict(adapter5p_window=170), "AdapterSearchWindow"),
+                       (dict(tso_scan="AACGCAGAGTACATGGG"), "tso_for3pBarcoding/sequence"), (dict(tso_scan="AACGCAGAGTACATG"), "tso_for3pBarcoding/sequence"),
+                       (dict(tso_scan_window=130), "tso_for3pBarcoding/windowForTSOsearch"), (dict(tso_scan_max_mm=-1), "tso_for3pBarcoding/maxNeedlemanMismatches")):
         with pytest.raises(lib.SmiError) as e:
             gpu_ctx.set_knobs(lib.run_knobs(**over))
         assert word in str(e.value), (over, str(e.value))
@@ -333,6 +341,10 @@ def test_knobs_outside_the_build_are_refused_by_name(pkg, gpu_ctx):
     with pytest.raises(lib.SmiError) as e:
         gpu_ctx.scan_device(torch.zeros((28, 2), dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"), 1,
                             gpu_ctx.scan_config(2, knobs=lib.run_knobs(min_read_length=100)), torch.zeros((1, 8), dtype=torch.int32, device="cuda"))
+    assert "readscanner/minReadLength" in str(e.value)
+    with pytest.raises(lib.SmiError) as e:   # the TSO scan of 3' barcoding cuts windowForTSOsearch + 26 bases (scanReadForTSOs L128-131): 138 here, above the polyA finder's 125
+        gpu_ctx.scan_device(torch.zeros((28, 2), dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"), 1,
+                            gpu_ctx.scan_config(2, knobs=lib.run_knobs(min_read_length=130, window_polya=100, tso_scan_window=112)), torch.zeros((1, 8), dtype=torch.int32, device="cuda"))
     assert "readscanner/minReadLength" in str(e.value)
     gpu_ctx.scan_device(torch.zeros((28, 2), dtype=torch.int32, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda"), 1,
                         gpu_ctx.scan_config(2, knobs=lib.run_knobs(min_read_length=150), five_prime=True, dont_search_polya=True),

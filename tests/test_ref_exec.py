@@ -308,8 +308,10 @@ def knob_values(sec):
              internal_pat_len=15, internal_pat_frac=0.70, adapter3p="CTTCCGATCT", adapter3p_complete="CTACACGACGCTCTTCCGATCT", adapter3p_max_mm=3,
              adapter3p_complete_max_mm=5, adapter5p="CTTCCGATCT", adapter5p_complete="CTACACGACGCTCTTCCGATCT", adapter5p_max_mm=3, adapter5p_complete_max_mm=5,
              adapter5p_window=110, adapter3p5_complete="AAGCAGTGGTATCAACGCAGAGTAC", adapter3p5_complete_max_mm=5, tso_complete="AAGCAGTGGTATCAACGCAGAGTACAT",
-             tso_complete_max_mm=6, umi_length=12)
-    names = {"readscanner/minReadLength": "min_read_length", "readscanner/minMeanBCqv": "min_mean_bc_qv", "readscanner/minMeanReadqv": "min_mean_read_qv",
+             tso_complete_max_mm=6, umi_length=12, tso_scan="AACGCAGAGTACATGG", tso_scan_max_mm=5, tso_scan_min_consec=8, tso_scan_min_two_best=12, tso_scan_window=90)
+    names = {"tso_for3pBarcoding/sequence": "tso_scan", "tso_for3pBarcoding/maxNeedlemanMismatches": "tso_scan_max_mm",
+             "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": "tso_scan_min_consec", "tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches": "tso_scan_min_two_best",
+             "tso_for3pBarcoding/windowForTSOsearch": "tso_scan_window","readscanner/minReadLength": "min_read_length", "readscanner/minMeanBCqv": "min_mean_bc_qv", "readscanner/minMeanReadqv": "min_mean_read_qv",
              "readscanner/minAdapter3pMatches": "min_adapter_3p_matches", "polyAT/polyATlength": "polya_len", "polyAT/fractionATInPolyAT": "polya_frac",
              "polyAT/windowSearchForPolyA": "window_polya", "polyAT/internalpATlength": "internal_pat_len", "polyAT/internalFractionATInPolyAT": "internal_pat_frac",
              "adapter_for3pBarcoding/sequence": "adapter3p", "adapter_for3pBarcoding/sequence_complete": "adapter3p_complete",
@@ -340,6 +342,7 @@ def oracle_chunk(sor, bset, rank_of, sec, case):
     if sec.get("knobs"):       # config.xml with other knob values (round 6): the scan's and the splitter's parameters from them
         scan_par = sor.default_scan_params()
         scan_par["min_read_length"], scan_par["polya_len"], scan_par["polya_frac"], scan_par["window_polya"] = kv["min_read_length"], kv["polya_len"], kv["polya_frac"], kv["window_polya"]
+        sor.set_tso_params(scan_par, kv["tso_scan"], kv["tso_scan_window"], kv["tso_scan_max_mm"], kv["tso_scan_min_consec"], kv["tso_scan_min_two_best"])
         par.internal_pat_len, par.internal_pat_frac, par.window_polya = kv["internal_pat_len"], kv["internal_pat_frac"], kv["window_polya"]
     if sec.get("polya"):       # -p / -f / -w: the finder's parameters; the splitter keeps windowSearchForPolyA + 70 away from the read ends
         scan_par = sor.default_scan_params()
@@ -449,6 +452,19 @@ def test_pass2_chunks_under_other_config_knobs_equal_reference_bytecode(sor):
     for sec in secs:
         n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
         assert n_in >= 150 and n_rec >= 140 and n_passed >= 40 and n_bc >= 30, (sec["knobs"], n_in, n_rec, n_passed, n_bc)
+        with pytest.raises(AssertionError):
+            _check_chunk_section(sor, dict(sec, knobs=None))
+
+
+def test_pass2_chunks_under_other_tso_scan_parameters_equal_reference_bytecode(sor):
+    """pass2t (round 6): the wide 3' reads through Parser.call with another TSO for the READ SCAN in config.xml (sequence, maxNeedlemanMismatches, the two
+    rescue rules, windowForTSOsearch: scanReadForTSOs / scanForTSO): the oracle with the same values writes the same records (the T= field, the TSO flags
+    behind the statistics); with the shipped values it does not"""
+    secs = load("pass2t")["sections"]
+    assert len(secs) == 2 and all(any(k.startswith("tso_for3pBarcoding/") for k in s_["knobs"]) for s_ in secs)
+    for sec in secs:
+        n_in, n_rec, n_passed, n_bc, kinds, _ = _check_chunk_section(sor, sec)
+        assert n_in >= 140 and n_rec >= 140 and n_passed >= 80 and n_bc >= 60, (sec["knobs"], n_in, n_rec, n_passed, n_bc)
         with pytest.raises(AssertionError):
             _check_chunk_section(sor, dict(sec, knobs=None))
 

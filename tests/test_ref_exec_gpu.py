@@ -63,7 +63,7 @@ def test_chunk_worker_records_equal_reference_bytecode(pkg, gpu_ctx, name, packe
 
 
 @pytest.mark.parametrize("packed", [False, True], ids=["text", "packed"])
-@pytest.mark.parametrize("name", ["pass2w_3p", "pass2w_3p_ed2", "pass2w_5p", "pass2w_5p_polya", "pass2x_3p", "pass2x_5p", "pass2p", "pass2k"])
+@pytest.mark.parametrize("name", ["pass2w_3p", "pass2w_3p_ed2", "pass2w_5p", "pass2w_5p_polya", "pass2x_3p", "pass2x_5p", "pass2p", "pass2k", "pass2t"])
 def test_chunk_worker_equals_parser_call(pkg, gpu_ctx, name, packed):
     """whole chunks (five reads) through the chunk workers with the chimera splitter on, against the records the reference's
     Parser.call left in the chunk (tests/golden/ref_exec_pass2w_*.json: >= 500 input reads per configuration, fragments of split
@@ -71,7 +71,7 @@ def test_chunk_worker_equals_parser_call(pkg, gpu_ctx, name, packed):
     with open(os.path.join(GOLD, f"ref_exec_{name}.json")) as f:
         secs = json.load(f)["sections"]
     for sec in secs:     # (pass2x_*: a section of targeted reads and one with --trimfastq; pass2p: -p / -f / -w, a 3' and a 5' section;
-        #                   pass2k, round 6: the reference started with other values of config.xml's knobs -- the context gets the same: smi_ctx_set_knobs)
+        #                   pass2k / pass2t, round 6: the reference started with other values of config.xml's knobs (pass2t: the read scan's TSO) -- the context gets the same: smi_ctx_set_knobs)
         if sec.get("polya"):
             gpu_ctx.set_polya(*sec["polya"])
         if sec.get("knobs"):

@@ -1122,6 +1122,21 @@ def gen_pass2k(g):
     return a
 
 
+def gen_pass2t(g):
+    """round 6: the wide 3' reads through Parser.call with OTHER TSO PARAMETERS OF THE READ SCAN in config.xml (tso_for3pBarcoding: sequence -- two bases of the
+    shipped one changed --, maxNeedlemanMismatches, the two rescue rules, windowForTSOsearch): PolyATadapterAnalyzer_3pBCUMI.scanReadForTSOs /
+    PolyATadapterAnalyzerBase.scanForTSO with the values the product takes at run time (smi_run_knobs.tso_scan*)"""
+    kt = {"tso_for3pBarcoding/sequence": "AACGCAGAGTGAATGG", "tso_for3pBarcoding/maxNeedlemanMismatches": 4, "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": 7,
+          "tso_for3pBarcoding/minTSO_TwoBestConsecutiveMatches": 11, "tso_for3pBarcoding/windowForTSOsearch": 70}
+    ku = {"tso_for3pBarcoding/maxNeedlemanMismatches": 7, "tso_for3pBarcoding/minTSO_NeedlemanConsecutiveMatches": 10, "tso_for3pBarcoding/windowForTSOsearch": 110}
+    a = gen_pass2w(g, False, 1, False, 4101, n_chunks=30, per_chunk=5, knobs=kt, note=", config.xml with another TSO for the read scan (see `knobs`)")
+    b = gen_pass2w(g, False, 1, False, 4101, n_chunks=30, per_chunk=5, knobs=ku, note=", config.xml with other limits and another window of the read scan's TSO (see `knobs`)")
+    a["sections"] += b["sections"]
+    a["_steps"] += b["_steps"]
+    merge_hits(a["_hits"], b["_hits"])
+    return a
+
+
 def gen_pass2w_3p_ed2(g):
     return gen_pass2w(g, False, 2, False, 4102)
 
@@ -3028,7 +3043,7 @@ def gen_auxorder(g, seed=2222):
     return out
 
 
-SECTIONS = {"pass2k": gen_pass2k, "umi_3p_len10": gen_umi_3p_len10, "umi_5p_len10": gen_umi_5p_len10, "auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
+SECTIONS = {"pass2t": gen_pass2t, "pass2k": gen_pass2k, "umi_3p_len10": gen_umi_3p_len10, "umi_5p_len10": gen_umi_5p_len10, "auxorder": gen_auxorder, "bamorder": gen_bamorder, "clusterpos": gen_clusterpos, "samtags": gen_samtags, "genecounts": gen_genecounts, "cluster_own": gen_cluster_own, "pass1": gen_pass1, "cluster": gen_cluster, "group": gen_group, "finalize": gen_finalize, "gene": gen_gene, "gene_gtf": gen_gene_gtf, "twobit": gen_twobit, "onebyte": gen_onebyte, "nw": gen_nw, "lev": gen_lev, "bcmatch": gen_bcmatch, "polyat": gen_polyat, "polyat_params": gen_polyat_params,
             "pass2_3p": gen_pass2_3p, "pass2_3p_ed2": gen_pass2_3p_ed2, "pass2_5p": gen_pass2_5p, "pass2_5p_polya": gen_pass2_5p_polya,
             "umi_3p": gen_umi_3p, "umi_5p": gen_umi_5p, "chimera_3p": gen_chimera_3p, "stats_print": gen_stats_print,
             "pass2w_3p": gen_pass2w_3p, "pass2w_3p_ed2": gen_pass2w_3p_ed2, "pass2w_5p": gen_pass2w_5p, "pass2w_5p_polya": gen_pass2w_5p_polya,
