@@ -256,6 +256,47 @@ def check_scan_params(pkg, synth, sor, ctx, seed):
     return ok, f"scan_params seed={seed} polya={polya} found={found}"
 
 
+def check_scan_knobs(pkg, synth, sor, ctx, seed):
+    """round 6: K-SCAN under a random set of config.xml's scan knobs (smi_run_knobs: the read scan's TSO -- a random 16-mer or the shipped one with a few bases
+    changed --, its window, mismatch limit and rescue rules; the adapter's mismatch limit; minAdapter3pMatches; the quality thresholds) against the oracle
+    with the same values, pass 2 and pass 1 and the T-rich reads"""
+    from test_knobs_gpu import _oracle_scan_params, _scan_with
+    from test_scan_gpu import _ascii_batch, _compare, _t_rich_reads
+
+    lib = importlib.import_module(graft.PKG_NAME + ".lib")
+    rng = np.random.default_rng(seed)
+    tso = list("AACGCAGAGTACATGG")
+    if rng.integers(0, 3) == 0:
+        tso = list(rng.choice(list("ACGT"), 16))
+    else:
+        for p in rng.choice(16, int(rng.integers(0, 4)), replace=False):
+            tso[int(p)] = str(rng.choice(list("ACGT")))
+    over = dict(tso_scan="".join(tso), tso_scan_window=int(rng.integers(16, 113)), tso_scan_max_mm=int(rng.integers(0, 9)), tso_scan_min_consec=int(rng.integers(4, 14)),
+                tso_scan_min_two_best=int(rng.integers(8, 17)), adapter3p_max_mm=int(rng.integers(0, 6)), min_adapter_3p_matches=int(rng.integers(4, 11)),
+                min_mean_bc_qv=int(rng.integers(5, 15)), min_mean_read_qv=int(rng.integers(5, 15)), min_read_length=int(rng.choice([180, 200, 400])))
+    k = lib.run_knobs(**over)
+    par = _oracle_scan_params(sor, k)
+    wl = synth.make_whitelist(20_000, seed=seed)
+    used = synth.pick_used(wl, 200, seed=seed + 1)
+    n = 2000
+    reads = synth.gen_reads(n, used, seed=seed + 2, n_rate=float(rng.choice([0.0, 0.003])), err=float(rng.choice([0.03, 0.063, 0.1])))
+    ra, qa, offs = _ascii_batch(synth, reads, n, short_every=40)
+    found = 0
+    try:
+        for pass_no in (2, 1):
+            got = _scan_with(pkg, ctx, ra, qa, offs, ctx.scan_config(pass_no, knobs=k))
+            ad = (k.adapter3p if pass_no == 2 else k.adapter3p_complete).decode()
+            st, exp = sor.scan_batch_3p(ra, qa, offs, ad, max_mm=k.adapter3p_max_mm, params=par, n_threads=16)
+            found += _compare(got, st, exp, pass1=True)
+        ra, qa, offs = _t_rich_reads(3000, seed=seed + 3)
+        got = _scan_with(pkg, ctx, ra, qa, offs, ctx.scan_config(2, knobs=k))
+        st, exp = sor.scan_batch_3p(ra, qa, offs, k.adapter3p.decode(), max_mm=k.adapter3p_max_mm, params=par, n_threads=16)
+        _compare(got, st, exp, pass1=True)
+    except AssertionError as e:
+        return False, f"scan_knobs seed={seed} {over}: {e}"
+    return True, f"scan_knobs seed={seed} tso={over['tso_scan']} w={over['tso_scan_window']} mm={over['tso_scan_max_mm']} found={found}"
+
+
 def main():
     minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     pkg = graft.load_package()
@@ -270,6 +311,7 @@ def main():
                     if os.environ.get("SMI_FUZZ_LEGS") == "r3" else [check_host_inflate, check_bam_writer] if os.environ.get("SMI_FUZZ_LEGS") == "host"
                     else [check_umi_pairs, check_umi_stage] if os.environ.get("SMI_FUZZ_LEGS") == "umi"
                     else [check_scan_params] if os.environ.get("SMI_FUZZ_LEGS") == "scan"
+                    else [check_scan_knobs] if os.environ.get("SMI_FUZZ_LEGS") == "knobs"
                     else [check_umi_pairs, check_scan_params, check_bc, check_records, check_packed, check_umi_stage, check_deflate, check_inflate, check_host_inflate, check_bam_writer]):
             ok, msg = leg(pkg, synth, sor, ctx, seed)
             print(("ok   " if ok else "FAIL ") + msg, flush=True)
