@@ -352,6 +352,24 @@ __device__ __forceinline__ uint64_t gate64(const uint32_t *planes, int owner, in
     return two;
 }
 
+// the same gate for 32 scan positions (the second chunk of the TSO scan: positions 65 .. 90 of its window)
+template <int N, typename F>
+__device__ __forceinline__ uint32_t gate32(const uint32_t *planes, int owner, int b, F code) {
+    uint32_t any = 0, two = 0;
+    uint32_t m0 = match32(planes, owner, code(0), b), m1 = match32(planes, owner, code(1), b + 1), m2 = match32(planes, owner, code(2), b + 2);
+#pragma unroll
+    for (int i = 0; i + 3 < N; i++) {
+        const uint32_t m3 = match32(planes, owner, code(i + 3), b + i + 3);
+        const uint32_t k = m0 & m1 & m2 & m3;
+        two |= any & k;
+        any |= k;
+        m0 = m1;
+        m1 = m2;
+        m2 = m3;
+    }
+    return two;
+}
+
 __device__ __forceinline__ uint64_t keep_low(uint64_t m, int n_bits) {
     return n_bits <= 0 ? 0ull : (n_bits >= 64 ? m : (m & ((1ull << n_bits) - 1ull)));
 }
@@ -482,9 +500,14 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
                 uint64_t tm[2] = {0, 0};
                 if (active && long_enough && !FP && !SMI_ABLATED(8)) {
                     // TSO: positions 1 .. min(116 - 16, windowForTSOsearch = 90)  (scanForTSO L325); the 5' analyzer has no TSO scan
+                    if (SHIP) {  // window 90: 64 positions + 26 of the next 32 (a 64-position gate for those costs twice the operations)
+                        tm[0] = gate64<16>(planes, tid, 0, [](int i) { return tso4(i); });
+                        tm[1] = (uint64_t)(gate32<16>(planes, tid, 64, [](int i) { return tso4(i); }) & ((1u << (90 - 64)) - 1u));
+                    } else {
 #pragma unroll
-                    for (int ch = 0; ch < 2; ch++)
-                        tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [&](int i) { return SHIP ? tso4(i) : P.t4(i); }), (SHIP ? 90 : P.tso_window) - ch * 64);
+                        for (int ch = 0; ch < 2; ch++)
+                            tm[ch] = keep_low(gate64<16>(planes, tid, ch * 64, [&](int i) { return P.t4(i); }), P.tso_window - ch * 64);
+                    }
                 }
                 if (SHIP && !SMI_ABLATED(16)) {
                     // Exact pre-filter of the ISOLATED TSO candidates.  A candidate's alignment matters in two ways only: it may be
