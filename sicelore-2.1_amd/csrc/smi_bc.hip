@@ -1687,6 +1687,24 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         c[h] = child_of(root, pe[h] & 15, re[h], post1);
                         lows[e] = val[h] ? c[h].low : K;  // invalid slots mirror the root (never created)
                     }
+                    // Filter bit and membership of EVERY valid child, before any bookkeeping (kFilter: short used lists).  A child that is never
+                    // created is a copy of one that is, so "no valid child passes the filter and none is a barcode" says the same of the created ones:
+                    // then levels 1 and 2 have nothing to find, and the dedup table, the creation order and the expansion order -- most of this
+                    // kernel's work per window -- are not needed.  (A window that is itself a barcode asks its children for a SECOND barcode in
+                    // reach: the exact hits of a read, a fifth of the windows that get here, leave through this door.)
+                    hit0 = member(P, K);
+                    bool pany[2] = {false, false}, mem1[2] = {false, false};
+                    if (kFilter) {
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const bool k_counts = hit0 && !(re[h] == 7 && pe[h] == 0);
+                            const uint32_t *tab = k_counts ? P.n2 : P.n1;
+                            const bool live = val[h] && c[h].g == 0u;
+                            pany[h] = live && ((tab[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u);
+                            mem1[h] = live && member(P, c[h].low);
+                        }
+                    }
+                    if (!kFilter || __ballot(pany[0] || pany[1] || mem1[0] || mem1[1])) {  // (wave-uniform)
                     // clear the tables
 #pragma unroll
                     for (int k = 0; k < kTabSlots / 64; k++) {
@@ -1772,7 +1790,6 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         for (int h = 0; h < 2; h++)
                             pass_h[h] = pass_h[h] && ((P.nb[c[h].low >> 5] >> (c[h].low & 31u)) & 1u);
                     }
-                    hit0 = member(P, K);
                     if (kFilter) {
                         // K a barcode: its children have K as a neighbour by construction (substitutions; insertion children through the
                         // "base inserted, last dropped" members of K's neighbourhood or, behind position 14, as substitutions of the last
@@ -1781,9 +1798,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
                             if (!created[h]) continue;
-                            const bool k_counts = hit0 && !(re[h] == 7 && pe[h] == 0);
-                            const uint32_t *tab = k_counts ? P.n2 : P.n1;
-                            pass_h[h] = c[h].g == 0u && ((tab[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u);
+                            pass_h[h] = pany[h];  // (read above, for every valid child)
                             passf[ord[h]] = pass_h[h] ? 1u : 0u;
                         }
                     }
@@ -1801,8 +1816,8 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         pm1 = n_items <= 64 ? 0ull : (n_items >= 128 ? ~0ull : ((1ull << (n_items - 64)) - 1ull));
                     }
                     // ---- probes of level 0 and 1 (only created children are ever probed) ----------------------
-                    const bool h1a = created[0] && c[0].g == 0u && member(P, c[0].low);
-                    const bool h1b = created[1] && c[1].g == 0u && member(P, c[1].low);
+                    const bool h1a = created[0] && (kFilter ? mem1[0] : (c[0].g == 0u && member(P, c[0].low)));
+                    const bool h1b = created[1] && (kFilter ? mem1[1] : (c[1].g == 0u && member(P, c[1].low)));
                     const unsigned long long ha = __ballot(h1a), hb = __ballot(h1b);
                     if (ha | hb) {
                         const int e = ha ? __builtin_ctzll(ha) : 64 + __builtin_ctzll(hb);
@@ -2009,6 +2024,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                             }
                         }
                     }
+                    }  // levels 1 and 2
                 }
                 c_rs[q] = K;
                 c_bc[3 * q] = bc0;
