@@ -71,22 +71,36 @@ __device__ __forceinline__ uint32_t n1_member(uint32_t k, int slot) {
     return k;
 }
 __device__ __forceinline__ uint32_t n1_cell(uint32_t x) { return (l1_word(x) << 5) | l1_bit(x); }
+// The same filter a second time, indexed by the LAST nine bases first (round 6).  The 123 children of a window are probed together, and in the layout
+// above -- a 64-byte line per nine-base prefix -- the 52 children mutated at positions 9 .. 15 share the window's own line while the other 71 each
+// have a line of their own: 72 misses per window, and the kernel's L2 misses ran at the memory system's random-access rate.  A child mutated at
+// a position <= 6 keeps nine bases at its END: the substitutions end in the window's bases 7 .. 15, the insertions in 6 .. 14, the deletions in
+// 8 .. 15 + the appended base -- three lines of a suffix-major table for all 56 of them.  Only the 15 children of positions 7 and 8 keep neither end.
+// Both tables hold every member; a child is looked up in the one where its neighbours are.
+__device__ __forceinline__ uint32_t n1_cell_s(uint32_t x) {
+    const uint32_t rest = x >> 18;  // the first seven bases, folded into the nine bits inside the line
+    return ((x & 0x3FFFFu) << 9) | ((rest ^ (rest >> 9)) & 511u);
+}
 // pass 1: owner[cell] = smallest index of a barcode that reaches the cell, n1 bit set
+template <bool kSuffix>
 __global__ void k_set_n1(const uint32_t *__restrict__ keys, size_t n, uint32_t *__restrict__ n1, uint32_t *__restrict__ owner) {
     const size_t total = n * kN1Slots;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t b = (uint32_t)(i / kN1Slots);
-        const uint32_t cell = n1_cell(n1_member(keys[b], (int)(i % kN1Slots)));
+        const uint32_t x = n1_member(keys[b], (int)(i % kN1Slots));
+        const uint32_t cell = kSuffix ? n1_cell_s(x) : n1_cell(x);
         atomicOr(&n1[cell >> 5], 1u << (cell & 31));
         atomicMin(&owner[cell], b);
     }
 }
 // pass 2: a cell that a barcode other than its owner reaches is reached by two
+template <bool kSuffix>
 __global__ void k_set_n2(const uint32_t *__restrict__ keys, size_t n, const uint32_t *__restrict__ owner, uint32_t *__restrict__ n2) {
     const size_t total = n * kN1Slots;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t b = (uint32_t)(i / kN1Slots);
-        const uint32_t cell = n1_cell(n1_member(keys[b], (int)(i % kN1Slots)));
+        const uint32_t x = n1_member(keys[b], (int)(i % kN1Slots));
+        const uint32_t cell = kSuffix ? n1_cell_s(x) : n1_cell(x);
         if (owner[cell] != b) atomicOr(&n2[cell >> 5], 1u << (cell & 31));
     }
 }
@@ -497,13 +511,20 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     ctx->n1_valid = false;
     ctx->nb2_valid = false;
     if (n > 0 && !membership_only && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
-        if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 2 * kL1Words * 4));
-        SMI_HIP(hipMemsetAsync(ctx->n1, 0, 2 * kL1Words * 4, s));
+        // four tables: n1, n2 (prefix-major), n1s, n2s (suffix-major: n1_cell_s); the owner scratch serves one layout after the other
+        if (!ctx->n1) SMI_HIP(hipMalloc((void **)&ctx->n1, 4 * kL1Words * 4));
+        SMI_HIP(hipMemsetAsync(ctx->n1, 0, 4 * kL1Words * 4, s));
         if (!ctx->n1_owner) SMI_HIP(hipMalloc((void **)&ctx->n1_owner, kL1Words * 32 * sizeof(uint32_t)));  // one u32 per cell
-        SMI_HIP(hipMemsetAsync(ctx->n1_owner, 0xFF, kL1Words * 32 * sizeof(uint32_t), s));
         const unsigned g1 = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 64);
-        hipLaunchKernelGGL(k_set_n1, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1, ctx->n1_owner);
-        hipLaunchKernelGGL(k_set_n2, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1_owner, ctx->n1 + kL1Words);
+        SMI_HIP(hipMemsetAsync(ctx->n1_owner, 0xFF, kL1Words * 32 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_set_n1<false>, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1, ctx->n1_owner);
+        hipLaunchKernelGGL(k_set_n2<false>, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1_owner, ctx->n1 + kL1Words);
+        ctx->n1s_valid = !std::getenv("SMI_BC2_ONE_FILTER");  // (cross-check switch: every child through the prefix-major tables)
+        if (ctx->n1s_valid) {
+            SMI_HIP(hipMemsetAsync(ctx->n1_owner, 0xFF, kL1Words * 32 * sizeof(uint32_t), s));
+            hipLaunchKernelGGL(k_set_n1<true>, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1 + 2 * kL1Words, ctx->n1_owner);
+            hipLaunchKernelGGL(k_set_n2<true>, dim3(g1), dim3(256), 0, s, d_keys, n, ctx->n1_owner, ctx->n1 + 3 * kL1Words);
+        }
         SMI_HIP(hipGetLastError());
         ctx->n1_valid = true;
         ctx->nb2_valid = false;
@@ -1614,8 +1635,12 @@ __device__ __forceinline__ void pick_best15(const uint32_t (&bc)[15], const uint
 
 // kTwoStage: dense barcode sets (the whole whitelist): both stages of the top level from t2.  kFilter: short used lists: only the items
 // that P.n1 lets through are expanded (k_set_n1).
-template <bool kTwoStage, bool kFilter>
-__global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
+// kTable: level 2 comes from the neighbourhood table (P.nt) -- the kernel then carries neither the enumerating loop nor its lane masks, and is
+// held at seven waves per SIMD (72 registers, 29 of them spilled): a wavefront works one window at a time through a chain of dependent steps, and the
+// number of waves a SIMD can switch between is what the kernel's time follows -- per 2 M windows against a 5 k list: four waves (126 registers, what the
+// compiler picks) 9.37 ms, five 8.06, six 7.58, seven 7.41, eight (43 spills) 9.25.
+template <bool kTwoStage, bool kFilter, bool kTable = false>
+__global__ __launch_bounds__(256, kTable ? 7 : 1) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
     __shared__ uint32_t s_keys[4][kTabSlots];
     __shared__ uint32_t s_vals[4][kTabSlots];
@@ -1623,6 +1648,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
     __shared__ uint32_t s_ord2e[4][128];
     __shared__ uint32_t s_pass[4][128];
     __shared__ uint32_t s_vpos[4][kTabSlots];
+    __shared__ uint32_t s_res[4][36];  // bc[15] | rs[5] | imd[15]
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     uint32_t *keys = s_keys[wv], *vals = s_vals[wv], *lows = s_low[wv], *ord2e = s_ord2e[wv], *passf = s_pass[wv], *vpos = s_vpos[wv];
@@ -1631,8 +1657,12 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
     const bool fp = five_prime != 0;
     constexpr int OFFS[5] = {0, -1, 1, -2, 2};
     // level-2 child slots of a lane: slot = 8 * position + kind, the same enumeration as level 1 (slots >= 123 unused)
-    LaneMasks mk[2] = {make_masks(lane), make_masks(64 + lane)};
-    if (64 + lane >= 123) mk[1].valid = 0u;
+    LaneMasks mk[2];
+    if (!kTable) {
+        mk[0] = make_masks(lane);
+        mk[1] = make_masks(64 + lane);
+        if (64 + lane >= 123) mk[1].valid = 0u;
+    }
 
     for (size_t rd = wave; rd < n; rd += n_waves) {
         const smi_bc_window w = win[rd];  // wave-uniform (scalar loads)
@@ -1645,9 +1675,10 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
         res.ins_minus_del = 0;
         res.n_matches = 0;
         if (w.flags & SMI_WIN_VALID) {
-            uint32_t c_bc[15];
-            uint32_t c_rs[5];
-            int c_imd[15];
+            // the per-offset answers (wave-uniform) wait for pick_best15 in the wave's LDS, not in 35 registers across the offset loop: the
+            // kernel's register count decides how many waves a SIMD holds, and the waves' dependent chains are what the kernel waits for
+            uint32_t *r_bc = s_res[wv], *r_rs = s_res[wv] + 15;
+            int *r_imd = reinterpret_cast<int *>(s_res[wv] + 20);
             uint32_t present = 0;
             // the two-step filter bits of the five windows: five independent loads in front of the per-offset loop (inside it they
             // would be five dependent round trips per read)
@@ -1698,9 +1729,12 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
                             const bool k_counts = hit0 && !(re[h] == 7 && pe[h] == 0);
-                            const uint32_t *tab = k_counts ? P.n2 : P.n1;
+                            // (children of positions <= 6 in the suffix-major tables, where they share three lines: n1_cell_s)
+                            const bool sfx = P.n1s != nullptr && pe[h] <= 6;
+                            const uint32_t *tab = sfx ? (k_counts ? P.n2s : P.n1s) : (k_counts ? P.n2 : P.n1);
+                            const uint32_t cell = sfx ? n1_cell_s(c[h].low) : n1_cell(c[h].low);
                             const bool live = val[h] && c[h].g == 0u;
-                            pany[h] = live && ((tab[l1_word(c[h].low)] >> l1_bit(c[h].low)) & 1u);
+                            pany[h] = live && ((tab[cell >> 5] >> (cell & 31u)) & 1u);
                             mem1[h] = live && member(P, c[h].low);
                         }
                     }
@@ -1829,7 +1863,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                     // kGroup items (2 * kGroup half-rounds of 64 mutants) are generated, looked up in the dedup table and
                     // tested against the top level TOGETHER: the loads of a group are independent, so their latencies
                     // overlap; the (rare) survivors of the top level are then walked in order, which keeps "first hit".
-                    if (P.nt != nullptr) {
+                    if (kTable || P.nt != nullptr) {
                         // Level 2 from the neighbourhood table (k_set_nt): an item X is not expanded into its 123 children; the bucket of
                         // X lists every mutation that turns X into a barcode, and the rules of the expansion are applied to those few --
                         // the position the item was created at is not visited, an insertion behind position 14 needs X to end in A, a
@@ -1924,6 +1958,7 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                         pm0 = pm1 = 0ull;  // nothing is left for the enumerating loop
                     }
                     constexpr int kGroup = 4;
+                    if constexpr (!kTable)
                     while ((pm0 | pm1) && !hit2) {
                         uint32_t m_low[2 * kGroup], m_ok[2 * kGroup], w0[2 * kGroup], w1[2 * kGroup];
                         int t_sel[kGroup];  // the next kGroup items in expansion order (wave-uniform)
@@ -2026,18 +2061,31 @@ __global__ __launch_bounds__(256) void k_bc_match_ed2(const smi_bc_window *__res
                     }
                     }  // levels 1 and 2
                 }
-                c_rs[q] = K;
-                c_bc[3 * q] = bc0;
-                c_bc[3 * q + 1] = bc1;
-                c_bc[3 * q + 2] = bc2;
-                c_imd[3 * q] = 0;
-                c_imd[3 * q + 1] = imd1;
-                c_imd[3 * q + 2] = imd2;
+                if (lane == 0) {
+                    r_rs[q] = K;
+                    r_bc[3 * q] = bc0;
+                    r_bc[3 * q + 1] = bc1;
+                    r_bc[3 * q + 2] = bc2;
+                    r_imd[3 * q] = 0;
+                    r_imd[3 * q + 1] = imd1;
+                    r_imd[3 * q + 2] = imd2;
+                }
                 present |= (hit0 ? 1u : 0u) << (3 * q);
                 present |= (hit1 ? 1u : 0u) << (3 * q + 1);
                 present |= (hit2 ? 1u : 0u) << (3 * q + 2);
             }
+            wave_sync();
+            uint32_t c_bc[15], c_rs[5];
+            int c_imd[15];
+#pragma unroll
+            for (int i = 0; i < 15; i++) {
+                c_bc[i] = r_bc[i];
+                c_imd[i] = r_imd[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 5; i++) c_rs[i] = r_rs[i];
             pick_best15(c_bc, c_rs, c_imd, present, 2, res);
+            wave_sync();  // (the next read writes s_res again)
         }
         if (lane == 0) out[rd] = res;
     }
@@ -2055,6 +2103,8 @@ int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int fiv
     if (std::getenv("SMI_BC2_NO_TABLE") || (ctx->n_keys > 300000 && std::getenv("SMI_BC2_DENSE_ENUM"))) P.nt = nullptr;
     if (ctx->n_keys > 300000)
         hipLaunchKernelGGL((k_bc_match_ed2<true, false>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else if (P.n1 && P.nt)
+        hipLaunchKernelGGL((k_bc_match_ed2<false, true, true>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else if (P.n1)
         hipLaunchKernelGGL((k_bc_match_ed2<false, true>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else

@@ -44,6 +44,8 @@ Pyramid pyramid_of(const smi_ctx *ctx) {
     p.t2 = ctx->t2;
     p.n1 = ctx->n1_valid ? ctx->n1 : nullptr;
     p.n2 = ctx->n1_valid ? ctx->n1 + kL1Words : nullptr;
+    p.n1s = ctx->n1_valid && ctx->n1s_valid ? ctx->n1 + 2 * kL1Words : nullptr;
+    p.n2s = ctx->n1_valid && ctx->n1s_valid ? ctx->n1 + 3 * kL1Words : nullptr;
     p.nb2 = ctx->n1_valid && ctx->nb2_valid ? ctx->n1_owner : nullptr;
     p.nb = ctx->nb_valid ? ctx->nb : nullptr;
     p.nb5 = ctx->nb_valid && ctx->nb5_valid ? ctx->nb5 : nullptr;
@@ -199,6 +201,7 @@ int smi_ctx_lane_refresh(smi_ctx *lane) {
     lane->t2 = o->t2;
     lane->n1 = o->n1;
     lane->n1_valid = o->n1_valid;
+    lane->n1s_valid = o->n1s_valid;
     lane->n1_owner = o->n1_owner;
     lane->nb2_valid = o->nb2_valid;
     lane->nb = o->nb;
@@ -357,7 +360,7 @@ int smi_set_stats(smi_ctx *ctx, uint64_t out[8], int digests) {
     if (o->nb_valid) bytes += kFineWords * 4ull;
     if (o->nb5_valid) bytes += ((uint64_t)1 << 24) * 40 * 4;
     if (o->nt_cap) bytes += (uint64_t)o->nt_alloc * 8 + (o->nt_alloc >> 3) * 4;  // (the table as allocated, with the build's bucket counters behind it)
-    if (o->n1_valid) bytes += 2ull * kL1Words * 4;
+    if (o->n1_valid) bytes += 4ull * kL1Words * 4;
     if (o->nb2_valid) bytes += kFineWords * 4ull;
     out[1] = bytes;
     out[2] = o->set_build_us;

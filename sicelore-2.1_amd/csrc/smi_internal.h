@@ -100,6 +100,7 @@ struct Pyramid {
     const uint32_t *t2;  // two-stage top level of K-BC1: entry j = {word j of l0 | l0s, stage-2 word j}
     const uint32_t *n1;  // K-BC2, short used lists only (else null): the sequences one mutation step away FROM which a barcode can be reached (l1 layout)
     const uint32_t *n2;  // ... from which TWO OR MORE different barcodes can be reached (same layout)
+    const uint32_t *n1s, *n2s;  // the same two filters indexed by the last nine bases first (smi_bc.hip n1_cell_s), or null
     const uint32_t *nb2; // K-BC2's offset filter for short used lists (else null): 1 bit per key, set for every sequence TWO steps away from a barcode
     const uint32_t *nb;  // K-BC1's offset filter (else null): 1 bit per key, set for every sequence one mutation step away from a barcode (512 MiB)
     const uint32_t *nb5; // the same filter laid out by the 12 bases the five offsets' windows share (else null; smi_bc.hip "nb5"): the five bits of a read in 160 consecutive bytes
@@ -117,6 +118,7 @@ struct smi_ctx {
     uint32_t *t2 = nullptr;
     uint32_t *n1 = nullptr;   // allocated with the first short barcode list (2 x 16 MiB: n1, then n2)
     bool n1_valid = false;    // describes the set that is loaded now
+    bool n1s_valid = false;   // ... and the suffix-major copies behind n1 / n2 are built
     int polya_len = 0, polya_window = 0;  // smi_ctx_set_polya: the chunk workers' polyA finder parameters (0: the shipped config.xml values)
     float polya_frac = 0.0f;
     smi_run_knobs knobs = {};  // smi_ctx_set_knobs: config.xml's knobs for the chunk workers of this context (knobs_set false: the shipped file)
