@@ -1639,8 +1639,12 @@ __device__ __forceinline__ void pick_best15(const uint32_t (&bc)[15], const uint
 // held at seven waves per SIMD (72 registers, 29 of them spilled): a wavefront works one window at a time through a chain of dependent steps, and the
 // number of waves a SIMD can switch between is what the kernel's time follows -- per 2 M windows against a 5 k list: four waves (126 registers, what the
 // compiler picks) 9.37 ms, five 8.06, six 7.58, seven 7.41, eight (43 spills) 9.25.
+// (the dense-list form of the table path -- ed <= 2 against the whole 3.6 M list -- per 2 M windows: four waves 29.9 ms, five 26.3, six 24.6, seven 26.9)
+#ifndef SMI_BC2_DENSE_WAVES
+#define SMI_BC2_DENSE_WAVES 6
+#endif
 template <bool kTwoStage, bool kFilter, bool kTable = false>
-__global__ __launch_bounds__(256, kTable ? 7 : 1) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
+__global__ __launch_bounds__(256, kTable ? (kTwoStage ? SMI_BC2_DENSE_WAVES : 7) : 1) void k_bc_match_ed2(const smi_bc_window *__restrict__ win, size_t n, int five_prime,
                                                       Pyramid P, smi_bc_result *__restrict__ out) {
     __shared__ uint32_t s_keys[4][kTabSlots];
     __shared__ uint32_t s_vals[4][kTabSlots];
@@ -2101,7 +2105,9 @@ int launch_bc_match2(smi_ctx *ctx, const smi_bc_window *d_win, size_t n, int fiv
     // level 2 from the table pays when the table is small enough to stay in cache (a used list: 11 MB); against the whole whitelist the 550
     // bucket reads of a read miss to HBM (measured 29 instead of 32 M reads/s), so dense sets keep the enumeration through the two-stage top level
     if (std::getenv("SMI_BC2_NO_TABLE") || (ctx->n_keys > 300000 && std::getenv("SMI_BC2_DENSE_ENUM"))) P.nt = nullptr;
-    if (ctx->n_keys > 300000)
+    if (ctx->n_keys > 300000 && P.nt)
+        hipLaunchKernelGGL((k_bc_match_ed2<true, false, true>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
+    else if (ctx->n_keys > 300000)
         hipLaunchKernelGGL((k_bc_match_ed2<true, false>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
     else if (P.n1 && P.nt)
         hipLaunchKernelGGL((k_bc_match_ed2<false, true, true>), dim3(grid), dim3(256), 0, s, d_win, n, five_prime, P, d_out);
