@@ -359,6 +359,11 @@ def test_filters_change_nothing(pkg, synth, gpu_ctx, monkeypatch, case):
     gpu_ctx.set_barcode_set(keys, mode=mode)
     assert (with_filter.view(np.uint8) == _run_device(pkg, gpu_ctx, win, max_ed, five_prime).view(np.uint8)).all()
     monkeypatch.delenv("SMI_BC1_NO_NB5")
+    if max_ed == 2 or got2 is not None:
+        monkeypatch.setenv("SMI_BC2_ONE_FILTER", "1")   # K-BC2's item filter in its prefix-major layout only (round 6: the children of positions <= 6 read a suffix-major copy)
+        gpu_ctx.set_barcode_set(keys, mode=mode)
+        assert (_run_device(pkg, gpu_ctx, win, 2, five_prime).view(np.uint8) == (with_filter if max_ed == 2 else got2).view(np.uint8)).all()
+        monkeypatch.delenv("SMI_BC2_ONE_FILTER")
     monkeypatch.setenv("SMI_BC1_NO_TABLE", "1")  # K-BC1: offset filter, mutants of the flagged offsets enumerated (k_bc_match_ed1f)
     monkeypatch.setenv("SMI_BC2_NO_TABLE", "1")  # K-BC2: level 2 by enumeration of the items the filter lets through (read at launch)
     gpu_ctx.set_barcode_set(keys, mode=mode)
