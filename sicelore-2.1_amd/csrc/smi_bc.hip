@@ -363,6 +363,13 @@ static hipError_t fill_zero(void *p, size_t bytes, hipStream_t s) {
 
 int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStream_t s, bool membership_only) {
     const auto t_build0 = std::chrono::steady_clock::now();
+    const bool set_timing = std::getenv("SMI_SET_TIMING") != nullptr;  // host clock per phase on stderr (each mark waits for the stream: measurement only)
+    auto mark = [&](const char *what) {
+        if (!set_timing) return;
+        (void)hipStreamSynchronize(s);
+        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+        std::fprintf(stderr, "set build: %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count());
+    };
     SMI_HIP(hipMemsetAsync(ctx->l0, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l0s, 0, kL0Words * 4, s));
     SMI_HIP(hipMemsetAsync(ctx->l1, 0, kL1Words * 4, s));
@@ -384,6 +391,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
             if (p) (void)hipFree(p);
         }
     } tmp;
+    mark("pyramid bits + block counts");
     SMI_HIP(hipMalloc(&tmp.p, tmp_bytes));
     SMI_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tmp_bytes, ctx->block_counts, ctx->rank, (int)kRankEntries, s));
     // distinct keys = rank[last] + counts[last]
@@ -393,6 +401,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
     ctx->nb_valid = false;
     ctx->nb5_valid = false;
     ctx->nt_cap = 0;
+    mark("rank scan");
     if (n > 0 && !membership_only && !std::getenv("SMI_BC1_NO_FILTER")) {  // (the switch: tests run K-BC1 with and without the filter)
         if (!ctx->nb) SMI_HIP(hipMalloc((void **)&ctx->nb, kFineWords * 4));
         const unsigned gb = (unsigned)std::min<size_t>((n * kN1Slots + 255) / 256, 256 * 256);
@@ -508,6 +517,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
         if (int rc = join()) return rc;
 #undef SMI_SET_HIP
     }
+    mark("nb / nb5 / nt");
     ctx->n1_valid = false;
     ctx->nb2_valid = false;
     if (n > 0 && !membership_only && n <= kN1MaxKeys && !std::getenv("SMI_BC2_NO_FILTER")) {  // (the switch: tests run K-BC2 with and without the filter)
@@ -528,6 +538,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
         SMI_HIP(hipGetLastError());
         ctx->n1_valid = true;
         ctx->nb2_valid = false;
+        mark("n1 / n2 (two layouts)");
         if (n <= kNb2MaxKeys && !std::getenv("SMI_BC2_NO_OFFSET_FILTER")) {
             // stream order: k_set_n2 has read the scratch as the owner array before it is cleared and filled as the two-step bitmap
             SMI_HIP(fill_zero(ctx->n1_owner, kFineWords * 4, s));
@@ -537,6 +548,7 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
             ctx->nb2_valid = true;
         }
     }
+    mark("nb2");
     SMI_HIP(hipStreamSynchronize(s));
     ctx->n_keys = (size_t)last[0] + last[1];
     ctx->set_build_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t_build0).count();
@@ -1633,13 +1645,83 @@ __device__ __forceinline__ void pick_best15(const uint32_t (&bc)[15], const uint
     res.ins_minus_del = (int8_t)best_imd;
 }
 
+// pick_best15 with its fifteen candidates read where they lie (the wave's LDS) instead of held in 35 registers by every lane: three short passes
+// (least key; the barcode and ins - del under it; least key among the other barcodes).  Same rules, same order.
+__device__ __forceinline__ void pick_best15_mem(const uint32_t *bc, const uint32_t *rs, const int *imd, uint32_t present, int max_ed, smi_bc_result &res) {
+    constexpr int OFFS[5] = {0, -1, 1, -2, 2};
+    const int n = __popc(present);
+    res.bc = 0;
+    res.ed_sec = 2147483647;
+    res.found = 0;
+    res.ed = 0;
+    res.offset = 0;
+    res.ins_minus_del = 0;
+    res.n_matches = (uint32_t)n;
+    if (n == 0) return;
+    auto hq = [&](int q) -> uint32_t {
+        const uint32_t r = rs[q];
+        return r ^ (r >> 16);
+    };
+    int cap = 16;
+    if (n >= 9) {  // HashMap growth: size > 0.75 cap, or a 9th node in one bin while cap < 64 (treeifyBin -> resize)
+        int size = 0;
+        for (int i = 0; i < 15; i++) {
+            if (!((present >> i) & 1u)) continue;
+            int in_bin = 0;
+            for (int k = 0; k < i; k++)
+                in_bin += (((present >> k) & 1u) && ((hq(k / 3) ^ hq(i / 3)) & (uint32_t)(cap - 1)) == 0) ? 1 : 0;
+            size++;
+            if (in_bin >= 8) {
+                if (cap < 64) {
+                    cap <<= 1;
+                } else {
+                    res.found = -2;  // a real tree bin: the reference itself is not reproducible here (pick_best15)
+                    return;
+                }
+            }
+            if (size > (cap * 3) / 4) cap <<= 1;
+        }
+    }
+    auto key_of = [&](int i) -> uint32_t {
+        if (!((present >> i) & 1u)) return 0xFFFFFFFFu;
+        const int q = i / 3, lvl = i % 3;
+        return ((uint32_t)lvl << 20) | (q != 0 ? (1u << 16) : 0u) | ((hq(q) & (uint32_t)(cap - 1)) << 8) | (uint32_t)i;
+    };
+    uint32_t best_key = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int i = 0; i < 15; i++) best_key = min(best_key, key_of(i));
+    const int bi = (int)(best_key & 0xFFu);  // (a key carries its index; n > 0, so there is one)
+    const uint32_t best_bc = bc[bi];
+    const int best_imd = imd[bi];
+    uint32_t second_key = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int i = 0; i < 15; i++) {
+        const uint32_t k = key_of(i);
+        if (k != 0xFFFFFFFFu && bc[i] != best_bc) second_key = min(second_key, k);
+    }
+    const int best_ed = (int)(best_key >> 20), second_ed = (int)(second_key >> 20);
+    const bool has_second = second_key != 0xFFFFFFFFu;
+    if (best_ed > max_ed) return;
+    if (has_second && best_ed >= second_ed) return;
+    res.found = 1;
+    res.bc = best_bc;
+    res.ed = (int8_t)best_ed;
+    res.ed_sec = has_second ? second_ed : 2147483647;
+    res.offset = (int8_t)OFFS[(best_key & 0xFF) / 3];
+    res.ins_minus_del = (int8_t)best_imd;
+}
+
 // kTwoStage: dense barcode sets (the whole whitelist): both stages of the top level from t2.  kFilter: short used lists: only the items
 // that P.n1 lets through are expanded (k_set_n1).
-// kTable: level 2 comes from the neighbourhood table (P.nt) -- the kernel then carries neither the enumerating loop nor its lane masks, and is
-// held at seven waves per SIMD (72 registers, 29 of them spilled): a wavefront works one window at a time through a chain of dependent steps, and the
-// number of waves a SIMD can switch between is what the kernel's time follows -- per 2 M windows against a 5 k list: four waves (126 registers, what the
-// compiler picks) 9.37 ms, five 8.06, six 7.58, seven 7.41, eight (43 spills) 9.25.
-// (the dense-list form of the table path -- ed <= 2 against the whole 3.6 M list -- per 2 M windows: four waves 29.9 ms, five 26.3, six 24.6, seven 26.9)
+// kTable: level 2 comes from the neighbourhood table (P.nt) -- the kernel then carries neither the enumerating loop nor its lane masks, the final pick
+// reads the fifteen answers from LDS (pick_best15_mem) instead of holding them in 35 registers per lane, and the kernel fits SEVEN waves per SIMD
+// (72 registers, nothing spilled).  A wavefront works one window at a time through a chain of dependent steps, and the number of waves a SIMD can
+// switch between is what the kernel's time followed -- per 2 M windows against a 5 k list: four waves (126 registers, what the compiler picks for the
+// kernel with everything in it) 9.37 ms; the same code held to five / six / seven waves by the launch bounds, with 5 / 21 / 29 spilled values, 8.06 /
+// 7.58 / 7.41 (not shipped: a value spilled inside a divergent region is stored for the active lanes only, NOTES R4.5); this form 6.80, and at eight
+// waves (6 spills) 7.76.  At seven waves VALU + SALU issue fills the SIMD cycles: what is left is instruction count.
+// (the dense-list form of the table path -- ed <= 2 against the whole 3.6 M list: 79 registers, six waves, nothing spilled: 23.4 ms per 2 M windows;
+// with the answers in registers and spills: four waves 29.9 ms, five 26.3, six 24.6, seven 26.9)
 #ifndef SMI_BC2_DENSE_WAVES
 #define SMI_BC2_DENSE_WAVES 6
 #endif
@@ -2079,16 +2161,7 @@ __global__ __launch_bounds__(256, kTable ? (kTwoStage ? SMI_BC2_DENSE_WAVES : 7)
                 present |= (hit2 ? 1u : 0u) << (3 * q + 2);
             }
             wave_sync();
-            uint32_t c_bc[15], c_rs[5];
-            int c_imd[15];
-#pragma unroll
-            for (int i = 0; i < 15; i++) {
-                c_bc[i] = r_bc[i];
-                c_imd[i] = r_imd[i];
-            }
-#pragma unroll
-            for (int i = 0; i < 5; i++) c_rs[i] = r_rs[i];
-            pick_best15(c_bc, c_rs, c_imd, present, 2, res);
+            pick_best15_mem(r_bc, r_rs, r_imd, present, 2, res);
             wave_sync();  // (the next read writes s_res again)
         }
         if (lane == 0) out[rd] = res;

@@ -37,9 +37,18 @@ constexpr int kBlock = 256;
 // the registers they need to hold everything: at 128 VGPRs the 22-mer kernels spill 13 - 47 values, and a value spilled INSIDE a divergent region is
 // stored for the lanes active there only -- a lane that sat the region out reads back whatever its scratch slot held.  That is how two never-taken
 // branches made the 22-mer kernel drop the records of reads with no side chosen (the even lane's `side` and `read` came back from scratch: NOTES R4.5).
+// The generic kernels (any adapter / TSO / polyA window: what a config.xml with other sequences runs) fill the same exact band as the specialised ones --
+// the band follows from the 4-mer gate, not from the sequence (smi_nw.h "Band").  -DSMI_SCAN_GENERIC_FULL=1 (a variant build) gives them the whole matrix
+// again, as an independent check of the band.
+#ifndef SMI_SCAN_GENERIC_FULL
+#define SMI_SCAN_GENERIC_FULL 0
+#endif
+#ifndef SMI_SCAN_GENERIC_WAVES
+#define SMI_SCAN_GENERIC_WAVES 3  // (four: 128 registers with 17 spilled values -- not in this kernel, see above; 4.78 instead of 5.47 ms per 10 M reads)
+#endif
 template <int AD, bool SHIP>
 constexpr int scan_waves() {
-    return SHIP ? (AD == 10 ? SMI_SCAN_WAVES : 3) : 2;
+    return SHIP ? (AD == 10 ? SMI_SCAN_WAVES : 3) : (AD == 10 ? SMI_SCAN_GENERIC_WAVES : 2);
 }
 
 // SMI_SCAN_ABLATE's switches are compiled into measurement builds only.  (They used to be run-time tests of a field that is 0 in the shipped
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(kBlock, (scan_waves<AD, SHIP>())) void k_scan(const
     // Every aligned candidate passed gate64 on the slice that is aligned (>= 2 matching 4-mers = >= 5 matching bases on the main diagonal),
     // which bounds how far an optimal path can leave the diagonal (smi_nw.h "Band"): 3 cells for the 10-mer, 12 for the 22-mer, 7 for the
     // TSO.  The kernels of the shipped adapters fill the band only; the generic kernels fill the whole matrix, and the parity tests run both.
-    constexpr int kBandAd = SHIP ? nw_band<AD, 5>() : AD, kBandTso = SHIP ? nw_band<16, 5>() : 16;
+    constexpr int kBandAd = (SHIP || !SMI_SCAN_GENERIC_FULL) ? nw_band<AD, 5>() : AD, kBandTso = (SHIP || !SMI_SCAN_GENERIC_FULL) ? nw_band<16, 5>() : 16;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t *planes = lds;                                                           // [4][kLdsWords][kBlock]
     uint64_t *cmask = reinterpret_cast<uint64_t *>(planes + 4 * kLdsWords * kBlock);  // [3][kBlock] candidate bits
