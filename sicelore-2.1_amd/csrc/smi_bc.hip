@@ -1682,22 +1682,22 @@ __device__ __forceinline__ void pick_best15_mem(const uint32_t *bc, const uint32
             if (size > (cap * 3) / 4) cap <<= 1;
         }
     }
-    auto key_of = [&](int i) -> uint32_t {
-        if (!((present >> i) & 1u)) return 0xFFFFFFFFu;
+    auto key_of = [&](int i) -> uint32_t {  // (i: a set bit of `present`)
         const int q = i / 3, lvl = i % 3;
         return ((uint32_t)lvl << 20) | (q != 0 ? (1u << 16) : 0u) | ((hq(q) & (uint32_t)(cap - 1)) << 8) | (uint32_t)i;
     };
+    // the matches are few (one to three as a rule): both passes walk the set bits of `present`, not the fifteen slots
     uint32_t best_key = 0xFFFFFFFFu;
 #pragma unroll 1
-    for (int i = 0; i < 15; i++) best_key = min(best_key, key_of(i));
+    for (uint32_t m = present; m; m &= m - 1) best_key = min(best_key, key_of(__builtin_ctz(m)));
     const int bi = (int)(best_key & 0xFFu);  // (a key carries its index; n > 0, so there is one)
     const uint32_t best_bc = bc[bi];
     const int best_imd = imd[bi];
     uint32_t second_key = 0xFFFFFFFFu;
 #pragma unroll 1
-    for (int i = 0; i < 15; i++) {
-        const uint32_t k = key_of(i);
-        if (k != 0xFFFFFFFFu && bc[i] != best_bc) second_key = min(second_key, k);
+    for (uint32_t m = present; m; m &= m - 1) {
+        const int i = __builtin_ctz(m);
+        if (bc[i] != best_bc) second_key = min(second_key, key_of(i));
     }
     const int best_ed = (int)(best_key >> 20), second_ed = (int)(second_key >> 20);
     const bool has_second = second_key != 0xFFFFFFFFu;
