@@ -444,7 +444,10 @@ int launch_build_pyramid(smi_ctx *ctx, const uint32_t *d_keys, size_t n, hipStre
         }                                                \
     } while (0)
         SMI_SET_HIP(fill_zero(ctx->nb, kFineWords * 4, sb));
-        const bool nb5_atomic = std::getenv("SMI_BC1_NB5_ATOMIC") != nullptr;  // cross-check switch: nb5 by scattered atomics (round 5) instead of the transposition
+        // nb5 by scattered atomics (round 5's way) instead of the transposition: the cross-check switch, and the way of SHORT lists -- the transposition streams
+        // the whole 512 MiB bitmap into 2.5 GiB whatever the list holds (3.7 ms), five atomics per neighbour of a used list are a few microseconds behind a
+        // 0.6 ms zero fill.  SMI_BC1_NB5_TRANSPOSE keeps the transposition for every list.
+        const bool nb5_atomic = std::getenv("SMI_BC1_NB5_ATOMIC") != nullptr || (n <= kN1MaxKeys && !std::getenv("SMI_BC1_NB5_TRANSPOSE"));
         if (want_nb5 && ctx->nb5 && nb5_atomic) SMI_SET_HIP(fill_zero(ctx->nb5, kNb5Words * 4, sb));
         hipLaunchKernelGGL(k_set_nb, dim3(gb), dim3(256), 0, sb, d_keys, n, ctx->nb, want_nb5 && nb5_atomic ? ctx->nb5 : nullptr);
         SMI_SET_HIP(hipGetLastError());

@@ -435,12 +435,16 @@ def test_nb5_by_transposition_equals_nb5_by_atomics(pkg, synth, gpu_ctx, monkeyp
     count, same order-sensitive digest -- and nb5 holds five bits (one per offset) for every bit of nb; the table holds one entry per (barcode, step)"""
     wl = synth.make_whitelist(max(n_keys, 16), seed=71)[:n_keys]
     keys = wl.numpy().astype(np.uint64)
+    monkeypatch.setenv("SMI_BC1_NB5_TRANSPOSE", "1")   # (short lists take the atomics by themselves: the transposition costs 3.7 ms whatever the list holds)
     gpu_ctx.set_barcode_set(keys, mode=1)
     a = gpu_ctx.set_stats(digests=True)
+    monkeypatch.delenv("SMI_BC1_NB5_TRANSPOSE")
     monkeypatch.setenv("SMI_BC1_NB5_ATOMIC", "1")
     gpu_ctx.set_barcode_set(keys, mode=1)
     b = gpu_ctx.set_stats(digests=True)
     monkeypatch.delenv("SMI_BC1_NB5_ATOMIC")
+    gpu_ctx.set_barcode_set(keys, mode=1)              # the default for this list's size
+    assert gpu_ctx.set_stats(digests=True)["nb5_digest"] == a["nb5_digest"]
     assert a["keys"] == b["keys"] == n_keys
     assert a["nb_bits"] == b["nb_bits"] > 100 * n_keys
     assert a["nb5_bits"] == b["nb5_bits"] == 5 * a["nb_bits"]
