@@ -833,13 +833,14 @@ def config2(args, dist, rank, local_rank, world, dev):
         return
     k_bc2 = float(np.mean(bc2_ms))
     rf = roofline_entry("k_bc_match_ed2", "k_bc_match_ed2", k_bc2, ALG_BYTES_PER_READ_BC2, n, pmc_table())
-    rf.update({"bound": "hbm request rate (random 64-B sectors: `frac` is the counter traffic, FETCH_SIZE = L2 misses x 64 B, over the HBM peak)",
+    rf.update({"bound": "instruction issue (round 6: seven waves per SIMD; VALU + SALU fill the SIMD cycles, `valu_issue` has the vector share; `frac` is the counter "
+                        "traffic over the HBM peak, as the contract asks)",
                "launches_per_step": len(batches),
                "note": "SURVEY 8d prices a read at ~56,000 probes x 4 B; against a short used list K-BC2 dismisses ~98 % of the level-1 items with one "
                        "load each (the inverse one-step neighbourhood of the list, P.n1) and never enumerates their children, so the algorithmic "
                        "figure (in `algorithmic`) exceeds the HBM peak: it measures probes answered, not bytes moved",
-               "limiter": "dependent gathers into the 512 MiB neighbourhood bitmaps (2.0 G L2 misses per 10 M reads) + integer VALU / LDS atomics of the "
-                          "per-offset set-up; the level-2 work only runs for the items the filter lets through",
+               "limiter": "1,672 VALU + 1,081 SALU wave instructions per read (per-offset set-up: children, filter bits, LDS dedup table, creation order; the scalar "
+                          "bit loops) at ~ 97 % of the SIMD cycles; 0.5 G L2 misses per 10 M reads (profiles/r06/cfg2_pmc.json)",
                "kernels_ms": {"k_bc_match_ed2": k_bc2, "k_scan<10>": state["ms_scan"]}})
     print(json.dumps({
         "metric": "Nanopore reads/sec BC-assigned at ed<=2, two-pass (whitelist-build + assign), 3.6M whitelist",
